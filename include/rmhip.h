@@ -1,0 +1,227 @@
+/*
+ * rmhip.h -- C ABI of librmhip.so, the MI355X (gfx950) accelerate backend for RunMat's dense-array
+ * hot path.  This is the drop-in boundary: every entry point below replaces one method (or a
+ * small family of methods) of the reference's provider trait
+ *   `trait AccelProvider` -- crates/runmat-accelerate-api/src/lib.rs:1386-3151
+ * and is what a ~300-line `impl AccelProvider for HipProvider` (shim/hip_provider.rs,
+ * INTEGRATION.md) binds through `extern "C"`.
+ *
+ * Conventions
+ *   - Plain C types only: pointers, sizes, u64 buffer ids. No torch / C++ types.
+ *   - Tensors are f64, column-major, described by (shape[], rank) like `HostTensorView`
+ *     (lib.rs:3362-3372).  A buffer id is the `buffer_id` field of `GpuTensorHandle`
+ *     (lib.rs:260-264); the provider owns the device memory until rmhip_free.
+ *   - Every call returns 0 on success, else an RMHIP_ERR_* code; rmhip_last_error() returns a
+ *     thread-local message.  Errors are soft: the reference's callers fall back to the CPU path
+ *     on any provider Err (mtimes.rs:212-216, mldivide.rs:223-226, runner.rs:1140-1142), so
+ *     unsupported requests return RMHIP_ERR_UNSUPPORTED and never abort.
+ *   - Every op returns a NEW buffer (ResidencyPolicy::NewHandle); inputs are never mutated.
+ *   - Work is enqueued on the context's HIP stream; rmhip_download / rmhip_synchronize block.
+ *   - There is no CPU fallback inside the library: without a gfx950 device rmhip_init fails.
+ */
+#ifndef RMHIP_H
+#define RMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RMHIP_API __attribute__((visibility("default")))
+
+typedef struct rmhip_ctx rmhip_ctx;
+typedef uint64_t rmhip_buf;
+
+enum rmhip_status {
+    RMHIP_OK = 0,
+    RMHIP_ERR_INVALID = 1,     /* bad argument / null pointer                                   */
+    RMHIP_ERR_UNSUPPORTED = 2, /* request outside the supported subset -> caller falls back     */
+    RMHIP_ERR_SHAPE = 3,       /* shape / dimension mismatch ("Inner matrix dimensions ...")    */
+    RMHIP_ERR_HIP = 4,         /* HIP runtime error                                             */
+    RMHIP_ERR_NOT_FOUND = 5,   /* unknown buffer id (simple_provider.rs:7717 "buffer not found")*/
+    RMHIP_ERR_COMPILE = 6,     /* WGSL front-end or hipRTC failure                              */
+    RMHIP_ERR_SINGULAR = 7,    /* LU pivot <= 1e-12: caller must use the CPU SVD path           */
+    RMHIP_ERR_OOM = 8,
+    RMHIP_ERR_NO_DEVICE = 9
+};
+
+/* ---- library / context ---------------------------------------------------------------------- */
+
+RMHIP_API const char* rmhip_version(void);
+/* Thread-local message of the last failing call on this thread. Never NULL. */
+RMHIP_API const char* rmhip_last_error(void);
+
+/* Replaces provider construction + `register_provider` (lib.rs:3213-3225); one context per GPU
+ * (one process per GPU in multi-GPU jobs).  `device_ordinal` is the HIP device index. */
+RMHIP_API int rmhip_init(int device_ordinal, rmhip_ctx** out_ctx);
+RMHIP_API int rmhip_shutdown(rmhip_ctx* ctx);
+
+/* `device_info_struct` (lib.rs:1448-1456) + `precision` (:1458, always F64 here). */
+typedef struct rmhip_device_info {
+    char name[128];
+    char arch[32];          /* "gfx950" */
+    int device_ordinal;
+    int compute_units;
+    int wavefront_size;
+    int clock_mhz;
+    uint64_t total_memory_bytes;
+    int precision_bits;     /* 64: ProviderPrecision::F64 (lib.rs:815-818)                     */
+    uint32_t reduction_workgroup_size; /* default_reduction_workgroup_size (lib.rs:3048)       */
+    uint32_t two_pass_threshold;       /* two_pass_threshold (lib.rs:3053)                     */
+} rmhip_device_info_t;
+RMHIP_API int rmhip_device_info(rmhip_ctx* ctx, rmhip_device_info_t* out);
+
+/* Stream plumbing: by default the context owns a non-blocking stream.  A host that already has
+ * a stream (e.g. torch's current stream) can make the library enqueue there instead. */
+RMHIP_API int rmhip_set_stream(rmhip_ctx* ctx, void* hip_stream);
+RMHIP_API void* rmhip_get_stream(rmhip_ctx* ctx);
+RMHIP_API int rmhip_synchronize(rmhip_ctx* ctx);
+
+/* ---- memory: upload / download / free  (lib.rs:1387-1389) ----------------------------------- */
+
+RMHIP_API int rmhip_upload(rmhip_ctx* ctx, const double* host, const size_t* shape, size_t rank,
+                           rmhip_buf* out);
+/* Copies `n` doubles (must equal the buffer's element count) to `out_host`; blocks. */
+RMHIP_API int rmhip_download(rmhip_ctx* ctx, rmhip_buf id, double* out_host, size_t n);
+RMHIP_API int rmhip_free(rmhip_ctx* ctx, rmhip_buf id);
+/* On entry *rank_inout is the capacity of shape_out; on exit the rank. */
+RMHIP_API int rmhip_shape(rmhip_ctx* ctx, rmhip_buf id, size_t* rank_inout, size_t* shape_out);
+RMHIP_API int rmhip_numel(rmhip_ctx* ctx, rmhip_buf id, size_t* out);
+/* `zeros` / `ones` / `fill` (lib.rs:1468-1522). */
+RMHIP_API int rmhip_fill(rmhip_ctx* ctx, double value, const size_t* shape, size_t rank,
+                         rmhip_buf* out);
+/* `reshape` (lib.rs:2676): new handle over the same storage (reference counted), same numel. */
+RMHIP_API int rmhip_reshape(rmhip_ctx* ctx, rmhip_buf id, const size_t* shape, size_t rank,
+                            rmhip_buf* out);
+/* Zero-copy adoption of device memory owned by the host (torch tensor, RCCL receive buffer...).
+ * The library never frees it; rmhip_free only drops the table entry. */
+RMHIP_API int rmhip_wrap_external(rmhip_ctx* ctx, void* device_ptr, const size_t* shape,
+                                  size_t rank, rmhip_buf* out);
+/* Raw device pointer of a buffer (for RCCL collectives / torch views). NULL if unknown. */
+RMHIP_API void* rmhip_device_ptr(rmhip_ctx* ctx, rmhip_buf id);
+/* Deterministic device-side fill used by bench/tests: element i = lo + (hi-lo)*u53(splitmix64(
+ * seed + (i+1)*0x9e3779b97f4a7c15)) -- identical to oracle's orc_fill_uniform. */
+RMHIP_API int rmhip_fill_uniform(rmhip_ctx* ctx, uint64_t seed, double lo, double hi,
+                                 const size_t* shape, size_t rank, rmhip_buf* out);
+
+/* ---- fused kernels  (lib.rs:2946-3008) ------------------------------------------------------ */
+
+/* `fused_elementwise` / `fused_elementwise_multi` (lib.rs:2946-2978).
+ * `shader` is the WGSL text the reference planner emits (fusion.rs:1632-1763); the library parses
+ * the `let tmpK: f64 = <expr>;` / `output[k].data[g] = <expr>;` body into an expression tape and
+ * lowers it to a HIP kernel (hipRTC, cached by tape hash).  Inputs broadcast against `out_shape`
+ * with front-padded shapes (elementwise.rs:1680-1697).  `n_out` == 1 writes `output`, > 1 writes
+ * `output0..`.  `len` must equal prod(out_shape). */
+RMHIP_API int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf* inputs,
+                                      size_t n_in, const size_t* out_shape, size_t rank,
+                                      size_t len, size_t n_out, rmhip_buf* out_ids);
+
+enum rmhip_reduction_flavor { /* ReductionFlavor, lib.rs:865-890 */
+    RMHIP_FLAVOR_SUM = 0,
+    RMHIP_FLAVOR_MEAN = 1,          /* CPU semantics: sum / reduce_len (mean.rs:1134-1151)     */
+    RMHIP_FLAVOR_CUSTOM_SCALE = 2   /* sum * scale                                             */
+};
+/* `fused_reduction` (lib.rs:2996-3008). `shader` is the text of fusion.rs:1765-2077; the library
+ * reads from it: the folded `let val: f64 = <expr>;`, the axis (column-wise `(col * params.nrows)
+ * + r` vs row-wise `row + (c * params.ncols)` addressing) and `const OMITNAN`.  Output has
+ * `num_slices` elements with shape `out_shape`. `workgroup_size` is advisory (ignored). */
+RMHIP_API int rmhip_fused_reduction(rmhip_ctx* ctx, const char* shader, const rmhip_buf* inputs,
+                                    size_t n_in, const size_t* out_shape, size_t rank,
+                                    size_t reduce_len, size_t num_slices, uint32_t workgroup_size,
+                                    int flavor, double custom_scale, rmhip_buf* out);
+
+/* Front-end only (no GPU needed): translate a reference WGSL shader to the HIP source the library
+ * would compile. `kind` 0 = elementwise, 1 = reduction. Writes a NUL-terminated string of at most
+ * `cap` bytes to `out` and the required size to *needed. */
+RMHIP_API int rmhip_wgsl_translate(const char* shader, int kind, char* out, size_t cap,
+                                   size_t* needed);
+/* Front-end + hipRTC compile for gfx950 (no GPU needed); 0 if the generated kernel builds. */
+RMHIP_API int rmhip_wgsl_compile_check(const char* shader, int kind);
+
+/* ---- per-op kernels  (lib.rs:1890-1938, 1979, 2069, 2077-2355) ------------------------------ */
+
+enum rmhip_binary_op { /* elem_add/sub/mul/div/pow/max/min/hypot/atan2 */
+    RMHIP_ADD = 0, RMHIP_SUB, RMHIP_MUL, RMHIP_DIV, RMHIP_POW, RMHIP_MAX, RMHIP_MIN, RMHIP_HYPOT,
+    RMHIP_ATAN2, RMHIP_MOD, RMHIP_REM, RMHIP_BINARY_OP_COUNT
+};
+/* Operands broadcast under MATLAB implicit expansion (broadcast.rs:95-140). */
+RMHIP_API int rmhip_binary(rmhip_ctx* ctx, int op, rmhip_buf a, rmhip_buf b, rmhip_buf* out);
+
+enum rmhip_unary_op { /* unary_* ; numbering shared with oracle/oracle.c */
+    RMHIP_SIN = 0, RMHIP_COS, RMHIP_TAN, RMHIP_ASIN, RMHIP_ACOS, RMHIP_ATAN, RMHIP_SINH,
+    RMHIP_COSH, RMHIP_TANH, RMHIP_ASINH, RMHIP_ACOSH, RMHIP_ATANH, RMHIP_EXP, RMHIP_EXPM1,
+    RMHIP_LOG, RMHIP_LOG2, RMHIP_LOG10, RMHIP_LOG1P, RMHIP_SQRT, RMHIP_ABS, RMHIP_SIGN,
+    RMHIP_FLOOR, RMHIP_CEIL, RMHIP_ROUND, RMHIP_FIX, RMHIP_NEG, RMHIP_EXP2, RMHIP_HEAVISIDE,
+    RMHIP_ISNAN, RMHIP_ISINF, RMHIP_ISFINITE, RMHIP_UPLUS, RMHIP_UNARY_OP_COUNT
+};
+RMHIP_API int rmhip_unary(rmhip_ctx* ctx, int op, rmhip_buf a, rmhip_buf* out);
+
+enum rmhip_scalar_op { /* scalar_add/sub/mul/div/rsub/rdiv/max/min (lib.rs:2333-2355) */
+    RMHIP_SADD = 0, RMHIP_SSUB, RMHIP_SMUL, RMHIP_SDIV, RMHIP_SRSUB, RMHIP_SRDIV, RMHIP_SMAX,
+    RMHIP_SMIN, RMHIP_SCALAR_OP_COUNT
+};
+RMHIP_API int rmhip_scalar(rmhip_ctx* ctx, int op, rmhip_buf a, double s, rmhip_buf* out);
+
+/* ---- reductions  (lib.rs:2709-2721, 2756-2792, 2858-2883) ----------------------------------- */
+
+enum rmhip_reduce_op { RMHIP_RSUM = 0, RMHIP_RMEAN, RMHIP_RMIN, RMHIP_RMAX, RMHIP_RPROD,
+                       RMHIP_REDUCE_OP_COUNT };
+/* dim < 0: reduce all elements -> shape [1,1] (simple_provider.rs:6728-6748).
+ * dim 0 / 1 (zero-based, 2-D): -> [1,cols] / [rows,1] (simple_provider.rs:6750-6806).
+ * nan_mode 0 = include (any NaN => NaN, sum.rs:1038-1045), 1 = omit. */
+RMHIP_API int rmhip_reduce(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int nan_mode,
+                           rmhip_buf* out);
+
+/* ---- linear algebra  (lib.rs:2375-2405, 2477-2500) ------------------------------------------ */
+
+/* `matmul`: C = A*B, 2-D, column-major; inner dims must agree else RMHIP_ERR_SHAPE
+ * (simple_provider.rs:7698-7741). fp64 MFMA kernel. */
+RMHIP_API int rmhip_matmul(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out);
+/* `lu` -> ProviderLuResult {combined, lower, upper, perm_matrix, perm_vector} (lib.rs:649-698);
+ * pivot rule and singular cut-off of host_lu.rs:37-59.  out5 order: combined, L, U, P, pivots. */
+RMHIP_API int rmhip_lu(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf out5[5]);
+/* `mldivide`: x = A\b for square, numerically non-singular A via blocked LU; anything else
+ * (rectangular, pivot <= 1e-12) returns UNSUPPORTED/SINGULAR so the caller uses the CPU SVD path
+ * (mldivide.rs:223-229 `.ok()`). Scalar A => b * (1/A) (mldivide.rs:321-325). */
+RMHIP_API int rmhip_mldivide(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out);
+
+/* ---- RNG  (lib.rs:1713-1728, 1772) ---------------------------------------------------------- */
+
+/* `set_rng_state`: raw 64-bit LCG state (random.rs:7-13). rmhip_rng_seed applies mix_seed
+ * (random.rs:128-141) like `rng(seed)`. */
+RMHIP_API int rmhip_set_rng_state(rmhip_ctx* ctx, uint64_t state);
+RMHIP_API int rmhip_get_rng_state(rmhip_ctx* ctx, uint64_t* state);
+RMHIP_API int rmhip_rng_seed(rmhip_ctx* ctx, uint64_t seed);
+/* `random_uniform` / `random_normal`: CPU-parity stream (64-bit LCG + Box-Muller pairs,
+ * random.rs:271-288,530-543); the state advances exactly as the CPU generator's does. */
+RMHIP_API int rmhip_random_uniform(rmhip_ctx* ctx, const size_t* shape, size_t rank,
+                                   rmhip_buf* out);
+RMHIP_API int rmhip_random_normal(rmhip_ctx* ctx, const size_t* shape, size_t rank,
+                                  rmhip_buf* out);
+
+/* ---- telemetry  (lib.rs:1337-1376, 3023-3045) ----------------------------------------------- */
+
+typedef struct rmhip_telemetry {
+    uint64_t fused_elementwise_count, fused_elementwise_ns;
+    uint64_t fused_reduction_count, fused_reduction_ns;
+    uint64_t matmul_count, matmul_ns;
+    uint64_t mldivide_count, mldivide_ns;
+    uint64_t upload_bytes, download_bytes;
+    uint64_t fusion_cache_hits, fusion_cache_misses;
+    uint64_t kernel_launches;
+    uint64_t bytes_allocated, bytes_pooled;
+} rmhip_telemetry_t;
+RMHIP_API int rmhip_telemetry(rmhip_ctx* ctx, rmhip_telemetry_t* out);
+RMHIP_API int rmhip_reset_telemetry(rmhip_ctx* ctx);
+
+/* HIP-event timing on the context stream (for bench.py's roofline leg): begin records an event,
+ * end records another, synchronizes and returns the elapsed milliseconds between them. */
+RMHIP_API int rmhip_timer_begin(rmhip_ctx* ctx);
+RMHIP_API int rmhip_timer_end(rmhip_ctx* ctx, double* elapsed_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMHIP_H */

@@ -1,0 +1,641 @@
+/*
+ * oracle.c -- CPU restatement of the reference (runmat-org/runmat v0.6.1) dense-array hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE. Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load liboracle.so; the product path (runmat_amd/, librmhip.so)
+ * never links, imports or calls it.
+ *
+ * Every function restates, loop for loop, the reference's single-threaded CPU ("semantic
+ * baseline") implementation and cites the reference file:line it follows (paths relative to the
+ * reference root). Column-major storage, f64 everywhere (crates/runmat-builtins/src/lib.rs:73-118).
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - matmul / elementwise / broadcast / sum / mean / LCG-uniform / LU: pinned against the
+ *     reference's own KATs and sequence definitions (tests/test_oracle_kats.py, tests/golden/).
+ *   - transcendental maps: the reference calls Rust f64::{sin,cos,exp,ln,tanh,powf,...} which
+ *     lower to the platform libm; no golden bits exist in the reference => stated ulp tolerance.
+ *   - mldivide: the reference calls nalgebra 0.32.6 SVD::solve (third-party, absent from
+ *     /root/reference); restated here with a one-sided Jacobi SVD pseudo-inverse solve; the
+ *     reference pins it only by residual norms (mldivide.rs:662-696) => bit-level "parity
+ *     unpinned", residual/forward-error parity only.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off, no -ffast-math, no OpenMP).
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * matmul  -- crates/runmat-runtime/src/builtins/common/linalg.rs:6-32 (matmul_real)
+ *            (identical loop in crates/runmat-accelerate/src/simple_provider.rs:7698-7741)
+ * C[i + j*rows] = sum_k a[i + k*rows] * b[k + j*brows], k ascending, separate mul and add.
+ * ---------------------------------------------------------------------------------------- */
+ORC_API int orc_matmul(const double* a, size_t arows, size_t acols, const double* b, size_t brows,
+                       size_t bcols, double* out) {
+    if (acols != brows) return 1; /* "Inner matrix dimensions must agree" linalg.rs:7-15 */
+    for (size_t j = 0; j < bcols; ++j) {
+        for (size_t i = 0; i < arows; ++i) {
+            double sum = 0.0;
+            for (size_t k = 0; k < acols; ++k) {
+                sum += a[i + k * arows] * b[k + j * brows];
+            }
+            out[i + j * arows] = sum;
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Unary maps -- e.g. crates/runmat-runtime/src/builtins/math/trigonometry/sin.rs:245-255
+ * (`tensor.data.iter().map(|&v| v.sin()).collect()`): one libm call per element.
+ * Op codes are the oracle's own (shared with tests via oracle.py); they follow the unary op
+ * vocabulary of crates/runmat-accelerate/src/fusion.rs:2932-3026.
+ * ---------------------------------------------------------------------------------------- */
+enum {
+    ORC_SIN = 0, ORC_COS, ORC_TAN, ORC_ASIN, ORC_ACOS, ORC_ATAN, ORC_SINH, ORC_COSH, ORC_TANH,
+    ORC_ASINH, ORC_ACOSH, ORC_ATANH, ORC_EXP, ORC_EXPM1, ORC_LOG, ORC_LOG2, ORC_LOG10, ORC_LOG1P,
+    ORC_SQRT, ORC_ABS, ORC_SIGN, ORC_FLOOR, ORC_CEIL, ORC_ROUND, ORC_FIX, ORC_NEG, ORC_EXP2,
+    ORC_HEAVISIDE, ORC_ISNAN, ORC_ISINF, ORC_ISFINITE, ORC_UPLUS
+};
+
+/* crates/runmat-runtime/src/builtins/math/elementwise/sign.rs:236-246 */
+static double sign_real_scalar(double x) {
+    if (x > 0.0) return 1.0;
+    if (x < 0.0) return -1.0;
+    if (x == 0.0) return 0.0;
+    return x; /* NaN propagates */
+}
+
+static double unary_apply(int op, double v) {
+    switch (op) {
+        case ORC_SIN: return sin(v);
+        case ORC_COS: return cos(v);
+        case ORC_TAN: return tan(v);
+        case ORC_ASIN: return asin(v);
+        case ORC_ACOS: return acos(v);
+        case ORC_ATAN: return atan(v);
+        case ORC_SINH: return sinh(v);
+        case ORC_COSH: return cosh(v);
+        case ORC_TANH: return tanh(v);
+        case ORC_ASINH: return asinh(v);
+        case ORC_ACOSH: return acosh(v);
+        case ORC_ATANH: return atanh(v);
+        case ORC_EXP: return exp(v);
+        case ORC_EXPM1: return expm1(v);  /* Rust f64::exp_m1 */
+        case ORC_LOG: return log(v);      /* Rust f64::ln */
+        case ORC_LOG2: return log2(v);
+        case ORC_LOG10: return log10(v);
+        case ORC_LOG1P: return log1p(v);  /* Rust f64::ln_1p */
+        case ORC_SQRT: return sqrt(v);
+        case ORC_ABS: return fabs(v);
+        case ORC_SIGN: return sign_real_scalar(v);
+        case ORC_FLOOR: return floor(v);
+        case ORC_CEIL: return ceil(v);
+        case ORC_ROUND: return round(v);  /* Rust f64::round: half away from zero (round.rs:305) */
+        case ORC_FIX: return trunc(v);
+        case ORC_NEG: return -v;
+        case ORC_EXP2: return exp2(v);
+        case ORC_HEAVISIDE:               /* fusion.rs:2945-2953 select chain == CPU heaviside */
+            if (v != v) return v;
+            return v > 0.0 ? 1.0 : (v == 0.0 ? 0.5 : 0.0);
+        case ORC_ISNAN: return (v != v) ? 1.0 : 0.0;
+        case ORC_ISINF: return isinf(v) ? 1.0 : 0.0;
+        case ORC_ISFINITE: return isfinite(v) ? 1.0 : 0.0;
+        case ORC_UPLUS: return v;
+        default: return NAN;
+    }
+}
+
+ORC_API int orc_unary(int op, const double* x, size_t n, double* out) {
+    if (op < 0 || op > ORC_UPLUS) return 1;
+    for (size_t i = 0; i < n; ++i) out[i] = unary_apply(op, x[i]);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Binary maps with MATLAB implicit expansion.
+ *   shape rules + index walk: crates/runmat-runtime/src/builtins/common/broadcast.rs:95-228
+ *   (BroadcastPlan::new front-pads the shorter shape with 1s; iter() walks column-major and
+ *   advances each operand by its stride unless that extent is 1)
+ *   per-element ops: math/elementwise/times.rs:682-700 (a*b), plus.rs, minus.rs, rdivide.rs,
+ *   power.rs:345-360 (powf), reduction/max.rs:2323-2344 + 1715-1728 (NaN/-0 policy),
+ *   reduction/min.rs:1519-1531.
+ * ---------------------------------------------------------------------------------------- */
+enum { ORC_ADD = 0, ORC_SUB, ORC_MUL, ORC_DIV, ORC_POW, ORC_MAX, ORC_MIN, ORC_HYPOT, ORC_ATAN2,
+       ORC_MOD, ORC_REM };
+
+static double elem_max(double a, double b) { /* max.rs:2323-2344, Include-NaN, Auto comparison */
+    if (a != a || b != b) return NAN;
+    if (b > a) return b;
+    if (b < a) return a;
+    if (b == 0.0 && a == 0.0) return (!signbit(b) && signbit(a)) ? b : a;
+    return a;
+}
+static double elem_min(double a, double b) { /* min.rs:1519-1531 */
+    if (a != a || b != b) return NAN;
+    if (b < a) return b;
+    if (b > a) return a;
+    if (b == 0.0 && a == 0.0) return (signbit(b) && !signbit(a)) ? b : a;
+    return a;
+}
+/* mod/rem follow the select chains the fused generator emits (fusion.rs:2954-2970), which the
+ * reference's VM tests check against the CPU builtins (crates/runmat-vm/tests/fusion_gpu.rs:2965-3220). */
+static double elem_mod(double l, double r) {
+    if (isinf(r) && isfinite(l)) {
+        return (l == 0.0 || sign_real_scalar(l) == sign_real_scalar(r)) ? l : r;
+    }
+    return l - r * floor(l / r);
+}
+static double elem_rem(double l, double r) {
+    if (isinf(r) && isfinite(l)) return l;
+    return l - r * trunc(l / r);
+}
+
+static double binary_apply(int op, double a, double b) {
+    switch (op) {
+        case ORC_ADD: return a + b;
+        case ORC_SUB: return a - b;
+        case ORC_MUL: return a * b;
+        case ORC_DIV: return a / b;
+        case ORC_POW: return pow(a, b);
+        case ORC_MAX: return elem_max(a, b);
+        case ORC_MIN: return elem_min(a, b);
+        case ORC_HYPOT: return hypot(a, b);
+        case ORC_ATAN2: return atan2(a, b);
+        case ORC_MOD: return elem_mod(a, b);
+        case ORC_REM: return elem_rem(a, b);
+        default: return NAN;
+    }
+}
+
+#define ORC_MAX_RANK 16
+
+/* broadcast.rs:8-47 (broadcast_shapes): returns rank, or (size_t)-1 on mismatch. */
+ORC_API size_t orc_broadcast_shape(const size_t* sa, size_t ra, const size_t* sb, size_t rb,
+                                   size_t* out) {
+    size_t rank = ra > rb ? ra : rb;
+    if (rank > ORC_MAX_RANK) return (size_t)-1;
+    for (size_t d = 0; d < rank; ++d) {
+        size_t a = d < rank - ra ? 1 : sa[d - (rank - ra)];
+        size_t b = d < rank - rb ? 1 : sb[d - (rank - rb)];
+        if (a == b) out[d] = a;
+        else if (a == 1) out[d] = b;
+        else if (b == 1) out[d] = a;
+        else if (a == 0 || b == 0) out[d] = 0;
+        else return (size_t)-1;
+    }
+    return rank;
+}
+
+ORC_API int orc_binary(int op, const double* a, const size_t* sa, size_t ra, const double* b,
+                       const size_t* sb, size_t rb, double* out, size_t* out_shape,
+                       size_t* out_rank) {
+    size_t oshape[ORC_MAX_RANK];
+    size_t rank = orc_broadcast_shape(sa, ra, sb, rb, oshape);
+    if (rank == (size_t)-1) return 1;
+    size_t ext_a[ORC_MAX_RANK], ext_b[ORC_MAX_RANK], adv_a[ORC_MAX_RANK], adv_b[ORC_MAX_RANK];
+    size_t stride_a = 1, stride_b = 1, len = 1;
+    for (size_t d = 0; d < rank; ++d) {
+        ext_a[d] = d < rank - ra ? 1 : sa[d - (rank - ra)];
+        ext_b[d] = d < rank - rb ? 1 : sb[d - (rank - rb)];
+        adv_a[d] = ext_a[d] <= 1 ? 0 : stride_a; /* broadcast.rs:141-150 */
+        adv_b[d] = ext_b[d] <= 1 ? 0 : stride_b;
+        stride_a *= ext_a[d] > 1 ? ext_a[d] : 1;  /* compute_strides, broadcast.rs:50-58 */
+        stride_b *= ext_b[d] > 1 ? ext_b[d] : 1;
+        len *= oshape[d];
+    }
+    if (out_shape) memcpy(out_shape, oshape, rank * sizeof(size_t));
+    if (out_rank) *out_rank = rank;
+    size_t coords[ORC_MAX_RANK] = {0};
+    size_t ia = 0, ib = 0;
+    for (size_t off = 0; off < len; ++off) { /* BroadcastIter::next, broadcast.rs:196-228 */
+        out[off] = binary_apply(op, a[ia], b[ib]);
+        if (off + 1 == len) break;
+        for (size_t d = 0; d < rank; ++d) {
+            if (oshape[d] == 0) continue;
+            coords[d] += 1;
+            if (coords[d] < oshape[d]) {
+                ia += adv_a[d];
+                ib += adv_b[d];
+                break;
+            }
+            coords[d] = 0;
+            ia -= adv_a[d] * (oshape[d] - 1);
+            ib -= adv_b[d] * (oshape[d] - 1);
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * sum / mean  -- crates/runmat-runtime/src/builtins/math/reduction/sum.rs:996-1079 (sum_tensor)
+ * One pass over the column-major linear index; each element is added into the output slot whose
+ * reduced coordinates are zeroed => per output the additions happen in ascending linear order.
+ * nan_mode 0 = Include (any NaN => NaN), 1 = Omit.
+ * `reduce_mask[d]` nonzero marks a reduced dimension.
+ * mean: crates/runmat-runtime/src/builtins/math/reduction/mean.rs:1134-1151 divides the sum by the
+ * element count (a division, not a reciprocal multiply).
+ * ---------------------------------------------------------------------------------------- */
+ORC_API int orc_sum(const double* x, const size_t* shape, size_t rank, const int* reduce_mask,
+                    int nan_mode, int mean, double* out) {
+    if (rank > ORC_MAX_RANK) return 1;
+    size_t oshape[ORC_MAX_RANK], total = 1, out_len = 1, reduce_count = 1;
+    for (size_t d = 0; d < rank; ++d) {
+        oshape[d] = reduce_mask[d] ? 1 : shape[d];
+        total *= shape[d];
+        out_len *= oshape[d];
+        if (reduce_mask[d]) reduce_count *= shape[d];
+    }
+    double* sums = (double*)calloc(out_len ? out_len : 1, sizeof(double));
+    unsigned char* saw_nan = (unsigned char*)calloc(out_len ? out_len : 1, 1);
+    size_t* counts = (size_t*)calloc(out_len ? out_len : 1, sizeof(size_t));
+    if (!sums || !saw_nan || !counts) return 2;
+    size_t coords[ORC_MAX_RANK];
+    for (size_t linear = 0; linear < total; ++linear) {
+        size_t rem = linear; /* linear_to_multi */
+        for (size_t d = 0; d < rank; ++d) {
+            coords[d] = shape[d] ? rem % shape[d] : 0;
+            if (shape[d]) rem /= shape[d];
+        }
+        size_t out_idx = 0, stride = 1; /* multi_to_linear over the output shape */
+        for (size_t d = 0; d < rank; ++d) {
+            size_t c = reduce_mask[d] ? 0 : coords[d];
+            out_idx += c * stride;
+            stride *= oshape[d];
+        }
+        double value = x[linear];
+        if (value != value) {
+            if (nan_mode == 0) saw_nan[out_idx] = 1;
+        } else {
+            sums[out_idx] += value;
+            counts[out_idx] += 1;
+        }
+    }
+    for (size_t i = 0; i < out_len; ++i) {
+        double r;
+        if (nan_mode == 0 && saw_nan[i]) r = NAN;
+        else r = sums[i]; /* saw_value false => 0.0, which sums[i] already is */
+        if (mean) {
+            if (nan_mode == 0) r = saw_nan[i] ? NAN : r / (double)reduce_count;
+            else r = counts[i] ? r / (double)counts[i] : NAN;
+        }
+        out[i] = r;
+    }
+    free(sums);
+    free(saw_nan);
+    free(counts);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * RNG -- crates/runmat-runtime/src/builtins/common/random.rs
+ *   constants :7-13, mix_seed :128-141, advance_state :238-256, next_uniform_state :271-278,
+ *   next_normal_pair :279-288, generate_normal :530-543.
+ * 64-bit LCG s <- s*6364136223846793005 + 1; uniform = (s >> 11) * 2^-53.
+ * ---------------------------------------------------------------------------------------- */
+#define RNG_MULT 6364136223846793005ULL
+#define RNG_INC 1ULL
+#define DEFAULT_RNG_SEED 0x9e3779b97f4a7c15ULL
+
+ORC_API uint64_t orc_rng_default_seed(void) { return DEFAULT_RNG_SEED; }
+
+ORC_API uint64_t orc_rng_mix_seed(uint64_t seed) {
+    if (seed == 0) return DEFAULT_RNG_SEED;
+    uint64_t z = seed + 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    uint64_t mixed = z ^ (z >> 31);
+    return mixed == 0 ? DEFAULT_RNG_SEED : mixed;
+}
+
+ORC_API uint64_t orc_rng_advance(uint64_t state, uint64_t delta) {
+    if (delta == 0) return state;
+    uint64_t cur_mult = RNG_MULT, cur_plus = RNG_INC, acc_mult = 1, acc_plus = 0;
+    while (delta > 0) {
+        if (delta & 1) {
+            acc_mult = acc_mult * cur_mult;
+            acc_plus = acc_plus * cur_mult + cur_plus;
+        }
+        cur_plus = cur_plus * (cur_mult + 1);
+        cur_mult = cur_mult * cur_mult;
+        delta >>= 1;
+    }
+    return acc_mult * state + acc_plus;
+}
+
+static double next_uniform_state(uint64_t* state) {
+    *state = (*state) * RNG_MULT + RNG_INC;
+    uint64_t bits = *state >> 11;
+    return (double)bits * (1.0 / 9007199254740992.0);
+}
+
+/* generate_uniform: `len` draws; returns the advanced state through *state. */
+ORC_API void orc_rng_uniform(uint64_t* state, size_t len, double* out) {
+    for (size_t i = 0; i < len; ++i) out[i] = next_uniform_state(state);
+}
+
+/* generate_normal: Box-Muller pairs (z0, z1) emitted consecutively; odd len drops the last z1
+ * but the state has still advanced by 2 per pair (random.rs:530-543). */
+ORC_API void orc_rng_normal(uint64_t* state, size_t len, double* out) {
+    size_t n = 0;
+    while (n < len) {
+        double u1 = next_uniform_state(state);
+        if (u1 <= 0.0) u1 = 2.2250738585072014e-308; /* f64::MIN_POSITIVE, random.rs:13,281-283 */
+        double u2 = next_uniform_state(state);
+        double radius = sqrt(-2.0 * log(u1));
+        double angle = 2.0 * M_PI * u2;
+        out[n++] = radius * cos(angle);
+        if (n < len) out[n++] = radius * sin(angle);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * LU -- crates/runmat-accelerate/src/host_lu.rs:19-119 (lu_factor_host)
+ * Doolittle with partial pivoting on a row-major working copy; pivot = FIRST row with strictly
+ * larger |a| (:38-47); |pivot| <= 1e-12 zeroes the sub-column and skips the update (:54-59).
+ * Outputs (all column-major): combined rows x cols, lower rows x rows (unit diagonal),
+ * upper rows x cols, perm matrix rows x rows, pivot vector rows x 1 (1-based row ids).
+ * Any output pointer may be NULL.
+ * ---------------------------------------------------------------------------------------- */
+ORC_API int orc_lu(const double* data, size_t rows, size_t cols, double* combined, double* lower,
+                   double* upper, double* perm_matrix, double* pivot_vector) {
+    double* m = (double*)malloc(sizeof(double) * (rows * cols + 1));
+    size_t* perm = (size_t*)malloc(sizeof(size_t) * (rows ? rows : 1));
+    if (!m || !perm) return 2;
+    for (size_t r = 0; r < rows; ++r)
+        for (size_t c = 0; c < cols; ++c) m[r * cols + c] = data[r + c * rows];
+    for (size_t r = 0; r < rows; ++r) perm[r] = r;
+    size_t min_dim = rows < cols ? rows : cols;
+    for (size_t k = 0; k < min_dim; ++k) {
+        size_t pivot_row = k;
+        double pivot_abs = 0.0;
+        for (size_t r = k; r < rows; ++r) {
+            double a = fabs(m[r * cols + k]);
+            if (a > pivot_abs) {
+                pivot_abs = a;
+                pivot_row = r;
+            }
+        }
+        if (pivot_row != k) {
+            for (size_t c = 0; c < cols; ++c) {
+                double t = m[k * cols + c];
+                m[k * cols + c] = m[pivot_row * cols + c];
+                m[pivot_row * cols + c] = t;
+            }
+            size_t t = perm[k];
+            perm[k] = perm[pivot_row];
+            perm[pivot_row] = t;
+        }
+        if (pivot_abs <= 1.0e-12) {
+            for (size_t r = k + 1; r < rows; ++r) m[r * cols + k] = 0.0;
+            continue;
+        }
+        double pivot = m[k * cols + k];
+        for (size_t r = k + 1; r < rows; ++r) {
+            double factor = m[r * cols + k] / pivot;
+            m[r * cols + k] = factor;
+            for (size_t c = k + 1; c < cols; ++c) m[r * cols + c] -= factor * m[k * cols + c];
+        }
+    }
+    if (combined)
+        for (size_t r = 0; r < rows; ++r)
+            for (size_t c = 0; c < cols; ++c) combined[r + c * rows] = m[r * cols + c];
+    if (lower) {
+        size_t limit = min_dim;
+        for (size_t i = 0; i < rows; ++i)
+            for (size_t j = 0; j < rows; ++j) {
+                double v = 0.0;
+                if (i == j) v = 1.0;
+                else if (i > j && j < limit) v = m[i * cols + j];
+                lower[i + j * rows] = v;
+            }
+    }
+    if (upper)
+        for (size_t i = 0; i < rows; ++i)
+            for (size_t j = 0; j < cols; ++j) upper[i + j * rows] = (i <= j) ? m[i * cols + j] : 0.0;
+    if (perm_matrix) {
+        memset(perm_matrix, 0, sizeof(double) * rows * rows);
+        for (size_t r = 0; r < rows; ++r) perm_matrix[r + perm[r] * rows] = 1.0;
+    }
+    if (pivot_vector)
+        for (size_t r = 0; r < rows; ++r) pivot_vector[r] = (double)(perm[r] + 1);
+    free(m);
+    free(perm);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * mldivide -- crates/runmat-runtime/src/builtins/math/linalg/ops/mldivide.rs:317-404
+ * Reference: scalar lhs => rhs * (1/lhs) (:321-325); else x = pinv_tol(A) * B via nalgebra SVD
+ * with tol = eps * max(m,n) * max(sigma_max, 1) (:396-404).  nalgebra is third-party and absent
+ * from /root/reference, so the SVD here is a one-sided (Hestenes) Jacobi SVD -- same
+ * mathematical result (minimum-norm least-squares solution with singular values <= tol dropped),
+ * different rounding. PARITY UNPINNED at bit level; pinned by residuals only.
+ * A is m x n, B is m x nrhs, X is n x nrhs. Returns 0, or 1 on shape error.
+ * ---------------------------------------------------------------------------------------- */
+ORC_API int orc_mldivide_svd(const double* A, size_t m, size_t n, const double* B, size_t brows,
+                             size_t nrhs, double* X) {
+    if (m == 1 && n == 1) {
+        double r = 1.0 / A[0];
+        for (size_t i = 0; i < brows * nrhs; ++i) X[i] = B[i] * r;
+        return 0;
+    }
+    if (brows != m) return 1;
+    if (m == 0) {
+        memset(X, 0, sizeof(double) * n * nrhs);
+        return 0;
+    }
+    /* One-sided Jacobi on W (m x n, or on A^T when m < n so the working matrix is tall). */
+    int transposed = m < n;
+    size_t p = transposed ? n : m, q = transposed ? m : n; /* W is p x q, p >= q */
+    double* W = (double*)malloc(sizeof(double) * p * q);
+    double* V = (double*)calloc(q * q, sizeof(double));
+    double* sig = (double*)malloc(sizeof(double) * q);
+    if (!W || !V || !sig) return 2;
+    for (size_t j = 0; j < q; ++j)
+        for (size_t i = 0; i < p; ++i) W[i + j * p] = transposed ? A[j + i * m] : A[i + j * m];
+    for (size_t j = 0; j < q; ++j) V[j + j * q] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (size_t a = 0; a + 1 < q; ++a) {
+            for (size_t b = a + 1; b < q; ++b) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (size_t i = 0; i < p; ++i) {
+                    alpha += W[i + a * p] * W[i + a * p];
+                    beta += W[i + b * p] * W[i + b * p];
+                    gamma += W[i + a * p] * W[i + b * p];
+                }
+                if (gamma == 0.0) continue;
+                double lim = fabs(gamma) / sqrt(alpha * beta);
+                if (lim > off) off = lim;
+                if (lim < 1e-15) continue;
+                double zeta = (beta - alpha) / (2.0 * gamma);
+                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (size_t i = 0; i < p; ++i) {
+                    double wa = W[i + a * p], wb = W[i + b * p];
+                    W[i + a * p] = c * wa - s * wb;
+                    W[i + b * p] = s * wa + c * wb;
+                }
+                for (size_t i = 0; i < q; ++i) {
+                    double va = V[i + a * q], vb = V[i + b * q];
+                    V[i + a * q] = c * va - s * vb;
+                    V[i + b * q] = s * va + c * vb;
+                }
+            }
+        }
+        if (off < 1e-15) break;
+    }
+    double smax = 0.0;
+    for (size_t j = 0; j < q; ++j) {
+        double s2 = 0;
+        for (size_t i = 0; i < p; ++i) s2 += W[i + j * p] * W[i + j * p];
+        sig[j] = sqrt(s2);
+        if (sig[j] > smax) smax = sig[j];
+    }
+    double maxdim = (double)(m > n ? m : n);
+    double tol = 2.220446049250313e-16 * maxdim * (smax > 1.0 ? smax : 1.0); /* :396-404 */
+    /* W = U*diag(sig) (columns), so U_j = W_j / sig_j.
+     * not transposed: A = U S V^T  => X = V S^-1 U^T B
+     * transposed:     A^T = U S V^T => A = V S U^T => X = U S^-1 V^T B              */
+    for (size_t r = 0; r < nrhs; ++r) {
+        for (size_t i = 0; i < n; ++i) X[i + r * n] = 0.0;
+        for (size_t j = 0; j < q; ++j) {
+            if (sig[j] <= tol) continue;
+            double coef = 0.0;
+            if (!transposed) {
+                for (size_t i = 0; i < m; ++i) coef += (W[i + j * p] / sig[j]) * B[i + r * m];
+                coef /= sig[j];
+                for (size_t i = 0; i < n; ++i) X[i + r * n] += V[i + j * q] * coef;
+            } else {
+                for (size_t i = 0; i < m; ++i) coef += V[i + j * q] * B[i + r * m];
+                coef /= sig[j];
+                for (size_t i = 0; i < n; ++i) X[i + r * n] += (W[i + j * p] / sig[j]) * coef;
+            }
+        }
+    }
+    free(W);
+    free(V);
+    free(sig);
+    return 0;
+}
+
+/* LU-based A\b for square well-conditioned A: the algorithm the HIP path implements (LU with the
+ * host_lu.rs pivot rule, then forward/back substitution). Used as the bit-pattern-adjacent
+ * comparator at sizes where the SVD restatement is too slow. Returns 3 if a pivot is <= 1e-12. */
+ORC_API int orc_mldivide_lu(const double* A, size_t n, const double* B, size_t nrhs, double* X) {
+    double* comb = (double*)malloc(sizeof(double) * n * n);
+    double* piv = (double*)malloc(sizeof(double) * n);
+    if (!comb || !piv) return 2;
+    orc_lu(A, n, n, comb, NULL, NULL, NULL, piv);
+    for (size_t k = 0; k < n; ++k)
+        if (fabs(comb[k + k * n]) <= 1.0e-12) {
+            free(comb);
+            free(piv);
+            return 3;
+        }
+    for (size_t r = 0; r < nrhs; ++r) {
+        double* x = X + r * n;
+        for (size_t i = 0; i < n; ++i) x[i] = B[(size_t)(piv[i] - 1.0) + r * n];
+        for (size_t i = 0; i < n; ++i) { /* L y = Pb, unit lower */
+            double s = x[i];
+            for (size_t k = 0; k < i; ++k) s -= comb[i + k * n] * x[k];
+            x[i] = s;
+        }
+        for (size_t ii = n; ii-- > 0;) { /* U x = y */
+            double s = x[ii];
+            for (size_t k = ii + 1; k < n; ++k) s -= comb[ii + k * n] * x[k];
+            x[ii] = s / comb[ii + ii * n];
+        }
+    }
+    free(comb);
+    free(piv);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Benchmark workloads restated on the CPU path (one temporary array per op, serial), used as the
+ * `cpu_baseline` leg of bench.py and for parity at BASELINE.json sizes.
+ * ---------------------------------------------------------------------------------------- */
+
+/* D = sin(A).*B + C : three CPU builtin calls (sin.rs:245-255, times.rs:682-700, plus.rs), each
+ * allocating a fresh output like the reference's `.collect()`. */
+ORC_API int orc_sin_mul_add(const double* A, const double* B, const double* C, size_t n, double* D) {
+    double* t0 = (double*)malloc(sizeof(double) * (n ? n : 1));
+    double* t1 = (double*)malloc(sizeof(double) * (n ? n : 1));
+    if (!t0 || !t1) return 2;
+    for (size_t i = 0; i < n; ++i) t0[i] = sin(A[i]);
+    for (size_t i = 0; i < n; ++i) t1[i] = t0[i] * B[i];
+    for (size_t i = 0; i < n; ++i) D[i] = t1[i] + C[i];
+    free(t0);
+    free(t1);
+    return 0;
+}
+
+/* benchmarks/elementwise-math/runmat.m:10-13 in f64 (BASELINE.json configs[0]):
+ *   y0 = sin(x).*exp(-x/10); y1 = y0.*cos(x/4) + 0.25.*(y0.^2); y2 = tanh(y1) + 0.1.*y1
+ * evaluated op by op with temporaries (14 CPU builtin passes). y0.^2 uses powf (power.rs:358). */
+ORC_API int orc_elementwise_math_chain(const double* x, size_t n, double* y2) {
+    double* t[6];
+    for (int k = 0; k < 6; ++k) {
+        t[k] = (double*)malloc(sizeof(double) * (n ? n : 1));
+        if (!t[k]) return 2;
+    }
+    for (size_t i = 0; i < n; ++i) t[0][i] = sin(x[i]);
+    for (size_t i = 0; i < n; ++i) t[1][i] = -x[i];
+    for (size_t i = 0; i < n; ++i) t[2][i] = t[1][i] / 10.0;
+    for (size_t i = 0; i < n; ++i) t[1][i] = exp(t[2][i]);
+    for (size_t i = 0; i < n; ++i) t[2][i] = t[0][i] * t[1][i]; /* y0 */
+    for (size_t i = 0; i < n; ++i) t[0][i] = x[i] / 4.0;
+    for (size_t i = 0; i < n; ++i) t[1][i] = cos(t[0][i]);
+    for (size_t i = 0; i < n; ++i) t[3][i] = t[2][i] * t[1][i];
+    for (size_t i = 0; i < n; ++i) t[0][i] = pow(t[2][i], 2.0);
+    for (size_t i = 0; i < n; ++i) t[1][i] = 0.25 * t[0][i];
+    for (size_t i = 0; i < n; ++i) t[4][i] = t[3][i] + t[1][i]; /* y1 */
+    for (size_t i = 0; i < n; ++i) t[0][i] = tanh(t[4][i]);
+    for (size_t i = 0; i < n; ++i) t[1][i] = 0.1 * t[4][i];
+    for (size_t i = 0; i < n; ++i) y2[i] = t[0][i] + t[1][i];
+    for (int k = 0; k < 6; ++k) free(t[k]);
+    return 0;
+}
+
+/* benchmarks/monte-carlo-analysis/runmat_rng.m in f64 with the CPU randn stream:
+ *   S = S0; for t: Z = randn(M,1); S = S .* exp(drift + scale.*Z); end
+ *   price = mean(max(S-K,0),'all') * exp(-mu*T*dt)
+ * `state` is the LCG state on entry (advanced on exit). */
+ORC_API double orc_monte_carlo_price(uint64_t* state, size_t M, size_t T, double S0, double mu,
+                                     double sigma, double dt, double K) {
+    double* S = (double*)malloc(sizeof(double) * (M ? M : 1));
+    double* Z = (double*)malloc(sizeof(double) * (M ? M : 1));
+    if (!S || !Z) return NAN;
+    double drift = (mu - 0.5 * sigma * sigma) * dt;
+    double scale = sigma * sqrt(dt);
+    for (size_t i = 0; i < M; ++i) S[i] = S0;
+    for (size_t t = 0; t < T; ++t) {
+        orc_rng_normal(state, M, Z);
+        for (size_t i = 0; i < M; ++i) S[i] = S[i] * exp(drift + scale * Z[i]);
+    }
+    double sum = 0.0;
+    for (size_t i = 0; i < M; ++i) sum += elem_max(S[i] - K, 0.0);
+    double price = (sum / (double)M) * exp(-mu * (double)T * dt);
+    free(S);
+    free(Z);
+    return price;
+}
+
+/* splitmix64-based uniform fill used by bench/tests to build identical inputs on host and device
+ * (SURVEY.md 8(d) config 2/3): value = lo + (hi-lo) * (next53 * 2^-53), one splitmix64 step per
+ * element with state = seed + (i+1)*0x9e3779b97f4a7c15 (counter form => order independent). */
+ORC_API void orc_fill_uniform(uint64_t seed, double lo, double hi, size_t n, double* out) {
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t z = seed + (uint64_t)(i + 1) * 0x9e3779b97f4a7c15ULL;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+        z = z ^ (z >> 31);
+        out[i] = lo + (hi - lo) * ((double)(z >> 11) * (1.0 / 9007199254740992.0));
+    }
+}

@@ -1,0 +1,243 @@
+"""ctypes wrapper of oracle/liboracle.so -- the CPU restatement of the reference's hot path.
+
+TEST INFRASTRUCTURE ONLY (see oracle.c header): importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never from runmat_amd/.
+All arrays are column-major f64; matrices are passed as numpy arrays and flattened in Fortran order.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "liboracle.so"
+
+UNARY = {n: i for i, n in enumerate((
+    "sin", "cos", "tan", "asin", "acos", "atan", "sinh", "cosh", "tanh", "asinh", "acosh", "atanh", "exp", "expm1",
+    "log", "log2", "log10", "log1p", "sqrt", "abs", "sign", "floor", "ceil", "round", "fix", "neg", "exp2",
+    "heaviside", "isnan", "isinf", "isfinite", "uplus"))}
+BINARY = {"add": 0, "sub": 1, "mul": 2, "div": 3, "pow": 4, "max": 5, "min": 6, "hypot": 7, "atan2": 8, "mod": 9,
+          "rem": 10}
+
+_DP = C.POINTER(C.c_double)
+_SZP = C.POINTER(C.c_size_t)
+_lib = None
+
+
+def build() -> None:
+    subprocess.run(["make", "-C", str(_HERE), "-s"], check=True)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            build()
+        l = C.CDLL(str(LIB_PATH))
+        l.orc_matmul.restype = C.c_int
+        l.orc_matmul.argtypes = [_DP, C.c_size_t, C.c_size_t, _DP, C.c_size_t, C.c_size_t, _DP]
+        l.orc_unary.restype = C.c_int
+        l.orc_unary.argtypes = [C.c_int, _DP, C.c_size_t, _DP]
+        l.orc_binary.restype = C.c_int
+        l.orc_binary.argtypes = [C.c_int, _DP, _SZP, C.c_size_t, _DP, _SZP, C.c_size_t, _DP, _SZP, _SZP]
+        l.orc_broadcast_shape.restype = C.c_size_t
+        l.orc_broadcast_shape.argtypes = [_SZP, C.c_size_t, _SZP, C.c_size_t, _SZP]
+        l.orc_sum.restype = C.c_int
+        l.orc_sum.argtypes = [_DP, _SZP, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.c_int, _DP]
+        l.orc_rng_default_seed.restype = C.c_uint64
+        l.orc_rng_mix_seed.restype = C.c_uint64
+        l.orc_rng_mix_seed.argtypes = [C.c_uint64]
+        l.orc_rng_advance.restype = C.c_uint64
+        l.orc_rng_advance.argtypes = [C.c_uint64, C.c_uint64]
+        l.orc_rng_uniform.restype = None
+        l.orc_rng_uniform.argtypes = [C.POINTER(C.c_uint64), C.c_size_t, _DP]
+        l.orc_rng_normal.restype = None
+        l.orc_rng_normal.argtypes = [C.POINTER(C.c_uint64), C.c_size_t, _DP]
+        l.orc_lu.restype = C.c_int
+        l.orc_lu.argtypes = [_DP, C.c_size_t, C.c_size_t, _DP, _DP, _DP, _DP, _DP]
+        l.orc_mldivide_svd.restype = C.c_int
+        l.orc_mldivide_svd.argtypes = [_DP, C.c_size_t, C.c_size_t, _DP, C.c_size_t, C.c_size_t, _DP]
+        l.orc_mldivide_lu.restype = C.c_int
+        l.orc_mldivide_lu.argtypes = [_DP, C.c_size_t, _DP, C.c_size_t, _DP]
+        l.orc_sin_mul_add.restype = C.c_int
+        l.orc_sin_mul_add.argtypes = [_DP, _DP, _DP, C.c_size_t, _DP]
+        l.orc_elementwise_math_chain.restype = C.c_int
+        l.orc_elementwise_math_chain.argtypes = [_DP, C.c_size_t, _DP]
+        l.orc_monte_carlo_price.restype = C.c_double
+        l.orc_monte_carlo_price.argtypes = [C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t, C.c_double, C.c_double,
+                                            C.c_double, C.c_double, C.c_double]
+        l.orc_fill_uniform.restype = None
+        l.orc_fill_uniform.argtypes = [C.c_uint64, C.c_double, C.c_double, C.c_size_t, _DP]
+        _lib = l
+    return _lib
+
+
+def _f(a) -> np.ndarray:
+    """Column-major flat f64 copy."""
+    a = np.asarray(a, dtype=np.float64)
+    return np.ascontiguousarray(a.reshape(-1, order="F"))
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(_DP)
+
+
+def _shape(s):
+    return (C.c_size_t * max(len(s), 1))(*[int(x) for x in s])
+
+
+def matmul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    fa, fb = _f(a), _f(b)
+    out = np.empty(a.shape[0] * b.shape[1], dtype=np.float64)
+    rc = lib().orc_matmul(_p(fa), a.shape[0], a.shape[1], _p(fb), b.shape[0], b.shape[1], _p(out))
+    if rc:
+        raise ValueError("Inner matrix dimensions must agree")
+    return out.reshape((a.shape[0], b.shape[1]), order="F")
+
+
+def unary(op: str, x: np.ndarray) -> np.ndarray:
+    x = np.asarray(x, dtype=np.float64)
+    fx = _f(x)
+    out = np.empty_like(fx)
+    if lib().orc_unary(UNARY[op], _p(fx), fx.size, _p(out)):
+        raise ValueError(op)
+    return out.reshape(x.shape, order="F")
+
+
+def binary(op: str, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    sa, sb = _shape(a.shape), _shape(b.shape)
+    oshape = (C.c_size_t * 16)()
+    rank = lib().orc_broadcast_shape(sa, a.ndim, sb, b.ndim, oshape)
+    if rank == C.c_size_t(-1).value:
+        raise ValueError("size mismatch between inputs")
+    shape = tuple(int(oshape[i]) for i in range(rank))
+    out = np.empty(int(np.prod(shape, dtype=np.int64)), dtype=np.float64)
+    fa, fb = _f(a), _f(b)
+    orank = C.c_size_t()
+    if lib().orc_binary(BINARY[op], _p(fa), sa, a.ndim, _p(fb), sb, b.ndim, _p(out), oshape, C.byref(orank)):
+        raise ValueError("size mismatch between inputs")
+    return out.reshape(shape, order="F")
+
+
+def reduce_sum(x: np.ndarray, dims, omitnan: bool = False, mean: bool = False) -> np.ndarray:
+    """dims: iterable of zero-based dims to reduce, or 'all'."""
+    x = np.asarray(x, dtype=np.float64)
+    mask = np.zeros(max(x.ndim, 1), dtype=np.int32)
+    if dims == "all":
+        mask[:] = 1
+    else:
+        for d in dims:
+            mask[d] = 1
+    oshape = tuple(1 if mask[d] else x.shape[d] for d in range(x.ndim))
+    fx = _f(x)
+    out = np.empty(int(np.prod(oshape, dtype=np.int64)) if oshape else 1, dtype=np.float64)
+    rc = lib().orc_sum(_p(fx), _shape(x.shape), x.ndim, mask.ctypes.data_as(C.POINTER(C.c_int)), 1 if omitnan else 0,
+                       1 if mean else 0, _p(out))
+    if rc:
+        raise ValueError("sum")
+    return out.reshape(oshape, order="F")
+
+
+def rng_default_seed() -> int:
+    return int(lib().orc_rng_default_seed())
+
+
+def rng_mix_seed(seed: int) -> int:
+    return int(lib().orc_rng_mix_seed(seed))
+
+
+def rng_advance(state: int, delta: int) -> int:
+    return int(lib().orc_rng_advance(state, delta))
+
+
+def rng_uniform(state: int, n: int):
+    s = C.c_uint64(state)
+    out = np.empty(n, dtype=np.float64)
+    lib().orc_rng_uniform(C.byref(s), n, _p(out))
+    return out, int(s.value)
+
+
+def rng_normal(state: int, n: int):
+    s = C.c_uint64(state)
+    out = np.empty(n, dtype=np.float64)
+    lib().orc_rng_normal(C.byref(s), n, _p(out))
+    return out, int(s.value)
+
+
+def lu(a: np.ndarray):
+    a = np.asarray(a, dtype=np.float64)
+    rows, cols = a.shape
+    fa = _f(a)
+    comb = np.empty(rows * cols)
+    low = np.empty(rows * rows)
+    up = np.empty(rows * cols)
+    pm = np.empty(rows * rows)
+    pv = np.empty(rows)
+    if lib().orc_lu(_p(fa), rows, cols, _p(comb), _p(low), _p(up), _p(pm), _p(pv)):
+        raise MemoryError
+    return (comb.reshape((rows, cols), order="F"), low.reshape((rows, rows), order="F"),
+            up.reshape((rows, cols), order="F"), pm.reshape((rows, rows), order="F"), pv.reshape((rows, 1)))
+
+
+def mldivide_svd(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if b.ndim == 1:
+        b = b.reshape(-1, 1)
+    m, n = a.shape
+    fa, fb = _f(a), _f(b)
+    scalar = a.size == 1
+    xr = b.shape[0] if scalar else n
+    out = np.empty(xr * b.shape[1])
+    if lib().orc_mldivide_svd(_p(fa), m, n, _p(fb), b.shape[0], b.shape[1], _p(out)):
+        raise ValueError("mldivide: row mismatch")
+    return out.reshape((xr, b.shape[1]), order="F")
+
+
+def mldivide_lu(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if b.ndim == 1:
+        b = b.reshape(-1, 1)
+    n = a.shape[0]
+    fa, fb = _f(a), _f(b)
+    out = np.empty(n * b.shape[1])
+    rc = lib().orc_mldivide_lu(_p(fa), n, _p(fb), b.shape[1], _p(out))
+    if rc == 3:
+        raise np.linalg.LinAlgError("singular")
+    return out.reshape((n, b.shape[1]), order="F")
+
+
+def sin_mul_add(a, b, c) -> np.ndarray:
+    a = np.asarray(a, dtype=np.float64)
+    fa, fb, fc = _f(a), _f(b), _f(c)
+    out = np.empty_like(fa)
+    lib().orc_sin_mul_add(_p(fa), _p(fb), _p(fc), fa.size, _p(out))
+    return out.reshape(a.shape, order="F")
+
+
+def elementwise_math_chain(x) -> np.ndarray:
+    x = np.asarray(x, dtype=np.float64)
+    fx = _f(x)
+    out = np.empty_like(fx)
+    lib().orc_elementwise_math_chain(_p(fx), fx.size, _p(out))
+    return out.reshape(x.shape, order="F")
+
+
+def monte_carlo_price(state: int, M: int, T: int, S0=100.0, mu=0.05, sigma=0.2, dt=1.0 / 252.0, K=100.0):
+    s = C.c_uint64(state)
+    price = lib().orc_monte_carlo_price(C.byref(s), M, T, S0, mu, sigma, dt, K)
+    return float(price), int(s.value)
+
+
+def fill_uniform(seed: int, lo: float, hi: float, n: int) -> np.ndarray:
+    out = np.empty(n, dtype=np.float64)
+    lib().orc_fill_uniform(seed, lo, hi, n, _p(out))
+    return out

@@ -1,0 +1,117 @@
+"""ctypes binding of librmhip.so (include/rmhip.h).
+
+There is deliberately no fallback: if the shared library is missing or fails to load this module
+raises, and if no gfx950 device is present `rmhip_init` fails (RMHIP_ERR_NO_DEVICE).  The product
+path never imports anything under oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "csrc" / "librmhip.so"
+
+OK = 0
+ERR_INVALID, ERR_UNSUPPORTED, ERR_SHAPE, ERR_HIP, ERR_NOT_FOUND = 1, 2, 3, 4, 5
+ERR_COMPILE, ERR_SINGULAR, ERR_OOM, ERR_NO_DEVICE = 6, 7, 8, 9
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [
+        ("name", C.c_char * 128),
+        ("arch", C.c_char * 32),
+        ("device_ordinal", C.c_int),
+        ("compute_units", C.c_int),
+        ("wavefront_size", C.c_int),
+        ("clock_mhz", C.c_int),
+        ("total_memory_bytes", C.c_uint64),
+        ("precision_bits", C.c_int),
+        ("reduction_workgroup_size", C.c_uint32),
+        ("two_pass_threshold", C.c_uint32),
+    ]
+
+
+class Telemetry(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "fused_elementwise_count", "fused_elementwise_ns", "fused_reduction_count", "fused_reduction_ns",
+        "matmul_count", "matmul_ns", "mldivide_count", "mldivide_ns", "upload_bytes", "download_bytes",
+        "fusion_cache_hits", "fusion_cache_misses", "kernel_launches", "bytes_allocated", "bytes_pooled")]
+
+
+# Every symbol include/rmhip.h declares: name -> (restype, argtypes). Used both to bind and by the
+# CPU-side test that checks the library exports the full ABI.
+_P = C.c_void_p
+_SZ = C.c_size_t
+_SZP = C.POINTER(C.c_size_t)
+_DP = C.POINTER(C.c_double)
+_BUF = C.c_uint64
+_BUFP = C.POINTER(C.c_uint64)
+SIGNATURES = {
+    "rmhip_version": (C.c_char_p, []),
+    "rmhip_last_error": (C.c_char_p, []),
+    "rmhip_init": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "rmhip_shutdown": (C.c_int, [_P]),
+    "rmhip_device_info": (C.c_int, [_P, C.POINTER(DeviceInfo)]),
+    "rmhip_set_stream": (C.c_int, [_P, _P]),
+    "rmhip_get_stream": (_P, [_P]),
+    "rmhip_synchronize": (C.c_int, [_P]),
+    "rmhip_upload": (C.c_int, [_P, _DP, _SZP, _SZ, _BUFP]),
+    "rmhip_download": (C.c_int, [_P, _BUF, _DP, _SZ]),
+    "rmhip_free": (C.c_int, [_P, _BUF]),
+    "rmhip_shape": (C.c_int, [_P, _BUF, _SZP, _SZP]),
+    "rmhip_numel": (C.c_int, [_P, _BUF, _SZP]),
+    "rmhip_fill": (C.c_int, [_P, C.c_double, _SZP, _SZ, _BUFP]),
+    "rmhip_reshape": (C.c_int, [_P, _BUF, _SZP, _SZ, _BUFP]),
+    "rmhip_wrap_external": (C.c_int, [_P, _P, _SZP, _SZ, _BUFP]),
+    "rmhip_device_ptr": (_P, [_P, _BUF]),
+    "rmhip_fill_uniform": (C.c_int, [_P, C.c_uint64, C.c_double, C.c_double, _SZP, _SZ, _BUFP]),
+    "rmhip_fused_elementwise": (C.c_int, [_P, C.c_char_p, _BUFP, _SZ, _SZP, _SZ, _SZ, _SZ, _BUFP]),
+    "rmhip_fused_reduction": (C.c_int, [_P, C.c_char_p, _BUFP, _SZ, _SZP, _SZ, _SZ, _SZ, C.c_uint32, C.c_int,
+                                        C.c_double, _BUFP]),
+    "rmhip_wgsl_translate": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, _SZ, _SZP]),
+    "rmhip_wgsl_compile_check": (C.c_int, [C.c_char_p, C.c_int]),
+    "rmhip_binary": (C.c_int, [_P, C.c_int, _BUF, _BUF, _BUFP]),
+    "rmhip_unary": (C.c_int, [_P, C.c_int, _BUF, _BUFP]),
+    "rmhip_scalar": (C.c_int, [_P, C.c_int, _BUF, C.c_double, _BUFP]),
+    "rmhip_reduce": (C.c_int, [_P, C.c_int, _BUF, C.c_int, C.c_int, _BUFP]),
+    "rmhip_matmul": (C.c_int, [_P, _BUF, _BUF, _BUFP]),
+    "rmhip_lu": (C.c_int, [_P, _BUF, _BUFP]),
+    "rmhip_mldivide": (C.c_int, [_P, _BUF, _BUF, _BUFP]),
+    "rmhip_set_rng_state": (C.c_int, [_P, C.c_uint64]),
+    "rmhip_get_rng_state": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "rmhip_rng_seed": (C.c_int, [_P, C.c_uint64]),
+    "rmhip_random_uniform": (C.c_int, [_P, _SZP, _SZ, _BUFP]),
+    "rmhip_random_normal": (C.c_int, [_P, _SZP, _SZ, _BUFP]),
+    "rmhip_telemetry": (C.c_int, [_P, C.POINTER(Telemetry)]),
+    "rmhip_reset_telemetry": (C.c_int, [_P]),
+    "rmhip_timer_begin": (C.c_int, [_P]),
+    "rmhip_timer_end": (C.c_int, [_P, _DP]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load librmhip.so (once). Raises OSError with build instructions if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("RMHIP_LIBRARY", str(LIB_PATH)))
+    if not path.exists():
+        raise OSError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C runmat_amd/csrc`. runmat_amd has no CPU fallback."
+        )
+    lib = C.CDLL(str(path))
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().rmhip_last_error().decode("utf-8", "replace")

@@ -1,0 +1,347 @@
+// codegen.cpp -- lowers a parsed fused-kernel program to HIP source, compiles it with hipRTC for
+// gfx950 and caches the loaded function per context (see codegen.h).
+#include "codegen.h"
+
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace rmhip {
+
+static const char* kSkelCommon =
+#include "skel_common_str.inc"
+    ;
+static const char* kSkelReduce =
+#include "skel_reduce_str.inc"
+    ;
+
+uint64_t fnv1a(const std::string& s) {
+    uint64_t h = 1469598103934665603ULL;
+    for (unsigned char c : s) {
+        h ^= c;
+        h *= 1099511628211ULL;
+    }
+    return h;
+}
+
+static int env_int(const char* name, int dflt, int lo, int hi) {
+    const char* v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    int x = std::atoi(v);
+    if (x < lo) x = lo;
+    if (x > hi) x = hi;
+    return x;
+}
+
+EwTuning EwTuning::from_env() {
+    EwTuning t;
+    t.unroll = env_int("RMHIP_EW_UNROLL", t.unroll, 1, 8);
+    t.block = env_int("RMHIP_EW_BLOCK", t.block, 64, 1024);
+    t.block = (t.block / 64) * 64;
+    t.blocks_per_cu = env_int("RMHIP_EW_BLOCKS_PER_CU", t.blocks_per_cu, 1, 64);
+    t.nontemporal = env_int("RMHIP_EW_NT", t.nontemporal, 0, 1);
+    return t;
+}
+
+FusedKernel::~FusedKernel() {
+    if (module) (void)hipModuleUnload(module);
+}
+
+// ---- source generation -------------------------------------------------------------------------
+
+static std::string body_function(const ElementwiseProgram& p) {
+    std::ostringstream s;
+    s << "__device__ __forceinline__ void rm_body(";
+    for (int k = 0; k < p.n_inputs; ++k) s << (k ? ", " : "") << "const double x" << k;
+    for (size_t k = 0; k < p.outputs.size(); ++k) s << ", double& o" << k;
+    s << ") {\n";
+    for (const auto& st : p.lets) s << "    const double tmp" << st.tmp << " = " << emit_expr_f64(st.expr) << ";\n";
+    for (size_t k = 0; k < p.outputs.size(); ++k) s << "    o" << k << " = " << emit_expr_f64(p.outputs[k]) << ";\n";
+    s << "}\n\n";
+    return s.str();
+}
+
+// One streaming kernel. `vec` = 2 (16-byte accesses) or 1. Bit k of `mask` marks input k as a
+// 1-element tensor (the executor uploads scalars that way, fusion_exec.rs:305-326): it is read
+// once into an SGPR-resident value instead of being streamed.
+static void emit_fast_kernel(std::ostringstream& s, const ElementwiseProgram& p, const EwTuning& t, int vec,
+                             unsigned mask, const char* name) {
+    const int nin = p.n_inputs, nout = (int)p.outputs.size(), U = t.unroll;
+    const char* vt = vec == 2 ? "rm_v2" : "double";
+    auto is_scalar = [&](int k) { return (mask >> k) & 1u; };
+    s << "extern \"C\" __global__ void __launch_bounds__(" << t.block << ") " << name << "(";
+    for (int k = 0; k < nin; ++k) s << "const double* __restrict__ in" << k << ", ";
+    for (int k = 0; k < nout; ++k) s << "double* __restrict__ out" << k << ", ";
+    s << "const rm_u64 n) {\n";
+    s << "    const rm_u64 nvec = n / " << vec << ";\n";
+    s << "    const rm_u64 stride = (rm_u64)gridDim.x * " << t.block << ";\n";
+    s << "    rm_u64 i = (rm_u64)blockIdx.x * " << t.block << " + threadIdx.x;\n";
+    for (int k = 0; k < nin; ++k)
+        if (is_scalar(k)) s << "    const double s" << k << " = in" << k << "[0];\n";
+    auto load = [&](int k, const std::string& idx, const std::string& dst) {
+        if (is_scalar(k)) return;
+        s << "        const " << vt << " " << dst << " = " << (t.nontemporal ? "__builtin_nontemporal_load" : "*")
+          << "((const " << vt << "*)in" << k << " + (" << idx << "));\n";
+    };
+    auto operand = [&](int k, const std::string& sfx, const char* comp) {
+        if (is_scalar(k)) return "s" + std::to_string(k);
+        return "a" + std::to_string(k) + sfx + comp;
+    };
+    auto compute_store = [&](const std::string& sfx, const std::string& idx) {
+        for (int k = 0; k < nout; ++k) s << "        " << vt << " r" << k << sfx << ";\n";
+        if (vec == 2) {
+            for (int lane = 0; lane < 2; ++lane) {
+                const char* c = lane ? ".y" : ".x";
+                s << "        { ";
+                for (int k = 0; k < nout; ++k) s << "double q" << k << "; ";
+                s << "rm_body(";
+                for (int k = 0; k < nin; ++k) s << (k ? ", " : "") << operand(k, sfx, c);
+                for (int k = 0; k < nout; ++k) s << ", q" << k;
+                s << "); ";
+                for (int k = 0; k < nout; ++k) s << "r" << k << sfx << c << " = q" << k << "; ";
+                s << "}\n";
+            }
+        } else {
+            s << "        rm_body(";
+            for (int k = 0; k < nin; ++k) s << (k ? ", " : "") << operand(k, sfx, "");
+            for (int k = 0; k < nout; ++k) s << ", r" << k << sfx;
+            s << ");\n";
+        }
+        for (int k = 0; k < nout; ++k) {
+            if (t.nontemporal)
+                s << "        __builtin_nontemporal_store(r" << k << sfx << ", (" << vt << "*)out" << k << " + (" << idx << "));\n";
+            else
+                s << "        *((" << vt << "*)out" << k << " + (" << idx << ")) = r" << k << sfx << ";\n";
+        }
+    };
+    if (U > 1) {
+        s << "    for (; i + " << (U - 1) << " * stride < nvec; i += " << U << " * stride) {\n";
+        for (int u = 0; u < U; ++u)
+            for (int k = 0; k < nin; ++k)
+                load(k, "i + " + std::to_string(u) + " * stride", "a" + std::to_string(k) + "_" + std::to_string(u));
+        for (int u = 0; u < U; ++u) compute_store("_" + std::to_string(u), "i + " + std::to_string(u) + " * stride");
+        s << "    }\n";
+    }
+    s << "    for (; i < nvec; i += stride) {\n";
+    for (int k = 0; k < nin; ++k) load(k, "i", "a" + std::to_string(k) + "_t");
+    compute_store("_t", "i");
+    s << "    }\n";
+    if (vec == 2) {
+        s << "    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {\n";
+        s << "        ";
+        for (int k = 0; k < nout; ++k) s << "double q" << k << "; ";
+        s << "rm_body(";
+        for (int k = 0; k < nin; ++k)
+            s << (k ? ", " : "") << (is_scalar(k) ? "s" + std::to_string(k) : "in" + std::to_string(k) + "[n - 1]");
+        for (int k = 0; k < nout; ++k) s << ", q" << k;
+        s << ");\n";
+        for (int k = 0; k < nout; ++k) s << "        out" << k << "[n - 1] = q" << k << ";\n";
+        s << "    }\n";
+    }
+    s << "}\n\n";
+}
+
+static void emit_bcast_kernel(std::ostringstream& s, const ElementwiseProgram& p, const EwTuning& t) {
+    const int nin = p.n_inputs, nout = (int)p.outputs.size(), E = t.unroll;
+    // params: v[0]=d0, v[1]=nchunks, v[2]=rank, v[3..10]=shape, v[11+8k .. ] = stride of input k
+    s << "struct RmBcast { rm_u64 v[" << (11 + 8 * nin) << "]; };\n";
+    s << "extern \"C\" __global__ void __launch_bounds__(" << t.block << ") rm_ew_bcast(";
+    for (int k = 0; k < nin; ++k) s << "const double* __restrict__ in" << k << ", ";
+    for (int k = 0; k < nout; ++k) s << "double* __restrict__ out" << k << ", ";
+    s << "const RmBcast p) {\n";
+    s << "    const rm_u64 d0 = p.v[0], nchunks = p.v[1];\n";
+    s << "    const int rank = (int)p.v[2];\n";
+    s << "    const rm_u64 blk = blockIdx.x + (rm_u64)gridDim.x * blockIdx.y;\n";
+    s << "    const rm_u64 chunk = blk % nchunks;\n";
+    s << "    const rm_u64 outer = blk / nchunks;\n";
+    for (int k = 0; k < nin; ++k) s << "    rm_u64 off" << k << " = 0;\n";
+    s << "    rm_u64 rem = outer;\n";
+    s << "    for (int d = 1; d < rank; ++d) {\n";
+    s << "        const rm_u64 ext = p.v[3 + d];\n";
+    s << "        const rm_u64 c = rem % ext;\n";
+    s << "        rem /= ext;\n";
+    for (int k = 0; k < nin; ++k) s << "        off" << k << " += c * p.v[" << (11 + 8 * k) << " + d];\n";
+    s << "    }\n";
+    s << "    if (rem != 0) return;  // padding blocks of the 2-D grid\n";
+    s << "    const rm_u64 obase = outer * d0;\n";
+    s << "    const rm_u64 i0 = chunk * " << (t.block * E) << "ull + threadIdx.x;\n";
+    for (int e = 0; e < E; ++e) {
+        s << "    {\n        const rm_u64 i = i0 + " << (e * t.block) << "ull;\n        if (i < d0) {\n";
+        for (int k = 0; k < nout; ++k) s << "            double q" << k << ";\n";
+        s << "            rm_body(";
+        for (int k = 0; k < nin; ++k) s << (k ? ", " : "") << "in" << k << "[off" << k << " + i * p.v[" << (11 + 8 * k) << "]]";
+        for (int k = 0; k < nout; ++k) s << ", q" << k;
+        s << ");\n";
+        for (int k = 0; k < nout; ++k) s << "            out" << k << "[obase + i] = q" << k << ";\n";
+        s << "        }\n    }\n";
+    }
+    s << "}\n\n";
+}
+
+std::string generate_elementwise_source(const ElementwiseProgram& p, const EwTuning& t, unsigned mask) {
+    std::ostringstream s;
+    s << "// generated by librmhip from a fused elementwise plan (" << p.lets.size() << " ops, " << p.n_inputs
+      << " inputs, " << p.outputs.size() << " outputs)\n";
+    s << kSkelCommon << "\n";
+    s << "typedef double rm_v2 __attribute__((ext_vector_type(2)));\n\n";
+    s << body_function(p);
+    emit_fast_kernel(s, p, t, 2, mask, "rm_ew_fast");
+    emit_fast_kernel(s, p, t, 1, mask, "rm_ew_fast1");
+    emit_bcast_kernel(s, p, t);
+    return s.str();
+}
+
+std::string generate_reduction_source(const ReductionProgram& p) {
+    std::ostringstream s;
+    const int nin = p.n_inputs;
+    s << "// generated by librmhip from a fused reduction plan (" << nin << " inputs, axis " << p.axis << ")\n";
+    s << kSkelCommon << "\n" << kSkelReduce << "\n";
+    s << "struct RmVal {\n";
+    for (int k = 0; k < nin; ++k) s << "    const double* __restrict__ in" << k << ";\n    rm_u64 m" << k << ";\n";
+    s << "    __device__ __forceinline__ double operator()(rm_u64 idx) const {\n";
+    for (int k = 0; k < nin; ++k) s << "        const double v" << k << " = in" << k << "[idx * m" << k << "];\n";
+    s << "        return " << emit_expr_f64(p.val) << ";\n    }\n};\n\n";
+    auto args = [&]() {
+        std::string a;
+        for (int k = 0; k < nin; ++k)
+            a += "const double* __restrict__ in" + std::to_string(k) + ", const rm_u64 m" + std::to_string(k) + ", ";
+        return a;
+    };
+    auto init = [&]() {
+        std::string a = "    RmVal f;\n";
+        for (int k = 0; k < nin; ++k)
+            a += "    f.in" + std::to_string(k) + " = in" + std::to_string(k) + "; f.m" + std::to_string(k) + " = m" +
+                 std::to_string(k) + ";\n";
+        return a;
+    };
+    s << "extern \"C\" __global__ void __launch_bounds__(RM_RBLOCK) rm_red_contig(" << args()
+      << "const rm_u64 red, const rm_u64 nslices, const rm_u64 nsplit, double* part_v, double* part_nan) {\n"
+      << init() << "    rm_reduce_contig<RM_RSUM>(f, red, nslices, nsplit, part_v, part_nan);\n}\n\n";
+    s << "extern \"C\" __global__ void __launch_bounds__(RM_RBLOCK) rm_red_strided(" << args()
+      << "const rm_u64 pre, const rm_u64 red, const rm_u64 nsplit, const int tx, double* part_v, double* part_nan) {\n"
+      << init() << "    rm_reduce_strided<RM_RSUM>(f, pre, red, nsplit, tx, part_v, part_nan);\n}\n\n";
+    s << "extern \"C\" __global__ void __launch_bounds__(RM_RBLOCK) rm_red_final(const double* part_v, const double* "
+         "part_nan, const rm_u64 nslices, const rm_u64 nsplit, const rm_u64 red, const int mean, const int omitnan, "
+         "const double scale, double* out) {\n"
+         "    rm_reduce_finalize<RM_RSUM>(part_v, part_nan, nslices, nsplit, red, mean, omitnan, scale, out);\n}\n";
+    return s.str();
+}
+
+// ---- hipRTC ------------------------------------------------------------------------------------
+
+static std::string cache_dir() {
+    const char* d = std::getenv("RMHIP_CACHE_DIR");
+    if (d && *d) return d;
+    return "";
+}
+
+int compile_to_code_object(const std::string& source, std::vector<char>* code) {
+    const std::string dir = cache_dir();
+    char namebuf[64];
+    std::snprintf(namebuf, sizeof namebuf, "%016llx.hsaco", (unsigned long long)fnv1a(source + "|gfx950|v1"));
+    if (!dir.empty()) {  // persisted code objects keyed by source hash + arch
+        std::ifstream f(dir + "/" + namebuf, std::ios::binary);
+        if (f) {
+            code->assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+            if (!code->empty()) return RMHIP_OK;
+        }
+    }
+    hiprtcProgram prog;
+    hiprtcResult r = hiprtcCreateProgram(&prog, source.c_str(), "rmhip_fused.hip", 0, nullptr, nullptr);
+    if (r != HIPRTC_SUCCESS) return fail(RMHIP_ERR_COMPILE, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
+    // -ffp-contract=off: the CPU path rounds after every op (no FMA contraction in Rust), so
+    // `sin(A).*B + C` must be a multiply then an add.
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
+    r = hiprtcCompileProgram(prog, 4, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        if (log.size() > 1500) log.resize(1500);
+        return fail(RMHIP_ERR_COMPILE, "hipRTC compile failed: %s\n%s", hiprtcGetErrorString(r), log.c_str());
+    }
+    size_t sz = 0;
+    hiprtcGetCodeSize(prog, &sz);
+    code->resize(sz);
+    hiprtcGetCode(prog, code->data());
+    hiprtcDestroyProgram(&prog);
+    if (!dir.empty()) {
+        ::mkdir(dir.c_str(), 0755);
+        std::ofstream f(dir + "/" + namebuf, std::ios::binary);
+        if (f) f.write(code->data(), (std::streamsize)code->size());
+    }
+    return RMHIP_OK;
+}
+
+static int load_function(hipModule_t m, const char* name, hipFunction_t* fn) {
+    hipError_t e = hipModuleGetFunction(fn, m, name);
+    if (e != hipSuccess) return fail(RMHIP_ERR_HIP, "hipModuleGetFunction(%s): %s", name, hipGetErrorString(e));
+    return RMHIP_OK;
+}
+
+int get_elementwise_kernel(Context* c, const ElementwiseProgram& p, unsigned mask,
+                           std::shared_ptr<FusedKernel>* out) {
+    EwTuning t = EwTuning::from_env();
+    char tun[96];
+    std::snprintf(tun, sizeof tun, "|u%d|b%d|nt%d|m%x", t.unroll, t.block, t.nontemporal, mask);
+    const uint64_t key = fnv1a(p.canonical + tun);
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        auto it = c->kernel_cache.find(key);
+        if (it != c->kernel_cache.end()) {
+            c->tel.cache_hits++;
+            *out = it->second;
+            return RMHIP_OK;
+        }
+    }
+    c->tel.cache_misses++;
+    std::vector<char> code;
+    RMHIP_TRY(compile_to_code_object(generate_elementwise_source(p, t, mask), &code));
+    auto k = std::make_shared<FusedKernel>();
+    k->tuning = t;
+    k->n_inputs = p.n_inputs;
+    k->n_outputs = (int)p.outputs.size();
+    RMHIP_HIP_CHECK(hipModuleLoadData(&k->module, code.data()));
+    RMHIP_TRY(load_function(k->module, "rm_ew_fast", &k->fn_fast));
+    RMHIP_TRY(load_function(k->module, "rm_ew_fast1", &k->fn_fast1));
+    RMHIP_TRY(load_function(k->module, "rm_ew_bcast", &k->fn_bcast));
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->kernel_cache[key] = k;
+    *out = k;
+    return RMHIP_OK;
+}
+
+int get_reduction_kernel(Context* c, const ReductionProgram& p, std::shared_ptr<FusedKernel>* out) {
+    const uint64_t key = fnv1a(p.canonical);
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        auto it = c->kernel_cache.find(key);
+        if (it != c->kernel_cache.end()) {
+            c->tel.cache_hits++;
+            *out = it->second;
+            return RMHIP_OK;
+        }
+    }
+    c->tel.cache_misses++;
+    std::vector<char> code;
+    RMHIP_TRY(compile_to_code_object(generate_reduction_source(p), &code));
+    auto k = std::make_shared<FusedKernel>();
+    k->n_inputs = p.n_inputs;
+    k->n_outputs = 1;
+    RMHIP_HIP_CHECK(hipModuleLoadData(&k->module, code.data()));
+    RMHIP_TRY(load_function(k->module, "rm_red_contig", &k->fn_contig));
+    RMHIP_TRY(load_function(k->module, "rm_red_strided", &k->fn_strided));
+    RMHIP_TRY(load_function(k->module, "rm_red_final", &k->fn_final));
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->kernel_cache[key] = k;
+    *out = k;
+    return RMHIP_OK;
+}
+
+}  // namespace rmhip

@@ -1,0 +1,170 @@
+// common.h -- internal declarations shared by the librmhip.so translation units.
+// Context = one GPU: HIP stream, buffer table (buffer_id -> device allocation + shape, the
+// provider-side half of `GpuTensorHandle`, crates/runmat-accelerate-api/src/lib.rs:260-264),
+// a size-bucketed device-memory pool, the fused-kernel cache and telemetry counters.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/rmhip.h"
+
+namespace rmhip {
+
+// ---- errors ------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define RMHIP_HIP_CHECK(expr)                                                                  \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return ::rmhip::fail(RMHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                \
+                                 hipGetErrorString(_e), __FILE__, __LINE__);                   \
+    } while (0)
+
+#define RMHIP_TRY(expr)              \
+    do {                             \
+        int _rc = (expr);            \
+        if (_rc != RMHIP_OK) return _rc; \
+    } while (0)
+
+// ---- device allocations (reference counted so `reshape` can alias storage) -----------------------
+struct Context;
+struct Allocation {
+    Context* ctx = nullptr;
+    double* ptr = nullptr;
+    size_t bytes = 0;     // bucket size actually reserved
+    bool external = false;  // adopted via rmhip_wrap_external: never freed by us
+    ~Allocation();
+};
+
+struct Buffer {
+    std::shared_ptr<Allocation> alloc;
+    std::vector<size_t> shape;
+    size_t numel = 0;
+    double* data() const { return alloc ? alloc->ptr : nullptr; }
+};
+
+struct Telemetry {
+    std::atomic<uint64_t> fused_elementwise_count{0}, fused_elementwise_ns{0};
+    std::atomic<uint64_t> fused_reduction_count{0}, fused_reduction_ns{0};
+    std::atomic<uint64_t> matmul_count{0}, matmul_ns{0};
+    std::atomic<uint64_t> mldivide_count{0}, mldivide_ns{0};
+    std::atomic<uint64_t> upload_bytes{0}, download_bytes{0};
+    std::atomic<uint64_t> cache_hits{0}, cache_misses{0};
+    std::atomic<uint64_t> kernel_launches{0};
+    std::atomic<uint64_t> bytes_allocated{0}, bytes_pooled{0};
+};
+
+struct FusedKernel;  // codegen.h
+
+struct Context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    hipDeviceProp_t props{};
+    int num_cus = 256;
+
+    std::mutex mu;  // guards table, pool, kernel cache
+    std::unordered_map<uint64_t, Buffer> table;
+    uint64_t next_id = 1;
+
+    // pool: bucket bytes -> free device pointers
+    std::multimap<size_t, double*> pool;
+    size_t pooled_bytes = 0;
+    size_t pool_limit_bytes = 0;  // set at init (fraction of HBM)
+
+    std::unordered_map<uint64_t, std::shared_ptr<FusedKernel>> kernel_cache;
+
+    uint64_t rng_state = 0x9e3779b97f4a7c15ULL;  // DEFAULT_RNG_SEED, random.rs:7
+
+    // scratch for reductions / LU (grown on demand, reused)
+    double* scratch = nullptr;
+    size_t scratch_bytes = 0;
+
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    Telemetry tel;
+
+    // ---- helpers (rmhip_core.cpp) ----
+    int alloc_device(size_t numel, std::shared_ptr<Allocation>* out);
+    void release_device(double* ptr, size_t bytes);
+    int new_buffer(const size_t* shape, size_t rank, uint64_t* id, Buffer* out);
+    int register_buffer(Buffer&& b, uint64_t* id);
+    int get(uint64_t id, Buffer* out);  // copies the (small) Buffer record under the lock
+    int ensure_scratch(size_t bytes);
+};
+
+inline size_t shape_numel(const size_t* shape, size_t rank) {
+    size_t n = 1;
+    for (size_t i = 0; i < rank; ++i) n *= shape[i];
+    return n;
+}
+
+// RAII guard selecting the context's device for the calling thread.
+struct DeviceGuard {
+    explicit DeviceGuard(const Context* c) { (void)hipSetDevice(c->device); }
+};
+
+struct ScopedTimer {
+    std::atomic<uint64_t>* count;
+    std::atomic<uint64_t>* ns;
+    uint64_t t0;
+    ScopedTimer(std::atomic<uint64_t>* c, std::atomic<uint64_t>* n);
+    ~ScopedTimer();
+};
+
+// ---- kernel launchers implemented in the .hip translation units -------------------------------
+// elementwise (ew_kernels.hip)
+int launch_fill(Context* c, double* dst, size_t n, double value);
+int launch_fill_uniform(Context* c, double* dst, size_t n, uint64_t seed, double lo, double hi);
+int launch_unary(Context* c, int op, const double* a, double* out, size_t n);
+int launch_scalar(Context* c, int op, const double* a, double s, double* out, size_t n);
+struct BroadcastDesc {  // collapsed, front-padded; dim 0 fastest. rank <= 8.
+    int rank;
+    uint64_t out_shape[8];
+    uint64_t stride_a[8];
+    uint64_t stride_b[8];
+};
+int launch_binary_same(Context* c, int op, const double* a, const double* b, double* out, size_t n);
+int launch_binary_bcast(Context* c, int op, const double* a, const double* b, double* out,
+                        size_t n, const BroadcastDesc& d);
+
+// reductions (reduce_kernels.hip)
+int launch_reduce_all(Context* c, int op, int nan_mode, const double* x, size_t n, double* out);
+// x viewed as [pre, red, post] column-major; reduces the middle extent. out has pre*post elements.
+int launch_reduce_mid(Context* c, int op, int nan_mode, const double* x, size_t pre, size_t red,
+                      size_t post, double* out);
+
+// dgemm (dgemm.hip): C[m x n] = alpha * A[m x k] * B[k x n] + beta * C, column-major with leading
+// dimensions. beta == 0 ignores C's previous contents.
+int launch_dgemm(Context* c, size_t m, size_t n, size_t k, double alpha, const double* A, size_t lda,
+                 const double* B, size_t ldb, double beta, double* C, size_t ldc);
+
+// rng (rng.hip)
+int launch_rng_uniform(Context* c, uint64_t state, double* out, size_t n);
+int launch_rng_normal(Context* c, uint64_t state, double* out, size_t n);
+uint64_t lcg_advance(uint64_t state, uint64_t delta);
+
+// LU / solve (lu.hip)
+int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda, int* perm_dev,
+                     int* info_host);
+int lu_solve_device(Context* c, const double* LU, size_t n, size_t lda, const int* perm_dev,
+                    const double* B, size_t nrhs, size_t ldb, double* X, size_t ldx);
+int lu_extract_device(Context* c, const double* LU, size_t rows, size_t cols, const int* perm_dev,
+                      double* L, double* U, double* P, double* piv);
+
+// opaque handle -> Context (rmhip_core.cpp)
+Context* context_of(rmhip_ctx* h);
+
+}  // namespace rmhip

@@ -1,0 +1,345 @@
+// ew_kernels.hip -- ahead-of-time gfx950 kernels for the per-op provider hooks
+//   elem_add/sub/mul/div/pow/max/min/hypot/atan2   crates/runmat-accelerate-api/src/lib.rs:1890-1938,1979,2069
+//   unary_*                                        lib.rs:2077-2331
+//   scalar_*                                       lib.rs:2333-2355
+//   zeros/ones/fill                                lib.rs:1468-1522
+// These are HBM-bound streaming kernels: 16-byte accesses per lane (1 KiB per wave instruction),
+// several independent vectors in flight per thread, grid capped at 8 blocks per CU with a
+// grid-stride loop. Arithmetic follows the CPU builtins (see skel_common.h), compiled with
+// -ffp-contract=off.
+#include "common.h"
+#include "skel_common.h"
+
+namespace rmhip {
+
+typedef double v2 __attribute__((ext_vector_type(2)));
+
+static constexpr int kBlock = 256;
+static constexpr int kUnroll = 4;
+
+static inline unsigned stream_grid(const Context* c, size_t nvec) {
+    size_t want = (nvec + (size_t)kBlock * kUnroll - 1) / ((size_t)kBlock * kUnroll);
+    size_t cap = (size_t)c->num_cus * 8;
+    if (want < 1) want = 1;
+    return (unsigned)(want < cap ? want : cap);
+}
+
+template <int OP>
+__device__ __forceinline__ double unary_op(double v) {
+    switch (OP) {
+        case RMHIP_SIN: return sin(v);
+        case RMHIP_COS: return cos(v);
+        case RMHIP_TAN: return tan(v);
+        case RMHIP_ASIN: return asin(v);
+        case RMHIP_ACOS: return acos(v);
+        case RMHIP_ATAN: return atan(v);
+        case RMHIP_SINH: return sinh(v);
+        case RMHIP_COSH: return cosh(v);
+        case RMHIP_TANH: return tanh(v);
+        case RMHIP_ASINH: return asinh(v);
+        case RMHIP_ACOSH: return acosh(v);
+        case RMHIP_ATANH: return atanh(v);
+        case RMHIP_EXP: return exp(v);
+        case RMHIP_EXPM1: return expm1(v);
+        case RMHIP_LOG: return log(v);
+        case RMHIP_LOG2: return log2(v);
+        case RMHIP_LOG10: return log10(v);
+        case RMHIP_LOG1P: return log1p(v);
+        case RMHIP_SQRT: return sqrt(v);
+        case RMHIP_ABS: return fabs(v);
+        case RMHIP_SIGN: return rm_sign(v);
+        case RMHIP_FLOOR: return floor(v);
+        case RMHIP_CEIL: return ceil(v);
+        case RMHIP_ROUND: return round(v);
+        case RMHIP_FIX: return trunc(v);
+        case RMHIP_NEG: return -v;
+        case RMHIP_EXP2: return exp2(v);
+        case RMHIP_HEAVISIDE: return rm_heaviside(v);
+        case RMHIP_ISNAN: return rm_isnan(v) ? 1.0 : 0.0;
+        case RMHIP_ISINF: return rm_isinf(v) ? 1.0 : 0.0;
+        case RMHIP_ISFINITE: return rm_isfinite(v) ? 1.0 : 0.0;
+        default: return v;
+    }
+}
+
+template <int OP>
+__device__ __forceinline__ double binary_op(double a, double b) {
+    switch (OP) {
+        case RMHIP_ADD: return a + b;
+        case RMHIP_SUB: return a - b;
+        case RMHIP_MUL: return a * b;
+        case RMHIP_DIV: return a / b;
+        case RMHIP_POW: return pow(a, b);
+        case RMHIP_MAX: return rm_max(a, b);
+        case RMHIP_MIN: return rm_min(a, b);
+        case RMHIP_HYPOT: return hypot(a, b);
+        case RMHIP_ATAN2: return atan2(a, b);
+        case RMHIP_MOD: return rm_mod(a, b);
+        default: return rm_rem(a, b);
+    }
+}
+
+// scalar_*: a op s, with rsub = s - a, rdiv = s ./ a (lib.rs:2333-2338)
+template <int OP>
+__device__ __forceinline__ double scalar_op(double a, double s) {
+    switch (OP) {
+        case RMHIP_SADD: return a + s;
+        case RMHIP_SSUB: return a - s;
+        case RMHIP_SMUL: return a * s;
+        case RMHIP_SDIV: return a / s;
+        case RMHIP_SRSUB: return s - a;
+        case RMHIP_SRDIV: return s / a;
+        case RMHIP_SMAX: return rm_max(a, s);
+        default: return rm_min(a, s);
+    }
+}
+
+// ---- streaming skeleton: out[i] = f(i) over 16-byte vectors -------------------------------------
+template <class F>
+__global__ void __launch_bounds__(kBlock) k_stream1(const double* __restrict__ a, double* __restrict__ out, size_t n,
+                                                    F f) {
+    const size_t nvec = n >> 1;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const v2* __restrict__ av = (const v2*)a;
+    v2* __restrict__ ov = (v2*)out;
+    for (; i + (kUnroll - 1) * stride < nvec; i += kUnroll * stride) {
+        v2 x[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) x[u] = __builtin_nontemporal_load(av + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            v2 r;
+            r.x = f(x[u].x);
+            r.y = f(x[u].y);
+            __builtin_nontemporal_store(r, ov + i + u * stride);
+        }
+    }
+    for (; i < nvec; i += stride) {
+        v2 x = av[i], r;
+        r.x = f(x.x);
+        r.y = f(x.y);
+        ov[i] = r;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = f(a[n - 1]);
+}
+
+template <class F>
+__global__ void __launch_bounds__(kBlock) k_stream2(const double* __restrict__ a, const double* __restrict__ b,
+                                                    double* __restrict__ out, size_t n, F f) {
+    const size_t nvec = n >> 1;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const v2* __restrict__ av = (const v2*)a;
+    const v2* __restrict__ bv = (const v2*)b;
+    v2* __restrict__ ov = (v2*)out;
+    for (; i + (kUnroll - 1) * stride < nvec; i += kUnroll * stride) {
+        v2 x[kUnroll], y[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            x[u] = __builtin_nontemporal_load(av + i + u * stride);
+            y[u] = __builtin_nontemporal_load(bv + i + u * stride);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            v2 r;
+            r.x = f(x[u].x, y[u].x);
+            r.y = f(x[u].y, y[u].y);
+            __builtin_nontemporal_store(r, ov + i + u * stride);
+        }
+    }
+    for (; i < nvec; i += stride) {
+        v2 x = av[i], y = bv[i], r;
+        r.x = f(x.x, y.x);
+        r.y = f(x.y, y.y);
+        ov[i] = r;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = f(a[n - 1], b[n - 1]);
+}
+
+template <int OP>
+struct UnaryF {
+    __device__ __forceinline__ double operator()(double v) const { return unary_op<OP>(v); }
+};
+template <int OP>
+struct BinaryF {
+    __device__ __forceinline__ double operator()(double a, double b) const { return binary_op<OP>(a, b); }
+};
+template <int OP>
+struct ScalarF {
+    double s;
+    __device__ __forceinline__ double operator()(double a) const { return scalar_op<OP>(a, s); }
+};
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// Unaligned (externally wrapped) memory: plain 8-byte accesses.
+template <class F>
+__global__ void __launch_bounds__(kBlock) k_plain1(const double* __restrict__ a, double* __restrict__ out, size_t n,
+                                                   F f) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = f(a[i]);
+}
+template <class F>
+__global__ void __launch_bounds__(kBlock) k_plain2(const double* __restrict__ a, const double* __restrict__ b,
+                                                   double* __restrict__ out, size_t n, F f) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = f(a[i], b[i]);
+}
+
+template <class F>
+static int run1(Context* c, const double* a, double* out, size_t n, F f) {
+    if (n == 0) return RMHIP_OK;
+    if (aligned16(a) && aligned16(out))
+        hipLaunchKernelGGL((k_stream1<F>), dim3(stream_grid(c, n / 2)), dim3(kBlock), 0, c->stream, a, out, n, f);
+    else
+        hipLaunchKernelGGL((k_plain1<F>), dim3(stream_grid(c, n)), dim3(kBlock), 0, c->stream, a, out, n, f);
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+template <class F>
+static int run2(Context* c, const double* a, const double* b, double* out, size_t n, F f) {
+    if (n == 0) return RMHIP_OK;
+    if (aligned16(a) && aligned16(b) && aligned16(out))
+        hipLaunchKernelGGL((k_stream2<F>), dim3(stream_grid(c, n / 2)), dim3(kBlock), 0, c->stream, a, b, out, n, f);
+    else
+        hipLaunchKernelGGL((k_plain2<F>), dim3(stream_grid(c, n)), dim3(kBlock), 0, c->stream, a, b, out, n, f);
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+
+template <int OP>
+static int unary_dispatch(Context* c, int op, const double* a, double* out, size_t n) {
+    if (op == OP) return run1(c, a, out, n, UnaryF<OP>());
+    if constexpr (OP + 1 < RMHIP_UNARY_OP_COUNT) return unary_dispatch<OP + 1>(c, op, a, out, n);
+    return fail(RMHIP_ERR_UNSUPPORTED, "unary op %d not supported by provider", op);
+}
+int launch_unary(Context* c, int op, const double* a, double* out, size_t n) {
+    return unary_dispatch<0>(c, op, a, out, n);
+}
+
+template <int OP>
+static int scalar_dispatch(Context* c, int op, const double* a, double s, double* out, size_t n) {
+    if (op == OP) return run1(c, a, out, n, ScalarF<OP>{s});
+    if constexpr (OP + 1 < RMHIP_SCALAR_OP_COUNT) return scalar_dispatch<OP + 1>(c, op, a, s, out, n);
+    return fail(RMHIP_ERR_UNSUPPORTED, "scalar op %d not supported by provider", op);
+}
+int launch_scalar(Context* c, int op, const double* a, double s, double* out, size_t n) {
+    return scalar_dispatch<0>(c, op, a, s, out, n);
+}
+
+template <int OP>
+static int binary_same_dispatch(Context* c, int op, const double* a, const double* b, double* out, size_t n) {
+    if (op == OP) return run2(c, a, b, out, n, BinaryF<OP>());
+    if constexpr (OP + 1 < RMHIP_BINARY_OP_COUNT) return binary_same_dispatch<OP + 1>(c, op, a, b, out, n);
+    return fail(RMHIP_ERR_UNSUPPORTED, "binary op %d not supported by provider", op);
+}
+int launch_binary_same(Context* c, int op, const double* a, const double* b, double* out, size_t n) {
+    return binary_same_dispatch<0>(c, op, a, b, out, n);
+}
+
+// ---- broadcast binary: dim 0 along threads (coalesced when stride 1, uniform when 0), the outer
+// dims decoded once per block with scalar arithmetic (no per-element div/mod, unlike the
+// reference's per-thread 128-iteration coordinate loops, fusion.rs:1606-1616). ----------------------
+struct BcastParams {
+    unsigned long long d0, nchunks;
+    int rank;
+    unsigned long long shape[8], sa[8], sb[8];
+};
+
+template <class F>
+__global__ void __launch_bounds__(kBlock) k_bcast2(const double* __restrict__ a, const double* __restrict__ b,
+                                                   double* __restrict__ out, BcastParams p, F f) {
+    const unsigned long long blk = blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y;
+    const unsigned long long chunk = blk % p.nchunks;
+    const unsigned long long outer = blk / p.nchunks;
+    unsigned long long offa = 0, offb = 0, rem = outer;
+    for (int d = 1; d < p.rank; ++d) {
+        const unsigned long long cdim = rem % p.shape[d];
+        rem /= p.shape[d];
+        offa += cdim * p.sa[d];
+        offb += cdim * p.sb[d];
+    }
+    if (rem != 0) return;
+    const unsigned long long obase = outer * p.d0;
+    const unsigned long long i0 = chunk * (unsigned long long)(kBlock * kUnroll) + threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < kUnroll; ++e) {
+        const unsigned long long i = i0 + (unsigned long long)e * kBlock;
+        if (i < p.d0) out[obase + i] = f(a[offa + i * p.sa[0]], b[offb + i * p.sb[0]]);
+    }
+}
+
+template <int OP>
+static int binary_bcast_dispatch(Context* c, int op, const double* a, const double* b, double* out, size_t n,
+                                 const BroadcastDesc& d) {
+    if (op == OP) {
+        if (n == 0) return RMHIP_OK;
+        BcastParams p;
+        p.rank = d.rank;
+        p.d0 = d.out_shape[0];
+        p.nchunks = (p.d0 + (unsigned long long)kBlock * kUnroll - 1) / ((unsigned long long)kBlock * kUnroll);
+        unsigned long long outer = 1;
+        for (int i = 0; i < 8; ++i) {
+            p.shape[i] = i < d.rank ? d.out_shape[i] : 1;
+            p.sa[i] = i < d.rank ? d.stride_a[i] : 0;
+            p.sb[i] = i < d.rank ? d.stride_b[i] : 0;
+            if (i >= 1 && i < d.rank) outer *= d.out_shape[i];
+        }
+        const unsigned long long blocks = p.nchunks * outer;
+        const unsigned long long gx = blocks < 1048576ULL ? blocks : 1048576ULL;
+        const unsigned long long gy = (blocks + gx - 1) / gx;
+        if (gy > 65535ULL) return fail(RMHIP_ERR_UNSUPPORTED, "broadcast grid too large");
+        hipLaunchKernelGGL((k_bcast2<BinaryF<OP>>), dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, c->stream, a, b,
+                           out, p, BinaryF<OP>());
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+        return RMHIP_OK;
+    }
+    if constexpr (OP + 1 < RMHIP_BINARY_OP_COUNT) return binary_bcast_dispatch<OP + 1>(c, op, a, b, out, n, d);
+    return fail(RMHIP_ERR_UNSUPPORTED, "binary op %d not supported by provider", op);
+}
+int launch_binary_bcast(Context* c, int op, const double* a, const double* b, double* out, size_t n,
+                        const BroadcastDesc& d) {
+    return binary_bcast_dispatch<0>(c, op, a, b, out, n, d);
+}
+
+// ---- fills ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_fill(double* __restrict__ out, size_t n, double value) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = value;
+}
+
+// counter-based splitmix64 (identical to oracle.c orc_fill_uniform)
+__global__ void __launch_bounds__(kBlock) k_fill_uniform(double* __restrict__ out, size_t n, unsigned long long seed,
+                                                         double lo, double hi) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        unsigned long long z = seed + (unsigned long long)(i + 1) * 0x9e3779b97f4a7c15ULL;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+        z = z ^ (z >> 31);
+        out[i] = lo + (hi - lo) * ((double)(z >> 11) * (1.0 / 9007199254740992.0));
+    }
+}
+
+int launch_fill(Context* c, double* dst, size_t n, double value) {
+    if (n == 0) return RMHIP_OK;
+    hipLaunchKernelGGL(k_fill, dim3(stream_grid(c, n)), dim3(kBlock), 0, c->stream, dst, n, value);
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+
+int launch_fill_uniform(Context* c, double* dst, size_t n, uint64_t seed, double lo, double hi) {
+    if (n == 0) return RMHIP_OK;
+    hipLaunchKernelGGL(k_fill_uniform, dim3(stream_grid(c, n)), dim3(kBlock), 0, c->stream, dst, n,
+                       (unsigned long long)seed, lo, hi);
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+
+}  // namespace rmhip

@@ -1,0 +1,67 @@
+// reduce_plan.h -- launch geometry for the [pre, red, post] reduction skeletons (skel_reduce.h).
+// Shared by the ahead-of-time reductions and the hipRTC fused reductions.
+//
+// Contrast with the reference: its generated reduction runs ONE workgroup per slice
+// (crates/runmat-accelerate/src/fusion.rs:1983-2030), i.e. a single CU for `sum(x,'all')`.
+// Here every shape is split until the grid covers the 256 CUs several times over, with a
+// deterministic second stage.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+namespace rmhip {
+
+struct ReducePlan {
+    bool contiguous;  // kernel A (pre == 1) or kernel B
+    uint64_t nslices; // pre * post
+    uint64_t nsplit;  // partials per slice
+    int tx;           // kernel B: threads along `pre` per block (power of two)
+    unsigned gx, gy, gz;
+    bool valid;       // false: geometry exceeds grid limits (caller reports UNSUPPORTED)
+};
+
+inline uint64_t ceil_div_u64(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+inline ReducePlan plan_reduction(uint64_t pre, uint64_t red, uint64_t post, int num_cus) {
+    ReducePlan p{};
+    const uint64_t target_blocks = (uint64_t)num_cus * 8;  // ~2048 blocks of 256 threads
+    p.nslices = pre * post;
+    if (pre == 1) {
+        p.contiguous = true;
+        uint64_t max_split = ceil_div_u64(red, 256 * 8);  // >= 8 elements per thread per block
+        if (max_split < 1) max_split = 1;
+        uint64_t want = ceil_div_u64(target_blocks, post ? post : 1);
+        if (want < 1) want = 1;
+        p.nsplit = want < max_split ? want : max_split;
+        if (p.nsplit > 4096) p.nsplit = 4096;
+        p.tx = 256;
+        p.gx = (unsigned)p.nsplit;
+        // slices spread over (y, z)
+        uint64_t gy = post < 65535 ? post : 65535;
+        if (gy < 1) gy = 1;
+        p.gy = (unsigned)gy;
+        p.gz = (unsigned)ceil_div_u64(post ? post : 1, gy);
+    } else {
+        p.contiguous = false;
+        int tx = 256;
+        while (tx > 1 && (uint64_t)tx / 2 >= pre) tx /= 2;  // smallest power of two >= pre, capped at 256
+        p.tx = tx;
+        const uint64_t bx = ceil_div_u64(pre, (uint64_t)tx);
+        const uint64_t ty = 256 / tx;
+        uint64_t max_split = ceil_div_u64(red, 16 * ty);  // >= 16 elements per thread
+        if (max_split < 1) max_split = 1;
+        uint64_t want = ceil_div_u64(target_blocks, bx * (post ? post : 1));
+        if (want < 1) want = 1;
+        p.nsplit = want < max_split ? want : max_split;
+        if (p.nsplit > 65535) p.nsplit = 65535;
+        p.gx = (unsigned)bx;
+        p.gy = (unsigned)p.nsplit;
+        p.gz = (unsigned)(post ? post : 1);
+    }
+    p.valid = p.gz <= 65535u && p.gy <= 65535u && p.gx >= 1;
+    if (!p.contiguous && post > 65535) p.valid = false;
+    return p;
+}
+
+}  // namespace rmhip

@@ -1,0 +1,442 @@
+// rmhip_core.cpp -- context, buffer table, device-memory pool, telemetry and the memory half of the
+// C ABI (include/rmhip.h).  Mirrors the provider-side bookkeeping the reference keeps per
+// provider: buffer table + residency pool (crates/runmat-accelerate/src/backend/wgpu/provider,
+// SURVEY.md 2.1) and the InProcessProvider registry (simple_provider.rs:678-728).
+#include <chrono>
+#include <cstring>
+
+#include "common.h"
+
+namespace rmhip {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+    char buf[4096];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+    char buf[4096];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+static uint64_t now_ns() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+               std::chrono::steady_clock::now().time_since_epoch())
+        .count();
+}
+
+ScopedTimer::ScopedTimer(std::atomic<uint64_t>* c, std::atomic<uint64_t>* n) : count(c), ns(n), t0(now_ns()) {}
+ScopedTimer::~ScopedTimer() {
+    (*count)++;
+    (*ns) += now_ns() - t0;
+}
+
+// ---- pool --------------------------------------------------------------------------------------
+// Buckets: round up to 256 B below 1 MiB, to 1 MiB above. Frees go back to the pool (bounded), so
+// the steady state of "every op returns a new buffer" costs no hipMalloc.
+static size_t bucket_bytes(size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    if (bytes < (1u << 20)) return (bytes + 255) & ~(size_t)255;
+    return (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+}
+
+Allocation::~Allocation() {
+    if (ptr && !external && ctx) ctx->release_device(ptr, bytes);
+}
+
+int Context::alloc_device(size_t numel, std::shared_ptr<Allocation>* out) {
+    const size_t bytes = bucket_bytes(numel * sizeof(double));
+    double* p = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = pool.find(bytes);
+        if (it != pool.end()) {
+            p = it->second;
+            pool.erase(it);
+            pooled_bytes -= bytes;
+            tel.bytes_pooled = pooled_bytes;
+        }
+    }
+    if (!p) {
+        hipError_t e = hipMalloc((void**)&p, bytes);
+        if (e != hipSuccess) {
+            // drop the pool and retry once
+            std::vector<double*> victims;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                for (auto& kv : pool) victims.push_back(kv.second);
+                pool.clear();
+                pooled_bytes = 0;
+                tel.bytes_pooled = 0;
+            }
+            (void)hipStreamSynchronize(stream);
+            for (double* v : victims) (void)hipFree(v);
+            e = hipMalloc((void**)&p, bytes);
+            if (e != hipSuccess) return fail(RMHIP_ERR_OOM, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+        }
+        tel.bytes_allocated += bytes;
+    }
+    auto a = std::make_shared<Allocation>();
+    a->ctx = this;
+    a->ptr = p;
+    a->bytes = bytes;
+    *out = std::move(a);
+    return RMHIP_OK;
+}
+
+void Context::release_device(double* ptr, size_t bytes) {
+    // All work is stream-ordered on one stream, so a pooled block can be handed out again
+    // immediately: any later kernel that writes it is ordered after the kernels that read it.
+    std::unique_lock<std::mutex> lk(mu);
+    if (pooled_bytes + bytes <= pool_limit_bytes) {
+        pool.emplace(bytes, ptr);
+        pooled_bytes += bytes;
+        tel.bytes_pooled = pooled_bytes;
+        return;
+    }
+    lk.unlock();
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(ptr);
+    tel.bytes_allocated -= bytes;
+}
+
+int Context::register_buffer(Buffer&& b, uint64_t* id) {
+    std::lock_guard<std::mutex> lk(mu);
+    *id = next_id++;
+    table.emplace(*id, std::move(b));
+    return RMHIP_OK;
+}
+
+int Context::new_buffer(const size_t* shape, size_t rank, uint64_t* id, Buffer* out) {
+    Buffer b;
+    b.shape.assign(shape, shape + rank);
+    b.numel = shape_numel(shape, rank);
+    RMHIP_TRY(alloc_device(b.numel, &b.alloc));
+    if (out) *out = b;
+    return register_buffer(std::move(b), id);
+}
+
+int Context::get(uint64_t id, Buffer* out) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = table.find(id);
+    if (it == table.end()) return fail(RMHIP_ERR_NOT_FOUND, "buffer not found: %llu", (unsigned long long)id);
+    *out = it->second;
+    return RMHIP_OK;
+}
+
+int Context::ensure_scratch(size_t bytes) {
+    if (bytes <= scratch_bytes) return RMHIP_OK;
+    if (scratch) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(scratch);
+        scratch = nullptr;
+        scratch_bytes = 0;
+    }
+    size_t want = bucket_bytes(bytes);
+    RMHIP_HIP_CHECK(hipMalloc((void**)&scratch, want));
+    scratch_bytes = want;
+    return RMHIP_OK;
+}
+
+}  // namespace rmhip
+
+using namespace rmhip;
+
+struct rmhip_ctx {
+    Context c;
+};
+
+#define CTX_OR_FAIL(ctx)                                                  \
+    if (!(ctx)) return fail(RMHIP_ERR_INVALID, "null context");           \
+    Context* c = &(ctx)->c;                                               \
+    DeviceGuard _dg(c)
+
+extern "C" {
+
+const char* rmhip_version(void) { return "rmhip 0.1.0 (gfx950)"; }
+const char* rmhip_last_error(void) { return g_last_error.c_str(); }
+
+int rmhip_init(int device_ordinal, rmhip_ctx** out_ctx) {
+    if (!out_ctx) return fail(RMHIP_ERR_INVALID, "null out_ctx");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(RMHIP_ERR_NO_DEVICE, "no HIP device available (%s); librmhip has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device_ordinal < 0 || device_ordinal >= count)
+        return fail(RMHIP_ERR_INVALID, "device ordinal %d out of range (0..%d)", device_ordinal, count - 1);
+    RMHIP_HIP_CHECK(hipSetDevice(device_ordinal));
+    auto* h = new rmhip_ctx();
+    Context* c = &h->c;
+    c->device = device_ordinal;
+    e = hipGetDeviceProperties(&c->props, device_ordinal);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(RMHIP_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    }
+    if (std::strncmp(c->props.gcnArchName, "gfx950", 6) != 0 && !std::getenv("RMHIP_ALLOW_ANY_ARCH")) {
+        std::string arch = c->props.gcnArchName;
+        delete h;
+        return fail(RMHIP_ERR_NO_DEVICE, "device %d is %s; librmhip kernels are built for gfx950 only",
+                    device_ordinal, arch.c_str());
+    }
+    c->num_cus = c->props.multiProcessorCount > 0 ? c->props.multiProcessorCount : 256;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(RMHIP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    c->owns_stream = true;
+    (void)hipEventCreate(&c->ev_begin);
+    (void)hipEventCreate(&c->ev_end);
+    // Keep at most a quarter of HBM parked in the pool (288 GB parts: plenty for 512 MiB operands).
+    c->pool_limit_bytes = (size_t)(c->props.totalGlobalMem / 4);
+    if (const char* v = std::getenv("RMHIP_POOL_LIMIT_MB")) c->pool_limit_bytes = (size_t)std::atoll(v) << 20;
+    *out_ctx = h;
+    return RMHIP_OK;
+}
+
+int rmhip_shutdown(rmhip_ctx* ctx) {
+    if (!ctx) return RMHIP_OK;
+    Context* c = &ctx->c;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->kernel_cache.clear();
+    }
+    c->pool_limit_bytes = 0;  // frees bypass the pool from here on
+    c->table.clear();
+    for (auto& kv : c->pool) (void)hipFree(kv.second);
+    c->pool.clear();
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete ctx;
+    return RMHIP_OK;
+}
+
+int rmhip_device_info(rmhip_ctx* ctx, rmhip_device_info_t* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    std::memset(out, 0, sizeof *out);
+    std::snprintf(out->name, sizeof out->name, "%s", c->props.name);
+    std::snprintf(out->arch, sizeof out->arch, "%s", c->props.gcnArchName);
+    out->device_ordinal = c->device;
+    out->compute_units = c->num_cus;
+    out->wavefront_size = c->props.warpSize;
+    out->clock_mhz = c->props.clockRate / 1000;
+    out->total_memory_bytes = c->props.totalGlobalMem;
+    out->precision_bits = 64;
+    out->reduction_workgroup_size = 256;
+    out->two_pass_threshold = 262144;
+    return RMHIP_OK;
+}
+
+int rmhip_set_stream(rmhip_ctx* ctx, void* hip_stream) {
+    CTX_OR_FAIL(ctx);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)hip_stream;
+    c->owns_stream = false;
+    return RMHIP_OK;
+}
+
+void* rmhip_get_stream(rmhip_ctx* ctx) { return ctx ? (void*)ctx->c.stream : nullptr; }
+
+int rmhip_synchronize(rmhip_ctx* ctx) {
+    CTX_OR_FAIL(ctx);
+    RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return RMHIP_OK;
+}
+
+int rmhip_upload(rmhip_ctx* ctx, const double* host, const size_t* shape, size_t rank, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out || (rank && !shape)) return fail(RMHIP_ERR_INVALID, "upload: null argument");
+    const size_t n = shape_numel(shape, rank);
+    if (n && !host) return fail(RMHIP_ERR_INVALID, "upload: null host data");
+    Buffer b;
+    RMHIP_TRY(c->new_buffer(shape, rank, out, &b));
+    if (n) {
+        hipError_t e = hipMemcpyAsync(b.data(), host, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // host buffer may be reused on return
+        if (e != hipSuccess) {
+            rmhip_free(ctx, *out);
+            return fail(RMHIP_ERR_HIP, "upload memcpy: %s", hipGetErrorString(e));
+        }
+    }
+    c->tel.upload_bytes += n * sizeof(double);
+    return RMHIP_OK;
+}
+
+int rmhip_download(rmhip_ctx* ctx, rmhip_buf id, double* out_host, size_t n) {
+    CTX_OR_FAIL(ctx);
+    Buffer b;
+    RMHIP_TRY(c->get(id, &b));
+    if (n != b.numel) return fail(RMHIP_ERR_SHAPE, "download: expected %zu elements, got %zu", b.numel, n);
+    if (n && !out_host) return fail(RMHIP_ERR_INVALID, "download: null destination");
+    if (n) {
+        RMHIP_HIP_CHECK(hipMemcpyAsync(out_host, b.data(), n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->tel.download_bytes += n * sizeof(double);
+    return RMHIP_OK;
+}
+
+int rmhip_free(rmhip_ctx* ctx, rmhip_buf id) {
+    CTX_OR_FAIL(ctx);
+    Buffer victim;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        auto it = c->table.find(id);
+        if (it == c->table.end()) return fail(RMHIP_ERR_NOT_FOUND, "free: buffer not found: %llu", (unsigned long long)id);
+        victim = std::move(it->second);
+        c->table.erase(it);
+    }
+    return RMHIP_OK;  // `victim` drops the allocation reference outside the lock
+}
+
+int rmhip_shape(rmhip_ctx* ctx, rmhip_buf id, size_t* rank_inout, size_t* shape_out) {
+    CTX_OR_FAIL(ctx);
+    if (!rank_inout) return fail(RMHIP_ERR_INVALID, "null rank");
+    Buffer b;
+    RMHIP_TRY(c->get(id, &b));
+    if (*rank_inout < b.shape.size() || !shape_out) {
+        *rank_inout = b.shape.size();
+        return shape_out ? fail(RMHIP_ERR_INVALID, "shape buffer too small") : RMHIP_OK;
+    }
+    for (size_t i = 0; i < b.shape.size(); ++i) shape_out[i] = b.shape[i];
+    *rank_inout = b.shape.size();
+    return RMHIP_OK;
+}
+
+int rmhip_numel(rmhip_ctx* ctx, rmhip_buf id, size_t* out) {
+    CTX_OR_FAIL(ctx);
+    Buffer b;
+    RMHIP_TRY(c->get(id, &b));
+    *out = b.numel;
+    return RMHIP_OK;
+}
+
+int rmhip_fill(rmhip_ctx* ctx, double value, const size_t* shape, size_t rank, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    Buffer b;
+    RMHIP_TRY(c->new_buffer(shape, rank, out, &b));
+    int rc = launch_fill(c, b.data(), b.numel, value);
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+
+int rmhip_fill_uniform(rmhip_ctx* ctx, uint64_t seed, double lo, double hi, const size_t* shape, size_t rank,
+                       rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    Buffer b;
+    RMHIP_TRY(c->new_buffer(shape, rank, out, &b));
+    int rc = launch_fill_uniform(c, b.data(), b.numel, seed, lo, hi);
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+
+int rmhip_reshape(rmhip_ctx* ctx, rmhip_buf id, const size_t* shape, size_t rank, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    Buffer b;
+    RMHIP_TRY(c->get(id, &b));
+    if (shape_numel(shape, rank) != b.numel)
+        return fail(RMHIP_ERR_SHAPE, "reshape: element count mismatch (%zu vs %zu)", shape_numel(shape, rank), b.numel);
+    Buffer r;
+    r.alloc = b.alloc;
+    r.shape.assign(shape, shape + rank);
+    r.numel = b.numel;
+    return c->register_buffer(std::move(r), out);
+}
+
+int rmhip_wrap_external(rmhip_ctx* ctx, void* device_ptr, const size_t* shape, size_t rank, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!device_ptr && shape_numel(shape, rank)) return fail(RMHIP_ERR_INVALID, "wrap_external: null pointer");
+    Buffer b;
+    b.alloc = std::make_shared<Allocation>();
+    b.alloc->ctx = c;
+    b.alloc->ptr = (double*)device_ptr;
+    b.alloc->external = true;
+    b.shape.assign(shape, shape + rank);
+    b.numel = shape_numel(shape, rank);
+    b.alloc->bytes = b.numel * sizeof(double);
+    return c->register_buffer(std::move(b), out);
+}
+
+void* rmhip_device_ptr(rmhip_ctx* ctx, rmhip_buf id) {
+    if (!ctx) return nullptr;
+    Buffer b;
+    if (ctx->c.get(id, &b) != RMHIP_OK) return nullptr;
+    return b.data();
+}
+
+int rmhip_telemetry(rmhip_ctx* ctx, rmhip_telemetry_t* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Telemetry& t = c->tel;
+    out->fused_elementwise_count = t.fused_elementwise_count;
+    out->fused_elementwise_ns = t.fused_elementwise_ns;
+    out->fused_reduction_count = t.fused_reduction_count;
+    out->fused_reduction_ns = t.fused_reduction_ns;
+    out->matmul_count = t.matmul_count;
+    out->matmul_ns = t.matmul_ns;
+    out->mldivide_count = t.mldivide_count;
+    out->mldivide_ns = t.mldivide_ns;
+    out->upload_bytes = t.upload_bytes;
+    out->download_bytes = t.download_bytes;
+    out->fusion_cache_hits = t.cache_hits;
+    out->fusion_cache_misses = t.cache_misses;
+    out->kernel_launches = t.kernel_launches;
+    out->bytes_allocated = t.bytes_allocated;
+    out->bytes_pooled = t.bytes_pooled;
+    return RMHIP_OK;
+}
+
+int rmhip_reset_telemetry(rmhip_ctx* ctx) {
+    CTX_OR_FAIL(ctx);
+    Telemetry& t = c->tel;
+    t.fused_elementwise_count = t.fused_elementwise_ns = 0;
+    t.fused_reduction_count = t.fused_reduction_ns = 0;
+    t.matmul_count = t.matmul_ns = 0;
+    t.mldivide_count = t.mldivide_ns = 0;
+    t.upload_bytes = t.download_bytes = 0;
+    t.cache_hits = t.cache_misses = 0;
+    t.kernel_launches = 0;
+    return RMHIP_OK;
+}
+
+int rmhip_timer_begin(rmhip_ctx* ctx) {
+    CTX_OR_FAIL(ctx);
+    RMHIP_HIP_CHECK(hipEventRecord(c->ev_begin, c->stream));
+    return RMHIP_OK;
+}
+
+int rmhip_timer_end(rmhip_ctx* ctx, double* elapsed_ms) {
+    CTX_OR_FAIL(ctx);
+    RMHIP_HIP_CHECK(hipEventRecord(c->ev_end, c->stream));
+    RMHIP_HIP_CHECK(hipEventSynchronize(c->ev_end));
+    float ms = 0.f;
+    RMHIP_HIP_CHECK(hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
+    if (elapsed_ms) *elapsed_ms = (double)ms;
+    return RMHIP_OK;
+}
+
+}  // extern "C"
+
+// rmhip_ctx is an opaque wrapper; the other translation units reach the Context through this.
+namespace rmhip {
+Context* context_of(rmhip_ctx* h) { return h ? &h->c : nullptr; }
+}  // namespace rmhip

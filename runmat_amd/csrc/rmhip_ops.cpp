@@ -1,0 +1,584 @@
+// rmhip_ops.cpp -- the operator half of the C ABI (include/rmhip.h): fused elementwise / fused
+// reduction dispatch, per-op kernels, reductions, matmul, lu, mldivide, rng.
+// Host-side logic mirrors the provider duties of the reference's backends:
+//   broadcast shape/stride preparation  backend/wgpu/provider/ops/elementwise.rs:1655-1697
+//   reduction geometry handed in by     crates/runmat-vm/src/accel/fusion.rs:540-915 (reduce_len, num_slices)
+//   output shapes of the plain reducers crates/runmat-accelerate/src/simple_provider.rs:6728-6806
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "codegen.h"
+#include "common.h"
+#include "reduce_plan.h"
+#include "wgsl_front.h"
+
+using namespace rmhip;
+
+#define CTX_OR_FAIL(ctx)                                            \
+    if (!(ctx)) return fail(RMHIP_ERR_INVALID, "null context");     \
+    Context* c = context_of(ctx);                                   \
+    DeviceGuard _dg(c)
+
+namespace {
+
+// Front-pad `shape` to `rank` (broadcast.rs:108-115, elementwise.rs:1681-1687) and derive strides
+// with 0 on broadcast (extent 1) dims.  Returns false if the shape cannot broadcast to `out`.
+bool padded_strides(const std::vector<size_t>& shape, const size_t* out, size_t rank, std::vector<uint64_t>* strides) {
+    if (shape.size() > rank) {
+        // allow leading/trailing singleton excess (e.g. [1,1] scalar against a rank-1 request)
+        size_t numel = 1;
+        for (size_t d : shape) numel *= d;
+        if (numel != 1) return false;
+        strides->assign(rank, 0);
+        return true;
+    }
+    const size_t pad = rank - shape.size();
+    strides->assign(rank, 0);
+    uint64_t s = 1;
+    for (size_t d = 0; d < rank; ++d) {
+        const size_t ext = d < pad ? 1 : shape[d - pad];
+        if (ext != 1 && ext != out[d]) return false;
+        (*strides)[d] = ext == 1 ? 0 : s;
+        s *= ext;
+    }
+    return true;
+}
+
+// Collapse dims: drop extent-1 dims, merge dim d+1 into d when every operand is contiguous across
+// the boundary (stride[d+1] == stride[d]*shape[d]) or broadcast on both (0 and 0).
+void collapse(std::vector<uint64_t>* shape, std::vector<std::vector<uint64_t>>* strides) {
+    std::vector<uint64_t> ns;
+    std::vector<std::vector<uint64_t>> nst(strides->size());
+    for (size_t d = 0; d < shape->size(); ++d) {
+        if ((*shape)[d] == 1) continue;
+        bool merged = false;
+        if (!ns.empty()) {
+            bool ok = true;
+            for (size_t k = 0; k < strides->size(); ++k) {
+                const uint64_t prev = nst[k].back(), cur = (*strides)[k][d];
+                if (!((prev == 0 && cur == 0) || (prev != 0 && cur == prev * ns.back()))) {
+                    ok = false;
+                    break;
+                }
+            }
+            if (ok) {
+                ns.back() *= (*shape)[d];
+                merged = true;
+            }
+        }
+        if (!merged) {
+            ns.push_back((*shape)[d]);
+            for (size_t k = 0; k < strides->size(); ++k) nst[k].push_back((*strides)[k][d]);
+        }
+    }
+    if (ns.empty()) {
+        ns.push_back(1);
+        for (size_t k = 0; k < strides->size(); ++k) nst[k].push_back(0);
+    }
+    *shape = ns;
+    *strides = nst;
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+std::vector<size_t> normalize_matrix_shape(const std::vector<size_t>& s) {
+    if (s.empty()) return {1, 1};
+    if (s.size() == 1) return {s[0], 1};
+    return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rmhip_wgsl_translate(const char* shader, int kind, char* out, size_t cap, size_t* needed) {
+    if (!shader) return fail(RMHIP_ERR_INVALID, "null shader");
+    std::string err, src;
+    if (kind == 0) {
+        ElementwiseProgram p;
+        if (!parse_elementwise_wgsl(shader, &p, &err)) return fail(RMHIP_ERR_COMPILE, "WGSL front-end: %s", err.c_str());
+        src = generate_elementwise_source(p, EwTuning::from_env(), 0u);
+    } else {
+        ReductionProgram p;
+        if (!parse_reduction_wgsl(shader, &p, &err)) return fail(RMHIP_ERR_COMPILE, "WGSL front-end: %s", err.c_str());
+        src = generate_reduction_source(p);
+    }
+    if (needed) *needed = src.size() + 1;
+    if (out && cap) {
+        const size_t n = std::min(cap - 1, src.size());
+        std::memcpy(out, src.data(), n);
+        out[n] = '\0';
+    }
+    return RMHIP_OK;
+}
+
+int rmhip_wgsl_compile_check(const char* shader, int kind) {
+    if (!shader) return fail(RMHIP_ERR_INVALID, "null shader");
+    std::string err, src;
+    if (kind == 0) {
+        ElementwiseProgram p;
+        if (!parse_elementwise_wgsl(shader, &p, &err)) return fail(RMHIP_ERR_COMPILE, "WGSL front-end: %s", err.c_str());
+        src = generate_elementwise_source(p, EwTuning::from_env(), 0u);
+    } else {
+        ReductionProgram p;
+        if (!parse_reduction_wgsl(shader, &p, &err)) return fail(RMHIP_ERR_COMPILE, "WGSL front-end: %s", err.c_str());
+        src = generate_reduction_source(p);
+    }
+    std::vector<char> code;
+    return compile_to_code_object(src, &code);
+}
+
+int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf* inputs, size_t n_in,
+                            const size_t* out_shape, size_t rank, size_t len, size_t n_out, rmhip_buf* out_ids) {
+    CTX_OR_FAIL(ctx);
+    ScopedTimer timer(&c->tel.fused_elementwise_count, &c->tel.fused_elementwise_ns);
+    if (!shader || !inputs || !out_ids || (rank && !out_shape)) return fail(RMHIP_ERR_INVALID, "fused_elementwise: null argument");
+    if (n_in == 0) return fail(RMHIP_ERR_INVALID, "fused_elementwise: no inputs");  // elementwise.rs:1574
+    if (n_in > 24) return fail(RMHIP_ERR_UNSUPPORTED, "fused_elementwise: more than 24 inputs");
+    if (rank > 8 + 8) return fail(RMHIP_ERR_UNSUPPORTED, "fused_elementwise: rank too large");
+    if (shape_numel(out_shape, rank) != len) return fail(RMHIP_ERR_SHAPE, "fused_elementwise: len %zu != prod(output_shape)", len);
+    if (len == 0) return fail(RMHIP_ERR_UNSUPPORTED, "fusion: zero-length execution not supported");  // fusion_exec.rs:273
+    ElementwiseProgram prog;
+    std::string err;
+    if (!parse_elementwise_wgsl(shader, &prog, &err)) return fail(RMHIP_ERR_COMPILE, "WGSL front-end: %s", err.c_str());
+    if ((size_t)prog.n_inputs != n_in) return fail(RMHIP_ERR_INVALID, "fused_elementwise: shader binds %d inputs, got %zu", prog.n_inputs, n_in);
+    if (prog.outputs.size() != n_out) return fail(RMHIP_ERR_INVALID, "fused_elementwise: shader writes %zu outputs, caller expects %zu", prog.outputs.size(), n_out);
+
+    std::vector<Buffer> in(n_in);
+    std::vector<uint64_t> oshape(out_shape, out_shape + rank);
+    std::vector<std::vector<uint64_t>> strides(n_in);
+    for (size_t k = 0; k < n_in; ++k) {
+        RMHIP_TRY(c->get(inputs[k], &in[k]));
+        if (!padded_strides(in[k].shape, out_shape, rank, &strides[k]))
+            return fail(RMHIP_ERR_SHAPE, "fused_elementwise: input %zu does not broadcast to the output shape", k);
+    }
+    collapse(&oshape, &strides);
+    const size_t crank = oshape.size();
+    if (crank > 8) return fail(RMHIP_ERR_UNSUPPORTED, "fused_elementwise: broadcast rank %zu > 8 after collapsing", crank);
+
+    bool fast = crank == 1;
+    unsigned mask = 0;
+    if (fast)
+        for (size_t k = 0; k < n_in; ++k)
+            if (strides[k][0] == 0) mask |= 1u << k;
+    if (!fast) mask = 0;
+
+    std::shared_ptr<FusedKernel> kern;
+    RMHIP_TRY(get_elementwise_kernel(c, prog, mask, &kern));
+
+    std::vector<Buffer> outs(n_out);
+    std::vector<rmhip_buf> ids(n_out, 0);
+    for (size_t k = 0; k < n_out; ++k) {
+        int rc = c->new_buffer(out_shape, rank, &ids[k], &outs[k]);
+        if (rc != RMHIP_OK) {
+            for (size_t j = 0; j < k; ++j) rmhip_free(ctx, ids[j]);
+            return rc;
+        }
+    }
+
+    std::vector<const double*> in_ptr(n_in);
+    std::vector<double*> out_ptr(n_out);
+    for (size_t k = 0; k < n_in; ++k) in_ptr[k] = in[k].data();
+    for (size_t k = 0; k < n_out; ++k) out_ptr[k] = outs[k].data();
+    std::vector<void*> args;
+    for (size_t k = 0; k < n_in; ++k) args.push_back(&in_ptr[k]);
+    for (size_t k = 0; k < n_out; ++k) args.push_back(&out_ptr[k]);
+
+    const EwTuning& t = kern->tuning;
+    hipError_t e;
+    if (fast) {
+        bool vec_ok = true;
+        for (size_t k = 0; k < n_in; ++k)
+            if (!((mask >> k) & 1u) && !aligned16(in_ptr[k])) vec_ok = false;
+        for (size_t k = 0; k < n_out; ++k)
+            if (!aligned16(out_ptr[k])) vec_ok = false;
+        unsigned long long n = len;
+        args.push_back(&n);
+        const size_t work = vec_ok ? len / 2 : len;
+        size_t want = (work + (size_t)t.block * t.unroll - 1) / ((size_t)t.block * t.unroll);
+        const size_t cap = (size_t)c->num_cus * t.blocks_per_cu;
+        if (want < 1) want = 1;
+        const unsigned grid = (unsigned)std::min(want, cap);
+        e = hipModuleLaunchKernel(vec_ok ? kern->fn_fast : kern->fn_fast1, grid, 1, 1, t.block, 1, 1, 0, c->stream,
+                                  args.data(), nullptr);
+    } else {
+        std::vector<unsigned long long> p(11 + 8 * n_in, 0);
+        const unsigned long long d0 = oshape[0];
+        const unsigned long long per_block = (unsigned long long)t.block * t.unroll;
+        const unsigned long long nchunks = (d0 + per_block - 1) / per_block;
+        unsigned long long outer = 1;
+        p[0] = d0;
+        p[1] = nchunks;
+        p[2] = crank;
+        for (size_t d = 0; d < 8; ++d) p[3 + d] = d < crank ? oshape[d] : 1;
+        for (size_t d = 1; d < crank; ++d) outer *= oshape[d];
+        for (size_t k = 0; k < n_in; ++k)
+            for (size_t d = 0; d < crank; ++d) p[11 + 8 * k + d] = strides[k][d];
+        args.push_back(p.data());
+        const unsigned long long blocks = nchunks * outer;
+        const unsigned long long gx = std::min<unsigned long long>(blocks, 1048576ULL);
+        const unsigned long long gy = (blocks + gx - 1) / gx;
+        if (gy > 65535ULL) {
+            for (size_t k = 0; k < n_out; ++k) rmhip_free(ctx, ids[k]);
+            return fail(RMHIP_ERR_UNSUPPORTED, "fused_elementwise: broadcast grid too large");
+        }
+        e = hipModuleLaunchKernel(kern->fn_bcast, (unsigned)gx, (unsigned)gy, 1, t.block, 1, 1, 0, c->stream, args.data(),
+                                  nullptr);
+    }
+    if (e != hipSuccess) {
+        for (size_t k = 0; k < n_out; ++k) rmhip_free(ctx, ids[k]);
+        return fail(RMHIP_ERR_HIP, "fused_elementwise launch: %s", hipGetErrorString(e));
+    }
+    c->tel.kernel_launches++;
+    for (size_t k = 0; k < n_out; ++k) out_ids[k] = ids[k];
+    return RMHIP_OK;
+}
+
+int rmhip_fused_reduction(rmhip_ctx* ctx, const char* shader, const rmhip_buf* inputs, size_t n_in,
+                          const size_t* out_shape, size_t rank, size_t reduce_len, size_t num_slices,
+                          uint32_t workgroup_size, int flavor, double custom_scale, rmhip_buf* out) {
+    (void)workgroup_size;
+    CTX_OR_FAIL(ctx);
+    ScopedTimer timer(&c->tel.fused_reduction_count, &c->tel.fused_reduction_ns);
+    if (!shader || !inputs || !out) return fail(RMHIP_ERR_INVALID, "fused_reduction: null argument");
+    if (n_in == 0 || n_in > 24) return fail(RMHIP_ERR_UNSUPPORTED, "fused_reduction: unsupported input count %zu", n_in);
+    if (reduce_len * num_slices == 0) return fail(RMHIP_ERR_UNSUPPORTED, "fusion: zero-length execution not supported");  // fusion_exec.rs:489
+    if (shape_numel(out_shape, rank) != num_slices)
+        return fail(RMHIP_ERR_SHAPE, "fused_reduction: prod(output_shape) != num_slices %zu", num_slices);
+    if (flavor < RMHIP_FLAVOR_SUM || flavor > RMHIP_FLAVOR_CUSTOM_SCALE) return fail(RMHIP_ERR_INVALID, "fused_reduction: bad flavor %d", flavor);
+    ReductionProgram prog;
+    std::string err;
+    if (!parse_reduction_wgsl(shader, &prog, &err)) return fail(RMHIP_ERR_COMPILE, "WGSL front-end: %s", err.c_str());
+    if ((size_t)prog.n_inputs != n_in) return fail(RMHIP_ERR_INVALID, "fused_reduction: shader binds %d inputs, got %zu", prog.n_inputs, n_in);
+
+    const size_t total = reduce_len * num_slices;
+    std::vector<Buffer> in(n_in);
+    std::vector<unsigned long long> mult(n_in);
+    for (size_t k = 0; k < n_in; ++k) {
+        RMHIP_TRY(c->get(inputs[k], &in[k]));
+        if (in[k].numel == total) mult[k] = 1;
+        else if (in[k].numel == 1) mult[k] = 0;  // scalar operand uploaded as a 1-element tensor (fusion_exec.rs:522-543)
+        else return fail(RMHIP_ERR_SHAPE, "fused_reduction: input %zu has %zu elements, expected %zu", k, in[k].numel, total);
+    }
+    std::shared_ptr<FusedKernel> kern;
+    RMHIP_TRY(get_reduction_kernel(c, prog, &kern));
+
+    // axis 0: slice s is contiguous (pre=1, red, post=slices); axis 1: element (s, r) at s + r*slices.
+    const size_t pre = prog.axis == 0 ? 1 : num_slices;
+    const size_t post = prog.axis == 0 ? num_slices : 1;
+    const ReducePlan plan = plan_reduction(pre, reduce_len, post, c->num_cus);
+    if (!plan.valid) return fail(RMHIP_ERR_UNSUPPORTED, "fused_reduction: geometry exceeds launch limits");
+    const size_t nparts = (size_t)(plan.nslices * plan.nsplit);
+    RMHIP_TRY(c->ensure_scratch(2 * nparts * sizeof(double)));
+    double* pv = c->scratch;
+    double* pn = c->scratch + nparts;
+
+    Buffer ob;
+    rmhip_buf oid = 0;
+    RMHIP_TRY(c->new_buffer(out_shape, rank, &oid, &ob));
+
+    std::vector<const double*> in_ptr(n_in);
+    std::vector<void*> args;
+    for (size_t k = 0; k < n_in; ++k) {
+        in_ptr[k] = in[k].data();
+        args.push_back(&in_ptr[k]);
+        args.push_back(&mult[k]);
+    }
+    unsigned long long u_pre = pre, u_red = reduce_len, u_nsplit = plan.nsplit, u_nslices = plan.nslices;
+    int tx = plan.tx;
+    hipError_t e;
+    if (plan.contiguous) {
+        args.push_back(&u_red);
+        args.push_back(&u_nslices);
+        args.push_back(&u_nsplit);
+        args.push_back(&pv);
+        args.push_back(&pn);
+        e = hipModuleLaunchKernel(kern->fn_contig, plan.gx, plan.gy, plan.gz, 256, 1, 1, 0, c->stream, args.data(), nullptr);
+    } else {
+        args.push_back(&u_pre);
+        args.push_back(&u_red);
+        args.push_back(&u_nsplit);
+        args.push_back(&tx);
+        args.push_back(&pv);
+        args.push_back(&pn);
+        e = hipModuleLaunchKernel(kern->fn_strided, plan.gx, plan.gy, plan.gz, 256, 1, 1, 0, c->stream, args.data(), nullptr);
+    }
+    if (e == hipSuccess) {
+        const double* cpv = pv;
+        const double* cpn = pn;
+        int mean = flavor == RMHIP_FLAVOR_MEAN ? 1 : 0;
+        int omit = prog.omitnan ? 1 : 0;
+        double scale = flavor == RMHIP_FLAVOR_CUSTOM_SCALE ? custom_scale : 1.0;
+        double* optr = ob.data();
+        void* fargs[] = {&cpv, &cpn, &u_nslices, &u_nsplit, &u_red, &mean, &omit, &scale, &optr};
+        const unsigned fb = (unsigned)ceil_div_u64(plan.nslices, 4);
+        e = hipModuleLaunchKernel(kern->fn_final, fb, 1, 1, 256, 1, 1, 0, c->stream, fargs, nullptr);
+    }
+    if (e != hipSuccess) {
+        rmhip_free(ctx, oid);
+        return fail(RMHIP_ERR_HIP, "fused_reduction launch: %s", hipGetErrorString(e));
+    }
+    c->tel.kernel_launches += 2;
+    *out = oid;
+    return RMHIP_OK;
+}
+
+int rmhip_unary(rmhip_ctx* ctx, int op, rmhip_buf a, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    if (op < 0 || op >= RMHIP_UNARY_OP_COUNT) return fail(RMHIP_ERR_UNSUPPORTED, "unary op %d not supported by provider", op);
+    Buffer ab, ob;
+    RMHIP_TRY(c->get(a, &ab));
+    RMHIP_TRY(c->new_buffer(ab.shape.data(), ab.shape.size(), out, &ob));
+    int rc = launch_unary(c, op, ab.data(), ob.data(), ab.numel);
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+
+int rmhip_scalar(rmhip_ctx* ctx, int op, rmhip_buf a, double s, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    if (op < 0 || op >= RMHIP_SCALAR_OP_COUNT) return fail(RMHIP_ERR_UNSUPPORTED, "scalar op %d not supported by provider", op);
+    Buffer ab, ob;
+    RMHIP_TRY(c->get(a, &ab));
+    RMHIP_TRY(c->new_buffer(ab.shape.data(), ab.shape.size(), out, &ob));
+    int rc = launch_scalar(c, op, ab.data(), s, ob.data(), ab.numel);
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+
+int rmhip_binary(rmhip_ctx* ctx, int op, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    if (op < 0 || op >= RMHIP_BINARY_OP_COUNT) return fail(RMHIP_ERR_UNSUPPORTED, "binary op %d not supported by provider", op);
+    Buffer ab, bb, ob;
+    RMHIP_TRY(c->get(a, &ab));
+    RMHIP_TRY(c->get(b, &bb));
+    // broadcast_shapes (broadcast.rs:8-47): front-pad, extents equal or 1
+    const size_t rank = std::max(ab.shape.size(), bb.shape.size());
+    if (rank > 16) return fail(RMHIP_ERR_UNSUPPORTED, "binary: rank too large");
+    std::vector<size_t> oshape(rank);
+    for (size_t d = 0; d < rank; ++d) {
+        const size_t ea = d < rank - ab.shape.size() ? 1 : ab.shape[d - (rank - ab.shape.size())];
+        const size_t eb = d < rank - bb.shape.size() ? 1 : bb.shape[d - (rank - bb.shape.size())];
+        if (ea == eb) oshape[d] = ea;
+        else if (ea == 1) oshape[d] = eb;
+        else if (eb == 1) oshape[d] = ea;
+        else
+            return fail(RMHIP_ERR_SHAPE, "size mismatch between inputs (dimension %zu has lengths %zu and %zu)", d + 1, ea, eb);
+    }
+    RMHIP_TRY(c->new_buffer(oshape.data(), rank, out, &ob));
+    int rc;
+    if (ab.numel == ob.numel && bb.numel == ob.numel) {
+        rc = launch_binary_same(c, op, ab.data(), bb.data(), ob.data(), ob.numel);
+    } else {
+        std::vector<std::vector<uint64_t>> strides(2);
+        std::vector<uint64_t> os(oshape.begin(), oshape.end());
+        padded_strides(ab.shape, oshape.data(), rank, &strides[0]);
+        padded_strides(bb.shape, oshape.data(), rank, &strides[1]);
+        collapse(&os, &strides);
+        if (os.size() > 8) {
+            rmhip_free(ctx, *out);
+            return fail(RMHIP_ERR_UNSUPPORTED, "binary: broadcast rank %zu > 8 after collapsing", os.size());
+        }
+        BroadcastDesc d{};
+        d.rank = (int)os.size();
+        for (size_t i = 0; i < os.size(); ++i) {
+            d.out_shape[i] = os[i];
+            d.stride_a[i] = strides[0][i];
+            d.stride_b[i] = strides[1][i];
+        }
+        rc = launch_binary_bcast(c, op, ab.data(), bb.data(), ob.data(), ob.numel, d);
+    }
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+
+int rmhip_reduce(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int nan_mode, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    if (op < 0 || op >= RMHIP_REDUCE_OP_COUNT) return fail(RMHIP_ERR_UNSUPPORTED, "reduce op %d not supported by provider", op);
+    Buffer ab, ob;
+    RMHIP_TRY(c->get(a, &ab));
+    if (dim < 0) {
+        const size_t oshape[2] = {1, 1};  // simple_provider.rs:6743
+        RMHIP_TRY(c->new_buffer(oshape, 2, out, &ob));
+        int rc = launch_reduce_all(c, op, nan_mode, ab.data(), ab.numel, ob.data());
+        if (rc) rmhip_free(ctx, *out);
+        return rc;
+    }
+    std::vector<size_t> shape = normalize_matrix_shape(ab.shape);
+    if ((size_t)dim >= shape.size()) return fail(RMHIP_ERR_UNSUPPORTED, "reduce: dim %d out of range for rank %zu", dim, shape.size());
+    size_t pre = 1, post = 1;
+    for (int d = 0; d < dim; ++d) pre *= shape[d];
+    for (size_t d = dim + 1; d < shape.size(); ++d) post *= shape[d];
+    const size_t red = shape[dim];
+    std::vector<size_t> oshape = shape;
+    oshape[dim] = 1;
+    RMHIP_TRY(c->new_buffer(oshape.data(), oshape.size(), out, &ob));
+    int rc = launch_reduce_mid(c, op, nan_mode, ab.data(), pre, red, post, ob.data());
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+
+int rmhip_matmul(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    ScopedTimer timer(&c->tel.matmul_count, &c->tel.matmul_ns);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer ab, bb, ob;
+    RMHIP_TRY(c->get(a, &ab));
+    RMHIP_TRY(c->get(b, &bb));
+    if (ab.shape.size() != 2 || bb.shape.size() != 2) return fail(RMHIP_ERR_UNSUPPORTED, "matmul: only 2D supported");  // simple_provider.rs:7705
+    const size_t m = ab.shape[0], k = ab.shape[1], kb = bb.shape[0], n = bb.shape[1];
+    if (k != kb) return fail(RMHIP_ERR_SHAPE, "matmul: inner dims must agree (%zux%zu * %zux%zu)", m, k, kb, n);
+    const size_t oshape[2] = {m, n};
+    RMHIP_TRY(c->new_buffer(oshape, 2, out, &ob));
+    int rc = RMHIP_OK;
+    if (k == 0) rc = launch_fill(c, ob.data(), ob.numel, 0.0);
+    else rc = launch_dgemm(c, m, n, k, 1.0, ab.data(), m, bb.data(), k, 0.0, ob.data(), m);
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+
+int rmhip_lu(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf out5[5]) {
+    CTX_OR_FAIL(ctx);
+    if (!out5) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer ab;
+    RMHIP_TRY(c->get(a, &ab));
+    if (ab.shape.size() > 2) return fail(RMHIP_ERR_UNSUPPORTED, "lu: only 2D supported");
+    const std::vector<size_t> shape = normalize_matrix_shape(ab.shape);
+    const size_t rows = shape[0], cols = shape[1];
+    Buffer comb, L, U, P, piv;
+    rmhip_buf ids[5] = {0, 0, 0, 0, 0};
+    const size_t s_comb[2] = {rows, cols}, s_l[2] = {rows, rows}, s_piv[2] = {rows, 1};
+    int rc = c->new_buffer(s_comb, 2, &ids[0], &comb);
+    if (!rc) rc = c->new_buffer(s_l, 2, &ids[1], &L);
+    if (!rc) rc = c->new_buffer(s_comb, 2, &ids[2], &U);
+    if (!rc) rc = c->new_buffer(s_l, 2, &ids[3], &P);
+    if (!rc) rc = c->new_buffer(s_piv, 2, &ids[4], &piv);
+    int* perm = nullptr;
+    if (!rc && hipMalloc((void**)&perm, sizeof(int) * (rows + 1)) != hipSuccess) rc = fail(RMHIP_ERR_OOM, "lu: pivot allocation failed");
+    if (!rc && ab.numel) {
+        hipError_t e = hipMemcpyAsync(comb.data(), ab.data(), ab.numel * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+        if (e != hipSuccess) rc = fail(RMHIP_ERR_HIP, "lu copy: %s", hipGetErrorString(e));
+    }
+    int info = 0;
+    if (!rc) rc = lu_factor_device(c, comb.data(), rows, cols, rows, perm, &info);
+    if (!rc) rc = lu_extract_device(c, comb.data(), rows, cols, perm, L.data(), U.data(), P.data(), piv.data());
+    if (perm) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(perm);
+    }
+    if (rc) {
+        for (auto id : ids)
+            if (id) rmhip_free(ctx, id);
+        return rc;
+    }
+    for (int i = 0; i < 5; ++i) out5[i] = ids[i];
+    return RMHIP_OK;
+}
+
+int rmhip_mldivide(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    ScopedTimer timer(&c->tel.mldivide_count, &c->tel.mldivide_ns);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer ab, bb;
+    RMHIP_TRY(c->get(a, &ab));
+    RMHIP_TRY(c->get(b, &bb));
+    if (ab.shape.size() > 2 || bb.shape.size() > 2) return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: only 2D supported");
+    const std::vector<size_t> as = normalize_matrix_shape(ab.shape), bs = normalize_matrix_shape(bb.shape);
+    if (ab.numel == 1) {  // scalar lhs: rhs * (1/lhs), mldivide.rs:321-325
+        double lhs = 0.0;
+        RMHIP_HIP_CHECK(hipMemcpyAsync(&lhs, ab.data(), sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        Buffer ob;
+        RMHIP_TRY(c->new_buffer(bs.data(), 2, out, &ob));
+        int rc = launch_scalar(c, RMHIP_SMUL, bb.data(), 1.0 / lhs, ob.data(), bb.numel);
+        if (rc) rmhip_free(ctx, *out);
+        return rc;
+    }
+    if (as[0] != bs[0]) return fail(RMHIP_ERR_SHAPE, "mldivide: row mismatch (%zu vs %zu)", as[0], bs[0]);
+    if (as[0] != as[1])
+        return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: rectangular systems use the CPU least-squares path (mldivide.rs:380-404)");
+    const size_t n = as[0], nrhs = bs[1];
+    if (n == 0) return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: empty system");
+    std::shared_ptr<Allocation> work;
+    RMHIP_TRY(c->alloc_device(n * n, &work));
+    RMHIP_HIP_CHECK(hipMemcpyAsync(work->ptr, ab.data(), n * n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    int* perm = nullptr;
+    RMHIP_HIP_CHECK(hipMalloc((void**)&perm, sizeof(int) * (n + 1)));
+    int info = 0;
+    int rc = lu_factor_device(c, work->ptr, n, n, n, perm, &info);
+    if (!rc && info > 0)
+        rc = fail(RMHIP_ERR_SINGULAR, "mldivide: %d pivot(s) <= 1e-12; matrix is numerically singular, use the CPU SVD path", info);
+    Buffer ob;
+    rmhip_buf oid = 0;
+    const size_t oshape[2] = {n, nrhs};
+    if (!rc) rc = c->new_buffer(oshape, 2, &oid, &ob);
+    if (!rc) rc = lu_solve_device(c, work->ptr, n, n, perm, bb.data(), nrhs, n, ob.data(), n);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(perm);
+    if (rc) {
+        if (oid) rmhip_free(ctx, oid);
+        return rc;
+    }
+    *out = oid;
+    return RMHIP_OK;
+}
+
+int rmhip_set_rng_state(rmhip_ctx* ctx, uint64_t state) {
+    CTX_OR_FAIL(ctx);
+    c->rng_state = state;
+    return RMHIP_OK;
+}
+
+int rmhip_get_rng_state(rmhip_ctx* ctx, uint64_t* state) {
+    CTX_OR_FAIL(ctx);
+    if (!state) return fail(RMHIP_ERR_INVALID, "null state");
+    *state = c->rng_state;
+    return RMHIP_OK;
+}
+
+int rmhip_rng_seed(rmhip_ctx* ctx, uint64_t seed) {  // mix_seed, random.rs:128-141
+    CTX_OR_FAIL(ctx);
+    uint64_t s;
+    if (seed == 0) s = 0x9e3779b97f4a7c15ULL;
+    else {
+        uint64_t z = seed + 0x9e3779b97f4a7c15ULL;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+        s = z ^ (z >> 31);
+        if (s == 0) s = 0x9e3779b97f4a7c15ULL;
+    }
+    c->rng_state = s;
+    return RMHIP_OK;
+}
+
+int rmhip_random_uniform(rmhip_ctx* ctx, const size_t* shape, size_t rank, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    Buffer ob;
+    RMHIP_TRY(c->new_buffer(shape, rank, out, &ob));
+    int rc = launch_rng_uniform(c, c->rng_state, ob.data(), ob.numel);
+    if (rc) {
+        rmhip_free(ctx, *out);
+        return rc;
+    }
+    c->rng_state = lcg_advance(c->rng_state, ob.numel);
+    return RMHIP_OK;
+}
+
+int rmhip_random_normal(rmhip_ctx* ctx, const size_t* shape, size_t rank, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    Buffer ob;
+    RMHIP_TRY(c->new_buffer(shape, rank, out, &ob));
+    int rc = launch_rng_normal(c, c->rng_state, ob.data(), ob.numel);
+    if (rc) {
+        rmhip_free(ctx, *out);
+        return rc;
+    }
+    c->rng_state = lcg_advance(c->rng_state, 2 * ((ob.numel + 1) / 2));  // whole pairs are consumed
+    return RMHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+// rng.hip -- `random_uniform` / `random_normal` on the CPU-parity stream
+// (crates/runmat-accelerate-api/src/lib.rs:1713-1728, 1772).
+//
+// The reference CPU generator (crates/runmat-runtime/src/builtins/common/random.rs) is a serial
+// 64-bit LCG  s <- s*6364136223846793005 + 1 (:7-13, :271-278), uniform = (s >> 11) * 2^-53, and
+// Box-Muller on consecutive pairs (u1, u2) -> (r cos t, r sin t) emitted consecutively
+// (:279-288, :530-543).  An LCG admits O(log n) skip-ahead (the reference's own advance_state,
+// :238-256), so the SAME stream is generated in parallel here: thread g starts at step 2g
+// (pairs) or g (uniforms) via skip-ahead and then jumps by the grid stride with a precomputed
+// (multiplier, increment) pair.  The integer stream is bit-exact with the CPU; only the libm
+// calls (log, sqrt, cos, sin) differ by rounding.  The reference's wgpu path uses a different
+// generator (Philox, backend/wgpu/shaders/creation.rs:707-794) and therefore a different stream
+// from its own CPU path; parity here is with the CPU.
+#include "common.h"
+
+namespace rmhip {
+
+static constexpr unsigned long long kMult = 6364136223846793005ULL;
+static constexpr unsigned long long kInc = 1ULL;
+
+// (mult, plus) such that advancing `delta` steps is s -> mult*s + plus   (random.rs:238-256)
+__host__ __device__ static inline void lcg_jump(unsigned long long delta, unsigned long long* mult,
+                                               unsigned long long* plus) {
+    unsigned long long cur_mult = kMult, cur_plus = kInc, acc_mult = 1ULL, acc_plus = 0ULL;
+    while (delta > 0) {
+        if (delta & 1ULL) {
+            acc_mult = acc_mult * cur_mult;
+            acc_plus = acc_plus * cur_mult + cur_plus;
+        }
+        cur_plus = cur_plus * (cur_mult + 1ULL);
+        cur_mult = cur_mult * cur_mult;
+        delta >>= 1;
+    }
+    *mult = acc_mult;
+    *plus = acc_plus;
+}
+
+uint64_t lcg_advance(uint64_t state, uint64_t delta) {
+    unsigned long long m, p;
+    lcg_jump(delta, &m, &p);
+    return m * state + p;
+}
+
+__device__ __forceinline__ double lcg_next_uniform(unsigned long long& s) {
+    s = s * kMult + kInc;
+    return (double)(s >> 11) * (1.0 / 9007199254740992.0);
+}
+
+__global__ void __launch_bounds__(256) k_rng_uniform(unsigned long long state, double* __restrict__ out, size_t n,
+                                                     unsigned long long jm, unsigned long long jp) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    if (g >= n) return;
+    unsigned long long m, p;
+    lcg_jump(g, &m, &p);
+    unsigned long long s = m * state + p;  // state before element g
+    for (size_t i = g; i < n; i += stride) {
+        unsigned long long t = s;
+        out[i] = lcg_next_uniform(t);
+        s = jm * s + jp;  // jump `stride` steps
+    }
+}
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+__global__ void __launch_bounds__(256) k_rng_normal(unsigned long long state, double* __restrict__ out, size_t n,
+                                                    unsigned long long jm, unsigned long long jp) {
+    const size_t npairs = (n + 1) / 2;
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    if (g >= npairs) return;
+    unsigned long long m, p;
+    lcg_jump(2 * g, &m, &p);
+    unsigned long long s = m * state + p;  // state before pair g
+    const bool aligned = (((uintptr_t)out) & 15) == 0;
+    for (size_t i = g; i < npairs; i += stride) {
+        unsigned long long t = s;
+        double u1 = lcg_next_uniform(t);
+        if (u1 <= 0.0) u1 = 2.2250738585072014e-308;  // f64::MIN_POSITIVE (random.rs:13,281-283)
+        const double u2 = lcg_next_uniform(t);
+        const double radius = sqrt(-2.0 * log(u1));
+        const double angle = 2.0 * 3.14159265358979323846 * u2;
+        double sn, cs;
+        sincos(angle, &sn, &cs);
+        const double z0 = radius * cs, z1 = radius * sn;
+        if (2 * i + 1 < n) {
+            if (aligned) *(v2d*)(out + 2 * i) = v2d{z0, z1};
+            else {
+                out[2 * i] = z0;
+                out[2 * i + 1] = z1;
+            }
+        } else {
+            out[2 * i] = z0;  // odd length: z1 of the last pair is dropped (random.rs:536-540)
+        }
+        s = jm * s + jp;  // jump 2*stride steps
+    }
+}
+
+static unsigned rng_grid(const Context* c, size_t work) {
+    size_t want = (work + 255) / 256;
+    const size_t cap = (size_t)c->num_cus * 8;
+    if (want < 1) want = 1;
+    return (unsigned)(want < cap ? want : cap);
+}
+
+int launch_rng_uniform(Context* c, uint64_t state, double* out, size_t n) {
+    if (n == 0) return RMHIP_OK;
+    const unsigned grid = rng_grid(c, n);
+    unsigned long long jm, jp;
+    lcg_jump((unsigned long long)grid * 256ULL, &jm, &jp);
+    hipLaunchKernelGGL(k_rng_uniform, dim3(grid), dim3(256), 0, c->stream, (unsigned long long)state, out, n, jm, jp);
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+
+int launch_rng_normal(Context* c, uint64_t state, double* out, size_t n) {
+    if (n == 0) return RMHIP_OK;
+    const unsigned grid = rng_grid(c, (n + 1) / 2);
+    unsigned long long jm, jp;
+    lcg_jump(2ULL * grid * 256ULL, &jm, &jp);
+    hipLaunchKernelGGL(k_rng_normal, dim3(grid), dim3(256), 0, c->stream, (unsigned long long)state, out, n, jm, jp);
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+
+}  // namespace rmhip

@@ -1,0 +1,207 @@
+// skel_reduce.h -- reduction kernel skeletons, templated on a value functor F (index -> f64).
+// Used twice: instantiated ahead of time with an identity functor (reduce_kernels.hip:
+// reduce_sum / reduce_sum_dim / reduce_mean / min / max / prod, reference semantics
+// crates/runmat-accelerate/src/simple_provider.rs:6728-6806) and embedded as text into the
+// hipRTC source of every fused reduction (the functor is then the folded producer expression of
+// crates/runmat-accelerate/src/fusion.rs:1765-2077).
+//
+// Data view: the tensor is [pre, red, post] column-major and the middle extent is reduced;
+// element (i, r, j) lives at i + pre*(r + red*j); output slice id = i + pre*j.
+//
+// Determinism: no atomics anywhere. Every partial is produced by a fixed thread in a fixed
+// order and combined in a fixed order, so results are run-to-run reproducible. NaNs are counted,
+// not propagated through the sum, so include/omit policies are applied once in finalize
+// (CPU: crates/runmat-runtime/src/builtins/math/reduction/sum.rs:1031-1076).
+// Requires skel_common.h first. No `#include` here (hipRTC inline text).
+#ifndef RMHIP_SKEL_REDUCE
+#define RMHIP_SKEL_REDUCE
+
+#define RM_RSUM 0
+#define RM_RMEAN 1
+#define RM_RMIN 2
+#define RM_RMAX 3
+#define RM_RPROD 4
+#define RM_RBLOCK 256
+
+struct RmAcc {
+    double v;
+    double nan;  // number of NaN inputs seen (exact in f64 up to 2^53)
+};
+
+template <int OP>
+__device__ __forceinline__ RmAcc rm_acc_init() {
+    RmAcc a;
+    a.nan = 0.0;
+    a.v = (OP == RM_RMIN) ? __builtin_inf() : (OP == RM_RMAX) ? -__builtin_inf() : (OP == RM_RPROD) ? 1.0 : 0.0;
+    return a;
+}
+template <int OP>
+__device__ __forceinline__ double rm_combine(double a, double b) {
+    if (OP == RM_RMIN) return b < a ? b : a;
+    if (OP == RM_RMAX) return b > a ? b : a;
+    if (OP == RM_RPROD) return a * b;
+    return a + b;
+}
+template <int OP>
+__device__ __forceinline__ void rm_acc_add(RmAcc& a, double x) {
+    if (x != x) a.nan += 1.0;
+    else a.v = rm_combine<OP>(a.v, x);
+}
+template <int OP>
+__device__ __forceinline__ void rm_acc_merge(RmAcc& a, const RmAcc& b) {
+    a.v = rm_combine<OP>(a.v, b.v);
+    a.nan += b.nan;
+}
+
+// Fixed-order reduction across the 256 threads of a block: wave64 shuffle tree, then wave 0
+// folds the four wave results in wave order. Result valid in thread 0.
+template <int OP>
+__device__ __forceinline__ RmAcc rm_block_reduce(RmAcc a, RmAcc* lds /* >= 4 entries */) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        RmAcc o;
+        o.v = __shfl_down(a.v, off, 64);
+        o.nan = __shfl_down(a.nan, off, 64);
+        rm_acc_merge<OP>(a, o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds[wave] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < RM_RBLOCK / 64; ++w) rm_acc_merge<OP>(a, lds[w]);
+    }
+    return a;
+}
+
+// Kernel A: pre == 1 (each slice is `red` contiguous elements). grid = (nsplit, post).
+template <int OP, class F>
+__device__ __forceinline__ void rm_reduce_contig(const F& f, rm_u64 red, rm_u64 nslices, rm_u64 nsplit,
+                                                 double* part_v, double* part_nan) {
+    __shared__ RmAcc lds[RM_RBLOCK / 64];
+    const rm_u64 slice = blockIdx.y + (rm_u64)gridDim.y * blockIdx.z;
+    if (slice >= nslices) return;  // padding blocks of the (y, z) slice grid; uniform per block
+    const rm_u64 split = blockIdx.x;
+    rm_u64 chunk = (red + nsplit - 1) / nsplit;
+    chunk = (chunk + RM_RBLOCK - 1) / RM_RBLOCK * RM_RBLOCK;  // block-aligned chunks
+    const rm_u64 begin = split * chunk;
+    rm_u64 end = begin + chunk;
+    if (end > red) end = red;
+    const rm_u64 base = slice * red;
+    RmAcc a0 = rm_acc_init<OP>(), a1 = rm_acc_init<OP>(), a2 = rm_acc_init<OP>(), a3 = rm_acc_init<OP>();
+    rm_u64 r = begin + threadIdx.x;
+    for (; r + 3 * RM_RBLOCK < end; r += 4 * RM_RBLOCK) {
+        const double x0 = f(base + r), x1 = f(base + r + RM_RBLOCK), x2 = f(base + r + 2 * RM_RBLOCK),
+                     x3 = f(base + r + 3 * RM_RBLOCK);
+        rm_acc_add<OP>(a0, x0);
+        rm_acc_add<OP>(a1, x1);
+        rm_acc_add<OP>(a2, x2);
+        rm_acc_add<OP>(a3, x3);
+    }
+    for (; r < end; r += RM_RBLOCK) rm_acc_add<OP>(a0, f(base + r));
+    rm_acc_merge<OP>(a0, a1);
+    rm_acc_merge<OP>(a2, a3);
+    rm_acc_merge<OP>(a0, a2);
+    a0 = rm_block_reduce<OP>(a0, lds);
+    if (threadIdx.x == 0) {
+        part_v[slice * nsplit + split] = a0.v;
+        part_nan[slice * nsplit + split] = a0.nan;
+    }
+}
+
+// Kernel B: pre > 1. Threads run along `pre` (coalesced); each thread walks its slice's `red`
+// extent in ascending order, so with nsplit == 1 and tx == RM_RBLOCK the per-output summation
+// order equals the CPU's. grid = (ceil(pre/tx), nsplit, post); tx is a power of two <= 256.
+template <int OP, class F>
+__device__ __forceinline__ void rm_reduce_strided(const F& f, rm_u64 pre, rm_u64 red, rm_u64 nsplit, int tx,
+                                                  double* part_v, double* part_nan) {
+    __shared__ RmAcc lds[RM_RBLOCK];
+    const int lx = threadIdx.x & (tx - 1);
+    const int ly = threadIdx.x / tx;
+    const int ty = RM_RBLOCK / tx;
+    const rm_u64 i = (rm_u64)blockIdx.x * tx + lx;
+    const rm_u64 split = blockIdx.y;
+    const rm_u64 j = blockIdx.z;
+    rm_u64 chunk = (red + nsplit - 1) / nsplit;
+    const rm_u64 begin = split * chunk;
+    rm_u64 end = begin + chunk;
+    if (end > red) end = red;
+    RmAcc a0 = rm_acc_init<OP>(), a1 = rm_acc_init<OP>();
+    if (i < pre) {
+        const rm_u64 base = i + pre * red * j;
+        rm_u64 r = begin + ly;
+        if (ty == 1) {  // sequential order; loads issued in groups of four, adds stay in order
+            for (; r + 3 < end; r += 4) {
+                const double x0 = f(base + pre * r), x1 = f(base + pre * (r + 1)), x2 = f(base + pre * (r + 2)),
+                             x3 = f(base + pre * (r + 3));
+                rm_acc_add<OP>(a0, x0);
+                rm_acc_add<OP>(a0, x1);
+                rm_acc_add<OP>(a0, x2);
+                rm_acc_add<OP>(a0, x3);
+            }
+            for (; r < end; ++r) rm_acc_add<OP>(a0, f(base + pre * r));
+        } else {
+            for (; r + ty < end; r += 2 * ty) {
+                const double x0 = f(base + pre * r), x1 = f(base + pre * (r + ty));
+                rm_acc_add<OP>(a0, x0);
+                rm_acc_add<OP>(a1, x1);
+            }
+            for (; r < end; r += ty) rm_acc_add<OP>(a0, f(base + pre * r));
+            rm_acc_merge<OP>(a0, a1);
+        }
+    }
+    if (ty > 1) {
+        lds[threadIdx.x] = a0;
+        __syncthreads();
+        if (ly == 0) {
+            for (int y = 1; y < ty; ++y) rm_acc_merge<OP>(a0, lds[y * tx + lx]);
+        }
+    }
+    if (ly == 0 && i < pre) {
+        const rm_u64 slice = i + pre * j;
+        part_v[slice * nsplit + split] = a0.v;
+        part_nan[slice * nsplit + split] = a0.nan;
+    }
+}
+
+// Finalize: one wave per slice folds its nsplit partials (lane-strided, then a shuffle tree) and
+// applies NaN policy + scaling.  mode: RM_RSUM => * scale (scale == 1 for plain sums);
+// RM_RMEAN => / count (CPU mean divides: mean.rs:1134-1151).
+template <int OP>
+__device__ __forceinline__ void rm_reduce_finalize(const double* part_v, const double* part_nan, rm_u64 nslices,
+                                                   rm_u64 nsplit, rm_u64 red, int mean, int omitnan, double scale,
+                                                   double* out) {
+    const rm_u64 slice = (rm_u64)blockIdx.x * (RM_RBLOCK / 64) + (threadIdx.x >> 6);
+    if (slice >= nslices) return;
+    const int lane = threadIdx.x & 63;
+    RmAcc a = rm_acc_init<OP>();
+    for (rm_u64 s = lane; s < nsplit; s += 64) {
+        RmAcc p;
+        p.v = part_v[slice * nsplit + s];
+        p.nan = part_nan[slice * nsplit + s];
+        rm_acc_merge<OP>(a, p);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        RmAcc o;
+        o.v = __shfl_down(a.v, off, 64);
+        o.nan = __shfl_down(a.nan, off, 64);
+        rm_acc_merge<OP>(a, o);
+    }
+    if (lane == 0) {
+        double r = a.v;
+        const double cnt = (double)red - a.nan;
+        if (OP == RM_RMIN || OP == RM_RMAX) {
+            if ((!omitnan && a.nan > 0.0) || cnt <= 0.0) r = rm_nan();
+        } else if (mean) {
+            if (omitnan) r = cnt > 0.0 ? r / cnt : rm_nan();
+            else r = a.nan > 0.0 ? rm_nan() : r / (double)red;
+        } else {
+            if (!omitnan && a.nan > 0.0) r = rm_nan();
+            else r = r * scale;
+        }
+        out[slice] = r;
+    }
+}
+
+#endif  // RMHIP_SKEL_REDUCE

@@ -1,0 +1,384 @@
+"""HipProvider -- host-side mirror of the reference's `trait AccelProvider`
+(crates/runmat-accelerate-api/src/lib.rs:1386-3151) for the dense-array hot path, calling the C ABI
+of librmhip.so (include/rmhip.h) through ctypes.
+
+Method names, argument meaning and error behaviour follow the trait so the parity tests read like
+the reference's own provider tests (crates/runmat-runtime-integration-tests/tests/gpu.rs,
+crates/runmat-accelerate/tests/*.rs): every op returns a NEW handle, inputs are never mutated,
+unsupported requests raise ProviderError (the reference's callers treat a provider Err as "fall
+back to the CPU builtin", mtimes.rs:212-216) -- and there is no CPU fallback in here.
+
+The Rust binding a RunMat maintainer would add is the same sequence of calls
+(shim/hip_provider.rs).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+# op codes of include/rmhip.h
+BINARY_OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3, "pow": 4, "max": 5, "min": 6, "hypot": 7, "atan2": 8,
+              "mod": 9, "rem": 10}
+UNARY_OPS = {n: i for i, n in enumerate((
+    "sin", "cos", "tan", "asin", "acos", "atan", "sinh", "cosh", "tanh", "asinh", "acosh", "atanh", "exp", "expm1",
+    "log", "log2", "log10", "log1p", "sqrt", "abs", "sign", "floor", "ceil", "round", "fix", "neg", "exp2",
+    "heaviside", "isnan", "isinf", "isfinite", "uplus"))}
+SCALAR_OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3, "rsub": 4, "rdiv": 5, "max": 6, "min": 7}
+REDUCE_OPS = {"sum": 0, "mean": 1, "min": 2, "max": 3, "prod": 4}
+
+
+class ProviderError(RuntimeError):
+    """`anyhow::Error` of a provider call. `.code` is the RMHIP_ERR_* status."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+@dataclass(frozen=True)
+class GpuTensorHandle:
+    """lib.rs:260-264 -- plain data; the provider owns the buffer until `free`."""
+    shape: Tuple[int, ...]
+    device_id: int
+    buffer_id: int
+
+
+@dataclass(frozen=True)
+class ReductionFlavor:
+    """lib.rs:865-890"""
+    kind: str  # "sum" | "mean" | "custom"
+    scale: float = 1.0
+
+    @staticmethod
+    def Sum() -> "ReductionFlavor":
+        return ReductionFlavor("sum")
+
+    @staticmethod
+    def Mean() -> "ReductionFlavor":
+        return ReductionFlavor("mean")
+
+    @staticmethod
+    def CustomScale(s: float) -> "ReductionFlavor":
+        return ReductionFlavor("custom", float(s))
+
+
+@dataclass
+class ProviderLuResult:
+    """lib.rs:649-698"""
+    combined: GpuTensorHandle
+    lower: GpuTensorHandle
+    upper: GpuTensorHandle
+    perm_matrix: GpuTensorHandle
+    perm_vector: GpuTensorHandle
+
+
+def _shape_array(shape: Sequence[int]):
+    arr = (C.c_size_t * max(len(shape), 1))(*[int(s) for s in shape])
+    return arr, len(shape)
+
+
+class HipProvider:
+    """One provider per GPU (one process per GPU in multi-GPU jobs)."""
+
+    _next_device_id = 1  # next_device_id(), lib.rs:3279
+
+    def __init__(self, device_ordinal: int = 0):
+        self._lib = _lib.load()
+        ctx = C.c_void_p()
+        rc = self._lib.rmhip_init(int(device_ordinal), C.byref(ctx))
+        if rc != _lib.OK:
+            raise ProviderError(rc, _lib.last_error())
+        self._ctx = ctx
+        self._device_id = HipProvider._next_device_id
+        HipProvider._next_device_id += 1
+        self.device_ordinal = device_ordinal
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _check(self, rc: int) -> None:
+        if rc != _lib.OK:
+            raise ProviderError(rc, _lib.last_error())
+
+    def _handle(self, buffer_id: int, shape: Optional[Sequence[int]] = None) -> GpuTensorHandle:
+        if shape is None:
+            rank = C.c_size_t(16)
+            buf = (C.c_size_t * 16)()
+            self._check(self._lib.rmhip_shape(self._ctx, buffer_id, C.byref(rank), buf))
+            shape = tuple(int(buf[i]) for i in range(rank.value))
+        return GpuTensorHandle(tuple(int(s) for s in shape), self._device_id, int(buffer_id))
+
+    def _id(self, h: GpuTensorHandle) -> int:
+        if h.device_id != self._device_id:  # io.rs:269-275: foreign handles are an error
+            raise ProviderError(_lib.ERR_INVALID, f"handle belongs to device {h.device_id}, not {self._device_id}")
+        return h.buffer_id
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None):
+            self._lib.rmhip_shutdown(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def synchronize(self) -> None:
+        self._check(self._lib.rmhip_synchronize(self._ctx))
+
+    # -- identity -------------------------------------------------------------------------------
+    def device_id(self) -> int:
+        return self._device_id
+
+    def precision(self) -> str:
+        return "F64"  # ProviderPrecision::F64 (lib.rs:815-818); host F64 tensors are accepted as-is
+
+    def device_info_struct(self) -> dict:
+        info = _lib.DeviceInfo()
+        self._check(self._lib.rmhip_device_info(self._ctx, C.byref(info)))
+        return {f: (getattr(info, f).decode() if isinstance(getattr(info, f), bytes) else getattr(info, f))
+                for f, _ in info._fields_}
+
+    def default_reduction_workgroup_size(self) -> int:
+        return 256
+
+    def two_pass_threshold(self) -> int:
+        return 262144
+
+    # -- memory ---------------------------------------------------------------------------------
+    def upload(self, data, shape: Optional[Sequence[int]] = None) -> GpuTensorHandle:
+        """`upload(&HostTensorView{data,shape})`: column-major f64 (lib.rs:3362-3372)."""
+        arr = np.asarray(data, dtype=np.float64)
+        if shape is None:
+            shape = arr.shape if arr.ndim >= 2 else (arr.size, 1) if arr.ndim == 1 else (1, 1)
+            flat = np.ascontiguousarray(arr.reshape(-1, order="F"))
+        else:
+            flat = np.ascontiguousarray(arr.reshape(-1))
+        if flat.size != int(np.prod(shape, dtype=np.int64)):
+            raise ProviderError(_lib.ERR_SHAPE, "upload: data length does not match shape")
+        sh, rank = _shape_array(shape)
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_upload(self._ctx, flat.ctypes.data_as(C.POINTER(C.c_double)), sh, rank, C.byref(out)))
+        return self._handle(out.value, shape)
+
+    def download(self, h: GpuTensorHandle) -> np.ndarray:
+        """Returns the column-major flat data (`HostTensorOwned.data`)."""
+        n = int(np.prod(h.shape, dtype=np.int64)) if len(h.shape) else 1
+        out = np.empty(n, dtype=np.float64)
+        self._check(self._lib.rmhip_download(self._ctx, self._id(h), out.ctypes.data_as(C.POINTER(C.c_double)), n))
+        return out
+
+    def download_matrix(self, h: GpuTensorHandle) -> np.ndarray:
+        """Convenience: data reshaped (Fortran order) to the handle's shape."""
+        return self.download(h).reshape(h.shape, order="F")
+
+    def free(self, h: GpuTensorHandle) -> None:
+        self._check(self._lib.rmhip_free(self._ctx, self._id(h)))
+
+    def fill(self, shape: Sequence[int], value: float) -> GpuTensorHandle:
+        sh, rank = _shape_array(shape)
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_fill(self._ctx, float(value), sh, rank, C.byref(out)))
+        return self._handle(out.value, shape)
+
+    def zeros(self, shape: Sequence[int]) -> GpuTensorHandle:
+        return self.fill(shape, 0.0)
+
+    def ones(self, shape: Sequence[int]) -> GpuTensorHandle:
+        return self.fill(shape, 1.0)
+
+    def fill_uniform(self, seed: int, lo: float, hi: float, shape: Sequence[int]) -> GpuTensorHandle:
+        sh, rank = _shape_array(shape)
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_fill_uniform(self._ctx, int(seed), float(lo), float(hi), sh, rank, C.byref(out)))
+        return self._handle(out.value, shape)
+
+    def reshape(self, h: GpuTensorHandle, shape: Sequence[int]) -> GpuTensorHandle:
+        sh, rank = _shape_array(shape)
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_reshape(self._ctx, self._id(h), sh, rank, C.byref(out)))
+        return self._handle(out.value, shape)
+
+    def wrap_external(self, device_ptr: int, shape: Sequence[int]) -> GpuTensorHandle:
+        sh, rank = _shape_array(shape)
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_wrap_external(self._ctx, C.c_void_p(device_ptr), sh, rank, C.byref(out)))
+        return self._handle(out.value, shape)
+
+    def device_ptr(self, h: GpuTensorHandle) -> int:
+        p = self._lib.rmhip_device_ptr(self._ctx, self._id(h))
+        return int(p or 0)
+
+    def set_stream(self, stream_ptr: int) -> None:
+        self._check(self._lib.rmhip_set_stream(self._ctx, C.c_void_p(stream_ptr)))
+
+    # -- fused kernels --------------------------------------------------------------------------
+    def fused_elementwise(self, shader: str, inputs: Sequence[GpuTensorHandle], output_shape: Sequence[int],
+                          length: int) -> GpuTensorHandle:
+        return self.fused_elementwise_multi(shader, inputs, output_shape, length, 1)[0]
+
+    def fused_elementwise_multi(self, shader: str, inputs: Sequence[GpuTensorHandle], output_shape: Sequence[int],
+                                length: int, num_outputs: int) -> List[GpuTensorHandle]:
+        ids = (C.c_uint64 * max(len(inputs), 1))(*[self._id(h) for h in inputs])
+        sh, rank = _shape_array(output_shape)
+        outs = (C.c_uint64 * max(num_outputs, 1))()
+        self._check(self._lib.rmhip_fused_elementwise(self._ctx, shader.encode(), ids, len(inputs), sh, rank,
+                                                      int(length), int(num_outputs), outs))
+        return [self._handle(outs[k], output_shape) for k in range(num_outputs)]
+
+    def fused_reduction(self, shader: str, inputs: Sequence[GpuTensorHandle], output_shape: Sequence[int],
+                        reduce_len: int, num_slices: int, workgroup_size: int,
+                        flavor: ReductionFlavor) -> GpuTensorHandle:
+        ids = (C.c_uint64 * max(len(inputs), 1))(*[self._id(h) for h in inputs])
+        sh, rank = _shape_array(output_shape)
+        out = C.c_uint64()
+        code = {"sum": 0, "mean": 1, "custom": 2}[flavor.kind]
+        self._check(self._lib.rmhip_fused_reduction(self._ctx, shader.encode(), ids, len(inputs), sh, rank,
+                                                    int(reduce_len), int(num_slices), int(workgroup_size), code,
+                                                    float(flavor.scale), C.byref(out)))
+        return self._handle(out.value, output_shape)
+
+    # -- per-op kernels -------------------------------------------------------------------------
+    def _binary(self, op: str, a: GpuTensorHandle, b: GpuTensorHandle) -> GpuTensorHandle:
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_binary(self._ctx, BINARY_OPS[op], self._id(a), self._id(b), C.byref(out)))
+        return self._handle(out.value)
+
+    def _unary(self, op: str, a: GpuTensorHandle) -> GpuTensorHandle:
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_unary(self._ctx, UNARY_OPS[op], self._id(a), C.byref(out)))
+        return self._handle(out.value, a.shape)
+
+    def _scalar(self, op: str, a: GpuTensorHandle, s: float) -> GpuTensorHandle:
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_scalar(self._ctx, SCALAR_OPS[op], self._id(a), float(s), C.byref(out)))
+        return self._handle(out.value, a.shape)
+
+    def elem_add(self, a, b): return self._binary("add", a, b)
+    def elem_sub(self, a, b): return self._binary("sub", a, b)
+    def elem_mul(self, a, b): return self._binary("mul", a, b)
+    def elem_div(self, a, b): return self._binary("div", a, b)
+    def elem_pow(self, a, b): return self._binary("pow", a, b)
+    def elem_max(self, a, b): return self._binary("max", a, b)
+    def elem_min(self, a, b): return self._binary("min", a, b)
+    def elem_hypot(self, a, b): return self._binary("hypot", a, b)
+    def elem_atan2(self, a, b): return self._binary("atan2", a, b)
+
+    def scalar_add(self, a, s): return self._scalar("add", a, s)
+    def scalar_sub(self, a, s): return self._scalar("sub", a, s)
+    def scalar_mul(self, a, s): return self._scalar("mul", a, s)
+    def scalar_div(self, a, s): return self._scalar("div", a, s)
+    def scalar_rsub(self, a, s): return self._scalar("rsub", a, s)
+    def scalar_rdiv(self, a, s): return self._scalar("rdiv", a, s)
+    def scalar_max(self, a, s): return self._scalar("max", a, s)
+    def scalar_min(self, a, s): return self._scalar("min", a, s)
+
+    def __getattr__(self, name: str):
+        # unary_sin, unary_cos, ... (lib.rs:2077-2331)
+        if name.startswith("unary_") and name[6:] in UNARY_OPS:
+            op = name[6:]
+            return lambda a: self._unary(op, a)
+        raise AttributeError(name)
+
+    # -- reductions -----------------------------------------------------------------------------
+    def _reduce(self, op: str, a: GpuTensorHandle, dim: int, omitnan: bool = False) -> GpuTensorHandle:
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_reduce(self._ctx, REDUCE_OPS[op], self._id(a), int(dim), 1 if omitnan else 0,
+                                           C.byref(out)))
+        return self._handle(out.value)
+
+    def reduce_sum(self, a): return self._reduce("sum", a, -1)
+    def reduce_sum_dim(self, a, dim): return self._reduce("sum", a, dim)
+    def reduce_mean(self, a): return self._reduce("mean", a, -1)
+    def reduce_mean_dim(self, a, dim): return self._reduce("mean", a, dim)
+    def reduce_min(self, a): return self._reduce("min", a, -1)
+    def reduce_max(self, a): return self._reduce("max", a, -1)
+    def reduce_min_dim(self, a, dim): return self._reduce("min", a, dim)
+    def reduce_max_dim(self, a, dim): return self._reduce("max", a, dim)
+    def reduce_prod(self, a): return self._reduce("prod", a, -1)
+    def reduce_prod_dim(self, a, dim): return self._reduce("prod", a, dim)
+
+    # -- linear algebra -------------------------------------------------------------------------
+    def matmul(self, a: GpuTensorHandle, b: GpuTensorHandle) -> GpuTensorHandle:
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_matmul(self._ctx, self._id(a), self._id(b), C.byref(out)))
+        return self._handle(out.value, (a.shape[0], b.shape[1]))
+
+    def lu(self, a: GpuTensorHandle) -> ProviderLuResult:
+        outs = (C.c_uint64 * 5)()
+        self._check(self._lib.rmhip_lu(self._ctx, self._id(a), outs))
+        hs = [self._handle(outs[i]) for i in range(5)]
+        return ProviderLuResult(*hs)
+
+    def mldivide(self, lhs: GpuTensorHandle, rhs: GpuTensorHandle) -> GpuTensorHandle:
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_mldivide(self._ctx, self._id(lhs), self._id(rhs), C.byref(out)))
+        return self._handle(out.value)
+
+    # -- RNG ------------------------------------------------------------------------------------
+    def set_rng_state(self, state: int) -> None:
+        self._check(self._lib.rmhip_set_rng_state(self._ctx, int(state) & 0xFFFFFFFFFFFFFFFF))
+
+    def get_rng_state(self) -> int:
+        s = C.c_uint64()
+        self._check(self._lib.rmhip_get_rng_state(self._ctx, C.byref(s)))
+        return int(s.value)
+
+    def rng_seed(self, seed: int) -> None:
+        self._check(self._lib.rmhip_rng_seed(self._ctx, int(seed)))
+
+    def random_uniform(self, shape: Sequence[int]) -> GpuTensorHandle:
+        sh, rank = _shape_array(shape)
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_random_uniform(self._ctx, sh, rank, C.byref(out)))
+        return self._handle(out.value, shape)
+
+    def random_normal(self, shape: Sequence[int]) -> GpuTensorHandle:
+        sh, rank = _shape_array(shape)
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_random_normal(self._ctx, sh, rank, C.byref(out)))
+        return self._handle(out.value, shape)
+
+    # -- telemetry / timing ---------------------------------------------------------------------
+    def telemetry_snapshot(self) -> dict:
+        t = _lib.Telemetry()
+        self._check(self._lib.rmhip_telemetry(self._ctx, C.byref(t)))
+        return {f: int(getattr(t, f)) for f, _ in t._fields_}
+
+    def reset_telemetry(self) -> None:
+        self._check(self._lib.rmhip_reset_telemetry(self._ctx))
+
+    def timer_begin(self) -> None:
+        self._check(self._lib.rmhip_timer_begin(self._ctx))
+
+    def timer_end(self) -> float:
+        ms = C.c_double()
+        self._check(self._lib.rmhip_timer_end(self._ctx, C.byref(ms)))
+        return float(ms.value)
+
+
+def wgsl_translate(shader: str, kind: str = "elementwise") -> str:
+    """Front-end only (no GPU): the HIP source librmhip would compile for `shader`."""
+    lib = _lib.load()
+    needed = C.c_size_t()
+    k = 0 if kind == "elementwise" else 1
+    rc = lib.rmhip_wgsl_translate(shader.encode(), k, None, 0, C.byref(needed))
+    if rc != _lib.OK:
+        raise ProviderError(rc, _lib.last_error())
+    buf = C.create_string_buffer(needed.value)
+    rc = lib.rmhip_wgsl_translate(shader.encode(), k, buf, needed.value, C.byref(needed))
+    if rc != _lib.OK:
+        raise ProviderError(rc, _lib.last_error())
+    return buf.value.decode()
+
+
+def wgsl_compile_check(shader: str, kind: str = "elementwise") -> None:
+    """Front-end + hipRTC compile for gfx950 (no GPU needed). Raises ProviderError on failure."""
+    lib = _lib.load()
+    rc = lib.rmhip_wgsl_compile_check(shader.encode(), 0 if kind == "elementwise" else 1)
+    if rc != _lib.OK:
+        raise ProviderError(rc, _lib.last_error())
