@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X accelerate backend (contract: see task brief).
+
+    python bench.py --gpus N --steps K --warmup W [--workload fused|dgemm]
+
+A "step" is one pass of the hot path over one batch of synthetic input, through the C ABI:
+  fused (default, BASELINE.json configs[1]): D = sin(A).*B + C on 8192x8192 f64 per GPU, i.e. one
+      `rmhip_fused_elementwise` call with the WGSL text the reference planner emits, inputs resident
+      in HBM, a NEW output buffer per call (freed to the pool afterwards), exactly what
+      `AccelProvider::fused_elementwise` does per fused span.  Algorithmic bytes per step per GPU
+      = 4 arrays x 8 B x 67 108 864 = 2 147 483 648.  Weak scaling: every rank owns
+      independent matrices, no data-path collective.
+  dgemm (BASELINE.json configs[2]): C = A*B 8192^3 f64 on the fp64 MFMA kernel; with N > 1 the
+      matrix is row-block sharded (rank g computes C[rows_g,:] = A[rows_g,:]*B, B replicated, no
+      collective in the timed region) -- strong scaling.
+The JSON line carries `roofline` (dominant kernel, HIP-event timed on the library's stream) and,
+on rank 0 at N=1, `cpu_baseline` (the oracle = C port of the reference CPU path, 1 thread, on a
+bounded sample). The secondary workload is reported under "also" at N=1.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+
+N_DIM = 8192
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_MFMA_PEAK_TF = 78.6   # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (v_mfma_f64_16x16x4_f64, 64 cyc)
+
+
+def cpu_baseline_fused(budget_s: float = 12.0):
+    """Oracle (C port of the reference CPU path: 3 passes, 3 temporaries, libm sin) on one core."""
+    from oracle import oracle
+
+    rows, cols = N_DIM, 1024  # 1/8 of the workload
+    n = rows * cols
+    A = oracle.fill_uniform(1, -np.pi, np.pi, n)
+    B = oracle.fill_uniform(2, -1.0, 1.0, n)
+    Cc = oracle.fill_uniform(3, -1.0, 1.0, n)
+    reps, t_total = 0, 0.0
+    while t_total < budget_s and reps < 64:
+        t0 = time.perf_counter()
+        oracle.sin_mul_add(A, B, Cc)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    gbs = 32.0 * n * reps / t_total / 1e9
+    return {"value": round(gbs, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} x D=sin(A).*B+C on {rows}x{cols} f64 (1/8 of the workload), oracle/oracle.c "
+                      f"orc_sin_mul_add, {t_total:.1f} s"}
+
+
+def cpu_baseline_dgemm():
+    from oracle import oracle
+
+    n = 1024
+    A = oracle.fill_uniform(11, -1.0, 1.0, n * n).reshape(n, n, order="F")
+    B = oracle.fill_uniform(12, -1.0, 1.0, n * n).reshape(n, n, order="F")
+    t0 = time.perf_counter()
+    oracle.matmul(A, B)
+    dt = time.perf_counter() - t0
+    return {"value": round(2.0 * n ** 3 / dt / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+            "sample": f"naive column-major triple loop (linalg.rs:6-32) at {n}^3, {dt:.1f} s; the 8192^3 "
+                      "workload extrapolates ~n^3"}
+
+
+def pmc_traffic(kernel_key: str):
+    """HBM bytes per launch measured with rocprofv3 --pmc (committed under profiles/), or None."""
+    f = ROOT / "profiles" / "pmc_traffic.json"
+    if f.exists():
+        try:
+            return json.loads(f.read_text()).get(kernel_key)
+        except Exception:
+            return None
+    return None
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=["fused", "dgemm"], default="fused")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    from runmat_amd import HipProvider
+    from runmat_amd.fusion import sin_mul_add_plan
+
+    prov = HipProvider(local_rank)
+    n = N_DIM
+
+    def barrier():
+        prov.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def run_fused(steps, warmup):
+        plan, out_id = sin_mul_add_plan()
+        shader = plan.generate_wgsl_for_output(out_id, "f64")
+        base = 100 * rank  # independent matrices per rank
+        ha = prov.fill_uniform(1 + base, -np.pi, np.pi, (n, n))
+        hb = prov.fill_uniform(2 + base, -1.0, 1.0, (n, n))
+        hc = prov.fill_uniform(3 + base, -1.0, 1.0, (n, n))
+
+        def step():
+            prov.free(prov.fused_elementwise(shader, [ha, hb, hc], (n, n), n * n))
+
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        wall = time.perf_counter() - t0
+        # roofline leg: HIP events on the library's stream around the same launches
+        prov.timer_begin()
+        for _ in range(steps):
+            step()
+        kern_ms = prov.timer_end() / steps
+        for h in (ha, hb, hc):
+            prov.free(h)
+        return wall, kern_ms
+
+    def run_dgemm(steps, warmup):
+        rows = n // world  # row-block shard of A and C; B replicated
+        ha = prov.fill_uniform(11 + 1000 * rank, -1.0, 1.0, (rows, n))
+        hb = prov.fill_uniform(12, -1.0, 1.0, (n, n))
+
+        def step():
+            prov.free(prov.matmul(ha, hb))
+
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        wall = time.perf_counter() - t0
+        prov.timer_begin()
+        for _ in range(steps):
+            step()
+        kern_ms = prov.timer_end() / steps
+        prov.free(ha)
+        prov.free(hb)
+        return wall, kern_ms
+
+    def max_over_ranks(x: float) -> float:
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    fused_bytes = 4 * 8 * n * n          # per GPU per step
+    dgemm_flops = 2.0 * n ** 3           # whole job per step
+
+    def fused_record(steps, warmup):
+        wall, kern_ms = run_fused(steps, warmup)
+        wall = max_over_ranks(wall)
+        ms = wall / steps * 1e3
+        achieved = fused_bytes / (kern_ms * 1e-3) / 1e9
+        return {
+            "metric": "fused elementwise GB/s (D = sin(A).*B + C, 8192x8192 f64, per-GPU matrices)",
+            "value": round(world * fused_bytes / (ms * 1e-3) / 1e9, 2), "unit": "GB/s",
+            "ms_per_step": round(ms, 5), "scaling": "weak", "dtype": "f64",
+            "config": {"workload": "fused D=sin(A).*B+C 8192x8192 f64 via rmhip_fused_elementwise (WGSL request)",
+                       "bytes_per_step_per_gpu": fused_bytes, "parallelism": f"independent x{world}"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("rm_ew_fast"),
+                         "kernel": "rm_ew_fast (hipRTC, generated)", "kernel_ms": round(kern_ms, 5)},
+        }
+
+    def dgemm_record(steps, warmup):
+        wall, kern_ms = run_dgemm(steps, warmup)
+        wall = max_over_ranks(wall)
+        ms = wall / steps * 1e3
+        achieved = (dgemm_flops / world) / (kern_ms * 1e-3) / 1e12
+        return {
+            "metric": "fp64 GFLOP/s (8192^3 matmul, row-block sharded across GPUs)",
+            "value": round(dgemm_flops / (ms * 1e-3) / 1e9, 1), "unit": "GFLOP/s",
+            "ms_per_step": round(ms, 5), "scaling": "strong", "dtype": "f64",
+            "config": {"workload": "C=A*B dgemm 8192x8192x8192 f64 via rmhip_matmul", "flops_per_step": dgemm_flops,
+                       "parallelism": f"row-block x{world}, B replicated, no collective"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TF, 4),
+                         "traffic": pmc_traffic("k_dgemm"), "kernel": "k_dgemm<false> (v_mfma_f64_16x16x4_f64)",
+                         "kernel_ms": round(kern_ms, 5)},
+        }
+
+    primary = fused_record if args.workload == "fused" else dgemm_record
+    secondary = dgemm_record if args.workload == "fused" else fused_record
+    rec = primary(args.steps, args.warmup)
+    out = {
+        "metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": rec["scaling"],
+        "vs_baseline": None, "dtype": rec["dtype"], "data": "synthetic", "config": rec["config"],
+        "roofline": rec["roofline"],
+    }
+    if world == 1 and not args.no_also:
+        sec_steps = max(3, min(args.steps, 10)) if args.workload == "fused" else args.steps
+        sec = secondary(sec_steps, 2)
+        out["also"] = {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline")}
+    elif world > 1 and not args.no_also and args.workload == "fused":
+        sec = secondary(max(3, min(args.steps, 10)), 2)
+        out["also"] = {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "roofline")}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_fused() if args.workload == "fused" else cpu_baseline_dgemm()
+        if "also" in out:
+            out["also"]["cpu_baseline"] = cpu_baseline_dgemm() if args.workload == "fused" else cpu_baseline_fused(6.0)
+    info = prov.device_info_struct()
+    out["device"] = {"arch": info["arch"], "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"],
+                     "hbm_bytes": info["total_memory_bytes"]}
+    prov.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,191 @@
+"""CPU-side tests of the boundary: the C-ABI library loads and exports every symbol
+include/rmhip.h declares, the WGSL front-end accepts exactly the reference planner's text
+(crates/runmat-accelerate/src/fusion.rs:1525-2077, 2874-3026) and the generated HIP cross-compiles
+for gfx950 with hipRTC -- no GPU and no compute calls involved."""
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol(built):
+    from runmat_amd import _lib
+
+    header = (ROOT / "include" / "rmhip.h").read_text()
+    declared = set(re.findall(r"RMHIP_API\s+[\w\s\*]+?\b(rmhip_\w+)\s*\(", header))
+    assert len(declared) >= 35
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"librmhip.so does not export {name}"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert b"gfx950" in lib.rmhip_version()
+
+
+def test_init_fails_loudly_without_gpu(built):
+    """No CPU fallback: on a box without a gfx950 device construction raises (on a GPU box it works)."""
+    import torch
+
+    from runmat_amd import HipProvider, ProviderError
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ProviderError) as e:
+        HipProvider(0)
+    assert e.value.code in (9, 4)
+    assert "no CPU fallback" in str(e.value) or "HIP" in str(e.value)
+
+
+def test_product_package_never_touches_oracle():
+    for f in (ROOT / "runmat_amd").rglob("*"):
+        if f.suffix in (".py", ".cpp", ".h", ".hip") and f.is_file():
+            text = f.read_text()
+            assert "liboracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_rust_float_display():
+    from runmat_amd.fusion import rust_f64_display as d
+
+    assert d(2.0) == "2" and d(0.25) == "0.25" and d(-0.1) == "-0.1" and d(10.0) == "10"
+    assert d(1e21) == "1000000000000000000000" and d(1e-7) == "0.0000001"
+    assert d(float("inf")) == "inf" and d(float("nan")) == "NaN" and d(1.5e300).startswith("15")
+
+
+def test_sin_mul_add_shader_text_and_translation(built):
+    from runmat_amd import wgsl_translate
+    from runmat_amd.fusion import sin_mul_add_plan
+
+    plan, out = sin_mul_add_plan()
+    sh = plan.generate_wgsl_for_output(out, "f64")
+    # the exact body lines the reference emits (fusion.rs:1730,1754)
+    assert "    let tmp0: f64 = sin(input0.data[i0]);\n" in sh
+    assert "    let tmp1: f64 = (tmp0 * input1.data[i1]);\n" in sh
+    assert "    let tmp2: f64 = (tmp1 + input2.data[i2]);\n" in sh
+    assert "    output.data[g] = tmp2;\n" in sh
+    assert "@group(0) @binding(3) var<storage, read_write> output: Tensor;" in sh
+    assert "@group(0) @binding(4) var<uniform> params: Params;" in sh
+    src = wgsl_translate(sh)
+    assert "const double tmp0 = sin(x0);" in src
+    assert "const double tmp1 = (tmp0 * x1);" in src and "const double tmp2 = (tmp1 + x2);" in src
+    assert "rm_ew_fast" in src and "rm_ew_bcast" in src
+
+
+def test_parity_rewrites_log10_log1p_expm1(built):
+    """fusion.rs:3005-3019 emits lossy forms; the CPU builtins use libm log10/ln_1p/exp_m1."""
+    from runmat_amd import wgsl_translate
+    from runmat_amd.fusion import FusionGroupPlan
+
+    p = FusionGroupPlan()
+    x = p.input()
+    a = p.builtin("log10", x)
+    b = p.builtin("log1p", a)
+    c = p.builtin("expm1", b)
+    sh = p.generate_wgsl_for_output(c)
+    assert "(log(input0.data[i0]) * f64(0.4342944819032518))" in sh
+    assert "log(tmp0 + f64(1.0))" in sh and "(exp(tmp1) - f64(1.0))" in sh
+    src = wgsl_translate(sh)
+    assert "tmp0 = log10(x0);" in src and "tmp1 = log1p(tmp0);" in src and "tmp2 = expm1(tmp1);" in src
+    # a user-written log(x+1) arrives as two tmps and must NOT be rewritten
+    q = FusionGroupPlan()
+    x, one = q.input(), q.input()
+    s = q.primitive("Add", x, one)
+    l = q.builtin("log", s)
+    src2 = wgsl_translate(q.generate_wgsl_for_output(l))
+    assert "log1p" not in src2 and "tmp1 = log(tmp0);" in src2
+
+
+def test_full_vocabulary_translates_and_compiles(built):
+    """Every function of builtin_expr / primitive_expr (fusion.rs:2874-3026) in one plan."""
+    from runmat_amd import wgsl_compile_check, wgsl_translate
+    from runmat_amd.fusion import FusionGroupPlan
+
+    p = FusionGroupPlan()
+    x, y = p.input(), p.input()
+    vals = []
+    for f in ("sin", "cos", "tan", "asin", "acos", "atan", "sinh", "cosh", "tanh", "exp", "log", "log2", "sqrt",
+              "abs", "exp2", "floor", "ceil", "round", "trunc", "asinh", "acosh", "atanh", "isfinite", "isinf",
+              "isnan", "fix", "sign", "pow2", "heaviside", "single", "double", "log10", "log1p", "expm1"):
+        vals.append(p.builtin(f, x))
+    for f in ("atan2", "hypot", "max", "min", "mod", "rem"):
+        vals.append(p.builtin(f, x, y))
+    for op in ("Add", "Sub", "Mul", "ElemMul", "ElemDiv", "ElemLeftDiv", "Pow", "ElemPow"):
+        vals.append(p.primitive(op, x, y))
+    vals.append(p.primitive("Neg", x))
+    vals.append(p.primitive("UPlus", x))
+    acc = vals[0]
+    for v in vals[1:]:
+        acc = p.primitive("Add", acc, v)
+    sh = p.generate_wgsl_for_output(acc)
+    src = wgsl_translate(sh)
+    for needle in ("rm_sign(", "rm_max(", "rm_min(", "rm_isnan(", "rm_isinf(", "rm_isfinite(", "hypot(", "atan2(",
+                   "pow(", "trunc(", "round(", "exp2(", "log10(", "log1p(", "expm1("):
+        assert needle in src, needle
+    wgsl_compile_check(sh)  # hipRTC, --offload-arch=gfx950
+
+
+def test_multi_output_shader(built):
+    from runmat_amd import wgsl_compile_check, wgsl_translate
+    from runmat_amd.fusion import FusionGroupPlan
+
+    p = FusionGroupPlan()
+    a, b = p.input(), p.input()
+    s = p.primitive("Add", a, b)
+    m = p.primitive("ElemMul", s, b)
+    sh = p.generate_wgsl_for_outputs([m, s])
+    assert "output0.data[g] = tmp1;" in sh and "output1.data[g] = tmp0;" in sh
+    src = wgsl_translate(sh)
+    assert "double& o0, double& o1" in src and "o0 = tmp1;" in src and "o1 = tmp0;" in src
+    wgsl_compile_check(sh)
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+def test_reduction_shader(built, axis):
+    from runmat_amd import wgsl_compile_check, wgsl_translate
+    from runmat_amd.fusion import FusionGroupPlan
+
+    p = FusionGroupPlan()
+    x, w = p.input(), p.input()
+    two = p.constant(2.0)
+    v = p.primitive("Add", p.primitive("ElemMul", p.builtin("sin", x), w), two)
+    sh = p.generate_reduction_wgsl(v, "f64", axis=axis, omitnan=(axis == 1), is_mean=True)
+    assert "let val: f64 = ((sin(v) * v1) + f64(2));" in sh  # constants inlined via Display (fusion.rs:1839-1873)
+    assert ("const OMITNAN: bool = true" in sh) == (axis == 1)
+    src = wgsl_translate(sh, "reduction")
+    assert "return ((sin(v0) * v1) + (0x1p+1));" in src
+    assert "rm_red_contig" in src and "rm_red_strided" in src and "rm_red_final" in src
+    wgsl_compile_check(sh, "reduction")
+
+
+@pytest.mark.parametrize("mutate,needle", [
+    (lambda s: s.replace("array<f64>", "array<f32>"), "F64 provider"),
+    (lambda s: s.replace("sin(input0.data[i0])", "frobnicate(input0.data[i0])"), "unsupported function"),
+    (lambda s: s.replace("(tmp0 * input1.data[i1])", "(tmp7 * input1.data[i1])"), "tmp used before definition"),
+    (lambda s: s.replace("input2.data[i2]", "input9.data[i9]"), "input index out of range"),
+    (lambda s: s.replace("    output.data[g] = tmp2;\n", ""), "no output store"),
+    (lambda s: s.replace("(tmp1 + input2.data[i2]);", "(tmp1 + input2.data[i2]) extra;"), "trailing tokens"),
+])
+def test_front_end_is_strict(built, mutate, needle):
+    """Anything outside the subset is an error (-> the caller's CPU fallback), never a guess."""
+    from runmat_amd import ProviderError, wgsl_translate
+    from runmat_amd.fusion import sin_mul_add_plan
+
+    plan, out = sin_mul_add_plan()
+    sh = mutate(plan.generate_wgsl_for_output(out))
+    with pytest.raises(ProviderError) as e:
+        wgsl_translate(sh)
+    assert e.value.code == 6 and needle in str(e.value)
+
+
+def test_literals_are_exact(built):
+    from runmat_amd import wgsl_translate
+    from runmat_amd.fusion import FusionGroupPlan
+
+    p = FusionGroupPlan()
+    x = p.input()
+    c1, c2, c3 = p.constant(0.1), p.constant(-3.0), p.constant(float("inf"))
+    v = p.primitive("Add", p.primitive("ElemMul", x, c1), p.primitive("Sub", c2, c3))
+    sh = p.generate_reduction_wgsl(v, "f64", axis=0)
+    assert "((v * f64(0.1)) + (f64(-3) - f64(inf)))" in sh
+    src = wgsl_translate(sh, "reduction")
+    assert (0.1).hex() in src and "(-0x1.8p+1)" in src and "__builtin_inf()" in src

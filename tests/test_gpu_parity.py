@@ -1,0 +1,653 @@
+"""GPU parity tests (-m gpu): every hot-path entry point of the C ABI against the CPU oracle on
+the same seeded inputs.  Bar: bit-exact for integer / index work and for IEEE-exact arithmetic
+(+,-,*,/,sqrt,abs,floor,...,max,min with the CPU NaN/-0 policy, broadcast indexing, the LCG
+stream, LU pivot vectors); stated ulp tolerances for libm functions (the reference's CPU path
+calls the platform libm through Rust std; ROCm's ocml rounds differently in the last place);
+k*eps*sum|a||b| for matmul (MFMA fma chain vs the CPU's separately rounded sum += a*b);
+residual / forward-error bounds for A\\b exactly as the reference's own tests state them."""
+import math
+
+import numpy as np
+import pytest
+
+from workloads import OracleOps, ProviderOps, golden_monte_carlo_cases, lcg_monte_carlo_price
+
+pytestmark = pytest.mark.gpu
+
+EPS = 2.220446049250313e-16
+
+
+def ulp_err(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    both_nan = np.isnan(got) & np.isnan(want)
+    same_inf = np.isinf(want) & (got == want)
+    sp = np.spacing(np.maximum(np.abs(want), 2.2250738585072014e-308))
+    with np.errstate(invalid="ignore"):
+        e = np.abs(got - want) / sp
+    e = np.where(both_nan | same_inf, 0.0, e)
+    return float(np.nanmax(np.where(np.isnan(e), np.inf, e))) if e.size else 0.0
+
+
+def bits_equal(got, want):
+    got, want = np.ascontiguousarray(got, dtype=np.float64), np.ascontiguousarray(want, dtype=np.float64)
+    a, b = got.view(np.uint64), want.view(np.uint64)
+    nan_ok = np.isnan(got) & np.isnan(want)
+    return bool(np.all((a == b) | nan_ok))
+
+
+# ---- memory / handles --------------------------------------------------------------------------
+def test_upload_download_roundtrip_and_errors(prov):
+    from runmat_amd import GpuTensorHandle, ProviderError
+
+    a = np.arange(12, dtype=np.float64).reshape(3, 4)
+    h = prov.upload(a)
+    assert h.shape == (3, 4) and h.device_id == prov.device_id()
+    assert np.array_equal(prov.download(h), a.reshape(-1, order="F"))  # column-major like HostTensorOwned
+    r = prov.reshape(h, (4, 3))
+    assert np.array_equal(prov.download(r), prov.download(h))
+    prov.free(h)
+    assert np.array_equal(prov.download(r)[:3], [0.0, 4.0, 8.0])  # reshape aliases storage, refcounted
+    prov.free(r)
+    with pytest.raises(ProviderError) as e:
+        prov.download(h)
+    assert e.value.code == 5 and "buffer not found" in str(e.value)
+    with pytest.raises(ProviderError):
+        prov.free(h)
+    with pytest.raises(ProviderError):  # foreign device id (io.rs:269-275)
+        prov.free(GpuTensorHandle((1, 1), prov.device_id() + 77, 1))
+    z = prov.zeros((5, 2))
+    o = prov.ones((5, 2))
+    assert np.array_equal(prov.download(z), np.zeros(10)) and np.array_equal(prov.download(o), np.ones(10))
+    e0 = prov.upload(np.zeros((0, 3)))
+    assert prov.download(e0).size == 0
+    for x in (z, o, e0):
+        prov.free(x)
+    assert prov.precision() == "F64"
+    info = prov.device_info_struct()
+    assert info["arch"].startswith("gfx950") and info["compute_units"] >= 200
+
+
+def test_fill_uniform_matches_oracle_bits(prov, oracle):
+    h = prov.fill_uniform(42, -np.pi, np.pi, (1001, 3))
+    assert bits_equal(prov.download(h), oracle.fill_uniform(42, -np.pi, np.pi, 3003))
+    prov.free(h)
+
+
+# ---- fused elementwise -------------------------------------------------------------------------
+def _run_fused(prov, plan, out_ids, arrays, out_shape):
+    hs = [prov.upload(a) for a in arrays]
+    n = int(np.prod(out_shape))
+    if isinstance(out_ids, int):
+        sh = plan.generate_wgsl_for_output(out_ids, "f64")
+        res = [prov.fused_elementwise(sh, hs, out_shape, n)]
+    else:
+        sh = plan.generate_wgsl_for_outputs(out_ids, "f64")
+        res = prov.fused_elementwise_multi(sh, hs, out_shape, n, len(out_ids))
+    outs = [prov.download_matrix(r) for r in res]
+    for h in hs + res:
+        prov.free(h)
+    return outs if not isinstance(out_ids, int) else outs[0]
+
+
+@pytest.mark.parametrize("shape", [(1024, 1024), (257, 131), (1, 1), (7, 1), (1, 9), (3, 5, 7), (2049,)])
+def test_fused_sin_mul_add_vs_oracle(prov, oracle, shape):
+    from runmat_amd.fusion import sin_mul_add_plan
+
+    rng = np.random.default_rng(hash(shape) % 1000)
+    A = rng.uniform(-np.pi, np.pi, shape)
+    B = rng.uniform(-1, 1, shape)
+    C = rng.uniform(-1, 1, shape)
+    plan, out = sin_mul_add_plan()
+    D = _run_fused(prov, plan, out, [A, B, C], shape)
+    ref = oracle.sin_mul_add(A, B, C)
+    # sin within 1 ulp of libm, then exact * and + : |err| <= ulp(sin)*|B| + rounding
+    assert np.max(np.abs(D - ref)) <= 2 * EPS
+    # the arithmetic after sin is exact: feeding the oracle's sin through mul/add must match bit for bit
+    s_dev = _run_fused(prov, *_unary_plan("sin"), [A], shape)
+    assert bits_equal(D, s_dev * B + C)
+
+
+def _unary_plan(name):
+    from runmat_amd.fusion import FusionGroupPlan
+
+    p = FusionGroupPlan()
+    x = p.input()
+    return p, p.builtin(name, x)
+
+
+def test_fused_large_argument_sin(prov, oracle):
+    # slow-path (Payne-Hanek) argument reduction: |x| up to 1e6 and a few huge values
+    rng = np.random.default_rng(11)
+    A = np.concatenate([rng.uniform(-1e6, 1e6, 4000), [1e15, -3e18, 1e300, 0.0, -0.0, np.inf, np.nan]]).reshape(-1, 1)
+    got = _run_fused(prov, *_unary_plan("sin"), [A], A.shape)
+    want = oracle.unary("sin", A)
+    assert ulp_err(got[:-2], want[:-2]) <= 2
+    assert math.isnan(got[-1, 0]) and math.isnan(got[-2, 0])
+    assert math.copysign(1, got[-3, 0]) < 0  # sin(-0) = -0
+
+
+def test_fused_broadcast_cases(prov, oracle):
+    from runmat_amd.fusion import FusionGroupPlan
+
+    rng = np.random.default_rng(12)
+    cases = [((4, 1), (1, 3), (4, 3)), ((2, 3), (2, 1), (2, 3)), ((300, 200), (1, 1), (300, 200)),
+             ((1, 200), (300, 1), (300, 200)), ((5, 1, 7), (1, 6, 1), (5, 6, 7)), ((4,), (2, 3, 4), (2, 3, 4)),
+             ((1, 1), (1, 1), (1, 1)), ((6, 5, 4, 3), (6, 1, 4, 1), (6, 5, 4, 3))]
+    for sa, sb, so in cases:
+        p = FusionGroupPlan()
+        a, b = p.input(), p.input()
+        out = p.primitive("Sub", p.primitive("ElemMul", a, b), a)
+        A, B = rng.standard_normal(sa), rng.standard_normal(sb)
+        got = _run_fused(prov, p, out, [A, B], so)
+        want = oracle.binary("sub", oracle.binary("mul", A, B), A)
+        assert want.shape == so and bits_equal(got, want), (sa, sb)
+
+
+def test_fused_scalar_inputs_are_broadcast_and_constants_are_inputs(prov, oracle):
+    # fusion_exec.rs:305-326: scalars arrive as 1-element tensors shaped [1,1]
+    from runmat_amd.fusion import elementwise_math_plan
+
+    x = np.linspace(0.0, 4.0 * np.pi, 1024 * 1024).reshape(1024, 1024, order="F")  # BASELINE configs[0]
+    plan, out = elementwise_math_plan()
+    consts = [np.array([[v]]) for v in (10.0, 4.0, 0.25, 2.0, 0.1)]
+    got = _run_fused(prov, plan, out, [x] + consts, x.shape)
+    want = oracle.elementwise_math_chain(x)
+    assert np.max(np.abs(got - want)) <= 8 * EPS  # |y2| < 1.2; a handful of <=1 ulp libm calls
+    assert np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-3)) <= 1e-12
+
+
+def test_fused_multi_output(prov, oracle):
+    from runmat_amd.fusion import FusionGroupPlan
+
+    rng = np.random.default_rng(13)
+    A, B = rng.standard_normal((129, 65)), rng.standard_normal((129, 65))
+    p = FusionGroupPlan()
+    a, b = p.input(), p.input()
+    s = p.primitive("Add", a, b)
+    m = p.primitive("ElemMul", s, b)
+    d = p.primitive("ElemDiv", m, a)
+    o_m, o_s, o_d = _run_fused(prov, p, [m, s, d], [A, B], A.shape)
+    assert bits_equal(o_s, A + B) and bits_equal(o_m, (A + B) * B) and bits_equal(o_d, ((A + B) * B) / A)
+
+
+def test_fused_exact_ops_and_policies_bitwise(prov, oracle):
+    from runmat_amd.fusion import FusionGroupPlan
+
+    special = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 1.5, -1.5, 2.5, -2.5, np.inf, -np.inf, np.nan, 1e-310, 3.0, -7.25])
+    X, Y = np.meshgrid(special, special, indexing="ij")
+    for name in ("abs", "floor", "ceil", "round", "trunc", "fix", "sign", "sqrt", "heaviside", "isnan", "isinf", "isfinite"):
+        got = _run_fused(prov, *_unary_plan(name), [X], X.shape)
+        oname = {"trunc": "fix"}.get(name, name)
+        assert bits_equal(got, oracle.unary(oname, X)), name
+    for name in ("max", "min", "mod", "rem"):
+        p = FusionGroupPlan()
+        a, b = p.input(), p.input()
+        out = p.builtin(name, a, b)
+        got = _run_fused(prov, p, out, [X, Y], X.shape)
+        assert bits_equal(got, oracle.binary(name, X, Y)), name
+    for op, oname in (("Add", "add"), ("Sub", "sub"), ("ElemMul", "mul"), ("ElemDiv", "div")):
+        p = FusionGroupPlan()
+        a, b = p.input(), p.input()
+        out = p.primitive(op, a, b)
+        assert bits_equal(_run_fused(prov, p, out, [X, Y], X.shape), oracle.binary(oname, X, Y)), op
+
+
+LIBM_ULP = {"sin": 2, "cos": 2, "tan": 3, "asin": 2, "acos": 2, "atan": 2, "sinh": 3, "cosh": 3, "tanh": 3,
+            "asinh": 3, "acosh": 3, "atanh": 3, "exp": 2, "expm1": 2, "log": 2, "log2": 2, "log10": 2, "log1p": 2,
+            "exp2": 2}
+
+
+@pytest.mark.parametrize("name", sorted(LIBM_ULP))
+def test_fused_libm_functions_ulp(prov, oracle, name):
+    rng = np.random.default_rng(14)
+    lo, hi = {"asin": (-1, 1), "acos": (-1, 1), "atanh": (-0.999, 0.999), "acosh": (1.0, 50.0), "log": (1e-6, 1e6),
+              "log2": (1e-6, 1e6), "log10": (1e-6, 1e6), "log1p": (-0.999, 50.0), "exp": (-50, 50), "exp2": (-50, 50),
+              "expm1": (-20, 20), "sinh": (-20, 20), "cosh": (-20, 20)}.get(name, (-10.0, 10.0))
+    X = rng.uniform(lo, hi, (4096, 1))
+    fused_name = {"exp2": "exp2"}.get(name, name)
+    got = _run_fused(prov, *_unary_plan(fused_name), [X], X.shape)
+    assert ulp_err(got, oracle.unary(name, X)) <= LIBM_ULP[name], name
+
+
+def test_fused_pow_hypot_atan2(prov, oracle):
+    from runmat_amd.fusion import FusionGroupPlan
+
+    rng = np.random.default_rng(15)
+    X, Y = rng.uniform(0.01, 20, (4096, 1)), rng.uniform(-5, 5, (4096, 1))
+    for name, prim in (("pow", "ElemPow"), ("hypot", None), ("atan2", None)):
+        p = FusionGroupPlan()
+        a, b = p.input(), p.input()
+        out = p.primitive(prim, a, b) if prim else p.builtin(name, a, b)
+        got = _run_fused(prov, p, out, [X, Y], X.shape)
+        assert ulp_err(got, oracle.binary(name, X, Y)) <= 2, name
+
+
+def test_fused_errors(prov):
+    from runmat_amd import ProviderError
+    from runmat_amd.fusion import sin_mul_add_plan
+
+    plan, out = sin_mul_add_plan()
+    sh = plan.generate_wgsl_for_output(out)
+    a = prov.upload(np.ones((4, 3)))
+    b = prov.upload(np.ones((5, 3)))
+    with pytest.raises(ProviderError) as e:  # wrong input count
+        prov.fused_elementwise(sh, [a, a], (4, 3), 12)
+    assert e.value.code == 1
+    with pytest.raises(ProviderError) as e:  # non-broadcastable
+        prov.fused_elementwise(sh, [a, b, a], (4, 3), 12)
+    assert e.value.code == 3
+    with pytest.raises(ProviderError) as e:  # len mismatch
+        prov.fused_elementwise(sh, [a, a, a], (4, 3), 13)
+    assert e.value.code == 3
+    with pytest.raises(ProviderError) as e:  # zero-length: fusion_exec.rs:273
+        z = prov.upload(np.zeros((0, 3)))
+        prov.fused_elementwise(sh, [z, z, z], (0, 3), 0)
+    assert e.value.code == 2
+    with pytest.raises(ProviderError) as e:
+        prov.fused_elementwise("not wgsl", [a], (4, 3), 12)
+    assert e.value.code == 6
+    t = prov.telemetry_snapshot()
+    assert t["fused_elementwise_count"] > 0 and t["kernel_launches"] > 0
+
+
+# ---- fused reductions --------------------------------------------------------------------------
+def _fused_reduce(prov, plan, data_vid, arrays, axis, reduce_len, num_slices, flavor=None, omitnan=False, is_mean=False):
+    from runmat_amd import ReductionFlavor
+
+    sh = plan.generate_reduction_wgsl(data_vid, "f64", axis=axis, omitnan=omitnan, is_mean=is_mean)
+    hs = [prov.upload(a) for a in arrays]
+    fl = flavor or (ReductionFlavor.Mean() if is_mean else ReductionFlavor.Sum())
+    h = prov.fused_reduction(sh, hs, (num_slices,), reduce_len, num_slices, 256, fl)
+    out = prov.download(h)
+    for x in hs + [h]:
+        prov.free(x)
+    return out
+
+
+def test_fused_reduction_sum_mul_kat(prov):
+    # crates/runmat-accelerate/tests/fused_reduction_sum_mul.rs:40-137 (X[r,c]=r+1, W[r,c]=c+1), tol 1e-6;
+    # integers => exact here
+    from runmat_amd.fusion import FusionGroupPlan
+
+    rows, cols = 1000, 37
+    X = np.fromfunction(lambda r, c: r + 1.0, (rows, cols))
+    W = np.fromfunction(lambda r, c: c + 1.0, (rows, cols))
+    p = FusionGroupPlan()
+    a, b = p.input(), p.input()
+    m = p.primitive("ElemMul", a, b)
+    got = _fused_reduce(prov, p, m, [X, W], 0, rows, cols)
+    assert np.array_equal(got, [(c + 1) * rows * (rows + 1) / 2 for c in range(cols)])
+
+
+@pytest.mark.parametrize("rows,cols", [(512, 512), (1024, 1024), (33, 7), (1, 300), (300, 1), (100000, 3), (3, 100000)])
+def test_fused_reduction_rows_of_sin_x_times_x(prov, oracle, rows, cols):
+    # crates/runmat-vm/tests/fusion_gpu.rs:1429-1449: Y = sin(X).*X + 2; S = sum(Y, 2); also sum(Y, 1) and 'all'
+    from runmat_amd.fusion import FusionGroupPlan
+
+    X = np.fromfunction(lambda r, c: ((c % 97) + 1) * 10.0 + (r % 1013) + 1, (rows, cols))
+    Y = oracle.binary("add", oracle.binary("mul", oracle.unary("sin", X), X), np.array([[2.0]]))
+    absY = np.abs(Y)
+
+    def plan():
+        p = FusionGroupPlan()
+        x = p.input()
+        two = p.constant(2.0)
+        return p, p.primitive("Add", p.primitive("ElemMul", p.builtin("sin", x), x), two)
+
+    # tolerance: summation-order bound n*eps*sum|y| plus 2 ulp per term from sin
+    p, v = plan()
+    s2 = _fused_reduce(prov, p, v, [X], 1, cols, rows)
+    assert np.all(np.abs(s2 - oracle.reduce_sum(Y, [1]).reshape(-1)) <= (cols + 4) * EPS * absY.sum(axis=1) + 1e-300)
+    p, v = plan()
+    s1 = _fused_reduce(prov, p, v, [X], 0, rows, cols)
+    assert np.all(np.abs(s1 - oracle.reduce_sum(Y, [0]).reshape(-1)) <= (rows + 4) * EPS * absY.sum(axis=0) + 1e-300)
+    p, v = plan()
+    sa = _fused_reduce(prov, p, v, [X], 0, rows * cols, 1)
+    assert abs(sa[0] - oracle.reduce_sum(Y, "all")[0, 0]) <= 64 * math.sqrt(rows * cols) * EPS * absY.sum()
+    p, v = plan()
+    assert bits_equal(sa, _fused_reduce(prov, p, v, [X], 0, rows * cols, 1))  # deterministic
+
+
+def test_fused_reduction_nan_policy_mean_and_scale(prov, oracle):
+    from runmat_amd import ReductionFlavor
+    from runmat_amd.fusion import FusionGroupPlan
+
+    rng = np.random.default_rng(16)
+    X = rng.standard_normal((400, 9))
+    X[5, 2] = np.nan
+    X[:, 4] = np.nan
+    p = FusionGroupPlan()
+    x = p.input()
+    v = p.primitive("ElemMul", x, x)
+    Y = X * X
+    inc = _fused_reduce(prov, p, v, [X], 0, 400, 9)
+    ref = oracle.reduce_sum(Y, [0]).reshape(-1)
+    assert np.isnan(inc[2]) and np.isnan(inc[4]) and np.allclose(inc[[0, 1, 3]], ref[[0, 1, 3]], rtol=1e-13)
+    assert inc.view(np.uint64)[2] == 0x7FF8000000000000  # canonical quiet NaN (fusion.rs:2013-2021)
+    om = _fused_reduce(prov, p, v, [X], 0, 400, 9, omitnan=True)
+    refo = oracle.reduce_sum(Y, [0], omitnan=True).reshape(-1)
+    assert om[4] == 0.0 and np.allclose(om, refo, rtol=1e-13)
+    # mean divides by the count (CPU mean.rs:1134-1151), also for counts that f32 cannot hold
+    mean = _fused_reduce(prov, p, v, [X[:, :2]], 0, 400, 2, is_mean=True)
+    assert np.allclose(mean, oracle.reduce_sum(Y[:, :2], [0], mean=True).reshape(-1), rtol=1e-13)
+    sc = _fused_reduce(prov, p, v, [X[:, :2]], 1, 2, 400, flavor=ReductionFlavor.CustomScale(0.125))
+    assert np.allclose(sc, 0.125 * oracle.reduce_sum(Y[:, :2], [1]).reshape(-1), rtol=1e-13)
+    # scalar operand uploaded as a 1-element tensor (fusion_exec.rs:522-543)
+    q = FusionGroupPlan()
+    a, s = q.input(), q.input()
+    w = q.primitive("ElemMul", a, s)
+    got = _fused_reduce(prov, q, w, [X[:, :2], np.array([[3.0]])], 0, 400, 2)
+    assert np.allclose(got, 3.0 * oracle.reduce_sum(X[:, :2], [0]).reshape(-1), rtol=1e-13)
+
+
+# ---- per-op kernels ----------------------------------------------------------------------------
+def test_unary_binary_scalar_ops_vs_oracle(prov, oracle):
+    rng = np.random.default_rng(17)
+    X = rng.uniform(0.05, 3.0, (333, 77))
+    Y = rng.uniform(0.05, 3.0, (333, 77))
+    hx, hy = prov.upload(X), prov.upload(Y)
+    exact_unary = ("sqrt", "abs", "sign", "floor", "ceil", "round", "fix", "neg", "heaviside", "isnan", "isinf", "isfinite", "uplus")
+    for op in exact_unary:
+        h = getattr(prov, "unary_" + op)(hx)
+        assert bits_equal(prov.download_matrix(h), oracle.unary(op, X)), op
+        prov.free(h)
+    for op, tol in LIBM_ULP.items():
+        Xa = np.clip(X / 3.1, 0.02, 0.98) if op in ("asin", "acos", "atanh") else (X + 1.0 if op == "acosh" else X)
+        ha = prov.upload(Xa)
+        h = getattr(prov, "unary_" + op)(ha)
+        assert ulp_err(prov.download_matrix(h), oracle.unary(op, Xa)) <= tol, op
+        prov.free(h)
+        prov.free(ha)
+    for op in ("add", "sub", "mul", "div", "max", "min"):
+        h = getattr(prov, "elem_" + op)(hx, hy)
+        assert bits_equal(prov.download_matrix(h), oracle.binary(op, X, Y)), op
+        prov.free(h)
+    for op in ("pow", "hypot", "atan2"):
+        h = getattr(prov, "elem_" + op)(hx, hy)
+        assert ulp_err(prov.download_matrix(h), oracle.binary(op, X, Y)) <= 2, op
+        prov.free(h)
+    s = 1.75
+    for op, ref in (("add", X + s), ("sub", X - s), ("mul", X * s), ("div", X / s), ("rsub", s - X), ("rdiv", s / X),
+                    ("max", np.maximum(X, s)), ("min", np.minimum(X, s))):
+        h = getattr(prov, "scalar_" + op)(hx, s)
+        assert bits_equal(prov.download_matrix(h), ref), op
+        prov.free(h)
+    prov.free(hx)
+    prov.free(hy)
+
+
+def test_binary_broadcast_and_mismatch(prov, oracle):
+    from runmat_amd import ProviderError
+
+    rng = np.random.default_rng(18)
+    for sa, sb in [((4, 1), (1, 3)), ((2, 3), (2, 1)), ((1, 1), (40, 30)), ((7, 1, 5), (1, 6, 1)), ((1000, 1), (1, 1000))]:
+        A, B = rng.standard_normal(sa), rng.standard_normal(sb)
+        ha, hb = prov.upload(A), prov.upload(B)
+        h = prov.elem_mul(ha, hb)
+        want = oracle.binary("mul", A, B)
+        assert h.shape == want.shape and bits_equal(prov.download_matrix(h), want)
+        for x in (ha, hb, h):
+            prov.free(x)
+    ha, hb = prov.upload(np.ones((2, 3))), prov.upload(np.ones((3, 2)))
+    with pytest.raises(ProviderError) as e:
+        prov.elem_add(ha, hb)
+    assert e.value.code == 3 and "size mismatch" in str(e.value)
+    # reference KATs: crates/runmat-runtime-integration-tests/tests/gpu.rs:28-60
+    a, b = prov.upload(np.array([1, 2, 3, 4.0]), (2, 2)), prov.upload(np.array([5, 6, 7, 8.0]), (2, 2))
+    assert list(prov.download(prov.elem_add(a, b))) == [6, 8, 10, 12]
+    assert list(prov.download(prov.elem_mul(a, b))) == [5, 12, 21, 32]
+
+
+# ---- reductions --------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1000, 1000), (1, 1), (5, 1), (1, 5), (3, 70000), (70000, 3), (257, 129)])
+def test_reduce_sum_mean_shapes_and_values(prov, oracle, shape):
+    rng = np.random.default_rng(19)
+    X = rng.uniform(-1, 1, shape)
+    h = prov.upload(X)
+    n = X.size
+    sabs = np.abs(X).sum()
+    r = prov.reduce_sum(h)
+    assert r.shape == (1, 1)  # simple_provider.rs:6743
+    assert abs(prov.download(r)[0] - oracle.reduce_sum(X, "all")[0, 0]) <= 64 * math.sqrt(n) * EPS * sabs
+    r0 = prov.reduce_sum_dim(h, 0)
+    r1 = prov.reduce_sum_dim(h, 1)
+    assert r0.shape == (1, shape[1]) and r1.shape == (shape[0], 1)  # :6765, :6777
+    assert np.all(np.abs(prov.download(r0) - oracle.reduce_sum(X, [0]).reshape(-1)) <= shape[0] * EPS * np.abs(X).sum(axis=0) + 1e-300)
+    assert np.all(np.abs(prov.download(r1) - oracle.reduce_sum(X, [1]).reshape(-1)) <= shape[1] * EPS * np.abs(X).sum(axis=1) + 1e-300)
+    m = prov.reduce_mean(h)
+    assert abs(prov.download(m)[0] - oracle.reduce_sum(X, "all", mean=True)[0, 0]) <= 64 * math.sqrt(n) * EPS * sabs / n
+    m1 = prov.reduce_mean_dim(h, 1)
+    assert np.allclose(prov.download(m1), oracle.reduce_sum(X, [1], mean=True).reshape(-1), rtol=1e-12, atol=1e-15)
+    assert prov.download(prov.reduce_min(h))[0] == X.min() and prov.download(prov.reduce_max(h))[0] == X.max()
+    assert np.array_equal(prov.download(prov.reduce_max_dim(h, 0)), X.max(axis=0))
+    assert np.array_equal(prov.download(prov.reduce_min_dim(h, 1)), X.min(axis=1))
+    # determinism
+    assert bits_equal(prov.download(prov.reduce_sum(h)), prov.download(r))
+
+
+def test_reduce_sum_dim1_sequential_order_is_bit_exact(prov, oracle):
+    # threads walk columns in ascending order (skel_reduce.h kernel B, nsplit == 1): identical to the
+    # CPU's ascending accumulation (sum.rs:1031-1053) when the slice count already fills the chip
+    rng = np.random.default_rng(20)
+    X = rng.standard_normal((600000, 12))
+    h = prov.upload(X)
+    got = prov.download(prov.reduce_sum_dim(h, 1))
+    assert bits_equal(got, oracle.reduce_sum(X, [1]).reshape(-1))
+
+
+def test_reduce_nan_and_integers_exact(prov, oracle):
+    X = np.arange(1, 100001, dtype=np.float64).reshape(1000, 100, order="F")
+    h = prov.upload(X)
+    assert prov.download(prov.reduce_sum(h))[0] == 100000 * 100001 / 2
+    assert np.array_equal(prov.download(prov.reduce_sum_dim(h, 0)), X.sum(axis=0))
+    assert np.array_equal(prov.download(prov.reduce_sum_dim(h, 1)), X.sum(axis=1))
+    X[7, 3] = np.nan
+    h = prov.upload(X)
+    assert math.isnan(prov.download(prov.reduce_sum(h))[0])
+    c = prov.download(prov.reduce_sum_dim(h, 0))
+    assert math.isnan(c[3]) and np.array_equal(np.delete(c, 3), np.delete(np.nansum(X, axis=0), 3))
+    assert prov.download(prov._reduce("sum", h, -1, omitnan=True))[0] == np.nansum(X)
+
+
+# ---- matmul ------------------------------------------------------------------------------------
+def test_matmul_reference_kats_exact(prov):
+    from runmat_amd import ProviderError
+
+    # mtimes.rs:495-503
+    a = prov.upload(np.array([[1, 2, 3], [4, 5, 6.0]]))
+    b = prov.upload(np.array([[7, 8], [9, 10], [11, 12.0]]))
+    c = prov.matmul(a, b)
+    assert c.shape == (2, 2) and np.array_equal(prov.download_matrix(c), [[58, 64], [139, 154]])
+    # mtimes.rs:688-706 (column-major data)
+    ha, hb = prov.upload(np.array([1, 2, 3, 4.0]), (2, 2)), prov.upload(np.array([5, 7, 6, 8.0]), (2, 2))
+    assert list(prov.download(prov.matmul(ha, hb))) == [26.0, 38.0, 30.0, 44.0]
+    with pytest.raises(ProviderError) as e:  # mtimes.rs:628-637 / simple_provider.rs:7709-7711
+        prov.matmul(a, a)
+    assert e.value.code == 3 and "inner dims must agree" in str(e.value)
+    with pytest.raises(ProviderError):  # simple_provider.rs:7704-7706
+        prov.matmul(prov.upload(np.ones((2, 2, 2))), b)
+    # crates/runmat-accelerate/tests/matmul_small_k.rs:52-96, tol 1e-9 (small integers + quarters: exact)
+    m, n, k = 64, 32, 4
+    A = np.fromfunction(lambda r, c: (r + 1) + 0.25 * c, (m, k))
+    B = np.fromfunction(lambda r, c: (r + 2 * c) % 7, (k, n))
+    assert np.array_equal(prov.download_matrix(prov.matmul(prov.upload(A), prov.upload(B))), A @ B)
+
+
+def test_matmul_identity_with_asymmetric_b_detects_transposes(prov):
+    n = 160
+    B = np.fromfunction(lambda i, j: 3.0 * i - 7.0 * j + 0.5, (n, n))
+    I = np.eye(n)
+    assert np.array_equal(prov.download_matrix(prov.matmul(prov.upload(I), prov.upload(B))), B)
+    assert np.array_equal(prov.download_matrix(prov.matmul(prov.upload(B), prov.upload(I))), B)
+
+
+@pytest.mark.parametrize("m,k,n", [(128, 16, 128), (256, 64, 128), (384, 1024, 256), (97, 45, 33), (1, 1, 1), (1, 77, 1),
+                                   (130, 17, 129), (5, 300, 7), (128, 20, 128), (127, 16, 128), (1024, 1024, 1024), (64, 0, 8)])
+def test_matmul_vs_oracle_bound(prov, oracle, m, k, n):
+    rng = np.random.default_rng(m * 7 + k * 3 + n)
+    A, B = rng.uniform(-1, 1, (m, k)), rng.uniform(-1, 1, (k, n))
+    got = prov.download_matrix(prov.matmul(prov.upload(A), prov.upload(B)))
+    want = oracle.matmul(A, B)
+    # both sides are k-ordered sums; they differ only in per-term rounding: |d| <= (k+2)*eps*sum|a||b|
+    bound = (k + 2) * EPS * (np.abs(A) @ np.abs(B)) + 1e-300
+    assert got.shape == (m, n) and np.all(np.abs(got - want) <= bound)
+    if k and max(m, n) <= 512:
+        assert np.max(np.abs(got - want)) < 1e-9  # the reference's own tolerance (matmul_small_k.rs:84-96)
+
+
+def test_matmul_profile_generator_shapes(prov, oracle):
+    # crates/runmat-accelerate/src/bin/wgpu_profile.rs:1219-1229, abs tol 1e-5 / rel 1e-4 there
+    def gen(rows, cols, base, delta):
+        idx = np.arange(rows * cols)
+        return (base + delta * ((idx % 128) / 127.0)).reshape((rows, cols), order="F")
+
+    for (m, k, n) in [(256, 256, 256), (128, 2048, 128)]:
+        A, B = gen(m, k, 0.5, 1.5), gen(k, n, -1.0, 2.0)
+        got = prov.download_matrix(prov.matmul(prov.upload(A), prov.upload(B)))
+        want = oracle.matmul(A, B)
+        assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) < 1e-12
+
+
+# ---- LU / mldivide -----------------------------------------------------------------------------
+def _check_lu(prov, oracle, A, tol=1e-11):
+    r = prov.lu(prov.upload(A))
+    comb, L, U, P, piv = oracle.lu(A)
+    g_piv = prov.download(r.perm_vector)
+    assert r.combined.shape == A.shape and r.lower.shape == (A.shape[0], A.shape[0]) and r.upper.shape == A.shape
+    assert r.perm_matrix.shape == (A.shape[0], A.shape[0]) and r.perm_vector.shape == (A.shape[0], 1)
+    assert np.array_equal(g_piv, piv.reshape(-1)), "pivot vector must be identical (integer work)"
+    assert np.array_equal(prov.download_matrix(r.perm_matrix), P)
+    scale = max(1.0, np.abs(comb).max())
+    assert np.max(np.abs(prov.download_matrix(r.combined) - comb)) <= tol * scale
+    gl, gu = prov.download_matrix(r.lower), prov.download_matrix(r.upper)
+    assert np.max(np.abs(gl - L)) <= tol * scale and np.max(np.abs(gu - U)) <= tol * scale
+    assert np.array_equal(np.diag(gl), np.ones(A.shape[0])) and np.array_equal(np.triu(gl, 1), np.zeros_like(gl))
+    assert np.array_equal(np.tril(gu, -1), np.zeros_like(gu))
+    assert np.max(np.abs(P @ A - gl @ gu)) <= 1e-12 * max(1.0, np.abs(A).max()) * A.shape[0]
+
+
+@pytest.mark.parametrize("shape", [(4, 4), (200, 200), (257, 257), (64, 40), (40, 64), (1, 1), (17, 1), (1, 17), (512, 512)])
+def test_lu_vs_oracle(prov, oracle, shape):
+    rng = np.random.default_rng(shape[0] * 31 + shape[1])
+    _check_lu(prov, oracle, rng.uniform(-1, 1, shape))
+
+
+def test_lu_tie_break_singular_and_structured(prov, oracle):
+    # host_lu.rs:38-47 (first max on ties), :54-59 (cut-off 1e-12)
+    _check_lu(prov, oracle, np.array([[1.0, 2.0], [-1.0, 5.0]]))
+    _check_lu(prov, oracle, np.array([[1e-13, 1.0], [5e-13, 2.0]]))
+    _check_lu(prov, oracle, np.zeros((5, 5)))
+    A = np.fromfunction(lambda i, j: ((i * 7 + j * 3) % 5) - 2.0, (48, 48))  # many exact ties / repeated values
+    _check_lu(prov, oracle, A + np.eye(48) * 0.5)
+    B = np.ones((20, 20))  # rank one: pivots hit the cut-off after the first column
+    _check_lu(prov, oracle, B)
+
+
+def test_mldivide_reference_tests(prov, oracle):
+    from runmat_amd import ProviderError
+
+    # mldivide.rs:662-680: A=[1 2;3 4], b=[5;6], residual < 1e-12
+    A, b = np.array([[1.0, 2.0], [3.0, 4.0]]), np.array([[5.0], [6.0]])
+    x = prov.download_matrix(prov.mldivide(prov.upload(A), prov.upload(b)))
+    assert x.shape == (2, 1) and np.linalg.norm(A @ x - b) < 1e-12
+    assert np.max(np.abs(x - oracle.mldivide_svd(A, b))) < 1e-12
+    # scalar lhs: mldivide.rs:321-325
+    s = prov.download_matrix(prov.mldivide(prov.upload(np.array([[4.0]])), prov.upload(np.array([[2.0, 8.0]]))))
+    assert np.array_equal(s, [[0.5, 2.0]])
+    # least squares (mldivide.rs:682-696) and rank-deficient inputs belong to the CPU SVD path: soft errors
+    with pytest.raises(ProviderError) as e:
+        prov.mldivide(prov.upload(np.ones((3, 2))), prov.upload(np.ones((3, 1))))
+    assert e.value.code == 2
+    with pytest.raises(ProviderError) as e:
+        prov.mldivide(prov.upload(np.array([[1.0, 2.0], [2.0, 4.0]])), prov.upload(np.ones((2, 1))))
+    assert e.value.code == 7
+    with pytest.raises(ProviderError) as e:
+        prov.mldivide(prov.upload(np.eye(3)), prov.upload(np.ones((2, 1))))
+    assert e.value.code == 3
+
+
+@pytest.mark.parametrize("n,nrhs", [(3, 1), (64, 1), (300, 3), (1000, 1), (2048, 2)])
+def test_mldivide_well_conditioned_vs_oracle(prov, oracle, n, nrhs):
+    # SURVEY.md 8(d) config 5 generator: A = U(-1,1) + n*I, b = A*1
+    rng = np.random.default_rng(n)
+    A = rng.uniform(-1, 1, (n, n)) + n * np.eye(n)
+    X = np.ones((n, nrhs)) * np.arange(1, nrhs + 1)
+    B = A @ X
+    x = prov.download_matrix(prov.mldivide(prov.upload(A), prov.upload(B)))
+    assert np.max(np.abs(x - X)) <= 1e-9
+    assert np.linalg.norm(A @ x - B) / (np.linalg.norm(A) * np.linalg.norm(x)) <= 1e-12 * n
+    if n <= 300:
+        assert np.max(np.abs(x - oracle.mldivide_svd(A, B))) <= 1e-11  # SVD solve (reference CPU algorithm)
+    assert np.max(np.abs(x - oracle.mldivide_lu(A, B))) <= 1e-11 if n <= 1000 else True
+
+
+def test_mldivide_general_matrix(prov, oracle):
+    rng = np.random.default_rng(77)
+    n = 384
+    A = rng.standard_normal((n, n))
+    b = rng.standard_normal((n, 1))
+    x = prov.download_matrix(prov.mldivide(prov.upload(A), prov.upload(b)))
+    ref = oracle.mldivide_lu(A, b)
+    cond = np.linalg.cond(A)
+    assert np.linalg.norm(A @ x - b) <= 1e-13 * n * np.linalg.norm(A) * np.linalg.norm(x)
+    assert np.max(np.abs(x - ref)) <= 1e-14 * cond * max(1.0, np.abs(ref).max())
+
+
+# ---- RNG ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 7, 1001, 65536, 1000003])
+def test_rng_uniform_stream_is_bit_exact(prov, oracle, n):
+    prov.set_rng_state(oracle.rng_default_seed())
+    got = prov.download(prov.random_uniform((n, 1)))
+    want, state = oracle.rng_uniform(oracle.rng_default_seed(), n)
+    assert bits_equal(got, want)
+    assert prov.get_rng_state() == state
+    more = prov.download(prov.random_uniform((5, 1)))  # the stream continues where the CPU's would
+    want2, _ = oracle.rng_uniform(state, 5)
+    assert bits_equal(more, want2)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 1000, 100001])
+def test_rng_normal_stream(prov, oracle, n):
+    prov.rng_seed(0)  # rng(0) == default seed (random.rs:128-131)
+    assert prov.get_rng_state() == oracle.rng_default_seed()
+    got = prov.download(prov.random_normal((n, 1)))
+    want, state = oracle.rng_normal(oracle.rng_default_seed(), n)
+    # same uniforms bit for bit; log/sqrt/cos/sin differ from libm by <= ~2 ulp each
+    assert np.max(np.abs(got - want)) <= 1e-14 * 8.0
+    assert prov.get_rng_state() == state  # odd n consumes a whole pair (random.rs:536-540)
+    prov.rng_seed(12345)
+    assert prov.get_rng_state() == oracle.rng_mix_seed(12345)
+
+
+def test_rng_moments(prov):
+    # crates/runmat-runtime/tests/rng.rs:19-63
+    prov.rng_seed(0)
+    z = prov.download(prov.random_normal((50000, 1)))
+    assert abs(z.mean()) < 0.01 and abs(z.var() - 1.0) < 0.02
+    u = prov.download(prov.random_uniform((50000, 1)))
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.01
+
+
+# ---- workloads / golden ------------------------------------------------------------------------
+@pytest.mark.parametrize("case", golden_monte_carlo_cases()[:2], ids=lambda c: f"M{c['M']}_T{c['T']}")
+def test_lcg_monte_carlo_vs_oracle_and_reference_golden(prov, oracle, case):
+    g = lcg_monte_carlo_price(ProviderOps(prov), case["M"], case["T"])
+    o = lcg_monte_carlo_price(OracleOps(oracle), case["M"], case["T"])
+    assert abs(g - o) <= 1e-10 * max(1.0, abs(o))          # rel 1e-10
+    assert abs(g - case["price"]) <= 2e-4 * max(1.0, abs(case["price"]))  # the reference script's own output (f32 pipeline)
+
+
+def test_rng_monte_carlo_price_vs_oracle(prov, oracle):
+    # benchmarks/monte-carlo-analysis/runmat_rng.m in f64 on the CPU-parity randn stream
+    M, T = 200000, 4
+    S0, mu, sigma, dt, K = 100.0, 0.05, 0.2, 1.0 / 252.0, 100.0
+    drift, scale = (mu - 0.5 * sigma * sigma) * dt, sigma * math.sqrt(dt)
+    prov.rng_seed(0)
+    S = prov.fill((M, 1), S0)
+    for _ in range(T):
+        Z = prov.random_normal((M, 1))
+        S = prov.elem_mul(S, prov.unary_exp(prov.scalar_add(prov.scalar_mul(Z, scale), drift)))
+    price = prov.download(prov.reduce_mean(prov.scalar_max(prov.scalar_sub(S, K), 0.0)))[0] * math.exp(-mu * T * dt)
+    want, state = oracle.monte_carlo_price(oracle.rng_default_seed(), M, T)
+    assert abs(price - want) <= 1e-10 * want
+    assert prov.get_rng_state() == state

@@ -1,0 +1,324 @@
+"""Pins the CPU oracle (oracle/oracle.c) against the reference's own known-answer tests and
+sequence definitions. Data below are the inputs / expected outputs the reference's
+tests hold; citations give the reference file:line of each vector."""
+import math
+
+import numpy as np
+import pytest
+
+
+def cm(data, shape):
+    """column-major data -> ndarray"""
+    return np.asarray(data, dtype=np.float64).reshape(shape, order="F")
+
+
+# ---- matmul ------------------------------------------------------------------------------------
+def test_matmul_2x3_3x2(oracle):
+    # crates/runmat-runtime/src/builtins/math/linalg/ops/mtimes.rs:495-503
+    a = np.array([[1, 2, 3], [4, 5, 6]], dtype=float)
+    b = np.array([[7, 8], [9, 10], [11, 12]], dtype=float)
+    assert np.array_equal(oracle.matmul(a, b), np.array([[58, 64], [139, 154]], dtype=float))
+
+
+def test_matmul_column_major_kat(oracle):
+    # mtimes.rs:688-706 (mtimes_gpu_roundtrip): column-major data [1,2,3,4] * [5,7,6,8] -> [26,38,30,44]
+    out = oracle.matmul(cm([1, 2, 3, 4], (2, 2)), cm([5, 7, 6, 8], (2, 2)))
+    assert list(out.reshape(-1, order="F")) == [26.0, 38.0, 30.0, 44.0]
+
+
+def test_matmul_dim_mismatch(oracle):
+    # mtimes.rs:628-637 / linalg.rs:7-15
+    with pytest.raises(ValueError, match="Inner matrix dimensions must agree"):
+        oracle.matmul(np.ones((2, 3)), np.ones((2, 3)))
+
+
+def test_matmul_small_k_generators(oracle):
+    # crates/runmat-accelerate/tests/matmul_small_k.rs:52-96: a[r,c]=(r+1)+0.25c, b[r,c]=(r+2c)%7, tol 1e-9
+    m, n, k = 64, 32, 4
+    a = np.fromfunction(lambda r, c: (r + 1) + 0.25 * c, (m, k))
+    b = np.fromfunction(lambda r, c: (r + 2 * c) % 7, (k, n))
+    assert np.max(np.abs(oracle.matmul(a, b) - a @ b)) < 1e-9
+
+
+def test_matmul_profile_generator(oracle):
+    # crates/runmat-accelerate/src/bin/wgpu_profile.rs:1219-1229: base + delta*((idx%128)/127)
+    def gen(rows, cols, base, delta):
+        idx = np.arange(rows * cols)
+        return (base + delta * ((idx % 128) / 127.0)).reshape((rows, cols), order="F")
+
+    a, b = gen(128, 96, 0.5, 1.5), gen(96, 64, -1.0, 2.0)
+    ref = a @ b
+    assert np.max(np.abs(oracle.matmul(a, b) - ref) / np.maximum(1.0, np.abs(ref))) < 1e-12
+
+
+def test_matmul_is_sequential_k_sum(oracle):
+    # linalg.rs:21-29: sum += a*b with k ascending, separate rounding of product and sum.
+    rng = np.random.default_rng(0)
+    a, b = rng.standard_normal((5, 300)), rng.standard_normal((300, 4))
+    out = oracle.matmul(a, b)
+    for i in range(5):
+        for j in range(4):
+            s = 0.0
+            for kk in range(300):
+                s += a[i, kk] * b[kk, j]
+            assert out[i, j] == s
+
+
+# ---- elementwise / broadcast -------------------------------------------------------------------
+def test_plus_times_kats(oracle):
+    # crates/runmat-runtime-integration-tests/tests/gpu.rs:28-60
+    a, b = cm([1, 2, 3, 4], (2, 2)), cm([5, 6, 7, 8], (2, 2))
+    assert np.array_equal(oracle.binary("add", a, b).reshape(-1, order="F"), [6, 8, 10, 12])
+    assert np.array_equal(oracle.binary("mul", a, b).reshape(-1, order="F"), [5, 12, 21, 32])
+
+
+def test_broadcast_shapes(oracle):
+    # crates/runmat-accelerate/src/graph.rs:252-271; broadcast.rs tests
+    assert oracle.binary("add", np.ones((4, 1)), np.ones((1, 3))).shape == (4, 3)
+    assert oracle.binary("add", np.ones((2, 3)), np.ones((2, 1))).shape == (2, 3)
+    with pytest.raises(ValueError):
+        oracle.binary("add", np.ones((2, 3)), np.ones((3, 2)))
+
+
+def test_broadcast_values_and_front_padding(oracle):
+    # broadcast.rs:108-115: shorter shape is FRONT-padded with ones (trailing dims align)
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((4, 1))
+    b = rng.standard_normal((1, 3))
+    assert np.array_equal(oracle.binary("mul", a, b), a * b)
+    c = rng.standard_normal((2, 3, 4))
+    d = rng.standard_normal((4,))  # rank-1 [4] aligns with the LAST dim after front padding
+    assert np.array_equal(oracle.binary("add", c, d), c + d.reshape(1, 1, 4))
+
+
+def test_max_min_nan_and_signed_zero(oracle):
+    # max.rs:2323-2344 (Include-NaN), :1715-1728 (-0 < +0); min.rs:1519-1531
+    a = np.array([[np.nan, 1.0, -0.0, 0.0, 3.0]])
+    b = np.array([[1.0, np.nan, 0.0, -0.0, 2.0]])
+    mx = oracle.binary("max", a, b).reshape(-1)
+    mn = oracle.binary("min", a, b).reshape(-1)
+    assert math.isnan(mx[0]) and math.isnan(mx[1]) and math.isnan(mn[0]) and math.isnan(mn[1])
+    assert mx[2] == 0.0 and not math.copysign(1, mx[2]) < 0 and not math.copysign(1, mx[3]) < 0
+    assert math.copysign(1, mn[2]) < 0 and math.copysign(1, mn[3]) < 0
+    assert mx[4] == 3.0 and mn[4] == 2.0
+
+
+def test_unary_semantics(oracle):
+    x = np.array([[-2.5, -0.5, 0.0, 0.5, 2.5, np.nan]])
+    assert np.array_equal(oracle.unary("round", x)[0, :5], [-3, -1, 0, 1, 3])  # half away from zero (round.rs:305)
+    assert np.array_equal(oracle.unary("fix", x)[0, :5], [-2, -0.0, 0, 0, 2])
+    s = oracle.unary("sign", x)[0]
+    assert list(s[:5]) == [-1, -1, 0, 1, 1] and math.isnan(s[5])  # sign.rs:236-246
+    h = oracle.unary("heaviside", x)[0]
+    assert list(h[:5]) == [0, 0, 0.5, 1, 1] and math.isnan(h[5])  # fusion.rs:2945-2953
+    assert np.array_equal(oracle.unary("sin", x[:, :5]), np.sin(x[:, :5]))  # same libm
+
+
+def test_mod_rem_select_chain(oracle):
+    # fusion.rs:2954-2970; cases from crates/runmat-vm/tests/fusion_gpu.rs:2965-3020
+    a = np.array([[5.0, -5.0, 5.0, -5.0, 5.0, -5.0, 0.0]])
+    b = np.array([[3.0, 3.0, -3.0, -3.0, np.inf, np.inf, np.inf]])
+    assert np.array_equal(oracle.binary("mod", a, b)[0], [2.0, 1.0, -1.0, -2.0, 5.0, np.inf, 0.0])
+    assert np.array_equal(oracle.binary("rem", a, b)[0], [2.0, -2.0, 2.0, -2.0, 5.0, -5.0, 0.0])
+
+
+# ---- reductions --------------------------------------------------------------------------------
+def test_fused_reduction_sum_mul_kat(oracle):
+    # crates/runmat-accelerate/tests/fused_reduction_sum_mul.rs:40-137: X[r,c]=r+1, W[r,c]=c+1,
+    # sum over rows of X.*W per column, tol 1e-6
+    rows, cols = 37, 11
+    X = np.fromfunction(lambda r, c: r + 1.0, (rows, cols))
+    W = np.fromfunction(lambda r, c: c + 1.0, (rows, cols))
+    got = oracle.reduce_sum(oracle.binary("mul", X, W), [0]).reshape(-1)
+    want = np.array([(c + 1) * rows * (rows + 1) / 2 for c in range(cols)])
+    assert np.max(np.abs(got - want)) < 1e-6
+
+
+def test_nlms_column_reductions(oracle):
+    # crates/runmat-runtime/tests/reduction_parity.rs:71-125 (f32 data; here the same values in f64)
+    x = cm([0.1, 0.2, 0.3, 0.4, -0.5, -0.4, -0.3, -0.2, 0.9, 0.7, 0.5, 0.3], (4, 3))
+    w = cm([0.05, 0.1, 0.15, 0.2, 0.8, 0.6, 0.4, 0.2, -0.3, -0.2, -0.1, 0.0], (4, 3))
+    got = oracle.reduce_sum(oracle.binary("mul", x, w), [0])
+    assert got.shape == (1, 3)
+    assert np.max(np.abs(got.reshape(-1) - np.sum(x * w, axis=0))) < 1e-12
+
+
+def test_sum_output_shapes_and_order(oracle):
+    # simple_provider.rs:6728-6806 shapes; sum.rs:1031-1053 ascending linear order per output
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((7, 5))
+    assert oracle.reduce_sum(X, "all").shape == (1, 1)
+    assert oracle.reduce_sum(X, [0]).shape == (1, 5)
+    assert oracle.reduce_sum(X, [1]).shape == (7, 1)
+    r = oracle.reduce_sum(X, [1]).reshape(-1)
+    for i in range(7):
+        s = 0.0
+        for c in range(5):
+            s += X[i, c]
+        assert r[i] == s
+    tot = 0.0
+    for v in X.reshape(-1, order="F"):
+        tot += v
+    assert oracle.reduce_sum(X, "all")[0, 0] == tot
+
+
+def test_sum_nan_policy_and_mean(oracle):
+    # sum.rs:1038-1045,1058-1066 (include => NaN, omit skips); mean.rs:1134-1151 divides by the count
+    X = np.array([[1.0, np.nan], [2.0, 4.0]])
+    inc = oracle.reduce_sum(X, [0]).reshape(-1)
+    assert inc[0] == 3.0 and math.isnan(inc[1])
+    om = oracle.reduce_sum(X, [0], omitnan=True).reshape(-1)
+    assert list(om) == [3.0, 4.0]
+    assert oracle.reduce_sum(np.array([[1.0, 2.0, 4.0]]), "all", mean=True)[0, 0] == 7.0 / 3.0
+    assert oracle.reduce_sum(X, [0], omitnan=True, mean=True).reshape(-1)[1] == 4.0
+
+
+def test_sum_rows_of_sin_x_times_x(oracle):
+    # crates/runmat-vm/tests/fusion_gpu.rs:1429-1449: X(r,c)=10c+r (1-based), S=sum(sin(X).*X+2, 2)
+    rows, cols = 64, 48
+    X = np.fromfunction(lambda r, c: (c + 1) * 10.0 + (r + 1), (rows, cols))
+    Y = oracle.binary("add", oracle.binary("mul", oracle.unary("sin", X), X), np.array([[2.0]]))
+    S = oracle.reduce_sum(Y, [1]).reshape(-1)
+    ref = np.sum(np.sin(X) * X + 2.0, axis=1)
+    assert np.max(np.abs(S - ref)) < 1e-9
+
+
+# ---- RNG ---------------------------------------------------------------------------------------
+def test_rng_constants_and_seed(oracle):
+    # random.rs:7-13, 128-141: default seed, rng(0) == default, splitmix mixing for nonzero seeds
+    assert oracle.rng_default_seed() == 0x9E3779B97F4A7C15
+    assert oracle.rng_mix_seed(0) == 0x9E3779B97F4A7C15
+    z = (42 + 0x9E3779B97F4A7C15) & (2**64 - 1)
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+    assert oracle.rng_mix_seed(42) == z ^ (z >> 31)
+
+
+def test_rng_uniform_sequence_definition(oracle):
+    # random.rs:271-278 + expected_uniform_sequence :613-621: s<-s*6364136223846793005+1, (s>>11)*2^-53
+    s = 0x9E3779B97F4A7C15
+    want = []
+    for _ in range(9):
+        s = (s * 6364136223846793005 + 1) & (2**64 - 1)
+        want.append((s >> 11) * (1.0 / (1 << 53)))
+    got, state = oracle.rng_uniform(0x9E3779B97F4A7C15, 9)
+    assert list(got) == want and state == s
+    assert oracle.rng_advance(0x9E3779B97F4A7C15, 9) == s  # advance_state :238-256
+
+
+def test_rng_normal_sequence_definition(oracle):
+    # random.rs:279-288, 530-543, expected_normal_sequence :631-643: consecutive (z0, z1) pairs
+    s = 0x9E3779B97F4A7C15
+    want = []
+
+    def nxt():
+        nonlocal s
+        s = (s * 6364136223846793005 + 1) & (2**64 - 1)
+        return (s >> 11) * (1.0 / (1 << 53))
+
+    while len(want) < 7:
+        u1 = nxt() or 2.2250738585072014e-308
+        u2 = nxt()
+        r = math.sqrt(-2.0 * math.log(u1))
+        ang = 2.0 * math.pi * u2
+        want.append(r * math.cos(ang))
+        if len(want) < 7:
+            want.append(r * math.sin(ang))
+    got, state = oracle.rng_normal(0x9E3779B97F4A7C15, 7)
+    assert list(got) == want
+    assert state == s  # odd length still consumes the whole last pair
+
+
+def test_rng_moments(oracle):
+    # crates/runmat-runtime/tests/rng.rs:19-63: |mean| < 0.01, |var-1| < 0.02 at n = 50 000
+    z, _ = oracle.rng_normal(oracle.rng_default_seed(), 50000)
+    assert abs(z.mean()) < 0.01 and abs(z.var() - 1.0) < 0.02
+
+
+# ---- LU / mldivide -----------------------------------------------------------------------------
+def test_lu_matches_scipy_and_pivot_rule(oracle):
+    import scipy.linalg as sl
+
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((9, 9))
+    comb, L, U, P, piv = oracle.lu(A)
+    assert np.allclose(P @ A, L @ U, atol=1e-12)          # host_lu.rs: P*A = L*U
+    p_s, l_s, u_s = sl.lu(A)                                 # A = p l u
+    assert np.allclose(L, l_s, atol=1e-12) and np.allclose(U, u_s, atol=1e-12)
+    assert np.array_equal(P, p_s.T)
+    assert np.array_equal(piv.reshape(-1) - 1, np.argmax(P, axis=1))  # 1-based row ids, host_lu.rs:107
+
+
+def test_lu_first_max_tie_break_and_singular_cut(oracle):
+    # host_lu.rs:38-47: strict '>' keeps the FIRST maximal row; :54-59: |pivot| <= 1e-12 zeroes the column
+    A = np.array([[1.0, 2.0], [-1.0, 5.0]])
+    _, _, _, _, piv = oracle.lu(A)
+    assert list(piv.reshape(-1)) == [1.0, 2.0]
+    S = np.array([[1e-13, 1.0], [5e-13, 2.0]])
+    comb, L, U, P, piv = oracle.lu(S)
+    assert list(piv.reshape(-1)) == [2.0, 1.0]  # swap happens before the cut-off check
+    assert comb[1, 0] == 0.0                     # sub-column zeroed, no elimination
+    assert comb[1, 1] == 1.0
+
+
+def test_lu_rectangular_shapes(oracle):
+    rng = np.random.default_rng(4)
+    for shape in [(6, 4), (4, 6)]:
+        A = rng.standard_normal(shape)
+        comb, L, U, P, piv = oracle.lu(A)
+        assert L.shape == (shape[0], shape[0]) and U.shape == shape  # host_lu.rs:72-100
+        assert np.allclose(P @ A, L @ U, atol=1e-12)
+
+
+def test_mldivide_square_residual(oracle):
+    # mldivide.rs:662-680: A=[1 2;3 4] (column-major 1,3,2,4), b=[5;6], ||Ax-b|| < 1e-12
+    A, b = cm([1, 3, 2, 4], (2, 2)), cm([5, 6], (2, 1))
+    for solve in (oracle.mldivide_svd, oracle.mldivide_lu):
+        x = solve(A, b)
+        assert np.linalg.norm(A @ x - b) < 1e-12
+
+
+def test_mldivide_least_squares_residual(oracle):
+    # mldivide.rs:682-696: 3x2 least squares, compare with the minimum-norm solution, tol 1e-10
+    A, b = cm([1, 3, 5, 2, 4, 6], (3, 2)), cm([7, 8, 9], (3, 1))
+    x = oracle.mldivide_svd(A, b)
+    ref = np.linalg.lstsq(A, b, rcond=None)[0]
+    assert np.linalg.norm(x - ref) < 1e-10
+    assert np.linalg.norm(A.T @ (A @ x - b)) < 1e-10
+
+
+def test_mldivide_scalar_and_rank_deficient(oracle):
+    # mldivide.rs:321-325 scalar lhs; :396-404 tolerance drops tiny singular values (min-norm solution)
+    assert np.array_equal(oracle.mldivide_svd(np.array([[4.0]]), np.array([[2.0, 8.0]])), [[0.5, 2.0]])
+    A = np.array([[1.0, 2.0], [2.0, 4.0]])
+    b = np.array([[1.0], [2.0]])
+    x = oracle.mldivide_svd(A, b)
+    assert np.allclose(x, np.linalg.pinv(A) @ b, atol=1e-12)
+
+
+def test_mldivide_svd_vs_lu_well_conditioned(oracle):
+    rng = np.random.default_rng(5)
+    n = 40
+    A = rng.uniform(-1, 1, (n, n)) + n * np.eye(n)
+    b = A @ np.ones((n, 1))
+    assert np.max(np.abs(oracle.mldivide_svd(A, b) - 1.0)) < 1e-12
+    assert np.max(np.abs(oracle.mldivide_lu(A, b) - 1.0)) < 1e-12
+
+
+# ---- workloads ---------------------------------------------------------------------------------
+def test_benchmark_chains_equal_composed_builtins(oracle):
+    rng = np.random.default_rng(6)
+    A, B, C = rng.uniform(-3, 3, (33, 17)), rng.uniform(-1, 1, (33, 17)), rng.uniform(-1, 1, (33, 17))
+    d = oracle.sin_mul_add(A, B, C)
+    assert np.array_equal(d, oracle.binary("add", oracle.binary("mul", oracle.unary("sin", A), B), C))
+    x = np.linspace(0, 4 * np.pi, 1001).reshape(-1, 1)
+    y0 = np.sin(x) * np.exp(-x / 10.0)
+    y1 = y0 * np.cos(x / 4.0) + 0.25 * np.power(y0, 2.0)
+    y2 = np.tanh(y1) + 0.1 * y1
+    assert np.max(np.abs(oracle.elementwise_math_chain(x) - y2)) < 1e-15
+
+
+def test_fill_uniform_is_counter_based(oracle):
+    a = oracle.fill_uniform(7, -1.0, 1.0, 1000)
+    assert np.all(a >= -1.0) and np.all(a < 1.0) and abs(a.mean()) < 0.1
+    assert np.array_equal(a[:10], oracle.fill_uniform(7, -1.0, 1.0, 10))

@@ -1,0 +1,97 @@
+"""Workloads written once against a tiny op-adapter so the SAME op sequence runs on the oracle
+(numpy arrays, CPU restatement) and on the HipProvider (device handles, C ABI)."""
+import json
+from pathlib import Path
+
+import numpy as np
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+class OracleOps:
+    """CPU side: each method is one reference builtin on the oracle."""
+
+    def __init__(self, oracle):
+        self.o = oracle
+
+    def tensor(self, a):
+        return np.asarray(a, dtype=np.float64)
+
+    def unary(self, op, a):
+        return self.o.unary(op, a)
+
+    def binary(self, op, a, b):
+        return self.o.binary(op, a, b)
+
+    def scalar(self, op, a, s):
+        s = np.array([[float(s)]])
+        if op == "rsub":
+            return self.o.binary("sub", s, a)
+        if op == "rdiv":
+            return self.o.binary("div", s, a)
+        return self.o.binary(op, a, s)
+
+    def mean_all(self, a):
+        return float(self.o.reduce_sum(a, "all", mean=True).reshape(-1)[0])
+
+    def sum_all(self, a):
+        return float(self.o.reduce_sum(a, "all").reshape(-1)[0])
+
+    def free(self, a):
+        pass
+
+
+class ProviderOps:
+    """GPU side: the same ops through the C ABI (per-op kernels)."""
+
+    def __init__(self, prov):
+        self.p = prov
+
+    def tensor(self, a):
+        return self.p.upload(np.asarray(a, dtype=np.float64))
+
+    def unary(self, op, a):
+        return getattr(self.p, "unary_" + op)(a)
+
+    def binary(self, op, a, b):
+        return self.p._binary(op, a, b)
+
+    def scalar(self, op, a, s):
+        return self.p._scalar(op, a, s)
+
+    def mean_all(self, a):
+        return float(self.p.download(self.p.reduce_mean(a))[0])
+
+    def sum_all(self, a):
+        return float(self.p.download(self.p.reduce_sum(a))[0])
+
+    def free(self, a):
+        self.p.free(a)
+
+
+def lcg_monte_carlo_price(ops, M, T, S0=100.0, mu=0.05, sigma=0.2, dt=1.0 / 252.0, K=100.0, seed=0):
+    """benchmarks/monte-carlo-analysis/runmat_lcg.m:27-52 in f64 (drift/scale pre-rounded through
+    f32 exactly as the reference scripts do)."""
+    drift = float(np.float32((mu - 0.5 * sigma * sigma) * dt))
+    scale = float(np.float32(sigma) * np.sqrt(np.float32(dt)))
+    rid = ops.tensor(np.arange(M, dtype=np.float64).reshape(M, 1))
+    S = ops.tensor(np.full((M, 1), S0))
+    two32 = ops.tensor(np.array([[4294967296.0]]))
+    for t in range(T):
+        salt = float(t) * 2.0 * M
+        idx1 = ops.scalar("add", rid, salt + seed)
+        idx2 = ops.scalar("add", rid, salt + M + seed)
+        st1 = ops.binary("mod", ops.scalar("add", ops.scalar("mul", idx1, 1664525.0), 1013904223.0), two32)
+        st2 = ops.binary("mod", ops.scalar("add", ops.scalar("mul", idx2, 1664525.0), 1013904223.0), two32)
+        u1 = ops.scalar("max", ops.scalar("div", st1, 4294967296.0), 1.0 / 4294967296.0)
+        u2 = ops.scalar("div", st2, 4294967296.0)
+        r = ops.unary("sqrt", ops.scalar("mul", ops.unary("log", u1), -2.0))
+        theta = ops.scalar("mul", u2, 2.0 * np.pi)
+        z = ops.binary("mul", r, ops.unary("cos", theta))
+        S = ops.binary("mul", S, ops.unary("exp", ops.scalar("add", ops.scalar("mul", z, scale), drift)))
+    payoff = ops.scalar("max", ops.scalar("sub", S, K), 0.0)
+    return ops.mean_all(payoff) * float(np.exp(-mu * T * dt))
+
+
+def golden_monte_carlo_cases():
+    return json.loads((GOLDEN / "monte_carlo_lcg.json").read_text())["cases"]
