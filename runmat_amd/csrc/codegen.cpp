@@ -39,12 +39,48 @@ static int env_int(const char* name, int dflt, int lo, int hi) {
 
 EwTuning EwTuning::from_env() {
     EwTuning t;
-    t.unroll = env_int("RMHIP_EW_UNROLL", t.unroll, 1, 8);
+    t.unroll = env_int("RMHIP_EW_UNROLL", t.unroll, 0, 8);
     t.block = env_int("RMHIP_EW_BLOCK", t.block, 64, 1024);
     t.block = (t.block / 64) * 64;
     t.blocks_per_cu = env_int("RMHIP_EW_BLOCKS_PER_CU", t.blocks_per_cu, 1, 64);
-    t.nontemporal = env_int("RMHIP_EW_NT", t.nontemporal, 0, 1);
+    t.nt_load = env_int("RMHIP_EW_NT_LOAD", env_int("RMHIP_EW_NT", t.nt_load, 0, 1), 0, 1);
+    t.nt_store = env_int("RMHIP_EW_NT_STORE", env_int("RMHIP_EW_NT", t.nt_store, 0, 1), 0, 1);
+    t.chunked = env_int("RMHIP_EW_CHUNKED", t.chunked, 0, 1);
     return t;
+}
+
+int EwTuning::unroll_for(int n_streamed_inputs, bool heavy_math) const {
+    if (unroll > 0) return unroll;
+    // scripts/tune_ew.py on MI355X, 8192^2 f64 (GB/s at unroll 1 / 4):
+    //   sin(A).*B+C 5974 / ~4500   A.*B+C ~4500 / 6001   A+B 6079 / ~5200   copy 5866 / ~5200   sin(A) 5458 / ~4900
+    // libm-heavy bodies want occupancy (unroll 1); a pure-arithmetic body over >= 3 equally sized
+    // streams runs into same-offset HBM channel contention unless each thread spreads its
+    // accesses (unroll 4).
+    if (heavy_math) return 1;
+    return n_streamed_inputs >= 3 ? 4 : 1;
+}
+
+static bool expr_is_heavy(const ExprPtr& e) {
+    if (!e) return false;
+    if (e->kind == Expr::Call) {
+        static const char* cheap[] = {"abs", "floor", "ceil", "round", "trunc", "sign", "max", "min", "isNan",
+                                      "isNanF", "isInf", "isFinite", "f32", "sqrt"};
+        bool is_cheap = false;
+        for (const char* c : cheap) is_cheap |= (e->op == c);
+        if (!is_cheap) return true;
+    }
+    if (e->kind == Expr::Binary && e->op == "/") return true;  // f64 division expands to ~10 VALU ops
+    for (const auto& a : e->args)
+        if (expr_is_heavy(a)) return true;
+    return false;
+}
+
+bool program_is_heavy(const ElementwiseProgram& p) {
+    for (const auto& st : p.lets)
+        if (expr_is_heavy(st.expr)) return true;
+    for (const auto& o : p.outputs)
+        if (expr_is_heavy(o)) return true;
+    return false;
 }
 
 FusedKernel::~FusedKernel() {
@@ -70,21 +106,36 @@ static std::string body_function(const ElementwiseProgram& p) {
 // once into an SGPR-resident value instead of being streamed.
 static void emit_fast_kernel(std::ostringstream& s, const ElementwiseProgram& p, const EwTuning& t, int vec,
                              unsigned mask, const char* name) {
-    const int nin = p.n_inputs, nout = (int)p.outputs.size(), U = t.unroll;
+    const int nin = p.n_inputs, nout = (int)p.outputs.size();
     const char* vt = vec == 2 ? "rm_v2" : "double";
     auto is_scalar = [&](int k) { return (mask >> k) & 1u; };
+    int n_stream = 0;
+    for (int k = 0; k < nin; ++k) n_stream += is_scalar(k) ? 0 : 1;
+    const int U = t.unroll_for(n_stream, program_is_heavy(p));
     s << "extern \"C\" __global__ void __launch_bounds__(" << t.block << ") " << name << "(";
     for (int k = 0; k < nin; ++k) s << "const double* __restrict__ in" << k << ", ";
     for (int k = 0; k < nout; ++k) s << "double* __restrict__ out" << k << ", ";
     s << "const rm_u64 n) {\n";
-    s << "    const rm_u64 nvec = n / " << vec << ";\n";
-    s << "    const rm_u64 stride = (rm_u64)gridDim.x * " << t.block << ";\n";
-    s << "    rm_u64 i = (rm_u64)blockIdx.x * " << t.block << " + threadIdx.x;\n";
+    s << "    const rm_u64 nvec_all = n / " << vec << ";\n";
+    if (t.chunked) {
+        // contiguous chunk per block (multiple of the per-iteration footprint), block-stride inside
+        s << "    const rm_u64 per_iter = " << (t.block * U) << "ull;\n";
+        s << "    rm_u64 chunk = (nvec_all + gridDim.x - 1) / gridDim.x;\n";
+        s << "    chunk = (chunk + per_iter - 1) / per_iter * per_iter;\n";
+        s << "    const rm_u64 begin = (rm_u64)blockIdx.x * chunk;\n";
+        s << "    const rm_u64 nvec = begin + chunk < nvec_all ? begin + chunk : nvec_all;\n";
+        s << "    const rm_u64 stride = " << t.block << "ull;\n";
+        s << "    rm_u64 i = begin + threadIdx.x;\n";
+    } else {
+        s << "    const rm_u64 nvec = nvec_all;\n";
+        s << "    const rm_u64 stride = (rm_u64)gridDim.x * " << t.block << ";\n";
+        s << "    rm_u64 i = (rm_u64)blockIdx.x * " << t.block << " + threadIdx.x;\n";
+    }
     for (int k = 0; k < nin; ++k)
         if (is_scalar(k)) s << "    const double s" << k << " = in" << k << "[0];\n";
     auto load = [&](int k, const std::string& idx, const std::string& dst) {
         if (is_scalar(k)) return;
-        s << "        const " << vt << " " << dst << " = " << (t.nontemporal ? "__builtin_nontemporal_load" : "*")
+        s << "        const " << vt << " " << dst << " = " << (t.nt_load ? "__builtin_nontemporal_load" : "*")
           << "((const " << vt << "*)in" << k << " + (" << idx << "));\n";
     };
     auto operand = [&](int k, const std::string& sfx, const char* comp) {
@@ -112,7 +163,7 @@ static void emit_fast_kernel(std::ostringstream& s, const ElementwiseProgram& p,
             s << ");\n";
         }
         for (int k = 0; k < nout; ++k) {
-            if (t.nontemporal)
+            if (t.nt_store)
                 s << "        __builtin_nontemporal_store(r" << k << sfx << ", (" << vt << "*)out" << k << " + (" << idx << "));\n";
             else
                 s << "        *((" << vt << "*)out" << k << " + (" << idx << ")) = r" << k << sfx << ";\n";
@@ -145,8 +196,10 @@ static void emit_fast_kernel(std::ostringstream& s, const ElementwiseProgram& p,
     s << "}\n\n";
 }
 
+static constexpr int kBcastElems = 4;  // elements per thread along dim 0 in the broadcast kernel
+
 static void emit_bcast_kernel(std::ostringstream& s, const ElementwiseProgram& p, const EwTuning& t) {
-    const int nin = p.n_inputs, nout = (int)p.outputs.size(), E = t.unroll;
+    const int nin = p.n_inputs, nout = (int)p.outputs.size(), E = kBcastElems;
     // params: v[0]=d0, v[1]=nchunks, v[2]=rank, v[3..10]=shape, v[11+8k .. ] = stride of input k
     s << "struct RmBcast { rm_u64 v[" << (11 + 8 * nin) << "]; };\n";
     s << "extern \"C\" __global__ void __launch_bounds__(" << t.block << ") rm_ew_bcast(";
@@ -289,7 +342,7 @@ int get_elementwise_kernel(Context* c, const ElementwiseProgram& p, unsigned mas
                            std::shared_ptr<FusedKernel>* out) {
     EwTuning t = EwTuning::from_env();
     char tun[96];
-    std::snprintf(tun, sizeof tun, "|u%d|b%d|nt%d|m%x", t.unroll, t.block, t.nontemporal, mask);
+    std::snprintf(tun, sizeof tun, "|u%d|b%d|nt%d%d|c%d|m%x", t.unroll, t.block, t.nt_load, t.nt_store, t.chunked, mask);
     const uint64_t key = fnv1a(p.canonical + tun);
     {
         std::lock_guard<std::mutex> lk(c->mu);

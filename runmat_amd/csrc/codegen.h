@@ -14,11 +14,17 @@
 namespace rmhip {
 
 struct EwTuning {
-    int unroll = 4;        // independent 16-byte vectors in flight per thread (fast path)
+    int unroll = 0;        // independent 16-byte vectors in flight per thread; 0 = pick from the stream count
     int block = 256;
-    int blocks_per_cu = 8; // grid cap = blocks_per_cu * CUs (grid-stride beyond that)
-    int nontemporal = 1;   // non-temporal loads/stores on the streaming fast path
+    int blocks_per_cu = 16; // grid cap = blocks_per_cu * CUs (grid-stride beyond that)
+    int nt_load = 1;       // non-temporal loads on the streaming fast path
+    int nt_store = 1;      // non-temporal stores
+    int chunked = 0;       // 1: each block walks one contiguous chunk instead of a grid-stride loop
     static EwTuning from_env();
+    // Measured on MI355X (scripts/tune_ew.py): what matters is bytes in flight per thread versus
+    // occupancy. Three streamed inputs already put 48 B per thread in flight, and unrolling only
+    // costs VGPRs (sin is register hungry): unroll 1 ran 5.9 TB/s, unroll 8 4.2 TB/s.
+    int unroll_for(int n_streamed_inputs, bool heavy_math) const;
 };
 
 struct FusedKernel {
@@ -33,6 +39,9 @@ struct FusedKernel {
     EwTuning tuning;
     ~FusedKernel();
 };
+
+// True if the body calls libm-class functions or divides (register hungry: prefers occupancy).
+bool program_is_heavy(const ElementwiseProgram& p);
 
 // Source generation (no GPU needed).
 std::string generate_elementwise_source(const ElementwiseProgram& p, const EwTuning& t, unsigned scalar_mask);

@@ -15,11 +15,11 @@ namespace rmhip {
 typedef double v2 __attribute__((ext_vector_type(2)));
 
 static constexpr int kBlock = 256;
-static constexpr int kUnroll = 4;
+static constexpr int kUnroll = 1;  // measured best for 1-2 stream kernels (scripts/tune_ew.py): occupancy over unrolling
 
 static inline unsigned stream_grid(const Context* c, size_t nvec) {
     size_t want = (nvec + (size_t)kBlock * kUnroll - 1) / ((size_t)kBlock * kUnroll);
-    size_t cap = (size_t)c->num_cus * 8;
+    size_t cap = (size_t)c->num_cus * 16;
     if (want < 1) want = 1;
     return (unsigned)(want < cap ? want : cap);
 }
@@ -116,10 +116,10 @@ __global__ void __launch_bounds__(kBlock) k_stream1(const double* __restrict__ a
         }
     }
     for (; i < nvec; i += stride) {
-        v2 x = av[i], r;
+        v2 x = __builtin_nontemporal_load(av + i), r;
         r.x = f(x.x);
         r.y = f(x.y);
-        ov[i] = r;
+        __builtin_nontemporal_store(r, ov + i);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = f(a[n - 1]);
 }
@@ -149,10 +149,10 @@ __global__ void __launch_bounds__(kBlock) k_stream2(const double* __restrict__ a
         }
     }
     for (; i < nvec; i += stride) {
-        v2 x = av[i], y = bv[i], r;
+        v2 x = __builtin_nontemporal_load(av + i), y = __builtin_nontemporal_load(bv + i), r;
         r.x = f(x.x, y.x);
         r.y = f(x.y, y.y);
-        ov[i] = r;
+        __builtin_nontemporal_store(r, ov + i);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = f(a[n - 1], b[n - 1]);
 }

@@ -24,15 +24,13 @@ namespace {
 
 // Front-pad `shape` to `rank` (broadcast.rs:108-115, elementwise.rs:1681-1687) and derive strides
 // with 0 on broadcast (extent 1) dims.  Returns false if the shape cannot broadcast to `out`.
-bool padded_strides(const std::vector<size_t>& shape, const size_t* out, size_t rank, std::vector<uint64_t>* strides) {
-    if (shape.size() > rank) {
-        // allow leading/trailing singleton excess (e.g. [1,1] scalar against a rank-1 request)
-        size_t numel = 1;
-        for (size_t d : shape) numel *= d;
-        if (numel != 1) return false;
-        strides->assign(rank, 0);
-        return true;
-    }
+bool padded_strides(const std::vector<size_t>& shape_in, const size_t* out, size_t rank, std::vector<uint64_t>* strides) {
+    // MATLAB shapes carry implicit trailing singletons ([n,1] == [n]): an operand of higher rank
+    // than the request is first stripped of trailing, then leading, extent-1 dims.
+    std::vector<size_t> shape = shape_in;
+    while (shape.size() > rank && !shape.empty() && shape.back() == 1) shape.pop_back();
+    while (shape.size() > rank && !shape.empty() && shape.front() == 1) shape.erase(shape.begin());
+    if (shape.size() > rank) return false;
     const size_t pad = rank - shape.size();
     strides->assign(rank, 0);
     uint64_t s = 1;
@@ -196,7 +194,10 @@ int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf*
         unsigned long long n = len;
         args.push_back(&n);
         const size_t work = vec_ok ? len / 2 : len;
-        size_t want = (work + (size_t)t.block * t.unroll - 1) / ((size_t)t.block * t.unroll);
+        int n_stream = 0;
+        for (size_t k = 0; k < n_in; ++k) n_stream += ((mask >> k) & 1u) ? 0 : 1;
+        const size_t per_block = (size_t)t.block * t.unroll_for(n_stream, program_is_heavy(prog));
+        size_t want = (work + per_block - 1) / per_block;
         const size_t cap = (size_t)c->num_cus * t.blocks_per_cu;
         if (want < 1) want = 1;
         const unsigned grid = (unsigned)std::min(want, cap);
@@ -205,7 +206,7 @@ int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf*
     } else {
         std::vector<unsigned long long> p(11 + 8 * n_in, 0);
         const unsigned long long d0 = oshape[0];
-        const unsigned long long per_block = (unsigned long long)t.block * t.unroll;
+        const unsigned long long per_block = (unsigned long long)t.block * 4;  // kBcastElems in codegen.cpp
         const unsigned long long nchunks = (d0 + per_block - 1) / per_block;
         unsigned long long outer = 1;
         p[0] = d0;

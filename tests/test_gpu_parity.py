@@ -75,7 +75,8 @@ def test_fill_uniform_matches_oracle_bits(prov, oracle):
 
 # ---- fused elementwise -------------------------------------------------------------------------
 def _run_fused(prov, plan, out_ids, arrays, out_shape):
-    hs = [prov.upload(a) for a in arrays]
+    # keep numpy's exact shape (a rank-1 [n] must stay rank 1 for front-padding, broadcast.rs:108-115)
+    hs = [prov.upload(np.asarray(a, dtype=np.float64).reshape(-1, order="F"), np.shape(a)) for a in arrays]
     n = int(np.prod(out_shape))
     if isinstance(out_ids, int):
         sh = plan.generate_wgsl_for_output(out_ids, "f64")
