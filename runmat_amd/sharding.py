@@ -1,0 +1,217 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, `torch.distributed` (backend "nccl" is
+RCCL over xGMI on ROCm; "gloo" in the CPU tests) for the few real exchange steps.
+
+The reference has no multi-device code at all; this is new work, designed for how
+the path shards:
+
+  * elementwise / independent matrices : contiguous slabs of the column-major index, no exchange;
+  * C = A*B                            : row-block -- rank g computes C[rows_g,:] = A[rows_g,:]*B
+                                         with B replicated; all-gather of the row blocks only when
+                                         a replicated C is asked for;
+  * sum / mean / Monte-Carlo           : local partial + a ONE-value exchange, summed in rank order
+                                         so results do not depend on collective reduction order;
+  * randn                              : every rank skips ahead in the same 64-bit LCG stream
+                                         (random.rs:238-256), so the sharded stream IS the
+                                         single-device / CPU stream.
+
+Everything here is host logic over a provider object (`HipProvider`, or any object with the same
+methods -- the CPU tests use an oracle-backed double), so it is testable with world_size 2 on gloo.
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): the only bulk collective (all-gather of C)
+moves each row block once to every peer; everything else is a few bytes.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+LCG_MULT = 6364136223846793005
+LCG_INC = 1
+MASK64 = (1 << 64) - 1
+
+
+def partition(total: int, world: int, rank: int, granule: int = 1) -> Tuple[int, int]:
+    """Balanced contiguous split of `total` items in units of `granule`: [start, stop) of `rank`.
+    The first (units % world) ranks get one extra unit; the last rank absorbs the ragged tail."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    units = (total + granule - 1) // granule
+    base, extra = divmod(units, world)
+    u0 = rank * base + min(rank, extra)
+    u1 = u0 + base + (1 if rank < extra else 0)
+    return min(u0 * granule, total), min(u1 * granule, total)
+
+
+def lcg_advance(state: int, delta: int) -> int:
+    """advance_state of crates/runmat-runtime/src/builtins/common/random.rs:238-256."""
+    cur_mult, cur_plus, acc_mult, acc_plus = LCG_MULT, LCG_INC, 1, 0
+    while delta > 0:
+        if delta & 1:
+            acc_mult = (acc_mult * cur_mult) & MASK64
+            acc_plus = (acc_plus * cur_mult + cur_plus) & MASK64
+        cur_plus = (cur_plus * (cur_mult + 1)) & MASK64
+        cur_mult = (cur_mult * cur_mult) & MASK64
+        delta >>= 1
+    return (acc_mult * state + acc_plus) & MASK64
+
+
+@dataclass
+class Group:
+    """Thin view of the process group: rank, world and an ordered all-gather of small f64 vectors."""
+    rank: int = 0
+    world: int = 1
+    dist: Optional[object] = None  # torch.distributed module when world > 1
+    device: str = "cpu"            # "cuda" for nccl, "cpu" for gloo
+
+    @staticmethod
+    def from_env() -> "Group":
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            return Group(dist.get_rank(), dist.get_world_size(), dist, dev)
+        return Group()
+
+    def all_gather_f64(self, values: Sequence[float]) -> np.ndarray:
+        """Returns a [world, len(values)] array, row r = rank r's values (identical on all ranks)."""
+        local = np.asarray(values, dtype=np.float64).reshape(1, -1)
+        if self.world == 1:
+            return local
+        import torch
+
+        t = torch.from_numpy(local.copy()).to(self.device)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return np.concatenate([o.cpu().numpy() for o in out], axis=0)
+
+    def ordered_sum(self, value: float) -> float:
+        """Sum of one value per rank, accumulated in rank order (deterministic, same on every rank)."""
+        parts = self.all_gather_f64([value])[:, 0]
+        s = 0.0
+        for v in parts:
+            s += float(v)
+        return s
+
+    def barrier(self) -> None:
+        if self.world > 1:
+            self.dist.barrier()
+
+
+# ---- matmul ------------------------------------------------------------------------------------
+def row_block(rows: int, group: Group, granule: int = 128) -> Tuple[int, int]:
+    """Rows of A / C owned by this rank. Multiples of the dgemm tile height keep every rank on the
+    unguarded kernel when rows % (128*world) == 0."""
+    return partition(rows, group.world, group.rank, granule)
+
+
+def matmul_row_sharded(prov, a_rows, b):
+    """C[rows_g,:] = A[rows_g,:] * B. `a_rows` is this rank's row block (rows_g x k, its own
+    column-major buffer), `b` the replicated k x n operand. No collective."""
+    return prov.matmul(a_rows, b)
+
+
+def gather_row_blocks(group: Group, local_block: np.ndarray, rows_total: int) -> np.ndarray:
+    """Host-side reassembly of a replicated C from per-rank row blocks (used by tests and by callers
+    that need C on the host). `local_block` is rows_g x n."""
+    if group.world == 1:
+        return local_block
+    import torch
+
+    n = local_block.shape[1]
+    counts = [partition(rows_total, group.world, r, 128) for r in range(group.world)]
+    # column-major rows_g x n == row-major n x rows_g: gather the transposes, concatenate along dim 1
+    # all_gather needs equal sizes: ragged blocks are padded to the widest and trimmed afterwards
+    width = max(c1 - c0 for c0, c1 in counts)
+    mine = torch.zeros((width, n), dtype=torch.float64, device=group.device)
+    mine[: local_block.shape[0], :] = torch.from_numpy(np.ascontiguousarray(local_block)).to(group.device)
+    outs = [torch.empty_like(mine) for _ in counts]
+    group.dist.all_gather(outs, mine)
+    return torch.cat([o[: c1 - c0, :] for o, (c0, c1) in zip(outs, counts)], dim=0).cpu().numpy()
+
+
+def gather_row_blocks_device(group: Group, prov, c_rows, rows_total: int):
+    """Device-side all-gather (RCCL over xGMI) of C row blocks into a replicated rows_total x n
+    buffer owned by the provider. Zero-copy: torch views the provider's memory through
+    `rmhip_device_ptr`, the result is adopted with `rmhip_wrap_external`."""
+    import torch
+
+    rows_g, n = c_rows.shape
+    if group.world == 1:
+        return c_rows, None
+    counts = [partition(rows_total, group.world, r, 128) for r in range(group.world)]
+    width = max(c1 - c0 for c0, c1 in counts)
+    view = _torch_view(prov, c_rows, (n, rows_g))  # column-major rows_g x n == row-major n x rows_g
+    prov.synchronize()
+    if rows_g == width:
+        mine = view
+    else:  # ragged last block: pad to the widest so all_gather sees equal sizes
+        mine = torch.zeros((n, width), dtype=torch.float64, device="cuda")
+        mine[:, :rows_g] = view
+    outs = [torch.empty((n, width), dtype=torch.float64, device="cuda") for _ in counts]
+    group.dist.all_gather(outs, mine)
+    full = torch.cat([o[:, : c1 - c0] for o, (c0, c1) in zip(outs, counts)], dim=1).contiguous()
+    # (n, rows_total) row-major == column-major rows_total x n
+    torch.cuda.synchronize()
+    handle = prov.wrap_external(full.data_ptr(), (rows_total, n))
+    return handle, full  # keep `full` alive as long as the handle is used
+
+
+class _CudaArray:
+    def __init__(self, ptr: int, shape: Tuple[int, ...]):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (ptr, False), "version": 3,
+                                         "strides": None}
+
+
+def _torch_view(prov, handle, shape):
+    import torch
+
+    return torch.as_tensor(_CudaArray(prov.device_ptr(handle), shape), device="cuda")
+
+
+# ---- reductions --------------------------------------------------------------------------------
+def sum_all_sharded(prov, group: Group, local) -> float:
+    """sum(x,'all') of a tensor sharded in contiguous slabs: local device sum + ordered exchange."""
+    part = float(prov.download(prov.reduce_sum(local))[0])
+    return group.ordered_sum(part)
+
+
+# ---- Monte-Carlo (benchmarks/monte-carlo-analysis/runmat_rng.m, f64) ----------------------------
+def monte_carlo_price_sharded(prov, group: Group, M: int, T: int, S0=100.0, mu=0.05, sigma=0.2, dt=1.0 / 252.0,
+                              K=100.0, rng_state: Optional[int] = None) -> Tuple[float, int]:
+    """price = mean(max(S_T - K, 0)) * exp(-mu*T*dt) with S evolved by T randn steps.
+
+    Rank g owns paths [start, stop), start even (pair boundary of Box-Muller). At step t the global
+    generator would be at state_t = advance(state_0, t * 2*ceil(M/2)); rank g starts its draw at
+    advance(state_t, start). Returns (price, final global rng state) -- identical on every rank."""
+    if rng_state is None:
+        rng_state = prov.get_rng_state()
+    start, stop = partition(M, group.world, group.rank, granule=2)
+    count = stop - start
+    per_step = 2 * ((M + 1) // 2)
+    drift = (mu - 0.5 * sigma * sigma) * dt
+    scale = sigma * math.sqrt(dt)
+    partial = 0.0
+    if count > 0:
+        S = prov.fill((count, 1), S0)
+        for t in range(T):
+            prov.set_rng_state(lcg_advance(rng_state, t * per_step + start))
+            Z = prov.random_normal((count, 1))
+            zs = prov.scalar_mul(Z, scale)
+            zd = prov.scalar_add(zs, drift)
+            e = prov.unary_exp(zd)
+            S_next = prov.elem_mul(S, e)
+            for h in (Z, zs, zd, e, S):
+                prov.free(h)
+            S = S_next
+        diff = prov.scalar_sub(S, K)
+        payoff = prov.scalar_max(diff, 0.0)
+        psum = prov.reduce_sum(payoff)
+        partial = float(prov.download(psum)[0])
+        for h in (S, diff, payoff, psum):
+            prov.free(h)
+    total = group.ordered_sum(partial)
+    final_state = lcg_advance(rng_state, T * per_step)
+    prov.set_rng_state(final_state)
+    return (total / float(M)) * math.exp(-mu * T * dt), final_state

@@ -1,0 +1,111 @@
+"""Host logic of the multi-GPU path on CPU: partitioning, LCG skip-ahead, and world_size-2 runs of
+the sharded matmul / Monte-Carlo over gloo with an oracle-backed provider double."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def test_partition_covers_exactly_once():
+    from runmat_amd.sharding import partition
+
+    for total in (0, 1, 7, 128, 1000, 8192, 100_000_001):
+        for world in (1, 2, 3, 8):
+            for gran in (1, 2, 128):
+                spans = [partition(total, world, r, gran) for r in range(world)]
+                assert spans[0][0] == 0 and spans[-1][1] == total
+                for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+                    assert a1 == b0 and a0 <= a1
+                for s0, s1 in spans:
+                    if s1 > s0:  # non-empty spans start on a granule boundary
+                        assert s0 % gran == 0 and (s1 % gran == 0 or s1 == total)
+                sizes = [s1 - s0 for s0, s1 in spans]
+                assert max(sizes) - min(sizes) < 2 * gran or total < world * gran  # one granule + ragged tail
+
+
+def test_lcg_advance_matches_oracle(oracle):
+    from runmat_amd.sharding import lcg_advance
+
+    s0 = oracle.rng_default_seed()
+    for d in (0, 1, 2, 63, 64, 1000, 2**33 + 5, 2**63 + 11):
+        assert lcg_advance(s0, d) == oracle.rng_advance(s0, d)
+    _, s = oracle.rng_uniform(s0, 1234)
+    assert lcg_advance(s0, 1234) == s
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    from oracle import oracle
+    from oracle_provider import OracleProvider
+    from runmat_amd import sharding as sh
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        group = sh.Group.from_env()
+        assert group.rank == rank and group.world == world and group.device == "cpu"
+        prov = OracleProvider(oracle)
+        # --- row-sharded matmul: each rank builds ITS rows of A from the global generator ---
+        m, k, n = 384, 96, 160
+        A = oracle.fill_uniform(11, -1.0, 1.0, m * k).reshape(m, k, order="F")
+        B = oracle.fill_uniform(12, -1.0, 1.0, k * n).reshape(k, n, order="F")
+        r0, r1 = sh.row_block(m, group)
+        c_rows = sh.matmul_row_sharded(prov, prov.upload(A[r0:r1, :]), prov.upload(B))
+        C = sh.gather_row_blocks(group, c_rows.arr, m)
+        # --- Monte-Carlo with skip-ahead ---
+        M, T = 20001, 3  # odd M: the last pair is half used
+        price, state = sh.monte_carlo_price_sharded(prov, group, M, T, rng_state=oracle.rng_default_seed())
+        # --- ordered sum ---
+        total = group.ordered_sum(0.1 * (rank + 1))
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), C=C, price=price, state=np.uint64(state), total=total,
+                 r0=r0, r1=r1)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_world2_gloo_sharded_matmul_and_monte_carlo(oracle, tmp_path):
+    import torch.multiprocessing as mp
+
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    m, k, n = 384, 96, 160
+    A = oracle.fill_uniform(11, -1.0, 1.0, m * k).reshape(m, k, order="F")
+    B = oracle.fill_uniform(12, -1.0, 1.0, k * n).reshape(k, n, order="F")
+    ref = oracle.matmul(A, B)
+    assert (res[0]["r0"], res[0]["r1"], res[1]["r0"], res[1]["r1"]) == (0, 256, 256, 384)  # 128-row granules
+    for r in res:
+        assert np.array_equal(r["C"], ref)  # row blocks are computed exactly as the unsharded rows
+    # Monte-Carlo: same stream as one device (skip-ahead), same price up to the summation grouping
+    want, want_state = oracle.monte_carlo_price(oracle.rng_default_seed(), 20001, 3)
+    for r in res:
+        assert abs(float(r["price"]) - want) <= 1e-12 * want
+        assert int(r["state"]) == want_state
+    assert res[0]["price"] == res[1]["price"]  # ordered sum: bit-identical on every rank
+    assert res[0]["total"] == res[1]["total"] == 0.1 + 0.2
+
+
+def test_single_process_group_is_identity(oracle):
+    from oracle_provider import OracleProvider
+    from runmat_amd import sharding as sh
+
+    g = sh.Group()
+    assert g.ordered_sum(3.5) == 3.5 and sh.row_block(1000, g) == (0, 1000)
+    price, state = sh.monte_carlo_price_sharded(OracleProvider(oracle), g, 5000, 2, rng_state=oracle.rng_default_seed())
+    want, want_state = oracle.monte_carlo_price(oracle.rng_default_seed(), 5000, 2)
+    assert price == want and state == want_state
