@@ -51,6 +51,7 @@ struct GemmArgs {
     unsigned tiles_m, tiles_n;
     double alpha, beta;
     int rowmap;  // accumulator row formula selector (see store code)
+    int vec_a, vec_b;  // EDGE kernel: 16-byte loads are legal for A / B (aligned base, even leading dimension)
 };
 
 __device__ __forceinline__ void tile_of_block(const GemmArgs& g, unsigned& tm, unsigned& tn) {
@@ -107,8 +108,12 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
                 v2d v = {0.0, 0.0};
                 if (kk < g.k) {
                     const double* src = g.A + (size_t)kk * g.lda + mm;
-                    if (mm < g.m) v.x = src[0];
-                    if (mm + 1 < g.m) v.y = src[1];
+                    if (g.vec_a && mm + 1 < g.m) {
+                        v = *(const v2d*)src;
+                    } else {
+                        if (mm < g.m) v.x = src[0];
+                        if (mm + 1 < g.m) v.y = src[1];
+                    }
                 }
                 ra[p] = v;
             }
@@ -123,8 +128,12 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
                 v2d v = {0.0, 0.0};
                 if (nn < g.n) {
                     const double* src = g.B + (size_t)nn * g.ldb + kk;
-                    if (kk < g.k) v.x = src[0];
-                    if (kk + 1 < g.k) v.y = src[1];
+                    if (g.vec_b && kk + 1 < g.k) {
+                        v = *(const v2d*)src;
+                    } else {
+                        if (kk < g.k) v.x = src[0];
+                        if (kk + 1 < g.k) v.y = src[1];
+                    }
                 }
                 rb[p] = v;
             }
@@ -178,8 +187,14 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
     // epilogue: D[r][c] -> C[m = c][n = r];  c = lane & 15.
     // rowmap 0: r = 4*reg + (lane >> 4)   (f64 16x16x4 map per the CDNA4 guide)
     // rowmap 1: r = 4*(lane >> 4) + reg   (the f32-family map; kept selectable for bring-up)
+    // beta != 0 (LU trailing update): the 16 C values of one n-tile row are loaded together before
+    // any store, so the read-modify-write costs one memory round trip per group instead of 64
+    // serialized ones (a load cannot be hoisted above an earlier store to the same array).
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+        double* dst[16];
+        bool ok[16];
+        double prev[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned mm = m0 + wm * 64 + i * 16 + l15;
@@ -187,11 +202,22 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
             for (int r = 0; r < 4; ++r) {
                 const unsigned row = g.rowmap ? (4 * lq + r) : (4 * r + lq);
                 const unsigned nn = n0 + wn * 64 + j * 16 + row;
-                if (EDGE && (mm >= g.m || nn >= g.n)) continue;
-                double* dst = g.C + (size_t)nn * g.ldc + mm;
+                ok[i * 4 + r] = !EDGE || (mm < g.m && nn < g.n);
+                dst[i * 4 + r] = g.C + (size_t)nn * g.ldc + mm;
+            }
+        }
+        if (g.beta != 0.0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) prev[e] = ok[e] ? *dst[e] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = i * 4 + r;
                 double v = g.alpha * acc[j][i][r];
-                if (g.beta != 0.0) v = g.beta * (*dst) + v;
-                *dst = v;
+                if (g.beta != 0.0) v = g.beta * prev[e] + v;
+                if (ok[e]) *dst[e] = v;
             }
         }
     }
@@ -223,6 +249,8 @@ int launch_dgemm(Context* c, size_t m, size_t n, size_t k, double alpha, const d
     g.alpha = alpha;
     g.beta = beta;
     g.rowmap = g_rowmap;
+    g.vec_a = ((((uintptr_t)A & 15) == 0) && (lda % 2 == 0)) ? 1 : 0;
+    g.vec_b = ((((uintptr_t)B & 15) == 0) && (ldb % 2 == 0)) ? 1 : 0;
     const size_t lds_bytes = (size_t)(2 * A_TILE + 2 * B_TILE) * sizeof(double);
     const bool fast = (m % BM == 0) && (n % BN == 0) && (k % BK == 0) && k > 0 && (lda % 2 == 0) && (ldb % 2 == 0) &&
                       (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);

@@ -13,102 +13,193 @@
 // Every flop outside the <=16-column base panels runs in launch_dgemm (dgemm.hip) with K equal to
 // the half-width, so the top levels (where the flops are) see K in the thousands.
 // Triangular solves recurse the same way down to a 32x32 substitution kernel.
+#include <chrono>
 #include <vector>
 
 #include "common.h"
 
 namespace rmhip {
 
+static int g_lu_dbg = 0;  // RMHIP_LU_DEBUG developer switches (timing experiments only; results are wrong when set)
+
 static constexpr double LU_EPS = 1.0e-12;  // host_lu.rs:3
-static constexpr int BASE_W = 16;          // base panel width (columns factored one by one)
+static constexpr int BASE_W = 64;          // base panel width (columns factored one launch each)
 static constexpr int TRSM_W = 32;          // base triangular solve size
 
 struct LuState {
     Context* c;
     double* A;
     size_t rows, cols, lda;
-    int* ipiv;   // device: ipiv[k] = row swapped with k at step k (LAPACK style, 0-based)
-    int* info;   // device: number of pivots with |p| <= LU_EPS
-    double* piv; // device scratch: [0] = pivot value of the current column, [1] = skip flag
+    int* ipiv;        // device: ipiv[k] = position swapped with k at step k (LAPACK style, 0-based)
+    int* info;        // device: number of pivots with |p| <= LU_EPS
+    int* pos_of;      // device [rows]: current position of physical row r inside the base panel, -1 once retired
+    int* row_at;      // device [rows]: physical row currently at position p (only entries >= k are meaningful)
+    double* cand_abs; // device: [2][MAX_PANEL_BLOCKS] per-block arg-max candidates (double buffered by column parity)
+    int* cand_pos;    //         position of the candidate row
+    int* cand_row;    //         physical row of the candidate
+    int dbg;          // developer switches (RMHIP_LU_DEBUG): timing experiments only
 };
 
-// ---- base panel: one column at a time -----------------------------------------------------------
-// (1) pivot search over A[k..rows, k] by ONE block (the column is contiguous: coalesced), then the
-//     row swap restricted to the base panel's columns [c0, c1), host_lu.rs:38-52.
-__global__ void __launch_bounds__(1024) k_lu_pivot(double* __restrict__ A, size_t lda, size_t rows, size_t k,
-                                                   size_t c0, size_t c1, int* __restrict__ ipiv, int* __restrict__ info,
-                                                   double* __restrict__ piv) {
-    __shared__ double s_abs[16];
-    __shared__ unsigned long long s_idx[16];
-    __shared__ unsigned long long s_prow;
-    const double* col = A + k * lda;
-    double best = 0.0;
-    unsigned long long bidx = k;
-    for (size_t r = k + threadIdx.x; r < rows; r += blockDim.x) {  // ascending per thread: first max kept
-        const double a = fabs(col[r]);
-        if (a > best) {
-            best = a;
-            bidx = r;
+static constexpr int MAX_PANEL_BLOCKS = 1024;  // 64 rows per block => up to 65536 rows per panel
+static constexpr int PANEL_JT = 8;            // panel columns per thread (unrolled batch; keep the code small)
+static constexpr int PANEL_GROUPS = BASE_W / PANEL_JT;
+static constexpr int PANEL_THREADS = 64 * PANEL_GROUPS;
+
+// ---- base panel: ONE launch per column, lazy pivoting ----------------------------------------------
+// Inside a base panel rows are NOT moved: a pivot row simply retires where it lies, and the position
+// permutation the reference's tie-break needs ("first row in CURRENT order with strictly larger
+// |a|", host_lu.rs:38-47) is tracked in two small maps (pos_of / row_at).  The physical interchange
+// of the panel columns happens once per panel (k_laswp over ipiv), which yields exactly the layout
+// sequential swapping would have produced.
+//
+// Launch k (j0 <= k < c1) of a panel [j0, c1):
+//   1. reduce the candidates the previous launch left for column k -> pivot (prow, ppos)
+//   2. eliminate column k from every still-active row (multiplier by division, unfused
+//      multiply-subtract over the remaining panel columns, host_lu.rs:61-70)
+//   3. while doing so collect the arg-max candidates of column k+1 for the next launch
+// Launch "first" (k == j0 - 1) resets the maps and only performs step 3 for column j0.
+//
+// CODE SIZE IS THE PERFORMANCE KNOB: the kernel runs once per column on cold instruction caches, and
+// measured launch-to-launch time grows ~1 us per KB of straight-line code (a 64-column unrolled body
+// took ~20 us even with its loads and stores removed).  Hence rolled loops, no per-row record scans,
+// and only a PANEL_JT-deep unrolled load/update/store batch.
+__global__ void __launch_bounds__(PANEL_THREADS) k_lu_col(double* __restrict__ A, size_t lda, size_t rows, int j0, int k,
+                                                          int c1, int first, int nblocks, int* __restrict__ pos_of,
+                                                          int* __restrict__ row_at, int* __restrict__ ipiv,
+                                                          int* __restrict__ info, double* __restrict__ cand_abs,
+                                                          int* __restrict__ cand_pos, int* __restrict__ cand_row) {
+    __shared__ int s_piv[4];  // prow, ppos, occ, skip
+    __shared__ double s_prow_vals[BASE_W];
+    const int t = threadIdx.x;
+    const int lane = t & 63, grp = t >> 6;
+    const int next_col = first ? j0 : k + 1;
+    const bool want_next = next_col < c1;
+    const size_t r = (size_t)j0 + (size_t)blockIdx.x * 64 + lane;  // grid covers every row once
+    const int jbase = grp * PANEL_JT;
+    const int ncols = c1 - k;  // panel columns k .. c1-1 (relative 0 .. ncols-1)
+    const bool in_rows = r < rows;
+
+    // ---- independent global reads issued together (ONE memory round trip)
+    double v[PANEL_JT];
+    double akk = 0.0, nextv = 0.0;
+    int pos = (int)r;
+    if (in_rows) {
+        if (first) {
+            if (grp == 0) {
+                nextv = A[r + (size_t)next_col * lda];
+                pos_of[r] = (int)r;
+                row_at[r] = (int)r;
+            }
+        } else {
+            pos = pos_of[r];
+            akk = A[r + (size_t)k * lda];
+#pragma unroll
+            for (int jj = 0; jj < PANEL_JT; ++jj)
+                if (jbase + jj < ncols) v[jj] = A[r + (size_t)(k + jbase + jj) * lda];
         }
     }
-    // wave reduce with (abs desc, index asc) order == "first strictly larger" over the whole column
-    for (int off = 32; off > 0; off >>= 1) {
-        const double oa = __shfl_down(best, off, 64);
-        const unsigned long long oi = __shfl_down(bidx, off, 64);
-        if (oa > best || (oa == best && oi < bidx)) {
-            best = oa;
-            bidx = oi;
-        }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-        s_abs[wave] = best;
-        s_idx[wave] = bidx;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int nw = blockDim.x >> 6;
-        for (int w = 1; w < nw; ++w) {
-            if (s_abs[w] > best || (s_abs[w] == best && s_idx[w] < bidx)) {
-                best = s_abs[w];
-                bidx = s_idx[w];
+    if (!first) {
+        if (grp == 0) {
+            // ---- pivot of column k: fold the per-block candidates, order (abs desc, pos asc)
+            double ba = 0.0;
+            int bp = 0x7fffffff, br = -1;
+            const int base = (k & 1) * MAX_PANEL_BLOCKS;
+            const int occ = lane == 0 ? row_at[k] : 0;  // physical row at position k
+            for (int b = lane; b < nblocks; b += 64) {
+                const double a = cand_abs[base + b];
+                const int p = cand_pos[base + b];
+                if (a > ba || (a == ba && a > 0.0 && p < bp)) {
+                    ba = a;
+                    bp = p;
+                    br = cand_row[base + b];
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double oa = __shfl_down(ba, off, 64);
+                const int op = __shfl_down(bp, off, 64);
+                const int orow = __shfl_down(br, off, 64);
+                if (oa > ba || (oa == ba && oa > 0.0 && op < bp)) {
+                    ba = oa;
+                    bp = op;
+                    br = orow;
+                }
+            }
+            if (lane == 0) {
+                if (!(ba > 0.0)) {  // all-zero (or NaN-only) column: pivot_row stays k (host_lu.rs:38)
+                    br = occ;
+                    bp = k;
+                }
+                const int skip = (ba <= LU_EPS) ? 1 : 0;
+                s_piv[0] = br;
+                s_piv[1] = bp;
+                s_piv[2] = occ;
+                s_piv[3] = skip;
+                if (blockIdx.x == 0) {
+                    ipiv[k] = bp;
+                    row_at[bp] = occ;  // position k is final from now on; only the displaced row moves
+                    if (skip) atomicAdd(info, 1);
+                }
             }
         }
-        if (best == 0.0) bidx = k;  // all-zero column: pivot_row stays k (host_lu.rs:38)
-        s_prow = bidx;
-        ipiv[k] = (int)bidx;
-        const bool skip = best <= LU_EPS;
-        if (skip) atomicAdd(info, 1);
-        piv[1] = skip ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    const size_t p = s_prow;
-    if (p != k) {
-        for (size_t cc = c0 + threadIdx.x; cc < c1; cc += blockDim.x) {
-            const double t = A[k + cc * lda];
-            A[k + cc * lda] = A[p + cc * lda];
-            A[p + cc * lda] = t;
+        __syncthreads();
+        // ---- second (and last) dependent round trip: the pivot row's panel values
+        if (t < ncols) s_prow_vals[t] = A[(size_t)s_piv[0] + (size_t)(k + t) * lda];
+        __syncthreads();
+        const int prow = s_piv[0];
+        if (in_rows && pos >= 0) {
+            if ((int)r == prow) {
+                pos = -1;  // retires as row k of U
+                if (grp == 0) pos_of[r] = -1;
+            } else if ((int)r == s_piv[2]) {
+                pos = s_piv[1];  // the old occupant of position k moves to the pivot's position
+                if (grp == 0) pos_of[r] = pos;
+            }
+        }
+        if (in_rows && pos >= 0) {
+            if (s_piv[3]) {
+                if (grp == 0) A[r + (size_t)k * lda] = 0.0;
+            } else {
+                const double factor = akk / s_prow_vals[0];
+                if (grp == 0) A[r + (size_t)k * lda] = factor;
+#pragma unroll
+                for (int jj = 0; jj < PANEL_JT; ++jj) {
+                    const int j = jbase + jj;
+                    if (j >= 1 && j < ncols) {
+                        const double prod = factor * s_prow_vals[j];
+                        v[jj] = v[jj] - prod;
+                        A[r + (size_t)(k + j) * lda] = v[jj];
+                    }
+                }
+            }
+            nextv = v[1];  // column k+1 lives in group 0 (only meaningful there)
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) piv[0] = A[k + k * lda];
-}
-
-// (2) multipliers + rank-1 update of the remaining base-panel columns (host_lu.rs:54-70).
-__global__ void __launch_bounds__(256) k_lu_update(double* __restrict__ A, size_t lda, size_t rows, size_t k,
-                                                   size_t c1, const double* __restrict__ piv) {
-    const size_t r = k + 1 + (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
-    if (piv[1] != 0.0) {  // singular column: zero it, no update
-        A[r + k * lda] = 0.0;
-        return;
+    if (!want_next || grp != 0) return;
+    double best = 0.0;
+    int bpos = 0x7fffffff, brow = -1;
+    if (in_rows && pos >= 0) {
+        const double a = fabs(nextv);
+        if (a > 0.0) {  // NaN or zero never wins (host_lu.rs: `abs > pivot_abs`)
+            best = a;
+            bpos = pos;
+            brow = (int)r;
+        }
     }
-    const double pivot = piv[0];
-    const double factor = A[r + k * lda] / pivot;
-    A[r + k * lda] = factor;
-    for (size_t cc = k + 1; cc < c1; ++cc) {
-        const double prod = factor * A[k + cc * lda];
-        A[r + cc * lda] -= prod;
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oa = __shfl_down(best, off, 64);
+        const int op = __shfl_down(bpos, off, 64);
+        const int orow = __shfl_down(brow, off, 64);
+        if (oa > best || (oa == best && oa > 0.0 && op < bpos)) {
+            best = oa;
+            bpos = op;
+            brow = orow;
+        }
+    }
+    if (lane == 0) {
+        const int slot = (next_col & 1) * MAX_PANEL_BLOCKS + blockIdx.x;
+        cand_abs[slot] = best;
+        cand_pos[slot] = bpos;
+        cand_row[slot] = brow;
     }
 }
 
@@ -129,58 +220,61 @@ __global__ void __launch_bounds__(256) k_laswp(double* __restrict__ A, size_t ld
 }
 
 // ---- small triangular solves (w <= 32): one thread per right-hand-side column ---------------------
+// Small triangular solves (w <= 32), cooperative: a half-wave (32 lanes) owns one right-hand-side
+// column at a time, lane i holds x_i and row i of the triangle in registers; step k broadcasts x_k
+// with a shuffle and every lane eliminates it.  Loads/stores of B are 256-byte contiguous segments.
+static constexpr int TRSM_THREADS = 256;
+
 // lower, unit diagonal: B <- L^-1 B ; T is w x w at T[0], ldt.
-__global__ void __launch_bounds__(64) k_trsm_lower_unit(const double* __restrict__ T, size_t ldt, int w,
-                                                        double* __restrict__ B, size_t ldb, size_t ncols) {
-    __shared__ double Ls[TRSM_W * TRSM_W];
-    for (int e = threadIdx.x; e < w * w; e += 64) Ls[e] = T[(e % w) + (size_t)(e / w) * ldt];
-    __syncthreads();
-    const size_t cc = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (cc >= ncols) return;
-    double* b = B + cc * ldb;
-    double x[TRSM_W];
+__global__ void __launch_bounds__(TRSM_THREADS) k_trsm_lower_unit(const double* __restrict__ T, size_t ldt, int w,
+                                                                  double* __restrict__ B, size_t ldb, size_t ncols) {
+    const int i = threadIdx.x & 31;
+    const size_t hw = ((size_t)blockIdx.x * TRSM_THREADS + threadIdx.x) >> 5;
+    const size_t nhw = ((size_t)gridDim.x * TRSM_THREADS) >> 5;
+    double lrow[TRSM_W];
 #pragma unroll
-    for (int i = 0; i < TRSM_W; ++i) x[i] = i < w ? b[i] : 0.0;
+    for (int k = 0; k < TRSM_W; ++k) lrow[k] = (i < w && k < i) ? T[i + (size_t)k * ldt] : 0.0;
+    for (size_t cc = hw; cc < ncols; cc += nhw) {
+        double* b = B + cc * ldb;
+        double x = i < w ? b[i] : 0.0;
 #pragma unroll
-    for (int i = 0; i < TRSM_W; ++i) {
-        if (i < w) {
-            double s = x[i];
-#pragma unroll
-            for (int k = 0; k < TRSM_W; ++k)
-                if (k < i) s -= Ls[i + k * w] * x[k];
-            x[i] = s;
+        for (int k = 0; k < TRSM_W - 1; ++k) {
+            const double xk = __shfl(x, k, 32);
+            if (i > k) x -= lrow[k] * xk;  // predicate (not a zero multiplier): 0 * inf must not poison finished lanes
         }
+        if (i < w) b[i] = x;
     }
-#pragma unroll
-    for (int i = 0; i < TRSM_W; ++i)
-        if (i < w) b[i] = x[i];
 }
 
 // upper, non-unit diagonal: B <- U^-1 B.
-__global__ void __launch_bounds__(64) k_trsm_upper(const double* __restrict__ T, size_t ldt, int w,
-                                                   double* __restrict__ B, size_t ldb, size_t ncols) {
-    __shared__ double Us[TRSM_W * TRSM_W];
-    for (int e = threadIdx.x; e < w * w; e += 64) Us[e] = T[(e % w) + (size_t)(e / w) * ldt];
-    __syncthreads();
-    const size_t cc = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (cc >= ncols) return;
-    double* b = B + cc * ldb;
-    double x[TRSM_W];
+__global__ void __launch_bounds__(TRSM_THREADS) k_trsm_upper(const double* __restrict__ T, size_t ldt, int w,
+                                                             double* __restrict__ B, size_t ldb, size_t ncols) {
+    const int i = threadIdx.x & 31;
+    const size_t hw = ((size_t)blockIdx.x * TRSM_THREADS + threadIdx.x) >> 5;
+    const size_t nhw = ((size_t)gridDim.x * TRSM_THREADS) >> 5;
+    double urow[TRSM_W];
 #pragma unroll
-    for (int i = 0; i < TRSM_W; ++i) x[i] = i < w ? b[i] : 0.0;
+    for (int k = 0; k < TRSM_W; ++k) urow[k] = (i < w && k < w && k > i) ? T[i + (size_t)k * ldt] : 0.0;
+    const double diag = i < w ? T[i + (size_t)i * ldt] : 1.0;
+    for (size_t cc = hw; cc < ncols; cc += nhw) {
+        double* b = B + cc * ldb;
+        double x = i < w ? b[i] : 0.0;
 #pragma unroll
-    for (int ii = TRSM_W - 1; ii >= 0; --ii) {
-        if (ii < w) {
-            double s = x[ii];
-#pragma unroll
-            for (int k = 0; k < TRSM_W; ++k)
-                if (k > ii && k < w) s -= Us[ii + k * w] * x[k];
-            x[ii] = s / Us[ii + ii * w];
+        for (int k = TRSM_W - 1; k >= 0; --k) {
+            const double xf = x / diag;          // final for the lane whose turn it is (k == i)
+            const double xk = __shfl(xf, k, 32);
+            if (i == k) x = xk;
+            else if (i < k) x -= urow[k] * xk;
         }
+        if (i < w) b[i] = x;
     }
-#pragma unroll
-    for (int i = 0; i < TRSM_W; ++i)
-        if (i < w) b[i] = x[i];
+}
+
+static unsigned trsm_grid(const Context* c, size_t nc) {
+    size_t want = (nc + 7) / 8;  // 8 half-waves per block, one column each per pass
+    const size_t cap = (size_t)c->num_cus * 4;
+    if (want < 1) want = 1;
+    return (unsigned)(want < cap ? want : cap);
 }
 
 static int launch_check(Context* c) {
@@ -193,33 +287,34 @@ static int launch_check(Context* c) {
 static int trsm_lower_rec(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
     if (w == 0 || nc == 0) return RMHIP_OK;
     if (w <= (size_t)TRSM_W) {
-        hipLaunchKernelGGL(k_trsm_lower_unit, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, c->stream, T, ldt, (int)w,
+        if (g_lu_dbg & 64) return RMHIP_OK;
+        hipLaunchKernelGGL(k_trsm_lower_unit, dim3(trsm_grid(c, nc)), dim3(TRSM_THREADS), 0, c->stream, T, ldt, (int)w,
                            B, ldb, nc);
         return launch_check(c);
     }
     size_t h = ((w / 2 + 15) / 16) * 16;
     if (h >= w) h = w / 2;
     RMHIP_TRY(trsm_lower_rec(c, T, ldt, h, B, ldb, nc));
-    RMHIP_TRY(launch_dgemm(c, w - h, nc, h, -1.0, T + h, ldt, B, ldb, 1.0, B + h, ldb));
+    RMHIP_TRY((g_lu_dbg & 32) ? RMHIP_OK : launch_dgemm(c, w - h, nc, h, -1.0, T + h, ldt, B, ldb, 1.0, B + h, ldb));
     return trsm_lower_rec(c, T + h + h * ldt, ldt, w - h, B + h, ldb, nc);
 }
 
 static int trsm_upper_rec(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
     if (w == 0 || nc == 0) return RMHIP_OK;
     if (w <= (size_t)TRSM_W) {
-        hipLaunchKernelGGL(k_trsm_upper, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, c->stream, T, ldt, (int)w, B,
+        hipLaunchKernelGGL(k_trsm_upper, dim3(trsm_grid(c, nc)), dim3(TRSM_THREADS), 0, c->stream, T, ldt, (int)w, B,
                            ldb, nc);
         return launch_check(c);
     }
     size_t h = ((w / 2 + 15) / 16) * 16;
     if (h >= w) h = w / 2;
     RMHIP_TRY(trsm_upper_rec(c, T + h + h * ldt, ldt, w - h, B + h, ldb, nc));
-    RMHIP_TRY(launch_dgemm(c, h, nc, w - h, -1.0, T + h * ldt, ldt, B + h, ldb, 1.0, B, ldb));
+    RMHIP_TRY((g_lu_dbg & 32) ? RMHIP_OK : launch_dgemm(c, h, nc, w - h, -1.0, T + h * ldt, ldt, B + h, ldb, 1.0, B, ldb));
     return trsm_upper_rec(c, T, ldt, h, B, ldb, nc);
 }
 
 static int laswp(LuState& s, size_t c0, size_t c1, size_t k0, size_t k1) {
-    if (c1 <= c0 || k1 <= k0) return RMHIP_OK;
+    if (c1 <= c0 || k1 <= k0 || (g_lu_dbg & 128)) return RMHIP_OK;
     hipLaunchKernelGGL(k_laswp, dim3((unsigned)((c1 - c0 + 255) / 256)), dim3(256), 0, s.c->stream, s.A, s.lda, c0, c1,
                        k0, k1, s.ipiv);
     return launch_check(s.c);
@@ -229,18 +324,22 @@ static int laswp(LuState& s, size_t c0, size_t c1, size_t k0, size_t k1) {
 static int getrf_rec(LuState& s, size_t j0, size_t w) {
     if (w == 0 || j0 >= s.rows) return RMHIP_OK;
     if (w <= (size_t)BASE_W) {
-        const size_t c1 = j0 + w;
-        for (size_t k = j0; k < c1 && k < s.rows; ++k) {
-            hipLaunchKernelGGL(k_lu_pivot, dim3(1), dim3(1024), 0, s.c->stream, s.A, s.lda, s.rows, k, j0, c1, s.ipiv,
-                               s.info, s.piv);
+        const size_t c1 = j0 + w;  // j0 + w <= min(rows, cols) always holds (see lu_factor_device)
+        const size_t nb = (s.rows - j0 + 63) / 64;  // one block per 64 rows
+        if (nb > (size_t)MAX_PANEL_BLOCKS)
+            return fail(RMHIP_ERR_UNSUPPORTED, "lu: more than %d rows per panel not supported yet", MAX_PANEL_BLOCKS * 64);
+        // init launch: candidates for column j0; then one launch per column
+        hipLaunchKernelGGL(k_lu_col, dim3((unsigned)nb), dim3(PANEL_THREADS), 0, s.c->stream, s.A, s.lda, s.rows, (int)j0,
+                           (int)j0 - 1, (int)c1, 1, (int)nb, s.pos_of, s.row_at, s.ipiv, s.info, s.cand_abs, s.cand_pos, s.cand_row);
+        RMHIP_TRY(launch_check(s.c));
+        for (size_t k = j0; k < c1 && !(g_lu_dbg & 16); ++k) {
+            hipLaunchKernelGGL(k_lu_col, dim3((unsigned)nb), dim3(PANEL_THREADS), 0, s.c->stream, s.A, s.lda, s.rows,
+                               (int)j0, (int)k, (int)c1, 0, (int)nb, s.pos_of, s.row_at, s.ipiv, s.info, s.cand_abs,
+                               s.cand_pos, s.cand_row);
             RMHIP_TRY(launch_check(s.c));
-            if (k + 1 < s.rows) {
-                hipLaunchKernelGGL(k_lu_update, dim3((unsigned)((s.rows - k - 1 + 255) / 256)), dim3(256), 0,
-                                   s.c->stream, s.A, s.lda, s.rows, k, c1, s.piv);
-                RMHIP_TRY(launch_check(s.c));
-            }
         }
-        return RMHIP_OK;
+        // physical interchange of the panel columns, once per panel
+        return laswp(s, j0, c1, j0, c1);
     }
     size_t h = ((w / 2 + 15) / 16) * 16;
     if (h >= w) h = w / 2;
@@ -253,7 +352,7 @@ static int getrf_rec(LuState& s, size_t j0, size_t w) {
     if (j0 + h < s.rows) {
         double* A21 = s.A + (j0 + h) + j0 * s.lda;
         double* A22 = s.A + (j0 + h) + (j0 + h) * s.lda;
-        RMHIP_TRY(launch_dgemm(s.c, s.rows - j0 - h, w - h, h, -1.0, A21, s.lda, A12, s.lda, 1.0, A22, s.lda));
+        RMHIP_TRY((g_lu_dbg & 32) ? RMHIP_OK : launch_dgemm(s.c, s.rows - j0 - h, w - h, h, -1.0, A21, s.lda, A12, s.lda, 1.0, A22, s.lda));
         RMHIP_TRY(getrf_rec(s, j0 + h, w - h));
         const size_t k1 = (j0 + w <= s.rows) ? (j0 + w) : s.rows;
         RMHIP_TRY(laswp(s, j0, j0 + h, j0 + h, k1));
@@ -261,23 +360,130 @@ static int getrf_rec(LuState& s, size_t j0, size_t w) {
     return RMHIP_OK;
 }
 
+// ---- blocked driver with look-ahead -------------------------------------------------------------
+// Panels (width nb, factored recursively by getrf_rec) are latency bound: one launch per column.
+// Trailing updates are throughput bound (MFMA dgemm).  Running them back to back on one stream adds
+// the two; here the update of everything right of the NEXT panel runs on a second, lower-priority
+// stream while the main stream already factors the next panel:
+//   main:  P_j -> LA_j (swap + trsm + gemm of the next panel's nb columns) -> P_{j+1} -> wait(S_j) -> LA_{j+1} ...
+//   side:  wait(P_j) -> S_j (swap + trsm + gemm of columns right of the next panel; swaps of the finished left columns) ...
+struct StreamScope {
+    Context* c;
+    hipStream_t saved;
+    StreamScope(Context* ctx, hipStream_t s) : c(ctx), saved(ctx->stream) { c->stream = s; }
+    ~StreamScope() { c->stream = saved; }
+};
+
+static int update_columns(LuState& s, size_t j, size_t w, size_t c0, size_t c1) {
+    // columns [c0, c1) receive the row interchanges of panel [j, j+w), the U block row and the Schur update
+    if (c1 <= c0) return RMHIP_OK;
+    RMHIP_TRY(laswp(s, c0, c1, j, j + w));
+    double* A11 = s.A + j + j * s.lda;
+    double* A12 = s.A + j + c0 * s.lda;
+    RMHIP_TRY(trsm_lower_rec(s.c, A11, s.lda, w, A12, s.lda, c1 - c0));
+    if (j + w < s.rows) {
+        double* A21 = s.A + (j + w) + j * s.lda;
+        double* A22 = s.A + (j + w) + c0 * s.lda;
+        RMHIP_TRY((g_lu_dbg & 32) ? RMHIP_OK
+                                  : launch_dgemm(s.c, s.rows - j - w, c1 - c0, w, -1.0, A21, s.lda, A12, s.lda, 1.0, A22, s.lda));
+    }
+    return RMHIP_OK;
+}
+
+static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
+    Context* c = s.c;
+    hipStream_t main_stream = c->stream;
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    hipStream_t side = nullptr;
+    RMHIP_HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio_low));
+    std::vector<hipEvent_t> events;
+    auto new_event = [&]() {
+        hipEvent_t e = nullptr;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        events.push_back(e);
+        return e;
+    };
+    int rc = RMHIP_OK;
+    hipEvent_t side_done = nullptr;  // S_{j-1} finished
+    {
+        hipEvent_t e0 = new_event();  // side starts after whatever main already has queued (the copy of A)
+        (void)hipEventRecord(e0, main_stream);
+        (void)hipStreamWaitEvent(side, e0, 0);
+    }
+    for (size_t j = 0; j < kmin && rc == RMHIP_OK; j += nb) {
+        const size_t w = (kmin - j) < nb ? (kmin - j) : nb;
+        rc = getrf_rec(s, j, w);  // P_j on main
+        if (rc != RMHIP_OK) break;
+        hipEvent_t panel_done = new_event();
+        (void)hipEventRecord(panel_done, main_stream);
+        const size_t next = j + w;
+        size_t la_w = 0;
+        if (next < kmin) {  // there is a next panel: update its columns on main right away
+            la_w = (kmin - next) < nb ? (kmin - next) : nb;
+            if (side_done) (void)hipStreamWaitEvent(main_stream, side_done, 0);
+            rc = update_columns(s, j, w, next, next + la_w);
+            if (rc != RMHIP_OK) break;
+        }
+        (void)hipStreamWaitEvent(side, panel_done, 0);
+        {
+            StreamScope scope(c, side);
+            rc = update_columns(s, j, w, next + la_w, s.cols);      // S_j
+            if (rc == RMHIP_OK && j > 0) rc = laswp(s, 0, j, j, j + w);  // finished left columns
+        }
+        side_done = new_event();
+        (void)hipEventRecord(side_done, side);
+    }
+    if (side_done) (void)hipStreamWaitEvent(main_stream, side_done, 0);
+    (void)hipStreamSynchronize(side);
+    (void)hipStreamSynchronize(main_stream);
+    for (hipEvent_t e : events)
+        if (e) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(side);
+    return rc;
+}
+
 // In-place LU of A (rows x cols, lda). perm_dev[rows] receives the row permutation as the
 // reference reports it (perm[k] = original row now at position k, host_lu.rs:50,107).
 // *info_host = number of pivots that hit the singular cut-off.
 int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda, int* perm_dev, int* info_host) {
     const size_t kmin = rows < cols ? rows : cols;
-    int* ipiv = nullptr;
-    RMHIP_HIP_CHECK(hipMalloc((void**)&ipiv, sizeof(int) * (rows + 4) + sizeof(double) * 2));
+    if (rows > 0x7fffffffULL || cols > 0x7fffffffULL) return fail(RMHIP_ERR_UNSUPPORTED, "lu: dimension exceeds 2^31");
+    // one device block: ipiv[rows] | info | pos_of[rows] | row_at[rows] | cand_abs[2*MAXB] | cand_pos | cand_row
+    const size_t n_int = rows + 4;
+    const size_t off_posof = (n_int * sizeof(int) + 15) & ~(size_t)15;
+    const size_t off_rowat = off_posof + ((rows * sizeof(int) + 15) & ~(size_t)15);
+    const size_t off_abs = off_rowat + ((rows * sizeof(int) + 15) & ~(size_t)15);
+    const size_t off_pos = off_abs + sizeof(double) * 2 * MAX_PANEL_BLOCKS;
+    const size_t off_row = off_pos + sizeof(int) * 2 * MAX_PANEL_BLOCKS;
+    const size_t total = off_row + sizeof(int) * 2 * MAX_PANEL_BLOCKS;
+    char* blk = nullptr;
+    RMHIP_HIP_CHECK(hipMalloc((void**)&blk, total));
+    int* ipiv = (int*)blk;
     int* info = ipiv + rows;
-    double* piv = (double*)(((uintptr_t)(ipiv + rows + 2) + 7) & ~(uintptr_t)7);
-    hipError_t e = hipMemsetAsync(ipiv, 0, sizeof(int) * (rows + 4) + sizeof(double) * 2, c->stream);
+    hipError_t e = hipMemsetAsync(blk, 0, total, c->stream);
     if (e != hipSuccess) {
-        (void)hipFree(ipiv);
+        (void)hipFree(blk);
         return fail(RMHIP_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
     }
-    LuState s{c, A, rows, cols, lda, ipiv, info, piv};
-    int rc = getrf_rec(s, 0, kmin);
-    if (rc == RMHIP_OK && cols > rows) {  // wide: finish U's right block
+    LuState s{c, A, rows, cols, lda, ipiv, info, (int*)(blk + off_posof), (int*)(blk + off_rowat), (double*)(blk + off_abs),
+              (int*)(blk + off_pos), (int*)(blk + off_row), std::getenv("RMHIP_LU_DEBUG") ? std::atoi(std::getenv("RMHIP_LU_DEBUG")) : 0};
+    g_lu_dbg = s.dbg;
+    const auto t_host0 = std::chrono::steady_clock::now();
+    size_t nb = 512;
+    if (const char* v = std::getenv("RMHIP_LU_NB")) nb = (size_t)std::atoll(v);
+    nb = nb < 64 ? 64 : (nb / 64) * 64;
+    const bool blocked = kmin > nb && !(s.dbg & 256);
+    int rc = blocked ? getrf_blocked(s, kmin, nb) : getrf_rec(s, 0, kmin);
+    if (s.dbg & 8) {
+        const auto t_host1 = std::chrono::steady_clock::now();
+        (void)hipStreamSynchronize(c->stream);
+        const auto t_host2 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[rmhip lu] rows=%zu enqueue %.2f ms, drain %.2f ms\n", rows,
+                     std::chrono::duration<double, std::milli>(t_host1 - t_host0).count(),
+                     std::chrono::duration<double, std::milli>(t_host2 - t_host1).count());
+    }
+    if (rc == RMHIP_OK && cols > rows && !blocked) {  // wide: finish U's right block (the blocked driver covers it)
         rc = laswp(s, rows, cols, 0, rows);
         if (rc == RMHIP_OK) rc = trsm_lower_rec(c, A, lda, rows, A + rows * lda, lda, cols - rows);
     }
@@ -289,7 +495,7 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     } else {
         (void)hipStreamSynchronize(c->stream);
     }
-    (void)hipFree(ipiv);
+    (void)hipFree(blk);
     if (rc != RMHIP_OK) return rc;
     if (info_host) *info_host = h_ipiv[rows];
     std::vector<int> perm(rows);

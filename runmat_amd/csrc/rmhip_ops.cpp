@@ -80,6 +80,8 @@ void collapse(std::vector<uint64_t>* shape, std::vector<std::vector<uint64_t>>* 
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+size_t lu_padded_ld(size_t rows) { return rows >= 256 ? ((rows + 1) & ~(size_t)1) + 32 : ((rows + 1) & ~(size_t)1); }
+
 std::vector<size_t> normalize_matrix_shape(const std::vector<size_t>& s) {
     if (s.empty()) return {1, 1};
     if (s.size() == 1) return {s[0], 1};
@@ -460,12 +462,21 @@ int rmhip_lu(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf out5[5]) {
     if (!rc) rc = c->new_buffer(s_piv, 2, &ids[4], &piv);
     int* perm = nullptr;
     if (!rc && hipMalloc((void**)&perm, sizeof(int) * (rows + 1)) != hipSuccess) rc = fail(RMHIP_ERR_OOM, "lu: pivot allocation failed");
+    const size_t ldw = lu_padded_ld(rows);
+    std::shared_ptr<Allocation> work;
+    if (!rc) rc = c->alloc_device(ldw * (cols ? cols : 1), &work);
     if (!rc && ab.numel) {
-        hipError_t e = hipMemcpyAsync(comb.data(), ab.data(), ab.numel * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+        hipError_t e = hipMemcpy2DAsync(work->ptr, ldw * sizeof(double), ab.data(), rows * sizeof(double), rows * sizeof(double),
+                                        cols, hipMemcpyDeviceToDevice, c->stream);
         if (e != hipSuccess) rc = fail(RMHIP_ERR_HIP, "lu copy: %s", hipGetErrorString(e));
     }
     int info = 0;
-    if (!rc) rc = lu_factor_device(c, comb.data(), rows, cols, rows, perm, &info);
+    if (!rc) rc = lu_factor_device(c, work->ptr, rows, cols, ldw, perm, &info);
+    if (!rc && ab.numel) {
+        hipError_t e = hipMemcpy2DAsync(comb.data(), rows * sizeof(double), work->ptr, ldw * sizeof(double), rows * sizeof(double),
+                                        cols, hipMemcpyDeviceToDevice, c->stream);
+        if (e != hipSuccess) rc = fail(RMHIP_ERR_HIP, "lu copy back: %s", hipGetErrorString(e));
+    }
     if (!rc) rc = lu_extract_device(c, comb.data(), rows, cols, perm, L.data(), U.data(), P.data(), piv.data());
     if (perm) {
         (void)hipStreamSynchronize(c->stream);
@@ -504,20 +515,25 @@ int rmhip_mldivide(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
         return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: rectangular systems use the CPU least-squares path (mldivide.rs:380-404)");
     const size_t n = as[0], nrhs = bs[1];
     if (n == 0) return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: empty system");
+    // Factorisation workspace with a PADDED leading dimension: with lda a large power of two every
+    // element of a row maps to the same HBM channel / L2 slice, and the panel kernels (one lane per
+    // row, walking across columns) serialise on it; +32 doubles rotates the channel per column.
+    const size_t ldw = lu_padded_ld(n);
     std::shared_ptr<Allocation> work;
-    RMHIP_TRY(c->alloc_device(n * n, &work));
-    RMHIP_HIP_CHECK(hipMemcpyAsync(work->ptr, ab.data(), n * n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    RMHIP_TRY(c->alloc_device(ldw * n, &work));
+    RMHIP_HIP_CHECK(hipMemcpy2DAsync(work->ptr, ldw * sizeof(double), ab.data(), n * sizeof(double), n * sizeof(double), n,
+                                     hipMemcpyDeviceToDevice, c->stream));
     int* perm = nullptr;
     RMHIP_HIP_CHECK(hipMalloc((void**)&perm, sizeof(int) * (n + 1)));
     int info = 0;
-    int rc = lu_factor_device(c, work->ptr, n, n, n, perm, &info);
+    int rc = lu_factor_device(c, work->ptr, n, n, ldw, perm, &info);
     if (!rc && info > 0)
         rc = fail(RMHIP_ERR_SINGULAR, "mldivide: %d pivot(s) <= 1e-12; matrix is numerically singular, use the CPU SVD path", info);
     Buffer ob;
     rmhip_buf oid = 0;
     const size_t oshape[2] = {n, nrhs};
     if (!rc) rc = c->new_buffer(oshape, 2, &oid, &ob);
-    if (!rc) rc = lu_solve_device(c, work->ptr, n, n, perm, bb.data(), nrhs, n, ob.data(), n);
+    if (!rc) rc = lu_solve_device(c, work->ptr, n, ldw, perm, bb.data(), nrhs, n, ob.data(), n);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(perm);
     if (rc) {
