@@ -10,17 +10,14 @@
 //
 // Algorithm: recursive (Toledo) right-looking LU.  getrf(j0, w): factor the left half, swap +
 // triangular-solve + MFMA dgemm-update the right half, factor the right half, swap the left half.
-// Every flop outside the <=16-column base panels runs in launch_dgemm (dgemm.hip) with K equal to
+// Every flop outside the <=64-column base panels runs in launch_dgemm (dgemm.hip) with K equal to
 // the half-width, so the top levels (where the flops are) see K in the thousands.
 // Triangular solves recurse the same way down to a 32x32 substitution kernel.
-#include <chrono>
 #include <vector>
 
 #include "common.h"
 
 namespace rmhip {
-
-static int g_lu_dbg = 0;  // RMHIP_LU_DEBUG developer switches (timing experiments only; results are wrong when set)
 
 static constexpr double LU_EPS = 1.0e-12;  // host_lu.rs:3
 static constexpr int BASE_W = 64;          // base panel width (columns factored one launch each)
@@ -34,10 +31,12 @@ struct LuState {
     int* info;        // device: number of pivots with |p| <= LU_EPS
     int* pos_of;      // device [rows]: current position of physical row r inside the base panel, -1 once retired
     int* row_at;      // device [rows]: physical row currently at position p (only entries >= k are meaningful)
+    int* prow;        // device [rows]: physical pivot row chosen at step k (before the panel's physical interchange)
+    int2* plist;      // device [max_panels][PLIST]: (dst, src) row moves of each base panel, applied as one parallel gather
+    std::vector<size_t>* panel_start;  // host: first column of every base panel factored so far (ascending)
     double* cand_abs; // device: [2][MAX_PANEL_BLOCKS] per-block arg-max candidates (double buffered by column parity)
     int* cand_pos;    //         position of the candidate row
     int* cand_row;    //         physical row of the candidate
-    int dbg;          // developer switches (RMHIP_LU_DEBUG): timing experiments only
 };
 
 static constexpr int MAX_PANEL_BLOCKS = 1024;  // 64 rows per block => up to 65536 rows per panel
@@ -65,9 +64,10 @@ static constexpr int PANEL_THREADS = 64 * PANEL_GROUPS;
 // and only a PANEL_JT-deep unrolled load/update/store batch.
 __global__ void __launch_bounds__(PANEL_THREADS) k_lu_col(double* __restrict__ A, size_t lda, size_t rows, int j0, int k,
                                                           int c1, int first, int nblocks, int* __restrict__ pos_of,
-                                                          int* __restrict__ row_at, int* __restrict__ ipiv,
-                                                          int* __restrict__ info, double* __restrict__ cand_abs,
-                                                          int* __restrict__ cand_pos, int* __restrict__ cand_row) {
+                                                          int* __restrict__ row_at, int* __restrict__ prow_arr,
+                                                          int* __restrict__ ipiv, int* __restrict__ info,
+                                                          double* __restrict__ cand_abs, int* __restrict__ cand_pos,
+                                                          int* __restrict__ cand_row) {
     __shared__ int s_piv[4];  // prow, ppos, occ, skip
     __shared__ double s_prow_vals[BASE_W];
     const int t = threadIdx.x;
@@ -136,6 +136,7 @@ __global__ void __launch_bounds__(PANEL_THREADS) k_lu_col(double* __restrict__ A
                 s_piv[3] = skip;
                 if (blockIdx.x == 0) {
                     ipiv[k] = bp;
+                    prow_arr[k] = br;
                     row_at[bp] = occ;  // position k is final from now on; only the displaced row moves
                     if (skip) atomicAdd(info, 1);
                 }
@@ -203,23 +204,59 @@ __global__ void __launch_bounds__(PANEL_THREADS) k_lu_col(double* __restrict__ A
     }
 }
 
-// Apply the row interchanges ipiv[k0..k1) to columns [c0, c1).
-__global__ void __launch_bounds__(256) k_laswp(double* __restrict__ A, size_t lda, size_t c0, size_t c1, size_t k0,
-                                               size_t k1, const int* __restrict__ ipiv) {
-    const size_t cc = c0 + (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (cc >= c1) return;
-    double* col = A + cc * lda;
-    for (size_t k = k0; k < k1; ++k) {
-        const size_t p = (size_t)ipiv[k];
-        if (p != k) {
-            const double t = col[k];
-            col[k] = col[p];
-            col[p] = t;
+static constexpr int PLIST = 2 * BASE_W;  // per base panel: BASE_W pivot rows brought to the top + <= BASE_W displaced rows
+
+// Turn the lazy bookkeeping of one finished base panel [j0, c1) into a list of row moves
+// new[dst] = old[src]: position k receives the pivot row prow[k]; a top-block row that was not
+// retired ends at pos_of[r].  Unused slots are (-1, -1).
+__global__ void __launch_bounds__(PLIST) k_build_plist(int j0, int c1, const int* __restrict__ pos_of,
+                                                       const int* __restrict__ prow_arr, int2* __restrict__ list) {
+    const int t = threadIdx.x;
+    int2 e = make_int2(-1, -1);
+    const int w = c1 - j0;
+    if (t < BASE_W) {
+        if (t < w) {
+            const int src = prow_arr[j0 + t];
+            if (src != j0 + t) e = make_int2(j0 + t, src);
         }
+    } else {
+        const int i = t - BASE_W;
+        if (i < w) {
+            const int r = j0 + i;
+            const int p = pos_of[r];
+            if (p >= 0 && p != r) e = make_int2(p, r);
+        }
+    }
+    list[t] = e;
+}
+
+// Apply the row moves of base panels [p0, p1) to columns [c0, c1): per panel one parallel gather
+// (all loads), a barrier, then the stores.  Replaces w sequential dependent swaps per column by
+// w/BASE_W phases with PLIST independent accesses each.
+static constexpr int LASWP_COLS = 8;  // columns per block
+__global__ void __launch_bounds__(2 * PLIST) k_laswp_lists(double* __restrict__ A, size_t lda, size_t c0, size_t c1,
+                                                           const int2* __restrict__ lists, int p0, int p1) {
+    const int i = threadIdx.x & (PLIST - 1);
+    const int half = threadIdx.x / PLIST;  // 0 or 1
+    const size_t cbase = c0 + (size_t)blockIdx.x * LASWP_COLS;
+    for (int p = p0; p < p1; ++p) {
+        const int2 e = lists[(size_t)p * PLIST + i];
+        double vals[LASWP_COLS / 2];
+#pragma unroll
+        for (int q = 0; q < LASWP_COLS / 2; ++q) {
+            const size_t cc = cbase + 2 * q + half;
+            if (e.x >= 0 && cc < c1) vals[q] = A[(size_t)e.y + cc * lda];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < LASWP_COLS / 2; ++q) {
+            const size_t cc = cbase + 2 * q + half;
+            if (e.x >= 0 && cc < c1) A[(size_t)e.x + cc * lda] = vals[q];
+        }
+        __syncthreads();
     }
 }
 
-// ---- small triangular solves (w <= 32): one thread per right-hand-side column ---------------------
 // Small triangular solves (w <= 32), cooperative: a half-wave (32 lanes) owns one right-hand-side
 // column at a time, lane i holds x_i and row i of the triangle in registers; step k broadcasts x_k
 // with a shuffle and every lane eliminates it.  Loads/stores of B are 256-byte contiguous segments.
@@ -287,7 +324,6 @@ static int launch_check(Context* c) {
 static int trsm_lower_rec(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
     if (w == 0 || nc == 0) return RMHIP_OK;
     if (w <= (size_t)TRSM_W) {
-        if (g_lu_dbg & 64) return RMHIP_OK;
         hipLaunchKernelGGL(k_trsm_lower_unit, dim3(trsm_grid(c, nc)), dim3(TRSM_THREADS), 0, c->stream, T, ldt, (int)w,
                            B, ldb, nc);
         return launch_check(c);
@@ -295,7 +331,7 @@ static int trsm_lower_rec(Context* c, const double* T, size_t ldt, size_t w, dou
     size_t h = ((w / 2 + 15) / 16) * 16;
     if (h >= w) h = w / 2;
     RMHIP_TRY(trsm_lower_rec(c, T, ldt, h, B, ldb, nc));
-    RMHIP_TRY((g_lu_dbg & 32) ? RMHIP_OK : launch_dgemm(c, w - h, nc, h, -1.0, T + h, ldt, B, ldb, 1.0, B + h, ldb));
+    RMHIP_TRY(launch_dgemm(c, w - h, nc, h, -1.0, T + h, ldt, B, ldb, 1.0, B + h, ldb));
     return trsm_lower_rec(c, T + h + h * ldt, ldt, w - h, B + h, ldb, nc);
 }
 
@@ -309,14 +345,25 @@ static int trsm_upper_rec(Context* c, const double* T, size_t ldt, size_t w, dou
     size_t h = ((w / 2 + 15) / 16) * 16;
     if (h >= w) h = w / 2;
     RMHIP_TRY(trsm_upper_rec(c, T + h + h * ldt, ldt, w - h, B + h, ldb, nc));
-    RMHIP_TRY((g_lu_dbg & 32) ? RMHIP_OK : launch_dgemm(c, h, nc, w - h, -1.0, T + h * ldt, ldt, B + h, ldb, 1.0, B, ldb));
+    RMHIP_TRY(launch_dgemm(c, h, nc, w - h, -1.0, T + h * ldt, ldt, B + h, ldb, 1.0, B, ldb));
     return trsm_upper_rec(c, T, ldt, h, B, ldb, nc);
 }
 
 static int laswp(LuState& s, size_t c0, size_t c1, size_t k0, size_t k1) {
-    if (c1 <= c0 || k1 <= k0 || (g_lu_dbg & 128)) return RMHIP_OK;
-    hipLaunchKernelGGL(k_laswp, dim3((unsigned)((c1 - c0 + 255) / 256)), dim3(256), 0, s.c->stream, s.A, s.lda, c0, c1,
-                       k0, k1, s.ipiv);
+    if (c1 <= c0 || k1 <= k0) return RMHIP_OK;
+    // base panels whose first column lies in [k0, k1): recursion ranges are unions of whole panels
+    const std::vector<size_t>& ps = *s.panel_start;
+    int p0 = -1, p1 = -1;
+    for (size_t i = 0; i < ps.size(); ++i) {
+        if (ps[i] >= k0 && ps[i] < k1) {
+            if (p0 < 0) p0 = (int)i;
+            p1 = (int)i + 1;
+        }
+    }
+    if (p0 < 0) return RMHIP_OK;
+    const size_t ncols = c1 - c0;
+    hipLaunchKernelGGL(k_laswp_lists, dim3((unsigned)((ncols + LASWP_COLS - 1) / LASWP_COLS)), dim3(2 * PLIST), 0,
+                       s.c->stream, s.A, s.lda, c0, c1, s.plist, p0, p1);
     return launch_check(s.c);
 }
 
@@ -330,15 +377,20 @@ static int getrf_rec(LuState& s, size_t j0, size_t w) {
             return fail(RMHIP_ERR_UNSUPPORTED, "lu: more than %d rows per panel not supported yet", MAX_PANEL_BLOCKS * 64);
         // init launch: candidates for column j0; then one launch per column
         hipLaunchKernelGGL(k_lu_col, dim3((unsigned)nb), dim3(PANEL_THREADS), 0, s.c->stream, s.A, s.lda, s.rows, (int)j0,
-                           (int)j0 - 1, (int)c1, 1, (int)nb, s.pos_of, s.row_at, s.ipiv, s.info, s.cand_abs, s.cand_pos, s.cand_row);
+                           (int)j0 - 1, (int)c1, 1, (int)nb, s.pos_of, s.row_at, s.prow, s.ipiv, s.info, s.cand_abs, s.cand_pos, s.cand_row);
         RMHIP_TRY(launch_check(s.c));
-        for (size_t k = j0; k < c1 && !(g_lu_dbg & 16); ++k) {
+        for (size_t k = j0; k < c1; ++k) {
             hipLaunchKernelGGL(k_lu_col, dim3((unsigned)nb), dim3(PANEL_THREADS), 0, s.c->stream, s.A, s.lda, s.rows,
-                               (int)j0, (int)k, (int)c1, 0, (int)nb, s.pos_of, s.row_at, s.ipiv, s.info, s.cand_abs,
-                               s.cand_pos, s.cand_row);
+                               (int)j0, (int)k, (int)c1, 0, (int)nb, s.pos_of, s.row_at, s.prow, s.ipiv, s.info,
+                               s.cand_abs, s.cand_pos, s.cand_row);
             RMHIP_TRY(launch_check(s.c));
         }
-        // physical interchange of the panel columns, once per panel
+        // the panel's row moves as one gather list, then the physical interchange of the panel columns
+        const size_t pid = s.panel_start->size();
+        s.panel_start->push_back(j0);
+        hipLaunchKernelGGL(k_build_plist, dim3(1), dim3(PLIST), 0, s.c->stream, (int)j0, (int)c1, s.pos_of, s.prow,
+                           s.plist + pid * PLIST);
+        RMHIP_TRY(launch_check(s.c));
         return laswp(s, j0, c1, j0, c1);
     }
     size_t h = ((w / 2 + 15) / 16) * 16;
@@ -352,7 +404,7 @@ static int getrf_rec(LuState& s, size_t j0, size_t w) {
     if (j0 + h < s.rows) {
         double* A21 = s.A + (j0 + h) + j0 * s.lda;
         double* A22 = s.A + (j0 + h) + (j0 + h) * s.lda;
-        RMHIP_TRY((g_lu_dbg & 32) ? RMHIP_OK : launch_dgemm(s.c, s.rows - j0 - h, w - h, h, -1.0, A21, s.lda, A12, s.lda, 1.0, A22, s.lda));
+        RMHIP_TRY(launch_dgemm(s.c, s.rows - j0 - h, w - h, h, -1.0, A21, s.lda, A12, s.lda, 1.0, A22, s.lda));
         RMHIP_TRY(getrf_rec(s, j0 + h, w - h));
         const size_t k1 = (j0 + w <= s.rows) ? (j0 + w) : s.rows;
         RMHIP_TRY(laswp(s, j0, j0 + h, j0 + h, k1));
@@ -384,8 +436,7 @@ static int update_columns(LuState& s, size_t j, size_t w, size_t c0, size_t c1) 
     if (j + w < s.rows) {
         double* A21 = s.A + (j + w) + j * s.lda;
         double* A22 = s.A + (j + w) + c0 * s.lda;
-        RMHIP_TRY((g_lu_dbg & 32) ? RMHIP_OK
-                                  : launch_dgemm(s.c, s.rows - j - w, c1 - c0, w, -1.0, A21, s.lda, A12, s.lda, 1.0, A22, s.lda));
+        RMHIP_TRY(launch_dgemm(s.c, s.rows - j - w, c1 - c0, w, -1.0, A21, s.lda, A12, s.lda, 1.0, A22, s.lda));
     }
     return RMHIP_OK;
 }
@@ -449,11 +500,15 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
 int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda, int* perm_dev, int* info_host) {
     const size_t kmin = rows < cols ? rows : cols;
     if (rows > 0x7fffffffULL || cols > 0x7fffffffULL) return fail(RMHIP_ERR_UNSUPPORTED, "lu: dimension exceeds 2^31");
-    // one device block: ipiv[rows] | info | pos_of[rows] | row_at[rows] | cand_abs[2*MAXB] | cand_pos | cand_row
+    // one device block: ipiv[rows] | info | pos_of | row_at | prow | panel lists | cand_abs[2*MAXB] | cand_pos | cand_row
     const size_t n_int = rows + 4;
+    const size_t isz = (rows * sizeof(int) + 15) & ~(size_t)15;
+    const size_t max_panels = kmin / 16 + 2;  // base panels are >= 16 columns wide except possibly the last
     const size_t off_posof = (n_int * sizeof(int) + 15) & ~(size_t)15;
-    const size_t off_rowat = off_posof + ((rows * sizeof(int) + 15) & ~(size_t)15);
-    const size_t off_abs = off_rowat + ((rows * sizeof(int) + 15) & ~(size_t)15);
+    const size_t off_rowat = off_posof + isz;
+    const size_t off_prow = off_rowat + isz;
+    const size_t off_plist = off_prow + isz;
+    const size_t off_abs = off_plist + max_panels * PLIST * sizeof(int2);
     const size_t off_pos = off_abs + sizeof(double) * 2 * MAX_PANEL_BLOCKS;
     const size_t off_row = off_pos + sizeof(int) * 2 * MAX_PANEL_BLOCKS;
     const size_t total = off_row + sizeof(int) * 2 * MAX_PANEL_BLOCKS;
@@ -466,23 +521,19 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
         (void)hipFree(blk);
         return fail(RMHIP_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
     }
-    LuState s{c, A, rows, cols, lda, ipiv, info, (int*)(blk + off_posof), (int*)(blk + off_rowat), (double*)(blk + off_abs),
-              (int*)(blk + off_pos), (int*)(blk + off_row), std::getenv("RMHIP_LU_DEBUG") ? std::atoi(std::getenv("RMHIP_LU_DEBUG")) : 0};
-    g_lu_dbg = s.dbg;
-    const auto t_host0 = std::chrono::steady_clock::now();
+    std::vector<size_t> panel_start;
+    panel_start.reserve(max_panels);
+    LuState s{c, A, rows, cols, lda, ipiv, info, (int*)(blk + off_posof), (int*)(blk + off_rowat), (int*)(blk + off_prow),
+              (int2*)(blk + off_plist), &panel_start, (double*)(blk + off_abs), (int*)(blk + off_pos), (int*)(blk + off_row)};
     size_t nb = 512;
     if (const char* v = std::getenv("RMHIP_LU_NB")) nb = (size_t)std::atoll(v);
     nb = nb < 64 ? 64 : (nb / 64) * 64;
-    const bool blocked = kmin > nb && !(s.dbg & 256);
+    // Look-ahead (second stream) is opt-in: measured on MI355X it does not yet beat the single-stream
+    // recursion, because the side stream's dgemm blocks (2 x 218 VGPRs per SIMD) leave no room for the
+    // 512-thread column kernels, which then wait for a dgemm block to retire.
+    const char* la = std::getenv("RMHIP_LU_LOOKAHEAD");
+    const bool blocked = kmin > nb && la && la[0] == '1';
     int rc = blocked ? getrf_blocked(s, kmin, nb) : getrf_rec(s, 0, kmin);
-    if (s.dbg & 8) {
-        const auto t_host1 = std::chrono::steady_clock::now();
-        (void)hipStreamSynchronize(c->stream);
-        const auto t_host2 = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[rmhip lu] rows=%zu enqueue %.2f ms, drain %.2f ms\n", rows,
-                     std::chrono::duration<double, std::milli>(t_host1 - t_host0).count(),
-                     std::chrono::duration<double, std::milli>(t_host2 - t_host1).count());
-    }
     if (rc == RMHIP_OK && cols > rows && !blocked) {  // wide: finish U's right block (the blocked driver covers it)
         rc = laswp(s, rows, cols, 0, rows);
         if (rc == RMHIP_OK) rc = trsm_lower_rec(c, A, lda, rows, A + rows * lda, lda, cols - rows);

@@ -16,7 +16,7 @@ int main(int argc, char** argv) {
         hipMemcpy(A, h.data(), h.size() * 8, hipMemcpyHostToDevice);
         char* blk; hipMalloc(&blk, 1 << 20); hipMemset(blk, 0, 1 << 20);
         int* ipiv = (int*)blk; int* info = ipiv + rows;
-        int* pos_of = (int*)(blk + 100000); int* row_at = (int*)(blk + 200000); double* ca = (double*)(blk + 300000); int* cp = (int*)(blk + 400000); int* cr = (int*)(blk + 500000);
+        int* pos_of = (int*)(blk + 100000); int* row_at = (int*)(blk + 200000); int* prow = (int*)(blk + 600000); double* ca = (double*)(blk + 300000); int* cp = (int*)(blk + 400000); int* cr = (int*)(blk + 500000);
         const int nb = (int)((rows + 63) / 64);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         for (int dbg : {0}) {
@@ -24,9 +24,9 @@ int main(int argc, char** argv) {
             const int reps = 20;
             hipEventRecord(e0, st);
             for (int rep = 0; rep < reps; ++rep) {
-                hipLaunchKernelGGL(k_lu_col, dim3(nb), dim3(PANEL_THREADS), 0, st, A, lda, rows, 0, -1, 64, 1, nb, pos_of, row_at, ipiv, info, ca, cp, cr);
+                hipLaunchKernelGGL(k_lu_col, dim3(nb), dim3(PANEL_THREADS), 0, st, A, lda, rows, 0, -1, 64, 1, nb, pos_of, row_at, prow, ipiv, info, ca, cp, cr);
                 for (int k = 0; k < 64; ++k)
-                    hipLaunchKernelGGL(k_lu_col, dim3(nb), dim3(PANEL_THREADS), 0, st, A, lda, rows, 0, k, 64, 0, nb, pos_of, row_at, ipiv, info, ca, cp, cr);
+                    hipLaunchKernelGGL(k_lu_col, dim3(nb), dim3(PANEL_THREADS), 0, st, A, lda, rows, 0, k, 64, 0, nb, pos_of, row_at, prow, ipiv, info, ca, cp, cr);
             }
             hipEventRecord(e1, st); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
