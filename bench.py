@@ -71,6 +71,35 @@ def cpu_baseline_dgemm():
                       "workload extrapolates ~n^3"}
 
 
+def cpu_baseline_mc():
+    """Oracle Monte-Carlo (serial LCG + Box-Muller + one temporary per op) on a bounded sample."""
+    from oracle import oracle
+
+    M = 10_000_000
+    t0 = time.perf_counter()
+    price, _ = oracle.monte_carlo_price(oracle.rng_default_seed(), M, 1)
+    dt = time.perf_counter() - t0
+    return {"value": round(M / dt, 1), "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": f"M=1e7 paths, T=1 (1/10 of the workload), oracle/oracle.c orc_monte_carlo_price, {dt:.1f} s, "
+                      f"price {price:.6f}"}
+
+
+def cpu_baseline_mldivide():
+    """Oracle A\\b (SVD pseudo-inverse solve, the reference CPU algorithm restated with a Jacobi SVD)."""
+    from oracle import oracle
+
+    n = 768
+    A = oracle.fill_uniform(31, -1.0, 1.0, n * n).reshape(n, n, order="F") + n * np.eye(n)
+    b = A @ np.ones((n, 1))
+    t0 = time.perf_counter()
+    x = oracle.mldivide_svd(A, b)
+    dt = time.perf_counter() - t0
+    flops = (2.0 / 3.0) * n ** 3 + 2.0 * n * n
+    return {"value": round(flops / dt / 1e9, 5), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+            "sample": f"SVD-based solve (mldivide.rs:380-404 restated) at n={n}, {dt:.1f} s, LU-equivalent flop count; "
+                      f"max|x-1|={float(np.max(np.abs(x - 1.0))):.1e}; cost grows ~n^3"}
+
+
 def pmc_traffic(kernel_key: str):
     """HBM bytes per launch measured with rocprofv3 --pmc (committed under profiles/), or None."""
     f = ROOT / "profiles" / "pmc_traffic.json"
@@ -87,7 +116,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["fused", "dgemm"], default="fused")
+    ap.add_argument("--workload", choices=["fused", "dgemm", "mc", "mldivide"], default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     args = ap.parse_args()
@@ -217,8 +246,69 @@ def main() -> None:
                          "kernel_ms": round(kern_ms, 5)},
         }
 
-    primary = fused_record if args.workload == "fused" else dgemm_record
-    secondary = dgemm_record if args.workload == "fused" else fused_record
+    def mc_record(steps, warmup):
+        """BASELINE configs[3]: Monte-Carlo GBM, M = 1e8 paths (sharded over ranks with LCG skip-ahead),
+        T = 1 step, planner-shaped fused kernels; one step = one full pricing."""
+        from runmat_amd import sharding as sh
+
+        group = sh.Group.from_env()
+        M, T = 100_000_000, 1
+        price = 0.0
+        for _ in range(warmup):
+            price, _ = sh.monte_carlo_price_fused(prov, group, M, T, rng_state=0x9E3779B97F4A7C15)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            price, _ = sh.monte_carlo_price_fused(prov, group, M, T, rng_state=0x9E3779B97F4A7C15)
+        barrier()
+        wall = max_over_ranks(time.perf_counter() - t0)
+        ms = wall / steps * 1e3
+        bytes_total = (32 * T + 8) * M
+        return {
+            "metric": "Monte-Carlo samples/s (1e8-sample randn + fused elementwise + sum reduction)",
+            "value": round(M * T / (ms * 1e-3), 1), "unit": "samples/s", "ms_per_step": round(ms, 4), "scaling": "strong",
+            "dtype": "f64",
+            "config": {"workload": "monte-carlo-analysis f64, M=1e8, T=1, CPU-parity LCG randn stream", "price": price,
+                       "algorithmic_bytes": bytes_total, "parallelism": f"sample ranges x{world}, ordered 1-value exchange"},
+            "roofline": {"bound": "hbm", "achieved": round(bytes_total / world / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(bytes_total / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": None, "kernel": "k_rng_normal + rm_ew_fast + rm_red_contig (whole step, wall clock)"},
+        }
+
+    def mldivide_record(steps, warmup):
+        """BASELINE configs[4] at the single-GPU size: x = A\\b, 16384x16384 f64, blocked recursive LU."""
+        nn = 16384
+        ha = prov.fill_uniform(31, -1.0, 1.0, (nn, nn))
+        ones = prov.ones((nn, 1))
+        hb = prov.matmul(ha, ones)  # b = A*1  => x = 1
+        err = None
+        for _ in range(max(1, warmup)):
+            hx = prov.mldivide(ha, hb)
+            err = float(np.max(np.abs(prov.download(hx) - 1.0)))
+            prov.free(hx)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            prov.free(prov.mldivide(ha, hb))
+        barrier()
+        wall = time.perf_counter() - t0
+        ms = wall / steps * 1e3
+        flops = (2.0 / 3.0) * nn ** 3 + 2.0 * nn * nn
+        for h in (ha, ones, hb):
+            prov.free(h)
+        return {
+            "metric": "fp64 GFLOP/s (x = A\\b, 16384x16384, LU with partial pivoting)",
+            "value": round(flops / (ms * 1e-3) / 1e9, 1), "unit": "GFLOP/s", "ms_per_step": round(ms, 3), "scaling": "replicas",
+            "dtype": "f64",
+            "config": {"workload": "x=A\\b 16384x16384 f64 via rmhip_mldivide, A=U(-1,1), b=A*1", "flops_per_step": flops,
+                       "max_abs_err_vs_ones": err, "parallelism": "single GPU (multi-GPU block-cyclic LU is next-round work)"},
+            "roofline": {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 3), "peak": FP64_MFMA_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF, 4), "traffic": None,
+                         "kernel": "k_lu_col chain + k_dgemm trailing updates (whole solve, wall clock)"},
+        }
+
+    records = {"fused": fused_record, "dgemm": dgemm_record, "mc": mc_record, "mldivide": mldivide_record}
+    primary = records[args.workload]
     rec = primary(args.steps, args.warmup)
     out = {
         "metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "n_gpus": world, "steps": args.steps,
@@ -226,17 +316,27 @@ def main() -> None:
         "vs_baseline": None, "dtype": rec["dtype"], "data": "synthetic", "config": rec["config"],
         "roofline": rec["roofline"],
     }
-    if world == 1 and not args.no_also:
-        sec_steps = max(3, min(args.steps, 10)) if args.workload == "fused" else args.steps
-        sec = secondary(sec_steps, 2)
-        out["also"] = {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline")}
-    elif world > 1 and not args.no_also and args.workload == "fused":
-        sec = secondary(max(3, min(args.steps, 10)), 2)
-        out["also"] = {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "roofline")}
+    if not args.no_also:
+        # the other configs of BASELINE.json, short runs; every rank takes part (collectives inside)
+        others = [w for w in ("fused", "dgemm", "mc") if w != args.workload]
+        if world == 1 and args.workload != "mldivide":
+            others.append("mldivide")
+        also = []
+        for w in others:
+            steps = {"fused": 20, "dgemm": 5, "mc": 3, "mldivide": 2}[w]
+            sec = records[w](steps, 2 if w != "mldivide" else 1)
+            also.append({k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "roofline")})
+        out["also"] = also
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_fused() if args.workload == "fused" else cpu_baseline_dgemm()
-        if "also" in out:
-            out["also"]["cpu_baseline"] = cpu_baseline_dgemm() if args.workload == "fused" else cpu_baseline_fused(6.0)
+        out["cpu_baseline"] = {"fused": cpu_baseline_fused, "dgemm": cpu_baseline_dgemm, "mc": cpu_baseline_mc,
+                               "mldivide": cpu_baseline_mldivide}[args.workload]()
+        for a in out.get("also", []):
+            if a["unit"] == "GFLOP/s" and "matmul" in a["metric"]:
+                a["cpu_baseline"] = cpu_baseline_dgemm()
+            elif a["unit"] == "samples/s":
+                a["cpu_baseline"] = cpu_baseline_mc()
+            elif "A\\b" in a["metric"]:
+                a["cpu_baseline"] = cpu_baseline_mldivide()
     info = prov.device_info_struct()
     out["device"] = {"arch": info["arch"], "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"],
                      "hbm_bytes": info["total_memory_bytes"]}

@@ -215,3 +215,50 @@ def monte_carlo_price_sharded(prov, group: Group, M: int, T: int, S0=100.0, mu=0
     final_state = lcg_advance(rng_state, T * per_step)
     prov.set_rng_state(final_state)
     return (total / float(M)) * math.exp(-mu * T * dt), final_state
+
+
+def monte_carlo_price_fused(prov, group: Group, M: int, T: int, S0=100.0, mu=0.05, sigma=0.2, dt=1.0 / 252.0, K=100.0,
+                            rng_state: Optional[int] = None) -> Tuple[float, int]:
+    """Same workload as `monte_carlo_price_sharded`, issued the way RunMat's planner would: one
+    fused elementwise kernel per time step (`S = S .* exp(drift + scale .* Z)`, constants as
+    1-element inputs) and one fused reduction for `sum(max(S - K, 0))`.  Materialised traffic per
+    path and step: randn write 8 B + fused update 24 B, plus 8 B for the final reduction
+    ((32*T + 8) * M bytes)."""
+    from .fusion import FusionGroupPlan
+    from .provider import ReductionFlavor
+
+    if rng_state is None:
+        rng_state = prov.get_rng_state()
+    start, stop = partition(M, group.world, group.rank, granule=2)
+    count = stop - start
+    per_step = 2 * ((M + 1) // 2)
+    drift = (mu - 0.5 * sigma * sigma) * dt
+    scale = sigma * math.sqrt(dt)
+    partial = 0.0
+    if count > 0:
+        step = FusionGroupPlan()
+        v_s, v_z, v_scale, v_drift = step.input(), step.input(), step.input(), step.input()
+        out = step.primitive("ElemMul", v_s, step.builtin("exp", step.primitive("Add", v_drift, step.primitive("ElemMul", v_scale, v_z))))
+        step_shader = step.generate_wgsl_for_output(out, "f64")
+        red = FusionGroupPlan()
+        r_s = red.input()
+        payoff = red.builtin("max", red.primitive("Sub", r_s, red.constant(K)), red.constant(0.0))
+        red_shader = red.generate_reduction_wgsl(payoff, "f64", axis=0)
+        h_scale = prov.upload(np.array([[scale]]))
+        h_drift = prov.upload(np.array([[drift]]))
+        S = prov.fill((count, 1), S0)
+        for t in range(T):
+            prov.set_rng_state(lcg_advance(rng_state, t * per_step + start))
+            Z = prov.random_normal((count, 1))
+            S_next = prov.fused_elementwise(step_shader, [S, Z, h_scale, h_drift], (count, 1), count)
+            prov.free(Z)
+            prov.free(S)
+            S = S_next
+        psum = prov.fused_reduction(red_shader, [S], (1,), count, 1, 256, ReductionFlavor.Sum())
+        partial = float(prov.download(psum)[0])
+        for h in (S, psum, h_scale, h_drift):
+            prov.free(h)
+    total = group.ordered_sum(partial)
+    final_state = lcg_advance(rng_state, T * per_step)
+    prov.set_rng_state(final_state)
+    return (total / float(M)) * math.exp(-mu * T * dt), final_state

@@ -652,3 +652,23 @@ def test_rng_monte_carlo_price_vs_oracle(prov, oracle):
     want, state = oracle.monte_carlo_price(oracle.rng_default_seed(), M, T)
     assert abs(price - want) <= 1e-10 * want
     assert prov.get_rng_state() == state
+
+
+def test_sharding_paths_on_one_gpu(prov, oracle):
+    """runmat_amd.sharding with a single-rank group through the real provider: the per-op and the
+    fused (planner-shaped) Monte-Carlo agree with the CPU generator's price and final RNG state."""
+    from runmat_amd import sharding as sh
+
+    g = sh.Group()
+    M, T = 100001, 3
+    want, want_state = oracle.monte_carlo_price(oracle.rng_default_seed(), M, T)
+    p1, s1 = sh.monte_carlo_price_sharded(prov, g, M, T, rng_state=oracle.rng_default_seed())
+    p2, s2 = sh.monte_carlo_price_fused(prov, g, M, T, rng_state=oracle.rng_default_seed())
+    assert s1 == want_state and s2 == want_state
+    assert abs(p1 - want) <= 1e-10 * want and abs(p2 - want) <= 1e-10 * want
+    # row-block matmul + device-side gather are identities at world 1
+    A = np.arange(12.0).reshape(3, 4)
+    h, keep = sh.gather_row_blocks_device(g, prov, prov.upload(A), 3)
+    assert np.array_equal(prov.download_matrix(h), A) and keep is None
+    x = prov.upload(np.linspace(0.0, 1.0, 1001))
+    assert abs(sh.sum_all_sharded(prov, g, x) - oracle.reduce_sum(np.linspace(0.0, 1.0, 1001).reshape(-1, 1), "all")[0, 0]) < 1e-12
