@@ -1,0 +1,252 @@
+// rmhip_provider.hpp -- C++ host side above the C ABI (include/rmhip.h): `rmhip::HipProvider`
+// mirrors the reference's `trait AccelProvider` (crates/runmat-accelerate-api/src/lib.rs:1386-3151)
+// for the dense-array hot path with the same method names, argument meaning and error behaviour:
+// every provider `Err` becomes a `rmhip::ProviderError` (callers fall back to the CPU builtin,
+// mtimes.rs:212-216); every op returns a NEW handle; inputs are never mutated.
+// Header-only; link with -lrmhip.  The Rust equivalent is shim/hip_provider.rs.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "rmhip.h"
+
+namespace rmhip {
+
+struct ProviderError : std::runtime_error {
+    int code;
+    ProviderError(int c, const std::string& msg) : std::runtime_error(msg), code(c) {}
+};
+
+// lib.rs:260-264
+struct GpuTensorHandle {
+    std::vector<size_t> shape;
+    uint32_t device_id = 0;
+    uint64_t buffer_id = 0;
+    size_t numel() const {
+        size_t n = 1;
+        for (size_t d : shape) n *= d;
+        return n;
+    }
+};
+
+// lib.rs:3362-3372: column-major f64 host data
+struct HostTensorView {
+    const double* data;
+    const size_t* shape;
+    size_t rank;
+};
+struct HostTensorOwned {
+    std::vector<double> data;
+    std::vector<size_t> shape;
+};
+
+// lib.rs:865-890
+struct ReductionFlavor {
+    enum Kind { Sum = 0, Mean = 1, CustomScale = 2 } kind = Sum;
+    double scale = 1.0;
+    static ReductionFlavor sum() { return {Sum, 1.0}; }
+    static ReductionFlavor mean() { return {Mean, 1.0}; }
+    static ReductionFlavor custom(double s) { return {CustomScale, s}; }
+};
+
+// lib.rs:649-698
+struct ProviderLuResult {
+    GpuTensorHandle combined, lower, upper, perm_matrix, perm_vector;
+};
+
+class HipProvider {
+public:
+    explicit HipProvider(int device_ordinal = 0) {
+        static uint32_t next_device_id = 1;  // next_device_id(), lib.rs:3279
+        check(rmhip_init(device_ordinal, &ctx_));
+        device_id_ = next_device_id++;
+    }
+    ~HipProvider() {
+        if (ctx_) rmhip_shutdown(ctx_);
+    }
+    HipProvider(const HipProvider&) = delete;
+    HipProvider& operator=(const HipProvider&) = delete;
+
+    uint32_t device_id() const { return device_id_; }
+    const char* precision() const { return "F64"; }  // ProviderPrecision::F64, lib.rs:815-818
+    rmhip_device_info_t device_info_struct() const {
+        rmhip_device_info_t info;
+        check(rmhip_device_info(ctx_, &info));
+        return info;
+    }
+    rmhip_telemetry_t telemetry_snapshot() const {
+        rmhip_telemetry_t t;
+        check(rmhip_telemetry(ctx_, &t));
+        return t;
+    }
+
+    // ---- memory (lib.rs:1387-1389, 1468-1522) ----
+    GpuTensorHandle upload(const HostTensorView& host) const {
+        uint64_t id = 0;
+        check(rmhip_upload(ctx_, host.data, host.shape, host.rank, &id));
+        return make(id, std::vector<size_t>(host.shape, host.shape + host.rank));
+    }
+    GpuTensorHandle upload(const std::vector<double>& data, const std::vector<size_t>& shape) const {
+        return upload(HostTensorView{data.data(), shape.data(), shape.size()});
+    }
+    HostTensorOwned download(const GpuTensorHandle& h) const {
+        HostTensorOwned out{std::vector<double>(h.numel()), h.shape};
+        check(rmhip_download(ctx_, own(h), out.data.data(), out.data.size()));
+        return out;
+    }
+    void free(const GpuTensorHandle& h) const { check(rmhip_free(ctx_, own(h))); }
+    GpuTensorHandle fill(const std::vector<size_t>& shape, double value) const {
+        uint64_t id = 0;
+        check(rmhip_fill(ctx_, value, shape.data(), shape.size(), &id));
+        return make(id, shape);
+    }
+    GpuTensorHandle zeros(const std::vector<size_t>& shape) const { return fill(shape, 0.0); }
+    GpuTensorHandle ones(const std::vector<size_t>& shape) const { return fill(shape, 1.0); }
+
+    // ---- fused kernels (lib.rs:2946-3008) ----
+    GpuTensorHandle fused_elementwise(const std::string& shader, const std::vector<GpuTensorHandle>& inputs,
+                                      const std::vector<size_t>& output_shape, size_t len) const {
+        return fused_elementwise_multi(shader, inputs, output_shape, len, 1)[0];
+    }
+    std::vector<GpuTensorHandle> fused_elementwise_multi(const std::string& shader,
+                                                         const std::vector<GpuTensorHandle>& inputs,
+                                                         const std::vector<size_t>& output_shape, size_t len,
+                                                         size_t num_outputs) const {
+        std::vector<uint64_t> ids = ids_of(inputs), outs(num_outputs, 0);
+        check(rmhip_fused_elementwise(ctx_, shader.c_str(), ids.data(), ids.size(), output_shape.data(),
+                                      output_shape.size(), len, num_outputs, outs.data()));
+        std::vector<GpuTensorHandle> r;
+        for (uint64_t id : outs) r.push_back(make(id, output_shape));
+        return r;
+    }
+    GpuTensorHandle fused_reduction(const std::string& shader, const std::vector<GpuTensorHandle>& inputs,
+                                    const std::vector<size_t>& output_shape, size_t reduce_len, size_t num_slices,
+                                    uint32_t workgroup_size, ReductionFlavor flavor) const {
+        std::vector<uint64_t> ids = ids_of(inputs);
+        uint64_t out = 0;
+        check(rmhip_fused_reduction(ctx_, shader.c_str(), ids.data(), ids.size(), output_shape.data(), output_shape.size(),
+                                    reduce_len, num_slices, workgroup_size, (int)flavor.kind, flavor.scale, &out));
+        return make(out, output_shape);
+    }
+
+    // ---- per-op hooks (lib.rs:1890-1938, 2077-2355) ----
+    GpuTensorHandle elem_add(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_ADD, a, b); }
+    GpuTensorHandle elem_sub(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_SUB, a, b); }
+    GpuTensorHandle elem_mul(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_MUL, a, b); }
+    GpuTensorHandle elem_div(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_DIV, a, b); }
+    GpuTensorHandle elem_pow(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_POW, a, b); }
+    GpuTensorHandle elem_max(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_MAX, a, b); }
+    GpuTensorHandle elem_min(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_MIN, a, b); }
+    GpuTensorHandle elem_hypot(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_HYPOT, a, b); }
+    GpuTensorHandle elem_atan2(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_ATAN2, a, b); }
+    GpuTensorHandle binary(rmhip_binary_op op, const GpuTensorHandle& a, const GpuTensorHandle& b) const {
+        uint64_t out = 0;
+        check(rmhip_binary(ctx_, op, own(a), own(b), &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle unary(rmhip_unary_op op, const GpuTensorHandle& a) const {
+        uint64_t out = 0;
+        check(rmhip_unary(ctx_, op, own(a), &out));
+        return make(out, a.shape);
+    }
+    GpuTensorHandle unary_sin(const GpuTensorHandle& a) const { return unary(RMHIP_SIN, a); }
+    GpuTensorHandle unary_cos(const GpuTensorHandle& a) const { return unary(RMHIP_COS, a); }
+    GpuTensorHandle unary_exp(const GpuTensorHandle& a) const { return unary(RMHIP_EXP, a); }
+    GpuTensorHandle unary_log(const GpuTensorHandle& a) const { return unary(RMHIP_LOG, a); }
+    GpuTensorHandle unary_sqrt(const GpuTensorHandle& a) const { return unary(RMHIP_SQRT, a); }
+    GpuTensorHandle unary_abs(const GpuTensorHandle& a) const { return unary(RMHIP_ABS, a); }
+    GpuTensorHandle unary_tanh(const GpuTensorHandle& a) const { return unary(RMHIP_TANH, a); }
+    GpuTensorHandle scalar(rmhip_scalar_op op, const GpuTensorHandle& a, double s) const {
+        uint64_t out = 0;
+        check(rmhip_scalar(ctx_, op, own(a), s, &out));
+        return make(out, a.shape);
+    }
+    GpuTensorHandle scalar_add(const GpuTensorHandle& a, double s) const { return scalar(RMHIP_SADD, a, s); }
+    GpuTensorHandle scalar_sub(const GpuTensorHandle& a, double s) const { return scalar(RMHIP_SSUB, a, s); }
+    GpuTensorHandle scalar_mul(const GpuTensorHandle& a, double s) const { return scalar(RMHIP_SMUL, a, s); }
+    GpuTensorHandle scalar_div(const GpuTensorHandle& a, double s) const { return scalar(RMHIP_SDIV, a, s); }
+    GpuTensorHandle scalar_rsub(const GpuTensorHandle& a, double s) const { return scalar(RMHIP_SRSUB, a, s); }
+    GpuTensorHandle scalar_rdiv(const GpuTensorHandle& a, double s) const { return scalar(RMHIP_SRDIV, a, s); }
+    GpuTensorHandle scalar_max(const GpuTensorHandle& a, double s) const { return scalar(RMHIP_SMAX, a, s); }
+    GpuTensorHandle scalar_min(const GpuTensorHandle& a, double s) const { return scalar(RMHIP_SMIN, a, s); }
+
+    // ---- reductions (lib.rs:2709-2883) ----
+    GpuTensorHandle reduce(rmhip_reduce_op op, const GpuTensorHandle& a, int dim, bool omitnan = false) const {
+        uint64_t out = 0;
+        check(rmhip_reduce(ctx_, op, own(a), dim, omitnan ? 1 : 0, &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle reduce_sum(const GpuTensorHandle& a) const { return reduce(RMHIP_RSUM, a, -1); }
+    GpuTensorHandle reduce_sum_dim(const GpuTensorHandle& a, size_t dim) const { return reduce(RMHIP_RSUM, a, (int)dim); }
+    GpuTensorHandle reduce_mean(const GpuTensorHandle& a) const { return reduce(RMHIP_RMEAN, a, -1); }
+    GpuTensorHandle reduce_mean_dim(const GpuTensorHandle& a, size_t dim) const { return reduce(RMHIP_RMEAN, a, (int)dim); }
+    GpuTensorHandle reduce_min(const GpuTensorHandle& a) const { return reduce(RMHIP_RMIN, a, -1); }
+    GpuTensorHandle reduce_max(const GpuTensorHandle& a) const { return reduce(RMHIP_RMAX, a, -1); }
+
+    // ---- linear algebra (lib.rs:2375, 2477-2500) ----
+    GpuTensorHandle matmul(const GpuTensorHandle& a, const GpuTensorHandle& b) const {
+        uint64_t out = 0;
+        check(rmhip_matmul(ctx_, own(a), own(b), &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle mldivide(const GpuTensorHandle& lhs, const GpuTensorHandle& rhs) const {
+        uint64_t out = 0;
+        check(rmhip_mldivide(ctx_, own(lhs), own(rhs), &out));
+        return with_shape(out);
+    }
+    ProviderLuResult lu(const GpuTensorHandle& a) const {
+        uint64_t ids[5] = {0, 0, 0, 0, 0};
+        check(rmhip_lu(ctx_, own(a), ids));
+        return {with_shape(ids[0]), with_shape(ids[1]), with_shape(ids[2]), with_shape(ids[3]), with_shape(ids[4])};
+    }
+
+    // ---- RNG (lib.rs:1713-1728, 1772) ----
+    void set_rng_state(uint64_t state) const { check(rmhip_set_rng_state(ctx_, state)); }
+    GpuTensorHandle random_uniform(const std::vector<size_t>& shape) const {
+        uint64_t out = 0;
+        check(rmhip_random_uniform(ctx_, shape.data(), shape.size(), &out));
+        return make(out, shape);
+    }
+    GpuTensorHandle random_normal(const std::vector<size_t>& shape) const {
+        uint64_t out = 0;
+        check(rmhip_random_normal(ctx_, shape.data(), shape.size(), &out));
+        return make(out, shape);
+    }
+
+    rmhip_ctx* raw() const { return ctx_; }
+
+private:
+    static void check(int rc) {
+        if (rc != RMHIP_OK) throw ProviderError(rc, rmhip_last_error());
+    }
+    GpuTensorHandle make(uint64_t id, std::vector<size_t> shape) const {
+        GpuTensorHandle h;
+        h.shape = std::move(shape);
+        h.device_id = device_id_;
+        h.buffer_id = id;
+        return h;
+    }
+    GpuTensorHandle with_shape(uint64_t id) const {
+        size_t rank = 16, shape[16];
+        check(rmhip_shape(ctx_, id, &rank, shape));
+        return make(id, std::vector<size_t>(shape, shape + rank));
+    }
+    uint64_t own(const GpuTensorHandle& h) const {
+        if (h.device_id != device_id_)  // foreign handles are an error (io.rs:269-275)
+            throw ProviderError(RMHIP_ERR_INVALID, "handle belongs to another device");
+        return h.buffer_id;
+    }
+    std::vector<uint64_t> ids_of(const std::vector<GpuTensorHandle>& hs) const {
+        std::vector<uint64_t> ids;
+        for (const auto& h : hs) ids.push_back(own(h));
+        return ids;
+    }
+    rmhip_ctx* ctx_ = nullptr;
+    uint32_t device_id_ = 0;
+};
+
+}  // namespace rmhip
