@@ -174,6 +174,10 @@ enum rmhip_reduce_op { RMHIP_RSUM = 0, RMHIP_RMEAN, RMHIP_RMIN, RMHIP_RMAX, RMHI
 RMHIP_API int rmhip_reduce(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int nan_mode,
                            rmhip_buf* out);
 
+/* `dot` (lib.rs:2722-2728): sum(a .* b) along `dim` (zero-based) of two same-shape tensors; dim < 0
+ * = first non-singleton dimension (vectors -> scalar [1,1]). One fused pass, no temporary. */
+RMHIP_API int rmhip_dot(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, int dim, rmhip_buf* out);
+
 /* ---- linear algebra  (lib.rs:2375-2405, 2477-2500) ------------------------------------------ */
 
 /* `matmul`: C = A*B, 2-D, column-major; inner dims must agree else RMHIP_ERR_SHAPE

@@ -146,6 +146,9 @@ int launch_reduce_all(Context* c, int op, int nan_mode, const double* x, size_t 
 int launch_reduce_mid(Context* c, int op, int nan_mode, const double* x, size_t pre, size_t red,
                       size_t post, double* out);
 
+// sum(a .* b) over the middle extent of [pre, red, post]
+int launch_reduce_dot(Context* c, const double* a, const double* b, size_t pre, size_t red, size_t post, double* out);
+
 // dgemm (dgemm.hip): C[m x n] = alpha * A[m x k] * B[k x n] + beta * C, column-major with leading
 // dimensions. beta == 0 ignores C's previous contents.
 int launch_dgemm(Context* c, size_t m, size_t n, size_t k, double alpha, const double* A, size_t lda,

@@ -42,7 +42,8 @@ struct LuState {
 static constexpr int MAX_PANEL_BLOCKS = 1024;  // 64 rows per block => up to 65536 rows per panel
 static constexpr int PANEL_JT = 8;            // panel columns per thread (unrolled batch; keep the code small)
 static constexpr int PANEL_GROUPS = BASE_W / PANEL_JT;
-static constexpr int PANEL_THREADS = 64 * PANEL_GROUPS;
+static constexpr int PANEL_ROWS = 64;          // rows per block (32 was measured slower: 278 vs 246 ms at n = 16384)
+static constexpr int PANEL_THREADS = PANEL_ROWS * PANEL_GROUPS;
 
 // ---- base panel: ONE launch per column, lazy pivoting ----------------------------------------------
 // Inside a base panel rows are NOT moved: a pivot row simply retires where it lies, and the position
@@ -71,10 +72,10 @@ __global__ void __launch_bounds__(PANEL_THREADS) k_lu_col(double* __restrict__ A
     __shared__ int s_piv[4];  // prow, ppos, occ, skip
     __shared__ double s_prow_vals[BASE_W];
     const int t = threadIdx.x;
-    const int lane = t & 63, grp = t >> 6;
+    const int lane = t & (PANEL_ROWS - 1), grp = t / PANEL_ROWS;
     const int next_col = first ? j0 : k + 1;
     const bool want_next = next_col < c1;
-    const size_t r = (size_t)j0 + (size_t)blockIdx.x * 64 + lane;  // grid covers every row once
+    const size_t r = (size_t)j0 + (size_t)blockIdx.x * PANEL_ROWS + lane;  // grid covers every row once
     const int jbase = grp * PANEL_JT;
     const int ncols = c1 - k;  // panel columns k .. c1-1 (relative 0 .. ncols-1)
     const bool in_rows = r < rows;
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(PANEL_THREADS) k_lu_col(double* __restrict__ A
             int bp = 0x7fffffff, br = -1;
             const int base = (k & 1) * MAX_PANEL_BLOCKS;
             const int occ = lane == 0 ? row_at[k] : 0;  // physical row at position k
-            for (int b = lane; b < nblocks; b += 64) {
+            for (int b = lane; b < nblocks; b += PANEL_ROWS) {
                 const double a = cand_abs[base + b];
                 const int p = cand_pos[base + b];
                 if (a > ba || (a == ba && a > 0.0 && p < bp)) {
@@ -114,10 +115,10 @@ __global__ void __launch_bounds__(PANEL_THREADS) k_lu_col(double* __restrict__ A
                     br = cand_row[base + b];
                 }
             }
-            for (int off = 32; off > 0; off >>= 1) {
-                const double oa = __shfl_down(ba, off, 64);
-                const int op = __shfl_down(bp, off, 64);
-                const int orow = __shfl_down(br, off, 64);
+            for (int off = PANEL_ROWS / 2; off > 0; off >>= 1) {
+                const double oa = __shfl_down(ba, off, PANEL_ROWS);
+                const int op = __shfl_down(bp, off, PANEL_ROWS);
+                const int orow = __shfl_down(br, off, PANEL_ROWS);
                 if (oa > ba || (oa == ba && oa > 0.0 && op < bp)) {
                     ba = oa;
                     bp = op;
@@ -186,10 +187,10 @@ __global__ void __launch_bounds__(PANEL_THREADS) k_lu_col(double* __restrict__ A
             brow = (int)r;
         }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double oa = __shfl_down(best, off, 64);
-        const int op = __shfl_down(bpos, off, 64);
-        const int orow = __shfl_down(brow, off, 64);
+    for (int off = PANEL_ROWS / 2; off > 0; off >>= 1) {
+        const double oa = __shfl_down(best, off, PANEL_ROWS);
+        const int op = __shfl_down(bpos, off, PANEL_ROWS);
+        const int orow = __shfl_down(brow, off, PANEL_ROWS);
         if (oa > best || (oa == best && oa > 0.0 && op < bpos)) {
             best = oa;
             bpos = op;
@@ -372,9 +373,9 @@ static int getrf_rec(LuState& s, size_t j0, size_t w) {
     if (w == 0 || j0 >= s.rows) return RMHIP_OK;
     if (w <= (size_t)BASE_W) {
         const size_t c1 = j0 + w;  // j0 + w <= min(rows, cols) always holds (see lu_factor_device)
-        const size_t nb = (s.rows - j0 + 63) / 64;  // one block per 64 rows
+        const size_t nb = (s.rows - j0 + PANEL_ROWS - 1) / PANEL_ROWS;  // one block per PANEL_ROWS rows
         if (nb > (size_t)MAX_PANEL_BLOCKS)
-            return fail(RMHIP_ERR_UNSUPPORTED, "lu: more than %d rows per panel not supported yet", MAX_PANEL_BLOCKS * 64);
+            return fail(RMHIP_ERR_UNSUPPORTED, "lu: more than %d rows per panel not supported yet", MAX_PANEL_BLOCKS * PANEL_ROWS);
         // init launch: candidates for column j0; then one launch per column
         hipLaunchKernelGGL(k_lu_col, dim3((unsigned)nb), dim3(PANEL_THREADS), 0, s.c->stream, s.A, s.lda, s.rows, (int)j0,
                            (int)j0 - 1, (int)c1, 1, (int)nb, s.pos_of, s.row_at, s.prow, s.ipiv, s.info, s.cand_abs, s.cand_pos, s.cand_row);

@@ -72,6 +72,46 @@ int launch_reduce_mid(Context* c, int op, int nan_mode, const double* x, size_t 
     }
 }
 
+// ---- dot: the producer a.*b folded into the same skeleton (no temporary array) -------------------
+struct ProductVal {
+    const double* __restrict__ a;
+    const double* __restrict__ b;
+    __device__ __forceinline__ double operator()(rm_u64 idx) const { return a[idx] * b[idx]; }
+};
+__global__ void __launch_bounds__(RM_RBLOCK) k_dot_contig(const double* a, const double* b, rm_u64 red, rm_u64 nslices,
+                                                          rm_u64 nsplit, double* pv, double* pn) {
+    ProductVal f{a, b};
+    rm_reduce_contig<RM_RSUM>(f, red, nslices, nsplit, pv, pn);
+}
+__global__ void __launch_bounds__(RM_RBLOCK) k_dot_strided(const double* a, const double* b, rm_u64 pre, rm_u64 red,
+                                                           rm_u64 nsplit, int tx, double* pv, double* pn) {
+    ProductVal f{a, b};
+    rm_reduce_strided<RM_RSUM>(f, pre, red, nsplit, tx, pv, pn);
+}
+
+int launch_reduce_dot(Context* c, const double* a, const double* b, size_t pre, size_t red, size_t post, double* out) {
+    const ReducePlan p = plan_reduction(pre, red, post, c->num_cus);
+    if (p.nslices == 0) return RMHIP_OK;
+    if (!p.valid) return fail(RMHIP_ERR_UNSUPPORTED, "dot: geometry [%zu,%zu,%zu] exceeds launch limits", pre, red, post);
+    const size_t nparts = (size_t)(p.nslices * p.nsplit);
+    RMHIP_TRY(c->ensure_scratch(2 * nparts * sizeof(double)));
+    double* pv = c->scratch;
+    double* pn = c->scratch + nparts;
+    if (p.contiguous)
+        hipLaunchKernelGGL(k_dot_contig, dim3(p.gx, p.gy, p.gz), dim3(RM_RBLOCK), 0, c->stream, a, b, (rm_u64)red,
+                           (rm_u64)p.nslices, (rm_u64)p.nsplit, pv, pn);
+    else
+        hipLaunchKernelGGL(k_dot_strided, dim3(p.gx, p.gy, p.gz), dim3(RM_RBLOCK), 0, c->stream, a, b, (rm_u64)pre,
+                           (rm_u64)red, (rm_u64)p.nsplit, p.tx, pv, pn);
+    RMHIP_HIP_CHECK(hipGetLastError());
+    const unsigned fb = (unsigned)ceil_div_u64(p.nslices, RM_RBLOCK / 64);
+    hipLaunchKernelGGL((k_reduce_final<RM_RSUM>), dim3(fb), dim3(RM_RBLOCK), 0, c->stream, pv, pn, (rm_u64)p.nslices,
+                       (rm_u64)p.nsplit, (rm_u64)red, 0, 0, 1.0, out);
+    RMHIP_HIP_CHECK(hipGetLastError());
+    c->tel.kernel_launches += 2;
+    return RMHIP_OK;
+}
+
 int launch_reduce_all(Context* c, int op, int nan_mode, const double* x, size_t n, double* out) {
     return launch_reduce_mid(c, op, nan_mode, x, 1, n, 1, out);
 }

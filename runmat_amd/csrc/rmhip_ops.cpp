@@ -425,6 +425,35 @@ int rmhip_reduce(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int nan_mode, rmh
     return rc;
 }
 
+int rmhip_dot(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, int dim, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer ab, bb, ob;
+    RMHIP_TRY(c->get(a, &ab));
+    RMHIP_TRY(c->get(b, &bb));
+    const std::vector<size_t> sa = normalize_matrix_shape(ab.shape), sb = normalize_matrix_shape(bb.shape);
+    if (sa != sb) return fail(RMHIP_ERR_SHAPE, "dot: A and B must be the same size");
+    int d = dim;
+    if (d < 0) {  // first non-singleton dimension
+        d = 0;
+        for (size_t i = 0; i < sa.size(); ++i)
+            if (sa[i] != 1) {
+                d = (int)i;
+                break;
+            }
+    }
+    if ((size_t)d >= sa.size()) return fail(RMHIP_ERR_UNSUPPORTED, "dot: dim %d out of range for rank %zu", d, sa.size());
+    size_t pre = 1, post = 1;
+    for (int i = 0; i < d; ++i) pre *= sa[i];
+    for (size_t i = d + 1; i < sa.size(); ++i) post *= sa[i];
+    std::vector<size_t> oshape = sa;
+    oshape[d] = 1;
+    RMHIP_TRY(c->new_buffer(oshape.data(), oshape.size(), out, &ob));
+    int rc = launch_reduce_dot(c, ab.data(), bb.data(), pre, sa[d], post, ob.data());
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+
 int rmhip_matmul(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);
     ScopedTimer timer(&c->tel.matmul_count, &c->tel.matmul_ns);

@@ -302,6 +302,12 @@ class HipProvider:
     def reduce_prod(self, a): return self._reduce("prod", a, -1)
     def reduce_prod_dim(self, a, dim): return self._reduce("prod", a, dim)
 
+    def dot(self, a: GpuTensorHandle, b: GpuTensorHandle, dim: Optional[int] = None) -> GpuTensorHandle:
+        """`dot(lhs, rhs, dim)` (lib.rs:2722): dim is zero-based, None = first non-singleton."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_dot(self._ctx, self._id(a), self._id(b), -1 if dim is None else int(dim), C.byref(out)))
+        return self._handle(out.value)
+
     # -- linear algebra -------------------------------------------------------------------------
     def matmul(self, a: GpuTensorHandle, b: GpuTensorHandle) -> GpuTensorHandle:
         out = C.c_uint64()

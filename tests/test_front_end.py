@@ -189,3 +189,19 @@ def test_literals_are_exact(built):
     assert "((v * f64(0.1)) + (f64(-3) - f64(inf)))" in sh
     src = wgsl_translate(sh, "reduction")
     assert (0.1).hex() in src and "(-0x1.8p+1)" in src and "__builtin_inf()" in src
+
+
+def test_runtime_broadcast_shape_rules():
+    """fusion_exec.rs:216-245"""
+    import numpy as np
+
+    from runmat_amd.fusion_exec import normalize_scalar_shape, runtime_broadcast_shape
+    from runmat_amd.provider import GpuTensorHandle
+
+    h = GpuTensorHandle((4, 1), 1, 1)
+    assert runtime_broadcast_shape([h, np.zeros((1, 3)), 2.0]) == (4, 3)
+    assert runtime_broadcast_shape([np.zeros((2, 3, 4)), np.zeros((4,))]) == (2, 3, 4)  # trailing alignment
+    assert runtime_broadcast_shape([np.zeros((2, 3)), np.zeros((3, 2))]) is None
+    assert runtime_broadcast_shape([1.0, 2]) == ()
+    assert runtime_broadcast_shape(["x"]) is None
+    assert normalize_scalar_shape(()) == (1, 1) and normalize_scalar_shape((5,)) == (5, 1) and normalize_scalar_shape((2, 3)) == (2, 3)

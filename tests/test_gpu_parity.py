@@ -672,3 +672,49 @@ def test_sharding_paths_on_one_gpu(prov, oracle):
     assert np.array_equal(prov.download_matrix(h), A) and keep is None
     x = prov.upload(np.linspace(0.0, 1.0, 1001))
     assert abs(sh.sum_all_sharded(prov, g, x) - oracle.reduce_sum(np.linspace(0.0, 1.0, 1001).reshape(-1, 1), "all")[0, 0]) < 1e-12
+
+
+def test_host_executors_mixed_operands(prov, oracle):
+    """execute_elementwise / execute_reduction (fusion_exec.rs:196-628): resident handles, host
+    tensors and scalars in one request; temporaries freed; shapes from runtime broadcast."""
+    from runmat_amd.fusion import FusionGroupPlan
+    from runmat_amd.fusion_exec import execute_elementwise, execute_reduction
+
+    rng = np.random.default_rng(21)
+    A = rng.standard_normal((64, 1))
+    B = rng.standard_normal((1, 48))
+    p = FusionGroupPlan()
+    a, b, c = p.input(), p.input(), p.input()
+    out = p.primitive("Add", p.primitive("ElemMul", a, b), c)
+    before = prov.telemetry_snapshot()["bytes_pooled"]
+    (h,) = execute_elementwise(prov, p, [out], [prov.upload(A), B, 0.5])
+    assert h.shape == (64, 48)
+    assert bits_equal(prov.download_matrix(h), A * B + 0.5)
+    assert prov.telemetry_snapshot()["bytes_pooled"] >= before  # the two temporaries went back to the pool
+    q = FusionGroupPlan()
+    x, s = q.input(), q.input()
+    v = q.primitive("ElemMul", x, s)
+    X = rng.standard_normal((100, 7))
+    r = execute_reduction(prov, q, v, [X, 2.0], 100, 7, axis=0)
+    assert r.shape == (7,) and np.allclose(prov.download(r), 2.0 * X.sum(axis=0), rtol=1e-13)
+
+
+def test_dot(prov, oracle):
+    from runmat_amd import ProviderError
+
+    rng = np.random.default_rng(22)
+    a, b = rng.standard_normal((5000, 1)), rng.standard_normal((5000, 1))
+    d = prov.dot(prov.upload(a), prov.upload(b))
+    assert d.shape == (1, 1)
+    want = oracle.reduce_sum(oracle.binary("mul", a, b), "all")[0, 0]
+    assert abs(prov.download(d)[0] - want) <= 5000 * EPS * np.abs(a * b).sum()
+    A, B = rng.standard_normal((300, 40)), rng.standard_normal((300, 40))
+    ha, hb = prov.upload(A), prov.upload(B)
+    c0 = prov.dot(ha, hb)          # first non-singleton dim = rows
+    c1 = prov.dot(ha, hb, 1)
+    assert c0.shape == (1, 40) and c1.shape == (300, 1)
+    assert np.allclose(prov.download(c0), (A * B).sum(axis=0), rtol=1e-12, atol=1e-13)
+    assert np.allclose(prov.download(c1), (A * B).sum(axis=1), rtol=1e-12, atol=1e-13)
+    with pytest.raises(ProviderError) as e:
+        prov.dot(ha, prov.upload(np.ones((40, 300))))
+    assert e.value.code == 3
