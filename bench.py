@@ -71,6 +71,24 @@ def cpu_baseline_dgemm():
                       "workload extrapolates ~n^3"}
 
 
+def cpu_baseline_chain():
+    """BASELINE configs[0]: the reference CPU path on elementwise-math @1024x1024 f64 -- 14 builtin
+    passes with one temporary each (oracle/oracle.c orc_elementwise_math_chain), one core."""
+    from oracle import oracle
+
+    m = 1024
+    x = np.linspace(0.0, 4.0 * np.pi, m * m)
+    reps, t_total = 0, 0.0
+    while t_total < 3.0 and reps < 200:
+        t0 = time.perf_counter()
+        oracle.elementwise_math_chain(x)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    ms = t_total / reps * 1e3
+    return {"value": round(16.0 * m * m / (ms * 1e-3) / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} x full 1024x1024 chain, {ms:.1f} ms each (16 B/elem algorithmic, fused form)"}
+
+
 def cpu_baseline_mc():
     """Oracle Monte-Carlo (serial LCG + Box-Muller + one temporary per op) on a bounded sample."""
     from oracle import oracle
@@ -116,7 +134,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["fused", "dgemm", "mc", "mldivide"], default="fused")
+    ap.add_argument("--workload", choices=["fused", "dgemm", "mc", "mldivide", "chain"], default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     args = ap.parse_args()
@@ -307,7 +325,46 @@ def main() -> None:
                          "kernel": "k_lu_col chain + k_dgemm trailing updates (whole solve, wall clock)"},
         }
 
-    records = {"fused": fused_record, "dgemm": dgemm_record, "mc": mc_record, "mldivide": mldivide_record}
+    def chain_record(steps, warmup):
+        """BASELINE configs[0] (the reference's CPU-runnable case) on the GPU: the 14-op
+        elementwise-math chain (benchmarks/elementwise-math/runmat.m:10-13, f64) as ONE fused kernel
+        over a 1024x1024 tensor; constants arrive as 1-element inputs like the planner sends them."""
+        from runmat_amd.fusion import elementwise_math_plan
+
+        m = 1024
+        plan, out_id = elementwise_math_plan()
+        shader = plan.generate_wgsl_for_output(out_id, "f64")
+        hx = prov.upload(np.linspace(0.0, 4.0 * np.pi, m * m), (m, m))
+        consts = [prov.upload(np.array([v]), (1, 1)) for v in (10.0, 4.0, 0.25, 2.0, 0.1)]
+
+        def step():
+            prov.free(prov.fused_elementwise(shader, [hx] + consts, (m, m), m * m))
+
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        wall = max_over_ranks(time.perf_counter() - t0)
+        ms = wall / steps * 1e3
+        for h in [hx] + consts:
+            prov.free(h)
+        nbytes = 16 * m * m  # fused form: one read + one write per element
+        return {
+            "metric": "fused elementwise GB/s (elementwise-math 14-op chain, 1024x1024 f64)",
+            "value": round(world * nbytes / (ms * 1e-3) / 1e9, 2), "unit": "GB/s", "ms_per_step": round(ms, 5),
+            "scaling": "weak", "dtype": "f64",
+            "config": {"workload": "benchmarks/elementwise-math chain, 1024x1024 f64, one fused kernel",
+                       "bytes_per_step_per_gpu": nbytes, "parallelism": f"independent x{world}"},
+            "roofline": {"bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "rm_ew_fast (16.8 MB per launch: launch-latency bound, not a roofline case)"},
+        }
+
+    records = {"fused": fused_record, "dgemm": dgemm_record, "mc": mc_record, "mldivide": mldivide_record,
+               "chain": chain_record}
     primary = records[args.workload]
     rec = primary(args.steps, args.warmup)
     out = {
@@ -318,18 +375,18 @@ def main() -> None:
     }
     if not args.no_also:
         # the other configs of BASELINE.json, short runs; every rank takes part (collectives inside)
-        others = [w for w in ("fused", "dgemm", "mc") if w != args.workload]
+        others = [w for w in ("fused", "dgemm", "mc", "chain") if w != args.workload]
         if world == 1 and args.workload != "mldivide":
             others.append("mldivide")
         also = []
         for w in others:
-            steps = {"fused": 20, "dgemm": 5, "mc": 3, "mldivide": 2}[w]
+            steps = {"fused": 20, "dgemm": 5, "mc": 3, "mldivide": 2, "chain": 100}[w]
             sec = records[w](steps, 2 if w != "mldivide" else 1)
             also.append({k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "roofline")})
         out["also"] = also
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = {"fused": cpu_baseline_fused, "dgemm": cpu_baseline_dgemm, "mc": cpu_baseline_mc,
-                               "mldivide": cpu_baseline_mldivide}[args.workload]()
+                               "mldivide": cpu_baseline_mldivide, "chain": cpu_baseline_chain}[args.workload]()
         for a in out.get("also", []):
             if a["unit"] == "GFLOP/s" and "matmul" in a["metric"]:
                 a["cpu_baseline"] = cpu_baseline_dgemm()
@@ -337,6 +394,8 @@ def main() -> None:
                 a["cpu_baseline"] = cpu_baseline_mc()
             elif "A\\b" in a["metric"]:
                 a["cpu_baseline"] = cpu_baseline_mldivide()
+            elif "14-op chain" in a["metric"]:
+                a["cpu_baseline"] = cpu_baseline_chain()
     info = prov.device_info_struct()
     out["device"] = {"arch": info["arch"], "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"],
                      "hbm_bytes": info["total_memory_bytes"]}
