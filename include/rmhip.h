@@ -183,6 +183,21 @@ RMHIP_API int rmhip_dot(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, int dim, rmhip
 /* `matmul`: C = A*B, 2-D, column-major; inner dims must agree else RMHIP_ERR_SHAPE
  * (simple_provider.rs:7698-7741). fp64 MFMA kernel. */
 RMHIP_API int rmhip_matmul(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out);
+/* `matmul_epilogue` (lib.rs:2394-2405, descriptor `MatmulEpilogue` lib.rs:3498-3560): the epilogue is
+ * folded into the dgemm store.  Order (simple_provider.rs:7800-7836): v = acc*alpha + beta; row scale;
+ * column scale; clamp_min (max); clamp_max (min); pow; then the diagonal copy.  Buffer ids of 0 mean
+ * "absent".  `diag_output` (length >= min(m,n)) is written in place -- the one documented exception to
+ * "inputs are never mutated". */
+typedef struct rmhip_matmul_epilogue {
+    double alpha, beta;
+    rmhip_buf row_scale, col_scale;  /* 0 = none; lengths m / n */
+    int row_op, col_op;              /* ScaleOp: 0 = Multiply, 1 = Divide */
+    int has_clamp_min, has_clamp_max, has_pow;
+    double clamp_min, clamp_max, pow_exponent;
+    rmhip_buf diag_output;           /* 0 = none */
+} rmhip_matmul_epilogue_t;
+RMHIP_API int rmhip_matmul_epilogue(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b,
+                                    const rmhip_matmul_epilogue_t* ep, rmhip_buf* out);
 /* `lu` -> ProviderLuResult {combined, lower, upper, perm_matrix, perm_vector} (lib.rs:649-698);
  * pivot rule and singular cut-off of host_lu.rs:37-59.  out5 order: combined, L, U, P, pivots. */
 RMHIP_API int rmhip_lu(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf out5[5]);

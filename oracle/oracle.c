@@ -49,6 +49,31 @@ ORC_API int orc_matmul(const double* a, size_t arows, size_t acols, const double
     return 0;
 }
 
+/* matmul_epilogue -- crates/runmat-accelerate/src/simple_provider.rs:7743-7846 (the reference
+ * provider's statement of `MatmulEpilogue`, lib.rs:3498-3560): plain matmul, then per element
+ * v = v*alpha + beta; row scale; col scale; clamp_min (f64::max); clamp_max (f64::min); powf; diag copy.
+ * NULL pointers / has_* == 0 mean "absent". */
+ORC_API int orc_matmul_epilogue(const double* a, size_t arows, size_t acols, const double* b, size_t brows,
+                                size_t bcols, double alpha, double beta, const double* row_scale, int row_div,
+                                const double* col_scale, int col_div, int has_min, double clamp_min, int has_max,
+                                double clamp_max, int has_pow, double pow_exp, double* diag, double* out) {
+    int rc = orc_matmul(a, arows, acols, b, brows, bcols, out);
+    if (rc) return rc;
+    for (size_t j = 0; j < bcols; ++j) {
+        for (size_t i = 0; i < arows; ++i) {
+            double v = out[i + j * arows] * alpha + beta;
+            if (row_scale) v = row_div ? v / row_scale[i] : v * row_scale[i];
+            if (col_scale) v = col_div ? v / col_scale[j] : v * col_scale[j];
+            if (has_min) v = fmax(v, clamp_min);
+            if (has_max) v = fmin(v, clamp_max);
+            if (has_pow) v = pow(v, pow_exp);
+            if (diag && i == j) diag[i] = v;
+            out[i + j * arows] = v;
+        }
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Unary maps -- e.g. crates/runmat-runtime/src/builtins/math/trigonometry/sin.rs:245-255
  * (`tensor.data.iter().map(|&v| v.sin()).collect()`): one libm call per element.

@@ -39,6 +39,10 @@ def lib() -> C.CDLL:
         l = C.CDLL(str(LIB_PATH))
         l.orc_matmul.restype = C.c_int
         l.orc_matmul.argtypes = [_DP, C.c_size_t, C.c_size_t, _DP, C.c_size_t, C.c_size_t, _DP]
+        l.orc_matmul_epilogue.restype = C.c_int
+        l.orc_matmul_epilogue.argtypes = [_DP, C.c_size_t, C.c_size_t, _DP, C.c_size_t, C.c_size_t, C.c_double, C.c_double,
+                                          _DP, C.c_int, _DP, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int,
+                                          C.c_double, _DP, _DP]
         l.orc_unary.restype = C.c_int
         l.orc_unary.argtypes = [C.c_int, _DP, C.c_size_t, _DP]
         l.orc_binary.restype = C.c_int
@@ -98,6 +102,27 @@ def matmul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     if rc:
         raise ValueError("Inner matrix dimensions must agree")
     return out.reshape((a.shape[0], b.shape[1]), order="F")
+
+
+def matmul_epilogue(a, b, alpha=1.0, beta=0.0, row_scale=None, col_scale=None, row_op="multiply", col_op="multiply",
+                    clamp_min=None, clamp_max=None, pow_exponent=None, diag=False):
+    """Returns (C, diag or None)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    fa, fb = _f(a), _f(b)
+    out = np.empty(a.shape[0] * b.shape[1], dtype=np.float64)
+    rs = _f(row_scale) if row_scale is not None else None
+    cs = _f(col_scale) if col_scale is not None else None
+    dg = np.zeros(min(a.shape[0], b.shape[1])) if diag else None
+    rc = lib().orc_matmul_epilogue(_p(fa), a.shape[0], a.shape[1], _p(fb), b.shape[0], b.shape[1], alpha, beta,
+                                   _p(rs) if rs is not None else None, int(row_op == "divide"),
+                                   _p(cs) if cs is not None else None, int(col_op == "divide"),
+                                   int(clamp_min is not None), float(clamp_min or 0.0), int(clamp_max is not None),
+                                   float(clamp_max or 0.0), int(pow_exponent is not None), float(pow_exponent or 0.0),
+                                   _p(dg) if dg is not None else None, _p(out))
+    if rc:
+        raise ValueError("Inner matrix dimensions must agree")
+    return out.reshape((a.shape[0], b.shape[1]), order="F"), dg
 
 
 def unary(op: str, x: np.ndarray) -> np.ndarray:

@@ -40,6 +40,14 @@ class Telemetry(C.Structure):
         "fusion_cache_hits", "fusion_cache_misses", "kernel_launches", "bytes_allocated", "bytes_pooled")]
 
 
+class MatmulEpilogue(C.Structure):
+    """rmhip_matmul_epilogue_t (MatmulEpilogue, lib.rs:3498-3560)"""
+    _fields_ = [("alpha", C.c_double), ("beta", C.c_double), ("row_scale", C.c_uint64), ("col_scale", C.c_uint64),
+                ("row_op", C.c_int), ("col_op", C.c_int), ("has_clamp_min", C.c_int), ("has_clamp_max", C.c_int),
+                ("has_pow", C.c_int), ("clamp_min", C.c_double), ("clamp_max", C.c_double), ("pow_exponent", C.c_double),
+                ("diag_output", C.c_uint64)]
+
+
 # Every symbol include/rmhip.h declares: name -> (restype, argtypes). Used both to bind and by the
 # CPU-side test that checks the library exports the full ABI.
 _P = C.c_void_p
@@ -78,6 +86,7 @@ SIGNATURES = {
     "rmhip_reduce": (C.c_int, [_P, C.c_int, _BUF, C.c_int, C.c_int, _BUFP]),
     "rmhip_dot": (C.c_int, [_P, _BUF, _BUF, C.c_int, _BUFP]),
     "rmhip_matmul": (C.c_int, [_P, _BUF, _BUF, _BUFP]),
+    "rmhip_matmul_epilogue": (C.c_int, [_P, _BUF, _BUF, C.POINTER(MatmulEpilogue), _BUFP]),
     "rmhip_lu": (C.c_int, [_P, _BUF, _BUFP]),
     "rmhip_mldivide": (C.c_int, [_P, _BUF, _BUF, _BUFP]),
     "rmhip_set_rng_state": (C.c_int, [_P, C.c_uint64]),

@@ -153,6 +153,19 @@ int launch_reduce_dot(Context* c, const double* a, const double* b, size_t pre, 
 // dimensions. beta == 0 ignores C's previous contents.
 int launch_dgemm(Context* c, size_t m, size_t n, size_t k, double alpha, const double* A, size_t lda,
                  const double* B, size_t ldb, double beta, double* C, size_t ldc);
+// C = epilogue(A*B): MatmulEpilogue folded into the store (lib.rs:3498-3560).
+struct GemmEpilogue {
+    int flags;  // EP_* bits
+    double alpha, beta_add;
+    const double* row_scale;
+    const double* col_scale;
+    double clamp_min, clamp_max, pow_exp;
+    double* diag;
+};
+enum { EP_ACTIVE = 1, EP_ROW = 2, EP_ROW_DIV = 4, EP_COL = 8, EP_COL_DIV = 16, EP_CLAMP_MIN = 32, EP_CLAMP_MAX = 64,
+       EP_POW = 128, EP_DIAG = 256 };
+int launch_dgemm_epilogue(Context* c, size_t m, size_t n, size_t k, const double* A, size_t lda, const double* B,
+                          size_t ldb, double* C, size_t ldc, const GemmEpilogue& ep);
 
 // rng (rng.hip)
 int launch_rng_uniform(Context* c, uint64_t state, double* out, size_t n);

@@ -52,7 +52,20 @@ struct GemmArgs {
     double alpha, beta;
     int rowmap;  // accumulator row formula selector (see store code)
     int vec_a, vec_b;  // EDGE kernel: 16-byte loads are legal for A / B (aligned base, even leading dimension)
+    GemmEpilogue ep;   // matmul_epilogue: flags == 0 for plain GEMM
 };
+
+// MatmulEpilogue on one output element, order of crates/runmat-accelerate/src/simple_provider.rs:7800-7836
+__device__ __noinline__ double apply_epilogue(const GemmEpilogue& e, double acc, unsigned mm, unsigned nn) {
+    double v = acc * e.alpha + e.beta_add;
+    if (e.flags & EP_ROW) v = (e.flags & EP_ROW_DIV) ? v / e.row_scale[mm] : v * e.row_scale[mm];
+    if (e.flags & EP_COL) v = (e.flags & EP_COL_DIV) ? v / e.col_scale[nn] : v * e.col_scale[nn];
+    if (e.flags & EP_CLAMP_MIN) v = fmax(v, e.clamp_min);  // Rust f64::max: NaN loses
+    if (e.flags & EP_CLAMP_MAX) v = fmin(v, e.clamp_max);
+    if (e.flags & EP_POW) v = pow(v, e.pow_exp);
+    if ((e.flags & EP_DIAG) && mm == nn) e.diag[mm] = v;
+    return v;
+}
 
 __device__ __forceinline__ void tile_of_block(const GemmArgs& g, unsigned& tm, unsigned& tn) {
     const unsigned nwg = g.tiles_m * g.tiles_n;
@@ -72,7 +85,10 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs& g, unsigned& tm, u
 }
 
 // EDGE = false: m % 128 == 0, n % 128 == 0, k % 16 == 0, lda/ldb even, 16-byte aligned bases.
-template <bool EDGE>
+// EPI = true: the MatmulEpilogue variant.  It is a SEPARATE instantiation on purpose: inlining the
+// epilogue (pow!) into the plain kernel cost 2.7x (66.8 -> 24.8 TFLOP/s) -- waves in the bloated
+// store phase evicted the main loop of their CU pair's instruction cache.
+template <bool EDGE, bool EPI>
 __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* As = lds;                    // [2][BK][SA]
@@ -206,7 +222,7 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
                 dst[i * 4 + r] = g.C + (size_t)nn * g.ldc + mm;
             }
         }
-        if (g.beta != 0.0) {
+        if (!EPI && g.beta != 0.0) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) prev[e] = ok[e] ? *dst[e] : 0.0;
         }
@@ -215,8 +231,16 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int e = i * 4 + r;
-                double v = g.alpha * acc[j][i][r];
-                if (g.beta != 0.0) v = g.beta * prev[e] + v;
+                double v;
+                if (EPI) {
+                    const unsigned mm = m0 + wm * 64 + i * 16 + l15;
+                    const unsigned row = g.rowmap ? (4 * lq + r) : (4 * r + lq);
+                    const unsigned nn = n0 + wn * 64 + j * 16 + row;
+                    v = ok[e] ? apply_epilogue(g.ep, acc[j][i][r], mm, nn) : 0.0;
+                } else {
+                    v = g.alpha * acc[j][i][r];
+                    if (g.beta != 0.0) v = g.beta * prev[e] + v;
+                }
                 if (ok[e]) *dst[e] = v;
             }
         }
@@ -225,8 +249,21 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
 
 static int g_rowmap = -1;
 
+static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double alpha, const double* A, size_t lda,
+                             const double* B, size_t ldb, double beta, double* C, size_t ldc, const GemmEpilogue* ep);
+
 int launch_dgemm(Context* c, size_t m, size_t n, size_t k, double alpha, const double* A, size_t lda,
                  const double* B, size_t ldb, double beta, double* C, size_t ldc) {
+    return launch_dgemm_impl(c, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, nullptr);
+}
+
+int launch_dgemm_epilogue(Context* c, size_t m, size_t n, size_t k, const double* A, size_t lda, const double* B,
+                          size_t ldb, double* C, size_t ldc, const GemmEpilogue& ep) {
+    return launch_dgemm_impl(c, m, n, k, 1.0, A, lda, B, ldb, 0.0, C, ldc, &ep);
+}
+
+static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double alpha, const double* A, size_t lda,
+                             const double* B, size_t ldb, double beta, double* C, size_t ldc, const GemmEpilogue* ep) {
     if (m == 0 || n == 0) return RMHIP_OK;
     if (m > 0xffffffffULL || n > 0xffffffffULL || k > 0xffffffffULL)
         return fail(RMHIP_ERR_UNSUPPORTED, "dgemm: dimension exceeds 2^32");
@@ -251,20 +288,25 @@ int launch_dgemm(Context* c, size_t m, size_t n, size_t k, double alpha, const d
     g.rowmap = g_rowmap;
     g.vec_a = ((((uintptr_t)A & 15) == 0) && (lda % 2 == 0)) ? 1 : 0;
     g.vec_b = ((((uintptr_t)B & 15) == 0) && (ldb % 2 == 0)) ? 1 : 0;
+    if (ep) g.ep = *ep;
+    else g.ep = GemmEpilogue{0, 1.0, 0.0, nullptr, nullptr, 0.0, 0.0, 0.0, nullptr};
     const size_t lds_bytes = (size_t)(2 * A_TILE + 2 * B_TILE) * sizeof(double);
     const bool fast = (m % BM == 0) && (n % BN == 0) && (k % BK == 0) && k > 0 && (lda % 2 == 0) && (ldb % 2 == 0) &&
                       (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
     const unsigned blocks = g.tiles_m * g.tiles_n;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_dgemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute((const void*)k_dgemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void*)k_dgemm<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void*)k_dgemm<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void*)k_dgemm<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
-    if (fast)
-        hipLaunchKernelGGL((k_dgemm<false>), dim3(blocks), dim3(256), lds_bytes, c->stream, g);
+    if (ep)
+        hipLaunchKernelGGL((k_dgemm<true, true>), dim3(blocks), dim3(256), lds_bytes, c->stream, g);
+    else if (fast)
+        hipLaunchKernelGGL((k_dgemm<false, false>), dim3(blocks), dim3(256), lds_bytes, c->stream, g);
     else
-        hipLaunchKernelGGL((k_dgemm<true>), dim3(blocks), dim3(256), lds_bytes, c->stream, g);
+        hipLaunchKernelGGL((k_dgemm<true, false>), dim3(blocks), dim3(256), lds_bytes, c->stream, g);
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;

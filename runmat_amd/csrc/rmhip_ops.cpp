@@ -473,6 +473,47 @@ int rmhip_matmul(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
     return rc;
 }
 
+int rmhip_matmul_epilogue(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, const rmhip_matmul_epilogue_t* ep, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    ScopedTimer timer(&c->tel.matmul_count, &c->tel.matmul_ns);
+    if (!out || !ep) return fail(RMHIP_ERR_INVALID, "matmul_epilogue: null argument");
+    Buffer ab, bb, ob, rs, cs, dg;
+    RMHIP_TRY(c->get(a, &ab));
+    RMHIP_TRY(c->get(b, &bb));
+    if (ab.shape.size() != 2 || bb.shape.size() != 2) return fail(RMHIP_ERR_UNSUPPORTED, "matmul: only 2D supported");
+    const size_t m = ab.shape[0], k = ab.shape[1], kb = bb.shape[0], n = bb.shape[1];
+    if (k != kb) return fail(RMHIP_ERR_SHAPE, "matmul: inner dims must agree (%zux%zu * %zux%zu)", m, k, kb, n);
+    GemmEpilogue e{EP_ACTIVE, ep->alpha, ep->beta, nullptr, nullptr, ep->clamp_min, ep->clamp_max, ep->pow_exponent, nullptr};
+    if (ep->row_scale) {
+        RMHIP_TRY(c->get(ep->row_scale, &rs));
+        if (rs.numel < m) return fail(RMHIP_ERR_SHAPE, "matmul_epilogue: row scale length %zu < %zu rows", rs.numel, m);
+        e.row_scale = rs.data();
+        e.flags |= EP_ROW | (ep->row_op ? EP_ROW_DIV : 0);
+    }
+    if (ep->col_scale) {
+        RMHIP_TRY(c->get(ep->col_scale, &cs));
+        if (cs.numel < n) return fail(RMHIP_ERR_SHAPE, "matmul_epilogue: col scale length %zu < %zu cols", cs.numel, n);
+        e.col_scale = cs.data();
+        e.flags |= EP_COL | (ep->col_op ? EP_COL_DIV : 0);
+    }
+    if (ep->diag_output) {
+        RMHIP_TRY(c->get(ep->diag_output, &dg));
+        const size_t expected = m < n ? m : n;
+        if (dg.numel < expected)  // simple_provider.rs:7790-7799
+            return fail(RMHIP_ERR_SHAPE, "matmul_epilogue: diag_output length %zu insufficient for diag size %zu", dg.numel, expected);
+        e.diag = dg.data();
+        e.flags |= EP_DIAG;
+    }
+    if (ep->has_clamp_min) e.flags |= EP_CLAMP_MIN;
+    if (ep->has_clamp_max) e.flags |= EP_CLAMP_MAX;
+    if (ep->has_pow) e.flags |= EP_POW;
+    const size_t oshape[2] = {m, n};
+    RMHIP_TRY(c->new_buffer(oshape, 2, out, &ob));
+    int rc = launch_dgemm_epilogue(c, m, n, k, ab.data(), m, bb.data(), k ? k : 1, ob.data(), m, e);
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+
 int rmhip_lu(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf out5[5]) {
     CTX_OR_FAIL(ctx);
     if (!out5) return fail(RMHIP_ERR_INVALID, "null out");

@@ -314,6 +314,21 @@ class HipProvider:
         self._check(self._lib.rmhip_matmul(self._ctx, self._id(a), self._id(b), C.byref(out)))
         return self._handle(out.value, (a.shape[0], b.shape[1]))
 
+    def matmul_epilogue(self, a: GpuTensorHandle, b: GpuTensorHandle, alpha: float = 1.0, beta: float = 0.0,
+                        row_scale: Optional[GpuTensorHandle] = None, col_scale: Optional[GpuTensorHandle] = None,
+                        row_op: str = "multiply", col_op: str = "multiply", clamp_min: Optional[float] = None,
+                        clamp_max: Optional[float] = None, pow_exponent: Optional[float] = None,
+                        diag_output: Optional[GpuTensorHandle] = None) -> GpuTensorHandle:
+        """`matmul_epilogue(a, b, &MatmulEpilogue)` (lib.rs:2394-2405, 3498-3560), folded into the dgemm store."""
+        ep = _lib.MatmulEpilogue(
+            float(alpha), float(beta), self._id(row_scale) if row_scale else 0, self._id(col_scale) if col_scale else 0,
+            1 if row_op == "divide" else 0, 1 if col_op == "divide" else 0, int(clamp_min is not None),
+            int(clamp_max is not None), int(pow_exponent is not None), float(clamp_min or 0.0), float(clamp_max or 0.0),
+            float(pow_exponent or 0.0), self._id(diag_output) if diag_output else 0)
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_matmul_epilogue(self._ctx, self._id(a), self._id(b), C.byref(ep), C.byref(out)))
+        return self._handle(out.value, (a.shape[0], b.shape[1]))
+
     def lu(self, a: GpuTensorHandle) -> ProviderLuResult:
         outs = (C.c_uint64 * 5)()
         self._check(self._lib.rmhip_lu(self._ctx, self._id(a), outs))

@@ -718,3 +718,32 @@ def test_dot(prov, oracle):
     with pytest.raises(ProviderError) as e:
         prov.dot(ha, prov.upload(np.ones((40, 300))))
     assert e.value.code == 3
+
+
+def test_matmul_epilogue_vs_oracle(prov, oracle):
+    """MatmulEpilogue folded into the dgemm store (lib.rs:3498-3560; order simple_provider.rs:7800-7836)."""
+    from runmat_amd import ProviderError
+
+    rng = np.random.default_rng(23)
+    m, k, n = 200, 96, 136
+    A, B = rng.uniform(-1, 1, (m, k)), rng.uniform(-1, 1, (k, n))
+    rs, cs = rng.uniform(0.5, 2.0, (m, 1)), rng.uniform(0.5, 2.0, (1, n))
+    ha, hb, hrs, hcs = prov.upload(A), prov.upload(B), prov.upload(rs), prov.upload(cs)
+    base = (k + 4) * EPS * (np.abs(A) @ np.abs(B))
+    cases = [dict(alpha=2.5, beta=-0.75), dict(row_scale=rs, row_op="divide"), dict(col_scale=cs),
+             dict(alpha=0.5, beta=0.1, row_scale=rs, col_scale=cs, col_op="divide", clamp_min=-0.2, clamp_max=0.4),
+             dict(clamp_min=0.0, pow_exponent=1.5), dict(alpha=1.0, beta=0.0)]
+    for kw in cases:
+        want, _ = oracle.matmul_epilogue(A, B, **kw)
+        gk = {kk: (hrs if kk == "row_scale" else hcs if kk == "col_scale" else v) for kk, v in kw.items()}
+        got = prov.download_matrix(prov.matmul_epilogue(ha, hb, **gk))
+        scale = abs(kw.get("alpha", 1.0)) * 4.0 + 1.0  # scales <= 2 each way
+        assert np.all(np.abs(got - want) <= scale * base + 1e-13), kw
+    diag = prov.zeros((min(m, n), 1))
+    want, wd = oracle.matmul_epilogue(A, B, alpha=3.0, diag=True)
+    got = prov.download_matrix(prov.matmul_epilogue(ha, hb, alpha=3.0, diag_output=diag))
+    assert np.all(np.abs(got - want) <= 4 * base + 1e-13)
+    assert np.array_equal(prov.download(diag), np.diag(got)[: min(m, n)])
+    with pytest.raises(ProviderError) as e:
+        prov.matmul_epilogue(ha, hb, diag_output=prov.zeros((5, 1)))
+    assert e.value.code == 3 and "diag_output length" in str(e.value)

@@ -322,3 +322,13 @@ def test_fill_uniform_is_counter_based(oracle):
     a = oracle.fill_uniform(7, -1.0, 1.0, 1000)
     assert np.all(a >= -1.0) and np.all(a < 1.0) and abs(a.mean()) < 0.1
     assert np.array_equal(a[:10], oracle.fill_uniform(7, -1.0, 1.0, 10))
+
+
+def test_matmul_epilogue_order(oracle):
+    # simple_provider.rs:7800-7836: alpha/beta, row scale, col scale, clamp, pow, diag -- in that order
+    a, b = cm([1, 2, 3, 4], (2, 2)), cm([5, 7, 6, 8], (2, 2))  # product [26 30; 38 44]
+    c, d = oracle.matmul_epilogue(a, b, alpha=0.5, beta=1.0, row_scale=np.array([2.0, 4.0]), col_scale=np.array([1.0, 10.0]),
+                                  col_op="divide", clamp_max=30.0, pow_exponent=2.0, diag=True)
+    want = np.array([[(26 * 0.5 + 1) * 2 / 1, (30 * 0.5 + 1) * 2 / 10], [(38 * 0.5 + 1) * 4 / 1, (44 * 0.5 + 1) * 4 / 10]])
+    want = np.minimum(want, 30.0) ** 2.0
+    assert np.allclose(c, want, rtol=1e-15) and np.allclose(d, np.diag(want), rtol=1e-15)
