@@ -38,8 +38,8 @@ __global__ void __launch_bounds__(RM_RBLOCK) k_reduce_final(const double* pv, co
 template <int OP>
 static int run_reduce(Context* c, int mean, int nan_mode, const double* x, size_t pre, size_t red, size_t post,
                       double* out) {
+    if (pre == 0 || post == 0) return RMHIP_OK;  // no output slices
     const ReducePlan p = plan_reduction(pre, red, post, c->num_cus);
-    if (p.nslices == 0) return RMHIP_OK;
     if (!p.valid) return fail(RMHIP_ERR_UNSUPPORTED, "reduce: geometry [%zu,%zu,%zu] exceeds launch limits", pre, red, post);
     const size_t nparts = (size_t)(p.nslices * p.nsplit);
     RMHIP_TRY(c->ensure_scratch(2 * nparts * sizeof(double)));
@@ -90,8 +90,8 @@ __global__ void __launch_bounds__(RM_RBLOCK) k_dot_strided(const double* a, cons
 }
 
 int launch_reduce_dot(Context* c, const double* a, const double* b, size_t pre, size_t red, size_t post, double* out) {
+    if (pre == 0 || post == 0) return RMHIP_OK;  // no output slices
     const ReducePlan p = plan_reduction(pre, red, post, c->num_cus);
-    if (p.nslices == 0) return RMHIP_OK;
     if (!p.valid) return fail(RMHIP_ERR_UNSUPPORTED, "dot: geometry [%zu,%zu,%zu] exceeds launch limits", pre, red, post);
     const size_t nparts = (size_t)(p.nslices * p.nsplit);
     RMHIP_TRY(c->ensure_scratch(2 * nparts * sizeof(double)));

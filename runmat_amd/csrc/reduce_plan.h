@@ -23,8 +23,13 @@ struct ReducePlan {
 
 inline uint64_t ceil_div_u64(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
+// Requires pre >= 1 and post >= 1 (callers return early when there are no output slices).
 inline ReducePlan plan_reduction(uint64_t pre, uint64_t red, uint64_t post, int num_cus) {
     ReducePlan p{};
+    if (pre == 0 || post == 0) {
+        p.valid = false;
+        return p;
+    }
     const uint64_t target_blocks = (uint64_t)num_cus * 8;  // ~2048 blocks of 256 threads
     p.nslices = pre * post;
     if (pre == 1) {

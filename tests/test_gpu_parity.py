@@ -747,3 +747,30 @@ def test_matmul_epilogue_vs_oracle(prov, oracle):
     with pytest.raises(ProviderError) as e:
         prov.matmul_epilogue(ha, hb, diag_output=prov.zeros((5, 1)))
     assert e.value.code == 3 and "diag_output length" in str(e.value)
+
+
+def test_empty_and_degenerate_shapes(prov, oracle):
+    """Empty tensors flow through every per-op entry point like the CPU builtins treat them."""
+    e = prov.upload(np.zeros((0, 3)))
+    assert prov.unary_sin(e).shape == (0, 3) and prov.download(prov.unary_sin(e)).size == 0
+    assert prov.elem_add(e, e).shape == (0, 3)
+    assert prov.elem_mul(e, prov.upload(np.ones((1, 3)))).shape == (0, 3)
+    assert prov.scalar_mul(e, 2.0).shape == (0, 3)
+    s0 = prov.reduce_sum_dim(e, 0)   # sum over an empty dim -> zeros (sum.rs: saw_value false => 0)
+    assert s0.shape == (1, 3) and np.array_equal(prov.download(s0), np.zeros(3))
+    s1 = prov.reduce_sum_dim(e, 1)
+    assert s1.shape == (0, 1) and prov.download(s1).size == 0
+    assert prov.download(prov.reduce_sum(e))[0] == 0.0
+    assert math.isnan(prov.download(prov.reduce_mean(e))[0])  # mean of nothing is NaN (mean.rs:1130-1133)
+    a = prov.upload(np.ones((4, 0)))
+    b = prov.upload(np.ones((0, 5)))
+    z = prov.matmul(a, b)             # k == 0: all-zero product
+    assert z.shape == (4, 5) and np.array_equal(prov.download(z), np.zeros(20))
+    assert prov.matmul(prov.upload(np.ones((0, 4))), prov.upload(np.ones((4, 2)))).shape == (0, 2)
+    one = prov.upload(np.array([[3.0]]))
+    assert prov.download(prov.matmul(one, one))[0] == 9.0
+    assert prov.download(prov.reduce_sum_dim(one, 0))[0] == 3.0 and prov.download(prov.reduce_max(one))[0] == 3.0
+    n0 = prov.random_normal((0, 1))
+    assert n0.shape == (0, 1)
+    same = prov.upload(np.arange(6.0).reshape(2, 3))
+    assert np.array_equal(prov.download(prov.elem_mul(same, same)), (np.arange(6.0).reshape(2, 3) ** 2).reshape(-1, order="F"))
