@@ -206,6 +206,31 @@ RMHIP_API int rmhip_lu(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf out5[5]);
  * (mldivide.rs:223-229 `.ok()`). Scalar A => b * (1/A) (mldivide.rs:321-325). */
 RMHIP_API int rmhip_mldivide(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out);
 
+/* ---- block-level building blocks for the multi-GPU solver ------------------------------------ *
+ * A distributed (block-column cyclic) A\b has no counterpart in the reference (it has no multi-device
+ * code at all); its host driver (runmat_amd/sharding.py) needs in-place operations on
+ * sub-blocks of provider buffers.  A view addresses rows [row_off, row_off+rows) x columns
+ * [col_off, col_off+cols) of a 2-D buffer.  These calls MUTATE the viewed buffer (documented exception
+ * to "every op returns a new buffer"; they are not part of the AccelProvider surface). */
+typedef struct rmhip_view {
+    rmhip_buf buf;
+    size_t row_off, col_off, rows, cols;
+} rmhip_view_t;
+/* Copy a sub-block into a new contiguous rows x cols buffer / write a contiguous buffer into a sub-block. */
+RMHIP_API int rmhip_blk_copy(rmhip_ctx* ctx, const rmhip_view_t* src, rmhip_buf* out);
+RMHIP_API int rmhip_blk_assign(rmhip_ctx* ctx, const rmhip_view_t* dst, rmhip_buf src);
+/* C = alpha*A*B + beta*C on views (fp64 MFMA dgemm). */
+RMHIP_API int rmhip_blk_gemm(rmhip_ctx* ctx, double alpha, const rmhip_view_t* a, const rmhip_view_t* b,
+                             double beta, const rmhip_view_t* c);
+/* B <- T^-1 B with T the (upper != 0 ? upper non-unit : lower unit-diagonal) triangle of a square view. */
+RMHIP_API int rmhip_blk_trsm(rmhip_ctx* ctx, int upper, const rmhip_view_t* t, const rmhip_view_t* b);
+/* In-place LU (host_lu.rs pivot rule) of a tall view; `ipiv_out` receives a [min(rows,cols),1] tensor
+ * of LAPACK-style interchange targets (row k swapped with row ipiv[k], zero-based, relative to the
+ * view).  *info = number of pivots <= 1e-12. */
+RMHIP_API int rmhip_blk_lu(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf* ipiv_out, int* info);
+/* Apply those interchanges (in order) to every column of a view whose row 0 is the panel's row 0. */
+RMHIP_API int rmhip_blk_swap_rows(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf ipiv);
+
 /* ---- RNG  (lib.rs:1713-1728, 1772) ---------------------------------------------------------- */
 
 /* `set_rng_state`: raw 64-bit LCG state (random.rs:7-13). rmhip_rng_seed applies mix_seed

@@ -48,6 +48,12 @@ class MatmulEpilogue(C.Structure):
                 ("diag_output", C.c_uint64)]
 
 
+class View(C.Structure):
+    """rmhip_view_t: rows [row_off, row_off+rows) x cols [col_off, col_off+cols) of a 2-D buffer."""
+    _fields_ = [("buf", C.c_uint64), ("row_off", C.c_size_t), ("col_off", C.c_size_t), ("rows", C.c_size_t),
+                ("cols", C.c_size_t)]
+
+
 # Every symbol include/rmhip.h declares: name -> (restype, argtypes). Used both to bind and by the
 # CPU-side test that checks the library exports the full ABI.
 _P = C.c_void_p
@@ -89,6 +95,12 @@ SIGNATURES = {
     "rmhip_matmul_epilogue": (C.c_int, [_P, _BUF, _BUF, C.POINTER(MatmulEpilogue), _BUFP]),
     "rmhip_lu": (C.c_int, [_P, _BUF, _BUFP]),
     "rmhip_mldivide": (C.c_int, [_P, _BUF, _BUF, _BUFP]),
+    "rmhip_blk_copy": (C.c_int, [_P, C.POINTER(View), _BUFP]),
+    "rmhip_blk_assign": (C.c_int, [_P, C.POINTER(View), _BUF]),
+    "rmhip_blk_gemm": (C.c_int, [_P, C.c_double, C.POINTER(View), C.POINTER(View), C.c_double, C.POINTER(View)]),
+    "rmhip_blk_trsm": (C.c_int, [_P, C.c_int, C.POINTER(View), C.POINTER(View)]),
+    "rmhip_blk_lu": (C.c_int, [_P, C.POINTER(View), _BUFP, C.POINTER(C.c_int)]),
+    "rmhip_blk_swap_rows": (C.c_int, [_P, C.POINTER(View), _BUF]),
     "rmhip_set_rng_state": (C.c_int, [_P, C.c_uint64]),
     "rmhip_get_rng_state": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "rmhip_rng_seed": (C.c_int, [_P, C.c_uint64]),

@@ -174,7 +174,10 @@ uint64_t lcg_advance(uint64_t state, uint64_t delta);
 
 // LU / solve (lu.hip)
 int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda, int* perm_dev,
-                     int* info_host);
+                     int* info_host, std::vector<int>* ipiv_host = nullptr);
+int lu_swap_rows_device(Context* c, double* A, size_t lda, size_t ncols, const std::vector<int>& ipiv);
+int trsm_lower_unit_device(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc);
+int trsm_upper_device(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc);
 int lu_solve_device(Context* c, const double* LU, size_t n, size_t lda, const int* perm_dev,
                     const double* B, size_t nrhs, size_t ldb, double* X, size_t ldx);
 int lu_extract_device(Context* c, const double* LU, size_t rows, size_t cols, const int* perm_dev,

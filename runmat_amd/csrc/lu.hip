@@ -13,6 +13,7 @@
 // Every flop outside the <=64-column base panels runs in launch_dgemm (dgemm.hip) with K equal to
 // the half-width, so the top levels (where the flops are) see K in the thousands.
 // Triangular solves recurse the same way down to a 32x32 substitution kernel.
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -498,7 +499,8 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
 // In-place LU of A (rows x cols, lda). perm_dev[rows] receives the row permutation as the
 // reference reports it (perm[k] = original row now at position k, host_lu.rs:50,107).
 // *info_host = number of pivots that hit the singular cut-off.
-int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda, int* perm_dev, int* info_host) {
+int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda, int* perm_dev, int* info_host,
+                     std::vector<int>* ipiv_host) {
     const size_t kmin = rows < cols ? rows : cols;
     if (rows > 0x7fffffffULL || cols > 0x7fffffffULL) return fail(RMHIP_ERR_UNSUPPORTED, "lu: dimension exceeds 2^31");
     // one device block: ipiv[rows] | info | pos_of | row_at | prow | panel lists | cand_abs[2*MAXB] | cand_pos | cand_row
@@ -550,6 +552,7 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     (void)hipFree(blk);
     if (rc != RMHIP_OK) return rc;
     if (info_host) *info_host = h_ipiv[rows];
+    if (ipiv_host) ipiv_host->assign(h_ipiv.begin(), h_ipiv.begin() + (long)kmin);
     std::vector<int> perm(rows);
     for (size_t r = 0; r < rows; ++r) perm[r] = (int)r;
     for (size_t k = 0; k < kmin; ++k) {
@@ -561,6 +564,79 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
         RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     return RMHIP_OK;
+}
+
+// Arbitrary row permutation of a block of columns, given as one (dst, src) list: every load of a
+// column precedes every store (one block per column, list entries spread over the threads).
+static constexpr int PERM_PER_THREAD = 8;  // up to 256*8 = 2048 moved rows per call
+__global__ void __launch_bounds__(256) k_permute_rows(double* __restrict__ A, size_t lda, size_t ncols,
+                                                      const int2* __restrict__ list, int len) {
+    const size_t cc = blockIdx.x;
+    if (cc >= ncols) return;
+    double* col = A + cc * lda;
+    double vals[PERM_PER_THREAD];
+    int dst[PERM_PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < PERM_PER_THREAD; ++q) {
+        const int i = threadIdx.x + 256 * q;
+        dst[q] = -1;
+        if (i < len) {
+            const int2 e = list[i];
+            dst[q] = e.x;
+            vals[q] = col[e.y];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PERM_PER_THREAD; ++q)
+        if (dst[q] >= 0) col[dst[q]] = vals[q];
+}
+
+// Apply the sequential interchanges k <-> ipiv[k] (k = 0..npiv-1, rows relative to A) to ncols columns.
+// The swaps are composed on the host into one permutation of the touched rows.
+int lu_swap_rows_device(Context* c, double* A, size_t lda, size_t ncols, const std::vector<int>& ipiv) {
+    if (ncols == 0 || ipiv.empty()) return RMHIP_OK;
+    std::unordered_map<int, int> content;  // position -> original row now stored there
+    auto get = [&](int p) {
+        auto it = content.find(p);
+        return it == content.end() ? p : it->second;
+    };
+    for (size_t k = 0; k < ipiv.size(); ++k) {
+        const int p = ipiv[k];
+        if (p == (int)k) continue;
+        const int a = get((int)k), b = get(p);
+        content[(int)k] = b;
+        content[p] = a;
+    }
+    std::vector<int2> list;
+    for (const auto& kv : content)
+        if (kv.first != kv.second) list.push_back(make_int2(kv.first, kv.second));
+    if (list.empty()) return RMHIP_OK;
+    if (list.size() > (size_t)256 * PERM_PER_THREAD)
+        return fail(RMHIP_ERR_UNSUPPORTED, "swap_rows: more than %d moved rows per call", 256 * PERM_PER_THREAD);
+    int2* dlist = nullptr;
+    RMHIP_HIP_CHECK(hipMalloc((void**)&dlist, sizeof(int2) * list.size()));
+    hipError_t e = hipMemcpyAsync(dlist, list.data(), sizeof(int2) * list.size(), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        for (size_t c0 = 0; c0 < ncols; c0 += 65535) {
+            const size_t nc = (ncols - c0) < 65535 ? (ncols - c0) : 65535;
+            hipLaunchKernelGGL(k_permute_rows, dim3((unsigned)nc), dim3(256), 0, c->stream, A + c0 * lda, lda, nc, dlist,
+                               (int)list.size());
+        }
+        e = hipGetLastError();
+        c->tel.kernel_launches++;
+    }
+    (void)hipStreamSynchronize(c->stream);  // the host list must outlive the copy; dlist is freed next
+    (void)hipFree(dlist);
+    if (e != hipSuccess) return fail(RMHIP_ERR_HIP, "swap_rows: %s", hipGetErrorString(e));
+    return RMHIP_OK;
+}
+
+int trsm_lower_unit_device(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
+    return trsm_lower_rec(c, T, ldt, w, B, ldb, nc);
+}
+int trsm_upper_device(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
+    return trsm_upper_rec(c, T, ldt, w, B, ldb, nc);
 }
 
 __global__ void __launch_bounds__(256) k_gather_rows(const double* __restrict__ B, size_t ldb, const int* __restrict__ perm,

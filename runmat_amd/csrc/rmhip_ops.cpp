@@ -614,6 +614,117 @@ int rmhip_mldivide(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
     return RMHIP_OK;
 }
 
+// ---- block-level building blocks (views) ----------------------------------------------------------
+namespace {
+struct ViewPtr {
+    Buffer buf;
+    double* ptr = nullptr;
+    size_t ld = 0, rows = 0, cols = 0;
+};
+int resolve_view(Context* c, const rmhip_view_t* v, ViewPtr* out) {
+    if (!v) return fail(RMHIP_ERR_INVALID, "null view");
+    RMHIP_TRY(c->get(v->buf, &out->buf));
+    const std::vector<size_t> s = normalize_matrix_shape(out->buf.shape);
+    if (s.size() != 2) return fail(RMHIP_ERR_UNSUPPORTED, "view: only 2D buffers");
+    if (v->row_off + v->rows > s[0] || v->col_off + v->cols > s[1])
+        return fail(RMHIP_ERR_SHAPE, "view [%zu+%zu, %zu+%zu] exceeds buffer %zux%zu", v->row_off, v->rows, v->col_off, v->cols, s[0], s[1]);
+    out->ld = s[0];
+    out->rows = v->rows;
+    out->cols = v->cols;
+    out->ptr = out->buf.data() + v->row_off + v->col_off * s[0];
+    return RMHIP_OK;
+}
+}  // namespace
+
+int rmhip_blk_copy(rmhip_ctx* ctx, const rmhip_view_t* src, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    ViewPtr v;
+    RMHIP_TRY(resolve_view(c, src, &v));
+    Buffer ob;
+    const size_t oshape[2] = {v.rows, v.cols};
+    RMHIP_TRY(c->new_buffer(oshape, 2, out, &ob));
+    if (v.rows && v.cols)
+        RMHIP_HIP_CHECK(hipMemcpy2DAsync(ob.data(), v.rows * sizeof(double), v.ptr, v.ld * sizeof(double), v.rows * sizeof(double),
+                                         v.cols, hipMemcpyDeviceToDevice, c->stream));
+    return RMHIP_OK;
+}
+
+int rmhip_blk_assign(rmhip_ctx* ctx, const rmhip_view_t* dst, rmhip_buf src) {
+    CTX_OR_FAIL(ctx);
+    ViewPtr v;
+    RMHIP_TRY(resolve_view(c, dst, &v));
+    Buffer sb;
+    RMHIP_TRY(c->get(src, &sb));
+    if (sb.numel != v.rows * v.cols) return fail(RMHIP_ERR_SHAPE, "blk_assign: source has %zu elements, view %zux%zu", sb.numel, v.rows, v.cols);
+    if (v.rows && v.cols)
+        RMHIP_HIP_CHECK(hipMemcpy2DAsync(v.ptr, v.ld * sizeof(double), sb.data(), v.rows * sizeof(double), v.rows * sizeof(double),
+                                         v.cols, hipMemcpyDeviceToDevice, c->stream));
+    return RMHIP_OK;
+}
+
+int rmhip_blk_gemm(rmhip_ctx* ctx, double alpha, const rmhip_view_t* a, const rmhip_view_t* b, double beta,
+                   const rmhip_view_t* cv) {
+    CTX_OR_FAIL(ctx);
+    ViewPtr va, vb, vc;
+    RMHIP_TRY(resolve_view(c, a, &va));
+    RMHIP_TRY(resolve_view(c, b, &vb));
+    RMHIP_TRY(resolve_view(c, cv, &vc));
+    if (va.cols != vb.rows || vc.rows != va.rows || vc.cols != vb.cols)
+        return fail(RMHIP_ERR_SHAPE, "blk_gemm: %zux%zu * %zux%zu -> %zux%zu", va.rows, va.cols, vb.rows, vb.cols, vc.rows, vc.cols);
+    if (va.cols == 0) return RMHIP_OK;
+    return launch_dgemm(c, va.rows, vb.cols, va.cols, alpha, va.ptr, va.ld, vb.ptr, vb.ld, beta, vc.ptr, vc.ld);
+}
+
+int rmhip_blk_trsm(rmhip_ctx* ctx, int upper, const rmhip_view_t* t, const rmhip_view_t* b) {
+    CTX_OR_FAIL(ctx);
+    ViewPtr vt, vb;
+    RMHIP_TRY(resolve_view(c, t, &vt));
+    RMHIP_TRY(resolve_view(c, b, &vb));
+    if (vt.rows != vt.cols || vb.rows != vt.rows) return fail(RMHIP_ERR_SHAPE, "blk_trsm: triangle %zux%zu vs rhs %zux%zu", vt.rows, vt.cols, vb.rows, vb.cols);
+    return upper ? trsm_upper_device(c, vt.ptr, vt.ld, vt.rows, vb.ptr, vb.ld, vb.cols)
+                 : trsm_lower_unit_device(c, vt.ptr, vt.ld, vt.rows, vb.ptr, vb.ld, vb.cols);
+}
+
+int rmhip_blk_lu(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf* ipiv_out, int* info) {
+    CTX_OR_FAIL(ctx);
+    if (!ipiv_out) return fail(RMHIP_ERR_INVALID, "null ipiv_out");
+    ViewPtr va;
+    RMHIP_TRY(resolve_view(c, a, &va));
+    std::vector<int> ipiv;
+    int inf = 0;
+    RMHIP_TRY(lu_factor_device(c, va.ptr, va.rows, va.cols, va.ld, nullptr, &inf, &ipiv));
+    if (info) *info = inf;
+    std::vector<double> host(ipiv.begin(), ipiv.end());
+    const size_t oshape[2] = {host.size(), 1};
+    Buffer ob;
+    RMHIP_TRY(c->new_buffer(oshape, 2, ipiv_out, &ob));
+    if (!host.empty()) {
+        RMHIP_HIP_CHECK(hipMemcpyAsync(ob.data(), host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    return RMHIP_OK;
+}
+
+int rmhip_blk_swap_rows(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf ipiv) {
+    CTX_OR_FAIL(ctx);
+    ViewPtr va;
+    RMHIP_TRY(resolve_view(c, a, &va));
+    Buffer pb;
+    RMHIP_TRY(c->get(ipiv, &pb));
+    std::vector<double> host(pb.numel);
+    if (pb.numel) {
+        RMHIP_HIP_CHECK(hipMemcpyAsync(host.data(), pb.data(), pb.numel * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    std::vector<int> piv(host.size());
+    for (size_t k = 0; k < host.size(); ++k) {
+        if (!(host[k] >= 0.0) || host[k] >= (double)va.rows) return fail(RMHIP_ERR_INVALID, "swap_rows: pivot %zu out of range", k);
+        piv[k] = (int)host[k];
+    }
+    return lu_swap_rows_device(c, va.ptr, va.ld, va.cols, piv);
+}
+
 int rmhip_set_rng_state(rmhip_ctx* ctx, uint64_t state) {
     CTX_OR_FAIL(ctx);
     c->rng_state = state;

@@ -340,6 +340,39 @@ class HipProvider:
         self._check(self._lib.rmhip_mldivide(self._ctx, self._id(lhs), self._id(rhs), C.byref(out)))
         return self._handle(out.value)
 
+    # -- block-level building blocks (views; used by the multi-GPU solver, they mutate the buffer) ----
+    def _view(self, v) -> "_lib.View":
+        h, r0, c0, rows, cols = v
+        return _lib.View(self._id(h), int(r0), int(c0), int(rows), int(cols))
+
+    def blk_copy(self, view) -> GpuTensorHandle:
+        out = C.c_uint64()
+        v = self._view(view)
+        self._check(self._lib.rmhip_blk_copy(self._ctx, C.byref(v), C.byref(out)))
+        return self._handle(out.value, (view[3], view[4]))
+
+    def blk_assign(self, view, src: GpuTensorHandle) -> None:
+        v = self._view(view)
+        self._check(self._lib.rmhip_blk_assign(self._ctx, C.byref(v), self._id(src)))
+
+    def blk_gemm(self, alpha: float, a, b, beta: float, c) -> None:
+        va, vb, vc = self._view(a), self._view(b), self._view(c)
+        self._check(self._lib.rmhip_blk_gemm(self._ctx, float(alpha), C.byref(va), C.byref(vb), float(beta), C.byref(vc)))
+
+    def blk_trsm(self, upper: bool, t, b) -> None:
+        vt, vb = self._view(t), self._view(b)
+        self._check(self._lib.rmhip_blk_trsm(self._ctx, 1 if upper else 0, C.byref(vt), C.byref(vb)))
+
+    def blk_lu(self, a) -> Tuple[GpuTensorHandle, int]:
+        out, info = C.c_uint64(), C.c_int()
+        va = self._view(a)
+        self._check(self._lib.rmhip_blk_lu(self._ctx, C.byref(va), C.byref(out), C.byref(info)))
+        return self._handle(out.value), int(info.value)
+
+    def blk_swap_rows(self, a, ipiv: GpuTensorHandle) -> None:
+        va = self._view(a)
+        self._check(self._lib.rmhip_blk_swap_rows(self._ctx, C.byref(va), self._id(ipiv)))
+
     # -- RNG ------------------------------------------------------------------------------------
     def set_rng_state(self, state: int) -> None:
         self._check(self._lib.rmhip_set_rng_state(self._ctx, int(state) & 0xFFFFFFFFFFFFFFFF))

@@ -262,3 +262,103 @@ def monte_carlo_price_fused(prov, group: Group, M: int, T: int, S0=100.0, mu=0.0
     final_state = lcg_advance(rng_state, T * per_step)
     prov.set_rng_state(final_state)
     return (total / float(M)) * math.exp(-mu * T * dt), final_state
+
+
+# ---- x = A\\b across GPUs: 1-D block-column cyclic LU with one panel broadcast per block -----------
+def owned_blocks(n: int, nb: int, group: Group) -> List[int]:
+    """Global column-block ids owned by this rank (block p -> rank p % world)."""
+    nblocks = (n + nb - 1) // nb
+    return [p for p in range(nblocks) if p % group.world == group.rank]
+
+
+def local_col_offset(p: int, nb: int, group: Group) -> int:
+    """First local column of global block p on its owner (blocks are stored in ownership order)."""
+    return (p // group.world) * nb
+
+
+def _bcast(group: Group, prov, handle, shape, src: int) -> None:
+    """In-place broadcast of a provider buffer. nccl: zero-copy torch view of the device memory;
+    gloo (CPU tests): the test double exposes `.arr`."""
+    if group.world == 1:
+        return
+    import torch
+
+    if group.device == "cuda":
+        prov.synchronize()
+        t = _torch_view(prov, handle, tuple(reversed(shape)))  # column-major (r, c) == row-major (c, r)
+        group.dist.broadcast(t, src)
+        torch.cuda.synchronize()
+    else:
+        t = torch.from_numpy(handle.arr)
+        group.dist.broadcast(t, src)
+
+
+def mldivide_block_cyclic(prov, group: Group, a_local, n: int, b, nb: int = 512):
+    """Solve A x = b with A distributed by column blocks (block p of width nb on rank p % world,
+    stored contiguously in ownership order in `a_local`, an n x ncols_local buffer that is
+    OVERWRITTEN with its part of the LU factors) and b (n x nrhs) replicated.  Returns the replicated
+    solution handle.
+
+    Per block p: the owner factors its panel (rows j.., the host_lu.rs pivot rule), broadcasts the
+    factored panel plus the interchanges (one RCCL broadcast of (n-j) x nb doubles: 64 MiB for the
+    first panel at n = 16384, nb = 512, shrinking linearly), then every rank applies interchanges,
+    triangular solve and the MFMA dgemm update to the trailing blocks IT owns and, redundantly, to its
+    copy of b.  The back substitution walks the blocks in reverse: the owner solves with its U_pp,
+    updates y[0:j] and broadcasts the finished prefix."""
+    from .provider import ProviderError
+
+    nrhs = b.shape[1] if len(b.shape) > 1 else 1
+    nblocks = (n + nb - 1) // nb
+    mine = owned_blocks(n, nb, group)
+    ncols_loc = sum(min(nb, n - p * nb) for p in mine)
+    y = prov.blk_copy((b, 0, 0, n, nrhs))
+    for p in range(nblocks):
+        j = p * nb
+        w = min(nb, n - j)
+        owner = p % group.world
+        if group.rank == owner:
+            lq = local_col_offset(p, nb, group)
+            ipiv, info = prov.blk_lu((a_local, j, lq, n - j, w))
+            panel = prov.blk_copy((a_local, j, lq, n - j, w))
+            meta = prov.upload(np.array([float(info)]), (1, 1))
+        else:
+            panel = prov.zeros((n - j, w))
+            ipiv = prov.zeros((w, 1))
+            meta = prov.zeros((1, 1))
+        _bcast(group, prov, panel, (n - j, w), owner)
+        _bcast(group, prov, ipiv, (w, 1), owner)
+        _bcast(group, prov, meta, (1, 1), owner)
+        if float(prov.download(meta)[0]) > 0:
+            for h in (panel, ipiv, meta, y):
+                prov.free(h)
+            raise ProviderError(7, "mldivide: pivot <= 1e-12; matrix is numerically singular, use the CPU SVD path")
+        later = [q for q in mine if q > p]
+        if later:
+            lc0 = local_col_offset(later[0], nb, group)
+            ncl = ncols_loc - lc0
+            prov.blk_swap_rows((a_local, j, lc0, n - j, ncl), ipiv)
+            prov.blk_trsm(False, (panel, 0, 0, w, w), (a_local, j, lc0, w, ncl))
+            if n - j - w > 0:
+                prov.blk_gemm(-1.0, (panel, w, 0, n - j - w, w), (a_local, j, lc0, w, ncl), 1.0,
+                              (a_local, j + w, lc0, n - j - w, ncl))
+        prov.blk_swap_rows((y, j, 0, n - j, nrhs), ipiv)
+        prov.blk_trsm(False, (panel, 0, 0, w, w), (y, j, 0, w, nrhs))
+        if n - j - w > 0:
+            prov.blk_gemm(-1.0, (panel, w, 0, n - j - w, w), (y, j, 0, w, nrhs), 1.0, (y, j + w, 0, n - j - w, nrhs))
+        for h in (panel, ipiv, meta):
+            prov.free(h)
+    for p in reversed(range(nblocks)):
+        j = p * nb
+        w = min(nb, n - j)
+        owner = p % group.world
+        if group.rank == owner:
+            lq = local_col_offset(p, nb, group)
+            prov.blk_trsm(True, (a_local, j, lq, w, w), (y, j, 0, w, nrhs))
+            if j > 0:
+                prov.blk_gemm(-1.0, (a_local, 0, lq, j, w), (y, j, 0, w, nrhs), 1.0, (y, 0, 0, j, nrhs))
+        if group.world > 1:
+            pre = prov.blk_copy((y, 0, 0, j + w, nrhs))
+            _bcast(group, prov, pre, (j + w, nrhs), owner)
+            prov.blk_assign((y, 0, 0, j + w, nrhs), pre)
+            prov.free(pre)
+    return y

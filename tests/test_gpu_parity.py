@@ -774,3 +774,44 @@ def test_empty_and_degenerate_shapes(prov, oracle):
     assert n0.shape == (0, 1)
     same = prov.upload(np.arange(6.0).reshape(2, 3))
     assert np.array_equal(prov.download(prov.elem_mul(same, same)), (np.arange(6.0).reshape(2, 3) ** 2).reshape(-1, order="F"))
+
+
+def test_block_ops_and_block_cyclic_solve_on_gpu(prov, oracle):
+    """The blk_* building blocks through the C ABI, and the distributed solver's driver with a
+    single-rank group (same code path as multi-GPU minus the broadcasts) against the oracle."""
+    from runmat_amd import ProviderError
+    from runmat_amd import sharding as sh
+
+    rng = np.random.default_rng(24)
+    M = rng.standard_normal((50, 40))
+    h = prov.upload(M)
+    sub = prov.blk_copy((h, 5, 7, 20, 11))
+    assert np.array_equal(prov.download_matrix(sub), M[5:25, 7:18])
+    prov.blk_assign((h, 0, 0, 20, 11), sub)
+    M2 = M.copy()
+    M2[0:20, 0:11] = M[5:25, 7:18]
+    assert np.array_equal(prov.download_matrix(h), M2)
+    a, b, c = prov.upload(rng.standard_normal((30, 20))), prov.upload(rng.standard_normal((20, 10))), prov.upload(np.ones((30, 10)))
+    prov.blk_gemm(-1.0, (a, 2, 3, 25, 16), (b, 4, 1, 16, 8), 1.0, (c, 5, 2, 25, 8))
+    want = np.ones((30, 10))
+    want[5:30, 2:10] -= prov.download_matrix(a)[2:27, 3:19] @ prov.download_matrix(b)[4:20, 1:9]
+    assert np.max(np.abs(prov.download_matrix(c) - want)) < 1e-13
+    with pytest.raises(ProviderError) as e:
+        prov.blk_copy((h, 45, 0, 10, 5))
+    assert e.value.code == 3
+    for n, nb, nrhs in [(300, 64, 1), (1000, 256, 2), (130, 512, 1)]:
+        A = rng.uniform(-1, 1, (n, n)) + n * np.eye(n)
+        X = np.ones((n, nrhs)) * np.arange(1, nrhs + 1)
+        B = A @ X
+        y = sh.mldivide_block_cyclic(prov, sh.Group(), prov.upload(A), n, prov.upload(B), nb=nb)
+        got = prov.download_matrix(y)
+        assert np.max(np.abs(got - X)) <= 1e-9
+        assert np.max(np.abs(got - oracle.mldivide_lu(A, B))) <= 1e-11
+    Ag = rng.standard_normal((257, 257))  # general matrix: real pivoting, ragged last block
+    bg = rng.standard_normal((257, 1))
+    yg = prov.download_matrix(sh.mldivide_block_cyclic(prov, sh.Group(), prov.upload(Ag), 257, prov.upload(bg), nb=64))
+    ref = prov.download_matrix(prov.mldivide(prov.upload(Ag), prov.upload(bg)))
+    assert np.max(np.abs(yg - ref)) <= 1e-10 * max(1.0, np.abs(ref).max())
+    with pytest.raises(ProviderError) as e:
+        sh.mldivide_block_cyclic(prov, sh.Group(), prov.upload(np.ones((64, 64))), 64, prov.upload(np.ones((64, 1))), nb=32)
+    assert e.value.code == 7
