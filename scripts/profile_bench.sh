@@ -1,6 +1,8 @@
 #!/bin/bash
 # Developer tool (GPU box): rocprofv3 kernel-trace stats + separate PMC passes for bench.py.
 # Usage: scripts/profile_bench.sh <tag>      (writes under gpurun_out/prof_<tag>/)
+# PMC passes use --no-also (one workload per pass): rocprofv3 --pmc crashed on the full default run,
+# whose LU workload issues ~50k dispatches.
 set -u
 TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -9,19 +11,25 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o fetch -- $BENCH > "$OUT/fetch_bench.json" 2> "$OUT/fetch.err"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o write -- $BENCH > "$OUT/write_bench.json" 2> "$OUT/write.err"
-find "$OUT" -name "*.csv" | head -30
-for f in $(find "$OUT/trace" -name "*kernel_stats.csv"); do echo "== $f"; head -12 "$f"; done
+for W in fused dgemm; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$W" -o trace -- $BENCH --no-also --workload $W > "$OUT/trace_${W}_bench.json" 2> "$OUT/trace_$W.err"
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_$W" -o fetch -- $BENCH --no-also --workload $W > "$OUT/fetch_${W}_bench.json" 2> "$OUT/fetch_$W.err"
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_$W" -o write -- $BENCH --no-also --workload $W > "$OUT/write_${W}_bench.json" 2> "$OUT/write_$W.err"
+done
+for f in $(find "$OUT/trace" -name "*kernel_stats.csv"); do echo "== $f"; head -14 "$f" | cut -c1-170; done
 python - "$OUT" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, sys, collections, json
 out = sys.argv[1]
-for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    agg = collections.defaultdict(list)
-    for f in glob.glob(f"{out}/{tag}/**/*counter_collection.csv", recursive=True):
-        for row in csv.DictReader(open(f)):
-            if row.get("Counter_Name") == counter:
-                agg[row["Kernel_Name"][:60]].append(float(row["Counter_Value"]))
-    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:8]:
-        print(f"{counter} {k}: n={len(v)} mean={sum(v)/len(v):.1f} max={max(v):.1f}")
+summary = []
+for w in ("fused", "dgemm"):
+    for tag, counter in ((f"pmc_fetch_{w}", "FETCH_SIZE"), (f"pmc_write_{w}", "WRITE_SIZE")):
+        agg = collections.defaultdict(list)
+        for f in glob.glob(f"{out}/{tag}/**/*counter_collection.csv", recursive=True):
+            for row in csv.DictReader(open(f)):
+                if row.get("Counter_Name") == counter:
+                    agg[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:4]:
+            summary.append({"workload": w, "kernel": k, "counter": counter, "launches": len(v), "mean": sum(v)/len(v), "min": min(v), "max": max(v)})
+            print(f"{w} {counter} {k[:50]}: n={len(v)} mean={sum(v)/len(v):.1f}")
+json.dump(summary, open(f"{out}/pmc_summary.json", "w"), indent=1)
 PY
