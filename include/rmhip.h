@@ -154,7 +154,8 @@ enum rmhip_unary_op { /* unary_* ; numbering shared with oracle/oracle.c */
     RMHIP_COSH, RMHIP_TANH, RMHIP_ASINH, RMHIP_ACOSH, RMHIP_ATANH, RMHIP_EXP, RMHIP_EXPM1,
     RMHIP_LOG, RMHIP_LOG2, RMHIP_LOG10, RMHIP_LOG1P, RMHIP_SQRT, RMHIP_ABS, RMHIP_SIGN,
     RMHIP_FLOOR, RMHIP_CEIL, RMHIP_ROUND, RMHIP_FIX, RMHIP_NEG, RMHIP_EXP2, RMHIP_HEAVISIDE,
-    RMHIP_ISNAN, RMHIP_ISINF, RMHIP_ISFINITE, RMHIP_UPLUS, RMHIP_UNARY_OP_COUNT
+    RMHIP_ISNAN, RMHIP_ISINF, RMHIP_ISFINITE, RMHIP_UPLUS, RMHIP_SINGLE /* round through f32 */, RMHIP_DOUBLE,
+    RMHIP_ERF, RMHIP_SINC, RMHIP_UNARY_OP_COUNT
 };
 RMHIP_API int rmhip_unary(rmhip_ctx* ctx, int op, rmhip_buf a, rmhip_buf* out);
 

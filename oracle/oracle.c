@@ -84,7 +84,7 @@ enum {
     ORC_SIN = 0, ORC_COS, ORC_TAN, ORC_ASIN, ORC_ACOS, ORC_ATAN, ORC_SINH, ORC_COSH, ORC_TANH,
     ORC_ASINH, ORC_ACOSH, ORC_ATANH, ORC_EXP, ORC_EXPM1, ORC_LOG, ORC_LOG2, ORC_LOG10, ORC_LOG1P,
     ORC_SQRT, ORC_ABS, ORC_SIGN, ORC_FLOOR, ORC_CEIL, ORC_ROUND, ORC_FIX, ORC_NEG, ORC_EXP2,
-    ORC_HEAVISIDE, ORC_ISNAN, ORC_ISINF, ORC_ISFINITE, ORC_UPLUS
+    ORC_HEAVISIDE, ORC_ISNAN, ORC_ISINF, ORC_ISFINITE, ORC_UPLUS, ORC_SINGLE, ORC_DOUBLE, ORC_ERF, ORC_SINC
 };
 
 /* crates/runmat-runtime/src/builtins/math/elementwise/sign.rs:236-246 */
@@ -131,12 +131,21 @@ static double unary_apply(int op, double v) {
         case ORC_ISINF: return isinf(v) ? 1.0 : 0.0;
         case ORC_ISFINITE: return isfinite(v) ? 1.0 : 0.0;
         case ORC_UPLUS: return v;
+        case ORC_SINGLE: return (double)(float)v; /* crates/runmat-builtins/src/lib.rs:426-436 */
+        case ORC_DOUBLE: return v;
+        case ORC_ERF: return erf(v);              /* libm::erf, elementwise/erf.rs:214-216 */
+        case ORC_SINC: {                          /* sinc.rs:302-311 */
+            if (v == 0.0) return 1.0;
+            if (isfinite(v) && v == trunc(v)) return 0.0;
+            double scaled = M_PI * v;
+            return sin(scaled) / scaled;
+        }
         default: return NAN;
     }
 }
 
 ORC_API int orc_unary(int op, const double* x, size_t n, double* out) {
-    if (op < 0 || op > ORC_UPLUS) return 1;
+    if (op < 0 || op > ORC_SINC) return 1;
     for (size_t i = 0; i < n; ++i) out[i] = unary_apply(op, x[i]);
     return 0;
 }

@@ -58,6 +58,9 @@ __device__ __forceinline__ double unary_op(double v) {
         case RMHIP_ISNAN: return rm_isnan(v) ? 1.0 : 0.0;
         case RMHIP_ISINF: return rm_isinf(v) ? 1.0 : 0.0;
         case RMHIP_ISFINITE: return rm_isfinite(v) ? 1.0 : 0.0;
+        case RMHIP_SINGLE: return rm_f32(v);  // `single`: f64 storage rounded through f32 (runmat-builtins lib.rs:426-436)
+        case RMHIP_ERF: return erf(v);        // libm::erf (elementwise/erf.rs:214-216)
+        case RMHIP_SINC: return rm_sinc(v);
         default: return v;
     }
 }

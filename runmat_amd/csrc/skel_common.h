@@ -51,6 +51,14 @@ __device__ __forceinline__ double rm_rem(double l, double r) {
     return l - r * trunc(l / r);
 }
 
+// sinc: crates/runmat-runtime/src/builtins/math/.../sinc.rs:302-311
+__device__ __forceinline__ double rm_sinc(double v) {
+    if (v == 0.0) return 1.0;
+    if (rm_isfinite(v) && v == trunc(v)) return 0.0;
+    const double scaled = 3.14159265358979323846 * v;
+    return sin(scaled) / scaled;
+}
+
 struct rm_d2 {
     double x, y;
 } __attribute__((aligned(16)));

@@ -27,7 +27,7 @@ BINARY_OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3, "pow": 4, "max": 5, "min":
 UNARY_OPS = {n: i for i, n in enumerate((
     "sin", "cos", "tan", "asin", "acos", "atan", "sinh", "cosh", "tanh", "asinh", "acosh", "atanh", "exp", "expm1",
     "log", "log2", "log10", "log1p", "sqrt", "abs", "sign", "floor", "ceil", "round", "fix", "neg", "exp2",
-    "heaviside", "isnan", "isinf", "isfinite", "uplus"))}
+    "heaviside", "isnan", "isinf", "isfinite", "uplus", "single", "double", "erf", "sinc"))}
 SCALAR_OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3, "rsub": 4, "rdiv": 5, "max": 6, "min": 7}
 REDUCE_OPS = {"sum": 0, "mean": 1, "min": 2, "max": 3, "prod": 4}
 

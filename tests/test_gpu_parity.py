@@ -347,7 +347,8 @@ def test_unary_binary_scalar_ops_vs_oracle(prov, oracle):
     X = rng.uniform(0.05, 3.0, (333, 77))
     Y = rng.uniform(0.05, 3.0, (333, 77))
     hx, hy = prov.upload(X), prov.upload(Y)
-    exact_unary = ("sqrt", "abs", "sign", "floor", "ceil", "round", "fix", "neg", "heaviside", "isnan", "isinf", "isfinite", "uplus")
+    exact_unary = ("sqrt", "abs", "sign", "floor", "ceil", "round", "fix", "neg", "heaviside", "isnan", "isinf", "isfinite", "uplus",
+                   "single", "double")
     for op in exact_unary:
         h = getattr(prov, "unary_" + op)(hx)
         assert bits_equal(prov.download_matrix(h), oracle.unary(op, X)), op
@@ -815,3 +816,14 @@ def test_block_ops_and_block_cyclic_solve_on_gpu(prov, oracle):
     with pytest.raises(ProviderError) as e:
         sh.mldivide_block_cyclic(prov, sh.Group(), prov.upload(np.ones((64, 64))), 64, prov.upload(np.ones((64, 1))), nb=32)
     assert e.value.code == 7
+
+
+def test_unary_erf_sinc_single(prov, oracle):
+    x = np.concatenate([np.linspace(-4, 4, 2001), [0.0, -0.0, 1.0, -3.0, 1e300, np.inf, -np.inf, np.nan, 0.1, 1e-310]]).reshape(-1, 1)
+    h = prov.upload(x)
+    assert ulp_err(prov.download_matrix(prov.unary_erf(h)), oracle.unary("erf", x)) <= 2
+    got, want = prov.download_matrix(prov.unary_sinc(h)), oracle.unary("sinc", x)
+    fin = np.isfinite(want)
+    assert np.max(np.abs(got[fin] - want[fin])) <= 4 * EPS and np.array_equal(np.isnan(got), np.isnan(want))
+    assert got[2001, 0] == 1.0 and got[2003, 0] == 0.0 and got[2004, 0] == 0.0  # sinc(0)=1, sinc(integer)=0
+    assert bits_equal(prov.download_matrix(prov.unary_single(h)), x.astype(np.float32).astype(np.float64))

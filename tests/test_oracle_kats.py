@@ -332,3 +332,12 @@ def test_matmul_epilogue_order(oracle):
     want = np.array([[(26 * 0.5 + 1) * 2 / 1, (30 * 0.5 + 1) * 2 / 10], [(38 * 0.5 + 1) * 4 / 1, (44 * 0.5 + 1) * 4 / 10]])
     want = np.minimum(want, 30.0) ** 2.0
     assert np.allclose(c, want, rtol=1e-15) and np.allclose(d, np.diag(want), rtol=1e-15)
+
+
+def test_erf_sinc_single_kats(oracle):
+    # erf.rs:279-287 scalar KATs (tol 1e-15); sinc.rs:302-311; single = f64 storage rounded through f32
+    e = oracle.unary("erf", np.array([[1.0, -0.5]]))[0]
+    assert abs(e[0] - 0.8427007929497149) < 1e-15 and abs(e[1] + 0.5204998778130465) < 1e-15
+    s = oracle.unary("sinc", np.array([[0.0, 1.0, -2.0, 0.5]]))[0]
+    assert s[0] == 1.0 and s[1] == 0.0 and s[2] == 0.0 and abs(s[3] - 2.0 / np.pi) < 1e-16
+    assert oracle.unary("single", np.array([[0.1]]))[0, 0] == float(np.float32(0.1))
