@@ -206,6 +206,24 @@ RMHIP_API int rmhip_lu(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf out5[5]);
  * (rectangular, pivot <= 1e-12) returns UNSUPPORTED/SINGULAR so the caller uses the CPU SVD path
  * (mldivide.rs:223-229 `.ok()`). Scalar A => b * (1/A) (mldivide.rs:321-325). */
 RMHIP_API int rmhip_mldivide(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out);
+/* `linsolve` + ProviderLinsolveOptions / ProviderLinsolveResult (lib.rs:2422-2429, 679-697); CPU
+ * semantics crates/runmat-runtime/src/builtins/math/linalg/solve/linsolve.rs:691-726 (option order:
+ * TRANSA transposes A and swaps LT<->UT), 769-833 (substitution; a zero diagonal entry is the
+ * "singular to working precision" error; rcond = min|d_ii| / max|d_ii|), 1000-1009 (RCOND threshold).
+ *   - lower / upper : triangular solve on the device, *rcond as the reference computes it.
+ *   - general square: LU solve as rmhip_mldivide; *rcond = NaN.  With need_rcond or has_rcond the
+ *     reference reports sigma_min/sigma_max of an SVD (linsolve.rs:933-944): UNSUPPORTED here so the
+ *     caller takes its CPU path (linsolve.rs:414-417 `.ok()`), as for rectangular systems.
+ *   - conjugate / symmetric / posdef are accepted and, as in the reference's real path, have no effect. */
+typedef struct rmhip_linsolve_options {
+    int lower, upper, rectangular, transposed, conjugate, symmetric, posdef, need_rcond;
+    int has_rcond;   /* Option<f64> rcond */
+    double rcond;
+} rmhip_linsolve_options_t;
+RMHIP_API int rmhip_linsolve(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, const rmhip_linsolve_options_t* opts,
+                             rmhip_buf* out, double* reciprocal_condition);
+/* `transpose` (lib.rs `fn transpose`): out[j,i] = a[i,j] for a 2-D tensor, new buffer [cols, rows]. */
+RMHIP_API int rmhip_transpose(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out);
 
 /* ---- block-level building blocks for the multi-GPU solver ------------------------------------ *
  * A distributed (block-column cyclic) A\b has no counterpart in the reference (it has no multi-device

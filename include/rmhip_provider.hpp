@@ -198,6 +198,22 @@ public:
         check(rmhip_mldivide(ctx_, own(lhs), own(rhs), &out));
         return with_shape(out);
     }
+    // ProviderLinsolveOptions / ProviderLinsolveResult (lib.rs:679-697, 2422-2429)
+    struct LinsolveResult {
+        GpuTensorHandle solution;
+        double reciprocal_condition;
+    };
+    LinsolveResult linsolve(const GpuTensorHandle& lhs, const GpuTensorHandle& rhs, const rmhip_linsolve_options_t& opts) const {
+        uint64_t out = 0;
+        double rcond = 0.0;
+        check(rmhip_linsolve(ctx_, own(lhs), own(rhs), &opts, &out, &rcond));
+        return {with_shape(out), rcond};
+    }
+    GpuTensorHandle transpose(const GpuTensorHandle& a) const {
+        uint64_t out = 0;
+        check(rmhip_transpose(ctx_, own(a), &out));
+        return with_shape(out);
+    }
     ProviderLuResult lu(const GpuTensorHandle& a) const {
         uint64_t ids[5] = {0, 0, 0, 0, 0};
         check(rmhip_lu(ctx_, own(a), ids));

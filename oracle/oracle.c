@@ -561,6 +561,39 @@ ORC_API int orc_mldivide_svd(const double* A, size_t m, size_t n, const double* 
 /* LU-based A\b for square well-conditioned A: the algorithm the HIP path implements (LU with the
  * host_lu.rs pivot rule, then forward/back substitution). Used as the bit-pattern-adjacent
  * comparator at sizes where the SVD restatement is too slow. Returns 3 if a pivot is <= 1e-12. */
+/* ---- linsolve (triangular hints) --------------------------------------------------------------
+ * crates/runmat-runtime/src/builtins/math/linalg/solve/linsolve.rs:769-800 (forward) / 802-833
+ * (backward): per rhs column, accum = sum_j T[i,j]*x[j] in ascending j, x[i] = (b[i]-accum)/d;
+ * rcond = min|d|/max|d| (common/linalg.rs:232-238, f64::min/max ignore NaN); a zero diagonal entry
+ * is the singular error (return 3).  TRANSA (linsolve.rs:698-705) is the caller's job: transpose
+ * (orc_transpose) and swap lower<->upper. */
+ORC_API int orc_linsolve_tri(int lower, const double* T, size_t n, const double* B, size_t nrhs, double* X, double* rcond) {
+    double min_diag = INFINITY, max_diag = 0.0;
+    memcpy(X, B, sizeof(double) * n * nrhs);
+    for (size_t col = 0; col < nrhs; ++col) {
+        for (size_t step = 0; step < n; ++step) {
+            const size_t i = lower ? step : n - 1 - step;
+            const double diag = T[i + i * n];
+            const double da = fabs(diag);
+            min_diag = fmin(min_diag, da);
+            max_diag = fmax(max_diag, da);
+            if (da == 0.0) return 3;
+            double accum = 0.0;
+            if (lower) for (size_t j = 0; j < i; ++j) accum += T[i + j * n] * X[j + col * n];
+            else for (size_t j = i + 1; j < n; ++j) accum += T[i + j * n] * X[j + col * n];
+            X[i + col * n] = (X[i + col * n] - accum) / diag;
+        }
+    }
+    if (rcond) *rcond = max_diag == 0.0 ? 0.0 : min_diag / max_diag;
+    return 0;
+}
+
+/* transpose_tensor, linsolve.rs:1067-1077 */
+ORC_API void orc_transpose(const double* A, size_t rows, size_t cols, double* out) {
+    for (size_t r = 0; r < rows; ++r)
+        for (size_t c = 0; c < cols; ++c) out[c + r * cols] = A[r + c * rows];
+}
+
 ORC_API int orc_mldivide_lu(const double* A, size_t n, const double* B, size_t nrhs, double* X) {
     double* comb = (double*)malloc(sizeof(double) * n * n);
     double* piv = (double*)malloc(sizeof(double) * n);

@@ -66,6 +66,10 @@ def lib() -> C.CDLL:
         l.orc_mldivide_svd.argtypes = [_DP, C.c_size_t, C.c_size_t, _DP, C.c_size_t, C.c_size_t, _DP]
         l.orc_mldivide_lu.restype = C.c_int
         l.orc_mldivide_lu.argtypes = [_DP, C.c_size_t, _DP, C.c_size_t, _DP]
+        l.orc_linsolve_tri.restype = C.c_int
+        l.orc_linsolve_tri.argtypes = [C.c_int, _DP, C.c_size_t, _DP, C.c_size_t, _DP, _DP]
+        l.orc_transpose.restype = None
+        l.orc_transpose.argtypes = [_DP, C.c_size_t, C.c_size_t, _DP]
         l.orc_sin_mul_add.restype = C.c_int
         l.orc_sin_mul_add.argtypes = [_DP, _DP, _DP, C.c_size_t, _DP]
         l.orc_elementwise_math_chain.restype = C.c_int
@@ -238,6 +242,37 @@ def mldivide_lu(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     if rc == 3:
         raise np.linalg.LinAlgError("singular")
     return out.reshape((n, b.shape[1]), order="F")
+
+
+def transpose(a: np.ndarray) -> np.ndarray:
+    a = np.asarray(a, dtype=np.float64)
+    out = np.empty(a.size)
+    lib().orc_transpose(_p(_f(a)), a.shape[0], a.shape[1], _p(out))
+    return out.reshape((a.shape[1], a.shape[0]), order="F")
+
+
+def linsolve(a: np.ndarray, b: np.ndarray, lower=False, upper=False, transposed=False):
+    """solve_real, linsolve.rs:691-726 -> (solution, rcond). General systems go through the SVD restatement
+    (rcond = sigma_min / sigma_max is not restated: returned as None)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if b.ndim == 1:
+        b = b.reshape(-1, 1)
+    if transposed:
+        a = transpose(a)
+        if lower or upper:
+            lower, upper = upper, lower
+    if a.shape[0] != b.shape[0]:
+        raise ValueError("Matrix dimensions must agree.")
+    if not (lower or upper):
+        return mldivide_svd(a, b), None
+    n = a.shape[0]
+    out = np.empty(n * b.shape[1])
+    rcond = C.c_double(0.0)
+    rc = lib().orc_linsolve_tri(1 if lower else 0, _p(_f(a)), n, _p(_f(b)), b.shape[1], _p(out), C.byref(rcond))
+    if rc == 3:
+        raise np.linalg.LinAlgError("linsolve: matrix is singular to working precision.")
+    return out.reshape((n, b.shape[1]), order="F"), rcond.value
 
 
 def sin_mul_add(a, b, c) -> np.ndarray:

@@ -5,8 +5,8 @@ include/rmhip.h); `provider.py` is the host-side mirror of the reference's `Acce
 `fusion.py` emits the WGSL requests the reference planner would send; `sharding.py` is the
 one-process-per-GPU partitioning used by multi-GPU runs.
 """
-from .provider import (GpuTensorHandle, HipProvider, ProviderError, ProviderLuResult, ReductionFlavor,
-                       wgsl_compile_check, wgsl_translate)
+from .provider import (GpuTensorHandle, HipProvider, ProviderError, ProviderLinsolveOptions, ProviderLinsolveResult,
+                       ProviderLuResult, ReductionFlavor, wgsl_compile_check, wgsl_translate)
 
-__all__ = ["GpuTensorHandle", "HipProvider", "ProviderError", "ProviderLuResult", "ReductionFlavor",
-           "wgsl_compile_check", "wgsl_translate"]
+__all__ = ["GpuTensorHandle", "HipProvider", "ProviderError", "ProviderLinsolveOptions", "ProviderLinsolveResult",
+           "ProviderLuResult", "ReductionFlavor", "wgsl_compile_check", "wgsl_translate"]

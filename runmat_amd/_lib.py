@@ -48,6 +48,12 @@ class MatmulEpilogue(C.Structure):
                 ("diag_output", C.c_uint64)]
 
 
+class LinsolveOptions(C.Structure):
+    """rmhip_linsolve_options_t (ProviderLinsolveOptions, lib.rs:679-690)"""
+    _fields_ = [(n, C.c_int) for n in ("lower", "upper", "rectangular", "transposed", "conjugate", "symmetric", "posdef",
+                                       "need_rcond", "has_rcond")] + [("rcond", C.c_double)]
+
+
 class View(C.Structure):
     """rmhip_view_t: rows [row_off, row_off+rows) x cols [col_off, col_off+cols) of a 2-D buffer."""
     _fields_ = [("buf", C.c_uint64), ("row_off", C.c_size_t), ("col_off", C.c_size_t), ("rows", C.c_size_t),
@@ -95,6 +101,8 @@ SIGNATURES = {
     "rmhip_matmul_epilogue": (C.c_int, [_P, _BUF, _BUF, C.POINTER(MatmulEpilogue), _BUFP]),
     "rmhip_lu": (C.c_int, [_P, _BUF, _BUFP]),
     "rmhip_mldivide": (C.c_int, [_P, _BUF, _BUF, _BUFP]),
+    "rmhip_linsolve": (C.c_int, [_P, _BUF, _BUF, C.POINTER(LinsolveOptions), _BUFP, _DP]),
+    "rmhip_transpose": (C.c_int, [_P, _BUF, _BUFP]),
     "rmhip_blk_copy": (C.c_int, [_P, C.POINTER(View), _BUFP]),
     "rmhip_blk_assign": (C.c_int, [_P, C.POINTER(View), _BUF]),
     "rmhip_blk_gemm": (C.c_int, [_P, C.c_double, C.POINTER(View), C.POINTER(View), C.c_double, C.POINTER(View)]),

@@ -178,6 +178,9 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
 int lu_swap_rows_device(Context* c, double* A, size_t lda, size_t ncols, const std::vector<int>& ipiv);
 int trsm_lower_unit_device(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc);
 int trsm_upper_device(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc);
+int trsm_lower_nonunit_device(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc);
+int transpose_device(Context* c, const double* src, size_t lds_, size_t rows, size_t cols, double* dst, size_t ldd);
+int diag_stats_device(Context* c, const double* A, size_t lda, size_t n, double* min_abs, double* max_abs, size_t* zeros);
 int lu_solve_device(Context* c, const double* LU, size_t n, size_t lda, const int* perm_dev,
                     const double* B, size_t nrhs, size_t ldb, double* X, size_t ldx);
 int lu_extract_device(Context* c, const double* LU, size_t rows, size_t cols, const int* perm_dev,

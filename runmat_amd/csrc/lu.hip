@@ -264,22 +264,27 @@ __global__ void __launch_bounds__(2 * PLIST) k_laswp_lists(double* __restrict__ 
 // with a shuffle and every lane eliminates it.  Loads/stores of B are 256-byte contiguous segments.
 static constexpr int TRSM_THREADS = 256;
 
-// lower, unit diagonal: B <- L^-1 B ; T is w x w at T[0], ldt.
-__global__ void __launch_bounds__(TRSM_THREADS) k_trsm_lower_unit(const double* __restrict__ T, size_t ldt, int w,
-                                                                  double* __restrict__ B, size_t ldb, size_t ncols) {
+// lower: B <- L^-1 B ; T is w x w at T[0], ldt.  UNIT: implicit unit diagonal (LU factors);
+// otherwise the stored diagonal divides (`linsolve` LT, linsolve.rs:769-800).
+template <bool UNIT>
+__global__ void __launch_bounds__(TRSM_THREADS) k_trsm_lower(const double* __restrict__ T, size_t ldt, int w,
+                                                             double* __restrict__ B, size_t ldb, size_t ncols) {
     const int i = threadIdx.x & 31;
     const size_t hw = ((size_t)blockIdx.x * TRSM_THREADS + threadIdx.x) >> 5;
     const size_t nhw = ((size_t)gridDim.x * TRSM_THREADS) >> 5;
     double lrow[TRSM_W];
 #pragma unroll
     for (int k = 0; k < TRSM_W; ++k) lrow[k] = (i < w && k < i) ? T[i + (size_t)k * ldt] : 0.0;
+    const double diag = (!UNIT && i < w) ? T[i + (size_t)i * ldt] : 1.0;
     for (size_t cc = hw; cc < ncols; cc += nhw) {
         double* b = B + cc * ldb;
         double x = i < w ? b[i] : 0.0;
 #pragma unroll
-        for (int k = 0; k < TRSM_W - 1; ++k) {
-            const double xk = __shfl(x, k, 32);
-            if (i > k) x -= lrow[k] * xk;  // predicate (not a zero multiplier): 0 * inf must not poison finished lanes
+        for (int k = 0; k < TRSM_W - (UNIT ? 1 : 0); ++k) {
+            const double xf = UNIT ? x : x / diag;  // final for the lane whose turn it is (k == i)
+            const double xk = __shfl(xf, k, 32);
+            if (!UNIT && i == k) x = xk;
+            else if (i > k) x -= lrow[k] * xk;  // predicate (not a zero multiplier): 0 * inf must not poison finished lanes
         }
         if (i < w) b[i] = x;
     }
@@ -323,18 +328,23 @@ static int launch_check(Context* c) {
 }
 
 // B[w x nc] <- L^-1 B with L = unit-lower part of T[w x w]; recursive halving, dgemm in between.
-static int trsm_lower_rec(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
+static int trsm_lower_rec(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc,
+                          bool unit = true) {
     if (w == 0 || nc == 0) return RMHIP_OK;
     if (w <= (size_t)TRSM_W) {
-        hipLaunchKernelGGL(k_trsm_lower_unit, dim3(trsm_grid(c, nc)), dim3(TRSM_THREADS), 0, c->stream, T, ldt, (int)w,
-                           B, ldb, nc);
+        if (unit)
+            hipLaunchKernelGGL(k_trsm_lower<true>, dim3(trsm_grid(c, nc)), dim3(TRSM_THREADS), 0, c->stream, T, ldt, (int)w,
+                               B, ldb, nc);
+        else
+            hipLaunchKernelGGL(k_trsm_lower<false>, dim3(trsm_grid(c, nc)), dim3(TRSM_THREADS), 0, c->stream, T, ldt, (int)w,
+                               B, ldb, nc);
         return launch_check(c);
     }
     size_t h = ((w / 2 + 15) / 16) * 16;
     if (h >= w) h = w / 2;
-    RMHIP_TRY(trsm_lower_rec(c, T, ldt, h, B, ldb, nc));
+    RMHIP_TRY(trsm_lower_rec(c, T, ldt, h, B, ldb, nc, unit));
     RMHIP_TRY(launch_dgemm(c, w - h, nc, h, -1.0, T + h, ldt, B, ldb, 1.0, B + h, ldb));
-    return trsm_lower_rec(c, T + h + h * ldt, ldt, w - h, B + h, ldb, nc);
+    return trsm_lower_rec(c, T + h + h * ldt, ldt, w - h, B + h, ldb, nc, unit);
 }
 
 static int trsm_upper_rec(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
@@ -637,6 +647,85 @@ int trsm_lower_unit_device(Context* c, const double* T, size_t ldt, size_t w, do
 }
 int trsm_upper_device(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
     return trsm_upper_rec(c, T, ldt, w, B, ldb, nc);
+}
+int trsm_lower_nonunit_device(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
+    return trsm_lower_rec(c, T, ldt, w, B, ldb, nc, false);
+}
+
+// ---- transpose (AccelProvider::transpose, lib.rs; also `linsolve` TRANSA, linsolve.rs:698-705) -----
+// 64x64 tiles through LDS (row stride 65 doubles: conflict-free both ways); a wave reads 512
+// contiguous bytes of a source column and writes 512 contiguous bytes of a destination column.
+static constexpr int TR_TILE = 64;
+__global__ void __launch_bounds__(256) k_transpose(const double* __restrict__ src, size_t lds_, size_t rows, size_t cols,
+                                                   double* __restrict__ dst, size_t ldd) {
+    __shared__ double tile[TR_TILE][TR_TILE + 1];
+    const size_t r0 = (size_t)blockIdx.x * TR_TILE, c0 = (size_t)blockIdx.y * TR_TILE;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int p = 0; p < TR_TILE / 4; ++p) {
+        const int cc = grp + 4 * p;
+        if (r0 + lane < rows && c0 + cc < cols) tile[cc][lane] = src[(r0 + lane) + (c0 + cc) * lds_];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int p = 0; p < TR_TILE / 4; ++p) {
+        const int rr = grp + 4 * p;
+        if (c0 + lane < cols && r0 + rr < rows) dst[(c0 + lane) + (r0 + rr) * ldd] = tile[lane][rr];
+    }
+}
+
+int transpose_device(Context* c, const double* src, size_t lds_, size_t rows, size_t cols, double* dst, size_t ldd) {
+    if (rows == 0 || cols == 0) return RMHIP_OK;
+    const size_t gx = (rows + TR_TILE - 1) / TR_TILE, gy = (cols + TR_TILE - 1) / TR_TILE;
+    if (gy > 65535) return fail(RMHIP_ERR_UNSUPPORTED, "transpose: more than %d columns", 65535 * TR_TILE);
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, c->stream, src, lds_, rows, cols, dst, ldd);
+    return launch_check(c);
+}
+
+// min |d_ii|, max |d_ii| and the number of exact zeros on the diagonal (linsolve.rs:776-786: a zero
+// diagonal entry is the "singular to working precision" error; rcond = min/max, linalg.rs:232-238).
+__global__ void __launch_bounds__(256) k_diag_stats(const double* __restrict__ A, size_t lda, size_t n, double* __restrict__ out3) {
+    __shared__ double s_min[256], s_max[256], s_zero[256];
+    double mn = __builtin_inf(), mx = 0.0, z = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += 256) {
+        const double a = fabs(A[i + i * lda]);
+        mn = fmin(mn, a);  // f64::min / max: a NaN operand is ignored
+        mx = fmax(mx, a);
+        if (a == 0.0) z += 1.0;
+    }
+    s_min[threadIdx.x] = mn;
+    s_max[threadIdx.x] = mx;
+    s_zero[threadIdx.x] = z;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            s_min[threadIdx.x] = fmin(s_min[threadIdx.x], s_min[threadIdx.x + off]);
+            s_max[threadIdx.x] = fmax(s_max[threadIdx.x], s_max[threadIdx.x + off]);
+            s_zero[threadIdx.x] += s_zero[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out3[0] = s_min[0];
+        out3[1] = s_max[0];
+        out3[2] = s_zero[0];
+    }
+}
+
+int diag_stats_device(Context* c, const double* A, size_t lda, size_t n, double* min_abs, double* max_abs, size_t* zeros) {
+    double* d = nullptr;
+    RMHIP_HIP_CHECK(hipMalloc((void**)&d, 3 * sizeof(double)));
+    hipLaunchKernelGGL(k_diag_stats, dim3(1), dim3(256), 0, c->stream, A, lda, n, d);
+    double h[3] = {0, 0, 0};
+    hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    c->tel.kernel_launches++;
+    if (e != hipSuccess) return fail(RMHIP_ERR_HIP, "diag_stats: %s", hipGetErrorString(e));
+    *min_abs = h[0];
+    *max_abs = h[1];
+    *zeros = (size_t)h[2];
+    return RMHIP_OK;
 }
 
 __global__ void __launch_bounds__(256) k_gather_rows(const double* __restrict__ B, size_t ldb, const int* __restrict__ perm,

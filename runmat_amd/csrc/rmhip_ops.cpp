@@ -9,6 +9,8 @@
 #include <cstring>
 
 #include "codegen.h"
+#include <limits>
+
 #include "common.h"
 #include "reduce_plan.h"
 #include "wgsl_front.h"
@@ -611,6 +613,100 @@ int rmhip_mldivide(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
         return rc;
     }
     *out = oid;
+    return RMHIP_OK;
+}
+
+int rmhip_transpose(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer ab;
+    RMHIP_TRY(c->get(a, &ab));
+    if (ab.shape.size() > 2) return fail(RMHIP_ERR_UNSUPPORTED, "transpose: only 2D supported");
+    const std::vector<size_t> as = normalize_matrix_shape(ab.shape);
+    const size_t oshape[2] = {as[1], as[0]};
+    Buffer ob;
+    RMHIP_TRY(c->new_buffer(oshape, 2, out, &ob));
+    int rc = transpose_device(c, ab.data(), as[0], as[0], as[1], ob.data(), as[1]);
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+
+int rmhip_linsolve(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, const rmhip_linsolve_options_t* opts, rmhip_buf* out,
+                   double* reciprocal_condition) {
+    CTX_OR_FAIL(ctx);
+    if (!out || !opts) return fail(RMHIP_ERR_INVALID, "linsolve: null argument");
+    Buffer ab, bb;
+    RMHIP_TRY(c->get(a, &ab));
+    RMHIP_TRY(c->get(b, &bb));
+    if (ab.shape.size() > 2 || bb.shape.size() > 2) return fail(RMHIP_ERR_UNSUPPORTED, "linsolve: only 2D supported");
+    std::vector<size_t> as = normalize_matrix_shape(ab.shape);
+    if (ab.numel == 1 || bb.numel == 1)  // linsolve.rs:408-412: scalar operands stay on the host path
+        return fail(RMHIP_ERR_UNSUPPORTED, "linsolve: scalar operands use the CPU path");
+    bool lower = opts->lower != 0, upper = opts->upper != 0;
+    const double* A = ab.data();
+    std::shared_ptr<Allocation> at;
+    if (opts->transposed) {  // linsolve.rs:698-705: materialise A' and swap the triangle hints
+        RMHIP_TRY(c->alloc_device(ab.numel ? ab.numel : 1, &at));
+        RMHIP_TRY(transpose_device(c, ab.data(), as[0], as[0], as[1], at->ptr, as[1]));
+        std::swap(as[0], as[1]);
+        A = at->ptr;
+        if (lower || upper) std::swap(lower, upper);
+    }
+    // normalize_rhs_tensor (linsolve.rs:972-984): a rank-1 rhs of the right length is a column
+    std::vector<size_t> bs = normalize_matrix_shape(bb.shape);
+    if (bs[0] != as[0]) {
+        if (bb.shape.size() == 1 && bb.shape[0] == as[0]) bs = {as[0], 1};
+        else return fail(RMHIP_ERR_SHAPE, "linsolve: Matrix dimensions must agree.");
+    }
+    const size_t n = as[0], nrhs = bs[1];
+    if ((lower || upper) && as[0] != as[1]) return fail(RMHIP_ERR_SHAPE, "linsolve: triangular solves need a square matrix");
+    if (!(lower || upper)) {
+        if (as[0] != as[1]) return fail(RMHIP_ERR_UNSUPPORTED, "linsolve: rectangular systems use the CPU least-squares path");
+        if (opts->need_rcond || opts->has_rcond)
+            return fail(RMHIP_ERR_UNSUPPORTED, "linsolve: rcond of a general matrix needs its singular values (CPU path)");
+    }
+    if (n == 0) return fail(RMHIP_ERR_UNSUPPORTED, "linsolve: empty system");
+    double rcond = std::numeric_limits<double>::quiet_NaN();
+    Buffer ob;
+    rmhip_buf oid = 0;
+    const size_t oshape[2] = {n, nrhs};
+    int rc = RMHIP_OK;
+    if (lower || upper) {
+        double mn = 0.0, mx = 0.0;
+        size_t zeros = 0;
+        RMHIP_TRY(diag_stats_device(c, A, n, n, &mn, &mx, &zeros));
+        if (zeros) return fail(RMHIP_ERR_SINGULAR, "linsolve: matrix is singular to working precision.");
+        rcond = mx == 0.0 ? 0.0 : mn / mx;
+        if (opts->has_rcond && rcond < opts->rcond)
+            return fail(RMHIP_ERR_SINGULAR, "linsolve: matrix is singular to working precision.");
+        RMHIP_TRY(c->new_buffer(oshape, 2, &oid, &ob));
+        hipError_t e = hipMemcpyAsync(ob.data(), bb.data(), sizeof(double) * n * nrhs, hipMemcpyDeviceToDevice, c->stream);
+        if (e != hipSuccess) rc = fail(RMHIP_ERR_HIP, "linsolve: %s", hipGetErrorString(e));
+        if (!rc)
+            rc = lower ? trsm_lower_nonunit_device(c, A, n, n, ob.data(), n, nrhs) : trsm_upper_device(c, A, n, n, ob.data(), n, nrhs);
+    } else {
+        const size_t ldw = lu_padded_ld(n);
+        std::shared_ptr<Allocation> work;
+        RMHIP_TRY(c->alloc_device(ldw * n, &work));
+        RMHIP_HIP_CHECK(hipMemcpy2DAsync(work->ptr, ldw * sizeof(double), A, n * sizeof(double), n * sizeof(double), n,
+                                         hipMemcpyDeviceToDevice, c->stream));
+        int* perm = nullptr;
+        RMHIP_HIP_CHECK(hipMalloc((void**)&perm, sizeof(int) * (n + 1)));
+        int info = 0;
+        rc = lu_factor_device(c, work->ptr, n, n, ldw, perm, &info);
+        if (!rc && info > 0) rc = fail(RMHIP_ERR_SINGULAR, "linsolve: %d pivot(s) <= 1e-12; use the CPU SVD path", info);
+        if (!rc) rc = c->new_buffer(oshape, 2, &oid, &ob);
+        if (!rc) rc = lu_solve_device(c, work->ptr, n, ldw, perm, bb.data(), nrhs, n, ob.data(), n);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(perm);
+    }
+    if (at) (void)hipStreamSynchronize(c->stream);  // the transposed copy is released on return
+    if (rc) {
+        if (oid) rmhip_free(ctx, oid);
+        return rc;
+    }
+    *out = oid;
+    if (reciprocal_condition) *reciprocal_condition = rcond;
     return RMHIP_OK;
 }
 

@@ -77,6 +77,27 @@ class ProviderLuResult:
     perm_vector: GpuTensorHandle
 
 
+@dataclass
+class ProviderLinsolveOptions:
+    """lib.rs:679-690"""
+    lower: bool = False
+    upper: bool = False
+    rectangular: bool = False
+    transposed: bool = False
+    conjugate: bool = False
+    symmetric: bool = False
+    posdef: bool = False
+    need_rcond: bool = False
+    rcond: Optional[float] = None
+
+
+@dataclass
+class ProviderLinsolveResult:
+    """lib.rs:692-696"""
+    solution: GpuTensorHandle
+    reciprocal_condition: float
+
+
 def _shape_array(shape: Sequence[int]):
     arr = (C.c_size_t * max(len(shape), 1))(*[int(s) for s in shape])
     return arr, len(shape)
@@ -338,6 +359,23 @@ class HipProvider:
     def mldivide(self, lhs: GpuTensorHandle, rhs: GpuTensorHandle) -> GpuTensorHandle:
         out = C.c_uint64()
         self._check(self._lib.rmhip_mldivide(self._ctx, self._id(lhs), self._id(rhs), C.byref(out)))
+        return self._handle(out.value)
+
+    def linsolve(self, lhs: GpuTensorHandle, rhs: GpuTensorHandle,
+                 options: Optional[ProviderLinsolveOptions] = None) -> ProviderLinsolveResult:
+        """lib.rs:2422-2429; CPU semantics linsolve.rs:691-726."""
+        o = options or ProviderLinsolveOptions()
+        co = _lib.LinsolveOptions(int(o.lower), int(o.upper), int(o.rectangular), int(o.transposed), int(o.conjugate),
+                                  int(o.symmetric), int(o.posdef), int(o.need_rcond), int(o.rcond is not None),
+                                  float(o.rcond) if o.rcond is not None else 0.0)
+        out = C.c_uint64()
+        rc = C.c_double(float("nan"))
+        self._check(self._lib.rmhip_linsolve(self._ctx, self._id(lhs), self._id(rhs), C.byref(co), C.byref(out), C.byref(rc)))
+        return ProviderLinsolveResult(self._handle(out.value), rc.value)
+
+    def transpose(self, a: GpuTensorHandle) -> GpuTensorHandle:
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_transpose(self._ctx, self._id(a), C.byref(out)))
         return self._handle(out.value)
 
     # -- block-level building blocks (views; used by the multi-GPU solver, they mutate the buffer) ----

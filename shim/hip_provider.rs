@@ -45,9 +45,17 @@ extern "C" {
     fn rmhip_matmul(ctx: *mut RmhipCtx, a: u64, b: u64, out: *mut u64) -> c_int;
     fn rmhip_lu(ctx: *mut RmhipCtx, a: u64, out5: *mut u64) -> c_int;
     fn rmhip_mldivide(ctx: *mut RmhipCtx, a: u64, b: u64, out: *mut u64) -> c_int;
+    fn rmhip_linsolve(ctx: *mut RmhipCtx, a: u64, b: u64, opts: *const RmhipLinsolveOptions, out: *mut u64, rcond: *mut c_double) -> c_int;
+    fn rmhip_transpose(ctx: *mut RmhipCtx, a: u64, out: *mut u64) -> c_int;
     fn rmhip_set_rng_state(ctx: *mut RmhipCtx, state: u64) -> c_int;
     fn rmhip_random_normal(ctx: *mut RmhipCtx, shape: *const usize, rank: usize, out: *mut u64) -> c_int;
     fn rmhip_random_uniform(ctx: *mut RmhipCtx, shape: *const usize, rank: usize, out: *mut u64) -> c_int;
+}
+
+#[repr(C)]
+struct RmhipLinsolveOptions {
+    lower: c_int, upper: c_int, rectangular: c_int, transposed: c_int, conjugate: c_int, symmetric: c_int, posdef: c_int,
+    need_rcond: c_int, has_rcond: c_int, rcond: c_double,
 }
 
 pub struct HipProvider {
@@ -187,6 +195,23 @@ impl AccelProvider for HipProvider {
             check(unsafe { rmhip_mldivide(self.ctx, self.own(lhs)?, self.own(rhs)?, &mut out) })?;
             self.handle(out)
         })
+    }
+    fn linsolve<'a>(&'a self, lhs: &'a GpuTensorHandle, rhs: &'a GpuTensorHandle, o: &'a ProviderLinsolveOptions)
+        -> AccelProviderFuture<'a, ProviderLinsolveResult> {
+        Box::pin(async move {
+            let c = RmhipLinsolveOptions { lower: o.lower as c_int, upper: o.upper as c_int, rectangular: o.rectangular as c_int,
+                transposed: o.transposed as c_int, conjugate: o.conjugate as c_int, symmetric: o.symmetric as c_int,
+                posdef: o.posdef as c_int, need_rcond: o.need_rcond as c_int, has_rcond: o.rcond.is_some() as c_int,
+                rcond: o.rcond.unwrap_or(0.0) };
+            let (mut out, mut rcond) = (0u64, f64::NAN);
+            check(unsafe { rmhip_linsolve(self.ctx, self.own(lhs)?, self.own(rhs)?, &c, &mut out, &mut rcond) })?;
+            Ok(ProviderLinsolveResult { solution: self.handle(out)?, reciprocal_condition: rcond })
+        })
+    }
+    fn transpose(&self, a: &GpuTensorHandle) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_transpose(self.ctx, self.own(a)?, &mut out) })?;
+        self.handle(out)
     }
     fn lu<'a>(&'a self, a: &'a GpuTensorHandle) -> AccelProviderFuture<'a, ProviderLuResult> {
         Box::pin(async move {

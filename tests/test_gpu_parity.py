@@ -826,4 +826,63 @@ def test_unary_erf_sinc_single(prov, oracle):
     fin = np.isfinite(want)
     assert np.max(np.abs(got[fin] - want[fin])) <= 4 * EPS and np.array_equal(np.isnan(got), np.isnan(want))
     assert got[2001, 0] == 1.0 and got[2003, 0] == 0.0 and got[2004, 0] == 0.0  # sinc(0)=1, sinc(integer)=0
-    assert bits_equal(prov.download_matrix(prov.unary_single(h)), x.astype(np.float32).astype(np.float64))
+    with np.errstate(over="ignore"):
+        want32 = x.astype(np.float32).astype(np.float64)
+    assert bits_equal(prov.download_matrix(prov.unary_single(h)), want32)
+
+
+# ---- linsolve / transpose --------------------------------------------------------------------------
+def test_linsolve_reference_tests(prov, oracle):
+    from runmat_amd import ProviderError, ProviderLinsolveOptions as Opt
+    # linsolve.rs:1224-1247: LT hint
+    a = np.array([3.0, -1.0, 4.0, 0.0, 2.0, 1.0, 0.0, 0.0, 5.0]).reshape(3, 3, order="F")
+    r = prov.linsolve(prov.upload(a), prov.upload(np.array([[9.0], [1.0], [19.0]])), Opt(lower=True, need_rcond=True))
+    assert np.max(np.abs(prov.download_matrix(r.solution)[:, 0] - [3.0, 2.0, 1.0])) < 1e-12
+    assert r.reciprocal_condition == 2.0 / 5.0
+    # linsolve.rs:1249-1285: LT + TRANSA=T (upper solve with A')
+    a2 = np.array([3.0, 1.0, 0.0, 0.0, 4.0, 2.0, 0.0, 0.0, 5.0]).reshape(3, 3, order="F")
+    b2 = np.array([[5.0], [14.0], [23.0]])
+    r2 = prov.linsolve(prov.upload(a2), prov.upload(b2), Opt(lower=True, transposed=True))
+    want, _ = oracle.linsolve(a2, b2, lower=True, transposed=True)
+    assert np.max(np.abs(prov.download_matrix(r2.solution) - want)) < 1e-12
+    # linsolve.rs:1209-1222: general square
+    r3 = prov.linsolve(prov.upload(np.array([[2.0, 1.0], [1.0, 2.0]])), prov.upload(np.array([[4.0], [5.0]])))
+    assert np.max(np.abs(prov.download_matrix(r3.solution)[:, 0] - [1.0, 2.0])) < 1e-12 and np.isnan(r3.reciprocal_condition)
+    # soft errors: zero diagonal, RCOND threshold, rcond of a general matrix, rectangular, row mismatch
+    with pytest.raises(ProviderError):
+        prov.linsolve(prov.upload(np.array([[1.0, 0.0], [1.0, 0.0]])), prov.upload(np.ones((2, 1))), Opt(lower=True))
+    with pytest.raises(ProviderError):
+        prov.linsolve(prov.upload(np.diag([1.0, 1e-9])), prov.upload(np.ones((2, 1))), Opt(upper=True, rcond=1e-6))
+    with pytest.raises(ProviderError):
+        prov.linsolve(prov.upload(np.eye(2) * 2), prov.upload(np.ones((2, 1))), Opt(need_rcond=True))
+    with pytest.raises(ProviderError):
+        prov.linsolve(prov.upload(np.ones((3, 2))), prov.upload(np.ones((3, 1))))
+    with pytest.raises(ProviderError):
+        prov.linsolve(prov.upload(np.eye(3)), prov.upload(np.ones((2, 1))), Opt(lower=True))
+    with pytest.raises(ProviderError):  # scalar operands stay on the host (linsolve.rs:408-412)
+        prov.linsolve(prov.upload(np.array([[2.0]])), prov.upload(np.ones((1, 1))), Opt(lower=True))
+
+
+@pytest.mark.parametrize("n,nrhs", [(2, 1), (31, 3), (32, 1), (33, 5), (257, 2), (1000, 7)])
+@pytest.mark.parametrize("kind", ["lower", "upper", "lower_t", "upper_t"])
+def test_linsolve_triangular_vs_oracle(prov, oracle, n, nrhs, kind):
+    from runmat_amd import ProviderLinsolveOptions as Opt
+    rng = np.random.default_rng(n * 7 + nrhs)
+    full = rng.uniform(-1, 1, (n, n)) / max(n, 1) + np.diag(rng.uniform(1.0, 2.0, n) * rng.choice([-1.0, 1.0], n))
+    b = rng.uniform(-1, 1, (n, nrhs))
+    lower, trans = kind.startswith("lower"), kind.endswith("_t")
+    # the unused triangle holds garbage on purpose: the solve must not read it
+    opts = Opt(lower=lower, upper=not lower, transposed=trans, need_rcond=True)
+    r = prov.linsolve(prov.upload(full), prov.upload(b), opts)
+    want, rc = oracle.linsolve(full, b, lower=lower, upper=not lower, transposed=trans)
+    got = prov.download_matrix(r.solution)
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= 64 * EPS * max(1.0, np.max(np.abs(want))) * n  # tolerance: summation order differs
+    assert r.reciprocal_condition == rc
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 5), (64, 64), (65, 127), (1000, 3), (1, 777), (513, 1025)])
+def test_transpose_bit_exact(prov, oracle, shape):
+    a = np.random.default_rng(shape[0]).uniform(-1, 1, shape)
+    got = prov.download_matrix(prov.transpose(prov.upload(a)))
+    assert got.shape == (shape[1], shape[0]) and bits_equal(got, oracle.transpose(a))

@@ -341,3 +341,18 @@ def test_erf_sinc_single_kats(oracle):
     s = oracle.unary("sinc", np.array([[0.0, 1.0, -2.0, 0.5]]))[0]
     assert s[0] == 1.0 and s[1] == 0.0 and s[2] == 0.0 and abs(s[3] - 2.0 / np.pi) < 1e-16
     assert oracle.unary("single", np.array([[0.1]]))[0, 0] == float(np.float32(0.1))
+
+
+def test_linsolve_triangular_kats(oracle):
+    # linsolve.rs:1224-1247 (LT hint) and 1249-1285 (LT + TRANSA='T' == plain solve with A')
+    a = np.array([3.0, -1.0, 4.0, 0.0, 2.0, 1.0, 0.0, 0.0, 5.0]).reshape(3, 3, order="F")
+    x, rcond = oracle.linsolve(a, np.array([9.0, 1.0, 19.0]), lower=True)
+    assert np.allclose(x[:, 0], [3.0, 2.0, 1.0], atol=1e-12) and rcond == 2.0 / 5.0
+    a2 = np.array([3.0, 1.0, 0.0, 0.0, 4.0, 2.0, 0.0, 0.0, 5.0]).reshape(3, 3, order="F")
+    b2 = np.array([5.0, 14.0, 23.0])
+    xt, _ = oracle.linsolve(a2, b2, lower=True, transposed=True)
+    assert np.allclose(a2.T @ xt[:, 0], b2, atol=1e-12)
+    xg, _ = oracle.linsolve(np.array([[2.0, 1.0], [1.0, 2.0]]), np.array([4.0, 5.0]))  # linsolve.rs:1209-1222
+    assert np.allclose(xg[:, 0], [1.0, 2.0], atol=1e-12)
+    with pytest.raises(np.linalg.LinAlgError):
+        oracle.linsolve(np.array([[1.0, 0.0], [1.0, 0.0]]), np.ones(2), lower=True)
