@@ -22,7 +22,7 @@ namespace rmhip {
 
 static constexpr double LU_EPS = 1.0e-12;  // host_lu.rs:3
 static constexpr int BASE_W = 64;          // base panel width (columns factored one launch each)
-static constexpr int TRSM_W = 32;          // base triangular solve size
+static constexpr int TRSM_W = 128;         // base triangular solve size (one fused launch)
 
 struct LuState {
     Context* c;
@@ -259,66 +259,129 @@ __global__ void __launch_bounds__(2 * PLIST) k_laswp_lists(double* __restrict__ 
     }
 }
 
-// Small triangular solves (w <= 32), cooperative: a half-wave (32 lanes) owns one right-hand-side
-// column at a time, lane i holds x_i and row i of the triangle in registers; step k broadcasts x_k
-// with a shuffle and every lane eliminates it.  Loads/stores of B are 256-byte contiguous segments.
-static constexpr int TRSM_THREADS = 256;
+// Small triangular solves (w <= TRSM_W = 128) in ONE launch: the triangle is staged in LDS as
+// Ts[k][r] (r contiguous), one wave owns one right-hand-side column at a time and lane i holds
+// x[i] and x[64 + i].  Step k broadcasts the finished x_k (uniform lane index -> v_readlane) and
+// every lane eliminates it from the rows it still owns, reading its multipliers from LDS
+// (512 contiguous bytes per wave: conflict free).  Before this kernel the same solve took seven
+// launches (four 32-wide substitutions + three MFMA dgemms with k <= 64), and at n = 16384 those
+// small dgemms alone cost ~35 ms of a 246 ms factorisation.
+//   MODE 0: lower, implicit unit diagonal (LU factors)        B <- L^-1 B
+//   MODE 1: lower, stored diagonal (`linsolve` LT, linsolve.rs:769-800)
+//   MODE 2: upper, stored diagonal                             B <- U^-1 B
+static constexpr int TRSM_THREADS = 512;
+static constexpr int TRSM_SW = TRSM_W + 1;  // LDS row stride (doubles)
 
-// lower: B <- L^-1 B ; T is w x w at T[0], ldt.  UNIT: implicit unit diagonal (LU factors);
-// otherwise the stored diagonal divides (`linsolve` LT, linsolve.rs:769-800).
-template <bool UNIT>
-__global__ void __launch_bounds__(TRSM_THREADS) k_trsm_lower(const double* __restrict__ T, size_t ldt, int w,
+// value of lane `lane` (wave-uniform index) in every lane: two v_readlane_b32, no LDS round trip
+__device__ __forceinline__ double bcast_lane(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(TRSM_THREADS) k_trsm_fused(const double* __restrict__ T, size_t ldt, int w,
                                                              double* __restrict__ B, size_t ldb, size_t ncols) {
-    const int i = threadIdx.x & 31;
-    const size_t hw = ((size_t)blockIdx.x * TRSM_THREADS + threadIdx.x) >> 5;
-    const size_t nhw = ((size_t)gridDim.x * TRSM_THREADS) >> 5;
-    double lrow[TRSM_W];
-#pragma unroll
-    for (int k = 0; k < TRSM_W; ++k) lrow[k] = (i < w && k < i) ? T[i + (size_t)k * ldt] : 0.0;
-    const double diag = (!UNIT && i < w) ? T[i + (size_t)i * ldt] : 1.0;
-    for (size_t cc = hw; cc < ncols; cc += nhw) {
+    extern __shared__ double Ts[];  // [w][TRSM_SW]
+    for (int idx = threadIdx.x; idx < w * TRSM_W; idx += TRSM_THREADS) {
+        const int r = idx & (TRSM_W - 1), k = idx / TRSM_W;
+        Ts[k * TRSM_SW + r] = r < w ? T[r + (size_t)k * ldt] : 0.0;
+    }
+    __syncthreads();
+    const int i = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * TRSM_THREADS + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * TRSM_THREADS) >> 6;
+    const bool two = w > 64;
+    double d0 = 1.0, d1 = 1.0;
+    if (MODE != 0) {
+        if (i < w) d0 = Ts[i * TRSM_SW + i];
+        if (64 + i < w) d1 = Ts[(64 + i) * TRSM_SW + 64 + i];
+    }
+    for (size_t cc = wave; cc < ncols; cc += nwaves) {
         double* b = B + cc * ldb;
-        double x = i < w ? b[i] : 0.0;
-#pragma unroll
-        for (int k = 0; k < TRSM_W - (UNIT ? 1 : 0); ++k) {
-            const double xf = UNIT ? x : x / diag;  // final for the lane whose turn it is (k == i)
-            const double xk = __shfl(xf, k, 32);
-            if (!UNIT && i == k) x = xk;
-            else if (i > k) x -= lrow[k] * xk;  // predicate (not a zero multiplier): 0 * inf must not poison finished lanes
+        double x0 = i < w ? b[i] : 0.0;
+        double x1 = 64 + i < w ? b[64 + i] : 0.0;
+        // selects, not branches and not zero multipliers: 0 * inf must not poison finished lanes
+        if (MODE != 2) {
+            const int k0end = w < 64 ? w : 64;
+#pragma unroll 1
+            for (int k = 0; k < k0end; ++k) {
+                const double xk = bcast_lane(MODE == 0 ? x0 : x0 / d0, k);  // final x_k
+                const double l0 = Ts[k * TRSM_SW + i], l1 = Ts[k * TRSM_SW + 64 + i];
+                const double u0 = x0 - l0 * xk;
+                x0 = (MODE != 0 && i == k) ? xk : (i > k ? u0 : x0);
+                x1 = two ? x1 - l1 * xk : x1;
+            }
+#pragma unroll 1
+            for (int k = 64; k < w; ++k) {
+                const double xk = bcast_lane(MODE == 0 ? x1 : x1 / d1, k - 64);
+                const double l1 = Ts[k * TRSM_SW + 64 + i];
+                const double u1 = x1 - l1 * xk;
+                x1 = (MODE != 0 && 64 + i == k) ? xk : (64 + i > k ? u1 : x1);
+            }
+        } else {
+#pragma unroll 1
+            for (int k = w - 1; k >= 64; --k) {
+                const double xk = bcast_lane(x1 / d1, k - 64);
+                const double u0 = Ts[k * TRSM_SW + i], u1 = Ts[k * TRSM_SW + 64 + i];
+                const double v1 = x1 - u1 * xk;
+                x1 = (64 + i == k) ? xk : (64 + i < k ? v1 : x1);
+                x0 -= u0 * xk;
+            }
+#pragma unroll 1
+            for (int k = (w < 64 ? w : 64) - 1; k >= 0; --k) {
+                const double xk = bcast_lane(x0 / d0, k);
+                const double u0 = Ts[k * TRSM_SW + i];
+                const double v0 = x0 - u0 * xk;
+                x0 = (i == k) ? xk : (i < k ? v0 : x0);
+            }
         }
-        if (i < w) b[i] = x;
+        if (i < w) b[i] = x0;
+        if (64 + i < w) b[64 + i] = x1;
     }
 }
 
-// upper, non-unit diagonal: B <- U^-1 B.
-__global__ void __launch_bounds__(TRSM_THREADS) k_trsm_upper(const double* __restrict__ T, size_t ldt, int w,
-                                                             double* __restrict__ B, size_t ldb, size_t ncols) {
-    const int i = threadIdx.x & 31;
-    const size_t hw = ((size_t)blockIdx.x * TRSM_THREADS + threadIdx.x) >> 5;
-    const size_t nhw = ((size_t)gridDim.x * TRSM_THREADS) >> 5;
-    double urow[TRSM_W];
-#pragma unroll
-    for (int k = 0; k < TRSM_W; ++k) urow[k] = (i < w && k < w && k > i) ? T[i + (size_t)k * ldt] : 0.0;
-    const double diag = i < w ? T[i + (size_t)i * ldt] : 1.0;
-    for (size_t cc = hw; cc < ncols; cc += nhw) {
-        double* b = B + cc * ldb;
-        double x = i < w ? b[i] : 0.0;
-#pragma unroll
-        for (int k = TRSM_W - 1; k >= 0; --k) {
-            const double xf = x / diag;          // final for the lane whose turn it is (k == i)
-            const double xk = __shfl(xf, k, 32);
-            if (i == k) x = xk;
-            else if (i < k) x -= urow[k] * xk;
-        }
-        if (i < w) b[i] = x;
+static int launch_check(Context* c);
+template <int MODE>
+static int launch_trsm_fused(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
+    const size_t lds_bytes = w * TRSM_SW * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_trsm_fused<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(TRSM_W * TRSM_SW * sizeof(double)));
+        attr_set = true;
     }
-}
-
-static unsigned trsm_grid(const Context* c, size_t nc) {
-    size_t want = (nc + 7) / 8;  // 8 half-waves per block, one column each per pass
-    const size_t cap = (size_t)c->num_cus * 4;
+    size_t want = (nc + 7) / 8;  // 8 waves per block, one column each per pass
+    const size_t cap = (size_t)c->num_cus * (w <= 64 ? 2 : 1);
     if (want < 1) want = 1;
-    return (unsigned)(want < cap ? want : cap);
+    const unsigned grid = (unsigned)(want < cap ? want : cap);
+    hipLaunchKernelGGL(k_trsm_fused<MODE>, dim3(grid), dim3(TRSM_THREADS), lds_bytes, c->stream, T, ldt, (int)w, B, ldb, nc);
+    return launch_check(c);
+}
+
+// Developer knob: RMHIP_LU_SKIP bitmask drops whole phases (results are then garbage) so wall-clock
+// differences attribute time to phases without a profiler: 1 column kernels, 2 dgemm, 4 trsm base
+// kernels, 8 row interchanges.
+static int lu_skip_mask() {
+    static int mask = -1;
+    if (mask < 0) {
+        const char* v = std::getenv("RMHIP_LU_SKIP");
+        mask = v ? std::atoi(v) : 0;
+    }
+    return mask;
+}
+static int lu_dgemm(Context* c, size_t m, size_t n, size_t k, double alpha, const double* A, size_t lda, const double* B,
+                    size_t ldb, double beta, double* C, size_t ldc) {
+    if (lu_skip_mask() & 2) return RMHIP_OK;
+    static long kmin = -1, mmax = -1;
+    if (kmin < 0) {
+        const char* v = std::getenv("RMHIP_LU_SKIP_K_BELOW");
+        kmin = v ? std::atol(v) : 0;
+        v = std::getenv("RMHIP_LU_SKIP_M_BELOW");
+        mmax = v ? std::atol(v) : 0;
+    }
+    if ((long)k < kmin || (long)m < mmax) return RMHIP_OK;
+    return launch_dgemm(c, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
 }
 
 static int launch_check(Context* c) {
@@ -327,37 +390,36 @@ static int launch_check(Context* c) {
     return RMHIP_OK;
 }
 
+// split point of a triangular solve wider than TRSM_W: whole base blocks on the left
+static size_t trsm_split(size_t w) {
+    size_t h = ((w / 2 + TRSM_W - 1) / TRSM_W) * TRSM_W;
+    if (h >= w) h = w / 2;
+    return h;
+}
+
 // B[w x nc] <- L^-1 B with L = unit-lower part of T[w x w]; recursive halving, dgemm in between.
 static int trsm_lower_rec(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc,
                           bool unit = true) {
     if (w == 0 || nc == 0) return RMHIP_OK;
     if (w <= (size_t)TRSM_W) {
-        if (unit)
-            hipLaunchKernelGGL(k_trsm_lower<true>, dim3(trsm_grid(c, nc)), dim3(TRSM_THREADS), 0, c->stream, T, ldt, (int)w,
-                               B, ldb, nc);
-        else
-            hipLaunchKernelGGL(k_trsm_lower<false>, dim3(trsm_grid(c, nc)), dim3(TRSM_THREADS), 0, c->stream, T, ldt, (int)w,
-                               B, ldb, nc);
-        return launch_check(c);
+        if (lu_skip_mask() & 4) return RMHIP_OK;
+        return unit ? launch_trsm_fused<0>(c, T, ldt, w, B, ldb, nc) : launch_trsm_fused<1>(c, T, ldt, w, B, ldb, nc);
     }
-    size_t h = ((w / 2 + 15) / 16) * 16;
-    if (h >= w) h = w / 2;
+    const size_t h = trsm_split(w);
     RMHIP_TRY(trsm_lower_rec(c, T, ldt, h, B, ldb, nc, unit));
-    RMHIP_TRY(launch_dgemm(c, w - h, nc, h, -1.0, T + h, ldt, B, ldb, 1.0, B + h, ldb));
+    RMHIP_TRY(lu_dgemm(c, w - h, nc, h, -1.0, T + h, ldt, B, ldb, 1.0, B + h, ldb));
     return trsm_lower_rec(c, T + h + h * ldt, ldt, w - h, B + h, ldb, nc, unit);
 }
 
 static int trsm_upper_rec(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
     if (w == 0 || nc == 0) return RMHIP_OK;
     if (w <= (size_t)TRSM_W) {
-        hipLaunchKernelGGL(k_trsm_upper, dim3(trsm_grid(c, nc)), dim3(TRSM_THREADS), 0, c->stream, T, ldt, (int)w, B,
-                           ldb, nc);
-        return launch_check(c);
+        if (lu_skip_mask() & 4) return RMHIP_OK;
+        return launch_trsm_fused<2>(c, T, ldt, w, B, ldb, nc);
     }
-    size_t h = ((w / 2 + 15) / 16) * 16;
-    if (h >= w) h = w / 2;
+    const size_t h = trsm_split(w);
     RMHIP_TRY(trsm_upper_rec(c, T + h + h * ldt, ldt, w - h, B + h, ldb, nc));
-    RMHIP_TRY(launch_dgemm(c, h, nc, w - h, -1.0, T + h * ldt, ldt, B + h, ldb, 1.0, B, ldb));
+    RMHIP_TRY(lu_dgemm(c, h, nc, w - h, -1.0, T + h * ldt, ldt, B + h, ldb, 1.0, B, ldb));
     return trsm_upper_rec(c, T, ldt, h, B, ldb, nc);
 }
 
@@ -372,7 +434,7 @@ static int laswp(LuState& s, size_t c0, size_t c1, size_t k0, size_t k1) {
             p1 = (int)i + 1;
         }
     }
-    if (p0 < 0) return RMHIP_OK;
+    if (p0 < 0 || (lu_skip_mask() & 8)) return RMHIP_OK;
     const size_t ncols = c1 - c0;
     hipLaunchKernelGGL(k_laswp_lists, dim3((unsigned)((ncols + LASWP_COLS - 1) / LASWP_COLS)), dim3(2 * PLIST), 0,
                        s.c->stream, s.A, s.lda, c0, c1, s.plist, p0, p1);
@@ -391,7 +453,7 @@ static int getrf_rec(LuState& s, size_t j0, size_t w) {
         hipLaunchKernelGGL(k_lu_col, dim3((unsigned)nb), dim3(PANEL_THREADS), 0, s.c->stream, s.A, s.lda, s.rows, (int)j0,
                            (int)j0 - 1, (int)c1, 1, (int)nb, s.pos_of, s.row_at, s.prow, s.ipiv, s.info, s.cand_abs, s.cand_pos, s.cand_row);
         RMHIP_TRY(launch_check(s.c));
-        for (size_t k = j0; k < c1; ++k) {
+        for (size_t k = j0; k < c1 && !(lu_skip_mask() & 1); ++k) {
             hipLaunchKernelGGL(k_lu_col, dim3((unsigned)nb), dim3(PANEL_THREADS), 0, s.c->stream, s.A, s.lda, s.rows,
                                (int)j0, (int)k, (int)c1, 0, (int)nb, s.pos_of, s.row_at, s.prow, s.ipiv, s.info,
                                s.cand_abs, s.cand_pos, s.cand_row);
@@ -416,7 +478,7 @@ static int getrf_rec(LuState& s, size_t j0, size_t w) {
     if (j0 + h < s.rows) {
         double* A21 = s.A + (j0 + h) + j0 * s.lda;
         double* A22 = s.A + (j0 + h) + (j0 + h) * s.lda;
-        RMHIP_TRY(launch_dgemm(s.c, s.rows - j0 - h, w - h, h, -1.0, A21, s.lda, A12, s.lda, 1.0, A22, s.lda));
+        RMHIP_TRY(lu_dgemm(s.c, s.rows - j0 - h, w - h, h, -1.0, A21, s.lda, A12, s.lda, 1.0, A22, s.lda));
         RMHIP_TRY(getrf_rec(s, j0 + h, w - h));
         const size_t k1 = (j0 + w <= s.rows) ? (j0 + w) : s.rows;
         RMHIP_TRY(laswp(s, j0, j0 + h, j0 + h, k1));
@@ -448,7 +510,7 @@ static int update_columns(LuState& s, size_t j, size_t w, size_t c0, size_t c1) 
     if (j + w < s.rows) {
         double* A21 = s.A + (j + w) + j * s.lda;
         double* A22 = s.A + (j + w) + c0 * s.lda;
-        RMHIP_TRY(launch_dgemm(s.c, s.rows - j - w, c1 - c0, w, -1.0, A21, s.lda, A12, s.lda, 1.0, A22, s.lda));
+        RMHIP_TRY(lu_dgemm(s.c, s.rows - j - w, c1 - c0, w, -1.0, A21, s.lda, A12, s.lda, 1.0, A22, s.lda));
     }
     return RMHIP_OK;
 }
