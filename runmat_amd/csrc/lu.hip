@@ -38,6 +38,14 @@ struct LuState {
     double* cand_abs; // device: [2][MAX_PANEL_BLOCKS] per-block arg-max candidates (double buffered by column parity)
     int* cand_pos;    //         position of the candidate row
     int* cand_row;    //         physical row of the candidate
+    // persistent panel kernel (k_lu_panel): inter-block exchange area
+    int* xerr;            // device: set when a bounded spin expired (blocks not co-resident)
+    unsigned long long* xa;  // device [2][PK_MAXB]: candidate |a| records (see k_lu_panel)
+    unsigned long long* xb;  // device [2][PK_MAXB]: candidate position / thread records
+    double* xvals;        // device [2][PK_MAXB][BASE_W]: candidate rows' panel values
+    unsigned xbase;       // host: panel columns factored so far (exchange step counter)
+    bool persistent;      // use k_lu_panel for base panels
+    unsigned long long* xdbg;  // device [16] phase ticks (RMHIP_LU_PANEL_DEBUG=1) or nullptr
 };
 
 static constexpr int MAX_PANEL_BLOCKS = 1024;  // 64 rows per block => up to 65536 rows per panel
@@ -204,6 +212,256 @@ __global__ void __launch_bounds__(PANEL_THREADS) k_lu_col(double* __restrict__ A
         cand_pos[slot] = bpos;
         cand_row[slot] = brow;
     }
+}
+
+// ---- base panel, persistent variant: ONE launch per panel ---------------------------------------------
+// The per-column kernel above pays a launch gap, a cold instruction fetch and two or three dependent
+// trips to memory per column (~6.9 us measured, 113 ms of the 219 ms at n = 16384).  Here the whole
+// panel (<= 64 columns) is factored by one grid of co-resident workgroups that keep their rows in LDS
+// and meet once per column in a software grid barrier:
+//   * block b owns rows j0 + b*PK_ROWS ..; thread t keeps its row's panel values in S[c][t] (LDS).
+//   * per column: block arg-max -> wave 0 publishes the block's candidate (|a|, position, row) AND that
+//     row's remaining panel values -> arrival counter -> wave 0 of every block folds the P candidates
+//     and fetches the winner's values -> every thread eliminates.  One exchange per column.
+//   * every cross-block access is a relaxed agent-scope atomic (sc1 loads/stores: coherent across the
+//     eight XCD L2s); scripts/micro/grid_barrier.hip measures the whole exchange at 1.3-1.6 us for
+//     32 blocks, whether or not they share an XCD.
+//   * spins are bounded: if the blocks are not co-resident (device shared with another context) the
+//     kernel sets *xerr and the factorisation fails loudly instead of hanging.
+// Pivot rule, tie-break, singular cut-off and the lazy-pivoting bookkeeping are those of k_lu_col.
+static constexpr int PK_ROWS = 256;              // rows per block
+static constexpr int PK_Q = 4;                   // threads per row (each takes every PK_Q-th column of the update)
+static constexpr int PK_THREADS = PK_ROWS * PK_Q;
+static constexpr int PK_MAXB = 256;              // at most one block per CU
+static constexpr int PK_SPIN_LIMIT = 400000;
+typedef unsigned long long pk_u64;
+
+// ---- wave reductions on the DPP network (a __shfl_down tree is ds_bpermute based: ~0.4 us per
+// 3-value arg-max, measured; these are a dozen VALU instructions).  Result is wave-uniform.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ pk_u64 dpp_u64(pk_u64 ident, pk_u64 v) {
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)ident, (int)(unsigned)v, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(ident >> 32), (int)(unsigned)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    return ((pk_u64)(unsigned)hi << 32) | (pk_u64)(unsigned)lo;
+}
+__device__ __forceinline__ pk_u64 umax64(pk_u64 a, pk_u64 b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned umin32(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ pk_u64 wave_max_u64(pk_u64 v) {
+    v = umax64(v, dpp_u64<0x111, 0xf>(0, v));  // row_shr:1
+    v = umax64(v, dpp_u64<0x112, 0xf>(0, v));  // row_shr:2
+    v = umax64(v, dpp_u64<0x114, 0xf>(0, v));  // row_shr:4
+    v = umax64(v, dpp_u64<0x118, 0xf>(0, v));  // row_shr:8  -> lane 15 of every row holds the row maximum
+    v = umax64(v, dpp_u64<0x142, 0xa>(0, v));  // row_bcast:15 into rows 1 and 3
+    v = umax64(v, dpp_u64<0x143, 0xc>(0, v));  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the maximum
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((pk_u64)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    v = umin32(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false));
+    v = umin32(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false));
+    v = umin32(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false));
+    v = umin32(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xf, 0xf, false));
+    v = umin32(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xa, 0xf, false));
+    v = umin32(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xc, 0xf, false));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// arg-max over the wave by (key descending, pos ascending); key == 0 never wins.  Returns the
+// winning lane (wave-uniform) or -1; *key_out / *pos_out receive the winning pair.
+__device__ __forceinline__ int wave_argmax(pk_u64 key, unsigned pos, pk_u64* key_out, unsigned* pos_out) {
+    const pk_u64 m = wave_max_u64(key);
+    const unsigned pm = wave_min_u32((key == m && m != 0) ? pos : 0xffffffffu);
+    *key_out = m;
+    *pos_out = pm;
+    if (m == 0) return -1;
+    const pk_u64 hit = __ballot(key == m && pos == pm);
+    return (int)__builtin_ctzll(hit);
+}
+
+// Exchange records (all 8-byte relaxed agent-scope atomics): step `seq` (counted over the whole
+// factorisation) uses slot parity seq & 1 and the freshness bit ((seq >> 1) & 1) ^ 1 in bit 63 of both
+// words, so consecutive uses of a slot always flip the bit and a zero-initialised slot is stale.
+//   word A: |a| bit pattern (sign bit is free)      word B: position | thread-in-block << 32
+__global__ void __launch_bounds__(PK_THREADS) k_lu_panel(double* __restrict__ A, size_t lda, size_t rows, int j0, int w,
+                                                         int nblocks, unsigned seq0, int* xerr, pk_u64* xa, pk_u64* xb,
+                                                         double* xvals, int* __restrict__ pos_of, int* __restrict__ prow_arr,
+                                                         int* __restrict__ ipiv, int* __restrict__ info, pk_u64* dbg) {
+    extern __shared__ double S[];  // [BASE_W][PK_ROWS] panel values, then s_prow[BASE_W]
+    double* s_prow = S + BASE_W * PK_ROWS;
+    __shared__ pk_u64 r_key[PK_ROWS / 64];
+    __shared__ unsigned r_pos[PK_ROWS / 64];
+    __shared__ int r_t[PK_ROWS / 64];
+    __shared__ int s_ctl[4];  // pivot row, pivot position, skip, error
+    // developer instrumentation (RMHIP_LU_PANEL_DEBUG=1): 100 MHz wall-clock ticks per phase, block 0 thread 0
+    pk_u64 tk = 0;
+#define PK_TICK(i)                                                   \
+    if (dbg && blockIdx.x == 0 && threadIdx.x == 0) {                \
+        const pk_u64 now_ = wall_clock64();                          \
+        dbg[i] += now_ - tk;                                         \
+        tk = now_;                                                   \
+    }
+    if (dbg && blockIdx.x == 0 && threadIdx.x == 0) tk = wall_clock64();
+    const int tid = threadIdx.x;
+    const int t = tid & (PK_ROWS - 1), q = tid / PK_ROWS;  // row slot, column phase
+    const int lane = tid & 63, wv = tid >> 6;
+    const int blk = blockIdx.x;
+    const size_t r = (size_t)j0 + (size_t)blk * PK_ROWS + t;
+    const bool in_rows = r < rows;
+    int pos = in_rows ? (int)r : -1;
+    for (int c = q; c < w; c += PK_Q) S[c * PK_ROWS + t] = in_rows ? A[r + (size_t)(j0 + c) * lda] : 0.0;
+    if (tid == 0) s_ctl[3] = 0;
+    __syncthreads();
+    PK_TICK(0)  // panel load
+
+    for (int k = 0; k < w; ++k) {
+        const int kabs = j0 + k;
+        const unsigned seq = seq0 + (unsigned)k;
+        const int par = (int)(seq & 1u);
+        const pk_u64 fresh = (pk_u64)(((seq >> 1) & 1u) ^ 1u) << 63;
+        const double akk = S[k * PK_ROWS + t];  // every column phase keeps its own copy (the q == 0 thread overwrites it)
+        // ---- block candidate for column k (waves of column phase 0)
+        if (q == 0) {
+            pk_u64 key = 0;
+            if (pos >= 0) {
+                const double a = fabs(akk);
+                if (a > 0.0) key = (pk_u64)__double_as_longlong(a);  // NaN or zero never wins (host_lu.rs: `abs > pivot_abs`)
+            }
+            pk_u64 wk;
+            unsigned wp;
+            const int wl = wave_argmax(key, (unsigned)pos, &wk, &wp);
+            if (lane == 0) {
+                r_key[wv] = wk;
+                r_pos[wv] = wp;
+                r_t[wv] = wl < 0 ? 0 : wv * 64 + wl;
+            }
+        }
+        __syncthreads();
+        PK_TICK(1)  // block arg-max + barrier
+        if (wv == 0) {
+            pk_u64 bk = r_key[0];
+            unsigned bp = r_pos[0];
+            int bt = r_t[0];
+#pragma unroll
+            for (int i = 1; i < PK_ROWS / 64; ++i)
+                if (r_key[i] > bk || (r_key[i] == bk && bk != 0 && r_pos[i] < bp)) {
+                    bk = r_key[i];
+                    bp = r_pos[i];
+                    bt = r_t[i];
+                }
+            // ---- publish the candidate row's panel values, wait for the acknowledgement, then the record
+            const int slot = par * PK_MAXB + blk;
+            if (lane >= k && lane < w)
+                __hip_atomic_store(&xvals[(size_t)slot * BASE_W + lane], S[lane * PK_ROWS + bt], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt: this wave's stores are acknowledged
+            if (lane == 0) {
+                __hip_atomic_store(&xa[slot], bk | fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&xb[slot], (pk_u64)bp | ((pk_u64)(unsigned)bt << 32) | fresh, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            PK_TICK(2)  // publish
+            // ---- poll every block's record until all carry this step's freshness bit, folding as they arrive
+            pk_u64 gk = 0;
+            unsigned gp = 0xffffffffu;
+            int gb = -1, gt = 0, bad = 0;
+            for (int b = lane; b < nblocks; b += 64) {
+                pk_u64 wa, wb;
+                int spins = 0;
+                for (;;) {
+                    wa = __hip_atomic_load(&xa[par * PK_MAXB + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    wb = __hip_atomic_load(&xb[par * PK_MAXB + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (((wa ^ fresh) >> 63) == 0 && ((wb ^ fresh) >> 63) == 0) break;
+                    if (++spins > PK_SPIN_LIMIT || __hip_atomic_load(xerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        bad = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const pk_u64 ck = wa & ~((pk_u64)1 << 63);
+                const unsigned cp = (unsigned)wb;
+                if (ck > gk || (ck == gk && gk != 0 && cp < gp)) {
+                    gk = ck;
+                    gp = cp;
+                    gb = b;
+                    gt = (int)((wb >> 32) & 0xffffu);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            bad = __any(bad) ? 1 : 0;
+            if (bad) {
+                if (lane == 0) {
+                    __hip_atomic_store(xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_ctl[3] = 1;
+                }
+            } else {
+                pk_u64 mk;
+                unsigned mp;
+                const int wl = wave_argmax(gk, gp, &mk, &mp);
+                PK_TICK(3)  // wait + fold
+                int grow = -1;
+                if (wl >= 0) {
+                    const int wb_ = __builtin_amdgcn_readlane(gb, wl);
+                    const int wt_ = __builtin_amdgcn_readlane(gt, wl);
+                    grow = j0 + wb_ * PK_ROWS + wt_;
+                    if (lane >= k && lane < w)
+                        s_prow[lane] = __hip_atomic_load(&xvals[(size_t)(par * PK_MAXB + wb_) * BASE_W + lane], __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (lane == 0) {
+                    s_ctl[0] = grow;
+                    s_ctl[1] = (int)mp;
+                    s_ctl[2] = (__longlong_as_double((long long)mk) <= LU_EPS) ? 1 : 0;
+                }
+                PK_TICK(4)  // winner's row values
+            }
+        }
+        __syncthreads();
+        PK_TICK(5)  // barrier
+        if (s_ctl[3]) return;
+        // ---- eliminate column k
+        const int prow = s_ctl[0], ppos = s_ctl[1], skip = s_ctl[2];
+        if (prow < 0) {
+            // all-zero (or NaN-only) column: pivot_row stays k (host_lu.rs:38); its occupant retires as row k of U
+            if (pos == kabs) {
+                pos = -1;
+                if (q == 0) {
+                    ipiv[kabs] = kabs;
+                    prow_arr[kabs] = (int)r;
+                    atomicAdd(info, 1);
+                }
+            }
+        } else if ((int)r == prow && pos >= 0) {
+            pos = -1;  // retires as row k of U
+            if (q == 0) {
+                ipiv[kabs] = ppos;
+                prow_arr[kabs] = prow;
+                if (skip) atomicAdd(info, 1);
+            }
+        } else if (pos == kabs) {
+            pos = ppos;  // the old occupant of position k moves to the pivot's position
+        }
+        if (pos >= 0) {
+            if (skip || prow < 0) {
+                if (q == 0) S[k * PK_ROWS + t] = 0.0;
+            } else {
+                const double factor = akk / s_prow[k];
+                if (q == 0) S[k * PK_ROWS + t] = factor;
+#pragma unroll 4
+                for (int c = k + 1 + q; c < w; c += PK_Q) {
+                    const double prod = factor * s_prow[c];
+                    S[c * PK_ROWS + t] = S[c * PK_ROWS + t] - prod;
+                }
+            }
+        }
+        PK_TICK(6)  // elimination
+    }
+    __syncthreads();
+    if (in_rows) {
+        for (int c = q; c < w; c += PK_Q) A[r + (size_t)(j0 + c) * lda] = S[c * PK_ROWS + t];
+        if (q == 0) pos_of[r] = pos;
+    }
+    PK_TICK(7)  // write back
+#undef PK_TICK
 }
 
 static constexpr int PLIST = 2 * BASE_W;  // per base panel: BASE_W pivot rows brought to the top + <= BASE_W displaced rows
@@ -446,6 +704,21 @@ static int getrf_rec(LuState& s, size_t j0, size_t w) {
     if (w == 0 || j0 >= s.rows) return RMHIP_OK;
     if (w <= (size_t)BASE_W) {
         const size_t c1 = j0 + w;  // j0 + w <= min(rows, cols) always holds (see lu_factor_device)
+        const size_t nbp = (s.rows - j0 + PK_ROWS - 1) / PK_ROWS;
+        if (s.persistent && nbp <= (size_t)PK_MAXB && nbp <= (size_t)s.c->num_cus && !(lu_skip_mask() & 1)) {
+            const size_t lds_bytes = (size_t)(BASE_W * PK_ROWS + BASE_W) * sizeof(double);
+            hipLaunchKernelGGL(k_lu_panel, dim3((unsigned)nbp), dim3(PK_THREADS), lds_bytes, s.c->stream, s.A, s.lda, s.rows,
+                               (int)j0, (int)w, (int)nbp, s.xbase, s.xerr, s.xa, s.xb, s.xvals, s.pos_of, s.prow, s.ipiv,
+                               s.info, s.xdbg);
+            RMHIP_TRY(launch_check(s.c));
+            s.xbase += (unsigned)w;
+            const size_t pid = s.panel_start->size();
+            s.panel_start->push_back(j0);
+            hipLaunchKernelGGL(k_build_plist, dim3(1), dim3(PLIST), 0, s.c->stream, (int)j0, (int)c1, s.pos_of, s.prow,
+                               s.plist + pid * PLIST);
+            RMHIP_TRY(launch_check(s.c));
+            return laswp(s, j0, c1, j0, c1);
+        }
         const size_t nb = (s.rows - j0 + PANEL_ROWS - 1) / PANEL_ROWS;  // one block per PANEL_ROWS rows
         if (nb > (size_t)MAX_PANEL_BLOCKS)
             return fail(RMHIP_ERR_UNSUPPORTED, "lu: more than %d rows per panel not supported yet", MAX_PANEL_BLOCKS * PANEL_ROWS);
@@ -586,7 +859,11 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     const size_t off_abs = off_plist + max_panels * PLIST * sizeof(int2);
     const size_t off_pos = off_abs + sizeof(double) * 2 * MAX_PANEL_BLOCKS;
     const size_t off_row = off_pos + sizeof(int) * 2 * MAX_PANEL_BLOCKS;
-    const size_t total = off_row + sizeof(int) * 2 * MAX_PANEL_BLOCKS;
+    const size_t off_xvals = (off_row + sizeof(int) * 2 * MAX_PANEL_BLOCKS + 15) & ~(size_t)15;
+    const size_t off_xa = off_xvals + sizeof(double) * 2 * PK_MAXB * BASE_W;
+    const size_t off_xb = off_xa + sizeof(unsigned long long) * 2 * PK_MAXB;
+    const size_t off_xctl = off_xb + sizeof(unsigned long long) * 2 * PK_MAXB;
+    const size_t total = off_xctl + 64 + 16 * sizeof(unsigned long long);
     char* blk = nullptr;
     RMHIP_HIP_CHECK(hipMalloc((void**)&blk, total));
     int* ipiv = (int*)blk;
@@ -599,7 +876,22 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     std::vector<size_t> panel_start;
     panel_start.reserve(max_panels);
     LuState s{c, A, rows, cols, lda, ipiv, info, (int*)(blk + off_posof), (int*)(blk + off_rowat), (int*)(blk + off_prow),
-              (int2*)(blk + off_plist), &panel_start, (double*)(blk + off_abs), (int*)(blk + off_pos), (int*)(blk + off_row)};
+              (int2*)(blk + off_plist), &panel_start, (double*)(blk + off_abs), (int*)(blk + off_pos), (int*)(blk + off_row),
+              (int*)(blk + off_xctl + 16), (unsigned long long*)(blk + off_xa), (unsigned long long*)(blk + off_xb),
+              (double*)(blk + off_xvals), 0u, true, nullptr};
+    {
+        // persistent panels need >64 KiB of dynamic LDS and all their blocks co-resident (one per CU)
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)k_lu_panel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)((BASE_W * PK_ROWS + BASE_W) * sizeof(double)));
+            attr_set = true;
+        }
+        const char* pm = std::getenv("RMHIP_LU_PANEL");  // "columns" selects the one-launch-per-column kernels
+        if (pm && pm[0] == 'c') s.persistent = false;
+        const char* dbgenv = std::getenv("RMHIP_LU_PANEL_DEBUG");
+        if (dbgenv && dbgenv[0] == '1') s.xdbg = (unsigned long long*)(blk + off_xctl + 64);
+    }
     size_t nb = 512;
     if (const char* v = std::getenv("RMHIP_LU_NB")) nb = (size_t)std::atoll(v);
     nb = nb < 64 ? 64 : (nb / 64) * 64;
@@ -608,6 +900,7 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     // 512-thread column kernels, which then wait for a dgemm block to retire.
     const char* la = std::getenv("RMHIP_LU_LOOKAHEAD");
     const bool blocked = kmin > nb && la && la[0] == '1';
+    if (blocked) s.persistent = false;  // a second stream's dgemm blocks would break the panels' co-residency
     int rc = blocked ? getrf_blocked(s, kmin, nb) : getrf_rec(s, 0, kmin);
     if (rc == RMHIP_OK && cols > rows && !blocked) {  // wide: finish U's right block (the blocked driver covers it)
         rc = laswp(s, rows, cols, 0, rows);
@@ -615,9 +908,23 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     }
     std::vector<int> h_ipiv(rows + 1, 0);
     if (rc == RMHIP_OK) {
+        int h_xerr = 0;
         e = hipMemcpyAsync(h_ipiv.data(), ipiv, sizeof(int) * (rows + 1), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_xerr, s.xerr, sizeof(int), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) rc = fail(RMHIP_ERR_HIP, "lu: reading pivots: %s", hipGetErrorString(e));
+        else if (h_xerr)
+            rc = fail(RMHIP_ERR_HIP, "lu: panel workgroups were not co-resident (device shared?); set RMHIP_LU_PANEL=columns");
+        if (s.xdbg) {
+            unsigned long long h[16];
+            if (hipMemcpy(h, s.xdbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+                static const char* names[8] = {"load", "argmax+sync", "publish", "wait+fold", "winner vals", "sync",
+                                               "eliminate", "write back"};
+                for (int i = 0; i < 8; ++i)
+                    std::fprintf(stderr, "[lu panel] %-12s %10.1f us total  %7.3f us/column\n", names[i], h[i] * 0.01,
+                                 kmin ? h[i] * 0.01 / (double)kmin : 0.0);
+            }
+        }
     } else {
         (void)hipStreamSynchronize(c->stream);
     }
