@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(PANEL_THREADS) k_lu_col(double* __restrict__ A
 //   * spins are bounded: if the blocks are not co-resident (device shared with another context) the
 //     kernel sets *xerr and the factorisation fails loudly instead of hanging.
 // Pivot rule, tie-break, singular cut-off and the lazy-pivoting bookkeeping are those of k_lu_col.
-static constexpr int PK_ROWS = 256;              // rows per block
+static constexpr int PK_ROWS = 256;              // rows per block (128 measured no faster: the exchange grows with the block count)
 static constexpr int PK_Q = 4;                   // threads per row (each takes every PK_Q-th column of the update)
 static constexpr int PK_THREADS = PK_ROWS * PK_Q;
 static constexpr int PK_MAXB = 256;              // at most one block per CU
@@ -293,14 +293,16 @@ __global__ void __launch_bounds__(PK_THREADS) k_lu_panel(double* __restrict__ A,
     __shared__ int r_t[PK_ROWS / 64];
     __shared__ int s_ctl[4];  // pivot row, pivot position, skip, error
     // developer instrumentation (RMHIP_LU_PANEL_DEBUG=1): 100 MHz wall-clock ticks per phase, block 0 thread 0
-    pk_u64 tk = 0;
+    // (ticks accumulate in registers: a global read-modify-write per tick would itself cost a memory round trip)
+    pk_u64 tk = 0, tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool dbg_on = dbg && blockIdx.x == 0 && threadIdx.x == 0;
 #define PK_TICK(i)                                                   \
-    if (dbg && blockIdx.x == 0 && threadIdx.x == 0) {                \
+    if (dbg_on) {                                                    \
         const pk_u64 now_ = wall_clock64();                          \
-        dbg[i] += now_ - tk;                                         \
+        tacc[i] += now_ - tk;                                        \
         tk = now_;                                                   \
     }
-    if (dbg && blockIdx.x == 0 && threadIdx.x == 0) tk = wall_clock64();
+    if (dbg_on) tk = wall_clock64();
     const int tid = threadIdx.x;
     const int t = tid & (PK_ROWS - 1), q = tid / PK_ROWS;  // row slot, column phase
     const int lane = tid & 63, wv = tid >> 6;
@@ -461,6 +463,8 @@ __global__ void __launch_bounds__(PK_THREADS) k_lu_panel(double* __restrict__ A,
         if (q == 0) pos_of[r] = pos;
     }
     PK_TICK(7)  // write back
+    if (dbg_on)
+        for (int i = 0; i < 8; ++i) dbg[i] += tacc[i];
 #undef PK_TICK
 }
 
