@@ -531,7 +531,6 @@ __global__ void __launch_bounds__(2 * PLIST) k_laswp_lists(double* __restrict__ 
 //   MODE 0: lower, implicit unit diagonal (LU factors)        B <- L^-1 B
 //   MODE 1: lower, stored diagonal (`linsolve` LT, linsolve.rs:769-800)
 //   MODE 2: upper, stored diagonal                             B <- U^-1 B
-static constexpr int TRSM_THREADS = 512;
 static constexpr int TRSM_SW = TRSM_W + 1;  // LDS row stride (doubles)
 
 // value of lane `lane` (wave-uniform index) in every lane: two v_readlane_b32, no LDS round trip
@@ -541,13 +540,30 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-template <int MODE>
+// TRSM_NC = right-hand sides a wave solves together: 4 when there are more columns than waves on the
+// chip (independent dependency chains interleave), 1 otherwise (dead column slots would cost issue cycles).
+// TRSM_THREADS: 256 (one wave per SIMD: the substitution is VALU-issue bound) for few columns, 512 for many.
+template <int MODE, int TRSM_NC, int TRSM_THREADS>
 __global__ void __launch_bounds__(TRSM_THREADS) k_trsm_fused(const double* __restrict__ T, size_t ldt, int w,
                                                              double* __restrict__ B, size_t ldb, size_t ncols) {
     extern __shared__ double Ts[];  // [w][TRSM_SW]
-    for (int idx = threadIdx.x; idx < w * TRSM_W; idx += TRSM_THREADS) {
-        const int r = idx & (TRSM_W - 1), k = idx / TRSM_W;
-        Ts[k * TRSM_SW + r] = r < w ? T[r + (size_t)k * ldt] : 0.0;
+    // stage the needed triangle: eight independent loads in flight per thread before the first LDS write
+    // (a rolled load->write loop serialises on memory latency: 32 round trips, ~30 us per call, measured)
+    for (int base = 0; base < w * TRSM_W; base += 8 * TRSM_THREADS) {
+        double stage[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * TRSM_THREADS + (int)threadIdx.x;
+            const int r = idx & (TRSM_W - 1), k = idx / TRSM_W;
+            const bool need = k < w && r < w && (MODE == 0 ? r > k : (MODE == 1 ? r >= k : r <= k));
+            stage[u] = need ? T[r + (size_t)k * ldt] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * TRSM_THREADS + (int)threadIdx.x;
+            const int r = idx & (TRSM_W - 1), k = idx / TRSM_W;
+            if (k < w) Ts[k * TRSM_SW + r] = stage[u];
+        }
     }
     __syncthreads();
     const int i = threadIdx.x & 63;
@@ -559,66 +575,149 @@ __global__ void __launch_bounds__(TRSM_THREADS) k_trsm_fused(const double* __res
         if (i < w) d0 = Ts[i * TRSM_SW + i];
         if (64 + i < w) d1 = Ts[(64 + i) * TRSM_SW + 64 + i];
     }
-    for (size_t cc = wave; cc < ncols; cc += nwaves) {
-        double* b = B + cc * ldb;
-        double x0 = i < w ? b[i] : 0.0;
-        double x1 = 64 + i < w ? b[64 + i] : 0.0;
-        // selects, not branches and not zero multipliers: 0 * inf must not poison finished lanes
+    // x / d sits on the dependency chain of every step (an fp64 division is ~30 dependent instructions).
+    // When every diagonal entry has a finite, normal reciprocal the chain uses x * (1/d) instead (<= 1 ulp
+    // from the quotient, far inside the solve's error bound); otherwise the exact division is kept.
+    const double r0 = 1.0 / d0, r1 = 1.0 / d1;
+    const bool recip_ok = MODE != 0 && !__any(!(fabs(r0) < 1.0e300 && fabs(r0) > 1.0e-300 && fabs(r1) < 1.0e300 && fabs(r1) > 1.0e-300));
+    auto scale = [=](double x, double d, double r) { return recip_ok ? x * r : x / d; };
+    for (size_t c0 = wave * TRSM_NC; c0 < ncols; c0 += nwaves * TRSM_NC) {
+        double x0[TRSM_NC], x1[TRSM_NC];
+#pragma unroll
+        for (int j = 0; j < TRSM_NC; ++j) {
+            const bool live = c0 + j < ncols;
+            x0[j] = (live && i < w) ? B[(c0 + j) * ldb + i] : 0.0;
+            x1[j] = (live && 64 + i < w) ? B[(c0 + j) * ldb + 64 + i] : 0.0;
+        }
+        // selects, not branches and not zero multipliers: 0 * inf must not poison finished lanes.
+        // Four steps per trip with their LDS operands fetched up front (a rolled loop exposes the LDS
+        // latency in every step: ~0.2 us per step, measured).
         if (MODE != 2) {
             const int k0end = w < 64 ? w : 64;
 #pragma unroll 1
-            for (int k = 0; k < k0end; ++k) {
-                const double xk = bcast_lane(MODE == 0 ? x0 : x0 / d0, k);  // final x_k
-                const double l0 = Ts[k * TRSM_SW + i], l1 = Ts[k * TRSM_SW + 64 + i];
-                const double u0 = x0 - l0 * xk;
-                x0 = (MODE != 0 && i == k) ? xk : (i > k ? u0 : x0);
-                x1 = two ? x1 - l1 * xk : x1;
+            for (int kb = 0; kb < k0end; kb += 4) {
+                double l0[4], l1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb + u < w ? kb + u : w - 1;
+                    l0[u] = Ts[k * TRSM_SW + i];
+                    l1[u] = Ts[k * TRSM_SW + 64 + i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb + u;
+                    if (k < k0end) {
+#pragma unroll
+                        for (int j = 0; j < TRSM_NC; ++j) {
+                            const double xk = bcast_lane(MODE == 0 ? x0[j] : scale(x0[j], d0, r0), k);  // final x_k
+                            const double u0 = x0[j] - l0[u] * xk;
+                            x0[j] = (MODE != 0 && i == k) ? xk : (i > k ? u0 : x0[j]);
+                            x1[j] = two ? x1[j] - l1[u] * xk : x1[j];
+                        }
+                    }
+                }
             }
 #pragma unroll 1
-            for (int k = 64; k < w; ++k) {
-                const double xk = bcast_lane(MODE == 0 ? x1 : x1 / d1, k - 64);
-                const double l1 = Ts[k * TRSM_SW + 64 + i];
-                const double u1 = x1 - l1 * xk;
-                x1 = (MODE != 0 && 64 + i == k) ? xk : (64 + i > k ? u1 : x1);
+            for (int kb = 64; kb < w; kb += 4) {
+                double l1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb + u < w ? kb + u : w - 1;
+                    l1[u] = Ts[k * TRSM_SW + 64 + i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb + u;
+                    if (k < w) {
+#pragma unroll
+                        for (int j = 0; j < TRSM_NC; ++j) {
+                            const double xk = bcast_lane(MODE == 0 ? x1[j] : scale(x1[j], d1, r1), k - 64);
+                            const double u1 = x1[j] - l1[u] * xk;
+                            x1[j] = (MODE != 0 && 64 + i == k) ? xk : (64 + i > k ? u1 : x1[j]);
+                        }
+                    }
+                }
             }
         } else {
 #pragma unroll 1
-            for (int k = w - 1; k >= 64; --k) {
-                const double xk = bcast_lane(x1 / d1, k - 64);
-                const double u0 = Ts[k * TRSM_SW + i], u1 = Ts[k * TRSM_SW + 64 + i];
-                const double v1 = x1 - u1 * xk;
-                x1 = (64 + i == k) ? xk : (64 + i < k ? v1 : x1);
-                x0 -= u0 * xk;
+            for (int kb = w - 1; kb >= 64; kb -= 4) {
+                double u0[4], u1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb - u >= 64 ? kb - u : 64;
+                    u0[u] = Ts[k * TRSM_SW + i];
+                    u1[u] = Ts[k * TRSM_SW + 64 + i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb - u;
+                    if (k >= 64) {
+#pragma unroll
+                        for (int j = 0; j < TRSM_NC; ++j) {
+                            const double xk = bcast_lane(scale(x1[j], d1, r1), k - 64);
+                            const double v1 = x1[j] - u1[u] * xk;
+                            x1[j] = (64 + i == k) ? xk : (64 + i < k ? v1 : x1[j]);
+                            x0[j] -= u0[u] * xk;
+                        }
+                    }
+                }
             }
 #pragma unroll 1
-            for (int k = (w < 64 ? w : 64) - 1; k >= 0; --k) {
-                const double xk = bcast_lane(x0 / d0, k);
-                const double u0 = Ts[k * TRSM_SW + i];
-                const double v0 = x0 - u0 * xk;
-                x0 = (i == k) ? xk : (i < k ? v0 : x0);
+            for (int kb = (w < 64 ? w : 64) - 1; kb >= 0; kb -= 4) {
+                double u0[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb - u >= 0 ? kb - u : 0;
+                    u0[u] = Ts[k * TRSM_SW + i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb - u;
+                    if (k >= 0) {
+#pragma unroll
+                        for (int j = 0; j < TRSM_NC; ++j) {
+                            const double xk = bcast_lane(scale(x0[j], d0, r0), k);
+                            const double v0 = x0[j] - u0[u] * xk;
+                            x0[j] = (i == k) ? xk : (i < k ? v0 : x0[j]);
+                        }
+                    }
+                }
             }
         }
-        if (i < w) b[i] = x0;
-        if (64 + i < w) b[64 + i] = x1;
+#pragma unroll
+        for (int j = 0; j < TRSM_NC; ++j) {
+            if (c0 + j < ncols) {
+                if (i < w) B[(c0 + j) * ldb + i] = x0[j];
+                if (64 + i < w) B[(c0 + j) * ldb + 64 + i] = x1[j];
+            }
+        }
     }
 }
 
 static int launch_check(Context* c);
-template <int MODE>
-static int launch_trsm_fused(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
+template <int MODE, int NC, int TRSM_THREADS>
+static int launch_trsm_fused_nc(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
     const size_t lds_bytes = w * TRSM_SW * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_trsm_fused<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)k_trsm_fused<MODE, NC, TRSM_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(TRSM_W * TRSM_SW * sizeof(double)));
         attr_set = true;
     }
-    size_t want = (nc + 7) / 8;  // 8 waves per block, one column each per pass
+    const size_t per_block = (size_t)(TRSM_THREADS / 64) * NC;  // columns one block solves per pass
+    size_t want = (nc + per_block - 1) / per_block;
     const size_t cap = (size_t)c->num_cus * (w <= 64 ? 2 : 1);
     if (want < 1) want = 1;
     const unsigned grid = (unsigned)(want < cap ? want : cap);
-    hipLaunchKernelGGL(k_trsm_fused<MODE>, dim3(grid), dim3(TRSM_THREADS), lds_bytes, c->stream, T, ldt, (int)w, B, ldb, nc);
+    hipLaunchKernelGGL((k_trsm_fused<MODE, NC, TRSM_THREADS>), dim3(grid), dim3(TRSM_THREADS), lds_bytes, c->stream, T, ldt, (int)w, B, ldb,
+                       nc);
     return launch_check(c);
+}
+template <int MODE>
+static int launch_trsm_fused(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
+    const size_t waves_on_chip = (size_t)c->num_cus * 4;  // one wave per SIMD
+    return nc > 2 * waves_on_chip ? launch_trsm_fused_nc<MODE, 4, 512>(c, T, ldt, w, B, ldb, nc)
+                                  : launch_trsm_fused_nc<MODE, 1, 256>(c, T, ldt, w, B, ldb, nc);
 }
 
 // Developer knob: RMHIP_LU_SKIP bitmask drops whole phases (results are then garbage) so wall-clock

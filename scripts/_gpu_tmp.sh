@@ -1,1 +1,3 @@
-timeout 300 python bench.py --workload mldivide --steps 5 --warmup 2 --no-also --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['metric'], d['value'], d['ms_per_step'])"
+timeout 300 python -m pytest tests -m gpu -q -x -k "lu or mldivide or linsolve or blk or cyclic" 2>&1 | tail -3
+timeout 200 python scripts/trsm_time.py 2>&1 | grep "w=128\|w=64 "
+timeout 100 python scripts/lu_time.py 16384 2>&1 | grep "rep=1"
