@@ -96,6 +96,10 @@ struct Context {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     Telemetry tel;
 
+    // LU look-ahead (lu.hip getrf_blocked): extra dynamic LDS requested by launch_dgemm so that only ONE
+    // dgemm block fits per CU and latency-bound kernels of the other stream find room beside it
+    size_t gemm_lds_pad = 0;
+
     // ---- helpers (rmhip_core.cpp) ----
     int alloc_device(size_t numel, std::shared_ptr<Allocation>* out);
     void release_device(double* ptr, size_t bytes);

@@ -290,15 +290,18 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
     g.vec_b = ((((uintptr_t)B & 15) == 0) && (ldb % 2 == 0)) ? 1 : 0;
     if (ep) g.ep = *ep;
     else g.ep = GemmEpilogue{0, 1.0, 0.0, nullptr, nullptr, 0.0, 0.0, 0.0, nullptr};
-    const size_t lds_bytes = (size_t)(2 * A_TILE + 2 * B_TILE) * sizeof(double);
+    const size_t lds_base = (size_t)(2 * A_TILE + 2 * B_TILE) * sizeof(double);
+    const size_t lds_bytes = lds_base + c->gemm_lds_pad;
     const bool fast = (m % BM == 0) && (n % BN == 0) && (k % BK == 0) && k > 0 && (lda % 2 == 0) && (ldb % 2 == 0) &&
                       (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
     const unsigned blocks = g.tiles_m * g.tiles_n;
     static bool attr_set = false;
+    const size_t kMaxLds = 128 * 1024;  // room for the look-ahead pad
+    if (lds_bytes > kMaxLds) return fail(RMHIP_ERR_INVALID, "dgemm: LDS pad too large");
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_dgemm<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute((const void*)k_dgemm<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute((const void*)k_dgemm<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void*)k_dgemm<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+        (void)hipFuncSetAttribute((const void*)k_dgemm<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+        (void)hipFuncSetAttribute((const void*)k_dgemm<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
         attr_set = true;
     }
     if (ep)

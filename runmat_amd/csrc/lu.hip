@@ -42,10 +42,11 @@ struct LuState {
     int* xerr;            // device: set when a bounded spin expired (blocks not co-resident)
     unsigned long long* xa;  // device [2][PK_MAXB]: candidate |a| records (see k_lu_panel)
     unsigned long long* xb;  // device [2][PK_MAXB]: candidate position / thread records
-    double* xvals;        // device [2][PK_MAXB][BASE_W]: candidate rows' panel values
+    unsigned long long* xvals;  // device [2][PK_MAXB][BASE_W][2]: candidate rows' panel values (tagged half words)
     unsigned xbase;       // host: panel columns factored so far (exchange step counter)
     bool persistent;      // use k_lu_panel for base panels
     unsigned long long* xdbg;  // device [16] phase ticks (RMHIP_LU_PANEL_DEBUG=1) or nullptr
+    int panel_rows;       // rows per persistent-panel block: 256, or 128 under look-ahead
 };
 
 static constexpr int MAX_PANEL_BLOCKS = 1024;  // 64 rows per block => up to 65536 rows per panel
@@ -229,9 +230,9 @@ __global__ void __launch_bounds__(PANEL_THREADS) k_lu_col(double* __restrict__ A
 //   * spins are bounded: if the blocks are not co-resident (device shared with another context) the
 //     kernel sets *xerr and the factorisation fails loudly instead of hanging.
 // Pivot rule, tie-break, singular cut-off and the lazy-pivoting bookkeeping are those of k_lu_col.
-static constexpr int PK_ROWS = 256;              // rows per block (128 measured no faster: the exchange grows with the block count)
+// PK_ROWS (template parameter) = rows per block: 256 normally (128 is no faster alone: the exchange grows
+// with the block count), 128 under look-ahead so that a block (66 KiB of LDS) fits beside a dgemm block.
 static constexpr int PK_Q = 4;                   // threads per row (each takes every PK_Q-th column of the update)
-static constexpr int PK_THREADS = PK_ROWS * PK_Q;
 static constexpr int PK_MAXB = 256;              // at most one block per CU
 static constexpr int PK_SPIN_LIMIT = 400000;
 typedef unsigned long long pk_u64;
@@ -282,9 +283,10 @@ __device__ __forceinline__ int wave_argmax(pk_u64 key, unsigned pos, pk_u64* key
 // factorisation) uses slot parity seq & 1 and the freshness bit ((seq >> 1) & 1) ^ 1 in bit 63 of both
 // words, so consecutive uses of a slot always flip the bit and a zero-initialised slot is stale.
 //   word A: |a| bit pattern (sign bit is free)      word B: position | thread-in-block << 32
-__global__ void __launch_bounds__(PK_THREADS) k_lu_panel(double* __restrict__ A, size_t lda, size_t rows, int j0, int w,
+template <int PK_ROWS>
+__global__ void __launch_bounds__(PK_ROWS * PK_Q) k_lu_panel(double* __restrict__ A, size_t lda, size_t rows, int j0, int w,
                                                          int nblocks, unsigned seq0, int* xerr, pk_u64* xa, pk_u64* xb,
-                                                         double* xvals, int* __restrict__ pos_of, int* __restrict__ prow_arr,
+                                                         pk_u64* xvals, int* __restrict__ pos_of, int* __restrict__ prow_arr,
                                                          int* __restrict__ ipiv, int* __restrict__ info, pk_u64* dbg) {
     extern __shared__ double S[];  // [BASE_W][PK_ROWS] panel values, then s_prow[BASE_W]
     double* s_prow = S + BASE_W * PK_ROWS;
@@ -320,9 +322,13 @@ __global__ void __launch_bounds__(PK_THREADS) k_lu_panel(double* __restrict__ A,
         const unsigned seq = seq0 + (unsigned)k;
         const int par = (int)(seq & 1u);
         const pk_u64 fresh = (pk_u64)(((seq >> 1) & 1u) ^ 1u) << 63;
-        const double akk = S[k * PK_ROWS + t];  // every column phase keeps its own copy (the q == 0 thread overwrites it)
+        // Column k of row t was last written by the row's phase-0 thread during the previous elimination:
+        // that thread may read it back at once, the other phases only after the barrier below (reading it
+        // here raced with that write whenever a co-running kernel skewed the waves).
+        double akk = 0.0;
         // ---- block candidate for column k (waves of column phase 0)
         if (q == 0) {
+            akk = S[k * PK_ROWS + t];
             pk_u64 key = 0;
             if (pos >= 0) {
                 const double a = fabs(akk);
@@ -338,6 +344,7 @@ __global__ void __launch_bounds__(PK_THREADS) k_lu_panel(double* __restrict__ A,
             }
         }
         __syncthreads();
+        if (q != 0) akk = S[k * PK_ROWS + t];  // before the phase-0 thread overwrites it with the multiplier (after the next barrier)
         PK_TICK(1)  // block arg-max + barrier
         if (wv == 0) {
             pk_u64 bk = r_key[0];
@@ -350,12 +357,17 @@ __global__ void __launch_bounds__(PK_THREADS) k_lu_panel(double* __restrict__ A,
                     bp = r_pos[i];
                     bt = r_t[i];
                 }
-            // ---- publish the candidate row's panel values, wait for the acknowledgement, then the record
+            // ---- publish the candidate row's panel values and the record together.  Nothing orders these
+            // stores (a workgroup-scope release fence emits no s_waitcnt for global stores, and under the
+            // look-ahead's memory traffic they do land out of order), so every word carries the freshness
+            // bit itself: a value travels as two words (low / high half), and readers retry stale words.
             const int slot = par * PK_MAXB + blk;
-            if (lane >= k && lane < w)
-                __hip_atomic_store(&xvals[(size_t)slot * BASE_W + lane], S[lane * PK_ROWS + bt], __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt: this wave's stores are acknowledged
+            if (lane >= k && lane < w) {
+                const pk_u64 bits = (pk_u64)__double_as_longlong(S[lane * PK_ROWS + bt]);
+                pk_u64* dst = xvals + ((size_t)slot * BASE_W + lane) * 2;
+                __hip_atomic_store(dst, (bits & 0xffffffffull) | fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, (bits >> 32) | fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (lane == 0) {
                 __hip_atomic_store(&xa[slot], bk | fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&xb[slot], (pk_u64)bp | ((pk_u64)(unsigned)bt << 32) | fresh, __ATOMIC_RELAXED,
@@ -400,19 +412,37 @@ __global__ void __launch_bounds__(PK_THREADS) k_lu_panel(double* __restrict__ A,
                 unsigned mp;
                 const int wl = wave_argmax(gk, gp, &mk, &mp);
                 PK_TICK(3)  // wait + fold
-                int grow = -1;
+                int grow = -1, vbad = 0;
                 if (wl >= 0) {
                     const int wb_ = __builtin_amdgcn_readlane(gb, wl);
                     const int wt_ = __builtin_amdgcn_readlane(gt, wl);
                     grow = j0 + wb_ * PK_ROWS + wt_;
-                    if (lane >= k && lane < w)
-                        s_prow[lane] = __hip_atomic_load(&xvals[(size_t)(par * PK_MAXB + wb_) * BASE_W + lane], __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane >= k && lane < w) {
+                        const pk_u64* src = xvals + ((size_t)(par * PK_MAXB + wb_) * BASE_W + lane) * 2;
+                        pk_u64 lo, hi;
+                        int spins = 0;
+                        for (;;) {
+                            lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (((lo ^ fresh) >> 63) == 0 && ((hi ^ fresh) >> 63) == 0) break;
+                            if (++spins > PK_SPIN_LIMIT) {
+                                vbad = 1;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        s_prow[lane] = __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32)));
+                    }
                 }
+                vbad = __any(vbad) ? 1 : 0;
                 if (lane == 0) {
                     s_ctl[0] = grow;
                     s_ctl[1] = (int)mp;
                     s_ctl[2] = (__longlong_as_double((long long)mk) <= LU_EPS) ? 1 : 0;
+                    if (vbad) {
+                        __hip_atomic_store(xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_ctl[3] = 1;
+                    }
                 }
                 PK_TICK(4)  // winner's row values
             }
@@ -807,12 +837,18 @@ static int getrf_rec(LuState& s, size_t j0, size_t w) {
     if (w == 0 || j0 >= s.rows) return RMHIP_OK;
     if (w <= (size_t)BASE_W) {
         const size_t c1 = j0 + w;  // j0 + w <= min(rows, cols) always holds (see lu_factor_device)
-        const size_t nbp = (s.rows - j0 + PK_ROWS - 1) / PK_ROWS;
+        const size_t prow_ = (size_t)s.panel_rows;
+        const size_t nbp = (s.rows - j0 + prow_ - 1) / prow_;
         if (s.persistent && nbp <= (size_t)PK_MAXB && nbp <= (size_t)s.c->num_cus && !(lu_skip_mask() & 1)) {
-            const size_t lds_bytes = (size_t)(BASE_W * PK_ROWS + BASE_W) * sizeof(double);
-            hipLaunchKernelGGL(k_lu_panel, dim3((unsigned)nbp), dim3(PK_THREADS), lds_bytes, s.c->stream, s.A, s.lda, s.rows,
-                               (int)j0, (int)w, (int)nbp, s.xbase, s.xerr, s.xa, s.xb, s.xvals, s.pos_of, s.prow, s.ipiv,
-                               s.info, s.xdbg);
+            const size_t lds_bytes = (size_t)(BASE_W * prow_ + BASE_W) * sizeof(double);
+            if (s.panel_rows == 256)
+                hipLaunchKernelGGL(k_lu_panel<256>, dim3((unsigned)nbp), dim3(256 * PK_Q), lds_bytes, s.c->stream, s.A, s.lda,
+                                   s.rows, (int)j0, (int)w, (int)nbp, s.xbase, s.xerr, s.xa, s.xb, s.xvals, s.pos_of, s.prow,
+                                   s.ipiv, s.info, s.xdbg);
+            else
+                hipLaunchKernelGGL(k_lu_panel<128>, dim3((unsigned)nbp), dim3(128 * PK_Q), lds_bytes, s.c->stream, s.A, s.lda,
+                                   s.rows, (int)j0, (int)w, (int)nbp, s.xbase, s.xerr, s.xa, s.xb, s.xvals, s.pos_of, s.prow,
+                                   s.ipiv, s.info, s.xdbg);
             RMHIP_TRY(launch_check(s.c));
             s.xbase += (unsigned)w;
             const size_t pid = s.panel_start->size();
@@ -872,8 +908,15 @@ static int getrf_rec(LuState& s, size_t j0, size_t w) {
 struct StreamScope {
     Context* c;
     hipStream_t saved;
-    StreamScope(Context* ctx, hipStream_t s) : c(ctx), saved(ctx->stream) { c->stream = s; }
-    ~StreamScope() { c->stream = saved; }
+    size_t saved_pad;
+    StreamScope(Context* ctx, hipStream_t s, size_t gemm_lds_pad) : c(ctx), saved(ctx->stream), saved_pad(ctx->gemm_lds_pad) {
+        c->stream = s;
+        c->gemm_lds_pad = gemm_lds_pad;
+    }
+    ~StreamScope() {
+        c->stream = saved;
+        c->gemm_lds_pad = saved_pad;
+    }
 };
 
 static int update_columns(LuState& s, size_t j, size_t w, size_t c0, size_t c1) {
@@ -905,6 +948,10 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         events.push_back(e);
         return e;
     };
+    // update-stream dgemm blocks ask for 84 KiB of LDS (73.7 needed): one per CU, leaving 76 KiB for a panel
+    // block (66 KiB) or a main-stream dgemm block (73.7 KiB)
+    size_t side_pad = 84 * 1024 - 73728;
+    if (const char* v = std::getenv("RMHIP_LU_LA_PAD")) side_pad = (size_t)std::atoll(v);
     int rc = RMHIP_OK;
     hipEvent_t side_done = nullptr;  // S_{j-1} finished
     {
@@ -928,7 +975,7 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         }
         (void)hipStreamWaitEvent(side, panel_done, 0);
         {
-            StreamScope scope(c, side);
+            StreamScope scope(c, side, side_pad);
             rc = update_columns(s, j, w, next + la_w, s.cols);      // S_j
             if (rc == RMHIP_OK && j > 0) rc = laswp(s, 0, j, j, j + w);  // finished left columns
         }
@@ -963,7 +1010,7 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     const size_t off_pos = off_abs + sizeof(double) * 2 * MAX_PANEL_BLOCKS;
     const size_t off_row = off_pos + sizeof(int) * 2 * MAX_PANEL_BLOCKS;
     const size_t off_xvals = (off_row + sizeof(int) * 2 * MAX_PANEL_BLOCKS + 15) & ~(size_t)15;
-    const size_t off_xa = off_xvals + sizeof(double) * 2 * PK_MAXB * BASE_W;
+    const size_t off_xa = off_xvals + sizeof(unsigned long long) * 2 * PK_MAXB * BASE_W * 2;
     const size_t off_xb = off_xa + sizeof(unsigned long long) * 2 * PK_MAXB;
     const size_t off_xctl = off_xb + sizeof(unsigned long long) * 2 * PK_MAXB;
     const size_t total = off_xctl + 64 + 16 * sizeof(unsigned long long);
@@ -981,17 +1028,20 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     LuState s{c, A, rows, cols, lda, ipiv, info, (int*)(blk + off_posof), (int*)(blk + off_rowat), (int*)(blk + off_prow),
               (int2*)(blk + off_plist), &panel_start, (double*)(blk + off_abs), (int*)(blk + off_pos), (int*)(blk + off_row),
               (int*)(blk + off_xctl + 16), (unsigned long long*)(blk + off_xa), (unsigned long long*)(blk + off_xb),
-              (double*)(blk + off_xvals), 0u, true, nullptr};
+              (unsigned long long*)(blk + off_xvals), 0u, true, nullptr, 256};
     {
         // persistent panels need >64 KiB of dynamic LDS and all their blocks co-resident (one per CU)
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)k_lu_panel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)((BASE_W * PK_ROWS + BASE_W) * sizeof(double)));
+            (void)hipFuncSetAttribute((const void*)k_lu_panel<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)((BASE_W * 256 + BASE_W) * sizeof(double)));
+            (void)hipFuncSetAttribute((const void*)k_lu_panel<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)((BASE_W * 128 + BASE_W) * sizeof(double)));
             attr_set = true;
         }
         const char* pm = std::getenv("RMHIP_LU_PANEL");  // "columns" selects the one-launch-per-column kernels
         if (pm && pm[0] == 'c') s.persistent = false;
+        if (const char* pr = std::getenv("RMHIP_LU_PANEL_ROWS")) s.panel_rows = std::atoi(pr) == 128 ? 128 : 256;  // developer knob
         const char* dbgenv = std::getenv("RMHIP_LU_PANEL_DEBUG");
         if (dbgenv && dbgenv[0] == '1') s.xdbg = (unsigned long long*)(blk + off_xctl + 64);
     }
@@ -1003,7 +1053,7 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     // 512-thread column kernels, which then wait for a dgemm block to retire.
     const char* la = std::getenv("RMHIP_LU_LOOKAHEAD");
     const bool blocked = kmin > nb && la && la[0] == '1';
-    if (blocked) s.persistent = false;  // a second stream's dgemm blocks would break the panels' co-residency
+    if (blocked) s.panel_rows = 128;  // a panel block (66 KiB LDS) must fit beside a dgemm block of the update stream
     int rc = blocked ? getrf_blocked(s, kmin, nb) : getrf_rec(s, 0, kmin);
     if (rc == RMHIP_OK && cols > rows && !blocked) {  // wide: finish U's right block (the blocked driver covers it)
         rc = laswp(s, rows, cols, 0, rows);
