@@ -568,7 +568,7 @@ def test_mldivide_reference_tests(prov, oracle):
     assert e.value.code == 3
 
 
-@pytest.mark.parametrize("n,nrhs", [(3, 1), (64, 1), (300, 3), (1000, 1), (2048, 2)])
+@pytest.mark.parametrize("n,nrhs", [(3, 1), (64, 1), (300, 3), (1000, 1), (2048, 2), (513, 8), (640, 4), (700, 9), (129, 5)])
 def test_mldivide_well_conditioned_vs_oracle(prov, oracle, n, nrhs):
     # SURVEY.md 8(d) config 5 generator: A = U(-1,1) + n*I, b = A*1
     rng = np.random.default_rng(n)
