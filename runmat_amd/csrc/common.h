@@ -99,6 +99,9 @@ struct Context {
     // LU look-ahead (lu.hip getrf_blocked): extra dynamic LDS requested by launch_dgemm so that only ONE
     // dgemm block fits per CU and latency-bound kernels of the other stream find room beside it
     size_t gemm_lds_pad = 0;
+    // set after a persistent-panel factorisation found its workgroups not co-resident (device shared with
+    // another context): from then on LU uses the one-launch-per-column panels on a single stream
+    bool lu_conservative = false;
 
     // ---- helpers (rmhip_core.cpp) ----
     int alloc_device(size_t numel, std::shared_ptr<Allocation>* out);
@@ -177,6 +180,8 @@ int launch_rng_normal(Context* c, uint64_t state, double* out, size_t n);
 uint64_t lcg_advance(uint64_t state, uint64_t delta);
 
 // LU / solve (lu.hip)
+// internal status of lu_factor_device: the matrix is clobbered, refactor a fresh copy (c->lu_conservative is now set)
+static constexpr int RMHIP_LU_RETRY = -77;
 int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda, int* perm_dev,
                      int* info_host, std::vector<int>* ipiv_host = nullptr);
 int lu_swap_rows_device(Context* c, double* A, size_t lda, size_t ncols, const std::vector<int>& ipiv);

@@ -82,6 +82,22 @@ void collapse(std::vector<uint64_t>* shape, std::vector<std::vector<uint64_t>>* 
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// Copy `src` (rows x cols, dense) into the padded workspace and factor it; when the persistent panel kernels
+// report that their workgroups were not co-resident the copy is refreshed and factored conservatively.
+static int lu_copy_and_factor(Context* c, const double* src, size_t rows, size_t cols, double* work, size_t ldw, int* perm,
+                              int* info) {
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (rows && cols) {
+            hipError_t e = hipMemcpy2DAsync(work, ldw * sizeof(double), src, rows * sizeof(double), rows * sizeof(double), cols,
+                                            hipMemcpyDeviceToDevice, c->stream);
+            if (e != hipSuccess) return fail(RMHIP_ERR_HIP, "lu copy: %s", hipGetErrorString(e));
+        }
+        const int rc = lu_factor_device(c, work, rows, cols, ldw, perm, info);
+        if (rc != RMHIP_LU_RETRY) return rc;
+    }
+    return fail(RMHIP_ERR_HIP, "lu: factorisation failed twice");
+}
+
 size_t lu_padded_ld(size_t rows) { return rows >= 256 ? ((rows + 1) & ~(size_t)1) + 32 : ((rows + 1) & ~(size_t)1); }
 
 std::vector<size_t> normalize_matrix_shape(const std::vector<size_t>& s) {
@@ -537,13 +553,8 @@ int rmhip_lu(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf out5[5]) {
     const size_t ldw = lu_padded_ld(rows);
     std::shared_ptr<Allocation> work;
     if (!rc) rc = c->alloc_device(ldw * (cols ? cols : 1), &work);
-    if (!rc && ab.numel) {
-        hipError_t e = hipMemcpy2DAsync(work->ptr, ldw * sizeof(double), ab.data(), rows * sizeof(double), rows * sizeof(double),
-                                        cols, hipMemcpyDeviceToDevice, c->stream);
-        if (e != hipSuccess) rc = fail(RMHIP_ERR_HIP, "lu copy: %s", hipGetErrorString(e));
-    }
     int info = 0;
-    if (!rc) rc = lu_factor_device(c, work->ptr, rows, cols, ldw, perm, &info);
+    if (!rc) rc = lu_copy_and_factor(c, ab.data(), rows, cols, work->ptr, ldw, perm, &info);
     if (!rc && ab.numel) {
         hipError_t e = hipMemcpy2DAsync(comb.data(), rows * sizeof(double), work->ptr, ldw * sizeof(double), rows * sizeof(double),
                                         cols, hipMemcpyDeviceToDevice, c->stream);
@@ -593,12 +604,10 @@ int rmhip_mldivide(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
     const size_t ldw = lu_padded_ld(n);
     std::shared_ptr<Allocation> work;
     RMHIP_TRY(c->alloc_device(ldw * n, &work));
-    RMHIP_HIP_CHECK(hipMemcpy2DAsync(work->ptr, ldw * sizeof(double), ab.data(), n * sizeof(double), n * sizeof(double), n,
-                                     hipMemcpyDeviceToDevice, c->stream));
     int* perm = nullptr;
     RMHIP_HIP_CHECK(hipMalloc((void**)&perm, sizeof(int) * (n + 1)));
     int info = 0;
-    int rc = lu_factor_device(c, work->ptr, n, n, ldw, perm, &info);
+    int rc = lu_copy_and_factor(c, ab.data(), n, n, work->ptr, ldw, perm, &info);
     if (!rc && info > 0)
         rc = fail(RMHIP_ERR_SINGULAR, "mldivide: %d pivot(s) <= 1e-12; matrix is numerically singular, use the CPU SVD path", info);
     Buffer ob;
@@ -688,12 +697,10 @@ int rmhip_linsolve(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, const rmhip_linsolv
         const size_t ldw = lu_padded_ld(n);
         std::shared_ptr<Allocation> work;
         RMHIP_TRY(c->alloc_device(ldw * n, &work));
-        RMHIP_HIP_CHECK(hipMemcpy2DAsync(work->ptr, ldw * sizeof(double), A, n * sizeof(double), n * sizeof(double), n,
-                                         hipMemcpyDeviceToDevice, c->stream));
         int* perm = nullptr;
         RMHIP_HIP_CHECK(hipMalloc((void**)&perm, sizeof(int) * (n + 1)));
         int info = 0;
-        rc = lu_factor_device(c, work->ptr, n, n, ldw, perm, &info);
+        rc = lu_copy_and_factor(c, A, n, n, work->ptr, ldw, perm, &info);
         if (!rc && info > 0) rc = fail(RMHIP_ERR_SINGULAR, "linsolve: %d pivot(s) <= 1e-12; use the CPU SVD path", info);
         if (!rc) rc = c->new_buffer(oshape, 2, &oid, &ob);
         if (!rc) rc = lu_solve_device(c, work->ptr, n, ldw, perm, bb.data(), nrhs, n, ob.data(), n);
@@ -789,7 +796,12 @@ int rmhip_blk_lu(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf* ipiv_out, int
     RMHIP_TRY(resolve_view(c, a, &va));
     std::vector<int> ipiv;
     int inf = 0;
-    RMHIP_TRY(lu_factor_device(c, va.ptr, va.rows, va.cols, va.ld, nullptr, &inf, &ipiv));
+    {
+        const int frc = lu_factor_device(c, va.ptr, va.rows, va.cols, va.ld, nullptr, &inf, &ipiv);
+        if (frc == RMHIP_LU_RETRY)  // in place: the block is clobbered and there is no copy to restart from
+            return fail(RMHIP_ERR_HIP, "blk_lu: panel workgroups were not co-resident (device shared?); the block is invalid");
+        RMHIP_TRY(frc);
+    }
     if (info) *info = inf;
     std::vector<double> host(ipiv.begin(), ipiv.end());
     const size_t oshape[2] = {host.size(), 1};
