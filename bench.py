@@ -134,7 +134,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["fused", "dgemm", "mc", "mldivide", "chain"], default="fused")
+    ap.add_argument("--workload", choices=["fused", "dgemm", "mc", "mldivide", "chain", "mc_evolved"], default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     args = ap.parse_args()
@@ -293,6 +293,38 @@ def main() -> None:
                          "traffic": None, "kernel": "k_rng_normal + rm_ew_fast + rm_red_contig (whole step, wall clock)"},
         }
 
+    def mc_evolved_record(steps, warmup):
+        """Benchmark-shaped secondary of SURVEY.md 8(d) config 4: M = 1e6 paths, T = 256 steps, the whole time
+        loop as ONE `stochastic_evolution` call (state in registers) + one fused payoff reduction."""
+        from runmat_amd import sharding as sh
+
+        group = sh.Group.from_env()
+        M, T = 1_000_000, 256
+        price = 0.0
+        for _ in range(warmup):
+            price, _ = sh.monte_carlo_price_evolved(prov, group, M, T, rng_state=0x9E3779B97F4A7C15)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            price, _ = sh.monte_carlo_price_evolved(prov, group, M, T, rng_state=0x9E3779B97F4A7C15)
+        barrier()
+        wall = max_over_ranks(time.perf_counter() - t0)
+        ms = wall / steps * 1e3
+        # per normal: LCG step + half a Box-Muller (log, sqrt, sincos) + exp + 3 mul/add: ~150 fp64 VALU
+        # instructions per sample-step (counted from the ISA); the kernel is VALU bound, not HBM bound
+        return {
+            "metric": "Monte-Carlo sample-steps/s (M=1e6 paths x T=256 steps, one stochastic_evolution call)",
+            "value": round(M * T / (ms * 1e-3), 1), "unit": "samples/s", "ms_per_step": round(ms, 4), "scaling": "strong",
+            "dtype": "f64",
+            "config": {"workload": "monte-carlo-analysis f64, M=1e6, T=256, CPU-parity LCG randn stream, fused time loop",
+                       "price": price, "algorithmic_bytes": 32 * M,
+                       "parallelism": f"sample ranges x{world}, ordered 1-value exchange"},
+            "roofline": {"bound": "hbm", "achieved": round(32 * M / world / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(32 * M / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "k_stochastic_evolution (32 B per path for the whole loop: fp64 VALU bound, "
+                                   "the HBM fraction is reported for completeness)"},
+        }
+
     def mldivide_record(steps, warmup):
         """BASELINE configs[4] at the single-GPU size: x = A\\b, 16384x16384 f64, blocked recursive LU."""
         nn = 16384
@@ -390,7 +422,7 @@ def main() -> None:
         }
 
     records = {"fused": fused_record, "dgemm": dgemm_record, "mc": mc_record, "mldivide": mldivide_record,
-               "chain": chain_record}
+               "chain": chain_record, "mc_evolved": mc_evolved_record}
     primary = records[args.workload]
     rec = primary(args.steps, args.warmup)
     out = {
@@ -401,22 +433,23 @@ def main() -> None:
     }
     if not args.no_also:
         # the other configs of BASELINE.json, short runs; every rank takes part (collectives inside)
-        others = [w for w in ("fused", "dgemm", "mc", "chain") if w != args.workload]
+        others = [w for w in ("fused", "dgemm", "mc", "mc_evolved", "chain") if w != args.workload]
         if world == 1 and args.workload != "mldivide":
             others.append("mldivide")
         also = []
         for w in others:
-            steps = {"fused": 20, "dgemm": 5, "mc": 3, "mldivide": 2, "chain": 100}[w]
+            steps = {"fused": 20, "dgemm": 5, "mc": 3, "mc_evolved": 3, "mldivide": 2, "chain": 100}[w]
             sec = records[w](steps, 2 if w != "mldivide" else 1)
             also.append({k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "roofline")})
         out["also"] = also
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = {"fused": cpu_baseline_fused, "dgemm": cpu_baseline_dgemm, "mc": cpu_baseline_mc,
-                               "mldivide": cpu_baseline_mldivide, "chain": cpu_baseline_chain}[args.workload]()
+                               "mldivide": cpu_baseline_mldivide, "chain": cpu_baseline_chain,
+                               "mc_evolved": cpu_baseline_mc}[args.workload]()
         for a in out.get("also", []):
             if a["unit"] == "GFLOP/s" and "matmul" in a["metric"]:
                 a["cpu_baseline"] = cpu_baseline_dgemm()
-            elif a["unit"] == "samples/s":
+            elif a["unit"] == "samples/s" and "stochastic_evolution" not in a["metric"]:
                 a["cpu_baseline"] = cpu_baseline_mc()
             elif "A\\b" in a["metric"]:
                 a["cpu_baseline"] = cpu_baseline_mldivide()

@@ -263,6 +263,19 @@ RMHIP_API int rmhip_random_uniform(rmhip_ctx* ctx, const size_t* shape, size_t r
                                    rmhip_buf* out);
 RMHIP_API int rmhip_random_normal(rmhip_ctx* ctx, const size_t* shape, size_t rank,
                                   rmhip_buf* out);
+/* `stochastic_evolution` (lib.rs:1759-1769; CPU loop builtins/stats/random/stochastic_evolution.rs:10-30):
+ * `steps` times { z = randn(size(state)) from the shared stream; state .*= exp(drift + scale .* z) }, as one
+ * kernel that keeps the state in registers.  Advances the RNG state exactly as the CPU loop does
+ * (steps * 2 * ceil(numel / 2) draws).  steps == 0 returns a copy. */
+RMHIP_API int rmhip_stochastic_evolution(rmhip_ctx* ctx, rmhip_buf state, double drift, double scale, uint32_t steps,
+                                         rmhip_buf* out);
+/* Multi-GPU form (no counterpart in the reference, which has no multi-device code): `state` is the
+ * shard [offset, offset + numel) of a global vector whose every step draws `draws_per_step` values
+ * (2 * ceil(global_numel / 2)); the caller positions the RNG at global_state + offset beforehand
+ * (rmhip_set_rng_state) and the shard then consumes exactly the normals the single-device run would give
+ * those elements.  The RNG state advances by steps * draws_per_step.  draws_per_step == 0 is the plain call. */
+RMHIP_API int rmhip_stochastic_evolution_sharded(rmhip_ctx* ctx, rmhip_buf state, double drift, double scale,
+                                                 uint32_t steps, uint64_t draws_per_step, rmhip_buf* out);
 
 /* ---- telemetry  (lib.rs:1337-1376, 3023-3045) ----------------------------------------------- */
 

@@ -220,7 +220,12 @@ public:
         return {with_shape(ids[0]), with_shape(ids[1]), with_shape(ids[2]), with_shape(ids[3]), with_shape(ids[4])};
     }
 
-    // ---- RNG (lib.rs:1713-1728, 1772) ----
+    // ---- RNG (lib.rs:1713-1728, 1759-1772) ----
+    GpuTensorHandle stochastic_evolution(const GpuTensorHandle& state, double drift, double scale, uint32_t steps) const {
+        uint64_t out = 0;
+        check(rmhip_stochastic_evolution(ctx_, own(state), drift, scale, steps, &out));
+        return make(out, state.shape);
+    }
     void set_rng_state(uint64_t state) const { check(rmhip_set_rng_state(ctx_, state)); }
     GpuTensorHandle random_uniform(const std::vector<size_t>& shape) const {
         uint64_t out = 0;

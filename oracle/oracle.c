@@ -694,6 +694,22 @@ ORC_API double orc_monte_carlo_price(uint64_t* state, size_t M, size_t T, double
     return price;
 }
 
+/* stochastic_evolution_host, builtins/stats/random/stochastic_evolution.rs:10-30 */
+ORC_API int orc_stochastic_evolution(uint64_t* state, double* data, size_t len, double drift, double scale, uint32_t steps) {
+    if (len == 0 || steps == 0) return 0;
+    double* z = (double*)malloc(sizeof(double) * len);
+    if (!z) return 2;
+    for (uint32_t s = 0; s < steps; ++s) {
+        orc_rng_normal(state, len, z);
+        for (size_t i = 0; i < len; ++i) {
+            double term = drift + scale * z[i];
+            data[i] *= exp(term);
+        }
+    }
+    free(z);
+    return 0;
+}
+
 /* splitmix64-based uniform fill used by bench/tests to build identical inputs on host and device
  * (SURVEY.md 8(d) config 2/3): value = lo + (hi-lo) * (next53 * 2^-53), one splitmix64 step per
  * element with state = seed + (i+1)*0x9e3779b97f4a7c15 (counter form => order independent). */

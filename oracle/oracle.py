@@ -66,6 +66,8 @@ def lib() -> C.CDLL:
         l.orc_mldivide_svd.argtypes = [_DP, C.c_size_t, C.c_size_t, _DP, C.c_size_t, C.c_size_t, _DP]
         l.orc_mldivide_lu.restype = C.c_int
         l.orc_mldivide_lu.argtypes = [_DP, C.c_size_t, _DP, C.c_size_t, _DP]
+        l.orc_stochastic_evolution.restype = C.c_int
+        l.orc_stochastic_evolution.argtypes = [C.POINTER(C.c_uint64), _DP, C.c_size_t, C.c_double, C.c_double, C.c_uint32]
         l.orc_linsolve_tri.restype = C.c_int
         l.orc_linsolve_tri.argtypes = [C.c_int, _DP, C.c_size_t, _DP, C.c_size_t, _DP, _DP]
         l.orc_transpose.restype = None
@@ -242,6 +244,17 @@ def mldivide_lu(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     if rc == 3:
         raise np.linalg.LinAlgError("singular")
     return out.reshape((n, b.shape[1]), order="F")
+
+
+def stochastic_evolution(state: int, data, drift: float, scale: float, steps: int):
+    """-> (evolved array, new rng state)"""
+    a = np.asarray(data, dtype=np.float64)
+    flat = _f(a).copy()
+    st = C.c_uint64(state)
+    rc = lib().orc_stochastic_evolution(C.byref(st), _p(flat), flat.size, drift, scale, steps)
+    if rc:
+        raise MemoryError("orc_stochastic_evolution")
+    return flat.reshape(a.shape, order="F"), st.value
 
 
 def transpose(a: np.ndarray) -> np.ndarray:

@@ -114,6 +114,8 @@ SIGNATURES = {
     "rmhip_rng_seed": (C.c_int, [_P, C.c_uint64]),
     "rmhip_random_uniform": (C.c_int, [_P, _SZP, _SZ, _BUFP]),
     "rmhip_random_normal": (C.c_int, [_P, _SZP, _SZ, _BUFP]),
+    "rmhip_stochastic_evolution": (C.c_int, [_P, _BUF, C.c_double, C.c_double, C.c_uint32, _BUFP]),
+    "rmhip_stochastic_evolution_sharded": (C.c_int, [_P, _BUF, C.c_double, C.c_double, C.c_uint32, C.c_uint64, _BUFP]),
     "rmhip_telemetry": (C.c_int, [_P, C.POINTER(Telemetry)]),
     "rmhip_reset_telemetry": (C.c_int, [_P]),
     "rmhip_timer_begin": (C.c_int, [_P]),

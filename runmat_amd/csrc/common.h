@@ -178,6 +178,8 @@ int launch_dgemm_epilogue(Context* c, size_t m, size_t n, size_t k, const double
 int launch_rng_uniform(Context* c, uint64_t state, double* out, size_t n);
 int launch_rng_normal(Context* c, uint64_t state, double* out, size_t n);
 uint64_t lcg_advance(uint64_t state, uint64_t delta);
+int launch_stochastic_evolution(Context* c, uint64_t state, const double* in, double* out, size_t n, double drift,
+                                double scale, unsigned steps, uint64_t draws_per_step);
 
 // LU / solve (lu.hip)
 // internal status of lu_factor_device: the matrix is clobbered, refactor a fresh copy (c->lu_conservative is now set)

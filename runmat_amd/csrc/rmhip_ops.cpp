@@ -887,4 +887,33 @@ int rmhip_random_normal(rmhip_ctx* ctx, const size_t* shape, size_t rank, rmhip_
     return RMHIP_OK;
 }
 
+int rmhip_stochastic_evolution(rmhip_ctx* ctx, rmhip_buf state, double drift, double scale, uint32_t steps, rmhip_buf* out) {
+    return rmhip_stochastic_evolution_sharded(ctx, state, drift, scale, steps, 0, out);
+}
+
+int rmhip_stochastic_evolution_sharded(rmhip_ctx* ctx, rmhip_buf state, double drift, double scale, uint32_t steps,
+                                       uint64_t draws_per_step, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer sb;
+    RMHIP_TRY(c->get(state, &sb));
+    Buffer ob;
+    RMHIP_TRY(c->new_buffer(sb.shape.data(), sb.shape.size(), out, &ob));
+    if (sb.numel == 0) return RMHIP_OK;
+    int rc = RMHIP_OK;
+    if (steps == 0) {  // stochastic_evolution.rs:16-18: nothing drawn, state unchanged
+        hipError_t e = hipMemcpyAsync(ob.data(), sb.data(), sizeof(double) * sb.numel, hipMemcpyDeviceToDevice, c->stream);
+        if (e != hipSuccess) rc = fail(RMHIP_ERR_HIP, "stochastic_evolution: %s", hipGetErrorString(e));
+    } else {
+        const uint64_t local = 2ULL * ((sb.numel + 1) / 2);
+        if (draws_per_step && draws_per_step < local)
+            rc = fail(RMHIP_ERR_INVALID, "stochastic_evolution: draws_per_step %llu < the shard's own %llu",
+                      (unsigned long long)draws_per_step, (unsigned long long)local);
+        if (!rc) rc = launch_stochastic_evolution(c, c->rng_state, sb.data(), ob.data(), sb.numel, drift, scale, steps, draws_per_step);
+        if (!rc) c->rng_state = lcg_advance(c->rng_state, (uint64_t)steps * (draws_per_step ? draws_per_step : local));
+    }
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+
 }  // extern "C"

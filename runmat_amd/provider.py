@@ -361,6 +361,14 @@ class HipProvider:
         self._check(self._lib.rmhip_mldivide(self._ctx, self._id(lhs), self._id(rhs), C.byref(out)))
         return self._handle(out.value)
 
+    def stochastic_evolution(self, state: GpuTensorHandle, drift: float, scale: float, steps: int,
+                             draws_per_step: int = 0) -> GpuTensorHandle:
+        """lib.rs:1759-1769; `draws_per_step` > 0 selects the sharded form (see include/rmhip.h)."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_stochastic_evolution_sharded(self._ctx, self._id(state), float(drift), float(scale),
+                                                                 int(steps), int(draws_per_step), C.byref(out)))
+        return self._handle(out.value, state.shape)
+
     def linsolve(self, lhs: GpuTensorHandle, rhs: GpuTensorHandle,
                  options: Optional[ProviderLinsolveOptions] = None) -> ProviderLinsolveResult:
         """lib.rs:2422-2429; CPU semantics linsolve.rs:691-726."""

@@ -264,6 +264,48 @@ def monte_carlo_price_fused(prov, group: Group, M: int, T: int, S0=100.0, mu=0.0
     return (total / float(M)) * math.exp(-mu * T * dt), final_state
 
 
+def monte_carlo_price_evolved(prov, group: Group, M: int, T: int, S0=100.0, mu=0.05, sigma=0.2, dt=1.0 / 252.0, K=100.0,
+                              rng_state: Optional[int] = None, fused_payoff: bool = True) -> Tuple[float, int]:
+    """Same workload and the same random stream again, with the whole time loop as ONE provider call
+    (`stochastic_evolution`, the idiom RunMat's VM recognises: crates/runmat-vm/src/accel/idioms/
+    stochastic_evolution.rs) followed by one fused reduction.  HBM traffic per path: fill 8 B + evolve 16 B +
+    payoff sum 8 B = 32 B for any T (the materialised plan moves (32*T + 8) B)."""
+    from .fusion import FusionGroupPlan
+    from .provider import ReductionFlavor
+
+    if rng_state is None:
+        rng_state = prov.get_rng_state()
+    start, stop = partition(M, group.world, group.rank, granule=2)
+    count = stop - start
+    per_step = 2 * ((M + 1) // 2)
+    drift = (mu - 0.5 * sigma * sigma) * dt
+    scale = sigma * math.sqrt(dt)
+    partial = 0.0
+    if count > 0:
+        S = prov.fill((count, 1), S0)
+        prov.set_rng_state(lcg_advance(rng_state, start))
+        S_end = prov.stochastic_evolution(S, drift, scale, T, draws_per_step=per_step)
+        temps = [S, S_end]
+        if fused_payoff:
+            red = FusionGroupPlan()
+            r_s = red.input()
+            payoff = red.builtin("max", red.primitive("Sub", r_s, red.constant(K)), red.constant(0.0))
+            psum = prov.fused_reduction(red.generate_reduction_wgsl(payoff, "f64", axis=0), [S_end], (1,), count, 1, 256,
+                                        ReductionFlavor.Sum())
+        else:  # per-op form (max(S - K, 0) then sum), as monte_carlo_price_sharded
+            d = prov.scalar_sub(S_end, K)
+            pay = prov.scalar_max(d, 0.0)
+            psum = prov.reduce_sum(pay)
+            temps += [d, pay]
+        partial = float(prov.download(psum)[0])
+        for h in temps + [psum]:
+            prov.free(h)
+    total = group.ordered_sum(partial)
+    final_state = lcg_advance(rng_state, T * per_step)
+    prov.set_rng_state(final_state)
+    return (total / float(M)) * math.exp(-mu * T * dt), final_state
+
+
 # ---- x = A\\b across GPUs: 1-D block-column cyclic LU with one panel broadcast per block -----------
 def owned_blocks(n: int, nb: int, group: Group) -> List[int]:
     """Global column-block ids owned by this rank (block p -> rank p % world)."""

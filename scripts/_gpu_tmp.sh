@@ -1,11 +1,3 @@
-mkdir -p gpurun_out
-timeout 600 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 600 gpurun_out/bench_default.err
-RMHIP_BENCH_FORCE_CYCLIC=1 timeout 300 python bench.py --workload mldivide --steps 3 --warmup 1 --no-also --no-cpu-baseline > gpurun_out/bench_cyclic.json 2>&1
-python - <<'PY'
-import json
-d = json.loads(open('gpurun_out/bench_default.json').read().strip().splitlines()[-1])
-print(d['metric'], d['value'], d['ms_per_step'], d['roofline']['frac'])
-for a in d.get('also', []): print(a['metric'], a['value'], a['ms_per_step'], a.get('roofline', {}).get('frac'))
-c = json.loads(open('gpurun_out/bench_cyclic.json').read().strip().splitlines()[-1])
-print('cyclic:', c['value'], c['ms_per_step'], c['config'])
-PY
+timeout 300 python -m pytest tests -m gpu -q -x -k "stochastic or sharding_paths or rng" 2>&1 | tail -3
+timeout 300 python bench.py --workload mc_evolved --steps 5 --warmup 2 --no-also --no-cpu-baseline | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['metric'], d['value'], d['ms_per_step'], d['config']['price'])"
+timeout 300 python bench.py --workload mc --steps 5 --warmup 2 --no-also --no-cpu-baseline | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['metric'], d['value'], d['ms_per_step'], d['config']['price'])"

@@ -48,6 +48,7 @@ extern "C" {
     fn rmhip_linsolve(ctx: *mut RmhipCtx, a: u64, b: u64, opts: *const RmhipLinsolveOptions, out: *mut u64, rcond: *mut c_double) -> c_int;
     fn rmhip_transpose(ctx: *mut RmhipCtx, a: u64, out: *mut u64) -> c_int;
     fn rmhip_set_rng_state(ctx: *mut RmhipCtx, state: u64) -> c_int;
+    fn rmhip_stochastic_evolution(ctx: *mut RmhipCtx, state: u64, drift: c_double, scale: c_double, steps: u32, out: *mut u64) -> c_int;
     fn rmhip_random_normal(ctx: *mut RmhipCtx, shape: *const usize, rank: usize, out: *mut u64) -> c_int;
     fn rmhip_random_uniform(ctx: *mut RmhipCtx, shape: *const usize, rank: usize, out: *mut u64) -> c_int;
 }
@@ -220,6 +221,11 @@ impl AccelProvider for HipProvider {
             Ok(ProviderLuResult { combined: self.handle(ids[0])?, lower: self.handle(ids[1])?, upper: self.handle(ids[2])?,
                 perm_matrix: self.handle(ids[3])?, perm_vector: self.handle(ids[4])? })
         })
+    }
+    fn stochastic_evolution(&self, state: &GpuTensorHandle, drift: f64, scale: f64, steps: u32) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_stochastic_evolution(self.ctx, self.own(state)?, drift, scale, steps, &mut out) })?;
+        self.handle(out)
     }
     fn random_normal(&self, shape: &[usize]) -> Result<GpuTensorHandle> {
         let mut out = 0u64;

@@ -41,6 +41,18 @@ class OracleProvider:
         z, self.state = self.o.rng_normal(self.state, n)
         return Handle(z.reshape(shape, order="F"))
 
+    def stochastic_evolution(self, h, drift, scale, steps, draws_per_step=0):
+        # sharded form of include/rmhip.h: step t draws from state + t * draws_per_step
+        x = h.arr.reshape(-1, order="F").copy()
+        per = draws_per_step or 2 * ((x.size + 1) // 2)
+        base = self.state
+        for t in range(steps):
+            z, _ = self.o.rng_normal(self.o.rng_advance(base, t * per), x.size)
+            x = self.o.binary("mul", x.reshape(-1, 1), self.o.unary("exp", self.o.binary("add", np.array([[float(drift)]]),
+                              self.o.binary("mul", np.array([[float(scale)]]), z.reshape(-1, 1))))).reshape(-1)
+        self.state = self.o.rng_advance(base, steps * per)
+        return Handle(x.reshape(h.arr.shape, order="F"))
+
     def scalar_mul(self, a, s):
         return Handle(self.o.binary("mul", a.arr, np.array([[float(s)]])))
 

@@ -665,8 +665,9 @@ def test_sharding_paths_on_one_gpu(prov, oracle):
     want, want_state = oracle.monte_carlo_price(oracle.rng_default_seed(), M, T)
     p1, s1 = sh.monte_carlo_price_sharded(prov, g, M, T, rng_state=oracle.rng_default_seed())
     p2, s2 = sh.monte_carlo_price_fused(prov, g, M, T, rng_state=oracle.rng_default_seed())
-    assert s1 == want_state and s2 == want_state
-    assert abs(p1 - want) <= 1e-10 * want and abs(p2 - want) <= 1e-10 * want
+    p3, s3 = sh.monte_carlo_price_evolved(prov, g, M, T, rng_state=oracle.rng_default_seed())  # one-call time loop
+    assert s1 == want_state and s2 == want_state and s3 == want_state
+    assert abs(p1 - want) <= 1e-10 * want and abs(p2 - want) <= 1e-10 * want and abs(p3 - want) <= 1e-10 * want
     # row-block matmul + device-side gather are identities at world 1
     A = np.arange(12.0).reshape(3, 4)
     h, keep = sh.gather_row_blocks_device(g, prov, prov.upload(A), 3)
@@ -906,3 +907,27 @@ def test_lu_conservative_retry(oracle):
     assert np.max(np.abs(x - oracle.mldivide_lu(A, B))) <= 1e-12
     x2 = p2.download_matrix(p2.mldivide(p2.upload(A), p2.upload(B)))  # the context stays conservative and keeps working
     assert bits_equal(x, x2)
+
+
+@pytest.mark.parametrize("n,steps", [(2, 3), (3, 4), (1, 1), (1001, 7), (4096, 16), (65537, 2)])
+def test_stochastic_evolution_vs_oracle(prov, oracle, n, steps):
+    seed = 0x1234567 + n
+    x = np.linspace(0.5, 2.0, n).reshape(n, 1)
+    prov.set_rng_state(seed)
+    got = prov.download_matrix(prov.stochastic_evolution(prov.upload(x), 0.001, 0.02, steps))
+    want, st = oracle.stochastic_evolution(seed, x, 0.001, 0.02, steps)
+    assert np.max(np.abs(got - want) / np.abs(want)) <= 64 * steps * EPS  # libm rounding of log/sqrt/sincos/exp per step
+    assert prov.get_rng_state() == st  # integer stream position: exact
+    # the stream continues exactly where the CPU's would
+    nxt = prov.download(prov.random_uniform((4, 1)))
+    assert np.array_equal(nxt, oracle.rng_uniform(st, 4)[0])
+
+
+def test_stochastic_evolution_reference_tests(prov, oracle):
+    # accelerate/tests/stochastic_evolution.rs:17-47: zero scale, tolerance 1e-9
+    out = prov.download(prov.stochastic_evolution(prov.upload(np.array([[1.0], [2.0], [3.0]])), 0.05, 0.0, 4))
+    assert np.max(np.abs(out - np.array([1.0, 2.0, 3.0]) * np.exp(0.2))) < 1e-9
+    h = prov.upload(np.array([[1.0, 2.0]]))
+    st = prov.get_rng_state()
+    same = prov.download(prov.stochastic_evolution(h, 0.1, 0.3, 0))  # steps == 0: unchanged, nothing drawn
+    assert np.array_equal(same, [1.0, 2.0]) and prov.get_rng_state() == st

@@ -356,3 +356,13 @@ def test_linsolve_triangular_kats(oracle):
     assert np.allclose(xg[:, 0], [1.0, 2.0], atol=1e-12)
     with pytest.raises(np.linalg.LinAlgError):
         oracle.linsolve(np.array([[1.0, 0.0], [1.0, 0.0]]), np.ones(2), lower=True)
+
+
+def test_stochastic_evolution_kat(oracle):
+    # stochastic_evolution.rs:39-51 (zero scale => pure drift) and accelerate/tests/stochastic_evolution.rs:17-47
+    out, st = oracle.stochastic_evolution(oracle.rng_default_seed(), np.array([[1.0], [2.0]]), 0.1, 0.0, 3)
+    assert np.max(np.abs(out[:, 0] - np.array([1.0, 2.0]) * np.exp(0.3))) < 1e-12
+    assert st == oracle.rng_advance(oracle.rng_default_seed(), 3 * 2)  # one pair per step
+    out3, st3 = oracle.stochastic_evolution(oracle.rng_default_seed(), np.array([[1.0], [2.0], [3.0]]), 0.05, 0.0, 4)
+    assert np.max(np.abs(out3[:, 0] - np.array([1.0, 2.0, 3.0]) * np.exp(0.2))) < 1e-9
+    assert st3 == oracle.rng_advance(oracle.rng_default_seed(), 4 * 4)  # odd length consumes whole pairs

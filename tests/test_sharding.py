@@ -68,10 +68,12 @@ def _worker(rank, world, port, out_dir):
         # --- Monte-Carlo with skip-ahead ---
         M, T = 20001, 3  # odd M: the last pair is half used
         price, state = sh.monte_carlo_price_sharded(prov, group, M, T, rng_state=oracle.rng_default_seed())
+        price_ev, state_ev = sh.monte_carlo_price_evolved(prov, group, M, T, rng_state=oracle.rng_default_seed(),
+                                                          fused_payoff=False)
         # --- ordered sum ---
         total = group.ordered_sum(0.1 * (rank + 1))
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), C=C, price=price, state=np.uint64(state), total=total,
-                 r0=r0, r1=r1)
+                 r0=r0, r1=r1, price_ev=price_ev, state_ev=np.uint64(state_ev))
     finally:
         dist.destroy_process_group()
 
@@ -96,6 +98,8 @@ def test_world2_gloo_sharded_matmul_and_monte_carlo(oracle, tmp_path):
     for r in res:
         assert abs(float(r["price"]) - want) <= 1e-12 * want
         assert int(r["state"]) == want_state
+        # the one-call time loop (stochastic_evolution with the global per-step stride) walks the same stream
+        assert float(r["price_ev"]) == float(r["price"]) and int(r["state_ev"]) == want_state
     assert res[0]["price"] == res[1]["price"]  # ordered sum: bit-identical on every rank
     assert res[0]["total"] == res[1]["total"] == 0.1 + 0.2
 
