@@ -16,6 +16,10 @@ for W in fused dgemm; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_$W" -o fetch -- $BENCH --no-also --workload $W > "$OUT/fetch_${W}_bench.json" 2> "$OUT/fetch_$W.err"
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_$W" -o write -- $BENCH --no-also --workload $W > "$OUT/write_${W}_bench.json" 2> "$OUT/write_$W.err"
 done
+# matrix-pipe evidence for the dgemm kernel (own pass: SQ + GRBM counters only)
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_mfma_dgemm" -o mfma -- $BENCH --no-also --workload dgemm > "$OUT/mfma_dgemm_bench.json" 2> "$OUT/mfma_dgemm.err"
+# kernel mix of the LU solve (kernel trace only)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_mldivide" -o trace -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also --workload mldivide > "$OUT/trace_mldivide_bench.json" 2> "$OUT/trace_mldivide.err"
 for f in $(find "$OUT/trace" -name "*kernel_stats.csv"); do echo "== $f"; head -14 "$f" | cut -c1-170; done
 python - "$OUT" <<'PY'
 import csv, glob, sys, collections, json
@@ -31,5 +35,20 @@ for w in ("fused", "dgemm"):
         for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:4]:
             summary.append({"workload": w, "kernel": k, "counter": counter, "launches": len(v), "mean": sum(v)/len(v), "min": min(v), "max": max(v)})
             print(f"{w} {counter} {k[:50]}: n={len(v)} mean={sum(v)/len(v):.1f}")
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f"{out}/pmc_mfma_dgemm/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "k_dgemm" in row["Kernel_Name"]:
+            agg[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for k, d in agg.items():
+    rec = {"workload": "dgemm", "kernel": k, "launches": len(next(iter(d.values())))}
+    for cn, v in d.items():
+        rec[cn + "_mean"] = sum(v) / len(v)
+    if "SQ_INSTS_VALU_MFMA_MOPS_F64_mean" in rec:
+        rec["mfma_flops_per_launch"] = rec["SQ_INSTS_VALU_MFMA_MOPS_F64_mean"] * 512
+    if "SQ_VALU_MFMA_BUSY_CYCLES_mean" in rec and "GRBM_GUI_ACTIVE_mean" in rec:
+        rec["mfma_util_pct(busy/(gui_active*1024 SIMDs))"] = 100.0 * rec["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / (rec["GRBM_GUI_ACTIVE_mean"] * 1024)
+    summary.append(rec)
+    print("MFMA", {k2: v2 for k2, v2 in rec.items() if k2 != "kernel"})
 json.dump(summary, open(f"{out}/pmc_summary.json", "w"), indent=1)
 PY
