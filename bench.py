@@ -148,12 +148,22 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
     dist = None
+    # Developer knob: RMHIP_BENCH_BACKEND=gloo lets several ranks share ONE GPU (device = local_rank mod
+    # device count) so the multi-rank control flow can be exercised on a single-GPU box; numbers from such a
+    # run are meaningless.  The driver's runs use nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("RMHIP_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+    coll_device = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(local_rank)
 
@@ -224,7 +234,7 @@ def main() -> None:
     def max_over_ranks(x: float) -> float:
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
