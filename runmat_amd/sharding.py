@@ -330,9 +330,21 @@ def _bcast(group: Group, prov, handle, shape, src: int) -> None:
         t = _torch_view(prov, handle, tuple(reversed(shape)))  # column-major (r, c) == row-major (c, r)
         group.dist.broadcast(t, src)
         torch.cuda.synchronize()
-    else:
+    elif hasattr(handle, "arr"):
         t = torch.from_numpy(handle.arr)
         group.dist.broadcast(t, src)
+    else:
+        # a device buffer with a CPU backend (several ranks sharing one GPU in a control-flow test): stage
+        # through the host -- download, broadcast, write back in place on the receivers
+        host = np.ascontiguousarray(prov.download(handle), dtype=np.float64)
+        t = torch.from_numpy(host)
+        group.dist.broadcast(t, src)
+        if group.rank != src:
+            rows = int(shape[0]) if len(shape) else 1
+            cols = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+            tmp = prov.upload(host.reshape((rows, cols), order="F"))
+            prov.blk_assign((handle, 0, 0, rows, cols), tmp)
+            prov.free(tmp)
 
 
 def mldivide_block_cyclic(prov, group: Group, a_local, n: int, b, nb: int = 512):
