@@ -177,6 +177,11 @@ RMHIP_API int rmhip_reduce(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int nan
 
 /* `dot` (lib.rs:2722-2728): sum(a .* b) along `dim` (zero-based) of two same-shape tensors; dim < 0
  * = first non-singleton dimension (vectors -> scalar [1,1]). One fused pass, no temporary. */
+/* `reduce_mean_nd` (lib.rs:2763-2769; shape rules backend/wgpu/provider/ops/reduction/nd.rs:59-72): reduce several
+ * zero-based dimensions, reduced extents become 1.  Dimensions are taken in ascending order one after the other,
+ * which is how the CPU computes `mean(x, vecdim)` (mean of means, mean.rs:1107-1116); works for every reduce op. */
+RMHIP_API int rmhip_reduce_nd(rmhip_ctx* ctx, int op, rmhip_buf a, const size_t* dims_zero_based, size_t ndims,
+                              int nan_mode, rmhip_buf* out);
 RMHIP_API int rmhip_dot(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, int dim, rmhip_buf* out);
 
 /* ---- linear algebra  (lib.rs:2375-2405, 2477-2500) ------------------------------------------ */

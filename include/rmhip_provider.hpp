@@ -184,6 +184,11 @@ public:
     GpuTensorHandle reduce_sum_dim(const GpuTensorHandle& a, size_t dim) const { return reduce(RMHIP_RSUM, a, (int)dim); }
     GpuTensorHandle reduce_mean(const GpuTensorHandle& a) const { return reduce(RMHIP_RMEAN, a, -1); }
     GpuTensorHandle reduce_mean_dim(const GpuTensorHandle& a, size_t dim) const { return reduce(RMHIP_RMEAN, a, (int)dim); }
+    GpuTensorHandle reduce_mean_nd(const GpuTensorHandle& a, const std::vector<size_t>& dims_zero_based) const {
+        uint64_t out = 0;
+        check(rmhip_reduce_nd(ctx_, RMHIP_RMEAN, own(a), dims_zero_based.data(), dims_zero_based.size(), 0, &out));
+        return with_shape(out);
+    }
     GpuTensorHandle reduce_min(const GpuTensorHandle& a) const { return reduce(RMHIP_RMIN, a, -1); }
     GpuTensorHandle reduce_max(const GpuTensorHandle& a) const { return reduce(RMHIP_RMAX, a, -1); }
 

@@ -443,6 +443,33 @@ int rmhip_reduce(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int nan_mode, rmh
     return rc;
 }
 
+int rmhip_reduce_nd(rmhip_ctx* ctx, int op, rmhip_buf a, const size_t* dims_zero_based, size_t ndims, int nan_mode,
+                    rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out || (!dims_zero_based && ndims)) return fail(RMHIP_ERR_INVALID, "reduce_nd: null argument");
+    Buffer ab;
+    RMHIP_TRY(c->get(a, &ab));
+    const size_t rank = normalize_matrix_shape(ab.shape).size();
+    // nd.rs:62-72: dims beyond the rank are ignored, duplicates dropped, ascending order
+    std::vector<size_t> dims;
+    for (size_t i = 0; i < ndims; ++i)
+        if (dims_zero_based[i] < rank) dims.push_back(dims_zero_based[i]);
+    std::sort(dims.begin(), dims.end());
+    dims.erase(std::unique(dims.begin(), dims.end()), dims.end());
+    if (dims.empty()) return fail(RMHIP_ERR_INVALID, "reduce_nd: no valid dims to reduce");
+    // the CPU reduces one dimension after the other in ascending order (mean of means, mean.rs:1107-1116)
+    rmhip_buf cur = a;
+    for (size_t i = 0; i < dims.size(); ++i) {
+        rmhip_buf next = 0;
+        const int rc = rmhip_reduce(ctx, op, cur, (int)dims[i], nan_mode, &next);
+        if (cur != a) rmhip_free(ctx, cur);
+        if (rc) return rc;
+        cur = next;
+    }
+    *out = cur;
+    return RMHIP_OK;
+}
+
 int rmhip_dot(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, int dim, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");

@@ -323,6 +323,17 @@ class HipProvider:
     def reduce_prod(self, a): return self._reduce("prod", a, -1)
     def reduce_prod_dim(self, a, dim): return self._reduce("prod", a, dim)
 
+    def reduce_mean_nd(self, a: GpuTensorHandle, dims_zero_based: Sequence[int], omitnan: bool = False) -> GpuTensorHandle:
+        """lib.rs:2763-2769: mean over several zero-based dims (reduced extents become 1)."""
+        return self._reduce_nd("mean", a, dims_zero_based, omitnan)
+
+    def _reduce_nd(self, op: str, a: GpuTensorHandle, dims_zero_based: Sequence[int], omitnan: bool = False) -> GpuTensorHandle:
+        dims = (C.c_size_t * max(len(dims_zero_based), 1))(*[int(d) for d in dims_zero_based])
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_reduce_nd(self._ctx, REDUCE_OPS[op], self._id(a), dims, len(dims_zero_based),
+                                              1 if omitnan else 0, C.byref(out)))
+        return self._handle(out.value)
+
     def dot(self, a: GpuTensorHandle, b: GpuTensorHandle, dim: Optional[int] = None) -> GpuTensorHandle:
         """`dot(lhs, rhs, dim)` (lib.rs:2722): dim is zero-based, None = first non-singleton."""
         out = C.c_uint64()

@@ -42,6 +42,7 @@ extern "C" {
     fn rmhip_unary(ctx: *mut RmhipCtx, op: c_int, a: u64, out: *mut u64) -> c_int;
     fn rmhip_scalar(ctx: *mut RmhipCtx, op: c_int, a: u64, s: c_double, out: *mut u64) -> c_int;
     fn rmhip_reduce(ctx: *mut RmhipCtx, op: c_int, a: u64, dim: c_int, nan_mode: c_int, out: *mut u64) -> c_int;
+    fn rmhip_reduce_nd(ctx: *mut RmhipCtx, op: c_int, a: u64, dims: *const usize, ndims: usize, nan_mode: c_int, out: *mut u64) -> c_int;
     fn rmhip_matmul(ctx: *mut RmhipCtx, a: u64, b: u64, out: *mut u64) -> c_int;
     fn rmhip_lu(ctx: *mut RmhipCtx, a: u64, out5: *mut u64) -> c_int;
     fn rmhip_mldivide(ctx: *mut RmhipCtx, a: u64, b: u64, out: *mut u64) -> c_int;
@@ -180,6 +181,13 @@ impl AccelProvider for HipProvider {
         Box::pin(async move {
             let mut out = 0u64;
             check(unsafe { rmhip_reduce(self.ctx, 0, self.own(a)?, dim as c_int, 0, &mut out) })?;
+            self.handle(out)
+        })
+    }
+    fn reduce_mean_nd<'a>(&'a self, a: &'a GpuTensorHandle, dims_zero_based: &'a [usize]) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_reduce_nd(self.ctx, 1 /* RMHIP_RMEAN */, self.own(a)?, dims_zero_based.as_ptr(), dims_zero_based.len(), 0, &mut out) })?;
             self.handle(out)
         })
     }

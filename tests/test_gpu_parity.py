@@ -931,3 +931,18 @@ def test_stochastic_evolution_reference_tests(prov, oracle):
     st = prov.get_rng_state()
     same = prov.download(prov.stochastic_evolution(h, 0.1, 0.3, 0))  # steps == 0: unchanged, nothing drawn
     assert np.array_equal(same, [1.0, 2.0]) and prov.get_rng_state() == st
+
+
+@pytest.mark.parametrize("shape,dims", [((6, 5, 4), [1, 2]), ((6, 5, 4), [0, 2]), ((3, 64, 48), [1, 2]), ((7, 9), [0, 1]),
+                                        ((8, 16, 16), [2, 1, 1, 7])])
+def test_reduce_mean_nd_vs_cpu_order(prov, oracle, shape, dims):
+    """mean(x, vecdim): the CPU takes the dims one after the other in ascending order (mean.rs:1107-1116)."""
+    x = np.random.default_rng(sum(shape)).uniform(-1, 1, shape)
+    got = prov.download(prov.reduce_mean_nd(prov.upload(x), dims))
+    want = x
+    for d in sorted({d for d in dims if d < x.ndim}):
+        want = oracle.reduce_sum(want, [d], mean=True)
+    assert got.shape[0] == want.size
+    assert np.max(np.abs(got - want.reshape(-1, order="F"))) <= 8 * EPS
+    with pytest.raises(Exception):
+        prov.reduce_mean_nd(prov.upload(x), [17])  # nd.rs:69-72: no valid dims
