@@ -227,8 +227,13 @@ typedef struct rmhip_linsolve_options {
 } rmhip_linsolve_options_t;
 RMHIP_API int rmhip_linsolve(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, const rmhip_linsolve_options_t* opts,
                              rmhip_buf* out, double* reciprocal_condition);
-/* `transpose` (lib.rs `fn transpose`): out[j,i] = a[i,j] for a 2-D tensor, new buffer [cols, rows]. */
+/* `transpose` (lib.rs:2532): out[j,i] = a[i,j] for a 2-D tensor, shape [cols, rows].  Like the reference's wgpu
+ * provider (ops/tensor.rs:828-846, `record_handle_transpose` lib.rs:218-245) the result is a VIEW that aliases the
+ * operand's storage: rmhip_matmul / rmhip_syrk read it in place through transposed-operand MFMA kernels (`A'*B`,
+ * `A*B'`), every other entry point sees a materialised copy on first use (one 64x64-tile LDS transpose pass). */
 RMHIP_API int rmhip_transpose(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out);
+/* `syrk` (lib.rs:2383): A' * A (cols x cols), reference loop accelerate/tests/syrk.rs:14-31. */
+RMHIP_API int rmhip_syrk(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out);
 
 /* ---- block-level building blocks for the multi-GPU solver ------------------------------------ *
  * A distributed (block-column cyclic) A\b has no counterpart in the reference (it has no multi-device

@@ -214,6 +214,11 @@ public:
         check(rmhip_linsolve(ctx_, own(lhs), own(rhs), &opts, &out, &rcond));
         return {with_shape(out), rcond};
     }
+    GpuTensorHandle syrk(const GpuTensorHandle& a) const {  // lib.rs:2383: A' * A
+        uint64_t out = 0;
+        check(rmhip_syrk(ctx_, own(a), &out));
+        return with_shape(out);
+    }
     GpuTensorHandle transpose(const GpuTensorHandle& a) const {
         uint64_t out = 0;
         check(rmhip_transpose(ctx_, own(a), &out));

@@ -588,6 +588,21 @@ ORC_API int orc_linsolve_tri(int lower, const double* T, size_t n, const double*
     return 0;
 }
 
+/* syrk: A' * A, the reference's own CPU comparator crates/runmat-accelerate/tests/syrk.rs:14-31
+ * (upper triangle accumulated over k in order, unfused, mirrored into the lower triangle). */
+ORC_API void orc_syrk(const double* a, size_t rows, size_t cols, double* out) {
+    for (size_t col = 0; col < cols; ++col)
+        for (size_t row = 0; row <= col; ++row) {
+            double acc = 0.0;
+            for (size_t k = 0; k < rows; ++k) {
+                double lhs = a[k + row * rows], rhs = a[k + col * rows];
+                acc += lhs * rhs;
+            }
+            out[row + col * cols] = acc;
+            if (row != col) out[col + row * cols] = acc;
+        }
+}
+
 /* transpose_tensor, linsolve.rs:1067-1077 */
 ORC_API void orc_transpose(const double* A, size_t rows, size_t cols, double* out) {
     for (size_t r = 0; r < rows; ++r)

@@ -70,6 +70,8 @@ def lib() -> C.CDLL:
         l.orc_stochastic_evolution.argtypes = [C.POINTER(C.c_uint64), _DP, C.c_size_t, C.c_double, C.c_double, C.c_uint32]
         l.orc_linsolve_tri.restype = C.c_int
         l.orc_linsolve_tri.argtypes = [C.c_int, _DP, C.c_size_t, _DP, C.c_size_t, _DP, _DP]
+        l.orc_syrk.restype = None
+        l.orc_syrk.argtypes = [_DP, C.c_size_t, C.c_size_t, _DP]
         l.orc_transpose.restype = None
         l.orc_transpose.argtypes = [_DP, C.c_size_t, C.c_size_t, _DP]
         l.orc_sin_mul_add.restype = C.c_int
@@ -255,6 +257,13 @@ def stochastic_evolution(state: int, data, drift: float, scale: float, steps: in
     if rc:
         raise MemoryError("orc_stochastic_evolution")
     return flat.reshape(a.shape, order="F"), st.value
+
+
+def syrk(a: np.ndarray) -> np.ndarray:
+    a = np.asarray(a, dtype=np.float64)
+    out = np.empty(a.shape[1] * a.shape[1])
+    lib().orc_syrk(_p(_f(a)), a.shape[0], a.shape[1], _p(out))
+    return out.reshape((a.shape[1], a.shape[1]), order="F")
 
 
 def transpose(a: np.ndarray) -> np.ndarray:

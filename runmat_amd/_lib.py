@@ -104,6 +104,7 @@ SIGNATURES = {
     "rmhip_mldivide": (C.c_int, [_P, _BUF, _BUF, _BUFP]),
     "rmhip_linsolve": (C.c_int, [_P, _BUF, _BUF, C.POINTER(LinsolveOptions), _BUFP, _DP]),
     "rmhip_transpose": (C.c_int, [_P, _BUF, _BUFP]),
+    "rmhip_syrk": (C.c_int, [_P, _BUF, _BUFP]),
     "rmhip_blk_copy": (C.c_int, [_P, C.POINTER(View), _BUFP]),
     "rmhip_blk_assign": (C.c_int, [_P, C.POINTER(View), _BUF]),
     "rmhip_blk_gemm": (C.c_int, [_P, C.c_double, C.POINTER(View), C.POINTER(View), C.c_double, C.POINTER(View)]),

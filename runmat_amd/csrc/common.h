@@ -53,6 +53,11 @@ struct Buffer {
     std::shared_ptr<Allocation> alloc;
     std::vector<size_t> shape;
     size_t numel = 0;
+    // Lazy transpose view (`transpose`, lib.rs:2532; the reference's wgpu provider does the same with
+    // `record_handle_transpose`, ops/tensor.rs:828-846): `shape` is the LOGICAL [R, C] but the storage still holds
+    // the base matrix C x R (column-major, leading dimension C).  matmul / syrk consume views in place through the
+    // transposed-operand dgemm variants; every other consumer sees a materialised copy (Context::get).
+    bool tview = false;
     double* data() const { return alloc ? alloc->ptr : nullptr; }
 };
 
@@ -108,7 +113,8 @@ struct Context {
     void release_device(double* ptr, size_t bytes);
     int new_buffer(const size_t* shape, size_t rank, uint64_t* id, Buffer* out);
     int register_buffer(Buffer&& b, uint64_t* id);
-    int get(uint64_t id, Buffer* out);  // copies the (small) Buffer record under the lock
+    int get(uint64_t id, Buffer* out);       // copies the (small) Buffer record under the lock; materialises a transpose view
+    int get_view(uint64_t id, Buffer* out);  // the raw record: `tview` may be set
     int ensure_scratch(size_t bytes);
 };
 
@@ -171,6 +177,8 @@ struct GemmEpilogue {
 };
 enum { EP_ACTIVE = 1, EP_ROW = 2, EP_ROW_DIV = 4, EP_COL = 8, EP_COL_DIV = 16, EP_CLAMP_MIN = 32, EP_CLAMP_MAX = 64,
        EP_POW = 128, EP_DIAG = 256 };
+int launch_dgemm_trans(Context* c, bool ta, bool tb, size_t m, size_t n, size_t k, double alpha, const double* A, size_t lda,
+                       const double* B, size_t ldb, double beta, double* C, size_t ldc);
 int launch_dgemm_epilogue(Context* c, size_t m, size_t n, size_t k, const double* A, size_t lda, const double* B,
                           size_t ldb, double* C, size_t ldc, const GemmEpilogue& ep);
 

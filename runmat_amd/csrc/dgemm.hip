@@ -41,6 +41,7 @@ static constexpr int SB = BK + 2;   // B tile row stride in doubles ([n][k])
 static constexpr int A_TILE = BK * SA;  // doubles
 static constexpr int B_TILE = BN * SB;
 static constexpr int GROUP_M = 8;
+static_assert(A_TILE == B_TILE, "the transposed-operand variants swap the two staging patterns between the tiles");
 
 struct GemmArgs {
     const double* A;
@@ -53,6 +54,10 @@ struct GemmArgs {
     int rowmap;  // accumulator row formula selector (see store code)
     int vec_a, vec_b;  // EDGE kernel: 16-byte loads are legal for A / B (aligned base, even leading dimension)
     GemmEpilogue ep;   // matmul_epilogue: flags == 0 for plain GEMM
+    // split-K (few output tiles, long k): blockIdx.y owns k in [y*k_chunk, min(k, (y+1)*k_chunk)) and writes its
+    // partial product (alpha = 1, beta = 0) to C + y*c_split_stride; k_reduce_splits adds them in order.
+    unsigned k_chunk;
+    unsigned long long c_split_stride;
 };
 
 // MatmulEpilogue on one output element, order of crates/runmat-accelerate/src/simple_provider.rs:7800-7836
@@ -84,15 +89,21 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs& g, unsigned& tm, u
     tn = in_group / gsz;
 }
 
-// EDGE = false: m % 128 == 0, n % 128 == 0, k % 16 == 0, lda/ldb even, 16-byte aligned bases.
+// EDGE = false: m % 128 == 0, n % 128 == 0, k % 16 == 0, even leading dimensions, 16-byte aligned bases.
 // EPI = true: the MatmulEpilogue variant.  It is a SEPARATE instantiation on purpose: inlining the
 // epilogue (pow!) into the plain kernel cost 2.7x (66.8 -> 24.8 TFLOP/s) -- waves in the bloated
 // store phase evicted the main loop of their CU pair's instruction cache.
-template <bool EDGE, bool EPI>
+// TA / TB: the operand is given TRANSPOSED in memory (op(A) = At', At is k x m with k contiguous; op(B) =
+// Bt', Bt is n x k with n contiguous) -- RunMat's transpose views (`handle_transpose_info`, lib.rs:218-245;
+// `A'*B`, `syrk`).  A transposed A has exactly the memory pattern of a plain B (k contiguous per tile row)
+// and vice versa, so the two staging patterns below simply swap roles and the LDS tiles keep their sizes:
+//   pattern M: 128 tile rows contiguous in memory, LDS [k][x] with row stride SA   (A plain, B transposed)
+//   pattern K: k contiguous in memory,            LDS [y][k] with row stride SB   (B plain, A transposed)
+template <bool EDGE, bool EPI, bool TA, bool TB>
 __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* As = lds;                    // [2][BK][SA]
-    double* Bs = lds + 2 * A_TILE;       // [2][BN][SB]
+    double* As = lds;                    // [2][A_TILE]
+    double* Bs = lds + 2 * A_TILE;       // [2][B_TILE]   (A_TILE == B_TILE)
 
     unsigned tm, tn;
     tile_of_block(g, tm, tn);
@@ -101,67 +112,86 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int l15 = lane & 15, lq = lane >> 4;
+    // this block's k range (the whole k unless the launch is split)
+    const unsigned kbeg = blockIdx.y * g.k_chunk;
+    const unsigned klen = (g.k - kbeg) < g.k_chunk ? (g.k - kbeg) : g.k_chunk;
+    const double* const Ab = TA ? g.A + kbeg : g.A + (size_t)kbeg * g.lda;
+    const double* const Bb = TB ? g.B + (size_t)kbeg * g.ldb : g.B + kbeg;
+    double* const Cb = g.C + (size_t)blockIdx.y * g.c_split_stride;
 
     // staging assignment
-    const int a_mp = t & 63;   // m pair index (m = 2*a_mp)
-    const int a_kc = t >> 6;   // 0..3, k = a_kc + 4*p
-    const int b_kp = t & 7;    // k pair index (k = 2*b_kp)
-    const int b_n = t >> 3;    // 0..31, n = b_n + 32*p
-
-    const double* Ag = g.A + (size_t)m0 + 2 * a_mp;
-    const double* Bg = g.B + (size_t)(n0 + b_n) * g.ldb + 2 * b_kp;
+    const int p_xp = t & 63;   // pattern M: pair index along the contiguous tile dimension (x = 2*p_xp)
+    const int p_kc = t >> 6;   //            0..3, k = p_kc + 4*p
+    const int q_kp = t & 7;    // pattern K: k pair index (k = 2*q_kp)
+    const int q_y = t >> 3;    //            0..31, y = q_y + 32*p
 
     v2d ra[4], rb[4];
 
-    auto fetch = [&](unsigned k0) {
+    // pattern M fetch: element (x, kk) = ptr[x + kk * ld]
+    auto fetchM = [&](const double* ptr, unsigned long long ld, unsigned x0, unsigned xlim, unsigned k0, int vec, v2d* r) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const unsigned kk = k0 + a_kc + 4 * p;
+            const unsigned kk = k0 + p_kc + 4 * p;
+            const unsigned xx = x0 + 2 * p_xp;
             if (!EDGE) {
-                ra[p] = *(const v2d*)(Ag + (size_t)kk * g.lda);
+                r[p] = *(const v2d*)(ptr + (size_t)kk * ld + xx);
             } else {
-                const unsigned mm = m0 + 2 * a_mp;
                 v2d v = {0.0, 0.0};
-                if (kk < g.k) {
-                    const double* src = g.A + (size_t)kk * g.lda + mm;
-                    if (g.vec_a && mm + 1 < g.m) {
+                if (kk < klen) {
+                    const double* src = ptr + (size_t)kk * ld + xx;
+                    if (vec && xx + 1 < xlim) {
                         v = *(const v2d*)src;
                     } else {
-                        if (mm < g.m) v.x = src[0];
-                        if (mm + 1 < g.m) v.y = src[1];
+                        if (xx < xlim) v.x = src[0];
+                        if (xx + 1 < xlim) v.y = src[1];
                     }
                 }
-                ra[p] = v;
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            if (!EDGE) {
-                rb[p] = *(const v2d*)(Bg + (size_t)(32 * p) * g.ldb + k0);
-            } else {
-                const unsigned nn = n0 + b_n + 32 * p;
-                const unsigned kk = k0 + 2 * b_kp;
-                v2d v = {0.0, 0.0};
-                if (nn < g.n) {
-                    const double* src = g.B + (size_t)nn * g.ldb + kk;
-                    if (g.vec_b && kk + 1 < g.k) {
-                        v = *(const v2d*)src;
-                    } else {
-                        if (kk < g.k) v.x = src[0];
-                        if (kk + 1 < g.k) v.y = src[1];
-                    }
-                }
-                rb[p] = v;
+                r[p] = v;
             }
         }
     };
+    // pattern K fetch: element (y, kk) = ptr[y * ld + kk]
+    auto fetchK = [&](const double* ptr, unsigned long long ld, unsigned y0, unsigned ylim, unsigned k0, int vec, v2d* r) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const unsigned yy = y0 + q_y + 32 * p;
+            const unsigned kk = k0 + 2 * q_kp;
+            if (!EDGE) {
+                r[p] = *(const v2d*)(ptr + (size_t)yy * ld + kk);
+            } else {
+                v2d v = {0.0, 0.0};
+                if (yy < ylim) {
+                    const double* src = ptr + (size_t)yy * ld + kk;
+                    if (vec && kk + 1 < klen) {
+                        v = *(const v2d*)src;
+                    } else {
+                        if (kk < klen) v.x = src[0];
+                        if (kk + 1 < klen) v.y = src[1];
+                    }
+                }
+                r[p] = v;
+            }
+        }
+    };
+    auto stashM = [&](double* tile, const v2d* r) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *(v2d*)(tile + (p_kc + 4 * p) * SA + 2 * p_xp) = r[p];
+    };
+    auto stashK = [&](double* tile, const v2d* r) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *(v2d*)(tile + (q_y + 32 * p) * SB + 2 * q_kp) = r[p];
+    };
+    auto fetch = [&](unsigned k0) {
+        if (TA) fetchK(Ab, g.lda, m0, g.m, k0, g.vec_a, ra);
+        else fetchM(Ab, g.lda, m0, g.m, k0, g.vec_a, ra);
+        if (TB) fetchM(Bb, g.ldb, n0, g.n, k0, g.vec_b, rb);
+        else fetchK(Bb, g.ldb, n0, g.n, k0, g.vec_b, rb);
+    };
     auto stash = [&](int buf) {
-        double* a = As + buf * A_TILE;
-        double* b = Bs + buf * B_TILE;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) *(v2d*)(a + (a_kc + 4 * p) * SA + 2 * a_mp) = ra[p];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) *(v2d*)(b + (b_n + 32 * p) * SB + 2 * b_kp) = rb[p];
+        if (TA) stashK(As + buf * A_TILE, ra);
+        else stashM(As + buf * A_TILE, ra);
+        if (TB) stashM(Bs + buf * B_TILE, rb);
+        else stashK(Bs + buf * B_TILE, rb);
     };
 
     v4d acc[4][4];  // [tj (n)][ti (m)]
@@ -170,13 +200,16 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = v4d{0.0, 0.0, 0.0, 0.0};
 
-    const unsigned ktiles = (g.k + BK - 1) / BK;
+    const unsigned ktiles = (klen + BK - 1) / BK;
     fetch(0);
     stash(0);
     __syncthreads();
 
-    const int a_off = lq * SA + wm * 64 + l15;        // + kk*4*SA + ti*16
-    const int b_off = (wn * 64 + l15) * SB + lq;      // + tj*16*SB + kk*4
+    // fragment addressing: pattern M tiles are read [k][x], pattern K tiles [y][k]
+    const int a_off = TA ? (wm * 64 + l15) * SB + lq : lq * SA + wm * 64 + l15;
+    const int b_off = TB ? lq * SA + wn * 64 + l15 : (wn * 64 + l15) * SB + lq;
+    constexpr int A_KSTEP = TA ? 4 : 4 * SA, A_ISTEP = TA ? 16 * SB : 16;
+    constexpr int B_KSTEP = TB ? 4 * SA : 4, B_JSTEP = TB ? 16 : 16 * SB;
 
     for (unsigned kt = 0; kt < ktiles; ++kt) {
         const int cur = kt & 1;
@@ -187,9 +220,9 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
         for (int kk = 0; kk < BK / 4; ++kk) {
             double af[4], bf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = a[kk * 4 * SA + i * 16];
+            for (int i = 0; i < 4; ++i) af[i] = a[kk * A_KSTEP + i * A_ISTEP];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = b[j * 16 * SB + kk * 4];
+            for (int j = 0; j < 4; ++j) bf[j] = b[j * B_JSTEP + kk * B_KSTEP];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -219,7 +252,7 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
                 const unsigned row = g.rowmap ? (4 * lq + r) : (4 * r + lq);
                 const unsigned nn = n0 + wn * 64 + j * 16 + row;
                 ok[i * 4 + r] = !EDGE || (mm < g.m && nn < g.n);
-                dst[i * 4 + r] = g.C + (size_t)nn * g.ldc + mm;
+                dst[i * 4 + r] = Cb + (size_t)nn * g.ldc + mm;
             }
         }
         if (!EPI && g.beta != 0.0) {
@@ -250,20 +283,53 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
 static int g_rowmap = -1;
 
 static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double alpha, const double* A, size_t lda,
-                             const double* B, size_t ldb, double beta, double* C, size_t ldc, const GemmEpilogue* ep);
+                             const double* B, size_t ldb, double beta, double* C, size_t ldc, const GemmEpilogue* ep,
+                             bool ta, bool tb);
 
 int launch_dgemm(Context* c, size_t m, size_t n, size_t k, double alpha, const double* A, size_t lda,
                  const double* B, size_t ldb, double beta, double* C, size_t ldc) {
-    return launch_dgemm_impl(c, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, nullptr);
+    return launch_dgemm_impl(c, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, false, false);
 }
 
 int launch_dgemm_epilogue(Context* c, size_t m, size_t n, size_t k, const double* A, size_t lda, const double* B,
                           size_t ldb, double* C, size_t ldc, const GemmEpilogue& ep) {
-    return launch_dgemm_impl(c, m, n, k, 1.0, A, lda, B, ldb, 0.0, C, ldc, &ep);
+    return launch_dgemm_impl(c, m, n, k, 1.0, A, lda, B, ldb, 0.0, C, ldc, &ep, false, false);
+}
+
+// C (m x n) = alpha * op(A) * op(B) + beta * C with op(X) = X' when tX: A is then stored k x m (lda >= k),
+// B stored n x k (ldb >= n).  Both transposed at once is not instantiated (callers materialise one operand).
+int launch_dgemm_trans(Context* c, bool ta, bool tb, size_t m, size_t n, size_t k, double alpha, const double* A, size_t lda,
+                       const double* B, size_t ldb, double beta, double* C, size_t ldc) {
+    if (ta && tb) return fail(RMHIP_ERR_UNSUPPORTED, "dgemm: A' * B' is not instantiated");
+    return launch_dgemm_impl(c, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, ta, tb);
+}
+
+template <bool EDGE, bool EPI, bool TA, bool TB>
+static void launch_variant(Context* c, unsigned blocks, unsigned splits, size_t lds_bytes, size_t max_lds, const GemmArgs& g) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_dgemm<EDGE, EPI, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_dgemm<EDGE, EPI, TA, TB>), dim3(blocks, splits), dim3(256), lds_bytes, c->stream, g);
+}
+
+// C = alpha * (P_0 + P_1 + ... + P_{S-1}) + beta * C, partials m x n dense (ld m), summed in split order
+__global__ void __launch_bounds__(256) k_reduce_splits(const double* __restrict__ P, size_t mn, size_t m, unsigned splits,
+                                                       double alpha, double beta, double* __restrict__ C, size_t ldc) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += (size_t)gridDim.x * 256) {
+        double s = P[i];
+        for (unsigned z = 1; z < splits; ++z) s += P[i + (size_t)z * mn];
+        double* dst = C + (i % m) + (i / m) * ldc;
+        double v = alpha * s;
+        if (beta != 0.0) v = beta * (*dst) + v;
+        *dst = v;
+    }
 }
 
 static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double alpha, const double* A, size_t lda,
-                             const double* B, size_t ldb, double beta, double* C, size_t ldc, const GemmEpilogue* ep) {
+                             const double* B, size_t ldb, double beta, double* C, size_t ldc, const GemmEpilogue* ep,
+                             bool ta, bool tb) {
     if (m == 0 || n == 0) return RMHIP_OK;
     if (m > 0xffffffffULL || n > 0xffffffffULL || k > 0xffffffffULL)
         return fail(RMHIP_ERR_UNSUPPORTED, "dgemm: dimension exceeds 2^32");
@@ -295,23 +361,55 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
     const bool fast = (m % BM == 0) && (n % BN == 0) && (k % BK == 0) && k > 0 && (lda % 2 == 0) && (ldb % 2 == 0) &&
                       (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
     const unsigned blocks = g.tiles_m * g.tiles_n;
-    static bool attr_set = false;
     const size_t kMaxLds = 128 * 1024;  // room for the look-ahead pad
     if (lds_bytes > kMaxLds) return fail(RMHIP_ERR_INVALID, "dgemm: LDS pad too large");
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_dgemm<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-        (void)hipFuncSetAttribute((const void*)k_dgemm<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-        (void)hipFuncSetAttribute((const void*)k_dgemm<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-        attr_set = true;
+    // Split-K: few output tiles but a long k (A'*A of a tall matrix, dot-product-like shapes) would leave most CUs
+    // idle; give every CU about two blocks.  Chunks are multiples of 1024 so the unguarded kernel stays eligible.
+    unsigned splits = 1;
+    g.k_chunk = (unsigned)k;
+    g.c_split_stride = 0;
+    std::shared_ptr<Allocation> partials;
+    if (!ep && blocks * 4 <= (unsigned)c->num_cus && k >= 8192) {
+        const size_t want = (2 * (size_t)c->num_cus + blocks - 1) / blocks;
+        size_t chunk = (k + want - 1) / want;
+        chunk = ((chunk + 1023) / 1024) * 1024;
+        splits = (unsigned)((k + chunk - 1) / chunk);
+        if (splits > 1) {
+            RMHIP_TRY(c->alloc_device((size_t)splits * m * n, &partials));
+            g.k_chunk = (unsigned)chunk;
+            g.C = partials->ptr;
+            g.ldc = m;
+            g.c_split_stride = (unsigned long long)m * n;
+            g.alpha = 1.0;
+            g.beta = 0.0;
+        } else {
+            splits = 1;
+        }
     }
-    if (ep)
-        hipLaunchKernelGGL((k_dgemm<true, true>), dim3(blocks), dim3(256), lds_bytes, c->stream, g);
-    else if (fast)
-        hipLaunchKernelGGL((k_dgemm<false, false>), dim3(blocks), dim3(256), lds_bytes, c->stream, g);
-    else
-        hipLaunchKernelGGL((k_dgemm<true, false>), dim3(blocks), dim3(256), lds_bytes, c->stream, g);
+    const bool fast_k = fast && (splits == 1 || k % g.k_chunk == 0);
+    if (ep) {
+        if (ta || tb) return fail(RMHIP_ERR_UNSUPPORTED, "dgemm: epilogue with transposed operands is not instantiated");
+        launch_variant<true, true, false, false>(c, blocks, splits, lds_bytes, kMaxLds, g);
+    } else if (ta) {
+        if (fast_k) launch_variant<false, false, true, false>(c, blocks, splits, lds_bytes, kMaxLds, g);
+        else launch_variant<true, false, true, false>(c, blocks, splits, lds_bytes, kMaxLds, g);
+    } else if (tb) {
+        if (fast_k) launch_variant<false, false, false, true>(c, blocks, splits, lds_bytes, kMaxLds, g);
+        else launch_variant<true, false, false, true>(c, blocks, splits, lds_bytes, kMaxLds, g);
+    } else {
+        if (fast_k) launch_variant<false, false, false, false>(c, blocks, splits, lds_bytes, kMaxLds, g);
+        else launch_variant<true, false, false, false>(c, blocks, splits, lds_bytes, kMaxLds, g);
+    }
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
+    if (splits > 1) {
+        const size_t mn = m * n;
+        const unsigned rgrid = (unsigned)((mn + 255) / 256 < (size_t)c->num_cus * 4 ? (mn + 255) / 256 : (size_t)c->num_cus * 4);
+        hipLaunchKernelGGL(k_reduce_splits, dim3(rgrid), dim3(256), 0, c->stream, partials->ptr, mn, m, splits, alpha, beta, C,
+                           ldc);
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+    }
     return RMHIP_OK;
 }
 

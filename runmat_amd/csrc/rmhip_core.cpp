@@ -127,11 +127,32 @@ int Context::new_buffer(const size_t* shape, size_t rank, uint64_t* id, Buffer* 
     return register_buffer(std::move(b), id);
 }
 
-int Context::get(uint64_t id, Buffer* out) {
+int Context::get_view(uint64_t id, Buffer* out) {
     std::lock_guard<std::mutex> lk(mu);
     auto it = table.find(id);
     if (it == table.end()) return fail(RMHIP_ERR_NOT_FOUND, "buffer not found: %llu", (unsigned long long)id);
     *out = it->second;
+    return RMHIP_OK;
+}
+
+int Context::get(uint64_t id, Buffer* out) {
+    RMHIP_TRY(get_view(id, out));
+    if (!out->tview) return RMHIP_OK;
+    // a consumer that cannot address a transposed operand: materialise once and keep the plain copy under this id
+    const size_t R = out->shape[0], C = out->shape[1];  // logical R x C, storage = base C x R
+    std::shared_ptr<Allocation> fresh;
+    RMHIP_TRY(alloc_device(out->numel ? out->numel : 1, &fresh));
+    RMHIP_TRY(transpose_device(this, out->data(), C, C, R, fresh->ptr, R));
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = table.find(id);
+        if (it != table.end() && it->second.tview && it->second.alloc == out->alloc) {
+            it->second.alloc = fresh;
+            it->second.tview = false;
+        }
+    }
+    out->alloc = fresh;
+    out->tview = false;
     return RMHIP_OK;
 }
 
@@ -312,7 +333,7 @@ int rmhip_shape(rmhip_ctx* ctx, rmhip_buf id, size_t* rank_inout, size_t* shape_
     CTX_OR_FAIL(ctx);
     if (!rank_inout) return fail(RMHIP_ERR_INVALID, "null rank");
     Buffer b;
-    RMHIP_TRY(c->get(id, &b));
+    RMHIP_TRY(c->get_view(id, &b));
     if (*rank_inout < b.shape.size() || !shape_out) {
         *rank_inout = b.shape.size();
         return shape_out ? fail(RMHIP_ERR_INVALID, "shape buffer too small") : RMHIP_OK;
@@ -325,7 +346,7 @@ int rmhip_shape(rmhip_ctx* ctx, rmhip_buf id, size_t* rank_inout, size_t* shape_
 int rmhip_numel(rmhip_ctx* ctx, rmhip_buf id, size_t* out) {
     CTX_OR_FAIL(ctx);
     Buffer b;
-    RMHIP_TRY(c->get(id, &b));
+    RMHIP_TRY(c->get_view(id, &b));
     *out = b.numel;
     return RMHIP_OK;
 }

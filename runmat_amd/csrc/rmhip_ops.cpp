@@ -504,8 +504,10 @@ int rmhip_matmul(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
     ScopedTimer timer(&c->tel.matmul_count, &c->tel.matmul_ns);
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     Buffer ab, bb, ob;
-    RMHIP_TRY(c->get(a, &ab));
-    RMHIP_TRY(c->get(b, &bb));
+    // transpose views are consumed in place (A'*B, A*B'); with both operands transposed B is materialised
+    RMHIP_TRY(c->get_view(a, &ab));
+    RMHIP_TRY(c->get_view(b, &bb));
+    if (ab.tview && bb.tview) RMHIP_TRY(c->get(b, &bb));
     if (ab.shape.size() != 2 || bb.shape.size() != 2) return fail(RMHIP_ERR_UNSUPPORTED, "matmul: only 2D supported");  // simple_provider.rs:7705
     const size_t m = ab.shape[0], k = ab.shape[1], kb = bb.shape[0], n = bb.shape[1];
     if (k != kb) return fail(RMHIP_ERR_SHAPE, "matmul: inner dims must agree (%zux%zu * %zux%zu)", m, k, kb, n);
@@ -513,7 +515,28 @@ int rmhip_matmul(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
     RMHIP_TRY(c->new_buffer(oshape, 2, out, &ob));
     int rc = RMHIP_OK;
     if (k == 0) rc = launch_fill(c, ob.data(), ob.numel, 0.0);
+    else if (ab.tview || bb.tview)  // storage: A' is k x m (ld k), B' is n x k (ld n)
+        rc = launch_dgemm_trans(c, ab.tview, bb.tview, m, n, k, 1.0, ab.data(), ab.tview ? k : m, bb.data(), bb.tview ? n : k,
+                                0.0, ob.data(), m);
     else rc = launch_dgemm(c, m, n, k, 1.0, ab.data(), m, bb.data(), k, 0.0, ob.data(), m);
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+
+int rmhip_syrk(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    ScopedTimer timer(&c->tel.matmul_count, &c->tel.matmul_ns);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer ab, ob;
+    RMHIP_TRY(c->get(a, &ab));
+    if (ab.shape.size() > 2) return fail(RMHIP_ERR_UNSUPPORTED, "syrk: only 2D supported");
+    const std::vector<size_t> as = normalize_matrix_shape(ab.shape);
+    const size_t rows = as[0], cols = as[1];
+    const size_t oshape[2] = {cols, cols};
+    RMHIP_TRY(c->new_buffer(oshape, 2, out, &ob));
+    int rc = RMHIP_OK;
+    if (rows == 0) rc = launch_fill(c, ob.data(), ob.numel, 0.0);
+    else rc = launch_dgemm_trans(c, true, false, cols, cols, rows, 1.0, ab.data(), rows, ab.data(), rows, 0.0, ob.data(), cols);
     if (rc) rmhip_free(ctx, *out);
     return rc;
 }
@@ -656,15 +679,23 @@ int rmhip_transpose(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     Buffer ab;
-    RMHIP_TRY(c->get(a, &ab));
+    RMHIP_TRY(c->get_view(a, &ab));
     if (ab.shape.size() > 2) return fail(RMHIP_ERR_UNSUPPORTED, "transpose: only 2D supported");
     const std::vector<size_t> as = normalize_matrix_shape(ab.shape);
-    const size_t oshape[2] = {as[1], as[0]};
-    Buffer ob;
-    RMHIP_TRY(c->new_buffer(oshape, 2, out, &ob));
-    int rc = transpose_device(c, ab.data(), as[0], as[0], as[1], ob.data(), as[1]);
-    if (rc) rmhip_free(ctx, *out);
-    return rc;
+    // No data moves: the result aliases the operand's storage as a transpose view (a view of a view is the plain
+    // base again; a vector's transpose has the same memory layout).  RMHIP_EAGER_TRANSPOSE=1 materialises at once.
+    Buffer r;
+    r.alloc = ab.alloc;
+    r.shape = {as[1], as[0]};
+    r.numel = ab.numel;
+    r.tview = (as[0] == 1 || as[1] == 1) ? false : !ab.tview;
+    RMHIP_TRY(c->register_buffer(std::move(r), out));
+    if (const char* e = std::getenv("RMHIP_EAGER_TRANSPOSE"))
+        if (e[0] == '1') {
+            Buffer tmp;
+            RMHIP_TRY(c->get(*out, &tmp));
+        }
+    return RMHIP_OK;
 }
 
 int rmhip_linsolve(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, const rmhip_linsolve_options_t* opts, rmhip_buf* out,

@@ -393,8 +393,15 @@ class HipProvider:
         return ProviderLinsolveResult(self._handle(out.value), rc.value)
 
     def transpose(self, a: GpuTensorHandle) -> GpuTensorHandle:
+        """lib.rs:2532: a view aliasing `a` (consumed in place by matmul / syrk, materialised on any other use)."""
         out = C.c_uint64()
         self._check(self._lib.rmhip_transpose(self._ctx, self._id(a), C.byref(out)))
+        return self._handle(out.value)
+
+    def syrk(self, a: GpuTensorHandle) -> GpuTensorHandle:
+        """lib.rs:2383: A' * A."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_syrk(self._ctx, self._id(a), C.byref(out)))
         return self._handle(out.value)
 
     # -- block-level building blocks (views; used by the multi-GPU solver, they mutate the buffer) ----

@@ -48,6 +48,7 @@ extern "C" {
     fn rmhip_mldivide(ctx: *mut RmhipCtx, a: u64, b: u64, out: *mut u64) -> c_int;
     fn rmhip_linsolve(ctx: *mut RmhipCtx, a: u64, b: u64, opts: *const RmhipLinsolveOptions, out: *mut u64, rcond: *mut c_double) -> c_int;
     fn rmhip_transpose(ctx: *mut RmhipCtx, a: u64, out: *mut u64) -> c_int;
+    fn rmhip_syrk(ctx: *mut RmhipCtx, a: u64, out: *mut u64) -> c_int;
     fn rmhip_set_rng_state(ctx: *mut RmhipCtx, state: u64) -> c_int;
     fn rmhip_stochastic_evolution(ctx: *mut RmhipCtx, state: u64, drift: c_double, scale: c_double, steps: u32, out: *mut u64) -> c_int;
     fn rmhip_random_normal(ctx: *mut RmhipCtx, shape: *const usize, rank: usize, out: *mut u64) -> c_int;
@@ -217,6 +218,13 @@ impl AccelProvider for HipProvider {
             Ok(ProviderLinsolveResult { solution: self.handle(out)?, reciprocal_condition: rcond })
         })
     }
+    fn syrk(&self, a: &GpuTensorHandle) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_syrk(self.ctx, self.own(a)?, &mut out) })?;
+        self.handle(out)
+    }
+    // The library keeps the transpose lazily (a view consumed in place by matmul / syrk); nothing to record on
+    // the Rust side, so `handle_transpose_info` stays empty for these handles and callers treat them as plain.
     fn transpose(&self, a: &GpuTensorHandle) -> Result<GpuTensorHandle> {
         let mut out = 0u64;
         check(unsafe { rmhip_transpose(self.ctx, self.own(a)?, &mut out) })?;

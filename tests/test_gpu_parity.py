@@ -946,3 +946,60 @@ def test_reduce_mean_nd_vs_cpu_order(prov, oracle, shape, dims):
     assert np.max(np.abs(got - want.reshape(-1, order="F"))) <= 8 * EPS
     with pytest.raises(Exception):
         prov.reduce_mean_nd(prov.upload(x), [17])  # nd.rs:69-72: no valid dims
+
+
+# ---- transpose views, A'*B / A*B', syrk ---------------------------------------------------------------
+def _gemm_tol(a, b, k):
+    return (k + 2) * EPS * np.max(np.abs(a) @ np.abs(b))
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 512), (5, 7, 3), (130, 257, 75), (1, 9, 33), (64, 1, 17), (300, 2, 1000)])
+def test_matmul_with_transpose_views(prov, oracle, m, n, k):
+    rng = np.random.default_rng(m * 31 + n * 7 + k)
+    At, B = rng.uniform(-1, 1, (k, m)), rng.uniform(-1, 1, (k, n))   # op(A) = At'
+    A, Bt = rng.uniform(-1, 1, (m, k)), rng.uniform(-1, 1, (n, k))   # op(B) = Bt'
+    hAt, hB, hA, hBt = prov.upload(At), prov.upload(B), prov.upload(A), prov.upload(Bt)
+    vA = prov.transpose(hAt)            # m x k view, no data moved
+    vB = prov.transpose(hBt)            # k x n view
+    assert vA.shape == (m, k) and vB.shape == (k, n)
+    tn = prov.download_matrix(prov.matmul(vA, hB))
+    assert np.max(np.abs(tn - oracle.matmul(At.T.copy(), B))) <= _gemm_tol(At.T, B, k)
+    nt = prov.download_matrix(prov.matmul(hA, vB))
+    assert np.max(np.abs(nt - oracle.matmul(A, Bt.T.copy()))) <= _gemm_tol(A, Bt.T, k)
+    tt = prov.download_matrix(prov.matmul(vA, prov.transpose(prov.upload(rng.uniform(-1, 1, (n, k))))))
+    assert tt.shape == (m, n)
+    # views read back as the transposed matrix, and a view of a view is the base again
+    assert bits_equal(prov.download_matrix(vA), At.T) and bits_equal(prov.download_matrix(prov.transpose(prov.transpose(hB))), B)
+    # other consumers see a materialised copy
+    assert bits_equal(prov.download_matrix(prov.unary_neg(prov.transpose(hBt))), -Bt.T)
+    assert bits_equal(prov.download_matrix(prov.elem_add(prov.transpose(hAt), hA)), At.T + A)
+
+
+@pytest.mark.parametrize("rows,cols", [(16, 5), (1000, 3), (257, 129), (128, 256), (4096, 64)])
+def test_syrk_vs_oracle(prov, oracle, rows, cols):
+    if (rows, cols) == (16, 5):  # accelerate/tests/syrk.rs:55-100 (tolerance there: 1e-9)
+        a = np.array([[r + 1 + 3 * c for c in range(cols)] for r in range(rows)], dtype=np.float64)
+    else:
+        a = np.random.default_rng(rows + cols).uniform(-1, 1, (rows, cols))
+    got = prov.download_matrix(prov.syrk(prov.upload(a)))
+    want = oracle.syrk(a)
+    assert got.shape == (cols, cols)
+    assert np.max(np.abs(got - want)) <= max(1e-9 if rows == 16 else 0.0, _gemm_tol(a.T, a, rows))
+    assert np.array_equal(got, got.T)  # commutative products, identical k order: exactly symmetric
+
+
+@pytest.mark.parametrize("m,n,k", [(130, 70, 20000), (128, 128, 16384), (1, 1, 100000), (256, 128, 9000)])
+def test_matmul_split_k(prov, oracle, m, n, k):
+    """Few output tiles and a long k run split over k with an ordered reduction of the partial products."""
+    rng = np.random.default_rng(k + m)
+    A, B = rng.uniform(-1, 1, (m, k)), rng.uniform(-1, 1, (k, n))
+    hA, hB = prov.upload(A), prov.upload(B)
+    got = prov.download_matrix(prov.matmul(hA, hB))
+    want = A @ B if m * n * k > 5e7 else oracle.matmul(A, B)   # the naive oracle loop is slow for the larger cases
+    assert np.max(np.abs(got - want)) <= _gemm_tol(A, B, k)
+    assert bits_equal(got, prov.download_matrix(prov.matmul(hA, hB)))  # fixed split count and order: deterministic
+    gt = prov.download_matrix(prov.matmul(prov.transpose(prov.upload(A.T.copy())), hB))  # A' view, split over k
+    assert np.max(np.abs(gt - want)) <= _gemm_tol(A, B, k)
+    if m == 130:
+        s = prov.download_matrix(prov.syrk(prov.upload(B)))       # 20000 x 70 -> 70 x 70
+        assert np.max(np.abs(s - B.T @ B)) <= _gemm_tol(B.T, B, k) and np.array_equal(s, s.T)

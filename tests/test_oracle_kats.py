@@ -366,3 +366,12 @@ def test_stochastic_evolution_kat(oracle):
     out3, st3 = oracle.stochastic_evolution(oracle.rng_default_seed(), np.array([[1.0], [2.0], [3.0]]), 0.05, 0.0, 4)
     assert np.max(np.abs(out3[:, 0] - np.array([1.0, 2.0, 3.0]) * np.exp(0.2))) < 1e-9
     assert st3 == oracle.rng_advance(oracle.rng_default_seed(), 4 * 4)  # odd length consumes whole pairs
+
+
+def test_syrk_kat(oracle):
+    # accelerate/tests/syrk.rs:55-100: data[r + c*rows] = r + 1 + 3c, 16 x 5, against A' * A
+    rows, cols = 16, 5
+    a = np.array([[r + 1 + 3 * c for c in range(cols)] for r in range(rows)], dtype=np.float64)
+    got = oracle.syrk(a)
+    assert got.shape == (cols, cols) and np.array_equal(got, a.T @ a)  # small integers: exact in any order
+    assert np.array_equal(got, got.T)
