@@ -204,6 +204,20 @@ typedef struct rmhip_matmul_epilogue {
 } rmhip_matmul_epilogue_t;
 RMHIP_API int rmhip_matmul_epilogue(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b,
                                     const rmhip_matmul_epilogue_t* ep, rmhip_buf* out);
+/* `matmul_power_step` + PowerStepEpilogue (lib.rs:2414-2421, 3553-3561; CPU semantics
+ * crates/runmat-accelerate/src/simple_provider.rs:7852-7891): P = lhs * rhs, then every column of P is divided by
+ * sqrt(sum(P(:,c).^2) + epsilon)  (the power-iteration step of the PCA benchmark). */
+RMHIP_API int rmhip_matmul_power_step(rmhip_ctx* ctx, rmhip_buf lhs, rmhip_buf rhs, double epsilon, rmhip_buf* out);
+/* `image_normalize` + ImageNormalizeDescriptor (lib.rs:2407-2413, 3563-3577; CPU semantics simple_provider.rs:7893-7993):
+ * input is [batch, height, width]; per batch element mean / two-pass variance over the plane, then
+ * y = (x - mean) / sqrt(var + epsilon) [* gain] [+ bias] [max 0] [^ gamma].  batch <= 256. */
+typedef struct rmhip_image_normalize {
+    size_t batch, height, width;
+    double epsilon;
+    int has_gain, has_bias, has_gamma, clamp_zero;
+    double gain, bias, gamma;
+} rmhip_image_normalize_t;
+RMHIP_API int rmhip_image_normalize(rmhip_ctx* ctx, rmhip_buf input, const rmhip_image_normalize_t* desc, rmhip_buf* out);
 /* `lu` -> ProviderLuResult {combined, lower, upper, perm_matrix, perm_vector} (lib.rs:649-698);
  * pivot rule and singular cut-off of host_lu.rs:37-59.  out5 order: combined, L, U, P, pivots. */
 RMHIP_API int rmhip_lu(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf out5[5]);

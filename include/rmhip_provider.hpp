@@ -214,6 +214,16 @@ public:
         check(rmhip_linsolve(ctx_, own(lhs), own(rhs), &opts, &out, &rcond));
         return {with_shape(out), rcond};
     }
+    GpuTensorHandle matmul_power_step(const GpuTensorHandle& lhs, const GpuTensorHandle& rhs, double epsilon) const {  // lib.rs:2414
+        uint64_t out = 0;
+        check(rmhip_matmul_power_step(ctx_, own(lhs), own(rhs), epsilon, &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle image_normalize(const GpuTensorHandle& input, const rmhip_image_normalize_t& desc) const {  // lib.rs:2407
+        uint64_t out = 0;
+        check(rmhip_image_normalize(ctx_, own(input), &desc, &out));
+        return make(out, input.shape);
+    }
     GpuTensorHandle syrk(const GpuTensorHandle& a) const {  // lib.rs:2383: A' * A
         uint64_t out = 0;
         check(rmhip_syrk(ctx_, own(a), &out));

@@ -588,6 +588,57 @@ ORC_API int orc_linsolve_tri(int lower, const double* T, size_t n, const double*
     return 0;
 }
 
+/* image_normalize: simple_provider.rs:7893-7993 == cpu_image_normalize (accelerate/tests/image_normalize.rs:7-66);
+ * data is [batch, height, width] column-major (batch fastest). */
+ORC_API void orc_image_normalize(const double* data, size_t batch, size_t height, size_t width, double epsilon, int has_gain,
+                                 double gain, int has_bias, double bias, int clamp_zero, int has_gamma, double gamma,
+                                 double* out) {
+    const size_t plane = height * width, stride_h = batch, stride_w = batch * height;
+    for (size_t b = 0; b < batch; ++b) {
+        double sum = 0.0;
+        for (size_t w = 0; w < width; ++w)
+            for (size_t h = 0; h < height; ++h) sum += data[b + h * stride_h + w * stride_w];
+        const double mean = sum / (double)plane;
+        double sq_sum = 0.0;
+        for (size_t w = 0; w < width; ++w)
+            for (size_t h = 0; h < height; ++h) {
+                double diff = data[b + h * stride_h + w * stride_w] - mean;
+                sq_sum += diff * diff;
+            }
+        const double variance = sq_sum / (double)plane;
+        const double sigma = sqrt(variance + epsilon);
+        const double inv_sigma = sigma > 0.0 ? 1.0 / sigma : 0.0;
+        for (size_t w = 0; w < width; ++w)
+            for (size_t h = 0; h < height; ++h) {
+                const size_t idx = b + h * stride_h + w * stride_w;
+                double value = (data[idx] - mean) * inv_sigma;
+                if (has_gain) value *= gain;
+                if (has_bias) value += bias;
+                if (clamp_zero) value = fmax(value, 0.0);
+                if (has_gamma) value = pow(value, gamma);
+                out[idx] = value;
+            }
+    }
+}
+
+/* matmul_power_step: simple_provider.rs:7852-7891 */
+ORC_API int orc_matmul_power_step(const double* a, size_t m, size_t k, const double* b, size_t kb, size_t n, double epsilon,
+                                  double* out) {
+    int rc = orc_matmul(a, m, k, b, kb, n, out);
+    if (rc) return rc;
+    for (size_t col = 0; col < n; ++col) {
+        double acc = 0.0;
+        for (size_t row = 0; row < m; ++row) {
+            double val = out[row + col * m];
+            acc += val * val;
+        }
+        acc += epsilon;
+        const double norm = sqrt(acc);
+        for (size_t row = 0; row < m; ++row) out[row + col * m] /= norm;
+    }
+    return 0;
+}
+
 /* syrk: A' * A, the reference's own CPU comparator crates/runmat-accelerate/tests/syrk.rs:14-31
  * (upper triangle accumulated over k in order, unfused, mirrored into the lower triangle). */
 ORC_API void orc_syrk(const double* a, size_t rows, size_t cols, double* out) {

@@ -70,6 +70,11 @@ def lib() -> C.CDLL:
         l.orc_stochastic_evolution.argtypes = [C.POINTER(C.c_uint64), _DP, C.c_size_t, C.c_double, C.c_double, C.c_uint32]
         l.orc_linsolve_tri.restype = C.c_int
         l.orc_linsolve_tri.argtypes = [C.c_int, _DP, C.c_size_t, _DP, C.c_size_t, _DP, _DP]
+        l.orc_image_normalize.restype = None
+        l.orc_image_normalize.argtypes = [_DP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.c_int, C.c_double, C.c_int,
+                                          C.c_double, C.c_int, C.c_int, C.c_double, _DP]
+        l.orc_matmul_power_step.restype = C.c_int
+        l.orc_matmul_power_step.argtypes = [_DP, C.c_size_t, C.c_size_t, _DP, C.c_size_t, C.c_size_t, C.c_double, _DP]
         l.orc_syrk.restype = None
         l.orc_syrk.argtypes = [_DP, C.c_size_t, C.c_size_t, _DP]
         l.orc_transpose.restype = None
@@ -257,6 +262,25 @@ def stochastic_evolution(state: int, data, drift: float, scale: float, steps: in
     if rc:
         raise MemoryError("orc_stochastic_evolution")
     return flat.reshape(a.shape, order="F"), st.value
+
+
+def image_normalize(x, epsilon, gain=None, bias=None, gamma=None, clamp_zero=True) -> np.ndarray:
+    x = np.asarray(x, dtype=np.float64)
+    b, h, w = x.shape
+    out = np.empty(x.size)
+    lib().orc_image_normalize(_p(_f(x)), b, h, w, epsilon, int(gain is not None), float(gain or 0.0), int(bias is not None),
+                              float(bias or 0.0), int(bool(clamp_zero)), int(gamma is not None), float(gamma or 0.0), _p(out))
+    return out.reshape(x.shape, order="F")
+
+
+def matmul_power_step(a, b, epsilon=0.0) -> np.ndarray:
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    out = np.empty(a.shape[0] * b.shape[1])
+    rc = lib().orc_matmul_power_step(_p(_f(a)), a.shape[0], a.shape[1], _p(_f(b)), b.shape[0], b.shape[1], epsilon, _p(out))
+    if rc:
+        raise ValueError("matmul_power_step: inner dims must agree")
+    return out.reshape((a.shape[0], b.shape[1]), order="F")
 
 
 def syrk(a: np.ndarray) -> np.ndarray:

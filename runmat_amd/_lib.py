@@ -54,6 +54,13 @@ class LinsolveOptions(C.Structure):
                                        "need_rcond", "has_rcond")] + [("rcond", C.c_double)]
 
 
+class ImageNormalize(C.Structure):
+    """rmhip_image_normalize_t (ImageNormalizeDescriptor, lib.rs:3563-3577)"""
+    _fields_ = [("batch", C.c_size_t), ("height", C.c_size_t), ("width", C.c_size_t), ("epsilon", C.c_double),
+                ("has_gain", C.c_int), ("has_bias", C.c_int), ("has_gamma", C.c_int), ("clamp_zero", C.c_int),
+                ("gain", C.c_double), ("bias", C.c_double), ("gamma", C.c_double)]
+
+
 class View(C.Structure):
     """rmhip_view_t: rows [row_off, row_off+rows) x cols [col_off, col_off+cols) of a 2-D buffer."""
     _fields_ = [("buf", C.c_uint64), ("row_off", C.c_size_t), ("col_off", C.c_size_t), ("rows", C.c_size_t),
@@ -105,6 +112,8 @@ SIGNATURES = {
     "rmhip_linsolve": (C.c_int, [_P, _BUF, _BUF, C.POINTER(LinsolveOptions), _BUFP, _DP]),
     "rmhip_transpose": (C.c_int, [_P, _BUF, _BUFP]),
     "rmhip_syrk": (C.c_int, [_P, _BUF, _BUFP]),
+    "rmhip_matmul_power_step": (C.c_int, [_P, _BUF, _BUF, C.c_double, _BUFP]),
+    "rmhip_image_normalize": (C.c_int, [_P, _BUF, C.POINTER(ImageNormalize), _BUFP]),
     "rmhip_blk_copy": (C.c_int, [_P, C.POINTER(View), _BUFP]),
     "rmhip_blk_assign": (C.c_int, [_P, C.POINTER(View), _BUF]),
     "rmhip_blk_gemm": (C.c_int, [_P, C.c_double, C.POINTER(View), C.POINTER(View), C.c_double, C.POINTER(View)]),

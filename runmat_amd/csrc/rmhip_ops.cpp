@@ -523,6 +523,40 @@ int rmhip_matmul(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
     return rc;
 }
 
+int rmhip_matmul_power_step(rmhip_ctx* ctx, rmhip_buf lhs, rmhip_buf rhs, double epsilon, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    // simple_provider.rs:7859-7884 composed from the provider's own ops: P = lhs*rhs; acc_c = sum_r P(r,c)^2 (+ eps);
+    // P(:,c) /= sqrt(acc_c).  The column sums run in the dot kernels (k_dot_*), the division in the broadcast kernel.
+    rmhip_buf p = 0, sq = 0, sq_eps = 0, norms = 0;
+    int rc = rmhip_matmul(ctx, lhs, rhs, &p);
+    if (!rc) rc = rmhip_dot(ctx, p, p, 0, &sq);
+    if (!rc) rc = rmhip_scalar(ctx, RMHIP_SADD, sq, epsilon, &sq_eps);
+    if (!rc) rc = rmhip_unary(ctx, RMHIP_SQRT, sq_eps, &norms);
+    if (!rc) rc = rmhip_binary(ctx, RMHIP_DIV, p, norms, out);
+    for (rmhip_buf t : {p, sq, sq_eps, norms})
+        if (t) rmhip_free(ctx, t);
+    return rc;
+}
+
+int rmhip_image_normalize(rmhip_ctx* ctx, rmhip_buf input, const rmhip_image_normalize_t* d, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out || !d) return fail(RMHIP_ERR_INVALID, "image_normalize: null argument");
+    if (!std::isfinite(d->epsilon)) return fail(RMHIP_ERR_INVALID, "image_normalize: epsilon must be finite");
+    if (d->epsilon < 0.0) return fail(RMHIP_ERR_INVALID, "image_normalize: epsilon must be non-negative");
+    Buffer ib, ob;
+    RMHIP_TRY(c->get(input, &ib));
+    if (ib.shape.size() != 3) return fail(RMHIP_ERR_SHAPE, "image_normalize: expected 3-D tensor, got rank %zu", ib.shape.size());
+    if (ib.shape[0] != d->batch || ib.shape[1] != d->height || ib.shape[2] != d->width)
+        return fail(RMHIP_ERR_SHAPE, "image_normalize: descriptor dims (%zu, %zu, %zu) do not match tensor shape (%zu, %zu, %zu)",
+                    d->batch, d->height, d->width, ib.shape[0], ib.shape[1], ib.shape[2]);
+    RMHIP_TRY(c->new_buffer(ib.shape.data(), 3, out, &ob));
+    int rc = image_normalize_device(c, ib.data(), ob.data(), d->batch, d->height, d->width, d->epsilon, d->has_gain, d->gain,
+                                    d->has_bias, d->bias, d->clamp_zero, d->has_gamma, d->gamma);
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+
 int rmhip_syrk(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);
     ScopedTimer timer(&c->tel.matmul_count, &c->tel.matmul_ns);

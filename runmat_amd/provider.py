@@ -398,6 +398,23 @@ class HipProvider:
         self._check(self._lib.rmhip_transpose(self._ctx, self._id(a), C.byref(out)))
         return self._handle(out.value)
 
+    def matmul_power_step(self, lhs: GpuTensorHandle, rhs: GpuTensorHandle, epsilon: float = 0.0) -> GpuTensorHandle:
+        """lib.rs:2414-2421 (PowerStepEpilogue.epsilon): lhs*rhs with every column divided by its 2-norm."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_matmul_power_step(self._ctx, self._id(lhs), self._id(rhs), float(epsilon), C.byref(out)))
+        return self._handle(out.value)
+
+    def image_normalize(self, x: GpuTensorHandle, batch: int, height: int, width: int, epsilon: float,
+                        gain: Optional[float] = None, bias: Optional[float] = None, gamma: Optional[float] = None,
+                        clamp_zero: bool = True) -> GpuTensorHandle:
+        """lib.rs:2407-2413 with the fields of ImageNormalizeDescriptor (lib.rs:3563-3577; clamp_zero defaults to true)."""
+        d = _lib.ImageNormalize(int(batch), int(height), int(width), float(epsilon), int(gain is not None), int(bias is not None),
+                                int(gamma is not None), int(bool(clamp_zero)), float(gain or 0.0), float(bias or 0.0),
+                                float(gamma or 0.0))
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_image_normalize(self._ctx, self._id(x), C.byref(d), C.byref(out)))
+        return self._handle(out.value, x.shape)
+
     def syrk(self, a: GpuTensorHandle) -> GpuTensorHandle:
         """lib.rs:2383: A' * A."""
         out = C.c_uint64()

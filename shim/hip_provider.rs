@@ -49,10 +49,19 @@ extern "C" {
     fn rmhip_linsolve(ctx: *mut RmhipCtx, a: u64, b: u64, opts: *const RmhipLinsolveOptions, out: *mut u64, rcond: *mut c_double) -> c_int;
     fn rmhip_transpose(ctx: *mut RmhipCtx, a: u64, out: *mut u64) -> c_int;
     fn rmhip_syrk(ctx: *mut RmhipCtx, a: u64, out: *mut u64) -> c_int;
+    fn rmhip_matmul_power_step(ctx: *mut RmhipCtx, lhs: u64, rhs: u64, epsilon: c_double, out: *mut u64) -> c_int;
+    fn rmhip_image_normalize(ctx: *mut RmhipCtx, input: u64, desc: *const RmhipImageNormalize, out: *mut u64) -> c_int;
     fn rmhip_set_rng_state(ctx: *mut RmhipCtx, state: u64) -> c_int;
     fn rmhip_stochastic_evolution(ctx: *mut RmhipCtx, state: u64, drift: c_double, scale: c_double, steps: u32, out: *mut u64) -> c_int;
     fn rmhip_random_normal(ctx: *mut RmhipCtx, shape: *const usize, rank: usize, out: *mut u64) -> c_int;
     fn rmhip_random_uniform(ctx: *mut RmhipCtx, shape: *const usize, rank: usize, out: *mut u64) -> c_int;
+}
+
+#[repr(C)]
+struct RmhipImageNormalize {
+    batch: usize, height: usize, width: usize, epsilon: c_double,
+    has_gain: c_int, has_bias: c_int, has_gamma: c_int, clamp_zero: c_int,
+    gain: c_double, bias: c_double, gamma: c_double,
 }
 
 #[repr(C)]
@@ -216,6 +225,24 @@ impl AccelProvider for HipProvider {
             let (mut out, mut rcond) = (0u64, f64::NAN);
             check(unsafe { rmhip_linsolve(self.ctx, self.own(lhs)?, self.own(rhs)?, &c, &mut out, &mut rcond) })?;
             Ok(ProviderLinsolveResult { solution: self.handle(out)?, reciprocal_condition: rcond })
+        })
+    }
+    fn matmul_power_step<'a>(&'a self, lhs: &'a GpuTensorHandle, rhs: &'a GpuTensorHandle, ep: &'a PowerStepEpilogue)
+        -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_matmul_power_step(self.ctx, self.own(lhs)?, self.own(rhs)?, ep.epsilon, &mut out) })?;
+            self.handle(out)
+        })
+    }
+    fn image_normalize<'a>(&'a self, input: &'a GpuTensorHandle, d: &'a ImageNormalizeDescriptor) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let c = RmhipImageNormalize { batch: d.batch, height: d.height, width: d.width, epsilon: d.epsilon,
+                has_gain: d.gain.is_some() as c_int, has_bias: d.bias.is_some() as c_int, has_gamma: d.gamma.is_some() as c_int,
+                clamp_zero: d.clamp_zero as c_int, gain: d.gain.unwrap_or(0.0), bias: d.bias.unwrap_or(0.0), gamma: d.gamma.unwrap_or(0.0) };
+            let mut out = 0u64;
+            check(unsafe { rmhip_image_normalize(self.ctx, self.own(input)?, &c, &mut out) })?;
+            self.handle(out)
         })
     }
     fn syrk(&self, a: &GpuTensorHandle) -> Result<GpuTensorHandle> {

@@ -1003,3 +1003,43 @@ def test_matmul_split_k(prov, oracle, m, n, k):
     if m == 130:
         s = prov.download_matrix(prov.syrk(prov.upload(B)))       # 20000 x 70 -> 70 x 70
         assert np.max(np.abs(s - B.T @ B)) <= _gemm_tol(B.T, B, k) and np.array_equal(s, s.T)
+
+
+# ---- special fusion-pattern hooks: image_normalize, matmul_power_step -----------------------------------
+@pytest.mark.parametrize("shape", [(3, 4, 5), (1, 7, 9), (16, 64, 48), (5, 33, 17), (256, 8, 8), (7, 1, 1)])
+@pytest.mark.parametrize("opts", [dict(gain=1.05, bias=-0.02, gamma=1.8, clamp_zero=True), dict(clamp_zero=False), dict(gain=2.0)])
+def test_image_normalize_vs_oracle(prov, oracle, shape, opts):
+    if shape == (3, 4, 5):  # accelerate/tests/image_normalize.rs:74-92
+        b, h, w = np.meshgrid(np.arange(3), np.arange(4), np.arange(5), indexing="ij")
+        x = b + 0.1 * h + 0.01 * w
+    else:
+        x = np.random.default_rng(sum(shape)).uniform(0.0, 1.0, shape)
+    got = prov.download(prov.image_normalize(prov.upload(x), *shape, 1e-6, **opts)).reshape(shape, order="F")
+    want = oracle.image_normalize(x, 1e-6, **opts)
+    # tolerance: the plane sums are tree-ordered here, sequential on the CPU; pow amplifies by gamma
+    assert np.max(np.abs(got - want)) <= 1e-12 * max(1.0, np.max(np.abs(want)))
+
+
+def test_image_normalize_errors_and_degenerate(prov):
+    from runmat_amd import ProviderError
+    h = prov.upload(np.ones((2, 3, 3)))
+    assert np.array_equal(prov.download(prov.image_normalize(h, 2, 3, 3, 0.0, clamp_zero=False)), np.zeros(18))  # sigma == 0
+    for bad in (dict(epsilon=float("nan")), dict(epsilon=-1.0)):
+        with pytest.raises(ProviderError):
+            prov.image_normalize(h, 2, 3, 3, bad["epsilon"])
+    with pytest.raises(ProviderError):
+        prov.image_normalize(h, 3, 3, 2, 1e-6)          # descriptor dims do not match
+    with pytest.raises(ProviderError):
+        prov.image_normalize(prov.upload(np.ones((4, 4))), 4, 4, 1, 1e-6)  # not 3-D
+    with pytest.raises(ProviderError):
+        prov.image_normalize(prov.upload(np.ones((300, 2, 2))), 300, 2, 2, 1e-6)  # batch > 256: CPU path
+
+
+@pytest.mark.parametrize("m,k,n", [(2, 2, 2), (64, 32, 8), (1000, 64, 5), (257, 129, 33)])
+def test_matmul_power_step_vs_oracle(prov, oracle, m, k, n):
+    rng = np.random.default_rng(m + k + n)
+    A, B = rng.uniform(-1, 1, (m, k)), rng.uniform(-1, 1, (k, n))
+    got = prov.download_matrix(prov.matmul_power_step(prov.upload(A), prov.upload(B), 1e-12))
+    want = oracle.matmul_power_step(A, B, 1e-12)
+    assert np.max(np.abs(got - want)) <= 64 * (k + m) * EPS
+    assert np.max(np.abs((got * got).sum(axis=0) - 1.0)) < 1e-9

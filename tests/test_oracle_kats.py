@@ -375,3 +375,29 @@ def test_syrk_kat(oracle):
     got = oracle.syrk(a)
     assert got.shape == (cols, cols) and np.array_equal(got, a.T @ a)  # small integers: exact in any order
     assert np.array_equal(got, got.T)
+
+
+def _image_case():
+    # accelerate/tests/image_normalize.rs:74-92: value(b,h,w) = b + 0.1 h + 0.01 w on a 3 x 4 x 5 tensor
+    b, h, w = np.meshgrid(np.arange(3), np.arange(4), np.arange(5), indexing="ij")
+    return b + 0.1 * h + 0.01 * w
+
+
+def test_image_normalize_kat(oracle):
+    x = _image_case()
+    y = oracle.image_normalize(x, 1e-6, gain=1.05, bias=-0.02, gamma=1.8, clamp_zero=True)
+    mu = x.mean(axis=(1, 2), keepdims=True)
+    sd = np.sqrt(((x - mu) ** 2).mean(axis=(1, 2), keepdims=True) + 1e-6)
+    want = np.maximum((x - mu) / sd * 1.05 - 0.02, 0.0) ** 1.8
+    assert y.shape == x.shape and np.max(np.abs(y - want)) < 1e-12   # the reference's own tolerance is 5e-4
+    flat = oracle.image_normalize(np.ones((2, 3, 3)), 0.0, clamp_zero=False)   # sigma == 0 -> inv_sigma = 0, not inf
+    assert np.array_equal(flat, np.zeros((2, 3, 3)))
+
+
+def test_matmul_power_step_kat(oracle):
+    a = np.array([[1.0, 2.0], [3.0, 4.0]])
+    b = np.array([[5.0, 6.0], [7.0, 8.0]])
+    p = a @ b
+    got = oracle.matmul_power_step(a, b, 0.0)
+    assert np.max(np.abs(got - p / np.sqrt((p * p).sum(axis=0)))) < 1e-15
+    assert np.max(np.abs((got * got).sum(axis=0) - 1.0)) < 1e-15
