@@ -218,6 +218,14 @@ typedef struct rmhip_image_normalize {
     double gain, bias, gamma;
 } rmhip_image_normalize_t;
 RMHIP_API int rmhip_image_normalize(rmhip_ctx* ctx, rmhip_buf input, const rmhip_image_normalize_t* desc, rmhip_buf* out);
+/* `covariance` (lib.rs:1857-1865, CovarianceOptions :937-953) for the dense unweighted case the CenteredGram fusion
+ * pattern issues (fusion_exec.rs:630-672: second = None, weights = None, rows = All): column means, centring,
+ * (Xc' * Xc) / denom with denom = rows - 1 (biased = 0) or rows (biased = 1), cov.rs:916-953, 1080-1100, 1218-1227.
+ * rows - 1 <= 0 gives the all-NaN matrix the CPU returns.  The centred product runs as A'*A on the MFMA path. */
+RMHIP_API int rmhip_covariance(rmhip_ctx* ctx, rmhip_buf matrix, int biased, rmhip_buf* out);
+/* `diag_extract` (lib.rs:1625-1632; simple_provider.rs:3281-3312): the offset-th diagonal of a matrix as a column
+ * vector [len, 1]; vectors are rejected ("matrix input required"). */
+RMHIP_API int rmhip_diag_extract(rmhip_ctx* ctx, rmhip_buf matrix, long long offset, rmhip_buf* out);
 /* `lu` -> ProviderLuResult {combined, lower, upper, perm_matrix, perm_vector} (lib.rs:649-698);
  * pivot rule and singular cut-off of host_lu.rs:37-59.  out5 order: combined, L, U, P, pivots. */
 RMHIP_API int rmhip_lu(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf out5[5]);

@@ -224,6 +224,16 @@ public:
         check(rmhip_image_normalize(ctx_, own(input), &desc, &out));
         return make(out, input.shape);
     }
+    GpuTensorHandle covariance(const GpuTensorHandle& matrix, bool biased) const {  // lib.rs:1857 (dense, unweighted)
+        uint64_t out = 0;
+        check(rmhip_covariance(ctx_, own(matrix), biased ? 1 : 0, &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle diag_extract(const GpuTensorHandle& matrix, long long offset) const {  // lib.rs:1625
+        uint64_t out = 0;
+        check(rmhip_diag_extract(ctx_, own(matrix), offset, &out));
+        return with_shape(out);
+    }
     GpuTensorHandle syrk(const GpuTensorHandle& a) const {  // lib.rs:2383: A' * A
         uint64_t out = 0;
         check(rmhip_syrk(ctx_, own(a), &out));

@@ -639,6 +639,46 @@ ORC_API int orc_matmul_power_step(const double* a, size_t m, size_t k, const dou
     return 0;
 }
 
+/* covariance_dense with CovWeightSpec::Scalar (cov.rs:916-953), covariance_unweighted_pair (:1080-1100),
+ * sanitize_covariance (:1218-1227).  data rows x cols column-major; out cols x cols. */
+ORC_API void orc_covariance(const double* data, size_t rows, size_t cols, int biased, double* out) {
+    for (size_t i = 0; i < cols * cols; ++i) out[i] = NAN;
+    if (cols == 0) return;
+    const double denom = biased ? (double)rows : (double)rows - 1.0;
+    if (denom <= 0.0) return;
+    double* means = (double*)malloc(sizeof(double) * cols);
+    for (size_t col = 0; col < cols; ++col) {
+        double sum = 0.0;
+        int valid = 1;
+        for (size_t r = 0; r < rows; ++r) {
+            double v = data[r + col * rows];
+            if (!isfinite(v)) { valid = 0; break; }
+            sum += v;
+        }
+        means[col] = valid ? sum / (double)rows : NAN;
+    }
+    for (size_t i = 0; i < cols; ++i)
+        for (size_t j = i; j < cols; ++j) {
+            double value;
+            if (!isfinite(means[i]) || !isfinite(means[j])) {
+                value = NAN;
+            } else {
+                double acc = 0.0;
+                int bad = 0;
+                for (size_t r = 0; r < rows; ++r) {
+                    double x = data[r + i * rows], y = data[r + j * rows];
+                    if (!isfinite(x) || !isfinite(y)) { bad = 1; break; }
+                    acc += (x - means[i]) * (y - means[j]);
+                }
+                value = bad ? NAN : acc / denom;
+            }
+            if (isfinite(value) && i == j && value < 0.0 && value > -1.0e-12) value = 0.0;
+            out[i + j * cols] = value;
+            out[j + i * cols] = value;
+        }
+    free(means);
+}
+
 /* syrk: A' * A, the reference's own CPU comparator crates/runmat-accelerate/tests/syrk.rs:14-31
  * (upper triangle accumulated over k in order, unfused, mirrored into the lower triangle). */
 ORC_API void orc_syrk(const double* a, size_t rows, size_t cols, double* out) {

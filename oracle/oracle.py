@@ -75,6 +75,8 @@ def lib() -> C.CDLL:
                                           C.c_double, C.c_int, C.c_int, C.c_double, _DP]
         l.orc_matmul_power_step.restype = C.c_int
         l.orc_matmul_power_step.argtypes = [_DP, C.c_size_t, C.c_size_t, _DP, C.c_size_t, C.c_size_t, C.c_double, _DP]
+        l.orc_covariance.restype = None
+        l.orc_covariance.argtypes = [_DP, C.c_size_t, C.c_size_t, C.c_int, _DP]
         l.orc_syrk.restype = None
         l.orc_syrk.argtypes = [_DP, C.c_size_t, C.c_size_t, _DP]
         l.orc_transpose.restype = None
@@ -281,6 +283,13 @@ def matmul_power_step(a, b, epsilon=0.0) -> np.ndarray:
     if rc:
         raise ValueError("matmul_power_step: inner dims must agree")
     return out.reshape((a.shape[0], b.shape[1]), order="F")
+
+
+def covariance(x: np.ndarray, biased: bool = False) -> np.ndarray:
+    x = np.asarray(x, dtype=np.float64)
+    out = np.empty(x.shape[1] * x.shape[1])
+    lib().orc_covariance(_p(_f(x)), x.shape[0], x.shape[1], int(bool(biased)), _p(out))
+    return out.reshape((x.shape[1], x.shape[1]), order="F")
 
 
 def syrk(a: np.ndarray) -> np.ndarray:

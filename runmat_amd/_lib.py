@@ -112,6 +112,8 @@ SIGNATURES = {
     "rmhip_linsolve": (C.c_int, [_P, _BUF, _BUF, C.POINTER(LinsolveOptions), _BUFP, _DP]),
     "rmhip_transpose": (C.c_int, [_P, _BUF, _BUFP]),
     "rmhip_syrk": (C.c_int, [_P, _BUF, _BUFP]),
+    "rmhip_covariance": (C.c_int, [_P, _BUF, C.c_int, _BUFP]),
+    "rmhip_diag_extract": (C.c_int, [_P, _BUF, C.c_longlong, _BUFP]),
     "rmhip_matmul_power_step": (C.c_int, [_P, _BUF, _BUF, C.c_double, _BUFP]),
     "rmhip_image_normalize": (C.c_int, [_P, _BUF, C.POINTER(ImageNormalize), _BUFP]),
     "rmhip_blk_copy": (C.c_int, [_P, C.POINTER(View), _BUFP]),

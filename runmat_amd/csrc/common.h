@@ -188,6 +188,8 @@ int launch_rng_normal(Context* c, uint64_t state, double* out, size_t n);
 uint64_t lcg_advance(uint64_t state, uint64_t delta);
 int image_normalize_device(Context* c, const double* x, double* y, size_t batch, size_t height, size_t width, double epsilon,
                            int has_gain, double gain, int has_bias, double bias, int clamp_zero, int has_gamma, double gamma);
+int diag_extract_device(Context* c, const double* a, size_t rows, long long offset, size_t len, double* out);
+int cov_sanitize_diag_device(Context* c, double* cm, size_t n);
 int launch_stochastic_evolution(Context* c, uint64_t state, const double* in, double* out, size_t n, double drift,
                                 double scale, unsigned steps, uint64_t draws_per_step);
 

@@ -557,6 +557,64 @@ int rmhip_image_normalize(rmhip_ctx* ctx, rmhip_buf input, const rmhip_image_nor
     return rc;
 }
 
+int rmhip_covariance(rmhip_ctx* ctx, rmhip_buf matrix, int biased, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer mb;
+    RMHIP_TRY(c->get(matrix, &mb));
+    if (mb.shape.size() > 2) return fail(RMHIP_ERR_UNSUPPORTED, "covariance: only 2D supported");
+    const std::vector<size_t> ms = normalize_matrix_shape(mb.shape);
+    const size_t rows = ms[0], cols = ms[1];
+    const size_t oshape[2] = {cols, cols};
+    const double denom = biased ? (double)rows : (double)rows - 1.0;
+    if (cols == 0 || denom <= 0.0) {  // cov.rs:920-934: empty, or the all-NaN matrix
+        Buffer ob;
+        RMHIP_TRY(c->new_buffer(oshape, 2, out, &ob));
+        int rc0 = launch_fill(c, ob.data(), ob.numel, std::numeric_limits<double>::quiet_NaN());
+        if (rc0) rmhip_free(ctx, *out);
+        return rc0;
+    }
+    rmhip_buf means = 0, centred = 0, gram = 0;
+    int rc = rmhip_reduce(ctx, RMHIP_RMEAN, matrix, 0, 0, &means);       // [1, cols]
+    if (!rc) rc = rmhip_binary(ctx, RMHIP_SUB, matrix, means, &centred);  // broadcast over rows
+    if (!rc) rc = rmhip_syrk(ctx, centred, &gram);                        // Xc' * Xc
+    if (!rc) rc = rmhip_scalar(ctx, RMHIP_SDIV, gram, denom, out);
+    if (!rc) {
+        Buffer ob;
+        rc = c->get(*out, &ob);
+        if (!rc) rc = cov_sanitize_diag_device(c, ob.data(), cols);
+        if (rc) rmhip_free(ctx, *out);
+    }
+    for (rmhip_buf t : {means, centred, gram})
+        if (t) rmhip_free(ctx, t);
+    return rc;
+}
+
+int rmhip_diag_extract(rmhip_ctx* ctx, rmhip_buf matrix, long long offset, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer mb;
+    RMHIP_TRY(c->get(matrix, &mb));
+    for (size_t d = 2; d < mb.shape.size(); ++d)
+        if (mb.shape[d] != 1) return fail(RMHIP_ERR_SHAPE, "diag: input must be 2-D");
+    const size_t rows = mb.shape.empty() ? 1 : mb.shape[0], cols = mb.shape.size() < 2 ? 1 : mb.shape[1];
+    if (rows == 1 || cols == 1 || mb.shape.size() <= 1) return fail(RMHIP_ERR_SHAPE, "diag: matrix input required");
+    size_t len = 0;  // simple_provider.rs:2357-2376
+    if (offset >= 0) {
+        const size_t shift = (size_t)offset;
+        len = shift >= cols ? 0 : std::min(rows, cols - shift);
+    } else {
+        const size_t shift = (size_t)(-offset);
+        len = shift >= rows ? 0 : std::min(rows - shift, cols);
+    }
+    const size_t oshape[2] = {len, 1};
+    Buffer ob;
+    RMHIP_TRY(c->new_buffer(oshape, 2, out, &ob));
+    int rc = diag_extract_device(c, mb.data(), rows, offset, len, ob.data());
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+
 int rmhip_syrk(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);
     ScopedTimer timer(&c->tel.matmul_count, &c->tel.matmul_ns);

@@ -132,4 +132,37 @@ int image_normalize_device(Context* c, const double* x, double* y, size_t batch,
     return RMHIP_OK;
 }
 
+// ---- diag_extract (lib.rs:1625-1632; simple_provider.rs:3281-3312, index rule :2386-2392) ----------------
+__global__ void __launch_bounds__(256) k_diag_extract(const double* __restrict__ a, size_t rows, long long offset, size_t len,
+                                                      double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= len) return;
+    const size_t r = offset >= 0 ? i : i + (size_t)(-offset), c = offset >= 0 ? i + (size_t)offset : i;
+    out[i] = a[r + c * rows];
+}
+
+int diag_extract_device(Context* c, const double* a, size_t rows, long long offset, size_t len, double* out) {
+    if (len == 0) return RMHIP_OK;
+    hipLaunchKernelGGL(k_diag_extract, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, a, rows, offset, len, out);
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+
+// sanitize_covariance (cov.rs:1218-1227): a finite diagonal entry in (-1e-12, 0) is rounding noise -> 0
+__global__ void __launch_bounds__(256) k_cov_sanitize_diag(double* __restrict__ cm, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double v = cm[i + i * n];
+    if (v == v && fabs(v) != __builtin_inf() && v < 0.0 && v > -1.0e-12) cm[i + i * n] = 0.0;
+}
+
+int cov_sanitize_diag_device(Context* c, double* cm, size_t n) {
+    if (n == 0) return RMHIP_OK;
+    hipLaunchKernelGGL(k_cov_sanitize_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, cm, n);
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+
 }  // namespace rmhip

@@ -415,6 +415,20 @@ class HipProvider:
         self._check(self._lib.rmhip_image_normalize(self._ctx, self._id(x), C.byref(d), C.byref(out)))
         return self._handle(out.value, x.shape)
 
+    def covariance(self, matrix: GpuTensorHandle, second=None, weights=None, biased: bool = False, rows: str = "all") -> GpuTensorHandle:
+        """lib.rs:1857-1865: only the dense unweighted form (what the CenteredGram pattern issues) is offloaded."""
+        if second is not None or weights is not None or rows != "all":
+            raise ProviderError(_lib.ERR_UNSUPPORTED, "covariance: second matrix / weights / row filtering use the CPU path")
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_covariance(self._ctx, self._id(matrix), int(bool(biased)), C.byref(out)))
+        return self._handle(out.value)
+
+    def diag_extract(self, matrix: GpuTensorHandle, offset: int = 0) -> GpuTensorHandle:
+        """lib.rs:1625-1632"""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_diag_extract(self._ctx, self._id(matrix), int(offset), C.byref(out)))
+        return self._handle(out.value)
+
     def syrk(self, a: GpuTensorHandle) -> GpuTensorHandle:
         """lib.rs:2383: A' * A."""
         out = C.c_uint64()

@@ -49,6 +49,8 @@ extern "C" {
     fn rmhip_linsolve(ctx: *mut RmhipCtx, a: u64, b: u64, opts: *const RmhipLinsolveOptions, out: *mut u64, rcond: *mut c_double) -> c_int;
     fn rmhip_transpose(ctx: *mut RmhipCtx, a: u64, out: *mut u64) -> c_int;
     fn rmhip_syrk(ctx: *mut RmhipCtx, a: u64, out: *mut u64) -> c_int;
+    fn rmhip_covariance(ctx: *mut RmhipCtx, matrix: u64, biased: c_int, out: *mut u64) -> c_int;
+    fn rmhip_diag_extract(ctx: *mut RmhipCtx, matrix: u64, offset: i64, out: *mut u64) -> c_int;
     fn rmhip_matmul_power_step(ctx: *mut RmhipCtx, lhs: u64, rhs: u64, epsilon: c_double, out: *mut u64) -> c_int;
     fn rmhip_image_normalize(ctx: *mut RmhipCtx, input: u64, desc: *const RmhipImageNormalize, out: *mut u64) -> c_int;
     fn rmhip_set_rng_state(ctx: *mut RmhipCtx, state: u64) -> c_int;
@@ -244,6 +246,23 @@ impl AccelProvider for HipProvider {
             check(unsafe { rmhip_image_normalize(self.ctx, self.own(input)?, &c, &mut out) })?;
             self.handle(out)
         })
+    }
+    fn covariance<'a>(&'a self, matrix: &'a GpuTensorHandle, second: Option<&'a GpuTensorHandle>, weights: Option<&'a GpuTensorHandle>,
+                      options: &'a CovarianceOptions) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            if second.is_some() || weights.is_some() || options.has_weight_vector || options.rows != CovRows::All {
+                return Err(anyhow!("covariance: only the dense unweighted form is offloaded"));  // callers use the CPU path
+            }
+            let mut out = 0u64;
+            let biased = matches!(options.normalization, CovNormalization::Biased) as c_int;
+            check(unsafe { rmhip_covariance(self.ctx, self.own(matrix)?, biased, &mut out) })?;
+            self.handle(out)
+        })
+    }
+    fn diag_extract(&self, matrix: &GpuTensorHandle, offset: isize) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_diag_extract(self.ctx, self.own(matrix)?, offset as i64, &mut out) })?;
+        self.handle(out)
     }
     fn syrk(&self, a: &GpuTensorHandle) -> Result<GpuTensorHandle> {
         let mut out = 0u64;

@@ -1043,3 +1043,37 @@ def test_matmul_power_step_vs_oracle(prov, oracle, m, k, n):
     want = oracle.matmul_power_step(A, B, 1e-12)
     assert np.max(np.abs(got - want)) <= 64 * (k + m) * EPS
     assert np.max(np.abs((got * got).sum(axis=0) - 1.0)) < 1e-9
+
+
+@pytest.mark.parametrize("rows,cols", [(4, 3), (1000, 7), (257, 129), (20000, 64), (1, 5), (2, 2)])
+@pytest.mark.parametrize("biased", [False, True])
+def test_covariance_vs_oracle(prov, oracle, rows, cols, biased):
+    x = np.random.default_rng(rows * 3 + cols).uniform(-1, 1, (rows, cols)) + np.arange(cols)
+    got = prov.download_matrix(prov.covariance(prov.upload(x), biased=biased))
+    want = oracle.covariance(x, biased)
+    assert got.shape == (cols, cols) and np.array_equal(np.isnan(got), np.isnan(want))
+    fin = np.isfinite(want)
+    if fin.any():  # tolerance: tree-ordered column means and MFMA-ordered products vs the sequential CPU loops
+        assert np.max(np.abs(got[fin] - want[fin])) <= 64 * EPS * (1.0 + np.max(np.abs(want[fin]))) * np.sqrt(rows)
+        assert np.array_equal(got, got.T)
+
+
+def test_covariance_nonfinite_and_unsupported(prov, oracle):
+    from runmat_amd import ProviderError
+    x = np.random.default_rng(9).uniform(-1, 1, (50, 4))
+    x[7, 2] = np.inf
+    got = prov.download_matrix(prov.covariance(prov.upload(x)))
+    want = oracle.covariance(x)
+    assert np.array_equal(np.isnan(got), np.isnan(want))  # the poisoned column's pairs are NaN, the others finite
+    with pytest.raises(ProviderError):
+        prov.covariance(prov.upload(x), weights=prov.upload(np.ones((50, 1))))
+
+
+def test_diag_extract(prov):
+    from runmat_amd import ProviderError
+    a = np.arange(20.0).reshape(4, 5)
+    for off in (0, 1, 3, 4, 5, -1, -3, -4):
+        got = prov.download(prov.diag_extract(prov.upload(a), off))
+        assert np.array_equal(got, np.diagonal(a, off))
+    with pytest.raises(ProviderError):
+        prov.diag_extract(prov.upload(np.ones((5, 1))), 0)  # "diag: matrix input required"

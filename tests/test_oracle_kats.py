@@ -401,3 +401,13 @@ def test_matmul_power_step_kat(oracle):
     got = oracle.matmul_power_step(a, b, 0.0)
     assert np.max(np.abs(got - p / np.sqrt((p * p).sum(axis=0)))) < 1e-15
     assert np.max(np.abs((got * got).sum(axis=0) - 1.0)) < 1e-15
+
+
+def test_covariance_kat(oracle):
+    x = np.array([[1.0, 2.0, 0.5], [2.0, 1.0, 0.25], [4.0, 3.0, 1.5], [7.0, 5.0, 2.0]])
+    assert np.max(np.abs(oracle.covariance(x) - np.cov(x, rowvar=False))) < 1e-14            # unbiased: rows - 1
+    assert np.max(np.abs(oracle.covariance(x, biased=True) - np.cov(x, rowvar=False, bias=True))) < 1e-14
+    assert np.all(np.isnan(oracle.covariance(x[:1])))                                          # rows - 1 <= 0 (cov.rs:931-934)
+    xn = x.copy(); xn[2, 1] = np.nan
+    c = oracle.covariance(xn)
+    assert np.isnan(c[1, :]).all() and np.isnan(c[:, 1]).all() and np.isfinite(c[0, 2])       # a non-finite column poisons its pairs only
