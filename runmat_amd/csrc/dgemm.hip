@@ -41,6 +41,11 @@ static constexpr int SB = BK + 2;   // B tile row stride in doubles ([n][k])
 static constexpr int A_TILE = BK * SA;  // doubles
 static constexpr int B_TILE = BN * SB;
 static constexpr int GROUP_M = 8;
+// after which of the four k-steps of a tile the next tile's registers go to LDS (3 = after the last MFMA;
+// measured at 8192^3: 3 -> 68.6, 2 -> 66.4, 1 -> 67.1 TFLOP/s; s_setprio around the MFMA section: no effect)
+#ifndef GEMM_STASH_KK
+#define GEMM_STASH_KK 3
+#endif
 static_assert(A_TILE == B_TILE, "the transposed-operand variants swap the two staging patterns between the tiles");
 
 struct GemmArgs {
@@ -228,8 +233,8 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[j][i], 0, 0, 0);
+            if (kk == GEMM_STASH_KK && kt + 1 < ktiles) stash(cur ^ 1);
         }
-        if (kt + 1 < ktiles) stash(cur ^ 1);
         __syncthreads();
     }
 
