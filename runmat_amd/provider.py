@@ -174,6 +174,14 @@ class HipProvider:
     def upload(self, data, shape: Optional[Sequence[int]] = None) -> GpuTensorHandle:
         """`upload(&HostTensorView{data,shape})`: column-major f64 (lib.rs:3362-3372)."""
         arr = np.asarray(data, dtype=np.float64)
+        if shape is None and arr.ndim == 2 and arr.flags.c_contiguous and not arr.flags.f_contiguous and arr.size >= 1 << 16:
+            # A row-major numpy matrix is the column-major storage of its transpose: hand the bytes over as they are
+            # and let the device transpose (numpy's strided gather runs at ~0.15 GB/s on an 8192x8192 matrix).
+            # RunMat itself always passes column-major data; this is a convenience of the Python mirror.
+            base = self.upload(arr.reshape(-1), (arr.shape[1], arr.shape[0]))
+            out = self.transpose(base)
+            self.free(base)
+            return out
         if shape is None:
             shape = arr.shape if arr.ndim >= 2 else (arr.size, 1) if arr.ndim == 1 else (1, 1)
             flat = np.ascontiguousarray(arr.reshape(-1, order="F"))
