@@ -1077,3 +1077,19 @@ def test_diag_extract(prov):
         assert np.array_equal(got, np.diagonal(a, off))
     with pytest.raises(ProviderError):
         prov.diag_extract(prov.upload(np.ones((5, 1))), 0)  # "diag: matrix input required"
+
+
+def test_image_normalize_golden_from_reference_script(prov):
+    """The device pipeline against the MSE printed by the reference's own benchmark comparator
+    (tests/golden/image_normalize_lcg.json, generated by tests/golden/make_golden.py)."""
+    from workloads import golden_image_cases, lcg_image_field
+    g = golden_image_cases()
+    p = g["params"]
+    f32 = lambda v: float(np.float32(v))
+    for case in g["cases"]:
+        imgs = lcg_image_field(case["B"], case["H"], case["W"], p["seed"])
+        h = prov.upload(imgs.reshape(-1, order="F"), imgs.shape)
+        out = prov.download(prov.image_normalize(h, case["B"], case["H"], case["W"], f32(p["eps0"]), gain=f32(p["gain"]),
+                                                 bias=f32(p["bias"]), gamma=f32(p["gamma"]), clamp_zero=True))
+        mse = float(np.mean((out - imgs.reshape(-1, order="F")) ** 2))
+        assert abs(mse - case["mse"]) <= 2e-5 * case["mse"], (mse, case["mse"])

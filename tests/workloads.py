@@ -95,3 +95,23 @@ def lcg_monte_carlo_price(ops, M, T, S0=100.0, mu=0.05, sigma=0.2, dt=1.0 / 252.
 
 def golden_monte_carlo_cases():
     return json.loads((GOLDEN / "monte_carlo_lcg.json").read_text())["cases"]
+
+
+def golden_image_cases():
+    return json.loads((GOLDEN / "image_normalize_lcg.json").read_text())
+
+
+def golden_elementwise_math():
+    return json.loads((GOLDEN / "elementwise_math.json").read_text())
+
+
+def lcg_image_field(B, H, W, seed=0):
+    """benchmarks/4k-image-processing/runmat_lcg.m (and python_numpy_lcg.py): imgs(b,y,x) = single(mod(1664525*idx +
+    1013904223, 2^32)) / 2^32 with idx = b*H*W + y*W + x + seed; returned as f64 holding the f32-rounded values,
+    shape [B, H, W]."""
+    b = np.arange(B, dtype=np.uint64)[:, None, None]
+    y = np.arange(H, dtype=np.uint64)[None, :, None]
+    x = np.arange(W, dtype=np.uint64)[None, None, :]
+    idx = b * np.uint64(H * W) + y * np.uint64(W) + x + np.uint64(seed)
+    state = (np.uint64(1664525) * idx + np.uint64(1013904223)) % np.uint64(1 << 32)
+    return (state.astype(np.float32) / np.float32(2.0 ** 32)).astype(np.float64)
