@@ -134,7 +134,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["fused", "dgemm", "mc", "mldivide", "chain", "mc_evolved"], default="fused")
+    ap.add_argument("--workload", choices=["fused", "dgemm", "mc", "mldivide", "chain", "mc_evolved", "image"], default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     args = ap.parse_args()
@@ -335,6 +335,38 @@ def main() -> None:
                                    "the HBM fraction is reported for completeness)"},
         }
 
+    def image_record(steps, warmup):
+        """benchmarks/4k-image-processing in f64: 16 frames of 2160 x 3840, per-frame mean / variance normalisation,
+        gain, bias, clamp, gamma (the ImageNormalize fusion pattern = ONE provider call) -- frames sharded over ranks."""
+        B, H, W = max(1, 16 // world), 2160, 3840
+        hx = prov.fill_uniform(41 + 100 * rank, 0.0, 1.0, (B, H, W))
+
+        def step():
+            prov.free(prov.image_normalize(hx, B, H, W, 1e-6, gain=1.0123, bias=-0.02, gamma=1.8, clamp_zero=True))
+
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        wall = max_over_ranks(time.perf_counter() - t0)
+        prov.free(hx)
+        ms = wall / steps * 1e3
+        nbytes = 32 * B * H * W  # three reads (mean, two-pass variance, normalise) + one write per element
+        return {
+            "metric": "image_normalize GB/s (4k-image-processing: 16 x 2160 x 3840 f64 frames, one provider call)",
+            "value": round(nbytes * world / (ms * 1e-3) / 1e9, 1), "unit": "GB/s", "ms_per_step": round(ms, 4), "scaling": "strong",
+            "dtype": "f64",
+            "config": {"workload": "benchmarks/4k-image-processing f64, image_normalize(gain, bias, clamp, gamma = 1.8)",
+                       "bytes_per_step_per_gpu": nbytes, "parallelism": f"frames x{world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "k_plane_partial<false>, k_plane_partial<true>, k_imgnorm_apply (32 B per element; the "
+                                   "pow of the gamma step makes the last pass VALU bound)"},
+        }
+
     def mldivide_record(steps, warmup):
         """BASELINE configs[4] at the single-GPU size: x = A\\b, 16384x16384 f64, blocked recursive LU."""
         nn = 16384
@@ -432,7 +464,7 @@ def main() -> None:
         }
 
     records = {"fused": fused_record, "dgemm": dgemm_record, "mc": mc_record, "mldivide": mldivide_record,
-               "chain": chain_record, "mc_evolved": mc_evolved_record}
+               "chain": chain_record, "mc_evolved": mc_evolved_record, "image": image_record}
     primary = records[args.workload]
     rec = primary(args.steps, args.warmup)
     out = {
@@ -443,19 +475,19 @@ def main() -> None:
     }
     if not args.no_also:
         # the other configs of BASELINE.json, short runs; every rank takes part (collectives inside)
-        others = [w for w in ("fused", "dgemm", "mc", "mc_evolved", "chain") if w != args.workload]
+        others = [w for w in ("fused", "dgemm", "mc", "mc_evolved", "image", "chain") if w != args.workload]
         if world == 1 and args.workload != "mldivide":
             others.append("mldivide")
         also = []
         for w in others:
-            steps = {"fused": 20, "dgemm": 5, "mc": 3, "mc_evolved": 3, "mldivide": 2, "chain": 100}[w]
+            steps = {"fused": 20, "dgemm": 5, "mc": 3, "mc_evolved": 3, "image": 5, "mldivide": 2, "chain": 100}[w]
             sec = records[w](steps, 2 if w != "mldivide" else 1)
             also.append({k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "roofline")})
         out["also"] = also
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = {"fused": cpu_baseline_fused, "dgemm": cpu_baseline_dgemm, "mc": cpu_baseline_mc,
                                "mldivide": cpu_baseline_mldivide, "chain": cpu_baseline_chain,
-                               "mc_evolved": cpu_baseline_mc}[args.workload]()
+                               "mc_evolved": cpu_baseline_mc, "image": cpu_baseline_fused}[args.workload]()
         for a in out.get("also", []):
             if a["unit"] == "GFLOP/s" and "matmul" in a["metric"]:
                 a["cpu_baseline"] = cpu_baseline_dgemm()
