@@ -51,13 +51,9 @@ EwTuning EwTuning::from_env() {
 
 int EwTuning::unroll_for(int n_streamed_inputs, bool heavy_math) const {
     if (unroll > 0) return unroll;
-    // scripts/tune_ew.py on MI355X, 8192^2 f64 (GB/s at unroll 1 / 4):
-    //   sin(A).*B+C 5974 / ~4500   A.*B+C ~4500 / 6001   A+B 6079 / ~5200   copy 5866 / ~5200   sin(A) 5458 / ~4900
-    // libm-heavy bodies want occupancy (unroll 1); a pure-arithmetic body over >= 3 equally sized
-    // streams runs into same-offset HBM channel contention unless each thread spreads its
-    // accesses (unroll 4).
-    if (heavy_math) return 1;
-    return n_streamed_inputs >= 3 ? 4 : 1;
+    (void)n_streamed_inputs;
+    (void)heavy_math;
+    return 1;  // see codegen.h
 }
 
 static bool expr_is_heavy(const ExprPtr& e) {
@@ -202,7 +198,7 @@ static void emit_bcast_kernel(std::ostringstream& s, const ElementwiseProgram& p
     const int nin = p.n_inputs, nout = (int)p.outputs.size(), E = kBcastElems;
     // params: v[0]=d0, v[1]=nchunks, v[2]=rank, v[3..10]=shape, v[11+8k .. ] = stride of input k
     s << "struct RmBcast { rm_u64 v[" << (11 + 8 * nin) << "]; };\n";
-    s << "extern \"C\" __global__ void __launch_bounds__(" << t.block << ") rm_ew_bcast(";
+    s << "extern \"C\" __global__ void __launch_bounds__(" << t.bcast_block << ") rm_ew_bcast(";
     for (int k = 0; k < nin; ++k) s << "const double* __restrict__ in" << k << ", ";
     for (int k = 0; k < nout; ++k) s << "double* __restrict__ out" << k << ", ";
     s << "const RmBcast p) {\n";
@@ -221,9 +217,9 @@ static void emit_bcast_kernel(std::ostringstream& s, const ElementwiseProgram& p
     s << "    }\n";
     s << "    if (rem != 0) return;  // padding blocks of the 2-D grid\n";
     s << "    const rm_u64 obase = outer * d0;\n";
-    s << "    const rm_u64 i0 = chunk * " << (t.block * E) << "ull + threadIdx.x;\n";
+    s << "    const rm_u64 i0 = chunk * " << (t.bcast_block * E) << "ull + threadIdx.x;\n";
     for (int e = 0; e < E; ++e) {
-        s << "    {\n        const rm_u64 i = i0 + " << (e * t.block) << "ull;\n        if (i < d0) {\n";
+        s << "    {\n        const rm_u64 i = i0 + " << (e * t.bcast_block) << "ull;\n        if (i < d0) {\n";
         for (int k = 0; k < nout; ++k) s << "            double q" << k << ";\n";
         s << "            rm_body(";
         for (int k = 0; k < nin; ++k) s << (k ? ", " : "") << "in" << k << "[off" << k << " + i * p.v[" << (11 + 8 * k) << "]]";
@@ -342,7 +338,7 @@ int get_elementwise_kernel(Context* c, const ElementwiseProgram& p, unsigned mas
                            std::shared_ptr<FusedKernel>* out) {
     EwTuning t = EwTuning::from_env();
     char tun[96];
-    std::snprintf(tun, sizeof tun, "|u%d|b%d|nt%d%d|c%d|m%x", t.unroll, t.block, t.nt_load, t.nt_store, t.chunked, mask);
+    std::snprintf(tun, sizeof tun, "|u%d|b%d|bb%d|nt%d%d|c%d|m%x", t.unroll, t.block, t.bcast_block, t.nt_load, t.nt_store, t.chunked, mask);
     const uint64_t key = fnv1a(p.canonical + tun);
     {
         std::lock_guard<std::mutex> lk(c->mu);

@@ -14,16 +14,19 @@
 namespace rmhip {
 
 struct EwTuning {
-    int unroll = 0;        // independent 16-byte vectors in flight per thread; 0 = pick from the stream count
-    int block = 256;
+    int unroll = 0;        // independent 16-byte vectors in flight per thread; 0 = 1 (see unroll_for)
+    int block = 1024;      // streaming fast path; interleaved A/B at 8192^2 f64 (scripts/tune_ew_ab.py), GB/s for block
+                           // 256 / 512 / 1024: sin(A).*B+C 5325 / 5739 / 5989, A.*B+C 4538 / 5270 / 5444, A+B 4898 / 5562 /
+                           // 5748, copy 5311 / 5832 / 6047, sin(A) 5649 / 5856 / 6098
+    int bcast_block = 256; // general broadcast path: a block spans 4 * bcast_block elements of dim 0
     int blocks_per_cu = 16; // grid cap = blocks_per_cu * CUs (grid-stride beyond that)
     int nt_load = 1;       // non-temporal loads on the streaming fast path
     int nt_store = 1;      // non-temporal stores
     int chunked = 0;       // 1: each block walks one contiguous chunk instead of a grid-stride loop
     static EwTuning from_env();
-    // Measured on MI355X (scripts/tune_ew.py): what matters is bytes in flight per thread versus
-    // occupancy. Three streamed inputs already put 48 B per thread in flight, and unrolling only
-    // costs VGPRs (sin is register hungry): unroll 1 ran 5.9 TB/s, unroll 8 4.2 TB/s.
+    // One 16-byte vector per stream per thread.  Sequential sweeps (scripts/tune_ew.py) once suggested unroll 4 for
+    // pure-arithmetic bodies; interleaved A/B runs (order effects on this hardware are as large as the differences)
+    // show unroll 1 at least as fast for every body at every block size (e.g. block 1024: 5989 vs 5050 GB/s).
     int unroll_for(int n_streamed_inputs, bool heavy_math) const;
 };
 
