@@ -267,7 +267,7 @@ std::string generate_reduction_source(const ReductionProgram& p) {
                  std::to_string(k) + ";\n";
         return a;
     };
-    s << "extern \"C\" __global__ void __launch_bounds__(RM_RBLOCK) rm_red_contig(" << args()
+    s << "extern \"C\" __global__ void __launch_bounds__(RM_ABLOCK) rm_red_contig(" << args()
       << "const rm_u64 red, const rm_u64 nslices, const rm_u64 nsplit, double* part_v, double* part_nan) {\n"
       << init() << "    rm_reduce_contig<RM_RSUM>(f, red, nslices, nsplit, part_v, part_nan);\n}\n\n";
     s << "extern \"C\" __global__ void __launch_bounds__(RM_RBLOCK) rm_red_strided(" << args()

@@ -14,11 +14,13 @@ namespace rmhip {
 
 typedef double v2 __attribute__((ext_vector_type(2)));
 
-static constexpr int kBlock = 256;
-static constexpr int kUnroll = 1;  // measured best for 1-2 stream kernels (scripts/tune_ew.py): occupancy over unrolling
+static constexpr int kBlock = 256;    // broadcast kernel: a block spans kBlock elements of dim 0
+static constexpr int kStream = 1024;  // streaming kernels: 1024-thread blocks measured 8-20 % faster than 256 (interleaved
+                                      // A/B on the generated kernels, scripts/tune_ew_ab.py; same skeleton here)
+static constexpr int kUnroll = 1;  // one 16-byte vector per stream per thread (interleaved A/B: unrolling never helped)
 
 static inline unsigned stream_grid(const Context* c, size_t nvec) {
-    size_t want = (nvec + (size_t)kBlock * kUnroll - 1) / ((size_t)kBlock * kUnroll);
+    size_t want = (nvec + (size_t)kStream * kUnroll - 1) / ((size_t)kStream * kUnroll);
     size_t cap = (size_t)c->num_cus * 16;
     if (want < 1) want = 1;
     return (unsigned)(want < cap ? want : cap);
@@ -99,25 +101,13 @@ __device__ __forceinline__ double scalar_op(double a, double s) {
 
 // ---- streaming skeleton: out[i] = f(i) over 16-byte vectors -------------------------------------
 template <class F>
-__global__ void __launch_bounds__(kBlock) k_stream1(const double* __restrict__ a, double* __restrict__ out, size_t n,
+__global__ void __launch_bounds__(kStream) k_stream1(const double* __restrict__ a, double* __restrict__ out, size_t n,
                                                     F f) {
     const size_t nvec = n >> 1;
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * kStream;
+    size_t i = (size_t)blockIdx.x * kStream + threadIdx.x;
     const v2* __restrict__ av = (const v2*)a;
     v2* __restrict__ ov = (v2*)out;
-    for (; i + (kUnroll - 1) * stride < nvec; i += kUnroll * stride) {
-        v2 x[kUnroll];
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) x[u] = __builtin_nontemporal_load(av + i + u * stride);
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            v2 r;
-            r.x = f(x[u].x);
-            r.y = f(x[u].y);
-            __builtin_nontemporal_store(r, ov + i + u * stride);
-        }
-    }
     for (; i < nvec; i += stride) {
         v2 x = __builtin_nontemporal_load(av + i), r;
         r.x = f(x.x);
@@ -128,29 +118,14 @@ __global__ void __launch_bounds__(kBlock) k_stream1(const double* __restrict__ a
 }
 
 template <class F>
-__global__ void __launch_bounds__(kBlock) k_stream2(const double* __restrict__ a, const double* __restrict__ b,
+__global__ void __launch_bounds__(kStream) k_stream2(const double* __restrict__ a, const double* __restrict__ b,
                                                     double* __restrict__ out, size_t n, F f) {
     const size_t nvec = n >> 1;
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * kStream;
+    size_t i = (size_t)blockIdx.x * kStream + threadIdx.x;
     const v2* __restrict__ av = (const v2*)a;
     const v2* __restrict__ bv = (const v2*)b;
     v2* __restrict__ ov = (v2*)out;
-    for (; i + (kUnroll - 1) * stride < nvec; i += kUnroll * stride) {
-        v2 x[kUnroll], y[kUnroll];
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            x[u] = __builtin_nontemporal_load(av + i + u * stride);
-            y[u] = __builtin_nontemporal_load(bv + i + u * stride);
-        }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            v2 r;
-            r.x = f(x[u].x, y[u].x);
-            r.y = f(x[u].y, y[u].y);
-            __builtin_nontemporal_store(r, ov + i + u * stride);
-        }
-    }
     for (; i < nvec; i += stride) {
         v2 x = __builtin_nontemporal_load(av + i), y = __builtin_nontemporal_load(bv + i), r;
         r.x = f(x.x, y.x);
@@ -178,25 +153,25 @@ static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // Unaligned (externally wrapped) memory: plain 8-byte accesses.
 template <class F>
-__global__ void __launch_bounds__(kBlock) k_plain1(const double* __restrict__ a, double* __restrict__ out, size_t n,
+__global__ void __launch_bounds__(kStream) k_plain1(const double* __restrict__ a, double* __restrict__ out, size_t n,
                                                    F f) {
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = f(a[i]);
+    const size_t stride = (size_t)gridDim.x * kStream;
+    for (size_t i = (size_t)blockIdx.x * kStream + threadIdx.x; i < n; i += stride) out[i] = f(a[i]);
 }
 template <class F>
-__global__ void __launch_bounds__(kBlock) k_plain2(const double* __restrict__ a, const double* __restrict__ b,
+__global__ void __launch_bounds__(kStream) k_plain2(const double* __restrict__ a, const double* __restrict__ b,
                                                    double* __restrict__ out, size_t n, F f) {
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = f(a[i], b[i]);
+    const size_t stride = (size_t)gridDim.x * kStream;
+    for (size_t i = (size_t)blockIdx.x * kStream + threadIdx.x; i < n; i += stride) out[i] = f(a[i], b[i]);
 }
 
 template <class F>
 static int run1(Context* c, const double* a, double* out, size_t n, F f) {
     if (n == 0) return RMHIP_OK;
     if (aligned16(a) && aligned16(out))
-        hipLaunchKernelGGL((k_stream1<F>), dim3(stream_grid(c, n / 2)), dim3(kBlock), 0, c->stream, a, out, n, f);
+        hipLaunchKernelGGL((k_stream1<F>), dim3(stream_grid(c, n / 2)), dim3(kStream), 0, c->stream, a, out, n, f);
     else
-        hipLaunchKernelGGL((k_plain1<F>), dim3(stream_grid(c, n)), dim3(kBlock), 0, c->stream, a, out, n, f);
+        hipLaunchKernelGGL((k_plain1<F>), dim3(stream_grid(c, n)), dim3(kStream), 0, c->stream, a, out, n, f);
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
@@ -205,9 +180,9 @@ template <class F>
 static int run2(Context* c, const double* a, const double* b, double* out, size_t n, F f) {
     if (n == 0) return RMHIP_OK;
     if (aligned16(a) && aligned16(b) && aligned16(out))
-        hipLaunchKernelGGL((k_stream2<F>), dim3(stream_grid(c, n / 2)), dim3(kBlock), 0, c->stream, a, b, out, n, f);
+        hipLaunchKernelGGL((k_stream2<F>), dim3(stream_grid(c, n / 2)), dim3(kStream), 0, c->stream, a, b, out, n, f);
     else
-        hipLaunchKernelGGL((k_plain2<F>), dim3(stream_grid(c, n)), dim3(kBlock), 0, c->stream, a, b, out, n, f);
+        hipLaunchKernelGGL((k_plain2<F>), dim3(stream_grid(c, n)), dim3(kStream), 0, c->stream, a, b, out, n, f);
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
@@ -310,16 +285,16 @@ int launch_binary_bcast(Context* c, int op, const double* a, const double* b, do
 }
 
 // ---- fills ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_fill(double* __restrict__ out, size_t n, double value) {
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = value;
+__global__ void __launch_bounds__(kStream) k_fill(double* __restrict__ out, size_t n, double value) {
+    const size_t stride = (size_t)gridDim.x * kStream;
+    for (size_t i = (size_t)blockIdx.x * kStream + threadIdx.x; i < n; i += stride) out[i] = value;
 }
 
 // counter-based splitmix64 (identical to oracle.c orc_fill_uniform)
-__global__ void __launch_bounds__(kBlock) k_fill_uniform(double* __restrict__ out, size_t n, unsigned long long seed,
+__global__ void __launch_bounds__(kStream) k_fill_uniform(double* __restrict__ out, size_t n, unsigned long long seed,
                                                          double lo, double hi) {
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const size_t stride = (size_t)gridDim.x * kStream;
+    for (size_t i = (size_t)blockIdx.x * kStream + threadIdx.x; i < n; i += stride) {
         unsigned long long z = seed + (unsigned long long)(i + 1) * 0x9e3779b97f4a7c15ULL;
         z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
         z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
@@ -330,7 +305,7 @@ __global__ void __launch_bounds__(kBlock) k_fill_uniform(double* __restrict__ ou
 
 int launch_fill(Context* c, double* dst, size_t n, double value) {
     if (n == 0) return RMHIP_OK;
-    hipLaunchKernelGGL(k_fill, dim3(stream_grid(c, n)), dim3(kBlock), 0, c->stream, dst, n, value);
+    hipLaunchKernelGGL(k_fill, dim3(stream_grid(c, n)), dim3(kStream), 0, c->stream, dst, n, value);
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
@@ -338,7 +313,7 @@ int launch_fill(Context* c, double* dst, size_t n, double value) {
 
 int launch_fill_uniform(Context* c, double* dst, size_t n, uint64_t seed, double lo, double hi) {
     if (n == 0) return RMHIP_OK;
-    hipLaunchKernelGGL(k_fill_uniform, dim3(stream_grid(c, n)), dim3(kBlock), 0, c->stream, dst, n,
+    hipLaunchKernelGGL(k_fill_uniform, dim3(stream_grid(c, n)), dim3(kStream), 0, c->stream, dst, n,
                        (unsigned long long)seed, lo, hi);
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());

@@ -17,7 +17,7 @@ struct IdentityVal {
 };
 
 template <int OP>
-__global__ void __launch_bounds__(RM_RBLOCK) k_reduce_contig(const double* x, rm_u64 red, rm_u64 nslices,
+__global__ void __launch_bounds__(RM_ABLOCK) k_reduce_contig(const double* x, rm_u64 red, rm_u64 nslices,
                                                              rm_u64 nsplit, double* pv, double* pn) {
     IdentityVal f{x};
     rm_reduce_contig<OP>(f, red, nslices, nsplit, pv, pn);
@@ -46,7 +46,7 @@ static int run_reduce(Context* c, int mean, int nan_mode, const double* x, size_
     double* pv = c->scratch;
     double* pn = c->scratch + nparts;
     if (p.contiguous)
-        hipLaunchKernelGGL((k_reduce_contig<OP>), dim3(p.gx, p.gy, p.gz), dim3(RM_RBLOCK), 0, c->stream, x,
+        hipLaunchKernelGGL((k_reduce_contig<OP>), dim3(p.gx, p.gy, p.gz), dim3(p.tx), 0, c->stream, x,
                            (rm_u64)red, (rm_u64)p.nslices, (rm_u64)p.nsplit, pv, pn);
     else
         hipLaunchKernelGGL((k_reduce_strided<OP>), dim3(p.gx, p.gy, p.gz), dim3(RM_RBLOCK), 0, c->stream, x,
@@ -78,7 +78,7 @@ struct ProductVal {
     const double* __restrict__ b;
     __device__ __forceinline__ double operator()(rm_u64 idx) const { return a[idx] * b[idx]; }
 };
-__global__ void __launch_bounds__(RM_RBLOCK) k_dot_contig(const double* a, const double* b, rm_u64 red, rm_u64 nslices,
+__global__ void __launch_bounds__(RM_ABLOCK) k_dot_contig(const double* a, const double* b, rm_u64 red, rm_u64 nslices,
                                                           rm_u64 nsplit, double* pv, double* pn) {
     ProductVal f{a, b};
     rm_reduce_contig<RM_RSUM>(f, red, nslices, nsplit, pv, pn);
@@ -98,7 +98,7 @@ int launch_reduce_dot(Context* c, const double* a, const double* b, size_t pre, 
     double* pv = c->scratch;
     double* pn = c->scratch + nparts;
     if (p.contiguous)
-        hipLaunchKernelGGL(k_dot_contig, dim3(p.gx, p.gy, p.gz), dim3(RM_RBLOCK), 0, c->stream, a, b, (rm_u64)red,
+        hipLaunchKernelGGL(k_dot_contig, dim3(p.gx, p.gy, p.gz), dim3(p.tx), 0, c->stream, a, b, (rm_u64)red,
                            (rm_u64)p.nslices, (rm_u64)p.nsplit, pv, pn);
     else
         hipLaunchKernelGGL(k_dot_strided, dim3(p.gx, p.gy, p.gz), dim3(RM_RBLOCK), 0, c->stream, a, b, (rm_u64)pre,

@@ -34,13 +34,14 @@ inline ReducePlan plan_reduction(uint64_t pre, uint64_t red, uint64_t post, int 
     p.nslices = pre * post;
     if (pre == 1) {
         p.contiguous = true;
-        uint64_t max_split = ceil_div_u64(red, 256 * 8);  // >= 8 elements per thread per block
+        const uint64_t bs = red >= 8192 ? 1024 : 256;  // long slices stream with RM_ABLOCK threads, short ones keep RM_RBLOCK
+        uint64_t max_split = ceil_div_u64(red, bs * 8);  // >= 8 elements per thread per block
         if (max_split < 1) max_split = 1;
         uint64_t want = ceil_div_u64(target_blocks, post ? post : 1);
         if (want < 1) want = 1;
         p.nsplit = want < max_split ? want : max_split;
         if (p.nsplit > 4096) p.nsplit = 4096;
-        p.tx = 256;
+        p.tx = (int)bs;  // block size of kernel A
         p.gx = (unsigned)p.nsplit;
         // slices spread over (y, z)
         uint64_t gy = post < 65535 ? post : 65535;

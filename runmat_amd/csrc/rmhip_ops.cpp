@@ -350,7 +350,7 @@ int rmhip_fused_reduction(rmhip_ctx* ctx, const char* shader, const rmhip_buf* i
         args.push_back(&u_nsplit);
         args.push_back(&pv);
         args.push_back(&pn);
-        e = hipModuleLaunchKernel(kern->fn_contig, plan.gx, plan.gy, plan.gz, 256, 1, 1, 0, c->stream, args.data(), nullptr);
+        e = hipModuleLaunchKernel(kern->fn_contig, plan.gx, plan.gy, plan.gz, (unsigned)plan.tx, 1, 1, 0, c->stream, args.data(), nullptr);
     } else {
         args.push_back(&u_pre);
         args.push_back(&u_red);

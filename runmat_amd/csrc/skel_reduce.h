@@ -22,6 +22,8 @@
 #define RM_RMAX 3
 #define RM_RPROD 4
 #define RM_RBLOCK 256
+#define RM_ABLOCK 1024  // kernel A (contiguous slices) streams: 1024-thread blocks measured 8-20 % faster than 256 on
+                        // the elementwise kernels (scripts/tune_ew_ab.py), and sum(x,'all') of 512 MiB went 0.105 -> see DESIGN.md
 
 struct RmAcc {
     double v;
@@ -53,10 +55,10 @@ __device__ __forceinline__ void rm_acc_merge(RmAcc& a, const RmAcc& b) {
     a.nan += b.nan;
 }
 
-// Fixed-order reduction across the 256 threads of a block: wave64 shuffle tree, then wave 0
-// folds the four wave results in wave order. Result valid in thread 0.
+// Fixed-order reduction across the RM_ABLOCK threads of a block: wave64 shuffle tree, then wave 0
+// folds the wave results in wave order. Result valid in thread 0.
 template <int OP>
-__device__ __forceinline__ RmAcc rm_block_reduce(RmAcc a, RmAcc* lds /* >= 4 entries */) {
+__device__ __forceinline__ RmAcc rm_block_reduce(RmAcc a, RmAcc* lds /* >= RM_ABLOCK / 64 entries */) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         RmAcc o;
@@ -68,8 +70,7 @@ __device__ __forceinline__ RmAcc rm_block_reduce(RmAcc a, RmAcc* lds /* >= 4 ent
     if (lane == 0) lds[wave] = a;
     __syncthreads();
     if (threadIdx.x == 0) {
-#pragma unroll
-        for (int w = 1; w < RM_RBLOCK / 64; ++w) rm_acc_merge<OP>(a, lds[w]);
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) rm_acc_merge<OP>(a, lds[w]);
     }
     return a;
 }
@@ -78,27 +79,27 @@ __device__ __forceinline__ RmAcc rm_block_reduce(RmAcc a, RmAcc* lds /* >= 4 ent
 template <int OP, class F>
 __device__ __forceinline__ void rm_reduce_contig(const F& f, rm_u64 red, rm_u64 nslices, rm_u64 nsplit,
                                                  double* part_v, double* part_nan) {
-    __shared__ RmAcc lds[RM_RBLOCK / 64];
+    __shared__ RmAcc lds[RM_ABLOCK / 64];
     const rm_u64 slice = blockIdx.y + (rm_u64)gridDim.y * blockIdx.z;
     if (slice >= nslices) return;  // padding blocks of the (y, z) slice grid; uniform per block
     const rm_u64 split = blockIdx.x;
     rm_u64 chunk = (red + nsplit - 1) / nsplit;
-    chunk = (chunk + RM_RBLOCK - 1) / RM_RBLOCK * RM_RBLOCK;  // block-aligned chunks
+    const rm_u64 bs = blockDim.x;  // RM_ABLOCK for long slices, RM_RBLOCK for short ones (host: reduce_plan.h)
+    chunk = (chunk + bs - 1) / bs * bs;  // block-aligned chunks
     const rm_u64 begin = split * chunk;
     rm_u64 end = begin + chunk;
     if (end > red) end = red;
     const rm_u64 base = slice * red;
     RmAcc a0 = rm_acc_init<OP>(), a1 = rm_acc_init<OP>(), a2 = rm_acc_init<OP>(), a3 = rm_acc_init<OP>();
     rm_u64 r = begin + threadIdx.x;
-    for (; r + 3 * RM_RBLOCK < end; r += 4 * RM_RBLOCK) {
-        const double x0 = f(base + r), x1 = f(base + r + RM_RBLOCK), x2 = f(base + r + 2 * RM_RBLOCK),
-                     x3 = f(base + r + 3 * RM_RBLOCK);
+    for (; r + 3 * bs < end; r += 4 * bs) {
+        const double x0 = f(base + r), x1 = f(base + r + bs), x2 = f(base + r + 2 * bs), x3 = f(base + r + 3 * bs);
         rm_acc_add<OP>(a0, x0);
         rm_acc_add<OP>(a1, x1);
         rm_acc_add<OP>(a2, x2);
         rm_acc_add<OP>(a3, x3);
     }
-    for (; r < end; r += RM_RBLOCK) rm_acc_add<OP>(a0, f(base + r));
+    for (; r < end; r += bs) rm_acc_add<OP>(a0, f(base + r));
     rm_acc_merge<OP>(a0, a1);
     rm_acc_merge<OP>(a2, a3);
     rm_acc_merge<OP>(a0, a2);

@@ -16,12 +16,13 @@
 namespace rmhip {
 
 static constexpr int IN_MAX_BATCH = 256;
+static constexpr int IN_BLOCK = 1024;  // streaming passes: the largest multiple of `batch` <= 1024 threads per block
 
 // partial[block][b] = sum over this block's share of plane elements of x (SQDEV: (x - mean[b])^2)
 template <bool SQDEV>
-__global__ void __launch_bounds__(256) k_plane_partial(const double* __restrict__ x, size_t total, int batch,
+__global__ void __launch_bounds__(IN_BLOCK) k_plane_partial(const double* __restrict__ x, size_t total, int batch,
                                                        const double* __restrict__ mean, double* __restrict__ partial) {
-    __shared__ double s[256];
+    __shared__ double s[IN_BLOCK];
     const int t = threadIdx.x;
     const int b = t % batch;  // blockDim.x is a multiple of batch, so is every thread's stride
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -89,7 +90,7 @@ __global__ void __launch_bounds__(IN_MAX_BATCH) k_plane_final(const double* __re
     }
 }
 
-__global__ void __launch_bounds__(256) k_imgnorm_apply(const double* __restrict__ x, double* __restrict__ y, size_t total,
+__global__ void __launch_bounds__(IN_BLOCK) k_imgnorm_apply(const double* __restrict__ x, double* __restrict__ y, size_t total,
                                                        int batch, const double* __restrict__ stats, int has_gain, double gain,
                                                        int has_bias, double bias, int clamp_zero, int has_gamma, double gamma) {
     const int b = threadIdx.x % batch;
@@ -111,7 +112,7 @@ int image_normalize_device(Context* c, const double* x, double* y, size_t batch,
     if (total == 0) return RMHIP_OK;
     if (batch > (size_t)IN_MAX_BATCH)
         return fail(RMHIP_ERR_UNSUPPORTED, "image_normalize: batch %zu > %d not supported by provider", batch, IN_MAX_BATCH);
-    const unsigned threads = (unsigned)((256 / batch) * batch);  // a multiple of batch
+    const unsigned threads = (unsigned)((IN_BLOCK / batch) * batch);  // a multiple of batch
     size_t want = (total + (size_t)threads * 8 - 1) / ((size_t)threads * 8);
     const size_t cap = (size_t)c->num_cus * 8;
     if (want < 1) want = 1;
