@@ -46,6 +46,8 @@ EwTuning EwTuning::from_env() {
     t.nt_load = env_int("RMHIP_EW_NT_LOAD", env_int("RMHIP_EW_NT", t.nt_load, 0, 1), 0, 1);
     t.nt_store = env_int("RMHIP_EW_NT_STORE", env_int("RMHIP_EW_NT", t.nt_store, 0, 1), 0, 1);
     t.chunked = env_int("RMHIP_EW_CHUNKED", t.chunked, 0, 1);
+    t.bcast_block = (env_int("RMHIP_EW_BCAST_BLOCK", t.bcast_block, 64, 1024) / 64) * 64;
+    t.bcast_elems = env_int("RMHIP_EW_BCAST_ELEMS", t.bcast_elems, 1, 8);
     return t;
 }
 
@@ -192,10 +194,8 @@ static void emit_fast_kernel(std::ostringstream& s, const ElementwiseProgram& p,
     s << "}\n\n";
 }
 
-static constexpr int kBcastElems = 4;  // elements per thread along dim 0 in the broadcast kernel
-
 static void emit_bcast_kernel(std::ostringstream& s, const ElementwiseProgram& p, const EwTuning& t) {
-    const int nin = p.n_inputs, nout = (int)p.outputs.size(), E = kBcastElems;
+    const int nin = p.n_inputs, nout = (int)p.outputs.size(), E = t.bcast_elems;
     // params: v[0]=d0, v[1]=nchunks, v[2]=rank, v[3..10]=shape, v[11+8k .. ] = stride of input k
     s << "struct RmBcast { rm_u64 v[" << (11 + 8 * nin) << "]; };\n";
     s << "extern \"C\" __global__ void __launch_bounds__(" << t.bcast_block << ") rm_ew_bcast(";
@@ -338,7 +338,7 @@ int get_elementwise_kernel(Context* c, const ElementwiseProgram& p, unsigned mas
                            std::shared_ptr<FusedKernel>* out) {
     EwTuning t = EwTuning::from_env();
     char tun[96];
-    std::snprintf(tun, sizeof tun, "|u%d|b%d|bb%d|nt%d%d|c%d|m%x", t.unroll, t.block, t.bcast_block, t.nt_load, t.nt_store, t.chunked, mask);
+    std::snprintf(tun, sizeof tun, "|u%d|b%d|bb%dx%d|nt%d%d|c%d|m%x", t.unroll, t.block, t.bcast_block, t.bcast_elems, t.nt_load, t.nt_store, t.chunked, mask);
     const uint64_t key = fnv1a(p.canonical + tun);
     {
         std::lock_guard<std::mutex> lk(c->mu);

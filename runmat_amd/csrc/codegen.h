@@ -18,7 +18,10 @@ struct EwTuning {
     int block = 1024;      // streaming fast path; interleaved A/B at 8192^2 f64 (scripts/tune_ew_ab.py), GB/s for block
                            // 256 / 512 / 1024: sin(A).*B+C 5325 / 5739 / 5989, A.*B+C 4538 / 5270 / 5444, A+B 4898 / 5562 /
                            // 5748, copy 5311 / 5832 / 6047, sin(A) 5649 / 5856 / 6098
-    int bcast_block = 256; // general broadcast path: a block spans 4 * bcast_block elements of dim 0
+    int bcast_block = 256; // general broadcast path: a block spans bcast_elems * bcast_block elements of dim 0
+    int bcast_elems = 4;   // elements per thread there (their loads overlap).  Interleaved A/B (scripts/tune_bcast_ab.py),
+                           // GB/s for `A - row` / `sin(A).*row + col` at 8192^2: 256x1 4422 / 3389, 256x2 5689 / 4218,
+                           // 256x4 5885 / 4798, 1024x1 3605 / 2879, 1024x4 5648 / 4381, 256x8 5796 / 4724
     int blocks_per_cu = 16; // grid cap = blocks_per_cu * CUs (grid-stride beyond that)
     int nt_load = 1;       // non-temporal loads on the streaming fast path
     int nt_store = 1;      // non-temporal stores

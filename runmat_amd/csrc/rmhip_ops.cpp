@@ -260,7 +260,7 @@ int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf*
     } else {
         std::vector<unsigned long long> p(11 + 8 * n_in, 0);
         const unsigned long long d0 = oshape[0];
-        const unsigned long long per_block = (unsigned long long)t.bcast_block * 4;  // kBcastElems in codegen.cpp
+        const unsigned long long per_block = (unsigned long long)t.bcast_block * t.bcast_elems;
         const unsigned long long nchunks = (d0 + per_block - 1) / per_block;
         unsigned long long outer = 1;
         p[0] = d0;
