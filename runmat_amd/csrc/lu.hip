@@ -1055,7 +1055,12 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     bool blocked = kmin >= 8192 && kmin > nb;
     if (la) blocked = kmin > nb && la[0] == '1';
     if (!s.persistent) blocked = false;
-    if (blocked) s.panel_rows = 128;  // a panel block (66 KiB LDS) must fit beside a dgemm block of the update stream
+    // Under look-ahead the panels keep 256-row blocks (132 KiB of LDS: a whole CU).  The update stream's dgemm runs one
+    // block per CU (84 KiB) at low priority, so a CU is empty whenever its dgemm block retires and the waiting panel
+    // block (main stream, higher priority) takes it: all blocks are resident after about one dgemm-block time
+    // (~55 us) and the bounded spins absorb that.  128-row blocks (66 KiB) fit BESIDE a dgemm block and start at
+    // once, but twice as many blocks make every exchange slower: measured 145.8 ms against 129.0 ms at n = 16384
+    // (RMHIP_LU_PANEL_ROWS=128 selects them).
     int rc = blocked ? getrf_blocked(s, kmin, nb) : getrf_rec(s, 0, kmin);
     if (rc == RMHIP_OK && cols > rows && !blocked) {  // wide: finish U's right block (the blocked driver covers it)
         rc = laswp(s, rows, cols, 0, rows);
