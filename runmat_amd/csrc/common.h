@@ -107,6 +107,7 @@ struct Context {
     // set after a persistent-panel factorisation found its workgroups not co-resident (device shared with
     // another context): from then on LU uses the one-launch-per-column panels on a single stream
     bool lu_conservative = false;
+    int trsm_base = 128;  // base width of the triangular-solve recursion (64 on the main stream under LU look-ahead)
 
     // ---- helpers (rmhip_core.cpp) ----
     int alloc_device(size_t numel, std::shared_ptr<Allocation>* out);

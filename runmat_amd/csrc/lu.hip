@@ -561,7 +561,7 @@ __global__ void __launch_bounds__(2 * PLIST) k_laswp_lists(double* __restrict__ 
 //   MODE 0: lower, implicit unit diagonal (LU factors)        B <- L^-1 B
 //   MODE 1: lower, stored diagonal (`linsolve` LT, linsolve.rs:769-800)
 //   MODE 2: upper, stored diagonal                             B <- U^-1 B
-static constexpr int TRSM_SW = TRSM_W + 1;  // LDS row stride (doubles)
+static constexpr int TRSM_SW = TRSM_W + 1;  // LDS row stride (doubles) of a 65..128-wide solve; 65 for <= 64
 
 // value of lane `lane` (wave-uniform index) in every lane: two v_readlane_b32, no LDS round trip
 __device__ __forceinline__ double bcast_lane(double v, int lane) {
@@ -576,23 +576,25 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
 template <int MODE, int TRSM_NC, int TRSM_THREADS>
 __global__ void __launch_bounds__(TRSM_THREADS) k_trsm_fused(const double* __restrict__ T, size_t ldt, int w,
                                                              double* __restrict__ B, size_t ldb, size_t ncols) {
-    extern __shared__ double Ts[];  // [w][TRSM_SW]
+    extern __shared__ double Ts[];  // [w][sw]
+    const int wr = w > 64 ? TRSM_W : 64;  // staged rows per column (64-wide solves keep a 33 KiB footprint)
+    const int sw = wr + 1;                // LDS row stride (doubles)
     // stage the needed triangle: eight independent loads in flight per thread before the first LDS write
     // (a rolled load->write loop serialises on memory latency: 32 round trips, ~30 us per call, measured)
-    for (int base = 0; base < w * TRSM_W; base += 8 * TRSM_THREADS) {
+    for (int base = 0; base < w * wr; base += 8 * TRSM_THREADS) {
         double stage[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int idx = base + u * TRSM_THREADS + (int)threadIdx.x;
-            const int r = idx & (TRSM_W - 1), k = idx / TRSM_W;
+            const int r = idx & (wr - 1), k = idx / wr;
             const bool need = k < w && r < w && (MODE == 0 ? r > k : (MODE == 1 ? r >= k : r <= k));
             stage[u] = need ? T[r + (size_t)k * ldt] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int idx = base + u * TRSM_THREADS + (int)threadIdx.x;
-            const int r = idx & (TRSM_W - 1), k = idx / TRSM_W;
-            if (k < w) Ts[k * TRSM_SW + r] = stage[u];
+            const int r = idx & (wr - 1), k = idx / wr;
+            if (k < w) Ts[k * sw + r] = stage[u];
         }
     }
     __syncthreads();
@@ -602,8 +604,8 @@ __global__ void __launch_bounds__(TRSM_THREADS) k_trsm_fused(const double* __res
     const bool two = w > 64;
     double d0 = 1.0, d1 = 1.0;
     if (MODE != 0) {
-        if (i < w) d0 = Ts[i * TRSM_SW + i];
-        if (64 + i < w) d1 = Ts[(64 + i) * TRSM_SW + 64 + i];
+        if (i < w) d0 = Ts[i * sw + i];
+        if (64 + i < w) d1 = Ts[(64 + i) * sw + 64 + i];
     }
     // x / d sits on the dependency chain of every step (an fp64 division is ~30 dependent instructions).
     // When every diagonal entry has a finite, normal reciprocal the chain uses x * (1/d) instead (<= 1 ulp
@@ -630,8 +632,8 @@ __global__ void __launch_bounds__(TRSM_THREADS) k_trsm_fused(const double* __res
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int k = kb + u < w ? kb + u : w - 1;
-                    l0[u] = Ts[k * TRSM_SW + i];
-                    l1[u] = Ts[k * TRSM_SW + 64 + i];
+                    l0[u] = Ts[k * sw + i];
+                    l1[u] = two ? Ts[k * sw + 64 + i] : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -653,7 +655,7 @@ __global__ void __launch_bounds__(TRSM_THREADS) k_trsm_fused(const double* __res
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int k = kb + u < w ? kb + u : w - 1;
-                    l1[u] = Ts[k * TRSM_SW + 64 + i];
+                    l1[u] = two ? Ts[k * sw + 64 + i] : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -675,8 +677,8 @@ __global__ void __launch_bounds__(TRSM_THREADS) k_trsm_fused(const double* __res
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int k = kb - u >= 64 ? kb - u : 64;
-                    u0[u] = Ts[k * TRSM_SW + i];
-                    u1[u] = Ts[k * TRSM_SW + 64 + i];
+                    u0[u] = Ts[k * sw + i];
+                    u1[u] = two ? Ts[k * sw + 64 + i] : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -698,7 +700,7 @@ __global__ void __launch_bounds__(TRSM_THREADS) k_trsm_fused(const double* __res
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int k = kb - u >= 0 ? kb - u : 0;
-                    u0[u] = Ts[k * TRSM_SW + i];
+                    u0[u] = Ts[k * sw + i];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -727,7 +729,7 @@ __global__ void __launch_bounds__(TRSM_THREADS) k_trsm_fused(const double* __res
 static int launch_check(Context* c);
 template <int MODE, int NC, int TRSM_THREADS>
 static int launch_trsm_fused_nc(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
-    const size_t lds_bytes = w * TRSM_SW * sizeof(double);
+    const size_t lds_bytes = w * (w > 64 ? (size_t)TRSM_SW : (size_t)65) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_trsm_fused<MODE, NC, TRSM_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -781,9 +783,13 @@ static int launch_check(Context* c) {
     return RMHIP_OK;
 }
 
-// split point of a triangular solve wider than TRSM_W: whole base blocks on the left
-static size_t trsm_split(size_t w) {
-    size_t h = ((w / 2 + TRSM_W - 1) / TRSM_W) * TRSM_W;
+// Base size of the recursion: TRSM_W, or 64 when Context::trsm_base says so (under look-ahead a 64-wide solve's
+// 33 KiB of LDS fits beside an update dgemm block, a 128-wide one needs a whole CU and waits for one to drain).
+static size_t trsm_base(const Context* c) { return c->trsm_base == 64 ? 64 : (size_t)TRSM_W; }
+
+// split point of a triangular solve wider than the base: whole base blocks on the left
+static size_t trsm_split(size_t w, size_t base) {
+    size_t h = ((w / 2 + base - 1) / base) * base;
     if (h >= w) h = w / 2;
     return h;
 }
@@ -792,11 +798,11 @@ static size_t trsm_split(size_t w) {
 static int trsm_lower_rec(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc,
                           bool unit = true) {
     if (w == 0 || nc == 0) return RMHIP_OK;
-    if (w <= (size_t)TRSM_W) {
+    if (w <= trsm_base(c)) {
         if (lu_skip_mask() & 4) return RMHIP_OK;
         return unit ? launch_trsm_fused<0>(c, T, ldt, w, B, ldb, nc) : launch_trsm_fused<1>(c, T, ldt, w, B, ldb, nc);
     }
-    const size_t h = trsm_split(w);
+    const size_t h = trsm_split(w, trsm_base(c));
     RMHIP_TRY(trsm_lower_rec(c, T, ldt, h, B, ldb, nc, unit));
     RMHIP_TRY(lu_dgemm(c, w - h, nc, h, -1.0, T + h, ldt, B, ldb, 1.0, B + h, ldb));
     return trsm_lower_rec(c, T + h + h * ldt, ldt, w - h, B + h, ldb, nc, unit);
@@ -804,11 +810,11 @@ static int trsm_lower_rec(Context* c, const double* T, size_t ldt, size_t w, dou
 
 static int trsm_upper_rec(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
     if (w == 0 || nc == 0) return RMHIP_OK;
-    if (w <= (size_t)TRSM_W) {
+    if (w <= trsm_base(c)) {
         if (lu_skip_mask() & 4) return RMHIP_OK;
         return launch_trsm_fused<2>(c, T, ldt, w, B, ldb, nc);
     }
-    const size_t h = trsm_split(w);
+    const size_t h = trsm_split(w, trsm_base(c));
     RMHIP_TRY(trsm_upper_rec(c, T + h + h * ldt, ldt, w - h, B + h, ldb, nc));
     RMHIP_TRY(lu_dgemm(c, h, nc, w - h, -1.0, T + h * ldt, ldt, B + h, ldb, 1.0, B, ldb));
     return trsm_upper_rec(c, T, ldt, h, B, ldb, nc);
@@ -909,13 +915,17 @@ struct StreamScope {
     Context* c;
     hipStream_t saved;
     size_t saved_pad;
-    StreamScope(Context* ctx, hipStream_t s, size_t gemm_lds_pad) : c(ctx), saved(ctx->stream), saved_pad(ctx->gemm_lds_pad) {
+    int saved_base;
+    StreamScope(Context* ctx, hipStream_t s, size_t gemm_lds_pad)
+        : c(ctx), saved(ctx->stream), saved_pad(ctx->gemm_lds_pad), saved_base(ctx->trsm_base) {
         c->stream = s;
         c->gemm_lds_pad = gemm_lds_pad;
+        c->trsm_base = 128;  // the update stream owns whole CUs between its dgemm blocks anyway
     }
     ~StreamScope() {
         c->stream = saved;
         c->gemm_lds_pad = saved_pad;
+        c->trsm_base = saved_base;
     }
 };
 
@@ -952,6 +962,11 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     // block (66 KiB) or a main-stream dgemm block (73.7 KiB)
     size_t side_pad = 84 * 1024 - 73728;
     if (const char* v = std::getenv("RMHIP_LU_LA_PAD")) side_pad = (size_t)std::atoll(v);
+    // main-stream triangular solves keep the 128-wide base: a 64-wide one (33 KiB of LDS) would fit beside an update
+    // dgemm block instead of waiting for a CU to drain, but the extra launches cost more (140.7 vs 129.6 ms at
+    // n = 16384; RMHIP_LU_LA_TRSM=64 selects it)
+    const int saved_trsm_base = c->trsm_base;
+    if (const char* v = std::getenv("RMHIP_LU_LA_TRSM")) c->trsm_base = std::atoi(v) == 64 ? 64 : 128;
     int rc = RMHIP_OK;
     hipEvent_t side_done = nullptr;  // S_{j-1} finished
     {
@@ -988,6 +1003,7 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     for (hipEvent_t e : events)
         if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(side);
+    c->trsm_base = saved_trsm_base;
     return rc;
 }
 
