@@ -298,6 +298,15 @@ int launch_binary_bcast(Context* c, int op, const double* a, const double* b, do
 // ---- fills ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kStream) k_fill(double* __restrict__ out, size_t n, double value) {
     const size_t stride = (size_t)gridDim.x * kStream;
+    const size_t nvec = n >> 1;  // hipMalloc'ed buffers are 256-byte aligned: 16-byte stores
+    v2* __restrict__ ov = (v2*)out;
+    const v2 vv = {value, value};
+    for (size_t i = (size_t)blockIdx.x * kStream + threadIdx.x; i < nvec; i += stride) __builtin_nontemporal_store(vv, ov + i);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = value;
+}
+
+__global__ void __launch_bounds__(kStream) k_fill8(double* __restrict__ out, size_t n, double value) {
+    const size_t stride = (size_t)gridDim.x * kStream;
     for (size_t i = (size_t)blockIdx.x * kStream + threadIdx.x; i < n; i += stride) out[i] = value;
 }
 
@@ -316,7 +325,11 @@ __global__ void __launch_bounds__(kStream) k_fill_uniform(double* __restrict__ o
 
 int launch_fill(Context* c, double* dst, size_t n, double value) {
     if (n == 0) return RMHIP_OK;
-    hipLaunchKernelGGL(k_fill, dim3(stream_grid(c, n)), dim3(kStream), 0, c->stream, dst, n, value);
+    if (((uintptr_t)dst & 15) != 0) {  // externally wrapped, unaligned memory
+        hipLaunchKernelGGL(k_fill8, dim3(stream_grid(c, n)), dim3(kStream), 0, c->stream, dst, n, value);
+    } else {
+        hipLaunchKernelGGL(k_fill, dim3(stream_grid(c, (n + 1) / 2)), dim3(kStream), 0, c->stream, dst, n, value);
+    }
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;

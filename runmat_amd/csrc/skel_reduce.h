@@ -131,14 +131,13 @@ __device__ __forceinline__ void rm_reduce_strided(const F& f, rm_u64 pre, rm_u64
     if (i < pre) {
         const rm_u64 base = i + pre * red * j;
         rm_u64 r = begin + ly;
-        if (ty == 1) {  // sequential order; loads issued in groups of four, adds stay in order
-            for (; r + 3 < end; r += 4) {
-                const double x0 = f(base + pre * r), x1 = f(base + pre * (r + 1)), x2 = f(base + pre * (r + 2)),
-                             x3 = f(base + pre * (r + 3));
-                rm_acc_add<OP>(a0, x0);
-                rm_acc_add<OP>(a0, x1);
-                rm_acc_add<OP>(a0, x2);
-                rm_acc_add<OP>(a0, x3);
+        if (ty == 1) {  // sequential order; loads issued in groups of eight, adds stay in order
+            for (; r + 7 < end; r += 8) {
+                double x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = f(base + pre * (r + u));
+#pragma unroll
+                for (int u = 0; u < 8; ++u) rm_acc_add<OP>(a0, x[u]);
             }
             for (; r < end; ++r) rm_acc_add<OP>(a0, f(base + pre * r));
         } else {
