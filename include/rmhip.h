@@ -144,7 +144,10 @@ RMHIP_API int rmhip_wgsl_compile_check(const char* shader, int kind);
 
 enum rmhip_binary_op { /* elem_add/sub/mul/div/pow/max/min/hypot/atan2 */
     RMHIP_ADD = 0, RMHIP_SUB, RMHIP_MUL, RMHIP_DIV, RMHIP_POW, RMHIP_MAX, RMHIP_MIN, RMHIP_HYPOT,
-    RMHIP_ATAN2, RMHIP_MOD, RMHIP_REM, RMHIP_BINARY_OP_COUNT
+    RMHIP_ATAN2, RMHIP_MOD, RMHIP_REM,
+    /* elem_eq/ne/lt/le/gt/ge and logical_and/or/xor (lib.rs:1939-2068): 1.0 / 0.0 results, IEEE comparisons (NaN
+     * compares false, != true), logical operands are "non-zero" tests (simple_provider.rs:4468-4760) */
+    RMHIP_EQ, RMHIP_NE, RMHIP_LT, RMHIP_LE, RMHIP_GT, RMHIP_GE, RMHIP_AND, RMHIP_OR, RMHIP_XOR, RMHIP_BINARY_OP_COUNT
 };
 /* Operands broadcast under MATLAB implicit expansion (broadcast.rs:95-140). */
 RMHIP_API int rmhip_binary(rmhip_ctx* ctx, int op, rmhip_buf a, rmhip_buf b, rmhip_buf* out);
@@ -155,7 +158,7 @@ enum rmhip_unary_op { /* unary_* ; numbering shared with oracle/oracle.c */
     RMHIP_LOG, RMHIP_LOG2, RMHIP_LOG10, RMHIP_LOG1P, RMHIP_SQRT, RMHIP_ABS, RMHIP_SIGN,
     RMHIP_FLOOR, RMHIP_CEIL, RMHIP_ROUND, RMHIP_FIX, RMHIP_NEG, RMHIP_EXP2, RMHIP_HEAVISIDE,
     RMHIP_ISNAN, RMHIP_ISINF, RMHIP_ISFINITE, RMHIP_UPLUS, RMHIP_SINGLE /* round through f32 */, RMHIP_DOUBLE,
-    RMHIP_ERF, RMHIP_SINC, RMHIP_UNARY_OP_COUNT
+    RMHIP_ERF, RMHIP_SINC, RMHIP_NOT /* logical_not: x == 0 */, RMHIP_UNARY_OP_COUNT
 };
 RMHIP_API int rmhip_unary(rmhip_ctx* ctx, int op, rmhip_buf a, rmhip_buf* out);
 

@@ -143,6 +143,17 @@ public:
     GpuTensorHandle elem_min(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_MIN, a, b); }
     GpuTensorHandle elem_hypot(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_HYPOT, a, b); }
     GpuTensorHandle elem_atan2(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_ATAN2, a, b); }
+    // comparisons / logicals (lib.rs:1939-2068): 1.0 / 0.0 tensors
+    GpuTensorHandle elem_eq(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_EQ, a, b); }
+    GpuTensorHandle elem_ne(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_NE, a, b); }
+    GpuTensorHandle elem_lt(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_LT, a, b); }
+    GpuTensorHandle elem_le(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_LE, a, b); }
+    GpuTensorHandle elem_gt(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_GT, a, b); }
+    GpuTensorHandle elem_ge(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_GE, a, b); }
+    GpuTensorHandle logical_and(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_AND, a, b); }
+    GpuTensorHandle logical_or(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_OR, a, b); }
+    GpuTensorHandle logical_xor(const GpuTensorHandle& a, const GpuTensorHandle& b) const { return binary(RMHIP_XOR, a, b); }
+    GpuTensorHandle logical_not(const GpuTensorHandle& a) const { return unary(RMHIP_NOT, a); }
     GpuTensorHandle binary(rmhip_binary_op op, const GpuTensorHandle& a, const GpuTensorHandle& b) const {
         uint64_t out = 0;
         check(rmhip_binary(ctx_, op, own(a), own(b), &out));

@@ -84,7 +84,7 @@ enum {
     ORC_SIN = 0, ORC_COS, ORC_TAN, ORC_ASIN, ORC_ACOS, ORC_ATAN, ORC_SINH, ORC_COSH, ORC_TANH,
     ORC_ASINH, ORC_ACOSH, ORC_ATANH, ORC_EXP, ORC_EXPM1, ORC_LOG, ORC_LOG2, ORC_LOG10, ORC_LOG1P,
     ORC_SQRT, ORC_ABS, ORC_SIGN, ORC_FLOOR, ORC_CEIL, ORC_ROUND, ORC_FIX, ORC_NEG, ORC_EXP2,
-    ORC_HEAVISIDE, ORC_ISNAN, ORC_ISINF, ORC_ISFINITE, ORC_UPLUS, ORC_SINGLE, ORC_DOUBLE, ORC_ERF, ORC_SINC
+    ORC_HEAVISIDE, ORC_ISNAN, ORC_ISINF, ORC_ISFINITE, ORC_UPLUS, ORC_SINGLE, ORC_DOUBLE, ORC_ERF, ORC_SINC, ORC_NOT
 };
 
 /* crates/runmat-runtime/src/builtins/math/elementwise/sign.rs:236-246 */
@@ -134,6 +134,7 @@ static double unary_apply(int op, double v) {
         case ORC_SINGLE: return (double)(float)v; /* crates/runmat-builtins/src/lib.rs:426-436 */
         case ORC_DOUBLE: return v;
         case ORC_ERF: return erf(v);              /* libm::erf, elementwise/erf.rs:214-216 */
+        case ORC_NOT: return v == 0.0 ? 1.0 : 0.0; /* logical_not, simple_provider.rs:4776-4780 */
         case ORC_SINC: {                          /* sinc.rs:302-311 */
             if (v == 0.0) return 1.0;
             if (isfinite(v) && v == trunc(v)) return 0.0;
@@ -145,7 +146,7 @@ static double unary_apply(int op, double v) {
 }
 
 ORC_API int orc_unary(int op, const double* x, size_t n, double* out) {
-    if (op < 0 || op > ORC_SINC) return 1;
+    if (op < 0 || op > ORC_NOT) return 1;
     for (size_t i = 0; i < n; ++i) out[i] = unary_apply(op, x[i]);
     return 0;
 }
@@ -160,7 +161,7 @@ ORC_API int orc_unary(int op, const double* x, size_t n, double* out) {
  *   reduction/min.rs:1519-1531.
  * ---------------------------------------------------------------------------------------- */
 enum { ORC_ADD = 0, ORC_SUB, ORC_MUL, ORC_DIV, ORC_POW, ORC_MAX, ORC_MIN, ORC_HYPOT, ORC_ATAN2,
-       ORC_MOD, ORC_REM };
+       ORC_MOD, ORC_REM, ORC_EQ, ORC_NE, ORC_LT, ORC_LE, ORC_GT, ORC_GE, ORC_AND, ORC_OR, ORC_XOR };
 
 static double elem_max(double a, double b) { /* max.rs:2323-2344, Include-NaN, Auto comparison */
     if (a != a || b != b) return NAN;
@@ -202,6 +203,16 @@ static double binary_apply(int op, double a, double b) {
         case ORC_ATAN2: return atan2(a, b);
         case ORC_MOD: return elem_mod(a, b);
         case ORC_REM: return elem_rem(a, b);
+        /* comparisons and logicals: simple_provider.rs:4468-4760 (`lhs < rhs`, `lhs != 0.0 && rhs != 0.0`, ...) */
+        case ORC_EQ: return a == b ? 1.0 : 0.0;
+        case ORC_NE: return a != b ? 1.0 : 0.0;
+        case ORC_LT: return a < b ? 1.0 : 0.0;
+        case ORC_LE: return a <= b ? 1.0 : 0.0;
+        case ORC_GT: return a > b ? 1.0 : 0.0;
+        case ORC_GE: return a >= b ? 1.0 : 0.0;
+        case ORC_AND: return (a != 0.0 && b != 0.0) ? 1.0 : 0.0;
+        case ORC_OR: return (a != 0.0 || b != 0.0) ? 1.0 : 0.0;
+        case ORC_XOR: return ((a != 0.0) != (b != 0.0)) ? 1.0 : 0.0;
         default: return NAN;
     }
 }

@@ -64,6 +64,7 @@ __device__ __forceinline__ double unary_op(double v) {
         case RMHIP_SINGLE: return rm_f32(v);  // `single`: f64 storage rounded through f32 (runmat-builtins lib.rs:426-436)
         case RMHIP_ERF: return erf(v);        // libm::erf (elementwise/erf.rs:214-216)
         case RMHIP_SINC: return rm_sinc(v);
+        case RMHIP_NOT: return v == 0.0 ? 1.0 : 0.0;
         default: return v;
     }
 }
@@ -81,7 +82,16 @@ __device__ __forceinline__ double binary_op(double a, double b) {
         case RMHIP_HYPOT: return hypot(a, b);
         case RMHIP_ATAN2: return atan2(a, b);
         case RMHIP_MOD: return rm_mod(a, b);
-        default: return rm_rem(a, b);
+        case RMHIP_REM: return rm_rem(a, b);
+        case RMHIP_EQ: return a == b ? 1.0 : 0.0;
+        case RMHIP_NE: return a != b ? 1.0 : 0.0;
+        case RMHIP_LT: return a < b ? 1.0 : 0.0;
+        case RMHIP_LE: return a <= b ? 1.0 : 0.0;
+        case RMHIP_GT: return a > b ? 1.0 : 0.0;
+        case RMHIP_GE: return a >= b ? 1.0 : 0.0;
+        case RMHIP_AND: return (a != 0.0 && b != 0.0) ? 1.0 : 0.0;
+        case RMHIP_OR: return (a != 0.0 || b != 0.0) ? 1.0 : 0.0;
+        default: return ((a != 0.0) != (b != 0.0)) ? 1.0 : 0.0;
     }
 }
 

@@ -23,11 +23,11 @@ from . import _lib
 
 # op codes of include/rmhip.h
 BINARY_OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3, "pow": 4, "max": 5, "min": 6, "hypot": 7, "atan2": 8,
-              "mod": 9, "rem": 10}
+              "mod": 9, "rem": 10, "eq": 11, "ne": 12, "lt": 13, "le": 14, "gt": 15, "ge": 16, "and": 17, "or": 18, "xor": 19}
 UNARY_OPS = {n: i for i, n in enumerate((
     "sin", "cos", "tan", "asin", "acos", "atan", "sinh", "cosh", "tanh", "asinh", "acosh", "atanh", "exp", "expm1",
     "log", "log2", "log10", "log1p", "sqrt", "abs", "sign", "floor", "ceil", "round", "fix", "neg", "exp2",
-    "heaviside", "isnan", "isinf", "isfinite", "uplus", "single", "double", "erf", "sinc"))}
+    "heaviside", "isnan", "isinf", "isfinite", "uplus", "single", "double", "erf", "sinc", "not"))}
 SCALAR_OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3, "rsub": 4, "rdiv": 5, "max": 6, "min": 7}
 REDUCE_OPS = {"sum": 0, "mean": 1, "min": 2, "max": 3, "prod": 4}
 
@@ -296,6 +296,17 @@ class HipProvider:
     def elem_min(self, a, b): return self._binary("min", a, b)
     def elem_hypot(self, a, b): return self._binary("hypot", a, b)
     def elem_atan2(self, a, b): return self._binary("atan2", a, b)
+    # comparisons / logicals (lib.rs:1939-2068): 1.0 / 0.0 tensors
+    def elem_eq(self, a, b): return self._binary("eq", a, b)
+    def elem_ne(self, a, b): return self._binary("ne", a, b)
+    def elem_lt(self, a, b): return self._binary("lt", a, b)
+    def elem_le(self, a, b): return self._binary("le", a, b)
+    def elem_gt(self, a, b): return self._binary("gt", a, b)
+    def elem_ge(self, a, b): return self._binary("ge", a, b)
+    def logical_and(self, a, b): return self._binary("and", a, b)
+    def logical_or(self, a, b): return self._binary("or", a, b)
+    def logical_xor(self, a, b): return self._binary("xor", a, b)
+    def logical_not(self, a): return self._unary("not", a)
 
     def scalar_add(self, a, s): return self._scalar("add", a, s)
     def scalar_sub(self, a, s): return self._scalar("sub", a, s)

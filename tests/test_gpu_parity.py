@@ -1093,3 +1093,21 @@ def test_image_normalize_golden_from_reference_script(prov):
                                                  bias=f32(p["bias"]), gamma=f32(p["gamma"]), clamp_zero=True))
         mse = float(np.mean((out - imgs.reshape(-1, order="F")) ** 2))
         assert abs(mse - case["mse"]) <= 2e-5 * case["mse"], (mse, case["mse"])
+
+
+def test_comparisons_and_logicals_bit_exact(prov, oracle):
+    """elem_eq/ne/lt/le/gt/ge, logical_and/or/xor/not (lib.rs:1939-2068): IEEE comparisons, non-zero tests, broadcast."""
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.nan, np.inf, -np.inf, 2.5])
+    a = special.reshape(-1, 1)
+    b = special.reshape(1, -1)            # 8 x 1 against 1 x 8: every pair, through the broadcast kernel
+    big = np.random.default_rng(3).integers(-2, 3, (257, 129)).astype(np.float64)
+    big2 = np.random.default_rng(4).integers(-2, 3, (257, 129)).astype(np.float64)
+    for name in ("eq", "ne", "lt", "le", "gt", "ge", "and", "or", "xor"):
+        f = getattr(prov, ("elem_" if name in ("eq", "ne", "lt", "le", "gt", "ge") else "logical_") + name)
+        assert bits_equal(prov.download_matrix(f(prov.upload(a), prov.upload(b))), oracle.binary(name, a, b)), name
+        assert bits_equal(prov.download_matrix(f(prov.upload(big), prov.upload(big2))), oracle.binary(name, big, big2)), name
+    assert bits_equal(prov.download_matrix(prov.logical_not(prov.upload(a))), oracle.unary("not", a))
+    nan_row = prov.download_matrix(prov.elem_eq(prov.upload(a), prov.upload(b)))[4]
+    assert np.array_equal(nan_row, np.zeros(8))           # NaN == anything is false ...
+    assert prov.download_matrix(prov.elem_ne(prov.upload(a), prov.upload(b)))[4].all()   # ... and != is true
+    assert prov.download_matrix(prov.logical_and(prov.upload(np.array([[np.nan]])), prov.upload(np.array([[1.0]]))))[0, 0] == 1.0

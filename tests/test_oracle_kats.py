@@ -411,3 +411,15 @@ def test_covariance_kat(oracle):
     xn = x.copy(); xn[2, 1] = np.nan
     c = oracle.covariance(xn)
     assert np.isnan(c[1, :]).all() and np.isnan(c[:, 1]).all() and np.isfinite(c[0, 2])       # a non-finite column poisons its pairs only
+
+
+def test_comparison_and_logical_kats(oracle):
+    a = np.array([[1.0, 2.0, np.nan, 0.0]])
+    b = np.array([[1.0, 3.0, np.nan, -0.0]])
+    assert np.array_equal(oracle.binary("eq", a, b), [[1.0, 0.0, 0.0, 1.0]])
+    assert np.array_equal(oracle.binary("ne", a, b), [[0.0, 1.0, 1.0, 0.0]])
+    assert np.array_equal(oracle.binary("lt", a, b), [[0.0, 1.0, 0.0, 0.0]])
+    assert np.array_equal(oracle.binary("ge", a, b), [[1.0, 0.0, 0.0, 1.0]])
+    assert np.array_equal(oracle.binary("and", a, b), [[1.0, 1.0, 1.0, 0.0]])   # NaN counts as non-zero
+    assert np.array_equal(oracle.binary("xor", a, np.zeros((1, 4))), [[1.0, 1.0, 1.0, 0.0]])
+    assert np.array_equal(oracle.unary("not", a), [[0.0, 0.0, 0.0, 1.0]])
