@@ -1,8 +1,10 @@
 // provider_kats.cpp -- the reference's provider KATs written against the C++ host-side mirror
 // (include/rmhip_provider.hpp).  Mirrors crates/runmat-runtime-integration-tests/tests/gpu.rs:28-60
-// (plus / times on [1 2 3 4], [5 6 7 8]) and mtimes.rs:688-706 (column-major matmul round trip).
+// (plus / times on [1 2 3 4], [5 6 7 8]) and mtimes.rs:688-706 (column-major matmul round trip), plus one KAT per
+// widened entry point (transpose view, syrk, linsolve, mldivide, stochastic_evolution, comparisons).
 // Build: g++ -std=c++17 -Iinclude examples/provider_kats.cpp -Lrunmat_amd/csrc -lrmhip -Wl,-rpath,$PWD/runmat_amd/csrc
 // Exit code 0 = all KATs pass; 2 = no gfx950 device (the provider has no CPU fallback); 1 = mismatch.
+#include <cmath>
 #include <cstdio>
 
 #include "rmhip_provider.hpp"
@@ -28,6 +30,31 @@ int main() {
         } catch (const rmhip::ProviderError& e) {
             ok = ok && e.code == RMHIP_ERR_SHAPE;
         }
+        auto near = [](const std::vector<double>& v, std::initializer_list<double> w, double tol) {
+            if (v.size() != w.size()) return false;
+            size_t i = 0;
+            for (double x : w)
+                if (std::fabs(v[i++] - x) > tol) return false;
+            return true;
+        };
+        // transpose view consumed in place: [1 3; 2 4]' * [5 6; 7 8]   (lib.rs:2532, matmul on a view)
+        ok = ok && near(p.download(p.matmul(p.transpose(a), b2)).data, {19, 43, 22, 50}, 1e-12);
+        ok = ok && eq(p.download(p.transpose(a)).data, {1, 3, 2, 4});
+        // syrk: accelerate/tests/syrk.rs (A' * A), here on [1 3; 2 4]
+        ok = ok && near(p.download(p.syrk(a)).data, {5, 11, 11, 25}, 1e-12);
+        // linsolve LT hint: linsolve.rs:1224-1247
+        rmhip_linsolve_options_t lt{};
+        lt.lower = 1;
+        lt.need_rcond = 1;
+        auto sol = p.linsolve(p.upload({3, -1, 4, 0, 2, 1, 0, 0, 5}, {3, 3}), p.upload({9, 1, 19}, {3, 1}), lt);
+        ok = ok && near(p.download(sol.solution).data, {3, 2, 1}, 1e-12) && sol.reciprocal_condition == 2.0 / 5.0;
+        // mldivide: mldivide.rs:662-680 ([1 2; 3 4] \ [5; 6] = [-4; 4.5])
+        ok = ok && near(p.download(p.mldivide(p.upload({1, 3, 2, 4}, {2, 2}), p.upload({5, 6}, {2, 1}))).data, {-4, 4.5}, 1e-12);
+        // stochastic_evolution with zero scale: accelerate/tests/stochastic_evolution.rs:17-47
+        ok = ok && near(p.download(p.stochastic_evolution(p.upload({1, 2, 3}, {3, 1}), 0.05, 0.0, 4)).data,
+                        {std::exp(0.2), 2 * std::exp(0.2), 3 * std::exp(0.2)}, 1e-9);
+        // comparisons: 1.0 / 0.0 tensors
+        ok = ok && eq(p.download(p.elem_lt(a, b)).data, {1, 1, 1, 1}) && eq(p.download(p.elem_eq(a, a)).data, {1, 1, 1, 1});
         std::printf(ok ? "provider KATs ok\n" : "provider KATs FAILED\n");
         return ok ? 0 : 1;
     } catch (const rmhip::ProviderError& e) {
