@@ -1,7 +1,7 @@
 """GPU bring-up probe (developer tool): exercises every C-ABI entry point once against the oracle
 and prints errors/timings. Not part of the test-suite."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import oracle
 from runmat_amd import HipProvider, ReductionFlavor, ProviderError

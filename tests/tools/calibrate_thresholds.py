@@ -2,7 +2,7 @@
 one host core) for RunMat's auto-offload thresholds (crates/runmat-accelerate/src/native_auto.rs:55-81, env overrides
 :1399-1444).  Prints one JSON object; profiles/r01_offload_calibration.json is a run of this on an MI355X box."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import oracle
 from runmat_amd import HipProvider
