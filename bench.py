@@ -134,7 +134,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["fused", "dgemm", "mc", "mldivide", "chain", "mc_evolved", "image"], default="fused")
+    ap.add_argument("--workload", choices=["fused", "dgemm", "mc", "mldivide", "chain", "mc_evolved", "image", "fused_f32"], default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     args = ap.parse_args()
@@ -463,7 +463,48 @@ def main() -> None:
                          "kernel": "rm_ew_fast (16.8 MB per launch: launch-latency bound, not a roofline case)"},
         }
 
-    records = {"fused": fused_record, "dgemm": dgemm_record, "mc": mc_record, "mldivide": mldivide_record,
+    def fused_f32_record(steps, warmup):
+        # the same request on a precision-32 provider (f32 in HBM, f64 arithmetic in registers)
+        p32 = HipProvider(local_rank, precision="F32")
+        plan, out_id = sin_mul_add_plan()
+        shader = plan.generate_wgsl_for_output(out_id, "f32")
+        base = 100 * rank
+        hs = [p32.fill_uniform(s + base, lo, hi, (n, n)) for s, lo, hi in ((1, -np.pi, np.pi), (2, -1.0, 1.0), (3, -1.0, 1.0))]
+
+        def step():
+            p32.free(p32.fused_elementwise(shader, hs, (n, n), n * n))
+
+        for _ in range(warmup):
+            step()
+        p32.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        p32.synchronize()
+        barrier()
+        wall = max_over_ranks(time.perf_counter() - t0)
+        p32.timer_begin()
+        for _ in range(steps):
+            step()
+        kern_ms = p32.timer_end() / steps
+        p32.close()
+        ms = wall / steps * 1e3
+        nbytes = 4 * 4 * n * n
+        achieved = nbytes / (kern_ms * 1e-3) / 1e9
+        return {
+            "metric": "fused elementwise GB/s (D = sin(A).*B + C, 8192x8192, f32 storage on a precision-32 provider)",
+            "value": round(world * nbytes / (ms * 1e-3) / 1e9, 2), "unit": "GB/s", "ms_per_step": round(ms, 5),
+            "scaling": "weak", "dtype": "f32 storage, f64 arithmetic",
+            "config": {"workload": "fused D=sin(A).*B+C 8192x8192 via rmhip_fused_elementwise (f32 WGSL request)",
+                       "bytes_per_step_per_gpu": nbytes, "elements_per_s": round(world * n * n / (ms * 1e-3), 1),
+                       "parallelism": f"independent x{world}"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "rm_ew_fast (f32 variant: 16-byte vectors of four, body in f64)", "kernel_ms": round(kern_ms, 5)},
+        }
+
+    records = {"fused_f32": fused_f32_record, "fused": fused_record, "dgemm": dgemm_record, "mc": mc_record, "mldivide": mldivide_record,
                "chain": chain_record, "mc_evolved": mc_evolved_record, "image": image_record}
     primary = records[args.workload]
     rec = primary(args.steps, args.warmup)
@@ -475,19 +516,20 @@ def main() -> None:
     }
     if not args.no_also:
         # the other configs of BASELINE.json, short runs; every rank takes part (collectives inside)
-        others = [w for w in ("fused", "dgemm", "mc", "mc_evolved", "image", "chain") if w != args.workload]
+        others = [w for w in ("fused", "dgemm", "mc", "mc_evolved", "image", "chain", "fused_f32") if w != args.workload]
         if world == 1 and args.workload != "mldivide":
             others.append("mldivide")
         also = []
         for w in others:
-            steps = {"fused": 20, "dgemm": 5, "mc": 3, "mc_evolved": 3, "image": 5, "mldivide": 2, "chain": 100}[w]
+            steps = {"fused": 20, "dgemm": 5, "mc": 3, "mc_evolved": 3, "image": 5, "mldivide": 2, "chain": 100, "fused_f32": 20}[w]
             sec = records[w](steps, 2 if w != "mldivide" else 1)
             also.append({k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "roofline")})
         out["also"] = also
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = {"fused": cpu_baseline_fused, "dgemm": cpu_baseline_dgemm, "mc": cpu_baseline_mc,
                                "mldivide": cpu_baseline_mldivide, "chain": cpu_baseline_chain,
-                               "mc_evolved": cpu_baseline_mc, "image": cpu_baseline_fused}[args.workload]()
+                               "mc_evolved": cpu_baseline_mc, "image": cpu_baseline_fused,
+                               "fused_f32": cpu_baseline_fused}[args.workload]()
         for a in out.get("also", []):
             if a["unit"] == "GFLOP/s" and "matmul" in a["metric"]:
                 a["cpu_baseline"] = cpu_baseline_dgemm()

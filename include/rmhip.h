@@ -58,7 +58,7 @@ RMHIP_API const char* rmhip_last_error(void);
 RMHIP_API int rmhip_init(int device_ordinal, rmhip_ctx** out_ctx);
 RMHIP_API int rmhip_shutdown(rmhip_ctx* ctx);
 
-/* `device_info_struct` (lib.rs:1448-1456) + `precision` (:1458, always F64 here). */
+/* `device_info_struct` (lib.rs:1448-1456) + `precision` (:1458; 64 unless rmhip_set_precision chose 32). */
 typedef struct rmhip_device_info {
     char name[128];
     char arch[32];          /* "gfx950" */
@@ -67,11 +67,23 @@ typedef struct rmhip_device_info {
     int wavefront_size;
     int clock_mhz;
     uint64_t total_memory_bytes;
-    int precision_bits;     /* 64: ProviderPrecision::F64 (lib.rs:815-818)                     */
+    int precision_bits;     /* 64 / 32: ProviderPrecision::F64 / F32 (lib.rs:815-818)          */
     uint32_t reduction_workgroup_size; /* default_reduction_workgroup_size (lib.rs:3048)       */
     uint32_t two_pass_threshold;       /* two_pass_threshold (lib.rs:3053)                     */
 } rmhip_device_info_t;
 RMHIP_API int rmhip_device_info(rmhip_ctx* ctx, rmhip_device_info_t* out);
+
+/* `ProviderPrecision` (lib.rs:815-818) is a property of the provider: 64 (default) or 32 bits, chosen before the
+ * first buffer exists.  At 32 the host boundary is unchanged (`HostTensorView` is always f64, lib.rs:3362-3372):
+ * upload rounds to f32, download widens; tensors live in HBM as f32 (half the traffic of every bandwidth-bound op) and
+ * the planner sends its f32 shaders (`scalar_ty`, fusion.rs:1525).  Arithmetic stays f64 in registers and is rounded
+ * once on store - what the CPU path does for `single` arrays (f64 storage pre-rounded through f32,
+ * runmat-builtins/src/lib.rs:426-436) - so results agree with the CPU to f32 rounding instead of accumulating f32
+ * error.  Fused elementwise / fused reduction, the per-op elementwise hooks, reductions and dot read and write f32
+ * storage directly; matmul, lu, mldivide/linsolve and the remaining hooks run their f64 kernels on widened copies
+ * and narrow the result.  rmhip_buffer_bits reports a buffer's storage width (externally wrapped memory stays f64). */
+RMHIP_API int rmhip_set_precision(rmhip_ctx* ctx, int bits);
+RMHIP_API int rmhip_buffer_bits(rmhip_ctx* ctx, rmhip_buf id, int* bits);
 
 /* Stream plumbing: by default the context owns a non-blocking stream.  A host that already has
  * a stream (e.g. torch's current stream) can make the library enqueue there instead. */

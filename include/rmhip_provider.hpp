@@ -60,9 +60,11 @@ struct ProviderLuResult {
 
 class HipProvider {
 public:
-    explicit HipProvider(int device_ordinal = 0) {
+    // precision_bits: 64 or 32 (ProviderPrecision, lib.rs:815-818), fixed for the provider's lifetime
+    explicit HipProvider(int device_ordinal = 0, int precision_bits = 64) : precision_bits_(precision_bits) {
         static uint32_t next_device_id = 1;  // next_device_id(), lib.rs:3279
         check(rmhip_init(device_ordinal, &ctx_));
+        if (precision_bits != 64) check(rmhip_set_precision(ctx_, precision_bits));
         device_id_ = next_device_id++;
     }
     ~HipProvider() {
@@ -72,7 +74,7 @@ public:
     HipProvider& operator=(const HipProvider&) = delete;
 
     uint32_t device_id() const { return device_id_; }
-    const char* precision() const { return "F64"; }  // ProviderPrecision::F64, lib.rs:815-818
+    const char* precision() const { return precision_bits_ == 32 ? "F32" : "F64"; }  // ProviderPrecision, lib.rs:815-818
     rmhip_device_info_t device_info_struct() const {
         rmhip_device_info_t info;
         check(rmhip_device_info(ctx_, &info));
@@ -308,6 +310,7 @@ private:
         return ids;
     }
     rmhip_ctx* ctx_ = nullptr;
+    int precision_bits_ = 64;
     uint32_t device_id_ = 0;
 };
 

@@ -81,6 +81,8 @@ SIGNATURES = {
     "rmhip_init": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "rmhip_shutdown": (C.c_int, [_P]),
     "rmhip_device_info": (C.c_int, [_P, C.POINTER(DeviceInfo)]),
+    "rmhip_set_precision": (C.c_int, [_P, C.c_int]),
+    "rmhip_buffer_bits": (C.c_int, [_P, _BUF, C.POINTER(C.c_int)]),
     "rmhip_set_stream": (C.c_int, [_P, _P]),
     "rmhip_get_stream": (_P, [_P]),
     "rmhip_synchronize": (C.c_int, [_P]),

@@ -103,16 +103,20 @@ static std::string body_function(const ElementwiseProgram& p) {
 // 1-element tensor (the executor uploads scalars that way, fusion_exec.rs:305-326): it is read
 // once into an SGPR-resident value instead of being streamed.
 static void emit_fast_kernel(std::ostringstream& s, const ElementwiseProgram& p, const EwTuning& t, int vec,
-                             unsigned mask, const char* name) {
+                             unsigned mask, const char* name, bool f32) {
     const int nin = p.n_inputs, nout = (int)p.outputs.size();
-    const char* vt = vec == 2 ? "rm_v2" : "double";
+    // storage type S: f32 tensors are read and written as f32 (16-byte vectors of four), the body computes in f64
+    const char* S = f32 ? "float" : "double";
+    const char* vt = vec == 4 ? "rm_v4f" : vec == 2 ? "rm_v2" : S;
+    const std::string cast_in = f32 ? "(double)" : "";
+    const std::string cast_out = f32 ? "(float)" : "";
     auto is_scalar = [&](int k) { return (mask >> k) & 1u; };
     int n_stream = 0;
     for (int k = 0; k < nin; ++k) n_stream += is_scalar(k) ? 0 : 1;
     const int U = t.unroll_for(n_stream, program_is_heavy(p));
     s << "extern \"C\" __global__ void __launch_bounds__(" << t.block << ") " << name << "(";
-    for (int k = 0; k < nin; ++k) s << "const double* __restrict__ in" << k << ", ";
-    for (int k = 0; k < nout; ++k) s << "double* __restrict__ out" << k << ", ";
+    for (int k = 0; k < nin; ++k) s << "const " << S << "* __restrict__ in" << k << ", ";
+    for (int k = 0; k < nout; ++k) s << S << "* __restrict__ out" << k << ", ";
     s << "const rm_u64 n) {\n";
     s << "    const rm_u64 nvec_all = n / " << vec << ";\n";
     if (t.chunked) {
@@ -130,7 +134,7 @@ static void emit_fast_kernel(std::ostringstream& s, const ElementwiseProgram& p,
         s << "    rm_u64 i = (rm_u64)blockIdx.x * " << t.block << " + threadIdx.x;\n";
     }
     for (int k = 0; k < nin; ++k)
-        if (is_scalar(k)) s << "    const double s" << k << " = in" << k << "[0];\n";
+        if (is_scalar(k)) s << "    const double s" << k << " = " << cast_in << "in" << k << "[0];\n";
     auto load = [&](int k, const std::string& idx, const std::string& dst) {
         if (is_scalar(k)) return;
         s << "        const " << vt << " " << dst << " = " << (t.nt_load ? "__builtin_nontemporal_load" : "*")
@@ -138,22 +142,32 @@ static void emit_fast_kernel(std::ostringstream& s, const ElementwiseProgram& p,
     };
     auto operand = [&](int k, const std::string& sfx, const char* comp) {
         if (is_scalar(k)) return "s" + std::to_string(k);
-        return "a" + std::to_string(k) + sfx + comp;
+        return cast_in + "a" + std::to_string(k) + sfx + comp;
     };
     auto compute_store = [&](const std::string& sfx, const std::string& idx) {
         for (int k = 0; k < nout; ++k) s << "        " << vt << " r" << k << sfx << ";\n";
-        if (vec == 2) {
-            for (int lane = 0; lane < 2; ++lane) {
-                const char* c = lane ? ".y" : ".x";
+        if (vec >= 2) {
+            static const char* comps[] = {".x", ".y", ".z", ".w"};
+            for (int lane = 0; lane < vec; ++lane) {
+                const char* c = comps[lane];
                 s << "        { ";
                 for (int k = 0; k < nout; ++k) s << "double q" << k << "; ";
                 s << "rm_body(";
                 for (int k = 0; k < nin; ++k) s << (k ? ", " : "") << operand(k, sfx, c);
                 for (int k = 0; k < nout; ++k) s << ", q" << k;
                 s << "); ";
-                for (int k = 0; k < nout; ++k) s << "r" << k << sfx << c << " = q" << k << "; ";
+                for (int k = 0; k < nout; ++k) s << "r" << k << sfx << c << " = " << cast_out << "q" << k << "; ";
                 s << "}\n";
             }
+        } else if (f32) {
+            s << "        { ";
+            for (int k = 0; k < nout; ++k) s << "double q" << k << "; ";
+            s << "rm_body(";
+            for (int k = 0; k < nin; ++k) s << (k ? ", " : "") << operand(k, sfx, "");
+            for (int k = 0; k < nout; ++k) s << ", q" << k;
+            s << "); ";
+            for (int k = 0; k < nout; ++k) s << "r" << k << sfx << " = (float)q" << k << "; ";
+            s << "}\n";
         } else {
             s << "        rm_body(";
             for (int k = 0; k < nin; ++k) s << (k ? ", " : "") << operand(k, sfx, "");
@@ -185,22 +199,36 @@ static void emit_fast_kernel(std::ostringstream& s, const ElementwiseProgram& p,
         for (int k = 0; k < nout; ++k) s << "double q" << k << "; ";
         s << "rm_body(";
         for (int k = 0; k < nin; ++k)
-            s << (k ? ", " : "") << (is_scalar(k) ? "s" + std::to_string(k) : "in" + std::to_string(k) + "[n - 1]");
+            s << (k ? ", " : "") << (is_scalar(k) ? "s" + std::to_string(k) : cast_in + "in" + std::to_string(k) + "[n - 1]");
         for (int k = 0; k < nout; ++k) s << ", q" << k;
         s << ");\n";
-        for (int k = 0; k < nout; ++k) s << "        out" << k << "[n - 1] = q" << k << ";\n";
+        for (int k = 0; k < nout; ++k) s << "        out" << k << "[n - 1] = " << cast_out << "q" << k << ";\n";
+        s << "    }\n";
+    } else if (vec == 4) {  // up to three tail elements, one thread each
+        s << "    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {\n";
+        s << "        const rm_u64 t = nvec_all * 4 + threadIdx.x;\n        ";
+        for (int k = 0; k < nout; ++k) s << "double q" << k << "; ";
+        s << "rm_body(";
+        for (int k = 0; k < nin; ++k)
+            s << (k ? ", " : "") << (is_scalar(k) ? "s" + std::to_string(k) : cast_in + "in" + std::to_string(k) + "[t]");
+        for (int k = 0; k < nout; ++k) s << ", q" << k;
+        s << ");\n";
+        for (int k = 0; k < nout; ++k) s << "        out" << k << "[t] = " << cast_out << "q" << k << ";\n";
         s << "    }\n";
     }
     s << "}\n\n";
 }
 
-static void emit_bcast_kernel(std::ostringstream& s, const ElementwiseProgram& p, const EwTuning& t) {
+static void emit_bcast_kernel(std::ostringstream& s, const ElementwiseProgram& p, const EwTuning& t, bool f32) {
     const int nin = p.n_inputs, nout = (int)p.outputs.size(), E = t.bcast_elems;
+    const char* S = f32 ? "float" : "double";
+    const char* cast_in = f32 ? "(double)" : "";
+    const char* cast_out = f32 ? "(float)" : "";
     // params: v[0]=d0, v[1]=nchunks, v[2]=rank, v[3..10]=shape, v[11+8k .. ] = stride of input k
     s << "struct RmBcast { rm_u64 v[" << (11 + 8 * nin) << "]; };\n";
     s << "extern \"C\" __global__ void __launch_bounds__(" << t.bcast_block << ") rm_ew_bcast(";
-    for (int k = 0; k < nin; ++k) s << "const double* __restrict__ in" << k << ", ";
-    for (int k = 0; k < nout; ++k) s << "double* __restrict__ out" << k << ", ";
+    for (int k = 0; k < nin; ++k) s << "const " << S << "* __restrict__ in" << k << ", ";
+    for (int k = 0; k < nout; ++k) s << S << "* __restrict__ out" << k << ", ";
     s << "const RmBcast p) {\n";
     s << "    const rm_u64 d0 = p.v[0], nchunks = p.v[1];\n";
     s << "    const int rank = (int)p.v[2];\n";
@@ -222,42 +250,45 @@ static void emit_bcast_kernel(std::ostringstream& s, const ElementwiseProgram& p
         s << "    {\n        const rm_u64 i = i0 + " << (e * t.bcast_block) << "ull;\n        if (i < d0) {\n";
         for (int k = 0; k < nout; ++k) s << "            double q" << k << ";\n";
         s << "            rm_body(";
-        for (int k = 0; k < nin; ++k) s << (k ? ", " : "") << "in" << k << "[off" << k << " + i * p.v[" << (11 + 8 * k) << "]]";
+        for (int k = 0; k < nin; ++k) s << (k ? ", " : "") << cast_in << "in" << k << "[off" << k << " + i * p.v[" << (11 + 8 * k) << "]]";
         for (int k = 0; k < nout; ++k) s << ", q" << k;
         s << ");\n";
-        for (int k = 0; k < nout; ++k) s << "            out" << k << "[obase + i] = q" << k << ";\n";
+        for (int k = 0; k < nout; ++k) s << "            out" << k << "[obase + i] = " << cast_out << "q" << k << ";\n";
         s << "        }\n    }\n";
     }
     s << "}\n\n";
 }
 
-std::string generate_elementwise_source(const ElementwiseProgram& p, const EwTuning& t, unsigned mask) {
+std::string generate_elementwise_source(const ElementwiseProgram& p, const EwTuning& t, unsigned mask, bool f32) {
     std::ostringstream s;
     s << "// generated by librmhip from a fused elementwise plan (" << p.lets.size() << " ops, " << p.n_inputs
       << " inputs, " << p.outputs.size() << " outputs)\n";
     s << kSkelCommon << "\n";
-    s << "typedef double rm_v2 __attribute__((ext_vector_type(2)));\n\n";
-    s << body_function(p);
-    emit_fast_kernel(s, p, t, 2, mask, "rm_ew_fast");
-    emit_fast_kernel(s, p, t, 1, mask, "rm_ew_fast1");
-    emit_bcast_kernel(s, p, t);
+    s << "typedef double rm_v2 __attribute__((ext_vector_type(2)));\n";
+    if (f32) s << "typedef float rm_v4f __attribute__((ext_vector_type(4)));\n";
+    s << "\n" << body_function(p);
+    emit_fast_kernel(s, p, t, f32 ? 4 : 2, mask, "rm_ew_fast", f32);
+    emit_fast_kernel(s, p, t, 1, mask, "rm_ew_fast1", f32);
+    emit_bcast_kernel(s, p, t, f32);
     return s.str();
 }
 
-std::string generate_reduction_source(const ReductionProgram& p) {
+std::string generate_reduction_source(const ReductionProgram& p, bool f32) {
     std::ostringstream s;
     const int nin = p.n_inputs;
+    const std::string S = f32 ? "float" : "double";
+    const std::string cast_in = f32 ? "(double)" : "";
     s << "// generated by librmhip from a fused reduction plan (" << nin << " inputs, axis " << p.axis << ")\n";
     s << kSkelCommon << "\n" << kSkelReduce << "\n";
     s << "struct RmVal {\n";
-    for (int k = 0; k < nin; ++k) s << "    const double* __restrict__ in" << k << ";\n    rm_u64 m" << k << ";\n";
+    for (int k = 0; k < nin; ++k) s << "    const " << S << "* __restrict__ in" << k << ";\n    rm_u64 m" << k << ";\n";
     s << "    __device__ __forceinline__ double operator()(rm_u64 idx) const {\n";
-    for (int k = 0; k < nin; ++k) s << "        const double v" << k << " = in" << k << "[idx * m" << k << "];\n";
+    for (int k = 0; k < nin; ++k) s << "        const double v" << k << " = " << cast_in << "in" << k << "[idx * m" << k << "];\n";
     s << "        return " << emit_expr_f64(p.val) << ";\n    }\n};\n\n";
     auto args = [&]() {
         std::string a;
         for (int k = 0; k < nin; ++k)
-            a += "const double* __restrict__ in" + std::to_string(k) + ", const rm_u64 m" + std::to_string(k) + ", ";
+            a += "const " + S + "* __restrict__ in" + std::to_string(k) + ", const rm_u64 m" + std::to_string(k) + ", ";
         return a;
     };
     auto init = [&]() {
@@ -334,12 +365,12 @@ static int load_function(hipModule_t m, const char* name, hipFunction_t* fn) {
     return RMHIP_OK;
 }
 
-int get_elementwise_kernel(Context* c, const ElementwiseProgram& p, unsigned mask,
+int get_elementwise_kernel(Context* c, const ElementwiseProgram& p, unsigned mask, bool f32,
                            std::shared_ptr<FusedKernel>* out) {
     EwTuning t = EwTuning::from_env();
     char tun[96];
     std::snprintf(tun, sizeof tun, "|u%d|b%d|bb%dx%d|nt%d%d|c%d|m%x", t.unroll, t.block, t.bcast_block, t.bcast_elems, t.nt_load, t.nt_store, t.chunked, mask);
-    const uint64_t key = fnv1a(p.canonical + tun);
+    const uint64_t key = fnv1a(p.canonical + tun + (f32 ? "|f32" : ""));
     {
         std::lock_guard<std::mutex> lk(c->mu);
         auto it = c->kernel_cache.find(key);
@@ -351,7 +382,7 @@ int get_elementwise_kernel(Context* c, const ElementwiseProgram& p, unsigned mas
     }
     c->tel.cache_misses++;
     std::vector<char> code;
-    RMHIP_TRY(compile_to_code_object(generate_elementwise_source(p, t, mask), &code));
+    RMHIP_TRY(compile_to_code_object(generate_elementwise_source(p, t, mask, f32), &code));
     auto k = std::make_shared<FusedKernel>();
     k->tuning = t;
     k->n_inputs = p.n_inputs;
@@ -366,8 +397,8 @@ int get_elementwise_kernel(Context* c, const ElementwiseProgram& p, unsigned mas
     return RMHIP_OK;
 }
 
-int get_reduction_kernel(Context* c, const ReductionProgram& p, std::shared_ptr<FusedKernel>* out) {
-    const uint64_t key = fnv1a(p.canonical);
+int get_reduction_kernel(Context* c, const ReductionProgram& p, bool f32, std::shared_ptr<FusedKernel>* out) {
+    const uint64_t key = fnv1a(p.canonical + (f32 ? "|f32" : ""));
     {
         std::lock_guard<std::mutex> lk(c->mu);
         auto it = c->kernel_cache.find(key);
@@ -379,7 +410,7 @@ int get_reduction_kernel(Context* c, const ReductionProgram& p, std::shared_ptr<
     }
     c->tel.cache_misses++;
     std::vector<char> code;
-    RMHIP_TRY(compile_to_code_object(generate_reduction_source(p), &code));
+    RMHIP_TRY(compile_to_code_object(generate_reduction_source(p, f32), &code));
     auto k = std::make_shared<FusedKernel>();
     k->n_inputs = p.n_inputs;
     k->n_outputs = 1;

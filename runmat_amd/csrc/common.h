@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -33,6 +34,16 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
                                  hipGetErrorString(_e), __FILE__, __LINE__);                   \
     } while (0)
 
+// RMHIP_TRACE=1: step-by-step host trace on stderr (debugging aid)
+#define RMHIP_TRACEF(...)                                  \
+    do {                                                   \
+        static const bool _on = std::getenv("RMHIP_TRACE") != nullptr; \
+        if (_on) {                                         \
+            std::fprintf(stderr, "[rmhip] " __VA_ARGS__);  \
+            std::fputc('\n', stderr);                      \
+        }                                                  \
+    } while (0)
+
 #define RMHIP_TRY(expr)              \
     do {                             \
         int _rc = (expr);            \
@@ -49,6 +60,8 @@ struct Allocation {
     ~Allocation();
 };
 
+enum : uint8_t { DT_F64 = 0, DT_F32 = 1 };
+
 struct Buffer {
     std::shared_ptr<Allocation> alloc;
     std::vector<size_t> shape;
@@ -58,7 +71,12 @@ struct Buffer {
     // the base matrix C x R (column-major, leading dimension C).  matmul / syrk consume views in place through the
     // transposed-operand dgemm variants; every other consumer sees a materialised copy (Context::get).
     bool tview = false;
+    // Storage type.  A context created with 32-bit precision (`ProviderPrecision::F32`, lib.rs:815-818) keeps its
+    // tensors as f32 in HBM; arithmetic stays f64 in registers (the CPU path computes `single` arrays in f64 and
+    // rounds the result, runmat-builtins lib.rs:426-436), so only loads and stores differ.
+    uint8_t dtype = DT_F64;
     double* data() const { return alloc ? alloc->ptr : nullptr; }
+    float* data_f32() const { return alloc ? reinterpret_cast<float*>(alloc->ptr) : nullptr; }
 };
 
 struct Telemetry {
@@ -107,6 +125,11 @@ struct Context {
     // set after a persistent-panel factorisation found its workgroups not co-resident (device shared with
     // another context): from then on LU uses the one-launch-per-column panels on a single stream
     bool lu_conservative = false;
+    // 64 or 32 (rmhip_set_precision).  At 32 every op output is stored as f32: kernels with a native f32-storage variant
+    // (fused elementwise / reduction, per-op elementwise, reductions, dot) read and write f32 directly, every other op
+    // runs its f64 kernel on widened temporaries and the entry point narrows what it created on return (NarrowScope).
+    int precision = 64;
+    std::vector<uint64_t> narrow_pending;  // buffers created by new_buffer since the enclosing entry point began
     int trsm_base = 128;  // base width of the triangular-solve recursion (64 on the main stream under LU look-ahead)
 
     // ---- helpers (rmhip_core.cpp) ----
@@ -114,8 +137,13 @@ struct Context {
     void release_device(double* ptr, size_t bytes);
     int new_buffer(const size_t* shape, size_t rank, uint64_t* id, Buffer* out);
     int register_buffer(Buffer&& b, uint64_t* id);
-    int get(uint64_t id, Buffer* out);       // copies the (small) Buffer record under the lock; materialises a transpose view
-    int get_view(uint64_t id, Buffer* out);  // the raw record: `tview` may be set
+    int new_buffer_f32(const size_t* shape, size_t rank, uint64_t* id, Buffer* out);  // f32 storage, never narrowed
+    int get(uint64_t id, Buffer* out);       // f64 data, plain layout: widens f32 storage into a temporary, materialises a transpose view
+    int get_view(uint64_t id, Buffer* out);  // f64 data, `tview` may be set (matmul / syrk read views in place)
+    int get_raw(uint64_t id, Buffer* out);   // the record as stored: dtype may be DT_F32, `tview` may be set
+    int settle_view(uint64_t id);            // materialise a transpose view in its own storage type and keep it under this id
+    int narrow(uint64_t id);                 // replace an f64 buffer's storage by its f32 rounding
+    void finish_outputs(size_t mark);        // narrow everything new_buffer created since `mark` (precision 32 only)
     int ensure_scratch(size_t bytes);
 };
 
@@ -130,6 +158,19 @@ struct DeviceGuard {
     explicit DeviceGuard(const Context* c) { (void)hipSetDevice(c->device); }
 };
 
+// Declared first in every C-ABI entry point (CTX_OR_FAIL): on return, outputs the entry point created through
+// new_buffer are rounded to f32 storage when the context runs at 32-bit precision.  Nested entry points narrow their
+// own outputs, which also reproduces the CPU path's rounding after every builtin.
+struct NarrowScope {
+    Context* c;
+    size_t mark;
+    explicit NarrowScope(Context* ctx) : c(ctx), mark(ctx->narrow_pending.size()) {}
+    ~NarrowScope() {
+        if (c->precision == 32) c->finish_outputs(mark);
+        else c->narrow_pending.resize(mark);
+    }
+};
+
 struct ScopedTimer {
     std::atomic<uint64_t>* count;
     std::atomic<uint64_t>* ns;
@@ -140,6 +181,12 @@ struct ScopedTimer {
 
 // ---- kernel launchers implemented in the .hip translation units -------------------------------
 // elementwise (ew_kernels.hip)
+int launch_widen(Context* c, const float* src, double* dst, size_t n);
+int launch_narrow(Context* c, const double* src, float* dst, size_t n);
+// f32-storage variants: same arithmetic (f64 in registers), f32 loads and stores
+int launch_unary_f32(Context* c, int op, const float* a, float* out, size_t n);
+int launch_scalar_f32(Context* c, int op, const float* a, double s, float* out, size_t n);
+int launch_binary_same_f32(Context* c, int op, const float* a, const float* b, float* out, size_t n);
 int launch_fill(Context* c, double* dst, size_t n, double value);
 int launch_fill_uniform(Context* c, double* dst, size_t n, uint64_t seed, double lo, double hi);
 int launch_unary(Context* c, int op, const double* a, double* out, size_t n);
@@ -153,12 +200,18 @@ struct BroadcastDesc {  // collapsed, front-padded; dim 0 fastest. rank <= 8.
 int launch_binary_same(Context* c, int op, const double* a, const double* b, double* out, size_t n);
 int launch_binary_bcast(Context* c, int op, const double* a, const double* b, double* out,
                         size_t n, const BroadcastDesc& d);
+int launch_binary_bcast_f32(Context* c, int op, const float* a, const float* b, float* out, size_t n,
+                            const BroadcastDesc& d);
 
 // reductions (reduce_kernels.hip)
 int launch_reduce_all(Context* c, int op, int nan_mode, const double* x, size_t n, double* out);
 // x viewed as [pre, red, post] column-major; reduces the middle extent. out has pre*post elements.
 int launch_reduce_mid(Context* c, int op, int nan_mode, const double* x, size_t pre, size_t red,
                       size_t post, double* out);
+
+// f32 storage in, f64 accumulation and f64 result (the caller narrows it)
+int launch_reduce_mid_f32(Context* c, int op, int nan_mode, const float* x, size_t pre, size_t red, size_t post, double* out);
+int launch_reduce_dot_f32(Context* c, const float* a, const float* b, size_t pre, size_t red, size_t post, double* out);
 
 // sum(a .* b) over the middle extent of [pre, red, post]
 int launch_reduce_dot(Context* c, const double* a, const double* b, size_t pre, size_t red, size_t post, double* out);
@@ -204,6 +257,7 @@ int trsm_lower_unit_device(Context* c, const double* T, size_t ldt, size_t w, do
 int trsm_upper_device(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc);
 int trsm_lower_nonunit_device(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc);
 int transpose_device(Context* c, const double* src, size_t lds_, size_t rows, size_t cols, double* dst, size_t ldd);
+int transpose_device_f32(Context* c, const float* src, size_t lds_, size_t rows, size_t cols, float* dst, size_t ldd);
 int diag_stats_device(Context* c, const double* A, size_t lda, size_t n, double* min_abs, double* max_abs, size_t* zeros);
 int lu_solve_device(Context* c, const double* LU, size_t n, size_t lda, const int* perm_dev,
                     const double* B, size_t nrhs, size_t ldb, double* X, size_t ldx);

@@ -13,6 +13,21 @@
 namespace rmhip {
 
 typedef double v2 __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// 16-byte vector of the storage type T; arithmetic is always f64 (see Buffer::dtype, common.h)
+template <class T>
+struct VecOf;
+template <>
+struct VecOf<double> {
+    typedef v2 type;
+    static constexpr int N = 2;
+};
+template <>
+struct VecOf<float> {
+    typedef v4f type;
+    static constexpr int N = 4;
+};
 
 static constexpr int kBlock = 256;    // broadcast kernel: a block spans kBlock elements of dim 0
 static constexpr int kBcastE = 4;     // elements per thread in the broadcast kernel (their loads overlap)
@@ -111,39 +126,48 @@ __device__ __forceinline__ double scalar_op(double a, double s) {
 }
 
 // ---- streaming skeleton: out[i] = f(i) over 16-byte vectors -------------------------------------
-template <class F>
-__global__ void __launch_bounds__(kStream) k_stream1(const double* __restrict__ a, double* __restrict__ out, size_t n,
-                                                    F f) {
-    const size_t nvec = n >> 1;
+template <class T, class F>
+__global__ void __launch_bounds__(kStream) k_stream1(const T* __restrict__ a, T* __restrict__ out, size_t n, F f) {
+    typedef typename VecOf<T>::type V;
+    constexpr int N = VecOf<T>::N;
+    const size_t nvec = n / N;
     const size_t stride = (size_t)gridDim.x * kStream;
     size_t i = (size_t)blockIdx.x * kStream + threadIdx.x;
-    const v2* __restrict__ av = (const v2*)a;
-    v2* __restrict__ ov = (v2*)out;
+    const V* __restrict__ av = (const V*)a;
+    V* __restrict__ ov = (V*)out;
     for (; i < nvec; i += stride) {
-        v2 x = __builtin_nontemporal_load(av + i), r;
-        r.x = f(x.x);
-        r.y = f(x.y);
+        V x = __builtin_nontemporal_load(av + i), r;
+#pragma unroll
+        for (int l = 0; l < N; ++l) r[l] = (T)f((double)x[l]);
         __builtin_nontemporal_store(r, ov + i);
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = f(a[n - 1]);
+    if (blockIdx.x == 0 && threadIdx.x < n - nvec * N) {
+        const size_t t = nvec * N + threadIdx.x;
+        out[t] = (T)f((double)a[t]);
+    }
 }
 
-template <class F>
-__global__ void __launch_bounds__(kStream) k_stream2(const double* __restrict__ a, const double* __restrict__ b,
-                                                    double* __restrict__ out, size_t n, F f) {
-    const size_t nvec = n >> 1;
+template <class T, class F>
+__global__ void __launch_bounds__(kStream) k_stream2(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+                                                    size_t n, F f) {
+    typedef typename VecOf<T>::type V;
+    constexpr int N = VecOf<T>::N;
+    const size_t nvec = n / N;
     const size_t stride = (size_t)gridDim.x * kStream;
     size_t i = (size_t)blockIdx.x * kStream + threadIdx.x;
-    const v2* __restrict__ av = (const v2*)a;
-    const v2* __restrict__ bv = (const v2*)b;
-    v2* __restrict__ ov = (v2*)out;
+    const V* __restrict__ av = (const V*)a;
+    const V* __restrict__ bv = (const V*)b;
+    V* __restrict__ ov = (V*)out;
     for (; i < nvec; i += stride) {
-        v2 x = __builtin_nontemporal_load(av + i), y = __builtin_nontemporal_load(bv + i), r;
-        r.x = f(x.x, y.x);
-        r.y = f(x.y, y.y);
+        V x = __builtin_nontemporal_load(av + i), y = __builtin_nontemporal_load(bv + i), r;
+#pragma unroll
+        for (int l = 0; l < N; ++l) r[l] = (T)f((double)x[l], (double)y[l]);
         __builtin_nontemporal_store(r, ov + i);
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = f(a[n - 1], b[n - 1]);
+    if (blockIdx.x == 0 && threadIdx.x < n - nvec * N) {
+        const size_t t = nvec * N + threadIdx.x;
+        out[t] = (T)f((double)a[t], (double)b[t]);
+    }
 }
 
 template <int OP>
@@ -162,45 +186,44 @@ struct ScalarF {
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-// Unaligned (externally wrapped) memory: plain 8-byte accesses.
-template <class F>
-__global__ void __launch_bounds__(kStream) k_plain1(const double* __restrict__ a, double* __restrict__ out, size_t n,
-                                                   F f) {
+// Unaligned (externally wrapped) memory: plain element-sized accesses.
+template <class T, class F>
+__global__ void __launch_bounds__(kStream) k_plain1(const T* __restrict__ a, T* __restrict__ out, size_t n, F f) {
     const size_t stride = (size_t)gridDim.x * kStream;
-    for (size_t i = (size_t)blockIdx.x * kStream + threadIdx.x; i < n; i += stride) out[i] = f(a[i]);
+    for (size_t i = (size_t)blockIdx.x * kStream + threadIdx.x; i < n; i += stride) out[i] = (T)f((double)a[i]);
 }
-template <class F>
-__global__ void __launch_bounds__(kStream) k_plain2(const double* __restrict__ a, const double* __restrict__ b,
-                                                   double* __restrict__ out, size_t n, F f) {
+template <class T, class F>
+__global__ void __launch_bounds__(kStream) k_plain2(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+                                                   size_t n, F f) {
     const size_t stride = (size_t)gridDim.x * kStream;
-    for (size_t i = (size_t)blockIdx.x * kStream + threadIdx.x; i < n; i += stride) out[i] = f(a[i], b[i]);
+    for (size_t i = (size_t)blockIdx.x * kStream + threadIdx.x; i < n; i += stride) out[i] = (T)f((double)a[i], (double)b[i]);
 }
 
-template <class F>
-static int run1(Context* c, const double* a, double* out, size_t n, F f) {
+template <class T, class F>
+static int run1(Context* c, const T* a, T* out, size_t n, F f) {
     if (n == 0) return RMHIP_OK;
     if (aligned16(a) && aligned16(out))
-        hipLaunchKernelGGL((k_stream1<F>), dim3(stream_grid(c, n / 2)), dim3(kStream), 0, c->stream, a, out, n, f);
+        hipLaunchKernelGGL((k_stream1<T, F>), dim3(stream_grid(c, n / VecOf<T>::N)), dim3(kStream), 0, c->stream, a, out, n, f);
     else
-        hipLaunchKernelGGL((k_plain1<F>), dim3(stream_grid(c, n)), dim3(kStream), 0, c->stream, a, out, n, f);
+        hipLaunchKernelGGL((k_plain1<T, F>), dim3(stream_grid(c, n)), dim3(kStream), 0, c->stream, a, out, n, f);
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
 }
-template <class F>
-static int run2(Context* c, const double* a, const double* b, double* out, size_t n, F f) {
+template <class T, class F>
+static int run2(Context* c, const T* a, const T* b, T* out, size_t n, F f) {
     if (n == 0) return RMHIP_OK;
     if (aligned16(a) && aligned16(b) && aligned16(out))
-        hipLaunchKernelGGL((k_stream2<F>), dim3(stream_grid(c, n / 2)), dim3(kStream), 0, c->stream, a, b, out, n, f);
+        hipLaunchKernelGGL((k_stream2<T, F>), dim3(stream_grid(c, n / VecOf<T>::N)), dim3(kStream), 0, c->stream, a, b, out, n, f);
     else
-        hipLaunchKernelGGL((k_plain2<F>), dim3(stream_grid(c, n)), dim3(kStream), 0, c->stream, a, b, out, n, f);
+        hipLaunchKernelGGL((k_plain2<T, F>), dim3(stream_grid(c, n)), dim3(kStream), 0, c->stream, a, b, out, n, f);
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
 }
 
-template <int OP>
-static int unary_dispatch(Context* c, int op, const double* a, double* out, size_t n) {
+template <int OP, class T>
+static int unary_dispatch(Context* c, int op, const T* a, T* out, size_t n) {
     if (op == OP) return run1(c, a, out, n, UnaryF<OP>());
     if constexpr (OP + 1 < RMHIP_UNARY_OP_COUNT) return unary_dispatch<OP + 1>(c, op, a, out, n);
     return fail(RMHIP_ERR_UNSUPPORTED, "unary op %d not supported by provider", op);
@@ -208,9 +231,12 @@ static int unary_dispatch(Context* c, int op, const double* a, double* out, size
 int launch_unary(Context* c, int op, const double* a, double* out, size_t n) {
     return unary_dispatch<0>(c, op, a, out, n);
 }
+int launch_unary_f32(Context* c, int op, const float* a, float* out, size_t n) {
+    return unary_dispatch<0>(c, op, a, out, n);
+}
 
-template <int OP>
-static int scalar_dispatch(Context* c, int op, const double* a, double s, double* out, size_t n) {
+template <int OP, class T>
+static int scalar_dispatch(Context* c, int op, const T* a, double s, T* out, size_t n) {
     if (op == OP) return run1(c, a, out, n, ScalarF<OP>{s});
     if constexpr (OP + 1 < RMHIP_SCALAR_OP_COUNT) return scalar_dispatch<OP + 1>(c, op, a, s, out, n);
     return fail(RMHIP_ERR_UNSUPPORTED, "scalar op %d not supported by provider", op);
@@ -218,15 +244,57 @@ static int scalar_dispatch(Context* c, int op, const double* a, double s, double
 int launch_scalar(Context* c, int op, const double* a, double s, double* out, size_t n) {
     return scalar_dispatch<0>(c, op, a, s, out, n);
 }
+int launch_scalar_f32(Context* c, int op, const float* a, double s, float* out, size_t n) {
+    return scalar_dispatch<0>(c, op, a, s, out, n);
+}
 
-template <int OP>
-static int binary_same_dispatch(Context* c, int op, const double* a, const double* b, double* out, size_t n) {
+template <int OP, class T>
+static int binary_same_dispatch(Context* c, int op, const T* a, const T* b, T* out, size_t n) {
     if (op == OP) return run2(c, a, b, out, n, BinaryF<OP>());
     if constexpr (OP + 1 < RMHIP_BINARY_OP_COUNT) return binary_same_dispatch<OP + 1>(c, op, a, b, out, n);
     return fail(RMHIP_ERR_UNSUPPORTED, "binary op %d not supported by provider", op);
 }
 int launch_binary_same(Context* c, int op, const double* a, const double* b, double* out, size_t n) {
     return binary_same_dispatch<0>(c, op, a, b, out, n);
+}
+int launch_binary_same_f32(Context* c, int op, const float* a, const float* b, float* out, size_t n) {
+    return binary_same_dispatch<0>(c, op, a, b, out, n);
+}
+
+// ---- storage conversions (precision 32: widen f32 operands for the f64-only kernels, narrow their results) ----------
+__global__ void __launch_bounds__(kStream) k_widen(const float* __restrict__ src, double* __restrict__ dst, size_t n) {
+    const size_t nvec = n >> 1, stride = (size_t)gridDim.x * kStream;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    for (size_t i = (size_t)blockIdx.x * kStream + threadIdx.x; i < nvec; i += stride) {
+        const v2f x = __builtin_nontemporal_load((const v2f*)src + i);
+        v2 r = {(double)x.x, (double)x.y};
+        __builtin_nontemporal_store(r, (v2*)dst + i);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = (double)src[n - 1];
+}
+__global__ void __launch_bounds__(kStream) k_narrow(const double* __restrict__ src, float* __restrict__ dst, size_t n) {
+    const size_t nvec = n >> 1, stride = (size_t)gridDim.x * kStream;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    for (size_t i = (size_t)blockIdx.x * kStream + threadIdx.x; i < nvec; i += stride) {
+        const v2 x = __builtin_nontemporal_load((const v2*)src + i);
+        v2f r = {(float)x.x, (float)x.y};
+        __builtin_nontemporal_store(r, (v2f*)dst + i);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = (float)src[n - 1];
+}
+int launch_widen(Context* c, const float* src, double* dst, size_t n) {
+    if (n == 0) return RMHIP_OK;
+    hipLaunchKernelGGL(k_widen, dim3(stream_grid(c, (n + 1) / 2)), dim3(kStream), 0, c->stream, src, dst, n);
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+int launch_narrow(Context* c, const double* src, float* dst, size_t n) {
+    if (n == 0) return RMHIP_OK;
+    hipLaunchKernelGGL(k_narrow, dim3(stream_grid(c, (n + 1) / 2)), dim3(kStream), 0, c->stream, src, dst, n);
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
 }
 
 // ---- broadcast binary: dim 0 along threads (coalesced when stride 1, uniform when 0), the outer
@@ -238,9 +306,9 @@ struct BcastParams {
     unsigned long long shape[8], sa[8], sb[8];
 };
 
-template <class F>
-__global__ void __launch_bounds__(kBlock) k_bcast2(const double* __restrict__ a, const double* __restrict__ b,
-                                                   double* __restrict__ out, BcastParams p, F f) {
+template <class T, class F>
+__global__ void __launch_bounds__(kBlock) k_bcast2(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+                                                   BcastParams p, F f) {
     const unsigned long long blk = blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y;
     const unsigned long long chunk = blk % p.nchunks;
     const unsigned long long outer = blk / p.nchunks;
@@ -261,19 +329,18 @@ __global__ void __launch_bounds__(kBlock) k_bcast2(const double* __restrict__ a,
     for (int e = 0; e < kBcastE; ++e) {
         const unsigned long long i = i0 + (unsigned long long)e * kBlock;
         const bool ok = i < p.d0;
-        x[e] = ok ? a[offa + i * p.sa[0]] : 0.0;
-        y[e] = ok ? b[offb + i * p.sb[0]] : 1.0;
+        x[e] = ok ? (double)a[offa + i * p.sa[0]] : 0.0;
+        y[e] = ok ? (double)b[offb + i * p.sb[0]] : 1.0;
     }
 #pragma unroll
     for (int e = 0; e < kBcastE; ++e) {
         const unsigned long long i = i0 + (unsigned long long)e * kBlock;
-        if (i < p.d0) out[obase + i] = f(x[e], y[e]);
+        if (i < p.d0) out[obase + i] = (T)f(x[e], y[e]);
     }
 }
 
-template <int OP>
-static int binary_bcast_dispatch(Context* c, int op, const double* a, const double* b, double* out, size_t n,
-                                 const BroadcastDesc& d) {
+template <int OP, class T>
+static int binary_bcast_dispatch(Context* c, int op, const T* a, const T* b, T* out, size_t n, const BroadcastDesc& d) {
     if (op == OP) {
         if (n == 0) return RMHIP_OK;
         BcastParams p;
@@ -291,7 +358,7 @@ static int binary_bcast_dispatch(Context* c, int op, const double* a, const doub
         const unsigned long long gx = blocks < 1048576ULL ? blocks : 1048576ULL;
         const unsigned long long gy = (blocks + gx - 1) / gx;
         if (gy > 65535ULL) return fail(RMHIP_ERR_UNSUPPORTED, "broadcast grid too large");
-        hipLaunchKernelGGL((k_bcast2<BinaryF<OP>>), dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, c->stream, a, b,
+        hipLaunchKernelGGL((k_bcast2<T, BinaryF<OP>>), dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, c->stream, a, b,
                            out, p, BinaryF<OP>());
         c->tel.kernel_launches++;
         RMHIP_HIP_CHECK(hipGetLastError());
@@ -302,6 +369,10 @@ static int binary_bcast_dispatch(Context* c, int op, const double* a, const doub
 }
 int launch_binary_bcast(Context* c, int op, const double* a, const double* b, double* out, size_t n,
                         const BroadcastDesc& d) {
+    return binary_bcast_dispatch<0>(c, op, a, b, out, n, d);
+}
+int launch_binary_bcast_f32(Context* c, int op, const float* a, const float* b, float* out, size_t n,
+                            const BroadcastDesc& d) {
     return binary_bcast_dispatch<0>(c, op, a, b, out, n, d);
 }
 

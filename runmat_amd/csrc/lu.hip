@@ -1207,9 +1207,10 @@ int trsm_lower_nonunit_device(Context* c, const double* T, size_t ldt, size_t w,
 // 64x64 tiles through LDS (row stride 65 doubles: conflict-free both ways); a wave reads 512
 // contiguous bytes of a source column and writes 512 contiguous bytes of a destination column.
 static constexpr int TR_TILE = 64;
-__global__ void __launch_bounds__(256) k_transpose(const double* __restrict__ src, size_t lds_, size_t rows, size_t cols,
-                                                   double* __restrict__ dst, size_t ldd) {
-    __shared__ double tile[TR_TILE][TR_TILE + 1];
+template <class T>
+__global__ void __launch_bounds__(256) k_transpose(const T* __restrict__ src, size_t lds_, size_t rows, size_t cols,
+                                                   T* __restrict__ dst, size_t ldd) {
+    __shared__ T tile[TR_TILE][TR_TILE + 1];
     const size_t r0 = (size_t)blockIdx.x * TR_TILE, c0 = (size_t)blockIdx.y * TR_TILE;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
 #pragma unroll 4
@@ -1229,7 +1230,15 @@ int transpose_device(Context* c, const double* src, size_t lds_, size_t rows, si
     if (rows == 0 || cols == 0) return RMHIP_OK;
     const size_t gx = (rows + TR_TILE - 1) / TR_TILE, gy = (cols + TR_TILE - 1) / TR_TILE;
     if (gy > 65535) return fail(RMHIP_ERR_UNSUPPORTED, "transpose: more than %d columns", 65535 * TR_TILE);
-    hipLaunchKernelGGL(k_transpose, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, c->stream, src, lds_, rows, cols, dst, ldd);
+    hipLaunchKernelGGL(k_transpose<double>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, c->stream, src, lds_, rows, cols, dst, ldd);
+    return launch_check(c);
+}
+
+int transpose_device_f32(Context* c, const float* src, size_t lds_, size_t rows, size_t cols, float* dst, size_t ldd) {
+    if (rows == 0 || cols == 0) return RMHIP_OK;
+    const size_t gx = (rows + TR_TILE - 1) / TR_TILE, gy = (cols + TR_TILE - 1) / TR_TILE;
+    if (gy > 65535) return fail(RMHIP_ERR_UNSUPPORTED, "transpose: more than %d columns", 65535 * TR_TILE);
+    hipLaunchKernelGGL(k_transpose<float>, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, c->stream, src, lds_, rows, cols, dst, ldd);
     return launch_check(c);
 }
 

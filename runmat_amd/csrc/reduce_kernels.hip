@@ -11,23 +11,33 @@
 
 namespace rmhip {
 
+// T = storage type (double, or float for precision-32 contexts); accumulation is f64 either way
+template <class T>
 struct IdentityVal {
-    const double* __restrict__ x;
-    __device__ __forceinline__ double operator()(rm_u64 idx) const { return x[idx]; }
+    const T* __restrict__ x;
+    __device__ __forceinline__ double operator()(rm_u64 idx) const { return (double)x[idx]; }
 };
 
-template <int OP>
-__global__ void __launch_bounds__(RM_ABLOCK) k_reduce_contig(const double* x, rm_u64 red, rm_u64 nslices,
+template <int OP, class T>
+__global__ void __launch_bounds__(RM_ABLOCK) k_reduce_contig(const T* x, rm_u64 red, rm_u64 nslices,
                                                              rm_u64 nsplit, double* pv, double* pn) {
-    IdentityVal f{x};
+    IdentityVal<T> f{x};
     rm_reduce_contig<OP>(f, red, nslices, nsplit, pv, pn);
 }
 // Same reduction over 16-byte vectors (plain tensors, even slice length, 16-byte aligned base): 1 KiB per wave
 // instruction instead of 512 B, non-temporal.  The pairing changes only the (deterministic) summation grouping.
 typedef double rm_rv2 __attribute__((ext_vector_type(2)));
+typedef float rm_rv2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rm_rv2 rm_load2(const double* x, rm_u64 i2) { return __builtin_nontemporal_load((const rm_rv2*)x + i2); }
+__device__ __forceinline__ rm_rv2 rm_load2(const float* x, rm_u64 i2) {
+    const rm_rv2f v = __builtin_nontemporal_load((const rm_rv2f*)x + i2);
+    rm_rv2 r = {(double)v.x, (double)v.y};
+    return r;
+}
+template <class T>
 struct IdentityVal2 {
-    const double* __restrict__ x;
-    __device__ __forceinline__ rm_rv2 operator()(rm_u64 i2) const { return __builtin_nontemporal_load((const rm_rv2*)x + i2); }
+    const T* __restrict__ x;
+    __device__ __forceinline__ rm_rv2 operator()(rm_u64 i2) const { return rm_load2(x, i2); }
 };
 template <int OP, class F2>
 __device__ __forceinline__ void rm_reduce_contig_v2(const F2& f2, rm_u64 red, rm_u64 nslices, rm_u64 nsplit, double* pv,
@@ -69,17 +79,17 @@ __device__ __forceinline__ void rm_reduce_contig_v2(const F2& f2, rm_u64 red, rm
         pn[slice * nsplit + split] = a0.nan;
     }
 }
-template <int OP>
-__global__ void __launch_bounds__(RM_ABLOCK) k_reduce_contig_v2(const double* x, rm_u64 red, rm_u64 nslices,
+template <int OP, class T>
+__global__ void __launch_bounds__(RM_ABLOCK) k_reduce_contig_v2(const T* x, rm_u64 red, rm_u64 nslices,
                                                                 rm_u64 nsplit, double* pv, double* pn) {
-    IdentityVal2 f2{x};
+    IdentityVal2<T> f2{x};
     rm_reduce_contig_v2<OP>(f2, red, nslices, nsplit, pv, pn);
 }
 
-template <int OP>
-__global__ void __launch_bounds__(RM_RBLOCK) k_reduce_strided(const double* x, rm_u64 pre, rm_u64 red, rm_u64 nsplit,
+template <int OP, class T>
+__global__ void __launch_bounds__(RM_RBLOCK) k_reduce_strided(const T* x, rm_u64 pre, rm_u64 red, rm_u64 nsplit,
                                                               int tx, double* pv, double* pn) {
-    IdentityVal f{x};
+    IdentityVal<T> f{x};
     rm_reduce_strided<OP>(f, pre, red, nsplit, tx, pv, pn);
 }
 template <int OP>
@@ -89,8 +99,8 @@ __global__ void __launch_bounds__(RM_RBLOCK) k_reduce_final(const double* pv, co
     rm_reduce_finalize<OP>(pv, pn, nslices, nsplit, red, mean, omitnan, scale, out);
 }
 
-template <int OP>
-static int run_reduce(Context* c, int mean, int nan_mode, const double* x, size_t pre, size_t red, size_t post,
+template <int OP, class T>
+static int run_reduce(Context* c, int mean, int nan_mode, const T* x, size_t pre, size_t red, size_t post,
                       double* out) {
     if (pre == 0 || post == 0) return RMHIP_OK;  // no output slices
     const ReducePlan p = plan_reduction(pre, red, post, c->num_cus);
@@ -100,13 +110,13 @@ static int run_reduce(Context* c, int mean, int nan_mode, const double* x, size_
     double* pv = c->scratch;
     double* pn = c->scratch + nparts;
     if (p.contiguous && (red & 1) == 0 && red >= 2048 && (((uintptr_t)x) & 15) == 0)
-        hipLaunchKernelGGL((k_reduce_contig_v2<OP>), dim3(p.gx, p.gy, p.gz), dim3(p.tx), 0, c->stream, x, (rm_u64)red,
+        hipLaunchKernelGGL((k_reduce_contig_v2<OP, T>), dim3(p.gx, p.gy, p.gz), dim3(p.tx), 0, c->stream, x, (rm_u64)red,
                            (rm_u64)p.nslices, (rm_u64)p.nsplit, pv, pn);
     else if (p.contiguous)
-        hipLaunchKernelGGL((k_reduce_contig<OP>), dim3(p.gx, p.gy, p.gz), dim3(p.tx), 0, c->stream, x,
+        hipLaunchKernelGGL((k_reduce_contig<OP, T>), dim3(p.gx, p.gy, p.gz), dim3(p.tx), 0, c->stream, x,
                            (rm_u64)red, (rm_u64)p.nslices, (rm_u64)p.nsplit, pv, pn);
     else
-        hipLaunchKernelGGL((k_reduce_strided<OP>), dim3(p.gx, p.gy, p.gz), dim3(RM_RBLOCK), 0, c->stream, x,
+        hipLaunchKernelGGL((k_reduce_strided<OP, T>), dim3(p.gx, p.gy, p.gz), dim3(RM_RBLOCK), 0, c->stream, x,
                            (rm_u64)pre, (rm_u64)red, (rm_u64)p.nsplit, p.tx, pv, pn);
     RMHIP_HIP_CHECK(hipGetLastError());
     const unsigned fb = (unsigned)ceil_div_u64(p.nslices, RM_RBLOCK / 64);
@@ -117,8 +127,8 @@ static int run_reduce(Context* c, int mean, int nan_mode, const double* x, size_
     return RMHIP_OK;
 }
 
-int launch_reduce_mid(Context* c, int op, int nan_mode, const double* x, size_t pre, size_t red, size_t post,
-                      double* out) {
+template <class T>
+static int reduce_mid_any(Context* c, int op, int nan_mode, const T* x, size_t pre, size_t red, size_t post, double* out) {
     switch (op) {
         case RMHIP_RSUM: return run_reduce<RM_RSUM>(c, 0, nan_mode, x, pre, red, post, out);
         case RMHIP_RMEAN: return run_reduce<RM_RSUM>(c, 1, nan_mode, x, pre, red, post, out);
@@ -128,38 +138,52 @@ int launch_reduce_mid(Context* c, int op, int nan_mode, const double* x, size_t 
         default: return fail(RMHIP_ERR_UNSUPPORTED, "reduce op %d not supported by provider", op);
     }
 }
+int launch_reduce_mid(Context* c, int op, int nan_mode, const double* x, size_t pre, size_t red, size_t post,
+                      double* out) {
+    return reduce_mid_any(c, op, nan_mode, x, pre, red, post, out);
+}
+int launch_reduce_mid_f32(Context* c, int op, int nan_mode, const float* x, size_t pre, size_t red, size_t post,
+                          double* out) {
+    return reduce_mid_any(c, op, nan_mode, x, pre, red, post, out);
+}
 
 // ---- dot: the producer a.*b folded into the same skeleton (no temporary array) -------------------
+template <class T>
 struct ProductVal {
-    const double* __restrict__ a;
-    const double* __restrict__ b;
-    __device__ __forceinline__ double operator()(rm_u64 idx) const { return a[idx] * b[idx]; }
+    const T* __restrict__ a;
+    const T* __restrict__ b;
+    __device__ __forceinline__ double operator()(rm_u64 idx) const { return (double)a[idx] * (double)b[idx]; }
 };
-__global__ void __launch_bounds__(RM_ABLOCK) k_dot_contig(const double* a, const double* b, rm_u64 red, rm_u64 nslices,
+template <class T>
+__global__ void __launch_bounds__(RM_ABLOCK) k_dot_contig(const T* a, const T* b, rm_u64 red, rm_u64 nslices,
                                                           rm_u64 nsplit, double* pv, double* pn) {
-    ProductVal f{a, b};
+    ProductVal<T> f{a, b};
     rm_reduce_contig<RM_RSUM>(f, red, nslices, nsplit, pv, pn);
 }
+template <class T>
 struct ProductVal2 {
-    const double* __restrict__ a;
-    const double* __restrict__ b;
+    const T* __restrict__ a;
+    const T* __restrict__ b;
     __device__ __forceinline__ rm_rv2 operator()(rm_u64 i2) const {
-        const rm_rv2 va = __builtin_nontemporal_load((const rm_rv2*)a + i2), vb = __builtin_nontemporal_load((const rm_rv2*)b + i2);
+        const rm_rv2 va = rm_load2(a, i2), vb = rm_load2(b, i2);
         return va * vb;
     }
 };
-__global__ void __launch_bounds__(RM_ABLOCK) k_dot_contig_v2(const double* a, const double* b, rm_u64 red, rm_u64 nslices,
+template <class T>
+__global__ void __launch_bounds__(RM_ABLOCK) k_dot_contig_v2(const T* a, const T* b, rm_u64 red, rm_u64 nslices,
                                                              rm_u64 nsplit, double* pv, double* pn) {
-    ProductVal2 f2{a, b};
+    ProductVal2<T> f2{a, b};
     rm_reduce_contig_v2<RM_RSUM>(f2, red, nslices, nsplit, pv, pn);
 }
-__global__ void __launch_bounds__(RM_RBLOCK) k_dot_strided(const double* a, const double* b, rm_u64 pre, rm_u64 red,
+template <class T>
+__global__ void __launch_bounds__(RM_RBLOCK) k_dot_strided(const T* a, const T* b, rm_u64 pre, rm_u64 red,
                                                            rm_u64 nsplit, int tx, double* pv, double* pn) {
-    ProductVal f{a, b};
+    ProductVal<T> f{a, b};
     rm_reduce_strided<RM_RSUM>(f, pre, red, nsplit, tx, pv, pn);
 }
 
-int launch_reduce_dot(Context* c, const double* a, const double* b, size_t pre, size_t red, size_t post, double* out) {
+template <class T>
+static int reduce_dot_any(Context* c, const T* a, const T* b, size_t pre, size_t red, size_t post, double* out) {
     if (pre == 0 || post == 0) return RMHIP_OK;  // no output slices
     const ReducePlan p = plan_reduction(pre, red, post, c->num_cus);
     if (!p.valid) return fail(RMHIP_ERR_UNSUPPORTED, "dot: geometry [%zu,%zu,%zu] exceeds launch limits", pre, red, post);
@@ -168,13 +192,13 @@ int launch_reduce_dot(Context* c, const double* a, const double* b, size_t pre, 
     double* pv = c->scratch;
     double* pn = c->scratch + nparts;
     if (p.contiguous && (red & 1) == 0 && red >= 2048 && ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0)
-        hipLaunchKernelGGL(k_dot_contig_v2, dim3(p.gx, p.gy, p.gz), dim3(p.tx), 0, c->stream, a, b, (rm_u64)red,
+        hipLaunchKernelGGL((k_dot_contig_v2<T>), dim3(p.gx, p.gy, p.gz), dim3(p.tx), 0, c->stream, a, b, (rm_u64)red,
                            (rm_u64)p.nslices, (rm_u64)p.nsplit, pv, pn);
     else if (p.contiguous)
-        hipLaunchKernelGGL(k_dot_contig, dim3(p.gx, p.gy, p.gz), dim3(p.tx), 0, c->stream, a, b, (rm_u64)red,
+        hipLaunchKernelGGL((k_dot_contig<T>), dim3(p.gx, p.gy, p.gz), dim3(p.tx), 0, c->stream, a, b, (rm_u64)red,
                            (rm_u64)p.nslices, (rm_u64)p.nsplit, pv, pn);
     else
-        hipLaunchKernelGGL(k_dot_strided, dim3(p.gx, p.gy, p.gz), dim3(RM_RBLOCK), 0, c->stream, a, b, (rm_u64)pre,
+        hipLaunchKernelGGL((k_dot_strided<T>), dim3(p.gx, p.gy, p.gz), dim3(RM_RBLOCK), 0, c->stream, a, b, (rm_u64)pre,
                            (rm_u64)red, (rm_u64)p.nsplit, p.tx, pv, pn);
     RMHIP_HIP_CHECK(hipGetLastError());
     const unsigned fb = (unsigned)ceil_div_u64(p.nslices, RM_RBLOCK / 64);
@@ -183,6 +207,12 @@ int launch_reduce_dot(Context* c, const double* a, const double* b, size_t pre, 
     RMHIP_HIP_CHECK(hipGetLastError());
     c->tel.kernel_launches += 2;
     return RMHIP_OK;
+}
+int launch_reduce_dot(Context* c, const double* a, const double* b, size_t pre, size_t red, size_t post, double* out) {
+    return reduce_dot_any(c, a, b, pre, red, post, out);
+}
+int launch_reduce_dot_f32(Context* c, const float* a, const float* b, size_t pre, size_t red, size_t post, double* out) {
+    return reduce_dot_any(c, a, b, pre, red, post, out);
 }
 
 int launch_reduce_all(Context* c, int op, int nan_mode, const double* x, size_t n, double* out) {

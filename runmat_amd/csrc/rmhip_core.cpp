@@ -124,36 +124,104 @@ int Context::new_buffer(const size_t* shape, size_t rank, uint64_t* id, Buffer* 
     b.numel = shape_numel(shape, rank);
     RMHIP_TRY(alloc_device(b.numel, &b.alloc));
     if (out) *out = b;
+    RMHIP_TRY(register_buffer(std::move(b), id));
+    if (precision == 32) narrow_pending.push_back(*id);
+    return RMHIP_OK;
+}
+
+int Context::new_buffer_f32(const size_t* shape, size_t rank, uint64_t* id, Buffer* out) {
+    Buffer b;
+    b.shape.assign(shape, shape + rank);
+    b.numel = shape_numel(shape, rank);
+    b.dtype = DT_F32;
+    RMHIP_TRY(alloc_device((b.numel + 1) / 2, &b.alloc));
+    if (out) *out = b;
     return register_buffer(std::move(b), id);
 }
 
-int Context::get_view(uint64_t id, Buffer* out) {
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = table.find(id);
-    if (it == table.end()) return fail(RMHIP_ERR_NOT_FOUND, "buffer not found: %llu", (unsigned long long)id);
-    *out = it->second;
-    return RMHIP_OK;
-}
-
-int Context::get(uint64_t id, Buffer* out) {
-    RMHIP_TRY(get_view(id, out));
-    if (!out->tview) return RMHIP_OK;
-    // a consumer that cannot address a transposed operand: materialise once and keep the plain copy under this id
-    const size_t R = out->shape[0], C = out->shape[1];  // logical R x C, storage = base C x R
-    std::shared_ptr<Allocation> fresh;
-    RMHIP_TRY(alloc_device(out->numel ? out->numel : 1, &fresh));
-    RMHIP_TRY(transpose_device(this, out->data(), C, C, R, fresh->ptr, R));
+int Context::get_raw(uint64_t id, Buffer* out) {
+    Buffer rec;
     {
         std::lock_guard<std::mutex> lk(mu);
         auto it = table.find(id);
-        if (it != table.end() && it->second.tview && it->second.alloc == out->alloc) {
-            it->second.alloc = fresh;
-            it->second.tview = false;
-        }
+        if (it == table.end()) return fail(RMHIP_ERR_NOT_FOUND, "buffer not found: %llu", (unsigned long long)id);
+        rec = it->second;
     }
-    out->alloc = fresh;
-    out->tview = false;
+    // assigned outside the lock: `*out` may hold the last reference to a temporary (a widened or materialised copy),
+    // whose release takes `mu` again
+    *out = std::move(rec);
     return RMHIP_OK;
+}
+
+int Context::get_view(uint64_t id, Buffer* out) {
+    RMHIP_TRY(get_raw(id, out));
+    if (out->dtype == DT_F64) return RMHIP_OK;
+    RMHIP_TRACEF("widen id %llu numel %zu tview %d", (unsigned long long)id, out->numel, (int)out->tview);
+    // f32 storage read by an f64 kernel: widen into a temporary that lives as long as the caller's Buffer copy
+    std::shared_ptr<Allocation> wide;
+    RMHIP_TRY(alloc_device(out->numel ? out->numel : 1, &wide));
+    RMHIP_TRY(launch_widen(this, out->data_f32(), wide->ptr, out->numel));
+    out->alloc = wide;
+    out->dtype = DT_F64;
+    return RMHIP_OK;
+}
+
+int Context::settle_view(uint64_t id) {
+    Buffer raw;
+    RMHIP_TRY(get_raw(id, &raw));
+    if (!raw.tview) return RMHIP_OK;
+    const size_t R = raw.shape[0], C = raw.shape[1];  // logical R x C, storage = base C x R
+    RMHIP_TRACEF("materialise view id %llu %zux%zu (%s storage)", (unsigned long long)id, R, C, raw.dtype == DT_F32 ? "f32" : "f64");
+    std::shared_ptr<Allocation> fresh;
+    if (raw.dtype == DT_F32) {
+        RMHIP_TRY(alloc_device((raw.numel + 1) / 2 ? (raw.numel + 1) / 2 : 1, &fresh));
+        RMHIP_TRY(transpose_device_f32(this, raw.data_f32(), C, C, R, reinterpret_cast<float*>(fresh->ptr), R));
+    } else {
+        RMHIP_TRY(alloc_device(raw.numel ? raw.numel : 1, &fresh));
+        RMHIP_TRY(transpose_device(this, raw.data(), C, C, R, fresh->ptr, R));
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = table.find(id);
+    if (it != table.end() && it->second.tview && it->second.alloc == raw.alloc) {
+        it->second.alloc = fresh;  // `raw` still references the base storage: nothing is released under the lock
+        it->second.tview = false;
+    }
+    return RMHIP_OK;
+}
+
+int Context::narrow(uint64_t id) {
+    Buffer b;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = table.find(id);
+        if (it == table.end()) return RMHIP_OK;  // freed on an error path
+        b = it->second;
+    }
+    if (b.dtype != DT_F64 || !b.alloc || b.alloc->external) return RMHIP_OK;
+    RMHIP_TRACEF("narrow id %llu numel %zu", (unsigned long long)id, b.numel);
+    std::shared_ptr<Allocation> slim;
+    RMHIP_TRY(alloc_device((b.numel + 1) / 2 ? (b.numel + 1) / 2 : 1, &slim));
+    RMHIP_TRY(launch_narrow(this, b.data(), reinterpret_cast<float*>(slim->ptr), b.numel));
+    std::lock_guard<std::mutex> lk(mu);
+    // every alias of this storage created inside the same entry point (reshape of a fresh result) moves with it
+    for (auto& kv : table)
+        if (kv.second.alloc == b.alloc && kv.second.dtype == DT_F64) {
+            kv.second.alloc = slim;
+            kv.second.dtype = DT_F32;
+        }
+    return RMHIP_OK;
+}
+
+void Context::finish_outputs(size_t mark) {
+    for (size_t i = mark; i < narrow_pending.size(); ++i) (void)narrow(narrow_pending[i]);  // on failure the buffer stays f64: still valid
+    narrow_pending.resize(mark);
+}
+
+int Context::get(uint64_t id, Buffer* out) {
+    // a consumer that cannot address a transposed operand: materialise once and keep the plain copy under this id
+    RMHIP_TRY(get_raw(id, out));
+    if (out->tview) RMHIP_TRY(settle_view(id));
+    return get_view(id, out);
 }
 
 int Context::ensure_scratch(size_t bytes) {
@@ -181,7 +249,8 @@ struct rmhip_ctx {
 #define CTX_OR_FAIL(ctx)                                                  \
     if (!(ctx)) return fail(RMHIP_ERR_INVALID, "null context");           \
     Context* c = &(ctx)->c;                                               \
-    DeviceGuard _dg(c)
+    DeviceGuard _dg(c);                                                   \
+    NarrowScope _ns(c)
 
 extern "C" {
 
@@ -260,7 +329,7 @@ int rmhip_device_info(rmhip_ctx* ctx, rmhip_device_info_t* out) {
     out->wavefront_size = c->props.warpSize;
     out->clock_mhz = c->props.clockRate / 1000;
     out->total_memory_bytes = c->props.totalGlobalMem;
-    out->precision_bits = 64;
+    out->precision_bits = c->precision;
     out->reduction_workgroup_size = 256;
     out->two_pass_threshold = 262144;
     return RMHIP_OK;
@@ -272,6 +341,25 @@ int rmhip_set_stream(rmhip_ctx* ctx, void* hip_stream) {
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)hip_stream;
     c->owns_stream = false;
+    return RMHIP_OK;
+}
+
+int rmhip_set_precision(rmhip_ctx* ctx, int bits) {
+    CTX_OR_FAIL(ctx);
+    if (bits != 32 && bits != 64) return fail(RMHIP_ERR_INVALID, "precision must be 32 or 64 bits, got %d", bits);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->table.empty() && bits != c->precision)
+        return fail(RMHIP_ERR_INVALID, "precision is a property of the provider: set it before the first buffer exists");
+    c->precision = bits;
+    return RMHIP_OK;
+}
+
+int rmhip_buffer_bits(rmhip_ctx* ctx, rmhip_buf id, int* bits) {
+    CTX_OR_FAIL(ctx);
+    if (!bits) return fail(RMHIP_ERR_INVALID, "null bits");
+    Buffer b;
+    RMHIP_TRY(c->get_raw(id, &b));
+    *bits = b.dtype == DT_F32 ? 32 : 64;
     return RMHIP_OK;
 }
 
@@ -333,7 +421,7 @@ int rmhip_shape(rmhip_ctx* ctx, rmhip_buf id, size_t* rank_inout, size_t* shape_
     CTX_OR_FAIL(ctx);
     if (!rank_inout) return fail(RMHIP_ERR_INVALID, "null rank");
     Buffer b;
-    RMHIP_TRY(c->get_view(id, &b));
+    RMHIP_TRY(c->get_raw(id, &b));
     if (*rank_inout < b.shape.size() || !shape_out) {
         *rank_inout = b.shape.size();
         return shape_out ? fail(RMHIP_ERR_INVALID, "shape buffer too small") : RMHIP_OK;
@@ -346,7 +434,7 @@ int rmhip_shape(rmhip_ctx* ctx, rmhip_buf id, size_t* rank_inout, size_t* shape_
 int rmhip_numel(rmhip_ctx* ctx, rmhip_buf id, size_t* out) {
     CTX_OR_FAIL(ctx);
     Buffer b;
-    RMHIP_TRY(c->get_view(id, &b));
+    RMHIP_TRY(c->get_raw(id, &b));
     *out = b.numel;
     return RMHIP_OK;
 }
@@ -373,14 +461,19 @@ int rmhip_fill_uniform(rmhip_ctx* ctx, uint64_t seed, double lo, double hi, cons
 int rmhip_reshape(rmhip_ctx* ctx, rmhip_buf id, const size_t* shape, size_t rank, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);
     Buffer b;
-    RMHIP_TRY(c->get(id, &b));
+    RMHIP_TRY(c->get_raw(id, &b));
     if (shape_numel(shape, rank) != b.numel)
         return fail(RMHIP_ERR_SHAPE, "reshape: element count mismatch (%zu vs %zu)", shape_numel(shape, rank), b.numel);
+    const bool view = b.tview;
+    if (view) RMHIP_TRY(c->get(id, &b));  // materialised (and, for f32 storage, widened) copy
     Buffer r;
     r.alloc = b.alloc;
     r.shape.assign(shape, shape + rank);
     r.numel = b.numel;
-    return c->register_buffer(std::move(r), out);
+    r.dtype = b.dtype;
+    RMHIP_TRY(c->register_buffer(std::move(r), out));
+    if (view && c->precision == 32) c->narrow_pending.push_back(*out);
+    return RMHIP_OK;
 }
 
 int rmhip_wrap_external(rmhip_ctx* ctx, void* device_ptr, const size_t* shape, size_t rank, rmhip_buf* out) {
@@ -400,6 +493,8 @@ int rmhip_wrap_external(rmhip_ctx* ctx, void* device_ptr, const size_t* shape, s
 void* rmhip_device_ptr(rmhip_ctx* ctx, rmhip_buf id) {
     if (!ctx) return nullptr;
     Buffer b;
+    if (ctx->c.get_raw(id, &b) != RMHIP_OK) return nullptr;
+    if (b.dtype == DT_F32) return b.tview ? nullptr : (void*)b.data();  // the f32 storage itself (rmhip_buffer_bits says which)
     if (ctx->c.get(id, &b) != RMHIP_OK) return nullptr;
     return b.data();
 }

@@ -24,7 +24,8 @@ using namespace rmhip;
 #define CTX_OR_FAIL(ctx)                                            \
     if (!(ctx)) return fail(RMHIP_ERR_INVALID, "null context");     \
     Context* c = context_of(ctx);                                   \
-    DeviceGuard _dg(c)
+    DeviceGuard _dg(c);                                             \
+    NarrowScope _ns(c)
 
 namespace {
 
@@ -104,6 +105,21 @@ static int lu_copy_and_factor(Context* c, const double* src, size_t rows, size_t
 
 size_t lu_padded_ld(size_t rows) { return rows >= 256 ? ((rows + 1) & ~(size_t)1) + 32 : ((rows + 1) & ~(size_t)1); }
 
+// Precision-32 contexts: fetch an operand for a kernel that has an f32-storage variant.  `*native` stays true while
+// every operand so far is plain f32 storage; otherwise the caller falls back to widened f64 copies (Context::get).
+int get_operand(Context* c, rmhip_buf id, Buffer* out, bool* native) {
+    if (*native) {
+        RMHIP_TRY(c->get_raw(id, out));
+        if (out->dtype == DT_F32 && out->tview) {  // materialise the view once, as f32
+            RMHIP_TRY(c->settle_view(id));
+            RMHIP_TRY(c->get_raw(id, out));
+        }
+        if (out->dtype == DT_F32 && !out->tview) return RMHIP_OK;
+        *native = false;
+    }
+    return c->get(id, out);
+}
+
 std::vector<size_t> normalize_matrix_shape(const std::vector<size_t>& s) {
     if (s.empty()) return {1, 1};
     if (s.size() == 1) return {s[0], 1};
@@ -149,11 +165,11 @@ int rmhip_wgsl_translate(const char* shader, int kind, char* out, size_t cap, si
     if (kind == 0) {
         ElementwiseProgram p;
         if (!parse_elementwise_wgsl(shader, &p, &err)) return fail(RMHIP_ERR_COMPILE, "WGSL front-end: %s", err.c_str());
-        src = generate_elementwise_source(p, EwTuning::from_env(), 0u);
+        src = generate_elementwise_source(p, EwTuning::from_env(), 0u, p.f32);
     } else {
         ReductionProgram p;
         if (!parse_reduction_wgsl(shader, &p, &err)) return fail(RMHIP_ERR_COMPILE, "WGSL front-end: %s", err.c_str());
-        src = generate_reduction_source(p);
+        src = generate_reduction_source(p, p.f32);
     }
     if (needed) *needed = src.size() + 1;
     if (out && cap) {
@@ -170,11 +186,11 @@ int rmhip_wgsl_compile_check(const char* shader, int kind) {
     if (kind == 0) {
         ElementwiseProgram p;
         if (!parse_elementwise_wgsl(shader, &p, &err)) return fail(RMHIP_ERR_COMPILE, "WGSL front-end: %s", err.c_str());
-        src = generate_elementwise_source(p, EwTuning::from_env(), 0u);
+        src = generate_elementwise_source(p, EwTuning::from_env(), 0u, p.f32);
     } else {
         ReductionProgram p;
         if (!parse_reduction_wgsl(shader, &p, &err)) return fail(RMHIP_ERR_COMPILE, "WGSL front-end: %s", err.c_str());
-        src = generate_reduction_source(p);
+        src = generate_reduction_source(p, p.f32);
     }
     std::vector<char> code;
     return compile_to_code_object(src, &code);
@@ -197,14 +213,23 @@ int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf*
     if ((size_t)prog.n_inputs != n_in) return fail(RMHIP_ERR_INVALID, "fused_elementwise: shader binds %d inputs, got %zu", prog.n_inputs, n_in);
     if (prog.outputs.size() != n_out) return fail(RMHIP_ERR_INVALID, "fused_elementwise: shader writes %zu outputs, caller expects %zu", prog.outputs.size(), n_out);
 
+    if (prog.f32 != (c->precision == 32))
+        return fail(RMHIP_ERR_COMPILE, "%s shader handed to an %s provider (precision() is %s)", prog.f32 ? "f32" : "f64",
+                    c->precision == 32 ? "F32" : "F64", c->precision == 32 ? "F32" : "F64");
     std::vector<Buffer> in(n_in);
     std::vector<uint64_t> oshape(out_shape, out_shape + rank);
     std::vector<std::vector<uint64_t>> strides(n_in);
+    // f32 storage is read and written in place by the f32 variant of the generated kernel; a mixed operand list
+    // (externally wrapped f64 memory, transpose views) runs the f64 variant on widened copies
+    bool f32 = c->precision == 32;
+    size_t tried = 0;  // when the native attempt gives up at operand tried - 1, that one already holds its f64 copy
+    for (; tried < n_in && f32; ++tried) RMHIP_TRY(get_operand(c, inputs[tried], &in[tried], &f32));
     for (size_t k = 0; k < n_in; ++k) {
-        RMHIP_TRY(c->get(inputs[k], &in[k]));
+        if (!f32 && k + 1 != tried) RMHIP_TRY(c->get(inputs[k], &in[k]));
         if (!padded_strides(in[k].shape, out_shape, rank, &strides[k]))
             return fail(RMHIP_ERR_SHAPE, "fused_elementwise: input %zu does not broadcast to the output shape", k);
     }
+    RMHIP_TRACEF("fused_elementwise: operands ready (f32 storage path %d)", (int)f32);
     collapse(&oshape, &strides);
     const size_t crank = oshape.size();
     if (crank > 8) return fail(RMHIP_ERR_UNSUPPORTED, "fused_elementwise: broadcast rank %zu > 8 after collapsing", crank);
@@ -217,12 +242,13 @@ int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf*
     if (!fast) mask = 0;
 
     std::shared_ptr<FusedKernel> kern;
-    RMHIP_TRY(get_elementwise_kernel(c, prog, mask, &kern));
+    RMHIP_TRY(get_elementwise_kernel(c, prog, mask, f32, &kern));
+    RMHIP_TRACEF("fused_elementwise: kernel ready (fast %d mask %x)", (int)fast, mask);
 
     std::vector<Buffer> outs(n_out);
     std::vector<rmhip_buf> ids(n_out, 0);
     for (size_t k = 0; k < n_out; ++k) {
-        int rc = c->new_buffer(out_shape, rank, &ids[k], &outs[k]);
+        int rc = f32 ? c->new_buffer_f32(out_shape, rank, &ids[k], &outs[k]) : c->new_buffer(out_shape, rank, &ids[k], &outs[k]);
         if (rc != RMHIP_OK) {
             for (size_t j = 0; j < k; ++j) rmhip_free(ctx, ids[j]);
             return rc;
@@ -247,7 +273,7 @@ int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf*
             if (!aligned16(out_ptr[k])) vec_ok = false;
         unsigned long long n = len;
         args.push_back(&n);
-        const size_t work = vec_ok ? len / 2 : len;
+        const size_t work = vec_ok ? len / (f32 ? 4 : 2) : len;
         int n_stream = 0;
         for (size_t k = 0; k < n_in; ++k) n_stream += ((mask >> k) & 1u) ? 0 : 1;
         const size_t per_block = (size_t)t.block * t.unroll_for(n_stream, program_is_heavy(prog));
@@ -287,6 +313,7 @@ int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf*
     }
     c->tel.kernel_launches++;
     for (size_t k = 0; k < n_out; ++k) out_ids[k] = ids[k];
+    RMHIP_TRACEF("fused_elementwise: launched");
     return RMHIP_OK;
 }
 
@@ -308,17 +335,23 @@ int rmhip_fused_reduction(rmhip_ctx* ctx, const char* shader, const rmhip_buf* i
     const ReductionProgram& prog = *prog_ptr;
     if ((size_t)prog.n_inputs != n_in) return fail(RMHIP_ERR_INVALID, "fused_reduction: shader binds %d inputs, got %zu", prog.n_inputs, n_in);
 
+    if (prog.f32 != (c->precision == 32))
+        return fail(RMHIP_ERR_COMPILE, "%s shader handed to an %s provider (precision() is %s)", prog.f32 ? "f32" : "f64",
+                    c->precision == 32 ? "F32" : "F64", c->precision == 32 ? "F32" : "F64");
     const size_t total = reduce_len * num_slices;
     std::vector<Buffer> in(n_in);
     std::vector<unsigned long long> mult(n_in);
+    bool f32 = c->precision == 32;  // f32 operands are read in place, partials and the result are f64 (narrowed on return)
+    size_t tried = 0;
+    for (; tried < n_in && f32; ++tried) RMHIP_TRY(get_operand(c, inputs[tried], &in[tried], &f32));
     for (size_t k = 0; k < n_in; ++k) {
-        RMHIP_TRY(c->get(inputs[k], &in[k]));
+        if (!f32 && k + 1 != tried) RMHIP_TRY(c->get(inputs[k], &in[k]));
         if (in[k].numel == total) mult[k] = 1;
         else if (in[k].numel == 1) mult[k] = 0;  // scalar operand uploaded as a 1-element tensor (fusion_exec.rs:522-543)
         else return fail(RMHIP_ERR_SHAPE, "fused_reduction: input %zu has %zu elements, expected %zu", k, in[k].numel, total);
     }
     std::shared_ptr<FusedKernel> kern;
-    RMHIP_TRY(get_reduction_kernel(c, prog, &kern));
+    RMHIP_TRY(get_reduction_kernel(c, prog, f32, &kern));
 
     // axis 0: slice s is contiguous (pre=1, red, post=slices); axis 1: element (s, r) at s + r*slices.
     const size_t pre = prog.axis == 0 ? 1 : num_slices;
@@ -385,9 +418,16 @@ int rmhip_unary(rmhip_ctx* ctx, int op, rmhip_buf a, rmhip_buf* out) {
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     if (op < 0 || op >= RMHIP_UNARY_OP_COUNT) return fail(RMHIP_ERR_UNSUPPORTED, "unary op %d not supported by provider", op);
     Buffer ab, ob;
-    RMHIP_TRY(c->get(a, &ab));
-    RMHIP_TRY(c->new_buffer(ab.shape.data(), ab.shape.size(), out, &ob));
-    int rc = launch_unary(c, op, ab.data(), ob.data(), ab.numel);
+    bool f32 = c->precision == 32;
+    RMHIP_TRY(get_operand(c, a, &ab, &f32));
+    int rc;
+    if (f32) {
+        RMHIP_TRY(c->new_buffer_f32(ab.shape.data(), ab.shape.size(), out, &ob));
+        rc = launch_unary_f32(c, op, ab.data_f32(), ob.data_f32(), ab.numel);
+    } else {
+        RMHIP_TRY(c->new_buffer(ab.shape.data(), ab.shape.size(), out, &ob));
+        rc = launch_unary(c, op, ab.data(), ob.data(), ab.numel);
+    }
     if (rc) rmhip_free(ctx, *out);
     return rc;
 }
@@ -397,9 +437,16 @@ int rmhip_scalar(rmhip_ctx* ctx, int op, rmhip_buf a, double s, rmhip_buf* out) 
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     if (op < 0 || op >= RMHIP_SCALAR_OP_COUNT) return fail(RMHIP_ERR_UNSUPPORTED, "scalar op %d not supported by provider", op);
     Buffer ab, ob;
-    RMHIP_TRY(c->get(a, &ab));
-    RMHIP_TRY(c->new_buffer(ab.shape.data(), ab.shape.size(), out, &ob));
-    int rc = launch_scalar(c, op, ab.data(), s, ob.data(), ab.numel);
+    bool f32 = c->precision == 32;
+    RMHIP_TRY(get_operand(c, a, &ab, &f32));
+    int rc;
+    if (f32) {
+        RMHIP_TRY(c->new_buffer_f32(ab.shape.data(), ab.shape.size(), out, &ob));
+        rc = launch_scalar_f32(c, op, ab.data_f32(), s, ob.data_f32(), ab.numel);
+    } else {
+        RMHIP_TRY(c->new_buffer(ab.shape.data(), ab.shape.size(), out, &ob));
+        rc = launch_scalar(c, op, ab.data(), s, ob.data(), ab.numel);
+    }
     if (rc) rmhip_free(ctx, *out);
     return rc;
 }
@@ -409,8 +456,10 @@ int rmhip_binary(rmhip_ctx* ctx, int op, rmhip_buf a, rmhip_buf b, rmhip_buf* ou
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     if (op < 0 || op >= RMHIP_BINARY_OP_COUNT) return fail(RMHIP_ERR_UNSUPPORTED, "binary op %d not supported by provider", op);
     Buffer ab, bb, ob;
-    RMHIP_TRY(c->get(a, &ab));
-    RMHIP_TRY(c->get(b, &bb));
+    bool f32 = c->precision == 32;
+    RMHIP_TRY(get_operand(c, a, &ab, &f32));
+    RMHIP_TRY(get_operand(c, b, &bb, &f32));
+    if (!f32 && ab.dtype == DT_F32) RMHIP_TRY(c->get(a, &ab));  // b turned out not to be plain f32 storage
     // broadcast_shapes (broadcast.rs:8-47): front-pad, extents equal or 1
     const size_t rank = std::max(ab.shape.size(), bb.shape.size());
     if (rank > 16) return fail(RMHIP_ERR_UNSUPPORTED, "binary: rank too large");
@@ -424,10 +473,12 @@ int rmhip_binary(rmhip_ctx* ctx, int op, rmhip_buf a, rmhip_buf b, rmhip_buf* ou
         else
             return fail(RMHIP_ERR_SHAPE, "size mismatch between inputs (dimension %zu has lengths %zu and %zu)", d + 1, ea, eb);
     }
-    RMHIP_TRY(c->new_buffer(oshape.data(), rank, out, &ob));
+    if (f32) RMHIP_TRY(c->new_buffer_f32(oshape.data(), rank, out, &ob));
+    else RMHIP_TRY(c->new_buffer(oshape.data(), rank, out, &ob));
     int rc;
     if (ab.numel == ob.numel && bb.numel == ob.numel) {
-        rc = launch_binary_same(c, op, ab.data(), bb.data(), ob.data(), ob.numel);
+        rc = f32 ? launch_binary_same_f32(c, op, ab.data_f32(), bb.data_f32(), ob.data_f32(), ob.numel)
+                 : launch_binary_same(c, op, ab.data(), bb.data(), ob.data(), ob.numel);
     } else {
         std::vector<std::vector<uint64_t>> strides(2);
         std::vector<uint64_t> os(oshape.begin(), oshape.end());
@@ -445,7 +496,8 @@ int rmhip_binary(rmhip_ctx* ctx, int op, rmhip_buf a, rmhip_buf b, rmhip_buf* ou
             d.stride_a[i] = strides[0][i];
             d.stride_b[i] = strides[1][i];
         }
-        rc = launch_binary_bcast(c, op, ab.data(), bb.data(), ob.data(), ob.numel, d);
+        rc = f32 ? launch_binary_bcast_f32(c, op, ab.data_f32(), bb.data_f32(), ob.data_f32(), ob.numel, d)
+                 : launch_binary_bcast(c, op, ab.data(), bb.data(), ob.data(), ob.numel, d);
     }
     if (rc) rmhip_free(ctx, *out);
     return rc;
@@ -456,11 +508,13 @@ int rmhip_reduce(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int nan_mode, rmh
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     if (op < 0 || op >= RMHIP_REDUCE_OP_COUNT) return fail(RMHIP_ERR_UNSUPPORTED, "reduce op %d not supported by provider", op);
     Buffer ab, ob;
-    RMHIP_TRY(c->get(a, &ab));
+    bool f32 = c->precision == 32;  // f32 storage is read in place; the (small) result is f64 and narrowed on return
+    RMHIP_TRY(get_operand(c, a, &ab, &f32));
     if (dim < 0) {
         const size_t oshape[2] = {1, 1};  // simple_provider.rs:6743
         RMHIP_TRY(c->new_buffer(oshape, 2, out, &ob));
-        int rc = launch_reduce_all(c, op, nan_mode, ab.data(), ab.numel, ob.data());
+        int rc = f32 ? launch_reduce_mid_f32(c, op, nan_mode, ab.data_f32(), 1, ab.numel, 1, ob.data())
+                     : launch_reduce_all(c, op, nan_mode, ab.data(), ab.numel, ob.data());
         if (rc) rmhip_free(ctx, *out);
         return rc;
     }
@@ -473,7 +527,8 @@ int rmhip_reduce(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int nan_mode, rmh
     std::vector<size_t> oshape = shape;
     oshape[dim] = 1;
     RMHIP_TRY(c->new_buffer(oshape.data(), oshape.size(), out, &ob));
-    int rc = launch_reduce_mid(c, op, nan_mode, ab.data(), pre, red, post, ob.data());
+    int rc = f32 ? launch_reduce_mid_f32(c, op, nan_mode, ab.data_f32(), pre, red, post, ob.data())
+                 : launch_reduce_mid(c, op, nan_mode, ab.data(), pre, red, post, ob.data());
     if (rc) rmhip_free(ctx, *out);
     return rc;
 }
@@ -509,8 +564,10 @@ int rmhip_dot(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, int dim, rmhip_buf* out)
     CTX_OR_FAIL(ctx);
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     Buffer ab, bb, ob;
-    RMHIP_TRY(c->get(a, &ab));
-    RMHIP_TRY(c->get(b, &bb));
+    bool f32 = c->precision == 32;
+    RMHIP_TRY(get_operand(c, a, &ab, &f32));
+    RMHIP_TRY(get_operand(c, b, &bb, &f32));
+    if (!f32 && ab.dtype == DT_F32) RMHIP_TRY(c->get(a, &ab));
     const std::vector<size_t> sa = normalize_matrix_shape(ab.shape), sb = normalize_matrix_shape(bb.shape);
     if (sa != sb) return fail(RMHIP_ERR_SHAPE, "dot: A and B must be the same size");
     int d = dim;
@@ -529,7 +586,8 @@ int rmhip_dot(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, int dim, rmhip_buf* out)
     std::vector<size_t> oshape = sa;
     oshape[d] = 1;
     RMHIP_TRY(c->new_buffer(oshape.data(), oshape.size(), out, &ob));
-    int rc = launch_reduce_dot(c, ab.data(), bb.data(), pre, sa[d], post, ob.data());
+    int rc = f32 ? launch_reduce_dot_f32(c, ab.data_f32(), bb.data_f32(), pre, sa[d], post, ob.data())
+                 : launch_reduce_dot(c, ab.data(), bb.data(), pre, sa[d], post, ob.data());
     if (rc) rmhip_free(ctx, *out);
     return rc;
 }
@@ -806,7 +864,7 @@ int rmhip_transpose(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     Buffer ab;
-    RMHIP_TRY(c->get_view(a, &ab));
+    RMHIP_TRY(c->get_raw(a, &ab));  // the alias keeps the operand's storage type
     if (ab.shape.size() > 2) return fail(RMHIP_ERR_UNSUPPORTED, "transpose: only 2D supported");
     const std::vector<size_t> as = normalize_matrix_shape(ab.shape);
     // No data moves: the result aliases the operand's storage as a transpose view (a view of a view is the plain
@@ -816,12 +874,10 @@ int rmhip_transpose(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out) {
     r.shape = {as[1], as[0]};
     r.numel = ab.numel;
     r.tview = (as[0] == 1 || as[1] == 1) ? false : !ab.tview;
+    r.dtype = ab.dtype;
     RMHIP_TRY(c->register_buffer(std::move(r), out));
     if (const char* e = std::getenv("RMHIP_EAGER_TRANSPOSE"))
-        if (e[0] == '1') {
-            Buffer tmp;
-            RMHIP_TRY(c->get(*out, &tmp));
-        }
+        if (e[0] == '1') RMHIP_TRY(c->settle_view(*out));
     return RMHIP_OK;
 }
 
@@ -911,6 +967,9 @@ struct ViewPtr {
 };
 int resolve_view(Context* c, const rmhip_view_t* v, ViewPtr* out) {
     if (!v) return fail(RMHIP_ERR_INVALID, "null view");
+    RMHIP_TRY(c->get_raw(v->buf, &out->buf));
+    if (out->buf.dtype != DT_F64)  // in-place block updates cannot go through a widened temporary
+        return fail(RMHIP_ERR_UNSUPPORTED, "block views address f64 storage; this buffer is f32 (precision-32 provider)");
     RMHIP_TRY(c->get(v->buf, &out->buf));
     const std::vector<size_t> s = normalize_matrix_shape(out->buf.shape);
     if (s.size() != 2) return fail(RMHIP_ERR_UNSUPPORTED, "view: only 2D buffers");

@@ -441,13 +441,15 @@ int count_inputs(const std::string& shader) {
     return n;
 }
 
-bool check_scalar_type(const std::string& shader, std::string* err) {
+// The planner emits the shader in the provider's precision (`scalar_ty`, fusion.rs:1525-1533): f64 or f32.
+bool check_scalar_type(const std::string& shader, bool* is_f32, std::string* err) {
+    *is_f32 = false;
     if (shader.find("data: array<f64>") != std::string::npos) return true;
     if (shader.find("data: array<f32>") != std::string::npos) {
-        *err = "f32 shader handed to an F64 provider (precision() is F64)";
-        return false;
+        *is_f32 = true;
+        return true;
     }
-    *err = "shader has no `struct Tensor { data: array<f64> }` declaration";
+    *err = "shader has no `struct Tensor { data: array<f64> }` (or f32) declaration";
     return false;
 }
 
@@ -512,7 +514,8 @@ bool parse_elementwise_wgsl(const std::string& shader, ElementwiseProgram* out, 
     std::string local;
     if (!err) err = &local;
     *out = ElementwiseProgram();
-    if (!check_scalar_type(shader, err)) return false;
+    if (!check_scalar_type(shader, &out->f32, err)) return false;
+    const std::string scalar_ty = out->f32 ? "f32" : "f64";
     out->n_inputs = count_inputs(shader);
     if (out->n_inputs == 0) {
         *err = "fused_elementwise: no inputs";  // elementwise.rs:1574-1576
@@ -536,7 +539,7 @@ bool parse_elementwise_wgsl(const std::string& shader, ElementwiseProgram* out, 
                 return false;
             }
             std::string ty = trim(t.substr(colon + 1, eq - colon - 1));
-            if (ty != "f64") {
+            if (ty != scalar_ty) {
                 *err = "unsupported scalar type '" + ty + "'";
                 return false;
             }
@@ -611,7 +614,7 @@ bool parse_reduction_wgsl(const std::string& shader, ReductionProgram* out, std:
     std::string local;
     if (!err) err = &local;
     *out = ReductionProgram();
-    if (!check_scalar_type(shader, err)) return false;
+    if (!check_scalar_type(shader, &out->f32, err)) return false;
     out->n_inputs = count_inputs(shader);
     if (out->n_inputs == 0) {
         *err = "fused_reduction: no inputs";
@@ -640,7 +643,7 @@ bool parse_reduction_wgsl(const std::string& shader, ReductionProgram* out, std:
         return false;
     }
     std::string ty = trim(t.substr(colon + 1, eq - colon - 1));
-    if (ty != "f64") {
+    if (ty != (out->f32 ? "f32" : "f64")) {
         *err = "unsupported scalar type '" + ty + "'";
         return false;
     }

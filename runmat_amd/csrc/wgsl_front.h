@@ -40,6 +40,7 @@ struct EwStatement {
 };
 
 struct ElementwiseProgram {
+    bool f32 = false;                // shader written for an F32 provider (`array<f32>`, `let tmpK: f32`)
     int n_inputs = 0;
     std::vector<EwStatement> lets;   // in order
     std::vector<ExprPtr> outputs;    // output k expression (usually a Tmp or Input leaf)
@@ -47,6 +48,7 @@ struct ElementwiseProgram {
 };
 
 struct ReductionProgram {
+    bool f32 = false;
     int n_inputs = 0;
     int axis = 0;          // 0: slice s = contiguous [s*reduce_len, ...); 1: element (s, c) at s + c*num_slices
     bool omitnan = false;

@@ -56,6 +56,11 @@ def normalize_scalar_shape(shape: Sequence[int]) -> Tuple[int, ...]:
     return shape
 
 
+def _scalar_ty(prov) -> str:
+    """`scalar_ty` follows the provider's precision (fusion_exec.rs:262-266)."""
+    return "f32" if prov.precision() == "F32" else "f64"
+
+
 def _prepare(prov, values, scalar_shape):
     prepared, owned = [], []
     for v in values:
@@ -95,7 +100,7 @@ def execute_elementwise(prov, plan: FusionGroupPlan, output_ids: Sequence[int], 
     scalar_shape = normalize_scalar_shape([1] * len(out_shape))
     prepared, owned = _prepare(prov, values, scalar_shape)
     try:
-        shader = plan.generate_wgsl_for_outputs(list(output_ids), "f64")
+        shader = plan.generate_wgsl_for_outputs(list(output_ids), _scalar_ty(prov))
         if len(output_ids) == 1:
             outs = [prov.fused_elementwise(shader, prepared, out_shape, length)]
         else:
@@ -116,7 +121,7 @@ def execute_reduction(prov, plan: FusionGroupPlan, data_vid: int, values: Sequen
     flavor = flavor or ReductionFlavor.Sum()
     prepared, owned = _prepare(prov, values, (1, 1))
     try:
-        shader = plan.generate_reduction_wgsl(data_vid, "f64", axis=axis, omitnan=omitnan, is_mean=flavor.kind == "mean")
+        shader = plan.generate_reduction_wgsl(data_vid, _scalar_ty(prov), axis=axis, omitnan=omitnan, is_mean=flavor.kind == "mean")
         wg = workgroup_size or prov.default_reduction_workgroup_size()
         return prov.fused_reduction(shader, prepared, (num_slices,), reduce_len, num_slices, wg, flavor)
     finally:

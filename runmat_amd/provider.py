@@ -108,13 +108,20 @@ class HipProvider:
 
     _next_device_id = 1  # next_device_id(), lib.rs:3279
 
-    def __init__(self, device_ordinal: int = 0):
+    def __init__(self, device_ordinal: int = 0, precision: str = "F64"):
+        """`precision`: "F64" (default) or "F32" -- `ProviderPrecision` (lib.rs:815-818), fixed for the provider's
+        lifetime.  At F32 tensors live in HBM as f32; the host boundary stays f64 (upload rounds, download widens)."""
+        if precision not in ("F64", "F32"):
+            raise ValueError("precision must be 'F64' or 'F32'")
         self._lib = _lib.load()
         ctx = C.c_void_p()
         rc = self._lib.rmhip_init(int(device_ordinal), C.byref(ctx))
         if rc != _lib.OK:
             raise ProviderError(rc, _lib.last_error())
         self._ctx = ctx
+        self._precision = precision
+        if precision == "F32":
+            self._check(self._lib.rmhip_set_precision(self._ctx, 32))
         self._device_id = HipProvider._next_device_id
         HipProvider._next_device_id += 1
         self.device_ordinal = device_ordinal
@@ -156,7 +163,16 @@ class HipProvider:
         return self._device_id
 
     def precision(self) -> str:
-        return "F64"  # ProviderPrecision::F64 (lib.rs:815-818); host F64 tensors are accepted as-is
+        return self._precision  # ProviderPrecision (lib.rs:815-818); the fusion emitter picks `scalar_ty` from it
+
+    def scalar_ty(self) -> str:
+        """WGSL scalar type the planner emits for this provider (fusion.rs:1525-1533)."""
+        return "f32" if self._precision == "F32" else "f64"
+
+    def buffer_bits(self, h: GpuTensorHandle) -> int:
+        bits = C.c_int()
+        self._check(self._lib.rmhip_buffer_bits(self._ctx, self._id(h), C.byref(bits)))
+        return bits.value
 
     def device_info_struct(self) -> dict:
         info = _lib.DeviceInfo()

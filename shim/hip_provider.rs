@@ -28,6 +28,7 @@ extern "C" {
     fn rmhip_last_error() -> *const c_char;
     fn rmhip_init(device_ordinal: c_int, out: *mut *mut RmhipCtx) -> c_int;
     fn rmhip_shutdown(ctx: *mut RmhipCtx) -> c_int;
+    fn rmhip_set_precision(ctx: *mut RmhipCtx, bits: c_int) -> c_int;
     fn rmhip_upload(ctx: *mut RmhipCtx, host: *const c_double, shape: *const usize, rank: usize, out: *mut u64) -> c_int;
     fn rmhip_download(ctx: *mut RmhipCtx, id: u64, out: *mut c_double, n: usize) -> c_int;
     fn rmhip_free(ctx: *mut RmhipCtx, id: u64) -> c_int;
@@ -74,6 +75,7 @@ struct RmhipLinsolveOptions {
 
 pub struct HipProvider {
     ctx: *mut RmhipCtx,
+    precision: ProviderPrecision,
     device_id: u32,
 }
 // One HIP stream per context; the library serialises table access internally.
@@ -90,9 +92,16 @@ fn check(rc: c_int) -> Result<()> {
 
 impl HipProvider {
     pub fn new(device_ordinal: i32) -> Result<Self> {
+        Self::with_precision(device_ordinal, ProviderPrecision::F64)
+    }
+    /// F32: tensors live in HBM as f32 (the planner then emits f32 shaders, fusion.rs:1525); host views stay f64.
+    pub fn with_precision(device_ordinal: i32, precision: ProviderPrecision) -> Result<Self> {
         let mut ctx = std::ptr::null_mut();
         check(unsafe { rmhip_init(device_ordinal, &mut ctx) })?;
-        Ok(Self { ctx, device_id: runmat_accelerate_api::next_device_id() }) // lib.rs:3279
+        if matches!(precision, ProviderPrecision::F32) {
+            check(unsafe { rmhip_set_precision(ctx, 32) })?;
+        }
+        Ok(Self { ctx, precision, device_id: runmat_accelerate_api::next_device_id() }) // lib.rs:3279
     }
     fn handle(&self, id: u64) -> Result<GpuTensorHandle> {
         let mut rank = 16usize;
@@ -142,7 +151,7 @@ impl AccelProvider for HipProvider {
         check(unsafe { rmhip_free(self.ctx, self.own(h)?) })
     }
     fn device_id(&self) -> u32 { self.device_id }
-    fn precision(&self) -> ProviderPrecision { ProviderPrecision::F64 }
+    fn precision(&self) -> ProviderPrecision { self.precision }
 
     fn fused_elementwise(&self, shader: &str, inputs: &[GpuTensorHandle], output_shape: &[usize], len: usize)
         -> Result<GpuTensorHandle> {

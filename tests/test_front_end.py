@@ -158,7 +158,7 @@ def test_reduction_shader(built, axis):
 
 
 @pytest.mark.parametrize("mutate,needle", [
-    (lambda s: s.replace("array<f64>", "array<f32>"), "F64 provider"),
+    (lambda s: s.replace("array<f64>", "array<f32>"), "unsupported scalar type"),  # storage and let types disagree
     (lambda s: s.replace("sin(input0.data[i0])", "frobnicate(input0.data[i0])"), "unsupported function"),
     (lambda s: s.replace("(tmp0 * input1.data[i1])", "(tmp7 * input1.data[i1])"), "tmp used before definition"),
     (lambda s: s.replace("input2.data[i2]", "input9.data[i9]"), "input index out of range"),
@@ -205,3 +205,34 @@ def test_runtime_broadcast_shape_rules():
     assert runtime_broadcast_shape([1.0, 2]) == ()
     assert runtime_broadcast_shape(["x"]) is None
     assert normalize_scalar_shape(()) == (1, 1) and normalize_scalar_shape((5,)) == (5, 1) and normalize_scalar_shape((2, 3)) == (2, 3)
+
+
+def test_f32_shaders_lower_to_f32_storage_with_f64_arithmetic(built):
+    """The planner emits `scalar_ty = f32` for an F32 provider (fusion.rs:1525-1533): the generated kernels read and
+    write `float` (four per 16-byte vector) while the body stays `double` -- the CPU path computes `single` arrays in
+    f64 and rounds once (elementwise/times.rs:750-760)."""
+    from runmat_amd import wgsl_compile_check, wgsl_translate
+    from runmat_amd.fusion import FusionGroupPlan, elementwise_math_plan, sin_mul_add_plan
+
+    plan, out = sin_mul_add_plan()
+    sh = plan.generate_wgsl_for_output(out, "f32")
+    assert "data: array<f32>" in sh and "let tmp0: f32 = sin(input0.data[i0]);" in sh
+    src = wgsl_translate(sh, "elementwise")
+    assert "const float* __restrict__ in0" in src and "float* __restrict__ out0" in src
+    assert "typedef float rm_v4f" in src and "const rm_v4f a0_t" in src
+    assert "const double tmp0 = sin(x0);" in src           # arithmetic unchanged
+    assert "(double)a0_t.w" in src and "r0_t.w = (float)q0;" in src
+    assert "threadIdx.x < (n & 3)" in src                  # up to three tail elements
+    wgsl_compile_check(sh, "elementwise")
+    plan2, outs2 = elementwise_math_plan()
+    wgsl_compile_check(plan2.generate_wgsl_for_output(outs2, "f32"), "elementwise")
+
+    p = FusionGroupPlan()
+    x, w = p.input(), p.input()
+    v = p.primitive("Add", p.primitive("ElemMul", p.builtin("sin", x), w), p.constant(2.0))
+    for axis in (0, 1):
+        rs = p.generate_reduction_wgsl(v, "f32", axis=axis, omitnan=False, is_mean=True)
+        assert "let val: f32 = ((sin(v) * v1) + 2.0);" in rs  # constants print as `{:?}` of the f32 value (fusion.rs:1839-1873)
+        rsrc = wgsl_translate(rs, "reduction")
+        assert "const float* __restrict__ in0" in rsrc and "const double v0 = (double)in0[idx * m0];" in rsrc
+        wgsl_compile_check(rs, "reduction")
