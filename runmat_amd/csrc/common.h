@@ -239,6 +239,12 @@ int launch_dgemm_epilogue(Context* c, size_t m, size_t n, size_t k, const double
 // rng (rng.hip)
 int launch_rng_uniform(Context* c, uint64_t state, double* out, size_t n);
 int launch_rng_normal(Context* c, uint64_t state, double* out, size_t n);
+int launch_rng_uniform_f32(Context* c, uint64_t state, float* out, size_t n);
+int launch_rng_normal_f32(Context* c, uint64_t state, float* out, size_t n);
+int launch_stochastic_evolution_f32(Context* c, uint64_t state, const float* in, float* out, size_t n, double drift,
+                                    double scale, unsigned steps, uint64_t draws_per_step);
+int image_normalize_device_f32(Context* c, const float* x, float* y, size_t batch, size_t height, size_t width, double epsilon,
+                               int has_gain, double gain, int has_bias, double bias, int clamp_zero, int has_gamma, double gamma);
 uint64_t lcg_advance(uint64_t state, uint64_t delta);
 int image_normalize_device(Context* c, const double* x, double* y, size_t batch, size_t height, size_t width, double epsilon,
                            int has_gain, double gain, int has_bias, double bias, int clamp_zero, int has_gamma, double gamma);

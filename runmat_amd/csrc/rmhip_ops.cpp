@@ -638,14 +638,22 @@ int rmhip_image_normalize(rmhip_ctx* ctx, rmhip_buf input, const rmhip_image_nor
     if (!std::isfinite(d->epsilon)) return fail(RMHIP_ERR_INVALID, "image_normalize: epsilon must be finite");
     if (d->epsilon < 0.0) return fail(RMHIP_ERR_INVALID, "image_normalize: epsilon must be non-negative");
     Buffer ib, ob;
-    RMHIP_TRY(c->get(input, &ib));
+    bool f32 = c->precision == 32;
+    RMHIP_TRY(get_operand(c, input, &ib, &f32));
     if (ib.shape.size() != 3) return fail(RMHIP_ERR_SHAPE, "image_normalize: expected 3-D tensor, got rank %zu", ib.shape.size());
     if (ib.shape[0] != d->batch || ib.shape[1] != d->height || ib.shape[2] != d->width)
         return fail(RMHIP_ERR_SHAPE, "image_normalize: descriptor dims (%zu, %zu, %zu) do not match tensor shape (%zu, %zu, %zu)",
                     d->batch, d->height, d->width, ib.shape[0], ib.shape[1], ib.shape[2]);
-    RMHIP_TRY(c->new_buffer(ib.shape.data(), 3, out, &ob));
-    int rc = image_normalize_device(c, ib.data(), ob.data(), d->batch, d->height, d->width, d->epsilon, d->has_gain, d->gain,
+    int rc;
+    if (f32) {
+        RMHIP_TRY(c->new_buffer_f32(ib.shape.data(), 3, out, &ob));
+        rc = image_normalize_device_f32(c, ib.data_f32(), ob.data_f32(), d->batch, d->height, d->width, d->epsilon, d->has_gain,
+                                        d->gain, d->has_bias, d->bias, d->clamp_zero, d->has_gamma, d->gamma);
+    } else {
+        RMHIP_TRY(c->new_buffer(ib.shape.data(), 3, out, &ob));
+        rc = image_normalize_device(c, ib.data(), ob.data(), d->batch, d->height, d->width, d->epsilon, d->has_gain, d->gain,
                                     d->has_bias, d->bias, d->clamp_zero, d->has_gamma, d->gamma);
+    }
     if (rc) rmhip_free(ctx, *out);
     return rc;
 }
@@ -1108,8 +1116,14 @@ int rmhip_rng_seed(rmhip_ctx* ctx, uint64_t seed) {  // mix_seed, random.rs:128-
 int rmhip_random_uniform(rmhip_ctx* ctx, const size_t* shape, size_t rank, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);
     Buffer ob;
-    RMHIP_TRY(c->new_buffer(shape, rank, out, &ob));
-    int rc = launch_rng_uniform(c, c->rng_state, ob.data(), ob.numel);
+    int rc;
+    if (c->precision == 32) {
+        RMHIP_TRY(c->new_buffer_f32(shape, rank, out, &ob));
+        rc = launch_rng_uniform_f32(c, c->rng_state, ob.data_f32(), ob.numel);
+    } else {
+        RMHIP_TRY(c->new_buffer(shape, rank, out, &ob));
+        rc = launch_rng_uniform(c, c->rng_state, ob.data(), ob.numel);
+    }
     if (rc) {
         rmhip_free(ctx, *out);
         return rc;
@@ -1121,8 +1135,14 @@ int rmhip_random_uniform(rmhip_ctx* ctx, const size_t* shape, size_t rank, rmhip
 int rmhip_random_normal(rmhip_ctx* ctx, const size_t* shape, size_t rank, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);
     Buffer ob;
-    RMHIP_TRY(c->new_buffer(shape, rank, out, &ob));
-    int rc = launch_rng_normal(c, c->rng_state, ob.data(), ob.numel);
+    int rc;
+    if (c->precision == 32) {
+        RMHIP_TRY(c->new_buffer_f32(shape, rank, out, &ob));
+        rc = launch_rng_normal_f32(c, c->rng_state, ob.data_f32(), ob.numel);
+    } else {
+        RMHIP_TRY(c->new_buffer(shape, rank, out, &ob));
+        rc = launch_rng_normal(c, c->rng_state, ob.data(), ob.numel);
+    }
     if (rc) {
         rmhip_free(ctx, *out);
         return rc;
@@ -1140,20 +1160,24 @@ int rmhip_stochastic_evolution_sharded(rmhip_ctx* ctx, rmhip_buf state, double d
     CTX_OR_FAIL(ctx);
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     Buffer sb;
-    RMHIP_TRY(c->get(state, &sb));
+    bool f32 = c->precision == 32;
+    RMHIP_TRY(get_operand(c, state, &sb, &f32));
     Buffer ob;
-    RMHIP_TRY(c->new_buffer(sb.shape.data(), sb.shape.size(), out, &ob));
+    if (f32) RMHIP_TRY(c->new_buffer_f32(sb.shape.data(), sb.shape.size(), out, &ob));
+    else RMHIP_TRY(c->new_buffer(sb.shape.data(), sb.shape.size(), out, &ob));
     if (sb.numel == 0) return RMHIP_OK;
     int rc = RMHIP_OK;
     if (steps == 0) {  // stochastic_evolution.rs:16-18: nothing drawn, state unchanged
-        hipError_t e = hipMemcpyAsync(ob.data(), sb.data(), sizeof(double) * sb.numel, hipMemcpyDeviceToDevice, c->stream);
+        hipError_t e = hipMemcpyAsync(ob.data(), sb.data(), (f32 ? sizeof(float) : sizeof(double)) * sb.numel, hipMemcpyDeviceToDevice, c->stream);
         if (e != hipSuccess) rc = fail(RMHIP_ERR_HIP, "stochastic_evolution: %s", hipGetErrorString(e));
     } else {
         const uint64_t local = 2ULL * ((sb.numel + 1) / 2);
         if (draws_per_step && draws_per_step < local)
             rc = fail(RMHIP_ERR_INVALID, "stochastic_evolution: draws_per_step %llu < the shard's own %llu",
                       (unsigned long long)draws_per_step, (unsigned long long)local);
-        if (!rc) rc = launch_stochastic_evolution(c, c->rng_state, sb.data(), ob.data(), sb.numel, drift, scale, steps, draws_per_step);
+        if (!rc)
+            rc = f32 ? launch_stochastic_evolution_f32(c, c->rng_state, sb.data_f32(), ob.data_f32(), sb.numel, drift, scale, steps, draws_per_step)
+                     : launch_stochastic_evolution(c, c->rng_state, sb.data(), ob.data(), sb.numel, drift, scale, steps, draws_per_step);
         if (!rc) c->rng_state = lcg_advance(c->rng_state, (uint64_t)steps * (draws_per_step ? draws_per_step : local));
     }
     if (rc) rmhip_free(ctx, *out);

@@ -46,7 +46,10 @@ __device__ __forceinline__ double lcg_next_uniform(unsigned long long& s) {
     return (double)(s >> 11) * (1.0 / 9007199254740992.0);
 }
 
-__global__ void __launch_bounds__(256) k_rng_uniform(unsigned long long state, double* __restrict__ out, size_t n,
+// T = storage type: double, or float on a precision-32 provider (the f64 stream rounded on store -- what the CPU's
+// rand/randn(..., 'single') produce)
+template <class T>
+__global__ void __launch_bounds__(256) k_rng_uniform(unsigned long long state, T* __restrict__ out, size_t n,
                                                      unsigned long long jm, unsigned long long jp) {
     const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
@@ -56,15 +59,28 @@ __global__ void __launch_bounds__(256) k_rng_uniform(unsigned long long state, d
     unsigned long long s = m * state + p;  // state before element g
     for (size_t i = g; i < n; i += stride) {
         unsigned long long t = s;
-        out[i] = lcg_next_uniform(t);
+        out[i] = (T)lcg_next_uniform(t);
         s = jm * s + jp;  // jump `stride` steps
     }
 }
 
 typedef double v2d __attribute__((ext_vector_type(2)));
+typedef float v2s __attribute__((ext_vector_type(2)));
+template <class T>
+struct PairOf;
+template <>
+struct PairOf<double> {
+    typedef v2d type;
+};
+template <>
+struct PairOf<float> {
+    typedef v2s type;
+};
 
-__global__ void __launch_bounds__(256) k_rng_normal(unsigned long long state, double* __restrict__ out, size_t n,
+template <class T>
+__global__ void __launch_bounds__(256) k_rng_normal(unsigned long long state, T* __restrict__ out, size_t n,
                                                     unsigned long long jm, unsigned long long jp) {
+    typedef typename PairOf<T>::type P;
     const size_t npairs = (n + 1) / 2;
     const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
@@ -72,7 +88,7 @@ __global__ void __launch_bounds__(256) k_rng_normal(unsigned long long state, do
     unsigned long long m, p;
     lcg_jump(2 * g, &m, &p);
     unsigned long long s = m * state + p;  // state before pair g
-    const bool aligned = (((uintptr_t)out) & 15) == 0;
+    const bool aligned = (((uintptr_t)out) & (2 * sizeof(T) - 1)) == 0;
     for (size_t i = g; i < npairs; i += stride) {
         unsigned long long t = s;
         double u1 = lcg_next_uniform(t);
@@ -84,13 +100,13 @@ __global__ void __launch_bounds__(256) k_rng_normal(unsigned long long state, do
         sincos(angle, &sn, &cs);
         const double z0 = radius * cs, z1 = radius * sn;
         if (2 * i + 1 < n) {
-            if (aligned) *(v2d*)(out + 2 * i) = v2d{z0, z1};
+            if (aligned) *(P*)(out + 2 * i) = P{(T)z0, (T)z1};
             else {
-                out[2 * i] = z0;
-                out[2 * i + 1] = z1;
+                out[2 * i] = (T)z0;
+                out[2 * i + 1] = (T)z1;
             }
         } else {
-            out[2 * i] = z0;  // odd length: z1 of the last pair is dropped (random.rs:536-540)
+            out[2 * i] = (T)z0;  // odd length: z1 of the last pair is dropped (random.rs:536-540)
         }
         s = jm * s + jp;  // jump 2*stride steps
     }
@@ -102,8 +118,9 @@ __global__ void __launch_bounds__(256) k_rng_normal(unsigned long long state, do
 // (2i, 2i+1) in step t starts at stream position 2*npairs*t + 2i: the thread skips ahead to 2i once and
 // then jumps by 2*npairs per step.  The state stays in registers across all steps -- 16 B of HBM
 // traffic per element for the whole time loop instead of (32*steps) B for the materialised plan.
-__global__ void __launch_bounds__(256) k_stochastic_evolution(unsigned long long state, const double* __restrict__ in,
-                                                              double* __restrict__ out, size_t n, double drift, double scale,
+template <class T>
+__global__ void __launch_bounds__(256) k_stochastic_evolution(unsigned long long state, const T* __restrict__ in,
+                                                              T* __restrict__ out, size_t n, double drift, double scale,
                                                               unsigned steps, unsigned long long gm, unsigned long long gp,
                                                               unsigned long long sm, unsigned long long sp) {
     const size_t npairs = (n + 1) / 2;
@@ -113,17 +130,18 @@ __global__ void __launch_bounds__(256) k_stochastic_evolution(unsigned long long
     unsigned long long m, p;
     lcg_jump(2 * g, &m, &p);
     unsigned long long s0 = m * state + p;  // state before pair g of step 0
-    const bool aligned = ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0;
+    typedef typename PairOf<T>::type P;
+    const bool aligned = ((((uintptr_t)in) | ((uintptr_t)out)) & (2 * sizeof(T) - 1)) == 0;
     for (size_t i = g; i < npairs; i += stride) {
         const bool two = 2 * i + 1 < n;
         double v0, v1 = 0.0;
         if (two && aligned) {
-            const v2d v = *(const v2d*)(in + 2 * i);
-            v0 = v.x;
-            v1 = v.y;
+            const P v = *(const P*)(in + 2 * i);
+            v0 = (double)v.x;
+            v1 = (double)v.y;
         } else {
-            v0 = in[2 * i];
-            if (two) v1 = in[2 * i + 1];
+            v0 = (double)in[2 * i];
+            if (two) v1 = (double)in[2 * i + 1];
         }
         unsigned long long s = s0;
         for (unsigned t = 0; t < steps; ++t) {
@@ -140,10 +158,10 @@ __global__ void __launch_bounds__(256) k_stochastic_evolution(unsigned long long
             v1 = v1 * exp(drift + t1);
             s = sm * s + sp;  // same pair, next step: 2*npairs draws later
         }
-        if (two && aligned) *(v2d*)(out + 2 * i) = v2d{v0, v1};
+        if (two && aligned) *(P*)(out + 2 * i) = P{(T)v0, (T)v1};
         else {
-            out[2 * i] = v0;
-            if (two) out[2 * i + 1] = v1;
+            out[2 * i] = (T)v0;
+            if (two) out[2 * i + 1] = (T)v1;
         }
         s0 = gm * s0 + gp;  // pair i + stride
     }
@@ -156,41 +174,56 @@ static unsigned rng_grid(const Context* c, size_t work) {
     return (unsigned)(want < cap ? want : cap);
 }
 
-int launch_rng_uniform(Context* c, uint64_t state, double* out, size_t n) {
+template <class T>
+static int rng_uniform_any(Context* c, uint64_t state, T* out, size_t n) {
     if (n == 0) return RMHIP_OK;
     const unsigned grid = rng_grid(c, n);
     unsigned long long jm, jp;
     lcg_jump((unsigned long long)grid * 256ULL, &jm, &jp);
-    hipLaunchKernelGGL(k_rng_uniform, dim3(grid), dim3(256), 0, c->stream, (unsigned long long)state, out, n, jm, jp);
+    hipLaunchKernelGGL(k_rng_uniform<T>, dim3(grid), dim3(256), 0, c->stream, (unsigned long long)state, out, n, jm, jp);
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
 }
+int launch_rng_uniform(Context* c, uint64_t state, double* out, size_t n) { return rng_uniform_any(c, state, out, n); }
+int launch_rng_uniform_f32(Context* c, uint64_t state, float* out, size_t n) { return rng_uniform_any(c, state, out, n); }
 
-int launch_rng_normal(Context* c, uint64_t state, double* out, size_t n) {
+template <class T>
+static int rng_normal_any(Context* c, uint64_t state, T* out, size_t n) {
     if (n == 0) return RMHIP_OK;
     const unsigned grid = rng_grid(c, (n + 1) / 2);
     unsigned long long jm, jp;
     lcg_jump(2ULL * grid * 256ULL, &jm, &jp);
-    hipLaunchKernelGGL(k_rng_normal, dim3(grid), dim3(256), 0, c->stream, (unsigned long long)state, out, n, jm, jp);
+    hipLaunchKernelGGL(k_rng_normal<T>, dim3(grid), dim3(256), 0, c->stream, (unsigned long long)state, out, n, jm, jp);
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
 }
+int launch_rng_normal(Context* c, uint64_t state, double* out, size_t n) { return rng_normal_any(c, state, out, n); }
+int launch_rng_normal_f32(Context* c, uint64_t state, float* out, size_t n) { return rng_normal_any(c, state, out, n); }
 
-int launch_stochastic_evolution(Context* c, uint64_t state, const double* in, double* out, size_t n, double drift,
-                                double scale, unsigned steps, uint64_t draws_per_step) {
+template <class T>
+static int stochastic_evolution_any(Context* c, uint64_t state, const T* in, T* out, size_t n, double drift, double scale,
+                                    unsigned steps, uint64_t draws_per_step) {
     if (n == 0) return RMHIP_OK;
     const size_t npairs = (n + 1) / 2;
     const unsigned grid = rng_grid(c, npairs);
     unsigned long long gm, gp, sm, sp;
     lcg_jump(2ULL * grid * 256ULL, &gm, &gp);
     lcg_jump(draws_per_step ? (unsigned long long)draws_per_step : 2ULL * (unsigned long long)npairs, &sm, &sp);
-    hipLaunchKernelGGL(k_stochastic_evolution, dim3(grid), dim3(256), 0, c->stream, (unsigned long long)state, in, out, n, drift,
-                       scale, steps, gm, gp, sm, sp);
+    hipLaunchKernelGGL(k_stochastic_evolution<T>, dim3(grid), dim3(256), 0, c->stream, (unsigned long long)state, in, out, n,
+                       drift, scale, steps, gm, gp, sm, sp);
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
+}
+int launch_stochastic_evolution(Context* c, uint64_t state, const double* in, double* out, size_t n, double drift,
+                                double scale, unsigned steps, uint64_t draws_per_step) {
+    return stochastic_evolution_any(c, state, in, out, n, drift, scale, steps, draws_per_step);
+}
+int launch_stochastic_evolution_f32(Context* c, uint64_t state, const float* in, float* out, size_t n, double drift,
+                                    double scale, unsigned steps, uint64_t draws_per_step) {
+    return stochastic_evolution_any(c, state, in, out, n, drift, scale, steps, draws_per_step);
 }
 
 }  // namespace rmhip

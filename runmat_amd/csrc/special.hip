@@ -19,8 +19,9 @@ static constexpr int IN_MAX_BATCH = 256;
 static constexpr int IN_BLOCK = 1024;  // streaming passes: the largest multiple of `batch` <= 1024 threads per block
 
 // partial[block][b] = sum over this block's share of plane elements of x (SQDEV: (x - mean[b])^2)
-template <bool SQDEV>
-__global__ void __launch_bounds__(IN_BLOCK) k_plane_partial(const double* __restrict__ x, size_t total, int batch,
+// T = storage type (float on a precision-32 provider); sums and statistics are f64 either way
+template <bool SQDEV, class T>
+__global__ void __launch_bounds__(IN_BLOCK) k_plane_partial(const T* __restrict__ x, size_t total, int batch,
                                                        const double* __restrict__ mean, double* __restrict__ partial) {
     __shared__ double s[IN_BLOCK];
     const int t = threadIdx.x;
@@ -30,7 +31,7 @@ __global__ void __launch_bounds__(IN_BLOCK) k_plane_partial(const double* __rest
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     size_t i = (size_t)blockIdx.x * blockDim.x + t;
     for (; i + 3 * stride < total; i += 4 * stride) {
-        const double v0 = x[i], v1 = x[i + stride], v2 = x[i + 2 * stride], v3 = x[i + 3 * stride];
+        const double v0 = (double)x[i], v1 = (double)x[i + stride], v2 = (double)x[i + 2 * stride], v3 = (double)x[i + 3 * stride];
         if (SQDEV) {
             const double d0 = v0 - mu, d1 = v1 - mu, d2 = v2 - mu, d3 = v3 - mu;
             a0 += d0 * d0;
@@ -45,7 +46,7 @@ __global__ void __launch_bounds__(IN_BLOCK) k_plane_partial(const double* __rest
         }
     }
     for (; i < total; i += stride) {
-        const double v = x[i];
+        const double v = (double)x[i];
         if (SQDEV) {
             const double d = v - mu;
             a0 += d * d;
@@ -90,24 +91,26 @@ __global__ void __launch_bounds__(IN_MAX_BATCH) k_plane_final(const double* __re
     }
 }
 
-__global__ void __launch_bounds__(IN_BLOCK) k_imgnorm_apply(const double* __restrict__ x, double* __restrict__ y, size_t total,
+template <class T>
+__global__ void __launch_bounds__(IN_BLOCK) k_imgnorm_apply(const T* __restrict__ x, T* __restrict__ y, size_t total,
                                                        int batch, const double* __restrict__ stats, int has_gain, double gain,
                                                        int has_bias, double bias, int clamp_zero, int has_gamma, double gamma) {
     const int b = threadIdx.x % batch;
     const double mu = stats[b], inv = stats[batch + b];
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        double v = (x[i] - mu) * inv;
+        double v = ((double)x[i] - mu) * inv;
         if (has_gain) v *= gain;
         if (has_bias) v += bias;
         if (clamp_zero) v = fmax(v, 0.0);  // f64::max: a NaN operand loses
         if (has_gamma) v = pow(v, gamma);
-        y[i] = v;
+        y[i] = (T)v;
     }
 }
 
-int image_normalize_device(Context* c, const double* x, double* y, size_t batch, size_t height, size_t width, double epsilon,
-                           int has_gain, double gain, int has_bias, double bias, int clamp_zero, int has_gamma, double gamma) {
+template <class T>
+static int image_normalize_any(Context* c, const T* x, T* y, size_t batch, size_t height, size_t width, double epsilon,
+                               int has_gain, double gain, int has_bias, double bias, int clamp_zero, int has_gamma, double gamma) {
     const size_t plane = height * width, total = batch * plane;
     if (total == 0) return RMHIP_OK;
     if (batch > (size_t)IN_MAX_BATCH)
@@ -120,17 +123,25 @@ int image_normalize_device(Context* c, const double* x, double* y, size_t batch,
     RMHIP_TRY(c->ensure_scratch(sizeof(double) * ((size_t)grid * batch + 2 * batch)));
     double* partial = c->scratch;
     double* stats = c->scratch + (size_t)grid * batch;
-    hipLaunchKernelGGL(k_plane_partial<false>, dim3(grid), dim3(threads), 0, c->stream, x, total, (int)batch, stats, partial);
+    hipLaunchKernelGGL((k_plane_partial<false, T>), dim3(grid), dim3(threads), 0, c->stream, x, total, (int)batch, stats, partial);
     hipLaunchKernelGGL(k_plane_final, dim3(1), dim3(IN_MAX_BATCH), 0, c->stream, partial, (int)grid, (int)batch, (double)plane,
                        epsilon, 0, stats);
-    hipLaunchKernelGGL(k_plane_partial<true>, dim3(grid), dim3(threads), 0, c->stream, x, total, (int)batch, stats, partial);
+    hipLaunchKernelGGL((k_plane_partial<true, T>), dim3(grid), dim3(threads), 0, c->stream, x, total, (int)batch, stats, partial);
     hipLaunchKernelGGL(k_plane_final, dim3(1), dim3(IN_MAX_BATCH), 0, c->stream, partial, (int)grid, (int)batch, (double)plane,
                        epsilon, 1, stats);
-    hipLaunchKernelGGL(k_imgnorm_apply, dim3(grid), dim3(threads), 0, c->stream, x, y, total, (int)batch, stats, has_gain, gain,
+    hipLaunchKernelGGL(k_imgnorm_apply<T>, dim3(grid), dim3(threads), 0, c->stream, x, y, total, (int)batch, stats, has_gain, gain,
                        has_bias, bias, clamp_zero, has_gamma, gamma);
     c->tel.kernel_launches += 5;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
+}
+int image_normalize_device(Context* c, const double* x, double* y, size_t batch, size_t height, size_t width, double epsilon,
+                           int has_gain, double gain, int has_bias, double bias, int clamp_zero, int has_gamma, double gamma) {
+    return image_normalize_any(c, x, y, batch, height, width, epsilon, has_gain, gain, has_bias, bias, clamp_zero, has_gamma, gamma);
+}
+int image_normalize_device_f32(Context* c, const float* x, float* y, size_t batch, size_t height, size_t width, double epsilon,
+                               int has_gain, double gain, int has_bias, double bias, int clamp_zero, int has_gamma, double gamma) {
+    return image_normalize_any(c, x, y, batch, height, width, epsilon, has_gain, gain, has_bias, bias, clamp_zero, has_gamma, gamma);
 }
 
 // ---- diag_extract (lib.rs:1625-1632; simple_provider.rs:3281-3312, index rule :2386-2392) ----------------
