@@ -134,7 +134,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["fused", "dgemm", "mc", "mldivide", "chain", "mc_evolved", "image", "fused_f32"], default="fused")
+    ap.add_argument("--workload", choices=["fused", "dgemm", "mc", "mldivide", "chain", "mc_evolved", "image", "fused_f32", "sgemm"], default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     args = ap.parse_args()
@@ -504,7 +504,45 @@ def main() -> None:
                          "kernel": "rm_ew_fast (f32 variant: 16-byte vectors of four, body in f64)", "kernel_ms": round(kern_ms, 5)},
         }
 
-    records = {"fused_f32": fused_f32_record, "fused": fused_record, "dgemm": dgemm_record, "mc": mc_record, "mldivide": mldivide_record,
+    def sgemm_record(steps, warmup):
+        # precision-32 provider: C = A*B on the f32 matrix cores (sgemm.hip), row-block sharded like the f64 workload
+        p32 = HipProvider(local_rank, precision="F32")
+        rows = n // world
+        ha = p32.fill_uniform(11 + 1000 * rank, -1.0, 1.0, (rows, n))
+        hb = p32.fill_uniform(12, -1.0, 1.0, (n, n))
+
+        def step():
+            p32.free(p32.matmul(ha, hb))
+
+        for _ in range(warmup):
+            step()
+        p32.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        p32.synchronize()
+        barrier()
+        wall = max_over_ranks(time.perf_counter() - t0)
+        p32.timer_begin()
+        for _ in range(steps):
+            step()
+        kern_ms = p32.timer_end() / steps
+        p32.close()
+        ms = wall / steps * 1e3
+        achieved = (dgemm_flops / world) / (kern_ms * 1e-3) / 1e12
+        return {
+            "metric": "fp32 GFLOP/s (8192^3 matmul on a precision-32 provider, row-block sharded across GPUs)",
+            "value": round(dgemm_flops / (ms * 1e-3) / 1e9, 1), "unit": "GFLOP/s", "ms_per_step": round(ms, 5),
+            "scaling": "strong", "dtype": "f32 (f32 MFMA accumulation)",
+            "config": {"workload": "C=A*B 8192x8192x8192 f32 storage via rmhip_matmul", "flops_per_step": dgemm_flops,
+                       "parallelism": f"row-block x{world}, B replicated, no collective"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": round(achieved / 157.3, 4), "traffic": None,
+                         "kernel": "k_sgemm<false,false,false> (v_mfma_f32_16x16x4_f32)", "kernel_ms": round(kern_ms, 5)},
+        }
+
+    records = {"sgemm": sgemm_record, "fused_f32": fused_f32_record, "fused": fused_record, "dgemm": dgemm_record, "mc": mc_record, "mldivide": mldivide_record,
                "chain": chain_record, "mc_evolved": mc_evolved_record, "image": image_record}
     primary = records[args.workload]
     rec = primary(args.steps, args.warmup)
@@ -516,12 +554,12 @@ def main() -> None:
     }
     if not args.no_also:
         # the other configs of BASELINE.json, short runs; every rank takes part (collectives inside)
-        others = [w for w in ("fused", "dgemm", "mc", "mc_evolved", "image", "chain", "fused_f32") if w != args.workload]
+        others = [w for w in ("fused", "dgemm", "mc", "mc_evolved", "image", "chain", "fused_f32", "sgemm") if w != args.workload]
         if world == 1 and args.workload != "mldivide":
             others.append("mldivide")
         also = []
         for w in others:
-            steps = {"fused": 20, "dgemm": 5, "mc": 3, "mc_evolved": 3, "image": 5, "mldivide": 2, "chain": 100, "fused_f32": 20}[w]
+            steps = {"fused": 20, "dgemm": 5, "mc": 3, "mc_evolved": 3, "image": 5, "mldivide": 2, "chain": 100, "fused_f32": 20, "sgemm": 5}[w]
             sec = records[w](steps, 2 if w != "mldivide" else 1)
             also.append({k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "roofline")})
         out["also"] = also
@@ -529,9 +567,9 @@ def main() -> None:
         out["cpu_baseline"] = {"fused": cpu_baseline_fused, "dgemm": cpu_baseline_dgemm, "mc": cpu_baseline_mc,
                                "mldivide": cpu_baseline_mldivide, "chain": cpu_baseline_chain,
                                "mc_evolved": cpu_baseline_mc, "image": cpu_baseline_fused,
-                               "fused_f32": cpu_baseline_fused}[args.workload]()
+                               "fused_f32": cpu_baseline_fused, "sgemm": cpu_baseline_dgemm}[args.workload]()
         for a in out.get("also", []):
-            if a["unit"] == "GFLOP/s" and "matmul" in a["metric"]:
+            if a["unit"] == "GFLOP/s" and "matmul" in a["metric"] and a["metric"].startswith("fp64"):
                 a["cpu_baseline"] = cpu_baseline_dgemm()
             elif a["unit"] == "samples/s" and "stochastic_evolution" not in a["metric"]:
                 a["cpu_baseline"] = cpu_baseline_mc()

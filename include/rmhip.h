@@ -79,9 +79,10 @@ RMHIP_API int rmhip_device_info(rmhip_ctx* ctx, rmhip_device_info_t* out);
  * the planner sends its f32 shaders (`scalar_ty`, fusion.rs:1525).  Arithmetic stays f64 in registers and is rounded
  * once on store - what the CPU path does for `single` arrays (f64 storage pre-rounded through f32,
  * runmat-builtins/src/lib.rs:426-436) - so results agree with the CPU to f32 rounding instead of accumulating f32
- * error.  Fused elementwise / fused reduction, the per-op elementwise hooks, reductions and dot read and write f32
- * storage directly; matmul, lu, mldivide/linsolve and the remaining hooks run their f64 kernels on widened copies
- * and narrow the result.  rmhip_buffer_bits reports a buffer's storage width (externally wrapped memory stays f64). */
+ * error.  Fused elementwise / fused reduction, the per-op elementwise hooks, reductions, dot, rng, stochastic_evolution
+ * and image_normalize read and write f32 storage directly; matmul runs on the f32 matrix cores (f32 accumulation, like
+ * the reference's F32 backend; RMHIP_F32_MATMUL=f64 selects the f64-exact path); lu, mldivide/linsolve and the
+ * remaining hooks run their f64 kernels on widened copies and narrow the result.  rmhip_buffer_bits reports a buffer's storage width (externally wrapped memory stays f64). */
 RMHIP_API int rmhip_set_precision(rmhip_ctx* ctx, int bits);
 RMHIP_API int rmhip_buffer_bits(rmhip_ctx* ctx, rmhip_buf id, int* bits);
 

@@ -233,6 +233,9 @@ enum { EP_ACTIVE = 1, EP_ROW = 2, EP_ROW_DIV = 4, EP_COL = 8, EP_COL_DIV = 16, E
        EP_POW = 128, EP_DIAG = 256 };
 int launch_dgemm_trans(Context* c, bool ta, bool tb, size_t m, size_t n, size_t k, double alpha, const double* A, size_t lda,
                        const double* B, size_t ldb, double beta, double* C, size_t ldc);
+// f32 GEMM for precision-32 providers (sgemm.hip): C = op(A) * op(B), f32 accumulation in the matrix cores
+int launch_sgemm_trans(Context* c, bool ta, bool tb, size_t m, size_t n, size_t k, const float* A, size_t lda, const float* B,
+                       size_t ldb, float* C, size_t ldc);
 int launch_dgemm_epilogue(Context* c, size_t m, size_t n, size_t k, const double* A, size_t lda, const double* B,
                           size_t ldb, double* C, size_t ldc, const GemmEpilogue& ep);
 

@@ -597,6 +597,34 @@ int rmhip_matmul(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
     ScopedTimer timer(&c->tel.matmul_count, &c->tel.matmul_ns);
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     Buffer ab, bb, ob;
+    // Precision 32: both operands in f32 storage run on the f32 matrix cores (sgemm.hip; f32 accumulation like the
+    // reference's F32 backend).  RMHIP_F32_MATMUL=f64 keeps the widen -> dgemm -> round-once path (the CPU's `single`
+    // result exactly); it is also what mixed operands, k == 0 and few-tile / long-k shapes (split-K) use.
+    if (c->precision == 32) {
+        const char* mode = std::getenv("RMHIP_F32_MATMUL");  // read per call: tests flip it
+        const bool want_f64 = mode && std::strcmp(mode, "f64") == 0;
+        Buffer ra, rb;
+        RMHIP_TRY(c->get_raw(a, &ra));
+        RMHIP_TRY(c->get_raw(b, &rb));
+        if (!want_f64 && ra.dtype == DT_F32 && rb.dtype == DT_F32 && ra.shape.size() == 2 && rb.shape.size() == 2) {
+            if (ra.tview && rb.tview) {
+                RMHIP_TRY(c->settle_view(b));
+                RMHIP_TRY(c->get_raw(b, &rb));
+            }
+            const size_t m = ra.shape[0], k = ra.shape[1], kb = rb.shape[0], n = rb.shape[1];
+            if (k != kb) return fail(RMHIP_ERR_SHAPE, "matmul: inner dims must agree (%zux%zu * %zux%zu)", m, k, kb, n);
+            const size_t tiles = ((m + 127) / 128) * ((n + 127) / 128);
+            const bool split_shape = tiles * 4 <= (size_t)c->num_cus && k >= 8192;
+            if (k > 0 && !split_shape) {
+                const size_t oshape[2] = {m, n};
+                RMHIP_TRY(c->new_buffer_f32(oshape, 2, out, &ob));
+                int rc = launch_sgemm_trans(c, ra.tview, rb.tview, m, n, k, ra.data_f32(), ra.tview ? k : m, rb.data_f32(),
+                                            rb.tview ? n : k, ob.data_f32(), m);
+                if (rc) rmhip_free(ctx, *out);
+                return rc;
+            }
+        }
+    }
     // transpose views are consumed in place (A'*B, A*B'); with both operands transposed B is materialised
     RMHIP_TRY(c->get_view(a, &ab));
     RMHIP_TRY(c->get_view(b, &bb));

@@ -1,0 +1,248 @@
+// sgemm.hip -- f32 GEMM on the CDNA4 matrix cores for precision-32 providers: C = op(A) * op(B), column-major,
+// f32 operands and result in HBM.  `AccelProvider::matmul` (crates/runmat-accelerate-api/src/lib.rs:2375-2381) when the
+// provider reports `ProviderPrecision::F32` (lib.rs:815-818); the reference's F32 backend accumulates in f32 too
+// (backend/wgpu/shaders/matmul.rs) and its own checks allow 1e-4 relative / 1e-5 absolute
+// (src/bin/wgpu_profile.rs:20-21,160-163).
+//
+// Same block design as dgemm.hip (128x128 block tile, 2x2 waves of 64x64, K step 16, register -> LDS double
+// buffering, XCD-aware tile order, roles transposed so that the lane-contiguous MFMA index is the memory-contiguous
+// row index of C) with the f32 instruction: v_mfma_f32_16x16x4_f32 = 2048 flop in 32 cycles, i.e. 64 flop/clk/SIMD,
+// 157 TFLOP/s at 2.4 GHz -- twice the f64 rate for the same instruction count, so every tile has half the time to
+// hide its loads in; the 64 accumulator VGPRs (f64: 128) leave room for more resident blocks per CU instead.
+//   LDS (floats): pattern-M tile [k][x] with row stride 144 (144 % 64 == 16: the four k-rows of a ds_read_b32 wave
+//   access fall in disjoint 16-bank groups), pattern-K tile [y][k] with row stride 20 (20 * l15 + lq covers the 64
+//   banks exactly once).  Staging moves 8-byte pairs.
+// Accumulation is f32 in the matrix core: the result differs from the f64 path (RMHIP_F32_MATMUL=f64: widen, dgemm,
+// round once -- the CPU's `single` semantics exactly) by at most ~k * eps32 * sum|a||b|; tests state the bound.
+#include "common.h"
+
+namespace rmhip {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+namespace sg {
+static constexpr int BM = 128, BN = 128, BK = 16;
+static constexpr int SA = BM + 16;  // pattern M row stride (floats)
+static constexpr int SB = BK + 4;   // pattern K row stride (floats)
+static constexpr int TILE = (BK * SA > BN * SB) ? BK * SA : BN * SB;  // floats; either pattern fits either buffer
+static constexpr int GROUP_M = 8;
+}  // namespace sg
+
+struct SgemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    unsigned long long lda, ldb, ldc;
+    unsigned m, n, k;
+    unsigned tiles_m, tiles_n;
+    int vec_a, vec_b;  // EDGE kernel: 8-byte loads are legal for A / B (aligned base, even leading dimension)
+};
+
+__device__ __forceinline__ void sg_tile_of_block(const SgemmArgs& g, unsigned& tm, unsigned& tn) {
+    using namespace sg;
+    const unsigned nwg = g.tiles_m * g.tiles_n;
+    const unsigned b = blockIdx.x;
+    const unsigned xcd = b & 7u, idx = b >> 3;  // block b runs on XCD b % 8: give each XCD a contiguous id range
+    const unsigned q = nwg >> 3, r = nwg & 7u;
+    const unsigned wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const unsigned per_group = GROUP_M * g.tiles_n;
+    const unsigned group = wg / per_group;
+    const unsigned first_m = group * GROUP_M;
+    const unsigned gsz = (g.tiles_m - first_m) < GROUP_M ? (g.tiles_m - first_m) : GROUP_M;
+    const unsigned in_group = wg - group * per_group;
+    tm = first_m + in_group % gsz;
+    tn = in_group / gsz;
+}
+
+#ifndef SGEMM_BLOCKS_PER_CU
+#define SGEMM_BLOCKS_PER_CU 2
+#endif
+
+// EDGE = false: m % 128 == 0, n % 128 == 0, k % 16 == 0, even leading dimensions, 8-byte aligned bases.
+// TA / TB: the operand is stored transposed (RunMat's transpose views), exactly as in k_dgemm.
+template <bool EDGE, bool TA, bool TB>
+__global__ void __launch_bounds__(256, SGEMM_BLOCKS_PER_CU) k_sgemm(const SgemmArgs g) {
+    using namespace sg;
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];
+    float* As = lds;             // [2][TILE]
+    float* Bs = lds + 2 * TILE;  // [2][TILE]
+
+    unsigned tm, tn;
+    sg_tile_of_block(g, tm, tn);
+    const unsigned m0 = tm * BM, n0 = tn * BN;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const unsigned klen = g.k;
+
+    const int p_xp = t & 63;  // pattern M: pair index along the contiguous tile dimension
+    const int p_kc = t >> 6;  //            k = p_kc + 4*p
+    const int q_kp = t & 7;   // pattern K: k pair index
+    const int q_y = t >> 3;   //            y = q_y + 32*p
+
+    v2f ra[4], rb[4];
+
+    auto fetchM = [&](const float* ptr, unsigned long long ld, unsigned x0, unsigned xlim, unsigned k0, int vec, v2f* r) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const unsigned kk = k0 + p_kc + 4 * p;
+            const unsigned xx = x0 + 2 * p_xp;
+            if (!EDGE) {
+                r[p] = *(const v2f*)(ptr + (size_t)kk * ld + xx);
+            } else {
+                v2f v = {0.f, 0.f};
+                if (kk < klen) {
+                    const float* src = ptr + (size_t)kk * ld + xx;
+                    if (vec && xx + 1 < xlim) {
+                        v = *(const v2f*)src;
+                    } else {
+                        if (xx < xlim) v.x = src[0];
+                        if (xx + 1 < xlim) v.y = src[1];
+                    }
+                }
+                r[p] = v;
+            }
+        }
+    };
+    auto fetchK = [&](const float* ptr, unsigned long long ld, unsigned y0, unsigned ylim, unsigned k0, int vec, v2f* r) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const unsigned yy = y0 + q_y + 32 * p;
+            const unsigned kk = k0 + 2 * q_kp;
+            if (!EDGE) {
+                r[p] = *(const v2f*)(ptr + (size_t)yy * ld + kk);
+            } else {
+                v2f v = {0.f, 0.f};
+                if (yy < ylim) {
+                    const float* src = ptr + (size_t)yy * ld + kk;
+                    if (vec && kk + 1 < klen) {
+                        v = *(const v2f*)src;
+                    } else {
+                        if (kk < klen) v.x = src[0];
+                        if (kk + 1 < klen) v.y = src[1];
+                    }
+                }
+                r[p] = v;
+            }
+        }
+    };
+    auto stashM = [&](float* tile, const v2f* r) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *(v2f*)(tile + (p_kc + 4 * p) * SA + 2 * p_xp) = r[p];
+    };
+    auto stashK = [&](float* tile, const v2f* r) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *(v2f*)(tile + (q_y + 32 * p) * SB + 2 * q_kp) = r[p];
+    };
+    auto fetch = [&](unsigned k0) {
+        if (TA) fetchK(g.A, g.lda, m0, g.m, k0, g.vec_a, ra);
+        else fetchM(g.A, g.lda, m0, g.m, k0, g.vec_a, ra);
+        if (TB) fetchM(g.B, g.ldb, n0, g.n, k0, g.vec_b, rb);
+        else fetchK(g.B, g.ldb, n0, g.n, k0, g.vec_b, rb);
+    };
+    auto stash = [&](int buf) {
+        if (TA) stashK(As + buf * TILE, ra);
+        else stashM(As + buf * TILE, ra);
+        if (TB) stashM(Bs + buf * TILE, rb);
+        else stashK(Bs + buf * TILE, rb);
+    };
+
+    v4f acc[4][4];  // [tj (n)][ti (m)]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    const unsigned ktiles = (klen + BK - 1) / BK;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+
+    const int a_off = TA ? (wm * 64 + l15) * SB + lq : lq * SA + wm * 64 + l15;
+    const int b_off = TB ? lq * SA + wn * 64 + l15 : (wn * 64 + l15) * SB + lq;
+    constexpr int A_KSTEP = TA ? 4 : 4 * SA, A_ISTEP = TA ? 16 * SB : 16;
+    constexpr int B_KSTEP = TB ? 4 * SA : 4, B_JSTEP = TB ? 16 : 16 * SB;
+
+    for (unsigned kt = 0; kt < ktiles; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < ktiles) fetch((kt + 1) * BK);
+        const float* a = As + cur * TILE + a_off;
+        const float* b = Bs + cur * TILE + b_off;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            float af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = a[kk * A_KSTEP + i * A_ISTEP];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = b[j * B_JSTEP + kk * B_KSTEP];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[j][i], 0, 0, 0);
+            if (kk == BK / 4 - 1 && kt + 1 < ktiles) stash(cur ^ 1);
+        }
+        __syncthreads();
+    }
+
+    // D[r][c] -> C[m = c][n = r]; c = lane & 15, r = 4 * (lane >> 4) + reg (the f32 16x16x4 accumulator layout)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned mm = m0 + wm * 64 + i * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned nn = n0 + wn * 64 + j * 16 + 4 * lq + r;
+                if (!EDGE || (mm < g.m && nn < g.n)) g.C[(size_t)nn * g.ldc + mm] = acc[j][i][r];
+            }
+        }
+}
+
+template <bool EDGE, bool TA, bool TB>
+static void sg_launch(Context* c, unsigned blocks, const SgemmArgs& g) {
+    hipLaunchKernelGGL((k_sgemm<EDGE, TA, TB>), dim3(blocks), dim3(256), 0, c->stream, g);
+}
+
+// C (m x n, f32) = op(A) * op(B); op(X) = X' when tX (A then stored k x m, B stored n x k).  k == 0 gives zeros.
+int launch_sgemm_trans(Context* c, bool ta, bool tb, size_t m, size_t n, size_t k, const float* A, size_t lda, const float* B,
+                       size_t ldb, float* C, size_t ldc) {
+    using namespace sg;
+    if (m == 0 || n == 0) return RMHIP_OK;
+    if (ta && tb) return fail(RMHIP_ERR_UNSUPPORTED, "sgemm: A' * B' is not instantiated");
+    if (m > 0xffffffffULL || n > 0xffffffffULL || k > 0xffffffffULL)
+        return fail(RMHIP_ERR_UNSUPPORTED, "sgemm: dimension exceeds 2^32");
+    SgemmArgs g;
+    g.A = A;
+    g.B = B;
+    g.C = C;
+    g.lda = lda;
+    g.ldb = ldb;
+    g.ldc = ldc;
+    g.m = (unsigned)m;
+    g.n = (unsigned)n;
+    g.k = (unsigned)k;
+    g.tiles_m = (unsigned)((m + BM - 1) / BM);
+    g.tiles_n = (unsigned)((n + BN - 1) / BN);
+    g.vec_a = ((((uintptr_t)A & 7) == 0) && (lda % 2 == 0)) ? 1 : 0;
+    g.vec_b = ((((uintptr_t)B & 7) == 0) && (ldb % 2 == 0)) ? 1 : 0;
+    const bool fast = (m % BM == 0) && (n % BN == 0) && (k % BK == 0) && k > 0 && g.vec_a && g.vec_b;
+    const unsigned blocks = g.tiles_m * g.tiles_n;
+    if (ta) {
+        if (fast) sg_launch<false, true, false>(c, blocks, g);
+        else sg_launch<true, true, false>(c, blocks, g);
+    } else if (tb) {
+        if (fast) sg_launch<false, false, true>(c, blocks, g);
+        else sg_launch<true, false, true>(c, blocks, g);
+    } else {
+        if (fast) sg_launch<false, false, false>(c, blocks, g);
+        else sg_launch<true, false, false>(c, blocks, g);
+    }
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+
+}  // namespace rmhip

@@ -53,9 +53,23 @@ def run(prec):
     out["randn_1e8"] = {"ms": round(ms, 4), "GBps": round(eb * 1e8 / ms / 1e6, 1)}
     ms = timed(p, lambda: free(p.matmul(a, b)), reps=3, warm=1)
     out["matmul_8192"] = {"ms": round(ms, 3), "TFLOPs": round(2.0 * N ** 3 / ms / 1e9, 2)}
+    if prec == "F32":
+        os.environ["RMHIP_F32_MATMUL"] = "f64"
+        ms = timed(p, lambda: free(p.matmul(a, b)), reps=3, warm=1)
+        out["matmul_8192_f64_path"] = {"ms": round(ms, 3), "TFLOPs": round(2.0 * N ** 3 / ms / 1e9, 2)}
+        del os.environ["RMHIP_F32_MATMUL"]
+        at = p.transpose(a)
+        ms = timed(p, lambda: free(p.matmul(at, b)), reps=3, warm=1)
+        out["matmul_8192_At_B"] = {"ms": round(ms, 3), "TFLOPs": round(2.0 * N ** 3 / ms / 1e9, 2)}
+        for sz in (1024, 2048, 4096):
+            x = p.fill_uniform(7, -1.0, 1.0, (sz, sz))
+            ms = timed(p, lambda: free(p.matmul(x, x)), reps=5, warm=2)
+            out[f"matmul_{sz}"] = {"ms": round(ms, 4), "TFLOPs": round(2.0 * sz ** 3 / ms / 1e9, 2)}
+            p.free(x)
     p.close()
     return out
 
 
 if __name__ == "__main__":
-    print(json.dumps({"F64": run("F64"), "F32": run("F32")}, indent=1))
+    which = sys.argv[1:] or ["F64", "F32"]
+    print(json.dumps({w: run(w) for w in which}, indent=1))

@@ -277,7 +277,13 @@ def test_f32_reductions_and_dot(prov32, prov, oracle, shape):
         assert got.shape == (1, shape[1], 1) and close32(prov32.download_matrix(got), want, ulps=2.0)
 
 
-def test_f32_matmul_solve_and_friends_use_f64_kernels_on_widened_operands(prov32, prov, oracle):
+@pytest.fixture
+def exact_f32_matmul(monkeypatch):
+    """RMHIP_F32_MATMUL=f64: widen -> dgemm -> round once (the CPU's `single` result) instead of the f32 matrix cores."""
+    monkeypatch.setenv("RMHIP_F32_MATMUL", "f64")
+
+
+def test_f32_matmul_solve_and_friends_use_f64_kernels_on_widened_operands(prov32, prov, oracle, exact_f32_matmul):
     rng = np.random.default_rng(33)
     A, B = f32r(rng.standard_normal((150, 70))), f32r(rng.standard_normal((70, 90)))
     c32, c64 = prov32.matmul(prov32.upload(A), prov32.upload(B)), prov.matmul(prov.upload(A), prov.upload(B))
@@ -313,6 +319,53 @@ def test_f32_matmul_solve_and_friends_use_f64_kernels_on_widened_operands(prov32
     assert np.allclose(prov32.download_matrix(p32), oracle.matmul_power_step(A, B, 1e-12), rtol=1e-5, atol=1e-6)
     d32 = prov32.diag_extract(prov32.upload(f32r(rng.standard_normal((9, 7)))), 1)
     assert prov32.buffer_bits(d32) == 32 and d32.shape[0] == 6
+
+
+@pytest.mark.parametrize("m,k,n", [(128, 16, 128), (256, 128, 384), (150, 70, 90), (1, 33, 1), (129, 1, 127), (5, 1000, 7),
+                                   (640, 515, 130), (1024, 1024, 1024), (3, 2, 4)])
+def test_f32_matmul_on_the_f32_matrix_cores(prov32, oracle, m, k, n, monkeypatch):
+    """Default precision-32 matmul: v_mfma_f32_16x16x4_f32 with f32 accumulation (what the reference's F32 backend
+    does; its checks allow 1e-4 relative, wgpu_profile.rs:20-21).  Bound: k * eps32 * sum|a||b| per element, the
+    forward error of any f32 dot product; the f64 path (RMHIP_F32_MATMUL=f64) is the comparison."""
+    monkeypatch.delenv("RMHIP_F32_MATMUL", raising=False)
+    rng = np.random.default_rng(m * 7 + k * 3 + n)
+    A, B = f32r(rng.standard_normal((m, k))), f32r(rng.standard_normal((k, n)))
+    want = oracle.matmul(A, B)
+    bound = (k + 2) * ULP32 * (np.abs(A) @ np.abs(B)) + 1e-30
+    ha, hb = prov32.upload(A), prov32.upload(B)
+    c = prov32.matmul(ha, hb)
+    assert c.shape == (m, n) and prov32.buffer_bits(c) == 32
+    got = prov32.download_matrix(c)
+    assert np.all(np.abs(got - want) <= bound), float(np.max(np.abs(got - want) / bound))
+    # transposed operands in place: A' * B and A * B' (views of f32 storage), both transposed (B is materialised)
+    hat, hbt = prov32.transpose(prov32.upload(np.ascontiguousarray(A.T))), prov32.transpose(prov32.upload(np.ascontiguousarray(B.T)))
+    for x, y in ((hat, hb), (ha, hbt), (hat, hbt)):
+        g2 = prov32.download_matrix(prov32.matmul(x, y))
+        assert np.all(np.abs(g2 - want) <= bound)
+    monkeypatch.setenv("RMHIP_F32_MATMUL", "f64")
+    exact = prov32.download_matrix(prov32.matmul(ha, hb))
+    assert same_bits(exact, f32r(want)) or np.max(np.abs(exact - f32r(want))) <= ULP32 * np.max(np.abs(want))
+
+
+def test_f32_matmul_exactness_cases_and_errors(prov32, monkeypatch):
+    from runmat_amd import ProviderError
+
+    monkeypatch.delenv("RMHIP_F32_MATMUL", raising=False)
+    # small integers are exact in f32 accumulation: the reference's matmul KATs (mtimes.rs:495-503,688-706)
+    a = prov32.upload(np.array([[1.0, 2.0, 3.0], [4.0, 5.0, 6.0]]))
+    b = prov32.upload(np.array([[7.0, 8.0], [9.0, 10.0], [11.0, 12.0]]))
+    assert np.array_equal(prov32.download_matrix(prov32.matmul(a, b)), np.array([[58.0, 64.0], [139.0, 154.0]]))
+    eye = prov32.upload(np.eye(200))
+    rngm = f32r(np.random.default_rng(4).standard_normal((200, 330)))
+    assert same_bits(prov32.download_matrix(prov32.matmul(eye, prov32.upload(rngm))), rngm)  # detects any transposition slip
+    with pytest.raises(ProviderError) as e:
+        prov32.matmul(a, a)
+    assert e.value.code == 3
+    z = prov32.matmul(prov32.upload(np.zeros((4, 0))), prov32.upload(np.zeros((0, 5))))  # k == 0: zeros
+    assert z.shape == (4, 5) and np.array_equal(prov32.download(z), np.zeros(20))
+    x = np.array([[np.inf, 1.0], [np.nan, 2.0]])
+    got = prov32.download_matrix(prov32.matmul(prov32.upload(x), prov32.upload(np.ones((2, 2)))))
+    assert np.isinf(got[0, 0]) and np.isnan(got[1, 0])
 
 
 def test_f32_rng_streams_are_the_f64_streams_rounded(prov32, prov, oracle):
