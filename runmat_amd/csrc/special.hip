@@ -63,21 +63,31 @@ __global__ void __launch_bounds__(IN_BLOCK) k_plane_partial(const T* __restrict_
     }
 }
 
-// stats[b] (mean) or stats[batch + b] (inv_sigma) from the block partials.  All 256 threads take part: thread t owns
-// batch element t % batch and every (256 / batch)-th block partial (independent loads, a fixed order), the
-// per-thread sums then meet in LDS in thread order -- deterministic, and ~100x faster than one thread per batch
-// element walking thousands of partials with dependent loads (0.66 ms -> a few us, measured).
-__global__ void __launch_bounds__(IN_MAX_BATCH) k_plane_final(const double* __restrict__ partial, int nblocks, int batch,
-                                                              double plane, double epsilon, int second,
-                                                              double* __restrict__ stats) {
-    __shared__ double s[IN_MAX_BATCH];
+// stats[b] (mean) or stats[batch + b] (inv_sigma) from the block partials.  All IN_BLOCK threads take part: thread t
+// owns batch element t % batch and every (lanes / batch)-th block partial, four independent loads in flight per
+// trip (one dependent load per trip made this kernel 45 us for 2048 partials: pure memory latency); the per-thread
+// sums then meet in LDS in thread order -- a fixed order, so the result is reproducible run to run.
+__global__ void __launch_bounds__(IN_BLOCK) k_plane_final(const double* __restrict__ partial, int nblocks, int batch,
+                                                          double plane, double epsilon, int second,
+                                                          double* __restrict__ stats) {
+    __shared__ double s[IN_BLOCK];
     const int t = threadIdx.x;
-    const int lanes = (IN_MAX_BATCH / batch) * batch;  // threads that take part (a multiple of batch)
+    const int lanes = ((int)blockDim.x / batch) * batch;  // threads that take part (a multiple of batch)
     const int b = t % batch, grp = t / batch, ngrp = lanes / batch;
-    double acc = 0.0;
-    if (t < lanes)
-        for (int k = grp; k < nblocks; k += ngrp) acc += partial[(size_t)k * batch + b];
-    s[t] = acc;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (t < lanes) {
+        int k = grp;
+        for (; k + 3 * ngrp < nblocks; k += 4 * ngrp) {
+            const double v0 = partial[(size_t)k * batch + b], v1 = partial[(size_t)(k + ngrp) * batch + b],
+                         v2 = partial[(size_t)(k + 2 * ngrp) * batch + b], v3 = partial[(size_t)(k + 3 * ngrp) * batch + b];
+            a0 += v0;
+            a1 += v1;
+            a2 += v2;
+            a3 += v3;
+        }
+        for (; k < nblocks; k += ngrp) a0 += partial[(size_t)k * batch + b];
+    }
+    s[t] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (t >= batch) return;
     double total = 0.0;
@@ -123,11 +133,13 @@ static int image_normalize_any(Context* c, const T* x, T* y, size_t batch, size_
     RMHIP_TRY(c->ensure_scratch(sizeof(double) * ((size_t)grid * batch + 2 * batch)));
     double* partial = c->scratch;
     double* stats = c->scratch + (size_t)grid * batch;
+    // few partials: a 256-thread final block (its serial LDS fold is shorter); thousands: all 1024 threads share the loads
+    const unsigned fthreads = (size_t)grid * batch >= 8192 ? IN_BLOCK : IN_MAX_BATCH;
     hipLaunchKernelGGL((k_plane_partial<false, T>), dim3(grid), dim3(threads), 0, c->stream, x, total, (int)batch, stats, partial);
-    hipLaunchKernelGGL(k_plane_final, dim3(1), dim3(IN_MAX_BATCH), 0, c->stream, partial, (int)grid, (int)batch, (double)plane,
+    hipLaunchKernelGGL(k_plane_final, dim3(1), dim3(fthreads), 0, c->stream, partial, (int)grid, (int)batch, (double)plane,
                        epsilon, 0, stats);
     hipLaunchKernelGGL((k_plane_partial<true, T>), dim3(grid), dim3(threads), 0, c->stream, x, total, (int)batch, stats, partial);
-    hipLaunchKernelGGL(k_plane_final, dim3(1), dim3(IN_MAX_BATCH), 0, c->stream, partial, (int)grid, (int)batch, (double)plane,
+    hipLaunchKernelGGL(k_plane_final, dim3(1), dim3(fthreads), 0, c->stream, partial, (int)grid, (int)batch, (double)plane,
                        epsilon, 1, stats);
     hipLaunchKernelGGL(k_imgnorm_apply<T>, dim3(grid), dim3(threads), 0, c->stream, x, y, total, (int)batch, stats, has_gain, gain,
                        has_bias, bias, clamp_zero, has_gamma, gamma);
