@@ -500,7 +500,7 @@ def main() -> None:
                        "bytes_per_step_per_gpu": nbytes, "elements_per_s": round(world * n * n / (ms * 1e-3), 1),
                        "parallelism": f"independent x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("rm_ew_fast_f32"),
                          "kernel": "rm_ew_fast (f32 variant: 16-byte vectors of four, body in f64)", "kernel_ms": round(kern_ms, 5)},
         }
 
