@@ -198,6 +198,10 @@ RMHIP_API int rmhip_reduce(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int nan
  * which is how the CPU computes `mean(x, vecdim)` (mean of means, mean.rs:1107-1116); works for every reduce op. */
 RMHIP_API int rmhip_reduce_nd(rmhip_ctx* ctx, int op, rmhip_buf a, const size_t* dims_zero_based, size_t ndims,
                               int nan_mode, rmhip_buf* out);
+/* `reduce_moments_nd` (lib.rs:2770-2778, `ProviderMoments2` :1317-1320): E[x] and E[x^2] over several zero-based
+ * dims in one call (same dim handling as rmhip_reduce_nd; NaNs propagate).  Both outputs keep the reduced extents as 1. */
+RMHIP_API int rmhip_reduce_moments_nd(rmhip_ctx* ctx, rmhip_buf a, const size_t* dims_zero_based, size_t ndims,
+                                      rmhip_buf* mean_out, rmhip_buf* ex2_out);
 RMHIP_API int rmhip_dot(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, int dim, rmhip_buf* out);
 
 /* ---- linear algebra  (lib.rs:2375-2405, 2477-2500) ------------------------------------------ */

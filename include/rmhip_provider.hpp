@@ -202,6 +202,12 @@ public:
         check(rmhip_reduce_nd(ctx_, RMHIP_RMEAN, own(a), dims_zero_based.data(), dims_zero_based.size(), 0, &out));
         return with_shape(out);
     }
+    // lib.rs:2770-2778 -> ProviderMoments2 { mean, ex2 } (lib.rs:1317-1320)
+    std::pair<GpuTensorHandle, GpuTensorHandle> reduce_moments_nd(const GpuTensorHandle& a, const std::vector<size_t>& dims_zero_based) const {
+        uint64_t mean = 0, ex2 = 0;
+        check(rmhip_reduce_moments_nd(ctx_, own(a), dims_zero_based.data(), dims_zero_based.size(), &mean, &ex2));
+        return {with_shape(mean), with_shape(ex2)};
+    }
     GpuTensorHandle reduce_min(const GpuTensorHandle& a) const { return reduce(RMHIP_RMIN, a, -1); }
     GpuTensorHandle reduce_max(const GpuTensorHandle& a) const { return reduce(RMHIP_RMAX, a, -1); }
 

@@ -120,6 +120,17 @@ int get_operand(Context* c, rmhip_buf id, Buffer* out, bool* native) {
     return c->get(id, out);
 }
 
+// Precision 32: may this product run on the f32 matrix cores (sgemm.hip)?  RMHIP_F32_MATMUL=f64 keeps the widen ->
+// dgemm -> round-once path (the CPU's `single` result exactly), which also serves k == 0 and the few-tile / long-k
+// shapes dgemm splits along k (sgemm has no split-K).  Read per call: tests flip the variable.
+bool f32_gemm_eligible(const Context* c, size_t m, size_t n, size_t k) {
+    if (c->precision != 32 || k == 0) return false;
+    const char* mode = std::getenv("RMHIP_F32_MATMUL");
+    if (mode && std::strcmp(mode, "f64") == 0) return false;
+    const size_t tiles = ((m + 127) / 128) * ((n + 127) / 128);
+    return !(tiles * 4 <= (size_t)c->num_cus && k >= 8192);
+}
+
 std::vector<size_t> normalize_matrix_shape(const std::vector<size_t>& s) {
     if (s.empty()) return {1, 1};
     if (s.size() == 1) return {s[0], 1};
@@ -560,6 +571,29 @@ int rmhip_reduce_nd(rmhip_ctx* ctx, int op, rmhip_buf a, const size_t* dims_zero
     return RMHIP_OK;
 }
 
+int rmhip_reduce_moments_nd(rmhip_ctx* ctx, rmhip_buf a, const size_t* dims_zero_based, size_t ndims, rmhip_buf* mean_out,
+                            rmhip_buf* ex2_out) {
+    CTX_OR_FAIL(ctx);
+    if (!mean_out || !ex2_out) return fail(RMHIP_ERR_INVALID, "reduce_moments_nd: null output");
+    size_t numel = 0;
+    RMHIP_TRY(rmhip_numel(ctx, a, &numel));
+    if (numel == 0) return fail(RMHIP_ERR_UNSUPPORTED, "reduce_moments_nd: empty tensor");  // nd.rs:318
+    rmhip_buf mean = 0, sq = 0, ex2 = 0;
+    RMHIP_TRY(rmhip_reduce_nd(ctx, RMHIP_RMEAN, a, dims_zero_based, ndims, 0, &mean));
+    int rc = rmhip_binary(ctx, RMHIP_MUL, a, a, &sq);  // x .* x, then the same mean-of-means as the CPU's mean(x.^2, dims)
+    if (!rc) {
+        rc = rmhip_reduce_nd(ctx, RMHIP_RMEAN, sq, dims_zero_based, ndims, 0, &ex2);
+        rmhip_free(ctx, sq);
+    }
+    if (rc) {
+        rmhip_free(ctx, mean);
+        return rc;
+    }
+    *mean_out = mean;
+    *ex2_out = ex2;
+    return RMHIP_OK;
+}
+
 int rmhip_dot(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, int dim, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
@@ -601,21 +635,17 @@ int rmhip_matmul(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
     // reference's F32 backend).  RMHIP_F32_MATMUL=f64 keeps the widen -> dgemm -> round-once path (the CPU's `single`
     // result exactly); it is also what mixed operands, k == 0 and few-tile / long-k shapes (split-K) use.
     if (c->precision == 32) {
-        const char* mode = std::getenv("RMHIP_F32_MATMUL");  // read per call: tests flip it
-        const bool want_f64 = mode && std::strcmp(mode, "f64") == 0;
         Buffer ra, rb;
         RMHIP_TRY(c->get_raw(a, &ra));
         RMHIP_TRY(c->get_raw(b, &rb));
-        if (!want_f64 && ra.dtype == DT_F32 && rb.dtype == DT_F32 && ra.shape.size() == 2 && rb.shape.size() == 2) {
+        if (ra.dtype == DT_F32 && rb.dtype == DT_F32 && ra.shape.size() == 2 && rb.shape.size() == 2) {
             if (ra.tview && rb.tview) {
                 RMHIP_TRY(c->settle_view(b));
                 RMHIP_TRY(c->get_raw(b, &rb));
             }
             const size_t m = ra.shape[0], k = ra.shape[1], kb = rb.shape[0], n = rb.shape[1];
             if (k != kb) return fail(RMHIP_ERR_SHAPE, "matmul: inner dims must agree (%zux%zu * %zux%zu)", m, k, kb, n);
-            const size_t tiles = ((m + 127) / 128) * ((n + 127) / 128);
-            const bool split_shape = tiles * 4 <= (size_t)c->num_cus && k >= 8192;
-            if (k > 0 && !split_shape) {
+            if (f32_gemm_eligible(c, m, n, k)) {
                 const size_t oshape[2] = {m, n};
                 RMHIP_TRY(c->new_buffer_f32(oshape, 2, out, &ob));
                 int rc = launch_sgemm_trans(c, ra.tview, rb.tview, m, n, k, ra.data_f32(), ra.tview ? k : m, rb.data_f32(),
@@ -749,11 +779,19 @@ int rmhip_syrk(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out) {
     ScopedTimer timer(&c->tel.matmul_count, &c->tel.matmul_ns);
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     Buffer ab, ob;
-    RMHIP_TRY(c->get(a, &ab));
+    bool f32 = c->precision == 32;
+    RMHIP_TRY(get_operand(c, a, &ab, &f32));
     if (ab.shape.size() > 2) return fail(RMHIP_ERR_UNSUPPORTED, "syrk: only 2D supported");
     const std::vector<size_t> as = normalize_matrix_shape(ab.shape);
     const size_t rows = as[0], cols = as[1];
     const size_t oshape[2] = {cols, cols};
+    if (f32 && f32_gemm_eligible(c, cols, cols, rows)) {  // A' * A on the f32 matrix cores
+        RMHIP_TRY(c->new_buffer_f32(oshape, 2, out, &ob));
+        int rc = launch_sgemm_trans(c, true, false, cols, cols, rows, ab.data_f32(), rows, ab.data_f32(), rows, ob.data_f32(), cols);
+        if (rc) rmhip_free(ctx, *out);
+        return rc;
+    }
+    if (f32) RMHIP_TRY(c->get(a, &ab));  // f64 kernel on a widened copy
     RMHIP_TRY(c->new_buffer(oshape, 2, out, &ob));
     int rc = RMHIP_OK;
     if (rows == 0) rc = launch_fill(c, ob.data(), ob.numel, 0.0);

@@ -362,6 +362,13 @@ class HipProvider:
         """lib.rs:2763-2769: mean over several zero-based dims (reduced extents become 1)."""
         return self._reduce_nd("mean", a, dims_zero_based, omitnan)
 
+    def reduce_moments_nd(self, a: GpuTensorHandle, dims_zero_based: Sequence[int]) -> Tuple[GpuTensorHandle, GpuTensorHandle]:
+        """lib.rs:2770-2778 -> `ProviderMoments2 { mean, ex2 }` (lib.rs:1317-1320): E[x] and E[x^2] over the dims."""
+        dims = (C.c_size_t * max(len(dims_zero_based), 1))(*[int(d) for d in dims_zero_based])
+        mean, ex2 = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.rmhip_reduce_moments_nd(self._ctx, self._id(a), dims, len(dims_zero_based), C.byref(mean), C.byref(ex2)))
+        return self._handle(mean.value), self._handle(ex2.value)
+
     def _reduce_nd(self, op: str, a: GpuTensorHandle, dims_zero_based: Sequence[int], omitnan: bool = False) -> GpuTensorHandle:
         dims = (C.c_size_t * max(len(dims_zero_based), 1))(*[int(d) for d in dims_zero_based])
         out = C.c_uint64()

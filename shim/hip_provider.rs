@@ -15,7 +15,7 @@
 use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, GpuTensorHandle, HostTensorOwned, HostTensorView,
-    ProviderLuResult, ProviderPrecision, ReductionFlavor,
+    ProviderLuResult, ProviderMoments2, ProviderPrecision, ReductionFlavor,
 };
 use std::ffi::{c_char, c_double, c_int, c_void, CStr, CString};
 
@@ -44,6 +44,7 @@ extern "C" {
     fn rmhip_scalar(ctx: *mut RmhipCtx, op: c_int, a: u64, s: c_double, out: *mut u64) -> c_int;
     fn rmhip_reduce(ctx: *mut RmhipCtx, op: c_int, a: u64, dim: c_int, nan_mode: c_int, out: *mut u64) -> c_int;
     fn rmhip_reduce_nd(ctx: *mut RmhipCtx, op: c_int, a: u64, dims: *const usize, ndims: usize, nan_mode: c_int, out: *mut u64) -> c_int;
+    fn rmhip_reduce_moments_nd(ctx: *mut RmhipCtx, a: u64, dims: *const usize, ndims: usize, mean: *mut u64, ex2: *mut u64) -> c_int;
     fn rmhip_matmul(ctx: *mut RmhipCtx, a: u64, b: u64, out: *mut u64) -> c_int;
     fn rmhip_lu(ctx: *mut RmhipCtx, a: u64, out5: *mut u64) -> c_int;
     fn rmhip_mldivide(ctx: *mut RmhipCtx, a: u64, b: u64, out: *mut u64) -> c_int;
@@ -210,6 +211,13 @@ impl AccelProvider for HipProvider {
             let mut out = 0u64;
             check(unsafe { rmhip_reduce_nd(self.ctx, 1 /* RMHIP_RMEAN */, self.own(a)?, dims_zero_based.as_ptr(), dims_zero_based.len(), 0, &mut out) })?;
             self.handle(out)
+        })
+    }
+    fn reduce_moments_nd<'a>(&'a self, a: &'a GpuTensorHandle, dims_zero_based: &'a [usize]) -> AccelProviderFuture<'a, ProviderMoments2> {
+        Box::pin(async move {
+            let (mut mean, mut ex2) = (0u64, 0u64);
+            check(unsafe { rmhip_reduce_moments_nd(self.ctx, self.own(a)?, dims_zero_based.as_ptr(), dims_zero_based.len(), &mut mean, &mut ex2) })?;
+            Ok(ProviderMoments2 { mean: self.handle(mean)?, ex2: self.handle(ex2)? })
         })
     }
     fn matmul<'a>(&'a self, a: &'a GpuTensorHandle, b: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> {

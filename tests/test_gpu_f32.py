@@ -342,6 +342,9 @@ def test_f32_matmul_on_the_f32_matrix_cores(prov32, oracle, m, k, n, monkeypatch
     for x, y in ((hat, hb), (ha, hbt), (hat, hbt)):
         g2 = prov32.download_matrix(prov32.matmul(x, y))
         assert np.all(np.abs(g2 - want) <= bound)
+    g3 = prov32.syrk(ha)  # A' * A on the same kernel (transposed-A variant)
+    assert g3.shape == (k, k) and prov32.buffer_bits(g3) == 32
+    assert np.all(np.abs(prov32.download_matrix(g3) - oracle.matmul(A.T, A)) <= (m + 2) * ULP32 * (np.abs(A).T @ np.abs(A)) + 1e-30)
     monkeypatch.setenv("RMHIP_F32_MATMUL", "f64")
     exact = prov32.download_matrix(prov32.matmul(ha, hb))
     assert same_bits(exact, f32r(want)) or np.max(np.abs(exact - f32r(want))) <= ULP32 * np.max(np.abs(want))

@@ -1111,3 +1111,28 @@ def test_comparisons_and_logicals_bit_exact(prov, oracle):
     assert np.array_equal(nan_row, np.zeros(8))           # NaN == anything is false ...
     assert prov.download_matrix(prov.elem_ne(prov.upload(a), prov.upload(b)))[4].all()   # ... and != is true
     assert prov.download_matrix(prov.logical_and(prov.upload(np.array([[np.nan]])), prov.upload(np.array([[1.0]]))))[0, 0] == 1.0
+
+
+@pytest.mark.parametrize("shape,dims", [((6, 5, 4), [0, 2]), ((300, 40), [0]), ((300, 40), [0, 1]), ((17, 1, 9), [2]), ((64, 64, 3), [0, 1])])
+def test_reduce_moments_nd_vs_oracle(prov, oracle, shape, dims):
+    """`reduce_moments_nd` (lib.rs:2770-2778): E[x] and E[x^2] == the CPU's mean(x, dims) and mean(x.^2, dims)."""
+    from runmat_amd import ProviderError
+
+    rng = np.random.default_rng(len(shape) * 100 + sum(dims))
+    X = rng.standard_normal(shape)
+    mean, ex2 = prov.reduce_moments_nd(prov.upload(X), dims)
+    want_shape = tuple(1 if d in dims else s for d, s in enumerate(shape))
+    assert mean.shape == want_shape and ex2.shape == want_shape
+    wm, w2 = X, oracle.binary("mul", X, X)
+    for d in sorted(dims):  # mean of means in ascending dim order (mean.rs:1107-1116)
+        wm, w2 = oracle.reduce_sum(wm, [d], mean=True), oracle.reduce_sum(w2, [d], mean=True)
+    assert np.allclose(prov.download_matrix(mean), wm, rtol=1e-13, atol=1e-15)
+    assert np.allclose(prov.download_matrix(ex2), w2, rtol=1e-13, atol=1e-15)
+    var = prov.download_matrix(ex2) - prov.download_matrix(mean) ** 2
+    assert np.all(var > -1e-12)
+    Xn = X.copy()
+    Xn.reshape(-1)[0] = np.nan
+    mn, e2 = prov.reduce_moments_nd(prov.upload(Xn), dims)
+    assert np.isnan(prov.download(mn)[0]) and np.isnan(prov.download(e2)[0])
+    with pytest.raises(ProviderError):
+        prov.reduce_moments_nd(prov.upload(np.zeros((0, 3))), [0])
