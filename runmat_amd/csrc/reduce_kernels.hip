@@ -103,7 +103,7 @@ template <int OP, class T>
 static int run_reduce(Context* c, int mean, int nan_mode, const T* x, size_t pre, size_t red, size_t post,
                       double* out) {
     if (pre == 0 || post == 0) return RMHIP_OK;  // no output slices
-    const ReducePlan p = plan_reduction(pre, red, post, c->num_cus);
+    const ReducePlan p = plan_reduction(pre, red, post, c->num_cus, (unsigned)sizeof(T));
     if (!p.valid) return fail(RMHIP_ERR_UNSUPPORTED, "reduce: geometry [%zu,%zu,%zu] exceeds launch limits", pre, red, post);
     const size_t nparts = (size_t)(p.nslices * p.nsplit);
     RMHIP_TRY(c->ensure_scratch(2 * nparts * sizeof(double)));
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(RM_RBLOCK) k_dot_strided(const T* a, const T* 
 template <class T>
 static int reduce_dot_any(Context* c, const T* a, const T* b, size_t pre, size_t red, size_t post, double* out) {
     if (pre == 0 || post == 0) return RMHIP_OK;  // no output slices
-    const ReducePlan p = plan_reduction(pre, red, post, c->num_cus);
+    const ReducePlan p = plan_reduction(pre, red, post, c->num_cus, (unsigned)sizeof(T));
     if (!p.valid) return fail(RMHIP_ERR_UNSUPPORTED, "dot: geometry [%zu,%zu,%zu] exceeds launch limits", pre, red, post);
     const size_t nparts = (size_t)(p.nslices * p.nsplit);
     RMHIP_TRY(c->ensure_scratch(2 * nparts * sizeof(double)));

@@ -24,7 +24,8 @@ struct ReducePlan {
 inline uint64_t ceil_div_u64(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
 // Requires pre >= 1 and post >= 1 (callers return early when there are no output slices).
-inline ReducePlan plan_reduction(uint64_t pre, uint64_t red, uint64_t post, int num_cus) {
+// `elem_bytes`: storage width of the reduced tensor (8, or 4 on a precision-32 provider).
+inline ReducePlan plan_reduction(uint64_t pre, uint64_t red, uint64_t post, int num_cus, unsigned elem_bytes = 8) {
     ReducePlan p{};
     if (pre == 0 || post == 0) {
         p.valid = false;
@@ -34,7 +35,9 @@ inline ReducePlan plan_reduction(uint64_t pre, uint64_t red, uint64_t post, int 
     p.nslices = pre * post;
     if (pre == 1) {
         p.contiguous = true;
-        const uint64_t bs = red >= 8192 ? 1024 : 256;  // long slices stream with RM_ABLOCK threads, short ones keep RM_RBLOCK
+        // slices of 64 KiB and more stream with RM_ABLOCK threads, shorter ones keep RM_RBLOCK (more resident blocks hide
+        // the fixed per-block reduction latency)
+        const uint64_t bs = red * elem_bytes >= 65536 ? 1024 : 256;
         uint64_t max_split = ceil_div_u64(red, bs * 8);  // >= 8 elements per thread per block
         if (max_split < 1) max_split = 1;
         uint64_t want = ceil_div_u64(target_blocks, post ? post : 1);

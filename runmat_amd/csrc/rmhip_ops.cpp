@@ -367,7 +367,7 @@ int rmhip_fused_reduction(rmhip_ctx* ctx, const char* shader, const rmhip_buf* i
     // axis 0: slice s is contiguous (pre=1, red, post=slices); axis 1: element (s, r) at s + r*slices.
     const size_t pre = prog.axis == 0 ? 1 : num_slices;
     const size_t post = prog.axis == 0 ? num_slices : 1;
-    const ReducePlan plan = plan_reduction(pre, reduce_len, post, c->num_cus);
+    const ReducePlan plan = plan_reduction(pre, reduce_len, post, c->num_cus, f32 ? 4u : 8u);
     if (!plan.valid) return fail(RMHIP_ERR_UNSUPPORTED, "fused_reduction: geometry exceeds launch limits");
     const size_t nparts = (size_t)(plan.nslices * plan.nsplit);
     RMHIP_TRY(c->ensure_scratch(2 * nparts * sizeof(double)));

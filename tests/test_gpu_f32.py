@@ -220,7 +220,7 @@ def test_f32_fused_scalars_broadcast_and_multi_output(prov32, prov, oracle):
             r32 = execute_reduction(prov32, q, v, [prov32.upload(X), prov32.upload(W)], rl, ns, axis=axis)
             r64 = execute_reduction(prov, q, v, [prov.upload(X), prov.upload(W)], rl, ns, axis=axis)
             assert prov32.buffer_bits(r32) == 32 and r32.shape == (ns,)
-            assert same_bits(prov32.download(r32), f32r(prov.download(r64))), (rows, cols, axis)
+            assert close32(prov32.download(r32), f32r(prov.download(r64)), ulps=1.0), (rows, cols, axis)
             want = (np.sin(X) * W + 2.0).sum(axis=axis)
             assert np.allclose(prov32.download(r32), want, rtol=4 * ULP32, atol=1e-5)
     r32 = execute_reduction(prov32, q, v, [prov32.upload(f32r(np.ones((50, 4)))), 3.0], 50, 4, axis=0)  # scalar operand
@@ -249,14 +249,17 @@ def test_f32_reductions_and_dot(prov32, prov, oracle, shape):
         X.reshape(-1)[::5] = np.round(X.reshape(-1)[::5] * 4)
     h32, h64 = prov32.upload(X), prov.upload(X)
     for op in ("sum", "mean", "min", "max", "prod"):
+        # min / max are exact; sums may group differently (the block size follows the slice's BYTES, so an f32 slice of
+        # 8192..16383 elements runs 256-thread blocks where the f64 one runs 1024): equal up to one f32 rounding flip
+        same = same_values if op in ("min", "max") else (lambda g, r: close32(g, r, ulps=1.0, atol=1e-30))
         got = getattr(prov32, "reduce_" + op)(h32)
         ref = getattr(prov, "reduce_" + op)(h64)
         assert got.shape == (1, 1) and prov32.buffer_bits(got) == 32
-        assert same_values(prov32.download(got), f32r(prov.download(ref))), op
+        assert same(prov32.download(got), f32r(prov.download(ref))), op
         for d in range(len(shape)):
             got = getattr(prov32, f"reduce_{op}_dim")(h32, d)
             ref = getattr(prov, f"reduce_{op}_dim")(h64, d)
-            assert got.shape == ref.shape and same_values(prov32.download(got), f32r(prov.download(ref))), (op, d)
+            assert got.shape == ref.shape and same(prov32.download(got), f32r(prov.download(ref))), (op, d)
     # CPU semantics for `sum`/`mean` of a single array: f64 accumulation of the f32 values, result rounded
     assert np.allclose(prov32.download(prov32.reduce_sum(h32))[0], f32r(oracle.reduce_sum(X.reshape(X.shape[0], -1), "all")[0, 0]),
                        rtol=2 * ULP32, atol=1e-6)
@@ -264,7 +267,7 @@ def test_f32_reductions_and_dot(prov32, prov, oracle, shape):
     dims = [None] + list(range(min(2, len(shape))))
     for d in dims:
         got, ref = prov32.dot(h32, g32, d), prov.dot(h64, g64, d)
-        assert got.shape == ref.shape and same_values(prov32.download(got), f32r(prov.download(ref))), d
+        assert got.shape == ref.shape and close32(prov32.download(got), f32r(prov.download(ref)), ulps=1.0, atol=1e-12), d
     Xn = X.copy()
     Xn.reshape(-1)[0] = np.nan
     hn = prov32.upload(Xn)
