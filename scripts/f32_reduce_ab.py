@@ -19,6 +19,8 @@ for shape in ((8192, 8192), (12288, 4096), (4096, 8192)):
     out["sum0_" + k] = timed(lambda: f(p.reduce_sum_dim(a, 0)))
     out["dot0_" + k] = timed(lambda: f(p.dot(a, b, 0)))
     out["sum1_" + k] = timed(lambda: f(p.reduce_sum_dim(a, 1)))
+    out["sumall_" + k] = timed(lambda: f(p.reduce_sum(a)))
+    out["dotall_" + k] = timed(lambda: f(p.dot(p.reshape(a, (shape[0] * shape[1], 1)), p.reshape(b, (shape[0] * shape[1], 1)))))
     p.free(a); p.free(b)
 print(json.dumps(out))
 ''' % ROOT
