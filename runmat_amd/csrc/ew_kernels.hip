@@ -30,7 +30,11 @@ struct VecOf<float> {
 };
 
 static constexpr int kBlock = 256;    // broadcast kernel: a block spans kBlock elements of dim 0
-static constexpr int kBcastE = 4;     // elements per thread in the broadcast kernel (their loads overlap)
+static constexpr int kBcastE = 4;     // elements per thread in the broadcast kernel (their loads overlap); 8 for f32 storage
+template <class T>
+struct BcastE {
+    static constexpr int value = sizeof(T) == 4 ? 2 * kBcastE : kBcastE;
+};
 static constexpr int kStream = 1024;  // streaming kernels: 1024-thread blocks measured 8-20 % faster than 256 (interleaved
                                       // A/B on the generated kernels, scripts/tune_ew_ab.py; same skeleton here)
 static constexpr int kUnroll = 1;  // one 16-byte vector per stream per thread (interleaved A/B: unrolling never helped)
@@ -321,19 +325,20 @@ __global__ void __launch_bounds__(kBlock) k_bcast2(const T* __restrict__ a, cons
     }
     if (rem != 0) return;
     const unsigned long long obase = outer * p.d0;
-    const unsigned long long i0 = chunk * (unsigned long long)(kBlock * kBcastE) + threadIdx.x;
-    // the loads of the kBcastE elements are issued together, then ONE rolled loop applies the op (a single copy of
+    constexpr int E = BcastE<T>::value;
+    const unsigned long long i0 = chunk * (unsigned long long)(kBlock * E) + threadIdx.x;
+    // the loads of the E elements are issued together, then ONE rolled loop applies the op (a single copy of
     // the body: pow / atan2 / hypot are large)
-    double x[kBcastE], y[kBcastE];
+    double x[E], y[E];
 #pragma unroll
-    for (int e = 0; e < kBcastE; ++e) {
+    for (int e = 0; e < E; ++e) {
         const unsigned long long i = i0 + (unsigned long long)e * kBlock;
         const bool ok = i < p.d0;
         x[e] = ok ? (double)a[offa + i * p.sa[0]] : 0.0;
         y[e] = ok ? (double)b[offb + i * p.sb[0]] : 1.0;
     }
 #pragma unroll
-    for (int e = 0; e < kBcastE; ++e) {
+    for (int e = 0; e < E; ++e) {
         const unsigned long long i = i0 + (unsigned long long)e * kBlock;
         if (i < p.d0) out[obase + i] = (T)f(x[e], y[e]);
     }
@@ -346,7 +351,7 @@ static int binary_bcast_dispatch(Context* c, int op, const T* a, const T* b, T* 
         BcastParams p;
         p.rank = d.rank;
         p.d0 = d.out_shape[0];
-        p.nchunks = (p.d0 + (unsigned long long)kBlock * kBcastE - 1) / ((unsigned long long)kBlock * kBcastE);
+        p.nchunks = (p.d0 + (unsigned long long)kBlock * BcastE<T>::value - 1) / ((unsigned long long)kBlock * BcastE<T>::value);
         unsigned long long outer = 1;
         for (int i = 0; i < 8; ++i) {
             p.shape[i] = i < d.rank ? d.out_shape[i] : 1;
