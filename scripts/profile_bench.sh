@@ -47,7 +47,17 @@ for k, d in agg.items():
     if "SQ_INSTS_VALU_MFMA_MOPS_F64_mean" in rec:
         rec["mfma_flops_per_launch"] = rec["SQ_INSTS_VALU_MFMA_MOPS_F64_mean"] * 512
     if "SQ_VALU_MFMA_BUSY_CYCLES_mean" in rec and "GRBM_GUI_ACTIVE_mean" in rec:
-        rec["mfma_util_pct(busy/(gui_active*1024 SIMDs))"] = 100.0 * rec["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / (rec["GRBM_GUI_ACTIVE_mean"] * 1024)
+        # GRBM_GUI_ACTIVE comes back either per XCD or summed over the 8 XCDs depending on the rocprofv3 build: decide
+        # from the kernel time the same run's bench line reports (cycles ~ 2.4 GHz * t)
+        gui = rec["GRBM_GUI_ACTIVE_mean"]
+        try:
+            t_ms = json.load(open(f"{out}/mfma_dgemm_bench.json"))["roofline"]["kernel_ms"]
+            if gui > 4.0 * 2.4e6 * t_ms:
+                gui /= 8.0
+        except Exception:
+            pass
+        rec["GRBM_GUI_ACTIVE_per_xcd"] = gui
+        rec["mfma_util_pct(busy/(gui_active_per_xcd*1024 SIMDs))"] = 100.0 * rec["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / (gui * 1024)
     summary.append(rec)
     print("MFMA", {k2: v2 for k2, v2 in rec.items() if k2 != "kernel"})
 json.dump(summary, open(f"{out}/pmc_summary.json", "w"), indent=1)
