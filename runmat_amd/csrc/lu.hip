@@ -1064,15 +1064,15 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     // Panel width of the look-ahead driver and its threshold, from an interleaved sweep (scripts/lu_knobs.py, ms for
     // x = A\b): n = 6144: 38.7 without look-ahead, 33.6 with nb 128, 34.9 with 256, 36.8 with 512; 8192: 51.2 (nb 512)
     // / 48.4 (256) / 47.2 (128); 10240: 67.3 / 63.4 / 62.2; 12288: 84.7 / 80.6 / 81.2; 16384: 130.8 / 130.7 / -;
-    // 4096: 22.2 without, 22.6-24 with.
+    // 5120: 31.6 without, 27.9 with; 4096: 22.2 without, 22.6-24 with.
     size_t nb = kmin < 12288 ? 128 : 256;
     if (const char* v = std::getenv("RMHIP_LU_NB")) nb = (size_t)std::atoll(v);
     nb = nb < 64 ? 64 : (nb / 64) * 64;
-    // Look-ahead (second stream): default from kmin = 6144; RMHIP_LU_LOOKAHEAD=1 forces it for every kmin > nb, =0
+    // Look-ahead (second stream): default from kmin = 5120; RMHIP_LU_LOOKAHEAD=1 forces it for every kmin > nb, =0
     // disables it.  It needs the persistent panels: with one launch per column the panel kernels wait behind the
     // update's dgemm blocks.
     const char* la = std::getenv("RMHIP_LU_LOOKAHEAD");
-    bool blocked = kmin >= 6144 && kmin > nb;
+    bool blocked = kmin >= 5120 && kmin > nb;
     if (la) blocked = kmin > nb && la[0] == '1';
     if (!s.persistent) blocked = false;
     // Under look-ahead the panels keep 256-row blocks (132 KiB of LDS: a whole CU).  The update stream's dgemm runs one

@@ -19,7 +19,10 @@ for n in [int(x) for x in __import__('os').environ.get('LU_SIZES', '16384,8192')
     prov.free(a); prov.free(b)
 print(json.dumps(out))
 ''' % ROOT
-if os.environ.get("LU_SWEEP") == "verify":
+if os.environ.get("LU_SWEEP") == "rows":
+    configs = [{}, dict(RMHIP_LU_PANEL_ROWS="128"), dict(RMHIP_LU_LOOKAHEAD="1"), dict(RMHIP_LU_LOOKAHEAD="1", RMHIP_LU_NB="64"),
+               dict(RMHIP_LU_LOOKAHEAD="1", RMHIP_LU_PANEL_ROWS="128")]
+elif os.environ.get("LU_SWEEP") == "verify":
     configs = [{}, dict(RMHIP_LU_NB="128"), dict(RMHIP_LU_NB="256"), dict(RMHIP_LU_NB="192")]
 elif os.environ.get("LU_SWEEP") == "small":
     configs = [{}, dict(RMHIP_LU_NB="256"), dict(RMHIP_LU_NB="256", RMHIP_LU_LOOKAHEAD="1"), dict(RMHIP_LU_NB="128", RMHIP_LU_LOOKAHEAD="1"),
