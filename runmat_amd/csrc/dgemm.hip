@@ -40,7 +40,12 @@ static constexpr int SA = BM + 16;  // A tile row stride in doubles ([k][m])
 static constexpr int SB = BK + 2;   // B tile row stride in doubles ([n][k])
 static constexpr int A_TILE = BK * SA;  // doubles
 static constexpr int B_TILE = BN * SB;
-static constexpr int GROUP_M = 8;
+// tile rows per group of the XCD-aware order; interleaved A/B at 8192^3 (scripts/dgemm_ab.py): 4 -> 68.7, 8 -> 68.6,
+// 16 -> 69.0, 32 -> 69.0 TFLOP/s
+#ifndef GEMM_GROUP_M
+#define GEMM_GROUP_M 16
+#endif
+static constexpr int GROUP_M = GEMM_GROUP_M;
 // after which of the four k-steps of a tile the next tile's registers go to LDS (3 = after the last MFMA;
 // measured at 8192^3: 3 -> 68.6, 2 -> 66.4, 1 -> 67.1 TFLOP/s; s_setprio around the MFMA section: no effect)
 #ifndef GEMM_STASH_KK

@@ -26,7 +26,10 @@ static constexpr int BM = 128, BN = 128, BK = 16;
 static constexpr int SA = BM + 16;  // pattern M row stride (floats)
 static constexpr int SB = BK + 4;   // pattern K row stride (floats)
 static constexpr int TILE = (BK * SA > BN * SB) ? BK * SA : BN * SB;  // floats; either pattern fits either buffer
-static constexpr int GROUP_M = 8;
+#ifndef SGEMM_GROUP_M
+#define SGEMM_GROUP_M 8
+#endif
+static constexpr int GROUP_M = SGEMM_GROUP_M;
 }  // namespace sg
 
 struct SgemmArgs {
