@@ -6,6 +6,7 @@
 // Exit code 0 = all KATs pass; 2 = no gfx950 device (the provider has no CPU fallback); 1 = mismatch.
 #include <cmath>
 #include <cstdio>
+#include <string>
 
 #include "rmhip_provider.hpp"
 
@@ -55,6 +56,22 @@ int main() {
                         {std::exp(0.2), 2 * std::exp(0.2), 3 * std::exp(0.2)}, 1e-9);
         // comparisons: 1.0 / 0.0 tensors
         ok = ok && eq(p.download(p.elem_lt(a, b)).data, {1, 1, 1, 1}) && eq(p.download(p.elem_eq(a, a)).data, {1, 1, 1, 1});
+        // reduce_moments_nd (lib.rs:2770-2778): E[x] and E[x^2] of [1 3; 2 4] over the rows
+        auto mom = p.reduce_moments_nd(a, {0});
+        ok = ok && near(p.download(mom.first).data, {1.5, 3.5}, 1e-15) && near(p.download(mom.second).data, {2.5, 12.5}, 1e-15);
+        {
+            // ProviderPrecision::F32 (lib.rs:815-818): host views stay f64, storage is f32, results round once
+            rmhip::HipProvider q(0, 32);
+            ok = ok && std::string(q.precision()) == "F32";
+            auto x = q.upload({0.1, 0.2, 0.3, 16777217.0}, {2, 2});
+            ok = ok && eq(q.download(x).data, {(double)0.1f, (double)0.2f, (double)0.3f, 16777216.0});
+            auto y = q.elem_add(x, x);  // f64 arithmetic on the f32 values, one rounding
+            ok = ok && eq(q.download(y).data, {(double)(float)(2.0 * (double)0.1f), (double)(float)(2.0 * (double)0.2f),
+                                               (double)(float)(2.0 * (double)0.3f), 33554432.0});
+            auto ai = q.upload({1, 2, 3, 4}, {2, 2});
+            auto bi = q.upload({5, 7, 6, 8}, {2, 2});
+            ok = ok && eq(q.download(q.matmul(ai, bi)).data, {26, 38, 30, 44});  // f32 matrix cores: integers stay exact
+        }
         std::printf(ok ? "provider KATs ok\n" : "provider KATs FAILED\n");
         return ok ? 0 : 1;
     } catch (const rmhip::ProviderError& e) {
