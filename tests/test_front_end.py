@@ -236,3 +236,47 @@ def test_f32_shaders_lower_to_f32_storage_with_f64_arithmetic(built):
         rsrc = wgsl_translate(rs, "reduction")
         assert "const float* __restrict__ in0" in rsrc and "const double v0 = (double)in0[idx * m0];" in rsrc
         wgsl_compile_check(rs, "reduction")
+
+
+def test_front_end_survives_mangled_shaders(built):
+    """`Err`, never a crash: truncations, deletions, duplications and byte flips of valid requests (elementwise and
+    reduction, f64 and f32) either translate or come back as a COMPILE error (the caller then takes its CPU path)."""
+    import random
+
+    from runmat_amd import ProviderError, wgsl_translate
+    from runmat_amd.fusion import FusionGroupPlan, elementwise_math_plan, sin_mul_add_plan
+
+    plan, out = sin_mul_add_plan()
+    plan2, out2 = elementwise_math_plan()
+    q = FusionGroupPlan()
+    x, w = q.input(), q.input()
+    v = q.primitive("Add", q.primitive("ElemMul", q.builtin("sin", x), w), q.constant(2.0))
+    seeds = [(plan.generate_wgsl_for_output(out, "f64"), "elementwise"), (plan2.generate_wgsl_for_output(out2, "f32"), "elementwise"),
+             (q.generate_reduction_wgsl(v, "f64", axis=0), "reduction"), (q.generate_reduction_wgsl(v, "f32", axis=1, omitnan=True), "reduction")]
+    rng = random.Random(20260927)
+    outcomes = {"ok": 0, "err": 0}
+    for text, kind in seeds:
+        body_at = text.index("let ")  # mutate around the statements the front-end actually reads
+        for _ in range(120):
+            s = text
+            op = rng.randrange(5)
+            pos = rng.randrange(body_at, len(s))
+            if op == 0:
+                s = s[:pos]
+            elif op == 1:
+                s = s[:pos] + s[pos + rng.randrange(1, 40):]
+            elif op == 2:
+                s = s[:pos] + s[pos:pos + rng.randrange(1, 60)] * 2 + s[pos:]
+            elif op == 3:
+                s = s[:pos] + rng.choice("()[];,.:=+-*/<>&|!0123456789abcxyz \n") + s[pos + 1:]
+            else:
+                a, b = sorted((pos, rng.randrange(body_at, len(s))))
+                s = s[:a] + s[b:] + s[a:b]
+            try:
+                src = wgsl_translate(s, kind)
+                assert "rm_" in src
+                outcomes["ok"] += 1
+            except ProviderError as e:
+                assert e.code == 6, (e.code, str(e))  # RMHIP_ERR_COMPILE
+                outcomes["err"] += 1
+    assert outcomes["err"] > 100 and outcomes["ok"] > 0, outcomes
