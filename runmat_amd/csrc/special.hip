@@ -19,47 +19,93 @@ static constexpr int IN_MAX_BATCH = 256;
 static constexpr int IN_BLOCK = 1024;  // streaming passes: the largest multiple of `batch` <= 1024 threads per block
 
 // partial[block][b] = sum over this block's share of plane elements of x (SQDEV: (x - mean[b])^2)
-// T = storage type (float on a precision-32 provider); sums and statistics are f64 either way
-template <bool SQDEV, class T>
+// T = storage type (float on a precision-32 provider); sums and statistics are f64 either way.
+// VEC = elements per access (a 16-byte vector when the batch extent allows it: VEC divides `batch`, so a thread's VEC
+// consecutive elements are VEC consecutive batch indices and every stride keeps them fixed).
+template <class T, int VEC>
+struct VecT {
+    typedef T type __attribute__((ext_vector_type(VEC)));
+};
+template <class T>
+struct VecT<T, 1> {
+    typedef T type;
+};
+template <class T, int VEC>
+__device__ __forceinline__ void load_vec(const T* __restrict__ x, size_t vi, double (&out)[VEC]) {
+    if constexpr (VEC == 1) {
+        out[0] = (double)x[vi];
+    } else {
+        const typename VecT<T, VEC>::type v = *((const typename VecT<T, VEC>::type*)x + vi);
+#pragma unroll
+        for (int l = 0; l < VEC; ++l) out[l] = (double)v[l];
+    }
+}
+
+template <bool SQDEV, class T, int VEC>
 __global__ void __launch_bounds__(IN_BLOCK) k_plane_partial(const T* __restrict__ x, size_t total, int batch,
                                                        const double* __restrict__ mean, double* __restrict__ partial) {
-    __shared__ double s[IN_BLOCK];
+    __shared__ double s[IN_BLOCK * VEC];
     const int t = threadIdx.x;
-    const int b = t % batch;  // blockDim.x is a multiple of batch, so is every thread's stride
+    const int b = (VEC * t) % batch;  // VEC * blockDim.x is a multiple of batch, so is every thread's stride
+    const size_t nvec = total / VEC;  // batch % VEC == 0, hence total % VEC == 0
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const double mu = SQDEV ? mean[b] : 0.0;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    double mu[VEC], acc[2][VEC];
+#pragma unroll
+    for (int l = 0; l < VEC; ++l) {
+        mu[l] = SQDEV ? mean[b + l] : 0.0;
+        acc[0][l] = acc[1][l] = 0.0;
+    }
     size_t i = (size_t)blockIdx.x * blockDim.x + t;
-    for (; i + 3 * stride < total; i += 4 * stride) {
-        const double v0 = (double)x[i], v1 = (double)x[i + stride], v2 = (double)x[i + 2 * stride], v3 = (double)x[i + 3 * stride];
-        if (SQDEV) {
-            const double d0 = v0 - mu, d1 = v1 - mu, d2 = v2 - mu, d3 = v3 - mu;
-            a0 += d0 * d0;
-            a1 += d1 * d1;
-            a2 += d2 * d2;
-            a3 += d3 * d3;
-        } else {
-            a0 += v0;
-            a1 += v1;
-            a2 += v2;
-            a3 += v3;
+    constexpr int UNROLL = VEC == 1 ? 4 : 2;  // independent vectors in flight
+    for (; i + (UNROLL - 1) * stride < nvec; i += UNROLL * stride) {
+        double v[UNROLL][VEC];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) load_vec<T, VEC>(x, i + u * stride, v[u]);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int l = 0; l < VEC; ++l) {
+                if (SQDEV) {
+                    const double d = v[u][l] - mu[l];
+                    acc[u & 1][l] += d * d;
+                } else {
+                    acc[u & 1][l] += v[u][l];
+                }
+            }
+    }
+    for (; i < nvec; i += stride) {
+        double v[VEC];
+        load_vec<T, VEC>(x, i, v);
+#pragma unroll
+        for (int l = 0; l < VEC; ++l) {
+            if (SQDEV) {
+                const double d = v[l] - mu[l];
+                acc[0][l] += d * d;
+            } else {
+                acc[0][l] += v[l];
+            }
         }
     }
-    for (; i < total; i += stride) {
-        const double v = (double)x[i];
-        if (SQDEV) {
-            const double d = v - mu;
-            a0 += d * d;
-        } else {
-            a0 += v;
-        }
+#pragma unroll
+    for (int l = 0; l < VEC; ++l) s[VEC * t + l] = acc[0][l] + acc[1][l];
+    __syncthreads();
+    // fold the VEC * blockDim.x entries (entry e belongs to batch element e % batch) in two levels: up to 32 groups of
+    // `batch` threads fold a strided share each, then `batch` threads fold the group sums -- a single level is a serial
+    // chain of up to 1024 LDS adds for a small batch extent
+    __shared__ double s2[IN_BLOCK];
+    const int ngroups = VEC * (int)blockDim.x / batch, m = (int)blockDim.x / batch;
+    const int g1 = ngroups < 32 ? (ngroups < m ? ngroups : m) : (m < 32 ? m : 32);
+    if (t < batch * g1) {
+        const int bb = t % batch, g = t / batch;
+        double a = 0.0;
+        for (int j = g; j < ngroups; j += g1) a += s[j * batch + bb];
+        s2[t] = a;
     }
-    s[t] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (t < batch) {
-        double acc = 0.0;
-        for (int j = t; j < (int)blockDim.x; j += batch) acc += s[j];
-        partial[(size_t)blockIdx.x * batch + t] = acc;
+        double a = 0.0;
+        for (int g = 0; g < g1; ++g) a += s2[g * batch + t];
+        partial[(size_t)blockIdx.x * batch + t] = a;
     }
 }
 
@@ -101,32 +147,48 @@ __global__ void __launch_bounds__(IN_BLOCK) k_plane_final(const double* __restri
     }
 }
 
-template <class T>
+template <class T, int VEC>
 __global__ void __launch_bounds__(IN_BLOCK) k_imgnorm_apply(const T* __restrict__ x, T* __restrict__ y, size_t total,
                                                        int batch, const double* __restrict__ stats, int has_gain, double gain,
                                                        int has_bias, double bias, int clamp_zero, int has_gamma, double gamma) {
-    const int b = threadIdx.x % batch;
-    const double mu = stats[b], inv = stats[batch + b];
+    const int b = (VEC * (int)threadIdx.x) % batch;
+    double mu[VEC], inv[VEC];
+#pragma unroll
+    for (int l = 0; l < VEC; ++l) {
+        mu[l] = stats[b + l];
+        inv[l] = stats[batch + b + l];
+    }
+    const size_t nvec = total / VEC;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        double v = ((double)x[i] - mu) * inv;
-        if (has_gain) v *= gain;
-        if (has_bias) v += bias;
-        if (clamp_zero) v = fmax(v, 0.0);  // f64::max: a NaN operand loses
-        if (has_gamma) v = pow(v, gamma);
-        y[i] = (T)v;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        double v[VEC];
+        load_vec<T, VEC>(x, i, v);
+#pragma unroll
+        for (int l = 0; l < VEC; ++l) {
+            double w = (v[l] - mu[l]) * inv[l];
+            if (has_gain) w *= gain;
+            if (has_bias) w += bias;
+            if (clamp_zero) w = fmax(w, 0.0);  // f64::max: a NaN operand loses
+            if (has_gamma) w = pow(w, gamma);
+            v[l] = w;
+        }
+        if constexpr (VEC == 1) {
+            y[i] = (T)v[0];
+        } else {
+            typename VecT<T, VEC>::type r;
+#pragma unroll
+            for (int l = 0; l < VEC; ++l) r[l] = (T)v[l];
+            *((typename VecT<T, VEC>::type*)y + i) = r;
+        }
     }
 }
 
-template <class T>
-static int image_normalize_any(Context* c, const T* x, T* y, size_t batch, size_t height, size_t width, double epsilon,
+template <class T, int VEC>
+static int image_normalize_vec(Context* c, const T* x, T* y, size_t batch, size_t height, size_t width, double epsilon,
                                int has_gain, double gain, int has_bias, double bias, int clamp_zero, int has_gamma, double gamma) {
     const size_t plane = height * width, total = batch * plane;
-    if (total == 0) return RMHIP_OK;
-    if (batch > (size_t)IN_MAX_BATCH)
-        return fail(RMHIP_ERR_UNSUPPORTED, "image_normalize: batch %zu > %d not supported by provider", batch, IN_MAX_BATCH);
     const unsigned threads = (unsigned)((IN_BLOCK / batch) * batch);  // a multiple of batch
-    size_t want = (total + (size_t)threads * 8 - 1) / ((size_t)threads * 8);
+    size_t want = (total / VEC + (size_t)threads * 2 - 1) / ((size_t)threads * 2);  // >= 2 vectors per thread, grid-stride above the cap
     const size_t cap = (size_t)c->num_cus * 8;
     if (want < 1) want = 1;
     const unsigned grid = (unsigned)(want < cap ? want : cap);
@@ -135,17 +197,34 @@ static int image_normalize_any(Context* c, const T* x, T* y, size_t batch, size_
     double* stats = c->scratch + (size_t)grid * batch;
     // few partials: a 256-thread final block (its serial LDS fold is shorter); thousands: all 1024 threads share the loads
     const unsigned fthreads = (size_t)grid * batch >= 8192 ? IN_BLOCK : IN_MAX_BATCH;
-    hipLaunchKernelGGL((k_plane_partial<false, T>), dim3(grid), dim3(threads), 0, c->stream, x, total, (int)batch, stats, partial);
+    hipLaunchKernelGGL((k_plane_partial<false, T, VEC>), dim3(grid), dim3(threads), 0, c->stream, x, total, (int)batch, stats, partial);
     hipLaunchKernelGGL(k_plane_final, dim3(1), dim3(fthreads), 0, c->stream, partial, (int)grid, (int)batch, (double)plane,
                        epsilon, 0, stats);
-    hipLaunchKernelGGL((k_plane_partial<true, T>), dim3(grid), dim3(threads), 0, c->stream, x, total, (int)batch, stats, partial);
+    hipLaunchKernelGGL((k_plane_partial<true, T, VEC>), dim3(grid), dim3(threads), 0, c->stream, x, total, (int)batch, stats, partial);
     hipLaunchKernelGGL(k_plane_final, dim3(1), dim3(fthreads), 0, c->stream, partial, (int)grid, (int)batch, (double)plane,
                        epsilon, 1, stats);
-    hipLaunchKernelGGL(k_imgnorm_apply<T>, dim3(grid), dim3(threads), 0, c->stream, x, y, total, (int)batch, stats, has_gain, gain,
+    hipLaunchKernelGGL((k_imgnorm_apply<T, VEC>), dim3(grid), dim3(threads), 0, c->stream, x, y, total, (int)batch, stats, has_gain, gain,
                        has_bias, bias, clamp_zero, has_gamma, gamma);
     c->tel.kernel_launches += 5;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
+}
+// 16-byte accesses when the batch extent and the alignment allow them (two f64 / four f32 per lane), else narrower
+template <class T>
+static int image_normalize_any(Context* c, const T* x, T* y, size_t batch, size_t height, size_t width, double epsilon,
+                               int has_gain, double gain, int has_bias, double bias, int clamp_zero, int has_gamma, double gamma) {
+    if (batch * height * width == 0) return RMHIP_OK;
+    if (batch > (size_t)IN_MAX_BATCH)
+        return fail(RMHIP_ERR_UNSUPPORTED, "image_normalize: batch %zu > %d not supported by provider", batch, IN_MAX_BATCH);
+    const bool a16 = ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+    constexpr int WIDE = 16 / (int)sizeof(T);
+    if (a16 && batch % WIDE == 0)
+        return image_normalize_vec<T, WIDE>(c, x, y, batch, height, width, epsilon, has_gain, gain, has_bias, bias, clamp_zero, has_gamma, gamma);
+    if constexpr (sizeof(T) == 4) {
+        if (a16 && batch % 2 == 0)
+            return image_normalize_vec<T, 2>(c, x, y, batch, height, width, epsilon, has_gain, gain, has_bias, bias, clamp_zero, has_gamma, gamma);
+    }
+    return image_normalize_vec<T, 1>(c, x, y, batch, height, width, epsilon, has_gain, gain, has_bias, bias, clamp_zero, has_gamma, gamma);
 }
 int image_normalize_device(Context* c, const double* x, double* y, size_t batch, size_t height, size_t width, double epsilon,
                            int has_gain, double gain, int has_bias, double bias, int clamp_zero, int has_gamma, double gamma) {

@@ -318,6 +318,12 @@ def test_f32_matmul_solve_and_friends_use_f64_kernels_on_widened_operands(prov32
     i32 = prov32.image_normalize(prov32.upload(img), 3, 16, 20, 1e-6, gain=1.5, bias=0.1, gamma=1.8, clamp_zero=True)
     i64 = prov.image_normalize(prov.upload(img), 3, 16, 20, 1e-6, gain=1.5, bias=0.1, gamma=1.8, clamp_zero=True)
     assert same_bits(prov32.download(i32), f32r(prov.download(i64)))
+    for bshape in ((4, 33, 20), (16, 64, 48), (2, 40, 30), (8, 7, 5)):  # vector widths differ between f32 (4) and f64 (2)
+        img = f32r(rng.uniform(0, 1, bshape))
+        j32 = prov32.image_normalize(prov32.upload(img), bshape[0], bshape[1], bshape[2], 1e-6, gain=1.5, bias=0.1)
+        j64 = prov.image_normalize(prov.upload(img), bshape[0], bshape[1], bshape[2], 1e-6, gain=1.5, bias=0.1)
+        assert prov32.buffer_bits(j32) == 32 and close32(prov32.download(j32), f32r(prov.download(j64)), ulps=1.0, atol=1e-7), bshape
+        assert np.allclose(prov32.download_matrix(j32), oracle.image_normalize(img, 1e-6, gain=1.5, bias=0.1), rtol=1e-5, atol=1e-5), bshape
     p32 = prov32.matmul_power_step(prov32.upload(A), prov32.upload(B), 1e-12)
     assert np.allclose(prov32.download_matrix(p32), oracle.matmul_power_step(A, B, 1e-12), rtol=1e-5, atol=1e-6)
     d32 = prov32.diag_extract(prov32.upload(f32r(rng.standard_normal((9, 7)))), 1)
