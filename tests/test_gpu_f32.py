@@ -447,3 +447,32 @@ def test_f32_large_fused_and_traffic_halves(prov32, prov):
     t32, t64 = time(prov32, sh32, in32), time(prov, sh64, in64)
     print(f"fused sin(A).*B+C {shape}: f32 storage {t32 * 1e3:.1f} us, f64 storage {t64 * 1e3:.1f} us")
     assert t32 < t64
+
+
+def test_f32_provider_against_the_reference_scripts_float32_outputs(prov32):
+    """The reference's own benchmark comparators run in float32 (tests/golden/*.json, generated by tests/golden/
+    make_golden.py from /root/reference/benchmarks); a precision-32 provider is the like-for-like configuration."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from workloads import golden_elementwise_math, golden_image_cases, lcg_image_field
+    from runmat_amd.fusion import elementwise_math_plan
+    from runmat_amd.fusion_exec import execute_elementwise
+
+    g = golden_image_cases()
+    p = g["params"]
+    for case in g["cases"]:  # 4k-image-processing/python_numpy_lcg.py: MSE of the normalised, gamma-corrected frames
+        imgs = lcg_image_field(case["B"], case["H"], case["W"], p["seed"])
+        h = prov32.upload(imgs.reshape(-1, order="F"), imgs.shape)
+        out = prov32.download(prov32.image_normalize(h, case["B"], case["H"], case["W"], p["eps0"], gain=p["gain"], bias=p["bias"],
+                                                     gamma=p["gamma"], clamp_zero=True))
+        mse = float(np.mean((out - imgs.reshape(-1, order="F")) ** 2))
+        assert abs(mse - case["mse"]) <= 2e-5 * case["mse"], (mse, case["mse"])
+    plan, out_id = elementwise_math_plan()
+    for case in golden_elementwise_math()["cases"]:  # elementwise-math/python_numpy.py: y2 at 17 sample points
+        n = case["points"]
+        x = np.linspace(0.0, 4.0 * np.pi, n, dtype=np.float32).astype(np.float64).reshape(n, 1)
+        (y,) = execute_elementwise(prov32, plan, [out_id], [prov32.upload(x), 10.0, 4.0, 0.25, 2.0, 0.1])
+        got = prov32.download(y)[case["indices"]]
+        assert np.max(np.abs(got - np.array(case["y2"]))) <= 2e-6, np.max(np.abs(got - np.array(case["y2"])))
