@@ -682,12 +682,17 @@ int rmhip_covariance(rmhip_ctx* ctx, rmhip_buf matrix, int biased, rmhip_buf* ou
     int rc = rmhip_reduce(ctx, RMHIP_RMEAN, matrix, 0, 0, &means);       // [1, cols]
     if (!rc) rc = rmhip_binary(ctx, RMHIP_SUB, matrix, means, &centred);  // broadcast over rows
     if (!rc) rc = rmhip_syrk(ctx, centred, &gram);                        // Xc' * Xc
-    if (!rc) rc = rmhip_scalar(ctx, RMHIP_SDIV, gram, denom, out);
     if (!rc) {
-        Buffer ob;
-        rc = c->get(*out, &ob);
-        if (!rc) rc = cov_sanitize_diag_device(c, ob.data(), cols);
-        if (rc) rmhip_free(ctx, *out);
+        // gram / denom and the CPU's diagonal rules on an f64 result; at precision 32 `gb` is a widened copy and the result
+        // is rounded to f32 storage on return (writing through Context::get of an f32 buffer would only touch a temporary)
+        Buffer gb, ob;
+        rc = c->get(gram, &gb);
+        if (!rc) rc = c->new_buffer(oshape, 2, out, &ob);
+        if (!rc) {
+            rc = launch_scalar(c, RMHIP_SDIV, gb.data(), denom, ob.data(), ob.numel);
+            if (!rc) rc = cov_sanitize_diag_device(c, ob.data(), cols);
+            if (rc) rmhip_free(ctx, *out);
+        }
     }
     for (rmhip_buf t : {means, centred, gram})
         if (t) rmhip_free(ctx, t);

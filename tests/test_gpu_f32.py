@@ -314,6 +314,11 @@ def test_f32_matmul_solve_and_friends_use_f64_kernels_on_widened_operands(prov32
     Xc = f32r(rng.standard_normal((200, 12)))
     cov32 = prov32.covariance(prov32.upload(Xc))
     assert prov32.buffer_bits(cov32) == 32 and np.allclose(prov32.download_matrix(cov32), np.cov(Xc, rowvar=False), rtol=1e-5, atol=1e-5)
+    xn = Xc.copy()
+    xn[7, 2] = np.inf  # the poisoned column's pairs are NaN, the others finite (cov.rs:916-953), also through f32 storage
+    covn = prov32.download_matrix(prov32.covariance(prov32.upload(xn)))
+    wantn = oracle.covariance(xn)
+    assert np.array_equal(np.isnan(covn), np.isnan(wantn)) and np.allclose(covn[~np.isnan(wantn)], wantn[~np.isnan(wantn)], rtol=1e-5, atol=1e-5)
     img = f32r(rng.uniform(0, 1, (3, 16, 20)))
     i32 = prov32.image_normalize(prov32.upload(img), 3, 16, 20, 1e-6, gain=1.5, bias=0.1, gamma=1.8, clamp_zero=True)
     i64 = prov.image_normalize(prov.upload(img), 3, 16, 20, 1e-6, gain=1.5, bias=0.1, gamma=1.8, clamp_zero=True)
