@@ -773,7 +773,10 @@ int rmhip_matmul_epilogue(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, const rmhip_
         e.col_scale = cs.data();
         e.flags |= EP_COL | (ep->col_op ? EP_COL_DIV : 0);
     }
+    Buffer dg_raw;  // diag_output is written IN PLACE: f32 storage gets the widened copy narrowed back after the launch
     if (ep->diag_output) {
+        RMHIP_TRY(c->get_raw(ep->diag_output, &dg_raw));
+        if (dg_raw.tview) return fail(RMHIP_ERR_UNSUPPORTED, "matmul_epilogue: diag_output must not be a transpose view");
         RMHIP_TRY(c->get(ep->diag_output, &dg));
         const size_t expected = m < n ? m : n;
         if (dg.numel < expected)  // simple_provider.rs:7790-7799
@@ -787,6 +790,7 @@ int rmhip_matmul_epilogue(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, const rmhip_
     const size_t oshape[2] = {m, n};
     RMHIP_TRY(c->new_buffer(oshape, 2, out, &ob));
     int rc = launch_dgemm_epilogue(c, m, n, k, ab.data(), m, bb.data(), k ? k : 1, ob.data(), m, e);
+    if (!rc && ep->diag_output && dg_raw.dtype == DT_F32) rc = launch_narrow(c, dg.data(), dg_raw.data_f32(), dg_raw.numel);
     if (rc) rmhip_free(ctx, *out);
     return rc;
 }

@@ -331,6 +331,17 @@ def test_f32_matmul_solve_and_friends_use_f64_kernels_on_widened_operands(prov32
         assert np.allclose(prov32.download_matrix(j32), oracle.image_normalize(img, 1e-6, gain=1.5, bias=0.1), rtol=1e-5, atol=1e-5), bshape
     p32 = prov32.matmul_power_step(prov32.upload(A), prov32.upload(B), 1e-12)
     assert np.allclose(prov32.download_matrix(p32), oracle.matmul_power_step(A, B, 1e-12), rtol=1e-5, atol=1e-6)
+    # matmul_epilogue: the in-place diag_output buffer must receive its values although its storage is f32
+    Ae, Be = f32r(rng.standard_normal((40, 30))), f32r(rng.standard_normal((30, 40)))
+    rsc = f32r(rng.uniform(0.5, 2.0, (40, 1)))
+    dg32, dg64 = prov32.zeros((40, 1)), prov.zeros((40, 1))
+    e32 = prov32.matmul_epilogue(prov32.upload(Ae), prov32.upload(Be), alpha=0.5, beta=0.25, row_scale=prov32.upload(rsc), clamp_min=-1.0,
+                                 diag_output=dg32)
+    e64 = prov.matmul_epilogue(prov.upload(Ae), prov.upload(Be), alpha=0.5, beta=0.25, row_scale=prov.upload(rsc), clamp_min=-1.0,
+                               diag_output=dg64)
+    assert same_bits(prov32.download(e32), f32r(prov.download(e64)))
+    assert prov32.buffer_bits(dg32) == 32 and same_bits(prov32.download(dg32), f32r(prov.download(dg64)))
+    assert np.any(prov32.download(dg32) != 0.0)
     d32 = prov32.diag_extract(prov32.upload(f32r(rng.standard_normal((9, 7)))), 1)
     assert prov32.buffer_bits(d32) == 32 and d32.shape[0] == 6
 
