@@ -494,7 +494,7 @@ int rmhip_reduce_nd(rmhip_ctx* ctx, int op, rmhip_buf a, const size_t* dims_zero
     CTX_OR_FAIL(ctx);
     if (!out || (!dims_zero_based && ndims)) return fail(RMHIP_ERR_INVALID, "reduce_nd: null argument");
     Buffer ab;
-    RMHIP_TRY(c->get(a, &ab));
+    RMHIP_TRY(c->get_raw(a, &ab));  // shape only
     const size_t rank = normalize_matrix_shape(ab.shape).size();
     // nd.rs:62-72: dims beyond the rank are ignored, duplicates dropped, ascending order
     std::vector<size_t> dims;
@@ -665,7 +665,7 @@ int rmhip_covariance(rmhip_ctx* ctx, rmhip_buf matrix, int biased, rmhip_buf* ou
     CTX_OR_FAIL(ctx);
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     Buffer mb;
-    RMHIP_TRY(c->get(matrix, &mb));
+    RMHIP_TRY(c->get_raw(matrix, &mb));  // shape only: the steps below fetch the data themselves
     if (mb.shape.size() > 2) return fail(RMHIP_ERR_UNSUPPORTED, "covariance: only 2D supported");
     const std::vector<size_t> ms = normalize_matrix_shape(mb.shape);
     const size_t rows = ms[0], cols = ms[1];
