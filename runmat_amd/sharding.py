@@ -140,6 +140,7 @@ def gather_row_blocks_device(group: Group, prov, c_rows, rows_total: int):
     rows_g, n = c_rows.shape
     if group.world == 1:
         return c_rows, None
+    _require_f64(prov, "gather_row_blocks_device")  # the gathered buffer is adopted with rmhip_wrap_external (f64 memory)
     counts = [partition(rows_total, group.world, r, 128) for r in range(group.world)]
     width = max(c1 - c0 for c0, c1 in counts)
     view = _torch_view(prov, c_rows, (n, rows_g))  # column-major rows_g x n == row-major n x rows_g
@@ -159,15 +160,26 @@ def gather_row_blocks_device(group: Group, prov, c_rows, rows_total: int):
 
 
 class _CudaArray:
-    def __init__(self, ptr: int, shape: Tuple[int, ...]):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (ptr, False), "version": 3,
+    def __init__(self, ptr: int, shape: Tuple[int, ...], typestr: str = "<f8"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 3,
                                          "strides": None}
 
 
+def _require_f64(prov, what: str) -> None:
+    """The exchange helpers below move f64 device memory; a precision-32 provider's shards are gathered on the host
+    (`gather_row_blocks`) or not at all (sharded results stay sharded)."""
+    if getattr(prov, "precision", lambda: "F64")() != "F64":
+        from .provider import ProviderError
+        raise ProviderError(2, f"{what}: needs a precision-64 provider")
+
+
 def _torch_view(prov, handle, shape):
+    """Zero-copy torch view of a library buffer for the collectives; the element type follows the buffer's storage
+    (f32 on a precision-32 provider, `rmhip_buffer_bits`)."""
     import torch
 
-    return torch.as_tensor(_CudaArray(prov.device_ptr(handle), shape), device="cuda")
+    typestr = "<f4" if hasattr(prov, "buffer_bits") and prov.buffer_bits(handle) == 32 else "<f8"
+    return torch.as_tensor(_CudaArray(prov.device_ptr(handle), shape, typestr), device="cuda")
 
 
 # ---- reductions --------------------------------------------------------------------------------
@@ -353,12 +365,15 @@ def mldivide_block_cyclic(prov, group: Group, a_local, n: int, b, nb: int = 512)
     OVERWRITTEN with its part of the LU factors) and b (n x nrhs) replicated.  Returns the replicated
     solution handle.
 
+    Needs a precision-64 provider (the block views update f64 storage in place).
+
     Per block p: the owner factors its panel (rows j.., the host_lu.rs pivot rule), broadcasts the
     factored panel plus the interchanges (one RCCL broadcast of (n-j) x nb doubles: 64 MiB for the
     first panel at n = 16384, nb = 512, shrinking linearly), then every rank applies interchanges,
     triangular solve and the MFMA dgemm update to the trailing blocks IT owns and, redundantly, to its
     copy of b.  The back substitution walks the blocks in reverse: the owner solves with its U_pp,
     updates y[0:j] and broadcasts the finished prefix."""
+    _require_f64(prov, "mldivide_block_cyclic")
     from .provider import ProviderError
 
     nrhs = b.shape[1] if len(b.shape) > 1 else 1
