@@ -40,6 +40,10 @@ struct SgemmArgs {
     unsigned m, n, k;
     unsigned tiles_m, tiles_n;
     int vec_a, vec_b;  // EDGE kernel: 8-byte loads are legal for A / B (aligned base, even leading dimension)
+    // split-K (few output tiles, long k -- A'*A of a tall matrix): blockIdx.y owns k in [y*k_chunk, min(k, (y+1)*k_chunk))
+    // and writes its partial product to C + y*c_split_stride; k_sreduce_splits adds the partials in split order
+    unsigned k_chunk;
+    unsigned long long c_split_stride;
 };
 
 __device__ __forceinline__ void sg_tile_of_block(const SgemmArgs& g, unsigned& tm, unsigned& tn) {
@@ -78,7 +82,11 @@ __global__ void __launch_bounds__(256, SGEMM_BLOCKS_PER_CU) k_sgemm(const SgemmA
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int l15 = lane & 15, lq = lane >> 4;
-    const unsigned klen = g.k;
+    const unsigned kbeg = blockIdx.y * g.k_chunk;
+    const unsigned klen = (g.k - kbeg) < g.k_chunk ? (g.k - kbeg) : g.k_chunk;
+    const float* const Ab = TA ? g.A + kbeg : g.A + (size_t)kbeg * g.lda;
+    const float* const Bb = TB ? g.B + (size_t)kbeg * g.ldb : g.B + kbeg;
+    float* const Cb = g.C + (size_t)blockIdx.y * g.c_split_stride;
 
     const int p_xp = t & 63;  // pattern M: pair index along the contiguous tile dimension
     const int p_kc = t >> 6;  //            k = p_kc + 4*p
@@ -140,10 +148,10 @@ __global__ void __launch_bounds__(256, SGEMM_BLOCKS_PER_CU) k_sgemm(const SgemmA
         for (int p = 0; p < 4; ++p) *(v2f*)(tile + (q_y + 32 * p) * SB + 2 * q_kp) = r[p];
     };
     auto fetch = [&](unsigned k0) {
-        if (TA) fetchK(g.A, g.lda, m0, g.m, k0, g.vec_a, ra);
-        else fetchM(g.A, g.lda, m0, g.m, k0, g.vec_a, ra);
-        if (TB) fetchM(g.B, g.ldb, n0, g.n, k0, g.vec_b, rb);
-        else fetchK(g.B, g.ldb, n0, g.n, k0, g.vec_b, rb);
+        if (TA) fetchK(Ab, g.lda, m0, g.m, k0, g.vec_a, ra);
+        else fetchM(Ab, g.lda, m0, g.m, k0, g.vec_a, ra);
+        if (TB) fetchM(Bb, g.ldb, n0, g.n, k0, g.vec_b, rb);
+        else fetchK(Bb, g.ldb, n0, g.n, k0, g.vec_b, rb);
     };
     auto stash = [&](int buf) {
         if (TA) stashK(As + buf * TILE, ra);
@@ -199,14 +207,24 @@ __global__ void __launch_bounds__(256, SGEMM_BLOCKS_PER_CU) k_sgemm(const SgemmA
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const unsigned nn = n0 + wn * 64 + j * 16 + 4 * lq + r;
-                if (!EDGE || (mm < g.m && nn < g.n)) g.C[(size_t)nn * g.ldc + mm] = acc[j][i][r];
+                if (!EDGE || (mm < g.m && nn < g.n)) Cb[(size_t)nn * g.ldc + mm] = acc[j][i][r];
             }
         }
 }
 
 template <bool EDGE, bool TA, bool TB>
-static void sg_launch(Context* c, unsigned blocks, const SgemmArgs& g) {
-    hipLaunchKernelGGL((k_sgemm<EDGE, TA, TB>), dim3(blocks), dim3(256), 0, c->stream, g);
+static void sg_launch(Context* c, unsigned blocks, unsigned splits, const SgemmArgs& g) {
+    hipLaunchKernelGGL((k_sgemm<EDGE, TA, TB>), dim3(blocks, splits), dim3(256), 0, c->stream, g);
+}
+
+// C = P_0 + P_1 + ... + P_{S-1} (partials m x n dense, ld m), summed in split order in f64 and rounded once
+__global__ void __launch_bounds__(256) k_sreduce_splits(const float* __restrict__ P, size_t mn, size_t m, unsigned splits,
+                                                        float* __restrict__ C, size_t ldc) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += (size_t)gridDim.x * 256) {
+        double s = (double)P[i];
+        for (unsigned z = 1; z < splits; ++z) s += (double)P[i + (size_t)z * mn];
+        C[(i % m) + (i / m) * ldc] = (float)s;
+    }
 }
 
 // C (m x n, f32) = op(A) * op(B); op(X) = X' when tX (A then stored k x m, B stored n x k).  k == 0 gives zeros.
@@ -233,18 +251,47 @@ int launch_sgemm_trans(Context* c, bool ta, bool tb, size_t m, size_t n, size_t 
     g.vec_b = ((((uintptr_t)B & 7) == 0) && (ldb % 2 == 0)) ? 1 : 0;
     const bool fast = (m % BM == 0) && (n % BN == 0) && (k % BK == 0) && k > 0 && g.vec_a && g.vec_b;
     const unsigned blocks = g.tiles_m * g.tiles_n;
+    // Split-K as in dgemm.hip: few output tiles but a long k would leave most CUs idle; about two blocks per CU.
+    unsigned splits = 1;
+    g.k_chunk = (unsigned)k;
+    g.c_split_stride = 0;
+    std::shared_ptr<Allocation> partials;
+    if (blocks * 4 <= (unsigned)c->num_cus && k >= 8192) {
+        const size_t want = (2 * (size_t)c->num_cus + blocks - 1) / blocks;
+        size_t chunk = (k + want - 1) / want;
+        chunk = ((chunk + 1023) / 1024) * 1024;  // multiples of 1024 keep the unguarded kernel eligible
+        splits = (unsigned)((k + chunk - 1) / chunk);
+        if (splits > 1) {
+            RMHIP_TRY(c->alloc_device(((size_t)splits * m * n + 1) / 2, &partials));
+            g.k_chunk = (unsigned)chunk;
+            g.C = reinterpret_cast<float*>(partials->ptr);
+            g.ldc = m;
+            g.c_split_stride = (unsigned long long)m * n;
+        } else {
+            splits = 1;
+        }
+    }
+    const bool fast_k = fast && (splits == 1 || k % g.k_chunk == 0);
     if (ta) {
-        if (fast) sg_launch<false, true, false>(c, blocks, g);
-        else sg_launch<true, true, false>(c, blocks, g);
+        if (fast_k) sg_launch<false, true, false>(c, blocks, splits, g);
+        else sg_launch<true, true, false>(c, blocks, splits, g);
     } else if (tb) {
-        if (fast) sg_launch<false, false, true>(c, blocks, g);
-        else sg_launch<true, false, true>(c, blocks, g);
+        if (fast_k) sg_launch<false, false, true>(c, blocks, splits, g);
+        else sg_launch<true, false, true>(c, blocks, splits, g);
     } else {
-        if (fast) sg_launch<false, false, false>(c, blocks, g);
-        else sg_launch<true, false, false>(c, blocks, g);
+        if (fast_k) sg_launch<false, false, false>(c, blocks, splits, g);
+        else sg_launch<true, false, false>(c, blocks, splits, g);
     }
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
+    if (splits > 1) {
+        const size_t mn = m * n;
+        const size_t want_blocks = (mn + 255) / 256, cap = (size_t)c->num_cus * 4;
+        hipLaunchKernelGGL(k_sreduce_splits, dim3((unsigned)(want_blocks < cap ? want_blocks : cap)), dim3(256), 0, c->stream,
+                           reinterpret_cast<const float*>(partials->ptr), mn, m, splits, C, ldc);
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+    }
     return RMHIP_OK;
 }
 

@@ -347,7 +347,8 @@ def test_f32_matmul_solve_and_friends_use_f64_kernels_on_widened_operands(prov32
 
 
 @pytest.mark.parametrize("m,k,n", [(128, 16, 128), (256, 128, 384), (150, 70, 90), (1, 33, 1), (129, 1, 127), (5, 1000, 7),
-                                   (640, 515, 130), (1024, 1024, 1024), (3, 2, 4)])
+                                   (640, 515, 130), (768, 1024, 512), (3, 2, 4),
+                                   (128, 16384, 128), (200, 9000, 70), (64, 20000, 64)])  # the last three split along k
 def test_f32_matmul_on_the_f32_matrix_cores(prov32, oracle, m, k, n, monkeypatch):
     """Default precision-32 matmul: v_mfma_f32_16x16x4_f32 with f32 accumulation (what the reference's F32 backend
     does; its checks allow 1e-4 relative, wgpu_profile.rs:20-21).  Bound: k * eps32 * sum|a||b| per element, the
@@ -367,9 +368,13 @@ def test_f32_matmul_on_the_f32_matrix_cores(prov32, oracle, m, k, n, monkeypatch
     for x, y in ((hat, hb), (ha, hbt), (hat, hbt)):
         g2 = prov32.download_matrix(prov32.matmul(x, y))
         assert np.all(np.abs(g2 - want) <= bound)
-    g3 = prov32.syrk(ha)  # A' * A on the same kernel (transposed-A variant)
-    assert g3.shape == (k, k) and prov32.buffer_bits(g3) == 32
-    assert np.all(np.abs(prov32.download_matrix(g3) - oracle.matmul(A.T, A)) <= (m + 2) * ULP32 * (np.abs(A).T @ np.abs(A)) + 1e-30)
+    if k <= 2048:  # A' * A (k x k) on the same kernel, transposed-A variant; the CPU check is O(m k^2)
+        g3 = prov32.syrk(ha)
+        assert g3.shape == (k, k) and prov32.buffer_bits(g3) == 32
+        assert np.all(np.abs(prov32.download_matrix(g3) - oracle.matmul(A.T, A)) <= (m + 2) * ULP32 * (np.abs(A).T @ np.abs(A)) + 1e-30)
+    else:  # tall operand: B' * B is n x n with the long k -- the split-K shape of a Gram matrix
+        g3 = prov32.syrk(hb)
+        assert g3.shape == (n, n) and np.all(np.abs(prov32.download_matrix(g3) - oracle.matmul(B.T, B)) <= (k + 2) * ULP32 * (np.abs(B).T @ np.abs(B)) + 1e-30)
     monkeypatch.setenv("RMHIP_F32_MATMUL", "f64")
     exact = prov32.download_matrix(prov32.matmul(ha, hb))
     assert same_bits(exact, f32r(want)) or np.max(np.abs(exact - f32r(want))) <= ULP32 * np.max(np.abs(want))
