@@ -280,3 +280,47 @@ def test_front_end_survives_mangled_shaders(built):
                 assert e.code == 6, (e.code, str(e))  # RMHIP_ERR_COMPILE
                 outcomes["err"] += 1
     assert outcomes["err"] > 100 and outcomes["ok"] > 0, outcomes
+
+
+def _split_params(text: str):
+    """Top-level comma split of a C / Rust parameter list (no nested parentheses in this ABI, brackets may occur)."""
+    text = text.strip()
+    if not text or text == "void":
+        return []
+    parts, depth, cur = [], 0, ""
+    for ch in text:
+        if ch in "([<":
+            depth += 1
+        elif ch in ")]>":
+            depth -= 1
+        if ch == "," and depth == 0:
+            parts.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        parts.append(cur.strip())
+    return parts
+
+
+def test_bindings_agree_with_the_header_on_every_arity():
+    """Three hand-written mirrors of include/rmhip.h exist (the ctypes table, the C++ provider header goes through the
+    C prototypes, the Rust shim cannot be compiled in this image): parameter counts must match the header for every
+    function a mirror declares, so a changed prototype cannot silently leave a stale binding behind."""
+    from runmat_amd import _lib
+
+    header = (ROOT / "include" / "rmhip.h").read_text()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = {m.group(1): _split_params(m.group(2))
+              for m in re.finditer(r"RMHIP_API\s+[\w\s\*]+?\b(rmhip_\w+)\s*\(([^;]*?)\)\s*;", header, flags=re.S)}
+    assert len(protos) >= 55, len(protos)
+    for name, (_, argtypes) in _lib.SIGNATURES.items():
+        assert len(argtypes) == len(protos[name]), (name, len(argtypes), protos[name])
+    shim = (ROOT / "shim" / "hip_provider.rs").read_text()
+    block = shim[shim.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    rust = {m.group(1): _split_params(m.group(2)) for m in re.finditer(r"fn\s+(rmhip_\w+)\s*\(([^;]*?)\)\s*(?:->\s*[\w\s\*]+)?;", block, flags=re.S)}
+    assert len(rust) >= 25, len(rust)
+    for name, params in rust.items():
+        assert name in protos, f"the Rust shim declares {name}, which include/rmhip.h does not"
+        assert len(params) == len(protos[name]), (name, params, protos[name])
