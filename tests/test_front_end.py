@@ -324,3 +324,33 @@ def test_bindings_agree_with_the_header_on_every_arity():
     for name, params in rust.items():
         assert name in protos, f"the Rust shim declares {name}, which include/rmhip.h does not"
         assert len(params) == len(protos[name]), (name, params, protos[name])
+
+
+def _c_struct_fields(header: str, tag: str):
+    """Field names, in declaration order, of `typedef struct <tag> { ... }` in the (comment-stripped) header."""
+    body = re.search(r"typedef\s+struct\s+" + tag + r"\s*\{(.*?)\}", header, flags=re.S).group(1)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        first, *rest = decl.split(",")
+        names.append(re.sub(r"\[.*?\]", "", first).split()[-1].lstrip("*"))
+        names += [re.sub(r"\[.*?\]", "", r).strip().lstrip("*") for r in rest]
+    return names
+
+
+def test_struct_mirrors_have_the_headers_fields_in_order():
+    """The by-value structs of the ABI are mirrored in ctypes and in the Rust shim: same fields, same order."""
+    from runmat_amd import _lib
+
+    header = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "rmhip.h").read_text(), flags=re.S)
+    pairs = {"rmhip_device_info": _lib.DeviceInfo, "rmhip_telemetry": _lib.Telemetry, "rmhip_matmul_epilogue": _lib.MatmulEpilogue,
+             "rmhip_linsolve_options": _lib.LinsolveOptions, "rmhip_image_normalize": _lib.ImageNormalize, "rmhip_view": _lib.View}
+    for tag, cls in pairs.items():
+        assert [n for n, *_ in cls._fields_] == _c_struct_fields(header, tag), tag
+    shim = (ROOT / "shim" / "hip_provider.rs").read_text()
+    for tag, rust_name in (("rmhip_image_normalize", "RmhipImageNormalize"), ("rmhip_linsolve_options", "RmhipLinsolveOptions")):
+        body = re.search(r"struct\s+" + rust_name + r"\s*\{(.*?)\}", shim, flags=re.S).group(1)
+        fields = [f.split(":")[0].strip() for f in body.replace("\n", " ").split(",") if ":" in f]
+        assert fields == _c_struct_fields(header, tag), (tag, fields)
