@@ -45,6 +45,8 @@ extern "C" {
     fn rmhip_reduce(ctx: *mut RmhipCtx, op: c_int, a: u64, dim: c_int, nan_mode: c_int, out: *mut u64) -> c_int;
     fn rmhip_reduce_nd(ctx: *mut RmhipCtx, op: c_int, a: u64, dims: *const usize, ndims: usize, nan_mode: c_int, out: *mut u64) -> c_int;
     fn rmhip_reduce_moments_nd(ctx: *mut RmhipCtx, a: u64, dims: *const usize, ndims: usize, mean: *mut u64, ex2: *mut u64) -> c_int;
+    fn rmhip_dot(ctx: *mut RmhipCtx, a: u64, b: u64, dim: c_int, out: *mut u64) -> c_int;
+    fn rmhip_reshape(ctx: *mut RmhipCtx, id: u64, shape: *const usize, rank: usize, out: *mut u64) -> c_int;
     fn rmhip_matmul(ctx: *mut RmhipCtx, a: u64, b: u64, out: *mut u64) -> c_int;
     fn rmhip_lu(ctx: *mut RmhipCtx, a: u64, out5: *mut u64) -> c_int;
     fn rmhip_mldivide(ctx: *mut RmhipCtx, a: u64, b: u64, out: *mut u64) -> c_int;
@@ -60,6 +62,78 @@ extern "C" {
     fn rmhip_random_normal(ctx: *mut RmhipCtx, shape: *const usize, rank: usize, out: *mut u64) -> c_int;
     fn rmhip_random_uniform(ctx: *mut RmhipCtx, shape: *const usize, rank: usize, out: *mut u64) -> c_int;
 }
+
+// Op codes: the enums of include/rmhip.h (tests/test_front_end.py checks every value against the header).
+const RMHIP_ADD: c_int = 0;
+const RMHIP_SUB: c_int = 1;
+const RMHIP_MUL: c_int = 2;
+const RMHIP_DIV: c_int = 3;
+const RMHIP_POW: c_int = 4;
+const RMHIP_MAX: c_int = 5;
+const RMHIP_MIN: c_int = 6;
+const RMHIP_HYPOT: c_int = 7;
+const RMHIP_ATAN2: c_int = 8;
+const RMHIP_MOD: c_int = 9;
+const RMHIP_REM: c_int = 10;
+const RMHIP_EQ: c_int = 11;
+const RMHIP_NE: c_int = 12;
+const RMHIP_LT: c_int = 13;
+const RMHIP_LE: c_int = 14;
+const RMHIP_GT: c_int = 15;
+const RMHIP_GE: c_int = 16;
+const RMHIP_AND: c_int = 17;
+const RMHIP_OR: c_int = 18;
+const RMHIP_XOR: c_int = 19;
+const RMHIP_SIN: c_int = 0;
+const RMHIP_COS: c_int = 1;
+const RMHIP_TAN: c_int = 2;
+const RMHIP_ASIN: c_int = 3;
+const RMHIP_ACOS: c_int = 4;
+const RMHIP_ATAN: c_int = 5;
+const RMHIP_SINH: c_int = 6;
+const RMHIP_COSH: c_int = 7;
+const RMHIP_TANH: c_int = 8;
+const RMHIP_ASINH: c_int = 9;
+const RMHIP_ACOSH: c_int = 10;
+const RMHIP_ATANH: c_int = 11;
+const RMHIP_EXP: c_int = 12;
+const RMHIP_EXPM1: c_int = 13;
+const RMHIP_LOG: c_int = 14;
+const RMHIP_LOG2: c_int = 15;
+const RMHIP_LOG10: c_int = 16;
+const RMHIP_LOG1P: c_int = 17;
+const RMHIP_SQRT: c_int = 18;
+const RMHIP_ABS: c_int = 19;
+const RMHIP_SIGN: c_int = 20;
+const RMHIP_FLOOR: c_int = 21;
+const RMHIP_CEIL: c_int = 22;
+const RMHIP_ROUND: c_int = 23;
+const RMHIP_FIX: c_int = 24;
+const RMHIP_NEG: c_int = 25;
+const RMHIP_EXP2: c_int = 26;
+const RMHIP_HEAVISIDE: c_int = 27;
+const RMHIP_ISNAN: c_int = 28;
+const RMHIP_ISINF: c_int = 29;
+const RMHIP_ISFINITE: c_int = 30;
+const RMHIP_UPLUS: c_int = 31;
+const RMHIP_SINGLE: c_int = 32;
+const RMHIP_DOUBLE: c_int = 33;
+const RMHIP_ERF: c_int = 34;
+const RMHIP_SINC: c_int = 35;
+const RMHIP_NOT: c_int = 36;
+const RMHIP_SADD: c_int = 0;
+const RMHIP_SSUB: c_int = 1;
+const RMHIP_SMUL: c_int = 2;
+const RMHIP_SDIV: c_int = 3;
+const RMHIP_SRSUB: c_int = 4;
+const RMHIP_SRDIV: c_int = 5;
+const RMHIP_SMAX: c_int = 6;
+const RMHIP_SMIN: c_int = 7;
+const RMHIP_RSUM: c_int = 0;
+const RMHIP_RMEAN: c_int = 1;
+const RMHIP_RMIN: c_int = 2;
+const RMHIP_RMAX: c_int = 3;
+const RMHIP_RPROD: c_int = 4;
 
 #[repr(C)]
 struct RmhipImageNormalize {
@@ -134,6 +208,42 @@ impl Drop for HipProvider {
     }
 }
 
+// One trait method per line: the hooks differ only in the op code handed to the library.
+macro_rules! unary_hooks { ($($name:ident => $op:expr),* $(,)?) => { $(
+    fn $name<'a>(&'a self, a: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> { Box::pin(async move { self.unary($op, a) }) }
+)* } }
+macro_rules! binary_hooks { ($($name:ident => $op:expr),* $(,)?) => { $(
+    fn $name<'a>(&'a self, a: &'a GpuTensorHandle, b: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> { Box::pin(async move { self.binary($op, a, b) }) }
+)* } }
+macro_rules! logical_hooks { ($($name:ident => $op:expr),* $(,)?) => { $(
+    fn $name(&self, a: &GpuTensorHandle, b: &GpuTensorHandle) -> Result<GpuTensorHandle> { self.binary($op, a, b) }
+)* } }
+macro_rules! scalar_hooks { ($($name:ident => $op:expr),* $(,)?) => { $(
+    fn $name(&self, a: &GpuTensorHandle, scalar: f64) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_scalar(self.ctx, $op, self.own(a)?, scalar, &mut out) })?;
+        self.handle(out)
+    }
+)* } }
+macro_rules! reduce_all_hooks { ($($name:ident => $op:expr),* $(,)?) => { $(
+    fn $name<'a>(&'a self, a: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_reduce(self.ctx, $op, self.own(a)?, -1, 0, &mut out) })?;
+            self.handle(out)
+        })
+    }
+)* } }
+macro_rules! reduce_dim_hooks { ($($name:ident => $op:expr),* $(,)?) => { $(
+    fn $name<'a>(&'a self, a: &'a GpuTensorHandle, dim: usize) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_reduce(self.ctx, $op, self.own(a)?, dim as c_int, 0, &mut out) })?;
+            self.handle(out)
+        })
+    }
+)* } }
+
 impl AccelProvider for HipProvider {
     fn upload(&self, host: &HostTensorView) -> Result<GpuTensorHandle> {
         let mut out = 0u64;
@@ -182,15 +292,55 @@ impl AccelProvider for HipProvider {
         Ok(GpuTensorHandle { shape: output_shape.to_vec(), device_id: self.device_id, buffer_id: out })
     }
 
-    // per-op hooks: op codes are the enums of include/rmhip.h
-    fn elem_add<'a>(&'a self, a: &'a GpuTensorHandle, b: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> { Box::pin(async move { self.binary(0, a, b) }) }
-    fn elem_sub<'a>(&'a self, a: &'a GpuTensorHandle, b: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> { Box::pin(async move { self.binary(1, a, b) }) }
-    fn elem_mul<'a>(&'a self, a: &'a GpuTensorHandle, b: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> { Box::pin(async move { self.binary(2, a, b) }) }
-    fn elem_div<'a>(&'a self, a: &'a GpuTensorHandle, b: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> { Box::pin(async move { self.binary(3, a, b) }) }
-    fn unary_sin<'a>(&'a self, a: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> { Box::pin(async move { self.unary(0, a) }) }
-    fn unary_cos<'a>(&'a self, a: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> { Box::pin(async move { self.unary(1, a) }) }
-    fn unary_exp<'a>(&'a self, a: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> { Box::pin(async move { self.unary(12, a) }) }
-    // ... the remaining elem_* / unary_* / scalar_* hooks follow the same two-line pattern.
+    // per-op hooks (lib.rs:1890-2355): one line per trait method, generated by the macros above the impl
+    unary_hooks! {
+        unary_sin => RMHIP_SIN, unary_cos => RMHIP_COS, unary_tan => RMHIP_TAN, unary_asin => RMHIP_ASIN, unary_acos => RMHIP_ACOS,
+        unary_atan => RMHIP_ATAN, unary_sinh => RMHIP_SINH, unary_cosh => RMHIP_COSH, unary_tanh => RMHIP_TANH,
+        unary_asinh => RMHIP_ASINH, unary_acosh => RMHIP_ACOSH, unary_atanh => RMHIP_ATANH, unary_exp => RMHIP_EXP,
+        unary_expm1 => RMHIP_EXPM1, unary_log => RMHIP_LOG, unary_log2 => RMHIP_LOG2, unary_log10 => RMHIP_LOG10,
+        unary_log1p => RMHIP_LOG1P, unary_sqrt => RMHIP_SQRT, unary_abs => RMHIP_ABS, unary_sign => RMHIP_SIGN,
+        unary_floor => RMHIP_FLOOR, unary_ceil => RMHIP_CEIL, unary_round => RMHIP_ROUND, unary_fix => RMHIP_FIX,
+        unary_pow2 => RMHIP_EXP2, unary_heaviside => RMHIP_HEAVISIDE, unary_single => RMHIP_SINGLE, unary_double => RMHIP_DOUBLE,
+        unary_erf => RMHIP_ERF, unary_sinc => RMHIP_SINC,
+    }
+    binary_hooks! {
+        elem_add => RMHIP_ADD, elem_sub => RMHIP_SUB, elem_mul => RMHIP_MUL, elem_div => RMHIP_DIV, elem_pow => RMHIP_POW,
+        elem_max => RMHIP_MAX, elem_min => RMHIP_MIN, elem_hypot => RMHIP_HYPOT, elem_atan2 => RMHIP_ATAN2,
+        elem_eq => RMHIP_EQ, elem_ne => RMHIP_NE, elem_lt => RMHIP_LT, elem_le => RMHIP_LE, elem_gt => RMHIP_GT, elem_ge => RMHIP_GE,
+    }
+    logical_hooks! { logical_and => RMHIP_AND, logical_or => RMHIP_OR, logical_xor => RMHIP_XOR }
+    fn logical_not(&self, a: &GpuTensorHandle) -> Result<GpuTensorHandle> { self.unary(RMHIP_NOT, a) }
+    fn logical_isnan(&self, a: &GpuTensorHandle) -> Result<GpuTensorHandle> { self.unary(RMHIP_ISNAN, a) }
+    fn logical_isinf(&self, a: &GpuTensorHandle) -> Result<GpuTensorHandle> { self.unary(RMHIP_ISINF, a) }
+    fn logical_isfinite(&self, a: &GpuTensorHandle) -> Result<GpuTensorHandle> { self.unary(RMHIP_ISFINITE, a) }
+    scalar_hooks! {
+        scalar_add => RMHIP_SADD, scalar_sub => RMHIP_SSUB, scalar_mul => RMHIP_SMUL, scalar_div => RMHIP_SDIV,
+        scalar_rsub => RMHIP_SRSUB, scalar_rdiv => RMHIP_SRDIV, scalar_max => RMHIP_SMAX, scalar_min => RMHIP_SMIN,
+    }
+    reduce_all_hooks! { reduce_mean => RMHIP_RMEAN, reduce_min => RMHIP_RMIN, reduce_max => RMHIP_RMAX, reduce_prod => RMHIP_RPROD }
+    reduce_dim_hooks! { reduce_mean_dim => RMHIP_RMEAN, reduce_prod_dim => RMHIP_RPROD }
+    fn dot<'a>(&'a self, lhs: &'a GpuTensorHandle, rhs: &'a GpuTensorHandle, dim: Option<usize>) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            let d = dim.map(|d| d as c_int).unwrap_or(-1); // None: first non-singleton dimension
+            check(unsafe { rmhip_dot(self.ctx, self.own(lhs)?, self.own(rhs)?, d, &mut out) })?;
+            self.handle(out)
+        })
+    }
+    // The library keeps each buffer's shape; a reshaped handle must be a new buffer id aliasing the same storage
+    // (the trait's default only edits the handle, lib.rs:2676-2684).
+    fn reshape(&self, handle: &GpuTensorHandle, new_shape: &[usize]) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_reshape(self.ctx, self.own(handle)?, new_shape.as_ptr(), new_shape.len(), &mut out) })?;
+        Ok(GpuTensorHandle { shape: new_shape.to_vec(), device_id: self.device_id, buffer_id: out })
+    }
+    fn zeros(&self, shape: &[usize]) -> Result<GpuTensorHandle> { self.fill(shape, 0.0) }
+    fn ones(&self, shape: &[usize]) -> Result<GpuTensorHandle> { self.fill(shape, 1.0) }
+    fn fill(&self, shape: &[usize], value: f64) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_fill(self.ctx, value, shape.as_ptr(), shape.len(), &mut out) })?;
+        Ok(GpuTensorHandle { shape: shape.to_vec(), device_id: self.device_id, buffer_id: out })
+    }
 
     fn reduce_sum<'a>(&'a self, a: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> {
         Box::pin(async move {

@@ -354,3 +354,29 @@ def test_struct_mirrors_have_the_headers_fields_in_order():
         body = re.search(r"struct\s+" + rust_name + r"\s*\{(.*?)\}", shim, flags=re.S).group(1)
         fields = [f.split(":")[0].strip() for f in body.replace("\n", " ").split(",") if ":" in f]
         assert fields == _c_struct_fields(header, tag), (tag, fields)
+
+
+def test_rust_shim_op_codes_are_the_header_enums():
+    """shim/hip_provider.rs repeats the op enums as constants (it cannot include the C header): every value must match."""
+    header = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "rmhip.h").read_text(), flags=re.S)
+    values = {}
+    for body in re.findall(r"enum\s+rmhip_\w+\s*\{(.*?)\}", header, flags=re.S):
+        v = -1
+        for item in body.split(","):
+            item = item.strip()
+            if not item:
+                continue
+            if "=" in item:
+                name, val = (x.strip() for x in item.split("="))
+                v = int(val)
+            else:
+                name, v = item, v + 1
+            values[name] = v
+    shim = (ROOT / "shim" / "hip_provider.rs").read_text()
+    consts = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"const\s+(RMHIP_\w+)\s*:\s*c_int\s*=\s*(\d+)\s*;", shim))
+    assert len(consts) >= 60, len(consts)
+    for name, v in consts.items():
+        assert values.get(name) == v, (name, v, values.get(name))
+    # every constant the hook tables use exists, and every hook name is a method of the reference trait's families
+    used = set(re.findall(r"=>\s*(RMHIP_\w+)", shim)) | set(re.findall(r"self\.unary\((RMHIP_\w+)", shim))
+    assert used <= set(consts), used - set(consts)
