@@ -367,7 +367,12 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
     if (ep) g.ep = *ep;
     else g.ep = GemmEpilogue{0, 1.0, 0.0, nullptr, nullptr, 0.0, 0.0, 0.0, nullptr};
     const size_t lds_base = (size_t)(2 * A_TILE + 2 * B_TILE) * sizeof(double);
-    const size_t lds_bytes = lds_base + c->gemm_lds_pad;
+    static long dev_pad = -1;  // developer knob: extra dynamic LDS for every launch (blocks per CU experiments)
+    if (dev_pad < 0) {
+        const char* v = std::getenv("RMHIP_GEMM_LDS_PAD");
+        dev_pad = v ? std::atol(v) : 0;
+    }
+    const size_t lds_bytes = lds_base + (c->gemm_lds_pad ? c->gemm_lds_pad : (size_t)dev_pad);
     const bool fast = (m % BM == 0) && (n % BN == 0) && (k % BK == 0) && k > 0 && (lda % 2 == 0) && (ldb % 2 == 0) &&
                       (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
     const unsigned blocks = g.tiles_m * g.tiles_n;
