@@ -38,15 +38,13 @@ struct LuState {
     double* cand_abs; // device: [2][MAX_PANEL_BLOCKS] per-block arg-max candidates (double buffered by column parity)
     int* cand_pos;    //         position of the candidate row
     int* cand_row;    //         physical row of the candidate
-    // persistent panel kernel (k_lu_panel): inter-block exchange area
+    // persistent panel kernel (k_lu_panel2): inter-block exchange area
     int* xerr;            // device: set when a bounded spin expired (blocks not co-resident)
-    unsigned long long* xa;  // device [2][PK_MAXB]: candidate |a| records (see k_lu_panel)
-    unsigned long long* xb;  // device [2][PK_MAXB]: candidate position / thread records
+    unsigned long long* xrec;   // device [2][PK_MAXB][2]: candidate records (16-byte granules, see k_lu_panel2)
     unsigned long long* xvals;  // device [2][PK_MAXB][BASE_W][2]: candidate rows' panel values (tagged half words)
     unsigned xbase;       // host: panel columns factored so far (exchange step counter)
-    bool persistent;      // use k_lu_panel for base panels
+    bool persistent;      // use k_lu_panel2 for base panels
     unsigned long long* xdbg;  // device [16] phase ticks (RMHIP_LU_PANEL_DEBUG=1) or nullptr
-    int panel_rows;       // rows per persistent-panel block: 256, or 128 under look-ahead
 };
 
 static constexpr int MAX_PANEL_BLOCKS = 1024;  // 64 rows per block => up to 65536 rows per panel
@@ -218,21 +216,16 @@ __global__ void __launch_bounds__(PANEL_THREADS) k_lu_col(double* __restrict__ A
 // ---- base panel, persistent variant: ONE launch per panel ---------------------------------------------
 // The per-column kernel above pays a launch gap, a cold instruction fetch and two or three dependent
 // trips to memory per column (~6.9 us measured, 113 ms of the 219 ms at n = 16384).  Here the whole
-// panel (<= 64 columns) is factored by one grid of co-resident workgroups that keep their rows in LDS
-// and meet once per column in a software grid barrier:
-//   * block b owns rows j0 + b*PK_ROWS ..; thread t keeps its row's panel values in S[c][t] (LDS).
+// panel (<= 64 columns) is factored by one grid of co-resident workgroups (256 rows each) that meet once
+// per column:
 //   * per column: block arg-max -> wave 0 publishes the block's candidate (|a|, position, row) AND that
-//     row's remaining panel values -> arrival counter -> wave 0 of every block folds the P candidates
-//     and fetches the winner's values -> every thread eliminates.  One exchange per column.
-//   * every cross-block access is a relaxed agent-scope atomic (sc1 loads/stores: coherent across the
-//     eight XCD L2s); scripts/micro/grid_barrier.hip measures the whole exchange at 1.3-1.6 us for
-//     32 blocks, whether or not they share an XCD.
+//     row's remaining panel values -> every block folds the P candidates and takes the winner's values
+//     -> every thread eliminates.  One exchange per column.
+//   * every cross-block access is a write-through store / L1-bypassing load (sc1: coherent across the
+//     eight XCD L2s) of a self-describing granule; there is no arrival counter and no fence.
 //   * spins are bounded: if the blocks are not co-resident (device shared with another context) the
 //     kernel sets *xerr and the factorisation fails loudly instead of hanging.
 // Pivot rule, tie-break, singular cut-off and the lazy-pivoting bookkeeping are those of k_lu_col.
-// PK_ROWS (template parameter) = rows per block: 256 normally (128 is no faster alone: the exchange grows
-// with the block count), 128 under look-ahead so that a block (66 KiB of LDS) fits beside a dgemm block.
-static constexpr int PK_Q = 4;                   // threads per row (each takes every PK_Q-th column of the update)
 static constexpr int PK_MAXB = 256;              // at most one block per CU
 static constexpr int PK_SPIN_LIMIT = 400000;
 typedef unsigned long long pk_u64;
@@ -279,226 +272,467 @@ __device__ __forceinline__ int wave_argmax(pk_u64 key, unsigned pos, pk_u64* key
     return (int)__builtin_ctzll(hit);
 }
 
-// Exchange records (all 8-byte relaxed agent-scope atomics): step `seq` (counted over the whole
-// factorisation) uses slot parity seq & 1 and the freshness bit ((seq >> 1) & 1) ^ 1 in bit 63 of both
-// words, so consecutive uses of a slot always flip the bit and a zero-initialised slot is stale.
-//   word A: |a| bit pattern (sign bit is free)      word B: position | thread-in-block << 32
-template <int PK_ROWS>
-__global__ void __launch_bounds__(PK_ROWS * PK_Q) k_lu_panel(double* __restrict__ A, size_t lda, size_t rows, int j0, int w,
-                                                         int nblocks, unsigned seq0, int* xerr, pk_u64* xa, pk_u64* xb,
-                                                         pk_u64* xvals, int* __restrict__ pos_of, int* __restrict__ prow_arr,
-                                                         int* __restrict__ ipiv, int* __restrict__ info, pk_u64* dbg) {
-    extern __shared__ double S[];  // [BASE_W][PK_ROWS] panel values, then s_prow[BASE_W]
-    double* s_prow = S + BASE_W * PK_ROWS;
-    __shared__ pk_u64 r_key[PK_ROWS / 64];
-    __shared__ unsigned r_pos[PK_ROWS / 64];
-    __shared__ int r_t[PK_ROWS / 64];
-    __shared__ int s_ctl[4];  // pivot row, pivot position, skip, error
-    // developer instrumentation (RMHIP_LU_PANEL_DEBUG=1): 100 MHz wall-clock ticks per phase, block 0 thread 0
-    // (ticks accumulate in registers: a global read-modify-write per tick would itself cost a memory round trip)
-    pk_u64 tk = 0, tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool dbg_on = dbg && blockIdx.x == 0 && threadIdx.x == 0;
-#define PK_TICK(i)                                                   \
-    if (dbg_on) {                                                    \
-        const pk_u64 now_ = wall_clock64();                          \
-        tacc[i] += now_ - tk;                                        \
-        tk = now_;                                                   \
-    }
-    if (dbg_on) tk = wall_clock64();
-    const int tid = threadIdx.x;
-    const int t = tid & (PK_ROWS - 1), q = tid / PK_ROWS;  // row slot, column phase
-    const int lane = tid & 63, wv = tid >> 6;
-    const int blk = blockIdx.x;
-    const size_t r = (size_t)j0 + (size_t)blk * PK_ROWS + t;
-    const bool in_rows = r < rows;
-    int pos = in_rows ? (int)r : -1;
-    for (int c = q; c < w; c += PK_Q) S[c * PK_ROWS + t] = in_rows ? A[r + (size_t)(j0 + c) * lda] : 0.0;
-    if (tid == 0) s_ctl[3] = 0;
-    __syncthreads();
-    PK_TICK(0)  // panel load
+static constexpr int PLIST = 2 * BASE_W;  // per base panel: BASE_W pivot rows brought to the top + <= BASE_W displaced rows
 
-    for (int k = 0; k < w; ++k) {
-        const int kabs = j0 + k;
-        const unsigned seq = seq0 + (unsigned)k;
-        const int par = (int)(seq & 1u);
-        const pk_u64 fresh = (pk_u64)(((seq >> 1) & 1u) ^ 1u) << 63;
-        // Column k of row t was last written by the row's phase-0 thread during the previous elimination:
-        // that thread may read it back at once, the other phases only after the barrier below (reading it
-        // here raced with that write whenever a co-running kernel skewed the waves).
-        double akk = 0.0;
-        // ---- block candidate for column k (waves of column phase 0)
-        if (q == 0) {
-            akk = S[k * PK_ROWS + t];
-            pk_u64 key = 0;
-            if (pos >= 0) {
-                const double a = fabs(akk);
-                if (a > 0.0) key = (pk_u64)__double_as_longlong(a);  // NaN or zero never wins (host_lu.rs: `abs > pivot_abs`)
-            }
-            pk_u64 wk;
-            unsigned wp;
-            const int wl = wave_argmax(key, (unsigned)pos, &wk, &wp);
-            if (lane == 0) {
-                r_key[wv] = wk;
-                r_pos[wv] = wp;
-                r_t[wv] = wl < 0 ? 0 : wv * 64 + wl;
-            }
-        }
-        __syncthreads();
-        if (q != 0) akk = S[k * PK_ROWS + t];  // before the phase-0 thread overwrites it with the multiplier (after the next barrier)
-        PK_TICK(1)  // block arg-max + barrier
-        if (wv == 0) {
-            pk_u64 bk = r_key[0];
-            unsigned bp = r_pos[0];
-            int bt = r_t[0];
-#pragma unroll
-            for (int i = 1; i < PK_ROWS / 64; ++i)
-                if (r_key[i] > bk || (r_key[i] == bk && bk != 0 && r_pos[i] < bp)) {
-                    bk = r_key[i];
-                    bp = r_pos[i];
-                    bt = r_t[i];
-                }
-            // ---- publish the candidate row's panel values and the record together.  Nothing orders these
-            // stores (a workgroup-scope release fence emits no s_waitcnt for global stores, and under the
-            // look-ahead's memory traffic they do land out of order), so every word carries the freshness
-            // bit itself: a value travels as two words (low / high half), and readers retry stale words.
-            const int slot = par * PK_MAXB + blk;
-            if (lane >= k && lane < w) {
-                const pk_u64 bits = (pk_u64)__double_as_longlong(S[lane * PK_ROWS + bt]);
-                pk_u64* dst = xvals + ((size_t)slot * BASE_W + lane) * 2;
-                __hip_atomic_store(dst, (bits & 0xffffffffull) | fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst + 1, (bits >> 32) | fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (lane == 0) {
-                __hip_atomic_store(&xa[slot], bk | fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&xb[slot], (pk_u64)bp | ((pk_u64)(unsigned)bt << 32) | fresh, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            }
-            PK_TICK(2)  // publish
-            // ---- poll every block's record until all carry this step's freshness bit, folding as they arrive
-            pk_u64 gk = 0;
-            unsigned gp = 0xffffffffu;
-            int gb = -1, gt = 0, bad = 0;
-            for (int b = lane; b < nblocks; b += 64) {
-                pk_u64 wa, wb;
-                int spins = 0;
-                for (;;) {
-                    wa = __hip_atomic_load(&xa[par * PK_MAXB + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    wb = __hip_atomic_load(&xb[par * PK_MAXB + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (((wa ^ fresh) >> 63) == 0 && ((wb ^ fresh) >> 63) == 0) break;
-                    if (++spins > PK_SPIN_LIMIT || __hip_atomic_load(xerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        bad = 1;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                const pk_u64 ck = wa & ~((pk_u64)1 << 63);
-                const unsigned cp = (unsigned)wb;
-                if (ck > gk || (ck == gk && gk != 0 && cp < gp)) {
-                    gk = ck;
-                    gp = cp;
-                    gb = b;
-                    gt = (int)((wb >> 32) & 0xffffu);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            bad = __any(bad) ? 1 : 0;
-            if (bad) {
-                if (lane == 0) {
-                    __hip_atomic_store(xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    s_ctl[3] = 1;
-                }
-            } else {
-                pk_u64 mk;
-                unsigned mp;
-                const int wl = wave_argmax(gk, gp, &mk, &mp);
-                PK_TICK(3)  // wait + fold
-                int grow = -1, vbad = 0;
-                if (wl >= 0) {
-                    const int wb_ = __builtin_amdgcn_readlane(gb, wl);
-                    const int wt_ = __builtin_amdgcn_readlane(gt, wl);
-                    grow = j0 + wb_ * PK_ROWS + wt_;
-                    if (lane >= k && lane < w) {
-                        const pk_u64* src = xvals + ((size_t)(par * PK_MAXB + wb_) * BASE_W + lane) * 2;
-                        pk_u64 lo, hi;
-                        int spins = 0;
-                        for (;;) {
-                            lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (((lo ^ fresh) >> 63) == 0 && ((hi ^ fresh) >> 63) == 0) break;
-                            if (++spins > PK_SPIN_LIMIT) {
-                                vbad = 1;
-                                break;
-                            }
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-                        s_prow[lane] = __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32)));
-                    }
-                }
-                vbad = __any(vbad) ? 1 : 0;
-                if (lane == 0) {
-                    s_ctl[0] = grow;
-                    s_ctl[1] = (int)mp;
-                    s_ctl[2] = (__longlong_as_double((long long)mk) <= LU_EPS) ? 1 : 0;
-                    if (vbad) {
-                        __hip_atomic_store(xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        s_ctl[3] = 1;
-                    }
-                }
-                PK_TICK(4)  // winner's row values
-            }
-        }
-        __syncthreads();
-        PK_TICK(5)  // barrier
-        if (s_ctl[3]) return;
-        // ---- eliminate column k
-        const int prow = s_ctl[0], ppos = s_ctl[1], skip = s_ctl[2];
-        if (prow < 0) {
-            // all-zero (or NaN-only) column: pivot_row stays k (host_lu.rs:38); its occupant retires as row k of U
-            if (pos == kabs) {
-                pos = -1;
-                if (q == 0) {
-                    ipiv[kabs] = kabs;
-                    prow_arr[kabs] = (int)r;
-                    atomicAdd(info, 1);
-                }
-            }
-        } else if ((int)r == prow && pos >= 0) {
-            pos = -1;  // retires as row k of U
-            if (q == 0) {
-                ipiv[kabs] = ppos;
-                prow_arr[kabs] = prow;
-                if (skip) atomicAdd(info, 1);
-            }
-        } else if (pos == kabs) {
-            pos = ppos;  // the old occupant of position k moves to the pivot's position
-        }
-        if (pos >= 0) {
-            if (skip || prow < 0) {
-                if (q == 0) S[k * PK_ROWS + t] = 0.0;
-            } else {
-                const double factor = akk / s_prow[k];
-                if (q == 0) S[k * PK_ROWS + t] = factor;
-#pragma unroll 4
-                for (int c = k + 1 + q; c < w; c += PK_Q) {
-                    const double prod = factor * s_prow[c];
-                    S[c * PK_ROWS + t] = S[c * PK_ROWS + t] - prod;
-                }
-            }
-        }
-        PK_TICK(6)  // elimination
+// Faster arg-max for the register panel: the keys are non-negative doubles, so the maximum is six v_max_f64 steps on
+// DPP-shifted copies; the (key descending, pos ascending) winner is then the only lane that holds the maximum except
+// on exact ties, and only those pay the second (minimum position) reduction.  The general routine above runs both
+// reductions back to back: ~0.27 us of dependent VALU latency with a single wave on the SIMD (measured), three times
+// per column.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int wave_argmax_f64(double key, unsigned pos, double* key_out, unsigned* pos_out) {
+    double m = key;
+    m = fmax(m, dpp_f64<0x111, 0xf>(m));
+    m = fmax(m, dpp_f64<0x112, 0xf>(m));
+    m = fmax(m, dpp_f64<0x114, 0xf>(m));
+    m = fmax(m, dpp_f64<0x118, 0xf>(m));
+    m = fmax(m, dpp_f64<0x142, 0xa>(m));
+    m = fmax(m, dpp_f64<0x143, 0xc>(m));
+    const double mx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m), 63), __builtin_amdgcn_readlane(__double2loint(m), 63));
+    *key_out = mx;
+    if (!(mx > 0.0)) {
+        *pos_out = 0xffffffffu;
+        return -1;
     }
-    __syncthreads();
-    if (in_rows) {
-        for (int c = q; c < w; c += PK_Q) A[r + (size_t)(j0 + c) * lda] = S[c * PK_ROWS + t];
-        if (q == 0) pos_of[r] = pos;
+    pk_u64 hit = __ballot(key == mx);
+    if (__popcll(hit) > 1) {  // exact tie: first position wins (host_lu.rs:38-47)
+        const unsigned pm = wave_min_u32(key == mx ? pos : 0xffffffffu);
+        hit = __ballot(key == mx && pos == pm);
     }
-    PK_TICK(7)  // write back
-    if (dbg_on)
-        for (int i = 0; i < 8; ++i) dbg[i] += tacc[i];
-#undef PK_TICK
+    const int wl = (int)__builtin_ctzll(hit);
+    *pos_out = (unsigned)__builtin_amdgcn_readlane((int)pos, wl);
+    return wl;
+}
+// the same over lanes 0..3 only (the four wave records of a block): two quad steps
+__device__ __forceinline__ int quad_argmax_f64(double key, unsigned pos, double* key_out, unsigned* pos_out) {
+    double m = key;
+    m = fmax(m, dpp_f64<0xb1, 0xf>(m));  // quad_perm [1,0,3,2]
+    m = fmax(m, dpp_f64<0x4e, 0xf>(m));  // quad_perm [2,3,0,1]
+    const double mx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m), 0), __builtin_amdgcn_readlane(__double2loint(m), 0));
+    *key_out = mx;
+    if (!(mx > 0.0)) {
+        *pos_out = 0xffffffffu;
+        return -1;
+    }
+    const int lane = threadIdx.x & 63;
+    pk_u64 hit = __ballot(lane < 4 && key == mx);
+    if (__popcll(hit) > 1) {
+        unsigned pm = 0xffffffffu;
+        for (int l = 0; l < 4; ++l)
+            if ((hit >> l) & 1) {
+                const unsigned pl = (unsigned)__builtin_amdgcn_readlane((int)pos, l);
+                pm = pl < pm ? pl : pm;
+            }
+        hit = __ballot(lane < 4 && key == mx && pos == pm);
+    }
+    const int wl = (int)__builtin_ctzll(hit);
+    *pos_out = (unsigned)__builtin_amdgcn_readlane((int)pos, wl);
+    return wl;
 }
 
-static constexpr int PLIST = 2 * BASE_W;  // per base panel: BASE_W pivot rows brought to the top + <= BASE_W displaced rows
+// ---- base panel, persistent variant 2: rows in REGISTERS, one-hop exchange ---------------------------------
+// Measured on this kernel's LDS-resident predecessor (round 1; n = 16384, in-kernel ticks): 4.0 us per column = block
+// arg-max 0.45 + publish 0.40 + wait/fold 1.85 + winner's row 0.40 + elimination 0.87, nearly independent of the
+// block count (4 blocks: 3.7 us).  The exchange itself is a memory-system hop (scripts/micro/xcd_exchange.hip: 0.7-1 us
+// per dependent hop idle, ~1.5 under the update stream's traffic, same XCD or not), so this variant removes what
+// surrounds it.  What a column costs locally is instructions per wave x waves per SIMD (the code is a serial chain of
+// short phases), so the block is FOUR waves - one per SIMD - and each thread does a whole row:
+//   * thread t owns row t of the block: its panel values sit in 64 REGISTERS (a[i] = column 4*jj + i; the window
+//     is shifted by four every four columns, so inside the four unrolled column steps every register index is
+//     static).  Elimination = one division + (63 - k) multiply-subtracts on registers with the pivot row read from LDS
+//     (broadcast reads, immediate offsets).  A first version with four threads per row (16 waves) spent 2.4 us per
+//     column in local work: every wave runs the whole per-column instruction stream, four to a SIMD.
+//   * every wave's arg-max winner dumps its row to LDS before the block barrier, wave 0 publishes the block's
+//     candidate from there (conflict-free read; the predecessor read S[lane][bt]: a 64-way bank conflict).
+//   * ONE hop for <= 32 blocks: every wave polls eight blocks' candidate rows (16-byte granules: two tagged half-words,
+//     one dwordx4 access, four in flight) while wave 0 folds the records, so the winner's row is already in LDS when
+//     it is known.  More blocks (tall panels, off the critical path under look-ahead) keep the second dependent read.
+//   * finished columns are parked in LDS and written back at their FINAL row positions (the panel's own interchange
+//     needs no k_laswp_lists launch), and the row-move list for the other columns is written by the threads that
+//     own the moves (no k_build_plist launch).
+// Pivot rule, tie-break, cut-off, lazy bookkeeping and the arithmetic (division, unfused multiply-subtract) are unchanged.
+static constexpr int P2_ROWS = 256;
+static constexpr int P2_THREADS = P2_ROWS;
+static constexpr int P2_WAVES = P2_THREADS / 64;
+static constexpr int P2_ONEHOP_MAXB = 32;
+static constexpr int P2_RB = BASE_W + 16;  // row stride of the wave candidate buffer (the dump runs in groups of 16 slots and may overshoot by 12)
+static constexpr size_t P2_LDS_DOUBLES = (size_t)BASE_W * P2_ROWS + (size_t)P2_ONEHOP_MAXB * BASE_W + (size_t)P2_WAVES * P2_RB;
+typedef unsigned int pk_v4u __attribute__((ext_vector_type(4)));
+
+struct P2Args {
+    double* A;
+    size_t lda, rows;
+    int j0, w, nblocks;
+    unsigned seq0;
+    int* xerr;
+    pk_u64* xrec;   // [2][PK_MAXB] records, 16 bytes each: |a| bits | fresh, position | row slot << 32 | fresh
+    pk_u64* xvals;  // [2][PK_MAXB][BASE_W] values, 16 bytes each: low half | tag << 32, high half | tag << 32 (tag = step + 1)
+    int* prow_arr;
+    int* ipiv;
+    int* info;
+    int2* plist;    // this panel's row-move list (PLIST entries)
+    pk_u64* dbg;
+};
+
+// 16-byte exchange granules: one write-through (sc1) store / one L1-bypassing load; each 8-byte half is self-describing,
+// so nothing depends on the two halves landing together.  Records are rewritten by every block at every step, so one
+// freshness bit per half (flipping between consecutive uses of a slot) identifies the step.  A VALUE granule is only
+// written while its column is still in play (columns >= k), i.e. an even number of slot uses can pass between two
+// writes: its halves carry the whole 32-bit step number instead (a bit would accept the previous panel's value).
+__device__ __forceinline__ void st_granule(pk_u64* p, pk_u64 w0, pk_u64 w1) {
+    const pk_v4u v = {(unsigned)w0, (unsigned)(w0 >> 32), (unsigned)w1, (unsigned)(w1 >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void ld_granule(const pk_u64* p, pk_u64& w0, pk_u64& w1) {
+    pk_v4u v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    w0 = ((pk_u64)v.y << 32) | v.x;
+    w1 = ((pk_u64)v.w << 32) | v.z;
+}
+// four granules in flight; value = (low | high << 32) when both tags match, else `ok` is cleared
+__device__ __forceinline__ void ld_values4(const pk_u64* p0, const pk_u64* p1, const pk_u64* p2, const pk_u64* p3, pk_u64 vtag,
+                                           double (&out)[4], bool& ok) {
+    pk_v4u v0, v1, v2, v3;
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
+        "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+        : "memory");
+    const unsigned tag = (unsigned)(vtag >> 32);
+    ok = v0.y == tag && v0.w == tag && v1.y == tag && v1.w == tag && v2.y == tag && v2.w == tag && v3.y == tag && v3.w == tag;
+    out[0] = __hiloint2double((int)v0.z, (int)v0.x);
+    out[1] = __hiloint2double((int)v1.z, (int)v1.x);
+    out[2] = __hiloint2double((int)v2.z, (int)v2.x);
+    out[3] = __hiloint2double((int)v3.z, (int)v3.x);
+}
+
+struct P2Lds {
+    double* fin;     // [BASE_W][P2_ROWS] finished columns
+    double* cand;    // [P2_ONEHOP_MAXB][BASE_W] candidate rows of the other blocks (slot 0 only beyond 32 blocks)
+    double* rowbuf;  // [P2_WAVES][BASE_W] every wave's candidate row
+    double* r_key;
+    unsigned* r_pos;
+    int* r_t;
+    int* s_ctl;      // pivot row, pivot position, skip, error, cand slot
+};
+struct P2Ticks {  // developer instrumentation (RMHIP_LU_PANEL_DEBUG=1): 100 MHz wall-clock ticks per phase, block 0 thread 0
+    pk_u64 tk, acc[16];
+};
+
+// one column (k = 4*jj + KK; its values sit in a[KK]).  Returns false when the exchange timed out (s_ctl[3]).
+template <int KK, bool DBG>
+__device__ __forceinline__ bool p2_column(const P2Args& g, const P2Lds& L, double (&a)[BASE_W], int& pos, int& retk, const int jj,
+                                         const size_t r, P2Ticks* ticks) {
+#define P2_TICK(i)                                              \
+    if (DBG && blockIdx.x == 0 && threadIdx.x == 0) {           \
+        const pk_u64 now_ = wall_clock64();                     \
+        ticks->acc[i] += now_ - ticks->tk;                      \
+        ticks->tk = now_;                                       \
+    }
+    const int k = 4 * jj + KK;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int blk = blockIdx.x;
+    const int kabs = g.j0 + k;
+    const unsigned seq = g.seq0 + (unsigned)k;
+    const int par = (int)(seq & 1u);
+    const pk_u64 fresh = (pk_u64)(((seq >> 1) & 1u) ^ 1u) << 63;
+    const pk_u64 topbit = (pk_u64)1 << 63;
+    const pk_u64 vtag = (pk_u64)(seq + 1u) << 32;  // value granules: exact step tag in the upper half of both words
+    // ---- wave candidate for column k
+    const double akk = a[KK];
+    double key = 0.0;
+    if (pos >= 0) {
+        const double av = fabs(akk);
+        if (av > 0.0) key = av;  // NaN or zero never wins (host_lu.rs: `abs > pivot_abs`)
+    }
+    double wk;
+    unsigned wp;
+    const int wl = wave_argmax_f64(key, (unsigned)pos, &wk, &wp);
+    P2_TICK(8)
+    if (lane == wl) {  // the wave's winner parks its row (the live part of the register window)
+        double* dst = L.rowbuf + wv * P2_RB + 4 * jj;
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+            if (jj < 16 - 4 * G) {  // uniform (an `if`, not a `break`: a loop with an early exit is not unrolled and the window would go to scratch)
+#pragma unroll
+                for (int u = 0; u < 16; ++u) dst[16 * G + u] = a[16 * G + u];
+            }
+        }
+    }
+    if (lane == 0) {
+        L.r_key[wv] = wk;
+        L.r_pos[wv] = wp;
+        L.r_t[wv] = wl < 0 ? 0 : wv * 64 + wl;
+    }
+    P2_TICK(9)
+    __syncthreads();
+    P2_TICK(1)  // wave arg-max + barrier
+    const bool onehop = g.nblocks <= P2_ONEHOP_MAXB;
+    int bad = 0;
+    if (wv == 0) {
+        // ---- block candidate = best of the wave records; publish its row and the record (nothing orders the stores:
+        // every half word is self-describing and readers retry stale ones)
+        const double k4 = lane < P2_WAVES ? L.r_key[lane] : 0.0;
+        const unsigned p4 = lane < P2_WAVES ? L.r_pos[lane] : 0xffffffffu;
+        double bkd;
+        unsigned bp;
+        const int bl = quad_argmax_f64(k4, p4, &bkd, &bp);
+        const pk_u64 bk = bl < 0 ? 0 : (pk_u64)__double_as_longlong(bkd);
+        const int bw = bl < 0 ? 0 : bl;
+        const int bt = L.r_t[bw];
+        const size_t slot = (size_t)par * PK_MAXB + blk;
+        if (lane == 0) st_granule(g.xrec + slot * 2, bk | fresh, (pk_u64)bp | ((pk_u64)(unsigned)bt << 32) | fresh);
+        if (lane >= k && lane < g.w) {
+            const pk_u64 bits = (pk_u64)__double_as_longlong(L.rowbuf[bw * P2_RB + lane]);
+            st_granule(g.xvals + (slot * BASE_W + lane) * 2, (bits & 0xffffffffull) | vtag, (bits >> 32) | vtag);
+        }
+        P2_TICK(2)  // publish
+    }
+    if (onehop && lane >= k && lane < g.w) {
+        // ---- wave wv fetches the candidate rows of blocks wv, wv + 4, ... (four loads in flight per round)
+#pragma unroll
+        for (int round = 0; round < P2_ONEHOP_MAXB / (4 * P2_WAVES); ++round) {
+            const int b0 = wv + 4 * P2_WAVES * round;
+            if (b0 >= g.nblocks) break;  // uniform
+            const pk_u64* base = g.xvals + ((size_t)par * PK_MAXB * BASE_W + lane) * 2;
+            const pk_u64* ptr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = b0 + P2_WAVES * u;
+                ptr[u] = base + (size_t)(b < g.nblocks ? b : b0) * BASE_W * 2;
+            }
+            double vals[4];
+            bool ok;
+            int spins = 0;
+            for (;;) {
+                ld_values4(ptr[0], ptr[1], ptr[2], ptr[3], vtag, vals, ok);
+                if (ok) break;
+                if (++spins > PK_SPIN_LIMIT || __hip_atomic_load(g.xerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    bad = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = b0 + P2_WAVES * u;
+                if (b < g.nblocks) L.cand[b * BASE_W + lane] = vals[u];
+            }
+        }
+    }
+    if (wv == 0) {
+        // ---- fold every block's record as it arrives
+        double gk = 0.0;
+        unsigned gp = 0xffffffffu;
+        int gb = -1, gt = 0;
+        for (int b = lane; b < g.nblocks; b += 64) {
+            pk_u64 wa, wb;
+            int spins = 0;
+            for (;;) {
+                ld_granule(g.xrec + ((size_t)par * PK_MAXB + b) * 2, wa, wb);
+                if ((((wa ^ fresh) | (wb ^ fresh)) >> 63) == 0) break;
+                if (++spins > PK_SPIN_LIMIT || __hip_atomic_load(g.xerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    bad = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const double ck = __longlong_as_double((long long)(wa & ~topbit));  // |a| >= 0, never NaN (NaN never becomes a key)
+            const unsigned cp = (unsigned)wb;
+            if (ck > gk || (ck == gk && gk != 0.0 && cp < gp)) {
+                gk = ck;
+                gp = cp;
+                gb = b;
+                gt = (int)((wb >> 32) & 0xffffu);
+            }
+        }
+        double mk;
+        unsigned mp;
+        const int wl2 = wave_argmax_f64(gk, gp, &mk, &mp);
+        P2_TICK(3)  // wait + fold
+        int grow = -1, sel = 0;
+        if (wl2 >= 0) {
+            const int wb_ = __builtin_amdgcn_readlane(gb, wl2);
+            const int wt_ = __builtin_amdgcn_readlane(gt, wl2);
+            grow = g.j0 + wb_ * P2_ROWS + wt_;
+            sel = wb_;
+            if (!onehop) {
+                sel = 0;
+                if (lane >= k && lane < g.w) {
+                    const pk_u64* src = g.xvals + (((size_t)par * PK_MAXB + wb_) * BASE_W + lane) * 2;
+                    pk_u64 lo, hi;
+                    int spins = 0;
+                    for (;;) {
+                        ld_granule(src, lo, hi);
+                        if ((((lo ^ vtag) | (hi ^ vtag)) >> 32) == 0) break;
+                        if (++spins > PK_SPIN_LIMIT) {
+                            bad = 1;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    L.cand[lane] = __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32)));
+                }
+            }
+        }
+        if (lane == 0) {
+            L.s_ctl[0] = grow;
+            L.s_ctl[1] = (int)mp;
+            L.s_ctl[2] = (mk <= LU_EPS) ? 1 : 0;
+            L.s_ctl[4] = sel;
+        }
+        P2_TICK(4)  // winner's row (beyond 32 blocks)
+    }
+    if (__any(bad)) {
+        if (lane == 0) {
+            __hip_atomic_store(g.xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            L.s_ctl[3] = 1;
+        }
+    }
+    __syncthreads();
+    P2_TICK(5)  // barrier
+    if (L.s_ctl[3]) return false;
+    // ---- eliminate column k
+    const int prow = L.s_ctl[0], ppos = L.s_ctl[1], skip = L.s_ctl[2];
+    const double* pr = L.cand + L.s_ctl[4] * BASE_W + 4 * jj;  // pr[i] pairs with a[i]
+    if (prow < 0) {
+        // all-zero (or NaN-only) column: pivot_row stays k (host_lu.rs:38); its occupant retires as row k of U
+        if (pos == kabs) {
+            pos = -1;
+            retk = k;
+            g.ipiv[kabs] = kabs;
+            g.prow_arr[kabs] = (int)r;
+            g.plist[k] = (int)r != kabs ? make_int2(kabs, (int)r) : make_int2(-1, -1);
+            atomicAdd(g.info, 1);
+        }
+    } else if ((int)r == prow && pos >= 0) {
+        pos = -1;  // retires as row k of U
+        retk = k;
+        g.ipiv[kabs] = ppos;
+        g.prow_arr[kabs] = prow;
+        g.plist[k] = prow != kabs ? make_int2(kabs, prow) : make_int2(-1, -1);
+        if (skip) atomicAdd(g.info, 1);
+    } else if (pos == kabs) {
+        pos = ppos;  // the old occupant of position k moves to the pivot's position
+    }
+    P2_TICK(10)
+    if (pos >= 0) {
+        if (skip || prow < 0) {
+            a[KK] = 0.0;
+        } else {
+            // Dead slots (columns >= w, the stale tail of the shifted window) hold zeros / old values and meet whatever
+            // the pivot buffer holds there; they are never stored.  No branch inside: with one wave per SIMD the
+            // compiler's load/compute software pipeline is what hides the LDS latency.
+            double pr0[8];  // the first batch holds the pivot itself
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pr0[u] = pr[u];
+            const double factor = akk / pr0[KK];
+            a[KK] = factor;
+            // One wave per SIMD: nothing else fills the slots behind a dependent pair, and the scheduler (register
+            // pressure mode at > 200 VGPRs) emits every product right in front of the subtraction that consumes it - a
+            // full fp64 latency each - and keeps two LDS reads in flight.  Hand-made pipeline instead: batches of eight
+            // columns, the pivot values fetched two batches ahead, eight independent products, then eight subtractions.
+            double pb[3][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pb[1][u] = pr[8 + u];
+#pragma unroll
+            for (int st = 0; st < BASE_W / 8; ++st) {
+                if (st + 2 < BASE_W / 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) pb[(st + 2) % 3][u] = pr[8 * (st + 2) + u];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                double prod[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) prod[u] = factor * (st == 0 ? pr0[u] : pb[st % 3][u]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (8 * st + u > KK) a[8 * st + u] = a[8 * st + u] - prod[u];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    P2_TICK(6)  // elimination
+    return true;
+#undef P2_TICK
+}
+
+template <bool DBG>
+__global__ void __launch_bounds__(P2_THREADS) k_lu_panel2(const P2Args g) {
+    extern __shared__ double p2_lds[];
+    __shared__ double r_key[P2_WAVES];
+    __shared__ unsigned r_pos[P2_WAVES];
+    __shared__ int r_t[P2_WAVES];
+    __shared__ int s_ctl[8];
+    __shared__ P2Ticks s_ticks;  // ticks live in LDS
+    P2Lds L;
+    L.fin = p2_lds;
+    L.cand = L.fin + (size_t)BASE_W * P2_ROWS;
+    L.rowbuf = L.cand + (size_t)P2_ONEHOP_MAXB * BASE_W;
+    L.r_key = r_key;
+    L.r_pos = r_pos;
+    L.r_t = r_t;
+    L.s_ctl = s_ctl;
+    const bool dbg_on = DBG && blockIdx.x == 0 && threadIdx.x == 0;
+    if (dbg_on) {
+        for (int i = 0; i < 16; ++i) s_ticks.acc[i] = 0;
+        s_ticks.tk = wall_clock64();
+    }
+    const int t = threadIdx.x;  // row slot
+    const size_t r = (size_t)g.j0 + (size_t)blockIdx.x * P2_ROWS + t;
+    const bool in_rows = r < g.rows;
+    int pos = in_rows ? (int)r : -1, retk = -1;
+    double a[BASE_W];
+#pragma unroll
+    for (int c = 0; c < BASE_W; ++c) a[c] = (in_rows && c < g.w) ? g.A[r + (size_t)(g.j0 + c) * g.lda] : 0.0;
+    if (t < 8) s_ctl[t] = 0;
+    for (int i = t; i < P2_ONEHOP_MAXB * BASE_W + P2_WAVES * P2_RB; i += P2_THREADS) L.cand[i] = 0.0;  // cand and rowbuf are contiguous
+    __syncthreads();
+    if (dbg_on) {
+        const pk_u64 now_ = wall_clock64();
+        s_ticks.acc[0] += now_ - s_ticks.tk;
+        s_ticks.tk = now_;
+    }
+    const int ngroups = (g.w + 3) >> 2;
+    for (int jj = 0; jj < ngroups; ++jj) {
+        if (!p2_column<0, DBG>(g, L, a, pos, retk, jj, r, &s_ticks)) return;
+        if (4 * jj + 1 < g.w && !p2_column<1, DBG>(g, L, a, pos, retk, jj, r, &s_ticks)) return;
+        if (4 * jj + 2 < g.w && !p2_column<2, DBG>(g, L, a, pos, retk, jj, r, &s_ticks)) return;
+        if (4 * jj + 3 < g.w && !p2_column<3, DBG>(g, L, a, pos, retk, jj, r, &s_ticks)) return;
+        // columns 4jj .. 4jj+3 are final: park them, shift the register window by four
+#pragma unroll
+        for (int i = 0; i < 4; ++i) L.fin[(size_t)(4 * jj + i) * P2_ROWS + t] = a[i];
+#pragma unroll
+        for (int i = 0; i < BASE_W - 4; ++i) a[i] = a[i + 4];
+    }
+    __syncthreads();
+    // ---- write back at the FINAL positions (pivot rows to the top, displaced rows to where the bookkeeping left
+    // them): the panel's own interchange.  Every block reads only its own LDS, and no block gets here before all
+    // blocks took part in the last exchange, i.e. long after they loaded their rows.
+    if (in_rows) {
+        const size_t fpos = retk >= 0 ? (size_t)(g.j0 + retk) : (size_t)pos;
+        for (int c = 0; c < g.w; ++c) g.A[fpos + (size_t)(g.j0 + c) * g.lda] = L.fin[(size_t)c * P2_ROWS + t];
+    }
+    // ---- the panel's row moves for every other column: slot k (k < w) was written by the thread that retired at
+    // step k; slots BASE_W + i are the top rows that were displaced instead of retired
+    if (blockIdx.x == 0 && t < BASE_W) {
+        int2 e = make_int2(-1, -1);
+        if (t < g.w && pos >= 0 && pos != (int)r) e = make_int2(pos, (int)r);
+        g.plist[BASE_W + t] = e;
+        if (t >= g.w) g.plist[t] = make_int2(-1, -1);
+    }
+    if (dbg_on) {
+        s_ticks.acc[7] += wall_clock64() - s_ticks.tk;
+        for (int i = 0; i < 16; ++i) g.dbg[i] += s_ticks.acc[i];
+    }
+}
 
 // Turn the lazy bookkeeping of one finished base panel [j0, c1) into a list of row moves
 // new[dst] = old[src]: position k receives the pivot row prow[k]; a top-block row that was not
@@ -843,26 +1077,32 @@ static int getrf_rec(LuState& s, size_t j0, size_t w) {
     if (w == 0 || j0 >= s.rows) return RMHIP_OK;
     if (w <= (size_t)BASE_W) {
         const size_t c1 = j0 + w;  // j0 + w <= min(rows, cols) always holds (see lu_factor_device)
-        const size_t prow_ = (size_t)s.panel_rows;
-        const size_t nbp = (s.rows - j0 + prow_ - 1) / prow_;
+        const size_t nbp = (s.rows - j0 + P2_ROWS - 1) / P2_ROWS;
         if (s.persistent && nbp <= (size_t)PK_MAXB && nbp <= (size_t)s.c->num_cus && !(lu_skip_mask() & 1)) {
-            const size_t lds_bytes = (size_t)(BASE_W * prow_ + BASE_W) * sizeof(double);
-            if (s.panel_rows == 256)
-                hipLaunchKernelGGL(k_lu_panel<256>, dim3((unsigned)nbp), dim3(256 * PK_Q), lds_bytes, s.c->stream, s.A, s.lda,
-                                   s.rows, (int)j0, (int)w, (int)nbp, s.xbase, s.xerr, s.xa, s.xb, s.xvals, s.pos_of, s.prow,
-                                   s.ipiv, s.info, s.xdbg);
-            else
-                hipLaunchKernelGGL(k_lu_panel<128>, dim3((unsigned)nbp), dim3(128 * PK_Q), lds_bytes, s.c->stream, s.A, s.lda,
-                                   s.rows, (int)j0, (int)w, (int)nbp, s.xbase, s.xerr, s.xa, s.xb, s.xvals, s.pos_of, s.prow,
-                                   s.ipiv, s.info, s.xdbg);
+            // one launch factors the panel, interchanges its own columns and leaves the row-move list for the others
+            const size_t pid = s.panel_start->size();
+            P2Args g;
+            g.A = s.A;
+            g.lda = s.lda;
+            g.rows = s.rows;
+            g.j0 = (int)j0;
+            g.w = (int)w;
+            g.nblocks = (int)nbp;
+            g.seq0 = s.xbase;
+            g.xerr = s.xerr;
+            g.xrec = s.xrec;
+            g.xvals = s.xvals;
+            g.prow_arr = s.prow;
+            g.ipiv = s.ipiv;
+            g.info = s.info;
+            g.plist = s.plist + pid * PLIST;
+            g.dbg = s.xdbg;
+            if (s.xdbg) hipLaunchKernelGGL(k_lu_panel2<true>, dim3((unsigned)nbp), dim3(P2_THREADS), P2_LDS_DOUBLES * sizeof(double), s.c->stream, g);
+            else hipLaunchKernelGGL(k_lu_panel2<false>, dim3((unsigned)nbp), dim3(P2_THREADS), P2_LDS_DOUBLES * sizeof(double), s.c->stream, g);
             RMHIP_TRY(launch_check(s.c));
             s.xbase += (unsigned)w;
-            const size_t pid = s.panel_start->size();
             s.panel_start->push_back(j0);
-            hipLaunchKernelGGL(k_build_plist, dim3(1), dim3(PLIST), 0, s.c->stream, (int)j0, (int)c1, s.pos_of, s.prow,
-                               s.plist + pid * PLIST);
-            RMHIP_TRY(launch_check(s.c));
-            return laswp(s, j0, c1, j0, c1);
+            return RMHIP_OK;
         }
         const size_t nb = (s.rows - j0 + PANEL_ROWS - 1) / PANEL_ROWS;  // one block per PANEL_ROWS rows
         if (nb > (size_t)MAX_PANEL_BLOCKS)
@@ -1043,21 +1283,20 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     panel_start.reserve(max_panels);
     LuState s{c, A, rows, cols, lda, ipiv, info, (int*)(blk + off_posof), (int*)(blk + off_rowat), (int*)(blk + off_prow),
               (int2*)(blk + off_plist), &panel_start, (double*)(blk + off_abs), (int*)(blk + off_pos), (int*)(blk + off_row),
-              (int*)(blk + off_xctl + 16), (unsigned long long*)(blk + off_xa), (unsigned long long*)(blk + off_xb),
-              (unsigned long long*)(blk + off_xvals), 0u, true, nullptr, 256};
+              (int*)(blk + off_xctl + 16), (unsigned long long*)(blk + off_xa), (unsigned long long*)(blk + off_xvals), 0u, true,
+              nullptr};
     {
         // persistent panels need >64 KiB of dynamic LDS and all their blocks co-resident (one per CU)
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)k_lu_panel<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)((BASE_W * 256 + BASE_W) * sizeof(double)));
-            (void)hipFuncSetAttribute((const void*)k_lu_panel<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)((BASE_W * 128 + BASE_W) * sizeof(double)));
+            (void)hipFuncSetAttribute((const void*)k_lu_panel2<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(P2_LDS_DOUBLES * sizeof(double)));
+            (void)hipFuncSetAttribute((const void*)k_lu_panel2<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(P2_LDS_DOUBLES * sizeof(double)));
             attr_set = true;
         }
         const char* pm = std::getenv("RMHIP_LU_PANEL");  // "columns" selects the one-launch-per-column kernels
         if ((pm && pm[0] == 'c') || c->lu_conservative) s.persistent = false;
-        if (const char* pr = std::getenv("RMHIP_LU_PANEL_ROWS")) s.panel_rows = std::atoi(pr) == 128 ? 128 : 256;  // developer knob
         const char* dbgenv = std::getenv("RMHIP_LU_PANEL_DEBUG");
         if (dbgenv && dbgenv[0] == '1') s.xdbg = (unsigned long long*)(blk + off_xctl + 64);
     }
@@ -1104,9 +1343,10 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
         if (s.xdbg) {
             unsigned long long h[16];
             if (hipMemcpy(h, s.xdbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-                static const char* names[8] = {"load", "argmax+sync", "publish", "wait+fold", "winner vals", "sync",
-                                               "eliminate", "write back"};
-                for (int i = 0; i < 8; ++i)
+                static const char* names[16] = {"load", "argmax+sync", "publish", "wait+fold", "winner vals", "sync",
+                                                "eliminate", "park+write back", "wave argmax", "row dump", "bookkeeping", "pivot row",
+                                                "division", "-", "-", "-"};
+                for (int i = 0; i < 13; ++i)
                     std::fprintf(stderr, "[lu panel] %-12s %10.1f us total  %7.3f us/column\n", names[i], h[i] * 0.01,
                                  kmin ? h[i] * 0.01 / (double)kmin : 0.0);
             }
