@@ -368,6 +368,7 @@ struct P2Args {
     double* A;
     size_t lda, rows;
     int j0, w, nblocks;
+    int onehop_max;  // one-hop exchange up to this many blocks (<= P2_ONEHOP_MAXB)
     unsigned seq0;
     int* xerr;
     pk_u64* xrec;   // [2][PK_MAXB] records, 16 bytes each: |a| bits | fresh, position | row slot << 32 | fresh
@@ -415,46 +416,51 @@ __device__ __forceinline__ void ld_values4(const pk_u64* p0, const pk_u64* p1, c
 struct P2Lds {
     double* fin;     // [BASE_W][P2_ROWS] finished columns
     double* cand;    // [P2_ONEHOP_MAXB][BASE_W] candidate rows of the other blocks (slot 0 only beyond 32 blocks)
-    double* rowbuf;  // [P2_WAVES][BASE_W] every wave's candidate row
+    double* rowbuf;  // [P2_WAVES][P2_RB] every wave's candidate row
     double* r_key;
     unsigned* r_pos;
     int* r_t;
-    int* s_ctl;      // pivot row, pivot position, skip, error, cand slot
+    int* s_ctl;      // {pivot row, pivot position, skip | error << 1 | cand slot << 8, -}
 };
 struct P2Ticks {  // developer instrumentation (RMHIP_LU_PANEL_DEBUG=1): 100 MHz wall-clock ticks per phase, block 0 thread 0
     pk_u64 tk, acc[16];
 };
-
-// one column (k = 4*jj + KK; its values sit in a[KK]).  Returns false when the exchange timed out (s_ctl[3]).
-template <int KK, bool DBG>
-__device__ __forceinline__ bool p2_column(const P2Args& g, const P2Lds& L, double (&a)[BASE_W], int& pos, int& retk, const int jj,
-                                         const size_t r, P2Ticks* ticks) {
 #define P2_TICK(i)                                              \
     if (DBG && blockIdx.x == 0 && threadIdx.x == 0) {           \
         const pk_u64 now_ = wall_clock64();                     \
         ticks->acc[i] += now_ - ticks->tk;                      \
         ticks->tk = now_;                                       \
     }
-    const int k = 4 * jj + KK;
+
+// ---- the column loop is software pipelined: the exchange for column k+1 runs under the bulk of elimination k.
+// Once the pivot row of column k is known, every thread updates ONLY column k+1 of its row, the block picks its
+// candidate for k+1 and publishes it, and the remaining columns are eliminated while the records travel.  A
+// candidate row is parked BEFORE its columns beyond k+1 saw pivot row k; wave 0 applies that update to the parked
+// copy (one multiply-subtract per lane, the same two operations the owning thread performs later, so the published
+// values are bit-identical to what the row will hold).
+//
+// p2_select<NS>: pick and publish the block's candidate for column kn (its values sit in window slot NS), then - after
+// `rest` ran (the elimination the exchange hides) - collect every block's candidate and leave the winner in
+// s_ctl / cand.  FIX: the parked row still needs pivot row kn-1 (factor in its slot NS-1) applied beyond column kn.
+template <int NS, bool FIX, bool DBG, class Rest>
+__device__ __forceinline__ bool p2_select(const P2Args& g, const P2Lds& L, double (&a)[BASE_W + 4], const int pos, const int jj, const int kn,
+                                         const int fix_skip, const double* fix_row, P2Ticks* ticks, Rest rest) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int blk = blockIdx.x;
-    const int kabs = g.j0 + k;
-    const unsigned seq = g.seq0 + (unsigned)k;
+    const unsigned seq = g.seq0 + (unsigned)kn;
     const int par = (int)(seq & 1u);
     const pk_u64 fresh = (pk_u64)(((seq >> 1) & 1u) ^ 1u) << 63;
     const pk_u64 topbit = (pk_u64)1 << 63;
     const pk_u64 vtag = (pk_u64)(seq + 1u) << 32;  // value granules: exact step tag in the upper half of both words
-    // ---- wave candidate for column k
-    const double akk = a[KK];
+    // ---- wave candidate
     double key = 0.0;
     if (pos >= 0) {
-        const double av = fabs(akk);
+        const double av = fabs(a[NS]);
         if (av > 0.0) key = av;  // NaN or zero never wins (host_lu.rs: `abs > pivot_abs`)
     }
     double wk;
     unsigned wp;
     const int wl = wave_argmax_f64(key, (unsigned)pos, &wk, &wp);
-    P2_TICK(8)
     if (lane == wl) {  // the wave's winner parks its row (the live part of the register window)
         double* dst = L.rowbuf + wv * P2_RB + 4 * jj;
 #pragma unroll
@@ -470,11 +476,8 @@ __device__ __forceinline__ bool p2_column(const P2Args& g, const P2Lds& L, doubl
         L.r_pos[wv] = wp;
         L.r_t[wv] = wl < 0 ? 0 : wv * 64 + wl;
     }
-    P2_TICK(9)
     __syncthreads();
-    P2_TICK(1)  // wave arg-max + barrier
-    const bool onehop = g.nblocks <= P2_ONEHOP_MAXB;
-    int bad = 0;
+    P2_TICK(1)  // wave arg-max + park + barrier
     if (wv == 0) {
         // ---- block candidate = best of the wave records; publish its row and the record (nothing orders the stores:
         // every half word is self-describing and readers retry stale ones)
@@ -488,13 +491,24 @@ __device__ __forceinline__ bool p2_column(const P2Args& g, const P2Lds& L, doubl
         const int bt = L.r_t[bw];
         const size_t slot = (size_t)par * PK_MAXB + blk;
         if (lane == 0) st_granule(g.xrec + slot * 2, bk | fresh, (pk_u64)bp | ((pk_u64)(unsigned)bt << 32) | fresh);
-        if (lane >= k && lane < g.w) {
-            const pk_u64 bits = (pk_u64)__double_as_longlong(L.rowbuf[bw * P2_RB + lane]);
+        if (lane >= kn && lane < g.w) {
+            double v = L.rowbuf[bw * P2_RB + lane];
+            if (FIX && !fix_skip && lane > kn) {
+                const double fw = L.rowbuf[bw * P2_RB + kn - 1];  // the row's multiplier for pivot row kn-1
+                const double prod = fw * fix_row[lane];
+                v = v - prod;
+            }
+            const pk_u64 bits = (pk_u64)__double_as_longlong(v);
             st_granule(g.xvals + (slot * BASE_W + lane) * 2, (bits & 0xffffffffull) | vtag, (bits >> 32) | vtag);
         }
         P2_TICK(2)  // publish
     }
-    if (onehop && lane >= k && lane < g.w) {
+    rest();
+    P2_TICK(6)  // elimination under the exchange
+    if (FIX) __syncthreads();  // every wave is done with the previous pivot row in `cand`
+    const bool onehop = g.nblocks <= g.onehop_max;
+    int bad = 0;
+    if (onehop && lane >= kn && lane < g.w) {
         // ---- wave wv fetches the candidate rows of blocks wv, wv + 4, ... (four loads in flight per round)
 #pragma unroll
         for (int round = 0; round < P2_ONEHOP_MAXB / (4 * P2_WAVES); ++round) {
@@ -564,7 +578,7 @@ __device__ __forceinline__ bool p2_column(const P2Args& g, const P2Lds& L, doubl
             sel = wb_;
             if (!onehop) {
                 sel = 0;
-                if (lane >= k && lane < g.w) {
+                if (lane >= kn && lane < g.w) {
                     const pk_u64* src = g.xvals + (((size_t)par * PK_MAXB + wb_) * BASE_W + lane) * 2;
                     pk_u64 lo, hi;
                     int spins = 0;
@@ -584,84 +598,95 @@ __device__ __forceinline__ bool p2_column(const P2Args& g, const P2Lds& L, doubl
         if (lane == 0) {
             L.s_ctl[0] = grow;
             L.s_ctl[1] = (int)mp;
-            L.s_ctl[2] = (mk <= LU_EPS) ? 1 : 0;
-            L.s_ctl[4] = sel;
+            L.s_ctl[2] = (L.s_ctl[2] & 2) | ((mk <= LU_EPS || grow < 0) ? 1 : 0) | (sel << 8);
         }
         P2_TICK(4)  // winner's row (beyond 32 blocks)
     }
     if (__any(bad)) {
         if (lane == 0) {
             __hip_atomic_store(g.xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            L.s_ctl[3] = 1;
+            atomicOr(&L.s_ctl[3], 1);
         }
     }
     __syncthreads();
     P2_TICK(5)  // barrier
-    if (L.s_ctl[3]) return false;
-    // ---- eliminate column k
-    const int prow = L.s_ctl[0], ppos = L.s_ctl[1], skip = L.s_ctl[2];
-    const double* pr = L.cand + L.s_ctl[4] * BASE_W + 4 * jj;  // pr[i] pairs with a[i]
+    return L.s_ctl[3] == 0;
+}
+
+// Rows of pivot-row multiply-subtracts on the register window, slots [FIRST, BASE_W + 4): hand-made pipeline (one wave
+// per SIMD: nothing else fills the slots behind a dependent pair, and the scheduler - in register-pressure mode at > 200
+// VGPRs - would emit every product right in front of the subtraction that consumes it and keep two LDS reads in
+// flight): batches of eight columns, the pivot values fetched two batches ahead, eight independent products, then
+// eight subtractions.  Dead slots (columns >= w, the stale tail of the shifted window) meet whatever the pivot buffer
+// holds there; they are never stored.
+template <int FIRST>
+__device__ __forceinline__ void p2_update(double (&a)[BASE_W + 4], const double factor, const double* pr) {
+    constexpr int NB = (BASE_W + 4 + 7) / 8;  // 9 batches cover slots 0..71 (a has 68: the last batch is clipped)
+    double pb[3][8];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (8 * st + u < BASE_W + 4) pb[st][u] = pr[8 * st + u];
+#pragma unroll
+    for (int st = 0; st < NB; ++st) {
+        if (8 * st + 7 < FIRST) continue;
+        if (st + 2 < NB) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (8 * (st + 2) + u < BASE_W + 4) pb[(st + 2) % 3][u] = pr[8 * (st + 2) + u];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        double prod[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) prod[u] = factor * pb[st % 3][u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (8 * st + u >= FIRST && 8 * st + u < BASE_W + 4) a[8 * st + u] = a[8 * st + u] - prod[u];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// one column (k = 4*jj + KK, window slot KK): its pivot is in s_ctl / cand; retire / displace rows, form the
+// multipliers, update column k+1, run the selection for k+1 with the bulk elimination under its exchange.
+template <int KK, bool DBG>
+__device__ __forceinline__ bool p2_column(const P2Args& g, const P2Lds& L, double (&a)[BASE_W + 4], int& pos, int& retk, int& rpiv,
+                                         const int jj, const size_t r, P2Ticks* ticks) {
+    const int k = 4 * jj + KK;
+    const int kabs = g.j0 + k;
+    const int prow = L.s_ctl[0], ppos = L.s_ctl[1], flags = L.s_ctl[2];
+    const int skip = flags & 1;  // |pivot| <= 1e-12, or an all-zero / NaN-only column: no elimination (host_lu.rs:54-59)
+    const double* pr = L.cand + (flags >> 8) * BASE_W + 4 * jj;  // pr[i] pairs with a[i]
     if (prow < 0) {
         // all-zero (or NaN-only) column: pivot_row stays k (host_lu.rs:38); its occupant retires as row k of U
         if (pos == kabs) {
             pos = -1;
             retk = k;
-            g.ipiv[kabs] = kabs;
-            g.prow_arr[kabs] = (int)r;
-            g.plist[k] = (int)r != kabs ? make_int2(kabs, (int)r) : make_int2(-1, -1);
-            atomicAdd(g.info, 1);
+            rpiv = kabs | 0x40000000;  // bit 30: counts as a singular pivot
         }
     } else if ((int)r == prow && pos >= 0) {
         pos = -1;  // retires as row k of U
         retk = k;
-        g.ipiv[kabs] = ppos;
-        g.prow_arr[kabs] = prow;
-        g.plist[k] = prow != kabs ? make_int2(kabs, prow) : make_int2(-1, -1);
-        if (skip) atomicAdd(g.info, 1);
+        rpiv = ppos | (skip ? 0x40000000 : 0);
     } else if (pos == kabs) {
         pos = ppos;  // the old occupant of position k moves to the pivot's position
     }
-    P2_TICK(10)
-    if (pos >= 0) {
-        if (skip || prow < 0) {
-            a[KK] = 0.0;
-        } else {
-            // Dead slots (columns >= w, the stale tail of the shifted window) hold zeros / old values and meet whatever
-            // the pivot buffer holds there; they are never stored.  No branch inside: with one wave per SIMD the
-            // compiler's load/compute software pipeline is what hides the LDS latency.
-            double pr0[8];  // the first batch holds the pivot itself
-#pragma unroll
-            for (int u = 0; u < 8; ++u) pr0[u] = pr[u];
-            const double factor = akk / pr0[KK];
-            a[KK] = factor;
-            // One wave per SIMD: nothing else fills the slots behind a dependent pair, and the scheduler (register
-            // pressure mode at > 200 VGPRs) emits every product right in front of the subtraction that consumes it - a
-            // full fp64 latency each - and keeps two LDS reads in flight.  Hand-made pipeline instead: batches of eight
-            // columns, the pivot values fetched two batches ahead, eight independent products, then eight subtractions.
-            double pb[3][8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) pb[1][u] = pr[8 + u];
-#pragma unroll
-            for (int st = 0; st < BASE_W / 8; ++st) {
-                if (st + 2 < BASE_W / 8) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) pb[(st + 2) % 3][u] = pr[8 * (st + 2) + u];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                double prod[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) prod[u] = factor * (st == 0 ? pr0[u] : pb[st % 3][u]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (8 * st + u > KK) a[8 * st + u] = a[8 * st + u] - prod[u];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+    const bool act = pos >= 0;
+    double factor = 0.0;
+    if (!skip) factor = a[KK] / pr[KK];
+    if (act) a[KK] = factor;  // 0.0 when the step is skipped (host_lu.rs:55-57)
+    P2_TICK(10)  // bookkeeping + division
+    const bool more = k + 1 < g.w;
+    auto rest = [&]() {
+        if (act && !skip) p2_update<KK + 2>(a, factor, pr);
+    };
+    if (!more) return true;
+    if (act && !skip) {
+        const double prod = factor * pr[KK + 1];
+        a[KK + 1] = a[KK + 1] - prod;
     }
-    P2_TICK(6)  // elimination
-    return true;
-#undef P2_TICK
+    return p2_select<KK + 1, true, DBG>(g, L, a, pos, jj, k + 1, skip, L.cand + (flags >> 8) * BASE_W, ticks, rest);
 }
 
 template <bool DBG>
@@ -680,6 +705,7 @@ __global__ void __launch_bounds__(P2_THREADS) k_lu_panel2(const P2Args g) {
     L.r_pos = r_pos;
     L.r_t = r_t;
     L.s_ctl = s_ctl;
+    P2Ticks* ticks = &s_ticks;
     const bool dbg_on = DBG && blockIdx.x == 0 && threadIdx.x == 0;
     if (dbg_on) {
         for (int i = 0; i < 16; ++i) s_ticks.acc[i] = 0;
@@ -688,40 +714,49 @@ __global__ void __launch_bounds__(P2_THREADS) k_lu_panel2(const P2Args g) {
     const int t = threadIdx.x;  // row slot
     const size_t r = (size_t)g.j0 + (size_t)blockIdx.x * P2_ROWS + t;
     const bool in_rows = r < g.rows;
-    int pos = in_rows ? (int)r : -1, retk = -1;
-    double a[BASE_W];
+    int pos = in_rows ? (int)r : -1, retk = -1, rpiv = 0;
+    double a[BASE_W + 4];  // register window: a[i] = column 4*jj + i (four spare slots: column k+1 of the last step of a group)
 #pragma unroll
     for (int c = 0; c < BASE_W; ++c) a[c] = (in_rows && c < g.w) ? g.A[r + (size_t)(g.j0 + c) * g.lda] : 0.0;
+#pragma unroll
+    for (int c = BASE_W; c < BASE_W + 4; ++c) a[c] = 0.0;
     if (t < 8) s_ctl[t] = 0;
     for (int i = t; i < P2_ONEHOP_MAXB * BASE_W + P2_WAVES * P2_RB; i += P2_THREADS) L.cand[i] = 0.0;  // cand and rowbuf are contiguous
     __syncthreads();
-    if (dbg_on) {
-        const pk_u64 now_ = wall_clock64();
-        s_ticks.acc[0] += now_ - s_ticks.tk;
-        s_ticks.tk = now_;
-    }
+    P2_TICK(0)  // load
+    // pivot of column 0: nothing to hide, nothing to fix up
+    if (!p2_select<0, false, DBG>(g, L, a, pos, 0, 0, 1, L.cand, ticks, [] {})) return;
     const int ngroups = (g.w + 3) >> 2;
     for (int jj = 0; jj < ngroups; ++jj) {
-        if (!p2_column<0, DBG>(g, L, a, pos, retk, jj, r, &s_ticks)) return;
-        if (4 * jj + 1 < g.w && !p2_column<1, DBG>(g, L, a, pos, retk, jj, r, &s_ticks)) return;
-        if (4 * jj + 2 < g.w && !p2_column<2, DBG>(g, L, a, pos, retk, jj, r, &s_ticks)) return;
-        if (4 * jj + 3 < g.w && !p2_column<3, DBG>(g, L, a, pos, retk, jj, r, &s_ticks)) return;
+        if (!p2_column<0, DBG>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
+        if (4 * jj + 1 < g.w && !p2_column<1, DBG>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
+        if (4 * jj + 2 < g.w && !p2_column<2, DBG>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
+        if (4 * jj + 3 < g.w && !p2_column<3, DBG>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
         // columns 4jj .. 4jj+3 are final: park them, shift the register window by four
 #pragma unroll
         for (int i = 0; i < 4; ++i) L.fin[(size_t)(4 * jj + i) * P2_ROWS + t] = a[i];
 #pragma unroll
-        for (int i = 0; i < BASE_W - 4; ++i) a[i] = a[i + 4];
+        for (int i = 0; i < BASE_W; ++i) a[i] = a[i + 4];
     }
     __syncthreads();
+    P2_TICK(7)
     // ---- write back at the FINAL positions (pivot rows to the top, displaced rows to where the bookkeeping left
     // them): the panel's own interchange.  Every block reads only its own LDS, and no block gets here before all
     // blocks took part in the last exchange, i.e. long after they loaded their rows.
     if (in_rows) {
         const size_t fpos = retk >= 0 ? (size_t)(g.j0 + retk) : (size_t)pos;
         for (int c = 0; c < g.w; ++c) g.A[fpos + (size_t)(g.j0 + c) * g.lda] = L.fin[(size_t)c * P2_ROWS + t];
+        // the interchange record of the step this row retired at (LAPACK-style target position), its row move for every
+        // other column, and the singular-pivot count
+        if (retk >= 0) {
+            const int kabs = g.j0 + retk;
+            g.ipiv[kabs] = rpiv & 0x3fffffff;
+            g.prow_arr[kabs] = (int)r;
+            g.plist[retk] = (int)r != kabs ? make_int2(kabs, (int)r) : make_int2(-1, -1);
+            if (rpiv & 0x40000000) atomicAdd(g.info, 1);
+        }
     }
-    // ---- the panel's row moves for every other column: slot k (k < w) was written by the thread that retired at
-    // step k; slots BASE_W + i are the top rows that were displaced instead of retired
+    // ---- slots BASE_W + i of the row-move list: top rows that were displaced instead of retired
     if (blockIdx.x == 0 && t < BASE_W) {
         int2 e = make_int2(-1, -1);
         if (t < g.w && pos >= 0 && pos != (int)r) e = make_int2(pos, (int)r);
@@ -729,10 +764,11 @@ __global__ void __launch_bounds__(P2_THREADS) k_lu_panel2(const P2Args g) {
         if (t >= g.w) g.plist[t] = make_int2(-1, -1);
     }
     if (dbg_on) {
-        s_ticks.acc[7] += wall_clock64() - s_ticks.tk;
+        s_ticks.acc[8] += wall_clock64() - s_ticks.tk;
         for (int i = 0; i < 16; ++i) g.dbg[i] += s_ticks.acc[i];
     }
 }
+#undef P2_TICK
 
 // Turn the lazy bookkeeping of one finished base panel [j0, c1) into a list of row moves
 // new[dst] = old[src]: position k receives the pivot row prow[k]; a top-block row that was not
@@ -1088,6 +1124,13 @@ static int getrf_rec(LuState& s, size_t j0, size_t w) {
             g.j0 = (int)j0;
             g.w = (int)w;
             g.nblocks = (int)nbp;
+            static int onehop_max = -1;  // developer knob
+            if (onehop_max < 0) {
+                const char* v = std::getenv("RMHIP_LU_ONEHOP");
+                onehop_max = v ? std::atoi(v) : P2_ONEHOP_MAXB;
+                if (onehop_max > P2_ONEHOP_MAXB) onehop_max = P2_ONEHOP_MAXB;
+            }
+            g.onehop_max = onehop_max;
             g.seq0 = s.xbase;
             g.xerr = s.xerr;
             g.xrec = s.xrec;
@@ -1214,8 +1257,21 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         (void)hipEventRecord(e0, main_stream);
         (void)hipStreamWaitEvent(side, e0, 0);
     }
-    for (size_t j = 0; j < kmin && rc == RMHIP_OK; j += nb) {
-        const size_t w = (kmin - j) < nb ? (kmin - j) : nb;
+    // Panel width by phase.  While the trailing matrix is large the update stream is the bottleneck and the main stream
+    // idles a third of the time: wider panels there (fewer, deeper rank-k updates: the dgemm runs 53 instead of 47
+    // TFLOP/s at k = 512 with one block per CU).  Once the panel chain is the critical path (about the last 8192
+    // columns) the narrower panel wins.  n = 16384: 128.3 -> 125.2 ms (interleaved, scripts/lu_env_ab.sh); giving the
+    // main stream a share of the trailing columns as well (its dgemm blocks fit beside the update stream's) measured
+    // nothing (127.3 vs 127.9).
+    size_t nb_early = 512, early_rows = 8192;
+    if (const char* v = std::getenv("RMHIP_LU_NB_EARLY")) nb_early = (size_t)std::atoll(v);
+    if (const char* v = std::getenv("RMHIP_LU_EARLY_ROWS")) early_rows = (size_t)std::atoll(v);
+    nb_early = nb_early < 64 ? 64 : (nb_early / 64) * 64;
+    if (nb_early < nb) nb_early = nb;
+    auto width_at = [&](size_t j) { return (early_rows && kmin - j > early_rows) ? nb_early : nb; };
+    for (size_t j = 0; j < kmin && rc == RMHIP_OK;) {
+        const size_t nbj = width_at(j);
+        const size_t w = (kmin - j) < nbj ? (kmin - j) : nbj;
         rc = getrf_rec(s, j, w);  // P_j on main
         if (rc != RMHIP_OK) break;
         hipEvent_t panel_done = new_event();
@@ -1223,7 +1279,8 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         const size_t next = j + w;
         size_t la_w = 0;
         if (next < kmin) {  // there is a next panel: update its columns on main right away
-            la_w = (kmin - next) < nb ? (kmin - next) : nb;
+            const size_t nbn = width_at(next);
+            la_w = (kmin - next) < nbn ? (kmin - next) : nbn;
             if (side_done) (void)hipStreamWaitEvent(main_stream, side_done, 0);
             rc = update_columns(s, j, w, next, next + la_w);
             if (rc != RMHIP_OK) break;
@@ -1236,6 +1293,7 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         }
         side_done = new_event();
         (void)hipEventRecord(side_done, side);
+        j = next;
     }
     if (side_done) (void)hipStreamWaitEvent(main_stream, side_done, 0);
     (void)hipStreamSynchronize(side);
@@ -1343,10 +1401,10 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
         if (s.xdbg) {
             unsigned long long h[16];
             if (hipMemcpy(h, s.xdbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-                static const char* names[16] = {"load", "argmax+sync", "publish", "wait+fold", "winner vals", "sync",
-                                                "eliminate", "park+write back", "wave argmax", "row dump", "bookkeeping", "pivot row",
-                                                "division", "-", "-", "-"};
-                for (int i = 0; i < 13; ++i)
+                static const char* names[16] = {"load", "argmax+park+sync", "publish", "wait+fold", "winner vals", "sync",
+                                                "elim under exch", "park+shift", "write back", "-", "bookkeep+div", "-",
+                                                "-", "-", "-", "-"};
+                for (int i = 0; i < 11; ++i)
                     std::fprintf(stderr, "[lu panel] %-12s %10.1f us total  %7.3f us/column\n", names[i], h[i] * 0.01,
                                  kmin ? h[i] * 0.01 / (double)kmin : 0.0);
             }

@@ -20,6 +20,9 @@ __device__ __forceinline__ void st64(u64* p, u64 v) {
     if (SB == 1) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
     if (SB == 2) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
     if (SB == 3) asm volatile("global_store_dwordx2 %0, %1, off sc0" ::"v"(p), "v"(v) : "memory");
+    if (SB == 4) asm volatile("global_atomic_swap_x2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");  // RMW at the coherence point, no return
+    if (SB == 5) asm volatile("global_atomic_swap_x2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    if (SB == 6) asm volatile("global_store_dwordx2 %0, %1, off nt sc1" ::"v"(p), "v"(v) : "memory");
 }
 template <int LB>
 __device__ __forceinline__ u64 ld64(const u64* p) {
@@ -137,13 +140,15 @@ int main() {
     CK(hipFuncSetAttribute((const void*)k_xchg<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     CK(hipFuncSetAttribute((const void*)k_xchg<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     CK(hipFuncSetAttribute((const void*)k_xchg<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_xchg<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_xchg<5, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_xchg<6, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     for (int loaded = 0; loaded < 2; ++loaded) {
         if (run<1, 1>("store sc1 / load sc1", loaded, s0, s1, rec, rows, xcc, err, out, ba, bb, big_n)) return 1;
-        if (run<2, 2>("store sc0sc1 / load sc0sc1", loaded, s0, s1, rec, rows, xcc, err, out, ba, bb, big_n)) return 1;
+        if (run<4, 1>("atomic swap sc1 / load sc1", loaded, s0, s1, rec, rows, xcc, err, out, ba, bb, big_n)) return 1;
+        if (run<5, 1>("atomic swap / load sc1", loaded, s0, s1, rec, rows, xcc, err, out, ba, bb, big_n)) return 1;
+        if (run<6, 1>("store nt sc1 / load sc1", loaded, s0, s1, rec, rows, xcc, err, out, ba, bb, big_n)) return 1;
         if (run<0, 1>("store plain / load sc1", loaded, s0, s1, rec, rows, xcc, err, out, ba, bb, big_n)) return 1;
-        if (run<0, 2>("store plain / load sc0sc1", loaded, s0, s1, rec, rows, xcc, err, out, ba, bb, big_n)) return 1;
-        if (run<0, 3>("store plain / load sc0", loaded, s0, s1, rec, rows, xcc, err, out, ba, bb, big_n)) return 1;
-        if (run<3, 3>("store sc0 / load sc0", loaded, s0, s1, rec, rows, xcc, err, out, ba, bb, big_n)) return 1;
     }
     return 0;
 }
