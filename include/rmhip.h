@@ -105,7 +105,9 @@ RMHIP_API int rmhip_numel(rmhip_ctx* ctx, rmhip_buf id, size_t* out);
 /* `zeros` / `ones` / `fill` (lib.rs:1468-1522). */
 RMHIP_API int rmhip_fill(rmhip_ctx* ctx, double value, const size_t* shape, size_t rank,
                          rmhip_buf* out);
-/* `reshape` (lib.rs:2676): new handle over the same storage (reference counted), same numel. */
+/* `reshape` (lib.rs:2676-2684): same numel, same buffer: the table entry's shape is updated in place and *out
+ * receives `id` itself, as the trait default and the wgpu provider (ops/tensor.rs reshape_exec) do - callers
+ * consume the source handle and never free it separately.  A transpose view is materialised first. */
 RMHIP_API int rmhip_reshape(rmhip_ctx* ctx, rmhip_buf id, const size_t* shape, size_t rank,
                             rmhip_buf* out);
 /* Zero-copy adoption of device memory owned by the host (torch tensor, RCCL receive buffer...).
@@ -171,7 +173,12 @@ enum rmhip_unary_op { /* unary_* ; numbering shared with oracle/oracle.c */
     RMHIP_LOG, RMHIP_LOG2, RMHIP_LOG10, RMHIP_LOG1P, RMHIP_SQRT, RMHIP_ABS, RMHIP_SIGN,
     RMHIP_FLOOR, RMHIP_CEIL, RMHIP_ROUND, RMHIP_FIX, RMHIP_NEG, RMHIP_EXP2, RMHIP_HEAVISIDE,
     RMHIP_ISNAN, RMHIP_ISINF, RMHIP_ISFINITE, RMHIP_UPLUS, RMHIP_SINGLE /* round through f32 */, RMHIP_DOUBLE,
-    RMHIP_ERF, RMHIP_SINC, RMHIP_NOT /* logical_not: x == 0 */, RMHIP_UNARY_OP_COUNT
+    RMHIP_ERF, RMHIP_SINC, RMHIP_NOT /* logical_not: x == 0 */,
+    /* special functions (lib.rs:2089-2118, 2319): the CPU builtins' own formulas - gamma / gammaln: Lanczos g = 7, 9 terms
+     * (math/elementwise/gamma.rs:289-343, gammaln.rs:254-281); factorial: product table up to 170, NaN for non-integers
+     * (factorial.rs:25-34, 272-314); nextpow2: ceil(log2(|x|)), 0 for 0 (nextpow2.rs:157-164); erfcinv: bracket +
+     * 110 bisection steps on erfc (erfcinv.rs:261-308) */
+    RMHIP_GAMMA, RMHIP_FACTORIAL, RMHIP_NEXTPOW2, RMHIP_GAMMALN, RMHIP_ERFCINV, RMHIP_UNARY_OP_COUNT
 };
 RMHIP_API int rmhip_unary(rmhip_ctx* ctx, int op, rmhip_buf a, rmhip_buf* out);
 

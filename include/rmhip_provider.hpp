@@ -173,6 +173,11 @@ public:
     GpuTensorHandle unary_sqrt(const GpuTensorHandle& a) const { return unary(RMHIP_SQRT, a); }
     GpuTensorHandle unary_abs(const GpuTensorHandle& a) const { return unary(RMHIP_ABS, a); }
     GpuTensorHandle unary_tanh(const GpuTensorHandle& a) const { return unary(RMHIP_TANH, a); }
+    GpuTensorHandle unary_gamma(const GpuTensorHandle& a) const { return unary(RMHIP_GAMMA, a); }        // lib.rs:2089
+    GpuTensorHandle unary_gammaln(const GpuTensorHandle& a) const { return unary(RMHIP_GAMMALN, a); }    // lib.rs:2095
+    GpuTensorHandle unary_erfcinv(const GpuTensorHandle& a) const { return unary(RMHIP_ERFCINV, a); }    // lib.rs:2107
+    GpuTensorHandle unary_factorial(const GpuTensorHandle& a) const { return unary(RMHIP_FACTORIAL, a); }  // lib.rs:2113
+    GpuTensorHandle unary_nextpow2(const GpuTensorHandle& a) const { return unary(RMHIP_NEXTPOW2, a); }  // lib.rs:2319
     GpuTensorHandle scalar(rmhip_scalar_op op, const GpuTensorHandle& a, double s) const {
         uint64_t out = 0;
         check(rmhip_scalar(ctx_, op, own(a), s, &out));

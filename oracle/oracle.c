@@ -22,6 +22,7 @@
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off, no -ffast-math, no OpenMP).
  */
 #define _GNU_SOURCE
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -84,8 +85,95 @@ enum {
     ORC_SIN = 0, ORC_COS, ORC_TAN, ORC_ASIN, ORC_ACOS, ORC_ATAN, ORC_SINH, ORC_COSH, ORC_TANH,
     ORC_ASINH, ORC_ACOSH, ORC_ATANH, ORC_EXP, ORC_EXPM1, ORC_LOG, ORC_LOG2, ORC_LOG10, ORC_LOG1P,
     ORC_SQRT, ORC_ABS, ORC_SIGN, ORC_FLOOR, ORC_CEIL, ORC_ROUND, ORC_FIX, ORC_NEG, ORC_EXP2,
-    ORC_HEAVISIDE, ORC_ISNAN, ORC_ISINF, ORC_ISFINITE, ORC_UPLUS, ORC_SINGLE, ORC_DOUBLE, ORC_ERF, ORC_SINC, ORC_NOT
+    ORC_HEAVISIDE, ORC_ISNAN, ORC_ISINF, ORC_ISFINITE, ORC_UPLUS, ORC_SINGLE, ORC_DOUBLE, ORC_ERF, ORC_SINC, ORC_NOT,
+    ORC_GAMMA, ORC_FACTORIAL, ORC_NEXTPOW2, ORC_GAMMALN, ORC_ERFCINV, ORC_UNARY_COUNT
 };
+
+/* ---- special functions: crates/runmat-runtime/src/builtins/math/elementwise/{gamma,gammaln,factorial,nextpow2,
+ * erfcinv}.rs.  gamma() runs in num-complex arithmetic there even for real arguments (gamma.rs:289-343); with zero
+ * imaginary parts every complex product is the real product, `powc` is powf (from_polar(r^w, 0)), and a complex
+ * quotient (c+0i)/(d+0i) evaluates (c*d)/(d*d) (num-complex 0.4 Div: re = (a.re*b.re + a.im*b.im) / b.norm_sqr()),
+ * which is what is written here.  erfc is libm's (the crate `libm`, a port of the same FreeBSD msun code as glibc's). */
+static const double LANCZOS_COEFFS[8] = { /* gamma.rs:30-39, gammaln.rs:30-39 */
+    676.5203681218851, -1259.1392167224028, 771.3234287776531, -176.6150291621406,
+    12.507343278686905, -0.13857109526572012, 9.984369578019572e-6, 1.5056327351493116e-7};
+
+static int close_to_integer(double x) { /* gamma.rs:353-364 */
+    if (!isfinite(x)) return 0;
+    double nearest = round(x), diff = fabs(x - nearest);
+    if (nearest == 0.0) return diff <= 1e-12 * 1e-12;
+    return diff <= 1e-12 * fmax(fabs(nearest), 1.0);
+}
+static double lanczos_gamma(double z) { /* gamma.rs:332-343 */
+    double zm1 = z - 1.0, sum = 0.9999999999998099;
+    for (int i = 0; i < 8; ++i) {
+        double d = zm1 + (double)(i + 1);
+        sum += (LANCZOS_COEFFS[i] * d) / (d * d);
+    }
+    double t = zm1 + (7.0 + 0.5);
+    return 2.5066282746310005 * pow(t, zm1 + 0.5) * exp(-t) * sum;
+}
+static double gamma_real_scalar(double x) { /* gamma.rs:289-330 */
+    if (isnan(x)) return NAN;
+    if (isinf(x)) return x > 0.0 ? INFINITY : NAN;
+    if (x <= 0.0 && close_to_integer(x)) return INFINITY;
+    if (x < 0.5) {
+        double s = sin(M_PI * x);
+        if (s * s <= 1e-12 * 1e-12) return INFINITY;
+        double d = s * lanczos_gamma(1.0 - x);
+        return (M_PI * d) / (d * d);
+    }
+    return lanczos_gamma(x);
+}
+static double lanczos_gammaln(double v) { /* gammaln.rs:273-281 */
+    double zm1 = v - 1.0, sum = 0.9999999999998099;
+    for (int i = 0; i < 8; ++i) sum += LANCZOS_COEFFS[i] / (zm1 + (double)(i + 1));
+    double t = zm1 + 7.0 + 0.5;
+    return 0.9189385332046727 + (zm1 + 0.5) * log(t) - t + log(sum);
+}
+static double gammaln_nonnegative_scalar(double v) { /* gammaln.rs:254-271 */
+    if (isnan(v)) return NAN;
+    if (v == 0.0 || v == INFINITY) return INFINITY;
+    if (v < 0.0) return NAN;
+    if (v < 1.0e-305) return -log(v);
+    if (v < 0.5) return log(M_PI) - log(sin(M_PI * v)) - lanczos_gammaln(1.0 - v);
+    return lanczos_gammaln(v);
+}
+static double factorial_scalar(double v) { /* factorial.rs:25-34, 272-314 */
+    if (isnan(v)) return NAN;
+    if (v == 0.0) return 1.0;
+    if (isinf(v)) return v > 0.0 ? INFINITY : NAN;
+    if (v < 0.0) return NAN;
+    double rounded = round(v);
+    if (fabs(v - rounded) > DBL_EPSILON * fmax(fabs(v), 1.0)) return NAN;
+    if (rounded > 170.0) return INFINITY;
+    double acc = 1.0;
+    for (int n = 1; n <= (int)rounded; ++n) acc *= (double)n;
+    return acc;
+}
+static double erfcinv_positive_tail(double target) { /* erfcinv.rs:287-308 */
+    double lo = 0.0, hi = 1.0;
+    while (hi < 32.0 && erfc(hi) > target) {
+        lo = hi;
+        hi *= 2.0;
+    }
+    if (erfc(hi) > target) return hi;
+    for (int i = 0; i < 110; ++i) {
+        double mid = 0.5 * (lo + hi);
+        if (erfc(mid) > target) lo = mid;
+        else hi = mid;
+    }
+    return 0.5 * (lo + hi);
+}
+static double erfcinv_scalar(double v) { /* erfcinv.rs:261-281 */
+    if (isnan(v)) return NAN;
+    if (!(v >= 0.0 && v <= 2.0)) return NAN;
+    if (v == 0.0) return INFINITY;
+    if (v == 2.0) return -INFINITY;
+    if (v == 1.0) return 0.0;
+    if (v > 1.0) return -erfcinv_positive_tail(2.0 - v);
+    return erfcinv_positive_tail(v);
+}
 
 /* crates/runmat-runtime/src/builtins/math/elementwise/sign.rs:236-246 */
 static double sign_real_scalar(double x) {
@@ -135,6 +223,11 @@ static double unary_apply(int op, double v) {
         case ORC_DOUBLE: return v;
         case ORC_ERF: return erf(v);              /* libm::erf, elementwise/erf.rs:214-216 */
         case ORC_NOT: return v == 0.0 ? 1.0 : 0.0; /* logical_not, simple_provider.rs:4776-4780 */
+        case ORC_GAMMA: return gamma_real_scalar(v);
+        case ORC_FACTORIAL: return factorial_scalar(v);
+        case ORC_NEXTPOW2: { double ax = fabs(v); return ax == 0.0 ? 0.0 : ceil(log2(ax)); } /* nextpow2.rs:157-164 */
+        case ORC_GAMMALN: return gammaln_nonnegative_scalar(v);
+        case ORC_ERFCINV: return erfcinv_scalar(v);
         case ORC_SINC: {                          /* sinc.rs:302-311 */
             if (v == 0.0) return 1.0;
             if (isfinite(v) && v == trunc(v)) return 0.0;
@@ -146,7 +239,7 @@ static double unary_apply(int op, double v) {
 }
 
 ORC_API int orc_unary(int op, const double* x, size_t n, double* out) {
-    if (op < 0 || op > ORC_NOT) return 1;
+    if (op < 0 || op >= ORC_UNARY_COUNT) return 1;
     for (size_t i = 0; i < n; ++i) out[i] = unary_apply(op, x[i]);
     return 0;
 }

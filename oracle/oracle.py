@@ -18,7 +18,8 @@ LIB_PATH = _HERE / "liboracle.so"
 UNARY = {n: i for i, n in enumerate((
     "sin", "cos", "tan", "asin", "acos", "atan", "sinh", "cosh", "tanh", "asinh", "acosh", "atanh", "exp", "expm1",
     "log", "log2", "log10", "log1p", "sqrt", "abs", "sign", "floor", "ceil", "round", "fix", "neg", "exp2",
-    "heaviside", "isnan", "isinf", "isfinite", "uplus", "single", "double", "erf", "sinc", "not"))}
+    "heaviside", "isnan", "isinf", "isfinite", "uplus", "single", "double", "erf", "sinc", "not",
+    "gamma", "factorial", "nextpow2", "gammaln", "erfcinv"))}
 BINARY = {"add": 0, "sub": 1, "mul": 2, "div": 3, "pow": 4, "max": 5, "min": 6, "hypot": 7, "atan2": 8, "mod": 9,
           "rem": 10, "eq": 11, "ne": 12, "lt": 13, "le": 14, "gt": 15, "ge": 16, "and": 17, "or": 18, "xor": 19}
 

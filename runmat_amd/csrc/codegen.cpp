@@ -4,6 +4,8 @@
 
 #include <hip/hiprtc.h>
 #include <sys/stat.h>
+#include <unistd.h>
+#include <cstdio>
 
 #include <cstdlib>
 #include <cstring>
@@ -321,8 +323,10 @@ static std::string cache_dir() {
 
 int compile_to_code_object(const std::string& source, std::vector<char>* code) {
     const std::string dir = cache_dir();
-    char namebuf[64];
-    std::snprintf(namebuf, sizeof namebuf, "%016llx.hsaco", (unsigned long long)fnv1a(source + "|gfx950|v1"));
+    // file name = two independent 64-bit hashes + the source length: a collision would have to match all three
+    char namebuf[96];
+    std::snprintf(namebuf, sizeof namebuf, "%016llx-%016llx-%zx.hsaco", (unsigned long long)fnv1a(source + "|gfx950|v2"),
+                  (unsigned long long)fnv1a("rmhip:" + source), source.size());
     if (!dir.empty()) {  // persisted code objects keyed by source hash + arch
         std::ifstream f(dir + "/" + namebuf, std::ios::binary);
         if (f) {
@@ -352,9 +356,22 @@ int compile_to_code_object(const std::string& source, std::vector<char>* code) {
     hiprtcGetCode(prog, code->data());
     hiprtcDestroyProgram(&prog);
     if (!dir.empty()) {
+        // one process per GPU compiles the same shaders at start-up: write a private temporary and rename() it into
+        // place, so a reader sees either no file or the complete one
         ::mkdir(dir.c_str(), 0755);
-        std::ofstream f(dir + "/" + namebuf, std::ios::binary);
-        if (f) f.write(code->data(), (std::streamsize)code->size());
+        char tmpbuf[160];
+        std::snprintf(tmpbuf, sizeof tmpbuf, "%s.tmp.%ld", namebuf, (long)::getpid());
+        const std::string tmp = dir + "/" + tmpbuf;
+        bool ok = false;
+        {
+            std::ofstream f(tmp, std::ios::binary | std::ios::trunc);
+            if (f) {
+                f.write(code->data(), (std::streamsize)code->size());
+                f.flush();
+                ok = f.good();
+            }
+        }
+        if (!ok || std::rename(tmp.c_str(), (dir + "/" + namebuf).c_str()) != 0) std::remove(tmp.c_str());
     }
     return RMHIP_OK;
 }
@@ -373,11 +390,12 @@ int get_elementwise_kernel(Context* c, const ElementwiseProgram& p, unsigned mas
     if (f32 && !std::getenv("RMHIP_EW_BCAST_ELEMS")) t.bcast_elems = 8;
     char tun[96];
     std::snprintf(tun, sizeof tun, "|u%d|b%d|bb%dx%d|nt%d%d|c%d|m%x", t.unroll, t.block, t.bcast_block, t.bcast_elems, t.nt_load, t.nt_store, t.chunked, mask);
-    const uint64_t key = fnv1a(p.canonical + tun + (f32 ? "|f32" : ""));
+    const std::string key_text = p.canonical + tun + (f32 ? "|f32" : "");
+    const uint64_t key = fnv1a(key_text);
     {
         std::lock_guard<std::mutex> lk(c->mu);
         auto it = c->kernel_cache.find(key);
-        if (it != c->kernel_cache.end()) {
+        if (it != c->kernel_cache.end() && it->second->key_text == key_text) {  // a 64-bit hash alone could run the wrong kernel
             c->tel.cache_hits++;
             *out = it->second;
             return RMHIP_OK;
@@ -387,6 +405,7 @@ int get_elementwise_kernel(Context* c, const ElementwiseProgram& p, unsigned mas
     std::vector<char> code;
     RMHIP_TRY(compile_to_code_object(generate_elementwise_source(p, t, mask, f32), &code));
     auto k = std::make_shared<FusedKernel>();
+    k->key_text = key_text;
     k->tuning = t;
     k->n_inputs = p.n_inputs;
     k->n_outputs = (int)p.outputs.size();
@@ -401,11 +420,12 @@ int get_elementwise_kernel(Context* c, const ElementwiseProgram& p, unsigned mas
 }
 
 int get_reduction_kernel(Context* c, const ReductionProgram& p, bool f32, std::shared_ptr<FusedKernel>* out) {
-    const uint64_t key = fnv1a(p.canonical + (f32 ? "|f32" : ""));
+    const std::string key_text = p.canonical + (f32 ? "|f32" : "") + "|red";
+    const uint64_t key = fnv1a(key_text);
     {
         std::lock_guard<std::mutex> lk(c->mu);
         auto it = c->kernel_cache.find(key);
-        if (it != c->kernel_cache.end()) {
+        if (it != c->kernel_cache.end() && it->second->key_text == key_text) {
             c->tel.cache_hits++;
             *out = it->second;
             return RMHIP_OK;
@@ -415,6 +435,7 @@ int get_reduction_kernel(Context* c, const ReductionProgram& p, bool f32, std::s
     std::vector<char> code;
     RMHIP_TRY(compile_to_code_object(generate_reduction_source(p, f32), &code));
     auto k = std::make_shared<FusedKernel>();
+    k->key_text = key_text;
     k->n_inputs = p.n_inputs;
     k->n_outputs = 1;
     RMHIP_HIP_CHECK(hipModuleLoadData(&k->module, code.data()));

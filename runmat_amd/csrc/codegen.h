@@ -43,6 +43,7 @@ struct FusedKernel {
     hipFunction_t fn_final = nullptr;   // reduction finalize
     int n_inputs = 0, n_outputs = 0;
     EwTuning tuning;
+    std::string key_text;  // what the cache key hashes: compared on every hit
     ~FusedKernel();
 };
 

@@ -100,6 +100,12 @@ struct Context {
     int num_cus = 256;
 
     std::mutex mu;  // guards table, pool, kernel cache
+    // One C-ABI call at a time per context: the provider trait is `Send + Sync` (lib.rs:1386) and calls may arrive from
+    // several host threads, but scratch, rng_state, narrow_pending and the stream retargeting of the look-ahead LU are
+    // per-context state.  Taken (recursively: entry points call entry points) by CTX_OR_FAIL; uncontended cost ~20 ns.
+    std::recursive_mutex call_mu;
+    // kernels whose dynamic-LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) was set on THIS context's device
+    std::vector<const void*> lds_opt_in;
     std::unordered_map<uint64_t, Buffer> table;
     uint64_t next_id = 1;
 
@@ -145,6 +151,7 @@ struct Context {
     int narrow(uint64_t id);                 // replace an f64 buffer's storage by its f32 rounding
     void finish_outputs(size_t mark);        // narrow everything new_buffer created since `mark` (precision 32 only)
     int ensure_scratch(size_t bytes);
+    void ensure_max_lds(const void* kernel, size_t bytes);  // once per kernel per context (the attribute is per device)
 };
 
 inline size_t shape_numel(const size_t* shape, size_t rank) {

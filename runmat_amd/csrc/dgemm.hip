@@ -316,11 +316,7 @@ int launch_dgemm_trans(Context* c, bool ta, bool tb, size_t m, size_t n, size_t 
 
 template <bool EDGE, bool EPI, bool TA, bool TB>
 static void launch_variant(Context* c, unsigned blocks, unsigned splits, size_t lds_bytes, size_t max_lds, const GemmArgs& g) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_dgemm<EDGE, EPI, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
-        attr_set = true;
-    }
+    c->ensure_max_lds((const void*)k_dgemm<EDGE, EPI, TA, TB>, max_lds);
     hipLaunchKernelGGL((k_dgemm<EDGE, EPI, TA, TB>), dim3(blocks, splits), dim3(256), lds_bytes, c->stream, g);
 }
 

@@ -46,6 +46,104 @@ static inline unsigned stream_grid(const Context* c, size_t nvec) {
     return (unsigned)(want < cap ? want : cap);
 }
 
+// ---- special functions: the CPU builtins' formulas restated (tolerance, not bit parity: pow / exp / log / sin / erfc
+// come from ocml here and from libm / num-complex there) ------------------------------------------------------------
+// Lanczos g = 7, 9 terms (math/elementwise/gamma.rs:25-38, gammaln.rs:25-39)
+__device__ const double kLanczos[8] = {676.5203681218851,   -1259.1392167224028,  771.3234287776531,     -176.6150291621406,
+                                       12.507343278686905,  -0.13857109526572012, 9.984369578019572e-6,  1.5056327351493116e-7};
+// gamma.rs:353-364
+__device__ __forceinline__ bool rm_close_to_integer(double x) {
+    if (!rm_isfinite(x)) return false;
+    const double nearest = round(x);
+    const double diff = fabs(x - nearest);
+    return nearest == 0.0 ? diff <= 1e-24 : diff <= 1e-12 * fmax(fabs(nearest), 1.0);
+}
+// gamma.rs:332-343 for a real argument >= 0.5.  The reference evaluates it in complex arithmetic with zero imaginary
+// parts: a complex quotient (c + 0i) / (d + 0i) is (c*d) / (d*d) there (num-complex Div), kept as is.
+__device__ __forceinline__ double rm_lanczos_gamma(double z) {
+    const double zm1 = z - 1.0;
+    double sum = 0.9999999999998099;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double d = zm1 + (double)(i + 1);
+        sum += (kLanczos[i] * d) / (d * d);
+    }
+    const double t = zm1 + 7.5;
+    return 2.5066282746310005 * pow(t, zm1 + 0.5) * exp(-t) * sum;
+}
+// gamma.rs:289-330
+__device__ __forceinline__ double rm_gamma(double x) {
+    if (rm_isnan(x)) return __builtin_nan("");
+    if (rm_isinf(x)) return x > 0.0 ? x : __builtin_nan("");
+    if (x <= 0.0 && rm_close_to_integer(x)) return __builtin_inf();
+    if (x < 0.5) {  // reflection: pi / (sin(pi x) * gamma(1 - x))
+        const double s = sin(M_PI * x);
+        if (s * s <= 1e-24) return __builtin_inf();
+        const double d = s * rm_lanczos_gamma(1.0 - x);
+        return (M_PI * d) / (d * d);
+    }
+    return rm_lanczos_gamma(x);
+}
+// gammaln.rs:254-281
+__device__ __forceinline__ double rm_lanczos_gammaln(double v) {
+    const double zm1 = v - 1.0;
+    double sum = 0.9999999999998099;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sum += kLanczos[i] / (zm1 + (double)(i + 1));
+    const double t = zm1 + 7.0 + 0.5;
+    return 0.9189385332046727 + (zm1 + 0.5) * log(t) - t + log(sum);
+}
+__device__ __forceinline__ double rm_gammaln(double v) {
+    if (rm_isnan(v)) return __builtin_nan("");
+    if (v == 0.0 || v == __builtin_inf()) return __builtin_inf();
+    if (v < 0.0) return __builtin_nan("");  // the builtin raises for negative input before it gets here (gammaln.rs:283-292)
+    if (v < 1.0e-305) return -log(v);
+    if (v < 0.5) return log(M_PI) - log(sin(M_PI * v)) - rm_lanczos_gammaln(1.0 - v);
+    return rm_lanczos_gammaln(v);
+}
+// factorial.rs:25-34, 272-314: n! as the running product 1*2*...*n (each step rounded), NaN unless n is a non-negative
+// integer to within eps * max(|n|, 1), Inf beyond 170
+__device__ __forceinline__ double rm_factorial(double v) {
+    if (rm_isnan(v)) return __builtin_nan("");
+    if (v == 0.0) return 1.0;
+    if (rm_isinf(v)) return v > 0.0 ? v : __builtin_nan("");
+    if (v < 0.0) return __builtin_nan("");
+    const double rounded = round(v);
+    if (fabs(v - rounded) > 2.220446049250313e-16 * fmax(fabs(v), 1.0)) return __builtin_nan("");
+    if (rounded > 170.0) return __builtin_inf();
+    double acc = 1.0;
+    const int n = (int)rounded;
+    for (int i = 2; i <= n; ++i) acc *= (double)i;
+    return acc;
+}
+// nextpow2.rs:157-164
+__device__ __forceinline__ double rm_nextpow2(double x) {
+    const double ax = fabs(x);
+    return ax == 0.0 ? 0.0 : ceil(log2(ax));
+}
+// erfcinv.rs:261-308
+__device__ __forceinline__ double rm_erfcinv_tail(double target) {
+    double lo = 0.0, hi = 1.0;
+    while (hi < 32.0 && erfc(hi) > target) {
+        lo = hi;
+        hi *= 2.0;
+    }
+    if (erfc(hi) > target) return hi;
+    for (int i = 0; i < 110; ++i) {
+        const double mid = 0.5 * (lo + hi);
+        if (erfc(mid) > target) lo = mid;
+        else hi = mid;
+    }
+    return 0.5 * (lo + hi);
+}
+__device__ __forceinline__ double rm_erfcinv(double v) {
+    if (rm_isnan(v) || !(v >= 0.0 && v <= 2.0)) return __builtin_nan("");
+    if (v == 0.0) return __builtin_inf();
+    if (v == 2.0) return -__builtin_inf();
+    if (v == 1.0) return 0.0;
+    return v > 1.0 ? -rm_erfcinv_tail(2.0 - v) : rm_erfcinv_tail(v);
+}
+
 template <int OP>
 __device__ __forceinline__ double unary_op(double v) {
     switch (OP) {
@@ -84,6 +182,11 @@ __device__ __forceinline__ double unary_op(double v) {
         case RMHIP_ERF: return erf(v);        // libm::erf (elementwise/erf.rs:214-216)
         case RMHIP_SINC: return rm_sinc(v);
         case RMHIP_NOT: return v == 0.0 ? 1.0 : 0.0;
+        case RMHIP_GAMMA: return rm_gamma(v);
+        case RMHIP_FACTORIAL: return rm_factorial(v);
+        case RMHIP_NEXTPOW2: return rm_nextpow2(v);
+        case RMHIP_GAMMALN: return rm_gammaln(v);
+        case RMHIP_ERFCINV: return rm_erfcinv(v);
         default: return v;
     }
 }

@@ -1000,12 +1000,7 @@ static int launch_check(Context* c);
 template <int MODE, int NC, int TRSM_THREADS>
 static int launch_trsm_fused_nc(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
     const size_t lds_bytes = w * (w > 64 ? (size_t)TRSM_SW : (size_t)65) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_trsm_fused<MODE, NC, TRSM_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(TRSM_W * TRSM_SW * sizeof(double)));
-        attr_set = true;
-    }
+    c->ensure_max_lds((const void*)k_trsm_fused<MODE, NC, TRSM_THREADS>, TRSM_W * TRSM_SW * sizeof(double));
     const size_t per_block = (size_t)(TRSM_THREADS / 64) * NC;  // columns one block solves per pass
     size_t want = (nc + per_block - 1) / per_block;
     const size_t cap = (size_t)c->num_cus * (w <= 64 ? 2 : 1);
@@ -1345,14 +1340,8 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
               nullptr};
     {
         // persistent panels need >64 KiB of dynamic LDS and all their blocks co-resident (one per CU)
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)k_lu_panel2<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)(P2_LDS_DOUBLES * sizeof(double)));
-            (void)hipFuncSetAttribute((const void*)k_lu_panel2<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)(P2_LDS_DOUBLES * sizeof(double)));
-            attr_set = true;
-        }
+        c->ensure_max_lds((const void*)k_lu_panel2<false>, P2_LDS_DOUBLES * sizeof(double));
+        c->ensure_max_lds((const void*)k_lu_panel2<true>, P2_LDS_DOUBLES * sizeof(double));
         const char* pm = std::getenv("RMHIP_LU_PANEL");  // "columns" selects the one-launch-per-column kernels
         if ((pm && pm[0] == 'c') || c->lu_conservative) s.persistent = false;
         const char* dbgenv = std::getenv("RMHIP_LU_PANEL_DEBUG");

@@ -224,6 +224,13 @@ int Context::get(uint64_t id, Buffer* out) {
     return get_view(id, out);
 }
 
+void Context::ensure_max_lds(const void* kernel, size_t bytes) {
+    for (const void* k : lds_opt_in)
+        if (k == kernel) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    lds_opt_in.push_back(kernel);
+}
+
 int Context::ensure_scratch(size_t bytes) {
     if (bytes <= scratch_bytes) return RMHIP_OK;
     if (scratch) {
@@ -249,6 +256,7 @@ struct rmhip_ctx {
 #define CTX_OR_FAIL(ctx)                                                  \
     if (!(ctx)) return fail(RMHIP_ERR_INVALID, "null context");           \
     Context* c = &(ctx)->c;                                               \
+    std::lock_guard<std::recursive_mutex> _call(c->call_mu);              \
     DeviceGuard _dg(c);                                                   \
     NarrowScope _ns(c)
 
@@ -460,19 +468,23 @@ int rmhip_fill_uniform(rmhip_ctx* ctx, uint64_t seed, double lo, double hi, cons
 
 int rmhip_reshape(rmhip_ctx* ctx, rmhip_buf id, const size_t* shape, size_t rank, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);
+    if (!out || (rank && !shape)) return fail(RMHIP_ERR_INVALID, "reshape: null argument");
     Buffer b;
     RMHIP_TRY(c->get_raw(id, &b));
     if (shape_numel(shape, rank) != b.numel)
         return fail(RMHIP_ERR_SHAPE, "reshape: element count mismatch (%zu vs %zu)", shape_numel(shape, rank), b.numel);
-    const bool view = b.tview;
-    if (view) RMHIP_TRY(c->get(id, &b));  // materialised (and, for f32 storage, widened) copy
-    Buffer r;
-    r.alloc = b.alloc;
-    r.shape.assign(shape, shape + rank);
-    r.numel = b.numel;
-    r.dtype = b.dtype;
-    RMHIP_TRY(c->register_buffer(std::move(r), out));
-    if (view && c->precision == 32) c->narrow_pending.push_back(*out);
+    // Same buffer, new shape: the trait default (lib.rs:2676-2684) and the wgpu provider (ops/tensor.rs reshape_exec)
+    // return the SAME buffer_id, and callers such as the reshape builtin consume the source handle without freeing
+    // it - a second table entry would orphan the first and pin the allocation.  A transpose view is materialised first
+    // (the bytes of a view are those of its base matrix).
+    if (b.tview) RMHIP_TRY(c->settle_view(id));
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        auto it = c->table.find(id);
+        if (it == c->table.end()) return fail(RMHIP_ERR_NOT_FOUND, "buffer not found: %llu", (unsigned long long)id);
+        it->second.shape.assign(shape, shape + rank);
+    }
+    *out = id;
     return RMHIP_OK;
 }
 
@@ -492,6 +504,8 @@ int rmhip_wrap_external(rmhip_ctx* ctx, void* device_ptr, const size_t* shape, s
 
 void* rmhip_device_ptr(rmhip_ctx* ctx, rmhip_buf id) {
     if (!ctx) return nullptr;
+    std::lock_guard<std::recursive_mutex> _call(ctx->c.call_mu);
+    DeviceGuard _dg(&ctx->c);
     Buffer b;
     if (ctx->c.get_raw(id, &b) != RMHIP_OK) return nullptr;
     if (b.dtype == DT_F32) return b.tview ? nullptr : (void*)b.data();  // the f32 storage itself (rmhip_buffer_bits says which)

@@ -25,6 +25,7 @@ using namespace rmhip;
 #define CTX_OR_FAIL(ctx)                                            \
     if (!(ctx)) return fail(RMHIP_ERR_INVALID, "null context");     \
     Context* c = context_of(ctx);                                   \
+    std::lock_guard<std::recursive_mutex> _call(c->call_mu);        \
     DeviceGuard _dg(c);                                             \
     NarrowScope _ns(c)
 
@@ -1080,8 +1081,13 @@ int rmhip_blk_lu(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf* ipiv_out, int
     Buffer ob;
     RMHIP_TRY(c->new_buffer(oshape, 2, ipiv_out, &ob));
     if (!host.empty()) {
-        RMHIP_HIP_CHECK(hipMemcpyAsync(ob.data(), host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        hipError_t e = hipMemcpyAsync(ob.data(), host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            rmhip_free(ctx, *ipiv_out);  // do not leak the interchange vector on the HIP error paths
+            *ipiv_out = 0;
+            return fail(RMHIP_ERR_HIP, "blk_lu: copying the interchanges: %s", hipGetErrorString(e));
+        }
     }
     return RMHIP_OK;
 }

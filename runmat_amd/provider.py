@@ -27,7 +27,8 @@ BINARY_OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3, "pow": 4, "max": 5, "min":
 UNARY_OPS = {n: i for i, n in enumerate((
     "sin", "cos", "tan", "asin", "acos", "atan", "sinh", "cosh", "tanh", "asinh", "acosh", "atanh", "exp", "expm1",
     "log", "log2", "log10", "log1p", "sqrt", "abs", "sign", "floor", "ceil", "round", "fix", "neg", "exp2",
-    "heaviside", "isnan", "isinf", "isfinite", "uplus", "single", "double", "erf", "sinc", "not"))}
+    "heaviside", "isnan", "isinf", "isfinite", "uplus", "single", "double", "erf", "sinc", "not",
+    "gamma", "factorial", "nextpow2", "gammaln", "erfcinv"))}
 SCALAR_OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3, "rsub": 4, "rdiv": 5, "max": 6, "min": 7}
 REDUCE_OPS = {"sum": 0, "mean": 1, "min": 2, "max": 3, "prod": 4}
 
@@ -243,6 +244,8 @@ class HipProvider:
         return self._handle(out.value, shape)
 
     def reshape(self, h: GpuTensorHandle, shape: Sequence[int]) -> GpuTensorHandle:
+        """`reshape` (lib.rs:2676-2684): the SAME buffer with a new shape - the returned handle carries `h`'s
+        buffer_id, and one `free` releases the storage (a transpose view is materialised first)."""
         sh, rank = _shape_array(shape)
         out = C.c_uint64()
         self._check(self._lib.rmhip_reshape(self._ctx, self._id(h), sh, rank, C.byref(out)))

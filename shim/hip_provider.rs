@@ -14,8 +14,9 @@
 
 use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
-    AccelProvider, AccelProviderFuture, GpuTensorHandle, HostTensorOwned, HostTensorView,
-    ProviderLuResult, ProviderMoments2, ProviderPrecision, ReductionFlavor,
+    AccelProvider, AccelProviderFuture, CovNormalization, CovRows, CovarianceOptions, GpuTensorHandle,
+    HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, PowerStepEpilogue, ProviderLinsolveOptions,
+    ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderPrecision, ReductionFlavor,
 };
 use std::ffi::{c_char, c_double, c_int, c_void, CStr, CString};
 
@@ -121,6 +122,11 @@ const RMHIP_DOUBLE: c_int = 33;
 const RMHIP_ERF: c_int = 34;
 const RMHIP_SINC: c_int = 35;
 const RMHIP_NOT: c_int = 36;
+const RMHIP_GAMMA: c_int = 37;
+const RMHIP_FACTORIAL: c_int = 38;
+const RMHIP_NEXTPOW2: c_int = 39;
+const RMHIP_GAMMALN: c_int = 40;
+const RMHIP_ERFCINV: c_int = 41;
 const RMHIP_SADD: c_int = 0;
 const RMHIP_SSUB: c_int = 1;
 const RMHIP_SMUL: c_int = 2;
@@ -153,7 +159,11 @@ pub struct HipProvider {
     precision: ProviderPrecision,
     device_id: u32,
 }
-// One HIP stream per context; the library serialises table access internally.
+// `AccelProvider: Send + Sync` (lib.rs:1386).  The context pointer is only ever handed to librmhip entry points, and
+// every entry point takes the context's call mutex first (`Context::call_mu`, taken by CTX_OR_FAIL in
+// runmat_amd/csrc/rmhip_core.cpp / rmhip_ops.cpp): overlapping calls from several host threads serialise inside the
+// library instead of interleaving on its per-context state (scratch, RNG state, the look-ahead LU's stream
+// retargeting).  tests/test_gpu_threads.py hammers one context from two threads.
 unsafe impl Send for HipProvider {}
 unsafe impl Sync for HipProvider {}
 
@@ -301,7 +311,8 @@ impl AccelProvider for HipProvider {
         unary_log1p => RMHIP_LOG1P, unary_sqrt => RMHIP_SQRT, unary_abs => RMHIP_ABS, unary_sign => RMHIP_SIGN,
         unary_floor => RMHIP_FLOOR, unary_ceil => RMHIP_CEIL, unary_round => RMHIP_ROUND, unary_fix => RMHIP_FIX,
         unary_pow2 => RMHIP_EXP2, unary_heaviside => RMHIP_HEAVISIDE, unary_single => RMHIP_SINGLE, unary_double => RMHIP_DOUBLE,
-        unary_erf => RMHIP_ERF, unary_sinc => RMHIP_SINC,
+        unary_erf => RMHIP_ERF, unary_sinc => RMHIP_SINC, unary_gamma => RMHIP_GAMMA, unary_factorial => RMHIP_FACTORIAL,
+        unary_nextpow2 => RMHIP_NEXTPOW2, unary_gammaln => RMHIP_GAMMALN, unary_erfcinv => RMHIP_ERFCINV,
     }
     binary_hooks! {
         elem_add => RMHIP_ADD, elem_sub => RMHIP_SUB, elem_mul => RMHIP_MUL, elem_div => RMHIP_DIV, elem_pow => RMHIP_POW,
@@ -327,8 +338,9 @@ impl AccelProvider for HipProvider {
             self.handle(out)
         })
     }
-    // The library keeps each buffer's shape; a reshaped handle must be a new buffer id aliasing the same storage
-    // (the trait's default only edits the handle, lib.rs:2676-2684).
+    // The library keeps each buffer's shape, so the trait default (edit the handle only, lib.rs:2676-2684) is not
+    // enough; like the wgpu provider's reshape_exec the library updates the entry in place and hands back the SAME
+    // buffer id (`out == handle.buffer_id`), so the consumed source handle needs no separate free.
     fn reshape(&self, handle: &GpuTensorHandle, new_shape: &[usize]) -> Result<GpuTensorHandle> {
         let mut out = 0u64;
         check(unsafe { rmhip_reshape(self.ctx, self.own(handle)?, new_shape.as_ptr(), new_shape.len(), &mut out) })?;

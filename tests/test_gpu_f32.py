@@ -76,10 +76,9 @@ def test_f32_boundary_is_f64_and_rounds_once(prov32, prov):
         A = rng.standard_normal(shape) * 10.0 ** rng.integers(-20, 20, size=shape)
         h = prov32.upload(A)
         assert h.shape == shape and same_bits(prov32.download_matrix(h), f32r(A))
-        r = prov32.reshape(h, (int(np.prod(shape)), 1))
-        assert prov32.buffer_bits(r) == 32 and same_bits(prov32.download(r), f32r(A).reshape(-1, order="F"))
+        r = prov32.reshape(h, (int(np.prod(shape)), 1))  # same buffer id, new shape
+        assert r.buffer_id == h.buffer_id and prov32.buffer_bits(r) == 32 and same_bits(prov32.download(r), f32r(A).reshape(-1, order="F"))
         prov32.free(r)
-        prov32.free(h)
     f = prov32.fill((5, 3), 0.1)
     assert prov32.buffer_bits(f) == 32 and same_bits(prov32.download(f), np.full(15, f32r(0.1)))
     B = rng.standard_normal((37, 19))

@@ -423,3 +423,45 @@ def test_comparison_and_logical_kats(oracle):
     assert np.array_equal(oracle.binary("and", a, b), [[1.0, 1.0, 1.0, 0.0]])   # NaN counts as non-zero
     assert np.array_equal(oracle.binary("xor", a, np.zeros((1, 4))), [[1.0, 1.0, 1.0, 0.0]])
     assert np.array_equal(oracle.unary("not", a), [[0.0, 0.0, 0.0, 1.0]])
+
+
+# ---- special functions: the reference's own known-answer tests (crates/runmat-runtime/src/builtins/math/elementwise) ----
+def test_special_function_kats(oracle):
+    import math
+
+    u = lambda op, xs: oracle.unary(op, np.array(xs, dtype=np.float64).reshape(-1, 1)).reshape(-1)
+    # gamma.rs tests `gamma_positive_integer`, `gamma_half_integer`, `gamma_negative_non_integer`, `gamma_matrix` (tol 1e-12),
+    # `gamma_pole_returns_inf`, `gamma_small_negative_not_infinite`
+    g = u("gamma", [5.0, 0.5, -0.5, 1.0, 3.0, 2.0, 4.0])
+    want = [24.0, math.sqrt(math.pi), -2.0 * math.sqrt(math.pi), 1.0, 2.0, 1.0, 6.0]
+    assert np.max(np.abs(g - want)) <= 1e-12
+    poles = u("gamma", [0.0, -3.0])
+    assert np.isposinf(poles[0]) and np.isinf(poles[1])
+    small = u("gamma", [-1.0e-10])[0]
+    assert np.isfinite(small) and small < 0 and abs(small) > 1e9
+    assert np.isnan(u("gamma", [np.nan, -np.inf])).all() and np.isposinf(u("gamma", [np.inf])[0])
+    # gammaln.rs `gammaln_scalar_values` (1e-14 / 1e-13), `gammaln_avoids_overflow_for_large_values` (1e-10),
+    # `gammaln_tiny_positive_values_use_log_asymptote` (1e-12), zero / inf / negative
+    gl = u("gammaln", [1.0, 5.0, 0.5, 171.0])
+    assert abs(gl[0]) <= 1e-14 and abs(gl[1] - math.log(24.0)) <= 1e-13 and abs(gl[2] - math.log(math.sqrt(math.pi))) <= 1e-14
+    assert abs(gl[3] - 706.5730622457875) <= 1e-10
+    tiny = 2.2250738585072014e-308 / 2.0
+    assert abs(u("gammaln", [tiny])[0] + math.log(tiny)) <= 1e-12
+    assert np.isposinf(u("gammaln", [0.0, np.inf])).all() and np.isnan(u("gammaln", [np.nan, -1.0])).all()
+    # factorial.rs: 5! = 120, 0! = 1, [0 1 3 5] -> [1 1 6 120], non-integers and negatives NaN, 171 -> Inf
+    assert np.array_equal(u("factorial", [5.0, 0.0, 1.0, 3.0, 4.0]), [120.0, 1.0, 1.0, 6.0, 24.0])
+    f = u("factorial", [2.5, -1.0, 171.0, np.inf, -np.inf, np.nan, 170.0])
+    assert np.isnan(f[0]) and np.isnan(f[1]) and np.isposinf(f[2]) and np.isposinf(f[3]) and np.isnan(f[4]) and np.isnan(f[5])
+    assert f[6] == math.prod(float(i) for i in range(1, 171)) or abs(f[6] / 7.257415615307994e306 - 1) < 1e-15
+    # nextpow2.rs: 9 -> 4, 0 -> 0, -3 -> 2, [0 1 3 9] -> [0 0 2 4], Inf -> Inf, NaN -> NaN
+    assert np.array_equal(u("nextpow2", [9.0, 0.0, -3.0, 1.0, 3.0]), [4.0, 0.0, 2.0, 0.0, 2.0])
+    assert np.isposinf(u("nextpow2", [np.inf])[0]) and np.isnan(u("nextpow2", [np.nan])[0])
+    # erfcinv.rs `scalar_values_match_reference_points` (values and tolerances verbatim), end points, domain
+    cases = [(0.3, 0.7328690779592166, 2e-14), (0.5, 0.4769362762044698, 2e-14), (1.5, -0.4769362762044698, 2e-14),
+             (0.999999999999, 8.862073205887489e-13, 2e-16), (1.000000000001, -8.863057115425171e-13, 2e-16),
+             (1e-100, 15.065574702592645, 5e-13), (2.2250738585072014e-308, 26.54325845425098, 5e-13)]
+    for x, want_v, tol in cases:
+        assert abs(u("erfcinv", [x])[0] - want_v) <= tol, x
+    e = u("erfcinv", [1.0, 0.0, 2.0, -0.1, 2.1, np.nan, 5e-324, 2.2250738585072014e-308])
+    assert e[0] == 0.0 and np.isposinf(e[1]) and np.isneginf(e[2]) and np.isnan(e[3:6]).all()
+    assert np.isfinite(e[6]) and e[6] > e[7] and e[6] < 32.0  # `tiny_tail_inputs_remain_ordered_and_finite`
