@@ -260,6 +260,10 @@ RMHIP_API int rmhip_lu(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf out5[5]);
  * (rectangular, pivot <= 1e-12) returns UNSUPPORTED/SINGULAR so the caller uses the CPU SVD path
  * (mldivide.rs:223-229 `.ok()`). Scalar A => b * (1/A) (mldivide.rs:321-325). */
 RMHIP_API int rmhip_mldivide(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out);
+/* `mrdivide` (lib.rs:2484-2490): X = B / A, i.e. X * A = B.  CPU semantics crates/runmat-runtime/src/builtins/math/linalg/ops/
+ * mrdivide.rs:317-341 (scalar A: B * (1/A); column counts must agree) and :379-388 (the solve is A' \ B' transposed
+ * back); here the same transposition around the LU solve, with the same soft failures as rmhip_mldivide. */
+RMHIP_API int rmhip_mrdivide(rmhip_ctx* ctx, rmhip_buf b, rmhip_buf a, rmhip_buf* out);
 /* `linsolve` + ProviderLinsolveOptions / ProviderLinsolveResult (lib.rs:2422-2429, 679-697); CPU
  * semantics crates/runmat-runtime/src/builtins/math/linalg/solve/linsolve.rs:691-726 (option order:
  * TRANSA transposes A and swaps LT<->UT), 769-833 (substitution; a zero diagonal entry is the
@@ -347,9 +351,31 @@ typedef struct rmhip_telemetry {
     uint64_t fusion_cache_hits, fusion_cache_misses;
     uint64_t kernel_launches;
     uint64_t bytes_allocated, bytes_pooled;
+    uint64_t linsolve_count, linsolve_ns;   /* ProviderTelemetry::linsolve / mrdivide (lib.rs:1342-1344) */
+    uint64_t mrdivide_count, mrdivide_ns;
 } rmhip_telemetry_t;
 RMHIP_API int rmhip_telemetry(rmhip_ctx* ctx, rmhip_telemetry_t* out);
 RMHIP_API int rmhip_reset_telemetry(rmhip_ctx* ctx);
+/* `ProviderTelemetry::solve_fallbacks` (lib.rs:1347, `ProviderFallbackStat` :1331-1335): one (reason, count) pair per
+ * distinct reason a solve was handed back to the caller's CPU path ("mldivide:unsupported", "mldivide:singular",
+ * "linsolve:unsupported", ...).  index >= the number of reasons returns RMHIP_ERR_NOT_FOUND. */
+RMHIP_API int rmhip_telemetry_solve_fallback(rmhip_ctx* ctx, size_t index, char* reason, size_t cap, uint64_t* count);
+/* `ProviderTelemetry::kernel_launches` (lib.rs:1355-1356, `KernelLaunchTelemetry` :1372-1378): bounded log of recent
+ * dispatches, oldest first (index 0); same kernel names and attribute keys as the reference's wgpu provider records
+ * (ops/telemetry.rs:26-34,140-146, helpers.rs:36-50): "fused_elementwise" {len, inputs, rank}, "fused_elementwise_multi"
+ * {.., num_outputs}, "fused_reduction" {reduce_len, slices, rank} / {wg, flavor}, "matmul" {m, n, k}. */
+typedef struct rmhip_kernel_attr {
+    char key[16];
+    uint64_t value;
+} rmhip_kernel_attr_t;
+typedef struct rmhip_kernel_launch {
+    char kernel[48];
+    char precision[8];  /* "f64" / "f32" */
+    uint32_t n_shape, n_tuning;
+    rmhip_kernel_attr_t shape[6];
+    rmhip_kernel_attr_t tuning[6];
+} rmhip_kernel_launch_t;
+RMHIP_API int rmhip_telemetry_kernel_launch(rmhip_ctx* ctx, size_t index, rmhip_kernel_launch_t* out);
 
 /* HIP-event timing on the context stream (for bench.py's roofline leg): begin records an event,
  * end records another, synchronizes and returns the elapsed milliseconds between them. */

@@ -227,6 +227,11 @@ public:
         check(rmhip_mldivide(ctx_, own(lhs), own(rhs), &out));
         return with_shape(out);
     }
+    GpuTensorHandle mrdivide(const GpuTensorHandle& lhs, const GpuTensorHandle& rhs) const {
+        uint64_t out = 0;
+        check(rmhip_mrdivide(ctx_, own(lhs), own(rhs), &out));
+        return with_shape(out);
+    }
     // ProviderLinsolveOptions / ProviderLinsolveResult (lib.rs:679-697, 2422-2429)
     struct LinsolveResult {
         GpuTensorHandle solution;

@@ -256,6 +256,18 @@ def mldivide_lu(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     return out.reshape((n, b.shape[1]), order="F")
 
 
+def mrdivide(b: np.ndarray, a: np.ndarray) -> np.ndarray:
+    """X = B / A as the CPU builtin computes it (crates/runmat-runtime/src/builtins/math/linalg/ops/mrdivide.rs:317-341,
+    379-388): scalar A divides by multiplying with its reciprocal; otherwise the SVD solve of A' X' = B', transposed back."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.size == 1:
+        return b * (1.0 / float(a.reshape(-1)[0]))
+    if b.shape[1] != a.shape[1]:
+        raise ValueError("mrdivide: column mismatch")
+    return mldivide_svd(np.ascontiguousarray(a.T), np.ascontiguousarray(b.T)).T
+
+
 def stochastic_evolution(state: int, data, drift: float, scale: float, steps: int):
     """-> (evolved array, new rng state)"""
     a = np.asarray(data, dtype=np.float64)

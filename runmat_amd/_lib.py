@@ -37,7 +37,19 @@ class Telemetry(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "fused_elementwise_count", "fused_elementwise_ns", "fused_reduction_count", "fused_reduction_ns",
         "matmul_count", "matmul_ns", "mldivide_count", "mldivide_ns", "upload_bytes", "download_bytes",
-        "fusion_cache_hits", "fusion_cache_misses", "kernel_launches", "bytes_allocated", "bytes_pooled")]
+        "fusion_cache_hits", "fusion_cache_misses", "kernel_launches", "bytes_allocated", "bytes_pooled",
+        "linsolve_count", "linsolve_ns", "mrdivide_count", "mrdivide_ns")]
+
+
+class KernelAttr(C.Structure):
+    """rmhip_kernel_attr_t (KernelAttrTelemetry, lib.rs:1366-1370)"""
+    _fields_ = [("key", C.c_char * 16), ("value", C.c_uint64)]
+
+
+class KernelLaunch(C.Structure):
+    """rmhip_kernel_launch_t (KernelLaunchTelemetry, lib.rs:1372-1378)"""
+    _fields_ = [("kernel", C.c_char * 48), ("precision", C.c_char * 8), ("n_shape", C.c_uint32), ("n_tuning", C.c_uint32),
+                ("shape", KernelAttr * 6), ("tuning", KernelAttr * 6)]
 
 
 class MatmulEpilogue(C.Structure):
@@ -112,6 +124,7 @@ SIGNATURES = {
     "rmhip_matmul_epilogue": (C.c_int, [_P, _BUF, _BUF, C.POINTER(MatmulEpilogue), _BUFP]),
     "rmhip_lu": (C.c_int, [_P, _BUF, _BUFP]),
     "rmhip_mldivide": (C.c_int, [_P, _BUF, _BUF, _BUFP]),
+    "rmhip_mrdivide": (C.c_int, [_P, _BUF, _BUF, _BUFP]),
     "rmhip_linsolve": (C.c_int, [_P, _BUF, _BUF, C.POINTER(LinsolveOptions), _BUFP, _DP]),
     "rmhip_transpose": (C.c_int, [_P, _BUF, _BUFP]),
     "rmhip_syrk": (C.c_int, [_P, _BUF, _BUFP]),
@@ -134,6 +147,8 @@ SIGNATURES = {
     "rmhip_stochastic_evolution_sharded": (C.c_int, [_P, _BUF, C.c_double, C.c_double, C.c_uint32, C.c_uint64, _BUFP]),
     "rmhip_telemetry": (C.c_int, [_P, C.POINTER(Telemetry)]),
     "rmhip_reset_telemetry": (C.c_int, [_P]),
+    "rmhip_telemetry_solve_fallback": (C.c_int, [_P, _SZ, C.c_char_p, _SZ, C.POINTER(C.c_uint64)]),
+    "rmhip_telemetry_kernel_launch": (C.c_int, [_P, _SZ, C.POINTER(KernelLaunch)]),
     "rmhip_timer_begin": (C.c_int, [_P]),
     "rmhip_timer_end": (C.c_int, [_P, _DP]),
 }

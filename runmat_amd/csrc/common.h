@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <initializer_list>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -88,7 +89,21 @@ struct Telemetry {
     std::atomic<uint64_t> cache_hits{0}, cache_misses{0};
     std::atomic<uint64_t> kernel_launches{0};
     std::atomic<uint64_t> bytes_allocated{0}, bytes_pooled{0};
+    std::atomic<uint64_t> linsolve_count{0}, linsolve_ns{0};
+    std::atomic<uint64_t> mrdivide_count{0}, mrdivide_ns{0};
 };
+
+// `KernelLaunchTelemetry` (lib.rs:1372-1378): names and keys are string literals, recording is a handful of stores
+struct LaunchRecord {
+    const char* kernel = nullptr;
+    int bits = 64;
+    int n_shape = 0, n_tuning = 0;
+    const char* shape_key[6];
+    uint64_t shape_val[6];
+    const char* tuning_key[6];
+    uint64_t tuning_val[6];
+};
+static constexpr int kLaunchLog = 64;  // bounded log, newest overwrites oldest
 
 struct FusedKernel;  // codegen.h
 
@@ -124,6 +139,12 @@ struct Context {
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     Telemetry tel;
+    LaunchRecord launch_log[kLaunchLog];
+    uint64_t launch_seq = 0;                                       // records written so far
+    std::vector<std::pair<const char*, uint64_t>> solve_fallbacks;  // reason (literal) -> count
+    void record_launch(const char* kernel, std::initializer_list<std::pair<const char*, uint64_t>> shape,
+                       std::initializer_list<std::pair<const char*, uint64_t>> tuning);
+    void record_solve_fallback(const char* reason);
 
     // LU look-ahead (lu.hip getrf_blocked): extra dynamic LDS requested by launch_dgemm so that only ONE
     // dgemm block fits per CU and latency-bound kernels of the other stream find room beside it

@@ -224,6 +224,33 @@ int Context::get(uint64_t id, Buffer* out) {
     return get_view(id, out);
 }
 
+void Context::record_launch(const char* kernel, std::initializer_list<std::pair<const char*, uint64_t>> shape,
+                            std::initializer_list<std::pair<const char*, uint64_t>> tuning) {
+    LaunchRecord& r = launch_log[launch_seq++ % kLaunchLog];
+    r.kernel = kernel;
+    r.bits = precision;
+    r.n_shape = r.n_tuning = 0;
+    for (const auto& kv : shape)
+        if (r.n_shape < 6) {
+            r.shape_key[r.n_shape] = kv.first;
+            r.shape_val[r.n_shape++] = kv.second;
+        }
+    for (const auto& kv : tuning)
+        if (r.n_tuning < 6) {
+            r.tuning_key[r.n_tuning] = kv.first;
+            r.tuning_val[r.n_tuning++] = kv.second;
+        }
+}
+
+void Context::record_solve_fallback(const char* reason) {
+    for (auto& kv : solve_fallbacks)
+        if (std::strcmp(kv.first, reason) == 0) {
+            kv.second++;
+            return;
+        }
+    solve_fallbacks.emplace_back(reason, 1);
+}
+
 void Context::ensure_max_lds(const void* kernel, size_t bytes) {
     for (const void* k : lds_opt_in)
         if (k == kernel) return;
@@ -532,6 +559,40 @@ int rmhip_telemetry(rmhip_ctx* ctx, rmhip_telemetry_t* out) {
     out->kernel_launches = t.kernel_launches;
     out->bytes_allocated = t.bytes_allocated;
     out->bytes_pooled = t.bytes_pooled;
+    out->linsolve_count = t.linsolve_count;
+    out->linsolve_ns = t.linsolve_ns;
+    out->mrdivide_count = t.mrdivide_count;
+    out->mrdivide_ns = t.mrdivide_ns;
+    return RMHIP_OK;
+}
+
+int rmhip_telemetry_solve_fallback(rmhip_ctx* ctx, size_t index, char* reason, size_t cap, uint64_t* count) {
+    CTX_OR_FAIL(ctx);
+    if (index >= c->solve_fallbacks.size()) return fail(RMHIP_ERR_NOT_FOUND, "solve_fallbacks: index %zu of %zu", index, c->solve_fallbacks.size());
+    if (reason && cap) std::snprintf(reason, cap, "%s", c->solve_fallbacks[index].first);
+    if (count) *count = c->solve_fallbacks[index].second;
+    return RMHIP_OK;
+}
+
+int rmhip_telemetry_kernel_launch(rmhip_ctx* ctx, size_t index, rmhip_kernel_launch_t* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    const uint64_t have = c->launch_seq < (uint64_t)kLaunchLog ? c->launch_seq : (uint64_t)kLaunchLog;
+    if (index >= have) return fail(RMHIP_ERR_NOT_FOUND, "kernel_launches: index %zu of %llu", index, (unsigned long long)have);
+    const LaunchRecord& r = c->launch_log[(c->launch_seq - have + index) % kLaunchLog];  // oldest first
+    std::memset(out, 0, sizeof *out);
+    std::snprintf(out->kernel, sizeof out->kernel, "%s", r.kernel ? r.kernel : "");
+    std::snprintf(out->precision, sizeof out->precision, "%s", r.bits == 32 ? "f32" : "f64");
+    out->n_shape = (uint32_t)r.n_shape;
+    out->n_tuning = (uint32_t)r.n_tuning;
+    for (int i = 0; i < r.n_shape; ++i) {
+        std::snprintf(out->shape[i].key, sizeof out->shape[i].key, "%s", r.shape_key[i]);
+        out->shape[i].value = r.shape_val[i];
+    }
+    for (int i = 0; i < r.n_tuning; ++i) {
+        std::snprintf(out->tuning[i].key, sizeof out->tuning[i].key, "%s", r.tuning_key[i]);
+        out->tuning[i].value = r.tuning_val[i];
+    }
     return RMHIP_OK;
 }
 
@@ -545,6 +606,10 @@ int rmhip_reset_telemetry(rmhip_ctx* ctx) {
     t.upload_bytes = t.download_bytes = 0;
     t.cache_hits = t.cache_misses = 0;
     t.kernel_launches = 0;
+    t.linsolve_count = t.linsolve_ns = 0;
+    t.mrdivide_count = t.mrdivide_ns = 0;
+    c->solve_fallbacks.clear();  // telemetry.rs:95-125: reset clears the fallback map and the launch log
+    c->launch_seq = 0;
     return RMHIP_OK;
 }
 

@@ -269,6 +269,9 @@ int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf*
         return fail(RMHIP_ERR_HIP, "fused_elementwise launch: %s", hipGetErrorString(e));
     }
     c->tel.kernel_launches++;
+    if (n_out == 1) c->record_launch("fused_elementwise", {{"len", len}, {"inputs", n_in}, {"rank", rank}}, {{"wg", (uint64_t)(fast ? t.block : t.bcast_block)}});
+    else c->record_launch("fused_elementwise_multi", {{"len", len}, {"inputs", n_in}, {"rank", rank}, {"num_outputs", n_out}},
+                          {{"wg", (uint64_t)(fast ? t.block : t.bcast_block)}});
     for (size_t k = 0; k < n_out; ++k) out_ids[k] = ids[k];
     RMHIP_TRACEF("fused_elementwise: launched");
     return RMHIP_OK;
@@ -366,6 +369,8 @@ int rmhip_fused_reduction(rmhip_ctx* ctx, const char* shader, const rmhip_buf* i
         return fail(RMHIP_ERR_HIP, "fused_reduction launch: %s", hipGetErrorString(e));
     }
     c->tel.kernel_launches += 2;
+    c->record_launch("fused_reduction", {{"reduce_len", reduce_len}, {"slices", num_slices}, {"rank", rank}},
+                     {{"wg", (uint64_t)(plan.contiguous ? plan.tx : 256)}, {"flavor", (uint64_t)flavor}});
     *out = oid;
     return RMHIP_OK;
 }
@@ -597,6 +602,7 @@ int rmhip_matmul(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
                 int rc = launch_sgemm_trans(c, ra.tview, rb.tview, m, n, k, ra.data_f32(), ra.tview ? k : m, rb.data_f32(),
                                             rb.tview ? n : k, ob.data_f32(), m);
                 if (rc) rmhip_free(ctx, *out);
+                else c->record_launch("matmul", {{"m", m}, {"n", n}, {"k", k}}, {{"mfma_f32", 1}, {"ta", (uint64_t)ra.tview}, {"tb", (uint64_t)rb.tview}});
                 return rc;
             }
         }
@@ -617,6 +623,7 @@ int rmhip_matmul(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
                                 0.0, ob.data(), m);
     else rc = launch_dgemm(c, m, n, k, 1.0, ab.data(), m, bb.data(), k, 0.0, ob.data(), m);
     if (rc) rmhip_free(ctx, *out);
+    else c->record_launch("matmul", {{"m", m}, {"n", n}, {"k", k}}, {{"mfma_f64", 1}, {"ta", (uint64_t)ab.tview}, {"tb", (uint64_t)bb.tview}});
     return rc;
 }
 
@@ -838,9 +845,63 @@ int rmhip_lu(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf out5[5]) {
     return RMHIP_OK;
 }
 
+static int mldivide_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, rmhip_buf* out);
+
+// solve_fallbacks (telemetry.rs:95-99): a soft failure of a solve is what sends the caller to its CPU path
+static int count_fallback(Context* c, int rc, const char* unsupported, const char* singular) {
+    if (rc == RMHIP_ERR_UNSUPPORTED) c->record_solve_fallback(unsupported);
+    else if (rc == RMHIP_ERR_SINGULAR) c->record_solve_fallback(singular);
+    return rc;
+}
+
 int rmhip_mldivide(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);
     ScopedTimer timer(&c->tel.mldivide_count, &c->tel.mldivide_ns);
+    return count_fallback(c, mldivide_impl(ctx, c, a, b, out), "mldivide:unsupported", "mldivide:singular");
+}
+
+int rmhip_mrdivide(rmhip_ctx* ctx, rmhip_buf b, rmhip_buf a, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    ScopedTimer timer(&c->tel.mrdivide_count, &c->tel.mrdivide_ns);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer ab, bb;
+    RMHIP_TRY(c->get_raw(a, &ab));
+    RMHIP_TRY(c->get_raw(b, &bb));
+    if (ab.shape.size() > 2 || bb.shape.size() > 2)
+        return count_fallback(c, fail(RMHIP_ERR_UNSUPPORTED, "mrdivide: only 2D supported"), "mrdivide:unsupported", "mrdivide:singular");
+    const std::vector<size_t> as = normalize_matrix_shape(ab.shape), bs = normalize_matrix_shape(bb.shape);
+    if (ab.numel == 1) {  // scalar divisor: lhs * (1/rhs), mrdivide.rs:321-325
+        RMHIP_TRY(c->get(a, &ab));
+        RMHIP_TRY(c->get(b, &bb));
+        double rhs = 0.0;
+        RMHIP_HIP_CHECK(hipMemcpyAsync(&rhs, ab.data(), sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        Buffer ob;
+        RMHIP_TRY(c->new_buffer(bs.data(), 2, out, &ob));
+        int rc = launch_scalar(c, RMHIP_SMUL, bb.data(), 1.0 / rhs, ob.data(), bb.numel);
+        if (rc) rmhip_free(ctx, *out);
+        return rc;
+    }
+    if (bs[1] != as[1]) return fail(RMHIP_ERR_SHAPE, "mrdivide: column mismatch (%zu vs %zu)", bs[1], as[1]);  // mrdivide.rs:327
+    // X = B / A  <=>  A' X' = B'  (mrdivide.rs:379-388): transpose views feed the LU path (a view is materialised on first use)
+    rmhip_buf at = 0, bt = 0, xt = 0, x = 0;
+    int rc = rmhip_transpose(ctx, a, &at);
+    if (!rc) rc = rmhip_transpose(ctx, b, &bt);
+    if (!rc) rc = mldivide_impl(ctx, c, at, bt, &xt);
+    if (!rc) rc = rmhip_transpose(ctx, xt, &x);
+    if (!rc) rc = c->settle_view(x);  // the result is a plain buffer, not a view of the temporary
+    if (at) rmhip_free(ctx, at);
+    if (bt) rmhip_free(ctx, bt);
+    if (xt) rmhip_free(ctx, xt);
+    if (rc) {
+        if (x) rmhip_free(ctx, x);
+        return count_fallback(c, rc, "mrdivide:unsupported", "mrdivide:singular");
+    }
+    *out = x;
+    return RMHIP_OK;
+}
+
+static int mldivide_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     Buffer ab, bb;
     RMHIP_TRY(c->get(a, &ab));
@@ -910,9 +971,18 @@ int rmhip_transpose(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out) {
     return RMHIP_OK;
 }
 
+static int linsolve_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, const rmhip_linsolve_options_t* opts, rmhip_buf* out,
+                         double* reciprocal_condition);
+
 int rmhip_linsolve(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, const rmhip_linsolve_options_t* opts, rmhip_buf* out,
                    double* reciprocal_condition) {
     CTX_OR_FAIL(ctx);
+    ScopedTimer timer(&c->tel.linsolve_count, &c->tel.linsolve_ns);
+    return count_fallback(c, linsolve_impl(ctx, c, a, b, opts, out, reciprocal_condition), "linsolve:unsupported", "linsolve:singular");
+}
+
+static int linsolve_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, const rmhip_linsolve_options_t* opts, rmhip_buf* out,
+                         double* reciprocal_condition) {
     if (!out || !opts) return fail(RMHIP_ERR_INVALID, "linsolve: null argument");
     Buffer ab, bb;
     RMHIP_TRY(c->get(a, &ab));

@@ -417,6 +417,12 @@ class HipProvider:
         self._check(self._lib.rmhip_mldivide(self._ctx, self._id(lhs), self._id(rhs), C.byref(out)))
         return self._handle(out.value)
 
+    def mrdivide(self, lhs: GpuTensorHandle, rhs: GpuTensorHandle) -> GpuTensorHandle:
+        """`mrdivide` (lib.rs:2484-2490): X = lhs / rhs, i.e. X * rhs = lhs."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_mrdivide(self._ctx, self._id(lhs), self._id(rhs), C.byref(out)))
+        return self._handle(out.value)
+
     def stochastic_evolution(self, state: GpuTensorHandle, drift: float, scale: float, steps: int,
                              draws_per_step: int = 0) -> GpuTensorHandle:
         """lib.rs:1759-1769; `draws_per_step` > 0 selects the sharded form (see include/rmhip.h)."""
@@ -539,9 +545,26 @@ class HipProvider:
 
     # -- telemetry / timing ---------------------------------------------------------------------
     def telemetry_snapshot(self) -> dict:
+        """`telemetry_snapshot` (lib.rs:3023-3045): the counters of `ProviderTelemetry` (:1337-1357) plus its two lists,
+        `solve_fallbacks` [(reason, count)] and `kernel_launches` [{kernel, precision, shape, tuning}] (oldest first)."""
         t = _lib.Telemetry()
         self._check(self._lib.rmhip_telemetry(self._ctx, C.byref(t)))
-        return {f: int(getattr(t, f)) for f, _ in t._fields_}
+        snap = {f: int(getattr(t, f)) for f, _ in t._fields_}
+        fallbacks, i = [], 0
+        buf, cnt = C.create_string_buffer(96), C.c_uint64()
+        while self._lib.rmhip_telemetry_solve_fallback(self._ctx, i, buf, 96, C.byref(cnt)) == _lib.OK:
+            fallbacks.append((buf.value.decode(), int(cnt.value)))
+            i += 1
+        launches, i = [], 0
+        rec = _lib.KernelLaunch()
+        while self._lib.rmhip_telemetry_kernel_launch(self._ctx, i, C.byref(rec)) == _lib.OK:
+            launches.append({"kernel": rec.kernel.decode(), "precision": rec.precision.decode(),
+                             "shape": {rec.shape[k].key.decode(): int(rec.shape[k].value) for k in range(rec.n_shape)},
+                             "tuning": {rec.tuning[k].key.decode(): int(rec.tuning[k].value) for k in range(rec.n_tuning)}})
+            i += 1
+        snap["solve_fallbacks"] = fallbacks
+        snap["kernel_launches_log"] = launches
+        return snap
 
     def reset_telemetry(self) -> None:
         self._check(self._lib.rmhip_reset_telemetry(self._ctx))

@@ -51,6 +51,7 @@ extern "C" {
     fn rmhip_matmul(ctx: *mut RmhipCtx, a: u64, b: u64, out: *mut u64) -> c_int;
     fn rmhip_lu(ctx: *mut RmhipCtx, a: u64, out5: *mut u64) -> c_int;
     fn rmhip_mldivide(ctx: *mut RmhipCtx, a: u64, b: u64, out: *mut u64) -> c_int;
+    fn rmhip_mrdivide(ctx: *mut RmhipCtx, b: u64, a: u64, out: *mut u64) -> c_int;
     fn rmhip_linsolve(ctx: *mut RmhipCtx, a: u64, b: u64, opts: *const RmhipLinsolveOptions, out: *mut u64, rcond: *mut c_double) -> c_int;
     fn rmhip_transpose(ctx: *mut RmhipCtx, a: u64, out: *mut u64) -> c_int;
     fn rmhip_syrk(ctx: *mut RmhipCtx, a: u64, out: *mut u64) -> c_int;
@@ -393,6 +394,13 @@ impl AccelProvider for HipProvider {
         Box::pin(async move {
             let mut out = 0u64;
             check(unsafe { rmhip_mldivide(self.ctx, self.own(lhs)?, self.own(rhs)?, &mut out) })?;
+            self.handle(out)
+        })
+    }
+    fn mrdivide<'a>(&'a self, lhs: &'a GpuTensorHandle, rhs: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_mrdivide(self.ctx, self.own(lhs)?, self.own(rhs)?, &mut out) })?;
             self.handle(out)
         })
     }

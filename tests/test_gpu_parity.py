@@ -1197,3 +1197,61 @@ def test_special_unary_vs_oracle(prov, oracle, op):
             sub = ~normal
             assert np.all(np.isfinite(got[fin][sub])) and np.all(got[fin][sub] < 32.0) and np.all(got[fin][sub] > 26.5)
             assert np.max(np.abs(got[fin][sub] - want[fin][sub])) <= 2e-3
+
+
+def test_mrdivide_and_solve_telemetry(prov, oracle):
+    """`mrdivide` (lib.rs:2484) with the reference's KATs (mrdivide.rs `solves_square_system`, `divides_matrix_by_scalar`,
+    `reports_dimension_mismatch`), a larger system vs the oracle, and the solve counters / fallback reasons /
+    kernel-launch log of `ProviderTelemetry` (lib.rs:1337-1357)."""
+    from runmat_amd import ProviderError
+
+    prov.reset_telemetry()
+    a = np.array([1.0, 3.0, 2.0, 4.0]).reshape(2, 2, order="F")
+    b = np.array([5.0, 7.0, 6.0, 8.0]).reshape(2, 2, order="F")
+    x = prov.download_matrix(prov.mrdivide(prov.upload(a), prov.upload(b)))
+    assert np.max(np.abs(x.reshape(-1, order="F") - [3.0, 2.0, -2.0, -1.0])) < 1e-12
+    s = prov.download_matrix(prov.mrdivide(prov.upload(np.array([[2.0, 4.0, 6.0]])), prov.upload(np.array([[2.0]]))))
+    assert np.array_equal(s, [[1.0, 2.0, 3.0]])
+    with pytest.raises(ProviderError) as e:  # column counts must agree (mrdivide.rs:327)
+        prov.mrdivide(prov.upload(np.ones((1, 2))), prov.upload(np.ones((3, 1))))
+    assert e.value.code == 3
+    rng = np.random.default_rng(9)
+    n, m = 300, 17
+    A = rng.uniform(-1, 1, (n, n)) + n * np.eye(n)
+    B = rng.uniform(-1, 1, (m, n))
+    X = prov.download_matrix(prov.mrdivide(prov.upload(B), prov.upload(A)))
+    assert X.shape == (m, n) and np.max(np.abs(X - oracle.mrdivide(B, A))) <= 1e-12
+    assert np.linalg.norm(X @ A - B) <= 1e-12 * n * np.linalg.norm(A) * np.linalg.norm(X)
+    # soft failures are counted by reason (telemetry.rs:95-99)
+    with pytest.raises(ProviderError):
+        prov.mrdivide(prov.upload(np.ones((2, 3))), prov.upload(np.ones((4, 3))))  # rectangular divisor: CPU least squares
+    with pytest.raises(ProviderError):
+        prov.mldivide(prov.upload(np.array([[1.0, 2.0], [2.0, 4.0]])), prov.upload(np.ones((2, 1))))
+    with pytest.raises(ProviderError):
+        prov.mldivide(prov.upload(np.ones((3, 2))), prov.upload(np.ones((3, 1))))
+    prov.linsolve(prov.upload(A), prov.upload(B.T.copy()))
+    t = prov.telemetry_snapshot()
+    assert t["mrdivide_count"] == 5 and t["mldivide_count"] == 2 and t["linsolve_count"] == 1 and t["mrdivide_ns"] > 0
+    fb = dict(t["solve_fallbacks"])
+    assert fb == {"mrdivide:unsupported": 1, "mldivide:singular": 1, "mldivide:unsupported": 1}
+    # kernel-launch log: names and attribute keys of the reference's wgpu provider (ops/telemetry.rs:26-34, 140-146; helpers.rs:36-50)
+    from runmat_amd.fusion import FusionGroupPlan, sin_mul_add_plan
+    from runmat_amd.provider import ReductionFlavor
+
+    prov.reset_telemetry()
+    plan, out_id = sin_mul_add_plan()
+    hs = [prov.upload(rng.uniform(-1, 1, (33, 5))) for _ in range(3)]
+    prov.fused_elementwise(plan.generate_wgsl_for_output(out_id, "f64"), hs, (33, 5), 165)
+    red = FusionGroupPlan()
+    v = red.primitive("ElemMul", red.input(), red.input())
+    prov.fused_reduction(red.generate_reduction_wgsl(v, "f64", axis=0), hs[:2], (5,), 33, 5, 256, ReductionFlavor.Mean())
+    prov.matmul(hs[0], prov.transpose(hs[1]))
+    log = prov.telemetry_snapshot()["kernel_launches_log"]
+    assert [r["kernel"] for r in log] == ["fused_elementwise", "fused_reduction", "matmul"]
+    assert log[0]["precision"] == "f64" and log[0]["shape"] == {"len": 165, "inputs": 3, "rank": 2} and "wg" in log[0]["tuning"]
+    assert log[1]["shape"] == {"reduce_len": 33, "slices": 5, "rank": 1} and log[1]["tuning"]["flavor"] == 1
+    assert log[2]["shape"] == {"m": 33, "n": 33, "k": 5} and log[2]["tuning"]["tb"] == 1
+    for _ in range(70):  # bounded log: newest last, oldest dropped
+        prov.free(prov.matmul(hs[0], prov.transpose(hs[1])))
+    log = prov.telemetry_snapshot()["kernel_launches_log"]
+    assert len(log) == 64 and all(r["kernel"] == "matmul" for r in log)

@@ -465,3 +465,12 @@ def test_special_function_kats(oracle):
     e = u("erfcinv", [1.0, 0.0, 2.0, -0.1, 2.1, np.nan, 5e-324, 2.2250738585072014e-308])
     assert e[0] == 0.0 and np.isposinf(e[1]) and np.isneginf(e[2]) and np.isnan(e[3:6]).all()
     assert np.isfinite(e[6]) and e[6] > e[7] and e[6] < 32.0  # `tiny_tail_inputs_remain_ordered_and_finite`
+
+
+def test_mrdivide_kats(oracle):
+    # mrdivide.rs tests `solves_square_system` ([1 2;3 4] / [5 6;7 8] = [3 -2;2 -1], 1e-12), `divides_matrix_by_scalar`
+    a = np.array([1.0, 3.0, 2.0, 4.0]).reshape(2, 2, order="F")
+    b = np.array([5.0, 7.0, 6.0, 8.0]).reshape(2, 2, order="F")
+    x = oracle.mrdivide(a, b)
+    assert np.max(np.abs(x.reshape(-1, order="F") - [3.0, 2.0, -2.0, -1.0])) < 1e-12
+    assert np.array_equal(oracle.mrdivide(np.array([[2.0, 4.0, 6.0]]), np.array([[2.0]])), [[1.0, 2.0, 3.0]])
