@@ -36,6 +36,20 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TF = 78.6   # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (v_mfma_f64_16x16x4_f64, 64 cyc)
 
 
+def host_info() -> dict:
+    """The box the CPU baseline ran on: CPU model and core count; the baselines use ONE thread, like
+    the reference's single-threaded CPU path."""
+    model = "unknown"
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"host_cpu": model, "host_logical_cores": os.cpu_count() or 0}
+
+
 def cpu_baseline_fused(budget_s: float = 12.0):
     """Oracle (C port of the reference CPU path: 3 passes, 3 temporaries, libm sin) on one core."""
     from oracle import oracle
@@ -58,17 +72,24 @@ def cpu_baseline_fused(budget_s: float = 12.0):
 
 
 def cpu_baseline_dgemm():
+    """Naive column-major triple loop (linalg.rs:6-32) at two sizes; the 8192^3 figure is the n^3 extrapolation the
+    survey planned, labelled as such."""
     from oracle import oracle
 
-    n = 1024
-    A = oracle.fill_uniform(11, -1.0, 1.0, n * n).reshape(n, n, order="F")
-    B = oracle.fill_uniform(12, -1.0, 1.0, n * n).reshape(n, n, order="F")
-    t0 = time.perf_counter()
-    oracle.matmul(A, B)
-    dt = time.perf_counter() - t0
-    return {"value": round(2.0 * n ** 3 / dt / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": "port",
-            "sample": f"naive column-major triple loop (linalg.rs:6-32) at {n}^3, {dt:.1f} s; the 8192^3 "
-                      "workload extrapolates ~n^3"}
+    pts = []
+    for n in (768, 1280):
+        A = oracle.fill_uniform(11, -1.0, 1.0, n * n).reshape(n, n, order="F")
+        B = oracle.fill_uniform(12, -1.0, 1.0, n * n).reshape(n, n, order="F")
+        t0 = time.perf_counter()
+        oracle.matmul(A, B)
+        pts.append((n, time.perf_counter() - t0))
+    (n0, t0_), (n1, t1_) = pts
+    rate = 2.0 * n1 ** 3 / t1_ / 1e9
+    expo = float(np.log(t1_ / t0_) / np.log(n1 / n0))  # measured growth exponent (cache effects push it above 3)
+    est_8192_s = t1_ * (8192.0 / n1) ** max(3.0, expo)
+    return {"value": round(rate, 4), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+            "sample": f"naive triple loop at {n0}^3 ({t0_:.2f} s) and {n1}^3 ({t1_:.2f} s): time ~ n^{expo:.2f}; "
+                      f"extrapolated to 8192^3: {est_8192_s / 60.0:.0f} min (not run)"}
 
 
 def cpu_baseline_chain():
@@ -116,6 +137,9 @@ def cpu_baseline_mldivide():
     return {"value": round(flops / dt / 1e9, 5), "unit": "GFLOP/s", "cores": 1, "kind": "port",
             "sample": f"SVD-based solve (mldivide.rs:380-404 restated) at n={n}, {dt:.1f} s, LU-equivalent flop count; "
                       f"max|x-1|={float(np.max(np.abs(x - 1.0))):.1e}; cost grows ~n^3"}
+
+
+PMC_TRAFFIC_SOURCE = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured in this run)"
 
 
 def pmc_traffic(kernel_key: str):
@@ -172,6 +196,13 @@ def main() -> None:
 
     prov = HipProvider(local_rank)
     n = N_DIM
+    # Data-path collectives go through the C ABI (rmhip_comm_*: RCCL over xGMI, one rank per GPU); torch.distributed
+    # is the control plane only (rendezvous of the 128-byte communicator id, the timing reduction).
+    from runmat_amd import sharding as sh
+
+    group = sh.Group.from_env()
+    if world > 1:
+        group.with_native_comm(prov, transport="rccl" if backend == "nccl" else "shm")
 
     def barrier():
         prov.synchronize()
@@ -253,7 +284,7 @@ def main() -> None:
             "config": {"workload": "fused D=sin(A).*B+C 8192x8192 f64 via rmhip_fused_elementwise (WGSL request)",
                        "bytes_per_step_per_gpu": fused_bytes, "parallelism": f"independent x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("rm_ew_fast"),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("rm_ew_fast"), "traffic_source": PMC_TRAFFIC_SOURCE,
                          "kernel": "rm_ew_fast (hipRTC, generated)", "kernel_ms": round(kern_ms, 5)},
         }
 
@@ -270,16 +301,13 @@ def main() -> None:
                        "parallelism": f"row-block x{world}, B replicated, no collective"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TF,
                          "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TF, 4),
-                         "traffic": pmc_traffic("k_dgemm"), "kernel": "k_dgemm<false,false> (v_mfma_f64_16x16x4_f64)",
+                         "traffic": pmc_traffic("k_dgemm"), "traffic_source": PMC_TRAFFIC_SOURCE, "kernel": "k_dgemm<false,false> (v_mfma_f64_16x16x4_f64)",
                          "kernel_ms": round(kern_ms, 5)},
         }
 
     def mc_record(steps, warmup):
         """BASELINE configs[3]: Monte-Carlo GBM, M = 1e8 paths (sharded over ranks with LCG skip-ahead),
         T = 1 step, planner-shaped fused kernels; one step = one full pricing."""
-        from runmat_amd import sharding as sh
-
-        group = sh.Group.from_env()
         M, T = 100_000_000, 1
         price = 0.0
         for _ in range(warmup):
@@ -306,9 +334,6 @@ def main() -> None:
     def mc_evolved_record(steps, warmup):
         """Benchmark-shaped secondary of SURVEY.md 8(d) config 4: M = 1e6 paths, T = 256 steps, the whole time
         loop as ONE `stochastic_evolution` call (state in registers) + one fused payoff reduction."""
-        from runmat_amd import sharding as sh
-
-        group = sh.Group.from_env()
         M, T = 1_000_000, 256
         price = 0.0
         for _ in range(warmup):
@@ -377,9 +402,6 @@ def main() -> None:
         if cyclic:
             # multi-GPU: 1-D block-column cyclic LU, one panel broadcast per block (runmat_amd/sharding.py).
             # Every rank builds the same A, keeps only the column blocks it owns.
-            from runmat_amd import sharding as sh
-
-            group = sh.Group.from_env()
             nbk = 512
             blocks = sh.owned_blocks(nn, nbk, group)
 
@@ -418,11 +440,11 @@ def main() -> None:
             "dtype": "f64",
             "config": {"workload": "x=A\\b 16384x16384 f64 via rmhip_mldivide, A=U(-1,1), b=A*1", "flops_per_step": flops,
                        "max_abs_err_vs_ones": err,
-                       "parallelism": (f"block-column cyclic x{world}, nb=512, one panel broadcast per block" if cyclic
-                                       else "single GPU, recursive LU")},
+                       "parallelism": (f"block-column cyclic x{world}, nb=512, one panel broadcast per block (rmhip_comm_bcast, depth-1 look-ahead)" if cyclic
+                                       else "single GPU, blocked LU with look-ahead")},
             "roofline": {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 3), "peak": FP64_MFMA_PEAK_TF,
                          "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF, 4), "traffic": None,
-                         "kernel": "k_lu_col chain + k_dgemm trailing updates (whole solve, wall clock)"},
+                         "kernel": "k_lu_panel2 chain + k_dgemm trailing updates (whole solve, wall clock)"},
         }
 
     def chain_record(steps, warmup):
@@ -500,7 +522,7 @@ def main() -> None:
                        "bytes_per_step_per_gpu": nbytes, "elements_per_s": round(world * n * n / (ms * 1e-3), 1),
                        "parallelism": f"independent x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("rm_ew_fast_f32"),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("rm_ew_fast_f32"), "traffic_source": PMC_TRAFFIC_SOURCE,
                          "kernel": "rm_ew_fast (f32 variant: 16-byte vectors of four, body in f64)", "kernel_ms": round(kern_ms, 5)},
         }
 
@@ -577,6 +599,11 @@ def main() -> None:
                 a["cpu_baseline"] = cpu_baseline_mldivide()
             elif "14-op chain" in a["metric"]:
                 a["cpu_baseline"] = cpu_baseline_chain()
+    if "cpu_baseline" in out:
+        out["cpu_baseline"].update(host_info())
+    for a in out.get("also", []):
+        if "cpu_baseline" in a:
+            a["cpu_baseline"].update(host_info())
     info = prov.device_info_struct()
     out["device"] = {"arch": info["arch"], "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"],
                      "hbm_bytes": info["total_memory_bytes"]}

@@ -313,6 +313,40 @@ RMHIP_API int rmhip_blk_lu(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf* ipi
 /* Apply those interchanges (in order) to every column of a view whose row 0 is the panel's row 0. */
 RMHIP_API int rmhip_blk_swap_rows(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf ipiv);
 
+/* ---- multi-GPU collectives ------------------------------------------------------------------------- *
+ * One process per GPU, one context per process.  The reference has no multi-device code; these entry
+ * points are what the sharded forms of the hot path need from a host that is not Python: a row-block
+ * all-gather for a replicated C = A*B, an ordered small-vector exchange for reductions / Monte-Carlo partial sums, and
+ * the panel broadcast of the block-column-cyclic A\b.  Rendezvous is the host's business: rank 0 creates an id, the
+ * host distributes its RMHIP_COMM_ID_BYTES bytes by any means (MPI, a file, torch.distributed), every rank calls
+ * rmhip_comm_init with it.  Collectives must be issued in the same order on every rank; they are enqueued on the
+ * context's stream like every other call (results are ordered behind them), except the asynchronous broadcast. */
+#define RMHIP_COMM_ID_BYTES 128
+enum rmhip_comm_transport {
+    RMHIP_COMM_RCCL = 0,     /* one rank per GPU; RCCL over xGMI / PCIe (librccl is loaded on first use)            */
+    RMHIP_COMM_HOST_SHM = 1  /* ranks of ONE node staged through POSIX shared memory: several ranks may share a GPU */
+};
+RMHIP_API int rmhip_comm_unique_id(int transport, void* id_out /* RMHIP_COMM_ID_BYTES */);
+RMHIP_API int rmhip_comm_init(rmhip_ctx* ctx, const void* unique_id, int rank, int world);
+RMHIP_API int rmhip_comm_destroy(rmhip_ctx* ctx);
+/* rank 0 / world 1 when the context has no communicator */
+RMHIP_API int rmhip_comm_rank(rmhip_ctx* ctx, int* rank, int* world);
+RMHIP_API int rmhip_comm_barrier(rmhip_ctx* ctx);
+/* In-place broadcast of a sub-block (or, with the full extent, of a whole buffer) from `root`.  async != 0: the
+ * broadcast runs on the context's communication stream behind everything enqueued so far, and later calls do NOT wait
+ * for it - the look-ahead of the block-cyclic solver posts the next panel's broadcast and keeps updating; call
+ * rmhip_comm_wait before anything reads (or frees) the block.  Only dense blocks (whole columns) stay asynchronous;
+ * a strided sub-block is packed through a staging buffer and the call stream waits for it. */
+RMHIP_API int rmhip_comm_bcast(rmhip_ctx* ctx, const rmhip_view_t* block, int root, int async);
+RMHIP_API int rmhip_comm_wait(rmhip_ctx* ctx);
+/* Every rank contributes its k-element f64 vector `local`; *out is a new [k, world] buffer, column r = rank r's values,
+ * identical on all ranks: the caller adds the columns in rank order, so sums do not depend on a reduction tree. */
+RMHIP_API int rmhip_comm_allgather_f64(rmhip_ctx* ctx, rmhip_buf local, rmhip_buf* out);
+/* Row-block all-gather of a column-major matrix: rank r holds rows [start_r, stop_r) x n of a rows_total x n matrix,
+ * the balanced contiguous split of rows_total in units of `granule` (first ranks take the extra units, the last one the
+ * ragged tail); *out is the replicated rows_total x n matrix. */
+RMHIP_API int rmhip_comm_allgather_rows(rmhip_ctx* ctx, rmhip_buf local, size_t rows_total, size_t granule, rmhip_buf* out);
+
 /* ---- RNG  (lib.rs:1713-1728, 1772) ---------------------------------------------------------- */
 
 /* `set_rng_state`: raw 64-bit LCG state (random.rs:7-13). rmhip_rng_seed applies mix_seed

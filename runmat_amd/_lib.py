@@ -14,6 +14,8 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "csrc" / "librmhip.so"
 
 OK = 0
+COMM_ID_BYTES = 128
+COMM_RCCL, COMM_HOST_SHM = 0, 1
 ERR_INVALID, ERR_UNSUPPORTED, ERR_SHAPE, ERR_HIP, ERR_NOT_FOUND = 1, 2, 3, 4, 5
 ERR_COMPILE, ERR_SINGULAR, ERR_OOM, ERR_NO_DEVICE = 6, 7, 8, 9
 
@@ -138,6 +140,15 @@ SIGNATURES = {
     "rmhip_blk_trsm": (C.c_int, [_P, C.c_int, C.POINTER(View), C.POINTER(View)]),
     "rmhip_blk_lu": (C.c_int, [_P, C.POINTER(View), _BUFP, C.POINTER(C.c_int)]),
     "rmhip_blk_swap_rows": (C.c_int, [_P, C.POINTER(View), _BUF]),
+    "rmhip_comm_unique_id": (C.c_int, [C.c_int, _P]),
+    "rmhip_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "rmhip_comm_destroy": (C.c_int, [_P]),
+    "rmhip_comm_rank": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rmhip_comm_barrier": (C.c_int, [_P]),
+    "rmhip_comm_bcast": (C.c_int, [_P, C.POINTER(View), C.c_int, C.c_int]),
+    "rmhip_comm_wait": (C.c_int, [_P]),
+    "rmhip_comm_allgather_f64": (C.c_int, [_P, _BUF, _BUFP]),
+    "rmhip_comm_allgather_rows": (C.c_int, [_P, _BUF, _SZ, _SZ, _BUFP]),
     "rmhip_set_rng_state": (C.c_int, [_P, C.c_uint64]),
     "rmhip_get_rng_state": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "rmhip_rng_seed": (C.c_int, [_P, C.c_uint64]),

@@ -106,6 +106,7 @@ struct LaunchRecord {
 static constexpr int kLaunchLog = 64;  // bounded log, newest overwrites oldest
 
 struct FusedKernel;  // codegen.h
+struct Comm;         // comm.cpp
 
 struct Context {
     int device = 0;
@@ -158,6 +159,7 @@ struct Context {
     int precision = 64;
     std::vector<uint64_t> narrow_pending;  // buffers created by new_buffer since the enclosing entry point began
     int trsm_base = 128;  // base width of the triangular-solve recursion (64 on the main stream under LU look-ahead)
+    Comm* comm = nullptr;  // communicator of the multi-GPU entry points (rmhip_comm_init), owned by the context
 
     // ---- helpers (rmhip_core.cpp) ----
     int alloc_device(size_t numel, std::shared_ptr<Allocation>* out);
@@ -303,5 +305,6 @@ int lu_extract_device(Context* c, const double* LU, size_t rows, size_t cols, co
 
 // opaque handle -> Context (rmhip_core.cpp)
 Context* context_of(rmhip_ctx* h);
+void comm_destroy(Context* c);  // comm.cpp
 
 }  // namespace rmhip

@@ -337,6 +337,7 @@ int rmhip_shutdown(rmhip_ctx* ctx) {
     Context* c = &ctx->c;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    comm_destroy(c);
     {
         std::lock_guard<std::mutex> lk(c->mu);
         c->kernel_cache.clear();

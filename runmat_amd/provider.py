@@ -519,6 +519,54 @@ class HipProvider:
         va = self._view(a)
         self._check(self._lib.rmhip_blk_swap_rows(self._ctx, C.byref(va), self._id(ipiv)))
 
+    # -- multi-GPU collectives (include/rmhip.h; no counterpart in the reference) ------------------
+    @staticmethod
+    def comm_unique_id(transport: str = "rccl") -> bytes:
+        """Rank 0 creates the id; the host distributes these 128 bytes to every rank (any transport)."""
+        lib = _lib.load()
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        rc = lib.rmhip_comm_unique_id(_lib.COMM_HOST_SHM if transport in ("shm", "host") else _lib.COMM_RCCL, buf)
+        if rc != _lib.OK:
+            raise ProviderError(rc, _lib.last_error())
+        return bytes(buf.raw)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int) -> None:
+        buf = C.create_string_buffer(bytes(unique_id), _lib.COMM_ID_BYTES)
+        self._check(self._lib.rmhip_comm_init(self._ctx, buf, int(rank), int(world)))
+
+    def comm_destroy(self) -> None:
+        self._check(self._lib.rmhip_comm_destroy(self._ctx))
+
+    def comm_rank(self) -> Tuple[int, int]:
+        r, w = C.c_int(), C.c_int()
+        self._check(self._lib.rmhip_comm_rank(self._ctx, C.byref(r), C.byref(w)))
+        return int(r.value), int(w.value)
+
+    def comm_barrier(self) -> None:
+        self._check(self._lib.rmhip_comm_barrier(self._ctx))
+
+    def comm_bcast(self, block, root: int, async_: bool = False) -> None:
+        """In-place broadcast of a handle (whole buffer) or a view tuple (buf, row_off, col_off, rows, cols)."""
+        if isinstance(block, GpuTensorHandle):
+            rows = block.shape[0] if block.shape else 1
+            cols = int(np.prod(block.shape[1:])) if len(block.shape) > 1 else 1
+            block = (block, 0, 0, rows, cols)
+        v = self._view(block)
+        self._check(self._lib.rmhip_comm_bcast(self._ctx, C.byref(v), int(root), 1 if async_ else 0))
+
+    def comm_wait(self) -> None:
+        self._check(self._lib.rmhip_comm_wait(self._ctx))
+
+    def comm_allgather_f64(self, local: GpuTensorHandle) -> GpuTensorHandle:
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_comm_allgather_f64(self._ctx, self._id(local), C.byref(out)))
+        return self._handle(out.value)
+
+    def comm_allgather_rows(self, local: GpuTensorHandle, rows_total: int, granule: int = 128) -> GpuTensorHandle:
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_comm_allgather_rows(self._ctx, self._id(local), int(rows_total), int(granule), C.byref(out)))
+        return self._handle(out.value)
+
     # -- RNG ------------------------------------------------------------------------------------
     def set_rng_state(self, state: int) -> None:
         self._check(self._lib.rmhip_set_rng_state(self._ctx, int(state) & 0xFFFFFFFFFFFFFFFF))

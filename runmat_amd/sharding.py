@@ -59,11 +59,29 @@ def lcg_advance(state: int, delta: int) -> int:
 
 @dataclass
 class Group:
-    """Thin view of the process group: rank, world and an ordered all-gather of small f64 vectors."""
+    """Thin view of the process group: rank, world and an ordered all-gather of small f64 vectors.
+
+    Two data paths: `native` (a provider whose context holds a communicator, `rmhip_comm_init`: every exchange below is
+    one C-ABI collective - RCCL over xGMI, or the host shared-memory transport when ranks share a GPU), or
+    `torch.distributed` tensors (the CPU tests' oracle-backed doubles on gloo).  `dist` stays the control plane
+    (rendezvous, the bench's timing reduction) in both."""
     rank: int = 0
     world: int = 1
     dist: Optional[object] = None  # torch.distributed module when world > 1
     device: str = "cpu"            # "cuda" for nccl, "cpu" for gloo
+    native: Optional[object] = None  # HipProvider with a communicator of this rank / world
+
+    def with_native_comm(self, prov, transport: str = "rccl") -> "Group":
+        """Create the C-ABI communicator on `prov`: rank 0 makes the id, the control plane distributes its 128 bytes."""
+        if self.world > 1:
+            payload = [prov.comm_unique_id(transport) if self.rank == 0 else None]
+            self.dist.broadcast_object_list(payload, src=0)
+            uid = payload[0]
+        else:
+            uid = prov.comm_unique_id(transport)
+        prov.comm_init(uid, self.rank, self.world)
+        self.native = prov
+        return self
 
     @staticmethod
     def from_env() -> "Group":
@@ -79,6 +97,14 @@ class Group:
         local = np.asarray(values, dtype=np.float64).reshape(1, -1)
         if self.world == 1:
             return local
+        if self.native is not None:
+            p = self.native
+            h = p.upload(local.reshape(-1, 1))
+            g = p.comm_allgather_f64(h)
+            out = p.download_matrix(g).T.copy()  # [k, world] -> [world, k]
+            p.free(h)
+            p.free(g)
+            return out
         import torch
 
         t = torch.from_numpy(local.copy()).to(self.device)
@@ -96,7 +122,10 @@ class Group:
 
     def barrier(self) -> None:
         if self.world > 1:
-            self.dist.barrier()
+            if self.native is not None:
+                self.native.comm_barrier()
+            else:
+                self.dist.barrier()
 
 
 # ---- matmul ------------------------------------------------------------------------------------
@@ -141,6 +170,8 @@ def gather_row_blocks_device(group: Group, prov, c_rows, rows_total: int):
     if group.world == 1:
         return c_rows, None
     _require_f64(prov, "gather_row_blocks_device")  # the gathered buffer is adopted with rmhip_wrap_external (f64 memory)
+    if group.native is not None:  # one C-ABI collective (rmhip_comm_allgather_rows): no torch tensor on the data path
+        return group.native.comm_allgather_rows(c_rows, rows_total, 128), None
     counts = [partition(rows_total, group.world, r, 128) for r in range(group.world)]
     width = max(c1 - c0 for c0, c1 in counts)
     view = _torch_view(prov, c_rows, (n, rows_g))  # column-major rows_g x n == row-major n x rows_g
@@ -335,6 +366,9 @@ def _bcast(group: Group, prov, handle, shape, src: int) -> None:
     gloo (CPU tests): the test double exposes `.arr`."""
     if group.world == 1:
         return
+    if group.native is not None:
+        group.native.comm_bcast(handle, src)
+        return
     import torch
 
     if group.device == "cuda":
@@ -381,41 +415,71 @@ def mldivide_block_cyclic(prov, group: Group, a_local, n: int, b, nb: int = 512)
     mine = owned_blocks(n, nb, group)
     ncols_loc = sum(min(nb, n - p * nb) for p in mine)
     y = prov.blk_copy((b, 0, 0, n, nrhs))
-    for p in range(nblocks):
-        j = p * nb
-        w = min(nb, n - j)
-        owner = p % group.world
+    overlap = group.native is not None and group.world > 1  # asynchronous broadcasts on the communication stream
+
+    def post_panel(p):
+        """Owner: factor block p (its columns are up to date) and send it; everyone else: post the receive.  With a
+        native communicator both are asynchronous: the transfer runs under whatever is enqueued next."""
+        j, w, owner = p * nb, min(nb, n - p * nb), p % group.world
         if group.rank == owner:
             lq = local_col_offset(p, nb, group)
             ipiv, info = prov.blk_lu((a_local, j, lq, n - j, w))
             panel = prov.blk_copy((a_local, j, lq, n - j, w))
-            meta = prov.upload(np.array([float(info)]), (1, 1))
+            aux = prov.upload(np.concatenate([prov.download(ipiv), [float(info)]]).reshape(-1, 1))
+            prov.free(ipiv)
         else:
             panel = prov.zeros((n - j, w))
-            ipiv = prov.zeros((w, 1))
-            meta = prov.zeros((1, 1))
-        _bcast(group, prov, panel, (n - j, w), owner)
-        _bcast(group, prov, ipiv, (w, 1), owner)
-        _bcast(group, prov, meta, (1, 1), owner)
-        if float(prov.download(meta)[0]) > 0:
-            for h in (panel, ipiv, meta, y):
+            aux = prov.zeros((w + 1, 1))
+        if overlap:
+            group.native.comm_bcast(panel, owner, async_=True)
+            group.native.comm_bcast(aux, owner, async_=True)
+        else:
+            _bcast(group, prov, panel, (n - j, w), owner)
+            _bcast(group, prov, aux, (w + 1, 1), owner)
+        return panel, aux
+
+    def update(panel, ipiv, j, w, lc0, ncl):
+        """interchanges, U block row and Schur update of local columns [lc0, lc0 + ncl) by panel (j, w)"""
+        if ncl <= 0:
+            return
+        prov.blk_swap_rows((a_local, j, lc0, n - j, ncl), ipiv)
+        prov.blk_trsm(False, (panel, 0, 0, w, w), (a_local, j, lc0, w, ncl))
+        if n - j - w > 0:
+            prov.blk_gemm(-1.0, (panel, w, 0, n - j - w, w), (a_local, j, lc0, w, ncl), 1.0, (a_local, j + w, lc0, n - j - w, ncl))
+
+    cur = post_panel(0)
+    for p in range(nblocks):
+        j = p * nb
+        w = min(nb, n - j)
+        panel, aux = cur
+        if overlap:
+            group.native.comm_wait()
+        auxh = prov.download(aux)
+        if float(auxh[w]) > 0:
+            for h in (panel, aux, y):
                 prov.free(h)
             raise ProviderError(7, "mldivide: pivot <= 1e-12; matrix is numerically singular, use the CPU SVD path")
+        ipiv = prov.upload(auxh[:w].reshape(-1, 1))
         later = [q for q in mine if q > p]
+        nxt = None
+        if p + 1 < nblocks:
+            # depth-1 look-ahead: block p+1 is brought up to date first and its factorisation / broadcast posted, so the
+            # transfer of panel p+1 overlaps the bulk of update p on every rank
+            if later and later[0] == p + 1:
+                lc = local_col_offset(p + 1, nb, group)
+                update(panel, ipiv, j, w, lc, min(nb, n - (p + 1) * nb))
+                later = later[1:]
+            nxt = post_panel(p + 1)
         if later:
             lc0 = local_col_offset(later[0], nb, group)
-            ncl = ncols_loc - lc0
-            prov.blk_swap_rows((a_local, j, lc0, n - j, ncl), ipiv)
-            prov.blk_trsm(False, (panel, 0, 0, w, w), (a_local, j, lc0, w, ncl))
-            if n - j - w > 0:
-                prov.blk_gemm(-1.0, (panel, w, 0, n - j - w, w), (a_local, j, lc0, w, ncl), 1.0,
-                              (a_local, j + w, lc0, n - j - w, ncl))
+            update(panel, ipiv, j, w, lc0, ncols_loc - lc0)
         prov.blk_swap_rows((y, j, 0, n - j, nrhs), ipiv)
         prov.blk_trsm(False, (panel, 0, 0, w, w), (y, j, 0, w, nrhs))
         if n - j - w > 0:
             prov.blk_gemm(-1.0, (panel, w, 0, n - j - w, w), (y, j, 0, w, nrhs), 1.0, (y, j + w, 0, n - j - w, nrhs))
-        for h in (panel, ipiv, meta):
+        for h in (panel, aux, ipiv):
             prov.free(h)
+        cur = nxt
     for p in reversed(range(nblocks)):
         j = p * nb
         w = min(nb, n - j)

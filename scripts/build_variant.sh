@@ -11,5 +11,5 @@ mkdir -p "$OUT"
 OBJ=$OUT/${UNIT%.*}.o
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fvisibility=hidden -Wno-unused-function -Wno-unused-result -I$ROOT/include $FLAGS -c $SRC/$UNIT -o $OBJ
 OTHERS=$(ls $SRC/*.o | grep -v "/${UNIT%.*}.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 $OTHERS $OBJ -shared -L/opt/rocm/lib -lhiprtc -Wl,-rpath,/opt/rocm/lib -o $OUT/librmhip.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 $OTHERS $OBJ -shared -L/opt/rocm/lib -lhiprtc -ldl -lrt -lpthread -Wl,-rpath,/opt/rocm/lib -o $OUT/librmhip.so
 echo "built $OUT/librmhip.so"

@@ -1,7 +1,9 @@
-"""Two ranks sharing cuda:0 over gloo: the multi-GPU drivers (sample-range Monte-Carlo with LCG skip-ahead, the
-one-call stochastic_evolution form, row-sharded matmul, block-column cyclic LU with panel broadcasts) through the
-REAL provider, checked against the oracle.  The data-path collectives are host-staged here (gloo); on a multi-GPU
-node the same drivers run over RCCL, one rank per GPU."""
+"""Two ranks sharing cuda:0: the multi-GPU drivers (sample-range Monte-Carlo with LCG skip-ahead, the one-call
+stochastic_evolution form, row-sharded matmul, block-column cyclic LU with panel broadcasts and depth-1 look-ahead)
+through the REAL provider, checked against the oracle.  Run twice: with the data path on torch.distributed (gloo,
+host-staged) and with every exchange going through the C-ABI collectives (`rmhip_comm_*`) on the host shared-memory
+transport - RCCL refuses two ranks on one device, so on this single-GPU box RCCL itself is exercised with a one-rank
+communicator; on a multi-GPU node the same entry points run over RCCL / xGMI, one rank per GPU."""
 import os
 import socket
 import sys
@@ -23,7 +25,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, native):
     import torch.distributed as dist
 
     from runmat_amd import HipProvider
@@ -33,6 +35,9 @@ def _worker(rank, world, port, out_dir):
     try:
         group = sh.Group.from_env()
         prov = HipProvider(0)
+        if native:  # control plane stays gloo (it carries the 128-byte id); the data path is rmhip_comm_*
+            group.with_native_comm(prov, transport="shm")
+            assert prov.comm_rank() == (rank, world)
         seed = 0x9E3779B97F4A7C15
         M, T = 200001, 3  # odd M: the last pair is half used
         p_fused, s_fused = sh.monte_carlo_price_fused(prov, group, M, T, rng_state=seed)
@@ -42,8 +47,12 @@ def _worker(rank, world, port, out_dir):
         rng = np.random.default_rng(11)
         A, B = rng.uniform(-1, 1, (m, k)), rng.uniform(-1, 1, (k, n))
         r0, r1 = sh.row_block(m, group)
-        c_rows = prov.download_matrix(sh.matmul_row_sharded(prov, prov.upload(A[r0:r1, :]), prov.upload(B)))
-        C = sh.gather_row_blocks(group, c_rows, m)
+        hc = sh.matmul_row_sharded(prov, prov.upload(A[r0:r1, :]), prov.upload(B))
+        if native:
+            full, _ = sh.gather_row_blocks_device(group, prov, hc, m)  # rmhip_comm_allgather_rows
+            C = prov.download_matrix(full)
+        else:
+            C = sh.gather_row_blocks(group, prov.download_matrix(hc), m)
         # block-column cyclic LU: every rank builds the same A and keeps the column blocks it owns
         nn, nb, nrhs = 1000, 128, 2
         rng2 = np.random.default_rng(12)
@@ -60,11 +69,12 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_on_one_gpu(oracle, tmp_path):
+@pytest.mark.parametrize("native", [False, True], ids=["torch-gloo", "c-abi-collectives"])
+def test_two_ranks_on_one_gpu(oracle, tmp_path, native):
     import torch.multiprocessing as mp
 
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), native), nprocs=world, join=True)
     res = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     want, want_state = oracle.monte_carlo_price(oracle.rng_default_seed(), 200001, 3)
     for r in res:
@@ -84,3 +94,40 @@ def test_two_ranks_on_one_gpu(oracle, tmp_path):
     for r in res:
         assert np.max(np.abs(r["x"] - xr)) <= 1e-9 * max(1.0, np.abs(xr).max())
     assert np.array_equal(res[0]["x"], res[1]["x"])
+
+
+def test_rccl_one_rank_communicator(prov, oracle):
+    """The RCCL transport itself (librccl through dlopen, ncclCommInitRank / ncclAllGather / ncclBroadcast on the
+    context's streams) with the one-rank communicator a single-GPU box allows, plus the sharded drivers on it."""
+    from runmat_amd import HipProvider
+    from runmat_amd import sharding as sh
+
+    p2 = HipProvider(0)
+    try:
+        g = sh.Group().with_native_comm(p2, transport="rccl")
+        assert p2.comm_rank() == (0, 1)
+        rng = np.random.default_rng(4)
+        X = rng.uniform(-1, 1, (300, 7))
+        h = p2.upload(X)
+        full = p2.comm_allgather_rows(h, 300, 128)
+        assert np.array_equal(p2.download_matrix(full), X)
+        v = p2.upload(np.array([[1.5], [-2.0], [3.25]]))
+        gv = p2.comm_allgather_f64(v)
+        assert gv.shape == (3, 1) and np.array_equal(p2.download(gv), [1.5, -2.0, 3.25])
+        p2.comm_bcast(h, 0)                      # whole buffer
+        p2.comm_bcast((h, 10, 2, 50, 3), 0)      # strided sub-block (packed)
+        p2.comm_bcast(h, 0, async_=True)         # communication stream
+        p2.comm_wait()
+        p2.comm_barrier()
+        assert np.array_equal(p2.download_matrix(h), X)
+        want, want_state = oracle.monte_carlo_price(oracle.rng_default_seed(), 50001, 2)
+        price, state = sh.monte_carlo_price_fused(p2, g, 50001, 2, rng_state=oracle.rng_default_seed())
+        assert state == want_state and abs(price - want) <= 1e-10 * want
+        n, nb = 700, 128
+        A = rng.standard_normal((n, n))
+        B = rng.standard_normal((n, 2))
+        x = p2.download_matrix(sh.mldivide_block_cyclic(p2, g, p2.upload(A), n, p2.upload(B), nb=nb))
+        assert np.max(np.abs(x - oracle.mldivide_lu(A, B))) <= 1e-9 * max(1.0, np.abs(oracle.mldivide_lu(A, B)).max())
+        p2.comm_destroy()
+    finally:
+        p2.close()
