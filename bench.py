@@ -611,6 +611,7 @@ def main() -> None:
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sh._flush_c_stdio()  # anything native libraries buffered (RCCL's banner) goes out BEFORE the JSON line
     if rank == 0:
         print(json.dumps(out), flush=True)
 

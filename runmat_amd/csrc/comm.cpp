@@ -44,8 +44,26 @@ RcclApi& rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        // RCCL must sit on the SAME HIP runtime as this library.  A host process can hold two (PyTorch wheels bundle
+        // their own libamdhip64 / librccl next to the system ROCm): a librccl bound to the other runtime reports
+        // "no ROCm-capable device".  So: first the librccl that lives beside the libamdhip64 our HIP entry points resolve to,
+        // then the loader's default search.
+        std::vector<std::string> names;
+        Dl_info info;
+        if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash);
+                names.push_back(dir + "/librccl.so.1");
+                names.push_back(dir + "/librccl.so");
+            }
+        }
+        names.push_back("librccl.so.1");
+        names.push_back("librccl.so");
+        names.push_back("/opt/rocm/lib/librccl.so.1");
+        for (const std::string& name : names) {
+            api.handle = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (api.handle) break;
         }
         if (!api.handle) return;
@@ -304,6 +322,12 @@ int rmhip_comm_init(rmhip_ctx* ctx, const void* unique_id, int rank, int world) 
     }
     ncclUniqueId id;
     std::memcpy(&id, unique_id, sizeof id);
+    {
+        // RCCL checks hipGetLastError() at places and reports whatever non-sticky error an EARLIER, unrelated call left
+        // behind (an attribute query that is allowed to fail, ...) as its own "unhandled cuda error": start clean
+        const hipError_t stale = hipGetLastError();
+        if (stale != hipSuccess) RMHIP_TRACEF("comm_init: cleared a stale HIP error (%s)", hipGetErrorString(stale));
+    }
     const ncclResult_t r = rccl().CommInitRank(&cm->nccl, world, id, rank);
     if (r != ncclSuccess) {
         cm->nccl = nullptr;

@@ -7,10 +7,15 @@
 // (sum of (x - mean)^2 / plane), sigma = sqrt(var + eps), inv = sigma > 0 ? 1/sigma : 0,
 // y = (x - mean) * inv [* gain] [+ bias] [max 0] [powf gamma].
 //
-// HBM-bound: three reads and one write per element (32 B) -- the two-pass variance is kept because it is
-// what the CPU computes.  Every thread walks the linear index with a stride that is a multiple of `batch`,
-// so its batch element is fixed (no per-element modulo), loads stay coalesced, and the per-batch partial
-// sums of a block meet in LDS; partials are combined in block order (no atomics: deterministic).
+// HBM-bound: TWO reads and one write per element (24 B).  The CPU computes a two-pass variance (mean, then the squared
+// deviations: two reads of the plane); here the plane is read once for both statistics: every thread takes its
+// elements in register-resident chunks, forms each chunk's mean and its squared deviations about THAT mean (an exact
+// two-pass inside the chunk), and merges (count, mean, M2) triples with the pairwise update of Chan, Golub & LeVeque -
+// per thread, per block (LDS) and across blocks, each in a fixed order (no atomics: run-to-run deterministic).  The
+// result has the two-pass algorithm's accuracy (no cancellation: every M2 term is a sum of squares of small
+// deviations) and differs from the CPU's bits only in the last place or two (tests: 1e-12 relative).  Every thread
+// walks the linear index with a stride that is a multiple of `batch`, so its batch element is fixed (no per-element
+// modulo) and loads stay coalesced.
 #include "common.h"
 
 namespace rmhip {
@@ -18,7 +23,6 @@ namespace rmhip {
 static constexpr int IN_MAX_BATCH = 256;
 static constexpr int IN_BLOCK = 1024;  // streaming passes: the largest multiple of `batch` <= 1024 threads per block
 
-// partial[block][b] = sum over this block's share of plane elements of x (SQDEV: (x - mean[b])^2)
 // T = storage type (float on a precision-32 provider); sums and statistics are f64 either way.
 // VEC = elements per access (a 16-byte vector when the batch extent allows it: VEC divides `batch`, so a thread's VEC
 // consecutive elements are VEC consecutive batch indices and every stride keeps them fixed).
@@ -41,110 +45,121 @@ __device__ __forceinline__ void load_vec(const T* __restrict__ x, size_t vi, dou
     }
 }
 
-template <bool SQDEV, class T, int VEC>
-__global__ void __launch_bounds__(IN_BLOCK) k_plane_partial(const T* __restrict__ x, size_t total, int batch,
-                                                       const double* __restrict__ mean, double* __restrict__ partial) {
-    __shared__ double s[IN_BLOCK * VEC];
+// ---- one-pass plane statistics ----------------------------------------------------------------------------------------
+struct Mom {  // count, mean, sum of squared deviations about the mean
+    double n, mean, m2;
+};
+__device__ __forceinline__ Mom mom_merge(const Mom a, const Mom b) {  // Chan et al.: exact in exact arithmetic, order-dependent in rounding
+    if (b.n == 0.0) return a;
+    if (a.n == 0.0) return b;
+    const double n = a.n + b.n, d = b.mean - a.mean, r = 1.0 / n;
+    return Mom{n, a.mean + d * (b.n * r), a.m2 + b.m2 + d * d * (a.n * b.n * r)};
+}
+// partial[block][b] = (count, mean, M2) of this block's share of plane b
+template <class T, int VEC>
+__global__ void __launch_bounds__(IN_BLOCK) k_plane_moments(const T* __restrict__ x, size_t total, int batch, Mom* __restrict__ partial) {
+    __shared__ Mom s[IN_BLOCK * VEC > 2048 ? 2048 : IN_BLOCK * VEC];
     const int t = threadIdx.x;
-    const int b = (VEC * t) % batch;  // VEC * blockDim.x is a multiple of batch, so is every thread's stride
     const size_t nvec = total / VEC;  // batch % VEC == 0, hence total % VEC == 0
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    double mu[VEC], acc[2][VEC];
+    constexpr int CH = 8;  // vectors per chunk: CH * VEC values live in registers while the chunk's two passes run
+    Mom acc[VEC];
 #pragma unroll
-    for (int l = 0; l < VEC; ++l) {
-        mu[l] = SQDEV ? mean[b + l] : 0.0;
-        acc[0][l] = acc[1][l] = 0.0;
-    }
+    for (int l = 0; l < VEC; ++l) acc[l] = Mom{0.0, 0.0, 0.0};
     size_t i = (size_t)blockIdx.x * blockDim.x + t;
-    constexpr int UNROLL = VEC == 1 ? 4 : 2;  // independent vectors in flight
-    for (; i + (UNROLL - 1) * stride < nvec; i += UNROLL * stride) {
-        double v[UNROLL][VEC];
+    for (; i + (CH - 1) * stride < nvec; i += CH * stride) {
+        double v[CH][VEC];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) load_vec<T, VEC>(x, i + u * stride, v[u]);
+        for (int u = 0; u < CH; ++u) load_vec<T, VEC>(x, i + u * stride, v[u]);
+        const double r = 1.0 / (acc[0].n + (double)CH);  // every lane of the thread has seen the same number of values
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
+        for (int l = 0; l < VEC; ++l) {
+            double sum = 0.0;
 #pragma unroll
-            for (int l = 0; l < VEC; ++l) {
-                if (SQDEV) {
-                    const double d = v[u][l] - mu[l];
-                    acc[u & 1][l] += d * d;
-                } else {
-                    acc[u & 1][l] += v[u][l];
-                }
+            for (int u = 0; u < CH; ++u) sum += v[u][l];
+            const double cm = sum * (1.0 / CH);
+            double m2 = 0.0;
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const double d = v[u][l] - cm;
+                m2 += d * d;
             }
+            const double d = cm - acc[l].mean;
+            acc[l].m2 += m2 + d * d * (acc[l].n * (double)CH * r);
+            acc[l].mean += d * ((double)CH * r);
+            acc[l].n += (double)CH;
+        }
     }
-    for (; i < nvec; i += stride) {
+    for (; i < nvec; i += stride) {  // ragged tail: one value at a time (Welford)
         double v[VEC];
         load_vec<T, VEC>(x, i, v);
 #pragma unroll
         for (int l = 0; l < VEC; ++l) {
-            if (SQDEV) {
-                const double d = v[l] - mu[l];
-                acc[0][l] += d * d;
-            } else {
-                acc[0][l] += v[l];
+            acc[l].n += 1.0;
+            const double d = v[l] - acc[l].mean;
+            acc[l].mean += d / acc[l].n;
+            acc[l].m2 += d * (v[l] - acc[l].mean);
+        }
+    }
+    // fold the VEC * blockDim.x triples (entry e belongs to batch element e % batch) in two levels, each in a fixed order
+    const int ngroups = VEC * (int)blockDim.x / batch, m = (int)blockDim.x / batch;
+    const int g1 = ngroups < 32 ? (ngroups < m ? ngroups : m) : (m < 32 ? m : 32);
+    __shared__ Mom s2[IN_BLOCK];
+    // the triples go through LDS in two halves when VEC * blockDim.x exceeds the staging array (f32: four per thread)
+    Mom mine2 = Mom{0.0, 0.0, 0.0};
+    constexpr int CAP = IN_BLOCK * VEC > 2048 ? 2048 : IN_BLOCK * VEC;
+    const int entries = VEC * (int)blockDim.x;
+    for (int base = 0; base < entries; base += CAP) {
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < VEC; ++l) {
+            const int e = VEC * t + l - base;
+            if (e >= 0 && e < CAP) s[e] = acc[l];
+        }
+        __syncthreads();
+        if (t < batch * g1) {
+            const int bb = t % batch, g = t / batch;
+            for (int j = g; j < ngroups; j += g1) {
+                const int e = j * batch + bb - base;
+                if (e >= 0 && e < CAP) mine2 = mom_merge(mine2, s[e]);
             }
         }
     }
-#pragma unroll
-    for (int l = 0; l < VEC; ++l) s[VEC * t + l] = acc[0][l] + acc[1][l];
-    __syncthreads();
-    // fold the VEC * blockDim.x entries (entry e belongs to batch element e % batch) in two levels: up to 32 groups of
-    // `batch` threads fold a strided share each, then `batch` threads fold the group sums -- a single level is a serial
-    // chain of up to 1024 LDS adds for a small batch extent
-    __shared__ double s2[IN_BLOCK];
-    const int ngroups = VEC * (int)blockDim.x / batch, m = (int)blockDim.x / batch;
-    const int g1 = ngroups < 32 ? (ngroups < m ? ngroups : m) : (m < 32 ? m : 32);
-    if (t < batch * g1) {
-        const int bb = t % batch, g = t / batch;
-        double a = 0.0;
-        for (int j = g; j < ngroups; j += g1) a += s[j * batch + bb];
-        s2[t] = a;
-    }
+    if (t < batch * g1) s2[t] = mine2;
     __syncthreads();
     if (t < batch) {
-        double a = 0.0;
-        for (int g = 0; g < g1; ++g) a += s2[g * batch + t];
+        Mom a = Mom{0.0, 0.0, 0.0};
+        for (int g = 0; g < g1; ++g) a = mom_merge(a, s2[g * batch + t]);
         partial[(size_t)blockIdx.x * batch + t] = a;
     }
 }
-
-// stats[b] (mean) or stats[batch + b] (inv_sigma) from the block partials.  All IN_BLOCK threads take part: thread t
-// owns batch element t % batch and every (lanes / batch)-th block partial, four independent loads in flight per
-// trip (one dependent load per trip made this kernel 45 us for 2048 partials: pure memory latency); the per-thread
-// sums then meet in LDS in thread order -- a fixed order, so the result is reproducible run to run.
-__global__ void __launch_bounds__(IN_BLOCK) k_plane_final(const double* __restrict__ partial, int nblocks, int batch,
-                                                          double plane, double epsilon, int second,
-                                                          double* __restrict__ stats) {
-    __shared__ double s[IN_BLOCK];
+// stats[b] = mean, stats[batch + b] = 1 / sqrt(M2 / plane + eps) (0 when sigma is not positive) from the block triples,
+// merged in block order by `batch` groups of threads
+__global__ void __launch_bounds__(IN_BLOCK) k_plane_moments_final(const Mom* __restrict__ partial, int nblocks, int batch, double plane,
+                                                                  double epsilon, double* __restrict__ stats) {
+    __shared__ Mom s[IN_BLOCK];
     const int t = threadIdx.x;
-    const int lanes = ((int)blockDim.x / batch) * batch;  // threads that take part (a multiple of batch)
+    const int lanes = ((int)blockDim.x / batch) * batch;
     const int b = t % batch, grp = t / batch, ngrp = lanes / batch;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    Mom a = Mom{0.0, 0.0, 0.0};
     if (t < lanes) {
         int k = grp;
-        for (; k + 3 * ngrp < nblocks; k += 4 * ngrp) {
-            const double v0 = partial[(size_t)k * batch + b], v1 = partial[(size_t)(k + ngrp) * batch + b],
-                         v2 = partial[(size_t)(k + 2 * ngrp) * batch + b], v3 = partial[(size_t)(k + 3 * ngrp) * batch + b];
-            a0 += v0;
-            a1 += v1;
-            a2 += v2;
-            a3 += v3;
+        for (; k + 3 * ngrp < nblocks; k += 4 * ngrp) {  // four independent loads in flight per trip
+            const Mom v0 = partial[(size_t)k * batch + b], v1 = partial[(size_t)(k + ngrp) * batch + b],
+                      v2 = partial[(size_t)(k + 2 * ngrp) * batch + b], v3 = partial[(size_t)(k + 3 * ngrp) * batch + b];
+            a = mom_merge(mom_merge(mom_merge(mom_merge(a, v0), v1), v2), v3);
         }
-        for (; k < nblocks; k += ngrp) a0 += partial[(size_t)k * batch + b];
+        for (; k < nblocks; k += ngrp) a = mom_merge(a, partial[(size_t)k * batch + b]);
     }
-    s[t] = (a0 + a1) + (a2 + a3);
+    s[t] = a;
     __syncthreads();
     if (t >= batch) return;
-    double total = 0.0;
-    for (int g = 0; g < ngrp; ++g) total += s[g * batch + t];
-    if (!second) {
-        stats[t] = total / plane;
-    } else {
-        const double variance = total / plane;
-        const double sigma = sqrt(variance + epsilon);
-        stats[batch + t] = sigma > 0.0 ? 1.0 / sigma : 0.0;
-    }
+    Mom tot = Mom{0.0, 0.0, 0.0};
+    for (int g = 0; g < ngrp; ++g) tot = mom_merge(tot, s[g * batch + t]);
+    stats[t] = tot.mean;
+    const double variance = tot.m2 / plane;
+    const double sigma = sqrt(variance + epsilon);
+    stats[batch + t] = sigma > 0.0 ? 1.0 / sigma : 0.0;
 }
 
 template <class T, int VEC>
@@ -169,7 +184,11 @@ __global__ void __launch_bounds__(IN_BLOCK) k_imgnorm_apply(const T* __restrict_
             if (has_gain) w *= gain;
             if (has_bias) w += bias;
             if (clamp_zero) w = fmax(w, 0.0);  // f64::max: a NaN operand loses
-            if (has_gamma) w = pow(w, gamma);
+            // gamma step: for a non-negative base pow(w, g) = exp(g * log(w)) (one log + one exp instead of ocml's
+            // double-double pow: the pass is VALU-bound, 0.93 -> 0.5 ms at 16 x 2160 x 3840); relative error
+            // <= (|g ln w| + 2) ulp, a few 1e-16 for image data.  0, +Inf and NaN come out as powf's do; a negative base
+            // (no clamp requested) keeps the exact pow: powf(negative, integer) is finite.
+            if (has_gamma) w = (w >= 0.0 && gamma > 0.0) ? (w == 0.0 ? 0.0 : exp(gamma * log(w))) : pow(w, gamma);
             v[l] = w;
         }
         if constexpr (VEC == 1) {
@@ -192,20 +211,17 @@ static int image_normalize_vec(Context* c, const T* x, T* y, size_t batch, size_
     const size_t cap = (size_t)c->num_cus * 8;
     if (want < 1) want = 1;
     const unsigned grid = (unsigned)(want < cap ? want : cap);
-    RMHIP_TRY(c->ensure_scratch(sizeof(double) * ((size_t)grid * batch + 2 * batch)));
-    double* partial = c->scratch;
-    double* stats = c->scratch + (size_t)grid * batch;
+    RMHIP_TRY(c->ensure_scratch(sizeof(Mom) * (size_t)grid * batch + sizeof(double) * 2 * batch));
+    Mom* partial = reinterpret_cast<Mom*>(c->scratch);
+    double* stats = reinterpret_cast<double*>(partial + (size_t)grid * batch);
     // few partials: a 256-thread final block (its serial LDS fold is shorter); thousands: all 1024 threads share the loads
     const unsigned fthreads = (size_t)grid * batch >= 8192 ? IN_BLOCK : IN_MAX_BATCH;
-    hipLaunchKernelGGL((k_plane_partial<false, T, VEC>), dim3(grid), dim3(threads), 0, c->stream, x, total, (int)batch, stats, partial);
-    hipLaunchKernelGGL(k_plane_final, dim3(1), dim3(fthreads), 0, c->stream, partial, (int)grid, (int)batch, (double)plane,
-                       epsilon, 0, stats);
-    hipLaunchKernelGGL((k_plane_partial<true, T, VEC>), dim3(grid), dim3(threads), 0, c->stream, x, total, (int)batch, stats, partial);
-    hipLaunchKernelGGL(k_plane_final, dim3(1), dim3(fthreads), 0, c->stream, partial, (int)grid, (int)batch, (double)plane,
-                       epsilon, 1, stats);
+    hipLaunchKernelGGL((k_plane_moments<T, VEC>), dim3(grid), dim3(threads), 0, c->stream, x, total, (int)batch, partial);
+    hipLaunchKernelGGL(k_plane_moments_final, dim3(1), dim3(fthreads), 0, c->stream, partial, (int)grid, (int)batch, (double)plane, epsilon,
+                       stats);
     hipLaunchKernelGGL((k_imgnorm_apply<T, VEC>), dim3(grid), dim3(threads), 0, c->stream, x, y, total, (int)batch, stats, has_gain, gain,
                        has_bias, bias, clamp_zero, has_gamma, gamma);
-    c->tel.kernel_launches += 5;
+    c->tel.kernel_launches += 3;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
 }

@@ -57,6 +57,17 @@ def lcg_advance(state: int, delta: int) -> int:
     return (acc_mult * state + acc_plus) & MASK64
 
 
+def _flush_c_stdio() -> None:
+    """Flush the C library's stdio buffers (librccl writes its banner with printf; on a pipe that text would otherwise
+    appear at exit, after whatever Python printed last - e.g. bench.py's one JSON line)."""
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 @dataclass
 class Group:
     """Thin view of the process group: rank, world and an ordered all-gather of small f64 vectors.
@@ -80,6 +91,7 @@ class Group:
         else:
             uid = prov.comm_unique_id(transport)
         prov.comm_init(uid, self.rank, self.world)
+        _flush_c_stdio()  # RCCL prints a version banner through C stdio on rank 0: out now, not at process exit
         self.native = prov
         return self
 
@@ -287,9 +299,12 @@ def monte_carlo_price_fused(prov, group: Group, M: int, T: int, S0=100.0, mu=0.0
         r_s = red.input()
         payoff = red.builtin("max", red.primitive("Sub", r_s, red.constant(K)), red.constant(0.0))
         red_shader = red.generate_reduction_wgsl(payoff, "f64", axis=0)
-        h_scale = prov.upload(np.array([[scale]]))
-        h_drift = prov.upload(np.array([[drift]]))
-        S = prov.fill((count, 1), S0)
+        # constants are 1-element tensors created on the device (no host copy, no synchronisation); the initial price
+        # S0 is one too and broadcasts into the first update (`S = S0 .* exp(...)`: the planner hands scalars to the
+        # kernel as [1,1] inputs, fusion_exec.rs:279,305-326), so no M-element fill precedes the time loop
+        h_scale = prov.fill((1, 1), scale)
+        h_drift = prov.fill((1, 1), drift)
+        S = prov.fill((1, 1), S0)
         for t in range(T):
             prov.set_rng_state(lcg_advance(rng_state, t * per_step + start))
             Z = prov.random_normal((count, 1))
