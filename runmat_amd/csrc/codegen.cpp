@@ -265,6 +265,7 @@ std::string generate_elementwise_source(const ElementwiseProgram& p, const EwTun
     std::ostringstream s;
     s << "// generated by librmhip from a fused elementwise plan (" << p.lets.size() << " ops, " << p.n_inputs
       << " inputs, " << p.outputs.size() << " outputs)\n";
+    if (f32) s << "#define RM_RESULT_F32 1\n";  // results are stored as f32: skel_common.h's short sin / cos
     s << kSkelCommon << "\n";
     s << "typedef double rm_v2 __attribute__((ext_vector_type(2)));\n";
     if (f32) s << "typedef float rm_v4f __attribute__((ext_vector_type(4)));\n";
@@ -281,6 +282,7 @@ std::string generate_reduction_source(const ReductionProgram& p, bool f32) {
     const std::string S = f32 ? "float" : "double";
     const std::string cast_in = f32 ? "(double)" : "";
     s << "// generated by librmhip from a fused reduction plan (" << nin << " inputs, axis " << p.axis << ")\n";
+    if (f32) s << "#define RM_RESULT_F32 1\n";
     s << kSkelCommon << "\n" << kSkelReduce << "\n";
     s << "struct RmVal {\n";
     for (int k = 0; k < nin; ++k) s << "    const " << S << "* __restrict__ in" << k << ";\n    rm_u64 m" << k << ";\n";

@@ -59,6 +59,53 @@ __device__ __forceinline__ double rm_sinc(double v) {
     return sin(scaled) / scaled;
 }
 
+// sin / cos for kernels whose results are stored as f32 (RM_RESULT_F32, set by the generator for a precision-32
+// provider).  The library sin spends ~60 fp64 instructions per call on a double-double argument reduction and on
+// polynomial tails that only matter for the last bits of an f64 result; with four of them per lane the f32 fused kernel
+// was VALU- and power-bound (169 -> 245 us per 8192^2 dispatch as the clock dropped).  Here: one-step Cody-Waite with
+// fma (n*PIO2_HI is exact inside the fma and the difference is a multiple of 2^-52 below 1, so r is exact; PIO2_LO adds
+// the next 53 bits), then the degree-13 / degree-14 minimax polynomials on [-pi/4, pi/4] (fdlibm's published
+// coefficients) without correction tails: ~30 instructions, error < 1.5 ulp of f64, i.e. 2^-28 of an f32 ulp - the
+// stored value is the correctly rounded f32 except when the exact result lies within that distance of a rounding
+// boundary.  |x| >= 2^20, Inf and NaN take the library path.
+// Horner step d = a*b + c with the coefficient as the (single allowed) scalar operand of v_fma_f64.  Written out because
+// the compiler otherwise keeps every coefficient in a VGPR pair and copies it into the accumulator of a v_fmac_f64
+// first (one v_mov_b64 per step, also in the library's own sin): a third of the VALU work of the function.
+#define RM_FMA_SC(d, a, b, c) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c))
+__device__ __forceinline__ double rm_sincos_r32(double x, int shift) {
+    const double ax = __builtin_fabs(x);  // odd symmetry is applied on the bits at the end: keeps sin(-0) = -0
+    if (!(ax < 1048576.0)) return shift ? cos(x) : sin(x);
+    const double n = __builtin_rint(ax * 0x1.45f306dc9c883p-1);
+    double r = __builtin_fma(n, -0x1.921fb54442d18p+0, ax);
+    r = __builtin_fma(n, -0x1.1a62633145c07p-54, r);
+    const unsigned q = (unsigned)(int)n + (unsigned)shift;
+    const double z = r * r;
+    double ps = __builtin_fma(z, 0x1.5d93a5acfd57cp-33, -0x1.ae5e68a2b9cebp-26);
+    RM_FMA_SC(ps, z, ps, 0x1.71de357b1fe7dp-19);
+    RM_FMA_SC(ps, z, ps, -0x1.a01a019c161d5p-13);
+    RM_FMA_SC(ps, z, ps, 0x1.111111110f8a6p-7);
+    RM_FMA_SC(ps, z, ps, -0x1.5555555555549p-3);
+    const double sn = __builtin_fma(r * z, ps, r);
+    double pc = __builtin_fma(z, -0x1.8fae9be8838d4p-37, 0x1.1ee9ebdb4b1c4p-29);
+    RM_FMA_SC(pc, z, pc, -0x1.27e4f809c52adp-22);
+    RM_FMA_SC(pc, z, pc, 0x1.a01a019cb1590p-16);
+    RM_FMA_SC(pc, z, pc, -0x1.6c16c16c15177p-10);
+    RM_FMA_SC(pc, z, pc, 0x1.555555555554cp-5);
+    pc = __builtin_fma(z, pc, -0.5);
+    const double cs = __builtin_fma(z, pc, 1.0);
+    const double v = (q & 1u) ? cs : sn;
+    unsigned flip = (q & 2u) << 30;
+    if (!shift) flip ^= (unsigned)((rm_u64)__double_as_longlong(x) >> 32) & 0x80000000u;
+    return __longlong_as_double(__double_as_longlong(v) ^ (long long)((rm_u64)flip << 32));
+}
+#ifdef RM_RESULT_F32
+__device__ __forceinline__ double rm_sin(double x) { return rm_sincos_r32(x, 0); }
+__device__ __forceinline__ double rm_cos(double x) { return rm_sincos_r32(x, 1); }
+#else
+__device__ __forceinline__ double rm_sin(double x) { return sin(x); }
+__device__ __forceinline__ double rm_cos(double x) { return cos(x); }
+#endif
+
 struct rm_d2 {
     double x, y;
 } __attribute__((aligned(16)));

@@ -366,7 +366,7 @@ struct FnInfo {
 const std::unordered_map<std::string, FnInfo>& fn_table() {
     // WGSL name (fusion.rs:2932-3026; test vocabulary fusion_gpu.rs:1291-1333) -> device function.
     static const std::unordered_map<std::string, FnInfo> t = {
-        {"sin", {"sin", 1}},       {"cos", {"cos", 1}},       {"tan", {"tan", 1}},
+        {"sin", {"rm_sin", 1}},    {"cos", {"rm_cos", 1}},       {"tan", {"tan", 1}},
         {"asin", {"asin", 1}},     {"acos", {"acos", 1}},     {"atan", {"atan", 1}},
         {"sinh", {"sinh", 1}},     {"cosh", {"cosh", 1}},     {"tanh", {"tanh", 1}},
         {"asinh", {"asinh", 1}},   {"acosh", {"acosh", 1}},   {"atanh", {"atanh", 1}},

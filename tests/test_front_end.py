@@ -66,7 +66,7 @@ def test_sin_mul_add_shader_text_and_translation(built):
     assert "@group(0) @binding(3) var<storage, read_write> output: Tensor;" in sh
     assert "@group(0) @binding(4) var<uniform> params: Params;" in sh
     src = wgsl_translate(sh)
-    assert "const double tmp0 = sin(x0);" in src
+    assert "const double tmp0 = rm_sin(x0);" in src  # rm_sin = sin for f64 storage, the short form for f32 (skel_common.h)
     assert "const double tmp1 = (tmp0 * x1);" in src and "const double tmp2 = (tmp1 + x2);" in src
     assert "rm_ew_fast" in src and "rm_ew_bcast" in src
 
@@ -152,7 +152,7 @@ def test_reduction_shader(built, axis):
     assert "let val: f64 = ((sin(v) * v1) + f64(2));" in sh  # constants inlined via Display (fusion.rs:1839-1873)
     assert ("const OMITNAN: bool = true" in sh) == (axis == 1)
     src = wgsl_translate(sh, "reduction")
-    assert "return ((sin(v0) * v1) + (0x1p+1));" in src
+    assert "return ((rm_sin(v0) * v1) + (0x1p+1));" in src
     assert "rm_red_contig" in src and "rm_red_strided" in src and "rm_red_final" in src
     wgsl_compile_check(sh, "reduction")
 
@@ -220,7 +220,7 @@ def test_f32_shaders_lower_to_f32_storage_with_f64_arithmetic(built):
     src = wgsl_translate(sh, "elementwise")
     assert "const float* __restrict__ in0" in src and "float* __restrict__ out0" in src
     assert "typedef float rm_v4f" in src and "const rm_v4f a0_t" in src
-    assert "const double tmp0 = sin(x0);" in src           # arithmetic unchanged
+    assert "const double tmp0 = rm_sin(x0);" in src  # rm_sin = sin for f64 storage, the short form for f32 (skel_common.h)           # arithmetic unchanged
     assert "(double)a0_t.w" in src and "r0_t.w = (float)q0;" in src
     assert "threadIdx.x < (n & 3)" in src                  # up to three tail elements
     wgsl_compile_check(sh, "elementwise")

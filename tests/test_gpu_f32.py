@@ -6,7 +6,9 @@ CPU path does for `single` arrays (f64 storage pre-rounded through f32 after eve
 builtins/math/elementwise/times.rs:750-760).  Two checks per op:
 
   * bit-exact against the F64 provider: the same f64 kernels run on the f32-rounded inputs, rounded once
-    (`f32r(F64(f32r(x)))`), so any f32-storage indexing / vector-tail / conversion bug shows up as a mismatch;
+    (`f32r(F64(f32r(x)))`), so any f32-storage indexing / vector-tail / conversion bug shows up as a mismatch
+    (generated f32 kernels evaluate sin / cos with skel_common.h's shorter form: same <= 1 ulp-of-f64 error, i.e. the
+    same f32 value except within 2^-28 of an f32 rounding boundary - `test_f32_generated_sin_cos_whole_range`);
   * against the oracle's CPU semantics with the tolerance the reference's own F32 provider tests use
     (1e-5 absolute, e.g. trigonometry/sin.rs:886-893), tightened to a few f32 ulps where one op is involved.
 """
@@ -188,6 +190,41 @@ def test_f32_fused_elementwise_fast_path(prov32, prov, oracle, shape):
     assert prov32.buffer_bits(g32) == 32 and same_bits(prov32.download(g32), f32r(prov.download(g64)))
     assert np.max(np.abs(prov32.download_matrix(g32) - _chain_cpu_single(oracle, x))) < 1e-5  # reference F32 tolerance
 
+
+
+def test_f32_generated_sin_cos_whole_range(prov32, oracle):
+    """Generated kernels of a precision-32 provider use rm_sincos_r32 (skel_common.h): one-step Cody-Waite + the plain
+    minimax polynomials below 2^20, the library path above.  Against the oracle's f64 sin / cos rounded once: never more
+    than 1 ulp of f32 away, and (because the f64 error is ~1 ulp of f64) the same f32 value everywhere on this sample."""
+    from runmat_amd.fusion import FusionGroupPlan
+
+    rng = np.random.default_rng(77)
+    k = np.arange(-4000, 4001, dtype=np.float64)
+    parts = [
+        np.array([0.0, -0.0, 1e-45, -1e-45, 1.17549435e-38, 1e-30, -1e-30, 1e-8, 0.5, -0.5, 1.0, np.pi / 4, -np.pi / 4, np.pi / 2, np.pi,
+                  1048575.9375, -1048575.9375, 1048576.0, -1048576.0, 1048576.125, 3e6, -7e9, 1e22, 3.4028234663852886e38,
+                  np.inf, -np.inf, np.nan]),
+        k * (np.pi / 2), np.nextafter(f32r(k * (np.pi / 2)).astype(np.float32), np.float32(np.inf)).astype(np.float64),
+        rng.uniform(-np.pi, np.pi, 200000), rng.uniform(-1e3, 1e3, 200000), rng.uniform(-1048576.0, 1048576.0, 400000),
+        np.ldexp(rng.uniform(0.5, 1.0, 100000), rng.integers(-126, 127, 100000)) * rng.choice([-1.0, 1.0], 100000),
+    ]
+    x = f32r(np.concatenate(parts)).reshape(-1, 1)
+    hx = prov32.upload(x)
+    for fn in ("sin", "cos"):
+        p = FusionGroupPlan()
+        a = p.input()
+        out = p.builtin(fn, a)
+        h = prov32.fused_elementwise(p.generate_wgsl_for_output(out, "f32"), [hx], x.shape, x.size)
+        got = prov32.download_matrix(h)
+        with np.errstate(invalid="ignore"):
+            want = f32r(oracle.unary(fn, x))
+        assert np.array_equal(np.isnan(got), np.isnan(want)), fn
+        m = ~np.isnan(want)
+        assert np.all(np.abs(got[m] - want[m]) <= ULP32 * np.abs(want[m])), fn
+        assert np.array_equal(np.signbit(got[m]), np.signbit(want[m])) or fn == "cos", fn  # sin(-0) = -0
+        same = np.count_nonzero(got[m] == want[m])
+        assert same == np.count_nonzero(m), (fn, np.count_nonzero(m) - same)
+        prov32.free(h)
 
 def test_f32_fused_scalars_broadcast_and_multi_output(prov32, prov, oracle):
     from runmat_amd.fusion import FusionGroupPlan
