@@ -290,6 +290,107 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
     }
 }
 
+
+// ---- small-tile variant: 64 x 64 block tile, the same four waves each owning 32 x 32 (2 x 2 MFMA tiles) -------------------
+// For products with few 128 x 128 tiles and a short k - the in-panel and look-ahead updates of the blocked LU (rows x 64..256
+// x 64..256, the main stream's critical path under look-ahead), small `matmul`s.  There the big kernel is latency bound:
+// a 128 x 128 x 128 block is eight dependent k tiles of 16 MFMAs per wave each (1.7 us per tile) on 1/4 of the CUs; four
+// times the blocks with a quarter of the MFMAs per tile finish the same product in about a third of the time.
+// Plain operands only (no transposed views, no epilogue), m % 64 == n % 64 == 0, k % 16 == 0, 16-byte aligned bases
+// and even leading dimensions; everything else stays with k_dgemm.  Same LDS layouts and operand roles as k_dgemm.
+static constexpr int SM = 64, SN = 64;
+static constexpr int SSA = SM + 16;          // A tile [k][m] row stride (80 % 32 == 16: the bank-half trick of k_dgemm)
+static constexpr int S_A_TILE = BK * SSA;    // 1280 doubles
+static constexpr int S_B_TILE = SN * SB;     // 1152 doubles
+__global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) double As[2][S_A_TILE];
+    __shared__ __attribute__((aligned(16))) double Bs[2][S_B_TILE];
+    const unsigned tm = blockIdx.x % g.tiles_m, tn = blockIdx.x / g.tiles_m;  // column-major tile order: neighbours share B
+    const unsigned m0 = tm * SM, n0 = tn * SN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int p_xp = t & 31, p_kc = t >> 5;  // A: pair along m (x = 2*p_xp), k = p_kc + 8*p
+    const int q_kp = t & 7, q_y = t >> 3;    // B: pair along k (k = 2*q_kp), y = q_y + 32*p
+    const double* const Ap = g.A + m0 + 2 * p_xp;
+    const double* const Bp = g.B + (size_t)n0 * g.ldb + 2 * q_kp;
+    v2d ra[2], rb[2];
+    auto fetch = [&](unsigned k0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            ra[p] = *(const v2d*)(Ap + (size_t)(k0 + p_kc + 8 * p) * g.lda);
+            rb[p] = *(const v2d*)(Bp + (size_t)(q_y + 32 * p) * g.ldb + k0);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            *(v2d*)(&As[buf][(p_kc + 8 * p) * SSA + 2 * p_xp]) = ra[p];
+            *(v2d*)(&Bs[buf][(q_y + 32 * p) * SB + 2 * q_kp]) = rb[p];
+        }
+    };
+    v4d acc[2][2];  // [tj (n)][ti (m)]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[j][i] = v4d{0.0, 0.0, 0.0, 0.0};
+    const unsigned ktiles = g.k / BK;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const int a_off = lq * SSA + wm * 32 + l15;
+    const int b_off = (wn * 32 + l15) * SB + lq;
+    for (unsigned kt = 0; kt < ktiles; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < ktiles) fetch((kt + 1) * BK);
+        const double* a = &As[cur][a_off];
+        const double* b = &Bs[cur][b_off];
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            double af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = a[kk * 4 * SSA + i * 16];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = b[j * 16 * SB + kk * 4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[j][i], 0, 0, 0);
+        }
+        if (kt + 1 < ktiles) stash(cur ^ 1);
+        __syncthreads();
+    }
+    // epilogue as in k_dgemm: all loads of the read-modify-write first, then the stores
+    double* dst[16];
+    double prev[16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned mm = m0 + wm * 32 + i * 16 + l15;
+                const unsigned row = g.rowmap ? (4 * lq + r) : (4 * r + lq);
+                const unsigned nn = n0 + wn * 32 + j * 16 + row;
+                dst[(j * 2 + i) * 4 + r] = g.C + (size_t)nn * g.ldc + mm;
+            }
+    if (g.beta != 0.0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) prev[e] = *dst[e];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = (j * 2 + i) * 4 + r;
+                double v = g.alpha * acc[j][i][r];
+                if (g.beta != 0.0) v = g.beta * prev[e] + v;
+                *dst[e] = v;
+            }
+}
+
 static int g_rowmap = -1;
 
 static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double alpha, const double* A, size_t lda,
@@ -398,6 +499,23 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
         }
     }
     const bool fast_k = fast && (splits == 1 || k % g.k_chunk == 0);
+    // small-tile kernel: the big tiles would cover at most half of the CUs and k is short (RMHIP_GEMM_SMALL=0 disables).  Not on
+    // the look-ahead update stream (gemm_lds_pad != 0): its blocks must stay too big to share a CU with a panel block.
+    static int small_on = -1;
+    if (small_on < 0) {
+        const char* v = std::getenv("RMHIP_GEMM_SMALL");
+        small_on = (v && *v == '0') ? 0 : 1;
+    }
+    if (small_on && !ep && !ta && !tb && splits == 1 && c->gemm_lds_pad == 0 && k > 0 && k <= 1024 && (m % SM == 0) && (n % SN == 0) && (k % BK == 0) &&
+        (lda % 2 == 0) && (ldb % 2 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0) &&
+        (size_t)blocks * 2 <= (size_t)c->num_cus) {
+        g.tiles_m = (unsigned)(m / SM);
+        g.tiles_n = (unsigned)(n / SN);
+        hipLaunchKernelGGL(k_dgemm_small, dim3(g.tiles_m * g.tiles_n), dim3(256), 0, c->stream, g);
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+        return RMHIP_OK;
+    }
     if (ep) {
         if (ta || tb) return fail(RMHIP_ERR_UNSUPPORTED, "dgemm: epilogue with transposed operands is not instantiated");
         launch_variant<true, true, false, false>(c, blocks, splits, lds_bytes, kMaxLds, g);

@@ -352,16 +352,19 @@ __device__ __forceinline__ int quad_argmax_f64(double key, unsigned pos, double*
 //   * ONE hop for <= 32 blocks: every wave polls eight blocks' candidate rows (16-byte granules: two tagged half-words,
 //     one dwordx4 access, four in flight) while wave 0 folds the records, so the winner's row is already in LDS when
 //     it is known.  More blocks (tall panels, off the critical path under look-ahead) keep the second dependent read.
-//   * finished columns are parked in LDS and written back at their FINAL row positions (the panel's own interchange
-//     needs no k_laswp_lists launch), and the row-move list for the other columns is written by the threads that
-//     own the moves (no k_build_plist launch).
+//   * finished columns leave the register window straight to memory at the row's ORIGINAL position (coalesced, fire and
+//     forget); the panel's own interchange is then one more column range for the k_laswp_lists call that moves the
+//     neighbouring columns anyway (getrf_rec), and the row-move list is written by the threads that own the moves (no
+//     k_build_plist launch).  An earlier version parked the finished columns in LDS (128 KiB) to write them at their
+//     final positions itself: the block then needed a whole CU and had to wait for one to drain under look-ahead; with
+//     18.5 KiB it starts beside the update stream's dgemm block.
 // Pivot rule, tie-break, cut-off, lazy bookkeeping and the arithmetic (division, unfused multiply-subtract) are unchanged.
 static constexpr int P2_ROWS = 256;
 static constexpr int P2_THREADS = P2_ROWS;
 static constexpr int P2_WAVES = P2_THREADS / 64;
 static constexpr int P2_ONEHOP_MAXB = 32;
 static constexpr int P2_RB = BASE_W + 16;  // row stride of the wave candidate buffer (the dump runs in groups of 16 slots and may overshoot by 12)
-static constexpr size_t P2_LDS_DOUBLES = (size_t)BASE_W * P2_ROWS + (size_t)P2_ONEHOP_MAXB * BASE_W + (size_t)P2_WAVES * P2_RB;
+static constexpr size_t P2_LDS_DOUBLES = (size_t)P2_ONEHOP_MAXB * BASE_W + (size_t)P2_WAVES * P2_RB;  // 18.5 KiB
 typedef unsigned int pk_v4u __attribute__((ext_vector_type(4)));
 
 struct P2Args {
@@ -414,7 +417,6 @@ __device__ __forceinline__ void ld_values4(const pk_u64* p0, const pk_u64* p1, c
 }
 
 struct P2Lds {
-    double* fin;     // [BASE_W][P2_ROWS] finished columns
     double* cand;    // [P2_ONEHOP_MAXB][BASE_W] candidate rows of the other blocks (slot 0 only beyond 32 blocks)
     double* rowbuf;  // [P2_WAVES][P2_RB] every wave's candidate row
     double* r_key;
@@ -698,8 +700,7 @@ __global__ void __launch_bounds__(P2_THREADS) k_lu_panel2(const P2Args g) {
     __shared__ int s_ctl[8];
     __shared__ P2Ticks s_ticks;  // ticks live in LDS
     P2Lds L;
-    L.fin = p2_lds;
-    L.cand = L.fin + (size_t)BASE_W * P2_ROWS;
+    L.cand = p2_lds;
     L.rowbuf = L.cand + (size_t)P2_ONEHOP_MAXB * BASE_W;
     L.r_key = r_key;
     L.r_pos = r_pos;
@@ -732,22 +733,20 @@ __global__ void __launch_bounds__(P2_THREADS) k_lu_panel2(const P2Args g) {
         if (4 * jj + 1 < g.w && !p2_column<1, DBG>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
         if (4 * jj + 2 < g.w && !p2_column<2, DBG>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
         if (4 * jj + 3 < g.w && !p2_column<3, DBG>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
-        // columns 4jj .. 4jj+3 are final: park them, shift the register window by four
+        // columns 4jj .. 4jj+3 are final (multipliers, or the U values of a retired row): store them where the row was
+        // loaded from - nobody reads the panel's columns before the kernel ends - and shift the register window by four
+        if (in_rows) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) L.fin[(size_t)(4 * jj + i) * P2_ROWS + t] = a[i];
+            for (int i = 0; i < 4; ++i)
+                if (4 * jj + i < g.w) g.A[r + (size_t)(g.j0 + 4 * jj + i) * g.lda] = a[i];
+        }
 #pragma unroll
         for (int i = 0; i < BASE_W; ++i) a[i] = a[i + 4];
     }
-    __syncthreads();
     P2_TICK(7)
-    // ---- write back at the FINAL positions (pivot rows to the top, displaced rows to where the bookkeeping left
-    // them): the panel's own interchange.  Every block reads only its own LDS, and no block gets here before all
-    // blocks took part in the last exchange, i.e. long after they loaded their rows.
     if (in_rows) {
-        const size_t fpos = retk >= 0 ? (size_t)(g.j0 + retk) : (size_t)pos;
-        for (int c = 0; c < g.w; ++c) g.A[fpos + (size_t)(g.j0 + c) * g.lda] = L.fin[(size_t)c * P2_ROWS + t];
-        // the interchange record of the step this row retired at (LAPACK-style target position), its row move for every
-        // other column, and the singular-pivot count
+        // the interchange record of the step this row retired at (LAPACK-style target position), its row move (applied to
+        // the panel's own columns and to every other column by k_laswp_lists), and the singular-pivot count
         if (retk >= 0) {
             const int kabs = g.j0 + retk;
             g.ipiv[kabs] = rpiv & 0x3fffffff;
@@ -1104,7 +1103,11 @@ static int laswp(LuState& s, size_t c0, size_t c1, size_t k0, size_t k1) {
 }
 
 // Factor columns [j0, j0+w) over rows [j0, rows); swaps are applied inside that column range only.
-static int getrf_rec(LuState& s, size_t j0, size_t w) {
+// own_swaps_by_caller: a base panel leaves its own columns un-interchanged (k_lu_panel2 stores every row where it was
+// loaded from); the recursion step above it then widens the k_laswp_lists call that moves the sibling's columns anyway
+// to this panel's columns, instead of a launch of its own.  *deferred reports that this happened.
+static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller = false, bool* deferred = nullptr) {
+    if (deferred) *deferred = false;
     if (w == 0 || j0 >= s.rows) return RMHIP_OK;
     if (w <= (size_t)BASE_W) {
         const size_t c1 = j0 + w;  // j0 + w <= min(rows, cols) always holds (see lu_factor_device)
@@ -1135,12 +1138,31 @@ static int getrf_rec(LuState& s, size_t j0, size_t w) {
             g.info = s.info;
             g.plist = s.plist + pid * PLIST;
             g.dbg = s.xdbg;
-            if (s.xdbg) hipLaunchKernelGGL(k_lu_panel2<true>, dim3((unsigned)nbp), dim3(P2_THREADS), P2_LDS_DOUBLES * sizeof(double), s.c->stream, g);
-            else hipLaunchKernelGGL(k_lu_panel2<false>, dim3((unsigned)nbp), dim3(P2_THREADS), P2_LDS_DOUBLES * sizeof(double), s.c->stream, g);
+            // The block needs 18.5 KiB of LDS but ASKS for 82.5: it then does not fit beside an update-stream dgemm block
+            // (84 KiB) and waits for a CU of its own.  Sharing a CU costs more than the wait: with the panel waves on the
+            // same SIMDs as a dgemm wave every column step slows down, and the column chain is the critical path
+            // (n = 16384: 135 ms sharing, 123 ms exclusive; RMHIP_LU_PANEL_PAD_KB).
+            static long pad_kb = -1;
+            if (pad_kb < 0) {
+                const char* v = std::getenv("RMHIP_LU_PANEL_PAD_KB");
+                pad_kb = v ? std::atol(v) : 64;
+                if (pad_kb > 128) pad_kb = 128;
+            }
+            const size_t lds_bytes = P2_LDS_DOUBLES * sizeof(double) + (size_t)pad_kb * 1024;
+            if (lds_bytes > 65536) {
+                s.c->ensure_max_lds((const void*)k_lu_panel2<false>, lds_bytes);
+                s.c->ensure_max_lds((const void*)k_lu_panel2<true>, lds_bytes);
+            }
+            if (s.xdbg) hipLaunchKernelGGL(k_lu_panel2<true>, dim3((unsigned)nbp), dim3(P2_THREADS), lds_bytes, s.c->stream, g);
+            else hipLaunchKernelGGL(k_lu_panel2<false>, dim3((unsigned)nbp), dim3(P2_THREADS), lds_bytes, s.c->stream, g);
             RMHIP_TRY(launch_check(s.c));
             s.xbase += (unsigned)w;
             s.panel_start->push_back(j0);
-            return RMHIP_OK;
+            if (own_swaps_by_caller && deferred) {
+                *deferred = true;
+                return RMHIP_OK;
+            }
+            return laswp(s, j0, c1, j0, c1);  // the panel's own interchange
         }
         const size_t nb = (s.rows - j0 + PANEL_ROWS - 1) / PANEL_ROWS;  // one block per PANEL_ROWS rows
         if (nb > (size_t)MAX_PANEL_BLOCKS)
@@ -1166,8 +1188,9 @@ static int getrf_rec(LuState& s, size_t j0, size_t w) {
     size_t h = ((w / 2 + 15) / 16) * 16;
     if (h >= w) h = w / 2;
     const size_t hk = (j0 + h <= s.rows) ? h : (s.rows - j0);  // pivots produced by the left half
-    RMHIP_TRY(getrf_rec(s, j0, h));
-    RMHIP_TRY(laswp(s, j0 + h, j0 + w, j0, j0 + hk));
+    bool left_deferred = false, right_deferred = false;
+    RMHIP_TRY(getrf_rec(s, j0, h, true, &left_deferred));
+    RMHIP_TRY(laswp(s, left_deferred ? j0 : j0 + h, j0 + w, j0, j0 + hk));
     double* A11 = s.A + j0 + j0 * s.lda;
     double* A12 = s.A + j0 + (j0 + h) * s.lda;
     RMHIP_TRY(trsm_lower_rec(s.c, A11, s.lda, hk, A12, s.lda, w - h));
@@ -1175,9 +1198,9 @@ static int getrf_rec(LuState& s, size_t j0, size_t w) {
         double* A21 = s.A + (j0 + h) + j0 * s.lda;
         double* A22 = s.A + (j0 + h) + (j0 + h) * s.lda;
         RMHIP_TRY(lu_dgemm(s.c, s.rows - j0 - h, w - h, h, -1.0, A21, s.lda, A12, s.lda, 1.0, A22, s.lda));
-        RMHIP_TRY(getrf_rec(s, j0 + h, w - h));
+        RMHIP_TRY(getrf_rec(s, j0 + h, w - h, true, &right_deferred));
         const size_t k1 = (j0 + w <= s.rows) ? (j0 + w) : s.rows;
-        RMHIP_TRY(laswp(s, j0, j0 + h, j0 + h, k1));
+        RMHIP_TRY(laswp(s, j0, right_deferred ? j0 + w : j0 + h, j0 + h, k1));
     }
     return RMHIP_OK;
 }
@@ -1229,6 +1252,9 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
     hipStream_t side = nullptr;
     RMHIP_HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio_low));
+    // (Tried: the update stream on a CU-masked stream - hipExtStreamCreateWithCUMask, mask bit i = CU i/8 of XCD i%8 - that
+    // leaves 32 or 64 CUs to the main stream, two unpadded dgemm blocks per CU on the rest: 140-169 ms against 123 at
+    // n = 16384; the main stream's updates crawl on the reserved CUs.)
     std::vector<hipEvent_t> events;
     auto new_event = [&]() {
         hipEvent_t e = nullptr;
@@ -1263,7 +1289,19 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     if (const char* v = std::getenv("RMHIP_LU_EARLY_ROWS")) early_rows = (size_t)std::atoll(v);
     nb_early = nb_early < 64 ? 64 : (nb_early / 64) * 64;
     if (nb_early < nb) nb_early = nb;
-    auto width_at = [&](size_t j) { return (early_rows && kmin - j > early_rows) ? nb_early : nb; };
+    // third tier (RMHIP_LU_NB_LATE / RMHIP_LU_LATE_ROWS): once the panel chain is the critical path, a narrower panel
+    // moves more of each update from the main stream (look-ahead columns) to the idle update stream
+    // (n = 16384, interleaved: 123.1 / 124.2 ms without, 120.8 / 120.6 with 128 below 6144 rows; 64 below 3072: 122.9 / 121.6)
+    size_t nb_late = 128, late_rows = 6144;
+    if (const char* v = std::getenv("RMHIP_LU_NB_LATE")) nb_late = (size_t)std::atoll(v);
+    if (const char* v = std::getenv("RMHIP_LU_LATE_ROWS")) late_rows = (size_t)std::atoll(v);
+    nb_late = nb_late < 64 ? 64 : (nb_late / 64) * 64;
+    if (nb_late > nb) nb_late = nb;
+    auto width_at = [&](size_t j) {
+        if (early_rows && kmin - j > early_rows) return nb_early;
+        if (late_rows && kmin - j <= late_rows) return nb_late;
+        return nb;
+    };
     for (size_t j = 0; j < kmin && rc == RMHIP_OK;) {
         const size_t nbj = width_at(j);
         const size_t w = (kmin - j) < nbj ? (kmin - j) : nbj;
@@ -1339,9 +1377,8 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
               (int*)(blk + off_xctl + 16), (unsigned long long*)(blk + off_xa), (unsigned long long*)(blk + off_xvals), 0u, true,
               nullptr};
     {
-        // persistent panels need >64 KiB of dynamic LDS and all their blocks co-resident (one per CU)
-        c->ensure_max_lds((const void*)k_lu_panel2<false>, P2_LDS_DOUBLES * sizeof(double));
-        c->ensure_max_lds((const void*)k_lu_panel2<true>, P2_LDS_DOUBLES * sizeof(double));
+        // persistent panels need all their blocks co-resident (18.5 KiB of LDS and 270 VGPRs per 4-wave block: at most one
+        // per CU beside a dgemm block, so up to num_cus blocks)
         const char* pm = std::getenv("RMHIP_LU_PANEL");  // "columns" selects the one-launch-per-column kernels
         if ((pm && pm[0] == 'c') || c->lu_conservative) s.persistent = false;
         const char* dbgenv = std::getenv("RMHIP_LU_PANEL_DEBUG");

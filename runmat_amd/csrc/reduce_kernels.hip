@@ -92,6 +92,46 @@ __global__ void __launch_bounds__(RM_RBLOCK) k_reduce_strided(const T* x, rm_u64
     IdentityVal<T> f{x};
     rm_reduce_strided<OP>(f, pre, red, nsplit, tx, pv, pn);
 }
+
+// Kernel B over 16-byte vectors (plain tensors, even `pre`, 16-byte aligned base): a thread owns TWO adjacent output
+// slices and walks its chunk of the reduced extent in ascending order with U non-temporal loads in flight - the same
+// per-slice summation order as rm_reduce_strided with ty == 1, at 1 KiB per wave instruction.  grid = (ceil(pre/512),
+// nsplit, post).
+template <int OP, class T, int U>
+__global__ void __launch_bounds__(RM_RBLOCK) k_reduce_strided_v2(const T* x, rm_u64 pre, rm_u64 red, rm_u64 nsplit, double* pv,
+                                                                 double* pn) {
+    const rm_u64 i2 = (rm_u64)blockIdx.x * RM_RBLOCK + threadIdx.x;  // pair index along `pre`
+    const rm_u64 pre2 = pre >> 1;
+    if (i2 >= pre2) return;
+    const rm_u64 split = blockIdx.y, j = blockIdx.z;
+    const rm_u64 chunk = (red + nsplit - 1) / nsplit;
+    const rm_u64 begin = split * chunk;
+    rm_u64 end = begin + chunk;
+    if (end > red) end = red;
+    RmAcc a0 = rm_acc_init<OP>(), a1 = rm_acc_init<OP>();
+    const rm_u64 base2 = i2 + pre2 * red * j;
+    rm_u64 r = begin;
+    for (; r + U <= end; r += U) {
+        rm_rv2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = rm_load2(x, base2 + pre2 * (r + u));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            rm_acc_add<OP>(a0, v[u].x);
+            rm_acc_add<OP>(a1, v[u].y);
+        }
+    }
+    for (; r < end; ++r) {
+        const rm_rv2 v = rm_load2(x, base2 + pre2 * r);
+        rm_acc_add<OP>(a0, v.x);
+        rm_acc_add<OP>(a1, v.y);
+    }
+    const rm_u64 slice = 2 * i2 + pre * j;
+    pv[slice * nsplit + split] = a0.v;
+    pn[slice * nsplit + split] = a0.nan;
+    pv[(slice + 1) * nsplit + split] = a1.v;
+    pn[(slice + 1) * nsplit + split] = a1.nan;
+}
 template <int OP>
 __global__ void __launch_bounds__(RM_RBLOCK) k_reduce_final(const double* pv, const double* pn, rm_u64 nslices,
                                                             rm_u64 nsplit, rm_u64 red, int mean, int omitnan,
@@ -105,9 +145,25 @@ static int run_reduce(Context* c, int mean, int nan_mode, const T* x, size_t pre
     if (pre == 0 || post == 0) return RMHIP_OK;  // no output slices
     const ReducePlan p = plan_reduction(pre, red, post, c->num_cus, (unsigned)sizeof(T));
     if (!p.valid) return fail(RMHIP_ERR_UNSUPPORTED, "reduce: geometry [%zu,%zu,%zu] exceeds launch limits", pre, red, post);
-    // (A 16-byte form of kernel B - two adjacent slices per thread, 1024-thread blocks, 16 KiB of every column per block -
-    // measured SLOWER than the generic kernel: sum(x,2) at 8192^2 0.137 vs 0.113 ms.)
-    const uint64_t nsplit = p.nsplit;
+    // Kernel B in its 16-byte form (two adjacent slices per thread, 256-thread blocks, non-temporal loads) with FOUR blocks
+    // per CU: sum(x,2) 8192^2 113.8 -> 111.5 us, 65536 x 1024 119.3 -> 105.6 us (scripts/red_b_ab.sh; more resident blocks
+    // are slower: 8 per CU 113.4 / 119.8, 16 per CU 129.8 / 139.6 - the streams are strided columns and every extra
+    // one costs DRAM page locality).  A 1024-thread version with 16 KiB of every column per block was slower still (137).
+    uint64_t nsplit = p.nsplit;
+    // dev knobs (A/B only): RMHIP_RED_B_MODE 0 = generic kernel B, 1/2 = the 16-byte form with 8 / 4 loads in flight;
+    // RMHIP_RED_B_BPC = its target blocks per CU
+    static const int b_mode = getenv("RMHIP_RED_B_MODE") ? atoi(getenv("RMHIP_RED_B_MODE")) : 1;
+    static const int b_bpc = getenv("RMHIP_RED_B_BPC") ? atoi(getenv("RMHIP_RED_B_BPC")) : 4;
+    const bool wide_b = !p.contiguous && b_mode > 0 && (pre & 1) == 0 && pre >= 512 && (((uintptr_t)x) & 15) == 0 && post <= 65535;
+    unsigned wide_bx = 0;
+    if (wide_b) {
+        wide_bx = (unsigned)ceil_div_u64(pre / 2, RM_RBLOCK);
+        uint64_t want = ceil_div_u64((uint64_t)c->num_cus * b_bpc, (uint64_t)wide_bx * post);
+        uint64_t max_split = ceil_div_u64(red, 16);
+        nsplit = want < 1 ? 1 : want;
+        if (nsplit > max_split) nsplit = max_split;
+        if (nsplit > 65535) nsplit = 65535;
+    }
     const size_t nparts = (size_t)(p.nslices * nsplit);
     RMHIP_TRY(c->ensure_scratch(2 * nparts * sizeof(double)));
     double* pv = c->scratch;
@@ -118,6 +174,12 @@ static int run_reduce(Context* c, int mean, int nan_mode, const T* x, size_t pre
     else if (p.contiguous)
         hipLaunchKernelGGL((k_reduce_contig<OP, T>), dim3(p.gx, p.gy, p.gz), dim3(p.tx), 0, c->stream, x,
                            (rm_u64)red, (rm_u64)p.nslices, (rm_u64)p.nsplit, pv, pn);
+    else if (wide_b && b_mode == 2)
+        hipLaunchKernelGGL((k_reduce_strided_v2<OP, T, 4>), dim3(wide_bx, (unsigned)nsplit, (unsigned)post), dim3(RM_RBLOCK), 0, c->stream,
+                           x, (rm_u64)pre, (rm_u64)red, (rm_u64)nsplit, pv, pn);
+    else if (wide_b)
+        hipLaunchKernelGGL((k_reduce_strided_v2<OP, T, 8>), dim3(wide_bx, (unsigned)nsplit, (unsigned)post), dim3(RM_RBLOCK), 0, c->stream,
+                           x, (rm_u64)pre, (rm_u64)red, (rm_u64)nsplit, pv, pn);
     else
         hipLaunchKernelGGL((k_reduce_strided<OP, T>), dim3(p.gx, p.gy, p.gz), dim3(RM_RBLOCK), 0, c->stream, x,
                            (rm_u64)pre, (rm_u64)red, (rm_u64)p.nsplit, p.tx, pv, pn);
