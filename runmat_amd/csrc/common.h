@@ -153,6 +153,8 @@ struct Context {
     // set after a persistent-panel factorisation found its workgroups not co-resident (device shared with
     // another context): from then on LU uses the one-launch-per-column panels on a single stream
     bool lu_conservative = false;
+    bool one_xcd_ok = true;  // LU panels may place their blocks on one XCD (cleared when such a panel timed out once)
+    bool lu_used_one_xcd = false;
     // 64 or 32 (rmhip_set_precision).  At 32 every op output is stored as f32: kernels with a native f32-storage variant
     // (fused elementwise / reduction, per-op elementwise, reductions, dot) read and write f32 directly, every other op
     // runs its f64 kernel on widened temporaries and the entry point narrows what it created on return (NarrowScope).

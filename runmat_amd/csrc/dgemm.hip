@@ -109,7 +109,11 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs& g, unsigned& tm, u
 // and vice versa, so the two staging patterns below simply swap roles and the LDS tiles keep their sizes:
 //   pattern M: 128 tile rows contiguous in memory, LDS [k][x] with row stride SA   (A plain, B transposed)
 //   pattern K: k contiguous in memory,            LDS [y][k] with row stride SB   (B plain, A transposed)
-template <bool EDGE, bool EPI, bool TA, bool TB>
+// PRE (only with EDGE = EPI = TA = TB = false): C <- C - A*B, the rank-k update of the blocked LU.  The C tile is loaded into
+// the accumulators (negated) BEFORE the k loop, where its latency hides behind the first operand tiles, and the epilogue
+// is stores only (-acc).  The plain beta path reads C at the end: four dependent load -> store round trips with the
+// matrix pipe idle - 10-25 % of a k = 256..512 tile when one block per CU runs (the look-ahead's update stream).
+template <bool EDGE, bool EPI, bool TA, bool TB, bool PRE = false>
 __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* As = lds;                    // [2][A_TILE]
@@ -205,10 +209,24 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
     };
 
     v4d acc[4][4];  // [tj (n)][ti (m)]
+    if (PRE) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = v4d{0.0, 0.0, 0.0, 0.0};
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned mm = m0 + wm * 64 + i * 16 + l15;
+                    const unsigned row = g.rowmap ? (4 * lq + r) : (4 * r + lq);
+                    const unsigned nn = n0 + wn * 64 + j * 16 + row;
+                    acc[j][i][r] = -Cb[(size_t)nn * g.ldc + mm];
+                }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = v4d{0.0, 0.0, 0.0, 0.0};
+    }
 
     const unsigned ktiles = (klen + BK - 1) / BK;
     fetch(0);
@@ -265,7 +283,7 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
                 dst[i * 4 + r] = Cb + (size_t)nn * g.ldc + mm;
             }
         }
-        if (!EPI && g.beta != 0.0) {
+        if (!EPI && !PRE && g.beta != 0.0) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) prev[e] = ok[e] ? *dst[e] : 0.0;
         }
@@ -280,6 +298,8 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
                     const unsigned row = g.rowmap ? (4 * lq + r) : (4 * r + lq);
                     const unsigned nn = n0 + wn * 64 + j * 16 + row;
                     v = ok[e] ? apply_epilogue(g.ep, acc[j][i][r], mm, nn) : 0.0;
+                } else if (PRE) {
+                    v = -acc[j][i][r];
                 } else {
                     v = g.alpha * acc[j][i][r];
                     if (g.beta != 0.0) v = g.beta * prev[e] + v;
@@ -302,6 +322,7 @@ static constexpr int SM = 64, SN = 64;
 static constexpr int SSA = SM + 16;          // A tile [k][m] row stride (80 % 32 == 16: the bank-half trick of k_dgemm)
 static constexpr int S_A_TILE = BK * SSA;    // 1280 doubles
 static constexpr int S_B_TILE = SN * SB;     // 1152 doubles
+template <bool PRE>  // PRE: C <- C - A*B with the C tile preloaded into the accumulators (see k_dgemm)
 __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) double As[2][S_A_TILE];
     __shared__ __attribute__((aligned(16))) double Bs[2][S_B_TILE];
@@ -330,10 +351,24 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
         }
     };
     v4d acc[2][2];  // [tj (n)][ti (m)]
+    double* dst[16];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[j][i] = v4d{0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned mm = m0 + wm * 32 + i * 16 + l15;
+                const unsigned row = g.rowmap ? (4 * lq + r) : (4 * r + lq);
+                const unsigned nn = n0 + wn * 32 + j * 16 + row;
+                dst[(j * 2 + i) * 4 + r] = g.C + (size_t)nn * g.ldc + mm;
+            }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[j][i][r] = PRE ? -*dst[(j * 2 + i) * 4 + r] : 0.0;
     const unsigned ktiles = g.k / BK;
     fetch(0);
     stash(0);
@@ -361,20 +396,8 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
         __syncthreads();
     }
     // epilogue as in k_dgemm: all loads of the read-modify-write first, then the stores
-    double* dst[16];
     double prev[16];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const unsigned mm = m0 + wm * 32 + i * 16 + l15;
-                const unsigned row = g.rowmap ? (4 * lq + r) : (4 * r + lq);
-                const unsigned nn = n0 + wn * 32 + j * 16 + row;
-                dst[(j * 2 + i) * 4 + r] = g.C + (size_t)nn * g.ldc + mm;
-            }
-    if (g.beta != 0.0) {
+    if (!PRE && g.beta != 0.0) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) prev[e] = *dst[e];
     }
@@ -385,8 +408,13 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int e = (j * 2 + i) * 4 + r;
-                double v = g.alpha * acc[j][i][r];
-                if (g.beta != 0.0) v = g.beta * prev[e] + v;
+                double v;
+                if (PRE) {
+                    v = -acc[j][i][r];
+                } else {
+                    v = g.alpha * acc[j][i][r];
+                    if (g.beta != 0.0) v = g.beta * prev[e] + v;
+                }
                 *dst[e] = v;
             }
 }
@@ -415,10 +443,10 @@ int launch_dgemm_trans(Context* c, bool ta, bool tb, size_t m, size_t n, size_t 
     return launch_dgemm_impl(c, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, ta, tb);
 }
 
-template <bool EDGE, bool EPI, bool TA, bool TB>
+template <bool EDGE, bool EPI, bool TA, bool TB, bool PRE = false>
 static void launch_variant(Context* c, unsigned blocks, unsigned splits, size_t lds_bytes, size_t max_lds, const GemmArgs& g) {
-    c->ensure_max_lds((const void*)k_dgemm<EDGE, EPI, TA, TB>, max_lds);
-    hipLaunchKernelGGL((k_dgemm<EDGE, EPI, TA, TB>), dim3(blocks, splits), dim3(256), lds_bytes, c->stream, g);
+    c->ensure_max_lds((const void*)k_dgemm<EDGE, EPI, TA, TB, PRE>, max_lds);
+    hipLaunchKernelGGL((k_dgemm<EDGE, EPI, TA, TB, PRE>), dim3(blocks, splits), dim3(256), lds_bytes, c->stream, g);
 }
 
 // C = alpha * (P_0 + P_1 + ... + P_{S-1}) + beta * C, partials m x n dense (ld m), summed in split order
@@ -499,6 +527,13 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
         }
     }
     const bool fast_k = fast && (splits == 1 || k % g.k_chunk == 0);
+    // C <- C - A*B (the LU's updates): preload C into the accumulators (RMHIP_GEMM_PRELOAD=0 keeps the read at the end)
+    static int preload_on = -1;
+    if (preload_on < 0) {
+        const char* v = std::getenv("RMHIP_GEMM_PRELOAD");
+        preload_on = (v && *v == '0') ? 0 : 1;
+    }
+    const bool preload = preload_on && !ep && !ta && !tb && splits == 1 && alpha == -1.0 && beta == 1.0 && k > 0;
     // small-tile kernel: the big tiles would cover at most half of the CUs and k is short (RMHIP_GEMM_SMALL=0 disables).  Not on
     // the look-ahead update stream (gemm_lds_pad != 0): its blocks must stay too big to share a CU with a panel block.
     static int small_on = -1;
@@ -506,12 +541,18 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
         const char* v = std::getenv("RMHIP_GEMM_SMALL");
         small_on = (v && *v == '0') ? 0 : 1;
     }
-    if (small_on && !ep && !ta && !tb && splits == 1 && c->gemm_lds_pad == 0 && k > 0 && k <= 1024 && (m % SM == 0) && (n % SN == 0) && (k % BK == 0) &&
-        (lda % 2 == 0) && (ldb % 2 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0) &&
-        (size_t)blocks * 2 <= (size_t)c->num_cus) {
+    static long small_force = -1, small_pad = 0;  // developer knobs: RMHIP_GEMM_SMALL_FORCE=1 (any size), RMHIP_GEMM_SMALL_PAD=<bytes of extra LDS>
+    if (small_force < 0) {
+        small_force = std::getenv("RMHIP_GEMM_SMALL_FORCE") ? std::atol(std::getenv("RMHIP_GEMM_SMALL_FORCE")) : 0;
+        small_pad = std::getenv("RMHIP_GEMM_SMALL_PAD") ? std::atol(std::getenv("RMHIP_GEMM_SMALL_PAD")) : 0;
+    }
+    if (small_on && !ep && !ta && !tb && splits == 1 && (c->gemm_lds_pad == 0 || small_force) && k > 0 && (k <= 1024 || small_force) &&
+        (m % SM == 0) && (n % SN == 0) && (k % BK == 0) && (lda % 2 == 0) && (ldb % 2 == 0) && (((uintptr_t)A & 15) == 0) &&
+        (((uintptr_t)B & 15) == 0) && ((size_t)blocks * 2 <= (size_t)c->num_cus || small_force)) {
         g.tiles_m = (unsigned)(m / SM);
         g.tiles_n = (unsigned)(n / SN);
-        hipLaunchKernelGGL(k_dgemm_small, dim3(g.tiles_m * g.tiles_n), dim3(256), 0, c->stream, g);
+        if (preload) hipLaunchKernelGGL(k_dgemm_small<true>, dim3(g.tiles_m * g.tiles_n), dim3(256), (size_t)small_pad, c->stream, g);
+        else hipLaunchKernelGGL(k_dgemm_small<false>, dim3(g.tiles_m * g.tiles_n), dim3(256), (size_t)small_pad, c->stream, g);
         c->tel.kernel_launches++;
         RMHIP_HIP_CHECK(hipGetLastError());
         return RMHIP_OK;
@@ -526,7 +567,8 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
         if (fast_k) launch_variant<false, false, false, true>(c, blocks, splits, lds_bytes, kMaxLds, g);
         else launch_variant<true, false, false, true>(c, blocks, splits, lds_bytes, kMaxLds, g);
     } else {
-        if (fast_k) launch_variant<false, false, false, false>(c, blocks, splits, lds_bytes, kMaxLds, g);
+        if (fast_k && preload) launch_variant<false, false, false, false, true>(c, blocks, splits, lds_bytes, kMaxLds, g);
+        else if (fast_k) launch_variant<false, false, false, false>(c, blocks, splits, lds_bytes, kMaxLds, g);
         else launch_variant<true, false, false, false>(c, blocks, splits, lds_bytes, kMaxLds, g);
     }
     c->tel.kernel_launches++;

@@ -45,6 +45,7 @@ struct LuState {
     unsigned xbase;       // host: panel columns factored so far (exchange step counter)
     bool persistent;      // use k_lu_panel2 for base panels
     unsigned long long* xdbg;  // device [16] phase ticks (RMHIP_LU_PANEL_DEBUG=1) or nullptr
+    long panel_pad_kb = -1;    // extra LDS a panel block asks for (-1: the default, see getrf_rec)
 };
 
 static constexpr int MAX_PANEL_BLOCKS = 1024;  // 64 rows per block => up to 65536 rows per panel
@@ -372,6 +373,8 @@ struct P2Args {
     size_t lda, rows;
     int j0, w, nblocks;
     int onehop_max;  // one-hop exchange up to this many blocks (<= P2_ONEHOP_MAXB)
+    int bstride;     // 1, or 8: only workgroups with blockIdx.x % 8 == 0 take part - all on ONE XCD (workgroup b is
+                     // dispatched to XCD b % 8), the exchange then stays inside that XCD's L2 (plain stores)
     unsigned seq0;
     int* xerr;
     pk_u64* xrec;   // [2][PK_MAXB] records, 16 bytes each: |a| bits | fresh, position | row slot << 32 | fresh
@@ -388,9 +391,11 @@ struct P2Args {
 // freshness bit per half (flipping between consecutive uses of a slot) identifies the step.  A VALUE granule is only
 // written while its column is still in play (columns >= k), i.e. an even number of slot uses can pass between two
 // writes: its halves carry the whole 32-bit step number instead (a bit would accept the previous panel's value).
-__device__ __forceinline__ void st_granule(pk_u64* p, pk_u64 w0, pk_u64 w1) {
+// `local`: every reader sits on the writer's XCD - the store only has to reach that XCD's L2 (no write-through to memory)
+__device__ __forceinline__ void st_granule(pk_u64* p, pk_u64 w0, pk_u64 w1, bool local) {
     const pk_v4u v = {(unsigned)w0, (unsigned)(w0 >> 32), (unsigned)w1, (unsigned)(w1 >> 32)};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    if (local) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void ld_granule(const pk_u64* p, pk_u64& w0, pk_u64& w1) {
     pk_v4u v;
@@ -448,7 +453,8 @@ template <int NS, bool FIX, bool DBG, class Rest>
 __device__ __forceinline__ bool p2_select(const P2Args& g, const P2Lds& L, double (&a)[BASE_W + 4], const int pos, const int jj, const int kn,
                                          const int fix_skip, const double* fix_row, P2Ticks* ticks, Rest rest) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int blk = blockIdx.x;
+    const int blk = blockIdx.x / g.bstride;
+    const bool local = g.bstride > 1;
     const unsigned seq = g.seq0 + (unsigned)kn;
     const int par = (int)(seq & 1u);
     const pk_u64 fresh = (pk_u64)(((seq >> 1) & 1u) ^ 1u) << 63;
@@ -492,7 +498,7 @@ __device__ __forceinline__ bool p2_select(const P2Args& g, const P2Lds& L, doubl
         const int bw = bl < 0 ? 0 : bl;
         const int bt = L.r_t[bw];
         const size_t slot = (size_t)par * PK_MAXB + blk;
-        if (lane == 0) st_granule(g.xrec + slot * 2, bk | fresh, (pk_u64)bp | ((pk_u64)(unsigned)bt << 32) | fresh);
+        if (lane == 0) st_granule(g.xrec + slot * 2, bk | fresh, (pk_u64)bp | ((pk_u64)(unsigned)bt << 32) | fresh, local);
         if (lane >= kn && lane < g.w) {
             double v = L.rowbuf[bw * P2_RB + lane];
             if (FIX && !fix_skip && lane > kn) {
@@ -501,7 +507,7 @@ __device__ __forceinline__ bool p2_select(const P2Args& g, const P2Lds& L, doubl
                 v = v - prod;
             }
             const pk_u64 bits = (pk_u64)__double_as_longlong(v);
-            st_granule(g.xvals + (slot * BASE_W + lane) * 2, (bits & 0xffffffffull) | vtag, (bits >> 32) | vtag);
+            st_granule(g.xvals + (slot * BASE_W + lane) * 2, (bits & 0xffffffffull) | vtag, (bits >> 32) | vtag, local);
         }
         P2_TICK(2)  // publish
     }
@@ -712,8 +718,9 @@ __global__ void __launch_bounds__(P2_THREADS) k_lu_panel2(const P2Args g) {
         for (int i = 0; i < 16; ++i) s_ticks.acc[i] = 0;
         s_ticks.tk = wall_clock64();
     }
+    if (blockIdx.x % g.bstride) return;  // one-XCD placement: the other seven XCDs' workgroups are placeholders
     const int t = threadIdx.x;  // row slot
-    const size_t r = (size_t)g.j0 + (size_t)blockIdx.x * P2_ROWS + t;
+    const size_t r = (size_t)g.j0 + (size_t)(blockIdx.x / g.bstride) * P2_ROWS + t;
     const bool in_rows = r < g.rows;
     int pos = in_rows ? (int)r : -1, retk = -1, rpiv = 0;
     double a[BASE_W + 4];  // register window: a[i] = column 4*jj + i (four spare slots: column k+1 of the last step of a group)
@@ -1129,6 +1136,15 @@ static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller =
                 if (onehop_max > P2_ONEHOP_MAXB) onehop_max = P2_ONEHOP_MAXB;
             }
             g.onehop_max = onehop_max;
+            // One-XCD placement when every block finds a CU of its own on one XCD (<= num_cus / 8 blocks): the exchange hop
+            // drops from a write-through + a miss in another XCD's L2 to two accesses of one L2 (scripts/micro/
+            // xcd_exchange.hip: 2.1-2.5 -> 1.45 us per step).  RMHIP_LU_ONE_XCD=0 disables.
+            static int one_xcd = -1;
+            if (one_xcd < 0) {
+                const char* v = std::getenv("RMHIP_LU_ONE_XCD");
+                one_xcd = (v && *v == '0') ? 0 : 1;
+            }
+            g.bstride = (one_xcd && s.c->one_xcd_ok && nbp <= (size_t)s.c->num_cus / 8) ? 8 : 1;
             g.seq0 = s.xbase;
             g.xerr = s.xerr;
             g.xrec = s.xrec;
@@ -1148,13 +1164,14 @@ static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller =
                 pad_kb = v ? std::atol(v) : 64;
                 if (pad_kb > 128) pad_kb = 128;
             }
-            const size_t lds_bytes = P2_LDS_DOUBLES * sizeof(double) + (size_t)pad_kb * 1024;
+            const size_t lds_bytes = P2_LDS_DOUBLES * sizeof(double) + (size_t)(s.panel_pad_kb >= 0 ? s.panel_pad_kb : pad_kb) * 1024;
             if (lds_bytes > 65536) {
                 s.c->ensure_max_lds((const void*)k_lu_panel2<false>, lds_bytes);
                 s.c->ensure_max_lds((const void*)k_lu_panel2<true>, lds_bytes);
             }
-            if (s.xdbg) hipLaunchKernelGGL(k_lu_panel2<true>, dim3((unsigned)nbp), dim3(P2_THREADS), lds_bytes, s.c->stream, g);
-            else hipLaunchKernelGGL(k_lu_panel2<false>, dim3((unsigned)nbp), dim3(P2_THREADS), lds_bytes, s.c->stream, g);
+            const unsigned grid = (unsigned)nbp * (unsigned)g.bstride;
+            if (s.xdbg) hipLaunchKernelGGL(k_lu_panel2<true>, dim3(grid), dim3(P2_THREADS), lds_bytes, s.c->stream, g);
+            else hipLaunchKernelGGL(k_lu_panel2<false>, dim3(grid), dim3(P2_THREADS), lds_bytes, s.c->stream, g);
             RMHIP_TRY(launch_check(s.c));
             s.xbase += (unsigned)w;
             s.panel_start->push_back(j0);
@@ -1302,8 +1319,20 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         if (late_rows && kmin - j <= late_rows) return nb_late;
         return nb;
     };
+    // While the trailing matrix is large the machine is throughput bound on the update dgemm (one block per CU: ~50 TFLOP/s
+    // in place, 56 alone) and the main stream has slack, so the panel blocks drop their LDS pad there and start beside a
+    // dgemm block instead of waiting for a CU to drain (n = 16384: 119.9 -> 118.8 ms).  Letting the update stream drop ITS
+    // pad there as well (two dgemm blocks per CU) starves the main stream: a retiring block's slot goes to the next block
+    // of the same kernel, stream priority or not (138 ms).  Developer knobs: RMHIP_LU_EARLY_SIDE_PAD (bytes),
+    // RMHIP_LU_EARLY_PANEL_PAD_KB.
+    size_t early_side_pad = side_pad;
+    long early_panel_pad = 0;
+    if (const char* v = std::getenv("RMHIP_LU_EARLY_SIDE_PAD")) early_side_pad = (size_t)std::atoll(v);
+    if (const char* v = std::getenv("RMHIP_LU_EARLY_PANEL_PAD_KB")) early_panel_pad = std::atol(v);
     for (size_t j = 0; j < kmin && rc == RMHIP_OK;) {
         const size_t nbj = width_at(j);
+        const bool early = early_rows && kmin - j > early_rows;
+        s.panel_pad_kb = early ? early_panel_pad : -1;
         const size_t w = (kmin - j) < nbj ? (kmin - j) : nbj;
         rc = getrf_rec(s, j, w);  // P_j on main
         if (rc != RMHIP_OK) break;
@@ -1320,7 +1349,7 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         }
         (void)hipStreamWaitEvent(side, panel_done, 0);
         {
-            StreamScope scope(c, side, side_pad);
+            StreamScope scope(c, side, early ? early_side_pad : side_pad);
             rc = update_columns(s, j, w, next + la_w, s.cols);      // S_j
             if (rc == RMHIP_OK && j > 0) rc = laswp(s, 0, j, j, j + w);  // finished left columns
         }
@@ -1328,6 +1357,7 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         (void)hipEventRecord(side_done, side);
         j = next;
     }
+    s.panel_pad_kb = -1;
     if (side_done) (void)hipStreamWaitEvent(main_stream, side_done, 0);
     (void)hipStreamSynchronize(side);
     (void)hipStreamSynchronize(main_stream);
@@ -1345,6 +1375,7 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
                      std::vector<int>* ipiv_host) {
     const size_t kmin = rows < cols ? rows : cols;
     if (rows > 0x7fffffffULL || cols > 0x7fffffffULL) return fail(RMHIP_ERR_UNSUPPORTED, "lu: dimension exceeds 2^31");
+    c->lu_used_one_xcd = false;
     // one device block: ipiv[rows] | info | pos_of | row_at | prow | panel lists | cand_abs[2*MAXB] | cand_pos | cand_row
     const size_t n_int = rows + 4;
     const size_t isz = (rows * sizeof(int) + 15) & ~(size_t)15;
@@ -1420,7 +1451,14 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
         if (e == hipSuccess && h_xerr) {
             // bounded spins expired: the panel workgroups were not co-resident (device shared with another
             // context?).  The matrix is clobbered; callers holding the original refactor it conservatively.
-            c->lu_conservative = true;
+            // A factorisation that placed panels on one XCD first gives that up (if the workgroup -> XCD assignment is not
+            // the expected round robin the plain stores of the exchange are never seen); only a failure of the spread
+            // placement makes the context conservative.
+            if (std::getenv("RMHIP_LU_VERBOSE"))
+                std::fprintf(stderr, "[lu] panel exchange timed out (one-XCD placement used: %d, allowed: %d)\n", (int)c->lu_used_one_xcd,
+                             (int)c->one_xcd_ok);
+            if (c->lu_used_one_xcd && c->one_xcd_ok && !std::getenv("RMHIP_LU_TEST_RETRY")) c->one_xcd_ok = false;
+            else c->lu_conservative = true;
             (void)fail(RMHIP_ERR_HIP, "lu: panel workgroups were not co-resident (device shared?)");
             rc = RMHIP_LU_RETRY;
         }

@@ -37,7 +37,7 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // report that their workgroups were not co-resident the copy is refreshed and factored conservatively.
 static int lu_copy_and_factor(Context* c, const double* src, size_t rows, size_t cols, double* work, size_t ldw, int* perm,
                               int* info) {
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < 3; ++attempt) {  // one-XCD panels -> spread panels -> one launch per column
         if (rows && cols) {
             hipError_t e = hipMemcpy2DAsync(work, ldw * sizeof(double), src, rows * sizeof(double), rows * sizeof(double), cols,
                                             hipMemcpyDeviceToDevice, c->stream);
@@ -46,7 +46,7 @@ static int lu_copy_and_factor(Context* c, const double* src, size_t rows, size_t
         const int rc = lu_factor_device(c, work, rows, cols, ldw, perm, info);
         if (rc != RMHIP_LU_RETRY) return rc;
     }
-    return fail(RMHIP_ERR_HIP, "lu: factorisation failed twice");
+    return fail(RMHIP_ERR_HIP, "lu: factorisation failed on every panel path");
 }
 
 size_t lu_padded_ld(size_t rows) { return rows >= 256 ? ((rows + 1) & ~(size_t)1) + 32 : ((rows + 1) & ~(size_t)1); }
