@@ -152,6 +152,8 @@ struct Context {
     size_t gemm_lds_pad = 0;
     // set after a persistent-panel factorisation found its workgroups not co-resident (device shared with
     // another context): from then on LU uses the one-launch-per-column panels on a single stream
+    hipStream_t lu_side_stream = nullptr;  // update stream of the look-ahead LU (low priority), created on first use
+    std::vector<hipEvent_t> lu_events;     // its event pool
     bool lu_conservative = false;
     bool one_xcd_ok = true;  // LU panels may place their blocks on one XCD (cleared when such a panel timed out once)
     bool lu_used_one_xcd = false;

@@ -1267,17 +1267,21 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     hipStream_t main_stream = c->stream;
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-    hipStream_t side = nullptr;
-    RMHIP_HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio_low));
+    // the update stream and the events live in the context (created once: a stream and ~200 events per factorisation cost
+    // about a millisecond of host time)
+    if (!c->lu_side_stream) RMHIP_HIP_CHECK(hipStreamCreateWithPriority(&c->lu_side_stream, hipStreamNonBlocking, prio_low));
+    hipStream_t side = c->lu_side_stream;
     // (Tried: the update stream on a CU-masked stream - hipExtStreamCreateWithCUMask, mask bit i = CU i/8 of XCD i%8 - that
     // leaves 32 or 64 CUs to the main stream, two unpadded dgemm blocks per CU on the rest: 140-169 ms against 123 at
     // n = 16384; the main stream's updates crawl on the reserved CUs.)
-    std::vector<hipEvent_t> events;
+    size_t events_used = 0;
     auto new_event = [&]() {
-        hipEvent_t e = nullptr;
-        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-        events.push_back(e);
-        return e;
+        if (events_used == c->lu_events.size()) {
+            hipEvent_t e = nullptr;
+            (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            c->lu_events.push_back(e);
+        }
+        return c->lu_events[events_used++];
     };
     // update-stream dgemm blocks ask for 84 KiB of LDS (73.7 needed): one per CU, leaving 76 KiB for a panel
     // block (66 KiB) or a main-stream dgemm block (73.7 KiB)
@@ -1363,9 +1367,6 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     if (side_done) (void)hipStreamWaitEvent(main_stream, side_done, 0);
     (void)hipStreamSynchronize(side);
     (void)hipStreamSynchronize(main_stream);
-    for (hipEvent_t e : events)
-        if (e) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(side);
     c->trsm_base = saved_trsm_base;
     return rc;
 }
@@ -1394,15 +1395,13 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     const size_t off_xb = off_xa + sizeof(unsigned long long) * 2 * PK_MAXB;
     const size_t off_xctl = off_xb + sizeof(unsigned long long) * 2 * PK_MAXB;
     const size_t total = off_xctl + 64 + 16 * sizeof(unsigned long long);
-    char* blk = nullptr;
-    RMHIP_HIP_CHECK(hipMalloc((void**)&blk, total));
+    std::shared_ptr<Allocation> blk_mem;  // pooled: a hipMalloc / hipFree pair costs two device synchronisations per factorisation
+    RMHIP_TRY(c->alloc_device(total / sizeof(double) + 2, &blk_mem));
+    char* blk = (char*)blk_mem->ptr;
     int* ipiv = (int*)blk;
     int* info = ipiv + rows;
     hipError_t e = hipMemsetAsync(blk, 0, total, c->stream);
-    if (e != hipSuccess) {
-        (void)hipFree(blk);
-        return fail(RMHIP_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
-    }
+    if (e != hipSuccess) return fail(RMHIP_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e));
     std::vector<size_t> panel_start;
     panel_start.reserve(max_panels);
     LuState s{c, A, rows, cols, lda, ipiv, info, (int*)(blk + off_posof), (int*)(blk + off_rowat), (int*)(blk + off_prow),
@@ -1478,7 +1477,6 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     } else {
         (void)hipStreamSynchronize(c->stream);
     }
-    (void)hipFree(blk);
     if (rc != RMHIP_OK) return rc;
     if (info_host) *info_host = h_ipiv[rows];
     if (ipiv_host) ipiv_host->assign(h_ipiv.begin(), h_ipiv.begin() + (long)kmin);

@@ -820,7 +820,9 @@ int rmhip_lu(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf out5[5]) {
     if (!rc) rc = c->new_buffer(s_l, 2, &ids[3], &P);
     if (!rc) rc = c->new_buffer(s_piv, 2, &ids[4], &piv);
     int* perm = nullptr;
-    if (!rc && hipMalloc((void**)&perm, sizeof(int) * (rows + 1)) != hipSuccess) rc = fail(RMHIP_ERR_OOM, "lu: pivot allocation failed");
+    std::shared_ptr<Allocation> perm_mem;  // pooled (a hipMalloc / hipFree pair costs two device synchronisations per call)
+    if (!rc) rc = c->alloc_device((rows + 2) / 2 + 1, &perm_mem);
+    if (!rc) perm = (int*)perm_mem->ptr;
     const size_t ldw = lu_padded_ld(rows);
     std::shared_ptr<Allocation> work;
     if (!rc) rc = c->alloc_device(ldw * (cols ? cols : 1), &work);
@@ -832,10 +834,6 @@ int rmhip_lu(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf out5[5]) {
         if (e != hipSuccess) rc = fail(RMHIP_ERR_HIP, "lu copy back: %s", hipGetErrorString(e));
     }
     if (!rc) rc = lu_extract_device(c, comb.data(), rows, cols, perm, L.data(), U.data(), P.data(), piv.data());
-    if (perm) {
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipFree(perm);
-    }
     if (rc) {
         for (auto id : ids)
             if (id) rmhip_free(ctx, id);
@@ -929,8 +927,9 @@ static int mldivide_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, r
     const size_t ldw = lu_padded_ld(n);
     std::shared_ptr<Allocation> work;
     RMHIP_TRY(c->alloc_device(ldw * n, &work));
-    int* perm = nullptr;
-    RMHIP_HIP_CHECK(hipMalloc((void**)&perm, sizeof(int) * (n + 1)));
+    std::shared_ptr<Allocation> perm_mem;  // pooled, released in stream order
+    RMHIP_TRY(c->alloc_device((n + 2) / 2 + 1, &perm_mem));
+    int* perm = (int*)perm_mem->ptr;
     int info = 0;
     int rc = lu_copy_and_factor(c, ab.data(), n, n, work->ptr, ldw, perm, &info);
     if (!rc && info > 0)
@@ -940,8 +939,6 @@ static int mldivide_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, r
     const size_t oshape[2] = {n, nrhs};
     if (!rc) rc = c->new_buffer(oshape, 2, &oid, &ob);
     if (!rc) rc = lu_solve_device(c, work->ptr, n, ldw, perm, bb.data(), nrhs, n, ob.data(), n);
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(perm);
     if (rc) {
         if (oid) rmhip_free(ctx, oid);
         return rc;
@@ -1037,15 +1034,14 @@ static int linsolve_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, c
         const size_t ldw = lu_padded_ld(n);
         std::shared_ptr<Allocation> work;
         RMHIP_TRY(c->alloc_device(ldw * n, &work));
-        int* perm = nullptr;
-        RMHIP_HIP_CHECK(hipMalloc((void**)&perm, sizeof(int) * (n + 1)));
+        std::shared_ptr<Allocation> perm_mem;
+        RMHIP_TRY(c->alloc_device((n + 2) / 2 + 1, &perm_mem));
+        int* perm = (int*)perm_mem->ptr;
         int info = 0;
         rc = lu_copy_and_factor(c, A, n, n, work->ptr, ldw, perm, &info);
         if (!rc && info > 0) rc = fail(RMHIP_ERR_SINGULAR, "linsolve: %d pivot(s) <= 1e-12; use the CPU SVD path", info);
         if (!rc) rc = c->new_buffer(oshape, 2, &oid, &ob);
         if (!rc) rc = lu_solve_device(c, work->ptr, n, ldw, perm, bb.data(), nrhs, n, ob.data(), n);
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipFree(perm);
     }
     if (at) (void)hipStreamSynchronize(c->stream);  // the transposed copy is released on return
     if (rc) {
