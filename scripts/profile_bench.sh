@@ -1,6 +1,7 @@
 #!/bin/bash
 # Developer tool (GPU box): rocprofv3 kernel-trace stats + separate PMC passes for bench.py.
 # Usage: scripts/profile_bench.sh <tag>      (writes under gpurun_out/prof_<tag>/)
+# Every rocprofv3 run sits under `timeout` (one hung for ten minutes once and took the GPU budget with it).
 # PMC passes use --no-also (one workload per pass): rocprofv3 --pmc crashed on the full default run,
 # whose LU workload issues ~50k dispatches.
 set -u
@@ -10,16 +11,16 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
 for W in fused dgemm; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$W" -o trace -- $BENCH --no-also --workload $W > "$OUT/trace_${W}_bench.json" 2> "$OUT/trace_$W.err"
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_$W" -o fetch -- $BENCH --no-also --workload $W > "$OUT/fetch_${W}_bench.json" 2> "$OUT/fetch_$W.err"
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_$W" -o write -- $BENCH --no-also --workload $W > "$OUT/write_${W}_bench.json" 2> "$OUT/write_$W.err"
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$W" -o trace -- $BENCH --no-also --workload $W > "$OUT/trace_${W}_bench.json" 2> "$OUT/trace_$W.err"
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_$W" -o fetch -- $BENCH --no-also --workload $W > "$OUT/fetch_${W}_bench.json" 2> "$OUT/fetch_$W.err"
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_$W" -o write -- $BENCH --no-also --workload $W > "$OUT/write_${W}_bench.json" 2> "$OUT/write_$W.err"
 done
 # matrix-pipe evidence for the dgemm kernel (own pass: SQ + GRBM counters only)
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_mfma_dgemm" -o mfma -- $BENCH --no-also --workload dgemm > "$OUT/mfma_dgemm_bench.json" 2> "$OUT/mfma_dgemm.err"
+timeout 400 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_mfma_dgemm" -o mfma -- $BENCH --no-also --workload dgemm > "$OUT/mfma_dgemm_bench.json" 2> "$OUT/mfma_dgemm.err"
 # kernel mix of the LU solve (kernel trace only)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_mldivide" -o trace -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also --workload mldivide > "$OUT/trace_mldivide_bench.json" 2> "$OUT/trace_mldivide.err"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_mldivide" -o trace -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also --workload mldivide > "$OUT/trace_mldivide_bench.json" 2> "$OUT/trace_mldivide.err"
 for f in $(find "$OUT/trace" -name "*kernel_stats.csv"); do echo "== $f"; head -14 "$f" | cut -c1-170; done
 python - "$OUT" <<'PY'
 import csv, glob, sys, collections, json

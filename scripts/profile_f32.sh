@@ -10,10 +10,10 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-also"
 for W in fused_f32 sgemm; do
   STEPS=20; [ $W = fused_f32 ] && STEPS=200   # 200 back-to-back dispatches: the per-dispatch trace below shows drift, if any
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$W" -o trace -- ${BENCH/--steps 20/--steps $STEPS} --workload $W > "$OUT/trace_${W}_bench.json" 2> "$OUT/trace_$W.err"
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$W" -o trace -- ${BENCH/--steps 20/--steps $STEPS} --workload $W > "$OUT/trace_${W}_bench.json" 2> "$OUT/trace_$W.err"
 done
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_fused_f32" -o fetch -- $BENCH --workload fused_f32 > "$OUT/fetch_bench.json" 2> "$OUT/fetch.err"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_fused_f32" -o write -- $BENCH --workload fused_f32 > "$OUT/write_bench.json" 2> "$OUT/write.err"
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_fused_f32" -o fetch -- $BENCH --workload fused_f32 > "$OUT/fetch_bench.json" 2> "$OUT/fetch.err"
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_fused_f32" -o write -- $BENCH --workload fused_f32 > "$OUT/write_bench.json" 2> "$OUT/write.err"
 for f in $(find "$OUT" -name "*kernel_stats.csv"); do echo "== $f"; head -5 "$f" | cut -c1-170; done
 python - "$OUT" <<'PY'
 import csv, glob, sys, collections, json

@@ -17,9 +17,6 @@ def rate(tag, f, nbytes, reps=10):
         best = min(best, prov.timer_end() / reps)
     print(f"{tag:34s} {best:.4f} ms  {nbytes/best/1e6:.0f} GB/s", flush=True)
 rate("reduce_sum dim1 (sum(x,2))", lambda: prov.reduce_sum_dim(a, 1), N)
-os.environ["RMHIP_REDUCE_NO_WIDE_B"] = "1"
-rate("reduce_sum dim1, generic kernel B", lambda: prov.reduce_sum_dim(a, 1), N)
-del os.environ["RMHIP_REDUCE_NO_WIDE_B"]
 rate("reduce_mean dim1", lambda: prov.reduce_mean_dim(a, 1), N)
 rate("reduce_sum dim0", lambda: prov.reduce_sum_dim(a, 0), N)
 rate("random_normal 1e8", lambda: prov.random_normal((100_000_000, 1)), 8e8)
