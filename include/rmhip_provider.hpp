@@ -10,6 +10,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <array>
 #include <vector>
 
 #include "rmhip.h"
@@ -295,6 +296,37 @@ public:
         uint64_t out = 0;
         check(rmhip_random_normal(ctx_, shape.data(), shape.size(), &out));
         return make(out, shape);
+    }
+
+    // ---- multi-GPU collectives (include/rmhip.h "multi-GPU collectives"; one process per GPU, no trait counterpart) ----
+    static std::array<unsigned char, RMHIP_COMM_ID_BYTES> comm_unique_id(bool rccl = true) {
+        std::array<unsigned char, RMHIP_COMM_ID_BYTES> id{};
+        check(rmhip_comm_unique_id(rccl ? RMHIP_COMM_RCCL : RMHIP_COMM_HOST_SHM, id.data()));
+        return id;
+    }
+    void comm_init(const std::array<unsigned char, RMHIP_COMM_ID_BYTES>& id, int rank, int world) const {
+        check(rmhip_comm_init(ctx_, id.data(), rank, world));
+    }
+    void comm_destroy() const { check(rmhip_comm_destroy(ctx_)); }
+    std::pair<int, int> comm_rank() const {
+        int r = 0, w = 1;
+        check(rmhip_comm_rank(ctx_, &r, &w));
+        return {r, w};
+    }
+    void comm_barrier() const { check(rmhip_comm_barrier(ctx_)); }
+    void comm_bcast(const rmhip_view_t& block, int root, bool asynchronous = false) const {
+        check(rmhip_comm_bcast(ctx_, &block, root, asynchronous ? 1 : 0));
+    }
+    void comm_wait() const { check(rmhip_comm_wait(ctx_)); }
+    GpuTensorHandle comm_allgather_f64(const GpuTensorHandle& local) const {
+        uint64_t out = 0;
+        check(rmhip_comm_allgather_f64(ctx_, own(local), &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle comm_allgather_rows(const GpuTensorHandle& local, size_t rows_total, size_t granule = 128) const {
+        uint64_t out = 0;
+        check(rmhip_comm_allgather_rows(ctx_, own(local), rows_total, granule, &out));
+        return with_shape(out);
     }
 
     rmhip_ctx* raw() const { return ctx_; }

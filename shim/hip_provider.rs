@@ -63,7 +63,30 @@ extern "C" {
     fn rmhip_stochastic_evolution(ctx: *mut RmhipCtx, state: u64, drift: c_double, scale: c_double, steps: u32, out: *mut u64) -> c_int;
     fn rmhip_random_normal(ctx: *mut RmhipCtx, shape: *const usize, rank: usize, out: *mut u64) -> c_int;
     fn rmhip_random_uniform(ctx: *mut RmhipCtx, shape: *const usize, rank: usize, out: *mut u64) -> c_int;
+    // multi-GPU collectives (one process per GPU; no counterpart in the trait - see `impl HipProvider` at the end)
+    fn rmhip_comm_unique_id(transport: c_int, id_out: *mut c_void) -> c_int;
+    fn rmhip_comm_init(ctx: *mut RmhipCtx, unique_id: *const c_void, rank: c_int, world: c_int) -> c_int;
+    fn rmhip_comm_destroy(ctx: *mut RmhipCtx) -> c_int;
+    fn rmhip_comm_rank(ctx: *mut RmhipCtx, rank: *mut c_int, world: *mut c_int) -> c_int;
+    fn rmhip_comm_barrier(ctx: *mut RmhipCtx) -> c_int;
+    fn rmhip_comm_bcast(ctx: *mut RmhipCtx, block: *const RmhipView, root: c_int, async_: c_int) -> c_int;
+    fn rmhip_comm_wait(ctx: *mut RmhipCtx) -> c_int;
+    fn rmhip_comm_allgather_f64(ctx: *mut RmhipCtx, local: u64, out: *mut u64) -> c_int;
+    fn rmhip_comm_allgather_rows(ctx: *mut RmhipCtx, local: u64, rows_total: usize, granule: usize, out: *mut u64) -> c_int;
 }
+
+/// `rmhip_view_t`: rows [row_off, row_off + rows) x columns [col_off, col_off + cols) of a 2-D buffer.
+#[repr(C)]
+pub struct RmhipView {
+    pub buf: u64,
+    pub row_off: usize,
+    pub col_off: usize,
+    pub rows: usize,
+    pub cols: usize,
+}
+pub const RMHIP_COMM_ID_BYTES: usize = 128;
+pub const RMHIP_COMM_RCCL: c_int = 0;
+pub const RMHIP_COMM_HOST_SHM: c_int = 1;
 
 // Op codes: the enums of include/rmhip.h (tests/test_front_end.py checks every value against the header).
 const RMHIP_ADD: c_int = 0;
@@ -484,6 +507,46 @@ impl AccelProvider for HipProvider {
     fn set_rng_state(&self, state: u64) -> Result<()> { check(unsafe { rmhip_set_rng_state(self.ctx, state) }) }
     // zeros/ones/fill, reduce_mean(_dim), reduce_min/max, scalar_*, telemetry_snapshot, device_info_struct:
     // same pattern over rmhip_fill / rmhip_reduce / rmhip_scalar / rmhip_telemetry / rmhip_device_info.
+}
+
+/// Sharded forms of the hot path: one process per GPU, one provider per process.  The trait has no
+/// multi-device surface (the reference has none), so these are inherent methods a multi-GPU host calls
+/// around the trait calls: rank 0 makes an id, the host ships its 128 bytes to every rank (MPI, a file, ...), every
+/// rank calls `comm_init`; then e.g. `matmul` on the local row block followed by `comm_allgather_rows`.
+impl HipProvider {
+    pub fn comm_unique_id(rccl: bool) -> Result<[u8; RMHIP_COMM_ID_BYTES]> {
+        let mut id = [0u8; RMHIP_COMM_ID_BYTES];
+        check(unsafe { rmhip_comm_unique_id(if rccl { RMHIP_COMM_RCCL } else { RMHIP_COMM_HOST_SHM }, id.as_mut_ptr() as *mut c_void) })?;
+        Ok(id)
+    }
+    pub fn comm_init(&self, id: &[u8; RMHIP_COMM_ID_BYTES], rank: i32, world: i32) -> Result<()> {
+        check(unsafe { rmhip_comm_init(self.ctx, id.as_ptr() as *const c_void, rank, world) })
+    }
+    pub fn comm_destroy(&self) -> Result<()> { check(unsafe { rmhip_comm_destroy(self.ctx) }) }
+    pub fn comm_rank(&self) -> Result<(i32, i32)> {
+        let (mut r, mut w) = (0, 1);
+        check(unsafe { rmhip_comm_rank(self.ctx, &mut r, &mut w) })?;
+        Ok((r, w))
+    }
+    pub fn comm_barrier(&self) -> Result<()> { check(unsafe { rmhip_comm_barrier(self.ctx) }) }
+    /// In-place broadcast of a sub-block from `root`; `asynchronous` posts it on the communication stream (the
+    /// block-cyclic solver's look-ahead) and `comm_wait` joins it before the block is read.
+    pub fn comm_bcast(&self, block: &RmhipView, root: i32, asynchronous: bool) -> Result<()> {
+        check(unsafe { rmhip_comm_bcast(self.ctx, block, root, asynchronous as c_int) })
+    }
+    pub fn comm_wait(&self) -> Result<()> { check(unsafe { rmhip_comm_wait(self.ctx) }) }
+    /// [k] per rank -> [k, world] on every rank, column r = rank r: the caller sums the columns in rank order.
+    pub fn comm_allgather_f64(&self, local: &GpuTensorHandle) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_comm_allgather_f64(self.ctx, self.own(local)?, &mut out) })?;
+        self.handle(out)
+    }
+    /// Row blocks (balanced split of `rows_total` in units of `granule`) -> the replicated matrix.
+    pub fn comm_allgather_rows(&self, local: &GpuTensorHandle, rows_total: usize, granule: usize) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_comm_allgather_rows(self.ctx, self.own(local)?, rows_total, granule, &mut out) })?;
+        self.handle(out)
+    }
 }
 
 /// Register before `initialize_acceleration_provider_with` so A/lib.rs:179-181 short-circuits.
