@@ -379,7 +379,7 @@ def main() -> None:
         wall = max_over_ranks(time.perf_counter() - t0)
         prov.free(hx)
         ms = wall / steps * 1e3
-        nbytes = 32 * B * H * W  # three reads (mean, two-pass variance, normalise) + one write per element
+        nbytes = 24 * B * H * W  # one-pass plane statistics (one read), normalise (one read + one write) per element
         return {
             "metric": "image_normalize GB/s (4k-image-processing: 16 x 2160 x 3840 f64 frames, one provider call)",
             "value": round(nbytes * world / (ms * 1e-3) / 1e9, 1), "unit": "GB/s", "ms_per_step": round(ms, 4), "scaling": "strong",
@@ -388,8 +388,8 @@ def main() -> None:
                        "bytes_per_step_per_gpu": nbytes, "parallelism": f"frames x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "k_plane_partial<false>, k_plane_partial<true>, k_imgnorm_apply (32 B per element; the "
-                                   "pow of the gamma step makes the last pass VALU bound)"},
+                         "kernel": "k_plane_moments (one-pass mean / M2, fixed-order Chan merge), k_plane_moments_final, k_imgnorm_apply "
+                                   "(24 B per element; round 1 moved 32 with a two-pass variance)"},
         }
 
     def mldivide_record(steps, warmup):
@@ -581,7 +581,7 @@ def main() -> None:
             others.append("mldivide")
         also = []
         for w in others:
-            steps = {"fused": 20, "dgemm": 5, "mc": 3, "mc_evolved": 3, "image": 5, "mldivide": 2, "chain": 100, "fused_f32": 20, "sgemm": 5}[w]
+            steps = {"fused": 20, "dgemm": 5, "mc": 10, "mc_evolved": 10, "image": 20, "mldivide": 2, "chain": 100, "fused_f32": 20, "sgemm": 5}[w]
             sec = records[w](steps, 2 if w != "mldivide" else 1)
             also.append({k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "roofline")})
         out["also"] = also

@@ -12,6 +12,7 @@
 // generator (Philox, backend/wgpu/shaders/creation.rs:707-794) and therefore a different stream
 // from its own CPU path; parity here is with the CPU.
 #include "common.h"
+#include "skel_common.h"
 
 namespace rmhip {
 
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(256) k_rng_normal(unsigned long long state, T*
         double u1 = lcg_next_uniform(t);
         if (u1 <= 0.0) u1 = 2.2250738585072014e-308;  // f64::MIN_POSITIVE (random.rs:13,281-283)
         const double u2 = lcg_next_uniform(t);
-        const double radius = sqrt(-2.0 * log(u1));
+        const double radius = sqrt(-2.0 * rm_log_pos(u1));  // skel_common.h: < 1 ulp, 40 instead of 102 VALU instructions
         // cos / sin of 2*pi*u2 through sincospi(2*u2): the argument reduction is exact and a third of the kernel's VALU
         // work disappears (the kernel is VALU-bound: ~250 fp64 instructions per pair).  The CPU evaluates cos(fl(2*pi*u2))
         // (random.rs:284-287); the two differ by the rounding of the angle, <= 4.5e-16 * radius in the result - the size
@@ -152,7 +153,7 @@ __global__ void __launch_bounds__(256) k_stochastic_evolution(unsigned long long
             double u1 = lcg_next_uniform(u);
             if (u1 <= 0.0) u1 = 2.2250738585072014e-308;
             const double u2 = lcg_next_uniform(u);
-            const double radius = sqrt(-2.0 * log(u1));
+            const double radius = sqrt(-2.0 * rm_log_pos(u1));  // skel_common.h: < 1 ulp, 40 instead of 102 VALU instructions
             double sn, cs;
             sincospi(2.0 * u2, &sn, &cs);  // as in k_rng_normal: same stream, exact argument reduction
             const double t0 = scale * (radius * cs), t1 = scale * (radius * sn);

@@ -17,6 +17,7 @@
 // walks the linear index with a stride that is a multiple of `batch`, so its batch element is fixed (no per-element
 // modulo) and loads stay coalesced.
 #include "common.h"
+#include "skel_common.h"
 
 namespace rmhip {
 
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(IN_BLOCK) k_imgnorm_apply(const T* __restrict_
             // double-double pow: the pass is VALU-bound, 0.93 -> 0.5 ms at 16 x 2160 x 3840); relative error
             // <= (|g ln w| + 2) ulp, a few 1e-16 for image data.  0, +Inf and NaN come out as powf's do; a negative base
             // (no clamp requested) keeps the exact pow: powf(negative, integer) is finite.
-            if (has_gamma) w = (w >= 0.0 && gamma > 0.0) ? (w == 0.0 ? 0.0 : exp(gamma * log(w))) : pow(w, gamma);
+            if (has_gamma) w = (w >= 0.0 && gamma > 0.0) ? (w == 0.0 ? 0.0 : exp(gamma * rm_log_pos(w))) : pow(w, gamma);
             v[l] = w;
         }
         if constexpr (VEC == 1) {
