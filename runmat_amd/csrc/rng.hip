@@ -96,12 +96,13 @@ __global__ void __launch_bounds__(256) k_rng_normal(unsigned long long state, T*
         if (u1 <= 0.0) u1 = 2.2250738585072014e-308;  // f64::MIN_POSITIVE (random.rs:13,281-283)
         const double u2 = lcg_next_uniform(t);
         const double radius = sqrt(-2.0 * rm_log_pos(u1));  // skel_common.h: < 1 ulp, 40 instead of 102 VALU instructions
-        // cos / sin of 2*pi*u2 through sincospi(2*u2): the argument reduction is exact and a third of the kernel's VALU
-        // work disappears (the kernel is VALU-bound: ~250 fp64 instructions per pair).  The CPU evaluates cos(fl(2*pi*u2))
+        // cos / sin of 2*pi*u2 through sin(pi t), cos(pi t) at t = 2*u2 (rm_sincospi2, skel_common.h): the argument reduction is
+        // exact and most of the kernel's VALU work disappears (the kernel is VALU-bound: ~250 fp64 instructions per pair with
+        // the library's log / cos / sin, ~145 now).  The CPU evaluates cos(fl(2*pi*u2))
         // (random.rs:284-287); the two differ by the rounding of the angle, <= 4.5e-16 * radius in the result - the size
         // of the libm differences the stream tolerance (8e-14 absolute) already covers.
         double sn, cs;
-        sincospi(2.0 * u2, &sn, &cs);
+        rm_sincospi2(2.0 * u2, &sn, &cs);
         const double z0 = radius * cs, z1 = radius * sn;
         if (2 * i + 1 < n) {
             if (aligned) *(P*)(out + 2 * i) = P{(T)z0, (T)z1};
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(256) k_stochastic_evolution(unsigned long long
             const double u2 = lcg_next_uniform(u);
             const double radius = sqrt(-2.0 * rm_log_pos(u1));  // skel_common.h: < 1 ulp, 40 instead of 102 VALU instructions
             double sn, cs;
-            sincospi(2.0 * u2, &sn, &cs);  // as in k_rng_normal: same stream, exact argument reduction
+            rm_sincospi2(2.0 * u2, &sn, &cs);  // as in k_rng_normal: same stream, exact argument reduction
             const double t0 = scale * (radius * cs), t1 = scale * (radius * sn);
             v0 = v0 * exp(drift + t0);
             v1 = v1 * exp(drift + t1);

@@ -128,6 +128,35 @@ __device__ __forceinline__ double rm_log_pos(double x) {
     return dk * 0x1.62e42fee00000p-1 - ((hfsq - (s * (hfsq + R) + dk * 0x1.a39ef35793c76p-33)) - f);  // ln2_hi, ln2_lo
 }
 
+
+// sin(pi t), cos(pi t) for the Box-Muller angle (t = 2 u in [0, 2); any |t| < 2^51 works): quarter-turn reduction in t itself
+// (exact: n = rint(2t), r = t - n/2 by one fma, |r| <= 1/4), x = pi r with a two-term pi, then the same two minimax
+// polynomials as rm_sincos_r32 and a rotation by n quarter turns.  ~30 VALU instructions against the library sincospi's 75;
+// absolute error <= 1.4e-16 (measured against sinl / cosl on 1e8 uniforms).
+__device__ __forceinline__ void rm_sincospi2(double t, double* sp, double* cp) {
+    const double n = __builtin_rint(2.0 * t);
+    const double r = __builtin_fma(n, -0.5, t);
+    const double x = __builtin_fma(r, 0x1.921fb54442d18p+1, r * 0x1.1a62633145c07p-53);
+    const double z = x * x;
+    double ps = __builtin_fma(z, 0x1.5d93a5acfd57cp-33, -0x1.ae5e68a2b9cebp-26);
+    RM_FMA_SC(ps, z, ps, 0x1.71de357b1fe7dp-19);
+    RM_FMA_SC(ps, z, ps, -0x1.a01a019c161d5p-13);
+    RM_FMA_SC(ps, z, ps, 0x1.111111110f8a6p-7);
+    RM_FMA_SC(ps, z, ps, -0x1.5555555555549p-3);
+    const double sn = __builtin_fma(x * z, ps, x);
+    double pc = __builtin_fma(z, -0x1.8fae9be8838d4p-37, 0x1.1ee9ebdb4b1c4p-29);
+    RM_FMA_SC(pc, z, pc, -0x1.27e4f809c52adp-22);
+    RM_FMA_SC(pc, z, pc, 0x1.a01a019cb1590p-16);
+    RM_FMA_SC(pc, z, pc, -0x1.6c16c16c15177p-10);
+    RM_FMA_SC(pc, z, pc, 0x1.555555555554cp-5);
+    pc = __builtin_fma(z, pc, -0.5);
+    const double cs = __builtin_fma(z, pc, 1.0);
+    const int q = (int)n & 3;
+    const double s = (q & 1) ? cs : sn, c = (q & 1) ? sn : cs;
+    *sp = (q >= 2) ? -s : s;
+    *cp = (q == 1 || q == 2) ? -c : c;
+}
+
 #ifdef RM_RESULT_F32
 __device__ __forceinline__ double rm_sin(double x) { return rm_sincos_r32(x, 0); }
 __device__ __forceinline__ double rm_cos(double x) { return rm_sincos_r32(x, 1); }
