@@ -121,10 +121,17 @@ __global__ void __launch_bounds__(RM_RBLOCK) k_reduce_strided_v2(const T* x, rm_
             rm_acc_add<OP>(a1, v[u].y);
         }
     }
-    for (; r < end; ++r) {
-        const rm_rv2 v = rm_load2(x, base2 + pre2 * r);
-        rm_acc_add<OP>(a0, v.x);
-        rm_acc_add<OP>(a1, v.y);
+    if (r < end) {  // the last, partial group: its loads go out together too (one at a time they cost a memory round trip each)
+        rm_rv2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (r + u < end) v[u] = rm_load2(x, base2 + pre2 * (r + u));
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (r + u < end) {
+                rm_acc_add<OP>(a0, v[u].x);
+                rm_acc_add<OP>(a1, v[u].y);
+            }
     }
     const rm_u64 slice = 2 * i2 + pre * j;
     pv[slice * nsplit + split] = a0.v;
@@ -145,15 +152,19 @@ static int run_reduce(Context* c, int mean, int nan_mode, const T* x, size_t pre
     if (pre == 0 || post == 0) return RMHIP_OK;  // no output slices
     const ReducePlan p = plan_reduction(pre, red, post, c->num_cus, (unsigned)sizeof(T));
     if (!p.valid) return fail(RMHIP_ERR_UNSUPPORTED, "reduce: geometry [%zu,%zu,%zu] exceeds launch limits", pre, red, post);
-    // Kernel B in its 16-byte form (two adjacent slices per thread, 256-thread blocks, non-temporal loads) with FOUR blocks
-    // per CU: sum(x,2) 8192^2 113.8 -> 111.5 us, 65536 x 1024 119.3 -> 105.6 us (scripts/red_b_ab.sh; more resident blocks
-    // are slower: 8 per CU 113.4 / 119.8, 16 per CU 129.8 / 139.6 - the streams are strided columns and every extra
-    // one costs DRAM page locality).  A 1024-thread version with 16 KiB of every column per block was slower still (137).
+    // Kernel B in its 16-byte form (two adjacent slices per thread, 256-thread blocks, non-temporal loads, the partial last
+    // group of a chunk loaded together like the full ones) with THREE blocks per CU.  The block count matters more than
+    // anything inside the kernel, and not monotonically (scripts/red_bpc_ab.sh, sum(x,2) in us for 8192^2 / 16384x4096 /
+    // 4096x16384 / 7936x8192): 1 per CU 104 / 95 / 104 / 105, 2: 100 / 103 / 104 / 99, 3: 86 / 88 / 86 / 86, 4: 101 /
+    // 100 / 109 / 92, 5: 93 / 96 / 89 / 93, 6: 96 / 106 / 93 / 91, 8: 113, 16: 130 - every stream is a strided column walk
+    // and the streams run in lockstep; 1024 blocks (exactly four per CU) with 128-column chunks is the worst point
+    // (112 us), 512 or 768 the best.  The generic kernel B at its 8 blocks per CU: 113.8 us.  A 1024-thread version with
+    // 16 KiB of every column per block: 137 us.
     uint64_t nsplit = p.nsplit;
     // dev knobs (A/B only): RMHIP_RED_B_MODE 0 = generic kernel B, 1/2 = the 16-byte form with 8 / 4 loads in flight;
     // RMHIP_RED_B_BPC = its target blocks per CU
     static const int b_mode = getenv("RMHIP_RED_B_MODE") ? atoi(getenv("RMHIP_RED_B_MODE")) : 1;
-    static const int b_bpc = getenv("RMHIP_RED_B_BPC") ? atoi(getenv("RMHIP_RED_B_BPC")) : 4;
+    static const int b_bpc = getenv("RMHIP_RED_B_BPC") ? atoi(getenv("RMHIP_RED_B_BPC")) : 3;
     const bool wide_b = !p.contiguous && b_mode > 0 && (pre & 1) == 0 && pre >= 512 && (((uintptr_t)x) & 15) == 0 && post <= 65535;
     unsigned wide_bx = 0;
     if (wide_b) {
@@ -162,6 +173,9 @@ static int run_reduce(Context* c, int mean, int nan_mode, const T* x, size_t pre
         uint64_t max_split = ceil_div_u64(red, 16);
         nsplit = want < 1 ? 1 : want;
         if (nsplit > max_split) nsplit = max_split;
+        nsplit = dealias_nsplit(red, nsplit, pre * sizeof(T), max_split);  // reduce_plan.h: chunks off the same memory channels
+        static const long dev_chunk = getenv("RMHIP_RED_B_CHUNK") ? atol(getenv("RMHIP_RED_B_CHUNK")) : 0;  // dev knob: columns per chunk
+        if (dev_chunk > 0) nsplit = ceil_div_u64(red, (uint64_t)dev_chunk);
         if (nsplit > 65535) nsplit = 65535;
     }
     const size_t nparts = (size_t)(p.nslices * nsplit);

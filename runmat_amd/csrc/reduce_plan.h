@@ -23,6 +23,21 @@ struct ReducePlan {
 
 inline uint64_t ceil_div_u64(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
+// Kernel B walks `red` in nsplit chunks of ceil(red / nsplit) columns and the blocks of all chunks run in lockstep.  When a
+// chunk spans a multiple of 256 KiB (power-of-two shapes: 8192 x 8192 f64 in 64 chunks = 8 MiB each) every block is at the
+// same offset of its chunk at the same time; 65 chunks of 127 columns instead measured 112 -> 105 us for sum(x,2) at 8192^2
+// and 115 -> 102 us at 16384 x 4096 (scripts/red_chunk_ab.sh).  The block COUNT matters more (reduce_kernels.hip); this
+// only moves the generic kernel off its worst point.
+inline uint64_t dealias_nsplit(uint64_t red, uint64_t nsplit, uint64_t column_stride_bytes, uint64_t max_split) {
+    if (nsplit <= 1 || column_stride_bytes == 0) return nsplit;
+    for (int tries = 0; tries < 8 && nsplit < max_split; ++tries) {
+        const uint64_t chunk = ceil_div_u64(red, nsplit);
+        if (chunk <= 8 || (chunk * column_stride_bytes) % (256u * 1024u) != 0) break;
+        ++nsplit;
+    }
+    return nsplit;
+}
+
 // Requires pre >= 1 and post >= 1 (callers return early when there are no output slices).
 // `elem_bytes`: storage width of the reduced tensor (8, or 4 on a precision-32 provider).
 inline ReducePlan plan_reduction(uint64_t pre, uint64_t red, uint64_t post, int num_cus, unsigned elem_bytes = 8) {
@@ -63,6 +78,7 @@ inline ReducePlan plan_reduction(uint64_t pre, uint64_t red, uint64_t post, int 
         uint64_t want = ceil_div_u64(target_blocks, bx * (post ? post : 1));
         if (want < 1) want = 1;
         p.nsplit = want < max_split ? want : max_split;
+        p.nsplit = dealias_nsplit(red, p.nsplit, pre * elem_bytes, max_split);
         if (p.nsplit > 65535) p.nsplit = 65535;
         p.gx = (unsigned)bx;
         p.gy = (unsigned)p.nsplit;

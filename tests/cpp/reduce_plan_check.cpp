@@ -63,8 +63,14 @@ int main() {
     const ReducePlan cols32 = plan_reduction(1, 8192, 8192, 256, 4);
     CHECK(cols32.nsplit == 1 && cols32.tx == 256, "sum over columns, f32 storage");
     const ReducePlan rows = plan_reduction(8192, 8192, 1, 256);
-    CHECK(!rows.contiguous && rows.tx == 256 && rows.gx == 32 && rows.nsplit == 64, "sum over rows: gx=%u nsplit=%llu", rows.gx,
+    // 64 chunks of 128 columns would each span 8 MiB - a multiple of 256 KiB, all chunks on the same memory channels at any moment -
+    // so the plan takes 65 chunks of 127 (dealias_nsplit)
+    CHECK(!rows.contiguous && rows.tx == 256 && rows.gx == 32 && rows.nsplit == 65, "sum over rows: gx=%u nsplit=%llu", rows.gx,
           (unsigned long long)rows.nsplit);
+    const ReducePlan rows_odd = plan_reduction(8192, 8000, 1, 256);  // 125 columns per chunk: left alone
+    CHECK(rows_odd.nsplit == 64, "sum over rows, 8000 columns: nsplit=%llu", (unsigned long long)rows_odd.nsplit);
+    CHECK(dealias_nsplit(8192, 64, 65536, 512) == 65 && dealias_nsplit(8192, 1, 65536, 512) == 1 && dealias_nsplit(8192, 64, 63000, 512) == 64,
+          "dealias_nsplit");
     const ReducePlan none = plan_reduction(0, 5, 1, 256);
     CHECK(!none.valid, "empty output");
     if (failures) return 1;
