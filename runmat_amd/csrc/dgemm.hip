@@ -419,6 +419,122 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
             }
 }
 
+
+// ---- eight-wave variant of the 128 x 128 tile: two waves per SIMD inside ONE block ------------------------------------------
+// Under the LU's look-ahead the update stream may keep only one dgemm block per CU (its LDS pad leaves the rest of the CU
+// to the main stream).  With k_dgemm that is one wave per SIMD, and every barrier, LDS refill and late global load of
+// the k loop is a bubble in the matrix pipe: 52-56 TFLOP/s alone against 62-65 with two blocks per CU.  Here the same
+// tile is computed by 2 (m) x 4 (n) waves of 64 x 32 each (64 accumulator registers instead of 128), so a second wave
+// is there to issue MFMAs while the first waits - at the same 73.7 KiB of LDS and ~2 x 130 VGPRs per SIMD, which still
+// leaves room for a main-stream dgemm block beside it.  Plain operands, unguarded shapes only (m, n % 128, k % 16, even
+// leading dimensions, aligned bases); PRE as in k_dgemm.  Same k-ordered MFMA chain per element: bit-identical results.
+template <bool PRE>
+__global__ void __launch_bounds__(512) k_dgemm_w8(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* As = lds;               // [2][A_TILE]
+    double* Bs = lds + 2 * A_TILE;  // [2][B_TILE]
+    unsigned tm, tn;
+    tile_of_block(g, tm, tn);
+    const unsigned m0 = tm * BM, n0 = tn * BN;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;  // wn 0..3: 32 columns each
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int p_xp = t & 63, p_kc = t >> 6;  // A (pattern M): pair along m, k = p_kc + 8*p
+    const int q_kp = t & 7, q_y = t >> 3;    // B (pattern K): pair along k, y = q_y + 64*p
+    const double* const Ap = g.A + m0 + 2 * p_xp;
+    const double* const Bp = g.B + (size_t)n0 * g.ldb + 2 * q_kp;
+    v2d ra[2], rb[2];
+    auto fetch = [&](unsigned k0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            ra[p] = *(const v2d*)(Ap + (size_t)(k0 + p_kc + 8 * p) * g.lda);
+            rb[p] = *(const v2d*)(Bp + (size_t)(q_y + 64 * p) * g.ldb + k0);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            *(v2d*)(As + buf * A_TILE + (p_kc + 8 * p) * SA + 2 * p_xp) = ra[p];
+            *(v2d*)(Bs + buf * B_TILE + (q_y + 64 * p) * SB + 2 * q_kp) = rb[p];
+        }
+    };
+    v4d acc[2][4];  // [tj (n)][ti (m)]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (PRE) {
+                    const unsigned mm = m0 + wm * 64 + i * 16 + l15;
+                    const unsigned row = g.rowmap ? (4 * lq + r) : (4 * r + lq);
+                    const unsigned nn = n0 + wn * 32 + j * 16 + row;
+                    acc[j][i][r] = -g.C[(size_t)nn * g.ldc + mm];
+                } else {
+                    acc[j][i][r] = 0.0;
+                }
+            }
+    const unsigned ktiles = g.k / BK;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const int a_off = lq * SA + wm * 64 + l15;
+    const int b_off = (wn * 32 + l15) * SB + lq;
+    for (unsigned kt = 0; kt < ktiles; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < ktiles) fetch((kt + 1) * BK);
+        const double* a = As + cur * A_TILE + a_off;
+        const double* b = Bs + cur * B_TILE + b_off;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            double af[4], bf[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = a[kk * 4 * SA + i * 16];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = b[j * 16 * SB + kk * 4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[j][i], 0, 0, 0);
+        }
+        if (kt + 1 < ktiles) stash(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        double* dst[16];
+        double prev[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned mm = m0 + wm * 64 + i * 16 + l15;
+                const unsigned row = g.rowmap ? (4 * lq + r) : (4 * r + lq);
+                const unsigned nn = n0 + wn * 32 + j * 16 + row;
+                dst[i * 4 + r] = g.C + (size_t)nn * g.ldc + mm;
+            }
+        if (!PRE && g.beta != 0.0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) prev[e] = *dst[e];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = i * 4 + r;
+                double v;
+                if (PRE) {
+                    v = -acc[j][i][r];
+                } else {
+                    v = g.alpha * acc[j][i][r];
+                    if (g.beta != 0.0) v = g.beta * prev[e] + v;
+                }
+                *dst[e] = v;
+            }
+    }
+}
+
 static int g_rowmap = -1;
 
 static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double alpha, const double* A, size_t lda,
@@ -553,6 +669,24 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
         g.tiles_n = (unsigned)(n / SN);
         if (preload) hipLaunchKernelGGL(k_dgemm_small<true>, dim3(g.tiles_m * g.tiles_n), dim3(256), (size_t)small_pad, c->stream, g);
         else hipLaunchKernelGGL(k_dgemm_small<false>, dim3(g.tiles_m * g.tiles_n), dim3(256), (size_t)small_pad, c->stream, g);
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+        return RMHIP_OK;
+    }
+    // eight-wave tile: on the look-ahead's update stream (one padded block per CU), or everywhere with RMHIP_GEMM_W8=2 (A/B)
+    static int w8_mode = -1;
+    if (w8_mode < 0) {
+        const char* v = std::getenv("RMHIP_GEMM_W8");
+        w8_mode = v ? std::atoi(v) : 1;
+    }
+    if (fast_k && splits == 1 && !ep && !ta && !tb && ((w8_mode == 1 && c->gemm_lds_pad != 0) || w8_mode == 2)) {
+        if (preload) {
+            c->ensure_max_lds((const void*)k_dgemm_w8<true>, kMaxLds);
+            hipLaunchKernelGGL(k_dgemm_w8<true>, dim3(blocks), dim3(512), lds_bytes, c->stream, g);
+        } else {
+            c->ensure_max_lds((const void*)k_dgemm_w8<false>, kMaxLds);
+            hipLaunchKernelGGL(k_dgemm_w8<false>, dim3(blocks), dim3(512), lds_bytes, c->stream, g);
+        }
         c->tel.kernel_launches++;
         RMHIP_HIP_CHECK(hipGetLastError());
         return RMHIP_OK;
