@@ -1305,7 +1305,7 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     // columns) the narrower panel wins.  n = 16384: 128.3 -> 125.2 ms (interleaved, scripts/lu_env_ab.sh); giving the
     // main stream a share of the trailing columns as well (its dgemm blocks fit beside the update stream's) measured
     // nothing (127.3 vs 127.9).
-    size_t nb_early = 512, early_rows = 8192;
+    size_t nb_early = 512, early_rows = 10240;  // (10240 since the update stream's eight-wave dgemm: 113.7 -> 112.7 ms; 8192 before)
     if (const char* v = std::getenv("RMHIP_LU_NB_EARLY")) nb_early = (size_t)std::atoll(v);
     if (const char* v = std::getenv("RMHIP_LU_EARLY_ROWS")) early_rows = (size_t)std::atoll(v);
     nb_early = nb_early < 64 ? 64 : (nb_early / 64) * 64;
