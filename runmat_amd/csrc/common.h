@@ -150,6 +150,7 @@ struct Context {
     // LU look-ahead (lu.hip getrf_blocked): extra dynamic LDS requested by launch_dgemm so that only ONE
     // dgemm block fits per CU and latency-bound kernels of the other stream find room beside it
     size_t gemm_lds_pad = 0;
+    bool in_lookahead = false;  // inside the LU's look-ahead driver: main-stream dgemm blocks must fit beside the update stream's
     // set after a persistent-panel factorisation found its workgroups not co-resident (device shared with
     // another context): from then on LU uses the one-launch-per-column panels on a single stream
     hipStream_t lu_side_stream = nullptr;  // update stream of the look-ahead LU (low priority), created on first use

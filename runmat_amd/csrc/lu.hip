@@ -1292,6 +1292,7 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     // n = 16384; RMHIP_LU_LA_TRSM=64 selects it)
     const int saved_trsm_base = c->trsm_base;
     if (const char* v = std::getenv("RMHIP_LU_LA_TRSM")) c->trsm_base = std::atoi(v) == 64 ? 64 : 128;
+    c->in_lookahead = true;
     int rc = RMHIP_OK;
     hipEvent_t side_done = nullptr;  // S_{j-1} finished
     {
@@ -1367,6 +1368,7 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     if (side_done) (void)hipStreamWaitEvent(main_stream, side_done, 0);
     (void)hipStreamSynchronize(side);
     (void)hipStreamSynchronize(main_stream);
+    c->in_lookahead = false;
     c->trsm_base = saved_trsm_base;
     return rc;
 }
