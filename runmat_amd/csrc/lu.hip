@@ -1273,7 +1273,10 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     hipStream_t side = c->lu_side_stream;
     // (Tried: the update stream on a CU-masked stream - hipExtStreamCreateWithCUMask, mask bit i = CU i/8 of XCD i%8 - that
     // leaves 32 or 64 CUs to the main stream, two unpadded dgemm blocks per CU on the rest: 140-169 ms against 123 at
-    // n = 16384; the main stream's updates crawl on the reserved CUs.)
+    // n = 16384; the main stream's updates crawl on the reserved CUs.  Second attempt, round 2: only while the panels sit on
+    // XCD 0, a mask that bars the update stream from XCD 0 except one CU - a mask that empties an XCD is ignored as a whole -
+    // with the usual padded blocks: 370 ms against 112.  Work submitted through a CU-masked queue is slow here for
+    // reasons beyond the CU count.)
     size_t events_used = 0;
     auto new_event = [&]() {
         if (events_used == c->lu_events.size()) {

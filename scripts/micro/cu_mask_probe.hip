@@ -19,7 +19,7 @@ int main() {
     const int nblk = 8192;
     unsigned* out; CK(hipMalloc(&out, nblk * 8));
     std::vector<unsigned> h(nblk * 2);
-    for (int mode = -1; mode < 4; ++mode) {
+    for (int mode = -1; mode < 7; ++mode) {
         uint32_t mask[8];
         for (int w = 0; w < 8; ++w) mask[w] = 0;
         for (unsigned i = 0; i < 256; ++i) {
@@ -28,6 +28,9 @@ int main() {
             if (mode == 1) keep = (i & 31u) < 24u;
             if (mode == 2) keep = i < 32;            // first 32 bits only
             if (mode == 3) keep = (i & 7u) == 0;     // every 8th bit
+            if (mode == 4) keep = (i & 7u) != 0;     // everything but bits 0, 8, 16, ... (XCD 0 empty if bit i -> XCD i % 8)
+            if (mode == 5) keep = (i & 7u) != 0 || i == 0;   // XCD 0 keeps one CU
+            if (mode == 6) keep = (i & 7u) != 0 || i < 32;    // XCD 0 keeps four CUs
             if (keep) mask[i >> 5] |= 1u << (i & 31u);
         }
         hipStream_t s;
@@ -42,7 +45,7 @@ int main() {
         int total = 0;
         for (auto& kv : per) { printf(" xcc%u=%zu", kv.first, kv.second.size()); total += (int)kv.second.size(); }
         printf("  total %d\n", total);
-        if (mode == 2 || mode == 3) { printf("   xcc0 ids:"); for (unsigned v : per[0]) printf(" %02x", v); printf("\n"); }
+        if (mode == 2 || mode == 3 || mode >= 4) { printf("   xcc0 ids:"); for (unsigned v : per[0]) printf(" %02x", v); printf("\n"); }
         CK(hipStreamDestroy(s));
     }
     return 0;
