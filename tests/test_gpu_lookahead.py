@@ -60,9 +60,10 @@ def _check_solution(A, b, x, n, fwd):
     assert err <= fwd, f"forward error {err:.3e}"
 
 
-@pytest.mark.parametrize("n", [6144, 8192])
+@pytest.mark.parametrize("n", [5250, 6144, 8192])
 def test_lookahead_driver_solve_and_pivots(prov, n):
-    """Default knobs take the look-ahead driver at these sizes (threshold 5120).  Solution bounds, run-to-run
+    """Default knobs take the look-ahead driver at these sizes (threshold 5120; 5250 = 82 base panels + 2 columns: ragged
+    last panel, trailing blocks that are no multiples of the dgemm tiles).  Solution bounds, run-to-run
     determinism, and the pivot vector against the single-stream recursive driver and the per-column panels."""
     ha, A, b = _system(prov, n, 31 + n, dominant=True)
     hb = prov.upload(b)
