@@ -156,6 +156,7 @@ struct Context {
     hipStream_t lu_side_stream = nullptr;  // update stream of the look-ahead LU (low priority), created on first use
     std::vector<hipEvent_t> lu_events;     // its event pool
     bool lu_conservative = false;
+    bool subst_chain_failed = false;  // the one-launch substitution timed out once: keep the launch-per-block form
     bool one_xcd_ok = true;  // LU panels may place their blocks on one XCD (cleared when such a panel timed out once)
     bool lu_used_one_xcd = false;
     // 64 or 32 (rmhip_set_precision).  At 32 every op output is stored as f32: kernels with a native f32-storage variant
@@ -294,6 +295,7 @@ int launch_stochastic_evolution(Context* c, uint64_t state, const double* in, do
 // LU / solve (lu.hip)
 // internal status of lu_factor_device: the matrix is clobbered, refactor a fresh copy (c->lu_conservative is now set)
 static constexpr int RMHIP_LU_RETRY = -77;
+static constexpr int RMHIP_SUBST_RETRY = -78;  // internal status of substitute_few_rhs: the chain kernel timed out, gather the right-hand side again
 int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda, int* perm_dev,
                      int* info_host, std::vector<int>* ipiv_host = nullptr);
 int lu_swap_rows_device(Context* c, double* A, size_t lda, size_t ncols, const std::vector<int>& ipiv);

@@ -1740,7 +1740,254 @@ static int launch_rhs_update(Context* c, const double* T, size_t ldt, size_t m, 
     return launch_check(c);
 }
 
+
+// ---- the whole substitution of a few right-hand sides as ONE launch per direction ------------------------------------------
+// 128-row block i is one workgroup.  It streams the tiles T[block i, block j] of the blocks solved before it (their values
+// are prefetched into registers while it waits for x_j's flag), subtracts T_ij x_j from its right-hand side, solves its
+// diagonal block from LDS (staged at kernel start, long before it is needed) and publishes x_i + a flag.  Workgroups only
+// wait for LOWER blockIdx values, and workgroups are dispatched in blockIdx order, so the chain cannot deadlock whatever
+// is co-resident; spins are bounded all the same and a timeout raises *err (the caller then repeats the solve with the
+// launch-per-block form).  The chain step is flag + last tile + diagonal solve + publish, ~9 us, against ~22-31 us for the
+// pair of launches per block (k_trsm_fused stages its triangle after the launch, on the critical path).
+// MODE 0: forward, unit lower (blocks ascend); MODE 2: backward, upper with diagonal (logical block = nblk-1-blockIdx.x).
+static constexpr int SC_THREADS = 512;
+template <int MODE, int NRHS>
+__global__ void __launch_bounds__(SC_THREADS) k_subst_chain(const double* __restrict__ LU, size_t lda, size_t n, double* X, size_t ldx,
+                                                     unsigned* flags, int* err) {
+    extern __shared__ double sc_lds[];
+    constexpr int SW = TRSM_W + 1;
+    double* Ts = sc_lds;                       // [128][129] triangle of the diagonal block
+    double* xs = Ts + TRSM_W * SW;             // [NRHS][128] x_j of the tile in flight, later this block's right-hand side
+    double* part = xs + NRHS * TRSM_W;         // [3][NRHS][128] partial sums of the other column quarters
+    const int nblk = (int)((n + TRSM_W - 1) / TRSM_W);
+    const int ib = MODE == 0 ? (int)blockIdx.x : nblk - 1 - (int)blockIdx.x;
+    const size_t r0g = (size_t)ib * TRSM_W;
+    const int w = (int)((n - r0g) < (size_t)TRSM_W ? (n - r0g) : (size_t)TRSM_W);
+    const int t = threadIdx.x, r = t & (TRSM_W - 1), h = t >> 7;  // row of the block, column quarter of a tile (32 columns)
+    const bool row_ok = r < w;
+    // stage the needed triangle (eight loads in flight per thread, as k_trsm_fused)
+    for (int base = 0; base < TRSM_W * TRSM_W; base += 8 * SC_THREADS) {
+        double stage[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * SC_THREADS + t;
+            const int rr = idx & (TRSM_W - 1), k = idx >> 7;
+            const bool need = k < w && rr < w && (MODE == 0 ? rr > k : rr <= k);
+            stage[u] = need ? LU[r0g + rr + (r0g + k) * lda] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * SC_THREADS + t;
+            Ts[(idx >> 7) * SW + (idx & (TRSM_W - 1))] = stage[u];
+        }
+    }
+    // ---- off-diagonal tiles: blocks 0..ib-1 (forward) / nblk-1..ib+1 (backward), in the order they finish
+    double acc[NRHS];
+#pragma unroll
+    for (int q = 0; q < NRHS; ++q) acc[q] = 0.0;
+    const int ntiles = MODE == 0 ? ib : nblk - 1 - ib;
+    double tv[32];  // this thread's 32 values of the tile in flight: row r, columns 32h .. 32h+31
+    auto tile_block = [&](int tix) { return MODE == 0 ? tix : nblk - 1 - tix; };
+    auto load_tile = [&](int jb) {
+        const size_t c0 = (size_t)jb * TRSM_W + 32 * h;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) tv[u] = (row_ok && c0 + u < n) ? LU[r0g + r + (c0 + u) * lda] : 0.0;
+    };
+    if (ntiles > 0) load_tile(tile_block(0));
+    for (int tix = 0; tix < ntiles; ++tix) {
+        const int jb = tile_block(tix);
+        // wait for x_jb (one lane polls, the block follows through the barrier)
+        if (t == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(flags + jb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                if (++spins > PK_SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();  // also: every thread is done with the previous tile's xs
+        if (t < TRSM_W) {
+#pragma unroll
+            for (int q = 0; q < NRHS; ++q) {
+                const size_t g = (size_t)jb * TRSM_W + t;
+                // the flag store follows the x stores in program order behind a fence; read x past the caches
+                xs[q * TRSM_W + t] = g < n ? __hip_atomic_load(X + g + (size_t)q * ldx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            }
+        }
+        __syncthreads();
+        double cur[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) cur[u] = tv[u];
+        if (tix + 1 < ntiles) load_tile(tile_block(tix + 1));  // next tile's values travel while this one is applied
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+#pragma unroll
+            for (int q = 0; q < NRHS; ++q) acc[q] += cur[u] * xs[q * TRSM_W + 32 * h + u];
+        }
+    }
+    __syncthreads();
+    // ---- this block's right-hand side: b - (both column halves), into xs
+    if (h > 0) {
+#pragma unroll
+        for (int q = 0; q < NRHS; ++q) part[((h - 1) * NRHS + q) * TRSM_W + r] = acc[q];
+    }
+    __syncthreads();
+    if (h == 0) {
+#pragma unroll
+        for (int q = 0; q < NRHS; ++q) {
+            const double b = row_ok ? X[r0g + r + (size_t)q * ldx] : 0.0;
+            xs[q * TRSM_W + r] = b - (((acc[q] + part[q * TRSM_W + r]) + part[(NRHS + q) * TRSM_W + r]) + part[(2 * NRHS + q) * TRSM_W + r]);
+        }
+    }
+    __syncthreads();
+    // ---- diagonal solve: wave q takes right-hand side q; lane i holds rows i and 64 + i (k_trsm_fused's scheme)
+    const int lane = t & 63, wv = t >> 6;
+    if (wv < NRHS) {
+        const int i = lane;
+        const bool two = w > 64;
+        double x0 = xs[wv * TRSM_W + i], x1 = xs[wv * TRSM_W + 64 + i];
+        if (MODE == 0) {
+            const int k0end = w < 64 ? w : 64;
+#pragma unroll 1
+            for (int kb = 0; kb < k0end; kb += 4) {
+                double l0[4], l1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb + u < w ? kb + u : w - 1;
+                    l0[u] = Ts[k * SW + i];
+                    l1[u] = two ? Ts[k * SW + 64 + i] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb + u;
+                    if (k < k0end) {
+                        const double xk = bcast_lane(x0, k);
+                        const double u0 = x0 - l0[u] * xk;
+                        x0 = i > k ? u0 : x0;
+                        x1 = two ? x1 - l1[u] * xk : x1;
+                    }
+                }
+            }
+#pragma unroll 1
+            for (int kb = 64; kb < w; kb += 4) {
+                double l1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb + u < w ? kb + u : w - 1;
+                    l1[u] = Ts[k * SW + 64 + i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb + u;
+                    if (k < w) {
+                        const double xk = bcast_lane(x1, k - 64);
+                        const double u1 = x1 - l1[u] * xk;
+                        x1 = 64 + i > k ? u1 : x1;
+                    }
+                }
+            }
+        } else {
+            const double d0 = i < w ? Ts[i * SW + i] : 1.0, d1 = 64 + i < w ? Ts[(64 + i) * SW + 64 + i] : 1.0;
+#pragma unroll 1
+            for (int kb = w - 1; kb >= 64; kb -= 4) {
+                double u0[4], u1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb - u >= 64 ? kb - u : 64;
+                    u0[u] = Ts[k * SW + i];
+                    u1[u] = Ts[k * SW + 64 + i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb - u;
+                    if (k >= 64) {
+                        const double xk = bcast_lane(x1 / d1, k - 64);
+                        const double v1 = x1 - u1[u] * xk;
+                        x1 = (64 + i == k) ? xk : (64 + i < k ? v1 : x1);
+                        x0 -= u0[u] * xk;
+                    }
+                }
+            }
+#pragma unroll 1
+            for (int kb = (w < 64 ? w : 64) - 1; kb >= 0; kb -= 4) {
+                double u0[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb - u >= 0 ? kb - u : 0;
+                    u0[u] = Ts[k * SW + i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb - u;
+                    if (k >= 0) {
+                        const double xk = bcast_lane(x0 / d0, k);
+                        const double v0 = x0 - u0[u] * xk;
+                        x0 = (i == k) ? xk : (i < k ? v0 : x0);
+                    }
+                }
+            }
+        }
+        if (i < w) __hip_atomic_store(X + r0g + i + (size_t)wv * ldx, x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (64 + i < w) __hip_atomic_store(X + r0g + 64 + i + (size_t)wv * ldx, x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(flags + ib, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int MODE>
+static int launch_subst_chain(Context* c, const double* LU, size_t lda, size_t n, double* X, size_t ldx, size_t nrhs, unsigned* flags,
+                              int* err) {
+    const unsigned nblk = (unsigned)((n + TRSM_W - 1) / TRSM_W);
+    const size_t lds = ((size_t)TRSM_W * (TRSM_W + 1) + 4 * nrhs * TRSM_W) * sizeof(double);
+    switch (nrhs) {
+        case 1:
+            c->ensure_max_lds((const void*)k_subst_chain<MODE, 1>, 160 * 1024 - 256);
+            hipLaunchKernelGGL((k_subst_chain<MODE, 1>), dim3(nblk), dim3(SC_THREADS), lds, c->stream, LU, lda, n, X, ldx, flags, err);
+            break;
+        case 2:
+            c->ensure_max_lds((const void*)k_subst_chain<MODE, 2>, 160 * 1024 - 256);
+            hipLaunchKernelGGL((k_subst_chain<MODE, 2>), dim3(nblk), dim3(SC_THREADS), lds, c->stream, LU, lda, n, X, ldx, flags, err);
+            break;
+        case 3:
+            c->ensure_max_lds((const void*)k_subst_chain<MODE, 3>, 160 * 1024 - 256);
+            hipLaunchKernelGGL((k_subst_chain<MODE, 3>), dim3(nblk), dim3(SC_THREADS), lds, c->stream, LU, lda, n, X, ldx, flags, err);
+            break;
+        default:
+            c->ensure_max_lds((const void*)k_subst_chain<MODE, 4>, 160 * 1024 - 256);
+            hipLaunchKernelGGL((k_subst_chain<MODE, 4>), dim3(nblk), dim3(SC_THREADS), lds, c->stream, LU, lda, n, X, ldx, flags, err);
+            break;
+    }
+    return launch_check(c);
+}
+
 static int substitute_few_rhs(Context* c, const double* LU, size_t n, size_t lda, double* X, size_t ldx, size_t nrhs) {
+    // One launch per direction (k_subst_chain) when the system is big enough for the launches to matter and the chain's
+    // workgroups (one per 128 rows) fit the chip; RMHIP_LU_SUBST=pair keeps the launch-per-block form.
+    const char* subst_env = std::getenv("RMHIP_LU_SUBST");  // read per call (tests switch it)
+    const int chain = (subst_env && subst_env[0] == 'p') ? 0 : 1;
+    const size_t nblk_chain = (n + TRSM_W - 1) / TRSM_W;
+    if (chain && nblk_chain >= 4 && nblk_chain <= (size_t)c->num_cus && !c->subst_chain_failed) {
+        std::shared_ptr<Allocation> ctl;  // flags of both directions + the error word, pooled
+        RMHIP_TRY(c->alloc_device(nblk_chain + 2, &ctl));
+        unsigned* flags = (unsigned*)ctl->ptr;
+        int* err = (int*)(flags + 2 * nblk_chain);
+        RMHIP_HIP_CHECK(hipMemsetAsync(flags, 0, (2 * nblk_chain + 1) * sizeof(unsigned), c->stream));
+        for (size_t q0 = 0; q0 < nrhs; q0 += 4) {
+            const size_t nq = nrhs - q0 < 4 ? nrhs - q0 : 4;
+            if (q0) RMHIP_HIP_CHECK(hipMemsetAsync(flags, 0, 2 * nblk_chain * sizeof(unsigned), c->stream));
+            RMHIP_TRY(launch_subst_chain<0>(c, LU, lda, n, X + q0 * ldx, ldx, nq, flags, err));
+            RMHIP_TRY(launch_subst_chain<2>(c, LU, lda, n, X + q0 * ldx, ldx, nq, flags + nblk_chain, err));
+        }
+        int h_err = 0;
+        RMHIP_HIP_CHECK(hipMemcpyAsync(&h_err, err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (!h_err) return RMHIP_OK;
+        c->subst_chain_failed = true;  // a spin timed out: X is clobbered, the caller gathers the right-hand side again
+        return RMHIP_SUBST_RETRY;
+    }
     // forward: unit lower
     for (size_t ib = 0; ib < n; ib += TRSM_W) {
         const size_t w = (n - ib) < (size_t)TRSM_W ? (n - ib) : (size_t)TRSM_W;
@@ -1766,7 +2013,16 @@ int lu_solve_device(Context* c, const double* LU, size_t n, size_t lda, const in
     hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n + 255) / 256), (unsigned)nrhs), dim3(256), 0, c->stream, B, ldb,
                        perm_dev, n, nrhs, X, ldx);
     RMHIP_TRY(launch_check(c));
-    if (nrhs <= (size_t)RU_MAX_RHS && !(lu_skip_mask() & 16)) return substitute_few_rhs(c, LU, n, lda, X, ldx, nrhs);
+    if (nrhs <= (size_t)RU_MAX_RHS && !(lu_skip_mask() & 16)) {
+        int rc = substitute_few_rhs(c, LU, n, lda, X, ldx, nrhs);
+        if (rc == RMHIP_SUBST_RETRY) {  // the chain kernel timed out (never seen; context flag now selects the pair form)
+            hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n + 255) / 256), (unsigned)nrhs), dim3(256), 0, c->stream, B, ldb,
+                               perm_dev, n, nrhs, X, ldx);
+            RMHIP_TRY(launch_check(c));
+            rc = substitute_few_rhs(c, LU, n, lda, X, ldx, nrhs);
+        }
+        return rc;
+    }
     RMHIP_TRY(trsm_lower_rec(c, LU, lda, n, X, ldx, nrhs));
     return trsm_upper_rec(c, LU, lda, n, X, ldx, nrhs);
 }

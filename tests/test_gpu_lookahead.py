@@ -157,3 +157,24 @@ def test_monte_carlo_price_full_size(prov, case):
         assert state == case["final_state"], f.__name__
         assert abs(price - want) <= 1e-10 * want, f"{f.__name__}: {price!r} vs {want!r}"
         assert math.isfinite(price)
+
+
+@pytest.mark.parametrize("n,nrhs", [(1024, 1), (1000, 3), (1536, 4), (1111, 5), (2048, 8)])
+def test_substitution_chain_kernel_vs_launch_per_block(prov, oracle, n, nrhs):
+    """x = A\\B with few right-hand sides runs its forward and backward substitution as one launch per direction
+    (k_subst_chain: one workgroup per 128 rows, flags between them).  Same answer as the launch-per-block form
+    (RMHIP_LU_SUBST=pair) up to the summation order, ragged last block and 4 + 1 / 4 + 4 column splits included."""
+    rng = np.random.default_rng(900 + n + nrhs)
+    A = rng.uniform(-1.0, 1.0, (n, n)) + n * np.eye(n)
+    B = rng.uniform(-1.0, 1.0, (n, nrhs))
+    ha, hb = prov.upload(A), prov.upload(B)
+    x_chain = prov.download_matrix(prov.mldivide(ha, hb))
+    with env(RMHIP_LU_SUBST="pair"):
+        x_pair = prov.download_matrix(prov.mldivide(ha, hb))
+    scale = np.max(np.abs(x_pair))
+    assert np.max(np.abs(x_chain - x_pair)) <= 1e-13 * scale
+    res = np.linalg.norm(A @ x_chain - B) / (np.linalg.norm(A) * np.linalg.norm(x_chain))
+    assert res <= 1e-14 * n
+    assert np.array_equal(x_chain, prov.download_matrix(prov.mldivide(ha, hb)))  # run-to-run deterministic
+    prov.free(ha)
+    prov.free(hb)
