@@ -1890,6 +1890,10 @@ __global__ void __launch_bounds__(SC_THREADS) k_subst_chain(const double* __rest
             }
         } else {
             const double d0 = i < w ? Ts[i * SW + i] : 1.0, d1 = 64 + i < w ? Ts[(64 + i) * SW + 64 + i] : 1.0;
+            // x * (1/d) instead of x / d on the dependency chain when every reciprocal is finite and normal (as k_trsm_fused)
+            const double rc0 = 1.0 / d0, rc1 = 1.0 / d1;
+            const bool recip_ok = !__any(!(fabs(rc0) < 1.0e300 && fabs(rc0) > 1.0e-300 && fabs(rc1) < 1.0e300 && fabs(rc1) > 1.0e-300));
+            auto scale = [=](double x, double d, double rc) { return recip_ok ? x * rc : x / d; };
 #pragma unroll 1
             for (int kb = w - 1; kb >= 64; kb -= 4) {
                 double u0[4], u1[4];
@@ -1903,7 +1907,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_subst_chain(const double* __rest
                 for (int u = 0; u < 4; ++u) {
                     const int k = kb - u;
                     if (k >= 64) {
-                        const double xk = bcast_lane(x1 / d1, k - 64);
+                        const double xk = bcast_lane(scale(x1, d1, rc1), k - 64);
                         const double v1 = x1 - u1[u] * xk;
                         x1 = (64 + i == k) ? xk : (64 + i < k ? v1 : x1);
                         x0 -= u0[u] * xk;
@@ -1922,7 +1926,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_subst_chain(const double* __rest
                 for (int u = 0; u < 4; ++u) {
                     const int k = kb - u;
                     if (k >= 0) {
-                        const double xk = bcast_lane(x0 / d0, k);
+                        const double xk = bcast_lane(scale(x0, d0, rc0), k);
                         const double v0 = x0 - u0[u] * xk;
                         x0 = (i == k) ? xk : (i < k ? v0 : x0);
                     }
