@@ -1342,6 +1342,8 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     // pad there as well (two dgemm blocks per CU) starves the main stream: a retiring block's slot goes to the next block
     // of the same kernel, stream priority or not (138 ms).  Developer knobs: RMHIP_LU_EARLY_SIDE_PAD (bytes),
     // RMHIP_LU_EARLY_PANEL_PAD_KB.
+    // (Also tried: the interchanges of the finished left columns on a third low-priority stream - they only depend on their panel and
+    // on the previous update - instead of behind the update: 109.25 vs 108.6 ms, 8192: 40.4 vs 39.7 ms.)
     // (Also tried: the first quarter / half of the trailing columns on a second update stream, so that its dgemm covers the
     // row interchange and triangular solve of the rest - 125-130 ms against 119.)
     size_t early_side_pad = side_pad;
