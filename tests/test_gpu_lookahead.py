@@ -178,3 +178,24 @@ def test_substitution_chain_kernel_vs_launch_per_block(prov, oracle, n, nrhs):
     assert np.array_equal(x_chain, prov.download_matrix(prov.mldivide(ha, hb)))  # run-to-run deterministic
     prov.free(ha)
     prov.free(hb)
+
+
+def test_substitution_chain_timeout_falls_back(built):
+    """A spin of the chain kernel that times out (never seen; forced by RMHIP_LU_TEST_SUBST_RETRY) clobbers X: the
+    right-hand side is gathered again and solved by the launch-per-block form, and the context keeps that form."""
+    from runmat_amd import HipProvider
+
+    p2 = HipProvider(0)
+    rng = np.random.default_rng(6)
+    n = 1280
+    A = rng.uniform(-1, 1, (n, n)) + n * np.eye(n)
+    B = rng.uniform(-1, 1, (n, 3))
+    ha, hb = p2.upload(A), p2.upload(B)
+    with env(RMHIP_LU_SUBST="pair"):
+        want = p2.download_matrix(p2.mldivide(ha, hb))
+    with env(RMHIP_LU_TEST_SUBST_RETRY="1"):
+        got = p2.download_matrix(p2.mldivide(ha, hb))
+    assert np.array_equal(got, want)  # the fallback IS the pair form
+    again = p2.download_matrix(p2.mldivide(ha, hb))  # the context stays on it
+    assert np.array_equal(again, want)
+    p2.close()
