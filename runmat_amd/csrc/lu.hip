@@ -1346,6 +1346,8 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     // on the previous update - instead of behind the update: 109.25 vs 108.6 ms, 8192: 40.4 vs 39.7 ms.)
     // (Also tried: the first quarter / half of the trailing columns on a second update stream, so that its dgemm covers the
     // row interchange and triangular solve of the rest - 125-130 ms against 119.)
+    // (With the eight-wave update kernel trimmed to 128 VGPRs and the panel to 256 the two do share a CU again - and the solve
+    // takes 119 ms instead of 108: a panel wave beside TWO MFMA waves per SIMD crawls.  Exclusive CUs for the panel it is.)
     size_t early_side_pad = side_pad;
     long early_panel_pad = 0;
     if (const char* v = std::getenv("RMHIP_LU_EARLY_SIDE_PAD")) early_side_pad = (size_t)std::atoll(v);
