@@ -201,8 +201,28 @@ def main() -> None:
     from runmat_amd import sharding as sh
 
     group = sh.Group.from_env()
+    comm_note = "none (single rank)"
     if world > 1:
-        group.with_native_comm(prov, transport="rccl" if backend == "nccl" else "shm")
+        # every rank tries; the ranks then agree (a min over a flag through the control plane) so that either all of them use the
+        # native communicator or all fall back to exchanging through torch.distributed - the run must not die on a comm init
+        transport = "rccl" if backend == "nccl" else "shm"
+        ok, why = 1, ""
+        try:
+            group.with_native_comm(prov, transport=transport)
+        except Exception as e:  # noqa: BLE001 - any failure means "fall back"
+            ok, why = 0, str(e)[:200]
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            comm_note = f"rmhip_comm_* ({'RCCL' if transport == 'rccl' else 'host shared memory'})"
+        else:
+            if group.native is not None:
+                try:
+                    prov.comm_destroy()
+                except Exception:  # noqa: BLE001
+                    pass
+                group.native = None
+            comm_note = "torch.distributed (native communicator unavailable" + (f": {why}" if why else " on another rank") + ")"
 
     def barrier():
         prov.synchronize()
@@ -574,6 +594,7 @@ def main() -> None:
         "vs_baseline": None, "dtype": rec["dtype"], "data": "synthetic", "config": rec["config"],
         "roofline": rec["roofline"],
     }
+    out["config"] = dict(out["config"], collectives=comm_note)
     if not args.no_also:
         # the other configs of BASELINE.json, short runs; every rank takes part (collectives inside)
         others = [w for w in ("fused", "dgemm", "mc", "mc_evolved", "image", "chain", "fused_f32", "sgemm") if w != args.workload]
