@@ -1352,6 +1352,13 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     long early_panel_pad = 0;
     if (const char* v = std::getenv("RMHIP_LU_EARLY_SIDE_PAD")) early_side_pad = (size_t)std::atoll(v);
     if (const char* v = std::getenv("RMHIP_LU_EARLY_PANEL_PAD_KB")) early_panel_pad = std::atol(v);
+    // (Tried: DEFERRED update of the far columns.  While the chain is left of column far_c every step updates only [next panel,
+    // far_c) and the columns right of it collect their panels - applied later, range by range, with one interchange pass
+    // (F may see later interchanges early: Pi (F - L U) = Pi F - (Pi L) U), one triangular solve and one rank-(b - a) update,
+    // scheduled by a cost model into the time the update stream has to spare and flushed before the chain gets there.
+    // Bit-identical pivots, correct factors - and slower at every far_c: 113.3 ms at 10240, 111.4 at 12288, 109.6 at 13312
+    // against 108.5 without.  The update stream's idle time in the second half is not free: whatever runs there slows the
+    // panel chain - exchange latency under load, CUs that must drain before a panel or a triangular solve starts.)
     for (size_t j = 0; j < kmin && rc == RMHIP_OK;) {
         const size_t nbj = width_at(j);
         const bool early = early_rows && kmin - j > early_rows;
