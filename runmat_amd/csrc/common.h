@@ -150,6 +150,10 @@ struct Context {
     // LU look-ahead (lu.hip getrf_blocked): extra dynamic LDS requested by launch_dgemm so that only ONE
     // dgemm block fits per CU and latency-bound kernels of the other stream find room beside it
     size_t gemm_lds_pad = 0;
+    // look-ahead LU, late phase: the update stream's dgemm runs as a persistent kernel that stays off the panels' XCD
+    unsigned* gemm_tile_counters = nullptr;  // device, zeroed by the driver; one per launch
+    size_t gemm_counter_next = 0, gemm_counter_cap = 0;
+    const int* gemm_avoid_xcc = nullptr;     // device word written by the panel kernel (-1: none)
     bool in_lookahead = false;  // inside the LU's look-ahead driver: main-stream dgemm blocks must fit beside the update stream's
     // set after a persistent-panel factorisation found its workgroups not co-resident (device shared with
     // another context): from then on LU uses the one-launch-per-column panels on a single stream

@@ -68,6 +68,9 @@ struct GemmArgs {
     // partial product (alpha = 1, beta = 0) to C + y*c_split_stride; k_reduce_splits adds them in order.
     unsigned k_chunk;
     unsigned long long c_split_stride;
+    // k_dgemm_w8p (persistent form): tile counter (zero before the launch) and the XCD to stay away from (may be null / -1)
+    unsigned* tile_counter;
+    const int* avoid_xcc;
 };
 
 // MatmulEpilogue on one output element, order of crates/runmat-accelerate/src/simple_provider.rs:7800-7836
@@ -429,12 +432,7 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
 // leaves room for a main-stream dgemm block beside it.  Plain operands, unguarded shapes only (m, n % 128, k % 16, even
 // leading dimensions, aligned bases); PRE as in k_dgemm.  Same k-ordered MFMA chain per element: bit-identical results.
 template <bool PRE>
-__global__ void __launch_bounds__(512) k_dgemm_w8(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* As = lds;               // [2][A_TILE]
-    double* Bs = lds + 2 * A_TILE;  // [2][B_TILE]
-    unsigned tm, tn;
-    tile_of_block(g, tm, tn);
+__device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, const unsigned tn, double* As, double* Bs) {
     const unsigned m0 = tm * BM, n0 = tn * BN;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -535,6 +533,45 @@ __global__ void __launch_bounds__(512) k_dgemm_w8(const GemmArgs g) {
     }
 }
 
+
+template <bool PRE>
+__global__ void __launch_bounds__(512) k_dgemm_w8(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    unsigned tm, tn;
+    tile_of_block(g, tm, tn);
+    w8_tile<PRE>(g, tm, tn, lds, lds + 2 * A_TILE);
+}
+
+// Persistent form for the look-ahead LU's late phase: one workgroup per CU, tiles handed out by a counter, and workgroups
+// that find themselves on the XCD the panel kernel occupies (g.avoid_xcc, written by k_lu_panel2) leave at once - the
+// update then runs on the other seven XCDs and the panel's XCD keeps free CUs and a quiet L2 (lu.hip, getrf_blocked).
+// The plain beta path (118 VGPRs): two waves of it fit beside a 270-register panel wave on a SIMD, so a placeholder
+// workgroup can always be scheduled - and leave - on a CU the panel holds.
+__global__ void __launch_bounds__(512) k_dgemm_w8p(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ unsigned s_tile;
+    if (g.avoid_xcc) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if ((int)(xcc & 0xf) == *g.avoid_xcc) return;
+    }
+    const unsigned nwg = g.tiles_m * g.tiles_n;
+    for (;;) {
+        if (threadIdx.x == 0) s_tile = atomicAdd(g.tile_counter, 1u);
+        __syncthreads();
+        const unsigned wg = s_tile;
+        if (wg >= nwg) break;
+        // grouped ordering as tile_of_block, without the per-XCD id remap (tiles are not tied to an XCD here)
+        const unsigned per_group = GROUP_M * g.tiles_n;
+        const unsigned group = wg / per_group;
+        const unsigned first_m = group * GROUP_M;
+        const unsigned gsz = (g.tiles_m - first_m) < GROUP_M ? (g.tiles_m - first_m) : GROUP_M;
+        const unsigned in_group = wg - group * per_group;
+        w8_tile<false>(g, first_m + in_group % gsz, in_group / gsz, lds, lds + 2 * A_TILE);
+        __syncthreads();  // LDS and s_tile are reused
+    }
+}
+
 static int g_rowmap = -1;
 
 static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double alpha, const double* A, size_t lda,
@@ -624,6 +661,8 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
     unsigned splits = 1;
     g.k_chunk = (unsigned)k;
     g.c_split_stride = 0;
+    g.tile_counter = nullptr;
+    g.avoid_xcc = nullptr;
     std::shared_ptr<Allocation> partials;
     if (!ep && blocks * 4 <= (unsigned)c->num_cus && k >= 8192) {
         const size_t want = (2 * (size_t)c->num_cus + blocks - 1) / blocks;
@@ -682,6 +721,18 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
     if (w8_mode < 0) {
         const char* v = std::getenv("RMHIP_GEMM_W8");
         w8_mode = v ? std::atoi(v) : 1;
+    }
+    if (fast_k && splits == 1 && !ep && !ta && !tb && c->gemm_tile_counters && c->gemm_lds_pad != 0 && w8_mode != 0 &&
+        c->gemm_counter_next < c->gemm_counter_cap) {
+        // update stream of the look-ahead LU while the panels sit on one XCD: persistent eight-wave kernel that stays off it
+        g.tile_counter = c->gemm_tile_counters + c->gemm_counter_next++;
+        g.avoid_xcc = c->gemm_avoid_xcc;
+        const unsigned grid = (unsigned)c->num_cus < blocks ? (unsigned)c->num_cus : blocks;
+        c->ensure_max_lds((const void*)k_dgemm_w8p, kMaxLds);
+        hipLaunchKernelGGL(k_dgemm_w8p, dim3(grid), dim3(512), lds_bytes, c->stream, g);
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+        return RMHIP_OK;
     }
     if (fast_k && splits == 1 && !ep && !ta && !tb &&
         ((w8_mode == 1 && (c->gemm_lds_pad != 0 || (!c->in_lookahead && k <= 2048))) || w8_mode == 2)) {

@@ -46,6 +46,7 @@ struct LuState {
     bool persistent;      // use k_lu_panel2 for base panels
     unsigned long long* xdbg;  // device [16] phase ticks (RMHIP_LU_PANEL_DEBUG=1) or nullptr
     long panel_pad_kb = -1;    // extra LDS a panel block asks for (-1: the default, see getrf_rec)
+    int* panel_xcc = nullptr;  // device word: the XCD of the last one-XCD panel (-1 otherwise)
 };
 
 static constexpr int MAX_PANEL_BLOCKS = 1024;  // 64 rows per block => up to 65536 rows per panel
@@ -384,6 +385,7 @@ struct P2Args {
     int* info;
     int2* plist;    // this panel's row-move list (PLIST entries)
     pk_u64* dbg;
+    int* xcc_out;   // receives the XCD the panel sits on (one-XCD placement) or -1; read by the update stream's persistent dgemm
 };
 
 // 16-byte exchange granules: one write-through (sc1) store / one L1-bypassing load; each 8-byte half is self-describing,
@@ -719,6 +721,11 @@ __global__ void __launch_bounds__(P2_THREADS) k_lu_panel2(const P2Args g) {
         s_ticks.tk = wall_clock64();
     }
     if (blockIdx.x % g.bstride) return;  // one-XCD placement: the other seven XCDs' workgroups are placeholders
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g.xcc_out) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        *g.xcc_out = g.bstride > 1 ? (int)(xcc & 0xf) : -1;
+    }
     const int t = threadIdx.x;  // row slot
     const size_t r = (size_t)g.j0 + (size_t)(blockIdx.x / g.bstride) * P2_ROWS + t;
     const bool in_rows = r < g.rows;
@@ -1154,6 +1161,7 @@ static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller =
             g.info = s.info;
             g.plist = s.plist + pid * PLIST;
             g.dbg = s.xdbg;
+            g.xcc_out = s.panel_xcc;
             // The block needs 18.5 KiB of LDS but ASKS for 82.5: it then does not fit beside an update-stream dgemm block
             // (84 KiB) and waits for a CU of its own.  Sharing a CU costs more than the wait: with the panel waves on the
             // same SIMDs as a dgemm wave every column step slows down, and the column chain is the critical path
@@ -1297,6 +1305,26 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     if (const char* v = std::getenv("RMHIP_LU_LA_TRSM")) c->trsm_base = std::atoi(v) == 64 ? 64 : 128;
     c->in_lookahead = true;
     int rc = RMHIP_OK;
+    // Late phase (the next panel fits one XCD, getrf_rec places it there): the update stream's dgemm runs as a persistent
+    // kernel whose workgroups leave the panel's XCD at once (k_dgemm_w8p), and the panel blocks drop their LDS pad so that
+    // such a placeholder can always be scheduled beside them.  The panel chain is the critical path there and everything
+    // the update stream does disturbs it (without ANY update work in that phase the solve takes 95.7 instead of 108.4 ms):
+    // this keeps the panel's CUs free (no drain before a panel or a 132 KiB triangular solve starts) and its L2 quiet.
+    // RMHIP_LU_LATE_XCD=0 disables.
+    static const int late_xcd_on = (std::getenv("RMHIP_LU_LATE_XCD") && std::getenv("RMHIP_LU_LATE_XCD")[0] == '0') ? 0 : 1;
+    constexpr size_t kCounters = 2048;
+    std::shared_ptr<Allocation> late_ctl;
+    unsigned* late_counters = nullptr;
+    if (late_xcd_on && c->one_xcd_ok) {
+        RMHIP_TRY(c->alloc_device(kCounters / 2 + 8, &late_ctl));
+        late_counters = (unsigned*)late_ctl->ptr;
+        s.panel_xcc = (int*)(late_counters + kCounters);
+        RMHIP_HIP_CHECK(hipMemsetAsync(late_counters, 0, kCounters * sizeof(unsigned), main_stream));
+        RMHIP_HIP_CHECK(hipMemsetAsync(s.panel_xcc, 0xff, sizeof(int), main_stream));  // -1: no XCD to avoid yet
+        c->gemm_counter_next = 0;
+        c->gemm_counter_cap = kCounters;
+        c->gemm_avoid_xcc = s.panel_xcc;
+    }
     hipEvent_t side_done = nullptr;  // S_{j-1} finished
     {
         hipEvent_t e0 = new_event();  // side starts after whatever main already has queued (the copy of A)
@@ -1362,7 +1390,10 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     for (size_t j = 0; j < kmin && rc == RMHIP_OK;) {
         const size_t nbj = width_at(j);
         const bool early = early_rows && kmin - j > early_rows;
-        s.panel_pad_kb = early ? early_panel_pad : -1;
+        // this panel on one XCD?  (the condition getrf_rec applies to its first base panel)
+        const bool late_xcd = late_counters && (s.rows - j + P2_ROWS - 1) / P2_ROWS <= (size_t)c->num_cus / 8;
+        static const long late_panel_pad = std::getenv("RMHIP_LU_LATE_PANEL_PAD_KB") ? std::atol(std::getenv("RMHIP_LU_LATE_PANEL_PAD_KB")) : 0;
+        s.panel_pad_kb = late_xcd ? late_panel_pad : (early ? early_panel_pad : -1);
         const size_t w = (kmin - j) < nbj ? (kmin - j) : nbj;
         rc = getrf_rec(s, j, w);  // P_j on main
         if (rc != RMHIP_OK) break;
@@ -1380,7 +1411,11 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         (void)hipStreamWaitEvent(side, panel_done, 0);
         {
             StreamScope scope(c, side, early ? early_side_pad : side_pad);
+            // S_j overlaps panel j+1: persistent, XCD-avoiding dgemm if that panel sits on one XCD
+            const bool next_late = late_counters && next < s.rows && (s.rows - next + P2_ROWS - 1) / P2_ROWS <= (size_t)c->num_cus / 8;
+            c->gemm_tile_counters = next_late ? late_counters : nullptr;
             rc = update_columns(s, j, w, next + la_w, s.cols);      // S_j
+            c->gemm_tile_counters = nullptr;
             if (rc == RMHIP_OK && j > 0) rc = laswp(s, 0, j, j, j + w);  // finished left columns
         }
         side_done = new_event();
@@ -1391,6 +1426,10 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     if (side_done) (void)hipStreamWaitEvent(main_stream, side_done, 0);
     (void)hipStreamSynchronize(side);
     (void)hipStreamSynchronize(main_stream);
+    c->gemm_tile_counters = nullptr;
+    c->gemm_avoid_xcc = nullptr;
+    c->gemm_counter_cap = 0;
+    s.panel_xcc = nullptr;
     c->in_lookahead = false;
     c->trsm_base = saved_trsm_base;
     return rc;
