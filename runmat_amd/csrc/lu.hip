@@ -1311,7 +1311,7 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     // the update stream does disturbs it (without ANY update work in that phase the solve takes 95.7 instead of 108.4 ms):
     // this keeps the panel's CUs free (no drain before a panel or a 132 KiB triangular solve starts) and its L2 quiet.
     // RMHIP_LU_LATE_XCD=0 disables.
-    static const int late_xcd_on = (std::getenv("RMHIP_LU_LATE_XCD") && std::getenv("RMHIP_LU_LATE_XCD")[0] == '0') ? 0 : 1;
+    static const int late_xcd_on = std::getenv("RMHIP_LU_LATE_XCD") ? std::atoi(std::getenv("RMHIP_LU_LATE_XCD")) : 1;  // 2: persistent dgemm in every phase (A/B)
     constexpr size_t kCounters = 2048;
     std::shared_ptr<Allocation> late_ctl;
     unsigned* late_counters = nullptr;
@@ -1413,7 +1413,7 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
             StreamScope scope(c, side, early ? early_side_pad : side_pad);
             // S_j overlaps panel j+1: persistent, XCD-avoiding dgemm if that panel sits on one XCD
             const bool next_late = late_counters && next < s.rows && (s.rows - next + P2_ROWS - 1) / P2_ROWS <= (size_t)c->num_cus / 8;
-            c->gemm_tile_counters = next_late ? late_counters : nullptr;
+            c->gemm_tile_counters = (next_late || (late_xcd_on == 2 && late_counters)) ? late_counters : nullptr;
             rc = update_columns(s, j, w, next + la_w, s.cols);      // S_j
             c->gemm_tile_counters = nullptr;
             if (rc == RMHIP_OK && j > 0) rc = laswp(s, 0, j, j, j + w);  // finished left columns

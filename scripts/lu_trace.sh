@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python $ROOT/scripts/lu_trace.py $N 4 > "$OUT/plain.log" 2>&1
 RMHIP_LU_PANEL_DEBUG=1 python $ROOT/scripts/lu_trace.py $N 2 > "$OUT/panel_debug.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python $ROOT/scripts/lu_trace.py $N 3 > "$OUT/trace.log" 2> "$OUT/trace.err"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python $ROOT/scripts/lu_trace.py $N 3 > "$OUT/trace.log" 2> "$OUT/trace.err"
 python $ROOT/scripts/lu_timeline.py "$OUT" > "$OUT/timeline.txt" 2>&1
 cat "$OUT/plain.log" "$OUT/panel_debug.log" "$OUT/trace.log"
 cat "$OUT/timeline.txt" | head -80
