@@ -811,11 +811,30 @@ __global__ void __launch_bounds__(PLIST) k_build_plist(int j0, int c1, const int
 // (all loads), a barrier, then the stores.  Replaces w sequential dependent swaps per column by
 // w/BASE_W phases with PLIST independent accesses each.
 static constexpr int LASWP_COLS = 8;  // columns per block
+// counter != nullptr: the column groups are handed out by a counter and workgroups on XCD *avoid_xcc leave at once (the
+// update stream in the LU's late phase, see k_dgemm_w8p) - the grid still has one workgroup per group.
 __global__ void __launch_bounds__(2 * PLIST) k_laswp_lists(double* __restrict__ A, size_t lda, size_t c0, size_t c1,
-                                                           const int2* __restrict__ lists, int p0, int p1) {
+                                                           const int2* __restrict__ lists, int p0, int p1, unsigned* counter,
+                                                           const int* avoid_xcc) {
+    __shared__ unsigned s_group;
     const int i = threadIdx.x & (PLIST - 1);
     const int half = threadIdx.x / PLIST;  // 0 or 1
-    const size_t cbase = c0 + (size_t)blockIdx.x * LASWP_COLS;
+    unsigned group = blockIdx.x;
+    if (counter) {
+        if (avoid_xcc) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            if ((int)(xcc & 0xf) == *avoid_xcc) return;
+        }
+    }
+  for (;;) {
+    if (counter) {
+        if (threadIdx.x == 0) s_group = atomicAdd(counter, 1u);
+        __syncthreads();
+        group = s_group;
+        if (group >= gridDim.x) return;
+    }
+    const size_t cbase = c0 + (size_t)group * LASWP_COLS;
     for (int p = p0; p < p1; ++p) {
         const int2 e = lists[(size_t)p * PLIST + i];
         double vals[LASWP_COLS / 2];
@@ -832,6 +851,8 @@ __global__ void __launch_bounds__(2 * PLIST) k_laswp_lists(double* __restrict__ 
         }
         __syncthreads();
     }
+    if (!counter) return;
+  }
 }
 
 // Small triangular solves (w <= TRSM_W = 128) in ONE launch: the triangle is staged in LDS as
@@ -858,8 +879,16 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
 // TRSM_THREADS: 256 (one wave per SIMD: the substitution is VALU-issue bound) for few columns, 512 for many.
 template <int MODE, int TRSM_NC, int TRSM_THREADS>
 __global__ void __launch_bounds__(TRSM_THREADS) k_trsm_fused(const double* __restrict__ T, size_t ldt, int w,
-                                                             double* __restrict__ B, size_t ldb, size_t ncols) {
+                                                             double* __restrict__ B, size_t ldb, size_t ncols, unsigned* counter,
+                                                             const int* avoid_xcc) {
     extern __shared__ double Ts[];  // [w][sw]
+    // counter != nullptr (update stream of the LU's late phase, see k_dgemm_w8p): column groups are handed out by a counter, wave
+    // by wave, and workgroups on XCD *avoid_xcc leave before they stage anything
+    if (counter && avoid_xcc) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if ((int)(xcc & 0xf) == *avoid_xcc) return;
+    }
     const int wr = w > 64 ? TRSM_W : 64;  // staged rows per column (64-wide solves keep a 33 KiB footprint)
     const int sw = wr + 1;                // LDS row stride (doubles)
     // stage the needed triangle: eight independent loads in flight per thread before the first LDS write
@@ -896,7 +925,16 @@ __global__ void __launch_bounds__(TRSM_THREADS) k_trsm_fused(const double* __res
     const double r0 = 1.0 / d0, r1 = 1.0 / d1;
     const bool recip_ok = MODE != 0 && !__any(!(fabs(r0) < 1.0e300 && fabs(r0) > 1.0e-300 && fabs(r1) < 1.0e300 && fabs(r1) > 1.0e-300));
     auto scale = [=](double x, double d, double r) { return recip_ok ? x * r : x / d; };
-    for (size_t c0 = wave * TRSM_NC; c0 < ncols; c0 += nwaves * TRSM_NC) {
+    for (size_t it = 0;; ++it) {
+        size_t c0;
+        if (counter) {
+            unsigned ch = 0;
+            if (i == 0) ch = atomicAdd(counter, 1u);
+            c0 = (size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)ch) * TRSM_NC;
+        } else {
+            c0 = (wave + it * nwaves) * TRSM_NC;
+        }
+        if (c0 >= ncols) break;
         double x0[TRSM_NC], x1[TRSM_NC];
 #pragma unroll
         for (int j = 0; j < TRSM_NC; ++j) {
@@ -1019,8 +1057,11 @@ static int launch_trsm_fused_nc(Context* c, const double* T, size_t ldt, size_t 
     const size_t cap = (size_t)c->num_cus * (w <= 64 ? 2 : 1);
     if (want < 1) want = 1;
     const unsigned grid = (unsigned)(want < cap ? want : cap);
+    // (counter-driven column groups + leaving the panels' XCD, as k_laswp_lists does in the LU's late phase, measured WORSE for
+    // this kernel: 104.7 vs 103.5 ms at n = 16384 - the kernel arguments stay, the driver passes none)
+    unsigned* counter = nullptr;
     hipLaunchKernelGGL((k_trsm_fused<MODE, NC, TRSM_THREADS>), dim3(grid), dim3(TRSM_THREADS), lds_bytes, c->stream, T, ldt, (int)w, B, ldb,
-                       nc);
+                       nc, counter, (const int*)nullptr);
     return launch_check(c);
 }
 template <int MODE>
@@ -1111,8 +1152,11 @@ static int laswp(LuState& s, size_t c0, size_t c1, size_t k0, size_t k1) {
     }
     if (p0 < 0 || (lu_skip_mask() & 8)) return RMHIP_OK;
     const size_t ncols = c1 - c0;
+    Context* c = s.c;
+    unsigned* counter = nullptr;
+    if (c->gemm_tile_counters && c->gemm_counter_next < c->gemm_counter_cap) counter = c->gemm_tile_counters + c->gemm_counter_next++;
     hipLaunchKernelGGL(k_laswp_lists, dim3((unsigned)((ncols + LASWP_COLS - 1) / LASWP_COLS)), dim3(2 * PLIST), 0,
-                       s.c->stream, s.A, s.lda, c0, c1, s.plist, p0, p1);
+                       s.c->stream, s.A, s.lda, c0, c1, s.plist, p0, p1, counter, counter ? c->gemm_avoid_xcc : nullptr);
     return launch_check(s.c);
 }
 
@@ -1312,7 +1356,7 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     // this keeps the panel's CUs free (no drain before a panel or a 132 KiB triangular solve starts) and its L2 quiet.
     // RMHIP_LU_LATE_XCD=0 disables.
     static const int late_xcd_on = std::getenv("RMHIP_LU_LATE_XCD") ? std::atoi(std::getenv("RMHIP_LU_LATE_XCD")) : 1;  // 2: persistent dgemm in every phase (A/B)
-    constexpr size_t kCounters = 2048;
+    constexpr size_t kCounters = 4096;
     std::shared_ptr<Allocation> late_ctl;
     unsigned* late_counters = nullptr;
     if (late_xcd_on && c->one_xcd_ok) {
@@ -1415,8 +1459,8 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
             const bool next_late = late_counters && next < s.rows && (s.rows - next + P2_ROWS - 1) / P2_ROWS <= (size_t)c->num_cus / 8;
             c->gemm_tile_counters = (next_late || (late_xcd_on == 2 && late_counters)) ? late_counters : nullptr;
             rc = update_columns(s, j, w, next + la_w, s.cols);      // S_j
-            c->gemm_tile_counters = nullptr;
             if (rc == RMHIP_OK && j > 0) rc = laswp(s, 0, j, j, j + w);  // finished left columns
+            c->gemm_tile_counters = nullptr;
         }
         side_done = new_event();
         (void)hipEventRecord(side_done, side);
