@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(512) k_dgemm_w8(const GemmArgs g) {
 __global__ void __launch_bounds__(512) k_dgemm_w8p(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ unsigned s_tile;
-    if (g.avoid_xcc) {
+    if (g.avoid_xcc && gridDim.x >= 16) {  // (a grid that small may sit on the avoided XCD entirely: somebody has to do the work)
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         if ((int)(xcc & 0xf) == *g.avoid_xcc) return;

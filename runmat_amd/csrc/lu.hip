@@ -821,7 +821,7 @@ __global__ void __launch_bounds__(2 * PLIST) k_laswp_lists(double* __restrict__ 
     const int half = threadIdx.x / PLIST;  // 0 or 1
     unsigned group = blockIdx.x;
     if (counter) {
-        if (avoid_xcc) {
+        if (avoid_xcc && gridDim.x >= 16) {  // (a smaller grid may sit on that XCD entirely)
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             if ((int)(xcc & 0xf) == *avoid_xcc) return;
@@ -884,7 +884,7 @@ __global__ void __launch_bounds__(TRSM_THREADS) k_trsm_fused(const double* __res
     extern __shared__ double Ts[];  // [w][sw]
     // counter != nullptr (update stream of the LU's late phase, see k_dgemm_w8p): column groups are handed out by a counter, wave
     // by wave, and workgroups on XCD *avoid_xcc leave before they stage anything
-    if (counter && avoid_xcc) {
+    if (counter && avoid_xcc && gridDim.x >= 16) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         if ((int)(xcc & 0xf) == *avoid_xcc) return;
