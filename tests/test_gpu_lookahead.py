@@ -199,3 +199,29 @@ def test_substitution_chain_timeout_falls_back(built):
     again = p2.download_matrix(p2.mldivide(ha, hb))  # the context stays on it
     assert np.array_equal(again, want)
     p2.close()
+
+
+@pytest.mark.parametrize("rows,cols", [(5632, 6400), (6400, 5376)])
+def test_lookahead_driver_rectangular_lu(prov, rows, cols):
+    """`lu` of wide and tall matrices through the look-ahead driver (min(rows, cols) >= 5120): pivots identical to the single-stream
+    recursive driver, |L| <= 1, P A = L U."""
+    hg = prov.fill_uniform(500 + rows, -1.0, 1.0, (rows, cols))
+    G = prov.download_matrix(hg)
+    r = prov.lu(hg)
+    piv = prov.download(r.perm_vector).astype(np.int64)
+    hlu = prov.matmul(r.lower, r.upper)
+    LU = prov.download_matrix(hlu)
+    L = prov.download_matrix(r.lower)
+    assert sorted(piv.tolist()) == list(range(1, rows + 1))
+    assert np.max(np.abs(L)) <= 1.0
+    assert np.max(np.abs(G[piv - 1, :] - LU)) <= 1e-12 * max(rows, cols)
+    for h in (r.combined, r.lower, r.upper, r.perm_matrix, r.perm_vector, hlu):
+        prov.free(h)
+    del L, LU
+    with env(RMHIP_LU_LOOKAHEAD="0"):
+        r0 = prov.lu(hg)
+        piv0 = prov.download(r0.perm_vector).astype(np.int64)
+        for h in (r0.combined, r0.lower, r0.upper, r0.perm_matrix, r0.perm_vector):
+            prov.free(h)
+    assert np.array_equal(piv, piv0)
+    prov.free(hg)
