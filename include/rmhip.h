@@ -256,9 +256,11 @@ RMHIP_API int rmhip_diag_extract(rmhip_ctx* ctx, rmhip_buf matrix, long long off
 /* `lu` -> ProviderLuResult {combined, lower, upper, perm_matrix, perm_vector} (lib.rs:649-698);
  * pivot rule and singular cut-off of host_lu.rs:37-59.  out5 order: combined, L, U, P, pivots. */
 RMHIP_API int rmhip_lu(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf out5[5]);
-/* `mldivide`: x = A\b for square, numerically non-singular A via blocked LU; anything else
- * (rectangular, pivot <= 1e-12) returns UNSUPPORTED/SINGULAR so the caller uses the CPU SVD path
- * (mldivide.rs:223-229 `.ok()`). Scalar A => b * (1/A) (mldivide.rs:321-325). */
+/* `mldivide`: x = A\b.  Square, numerically non-singular A: blocked LU with partial pivoting.  Rectangular FULL-RANK A with a
+ * Gram pivot ratio >= 1e-11 (cond(A) up to ~3e5): the least-squares (rows > cols) / minimum-norm (rows < cols) solution the
+ * reference's SVD solve returns (mldivide.rs:380-404), through the LU of A'A or AA' and one refinement step.  Anything
+ * else (a pivot <= 1e-12, rank-deficient or ill-conditioned rectangular systems) returns SINGULAR / UNSUPPORTED so the
+ * caller uses its CPU SVD path (mldivide.rs:223-229 `.ok()`).  Scalar A => b * (1/A) (mldivide.rs:321-325). */
 RMHIP_API int rmhip_mldivide(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out);
 /* `mrdivide` (lib.rs:2484-2490): X = B / A, i.e. X * A = B.  CPU semantics crates/runmat-runtime/src/builtins/math/linalg/ops/
  * mrdivide.rs:317-341 (scalar A: B * (1/A); column counts must agree) and :379-388 (the solve is A' \ B' transposed

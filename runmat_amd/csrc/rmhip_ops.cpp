@@ -899,6 +899,88 @@ int rmhip_mrdivide(rmhip_ctx* ctx, rmhip_buf b, rmhip_buf a, rmhip_buf* out) {
     return RMHIP_OK;
 }
 
+
+// Rectangular A\b for FULL-RANK, reasonably conditioned A.  The reference answers every shape with the SVD's minimum-norm
+// least-squares solution (mldivide.rs:380-404); for full column rank (rows > cols) that is the unique least-squares
+// solution, for full row rank (rows < cols) the minimum-norm solution A' (A A')^-1 b.  Both come from the kernels already
+// here: the Gram matrix on the MFMA path (A'A or AA'), its LU with partial pivoting, and ONE step of refinement on the
+// residual (corrected semi-normal equations): x0 = G^-1 A'b, r = b - A x0, x = x0 + G^-1 A'r - error ~ eps * cond(A) once
+// cond(A)^2 * eps < 1.  Anything else stays with the caller's CPU SVD path: a pivot of G below the LU's cut-off, or a
+// pivot ratio min|u_ii| / max|u_ii| below 1e-11 (cond(A) beyond ~3e5, or rank deficient) -> RMHIP_ERR_UNSUPPORTED.
+static int lstsq_full_rank(rmhip_ctx* ctx, Context* c, const Buffer& ab, const std::vector<size_t>& as, const Buffer& bb,
+                           const std::vector<size_t>& bs, rmhip_buf* out) {
+    const size_t m = as[0], n = as[1], nrhs = bs[1];
+    if (m == 0 || n == 0 || nrhs == 0) return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: empty system");
+    const bool tall = m > n;
+    const size_t g = tall ? n : m;  // order of the Gram matrix
+    const double* A = ab.data();
+    const double* B = bb.data();
+    std::shared_ptr<Allocation> gram, work, perm_mem, t1, t2, t3;
+    RMHIP_TRY(c->alloc_device(g * g, &gram));
+    // G = A'A (tall) or A A' (wide); the transposed operand is read in place
+    if (tall) RMHIP_TRY(launch_dgemm_trans(c, true, false, n, n, m, 1.0, A, m, A, m, 0.0, gram->ptr, n));
+    else RMHIP_TRY(launch_dgemm_trans(c, false, true, m, m, n, 1.0, A, m, A, m, 0.0, gram->ptr, m));
+    const size_t ldw = lu_padded_ld(g);
+    RMHIP_TRY(c->alloc_device(ldw * g, &work));
+    RMHIP_TRY(c->alloc_device((g + 2) / 2 + 1, &perm_mem));
+    int* perm = (int*)perm_mem->ptr;
+    int info = 0;
+    RMHIP_TRY(lu_copy_and_factor(c, gram->ptr, g, g, work->ptr, ldw, perm, &info));
+    if (info > 0)
+        return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: rank-deficient rectangular system (%d pivot(s) of the Gram matrix <= 1e-12): CPU SVD path", info);
+    {
+        std::vector<double> diag(g);
+        RMHIP_HIP_CHECK(hipMemcpy2DAsync(diag.data(), sizeof(double), work->ptr, (ldw + 1) * sizeof(double), sizeof(double), g,
+                                         hipMemcpyDeviceToHost, c->stream));
+        RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        double lo = INFINITY, hi = 0.0;
+        for (double d : diag) {
+            const double v = std::fabs(d);
+            lo = v < lo ? v : lo;
+            hi = v > hi ? v : hi;
+        }
+        if (!(lo > 1e-11 * hi))
+            return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: ill-conditioned rectangular system (Gram pivot ratio %.2e): CPU SVD path", hi > 0 ? lo / hi : 0.0);
+    }
+    Buffer ob;
+    rmhip_buf oid = 0;
+    const size_t oshape[2] = {n, nrhs};
+    RMHIP_TRY(c->new_buffer(oshape, 2, &oid, &ob));
+    double* X = ob.data();
+    int rc = RMHIP_OK;
+    auto run = [&]() -> int {
+        RMHIP_TRY(c->alloc_device(g * nrhs, &t1));  // right-hand side of the Gram system
+        RMHIP_TRY(c->alloc_device(g * nrhs, &t2));  // its solution
+        RMHIP_TRY(c->alloc_device(m * nrhs, &t3));  // residual b - A x
+        const size_t blk = 256;
+        if (tall) {
+            RMHIP_TRY(launch_dgemm_trans(c, true, false, n, nrhs, m, 1.0, A, m, B, m, 0.0, t1->ptr, n));              // A'b
+            RMHIP_TRY(lu_solve_device(c, work->ptr, n, ldw, perm, t1->ptr, nrhs, n, X, n));                           // x0
+            RMHIP_HIP_CHECK(hipMemcpyAsync(t3->ptr, B, m * nrhs * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            RMHIP_TRY(launch_dgemm(c, m, nrhs, n, -1.0, A, m, X, n, 1.0, t3->ptr, m));                                // r = b - A x0
+            RMHIP_TRY(launch_dgemm_trans(c, true, false, n, nrhs, m, 1.0, A, m, t3->ptr, m, 0.0, t1->ptr, n));        // A'r
+            RMHIP_TRY(lu_solve_device(c, work->ptr, n, ldw, perm, t1->ptr, nrhs, n, t2->ptr, n));                     // dx
+            RMHIP_TRY(launch_binary_same(c, RMHIP_ADD, X, t2->ptr, X, n * nrhs));
+        } else {
+            RMHIP_TRY(lu_solve_device(c, work->ptr, m, ldw, perm, B, nrhs, m, t2->ptr, m));                           // y0
+            RMHIP_TRY(launch_dgemm_trans(c, true, false, n, nrhs, m, 1.0, A, m, t2->ptr, m, 0.0, X, n));              // x0 = A'y0
+            RMHIP_HIP_CHECK(hipMemcpyAsync(t3->ptr, B, m * nrhs * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            RMHIP_TRY(launch_dgemm(c, m, nrhs, n, -1.0, A, m, X, n, 1.0, t3->ptr, m));                                // r = b - A x0
+            RMHIP_TRY(lu_solve_device(c, work->ptr, m, ldw, perm, t3->ptr, nrhs, m, t2->ptr, m));                     // dy
+            RMHIP_TRY(launch_dgemm_trans(c, true, false, n, nrhs, m, 1.0, A, m, t2->ptr, m, 1.0, X, n));              // x += A'dy
+        }
+        (void)blk;
+        return RMHIP_OK;
+    };
+    rc = run();
+    if (rc) {
+        rmhip_free(ctx, oid);
+        return rc;
+    }
+    *out = oid;
+    return RMHIP_OK;
+}
+
 static int mldivide_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     Buffer ab, bb;
@@ -917,8 +999,7 @@ static int mldivide_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, r
         return rc;
     }
     if (as[0] != bs[0]) return fail(RMHIP_ERR_SHAPE, "mldivide: row mismatch (%zu vs %zu)", as[0], bs[0]);
-    if (as[0] != as[1])
-        return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: rectangular systems use the CPU least-squares path (mldivide.rs:380-404)");
+    if (as[0] != as[1]) return lstsq_full_rank(ctx, c, ab, as, bb, bs, out);
     const size_t n = as[0], nrhs = bs[1];
     if (n == 0) return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: empty system");
     // Factorisation workspace with a PADDED leading dimension: with lda a large power of two every

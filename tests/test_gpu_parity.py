@@ -560,7 +560,7 @@ def test_mldivide_reference_tests(prov, oracle):
     # scalar lhs: mldivide.rs:321-325
     s = prov.download_matrix(prov.mldivide(prov.upload(np.array([[4.0]])), prov.upload(np.array([[2.0, 8.0]]))))
     assert np.array_equal(s, [[0.5, 2.0]])
-    # least squares (mldivide.rs:682-696) and rank-deficient inputs belong to the CPU SVD path: soft errors
+    # rank-deficient inputs belong to the CPU SVD path: soft errors (full-rank rectangular systems: next test)
     with pytest.raises(ProviderError) as e:
         prov.mldivide(prov.upload(np.ones((3, 2))), prov.upload(np.ones((3, 1))))
     assert e.value.code == 2
@@ -570,6 +570,57 @@ def test_mldivide_reference_tests(prov, oracle):
     with pytest.raises(ProviderError) as e:
         prov.mldivide(prov.upload(np.eye(3)), prov.upload(np.ones((2, 1))))
     assert e.value.code == 3
+
+
+@pytest.mark.parametrize("m,n,nrhs", [(300, 40, 3), (1500, 200, 1), (4096, 128, 2), (40, 300, 2), (128, 1000, 1), (700, 690, 1)])
+def test_mldivide_rectangular_full_rank_vs_svd_oracle(prov, oracle, m, n, nrhs):
+    """Rectangular A\\b on the device for full-rank A (round 2): least squares (rows > cols) / minimum norm (rows < cols)
+    through the Gram matrix's LU and one refinement step; the reference answers with the SVD's pseudo-inverse solve
+    (mldivide.rs:380-404), which the oracle restates.  Same solution to 1e-9 relative for cond(A) ~ 1e1..1e2."""
+    rng = np.random.default_rng(m * 7 + n)
+    A = rng.uniform(-1.0, 1.0, (m, n))
+    B = rng.uniform(-1.0, 1.0, (m, nrhs))
+    x = prov.download_matrix(prov.mldivide(prov.upload(A), prov.upload(B)))
+    assert x.shape == (n, nrhs)
+    want = oracle.mldivide_svd(A, B) if max(m, n) <= 1500 else np.linalg.lstsq(A, B, rcond=None)[0]
+    assert np.max(np.abs(x - want)) <= 1e-9 * max(1.0, np.max(np.abs(want)))
+    if m > n:  # least squares: the residual is orthogonal to the columns of A
+        assert np.max(np.abs(A.T @ (A @ x - B))) <= 1e-9 * np.linalg.norm(A) * np.linalg.norm(B)
+    else:  # minimum norm: exact solution that lies in the row space
+        assert np.max(np.abs(A @ x - B)) <= 1e-10 * np.linalg.norm(A) * max(1.0, np.linalg.norm(x))
+
+
+def test_mldivide_rectangular_reference_kat_and_guards(prov, oracle):
+    from runmat_amd import ProviderError
+
+    # mldivide.rs:681-697 `solves_least_squares`: residual norm < 1e-10
+    A = np.array([1.0, 3.0, 5.0, 2.0, 4.0, 6.0]).reshape(3, 2, order="F")
+    b = np.array([[7.0], [8.0], [9.0]])
+    x = prov.download_matrix(prov.mldivide(prov.upload(A), prov.upload(b)))
+    assert x.shape == (2, 1) and np.linalg.norm(A @ x - b) < 1e-10
+    assert np.max(np.abs(x - oracle.mldivide_svd(A, b))) < 1e-10
+    # B / A with a rectangular divisor goes the same way (mrdivide.rs:379-388)
+    rng = np.random.default_rng(44)
+    Ar, Br = rng.uniform(-1, 1, (30, 200)), rng.uniform(-1, 1, (5, 200))
+    X = prov.download_matrix(prov.mrdivide(prov.upload(Br), prov.upload(Ar)))
+    assert X.shape == (5, 30) and np.max(np.abs(X - np.linalg.lstsq(Ar.T, Br.T, rcond=None)[0].T)) < 1e-9
+    # rank deficient or badly conditioned: the caller's CPU SVD path (soft error, counted as a fallback)
+    bad = rng.uniform(-1, 1, (200, 20))
+    bad[:, 7] = bad[:, 3] * 2.0
+    with pytest.raises(ProviderError) as e:
+        prov.mldivide(prov.upload(bad), prov.upload(np.ones((200, 1))))
+    assert e.value.code == 2
+    U, _ = np.linalg.qr(rng.standard_normal((300, 30)))
+    V, _ = np.linalg.qr(rng.standard_normal((30, 30)))
+    ill = U @ np.diag(np.logspace(0, -8, 30)) @ V.T  # cond 1e8
+    with pytest.raises(ProviderError) as e:
+        prov.mldivide(prov.upload(ill), prov.upload(np.ones((300, 1))))
+    assert e.value.code == 2
+    ok = U @ np.diag(np.logspace(0, -4, 30)) @ V.T  # cond 1e4: accepted
+    rhs = rng.uniform(-1, 1, (300, 1))
+    xo = prov.download_matrix(prov.mldivide(prov.upload(ok), prov.upload(rhs)))
+    want = np.linalg.lstsq(ok, rhs, rcond=None)[0]
+    assert np.max(np.abs(xo - want)) <= 1e-7 * np.max(np.abs(want))
 
 
 @pytest.mark.parametrize("n,nrhs", [(3, 1), (64, 1), (300, 3), (1000, 1), (2048, 2), (513, 8), (640, 4), (700, 9), (129, 5)])
