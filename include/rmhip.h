@@ -273,7 +273,8 @@ RMHIP_API int rmhip_mrdivide(rmhip_ctx* ctx, rmhip_buf b, rmhip_buf a, rmhip_buf
  *   - lower / upper : triangular solve on the device, *rcond as the reference computes it.
  *   - general square: LU solve as rmhip_mldivide; *rcond = NaN.  With need_rcond or has_rcond the
  *     reference reports sigma_min/sigma_max of an SVD (linsolve.rs:933-944): UNSUPPORTED here so the
- *     caller takes its CPU path (linsolve.rs:414-417 `.ok()`), as for rectangular systems.
+ *     caller takes its CPU path (linsolve.rs:414-417 `.ok()`).
+ *   - general rectangular (no rcond requested): full-rank least squares / minimum norm as rmhip_mldivide; *rcond = NaN.
  *   - conjugate / symmetric / posdef are accepted and, as in the reference's real path, have no effect. */
 typedef struct rmhip_linsolve_options {
     int lower, upper, rectangular, transposed, conjugate, symmetric, posdef, need_rcond;

@@ -907,14 +907,11 @@ int rmhip_mrdivide(rmhip_ctx* ctx, rmhip_buf b, rmhip_buf a, rmhip_buf* out) {
 // residual (corrected semi-normal equations): x0 = G^-1 A'b, r = b - A x0, x = x0 + G^-1 A'r - error ~ eps * cond(A) once
 // cond(A)^2 * eps < 1.  Anything else stays with the caller's CPU SVD path: a pivot of G below the LU's cut-off, or a
 // pivot ratio min|u_ii| / max|u_ii| below 1e-11 (cond(A) beyond ~3e5, or rank deficient) -> RMHIP_ERR_UNSUPPORTED.
-static int lstsq_full_rank(rmhip_ctx* ctx, Context* c, const Buffer& ab, const std::vector<size_t>& as, const Buffer& bb,
-                           const std::vector<size_t>& bs, rmhip_buf* out) {
-    const size_t m = as[0], n = as[1], nrhs = bs[1];
+static int lstsq_full_rank(rmhip_ctx* ctx, Context* c, const double* A, size_t m, size_t n, const double* B, size_t nrhs,
+                           rmhip_buf* out) {
     if (m == 0 || n == 0 || nrhs == 0) return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: empty system");
     const bool tall = m > n;
     const size_t g = tall ? n : m;  // order of the Gram matrix
-    const double* A = ab.data();
-    const double* B = bb.data();
     std::shared_ptr<Allocation> gram, work, perm_mem, t1, t2, t3;
     RMHIP_TRY(c->alloc_device(g * g, &gram));
     // G = A'A (tall) or A A' (wide); the transposed operand is read in place
@@ -999,7 +996,7 @@ static int mldivide_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, r
         return rc;
     }
     if (as[0] != bs[0]) return fail(RMHIP_ERR_SHAPE, "mldivide: row mismatch (%zu vs %zu)", as[0], bs[0]);
-    if (as[0] != as[1]) return lstsq_full_rank(ctx, c, ab, as, bb, bs, out);
+    if (as[0] != as[1]) return lstsq_full_rank(ctx, c, ab.data(), as[0], as[1], bb.data(), bs[1], out);
     const size_t n = as[0], nrhs = bs[1];
     if (n == 0) return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: empty system");
     // Factorisation workspace with a PADDED leading dimension: with lda a large power of two every
@@ -1088,9 +1085,14 @@ static int linsolve_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, c
     const size_t n = as[0], nrhs = bs[1];
     if ((lower || upper) && as[0] != as[1]) return fail(RMHIP_ERR_SHAPE, "linsolve: triangular solves need a square matrix");
     if (!(lower || upper)) {
-        if (as[0] != as[1]) return fail(RMHIP_ERR_UNSUPPORTED, "linsolve: rectangular systems use the CPU least-squares path");
         if (opts->need_rcond || opts->has_rcond)
             return fail(RMHIP_ERR_UNSUPPORTED, "linsolve: rcond of a general matrix needs its singular values (CPU path)");
+        if (as[0] != as[1]) {  // full-rank rectangular system: least squares / minimum norm as rmhip_mldivide (linsolve.rs:933-970 is the SVD solve)
+            const int lrc = lstsq_full_rank(ctx, c, A, as[0], as[1], bb.data(), bs[1], out);
+            if (at) (void)hipStreamSynchronize(c->stream);  // the transposed copy is released on return
+            if (!lrc && reciprocal_condition) *reciprocal_condition = std::numeric_limits<double>::quiet_NaN();
+            return lrc;
+        }
     }
     if (n == 0) return fail(RMHIP_ERR_UNSUPPORTED, "linsolve: empty system");
     double rcond = std::numeric_limits<double>::quiet_NaN();

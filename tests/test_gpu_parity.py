@@ -616,6 +616,15 @@ def test_mldivide_rectangular_reference_kat_and_guards(prov, oracle):
     with pytest.raises(ProviderError) as e:
         prov.mldivide(prov.upload(ill), prov.upload(np.ones((300, 1))))
     assert e.value.code == 2
+    # linsolve without hints on a rectangular system: the same solve, rcond = NaN (linsolve.rs:933-970 is the SVD solve);
+    # with TRANSA the transposed system
+    At, bt = rng.uniform(-1, 1, (120, 25)), rng.uniform(-1, 1, (120, 2))
+    rl = prov.linsolve(prov.upload(At), prov.upload(bt))
+    assert np.isnan(rl.reciprocal_condition)
+    assert np.max(np.abs(prov.download_matrix(rl.solution) - np.linalg.lstsq(At, bt, rcond=None)[0])) < 1e-10
+    from runmat_amd import ProviderLinsolveOptions as Opt
+    rt = prov.linsolve(prov.upload(At.T.copy()), prov.upload(bt), Opt(transposed=True))
+    assert np.max(np.abs(prov.download_matrix(rt.solution) - np.linalg.lstsq(At, bt, rcond=None)[0])) < 1e-10
     ok = U @ np.diag(np.logspace(0, -4, 30)) @ V.T  # cond 1e4: accepted
     rhs = rng.uniform(-1, 1, (300, 1))
     xo = prov.download_matrix(prov.mldivide(prov.upload(ok), prov.upload(rhs)))
