@@ -550,10 +550,15 @@ __global__ void __launch_bounds__(512) k_dgemm_w8(const GemmArgs g) {
 __global__ void __launch_bounds__(512) k_dgemm_w8p(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ unsigned s_tile;
+    __shared__ int s_avoid;
     if (g.avoid_xcc && gridDim.x >= 16) {  // (a grid that small may sit on the avoided XCD entirely: somebody has to do the work)
+        // ONE read per workgroup: the panel kernel may write *avoid_xcc while this workgroup starts, and waves that saw different
+        // values would split it - half a workgroup computing half of every tile it draws
+        if (threadIdx.x == 0) s_avoid = __hip_atomic_load(g.avoid_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        if ((int)(xcc & 0xf) == *g.avoid_xcc) return;
+        if ((int)(xcc & 0xf) == s_avoid) return;
     }
     const unsigned nwg = g.tiles_m * g.tiles_n;
     for (;;) {

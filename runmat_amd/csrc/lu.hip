@@ -817,14 +817,18 @@ __global__ void __launch_bounds__(2 * PLIST) k_laswp_lists(double* __restrict__ 
                                                            const int2* __restrict__ lists, int p0, int p1, unsigned* counter,
                                                            const int* avoid_xcc) {
     __shared__ unsigned s_group;
+    __shared__ int s_avoid;
     const int i = threadIdx.x & (PLIST - 1);
     const int half = threadIdx.x / PLIST;  // 0 or 1
     unsigned group = blockIdx.x;
     if (counter) {
         if (avoid_xcc && gridDim.x >= 16) {  // (a smaller grid may sit on that XCD entirely)
+            // one read per workgroup (the panel kernel may be writing it right now: see k_dgemm_w8p)
+            if (threadIdx.x == 0) s_avoid = __hip_atomic_load(avoid_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            if ((int)(xcc & 0xf) == *avoid_xcc) return;
+            if ((int)(xcc & 0xf) == s_avoid) return;
         }
     }
   for (;;) {
@@ -885,9 +889,12 @@ __global__ void __launch_bounds__(TRSM_THREADS) k_trsm_fused(const double* __res
     // counter != nullptr (update stream of the LU's late phase, see k_dgemm_w8p): column groups are handed out by a counter, wave
     // by wave, and workgroups on XCD *avoid_xcc leave before they stage anything
     if (counter && avoid_xcc && gridDim.x >= 16) {
+        __shared__ int s_avoid;  // one read per workgroup (see k_dgemm_w8p)
+        if (threadIdx.x == 0) s_avoid = __hip_atomic_load(avoid_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        if ((int)(xcc & 0xf) == *avoid_xcc) return;
+        if ((int)(xcc & 0xf) == s_avoid) return;
     }
     const int wr = w > 64 ? TRSM_W : 64;  // staged rows per column (64-wide solves keep a 33 KiB footprint)
     const int sw = wr + 1;                // LDS row stride (doubles)
@@ -1160,6 +1167,21 @@ static int laswp(LuState& s, size_t c0, size_t c1, size_t k0, size_t k1) {
     return launch_check(s.c);
 }
 
+// Most blocks a base panel may have and still sit on ONE XCD, one per CU (getrf_rec's placement rule; 0: never;
+// RMHIP_LU_ONE_XCD=0 disables).
+// (Tried: twice as many - tall panels, two blocks per CU in a 256-register build of the kernel - so that the update stream's
+// persistent dgemm has the other seven XCDs to itself in the first half too: 124 ms against 102 at n = 16384.  A panel block
+// that needs a whole SIMD's registers waits for every small kernel of the other streams to leave its CU; the panels then
+// average 450 us instead of 210 and the main stream becomes the critical path from the start.)
+static size_t one_xcd_block_limit(const Context* c) {
+    static int one_xcd = -1;
+    if (one_xcd < 0) {
+        const char* v = std::getenv("RMHIP_LU_ONE_XCD");
+        one_xcd = (v && *v == '0') ? 0 : 1;
+    }
+    return (one_xcd && c->one_xcd_ok) ? (size_t)c->num_cus / 8 : 0;
+}
+
 // Factor columns [j0, j0+w) over rows [j0, rows); swaps are applied inside that column range only.
 // own_swaps_by_caller: a base panel leaves its own columns un-interchanged (k_lu_panel2 stores every row where it was
 // loaded from); the recursion step above it then widens the k_laswp_lists call that moves the sibling's columns anyway
@@ -1190,12 +1212,8 @@ static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller =
             // One-XCD placement when every block finds a CU of its own on one XCD (<= num_cus / 8 blocks): the exchange hop
             // drops from a write-through + a miss in another XCD's L2 to two accesses of one L2 (scripts/micro/
             // xcd_exchange.hip: 2.1-2.5 -> 1.45 us per step).  RMHIP_LU_ONE_XCD=0 disables.
-            static int one_xcd = -1;
-            if (one_xcd < 0) {
-                const char* v = std::getenv("RMHIP_LU_ONE_XCD");
-                one_xcd = (v && *v == '0') ? 0 : 1;
-            }
-            g.bstride = (one_xcd && s.c->one_xcd_ok && nbp <= (size_t)s.c->num_cus / 8) ? 8 : 1;
+            g.bstride = nbp <= one_xcd_block_limit(s.c) ? 8 : 1;
+            if (g.bstride > 1) s.c->lu_used_one_xcd = true;
             g.seq0 = s.xbase;
             g.xerr = s.xerr;
             g.xrec = s.xrec;
@@ -1286,11 +1304,11 @@ struct StreamScope {
     hipStream_t saved;
     size_t saved_pad;
     int saved_base;
-    StreamScope(Context* ctx, hipStream_t s, size_t gemm_lds_pad)
+    StreamScope(Context* ctx, hipStream_t s, size_t gemm_lds_pad, int base = 128)
         : c(ctx), saved(ctx->stream), saved_pad(ctx->gemm_lds_pad), saved_base(ctx->trsm_base) {
         c->stream = s;
         c->gemm_lds_pad = gemm_lds_pad;
-        c->trsm_base = 128;  // the update stream owns whole CUs between its dgemm blocks anyway
+        c->trsm_base = base;  // (128: the update stream owns whole CUs between its dgemm blocks anyway)
     }
     ~StreamScope() {
         c->stream = saved;
@@ -1299,19 +1317,25 @@ struct StreamScope {
     }
 };
 
-static int update_columns(LuState& s, size_t j, size_t w, size_t c0, size_t c1) {
-    // columns [c0, c1) receive the row interchanges of panel [j, j+w), the U block row and the Schur update
+// columns [c0, c1) receive the row interchanges of panel [j, j+w) and the U block row ...
+static int prep_columns(LuState& s, size_t j, size_t w, size_t c0, size_t c1) {
     if (c1 <= c0) return RMHIP_OK;
     RMHIP_TRY(laswp(s, c0, c1, j, j + w));
     double* A11 = s.A + j + j * s.lda;
     double* A12 = s.A + j + c0 * s.lda;
-    RMHIP_TRY(trsm_lower_rec(s.c, A11, s.lda, w, A12, s.lda, c1 - c0));
-    if (j + w < s.rows) {
-        double* A21 = s.A + (j + w) + j * s.lda;
-        double* A22 = s.A + (j + w) + c0 * s.lda;
-        RMHIP_TRY(lu_dgemm(s.c, s.rows - j - w, c1 - c0, w, -1.0, A21, s.lda, A12, s.lda, 1.0, A22, s.lda));
-    }
-    return RMHIP_OK;
+    return trsm_lower_rec(s.c, A11, s.lda, w, A12, s.lda, c1 - c0);
+}
+// ... and the Schur update
+static int gemm_columns(LuState& s, size_t j, size_t w, size_t c0, size_t c1, double* c_base = nullptr) {
+    if (c1 <= c0 || j + w >= s.rows) return RMHIP_OK;
+    double* A12 = s.A + j + c0 * s.lda;
+    double* A21 = s.A + (j + w) + j * s.lda;
+    double* A22 = (c_base ? c_base : s.A) + (j + w) + c0 * s.lda;  // (c_base: a load experiment's scratch copy)
+    return lu_dgemm(s.c, s.rows - j - w, c1 - c0, w, -1.0, A21, s.lda, A12, s.lda, 1.0, A22, s.lda);
+}
+static int update_columns(LuState& s, size_t j, size_t w, size_t c0, size_t c1) {
+    RMHIP_TRY(prep_columns(s, j, w, c0, c1));
+    return gemm_columns(s, j, w, c0, c1);
 }
 
 static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
@@ -1369,11 +1393,31 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         c->gemm_counter_cap = kCounters;
         c->gemm_avoid_xcc = s.panel_xcc;
     }
-    hipEvent_t side_done = nullptr;  // S_{j-1} finished
+    // Split update (RMHIP_LU_SPLIT=0 disables): on the update stream the interchanges and triangular solves are 14 % of the
+    // throughput-bound first half, and the matrix cores idle meanwhile.  While more than split_rows rows remain the trailing
+    // columns are cut at a fixed column csplit into A | B; a third stream prepares (interchange + solve) one part while the
+    // update stream's dgemm runs on the other:
+    //   prep:    wait(P_j, dgemm_{j-1}(A)) -> prep_j(A) -> wait(dgemm_{j-1}(B)) -> prep_j(B)
+    //   update:  wait(prep_j(A)) -> dgemm_j(A) -> wait(prep_j(B)) -> dgemm_j(B) -> interchanges of the finished left columns
+    // csplit stays put (so A_j lies inside A_{j-1}) until A has shrunk below a fifth of the range, then it moves to the
+    // middle again (that one step waits for all of step j-1).  The main stream waits for dgemm_{j-1}(A) only - the next
+    // panel's columns are its first ones - in either mode.  Same kernels on the same columns: bit-identical factors.
+    static const int split_on = std::getenv("RMHIP_LU_SPLIT") ? std::atoi(std::getenv("RMHIP_LU_SPLIT")) : 1;
+    static const long split_rows_env = std::getenv("RMHIP_LU_SPLIT_ROWS") ? std::atol(std::getenv("RMHIP_LU_SPLIT_ROWS")) : 8192;
+    static const int prep_base = std::getenv("RMHIP_LU_PREP_TRSM") ? std::atoi(std::getenv("RMHIP_LU_PREP_TRSM")) : 128;
+    hipStream_t prep = nullptr;
+    if (split_on) {
+        if (!c->lu_prep_stream) RMHIP_HIP_CHECK(hipStreamCreateWithPriority(&c->lu_prep_stream, hipStreamNonBlocking, prio_low));
+        prep = c->lu_prep_stream;
+    }
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;  // dgemm of the previous step finished on [.., a_end) / everything of that step finished
+    size_t a_end = s.cols;                      // right edge of the previous step's part A
+    size_t csplit = 0;
     {
         hipEvent_t e0 = new_event();  // side starts after whatever main already has queued (the copy of A)
         (void)hipEventRecord(e0, main_stream);
         (void)hipStreamWaitEvent(side, e0, 0);
+        if (prep) (void)hipStreamWaitEvent(prep, e0, 0);
     }
     // Panel width by phase.  While the trailing matrix is large the update stream is the bottleneck and the main stream
     // idles a third of the time: wider panels there (fewer, deeper rank-k updates: the dgemm runs 53 instead of 47
@@ -1435,7 +1479,7 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         const size_t nbj = width_at(j);
         const bool early = early_rows && kmin - j > early_rows;
         // this panel on one XCD?  (the condition getrf_rec applies to its first base panel)
-        const bool late_xcd = late_counters && (s.rows - j + P2_ROWS - 1) / P2_ROWS <= (size_t)c->num_cus / 8;
+        const bool late_xcd = late_counters && (s.rows - j + P2_ROWS - 1) / P2_ROWS <= one_xcd_block_limit(c);
         static const long late_panel_pad = std::getenv("RMHIP_LU_LATE_PANEL_PAD_KB") ? std::atol(std::getenv("RMHIP_LU_LATE_PANEL_PAD_KB")) : 0;
         s.panel_pad_kb = late_xcd ? late_panel_pad : (early ? early_panel_pad : -1);
         const size_t w = (kmin - j) < nbj ? (kmin - j) : nbj;
@@ -1448,26 +1492,96 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         if (next < kmin) {  // there is a next panel: update its columns on main right away
             const size_t nbn = width_at(next);
             la_w = (kmin - next) < nbn ? (kmin - next) : nbn;
-            if (side_done) (void)hipStreamWaitEvent(main_stream, side_done, 0);
+            if (ev_a) (void)hipStreamWaitEvent(main_stream, ev_a, 0);
+            if (ev_b && next + la_w > a_end) (void)hipStreamWaitEvent(main_stream, ev_b, 0);
             rc = update_columns(s, j, w, next, next + la_w);
             if (rc != RMHIP_OK) break;
         }
-        (void)hipStreamWaitEvent(side, panel_done, 0);
-        {
+        const size_t t0 = next + la_w;  // trailing columns [t0, cols)
+        const bool next_late = late_counters && next < s.rows && (s.rows - next + P2_ROWS - 1) / P2_ROWS <= one_xcd_block_limit(c);
+        bool split = prep && kmin - j > (size_t)split_rows_env && s.cols > t0 && s.cols - t0 >= 2048;
+        bool moved = false;
+        if (split) {
+            if (csplit < t0 + 256 || csplit >= s.cols || (csplit - t0) * 5 < (s.cols - t0)) {
+                csplit = t0 + (((s.cols - t0) / 2 + 127) / 128) * 128;
+                moved = true;
+            }
+            if (csplit >= s.cols) split = false;
+        }
+        if (split) {
+            c->gemm_tile_counters = next_late ? late_counters : nullptr;  // persistent, XCD-avoiding kernels if the next panel sits on one XCD
+            hipEvent_t ra = new_event(), rb = new_event();
+            (void)hipStreamWaitEvent(prep, panel_done, 0);
+            {
+                StreamScope scope(c, prep, 0, prep_base);  // unpadded small blocks: they run beside the update stream's dgemm
+                if (ev_a) (void)hipStreamWaitEvent(prep, ev_a, 0);
+                if (ev_b && (moved || csplit > a_end)) (void)hipStreamWaitEvent(prep, ev_b, 0);
+                rc = prep_columns(s, j, w, t0, csplit);
+                (void)hipEventRecord(ra, prep);
+                if (ev_b) (void)hipStreamWaitEvent(prep, ev_b, 0);
+                if (rc == RMHIP_OK) rc = prep_columns(s, j, w, csplit, s.cols);
+                (void)hipEventRecord(rb, prep);
+            }
             StreamScope scope(c, side, early ? early_side_pad : side_pad);
-            // S_j overlaps panel j+1: persistent, XCD-avoiding dgemm if that panel sits on one XCD
-            const bool next_late = late_counters && next < s.rows && (s.rows - next + P2_ROWS - 1) / P2_ROWS <= (size_t)c->num_cus / 8;
-            c->gemm_tile_counters = (next_late || (late_xcd_on == 2 && late_counters)) ? late_counters : nullptr;
-            rc = update_columns(s, j, w, next + la_w, s.cols);      // S_j
+            (void)hipStreamWaitEvent(side, ra, 0);
+            if (rc == RMHIP_OK) rc = gemm_columns(s, j, w, t0, csplit);
+            ev_a = new_event();
+            (void)hipEventRecord(ev_a, side);
+            (void)hipStreamWaitEvent(side, rb, 0);
+            if (rc == RMHIP_OK) rc = gemm_columns(s, j, w, csplit, s.cols);
             if (rc == RMHIP_OK && j > 0) rc = laswp(s, 0, j, j, j + w);  // finished left columns
             c->gemm_tile_counters = nullptr;
+            a_end = csplit;
+        } else {
+            (void)hipStreamWaitEvent(side, panel_done, 0);
+            StreamScope scope(c, side, early ? early_side_pad : side_pad);
+            // S_j overlaps panel j+1: persistent, XCD-avoiding dgemm if that panel sits on one XCD
+            c->gemm_tile_counters = (next_late || (late_xcd_on == 2 && late_counters)) ? late_counters : nullptr;
+            // (attribution knobs, results are garbage: RMHIP_LU_LATE_SKIP=1 drops the update stream's work once the panels sit on
+            // one XCD, RMHIP_LU_LATE_DUP=<k> repeats its dgemm k more times - what extra load costs the chain there)
+            static const int late_skip = std::getenv("RMHIP_LU_LATE_SKIP") ? std::atoi(std::getenv("RMHIP_LU_LATE_SKIP")) : 0;
+            static const int late_dup_n = std::getenv("RMHIP_LU_LATE_DUP") ? std::atoi(std::getenv("RMHIP_LU_LATE_DUP")) : 0;
+            static const long late_dup_rows = std::getenv("RMHIP_LU_LATE_DUP_ROWS") ? std::atol(std::getenv("RMHIP_LU_LATE_DUP_ROWS")) : (1L << 40);
+            const int late_dup = (long)(kmin - j) <= late_dup_rows ? late_dup_n : 0;
+            static std::shared_ptr<Allocation> dup_buf;  // the repeats write a scratch copy (zero-filled once; the factors stay intact)
+            if (late_dup_n && !dup_buf) {
+                RMHIP_TRY(c->alloc_device(s.lda * s.cols, &dup_buf));
+                RMHIP_HIP_CHECK(hipMemsetAsync(dup_buf->ptr, 0, s.lda * s.cols * sizeof(double), main_stream));
+                RMHIP_HIP_CHECK(hipStreamSynchronize(main_stream));
+            }
+            double* const dup_c = dup_buf ? (double*)dup_buf->ptr : nullptr;
+            if (!(next_late && late_skip)) rc = update_columns(s, j, w, t0, s.cols);      // S_j
+            static const int late_dup_stream = std::getenv("RMHIP_LU_LATE_DUP_STREAM") ? std::atoi(std::getenv("RMHIP_LU_LATE_DUP_STREAM")) : 0;
+            for (int d = 0; d < late_dup && !late_dup_stream && next_late && rc == RMHIP_OK; ++d) rc = gemm_columns(s, j, w, t0, s.cols, dup_c);
+            ev_a = new_event();
+            (void)hipEventRecord(ev_a, side);
+            if (late_dup && late_dup_stream == 3 && next_late) {  // on the update stream, but behind the event the main stream waits for
+                for (int d = 0; d < late_dup && rc == RMHIP_OK; ++d) rc = gemm_columns(s, j, w, t0, s.cols, dup_c);
+            } else if (late_dup && late_dup_stream && next_late && prep) {  // the same extra load off the dependency path (third stream)
+                (void)hipStreamWaitEvent(prep, ev_a, 0);
+                c->stream = prep;
+                const size_t pad_saved = c->gemm_lds_pad;
+                unsigned* counters_saved = c->gemm_tile_counters;
+                if (late_dup_stream == 2) {  // unpadded four-wave blocks on every XCD: they fit beside the update stream's
+                    c->gemm_lds_pad = 0;
+                    c->gemm_tile_counters = nullptr;
+                }
+                for (int d = 0; d < late_dup && rc == RMHIP_OK; ++d) rc = gemm_columns(s, j, w, t0, s.cols, dup_c);
+                c->gemm_lds_pad = pad_saved;
+                c->gemm_tile_counters = counters_saved;
+                c->stream = side;
+            }
+            if (rc == RMHIP_OK && j > 0) rc = laswp(s, 0, j, j, j + w);  // finished left columns
+            c->gemm_tile_counters = nullptr;
+            a_end = s.cols;
         }
-        side_done = new_event();
-        (void)hipEventRecord(side_done, side);
+        ev_b = new_event();
+        (void)hipEventRecord(ev_b, side);
         j = next;
     }
     s.panel_pad_kb = -1;
-    if (side_done) (void)hipStreamWaitEvent(main_stream, side_done, 0);
+    if (ev_b) (void)hipStreamWaitEvent(main_stream, ev_b, 0);
+    if (prep) (void)hipStreamSynchronize(prep);
     (void)hipStreamSynchronize(side);
     (void)hipStreamSynchronize(main_stream);
     c->gemm_tile_counters = nullptr;

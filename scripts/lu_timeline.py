@@ -51,3 +51,24 @@ for si, s in enumerate(solves):
             busy = sum(max(0, min(r[1], b) - max(r[0], a)) for r in by_q[q])
             cells.append(f"{100.0*busy/(b-a):9.0f}%")
         print(f"  {i:5d}  " + "  ".join(cells))
+
+# ---- last solve (from its copy of A into the workspace on): 5 ms slices, per stream the busy share by kernel
+starts = [r[0] for r in rows if "copyBufferRect" in r[2]]
+if starts:
+    s0 = starts[-1]
+    last = [r for r in rows if r[0] >= s0]
+    qs = collections.Counter((r[3], r[4]) for r in last)
+    end = max(r[1] for r in last)
+    print(f"== last solve: {len(last)} kernels, span {(end - s0)/1e6:.2f} ms")
+    T = 5_000_000
+    for q, cnt in qs.most_common():
+        if cnt < 20: continue
+        print(f"  stream {q} ({cnt} kernels)")
+        for i in range(int((end - s0) / T) + 1):
+            a, b = s0 + i * T, s0 + (i + 1) * T
+            acc = collections.Counter()
+            for r in last:
+                if (r[3], r[4]) != q: continue
+                o = min(r[1], b) - max(r[0], a)
+                if o > 0: acc[short(r[2])] += o
+            print(f"    {i*5:3d} ms busy {100.0*sum(acc.values())/T:5.1f}%  " + " ".join(f"{k}:{100.0*v/T:.0f}" for k, v in acc.most_common()))

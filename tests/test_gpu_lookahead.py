@@ -225,3 +225,27 @@ def test_lookahead_driver_rectangular_lu(prov, rows, cols):
             prov.free(h)
     assert np.array_equal(piv, piv0)
     prov.free(hg)
+
+
+@pytest.mark.parametrize("n,reps", [(12288, 12)])
+def test_lookahead_driver_repeated_solves_are_identical(prov, n, reps):
+    """Three streams run the factorisation (panels, dgemm, interchange + solve of the other column half), and once the panels
+    sit on one XCD the update kernels are persistent workgroups that leave that XCD - deciding on a word the panel kernel
+    writes while they start.  Every repeat must give the bits of the first and a small residual (a workgroup that split
+    over that decision once left half of some 128 x 128 tiles un-updated in one solve out of four at this size)."""
+    hu = prov.fill_uniform(41, -1.0, 1.0, (n, n))
+    hb = prov.fill_uniform(42, -1.0, 1.0, (n, 1))
+    first = None
+    for rep in range(reps):
+        hx = prov.mldivide(hu, hb)
+        hr = prov.elem_sub(prov.matmul(hu, hx), hb)
+        res = float(np.abs(prov.download(hr)).max())
+        x = prov.download(hx).ravel()
+        prov.free(hx)
+        prov.free(hr)
+        assert res < 1e-7, f"solve {rep}: max |A x - b| = {res:.3e}"
+        if first is None:
+            first = x
+        assert np.array_equal(x, first), f"solve {rep} differs from solve 0"
+    prov.free(hu)
+    prov.free(hb)
