@@ -1326,11 +1326,11 @@ static int prep_columns(LuState& s, size_t j, size_t w, size_t c0, size_t c1) {
     return trsm_lower_rec(s.c, A11, s.lda, w, A12, s.lda, c1 - c0);
 }
 // ... and the Schur update
-static int gemm_columns(LuState& s, size_t j, size_t w, size_t c0, size_t c1, double* c_base = nullptr) {
+static int gemm_columns(LuState& s, size_t j, size_t w, size_t c0, size_t c1) {
     if (c1 <= c0 || j + w >= s.rows) return RMHIP_OK;
     double* A12 = s.A + j + c0 * s.lda;
     double* A21 = s.A + (j + w) + j * s.lda;
-    double* A22 = (c_base ? c_base : s.A) + (j + w) + c0 * s.lda;  // (c_base: a load experiment's scratch copy)
+    double* A22 = s.A + (j + w) + c0 * s.lda;
     return lu_dgemm(s.c, s.rows - j - w, c1 - c0, w, -1.0, A21, s.lda, A12, s.lda, 1.0, A22, s.lda);
 }
 static int update_columns(LuState& s, size_t j, size_t w, size_t c0, size_t c1) {
@@ -1343,6 +1343,7 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     hipStream_t main_stream = c->stream;
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    // (a high-priority stand-in for the context stream makes no difference: 100.7 vs 100.8 ms)
     // the update stream and the events live in the context (created once: a stream and ~200 events per factorisation cost
     // about a millisecond of host time)
     if (!c->lu_side_stream) RMHIP_HIP_CHECK(hipStreamCreateWithPriority(&c->lu_side_stream, hipStreamNonBlocking, prio_low));
@@ -1489,13 +1490,9 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         (void)hipEventRecord(panel_done, main_stream);
         const size_t next = j + w;
         size_t la_w = 0;
-        if (next < kmin) {  // there is a next panel: update its columns on main right away
+        if (next < kmin) {  // there is a next panel: the main stream updates its columns right away
             const size_t nbn = width_at(next);
             la_w = (kmin - next) < nbn ? (kmin - next) : nbn;
-            if (ev_a) (void)hipStreamWaitEvent(main_stream, ev_a, 0);
-            if (ev_b && next + la_w > a_end) (void)hipStreamWaitEvent(main_stream, ev_b, 0);
-            rc = update_columns(s, j, w, next, next + la_w);
-            if (rc != RMHIP_OK) break;
         }
         const size_t t0 = next + la_w;  // trailing columns [t0, cols)
         const bool next_late = late_counters && next < s.rows && (s.rows - next + P2_ROWS - 1) / P2_ROWS <= one_xcd_block_limit(c);
@@ -1507,6 +1504,14 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
                 moved = true;
             }
             if (csplit >= s.cols) split = false;
+        }
+        // (Tried: while the update stream is the bottleneck, hand it the next panel's columns as well - first in line, prepared by
+        // the third stream - so that the main stream only factors panels: 101.9-103.9 ms against 101.3, worse the longer it is kept up.)
+        if (la_w) {
+            if (ev_a) (void)hipStreamWaitEvent(main_stream, ev_a, 0);
+            if (ev_b && next + la_w > a_end) (void)hipStreamWaitEvent(main_stream, ev_b, 0);
+            rc = update_columns(s, j, w, next, next + la_w);
+            if (rc != RMHIP_OK) break;
         }
         if (split) {
             c->gemm_tile_counters = next_late ? late_counters : nullptr;  // persistent, XCD-avoiding kernels if the next panel sits on one XCD
@@ -1537,40 +1542,16 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
             StreamScope scope(c, side, early ? early_side_pad : side_pad);
             // S_j overlaps panel j+1: persistent, XCD-avoiding dgemm if that panel sits on one XCD
             c->gemm_tile_counters = (next_late || (late_xcd_on == 2 && late_counters)) ? late_counters : nullptr;
-            // (attribution knobs, results are garbage: RMHIP_LU_LATE_SKIP=1 drops the update stream's work once the panels sit on
-            // one XCD, RMHIP_LU_LATE_DUP=<k> repeats its dgemm k more times - what extra load costs the chain there)
+            // (Attribution, n = 16384 at 100.9 ms: dropping the update stream's work of this phase altogether - knob below, results
+            // are garbage - gives 100.3: with the XCD partition it no longer disturbs the chain.  But the phase has no room to
+            // spare either: repeating its dgemm into a scratch copy k more times, on this stream before or behind the event the main
+            // stream waits for or on the third stream, costs 6 ms per repeat (12 ms of kernel time each); repeats only below 6144 /
+            // 4096 remaining rows cost what the work takes at 55-75 TFLOP/s.  Each step's update just fits the time of the next
+            // panel, so deferring first-half work into this phase buys (1/43 - 1/60 TFLOP/s) per flop at best.)
             static const int late_skip = std::getenv("RMHIP_LU_LATE_SKIP") ? std::atoi(std::getenv("RMHIP_LU_LATE_SKIP")) : 0;
-            static const int late_dup_n = std::getenv("RMHIP_LU_LATE_DUP") ? std::atoi(std::getenv("RMHIP_LU_LATE_DUP")) : 0;
-            static const long late_dup_rows = std::getenv("RMHIP_LU_LATE_DUP_ROWS") ? std::atol(std::getenv("RMHIP_LU_LATE_DUP_ROWS")) : (1L << 40);
-            const int late_dup = (long)(kmin - j) <= late_dup_rows ? late_dup_n : 0;
-            static std::shared_ptr<Allocation> dup_buf;  // the repeats write a scratch copy (zero-filled once; the factors stay intact)
-            if (late_dup_n && !dup_buf) {
-                RMHIP_TRY(c->alloc_device(s.lda * s.cols, &dup_buf));
-                RMHIP_HIP_CHECK(hipMemsetAsync(dup_buf->ptr, 0, s.lda * s.cols * sizeof(double), main_stream));
-                RMHIP_HIP_CHECK(hipStreamSynchronize(main_stream));
-            }
-            double* const dup_c = dup_buf ? (double*)dup_buf->ptr : nullptr;
             if (!(next_late && late_skip)) rc = update_columns(s, j, w, t0, s.cols);      // S_j
-            static const int late_dup_stream = std::getenv("RMHIP_LU_LATE_DUP_STREAM") ? std::atoi(std::getenv("RMHIP_LU_LATE_DUP_STREAM")) : 0;
-            for (int d = 0; d < late_dup && !late_dup_stream && next_late && rc == RMHIP_OK; ++d) rc = gemm_columns(s, j, w, t0, s.cols, dup_c);
             ev_a = new_event();
             (void)hipEventRecord(ev_a, side);
-            if (late_dup && late_dup_stream == 3 && next_late) {  // on the update stream, but behind the event the main stream waits for
-                for (int d = 0; d < late_dup && rc == RMHIP_OK; ++d) rc = gemm_columns(s, j, w, t0, s.cols, dup_c);
-            } else if (late_dup && late_dup_stream && next_late && prep) {  // the same extra load off the dependency path (third stream)
-                (void)hipStreamWaitEvent(prep, ev_a, 0);
-                c->stream = prep;
-                const size_t pad_saved = c->gemm_lds_pad;
-                unsigned* counters_saved = c->gemm_tile_counters;
-                if (late_dup_stream == 2) {  // unpadded four-wave blocks on every XCD: they fit beside the update stream's
-                    c->gemm_lds_pad = 0;
-                    c->gemm_tile_counters = nullptr;
-                }
-                for (int d = 0; d < late_dup && rc == RMHIP_OK; ++d) rc = gemm_columns(s, j, w, t0, s.cols, dup_c);
-                c->gemm_lds_pad = pad_saved;
-                c->gemm_tile_counters = counters_saved;
-                c->stream = side;
-            }
             if (rc == RMHIP_OK && j > 0) rc = laswp(s, 0, j, j, j + w);  // finished left columns
             c->gemm_tile_counters = nullptr;
             a_end = s.cols;
