@@ -48,6 +48,9 @@ static constexpr int B_TILE = BN * SB;
 static constexpr int GROUP_M = GEMM_GROUP_M;
 // after which of the four k-steps of a tile the next tile's registers go to LDS (3 = after the last MFMA;
 // measured at 8192^3: 3 -> 68.6, 2 -> 66.4, 1 -> 67.1 TFLOP/s; s_setprio around the MFMA section: no effect)
+#ifndef GEMM_PIPE
+#define GEMM_PIPE 1
+#endif
 #ifndef GEMM_STASH_KK
 #define GEMM_STASH_KK 3
 #endif
@@ -242,6 +245,90 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
     constexpr int A_KSTEP = TA ? 4 : 4 * SA, A_ISTEP = TA ? 16 * SB : 16;
     constexpr int B_KSTEP = TB ? 4 * SA : 4, B_JSTEP = TB ? 16 : 16 * SB;
 
+#if GEMM_PIPE
+    if (!EDGE && !PRE) {  // (the C-preloading variant has no registers to spare for the second prefetch set: 132 bytes of scratch)
+        // Software-pipelined k loop (one barrier per tile, nothing exposed around it): the fragments of step kk+1 are read while
+        // step kk multiplies; the next tile is stashed during step 2 from registers that were loaded a whole tile earlier (and
+        // refilled at once with the tile after it); the barrier sits before step 3 - every wave has issued all its reads of the
+        // current buffer by then, so the buffer may be overwritten any time after it - and step 3 already reads the next
+        // tile's first fragments.  The barrier is raw (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads would also wait for
+        // the global loads just issued.
+        auto frags = [&](const double* a, const double* b, int kk, double (&af)[4], double (&bf)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = a[kk * A_KSTEP + i * A_ISTEP];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = b[j * B_JSTEP + kk * B_KSTEP];
+        };
+        auto mma = [&](const double (&af)[4], const double (&bf)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[j][i], 0, 0, 0);
+        };
+        // global prefetch distance: TWO tiles (register sets A = ra/rb and B = ra2/rb2 alternate; the loop is unrolled by two)
+        v2d ra2[4], rb2[4];
+        auto fetch_into = [&](unsigned k0, v2d* pa, v2d* pb) {
+            if (TA) fetchK(Ab, g.lda, m0, g.m, k0, g.vec_a, pa);
+            else fetchM(Ab, g.lda, m0, g.m, k0, g.vec_a, pa);
+            if (TB) fetchM(Bb, g.ldb, n0, g.n, k0, g.vec_b, pb);
+            else fetchK(Bb, g.ldb, n0, g.n, k0, g.vec_b, pb);
+        };
+        auto stash_from = [&](int buf, const v2d* pa, const v2d* pb) {
+            if (TA) stashK(As + buf * A_TILE, pa);
+            else stashM(As + buf * A_TILE, pa);
+            if (TB) stashM(Bs + buf * B_TILE, pb);
+            else stashK(Bs + buf * B_TILE, pb);
+        };
+        auto clampt = [&](unsigned t) { return (t < ktiles ? t : ktiles - 1) * BK; };
+        fetch_into(clampt(1), ra, rb);
+        fetch_into(clampt(2), ra2, rb2);
+        double af0[4], bf0[4], af1[4], bf1[4];
+        frags(As + a_off, Bs + b_off, 0, af0, bf0);
+        auto step = [&](unsigned kt, v2d* pa, v2d* pb) {
+            const int cur = kt & 1;
+            const double* a = As + cur * A_TILE + a_off;
+            const double* b = Bs + cur * B_TILE + b_off;
+            // (sched_group_barrier: mask 0x100 = LDS reads, 0x200 = LDS writes, 0x020 = global loads, 0x008 = MFMA.  Left alone the
+            // scheduler issues each step's reads BEHIND the previous step's MFMAs and then waits for them.)
+            frags(a, b, 1, af1, bf1);
+            mma(af0, bf0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            frags(a, b, 2, af0, bf0);
+            mma(af1, bf1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // (no branches here: the last tiles stash / fetch a tile nobody reads, so that the writes and loads can sit between MFMAs)
+            stash_from(cur ^ 1, pa, pb);     // tile kt + 1, loaded two tiles ago
+            fetch_into(clampt(kt + 3), pa, pb);
+            frags(a, b, 3, af1, bf1);
+            mma(af0, bf0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            frags(As + (cur ^ 1) * A_TILE + a_off, Bs + (cur ^ 1) * B_TILE + b_off, 0, af0, bf0);
+            mma(af1, bf1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // the prefetched fragments are "used" here, behind 16 MFMAs: the wait the compiler owes them lands where it is free
+            // instead of in front of the next step's first MFMA, where it would also cover that step's own reads
+            asm volatile("" : "+v"(af0[0]), "+v"(af0[1]), "+v"(af0[2]), "+v"(af0[3]), "+v"(bf0[0]), "+v"(bf0[1]), "+v"(bf0[2]), "+v"(bf0[3]));
+        };
+        for (unsigned kt = 0; kt < ktiles; kt += 2) {
+            step(kt, ra, rb);
+            if (kt + 1 < ktiles) step(kt + 1, ra2, rb2);
+        }
+    } else
+#endif
     for (unsigned kt = 0; kt < ktiles; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < ktiles) fetch((kt + 1) * BK);

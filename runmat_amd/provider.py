@@ -140,6 +140,17 @@ class HipProvider:
             shape = tuple(int(buf[i]) for i in range(rank.value))
         return GpuTensorHandle(tuple(int(s) for s in shape), self._device_id, int(buffer_id))
 
+    def _shader_bytes(self, shader: str) -> bytes:
+        """One bytes object per shader text: the library recognises a repeated (pointer, length) before it hashes the text
+        (RunMat hands it the plan's cached `Arc<str>` the same way)."""
+        cache = self.__dict__.setdefault("_shader_cache", {})
+        b = cache.get(shader)
+        if b is None:
+            if len(cache) > 4096:
+                cache.clear()
+            b = cache[shader] = shader.encode()
+        return b
+
     def _id(self, h: GpuTensorHandle) -> int:
         if h.device_id != self._device_id:  # io.rs:269-275: foreign handles are an error
             raise ProviderError(_lib.ERR_INVALID, f"handle belongs to device {h.device_id}, not {self._device_id}")
@@ -274,7 +285,7 @@ class HipProvider:
         ids = (C.c_uint64 * max(len(inputs), 1))(*[self._id(h) for h in inputs])
         sh, rank = _shape_array(output_shape)
         outs = (C.c_uint64 * max(num_outputs, 1))()
-        self._check(self._lib.rmhip_fused_elementwise(self._ctx, shader.encode(), ids, len(inputs), sh, rank,
+        self._check(self._lib.rmhip_fused_elementwise(self._ctx, self._shader_bytes(shader), ids, len(inputs), sh, rank,
                                                       int(length), int(num_outputs), outs))
         return [self._handle(outs[k], output_shape) for k in range(num_outputs)]
 
@@ -285,7 +296,7 @@ class HipProvider:
         sh, rank = _shape_array(output_shape)
         out = C.c_uint64()
         code = {"sum": 0, "mean": 1, "custom": 2}[flavor.kind]
-        self._check(self._lib.rmhip_fused_reduction(self._ctx, shader.encode(), ids, len(inputs), sh, rank,
+        self._check(self._lib.rmhip_fused_reduction(self._ctx, self._shader_bytes(shader), ids, len(inputs), sh, rank,
                                                     int(reduce_len), int(num_slices), int(workgroup_size), code,
                                                     float(flavor.scale), C.byref(out)))
         return self._handle(out.value, output_shape)
