@@ -48,6 +48,9 @@ static constexpr int B_TILE = BN * SB;
 static constexpr int GROUP_M = GEMM_GROUP_M;
 // after which of the four k-steps of a tile the next tile's registers go to LDS (3 = after the last MFMA;
 // measured at 8192^3: 3 -> 68.6, 2 -> 66.4, 1 -> 67.1 TFLOP/s; s_setprio around the MFMA section: no effect)
+#ifndef GEMM_PIPE_W8
+#define GEMM_PIPE_W8 1
+#endif
 #ifndef GEMM_PIPE
 #define GEMM_PIPE 1
 #endif
@@ -566,6 +569,65 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
     __syncthreads();
     const int a_off = lq * SA + wm * 64 + l15;
     const int b_off = (wn * 32 + l15) * SB + lq;
+#if GEMM_PIPE_W8
+    {
+        // the software-pipelined k loop of k_dgemm (there: two blocks per CU fill each other's bubbles and it is worth 1 %; here all
+        // eight waves of the CU share ONE barrier, and what surrounds it - LDS write completion, the first reads of the next tile -
+        // is matrix-pipe idle time).  One tile of global prefetch only: the kernel has to stay near 130 VGPRs (two of its waves
+        // and a main-stream dgemm wave share a SIMD under the LU's look-ahead).
+        auto frags = [&](const double* a, const double* b, int kk, double (&af)[4], double (&bf)[2]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = a[kk * 4 * SA + i * 16];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = b[j * 16 * SB + kk * 4];
+        };
+        auto mma = [&](const double (&af)[4], const double (&bf)[2]) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc[j][i], 0, 0, 0);
+        };
+        auto clampt = [&](unsigned tt) { return (tt < ktiles ? tt : ktiles - 1) * BK; };
+        fetch(clampt(1));
+        double af0[4], bf0[2], af1[4], bf1[2];
+        frags(As + a_off, Bs + b_off, 0, af0, bf0);
+        for (unsigned kt = 0; kt < ktiles; ++kt) {
+            const int cur = kt & 1;
+            const double* a = As + cur * A_TILE + a_off;
+            const double* b = Bs + cur * B_TILE + b_off;
+            frags(a, b, 1, af1, bf1);
+            mma(af0, bf0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            frags(a, b, 2, af0, bf0);
+            mma(af1, bf1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            stash(cur ^ 1);            // tile kt + 1 (the last tile stashes a copy nobody reads: no branch between the MFMAs)
+            fetch(clampt(kt + 2));
+            frags(a, b, 3, af1, bf1);
+            mma(af0, bf0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            frags(As + (cur ^ 1) * A_TILE + a_off, Bs + (cur ^ 1) * B_TILE + b_off, 0, af0, bf0);
+            mma(af1, bf1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" : "+v"(af0[0]), "+v"(af0[1]), "+v"(af0[2]), "+v"(af0[3]), "+v"(bf0[0]), "+v"(bf0[1]));
+        }
+        __syncthreads();  // the caller may reuse the LDS tiles (persistent form)
+    }
+#else
     for (unsigned kt = 0; kt < ktiles; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < ktiles) fetch((kt + 1) * BK);
@@ -586,6 +648,7 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
         if (kt + 1 < ktiles) stash(cur ^ 1);
         __syncthreads();
     }
+#endif
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         double* dst[16];
