@@ -573,8 +573,10 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
     {
         // the software-pipelined k loop of k_dgemm (there: two blocks per CU fill each other's bubbles and it is worth 1 %; here all
         // eight waves of the CU share ONE barrier, and what surrounds it - LDS write completion, the first reads of the next tile -
-        // is matrix-pipe idle time).  One tile of global prefetch only: the kernel has to stay near 130 VGPRs (two of its waves
-        // and a main-stream dgemm wave share a SIMD under the LU's look-ahead).
+        // is matrix-pipe idle time).  One tile of global prefetch only: with two (140-162 VGPRs) one padded block per CU gains
+        // another 2.8 % at 8192^3 (66.9 TFLOP/s) but nothing at the LU's k = 128..512 (solve 100.4-100.9 vs 100.4-100.6 ms), and
+        // the plain variant would no longer fit two blocks per CU.  (Capped at 128 VGPRs - so that a main-stream dgemm wave still
+        // shares the SIMD - it spills and the solve takes 101.6 ms.)
         auto frags = [&](const double* a, const double* b, int kk, double (&af)[4], double (&bf)[2]) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = a[kk * 4 * SA + i * 16];
