@@ -321,7 +321,7 @@ def main() -> None:
                        "parallelism": f"row-block x{world}, B replicated, no collective"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TF,
                          "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TF, 4),
-                         "traffic": pmc_traffic("k_dgemm"), "traffic_source": PMC_TRAFFIC_SOURCE, "kernel": "k_dgemm<false,false> (v_mfma_f64_16x16x4_f64)",
+                         "traffic": pmc_traffic("k_dgemm"), "traffic_source": PMC_TRAFFIC_SOURCE, "kernel": "k_dgemm_w8<false> (eight waves, pipelined k loop; v_mfma_f64_16x16x4_f64)",
                          "kernel_ms": round(kern_ms, 5)},
         }
 

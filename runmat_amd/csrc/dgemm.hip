@@ -869,10 +869,11 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
         RMHIP_HIP_CHECK(hipGetLastError());
         return RMHIP_OK;
     }
-    // eight-wave tile: on the look-ahead's update stream (one padded block per CU), and for every plain product with k <= 2048
-    // (scripts/gemm_w8_ab.py, TFLOP/s four-wave -> eight-wave: 2048^3 54.0 -> 56.2, 8192^2 x 1024 66.6 -> 68.0, 16384^2 x 256
-    // 63.0 -> 65.4, 12288 x 4096 x 2048 67.4 -> 68.4; equal at 8192^3, 1 % behind at 4096^2 x 16384) - but not on the main stream
-    // inside the look-ahead LU, whose blocks must fit beside the update stream's (2 x 130 + 2 x 130 VGPRs per SIMD do not).
+    // eight-wave tile: on the look-ahead's update stream (one padded block per CU), and for every plain unguarded product
+    // (scripts/gemm_w8_ab.py, TFLOP/s four-wave -> eight-wave, both with the pipelined k loop: 4096^3 68.6 -> 71.9, 8192^3 69.5 ->
+    // 72.3, 4096^2 x 16384 68.8 -> 72.5, 8192^2 x 1024 68.4 -> 70.7, 12288 x 4096 x 2048 68.5 -> 71.4; equal at 2048^3 and at
+    // 16384^2 x 128 / 256: four pipelined waves per SIMD leave the matrix pipe fewer gaps than two) - but not on the main stream
+    // inside the look-ahead LU, whose blocks must fit beside the update stream's.
     // RMHIP_GEMM_W8: 0 never, 2 always (A/B).
     static int w8_mode = -1;
     if (w8_mode < 0) {
@@ -892,7 +893,7 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
         return RMHIP_OK;
     }
     if (fast_k && splits == 1 && !ep && !ta && !tb &&
-        ((w8_mode == 1 && (c->gemm_lds_pad != 0 || (!c->in_lookahead && k <= 2048))) || w8_mode == 2)) {
+        ((w8_mode == 1 && (c->gemm_lds_pad != 0 || !c->in_lookahead)) || w8_mode == 2)) {
         if (preload) {
             c->ensure_max_lds((const void*)k_dgemm_w8<true>, kMaxLds);
             hipLaunchKernelGGL(k_dgemm_w8<true>, dim3(blocks), dim3(512), lds_bytes, c->stream, g);
