@@ -581,7 +581,7 @@ def main() -> None:
                        "parallelism": f"row-block x{world}, B replicated, no collective"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": 157.3, "unit": "TFLOP/s",
                          "frac": round(achieved / 157.3, 4), "traffic": None,
-                         "kernel": "k_sgemm<false,false,false> (v_mfma_f32_16x16x4_f32)", "kernel_ms": round(kern_ms, 5)},
+                         "kernel": "k_sgemm_w8 (eight waves, pipelined k loop; v_mfma_f32_16x16x4_f32)", "kernel_ms": round(kern_ms, 5)},
         }
 
     records = {"sgemm": sgemm_record, "fused_f32": fused_f32_record, "fused": fused_record, "dgemm": dgemm_record, "mc": mc_record, "mldivide": mldivide_record,

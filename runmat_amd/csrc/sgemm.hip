@@ -212,6 +212,123 @@ __global__ void __launch_bounds__(256, SGEMM_BLOCKS_PER_CU) k_sgemm(const SgemmA
         }
 }
 
+// ---- eight-wave form of the 128 x 128 tile with the software-pipelined k loop (dgemm.hip: k_dgemm_w8) ---------------------------
+// 2 (m) x 4 (n) waves of 64 x 32; fragments of step kk+1 are read under step kk, the next tile is stashed during step 2 from
+// registers loaded two tiles earlier, ONE raw LDS-only barrier per tile before step 3, and step 3 already reads the next tile's
+// first fragments.  An f32 tile is 1024 MFMA cycles per wave, so the bubbles around the barrier weigh four times what they do in
+// the f64 kernel: with several pipelined waves per SIMD the matrix pipe stays fed.  Plain operands, unguarded shapes, one split.
+// Same k-ordered chain per element as k_sgemm: bit-identical results.
+__global__ void __launch_bounds__(512) k_sgemm_w8(const SgemmArgs g) {
+    using namespace sg;
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];
+    float* As = lds;
+    float* Bs = lds + 2 * TILE;
+    unsigned tm, tn;
+    sg_tile_of_block(g, tm, tn);
+    const unsigned m0 = tm * BM, n0 = tn * BN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;  // wn 0..3: 32 columns each
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int p_xp = t & 63, p_kc = t >> 6;  // A (pattern M): pair along m, k = p_kc + 8*p
+    const int q_kp = t & 7, q_y = t >> 3;    // B (pattern K): pair along k, y = q_y + 64*p
+    const float* const Ap = g.A + m0 + 2 * p_xp;
+    const float* const Bp = g.B + (size_t)n0 * g.ldb + 2 * q_kp;
+    v2f ra[2], rb[2], ra2[2], rb2[2];
+    auto fetch_into = [&](unsigned k0, v2f* pa, v2f* pb) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            pa[p] = *(const v2f*)(Ap + (size_t)(k0 + p_kc + 8 * p) * g.lda);
+            pb[p] = *(const v2f*)(Bp + (size_t)(q_y + 64 * p) * g.ldb + k0);
+        }
+    };
+    auto stash_from = [&](int buf, const v2f* pa, const v2f* pb) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            *(v2f*)(As + buf * TILE + (p_kc + 8 * p) * SA + 2 * p_xp) = pa[p];
+            *(v2f*)(Bs + buf * TILE + (q_y + 64 * p) * SB + 2 * q_kp) = pb[p];
+        }
+    };
+    v4f acc[2][4];  // [tj (n)][ti (m)]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = v4f{0.f, 0.f, 0.f, 0.f};
+    const unsigned ktiles = g.k / BK;
+    auto clampt = [&](unsigned tt) { return (tt < ktiles ? tt : ktiles - 1) * BK; };
+    fetch_into(0, ra, rb);
+    stash_from(0, ra, rb);
+    fetch_into(clampt(1), ra, rb);
+    fetch_into(clampt(2), ra2, rb2);
+    __syncthreads();
+    const int a_off = lq * SA + wm * 64 + l15;
+    const int b_off = (wn * 32 + l15) * SB + lq;
+    auto frags = [&](const float* a, const float* b, int kk, float (&af)[4], float (&bf)[2]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = a[kk * 4 * SA + i * 16];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j] = b[j * 16 * SB + kk * 4];
+    };
+    auto mma = [&](const float (&af)[4], const float (&bf)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[j][i], 0, 0, 0);
+    };
+    float af0[4], bf0[2], af1[4], bf1[2];
+    frags(As + a_off, Bs + b_off, 0, af0, bf0);
+    auto step = [&](unsigned kt, v2f* pa, v2f* pb) {
+        const int cur = kt & 1;
+        const float* a = As + cur * TILE + a_off;
+        const float* b = Bs + cur * TILE + b_off;
+        frags(a, b, 1, af1, bf1);
+        mma(af0, bf0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        frags(a, b, 2, af0, bf0);
+        mma(af1, bf1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        stash_from(cur ^ 1, pa, pb);  // tile kt + 1 (the last tiles stash / fetch a copy nobody reads: no branches here)
+        fetch_into(clampt(kt + 3), pa, pb);
+        frags(a, b, 3, af1, bf1);
+        mma(af0, bf0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        frags(As + (cur ^ 1) * TILE + a_off, Bs + (cur ^ 1) * TILE + b_off, 0, af0, bf0);
+        mma(af1, bf1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // the prefetched fragments are "used" here: the wait the compiler owes them lands behind these MFMAs
+        asm volatile("" : "+v"(af0[0]), "+v"(af0[1]), "+v"(af0[2]), "+v"(af0[3]), "+v"(bf0[0]), "+v"(bf0[1]));
+    };
+    for (unsigned kt = 0; kt < ktiles; kt += 2) {
+        step(kt, ra, rb);
+        if (kt + 1 < ktiles) step(kt + 1, ra2, rb2);
+    }
+    // D[r][c] -> C[m = c][n = r]; c = lane & 15, r = 4 * (lane >> 4) + reg
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned mm = m0 + wm * 64 + i * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned nn = n0 + wn * 32 + j * 16 + 4 * lq + r;
+                g.C[(size_t)nn * g.ldc + mm] = acc[j][i][r];
+            }
+        }
+}
+
 template <bool EDGE, bool TA, bool TB>
 static void sg_launch(Context* c, unsigned blocks, unsigned splits, const SgemmArgs& g) {
     hipLaunchKernelGGL((k_sgemm<EDGE, TA, TB>), dim3(blocks, splits), dim3(256), 0, c->stream, g);
@@ -279,7 +396,13 @@ int launch_sgemm_trans(Context* c, bool ta, bool tb, size_t m, size_t n, size_t 
         if (fast_k) sg_launch<false, false, true>(c, blocks, splits, g);
         else sg_launch<true, false, true>(c, blocks, splits, g);
     } else {
-        if (fast_k) sg_launch<false, false, false>(c, blocks, splits, g);
+        static int w8_mode = -1;  // RMHIP_SGEMM_W8=0: the four-wave kernel for everything (A/B)
+        if (w8_mode < 0) {
+            const char* v = std::getenv("RMHIP_SGEMM_W8");
+            w8_mode = (v && *v == '0') ? 0 : 1;
+        }
+        if (fast_k && splits == 1 && w8_mode) hipLaunchKernelGGL(k_sgemm_w8, dim3(blocks), dim3(512), 0, c->stream, g);
+        else if (fast_k) sg_launch<false, false, false>(c, blocks, splits, g);
         else sg_launch<true, false, false>(c, blocks, splits, g);
     }
     c->tel.kernel_launches++;
