@@ -521,30 +521,35 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
 // is there to issue MFMAs while the first waits - at the same 73.7 KiB of LDS and ~2 x 130 VGPRs per SIMD, which still
 // leaves room for a main-stream dgemm block beside it.  Plain operands, unguarded shapes only (m, n % 128, k % 16, even
 // leading dimensions, aligned bases); PRE as in k_dgemm.  Same k-ordered MFMA chain per element: bit-identical results.
-template <bool PRE>
+// TA / TB: the operand is stored transposed, as in k_dgemm (a transposed A is staged with B's pattern and vice versa).
+template <bool PRE, bool TA = false, bool TB = false>
 __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, const unsigned tn, double* As, double* Bs) {
     const unsigned m0 = tm * BM, n0 = tn * BN;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave & 1, wn = wave >> 1;  // wn 0..3: 32 columns each
     const int l15 = lane & 15, lq = lane >> 4;
-    const int p_xp = t & 63, p_kc = t >> 6;  // A (pattern M): pair along m, k = p_kc + 8*p
-    const int q_kp = t & 7, q_y = t >> 3;    // B (pattern K): pair along k, y = q_y + 64*p
-    const double* const Ap = g.A + m0 + 2 * p_xp;
-    const double* const Bp = g.B + (size_t)n0 * g.ldb + 2 * q_kp;
+    const int p_xp = t & 63, p_kc = t >> 6;  // pattern M (128 contiguous x 16 k): pair along the tile dimension, k = p_kc + 8*p
+    const int q_kp = t & 7, q_y = t >> 3;    // pattern K (k contiguous): pair along k, y = q_y + 64*p
+    // A: plain = pattern M on (m, k) with ld = lda; transposed (stored k x m... as At[k + m*lda]) = pattern K over rows m
+    const double* const Ap = TA ? g.A + (size_t)m0 * g.lda + 2 * q_kp : g.A + m0 + 2 * p_xp;
+    // B: plain = pattern K over rows n (B[k + n*ldb]); transposed (Bt[n + k*ldb]) = pattern M on (n, k)
+    const double* const Bp = TB ? g.B + n0 + 2 * p_xp : g.B + (size_t)n0 * g.ldb + 2 * q_kp;
     v2d ra[2], rb[2];
     auto fetch = [&](unsigned k0) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            ra[p] = *(const v2d*)(Ap + (size_t)(k0 + p_kc + 8 * p) * g.lda);
-            rb[p] = *(const v2d*)(Bp + (size_t)(q_y + 64 * p) * g.ldb + k0);
+            ra[p] = TA ? *(const v2d*)(Ap + (size_t)(q_y + 64 * p) * g.lda + k0) : *(const v2d*)(Ap + (size_t)(k0 + p_kc + 8 * p) * g.lda);
+            rb[p] = TB ? *(const v2d*)(Bp + (size_t)(k0 + p_kc + 8 * p) * g.ldb) : *(const v2d*)(Bp + (size_t)(q_y + 64 * p) * g.ldb + k0);
         }
     };
     auto stash = [&](int buf) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            *(v2d*)(As + buf * A_TILE + (p_kc + 8 * p) * SA + 2 * p_xp) = ra[p];
-            *(v2d*)(Bs + buf * B_TILE + (q_y + 64 * p) * SB + 2 * q_kp) = rb[p];
+            if (TA) *(v2d*)(As + buf * A_TILE + (q_y + 64 * p) * SB + 2 * q_kp) = ra[p];
+            else *(v2d*)(As + buf * A_TILE + (p_kc + 8 * p) * SA + 2 * p_xp) = ra[p];
+            if (TB) *(v2d*)(Bs + buf * B_TILE + (p_kc + 8 * p) * SA + 2 * p_xp) = rb[p];
+            else *(v2d*)(Bs + buf * B_TILE + (q_y + 64 * p) * SB + 2 * q_kp) = rb[p];
         }
     };
     v4d acc[2][4];  // [tj (n)][ti (m)]
@@ -567,8 +572,10 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
     fetch(0);
     stash(0);
     __syncthreads();
-    const int a_off = lq * SA + wm * 64 + l15;
-    const int b_off = (wn * 32 + l15) * SB + lq;
+    const int a_off = TA ? (wm * 64 + l15) * SB + lq : lq * SA + wm * 64 + l15;
+    const int b_off = TB ? lq * SA + wn * 32 + l15 : (wn * 32 + l15) * SB + lq;
+    constexpr int A_KSTEP = TA ? 4 : 4 * SA, A_ISTEP = TA ? 16 * SB : 16;
+    constexpr int B_KSTEP = TB ? 4 * SA : 4, B_JSTEP = TB ? 16 : 16 * SB;
 #if GEMM_PIPE_W8
     {
         // the software-pipelined k loop of k_dgemm (there: two blocks per CU fill each other's bubbles and it is worth 1 %; here all
@@ -579,9 +586,9 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
         // shares the SIMD - it spills and the solve takes 101.6 ms.)
         auto frags = [&](const double* a, const double* b, int kk, double (&af)[4], double (&bf)[2]) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = a[kk * 4 * SA + i * 16];
+            for (int i = 0; i < 4; ++i) af[i] = a[kk * A_KSTEP + i * A_ISTEP];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = b[j * 16 * SB + kk * 4];
+            for (int j = 0; j < 2; ++j) bf[j] = b[j * B_JSTEP + kk * B_KSTEP];
         };
         auto mma = [&](const double (&af)[4], const double (&bf)[2]) {
 #pragma unroll
@@ -639,9 +646,9 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
         for (int kk = 0; kk < BK / 4; ++kk) {
             double af[4], bf[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = a[kk * 4 * SA + i * 16];
+            for (int i = 0; i < 4; ++i) af[i] = a[kk * A_KSTEP + i * A_ISTEP];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = b[j * 16 * SB + kk * 4];
+            for (int j = 0; j < 2; ++j) bf[j] = b[j * B_JSTEP + kk * B_KSTEP];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -686,12 +693,12 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
 }
 
 
-template <bool PRE>
+template <bool PRE, bool TA = false, bool TB = false>
 __global__ void __launch_bounds__(512) k_dgemm_w8(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     unsigned tm, tn;
     tile_of_block(g, tm, tn);
-    w8_tile<PRE>(g, tm, tn, lds, lds + 2 * A_TILE);
+    w8_tile<PRE, TA, TB>(g, tm, tn, lds, lds + 2 * A_TILE);
 }
 
 // Persistent form for the look-ahead LU's late phase: one workgroup per CU, tiles handed out by a counter, and workgroups
@@ -888,6 +895,15 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
         const unsigned grid = (unsigned)c->num_cus < blocks ? (unsigned)c->num_cus : blocks;
         c->ensure_max_lds((const void*)k_dgemm_w8p, kMaxLds);
         hipLaunchKernelGGL(k_dgemm_w8p, dim3(grid), dim3(512), lds_bytes, c->stream, g);
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+        return RMHIP_OK;
+    }
+    if (fast_k && splits == 1 && !ep && ta && !tb && w8_mode != 0 && !c->in_lookahead && c->gemm_lds_pad == 0) {
+        // A' * B (transpose views, syrk, the Gram matrices of covariance and least squares): 70.7 -> 72.5 TFLOP/s at 8192^3 as
+        // well.  (A * B' measured 69.8 against 70.2 in this form and stays on k_dgemm.)
+        c->ensure_max_lds((const void*)k_dgemm_w8<false, true, false>, kMaxLds);
+        hipLaunchKernelGGL((k_dgemm_w8<false, true, false>), dim3(blocks), dim3(512), lds_bytes, c->stream, g);
         c->tel.kernel_launches++;
         RMHIP_HIP_CHECK(hipGetLastError());
         return RMHIP_OK;
