@@ -1054,9 +1054,141 @@ __global__ void __launch_bounds__(TRSM_THREADS) k_trsm_fused(const double* __res
     }
 }
 
+// Unit-lower solve of 65..128 columns of T in TWO passes with half the LDS (64 x 129 doubles = 66 KiB instead of 132): pass 1
+// stages T[:, 0:64] and runs steps 0..63 for every right-hand side of the block (x[0:64] final, x[64:128] partially updated, both
+// written back), pass 2 stages the lower-right triangle into the same buffer and runs steps 64..w-1.  Per element the same
+// operations in the same order as k_trsm_fused<0>: identical results.  At 66 KiB the block fits beside an update-stream dgemm
+// block (84 KiB) instead of waiting for a whole CU - and keeping the dgemm off that CU while it runs.
+template <int TRSM_NC, int TRSM_THREADS>
+__global__ void __launch_bounds__(TRSM_THREADS) k_trsm_lower_2p(const double* __restrict__ T, size_t ldt, int w, double* __restrict__ B,
+                                                                size_t ldb, size_t ncols) {
+    extern __shared__ double Ts[];  // [64][sw]
+    constexpr int sw = TRSM_W + 1;
+    const int i = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * TRSM_THREADS + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * TRSM_THREADS) >> 6;
+    // ---- pass 1: columns 0..63 of T, rows 0..w-1
+    for (int base = 0; base < 64 * TRSM_W; base += 8 * TRSM_THREADS) {
+        double stage[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * TRSM_THREADS + (int)threadIdx.x;
+            const int r = idx & (TRSM_W - 1), k = idx / TRSM_W;
+            stage[u] = (k < 64 && r < w && r > k) ? T[r + (size_t)k * ldt] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * TRSM_THREADS + (int)threadIdx.x;
+            const int r = idx & (TRSM_W - 1), k = idx / TRSM_W;
+            if (k < 64) Ts[k * sw + r] = stage[u];
+        }
+    }
+    __syncthreads();
+    for (size_t it = 0;; ++it) {
+        const size_t c0 = (wave + it * nwaves) * TRSM_NC;
+        if (c0 >= ncols) break;
+        double x0[TRSM_NC], x1[TRSM_NC];
+#pragma unroll
+        for (int j = 0; j < TRSM_NC; ++j) {
+            const bool live = c0 + j < ncols;
+            x0[j] = live ? B[(c0 + j) * ldb + i] : 0.0;
+            x1[j] = (live && 64 + i < w) ? B[(c0 + j) * ldb + 64 + i] : 0.0;
+        }
+#pragma unroll 1
+        for (int kb = 0; kb < 64; kb += 4) {
+            double l0[4], l1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                l0[u] = Ts[(kb + u) * sw + i];
+                l1[u] = Ts[(kb + u) * sw + 64 + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = kb + u;
+#pragma unroll
+                for (int j = 0; j < TRSM_NC; ++j) {
+                    const double xk = bcast_lane(x0[j], k);  // final x_k
+                    const double u0 = x0[j] - l0[u] * xk;
+                    x0[j] = i > k ? u0 : x0[j];
+                    x1[j] = x1[j] - l1[u] * xk;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TRSM_NC; ++j) {
+            if (c0 + j < ncols) {
+                B[(c0 + j) * ldb + i] = x0[j];
+                if (64 + i < w) B[(c0 + j) * ldb + 64 + i] = x1[j];
+            }
+        }
+    }
+    __syncthreads();  // every wave is done with the first half of T (and its partial x[64:] is on its way to memory)
+    // ---- pass 2: the lower-right triangle, Ts[k - 64][r - 64]
+    for (int base = 0; base < 64 * 64; base += 8 * TRSM_THREADS) {
+        double stage[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * TRSM_THREADS + (int)threadIdx.x;
+            const int r = 64 + (idx & 63), k = 64 + idx / 64;
+            stage[u] = (idx < 64 * 64 && k < w && r < w && r > k) ? T[r + (size_t)k * ldt] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * TRSM_THREADS + (int)threadIdx.x;
+            if (idx < 64 * 64) Ts[(idx / 64) * sw + (idx & 63)] = stage[u];
+        }
+    }
+    __syncthreads();
+    for (size_t it = 0;; ++it) {
+        const size_t c0 = (wave + it * nwaves) * TRSM_NC;
+        if (c0 >= ncols) break;
+        double x1[TRSM_NC];
+#pragma unroll
+        for (int j = 0; j < TRSM_NC; ++j) x1[j] = (c0 + j < ncols && 64 + i < w) ? B[(c0 + j) * ldb + 64 + i] : 0.0;  // this wave's own pass-1 stores
+#pragma unroll 1
+        for (int kb = 64; kb < w; kb += 4) {
+            double l1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = kb + u < w ? kb + u : w - 1;
+                l1[u] = Ts[(k - 64) * sw + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = kb + u;
+                if (k < w) {
+#pragma unroll
+                    for (int j = 0; j < TRSM_NC; ++j) {
+                        const double xk = bcast_lane(x1[j], k - 64);
+                        const double u1 = x1[j] - l1[u] * xk;
+                        x1[j] = 64 + i > k ? u1 : x1[j];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TRSM_NC; ++j)
+            if (c0 + j < ncols && 64 + i < w) B[(c0 + j) * ldb + 64 + i] = x1[j];
+    }
+}
+
 static int launch_check(Context* c);
 template <int MODE, int NC, int TRSM_THREADS>
 static int launch_trsm_fused_nc(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
+    // inside the look-ahead LU a 65..128-wide unit-lower solve takes the two-pass kernel (66 KiB: it shares CUs with the update
+    // stream's dgemm blocks; RMHIP_LU_TRSM_2P=0: the 132 KiB one-pass kernel everywhere)
+    static const int two_pass = std::getenv("RMHIP_LU_TRSM_2P") ? std::atoi(std::getenv("RMHIP_LU_TRSM_2P")) : 1;
+    if (MODE == 0 && w > 64 && c->in_lookahead && two_pass) {
+        const size_t lds2 = (size_t)64 * TRSM_SW * sizeof(double);
+        c->ensure_max_lds((const void*)k_trsm_lower_2p<NC, TRSM_THREADS>, lds2);
+        const size_t per_block2 = (size_t)(TRSM_THREADS / 64) * NC;
+        size_t want2 = (nc + per_block2 - 1) / per_block2;
+        const size_t cap2 = (size_t)c->num_cus * (two_pass > 1 ? (size_t)two_pass : 1);
+        if (want2 < 1) want2 = 1;
+        hipLaunchKernelGGL((k_trsm_lower_2p<NC, TRSM_THREADS>), dim3((unsigned)(want2 < cap2 ? want2 : cap2)), dim3(TRSM_THREADS), lds2,
+                           c->stream, T, ldt, (int)w, B, ldb, nc);
+        return launch_check(c);
+    }
     const size_t lds_bytes = w * (w > 64 ? (size_t)TRSM_SW : (size_t)65) * sizeof(double);
     c->ensure_max_lds((const void*)k_trsm_fused<MODE, NC, TRSM_THREADS>, TRSM_W * TRSM_SW * sizeof(double));
     const size_t per_block = (size_t)(TRSM_THREADS / 64) * NC;  // columns one block solves per pass
@@ -1395,7 +1527,8 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         c->gemm_avoid_xcc = s.panel_xcc;
     }
     // Split update (RMHIP_LU_SPLIT=0 disables): on the update stream the interchanges and triangular solves are 14 % of the
-    // throughput-bound first half, and the matrix cores idle meanwhile.  While more than split_rows rows remain the trailing
+    // throughput-bound first half, and the matrix cores idle meanwhile.  While more than split_rows rows remain (6144: into the
+    // beginning of the late phase; 8192 measured 0.5 ms slower at n = 16384 and 8192) the trailing
     // columns are cut at a fixed column csplit into A | B; a third stream prepares (interchange + solve) one part while the
     // update stream's dgemm runs on the other:
     //   prep:    wait(P_j, dgemm_{j-1}(A)) -> prep_j(A) -> wait(dgemm_{j-1}(B)) -> prep_j(B)
@@ -1404,7 +1537,7 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     // middle again (that one step waits for all of step j-1).  The main stream waits for dgemm_{j-1}(A) only - the next
     // panel's columns are its first ones - in either mode.  Same kernels on the same columns: bit-identical factors.
     static const int split_on = std::getenv("RMHIP_LU_SPLIT") ? std::atoi(std::getenv("RMHIP_LU_SPLIT")) : 1;
-    static const long split_rows_env = std::getenv("RMHIP_LU_SPLIT_ROWS") ? std::atol(std::getenv("RMHIP_LU_SPLIT_ROWS")) : 8192;
+    static const long split_rows_env = std::getenv("RMHIP_LU_SPLIT_ROWS") ? std::atol(std::getenv("RMHIP_LU_SPLIT_ROWS")) : 6144;
     static const int prep_base = std::getenv("RMHIP_LU_PREP_TRSM") ? std::atoi(std::getenv("RMHIP_LU_PREP_TRSM")) : 128;
     hipStream_t prep = nullptr;
     if (split_on) {
