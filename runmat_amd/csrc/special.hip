@@ -37,10 +37,11 @@ struct VecT<T, 1> {
 };
 template <class T, int VEC>
 __device__ __forceinline__ void load_vec(const T* __restrict__ x, size_t vi, double (&out)[VEC]) {
+    // streamed once per pass: non-temporal, as in the fused elementwise kernels (worth 5 % on loads, 10 % on stores there)
     if constexpr (VEC == 1) {
-        out[0] = (double)x[vi];
+        out[0] = (double)__builtin_nontemporal_load(x + vi);
     } else {
-        const typename VecT<T, VEC>::type v = *((const typename VecT<T, VEC>::type*)x + vi);
+        const typename VecT<T, VEC>::type v = __builtin_nontemporal_load((const typename VecT<T, VEC>::type*)x + vi);
 #pragma unroll
         for (int l = 0; l < VEC; ++l) out[l] = (double)v[l];
     }
@@ -193,12 +194,12 @@ __global__ void __launch_bounds__(IN_BLOCK) k_imgnorm_apply(const T* __restrict_
             v[l] = w;
         }
         if constexpr (VEC == 1) {
-            y[i] = (T)v[0];
+            __builtin_nontemporal_store((T)v[0], y + i);
         } else {
             typename VecT<T, VEC>::type r;
 #pragma unroll
             for (int l = 0; l < VEC; ++l) r[l] = (T)v[l];
-            *((typename VecT<T, VEC>::type*)y + i) = r;
+            __builtin_nontemporal_store(r, (typename VecT<T, VEC>::type*)y + i);
         }
     }
 }
