@@ -518,8 +518,8 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
 // to the main stream).  With k_dgemm that is one wave per SIMD, and every barrier, LDS refill and late global load of
 // the k loop is a bubble in the matrix pipe: 52-56 TFLOP/s alone against 62-65 with two blocks per CU.  Here the same
 // tile is computed by 2 (m) x 4 (n) waves of 64 x 32 each (64 accumulator registers instead of 128), so a second wave
-// is there to issue MFMAs while the first waits - at the same 73.7 KiB of LDS and ~2 x 130 VGPRs per SIMD, which still
-// leaves room for a main-stream dgemm block beside it.  Plain operands, unguarded shapes only (m, n % 128, k % 16, even
+// is there to issue MFMAs while the first waits - at the same 73.7 KiB of LDS and 125-147 VGPRs (two blocks of the plain
+// variant per CU).  Plain operands, unguarded shapes only (m, n % 128, k % 16, even
 // leading dimensions, aligned bases); PRE as in k_dgemm.  Same k-ordered MFMA chain per element: bit-identical results.
 // TA / TB: the operand is stored transposed, as in k_dgemm (a transposed A is staged with B's pattern and vice versa).
 template <bool PRE, bool TA = false, bool TB = false>
@@ -704,8 +704,8 @@ __global__ void __launch_bounds__(512) k_dgemm_w8(const GemmArgs g) {
 // Persistent form for the look-ahead LU's late phase: one workgroup per CU, tiles handed out by a counter, and workgroups
 // that find themselves on the XCD the panel kernel occupies (g.avoid_xcc, written by k_lu_panel2) leave at once - the
 // update then runs on the other seven XCDs and the panel's XCD keeps free CUs and a quiet L2 (lu.hip, getrf_blocked).
-// The plain beta path (118 VGPRs): two waves of it fit beside a 270-register panel wave on a SIMD, so a placeholder
-// workgroup can always be scheduled - and leave - on a CU the panel holds.
+// (Before the pipelined k loop this kernel had 118 VGPRs and a placeholder workgroup fitted beside a 270-register panel wave; at
+// 147 the ones dispatched to the panel's CUs start - and leave - when the panel block retires.  Measured: no difference.)
 __global__ void __launch_bounds__(512) k_dgemm_w8p(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ unsigned s_tile;
