@@ -21,7 +21,9 @@ moves each row block once to every peer; everything else is a few bytes.
 """
 from __future__ import annotations
 
+import functools
 import math
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -272,6 +274,21 @@ def monte_carlo_price_sharded(prov, group: Group, M: int, T: int, S0=100.0, mu=0
     return (total / float(M)) * math.exp(-mu * T * dt), final_state
 
 
+@functools.lru_cache(maxsize=64)
+def _mc_shaders(K: float) -> Tuple[str, str]:
+    """WGSL of the Monte-Carlo step (`S .* exp(drift + scale .* Z)`) and of the payoff reduction `sum(max(S - K, 0))`, as the
+    planner emits them once when it compiles the script's fusion groups."""
+    from .fusion import FusionGroupPlan
+
+    step = FusionGroupPlan()
+    v_s, v_z, v_scale, v_drift = step.input(), step.input(), step.input(), step.input()
+    out = step.primitive("ElemMul", v_s, step.builtin("exp", step.primitive("Add", v_drift, step.primitive("ElemMul", v_scale, v_z))))
+    red = FusionGroupPlan()
+    r_s = red.input()
+    payoff = red.builtin("max", red.primitive("Sub", r_s, red.constant(K)), red.constant(0.0))
+    return step.generate_wgsl_for_output(out, "f64"), red.generate_reduction_wgsl(payoff, "f64", axis=0)
+
+
 def monte_carlo_price_fused(prov, group: Group, M: int, T: int, S0=100.0, mu=0.05, sigma=0.2, dt=1.0 / 252.0, K=100.0,
                             rng_state: Optional[int] = None) -> Tuple[float, int]:
     """Same workload as `monte_carlo_price_sharded`, issued the way RunMat's planner would: one
@@ -291,14 +308,7 @@ def monte_carlo_price_fused(prov, group: Group, M: int, T: int, S0=100.0, mu=0.0
     scale = sigma * math.sqrt(dt)
     partial = 0.0
     if count > 0:
-        step = FusionGroupPlan()
-        v_s, v_z, v_scale, v_drift = step.input(), step.input(), step.input(), step.input()
-        out = step.primitive("ElemMul", v_s, step.builtin("exp", step.primitive("Add", v_drift, step.primitive("ElemMul", v_scale, v_z))))
-        step_shader = step.generate_wgsl_for_output(out, "f64")
-        red = FusionGroupPlan()
-        r_s = red.input()
-        payoff = red.builtin("max", red.primitive("Sub", r_s, red.constant(K)), red.constant(0.0))
-        red_shader = red.generate_reduction_wgsl(payoff, "f64", axis=0)
+        step_shader, red_shader = _mc_shaders(float(K))  # the plan is compiled once per script, not per call (fusion.rs:679-682)
         # constants are 1-element tensors created on the device (no host copy, no synchronisation); the initial price
         # S0 is one too and broadcasts into the first update (`S = S0 .* exp(...)`: the planner hands scalars to the
         # kernel as [1,1] inputs, fusion_exec.rs:279,305-326), so no M-element fill precedes the time loop
