@@ -23,7 +23,6 @@ from __future__ import annotations
 
 import functools
 import math
-import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
