@@ -411,6 +411,8 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
 // times the blocks with a quarter of the MFMAs per tile finish the same product in about a third of the time.
 // Plain operands only (no transposed views, no epilogue), m % 64 == n % 64 == 0, k % 16 == 0, 16-byte aligned bases
 // and even leading dimensions; everything else stays with k_dgemm.  Same LDS layouts and operand roles as k_dgemm.
+// (Tried: for k <= 128 request every operand tile before the first MFMA - one memory latency instead of one per tile.  8192 x 64 x 64
+// alone 7.2 -> 6.9 us, launch overhead dominates; inside the LU the 188 VGPRs it needs cost more than that: n = 8192 solve 34.6 -> 35.7 ms.)
 static constexpr int SM = 64, SN = 64;
 static constexpr int SSA = SM + 16;          // A tile [k][m] row stride (80 % 32 == 16: the bank-half trick of k_dgemm)
 static constexpr int S_A_TILE = BK * SSA;    // 1280 doubles
