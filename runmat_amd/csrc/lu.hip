@@ -1502,7 +1502,25 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     // main-stream triangular solves keep the 128-wide base: a 64-wide one (33 KiB of LDS) would fit beside an update
     // dgemm block instead of waiting for a CU to drain, but the extra launches cost more (140.7 vs 129.6 ms at
     // n = 16384; RMHIP_LU_LA_TRSM=64 selects it)
-    const int saved_trsm_base = c->trsm_base;
+    std::shared_ptr<Allocation> late_ctl;  // tile counters of the persistent kernels (outlives the guard below)
+    // the context fields this driver borrows go back on EVERY way out (an allocation or stream-creation failure below returns early),
+    // and nothing of this factorisation is still running when they do
+    struct Restore {
+        Context* c;
+        LuState* s;
+        int trsm_base;
+        ~Restore() {
+            if (c->lu_prep_stream) (void)hipStreamSynchronize(c->lu_prep_stream);
+            if (c->lu_side_stream) (void)hipStreamSynchronize(c->lu_side_stream);
+            c->gemm_tile_counters = nullptr;
+            c->gemm_avoid_xcc = nullptr;
+            c->gemm_counter_cap = 0;
+            s->panel_xcc = nullptr;
+            s->panel_pad_kb = -1;
+            c->in_lookahead = false;
+            c->trsm_base = trsm_base;
+        }
+    } restore{c, &s, c->trsm_base};
     if (const char* v = std::getenv("RMHIP_LU_LA_TRSM")) c->trsm_base = std::atoi(v) == 64 ? 64 : 128;
     c->in_lookahead = true;
     int rc = RMHIP_OK;
@@ -1514,7 +1532,6 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     // RMHIP_LU_LATE_XCD=0 disables.
     static const int late_xcd_on = std::getenv("RMHIP_LU_LATE_XCD") ? std::atoi(std::getenv("RMHIP_LU_LATE_XCD")) : 1;  // 2: persistent dgemm in every phase (A/B)
     constexpr size_t kCounters = 4096;
-    std::shared_ptr<Allocation> late_ctl;
     unsigned* late_counters = nullptr;
     if (late_xcd_on && c->one_xcd_ok) {
         RMHIP_TRY(c->alloc_device(kCounters / 2 + 8, &late_ctl));
@@ -1698,12 +1715,6 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     if (prep) (void)hipStreamSynchronize(prep);
     (void)hipStreamSynchronize(side);
     (void)hipStreamSynchronize(main_stream);
-    c->gemm_tile_counters = nullptr;
-    c->gemm_avoid_xcc = nullptr;
-    c->gemm_counter_cap = 0;
-    s.panel_xcc = nullptr;
-    c->in_lookahead = false;
-    c->trsm_base = saved_trsm_base;
     return rc;
 }
 
