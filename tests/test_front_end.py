@@ -380,3 +380,18 @@ def test_rust_shim_op_codes_are_the_header_enums():
     # every constant the hook tables use exists, and every hook name is a method of the reference trait's families
     used = set(re.findall(r"=>\s*(RMHIP_\w+)", shim)) | set(re.findall(r"self\.unary\((RMHIP_\w+)", shim))
     assert used <= set(consts), used - set(consts)
+
+
+def test_every_environment_knob_is_documented():
+    """Every RMHIP_* variable the library reads with getenv is named in INTEGRATION.md or DESIGN.md (developer knobs included:
+    a maintainer who meets one in a bug report must be able to look it up)."""
+    import re
+
+    src = ROOT / "runmat_amd" / "csrc"
+    knobs = set()
+    for f in list(src.glob("*.cpp")) + list(src.glob("*.hip")) + list(src.glob("*.h")):
+        knobs.update(re.findall(r'getenv\("(RMHIP_[A-Z0-9_]+)"\)', f.read_text()))
+    assert len(knobs) > 20
+    docs = (ROOT / "INTEGRATION.md").read_text() + (ROOT / "DESIGN.md").read_text()
+    missing = sorted(k for k in knobs if k not in docs)
+    assert not missing, f"undocumented environment variables: {missing}"
