@@ -311,16 +311,20 @@ def monte_carlo_price_fused(prov, group: Group, M: int, T: int, S0=100.0, mu=0.0
         # constants are 1-element tensors created on the device (no host copy, no synchronisation); the initial price
         # S0 is one too and broadcasts into the first update (`S = S0 .* exp(...)`: the planner hands scalars to the
         # kernel as [1,1] inputs, fusion_exec.rs:279,305-326), so no M-element fill precedes the time loop
-        h_scale = prov.fill((1, 1), scale)
-        h_drift = prov.fill((1, 1), drift)
-        S = prov.fill((1, 1), S0)
+        h_scale = h_drift = S = None
         for t in range(T):
             prov.set_rng_state(lcg_advance(rng_state, t * per_step + start))
             Z = prov.random_normal((count, 1))
+            if S is None:  # the three scalar fills are enqueued BEHIND the first randn: the host's work for them hides under that kernel
+                h_scale = prov.fill((1, 1), scale)
+                h_drift = prov.fill((1, 1), drift)
+                S = prov.fill((1, 1), S0)
             S_next = prov.fused_elementwise(step_shader, [S, Z, h_scale, h_drift], (count, 1), count)
             prov.free(Z)
             prov.free(S)
             S = S_next
+        if S is None:  # T == 0
+            h_scale, h_drift, S = prov.fill((1, 1), scale), prov.fill((1, 1), drift), prov.fill((count, 1), S0)
         psum = prov.fused_reduction(red_shader, [S], (1,), count, 1, 256, ReductionFlavor.Sum())
         partial = float(prov.download(psum)[0])
         for h in (S, psum, h_scale, h_drift):
