@@ -218,6 +218,7 @@ __global__ void __launch_bounds__(256, SGEMM_BLOCKS_PER_CU) k_sgemm(const SgemmA
 // first fragments.  An f32 tile is 1024 MFMA cycles per wave, so the bubbles around the barrier weigh four times what they do in
 // the f64 kernel: with several pipelined waves per SIMD the matrix pipe stays fed.  Plain operands, unguarded shapes, one split.
 // Same k-ordered chain per element as k_sgemm: bit-identical results.
+template <bool TA>  // TA: A is stored transposed (k contiguous per tile row), staged with B's pattern as in k_sgemm
 __global__ void __launch_bounds__(512) k_sgemm_w8(const SgemmArgs g) {
     using namespace sg;
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE];
@@ -231,20 +232,21 @@ __global__ void __launch_bounds__(512) k_sgemm_w8(const SgemmArgs g) {
     const int l15 = lane & 15, lq = lane >> 4;
     const int p_xp = t & 63, p_kc = t >> 6;  // A (pattern M): pair along m, k = p_kc + 8*p
     const int q_kp = t & 7, q_y = t >> 3;    // B (pattern K): pair along k, y = q_y + 64*p
-    const float* const Ap = g.A + m0 + 2 * p_xp;
+    const float* const Ap = TA ? g.A + (size_t)m0 * g.lda + 2 * q_kp : g.A + m0 + 2 * p_xp;
     const float* const Bp = g.B + (size_t)n0 * g.ldb + 2 * q_kp;
     v2f ra[2], rb[2], ra2[2], rb2[2];
     auto fetch_into = [&](unsigned k0, v2f* pa, v2f* pb) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            pa[p] = *(const v2f*)(Ap + (size_t)(k0 + p_kc + 8 * p) * g.lda);
+            pa[p] = TA ? *(const v2f*)(Ap + (size_t)(q_y + 64 * p) * g.lda + k0) : *(const v2f*)(Ap + (size_t)(k0 + p_kc + 8 * p) * g.lda);
             pb[p] = *(const v2f*)(Bp + (size_t)(q_y + 64 * p) * g.ldb + k0);
         }
     };
     auto stash_from = [&](int buf, const v2f* pa, const v2f* pb) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            *(v2f*)(As + buf * TILE + (p_kc + 8 * p) * SA + 2 * p_xp) = pa[p];
+            if (TA) *(v2f*)(As + buf * TILE + (q_y + 64 * p) * SB + 2 * q_kp) = pa[p];
+            else *(v2f*)(As + buf * TILE + (p_kc + 8 * p) * SA + 2 * p_xp) = pa[p];
             *(v2f*)(Bs + buf * TILE + (q_y + 64 * p) * SB + 2 * q_kp) = pb[p];
         }
     };
@@ -260,11 +262,12 @@ __global__ void __launch_bounds__(512) k_sgemm_w8(const SgemmArgs g) {
     fetch_into(clampt(1), ra, rb);
     fetch_into(clampt(2), ra2, rb2);
     __syncthreads();
-    const int a_off = lq * SA + wm * 64 + l15;
+    const int a_off = TA ? (wm * 64 + l15) * SB + lq : lq * SA + wm * 64 + l15;
     const int b_off = (wn * 32 + l15) * SB + lq;
+    constexpr int A_KSTEP = TA ? 4 : 4 * SA, A_ISTEP = TA ? 16 * SB : 16;
     auto frags = [&](const float* a, const float* b, int kk, float (&af)[4], float (&bf)[2]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = a[kk * 4 * SA + i * 16];
+        for (int i = 0; i < 4; ++i) af[i] = a[kk * A_KSTEP + i * A_ISTEP];
 #pragma unroll
         for (int j = 0; j < 2; ++j) bf[j] = b[j * 16 * SB + kk * 4];
     };
@@ -390,7 +393,9 @@ int launch_sgemm_trans(Context* c, bool ta, bool tb, size_t m, size_t n, size_t 
     }
     const bool fast_k = fast && (splits == 1 || k % g.k_chunk == 0);
     if (ta) {
-        if (fast_k) sg_launch<false, true, false>(c, blocks, splits, g);
+        if (fast_k && splits == 1 && !(std::getenv("RMHIP_SGEMM_W8") && *std::getenv("RMHIP_SGEMM_W8") == '0'))
+            hipLaunchKernelGGL(k_sgemm_w8<true>, dim3(blocks), dim3(512), 0, c->stream, g);  // A' * B (syrk, covariance, transpose views)
+        else if (fast_k) sg_launch<false, true, false>(c, blocks, splits, g);
         else sg_launch<true, true, false>(c, blocks, splits, g);
     } else if (tb) {
         if (fast_k) sg_launch<false, false, true>(c, blocks, splits, g);
@@ -401,7 +406,7 @@ int launch_sgemm_trans(Context* c, bool ta, bool tb, size_t m, size_t n, size_t 
             const char* v = std::getenv("RMHIP_SGEMM_W8");
             w8_mode = (v && *v == '0') ? 0 : 1;
         }
-        if (fast_k && splits == 1 && w8_mode) hipLaunchKernelGGL(k_sgemm_w8, dim3(blocks), dim3(512), 0, c->stream, g);
+        if (fast_k && splits == 1 && w8_mode) hipLaunchKernelGGL(k_sgemm_w8<false>, dim3(blocks), dim3(512), 0, c->stream, g);
         else if (fast_k) sg_launch<false, false, false>(c, blocks, splits, g);
         else sg_launch<true, false, false>(c, blocks, splits, g);
     }
