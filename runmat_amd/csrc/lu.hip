@@ -1584,7 +1584,7 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     // third tier (RMHIP_LU_NB_LATE / RMHIP_LU_LATE_ROWS): once the panel chain is the critical path, a narrower panel
     // moves more of each update from the main stream (look-ahead columns) to the idle update stream
     // (n = 16384, interleaved: 123.1 / 124.2 ms without, 120.8 / 120.6 with 128 below 6144 rows; 64 below 3072: 122.9 / 121.6)
-    size_t nb_late = 128, late_rows = 6144;
+    size_t nb_late = 128, late_rows = 8192;  // (8192 since the two-pass solve and the third stream: 98.4 vs 99.1 ms at n = 16384; 6144 before)
     if (const char* v = std::getenv("RMHIP_LU_NB_LATE")) nb_late = (size_t)std::atoll(v);
     if (const char* v = std::getenv("RMHIP_LU_LATE_ROWS")) late_rows = (size_t)std::atoll(v);
     nb_late = nb_late < 64 ? 64 : (nb_late / 64) * 64;

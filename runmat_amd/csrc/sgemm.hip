@@ -218,6 +218,8 @@ __global__ void __launch_bounds__(256, SGEMM_BLOCKS_PER_CU) k_sgemm(const SgemmA
 // first fragments.  An f32 tile is 1024 MFMA cycles per wave, so the bubbles around the barrier weigh four times what they do in
 // the f64 kernel: with several pipelined waves per SIMD the matrix pipe stays fed.  Plain operands, unguarded shapes, one split.
 // Same k-ordered chain per element as k_sgemm: bit-identical results.
+// (86 VGPRs: five waves per SIMD by registers, four - two blocks per CU - by LDS.  Capped at 80 for a third block it spills and
+// runs 122 instead of 136 TFLOP/s.)
 template <bool TA>  // TA: A is stored transposed (k contiguous per tile row), staged with B's pattern as in k_sgemm
 __global__ void __launch_bounds__(512) k_sgemm_w8(const SgemmArgs g) {
     using namespace sg;
