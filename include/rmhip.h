@@ -70,6 +70,10 @@ typedef struct rmhip_device_info {
     int precision_bits;     /* 64 / 32: ProviderPrecision::F64 / F32 (lib.rs:815-818)          */
     uint32_t reduction_workgroup_size; /* default_reduction_workgroup_size (lib.rs:3048)       */
     uint32_t two_pass_threshold;       /* two_pass_threshold (lib.rs:3053)                     */
+    char vendor[32];        /* ApiDeviceInfo::vendor (lib.rs:505-511): "AMD"                               */
+    char backend[32];       /* ApiDeviceInfo::backend: "hip"                                                */
+    int xcd_count;          /* accelerator dies the workgroup dispatcher interleaves over (8 on an MI355X in SPX mode, 1 in CPX),
+                               probed at init; the LU's one-XCD placement and XCD-avoiding update kernels need exactly 8    */
 } rmhip_device_info_t;
 RMHIP_API int rmhip_device_info(rmhip_ctx* ctx, rmhip_device_info_t* out);
 
@@ -413,6 +417,21 @@ typedef struct rmhip_kernel_launch {
     rmhip_kernel_attr_t tuning[6];
 } rmhip_kernel_launch_t;
 RMHIP_API int rmhip_telemetry_kernel_launch(rmhip_ctx* ctx, size_t index, rmhip_kernel_launch_t* out);
+
+/* Counters of the LU / solve machinery (no counterpart in the reference, whose GPU solve is a host round trip,
+ * backend/wgpu/provider/ops/solve.rs:144-168).  They are what telemetry.solve_fallbacks cannot say: a solve that was
+ * answered on the device but not on its first attempt. */
+typedef struct rmhip_lu_stats {
+    uint64_t solve_path_factorizations; /* mldivide / linsolve / mrdivide factorisations accepted with pivoting restricted to the panels' top blocks */
+    uint64_t pivot_growth_fallbacks;    /* ... refactored with the grid-wide pivot rule: a multiplier exceeded tau (also in solve_fallbacks as "lu:pivot_growth") */
+    uint64_t panel_exchange_timeouts;   /* persistent panel: a bounded spin expired (workgroups not co-resident), matrix refactored on the next, more conservative path */
+    uint64_t subst_chain_timeouts;      /* one-launch substitution timed out, repeated as one launch per block */
+    double last_max_multiplier;         /* largest |l| below a top block in the last solve-path factorisation */
+    double tau;                         /* the bound it is checked against (RMHIP_LU_TAU, default 8) */
+    int one_xcd_panels;                 /* 1 while panels of <= 32 workgroups are placed on one XCD */
+    int conservative_panels;            /* 1 once the context fell back to one launch per column */
+} rmhip_lu_stats_t;
+RMHIP_API int rmhip_lu_stats(rmhip_ctx* ctx, rmhip_lu_stats_t* out);
 
 /* HIP-event timing on the context stream (for bench.py's roofline leg): begin records an event,
  * end records another, synchronizes and returns the elapsed milliseconds between them. */

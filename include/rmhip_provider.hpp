@@ -86,6 +86,11 @@ public:
         check(rmhip_telemetry(ctx_, &t));
         return t;
     }
+    rmhip_lu_stats_t lu_stats() const {  // solve-path factorisations, pivot-growth refactorisations, time-outs
+        rmhip_lu_stats_t st;
+        check(rmhip_lu_stats(ctx_, &st));
+        return st;
+    }
 
     // ---- memory (lib.rs:1387-1389, 1468-1522) ----
     GpuTensorHandle upload(const HostTensorView& host) const {

@@ -32,6 +32,9 @@ class DeviceInfo(C.Structure):
         ("precision_bits", C.c_int),
         ("reduction_workgroup_size", C.c_uint32),
         ("two_pass_threshold", C.c_uint32),
+        ("vendor", C.c_char * 32),
+        ("backend", C.c_char * 32),
+        ("xcd_count", C.c_int),
     ]
 
 
@@ -41,6 +44,14 @@ class Telemetry(C.Structure):
         "matmul_count", "matmul_ns", "mldivide_count", "mldivide_ns", "upload_bytes", "download_bytes",
         "fusion_cache_hits", "fusion_cache_misses", "kernel_launches", "bytes_allocated", "bytes_pooled",
         "linsolve_count", "linsolve_ns", "mrdivide_count", "mrdivide_ns")]
+
+
+class LuStats(C.Structure):
+    """rmhip_lu_stats_t"""
+    _fields_ = [("solve_path_factorizations", C.c_uint64), ("pivot_growth_fallbacks", C.c_uint64),
+                ("panel_exchange_timeouts", C.c_uint64), ("subst_chain_timeouts", C.c_uint64),
+                ("last_max_multiplier", C.c_double), ("tau", C.c_double), ("one_xcd_panels", C.c_int),
+                ("conservative_panels", C.c_int)]
 
 
 class KernelAttr(C.Structure):
@@ -160,6 +171,7 @@ SIGNATURES = {
     "rmhip_reset_telemetry": (C.c_int, [_P]),
     "rmhip_telemetry_solve_fallback": (C.c_int, [_P, _SZ, C.c_char_p, _SZ, C.POINTER(C.c_uint64)]),
     "rmhip_telemetry_kernel_launch": (C.c_int, [_P, _SZ, C.POINTER(KernelLaunch)]),
+    "rmhip_lu_stats": (C.c_int, [_P, C.POINTER(LuStats)]),
     "rmhip_timer_begin": (C.c_int, [_P]),
     "rmhip_timer_end": (C.c_int, [_P, _DP]),
 }

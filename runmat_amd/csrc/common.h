@@ -164,6 +164,11 @@ struct Context {
     bool subst_chain_failed = false;  // the one-launch substitution timed out once: keep the launch-per-block form
     bool one_xcd_ok = true;  // LU panels may place their blocks on one XCD (cleared when such a panel timed out once)
     bool lu_used_one_xcd = false;
+    double lu_last_growth = 0.0;       // largest multiplier the last solve-path factorisation saw below its top blocks
+    uint64_t lu_fast_count = 0, lu_growth_fallbacks = 0;  // solve-path factorisations accepted / refactored with the grid-wide rule
+    uint64_t lu_exchange_timeouts = 0, lu_subst_timeouts = 0;
+    double lu_tau = 8.0;
+    int num_xcc = 8;  // accelerator dies the dispatcher interleaves workgroups over (probed at init; 1 on a CPX partition)
     // 64 or 32 (rmhip_set_precision).  At 32 every op output is stored as f32: kernels with a native f32-storage variant
     // (fused elementwise / reduction, per-op elementwise, reductions, dot) read and write f32 directly, every other op
     // runs its f64 kernel on widened temporaries and the entry point narrows what it created on return (NarrowScope).
@@ -300,9 +305,10 @@ int launch_stochastic_evolution(Context* c, uint64_t state, const double* in, do
 // LU / solve (lu.hip)
 // internal status of lu_factor_device: the matrix is clobbered, refactor a fresh copy (c->lu_conservative is now set)
 static constexpr int RMHIP_LU_RETRY = -77;
+static constexpr int RMHIP_LU_GROWTH = -79;  // internal status of lu_factor_device (mode 1): a multiplier exceeded the bound, refactor a fresh copy in mode 0
 static constexpr int RMHIP_SUBST_RETRY = -78;  // internal status of substitute_few_rhs: the chain kernel timed out, gather the right-hand side again
 int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda, int* perm_dev,
-                     int* info_host, std::vector<int>* ipiv_host = nullptr);
+                     int* info_host, std::vector<int>* ipiv_host = nullptr, int mode = 0);
 int lu_swap_rows_device(Context* c, double* A, size_t lda, size_t ncols, const std::vector<int>& ipiv);
 int trsm_lower_unit_device(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc);
 int trsm_upper_device(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc);

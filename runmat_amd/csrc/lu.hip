@@ -13,6 +13,7 @@
 // Every flop outside the <=64-column base panels runs in launch_dgemm (dgemm.hip) with K equal to
 // the half-width, so the top levels (where the flops are) see K in the thousands.
 // Triangular solves recurse the same way down to a 32x32 substitution kernel.
+#include <cstring>
 #include <unordered_map>
 #include <vector>
 
@@ -47,6 +48,12 @@ struct LuState {
     unsigned long long* xdbg;  // device [16] phase ticks (RMHIP_LU_PANEL_DEBUG=1) or nullptr
     long panel_pad_kb = -1;    // extra LDS a panel block asks for (-1: the default, see getrf_rec)
     int* panel_xcc = nullptr;  // device word: the XCD of the last one-XCD panel (-1 otherwise)
+    // solve path (k_lu_panel2<SOLO> + k_rp_below): pivoting restricted to the panel's top block, multipliers checked against tau
+    bool fast = false;
+    double tau = 8.0;
+    double* ucomp = nullptr;              // device [BASE_W][BASE_W]: the pivot rows of the panel in flight
+    unsigned long long* growth = nullptr; // device: bits of the largest multiplier below the top block so far
+    bool screened = false;                // the first panel's multipliers were checked on the host (early way out)
 };
 
 static constexpr int MAX_PANEL_BLOCKS = 1024;  // 64 rows per block => up to 65536 rows per panel
@@ -386,6 +393,7 @@ struct P2Args {
     int2* plist;    // this panel's row-move list (PLIST entries)
     pk_u64* dbg;
     int* xcc_out;   // receives the XCD the panel sits on (one-XCD placement) or -1; read by the update stream's persistent dgemm
+    double* ucomp;  // SOLO: [BASE_W][BASE_W] compact TRANSPOSED copy of the pivot rows (ucomp[c][k] = U[k][c]) for k_rp_below
 };
 
 // 16-byte exchange granules: one write-through (sc1) store / one L1-bypassing load; each 8-byte half is self-describing,
@@ -451,7 +459,11 @@ struct P2Ticks {  // developer instrumentation (RMHIP_LU_PANEL_DEBUG=1): 100 MHz
 // p2_select<NS>: pick and publish the block's candidate for column kn (its values sit in window slot NS), then - after
 // `rest` ran (the elimination the exchange hides) - collect every block's candidate and leave the winner in
 // s_ctl / cand.  FIX: the parked row still needs pivot row kn-1 (factor in its slot NS-1) applied beyond column kn.
-template <int NS, bool FIX, bool DBG, class Rest>
+//
+// SOLO (the solve path's panel, see k_rp_below): the grid is ONE workgroup over the top P2_ROWS rows of the panel, so the block's
+// candidate IS the pivot.  Wave 0 writes the winner's row (with the pending update applied) straight into the other one of two
+// LDS slots - the slot of pivot row kn-1 is still being read by `rest` - and nothing goes through memory.
+template <int NS, bool FIX, bool DBG, bool SOLO, class Rest>
 __device__ __forceinline__ bool p2_select(const P2Args& g, const P2Lds& L, double (&a)[BASE_W + 4], const int pos, const int jj, const int kn,
                                          const int fix_skip, const double* fix_row, P2Ticks* ticks, Rest rest) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -499,9 +511,27 @@ __device__ __forceinline__ bool p2_select(const P2Args& g, const P2Lds& L, doubl
         const pk_u64 bk = bl < 0 ? 0 : (pk_u64)__double_as_longlong(bkd);
         const int bw = bl < 0 ? 0 : bl;
         const int bt = L.r_t[bw];
+        if (SOLO) {
+            const int sel = kn & 1;
+            if (lane >= kn && lane < g.w) {
+                double v = L.rowbuf[bw * P2_RB + lane];
+                if (FIX && !fix_skip && lane > kn) {
+                    const double fw = L.rowbuf[bw * P2_RB + kn - 1];  // the row's multiplier for pivot row kn-1
+                    const double prod = fw * fix_row[lane];
+                    v = v - prod;
+                }
+                L.cand[sel * BASE_W + lane] = v;
+            }
+            if (lane == 0) {
+                L.s_ctl[0] = bl < 0 ? -1 : g.j0 + bt;
+                L.s_ctl[1] = (int)bp;
+                L.s_ctl[2] = (L.s_ctl[2] & 2) | ((bkd <= LU_EPS || bl < 0) ? 1 : 0) | (sel << 8);
+            }
+            P2_TICK(2)
+        }
         const size_t slot = (size_t)par * PK_MAXB + blk;
-        if (lane == 0) st_granule(g.xrec + slot * 2, bk | fresh, (pk_u64)bp | ((pk_u64)(unsigned)bt << 32) | fresh, local);
-        if (lane >= kn && lane < g.w) {
+        if (!SOLO && lane == 0) st_granule(g.xrec + slot * 2, bk | fresh, (pk_u64)bp | ((pk_u64)(unsigned)bt << 32) | fresh, local);
+        if (!SOLO && lane >= kn && lane < g.w) {
             double v = L.rowbuf[bw * P2_RB + lane];
             if (FIX && !fix_skip && lane > kn) {
                 const double fw = L.rowbuf[bw * P2_RB + kn - 1];  // the row's multiplier for pivot row kn-1
@@ -511,10 +541,15 @@ __device__ __forceinline__ bool p2_select(const P2Args& g, const P2Lds& L, doubl
             const pk_u64 bits = (pk_u64)__double_as_longlong(v);
             st_granule(g.xvals + (slot * BASE_W + lane) * 2, (bits & 0xffffffffull) | vtag, (bits >> 32) | vtag, local);
         }
-        P2_TICK(2)  // publish
+        if (!SOLO) P2_TICK(2)  // publish
     }
     rest();
     P2_TICK(6)  // elimination under the exchange
+    if (SOLO) {
+        __syncthreads();
+        P2_TICK(5)
+        return true;
+    }
     if (FIX) __syncthreads();  // every wave is done with the previous pivot row in `cand`
     const bool onehop = g.nblocks <= g.onehop_max;
     int bad = 0;
@@ -660,7 +695,7 @@ __device__ __forceinline__ void p2_update(double (&a)[BASE_W + 4], const double 
 
 // one column (k = 4*jj + KK, window slot KK): its pivot is in s_ctl / cand; retire / displace rows, form the
 // multipliers, update column k+1, run the selection for k+1 with the bulk elimination under its exchange.
-template <int KK, bool DBG>
+template <int KK, bool DBG, bool SOLO>
 __device__ __forceinline__ bool p2_column(const P2Args& g, const P2Lds& L, double (&a)[BASE_W + 4], int& pos, int& retk, int& rpiv,
                                          const int jj, const size_t r, P2Ticks* ticks) {
     const int k = 4 * jj + KK;
@@ -696,10 +731,10 @@ __device__ __forceinline__ bool p2_column(const P2Args& g, const P2Lds& L, doubl
         const double prod = factor * pr[KK + 1];
         a[KK + 1] = a[KK + 1] - prod;
     }
-    return p2_select<KK + 1, true, DBG>(g, L, a, pos, jj, k + 1, skip, L.cand + (flags >> 8) * BASE_W, ticks, rest);
+    return p2_select<KK + 1, true, DBG, SOLO>(g, L, a, pos, jj, k + 1, skip, L.cand + (flags >> 8) * BASE_W, ticks, rest);
 }
 
-template <bool DBG>
+template <bool DBG, bool SOLO>
 __global__ void __launch_bounds__(P2_THREADS) k_lu_panel2(const P2Args g) {
     extern __shared__ double p2_lds[];
     __shared__ double r_key[P2_WAVES];
@@ -724,7 +759,7 @@ __global__ void __launch_bounds__(P2_THREADS) k_lu_panel2(const P2Args g) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && g.xcc_out) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        *g.xcc_out = g.bstride > 1 ? (int)(xcc & 0xf) : -1;
+        *g.xcc_out = (SOLO || g.bstride > 1) ? (int)(xcc & 0xf) : -1;
     }
     const int t = threadIdx.x;  // row slot
     const size_t r = (size_t)g.j0 + (size_t)(blockIdx.x / g.bstride) * P2_ROWS + t;
@@ -740,19 +775,24 @@ __global__ void __launch_bounds__(P2_THREADS) k_lu_panel2(const P2Args g) {
     __syncthreads();
     P2_TICK(0)  // load
     // pivot of column 0: nothing to hide, nothing to fix up
-    if (!p2_select<0, false, DBG>(g, L, a, pos, 0, 0, 1, L.cand, ticks, [] {})) return;
+    if (!p2_select<0, false, DBG, SOLO>(g, L, a, pos, 0, 0, 1, L.cand, ticks, [] {})) return;
     const int ngroups = (g.w + 3) >> 2;
     for (int jj = 0; jj < ngroups; ++jj) {
-        if (!p2_column<0, DBG>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
-        if (4 * jj + 1 < g.w && !p2_column<1, DBG>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
-        if (4 * jj + 2 < g.w && !p2_column<2, DBG>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
-        if (4 * jj + 3 < g.w && !p2_column<3, DBG>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
+        if (!p2_column<0, DBG, SOLO>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
+        if (4 * jj + 1 < g.w && !p2_column<1, DBG, SOLO>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
+        if (4 * jj + 2 < g.w && !p2_column<2, DBG, SOLO>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
+        if (4 * jj + 3 < g.w && !p2_column<3, DBG, SOLO>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
         // columns 4jj .. 4jj+3 are final (multipliers, or the U values of a retired row): store them where the row was
         // loaded from - nobody reads the panel's columns before the kernel ends - and shift the register window by four
         if (in_rows) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (4 * jj + i < g.w) g.A[r + (size_t)(g.j0 + 4 * jj + i) * g.lda] = a[i];
+            if (SOLO && retk >= 0) {  // a retired row is row retk of U: its values from column retk on are final
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (4 * jj + i < g.w) g.ucomp[(4 * jj + i) * BASE_W + retk] = a[i];  // transposed: [column][pivot row]
+            }
         }
 #pragma unroll
         for (int i = 0; i < BASE_W; ++i) a[i] = a[i + 4];
@@ -782,6 +822,92 @@ __global__ void __launch_bounds__(P2_THREADS) k_lu_panel2(const P2Args g) {
     }
 }
 #undef P2_TICK
+
+// ---- solve path (`mldivide` / `linsolve` / `mrdivide`): panel with pivoting RESTRICTED to the top block ----------------------------
+// The reference's contract for a solve is the solution to a residual tolerance (mldivide.rs:380-404, tests :662-696); the pivot
+// sequence never leaves the provider there (it does for `lu`, which keeps k_lu_panel2's grid-wide first-maximum rule).  What the
+// grid-wide rule costs is one memory-system exchange per column (2.97-3.6 us x n columns, 59 of 98 ms at n = 16384).  On the solve
+// path a base panel is therefore factored like the LU step of the hybrid LU-QR algorithm (Faverge, Herrmann, Langou, Lowery, Robert,
+// Dongarra, "Designing LU-QR hybrid solvers for performance and stability", IPDPS 2014): partial pivoting inside the DIAGONAL DOMAIN -
+// the top P2_ROWS = 256 rows of the panel, one workgroup, k_lu_panel2<SOLO>, no exchange - and every row below becomes
+// l = a U11^-1 by substitution (this kernel, all rows in parallel), with their "Max criterion" as the guard: the factorisation is
+// accepted only if every multiplier satisfies |l| <= tau (threshold partial pivoting, tau = 8 by default; the sparse direct solvers'
+// usual threshold u = 0.1 corresponds to tau = 10).  The largest |l| is accumulated in *growth; a violation, a pivot at the
+// singular cut-off or a NaN makes lu_factor_device report RMHIP_LU_GROWTH and the caller refactors a fresh copy with the grid-wide
+// rule (counted in telemetry.solve_fallbacks as "lu:pivot_growth").  For matrices whose entries are not arranged to defeat it (random
+// dense, diagonally dominant, SPD Gram matrices) the 256 candidates hold an entry within a small factor of the column maximum: max|l|
+// measured 1.7-2.6 on U(-1,1) / N(0,1) matrices up to n = 8192, residuals equal to partial pivoting's (tests/test_gpu_solvepath.py).
+//
+// One thread per row, the row's w <= 64 panel values in registers; the loop is rolled over groups of eight columns with the register
+// window shifted by eight (static indices; straight-line code for all 64 steps would be 16 KiB executed once per launch on cold
+// instruction caches).
+static constexpr int RB_THREADS = 256;
+// `ut` is the TRANSPOSED compact copy k_lu_panel2<SOLO> leaves: ut[c * BASE_W + k] = U[k][c] (k <= c).  Every thread needs the same
+// value at the same time, so the operands are wave-uniform loads of read-only memory - scalar loads into SGPRs, the FMA's scalar
+// operand - and the kernel uses neither LDS nor a barrier (through LDS the operands would be bound by its 128 B/clk: one 8-byte operand
+// per FMA is four times what a CU's four SIMDs can be fed).  Per group of eight columns: the 8 x 8 triangle (36 operations), then ONE
+// pass over the window's live columns with the eight multipliers (eight chained FMAs per column) - written this way, not as eight
+// rank-1 sweeps, because the compiler sinks the FMAs of a sweep that nothing needs yet and keeps every operand alive (2 KiB of scratch).
+__global__ void __launch_bounds__(RB_THREADS) k_rp_below(double* __restrict__ A, const size_t lda, const size_t rows, const size_t r0,
+                                                         const int j0, const int w, const double* __restrict__ ut,
+                                                         pk_u64* __restrict__ growth, const double tau) {
+    const int t = threadIdx.x;
+    const size_t r = r0 + (size_t)blockIdx.x * RB_THREADS + t;
+    const bool live = r < rows;
+    double a[BASE_W];
+#pragma unroll
+    for (int c = 0; c < BASE_W; ++c) a[c] = (live && c < w) ? A[r + (size_t)(j0 + c) * lda] : 0.0;
+    double mx = 0.0;
+    int bad = 0;
+#pragma unroll 1
+    for (int it = 0; it < BASE_W / 8; ++it) {
+        const double* ud = ut + (size_t)(8 * it) * BASE_W + 8 * it;  // ud[i * BASE_W + kk] = U[8 it + kk][8 it + i]
+        double nx[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            // columns beyond w hold zeros here and whatever an earlier panel left in ut: their multiplier is 0 by definition
+            const double x = (8 * it + kk < w) ? a[kk] / ud[kk * BASE_W + kk] : 0.0;
+            a[kk] = x;
+            const double ax = fabs(x);
+            bad |= !(ax <= tau);
+            mx = fmax(mx, ax);
+            nx[kk] = -x;
+#pragma unroll
+            for (int i = kk + 1; i < 8; ++i) a[i] = __builtin_fma(nx[kk], ud[i * BASE_W + kk], a[i]);
+        }
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (8 * it + i < w) A[r + (size_t)(j0 + 8 * it + i) * lda] = a[i];
+        }
+#pragma unroll
+        for (int bch = 1; bch < BASE_W / 8; ++bch) {
+            if (it + bch < BASE_W / 8) {  // uniform: the window's tail beyond column 63 is dead
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = 8 * bch + q;
+                    const double* uc = ud + i * BASE_W;
+                    double v = a[i];
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) v = __builtin_fma(nx[kk], uc[kk], v);
+                    a[i] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BASE_W - 8; ++i) a[i] = a[i + 8];
+#pragma unroll
+        for (int i = BASE_W - 8; i < BASE_W; ++i) a[i] = 0.0;
+    }
+    // block maximum -> one atomic per wave that has something to report
+    if (!live) {
+        mx = 0.0;
+        bad = 0;
+    }
+    pk_u64 bits = bad ? 0x7ff8000000000000ull : (pk_u64)__double_as_longlong(mx);
+    bits = wave_max_u64(bits);
+    if ((t & 63) == 0 && bits != 0) atomicMax(growth, bits);
+}
 
 // Turn the lazy bookkeeping of one finished base panel [j0, c1) into a list of row moves
 // new[dst] = old[src]: position k receives the pivot row prow[k]; a top-block row that was not
@@ -1324,6 +1450,69 @@ static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller =
     if (w <= (size_t)BASE_W) {
         const size_t c1 = j0 + w;  // j0 + w <= min(rows, cols) always holds (see lu_factor_device)
         const size_t nbp = (s.rows - j0 + P2_ROWS - 1) / P2_ROWS;
+        if (s.fast && !(lu_skip_mask() & 1)) {
+            // solve path: ONE workgroup factors the top P2_ROWS rows with partial pivoting (no exchange), k_rp_below turns every row
+            // below into multipliers and records the largest one
+            const size_t pid = s.panel_start->size();
+            P2Args g;
+            g.A = s.A;
+            g.lda = s.lda;
+            g.rows = (s.rows - j0) > (size_t)P2_ROWS ? j0 + P2_ROWS : s.rows;
+            g.j0 = (int)j0;
+            g.w = (int)w;
+            g.nblocks = 1;
+            g.onehop_max = P2_ONEHOP_MAXB;
+            g.bstride = 1;
+            g.seq0 = s.xbase;
+            g.xerr = s.xerr;
+            g.xrec = s.xrec;
+            g.xvals = s.xvals;
+            g.prow_arr = s.prow;
+            g.ipiv = s.ipiv;
+            g.info = s.info;
+            g.plist = s.plist + pid * PLIST;
+            g.dbg = s.xdbg;
+            g.xcc_out = s.panel_xcc;
+            g.ucomp = s.ucomp;
+            static long pad_kb_solo = -1;  // as below: a panel block that shares its CU with a dgemm block runs every column step slower
+            if (pad_kb_solo < 0) {
+                const char* v = std::getenv("RMHIP_LU_PANEL_PAD_KB");
+                pad_kb_solo = v ? std::atol(v) : 64;
+                if (pad_kb_solo > 128) pad_kb_solo = 128;
+            }
+            const size_t lds_bytes = P2_LDS_DOUBLES * sizeof(double) + (size_t)(s.panel_pad_kb >= 0 ? s.panel_pad_kb : pad_kb_solo) * 1024;
+            if (lds_bytes > 65536) {
+                s.c->ensure_max_lds((const void*)k_lu_panel2<false, true>, lds_bytes);
+                s.c->ensure_max_lds((const void*)k_lu_panel2<true, true>, lds_bytes);
+            }
+            if (s.xdbg) hipLaunchKernelGGL((k_lu_panel2<true, true>), dim3(1), dim3(P2_THREADS), lds_bytes, s.c->stream, g);
+            else hipLaunchKernelGGL((k_lu_panel2<false, true>), dim3(1), dim3(P2_THREADS), lds_bytes, s.c->stream, g);
+            RMHIP_TRY(launch_check(s.c));
+            if (g.rows < s.rows) {
+                const size_t nbb = (s.rows - g.rows + RB_THREADS - 1) / RB_THREADS;
+                hipLaunchKernelGGL(k_rp_below, dim3((unsigned)nbb), dim3(RB_THREADS), 0, s.c->stream, s.A, s.lda, s.rows, (size_t)g.rows, (int)j0,
+                                   (int)w, (const double*)s.ucomp, (pk_u64*)s.growth, s.tau);
+                RMHIP_TRY(launch_check(s.c));
+            }
+            s.xbase += (unsigned)w;
+            s.panel_start->push_back(j0);
+            if (!s.screened) {
+                // Early way out: a matrix whose large entries lie outside the top block (a row-permuted diagonally dominant one, say)
+                // fails at its first panel; one small read here instead of a whole factorisation of wasted work.
+                s.screened = true;
+                unsigned long long bits = 0;
+                RMHIP_HIP_CHECK(hipMemcpyAsync(&bits, s.growth, sizeof(bits), hipMemcpyDeviceToHost, s.c->stream));
+                RMHIP_HIP_CHECK(hipStreamSynchronize(s.c->stream));
+                double gmax;
+                std::memcpy(&gmax, &bits, sizeof(gmax));
+                if (!(gmax <= s.tau)) return RMHIP_LU_GROWTH;
+            }
+            if (own_swaps_by_caller && deferred) {
+                *deferred = true;
+                return RMHIP_OK;
+            }
+            return laswp(s, j0, c1, j0, c1);  // the panel's own interchange
+        }
         if (s.persistent && nbp <= (size_t)PK_MAXB && nbp <= (size_t)s.c->num_cus && !(lu_skip_mask() & 1)) {
             // one launch factors the panel, interchanges its own columns and leaves the row-move list for the others
             const size_t pid = s.panel_start->size();
@@ -1368,12 +1557,13 @@ static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller =
             }
             const size_t lds_bytes = P2_LDS_DOUBLES * sizeof(double) + (size_t)(s.panel_pad_kb >= 0 ? s.panel_pad_kb : pad_kb) * 1024;
             if (lds_bytes > 65536) {
-                s.c->ensure_max_lds((const void*)k_lu_panel2<false>, lds_bytes);
-                s.c->ensure_max_lds((const void*)k_lu_panel2<true>, lds_bytes);
+                s.c->ensure_max_lds((const void*)k_lu_panel2<false, false>, lds_bytes);
+                s.c->ensure_max_lds((const void*)k_lu_panel2<true, false>, lds_bytes);
             }
             const unsigned grid = (unsigned)nbp * (unsigned)g.bstride;
-            if (s.xdbg) hipLaunchKernelGGL(k_lu_panel2<true>, dim3(grid), dim3(P2_THREADS), lds_bytes, s.c->stream, g);
-            else hipLaunchKernelGGL(k_lu_panel2<false>, dim3(grid), dim3(P2_THREADS), lds_bytes, s.c->stream, g);
+            g.ucomp = nullptr;
+            if (s.xdbg) hipLaunchKernelGGL((k_lu_panel2<true, false>), dim3(grid), dim3(P2_THREADS), lds_bytes, s.c->stream, g);
+            else hipLaunchKernelGGL((k_lu_panel2<false, false>), dim3(grid), dim3(P2_THREADS), lds_bytes, s.c->stream, g);
             RMHIP_TRY(launch_check(s.c));
             s.xbase += (unsigned)w;
             s.panel_start->push_back(j0);
@@ -1721,8 +1911,11 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
 // In-place LU of A (rows x cols, lda). perm_dev[rows] receives the row permutation as the
 // reference reports it (perm[k] = original row now at position k, host_lu.rs:50,107).
 // *info_host = number of pivots that hit the singular cut-off.
+// mode 0: the reference's pivot sequence (host_lu.rs:37-59: grid-wide first maximum) - `lu`, and the fallback of the solve path.
+// mode 1: solve path (pivots unobservable): pivoting restricted to each panel's top block, multipliers checked against tau
+//         (k_rp_below); RMHIP_LU_GROWTH when the check fails - the matrix is clobbered, the caller refactors a fresh copy in mode 0.
 int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda, int* perm_dev, int* info_host,
-                     std::vector<int>* ipiv_host) {
+                     std::vector<int>* ipiv_host, int mode) {
     const size_t kmin = rows < cols ? rows : cols;
     if (rows > 0x7fffffffULL || cols > 0x7fffffffULL) return fail(RMHIP_ERR_UNSUPPORTED, "lu: dimension exceeds 2^31");
     c->lu_used_one_xcd = false;
@@ -1741,7 +1934,8 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     const size_t off_xa = off_xvals + sizeof(unsigned long long) * 2 * PK_MAXB * BASE_W * 2;
     const size_t off_xb = off_xa + sizeof(unsigned long long) * 2 * PK_MAXB;
     const size_t off_xctl = off_xb + sizeof(unsigned long long) * 2 * PK_MAXB;
-    const size_t total = off_xctl + 64 + 16 * sizeof(unsigned long long);
+    const size_t off_ucomp = off_xctl + 64 + 16 * sizeof(unsigned long long);
+    const size_t total = off_ucomp + sizeof(double) * BASE_W * BASE_W;
     std::shared_ptr<Allocation> blk_mem;  // pooled: a hipMalloc / hipFree pair costs two device synchronisations per factorisation
     RMHIP_TRY(c->alloc_device(total / sizeof(double) + 2, &blk_mem));
     char* blk = (char*)blk_mem->ptr;
@@ -1762,6 +1956,13 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
         if ((pm && pm[0] == 'c') || c->lu_conservative) s.persistent = false;
         const char* dbgenv = std::getenv("RMHIP_LU_PANEL_DEBUG");
         if (dbgenv && dbgenv[0] == '1') s.xdbg = (unsigned long long*)(blk + off_xctl + 64);
+        // solve path: RMHIP_LU_FAST=0 keeps the grid-wide pivot rule everywhere; RMHIP_LU_TAU sets the multiplier bound (read per call: tests)
+        const char* fe = std::getenv("RMHIP_LU_FAST");
+        s.fast = mode == 1 && !(fe && fe[0] == '0') && s.persistent;
+        if (const char* tv = std::getenv("RMHIP_LU_TAU")) s.tau = std::atof(tv);
+        c->lu_tau = s.tau;
+        s.ucomp = (double*)(blk + off_ucomp);
+        s.growth = (unsigned long long*)(blk + off_xctl + 32);
     }
     // Panel width of the look-ahead driver and its threshold, from an interleaved sweep (scripts/lu_knobs.py, ms for
     // x = A\b): n = 6144: 38.7 without look-ahead, 33.6 with nb 128, 34.9 with 256, 36.8 with 512; 8192: 51.2 (nb 512)
@@ -1791,12 +1992,27 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     std::vector<int> h_ipiv(rows + 1, 0);
     if (rc == RMHIP_OK) {
         int h_xerr = 0;
+        unsigned long long h_growth = 0;
         e = hipMemcpyAsync(h_ipiv.data(), ipiv, sizeof(int) * (rows + 1), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(&h_xerr, s.xerr, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && s.fast) e = hipMemcpyAsync(&h_growth, s.growth, sizeof(h_growth), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) rc = fail(RMHIP_ERR_HIP, "lu: reading pivots: %s", hipGetErrorString(e));
+        if (e == hipSuccess && s.fast) {
+            double gmax;
+            std::memcpy(&gmax, &h_growth, sizeof(gmax));
+            c->lu_last_growth = gmax;
+            // a multiplier beyond tau, a NaN, or a pivot at the singular cut-off inside a top block (a larger entry may lie below it)
+            if (!(gmax <= s.tau) || h_ipiv[rows] > 0 || std::getenv("RMHIP_LU_TEST_GROWTH")) {
+                if (std::getenv("RMHIP_LU_VERBOSE"))
+                    std::fprintf(stderr, "[lu] solve path: max multiplier %.3g (tau %.3g), %d small pivot(s): refactoring with the grid-wide rule\n", gmax,
+                                 s.tau, h_ipiv[rows]);
+                return RMHIP_LU_GROWTH;
+            }
+        }
         if (!h_xerr && s.persistent && std::getenv("RMHIP_LU_TEST_RETRY")) h_xerr = 1;  // test hook for the retry path
         if (e == hipSuccess && h_xerr) {
+            c->lu_exchange_timeouts++;
             // bounded spins expired: the panel workgroups were not co-resident (device shared with another
             // context?).  The matrix is clobbered; callers holding the original refactor it conservatively.
             // A factorisation that placed panels on one XCD first gives that up (if the workgroup -> XCD assignment is not
@@ -2332,6 +2548,7 @@ static int substitute_few_rhs(Context* c, const double* LU, size_t n, size_t lda
         RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
         if (!h_err && std::getenv("RMHIP_LU_TEST_SUBST_RETRY")) h_err = 1;  // test hook for the fallback below
         if (!h_err) return RMHIP_OK;
+        c->lu_subst_timeouts++;
         c->subst_chain_failed = true;  // a spin timed out: X is clobbered, the caller gathers the right-hand side again
         return RMHIP_SUBST_RETRY;
     }

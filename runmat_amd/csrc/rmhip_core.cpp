@@ -287,6 +287,46 @@ struct rmhip_ctx {
     DeviceGuard _dg(c);                                                   \
     NarrowScope _ns(c)
 
+// Which XCD does workgroup b of a launch run on?  The LU places small panels on ONE XCD by launching 8x the grid and keeping
+// workgroups b % 8 == 0, and its late-phase update kernels leave the panel's XCD: both assume eight dies and a round-robin
+// dispatcher.  A CPX partition (one die, 32 CUs) passes the gfx950 check and breaks both - every update workgroup would leave.
+// Probe instead of assuming: the placement tricks stay on only for exactly 8 dies visited round robin.
+namespace {
+__global__ void k_probe_xcc(int* out) {
+    if (threadIdx.x == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        out[blockIdx.x] = (int)(xcc & 0xf);
+    }
+}
+void probe_xcds(rmhip::Context* c) {
+    constexpr int kBlocks = 64;
+    int* d = nullptr;
+    int h[kBlocks];
+    c->num_xcc = 1;
+    c->one_xcd_ok = false;
+    if (hipMalloc((void**)&d, sizeof h) != hipSuccess) return;
+    hipLaunchKernelGGL(k_probe_xcc, dim3(kBlocks), dim3(64), 0, c->stream, d);
+    const bool ok = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+    (void)hipFree(d);
+    if (!ok) {
+        (void)hipGetLastError();
+        return;
+    }
+    bool seen[16] = {false};
+    int n = 0;
+    for (int b = 0; b < kBlocks; ++b)
+        if (!seen[h[b] & 15]) {
+            seen[h[b] & 15] = true;
+            ++n;
+        }
+    bool round_robin = n == 8;
+    for (int b = 8; b < kBlocks && round_robin; ++b) round_robin = h[b] == h[b - 8];
+    c->num_xcc = n;
+    c->one_xcd_ok = round_robin;
+}
+}  // namespace
+
 extern "C" {
 
 const char* rmhip_version(void) { return "rmhip 0.1.0 (gfx950)"; }
@@ -328,6 +368,7 @@ int rmhip_init(int device_ordinal, rmhip_ctx** out_ctx) {
     // Keep at most a quarter of HBM parked in the pool (288 GB parts: plenty for 512 MiB operands).
     c->pool_limit_bytes = (size_t)(c->props.totalGlobalMem / 4);
     if (const char* v = std::getenv("RMHIP_POOL_LIMIT_MB")) c->pool_limit_bytes = (size_t)std::atoll(v) << 20;
+    probe_xcds(c);
     *out_ctx = h;
     return RMHIP_OK;
 }
@@ -362,7 +403,12 @@ int rmhip_device_info(rmhip_ctx* ctx, rmhip_device_info_t* out) {
     CTX_OR_FAIL(ctx);
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     std::memset(out, 0, sizeof *out);
-    std::snprintf(out->name, sizeof out->name, "%s", c->props.name);
+    // (hipDeviceProp_t::name comes back empty on some driver / container combinations: say at least what the part is)
+    if (c->props.name[0]) std::snprintf(out->name, sizeof out->name, "%s", c->props.name);
+    else std::snprintf(out->name, sizeof out->name, "AMD Instinct (%s, %d CUs)", c->props.gcnArchName, c->num_cus);
+    std::snprintf(out->vendor, sizeof out->vendor, "AMD");
+    std::snprintf(out->backend, sizeof out->backend, "hip");
+    out->xcd_count = c->num_xcc;
     std::snprintf(out->arch, sizeof out->arch, "%s", c->props.gcnArchName);
     out->device_ordinal = c->device;
     out->compute_units = c->num_cus;
@@ -598,6 +644,21 @@ int rmhip_telemetry_kernel_launch(rmhip_ctx* ctx, size_t index, rmhip_kernel_lau
         std::snprintf(out->tuning[i].key, sizeof out->tuning[i].key, "%s", r.tuning_key[i]);
         out->tuning[i].value = r.tuning_val[i];
     }
+    return RMHIP_OK;
+}
+
+int rmhip_lu_stats(rmhip_ctx* ctx, rmhip_lu_stats_t* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    std::memset(out, 0, sizeof *out);
+    out->solve_path_factorizations = c->lu_fast_count;
+    out->pivot_growth_fallbacks = c->lu_growth_fallbacks;
+    out->panel_exchange_timeouts = c->lu_exchange_timeouts;
+    out->subst_chain_timeouts = c->lu_subst_timeouts;
+    out->last_max_multiplier = c->lu_last_growth;
+    out->tau = c->lu_tau;
+    out->one_xcd_panels = c->one_xcd_ok ? 1 : 0;
+    out->conservative_panels = c->lu_conservative ? 1 : 0;
     return RMHIP_OK;
 }
 

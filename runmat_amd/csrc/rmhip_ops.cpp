@@ -36,8 +36,12 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // Copy `src` (rows x cols, dense) into the padded workspace and factor it; when the persistent panel kernels
 // report that their workgroups were not co-resident the copy is refreshed and factored conservatively.
 static int lu_copy_and_factor(Context* c, const double* src, size_t rows, size_t cols, double* work, size_t ldw, int* perm,
-                              int* info) {
-    for (int attempt = 0; attempt < 3; ++attempt) {  // one-XCD panels -> spread panels -> one launch per column
+                              int* info, bool solve_path = false) {
+    // solve_path: the caller only needs SOME stable factorisation (mldivide / linsolve / mrdivide: the pivots never leave the provider),
+    // so the first attempt restricts pivoting to each panel's top block and checks the multipliers (lu.hip, k_rp_below); when that
+    // check fails the copy is refreshed and factored with the reference's grid-wide rule.
+    int mode = solve_path ? 1 : 0;
+    for (int attempt = 0; attempt < 4; ++attempt) {  // [solve path ->] one-XCD panels -> spread panels -> one launch per column
         // (Tried: only the first 1024 columns here and the rest on the factorisation's update stream, under the first panel - the 0.8 ms
         // of a 2 GiB copy off the critical path on paper; n = 16384 98.9 vs 98.6-99.0 ms, n = 8192 34.6 vs 34.6: nothing.)
         if (rows && cols) {
@@ -45,7 +49,14 @@ static int lu_copy_and_factor(Context* c, const double* src, size_t rows, size_t
                                             hipMemcpyDeviceToDevice, c->stream);
             if (e != hipSuccess) return fail(RMHIP_ERR_HIP, "lu copy: %s", hipGetErrorString(e));
         }
-        const int rc = lu_factor_device(c, work, rows, cols, ldw, perm, info);
+        const int rc = lu_factor_device(c, work, rows, cols, ldw, perm, info, nullptr, mode);
+        if (rc == RMHIP_LU_GROWTH) {
+            mode = 0;
+            c->lu_growth_fallbacks++;
+            c->record_solve_fallback("lu:pivot_growth");
+            continue;
+        }
+        if (rc == RMHIP_OK && mode == 1) c->lu_fast_count++;
         if (rc != RMHIP_LU_RETRY) return rc;
     }
     return fail(RMHIP_ERR_HIP, "lu: factorisation failed on every panel path");
@@ -924,7 +935,7 @@ static int lstsq_full_rank(rmhip_ctx* ctx, Context* c, const double* A, size_t m
     RMHIP_TRY(c->alloc_device((g + 2) / 2 + 1, &perm_mem));
     int* perm = (int*)perm_mem->ptr;
     int info = 0;
-    RMHIP_TRY(lu_copy_and_factor(c, gram->ptr, g, g, work->ptr, ldw, perm, &info));
+    RMHIP_TRY(lu_copy_and_factor(c, gram->ptr, g, g, work->ptr, ldw, perm, &info, true));
     if (info > 0)
         return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: rank-deficient rectangular system (%d pivot(s) of the Gram matrix <= 1e-12): CPU SVD path", info);
     {
@@ -1011,7 +1022,7 @@ static int mldivide_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, r
     RMHIP_TRY(c->alloc_device((n + 2) / 2 + 1, &perm_mem));
     int* perm = (int*)perm_mem->ptr;
     int info = 0;
-    int rc = lu_copy_and_factor(c, ab.data(), n, n, work->ptr, ldw, perm, &info);
+    int rc = lu_copy_and_factor(c, ab.data(), n, n, work->ptr, ldw, perm, &info, true);
     if (!rc && info > 0)
         rc = fail(RMHIP_ERR_SINGULAR, "mldivide: %d pivot(s) <= 1e-12; matrix is numerically singular, use the CPU SVD path", info);
     Buffer ob;
@@ -1123,7 +1134,7 @@ static int linsolve_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, c
         RMHIP_TRY(c->alloc_device((n + 2) / 2 + 1, &perm_mem));
         int* perm = (int*)perm_mem->ptr;
         int info = 0;
-        rc = lu_copy_and_factor(c, A, n, n, work->ptr, ldw, perm, &info);
+        rc = lu_copy_and_factor(c, A, n, n, work->ptr, ldw, perm, &info, true);
         if (!rc && info > 0) rc = fail(RMHIP_ERR_SINGULAR, "linsolve: %d pivot(s) <= 1e-12; use the CPU SVD path", info);
         if (!rc) rc = c->new_buffer(oshape, 2, &oid, &ob);
         if (!rc) rc = lu_solve_device(c, work->ptr, n, ldw, perm, bb.data(), nrhs, n, ob.data(), n);

@@ -625,6 +625,13 @@ class HipProvider:
         snap["kernel_launches_log"] = launches
         return snap
 
+    def lu_stats(self) -> dict:
+        """`rmhip_lu_stats`: what a solve did on the device beyond `solve_fallbacks` - solve-path factorisations accepted,
+        refactorisations after a multiplier exceeded tau, exchange / substitution time-outs, the last largest multiplier."""
+        st = _lib.LuStats()
+        self._check(self._lib.rmhip_lu_stats(self._ctx, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in st._fields_}
+
     def reset_telemetry(self) -> None:
         self._check(self._lib.rmhip_reset_telemetry(self._ctx))
 

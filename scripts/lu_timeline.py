@@ -19,7 +19,7 @@ for a, b in zip(rows, rows[1:]):
     cur.append(b)
 solves.append(cur)
 def short(n):
-    for k in ("k_dgemm", "k_lu_panel", "k_laswp_lists", "k_trsm_fused", "k_build_plist", "k_rhs_update", "k_lu_col", "k_gather_rows"):
+    for k in ("k_dgemm", "k_lu_panel", "k_rp_below", "k_laswp_lists", "k_trsm_fused", "k_trsm_lower_2p", "k_subst_chain", "k_build_plist", "k_rhs_update", "k_lu_col", "k_gather_rows"):
         if k in n: return k
     return n[:30]
 for si, s in enumerate(solves):
