@@ -48,7 +48,7 @@ struct LuState {
     unsigned long long* xdbg;  // device [16] phase ticks (RMHIP_LU_PANEL_DEBUG=1) or nullptr
     long panel_pad_kb = -1;    // extra LDS a panel block asks for (-1: the default, see getrf_rec)
     int* panel_xcc = nullptr;  // device word: the XCD of the last one-XCD panel (-1 otherwise)
-    // solve path (k_lu_panel2<SOLO> + k_rp_below): pivoting restricted to the panel's top block, multipliers checked against tau
+    // solve path (k_rp_top + k_rp_below): pivoting restricted to the panel's top block, multipliers checked against tau
     bool fast = false;
     double tau = 8.0;
     double* ucomp = nullptr;              // device [BASE_W][BASE_W]: the pivot rows of the panel in flight
@@ -269,6 +269,16 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     v = umin32(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xc, 0xf, false));
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+__device__ __forceinline__ unsigned umax32(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = umax32(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    v = umax32(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    v = umax32(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+    v = umax32(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+    v = umax32(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = umax32(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 // arg-max over the wave by (key descending, pos ascending); key == 0 never wins.  Returns the
 // winning lane (wave-uniform) or -1; *key_out / *pos_out receive the winning pair.
 __device__ __forceinline__ int wave_argmax(pk_u64 key, unsigned pos, pk_u64* key_out, unsigned* pos_out) {
@@ -393,7 +403,6 @@ struct P2Args {
     int2* plist;    // this panel's row-move list (PLIST entries)
     pk_u64* dbg;
     int* xcc_out;   // receives the XCD the panel sits on (one-XCD placement) or -1; read by the update stream's persistent dgemm
-    double* ucomp;  // SOLO: [BASE_W][BASE_W] compact TRANSPOSED copy of the pivot rows (ucomp[c][k] = U[k][c]) for k_rp_below
 };
 
 // 16-byte exchange granules: one write-through (sc1) store / one L1-bypassing load; each 8-byte half is self-describing,
@@ -459,11 +468,7 @@ struct P2Ticks {  // developer instrumentation (RMHIP_LU_PANEL_DEBUG=1): 100 MHz
 // p2_select<NS>: pick and publish the block's candidate for column kn (its values sit in window slot NS), then - after
 // `rest` ran (the elimination the exchange hides) - collect every block's candidate and leave the winner in
 // s_ctl / cand.  FIX: the parked row still needs pivot row kn-1 (factor in its slot NS-1) applied beyond column kn.
-//
-// SOLO (the solve path's panel, see k_rp_below): the grid is ONE workgroup over the top P2_ROWS rows of the panel, so the block's
-// candidate IS the pivot.  Wave 0 writes the winner's row (with the pending update applied) straight into the other one of two
-// LDS slots - the slot of pivot row kn-1 is still being read by `rest` - and nothing goes through memory.
-template <int NS, bool FIX, bool DBG, bool SOLO, class Rest>
+template <int NS, bool FIX, bool DBG, class Rest>
 __device__ __forceinline__ bool p2_select(const P2Args& g, const P2Lds& L, double (&a)[BASE_W + 4], const int pos, const int jj, const int kn,
                                          const int fix_skip, const double* fix_row, P2Ticks* ticks, Rest rest) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -511,27 +516,9 @@ __device__ __forceinline__ bool p2_select(const P2Args& g, const P2Lds& L, doubl
         const pk_u64 bk = bl < 0 ? 0 : (pk_u64)__double_as_longlong(bkd);
         const int bw = bl < 0 ? 0 : bl;
         const int bt = L.r_t[bw];
-        if (SOLO) {
-            const int sel = kn & 1;
-            if (lane >= kn && lane < g.w) {
-                double v = L.rowbuf[bw * P2_RB + lane];
-                if (FIX && !fix_skip && lane > kn) {
-                    const double fw = L.rowbuf[bw * P2_RB + kn - 1];  // the row's multiplier for pivot row kn-1
-                    const double prod = fw * fix_row[lane];
-                    v = v - prod;
-                }
-                L.cand[sel * BASE_W + lane] = v;
-            }
-            if (lane == 0) {
-                L.s_ctl[0] = bl < 0 ? -1 : g.j0 + bt;
-                L.s_ctl[1] = (int)bp;
-                L.s_ctl[2] = (L.s_ctl[2] & 2) | ((bkd <= LU_EPS || bl < 0) ? 1 : 0) | (sel << 8);
-            }
-            P2_TICK(2)
-        }
         const size_t slot = (size_t)par * PK_MAXB + blk;
-        if (!SOLO && lane == 0) st_granule(g.xrec + slot * 2, bk | fresh, (pk_u64)bp | ((pk_u64)(unsigned)bt << 32) | fresh, local);
-        if (!SOLO && lane >= kn && lane < g.w) {
+        if (lane == 0) st_granule(g.xrec + slot * 2, bk | fresh, (pk_u64)bp | ((pk_u64)(unsigned)bt << 32) | fresh, local);
+        if (lane >= kn && lane < g.w) {
             double v = L.rowbuf[bw * P2_RB + lane];
             if (FIX && !fix_skip && lane > kn) {
                 const double fw = L.rowbuf[bw * P2_RB + kn - 1];  // the row's multiplier for pivot row kn-1
@@ -541,15 +528,10 @@ __device__ __forceinline__ bool p2_select(const P2Args& g, const P2Lds& L, doubl
             const pk_u64 bits = (pk_u64)__double_as_longlong(v);
             st_granule(g.xvals + (slot * BASE_W + lane) * 2, (bits & 0xffffffffull) | vtag, (bits >> 32) | vtag, local);
         }
-        if (!SOLO) P2_TICK(2)  // publish
+        P2_TICK(2)  // publish
     }
     rest();
     P2_TICK(6)  // elimination under the exchange
-    if (SOLO) {
-        __syncthreads();
-        P2_TICK(5)
-        return true;
-    }
     if (FIX) __syncthreads();  // every wave is done with the previous pivot row in `cand`
     const bool onehop = g.nblocks <= g.onehop_max;
     int bad = 0;
@@ -695,7 +677,7 @@ __device__ __forceinline__ void p2_update(double (&a)[BASE_W + 4], const double 
 
 // one column (k = 4*jj + KK, window slot KK): its pivot is in s_ctl / cand; retire / displace rows, form the
 // multipliers, update column k+1, run the selection for k+1 with the bulk elimination under its exchange.
-template <int KK, bool DBG, bool SOLO>
+template <int KK, bool DBG>
 __device__ __forceinline__ bool p2_column(const P2Args& g, const P2Lds& L, double (&a)[BASE_W + 4], int& pos, int& retk, int& rpiv,
                                          const int jj, const size_t r, P2Ticks* ticks) {
     const int k = 4 * jj + KK;
@@ -731,10 +713,10 @@ __device__ __forceinline__ bool p2_column(const P2Args& g, const P2Lds& L, doubl
         const double prod = factor * pr[KK + 1];
         a[KK + 1] = a[KK + 1] - prod;
     }
-    return p2_select<KK + 1, true, DBG, SOLO>(g, L, a, pos, jj, k + 1, skip, L.cand + (flags >> 8) * BASE_W, ticks, rest);
+    return p2_select<KK + 1, true, DBG>(g, L, a, pos, jj, k + 1, skip, L.cand + (flags >> 8) * BASE_W, ticks, rest);
 }
 
-template <bool DBG, bool SOLO>
+template <bool DBG>
 __global__ void __launch_bounds__(P2_THREADS) k_lu_panel2(const P2Args g) {
     extern __shared__ double p2_lds[];
     __shared__ double r_key[P2_WAVES];
@@ -759,7 +741,7 @@ __global__ void __launch_bounds__(P2_THREADS) k_lu_panel2(const P2Args g) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && g.xcc_out) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        *g.xcc_out = (SOLO || g.bstride > 1) ? (int)(xcc & 0xf) : -1;
+        *g.xcc_out = g.bstride > 1 ? (int)(xcc & 0xf) : -1;
     }
     const int t = threadIdx.x;  // row slot
     const size_t r = (size_t)g.j0 + (size_t)(blockIdx.x / g.bstride) * P2_ROWS + t;
@@ -775,24 +757,19 @@ __global__ void __launch_bounds__(P2_THREADS) k_lu_panel2(const P2Args g) {
     __syncthreads();
     P2_TICK(0)  // load
     // pivot of column 0: nothing to hide, nothing to fix up
-    if (!p2_select<0, false, DBG, SOLO>(g, L, a, pos, 0, 0, 1, L.cand, ticks, [] {})) return;
+    if (!p2_select<0, false, DBG>(g, L, a, pos, 0, 0, 1, L.cand, ticks, [] {})) return;
     const int ngroups = (g.w + 3) >> 2;
     for (int jj = 0; jj < ngroups; ++jj) {
-        if (!p2_column<0, DBG, SOLO>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
-        if (4 * jj + 1 < g.w && !p2_column<1, DBG, SOLO>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
-        if (4 * jj + 2 < g.w && !p2_column<2, DBG, SOLO>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
-        if (4 * jj + 3 < g.w && !p2_column<3, DBG, SOLO>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
+        if (!p2_column<0, DBG>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
+        if (4 * jj + 1 < g.w && !p2_column<1, DBG>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
+        if (4 * jj + 2 < g.w && !p2_column<2, DBG>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
+        if (4 * jj + 3 < g.w && !p2_column<3, DBG>(g, L, a, pos, retk, rpiv, jj, r, ticks)) return;
         // columns 4jj .. 4jj+3 are final (multipliers, or the U values of a retired row): store them where the row was
         // loaded from - nobody reads the panel's columns before the kernel ends - and shift the register window by four
         if (in_rows) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (4 * jj + i < g.w) g.A[r + (size_t)(g.j0 + 4 * jj + i) * g.lda] = a[i];
-            if (SOLO && retk >= 0) {  // a retired row is row retk of U: its values from column retk on are final
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (4 * jj + i < g.w) g.ucomp[(4 * jj + i) * BASE_W + retk] = a[i];  // transposed: [column][pivot row]
-            }
         }
 #pragma unroll
         for (int i = 0; i < BASE_W; ++i) a[i] = a[i + 4];
@@ -826,80 +803,351 @@ __global__ void __launch_bounds__(P2_THREADS) k_lu_panel2(const P2Args g) {
 // ---- solve path (`mldivide` / `linsolve` / `mrdivide`): panel with pivoting RESTRICTED to the top block ----------------------------
 // The reference's contract for a solve is the solution to a residual tolerance (mldivide.rs:380-404, tests :662-696); the pivot
 // sequence never leaves the provider there (it does for `lu`, which keeps k_lu_panel2's grid-wide first-maximum rule).  What the
-// grid-wide rule costs is one memory-system exchange per column (2.97-3.6 us x n columns, 59 of 98 ms at n = 16384).  On the solve
-// path a base panel is therefore factored like the LU step of the hybrid LU-QR algorithm (Faverge, Herrmann, Langou, Lowery, Robert,
-// Dongarra, "Designing LU-QR hybrid solvers for performance and stability", IPDPS 2014): partial pivoting inside the DIAGONAL DOMAIN -
-// the top P2_ROWS = 256 rows of the panel, one workgroup, k_lu_panel2<SOLO>, no exchange - and every row below becomes
-// l = a U11^-1 by substitution (this kernel, all rows in parallel), with their "Max criterion" as the guard: the factorisation is
-// accepted only if every multiplier satisfies |l| <= tau (threshold partial pivoting, tau = 8 by default; the sparse direct solvers'
-// usual threshold u = 0.1 corresponds to tau = 10).  The largest |l| is accumulated in *growth; a violation, a pivot at the
-// singular cut-off or a NaN makes lu_factor_device report RMHIP_LU_GROWTH and the caller refactors a fresh copy with the grid-wide
-// rule (counted in telemetry.solve_fallbacks as "lu:pivot_growth").  For matrices whose entries are not arranged to defeat it (random
-// dense, diagonally dominant, SPD Gram matrices) the 256 candidates hold an entry within a small factor of the column maximum: max|l|
-// measured 1.7-2.6 on U(-1,1) / N(0,1) matrices up to n = 8192, residuals equal to partial pivoting's (tests/test_gpu_solvepath.py).
+// grid-wide rule costs is a grid of workgroups that meet once per column: 2.97-3.6 us x n columns, 59 of 98 ms at n = 16384, and
+// 32-64 CUs held while they wait.  On the solve path a base panel is therefore factored like the LU step of the hybrid LU-QR
+// algorithm (Faverge, Herrmann, Langou, Lowery, Robert, Dongarra, "Designing LU-QR hybrid solvers for performance and stability",
+// IPDPS 2014): partial pivoting inside the DIAGONAL DOMAIN - the top RT_ROWS = 256 rows of the panel, ONE workgroup (k_rp_top), no
+// exchange - and every row below becomes l = a U11^-1 by substitution (k_rp_below, all rows in parallel), with their "Max
+// criterion" as the guard: the factorisation is accepted only if every multiplier satisfies |l| <= tau (threshold partial
+// pivoting; tau = 8 by default - the sparse direct solvers' usual threshold u = 0.1 is tau = 10).  The largest |l| is accumulated
+// in *growth; a violation, a pivot at the singular cut-off or a NaN makes lu_factor_device report RMHIP_LU_GROWTH and the caller
+// refactors a fresh copy with the grid-wide rule (telemetry.solve_fallbacks "lu:pivot_growth", rmhip_lu_stats).  For matrices
+// whose entries are not arranged to defeat it (random dense, diagonally dominant, SPD Gram matrices) the 256 candidates hold an
+// entry within a small factor of the column maximum: max|l| 1.8-2.5 on U(-1,1) matrices up to n = 16384, residuals equal to
+// partial pivoting's (tests/test_gpu_solvepath.py); a row-permuted diagonally dominant matrix fails at its first panel and costs
+// one small read before the grid-wide rule takes over.
 //
-// One thread per row, the row's w <= 64 panel values in registers; the loop is rolled over groups of eight columns with the register
-// window shifted by eight (static indices; straight-line code for all 64 steps would be 16 KiB executed once per launch on cold
-// instruction caches).
-static constexpr int RB_THREADS = 256;
-// `ut` is the TRANSPOSED compact copy k_lu_panel2<SOLO> leaves: ut[c * BASE_W + k] = U[k][c] (k <= c).  Every thread needs the same
-// value at the same time, so the operands are wave-uniform loads of read-only memory - scalar loads into SGPRs, the FMA's scalar
-// operand - and the kernel uses neither LDS nor a barrier (through LDS the operands would be bound by its 128 B/clk: one 8-byte operand
-// per FMA is four times what a CU's four SIMDs can be fed).  Per group of eight columns: the 8 x 8 triangle (36 operations), then ONE
-// pass over the window's live columns with the eight multipliers (eight chained FMAs per column) - written this way, not as eight
-// rank-1 sweeps, because the compiler sinks the FMAs of a sweep that nothing needs yet and keeps every operand alive (2 KiB of scratch).
-__global__ void __launch_bounds__(RB_THREADS) k_rp_below(double* __restrict__ A, const size_t lda, const size_t rows, const size_t r0,
-                                                         const int j0, const int w, const double* __restrict__ ut,
-                                                         pk_u64* __restrict__ growth, const double tau) {
-    const int t = threadIdx.x;
-    const size_t r = r0 + (size_t)blockIdx.x * RB_THREADS + t;
-    const bool live = r < rows;
-    double a[BASE_W];
+// Both kernels keep one matrix row per thread in a 64-register window and work in MICRO-PANELS of eight columns: inside a
+// micro-panel only the eight window columns are eliminated step by step (the latency chain), everything to the right receives
+// the eight pivots at once - eight chained FMAs per element with the operands fetched from LDS in bulk, instead of 64 sweeps that
+// each wait for their own operands.  The loop over micro-panels is rolled and the window shifts by eight (static register
+// indices; straight-line code for 64 steps would be executed once per launch from cold instruction caches).
+static constexpr int RT_ROWS = 256;  // rows of the top block = threads of k_rp_top
+static constexpr int RT_VS = 10;     // doubles per 8-value LDS record: 80 bytes put the 16-byte accesses of consecutive records on distinct banks
+static constexpr int RT_TRAIL = BASE_W - 8;
+
+// workgroup barrier that does not wait for this wave's global stores (on gfx9 `__syncthreads` waits for vmcnt too)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// a[8 + c] += sum_i ng[i] * T[i * ldt + c] over the live trailing slots c of micro-panel m.  Per batch of eight columns the eight
+// pivots are applied one after the other to eight INDEPENDENT accumulators (a column's eight FMAs are a dependent chain: done column
+// by column, as first written, every column paid the LDS latency and the chain latency - 145 cycles per column, measured), and the
+// operands of pivot i + 1 are fetched before the FMAs of pivot i.
+__device__ __forceinline__ void rank8_update(double (&a)[BASE_W], const double (&ng)[8], const double* T, const int ldt, const int m) {
 #pragma unroll
-    for (int c = 0; c < BASE_W; ++c) a[c] = (live && c < w) ? A[r + (size_t)(j0 + c) * lda] : 0.0;
-    double mx = 0.0;
-    int bad = 0;
-#pragma unroll 1
-    for (int it = 0; it < BASE_W / 8; ++it) {
-        const double* ud = ut + (size_t)(8 * it) * BASE_W + 8 * it;  // ud[i * BASE_W + kk] = U[8 it + kk][8 it + i]
-        double nx[8];
+    for (int bch = 0; bch < RT_TRAIL / 8; ++bch) {
+        if (m + 1 + bch < BASE_W / 8) {  // uniform: window slots beyond column 63 are dead
+            double u[2][8];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            // columns beyond w hold zeros here and whatever an earlier panel left in ut: their multiplier is 0 by definition
-            const double x = (8 * it + kk < w) ? a[kk] / ud[kk * BASE_W + kk] : 0.0;
-            a[kk] = x;
-            const double ax = fabs(x);
-            bad |= !(ax <= tau);
-            mx = fmax(mx, ax);
-            nx[kk] = -x;
+            for (int q = 0; q < 8; ++q) u[0][q] = T[8 * bch + q];
 #pragma unroll
-            for (int i = kk + 1; i < 8; ++i) a[i] = __builtin_fma(nx[kk], ud[i * BASE_W + kk], a[i]);
+            for (int i = 0; i < 8; ++i) {
+                if (i + 1 < 8) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) u[(i + 1) & 1][q] = T[(i + 1) * ldt + 8 * bch + q];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a[8 + 8 * bch + q] = __builtin_fma(ng[i], u[i & 1][q], a[8 + 8 * bch + q]);
+            }
         }
-        if (live) {
+    }
+}
+
+struct RtArgs {
+    double* A;
+    size_t lda, rows;  // rows: one past the last row of the top block (<= j0 + RT_ROWS)
+    int j0, w;
+    int* prow_arr;
+    int* ipiv;
+    int* info;
+    int2* plist;    // this panel's row-move list (PLIST entries, the layout k_lu_panel2 writes)
+    double* ucomp;  // [BASE_W][BASE_W] compact copy of the pivot rows for k_rp_below: ucomp[k * BASE_W + c] = U[k][c], 1 / u_kk on the diagonal
+    int* xcc_out;   // receives the XCD this workgroup runs on (read by the update stream's persistent kernels), or nullptr
+};
+struct RtLds {
+    unsigned* wmax; // [2][4] every wave's best key (high word of |a|, low byte = 255 - thread), by step parity
+    double* vals;   // [2][4][RT_VS] the wave candidate's window values (+ its reciprocal in slot 8)
+    int* posv;      // [2][4] its current position
+    double* pw;     // [8][RT_VS] pivot j of the micro-panel: its window values (multipliers w.r.t. pivots < j, then u_jj ...)
+    double* pt;     // [8][RT_TRAIL] pt[j][c] = pivot j's value in trailing slot c, as it was when the micro-panel began
+};
+
+struct RtTicks {  // developer instrumentation (RMHIP_LU_PANEL_DEBUG=1): 100 MHz ticks per phase, thread 0
+    pk_u64 tk, acc[12];
+};
+#define RT_TICK(i)                              \
+    if (DBG && threadIdx.x == 0) {              \
+        const pk_u64 now_ = wall_clock64();     \
+        ticks.acc[i] += now_ - ticks.tk;        \
+        ticks.tk = now_;                        \
+    }
+// One column (k = 8 m + J, window slot J).  The pivot search runs on 32-bit keys: the high word of |a_k| with its low byte replaced
+// by 255 - thread, so the maximum is ONE v_max_u32 per DPP step (a 64-bit arg-max is three instructions and two reductions),
+// names its owner, and picks the largest candidate up to 2^-12 relative, ties to the lowest row - the solve path need not
+// reproduce host_lu.rs's first-maximum rule, only keep the multipliers small (they stay below 1 + 2^-12 inside the block).
+// Each wave's candidate leaves its window values, its reciprocal and its position in LDS; one barrier; every thread folds the four
+// wave records itself.  (A first version let all 256 rows issue one LDS atomic max on the same word: 2.8 us per column - same-address
+// LDS atomics serialise at ~25 cycles each.)
+template <int J, bool DBG>
+__device__ __forceinline__ void rt_step(const RtArgs& g, const RtLds& L, const int m, double (&a)[BASE_W], int& pos, int& retk, int& rpiv,
+                                        double& myrinv, RtTicks& ticks) {
+    const int k = 8 * m + J;
+    if (k >= g.w) return;  // uniform
+    const int kabs = g.j0 + k, par = J & 1, t = threadIdx.x, wv = t >> 6;
+    unsigned key = 0;
+    if (pos >= 0) {
+        const double av = fabs(a[J]);
+        if (av > 0.0) key = ((unsigned)__double2hiint(av) & ~0xffu) | (unsigned)(255 - t);  // NaN or zero never wins
+    }
+    // 1 / a[J]: hardware estimate + two Newton steps (the error squares twice: full precision from any estimate good to 2^-14); a
+    // division is three times the instructions on this chain.  Zero / tiny / non-finite candidates give garbage nobody multiplies by
+    // (such a pivot is skipped).
+    double rinv = __builtin_amdgcn_rcp(a[J]);
+    rinv = __builtin_fma(rinv, __builtin_fma(-a[J], rinv, 1.0), rinv);
+    rinv = __builtin_fma(rinv, __builtin_fma(-a[J], rinv, 1.0), rinv);
+    const unsigned wm = wave_max_u32(key);
+    if (key != 0 && key == wm) {  // exactly one lane: the keys carry the thread number
+        double* mine = L.vals + (par * 4 + wv) * RT_VS;
+#pragma unroll
+        for (int i = J; i < 8; ++i) mine[i] = a[i];
+        mine[8] = rinv;
+        L.posv[par * 4 + wv] = pos;
+    }
+    if ((t & 63) == 0) L.wmax[par * 4 + wv] = wm;
+    RT_TICK(1)  // candidate: wave maximum, reciprocal, the wave winner's record
+    lds_barrier();
+    RT_TICK(2)  // barrier
+    const uint4 w4 = *reinterpret_cast<const uint4*>(L.wmax + par * 4);
+    const unsigned b01 = w4.x > w4.y ? w4.x : w4.y, b23 = w4.z > w4.w ? w4.z : w4.w;
+    const unsigned best = b01 > b23 ? b01 : b23;
+    const bool none = best == 0;  // all-zero / NaN-only column: the row at position k retires (host_lu.rs:38)
+    const int btid = 255 - (int)(best & 0xffu), bwv = btid >> 6;
+    const double* pv = L.vals + (par * 4 + bwv) * RT_VS;
+    const bool skip = none || !(fabs(pv[J]) > LU_EPS);  // counted as a singular pivot; the solve path then refactors with the grid-wide rule
+    if (none) {
+        if (pos == kabs) {
+            pos = -1;
+            retk = k;
+            rpiv = kabs | 0x40000000;
+        }
+    } else {
+        const int bpos = L.posv[par * 4 + bwv];
+        if (t == btid) {
+            pos = -1;  // retires as row k of U
+            retk = k;
+            rpiv = bpos | (skip ? 0x40000000 : 0);
+            myrinv = rinv;
+        } else if (pos == kabs) {
+            pos = bpos;  // the old occupant of position k moves to the pivot's position
+        }
+    }
+    if (pos >= 0) {
+        if (skip) {
+            a[J] = 0.0;  // host_lu.rs:55-57
+        } else {
+            const double f = a[J] * pv[8];
+            a[J] = f;
+#pragma unroll
+            for (int i = J + 1; i < 8; ++i) a[i] = __builtin_fma(-f, pv[i], a[i]);
+        }
+    }
+    RT_TICK(3)  // winner, bookkeeping, window elimination
+}
+template <int J, bool DBG>
+__device__ __forceinline__ void rt_steps(const RtArgs& g, const RtLds& L, const int m, double (&a)[BASE_W], int& pos, int& retk, int& rpiv,
+                                         double& myrinv, RtTicks& ticks) {
+    if constexpr (J < 8) {
+        rt_step<J, DBG>(g, L, m, a, pos, retk, rpiv, myrinv, ticks);
+        rt_steps<J + 1, DBG>(g, L, m, a, pos, retk, rpiv, myrinv, ticks);
+    }
+}
+
+template <bool DBG>
+__global__ void __launch_bounds__(RT_ROWS) k_rp_top(const RtArgs g, pk_u64* dbg) {
+    __shared__ __attribute__((aligned(16))) unsigned s_wmax[2 * 4];
+    __shared__ __attribute__((aligned(16))) double s_vals[2 * 4 * RT_VS];
+    __shared__ int s_pos[2 * 4];
+    __shared__ __attribute__((aligned(16))) double s_pw[8 * RT_VS];
+    __shared__ __attribute__((aligned(16))) double s_pt[8 * RT_TRAIL];
+    extern __shared__ double rt_pad[];  // only asked for: keeps update-stream dgemm blocks off this CU (getrf_rec)
+    RtLds L;
+    L.wmax = s_wmax;
+    L.vals = s_vals;
+    L.posv = s_pos;
+    L.pw = s_pw;
+    L.pt = s_pt;
+    const int t = threadIdx.x;
+    RtTicks ticks;
+    if (DBG) {
+        for (int i = 0; i < 12; ++i) ticks.acc[i] = 0;
+        ticks.tk = wall_clock64();
+    }
+    if (t == 0 && g.xcc_out) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        *g.xcc_out = (int)(xcc & 0xf);
+    }
+    const size_t r = (size_t)g.j0 + t;
+    const bool in_rows = r < g.rows;
+    int pos = in_rows ? (int)r : -1, retk = -1, rpiv = 0;
+    double a[BASE_W];  // register window: a[i] = column 8 m + i
+#pragma unroll
+    for (int c = 0; c < BASE_W; ++c) a[c] = (in_rows && c < g.w) ? g.A[r + (size_t)(g.j0 + c) * g.lda] : 0.0;
+    double myrinv = 0.0;  // a pivot row keeps the reciprocal of its pivot: k_rp_below multiplies by it
+    RT_TICK(0)  // load
+    const int nmp = (g.w + 7) >> 3;
+#pragma unroll 1
+    for (int m = 0; m < nmp; ++m) {
+        rt_steps<0, DBG>(g, L, m, a, pos, retk, rpiv, myrinv, ticks);
+        // ---- the micro-panel's pivot rows park their window and their (not yet updated) trailing values
+        if (retk >= 8 * m) {
+            const int jr = retk - 8 * m;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s_pw[jr * RT_VS + i] = a[i];
+#pragma unroll
+            for (int bch = 0; bch < RT_TRAIL / 8; ++bch) {
+                if (m + 1 + bch < BASE_W / 8) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) s_pt[jr * RT_TRAIL + 8 * bch + q] = a[8 + 8 * bch + q];
+                }
+            }
+        }
+        if (t < 8 && 8 * m + t >= g.w) {  // steps beyond a ragged panel's width have no pivot: their records must not hold an earlier micro-panel's
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s_pw[t * RT_VS + i] = 0.0;
+        }
+        RT_TICK(4)  // park
+        lds_barrier();
+        RT_TICK(5)
+        // ---- multipliers this row holds for pivots i of the micro-panel: valid while it was active at step i.  The trailing rows
+        // in s_pt are RAW (pivot j's row still lacks pivots i < j of this micro-panel), so instead of fixing them up in a serial
+        // pass the multipliers are transformed: a -= f U = f (L8^-1 R) = (f L8^-1) R with L8 the unit-lower triangle in s_pw;
+        // g L8 = f is 28 operations per row.  A pivot row takes part with the multipliers it collected before it retired, which
+        // is exactly its own row of L8^-1 R - its final U values.
+        double gm[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gm[i] = (retk < 0 || 8 * m + i < retk) ? a[i] : 0.0;
+#pragma unroll
+        for (int i = 6; i >= 0; --i) {
+#pragma unroll
+            for (int j = i + 1; j < 8; ++j) gm[i] = __builtin_fma(-gm[j], s_pw[j * RT_VS + i], gm[i]);
+        }
+        double ng[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ng[i] = -gm[i];
+        RT_TICK(6)  // multipliers -> g
+        rank8_update(a, ng, s_pt, RT_TRAIL, m);
+        RT_TICK(7)  // rank-8 update
+        // ---- columns 8 m .. 8 m + 7 are final: multipliers, or the U values of a retired row.  They go where the row was loaded from
+        // (the interchange is a k_laswp_lists call, as for k_lu_panel2); pivot rows also leave the transposed copy for k_rp_below.
+        if (in_rows) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if (8 * it + i < w) A[r + (size_t)(j0 + 8 * it + i) * lda] = a[i];
-        }
+                if (8 * m + i < g.w) g.A[r + (size_t)(g.j0 + 8 * m + i) * g.lda] = a[i];
+            if (retk >= 0) {
 #pragma unroll
-        for (int bch = 1; bch < BASE_W / 8; ++bch) {
-            if (it + bch < BASE_W / 8) {  // uniform: the window's tail beyond column 63 is dead
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int i = 8 * bch + q;
-                    const double* uc = ud + i * BASE_W;
-                    double v = a[i];
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) v = __builtin_fma(nx[kk], uc[kk], v);
-                    a[i] = v;
-                }
+                for (int i = 0; i < 8; ++i)
+                    if (8 * m + i < g.w) g.ucomp[retk * BASE_W + 8 * m + i] = (8 * m + i == retk) ? myrinv : a[i];  // diagonal: 1 / u_kk
             }
         }
 #pragma unroll
         for (int i = 0; i < BASE_W - 8; ++i) a[i] = a[i + 8];
 #pragma unroll
         for (int i = BASE_W - 8; i < BASE_W; ++i) a[i] = 0.0;
+        RT_TICK(8)  // store + shift
     }
-    // block maximum -> one atomic per wave that has something to report
+    if (DBG && t == 0)
+        for (int i = 0; i < 12; ++i) dbg[i] += ticks.acc[i];
+    if (in_rows && retk >= 0) {
+        // interchange record of the step this row retired at, its row move, and the singular-pivot count (as k_lu_panel2)
+        const int kabs = g.j0 + retk;
+        g.ipiv[kabs] = rpiv & 0x3fffffff;
+        g.prow_arr[kabs] = (int)r;
+        g.plist[retk] = (int)r != kabs ? make_int2(kabs, (int)r) : make_int2(-1, -1);
+        if (rpiv & 0x40000000) atomicAdd(g.info, 1);
+    }
+    if (t < BASE_W) {  // top rows that were displaced instead of retired
+        int2 e = make_int2(-1, -1);
+        if (t < g.w && pos >= 0 && pos != (int)r) e = make_int2(pos, (int)r);
+        g.plist[BASE_W + t] = e;
+        if (t >= g.w) g.plist[t] = make_int2(-1, -1);
+    }
+}
+
+// Rows below the top block: l = a U11^-1, one thread per row, U (transposed, as k_rp_top left it) staged in LDS.  One wave per
+// workgroup: every FMA takes an 8-byte operand from LDS, so a CU's LDS feeds about one wave at the rate its SIMD multiplies, and the
+// rows should spread over as many CUs as there are.
+template <int RB_THREADS, bool DBG>
+__global__ void __launch_bounds__(RB_THREADS) k_rp_below(double* __restrict__ A, const size_t lda, const size_t rows, const size_t r0,
+                                                         const int j0, const int w, const double* __restrict__ ut,
+                                                         pk_u64* __restrict__ growth, const double /*tau: the host compares*/, pk_u64* dbg) {
+    __shared__ __attribute__((aligned(16))) double U[BASE_W * BASE_W + BASE_W];  // U[k * BASE_W + c] = U11[k][c], 1 / u_kk on the diagonal (+ slack for dead slots)
+    const int t = threadIdx.x;
+    RtTicks ticks;
+    if (DBG) {
+        for (int i = 0; i < 12; ++i) ticks.acc[i] = 0;
+        ticks.tk = wall_clock64();
+    }
+    {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const d2* src = reinterpret_cast<const d2*>(ut);
+        d2* dst = reinterpret_cast<d2*>(U);
+        constexpr int PER = BASE_W * BASE_W / 2 / RB_THREADS;
+        d2 stage[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) stage[u] = src[u * RB_THREADS + t];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) dst[u * RB_THREADS + t] = stage[u];
+        if (t < BASE_W) U[BASE_W * BASE_W + t] = 0.0;
+    }
+    RT_TICK(0)  // stage U
+    const size_t r = r0 + (size_t)blockIdx.x * RB_THREADS + t;
+    const bool live = r < rows;
+    double a[BASE_W];
+#pragma unroll
+    for (int c = 0; c < BASE_W; ++c) a[c] = (live && c < w) ? A[r + (size_t)(j0 + c) * lda] : 0.0;
+    lds_barrier();
+    if (DBG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RT_TICK(1)  // load the rows
+    double mx = 0.0;
+    int bad = 0;
+#pragma unroll 1
+    for (int m = 0; m < BASE_W / 8; ++m) {
+        const double* ud = U + (8 * m) * BASE_W + 8 * m;  // ud[kk * BASE_W + i] = U11[8 m + kk][8 m + i]
+        // the 8 x 8 triangle's 36 operands first, so that the eight dependent steps below wait for nothing
+        double tri[8][8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+#pragma unroll
+            for (int i = kk; i < 8; ++i) tri[kk][i] = ud[kk * BASE_W + i];
+        }
+        double nx[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            // columns beyond w hold zeros here and whatever an earlier panel left in ut: their multiplier is 0 by definition
+            const double x = (8 * m + kk < w) ? a[kk] * tri[kk][kk] : 0.0;  // the diagonal holds 1 / u_kk
+            a[kk] = x;
+            const double ax = fabs(x);
+            bad |= (ax != ax);  // NaN: fmax below would drop it
+            mx = fmax(mx, ax);
+            nx[kk] = -x;
+#pragma unroll
+            for (int i = kk + 1; i < 8; ++i) a[i] = __builtin_fma(nx[kk], tri[kk][i], a[i]);
+        }
+        RT_TICK(2)  // 8 x 8 triangle
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (8 * m + i < w) A[r + (size_t)(j0 + 8 * m + i) * lda] = a[i];
+        }
+        RT_TICK(3)  // stores
+        rank8_update(a, nx, ud + 8, BASE_W, m);
+        RT_TICK(4)  // rank-8 update
+#pragma unroll
+        for (int i = 0; i < BASE_W - 8; ++i) a[i] = a[i + 8];
+#pragma unroll
+        for (int i = BASE_W - 8; i < BASE_W; ++i) a[i] = 0.0;
+    }
     if (!live) {
         mx = 0.0;
         bad = 0;
@@ -907,6 +1155,10 @@ __global__ void __launch_bounds__(RB_THREADS) k_rp_below(double* __restrict__ A,
     pk_u64 bits = bad ? 0x7ff8000000000000ull : (pk_u64)__double_as_longlong(mx);
     bits = wave_max_u64(bits);
     if ((t & 63) == 0 && bits != 0) atomicMax(growth, bits);
+    if (DBG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RT_TICK(5)  // tail
+    if (DBG && t == 0 && blockIdx.x == 0)
+        for (int i = 0; i < 6; ++i) dbg[9 + i] += ticks.acc[i];
 }
 
 // Turn the lazy bookkeeping of one finished base panel [j0, c1) into a list of row moves
@@ -1454,44 +1706,44 @@ static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller =
             // solve path: ONE workgroup factors the top P2_ROWS rows with partial pivoting (no exchange), k_rp_below turns every row
             // below into multipliers and records the largest one
             const size_t pid = s.panel_start->size();
-            P2Args g;
+            RtArgs g;
             g.A = s.A;
             g.lda = s.lda;
-            g.rows = (s.rows - j0) > (size_t)P2_ROWS ? j0 + P2_ROWS : s.rows;
+            g.rows = (s.rows - j0) > (size_t)RT_ROWS ? j0 + RT_ROWS : s.rows;
             g.j0 = (int)j0;
             g.w = (int)w;
-            g.nblocks = 1;
-            g.onehop_max = P2_ONEHOP_MAXB;
-            g.bstride = 1;
-            g.seq0 = s.xbase;
-            g.xerr = s.xerr;
-            g.xrec = s.xrec;
-            g.xvals = s.xvals;
             g.prow_arr = s.prow;
             g.ipiv = s.ipiv;
             g.info = s.info;
             g.plist = s.plist + pid * PLIST;
-            g.dbg = s.xdbg;
-            g.xcc_out = s.panel_xcc;
             g.ucomp = s.ucomp;
-            static long pad_kb_solo = -1;  // as below: a panel block that shares its CU with a dgemm block runs every column step slower
-            if (pad_kb_solo < 0) {
+            g.xcc_out = s.panel_xcc;
+            // like k_lu_panel2 the block ASKS for more LDS than it uses (48.6 KiB static) so that it does not share its CU with an
+            // update-stream dgemm block: every column step would run slower beside one (RMHIP_LU_PANEL_PAD_KB; the phase-dependent
+            // values of getrf_blocked apply)
+            static long pad_kb_top = -1;
+            if (pad_kb_top < 0) {
                 const char* v = std::getenv("RMHIP_LU_PANEL_PAD_KB");
-                pad_kb_solo = v ? std::atol(v) : 64;
-                if (pad_kb_solo > 128) pad_kb_solo = 128;
+                pad_kb_top = v ? std::atol(v) : 96;  // (96: the workgroup has its CU to itself; 32: 78.3 -> 77.3 ms at n = 16384)
+                if (pad_kb_top > 96) pad_kb_top = 96;
             }
-            const size_t lds_bytes = P2_LDS_DOUBLES * sizeof(double) + (size_t)(s.panel_pad_kb >= 0 ? s.panel_pad_kb : pad_kb_solo) * 1024;
-            if (lds_bytes > 65536) {
-                s.c->ensure_max_lds((const void*)k_lu_panel2<false, true>, lds_bytes);
-                s.c->ensure_max_lds((const void*)k_lu_panel2<true, true>, lds_bytes);
+            const size_t pad_bytes = (size_t)(s.panel_pad_kb >= 0 ? (s.panel_pad_kb > 96 ? 96 : s.panel_pad_kb) : pad_kb_top) * 1024;
+            if (pad_bytes) {
+                s.c->ensure_max_lds((const void*)k_rp_top<false>, 96 * 1024);
+                s.c->ensure_max_lds((const void*)k_rp_top<true>, 96 * 1024);
             }
-            if (s.xdbg) hipLaunchKernelGGL((k_lu_panel2<true, true>), dim3(1), dim3(P2_THREADS), lds_bytes, s.c->stream, g);
-            else hipLaunchKernelGGL((k_lu_panel2<false, true>), dim3(1), dim3(P2_THREADS), lds_bytes, s.c->stream, g);
+            if (s.xdbg) hipLaunchKernelGGL(k_rp_top<true>, dim3(1), dim3(RT_ROWS), pad_bytes, s.c->stream, g, (pk_u64*)s.xdbg);
+            else hipLaunchKernelGGL(k_rp_top<false>, dim3(1), dim3(RT_ROWS), pad_bytes, s.c->stream, g, (pk_u64*)nullptr);
             RMHIP_TRY(launch_check(s.c));
             if (g.rows < s.rows) {
-                const size_t nbb = (s.rows - g.rows + RB_THREADS - 1) / RB_THREADS;
-                hipLaunchKernelGGL(k_rp_below, dim3((unsigned)nbb), dim3(RB_THREADS), 0, s.c->stream, s.A, s.lda, s.rows, (size_t)g.rows, (int)j0,
-                                   (int)w, (const double*)s.ucomp, (pk_u64*)s.growth, s.tau);
+                static const int rb_threads = std::getenv("RMHIP_LU_RB_THREADS") ? std::atoi(std::getenv("RMHIP_LU_RB_THREADS")) : 64;  // developer knob (A/B)
+                const size_t rbt = rb_threads == 256 ? 256 : (rb_threads == 128 ? 128 : 64);
+                const size_t nbb = (s.rows - g.rows + rbt - 1) / rbt;
+                void (*kern)(double*, size_t, size_t, size_t, int, int, const double*, pk_u64*, double, pk_u64*) =
+                    s.xdbg ? (rbt == 256 ? k_rp_below<256, true> : (rbt == 128 ? k_rp_below<128, true> : k_rp_below<64, true>))
+                           : (rbt == 256 ? k_rp_below<256, false> : (rbt == 128 ? k_rp_below<128, false> : k_rp_below<64, false>));
+                hipLaunchKernelGGL(kern, dim3((unsigned)nbb), dim3((unsigned)rbt), 0, s.c->stream, s.A, s.lda, s.rows, (size_t)g.rows, (int)j0, (int)w,
+                                   (const double*)s.ucomp, (pk_u64*)s.growth, s.tau, (pk_u64*)s.xdbg);
                 RMHIP_TRY(launch_check(s.c));
             }
             s.xbase += (unsigned)w;
@@ -1505,7 +1757,10 @@ static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller =
                 RMHIP_HIP_CHECK(hipStreamSynchronize(s.c->stream));
                 double gmax;
                 std::memcpy(&gmax, &bits, sizeof(gmax));
-                if (!(gmax <= s.tau)) return RMHIP_LU_GROWTH;
+                if (!(gmax <= s.tau)) {
+                    s.c->lu_last_growth = gmax;
+                    return RMHIP_LU_GROWTH;
+                }
             }
             if (own_swaps_by_caller && deferred) {
                 *deferred = true;
@@ -1557,13 +1812,12 @@ static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller =
             }
             const size_t lds_bytes = P2_LDS_DOUBLES * sizeof(double) + (size_t)(s.panel_pad_kb >= 0 ? s.panel_pad_kb : pad_kb) * 1024;
             if (lds_bytes > 65536) {
-                s.c->ensure_max_lds((const void*)k_lu_panel2<false, false>, lds_bytes);
-                s.c->ensure_max_lds((const void*)k_lu_panel2<true, false>, lds_bytes);
+                s.c->ensure_max_lds((const void*)k_lu_panel2<false>, lds_bytes);
+                s.c->ensure_max_lds((const void*)k_lu_panel2<true>, lds_bytes);
             }
             const unsigned grid = (unsigned)nbp * (unsigned)g.bstride;
-            g.ucomp = nullptr;
-            if (s.xdbg) hipLaunchKernelGGL((k_lu_panel2<true, false>), dim3(grid), dim3(P2_THREADS), lds_bytes, s.c->stream, g);
-            else hipLaunchKernelGGL((k_lu_panel2<false, false>), dim3(grid), dim3(P2_THREADS), lds_bytes, s.c->stream, g);
+            if (s.xdbg) hipLaunchKernelGGL((k_lu_panel2<true>), dim3(grid), dim3(P2_THREADS), lds_bytes, s.c->stream, g);
+            else hipLaunchKernelGGL((k_lu_panel2<false>), dim3(grid), dim3(P2_THREADS), lds_bytes, s.c->stream, g);
             RMHIP_TRY(launch_check(s.c));
             s.xbase += (unsigned)w;
             s.panel_start->push_back(j0);
@@ -1720,7 +1974,10 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     // the update stream does disturbs it (without ANY update work in that phase the solve takes 95.7 instead of 108.4 ms):
     // this keeps the panel's CUs free (no drain before a panel or a 132 KiB triangular solve starts) and its L2 quiet.
     // RMHIP_LU_LATE_XCD=0 disables.
-    static const int late_xcd_on = std::getenv("RMHIP_LU_LATE_XCD") ? std::atoi(std::getenv("RMHIP_LU_LATE_XCD")) : 1;  // 2: persistent dgemm in every phase (A/B)
+    // (solve path: off by default - its panel is one workgroup and k_rp_below's workgroups fit beside a dgemm block, so there is no XCD to
+    // keep free; n = 16384: 78.8 -> 76.4 ms without the persistent form)
+    static const int late_xcd_env = std::getenv("RMHIP_LU_LATE_XCD") ? std::atoi(std::getenv("RMHIP_LU_LATE_XCD")) : -1;  // 2: persistent dgemm in every phase (A/B)
+    const int late_xcd_on = late_xcd_env >= 0 ? late_xcd_env : (s.fast ? 0 : 1);
     constexpr size_t kCounters = 4096;
     unsigned* late_counters = nullptr;
     if (late_xcd_on && c->one_xcd_ok) {
@@ -2029,10 +2286,14 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
         if (s.xdbg) {
             unsigned long long h[16];
             if (hipMemcpy(h, s.xdbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-                static const char* names[16] = {"load", "argmax+park+sync", "publish", "wait+fold", "winner vals", "sync",
-                                                "elim under exch", "park+shift", "write back", "-", "bookkeep+div", "-",
-                                                "-", "-", "-", "-"};
-                for (int i = 0; i < 11; ++i)
+                static const char* names_grid[16] = {"load", "argmax+park+sync", "publish", "wait+fold", "winner vals", "sync",
+                                                     "elim under exch", "park+shift", "write back", "-", "bookkeep+div", "-",
+                                                     "-", "-", "-", "-"};
+                static const char* names_top[16] = {"load", "candidate", "barrier", "winner+window", "park", "barrier", "g solve", "rank-8",
+                                                    "store+shift", "below: stage U", "below: load", "below: triangle", "below: stores", "below: rank-8",
+                                                    "below: tail", "-"};
+                const char* const* names = s.fast ? names_top : names_grid;
+                for (int i = 0; i < 15; ++i)
                     std::fprintf(stderr, "[lu panel] %-12s %10.1f us total  %7.3f us/column\n", names[i], h[i] * 0.01,
                                  kmin ? h[i] * 0.01 / (double)kmin : 0.0);
             }

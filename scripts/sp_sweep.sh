@@ -1,0 +1,23 @@
+#!/bin/bash
+# Developer tool (GPU box): A/B of the look-ahead driver's knobs on the solve path.  Usage: scripts/sp_sweep.sh [n]
+N=${1:-16384}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd /tmp
+run() { echo -n "$* : "; env "$@" python $ROOT/scripts/lu_trace.py $N 4 2>&1 | grep "rep=" | tail -2 | awk '{printf "%s ", $3}'; echo; }
+run X=1
+run RMHIP_LU_EARLY_SIDE_PAD=0
+run RMHIP_LU_LA_PAD=0
+run RMHIP_LU_LATE_XCD=0
+run RMHIP_LU_LATE_XCD=0 RMHIP_LU_LA_PAD=0
+run RMHIP_LU_SPLIT=0
+run RMHIP_LU_SPLIT=0 RMHIP_LU_LA_PAD=0
+run RMHIP_LU_NB_LATE=256
+run RMHIP_LU_NB_LATE=256 RMHIP_LU_NB=512
+run RMHIP_LU_NB_LATE=512 RMHIP_LU_NB=512
+run RMHIP_LU_NB_EARLY=1024
+run RMHIP_LU_PANEL_PAD_KB=0
+run RMHIP_LU_PANEL_PAD_KB=96
+run RMHIP_LU_NB_FIRST=0
+run RMHIP_LU_TRSM_2P=0
+run RMHIP_LU_LA_TRSM=64
+run X=1
