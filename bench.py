@@ -28,6 +28,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+sys.path.insert(1, str(ROOT / "tests"))  # the request emitter (tests/planner_requests.py: what RunMat's planner would send) is test / bench infrastructure
 
 import numpy as np  # noqa: E402
 
@@ -192,7 +193,7 @@ def main() -> None:
         torch.cuda.set_device(local_rank)
 
     from runmat_amd import HipProvider
-    from runmat_amd.fusion import sin_mul_add_plan
+    from planner_requests import sin_mul_add_plan
 
     prov = HipProvider(local_rank)
     n = N_DIM
@@ -328,14 +329,17 @@ def main() -> None:
     def mc_record(steps, warmup):
         """BASELINE configs[3]: Monte-Carlo GBM, M = 1e8 paths (sharded over ranks with LCG skip-ahead),
         T = 1 step, planner-shaped fused kernels; one step = one full pricing."""
+        from planner_requests import monte_carlo_shaders
+
         M, T = 100_000_000, 1
+        shaders = monte_carlo_shaders(100.0)  # compiled once per script by the planner, not per call (fusion.rs:679-682)
         price = 0.0
         for _ in range(warmup):
-            price, _ = sh.monte_carlo_price_fused(prov, group, M, T, rng_state=0x9E3779B97F4A7C15)
+            price, _ = sh.monte_carlo_price_fused(prov, group, M, T, shaders, rng_state=0x9E3779B97F4A7C15)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            price, _ = sh.monte_carlo_price_fused(prov, group, M, T, rng_state=0x9E3779B97F4A7C15)
+            price, _ = sh.monte_carlo_price_fused(prov, group, M, T, shaders, rng_state=0x9E3779B97F4A7C15)
         barrier()
         wall = max_over_ranks(time.perf_counter() - t0)
         ms = wall / steps * 1e3
@@ -354,14 +358,17 @@ def main() -> None:
     def mc_evolved_record(steps, warmup):
         """Benchmark-shaped secondary of SURVEY.md 8(d) config 4: M = 1e6 paths, T = 256 steps, the whole time
         loop as ONE `stochastic_evolution` call (state in registers) + one fused payoff reduction."""
+        from planner_requests import monte_carlo_shaders
+
         M, T = 1_000_000, 256
+        payoff = monte_carlo_shaders(100.0)[1]
         price = 0.0
         for _ in range(warmup):
-            price, _ = sh.monte_carlo_price_evolved(prov, group, M, T, rng_state=0x9E3779B97F4A7C15)
+            price, _ = sh.monte_carlo_price_evolved(prov, group, M, T, rng_state=0x9E3779B97F4A7C15, payoff_shader=payoff)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            price, _ = sh.monte_carlo_price_evolved(prov, group, M, T, rng_state=0x9E3779B97F4A7C15)
+            price, _ = sh.monte_carlo_price_evolved(prov, group, M, T, rng_state=0x9E3779B97F4A7C15, payoff_shader=payoff)
         barrier()
         wall = max_over_ranks(time.perf_counter() - t0)
         ms = wall / steps * 1e3
@@ -471,7 +478,7 @@ def main() -> None:
         """BASELINE configs[0] (the reference's CPU-runnable case) on the GPU: the 14-op
         elementwise-math chain (benchmarks/elementwise-math/runmat.m:10-13, f64) as ONE fused kernel
         over a 1024x1024 tensor; constants arrive as 1-element inputs like the planner sends them."""
-        from runmat_amd.fusion import elementwise_math_plan
+        from planner_requests import elementwise_math_plan
 
         m = 1024
         plan, out_id = elementwise_math_plan()

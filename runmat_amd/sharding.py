@@ -273,29 +273,17 @@ def monte_carlo_price_sharded(prov, group: Group, M: int, T: int, S0=100.0, mu=0
     return (total / float(M)) * math.exp(-mu * T * dt), final_state
 
 
-@functools.lru_cache(maxsize=64)
-def _mc_shaders(K: float) -> Tuple[str, str]:
-    """WGSL of the Monte-Carlo step (`S .* exp(drift + scale .* Z)`) and of the payoff reduction `sum(max(S - K, 0))`, as the
-    planner emits them once when it compiles the script's fusion groups."""
-    from .fusion import FusionGroupPlan
-
-    step = FusionGroupPlan()
-    v_s, v_z, v_scale, v_drift = step.input(), step.input(), step.input(), step.input()
-    out = step.primitive("ElemMul", v_s, step.builtin("exp", step.primitive("Add", v_drift, step.primitive("ElemMul", v_scale, v_z))))
-    red = FusionGroupPlan()
-    r_s = red.input()
-    payoff = red.builtin("max", red.primitive("Sub", r_s, red.constant(K)), red.constant(0.0))
-    return step.generate_wgsl_for_output(out, "f64"), red.generate_reduction_wgsl(payoff, "f64", axis=0)
-
-
-def monte_carlo_price_fused(prov, group: Group, M: int, T: int, S0=100.0, mu=0.05, sigma=0.2, dt=1.0 / 252.0, K=100.0,
+def monte_carlo_price_fused(prov, group: Group, M: int, T: int, shaders: Tuple[str, str], S0=100.0, mu=0.05, sigma=0.2, dt=1.0 / 252.0,
                             rng_state: Optional[int] = None) -> Tuple[float, int]:
     """Same workload as `monte_carlo_price_sharded`, issued the way RunMat's planner would: one
     fused elementwise kernel per time step (`S = S .* exp(drift + scale .* Z)`, constants as
     1-element inputs) and one fused reduction for `sum(max(S - K, 0))`.  Materialised traffic per
     path and step: randn write 8 B + fused update 24 B, plus 8 B for the final reduction
-    ((32*T + 8) * M bytes)."""
-    from .fusion import FusionGroupPlan
+    ((32*T + 8) * M bytes).
+
+    `shaders` = (step, payoff): the WGSL text of `S .* exp(drift + scale .* Z)` (inputs S, Z, scale, drift) and of the reduction
+    `sum(max(S - K, 0))`, as RunMat's planner emits them once when it compiles the script's fusion groups (fusion.rs:679-682).
+    This module does not generate requests - the caller brings them (tests/workloads.py `monte_carlo_shaders(K)` for tests and bench)."""
     from .provider import ReductionFlavor
 
     if rng_state is None:
@@ -307,7 +295,7 @@ def monte_carlo_price_fused(prov, group: Group, M: int, T: int, S0=100.0, mu=0.0
     scale = sigma * math.sqrt(dt)
     partial = 0.0
     if count > 0:
-        step_shader, red_shader = _mc_shaders(float(K))  # the plan is compiled once per script, not per call (fusion.rs:679-682)
+        step_shader, red_shader = shaders
         # constants are 1-element tensors created on the device (no host copy, no synchronisation); the initial price
         # S0 is one too and broadcasts into the first update (`S = S0 .* exp(...)`: the planner hands scalars to the
         # kernel as [1,1] inputs, fusion_exec.rs:279,305-326), so no M-element fill precedes the time loop
@@ -336,12 +324,12 @@ def monte_carlo_price_fused(prov, group: Group, M: int, T: int, S0=100.0, mu=0.0
 
 
 def monte_carlo_price_evolved(prov, group: Group, M: int, T: int, S0=100.0, mu=0.05, sigma=0.2, dt=1.0 / 252.0, K=100.0,
-                              rng_state: Optional[int] = None, fused_payoff: bool = True) -> Tuple[float, int]:
+                              rng_state: Optional[int] = None, payoff_shader: Optional[str] = None) -> Tuple[float, int]:
     """Same workload and the same random stream again, with the whole time loop as ONE provider call
     (`stochastic_evolution`, the idiom RunMat's VM recognises: crates/runmat-vm/src/accel/idioms/
     stochastic_evolution.rs) followed by one fused reduction.  HBM traffic per path: fill 8 B + evolve 16 B +
-    payoff sum 8 B = 32 B for any T (the materialised plan moves (32*T + 8) B)."""
-    from .fusion import FusionGroupPlan
+    payoff sum 8 B = 32 B for any T (the materialised plan moves (32*T + 8) B).  `payoff_shader`: the planner's fused reduction
+    `sum(max(S - K, 0))` (see `monte_carlo_price_fused`); without it the payoff is the three per-op calls."""
     from .provider import ReductionFlavor
 
     if rng_state is None:
@@ -357,12 +345,8 @@ def monte_carlo_price_evolved(prov, group: Group, M: int, T: int, S0=100.0, mu=0
         prov.set_rng_state(lcg_advance(rng_state, start))
         S_end = prov.stochastic_evolution(S, drift, scale, T, draws_per_step=per_step)
         temps = [S, S_end]
-        if fused_payoff:
-            red = FusionGroupPlan()
-            r_s = red.input()
-            payoff = red.builtin("max", red.primitive("Sub", r_s, red.constant(K)), red.constant(0.0))
-            psum = prov.fused_reduction(red.generate_reduction_wgsl(payoff, "f64", axis=0), [S_end], (1,), count, 1, 256,
-                                        ReductionFlavor.Sum())
+        if payoff_shader is not None:
+            psum = prov.fused_reduction(payoff_shader, [S_end], (1,), count, 1, 256, ReductionFlavor.Sum())
         else:  # per-op form (max(S - K, 0) then sum), as monte_carlo_price_sharded
             d = prov.scalar_sub(S_end, K)
             pay = prov.scalar_max(d, 0.0)

@@ -1,9 +1,10 @@
 """Developer tool: rates of the general-broadcast kernels at 8192^2 f64."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(1, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from runmat_amd import HipProvider
-from runmat_amd.fusion import FusionGroupPlan
+from planner_requests import FusionGroupPlan
 prov = HipProvider(0)
 n = 8192
 a = prov.fill_uniform(1, -1, 1, (n, n)); row = prov.fill_uniform(2, -1, 1, (1, n)); col = prov.fill_uniform(3, -1, 1, (n, 1))

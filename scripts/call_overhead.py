@@ -1,9 +1,10 @@
 """Developer tool: host-side cost of one provider call (tiny operands, so the kernel itself is negligible)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(1, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from runmat_amd import HipProvider
-from runmat_amd.fusion import sin_mul_add_plan, elementwise_math_plan
+from planner_requests import sin_mul_add_plan, elementwise_math_plan
 prov = HipProvider(0)
 def rate(tag, f, n=3000):
     for _ in range(50): prov.free(f())

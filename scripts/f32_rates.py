@@ -3,8 +3,9 @@ Bytes are the algorithmic bytes of each storage type."""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(1, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from runmat_amd import HipProvider
-from runmat_amd.fusion import sin_mul_add_plan
+from planner_requests import sin_mul_add_plan
 
 N = 8192
 

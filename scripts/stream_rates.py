@@ -1,6 +1,7 @@
 """Developer tool: rates of the ahead-of-time streaming kernels at 8192^2 f64 (per-op elementwise, reductions, dot, fill)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(1, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from runmat_amd import HipProvider
 prov = HipProvider(0)
@@ -28,6 +29,6 @@ rate("random_normal", lambda: prov.random_normal((n, n)), N)
 rate("random_uniform", lambda: prov.random_uniform((n, n)), N)
 for nm in ("abs", "sqrt", "exp", "cos", "tanh", "neg"):
     rate("unary_" + nm, (lambda f: (lambda: f(a)))(getattr(prov, "unary_" + nm)), 2 * N)
-from runmat_amd.fusion import FusionGroupPlan
+from planner_requests import FusionGroupPlan
 t = FusionGroupPlan(); x = t.input(); sh = t.generate_wgsl_for_output(t.builtin("sin", x))
 rate("fused sin(A)", lambda: prov.fused_elementwise(sh, [a], (n, n), n * n), 2 * N)

@@ -1,6 +1,8 @@
 """Developer tool: the second-tier kernels of VERDICT round 1 (Monte-Carlo step, image_normalize, sum(x,2)) - ms and GB/s."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(1, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from planner_requests import monte_carlo_shaders
 import numpy as np
 from runmat_amd import HipProvider
 from runmat_amd import sharding as sh
@@ -29,6 +31,6 @@ prov.free(img); prov.free(a)
 g = sh.Group()
 for rep in range(4):
     prov.synchronize(); t0 = time.perf_counter()
-    price, _ = sh.monte_carlo_price_fused(prov, g, 100_000_000, 1, rng_state=0x9E3779B97F4A7C15)
+    price, _ = sh.monte_carlo_price_fused(prov, g, 100_000_000, 1, monte_carlo_shaders(100.0), rng_state=0x9E3779B97F4A7C15)
     dt = time.perf_counter() - t0
     print(f"monte_carlo_price_fused 1e8: {dt*1e3:.3f} ms  {40*1e8/dt/1e9:.0f} GB/s  price {price:.9f}", flush=True)

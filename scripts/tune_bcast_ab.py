@@ -1,9 +1,10 @@
 """Developer tool: interleaved A/B of the generated broadcast kernel's block size / elements per thread."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(1, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from runmat_amd import HipProvider
-from runmat_amd.fusion import FusionGroupPlan
+from planner_requests import FusionGroupPlan
 PREC = os.environ.get("RMHIP_TUNE_PRECISION", "F64")  # F32: the f32-storage variant (bytes per element halve)
 prov = HipProvider(0, precision=PREC)
 TY = "f32" if PREC == "F32" else "f64"

@@ -1,9 +1,10 @@
 """Developer tool: sweep the fused-elementwise code generator's tunables on the GPU."""
 import itertools, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(1, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from runmat_amd import HipProvider
-from runmat_amd.fusion import sin_mul_add_plan, FusionGroupPlan
+from planner_requests import sin_mul_add_plan, FusionGroupPlan
 
 prov = HipProvider(0)
 n = 8192

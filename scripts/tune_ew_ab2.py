@@ -1,9 +1,10 @@
 """Developer tool: interleaved A/B of grid cap / chunking / non-temporal hints for the headline fused kernel at block 1024."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(1, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from runmat_amd import HipProvider
-from runmat_amd.fusion import sin_mul_add_plan
+from planner_requests import sin_mul_add_plan
 prov = HipProvider(0)
 n = 8192
 ins = [prov.fill_uniform(1, -np.pi, np.pi, (n, n)), prov.fill_uniform(2, -1, 1, (n, n)), prov.fill_uniform(3, -1, 1, (n, n))]

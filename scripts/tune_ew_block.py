@@ -1,9 +1,10 @@
 """Developer tool: block-size / blocks-per-CU sweep for the headline fused kernel (complements tune_ew.py)."""
 import itertools, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(1, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from runmat_amd import HipProvider
-from runmat_amd.fusion import sin_mul_add_plan
+from planner_requests import sin_mul_add_plan
 prov = HipProvider(0)
 n = 8192
 ins = [prov.fill_uniform(1, -np.pi, np.pi, (n, n)), prov.fill_uniform(2, -1, 1, (n, n)), prov.fill_uniform(3, -1, 1, (n, n))]

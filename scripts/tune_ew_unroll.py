@@ -1,9 +1,10 @@
 """Developer tool: unroll sweep (1, 2, 3, 4, 8) for representative fused bodies at 8192^2 f64."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(1, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from runmat_amd import HipProvider
-from runmat_amd.fusion import sin_mul_add_plan, FusionGroupPlan, elementwise_math_plan
+from planner_requests import sin_mul_add_plan, FusionGroupPlan, elementwise_math_plan
 prov = HipProvider(0)
 n = 8192
 ha = prov.fill_uniform(1, -np.pi, np.pi, (n, n)); hb = prov.fill_uniform(2, -1, 1, (n, n)); hc = prov.fill_uniform(3, -1, 1, (n, n))

@@ -1,4 +1,6 @@
-"""Host-side executors: mirror of `execute_elementwise` / `execute_reduction`
+"""TEST / BENCH INFRASTRUCTURE (not product code; the product is librmhip.so behind include/rmhip.h).
+
+Host-side executors: mirror of `execute_elementwise` / `execute_reduction`
 (crates/runmat-accelerate/src/fusion_exec.rs:196-628), i.e. what sits between the VM and the
 provider call: resolve the output shape (plan shape or runtime broadcast, trailing-aligned,
 :216-277), upload host operands and scalars (scalars become 1-element tensors shaped [1,1,...],
@@ -12,8 +14,8 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .fusion import FusionGroupPlan
-from .provider import GpuTensorHandle, ProviderError, ReductionFlavor
+from planner_requests import FusionGroupPlan
+from runmat_amd.provider import GpuTensorHandle, ProviderError, ReductionFlavor
 
 ERR_UNSUPPORTED = 2
 

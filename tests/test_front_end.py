@@ -42,10 +42,12 @@ def test_product_package_never_touches_oracle():
         if f.suffix in (".py", ".cpp", ".h", ".hip") and f.is_file():
             text = f.read_text()
             assert "liboracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+            # ... nor the request emitter: what RunMat's planner sends is reproduced under tests/ only
+            assert "planner_requests" not in text and "planner_exec" not in text and "FusionGroupPlan" not in text, f
 
 
 def test_rust_float_display():
-    from runmat_amd.fusion import rust_f64_display as d
+    from planner_requests import rust_f64_display as d
 
     assert d(2.0) == "2" and d(0.25) == "0.25" and d(-0.1) == "-0.1" and d(10.0) == "10"
     assert d(1e21) == "1000000000000000000000" and d(1e-7) == "0.0000001"
@@ -54,7 +56,7 @@ def test_rust_float_display():
 
 def test_sin_mul_add_shader_text_and_translation(built):
     from runmat_amd import wgsl_translate
-    from runmat_amd.fusion import sin_mul_add_plan
+    from planner_requests import sin_mul_add_plan
 
     plan, out = sin_mul_add_plan()
     sh = plan.generate_wgsl_for_output(out, "f64")
@@ -74,7 +76,7 @@ def test_sin_mul_add_shader_text_and_translation(built):
 def test_parity_rewrites_log10_log1p_expm1(built):
     """fusion.rs:3005-3019 emits lossy forms; the CPU builtins use libm log10/ln_1p/exp_m1."""
     from runmat_amd import wgsl_translate
-    from runmat_amd.fusion import FusionGroupPlan
+    from planner_requests import FusionGroupPlan
 
     p = FusionGroupPlan()
     x = p.input()
@@ -98,7 +100,7 @@ def test_parity_rewrites_log10_log1p_expm1(built):
 def test_full_vocabulary_translates_and_compiles(built):
     """Every function of builtin_expr / primitive_expr (fusion.rs:2874-3026) in one plan."""
     from runmat_amd import wgsl_compile_check, wgsl_translate
-    from runmat_amd.fusion import FusionGroupPlan
+    from planner_requests import FusionGroupPlan
 
     p = FusionGroupPlan()
     x, y = p.input(), p.input()
@@ -126,7 +128,7 @@ def test_full_vocabulary_translates_and_compiles(built):
 
 def test_multi_output_shader(built):
     from runmat_amd import wgsl_compile_check, wgsl_translate
-    from runmat_amd.fusion import FusionGroupPlan
+    from planner_requests import FusionGroupPlan
 
     p = FusionGroupPlan()
     a, b = p.input(), p.input()
@@ -142,7 +144,7 @@ def test_multi_output_shader(built):
 @pytest.mark.parametrize("axis", [0, 1])
 def test_reduction_shader(built, axis):
     from runmat_amd import wgsl_compile_check, wgsl_translate
-    from runmat_amd.fusion import FusionGroupPlan
+    from planner_requests import FusionGroupPlan
 
     p = FusionGroupPlan()
     x, w = p.input(), p.input()
@@ -168,7 +170,7 @@ def test_reduction_shader(built, axis):
 def test_front_end_is_strict(built, mutate, needle):
     """Anything outside the subset is an error (-> the caller's CPU fallback), never a guess."""
     from runmat_amd import ProviderError, wgsl_translate
-    from runmat_amd.fusion import sin_mul_add_plan
+    from planner_requests import sin_mul_add_plan
 
     plan, out = sin_mul_add_plan()
     sh = mutate(plan.generate_wgsl_for_output(out))
@@ -179,7 +181,7 @@ def test_front_end_is_strict(built, mutate, needle):
 
 def test_literals_are_exact(built):
     from runmat_amd import wgsl_translate
-    from runmat_amd.fusion import FusionGroupPlan
+    from planner_requests import FusionGroupPlan
 
     p = FusionGroupPlan()
     x = p.input()
@@ -195,7 +197,7 @@ def test_runtime_broadcast_shape_rules():
     """fusion_exec.rs:216-245"""
     import numpy as np
 
-    from runmat_amd.fusion_exec import normalize_scalar_shape, runtime_broadcast_shape
+    from planner_exec import normalize_scalar_shape, runtime_broadcast_shape
     from runmat_amd.provider import GpuTensorHandle
 
     h = GpuTensorHandle((4, 1), 1, 1)
@@ -212,7 +214,7 @@ def test_f32_shaders_lower_to_f32_storage_with_f64_arithmetic(built):
     write `float` (four per 16-byte vector) while the body stays `double` -- the CPU path computes `single` arrays in
     f64 and rounds once (elementwise/times.rs:750-760)."""
     from runmat_amd import wgsl_compile_check, wgsl_translate
-    from runmat_amd.fusion import FusionGroupPlan, elementwise_math_plan, sin_mul_add_plan
+    from planner_requests import FusionGroupPlan, elementwise_math_plan, sin_mul_add_plan
 
     plan, out = sin_mul_add_plan()
     sh = plan.generate_wgsl_for_output(out, "f32")
@@ -244,7 +246,7 @@ def test_front_end_survives_mangled_shaders(built):
     import random
 
     from runmat_amd import ProviderError, wgsl_translate
-    from runmat_amd.fusion import FusionGroupPlan, elementwise_math_plan, sin_mul_add_plan
+    from planner_requests import FusionGroupPlan, elementwise_math_plan, sin_mul_add_plan
 
     plan, out = sin_mul_add_plan()
     plan2, out2 = elementwise_math_plan()

@@ -166,7 +166,7 @@ def _chain_cpu_single(oracle, x):
 
 @pytest.mark.parametrize("shape", [(1, 1), (3, 1), (7, 1), (5, 3), (127, 9), (1024, 33), (4093, 1), (512, 512)])
 def test_f32_fused_elementwise_fast_path(prov32, prov, oracle, shape):
-    from runmat_amd.fusion import elementwise_math_plan, sin_mul_add_plan
+    from planner_requests import elementwise_math_plan, sin_mul_add_plan
 
     rng = np.random.default_rng(shape[0] * 31 + shape[1])
     A, B, C = (f32r(rng.uniform(-np.pi, np.pi, shape)) for _ in range(3))
@@ -180,7 +180,7 @@ def test_f32_fused_elementwise_fast_path(prov32, prov, oracle, shape):
     want = f32r(f32r(f32r(oracle.unary("sin", A)) * B) + C)
     assert close32(prov32.download_matrix(h32), want, ulps=2.0, atol=2 * ULP32)
     # the 14-op benchmark chain; its constants arrive as 1-element inputs (stored as f32 like every tensor of this provider)
-    from runmat_amd.fusion_exec import execute_elementwise
+    from planner_exec import execute_elementwise
 
     plan2, out2 = elementwise_math_plan()
     x = f32r(np.linspace(0.0, 4.0 * np.pi, n).reshape(shape, order="F"))
@@ -196,7 +196,7 @@ def test_f32_generated_sin_cos_whole_range(prov32, oracle):
     """Generated kernels of a precision-32 provider use rm_sincos_r32 (skel_common.h): one-step Cody-Waite + the plain
     minimax polynomials below 2^20, the library path above.  Against the oracle's f64 sin / cos rounded once: never more
     than 1 ulp of f32 away, and (because the f64 error is ~1 ulp of f64) the same f32 value everywhere on this sample."""
-    from runmat_amd.fusion import FusionGroupPlan
+    from planner_requests import FusionGroupPlan
 
     rng = np.random.default_rng(77)
     k = np.arange(-4000, 4001, dtype=np.float64)
@@ -227,8 +227,8 @@ def test_f32_generated_sin_cos_whole_range(prov32, oracle):
         prov32.free(h)
 
 def test_f32_fused_scalars_broadcast_and_multi_output(prov32, prov, oracle):
-    from runmat_amd.fusion import FusionGroupPlan
-    from runmat_amd.fusion_exec import execute_elementwise, execute_reduction
+    from planner_requests import FusionGroupPlan
+    from planner_exec import execute_elementwise, execute_reduction
 
     rng = np.random.default_rng(9)
     p = FusionGroupPlan()
@@ -265,7 +265,7 @@ def test_f32_fused_scalars_broadcast_and_multi_output(prov32, prov, oracle):
 
 def test_f32_shader_precision_must_match_provider(prov32, prov):
     from runmat_amd import ProviderError
-    from runmat_amd.fusion import sin_mul_add_plan
+    from planner_requests import sin_mul_add_plan
 
     plan, out = sin_mul_add_plan()
     A = np.ones((4, 4))
@@ -481,7 +481,7 @@ def test_f32_context_with_external_f64_memory_and_block_views(prov32, prov):
 def test_f32_large_fused_and_traffic_halves(prov32, prov):
     """8192 x 2048 keeps the test quick: the f32 kernel must agree with the f64 kernel everywhere and run measurably
     faster (half the bytes); the strict bandwidth numbers live in bench.py / DESIGN.md."""
-    from runmat_amd.fusion import sin_mul_add_plan
+    from planner_requests import sin_mul_add_plan
 
     shape = (8192, 2048)
     n = shape[0] * shape[1]
@@ -514,8 +514,8 @@ def test_f32_provider_against_the_reference_scripts_float32_outputs(prov32):
 
     sys.path.insert(0, str(Path(__file__).resolve().parent))
     from workloads import golden_elementwise_math, golden_image_cases, lcg_image_field
-    from runmat_amd.fusion import elementwise_math_plan
-    from runmat_amd.fusion_exec import execute_elementwise
+    from planner_requests import elementwise_math_plan
+    from planner_exec import execute_elementwise
 
     g = golden_image_cases()
     p = g["params"]

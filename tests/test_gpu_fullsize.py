@@ -15,7 +15,7 @@ N = 8192
 def test_fused_sin_mul_add_8192(prov, oracle):
     """BASELINE configs[1]: D = sin(A).*B + C on 8192x8192 f64, inputs generated on device with the
     same counter-based splitmix64 fill the oracle uses."""
-    from runmat_amd.fusion import sin_mul_add_plan
+    from planner_requests import sin_mul_add_plan
 
     plan, out = sin_mul_add_plan()
     sh = plan.generate_wgsl_for_output(out, "f64")

@@ -149,9 +149,20 @@ def test_monte_carlo_price_full_size(prov, case):
     g = sh.Group()
     M, T, want = case["M"], case["T"], case["price"]
     s0 = case["seed_state"]
-    forms = [sh.monte_carlo_price_evolved]
+    from planner_requests import monte_carlo_shaders
+
+    shaders = monte_carlo_shaders(100.0)
+
+    def evolved(prov, g, M, T, rng_state):
+        return sh.monte_carlo_price_evolved(prov, g, M, T, rng_state=rng_state, payoff_shader=shaders[1])
+
+    def fused(prov, g, M, T, rng_state):
+        return sh.monte_carlo_price_fused(prov, g, M, T, shaders, rng_state=rng_state)
+
+    evolved.__name__, fused.__name__ = "monte_carlo_price_evolved", "monte_carlo_price_fused"
+    forms = [evolved]
     if T <= 4:
-        forms += [sh.monte_carlo_price_fused, sh.monte_carlo_price_sharded]
+        forms += [fused, sh.monte_carlo_price_sharded]
     for f in forms:
         price, state = f(prov, g, M, T, rng_state=s0)
         assert state == case["final_state"], f.__name__

@@ -38,10 +38,13 @@ def _worker(rank, world, port, out_dir, native):
         if native:  # control plane stays gloo (it carries the 128-byte id); the data path is rmhip_comm_*
             group.with_native_comm(prov, transport="shm")
             assert prov.comm_rank() == (rank, world)
+        from planner_requests import monte_carlo_shaders
+
+        shaders = monte_carlo_shaders(100.0)
         seed = 0x9E3779B97F4A7C15
         M, T = 200001, 3  # odd M: the last pair is half used
-        p_fused, s_fused = sh.monte_carlo_price_fused(prov, group, M, T, rng_state=seed)
-        p_evol, s_evol = sh.monte_carlo_price_evolved(prov, group, M, T, rng_state=seed)
+        p_fused, s_fused = sh.monte_carlo_price_fused(prov, group, M, T, shaders, rng_state=seed)
+        p_evol, s_evol = sh.monte_carlo_price_evolved(prov, group, M, T, rng_state=seed, payoff_shader=shaders[1])
         # row-sharded matmul: this rank's rows of A from the global generator, B replicated
         m, k, n = 384, 96, 160
         rng = np.random.default_rng(11)
@@ -121,7 +124,9 @@ def test_rccl_one_rank_communicator(prov, oracle):
         p2.comm_barrier()
         assert np.array_equal(p2.download_matrix(h), X)
         want, want_state = oracle.monte_carlo_price(oracle.rng_default_seed(), 50001, 2)
-        price, state = sh.monte_carlo_price_fused(p2, g, 50001, 2, rng_state=oracle.rng_default_seed())
+        from planner_requests import monte_carlo_shaders
+
+        price, state = sh.monte_carlo_price_fused(p2, g, 50001, 2, monte_carlo_shaders(100.0), rng_state=oracle.rng_default_seed())
         assert state == want_state and abs(price - want) <= 1e-10 * want
         n, nb = 700, 128
         A = rng.standard_normal((n, n))

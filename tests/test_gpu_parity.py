@@ -96,7 +96,7 @@ def _run_fused(prov, plan, out_ids, arrays, out_shape):
 
 @pytest.mark.parametrize("shape", [(1024, 1024), (257, 131), (1, 1), (7, 1), (1, 9), (3, 5, 7), (2049,)])
 def test_fused_sin_mul_add_vs_oracle(prov, oracle, shape):
-    from runmat_amd.fusion import sin_mul_add_plan
+    from planner_requests import sin_mul_add_plan
 
     rng = np.random.default_rng(hash(shape) % 1000)
     A = rng.uniform(-np.pi, np.pi, shape)
@@ -113,7 +113,7 @@ def test_fused_sin_mul_add_vs_oracle(prov, oracle, shape):
 
 
 def _unary_plan(name):
-    from runmat_amd.fusion import FusionGroupPlan
+    from planner_requests import FusionGroupPlan
 
     p = FusionGroupPlan()
     x = p.input()
@@ -132,7 +132,7 @@ def test_fused_large_argument_sin(prov, oracle):
 
 
 def test_fused_broadcast_cases(prov, oracle):
-    from runmat_amd.fusion import FusionGroupPlan
+    from planner_requests import FusionGroupPlan
 
     rng = np.random.default_rng(12)
     cases = [((4, 1), (1, 3), (4, 3)), ((2, 3), (2, 1), (2, 3)), ((300, 200), (1, 1), (300, 200)),
@@ -150,7 +150,7 @@ def test_fused_broadcast_cases(prov, oracle):
 
 def test_fused_scalar_inputs_are_broadcast_and_constants_are_inputs(prov, oracle):
     # fusion_exec.rs:305-326: scalars arrive as 1-element tensors shaped [1,1]
-    from runmat_amd.fusion import elementwise_math_plan
+    from planner_requests import elementwise_math_plan
 
     x = np.linspace(0.0, 4.0 * np.pi, 1024 * 1024).reshape(1024, 1024, order="F")  # BASELINE configs[0]
     plan, out = elementwise_math_plan()
@@ -162,7 +162,7 @@ def test_fused_scalar_inputs_are_broadcast_and_constants_are_inputs(prov, oracle
 
 
 def test_fused_multi_output(prov, oracle):
-    from runmat_amd.fusion import FusionGroupPlan
+    from planner_requests import FusionGroupPlan
 
     rng = np.random.default_rng(13)
     A, B = rng.standard_normal((129, 65)), rng.standard_normal((129, 65))
@@ -176,7 +176,7 @@ def test_fused_multi_output(prov, oracle):
 
 
 def test_fused_exact_ops_and_policies_bitwise(prov, oracle):
-    from runmat_amd.fusion import FusionGroupPlan
+    from planner_requests import FusionGroupPlan
 
     special = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 1.5, -1.5, 2.5, -2.5, np.inf, -np.inf, np.nan, 1e-310, 3.0, -7.25])
     X, Y = np.meshgrid(special, special, indexing="ij")
@@ -215,7 +215,7 @@ def test_fused_libm_functions_ulp(prov, oracle, name):
 
 
 def test_fused_pow_hypot_atan2(prov, oracle):
-    from runmat_amd.fusion import FusionGroupPlan
+    from planner_requests import FusionGroupPlan
 
     rng = np.random.default_rng(15)
     X, Y = rng.uniform(0.01, 20, (4096, 1)), rng.uniform(-5, 5, (4096, 1))
@@ -229,7 +229,7 @@ def test_fused_pow_hypot_atan2(prov, oracle):
 
 def test_fused_errors(prov):
     from runmat_amd import ProviderError
-    from runmat_amd.fusion import sin_mul_add_plan
+    from planner_requests import sin_mul_add_plan
 
     plan, out = sin_mul_add_plan()
     sh = plan.generate_wgsl_for_output(out)
@@ -272,7 +272,7 @@ def _fused_reduce(prov, plan, data_vid, arrays, axis, reduce_len, num_slices, fl
 def test_fused_reduction_sum_mul_kat(prov):
     # crates/runmat-accelerate/tests/fused_reduction_sum_mul.rs:40-137 (X[r,c]=r+1, W[r,c]=c+1), tol 1e-6;
     # integers => exact here
-    from runmat_amd.fusion import FusionGroupPlan
+    from planner_requests import FusionGroupPlan
 
     rows, cols = 1000, 37
     X = np.fromfunction(lambda r, c: r + 1.0, (rows, cols))
@@ -287,7 +287,7 @@ def test_fused_reduction_sum_mul_kat(prov):
 @pytest.mark.parametrize("rows,cols", [(512, 512), (1024, 1024), (33, 7), (1, 300), (300, 1), (100000, 3), (3, 100000)])
 def test_fused_reduction_rows_of_sin_x_times_x(prov, oracle, rows, cols):
     # crates/runmat-vm/tests/fusion_gpu.rs:1429-1449: Y = sin(X).*X + 2; S = sum(Y, 2); also sum(Y, 1) and 'all'
-    from runmat_amd.fusion import FusionGroupPlan
+    from planner_requests import FusionGroupPlan
 
     X = np.fromfunction(lambda r, c: ((c % 97) + 1) * 10.0 + (r % 1013) + 1, (rows, cols))
     Y = oracle.binary("add", oracle.binary("mul", oracle.unary("sin", X), X), np.array([[2.0]]))
@@ -315,7 +315,7 @@ def test_fused_reduction_rows_of_sin_x_times_x(prov, oracle, rows, cols):
 
 def test_fused_reduction_nan_policy_mean_and_scale(prov, oracle):
     from runmat_amd import ReductionFlavor
-    from runmat_amd.fusion import FusionGroupPlan
+    from planner_requests import FusionGroupPlan
 
     rng = np.random.default_rng(16)
     X = rng.standard_normal((400, 9))
@@ -728,8 +728,11 @@ def test_sharding_paths_on_one_gpu(prov, oracle):
     M, T = 100001, 3
     want, want_state = oracle.monte_carlo_price(oracle.rng_default_seed(), M, T)
     p1, s1 = sh.monte_carlo_price_sharded(prov, g, M, T, rng_state=oracle.rng_default_seed())
-    p2, s2 = sh.monte_carlo_price_fused(prov, g, M, T, rng_state=oracle.rng_default_seed())
-    p3, s3 = sh.monte_carlo_price_evolved(prov, g, M, T, rng_state=oracle.rng_default_seed())  # one-call time loop
+    from planner_requests import monte_carlo_shaders
+
+    shaders = monte_carlo_shaders(100.0)
+    p2, s2 = sh.monte_carlo_price_fused(prov, g, M, T, shaders, rng_state=oracle.rng_default_seed())
+    p3, s3 = sh.monte_carlo_price_evolved(prov, g, M, T, rng_state=oracle.rng_default_seed(), payoff_shader=shaders[1])  # one-call time loop
     assert s1 == want_state and s2 == want_state and s3 == want_state
     assert abs(p1 - want) <= 1e-10 * want and abs(p2 - want) <= 1e-10 * want and abs(p3 - want) <= 1e-10 * want
     # row-block matmul + device-side gather are identities at world 1
@@ -743,8 +746,8 @@ def test_sharding_paths_on_one_gpu(prov, oracle):
 def test_host_executors_mixed_operands(prov, oracle):
     """execute_elementwise / execute_reduction (fusion_exec.rs:196-628): resident handles, host
     tensors and scalars in one request; temporaries freed; shapes from runtime broadcast."""
-    from runmat_amd.fusion import FusionGroupPlan
-    from runmat_amd.fusion_exec import execute_elementwise, execute_reduction
+    from planner_requests import FusionGroupPlan
+    from planner_exec import execute_elementwise, execute_reduction
 
     rng = np.random.default_rng(21)
     A = rng.standard_normal((64, 1))
@@ -1295,7 +1298,7 @@ def test_mrdivide_and_solve_telemetry(prov, oracle):
     fb = dict(t["solve_fallbacks"])
     assert fb == {"mrdivide:unsupported": 1, "mldivide:singular": 1, "mldivide:unsupported": 1}
     # kernel-launch log: names and attribute keys of the reference's wgpu provider (ops/telemetry.rs:26-34, 140-146; helpers.rs:36-50)
-    from runmat_amd.fusion import FusionGroupPlan, sin_mul_add_plan
+    from planner_requests import FusionGroupPlan, sin_mul_add_plan
     from runmat_amd.provider import ReductionFlavor
 
     prov.reset_telemetry()

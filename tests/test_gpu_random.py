@@ -4,7 +4,7 @@ generator, broadcast addressing and CPU-policy helpers all in one property)."""
 import numpy as np
 import pytest
 
-from runmat_amd.fusion import FusionGroupPlan
+from planner_requests import FusionGroupPlan
 
 pytestmark = pytest.mark.gpu
 

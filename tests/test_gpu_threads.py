@@ -30,7 +30,7 @@ def _work_solve(prov, ha, hb, out, reps):
 
 
 def test_two_threads_one_context(prov):
-    from runmat_amd.fusion import sin_mul_add_plan
+    from planner_requests import sin_mul_add_plan
 
     rng = np.random.default_rng(3)
     n = 1536

@@ -11,7 +11,7 @@
                                                                     the tree; its shape - 1024 x 1024 times 1024 x 8, repeated,
                                                                     product never collapsing to zero - is kept on a seeded input)
   crates/runmat-accelerate/src/fusion.rs:3736-3875                  (unit tests of the shader generator: `builds_plan_and_template`,
-                                                                    `builtin_expr_supports_extended_set`) against runmat_amd/fusion.py,
+                                                                    `builtin_expr_supports_extended_set`) against tests/planner_requests.py,
                                                                     the request emitter the tests and bench.py drive the ABI with.
 
 Each case runs twice: on the oracle (CPU, `-m "not gpu"`: pins the restatement to the reference's expected values with
@@ -40,7 +40,7 @@ def _epilogue_case_1():
 
 
 def _fused_plan_mul(inputs=2):
-    from runmat_amd.fusion import FusionGroupPlan
+    from planner_requests import FusionGroupPlan
 
     p = FusionGroupPlan()
     ids = [p.input() for _ in range(inputs)]
@@ -98,9 +98,9 @@ def test_oracle_transpose_kats(oracle):
 
 
 def test_request_emitter_matches_the_generators_unit_tests():
-    """fusion.rs unit tests on runmat_amd/fusion.py: `builds_plan_and_template` (:3736-3747), `builtin_expr_supports_
+    """fusion.rs unit tests on tests/planner_requests.py: `builds_plan_and_template` (:3736-3747), `builtin_expr_supports_
     extended_set` (:3821-3875), and the module prologue build_wgsl_shader writes (:1536-1610)."""
-    from runmat_amd.fusion import FusionGroupPlan, builtin_expr, sin_mul_add_plan
+    from planner_requests import FusionGroupPlan, builtin_expr, sin_mul_add_plan
 
     plan, out = sin_mul_add_plan()
     for ty in ("f32", "f64"):
@@ -156,7 +156,7 @@ def test_gpu_matmul_epilogue_kats(prov, oracle):
 
 @pytest.mark.gpu
 def test_gpu_fused_reduction_kats(prov, oracle):
-    from runmat_amd.fusion import FusionGroupPlan
+    from planner_requests import FusionGroupPlan
     from runmat_amd.provider import ReductionFlavor
 
     # fused_square_mean_all_parity.rs / reduction_mean_all.rs: mean(x.*x, 'all') as ONE fused reduction request

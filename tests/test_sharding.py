@@ -68,8 +68,7 @@ def _worker(rank, world, port, out_dir):
         # --- Monte-Carlo with skip-ahead ---
         M, T = 20001, 3  # odd M: the last pair is half used
         price, state = sh.monte_carlo_price_sharded(prov, group, M, T, rng_state=oracle.rng_default_seed())
-        price_ev, state_ev = sh.monte_carlo_price_evolved(prov, group, M, T, rng_state=oracle.rng_default_seed(),
-                                                          fused_payoff=False)
+        price_ev, state_ev = sh.monte_carlo_price_evolved(prov, group, M, T, rng_state=oracle.rng_default_seed())
         # --- ordered sum ---
         total = group.ordered_sum(0.1 * (rank + 1))
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), C=C, price=price, state=np.uint64(state), total=total,

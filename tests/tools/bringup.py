@@ -2,10 +2,11 @@
 and prints errors/timings. Not part of the test-suite."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(1, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np
 from oracle import oracle
 from runmat_amd import HipProvider, ReductionFlavor, ProviderError
-from runmat_amd.fusion import sin_mul_add_plan, elementwise_math_plan, FusionGroupPlan
+from planner_requests import sin_mul_add_plan, elementwise_math_plan, FusionGroupPlan
 
 def t(name, f):
     try:
