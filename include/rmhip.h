@@ -202,6 +202,32 @@ enum rmhip_reduce_op { RMHIP_RSUM = 0, RMHIP_RMEAN, RMHIP_RMIN, RMHIP_RMAX, RMHI
 RMHIP_API int rmhip_reduce(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int nan_mode,
                            rmhip_buf* out);
 
+/* `reduce_min_dim` / `reduce_max_dim` (lib.rs:2864-2883) -> `ReduceDimResult{values, indices}` (:513-517): minimum / maximum
+ * along `dim` (zero-based) of an N-d tensor and WHERE it is - both outputs have the input's shape with extent 1 at `dim`; indices
+ * are 1-based positions along `dim`, as f64.  op = RMHIP_RMIN / RMHIP_RMAX.  Semantics are the CPU builtin's
+ * (runtime/builtins/math/reduction/min.rs:1443-1531, max.rs:1715-1727), which is what the runtime expects back (it calls the hook
+ * in "includenan" mode only, min.rs:795-800): the FIRST occurrence wins ties, -0 is below +0, and with nan_mode 0 (include) the
+ * first NaN of a slice fixes the result (value NaN, index of that NaN); nan_mode 1 (omit) skips NaNs, a slice of NaNs gives
+ * (NaN, NaN).  Integer work: values and indices are bit-exact with the CPU's. */
+RMHIP_API int rmhip_reduce_minmax_dim(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int nan_mode, rmhip_buf* values,
+                                      rmhip_buf* indices);
+/* `reduce_std` / `reduce_std_dim` (lib.rs:2786-2802): standard deviation along `dim` (zero-based; dim < 0: all elements ->
+ * [1,1]).  normalization 0 = sample (n - 1; 0 for a single value), 1 = population (`ProviderStdNormalization`, :957-960);
+ * nan_mode as above (include: any NaN => NaN; omit: NaNs skipped, none left => NaN).  std.rs:858-935: Welford's update,
+ * merged over chunks with Chan's formula. */
+RMHIP_API int rmhip_reduce_std(rmhip_ctx* ctx, rmhip_buf a, int dim, int normalization, int nan_mode, rmhip_buf* out);
+/* `reduce_nnz(_dim)` (lib.rs:2730-2742), `reduce_any(_dim)` / `reduce_all(_dim)` (:2803-2850): counts / truth values as f64.
+ * nnz counts NaNs as non-zero (nnz.rs:358).  any: include => a NaN is true, omit_nan => NaNs are skipped (any.rs:722-733);
+ * all: NaNs are skipped in both modes and a slice with nothing left is true (all.rs:671-703).  dim < 0: all elements. */
+enum rmhip_truth_op { RMHIP_TNNZ = 0, RMHIP_TANY, RMHIP_TALL, RMHIP_TRUTH_OP_COUNT };
+RMHIP_API int rmhip_reduce_truth(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int omit_nan, rmhip_buf* out);
+/* `cumsum_scan` / `cumprod_scan` (lib.rs:2884-2891, 2908-2915): running sum (op 0) / product (op 1) along `dim` (zero-based),
+ * forward or reverse (`ProviderScanDirection`, :1053-1056), NaN modes of cumsum.rs:586-650 (include: NaN from the first NaN
+ * on; omit: NaNs leave the running value unchanged).  Same shape as the input.  Along a strided dimension every line is the
+ * CPU's own left-to-right sequence (bit-identical); long contiguous lines are scanned in blocks (equal up to rounding, exact for
+ * integer-valued data). */
+RMHIP_API int rmhip_cumulative(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int reverse, int nan_mode, rmhip_buf* out);
+
 /* `dot` (lib.rs:2722-2728): sum(a .* b) along `dim` (zero-based) of two same-shape tensors; dim < 0
  * = first non-singleton dimension (vectors -> scalar [1,1]). One fused pass, no temporary. */
 /* `reduce_mean_nd` (lib.rs:2763-2769; shape rules backend/wgpu/provider/ops/reduction/nd.rs:59-72): reduce several

@@ -221,6 +221,47 @@ public:
     }
     GpuTensorHandle reduce_min(const GpuTensorHandle& a) const { return reduce(RMHIP_RMIN, a, -1); }
     GpuTensorHandle reduce_max(const GpuTensorHandle& a) const { return reduce(RMHIP_RMAX, a, -1); }
+    // lib.rs:2864-2883 -> ReduceDimResult { values, indices } (lib.rs:513-517); CPU semantics (first occurrence, first NaN wins)
+    struct ReduceDimResult {
+        GpuTensorHandle values, indices;
+    };
+    ReduceDimResult reduce_min_dim(const GpuTensorHandle& a, size_t dim) const { return minmax_dim(RMHIP_RMIN, a, dim); }
+    ReduceDimResult reduce_max_dim(const GpuTensorHandle& a, size_t dim) const { return minmax_dim(RMHIP_RMAX, a, dim); }
+    // lib.rs:2786-2802 (normalization: 0 sample / 1 population; nan_mode: 0 include / 1 omit)
+    GpuTensorHandle reduce_std(const GpuTensorHandle& a, int normalization, int nan_mode) const { return reduce_std_dim_(a, -1, normalization, nan_mode); }
+    GpuTensorHandle reduce_std_dim(const GpuTensorHandle& a, size_t dim, int normalization, int nan_mode) const {
+        return reduce_std_dim_(a, (int)dim, normalization, nan_mode);
+    }
+    // lib.rs:2730-2742, 2803-2850
+    GpuTensorHandle reduce_nnz(const GpuTensorHandle& a) const { return truth(RMHIP_TNNZ, a, -1, false); }
+    GpuTensorHandle reduce_nnz_dim(const GpuTensorHandle& a, size_t dim) const { return truth(RMHIP_TNNZ, a, (int)dim, false); }
+    GpuTensorHandle reduce_any(const GpuTensorHandle& a, bool omit_nan) const { return truth(RMHIP_TANY, a, -1, omit_nan); }
+    GpuTensorHandle reduce_any_dim(const GpuTensorHandle& a, size_t dim, bool omit_nan) const { return truth(RMHIP_TANY, a, (int)dim, omit_nan); }
+    GpuTensorHandle reduce_all(const GpuTensorHandle& a, bool omit_nan) const { return truth(RMHIP_TALL, a, -1, omit_nan); }
+    GpuTensorHandle reduce_all_dim(const GpuTensorHandle& a, size_t dim, bool omit_nan) const { return truth(RMHIP_TALL, a, (int)dim, omit_nan); }
+    // lib.rs:2884-2891, 2908-2915 (reverse: ProviderScanDirection::Reverse; nan_mode: ProviderNanMode)
+    GpuTensorHandle cumsum_scan(const GpuTensorHandle& a, size_t dim, bool reverse, int nan_mode) const { return cumulative(0, a, dim, reverse, nan_mode); }
+    GpuTensorHandle cumprod_scan(const GpuTensorHandle& a, size_t dim, bool reverse, int nan_mode) const { return cumulative(1, a, dim, reverse, nan_mode); }
+    ReduceDimResult minmax_dim(int op, const GpuTensorHandle& a, size_t dim) const {
+        uint64_t v = 0, i = 0;
+        check(rmhip_reduce_minmax_dim(ctx_, op, own(a), (int)dim, 0, &v, &i));
+        return {with_shape(v), with_shape(i)};
+    }
+    GpuTensorHandle reduce_std_dim_(const GpuTensorHandle& a, int dim, int normalization, int nan_mode) const {
+        uint64_t out = 0;
+        check(rmhip_reduce_std(ctx_, own(a), dim, normalization, nan_mode, &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle truth(int op, const GpuTensorHandle& a, int dim, bool omit_nan) const {
+        uint64_t out = 0;
+        check(rmhip_reduce_truth(ctx_, op, own(a), dim, omit_nan ? 1 : 0, &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle cumulative(int op, const GpuTensorHandle& a, size_t dim, bool reverse, int nan_mode) const {
+        uint64_t out = 0;
+        check(rmhip_cumulative(ctx_, op, own(a), (int)dim, reverse ? 1 : 0, nan_mode, &out));
+        return with_shape(out);
+    }
 
     // ---- linear algebra (lib.rs:2375, 2477-2500) ----
     GpuTensorHandle matmul(const GpuTensorHandle& a, const GpuTensorHandle& b) const {

@@ -932,3 +932,151 @@ ORC_API void orc_fill_uniform(uint64_t seed, double lo, double hi, size_t n, dou
         out[i] = lo + (hi - lo) * ((double)(z >> 11) * (1.0 / 9007199254740992.0));
     }
 }
+
+/* ---- reductions next to sum / mean on the provider trait (round 3) ------------------------------------------------------
+ * All take the [pre, red, post] view of a column-major tensor (element (i, k, j) at i + pre * (k + red * j)) and reduce /
+ * scan the middle extent, walking it in ascending order like the CPU's element loop does per output slot. */
+
+/* min / max with indices: runtime/builtins/math/reduction/min.rs:1437-1477 (`update_best_real`), :1519-1531
+ * (`should_replace_real`, Auto comparison), output :1056-1075; max.rs:1715-1727.  includenan: the first NaN fixes value NaN and
+ * its index; omitnan: NaNs are skipped, nothing left gives (NaN, NaN).  Indices are 1-based positions along the reduced dim. */
+static int orc_should_replace(int is_max, double current, double candidate) {
+    if (is_max) {
+        if (candidate > current) return 1;
+        if (candidate < current) return 0;
+        if (candidate == 0.0 && current == 0.0) return !signbit(candidate) && signbit(current);
+        return 0;
+    }
+    if (candidate < current) return 1;
+    if (candidate > current) return 0;
+    if (candidate == 0.0 && current == 0.0) return signbit(candidate) && !signbit(current);
+    return 0;
+}
+ORC_API int orc_minmax_dim(const double* x, size_t pre, size_t red, size_t post, int is_max, int omitnan, double* values,
+                           double* indices) {
+    for (size_t j = 0; j < post; ++j)
+        for (size_t i = 0; i < pre; ++i) {
+            double best = 0.0;
+            size_t best_k = 0;
+            int has_value = 0, nan_fixed = 0;
+            for (size_t k = 0; k < red; ++k) {
+                const double v = x[i + pre * (k + red * j)];
+                if (isnan(v)) {
+                    if (!omitnan && !nan_fixed) {
+                        best_k = k;
+                        has_value = 1;
+                        nan_fixed = 1;
+                    }
+                    continue;
+                }
+                if (nan_fixed) continue;
+                if (!has_value) {
+                    best = v;
+                    best_k = k;
+                    has_value = 1;
+                    continue;
+                }
+                if (orc_should_replace(is_max, best, v)) {
+                    best = v;
+                    best_k = k;
+                }
+            }
+            const size_t o = i + pre * j;
+            if (nan_fixed) {
+                values[o] = NAN;
+                indices[o] = (double)(best_k + 1);
+            } else if (!has_value) {
+                values[o] = NAN;
+                indices[o] = NAN;
+            } else {
+                values[o] = best;
+                indices[o] = (double)(best_k + 1);
+            }
+        }
+    return 0;
+}
+
+/* std: std.rs:858-935 - Welford's update per element, NaNs set saw_nan (include) or are skipped (omit); sample: m2 / (n - 1),
+ * 0 for one value; population: m2 / n; variance clamped at 0; no values -> NaN. */
+ORC_API int orc_std_dim(const double* x, size_t pre, size_t red, size_t post, int population, int omitnan, double* out) {
+    for (size_t j = 0; j < post; ++j)
+        for (size_t i = 0; i < pre; ++i) {
+            size_t count = 0;
+            double mean = 0.0, m2 = 0.0;
+            int saw_nan = 0;
+            for (size_t k = 0; k < red; ++k) {
+                const double v = x[i + pre * (k + red * j)];
+                if (isnan(v)) {
+                    if (!omitnan) saw_nan = 1;
+                    continue;
+                }
+                count += 1;
+                const double delta = v - mean;
+                mean += delta / (double)count;
+                const double delta2 = v - mean;
+                m2 += delta * delta2;
+            }
+            double r;
+            if ((saw_nan && !omitnan) || count == 0) r = NAN;
+            else {
+                double variance;
+                if (population) variance = fmax(m2 / (double)count, 0.0);
+                else variance = count > 1 ? fmax(m2 / (double)(count - 1), 0.0) : 0.0;
+                r = sqrt(variance);
+            }
+            out[i + pre * j] = r;
+        }
+    return 0;
+}
+
+/* nnz (nnz.rs:358: NaN counts as non-zero), any (any.rs:620-621, 722-733), all (all.rs:568-569, 671-703: NaNs skipped in BOTH
+ * modes, nothing left -> true).  op 0 / 1 / 2; results are f64 counts / 0-1 values. */
+ORC_API int orc_truth_dim(const double* x, size_t pre, size_t red, size_t post, int op, int omitnan, double* out) {
+    for (size_t j = 0; j < post; ++j)
+        for (size_t i = 0; i < pre; ++i) {
+            size_t nz = 0, nn = 0;
+            for (size_t k = 0; k < red; ++k) {
+                const double v = x[i + pre * (k + red * j)];
+                if (isnan(v)) nn++;
+                else if (v != 0.0) nz++;
+            }
+            double r;
+            if (op == 0) r = (double)(nz + nn);
+            else if (op == 1) r = (omitnan ? nz : nz + nn) > 0 ? 1.0 : 0.0;
+            else r = (red - nz - nn) == 0 ? 1.0 : 0.0;
+            out[i + pre * j] = r;
+        }
+    return 0;
+}
+
+/* cumsum / cumprod: cumsum.rs:586-650, cumprod.rs:606-670 - running value per line, forward or reverse; include: NaN from the
+ * first NaN input on; omit: NaN inputs leave the running value unchanged. */
+ORC_API int orc_cumulative(const double* x, size_t pre, size_t len, size_t post, int prod, int reverse, int omitnan, double* y) {
+    for (size_t j = 0; j < post; ++j)
+        for (size_t i = 0; i < pre; ++i) {
+            double run = prod ? 1.0 : 0.0;
+            int is_nan = 0;
+            for (size_t s = 0; s < len; ++s) {
+                const size_t k = reverse ? len - 1 - s : s;
+                const size_t idx = i + pre * (k + len * j);
+                const double v = x[idx];
+                if (!omitnan) {
+                    if (is_nan) {
+                        y[idx] = NAN;
+                        continue;
+                    }
+                    if (isnan(v)) {
+                        is_nan = 1;
+                        y[idx] = NAN;
+                    } else {
+                        run = prod ? run * v : run + v;
+                        y[idx] = run;
+                    }
+                } else {
+                    if (!isnan(v)) run = prod ? run * v : run + v;
+                    y[idx] = run;
+                }
+            }
+        }
+    return 0;
+}

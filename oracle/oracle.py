@@ -369,3 +369,62 @@ def fill_uniform(seed: int, lo: float, hi: float, n: int) -> np.ndarray:
     out = np.empty(n, dtype=np.float64)
     lib().orc_fill_uniform(seed, lo, hi, n, _p(out))
     return out
+
+
+# ---- reductions next to sum / mean (round 3): [pre, red, post] view around a zero-based `dim`; dim None = all elements ----
+def _dim_view(x: np.ndarray, dim):
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim < 2:
+        x = x.reshape(-1, 1)
+    if dim is None:
+        return x, 1, x.size, 1, (1, 1)
+    shape = x.shape
+    pre = int(np.prod(shape[:dim], dtype=np.int64))
+    post = int(np.prod(shape[dim + 1:], dtype=np.int64))
+    oshape = tuple(1 if d == dim else e for d, e in enumerate(shape))
+    return x, pre, shape[dim], post, oshape
+
+
+def _bind(name, argtypes):
+    f = getattr(lib(), name)
+    f.restype = C.c_int
+    f.argtypes = argtypes
+    return f
+
+
+def minmax_dim(x, dim: int, is_max: bool, omitnan: bool = False):
+    """(values, indices) of min / max along `dim` with the CPU builtin's rules (min.rs:1437-1531, max.rs:1715-1727)."""
+    x, pre, red, post, oshape = _dim_view(x, dim)
+    f = _bind("orc_minmax_dim", [_DP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _DP, _DP])
+    xf = _f(x)
+    v, i = np.empty(pre * post), np.empty(pre * post)
+    f(_p(xf), pre, red, post, int(is_max), int(omitnan), _p(v), _p(i))
+    return v.reshape(oshape, order="F"), i.reshape(oshape, order="F")
+
+
+def std_dim(x, dim, population: bool = False, omitnan: bool = False) -> np.ndarray:
+    x, pre, red, post, oshape = _dim_view(x, dim)
+    f = _bind("orc_std_dim", [_DP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _DP])
+    xf = _f(x)
+    out = np.empty(pre * post)
+    f(_p(xf), pre, red, post, int(population), int(omitnan), _p(out))
+    return out.reshape(oshape, order="F")
+
+
+def truth_dim(x, dim, op: str, omitnan: bool = False) -> np.ndarray:
+    """op: "nnz" | "any" | "all" (nnz.rs:358, any.rs:722-733, all.rs:671-703)."""
+    x, pre, red, post, oshape = _dim_view(x, dim)
+    f = _bind("orc_truth_dim", [_DP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _DP])
+    xf = _f(x)
+    out = np.empty(pre * post)
+    f(_p(xf), pre, red, post, {"nnz": 0, "any": 1, "all": 2}[op], int(omitnan), _p(out))
+    return out.reshape(oshape, order="F")
+
+
+def cumulative(x, dim: int, prod: bool = False, reverse: bool = False, omitnan: bool = False) -> np.ndarray:
+    x, pre, red, post, _ = _dim_view(x, dim)
+    f = _bind("orc_cumulative", [_DP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, _DP])
+    xf = _f(x)
+    out = np.empty(xf.size)
+    f(_p(xf), pre, red, post, int(prod), int(reverse), int(omitnan), _p(out))
+    return out.reshape(x.shape, order="F")

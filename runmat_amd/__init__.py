@@ -9,7 +9,7 @@ reproduced for tests and bench.py by the request emitter under tests/, outside t
 sharded Monte-Carlo drivers take their two shaders as arguments.
 """
 from .provider import (GpuTensorHandle, HipProvider, ProviderError, ProviderLinsolveOptions, ProviderLinsolveResult,
-                       ProviderLuResult, ReductionFlavor, wgsl_compile_check, wgsl_translate)
+                       ProviderLuResult, ReduceDimResult, ReductionFlavor, wgsl_compile_check, wgsl_translate)
 
 __all__ = ["GpuTensorHandle", "HipProvider", "ProviderError", "ProviderLinsolveOptions", "ProviderLinsolveResult",
-           "ProviderLuResult", "ReductionFlavor", "wgsl_compile_check", "wgsl_translate"]
+           "ProviderLuResult", "ReduceDimResult", "ReductionFlavor", "wgsl_compile_check", "wgsl_translate"]

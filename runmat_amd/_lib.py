@@ -130,6 +130,10 @@ SIGNATURES = {
     "rmhip_unary": (C.c_int, [_P, C.c_int, _BUF, _BUFP]),
     "rmhip_scalar": (C.c_int, [_P, C.c_int, _BUF, C.c_double, _BUFP]),
     "rmhip_reduce": (C.c_int, [_P, C.c_int, _BUF, C.c_int, C.c_int, _BUFP]),
+    "rmhip_reduce_minmax_dim": (C.c_int, [_P, C.c_int, _BUF, C.c_int, C.c_int, _BUFP, _BUFP]),
+    "rmhip_reduce_std": (C.c_int, [_P, _BUF, C.c_int, C.c_int, C.c_int, _BUFP]),
+    "rmhip_reduce_truth": (C.c_int, [_P, C.c_int, _BUF, C.c_int, C.c_int, _BUFP]),
+    "rmhip_cumulative": (C.c_int, [_P, C.c_int, _BUF, C.c_int, C.c_int, C.c_int, _BUFP]),
     "rmhip_reduce_nd": (C.c_int, [_P, C.c_int, _BUF, _SZP, _SZ, C.c_int, _BUFP]),
     "rmhip_reduce_moments_nd": (C.c_int, [_P, _BUF, _SZP, _SZ, _BUFP, _BUFP]),
     "rmhip_dot": (C.c_int, [_P, _BUF, _BUF, C.c_int, _BUFP]),

@@ -259,6 +259,12 @@ int launch_reduce_mid(Context* c, int op, int nan_mode, const double* x, size_t 
 int launch_reduce_mid_f32(Context* c, int op, int nan_mode, const float* x, size_t pre, size_t red, size_t post, double* out);
 int launch_reduce_dot_f32(Context* c, const float* a, const float* b, size_t pre, size_t red, size_t post, double* out);
 
+// reduce2.hip: arg-min / arg-max with indices, std, truth counts, cumulative scans over the [pre, red, post] view
+int launch_argreduce(Context* c, int op, int nan_mode, const double* x, size_t pre, size_t red, size_t post, double* values, double* indices);
+int launch_reduce_std(Context* c, int population, int nan_mode, const double* x, size_t pre, size_t red, size_t post, double* out);
+int launch_reduce_truth(Context* c, int op, int omit_nan, const double* x, size_t pre, size_t red, size_t post, double* out);
+int launch_cumulative(Context* c, int prod, int reverse, int omit, const double* x, size_t pre, size_t len, size_t post, double* y);
+
 // sum(a .* b) over the middle extent of [pre, red, post]
 int launch_reduce_dot(Context* c, const double* a, const double* b, size_t pre, size_t red, size_t post, double* out);
 

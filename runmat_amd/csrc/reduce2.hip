@@ -1,0 +1,473 @@
+// reduce2.hip -- the reduction hooks next to sum / mean / min / max on the provider trait
+// (crates/runmat-accelerate-api/src/lib.rs):
+//   reduce_min_dim / reduce_max_dim -> ReduceDimResult{values, indices}   :2864-2883, :513-517
+//   reduce_std / reduce_std_dim                                           :2786-2802
+//   reduce_nnz(_dim), reduce_any(_dim), reduce_all(_dim)                  :2730-2742, :2803-2850
+//   cumsum_scan / cumprod_scan                                            :2884-2891, :2908-2915
+// Semantics are the CPU builtins' (crates/runmat-runtime/src/builtins/math/reduction/{min,max,std,nnz,any,all,cumsum,
+// cumprod}.rs; cited at each accumulator), not the in-process test provider's where the two differ (its reduce_min_dim
+// ignores NaNs, simple_provider.rs:7301-7345; the runtime only calls the hook in "includenan" mode, min.rs:795-800, and
+// expects what its host path gives).
+//
+// One skeleton for everything that reduces: the tensor is viewed as [pre, red, post] (column-major, the middle extent is
+// reduced), every slice is cut into nsplit chunks so that the grid covers the chip several times (reduce_plan.h), a chunk
+// folds into an accumulator, and a final kernel merges the chunks of a slice IN CHUNK ORDER - no atomics, results do not
+// depend on scheduling.  HBM-bound: one 8-byte read per element.
+#include "common.h"
+#include "reduce_plan.h"
+
+namespace rmhip {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ double r2_nan() { return __longlong_as_double(0x7ff8000000000000ll); }  // f64::NAN
+
+// ---- accumulators ---------------------------------------------------------------------------------------------------------
+// arg-min / arg-max.  Values map to integer keys whose unsigned order is the builtin's order, smaller = better:
+//   * total order of the doubles with -0 below +0 (min.rs:1519-1531 prefers -0 over +0, max.rs:1715-1727 +0 over -0);
+//     for max the key is complemented;
+//   * ties keep the FIRST index (a later equal value never replaces, same functions);
+//   * includenan: the first NaN fixes the result - value NaN, index of that NaN (min.rs:1443-1455): NaN gets key 0;
+//     omitnan: NaNs never win (key ~0); a slice of NaNs only gives value NaN and index NaN (min.rs:1060-1064).
+// No real value maps to 0 or ~0 (only NaN bit patterns do), so the two sentinels are unambiguous.
+template <bool MAX, bool OMIT>
+struct ArgAcc {
+    u64 key, idx;
+    __device__ __forceinline__ void init() {
+        key = ~0ull;
+        idx = ~0ull;
+    }
+    __device__ __forceinline__ void add(u64 k, double v) {
+        const u64 b = (u64)__double_as_longlong(v);
+        u64 ord = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+        if (MAX) ord = ~ord;
+        if (v != v) ord = OMIT ? ~0ull : 0ull;
+        if (ord < key || (ord == key && k < idx)) {
+            key = ord;
+            idx = k;
+        }
+    }
+    __device__ __forceinline__ void merge(const ArgAcc& o) {
+        if (o.key < key || (o.key == key && o.idx < idx)) {
+            key = o.key;
+            idx = o.idx;
+        }
+    }
+};
+template <bool MAX>
+__device__ __forceinline__ void arg_decode(u64 key, u64 idx, double* value, double* index) {
+    if (key == ~0ull) {  // nothing but NaNs under omitnan (or an empty slice)
+        *value = r2_nan();
+        *index = r2_nan();
+        return;
+    }
+    *index = (double)(idx + 1);  // 1-based (min.rs:1067-1074)
+    if (key == 0) {
+        *value = r2_nan();
+        return;
+    }
+    const u64 ord = MAX ? ~key : key;
+    const u64 b = (ord >> 63) ? (ord & 0x7fffffffffffffffull) : ~ord;
+    *value = __longlong_as_double((long long)b);
+}
+
+// count / mean / M2 (std.rs:858-935: Welford's update element by element, NaNs counted apart).  One chunk is exactly the
+// CPU's sequence; chunks merge with Chan's formula in chunk order.
+struct MomAcc {
+    double n, mean, m2, nan;
+    __device__ __forceinline__ void init() { n = mean = m2 = nan = 0.0; }
+    __device__ __forceinline__ void add(u64, double v) {
+        if (v != v) {
+            nan += 1.0;
+            return;
+        }
+        n += 1.0;
+        const double delta = v - mean;
+        mean += delta / n;
+        const double delta2 = v - mean;
+        m2 += delta * delta2;
+    }
+    __device__ __forceinline__ void merge(const MomAcc& o) {
+        nan += o.nan;
+        if (o.n == 0.0) return;
+        if (n == 0.0) {
+            n = o.n;
+            mean = o.mean;
+            m2 = o.m2;
+            return;
+        }
+        const double tot = n + o.n, delta = o.mean - mean;
+        mean += delta * (o.n / tot);
+        m2 += o.m2 + delta * delta * (n * (o.n / tot));
+        n = tot;
+    }
+};
+
+// truth counts: nonzero non-NaN elements and NaNs (nnz.rs:358 `is_nan() || v != 0`; any.rs:620-621, 722-733;
+// all.rs:568-569, 671-703)
+struct TruthAcc {
+    u64 nz, nan;
+    __device__ __forceinline__ void init() { nz = nan = 0; }
+    __device__ __forceinline__ void add(u64, double v) {
+        if (v != v) ++nan;
+        else if (v != 0.0) ++nz;
+    }
+    __device__ __forceinline__ void merge(const TruthAcc& o) {
+        nz += o.nz;
+        nan += o.nan;
+    }
+};
+
+// ---- stage 1 ----------------------------------------------------------------------------------------------------------------
+static constexpr int R2_BLOCK = 256;
+
+// pre == 1: slice s is `red` contiguous elements.  grid (nsplit, slices in y, z)
+template <class Acc>
+__global__ void __launch_bounds__(R2_BLOCK) k_r2_contig(const double* __restrict__ x, u64 red, u64 nslices, u64 nsplit, Acc* __restrict__ part) {
+    __shared__ Acc lds[R2_BLOCK];
+    const u64 slice = blockIdx.y + (u64)gridDim.y * blockIdx.z;
+    if (slice >= nslices) return;
+    const u64 split = blockIdx.x;
+    u64 chunk = (red + nsplit - 1) / nsplit;
+    chunk = (chunk + R2_BLOCK - 1) / R2_BLOCK * R2_BLOCK;
+    const u64 begin = split * chunk;
+    u64 end = begin + chunk;
+    if (end > red) end = red;
+    const double* xs = x + slice * red;
+    Acc a;
+    a.init();
+    u64 r = begin + threadIdx.x;
+    for (; r + 3 * R2_BLOCK < end; r += 4 * R2_BLOCK) {  // four loads in flight; folded in index order
+        const double v0 = __builtin_nontemporal_load(xs + r), v1 = __builtin_nontemporal_load(xs + r + R2_BLOCK);
+        const double v2 = __builtin_nontemporal_load(xs + r + 2 * R2_BLOCK), v3 = __builtin_nontemporal_load(xs + r + 3 * R2_BLOCK);
+        a.add(r, v0);
+        a.add(r + R2_BLOCK, v1);
+        a.add(r + 2 * R2_BLOCK, v2);
+        a.add(r + 3 * R2_BLOCK, v3);
+    }
+    for (; r < end; r += R2_BLOCK) a.add(r, __builtin_nontemporal_load(xs + r));
+    lds[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = R2_BLOCK / 2; s > 0; s >>= 1) {  // fixed tree
+        if ((int)threadIdx.x < s) {
+            Acc m = lds[threadIdx.x];
+            m.merge(lds[threadIdx.x + s]);
+            lds[threadIdx.x] = m;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[slice * nsplit + split] = lds[0];
+}
+
+// pre > 1: threads run along `pre` (coalesced), each walks its chunk of `red` in ascending order.  grid (ceil(pre / 256), nsplit, post)
+template <class Acc>
+__global__ void __launch_bounds__(R2_BLOCK) k_r2_strided(const double* __restrict__ x, u64 pre, u64 red, u64 nsplit, Acc* __restrict__ part) {
+    const u64 i = (u64)blockIdx.x * R2_BLOCK + threadIdx.x;
+    if (i >= pre) return;
+    const u64 split = blockIdx.y, j = blockIdx.z;
+    const u64 chunk = (red + nsplit - 1) / nsplit;
+    const u64 begin = split * chunk;
+    u64 end = begin + chunk;
+    if (end > red) end = red;
+    const double* xs = x + i + pre * red * j;
+    Acc a;
+    a.init();
+    u64 r = begin;
+    for (; r + 8 <= end; r += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(xs + pre * (r + u));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a.add(r + u, v[u]);
+    }
+    if (r < end) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (r + u < end) v[u] = __builtin_nontemporal_load(xs + pre * (r + u));
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (r + u < end) a.add(r + u, v[u]);
+    }
+    part[(i + pre * j) * nsplit + split] = a;
+}
+
+// ---- stage 2: one wave per slice merges the chunks in chunk order (lane l takes a contiguous run) ------------------------------
+template <class Acc, class Fin>
+__global__ void __launch_bounds__(R2_BLOCK) k_r2_final(const Acc* __restrict__ part, u64 nslices, u64 nsplit, Fin fin) {
+    __shared__ Acc lds[R2_BLOCK];
+    const u64 slice = (u64)blockIdx.x * (R2_BLOCK / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    Acc a;
+    a.init();
+    if (slice < nslices) {
+        const u64 per = (nsplit + 63) / 64;
+        const u64 b = (u64)lane * per;
+        u64 e = b + per;
+        if (e > nsplit) e = nsplit;
+        for (u64 s = b; s < e; ++s) a.merge(part[slice * nsplit + s]);
+    }
+    lds[threadIdx.x] = a;
+    __syncthreads();
+    if (lane == 0 && slice < nslices) {
+        Acc m = lds[threadIdx.x];
+        for (int l = 1; l < 64; ++l) m.merge(lds[threadIdx.x + l]);
+        fin(slice, m);
+    }
+}
+
+template <bool MAX>
+struct ArgFin {
+    double* values;
+    double* indices;
+    template <class Acc>
+    __device__ __forceinline__ void operator()(u64 slice, const Acc& a) const {
+        arg_decode<MAX>(a.key, a.idx, values + slice, indices + slice);
+    }
+};
+struct StdFin {  // std.rs:918-935
+    double* out;
+    int population, omitnan;
+    __device__ __forceinline__ void operator()(u64 slice, const MomAcc& a) const {
+        double r;
+        if ((a.nan > 0.0 && !omitnan) || a.n == 0.0) r = r2_nan();
+        else {
+            double var;
+            if (population) var = a.m2 / a.n;
+            else var = a.n > 1.0 ? a.m2 / (a.n - 1.0) : 0.0;
+            r = sqrt(var > 0.0 ? var : 0.0);
+        }
+        out[slice] = r;
+    }
+};
+struct TruthFin {
+    double* out;
+    int op, omitnan;  // RMHIP_TNNZ / RMHIP_TANY / RMHIP_TALL
+    u64 red;
+    __device__ __forceinline__ void operator()(u64 slice, const TruthAcc& a) const {
+        double r;
+        if (op == RMHIP_TNNZ) r = (double)(a.nz + a.nan);
+        else if (op == RMHIP_TANY) r = (omitnan ? a.nz : a.nz + a.nan) > 0 ? 1.0 : 0.0;
+        else r = (red - a.nz - a.nan) == 0 ? 1.0 : 0.0;  // all: NaNs are skipped in both modes; nothing left counts as true
+        out[slice] = r;
+    }
+};
+
+template <class Acc, class Fin>
+static int run_r2(Context* c, const double* x, size_t pre, size_t red, size_t post, const Fin& fin, const char* what) {
+    if (pre == 0 || post == 0 || red == 0) return RMHIP_OK;
+    ReducePlan p = plan_reduction(pre, red, post, c->num_cus, 8);
+    if (!p.valid) return fail(RMHIP_ERR_UNSUPPORTED, "%s: geometry [%zu,%zu,%zu] exceeds launch limits", what, pre, red, post);
+    u64 nsplit = p.nsplit;
+    unsigned gx = p.gx;
+    if (!p.contiguous) {  // this kernel keeps 256 threads along `pre`
+        gx = (unsigned)ceil_div_u64(pre, R2_BLOCK);
+        u64 want = ceil_div_u64((u64)c->num_cus * 8, (u64)gx * post);
+        u64 max_split = ceil_div_u64(red, 16);
+        nsplit = want < 1 ? 1 : (want > max_split ? max_split : want);
+        nsplit = dealias_nsplit(red, nsplit, pre * 8, max_split);
+        if (nsplit > 65535) nsplit = 65535;
+    }
+    const size_t nparts = (size_t)(p.nslices * nsplit);
+    RMHIP_TRY(c->ensure_scratch(nparts * sizeof(Acc)));
+    Acc* part = reinterpret_cast<Acc*>(c->scratch);
+    if (p.contiguous)
+        hipLaunchKernelGGL((k_r2_contig<Acc>), dim3((unsigned)nsplit, p.gy, p.gz), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices, nsplit, part);
+    else
+        hipLaunchKernelGGL((k_r2_strided<Acc>), dim3(gx, (unsigned)nsplit, (unsigned)post), dim3(R2_BLOCK), 0, c->stream, x, (u64)pre, (u64)red, nsplit, part);
+    RMHIP_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL((k_r2_final<Acc, Fin>), dim3((unsigned)ceil_div_u64(p.nslices, R2_BLOCK / 64)), dim3(R2_BLOCK), 0, c->stream, part,
+                       (u64)p.nslices, nsplit, fin);
+    RMHIP_HIP_CHECK(hipGetLastError());
+    c->tel.kernel_launches += 2;
+    return RMHIP_OK;
+}
+
+int launch_argreduce(Context* c, int op, int nan_mode, const double* x, size_t pre, size_t red, size_t post, double* values, double* indices) {
+    const bool mx = op == RMHIP_RMAX;
+    if (mx) {
+        ArgFin<true> fin{values, indices};
+        return nan_mode ? run_r2<ArgAcc<true, true>>(c, x, pre, red, post, fin, "reduce_max_dim")
+                        : run_r2<ArgAcc<true, false>>(c, x, pre, red, post, fin, "reduce_max_dim");
+    }
+    ArgFin<false> fin{values, indices};
+    return nan_mode ? run_r2<ArgAcc<false, true>>(c, x, pre, red, post, fin, "reduce_min_dim")
+                    : run_r2<ArgAcc<false, false>>(c, x, pre, red, post, fin, "reduce_min_dim");
+}
+int launch_reduce_std(Context* c, int population, int nan_mode, const double* x, size_t pre, size_t red, size_t post, double* out) {
+    StdFin fin{out, population, nan_mode};
+    return run_r2<MomAcc>(c, x, pre, red, post, fin, "reduce_std");
+}
+int launch_reduce_truth(Context* c, int op, int omit_nan, const double* x, size_t pre, size_t red, size_t post, double* out) {
+    TruthFin fin{out, op, omit_nan, (u64)red};
+    return run_r2<TruthAcc>(c, x, pre, red, post, fin, "reduce_truth");
+}
+
+// ---- cumulative sum / product along one dimension (cumsum.rs:559-650, cumprod.rs:581-670) ----------------------------------------
+// includenan: from the first NaN on every output is NaN (what the running value does by itself; the outputs are canonical
+// NaNs like the CPU's); omitnan: a NaN leaves the running value unchanged.  Reverse runs from the last element.
+template <bool PROD>
+__device__ __forceinline__ double scan_op(double a, double b) { return PROD ? a * b : a + b; }
+template <bool PROD>
+__device__ __forceinline__ double scan_in(double v, int omit) { return (omit && v != v) ? (PROD ? 1.0 : 0.0) : v; }
+__device__ __forceinline__ double scan_out(double v) { return v != v ? r2_nan() : v; }
+
+// pre > 1 (or short lines): one thread per line, the CPU's own sequence of operations - bit-identical results.  Threads run along
+// `pre`, so every step is a coalesced read and write.
+template <bool PROD>
+__global__ void __launch_bounds__(R2_BLOCK) k_scan_lines(const double* __restrict__ x, double* __restrict__ y, u64 pre, u64 len, u64 post, int reverse,
+                                                         int omit) {
+    const u64 line = (u64)blockIdx.x * R2_BLOCK + threadIdx.x;
+    if (line >= pre * post) return;
+    const u64 i = line % pre, j = line / pre;
+    const u64 base = i + pre * len * j;
+    double run = PROD ? 1.0 : 0.0;
+    for (u64 k0 = 0; k0 < len; k0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const u64 k = k0 + u;
+            if (k < len) v[u] = x[base + pre * (reverse ? len - 1 - k : k)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const u64 k = k0 + u;
+            if (k < len) {
+                run = scan_op<PROD>(run, scan_in<PROD>(v[u], omit));
+                y[base + pre * (reverse ? len - 1 - k : k)] = scan_out(run);
+            }
+        }
+    }
+}
+
+// pre == 1, long lines: three passes over chunks of SCAN_CHUNK elements - chunk totals, a serial scan of the totals per line,
+// then every chunk scans itself from its carry.  Inside a chunk a block scans tiles of 256 x 8 elements (serial per thread,
+// Hillis-Steele over the thread totals).  The grouping differs from the CPU's left-to-right sequence: results agree to
+// rounding (exactly, for integer-valued data below 2^53).
+static constexpr int SCAN_PER_THREAD = 8;
+static constexpr int SCAN_TILE = R2_BLOCK * SCAN_PER_THREAD;
+static constexpr u64 SCAN_CHUNK = 32 * SCAN_TILE;  // 65536 elements
+
+template <bool PROD>
+__device__ __forceinline__ double block_exclusive(double total, double* lds, double* block_total) {
+    const int t = threadIdx.x;
+    lds[t] = total;
+    __syncthreads();
+    for (int off = 1; off < R2_BLOCK; off <<= 1) {
+        double v = lds[t];
+        if (t >= off) v = scan_op<PROD>(lds[t - off], v);
+        __syncthreads();
+        lds[t] = v;
+        __syncthreads();
+    }
+    const double incl = lds[t];
+    *block_total = lds[R2_BLOCK - 1];
+    double excl = PROD ? 1.0 : 0.0;
+    if (t > 0) excl = lds[t - 1];
+    __syncthreads();
+    (void)incl;
+    return excl;
+}
+
+template <bool PROD>
+__global__ void __launch_bounds__(R2_BLOCK) k_scan_chunk_totals(const double* __restrict__ x, u64 len, u64 nchunks, int reverse, int omit,
+                                                                double* __restrict__ totals) {
+    __shared__ double lds[R2_BLOCK];
+    const u64 chunk = blockIdx.x, line = blockIdx.y;
+    const u64 b = chunk * SCAN_CHUNK;
+    u64 e = b + SCAN_CHUNK;
+    if (e > len) e = len;
+    const double* xs = x + line * len;
+    double acc = PROD ? 1.0 : 0.0;
+    // the same grouping as pass 3 (thread t owns runs of eight consecutive elements of every tile), so that carry + local scan
+    // reproduces the totals
+    for (u64 tile = b; tile < e; tile += SCAN_TILE) {
+        double tot = PROD ? 1.0 : 0.0;
+#pragma unroll
+        for (int u = 0; u < SCAN_PER_THREAD; ++u) {
+            const u64 k = tile + (u64)threadIdx.x * SCAN_PER_THREAD + u;
+            if (k < e) tot = scan_op<PROD>(tot, scan_in<PROD>(xs[reverse ? len - 1 - k : k], omit));
+        }
+        double bt;
+        (void)block_exclusive<PROD>(tot, lds, &bt);
+        acc = scan_op<PROD>(acc, bt);
+    }
+    if (threadIdx.x == 0) totals[line * nchunks + chunk] = acc;
+}
+template <bool PROD>
+__global__ void __launch_bounds__(R2_BLOCK) k_scan_carries(double* __restrict__ totals, u64 nchunks, u64 nlines) {
+    const u64 line = (u64)blockIdx.x * R2_BLOCK + threadIdx.x;
+    if (line >= nlines) return;
+    double run = PROD ? 1.0 : 0.0;
+    for (u64 c = 0; c < nchunks; ++c) {  // totals[c] <- carry into chunk c
+        const double t = totals[line * nchunks + c];
+        totals[line * nchunks + c] = run;
+        run = scan_op<PROD>(run, t);
+    }
+}
+template <bool PROD>
+__global__ void __launch_bounds__(R2_BLOCK) k_scan_chunks(const double* __restrict__ x, double* __restrict__ y, u64 len, u64 nchunks, int reverse,
+                                                          int omit, const double* __restrict__ carries) {
+    __shared__ double lds[R2_BLOCK];
+    const u64 chunk = blockIdx.x, line = blockIdx.y;
+    const u64 b = chunk * SCAN_CHUNK;
+    u64 e = b + SCAN_CHUNK;
+    if (e > len) e = len;
+    const double* xs = x + line * len;
+    double* ys = y + line * len;
+    double carry = carries[line * nchunks + chunk];
+    for (u64 tile = b; tile < e; tile += SCAN_TILE) {
+        double v[SCAN_PER_THREAD];
+        double tot = PROD ? 1.0 : 0.0;
+#pragma unroll
+        for (int u = 0; u < SCAN_PER_THREAD; ++u) {
+            const u64 k = tile + (u64)threadIdx.x * SCAN_PER_THREAD + u;
+            v[u] = PROD ? 1.0 : 0.0;
+            if (k < e) v[u] = scan_in<PROD>(xs[reverse ? len - 1 - k : k], omit);
+            tot = scan_op<PROD>(tot, v[u]);
+            v[u] = tot;  // inclusive within the thread
+        }
+        double bt;
+        const double excl = block_exclusive<PROD>(tot, lds, &bt);
+        const double lead = scan_op<PROD>(carry, excl);
+#pragma unroll
+        for (int u = 0; u < SCAN_PER_THREAD; ++u) {
+            const u64 k = tile + (u64)threadIdx.x * SCAN_PER_THREAD + u;
+            if (k < e) ys[reverse ? len - 1 - k : k] = scan_out(scan_op<PROD>(lead, v[u]));
+        }
+        carry = scan_op<PROD>(carry, bt);
+    }
+}
+
+int launch_cumulative(Context* c, int prod, int reverse, int omit, const double* x, size_t pre, size_t len, size_t post, double* y) {
+    if (pre == 0 || len == 0 || post == 0) return RMHIP_OK;
+    const size_t lines = pre * post;
+    // thread-per-line whenever the lines run along a strided dimension, or there are enough short contiguous lines to fill the chip
+    if (pre > 1 || (len <= 4096 && lines >= (size_t)c->num_cus * 64)) {
+        const unsigned grid = (unsigned)ceil_div_u64(lines, R2_BLOCK);
+        if (prod) hipLaunchKernelGGL(k_scan_lines<true>, dim3(grid), dim3(R2_BLOCK), 0, c->stream, x, y, (u64)pre, (u64)len, (u64)post, reverse, omit);
+        else hipLaunchKernelGGL(k_scan_lines<false>, dim3(grid), dim3(R2_BLOCK), 0, c->stream, x, y, (u64)pre, (u64)len, (u64)post, reverse, omit);
+        RMHIP_HIP_CHECK(hipGetLastError());
+        c->tel.kernel_launches++;
+        return RMHIP_OK;
+    }
+    if (lines > 65535) return fail(RMHIP_ERR_UNSUPPORTED, "cumulative scan: %zu contiguous lines exceed the launch limits", lines);
+    const u64 nchunks = ceil_div_u64(len, SCAN_CHUNK);
+    RMHIP_TRY(c->ensure_scratch(lines * nchunks * sizeof(double)));
+    double* totals = c->scratch;
+    const dim3 grid((unsigned)nchunks, (unsigned)lines);
+    if (prod) {
+        hipLaunchKernelGGL(k_scan_chunk_totals<true>, grid, dim3(R2_BLOCK), 0, c->stream, x, (u64)len, nchunks, reverse, omit, totals);
+        hipLaunchKernelGGL(k_scan_carries<true>, dim3((unsigned)ceil_div_u64(lines, R2_BLOCK)), dim3(R2_BLOCK), 0, c->stream, totals, nchunks, (u64)lines);
+        hipLaunchKernelGGL(k_scan_chunks<true>, grid, dim3(R2_BLOCK), 0, c->stream, x, y, (u64)len, nchunks, reverse, omit, (const double*)totals);
+    } else {
+        hipLaunchKernelGGL(k_scan_chunk_totals<false>, grid, dim3(R2_BLOCK), 0, c->stream, x, (u64)len, nchunks, reverse, omit, totals);
+        hipLaunchKernelGGL(k_scan_carries<false>, dim3((unsigned)ceil_div_u64(lines, R2_BLOCK)), dim3(R2_BLOCK), 0, c->stream, totals, nchunks, (u64)lines);
+        hipLaunchKernelGGL(k_scan_chunks<false>, grid, dim3(R2_BLOCK), 0, c->stream, x, y, (u64)len, nchunks, reverse, omit, (const double*)totals);
+    }
+    RMHIP_HIP_CHECK(hipGetLastError());
+    c->tel.kernel_launches += 3;
+    return RMHIP_OK;
+}
+
+}  // namespace rmhip

@@ -510,6 +510,97 @@ int rmhip_reduce(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int nan_mode, rmh
     return rc;
 }
 
+namespace {
+// [pre, red, post] view of `shape` around `dim` (dim < 0: everything is reduced) and the output shape (extent 1 at `dim`; [1,1] for all)
+struct DimView {
+    size_t pre = 1, red = 1, post = 1;
+    std::vector<size_t> oshape;
+};
+int dim_view(const Buffer& b, int dim, const char* what, DimView* v) {
+    const std::vector<size_t> shape = normalize_matrix_shape(b.shape);
+    if (dim < 0) {
+        v->red = b.numel;
+        v->oshape = {1, 1};
+        return RMHIP_OK;
+    }
+    if ((size_t)dim >= shape.size()) return fail(RMHIP_ERR_UNSUPPORTED, "%s: dim %d out of range for rank %zu", what, dim, shape.size());
+    for (int d = 0; d < dim; ++d) v->pre *= shape[d];
+    for (size_t d = dim + 1; d < shape.size(); ++d) v->post *= shape[d];
+    v->red = shape[dim];
+    v->oshape = shape;
+    v->oshape[dim] = 1;
+    return RMHIP_OK;
+}
+}  // namespace
+
+int rmhip_reduce_minmax_dim(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int nan_mode, rmhip_buf* values, rmhip_buf* indices) {
+    CTX_OR_FAIL(ctx);
+    if (!values || !indices) return fail(RMHIP_ERR_INVALID, "reduce_minmax_dim: null output");
+    if (op != RMHIP_RMIN && op != RMHIP_RMAX) return fail(RMHIP_ERR_INVALID, "reduce_minmax_dim: op must be RMHIP_RMIN or RMHIP_RMAX");
+    if (dim < 0) return fail(RMHIP_ERR_INVALID, "reduce_minmax_dim: dim must be >= 0");
+    Buffer ab, vb, ib;
+    RMHIP_TRY(c->get(a, &ab));  // (precision 32: a widened copy - f32 -> f64 is exact and order preserving; outputs are narrowed on return)
+    DimView v;
+    RMHIP_TRY(dim_view(ab, dim, "reduce_minmax_dim", &v));
+    if (ab.numel == 0) return fail(RMHIP_ERR_UNSUPPORTED, "reduce_minmax_dim: empty tensor");
+    RMHIP_TRY(c->new_buffer(v.oshape.data(), v.oshape.size(), values, &vb));
+    int rc = c->new_buffer(v.oshape.data(), v.oshape.size(), indices, &ib);
+    if (!rc) rc = launch_argreduce(c, op, nan_mode, ab.data(), v.pre, v.red, v.post, vb.data(), ib.data());
+    if (rc) {
+        rmhip_free(ctx, *values);
+        if (*indices) rmhip_free(ctx, *indices);
+        return rc;
+    }
+    c->record_launch(op == RMHIP_RMIN ? "reduce_min_dim" : "reduce_max_dim", {{"reduce_len", v.red}, {"slices", v.pre * v.post}}, {{"wg", 256}});
+    return RMHIP_OK;
+}
+
+int rmhip_reduce_std(rmhip_ctx* ctx, rmhip_buf a, int dim, int normalization, int nan_mode, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    if (normalization != 0 && normalization != 1) return fail(RMHIP_ERR_INVALID, "reduce_std: normalization must be 0 (sample) or 1 (population)");
+    Buffer ab, ob;
+    RMHIP_TRY(c->get(a, &ab));
+    DimView v;
+    RMHIP_TRY(dim_view(ab, dim, "reduce_std", &v));
+    if (ab.numel == 0) return fail(RMHIP_ERR_UNSUPPORTED, "reduce_std: empty tensor");
+    RMHIP_TRY(c->new_buffer(v.oshape.data(), v.oshape.size(), out, &ob));
+    const int rc = launch_reduce_std(c, normalization, nan_mode, ab.data(), v.pre, v.red, v.post, ob.data());
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+
+int rmhip_reduce_truth(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int omit_nan, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    if (op < 0 || op >= RMHIP_TRUTH_OP_COUNT) return fail(RMHIP_ERR_INVALID, "reduce_truth: bad op %d", op);
+    Buffer ab, ob;
+    RMHIP_TRY(c->get(a, &ab));
+    DimView v;
+    RMHIP_TRY(dim_view(ab, dim, "reduce_truth", &v));
+    if (ab.numel == 0) return fail(RMHIP_ERR_UNSUPPORTED, "reduce_truth: empty tensor");
+    RMHIP_TRY(c->new_buffer(v.oshape.data(), v.oshape.size(), out, &ob));
+    const int rc = launch_reduce_truth(c, op, omit_nan, ab.data(), v.pre, v.red, v.post, ob.data());
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+
+int rmhip_cumulative(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int reverse, int nan_mode, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    if (op != 0 && op != 1) return fail(RMHIP_ERR_INVALID, "cumulative: op must be 0 (sum) or 1 (prod)");
+    if (dim < 0) return fail(RMHIP_ERR_INVALID, "cumulative: dim must be >= 0");
+    Buffer ab, ob;
+    RMHIP_TRY(c->get(a, &ab));
+    const std::vector<size_t> shape = normalize_matrix_shape(ab.shape);
+    DimView v;
+    RMHIP_TRY(dim_view(ab, dim, "cumulative", &v));
+    RMHIP_TRY(c->new_buffer(shape.data(), shape.size(), out, &ob));
+    const int rc = launch_cumulative(c, op, reverse, nan_mode, ab.data(), v.pre, v.red, v.post, ob.data());
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+
 int rmhip_reduce_nd(rmhip_ctx* ctx, int op, rmhip_buf a, const size_t* dims_zero_based, size_t ndims, int nan_mode,
                     rmhip_buf* out) {
     CTX_OR_FAIL(ctx);

@@ -69,6 +69,13 @@ class ReductionFlavor:
 
 
 @dataclass
+class ReduceDimResult:
+    """`ReduceDimResult` (lib.rs:513-517)."""
+    values: "GpuTensorHandle"
+    indices: "GpuTensorHandle"
+
+
+@dataclass
 class ProviderLuResult:
     """lib.rs:649-698"""
     combined: GpuTensorHandle
@@ -367,8 +374,57 @@ class HipProvider:
     def reduce_mean_dim(self, a, dim): return self._reduce("mean", a, dim)
     def reduce_min(self, a): return self._reduce("min", a, -1)
     def reduce_max(self, a): return self._reduce("max", a, -1)
-    def reduce_min_dim(self, a, dim): return self._reduce("min", a, dim)
-    def reduce_max_dim(self, a, dim): return self._reduce("max", a, dim)
+
+    def _reduce_minmax_dim(self, op: str, a: GpuTensorHandle, dim: int, omitnan: bool) -> "ReduceDimResult":
+        values, indices = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.rmhip_reduce_minmax_dim(self._ctx, REDUCE_OPS[op], self._id(a), int(dim), 1 if omitnan else 0,
+                                                      C.byref(values), C.byref(indices)))
+        return ReduceDimResult(self._handle(values.value), self._handle(indices.value))
+
+    def reduce_min_dim(self, a, dim, omitnan: bool = False) -> "ReduceDimResult":
+        """lib.rs:2864-2870 -> `ReduceDimResult{values, indices}` (:513-517): minimum along zero-based `dim` and its 1-based position
+        (first occurrence, -0 below +0, the first NaN of a slice wins unless omitnan: min.rs:1443-1531)."""
+        return self._reduce_minmax_dim("min", a, dim, omitnan)
+
+    def reduce_max_dim(self, a, dim, omitnan: bool = False) -> "ReduceDimResult":
+        """lib.rs:2877-2883; max.rs:1715-1727."""
+        return self._reduce_minmax_dim("max", a, dim, omitnan)
+
+    def reduce_std(self, a, normalization: str = "sample", omitnan: bool = False) -> GpuTensorHandle:
+        """lib.rs:2786-2793 (`ProviderStdNormalization::{Sample, Population}`, `ProviderNanMode`): std of all elements -> [1,1]."""
+        return self.reduce_std_dim(a, -1, normalization, omitnan)
+
+    def reduce_std_dim(self, a, dim: int, normalization: str = "sample", omitnan: bool = False) -> GpuTensorHandle:
+        """lib.rs:2794-2802; CPU semantics std.rs:858-935."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_reduce_std(self._ctx, self._id(a), int(dim), {"sample": 0, "population": 1}[normalization],
+                                               1 if omitnan else 0, C.byref(out)))
+        return self._handle(out.value)
+
+    def _truth(self, op: int, a, dim: int, omit_nan: bool) -> GpuTensorHandle:
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_reduce_truth(self._ctx, op, self._id(a), int(dim), 1 if omit_nan else 0, C.byref(out)))
+        return self._handle(out.value)
+
+    def reduce_nnz(self, a): return self._truth(0, a, -1, False)            # lib.rs:2730-2735
+    def reduce_nnz_dim(self, a, dim): return self._truth(0, a, dim, False)  # lib.rs:2736-2742
+    def reduce_any(self, a, omit_nan: bool = False): return self._truth(1, a, -1, omit_nan)            # lib.rs:2803-2809
+    def reduce_any_dim(self, a, dim, omit_nan: bool = False): return self._truth(1, a, dim, omit_nan)  # lib.rs:2810-2817
+    def reduce_all(self, a, omit_nan: bool = False): return self._truth(2, a, -1, omit_nan)            # lib.rs:2818-2824
+    def reduce_all_dim(self, a, dim, omit_nan: bool = False): return self._truth(2, a, dim, omit_nan)  # lib.rs:2825-2832
+
+    def _cumulative(self, op: int, a, dim: int, reverse: bool, omitnan: bool) -> GpuTensorHandle:
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_cumulative(self._ctx, op, self._id(a), int(dim), 1 if reverse else 0, 1 if omitnan else 0, C.byref(out)))
+        return self._handle(out.value)
+
+    def cumsum_scan(self, a, dim: int, reverse: bool = False, omitnan: bool = False) -> GpuTensorHandle:
+        """lib.rs:2884-2891 (`ProviderScanDirection`, `ProviderNanMode`); zero-based dim; cumsum.rs:559-650."""
+        return self._cumulative(0, a, dim, reverse, omitnan)
+
+    def cumprod_scan(self, a, dim: int, reverse: bool = False, omitnan: bool = False) -> GpuTensorHandle:
+        """lib.rs:2908-2915; cumprod.rs:581-670."""
+        return self._cumulative(1, a, dim, reverse, omitnan)
     def reduce_prod(self, a): return self._reduce("prod", a, -1)
     def reduce_prod_dim(self, a, dim): return self._reduce("prod", a, dim)
 

@@ -16,7 +16,8 @@ use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, CovNormalization, CovRows, CovarianceOptions, GpuTensorHandle,
     HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, PowerStepEpilogue, ProviderLinsolveOptions,
-    ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderPrecision, ReductionFlavor,
+    ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderNanMode, ProviderPrecision, ProviderScanDirection,
+    ProviderStdNormalization, ReduceDimResult, ReductionFlavor,
 };
 use std::ffi::{c_char, c_double, c_int, c_void, CStr, CString};
 
@@ -44,6 +45,10 @@ extern "C" {
     fn rmhip_unary(ctx: *mut RmhipCtx, op: c_int, a: u64, out: *mut u64) -> c_int;
     fn rmhip_scalar(ctx: *mut RmhipCtx, op: c_int, a: u64, s: c_double, out: *mut u64) -> c_int;
     fn rmhip_reduce(ctx: *mut RmhipCtx, op: c_int, a: u64, dim: c_int, nan_mode: c_int, out: *mut u64) -> c_int;
+    fn rmhip_reduce_minmax_dim(ctx: *mut RmhipCtx, op: c_int, a: u64, dim: c_int, nan_mode: c_int, values: *mut u64, indices: *mut u64) -> c_int;
+    fn rmhip_reduce_std(ctx: *mut RmhipCtx, a: u64, dim: c_int, normalization: c_int, nan_mode: c_int, out: *mut u64) -> c_int;
+    fn rmhip_reduce_truth(ctx: *mut RmhipCtx, op: c_int, a: u64, dim: c_int, omit_nan: c_int, out: *mut u64) -> c_int;
+    fn rmhip_cumulative(ctx: *mut RmhipCtx, op: c_int, a: u64, dim: c_int, reverse: c_int, nan_mode: c_int, out: *mut u64) -> c_int;
     fn rmhip_reduce_nd(ctx: *mut RmhipCtx, op: c_int, a: u64, dims: *const usize, ndims: usize, nan_mode: c_int, out: *mut u64) -> c_int;
     fn rmhip_reduce_moments_nd(ctx: *mut RmhipCtx, a: u64, dims: *const usize, ndims: usize, mean: *mut u64, ex2: *mut u64) -> c_int;
     fn rmhip_dot(ctx: *mut RmhipCtx, a: u64, b: u64, dim: c_int, out: *mut u64) -> c_int;
@@ -391,6 +396,77 @@ impl AccelProvider for HipProvider {
             check(unsafe { rmhip_reduce(self.ctx, 0, self.own(a)?, dim as c_int, 0, &mut out) })?;
             self.handle(out)
         })
+    }
+    // reduce_min_dim / reduce_max_dim -> ReduceDimResult { values, indices } (lib.rs:2864-2883): the runtime calls these in
+    // "includenan" mode only (min.rs:795-800) and expects its host path's answer: first occurrence, first NaN wins
+    fn reduce_min_dim<'a>(&'a self, a: &'a GpuTensorHandle, dim: usize) -> AccelProviderFuture<'a, ReduceDimResult> {
+        Box::pin(async move {
+            let (mut v, mut i) = (0u64, 0u64);
+            check(unsafe { rmhip_reduce_minmax_dim(self.ctx, 2 /* RMHIP_RMIN */, self.own(a)?, dim as c_int, 0, &mut v, &mut i) })?;
+            Ok(ReduceDimResult { values: self.handle(v)?, indices: self.handle(i)? })
+        })
+    }
+    fn reduce_max_dim<'a>(&'a self, a: &'a GpuTensorHandle, dim: usize) -> AccelProviderFuture<'a, ReduceDimResult> {
+        Box::pin(async move {
+            let (mut v, mut i) = (0u64, 0u64);
+            check(unsafe { rmhip_reduce_minmax_dim(self.ctx, 3 /* RMHIP_RMAX */, self.own(a)?, dim as c_int, 0, &mut v, &mut i) })?;
+            Ok(ReduceDimResult { values: self.handle(v)?, indices: self.handle(i)? })
+        })
+    }
+    fn reduce_std_dim<'a>(&'a self, a: &'a GpuTensorHandle, dim: usize, normalization: ProviderStdNormalization, nan_mode: ProviderNanMode) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            let norm = matches!(normalization, ProviderStdNormalization::Population) as c_int;
+            let nan = matches!(nan_mode, ProviderNanMode::Omit) as c_int;
+            check(unsafe { rmhip_reduce_std(self.ctx, self.own(a)?, dim as c_int, norm, nan, &mut out) })?;
+            self.handle(out)
+        })
+    }
+    fn reduce_std<'a>(&'a self, a: &'a GpuTensorHandle, normalization: ProviderStdNormalization, nan_mode: ProviderNanMode) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            let norm = matches!(normalization, ProviderStdNormalization::Population) as c_int;
+            let nan = matches!(nan_mode, ProviderNanMode::Omit) as c_int;
+            check(unsafe { rmhip_reduce_std(self.ctx, self.own(a)?, -1, norm, nan, &mut out) })?;
+            self.handle(out)
+        })
+    }
+    // reduce_nnz(_dim) / reduce_any(_dim) / reduce_all(_dim) (lib.rs:2730-2742, 2803-2850): op 0 / 1 / 2 of rmhip_reduce_truth; the
+    // forms without `_dim` are the same calls with dim = -1
+    fn reduce_nnz_dim<'a>(&'a self, a: &'a GpuTensorHandle, dim: usize) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_reduce_truth(self.ctx, 0, self.own(a)?, dim as c_int, 0, &mut out) })?;
+            self.handle(out)
+        })
+    }
+    fn reduce_any_dim<'a>(&'a self, a: &'a GpuTensorHandle, dim: usize, omit_nan: bool) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_reduce_truth(self.ctx, 1, self.own(a)?, dim as c_int, omit_nan as c_int, &mut out) })?;
+            self.handle(out)
+        })
+    }
+    fn reduce_all_dim<'a>(&'a self, a: &'a GpuTensorHandle, dim: usize, omit_nan: bool) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_reduce_truth(self.ctx, 2, self.own(a)?, dim as c_int, omit_nan as c_int, &mut out) })?;
+            self.handle(out)
+        })
+    }
+    fn cumsum_scan(&self, input: &GpuTensorHandle, dim: usize, direction: ProviderScanDirection, nan_mode: ProviderNanMode) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        let rev = matches!(direction, ProviderScanDirection::Reverse) as c_int;
+        let nan = matches!(nan_mode, ProviderNanMode::Omit) as c_int;
+        check(unsafe { rmhip_cumulative(self.ctx, 0, self.own(input)?, dim as c_int, rev, nan, &mut out) })?;
+        self.handle(out)
+    }
+    fn cumprod_scan(&self, input: &GpuTensorHandle, dim: usize, direction: ProviderScanDirection, nan_mode: ProviderNanMode) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        let rev = matches!(direction, ProviderScanDirection::Reverse) as c_int;
+        let nan = matches!(nan_mode, ProviderNanMode::Omit) as c_int;
+        check(unsafe { rmhip_cumulative(self.ctx, 1, self.own(input)?, dim as c_int, rev, nan, &mut out) })?;
+        self.handle(out)
     }
     fn reduce_mean_nd<'a>(&'a self, a: &'a GpuTensorHandle, dims_zero_based: &'a [usize]) -> AccelProviderFuture<'a, GpuTensorHandle> {
         Box::pin(async move {

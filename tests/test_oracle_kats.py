@@ -474,3 +474,54 @@ def test_mrdivide_kats(oracle):
     x = oracle.mrdivide(a, b)
     assert np.max(np.abs(x.reshape(-1, order="F") - [3.0, 2.0, -2.0, -1.0])) < 1e-12
     assert np.array_equal(oracle.mrdivide(np.array([[2.0, 4.0, 6.0]]), np.array([[2.0]])), [[1.0, 2.0, 3.0]])
+
+
+# ---- round 3: min / max with indices, std, nnz / any / all, cumulative scans (oracle.c "reductions next to sum / mean") ----
+def test_minmax_with_indices_reference_kats(oracle):
+    """max.rs / min.rs unit tests: `max_vector_with_indices` (:2470-2477), `max_row_vector_reduces_across_columns` (:2568-2575),
+    `max_matrix_default_dimension` (:2607-2626), `max_with_omitnan` (:2651-2659), `max_omitnan_all_nan_slice` (:2662-2676), and the
+    rules they do not cover but the code states: first occurrence, -0 < +0 (min.rs:1519-1531), first NaN wins (min.rs:1443-1455)."""
+    v, i = oracle.minmax_dim(np.array([[3.0], [1.0], [5.0]]), 0, True)
+    assert v.item() == 5.0 and i.item() == 3.0
+    v, i = oracle.minmax_dim(np.array([[3.0, 1.0, 5.0]]), 1, True)
+    assert v.item() == 5.0 and i.item() == 3.0
+    A = np.array([3.0, 4.0, 1.0, 2.0, 5.0, 6.0]).reshape(2, 3, order="F")
+    v, i = oracle.minmax_dim(A, 0, True)
+    assert v.tolist() == [[4.0, 2.0, 6.0]] and i.tolist() == [[2.0, 2.0, 2.0]]
+    v, i = oracle.minmax_dim(np.array([[np.nan], [4.0], [2.0]]), 0, True, omitnan=True)
+    assert v.item() == 4.0 and i.item() == 2.0
+    v, i = oracle.minmax_dim(np.array([[np.nan], [np.nan]]), 0, True, omitnan=True)
+    assert np.isnan(v.item()) and np.isnan(i.item())
+    v, i = oracle.minmax_dim(np.array([[2.0, np.nan, 1.0, np.nan]]), 1, False)  # includenan: the FIRST NaN
+    assert np.isnan(v.item()) and i.item() == 2.0
+    v, i = oracle.minmax_dim(np.array([[0.0, -0.0, 0.0, -0.0]]), 1, False)
+    assert np.signbit(v.item()) and i.item() == 2.0
+    v, i = oracle.minmax_dim(np.array([[-0.0, 0.0, -0.0]]), 1, True)
+    assert not np.signbit(v.item()) and i.item() == 2.0
+    v, i = oracle.minmax_dim(np.array([[7.0, 1.0, 1.0, 7.0]]), 1, False)  # ties: first occurrence
+    assert v.item() == 1.0 and i.item() == 2.0
+
+
+def test_std_truth_and_scans_reference_rules(oracle):
+    """std.rs:858-935 (sample / population, NaN modes, single value), nnz.rs:358, any.rs:722-733, all.rs:671-703,
+    cumsum.rs:586-650 / cumprod.rs (include: NaN from the first NaN on; omit: NaNs leave the running value; reverse)."""
+    x = np.array([[1.0, 2.0, 3.0, 4.0]])
+    assert abs(oracle.std_dim(x, 1).item() - np.std([1, 2, 3, 4], ddof=1)) < 1e-15
+    assert abs(oracle.std_dim(x, 1, population=True).item() - np.std([1, 2, 3, 4])) < 1e-15
+    assert oracle.std_dim(np.array([[5.0]]), None).item() == 0.0
+    assert np.isnan(oracle.std_dim(np.array([[1.0, np.nan, 3.0]]), 1).item())
+    assert abs(oracle.std_dim(np.array([[1.0, np.nan, 3.0]]), 1, omitnan=True).item() - np.sqrt(2.0)) < 1e-15
+    assert np.isnan(oracle.std_dim(np.array([[np.nan, np.nan]]), 1, omitnan=True).item())
+    t = np.array([[0.0, np.nan, 2.0], [0.0, 0.0, np.nan]])
+    assert oracle.truth_dim(t, 0, "nnz").tolist() == [[0.0, 1.0, 2.0]]
+    assert oracle.truth_dim(t, 0, "any").tolist() == [[0.0, 1.0, 1.0]] and oracle.truth_dim(t, 0, "any", True).tolist() == [[0.0, 0.0, 1.0]]
+    assert oracle.truth_dim(t, 0, "all").tolist() == [[0.0, 0.0, 1.0]]  # NaNs are skipped; [2, NaN] has no zero left
+    assert oracle.truth_dim(np.array([[np.nan, np.nan]]), 1, "all").item() == 1.0
+    assert oracle.cumulative(np.array([[1.0, 2.0], [3.0, 4.0]]), 0).tolist() == [[1.0, 2.0], [4.0, 6.0]]
+    r = oracle.cumulative(np.array([[1.0, np.nan, 3.0]]), 1)
+    assert r[0, 0] == 1.0 and np.isnan(r[0, 1]) and np.isnan(r[0, 2])
+    assert oracle.cumulative(np.array([[1.0, np.nan, 3.0]]), 1, omitnan=True).tolist() == [[1.0, 1.0, 4.0]]
+    r = oracle.cumulative(np.array([[1.0, np.nan, 3.0]]), 1, reverse=True)
+    assert np.isnan(r[0, 0]) and np.isnan(r[0, 1]) and r[0, 2] == 3.0
+    assert oracle.cumulative(np.array([[2.0, 3.0, 4.0]]), 1, prod=True).tolist() == [[2.0, 6.0, 24.0]]
+    assert oracle.cumulative(np.array([[2.0, np.nan, 4.0]]), 1, prod=True, omitnan=True, reverse=True).tolist() == [[8.0, 4.0, 4.0]]
