@@ -37,12 +37,14 @@ struct ArgAcc {
         key = ~0ull;
         idx = ~0ull;
     }
+    // every thread feeds its elements in ASCENDING index order, so a strict compare keeps the first occurrence (the index only breaks
+    // ties between threads / chunks, in merge)
     __device__ __forceinline__ void add(u64 k, double v) {
-        const u64 b = (u64)__double_as_longlong(v);
-        u64 ord = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+        const long long b = __double_as_longlong(v);
+        u64 ord = (u64)b ^ ((u64)(b >> 63) | 0x8000000000000000ull);  // negative: ~b, else b with the sign bit set
         if (MAX) ord = ~ord;
         if (v != v) ord = OMIT ? ~0ull : 0ull;
-        if (ord < key || (ord == key && k < idx)) {
+        if (ord < key) {
             key = ord;
             idx = k;
         }
@@ -83,7 +85,13 @@ struct MomAcc {
         }
         n += 1.0;
         const double delta = v - mean;
-        mean += delta / n;
+        // delta / n with the hardware reciprocal + two Newton steps (n is a small exact integer: the quotient differs from the CPU's
+        // division by at most an ulp, far inside what merging chunks changes anyway); an IEEE division is ~35 instructions per
+        // element and made the kernel VALU-bound at 2.8 TB/s
+        double rn = __builtin_amdgcn_rcp(n);
+        rn = __builtin_fma(rn, __builtin_fma(-n, rn, 1.0), rn);
+        rn = __builtin_fma(rn, __builtin_fma(-n, rn, 1.0), rn);
+        mean += delta * rn;
         const double delta2 = v - mean;
         m2 += delta * delta2;
     }
@@ -137,13 +145,12 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_contig(const double* __restrict
     Acc a;
     a.init();
     u64 r = begin + threadIdx.x;
-    for (; r + 3 * R2_BLOCK < end; r += 4 * R2_BLOCK) {  // four loads in flight; folded in index order
-        const double v0 = __builtin_nontemporal_load(xs + r), v1 = __builtin_nontemporal_load(xs + r + R2_BLOCK);
-        const double v2 = __builtin_nontemporal_load(xs + r + 2 * R2_BLOCK), v3 = __builtin_nontemporal_load(xs + r + 3 * R2_BLOCK);
-        a.add(r, v0);
-        a.add(r + R2_BLOCK, v1);
-        a.add(r + 2 * R2_BLOCK, v2);
-        a.add(r + 3 * R2_BLOCK, v3);
+    for (; r + 7 * R2_BLOCK < end; r += 8 * R2_BLOCK) {  // eight loads in flight; folded in index order
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(xs + r + u * R2_BLOCK);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a.add(r + u * R2_BLOCK, v[u]);
     }
     for (; r < end; r += R2_BLOCK) a.add(r, __builtin_nontemporal_load(xs + r));
     lds[threadIdx.x] = a;
@@ -190,6 +197,50 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_strided(const double* __restric
             if (r + u < end) a.add(r + u, v[u]);
     }
     part[(i + pre * j) * nsplit + split] = a;
+}
+
+// the same with 16-byte loads: a thread owns two adjacent lines (even `pre`, 16-byte aligned base).  As for sum(x,2)
+// (reduce_kernels.hip) what decides the rate of these lock-step column walks is the number of blocks: three per CU.
+typedef double r2_d2 __attribute__((ext_vector_type(2)));
+template <class Acc>
+__global__ void __launch_bounds__(R2_BLOCK) k_r2_strided_v2(const double* __restrict__ x, u64 pre, u64 red, u64 nsplit, Acc* __restrict__ part) {
+    const u64 i2 = (u64)blockIdx.x * R2_BLOCK + threadIdx.x, pre2 = pre >> 1;
+    if (i2 >= pre2) return;
+    const u64 split = blockIdx.y, j = blockIdx.z;
+    const u64 chunk = (red + nsplit - 1) / nsplit;
+    const u64 begin = split * chunk;
+    u64 end = begin + chunk;
+    if (end > red) end = red;
+    const r2_d2* xs = reinterpret_cast<const r2_d2*>(x) + i2 + pre2 * red * j;
+    Acc a0, a1;
+    a0.init();
+    a1.init();
+    u64 r = begin;
+    for (; r + 8 <= end; r += 8) {
+        r2_d2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(xs + pre2 * (r + u));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a0.add(r + u, v[u].x);
+            a1.add(r + u, v[u].y);
+        }
+    }
+    if (r < end) {
+        r2_d2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (r + u < end) v[u] = __builtin_nontemporal_load(xs + pre2 * (r + u));
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (r + u < end) {
+                a0.add(r + u, v[u].x);
+                a1.add(r + u, v[u].y);
+            }
+    }
+    const u64 line = 2 * i2 + pre * j;
+    part[line * nsplit + split] = a0;
+    part[(line + 1) * nsplit + split] = a1;
 }
 
 // ---- stage 2: one wave per slice merges the chunks in chunk order (lane l takes a contiguous run) ------------------------------
@@ -260,9 +311,10 @@ static int run_r2(Context* c, const double* x, size_t pre, size_t red, size_t po
     if (!p.valid) return fail(RMHIP_ERR_UNSUPPORTED, "%s: geometry [%zu,%zu,%zu] exceeds launch limits", what, pre, red, post);
     u64 nsplit = p.nsplit;
     unsigned gx = p.gx;
-    if (!p.contiguous) {  // this kernel keeps 256 threads along `pre`
-        gx = (unsigned)ceil_div_u64(pre, R2_BLOCK);
-        u64 want = ceil_div_u64((u64)c->num_cus * 8, (u64)gx * post);
+    const bool wide = !p.contiguous && (pre & 1) == 0 && pre >= 512 && (((uintptr_t)x) & 15) == 0;
+    if (!p.contiguous) {  // these kernels keep 256 threads along `pre`
+        gx = (unsigned)ceil_div_u64(wide ? pre / 2 : pre, R2_BLOCK);
+        u64 want = ceil_div_u64((u64)c->num_cus * (wide ? 3 : 8), (u64)gx * post);
         u64 max_split = ceil_div_u64(red, 16);
         nsplit = want < 1 ? 1 : (want > max_split ? max_split : want);
         nsplit = dealias_nsplit(red, nsplit, pre * 8, max_split);
@@ -273,6 +325,8 @@ static int run_r2(Context* c, const double* x, size_t pre, size_t red, size_t po
     Acc* part = reinterpret_cast<Acc*>(c->scratch);
     if (p.contiguous)
         hipLaunchKernelGGL((k_r2_contig<Acc>), dim3((unsigned)nsplit, p.gy, p.gz), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices, nsplit, part);
+    else if (wide)
+        hipLaunchKernelGGL((k_r2_strided_v2<Acc>), dim3(gx, (unsigned)nsplit, (unsigned)post), dim3(R2_BLOCK), 0, c->stream, x, (u64)pre, (u64)red, nsplit, part);
     else
         hipLaunchKernelGGL((k_r2_strided<Acc>), dim3(gx, (unsigned)nsplit, (unsigned)post), dim3(R2_BLOCK), 0, c->stream, x, (u64)pre, (u64)red, nsplit, part);
     RMHIP_HIP_CHECK(hipGetLastError());
