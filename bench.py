@@ -591,27 +591,73 @@ def main() -> None:
                          "kernel": "k_sgemm_w8 (eight waves, pipelined k loop; v_mfma_f32_16x16x4_f32)", "kernel_ms": round(kern_ms, 5)},
         }
 
+    def agreed(ok: bool) -> bool:
+        """Every rank reports whether its last workload went through; a failure anywhere fails it everywhere, so that the ranks stay in
+        step for the next workload's collectives (control plane, one small all-reduce)."""
+        if dist is None:
+            return ok
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=coll_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    def safe_record(name, fn, steps, warmup):
+        """One workload; an exception becomes an "error" record instead of a dead run (a missing workload costs the line one entry)."""
+        rec, why = None, ""
+        try:
+            if os.environ.get("RMHIP_BENCH_TEST_FAIL") == name:  # test hook (every rank): the error path of this function
+                raise RuntimeError("forced by RMHIP_BENCH_TEST_FAIL")
+            rec = fn(steps, warmup)
+        except Exception as e:  # noqa: BLE001
+            why = f"{type(e).__name__}: {e}"[:300]
+            try:
+                prov.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
+        if not agreed(rec is not None):
+            return {"workload": name, "error": why or "failed on another rank"}
+        return rec
+
     records = {"sgemm": sgemm_record, "fused_f32": fused_f32_record, "fused": fused_record, "dgemm": dgemm_record, "mc": mc_record, "mldivide": mldivide_record,
                "chain": chain_record, "mc_evolved": mc_evolved_record, "image": image_record}
     primary = records[args.workload]
-    rec = primary(args.steps, args.warmup)
+    rec = safe_record(args.workload, primary, args.steps, args.warmup)
+    if "error" in rec:  # the line still comes out, with the reason where the number would be
+        rec = {"metric": f"{args.workload} (failed)", "value": None, "unit": "", "ms_per_step": None, "scaling": "weak", "dtype": "f64",
+               "config": {"workload": args.workload}, "roofline": None, "error": rec["error"]}
     out = {
         "metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": rec["scaling"],
         "vs_baseline": None, "dtype": rec["dtype"], "data": "synthetic", "config": rec["config"],
         "roofline": rec["roofline"],
     }
+    if "error" in rec:
+        out["error"] = rec["error"]
     out["config"] = dict(out["config"], collectives=comm_note)
+    # what the data path actually ran on: the library's own view of the communicator (rmhip_comm_rank), not what was asked for
+    comm = {"transport": "none", "world_seen": 1}
+    if world > 1:
+        try:
+            if group.native is not None:
+                r_seen, w_seen = prov.comm_rank()
+                comm = {"transport": "rccl" if backend == "nccl" else "host-shm", "world_seen": int(w_seen), "rank_seen": int(r_seen)}
+            else:
+                comm = {"transport": f"torch.distributed/{backend}", "world_seen": int(dist.get_world_size())}
+        except Exception as e:  # noqa: BLE001
+            comm = {"transport": "unknown", "error": str(e)[:200]}
+    out["comm"] = comm
     if not args.no_also:
         # the other configs of BASELINE.json, short runs; every rank takes part (collectives inside)
         others = [w for w in ("fused", "dgemm", "mc", "mc_evolved", "image", "chain", "fused_f32", "sgemm") if w != args.workload]
-        if world == 1 and args.workload != "mldivide":
-            others.append("mldivide")
+        if args.workload != "mldivide":
+            others.append("mldivide")  # one GPU: rmhip_mldivide; N > 1: the block-column cyclic driver (BASELINE configs[4])
         also = []
         for w in others:
             steps = {"fused": 20, "dgemm": 5, "mc": 10, "mc_evolved": 10, "image": 20, "mldivide": 2, "chain": 100, "fused_f32": 20, "sgemm": 5}[w]
-            sec = records[w](steps, 2 if w != "mldivide" else 1)
-            also.append({k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "roofline")})
+            sec = safe_record(w, records[w], steps, 2 if w != "mldivide" else 1)
+            if "error" in sec:
+                also.append(sec)
+            else:
+                also.append({k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "roofline")})
         out["also"] = also
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = {"fused": cpu_baseline_fused, "dgemm": cpu_baseline_dgemm, "mc": cpu_baseline_mc,
@@ -619,6 +665,8 @@ def main() -> None:
                                "mc_evolved": cpu_baseline_mc, "image": cpu_baseline_fused,
                                "fused_f32": cpu_baseline_fused, "sgemm": cpu_baseline_dgemm}[args.workload]()
         for a in out.get("also", []):
+            if "error" in a:
+                continue
             if a["unit"] == "GFLOP/s" and "matmul" in a["metric"] and a["metric"].startswith("fp64"):
                 a["cpu_baseline"] = cpu_baseline_dgemm()
             elif a["unit"] == "samples/s" and "stochastic_evolution" not in a["metric"]:

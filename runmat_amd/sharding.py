@@ -86,9 +86,18 @@ class Group:
     def with_native_comm(self, prov, transport: str = "rccl") -> "Group":
         """Create the C-ABI communicator on `prov`: rank 0 makes the id, the control plane distributes its 128 bytes."""
         if self.world > 1:
-            payload = [prov.comm_unique_id(transport) if self.rank == 0 else None]
+            # rank 0 may fail to make the id (librccl not loadable, ...): it still broadcasts - an error sentinel - so that every
+            # rank leaves this collective and raises the same way (a rank 0 that raised before the broadcast left the others in it)
+            payload = [None]
+            if self.rank == 0:
+                try:
+                    payload = [("ok", prov.comm_unique_id(transport))]
+                except Exception as e:  # noqa: BLE001
+                    payload = [("error", str(e)[:300])]
             self.dist.broadcast_object_list(payload, src=0)
-            uid = payload[0]
+            status, uid = payload[0]
+            if status != "ok":
+                raise RuntimeError(f"native communicator: rank 0 could not create the id: {uid}")
         else:
             uid = prov.comm_unique_id(transport)
         prov.comm_init(uid, self.rank, self.world)

@@ -1,0 +1,68 @@
+"""The driver's N > 1 bench line, exercised on ONE GPU: two ranks share cuda:0 (RMHIP_BENCH_BACKEND=gloo: gloo control plane, the
+library's host shared-memory transport as the data path).  The numbers of such a run mean nothing; what is checked is that the
+first run on a multi-GPU node cannot die of a schema slip or of one failing workload: ONE JSON line, every BASELINE config present
+with its roofline, the communicator the library itself reports, and a failing workload turned into an "error" record."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_bench(extra_args, extra_env, nproc=2, timeout=900):
+    env = dict(os.environ, RMHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", str(nproc)] + extra_args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line, got {len(lines)}: {r.stdout[-1500:]}"
+    return json.loads(lines[0])
+
+
+def _check_roofline(rf):
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s")
+    assert rf["achieved"] > 0 and rf["peak"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 2e-3
+    assert "traffic" in rf and "kernel" in rf
+
+
+def test_two_rank_line_has_every_config_and_a_communicator():
+    out = _run_bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline"], {})
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "comm", "also"):
+        assert k in out, k
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["data"] == "synthetic" and out["vs_baseline"] is None
+    assert out["value"] > 0 and out["scaling"] == "weak" and "workload" in out["config"]
+    _check_roofline(out["roofline"])
+    assert out["comm"] == {"transport": "host-shm", "world_seen": 2, "rank_seen": 0}
+    seen = {}
+    for a in out["also"]:
+        assert "error" not in a, a
+        for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "roofline"):
+            assert k in a, (k, a.get("metric"))
+        assert a["value"] > 0 and a["ms_per_step"] > 0
+        _check_roofline(a["roofline"])
+        seen[a["metric"]] = a
+    joined = " | ".join(seen)
+    # BASELINE.json configs[2..4] under N > 1: row-sharded dgemm, sample-sharded Monte-Carlo, the multi-GPU solve
+    assert "8192^3 matmul" in joined and "Monte-Carlo" in joined and "A\\b" in joined
+    solve = next(a for m, a in seen.items() if "A\\b" in m)
+    assert "cyclic x2" in solve["config"]["parallelism"] and solve["config"]["max_abs_err_vs_ones"] < 1e-6
+
+
+def test_a_failing_workload_becomes_an_error_record():
+    out = _run_bench(["--steps", "2", "--warmup", "1", "--workload", "chain", "--no-also", "--no-cpu-baseline"], {"RMHIP_BENCH_TEST_FAIL": "chain"})
+    assert out["value"] is None and "forced by RMHIP_BENCH_TEST_FAIL" in out["error"] and out["n_gpus"] == 2
+    assert out["comm"]["world_seen"] == 2
