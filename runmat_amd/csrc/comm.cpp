@@ -12,7 +12,6 @@
 //     Slow and node-local by construction; it exists so that the same entry points run on the single-GPU test box.
 #include <dlfcn.h>
 #include <fcntl.h>
-#include <rccl/rccl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -29,6 +28,19 @@ namespace rmhip {
 namespace {
 
 // ---- RCCL through dlopen ---------------------------------------------------------------------------------------------
+// The handful of NCCL-API types and constants used here, declared locally (they are fixed by the NCCL ABI: rccl.h
+// `ncclUniqueId` = 128 opaque bytes, `ncclResult_t` 0 = success, `ncclDataType_t` 8 = f64): the library is only ever loaded at run
+// time, so it should not need RCCL's development headers to BUILD either.
+struct ncclComm;
+typedef ncclComm* ncclComm_t;
+typedef struct {
+    char internal[128];
+} ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+static constexpr ncclResult_t ncclSuccess = 0;
+static constexpr ncclDataType_t ncclFloat64 = 8;
+
 struct RcclApi {
     void* handle = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
@@ -38,6 +50,7 @@ struct RcclApi {
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    std::string load_error;  // why `ok` is false: captured ONCE where it happened (dlerror() clears itself when read)
 };
 
 RcclApi& rccl() {
@@ -65,8 +78,11 @@ RcclApi& rccl() {
         for (const std::string& name : names) {
             api.handle = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (api.handle) break;
+            const char* e = dlerror();
+            api.load_error = e ? e : "dlopen failed";
         }
         if (!api.handle) return;
+        api.load_error.clear();
         auto sym = [&](const char* n) { return dlsym(api.handle, n); };
         api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
         api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
@@ -75,6 +91,7 @@ RcclApi& rccl() {
         api.Broadcast = (decltype(api.Broadcast))sym("ncclBroadcast");
         api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
         api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.Broadcast && api.GetErrorString;
+        if (!api.ok) api.load_error = "librccl lacks one of ncclGetUniqueId / CommInitRank / CommDestroy / AllGather / Broadcast / GetErrorString";
     });
     return api;
 }
@@ -181,6 +198,12 @@ void partition(size_t total, int world, int rank, size_t granule, size_t* start,
 // what the call stream has enqueued so far
 int begin_collective(Context* c, Comm* cm, bool async, hipStream_t* s) {
     if (!async || cm->host) {
+        // a broadcast posted on the communication stream may still be in flight: RCCL does not order two operations of one
+        // communicator that sit on different streams, so the call stream waits for it first
+        if (cm->pending) {
+            RMHIP_HIP_CHECK(hipStreamWaitEvent(c->stream, cm->ev_done, 0));
+            cm->pending = false;
+        }
         *s = c->stream;
         return RMHIP_OK;
     }
@@ -194,6 +217,15 @@ int end_collective(Context* c, Comm* cm, bool async) {
     if (!async || cm->host) return RMHIP_OK;
     RMHIP_HIP_CHECK(hipEventRecord(cm->ev_done, cm->stream));
     cm->pending = true;
+    return RMHIP_OK;
+}
+
+// synchronous collectives run on the call stream: first join a broadcast still in flight on the communication stream
+int join_pending(Context* c, Comm* cm) {
+    if (cm->pending && !cm->host) {
+        RMHIP_HIP_CHECK(hipStreamWaitEvent(c->stream, cm->ev_done, 0));
+        cm->pending = false;
+    }
     return RMHIP_OK;
 }
 
@@ -214,7 +246,7 @@ void comm_destroy(Context* c) {
     if (cm->ev_done) (void)hipEventDestroy(cm->ev_done);
     if (cm->hdr) {
         (void)munmap((void*)cm->hdr, cm->map_bytes);
-        if (cm->rank == 0) (void)shm_unlink(cm->shm_name.c_str());
+        if (cm->rank == 0 && !cm->shm_name.empty()) (void)shm_unlink(cm->shm_name.c_str());  // only if init never got to its barrier
     }
     delete cm;
     c->comm = nullptr;
@@ -244,7 +276,7 @@ int rmhip_comm_unique_id(int transport, void* id_out) {
         return RMHIP_OK;
     }
     if (transport != RMHIP_COMM_RCCL) return fail(RMHIP_ERR_INVALID, "unknown transport %d", transport);
-    if (!rccl().ok) return fail(RMHIP_ERR_UNSUPPORTED, "librccl could not be loaded (%s)", dlerror() ? dlerror() : "missing symbols");
+    if (!rccl().ok) return fail(RMHIP_ERR_UNSUPPORTED, "librccl could not be loaded (%s)", rccl().load_error.c_str());
     ncclUniqueId id;
     const ncclResult_t r = rccl().GetUniqueId(&id);
     if (r != ncclSuccess) return nccl_fail("ncclGetUniqueId", r);
@@ -314,11 +346,19 @@ int rmhip_comm_init(rmhip_ctx* ctx, const void* unique_id, int rank, int world) 
             }
         }
         cm->hdr->attached.fetch_add(1);
-        return shm_barrier(cm);
+        const int brc = shm_barrier(cm);
+        // every rank has the segment mapped now (or the barrier timed out): the NAME can go - a rank that crashes later, or a
+        // communicator nobody destroys, no longer leaves world x 8 MiB behind in /dev/shm
+        if (rank == 0) {
+            (void)shm_unlink(cm->shm_name.c_str());
+            cm->shm_name.clear();
+        }
+        if (brc != RMHIP_OK) comm_destroy(c);
+        return brc;
     }
     if (!rccl().ok) {
         comm_destroy(c);
-        return fail(RMHIP_ERR_UNSUPPORTED, "librccl could not be loaded");
+        return fail(RMHIP_ERR_UNSUPPORTED, "librccl could not be loaded (%s)", rccl().load_error.c_str());
     }
     ncclUniqueId id;
     std::memcpy(&id, unique_id, sizeof id);
@@ -427,6 +467,7 @@ int rmhip_comm_allgather_f64(rmhip_ctx* ctx, rmhip_buf local, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);
     Comm* cm;
     RMHIP_TRY(require_comm(c, &cm));
+    RMHIP_TRY(join_pending(c, cm));
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     Buffer b;
     RMHIP_TRY(c->get(local, &b));  // f64, plain layout (a precision-32 buffer is widened: the exchange is f64)
@@ -466,6 +507,7 @@ int rmhip_comm_allgather_rows(rmhip_ctx* ctx, rmhip_buf local, size_t rows_total
     CTX_OR_FAIL(ctx);
     Comm* cm;
     RMHIP_TRY(require_comm(c, &cm));
+    RMHIP_TRY(join_pending(c, cm));
     if (!out || granule == 0) return fail(RMHIP_ERR_INVALID, "allgather_rows: bad argument");
     Buffer b;
     RMHIP_TRY(c->get_raw(local, &b));
@@ -533,6 +575,7 @@ int rmhip_comm_barrier(rmhip_ctx* ctx) {
     CTX_OR_FAIL(ctx);
     Comm* cm;
     RMHIP_TRY(require_comm(c, &cm));
+    RMHIP_TRY(join_pending(c, cm));
     RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (cm->world == 1) return RMHIP_OK;
     if (cm->host) return shm_barrier(cm);
