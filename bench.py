@@ -426,13 +426,34 @@ def main() -> None:
         ones = prov.ones((nn, 1))
         hb = prov.matmul(ha, ones)  # b = A*1  => x = 1
         cyclic = world > 1 or os.environ.get("RMHIP_BENCH_FORCE_CYCLIC") == "1"
+        form = {"name": "single GPU, blocked LU with look-ahead (solve path: diagonal-domain pivoting + multiplier check)"}
         if cyclic:
-            # multi-GPU: 1-D block-column cyclic LU, one panel broadcast per block (runmat_amd/sharding.py).
-            # Every rank builds the same A, keeps only the column blocks it owns.
+            # multi-GPU: BASELINE configs[4]'s row-partitioned form (runmat_amd/sharding.py mldivide_row_partitioned: every rank keeps
+            # the row blocks of [A | b] it owns, pivoting inside the owner's rows, one tile-row broadcast per panel, the last `world`
+            # blocks all-gathered); if its multiplier guard refuses the matrix, the block-column cyclic form with the grid-wide rule.
+            # Every rank builds the same A and keeps only what it owns.
             nbk = 512
             blocks = sh.owned_blocks(nn, nbk, group)
+            row_blocks = sh.owned_row_blocks(nn, nbk, group)
+            form["name"] = (f"row-partitioned x{world}, rb=512: diagonal-domain pivoting, one tile-row broadcast per panel (rmhip_comm_bcast), "
+                            f"last {world} row blocks all-gathered")
 
-            def solve():
+            def solve_rows():
+                nloc = sum(min(nbk, nn - q * nbk) for q in row_blocks)
+                ab = prov.zeros((max(nloc, 1), nn + 1))
+                for q in row_blocks:
+                    h = min(nbk, nn - q * nbk)
+                    lo = sh.local_row_offset(q, nbk, group)
+                    for src, c0, wd in ((ha, 0, nn), (hb, nn, 1)):
+                        blk = prov.blk_copy((src, q * nbk, 0, h, wd))
+                        prov.blk_assign((ab, lo, c0, h, wd), blk)
+                        prov.free(blk)
+                try:
+                    return sh.mldivide_row_partitioned(prov, group, ab, nn, 1, rb=nbk)
+                finally:
+                    prov.free(ab)
+
+            def solve_cols():
                 ncl = sum(min(nbk, nn - p * nbk) for p in blocks)
                 a_loc = prov.zeros((nn, max(ncl, 1)))
                 for p in blocks:
@@ -443,6 +464,15 @@ def main() -> None:
                 x = sh.mldivide_block_cyclic(prov, group, a_loc, nn, hb, nb=nbk)
                 prov.free(a_loc)
                 return x
+
+            def solve():
+                if not form.get("cols"):
+                    try:
+                        return solve_rows()
+                    except sh.PivotGrowth:  # raised on every rank alike (the guard is one exchange)
+                        form["cols"] = True
+                        form["name"] = f"block-column cyclic x{world}, nb=512, one panel broadcast per block (rmhip_comm_bcast, depth-1 look-ahead)"
+                return solve_cols()
         else:
             def solve():
                 return prov.mldivide(ha, hb)
@@ -462,16 +492,15 @@ def main() -> None:
         for h in (ha, ones, hb):
             prov.free(h)
         return {
-            "metric": "fp64 GFLOP/s (x = A\\b, 16384x16384, LU with partial pivoting)",
+            "metric": "fp64 GFLOP/s (x = A\\b, 16384x16384, blocked LU)",
             "value": round(flops / (ms * 1e-3) / 1e9, 1), "unit": "GFLOP/s", "ms_per_step": round(ms, 3), "scaling": "strong",
             "dtype": "f64",
             "config": {"workload": "x=A\\b 16384x16384 f64 via rmhip_mldivide, A=U(-1,1), b=A*1", "flops_per_step": flops,
                        "max_abs_err_vs_ones": err,
-                       "parallelism": (f"block-column cyclic x{world}, nb=512, one panel broadcast per block (rmhip_comm_bcast, depth-1 look-ahead)" if cyclic
-                                       else "single GPU, blocked LU with look-ahead")},
+                       "parallelism": form["name"]},
             "roofline": {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 3), "peak": FP64_MFMA_PEAK_TF,
                          "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF, 4), "traffic": None,
-                         "kernel": "k_lu_panel2 chain + k_dgemm trailing updates (whole solve, wall clock)"},
+                         "kernel": "k_rp_top / k_rp_below panels + k_dgemm_w8 trailing updates (whole solve, wall clock)"},
         }
 
     def chain_record(steps, warmup):

@@ -337,7 +337,9 @@ RMHIP_API int rmhip_blk_assign(rmhip_ctx* ctx, const rmhip_view_t* dst, rmhip_bu
 /* C = alpha*A*B + beta*C on views (fp64 MFMA dgemm). */
 RMHIP_API int rmhip_blk_gemm(rmhip_ctx* ctx, double alpha, const rmhip_view_t* a, const rmhip_view_t* b,
                              double beta, const rmhip_view_t* c);
-/* B <- T^-1 B with T the (upper != 0 ? upper non-unit : lower unit-diagonal) triangle of a square view. */
+/* upper 0: B <- L^-1 B with L the unit-diagonal lower triangle of the square view `t`; 1: B <- U^-1 B, U its upper triangle with the
+ * stored diagonal; 2: B <- B U^-1 (right-hand side: `b` is rows x w against a w x w triangle - the multipliers of a row block against a
+ * factored diagonal tile, used by the row-partitioned multi-GPU solve). */
 RMHIP_API int rmhip_blk_trsm(rmhip_ctx* ctx, int upper, const rmhip_view_t* t, const rmhip_view_t* b);
 /* In-place LU (host_lu.rs pivot rule) of a tall view; `ipiv_out` receives a [min(rows,cols),1] tensor
  * of LAPACK-style interchange targets (row k swapped with row ipiv[k], zero-based, relative to the

@@ -1312,6 +1312,24 @@ int rmhip_blk_trsm(rmhip_ctx* ctx, int upper, const rmhip_view_t* t, const rmhip
     ViewPtr vt, vb;
     RMHIP_TRY(resolve_view(c, t, &vt));
     RMHIP_TRY(resolve_view(c, b, &vb));
+    if (upper == 2) {
+        // B <- B U^-1 (the multipliers of a row block against a factored diagonal tile: L21 = A21 U11^-1).  X U = B is U' X' = B': both
+        // operands are transposed into temporaries (k_transpose, 64 x 64 LDS tiles), U' is lower with a stored diagonal - the
+        // kernels of `linsolve`'s LT hint - and the solution is transposed back in place.  O(rows w) extra traffic around O(rows w^2) work.
+        if (vt.rows != vt.cols || vb.cols != vt.rows)
+            return fail(RMHIP_ERR_SHAPE, "blk_trsm (right): triangle %zux%zu vs block %zux%zu", vt.rows, vt.cols, vb.rows, vb.cols);
+        const size_t w = vt.rows, m = vb.rows;
+        if (w == 0 || m == 0) return RMHIP_OK;
+        std::shared_ptr<Allocation> tt, bt;
+        RMHIP_TRY(c->alloc_device(w * w, &tt));
+        RMHIP_TRY(c->alloc_device(w * m, &bt));
+        RMHIP_TRY(transpose_device(c, vt.ptr, vt.ld, w, w, tt->ptr, w));
+        RMHIP_TRY(transpose_device(c, vb.ptr, vb.ld, m, w, bt->ptr, w));
+        RMHIP_TRY(trsm_lower_nonunit_device(c, tt->ptr, w, w, bt->ptr, w, m));
+        RMHIP_TRY(transpose_device(c, bt->ptr, w, w, m, vb.ptr, vb.ld));
+        RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));  // the temporaries go back to the pool on return
+        return RMHIP_OK;
+    }
     if (vt.rows != vt.cols || vb.rows != vt.rows) return fail(RMHIP_ERR_SHAPE, "blk_trsm: triangle %zux%zu vs rhs %zux%zu", vt.rows, vt.cols, vb.rows, vb.cols);
     return upper ? trsm_upper_device(c, vt.ptr, vt.ld, vt.rows, vb.ptr, vb.ld, vb.cols)
                  : trsm_lower_unit_device(c, vt.ptr, vt.ld, vt.rows, vb.ptr, vb.ld, vb.cols);

@@ -572,9 +572,21 @@ class HipProvider:
         va, vb, vc = self._view(a), self._view(b), self._view(c)
         self._check(self._lib.rmhip_blk_gemm(self._ctx, float(alpha), C.byref(va), C.byref(vb), float(beta), C.byref(vc)))
 
-    def blk_trsm(self, upper: bool, t, b) -> None:
+    def blk_trsm(self, upper, t, b) -> None:
+        """upper False / 0: B <- L^-1 B (unit lower); True / 1: B <- U^-1 B; 2 or "right": B <- B U^-1."""
         vt, vb = self._view(t), self._view(b)
-        self._check(self._lib.rmhip_blk_trsm(self._ctx, 1 if upper else 0, C.byref(vt), C.byref(vb)))
+        mode = 2 if upper in (2, "right") else (1 if upper else 0)
+        self._check(self._lib.rmhip_blk_trsm(self._ctx, mode, C.byref(vt), C.byref(vb)))
+
+    def blk_absmax(self, view) -> float:
+        """max |a_ij| over a view (copy, abs, max: three calls and a download - a host-side check, not a hot path)."""
+        blk = self.blk_copy(view)
+        ab = self._unary("abs", blk)
+        mx = self._reduce("max", ab, -1)
+        v = float(self.download(mx)[0])
+        for h in (blk, ab, mx):
+            self.free(h)
+        return v
 
     def blk_lu(self, a) -> Tuple[GpuTensorHandle, int]:
         out, info = C.c_uint64(), C.c_int()

@@ -516,3 +516,139 @@ def mldivide_block_cyclic(prov, group: Group, a_local, n: int, b, nb: int = 512)
             prov.blk_assign((y, 0, 0, j + w, nrhs), pre)
             prov.free(pre)
     return y
+
+
+# ---- row-partitioned A \\ b (BASELINE.json configs[4]: "row-partitioned ... RCCL all-gather") ------------------------------------
+class PivotGrowth(RuntimeError):
+    """A multiplier outside the diagonal domain exceeded the bound: solve with `mldivide_block_cyclic` (grid-wide pivot rule)."""
+
+
+def owned_row_blocks(n: int, rb: int, group: Group) -> List[int]:
+    """Row blocks of height `rb` owned by this rank (block q on rank q % world), ascending = local storage order."""
+    return [q for q in range((n + rb - 1) // rb) if q % group.world == group.rank]
+
+
+def local_row_offset(q: int, rb: int, group: Group) -> int:
+    """First local row of row block q on its owner (blocks are stored in ownership order, all but the last full)."""
+    return (q // group.world) * rb
+
+
+def mldivide_row_partitioned(prov, group: Group, ab_local, n: int, nrhs: int, rb: int = 512, tau: float = 8.0):
+    """Solve A x = b with [A | b] distributed BY ROWS: row block q (height rb) of the n x (n + nrhs) augmented matrix lives on rank
+    q % world, stored in ownership order in `ab_local` (OVERWRITTEN with this rank's rows of the factors).  Returns the replicated
+    solution handle (n x nrhs), identical on every rank.
+
+    Pivots never leave a solve, so - as on one GPU (lu.hip, solve path) - pivoting is restricted to a DIAGONAL DOMAIN and verified:
+    panel p (columns of row block p) is factored by its owner with partial pivoting among the owner's OWN rows from the diagonal tile
+    down ((n - j) / world of them): every interchange is local to one rank, no row ever crosses the fabric.  What does:
+      * ONE broadcast per panel of the owner's tile row [L11\\U11 | U12 | y-part] - rb x (n + nrhs - j) doubles, 64 MiB for the first
+        panel at n = 16384, rb = 512, shrinking linearly: the same volume the block-column form moves, but every rank then
+        computes ITS rows' multipliers (L21 = A21 U11^-1) and trailing update (A22 -= L21 U12) with no further exchange;
+      * the last `world` row blocks, whose owners have no rows left below the diagonal tile to pivot among, are ALL-GATHERED
+        (<= world * rb rows) and finished by every rank redundantly with the single-GPU solve;
+      * the back substitution broadcasts one rb x nrhs solution block per panel.
+    The right-hand sides ride along as extra columns, so the forward substitution is part of the trailing update.
+    Guard: the largest multiplier a rank computes for rows outside the owner's domain; beyond `tau` (one exchange at the end) the
+    factorisation is not trusted and `PivotGrowth` is raised - callers then use `mldivide_block_cyclic` (the grid-wide rule).
+    Needs a precision-64 provider."""
+    _require_f64(prov, "mldivide_row_partitioned")
+    from .provider import ProviderError
+
+    world, rank = group.world, group.rank
+    ncols = n + nrhs
+    nblocks = (n + rb - 1) // rb
+    mine = owned_row_blocks(n, rb, group)
+    nloc = sum(min(rb, n - q * rb) for q in mine)
+    # phase 1 covers the panels whose owner still has a block below the tile; the rest is gathered
+    n_direct = max(0, nblocks - world)
+    growth = 0.0
+
+    def bcast(handle, shape, src):
+        if group.native is not None and world > 1:
+            group.native.comm_bcast(handle, src)
+        elif world > 1:
+            _bcast(group, prov, handle, shape, src)
+
+    def first_local_row_at_or_after(q):
+        """local row offset of this rank's first block with index >= q (nloc when there is none)"""
+        for b in mine:
+            if b >= q:
+                return local_row_offset(b, rb, group)
+        return nloc
+
+    tiles = []  # (j, w, tile-row handle [w x (ncols - j)]) of every direct panel, kept for the back substitution
+    for p in range(n_direct):
+        j, w, owner = p * rb, rb, p % world
+        width = ncols - j
+        if rank == owner:
+            lr = local_row_offset(p, rb, group)
+            ipiv, info = prov.blk_lu((ab_local, lr, j, nloc - lr, w))  # partial pivoting among this rank's rows from the tile down
+            if info > 0:
+                prov.free(ipiv)
+                raise PivotGrowth(f"panel {p}: {info} pivot(s) at the singular cut-off inside the diagonal domain")
+            if j > 0:
+                prov.blk_swap_rows((ab_local, lr, 0, nloc - lr, j), ipiv)               # the interchanges on the L part ...
+            prov.blk_swap_rows((ab_local, lr, j + w, nloc - lr, width - w), ipiv)       # ... and on everything to the right (b included)
+            prov.free(ipiv)
+            prov.blk_trsm(False, (ab_local, lr, j, w, w), (ab_local, lr, j + w, w, width - w))  # U12 and the y part: L11^-1 [A12 | b]
+            tile = prov.blk_copy((ab_local, lr, j, w, width))
+            below = lr + w
+        else:
+            tile = prov.zeros((w, width))
+            below = first_local_row_at_or_after(p + 1)
+        bcast(tile, (w, width), owner)
+        mb = nloc - below
+        if mb > 0:
+            if rank != owner:  # the owner's rows below the tile were factored with it
+                prov.blk_trsm(2, (tile, 0, 0, w, w), (ab_local, below, j, mb, w))       # L21 = A21 U11^-1
+                growth = max(growth, prov.blk_absmax((ab_local, below, j, mb, w)))
+            prov.blk_gemm(-1.0, (ab_local, below, j, mb, w), (tile, 0, w, w, width - w), 1.0, (ab_local, below, j + w, mb, width - w))
+        tiles.append((j, w, tile))
+    # ---- the guard: one exchange, every rank decides the same way
+    worst = float(np.max(group.all_gather_f64([growth])))
+    if not worst <= tau:
+        for _, _, t in tiles:
+            prov.free(t)
+        raise PivotGrowth(f"largest multiplier outside the diagonal domains {worst:.3g} > {tau:g}")
+    # ---- the remaining rows: gathered, then the single-GPU solve on every rank
+    j0 = n_direct * rb
+    m_rem = n - j0
+    x = prov.zeros((n, nrhs))
+    if m_rem > 0:
+        trailing = prov.zeros((m_rem, m_rem + nrhs))
+        for q in range(n_direct, nblocks):
+            h = min(rb, n - q * rb)
+            owner = q % world
+            if rank == owner:
+                blk = prov.blk_copy((ab_local, local_row_offset(q, rb, group), j0, h, m_rem + nrhs))
+            else:
+                blk = prov.zeros((h, m_rem + nrhs))
+            bcast(blk, (h, m_rem + nrhs), owner)
+            prov.blk_assign((trailing, q * rb - j0, 0, h, m_rem + nrhs), blk)
+            prov.free(blk)
+        a_rem = prov.blk_copy((trailing, 0, 0, m_rem, m_rem))
+        b_rem = prov.blk_copy((trailing, 0, m_rem, m_rem, nrhs))
+        try:
+            x_rem = prov.mldivide(a_rem, b_rem)
+        except ProviderError:
+            for h in (trailing, a_rem, b_rem, x):
+                prov.free(h)
+            for _, _, t in tiles:
+                prov.free(t)
+            raise
+        prov.blk_assign((x, j0, 0, m_rem, nrhs), x_rem)
+        for h in (trailing, a_rem, b_rem, x_rem):
+            prov.free(h)
+    # ---- back substitution over the direct panels: every rank holds every tile row, so it is redundant and needs no exchange at all
+    for j, w, tile in reversed(tiles):
+        width = ncols - j
+        rhs = prov.blk_copy((tile, 0, width - nrhs, w, nrhs))                # y_p
+        later = n - j - w
+        if later > 0:
+            prov.blk_gemm(-1.0, (tile, 0, w, w, later), (x, j + w, 0, later, nrhs), 1.0, (rhs, 0, 0, w, nrhs))  # y_p - U12 x_later
+        prov.blk_trsm(True, (tile, 0, 0, w, w), (rhs, 0, 0, w, nrhs))        # U11^-1
+        prov.blk_assign((x, j, 0, w, nrhs), rhs)
+        prov.free(rhs)
+        prov.free(tile)
+    return x
+

@@ -48,7 +48,17 @@ class NumpyBlockProvider:
         import scipy.linalg as sl
 
         T, Bv = self._v(t).T, self._v(b)
+        if upper in (2, "right"):  # B <- B U^-1
+            Bv[...] = sl.solve_triangular(T, Bv, trans="T", lower=False)  # Bv is B' : U' X' = B'
+            return
         Bv[...] = sl.solve_triangular(T, Bv.T, lower=not upper, unit_diagonal=not upper).T
+
+    def blk_absmax(self, v):
+        a = self._v(v)
+        return float(np.max(np.abs(a))) if a.size else 0.0
+
+    def mldivide(self, a, b):
+        return H(np.linalg.solve(a.arr.T, b.arr.T).T)
 
     def blk_lu(self, a):
         Av = self._v(a)  # transposed

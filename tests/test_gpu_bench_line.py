@@ -59,7 +59,7 @@ def test_two_rank_line_has_every_config_and_a_communicator():
     # BASELINE.json configs[2..4] under N > 1: row-sharded dgemm, sample-sharded Monte-Carlo, the multi-GPU solve
     assert "8192^3 matmul" in joined and "Monte-Carlo" in joined and "A\\b" in joined
     solve = next(a for m, a in seen.items() if "A\\b" in m)
-    assert "cyclic x2" in solve["config"]["parallelism"] and solve["config"]["max_abs_err_vs_ones"] < 1e-6
+    assert "row-partitioned x2" in solve["config"]["parallelism"] and solve["config"]["max_abs_err_vs_ones"] < 1e-6
 
 
 def test_a_failing_workload_becomes_an_error_record():

@@ -1,5 +1,6 @@
 """Two ranks sharing cuda:0: the multi-GPU drivers (sample-range Monte-Carlo with LCG skip-ahead, the one-call
-stochastic_evolution form, row-sharded matmul, block-column cyclic LU with panel broadcasts and depth-1 look-ahead)
+stochastic_evolution form, row-sharded matmul, block-column cyclic LU with panel broadcasts and depth-1 look-ahead, the
+row-partitioned solve with diagonal-domain pivoting)
 through the REAL provider, checked against the oracle.  Run twice: with the data path on torch.distributed (gloo,
 host-staged) and with every exchange going through the C-ABI collectives (`rmhip_comm_*`) on the host shared-memory
 transport - RCCL refuses two ranks on one device, so on this single-GPU box RCCL itself is exercised with a one-rank
@@ -64,8 +65,20 @@ def _worker(rank, world, port, out_dir, native):
         blocks = sh.owned_blocks(nn, nb, group)
         cols = [c for p in blocks for c in range(p * nb, min(nn, (p + 1) * nb))]
         x = prov.download_matrix(sh.mldivide_block_cyclic(prov, group, prov.upload(AA[:, cols]), nn, prov.upload(BB), nb=nb))
+        # row-partitioned solve: every rank keeps the row blocks of [A | b] it owns; diagonal-domain pivoting, one tile-row broadcast
+        # per panel, the last `world` blocks gathered (sharding.mldivide_row_partitioned).  Also: a matrix whose large entries sit
+        # outside the owners' domains must be refused (PivotGrowth), on every rank alike.
+        rbk = 128
+        rows = [r for q in sh.owned_row_blocks(nn, rbk, group) for r in range(q * rbk, min(nn, (q + 1) * rbk))]
+        xr = prov.download_matrix(sh.mldivide_row_partitioned(prov, group, prov.upload(np.hstack([AA, BB])[rows, :]), nn, nrhs, rb=rbk))
+        bad = (rng2.uniform(-1, 1, (nn, nn)) + nn * np.eye(nn))[np.roll(np.arange(nn), 3 * rbk)]  # the diagonal moved three blocks down
+        refused = False
+        try:
+            sh.mldivide_row_partitioned(prov, group, prov.upload(np.hstack([bad, BB])[rows, :]), nn, nrhs, rb=rbk)
+        except sh.PivotGrowth:
+            refused = True
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), p_fused=p_fused, s_fused=np.uint64(s_fused), p_evol=p_evol,
-                 s_evol=np.uint64(s_evol), C=C, x=x)
+                 s_evol=np.uint64(s_evol), C=C, x=x, xr=xr, refused=refused)
         prov.close()
     finally:
         dist.destroy_process_group()
@@ -96,7 +109,10 @@ def test_two_ranks_on_one_gpu(oracle, tmp_path, native):
     xr = oracle.mldivide_lu(AA, BB)
     for r in res:
         assert np.max(np.abs(r["x"] - xr)) <= 1e-9 * max(1.0, np.abs(xr).max())
+        assert np.max(np.abs(r["xr"] - xr)) <= 1e-9 * max(1.0, np.abs(xr).max())  # row-partitioned form vs the oracle's LU solve
+        assert bool(r["refused"])
     assert np.array_equal(res[0]["x"], res[1]["x"])
+    assert np.array_equal(res[0]["xr"], res[1]["xr"])  # replicated, bit-identical
 
 
 def test_rccl_one_rank_communicator(prov, oracle):

@@ -162,3 +162,60 @@ def test_block_cyclic_solve_single_rank_double():
     y = sh.mldivide_block_cyclic(prov, g, prov.upload(A.copy()), n, prov.upload(b), nb=16)
     assert np.allclose(prov.download(y), np.linalg.solve(A, b).reshape(-1), atol=1e-10)
     assert sh.owned_blocks(100, 32, sh.Group(1, 3)) == [1] and sh.local_col_offset(5, 32, sh.Group(1, 2)) == 64
+
+
+def _rows_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    from numpy_block_provider import NumpyBlockProvider
+    from runmat_amd import sharding as sh
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        group = sh.Group.from_env()
+        prov = NumpyBlockProvider()
+        n, rb, nrhs = 150, 32, 2  # 5 row blocks (the last one ragged) over 2 ranks: 3 direct panels, 2 gathered blocks
+        rng = np.random.default_rng(5)
+        A = rng.uniform(-1, 1, (n, n))
+        X = np.stack([np.ones(n), np.arange(n) / n], axis=1)
+        AB = np.hstack([A, A @ X])
+        rows = np.concatenate([np.arange(q * rb, min((q + 1) * rb, n)) for q in sh.owned_row_blocks(n, rb, group)])
+        x = sh.mldivide_row_partitioned(prov, group, prov.upload(AB[rows, :]), n, nrhs, rb=rb, tau=64.0)
+        # rows shuffled so that the big entries are NOT in the owners' domains: every rank must refuse, at the same point
+        bad = (rng.uniform(-1, 1, (n, n)) + n * np.eye(n))[np.roll(np.arange(n), 2 * rb + 1)]
+        refused = False
+        try:
+            sh.mldivide_row_partitioned(prov, group, prov.upload(np.hstack([bad, A @ X])[rows, :]), n, nrhs, rb=rb)
+        except sh.PivotGrowth:
+            refused = True
+        np.savez(os.path.join(out_dir, f"rows_rank{rank}.npz"), x=prov.download(x).reshape(n, nrhs, order="F"), X=X, refused=refused)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_world2_gloo_row_partitioned_solve(tmp_path):
+    """Host logic of the row-partitioned A\\b (row ownership, the per-panel tile-row broadcast, the gathered tail, the guard)."""
+    import torch.multiprocessing as mp
+
+    world, port = 2, _free_port()
+    mp.spawn(_rows_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(tmp_path / f"rows_rank{r}.npz") for r in range(world)]
+    for r in res:
+        assert np.max(np.abs(r["x"] - r["X"])) < 1e-9 and bool(r["refused"])
+    assert np.array_equal(res[0]["x"], res[1]["x"])
+
+
+def test_row_partitioned_solve_single_rank_double():
+    from numpy_block_provider import NumpyBlockProvider
+    from runmat_amd import sharding as sh
+
+    prov, g = NumpyBlockProvider(), sh.Group()
+    for n, rb, nrhs in ((70, 16, 1), (64, 16, 2), (33, 64, 1)):
+        rng = np.random.default_rng(n)
+        A = rng.standard_normal((n, n))
+        B = rng.standard_normal((n, nrhs))
+        x = sh.mldivide_row_partitioned(prov, g, prov.upload(np.hstack([A, B])), n, nrhs, rb=rb)
+        assert np.allclose(prov.download(x).reshape(n, nrhs, order="F"), np.linalg.solve(A, B), atol=1e-10)
+    assert sh.owned_row_blocks(100, 32, sh.Group(1, 3)) == [1] and sh.local_row_offset(5, 32, sh.Group(1, 2)) == 64
+
