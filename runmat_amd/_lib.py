@@ -51,7 +51,7 @@ class LuStats(C.Structure):
     _fields_ = [("solve_path_factorizations", C.c_uint64), ("pivot_growth_fallbacks", C.c_uint64),
                 ("panel_exchange_timeouts", C.c_uint64), ("subst_chain_timeouts", C.c_uint64),
                 ("last_max_multiplier", C.c_double), ("tau", C.c_double), ("one_xcd_panels", C.c_int),
-                ("conservative_panels", C.c_int)]
+                ("conservative_panels", C.c_int), ("svd_solves", C.c_uint64)]
 
 
 class KernelAttr(C.Structure):

@@ -167,6 +167,7 @@ struct Context {
     double lu_last_growth = 0.0;       // largest multiplier the last solve-path factorisation saw below its top blocks
     uint64_t lu_fast_count = 0, lu_growth_fallbacks = 0;  // solve-path factorisations accepted / refactored with the grid-wide rule
     uint64_t lu_exchange_timeouts = 0, lu_subst_timeouts = 0;
+    uint64_t svd_solves = 0;  // systems answered by the Jacobi-SVD path (svdsolve.hip)
     double lu_tau = 8.0;
     int num_xcc = 8;  // accelerator dies the dispatcher interleaves workgroups over (probed at init; 1 on a CPX partition)
     // 64 or 32 (rmhip_set_precision).  At 32 every op output is stored as f32: kernels with a native f32-storage variant
@@ -326,6 +327,11 @@ int lu_solve_device(Context* c, const double* LU, size_t n, size_t lda, const in
                     const double* B, size_t nrhs, size_t ldb, double* X, size_t ldx);
 int lu_extract_device(Context* c, const double* LU, size_t rows, size_t cols, const int* perm_dev,
                       double* L, double* U, double* P, double* piv);
+
+// svdsolve.hip: minimum-norm least squares by a one-sided Jacobi SVD with the reference's tolerance rule (mldivide.rs:380-404) - what the
+// LU / Gram paths refuse (rank deficient, ill conditioned, singular), for min(rows, cols) <= kSvdMaxCols
+static constexpr int kSvdMaxCols = 1024;
+int svd_solve_device(Context* c, const double* A, size_t m, size_t n, const double* B, size_t nrhs, double* X, int* rank_out);
 
 // opaque handle -> Context (rmhip_core.cpp)
 Context* context_of(rmhip_ctx* h);

@@ -659,6 +659,7 @@ int rmhip_lu_stats(rmhip_ctx* ctx, rmhip_lu_stats_t* out) {
     out->tau = c->lu_tau;
     out->one_xcd_panels = c->one_xcd_ok ? 1 : 0;
     out->conservative_panels = c->lu_conservative ? 1 : 0;
+    out->svd_solves = c->svd_solves;
     return RMHIP_OK;
 }
 

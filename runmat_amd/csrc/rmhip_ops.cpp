@@ -1084,6 +1084,26 @@ static int lstsq_full_rank(rmhip_ctx* ctx, Context* c, const double* A, size_t m
     return RMHIP_OK;
 }
 
+// What the LU / Gram paths refuse - singular, rank-deficient or ill-conditioned systems - answered the way the reference answers every
+// system: minimum-norm least squares from an SVD with its tolerance rule (svdsolve.hip), as long as min(rows, cols) <= kSvdMaxCols.
+// `refused` is the status of the path that gave up (returned unchanged when the system is too large for the SVD path).
+static int svd_fallback(rmhip_ctx* ctx, Context* c, int refused, const double* A, size_t m, size_t n, const double* B, size_t nrhs, rmhip_buf* out) {
+    if ((m < n ? m : n) > (size_t)kSvdMaxCols || std::getenv("RMHIP_NO_SVD_PATH")) return refused;
+    Buffer ob;
+    rmhip_buf oid = 0;
+    const size_t oshape[2] = {n, nrhs};
+    RMHIP_TRY(c->new_buffer(oshape, 2, &oid, &ob));
+    int rank = 0;
+    const int rc = svd_solve_device(c, A, m, n, B, nrhs, ob.data(), &rank);
+    if (rc) {
+        rmhip_free(ctx, oid);
+        return rc;
+    }
+    c->svd_solves++;
+    *out = oid;
+    return RMHIP_OK;
+}
+
 static int mldivide_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     Buffer ab, bb;
@@ -1102,7 +1122,10 @@ static int mldivide_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, r
         return rc;
     }
     if (as[0] != bs[0]) return fail(RMHIP_ERR_SHAPE, "mldivide: row mismatch (%zu vs %zu)", as[0], bs[0]);
-    if (as[0] != as[1]) return lstsq_full_rank(ctx, c, ab.data(), as[0], as[1], bb.data(), bs[1], out);
+    if (as[0] != as[1]) {
+        const int lrc = lstsq_full_rank(ctx, c, ab.data(), as[0], as[1], bb.data(), bs[1], out);
+        return lrc == RMHIP_ERR_UNSUPPORTED && as[0] && as[1] && bs[1] ? svd_fallback(ctx, c, lrc, ab.data(), as[0], as[1], bb.data(), bs[1], out) : lrc;
+    }
     const size_t n = as[0], nrhs = bs[1];
     if (n == 0) return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: empty system");
     // Factorisation workspace with a PADDED leading dimension: with lda a large power of two every
@@ -1116,8 +1139,20 @@ static int mldivide_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, r
     int* perm = (int*)perm_mem->ptr;
     int info = 0;
     int rc = lu_copy_and_factor(c, ab.data(), n, n, work->ptr, ldw, perm, &info, true);
-    if (!rc && info > 0)
+    if (!rc && info > 0) {
         rc = fail(RMHIP_ERR_SINGULAR, "mldivide: %d pivot(s) <= 1e-12; matrix is numerically singular, use the CPU SVD path", info);
+        if (nrhs) return svd_fallback(ctx, c, rc, ab.data(), n, n, bb.data(), nrhs, out);  // n <= 1024: the SVD answer on the device
+    }
+    if (!rc && n <= (size_t)kSvdMaxCols && n > 1 && nrhs && !std::getenv("RMHIP_NO_SVD_PATH")) {
+        // A nearly singular matrix need not produce a pivot below the cut-off, yet the reference would DROP its small singular values
+        // (s_i <= eps * n * max(s_max, 1), mldivide.rs:396-404) where an LU divides by them.  Pivot ratio as the (cheap, rough) proxy of
+        // the condition number: below 1e3 * n * eps the SVD decides.  Only where the SVD path exists; larger systems keep the LU answer.
+        double mn = 0.0, mx = 0.0;
+        size_t zeros = 0;
+        if (diag_stats_device(c, work->ptr, ldw, n, &mn, &mx, &zeros) == RMHIP_OK && !(mn > 1.0e3 * (double)n * 2.220446049250313e-16 * mx))
+            return svd_fallback(ctx, c, fail(RMHIP_ERR_SINGULAR, "mldivide: pivot ratio %.2e: numerically singular", mx > 0 ? mn / mx : 0.0), ab.data(), n, n,
+                                bb.data(), nrhs, out);
+    }
     Buffer ob;
     rmhip_buf oid = 0;
     const size_t oshape[2] = {n, nrhs};
@@ -1194,7 +1229,8 @@ static int linsolve_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, c
         if (opts->need_rcond || opts->has_rcond)
             return fail(RMHIP_ERR_UNSUPPORTED, "linsolve: rcond of a general matrix needs its singular values (CPU path)");
         if (as[0] != as[1]) {  // full-rank rectangular system: least squares / minimum norm as rmhip_mldivide (linsolve.rs:933-970 is the SVD solve)
-            const int lrc = lstsq_full_rank(ctx, c, A, as[0], as[1], bb.data(), bs[1], out);
+            int lrc = lstsq_full_rank(ctx, c, A, as[0], as[1], bb.data(), bs[1], out);
+            if (lrc == RMHIP_ERR_UNSUPPORTED && as[0] && as[1] && bs[1]) lrc = svd_fallback(ctx, c, lrc, A, as[0], as[1], bb.data(), bs[1], out);
             if (at) (void)hipStreamSynchronize(c->stream);  // the transposed copy is released on return
             if (!lrc && reciprocal_condition) *reciprocal_condition = std::numeric_limits<double>::quiet_NaN();
             return lrc;
@@ -1228,7 +1264,17 @@ static int linsolve_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, c
         int* perm = (int*)perm_mem->ptr;
         int info = 0;
         rc = lu_copy_and_factor(c, A, n, n, work->ptr, ldw, perm, &info, true);
-        if (!rc && info > 0) rc = fail(RMHIP_ERR_SINGULAR, "linsolve: %d pivot(s) <= 1e-12; use the CPU SVD path", info);
+        if (!rc && info > 0) {
+            rc = fail(RMHIP_ERR_SINGULAR, "linsolve: %d pivot(s) <= 1e-12; use the CPU SVD path", info);
+            if (nrhs) {
+                rc = svd_fallback(ctx, c, rc, A, n, n, bb.data(), nrhs, &oid);
+                if (at) (void)hipStreamSynchronize(c->stream);
+                if (rc) return rc;
+                *out = oid;
+                if (reciprocal_condition) *reciprocal_condition = std::numeric_limits<double>::quiet_NaN();
+                return RMHIP_OK;
+            }
+        }
         if (!rc) rc = c->new_buffer(oshape, 2, &oid, &ob);
         if (!rc) rc = lu_solve_device(c, work->ptr, n, ldw, perm, bb.data(), nrhs, n, ob.data(), n);
     }

@@ -1,0 +1,73 @@
+"""Summarise scripts/profile_r03.sh's passes: per workload and kernel the launches, the average duration (kernel-trace pass) and the HBM-side
+bytes per launch from the FETCH_SIZE / WRITE_SIZE passes - bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB, and on
+gfx950 FETCH_SIZE reports half of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM section; WRITE_SIZE calibrates exactly on a
+512 MiB output) - and per workload the bytes per bench step.  Writes <dir>/pmc_summary.json and <dir>/pmc_traffic.json."""
+import collections, csv, glob, json, sys
+
+out = sys.argv[1]
+workloads = sys.argv[2:]
+LEGS = {"fused": 2, "dgemm": 2, "sgemm": 2, "fused_f32": 2}  # workloads whose record runs its steps twice (wall-clock leg + HIP-event leg)
+SETUP = ("k_fill", "k_probe_xcc", "__amd_rocclr", "k_narrow", "k_widen")  # not part of a step
+
+
+def counters(tag, name):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(f"{out}/{tag}/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") == name:
+                agg[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return agg
+
+
+def durations(tag):
+    d = {}
+    for f in glob.glob(f"{out}/{tag}/**/*kernel_stats.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            d[row["Name"]] = (int(row["Calls"]), float(row["AverageNs"]) / 1e3)
+    return d
+
+
+summary, traffic = [], {}
+for w in workloads:
+    fetch, write, dur = counters(f"pmc_fetch_{w}", "FETCH_SIZE"), counters(f"pmc_write_{w}", "WRITE_SIZE"), durations(f"trace_{w}")
+    steps = None
+    try:
+        line = [ln for ln in open(f"{out}/fetch_{w}_bench.json") if ln.startswith("{")][-1]
+        j = json.loads(line)
+        steps = (j["steps"] * LEGS.get(w, 1) + j["warmup"])
+    except Exception:
+        pass
+    total = 0.0
+    for k in sorted(set(fetch) | set(write), key=lambda k: -(2 * sum(fetch.get(k, [0])) + sum(write.get(k, [0])))):
+        fv, wv = fetch.get(k, []), write.get(k, [])
+        n = max(len(fv), len(wv))
+        if n == 0:
+            continue
+        bytes_per = (2 * (sum(fv) / len(fv) if fv else 0.0) + (sum(wv) / len(wv) if wv else 0.0)) * 1024
+        calls, avg_us = dur.get(k, (n, float("nan")))
+        rec = {"workload": w, "kernel": k[:120], "launches": n, "fetch_kib_mean": sum(fv) / len(fv) if fv else None,
+               "write_kib_mean": sum(wv) / len(wv) if wv else None, "bytes_per_launch": round(bytes_per), "avg_us": round(avg_us, 2),
+               "tb_per_s": round(bytes_per / avg_us / 1e6, 3) if avg_us == avg_us and avg_us > 0 else None}
+        summary.append(rec)
+        if not any(k.startswith(s) or s in k[:40] for s in SETUP):
+            total += bytes_per * n
+        short = k.split("(")[0].replace("void rmhip::", "").replace("rmhip::", "")
+        traffic.setdefault(w, {})[short[:80]] = round(bytes_per)
+    if steps:
+        traffic.setdefault(w, {})["_bytes_per_step"] = round(total / steps)
+        traffic[w]["_steps_in_run"] = steps
+    # matrix pipe
+    for f in glob.glob(f"{out}/pmc_mfma_{w}/**/*counter_collection.csv", recursive=True):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for row in csv.DictReader(open(f)):
+            if "gemm" in row["Kernel_Name"]:
+                agg[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        for k, d in agg.items():
+            rec = {"workload": w, "kernel": k[:120], "launches": len(next(iter(d.values())))}
+            for cn, v in d.items():
+                rec[cn + "_mean"] = sum(v) / len(v)
+            summary.append(rec)
+json.dump(summary, open(f"{out}/pmc_summary.json", "w"), indent=1)
+json.dump(traffic, open(f"{out}/pmc_traffic.json", "w"), indent=1)
+for w, t in traffic.items():
+    print(w, json.dumps(t)[:600])

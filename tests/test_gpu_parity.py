@@ -7,6 +7,8 @@ k*eps*sum|a||b| for matmul (MFMA fma chain vs the CPU's separately rounded sum +
 residual / forward-error bounds for A\\b exactly as the reference's own tests state them."""
 import math
 
+import os
+
 import numpy as np
 import pytest
 
@@ -560,13 +562,18 @@ def test_mldivide_reference_tests(prov, oracle):
     # scalar lhs: mldivide.rs:321-325
     s = prov.download_matrix(prov.mldivide(prov.upload(np.array([[4.0]])), prov.upload(np.array([[2.0, 8.0]]))))
     assert np.array_equal(s, [[0.5, 2.0]])
-    # rank-deficient inputs belong to the CPU SVD path: soft errors (full-rank rectangular systems: next test)
-    with pytest.raises(ProviderError) as e:
-        prov.mldivide(prov.upload(np.ones((3, 2))), prov.upload(np.ones((3, 1))))
-    assert e.value.code == 2
-    with pytest.raises(ProviderError) as e:
-        prov.mldivide(prov.upload(np.array([[1.0, 2.0], [2.0, 4.0]])), prov.upload(np.ones((2, 1))))
-    assert e.value.code == 7
+    # rank-deficient inputs: the LU / Gram paths refuse them - soft errors RMHIP_NO_SVD_PATH=1 still shows (and every system beyond 1024
+    # columns gets); up to 1024 columns the Jacobi-SVD path answers with the reference's minimum-norm solution (tests/test_gpu_svdpath.py)
+    for Ax, bx, code in ((np.ones((3, 2)), np.ones((3, 1)), 2), (np.array([[1.0, 2.0], [2.0, 4.0]]), np.ones((2, 1)), 7)):
+        os.environ["RMHIP_NO_SVD_PATH"] = "1"
+        try:
+            with pytest.raises(ProviderError) as e:
+                prov.mldivide(prov.upload(Ax), prov.upload(bx))
+            assert e.value.code == code
+        finally:
+            del os.environ["RMHIP_NO_SVD_PATH"]
+        xs = prov.download_matrix(prov.mldivide(prov.upload(Ax), prov.upload(bx)))
+        assert np.max(np.abs(xs - oracle.mldivide_svd(Ax, bx))) < 1e-12
     with pytest.raises(ProviderError) as e:
         prov.mldivide(prov.upload(np.eye(3)), prov.upload(np.ones((2, 1))))
     assert e.value.code == 3
@@ -607,15 +614,21 @@ def test_mldivide_rectangular_reference_kat_and_guards(prov, oracle):
     # rank deficient or badly conditioned: the caller's CPU SVD path (soft error, counted as a fallback)
     bad = rng.uniform(-1, 1, (200, 20))
     bad[:, 7] = bad[:, 3] * 2.0
-    with pytest.raises(ProviderError) as e:
-        prov.mldivide(prov.upload(bad), prov.upload(np.ones((200, 1))))
-    assert e.value.code == 2
     U, _ = np.linalg.qr(rng.standard_normal((300, 30)))
     V, _ = np.linalg.qr(rng.standard_normal((30, 30)))
     ill = U @ np.diag(np.logspace(0, -8, 30)) @ V.T  # cond 1e8
-    with pytest.raises(ProviderError) as e:
-        prov.mldivide(prov.upload(ill), prov.upload(np.ones((300, 1))))
-    assert e.value.code == 2
+    os.environ["RMHIP_NO_SVD_PATH"] = "1"  # the Gram route's own guards (with the SVD path on, both are answered: test_gpu_svdpath.py)
+    try:
+        with pytest.raises(ProviderError) as e:
+            prov.mldivide(prov.upload(bad), prov.upload(np.ones((200, 1))))
+        assert e.value.code == 2
+        with pytest.raises(ProviderError) as e:
+            prov.mldivide(prov.upload(ill), prov.upload(np.ones((300, 1))))
+        assert e.value.code == 2
+    finally:
+        del os.environ["RMHIP_NO_SVD_PATH"]
+    xb = prov.download_matrix(prov.mldivide(prov.upload(bad), prov.upload(np.ones((200, 1)))))
+    assert np.max(np.abs(xb - oracle.mldivide_svd(bad, np.ones((200, 1))))) <= 1e-10 * np.max(np.abs(xb))
     # linsolve without hints on a rectangular system: the same solve, rcond = NaN (linsolve.rs:933-970 is the SVD solve);
     # with TRANSA the transposed system
     At, bt = rng.uniform(-1, 1, (120, 25)), rng.uniform(-1, 1, (120, 2))
@@ -923,8 +936,12 @@ def test_linsolve_reference_tests(prov, oracle):
         prov.linsolve(prov.upload(np.diag([1.0, 1e-9])), prov.upload(np.ones((2, 1))), Opt(upper=True, rcond=1e-6))
     with pytest.raises(ProviderError):
         prov.linsolve(prov.upload(np.eye(2) * 2), prov.upload(np.ones((2, 1))), Opt(need_rcond=True))
-    with pytest.raises(ProviderError):
-        prov.linsolve(prov.upload(np.ones((3, 2))), prov.upload(np.ones((3, 1))))
+    os.environ["RMHIP_NO_SVD_PATH"] = "1"
+    try:
+        with pytest.raises(ProviderError):
+            prov.linsolve(prov.upload(np.ones((3, 2))), prov.upload(np.ones((3, 1))))
+    finally:
+        del os.environ["RMHIP_NO_SVD_PATH"]
     with pytest.raises(ProviderError):
         prov.linsolve(prov.upload(np.eye(3)), prov.upload(np.ones((2, 1))), Opt(lower=True))
     with pytest.raises(ProviderError):  # scalar operands stay on the host (linsolve.rs:408-412)
@@ -1285,13 +1302,18 @@ def test_mrdivide_and_solve_telemetry(prov, oracle):
     X = prov.download_matrix(prov.mrdivide(prov.upload(B), prov.upload(A)))
     assert X.shape == (m, n) and np.max(np.abs(X - oracle.mrdivide(B, A))) <= 1e-12
     assert np.linalg.norm(X @ A - B) <= 1e-12 * n * np.linalg.norm(A) * np.linalg.norm(X)
-    # soft failures are counted by reason (telemetry.rs:95-99)
-    with pytest.raises(ProviderError):
-        prov.mrdivide(prov.upload(np.ones((2, 3))), prov.upload(np.ones((4, 3))))  # rectangular divisor: CPU least squares
-    with pytest.raises(ProviderError):
-        prov.mldivide(prov.upload(np.array([[1.0, 2.0], [2.0, 4.0]])), prov.upload(np.ones((2, 1))))
-    with pytest.raises(ProviderError):
-        prov.mldivide(prov.upload(np.ones((3, 2))), prov.upload(np.ones((3, 1))))
+    # soft failures are counted by reason (telemetry.rs:95-99).  Singular / rank-deficient systems up to 1024 columns are answered on
+    # the device by the Jacobi-SVD path (tests/test_gpu_svdpath.py); RMHIP_NO_SVD_PATH=1 shows the hand-back every larger system gets
+    os.environ["RMHIP_NO_SVD_PATH"] = "1"
+    try:
+        with pytest.raises(ProviderError):
+            prov.mrdivide(prov.upload(np.ones((2, 3))), prov.upload(np.ones((4, 3))))  # rectangular divisor: CPU least squares
+        with pytest.raises(ProviderError):
+            prov.mldivide(prov.upload(np.array([[1.0, 2.0], [2.0, 4.0]])), prov.upload(np.ones((2, 1))))
+        with pytest.raises(ProviderError):
+            prov.mldivide(prov.upload(np.ones((3, 2))), prov.upload(np.ones((3, 1))))
+    finally:
+        del os.environ["RMHIP_NO_SVD_PATH"]
     prov.linsolve(prov.upload(A), prov.upload(B.T.copy()))
     t = prov.telemetry_snapshot()
     assert t["mrdivide_count"] == 5 and t["mldivide_count"] == 2 and t["linsolve_count"] == 1 and t["mrdivide_ns"] > 0
