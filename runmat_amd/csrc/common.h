@@ -158,6 +158,7 @@ struct Context {
     // set after a persistent-panel factorisation found its workgroups not co-resident (device shared with
     // another context): from then on LU uses the one-launch-per-column panels on a single stream
     hipStream_t lu_side_stream = nullptr;  // update stream of the look-ahead LU (low priority), created on first use
+    hipStream_t lu_aux_stream = nullptr;   // solve path: the full-height kernels' rows below the band of the panel in flight (lu.hip, LuState::aux)
     hipStream_t lu_prep_stream = nullptr;  // interchanges + triangular solves of one half of the trailing columns under the other half's dgemm
     std::vector<hipEvent_t> lu_events;     // its event pool
     bool lu_conservative = false;

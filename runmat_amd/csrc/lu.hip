@@ -54,7 +54,26 @@ struct LuState {
     double* ucomp = nullptr;              // device [BASE_W][BASE_W]: the pivot rows of the panel in flight
     unsigned long long* growth = nullptr; // device: bits of the largest multiplier below the top block so far
     bool screened = false;                // the first panel's multipliers were checked on the host (early way out)
+    // band split (look-ahead driver, solve path): rows below band_end of the panel in flight are nobody's dependency until the NEXT
+    // panel's look-ahead update, so their share of the full-height kernels (k_rp_below, the in-panel dgemm) runs on `aux` and the main
+    // stream - the critical chain of k_rp_top launches - only touches rows [j, band_end)
+    hipStream_t aux = nullptr;
+    size_t band_end = 0;                  // 0: no split
+    size_t ev_used = 0;                   // events drawn from the context's pool by this factorisation
+    unsigned ucomp_slot = 0;              // ring of compact U copies: k_rp_below on `aux` may still read panel p's while k_rp_top writes p + 1's
+    hipEvent_t aux_tail = nullptr;        // last event recorded on aux (what the main stream's next look-ahead update has to wait for)
 };
+static constexpr unsigned kUcompSlots = 16;  // >= base panels per look-ahead panel (512 / 64) with room to spare
+
+static hipEvent_t lu_new_event(LuState& s) {
+    Context* c = s.c;
+    if (s.ev_used == c->lu_events.size()) {
+        hipEvent_t e = nullptr;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        c->lu_events.push_back(e);
+    }
+    return c->lu_events[s.ev_used++];
+}
 
 static constexpr int MAX_PANEL_BLOCKS = 1024;  // 64 rows per block => up to 65536 rows per panel
 static constexpr int PANEL_JT = 8;            // panel columns per thread (unrolled batch; keep the code small)
@@ -1692,6 +1711,25 @@ static size_t one_xcd_block_limit(const Context* c) {
     return (one_xcd && c->one_xcd_ok) ? (size_t)c->num_cus / 8 : 0;
 }
 
+// retarget the context's stream (and the LDS pad / triangular-solve base that go with it) for a scope
+struct StreamScope {
+    Context* c;
+    hipStream_t saved;
+    size_t saved_pad;
+    int saved_base;
+    StreamScope(Context* ctx, hipStream_t s, size_t gemm_lds_pad, int base = 128)
+        : c(ctx), saved(ctx->stream), saved_pad(ctx->gemm_lds_pad), saved_base(ctx->trsm_base) {
+        c->stream = s;
+        c->gemm_lds_pad = gemm_lds_pad;
+        c->trsm_base = base;  // (128: the update stream owns whole CUs between its dgemm blocks anyway)
+    }
+    ~StreamScope() {
+        c->stream = saved;
+        c->gemm_lds_pad = saved_pad;
+        c->trsm_base = saved_base;
+    }
+};
+
 // Factor columns [j0, j0+w) over rows [j0, rows); swaps are applied inside that column range only.
 // own_swaps_by_caller: a base panel leaves its own columns un-interchanged (k_lu_panel2 stores every row where it was
 // loaded from); the recursion step above it then widens the k_laswp_lists call that moves the sibling's columns anyway
@@ -1716,7 +1754,8 @@ static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller =
             g.ipiv = s.ipiv;
             g.info = s.info;
             g.plist = s.plist + pid * PLIST;
-            g.ucomp = s.ucomp;
+            double* const ucomp = s.ucomp + (size_t)(s.ucomp_slot++ % kUcompSlots) * BASE_W * BASE_W;
+            g.ucomp = ucomp;
             g.xcc_out = s.panel_xcc;
             // like k_lu_panel2 the block ASKS for more LDS than it uses (48.6 KiB static) so that it does not share its CU with an
             // update-stream dgemm block: every column step would run slower beside one (RMHIP_LU_PANEL_PAD_KB; the phase-dependent
@@ -1738,13 +1777,26 @@ static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller =
             if (g.rows < s.rows) {
                 static const int rb_threads = std::getenv("RMHIP_LU_RB_THREADS") ? std::atoi(std::getenv("RMHIP_LU_RB_THREADS")) : 64;  // developer knob (A/B)
                 const size_t rbt = rb_threads == 256 ? 256 : (rb_threads == 128 ? 128 : 64);
-                const size_t nbb = (s.rows - g.rows + rbt - 1) / rbt;
                 void (*kern)(double*, size_t, size_t, size_t, int, int, const double*, pk_u64*, double, pk_u64*) =
                     s.xdbg ? (rbt == 256 ? k_rp_below<256, true> : (rbt == 128 ? k_rp_below<128, true> : k_rp_below<64, true>))
                            : (rbt == 256 ? k_rp_below<256, false> : (rbt == 128 ? k_rp_below<128, false> : k_rp_below<64, false>));
-                hipLaunchKernelGGL(kern, dim3((unsigned)nbb), dim3((unsigned)rbt), 0, s.c->stream, s.A, s.lda, s.rows, (size_t)g.rows, (int)j0, (int)w,
-                                   (const double*)s.ucomp, (pk_u64*)s.growth, s.tau, (pk_u64*)s.xdbg);
-                RMHIP_TRY(launch_check(s.c));
+                auto below = [&](hipStream_t st, size_t r0, size_t r1) {  // rows [r0, r1)
+                    if (r1 <= r0) return;
+                    hipLaunchKernelGGL(kern, dim3((unsigned)((r1 - r0 + rbt - 1) / rbt)), dim3((unsigned)rbt), 0, st, s.A, s.lda, r1, r0, (int)j0, (int)w,
+                                       (const double*)ucomp, (pk_u64*)s.growth, s.tau, (pk_u64*)s.xdbg);
+                    s.c->tel.kernel_launches++;
+                };
+                const size_t split = (s.aux && s.band_end > (size_t)g.rows && s.band_end < s.rows) ? s.band_end : s.rows;
+                below(s.c->stream, g.rows, split);
+                if (split < s.rows) {  // the rest of the rows: off the critical chain
+                    hipEvent_t top_done = lu_new_event(s);
+                    (void)hipEventRecord(top_done, s.c->stream);  // (recorded behind the band's k_rp_below: same stream order as the top block)
+                    (void)hipStreamWaitEvent(s.aux, top_done, 0);
+                    below(s.aux, split, s.rows);
+                    s.aux_tail = lu_new_event(s);
+                    (void)hipEventRecord(s.aux_tail, s.aux);
+                }
+                RMHIP_HIP_CHECK(hipGetLastError());
             }
             s.xbase += (unsigned)w;
             s.panel_start->push_back(j0);
@@ -1753,6 +1805,7 @@ static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller =
                 // fails at its first panel; one small read here instead of a whole factorisation of wasted work.
                 s.screened = true;
                 unsigned long long bits = 0;
+                if (s.aux) RMHIP_HIP_CHECK(hipStreamSynchronize(s.aux));  // its rows of the first panel count too
                 RMHIP_HIP_CHECK(hipMemcpyAsync(&bits, s.growth, sizeof(bits), hipMemcpyDeviceToHost, s.c->stream));
                 RMHIP_HIP_CHECK(hipStreamSynchronize(s.c->stream));
                 double gmax;
@@ -1860,7 +1913,22 @@ static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller =
     if (j0 + h < s.rows) {
         double* A21 = s.A + (j0 + h) + j0 * s.lda;
         double* A22 = s.A + (j0 + h) + (j0 + h) * s.lda;
-        RMHIP_TRY(lu_dgemm(s.c, s.rows - j0 - h, w - h, h, -1.0, A21, s.lda, A12, s.lda, 1.0, A22, s.lda));
+        const size_t r0 = j0 + h;
+        const size_t split = (s.fast && s.aux && s.band_end > r0 && s.band_end < s.rows) ? s.band_end : s.rows;
+        RMHIP_TRY(lu_dgemm(s.c, split - r0, w - h, h, -1.0, A21, s.lda, A12, s.lda, 1.0, A22, s.lda));
+        if (split < s.rows) {
+            // rows below the band: their multipliers come from aux's own k_rp_below launches (stream order), the U block row from the
+            // triangular solve the main stream just enqueued
+            hipEvent_t u_ready = lu_new_event(s);
+            (void)hipEventRecord(u_ready, s.c->stream);
+            (void)hipStreamWaitEvent(s.aux, u_ready, 0);
+            {
+                StreamScope scope(s.c, s.aux, s.c->gemm_lds_pad, s.c->trsm_base);
+                RMHIP_TRY(lu_dgemm(s.c, s.rows - split, w - h, h, -1.0, A21 + (split - r0), s.lda, A12, s.lda, 1.0, A22 + (split - r0), s.lda));
+            }
+            s.aux_tail = lu_new_event(s);
+            (void)hipEventRecord(s.aux_tail, s.aux);
+        }
         RMHIP_TRY(getrf_rec(s, j0 + h, w - h, true, &right_deferred));
         const size_t k1 = (j0 + w <= s.rows) ? (j0 + w) : s.rows;
         RMHIP_TRY(laswp(s, j0, right_deferred ? j0 + w : j0 + h, j0 + h, k1));
@@ -1875,23 +1943,6 @@ static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller =
 // stream while the main stream already factors the next panel:
 //   main:  P_j -> LA_j (swap + trsm + gemm of the next panel's nb columns) -> P_{j+1} -> wait(S_j) -> LA_{j+1} ...
 //   side:  wait(P_j) -> S_j (swap + trsm + gemm of columns right of the next panel; swaps of the finished left columns) ...
-struct StreamScope {
-    Context* c;
-    hipStream_t saved;
-    size_t saved_pad;
-    int saved_base;
-    StreamScope(Context* ctx, hipStream_t s, size_t gemm_lds_pad, int base = 128)
-        : c(ctx), saved(ctx->stream), saved_pad(ctx->gemm_lds_pad), saved_base(ctx->trsm_base) {
-        c->stream = s;
-        c->gemm_lds_pad = gemm_lds_pad;
-        c->trsm_base = base;  // (128: the update stream owns whole CUs between its dgemm blocks anyway)
-    }
-    ~StreamScope() {
-        c->stream = saved;
-        c->gemm_lds_pad = saved_pad;
-        c->trsm_base = saved_base;
-    }
-};
 
 // columns [c0, c1) receive the row interchanges of panel [j, j+w) and the U block row ...
 static int prep_columns(LuState& s, size_t j, size_t w, size_t c0, size_t c1) {
@@ -1930,15 +1981,16 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     // XCD 0, a mask that bars the update stream from XCD 0 except one CU - a mask that empties an XCD is ignored as a whole -
     // with the usual padded blocks: 370 ms against 112.  Work submitted through a CU-masked queue is slow here for
     // reasons beyond the CU count.)
-    size_t events_used = 0;
-    auto new_event = [&]() {
-        if (events_used == c->lu_events.size()) {
-            hipEvent_t e = nullptr;
-            (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-            c->lu_events.push_back(e);
-        }
-        return c->lu_events[events_used++];
-    };
+    auto new_event = [&]() { return lu_new_event(s); };
+    // solve path: the band split (LuState::aux).  Off by default: measured 75.0 / 42.6 / 21.7 ms with it against 74.4 / 42.0 / 20.8
+    // without (n = 16384 / 12288 / 8192) - the update stream is the busy one for the first 60 ms and the extra stream only takes CUs
+    // from it (profiles/r03_mldivide_timeline.txt).  RMHIP_LU_BAND=1 turns it on for A/B runs.
+    static const int band_on = std::getenv("RMHIP_LU_BAND") ? std::atoi(std::getenv("RMHIP_LU_BAND")) : 0;
+    static const long band_extra = std::getenv("RMHIP_LU_BAND_ROWS") ? std::atol(std::getenv("RMHIP_LU_BAND_ROWS")) : 320;  // rows of a top block (256) + one base panel
+    if (s.fast && band_on) {
+        if (!c->lu_aux_stream) RMHIP_HIP_CHECK(hipStreamCreateWithFlags(&c->lu_aux_stream, hipStreamNonBlocking));
+        s.aux = c->lu_aux_stream;
+    }
     // update-stream dgemm blocks ask for 84 KiB of LDS (73.7 needed): one per CU, leaving 76 KiB for a panel
     // block (66 KiB) or a main-stream dgemm block (73.7 KiB)
     size_t side_pad = 84 * 1024 - 73728;
@@ -1956,6 +2008,9 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         ~Restore() {
             if (c->lu_prep_stream) (void)hipStreamSynchronize(c->lu_prep_stream);
             if (c->lu_side_stream) (void)hipStreamSynchronize(c->lu_side_stream);
+            if (c->lu_aux_stream) (void)hipStreamSynchronize(c->lu_aux_stream);
+            s->aux = nullptr;
+            s->band_end = 0;
             c->gemm_tile_counters = nullptr;
             c->gemm_avoid_xcc = nullptr;
             c->gemm_counter_cap = 0;
@@ -2016,6 +2071,7 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         (void)hipEventRecord(e0, main_stream);
         (void)hipStreamWaitEvent(side, e0, 0);
         if (prep) (void)hipStreamWaitEvent(prep, e0, 0);
+        if (s.aux) (void)hipStreamWaitEvent(s.aux, e0, 0);
     }
     // Panel width by phase.  While the trailing matrix is large the update stream is the bottleneck and the main stream
     // idles a third of the time: wider panels there (fewer, deeper rank-k updates: the dgemm runs 53 instead of 47
@@ -2081,10 +2137,17 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         static const long late_panel_pad = std::getenv("RMHIP_LU_LATE_PANEL_PAD_KB") ? std::atol(std::getenv("RMHIP_LU_LATE_PANEL_PAD_KB")) : 0;
         s.panel_pad_kb = late_xcd ? late_panel_pad : (early ? early_panel_pad : -1);
         const size_t w = (kmin - j) < nbj ? (kmin - j) : nbj;
-        rc = getrf_rec(s, j, w);  // P_j on main
+        if (s.aux) {
+            const size_t be = j + w + (size_t)band_extra;
+            s.band_end = be < s.rows ? be : 0;  // nothing below the band: no split
+            s.aux_tail = nullptr;
+        }
+        rc = getrf_rec(s, j, w);  // P_j on main (and, below the band, on aux)
         if (rc != RMHIP_OK) break;
         hipEvent_t panel_done = new_event();
         (void)hipEventRecord(panel_done, main_stream);
+        hipEvent_t aux_done = s.aux_tail;  // aux's share of P_j (nullptr: it had none)
+        const size_t panel_band_end = s.band_end;
         const size_t next = j + w;
         size_t la_w = 0;
         if (next < kmin) {  // there is a next panel: the main stream updates its columns right away
@@ -2107,13 +2170,45 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         if (la_w) {
             if (ev_a) (void)hipStreamWaitEvent(main_stream, ev_a, 0);
             if (ev_b && next + la_w > a_end) (void)hipStreamWaitEvent(main_stream, ev_b, 0);
-            rc = update_columns(s, j, w, next, next + la_w);
-            if (rc != RMHIP_OK) break;
+            if (s.aux && panel_band_end) {
+                // Band split of the look-ahead update: the next panel's chain needs rows [next, next + la_w + band) of its columns;
+                // of those, rows beyond THIS panel's band got their multipliers on aux (one wait per look-ahead panel).  Everything below
+                // goes to aux, behind its share of P_j.
+                rc = prep_columns(s, j, w, next, next + la_w);  // interchange + U block row: top rows only
+                if (rc != RMHIP_OK) break;
+                hipEvent_t u_ready = new_event();
+                (void)hipEventRecord(u_ready, main_stream);
+                size_t be_next = next + la_w + (size_t)band_extra;
+                if (be_next > s.rows) be_next = s.rows;
+                const size_t r0 = j + w;
+                double* A12 = s.A + j + next * s.lda;
+                double* A21 = s.A + r0 + j * s.lda;
+                double* A22 = s.A + r0 + next * s.lda;
+                if (aux_done) (void)hipStreamWaitEvent(main_stream, aux_done, 0);
+                if (be_next > r0) rc = lu_dgemm(c, be_next - r0, la_w, w, -1.0, A21, s.lda, A12, s.lda, 1.0, A22, s.lda);
+                if (rc != RMHIP_OK) break;
+                if (be_next < s.rows) {
+                    (void)hipStreamWaitEvent(s.aux, u_ready, 0);
+                    if (ev_a) (void)hipStreamWaitEvent(s.aux, ev_a, 0);
+                    if (ev_b && next + la_w > a_end) (void)hipStreamWaitEvent(s.aux, ev_b, 0);
+                    {
+                        StreamScope scope(c, s.aux, c->gemm_lds_pad, c->trsm_base);
+                        rc = lu_dgemm(c, s.rows - be_next, la_w, w, -1.0, A21 + (be_next - r0), s.lda, A12, s.lda, 1.0, A22 + (be_next - r0), s.lda);
+                    }
+                    if (rc != RMHIP_OK) break;
+                    s.aux_tail = new_event();
+                    (void)hipEventRecord(s.aux_tail, s.aux);
+                }
+            } else {
+                rc = update_columns(s, j, w, next, next + la_w);
+                if (rc != RMHIP_OK) break;
+            }
         }
         if (split) {
             c->gemm_tile_counters = next_late ? late_counters : nullptr;  // persistent, XCD-avoiding kernels if the next panel sits on one XCD
             hipEvent_t ra = new_event(), rb = new_event();
             (void)hipStreamWaitEvent(prep, panel_done, 0);
+            if (aux_done) (void)hipStreamWaitEvent(side, aux_done, 0);  // the Schur update reads every row of L(P_j)
             {
                 StreamScope scope(c, prep, 0, prep_base);  // unpadded small blocks: they run beside the update stream's dgemm
                 if (ev_a) (void)hipStreamWaitEvent(prep, ev_a, 0);
@@ -2136,6 +2231,7 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
             a_end = csplit;
         } else {
             (void)hipStreamWaitEvent(side, panel_done, 0);
+            if (aux_done) (void)hipStreamWaitEvent(side, aux_done, 0);
             StreamScope scope(c, side, early ? early_side_pad : side_pad);
             // S_j overlaps panel j+1: persistent, XCD-avoiding dgemm if that panel sits on one XCD
             c->gemm_tile_counters = (next_late || (late_xcd_on == 2 && late_counters)) ? late_counters : nullptr;
@@ -2161,6 +2257,7 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     if (ev_b) (void)hipStreamWaitEvent(main_stream, ev_b, 0);
     if (prep) (void)hipStreamSynchronize(prep);
     (void)hipStreamSynchronize(side);
+    if (s.aux) (void)hipStreamSynchronize(s.aux);
     (void)hipStreamSynchronize(main_stream);
     return rc;
 }
@@ -2192,7 +2289,7 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     const size_t off_xb = off_xa + sizeof(unsigned long long) * 2 * PK_MAXB;
     const size_t off_xctl = off_xb + sizeof(unsigned long long) * 2 * PK_MAXB;
     const size_t off_ucomp = off_xctl + 64 + 16 * sizeof(unsigned long long);
-    const size_t total = off_ucomp + sizeof(double) * BASE_W * BASE_W;
+    const size_t total = off_ucomp + sizeof(double) * BASE_W * BASE_W * kUcompSlots;
     std::shared_ptr<Allocation> blk_mem;  // pooled: a hipMalloc / hipFree pair costs two device synchronisations per factorisation
     RMHIP_TRY(c->alloc_device(total / sizeof(double) + 2, &blk_mem));
     char* blk = (char*)blk_mem->ptr;

@@ -392,6 +392,7 @@ int rmhip_shutdown(rmhip_ctx* ctx) {
         if (e) (void)hipEventDestroy(e);
     if (c->lu_side_stream) (void)hipStreamDestroy(c->lu_side_stream);
     if (c->lu_prep_stream) (void)hipStreamDestroy(c->lu_prep_stream);
+    if (c->lu_aux_stream) (void)hipStreamDestroy(c->lu_aux_stream);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);

@@ -147,7 +147,7 @@ def test_singular_and_nan_inputs_still_end_in_the_reference_errors(prov):
     CPU's caller expects (SINGULAR -> its SVD path)."""
     from runmat_amd import ProviderError
 
-    n = 600
+    n = 1500  # beyond the Jacobi-SVD path's 1024 columns (up to there the device answers itself: tests/test_gpu_svdpath.py)
     rng = np.random.default_rng(3)
     A = rng.uniform(-1, 1, (n, n))
     A[:, 17] = A[:, 3]  # two equal columns: exactly singular
