@@ -14,12 +14,23 @@
 // the half-width, so the top levels (where the flops are) see K in the thousands.
 // Triangular solves recurse the same way down to a 32x32 substitution kernel.
 #include <cstring>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
 #include "common.h"
 
 namespace rmhip {
+
+// Wave priority of the panel chain's kernels (s_setprio): they share CUs with the update stream's dgemm blocks, and every
+// instruction they wait to issue is on the critical path.  Set once per process (lu_factor_device); RMHIP_LU_CHAIN_PRIO=0 turns it
+// off.  Measured at n = 16384: 74.0-74.1 ms with, 74.6-75.2 without; with the panel block sharing its CU (no LDS padding) 75.1
+// against 77.4 - the priority recovers most of what sharing costs, a CU of its own is still better.
+__device__ int d_chain_prio = 0;
+__device__ __forceinline__ void chain_prio() {
+    if (d_chain_prio) __builtin_amdgcn_s_setprio(3);
+}
+
 
 static constexpr double LU_EPS = 1.0e-12;  // host_lu.rs:3
 static constexpr int BASE_W = 64;          // base panel width (columns factored one launch each)
@@ -996,6 +1007,7 @@ __global__ void __launch_bounds__(RT_ROWS) k_rp_top(const RtArgs g, pk_u64* dbg)
     L.pw = s_pw;
     L.pt = s_pt;
     const int t = threadIdx.x;
+    chain_prio();
     RtTicks ticks;
     if (DBG) {
         for (int i = 0; i < 12; ++i) ticks.acc[i] = 0;
@@ -1102,6 +1114,7 @@ __global__ void __launch_bounds__(RB_THREADS) k_rp_below(double* __restrict__ A,
                                                          pk_u64* __restrict__ growth, const double /*tau: the host compares*/, pk_u64* dbg) {
     __shared__ __attribute__((aligned(16))) double U[BASE_W * BASE_W + BASE_W];  // U[k * BASE_W + c] = U11[k][c], 1 / u_kk on the diagonal (+ slack for dead slots)
     const int t = threadIdx.x;
+    chain_prio();
     RtTicks ticks;
     if (DBG) {
         for (int i = 0; i < 12; ++i) ticks.acc[i] = 0;
@@ -1218,6 +1231,7 @@ __global__ void __launch_bounds__(2 * PLIST) k_laswp_lists(double* __restrict__ 
     const int i = threadIdx.x & (PLIST - 1);
     const int half = threadIdx.x / PLIST;  // 0 or 1
     unsigned group = blockIdx.x;
+    if (!counter) chain_prio();
     if (counter) {
         if (avoid_xcc && gridDim.x >= 16) {  // (a smaller grid may sit on that XCD entirely)
             // one read per workgroup (the panel kernel may be writing it right now: see k_dgemm_w8p)
@@ -1283,6 +1297,7 @@ __global__ void __launch_bounds__(TRSM_THREADS) k_trsm_fused(const double* __res
                                                              double* __restrict__ B, size_t ldb, size_t ncols, unsigned* counter,
                                                              const int* avoid_xcc) {
     extern __shared__ double Ts[];  // [w][sw]
+    if (!counter) chain_prio();
     // counter != nullptr (update stream of the LU's late phase, see k_dgemm_w8p): column groups are handed out by a counter, wave
     // by wave, and workgroups on XCD *avoid_xcc leave before they stage anything
     if (counter && avoid_xcc && gridDim.x >= 16) {
@@ -1461,6 +1476,7 @@ __global__ void __launch_bounds__(TRSM_THREADS) k_trsm_lower_2p(const double* __
                                                                 size_t ldb, size_t ncols) {
     extern __shared__ double Ts[];  // [64][sw]
     constexpr int sw = TRSM_W + 1;
+    chain_prio();
     const int i = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * TRSM_THREADS + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * TRSM_THREADS) >> 6;
@@ -2273,6 +2289,13 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     const size_t kmin = rows < cols ? rows : cols;
     if (rows > 0x7fffffffULL || cols > 0x7fffffffULL) return fail(RMHIP_ERR_UNSUPPORTED, "lu: dimension exceeds 2^31");
     c->lu_used_one_xcd = false;
+    {
+        static std::once_flag prio_once;  // (one device per process: rmhip_init binds the context to its device)
+        std::call_once(prio_once, [] {
+            const int p = std::getenv("RMHIP_LU_CHAIN_PRIO") ? std::atoi(std::getenv("RMHIP_LU_CHAIN_PRIO")) : 1;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(d_chain_prio), &p, sizeof(int));
+        });
+    }
     // one device block: ipiv[rows] | info | pos_of | row_at | prow | panel lists | cand_abs[2*MAXB] | cand_pos | cand_row
     const size_t n_int = rows + 4;
     const size_t isz = (rows * sizeof(int) + 15) & ~(size_t)15;
