@@ -698,6 +698,58 @@ def test_rng_normal_stream(prov, oracle, n):
     assert prov.get_rng_state() == oracle.rng_mix_seed(12345)
 
 
+def _normals_80bit(oracle, state, n):
+    """Box-Muller on the oracle's (bit-exact) uniform stream in 80-bit arithmetic, the angle reduced exactly."""
+    L = np.longdouble
+    u, _ = oracle.rng_uniform(state, n + (n & 1))
+    u1, u2 = u[0::2].astype(L), u[1::2].astype(L)
+    u1 = np.where(u1 <= 0, L(2.2250738585072014e-308), u1)
+    r = np.sqrt(L(-2) * np.log(u1))
+    t = 2 * u2
+    q = np.rint(2 * t)
+    x = (t - q / 2) * L("3.14159265358979323846264338327950288")
+    s0, c0 = np.sin(x), np.cos(x)
+    k = q.astype(np.int64) % 4
+    z = np.empty(2 * len(r), dtype=L)
+    z[0::2] = r * np.choose(k, [c0, -s0, -c0, s0])
+    z[1::2] = r * np.choose(k, [s0, c0, -s0, -c0])
+    return z[:n], np.repeat(r, 2)[:n]
+
+
+def test_rng_normal_accuracy_vs_80bit_reference(prov, oracle):
+    """The device's table-based log / rsq / sincos (rng.hip) against exact arithmetic on the same uniforms: every sample within
+    6e-16 of its radius - tighter than the CPU's own libm chain manages (7e-16 here), so the 8e-14 stream tolerance above is
+    all libm's."""
+    n = 400000
+    for seed in (oracle.rng_default_seed(), 0x9E3779B97F4A7C15):
+        prov.set_rng_state(seed)
+        got = prov.download(prov.random_normal((n, 1))).ravel()
+        ref, radius = _normals_80bit(oracle, seed, n)
+        err = np.abs(got.astype(np.longdouble) - ref)
+        assert float((err / radius).max()) <= 6e-16
+
+
+def test_rng_normal_edge_uniforms(prov, oracle):
+    """States chosen so that the first pair draws the extreme uniforms: u1 = 0 (replaced by f64::MIN_POSITIVE, random.rs:281-283),
+    u1 = 2^-53, u1 = 1 - 2^-53 (radius 1.5e-8: the logarithm must keep its RELATIVE accuracy there), u1 at the table's split
+    and cell edges, u2 = 0 and u2 = 1 - 2^-53."""
+    a, mask = 6364136223846793005, (1 << 64) - 1
+    ainv = pow(a, -1, 1 << 64)
+    before = lambda x: ((x - 1) * ainv) & mask  # noqa: E731  the state whose successor is x
+    firsts = [0, 5, 1 << 11, ((1 << 53) - 1) << 11, (1 << 63), (1 << 63) | (1 << 62), ((1 << 52) | (54 << 45)) << 11,
+              (((1 << 52) | (54 << 45)) << 11) - (1 << 11), ((1 << 52) | (1 << 44)) << 11, (((1 << 52) | (1 << 44)) << 11) - (1 << 11)]
+    seconds = [0, 7, ((1 << 53) - 1) << 11, 1 << 63, (1 << 62), (1 << 62) - (1 << 11), ((1 << 44) - 1) << 11, (1 << 44) << 11]
+    states = [before(x1) for x1 in firsts] + [before(before(x2)) for x2 in seconds]
+    for st in states:
+        prov.set_rng_state(st)
+        got = prov.download(prov.random_normal((2, 1))).ravel()
+        want, st2 = oracle.rng_normal(st, 2)
+        assert prov.get_rng_state() == st2
+        assert np.max(np.abs(got - want)) <= 8e-14
+        ref, radius = _normals_80bit(oracle, st, 2)
+        assert float(np.max(np.abs(got.astype(np.longdouble) - ref) / radius)) <= 6e-16
+
+
 def test_rng_moments(prov):
     # crates/runmat-runtime/tests/rng.rs:19-63
     prov.rng_seed(0)
