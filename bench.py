@@ -143,14 +143,20 @@ def cpu_baseline_mldivide():
 PMC_TRAFFIC_SOURCE = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured in this run)"
 
 
-def pmc_traffic(kernel_key: str):
-    """HBM bytes per launch measured with rocprofv3 --pmc (committed under profiles/), or None."""
+def pmc_traffic(workload: str, kernel: str = None):
+    """HBM-side bytes measured with rocprofv3 --pmc (committed under profiles/, scripts/profile_r03.sh): per launch of `kernel`
+    (prefix match) in the run of `workload`, or - kernel None - per bench step of that workload (all its kernels).  None when the
+    file or the entry is missing."""
     f = ROOT / "profiles" / "pmc_traffic.json"
-    if f.exists():
-        try:
-            return json.loads(f.read_text()).get(kernel_key)
-        except Exception:
-            return None
+    try:
+        t = json.loads(f.read_text()).get(workload) or {}
+    except Exception:
+        return None
+    if kernel is None:
+        return t.get("_bytes_per_step")
+    for k, v in t.items():
+        if k.startswith(kernel):
+            return v
     return None
 
 
@@ -305,7 +311,7 @@ def main() -> None:
             "config": {"workload": "fused D=sin(A).*B+C 8192x8192 f64 via rmhip_fused_elementwise (WGSL request)",
                        "bytes_per_step_per_gpu": fused_bytes, "parallelism": f"independent x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("rm_ew_fast"), "traffic_source": PMC_TRAFFIC_SOURCE,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("fused", "rm_ew_fast"), "traffic_source": PMC_TRAFFIC_SOURCE,
                          "kernel": "rm_ew_fast (hipRTC, generated)", "kernel_ms": round(kern_ms, 5)},
         }
 
@@ -322,7 +328,7 @@ def main() -> None:
                        "parallelism": f"row-block x{world}, B replicated, no collective"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TF,
                          "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TF, 4),
-                         "traffic": pmc_traffic("k_dgemm"), "traffic_source": PMC_TRAFFIC_SOURCE, "kernel": "k_dgemm_w8<false> (eight waves, pipelined k loop; v_mfma_f64_16x16x4_f64)",
+                         "traffic": pmc_traffic("dgemm", "k_dgemm_w8"), "traffic_source": PMC_TRAFFIC_SOURCE, "kernel": "k_dgemm_w8<false> (eight waves, pipelined k loop; v_mfma_f64_16x16x4_f64)",
                          "kernel_ms": round(kern_ms, 5)},
         }
 
@@ -352,7 +358,8 @@ def main() -> None:
                        "algorithmic_bytes": bytes_total, "parallelism": f"sample ranges x{world}, ordered 1-value exchange"},
             "roofline": {"bound": "hbm", "achieved": round(bytes_total / world / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(bytes_total / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": None, "kernel": "k_rng_normal + rm_ew_fast + rm_red_contig (whole step, wall clock)"},
+                         "traffic": pmc_traffic("mc"), "traffic_source": PMC_TRAFFIC_SOURCE + " - per step, all kernels",
+                         "kernel": "k_rng_normal + rm_ew_fast + rm_red_contig (whole step, wall clock)"},
         }
 
     def mc_evolved_record(steps, warmup):
@@ -382,7 +389,8 @@ def main() -> None:
                        "price": price, "algorithmic_bytes": 32 * M,
                        "parallelism": f"sample ranges x{world}, ordered 1-value exchange"},
             "roofline": {"bound": "hbm", "achieved": round(32 * M / world / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(32 * M / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(32 * M / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic("mc_evolved"), "traffic_source": PMC_TRAFFIC_SOURCE + " - per step, all kernels",
                          "kernel": "k_stochastic_evolution (32 B per path for the whole loop: fp64 VALU bound, "
                                    "the HBM fraction is reported for completeness)"},
         }
@@ -414,7 +422,8 @@ def main() -> None:
             "config": {"workload": "benchmarks/4k-image-processing f64, image_normalize(gain, bias, clamp, gamma = 1.8)",
                        "bytes_per_step_per_gpu": nbytes, "parallelism": f"frames x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic("image"), "traffic_source": PMC_TRAFFIC_SOURCE + " - per step, all kernels",
                          "kernel": "k_plane_moments (one-pass mean / M2, fixed-order Chan merge), k_plane_moments_final, k_imgnorm_apply "
                                    "(24 B per element; round 1 moved 32 with a two-pass variance)"},
         }
@@ -499,7 +508,8 @@ def main() -> None:
                        "max_abs_err_vs_ones": err,
                        "parallelism": form["name"]},
             "roofline": {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 3), "peak": FP64_MFMA_PEAK_TF,
-                         "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF, 4),
+                         "traffic": pmc_traffic("mldivide"), "traffic_source": PMC_TRAFFIC_SOURCE + " - per solve, all kernels (fabric side: Infinity-Cache hits included)",
                          "kernel": "k_rp_top / k_rp_below panels + k_dgemm_w8 trailing updates (whole solve, wall clock)"},
         }
 
@@ -537,7 +547,8 @@ def main() -> None:
             "config": {"workload": "benchmarks/elementwise-math chain, 1024x1024 f64, one fused kernel",
                        "bytes_per_step_per_gpu": nbytes, "parallelism": f"independent x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic("chain", "rm_ew_fast"), "traffic_source": PMC_TRAFFIC_SOURCE,
                          "kernel": "rm_ew_fast (16.8 MB per launch: launch-latency bound, not a roofline case)"},
         }
 
@@ -578,7 +589,7 @@ def main() -> None:
                        "bytes_per_step_per_gpu": nbytes, "elements_per_s": round(world * n * n / (ms * 1e-3), 1),
                        "parallelism": f"independent x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("rm_ew_fast_f32"), "traffic_source": PMC_TRAFFIC_SOURCE,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("fused_f32", "rm_ew_fast"), "traffic_source": PMC_TRAFFIC_SOURCE,
                          "kernel": "rm_ew_fast (f32 variant: 16-byte vectors of four, body in f64)", "kernel_ms": round(kern_ms, 5)},
         }
 
@@ -616,7 +627,8 @@ def main() -> None:
             "config": {"workload": "C=A*B 8192x8192x8192 f32 storage via rmhip_matmul", "flops_per_step": dgemm_flops,
                        "parallelism": f"row-block x{world}, B replicated, no collective"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": round(achieved / 157.3, 4), "traffic": None,
+                         "frac": round(achieved / 157.3, 4),
+                         "traffic": pmc_traffic("sgemm", "k_sgemm_w8"), "traffic_source": PMC_TRAFFIC_SOURCE,
                          "kernel": "k_sgemm_w8 (eight waves, pipelined k loop; v_mfma_f32_16x16x4_f32)", "kernel_ms": round(kern_ms, 5)},
         }
 

@@ -1,0 +1,22 @@
+"""Developer tool (this container): copy what scripts/profile_r03.sh left under gpurun_out/prof_<tag>/ into profiles/ under the round's
+names - per workload the `--kernel-trace --stats` kernel summary and the bench line printed under the profiler, the counter summary
+and the traffic table bench.py reads.  Usage: collect_profiles.py <tag>   (e.g. r03)"""
+import glob, shutil, sys
+from pathlib import Path
+
+tag = sys.argv[1]
+root = Path(__file__).resolve().parent.parent
+src, dst = root / "gpurun_out" / f"prof_{tag}", root / "profiles"
+n = 0
+for d in sorted(src.glob("trace_*")):
+    if not d.is_dir():
+        continue
+    w = d.name[len("trace_"):]
+    for f in glob.glob(str(d / "**" / "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, dst / f"{tag}_{w}_kernel_stats.csv"); n += 1
+    b = src / f"trace_{w}_bench.json"
+    if b.exists() and b.stat().st_size:
+        shutil.copy(b, dst / f"{tag}_{w}_bench_under_rocprof.json"); n += 1
+shutil.copy(src / "pmc_summary.json", dst / f"{tag}_pmc_summary.json")
+shutil.copy(src / "pmc_traffic.json", dst / "pmc_traffic.json")
+print(f"copied {n + 2} files into {dst}")

@@ -8,6 +8,7 @@ out = sys.argv[1]
 workloads = sys.argv[2:]
 LEGS = {"fused": 2, "dgemm": 2, "sgemm": 2, "fused_f32": 2}  # workloads whose record runs its steps twice (wall-clock leg + HIP-event leg)
 SETUP = ("k_fill", "k_probe_xcc", "__amd_rocclr", "k_narrow", "k_widen")  # not part of a step
+SETUP_BY_WORKLOAD = {"mldivide": ("k_fill", "k_probe_xcc", "__amd_rocclr_fillBuffer", "__amd_rocclr_copyBuffer(", "__amd_rocclr_copyBufferAligned")}  # the rect copy of A into the padded workspace IS part of a solve
 
 
 def counters(tag, name):
@@ -49,7 +50,7 @@ for w in workloads:
                "write_kib_mean": sum(wv) / len(wv) if wv else None, "bytes_per_launch": round(bytes_per), "avg_us": round(avg_us, 2),
                "tb_per_s": round(bytes_per / avg_us / 1e6, 3) if avg_us == avg_us and avg_us > 0 else None}
         summary.append(rec)
-        if not any(k.startswith(s) or s in k[:40] for s in SETUP):
+        if not any(k.startswith(s) or s in k[:40] for s in SETUP_BY_WORKLOAD.get(w, SETUP)):
             total += bytes_per * n
         short = k.split("(")[0].replace("void rmhip::", "").replace("rmhip::", "")
         traffic.setdefault(w, {})[short[:80]] = round(bytes_per)
@@ -68,6 +69,13 @@ for w in workloads:
                 rec[cn + "_mean"] = sum(v) / len(v)
             summary.append(rec)
 json.dump(summary, open(f"{out}/pmc_summary.json", "w"), indent=1)
+traffic = {"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (plus a --kernel-trace --stats pass for the durations) over "
+                      "`bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-also --workload <w>` (mldivide: --steps 2 --warmup 1; reductions: scripts/red_driver.py) - "
+                      "scripts/profile_r03.sh.  bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024: both counters are in KiB and on gfx950 FETCH_SIZE reports half of a wide "
+                      "(16 B/lane) coalesced streaming read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE calibrates exactly (524288 KiB = a 512 MiB output).  For the GEMMs the "
+                      "fetch figure is memory-side (fabric) traffic including Infinity-Cache hits, not DRAM bytes.  `_bytes_per_step` = all kernels of the run except set-up "
+                      "(fills, uploads, narrowing) divided by the steps executed.", **traffic}
 json.dump(traffic, open(f"{out}/pmc_traffic.json", "w"), indent=1)
 for w, t in traffic.items():
-    print(w, json.dumps(t)[:600])
+    if not w.startswith("_"):
+        print(w, json.dumps(t)[:600])

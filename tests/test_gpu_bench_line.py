@@ -35,7 +35,9 @@ def _run_bench(extra_args, extra_env, nproc=2, timeout=900):
 def _check_roofline(rf):
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s")
     assert rf["achieved"] > 0 and rf["peak"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 2e-3
-    assert "traffic" in rf and "kernel" in rf
+    assert "kernel" in rf
+    # every roofline that names a kernel carries the counter-measured bytes (profiles/pmc_traffic.json): never null
+    assert isinstance(rf["traffic"], int) and rf["traffic"] > 0 and "pmc_traffic.json" in rf["traffic_source"]
 
 
 def test_two_rank_line_has_every_config_and_a_communicator():
