@@ -367,128 +367,180 @@ __device__ __forceinline__ double scan_in(double v, int omit) { return (omit && 
 __device__ __forceinline__ double scan_out(double v) { return v != v ? r2_nan() : v; }
 
 // pre > 1 (or short lines): one thread per line, the CPU's own sequence of operations - bit-identical results.  Threads run along
-// `pre`, so every step is a coalesced read and write.
-template <bool PROD>
-__global__ void __launch_bounds__(R2_BLOCK) k_scan_lines(const double* __restrict__ x, double* __restrict__ y, u64 pre, u64 len, u64 post, int reverse,
-                                                         int omit) {
-    const u64 line = (u64)blockIdx.x * R2_BLOCK + threadIdx.x;
+// `pre`, so every step is a coalesced read and write.  The chain itself is cheap (one dependent operation per element); what the
+// kernel waits for is memory, so a thread keeps two batches of U loads in flight - the next batch is requested before the current
+// one is consumed - and few lines are spread over many small blocks (BLOCK = 64: 8192 lines reach 128 CUs instead of 32).
+template <bool PROD, int BLOCK, int U>
+__global__ void __launch_bounds__(BLOCK) k_scan_lines(const double* __restrict__ x, double* __restrict__ y, u64 pre, u64 len, u64 post, int reverse,
+                                                      int omit) {
+    const u64 line = (u64)blockIdx.x * BLOCK + threadIdx.x;
     if (line >= pre * post) return;
     const u64 i = line % pre, j = line / pre;
     const u64 base = i + pre * len * j;
+    auto at = [&](u64 k) { return base + pre * (reverse ? len - 1 - k : k); };
     double run = PROD ? 1.0 : 0.0;
-    for (u64 k0 = 0; k0 < len; k0 += 8) {
-        double v[8];
+    double cur[U], nxt[U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const u64 k = k0 + u;
-            if (k < len) v[u] = x[base + pre * (reverse ? len - 1 - k : k)];
+    for (int u = 0; u < U; ++u) cur[u] = (u64)u < len ? __builtin_nontemporal_load(x + at(u)) : 0.0;
+    for (u64 k0 = 0; k0 < len; k0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const u64 k = k0 + U + u;
+            nxt[u] = k < len ? __builtin_nontemporal_load(x + at(k)) : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < U; ++u) {
             const u64 k = k0 + u;
             if (k < len) {
-                run = scan_op<PROD>(run, scan_in<PROD>(v[u], omit));
-                y[base + pre * (reverse ? len - 1 - k : k)] = scan_out(run);
+                run = scan_op<PROD>(run, scan_in<PROD>(cur[u], omit));
+                __builtin_nontemporal_store(scan_out(run), y + at(k));
             }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
     }
 }
 
 // pre == 1, long lines: three passes over chunks of SCAN_CHUNK elements - chunk totals, a serial scan of the totals per line,
-// then every chunk scans itself from its carry.  Inside a chunk a block scans tiles of 256 x 8 elements (serial per thread,
-// Hillis-Steele over the thread totals).  The grouping differs from the CPU's left-to-right sequence: results agree to
-// rounding (exactly, for integer-valued data below 2^53).
+// then every chunk scans itself from its carry (a line of one chunk skips the first two).  Inside a chunk a block scans tiles of
+// 256 x 8 elements: the tile is read COALESCED (lane l of a load takes element l + 256 u), turned through LDS so that a thread
+// owns eight consecutive elements, scanned serially in the thread, the thread totals scanned by shuffles inside a wave and through
+// LDS across the four waves, and written back the same way.  (First version: every thread loaded its own eight consecutive
+// elements - 64-byte strides between lanes; the counters showed 1.4-1.5x the algorithmic bytes, profiles/r03_pmc_summary.json.)
+// The grouping differs from the CPU's left-to-right sequence: results agree to rounding (exactly, for integer-valued data below
+// 2^53).
 static constexpr int SCAN_PER_THREAD = 8;
 static constexpr int SCAN_TILE = R2_BLOCK * SCAN_PER_THREAD;
-static constexpr u64 SCAN_CHUNK = 32 * SCAN_TILE;  // 65536 elements
+static constexpr u64 SCAN_CHUNK = 8 * SCAN_TILE;  // 16384 elements: a 6.7e7-element vector gives 4096 blocks (with 32 tiles per block, 1024 blocks, that vector took 508 us against 332)
+static constexpr int SCAN_LDS = SCAN_TILE + SCAN_TILE / 8;  // one pad per eight: the transposed accesses spread over the banks
+__device__ __forceinline__ int scan_pad(int i) { return i + (i >> 3); }
+static_assert(R2_BLOCK == 256, "the scan kernels assume four waves per block");
 
+// exclusive prefix of the threads' totals in thread order, and the block total
 template <bool PROD>
-__device__ __forceinline__ double block_exclusive(double total, double* lds, double* block_total) {
-    const int t = threadIdx.x;
-    lds[t] = total;
-    __syncthreads();
-    for (int off = 1; off < R2_BLOCK; off <<= 1) {
-        double v = lds[t];
-        if (t >= off) v = scan_op<PROD>(lds[t - off], v);
-        __syncthreads();
-        lds[t] = v;
-        __syncthreads();
+__device__ __forceinline__ double block_exclusive(double total, double* wsum /*[4]*/, double* block_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double incl = total;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double n = __shfl_up(incl, off, 64);
+        if (lane >= off) incl = scan_op<PROD>(n, incl);
     }
-    const double incl = lds[t];
-    *block_total = lds[R2_BLOCK - 1];
-    double excl = PROD ? 1.0 : 0.0;
-    if (t > 0) excl = lds[t - 1];
+    double prev = __shfl_up(incl, 1, 64);
+    if (lane == 0) prev = PROD ? 1.0 : 0.0;
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    (void)incl;
-    return excl;
+    double lead = PROD ? 1.0 : 0.0, all = PROD ? 1.0 : 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const double s = wsum[w];
+        if (w < wave) lead = scan_op<PROD>(lead, s);
+        all = scan_op<PROD>(all, s);
+    }
+    __syncthreads();  // wsum is reused by the next tile
+    *block_total = all;
+    return scan_op<PROD>(lead, prev);
 }
 
+// the tile's elements (identity beyond `e`), coalesced, into v[] = the thread's eight consecutive ones
+template <bool PROD>
+__device__ __forceinline__ void scan_tile_in(const double* __restrict__ xs, u64 len, u64 tile, u64 e, int reverse, int omit, double* tl,
+                                             double (&v)[SCAN_PER_THREAD]) {
+    const int t = threadIdx.x;
+    double in[SCAN_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < SCAN_PER_THREAD; ++u) {
+        const u64 k = tile + (u64)(t + R2_BLOCK * u);
+        in[u] = PROD ? 1.0 : 0.0;
+        if (k < e) in[u] = scan_in<PROD>(__builtin_nontemporal_load(xs + (reverse ? len - 1 - k : k)), omit);
+    }
+#pragma unroll
+    for (int u = 0; u < SCAN_PER_THREAD; ++u) tl[scan_pad(t + R2_BLOCK * u)] = in[u];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SCAN_PER_THREAD; ++u) v[u] = tl[scan_pad(t * SCAN_PER_THREAD + u)];
+}
+
+// pass 1: the chunk's total.  Any grouping will do - the carries only have to be right to rounding - so this is a plain streaming
+// reduction: eight independent accumulators per thread over coalesced loads, folded in a fixed order (deterministic).
 template <bool PROD>
 __global__ void __launch_bounds__(R2_BLOCK) k_scan_chunk_totals(const double* __restrict__ x, u64 len, u64 nchunks, int reverse, int omit,
                                                                 double* __restrict__ totals) {
-    __shared__ double lds[R2_BLOCK];
+    __shared__ double wsum[4];
     const u64 chunk = blockIdx.x, line = blockIdx.y;
     const u64 b = chunk * SCAN_CHUNK;
     u64 e = b + SCAN_CHUNK;
     if (e > len) e = len;
     const double* xs = x + line * len;
-    double acc = PROD ? 1.0 : 0.0;
-    // the same grouping as pass 3 (thread t owns runs of eight consecutive elements of every tile), so that carry + local scan
-    // reproduces the totals
+    double acc[SCAN_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < SCAN_PER_THREAD; ++u) acc[u] = PROD ? 1.0 : 0.0;
     for (u64 tile = b; tile < e; tile += SCAN_TILE) {
-        double tot = PROD ? 1.0 : 0.0;
 #pragma unroll
         for (int u = 0; u < SCAN_PER_THREAD; ++u) {
-            const u64 k = tile + (u64)threadIdx.x * SCAN_PER_THREAD + u;
-            if (k < e) tot = scan_op<PROD>(tot, scan_in<PROD>(xs[reverse ? len - 1 - k : k], omit));
+            const u64 k = tile + (u64)(threadIdx.x + R2_BLOCK * u);
+            if (k < e) acc[u] = scan_op<PROD>(acc[u], scan_in<PROD>(__builtin_nontemporal_load(xs + (reverse ? len - 1 - k : k)), omit));
         }
-        double bt;
-        (void)block_exclusive<PROD>(tot, lds, &bt);
-        acc = scan_op<PROD>(acc, bt);
     }
-    if (threadIdx.x == 0) totals[line * nchunks + chunk] = acc;
+    double tot = acc[0];
+#pragma unroll
+    for (int u = 1; u < SCAN_PER_THREAD; ++u) tot = scan_op<PROD>(tot, acc[u]);
+    double bt;
+    (void)block_exclusive<PROD>(tot, wsum, &bt);
+    if (threadIdx.x == 0) totals[line * nchunks + chunk] = bt;
 }
+// pass 2: totals[c] <- carry into chunk c.  One block per line, 256 totals per trip, the same shuffle scan as inside a tile.  (First
+// version: one THREAD per line walking its chunks - a 6.7e7-element vector has 1024 of them and the walk, a dependent global
+// round trip per chunk, took longer than both streaming passes together.)
 template <bool PROD>
 __global__ void __launch_bounds__(R2_BLOCK) k_scan_carries(double* __restrict__ totals, u64 nchunks, u64 nlines) {
-    const u64 line = (u64)blockIdx.x * R2_BLOCK + threadIdx.x;
-    if (line >= nlines) return;
-    double run = PROD ? 1.0 : 0.0;
-    for (u64 c = 0; c < nchunks; ++c) {  // totals[c] <- carry into chunk c
-        const double t = totals[line * nchunks + c];
-        totals[line * nchunks + c] = run;
-        run = scan_op<PROD>(run, t);
+    __shared__ double wsum[4];
+    double* tl = totals + (u64)blockIdx.x * nchunks;
+    double carry = PROD ? 1.0 : 0.0;
+    for (u64 c0 = 0; c0 < nchunks; c0 += R2_BLOCK) {
+        const u64 c = c0 + threadIdx.x;
+        const double v = c < nchunks ? tl[c] : (PROD ? 1.0 : 0.0);
+        double bt;
+        const double excl = block_exclusive<PROD>(v, wsum, &bt);
+        if (c < nchunks) tl[c] = scan_op<PROD>(carry, excl);
+        carry = scan_op<PROD>(carry, bt);
     }
 }
+// carries == nullptr: one chunk per line, nothing carried in
 template <bool PROD>
 __global__ void __launch_bounds__(R2_BLOCK) k_scan_chunks(const double* __restrict__ x, double* __restrict__ y, u64 len, u64 nchunks, int reverse,
                                                           int omit, const double* __restrict__ carries) {
-    __shared__ double lds[R2_BLOCK];
+    __shared__ double tl[SCAN_LDS];
+    __shared__ double wsum[4];
+    const int t = threadIdx.x;
     const u64 chunk = blockIdx.x, line = blockIdx.y;
     const u64 b = chunk * SCAN_CHUNK;
     u64 e = b + SCAN_CHUNK;
     if (e > len) e = len;
     const double* xs = x + line * len;
     double* ys = y + line * len;
-    double carry = carries[line * nchunks + chunk];
+    double carry = carries ? carries[line * nchunks + chunk] : (PROD ? 1.0 : 0.0);
     for (u64 tile = b; tile < e; tile += SCAN_TILE) {
         double v[SCAN_PER_THREAD];
+        scan_tile_in<PROD>(xs, len, tile, e, reverse, omit, tl, v);
         double tot = PROD ? 1.0 : 0.0;
 #pragma unroll
         for (int u = 0; u < SCAN_PER_THREAD; ++u) {
-            const u64 k = tile + (u64)threadIdx.x * SCAN_PER_THREAD + u;
-            v[u] = PROD ? 1.0 : 0.0;
-            if (k < e) v[u] = scan_in<PROD>(xs[reverse ? len - 1 - k : k], omit);
             tot = scan_op<PROD>(tot, v[u]);
             v[u] = tot;  // inclusive within the thread
         }
         double bt;
-        const double excl = block_exclusive<PROD>(tot, lds, &bt);
+        const double excl = block_exclusive<PROD>(tot, wsum, &bt);  // (barriers: every thread has read its eight by now)
         const double lead = scan_op<PROD>(carry, excl);
 #pragma unroll
+        for (int u = 0; u < SCAN_PER_THREAD; ++u) tl[scan_pad(t * SCAN_PER_THREAD + u)] = scan_out(scan_op<PROD>(lead, v[u]));
+        __syncthreads();
+#pragma unroll
         for (int u = 0; u < SCAN_PER_THREAD; ++u) {
-            const u64 k = tile + (u64)threadIdx.x * SCAN_PER_THREAD + u;
-            if (k < e) ys[reverse ? len - 1 - k : k] = scan_out(scan_op<PROD>(lead, v[u]));
+            const u64 k = tile + (u64)(t + R2_BLOCK * u);
+            if (k < e) __builtin_nontemporal_store(tl[scan_pad(t + R2_BLOCK * u)], ys + (reverse ? len - 1 - k : k));
         }
+        __syncthreads();  // the next tile overwrites tl
         carry = scan_op<PROD>(carry, bt);
     }
 }
@@ -498,9 +550,15 @@ int launch_cumulative(Context* c, int prod, int reverse, int omit, const double*
     const size_t lines = pre * post;
     // thread-per-line whenever the lines run along a strided dimension, or there are enough short contiguous lines to fill the chip
     if (pre > 1 || (len <= 4096 && lines >= (size_t)c->num_cus * 64)) {
-        const unsigned grid = (unsigned)ceil_div_u64(lines, R2_BLOCK);
-        if (prod) hipLaunchKernelGGL(k_scan_lines<true>, dim3(grid), dim3(R2_BLOCK), 0, c->stream, x, y, (u64)pre, (u64)len, (u64)post, reverse, omit);
-        else hipLaunchKernelGGL(k_scan_lines<false>, dim3(grid), dim3(R2_BLOCK), 0, c->stream, x, y, (u64)pre, (u64)len, (u64)post, reverse, omit);
+        if (lines >= (size_t)c->num_cus * 1024) {  // plenty of lines: four waves per block, eight loads deep
+            const unsigned grid = (unsigned)ceil_div_u64(lines, 256);
+            if (prod) hipLaunchKernelGGL((k_scan_lines<true, 256, 8>), dim3(grid), dim3(256), 0, c->stream, x, y, (u64)pre, (u64)len, (u64)post, reverse, omit);
+            else hipLaunchKernelGGL((k_scan_lines<false, 256, 8>), dim3(grid), dim3(256), 0, c->stream, x, y, (u64)pre, (u64)len, (u64)post, reverse, omit);
+        } else {
+            const unsigned grid = (unsigned)ceil_div_u64(lines, 64);
+            if (prod) hipLaunchKernelGGL((k_scan_lines<true, 64, 32>), dim3(grid), dim3(64), 0, c->stream, x, y, (u64)pre, (u64)len, (u64)post, reverse, omit);
+            else hipLaunchKernelGGL((k_scan_lines<false, 64, 32>), dim3(grid), dim3(64), 0, c->stream, x, y, (u64)pre, (u64)len, (u64)post, reverse, omit);
+        }
         RMHIP_HIP_CHECK(hipGetLastError());
         c->tel.kernel_launches++;
         return RMHIP_OK;
@@ -510,17 +568,22 @@ int launch_cumulative(Context* c, int prod, int reverse, int omit, const double*
     RMHIP_TRY(c->ensure_scratch(lines * nchunks * sizeof(double)));
     double* totals = c->scratch;
     const dim3 grid((unsigned)nchunks, (unsigned)lines);
+    const double* carries = nchunks > 1 ? totals : nullptr;
     if (prod) {
-        hipLaunchKernelGGL(k_scan_chunk_totals<true>, grid, dim3(R2_BLOCK), 0, c->stream, x, (u64)len, nchunks, reverse, omit, totals);
-        hipLaunchKernelGGL(k_scan_carries<true>, dim3((unsigned)ceil_div_u64(lines, R2_BLOCK)), dim3(R2_BLOCK), 0, c->stream, totals, nchunks, (u64)lines);
-        hipLaunchKernelGGL(k_scan_chunks<true>, grid, dim3(R2_BLOCK), 0, c->stream, x, y, (u64)len, nchunks, reverse, omit, (const double*)totals);
+        if (carries) {
+            hipLaunchKernelGGL(k_scan_chunk_totals<true>, grid, dim3(R2_BLOCK), 0, c->stream, x, (u64)len, nchunks, reverse, omit, totals);
+            hipLaunchKernelGGL(k_scan_carries<true>, dim3((unsigned)lines), dim3(R2_BLOCK), 0, c->stream, totals, nchunks, (u64)lines);
+        }
+        hipLaunchKernelGGL(k_scan_chunks<true>, grid, dim3(R2_BLOCK), 0, c->stream, x, y, (u64)len, nchunks, reverse, omit, carries);
     } else {
-        hipLaunchKernelGGL(k_scan_chunk_totals<false>, grid, dim3(R2_BLOCK), 0, c->stream, x, (u64)len, nchunks, reverse, omit, totals);
-        hipLaunchKernelGGL(k_scan_carries<false>, dim3((unsigned)ceil_div_u64(lines, R2_BLOCK)), dim3(R2_BLOCK), 0, c->stream, totals, nchunks, (u64)lines);
-        hipLaunchKernelGGL(k_scan_chunks<false>, grid, dim3(R2_BLOCK), 0, c->stream, x, y, (u64)len, nchunks, reverse, omit, (const double*)totals);
+        if (carries) {
+            hipLaunchKernelGGL(k_scan_chunk_totals<false>, grid, dim3(R2_BLOCK), 0, c->stream, x, (u64)len, nchunks, reverse, omit, totals);
+            hipLaunchKernelGGL(k_scan_carries<false>, dim3((unsigned)lines), dim3(R2_BLOCK), 0, c->stream, totals, nchunks, (u64)lines);
+        }
+        hipLaunchKernelGGL(k_scan_chunks<false>, grid, dim3(R2_BLOCK), 0, c->stream, x, y, (u64)len, nchunks, reverse, omit, carries);
     }
     RMHIP_HIP_CHECK(hipGetLastError());
-    c->tel.kernel_launches += 3;
+    c->tel.kernel_launches += carries ? 3 : 1;
     return RMHIP_OK;
 }
 
