@@ -73,8 +73,9 @@ __device__ __forceinline__ void arg_decode(u64 key, u64 idx, double* value, doub
     *value = __longlong_as_double((long long)b);
 }
 
-// count / mean / M2 (std.rs:858-935: Welford's update element by element, NaNs counted apart).  One chunk is exactly the
-// CPU's sequence; chunks merge with Chan's formula in chunk order.
+// count / mean / M2 (std.rs:858-935: Welford's update element by element, NaNs counted apart).  Here: batches of eight by the
+// two-pass formula, batches and chunks merged with Chan's formula in a fixed order (tails and NaN-carrying batches element by
+// element) - the same quantities to rounding, not the CPU's operation sequence.
 struct MomAcc {
     double n, mean, m2, nan;
     __device__ __forceinline__ void init() { n = mean = m2 = nan = 0.0; }
@@ -94,6 +95,36 @@ struct MomAcc {
         mean += delta * rn;
         const double delta2 = v - mean;
         m2 += delta * delta2;
+    }
+    // eight values at once: their own mean and M2 by the two-pass formula in registers (independent operations), then ONE Chan
+    // merge - a third of the instructions of eight Welford updates and no eight-deep dependent chain (the per-element form ran at
+    // 3 TB/s).  A batch holding a NaN goes element by element.
+    __device__ __forceinline__ void add8(const double (&v)[8]) {
+        bool clean = true;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) clean = clean && (v[u] == v[u]);
+        if (!clean) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) add(0, v[u]);
+            return;
+        }
+        const double s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        const double mb = s * 0.125;
+        double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            const double d0 = v[u] - mb, d1 = v[u + 1] - mb;
+            q0 = __builtin_fma(d0, d0, q0);
+            q1 = __builtin_fma(d1, d1, q1);
+        }
+        const double tot = n + 8.0, delta = mb - mean;
+        double rt = __builtin_amdgcn_rcp(tot);
+        rt = __builtin_fma(rt, __builtin_fma(-tot, rt, 1.0), rt);
+        rt = __builtin_fma(rt, __builtin_fma(-tot, rt, 1.0), rt);
+        const double f = 8.0 * rt;  // n_b / tot
+        mean = __builtin_fma(delta, f, mean);
+        m2 += (q0 + q1) + delta * delta * (n * f);
+        n = tot;
     }
     __device__ __forceinline__ void merge(const MomAcc& o) {
         nan += o.nan;
@@ -127,6 +158,17 @@ struct TruthAcc {
 };
 
 // ---- stage 1 ----------------------------------------------------------------------------------------------------------------
+// eight elements of a thread's run, in ascending index order
+template <class Acc>
+__device__ __forceinline__ void r2_fold8(Acc& a, const u64 (&k)[8], const double (&v)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a.add(k[u], v[u]);
+}
+template <>
+__device__ __forceinline__ void r2_fold8<MomAcc>(MomAcc& a, const u64 (&)[8], const double (&v)[8]) {
+    a.add8(v);
+}
+
 static constexpr int R2_BLOCK = 256;
 
 // pre == 1: slice s is `red` contiguous elements.  grid (nsplit, slices in y, z)
@@ -149,10 +191,86 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_contig(const double* __restrict
         double v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(xs + r + u * R2_BLOCK);
+        u64 k[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a.add(r + u * R2_BLOCK, v[u]);
+        for (int u = 0; u < 8; ++u) k[u] = r + u * R2_BLOCK;
+        r2_fold8(a, k, v);
     }
     for (; r < end; r += R2_BLOCK) a.add(r, __builtin_nontemporal_load(xs + r));
+    lds[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = R2_BLOCK / 2; s > 0; s >>= 1) {  // fixed tree
+        if ((int)threadIdx.x < s) {
+            Acc m = lds[threadIdx.x];
+            m.merge(lds[threadIdx.x + s]);
+            lds[threadIdx.x] = m;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[slice * nsplit + split] = lds[0];
+}
+
+// the same with 16-byte loads (even `red`, 16-byte aligned base: every slice starts on a pair) and the next batch requested before
+// the current one is folded - the fold of an arg accumulator is a chain of dependent compare / selects during which a wave would
+// otherwise have nothing in flight.  A thread's elements still arrive in ascending index order.
+typedef double r2_d2 __attribute__((ext_vector_type(2)));
+template <class Acc>
+__global__ void __launch_bounds__(R2_BLOCK) k_r2_contig_v2(const double* __restrict__ x, u64 red, u64 nslices, u64 nsplit, Acc* __restrict__ part) {
+    __shared__ Acc lds[R2_BLOCK];
+    const u64 slice = blockIdx.y + (u64)gridDim.y * blockIdx.z;
+    if (slice >= nslices) return;
+    const u64 split = blockIdx.x, red2 = red >> 1;
+    u64 chunk = (red2 + nsplit - 1) / nsplit;
+    chunk = (chunk + R2_BLOCK - 1) / R2_BLOCK * R2_BLOCK;
+    const u64 begin = split * chunk;
+    u64 end = begin + chunk;
+    if (end > red2) end = red2;
+    const r2_d2* xs = reinterpret_cast<const r2_d2*>(x + slice * red);
+    Acc a;
+    a.init();
+    u64 r = begin + threadIdx.x;
+    constexpr int U = 4;
+    if (r + (U - 1) * R2_BLOCK < end) {
+        r2_d2 cur[U], nxt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = __builtin_nontemporal_load(xs + r + u * R2_BLOCK);
+        for (; r + (2 * U - 1) * R2_BLOCK < end; r += U * R2_BLOCK) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[u] = __builtin_nontemporal_load(xs + r + (U + u) * R2_BLOCK);
+            {
+                u64 k[8];
+                double w[8];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    k[2 * u] = 2 * (r + u * R2_BLOCK);
+                    k[2 * u + 1] = 2 * (r + u * R2_BLOCK) + 1;
+                    w[2 * u] = cur[u].x;
+                    w[2 * u + 1] = cur[u].y;
+                }
+                r2_fold8(a, k, w);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        }
+        {
+            u64 k[8];
+            double w[8];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                k[2 * u] = 2 * (r + u * R2_BLOCK);
+                k[2 * u + 1] = 2 * (r + u * R2_BLOCK) + 1;
+                w[2 * u] = cur[u].x;
+                w[2 * u + 1] = cur[u].y;
+            }
+            r2_fold8(a, k, w);
+        }
+        r += U * R2_BLOCK;
+    }
+    for (; r < end; r += R2_BLOCK) {
+        const r2_d2 v = __builtin_nontemporal_load(xs + r);
+        a.add(2 * r, v.x);
+        a.add(2 * r + 1, v.y);
+    }
     lds[threadIdx.x] = a;
     __syncthreads();
     for (int s = R2_BLOCK / 2; s > 0; s >>= 1) {  // fixed tree
@@ -184,8 +302,10 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_strided(const double* __restric
         double v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(xs + pre * (r + u));
+        u64 k[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a.add(r + u, v[u]);
+        for (int u = 0; u < 8; ++u) k[u] = r + u;
+        r2_fold8(a, k, v);
     }
     if (r < end) {
         double v[8];
@@ -201,7 +321,6 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_strided(const double* __restric
 
 // the same with 16-byte loads: a thread owns two adjacent lines (even `pre`, 16-byte aligned base).  As for sum(x,2)
 // (reduce_kernels.hip) what decides the rate of these lock-step column walks is the number of blocks: three per CU.
-typedef double r2_d2 __attribute__((ext_vector_type(2)));
 template <class Acc>
 __global__ void __launch_bounds__(R2_BLOCK) k_r2_strided_v2(const double* __restrict__ x, u64 pre, u64 red, u64 nsplit, Acc* __restrict__ part) {
     const u64 i2 = (u64)blockIdx.x * R2_BLOCK + threadIdx.x, pre2 = pre >> 1;
@@ -216,15 +335,41 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_strided_v2(const double* __rest
     a0.init();
     a1.init();
     u64 r = begin;
-    for (; r + 8 <= end; r += 8) {
-        r2_d2 v[8];
+    if (r + 8 <= end) {  // two batches in flight: the next one is requested before the current one is folded
+        r2_d2 cur[8], nxt[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(xs + pre2 * (r + u));
+        for (int u = 0; u < 8; ++u) cur[u] = __builtin_nontemporal_load(xs + pre2 * (r + u));
+        for (; r + 16 <= end; r += 8) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            a0.add(r + u, v[u].x);
-            a1.add(r + u, v[u].y);
+            for (int u = 0; u < 8; ++u) nxt[u] = __builtin_nontemporal_load(xs + pre2 * (r + 8 + u));
+            {
+                u64 k[8];
+                double w0[8], w1[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    k[u] = r + u;
+                    w0[u] = cur[u].x;
+                    w1[u] = cur[u].y;
+                }
+                r2_fold8(a0, k, w0);
+                r2_fold8(a1, k, w1);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
         }
+        {
+            u64 k[8];
+            double w0[8], w1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                k[u] = r + u;
+                w0[u] = cur[u].x;
+                w1[u] = cur[u].y;
+            }
+            r2_fold8(a0, k, w0);
+            r2_fold8(a1, k, w1);
+        }
+        r += 8;
     }
     if (r < end) {
         r2_d2 v[8];
@@ -243,28 +388,39 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_strided_v2(const double* __rest
     part[(line + 1) * nsplit + split] = a1;
 }
 
-// ---- stage 2: one wave per slice merges the chunks in chunk order (lane l takes a contiguous run) ------------------------------
+// ---- stage 2: one wave per slice merges the chunks - lane l folds a contiguous run in chunk order, the 64 lane results merge in a
+// fixed shuffle tree (lower lanes = earlier chunks on the left of every merge).  (First version: lane 0 folded the 64 lane
+// results one after the other out of LDS - 28 us at 8192 slices, a third of the whole min / max call.)
+template <class Acc>
+__device__ __forceinline__ Acc r2_shfl_down(const Acc& a, int off) {
+    static_assert(sizeof(Acc) % 4 == 0, "accumulators are shuffled word by word");
+    constexpr int W = sizeof(Acc) / 4;
+    int w[W];
+    __builtin_memcpy(w, &a, sizeof(Acc));
+#pragma unroll
+    for (int i = 0; i < W; ++i) w[i] = __shfl_down(w[i], off, 64);
+    Acc o;
+    __builtin_memcpy(&o, w, sizeof(Acc));
+    return o;
+}
 template <class Acc, class Fin>
 __global__ void __launch_bounds__(R2_BLOCK) k_r2_final(const Acc* __restrict__ part, u64 nslices, u64 nsplit, Fin fin) {
-    __shared__ Acc lds[R2_BLOCK];
     const u64 slice = (u64)blockIdx.x * (R2_BLOCK / 64) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    if (slice >= nslices) return;  // whole waves leave together
     Acc a;
     a.init();
-    if (slice < nslices) {
-        const u64 per = (nsplit + 63) / 64;
-        const u64 b = (u64)lane * per;
-        u64 e = b + per;
-        if (e > nsplit) e = nsplit;
-        for (u64 s = b; s < e; ++s) a.merge(part[slice * nsplit + s]);
+    const u64 per = (nsplit + 63) / 64;
+    const u64 b = (u64)lane * per;
+    u64 e = b + per;
+    if (e > nsplit) e = nsplit;
+    for (u64 s = b; s < e; ++s) a.merge(part[slice * nsplit + s]);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const Acc o = r2_shfl_down(a, off);
+        if ((lane & (2 * off - 1)) == 0) a.merge(o);  // lane, lane + off: the earlier chunks stay on the left
     }
-    lds[threadIdx.x] = a;
-    __syncthreads();
-    if (lane == 0 && slice < nslices) {
-        Acc m = lds[threadIdx.x];
-        for (int l = 1; l < 64; ++l) m.merge(lds[threadIdx.x + l]);
-        fin(slice, m);
-    }
+    if (lane == 0) fin(slice, a);
 }
 
 template <bool MAX>
@@ -323,7 +479,9 @@ static int run_r2(Context* c, const double* x, size_t pre, size_t red, size_t po
     const size_t nparts = (size_t)(p.nslices * nsplit);
     RMHIP_TRY(c->ensure_scratch(nparts * sizeof(Acc)));
     Acc* part = reinterpret_cast<Acc*>(c->scratch);
-    if (p.contiguous)
+    if (p.contiguous && (red & 1) == 0 && red >= 4 * R2_BLOCK && (((uintptr_t)x) & 15) == 0)
+        hipLaunchKernelGGL((k_r2_contig_v2<Acc>), dim3((unsigned)nsplit, p.gy, p.gz), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices, nsplit, part);
+    else if (p.contiguous)
         hipLaunchKernelGGL((k_r2_contig<Acc>), dim3((unsigned)nsplit, p.gy, p.gz), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices, nsplit, part);
     else if (wide)
         hipLaunchKernelGGL((k_r2_strided_v2<Acc>), dim3(gx, (unsigned)nsplit, (unsigned)post), dim3(R2_BLOCK), 0, c->stream, x, (u64)pre, (u64)red, nsplit, part);
