@@ -322,9 +322,10 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_strided(const double* __restric
 // the same with 16-byte loads: a thread owns two adjacent lines (even `pre`, 16-byte aligned base).  As for sum(x,2)
 // (reduce_kernels.hip) what decides the rate of these lock-step column walks is the number of blocks: three per CU.
 template <class Acc>
-__global__ void __launch_bounds__(R2_BLOCK) k_r2_strided_v2(const double* __restrict__ x, u64 pre, u64 red, u64 nsplit, Acc* __restrict__ part) {
-    const u64 i2 = (u64)blockIdx.x * R2_BLOCK + threadIdx.x, pre2 = pre >> 1;
-    if (i2 >= pre2) return;
+__global__ void __launch_bounds__(R2_BLOCK) k_r2_strided_v2(const double* __restrict__ x, u64 pre, u64 red, u64 nsplit, unsigned win,
+                                                            Acc* __restrict__ part) {
+    const u64 i2 = (u64)blockIdx.x * win + threadIdx.x, pre2 = pre >> 1;  // balanced windows, their number a multiple of the XCD count (run_r2)
+    if (threadIdx.x >= win || i2 >= pre2) return;
     const u64 split = blockIdx.y, j = blockIdx.z;
     const u64 chunk = (red + nsplit - 1) / nsplit;
     const u64 begin = split * chunk;
@@ -468,8 +469,18 @@ static int run_r2(Context* c, const double* x, size_t pre, size_t red, size_t po
     u64 nsplit = p.nsplit;
     unsigned gx = p.gx;
     const bool wide = !p.contiguous && (pre & 1) == 0 && pre >= 512 && (((uintptr_t)x) & 15) == 0;
-    if (!p.contiguous) {  // these kernels keep 256 threads along `pre`
+    unsigned win = R2_BLOCK, threads = R2_BLOCK;
+    if (!p.contiguous) {  // these kernels keep up to 256 threads along `pre`
         gx = (unsigned)ceil_div_u64(wide ? pre / 2 : pre, R2_BLOCK);
+        if (wide) {  // as for sum(x,2) (reduce_kernels.hip): a window count that is a multiple of the XCD count pins every window to one XCD
+            const unsigned xcds = c->num_xcc > 0 ? (unsigned)c->num_xcc : 8u;
+            if (pre / 2 >= xcds * 64) gx = (gx + xcds - 1) / xcds * xcds;
+            win = (unsigned)((ceil_div_u64(pre / 2, gx) + 7) / 8 * 8);
+            if (win > R2_BLOCK) win = R2_BLOCK;
+            gx = (unsigned)ceil_div_u64(pre / 2, win);
+            if (pre / 2 >= xcds * 64) gx = (gx + xcds - 1) / xcds * xcds;
+            threads = (win + 63) / 64 * 64;
+        }
         u64 want = ceil_div_u64((u64)c->num_cus * (wide ? 3 : 8), (u64)gx * post);
         u64 max_split = ceil_div_u64(red, 16);
         nsplit = want < 1 ? 1 : (want > max_split ? max_split : want);
@@ -484,7 +495,7 @@ static int run_r2(Context* c, const double* x, size_t pre, size_t red, size_t po
     else if (p.contiguous)
         hipLaunchKernelGGL((k_r2_contig<Acc>), dim3((unsigned)nsplit, p.gy, p.gz), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices, nsplit, part);
     else if (wide)
-        hipLaunchKernelGGL((k_r2_strided_v2<Acc>), dim3(gx, (unsigned)nsplit, (unsigned)post), dim3(R2_BLOCK), 0, c->stream, x, (u64)pre, (u64)red, nsplit, part);
+        hipLaunchKernelGGL((k_r2_strided_v2<Acc>), dim3(gx, (unsigned)nsplit, (unsigned)post), dim3(threads), 0, c->stream, x, (u64)pre, (u64)red, nsplit, win, part);
     else
         hipLaunchKernelGGL((k_r2_strided<Acc>), dim3(gx, (unsigned)nsplit, (unsigned)post), dim3(R2_BLOCK), 0, c->stream, x, (u64)pre, (u64)red, nsplit, part);
     RMHIP_HIP_CHECK(hipGetLastError());

@@ -98,11 +98,13 @@ __global__ void __launch_bounds__(RM_RBLOCK) k_reduce_strided(const T* x, rm_u64
 // per-slice summation order as rm_reduce_strided with ty == 1, at 1 KiB per wave instruction.  grid = (ceil(pre/512),
 // nsplit, post).
 template <int OP, class T, int U>
-__global__ void __launch_bounds__(RM_RBLOCK) k_reduce_strided_v2(const T* x, rm_u64 pre, rm_u64 red, rm_u64 nsplit, double* pv,
-                                                                 double* pn) {
-    const rm_u64 i2 = (rm_u64)blockIdx.x * RM_RBLOCK + threadIdx.x;  // pair index along `pre`
+__global__ void __launch_bounds__(RM_RBLOCK) k_reduce_strided_v2(const T* x, rm_u64 pre, rm_u64 red, rm_u64 nsplit, unsigned win,
+                                                                 double* pv, double* pn) {
+    // a block owns `win` <= 256 pairs: the windows are balanced (host), so a row count just above a multiple of 512 does not
+    // leave a column of nearly empty blocks behind (8256 rows: 16 full windows + one of 32 pairs ran 109 us against 86)
+    const rm_u64 i2 = (rm_u64)blockIdx.x * win + threadIdx.x;  // pair index along `pre`
     const rm_u64 pre2 = pre >> 1;
-    if (i2 >= pre2) return;
+    if (threadIdx.x >= win || i2 >= pre2) return;
     const rm_u64 split = blockIdx.y, j = blockIdx.z;
     const rm_u64 chunk = (red + nsplit - 1) / nsplit;
     const rm_u64 begin = split * chunk;
@@ -166,9 +168,25 @@ static int run_reduce(Context* c, int mean, int nan_mode, const T* x, size_t pre
     static const int b_mode = getenv("RMHIP_RED_B_MODE") ? atoi(getenv("RMHIP_RED_B_MODE")) : 1;
     static const int b_bpc = getenv("RMHIP_RED_B_BPC") ? atoi(getenv("RMHIP_RED_B_BPC")) : 3;
     const bool wide_b = !p.contiguous && b_mode > 0 && (pre & 1) == 0 && pre >= 512 && (((uintptr_t)x) & 15) == 0 && post <= 65535;
-    unsigned wide_bx = 0;
+    unsigned wide_bx = 0, wide_win = RM_RBLOCK, wide_threads = RM_RBLOCK;
     if (wide_b) {
+        // The number of windows along `pre` is a multiple of the XCD count.  Workgroups go to XCDs round robin in launch order
+        // (x fastest), so with gridDim.x % 8 == 0 a window - the same 4 KiB of every column - is always walked by the same XCD,
+        // whatever the chunk; otherwise the windows rotate over the XCDs from chunk to chunk.  Measured (sum(x,2), us, windows
+        // before -> after): 8200 x 8192 17 -> 24: 109 -> 90; 8256 x 8192 17 -> 24: 108 -> 95; 16400 x 4096 33 -> 40: 110 -> 97;
+        // 5000 x 13000 10 -> 16: 104 -> 84; 12000 x 6000: 93; shapes whose count already was a multiple of eight (8192, 7936,
+        // 8190, 16384 rows: 16 / 32 windows) are where round 2's 84-89 us came from - "rows a multiple of 512" was a proxy.
+        // The windows are balanced (128-byte granules) and a block has as many waves as its window needs.  RMHIP_RED_B_X8=0
+        // restores the old geometry.  (Also measured: two or four pairs per thread, 8-16 KiB of every column per block: 103-152 us.)
+        static const int b_x8 = getenv("RMHIP_RED_B_X8") ? atoi(getenv("RMHIP_RED_B_X8")) : 1;
+        const unsigned xcds = c->num_xcc > 0 ? (unsigned)c->num_xcc : 8u;
         wide_bx = (unsigned)ceil_div_u64(pre / 2, RM_RBLOCK);
+        if (b_x8 && pre / 2 >= xcds * 64) wide_bx = (wide_bx + xcds - 1) / xcds * xcds;
+        wide_win = (unsigned)((ceil_div_u64(pre / 2, wide_bx) + 7) / 8 * 8);
+        if (wide_win > RM_RBLOCK) wide_win = RM_RBLOCK;
+        wide_bx = (unsigned)ceil_div_u64(pre / 2, wide_win);
+        if (b_x8 && pre / 2 >= xcds * 64) wide_bx = (wide_bx + xcds - 1) / xcds * xcds;  // (trailing windows may be empty)
+        wide_threads = (wide_win + 63) / 64 * 64;
         uint64_t want = ceil_div_u64((uint64_t)c->num_cus * b_bpc, (uint64_t)wide_bx * post);
         uint64_t max_split = ceil_div_u64(red, 16);
         nsplit = want < 1 ? 1 : want;
@@ -189,11 +207,11 @@ static int run_reduce(Context* c, int mean, int nan_mode, const T* x, size_t pre
         hipLaunchKernelGGL((k_reduce_contig<OP, T>), dim3(p.gx, p.gy, p.gz), dim3(p.tx), 0, c->stream, x,
                            (rm_u64)red, (rm_u64)p.nslices, (rm_u64)p.nsplit, pv, pn);
     else if (wide_b && b_mode == 2)
-        hipLaunchKernelGGL((k_reduce_strided_v2<OP, T, 4>), dim3(wide_bx, (unsigned)nsplit, (unsigned)post), dim3(RM_RBLOCK), 0, c->stream,
-                           x, (rm_u64)pre, (rm_u64)red, (rm_u64)nsplit, pv, pn);
+        hipLaunchKernelGGL((k_reduce_strided_v2<OP, T, 4>), dim3(wide_bx, (unsigned)nsplit, (unsigned)post), dim3(wide_threads), 0, c->stream,
+                           x, (rm_u64)pre, (rm_u64)red, (rm_u64)nsplit, wide_win, pv, pn);
     else if (wide_b)
-        hipLaunchKernelGGL((k_reduce_strided_v2<OP, T, 8>), dim3(wide_bx, (unsigned)nsplit, (unsigned)post), dim3(RM_RBLOCK), 0, c->stream,
-                           x, (rm_u64)pre, (rm_u64)red, (rm_u64)nsplit, pv, pn);
+        hipLaunchKernelGGL((k_reduce_strided_v2<OP, T, 8>), dim3(wide_bx, (unsigned)nsplit, (unsigned)post), dim3(wide_threads), 0, c->stream,
+                           x, (rm_u64)pre, (rm_u64)red, (rm_u64)nsplit, wide_win, pv, pn);
     else
         hipLaunchKernelGGL((k_reduce_strided<OP, T>), dim3(p.gx, p.gy, p.gz), dim3(RM_RBLOCK), 0, c->stream, x,
                            (rm_u64)pre, (rm_u64)red, (rm_u64)p.nsplit, p.tx, pv, pn);

@@ -39,3 +39,12 @@ rate("reduce_any all", lambda: prov.reduce_any(a), N)
 v = prov.fill_uniform(4, -1.0, 1.0, (n * n, 1))
 rate("cumsum_scan 6.7e7 vector", lambda: prov.cumsum_scan(v, 0), 2 * N)
 rate("reduce_min_dim 6.7e7 vector", lambda: mm(prov.reduce_min_dim, 0) if False else (lambda r: (r.values, r.indices))(prov.reduce_min_dim(v, 0)), N)
+prov.free(a); prov.free(v)
+# ragged shapes: rows just above a multiple of 512 (the window count along the rows is rounded to a multiple of the XCD count)
+for shape in ((8200, 8192), (5000, 13000)):
+    a = prov.fill_uniform(5, -1.0, 1.0, shape)
+    Ns = shape[0] * shape[1] * 8.0
+    rate(f"reduce_sum_dim dim1 {shape}", lambda: prov.reduce_sum_dim(a, 1), Ns)
+    rate(f"reduce_min_dim dim1 {shape}", lambda: mm(prov.reduce_min_dim, 1), Ns)
+    rate(f"reduce_std_dim dim1 {shape}", lambda: prov.reduce_std_dim(a, 1), Ns)
+    prov.free(a)
