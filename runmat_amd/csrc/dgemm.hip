@@ -80,6 +80,18 @@ struct GemmArgs {
 };
 
 // MatmulEpilogue on one output element, order of crates/runmat-accelerate/src/simple_provider.rs:7800-7836
+// The same without the pow step, inlined: what the eight-wave kernel uses when the request has no exponent.  (The out-of-line
+// function with pow in it costs the caller 224 bytes of scratch per lane and a large store phase that evicts its neighbours' k loop
+// from the instruction cache: 62.7 TFLOP/s at 8192^3 against 70+ for the inlined short form.)
+__device__ __forceinline__ double apply_epilogue_nopow(const GemmEpilogue& e, double acc, unsigned mm, unsigned nn) {
+    double v = acc * e.alpha + e.beta_add;
+    if (e.flags & EP_ROW) v = (e.flags & EP_ROW_DIV) ? v / e.row_scale[mm] : v * e.row_scale[mm];
+    if (e.flags & EP_COL) v = (e.flags & EP_COL_DIV) ? v / e.col_scale[nn] : v * e.col_scale[nn];
+    if (e.flags & EP_CLAMP_MIN) v = fmax(v, e.clamp_min);
+    if (e.flags & EP_CLAMP_MAX) v = fmin(v, e.clamp_max);
+    if ((e.flags & EP_DIAG) && mm == nn) e.diag[mm] = v;
+    return v;
+}
 __device__ __noinline__ double apply_epilogue(const GemmEpilogue& e, double acc, unsigned mm, unsigned nn) {
     double v = acc * e.alpha + e.beta_add;
     if (e.flags & EP_ROW) v = (e.flags & EP_ROW_DIV) ? v / e.row_scale[mm] : v * e.row_scale[mm];
@@ -524,9 +536,17 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
 // variant per CU).  Plain operands, unguarded shapes only (m, n % 128, k % 16, even
 // leading dimensions, aligned bases); PRE as in k_dgemm.  Same k-ordered MFMA chain per element: bit-identical results.
 // TA / TB: the operand is stored transposed, as in k_dgemm (a transposed A is staged with B's pattern and vice versa).
-template <bool PRE, bool TA = false, bool TB = false>
-__device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, const unsigned tn, double* As, double* Bs) {
+// EPI: the MatmulEpilogue on every output element (separate instantiations, as for k_dgemm): 1 = without a pow step (inlined),
+// 2 = any request (out of line).
+template <bool PRE, bool TA = false, bool TB = false, int EPI = 0>
+__device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, const unsigned tn, double* As, double* Bs,
+                                        const unsigned kbeg = 0, const unsigned klen_or_0 = 0, const size_t c_off = 0) {
+    // (kbeg, klen, c_off): the k slice and the partial-product offset of a split-K block; defaults = the whole product
     const unsigned m0 = tm * BM, n0 = tn * BN;
+    const double* const gA = g.A + (TA ? (size_t)kbeg : (size_t)kbeg * g.lda);
+    const double* const gB = g.B + (TB ? (size_t)kbeg * g.ldb : (size_t)kbeg);
+    double* const gC = g.C + c_off;
+    const unsigned gk = klen_or_0 ? klen_or_0 : g.k;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave & 1, wn = wave >> 1;  // wn 0..3: 32 columns each
@@ -534,9 +554,9 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
     const int p_xp = t & 63, p_kc = t >> 6;  // pattern M (128 contiguous x 16 k): pair along the tile dimension, k = p_kc + 8*p
     const int q_kp = t & 7, q_y = t >> 3;    // pattern K (k contiguous): pair along k, y = q_y + 64*p
     // A: plain = pattern M on (m, k) with ld = lda; transposed (stored k x m... as At[k + m*lda]) = pattern K over rows m
-    const double* const Ap = TA ? g.A + (size_t)m0 * g.lda + 2 * q_kp : g.A + m0 + 2 * p_xp;
+    const double* const Ap = TA ? gA + (size_t)m0 * g.lda + 2 * q_kp : gA + m0 + 2 * p_xp;
     // B: plain = pattern K over rows n (B[k + n*ldb]); transposed (Bt[n + k*ldb]) = pattern M on (n, k)
-    const double* const Bp = TB ? g.B + n0 + 2 * p_xp : g.B + (size_t)n0 * g.ldb + 2 * q_kp;
+    const double* const Bp = TB ? gB + n0 + 2 * p_xp : gB + (size_t)n0 * g.ldb + 2 * q_kp;
     v2d ra[2], rb[2];
     auto fetch = [&](unsigned k0) {
 #pragma unroll
@@ -565,12 +585,12 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
                     const unsigned mm = m0 + wm * 64 + i * 16 + l15;
                     const unsigned row = g.rowmap ? (4 * lq + r) : (4 * r + lq);
                     const unsigned nn = n0 + wn * 32 + j * 16 + row;
-                    acc[j][i][r] = -g.C[(size_t)nn * g.ldc + mm];
+                    acc[j][i][r] = -gC[(size_t)nn * g.ldc + mm];
                 } else {
                     acc[j][i][r] = 0.0;
                 }
             }
-    const unsigned ktiles = g.k / BK;
+    const unsigned ktiles = gk / BK;
     fetch(0);
     stash(0);
     __syncthreads();
@@ -671,9 +691,9 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
                 const unsigned mm = m0 + wm * 64 + i * 16 + l15;
                 const unsigned row = g.rowmap ? (4 * lq + r) : (4 * r + lq);
                 const unsigned nn = n0 + wn * 32 + j * 16 + row;
-                dst[i * 4 + r] = g.C + (size_t)nn * g.ldc + mm;
+                dst[i * 4 + r] = gC + (size_t)nn * g.ldc + mm;
             }
-        if (!PRE && g.beta != 0.0) {
+        if (!PRE && !EPI && g.beta != 0.0) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) prev[e] = *dst[e];
         }
@@ -685,6 +705,11 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
                 double v;
                 if (PRE) {
                     v = -acc[j][i][r];
+                } else if (EPI) {
+                    const unsigned mm = m0 + wm * 64 + i * 16 + l15;
+                    const unsigned row = g.rowmap ? (4 * lq + r) : (4 * r + lq);
+                    v = EPI == 1 ? apply_epilogue_nopow(g.ep, acc[j][i][r], mm, n0 + wn * 32 + j * 16 + row)
+                                 : apply_epilogue(g.ep, acc[j][i][r], mm, n0 + wn * 32 + j * 16 + row);
                 } else {
                     v = g.alpha * acc[j][i][r];
                     if (g.beta != 0.0) v = g.beta * prev[e] + v;
@@ -695,12 +720,15 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
 }
 
 
-template <bool PRE, bool TA = false, bool TB = false>
+// gridDim.y > 1: split-K (GemmArgs::k_chunk) - blockIdx.y owns a slice of k and writes its partial product
+template <bool PRE, bool TA = false, bool TB = false, int EPI = 0>
 __global__ void __launch_bounds__(512) k_dgemm_w8(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     unsigned tm, tn;
     tile_of_block(g, tm, tn);
-    w8_tile<PRE, TA, TB>(g, tm, tn, lds, lds + 2 * A_TILE);
+    const unsigned kbeg = blockIdx.y * g.k_chunk;  // one slice (gridDim.y == 1): k_chunk == k
+    const unsigned klen = (g.k - kbeg) < g.k_chunk ? (g.k - kbeg) : g.k_chunk;
+    w8_tile<PRE, TA, TB, EPI>(g, tm, tn, lds, lds + 2 * A_TILE, kbeg, klen, (size_t)blockIdx.y * g.c_split_stride);
 }
 
 // Persistent form for the look-ahead LU's late phase: one workgroup per CU, tiles handed out by a counter, and workgroups
@@ -901,14 +929,46 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
         RMHIP_HIP_CHECK(hipGetLastError());
         return RMHIP_OK;
     }
-    if (fast_k && splits == 1 && !ep && ta && !tb && w8_mode != 0 && !c->in_lookahead && c->gemm_lds_pad == 0) {
-        // A' * B (transpose views, syrk, the Gram matrices of covariance and least squares): 70.7 -> 72.5 TFLOP/s at 8192^3 as
-        // well.  (A * B' measured 69.8 against 70.2 in this form and stays on k_dgemm.)
-        c->ensure_max_lds((const void*)k_dgemm_w8<false, true, false>, kMaxLds);
-        hipLaunchKernelGGL((k_dgemm_w8<false, true, false>), dim3(blocks), dim3(512), lds_bytes, c->stream, g);
+    const bool w8_fast = fast && g.k_chunk % BK == 0;  // every k slice a whole number of tiles
+    auto reduce_splits = [&]() -> int {
+        if (splits > 1) {
+            const size_t mn = m * n;
+            const unsigned rgrid = (unsigned)((mn + 255) / 256 < (size_t)c->num_cus * 4 ? (mn + 255) / 256 : (size_t)c->num_cus * 4);
+            hipLaunchKernelGGL(k_reduce_splits, dim3(rgrid), dim3(256), 0, c->stream, partials->ptr, mn, m, splits, alpha, beta, C, ldc);
+            c->tel.kernel_launches++;
+            RMHIP_HIP_CHECK(hipGetLastError());
+        }
+        return RMHIP_OK;
+    };
+    if (w8_fast && ep && !ta && !tb && w8_mode != 0 && !c->in_lookahead && c->gemm_lds_pad == 0) {
+        // matmul_epilogue on the eight-wave tile (splits == 1 whenever there is an epilogue)
+        if (g.ep.flags & EP_POW) {
+            c->ensure_max_lds((const void*)k_dgemm_w8<false, false, false, 2>, kMaxLds);
+            hipLaunchKernelGGL((k_dgemm_w8<false, false, false, 2>), dim3(blocks), dim3(512), lds_bytes, c->stream, g);
+        } else {
+            c->ensure_max_lds((const void*)k_dgemm_w8<false, false, false, 1>, kMaxLds);
+            hipLaunchKernelGGL((k_dgemm_w8<false, false, false, 1>), dim3(blocks), dim3(512), lds_bytes, c->stream, g);
+        }
         c->tel.kernel_launches++;
         RMHIP_HIP_CHECK(hipGetLastError());
         return RMHIP_OK;
+    }
+    if (w8_fast && !ep && ta && !tb && w8_mode != 0 && !c->in_lookahead && c->gemm_lds_pad == 0) {
+        // A' * B (transpose views, syrk, the Gram matrices of covariance and least squares): 70.7 -> 72.5 TFLOP/s at 8192^3 as
+        // well.  (A * B' measured 69.8 against 70.2 in this form and stays on k_dgemm.)
+        // Split-K (tall A'*A: few output tiles, long k) runs the same kernel with blockIdx.y over the k slices.
+        c->ensure_max_lds((const void*)k_dgemm_w8<false, true, false>, kMaxLds);
+        hipLaunchKernelGGL((k_dgemm_w8<false, true, false>), dim3(blocks, splits), dim3(512), lds_bytes, c->stream, g);
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+        return reduce_splits();
+    }
+    if (w8_fast && splits > 1 && !ep && !ta && !tb && w8_mode != 0 && !c->in_lookahead && c->gemm_lds_pad == 0) {
+        c->ensure_max_lds((const void*)k_dgemm_w8<false>, kMaxLds);
+        hipLaunchKernelGGL(k_dgemm_w8<false>, dim3(blocks, splits), dim3(512), lds_bytes, c->stream, g);
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+        return reduce_splits();
     }
     if (fast_k && splits == 1 && !ep && !ta && !tb &&
         ((w8_mode == 1 && (c->gemm_lds_pad != 0 || !c->in_lookahead)) || w8_mode == 2)) {
