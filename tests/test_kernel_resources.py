@@ -39,12 +39,13 @@ def _pick(res: dict, *needles: str) -> dict:
 
 def test_dgemm_kernels_keep_their_register_budgets():
     res = _resources("dgemm.hip")
-    # plain and transposed-A eight-wave tiles: two blocks per CU need <= 128 VGPRs (four waves per SIMD)
-    for name, r in {**_pick(res, "k_dgemm_w8ILb0ELb0ELb0"), **_pick(res, "k_dgemm_w8ILb0ELb1ELb0")}.items():
+    # plain, transposed-A and short-epilogue (ELi1E) eight-wave tiles: two blocks per CU need <= 128 VGPRs (four waves per SIMD)
+    for name, r in {**_pick(res, "k_dgemm_w8ILb0ELb0ELb0ELi0E"), **_pick(res, "k_dgemm_w8ILb0ELb0ELb0ELi1E"), **_pick(res, "k_dgemm_w8ILb0ELb1ELb0")}.items():
         assert r["vgpr"] + r["agpr"] <= 128 and r["scratch"] == 0 and r["occupancy"] >= 4, (name, r)
-    # every eight-wave variant: no scratch
+    # every eight-wave variant: no scratch - except the one that calls the out-of-line epilogue (pow step, ELi2E)
     for name, r in _pick(res, "k_dgemm_w8").items():
-        assert r["scratch"] == 0, (name, r)
+        if "ELi2E" not in name:
+            assert r["scratch"] == 0, (name, r)
     # four-wave kernels: two blocks per CU (<= 256 registers); only the epilogue variant (a noinline call) may use scratch
     for name, r in _pick(res, "7k_dgemmIL").items():
         assert r["vgpr"] + r["agpr"] <= 256, (name, r)
