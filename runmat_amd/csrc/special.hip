@@ -135,33 +135,40 @@ __global__ void __launch_bounds__(IN_BLOCK) k_plane_moments(const T* __restrict_
         partial[(size_t)blockIdx.x * batch + t] = a;
     }
 }
-// stats[b] = mean, stats[batch + b] = 1 / sqrt(M2 / plane + eps) (0 when sigma is not positive) from the block triples,
-// merged in block order by `batch` groups of threads
-__global__ void __launch_bounds__(IN_BLOCK) k_plane_moments_final(const Mom* __restrict__ partial, int nblocks, int batch, double plane,
-                                                                  double epsilon, double* __restrict__ stats) {
-    __shared__ Mom s[IN_BLOCK];
-    const int t = threadIdx.x;
-    const int lanes = ((int)blockDim.x / batch) * batch;
-    const int b = t % batch, grp = t / batch, ngrp = lanes / batch;
+// stats[b] = mean, stats[batch + b] = 1 / sqrt(M2 / plane + eps) (0 when sigma is not positive) from the block triples: one
+// 256-thread block per plane b - thread t folds blocks t, t + 256, ... in that order, the 256 results merge in a fixed shuffle /
+// LDS tree.  (Round 2: ONE block for all planes, every thread a serial chain of 32 merges and then 16 threads a serial chain of
+// 64 more - 22 us, 3 % of a 16 x 2160 x 3840 call, for a few hundred KiB of partials.)
+static constexpr int FIN_BLOCK = 256;
+__device__ __forceinline__ Mom mom_shfl_down(const Mom a, int off) {
+    return Mom{__shfl_down(a.n, off, 64), __shfl_down(a.mean, off, 64), __shfl_down(a.m2, off, 64)};
+}
+__global__ void __launch_bounds__(FIN_BLOCK) k_plane_moments_final(const Mom* __restrict__ partial, int nblocks, int batch, double plane,
+                                                                   double epsilon, double* __restrict__ stats) {
+    __shared__ Mom s[FIN_BLOCK / 64];
+    const int t = threadIdx.x, b = blockIdx.x, lane = t & 63;
     Mom a = Mom{0.0, 0.0, 0.0};
-    if (t < lanes) {
-        int k = grp;
-        for (; k + 3 * ngrp < nblocks; k += 4 * ngrp) {  // four independent loads in flight per trip
-            const Mom v0 = partial[(size_t)k * batch + b], v1 = partial[(size_t)(k + ngrp) * batch + b],
-                      v2 = partial[(size_t)(k + 2 * ngrp) * batch + b], v3 = partial[(size_t)(k + 3 * ngrp) * batch + b];
-            a = mom_merge(mom_merge(mom_merge(mom_merge(a, v0), v1), v2), v3);
-        }
-        for (; k < nblocks; k += ngrp) a = mom_merge(a, partial[(size_t)k * batch + b]);
+    int k = t;
+    for (; k + 3 * FIN_BLOCK < nblocks; k += 4 * FIN_BLOCK) {  // four independent loads in flight per trip
+        const Mom v0 = partial[(size_t)k * batch + b], v1 = partial[(size_t)(k + FIN_BLOCK) * batch + b],
+                  v2 = partial[(size_t)(k + 2 * FIN_BLOCK) * batch + b], v3 = partial[(size_t)(k + 3 * FIN_BLOCK) * batch + b];
+        a = mom_merge(mom_merge(mom_merge(mom_merge(a, v0), v1), v2), v3);
     }
-    s[t] = a;
+    for (; k < nblocks; k += FIN_BLOCK) a = mom_merge(a, partial[(size_t)k * batch + b]);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const Mom o = mom_shfl_down(a, off);
+        if ((lane & (2 * off - 1)) == 0) a = mom_merge(a, o);
+    }
+    if (lane == 0) s[t >> 6] = a;
     __syncthreads();
-    if (t >= batch) return;
-    Mom tot = Mom{0.0, 0.0, 0.0};
-    for (int g = 0; g < ngrp; ++g) tot = mom_merge(tot, s[g * batch + t]);
-    stats[t] = tot.mean;
+    if (t != 0) return;
+    Mom tot = s[0];
+    for (int w = 1; w < FIN_BLOCK / 64; ++w) tot = mom_merge(tot, s[w]);
+    stats[b] = tot.mean;
     const double variance = tot.m2 / plane;
     const double sigma = sqrt(variance + epsilon);
-    stats[batch + t] = sigma > 0.0 ? 1.0 / sigma : 0.0;
+    stats[batch + b] = sigma > 0.0 ? 1.0 / sigma : 0.0;
 }
 
 template <class T, int VEC>
@@ -233,11 +240,9 @@ static int image_normalize_vec(Context* c, const T* x, T* y, size_t batch, size_
     RMHIP_TRY(c->ensure_scratch(sizeof(Mom) * (size_t)grid * batch + sizeof(double) * 2 * batch));
     Mom* partial = reinterpret_cast<Mom*>(c->scratch);
     double* stats = reinterpret_cast<double*>(partial + (size_t)grid * batch);
-    // few partials: a 256-thread final block (its serial LDS fold is shorter); thousands: all 1024 threads share the loads
-    const unsigned fthreads = (size_t)grid * batch >= 8192 ? IN_BLOCK : IN_MAX_BATCH;
     hipLaunchKernelGGL((k_plane_moments<T, VEC>), dim3(grid), dim3(threads), 0, c->stream, x, total, (int)batch, partial);
-    hipLaunchKernelGGL(k_plane_moments_final, dim3(1), dim3(fthreads), 0, c->stream, partial, (int)grid, (int)batch, (double)plane, epsilon,
-                       stats);
+    hipLaunchKernelGGL(k_plane_moments_final, dim3((unsigned)batch), dim3(FIN_BLOCK), 0, c->stream, partial, (int)grid, (int)batch, (double)plane,
+                       epsilon, stats);
     hipLaunchKernelGGL((k_imgnorm_apply<T, VEC>), dim3(grid), dim3(threads), 0, c->stream, x, y, total, (int)batch, stats, has_gain, gain,
                        has_bias, bias, clamp_zero, has_gamma, gamma);
     c->tel.kernel_launches += 3;
