@@ -78,7 +78,7 @@ def cpu_baseline_dgemm():
     from oracle import oracle
 
     pts = []
-    for n in (768, 1280):
+    for n in (1024, 2048):  # the sizes SURVEY.md 8(d) planned (about 20-40 s of one host core)
         A = oracle.fill_uniform(11, -1.0, 1.0, n * n).reshape(n, n, order="F")
         B = oracle.fill_uniform(12, -1.0, 1.0, n * n).reshape(n, n, order="F")
         t0 = time.perf_counter()
