@@ -854,12 +854,13 @@ def test_dot(prov, oracle):
     assert e.value.code == 3
 
 
-def test_matmul_epilogue_vs_oracle(prov, oracle):
-    """MatmulEpilogue folded into the dgemm store (lib.rs:3498-3560; order simple_provider.rs:7800-7836)."""
+@pytest.mark.parametrize("m,k,n", [(200, 96, 136), (256, 64, 128), (384, 160, 256)], ids=["edge-tiles", "eight-wave-tile", "eight-wave-3x2"])
+def test_matmul_epilogue_vs_oracle(prov, oracle, m, k, n):
+    """MatmulEpilogue folded into the dgemm store (lib.rs:3498-3560; order simple_provider.rs:7800-7836).  Shapes that are whole
+    128 x 128 x 16 tiles take the eight-wave kernel: the short epilogue inlined, requests with an exponent out of line (dgemm.hip)."""
     from runmat_amd import ProviderError
 
     rng = np.random.default_rng(23)
-    m, k, n = 200, 96, 136
     A, B = rng.uniform(-1, 1, (m, k)), rng.uniform(-1, 1, (k, n))
     rs, cs = rng.uniform(0.5, 2.0, (m, 1)), rng.uniform(0.5, 2.0, (1, n))
     ha, hb, hrs, hcs = prov.upload(A), prov.upload(B), prov.upload(rs), prov.upload(cs)
