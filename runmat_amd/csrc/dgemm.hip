@@ -429,7 +429,10 @@ static constexpr int SM = 64, SN = 64;
 static constexpr int SSA = SM + 16;          // A tile [k][m] row stride (80 % 32 == 16: the bank-half trick of k_dgemm)
 static constexpr int S_A_TILE = BK * SSA;    // 1280 doubles
 static constexpr int S_B_TILE = SN * SB;     // 1152 doubles
-template <bool PRE>  // PRE: C <- C - A*B with the C tile preloaded into the accumulators (see k_dgemm)
+// GUARD: m, n need not be multiples of 64 nor k of 16 (even m, k and leading dimensions, aligned bases): tile rows / columns beyond
+// the matrix re-read its last ones, the k tail of the last tile is zeroed, stores are checked - as in the eight-wave tile below.
+// 1000^3 on the guarded 128 x 128 kernel: 173 us (64 blocks, every element checked); 1024^3 here: 65 us.
+template <bool PRE, bool GUARD = false>  // PRE: C <- C - A*B with the C tile preloaded into the accumulators (see k_dgemm)
 __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) double As[2][S_A_TILE];
     __shared__ __attribute__((aligned(16))) double Bs[2][S_B_TILE];
@@ -440,14 +443,33 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
     const int l15 = lane & 15, lq = lane >> 4;
     const int p_xp = t & 31, p_kc = t >> 5;  // A: pair along m (x = 2*p_xp), k = p_kc + 8*p
     const int q_kp = t & 7, q_y = t >> 3;    // B: pair along k (k = 2*q_kp), y = q_y + 32*p
-    const double* const Ap = g.A + m0 + 2 * p_xp;
-    const double* const Bp = g.B + (size_t)n0 * g.ldb + 2 * q_kp;
+    const unsigned am = m0 + 2 * p_xp;
+    const double* const Ap = g.A + ((GUARD && am + 2 > g.m) ? g.m - 2 : am);
+    const double* const Bp = g.B + 2 * q_kp;
+    size_t b_row[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const unsigned bn = n0 + q_y + 32 * p;
+        b_row[p] = (size_t)((GUARD && bn >= g.n) ? g.n - 1 : bn) * g.ldb;
+    }
     v2d ra[2], rb[2];
     auto fetch = [&](unsigned k0) {
+        if (GUARD && k0 + BK > g.k) {  // last, partial k tile (uniform)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const unsigned km = k0 + p_kc + 8 * p, kp = k0 + 2 * q_kp;
+                const unsigned kmc = km < g.k ? km : g.k - 1, kpc = kp < g.k ? kp : g.k - 2;
+                ra[p] = *(const v2d*)(Ap + (size_t)kmc * g.lda);
+                rb[p] = *(const v2d*)(Bp + b_row[p] + ((long)kpc - 2 * q_kp));  // signed: Bp already carries + 2 q_kp
+                if (km >= g.k) ra[p] = v2d{0.0, 0.0};
+                if (kp >= g.k) rb[p] = v2d{0.0, 0.0};
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             ra[p] = *(const v2d*)(Ap + (size_t)(k0 + p_kc + 8 * p) * g.lda);
-            rb[p] = *(const v2d*)(Bp + (size_t)(q_y + 32 * p) * g.ldb + k0);
+            rb[p] = *(const v2d*)(Bp + b_row[p] + k0);
         }
     };
     auto stash = [&](int buf) {
@@ -459,6 +481,7 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
     };
     v4d acc[2][2];  // [tj (n)][ti (m)]
     double* dst[16];
+    bool ok[16];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -469,14 +492,15 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
                 const unsigned row = g.rowmap ? (4 * lq + r) : (4 * r + lq);
                 const unsigned nn = n0 + wn * 32 + j * 16 + row;
                 dst[(j * 2 + i) * 4 + r] = g.C + (size_t)nn * g.ldc + mm;
+                ok[(j * 2 + i) * 4 + r] = !GUARD || (mm < g.m && nn < g.n);
             }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[j][i][r] = PRE ? -*dst[(j * 2 + i) * 4 + r] : 0.0;
-    const unsigned ktiles = g.k / BK;
+            for (int r = 0; r < 4; ++r) acc[j][i][r] = (PRE && ok[(j * 2 + i) * 4 + r]) ? -*dst[(j * 2 + i) * 4 + r] : 0.0;
+    const unsigned ktiles = GUARD ? (g.k + BK - 1) / BK : g.k / BK;
     fetch(0);
     stash(0);
     __syncthreads();
@@ -506,7 +530,7 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
     double prev[16];
     if (!PRE && g.beta != 0.0) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) prev[e] = *dst[e];
+        for (int e = 0; e < 16; ++e) prev[e] = ok[e] ? *dst[e] : 0.0;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -522,7 +546,7 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
                     v = g.alpha * acc[j][i][r];
                     if (g.beta != 0.0) v = g.beta * prev[e] + v;
                 }
-                *dst[e] = v;
+                if (ok[e]) *dst[e] = v;
             }
 }
 
@@ -538,7 +562,11 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
 // TA / TB: the operand is stored transposed, as in k_dgemm (a transposed A is staged with B's pattern and vice versa).
 // EPI: the MatmulEpilogue on every output element (separate instantiations, as for k_dgemm): 1 = without a pow step (inlined),
 // 2 = any request (out of line).
-template <bool PRE, bool TA = false, bool TB = false, int EPI = 0>
+// GUARD: m, n need not be multiples of 128 nor k of 16 (still: even leading dimensions and aligned bases, an even k, an even m for
+// a plain A, no transposed B).  Tile rows / columns beyond the matrix re-read its last ones - their accumulators are never stored -
+// and the k tail of the LAST tile is zeroed in both operands; every other iteration runs the unguarded loads.  The guarded k_dgemm
+// checks every element of every tile: 8200^3 58.8 TFLOP/s against 72.5 at 8192^3.
+template <bool PRE, bool TA = false, bool TB = false, int EPI = 0, bool GUARD = false>
 __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, const unsigned tn, double* As, double* Bs,
                                         const unsigned kbeg = 0, const unsigned klen_or_0 = 0, const size_t c_off = 0) {
     // (kbeg, klen, c_off): the k slice and the partial-product offset of a split-K block; defaults = the whole product
@@ -553,16 +581,39 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
     const int l15 = lane & 15, lq = lane >> 4;
     const int p_xp = t & 63, p_kc = t >> 6;  // pattern M (128 contiguous x 16 k): pair along the tile dimension, k = p_kc + 8*p
     const int q_kp = t & 7, q_y = t >> 3;    // pattern K (k contiguous): pair along k, y = q_y + 64*p
+    static_assert(!(GUARD && TB), "the guarded tile is not instantiated for a transposed B");
     // A: plain = pattern M on (m, k) with ld = lda; transposed (stored k x m... as At[k + m*lda]) = pattern K over rows m
-    const double* const Ap = TA ? gA + (size_t)m0 * g.lda + 2 * q_kp : gA + m0 + 2 * p_xp;
     // B: plain = pattern K over rows n (B[k + n*ldb]); transposed (Bt[n + k*ldb]) = pattern M on (n, k)
-    const double* const Bp = TB ? gB + n0 + 2 * p_xp : gB + (size_t)n0 * g.ldb + 2 * q_kp;
+    // GUARD: the pair / row this thread stages is clamped into the matrix
+    auto pairM = [&](unsigned r, unsigned lim) { return (GUARD && r + 2 > lim) ? lim - 2 : r; };
+    auto rowY = [&](unsigned r, unsigned lim) { return (GUARD && r >= lim) ? lim - 1 : r; };
+    const double* const Ap = TA ? gA + 2 * q_kp : gA + pairM(m0 + 2 * p_xp, g.m);
+    const double* const Bp = TB ? gB + n0 + 2 * p_xp : gB + 2 * q_kp;
+    size_t a_row[2], b_row[2];  // pattern K: element offset of this thread's two rows
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        a_row[p] = (size_t)rowY(m0 + q_y + 64 * p, g.m) * g.lda;
+        b_row[p] = (size_t)rowY(n0 + q_y + 64 * p, g.n) * g.ldb;
+    }
     v2d ra[2], rb[2];
     auto fetch = [&](unsigned k0) {
+        if (GUARD && k0 + BK > gk) {  // the last, partial k tile (uniform): clamp the k index and zero what lies beyond k
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const unsigned km = k0 + p_kc + 8 * p, kp = k0 + 2 * q_kp;  // pattern M: one k per load; pattern K: a pair along k (k is even)
+                const unsigned kmc = km < gk ? km : gk - 1, kpc = kp < gk ? kp : gk - 2;
+                const long dk = (long)kpc - 2 * q_kp;  // signed: Ap / Bp already carry + 2 q_kp (pattern K)
+                ra[p] = TA ? *(const v2d*)(Ap + a_row[p] + dk) : *(const v2d*)(Ap + (size_t)kmc * g.lda);
+                rb[p] = TB ? *(const v2d*)(Bp + (size_t)kmc * g.ldb) : *(const v2d*)(Bp + b_row[p] + dk);
+                if (TA ? kp >= gk : km >= gk) ra[p] = v2d{0.0, 0.0};
+                if (TB ? km >= gk : kp >= gk) rb[p] = v2d{0.0, 0.0};
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            ra[p] = TA ? *(const v2d*)(Ap + (size_t)(q_y + 64 * p) * g.lda + k0) : *(const v2d*)(Ap + (size_t)(k0 + p_kc + 8 * p) * g.lda);
-            rb[p] = TB ? *(const v2d*)(Bp + (size_t)(k0 + p_kc + 8 * p) * g.ldb) : *(const v2d*)(Bp + (size_t)(q_y + 64 * p) * g.ldb + k0);
+            ra[p] = TA ? *(const v2d*)(Ap + a_row[p] + k0) : *(const v2d*)(Ap + (size_t)(k0 + p_kc + 8 * p) * g.lda);
+            rb[p] = TB ? *(const v2d*)(Bp + (size_t)(k0 + p_kc + 8 * p) * g.ldb) : *(const v2d*)(Bp + b_row[p] + k0);
         }
     };
     auto stash = [&](int buf) {
@@ -585,12 +636,12 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
                     const unsigned mm = m0 + wm * 64 + i * 16 + l15;
                     const unsigned row = g.rowmap ? (4 * lq + r) : (4 * r + lq);
                     const unsigned nn = n0 + wn * 32 + j * 16 + row;
-                    acc[j][i][r] = -gC[(size_t)nn * g.ldc + mm];
+                    acc[j][i][r] = (!GUARD || (mm < g.m && nn < g.n)) ? -gC[(size_t)nn * g.ldc + mm] : 0.0;
                 } else {
                     acc[j][i][r] = 0.0;
                 }
             }
-    const unsigned ktiles = gk / BK;
+    const unsigned ktiles = GUARD ? (gk + BK - 1) / BK : gk / BK;
     fetch(0);
     stash(0);
     __syncthreads();
@@ -684,6 +735,7 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
     for (int j = 0; j < 2; ++j) {
         double* dst[16];
         double prev[16];
+        bool ok[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -692,10 +744,11 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
                 const unsigned row = g.rowmap ? (4 * lq + r) : (4 * r + lq);
                 const unsigned nn = n0 + wn * 32 + j * 16 + row;
                 dst[i * 4 + r] = gC + (size_t)nn * g.ldc + mm;
+                ok[i * 4 + r] = !GUARD || (mm < g.m && nn < g.n);
             }
         if (!PRE && !EPI && g.beta != 0.0) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) prev[e] = *dst[e];
+            for (int e = 0; e < 16; ++e) prev[e] = ok[e] ? *dst[e] : 0.0;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -708,27 +761,27 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
                 } else if (EPI) {
                     const unsigned mm = m0 + wm * 64 + i * 16 + l15;
                     const unsigned row = g.rowmap ? (4 * lq + r) : (4 * r + lq);
+                    if (GUARD && !ok[e]) continue;
                     v = EPI == 1 ? apply_epilogue_nopow(g.ep, acc[j][i][r], mm, n0 + wn * 32 + j * 16 + row)
                                  : apply_epilogue(g.ep, acc[j][i][r], mm, n0 + wn * 32 + j * 16 + row);
                 } else {
                     v = g.alpha * acc[j][i][r];
                     if (g.beta != 0.0) v = g.beta * prev[e] + v;
                 }
-                *dst[e] = v;
+                if (ok[e]) *dst[e] = v;
             }
     }
 }
 
-
 // gridDim.y > 1: split-K (GemmArgs::k_chunk) - blockIdx.y owns a slice of k and writes its partial product
-template <bool PRE, bool TA = false, bool TB = false, int EPI = 0>
+template <bool PRE, bool TA = false, bool TB = false, int EPI = 0, bool GUARD = false>
 __global__ void __launch_bounds__(512) k_dgemm_w8(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     unsigned tm, tn;
     tile_of_block(g, tm, tn);
     const unsigned kbeg = blockIdx.y * g.k_chunk;  // one slice (gridDim.y == 1): k_chunk == k
     const unsigned klen = (g.k - kbeg) < g.k_chunk ? (g.k - kbeg) : g.k_chunk;
-    w8_tile<PRE, TA, TB, EPI>(g, tm, tn, lds, lds + 2 * A_TILE, kbeg, klen, (size_t)blockIdx.y * g.c_split_stride);
+    w8_tile<PRE, TA, TB, EPI, GUARD>(g, tm, tn, lds, lds + 2 * A_TILE, kbeg, klen, (size_t)blockIdx.y * g.c_split_stride);
 }
 
 // Persistent form for the look-ahead LU's late phase: one workgroup per CU, tiles handed out by a counter, and workgroups
@@ -895,13 +948,27 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
         small_force = std::getenv("RMHIP_GEMM_SMALL_FORCE") ? std::atol(std::getenv("RMHIP_GEMM_SMALL_FORCE")) : 0;
         small_pad = std::getenv("RMHIP_GEMM_SMALL_PAD") ? std::atol(std::getenv("RMHIP_GEMM_SMALL_PAD")) : 0;
     }
-    if (small_on && !ep && !ta && !tb && splits == 1 && (c->gemm_lds_pad == 0 || small_force) && k > 0 && (k <= 1024 || small_force) &&
-        (m % SM == 0) && (n % SN == 0) && (k % BK == 0) && (lda % 2 == 0) && (ldb % 2 == 0) && (((uintptr_t)A & 15) == 0) &&
-        (((uintptr_t)B & 15) == 0) && ((size_t)blocks * 2 <= (size_t)c->num_cus || small_force)) {
-        g.tiles_m = (unsigned)(m / SM);
-        g.tiles_n = (unsigned)(n / SN);
-        if (preload) hipLaunchKernelGGL(k_dgemm_small<true>, dim3(g.tiles_m * g.tiles_n), dim3(256), (size_t)small_pad, c->stream, g);
-        else hipLaunchKernelGGL(k_dgemm_small<false>, dim3(g.tiles_m * g.tiles_n), dim3(256), (size_t)small_pad, c->stream, g);
+    // shapes that are not whole tiles run the same kernels with clamped operand loads, a zeroed k tail and checked stores (GUARD): what
+    // they still need is 16-byte accesses - aligned bases, even leading dimensions, an even k, an even m for a plain A.
+    // RMHIP_GEMM_GUARD=0 sends them to the element-checking k_dgemm as before.
+    static const int guard_on = std::getenv("RMHIP_GEMM_GUARD") ? std::atoi(std::getenv("RMHIP_GEMM_GUARD")) : 1;
+    const bool vec_ok = (lda % 2 == 0) && (ldb % 2 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
+    const bool guard_ok = guard_on && vec_ok && !tb && k >= 2 && k % 2 == 0 && (ta || (m >= 2 && m % 2 == 0)) && !c->in_lookahead &&
+                          c->gemm_lds_pad == 0;
+    const bool small_shape = !ep && !ta && !tb && splits == 1 && (c->gemm_lds_pad == 0 || small_force) && k > 0 && (k <= 1024 || small_force) &&
+                             ((size_t)blocks * 2 <= (size_t)c->num_cus || small_force);
+    const bool small_whole = (m % SM == 0) && (n % SN == 0) && (k % BK == 0) && vec_ok;
+    if (small_on && small_shape && (small_whole || guard_ok)) {
+        g.tiles_m = (unsigned)((m + SM - 1) / SM);
+        g.tiles_n = (unsigned)((n + SN - 1) / SN);
+        const dim3 sgrid(g.tiles_m * g.tiles_n);
+        if (small_whole) {
+            if (preload) hipLaunchKernelGGL(k_dgemm_small<true>, sgrid, dim3(256), (size_t)small_pad, c->stream, g);
+            else hipLaunchKernelGGL(k_dgemm_small<false>, sgrid, dim3(256), (size_t)small_pad, c->stream, g);
+        } else {
+            if (preload) hipLaunchKernelGGL((k_dgemm_small<true, true>), sgrid, dim3(256), (size_t)small_pad, c->stream, g);
+            else hipLaunchKernelGGL((k_dgemm_small<false, true>), sgrid, dim3(256), (size_t)small_pad, c->stream, g);
+        }
         c->tel.kernel_launches++;
         RMHIP_HIP_CHECK(hipGetLastError());
         return RMHIP_OK;
@@ -982,6 +1049,29 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
         c->tel.kernel_launches++;
         RMHIP_HIP_CHECK(hipGetLastError());
         return RMHIP_OK;
+    }
+    if (!fast && guard_ok && w8_mode != 0 && (splits == 1 || g.k_chunk % BK == 0) && !(ep && ta)) {
+        // guarded eight-wave tile (plain or transposed A; plain, preloaded-C or epilogue store; split-K slices are whole tiles except the last)
+        const dim3 ggrid(blocks, splits);
+#define RMHIP_W8G(...)                                                                        \
+    do {                                                                                      \
+        c->ensure_max_lds((const void*)k_dgemm_w8<__VA_ARGS__>, kMaxLds);                     \
+        hipLaunchKernelGGL((k_dgemm_w8<__VA_ARGS__>), ggrid, dim3(512), lds_bytes, c->stream, g); \
+    } while (0)
+        if (ep) {
+            if (g.ep.flags & EP_POW) RMHIP_W8G(false, false, false, 2, true);
+            else RMHIP_W8G(false, false, false, 1, true);
+        } else if (ta) {
+            RMHIP_W8G(false, true, false, 0, true);
+        } else if (preload) {
+            RMHIP_W8G(true, false, false, 0, true);
+        } else {
+            RMHIP_W8G(false, false, false, 0, true);
+        }
+#undef RMHIP_W8G
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+        return reduce_splits();
     }
     if (ep) {
         if (ta || tb) return fail(RMHIP_ERR_UNSUPPORTED, "dgemm: epilogue with transposed operands is not instantiated");

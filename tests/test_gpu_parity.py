@@ -481,6 +481,43 @@ def test_matmul_reference_kats_exact(prov):
     assert np.array_equal(prov.download_matrix(prov.matmul(prov.upload(A), prov.upload(B))), A @ B)
 
 
+@pytest.mark.parametrize("m,k,n", [(2, 2, 2), (130, 66, 258), (258, 130, 70), (64, 1030, 200), (384, 2050, 130), (1000, 1000, 1000),
+                                   (6, 18, 3), (640, 48, 1290), (256, 9000, 128)])
+def test_matmul_ragged_even_shapes(prov, oracle, m, k, n):
+    """Shapes that are not whole tiles but have even m and k run the tile kernels with clamped operand loads, a zeroed k tail and
+    checked stores (dgemm.hip, GUARD): the 64 x 64 kernel for few tiles and k <= 1024, the eight-wave kernel otherwise - plain,
+    A' * B, C <- C - A * B on a view (preloaded C) and the epilogue store.  Neighbouring memory must stay untouched."""
+    rng = np.random.default_rng(m * 7 + k * 3 + n)
+    A, B = rng.uniform(-1, 1, (m, k)), rng.uniform(-1, 1, (k, n))
+    want = A @ B if m * n * k > 3e7 else oracle.matmul(A, B)
+    tol = _gemm_tol(A, B, k)
+    hA, hB = prov.upload(A), prov.upload(B)
+    got = prov.download_matrix(prov.matmul(hA, hB))
+    assert got.shape == (m, n) and np.max(np.abs(got - want)) <= tol
+    gt = prov.download_matrix(prov.matmul(prov.transpose(prov.upload(A.T.copy())), hB))  # A' view read in place
+    assert np.max(np.abs(gt - want)) <= tol
+    # the update form on a view inside a larger buffer: a frame of sentinels around C must survive
+    if m >= 4 and n >= 2:
+        big = np.full((m + 4, n + 3), 7.25)
+        C0 = rng.uniform(-1, 1, (m, n))
+        big[2:2 + m, 1:1 + n] = C0
+        hC = prov.upload(big)
+        prov.blk_gemm(-1.0, (hA, 0, 0, m, k), (hB, 0, 0, k, n), 1.0, (hC, 2, 1, m, n))
+        out = prov.download_matrix(hC)
+        assert np.max(np.abs(out[2:2 + m, 1:1 + n] - (C0 - want))) <= tol + 4 * EPS
+        frame = out.copy()
+        frame[2:2 + m, 1:1 + n] = 7.25
+        assert np.all(frame == 7.25)
+    rs = rng.uniform(0.5, 2.0, (m, 1))
+    for kw in (dict(alpha=0.5, beta=0.25, row_scale=rs, clamp_min=-0.3), dict(clamp_min=0.0, pow_exponent=1.5)):
+        we, _ = oracle.matmul_epilogue(A, B, **kw) if m * n * k <= 3e7 else (None, None)
+        if we is None:
+            continue
+        gk = {kk: (prov.upload(rs) if kk == "row_scale" else v) for kk, v in kw.items()}
+        ge = prov.download_matrix(prov.matmul_epilogue(hA, hB, **gk))
+        assert np.all(np.abs(ge - we) <= 3.0 * (k + 4) * EPS * (np.abs(A) @ np.abs(B)) + 1e-13), kw
+
+
 def test_matmul_identity_with_asymmetric_b_detects_transposes(prov):
     n = 160
     B = np.fromfunction(lambda i, j: 3.0 * i - 7.0 * j + 0.5, (n, n))

@@ -42,6 +42,9 @@ def test_dgemm_kernels_keep_their_register_budgets():
     # plain, transposed-A and short-epilogue (ELi1E) eight-wave tiles: two blocks per CU need <= 128 VGPRs (four waves per SIMD)
     for name, r in {**_pick(res, "k_dgemm_w8ILb0ELb0ELb0ELi0E"), **_pick(res, "k_dgemm_w8ILb0ELb0ELb0ELi1E"), **_pick(res, "k_dgemm_w8ILb0ELb1ELb0")}.items():
         assert r["vgpr"] + r["agpr"] <= 128 and r["scratch"] == 0 and r["occupancy"] >= 4, (name, r)
+    # the guarded forms of the same three (shapes that are not whole tiles) must fit two blocks per CU as well
+    for name, r in {**_pick(res, "k_dgemm_w8ILb0ELb0ELb0ELi0ELb1E"), **_pick(res, "k_dgemm_w8ILb0ELb0ELb0ELi1ELb1E"), **_pick(res, "k_dgemm_w8ILb0ELb1ELb0ELi0ELb1E")}.items():
+        assert r["vgpr"] + r["agpr"] <= 128 and r["scratch"] == 0 and r["occupancy"] >= 4, (name, r)
     # every eight-wave variant: no scratch - except the one that calls the out-of-line epilogue (pow step, ELi2E)
     for name, r in _pick(res, "k_dgemm_w8").items():
         if "ELi2E" not in name:
