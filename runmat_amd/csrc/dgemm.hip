@@ -34,6 +34,7 @@ namespace rmhip {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
+typedef v2d v2du __attribute__((aligned(8)));  // the same pair on an 8-byte aligned address (guarded kernels)
 
 static constexpr int BM = 128, BN = 128, BK = 16;
 static constexpr int SA = BM + 16;  // A tile row stride in doubles ([k][m])
@@ -444,7 +445,10 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
     const int p_xp = t & 31, p_kc = t >> 5;  // A: pair along m (x = 2*p_xp), k = p_kc + 8*p
     const int q_kp = t & 7, q_y = t >> 3;    // B: pair along k (k = 2*q_kp), y = q_y + 32*p
     const unsigned am = m0 + 2 * p_xp;
-    const double* const Ap = g.A + ((GUARD && am + 2 > g.m) ? g.m - 2 : am);
+    const unsigned a_r0 = (GUARD && am >= g.m) ? g.m - 1 : am;
+    const bool a_single = GUARD && a_r0 + 1 >= g.m;                 // the matrix's last row alone (odd m) or a clamped pair
+    const bool a_edge = GUARD && (g.m & 1u) && m0 + SM > g.m;       // uniform: such threads exist in this block
+    const double* const Ap = g.A + a_r0;
     const double* const Bp = g.B + 2 * q_kp;
     size_t b_row[2];
 #pragma unroll
@@ -452,24 +456,27 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
         const unsigned bn = n0 + q_y + 32 * p;
         b_row[p] = (size_t)((GUARD && bn >= g.n) ? g.n - 1 : bn) * g.ldb;
     }
+    auto ld2 = [&](const double* q) -> v2d { return GUARD ? (v2d)(*(const v2du*)q) : *(const v2d*)q; };
+    auto ldM = [&](const double* q) -> v2d {
+        if (a_edge && a_single) return v2d{*q, 0.0};
+        return ld2(q);
+    };
     v2d ra[2], rb[2];
     auto fetch = [&](unsigned k0) {
         if (GUARD && k0 + BK > g.k) {  // last, partial k tile (uniform)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const unsigned km = k0 + p_kc + 8 * p, kp = k0 + 2 * q_kp;
-                const unsigned kmc = km < g.k ? km : g.k - 1, kpc = kp < g.k ? kp : g.k - 2;
-                ra[p] = *(const v2d*)(Ap + (size_t)kmc * g.lda);
-                rb[p] = *(const v2d*)(Bp + b_row[p] + ((long)kpc - 2 * q_kp));  // signed: Bp already carries + 2 q_kp
-                if (km >= g.k) ra[p] = v2d{0.0, 0.0};
-                if (kp >= g.k) rb[p] = v2d{0.0, 0.0};
+                ra[p] = km < g.k ? ldM(Ap + (size_t)km * g.lda) : v2d{0.0, 0.0};
+                const double* pair = Bp + b_row[p] + k0;
+                rb[p] = kp + 1 < g.k ? ld2(pair) : (kp < g.k ? v2d{*pair, 0.0} : v2d{0.0, 0.0});
             }
             return;
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            ra[p] = *(const v2d*)(Ap + (size_t)(k0 + p_kc + 8 * p) * g.lda);
-            rb[p] = *(const v2d*)(Bp + b_row[p] + k0);
+            ra[p] = ldM(Ap + (size_t)(k0 + p_kc + 8 * p) * g.lda);
+            rb[p] = ld2(Bp + b_row[p] + k0);
         }
     };
     auto stash = [&](int buf) {
@@ -584,10 +591,15 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
     static_assert(!(GUARD && TB), "the guarded tile is not instantiated for a transposed B");
     // A: plain = pattern M on (m, k) with ld = lda; transposed (stored k x m... as At[k + m*lda]) = pattern K over rows m
     // B: plain = pattern K over rows n (B[k + n*ldb]); transposed (Bt[n + k*ldb]) = pattern M on (n, k)
-    // GUARD: the pair / row this thread stages is clamped into the matrix
-    auto pairM = [&](unsigned r, unsigned lim) { return (GUARD && r + 2 > lim) ? lim - 2 : r; };
+    // GUARD: any m, n, k, leading dimensions and 8-byte aligned bases.  The row (pattern K) or first row of the pair (pattern M) this
+    // thread stages is clamped into the matrix; 16-byte loads are issued on 8-byte aligned addresses (v2du: the hardware splits the
+    // ones that straddle); a pair whose second element lies outside the matrix - the last row of an odd m, the last k of an odd
+    // k - is loaded as a scalar, in the hot loop only by the blocks on the matrix's lower edge (uniform flag).
     auto rowY = [&](unsigned r, unsigned lim) { return (GUARD && r >= lim) ? lim - 1 : r; };
-    const double* const Ap = TA ? gA + 2 * q_kp : gA + pairM(m0 + 2 * p_xp, g.m);
+    const unsigned a_r0 = rowY(m0 + 2 * p_xp, g.m);
+    const bool a_single = GUARD && !TA && a_r0 + 1 >= g.m;                 // this thread's pair is the matrix's last row alone (or clamped)
+    const bool a_edge = GUARD && !TA && (g.m & 1u) && m0 + BM > g.m;       // uniform: such threads exist in this block
+    const double* const Ap = TA ? gA + 2 * q_kp : gA + a_r0;
     const double* const Bp = TB ? gB + n0 + 2 * p_xp : gB + 2 * q_kp;
     size_t a_row[2], b_row[2];  // pattern K: element offset of this thread's two rows
 #pragma unroll
@@ -595,25 +607,31 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
         a_row[p] = (size_t)rowY(m0 + q_y + 64 * p, g.m) * g.lda;
         b_row[p] = (size_t)rowY(n0 + q_y + 64 * p, g.n) * g.ldb;
     }
+    auto ld2 = [&](const double* q) -> v2d { return GUARD ? (v2d)(*(const v2du*)q) : *(const v2d*)q; };
+    auto ldM = [&](const double* q) -> v2d {  // pattern M pair of A
+        if (a_edge && a_single) return v2d{*q, 0.0};
+        return ld2(q);
+    };
     v2d ra[2], rb[2];
     auto fetch = [&](unsigned k0) {
-        if (GUARD && k0 + BK > gk) {  // the last, partial k tile (uniform): clamp the k index and zero what lies beyond k
+        if (GUARD && k0 + BK > gk) {  // the last, partial k tile (uniform): nothing beyond k is loaded, the tail is zero in both operands
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const unsigned km = k0 + p_kc + 8 * p, kp = k0 + 2 * q_kp;  // pattern M: one k per load; pattern K: a pair along k (k is even)
-                const unsigned kmc = km < gk ? km : gk - 1, kpc = kp < gk ? kp : gk - 2;
-                const long dk = (long)kpc - 2 * q_kp;  // signed: Ap / Bp already carry + 2 q_kp (pattern K)
-                ra[p] = TA ? *(const v2d*)(Ap + a_row[p] + dk) : *(const v2d*)(Ap + (size_t)kmc * g.lda);
-                rb[p] = TB ? *(const v2d*)(Bp + (size_t)kmc * g.ldb) : *(const v2d*)(Bp + b_row[p] + dk);
-                if (TA ? kp >= gk : km >= gk) ra[p] = v2d{0.0, 0.0};
-                if (TB ? km >= gk : kp >= gk) rb[p] = v2d{0.0, 0.0};
+                const unsigned km = k0 + p_kc + 8 * p, kp = k0 + 2 * q_kp;  // pattern M: one k per load; pattern K: a pair along k
+                auto ldK = [&](const double* pair) -> v2d {  // pair = address of element kp of the row (Ap / Bp carry the + 2 q_kp)
+                    if (kp + 1 < gk) return ld2(pair);
+                    if (kp < gk) return v2d{*pair, 0.0};
+                    return v2d{0.0, 0.0};
+                };
+                ra[p] = TA ? ldK(Ap + a_row[p] + k0) : (km < gk ? ldM(Ap + (size_t)km * g.lda) : v2d{0.0, 0.0});
+                rb[p] = TB ? (km < gk ? *(const v2d*)(Bp + (size_t)km * g.ldb) : v2d{0.0, 0.0}) : ldK(Bp + b_row[p] + k0);
             }
             return;
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            ra[p] = TA ? *(const v2d*)(Ap + a_row[p] + k0) : *(const v2d*)(Ap + (size_t)(k0 + p_kc + 8 * p) * g.lda);
-            rb[p] = TB ? *(const v2d*)(Bp + (size_t)(k0 + p_kc + 8 * p) * g.ldb) : *(const v2d*)(Bp + b_row[p] + k0);
+            ra[p] = TA ? ld2(Ap + a_row[p] + k0) : ldM(Ap + (size_t)(k0 + p_kc + 8 * p) * g.lda);
+            rb[p] = TB ? *(const v2d*)(Bp + (size_t)(k0 + p_kc + 8 * p) * g.ldb) : ld2(Bp + b_row[p] + k0);
         }
     };
     auto stash = [&](int buf) {
@@ -774,14 +792,25 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
 }
 
 // gridDim.y > 1: split-K (GemmArgs::k_chunk) - blockIdx.y owns a slice of k and writes its partial product
-template <bool PRE, bool TA = false, bool TB = false, int EPI = 0, bool GUARD = false>
+template <bool PRE, bool TA = false, bool TB = false, int EPI = 0>
 __global__ void __launch_bounds__(512) k_dgemm_w8(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     unsigned tm, tn;
     tile_of_block(g, tm, tn);
     const unsigned kbeg = blockIdx.y * g.k_chunk;  // one slice (gridDim.y == 1): k_chunk == k
     const unsigned klen = (g.k - kbeg) < g.k_chunk ? (g.k - kbeg) : g.k_chunk;
-    w8_tile<PRE, TA, TB, EPI, GUARD>(g, tm, tn, lds, lds + 2 * A_TILE, kbeg, klen, (size_t)blockIdx.y * g.c_split_stride);
+    w8_tile<PRE, TA, TB, EPI, false>(g, tm, tn, lds, lds + 2 * A_TILE, kbeg, klen, (size_t)blockIdx.y * g.c_split_stride);
+}
+// the guarded tile (any shape).  Four waves per SIMD (two blocks per CU) are asked for explicitly: the edge bookkeeping would otherwise push the kernel a
+// couple of registers over the 128 that four waves per SIMD allow (one block per CU: 59.5 instead of 63.8 TFLOP/s at 8200^3).
+template <bool PRE, bool TA = false, int EPI = 0>
+__global__ void __launch_bounds__(512, 4) k_dgemm_w8g(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    unsigned tm, tn;
+    tile_of_block(g, tm, tn);
+    const unsigned kbeg = blockIdx.y * g.k_chunk;
+    const unsigned klen = (g.k - kbeg) < g.k_chunk ? (g.k - kbeg) : g.k_chunk;
+    w8_tile<PRE, TA, false, EPI, true>(g, tm, tn, lds, lds + 2 * A_TILE, kbeg, klen, (size_t)blockIdx.y * g.c_split_stride);
 }
 
 // Persistent form for the look-ahead LU's late phase: one workgroup per CU, tiles handed out by a counter, and workgroups
@@ -948,13 +977,12 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
         small_force = std::getenv("RMHIP_GEMM_SMALL_FORCE") ? std::atol(std::getenv("RMHIP_GEMM_SMALL_FORCE")) : 0;
         small_pad = std::getenv("RMHIP_GEMM_SMALL_PAD") ? std::atol(std::getenv("RMHIP_GEMM_SMALL_PAD")) : 0;
     }
-    // shapes that are not whole tiles run the same kernels with clamped operand loads, a zeroed k tail and checked stores (GUARD): what
-    // they still need is 16-byte accesses - aligned bases, even leading dimensions, an even k, an even m for a plain A.
-    // RMHIP_GEMM_GUARD=0 sends them to the element-checking k_dgemm as before.
+    // shapes that are not whole tiles - any m, n, k, leading dimensions, 8-byte aligned bases - run the same kernels with clamped
+    // operand loads, a zeroed k tail and checked stores (GUARD).  RMHIP_GEMM_GUARD=0 sends them to the element-checking k_dgemm as
+    // before (which keeps A * B' and the epilogue of a transposed product).
     static const int guard_on = std::getenv("RMHIP_GEMM_GUARD") ? std::atoi(std::getenv("RMHIP_GEMM_GUARD")) : 1;
     const bool vec_ok = (lda % 2 == 0) && (ldb % 2 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
-    const bool guard_ok = guard_on && vec_ok && !tb && k >= 2 && k % 2 == 0 && (ta || (m >= 2 && m % 2 == 0)) && !c->in_lookahead &&
-                          c->gemm_lds_pad == 0;
+    const bool guard_ok = guard_on && !tb && k >= 1 && !c->in_lookahead && c->gemm_lds_pad == 0;
     const bool small_shape = !ep && !ta && !tb && splits == 1 && (c->gemm_lds_pad == 0 || small_force) && k > 0 && (k <= 1024 || small_force) &&
                              ((size_t)blocks * 2 <= (size_t)c->num_cus || small_force);
     const bool small_whole = (m % SM == 0) && (n % SN == 0) && (k % BK == 0) && vec_ok;
@@ -1053,20 +1081,20 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
     if (!fast && guard_ok && w8_mode != 0 && (splits == 1 || g.k_chunk % BK == 0) && !(ep && ta)) {
         // guarded eight-wave tile (plain or transposed A; plain, preloaded-C or epilogue store; split-K slices are whole tiles except the last)
         const dim3 ggrid(blocks, splits);
-#define RMHIP_W8G(...)                                                                        \
-    do {                                                                                      \
-        c->ensure_max_lds((const void*)k_dgemm_w8<__VA_ARGS__>, kMaxLds);                     \
-        hipLaunchKernelGGL((k_dgemm_w8<__VA_ARGS__>), ggrid, dim3(512), lds_bytes, c->stream, g); \
+#define RMHIP_W8G(...)                                                                         \
+    do {                                                                                       \
+        c->ensure_max_lds((const void*)k_dgemm_w8g<__VA_ARGS__>, kMaxLds);                     \
+        hipLaunchKernelGGL((k_dgemm_w8g<__VA_ARGS__>), ggrid, dim3(512), lds_bytes, c->stream, g); \
     } while (0)
         if (ep) {
-            if (g.ep.flags & EP_POW) RMHIP_W8G(false, false, false, 2, true);
-            else RMHIP_W8G(false, false, false, 1, true);
+            if (g.ep.flags & EP_POW) RMHIP_W8G(false, false, 2);
+            else RMHIP_W8G(false, false, 1);
         } else if (ta) {
-            RMHIP_W8G(false, true, false, 0, true);
+            RMHIP_W8G(false, true, 0);
         } else if (preload) {
-            RMHIP_W8G(true, false, false, 0, true);
+            RMHIP_W8G(true, false, 0);
         } else {
-            RMHIP_W8G(false, false, false, 0, true);
+            RMHIP_W8G(false, false, 0);
         }
 #undef RMHIP_W8G
         c->tel.kernel_launches++;

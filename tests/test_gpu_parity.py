@@ -482,11 +482,13 @@ def test_matmul_reference_kats_exact(prov):
 
 
 @pytest.mark.parametrize("m,k,n", [(2, 2, 2), (130, 66, 258), (258, 130, 70), (64, 1030, 200), (384, 2050, 130), (1000, 1000, 1000),
-                                   (6, 18, 3), (640, 48, 1290), (256, 9000, 128)])
-def test_matmul_ragged_even_shapes(prov, oracle, m, k, n):
-    """Shapes that are not whole tiles but have even m and k run the tile kernels with clamped operand loads, a zeroed k tail and
-    checked stores (dgemm.hip, GUARD): the 64 x 64 kernel for few tiles and k <= 1024, the eight-wave kernel otherwise - plain,
-    A' * B, C <- C - A * B on a view (preloaded C) and the epilogue store.  Neighbouring memory must stay untouched."""
+                                   (6, 18, 3), (640, 48, 1290), (256, 9000, 128), (1, 1, 1), (3, 5, 7), (131, 67, 259), (257, 1031, 129),
+                                   (999, 1001, 997), (129, 17, 1), (1, 4097, 255)])
+def test_matmul_ragged_shapes(prov, oracle, m, k, n):
+    """Shapes that are not whole tiles - odd m, n, k and leading dimensions included - run the tile kernels with clamped operand
+    loads, scalar loads for the pairs that straddle the matrix edge, a zeroed k tail and checked stores (dgemm.hip, GUARD): the
+    64 x 64 kernel for few tiles and k <= 1024, the eight-wave kernel otherwise - plain, A' * B, C <- C - A * B on a view
+    (preloaded C) and the epilogue store.  Neighbouring memory must stay untouched."""
     rng = np.random.default_rng(m * 7 + k * 3 + n)
     A, B = rng.uniform(-1, 1, (m, k)), rng.uniform(-1, 1, (k, n))
     want = A @ B if m * n * k > 3e7 else oracle.matmul(A, B)
