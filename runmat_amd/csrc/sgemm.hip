@@ -20,6 +20,7 @@ namespace rmhip {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef v2f v2fu __attribute__((aligned(4)));  // the same pair on a 4-byte aligned address (guarded kernel)
 
 namespace sg {
 static constexpr int BM = 128, BN = 128, BK = 16;
@@ -220,10 +221,12 @@ __global__ void __launch_bounds__(256, SGEMM_BLOCKS_PER_CU) k_sgemm(const SgemmA
 // Same k-ordered chain per element as k_sgemm: bit-identical results.
 // (86 VGPRs: five waves per SIMD by registers, four - two blocks per CU - by LDS.  Capped at 80 for a third block it spills and
 // runs 122 instead of 136 TFLOP/s.)
-template <bool TA>  // TA: A is stored transposed (k contiguous per tile row), staged with B's pattern as in k_sgemm
-__global__ void __launch_bounds__(512) k_sgemm_w8(const SgemmArgs g) {
+// GUARD (k_sgemm_w8g): any m, n, k, leading dimensions, 4-byte aligned bases - as the guarded f64 tile (dgemm.hip: w8_tile): rows / columns
+// beyond the matrix re-read its last ones, 8-byte loads on 4-byte aligned addresses, scalar loads for the pairs that straddle the
+// matrix edge (in the hot loop only in blocks on the lower edge of an odd m), a zero k tail in the last tile, checked stores.
+template <bool TA, bool GUARD>  // TA: A is stored transposed (k contiguous per tile row), staged with B's pattern as in k_sgemm
+__device__ __forceinline__ void sgemm_w8_body(const SgemmArgs& g, float* lds) {
     using namespace sg;
-    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];
     float* As = lds;
     float* Bs = lds + 2 * TILE;
     unsigned tm, tn;
@@ -234,14 +237,43 @@ __global__ void __launch_bounds__(512) k_sgemm_w8(const SgemmArgs g) {
     const int l15 = lane & 15, lq = lane >> 4;
     const int p_xp = t & 63, p_kc = t >> 6;  // A (pattern M): pair along m, k = p_kc + 8*p
     const int q_kp = t & 7, q_y = t >> 3;    // B (pattern K): pair along k, y = q_y + 64*p
-    const float* const Ap = TA ? g.A + (size_t)m0 * g.lda + 2 * q_kp : g.A + m0 + 2 * p_xp;
-    const float* const Bp = g.B + (size_t)n0 * g.ldb + 2 * q_kp;
+    auto rowY = [&](unsigned r, unsigned lim) { return (GUARD && r >= lim) ? lim - 1 : r; };
+    const unsigned a_r0 = rowY(m0 + 2 * p_xp, g.m);
+    const bool a_single = GUARD && !TA && a_r0 + 1 >= g.m;            // the matrix's last row alone (odd m) or a clamped pair
+    const bool a_edge = GUARD && !TA && (g.m & 1u) && m0 + BM > g.m;  // uniform: such threads exist in this block
+    const float* const Ap = TA ? g.A + 2 * q_kp : g.A + a_r0;
+    const float* const Bp = g.B + 2 * q_kp;
+    size_t a_row[2], b_row[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        a_row[p] = (size_t)rowY(m0 + q_y + 64 * p, g.m) * g.lda;
+        b_row[p] = (size_t)rowY(n0 + q_y + 64 * p, g.n) * g.ldb;
+    }
+    auto ld2 = [&](const float* q) -> v2f { return GUARD ? (v2f)(*(const v2fu*)q) : *(const v2f*)q; };
+    auto ldM = [&](const float* q) -> v2f {
+        if (a_edge && a_single) return v2f{*q, 0.f};
+        return ld2(q);
+    };
     v2f ra[2], rb[2], ra2[2], rb2[2];
     auto fetch_into = [&](unsigned k0, v2f* pa, v2f* pb) {
+        if (GUARD && k0 + BK > g.k) {  // the last, partial k tile (uniform)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const unsigned km = k0 + p_kc + 8 * p, kp = k0 + 2 * q_kp;
+                auto ldK = [&](const float* pair) -> v2f {
+                    if (kp + 1 < g.k) return ld2(pair);
+                    if (kp < g.k) return v2f{*pair, 0.f};
+                    return v2f{0.f, 0.f};
+                };
+                pa[p] = TA ? ldK(Ap + a_row[p] + k0) : (km < g.k ? ldM(Ap + (size_t)km * g.lda) : v2f{0.f, 0.f});
+                pb[p] = ldK(Bp + b_row[p] + k0);
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            pa[p] = TA ? *(const v2f*)(Ap + (size_t)(q_y + 64 * p) * g.lda + k0) : *(const v2f*)(Ap + (size_t)(k0 + p_kc + 8 * p) * g.lda);
-            pb[p] = *(const v2f*)(Bp + (size_t)(q_y + 64 * p) * g.ldb + k0);
+            pa[p] = TA ? ld2(Ap + a_row[p] + k0) : ldM(Ap + (size_t)(k0 + p_kc + 8 * p) * g.lda);
+            pb[p] = ld2(Bp + b_row[p] + k0);
         }
     };
     auto stash_from = [&](int buf, const v2f* pa, const v2f* pb) {
@@ -257,7 +289,7 @@ __global__ void __launch_bounds__(512) k_sgemm_w8(const SgemmArgs g) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = v4f{0.f, 0.f, 0.f, 0.f};
-    const unsigned ktiles = g.k / BK;
+    const unsigned ktiles = GUARD ? (g.k + BK - 1) / BK : g.k / BK;
     auto clampt = [&](unsigned tt) { return (tt < ktiles ? tt : ktiles - 1) * BK; };
     fetch_into(0, ra, rb);
     stash_from(0, ra, rb);
@@ -329,9 +361,19 @@ __global__ void __launch_bounds__(512) k_sgemm_w8(const SgemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const unsigned nn = n0 + wn * 32 + j * 16 + 4 * lq + r;
-                g.C[(size_t)nn * g.ldc + mm] = acc[j][i][r];
+                if (!GUARD || (mm < g.m && nn < g.n)) g.C[(size_t)nn * g.ldc + mm] = acc[j][i][r];
             }
         }
+}
+template <bool TA>
+__global__ void __launch_bounds__(512) k_sgemm_w8(const SgemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * sg::TILE];
+    sgemm_w8_body<TA, false>(g, lds);
+}
+template <bool TA>
+__global__ void __launch_bounds__(512, 4) k_sgemm_w8g(const SgemmArgs g) {  // four waves per SIMD = two blocks per CU, as the plain form
+    __shared__ __attribute__((aligned(16))) float lds[4 * sg::TILE];
+    sgemm_w8_body<TA, true>(g, lds);
 }
 
 template <bool EDGE, bool TA, bool TB>
@@ -394,8 +436,18 @@ int launch_sgemm_trans(Context* c, bool ta, bool tb, size_t m, size_t n, size_t 
         }
     }
     const bool fast_k = fast && (splits == 1 || k % g.k_chunk == 0);
+    // shapes that are not whole tiles: the guarded eight-wave tile (RMHIP_GEMM_GUARD=0: the element-checking k_sgemm as before)
+    static const int guard_on = std::getenv("RMHIP_GEMM_GUARD") ? std::atoi(std::getenv("RMHIP_GEMM_GUARD")) : 1;
+    const bool w8_env_off = std::getenv("RMHIP_SGEMM_W8") && *std::getenv("RMHIP_SGEMM_W8") == '0';
+    if (!fast && guard_on && !w8_env_off && !tb && splits == 1 && k >= 1) {
+        if (ta) hipLaunchKernelGGL(k_sgemm_w8g<true>, dim3(blocks), dim3(512), 0, c->stream, g);
+        else hipLaunchKernelGGL(k_sgemm_w8g<false>, dim3(blocks), dim3(512), 0, c->stream, g);
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+        return RMHIP_OK;
+    }
     if (ta) {
-        if (fast_k && splits == 1 && !(std::getenv("RMHIP_SGEMM_W8") && *std::getenv("RMHIP_SGEMM_W8") == '0'))
+        if (fast_k && splits == 1 && !w8_env_off)
             hipLaunchKernelGGL(k_sgemm_w8<true>, dim3(blocks), dim3(512), 0, c->stream, g);  // A' * B (syrk, covariance, transpose views)
         else if (fast_k) sg_launch<false, true, false>(c, blocks, splits, g);
         else sg_launch<true, true, false>(c, blocks, splits, g);

@@ -4,7 +4,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from runmat_amd import HipProvider
 
-prov = HipProvider(0)
+F32 = os.environ.get("GEMM_F32") == "1"  # GEMM_F32=1: precision-32 provider (f32 storage, f32 matrix cores)
+prov = HipProvider(0, precision="F32") if F32 else HipProvider(0)
 
 
 def rate(m, n, k, reps=4):
