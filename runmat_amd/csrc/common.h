@@ -324,6 +324,7 @@ int trsm_lower_nonunit_device(Context* c, const double* T, size_t ldt, size_t w,
 int transpose_device(Context* c, const double* src, size_t lds_, size_t rows, size_t cols, double* dst, size_t ldd);
 int transpose_device_f32(Context* c, const float* src, size_t lds_, size_t rows, size_t cols, float* dst, size_t ldd);
 int diag_stats_device(Context* c, const double* A, size_t lda, size_t n, double* min_abs, double* max_abs, size_t* zeros);
+int lu_pad_identity_device(Context* c, double* W, size_t ldw, size_t n, size_t np);
 int lu_solve_device(Context* c, const double* LU, size_t n, size_t lda, const int* perm_dev,
                     const double* B, size_t nrhs, size_t ldb, double* X, size_t ldx);
 int lu_extract_device(Context* c, const double* LU, size_t rows, size_t cols, const int* perm_dev,

@@ -982,7 +982,8 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
     // before (which keeps A * B' and the epilogue of a transposed product).
     static const int guard_on = std::getenv("RMHIP_GEMM_GUARD") ? std::atoi(std::getenv("RMHIP_GEMM_GUARD")) : 1;
     const bool vec_ok = (lda % 2 == 0) && (ldb % 2 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
-    const bool guard_ok = guard_on && !tb && k >= 1 && !c->in_lookahead && c->gemm_lds_pad == 0;
+    static const int guard_lu = std::getenv("RMHIP_GEMM_GUARD_LU") ? std::atoi(std::getenv("RMHIP_GEMM_GUARD_LU")) : 1;  // A/B: guarded tiles inside the look-ahead LU
+    const bool guard_ok = guard_on && !tb && k >= 1 && (guard_lu || (!c->in_lookahead && c->gemm_lds_pad == 0));
     const bool small_shape = !ep && !ta && !tb && splits == 1 && (c->gemm_lds_pad == 0 || small_force) && k > 0 && (k <= 1024 || small_force) &&
                              ((size_t)blocks * 2 <= (size_t)c->num_cus || small_force);
     const bool small_whole = (m % SM == 0) && (n % SN == 0) && (k % BK == 0) && vec_ok;
@@ -1078,7 +1079,8 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
         RMHIP_HIP_CHECK(hipGetLastError());
         return RMHIP_OK;
     }
-    if (!fast && guard_ok && w8_mode != 0 && (splits == 1 || g.k_chunk % BK == 0) && !(ep && ta)) {
+    // (inside the look-ahead LU only the update stream - the one with the LDS pad - runs eight-wave blocks, as for whole tiles)
+    if (!fast && guard_ok && w8_mode != 0 && (splits == 1 || g.k_chunk % BK == 0) && !(ep && ta) && (c->gemm_lds_pad != 0 || !c->in_lookahead)) {
         // guarded eight-wave tile (plain or transposed A; plain, preloaded-C or epilogue store; split-K slices are whole tiles except the last)
         const dim3 ggrid(blocks, splits);
 #define RMHIP_W8G(...)                                                                         \

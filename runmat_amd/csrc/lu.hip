@@ -2950,6 +2950,29 @@ static int substitute_few_rhs(Context* c, const double* LU, size_t n, size_t lda
     return RMHIP_OK;
 }
 
+// W (np x np, ld ldw) holds an n x n matrix in its top-left corner: make the rest [0; 0 I] - the padded system [A 0; 0 I] has the
+// factors of A in its leading block, the padded rows are never chosen as pivots for A's columns (zeros there) and the padded
+// unknowns come out zero.  Used by the solves for n that is not a multiple of 128 (rmhip_ops.cpp: lu_pad_rows).
+__global__ void __launch_bounds__(256) k_lu_pad_identity(double* __restrict__ W, size_t ldw, size_t n, size_t np) {
+    const size_t pad = np - n;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // row 0 .. np-1
+    const size_t j = blockIdx.y;                               // 0 .. np-1: columns < n get their rows >= n, columns >= n whole
+    if (i >= np || j >= np) return;
+    if (j < n) {
+        if (i < pad) W[(n + i) + j * ldw] = 0.0;
+    } else {
+        W[i + j * ldw] = (i == j) ? 1.0 : 0.0;
+    }
+}
+int lu_pad_identity_device(Context* c, double* W, size_t ldw, size_t n, size_t np) {
+    if (np <= n) return RMHIP_OK;
+    if (np > 65535) {  // blockIdx.y
+        return fail(RMHIP_ERR_UNSUPPORTED, "lu padding: dimension %zu too large", np);
+    }
+    hipLaunchKernelGGL(k_lu_pad_identity, dim3((unsigned)((np + 255) / 256), (unsigned)np), dim3(256), 0, c->stream, W, ldw, n, np);
+    return launch_check(c);
+}
+
 // X = U^-1 L^-1 (P B) for square LU (n x n).
 int lu_solve_device(Context* c, const double* LU, size_t n, size_t lda, const int* perm_dev, const double* B,
                     size_t nrhs, size_t ldb, double* X, size_t ldx) {

@@ -35,8 +35,9 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // Copy `src` (rows x cols, dense) into the padded workspace and factor it; when the persistent panel kernels
 // report that their workgroups were not co-resident the copy is refreshed and factored conservatively.
+// pad_n > rows (square systems on the solve path): factor [A 0; 0 I] of order pad_n instead - see lu_pad_rows
 static int lu_copy_and_factor(Context* c, const double* src, size_t rows, size_t cols, double* work, size_t ldw, int* perm,
-                              int* info, bool solve_path = false) {
+                              int* info, bool solve_path = false, size_t pad_n = 0) {
     // solve_path: the caller only needs SOME stable factorisation (mldivide / linsolve / mrdivide: the pivots never leave the provider),
     // so the first attempt restricts pivoting to each panel's top block and checks the multipliers (lu.hip, k_rp_below); when that
     // check fails the copy is refreshed and factored with the reference's grid-wide rule.
@@ -49,7 +50,9 @@ static int lu_copy_and_factor(Context* c, const double* src, size_t rows, size_t
                                             hipMemcpyDeviceToDevice, c->stream);
             if (e != hipSuccess) return fail(RMHIP_ERR_HIP, "lu copy: %s", hipGetErrorString(e));
         }
-        const int rc = lu_factor_device(c, work, rows, cols, ldw, perm, info, nullptr, mode);
+        const bool padded = pad_n > rows && rows == cols;
+        if (padded) RMHIP_TRY(lu_pad_identity_device(c, work, ldw, rows, pad_n));
+        const int rc = lu_factor_device(c, work, padded ? pad_n : rows, padded ? pad_n : cols, ldw, perm, info, nullptr, mode);
         if (rc == RMHIP_LU_GROWTH) {
             mode = 0;
             c->lu_growth_fallbacks++;
@@ -65,6 +68,30 @@ static int lu_copy_and_factor(Context* c, const double* src, size_t rows, size_t
 }
 
 size_t lu_padded_ld(size_t rows) { return rows >= 256 ? ((rows + 1) & ~(size_t)1) + 32 : ((rows + 1) & ~(size_t)1); }
+
+// Order the solves factor at.  The blocked driver's trailing updates are whole 128 x 128 x 16 tiles only when n is a multiple of
+// 128; otherwise EVERY update of the factorisation runs a guarded kernel (n = 10000: 37.0 ms against 31.7 at 10240, n = 13001: 55.6
+// against 47.2 at 13056).  The solves therefore factor [A 0; 0 I] at the next multiple of 128 - 2-4 % more flops, all of them on
+// the fast kernels - and drop the padded unknowns (zero).  `lu` itself returns factors of the order it was given.
+// RMHIP_LU_PAD=0 disables.
+static size_t lu_pad_rows(size_t n) {
+    const char* v = std::getenv("RMHIP_LU_PAD");  // read per call: the tests compare both forms
+    if ((v && *v == '0') || n < 2048 || n % 128 == 0) return n;
+    const size_t np = (n + 127) / 128 * 128;
+    return np <= 65535 ? np : n;
+}
+// X (n x nrhs, ld n) = A^-1 B from factors of order np >= n (np > n: the padded system)
+static int lu_solve_padded(Context* c, const double* LU, size_t n, size_t np, size_t ldw, const int* perm, const double* B, size_t nrhs, double* X) {
+    if (np == n) return lu_solve_device(c, LU, n, ldw, perm, B, nrhs, n, X, n);
+    std::shared_ptr<Allocation> bp, xp;
+    RMHIP_TRY(c->alloc_device(np * nrhs, &bp));
+    RMHIP_TRY(c->alloc_device(np * nrhs, &xp));
+    RMHIP_HIP_CHECK(hipMemsetAsync(bp->ptr, 0, sizeof(double) * np * nrhs, c->stream));
+    RMHIP_HIP_CHECK(hipMemcpy2DAsync(bp->ptr, np * sizeof(double), B, n * sizeof(double), n * sizeof(double), nrhs, hipMemcpyDeviceToDevice, c->stream));
+    RMHIP_TRY(lu_solve_device(c, LU, np, ldw, perm, bp->ptr, nrhs, np, xp->ptr, np));
+    RMHIP_HIP_CHECK(hipMemcpy2DAsync(X, n * sizeof(double), xp->ptr, np * sizeof(double), n * sizeof(double), nrhs, hipMemcpyDeviceToDevice, c->stream));
+    return RMHIP_OK;
+}
 
 // Precision-32 contexts: fetch an operand for a kernel that has an f32-storage variant.  `*native` stays true while
 // every operand so far is plain f32 storage; otherwise the caller falls back to widened f64 copies (Context::get).
@@ -1131,14 +1158,15 @@ static int mldivide_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, r
     // Factorisation workspace with a PADDED leading dimension: with lda a large power of two every
     // element of a row maps to the same HBM channel / L2 slice, and the panel kernels (one lane per
     // row, walking across columns) serialise on it; +32 doubles rotates the channel per column.
-    const size_t ldw = lu_padded_ld(n);
+    const size_t np = lu_pad_rows(n);  // order of the factorisation (the next multiple of 128 for a large ragged n)
+    const size_t ldw = lu_padded_ld(np);
     std::shared_ptr<Allocation> work;
-    RMHIP_TRY(c->alloc_device(ldw * n, &work));
+    RMHIP_TRY(c->alloc_device(ldw * np, &work));
     std::shared_ptr<Allocation> perm_mem;  // pooled, released in stream order
-    RMHIP_TRY(c->alloc_device((n + 2) / 2 + 1, &perm_mem));
+    RMHIP_TRY(c->alloc_device((np + 2) / 2 + 1, &perm_mem));
     int* perm = (int*)perm_mem->ptr;
     int info = 0;
-    int rc = lu_copy_and_factor(c, ab.data(), n, n, work->ptr, ldw, perm, &info, true);
+    int rc = lu_copy_and_factor(c, ab.data(), n, n, work->ptr, ldw, perm, &info, true, np);
     if (!rc && info > 0) {
         rc = fail(RMHIP_ERR_SINGULAR, "mldivide: %d pivot(s) <= 1e-12; matrix is numerically singular, use the CPU SVD path", info);
         if (nrhs) return svd_fallback(ctx, c, rc, ab.data(), n, n, bb.data(), nrhs, out);  // n <= 1024: the SVD answer on the device
@@ -1157,7 +1185,7 @@ static int mldivide_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, r
     rmhip_buf oid = 0;
     const size_t oshape[2] = {n, nrhs};
     if (!rc) rc = c->new_buffer(oshape, 2, &oid, &ob);
-    if (!rc) rc = lu_solve_device(c, work->ptr, n, ldw, perm, bb.data(), nrhs, n, ob.data(), n);
+    if (!rc) rc = lu_solve_padded(c, work->ptr, n, np, ldw, perm, bb.data(), nrhs, ob.data());
     if (rc) {
         if (oid) rmhip_free(ctx, oid);
         return rc;
@@ -1256,14 +1284,15 @@ static int linsolve_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, c
         if (!rc)
             rc = lower ? trsm_lower_nonunit_device(c, A, n, n, ob.data(), n, nrhs) : trsm_upper_device(c, A, n, n, ob.data(), n, nrhs);
     } else {
-        const size_t ldw = lu_padded_ld(n);
+        const size_t np = lu_pad_rows(n);
+        const size_t ldw = lu_padded_ld(np);
         std::shared_ptr<Allocation> work;
-        RMHIP_TRY(c->alloc_device(ldw * n, &work));
+        RMHIP_TRY(c->alloc_device(ldw * np, &work));
         std::shared_ptr<Allocation> perm_mem;
-        RMHIP_TRY(c->alloc_device((n + 2) / 2 + 1, &perm_mem));
+        RMHIP_TRY(c->alloc_device((np + 2) / 2 + 1, &perm_mem));
         int* perm = (int*)perm_mem->ptr;
         int info = 0;
-        rc = lu_copy_and_factor(c, A, n, n, work->ptr, ldw, perm, &info, true);
+        rc = lu_copy_and_factor(c, A, n, n, work->ptr, ldw, perm, &info, true, np);
         if (!rc && info > 0) {
             rc = fail(RMHIP_ERR_SINGULAR, "linsolve: %d pivot(s) <= 1e-12; use the CPU SVD path", info);
             if (nrhs) {
@@ -1276,7 +1305,7 @@ static int linsolve_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, c
             }
         }
         if (!rc) rc = c->new_buffer(oshape, 2, &oid, &ob);
-        if (!rc) rc = lu_solve_device(c, work->ptr, n, ldw, perm, bb.data(), nrhs, n, ob.data(), n);
+        if (!rc) rc = lu_solve_padded(c, work->ptr, n, np, ldw, perm, bb.data(), nrhs, ob.data());
     }
     if (at) (void)hipStreamSynchronize(c->stream);  // the transposed copy is released on return
     if (rc) {

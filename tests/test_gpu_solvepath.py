@@ -86,6 +86,29 @@ def test_solve_path_matches_partial_pivoting_quality(prov, kind, n):
         assert np.max(np.abs(x - 1.0)) <= 50.0 * max(np.max(np.abs(y - 1.0)), 1e-7)
 
 
+@pytest.mark.parametrize("n,nrhs", [(2100, 1), (4100, 3), (5001, 2)])
+def test_ragged_orders_factor_at_the_padded_order(prov, n, nrhs):
+    """n >= 2048 that is not a multiple of 128: the solves factor [A 0; 0 I] at the next multiple (every trailing update a whole
+    tile; rmhip_ops.cpp: lu_pad_rows).  The padded rows hold zeros in A's columns and are never chosen as pivots; the solution agrees
+    with the unpadded factorisation's (RMHIP_LU_PAD=0) to rounding - the panel boundaries, hence the grouping of the updates, depend
+    on the order - and has the same backward error; linsolve and mrdivide take the same route."""
+    rng = np.random.default_rng(n)
+    A = rng.uniform(-1, 1, (n, n))
+    B = rng.uniform(-1, 1, (n, nrhs))
+    hA, hB = prov.upload(A), prov.upload(B)
+    x1 = prov.download_matrix(prov.mldivide(hA, hB))
+    with env(RMHIP_LU_PAD="0"):
+        x0 = prov.download_matrix(prov.mldivide(hA, hB))
+    assert x1.shape == (n, nrhs) and np.max(np.abs(x0 - x1)) <= 1e-9 * max(1.0, np.abs(x1).max())
+    for j in range(nrhs):
+        assert _backward_error(A, x1[:, j], B[:, j]) <= 64 * n * 2.3e-16 and _backward_error(A, x0[:, j], B[:, j]) <= 64 * n * 2.3e-16
+    xl = prov.download_matrix(prov.linsolve(hA, hB).solution)
+    assert np.array_equal(xl, x1)
+    Bt = np.ascontiguousarray(B.T)
+    xr = prov.download_matrix(prov.mrdivide(prov.upload(Bt), prov.upload(np.ascontiguousarray(A.T))))  # B' / A' = (A \ B)'
+    assert xr.shape == (nrhs, n) and np.max(np.abs(xr.T - x1)) <= 1e-9 * max(1.0, np.abs(x1).max())
+
+
 def test_wilkinson_growth_matrix(prov):
     """Wilkinson's matrix (1 on the diagonal and in the last column, -1 below the diagonal) doubles the last column at every
     step under partial pivoting: growth 2^(n-1).  Every multiplier is exactly 1, so the solve path accepts it - and must then
