@@ -213,8 +213,16 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_contig(const double* __restrict
 // the same with 16-byte loads (even `red`, 16-byte aligned base: every slice starts on a pair) and the next batch requested before
 // the current one is folded - the fold of an arg accumulator is a chain of dependent compare / selects during which a wave would
 // otherwise have nothing in flight.  A thread's elements still arrive in ascending index order.
+// ODD: odd `red` or an element-aligned base - the pairs are loaded from 8-byte aligned addresses and the slice's last element is folded
+// by the thread whose walk ends at its pair index (still ascending within the thread).
 typedef double r2_d2 __attribute__((ext_vector_type(2)));
-template <class Acc>
+typedef r2_d2 r2_d2u __attribute__((aligned(8)));
+template <bool ODD>
+__device__ __forceinline__ r2_d2 r2_ld2(const r2_d2* p) {
+    if constexpr (ODD) return (r2_d2)__builtin_nontemporal_load(reinterpret_cast<const r2_d2u*>(p));
+    else return __builtin_nontemporal_load(p);
+}
+template <class Acc, bool ODD = false>
 __global__ void __launch_bounds__(R2_BLOCK) k_r2_contig_v2(const double* __restrict__ x, u64 red, u64 nslices, u64 nsplit, Acc* __restrict__ part) {
     __shared__ Acc lds[R2_BLOCK];
     const u64 slice = blockIdx.y + (u64)gridDim.y * blockIdx.z;
@@ -233,10 +241,10 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_contig_v2(const double* __restr
     if (r + (U - 1) * R2_BLOCK < end) {
         r2_d2 cur[U], nxt[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = __builtin_nontemporal_load(xs + r + u * R2_BLOCK);
+        for (int u = 0; u < U; ++u) cur[u] = r2_ld2<ODD>(xs + r + u * R2_BLOCK);
         for (; r + (2 * U - 1) * R2_BLOCK < end; r += U * R2_BLOCK) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) nxt[u] = __builtin_nontemporal_load(xs + r + (U + u) * R2_BLOCK);
+            for (int u = 0; u < U; ++u) nxt[u] = r2_ld2<ODD>(xs + r + (U + u) * R2_BLOCK);
             {
                 u64 k[8];
                 double w[8];
@@ -267,9 +275,13 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_contig_v2(const double* __restr
         r += U * R2_BLOCK;
     }
     for (; r < end; r += R2_BLOCK) {
-        const r2_d2 v = __builtin_nontemporal_load(xs + r);
+        const r2_d2 v = r2_ld2<ODD>(xs + r);
         a.add(2 * r, v.x);
         a.add(2 * r + 1, v.y);
+    }
+    if constexpr (ODD) {  // the leftover element of an odd slice: owned by the chunk that contains pair index red2
+        const u64 owner = red2 / chunk < nsplit - 1 ? red2 / chunk : nsplit - 1;
+        if ((red & 1) && split == owner && r == red2) a.add(red - 1, __builtin_nontemporal_load(x + slice * red + red - 1));
     }
     lds[threadIdx.x] = a;
     __syncthreads();
@@ -321,17 +333,24 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_strided(const double* __restric
 
 // the same with 16-byte loads: a thread owns two adjacent lines (even `pre`, 16-byte aligned base).  As for sum(x,2)
 // (reduce_kernels.hip) what decides the rate of these lock-step column walks is the number of blocks: three per CU.
-template <class Acc>
+// ODD: odd `pre` (or an element-aligned base): unaligned pairs, the last line alone in its pair.
+template <class Acc, bool ODD = false>
 __global__ void __launch_bounds__(R2_BLOCK) k_r2_strided_v2(const double* __restrict__ x, u64 pre, u64 red, u64 nsplit, unsigned win,
                                                             Acc* __restrict__ part) {
-    const u64 i2 = (u64)blockIdx.x * win + threadIdx.x, pre2 = pre >> 1;  // balanced windows, their number a multiple of the XCD count (run_r2)
+    const u64 i2 = (u64)blockIdx.x * win + threadIdx.x, pre2 = ODD ? (pre + 1) >> 1 : pre >> 1;  // balanced windows, their number a multiple of the XCD count (run_r2)
     if (threadIdx.x >= win || i2 >= pre2) return;
+    const bool single = ODD && 2 * i2 + 1 >= pre;
     const u64 split = blockIdx.y, j = blockIdx.z;
     const u64 chunk = (red + nsplit - 1) / nsplit;
     const u64 begin = split * chunk;
     u64 end = begin + chunk;
     if (end > red) end = red;
-    const r2_d2* xs = reinterpret_cast<const r2_d2*>(x) + i2 + pre2 * red * j;
+    const double* const xo = x + 2 * i2 + pre * red * j;  // element offsets: with an odd `pre` the lines alternate between 16- and 8-byte alignment
+    auto ldp = [&](u64 rr) -> r2_d2 {
+        const double* q = xo + pre * rr;
+        if (ODD && single) return r2_d2{__builtin_nontemporal_load(q), 0.0};
+        return r2_ld2<ODD>(reinterpret_cast<const r2_d2*>(q));
+    };
     Acc a0, a1;
     a0.init();
     a1.init();
@@ -339,10 +358,10 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_strided_v2(const double* __rest
     if (r + 8 <= end) {  // two batches in flight: the next one is requested before the current one is folded
         r2_d2 cur[8], nxt[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cur[u] = __builtin_nontemporal_load(xs + pre2 * (r + u));
+        for (int u = 0; u < 8; ++u) cur[u] = ldp(r + u);
         for (; r + 16 <= end; r += 8) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) nxt[u] = __builtin_nontemporal_load(xs + pre2 * (r + 8 + u));
+            for (int u = 0; u < 8; ++u) nxt[u] = ldp(r + 8 + u);
             {
                 u64 k[8];
                 double w0[8], w1[8];
@@ -353,7 +372,7 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_strided_v2(const double* __rest
                     w1[u] = cur[u].y;
                 }
                 r2_fold8(a0, k, w0);
-                r2_fold8(a1, k, w1);
+                if (!single) r2_fold8(a1, k, w1);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
@@ -368,7 +387,7 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_strided_v2(const double* __rest
                 w1[u] = cur[u].y;
             }
             r2_fold8(a0, k, w0);
-            r2_fold8(a1, k, w1);
+            if (!single) r2_fold8(a1, k, w1);
         }
         r += 8;
     }
@@ -376,17 +395,17 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_strided_v2(const double* __rest
         r2_d2 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (r + u < end) v[u] = __builtin_nontemporal_load(xs + pre2 * (r + u));
+            if (r + u < end) v[u] = ldp(r + u);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (r + u < end) {
                 a0.add(r + u, v[u].x);
-                a1.add(r + u, v[u].y);
+                if (!single) a1.add(r + u, v[u].y);
             }
     }
     const u64 line = 2 * i2 + pre * j;
     part[line * nsplit + split] = a0;
-    part[(line + 1) * nsplit + split] = a1;
+    if (!single) part[(line + 1) * nsplit + split] = a1;
 }
 
 // ---- stage 2: one wave per slice merges the chunks - lane l folds a contiguous run in chunk order, the 64 lane results merge in a
@@ -468,16 +487,18 @@ static int run_r2(Context* c, const double* x, size_t pre, size_t red, size_t po
     if (!p.valid) return fail(RMHIP_ERR_UNSUPPORTED, "%s: geometry [%zu,%zu,%zu] exceeds launch limits", what, pre, red, post);
     u64 nsplit = p.nsplit;
     unsigned gx = p.gx;
-    const bool wide = !p.contiguous && (pre & 1) == 0 && pre >= 512 && (((uintptr_t)x) & 15) == 0;
+    const bool wide = !p.contiguous && pre >= 512;
+    const bool wide_odd = wide && ((pre & 1) != 0 || (((uintptr_t)x) & 15) != 0);
     unsigned win = R2_BLOCK, threads = R2_BLOCK;
     if (!p.contiguous) {  // these kernels keep up to 256 threads along `pre`
-        gx = (unsigned)ceil_div_u64(wide ? pre / 2 : pre, R2_BLOCK);
+        const u64 npairs = (pre + 1) / 2;
+        gx = (unsigned)ceil_div_u64(wide ? npairs : pre, R2_BLOCK);
         if (wide) {  // as for sum(x,2) (reduce_kernels.hip): a window count that is a multiple of the XCD count pins every window to one XCD
             const unsigned xcds = c->num_xcc > 0 ? (unsigned)c->num_xcc : 8u;
             if (pre / 2 >= xcds * 64) gx = (gx + xcds - 1) / xcds * xcds;
-            win = (unsigned)((ceil_div_u64(pre / 2, gx) + 7) / 8 * 8);
+            win = (unsigned)((ceil_div_u64(npairs, gx) + 7) / 8 * 8);
             if (win > R2_BLOCK) win = R2_BLOCK;
-            gx = (unsigned)ceil_div_u64(pre / 2, win);
+            gx = (unsigned)ceil_div_u64(npairs, win);
             if (pre / 2 >= xcds * 64) gx = (gx + xcds - 1) / xcds * xcds;
             threads = (win + 63) / 64 * 64;
         }
@@ -492,8 +513,12 @@ static int run_r2(Context* c, const double* x, size_t pre, size_t red, size_t po
     Acc* part = reinterpret_cast<Acc*>(c->scratch);
     if (p.contiguous && (red & 1) == 0 && red >= 4 * R2_BLOCK && (((uintptr_t)x) & 15) == 0)
         hipLaunchKernelGGL((k_r2_contig_v2<Acc>), dim3((unsigned)nsplit, p.gy, p.gz), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices, nsplit, part);
+    else if (p.contiguous && red >= 4 * R2_BLOCK)  // odd slice length or element-aligned base
+        hipLaunchKernelGGL((k_r2_contig_v2<Acc, true>), dim3((unsigned)nsplit, p.gy, p.gz), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices, nsplit, part);
     else if (p.contiguous)
         hipLaunchKernelGGL((k_r2_contig<Acc>), dim3((unsigned)nsplit, p.gy, p.gz), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices, nsplit, part);
+    else if (wide_odd)
+        hipLaunchKernelGGL((k_r2_strided_v2<Acc, true>), dim3(gx, (unsigned)nsplit, (unsigned)post), dim3(threads), 0, c->stream, x, (u64)pre, (u64)red, nsplit, win, part);
     else if (wide)
         hipLaunchKernelGGL((k_r2_strided_v2<Acc>), dim3(gx, (unsigned)nsplit, (unsigned)post), dim3(threads), 0, c->stream, x, (u64)pre, (u64)red, nsplit, win, part);
     else

@@ -34,12 +34,28 @@ __device__ __forceinline__ rm_rv2 rm_load2(const float* x, rm_u64 i2) {
     rm_rv2 r = {(double)v.x, (double)v.y};
     return r;
 }
+typedef rm_rv2 rm_rv2u __attribute__((aligned(8)));
+typedef rm_rv2f rm_rv2fu __attribute__((aligned(4)));
+__device__ __forceinline__ rm_rv2 rm_load2_at(const double* p, bool single) {
+    if (single) return rm_rv2{__builtin_nontemporal_load(p), 0.0};
+    return (rm_rv2)__builtin_nontemporal_load((const rm_rv2u*)p);
+}
+__device__ __forceinline__ rm_rv2 rm_load2_at(const float* p, bool single) {
+    if (single) return rm_rv2{(double)__builtin_nontemporal_load(p), 0.0};
+    const rm_rv2f v = (rm_rv2f)__builtin_nontemporal_load((const rm_rv2fu*)p);
+    return rm_rv2{(double)v.x, (double)v.y};
+}
 template <class T>
 struct IdentityVal2 {
     const T* __restrict__ x;
     __device__ __forceinline__ rm_rv2 operator()(rm_u64 i2) const { return rm_load2(x, i2); }
+    // odd slice length: pairs at element offsets that are only element-aligned in every other slice, and one leftover element
+    __device__ __forceinline__ rm_rv2 pair_at(rm_u64 e) const { return rm_load2_at(x + e, false); }
+    __device__ __forceinline__ double one_at(rm_u64 e) const { return (double)__builtin_nontemporal_load(x + e); }
 };
-template <int OP, class F2>
+// ODD: `red` is odd (or the base only element-aligned): slice s starts at element s * red, its red / 2 pairs are loaded with
+// unaligned 16-byte loads and the last element joins the accumulator of the thread that would own the next pair.
+template <int OP, bool ODD = false, class F2>
 __device__ __forceinline__ void rm_reduce_contig_v2(const F2& f2, rm_u64 red, rm_u64 nslices, rm_u64 nsplit, double* pv,
                                                     double* pn) {
     __shared__ RmAcc lds[RM_ABLOCK / 64];
@@ -51,11 +67,15 @@ __device__ __forceinline__ void rm_reduce_contig_v2(const F2& f2, rm_u64 red, rm
     const rm_u64 begin = split * chunk;
     rm_u64 end = begin + chunk;
     if (end > red2) end = red2;
-    const rm_u64 base = slice * red2;
+    const rm_u64 base = slice * red2, ebase = slice * red;
+    auto ld = [&](rm_u64 rr) -> rm_rv2 {
+        if constexpr (ODD) return f2.pair_at(ebase + 2 * rr);
+        else return f2(base + rr);
+    };
     RmAcc a0 = rm_acc_init<OP>(), a1 = rm_acc_init<OP>(), a2 = rm_acc_init<OP>(), a3 = rm_acc_init<OP>();
     rm_u64 r = begin + threadIdx.x;
     for (; r + 3 * bs < end; r += 4 * bs) {
-        const rm_rv2 x0 = f2(base + r), x1 = f2(base + r + bs), x2 = f2(base + r + 2 * bs), x3 = f2(base + r + 3 * bs);
+        const rm_rv2 x0 = ld(r), x1 = ld(r + bs), x2 = ld(r + 2 * bs), x3 = ld(r + 3 * bs);
         rm_acc_add<OP>(a0, x0.x);
         rm_acc_add<OP>(a1, x1.x);
         rm_acc_add<OP>(a2, x2.x);
@@ -66,9 +86,15 @@ __device__ __forceinline__ void rm_reduce_contig_v2(const F2& f2, rm_u64 red, rm
         rm_acc_add<OP>(a3, x3.y);
     }
     for (; r < end; r += bs) {
-        const rm_rv2 v = f2(base + r);
+        const rm_rv2 v = ld(r);
         rm_acc_add<OP>(a0, v.x);
         rm_acc_add<OP>(a0, v.y);
+    }
+    if constexpr (ODD) {
+        // the leftover element: pair index red2 would be its pair - the chunk that contains that index owns it, and exactly one of
+        // its threads ends its walk there
+        const rm_u64 owner = red2 / chunk < nsplit - 1 ? red2 / chunk : nsplit - 1;
+        if ((red & 1) && split == owner && r == red2) rm_acc_add<OP>(a0, f2.one_at(ebase + red - 1));
     }
     rm_acc_merge<OP>(a0, a1);
     rm_acc_merge<OP>(a2, a3);
@@ -79,11 +105,11 @@ __device__ __forceinline__ void rm_reduce_contig_v2(const F2& f2, rm_u64 red, rm
         pn[slice * nsplit + split] = a0.nan;
     }
 }
-template <int OP, class T>
+template <int OP, class T, bool ODD = false>
 __global__ void __launch_bounds__(RM_ABLOCK) k_reduce_contig_v2(const T* x, rm_u64 red, rm_u64 nslices,
                                                                 rm_u64 nsplit, double* pv, double* pn) {
     IdentityVal2<T> f2{x};
-    rm_reduce_contig_v2<OP>(f2, red, nslices, nsplit, pv, pn);
+    rm_reduce_contig_v2<OP, ODD>(f2, red, nslices, nsplit, pv, pn);
 }
 
 template <int OP, class T>
@@ -97,26 +123,32 @@ __global__ void __launch_bounds__(RM_RBLOCK) k_reduce_strided(const T* x, rm_u64
 // slices and walks its chunk of the reduced extent in ascending order with U non-temporal loads in flight - the same
 // per-slice summation order as rm_reduce_strided with ty == 1, at 1 KiB per wave instruction.  grid = (ceil(pre/512),
 // nsplit, post).
-template <int OP, class T, int U>
+// ODD: `pre` is odd (or the base only element-aligned).  Pairs start at even element offsets of every line, which are then only
+// 8-byte (f64) / 4-byte (f32) aligned in every other line: the same 16-/8-byte loads on unaligned addresses (the hardware splits the
+// ones that straddle), and the last row - a pair of one - is loaded as a scalar.  8191 x 8192: 110 us on the generic 8-byte kernel.
+template <int OP, class T, int U, bool ODD = false>
 __global__ void __launch_bounds__(RM_RBLOCK) k_reduce_strided_v2(const T* x, rm_u64 pre, rm_u64 red, rm_u64 nsplit, unsigned win,
                                                                  double* pv, double* pn) {
     // a block owns `win` <= 256 pairs: the windows are balanced (host), so a row count just above a multiple of 512 does not
     // leave a column of nearly empty blocks behind (8256 rows: 16 full windows + one of 32 pairs ran 109 us against 86)
     const rm_u64 i2 = (rm_u64)blockIdx.x * win + threadIdx.x;  // pair index along `pre`
-    const rm_u64 pre2 = pre >> 1;
+    const rm_u64 pre2 = ODD ? (pre + 1) >> 1 : pre >> 1;
     if (threadIdx.x >= win || i2 >= pre2) return;
+    const bool single = ODD && 2 * i2 + 1 >= pre;  // the last row of an odd `pre`
     const rm_u64 split = blockIdx.y, j = blockIdx.z;
     const rm_u64 chunk = (red + nsplit - 1) / nsplit;
     const rm_u64 begin = split * chunk;
     rm_u64 end = begin + chunk;
     if (end > red) end = red;
     RmAcc a0 = rm_acc_init<OP>(), a1 = rm_acc_init<OP>();
-    const rm_u64 base2 = i2 + pre2 * red * j;
+    const rm_u64 base2 = i2 + pre2 * red * j;          // even form: in pairs
+    const T* const xo = x + 2 * i2 + pre * red * j;     // odd form: in elements
+    auto ld = [&](rm_u64 rr) -> rm_rv2 { return ODD ? rm_load2_at(xo + pre * rr, single) : rm_load2(x, base2 + pre2 * rr); };
     rm_u64 r = begin;
     for (; r + U <= end; r += U) {
         rm_rv2 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = rm_load2(x, base2 + pre2 * (r + u));
+        for (int u = 0; u < U; ++u) v[u] = ld(r + u);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             rm_acc_add<OP>(a0, v[u].x);
@@ -127,7 +159,7 @@ __global__ void __launch_bounds__(RM_RBLOCK) k_reduce_strided_v2(const T* x, rm_
         rm_rv2 v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (r + u < end) v[u] = rm_load2(x, base2 + pre2 * (r + u));
+            if (r + u < end) v[u] = ld(r + u);
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (r + u < end) {
@@ -138,8 +170,10 @@ __global__ void __launch_bounds__(RM_RBLOCK) k_reduce_strided_v2(const T* x, rm_
     const rm_u64 slice = 2 * i2 + pre * j;
     pv[slice * nsplit + split] = a0.v;
     pn[slice * nsplit + split] = a0.nan;
-    pv[(slice + 1) * nsplit + split] = a1.v;
-    pn[(slice + 1) * nsplit + split] = a1.nan;
+    if (!single) {
+        pv[(slice + 1) * nsplit + split] = a1.v;
+        pn[(slice + 1) * nsplit + split] = a1.nan;
+    }
 }
 template <int OP>
 __global__ void __launch_bounds__(RM_RBLOCK) k_reduce_final(const double* pv, const double* pn, rm_u64 nslices,
@@ -167,7 +201,8 @@ static int run_reduce(Context* c, int mean, int nan_mode, const T* x, size_t pre
     // RMHIP_RED_B_BPC = its target blocks per CU
     static const int b_mode = getenv("RMHIP_RED_B_MODE") ? atoi(getenv("RMHIP_RED_B_MODE")) : 1;
     static const int b_bpc = getenv("RMHIP_RED_B_BPC") ? atoi(getenv("RMHIP_RED_B_BPC")) : 3;
-    const bool wide_b = !p.contiguous && b_mode > 0 && (pre & 1) == 0 && pre >= 512 && (((uintptr_t)x) & 15) == 0 && post <= 65535;
+    const bool wide_b = !p.contiguous && b_mode > 0 && pre >= 512 && post <= 65535;
+    const bool wide_odd = wide_b && ((pre & 1) != 0 || (((uintptr_t)x) & 15) != 0);  // unaligned pairs + a scalar last row
     unsigned wide_bx = 0, wide_win = RM_RBLOCK, wide_threads = RM_RBLOCK;
     if (wide_b) {
         // The number of windows along `pre` is a multiple of the XCD count.  Workgroups go to XCDs round robin in launch order
@@ -180,11 +215,12 @@ static int run_reduce(Context* c, int mean, int nan_mode, const T* x, size_t pre
         // restores the old geometry.  (Also measured: two or four pairs per thread, 8-16 KiB of every column per block: 103-152 us.)
         static const int b_x8 = getenv("RMHIP_RED_B_X8") ? atoi(getenv("RMHIP_RED_B_X8")) : 1;
         const unsigned xcds = c->num_xcc > 0 ? (unsigned)c->num_xcc : 8u;
-        wide_bx = (unsigned)ceil_div_u64(pre / 2, RM_RBLOCK);
+        const uint64_t npairs = (pre + 1) / 2;
+        wide_bx = (unsigned)ceil_div_u64(npairs, RM_RBLOCK);
         if (b_x8 && pre / 2 >= xcds * 64) wide_bx = (wide_bx + xcds - 1) / xcds * xcds;
-        wide_win = (unsigned)((ceil_div_u64(pre / 2, wide_bx) + 7) / 8 * 8);
+        wide_win = (unsigned)((ceil_div_u64(npairs, wide_bx) + 7) / 8 * 8);
         if (wide_win > RM_RBLOCK) wide_win = RM_RBLOCK;
-        wide_bx = (unsigned)ceil_div_u64(pre / 2, wide_win);
+        wide_bx = (unsigned)ceil_div_u64(npairs, wide_win);
         if (b_x8 && pre / 2 >= xcds * 64) wide_bx = (wide_bx + xcds - 1) / xcds * xcds;  // (trailing windows may be empty)
         wide_threads = (wide_win + 63) / 64 * 64;
         uint64_t want = ceil_div_u64((uint64_t)c->num_cus * b_bpc, (uint64_t)wide_bx * post);
@@ -203,11 +239,17 @@ static int run_reduce(Context* c, int mean, int nan_mode, const T* x, size_t pre
     if (p.contiguous && (red & 1) == 0 && red >= 2048 && (((uintptr_t)x) & 15) == 0)
         hipLaunchKernelGGL((k_reduce_contig_v2<OP, T>), dim3(p.gx, p.gy, p.gz), dim3(p.tx), 0, c->stream, x, (rm_u64)red,
                            (rm_u64)p.nslices, (rm_u64)p.nsplit, pv, pn);
+    else if (p.contiguous && red >= 2048)  // odd slice length or an element-aligned base: the same kernel on unaligned pairs
+        hipLaunchKernelGGL((k_reduce_contig_v2<OP, T, true>), dim3(p.gx, p.gy, p.gz), dim3(p.tx), 0, c->stream, x, (rm_u64)red,
+                           (rm_u64)p.nslices, (rm_u64)p.nsplit, pv, pn);
     else if (p.contiguous)
         hipLaunchKernelGGL((k_reduce_contig<OP, T>), dim3(p.gx, p.gy, p.gz), dim3(p.tx), 0, c->stream, x,
                            (rm_u64)red, (rm_u64)p.nslices, (rm_u64)p.nsplit, pv, pn);
-    else if (wide_b && b_mode == 2)
+    else if (wide_b && b_mode == 2 && !wide_odd)
         hipLaunchKernelGGL((k_reduce_strided_v2<OP, T, 4>), dim3(wide_bx, (unsigned)nsplit, (unsigned)post), dim3(wide_threads), 0, c->stream,
+                           x, (rm_u64)pre, (rm_u64)red, (rm_u64)nsplit, wide_win, pv, pn);
+    else if (wide_odd)
+        hipLaunchKernelGGL((k_reduce_strided_v2<OP, T, 8, true>), dim3(wide_bx, (unsigned)nsplit, (unsigned)post), dim3(wide_threads), 0, c->stream,
                            x, (rm_u64)pre, (rm_u64)red, (rm_u64)nsplit, wide_win, pv, pn);
     else if (wide_b)
         hipLaunchKernelGGL((k_reduce_strided_v2<OP, T, 8>), dim3(wide_bx, (unsigned)nsplit, (unsigned)post), dim3(wide_threads), 0, c->stream,

@@ -407,7 +407,8 @@ def test_binary_broadcast_and_mismatch(prov, oracle):
 
 
 # ---- reductions --------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(1000, 1000), (1, 1), (5, 1), (1, 5), (3, 70000), (70000, 3), (257, 129)])
+@pytest.mark.parametrize("shape", [(1000, 1000), (1, 1), (5, 1), (1, 5), (3, 70000), (70000, 3), (257, 129),
+                                   (513, 37), (1001, 9), (4097, 5), (2049, 7), (4099, 3), (8191, 33)])  # odd extents >= 512 / 2048: the unaligned-pair kernels
 def test_reduce_sum_mean_shapes_and_values(prov, oracle, shape):
     rng = np.random.default_rng(19)
     X = rng.uniform(-1, 1, shape)

@@ -25,7 +25,7 @@ def _special(rng, shape):
 
 
 @pytest.mark.parametrize("shape", [(1, 1), (7, 1), (1, 9), (33, 5), (257, 130), (1000, 3), (3, 1000), (64, 64, 3), (5, 7, 11), (2, 70000),
-                                   (70000, 2)])
+                                   (70000, 2), (513, 37), (1001, 9), (2049, 7), (4099, 3)])  # odd extents: the unaligned-pair kernels
 def test_minmax_dim_values_and_indices_bit_exact(prov, oracle, shape):
     rng = np.random.default_rng(sum(shape))
     for x in (rng.uniform(-1, 1, shape), _special(rng, shape)):
@@ -77,7 +77,7 @@ def test_minmax_dim_full_size_against_numpy(prov, dim):
     prov.free(h)
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (9, 1), (1, 9), (300, 40), (40, 300), (17, 5, 9), (100000, 2), (2, 100000)])
+@pytest.mark.parametrize("shape", [(1, 1), (9, 1), (1, 9), (300, 40), (40, 300), (17, 5, 9), (100000, 2), (2, 100000), (513, 37), (2049, 7)])
 def test_std_matches_welford_oracle(prov, oracle, shape):
     rng = np.random.default_rng(5 + sum(shape))
     x = rng.normal(3.0, 2.0, shape)
@@ -101,7 +101,7 @@ def test_std_matches_welford_oracle(prov, oracle, shape):
         prov.free(h)
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (6, 1), (33, 7), (257, 129), (4, 5, 6), (3, 90000)])
+@pytest.mark.parametrize("shape", [(1, 1), (6, 1), (33, 7), (257, 129), (4, 5, 6), (3, 90000), (1001, 9), (4099, 3)])
 def test_truth_reductions_exact(prov, oracle, shape):
     rng = np.random.default_rng(9 + sum(shape))
     x = (rng.random(shape) < 0.3).astype(np.float64) * rng.uniform(-2, 2, shape)
