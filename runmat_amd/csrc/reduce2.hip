@@ -595,6 +595,66 @@ __global__ void __launch_bounds__(BLOCK) k_scan_lines(const double* __restrict__
     }
 }
 
+// Few long strided lines (8192 x 8192 along dim 2: 8192 lines, 128 waves): one thread per line cannot keep enough loads in flight to
+// cover the memory latency - 1.09 ms where the bytes would take 0.2.  Here a block of eight waves owns 64 adjacent lines and walks them
+// in tiles of 64 steps: ALL waves fetch the next tile (64 lines x 64 steps, 32 KiB, coalesced rows of 512 bytes) while wave 0 runs the
+// 64 chains over the current one in LDS - still each line's own left-to-right sequence, so the result stays bit-identical to the
+// CPU's - then all waves write the tile out and drop the fetched one into the cells they just emptied (no barrier in between: a thread
+// stores and refills exactly its own cells).
+// LINES = 64, or 32 when 64 would leave CUs without a block (8192 lines: 128 blocks on 256 CUs).
+static constexpr int ST_STEPS = 64, ST_THREADS = 512;
+template <bool PROD, int LINES>
+__global__ void __launch_bounds__(ST_THREADS) k_scan_lines_staged(const double* __restrict__ x, double* __restrict__ y, u64 pre, u64 len, u64 post,
+                                                                  int reverse, int omit) {
+    __shared__ double buf[ST_STEPS][LINES];
+    (void)post;
+    constexpr int RP = ST_THREADS / LINES;   // rows of a tile the block touches per pass (8 or 16)
+    constexpr int ROWS = ST_STEPS / RP;      // passes = rows per thread (8 or 4)
+    const int line = threadIdx.x % LINES, row0 = threadIdx.x / LINES;
+    const u64 i = (u64)blockIdx.x * LINES + line, j = blockIdx.y;
+    const bool live = i < pre;
+    const u64 base = i + pre * len * j;
+    const u64 ntiles = (len + ST_STEPS - 1) / ST_STEPS;
+    const double ident = PROD ? 1.0 : 0.0;
+    double regs[ROWS];
+    auto at = [&](u64 k) { return base + pre * (reverse ? len - 1 - k : k); };
+    auto gload = [&](u64 t) {
+#pragma unroll
+        for (int u = 0; u < ROWS; ++u) {
+            const u64 k = t * ST_STEPS + (u64)(u * RP + row0);
+            regs[u] = (live && k < len) ? __builtin_nontemporal_load(x + at(k)) : ident;
+        }
+    };
+    gload(0);
+#pragma unroll
+    for (int u = 0; u < ROWS; ++u) buf[u * RP + row0][line] = regs[u];
+    __syncthreads();
+    double run = ident;
+    for (u64 t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) gload(t + 1);  // in flight while the first LINES threads scan
+        if (threadIdx.x < LINES) {
+            double v[ST_STEPS];
+#pragma unroll
+            for (int k = 0; k < ST_STEPS; ++k) v[k] = buf[k][line];
+#pragma unroll
+            for (int k = 0; k < ST_STEPS; ++k) {  // rows beyond `len` hold the identity: they leave the running value alone and are not stored
+                run = scan_op<PROD>(run, scan_in<PROD>(v[k], omit));
+                v[k] = scan_out(run);
+            }
+#pragma unroll
+            for (int k = 0; k < ST_STEPS; ++k) buf[k][line] = v[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < ROWS; ++u) {
+            const u64 k = t * ST_STEPS + (u64)(u * RP + row0);
+            if (live && k < len) __builtin_nontemporal_store(buf[u * RP + row0][line], y + at(k));
+            buf[u * RP + row0][line] = regs[u];  // the next tile (garbage after the last one: nobody reads it)
+        }
+        __syncthreads();
+    }
+}
+
 // pre == 1, long lines: three passes over chunks of SCAN_CHUNK elements - chunk totals, a serial scan of the totals per line,
 // then every chunk scans itself from its carry (a line of one chunk skips the first two).  Inside a chunk a block scans tiles of
 // 256 x 8 elements: the tile is read COALESCED (lane l of a load takes element l + 256 u), turned through LDS so that a thread
@@ -744,7 +804,16 @@ int launch_cumulative(Context* c, int prod, int reverse, int omit, const double*
     const size_t lines = pre * post;
     // thread-per-line whenever the lines run along a strided dimension, or there are enough short contiguous lines to fill the chip
     if (pre > 1 || (len <= 4096 && lines >= (size_t)c->num_cus * 64)) {
-        if (lines >= (size_t)c->num_cus * 1024) {  // plenty of lines: four waves per block, eight loads deep
+        if (pre >= 64 && len >= 256 && lines < (size_t)c->num_cus * 256 && post <= 65535) {  // few long strided lines: staged tiles
+            const bool half = ceil_div_u64(pre, 64) * post < (u64)c->num_cus;  // 64 lines per block would leave CUs idle
+            const dim3 sgrid((unsigned)ceil_div_u64(pre, half ? 32 : 64), (unsigned)post);
+#define RMHIP_STAGED(P, L) hipLaunchKernelGGL((k_scan_lines_staged<P, L>), sgrid, dim3(ST_THREADS), 0, c->stream, x, y, (u64)pre, (u64)len, (u64)post, reverse, omit)
+            if (prod && half) RMHIP_STAGED(true, 32);
+            else if (prod) RMHIP_STAGED(true, 64);
+            else if (half) RMHIP_STAGED(false, 32);
+            else RMHIP_STAGED(false, 64);
+#undef RMHIP_STAGED
+        } else if (lines >= (size_t)c->num_cus * 1024) {  // plenty of lines: four waves per block, eight loads deep
             const unsigned grid = (unsigned)ceil_div_u64(lines, 256);
             if (prod) hipLaunchKernelGGL((k_scan_lines<true, 256, 8>), dim3(grid), dim3(256), 0, c->stream, x, y, (u64)pre, (u64)len, (u64)post, reverse, omit);
             else hipLaunchKernelGGL((k_scan_lines<false, 256, 8>), dim3(grid), dim3(256), 0, c->stream, x, y, (u64)pre, (u64)len, (u64)post, reverse, omit);

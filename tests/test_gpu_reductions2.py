@@ -157,12 +157,25 @@ def test_cumulative_scans(prov, oracle, shape):
     prov.free(h)
 
 
-def test_strided_scan_is_the_cpu_sequence_bit_for_bit(prov, oracle):
-    """Along a strided dimension every line is one thread running the CPU's own left-to-right chain."""
-    rng = np.random.default_rng(21)
-    x = rng.uniform(-1, 1, (513, 700))
-    got = prov.download(prov.cumsum_scan(prov.upload(x), 1)).reshape(x.shape, order="F")
-    assert np.array_equal(got, oracle.cumulative(x, 1))
+@pytest.mark.parametrize("shape,dim", [((513, 700), 1), ((64, 256), 1), ((100, 1000, 3), 1), ((65, 300, 2), 1), ((300, 70), 1), ((7, 5000), 1),
+                                       ((70, 33, 400), 2)])
+def test_strided_scan_is_the_cpu_sequence_bit_for_bit(prov, oracle, shape, dim):
+    """Along a strided dimension every line is the CPU's own left-to-right chain - whether one thread walks it (many or short lines)
+    or a block stages tiles of 64 lines x 64 steps through LDS and one wave runs the chains (few long lines): sums, products, both
+    directions, both NaN modes."""
+    rng = np.random.default_rng(21 + sum(shape))
+    x = rng.uniform(-1, 1, shape)
+    xn = x.copy()
+    xn.ravel()[rng.integers(0, x.size, max(1, x.size // 97))] = np.nan
+    h, hn = prov.upload(x), prov.upload(xn)
+    for prod in (False, True):
+        f = prov.cumprod_scan if prod else prov.cumsum_scan
+        for reverse in (False, True):
+            got = prov.download(f(h, dim, reverse=reverse)).reshape(shape, order="F")
+            assert np.array_equal(got, oracle.cumulative(x, dim, prod=prod, reverse=reverse))
+            for omit in (False, True):
+                gn = prov.download(f(hn, dim, reverse=reverse, omitnan=omit)).reshape(shape, order="F")
+                assert np.array_equal(gn, oracle.cumulative(xn, dim, prod=prod, reverse=reverse, omitnan=omit), equal_nan=True)
 
 
 def test_new_reductions_on_a_precision32_provider(built):
