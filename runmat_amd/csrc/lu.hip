@@ -2351,8 +2351,11 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     // Look-ahead (second stream): default from kmin = 5120; RMHIP_LU_LOOKAHEAD=1 forces it for every kmin > nb, =0
     // disables it.  It needs the persistent panels: with one launch per column the panel kernels wait behind the
     // update's dgemm blocks.
+    // Solve path (one-workgroup panels: nothing has to be co-resident, and the chain is all there is at these sizes): from 1152 -
+    // n = 1280 3.30 -> 2.52 ms, 1536 3.63 -> 2.95, 2048 4.30 -> 3.91, 3072 8.06 -> 5.98, 4096 9.92 -> 8.17 (5120: 16.9 without,
+    // 10.6 with; 1024: 2.03 / 2.00).
     const char* la = std::getenv("RMHIP_LU_LOOKAHEAD");
-    bool blocked = kmin >= 5120 && kmin > nb;
+    bool blocked = kmin >= (s.fast ? 1152u : 5120u) && kmin > nb;
     if (la) blocked = kmin > nb && la[0] == '1';
     if (!s.persistent) blocked = false;
     // Under look-ahead the panels keep 256-row blocks (132 KiB of LDS: a whole CU).  The update stream's dgemm runs one
