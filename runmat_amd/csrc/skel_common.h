@@ -137,8 +137,11 @@ __device__ __forceinline__ double rm_log_pos(double x) {
 // Error: (0.45 |g ln x| + 1.5) units of 2^-53 relative - the logarithm's own sub-ulp error is what the exponent multiplies;
 // measured max 14.9 units (1.7e-15) over 3e7 (x, g) with |g ln x| <= 32 against powl, 2-3 units on image data (x in (0, 4], g in
 // [0.2, 3.2]).  The CPU's powf is < 1 ulp; tests/test_gpu_parity.py states 4e-15.
+// the library pow, out of line: it is the cold path of rm_pow_pos (non-positive / non-finite bases, |g ln x| > 32) and inlining its
+// special-case ladders into the caller costs the hot path ~20 registers
+__device__ __noinline__ double rm_pow_cold(double x, double g) { return pow(x, g); }
 __device__ __forceinline__ double rm_pow_pos(double x, double g) {
-    if (!(x > 0.0 && x < __builtin_inf())) return pow(x, g);
+    if (!(x > 0.0 && x < __builtin_inf())) return rm_pow_cold(x, g);
     double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
     int e = __builtin_amdgcn_frexp_exp(x);
     if (m < 0x1.6a09e667f3bcdp-1) {  // sqrt(1/2): keep 1 + f in [sqrt(1/2), sqrt(2))
@@ -164,7 +167,7 @@ __device__ __forceinline__ double rm_pow_pos(double x, double g) {
     const double L = hi + lo;
     const double l = lo - (L - hi);
     const double yh = g * L;
-    if (!(__builtin_fabs(yh) <= 32.0)) return pow(x, g);
+    if (!(__builtin_fabs(yh) <= 32.0)) return rm_pow_cold(x, g);
     const double yl = __builtin_fma(g, L, -yh) + g * l;
     const double n = __builtin_rint(yh * 0x1.71547652b82fep+0);
     double r = __builtin_fma(n, -0x1.62e42fee00000p-1, yh);

@@ -16,6 +16,7 @@
 // deviations) and differs from the CPU's bits only in the last place or two (tests: 1e-12 relative).  Every thread
 // walks the linear index with a stride that is a multiple of `batch`, so its batch element is fixed (no per-element
 // modulo) and loads stay coalesced.
+#include <cstdlib>
 #include "common.h"
 #include "skel_common.h"
 
@@ -200,7 +201,7 @@ __global__ void __launch_bounds__(IN_BLOCK) k_imgnorm_apply(const T* __restrict_
             // (+0 - half of a clamped image - is answered in place: pow(+0, g > 0) = +0)
             if (has_gamma) {
                 if (gamma > 0.0 && w > 0.0) w = rm_pow_pos(w, gamma);
-                else if (!(gamma > 0.0 && __double_as_longlong(w) == 0ll)) w = pow(w, gamma);
+                else if (!(gamma > 0.0 && __double_as_longlong(w) == 0ll)) w = rm_pow_cold(w, gamma);
             }
             v[l] = w;
         }
@@ -243,7 +244,17 @@ static int image_normalize_vec(Context* c, const T* x, T* y, size_t batch, size_
     hipLaunchKernelGGL((k_plane_moments<T, VEC>), dim3(grid), dim3(threads), 0, c->stream, x, total, (int)batch, partial);
     hipLaunchKernelGGL(k_plane_moments_final, dim3((unsigned)batch), dim3(FIN_BLOCK), 0, c->stream, partial, (int)grid, (int)batch, (double)plane,
                        epsilon, stats);
-    hipLaunchKernelGGL((k_imgnorm_apply<T, VEC>), dim3(grid), dim3(threads), 0, c->stream, x, y, total, (int)batch, stats, has_gain, gain,
+    // the apply pass with the gamma step runs 512-thread blocks: with the cold pow out of line (skel_common.h: rm_pow_cold) it needs 51
+    // registers instead of 84 and three such blocks share a CU - 0.645 -> 0.633 ms at 16 x 2160 x 3840; without gamma the 1024-thread
+    // blocks stay (0.551 against 0.567 / 0.587 ms with 512 / 256).  RMHIP_IMG_APPLY_BLOCK overrides (A/B).
+    static const int apply_env = std::getenv("RMHIP_IMG_APPLY_BLOCK") ? std::atoi(std::getenv("RMHIP_IMG_APPLY_BLOCK")) : 0;
+    const int apply_block = apply_env > 0 ? apply_env : (has_gamma ? 512 : IN_BLOCK);
+    const unsigned athreads = (unsigned)(((size_t)(apply_block < 64 ? 64 : (apply_block > IN_BLOCK ? IN_BLOCK : apply_block)) / batch) * batch);
+    const unsigned at = athreads ? athreads : threads;
+    size_t awant = (total / VEC + (size_t)at * 2 - 1) / ((size_t)at * 2);
+    const size_t acap = (size_t)c->num_cus * 8 * (threads / at ? threads / at : 1);
+    const unsigned agrid = (unsigned)(awant < acap ? (awant < 1 ? 1 : awant) : acap);
+    hipLaunchKernelGGL((k_imgnorm_apply<T, VEC>), dim3(agrid), dim3(at), 0, c->stream, x, y, total, (int)batch, stats, has_gain, gain,
                        has_bias, bias, clamp_zero, has_gamma, gamma);
     c->tel.kernel_launches += 3;
     RMHIP_HIP_CHECK(hipGetLastError());
