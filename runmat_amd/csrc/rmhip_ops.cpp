@@ -76,7 +76,8 @@ size_t lu_padded_ld(size_t rows) { return rows >= 256 ? ((rows + 1) & ~(size_t)1
 // RMHIP_LU_PAD=0 disables.
 static size_t lu_pad_rows(size_t n) {
     const char* v = std::getenv("RMHIP_LU_PAD");  // read per call: the tests compare both forms
-    if ((v && *v == '0') || n < 2048 || n % 128 == 0) return n;
+    static const size_t min_n = std::getenv("RMHIP_LU_PAD_MIN") ? (size_t)std::atol(std::getenv("RMHIP_LU_PAD_MIN")) : 2048;  // dev knob
+    if ((v && *v == '0') || n < min_n || n % 128 == 0) return n;
     const size_t np = (n + 127) / 128 * 128;
     return np <= 65535 ? np : n;
 }
