@@ -419,6 +419,31 @@ def test_f32_matmul_on_the_f32_matrix_cores(prov32, oracle, m, k, n, monkeypatch
     assert same_bits(exact, f32r(want)) or np.max(np.abs(exact - f32r(want))) <= ULP32 * np.max(np.abs(want))
 
 
+def test_f32_matmul_random_shapes_fuzz(prov32, monkeypatch):
+    """80 random shapes through the f32 matrix-core product and its A' * B form (whole and guarded eight-wave tiles, the element-checking
+    kernel for A * B', split-K) against the f64 product of the same f32 operands."""
+    monkeypatch.delenv("RMHIP_F32_MATMUL", raising=False)
+    rng = np.random.default_rng(927)
+    edges = np.array([1, 2, 3, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513])
+
+    def dim():
+        return int(rng.choice(edges)) if rng.random() < 0.6 else int(rng.integers(1, 600))
+
+    for _ in range(80):
+        m, k, n = dim(), dim(), dim()
+        A, B = f32r(rng.standard_normal((m, k))), f32r(rng.standard_normal((k, n)))
+        want = A @ B
+        bound = (k + 2) * ULP32 * (np.abs(A) @ np.abs(B)) + 1e-30
+        ha, hb = prov32.upload(A), prov32.upload(B)
+        got = prov32.download_matrix(prov32.matmul(ha, hb))
+        assert got.shape == (m, n) and np.all(np.abs(got - want) <= bound), (m, k, n)
+        hat = prov32.upload(np.ascontiguousarray(A.T))
+        g2 = prov32.download_matrix(prov32.matmul(prov32.transpose(hat), hb))
+        assert np.all(np.abs(g2 - want) <= bound), ("A'", m, k, n)
+        for h in (ha, hb, hat):
+            prov32.free(h)
+
+
 def test_f32_matmul_exactness_cases_and_errors(prov32, monkeypatch):
     from runmat_amd import ProviderError
 

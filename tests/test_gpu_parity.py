@@ -521,6 +521,42 @@ def test_matmul_ragged_shapes(prov, oracle, m, k, n):
         assert np.all(np.abs(ge - we) <= 3.0 * (k + 4) * EPS * (np.abs(A) @ np.abs(B)) + 1e-13), kw
 
 
+def test_matmul_random_shapes_fuzz(prov):
+    """120 random shapes (1 .. 700 in every dimension, biased towards tile boundaries) through matmul, A' * B, syrk and the update
+    form on a view: every dispatch decision of dgemm.hip (whole tiles, guarded tiles, 64 x 64 kernel, split-K) against numpy."""
+    rng = np.random.default_rng(20260927)
+    edges = np.array([1, 2, 3, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 511, 512, 513])
+
+    def dim():
+        return int(rng.choice(edges)) if rng.random() < 0.6 else int(rng.integers(1, 700))
+
+    for _ in range(120):
+        m, k, n = dim(), dim(), dim()
+        A, B = rng.uniform(-1, 1, (m, k)), rng.uniform(-1, 1, (k, n))
+        want = A @ B
+        tol = _gemm_tol(A, B, k)
+        hA, hB = prov.upload(A), prov.upload(B)
+        got = prov.download_matrix(prov.matmul(hA, hB))
+        assert got.shape == (m, n) and np.max(np.abs(got - want)) <= tol, (m, k, n)
+        hAt = prov.upload(np.ascontiguousarray(A.T))
+        gt = prov.download_matrix(prov.matmul(prov.transpose(hAt), hB))
+        assert np.max(np.abs(gt - want)) <= tol, ("A'", m, k, n)
+        if k <= 300:
+            sy = prov.download_matrix(prov.syrk(hA))
+            assert np.max(np.abs(sy - A.T @ A)) <= _gemm_tol(A.T, A, m), ("syrk", m, k)
+        big = np.full((m + 3, n + 2), -3.5)
+        C0 = rng.uniform(-1, 1, (m, n))
+        big[1:1 + m, 2:2 + n] = C0
+        hC = prov.upload(big)
+        prov.blk_gemm(-1.0, (hA, 0, 0, m, k), (hB, 0, 0, k, n), 1.0, (hC, 1, 2, m, n))
+        out = prov.download_matrix(hC)
+        assert np.max(np.abs(out[1:1 + m, 2:2 + n] - (C0 - want))) <= tol + 4 * EPS, ("update", m, k, n)
+        out[1:1 + m, 2:2 + n] = -3.5
+        assert np.all(out == -3.5), ("frame", m, k, n)
+        for h in (hA, hB, hAt, hC):
+            prov.free(h)
+
+
 def test_matmul_identity_with_asymmetric_b_detects_transposes(prov):
     n = 160
     B = np.fromfunction(lambda i, j: 3.0 * i - 7.0 * j + 0.5, (n, n))
