@@ -178,6 +178,34 @@ def test_strided_scan_is_the_cpu_sequence_bit_for_bit(prov, oracle, shape, dim):
                 assert np.array_equal(gn, oracle.cumulative(xn, dim, prod=prod, reverse=reverse, omitnan=omit), equal_nan=True)
 
 
+def test_reductions_random_shapes_fuzz(prov, oracle):
+    """60 random 2-D shapes around the kernels' switching points (512 / 2048 extents, odd and even, few and many lines) through sum,
+    min / max with indices (against the oracle: the rounding produces -0.0, which the CPU builtins order below +0), nnz, std and
+    cumsum along both dimensions, against numpy."""
+    rng = np.random.default_rng(31)
+    longs = [511, 512, 513, 1023, 1025, 2047, 2048, 2049, 3000, 4097, 6001]
+    for it in range(60):
+        a, b = int(rng.choice(longs)), int(rng.integers(1, 48))
+        shape = (a, b) if it % 2 == 0 else (b, a)
+        x = np.round(rng.uniform(-8, 8, shape) * 4) / 4  # quarters: sums are exact, ties are frequent
+        x[rng.random(shape) < 0.1] = 0.0
+        h = prov.upload(x)
+        for dim in (0, 1):
+            assert np.array_equal(prov.download(prov.reduce_sum_dim(h, dim)).ravel(), x.sum(axis=dim)), (shape, dim, "sum")
+            for is_max, f in ((False, prov.reduce_min_dim), (True, prov.reduce_max_dim)):
+                r = f(h, dim)
+                wv, wi = oracle.minmax_dim(x, dim, is_max)
+                gv, gi = prov.download(r.values).ravel(), prov.download(r.indices).ravel()
+                assert np.array_equal(gv.view(np.uint64), wv.ravel(order="F").view(np.uint64)) and np.array_equal(gi, wi.ravel(order="F")), (shape, dim, is_max)
+            assert np.array_equal(prov.download(prov.reduce_nnz_dim(h, dim)).ravel(), np.count_nonzero(x, axis=dim).astype(np.float64)), (shape, dim, "nnz")
+            sd = prov.download(prov.reduce_std_dim(h, dim)).ravel()
+            want = x.std(axis=dim, ddof=1) if x.shape[dim] > 1 else np.zeros(x.shape[1 - dim])
+            assert np.max(np.abs(sd - want)) <= 1e-12 * max(1.0, np.abs(want).max()), (shape, dim, "std")
+            cs = prov.download(prov.cumsum_scan(h, dim)).reshape(shape, order="F")
+            assert np.array_equal(cs, np.cumsum(x, axis=dim)), (shape, dim, "cumsum")  # exact on quarters
+        prov.free(h)
+
+
 def test_new_reductions_on_a_precision32_provider(built):
     """f32 storage: operands are widened (exact, order preserving), results narrowed once - indices stay exact integers."""
     from runmat_amd import HipProvider
