@@ -109,6 +109,31 @@ def test_ragged_orders_factor_at_the_padded_order(prov, n, nrhs):
     assert xr.shape == (nrhs, n) and np.max(np.abs(xr.T - x1)) <= 1e-9 * max(1.0, np.abs(x1).max())
 
 
+def test_solve_random_orders_fuzz(prov):
+    """Orders across every driver switch - the single-panel sizes, the recursion, the look-ahead driver's threshold (1152), the padded
+    orders (>= 2048, not a multiple of 128) - with 1 .. 4 right-hand sides: backward error of partial-pivoting quality for mldivide,
+    the same solution from linsolve, and mrdivide on the transposed system."""
+    rng = np.random.default_rng(77)
+    orders = [1, 2, 3, 17, 63, 64, 65, 129, 255, 256, 257, 300, 511, 513, 700, 1023, 1025, 1151, 1152, 1153, 1280, 1500, 2047, 2049, 2100, 2176, 2500]
+    orders += [int(v) for v in rng.integers(4, 900, 12)]
+    for n in orders:
+        nrhs = int(rng.integers(1, 5))
+        A = rng.uniform(-1, 1, (n, n))
+        B = rng.uniform(-1, 1, (n, nrhs))
+        hA, hB = prov.upload(A), prov.upload(B)
+        x = prov.download_matrix(prov.mldivide(hA, hB))
+        assert x.shape == (n, nrhs)
+        for j in range(nrhs):
+            assert _backward_error(A, x[:, j], B[:, j]) <= 64 * max(n, 8) * 2.3e-16, (n, j)
+        if n > 1:  # (scalar operands: linsolve hands back to the CPU path, as the reference's provider does)
+            xl = prov.download_matrix(prov.linsolve(hA, hB).solution)
+            assert np.array_equal(xl, x), n
+        xr = prov.download_matrix(prov.mrdivide(prov.upload(np.ascontiguousarray(B.T)), prov.upload(np.ascontiguousarray(A.T))))
+        assert np.max(np.abs(xr.T - x)) <= 1e-8 * max(1.0, np.abs(x).max()), n
+        for h in (hA, hB):
+            prov.free(h)
+
+
 def test_wilkinson_growth_matrix(prov):
     """Wilkinson's matrix (1 on the diagonal and in the last column, -1 below the diagonal) doubles the last column at every
     step under partial pivoting: growth 2^(n-1).  Every multiplier is exactly 1, so the solve path accepts it - and must then
