@@ -198,7 +198,7 @@ __device__ __forceinline__ double binary_op(double a, double b) {
         case RMHIP_SUB: return a - b;
         case RMHIP_MUL: return a * b;
         case RMHIP_DIV: return a / b;
-        case RMHIP_POW: return pow(a, b);
+        case RMHIP_POW: return rm_pow(a, b);  // skel_common.h: exponent 2 -> the exact product
         case RMHIP_MAX: return rm_max(a, b);
         case RMHIP_MIN: return rm_min(a, b);
         case RMHIP_HYPOT: return hypot(a, b);

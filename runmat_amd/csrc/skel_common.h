@@ -137,6 +137,13 @@ __device__ __forceinline__ double rm_log_pos(double x) {
 // Error: (0.45 |g ln x| + 1.5) units of 2^-53 relative - the logarithm's own sub-ulp error is what the exponent multiplies;
 // measured max 14.9 units (1.7e-15) over 3e7 (x, g) with |g ln x| <= 32 against powl, 2-3 units on image data (x in (0, 4], g in
 // [0.2, 3.2]).  The CPU's powf is < 1 ulp; tests/test_gpu_parity.py states 4e-15.
+// pow as the fused kernels and the per-op kernel call it.  An exponent of exactly 2 - `x.^2`, the common case by far - is the exact
+// product rounded once (what fdlibm-derived libms return for it, and within half an ulp of any other); everything else is the
+// library's.  In the 14-op chain of benchmarks/elementwise-math the library pow was a third of the kernel's instructions.
+__device__ __forceinline__ double rm_pow(double x, double y) {
+    if (y == 2.0) return x * x;
+    return pow(x, y);
+}
 // the library pow, out of line: it is the cold path of rm_pow_pos (non-positive / non-finite bases, |g ln x| > 32) and inlining its
 // special-case ladders into the caller costs the hot path ~20 registers
 __device__ __noinline__ double rm_pow_cold(double x, double g) { return pow(x, g); }

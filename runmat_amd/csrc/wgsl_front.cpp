@@ -375,7 +375,7 @@ const std::unordered_map<std::string, FnInfo>& fn_table() {
         {"expm1", {"expm1", 1}},   {"sqrt", {"sqrt", 1}},     {"abs", {"fabs", 1}},
         {"floor", {"floor", 1}},   {"ceil", {"ceil", 1}},     {"round", {"round", 1}},
         {"trunc", {"trunc", 1}},   {"sign", {"rm_sign", 1}},  {"atan2", {"atan2", 2}},
-        {"hypot", {"hypot", 2}},   {"pow", {"pow", 2}},       {"max", {"rm_max", 2}},
+        {"hypot", {"hypot", 2}},   {"pow", {"rm_pow", 2}},       {"max", {"rm_max", 2}},
         {"min", {"rm_min", 2}},    {"isNan", {"rm_isnan", 1}}, {"isNanF", {"rm_isnan", 1}},
         {"isInf", {"rm_isinf", 1}}, {"isFinite", {"rm_isfinite", 1}}, {"f32", {"rm_f32", 1}},
     };
