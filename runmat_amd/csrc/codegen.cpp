@@ -289,6 +289,22 @@ std::string generate_reduction_source(const ReductionProgram& p, bool f32) {
     s << "    __device__ __forceinline__ double operator()(rm_u64 idx) const {\n";
     for (int k = 0; k < nin; ++k) s << "        const double v" << k << " = " << cast_in << "in" << k << "[idx * m" << k << "];\n";
     s << "        return " << emit_expr_f64(p.val) << ";\n    }\n};\n\n";
+    // the same value for two adjacent elements of a contiguous slice (kernel A over 16-byte vectors, skel_reduce.h:
+    // rm_reduce_contig_v2): full-size inputs are read as pairs, 1-element inputs broadcast
+    s << "typedef " << S << " rm_sv2 __attribute__((ext_vector_type(2)));\n";
+    s << "struct RmVal2 {\n";
+    for (int k = 0; k < nin; ++k) s << "    const " << S << "* __restrict__ in" << k << ";\n    rm_u64 m" << k << ";\n";
+    s << "    __device__ __forceinline__ rm_rv2 operator()(rm_u64 i2) const {\n";
+    for (int k = 0; k < nin; ++k)
+        s << "        rm_sv2 p" << k << ";\n        if (m" << k << ") p" << k << " = __builtin_nontemporal_load((const rm_sv2*)in" << k
+          << " + i2);\n        else p" << k << " = rm_sv2{in" << k << "[0], in" << k << "[0]};\n";
+    s << "        rm_rv2 r;\n";
+    for (const char* lane : {"x", "y"}) {
+        s << "        {\n";
+        for (int k = 0; k < nin; ++k) s << "            const double v" << k << " = " << cast_in << "p" << k << "." << lane << ";\n";
+        s << "            r." << lane << " = " << emit_expr_f64(p.val) << ";\n        }\n";
+    }
+    s << "        return r;\n    }\n};\n\n";
     auto args = [&]() {
         std::string a;
         for (int k = 0; k < nin; ++k)
@@ -305,6 +321,11 @@ std::string generate_reduction_source(const ReductionProgram& p, bool f32) {
     s << "extern \"C\" __global__ void __launch_bounds__(RM_ABLOCK) rm_red_contig(" << args()
       << "const rm_u64 red, const rm_u64 nslices, const rm_u64 nsplit, double* part_v, double* part_nan) {\n"
       << init() << "    rm_reduce_contig<RM_RSUM>(f, red, nslices, nsplit, part_v, part_nan);\n}\n\n";
+    s << "extern \"C\" __global__ void __launch_bounds__(RM_ABLOCK) rm_red_contig2(" << args()
+      << "const rm_u64 red, const rm_u64 nslices, const rm_u64 nsplit, double* part_v, double* part_nan) {\n"
+      << "    RmVal2 f2;\n";
+    for (int k = 0; k < nin; ++k) s << "    f2.in" << k << " = in" << k << "; f2.m" << k << " = m" << k << ";\n";
+    s << "    rm_reduce_contig_v2<RM_RSUM>(f2, red, nslices, nsplit, part_v, part_nan);\n}\n\n";
     s << "extern \"C\" __global__ void __launch_bounds__(RM_RBLOCK) rm_red_strided(" << args()
       << "const rm_u64 pre, const rm_u64 red, const rm_u64 nsplit, const int tx, double* part_v, double* part_nan) {\n"
       << init() << "    rm_reduce_strided<RM_RSUM>(f, pre, red, nsplit, tx, part_v, part_nan);\n}\n\n";
@@ -442,6 +463,7 @@ int get_reduction_kernel(Context* c, const ReductionProgram& p, bool f32, std::s
     k->n_outputs = 1;
     RMHIP_HIP_CHECK(hipModuleLoadData(&k->module, code.data()));
     RMHIP_TRY(load_function(k->module, "rm_red_contig", &k->fn_contig));
+    RMHIP_TRY(load_function(k->module, "rm_red_contig2", &k->fn_contig2));
     RMHIP_TRY(load_function(k->module, "rm_red_strided", &k->fn_strided));
     RMHIP_TRY(load_function(k->module, "rm_red_final", &k->fn_final));
     std::lock_guard<std::mutex> lk(c->mu);

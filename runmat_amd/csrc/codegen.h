@@ -39,6 +39,7 @@ struct FusedKernel {
     hipFunction_t fn_fast1 = nullptr;   // elementwise: same, 8 B accesses (unaligned external memory)
     hipFunction_t fn_bcast = nullptr;   // elementwise: general broadcast, rank <= 8
     hipFunction_t fn_contig = nullptr;  // reduction kernel A
+    hipFunction_t fn_contig2 = nullptr; // reduction kernel A over 16-byte vectors (even slices, aligned full-size inputs)
     hipFunction_t fn_strided = nullptr; // reduction kernel B
     hipFunction_t fn_final = nullptr;   // reduction finalize
     int n_inputs = 0, n_outputs = 0;

@@ -26,7 +26,6 @@ __global__ void __launch_bounds__(RM_ABLOCK) k_reduce_contig(const T* x, rm_u64 
 }
 // Same reduction over 16-byte vectors (plain tensors, even slice length, 16-byte aligned base): 1 KiB per wave
 // instruction instead of 512 B, non-temporal.  The pairing changes only the (deterministic) summation grouping.
-typedef double rm_rv2 __attribute__((ext_vector_type(2)));
 typedef float rm_rv2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ rm_rv2 rm_load2(const double* x, rm_u64 i2) { return __builtin_nontemporal_load((const rm_rv2*)x + i2); }
 __device__ __forceinline__ rm_rv2 rm_load2(const float* x, rm_u64 i2) {
@@ -53,58 +52,6 @@ struct IdentityVal2 {
     __device__ __forceinline__ rm_rv2 pair_at(rm_u64 e) const { return rm_load2_at(x + e, false); }
     __device__ __forceinline__ double one_at(rm_u64 e) const { return (double)__builtin_nontemporal_load(x + e); }
 };
-// ODD: `red` is odd (or the base only element-aligned): slice s starts at element s * red, its red / 2 pairs are loaded with
-// unaligned 16-byte loads and the last element joins the accumulator of the thread that would own the next pair.
-template <int OP, bool ODD = false, class F2>
-__device__ __forceinline__ void rm_reduce_contig_v2(const F2& f2, rm_u64 red, rm_u64 nslices, rm_u64 nsplit, double* pv,
-                                                    double* pn) {
-    __shared__ RmAcc lds[RM_ABLOCK / 64];
-    const rm_u64 slice = blockIdx.y + (rm_u64)gridDim.y * blockIdx.z;
-    if (slice >= nslices) return;
-    const rm_u64 split = blockIdx.x, bs = blockDim.x, red2 = red >> 1;
-    rm_u64 chunk = (red2 + nsplit - 1) / nsplit;
-    chunk = (chunk + bs - 1) / bs * bs;
-    const rm_u64 begin = split * chunk;
-    rm_u64 end = begin + chunk;
-    if (end > red2) end = red2;
-    const rm_u64 base = slice * red2, ebase = slice * red;
-    auto ld = [&](rm_u64 rr) -> rm_rv2 {
-        if constexpr (ODD) return f2.pair_at(ebase + 2 * rr);
-        else return f2(base + rr);
-    };
-    RmAcc a0 = rm_acc_init<OP>(), a1 = rm_acc_init<OP>(), a2 = rm_acc_init<OP>(), a3 = rm_acc_init<OP>();
-    rm_u64 r = begin + threadIdx.x;
-    for (; r + 3 * bs < end; r += 4 * bs) {
-        const rm_rv2 x0 = ld(r), x1 = ld(r + bs), x2 = ld(r + 2 * bs), x3 = ld(r + 3 * bs);
-        rm_acc_add<OP>(a0, x0.x);
-        rm_acc_add<OP>(a1, x1.x);
-        rm_acc_add<OP>(a2, x2.x);
-        rm_acc_add<OP>(a3, x3.x);
-        rm_acc_add<OP>(a0, x0.y);
-        rm_acc_add<OP>(a1, x1.y);
-        rm_acc_add<OP>(a2, x2.y);
-        rm_acc_add<OP>(a3, x3.y);
-    }
-    for (; r < end; r += bs) {
-        const rm_rv2 v = ld(r);
-        rm_acc_add<OP>(a0, v.x);
-        rm_acc_add<OP>(a0, v.y);
-    }
-    if constexpr (ODD) {
-        // the leftover element: pair index red2 would be its pair - the chunk that contains that index owns it, and exactly one of
-        // its threads ends its walk there
-        const rm_u64 owner = red2 / chunk < nsplit - 1 ? red2 / chunk : nsplit - 1;
-        if ((red & 1) && split == owner && r == red2) rm_acc_add<OP>(a0, f2.one_at(ebase + red - 1));
-    }
-    rm_acc_merge<OP>(a0, a1);
-    rm_acc_merge<OP>(a2, a3);
-    rm_acc_merge<OP>(a0, a2);
-    a0 = rm_block_reduce<OP>(a0, lds);
-    if (threadIdx.x == 0) {
-        pv[slice * nsplit + split] = a0.v;
-        pn[slice * nsplit + split] = a0.nan;
-    }
-}
 template <int OP, class T, bool ODD = false>
 __global__ void __launch_bounds__(RM_ABLOCK) k_reduce_contig_v2(const T* x, rm_u64 red, rm_u64 nslices,
                                                                 rm_u64 nsplit, double* pv, double* pn) {

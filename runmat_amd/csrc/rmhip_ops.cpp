@@ -386,7 +386,14 @@ int rmhip_fused_reduction(rmhip_ctx* ctx, const char* shader, const rmhip_buf* i
         args.push_back(&u_nsplit);
         args.push_back(&pv);
         args.push_back(&pn);
-        e = hipModuleLaunchKernel(kern->fn_contig, plan.gx, plan.gy, plan.gz, (unsigned)plan.tx, 1, 1, 0, c->stream, args.data(), nullptr);
+        // 16-byte form (two adjacent elements per call of the value functor): even slices of at least 2048 elements, every full-size
+        // input aligned to its pair - as k_reduce_contig_v2 for plain tensors (+12-18 % there; the Monte-Carlo payoff sum 160 -> us)
+        bool wide = (reduce_len & 1) == 0 && reduce_len >= 2048;
+        const uintptr_t amask = f32 ? 7 : 15;
+        for (size_t k = 0; k < n_in && wide; ++k)
+            if (mult[k] && (((uintptr_t)in_ptr[k]) & amask) != 0) wide = false;
+        e = hipModuleLaunchKernel(wide ? kern->fn_contig2 : kern->fn_contig, plan.gx, plan.gy, plan.gz, (unsigned)plan.tx, 1, 1, 0, c->stream,
+                                  args.data(), nullptr);
     } else {
         args.push_back(&u_pre);
         args.push_back(&u_red);
