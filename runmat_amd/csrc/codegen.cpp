@@ -329,6 +329,11 @@ std::string generate_reduction_source(const ReductionProgram& p, bool f32) {
     s << "extern \"C\" __global__ void __launch_bounds__(RM_RBLOCK) rm_red_strided(" << args()
       << "const rm_u64 pre, const rm_u64 red, const rm_u64 nsplit, const int tx, double* part_v, double* part_nan) {\n"
       << init() << "    rm_reduce_strided<RM_RSUM>(f, pre, red, nsplit, tx, part_v, part_nan);\n}\n\n";
+    s << "extern \"C\" __global__ void __launch_bounds__(RM_RBLOCK) rm_red_strided2(" << args()
+      << "const rm_u64 pre, const rm_u64 red, const rm_u64 nsplit, const unsigned win, double* part_v, double* part_nan) {\n"
+      << "    RmVal2 f2;\n";
+    for (int k = 0; k < nin; ++k) s << "    f2.in" << k << " = in" << k << "; f2.m" << k << " = m" << k << ";\n";
+    s << "    rm_reduce_strided_v2<RM_RSUM, 4>(f2, pre, red, nsplit, win, part_v, part_nan);\n}\n\n";
     s << "extern \"C\" __global__ void __launch_bounds__(RM_RBLOCK) rm_red_final(const double* part_v, const double* "
          "part_nan, const rm_u64 nslices, const rm_u64 nsplit, const rm_u64 red, const int mean, const int omitnan, "
          "const double scale, double* out) {\n"
@@ -465,6 +470,7 @@ int get_reduction_kernel(Context* c, const ReductionProgram& p, bool f32, std::s
     RMHIP_TRY(load_function(k->module, "rm_red_contig", &k->fn_contig));
     RMHIP_TRY(load_function(k->module, "rm_red_contig2", &k->fn_contig2));
     RMHIP_TRY(load_function(k->module, "rm_red_strided", &k->fn_strided));
+    RMHIP_TRY(load_function(k->module, "rm_red_strided2", &k->fn_strided2));
     RMHIP_TRY(load_function(k->module, "rm_red_final", &k->fn_final));
     std::lock_guard<std::mutex> lk(c->mu);
     c->kernel_cache[key] = k;

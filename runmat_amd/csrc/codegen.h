@@ -41,6 +41,7 @@ struct FusedKernel {
     hipFunction_t fn_contig = nullptr;  // reduction kernel A
     hipFunction_t fn_contig2 = nullptr; // reduction kernel A over 16-byte vectors (even slices, aligned full-size inputs)
     hipFunction_t fn_strided = nullptr; // reduction kernel B
+    hipFunction_t fn_strided2 = nullptr; // reduction kernel B over 16-byte vectors (even `pre` >= 512, aligned full-size inputs)
     hipFunction_t fn_final = nullptr;   // reduction finalize
     int n_inputs = 0, n_outputs = 0;
     EwTuning tuning;

@@ -491,22 +491,20 @@ static int run_r2(Context* c, const double* x, size_t pre, size_t red, size_t po
     const bool wide_odd = wide && ((pre & 1) != 0 || (((uintptr_t)x) & 15) != 0);
     unsigned win = R2_BLOCK, threads = R2_BLOCK;
     if (!p.contiguous) {  // these kernels keep up to 256 threads along `pre`
-        const u64 npairs = (pre + 1) / 2;
-        gx = (unsigned)ceil_div_u64(wide ? npairs : pre, R2_BLOCK);
-        if (wide) {  // as for sum(x,2) (reduce_kernels.hip): a window count that is a multiple of the XCD count pins every window to one XCD
-            const unsigned xcds = c->num_xcc > 0 ? (unsigned)c->num_xcc : 8u;
-            if (pre / 2 >= xcds * 64) gx = (gx + xcds - 1) / xcds * xcds;
-            win = (unsigned)((ceil_div_u64(npairs, gx) + 7) / 8 * 8);
-            if (win > R2_BLOCK) win = R2_BLOCK;
-            gx = (unsigned)ceil_div_u64(npairs, win);
-            if (pre / 2 >= xcds * 64) gx = (gx + xcds - 1) / xcds * xcds;
-            threads = (win + 63) / 64 * 64;
+        if (wide) {  // as for sum(x,2): a window count that is a multiple of the XCD count pins every window to one XCD (reduce_plan.h)
+            const StridedWidePlan w = plan_strided_wide(pre, red, post, c->num_cus, c->num_xcc, 8u);
+            gx = w.bx;
+            win = w.win;
+            threads = w.threads;
+            nsplit = w.nsplit;
+        } else {
+            gx = (unsigned)ceil_div_u64(pre, R2_BLOCK);
+            u64 want = ceil_div_u64((u64)c->num_cus * 8, (u64)gx * post);
+            u64 max_split = ceil_div_u64(red, 16);
+            nsplit = want < 1 ? 1 : (want > max_split ? max_split : want);
+            nsplit = dealias_nsplit(red, nsplit, pre * 8, max_split);
+            if (nsplit > 65535) nsplit = 65535;
         }
-        u64 want = ceil_div_u64((u64)c->num_cus * (wide ? 3 : 8), (u64)gx * post);
-        u64 max_split = ceil_div_u64(red, 16);
-        nsplit = want < 1 ? 1 : (want > max_split ? max_split : want);
-        nsplit = dealias_nsplit(red, nsplit, pre * 8, max_split);
-        if (nsplit > 65535) nsplit = 65535;
     }
     const size_t nparts = (size_t)(p.nslices * nsplit);
     RMHIP_TRY(c->ensure_scratch(nparts * sizeof(Acc)));

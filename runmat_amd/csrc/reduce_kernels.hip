@@ -161,20 +161,11 @@ static int run_reduce(Context* c, int mean, int nan_mode, const T* x, size_t pre
         // The windows are balanced (128-byte granules) and a block has as many waves as its window needs.  RMHIP_RED_B_X8=0
         // restores the old geometry.  (Also measured: two or four pairs per thread, 8-16 KiB of every column per block: 103-152 us.)
         static const int b_x8 = getenv("RMHIP_RED_B_X8") ? atoi(getenv("RMHIP_RED_B_X8")) : 1;
-        const unsigned xcds = c->num_xcc > 0 ? (unsigned)c->num_xcc : 8u;
-        const uint64_t npairs = (pre + 1) / 2;
-        wide_bx = (unsigned)ceil_div_u64(npairs, RM_RBLOCK);
-        if (b_x8 && pre / 2 >= xcds * 64) wide_bx = (wide_bx + xcds - 1) / xcds * xcds;
-        wide_win = (unsigned)((ceil_div_u64(npairs, wide_bx) + 7) / 8 * 8);
-        if (wide_win > RM_RBLOCK) wide_win = RM_RBLOCK;
-        wide_bx = (unsigned)ceil_div_u64(npairs, wide_win);
-        if (b_x8 && pre / 2 >= xcds * 64) wide_bx = (wide_bx + xcds - 1) / xcds * xcds;  // (trailing windows may be empty)
-        wide_threads = (wide_win + 63) / 64 * 64;
-        uint64_t want = ceil_div_u64((uint64_t)c->num_cus * b_bpc, (uint64_t)wide_bx * post);
-        uint64_t max_split = ceil_div_u64(red, 16);
-        nsplit = want < 1 ? 1 : want;
-        if (nsplit > max_split) nsplit = max_split;
-        nsplit = dealias_nsplit(red, nsplit, pre * sizeof(T), max_split);  // reduce_plan.h: chunks off the same memory channels
+        const StridedWidePlan w = plan_strided_wide(pre, red, post, c->num_cus, c->num_xcc, (unsigned)sizeof(T), b_bpc, b_x8 != 0);  // reduce_plan.h
+        wide_bx = w.bx;
+        wide_win = w.win;
+        wide_threads = w.threads;
+        nsplit = w.nsplit;
         static const long dev_chunk = getenv("RMHIP_RED_B_CHUNK") ? atol(getenv("RMHIP_RED_B_CHUNK")) : 0;  // dev knob: columns per chunk
         if (dev_chunk > 0) nsplit = ceil_div_u64(red, (uint64_t)dev_chunk);
         if (nsplit > 65535) nsplit = 65535;

@@ -89,4 +89,34 @@ inline ReducePlan plan_reduction(uint64_t pre, uint64_t red, uint64_t post, int 
     return p;
 }
 
+// Geometry of kernel B over 16-byte vectors (a thread owns two adjacent lines; reduce_kernels.hip k_reduce_strided_v2, reduce2.hip,
+// generated rm_red_strided2): `bx` windows of `win` pairs along `pre`, their number a multiple of the XCD count - workgroups go to the
+// XCDs round robin in launch order (x fastest), so with bx % xcds == 0 a window is always walked by the same XCD whatever the chunk -,
+// balanced (128-byte granules), a block of as many waves as its window needs, and `blocks_per_cu` blocks per CU over (bx, nsplit, post).
+struct StridedWidePlan {
+    unsigned bx, win, threads;
+    uint64_t nsplit;
+};
+inline StridedWidePlan plan_strided_wide(uint64_t pre, uint64_t red, uint64_t post, int num_cus, int xcds_probed, unsigned elem_bytes,
+                                         int blocks_per_cu = 3, bool pin_xcds = true) {
+    StridedWidePlan w{};
+    const unsigned xcds = xcds_probed > 0 ? (unsigned)xcds_probed : 8u;
+    const uint64_t npairs = (pre + 1) / 2;
+    const bool pin = pin_xcds && pre / 2 >= (uint64_t)xcds * 64;
+    w.bx = (unsigned)ceil_div_u64(npairs, 256);
+    if (pin) w.bx = (w.bx + xcds - 1) / xcds * xcds;
+    w.win = (unsigned)((ceil_div_u64(npairs, w.bx) + 7) / 8 * 8);
+    if (w.win > 256) w.win = 256;
+    w.bx = (unsigned)ceil_div_u64(npairs, w.win);
+    if (pin) w.bx = (w.bx + xcds - 1) / xcds * xcds;  // (trailing windows may be empty)
+    w.threads = (w.win + 63) / 64 * 64;
+    uint64_t want = ceil_div_u64((uint64_t)num_cus * blocks_per_cu, (uint64_t)w.bx * (post ? post : 1));
+    const uint64_t max_split = ceil_div_u64(red, 16);
+    w.nsplit = want < 1 ? 1 : want;
+    if (w.nsplit > max_split) w.nsplit = max_split;
+    w.nsplit = dealias_nsplit(red, w.nsplit, pre * elem_bytes, max_split);
+    if (w.nsplit > 65535) w.nsplit = 65535;
+    return w;
+}
+
 }  // namespace rmhip

@@ -361,7 +361,24 @@ int rmhip_fused_reduction(rmhip_ctx* ctx, const char* shader, const rmhip_buf* i
     const size_t post = prog.axis == 0 ? num_slices : 1;
     const ReducePlan plan = plan_reduction(pre, reduce_len, post, c->num_cus, f32 ? 4u : 8u);
     if (!plan.valid) return fail(RMHIP_ERR_UNSUPPORTED, "fused_reduction: geometry exceeds launch limits");
-    const size_t nparts = (size_t)(plan.nslices * plan.nsplit);
+    std::vector<const double*> in_ptr(n_in);
+    std::vector<void*> args;
+    for (size_t k = 0; k < n_in; ++k) {
+        in_ptr[k] = in[k].data();
+        args.push_back(&in_ptr[k]);
+        args.push_back(&mult[k]);
+    }
+    // the 16-byte forms need every full-size input aligned to its pair
+    bool pairs_ok = true;
+    for (size_t k = 0; k < n_in && pairs_ok; ++k)
+        if (mult[k] && (((uintptr_t)in_ptr[k]) & (f32 ? 7u : 15u)) != 0) pairs_ok = false;
+    // kernel B over 16-byte vectors (two adjacent slices per thread) with the XCD-pinned window geometry of sum(x,2) (reduce_plan.h):
+    // even `pre` >= 512
+    const bool wide_b = !plan.contiguous && pairs_ok && (pre & 1) == 0 && pre >= 512 && post <= 65535;
+    StridedWidePlan wplan{};
+    if (wide_b) wplan = plan_strided_wide(pre, reduce_len, post, c->num_cus, c->num_xcc, f32 ? 4u : 8u);
+    const unsigned long long nsplit_used = wide_b ? wplan.nsplit : plan.nsplit;
+    const size_t nparts = (size_t)(plan.nslices * nsplit_used);
     RMHIP_TRY(c->ensure_scratch(2 * nparts * sizeof(double)));
     double* pv = c->scratch;
     double* pn = c->scratch + nparts;
@@ -370,14 +387,7 @@ int rmhip_fused_reduction(rmhip_ctx* ctx, const char* shader, const rmhip_buf* i
     rmhip_buf oid = 0;
     RMHIP_TRY(c->new_buffer(out_shape, rank, &oid, &ob));
 
-    std::vector<const double*> in_ptr(n_in);
-    std::vector<void*> args;
-    for (size_t k = 0; k < n_in; ++k) {
-        in_ptr[k] = in[k].data();
-        args.push_back(&in_ptr[k]);
-        args.push_back(&mult[k]);
-    }
-    unsigned long long u_pre = pre, u_red = reduce_len, u_nsplit = plan.nsplit, u_nslices = plan.nslices;
+    unsigned long long u_pre = pre, u_red = reduce_len, u_nsplit = nsplit_used, u_nslices = plan.nslices;
     int tx = plan.tx;
     hipError_t e;
     if (plan.contiguous) {
@@ -388,12 +398,19 @@ int rmhip_fused_reduction(rmhip_ctx* ctx, const char* shader, const rmhip_buf* i
         args.push_back(&pn);
         // 16-byte form (two adjacent elements per call of the value functor): even slices of at least 2048 elements, every full-size
         // input aligned to its pair - as k_reduce_contig_v2 for plain tensors (+12-18 % there; the Monte-Carlo payoff sum 160 -> us)
-        bool wide = (reduce_len & 1) == 0 && reduce_len >= 2048;
-        const uintptr_t amask = f32 ? 7 : 15;
-        for (size_t k = 0; k < n_in && wide; ++k)
-            if (mult[k] && (((uintptr_t)in_ptr[k]) & amask) != 0) wide = false;
+        const bool wide = pairs_ok && (reduce_len & 1) == 0 && reduce_len >= 2048;
         e = hipModuleLaunchKernel(wide ? kern->fn_contig2 : kern->fn_contig, plan.gx, plan.gy, plan.gz, (unsigned)plan.tx, 1, 1, 0, c->stream,
                                   args.data(), nullptr);
+    } else if (wide_b) {
+        unsigned win = wplan.win;
+        args.push_back(&u_pre);
+        args.push_back(&u_red);
+        args.push_back(&u_nsplit);
+        args.push_back(&win);
+        args.push_back(&pv);
+        args.push_back(&pn);
+        e = hipModuleLaunchKernel(kern->fn_strided2, wplan.bx, (unsigned)wplan.nsplit, (unsigned)post, wplan.threads, 1, 1, 0, c->stream, args.data(),
+                                  nullptr);
     } else {
         args.push_back(&u_pre);
         args.push_back(&u_red);

@@ -280,4 +280,43 @@ __device__ __forceinline__ void rm_reduce_contig_v2(const F2& f2, rm_u64 red, rm
     }
 }
 
+// ---- kernel B over 16-byte vectors for generated fused reductions: a thread owns TWO adjacent slices (pair index along `pre`) and
+// walks its chunk of the reduced extent in ascending order with U vector loads in flight - the per-slice summation order of
+// rm_reduce_strided with ty == 1.  Geometry from reduce_plan.h (plan_strided_wide): blockIdx.x = window of `win` pairs, blockIdx.y =
+// chunk, blockIdx.z = post.  (The plain-tensor kernel k_reduce_strided_v2 in reduce_kernels.hip is the same walk plus the odd-extent form.)
+template <int OP, int U, class F2>
+__device__ __forceinline__ void rm_reduce_strided_v2(const F2& f2, rm_u64 pre, rm_u64 red, rm_u64 nsplit, unsigned win, double* pv, double* pn) {
+    const rm_u64 i2 = (rm_u64)blockIdx.x * win + threadIdx.x;
+    const rm_u64 pre2 = pre >> 1;
+    if (threadIdx.x >= win || i2 >= pre2) return;
+    const rm_u64 split = blockIdx.y, j = blockIdx.z;
+    const rm_u64 chunk = (red + nsplit - 1) / nsplit;
+    const rm_u64 begin = split * chunk;
+    rm_u64 end = begin + chunk;
+    if (end > red) end = red;
+    RmAcc a0 = rm_acc_init<OP>(), a1 = rm_acc_init<OP>();
+    const rm_u64 base2 = i2 + pre2 * red * j;
+    rm_u64 r = begin;
+    for (; r + U <= end; r += U) {
+        rm_rv2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = f2(base2 + pre2 * (r + u));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            rm_acc_add<OP>(a0, v[u].x);
+            rm_acc_add<OP>(a1, v[u].y);
+        }
+    }
+    for (; r < end; ++r) {
+        const rm_rv2 v = f2(base2 + pre2 * r);
+        rm_acc_add<OP>(a0, v.x);
+        rm_acc_add<OP>(a1, v.y);
+    }
+    const rm_u64 slice = 2 * i2 + pre * j;
+    pv[slice * nsplit + split] = a0.v;
+    pn[slice * nsplit + split] = a0.nan;
+    pv[(slice + 1) * nsplit + split] = a1.v;
+    pn[(slice + 1) * nsplit + split] = a1.nan;
+}
+
 #endif  // RMHIP_SKEL_REDUCE
