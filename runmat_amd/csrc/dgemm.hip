@@ -984,8 +984,11 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
     const bool vec_ok = (lda % 2 == 0) && (ldb % 2 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
     static const int guard_lu = std::getenv("RMHIP_GEMM_GUARD_LU") ? std::atoi(std::getenv("RMHIP_GEMM_GUARD_LU")) : 1;  // A/B: guarded tiles inside the look-ahead LU
     const bool guard_ok = guard_on && !tb && k >= 1 && (guard_lu || (!c->in_lookahead && c->gemm_lds_pad == 0));
-    const bool small_shape = !ep && !ta && !tb && splits == 1 && (c->gemm_lds_pad == 0 || small_force) && k > 0 && (k <= 1024 || small_force) &&
-                             ((size_t)blocks * 2 <= (size_t)c->num_cus || small_force);
+    // (skinny products - at most 64 rows or columns of output - waste half of every 128 x 128 tile or more: 100000 x 50 x 50 52 -> 30 us,
+    // 200000 x 16 x 16 34 -> 20 us, 4096 x 4096 x 32 544 -> 249 us on the 64 x 64 tiles, whatever the block count)
+    const bool skinny = (m <= (size_t)SM || n <= (size_t)SN) && k <= 4096 && !c->in_lookahead;
+    const bool small_shape = !ep && !ta && !tb && splits == 1 && (c->gemm_lds_pad == 0 || small_force) && k > 0 &&
+                             ((k <= 1024 && (size_t)blocks * 2 <= (size_t)c->num_cus) || skinny || small_force);
     const bool small_whole = (m % SM == 0) && (n % SN == 0) && (k % BK == 0) && vec_ok;
     if (small_on && small_shape && (small_whole || guard_ok)) {
         g.tiles_m = (unsigned)((m + SM - 1) / SM);
