@@ -940,10 +940,13 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
     g.tile_counter = nullptr;
     g.avoid_xcc = nullptr;
     std::shared_ptr<Allocation> partials;
-    if (!ep && blocks * 4 <= (unsigned)c->num_cus && k >= 8192) {
+    // (round 3: from k = 2048 - slices of multiples of 256 - outside the LU: 4096 x 4096 x 100 (32 tiles) 547 us on one slice)
+    const size_t split_min_k = c->in_lookahead ? 8192 : 2048;
+    if (!ep && blocks * 4 <= (unsigned)c->num_cus && k >= split_min_k && !(m <= (size_t)SM || n <= (size_t)SN)) {
         const size_t want = (2 * (size_t)c->num_cus + blocks - 1) / blocks;
         size_t chunk = (k + want - 1) / want;
-        chunk = ((chunk + 1023) / 1024) * 1024;
+        const size_t gran = k >= 8192 ? 1024 : 256;
+        chunk = ((chunk + gran - 1) / gran) * gran;
         splits = (unsigned)((k + chunk - 1) / chunk);
         if (splits > 1) {
             RMHIP_TRY(c->alloc_device((size_t)splits * m * n, &partials));
