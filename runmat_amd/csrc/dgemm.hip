@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
     const unsigned am = m0 + 2 * p_xp;
     const unsigned a_r0 = (GUARD && am >= g.m) ? g.m - 1 : am;
     const bool a_single = GUARD && a_r0 + 1 >= g.m;                 // the matrix's last row alone (odd m) or a clamped pair
-    const bool a_edge = GUARD && (g.m & 1u) && m0 + SM > g.m;       // uniform: such threads exist in this block
+    const bool a_edge = GUARD && m0 + SM > g.m;  // uniform: such threads exist in this block (an even m too: its clamped threads sit on the last row and must not read a pair)
     const double* const Ap = g.A + a_r0;
     const double* const Bp = g.B + 2 * q_kp;
     size_t b_row[2];
@@ -598,7 +598,7 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
     auto rowY = [&](unsigned r, unsigned lim) { return (GUARD && r >= lim) ? lim - 1 : r; };
     const unsigned a_r0 = rowY(m0 + 2 * p_xp, g.m);
     const bool a_single = GUARD && !TA && a_r0 + 1 >= g.m;                 // this thread's pair is the matrix's last row alone (or clamped)
-    const bool a_edge = GUARD && !TA && (g.m & 1u) && m0 + BM > g.m;       // uniform: such threads exist in this block
+    const bool a_edge = GUARD && !TA && m0 + BM > g.m;  // uniform: such threads exist in this block (an even m too: its clamped threads sit on the last row and must not read a pair)
     const double* const Ap = TA ? gA + 2 * q_kp : gA + a_r0;
     const double* const Bp = TB ? gB + n0 + 2 * p_xp : gB + 2 * q_kp;
     size_t a_row[2], b_row[2];  // pattern K: element offset of this thread's two rows

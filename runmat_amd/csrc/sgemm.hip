@@ -240,7 +240,7 @@ __device__ __forceinline__ void sgemm_w8_body(const SgemmArgs& g, float* lds) {
     auto rowY = [&](unsigned r, unsigned lim) { return (GUARD && r >= lim) ? lim - 1 : r; };
     const unsigned a_r0 = rowY(m0 + 2 * p_xp, g.m);
     const bool a_single = GUARD && !TA && a_r0 + 1 >= g.m;            // the matrix's last row alone (odd m) or a clamped pair
-    const bool a_edge = GUARD && !TA && (g.m & 1u) && m0 + BM > g.m;  // uniform: such threads exist in this block
+    const bool a_edge = GUARD && !TA && m0 + BM > g.m;  // uniform: such threads exist in this block (an even m too: its clamped threads sit on the last row and must not read a pair)
     const float* const Ap = TA ? g.A + 2 * q_kp : g.A + a_r0;
     const float* const Bp = g.B + 2 * q_kp;
     size_t a_row[2], b_row[2];

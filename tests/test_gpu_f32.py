@@ -387,7 +387,8 @@ def test_f32_matmul_solve_and_friends_use_f64_kernels_on_widened_operands(prov32
 
 @pytest.mark.parametrize("m,k,n", [(128, 16, 128), (256, 128, 384), (150, 70, 90), (1, 33, 1), (129, 1, 127), (5, 1000, 7),
                                    (640, 515, 130), (768, 1024, 512), (3, 2, 4),
-                                   (128, 16384, 128), (200, 9000, 70), (64, 20000, 64)])  # the last three split along k
+                                   (128, 16384, 128), (200, 9000, 70), (64, 20000, 64),  # these three split along k
+                                   (64, 8192, 48), (32, 16384, 20)])  # A fills whole 2 MiB pages, partial tile of rows: no pair read behind the buffer
 def test_f32_matmul_on_the_f32_matrix_cores(prov32, oracle, m, k, n, monkeypatch):
     """Default precision-32 matmul: v_mfma_f32_16x16x4_f32 with f32 accumulation (what the reference's F32 backend
     does; its checks allow 1e-4 relative, wgpu_profile.rs:20-21).  Bound: k * eps32 * sum|a||b| per element, the

@@ -484,7 +484,10 @@ def test_matmul_reference_kats_exact(prov):
 
 @pytest.mark.parametrize("m,k,n", [(2, 2, 2), (130, 66, 258), (258, 130, 70), (64, 1030, 200), (384, 2050, 130), (1000, 1000, 1000),
                                    (6, 18, 3), (640, 48, 1290), (256, 9000, 128), (1, 1, 1), (3, 5, 7), (131, 67, 259), (257, 1031, 129),
-                                   (999, 1001, 997), (129, 17, 1), (1, 4097, 255)])
+                                   (999, 1001, 997), (129, 17, 1), (1, 4097, 255),
+                                   # A fills whole 2 MiB pages and m is a partial tile: a clamped thread reading a PAIR from the last row
+                                   # would touch the page behind the buffer (found by scripts/gemm_grid.py at 32 x 8192 x 32)
+                                   (32, 8192, 32), (64, 4096, 48), (96, 8192, 17), (160, 16384, 40)])
 def test_matmul_ragged_shapes(prov, oracle, m, k, n):
     """Shapes that are not whole tiles - odd m, n, k and leading dimensions included - run the tile kernels with clamped operand
     loads, scalar loads for the pairs that straddle the matrix edge, a zeroed k tail and checked stores (dgemm.hip, GUARD): the
