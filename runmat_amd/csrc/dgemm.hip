@@ -940,12 +940,14 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
     g.tile_counter = nullptr;
     g.avoid_xcc = nullptr;
     std::shared_ptr<Allocation> partials;
-    // (round 3: from k = 2048 - slices of multiples of 256 - outside the LU: 4096 x 4096 x 100 (32 tiles) 547 us on one slice)
-    const size_t split_min_k = c->in_lookahead ? 8192 : 2048;
-    if (!ep && blocks * 4 <= (unsigned)c->num_cus && k >= split_min_k && !(m <= (size_t)SM || n <= (size_t)SN)) {
+    // (round 3: from k = 1024 - slices of multiples of 128 - outside the LU.  A block walks its k range at about 1 us per 16 columns
+    // - one memory latency per tile with nothing else resident - so few blocks with a long k are latency bound whatever the tile:
+    // 4096 x 100 with k = 4096 (32 tiles) 547 -> 97 us, 32 x 512 with k = 8192 on one slice 1100 us.)
+    const size_t split_min_k = c->in_lookahead ? 8192 : 1024;
+    if (!ep && blocks * 4 <= (unsigned)c->num_cus && k >= split_min_k) {
         const size_t want = (2 * (size_t)c->num_cus + blocks - 1) / blocks;
         size_t chunk = (k + want - 1) / want;
-        const size_t gran = k >= 8192 ? 1024 : 256;
+        const size_t gran = k >= 8192 ? 1024 : (k >= 2048 ? 256 : 128);
         chunk = ((chunk + gran - 1) / gran) * gran;
         splits = (unsigned)((k + chunk - 1) / chunk);
         if (splits > 1) {
@@ -988,8 +990,8 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
     static const int guard_lu = std::getenv("RMHIP_GEMM_GUARD_LU") ? std::atoi(std::getenv("RMHIP_GEMM_GUARD_LU")) : 1;  // A/B: guarded tiles inside the look-ahead LU
     const bool guard_ok = guard_on && !tb && k >= 1 && (guard_lu || (!c->in_lookahead && c->gemm_lds_pad == 0));
     // (skinny products - at most 64 rows or columns of output - waste half of every 128 x 128 tile or more: 100000 x 50 x 50 52 -> 30 us,
-    // 200000 x 16 x 16 34 -> 20 us, 4096 x 4096 x 32 544 -> 249 us on the 64 x 64 tiles, whatever the block count)
-    const bool skinny = (m <= (size_t)SM || n <= (size_t)SN) && k <= 4096 && !c->in_lookahead;
+    // 200000 x 16 x 16 34 -> 20 us on the 64 x 64 tiles, whatever the block count)
+    const bool skinny = (m <= (size_t)SM || n <= (size_t)SN) && k < 1024 && !c->in_lookahead;  // (longer k: split-K above)
     const bool small_shape = !ep && !ta && !tb && splits == 1 && (c->gemm_lds_pad == 0 || small_force) && k > 0 &&
                              ((k <= 1024 && (size_t)blocks * 2 <= (size_t)c->num_cus) || skinny || small_force);
     const bool small_whole = (m % SM == 0) && (n % SN == 0) && (k % BK == 0) && vec_ok;
