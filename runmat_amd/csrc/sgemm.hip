@@ -420,10 +420,11 @@ int launch_sgemm_trans(Context* c, bool ta, bool tb, size_t m, size_t n, size_t 
     g.k_chunk = (unsigned)k;
     g.c_split_stride = 0;
     std::shared_ptr<Allocation> partials;
-    if (blocks * 4 <= (unsigned)c->num_cus && k >= 8192) {
+    if (blocks * 4 <= (unsigned)c->num_cus && k >= 1024) {  // (from k = 1024, as dgemm.hip: few blocks with a long k are latency bound)
         const size_t want = (2 * (size_t)c->num_cus + blocks - 1) / blocks;
         size_t chunk = (k + want - 1) / want;
-        chunk = ((chunk + 1023) / 1024) * 1024;  // multiples of 1024 keep the unguarded kernel eligible
+        const size_t gran = k >= 8192 ? 1024 : (k >= 2048 ? 256 : 128);  // multiples of the k tile keep the unguarded kernel eligible
+        chunk = ((chunk + gran - 1) / gran) * gran;
         splits = (unsigned)((k + chunk - 1) / chunk);
         if (splits > 1) {
             RMHIP_TRY(c->alloc_device(((size_t)splits * m * n + 1) / 2, &partials));
