@@ -337,7 +337,11 @@ std::string generate_reduction_source(const ReductionProgram& p, bool f32) {
     s << "extern \"C\" __global__ void __launch_bounds__(RM_RBLOCK) rm_red_final(const double* part_v, const double* "
          "part_nan, const rm_u64 nslices, const rm_u64 nsplit, const rm_u64 red, const int mean, const int omitnan, "
          "const double scale, double* out) {\n"
-         "    rm_reduce_finalize<RM_RSUM>(part_v, part_nan, nslices, nsplit, red, mean, omitnan, scale, out);\n}\n";
+         "    rm_reduce_finalize<RM_RSUM>(part_v, part_nan, nslices, nsplit, red, mean, omitnan, scale, out);\n}\n\n";
+    s << "extern \"C\" __global__ void __launch_bounds__(RM_RBLOCK) rm_red_final_flat(const double* part_v, const double* "
+         "part_nan, const rm_u64 nslices, const rm_u64 nsplit, const rm_u64 red, const int mean, const int omitnan, "
+         "const double scale, double* out) {\n"
+         "    rm_reduce_finalize_flat<RM_RSUM>(part_v, part_nan, nslices, nsplit, red, mean, omitnan, scale, out);\n}\n";
     return s.str();
 }
 
@@ -472,6 +476,7 @@ int get_reduction_kernel(Context* c, const ReductionProgram& p, bool f32, std::s
     RMHIP_TRY(load_function(k->module, "rm_red_strided", &k->fn_strided));
     RMHIP_TRY(load_function(k->module, "rm_red_strided2", &k->fn_strided2));
     RMHIP_TRY(load_function(k->module, "rm_red_final", &k->fn_final));
+    RMHIP_TRY(load_function(k->module, "rm_red_final_flat", &k->fn_final_flat));
     std::lock_guard<std::mutex> lk(c->mu);
     c->kernel_cache[key] = k;
     *out = k;

@@ -43,6 +43,7 @@ struct FusedKernel {
     hipFunction_t fn_strided = nullptr; // reduction kernel B
     hipFunction_t fn_strided2 = nullptr; // reduction kernel B over 16-byte vectors (even `pre` >= 512, aligned full-size inputs)
     hipFunction_t fn_final = nullptr;   // reduction finalize
+    hipFunction_t fn_final_flat = nullptr;  // the same, one thread per slice (many slices, a handful of partials each)
     int n_inputs = 0, n_outputs = 0;
     EwTuning tuning;
     std::string key_text;  // what the cache key hashes: compared on every hit

@@ -296,6 +296,28 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_contig_v2(const double* __restr
     if (threadIdx.x == 0) part[slice * nsplit + split] = lds[0];
 }
 
+// many short contiguous slices (red < 256): a block stages a tile of consecutive slices in LDS with coalesced loads and thread t folds
+// slice t in ascending order (reduce_kernels.hip: k_reduce_short) - one block per slice is half a million blocks for min(x,[],1) of a
+// 32 x 524288 matrix
+static constexpr int R2_SHORT_TILE = 4096;
+__device__ __forceinline__ int r2_short_pad(int i) { return i + (i >> 5); }
+template <class Acc>
+__global__ void __launch_bounds__(R2_BLOCK) k_r2_short(const double* __restrict__ x, u64 red, u64 nslices, unsigned per_block, Acc* __restrict__ part) {
+    __shared__ double tile[R2_SHORT_TILE + R2_SHORT_TILE / 32 + 1];
+    const u64 s0 = (u64)blockIdx.x * per_block;
+    const u64 ns = nslices - s0 < per_block ? nslices - s0 : per_block;
+    const u64 count = ns * red;
+    const double* src = x + s0 * red;
+    for (u64 i = threadIdx.x; i < count; i += R2_BLOCK) tile[r2_short_pad((int)i)] = __builtin_nontemporal_load(src + i);
+    __syncthreads();
+    if (threadIdx.x >= ns) return;
+    Acc a;
+    a.init();
+    const int b = (int)(threadIdx.x * red);
+    for (int r = 0; r < (int)red; ++r) a.add((u64)r, tile[r2_short_pad(b + r)]);
+    part[s0 + threadIdx.x] = a;
+}
+
 // pre > 1: threads run along `pre` (coalesced), each walks its chunk of `red` in ascending order.  grid (ceil(pre / 256), nsplit, post)
 template <class Acc>
 __global__ void __launch_bounds__(R2_BLOCK) k_r2_strided(const double* __restrict__ x, u64 pre, u64 red, u64 nsplit, Acc* __restrict__ part) {
@@ -443,6 +465,17 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_final(const Acc* __restrict__ p
     if (lane == 0) fin(slice, a);
 }
 
+// one thread per slice, its few chunks merged in chunk order (many slices with one or a handful of chunks each)
+template <class Acc, class Fin>
+__global__ void __launch_bounds__(R2_BLOCK) k_r2_final_flat(const Acc* __restrict__ part, u64 nslices, u64 nsplit, Fin fin) {
+    const u64 slice = (u64)blockIdx.x * R2_BLOCK + threadIdx.x;
+    if (slice >= nslices) return;
+    Acc a;
+    a.init();
+    for (u64 s = 0; s < nsplit; ++s) a.merge(part[slice * nsplit + s]);
+    fin(slice, a);
+}
+
 template <bool MAX>
 struct ArgFin {
     double* values;
@@ -506,10 +539,17 @@ static int run_r2(Context* c, const double* x, size_t pre, size_t red, size_t po
             if (nsplit > 65535) nsplit = 65535;
         }
     }
+    const bool short_a = p.contiguous && red < 256 && p.nslices >= 1024;
+    if (short_a) nsplit = 1;
     const size_t nparts = (size_t)(p.nslices * nsplit);
     RMHIP_TRY(c->ensure_scratch(nparts * sizeof(Acc)));
     Acc* part = reinterpret_cast<Acc*>(c->scratch);
-    if (p.contiguous && (red & 1) == 0 && red >= 4 * R2_BLOCK && (((uintptr_t)x) & 15) == 0)
+    if (short_a) {
+        unsigned per_block = (unsigned)(R2_SHORT_TILE / red);
+        if (per_block > R2_BLOCK) per_block = R2_BLOCK;
+        hipLaunchKernelGGL((k_r2_short<Acc>), dim3((unsigned)ceil_div_u64(p.nslices, per_block)), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices,
+                           per_block, part);
+    } else if (p.contiguous && (red & 1) == 0 && red >= 4 * R2_BLOCK && (((uintptr_t)x) & 15) == 0)
         hipLaunchKernelGGL((k_r2_contig_v2<Acc>), dim3((unsigned)nsplit, p.gy, p.gz), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices, nsplit, part);
     else if (p.contiguous && red >= 4 * R2_BLOCK)  // odd slice length or element-aligned base
         hipLaunchKernelGGL((k_r2_contig_v2<Acc, true>), dim3((unsigned)nsplit, p.gy, p.gz), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices, nsplit, part);
@@ -522,8 +562,12 @@ static int run_r2(Context* c, const double* x, size_t pre, size_t red, size_t po
     else
         hipLaunchKernelGGL((k_r2_strided<Acc>), dim3(gx, (unsigned)nsplit, (unsigned)post), dim3(R2_BLOCK), 0, c->stream, x, (u64)pre, (u64)red, nsplit, part);
     RMHIP_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL((k_r2_final<Acc, Fin>), dim3((unsigned)ceil_div_u64(p.nslices, R2_BLOCK / 64)), dim3(R2_BLOCK), 0, c->stream, part,
-                       (u64)p.nslices, nsplit, fin);
+    if (nsplit <= 8 && p.nslices >= 1024)
+        hipLaunchKernelGGL((k_r2_final_flat<Acc, Fin>), dim3((unsigned)ceil_div_u64(p.nslices, R2_BLOCK)), dim3(R2_BLOCK), 0, c->stream, part,
+                           (u64)p.nslices, nsplit, fin);
+    else
+        hipLaunchKernelGGL((k_r2_final<Acc, Fin>), dim3((unsigned)ceil_div_u64(p.nslices, R2_BLOCK / 64)), dim3(R2_BLOCK), 0, c->stream, part,
+                           (u64)p.nslices, nsplit, fin);
     RMHIP_HIP_CHECK(hipGetLastError());
     c->tel.kernel_launches += 2;
     return RMHIP_OK;

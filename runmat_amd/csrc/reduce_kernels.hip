@@ -59,6 +59,31 @@ __global__ void __launch_bounds__(RM_ABLOCK) k_reduce_contig_v2(const T* x, rm_u
     rm_reduce_contig_v2<OP, ODD>(f2, red, nslices, nsplit, pv, pn);
 }
 
+// Many SHORT contiguous slices (red < 256: sum(x,1) of a 3 x N or 32 x N matrix).  Kernel A gives every slice a block of its own -
+// 256 threads for a few elements, half a million blocks for a 32 x 524288 matrix: 731 us where the bytes take 25.  Here a block
+// takes S = min(256, 4096 / red) consecutive slices - one contiguous tile of S * red elements -, stages it in LDS with coalesced
+// loads (one pad per 32 elements: the per-thread walks then fall on distinct banks) and thread t folds slice t in ascending order,
+// the CPU's own sequence.  One partial per slice; the flat finalize applies the NaN / mean policy.
+static constexpr int SHORT_TILE = 4096;
+__device__ __forceinline__ int short_pad(int i) { return i + (i >> 5); }
+template <int OP, class T>
+__global__ void __launch_bounds__(RM_RBLOCK) k_reduce_short(const T* __restrict__ x, rm_u64 red, rm_u64 nslices, unsigned per_block, double* pv,
+                                                            double* pn) {
+    __shared__ double tile[SHORT_TILE + SHORT_TILE / 32 + 1];
+    const rm_u64 s0 = (rm_u64)blockIdx.x * per_block;
+    const rm_u64 ns = nslices - s0 < per_block ? nslices - s0 : per_block;
+    const rm_u64 count = ns * red;
+    const T* src = x + s0 * red;
+    for (rm_u64 i = threadIdx.x; i < count; i += RM_RBLOCK) tile[short_pad((int)i)] = (double)__builtin_nontemporal_load(src + i);
+    __syncthreads();
+    if (threadIdx.x >= ns) return;
+    RmAcc a = rm_acc_init<OP>();
+    const int b = (int)(threadIdx.x * red);
+    for (int r = 0; r < (int)red; ++r) rm_acc_add<OP>(a, tile[short_pad(b + r)]);
+    pv[s0 + threadIdx.x] = a.v;
+    pn[s0 + threadIdx.x] = a.nan;
+}
+
 template <int OP, class T>
 __global__ void __launch_bounds__(RM_RBLOCK) k_reduce_strided(const T* x, rm_u64 pre, rm_u64 red, rm_u64 nsplit,
                                                               int tx, double* pv, double* pn) {
@@ -128,6 +153,11 @@ __global__ void __launch_bounds__(RM_RBLOCK) k_reduce_final(const double* pv, co
                                                             double scale, double* out) {
     rm_reduce_finalize<OP>(pv, pn, nslices, nsplit, red, mean, omitnan, scale, out);
 }
+template <int OP>
+__global__ void __launch_bounds__(RM_RBLOCK) k_reduce_final_flat(const double* pv, const double* pn, rm_u64 nslices, rm_u64 nsplit, rm_u64 red,
+                                                                 int mean, int omitnan, double scale, double* out) {
+    rm_reduce_finalize_flat<OP>(pv, pn, nslices, nsplit, red, mean, omitnan, scale, out);
+}
 
 template <int OP, class T>
 static int run_reduce(Context* c, int mean, int nan_mode, const T* x, size_t pre, size_t red, size_t post,
@@ -170,11 +200,18 @@ static int run_reduce(Context* c, int mean, int nan_mode, const T* x, size_t pre
         if (dev_chunk > 0) nsplit = ceil_div_u64(red, (uint64_t)dev_chunk);
         if (nsplit > 65535) nsplit = 65535;
     }
+    const bool short_a = p.contiguous && red >= 1 && red < 256 && p.nslices >= 1024;  // many short contiguous slices: a tile of slices per block
+    if (short_a) nsplit = 1;
     const size_t nparts = (size_t)(p.nslices * nsplit);
     RMHIP_TRY(c->ensure_scratch(2 * nparts * sizeof(double)));
     double* pv = c->scratch;
     double* pn = c->scratch + nparts;
-    if (p.contiguous && (red & 1) == 0 && red >= 2048 && (((uintptr_t)x) & 15) == 0)
+    if (short_a) {
+        unsigned per_block = (unsigned)(SHORT_TILE / red);
+        if (per_block > RM_RBLOCK) per_block = RM_RBLOCK;
+        hipLaunchKernelGGL((k_reduce_short<OP, T>), dim3((unsigned)ceil_div_u64(p.nslices, per_block)), dim3(RM_RBLOCK), 0, c->stream, x, (rm_u64)red,
+                           (rm_u64)p.nslices, per_block, pv, pn);
+    } else if (p.contiguous && (red & 1) == 0 && red >= 2048 && (((uintptr_t)x) & 15) == 0)
         hipLaunchKernelGGL((k_reduce_contig_v2<OP, T>), dim3(p.gx, p.gy, p.gz), dim3(p.tx), 0, c->stream, x, (rm_u64)red,
                            (rm_u64)p.nslices, (rm_u64)p.nsplit, pv, pn);
     else if (p.contiguous && red >= 2048)  // odd slice length or an element-aligned base: the same kernel on unaligned pairs
@@ -196,9 +233,14 @@ static int run_reduce(Context* c, int mean, int nan_mode, const T* x, size_t pre
         hipLaunchKernelGGL((k_reduce_strided<OP, T>), dim3(p.gx, p.gy, p.gz), dim3(RM_RBLOCK), 0, c->stream, x,
                            (rm_u64)pre, (rm_u64)red, (rm_u64)p.nsplit, p.tx, pv, pn);
     RMHIP_HIP_CHECK(hipGetLastError());
-    const unsigned fb = (unsigned)ceil_div_u64(p.nslices, RM_RBLOCK / 64);
-    hipLaunchKernelGGL((k_reduce_final<OP>), dim3(fb), dim3(RM_RBLOCK), 0, c->stream, pv, pn, (rm_u64)p.nslices,
-                       (rm_u64)nsplit, (rm_u64)red, mean, nan_mode, 1.0, out);
+    if (nsplit <= 8 && p.nslices >= 1024) {  // many slices, a handful of partials each: one thread per slice
+        hipLaunchKernelGGL((k_reduce_final_flat<OP>), dim3((unsigned)ceil_div_u64(p.nslices, RM_RBLOCK)), dim3(RM_RBLOCK), 0, c->stream, pv, pn,
+                           (rm_u64)p.nslices, (rm_u64)nsplit, (rm_u64)red, mean, nan_mode, 1.0, out);
+    } else {
+        const unsigned fb = (unsigned)ceil_div_u64(p.nslices, RM_RBLOCK / 64);
+        hipLaunchKernelGGL((k_reduce_final<OP>), dim3(fb), dim3(RM_RBLOCK), 0, c->stream, pv, pn, (rm_u64)p.nslices,
+                           (rm_u64)nsplit, (rm_u64)red, mean, nan_mode, 1.0, out);
+    }
     RMHIP_HIP_CHECK(hipGetLastError());
     c->tel.kernel_launches += 2;
     return RMHIP_OK;
@@ -278,9 +320,14 @@ static int reduce_dot_any(Context* c, const T* a, const T* b, size_t pre, size_t
         hipLaunchKernelGGL((k_dot_strided<T>), dim3(p.gx, p.gy, p.gz), dim3(RM_RBLOCK), 0, c->stream, a, b, (rm_u64)pre,
                            (rm_u64)red, (rm_u64)p.nsplit, p.tx, pv, pn);
     RMHIP_HIP_CHECK(hipGetLastError());
-    const unsigned fb = (unsigned)ceil_div_u64(p.nslices, RM_RBLOCK / 64);
-    hipLaunchKernelGGL((k_reduce_final<RM_RSUM>), dim3(fb), dim3(RM_RBLOCK), 0, c->stream, pv, pn, (rm_u64)p.nslices,
-                       (rm_u64)p.nsplit, (rm_u64)red, 0, 0, 1.0, out);
+    if (p.nsplit <= 8 && p.nslices >= 1024) {
+        hipLaunchKernelGGL((k_reduce_final_flat<RM_RSUM>), dim3((unsigned)ceil_div_u64(p.nslices, RM_RBLOCK)), dim3(RM_RBLOCK), 0, c->stream, pv, pn,
+                           (rm_u64)p.nslices, (rm_u64)p.nsplit, (rm_u64)red, 0, 0, 1.0, out);
+    } else {
+        const unsigned fb = (unsigned)ceil_div_u64(p.nslices, RM_RBLOCK / 64);
+        hipLaunchKernelGGL((k_reduce_final<RM_RSUM>), dim3(fb), dim3(RM_RBLOCK), 0, c->stream, pv, pn, (rm_u64)p.nslices,
+                           (rm_u64)p.nsplit, (rm_u64)red, 0, 0, 1.0, out);
+    }
     RMHIP_HIP_CHECK(hipGetLastError());
     c->tel.kernel_launches += 2;
     return RMHIP_OK;

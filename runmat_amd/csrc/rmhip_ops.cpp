@@ -428,8 +428,12 @@ int rmhip_fused_reduction(rmhip_ctx* ctx, const char* shader, const rmhip_buf* i
         double scale = flavor == RMHIP_FLAVOR_CUSTOM_SCALE ? custom_scale : 1.0;
         double* optr = ob.data();
         void* fargs[] = {&cpv, &cpn, &u_nslices, &u_nsplit, &u_red, &mean, &omit, &scale, &optr};
-        const unsigned fb = (unsigned)ceil_div_u64(plan.nslices, 4);
-        e = hipModuleLaunchKernel(kern->fn_final, fb, 1, 1, 256, 1, 1, 0, c->stream, fargs, nullptr);
+        if (nsplit_used <= 8 && plan.nslices >= 1024) {
+            e = hipModuleLaunchKernel(kern->fn_final_flat, (unsigned)ceil_div_u64(plan.nslices, 256), 1, 1, 256, 1, 1, 0, c->stream, fargs, nullptr);
+        } else {
+            const unsigned fb = (unsigned)ceil_div_u64(plan.nslices, 4);
+            e = hipModuleLaunchKernel(kern->fn_final, fb, 1, 1, 256, 1, 1, 0, c->stream, fargs, nullptr);
+        }
     }
     if (e != hipSuccess) {
         rmhip_free(ctx, oid);

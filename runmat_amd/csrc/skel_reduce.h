@@ -168,6 +168,21 @@ __device__ __forceinline__ void rm_reduce_strided(const F& f, rm_u64 pre, rm_u64
 // applies NaN policy + scaling.  mode: RM_RSUM => * scale (scale == 1 for plain sums);
 // RM_RMEAN => / count (CPU mean divides: mean.rs:1134-1151).
 template <int OP>
+__device__ __forceinline__ double rm_finalize_value(const RmAcc& a, rm_u64 red, int mean, int omitnan, double scale) {
+    double r = a.v;
+    const double cnt = (double)red - a.nan;
+    if (OP == RM_RMIN || OP == RM_RMAX) {
+        if ((!omitnan && a.nan > 0.0) || cnt <= 0.0) r = rm_nan();
+    } else if (mean) {
+        if (omitnan) r = cnt > 0.0 ? r / cnt : rm_nan();
+        else r = a.nan > 0.0 ? rm_nan() : r / (double)red;
+    } else {
+        if (!omitnan && a.nan > 0.0) r = rm_nan();
+        else r = r * scale;
+    }
+    return r;
+}
+template <int OP>
 __device__ __forceinline__ void rm_reduce_finalize(const double* part_v, const double* part_nan, rm_u64 nslices,
                                                    rm_u64 nsplit, rm_u64 red, int mean, int omitnan, double scale,
                                                    double* out) {
@@ -208,20 +223,25 @@ __device__ __forceinline__ void rm_reduce_finalize(const double* part_v, const d
         o.nan = __shfl_down(a.nan, off, 64);
         rm_acc_merge<OP>(a, o);
     }
-    if (lane == 0) {
-        double r = a.v;
-        const double cnt = (double)red - a.nan;
-        if (OP == RM_RMIN || OP == RM_RMAX) {
-            if ((!omitnan && a.nan > 0.0) || cnt <= 0.0) r = rm_nan();
-        } else if (mean) {
-            if (omitnan) r = cnt > 0.0 ? r / cnt : rm_nan();
-            else r = a.nan > 0.0 ? rm_nan() : r / (double)red;
-        } else {
-            if (!omitnan && a.nan > 0.0) r = rm_nan();
-            else r = r * scale;
-        }
-        out[slice] = r;
+    if (lane == 0) out[slice] = rm_finalize_value<OP>(a, red, mean, omitnan, scale);
+}
+
+// The same with ONE THREAD per slice, its few partials merged in split order: for many slices with one or a handful of partials each
+// (sum(x,2) of a 524288 x 32 matrix: 524288 slices, one partial) a wave per slice is 64 times the launch the work needs - there the
+// finalize took longer than the reduction itself.
+template <int OP>
+__device__ __forceinline__ void rm_reduce_finalize_flat(const double* part_v, const double* part_nan, rm_u64 nslices, rm_u64 nsplit, rm_u64 red,
+                                                        int mean, int omitnan, double scale, double* out) {
+    const rm_u64 slice = (rm_u64)blockIdx.x * RM_RBLOCK + threadIdx.x;
+    if (slice >= nslices) return;
+    RmAcc a = rm_acc_init<OP>();
+    for (rm_u64 s = 0; s < nsplit; ++s) {
+        RmAcc p;
+        p.v = part_v[slice * nsplit + s];
+        p.nan = part_nan[slice * nsplit + s];
+        rm_acc_merge<OP>(a, p);
     }
+    out[slice] = rm_finalize_value<OP>(a, red, mean, omitnan, scale);
 }
 
 // ---- kernel A over 16-byte vectors: the functor returns two adjacent elements of a slice per call (plain tensors in
