@@ -658,43 +658,75 @@ __global__ void __launch_bounds__(ST_THREADS) k_scan_lines_staged(const double* 
     const u64 base = i + pre * len * j;
     const u64 ntiles = (len + ST_STEPS - 1) / ST_STEPS;
     const double ident = PROD ? 1.0 : 0.0;
-    double regs[ROWS];
+    double regs[ROWS], regs2[ROWS];  // tiles t + 1 and t + 2 in flight (few blocks run this kernel: a tile takes its full memory latency)
     auto at = [&](u64 k) { return base + pre * (reverse ? len - 1 - k : k); };
-    auto gload = [&](u64 t) {
+    auto gload = [&](u64 t, double (&r)[ROWS]) {
 #pragma unroll
         for (int u = 0; u < ROWS; ++u) {
             const u64 k = t * ST_STEPS + (u64)(u * RP + row0);
-            regs[u] = (live && k < len) ? __builtin_nontemporal_load(x + at(k)) : ident;
+            r[u] = (live && k < len) ? __builtin_nontemporal_load(x + at(k)) : ident;
         }
     };
-    gload(0);
+    gload(0, regs);
 #pragma unroll
     for (int u = 0; u < ROWS; ++u) buf[u * RP + row0][line] = regs[u];
+    if (ntiles > 1) gload(1, regs);
     __syncthreads();
     double run = ident;
     for (u64 t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) gload(t + 1);  // in flight while the first LINES threads scan
+        if (t + 2 < ntiles) gload(t + 2, regs2);  // in flight while the first LINES threads scan this tile and the next
         if (threadIdx.x < LINES) {
             double v[ST_STEPS];
 #pragma unroll
-            for (int k = 0; k < ST_STEPS; ++k) v[k] = buf[k][line];
+            for (int k = 0; k < ST_STEPS; ++k) v[k] = scan_in<PROD>(buf[k][line], omit);  // (the NaN policies stay off the dependent chain)
 #pragma unroll
             for (int k = 0; k < ST_STEPS; ++k) {  // rows beyond `len` hold the identity: they leave the running value alone and are not stored
-                run = scan_op<PROD>(run, scan_in<PROD>(v[k], omit));
-                v[k] = scan_out(run);
+                run = scan_op<PROD>(run, v[k]);
+                v[k] = run;
             }
 #pragma unroll
-            for (int k = 0; k < ST_STEPS; ++k) buf[k][line] = v[k];
+            for (int k = 0; k < ST_STEPS; ++k) buf[k][line] = scan_out(v[k]);
         }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < ROWS; ++u) {
             const u64 k = t * ST_STEPS + (u64)(u * RP + row0);
             if (live && k < len) __builtin_nontemporal_store(buf[u * RP + row0][line], y + at(k));
-            buf[u * RP + row0][line] = regs[u];  // the next tile (garbage after the last one: nobody reads it)
+            buf[u * RP + row0][line] = regs[u];  // tile t + 1 (garbage after the last one: nobody reads it)
+            regs[u] = regs2[u];
         }
         __syncthreads();
     }
+}
+
+// pre == 1, SHORT contiguous lines (len < 256: cumsum(x,1) of a 32 x N matrix): one thread per line would read with a stride of one
+// line between lanes.  A block stages a tile of consecutive lines - one contiguous piece of memory - in LDS with coalesced loads
+// (padded: the per-thread walks fall on distinct banks), thread t scans line t in place - the CPU's own sequence - and the tile goes
+// back the same way.
+static constexpr int SS_TILE = 4096;
+__device__ __forceinline__ int ss_pad(int i) { return i + (i >> 5); }
+template <bool PROD>
+__global__ void __launch_bounds__(R2_BLOCK) k_scan_short(const double* __restrict__ x, double* __restrict__ y, u64 len, u64 nlines, unsigned per_block,
+                                                         int reverse, int omit) {
+    __shared__ double tile[SS_TILE + SS_TILE / 32 + 1];
+    const u64 l0 = (u64)blockIdx.x * per_block;
+    const u64 nl = nlines - l0 < per_block ? nlines - l0 : per_block;
+    const u64 count = nl * len;
+    const double* src = x + l0 * len;
+    double* dst = y + l0 * len;
+    for (u64 i = threadIdx.x; i < count; i += R2_BLOCK) tile[ss_pad((int)i)] = scan_in<PROD>(__builtin_nontemporal_load(src + i), omit);
+    __syncthreads();
+    if (threadIdx.x < nl) {
+        const int b = (int)(threadIdx.x * len);
+        double run = PROD ? 1.0 : 0.0;
+        for (int k = 0; k < (int)len; ++k) {
+            const int idx = ss_pad(b + (reverse ? (int)len - 1 - k : k));
+            run = scan_op<PROD>(run, tile[idx]);
+            tile[idx] = scan_out(run);
+        }
+    }
+    __syncthreads();
+    for (u64 i = threadIdx.x; i < count; i += R2_BLOCK) __builtin_nontemporal_store(tile[ss_pad((int)i)], dst + i);
 }
 
 // pre == 1, long lines: three passes over chunks of SCAN_CHUNK elements - chunk totals, a serial scan of the totals per line,
@@ -760,10 +792,11 @@ __device__ __forceinline__ void scan_tile_in(const double* __restrict__ xs, u64 
 // pass 1: the chunk's total.  Any grouping will do - the carries only have to be right to rounding - so this is a plain streaming
 // reduction: eight independent accumulators per thread over coalesced loads, folded in a fixed order (deterministic).
 template <bool PROD>
-__global__ void __launch_bounds__(R2_BLOCK) k_scan_chunk_totals(const double* __restrict__ x, u64 len, u64 nchunks, int reverse, int omit,
+__global__ void __launch_bounds__(R2_BLOCK) k_scan_chunk_totals(const double* __restrict__ x, u64 len, u64 nchunks, u64 nlines, int reverse, int omit,
                                                                 double* __restrict__ totals) {
     __shared__ double wsum[4];
-    const u64 chunk = blockIdx.x, line = blockIdx.y;
+    const u64 chunk = blockIdx.x, line = blockIdx.y + (u64)gridDim.y * blockIdx.z;  // (more than 65535 lines spill into z)
+    if (line >= nlines) return;
     const u64 b = chunk * SCAN_CHUNK;
     u64 e = b + SCAN_CHUNK;
     if (e > len) e = len;
@@ -804,12 +837,13 @@ __global__ void __launch_bounds__(R2_BLOCK) k_scan_carries(double* __restrict__ 
 }
 // carries == nullptr: one chunk per line, nothing carried in
 template <bool PROD>
-__global__ void __launch_bounds__(R2_BLOCK) k_scan_chunks(const double* __restrict__ x, double* __restrict__ y, u64 len, u64 nchunks, int reverse,
-                                                          int omit, const double* __restrict__ carries) {
+__global__ void __launch_bounds__(R2_BLOCK) k_scan_chunks(const double* __restrict__ x, double* __restrict__ y, u64 len, u64 nchunks, u64 nlines,
+                                                          int reverse, int omit, const double* __restrict__ carries) {
     __shared__ double tl[SCAN_LDS];
     __shared__ double wsum[4];
     const int t = threadIdx.x;
-    const u64 chunk = blockIdx.x, line = blockIdx.y;
+    const u64 chunk = blockIdx.x, line = blockIdx.y + (u64)gridDim.y * blockIdx.z;
+    if (line >= nlines) return;
     const u64 b = chunk * SCAN_CHUNK;
     u64 e = b + SCAN_CHUNK;
     if (e > len) e = len;
@@ -844,10 +878,9 @@ __global__ void __launch_bounds__(R2_BLOCK) k_scan_chunks(const double* __restri
 int launch_cumulative(Context* c, int prod, int reverse, int omit, const double* x, size_t pre, size_t len, size_t post, double* y) {
     if (pre == 0 || len == 0 || post == 0) return RMHIP_OK;
     const size_t lines = pre * post;
-    // thread-per-line whenever the lines run along a strided dimension, or there are enough short contiguous lines to fill the chip
-    if (pre > 1 || (len <= 4096 && lines >= (size_t)c->num_cus * 64)) {
-        if (pre >= 64 && len >= 256 && lines < (size_t)c->num_cus * 256 && post <= 65535) {  // few long strided lines: staged tiles
-            const bool half = ceil_div_u64(pre, 64) * post < (u64)c->num_cus;  // 64 lines per block would leave CUs idle
+    if (pre > 1) {  // lines along a strided dimension: every line is the CPU's own chain
+        if (pre >= 8 && len >= 256 && lines < (size_t)c->num_cus * 256 && post <= 65535) {  // few long lines: staged tiles
+            const bool half = pre < 64 || ceil_div_u64(pre, 64) * post < (u64)c->num_cus;   // 64 lines per block would leave CUs (or lanes) idle
             const dim3 sgrid((unsigned)ceil_div_u64(pre, half ? 32 : 64), (unsigned)post);
 #define RMHIP_STAGED(P, L) hipLaunchKernelGGL((k_scan_lines_staged<P, L>), sgrid, dim3(ST_THREADS), 0, c->stream, x, y, (u64)pre, (u64)len, (u64)post, reverse, omit)
             if (prod && half) RMHIP_STAGED(true, 32);
@@ -868,24 +901,36 @@ int launch_cumulative(Context* c, int prod, int reverse, int omit, const double*
         c->tel.kernel_launches++;
         return RMHIP_OK;
     }
-    if (lines > 65535) return fail(RMHIP_ERR_UNSUPPORTED, "cumulative scan: %zu contiguous lines exceed the launch limits", lines);
+    if (len < 256) {  // short contiguous lines: a tile of lines per block, a thread per line
+        unsigned per_block = (unsigned)(SS_TILE / len);
+        if (per_block > R2_BLOCK) per_block = R2_BLOCK;
+        const unsigned grid = (unsigned)ceil_div_u64(lines, per_block);
+        if (prod) hipLaunchKernelGGL(k_scan_short<true>, dim3(grid), dim3(R2_BLOCK), 0, c->stream, x, y, (u64)len, (u64)lines, per_block, reverse, omit);
+        else hipLaunchKernelGGL(k_scan_short<false>, dim3(grid), dim3(R2_BLOCK), 0, c->stream, x, y, (u64)len, (u64)lines, per_block, reverse, omit);
+        RMHIP_HIP_CHECK(hipGetLastError());
+        c->tel.kernel_launches++;
+        return RMHIP_OK;
+    }
+    // long contiguous lines: blocked scans over chunks (a line of one chunk: the last pass only)
+    const u64 gy = lines < 65535 ? lines : 65535, gz = ceil_div_u64(lines, gy);
+    if (gz > 65535) return fail(RMHIP_ERR_UNSUPPORTED, "cumulative scan: %zu contiguous lines exceed the launch limits", lines);
     const u64 nchunks = ceil_div_u64(len, SCAN_CHUNK);
     RMHIP_TRY(c->ensure_scratch(lines * nchunks * sizeof(double)));
     double* totals = c->scratch;
-    const dim3 grid((unsigned)nchunks, (unsigned)lines);
+    const dim3 grid((unsigned)nchunks, (unsigned)gy, (unsigned)gz);
     const double* carries = nchunks > 1 ? totals : nullptr;
     if (prod) {
         if (carries) {
-            hipLaunchKernelGGL(k_scan_chunk_totals<true>, grid, dim3(R2_BLOCK), 0, c->stream, x, (u64)len, nchunks, reverse, omit, totals);
+            hipLaunchKernelGGL(k_scan_chunk_totals<true>, grid, dim3(R2_BLOCK), 0, c->stream, x, (u64)len, nchunks, (u64)lines, reverse, omit, totals);
             hipLaunchKernelGGL(k_scan_carries<true>, dim3((unsigned)lines), dim3(R2_BLOCK), 0, c->stream, totals, nchunks, (u64)lines);
         }
-        hipLaunchKernelGGL(k_scan_chunks<true>, grid, dim3(R2_BLOCK), 0, c->stream, x, y, (u64)len, nchunks, reverse, omit, carries);
+        hipLaunchKernelGGL(k_scan_chunks<true>, grid, dim3(R2_BLOCK), 0, c->stream, x, y, (u64)len, nchunks, (u64)lines, reverse, omit, carries);
     } else {
         if (carries) {
-            hipLaunchKernelGGL(k_scan_chunk_totals<false>, grid, dim3(R2_BLOCK), 0, c->stream, x, (u64)len, nchunks, reverse, omit, totals);
+            hipLaunchKernelGGL(k_scan_chunk_totals<false>, grid, dim3(R2_BLOCK), 0, c->stream, x, (u64)len, nchunks, (u64)lines, reverse, omit, totals);
             hipLaunchKernelGGL(k_scan_carries<false>, dim3((unsigned)lines), dim3(R2_BLOCK), 0, c->stream, totals, nchunks, (u64)lines);
         }
-        hipLaunchKernelGGL(k_scan_chunks<false>, grid, dim3(R2_BLOCK), 0, c->stream, x, y, (u64)len, nchunks, reverse, omit, carries);
+        hipLaunchKernelGGL(k_scan_chunks<false>, grid, dim3(R2_BLOCK), 0, c->stream, x, y, (u64)len, nchunks, (u64)lines, reverse, omit, carries);
     }
     RMHIP_HIP_CHECK(hipGetLastError());
     c->tel.kernel_launches += carries ? 3 : 1;

@@ -158,7 +158,9 @@ def test_cumulative_scans(prov, oracle, shape):
 
 
 @pytest.mark.parametrize("shape,dim", [((513, 700), 1), ((64, 256), 1), ((100, 1000, 3), 1), ((65, 300, 2), 1), ((300, 70), 1), ((7, 5000), 1),
-                                       ((70, 33, 400), 2)])
+                                       ((70, 33, 400), 2), ((8, 3000), 1), ((33, 1000, 2), 1),
+                                       # short contiguous lines (len < 256 along dim 0): a tile of lines per block, thread per line
+                                       ((32, 5000), 0), ((3, 70000), 0), ((255, 300), 0), ((17, 9, 40), 0)])
 def test_strided_scan_is_the_cpu_sequence_bit_for_bit(prov, oracle, shape, dim):
     """Along a strided dimension every line is the CPU's own left-to-right chain - whether one thread walks it (many or short lines)
     or a block stages tiles of 64 lines x 64 steps through LDS and one wave runs the chains (few long lines): sums, products, both
