@@ -259,6 +259,28 @@ static void emit_bcast_kernel(std::ostringstream& s, const ElementwiseProgram& p
         s << "        }\n    }\n";
     }
     s << "}\n\n";
+    // short dim 0 with many outer indices (a 32 x N matrix and a row or column operand): threads over the FLAT output, each decoding
+    // its coordinates with 32-bit arithmetic (ew_kernels.hip: k_bcast2_flat) - the kernel above would run 32 lanes per block
+    s << "extern \"C\" __global__ void __launch_bounds__(256) rm_ew_bcast_flat(";
+    for (int k = 0; k < nin; ++k) s << "const " << S << "* __restrict__ in" << k << ", ";
+    for (int k = 0; k < nout; ++k) s << S << "* __restrict__ out" << k << ", ";
+    s << "const RmBcast p, const unsigned n) {\n";
+    s << "    const unsigned d0 = (unsigned)p.v[0], stride = gridDim.x * 256u;\n";
+    s << "    const int rank = (int)p.v[2];\n";
+    s << "    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < n; idx += stride) {\n";
+    s << "        unsigned rem = idx / d0;\n        const unsigned i = idx - rem * d0;\n";
+    for (int k = 0; k < nin; ++k) s << "        rm_u64 off" << k << " = (rm_u64)i * p.v[" << (11 + 8 * k) << "];\n";
+    s << "        for (int d = 1; d < rank; ++d) {\n            const unsigned ext = (unsigned)p.v[3 + d];\n"
+         "            const unsigned q = rem / ext, c = rem - q * ext;\n            rem = q;\n";
+    for (int k = 0; k < nin; ++k) s << "            off" << k << " += (rm_u64)c * p.v[" << (11 + 8 * k) << " + d];\n";
+    s << "        }\n";
+    for (int k = 0; k < nout; ++k) s << "        double q" << k << ";\n";
+    s << "        rm_body(";
+    for (int k = 0; k < nin; ++k) s << (k ? ", " : "") << cast_in << "in" << k << "[off" << k << "]";
+    for (int k = 0; k < nout; ++k) s << ", q" << k;
+    s << ");\n";
+    for (int k = 0; k < nout; ++k) s << "        out" << k << "[idx] = " << cast_out << "q" << k << ";\n";
+    s << "    }\n}\n\n";
 }
 
 std::string generate_elementwise_source(const ElementwiseProgram& p, const EwTuning& t, unsigned mask, bool f32) {
@@ -445,6 +467,7 @@ int get_elementwise_kernel(Context* c, const ElementwiseProgram& p, unsigned mas
     RMHIP_TRY(load_function(k->module, "rm_ew_fast", &k->fn_fast));
     RMHIP_TRY(load_function(k->module, "rm_ew_fast1", &k->fn_fast1));
     RMHIP_TRY(load_function(k->module, "rm_ew_bcast", &k->fn_bcast));
+    RMHIP_TRY(load_function(k->module, "rm_ew_bcast_flat", &k->fn_bcast_flat));
     std::lock_guard<std::mutex> lk(c->mu);
     c->kernel_cache[key] = k;
     *out = k;

@@ -38,6 +38,7 @@ struct FusedKernel {
     hipFunction_t fn_fast = nullptr;    // elementwise: all inputs full-size or scalar, 16 B vectors
     hipFunction_t fn_fast1 = nullptr;   // elementwise: same, 8 B accesses (unaligned external memory)
     hipFunction_t fn_bcast = nullptr;   // elementwise: general broadcast, rank <= 8
+    hipFunction_t fn_bcast_flat = nullptr;  // the same for a short dim 0: threads over the flat output
     hipFunction_t fn_contig = nullptr;  // reduction kernel A
     hipFunction_t fn_contig2 = nullptr; // reduction kernel A over 16-byte vectors (even slices, aligned full-size inputs)
     hipFunction_t fn_strided = nullptr; // reduction kernel B

@@ -297,15 +297,22 @@ int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf*
         for (size_t k = 0; k < n_in; ++k)
             for (size_t d = 0; d < crank; ++d) p[11 + 8 * k + d] = strides[k][d];
         args.push_back(p.data());
-        const unsigned long long blocks = nchunks * outer;
-        const unsigned long long gx = std::min<unsigned long long>(blocks, 1048576ULL);
-        const unsigned long long gy = (blocks + gx - 1) / gx;
-        if (gy > 65535ULL) {
-            for (size_t k = 0; k < n_out; ++k) rmhip_free(ctx, ids[k]);
-            return fail(RMHIP_ERR_UNSUPPORTED, "fused_elementwise: broadcast grid too large");
+        if (d0 < 128 && outer >= 64 && len < 0xffffffffULL) {  // short dim 0, many outer indices: flat threads
+            unsigned n32 = (unsigned)len;
+            args.push_back(&n32);
+            const unsigned long long want = (len + 255) / 256, cap = (unsigned long long)c->num_cus * 16;
+            e = hipModuleLaunchKernel(kern->fn_bcast_flat, (unsigned)std::min(want, cap), 1, 1, 256, 1, 1, 0, c->stream, args.data(), nullptr);
+        } else {
+            const unsigned long long blocks = nchunks * outer;
+            const unsigned long long gx = std::min<unsigned long long>(blocks, 1048576ULL);
+            const unsigned long long gy = (blocks + gx - 1) / gx;
+            if (gy > 65535ULL) {
+                for (size_t k = 0; k < n_out; ++k) rmhip_free(ctx, ids[k]);
+                return fail(RMHIP_ERR_UNSUPPORTED, "fused_elementwise: broadcast grid too large");
+            }
+            e = hipModuleLaunchKernel(kern->fn_bcast, (unsigned)gx, (unsigned)gy, 1, t.bcast_block, 1, 1, 0, c->stream, args.data(),
+                                      nullptr);
         }
-        e = hipModuleLaunchKernel(kern->fn_bcast, (unsigned)gx, (unsigned)gy, 1, t.bcast_block, 1, 1, 0, c->stream, args.data(),
-                                  nullptr);
     }
     if (e != hipSuccess) {
         for (size_t k = 0; k < n_out; ++k) rmhip_free(ctx, ids[k]);

@@ -142,7 +142,7 @@ def test_f32_binary_broadcast(prov32, prov, oracle):
 
     rng = np.random.default_rng(7)
     cases = [((300, 1), (1, 70)), ((300, 70), (1, 70)), ((300, 70), (300, 1)), ((1, 1), (33, 5)), ((5, 1, 7), (1, 6, 1)),
-             ((4, 3, 2), (4, 1, 2)), ((1025, 3), (1025, 3))]
+             ((4, 3, 2), (4, 1, 2)), ((1025, 3), (1025, 3)), ((32, 700), (1, 700)), ((32, 1), (32, 700)), ((3, 1, 70), (1, 90, 1))]
     for sa, sb in cases:
         A, B = f32r(rng.standard_normal(sa)), f32r(rng.standard_normal(sb))
         for name in ("add", "mul", "atan2", "lt"):

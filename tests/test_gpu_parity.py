@@ -139,7 +139,10 @@ def test_fused_broadcast_cases(prov, oracle):
     rng = np.random.default_rng(12)
     cases = [((4, 1), (1, 3), (4, 3)), ((2, 3), (2, 1), (2, 3)), ((300, 200), (1, 1), (300, 200)),
              ((1, 200), (300, 1), (300, 200)), ((5, 1, 7), (1, 6, 1), (5, 6, 7)), ((4,), (2, 3, 4), (2, 3, 4)),
-             ((1, 1), (1, 1), (1, 1)), ((6, 5, 4, 3), (6, 1, 4, 1), (6, 5, 4, 3))]
+             ((1, 1), (1, 1), (1, 1)), ((6, 5, 4, 3), (6, 1, 4, 1), (6, 5, 4, 3)),
+             # a short leading dimension under many outer indices: the flat-thread broadcast kernels
+             ((32, 5000), (1, 5000), (32, 5000)), ((32, 1), (32, 5000), (32, 5000)), ((3, 1, 70), (1, 700, 1), (3, 700, 70)),
+             ((127, 64), (127, 1), (127, 64)), ((1, 64), (2, 1), (2, 64)), ((5, 7, 11, 13), (5, 1, 11, 1), (5, 7, 11, 13))]
     for sa, sb, so in cases:
         p = FusionGroupPlan()
         a, b = p.input(), p.input()
@@ -388,7 +391,9 @@ def test_binary_broadcast_and_mismatch(prov, oracle):
     from runmat_amd import ProviderError
 
     rng = np.random.default_rng(18)
-    for sa, sb in [((4, 1), (1, 3)), ((2, 3), (2, 1)), ((1, 1), (40, 30)), ((7, 1, 5), (1, 6, 1)), ((1000, 1), (1, 1000))]:
+    for sa, sb in [((4, 1), (1, 3)), ((2, 3), (2, 1)), ((1, 1), (40, 30)), ((7, 1, 5), (1, 6, 1)), ((1000, 1), (1, 1000)),
+                   ((32, 5000), (1, 5000)), ((32, 1), (32, 5000)), ((3, 1, 70), (1, 700, 1)), ((127, 64), (127, 1)), ((2, 1), (1, 64)),
+                   ((5, 7, 11, 13), (5, 1, 11, 1))]:  # the last six: short leading dimension, flat-thread kernel
         A, B = rng.standard_normal(sa), rng.standard_normal(sb)
         ha, hb = prov.upload(A), prov.upload(B)
         h = prov.elem_mul(ha, hb)
