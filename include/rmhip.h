@@ -459,7 +459,7 @@ typedef struct rmhip_lu_stats {
     int one_xcd_panels;                 /* 1 while panels of <= 32 workgroups are placed on one XCD */
     int conservative_panels;            /* 1 once the context fell back to one launch per column */
     uint64_t svd_solves;                /* systems the LU / Gram paths refused (singular, rank deficient, ill conditioned) that were answered by the
-                                           Jacobi-SVD path with the reference's tolerance rule (min(rows, cols) <= 1024) */
+                                           Jacobi-SVD path with the reference's tolerance rule (min(rows, cols) <= 4096) */
 } rmhip_lu_stats_t;
 RMHIP_API int rmhip_lu_stats(rmhip_ctx* ctx, rmhip_lu_stats_t* out);
 

@@ -331,8 +331,10 @@ int lu_extract_device(Context* c, const double* LU, size_t rows, size_t cols, co
                       double* L, double* U, double* P, double* piv);
 
 // svdsolve.hip: minimum-norm least squares by a one-sided Jacobi SVD with the reference's tolerance rule (mldivide.rs:380-404) - what the
-// LU / Gram paths refuse (rank deficient, ill conditioned, singular), for min(rows, cols) <= kSvdMaxCols
-static constexpr int kSvdMaxCols = 1024;
+// LU / Gram paths refuse (rank deficient, ill conditioned, singular), for min(rows, cols) <= svd_max_cols() (RMHIP_SVD_MAX_COLS)
+static constexpr int kSvdMaxColsDefault = 4096;  // 0.15 s at 512, 0.45 s at 1024, 1.7 s at 2048, 9.6 s at 4096 (scripts/svd_sizes.py)
+int svd_max_cols();
+static constexpr int kSvdProxyMaxCols = 1024;  // up to here an LU with a tiny pivot RATIO (no pivot below the cut-off) is re-answered by the SVD
 int svd_solve_device(Context* c, const double* A, size_t m, size_t n, const double* B, size_t nrhs, double* X, int* rank_out);
 
 // opaque handle -> Context (rmhip_core.cpp)

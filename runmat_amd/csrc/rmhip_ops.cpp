@@ -1148,10 +1148,10 @@ static int lstsq_full_rank(rmhip_ctx* ctx, Context* c, const double* A, size_t m
 }
 
 // What the LU / Gram paths refuse - singular, rank-deficient or ill-conditioned systems - answered the way the reference answers every
-// system: minimum-norm least squares from an SVD with its tolerance rule (svdsolve.hip), as long as min(rows, cols) <= kSvdMaxCols.
+// system: minimum-norm least squares from an SVD with its tolerance rule (svdsolve.hip), as long as min(rows, cols) <= svd_max_cols().
 // `refused` is the status of the path that gave up (returned unchanged when the system is too large for the SVD path).
 static int svd_fallback(rmhip_ctx* ctx, Context* c, int refused, const double* A, size_t m, size_t n, const double* B, size_t nrhs, rmhip_buf* out) {
-    if ((m < n ? m : n) > (size_t)kSvdMaxCols || std::getenv("RMHIP_NO_SVD_PATH")) return refused;
+    if ((m < n ? m : n) > (size_t)svd_max_cols() || std::getenv("RMHIP_NO_SVD_PATH")) return refused;
     Buffer ob;
     rmhip_buf oid = 0;
     const size_t oshape[2] = {n, nrhs};
@@ -1205,12 +1205,13 @@ static int mldivide_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, r
     int rc = lu_copy_and_factor(c, ab.data(), n, n, work->ptr, ldw, perm, &info, true, np);
     if (!rc && info > 0) {
         rc = fail(RMHIP_ERR_SINGULAR, "mldivide: %d pivot(s) <= 1e-12; matrix is numerically singular, use the CPU SVD path", info);
-        if (nrhs) return svd_fallback(ctx, c, rc, ab.data(), n, n, bb.data(), nrhs, out);  // n <= 1024: the SVD answer on the device
+        if (nrhs) return svd_fallback(ctx, c, rc, ab.data(), n, n, bb.data(), nrhs, out);  // up to svd_max_cols(): the SVD answer on the device
     }
-    if (!rc && n <= (size_t)kSvdMaxCols && n > 1 && nrhs && !std::getenv("RMHIP_NO_SVD_PATH")) {
+    if (!rc && n <= (size_t)kSvdProxyMaxCols && n <= (size_t)svd_max_cols() && n > 1 && nrhs && !std::getenv("RMHIP_NO_SVD_PATH")) {
         // A nearly singular matrix need not produce a pivot below the cut-off, yet the reference would DROP its small singular values
         // (s_i <= eps * n * max(s_max, 1), mldivide.rs:396-404) where an LU divides by them.  Pivot ratio as the (cheap, rough) proxy of
-        // the condition number: below 1e3 * n * eps the SVD decides.  Only where the SVD path exists; larger systems keep the LU answer.
+        // the condition number: below 1e3 * n * eps the SVD decides.  Only where the SVD path is cheap (n <= kSvdProxyMaxCols, < 0.5 s); larger
+        // systems keep the LU answer unless a pivot fell below the cut-off.
         double mn = 0.0, mx = 0.0;
         size_t zeros = 0;
         if (diag_stats_device(c, work->ptr, ldw, n, &mn, &mx, &zeros) == RMHIP_OK && !(mn > 1.0e3 * (double)n * 2.220446049250313e-16 * mx))

@@ -5,14 +5,16 @@
 // (crates/runmat-runtime/src/builtins/math/linalg/ops/mldivide.rs:380-404; nalgebra `SVD::solve`).  The LU solve and the
 // Gram-matrix least squares (rmhip_ops.cpp) reproduce that answer only for full-rank, reasonably conditioned systems and hand
 // everything else back to the caller (RMHIP_ERR_SINGULAR / UNSUPPORTED).  For systems whose smaller dimension is at most
-// kSvdMaxCols this file computes the same thing the reference computes: a one-sided Jacobi SVD of the tall orientation W (p x q,
+// svd_max_cols() (4096, RMHIP_SVD_MAX_COLS) this file computes the same thing the reference computes: a one-sided Jacobi SVD of the tall orientation W (p x q,
 // p >= q) - rotations of column pairs until every pair is orthogonal to 1e-15, singular values = column norms, right vectors
 // accumulated in V - and the pseudo-inverse applied with the reference's tolerance rule.  One-sided Jacobi is what oracle.c
 // restates nalgebra's SVD with, it is accurate for small singular values (relative, not absolute, accuracy), and it is a chain of
 // embarrassingly parallel steps: a sweep is q - 1 steps of q / 2 independent column pairs (round-robin tournament), one workgroup per
 // pair - two dot products and a norm by a block reduction, then the rotation of the two columns of W and of V.  Launch-bound
-// (sweeps x (q - 1) launches of a few us): ~40 ms at q = 512; that is the price of exact rank semantics, against a host round
-// trip of the whole matrix plus a CPU SVD.
+// (sweeps x (q - 1) launches of a few us) up to q ~ 1024 - 0.15 s at 512, 0.45 s at 1024 -, bound by the traffic of the column pairs
+// beyond (1.7 s at 2048, 9.6 s at 4096: every step streams W and V once and a half); that is the price of exact rank semantics,
+// against a host round trip of the whole matrix plus a CPU SVD of the same order (minutes at 4096).
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -20,6 +22,15 @@
 namespace rmhip {
 
 static constexpr int JAC_THREADS = 256;
+
+int svd_max_cols() {
+    static const int v = [] {
+        const char* e = std::getenv("RMHIP_SVD_MAX_COLS");
+        const long x = e ? std::strtol(e, nullptr, 10) : 0;
+        return x > 0 && x <= 32768 ? (int)x : kSvdMaxColsDefault;
+    }();
+    return v;
+}
 
 __device__ __forceinline__ double jac_block_sum(double v, double* lds) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -133,7 +144,7 @@ int svd_solve_device(Context* c, const double* A, size_t m, size_t n, const doub
     const bool transposed = m < n;
     const size_t p = transposed ? n : m, q = transposed ? m : n;  // W is p x q, tall
     if (q == 0 || p == 0 || nrhs == 0) return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: empty system");
-    if (q > (size_t)kSvdMaxCols) return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: the SVD path handles min(rows, cols) <= %d, got %zu", kSvdMaxCols, q);
+    if (q > (size_t)svd_max_cols()) return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: the SVD path handles min(rows, cols) <= %d, got %zu", svd_max_cols(), q);
     std::shared_ptr<Allocation> w_mem, v_mem, aux_mem, coef_mem;
     RMHIP_TRY(c->alloc_device(p * q, &w_mem));
     RMHIP_TRY(c->alloc_device(q * q, &v_mem));

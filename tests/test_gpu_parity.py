@@ -646,8 +646,8 @@ def test_mldivide_reference_tests(prov, oracle):
     # scalar lhs: mldivide.rs:321-325
     s = prov.download_matrix(prov.mldivide(prov.upload(np.array([[4.0]])), prov.upload(np.array([[2.0, 8.0]]))))
     assert np.array_equal(s, [[0.5, 2.0]])
-    # rank-deficient inputs: the LU / Gram paths refuse them - soft errors RMHIP_NO_SVD_PATH=1 still shows (and every system beyond 1024
-    # columns gets); up to 1024 columns the Jacobi-SVD path answers with the reference's minimum-norm solution (tests/test_gpu_svdpath.py)
+    # rank-deficient inputs: the LU / Gram paths refuse them - soft errors RMHIP_NO_SVD_PATH=1 still shows (and every system beyond 4096
+    # columns gets); up to 4096 columns the Jacobi-SVD path answers with the reference's minimum-norm solution (tests/test_gpu_svdpath.py)
     for Ax, bx, code in ((np.ones((3, 2)), np.ones((3, 1)), 2), (np.array([[1.0, 2.0], [2.0, 4.0]]), np.ones((2, 1)), 7)):
         os.environ["RMHIP_NO_SVD_PATH"] = "1"
         try:
@@ -1439,7 +1439,7 @@ def test_mrdivide_and_solve_telemetry(prov, oracle):
     X = prov.download_matrix(prov.mrdivide(prov.upload(B), prov.upload(A)))
     assert X.shape == (m, n) and np.max(np.abs(X - oracle.mrdivide(B, A))) <= 1e-12
     assert np.linalg.norm(X @ A - B) <= 1e-12 * n * np.linalg.norm(A) * np.linalg.norm(X)
-    # soft failures are counted by reason (telemetry.rs:95-99).  Singular / rank-deficient systems up to 1024 columns are answered on
+    # soft failures are counted by reason (telemetry.rs:95-99).  Singular / rank-deficient systems up to 4096 columns are answered on
     # the device by the Jacobi-SVD path (tests/test_gpu_svdpath.py); RMHIP_NO_SVD_PATH=1 shows the hand-back every larger system gets
     os.environ["RMHIP_NO_SVD_PATH"] = "1"
     try:

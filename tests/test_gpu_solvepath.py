@@ -195,12 +195,16 @@ def test_singular_and_nan_inputs_still_end_in_the_reference_errors(prov):
     CPU's caller expects (SINGULAR -> its SVD path)."""
     from runmat_amd import ProviderError
 
-    n = 1500  # beyond the Jacobi-SVD path's 1024 columns (up to there the device answers itself: tests/test_gpu_svdpath.py)
+    n = 1500
     rng = np.random.default_rng(3)
     A = rng.uniform(-1, 1, (n, n))
     A[:, 17] = A[:, 3]  # two equal columns: exactly singular
-    with pytest.raises(ProviderError) as e:
-        prov.mldivide(prov.upload(A), prov.upload(np.ones((n, 1))))
+    os.environ["RMHIP_NO_SVD_PATH"] = "1"  # (without it the Jacobi-SVD path answers on the device: tests/test_gpu_svdpath.py)
+    try:
+        with pytest.raises(ProviderError) as e:
+            prov.mldivide(prov.upload(A), prov.upload(np.ones((n, 1))))
+    finally:
+        del os.environ["RMHIP_NO_SVD_PATH"]
     assert e.value.code == 7
     B = rng.uniform(-1, 1, (n, n))
     B[400, 5] = np.nan
@@ -268,9 +272,13 @@ def test_solve_under_real_contention(prov, built, fast):
             other = HipProvider(0)
             try:
                 a = other.fill_uniform(5, -1.0, 1.0, (4096, 4096))
+                k = 0
                 while not stop.is_set():
                     other.free(other.matmul(a, a))
                     started.set()
+                    k += 1
+                    if k % 8 == 0:  # a bounded queue: the hog must stop when told to, not seconds of queued products later
+                        other.synchronize()
                 other.synchronize()
             finally:
                 other.close()

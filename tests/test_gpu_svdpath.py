@@ -1,5 +1,5 @@
 """GPU tests of the Jacobi-SVD path (svdsolve.hip): what the LU / Gram solves refuse - singular, rank-deficient and ill-conditioned
-systems with min(rows, cols) <= 1024 - gets the reference's own answer on the device: the minimum-norm least-squares solution of an SVD
+systems with min(rows, cols) <= 4096 - gets the reference's own answer on the device: the minimum-norm least-squares solution of an SVD
 with the tolerance eps * max(m, n) * max(s_max, 1) (crates/runmat-runtime/src/builtins/math/linalg/ops/mldivide.rs:380-404), checked against
 the oracle's restatement (oracle.c `orc_mldivide_svd`, the same one-sided Jacobi) to 1e-10 relative."""
 import numpy as np
@@ -72,7 +72,22 @@ def test_beyond_the_cap_is_still_handed_back(prov):
     from runmat_amd import ProviderError
 
     rng = np.random.default_rng(3)
-    A = rng.standard_normal((1500, 10)) @ rng.standard_normal((10, 1500))
+    n = 4224
+    A = rng.standard_normal((n, 10)) @ rng.standard_normal((10, n))
     with pytest.raises(ProviderError) as e:
-        prov.mldivide(prov.upload(A), prov.upload(np.ones((1500, 1))))
+        prov.mldivide(prov.upload(A), prov.upload(np.ones((n, 1))))
     assert e.value.code == 7
+
+
+@pytest.mark.parametrize("m,n,rank", [(1300, 1300, 1250), (2600, 1100, 1000), (1100, 2600, 1000)])
+def test_rank_deficient_systems_beyond_1024_columns(prov, m, n, rank):
+    """orders the oracle's scalar Jacobi would take minutes for: against LAPACK's minimum-norm least squares (numpy.linalg.lstsq, the same
+    definition with a relative cut-off far from any singular value of these matrices)"""
+    rng = np.random.default_rng(m + n)
+    A = rng.standard_normal((m, rank)) @ rng.standard_normal((rank, n)) / np.sqrt(rank)
+    B = rng.standard_normal((m, 2))
+    s0 = prov.lu_stats()["svd_solves"]
+    x = prov.download_matrix(prov.mldivide(prov.upload(A), prov.upload(B)))
+    assert prov.lu_stats()["svd_solves"] == s0 + 1
+    want = np.linalg.lstsq(A, B, rcond=1e-12)[0]
+    assert x.shape == want.shape and np.max(np.abs(x - want)) <= 1e-9 * np.max(np.abs(want))
