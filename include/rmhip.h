@@ -267,7 +267,8 @@ RMHIP_API int rmhip_matmul_epilogue(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b,
 RMHIP_API int rmhip_matmul_power_step(rmhip_ctx* ctx, rmhip_buf lhs, rmhip_buf rhs, double epsilon, rmhip_buf* out);
 /* `image_normalize` + ImageNormalizeDescriptor (lib.rs:2407-2413, 3563-3577; CPU semantics simple_provider.rs:7893-7993):
  * input is [batch, height, width]; per batch element mean / two-pass variance over the plane, then
- * y = (x - mean) / sqrt(var + epsilon) [* gain] [+ bias] [max 0] [^ gamma].  batch <= 256. */
+ * y = (x - mean) / sqrt(var + epsilon) [* gain] [+ bias] [max 0] [^ gamma].  Any batch extent (up to 256 planes: one block layout with fixed planes per
+ * thread; more: the statistics by the strided moments reduction and flat apply threads). */
 typedef struct rmhip_image_normalize {
     size_t batch, height, width;
     double epsilon;

@@ -157,6 +157,20 @@ struct TruthAcc {
     }
 };
 
+// sum and sum of squares in one pass (reduce_moments_nd: E[x] and E[x^2] along a dimension); NaNs propagate through both sums
+struct SqAcc {
+    double s, q;
+    __device__ __forceinline__ void init() { s = q = 0.0; }
+    __device__ __forceinline__ void add(u64, double v) {
+        s += v;
+        q += v * v;
+    }
+    __device__ __forceinline__ void merge(const SqAcc& o) {
+        s += o.s;
+        q += o.q;
+    }
+};
+
 // ---- stage 1 ----------------------------------------------------------------------------------------------------------------
 // eight elements of a thread's run, in ascending index order
 template <class Acc>
@@ -167,6 +181,12 @@ __device__ __forceinline__ void r2_fold8(Acc& a, const u64 (&k)[8], const double
 template <>
 __device__ __forceinline__ void r2_fold8<MomAcc>(MomAcc& a, const u64 (&)[8], const double (&v)[8]) {
     a.add8(v);
+}
+template <>
+__device__ __forceinline__ void r2_fold8<SqAcc>(SqAcc& a, const u64 (&)[8], const double (&v)[8]) {
+    // pairwise inside the batch (independent adds instead of two eight-deep chains), then one add into the running sums
+    a.s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    a.q += ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
 }
 
 static constexpr int R2_BLOCK = 256;
@@ -587,6 +607,42 @@ int launch_argreduce(Context* c, int op, int nan_mode, const double* x, size_t p
 int launch_reduce_std(Context* c, int population, int nan_mode, const double* x, size_t pre, size_t red, size_t post, double* out) {
     StdFin fin{out, population, nan_mode};
     return run_r2<MomAcc>(c, x, pre, red, post, fin, "reduce_std");
+}
+// image_normalize with more planes than special.hip's block layout takes (batch > 256): the tensor is a batch x plane matrix and the
+// statistics are a moments reduction along its second dimension - many short-stride lines, the strided kernels' home ground.
+// stats[b] = mean, stats[batch + b] = 1 / sqrt(M2 / plane + eps) (0 when that is not positive: simple_provider.rs:7961-7963)
+struct PlaneStatFin {
+    double* stats;
+    u64 batch;
+    double plane, eps;
+    __device__ __forceinline__ void operator()(u64 slice, const MomAcc& a) const {
+        double mean = a.mean, inv = 0.0;
+        if (a.nan > 0.0) mean = r2_nan();  // the CPU's running sum turns NaN; its sigma test then fails and inv stays 0
+        else {
+            const double sigma = sqrt(a.m2 / plane + eps);
+            inv = sigma > 0.0 ? 1.0 / sigma : 0.0;
+        }
+        stats[slice] = mean;
+        stats[batch + slice] = inv;
+    }
+};
+int launch_plane_stats(Context* c, const double* x, size_t batch, size_t plane, double eps, double* stats) {
+    PlaneStatFin fin{stats, (u64)batch, (double)plane, eps};
+    return run_r2<MomAcc>(c, x, batch, plane, 1, fin, "image_normalize");
+}
+// mean(x, dim) and mean(x .* x, dim) from one pass over x (the first, full-size step of reduce_moments_nd)
+struct MomentsFin {
+    double* mean;
+    double* ex2;
+    double count;
+    __device__ __forceinline__ void operator()(u64 slice, const SqAcc& a) const {
+        mean[slice] = a.s / count;
+        ex2[slice] = a.q / count;
+    }
+};
+int launch_reduce_moments(Context* c, const double* x, size_t pre, size_t red, size_t post, double* mean, double* ex2) {
+    MomentsFin fin{mean, ex2, (double)red};
+    return run_r2<SqAcc>(c, x, pre, red, post, fin, "reduce_moments_nd");
 }
 int launch_reduce_truth(Context* c, int op, int omit_nan, const double* x, size_t pre, size_t red, size_t post, double* out) {
     TruthFin fin{out, op, omit_nan, (u64)red};

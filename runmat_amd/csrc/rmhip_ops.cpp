@@ -698,15 +698,44 @@ int rmhip_reduce_moments_nd(rmhip_ctx* ctx, rmhip_buf a, const size_t* dims_zero
     size_t numel = 0;
     RMHIP_TRY(rmhip_numel(ctx, a, &numel));
     if (numel == 0) return fail(RMHIP_ERR_UNSUPPORTED, "reduce_moments_nd: empty tensor");  // nd.rs:318
-    rmhip_buf mean = 0, sq = 0, ex2 = 0;
-    RMHIP_TRY(rmhip_reduce_nd(ctx, RMHIP_RMEAN, a, dims_zero_based, ndims, 0, &mean));
-    int rc = rmhip_binary(ctx, RMHIP_MUL, a, a, &sq);  // x .* x, then the same mean-of-means as the CPU's mean(x.^2, dims)
-    if (!rc) {
-        rc = rmhip_reduce_nd(ctx, RMHIP_RMEAN, sq, dims_zero_based, ndims, 0, &ex2);
-        rmhip_free(ctx, sq);
+    // The CPU's mean(x, dims) and mean(x .^ 2, dims) are means of means, one dimension after the other in ascending order
+    // (mean.rs:1107-1116).  The first step is the only one that reads the whole tensor: ONE pass gives both of its results (sum and
+    // sum of squares side by side, reduce2.hip SqAcc - x .* x is never materialised); the later steps run on the small intermediates.
+    Buffer ab;
+    RMHIP_TRY(c->get(a, &ab));
+    const std::vector<size_t> shape = normalize_matrix_shape(ab.shape);
+    std::vector<size_t> dims;  // nd.rs:62-72: dims beyond the rank are ignored, duplicates dropped, ascending order
+    for (size_t i = 0; i < ndims; ++i)
+        if (dims_zero_based && dims_zero_based[i] < shape.size()) dims.push_back(dims_zero_based[i]);
+    std::sort(dims.begin(), dims.end());
+    dims.erase(std::unique(dims.begin(), dims.end()), dims.end());
+    if (dims.empty()) return fail(RMHIP_ERR_INVALID, "reduce_nd: no valid dims to reduce");
+    const size_t d0 = dims[0];
+    size_t pre = 1, post = 1;
+    for (size_t i = 0; i < d0; ++i) pre *= shape[i];
+    for (size_t i = d0 + 1; i < shape.size(); ++i) post *= shape[i];
+    std::vector<size_t> oshape = shape;
+    oshape[d0] = 1;
+    rmhip_buf mean = 0, ex2 = 0;
+    Buffer mb, eb;
+    RMHIP_TRY(c->new_buffer(oshape.data(), oshape.size(), &mean, &mb));
+    int rc = c->new_buffer(oshape.data(), oshape.size(), &ex2, &eb);
+    if (!rc) rc = launch_reduce_moments(c, ab.data(), pre, shape[d0], post, mb.data(), eb.data());
+    if (!rc && dims.size() > 1) {
+        rmhip_buf m2 = 0, e2 = 0;
+        rc = rmhip_reduce_nd(ctx, RMHIP_RMEAN, mean, dims.data() + 1, dims.size() - 1, 0, &m2);
+        if (!rc) rc = rmhip_reduce_nd(ctx, RMHIP_RMEAN, ex2, dims.data() + 1, dims.size() - 1, 0, &e2);
+        if (rc && m2) rmhip_free(ctx, m2);
+        if (!rc) {
+            rmhip_free(ctx, mean);
+            rmhip_free(ctx, ex2);
+            mean = m2;
+            ex2 = e2;
+        }
     }
     if (rc) {
-        rmhip_free(ctx, mean);
+        if (mean) rmhip_free(ctx, mean);
+        if (ex2) rmhip_free(ctx, ex2);
         return rc;
     }
     *mean_out = mean;
@@ -818,7 +847,7 @@ int rmhip_image_normalize(rmhip_ctx* ctx, rmhip_buf input, const rmhip_image_nor
     if (!std::isfinite(d->epsilon)) return fail(RMHIP_ERR_INVALID, "image_normalize: epsilon must be finite");
     if (d->epsilon < 0.0) return fail(RMHIP_ERR_INVALID, "image_normalize: epsilon must be non-negative");
     Buffer ib, ob;
-    bool f32 = c->precision == 32;
+    bool f32 = c->precision == 32 && d->batch <= 256;  // more planes than that: the f64 kernels on a widened copy (special.hip IN_MAX_BATCH)
     RMHIP_TRY(get_operand(c, input, &ib, &f32));
     if (ib.shape.size() != 3) return fail(RMHIP_ERR_SHAPE, "image_normalize: expected 3-D tensor, got rank %zu", ib.shape.size());
     if (ib.shape[0] != d->batch || ib.shape[1] != d->height || ib.shape[2] != d->width)

@@ -22,12 +22,12 @@
 
 namespace rmhip {
 
-static constexpr int IN_MAX_BATCH = 256;
+static constexpr int IN_MAX_BATCH = 256;  // above: the statistics by the strided moments reduction (reduce2.hip), flat apply threads
 static constexpr int IN_BLOCK = 1024;  // streaming passes: the largest multiple of `batch` <= 1024 threads per block
 
 // T = storage type (float on a precision-32 provider); sums and statistics are f64 either way.
-// VEC = elements per access (a 16-byte vector when the batch extent allows it: VEC divides `batch`, so a thread's VEC
-// consecutive elements are VEC consecutive batch indices and every stride keeps them fixed).
+// VEC = elements per access (a 16-byte vector when the element count allows it: a thread's VEC consecutive elements are VEC
+// consecutive batch indices - modulo the extent - and every stride, a multiple of the extent, keeps them fixed).
 template <class T, int VEC>
 struct VecT {
     typedef T type __attribute__((ext_vector_type(VEC)));
@@ -63,7 +63,7 @@ template <class T, int VEC>
 __global__ void __launch_bounds__(IN_BLOCK) k_plane_moments(const T* __restrict__ x, size_t total, int batch, Mom* __restrict__ partial) {
     __shared__ Mom s[IN_BLOCK * VEC > 2048 ? 2048 : IN_BLOCK * VEC];
     const int t = threadIdx.x;
-    const size_t nvec = total / VEC;  // batch % VEC == 0, hence total % VEC == 0
+    const size_t nvec = total / VEC;  // total % VEC == 0 (the host's choice of VEC)
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     constexpr int CH = 8;  // vectors per chunk: CH * VEC values live in registers while the chunk's two passes run
     Mom acc[VEC];
@@ -172,6 +172,24 @@ __global__ void __launch_bounds__(FIN_BLOCK) k_plane_moments_final(const Mom* __
     stats[batch + b] = sigma > 0.0 ? 1.0 / sigma : 0.0;
 }
 
+// one pixel: y = (x - mean) * inv [* gain] [+ bias] [max 0] [^ gamma]
+__device__ __forceinline__ double imgnorm_value(double x, double mu, double inv, int has_gain, double gain, int has_bias, double bias,
+                                                int clamp_zero, int has_gamma, double gamma) {
+    double w = (x - mu) * inv;
+    if (has_gain) w *= gain;
+    if (has_bias) w += bias;
+    if (clamp_zero) w = fmax(w, 0.0);  // f64::max: a NaN operand loses
+    // gamma step: for a positive base one fused log -> multiply -> exp (rm_pow_pos, skel_common.h: ~55 instructions, the
+    // library pow is ~200 and made this pass VALU-bound); relative error <= (0.45 |g ln w| + 1.5) 2^-53, |g ln w| <= 32,
+    // beyond that (pixels below e^(-32 / g)) and for 0, +Inf, NaN and negative bases (no clamp requested) the library pow.
+    // (+0 - half of a clamped image - is answered in place: pow(+0, g > 0) = +0)
+    if (has_gamma) {
+        if (gamma > 0.0 && w > 0.0) w = rm_pow_pos(w, gamma);
+        else if (!(gamma > 0.0 && __double_as_longlong(w) == 0ll)) w = rm_pow_cold(w, gamma);
+    }
+    return w;
+}
+
 template <class T, int VEC>
 __global__ void __launch_bounds__(IN_BLOCK) k_imgnorm_apply(const T* __restrict__ x, T* __restrict__ y, size_t total,
                                                        int batch, const double* __restrict__ stats, int has_gain, double gain,
@@ -180,8 +198,9 @@ __global__ void __launch_bounds__(IN_BLOCK) k_imgnorm_apply(const T* __restrict_
     double mu[VEC], inv[VEC];
 #pragma unroll
     for (int l = 0; l < VEC; ++l) {
-        mu[l] = stats[b + l];
-        inv[l] = stats[batch + b + l];
+        const int bl = (b + l) % batch;  // VEC need not divide an odd batch extent: the thread's elements wrap around it
+        mu[l] = stats[bl];
+        inv[l] = stats[batch + bl];
     }
     const size_t nvec = total / VEC;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -190,21 +209,7 @@ __global__ void __launch_bounds__(IN_BLOCK) k_imgnorm_apply(const T* __restrict_
     constexpr int APPLY_U = 1;
     auto one = [&](double (&v)[VEC], size_t i) {
 #pragma unroll
-        for (int l = 0; l < VEC; ++l) {
-            double w = (v[l] - mu[l]) * inv[l];
-            if (has_gain) w *= gain;
-            if (has_bias) w += bias;
-            if (clamp_zero) w = fmax(w, 0.0);  // f64::max: a NaN operand loses
-            // gamma step: for a positive base one fused log -> multiply -> exp (rm_pow_pos, skel_common.h: ~55 instructions, the
-            // library pow is ~200 and made this pass VALU-bound); relative error <= (0.45 |g ln w| + 1.5) 2^-53, |g ln w| <= 32,
-            // beyond that (pixels below e^(-32 / g)) and for 0, +Inf, NaN and negative bases (no clamp requested) the library pow.
-            // (+0 - half of a clamped image - is answered in place: pow(+0, g > 0) = +0)
-            if (has_gamma) {
-                if (gamma > 0.0 && w > 0.0) w = rm_pow_pos(w, gamma);
-                else if (!(gamma > 0.0 && __double_as_longlong(w) == 0ll)) w = rm_pow_cold(w, gamma);
-            }
-            v[l] = w;
-        }
+        for (int l = 0; l < VEC; ++l) v[l] = imgnorm_value(v[l], mu[l], inv[l], has_gain, gain, has_bias, bias, clamp_zero, has_gamma, gamma);
         if constexpr (VEC == 1) {
             __builtin_nontemporal_store((T)v[0], y + i);
         } else {
@@ -227,6 +232,51 @@ __global__ void __launch_bounds__(IN_BLOCK) k_imgnorm_apply(const T* __restrict_
         load_vec<T, VEC>(x, i, v);
         one(v, i);
     }
+}
+
+// more planes than a block has threads for (batch > IN_MAX_BATCH): flat threads, the plane of an element from its index
+template <int VEC>
+__global__ void __launch_bounds__(256) k_imgnorm_apply_flat(const double* __restrict__ x, double* __restrict__ y, size_t total, unsigned batch,
+                                                            const double* __restrict__ stats, int has_gain, double gain, int has_bias, double bias,
+                                                            int clamp_zero, int has_gamma, double gamma) {
+    const size_t nvec = total / VEC, stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+        double v[VEC];
+        load_vec<double, VEC>(x, i, v);
+        const unsigned b = (unsigned)((i * VEC) % batch);  // VEC divides batch: b + l stays below it
+#pragma unroll
+        for (int l = 0; l < VEC; ++l) v[l] = imgnorm_value(v[l], stats[b + l], stats[batch + b + l], has_gain, gain, has_bias, bias, clamp_zero, has_gamma, gamma);
+        if constexpr (VEC == 1) {
+            __builtin_nontemporal_store(v[0], y + i);
+        } else {
+            typename VecT<double, VEC>::type r;
+#pragma unroll
+            for (int l = 0; l < VEC; ++l) r[l] = v[l];
+            __builtin_nontemporal_store(r, (typename VecT<double, VEC>::type*)y + i);
+        }
+    }
+}
+static int image_normalize_many(Context* c, const double* x, double* y, size_t batch, size_t plane, double epsilon, int has_gain, double gain,
+                                int has_bias, double bias, int clamp_zero, int has_gamma, double gamma) {
+    if (batch > 0xffffffffULL) return fail(RMHIP_ERR_UNSUPPORTED, "image_normalize: batch %zu not supported by provider", batch);
+    std::shared_ptr<Allocation> st;
+    RMHIP_TRY(c->alloc_device(2 * batch, &st));
+    RMHIP_TRY(launch_plane_stats(c, x, batch, plane, epsilon, st->ptr));
+    const size_t total = batch * plane;
+    const bool v2 = batch % 2 == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+    const size_t nvec = v2 ? total / 2 : total;
+    const size_t want = (nvec + 511) / 512, cap = (size_t)c->num_cus * 32;
+    const unsigned grid = (unsigned)(want < cap ? (want < 1 ? 1 : want) : cap);
+    if (v2)
+        hipLaunchKernelGGL(k_imgnorm_apply_flat<2>, dim3(grid), dim3(256), 0, c->stream, x, y, total, (unsigned)batch, (const double*)st->ptr, has_gain, gain,
+                           has_bias, bias, clamp_zero, has_gamma, gamma);
+    else
+        hipLaunchKernelGGL(k_imgnorm_apply_flat<1>, dim3(grid), dim3(256), 0, c->stream, x, y, total, (unsigned)batch, (const double*)st->ptr, has_gain, gain,
+                           has_bias, bias, clamp_zero, has_gamma, gamma);
+    c->tel.kernel_launches += 1;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    // (the statistics go back to the pool on return: reuse is stream-ordered, rmhip_core.cpp release_device)
+    return RMHIP_OK;
 }
 
 template <class T, int VEC>
@@ -260,19 +310,25 @@ static int image_normalize_vec(Context* c, const T* x, T* y, size_t batch, size_
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
 }
-// 16-byte accesses when the batch extent and the alignment allow them (two f64 / four f32 per lane), else narrower
 template <class T>
 static int image_normalize_any(Context* c, const T* x, T* y, size_t batch, size_t height, size_t width, double epsilon,
                                int has_gain, double gain, int has_bias, double bias, int clamp_zero, int has_gamma, double gamma) {
     if (batch * height * width == 0) return RMHIP_OK;
-    if (batch > (size_t)IN_MAX_BATCH)
-        return fail(RMHIP_ERR_UNSUPPORTED, "image_normalize: batch %zu > %d not supported by provider", batch, IN_MAX_BATCH);
+    if (batch > (size_t)IN_MAX_BATCH) {
+        if constexpr (sizeof(T) == 8)
+            return image_normalize_many(c, x, y, batch, height * width, epsilon, has_gain, gain, has_bias, bias, clamp_zero, has_gamma, gamma);
+        else
+            return fail(RMHIP_ERR_UNSUPPORTED, "image_normalize: batch %zu > %d takes the f64 kernels", batch, IN_MAX_BATCH);  // rmhip_ops.cpp widens first
+    }
+    // 16-byte accesses whenever the element count and the alignment allow them: a vector's elements are consecutive batch indices
+    // (wrapping around an extent the width does not divide) and every stride is a multiple of the extent, so they stay fixed
     const bool a16 = ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+    const size_t total = batch * height * width;
     constexpr int WIDE = 16 / (int)sizeof(T);
-    if (a16 && batch % WIDE == 0)
+    if (a16 && total % WIDE == 0)
         return image_normalize_vec<T, WIDE>(c, x, y, batch, height, width, epsilon, has_gain, gain, has_bias, bias, clamp_zero, has_gamma, gamma);
     if constexpr (sizeof(T) == 4) {
-        if (a16 && batch % 2 == 0)
+        if (a16 && total % 2 == 0)
             return image_normalize_vec<T, 2>(c, x, y, batch, height, width, epsilon, has_gain, gain, has_bias, bias, clamp_zero, has_gamma, gamma);
     }
     return image_normalize_vec<T, 1>(c, x, y, batch, height, width, epsilon, has_gain, gain, has_bias, bias, clamp_zero, has_gamma, gamma);

@@ -138,3 +138,30 @@ def test_transposes_and_products_of_views_random_2d_shapes(prov, prov32, precisi
         assert np.array_equal(p.download(g).reshape((n, n), order="F"), xi.T @ xi), (precision, m, n, "A'*A")
         p.free(h)
         p.free(hi)
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_dot_and_moments_of_random_3d_shapes(prov, prov32, precision):
+    """dot along every dimension (products of quarters and their sums are exact in f64; on f32 storage the result rounds once) and
+    reduce_moments_nd over dimension subsets (one fused pass for the first dimension, the rest on the intermediates)"""
+    p = prov if precision == "f64" else prov32
+    rng = np.random.default_rng(109 if precision == "f64" else 110)
+    r32 = (lambda a: a.astype(np.float32).astype(np.float64)) if precision == "f32" else (lambda a: a)
+    for it, shape in enumerate(_shapes(rng, 30)):
+        a, b = _quarters(rng, shape), _quarters(rng, shape)
+        ha, hb = p.upload(a), p.upload(b)
+        for dim in (0, 1, 2):
+            oshape = tuple(1 if d == dim else e for d, e in enumerate(shape))
+            got = _dl(p, p.dot(ha, hb, dim), oshape)
+            assert np.array_equal(got, r32((a * b).sum(axis=dim, keepdims=True))), (precision, shape, dim, "dot")
+        dims = [(0,), (1,), (2,), (0, 1), (1, 2), (0, 2), (0, 1, 2)][it % 7]
+        mean, ex2 = p.reduce_moments_nd(ha, dims)
+        wm, w2 = a, a * a
+        for d in dims:
+            wm, w2 = wm.mean(axis=d, keepdims=True), w2.mean(axis=d, keepdims=True)
+        tol = 1e-13 if precision == "f64" else 2e-6
+        gm, g2 = _dl(p, mean, wm.shape), _dl(p, ex2, w2.shape)
+        assert np.max(np.abs(gm - wm)) <= tol * max(1.0, float(np.abs(wm).max())), (precision, shape, dims, "mean")
+        assert np.max(np.abs(g2 - w2)) <= tol * max(1.0, float(np.abs(w2).max())), (precision, shape, dims, "ex2")
+        p.free(ha)
+        p.free(hb)

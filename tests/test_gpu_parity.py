@@ -1227,7 +1227,9 @@ def test_matmul_split_k(prov, oracle, m, n, k):
 
 
 # ---- special fusion-pattern hooks: image_normalize, matmul_power_step -----------------------------------
-@pytest.mark.parametrize("shape", [(3, 4, 5), (1, 7, 9), (16, 64, 48), (5, 33, 17), (256, 8, 8), (7, 1, 1)])
+@pytest.mark.parametrize("shape", [(3, 4, 5), (1, 7, 9), (16, 64, 48), (5, 33, 17), (256, 8, 8), (7, 1, 1),
+                                   (1, 64, 50), (3, 31, 20), (5, 7, 9), (1, 300, 201), (15, 16, 9),  # 16-byte vectors over an odd batch extent / none for an odd count
+                                   (300, 16, 16), (1001, 9, 7), (4096, 8, 8), (257, 3, 3), (70000, 2, 1)])  # more than 256 planes
 @pytest.mark.parametrize("opts", [dict(gain=1.05, bias=-0.02, gamma=1.8, clamp_zero=True), dict(clamp_zero=False), dict(gain=2.0)])
 def test_image_normalize_vs_oracle(prov, oracle, shape, opts):
     if shape == (3, 4, 5):  # accelerate/tests/image_normalize.rs:74-92
@@ -1252,8 +1254,6 @@ def test_image_normalize_errors_and_degenerate(prov):
         prov.image_normalize(h, 3, 3, 2, 1e-6)          # descriptor dims do not match
     with pytest.raises(ProviderError):
         prov.image_normalize(prov.upload(np.ones((4, 4))), 4, 4, 1, 1e-6)  # not 3-D
-    with pytest.raises(ProviderError):
-        prov.image_normalize(prov.upload(np.ones((300, 2, 2))), 300, 2, 2, 1e-6)  # batch > 256: CPU path
 
 
 @pytest.mark.parametrize("m,k,n", [(2, 2, 2), (64, 32, 8), (1000, 64, 5), (257, 129, 33)])
