@@ -582,7 +582,9 @@ static int run_r2(Context* c, const double* x, size_t pre, size_t red, size_t po
     else
         hipLaunchKernelGGL((k_r2_strided<Acc>), dim3(gx, (unsigned)nsplit, (unsigned)post), dim3(R2_BLOCK), 0, c->stream, x, (u64)pre, (u64)red, nsplit, part);
     RMHIP_HIP_CHECK(hipGetLastError());
-    if (nsplit <= 8 && p.nslices >= 1024)
+    // many slices with a handful of partials each: one thread per slice (a wave per slice would idle 50 of its lanes; 65536 slices
+    // x 14 partials took 37 us that way)
+    if ((nsplit <= 8 && p.nslices >= 1024) || (nsplit <= 32 && p.nslices >= 16384))
         hipLaunchKernelGGL((k_r2_final_flat<Acc, Fin>), dim3((unsigned)ceil_div_u64(p.nslices, R2_BLOCK)), dim3(R2_BLOCK), 0, c->stream, part,
                            (u64)p.nslices, nsplit, fin);
     else

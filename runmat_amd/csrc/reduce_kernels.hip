@@ -233,7 +233,7 @@ static int run_reduce(Context* c, int mean, int nan_mode, const T* x, size_t pre
         hipLaunchKernelGGL((k_reduce_strided<OP, T>), dim3(p.gx, p.gy, p.gz), dim3(RM_RBLOCK), 0, c->stream, x,
                            (rm_u64)pre, (rm_u64)red, (rm_u64)p.nsplit, p.tx, pv, pn);
     RMHIP_HIP_CHECK(hipGetLastError());
-    if (nsplit <= 8 && p.nslices >= 1024) {  // many slices, a handful of partials each: one thread per slice
+    if ((nsplit <= 8 && p.nslices >= 1024) || (nsplit <= 32 && p.nslices >= 16384)) {  // many slices, a handful of partials each: one thread per slice
         hipLaunchKernelGGL((k_reduce_final_flat<OP>), dim3((unsigned)ceil_div_u64(p.nslices, RM_RBLOCK)), dim3(RM_RBLOCK), 0, c->stream, pv, pn,
                            (rm_u64)p.nslices, (rm_u64)nsplit, (rm_u64)red, mean, nan_mode, 1.0, out);
     } else {

@@ -886,8 +886,23 @@ int rmhip_covariance(rmhip_ctx* ctx, rmhip_buf matrix, int biased, rmhip_buf* ou
     }
     rmhip_buf means = 0, centred = 0, gram = 0;
     int rc = rmhip_reduce(ctx, RMHIP_RMEAN, matrix, 0, 0, &means);       // [1, cols]
-    if (!rc) rc = rmhip_binary(ctx, RMHIP_SUB, matrix, means, &centred);  // broadcast over rows
-    if (!rc) rc = rmhip_syrk(ctx, centred, &gram);                        // Xc' * Xc
+    if (!rc && c->precision == 64 && gram_skinny_applies(rows, cols) && !std::getenv("RMHIP_NO_GRAM_SKINNY")) {
+        // many samples of a few variables: centred on the way, no centred copy, no 256-wide MFMA tiles of 8-32 columns (special.hip)
+        // (the division by the denominator and the diagonal rule ride on its second kernel)
+        Buffer xb, mub, ob;
+        rc = c->get(matrix, &xb);
+        if (!rc) rc = c->get(means, &mub);
+        if (!rc) rc = c->new_buffer(oshape, 2, out, &ob);
+        if (!rc) {
+            rc = gram_skinny_device(c, xb.data(), rows, cols, mub.data(), denom, true, ob.data());
+            if (rc) rmhip_free(ctx, *out);
+        }
+        rmhip_free(ctx, means);
+        return rc;
+    } else {
+        if (!rc) rc = rmhip_binary(ctx, RMHIP_SUB, matrix, means, &centred);  // broadcast over rows
+        if (!rc) rc = rmhip_syrk(ctx, centred, &gram);                        // Xc' * Xc
+    }
     if (!rc) {
         // gram / denom and the CPU's diagonal rules on an f64 result; at precision 32 `gb` is a widened copy and the result
         // is rounded to f32 storage on return (writing through Context::get of an f32 buffer would only touch a temporary)
@@ -951,6 +966,8 @@ int rmhip_syrk(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out) {
     RMHIP_TRY(c->new_buffer(oshape, 2, out, &ob));
     int rc = RMHIP_OK;
     if (rows == 0) rc = launch_fill(c, ob.data(), ob.numel, 0.0);
+    else if (!f32 && c->precision == 64 && gram_skinny_applies(rows, cols) && !std::getenv("RMHIP_NO_GRAM_SKINNY"))
+        rc = gram_skinny_device(c, ab.data(), rows, cols, nullptr, 1.0, false, ob.data());
     else rc = launch_dgemm_trans(c, true, false, cols, cols, rows, 1.0, ab.data(), rows, ab.data(), rows, 0.0, ob.data(), cols);
     if (rc) rmhip_free(ctx, *out);
     return rc;

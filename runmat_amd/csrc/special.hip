@@ -104,14 +104,17 @@ __global__ void __launch_bounds__(IN_BLOCK) k_plane_moments(const T* __restrict_
             acc[l].m2 += d * (v[l] - acc[l].mean);
         }
     }
-    // fold the VEC * blockDim.x triples (entry e belongs to batch element e % batch) in two levels, each in a fixed order
-    const int ngroups = VEC * (int)blockDim.x / batch, m = (int)blockDim.x / batch;
-    const int g1 = ngroups < 32 ? (ngroups < m ? ngroups : m) : (m < 32 ? m : 32);
+    // fold the VEC * blockDim.x triples (entry e belongs to batch element e % batch): g1 = blockDim.x / batch threads per batch
+    // element each merge their share of its ngroups entries in order, then a binary tree over the g1 results (fixed order; the first
+    // version - 32 threads per element in chains of up to 64 merges, then one thread over the 32 - took longer than the streaming
+    // part of a single 4K plane: 79 us)
+    const int ngroups = VEC * (int)blockDim.x / batch, g1 = (int)blockDim.x / batch;
     __shared__ Mom s2[IN_BLOCK];
     // the triples go through LDS in two halves when VEC * blockDim.x exceeds the staging array (f32: four per thread)
     Mom mine2 = Mom{0.0, 0.0, 0.0};
     constexpr int CAP = IN_BLOCK * VEC > 2048 ? 2048 : IN_BLOCK * VEC;
     const int entries = VEC * (int)blockDim.x;
+    const int bb = t % batch, g = t / batch;  // t < batch * g1 == blockDim.x
     for (int base = 0; base < entries; base += CAP) {
         __syncthreads();
 #pragma unroll
@@ -120,21 +123,22 @@ __global__ void __launch_bounds__(IN_BLOCK) k_plane_moments(const T* __restrict_
             if (e >= 0 && e < CAP) s[e] = acc[l];
         }
         __syncthreads();
-        if (t < batch * g1) {
-            const int bb = t % batch, g = t / batch;
-            for (int j = g; j < ngroups; j += g1) {
-                const int e = j * batch + bb - base;
-                if (e >= 0 && e < CAP) mine2 = mom_merge(mine2, s[e]);
-            }
+        for (int j = g; j < ngroups; j += g1) {
+            const int e = j * batch + bb - base;
+            if (e >= 0 && e < CAP) mine2 = mom_merge(mine2, s[e]);
         }
     }
-    if (t < batch * g1) s2[t] = mine2;
+    s2[t] = mine2;
     __syncthreads();
-    if (t < batch) {
-        Mom a = Mom{0.0, 0.0, 0.0};
-        for (int g = 0; g < g1; ++g) a = mom_merge(a, s2[g * batch + t]);
-        partial[(size_t)blockIdx.x * batch + t] = a;
+    int h = 1;
+    while (h < g1) h <<= 1;
+    int cnt = g1;
+    for (h >>= 1; h >= 1; h >>= 1) {
+        if (g < h && g + h < cnt) s2[t] = mom_merge(s2[t], s2[t + h * batch]);
+        cnt = h < cnt ? h : cnt;
+        __syncthreads();
     }
+    if (t < batch) partial[(size_t)blockIdx.x * batch + t] = s2[t];
 }
 // stats[b] = mean, stats[batch + b] = 1 / sqrt(M2 / plane + eps) (0 when sigma is not positive) from the block triples: one
 // 256-thread block per plane b - thread t folds blocks t, t + 256, ... in that order, the 256 results merge in a fixed shuffle /
@@ -284,7 +288,7 @@ static int image_normalize_vec(Context* c, const T* x, T* y, size_t batch, size_
                                int has_gain, double gain, int has_bias, double bias, int clamp_zero, int has_gamma, double gamma) {
     const size_t plane = height * width, total = batch * plane;
     const unsigned threads = (unsigned)((IN_BLOCK / batch) * batch);  // a multiple of batch
-    size_t want = (total / VEC + (size_t)threads * 2 - 1) / ((size_t)threads * 2);  // >= 2 vectors per thread, grid-stride above the cap
+    size_t want = (total / VEC + (size_t)threads * 8 - 1) / ((size_t)threads * 8);  // >= 8 vectors (one register chunk) per thread, grid-stride above the cap
     const size_t cap = (size_t)c->num_cus * 8;
     if (want < 1) want = 1;
     const unsigned grid = (unsigned)(want < cap ? want : cap);
@@ -355,6 +359,162 @@ int diag_extract_device(Context* c, const double* a, size_t rows, long long offs
     if (len == 0) return RMHIP_OK;
     hipLaunchKernelGGL(k_diag_extract, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, a, rows, offset, len, out);
     c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+
+// ---- tall-skinny (centred) Gram matrix: G = (X - 1 mu)' (X - 1 mu), X rows x cols column-major, cols <= 32 ---------------------------
+// `cov` of many samples of a few variables (and `syrk` of such a matrix, mu = null).  The MFMA route runs a split-k product whose
+// 256-wide tiles hold 8-32 useful columns and needs the centred copy first: 688 us for 2^20 x 8, 245 us for 2^18 x 32.  Here the
+// matrix is read in place, coalesced (consecutive threads = consecutive rows of each column), the means subtracted on the way; a
+// thread keeps the 8 x 8 products of one pair of eight-column blocks in registers (grid.y = the block pairs of the lower triangle,
+// 1 / 3 / 6 / 10 for 8 / 16 / 24 / 32 columns: the second to tenth read of a row chunk comes from L2), a workgroup folds its threads
+// in a fixed shuffle / LDS tree and the chunks are summed in order by a second kernel: deterministic, no atomics.  VALU fp64 - at 64
+// fused multiply-adds per 16 loaded values the pass stays bound by the reads.
+static constexpr int GS_BLOCK = 256;
+// wave sum on the DPP network, result in lane 63 (a __shfl_down tree is ds_bpermute based and 64 of them per wave cost more than
+// the streaming pass they follow); fixed order
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double gs_dpp(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+__device__ __forceinline__ double gs_wave_sum63(double v) {
+    v += gs_dpp<0x111, 0xf>(v);  // row_shr:1
+    v += gs_dpp<0x112, 0xf>(v);  // row_shr:2
+    v += gs_dpp<0x114, 0xf>(v);  // row_shr:4
+    v += gs_dpp<0x118, 0xf>(v);  // row_shr:8 -> lane 15 of every row holds the row sum
+    v += gs_dpp<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += gs_dpp<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+    return v;
+}
+__device__ __forceinline__ void gs_pair(int p, int* jb, int* kb) {
+    int j = 0;
+    while ((j + 1) * (j + 2) / 2 <= p) ++j;
+    *jb = j;
+    *kb = p - j * (j + 1) / 2;
+}
+__global__ void __launch_bounds__(GS_BLOCK) k_gram_skinny(const double* __restrict__ x, size_t rows, int cols, const double* __restrict__ mu,
+                                                          double* __restrict__ partial) {
+    __shared__ double lds[GS_BLOCK / 64][64];
+    int jb, kb;
+    gs_pair((int)blockIdx.y, &jb, &kb);
+    const int j0 = jb * 8, k0 = kb * 8;
+    const bool diag = jb == kb;
+    double mj[8], mk[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        mj[u] = (mu && j0 + u < cols) ? mu[j0 + u] : 0.0;
+        mk[u] = (mu && k0 + u < cols) ? mu[k0 + u] : 0.0;
+    }
+    double acc[8][8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int v = 0; v < 8; ++v) acc[u][v] = 0.0;
+    size_t chunk = (rows + gridDim.x - 1) / gridDim.x;
+    chunk = (chunk + GS_BLOCK - 1) / GS_BLOCK * GS_BLOCK;
+    const size_t begin = (size_t)blockIdx.x * chunk;
+    size_t end = begin + chunk;
+    if (end > rows) end = rows;
+    // columns past the last one are loaded from the last one and zeroed afterwards: a load under a condition is a branch whose
+    // merge point waits for the value, which serialised the sixteen loads of an iteration (2^20 x 8: 30 us of kernel for 67 MB)
+    const double* cj[8];
+    const double* ck[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        cj[u] = x + (size_t)(j0 + u < cols ? j0 + u : cols - 1) * rows;
+        ck[u] = x + (size_t)(k0 + u < cols ? k0 + u : cols - 1) * rows;
+    }
+    auto load_row = [&](size_t r, double (&a)[8], double (&b)[8]) {
+        double ra[8], rb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ra[u] = cj[u][r];
+        if (!diag) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rb[u] = ck[u][r];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = j0 + u < cols ? ra[u] - mj[u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b[u] = diag ? a[u] : (k0 + u < cols ? rb[u] - mk[u] : 0.0);
+    };
+    auto fold_row = [&](const double (&a)[8], const double (&b)[8]) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int v = 0; v < 8; ++v) acc[u][v] = __builtin_fma(a[u], b[v], acc[u][v]);
+    };
+    size_t r = begin + threadIdx.x;
+    for (; r + GS_BLOCK < end; r += 2 * GS_BLOCK) {  // two rows' loads in flight before the first product
+        double a0[8], b0[8], a1[8], b1[8];
+        load_row(r, a0, b0);
+        load_row(r + GS_BLOCK, a1, b1);
+        fold_row(a0, b0);
+        fold_row(a1, b1);
+    }
+    if (r < end) {
+        double a0[8], b0[8];
+        load_row(r, a0, b0);
+        fold_row(a0, b0);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const double s = gs_wave_sum63(acc[u][v]);
+            if (lane == 63) lds[wave][u * 8 + v] = s;
+        }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int t = threadIdx.x;
+        partial[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 64 + t] = ((lds[0][t] + lds[1][t]) + lds[2][t]) + lds[3][t];
+    }
+}
+// G (cols x cols, both triangles) from the chunk partials: 16 groups of 64 threads each sum every 16th chunk in order, the group sums
+// are added in group order (one thread summing 256 partials one load after the other took longer than the streaming pass)
+static constexpr int GS_FGROUPS = 16;
+// The covariance form divides by the denominator and applies sanitize_covariance's diagonal rule (cov.rs:1218-1227) on the way out.
+__global__ void __launch_bounds__(64 * GS_FGROUPS) k_gram_skinny_final(const double* __restrict__ partial, int nchunks, int npairs, int cols,
+                                                                        double denom, int sanitize, double* __restrict__ g) {
+    __shared__ double lds[GS_FGROUPS][64];
+    int jb, kb;
+    gs_pair((int)blockIdx.x, &jb, &kb);
+    const int t = threadIdx.x & 63, q = threadIdx.x >> 6, j = jb * 8 + (t >> 3), k = kb * 8 + (t & 7);
+    double part = 0.0;
+    for (int cchunk = q; cchunk < nchunks; cchunk += GS_FGROUPS) part += partial[((size_t)cchunk * npairs + blockIdx.x) * 64 + t];
+    lds[q][t] = part;
+    __syncthreads();
+    if (q != 0) return;
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < GS_FGROUPS; ++w) s += lds[w][t];
+    if (j >= cols || k >= cols) return;
+    if (jb == kb && k > j) return;  // the diagonal blocks hold both triangles: keep the lower one, mirror it
+    s = s / denom;
+    if (sanitize && j == k && s == s && fabs(s) != __builtin_inf() && s < 0.0 && s > -1.0e-12) s = 0.0;
+    g[(size_t)j + (size_t)k * cols] = s;
+    g[(size_t)k + (size_t)j * cols] = s;
+}
+bool gram_skinny_applies(size_t rows, size_t cols) { return cols >= 1 && cols <= 32 && rows >= 4096 && rows >= 64 * cols; }
+int gram_skinny_device(Context* c, const double* x, size_t rows, size_t cols, const double* mu, double denom, bool sanitize, double* g) {
+    const int nb = (int)((cols + 7) / 8), npairs = nb * (nb + 1) / 2;
+    // the loop is a load -> 64 fma chain per row with nothing else in flight: three workgroups per CU (the register budget's
+    // occupancy) hide it, one per CU ran 62 us for 2^20 x 8 (67 MB)
+    size_t nchunks = (rows + (size_t)GS_BLOCK * 8 - 1) / ((size_t)GS_BLOCK * 8);  // >= 8 rows per thread
+    static const int gs_bpc = std::getenv("RMHIP_GRAM_BPC") ? std::atoi(std::getenv("RMHIP_GRAM_BPC")) : 2;  // dev knob (A/B): workgroups per CU
+    const size_t cap = (size_t)c->num_cus * (size_t)(gs_bpc > 0 ? gs_bpc : 2) / (size_t)npairs;
+    if (nchunks > cap) nchunks = cap ? cap : 1;
+    if (nchunks < 1) nchunks = 1;
+    RMHIP_TRY(c->ensure_scratch(sizeof(double) * nchunks * (size_t)npairs * 64));
+    double* partial = c->scratch;
+    hipLaunchKernelGGL(k_gram_skinny, dim3((unsigned)nchunks, (unsigned)npairs), dim3(GS_BLOCK), 0, c->stream, x, rows, (int)cols, mu, partial);
+    hipLaunchKernelGGL(k_gram_skinny_final, dim3((unsigned)npairs), dim3(64 * GS_FGROUPS), 0, c->stream, (const double*)partial, (int)nchunks, npairs, (int)cols, denom,
+                       sanitize ? 1 : 0, g);
+    c->tel.kernel_launches += 2;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
 }

@@ -1266,7 +1266,8 @@ def test_matmul_power_step_vs_oracle(prov, oracle, m, k, n):
     assert np.max(np.abs((got * got).sum(axis=0) - 1.0)) < 1e-9
 
 
-@pytest.mark.parametrize("rows,cols", [(4, 3), (1000, 7), (257, 129), (20000, 64), (1, 5), (2, 2)])
+@pytest.mark.parametrize("rows,cols", [(4, 3), (1000, 7), (257, 129), (20000, 64), (1, 5), (2, 2),
+                                       (5000, 1), (4096, 8), (100003, 17), (70001, 32), (9000, 24), (300000, 3), (40000, 33)])  # many samples of <= 32 variables: the VALU Gram kernel
 @pytest.mark.parametrize("biased", [False, True])
 def test_covariance_vs_oracle(prov, oracle, rows, cols, biased):
     x = np.random.default_rng(rows * 3 + cols).uniform(-1, 1, (rows, cols)) + np.arange(cols)
@@ -1286,6 +1287,14 @@ def test_covariance_nonfinite_and_unsupported(prov, oracle):
     got = prov.download_matrix(prov.covariance(prov.upload(x)))
     want = oracle.covariance(x)
     assert np.array_equal(np.isnan(got), np.isnan(want))  # the poisoned column's pairs are NaN, the others finite
+    y = np.random.default_rng(10).uniform(-1, 1, (30000, 11))  # the same through the tall-skinny kernel, and its syrk form
+    y[12345, 9] = np.inf
+    y[77, 3] = np.nan
+    got, want = prov.download_matrix(prov.covariance(prov.upload(y))), oracle.covariance(y)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.allclose(got[np.isfinite(want)], want[np.isfinite(want)], rtol=1e-11, atol=1e-13)
+    z = np.round(np.random.default_rng(11).uniform(-8, 8, (50001, 19)) * 4) / 4  # quarters: the Gram matrix is exact
+    g = prov.download_matrix(prov.syrk(prov.upload(z)))
+    assert np.array_equal(g, z.T @ z)
     with pytest.raises(ProviderError):
         prov.covariance(prov.upload(x), weights=prov.upload(np.ones((50, 1))))
 
