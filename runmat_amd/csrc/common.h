@@ -309,9 +309,11 @@ int image_normalize_device(Context* c, const double* x, double* y, size_t batch,
                            int has_gain, double gain, int has_bias, double bias, int clamp_zero, int has_gamma, double gamma);
 int diag_extract_device(Context* c, const double* a, size_t rows, long long offset, size_t len, double* out);
 int cov_sanitize_diag_device(Context* c, double* cm, size_t n);
-// tall-skinny Gram matrix (X - 1 mu)' (X - 1 mu) on the VALU, cols <= 32 (special.hip); mu may be null
+// tall-skinny Gram matrix (X - 1 mu)' (X - 1 mu) on the VALU, cols <= 40 (special.hip); mu may be null
 bool gram_skinny_applies(size_t rows, size_t cols);
-int gram_skinny_device(Context* c, const double* x, size_t rows, size_t cols, const double* mu, double denom, bool sanitize, double* g);
+// x2 / cols2: further columns from a second matrix of the same height (g is then (cols + cols2)^2)
+int gram_skinny_device(Context* c, const double* x, size_t rows, size_t cols, const double* mu, double denom, bool sanitize, double* g,
+                       const double* x2 = nullptr, size_t cols2 = 0);
 int launch_stochastic_evolution(Context* c, uint64_t state, const double* in, double* out, size_t n, double drift,
                                 double scale, unsigned steps, uint64_t draws_per_step);
 

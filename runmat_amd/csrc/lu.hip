@@ -2586,13 +2586,13 @@ __global__ void __launch_bounds__(256) k_diag_stats(const double* __restrict__ A
 }
 
 int diag_stats_device(Context* c, const double* A, size_t lda, size_t n, double* min_abs, double* max_abs, size_t* zeros) {
-    double* d = nullptr;
-    RMHIP_HIP_CHECK(hipMalloc((void**)&d, 3 * sizeof(double)));
+    std::shared_ptr<Allocation> mem;  // from the context's pool (a hipMalloc / hipFree pair per call cost more than the solve of a small system)
+    RMHIP_TRY(c->alloc_device(4, &mem));
+    double* d = mem->ptr;
     hipLaunchKernelGGL(k_diag_stats, dim3(1), dim3(256), 0, c->stream, A, lda, n, d);
     double h[3] = {0, 0, 0};
     hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
     c->tel.kernel_launches++;
     if (e != hipSuccess) return fail(RMHIP_ERR_HIP, "diag_stats: %s", hipGetErrorString(e));
     *min_abs = h[0];

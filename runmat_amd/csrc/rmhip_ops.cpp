@@ -1128,29 +1128,35 @@ static int lstsq_full_rank(rmhip_ctx* ctx, Context* c, const double* A, size_t m
     const bool tall = m > n;
     const size_t g = tall ? n : m;  // order of the Gram matrix
     std::shared_ptr<Allocation> gram, work, perm_mem, t1, t2, t3;
-    RMHIP_TRY(c->alloc_device(g * g, &gram));
+    // Regression shapes - many observations of a few variables: the Gram matrix of [A | b] on the VALU kernel (special.hip) holds A'A
+    // and A'b from ONE pass over both; the MFMA route ran 256-wide split-k tiles for 8-32 useful columns (2^20 x 8 \ b: 2.0 ms).
+    const bool skinny = tall && gram_skinny_applies(m, n + nrhs) && !std::getenv("RMHIP_NO_GRAM_SKINNY");
+    const size_t gl = skinny ? n + nrhs : g;  // leading dimension of the Gram buffer
+    RMHIP_TRY(c->alloc_device(gl * gl, &gram));
     // G = A'A (tall) or A A' (wide); the transposed operand is read in place
-    if (tall) RMHIP_TRY(launch_dgemm_trans(c, true, false, n, n, m, 1.0, A, m, A, m, 0.0, gram->ptr, n));
+    if (skinny) RMHIP_TRY(gram_skinny_device(c, A, m, n, nullptr, 1.0, false, gram->ptr, B, nrhs));
+    else if (tall) RMHIP_TRY(launch_dgemm_trans(c, true, false, n, n, m, 1.0, A, m, A, m, 0.0, gram->ptr, n));
     else RMHIP_TRY(launch_dgemm_trans(c, false, true, m, m, n, 1.0, A, m, A, m, 0.0, gram->ptr, m));
     const size_t ldw = lu_padded_ld(g);
     RMHIP_TRY(c->alloc_device(ldw * g, &work));
     RMHIP_TRY(c->alloc_device((g + 2) / 2 + 1, &perm_mem));
     int* perm = (int*)perm_mem->ptr;
     int info = 0;
-    RMHIP_TRY(lu_copy_and_factor(c, gram->ptr, g, g, work->ptr, ldw, perm, &info, true));
+    if (skinny) {  // the leading n x n block of the (n + nrhs)^2 Gram matrix
+        std::shared_ptr<Allocation> sq;
+        RMHIP_TRY(c->alloc_device(g * g, &sq));
+        RMHIP_HIP_CHECK(hipMemcpy2DAsync(sq->ptr, g * sizeof(double), gram->ptr, gl * sizeof(double), g * sizeof(double), g, hipMemcpyDeviceToDevice, c->stream));
+        RMHIP_TRY(lu_copy_and_factor(c, sq->ptr, g, g, work->ptr, ldw, perm, &info, true));
+    } else {
+        RMHIP_TRY(lu_copy_and_factor(c, gram->ptr, g, g, work->ptr, ldw, perm, &info, true));
+    }
     if (info > 0)
         return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: rank-deficient rectangular system (%d pivot(s) of the Gram matrix <= 1e-12): CPU SVD path", info);
     {
-        std::vector<double> diag(g);
-        RMHIP_HIP_CHECK(hipMemcpy2DAsync(diag.data(), sizeof(double), work->ptr, (ldw + 1) * sizeof(double), sizeof(double), g,
-                                         hipMemcpyDeviceToHost, c->stream));
-        RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        // (a strided device-to-host copy of the diagonal - one 8-byte row per pivot - took 15 of the 20 ms of a 1000 x 10000 solve)
         double lo = INFINITY, hi = 0.0;
-        for (double d : diag) {
-            const double v = std::fabs(d);
-            lo = v < lo ? v : lo;
-            hi = v > hi ? v : hi;
-        }
+        size_t zeros = 0;
+        RMHIP_TRY(diag_stats_device(c, work->ptr, ldw, g, &lo, &hi, &zeros));
         if (!(lo > 1e-11 * hi))
             return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: ill-conditioned rectangular system (Gram pivot ratio %.2e): CPU SVD path", hi > 0 ? lo / hi : 0.0);
     }
@@ -1166,11 +1172,18 @@ static int lstsq_full_rank(rmhip_ctx* ctx, Context* c, const double* A, size_t m
         RMHIP_TRY(c->alloc_device(m * nrhs, &t3));  // residual b - A x
         const size_t blk = 256;
         if (tall) {
-            RMHIP_TRY(launch_dgemm_trans(c, true, false, n, nrhs, m, 1.0, A, m, B, m, 0.0, t1->ptr, n));              // A'b
+            if (skinny)  // A'b = the last nrhs columns of the Gram matrix of [A | b]
+                RMHIP_HIP_CHECK(hipMemcpy2DAsync(t1->ptr, n * sizeof(double), gram->ptr + n * gl, gl * sizeof(double), n * sizeof(double), nrhs,
+                                                 hipMemcpyDeviceToDevice, c->stream));
+            else RMHIP_TRY(launch_dgemm_trans(c, true, false, n, nrhs, m, 1.0, A, m, B, m, 0.0, t1->ptr, n));         // A'b
             RMHIP_TRY(lu_solve_device(c, work->ptr, n, ldw, perm, t1->ptr, nrhs, n, X, n));                           // x0
             RMHIP_HIP_CHECK(hipMemcpyAsync(t3->ptr, B, m * nrhs * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
             RMHIP_TRY(launch_dgemm(c, m, nrhs, n, -1.0, A, m, X, n, 1.0, t3->ptr, m));                                // r = b - A x0
-            RMHIP_TRY(launch_dgemm_trans(c, true, false, n, nrhs, m, 1.0, A, m, t3->ptr, m, 0.0, t1->ptr, n));        // A'r
+            if (skinny) {  // A'r the same way
+                RMHIP_TRY(gram_skinny_device(c, A, m, n, nullptr, 1.0, false, gram->ptr, t3->ptr, nrhs));
+                RMHIP_HIP_CHECK(hipMemcpy2DAsync(t1->ptr, n * sizeof(double), gram->ptr + n * gl, gl * sizeof(double), n * sizeof(double), nrhs,
+                                                 hipMemcpyDeviceToDevice, c->stream));
+            } else RMHIP_TRY(launch_dgemm_trans(c, true, false, n, nrhs, m, 1.0, A, m, t3->ptr, m, 0.0, t1->ptr, n));  // A'r
             RMHIP_TRY(lu_solve_device(c, work->ptr, n, ldw, perm, t1->ptr, nrhs, n, t2->ptr, n));                     // dx
             RMHIP_TRY(launch_binary_same(c, RMHIP_ADD, X, t2->ptr, X, n * nrhs));
         } else {

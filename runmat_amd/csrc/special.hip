@@ -363,12 +363,12 @@ int diag_extract_device(Context* c, const double* a, size_t rows, long long offs
     return RMHIP_OK;
 }
 
-// ---- tall-skinny (centred) Gram matrix: G = (X - 1 mu)' (X - 1 mu), X rows x cols column-major, cols <= 32 ---------------------------
+// ---- tall-skinny (centred) Gram matrix: G = (X - 1 mu)' (X - 1 mu), X rows x cols column-major, cols <= 40 ---------------------------
 // `cov` of many samples of a few variables (and `syrk` of such a matrix, mu = null).  The MFMA route runs a split-k product whose
 // 256-wide tiles hold 8-32 useful columns and needs the centred copy first: 688 us for 2^20 x 8, 245 us for 2^18 x 32.  Here the
 // matrix is read in place, coalesced (consecutive threads = consecutive rows of each column), the means subtracted on the way; a
 // thread keeps the 8 x 8 products of one pair of eight-column blocks in registers (grid.y = the block pairs of the lower triangle,
-// 1 / 3 / 6 / 10 for 8 / 16 / 24 / 32 columns: the second to tenth read of a row chunk comes from L2), a workgroup folds its threads
+// 1 / 3 / 6 / 10 / 15 for 8 / 16 / 24 / 32 / 40 columns: the second to tenth read of a row chunk comes from L2), a workgroup folds its threads
 // in a fixed shuffle / LDS tree and the chunks are summed in order by a second kernel: deterministic, no atomics.  VALU fp64 - at 64
 // fused multiply-adds per 16 loaded values the pass stays bound by the reads.
 static constexpr int GS_BLOCK = 256;
@@ -396,8 +396,10 @@ __device__ __forceinline__ void gs_pair(int p, int* jb, int* kb) {
     *jb = j;
     *kb = p - j * (j + 1) / 2;
 }
-__global__ void __launch_bounds__(GS_BLOCK) k_gram_skinny(const double* __restrict__ x, size_t rows, int cols, const double* __restrict__ mu,
-                                                          double* __restrict__ partial) {
+// Columns cols1 .. cols - 1 come from a second matrix x2 of the same height (least squares: the Gram matrix of [A | b] holds A'A and
+// A'b, one pass over both).
+__global__ void __launch_bounds__(GS_BLOCK) k_gram_skinny(const double* __restrict__ x, const double* __restrict__ x2, int cols1, size_t rows, int cols,
+                                                          const double* __restrict__ mu, double* __restrict__ partial) {
     __shared__ double lds[GS_BLOCK / 64][64];
     int jb, kb;
     gs_pair((int)blockIdx.y, &jb, &kb);
@@ -425,8 +427,9 @@ __global__ void __launch_bounds__(GS_BLOCK) k_gram_skinny(const double* __restri
     const double* ck[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        cj[u] = x + (size_t)(j0 + u < cols ? j0 + u : cols - 1) * rows;
-        ck[u] = x + (size_t)(k0 + u < cols ? k0 + u : cols - 1) * rows;
+        const int jc = j0 + u < cols ? j0 + u : cols - 1, kc = k0 + u < cols ? k0 + u : cols - 1;
+        cj[u] = jc < cols1 ? x + (size_t)jc * rows : x2 + (size_t)(jc - cols1) * rows;
+        ck[u] = kc < cols1 ? x + (size_t)kc * rows : x2 + (size_t)(kc - cols1) * rows;
     }
     auto load_row = [&](size_t r, double (&a)[8], double (&b)[8]) {
         double ra[8], rb[8];
@@ -499,8 +502,11 @@ __global__ void __launch_bounds__(64 * GS_FGROUPS) k_gram_skinny_final(const dou
     g[(size_t)j + (size_t)k * cols] = s;
     g[(size_t)k + (size_t)j * cols] = s;
 }
-bool gram_skinny_applies(size_t rows, size_t cols) { return cols >= 1 && cols <= 32 && rows >= 4096 && rows >= 64 * cols; }
-int gram_skinny_device(Context* c, const double* x, size_t rows, size_t cols, const double* mu, double denom, bool sanitize, double* g) {
+bool gram_skinny_applies(size_t rows, size_t cols) { return cols >= 1 && cols <= 40 && rows >= 4096 && rows >= 64 * cols; }
+int gram_skinny_device(Context* c, const double* x, size_t rows, size_t cols, const double* mu, double denom, bool sanitize, double* g,
+                       const double* x2, size_t cols2) {
+    const size_t cols1 = cols;
+    cols += x2 ? cols2 : 0;  // g is (cols1 + cols2)^2
     const int nb = (int)((cols + 7) / 8), npairs = nb * (nb + 1) / 2;
     // the loop is a load -> 64 fma chain per row with nothing else in flight: three workgroups per CU (the register budget's
     // occupancy) hide it, one per CU ran 62 us for 2^20 x 8 (67 MB)
@@ -511,7 +517,8 @@ int gram_skinny_device(Context* c, const double* x, size_t rows, size_t cols, co
     if (nchunks < 1) nchunks = 1;
     RMHIP_TRY(c->ensure_scratch(sizeof(double) * nchunks * (size_t)npairs * 64));
     double* partial = c->scratch;
-    hipLaunchKernelGGL(k_gram_skinny, dim3((unsigned)nchunks, (unsigned)npairs), dim3(GS_BLOCK), 0, c->stream, x, rows, (int)cols, mu, partial);
+    hipLaunchKernelGGL(k_gram_skinny, dim3((unsigned)nchunks, (unsigned)npairs), dim3(GS_BLOCK), 0, c->stream, x, x2 ? x2 : x, (int)cols1, rows, (int)cols, mu,
+                       partial);
     hipLaunchKernelGGL(k_gram_skinny_final, dim3((unsigned)npairs), dim3(64 * GS_FGROUPS), 0, c->stream, (const double*)partial, (int)nchunks, npairs, (int)cols, denom,
                        sanitize ? 1 : 0, g);
     c->tel.kernel_launches += 2;

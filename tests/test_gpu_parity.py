@@ -663,7 +663,8 @@ def test_mldivide_reference_tests(prov, oracle):
     assert e.value.code == 3
 
 
-@pytest.mark.parametrize("m,n,nrhs", [(300, 40, 3), (1500, 200, 1), (4096, 128, 2), (40, 300, 2), (128, 1000, 1), (700, 690, 1)])
+@pytest.mark.parametrize("m,n,nrhs", [(300, 40, 3), (1500, 200, 1), (4096, 128, 2), (40, 300, 2), (128, 1000, 1), (700, 690, 1),
+                                      (5000, 7, 1), (100003, 17, 3), (20000, 30, 2), (4096, 1, 1), (70000, 24, 8)])  # regression shapes: the Gram matrix of [A | b] on the VALU kernel
 def test_mldivide_rectangular_full_rank_vs_svd_oracle(prov, oracle, m, n, nrhs):
     """Rectangular A\\b on the device for full-rank A (round 2): least squares (rows > cols) / minimum norm (rows < cols)
     through the Gram matrix's LU and one refinement step; the reference answers with the SVD's pseudo-inverse solve
