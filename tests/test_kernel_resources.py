@@ -79,3 +79,13 @@ def test_lu_kernels_do_not_spill():
     # the two-pass solve must fit beside an update-stream dgemm block: few registers, 66 KiB of LDS (checked at launch)
     for name, r in _pick(res, "k_trsm_lower_2p").items():
         assert r["vgpr"] + r["agpr"] <= 96, (name, r)
+
+
+def test_special_kernels_keep_their_register_budgets():
+    res = _resources("special.hip")
+    # the tall-skinny Gram kernel holds an 8 x 8 block of products and two rows of operands per thread: no spills, two workgroups per CU
+    for name, r in _pick(res, "13k_gram_skinnyE").items():
+        assert r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 256 and r["occupancy"] >= 2, (name, r)
+    # the image passes stream: the statistics and the plain apply pass without scratch (the gamma step may call the out-of-line pow)
+    for name, r in _pick(res, "k_plane_moments").items():
+        assert r["scratch"] == 0, (name, r)
