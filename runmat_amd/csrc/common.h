@@ -314,6 +314,8 @@ bool gram_skinny_applies(size_t rows, size_t cols);
 // x2 / cols2: further columns from a second matrix of the same height (g is then (cols + cols2)^2)
 int gram_skinny_device(Context* c, const double* x, size_t rows, size_t cols, const double* mu, double denom, bool sanitize, double* g,
                        const double* x2 = nullptr, size_t cols2 = 0);
+// f32 storage read in place, f64 products and sums (a precision-32 provider's covariance / syrk of such shapes)
+int gram_skinny_device_f32(Context* c, const float* x, size_t rows, size_t cols, const double* mu, double denom, bool sanitize, double* g);
 int launch_stochastic_evolution(Context* c, uint64_t state, const double* in, double* out, size_t n, double drift,
                                 double scale, unsigned steps, uint64_t draws_per_step);
 

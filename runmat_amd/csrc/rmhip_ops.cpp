@@ -886,15 +886,18 @@ int rmhip_covariance(rmhip_ctx* ctx, rmhip_buf matrix, int biased, rmhip_buf* ou
     }
     rmhip_buf means = 0, centred = 0, gram = 0;
     int rc = rmhip_reduce(ctx, RMHIP_RMEAN, matrix, 0, 0, &means);       // [1, cols]
-    if (!rc && c->precision == 64 && gram_skinny_applies(rows, cols) && !std::getenv("RMHIP_NO_GRAM_SKINNY")) {
+    if (!rc && gram_skinny_applies(rows, cols) && !std::getenv("RMHIP_NO_GRAM_SKINNY")) {
         // many samples of a few variables: centred on the way, no centred copy, no 256-wide MFMA tiles of 8-32 columns (special.hip)
-        // (the division by the denominator and the diagonal rule ride on its second kernel)
+        // (the division by the denominator and the diagonal rule ride on its second kernel).  f32 storage is read in place; the
+        // products and sums are f64 either way and the result rounds once on the way out.
         Buffer xb, mub, ob;
-        rc = c->get(matrix, &xb);
+        bool f32 = c->precision == 32;
+        rc = get_operand(c, matrix, &xb, &f32);
         if (!rc) rc = c->get(means, &mub);
         if (!rc) rc = c->new_buffer(oshape, 2, out, &ob);
         if (!rc) {
-            rc = gram_skinny_device(c, xb.data(), rows, cols, mub.data(), denom, true, ob.data());
+            rc = f32 ? gram_skinny_device_f32(c, xb.data_f32(), rows, cols, mub.data(), denom, true, ob.data())
+                     : gram_skinny_device(c, xb.data(), rows, cols, mub.data(), denom, true, ob.data());
             if (rc) rmhip_free(ctx, *out);
         }
         rmhip_free(ctx, means);

@@ -398,7 +398,8 @@ __device__ __forceinline__ void gs_pair(int p, int* jb, int* kb) {
 }
 // Columns cols1 .. cols - 1 come from a second matrix x2 of the same height (least squares: the Gram matrix of [A | b] holds A'A and
 // A'b, one pass over both).
-__global__ void __launch_bounds__(GS_BLOCK) k_gram_skinny(const double* __restrict__ x, const double* __restrict__ x2, int cols1, size_t rows, int cols,
+template <class T>
+__global__ void __launch_bounds__(GS_BLOCK) k_gram_skinny(const T* __restrict__ x, const T* __restrict__ x2, int cols1, size_t rows, int cols,
                                                           const double* __restrict__ mu, double* __restrict__ partial) {
     __shared__ double lds[GS_BLOCK / 64][64];
     int jb, kb;
@@ -423,8 +424,8 @@ __global__ void __launch_bounds__(GS_BLOCK) k_gram_skinny(const double* __restri
     if (end > rows) end = rows;
     // columns past the last one are loaded from the last one and zeroed afterwards: a load under a condition is a branch whose
     // merge point waits for the value, which serialised the sixteen loads of an iteration (2^20 x 8: 30 us of kernel for 67 MB)
-    const double* cj[8];
-    const double* ck[8];
+    const T* cj[8];
+    const T* ck[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int jc = j0 + u < cols ? j0 + u : cols - 1, kc = k0 + u < cols ? k0 + u : cols - 1;
@@ -434,10 +435,10 @@ __global__ void __launch_bounds__(GS_BLOCK) k_gram_skinny(const double* __restri
     auto load_row = [&](size_t r, double (&a)[8], double (&b)[8]) {
         double ra[8], rb[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) ra[u] = cj[u][r];
+        for (int u = 0; u < 8; ++u) ra[u] = (double)cj[u][r];
         if (!diag) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) rb[u] = ck[u][r];
+            for (int u = 0; u < 8; ++u) rb[u] = (double)ck[u][r];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) a[u] = j0 + u < cols ? ra[u] - mj[u] : 0.0;
@@ -503,13 +504,14 @@ __global__ void __launch_bounds__(64 * GS_FGROUPS) k_gram_skinny_final(const dou
     g[(size_t)k + (size_t)j * cols] = s;
 }
 bool gram_skinny_applies(size_t rows, size_t cols) { return cols >= 1 && cols <= 40 && rows >= 4096 && rows >= 64 * cols; }
-int gram_skinny_device(Context* c, const double* x, size_t rows, size_t cols, const double* mu, double denom, bool sanitize, double* g,
-                       const double* x2, size_t cols2) {
+template <class T>
+static int gram_skinny_any(Context* c, const T* x, size_t rows, size_t cols, const double* mu, double denom, bool sanitize, double* g, const T* x2,
+                           size_t cols2) {
     const size_t cols1 = cols;
     cols += x2 ? cols2 : 0;  // g is (cols1 + cols2)^2
     const int nb = (int)((cols + 7) / 8), npairs = nb * (nb + 1) / 2;
-    // the loop is a load -> 64 fma chain per row with nothing else in flight: three workgroups per CU (the register budget's
-    // occupancy) hide it, one per CU ran 62 us for 2^20 x 8 (67 MB)
+    // the loop is a load -> 64 fma chain per row with nothing else in flight: two workgroups per CU (the register budget's
+    // occupancy) with two rows' loads ahead of the products; one per CU without the unrolling ran 62 us for 2^20 x 8 (67 MB)
     size_t nchunks = (rows + (size_t)GS_BLOCK * 8 - 1) / ((size_t)GS_BLOCK * 8);  // >= 8 rows per thread
     static const int gs_bpc = std::getenv("RMHIP_GRAM_BPC") ? std::atoi(std::getenv("RMHIP_GRAM_BPC")) : 2;  // dev knob (A/B): workgroups per CU
     const size_t cap = (size_t)c->num_cus * (size_t)(gs_bpc > 0 ? gs_bpc : 2) / (size_t)npairs;
@@ -517,13 +519,20 @@ int gram_skinny_device(Context* c, const double* x, size_t rows, size_t cols, co
     if (nchunks < 1) nchunks = 1;
     RMHIP_TRY(c->ensure_scratch(sizeof(double) * nchunks * (size_t)npairs * 64));
     double* partial = c->scratch;
-    hipLaunchKernelGGL(k_gram_skinny, dim3((unsigned)nchunks, (unsigned)npairs), dim3(GS_BLOCK), 0, c->stream, x, x2 ? x2 : x, (int)cols1, rows, (int)cols, mu,
+    hipLaunchKernelGGL(k_gram_skinny<T>, dim3((unsigned)nchunks, (unsigned)npairs), dim3(GS_BLOCK), 0, c->stream, x, x2 ? x2 : x, (int)cols1, rows, (int)cols, mu,
                        partial);
     hipLaunchKernelGGL(k_gram_skinny_final, dim3((unsigned)npairs), dim3(64 * GS_FGROUPS), 0, c->stream, (const double*)partial, (int)nchunks, npairs, (int)cols, denom,
                        sanitize ? 1 : 0, g);
     c->tel.kernel_launches += 2;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
+}
+int gram_skinny_device(Context* c, const double* x, size_t rows, size_t cols, const double* mu, double denom, bool sanitize, double* g,
+                       const double* x2, size_t cols2) {
+    return gram_skinny_any(c, x, rows, cols, mu, denom, sanitize, g, x2, cols2);
+}
+int gram_skinny_device_f32(Context* c, const float* x, size_t rows, size_t cols, const double* mu, double denom, bool sanitize, double* g) {
+    return gram_skinny_any<float>(c, x, rows, cols, mu, denom, sanitize, g, nullptr, 0);
 }
 
 // sanitize_covariance (cov.rs:1218-1227): a finite diagonal entry in (-1e-12, 0) is rounding noise -> 0

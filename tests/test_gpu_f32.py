@@ -353,6 +353,9 @@ def test_f32_matmul_solve_and_friends_use_f64_kernels_on_widened_operands(prov32
     Xc = f32r(rng.standard_normal((200, 12)))
     cov32 = prov32.covariance(prov32.upload(Xc))
     assert prov32.buffer_bits(cov32) == 32 and np.allclose(prov32.download_matrix(cov32), np.cov(Xc, rowvar=False), rtol=1e-5, atol=1e-5)
+    Xt = f32r(rng.standard_normal((30000, 11)) + np.arange(11))  # many samples of a few variables: f32 storage read in place by the VALU Gram kernel
+    covt = prov32.covariance(prov32.upload(Xt))
+    assert prov32.buffer_bits(covt) == 32 and close32(prov32.download_matrix(covt), f32r(np.cov(Xt, rowvar=False)), ulps=2.0, atol=1e-7)
     xn = Xc.copy()
     xn[7, 2] = np.inf  # the poisoned column's pairs are NaN, the others finite (cov.rs:916-953), also through f32 storage
     covn = prov32.download_matrix(prov32.covariance(prov32.upload(xn)))
