@@ -1253,6 +1253,40 @@ static int mldivide_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, r
     }
     const size_t n = as[0], nrhs = bs[1];
     if (n == 0) return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: empty system");
+    {
+        // Small systems: elimination, substitution and the pivot statistics in ONE launch of one workgroup (small_solve.hip) - the blocked
+        // path below is a dozen launches and two read-backs whatever the order.  Same decisions: a pivot <= 1e-12 is SINGULAR (-> the SVD
+        // path), a pivot ratio below 1e3 n eps lets the SVD decide.  RMHIP_LU_FAST=0 (the grid-wide rule everywhere) and
+        // RMHIP_NO_SMALL_SOLVE=1 keep the blocked path.
+        const char* fe = std::getenv("RMHIP_LU_FAST");
+        if (small_solve_applies(n, nrhs) && !(fe && fe[0] == '0') && !std::getenv("RMHIP_NO_SMALL_SOLVE")) {
+            Buffer sb;
+            rmhip_buf sid = 0;
+            const size_t sshape[2] = {n, nrhs};
+            RMHIP_TRY(c->new_buffer(sshape, 2, &sid, &sb));
+            double mn = 0.0, mx = 0.0;
+            size_t bad = 0;
+            int src = small_solve_device(c, ab.data(), bb.data(), n, nrhs, sb.data(), &mn, &mx, &bad);
+            if (src) {
+                rmhip_free(ctx, sid);
+                return src;
+            }
+            if (bad > 0) {
+                rmhip_free(ctx, sid);
+                src = fail(RMHIP_ERR_SINGULAR, "mldivide: %zu pivot(s) <= 1e-12; matrix is numerically singular, use the CPU SVD path", bad);
+                return svd_fallback(ctx, c, src, ab.data(), n, n, bb.data(), nrhs, out);
+            }
+            if (!std::getenv("RMHIP_NO_SVD_PATH") && !(mn > 1.0e3 * (double)n * 2.220446049250313e-16 * mx)) {
+                rmhip_free(ctx, sid);
+                return svd_fallback(ctx, c, fail(RMHIP_ERR_SINGULAR, "mldivide: pivot ratio %.2e: numerically singular", mx > 0 ? mn / mx : 0.0), ab.data(), n, n,
+                                    bb.data(), nrhs, out);
+            }
+            c->lu_fast_count++;
+            c->lu_last_growth = 0.0;  // partial pivoting over the whole column: every multiplier is <= 1
+            *out = sid;
+            return RMHIP_OK;
+        }
+    }
     // Factorisation workspace with a PADDED leading dimension: with lda a large power of two every
     // element of a row maps to the same HBM channel / L2 slice, and the panel kernels (one lane per
     // row, walking across columns) serialise on it; +32 doubles rotates the channel per column.
@@ -1386,12 +1420,30 @@ static int linsolve_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, c
         const size_t np = lu_pad_rows(n);
         const size_t ldw = lu_padded_ld(np);
         std::shared_ptr<Allocation> work;
-        RMHIP_TRY(c->alloc_device(ldw * np, &work));
         std::shared_ptr<Allocation> perm_mem;
-        RMHIP_TRY(c->alloc_device((np + 2) / 2 + 1, &perm_mem));
-        int* perm = (int*)perm_mem->ptr;
+        int* perm = nullptr;
         int info = 0;
-        rc = lu_copy_and_factor(c, A, n, n, work->ptr, ldw, perm, &info, true, np);
+        const char* fe = std::getenv("RMHIP_LU_FAST");
+        const bool small = small_solve_applies(n, nrhs) && !(fe && fe[0] == '0') && !std::getenv("RMHIP_NO_SMALL_SOLVE");
+        if (small) {  // one launch (small_solve.hip), the same kernel and therefore the same bits as mldivide's
+            rc = c->new_buffer(oshape, 2, &oid, &ob);
+            double mn = 0.0, mx = 0.0;
+            size_t bad = 0;
+            if (!rc) rc = small_solve_device(c, A, bb.data(), n, nrhs, ob.data(), &mn, &mx, &bad);
+            if (!rc && bad > 0) {
+                rmhip_free(ctx, oid);
+                oid = 0;
+                info = (int)bad;
+            } else if (!rc) {
+                c->lu_fast_count++;
+                c->lu_last_growth = 0.0;
+            }
+        } else {
+            RMHIP_TRY(c->alloc_device(ldw * np, &work));
+            RMHIP_TRY(c->alloc_device((np + 2) / 2 + 1, &perm_mem));
+            perm = (int*)perm_mem->ptr;
+            rc = lu_copy_and_factor(c, A, n, n, work->ptr, ldw, perm, &info, true, np);
+        }
         if (!rc && info > 0) {
             rc = fail(RMHIP_ERR_SINGULAR, "linsolve: %d pivot(s) <= 1e-12; use the CPU SVD path", info);
             if (nrhs) {
@@ -1403,8 +1455,8 @@ static int linsolve_impl(rmhip_ctx* ctx, Context* c, rmhip_buf a, rmhip_buf b, c
                 return RMHIP_OK;
             }
         }
-        if (!rc) rc = c->new_buffer(oshape, 2, &oid, &ob);
-        if (!rc) rc = lu_solve_padded(c, work->ptr, n, np, ldw, perm, bb.data(), nrhs, ob.data());
+        if (!rc && !small) rc = c->new_buffer(oshape, 2, &oid, &ob);
+        if (!rc && !small) rc = lu_solve_padded(c, work->ptr, n, np, ldw, perm, bb.data(), nrhs, ob.data());
     }
     if (at) (void)hipStreamSynchronize(c->stream);  // the transposed copy is released on return
     if (rc) {

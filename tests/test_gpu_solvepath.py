@@ -304,3 +304,72 @@ def test_solve_under_real_contention(prov, built, fast):
         assert _backward_error(A, x, b) <= 1e-13  # a retried solve took another panel path: same quality, other bits
     prov.free(hu)
     prov.free(hb)
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 8, 17, 31, 33, 63, 64, 65, 100, 127, 128])
+def test_small_systems_in_one_launch(prov, oracle, n):
+    """n <= 128 with up to 16 right-hand sides: one workgroup eliminates [A | B] in LDS with partial pivoting and substitutes back
+    (small_solve.hip).  Same answer quality as the blocked path, same decisions on singular and nearly singular input."""
+    rng = np.random.default_rng(1000 + n)
+    for nrhs in (1, 3, 16):
+        A = rng.uniform(-1, 1, (n, n))
+        B = rng.uniform(-1, 1, (n, nrhs))
+        ha, hb = prov.upload(A), prov.upload(B)
+        s0 = prov.lu_stats()
+        x = prov.download_matrix(prov.mldivide(ha, hb))
+        s1 = prov.lu_stats()
+        assert s1["solve_path_factorizations"] == s0["solve_path_factorizations"] + 1 and s1["last_max_multiplier"] == 0.0
+        assert x.shape == (n, nrhs) and _backward_error(A, x, B) <= 1e-14
+        with env(RMHIP_NO_SMALL_SOLVE="1"):
+            y = prov.download_matrix(prov.mldivide(ha, hb))
+        assert np.max(np.abs(x - y)) <= 1e-9 * max(1.0, float(np.abs(y).max()))  # the same system through the blocked kernels
+        assert np.max(np.abs(x - oracle.mldivide_lu(A, B))) <= 1e-9 * max(1.0, float(np.abs(x).max()))
+    # exact arithmetic: integers, unit lower triangular times upper triangular with a permutation -> the exact solution
+    L = np.tril(rng.integers(-2, 3, (n, n)).astype(float), -1) + np.eye(n)
+    U = np.triu(rng.integers(-2, 3, (n, n)).astype(float), 1) + np.diag(rng.choice([1.0, -1.0, 2.0], n))
+    P = np.eye(n)[rng.permutation(n)]
+    A = P @ L @ U
+    xs = rng.integers(-3, 4, (n, 2)).astype(float)
+    if n <= 17:  # entries stay small integers: every step of the elimination is exact
+        x = prov.download_matrix(prov.mldivide(prov.upload(A), prov.upload(A @ xs)))
+        assert np.max(np.abs(x - xs)) <= 1e-9
+
+
+def test_small_systems_singular_nan_and_limits(prov, oracle):
+    from runmat_amd import ProviderError
+
+    rng = np.random.default_rng(77)
+    A = rng.uniform(-1, 1, (12, 12))
+    A[:, 7] = A[:, 2]  # exactly singular: the SVD path answers with the reference's minimum-norm solution
+    b = rng.uniform(-1, 1, (12, 2))
+    s0 = prov.lu_stats()["svd_solves"]
+    x = prov.download_matrix(prov.mldivide(prov.upload(A), prov.upload(b)))
+    assert prov.lu_stats()["svd_solves"] == s0 + 1
+    assert np.max(np.abs(x - oracle.mldivide_svd(A, b))) <= 1e-9 * max(1.0, float(np.abs(x).max()))
+    with env(RMHIP_NO_SVD_PATH="1"):
+        with pytest.raises(ProviderError) as e:
+            prov.mldivide(prov.upload(A), prov.upload(b))
+    assert e.value.code == 7
+    H = 1.0 / (np.arange(1, 13)[:, None] + np.arange(12)[None, :])  # Hilbert 12: cond ~ 1e16 -> the reference drops singular values
+    s0 = prov.lu_stats()["svd_solves"]
+    xh = prov.download_matrix(prov.mldivide(prov.upload(H), prov.upload(np.ones((12, 1)))))
+    assert prov.lu_stats()["svd_solves"] == s0 + 1  # no pivot below the cut-off, but a pivot ratio ~1e-16: the SVD decides
+    assert np.all(np.isfinite(xh)) and np.max(np.abs(H @ xh - 1.0)) <= 1e-6
+    N = rng.uniform(-1, 1, (20, 20))
+    N[3, 4] = np.nan
+    try:
+        xn = prov.download(prov.mldivide(prov.upload(N), prov.upload(np.ones((20, 1)))))
+        assert not np.all(np.isfinite(xn))
+    except ProviderError as err:
+        assert err.code in (2, 7)
+    # one past the limits: the blocked path, same answers
+    for n, nrhs in ((129, 1), (64, 17)):
+        A = rng.uniform(-1, 1, (n, n)) + 2 * np.eye(n)
+        B = rng.uniform(-1, 1, (n, nrhs))
+        x = prov.download_matrix(prov.mldivide(prov.upload(A), prov.upload(B)))
+        assert _backward_error(A, x, B) <= 1e-14
+    # mrdivide and linsolve reach it through the same entry
+    A = rng.uniform(-1, 1, (40, 40))
+    B = rng.uniform(-1, 1, (5, 40))
+    y = prov.download_matrix(prov.mrdivide(prov.upload(B), prov.upload(A)))
+    assert np.max(np.abs(y @ A - B)) <= 1e-12 * 40 * np.linalg.norm(A) * max(1.0, np.linalg.norm(y))
