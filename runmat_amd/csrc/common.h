@@ -346,7 +346,7 @@ int svd_max_cols();
 static constexpr int kSvdProxyMaxCols = 1024;  // up to here an LU with a tiny pivot RATIO (no pivot below the cut-off) is re-answered by the SVD
 int svd_solve_device(Context* c, const double* A, size_t m, size_t n, const double* B, size_t nrhs, double* X, int* rank_out);
 
-// small_solve.hip: x = A \ B for n <= 128, nrhs <= 16 in one launch (the augmented matrix in the LDS of one CU) + the pivot statistics
+// small_solve.hip: x = A \ B for small n (policy: <= 64), nrhs <= 16 in one launch (the augmented matrix in the LDS of one CU) + the pivot statistics
 bool small_solve_applies(size_t n, size_t nrhs);
 int small_solve_device(Context* c, const double* A, const double* B, size_t n, size_t nrhs, double* X, double* min_abs, double* max_abs, size_t* bad);
 

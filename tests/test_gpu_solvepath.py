@@ -308,8 +308,9 @@ def test_solve_under_real_contention(prov, built, fast):
 
 @pytest.mark.parametrize("n", [2, 3, 5, 8, 17, 31, 33, 63, 64, 65, 100, 127, 128])
 def test_small_systems_in_one_launch(prov, oracle, n):
-    """n <= 128 with up to 16 right-hand sides: one workgroup eliminates [A | B] in LDS with partial pivoting and substitutes back
-    (small_solve.hip).  Same answer quality as the blocked path, same decisions on singular and nearly singular input."""
+    """n <= 64 with up to 16 right-hand sides: one workgroup eliminates [A | B] in LDS with partial pivoting and substitutes back
+    (small_solve.hip; the orders above 64 in the list take the blocked kernels and must meet the same assertions).  Same answer quality
+    as the blocked path, same decisions on singular and nearly singular input."""
     rng = np.random.default_rng(1000 + n)
     for nrhs in (1, 3, 16):
         A = rng.uniform(-1, 1, (n, n))
