@@ -703,9 +703,14 @@ __global__ void __launch_bounds__(BLOCK) k_scan_lines(const double* __restrict__
 // stores and refills exactly its own cells).
 // LINES = 64, or 32 when 64 would leave CUs without a block (8192 lines: 128 blocks on 256 CUs).
 static constexpr int ST_STEPS = 64, ST_THREADS = 512;
-template <bool PROD, int LINES>
+// Few LONG lines (512 lines of 65536 steps: 16 workgroups, each a chain of 65536 - 3 ms) are cut into chunks along the line
+// (blockIdx.z): a first launch (TOT) only forms every chunk's total, k_scan_carries turns the totals of a line into the value carried
+// into each chunk, and the second launch scans every chunk from its carry - the scheme of the contiguous path below.  chunk_steps is
+// a multiple of ST_STEPS; one chunk (carries == nullptr) is the single-launch form.
+template <bool PROD, int LINES, bool TOT>
 __global__ void __launch_bounds__(ST_THREADS) k_scan_lines_staged(const double* __restrict__ x, double* __restrict__ y, u64 pre, u64 len, u64 post,
-                                                                  int reverse, int omit) {
+                                                                  int reverse, int omit, u64 chunk_steps, u64 nchunks,
+                                                                  const double* __restrict__ carries, double* __restrict__ totals) {
     __shared__ double buf[ST_STEPS][LINES];
     (void)post;
     constexpr int RP = ST_THREADS / LINES;   // rows of a tile the block touches per pass (8 or 16)
@@ -714,15 +719,17 @@ __global__ void __launch_bounds__(ST_THREADS) k_scan_lines_staged(const double* 
     const u64 i = (u64)blockIdx.x * LINES + line, j = blockIdx.y;
     const bool live = i < pre;
     const u64 base = i + pre * len * j;
-    const u64 ntiles = (len + ST_STEPS - 1) / ST_STEPS;
+    const u64 chunk = blockIdx.z, kbeg = chunk * chunk_steps;
+    const u64 kend = kbeg + chunk_steps < len ? kbeg + chunk_steps : len;
+    const u64 ntiles = (kend - kbeg + ST_STEPS - 1) / ST_STEPS;
     const double ident = PROD ? 1.0 : 0.0;
     double regs[ROWS], regs2[ROWS];  // tiles t + 1 and t + 2 in flight (few blocks run this kernel: a tile takes its full memory latency)
     auto at = [&](u64 k) { return base + pre * (reverse ? len - 1 - k : k); };
     auto gload = [&](u64 t, double (&r)[ROWS]) {
 #pragma unroll
         for (int u = 0; u < ROWS; ++u) {
-            const u64 k = t * ST_STEPS + (u64)(u * RP + row0);
-            r[u] = (live && k < len) ? __builtin_nontemporal_load(x + at(k)) : ident;
+            const u64 k = kbeg + t * ST_STEPS + (u64)(u * RP + row0);
+            r[u] = (live && k < kend) ? __builtin_nontemporal_load(x + at(k)) : ident;
         }
     };
     gload(0, regs);
@@ -730,7 +737,7 @@ __global__ void __launch_bounds__(ST_THREADS) k_scan_lines_staged(const double* 
     for (int u = 0; u < ROWS; ++u) buf[u * RP + row0][line] = regs[u];
     if (ntiles > 1) gload(1, regs);
     __syncthreads();
-    double run = ident;
+    double run = (carries && live && threadIdx.x < LINES) ? carries[(i + pre * j) * nchunks + chunk] : ident;
     for (u64 t = 0; t < ntiles; ++t) {
         if (t + 2 < ntiles) gload(t + 2, regs2);  // in flight while the first LINES threads scan this tile and the next
         if (threadIdx.x < LINES) {
@@ -748,13 +755,14 @@ __global__ void __launch_bounds__(ST_THREADS) k_scan_lines_staged(const double* 
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < ROWS; ++u) {
-            const u64 k = t * ST_STEPS + (u64)(u * RP + row0);
-            if (live && k < len) __builtin_nontemporal_store(buf[u * RP + row0][line], y + at(k));
+            const u64 k = kbeg + t * ST_STEPS + (u64)(u * RP + row0);
+            if (!TOT && live && k < kend) __builtin_nontemporal_store(buf[u * RP + row0][line], y + at(k));
             buf[u * RP + row0][line] = regs[u];  // tile t + 1 (garbage after the last one: nobody reads it)
             regs[u] = regs2[u];
         }
         __syncthreads();
     }
+    if (TOT && live && threadIdx.x < LINES) totals[(i + pre * j) * nchunks + chunk] = run;
 }
 
 // pre == 1, SHORT contiguous lines (len < 256: cumsum(x,1) of a 32 x N matrix): one thread per line would read with a stride of one
@@ -939,12 +947,41 @@ int launch_cumulative(Context* c, int prod, int reverse, int omit, const double*
     if (pre > 1) {  // lines along a strided dimension: every line is the CPU's own chain
         if (pre >= 8 && len >= 256 && lines < (size_t)c->num_cus * 256 && post <= 65535) {  // few long lines: staged tiles
             const bool half = pre < 64 || ceil_div_u64(pre, 64) * post < (u64)c->num_cus;   // 64 lines per block would leave CUs (or lanes) idle
-            const dim3 sgrid((unsigned)ceil_div_u64(pre, half ? 32 : 64), (unsigned)post);
-#define RMHIP_STAGED(P, L) hipLaunchKernelGGL((k_scan_lines_staged<P, L>), sgrid, dim3(ST_THREADS), 0, c->stream, x, y, (u64)pre, (u64)len, (u64)post, reverse, omit)
-            if (prod && half) RMHIP_STAGED(true, 32);
-            else if (prod) RMHIP_STAGED(true, 64);
-            else if (half) RMHIP_STAGED(false, 32);
-            else RMHIP_STAGED(false, 64);
+            const u64 line_blocks = ceil_div_u64(pre, half ? 32 : 64) * post;
+            u64 nchunks = 1, chunk_steps = ceil_div_u64(len, ST_STEPS) * ST_STEPS;
+            if (line_blocks * 4 <= (u64)c->num_cus && len >= 4096) {  // a quarter of the CUs or fewer would run chains of len steps: chunks along the line
+                u64 want = ceil_div_u64((u64)c->num_cus * 4, line_blocks), most = len / 1024;  // chunks of >= 1024 steps
+                if (want > most) want = most;
+                if (want > 65535) want = 65535;
+                if (want > 1) {
+                    chunk_steps = ceil_div_u64(ceil_div_u64(len, want), ST_STEPS) * ST_STEPS;
+                    nchunks = ceil_div_u64(len, chunk_steps);
+                }
+            }
+            double* totals = nullptr;
+            if (nchunks > 1) {
+                RMHIP_TRY(c->ensure_scratch(sizeof(double) * lines * nchunks));
+                totals = c->scratch;
+            }
+            const dim3 sgrid((unsigned)ceil_div_u64(pre, half ? 32 : 64), (unsigned)post, (unsigned)nchunks);
+#define RMHIP_STAGED(P, L, T, CAR, TOTP)                                                                                                       \
+    hipLaunchKernelGGL((k_scan_lines_staged<P, L, T>), sgrid, dim3(ST_THREADS), 0, c->stream, x, y, (u64)pre, (u64)len, (u64)post, reverse, omit, \
+                       chunk_steps, nchunks, (const double*)(CAR), (double*)(TOTP))
+#define RMHIP_STAGED_PL(T, CAR, TOTP)                    \
+    do {                                                 \
+        if (prod && half) RMHIP_STAGED(true, 32, T, CAR, TOTP);   \
+        else if (prod) RMHIP_STAGED(true, 64, T, CAR, TOTP);      \
+        else if (half) RMHIP_STAGED(false, 32, T, CAR, TOTP);     \
+        else RMHIP_STAGED(false, 64, T, CAR, TOTP);               \
+    } while (0)
+            if (nchunks > 1) {
+                RMHIP_STAGED_PL(true, nullptr, totals);
+                if (prod) hipLaunchKernelGGL(k_scan_carries<true>, dim3((unsigned)lines), dim3(R2_BLOCK), 0, c->stream, totals, nchunks, (u64)lines);
+                else hipLaunchKernelGGL(k_scan_carries<false>, dim3((unsigned)lines), dim3(R2_BLOCK), 0, c->stream, totals, nchunks, (u64)lines);
+                c->tel.kernel_launches += 2;
+            }
+            RMHIP_STAGED_PL(false, totals, nullptr);
+#undef RMHIP_STAGED_PL
 #undef RMHIP_STAGED
         } else if (lines >= (size_t)c->num_cus * 1024) {  // plenty of lines: four waves per block, eight loads deep
             const unsigned grid = (unsigned)ceil_div_u64(lines, 256);

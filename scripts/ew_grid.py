@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from runmat_amd import HipProvider
-prov = HipProvider(0)
+prov = HipProvider(0, precision="F32") if os.environ.get("GRID_F32") == "1" else HipProvider(0)  # GRID_F32=1: precision-32 provider (byte counts printed are still those of f64)
 dims = [32, 512, 8192, 524288]
 for rows in dims:
     for cols in dims:

@@ -3,7 +3,7 @@ sum / min-with-indices / std / cumsum along both dimensions - us and GB/s, to sp
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from runmat_amd import HipProvider
-prov = HipProvider(0)
+prov = HipProvider(0, precision="F32") if os.environ.get("GRID_F32") == "1" else HipProvider(0)  # GRID_F32=1: precision-32 provider (byte counts printed are still those of f64)
 dims = [32, 512, 2048, 8192, 65536, 524288]
 def free(r):
     for h in ((r.values, r.indices) if hasattr(r, "values") else (r,)):

@@ -180,6 +180,32 @@ def test_strided_scan_is_the_cpu_sequence_bit_for_bit(prov, oracle, shape, dim):
                 assert np.array_equal(gn, oracle.cumulative(xn, dim, prod=prod, reverse=reverse, omitnan=omit), equal_nan=True)
 
 
+@pytest.mark.parametrize("shape,dim", [((40, 9001), 1), ((300, 20000), 1), ((17, 9001, 3), 1), ((64, 4096), 1), ((9, 70000), 1), ((2000, 8192), 1)])
+def test_few_long_strided_lines_are_scanned_in_chunks(prov, oracle, shape, dim):
+    """A handful of workgroups would each run chains of `len` steps: the line is cut into chunks (totals, carries, scan from the carry -
+    reduce2.hip k_scan_lines_staged).  The grouping differs from the CPU's one chain, so: exact on quarters (no rounding anywhere), to
+    rounding on general data, NaN policies and directions as ever."""
+    rng = np.random.default_rng(5 + sum(shape))
+    q = np.round(rng.uniform(-8, 8, shape) * 4) / 4
+    x = rng.uniform(-1, 1, shape)
+    xn = q.copy()
+    xn.ravel()[rng.integers(0, q.size, max(1, q.size // 4001))] = np.nan
+    hq, hx, hn = prov.upload(q), prov.upload(x), prov.upload(xn)
+    n = shape[dim]
+    for reverse in (False, True):
+        got = prov.download(prov.cumsum_scan(hq, dim, reverse=reverse)).reshape(shape, order="F")
+        assert np.array_equal(got, oracle.cumulative(q, dim, reverse=reverse)), (shape, reverse, "quarters")
+        got = prov.download(prov.cumsum_scan(hx, dim, reverse=reverse)).reshape(shape, order="F")
+        want = oracle.cumulative(x, dim, reverse=reverse)
+        assert np.max(np.abs(got - want)) <= 4 * n * 2.3e-16 * max(1.0, float(np.abs(want).max())), (shape, reverse, "uniform")
+        for omit in (False, True):
+            gn = prov.download(prov.cumsum_scan(hn, dim, reverse=reverse, omitnan=omit)).reshape(shape, order="F")
+            assert np.array_equal(gn, oracle.cumulative(xn, dim, reverse=reverse, omitnan=omit), equal_nan=True), (shape, reverse, omit)
+    s = np.where(rng.random(shape) < 0.5, 1.0, -1.0)
+    got = prov.download(prov.cumprod_scan(prov.upload(s), dim)).reshape(shape, order="F")
+    assert np.array_equal(got, oracle.cumulative(s, dim, prod=True)), (shape, "cumprod of signs")
+
+
 def test_reductions_random_shapes_fuzz(prov, oracle):
     """60 random 2-D shapes around the kernels' switching points (512 / 2048 extents, odd and even, few and many lines) through sum,
     min / max with indices (against the oracle: the rounding produces -0.0, which the CPU builtins order below +0), nnz, std and
