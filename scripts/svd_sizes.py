@@ -18,7 +18,7 @@ for n in [int(a) for a in sys.argv[1:]] or [512, 1024, 1536, 2048]:
     dt = time.perf_counter() - t0
     x = prov.download(hx).reshape((n, 2), order="F")
     res = np.linalg.norm(A @ x - b) / np.linalg.norm(b)
-    line = f"n={n:5d} rank={r:5d}  {dt*1e3:9.1f} ms  residual {res:.2e}  svd_solves {prov.telemetry_snapshot().get('svd_solves')}"
+    line = f"n={n:5d} rank={r:5d}  {dt*1e3:9.1f} ms  residual {res:.2e}  svd_solves {prov.lu_stats()['svd_solves']}"
     if n <= 2048:
         want = np.linalg.lstsq(A, b, rcond=None)[0]
         line += f"  |x - lstsq| / |lstsq| {np.linalg.norm(x - want) / np.linalg.norm(want):.2e}"
