@@ -485,7 +485,7 @@ static int binary_bcast_dispatch(Context* c, int op, const T* a, const T* b, T* 
             p.sb[i] = i < d.rank ? d.stride_b[i] : 0;
             if (i >= 1 && i < d.rank) outer *= d.out_shape[i];
         }
-        if (p.d0 < 128 && outer >= 64 && n < 0xffffffffULL) {  // short dim 0, many outer indices: flat threads
+        if (p.d0 < 128 && outer >= 64 && n < 0x80000000ULL) {  // short dim 0, many outer indices: flat threads (32-bit index + stride cannot wrap below 2^31)
             const unsigned long long want = (n + kBlock - 1) / kBlock, cap = (unsigned long long)c->num_cus * 16;
             hipLaunchKernelGGL((k_bcast2_flat<T, BinaryF<OP>>), dim3((unsigned)(want < cap ? want : cap)), dim3(kBlock), 0, c->stream, a, b, out, p,
                                (unsigned)n, BinaryF<OP>());

@@ -297,7 +297,7 @@ int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf*
         for (size_t k = 0; k < n_in; ++k)
             for (size_t d = 0; d < crank; ++d) p[11 + 8 * k + d] = strides[k][d];
         args.push_back(p.data());
-        if (d0 < 128 && outer >= 64 && len < 0xffffffffULL) {  // short dim 0, many outer indices: flat threads
+        if (d0 < 128 && outer >= 64 && len < 0x80000000ULL) {  // short dim 0, many outer indices: flat threads (32-bit index + stride cannot wrap below 2^31)
             unsigned n32 = (unsigned)len;
             args.push_back(&n32);
             const unsigned long long want = (len + 255) / 256, cap = (unsigned long long)c->num_cus * 16;
