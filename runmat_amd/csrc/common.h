@@ -264,6 +264,9 @@ int launch_reduce_dot_f32(Context* c, const float* a, const float* b, size_t pre
 // reduce2.hip: arg-min / arg-max with indices, std, truth counts, cumulative scans over the [pre, red, post] view
 int launch_argreduce(Context* c, int op, int nan_mode, const double* x, size_t pre, size_t red, size_t post, double* values, double* indices);
 int launch_reduce_std(Context* c, int population, int nan_mode, const double* x, size_t pre, size_t red, size_t post, double* out);
+int launch_reduce_std_f32(Context* c, int population, int nan_mode, const float* x, size_t pre, size_t red, size_t post, double* out);
+int launch_argreduce_f32(Context* c, int op, int nan_mode, const float* x, size_t pre, size_t red, size_t post, double* values, double* indices);
+int launch_reduce_truth_f32(Context* c, int op, int omit_nan, const float* x, size_t pre, size_t red, size_t post, double* out);
 int launch_reduce_moments(Context* c, const double* x, size_t pre, size_t red, size_t post, double* mean, double* ex2);
 int launch_plane_stats(Context* c, const double* x, size_t batch, size_t plane, double eps, double* stats);  // image_normalize, batch > 256
 int launch_reduce_truth(Context* c, int op, int omit_nan, const double* x, size_t pre, size_t red, size_t post, double* out);

@@ -192,8 +192,8 @@ __device__ __forceinline__ void r2_fold8<SqAcc>(SqAcc& a, const u64 (&)[8], cons
 static constexpr int R2_BLOCK = 256;
 
 // pre == 1: slice s is `red` contiguous elements.  grid (nsplit, slices in y, z)
-template <class Acc>
-__global__ void __launch_bounds__(R2_BLOCK) k_r2_contig(const double* __restrict__ x, u64 red, u64 nslices, u64 nsplit, Acc* __restrict__ part) {
+template <class Acc, class T = double>
+__global__ void __launch_bounds__(R2_BLOCK) k_r2_contig(const T* __restrict__ x, u64 red, u64 nslices, u64 nsplit, Acc* __restrict__ part) {
     __shared__ Acc lds[R2_BLOCK];
     const u64 slice = blockIdx.y + (u64)gridDim.y * blockIdx.z;
     if (slice >= nslices) return;
@@ -203,20 +203,20 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_contig(const double* __restrict
     const u64 begin = split * chunk;
     u64 end = begin + chunk;
     if (end > red) end = red;
-    const double* xs = x + slice * red;
+    const T* xs = x + slice * red;
     Acc a;
     a.init();
     u64 r = begin + threadIdx.x;
     for (; r + 7 * R2_BLOCK < end; r += 8 * R2_BLOCK) {  // eight loads in flight; folded in index order
         double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(xs + r + u * R2_BLOCK);
+        for (int u = 0; u < 8; ++u) v[u] = (double)__builtin_nontemporal_load(xs + r + u * R2_BLOCK);
         u64 k[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) k[u] = r + u * R2_BLOCK;
         r2_fold8(a, k, v);
     }
-    for (; r < end; r += R2_BLOCK) a.add(r, __builtin_nontemporal_load(xs + r));
+    for (; r < end; r += R2_BLOCK) a.add(r, (double)__builtin_nontemporal_load(xs + r));
     lds[threadIdx.x] = a;
     __syncthreads();
     for (int s = R2_BLOCK / 2; s > 0; s >>= 1) {  // fixed tree
@@ -235,15 +235,32 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_contig(const double* __restrict
 // otherwise have nothing in flight.  A thread's elements still arrive in ascending index order.
 // ODD: odd `red` or an element-aligned base - the pairs are loaded from 8-byte aligned addresses and the slice's last element is folded
 // by the thread whose walk ends at its pair index (still ascending within the thread).
+// T = storage type: float on a precision-32 provider (widened in registers: exact and order preserving), a pair is then 8 bytes.
 typedef double r2_d2 __attribute__((ext_vector_type(2)));
-typedef r2_d2 r2_d2u __attribute__((aligned(8)));
-template <bool ODD>
-__device__ __forceinline__ r2_d2 r2_ld2(const r2_d2* p) {
-    if constexpr (ODD) return (r2_d2)__builtin_nontemporal_load(reinterpret_cast<const r2_d2u*>(p));
-    else return __builtin_nontemporal_load(p);
+template <class T>
+struct R2Pair;
+template <>
+struct R2Pair<double> {
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    typedef v2 v2u __attribute__((aligned(8)));
+};
+template <>
+struct R2Pair<float> {
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    typedef v2 v2u __attribute__((aligned(4)));
+};
+// the pair that starts at element pointer p
+template <class T, bool ODD>
+__device__ __forceinline__ r2_d2 r2_ld2(const T* p) {
+    typedef typename R2Pair<T>::v2 V;
+    typedef typename R2Pair<T>::v2u VU;
+    V v;
+    if constexpr (ODD) v = (V)__builtin_nontemporal_load(reinterpret_cast<const VU*>(p));
+    else v = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+    return r2_d2{(double)v.x, (double)v.y};
 }
-template <class Acc, bool ODD = false>
-__global__ void __launch_bounds__(R2_BLOCK) k_r2_contig_v2(const double* __restrict__ x, u64 red, u64 nslices, u64 nsplit, Acc* __restrict__ part) {
+template <class Acc, bool ODD = false, class T = double>
+__global__ void __launch_bounds__(R2_BLOCK) k_r2_contig_v2(const T* __restrict__ x, u64 red, u64 nslices, u64 nsplit, Acc* __restrict__ part) {
     __shared__ Acc lds[R2_BLOCK];
     const u64 slice = blockIdx.y + (u64)gridDim.y * blockIdx.z;
     if (slice >= nslices) return;
@@ -253,7 +270,7 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_contig_v2(const double* __restr
     const u64 begin = split * chunk;
     u64 end = begin + chunk;
     if (end > red2) end = red2;
-    const r2_d2* xs = reinterpret_cast<const r2_d2*>(x + slice * red);
+    const T* xs = x + slice * red;  // pair q starts at element 2 q
     Acc a;
     a.init();
     u64 r = begin + threadIdx.x;
@@ -261,10 +278,10 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_contig_v2(const double* __restr
     if (r + (U - 1) * R2_BLOCK < end) {
         r2_d2 cur[U], nxt[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = r2_ld2<ODD>(xs + r + u * R2_BLOCK);
+        for (int u = 0; u < U; ++u) cur[u] = r2_ld2<T, ODD>(xs + 2 * (r + u * R2_BLOCK));
         for (; r + (2 * U - 1) * R2_BLOCK < end; r += U * R2_BLOCK) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) nxt[u] = r2_ld2<ODD>(xs + r + (U + u) * R2_BLOCK);
+            for (int u = 0; u < U; ++u) nxt[u] = r2_ld2<T, ODD>(xs + 2 * (r + (U + u) * R2_BLOCK));
             {
                 u64 k[8];
                 double w[8];
@@ -295,13 +312,13 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_contig_v2(const double* __restr
         r += U * R2_BLOCK;
     }
     for (; r < end; r += R2_BLOCK) {
-        const r2_d2 v = r2_ld2<ODD>(xs + r);
+        const r2_d2 v = r2_ld2<T, ODD>(xs + 2 * r);
         a.add(2 * r, v.x);
         a.add(2 * r + 1, v.y);
     }
     if constexpr (ODD) {  // the leftover element of an odd slice: owned by the chunk that contains pair index red2
         const u64 owner = red2 / chunk < nsplit - 1 ? red2 / chunk : nsplit - 1;
-        if ((red & 1) && split == owner && r == red2) a.add(red - 1, __builtin_nontemporal_load(x + slice * red + red - 1));
+        if ((red & 1) && split == owner && r == red2) a.add(red - 1, (double)__builtin_nontemporal_load(x + slice * red + red - 1));
     }
     lds[threadIdx.x] = a;
     __syncthreads();
@@ -321,14 +338,14 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_contig_v2(const double* __restr
 // 32 x 524288 matrix
 static constexpr int R2_SHORT_TILE = 4096;
 __device__ __forceinline__ int r2_short_pad(int i) { return i + (i >> 5); }
-template <class Acc>
-__global__ void __launch_bounds__(R2_BLOCK) k_r2_short(const double* __restrict__ x, u64 red, u64 nslices, unsigned per_block, Acc* __restrict__ part) {
+template <class Acc, class T = double>
+__global__ void __launch_bounds__(R2_BLOCK) k_r2_short(const T* __restrict__ x, u64 red, u64 nslices, unsigned per_block, Acc* __restrict__ part) {
     __shared__ double tile[R2_SHORT_TILE + R2_SHORT_TILE / 32 + 1];
     const u64 s0 = (u64)blockIdx.x * per_block;
     const u64 ns = nslices - s0 < per_block ? nslices - s0 : per_block;
     const u64 count = ns * red;
-    const double* src = x + s0 * red;
-    for (u64 i = threadIdx.x; i < count; i += R2_BLOCK) tile[r2_short_pad((int)i)] = __builtin_nontemporal_load(src + i);
+    const T* src = x + s0 * red;
+    for (u64 i = threadIdx.x; i < count; i += R2_BLOCK) tile[r2_short_pad((int)i)] = (double)__builtin_nontemporal_load(src + i);
     __syncthreads();
     if (threadIdx.x >= ns) return;
     Acc a;
@@ -339,8 +356,8 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_short(const double* __restrict_
 }
 
 // pre > 1: threads run along `pre` (coalesced), each walks its chunk of `red` in ascending order.  grid (ceil(pre / 256), nsplit, post)
-template <class Acc>
-__global__ void __launch_bounds__(R2_BLOCK) k_r2_strided(const double* __restrict__ x, u64 pre, u64 red, u64 nsplit, Acc* __restrict__ part) {
+template <class Acc, class T = double>
+__global__ void __launch_bounds__(R2_BLOCK) k_r2_strided(const T* __restrict__ x, u64 pre, u64 red, u64 nsplit, Acc* __restrict__ part) {
     const u64 i = (u64)blockIdx.x * R2_BLOCK + threadIdx.x;
     if (i >= pre) return;
     const u64 split = blockIdx.y, j = blockIdx.z;
@@ -348,14 +365,14 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_strided(const double* __restric
     const u64 begin = split * chunk;
     u64 end = begin + chunk;
     if (end > red) end = red;
-    const double* xs = x + i + pre * red * j;
+    const T* xs = x + i + pre * red * j;
     Acc a;
     a.init();
     u64 r = begin;
     for (; r + 8 <= end; r += 8) {
         double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(xs + pre * (r + u));
+        for (int u = 0; u < 8; ++u) v[u] = (double)__builtin_nontemporal_load(xs + pre * (r + u));
         u64 k[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) k[u] = r + u;
@@ -365,7 +382,7 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_strided(const double* __restric
         double v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (r + u < end) v[u] = __builtin_nontemporal_load(xs + pre * (r + u));
+            if (r + u < end) v[u] = (double)__builtin_nontemporal_load(xs + pre * (r + u));
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (r + u < end) a.add(r + u, v[u]);
@@ -376,8 +393,8 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_strided(const double* __restric
 // the same with 16-byte loads: a thread owns two adjacent lines (even `pre`, 16-byte aligned base).  As for sum(x,2)
 // (reduce_kernels.hip) what decides the rate of these lock-step column walks is the number of blocks: three per CU.
 // ODD: odd `pre` (or an element-aligned base): unaligned pairs, the last line alone in its pair.
-template <class Acc, bool ODD = false>
-__global__ void __launch_bounds__(R2_BLOCK) k_r2_strided_v2(const double* __restrict__ x, u64 pre, u64 red, u64 nsplit, unsigned win,
+template <class Acc, bool ODD = false, class T = double>
+__global__ void __launch_bounds__(R2_BLOCK) k_r2_strided_v2(const T* __restrict__ x, u64 pre, u64 red, u64 nsplit, unsigned win,
                                                             Acc* __restrict__ part) {
     const u64 i2 = (u64)blockIdx.x * win + threadIdx.x, pre2 = ODD ? (pre + 1) >> 1 : pre >> 1;  // balanced windows, their number a multiple of the XCD count (run_r2)
     if (threadIdx.x >= win || i2 >= pre2) return;
@@ -387,11 +404,11 @@ __global__ void __launch_bounds__(R2_BLOCK) k_r2_strided_v2(const double* __rest
     const u64 begin = split * chunk;
     u64 end = begin + chunk;
     if (end > red) end = red;
-    const double* const xo = x + 2 * i2 + pre * red * j;  // element offsets: with an odd `pre` the lines alternate between 16- and 8-byte alignment
+    const T* const xo = x + 2 * i2 + pre * red * j;  // element offsets: with an odd `pre` the lines alternate between 16- and 8-byte alignment
     auto ldp = [&](u64 rr) -> r2_d2 {
-        const double* q = xo + pre * rr;
-        if (ODD && single) return r2_d2{__builtin_nontemporal_load(q), 0.0};
-        return r2_ld2<ODD>(reinterpret_cast<const r2_d2*>(q));
+        const T* q = xo + pre * rr;
+        if (ODD && single) return r2_d2{(double)__builtin_nontemporal_load(q), 0.0};
+        return r2_ld2<T, ODD>(q);
     };
     Acc a0, a1;
     a0.init();
@@ -533,19 +550,19 @@ struct TruthFin {
     }
 };
 
-template <class Acc, class Fin>
-static int run_r2(Context* c, const double* x, size_t pre, size_t red, size_t post, const Fin& fin, const char* what) {
+template <class Acc, class Fin, class T = double>
+static int run_r2(Context* c, const T* x, size_t pre, size_t red, size_t post, const Fin& fin, const char* what) {
     if (pre == 0 || post == 0 || red == 0) return RMHIP_OK;
-    ReducePlan p = plan_reduction(pre, red, post, c->num_cus, 8);
+    ReducePlan p = plan_reduction(pre, red, post, c->num_cus, (unsigned)sizeof(T));
     if (!p.valid) return fail(RMHIP_ERR_UNSUPPORTED, "%s: geometry [%zu,%zu,%zu] exceeds launch limits", what, pre, red, post);
     u64 nsplit = p.nsplit;
     unsigned gx = p.gx;
     const bool wide = !p.contiguous && pre >= 512;
-    const bool wide_odd = wide && ((pre & 1) != 0 || (((uintptr_t)x) & 15) != 0);
+    const bool wide_odd = wide && ((pre & 1) != 0 || (((uintptr_t)x) & (2 * sizeof(T) - 1)) != 0);  // a pair of T
     unsigned win = R2_BLOCK, threads = R2_BLOCK;
     if (!p.contiguous) {  // these kernels keep up to 256 threads along `pre`
         if (wide) {  // as for sum(x,2): a window count that is a multiple of the XCD count pins every window to one XCD (reduce_plan.h)
-            const StridedWidePlan w = plan_strided_wide(pre, red, post, c->num_cus, c->num_xcc, 8u);
+            const StridedWidePlan w = plan_strided_wide(pre, red, post, c->num_cus, c->num_xcc, (unsigned)sizeof(T));
             gx = w.bx;
             win = w.win;
             threads = w.threads;
@@ -555,7 +572,7 @@ static int run_r2(Context* c, const double* x, size_t pre, size_t red, size_t po
             u64 want = ceil_div_u64((u64)c->num_cus * 8, (u64)gx * post);
             u64 max_split = ceil_div_u64(red, 16);
             nsplit = want < 1 ? 1 : (want > max_split ? max_split : want);
-            nsplit = dealias_nsplit(red, nsplit, pre * 8, max_split);
+            nsplit = dealias_nsplit(red, nsplit, pre * sizeof(T), max_split);
             if (nsplit > 65535) nsplit = 65535;
         }
     }
@@ -567,20 +584,20 @@ static int run_r2(Context* c, const double* x, size_t pre, size_t red, size_t po
     if (short_a) {
         unsigned per_block = (unsigned)(R2_SHORT_TILE / red);
         if (per_block > R2_BLOCK) per_block = R2_BLOCK;
-        hipLaunchKernelGGL((k_r2_short<Acc>), dim3((unsigned)ceil_div_u64(p.nslices, per_block)), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices,
+        hipLaunchKernelGGL((k_r2_short<Acc, T>), dim3((unsigned)ceil_div_u64(p.nslices, per_block)), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices,
                            per_block, part);
-    } else if (p.contiguous && (red & 1) == 0 && red >= 4 * R2_BLOCK && (((uintptr_t)x) & 15) == 0)
-        hipLaunchKernelGGL((k_r2_contig_v2<Acc>), dim3((unsigned)nsplit, p.gy, p.gz), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices, nsplit, part);
+    } else if (p.contiguous && (red & 1) == 0 && red >= 4 * R2_BLOCK && (((uintptr_t)x) & (2 * sizeof(T) - 1)) == 0)
+        hipLaunchKernelGGL((k_r2_contig_v2<Acc, false, T>), dim3((unsigned)nsplit, p.gy, p.gz), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices, nsplit, part);
     else if (p.contiguous && red >= 4 * R2_BLOCK)  // odd slice length or element-aligned base
-        hipLaunchKernelGGL((k_r2_contig_v2<Acc, true>), dim3((unsigned)nsplit, p.gy, p.gz), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices, nsplit, part);
+        hipLaunchKernelGGL((k_r2_contig_v2<Acc, true, T>), dim3((unsigned)nsplit, p.gy, p.gz), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices, nsplit, part);
     else if (p.contiguous)
-        hipLaunchKernelGGL((k_r2_contig<Acc>), dim3((unsigned)nsplit, p.gy, p.gz), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices, nsplit, part);
+        hipLaunchKernelGGL((k_r2_contig<Acc, T>), dim3((unsigned)nsplit, p.gy, p.gz), dim3(R2_BLOCK), 0, c->stream, x, (u64)red, (u64)p.nslices, nsplit, part);
     else if (wide_odd)
-        hipLaunchKernelGGL((k_r2_strided_v2<Acc, true>), dim3(gx, (unsigned)nsplit, (unsigned)post), dim3(threads), 0, c->stream, x, (u64)pre, (u64)red, nsplit, win, part);
+        hipLaunchKernelGGL((k_r2_strided_v2<Acc, true, T>), dim3(gx, (unsigned)nsplit, (unsigned)post), dim3(threads), 0, c->stream, x, (u64)pre, (u64)red, nsplit, win, part);
     else if (wide)
-        hipLaunchKernelGGL((k_r2_strided_v2<Acc>), dim3(gx, (unsigned)nsplit, (unsigned)post), dim3(threads), 0, c->stream, x, (u64)pre, (u64)red, nsplit, win, part);
+        hipLaunchKernelGGL((k_r2_strided_v2<Acc, false, T>), dim3(gx, (unsigned)nsplit, (unsigned)post), dim3(threads), 0, c->stream, x, (u64)pre, (u64)red, nsplit, win, part);
     else
-        hipLaunchKernelGGL((k_r2_strided<Acc>), dim3(gx, (unsigned)nsplit, (unsigned)post), dim3(R2_BLOCK), 0, c->stream, x, (u64)pre, (u64)red, nsplit, part);
+        hipLaunchKernelGGL((k_r2_strided<Acc, T>), dim3(gx, (unsigned)nsplit, (unsigned)post), dim3(R2_BLOCK), 0, c->stream, x, (u64)pre, (u64)red, nsplit, part);
     RMHIP_HIP_CHECK(hipGetLastError());
     // many slices with a handful of partials each: one thread per slice (a wave per slice would idle 50 of its lanes; 65536 slices
     // x 14 partials took 37 us that way)
@@ -595,20 +612,32 @@ static int run_r2(Context* c, const double* x, size_t pre, size_t red, size_t po
     return RMHIP_OK;
 }
 
-int launch_argreduce(Context* c, int op, int nan_mode, const double* x, size_t pre, size_t red, size_t post, double* values, double* indices) {
+template <class T>
+static int argreduce_any(Context* c, int op, int nan_mode, const T* x, size_t pre, size_t red, size_t post, double* values, double* indices) {
     const bool mx = op == RMHIP_RMAX;
     if (mx) {
         ArgFin<true> fin{values, indices};
-        return nan_mode ? run_r2<ArgAcc<true, true>>(c, x, pre, red, post, fin, "reduce_max_dim")
-                        : run_r2<ArgAcc<true, false>>(c, x, pre, red, post, fin, "reduce_max_dim");
+        return nan_mode ? run_r2<ArgAcc<true, true>, ArgFin<true>, T>(c, x, pre, red, post, fin, "reduce_max_dim")
+                        : run_r2<ArgAcc<true, false>, ArgFin<true>, T>(c, x, pre, red, post, fin, "reduce_max_dim");
     }
     ArgFin<false> fin{values, indices};
-    return nan_mode ? run_r2<ArgAcc<false, true>>(c, x, pre, red, post, fin, "reduce_min_dim")
-                    : run_r2<ArgAcc<false, false>>(c, x, pre, red, post, fin, "reduce_min_dim");
+    return nan_mode ? run_r2<ArgAcc<false, true>, ArgFin<false>, T>(c, x, pre, red, post, fin, "reduce_min_dim")
+                    : run_r2<ArgAcc<false, false>, ArgFin<false>, T>(c, x, pre, red, post, fin, "reduce_min_dim");
+}
+int launch_argreduce(Context* c, int op, int nan_mode, const double* x, size_t pre, size_t red, size_t post, double* values, double* indices) {
+    return argreduce_any(c, op, nan_mode, x, pre, red, post, values, indices);
+}
+// f32 storage read in place (a precision-32 provider): the same accumulators on values widened in registers - no widened copy
+int launch_argreduce_f32(Context* c, int op, int nan_mode, const float* x, size_t pre, size_t red, size_t post, double* values, double* indices) {
+    return argreduce_any(c, op, nan_mode, x, pre, red, post, values, indices);
 }
 int launch_reduce_std(Context* c, int population, int nan_mode, const double* x, size_t pre, size_t red, size_t post, double* out) {
     StdFin fin{out, population, nan_mode};
     return run_r2<MomAcc>(c, x, pre, red, post, fin, "reduce_std");
+}
+int launch_reduce_std_f32(Context* c, int population, int nan_mode, const float* x, size_t pre, size_t red, size_t post, double* out) {
+    StdFin fin{out, population, nan_mode};
+    return run_r2<MomAcc, StdFin, float>(c, x, pre, red, post, fin, "reduce_std");
 }
 // image_normalize with more planes than special.hip's block layout takes (batch > 256): the tensor is a batch x plane matrix and the
 // statistics are a moments reduction along its second dimension - many short-stride lines, the strided kernels' home ground.
@@ -649,6 +678,10 @@ int launch_reduce_moments(Context* c, const double* x, size_t pre, size_t red, s
 int launch_reduce_truth(Context* c, int op, int omit_nan, const double* x, size_t pre, size_t red, size_t post, double* out) {
     TruthFin fin{out, op, omit_nan, (u64)red};
     return run_r2<TruthAcc>(c, x, pre, red, post, fin, "reduce_truth");
+}
+int launch_reduce_truth_f32(Context* c, int op, int omit_nan, const float* x, size_t pre, size_t red, size_t post, double* out) {
+    TruthFin fin{out, op, omit_nan, (u64)red};
+    return run_r2<TruthAcc, TruthFin, float>(c, x, pre, red, post, fin, "reduce_truth");
 }
 
 // ---- cumulative sum / product along one dimension (cumsum.rs:559-650, cumprod.rs:581-670) ----------------------------------------

@@ -602,13 +602,16 @@ int rmhip_reduce_minmax_dim(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int na
     if (op != RMHIP_RMIN && op != RMHIP_RMAX) return fail(RMHIP_ERR_INVALID, "reduce_minmax_dim: op must be RMHIP_RMIN or RMHIP_RMAX");
     if (dim < 0) return fail(RMHIP_ERR_INVALID, "reduce_minmax_dim: dim must be >= 0");
     Buffer ab, vb, ib;
-    RMHIP_TRY(c->get(a, &ab));  // (precision 32: a widened copy - f32 -> f64 is exact and order preserving; outputs are narrowed on return)
+    bool f32 = c->precision == 32;  // f32 storage is read in place and widened in registers (exact, order preserving); outputs are narrowed on return
+    RMHIP_TRY(get_operand(c, a, &ab, &f32));
     DimView v;
     RMHIP_TRY(dim_view(ab, dim, "reduce_minmax_dim", &v));
     if (ab.numel == 0) return fail(RMHIP_ERR_UNSUPPORTED, "reduce_minmax_dim: empty tensor");
     RMHIP_TRY(c->new_buffer(v.oshape.data(), v.oshape.size(), values, &vb));
     int rc = c->new_buffer(v.oshape.data(), v.oshape.size(), indices, &ib);
-    if (!rc) rc = launch_argreduce(c, op, nan_mode, ab.data(), v.pre, v.red, v.post, vb.data(), ib.data());
+    if (!rc)
+        rc = f32 ? launch_argreduce_f32(c, op, nan_mode, ab.data_f32(), v.pre, v.red, v.post, vb.data(), ib.data())
+                 : launch_argreduce(c, op, nan_mode, ab.data(), v.pre, v.red, v.post, vb.data(), ib.data());
     if (rc) {
         rmhip_free(ctx, *values);
         if (*indices) rmhip_free(ctx, *indices);
@@ -623,12 +626,14 @@ int rmhip_reduce_std(rmhip_ctx* ctx, rmhip_buf a, int dim, int normalization, in
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     if (normalization != 0 && normalization != 1) return fail(RMHIP_ERR_INVALID, "reduce_std: normalization must be 0 (sample) or 1 (population)");
     Buffer ab, ob;
-    RMHIP_TRY(c->get(a, &ab));
+    bool f32 = c->precision == 32;
+    RMHIP_TRY(get_operand(c, a, &ab, &f32));
     DimView v;
     RMHIP_TRY(dim_view(ab, dim, "reduce_std", &v));
     if (ab.numel == 0) return fail(RMHIP_ERR_UNSUPPORTED, "reduce_std: empty tensor");
     RMHIP_TRY(c->new_buffer(v.oshape.data(), v.oshape.size(), out, &ob));
-    const int rc = launch_reduce_std(c, normalization, nan_mode, ab.data(), v.pre, v.red, v.post, ob.data());
+    const int rc = f32 ? launch_reduce_std_f32(c, normalization, nan_mode, ab.data_f32(), v.pre, v.red, v.post, ob.data())
+                       : launch_reduce_std(c, normalization, nan_mode, ab.data(), v.pre, v.red, v.post, ob.data());
     if (rc) rmhip_free(ctx, *out);
     return rc;
 }
@@ -638,12 +643,14 @@ int rmhip_reduce_truth(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int omit_na
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");
     if (op < 0 || op >= RMHIP_TRUTH_OP_COUNT) return fail(RMHIP_ERR_INVALID, "reduce_truth: bad op %d", op);
     Buffer ab, ob;
-    RMHIP_TRY(c->get(a, &ab));
+    bool f32 = c->precision == 32;
+    RMHIP_TRY(get_operand(c, a, &ab, &f32));
     DimView v;
     RMHIP_TRY(dim_view(ab, dim, "reduce_truth", &v));
     if (ab.numel == 0) return fail(RMHIP_ERR_UNSUPPORTED, "reduce_truth: empty tensor");
     RMHIP_TRY(c->new_buffer(v.oshape.data(), v.oshape.size(), out, &ob));
-    const int rc = launch_reduce_truth(c, op, omit_nan, ab.data(), v.pre, v.red, v.post, ob.data());
+    const int rc = f32 ? launch_reduce_truth_f32(c, op, omit_nan, ab.data_f32(), v.pre, v.red, v.post, ob.data())
+                       : launch_reduce_truth(c, op, omit_nan, ab.data(), v.pre, v.red, v.post, ob.data());
     if (rc) rmhip_free(ctx, *out);
     return rc;
 }
