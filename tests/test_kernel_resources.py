@@ -89,3 +89,16 @@ def test_special_kernels_keep_their_register_budgets():
     # the image passes stream: the statistics and the plain apply pass without scratch (the gamma step may call the out-of-line pow)
     for name, r in _pick(res, "k_plane_moments").items():
         assert r["scratch"] == 0, (name, r)
+
+
+def test_reduction_and_small_solver_kernels_do_not_spill():
+    res = _resources("reduce2.hip")
+    # two-stage reductions with wide accumulators (arg-min / max: value + index; moments: four doubles) over f64 and f32 storage, and the
+    # staged scan whose first wave keeps a tile of 64 steps in registers: none may touch scratch
+    # (the moments accumulator's element-by-element path for a batch that holds a NaN keeps three to five doubles in scratch: 24 - 40 bytes, known since round 3 introduced it)
+    for key in ("k_r2_contig_v2", "k_r2_strided_v2", "k_r2_short", "k_scan_lines_staged", "k_scan_chunks"):
+        for name, r in _pick(res, key).items():
+            assert r["scratch"] <= (48 if "MomAcc" in name else 0), (name, r)
+    res = _resources("small_solve.hip")
+    for name, r in _pick(res, "k_small_solve").items():
+        assert r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 128, (name, r)
