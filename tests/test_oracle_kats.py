@@ -525,3 +525,63 @@ def test_std_truth_and_scans_reference_rules(oracle):
     assert np.isnan(r[0, 0]) and np.isnan(r[0, 1]) and r[0, 2] == 3.0
     assert oracle.cumulative(np.array([[2.0, 3.0, 4.0]]), 1, prod=True).tolist() == [[2.0, 6.0, 24.0]]
     assert oracle.cumulative(np.array([[2.0, np.nan, 4.0]]), 1, prod=True, omitnan=True, reverse=True).tolist() == [[8.0, 4.0, 4.0]]
+
+
+def test_oracle_reductions_and_scans_on_random_3d_shapes_against_numpy(oracle):
+    """The GPU shape-fuzz tests (tests/test_gpu_fuzz_nd.py, test_gpu_reductions2.py) check the device against these oracle functions on
+    3-D shapes along every dimension: here the oracle itself against independent numpy formulations on quarter-valued data (sums and
+    scans exact, ties frequent), so a dimension-handling slip in the checker cannot hide one in the product."""
+    rng = np.random.default_rng(2024)
+    for _ in range(25):
+        shape = tuple(int(v) for v in rng.choice([1, 2, 3, 5, 17, 33, 64, 100], 3))
+        x = np.round(rng.uniform(-8, 8, shape) * 4) / 4
+        x[rng.random(shape) < 0.1] = 0.0
+        for dim in (0, 1, 2):
+            for is_max in (False, True):
+                v, i = oracle.minmax_dim(x, dim, is_max)
+                ref = x.max(axis=dim, keepdims=True) if is_max else x.min(axis=dim, keepdims=True)
+                assert np.array_equal(v, ref), (shape, dim, is_max)
+                # the index is 1-based and names an element that attains the extreme value; no earlier element does
+                taken = np.take_along_axis(x, (i - 1).astype(np.int64), axis=dim)
+                assert np.array_equal(taken, ref), (shape, dim, is_max)
+                first = np.argmax(x == ref, axis=dim)
+                # (-0.0 == +0.0 in numpy: where both occur the CPU rule orders -0 below +0, so only compare slices without a signed-zero tie)
+                no_zero_tie = ~np.any((x == 0.0) & (ref == 0.0), axis=dim)
+                assert np.array_equal((np.squeeze(i, axis=dim) - 1)[no_zero_tie], first[no_zero_tie]), (shape, dim, is_max)
+            assert np.array_equal(oracle.truth_dim(x, dim, "nnz"), np.count_nonzero(x, axis=dim, keepdims=True).astype(np.float64))
+            assert np.array_equal(oracle.truth_dim(x, dim, "any"), x.any(axis=dim, keepdims=True).astype(np.float64))
+            assert np.array_equal(oracle.truth_dim(x, dim, "all"), x.all(axis=dim, keepdims=True).astype(np.float64))
+            want = x.std(axis=dim, ddof=1, keepdims=True) if shape[dim] > 1 else np.zeros_like(x.sum(axis=dim, keepdims=True))
+            assert np.max(np.abs(oracle.std_dim(x, dim) - want)) <= 1e-12 * max(1.0, float(np.abs(want).max())), (shape, dim)
+            for reverse in (False, True):
+                flip = (lambda a: np.flip(a, axis=dim)) if reverse else (lambda a: a)
+                assert np.array_equal(oracle.cumulative(x, dim, reverse=reverse), flip(np.cumsum(flip(x), axis=dim))), (shape, dim, reverse)
+        s = np.where(rng.random(shape) < 0.5, 1.0, -1.0)
+        for dim in (0, 1, 2):
+            assert np.array_equal(oracle.cumulative(s, dim, prod=True), np.cumprod(s, axis=dim)), (shape, dim)
+
+
+def test_oracle_special_hooks_against_numpy(oracle):
+    """image_normalize for any batch extent, covariance of many samples of a few variables, least squares of regression shapes, dot and
+    the moments along a dimension: what the new GPU paths of late round 3 are compared with, against numpy's own formulations."""
+    rng = np.random.default_rng(11)
+    for shape in [(1, 30, 22), (3, 5, 7), (300, 6, 5), (1000, 4, 4)]:
+        x = rng.uniform(0.0, 1.0, shape)
+        got = oracle.image_normalize(x, 1e-6, gain=1.5, bias=0.1, gamma=1.8, clamp_zero=True)
+        mu = x.mean(axis=(1, 2), keepdims=True)
+        var = ((x - mu) ** 2).mean(axis=(1, 2), keepdims=True)
+        want = np.maximum((x - mu) / np.sqrt(var + 1e-6) * 1.5 + 0.1, 0.0) ** 1.8
+        assert np.max(np.abs(got - want)) <= 1e-12 * max(1.0, float(np.abs(want).max())), shape
+    for rows, cols in [(5000, 1), (4096, 8), (20003, 17), (9000, 24)]:
+        x = rng.uniform(-1, 1, (rows, cols)) + np.arange(cols)
+        assert np.allclose(oracle.covariance(x, False), np.cov(x, rowvar=False).reshape(cols, cols), rtol=1e-10, atol=1e-12), (rows, cols)
+        assert np.allclose(oracle.covariance(x, True), np.cov(x, rowvar=False, bias=True).reshape(cols, cols), rtol=1e-10, atol=1e-12), (rows, cols)
+    for m, n, nrhs in [(500, 7, 1), (1200, 17, 3)]:
+        A, B = rng.uniform(-1, 1, (m, n)), rng.uniform(-1, 1, (m, nrhs))
+        want = np.linalg.lstsq(A, B, rcond=None)[0]
+        assert np.max(np.abs(oracle.mldivide_svd(A, B) - want)) <= 1e-10 * max(1.0, float(np.abs(want).max())), (m, n, nrhs)
+    a, b = rng.uniform(-1, 1, (32, 300)), rng.uniform(-1, 1, (32, 300))
+    for dim in (0, 1):
+        prod = oracle.binary("mul", a, b)
+        assert np.allclose(oracle.reduce_sum(prod, [dim]), (a * b).sum(axis=dim, keepdims=True), rtol=1e-13, atol=1e-14)
+        assert np.allclose(oracle.reduce_sum(a, [dim], mean=True), a.mean(axis=dim, keepdims=True), rtol=1e-13, atol=1e-15)
