@@ -1,6 +1,7 @@
 // auto_offload_kats.cpp -- known-answer tests of the auto-offload decision mirror (include/rmhip_auto_offload.hpp) against the rules of
 // crates/runmat-accelerate/src/native_auto.rs (cited per block).  Pure host code: runs on the CPU (tests/test_auto_offload.py).
-// Usage: auto_offload_kats [calibration.json]   - with a file: also load it and print the coefficients it yields.
+// Usage: auto_offload_kats [calibration.json]                       - with a file: also load it and print the coefficients it yields
+//        auto_offload_kats --profile profile.json [calibration.json] - fit the GPU cost models of a profile file and print decisions
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -107,6 +108,11 @@ int main(int argc, char** argv) {
     q.thresholds.cpu_matmul_per_flop = std::nan("");      // no CPU estimate: the device is taken to win
     CHECK(q.evaluate_matmul(1000).gpu && !q.evaluate_matmul(1000).cpu_secs);
 
+    const std::vector<ProfileReport> parsed = load_profile_reports(R"([{"category": "elementwise", "input_shapes": [[1000, 1]], "total_ms": {"avg_ms": 0.006, "p95_ms": 1}},
+        {"category": "matmul", "input_shapes": [[100, 50], [50, 20]], "total_ms": {"avg_ms": 0.02}}, {"input_shapes": []}, {"category": "reduction", "total_ms": {}}])");
+    CHECK(parsed.size() == 3 && parsed[0].category == "elementwise" && parsed[0].input_shapes[0][0] == 1000 && parsed[0].avg_total_ms == 0.006 &&
+          parsed[1].input_shapes.size() == 2 && parsed[1].input_shapes[1][1] == 20 && parsed[2].avg_total_ms == 0.0 && parsed[2].input_shapes.empty());
+
     // ---- environment overrides (:1416-1449) ----
     std::map<std::string, std::string> env = {{"RUNMAT_ACCEL_THRESHOLD_UNARY", "100"}, {"RUNMAT_ACCEL_THRESHOLD_MATMUL", "12345"},
                                               {"RUNMAT_ACCEL_THRESHOLD_REDUCTION", "x1"}, {"RUNMAT_ACCEL_SMALL_BATCH_MAX_DIM", "0"}};
@@ -165,6 +171,30 @@ int main(int argc, char** argv) {
     }
     CHECK(threw);
 
+    // ---- a GPU profile file (RUNMAT_ACCEL_PROFILE format), when given as `--profile file`: the fitted models and a few decisions ----
+    if (argc > 2 && std::strcmp(argv[1], "--profile") == 0) {
+        std::ifstream f(argv[2]);
+        std::stringstream ss;
+        ss << f.rdbuf();
+        const std::vector<ProfileReport> file_reports = load_profile_reports(ss.str());
+        Planner fp;
+        fp.profile = ProfileCostModel::from_reports(file_reports);
+        if (argc > 3) {  // the CPU side from a calibration sample of the same box
+            std::ifstream cf(argv[3]);
+            std::stringstream cs;
+            cs << cf.rdbuf();
+            CHECK(apply_calibration_sample(fp.thresholds, load_calibration_sample(cs.str())));
+        }
+        CHECK(!file_reports.empty() && fp.profile->elem && fp.profile->reduction && fp.profile->matmul);
+        std::printf("profile: reports %zu  elem %.6e %.6e  reduction %.6e %.6e  matmul %.6e %.6e\n", file_reports.size(), fp.profile->elem->slope,
+                    fp.profile->elem->intercept, fp.profile->reduction->slope, fp.profile->reduction->intercept, fp.profile->matmul->slope, fp.profile->matmul->intercept);
+        for (size_t n : {64u, 1024u, 2048u, 4096u, 65536u, 1048576u}) {
+            const Decision de = fp.evaluate_elementwise(n, false), dr = fp.evaluate_reduction(n);
+            std::printf("decide: elementwise %zu -> %s (%s)  reduction -> %s\n", n, de.gpu ? "gpu" : "cpu", reason_name(de.reason), dr.gpu ? "gpu" : "cpu");
+        }
+        for (size_t n : {8u, 16u, 32u, 48u, 128u}) std::printf("decide: matmul %zu^3 -> %s\n", n, fp.evaluate_matmul(n * n * n).gpu ? "gpu" : "cpu");
+        return failures ? 1 : 0;
+    }
     // ---- a file from the calibrator (tests/tools/offload_calibrate.cpp), when given ----
     if (argc > 1) {
         std::ifstream f(argv[1]);

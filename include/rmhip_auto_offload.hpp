@@ -12,7 +12,7 @@
 //   apply_env_overrides        :1416-1449             (RUNMAT_ACCEL_THRESHOLD_{UNARY,ELEMWISE,REDUCTION,MATMUL,ALL}, RUNMAT_ACCEL_SMALL_BATCH_*)
 //   Reason / reason_name       :105-114               (serialised kebab-case)
 //   LinearModel, fit           :1937-1955, 2044-2075
-//   ProfileCostModel           :1957-2042             (reports by category; matmul samples in m*k*n)
+//   ProfileCostModel, load     :1921-2042, 2081-2125  (reports by category; matmul samples in m*k*n; `RUNMAT_ACCEL_PROFILE` file)
 //   CalibrationSample, load    :330-417               (`suite.auto_offload_calibration` wins over the top-level section)
 //   apply_calibration_sample   :419-476               (ms / units -> seconds per element / flop; only real changes count)
 //   Planner::evaluate_*        :923-1118, small_batch_guard :824-839, batch dimension :570-583
@@ -308,6 +308,32 @@ inline CalibrationSample load_calibration_sample(const std::string& json_text) {
     }
     if (const detail::Json* v = sec->get("provider_conflict"); v && v->kind == detail::Json::Bool) s.provider_conflict = v->b;
     return s;
+}
+
+// A GPU profile file (`RUNMAT_ACCEL_PROFILE`, native_auto.rs:2081-2125): a JSON array of reports {category, input_shapes, total_ms{avg_ms}}
+// (:1921-1935); reports without a category or a total are skipped.
+inline std::vector<ProfileReport> load_profile_reports(const std::string& json_text) {
+    detail::JsonParser p(json_text);
+    const detail::Json root = p.value();
+    if (root.kind != detail::Json::Arr) throw std::runtime_error("GPU profile: expected an array of reports");
+    std::vector<ProfileReport> out;
+    for (const detail::Json& r : root.arr) {
+        const detail::Json* cat = r.get("category");
+        const detail::Json* tot = r.get("total_ms");
+        if (!cat || cat->kind != detail::Json::Str || !tot) continue;
+        ProfileReport rep;
+        rep.category = cat->str;
+        rep.avg_total_ms = detail::num_or(tot, "avg_ms", 0.0);
+        if (const detail::Json* shapes = r.get("input_shapes"); shapes && shapes->kind == detail::Json::Arr)
+            for (const detail::Json& sh : shapes->arr) {
+                std::vector<size_t> dims;
+                if (sh.kind == detail::Json::Arr)
+                    for (const detail::Json& d : sh.arr) dims.push_back(d.kind == detail::Json::Num && d.num >= 0.0 ? (size_t)d.num : 0);
+                rep.input_shapes.push_back(std::move(dims));
+            }
+        out.push_back(std::move(rep));
+    }
+    return out;
 }
 
 struct CalibrationDelta {  // before / after of every coefficient the sample changed
