@@ -113,6 +113,16 @@ int main(int argc, char** argv) {
     CHECK(parsed.size() == 3 && parsed[0].category == "elementwise" && parsed[0].input_shapes[0][0] == 1000 && parsed[0].avg_total_ms == 0.006 &&
           parsed[1].input_shapes.size() == 2 && parsed[1].input_shapes[1][1] == 20 && parsed[2].avg_total_ms == 0.0 && parsed[2].input_shapes.empty());
 
+    // ---- precision policy (precision.rs:22-81) ----
+    CHECK(*parse_bool(" Yes\n") && *parse_bool("ON") && !*parse_bool("off") && !*parse_bool("0") && !parse_bool("maybe") && !parse_bool(""));
+    CHECK(provider_supports_dtype(64, NumericDType::F64) && provider_supports_dtype(64, NumericDType::F32) && provider_supports_dtype(32, NumericDType::F32) &&
+          !provider_supports_dtype(32, NumericDType::F64) && !provider_supports_dtype(64, NumericDType::U8));
+    bool down = true;
+    CHECK(ensure_provider_supports_dtype(64, NumericDType::F64, false, &down).empty() && !down);
+    CHECK(ensure_provider_supports_dtype(32, NumericDType::F64, false) == "active provider does not advertise f64 kernels; refusing implicit downcast");
+    CHECK(ensure_provider_supports_dtype(32, NumericDType::F64, true, &down).empty() && down);  // RUNMAT_ALLOW_PRECISION_DOWNCAST
+    CHECK(ensure_provider_supports_dtype(64, NumericDType::U16, true) == "active provider does not support uint16 kernels");
+
     // ---- environment overrides (:1416-1449) ----
     std::map<std::string, std::string> env = {{"RUNMAT_ACCEL_THRESHOLD_UNARY", "100"}, {"RUNMAT_ACCEL_THRESHOLD_MATMUL", "12345"},
                                               {"RUNMAT_ACCEL_THRESHOLD_REDUCTION", "x1"}, {"RUNMAT_ACCEL_SMALL_BATCH_MAX_DIM", "0"}};

@@ -16,6 +16,7 @@
 //   CalibrationSample, load    :330-417               (`suite.auto_offload_calibration` wins over the top-level section)
 //   apply_calibration_sample   :419-476               (ms / units -> seconds per element / flop; only real changes count)
 //   Planner::evaluate_*        :923-1118, small_batch_guard :824-839, batch dimension :570-583
+//   precision policy           crates/runmat-accelerate/src/precision.rs:22-81 (what may be promoted to an F64 / F32 provider)
 #pragma once
 
 #include <cmath>
@@ -365,6 +366,46 @@ inline bool apply_calibration_sample(Thresholds& t, const CalibrationSample& s, 
 inline bool provider_matches(const CalibrationProvider& p, const std::string& name, const std::string& vendor, const std::optional<std::string>& backend,
                              uint32_t device_id) {
     return p.name == name && p.vendor == vendor && p.backend == backend && p.device_id == device_id;
+}
+
+// ---- precision policy of a promotion (crates/runmat-accelerate/src/precision.rs) ----------------------------------------------------
+// Before a host tensor is promoted the caller checks that the provider can run its logical dtype: an F64 provider
+// (`rmhip_set_precision(ctx, 64)`, the default) takes f64 and f32 data, an F32 provider only f32 - unless the user allowed the implicit
+// downcast of doubles with RUNMAT_ALLOW_PRECISION_DOWNCAST (parsed like the reference's `parse_bool`); integer classes never go.
+enum class NumericDType { F64, F32, U8, U16, U32 };
+inline std::optional<bool> parse_bool(const std::string& text) {  // precision.rs:22-28
+    size_t b = 0, e = text.size();
+    while (b < e && (text[b] == ' ' || text[b] == '\t' || text[b] == '\n' || text[b] == '\r')) ++b;
+    while (e > b && (text[e - 1] == ' ' || text[e - 1] == '\t' || text[e - 1] == '\n' || text[e - 1] == '\r')) --e;
+    std::string v;
+    for (size_t i = b; i < e; ++i) v += (char)(text[i] >= 'A' && text[i] <= 'Z' ? text[i] - 'A' + 'a' : text[i]);
+    if (v == "1" || v == "true" || v == "yes" || v == "on") return true;
+    if (v == "0" || v == "false" || v == "no" || v == "off") return false;
+    return std::nullopt;
+}
+// `provider_bits` = rmhip_buffer_bits / the context's precision: 64 or 32
+inline bool provider_supports_dtype(int provider_bits, NumericDType dtype) {  // precision.rs:40-46
+    switch (dtype) {
+        case NumericDType::F32: return true;
+        case NumericDType::F64: return provider_bits == 64;
+        default: return false;
+    }
+}
+// empty string = go ahead (possibly with the one-time downcast warning, *downcast set); otherwise the reference's refusal text
+inline std::string ensure_provider_supports_dtype(int provider_bits, NumericDType dtype, bool allow_downcast, bool* downcast = nullptr) {  // precision.rs:53-81
+    if (downcast) *downcast = false;
+    if (provider_supports_dtype(provider_bits, dtype)) return std::string();
+    if (dtype == NumericDType::F64 && allow_downcast) {
+        if (downcast) *downcast = true;
+        return std::string();
+    }
+    switch (dtype) {
+        case NumericDType::F64: return "active provider does not advertise f64 kernels; refusing implicit downcast";
+        case NumericDType::F32: return "active provider does not support f32 kernels";
+        case NumericDType::U8: return "active provider does not support uint8 kernels";
+        case NumericDType::U16: return "active provider does not support uint16 kernels";
+        default: return "active provider does not support uint32 kernels";
+    }
 }
 
 // ---- the decision ----------------------------------------------------------------------------------------------------------------
