@@ -18,6 +18,10 @@
  *   - Every op returns a NEW buffer (ResidencyPolicy::NewHandle); inputs are never mutated.
  *   - Work is enqueued on the context's HIP stream; rmhip_download / rmhip_synchronize block.
  *   - There is no CPU fallback inside the library: without a gfx950 device rmhip_init fails.
+ *   - Every prototype carries a machine-readable `@serves` tag: the `AccelProvider` methods (lib.rs:1386-3151) it
+ *     implements, `-` for entry points without a trait counterpart.  scripts/gen_bindings.py derives the ctypes table
+ *     (runmat_amd/_abi.py) and the Rust `extern "C"` block (shim/rmhip_sys.rs) from this header, and
+ *     tests/test_bindings.py checks that every served method exists in all host mirrors (Python, C++, Rust).
  */
 #ifndef RMHIP_H
 #define RMHIP_H
@@ -49,13 +53,17 @@ enum rmhip_status {
 
 /* ---- library / context ---------------------------------------------------------------------- */
 
+/* @serves - */
 RMHIP_API const char* rmhip_version(void);
 /* Thread-local message of the last failing call on this thread. Never NULL. */
+/* @serves - */
 RMHIP_API const char* rmhip_last_error(void);
 
 /* Replaces provider construction + `register_provider` (lib.rs:3213-3225); one context per GPU
  * (one process per GPU in multi-GPU jobs).  `device_ordinal` is the HIP device index. */
+/* @serves - */
 RMHIP_API int rmhip_init(int device_ordinal, rmhip_ctx** out_ctx);
+/* @serves - */
 RMHIP_API int rmhip_shutdown(rmhip_ctx* ctx);
 
 /* `device_info_struct` (lib.rs:1448-1456) + `precision` (:1458; 64 unless rmhip_set_precision chose 32). */
@@ -75,6 +83,7 @@ typedef struct rmhip_device_info {
     int xcd_count;          /* accelerator dies the workgroup dispatcher interleaves over (8 on an MI355X in SPX mode, 1 in CPX),
                                probed at init; the LU's one-XCD placement and XCD-avoiding update kernels need exactly 8    */
 } rmhip_device_info_t;
+/* @serves device_info device_info_struct default_reduction_workgroup_size two_pass_threshold */
 RMHIP_API int rmhip_device_info(rmhip_ctx* ctx, rmhip_device_info_t* out);
 
 /* `ProviderPrecision` (lib.rs:815-818) is a property of the provider: 64 (default) or 32 bits, chosen before the
@@ -87,41 +96,56 @@ RMHIP_API int rmhip_device_info(rmhip_ctx* ctx, rmhip_device_info_t* out);
  * and image_normalize read and write f32 storage directly; matmul runs on the f32 matrix cores (f32 accumulation, like
  * the reference's F32 backend; RMHIP_F32_MATMUL=f64 selects the f64-exact path); lu, mldivide/linsolve and the
  * remaining hooks run their f64 kernels on widened copies and narrow the result.  rmhip_buffer_bits reports a buffer's storage width (externally wrapped memory stays f64). */
+/* @serves precision */
 RMHIP_API int rmhip_set_precision(rmhip_ctx* ctx, int bits);
+/* @serves - */
 RMHIP_API int rmhip_buffer_bits(rmhip_ctx* ctx, rmhip_buf id, int* bits);
 
 /* Stream plumbing: by default the context owns a non-blocking stream.  A host that already has
  * a stream (e.g. torch's current stream) can make the library enqueue there instead. */
+/* @serves - */
 RMHIP_API int rmhip_set_stream(rmhip_ctx* ctx, void* hip_stream);
+/* @serves - */
 RMHIP_API void* rmhip_get_stream(rmhip_ctx* ctx);
+/* @serves - */
 RMHIP_API int rmhip_synchronize(rmhip_ctx* ctx);
 
 /* ---- memory: upload / download / free  (lib.rs:1387-1389) ----------------------------------- */
 
+/* @serves upload */
 RMHIP_API int rmhip_upload(rmhip_ctx* ctx, const double* host, const size_t* shape, size_t rank,
                            rmhip_buf* out);
 /* Copies `n` doubles (must equal the buffer's element count) to `out_host`; blocks. */
+/* @serves download */
 RMHIP_API int rmhip_download(rmhip_ctx* ctx, rmhip_buf id, double* out_host, size_t n);
+/* @serves free */
 RMHIP_API int rmhip_free(rmhip_ctx* ctx, rmhip_buf id);
 /* On entry *rank_inout is the capacity of shape_out; on exit the rank. */
+/* @serves - */
 RMHIP_API int rmhip_shape(rmhip_ctx* ctx, rmhip_buf id, size_t* rank_inout, size_t* shape_out);
+/* @serves - */
 RMHIP_API int rmhip_numel(rmhip_ctx* ctx, rmhip_buf id, size_t* out);
 /* `zeros` / `ones` / `fill` (lib.rs:1468-1522). */
+/* @serves zeros ones fill */
 RMHIP_API int rmhip_fill(rmhip_ctx* ctx, double value, const size_t* shape, size_t rank,
                          rmhip_buf* out);
 /* `reshape` (lib.rs:2676-2684): same numel, same buffer: the table entry's shape is updated in place and *out
  * receives `id` itself, as the trait default and the wgpu provider (ops/tensor.rs reshape_exec) do - callers
  * consume the source handle and never free it separately.  A transpose view is materialised first. */
+/* @serves reshape */
 RMHIP_API int rmhip_reshape(rmhip_ctx* ctx, rmhip_buf id, const size_t* shape, size_t rank,
                             rmhip_buf* out);
 /* Zero-copy adoption of device memory owned by the host (torch tensor, RCCL receive buffer...).
  * The library never frees it; rmhip_free only drops the table entry. */
+/* @serves - */
 RMHIP_API int rmhip_wrap_external(rmhip_ctx* ctx, void* device_ptr, const size_t* shape,
                                   size_t rank, rmhip_buf* out);
 /* Raw device pointer of a buffer (for RCCL collectives / torch views). NULL if unknown. */
+/* @serves - */
 RMHIP_API void* rmhip_device_ptr(rmhip_ctx* ctx, rmhip_buf id);
 /* Deterministic device-side fill used by bench/tests: element i = lo + (hi-lo)*u53(splitmix64(
  * seed + (i+1)*0x9e3779b97f4a7c15)) -- identical to oracle's orc_fill_uniform. */
+/* @serves - */
 RMHIP_API int rmhip_fill_uniform(rmhip_ctx* ctx, uint64_t seed, double lo, double hi,
                                  const size_t* shape, size_t rank, rmhip_buf* out);
 
@@ -133,6 +157,7 @@ RMHIP_API int rmhip_fill_uniform(rmhip_ctx* ctx, uint64_t seed, double lo, doubl
  * lowers it to a HIP kernel (hipRTC, cached by tape hash).  Inputs broadcast against `out_shape`
  * with front-padded shapes (elementwise.rs:1680-1697).  `n_out` == 1 writes `output`, > 1 writes
  * `output0..`.  `len` must equal prod(out_shape). */
+/* @serves fused_elementwise fused_elementwise_multi */
 RMHIP_API int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf* inputs,
                                       size_t n_in, const size_t* out_shape, size_t rank,
                                       size_t len, size_t n_out, rmhip_buf* out_ids);
@@ -146,6 +171,7 @@ enum rmhip_reduction_flavor { /* ReductionFlavor, lib.rs:865-890 */
  * reads from it: the folded `let val: f64 = <expr>;`, the axis (column-wise `(col * params.nrows)
  * + r` vs row-wise `row + (c * params.ncols)` addressing) and `const OMITNAN`.  Output has
  * `num_slices` elements with shape `out_shape`. `workgroup_size` is advisory (ignored). */
+/* @serves fused_reduction */
 RMHIP_API int rmhip_fused_reduction(rmhip_ctx* ctx, const char* shader, const rmhip_buf* inputs,
                                     size_t n_in, const size_t* out_shape, size_t rank,
                                     size_t reduce_len, size_t num_slices, uint32_t workgroup_size,
@@ -154,9 +180,11 @@ RMHIP_API int rmhip_fused_reduction(rmhip_ctx* ctx, const char* shader, const rm
 /* Front-end only (no GPU needed): translate a reference WGSL shader to the HIP source the library
  * would compile. `kind` 0 = elementwise, 1 = reduction. Writes a NUL-terminated string of at most
  * `cap` bytes to `out` and the required size to *needed. */
+/* @serves - */
 RMHIP_API int rmhip_wgsl_translate(const char* shader, int kind, char* out, size_t cap,
                                    size_t* needed);
 /* Front-end + hipRTC compile for gfx950 (no GPU needed); 0 if the generated kernel builds. */
+/* @serves - */
 RMHIP_API int rmhip_wgsl_compile_check(const char* shader, int kind);
 
 /* ---- per-op kernels  (lib.rs:1890-1938, 1979, 2069, 2077-2355) ------------------------------ */
@@ -169,6 +197,7 @@ enum rmhip_binary_op { /* elem_add/sub/mul/div/pow/max/min/hypot/atan2 */
     RMHIP_EQ, RMHIP_NE, RMHIP_LT, RMHIP_LE, RMHIP_GT, RMHIP_GE, RMHIP_AND, RMHIP_OR, RMHIP_XOR, RMHIP_BINARY_OP_COUNT
 };
 /* Operands broadcast under MATLAB implicit expansion (broadcast.rs:95-140). */
+/* @serves elem_add elem_sub elem_mul elem_div elem_pow elem_max elem_min elem_hypot elem_atan2 elem_eq elem_ne elem_lt elem_le elem_gt elem_ge logical_and logical_or logical_xor */
 RMHIP_API int rmhip_binary(rmhip_ctx* ctx, int op, rmhip_buf a, rmhip_buf b, rmhip_buf* out);
 
 enum rmhip_unary_op { /* unary_* ; numbering shared with oracle/oracle.c */
@@ -182,14 +211,20 @@ enum rmhip_unary_op { /* unary_* ; numbering shared with oracle/oracle.c */
      * (math/elementwise/gamma.rs:289-343, gammaln.rs:254-281); factorial: product table up to 170, NaN for non-integers
      * (factorial.rs:25-34, 272-314); nextpow2: ceil(log2(|x|)), 0 for 0 (nextpow2.rs:157-164); erfcinv: bracket +
      * 110 bisection steps on erfc (erfcinv.rs:261-308) */
-    RMHIP_GAMMA, RMHIP_FACTORIAL, RMHIP_NEXTPOW2, RMHIP_GAMMALN, RMHIP_ERFCINV, RMHIP_UNARY_OP_COUNT
+    RMHIP_GAMMA, RMHIP_FACTORIAL, RMHIP_NEXTPOW2, RMHIP_GAMMALN, RMHIP_ERFCINV,
+    /* `map_nan_to_zero` / `not_nan_mask` (lib.rs:2980-2988; the omitnan forms of sum / mean call them on resident
+     * tensors, reduction/sum.rs:795, mean.rs:1077-1078): NaN -> 0, everything else unchanged / 1.0 where the value is not NaN,
+     * else 0.0 (backend/wgpu/shaders/nan.rs: `select(v, 0, v != v)`, `select(0, 1, !(v != v))`) */
+    RMHIP_NAN_TO_ZERO, RMHIP_NOT_NAN, RMHIP_UNARY_OP_COUNT
 };
+/* @serves unary_sin unary_cos unary_tan unary_asin unary_acos unary_atan unary_sinh unary_cosh unary_tanh unary_asinh unary_acosh unary_atanh unary_exp unary_expm1 unary_log unary_log2 unary_log10 unary_log1p unary_sqrt unary_abs unary_sign unary_floor unary_ceil unary_round unary_fix unary_pow2 unary_heaviside unary_single unary_double unary_erf unary_sinc unary_gamma unary_factorial unary_nextpow2 unary_gammaln unary_erfcinv logical_not logical_isnan logical_isinf logical_isfinite map_nan_to_zero not_nan_mask */
 RMHIP_API int rmhip_unary(rmhip_ctx* ctx, int op, rmhip_buf a, rmhip_buf* out);
 
 enum rmhip_scalar_op { /* scalar_add/sub/mul/div/rsub/rdiv/max/min (lib.rs:2333-2355) */
     RMHIP_SADD = 0, RMHIP_SSUB, RMHIP_SMUL, RMHIP_SDIV, RMHIP_SRSUB, RMHIP_SRDIV, RMHIP_SMAX,
     RMHIP_SMIN, RMHIP_SCALAR_OP_COUNT
 };
+/* @serves scalar_add scalar_sub scalar_mul scalar_div scalar_rsub scalar_rdiv scalar_max scalar_min */
 RMHIP_API int rmhip_scalar(rmhip_ctx* ctx, int op, rmhip_buf a, double s, rmhip_buf* out);
 
 /* ---- reductions  (lib.rs:2709-2721, 2756-2792, 2858-2883) ----------------------------------- */
@@ -199,6 +234,7 @@ enum rmhip_reduce_op { RMHIP_RSUM = 0, RMHIP_RMEAN, RMHIP_RMIN, RMHIP_RMAX, RMHI
 /* dim < 0: reduce all elements -> shape [1,1] (simple_provider.rs:6728-6748).
  * dim 0 / 1 (zero-based, 2-D): -> [1,cols] / [rows,1] (simple_provider.rs:6750-6806).
  * nan_mode 0 = include (any NaN => NaN, sum.rs:1038-1045), 1 = omit. */
+/* @serves reduce_sum reduce_sum_dim reduce_mean reduce_mean_dim reduce_min reduce_max reduce_prod reduce_prod_dim */
 RMHIP_API int rmhip_reduce(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int nan_mode,
                            rmhip_buf* out);
 
@@ -209,23 +245,27 @@ RMHIP_API int rmhip_reduce(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int nan
  * in "includenan" mode only, min.rs:795-800): the FIRST occurrence wins ties, -0 is below +0, and with nan_mode 0 (include) the
  * first NaN of a slice fixes the result (value NaN, index of that NaN); nan_mode 1 (omit) skips NaNs, a slice of NaNs gives
  * (NaN, NaN).  Integer work: values and indices are bit-exact with the CPU's. */
+/* @serves reduce_min_dim reduce_max_dim */
 RMHIP_API int rmhip_reduce_minmax_dim(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int nan_mode, rmhip_buf* values,
                                       rmhip_buf* indices);
 /* `reduce_std` / `reduce_std_dim` (lib.rs:2786-2802): standard deviation along `dim` (zero-based; dim < 0: all elements ->
  * [1,1]).  normalization 0 = sample (n - 1; 0 for a single value), 1 = population (`ProviderStdNormalization`, :957-960);
  * nan_mode as above (include: any NaN => NaN; omit: NaNs skipped, none left => NaN).  std.rs:858-935: Welford's update,
  * merged over chunks with Chan's formula. */
+/* @serves reduce_std reduce_std_dim */
 RMHIP_API int rmhip_reduce_std(rmhip_ctx* ctx, rmhip_buf a, int dim, int normalization, int nan_mode, rmhip_buf* out);
 /* `reduce_nnz(_dim)` (lib.rs:2730-2742), `reduce_any(_dim)` / `reduce_all(_dim)` (:2803-2850): counts / truth values as f64.
  * nnz counts NaNs as non-zero (nnz.rs:358).  any: include => a NaN is true, omit_nan => NaNs are skipped (any.rs:722-733);
  * all: NaNs are skipped in both modes and a slice with nothing left is true (all.rs:671-703).  dim < 0: all elements. */
 enum rmhip_truth_op { RMHIP_TNNZ = 0, RMHIP_TANY, RMHIP_TALL, RMHIP_TRUTH_OP_COUNT };
+/* @serves reduce_nnz reduce_nnz_dim reduce_any reduce_any_dim reduce_all reduce_all_dim */
 RMHIP_API int rmhip_reduce_truth(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int omit_nan, rmhip_buf* out);
 /* `cumsum_scan` / `cumprod_scan` (lib.rs:2884-2891, 2908-2915): running sum (op 0) / product (op 1) along `dim` (zero-based),
  * forward or reverse (`ProviderScanDirection`, :1053-1056), NaN modes of cumsum.rs:586-650 (include: NaN from the first NaN
  * on; omit: NaNs leave the running value unchanged).  Same shape as the input.  Along a strided dimension every line is the
  * CPU's own left-to-right sequence (bit-identical); long contiguous lines are scanned in blocks (equal up to rounding, exact for
  * integer-valued data). */
+/* @serves cumsum_scan cumprod_scan */
 RMHIP_API int rmhip_cumulative(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int reverse, int nan_mode, rmhip_buf* out);
 
 /* `dot` (lib.rs:2722-2728): sum(a .* b) along `dim` (zero-based) of two same-shape tensors; dim < 0
@@ -233,18 +273,22 @@ RMHIP_API int rmhip_cumulative(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int
 /* `reduce_mean_nd` (lib.rs:2763-2769; shape rules backend/wgpu/provider/ops/reduction/nd.rs:59-72): reduce several
  * zero-based dimensions, reduced extents become 1.  Dimensions are taken in ascending order one after the other,
  * which is how the CPU computes `mean(x, vecdim)` (mean of means, mean.rs:1107-1116); works for every reduce op. */
+/* @serves reduce_mean_nd */
 RMHIP_API int rmhip_reduce_nd(rmhip_ctx* ctx, int op, rmhip_buf a, const size_t* dims_zero_based, size_t ndims,
                               int nan_mode, rmhip_buf* out);
 /* `reduce_moments_nd` (lib.rs:2770-2778, `ProviderMoments2` :1317-1320): E[x] and E[x^2] over several zero-based
  * dims in one call (same dim handling as rmhip_reduce_nd; NaNs propagate).  Both outputs keep the reduced extents as 1. */
+/* @serves reduce_moments_nd */
 RMHIP_API int rmhip_reduce_moments_nd(rmhip_ctx* ctx, rmhip_buf a, const size_t* dims_zero_based, size_t ndims,
                                       rmhip_buf* mean_out, rmhip_buf* ex2_out);
+/* @serves dot */
 RMHIP_API int rmhip_dot(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, int dim, rmhip_buf* out);
 
 /* ---- linear algebra  (lib.rs:2375-2405, 2477-2500) ------------------------------------------ */
 
 /* `matmul`: C = A*B, 2-D, column-major; inner dims must agree else RMHIP_ERR_SHAPE
  * (simple_provider.rs:7698-7741). fp64 MFMA kernel. */
+/* @serves matmul */
 RMHIP_API int rmhip_matmul(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out);
 /* `matmul_epilogue` (lib.rs:2394-2405, descriptor `MatmulEpilogue` lib.rs:3498-3560): the epilogue is
  * folded into the dgemm store.  Order (simple_provider.rs:7800-7836): v = acc*alpha + beta; row scale;
@@ -259,11 +303,13 @@ typedef struct rmhip_matmul_epilogue {
     double clamp_min, clamp_max, pow_exponent;
     rmhip_buf diag_output;           /* 0 = none */
 } rmhip_matmul_epilogue_t;
+/* @serves matmul_epilogue */
 RMHIP_API int rmhip_matmul_epilogue(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b,
                                     const rmhip_matmul_epilogue_t* ep, rmhip_buf* out);
 /* `matmul_power_step` + PowerStepEpilogue (lib.rs:2414-2421, 3553-3561; CPU semantics
  * crates/runmat-accelerate/src/simple_provider.rs:7852-7891): P = lhs * rhs, then every column of P is divided by
  * sqrt(sum(P(:,c).^2) + epsilon)  (the power-iteration step of the PCA benchmark). */
+/* @serves matmul_power_step */
 RMHIP_API int rmhip_matmul_power_step(rmhip_ctx* ctx, rmhip_buf lhs, rmhip_buf rhs, double epsilon, rmhip_buf* out);
 /* `image_normalize` + ImageNormalizeDescriptor (lib.rs:2407-2413, 3563-3577; CPU semantics simple_provider.rs:7893-7993):
  * input is [batch, height, width]; per batch element mean / two-pass variance over the plane, then
@@ -275,27 +321,33 @@ typedef struct rmhip_image_normalize {
     int has_gain, has_bias, has_gamma, clamp_zero;
     double gain, bias, gamma;
 } rmhip_image_normalize_t;
+/* @serves image_normalize */
 RMHIP_API int rmhip_image_normalize(rmhip_ctx* ctx, rmhip_buf input, const rmhip_image_normalize_t* desc, rmhip_buf* out);
 /* `covariance` (lib.rs:1857-1865, CovarianceOptions :937-953) for the dense unweighted case the CenteredGram fusion
  * pattern issues (fusion_exec.rs:630-672: second = None, weights = None, rows = All): column means, centring,
  * (Xc' * Xc) / denom with denom = rows - 1 (biased = 0) or rows (biased = 1), cov.rs:916-953, 1080-1100, 1218-1227.
  * rows - 1 <= 0 gives the all-NaN matrix the CPU returns.  The centred product runs as A'*A on the MFMA path. */
+/* @serves covariance */
 RMHIP_API int rmhip_covariance(rmhip_ctx* ctx, rmhip_buf matrix, int biased, rmhip_buf* out);
 /* `diag_extract` (lib.rs:1625-1632; simple_provider.rs:3281-3312): the offset-th diagonal of a matrix as a column
  * vector [len, 1]; vectors are rejected ("matrix input required"). */
+/* @serves diag_extract */
 RMHIP_API int rmhip_diag_extract(rmhip_ctx* ctx, rmhip_buf matrix, long long offset, rmhip_buf* out);
 /* `lu` -> ProviderLuResult {combined, lower, upper, perm_matrix, perm_vector} (lib.rs:649-698);
  * pivot rule and singular cut-off of host_lu.rs:37-59.  out5 order: combined, L, U, P, pivots. */
+/* @serves lu */
 RMHIP_API int rmhip_lu(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf out5[5]);
 /* `mldivide`: x = A\b.  Square, numerically non-singular A: blocked LU with partial pivoting.  Rectangular FULL-RANK A with a
  * Gram pivot ratio >= 1e-11 (cond(A) up to ~3e5): the least-squares (rows > cols) / minimum-norm (rows < cols) solution the
  * reference's SVD solve returns (mldivide.rs:380-404), through the LU of A'A or AA' and one refinement step.  Anything
  * else (a pivot <= 1e-12, rank-deficient or ill-conditioned rectangular systems) returns SINGULAR / UNSUPPORTED so the
  * caller uses its CPU SVD path (mldivide.rs:223-229 `.ok()`).  Scalar A => b * (1/A) (mldivide.rs:321-325). */
+/* @serves mldivide */
 RMHIP_API int rmhip_mldivide(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out);
 /* `mrdivide` (lib.rs:2484-2490): X = B / A, i.e. X * A = B.  CPU semantics crates/runmat-runtime/src/builtins/math/linalg/ops/
  * mrdivide.rs:317-341 (scalar A: B * (1/A); column counts must agree) and :379-388 (the solve is A' \ B' transposed
  * back); here the same transposition around the LU solve, with the same soft failures as rmhip_mldivide. */
+/* @serves mrdivide */
 RMHIP_API int rmhip_mrdivide(rmhip_ctx* ctx, rmhip_buf b, rmhip_buf a, rmhip_buf* out);
 /* `linsolve` + ProviderLinsolveOptions / ProviderLinsolveResult (lib.rs:2422-2429, 679-697); CPU
  * semantics crates/runmat-runtime/src/builtins/math/linalg/solve/linsolve.rs:691-726 (option order:
@@ -312,15 +364,59 @@ typedef struct rmhip_linsolve_options {
     int has_rcond;   /* Option<f64> rcond */
     double rcond;
 } rmhip_linsolve_options_t;
+/* @serves linsolve */
 RMHIP_API int rmhip_linsolve(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, const rmhip_linsolve_options_t* opts,
                              rmhip_buf* out, double* reciprocal_condition);
 /* `transpose` (lib.rs:2532): out[j,i] = a[i,j] for a 2-D tensor, shape [cols, rows].  Like the reference's wgpu
  * provider (ops/tensor.rs:828-846, `record_handle_transpose` lib.rs:218-245) the result is a VIEW that aliases the
  * operand's storage: rmhip_matmul / rmhip_syrk read it in place through transposed-operand MFMA kernels (`A'*B`,
  * `A*B'`), every other entry point sees a materialised copy on first use (one 64x64-tile LDS transpose pass). */
+/* @serves transpose */
 RMHIP_API int rmhip_transpose(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out);
 /* `syrk` (lib.rs:2383): A' * A (cols x cols), reference loop accelerate/tests/syrk.rs:14-31. */
+/* @serves syrk */
 RMHIP_API int rmhip_syrk(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out);
+
+/* ---- shape / indexing hooks the hot-path builtins call around the kernels above --------------------------- */
+
+/* `repmat` (lib.rs:2689-2695; tiling rule crates/runmat-accelerate/src/simple_provider.rs:2174-2240, 6681-6697).  `reps` has
+ * n_reps >= 1 factors; ONE factor r means r along every dimension of max(rank, 2) dimensions, otherwise the rank is
+ * max(rank, n_reps) with missing factors 1; the shape is base .* factors.
+ * The result is a VIEW that aliases the operand's storage (like rmhip_transpose): the reference's plus / minus / times /
+ * rdivide / power builtins expand an operand with `repmat` only to hand it to `elem_*` and free it again
+ * (math/elementwise/times.rs:501-543 - the error of a provider without `repmat` goes to the user there, `?`), so
+ * rmhip_binary and rmhip_fused_elementwise read the view in place with stride-0 indexing and the tiled tensor never exists
+ * in HBM; any other entry point (download included) materialises it once, on first use, under the same id.  The base may
+ * be freed while the view lives.  A tiled extent of 0 gives an empty tensor. */
+/* @serves repmat */
+RMHIP_API int rmhip_repmat(rmhip_ctx* ctx, rmhip_buf a, const size_t* reps, size_t n_reps, rmhip_buf* out);
+/* `permute` (lib.rs:2579-2585; simple_provider.rs:1645-1740, 6402-6417): `order` is zero-based, a permutation of
+ * 0..n_order-1 with n_order >= rank (the shape is padded with 1s); out dimension d is source dimension order[d]. */
+/* @serves permute */
+RMHIP_API int rmhip_permute(rmhip_ctx* ctx, rmhip_buf a, const size_t* order, size_t n_order, rmhip_buf* out);
+/* `zeros_like` / `ones_like` / `fill_like` (lib.rs:1497, 1547, 1524-1545): a constant tensor of the prototype's shape
+ * (power.rs:577,617, reduction/max.rs:2047-2105, any.rs:397 ask for these next to a resident operand). */
+/* @serves zeros_like ones_like fill_like */
+RMHIP_API int rmhip_fill_like(rmhip_ctx* ctx, rmhip_buf prototype, double value, rmhip_buf* out);
+/* `read_scalar` (lib.rs:1463; simple_provider.rs:3415-3429): element `linear_index` (zero-based, column-major) of a
+ * resident tensor as f64 - every `y(i)` on a device result (common/indexing.rs:533).  Blocks on the context's stream;
+ * views are indexed in place, nothing is materialised.  Out of range: RMHIP_ERR_INVALID. */
+/* @serves read_scalar */
+RMHIP_API int rmhip_read_scalar(rmhip_ctx* ctx, rmhip_buf a, size_t linear_index, double* out);
+/* `gather_linear` (lib.rs:1423-1430; simple_provider.rs:2609-2654): out[k] = source[indices[k]] (zero-based linear
+ * indices) with shape `out_shape` (prod == n_indices).  An index >= numel(source) is RMHIP_ERR_INVALID. */
+/* @serves gather_linear */
+RMHIP_API int rmhip_gather_linear(rmhip_ctx* ctx, rmhip_buf source, const uint32_t* indices, size_t n_indices,
+                                  const size_t* out_shape, size_t rank, rmhip_buf* out);
+/* `scatter_linear` (lib.rs:1438-1445; simple_provider.rs:2656-2720): target[indices[k]] = values[k], in place (the
+ * trait's one mutating hook); later duplicates win, as in the reference's sequential loop.  numel(values) must be
+ * n_indices. */
+/* @serves scatter_linear */
+RMHIP_API int rmhip_scatter_linear(rmhip_ctx* ctx, rmhip_buf target, const uint32_t* indices, size_t n_indices, rmhip_buf values);
+/* `linspace` (lib.rs:1887; simple_provider.rs:3488-3513): [1, count]; element i = start + i * ((stop - start) / (count - 1)),
+ * the last one is `stop` exactly; count == 1 gives [stop]. */
+/* @serves linspace */
+RMHIP_API int rmhip_linspace(rmhip_ctx* ctx, double start, double stop, size_t count, rmhip_buf* out);
 
 /* ---- block-level building blocks for the multi-GPU solver ------------------------------------ *
  * A distributed (block-column cyclic) A\b has no counterpart in the reference (it has no multi-device
@@ -333,20 +429,26 @@ typedef struct rmhip_view {
     size_t row_off, col_off, rows, cols;
 } rmhip_view_t;
 /* Copy a sub-block into a new contiguous rows x cols buffer / write a contiguous buffer into a sub-block. */
+/* @serves - */
 RMHIP_API int rmhip_blk_copy(rmhip_ctx* ctx, const rmhip_view_t* src, rmhip_buf* out);
+/* @serves - */
 RMHIP_API int rmhip_blk_assign(rmhip_ctx* ctx, const rmhip_view_t* dst, rmhip_buf src);
 /* C = alpha*A*B + beta*C on views (fp64 MFMA dgemm). */
+/* @serves - */
 RMHIP_API int rmhip_blk_gemm(rmhip_ctx* ctx, double alpha, const rmhip_view_t* a, const rmhip_view_t* b,
                              double beta, const rmhip_view_t* c);
 /* upper 0: B <- L^-1 B with L the unit-diagonal lower triangle of the square view `t`; 1: B <- U^-1 B, U its upper triangle with the
  * stored diagonal; 2: B <- B U^-1 (right-hand side: `b` is rows x w against a w x w triangle - the multipliers of a row block against a
  * factored diagonal tile, used by the row-partitioned multi-GPU solve). */
+/* @serves - */
 RMHIP_API int rmhip_blk_trsm(rmhip_ctx* ctx, int upper, const rmhip_view_t* t, const rmhip_view_t* b);
 /* In-place LU (host_lu.rs pivot rule) of a tall view; `ipiv_out` receives a [min(rows,cols),1] tensor
  * of LAPACK-style interchange targets (row k swapped with row ipiv[k], zero-based, relative to the
  * view).  *info = number of pivots <= 1e-12. */
+/* @serves - */
 RMHIP_API int rmhip_blk_lu(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf* ipiv_out, int* info);
 /* Apply those interchanges (in order) to every column of a view whose row 0 is the panel's row 0. */
+/* @serves - */
 RMHIP_API int rmhip_blk_swap_rows(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf ipiv);
 
 /* ---- multi-GPU collectives ------------------------------------------------------------------------- *
@@ -362,44 +464,59 @@ enum rmhip_comm_transport {
     RMHIP_COMM_RCCL = 0,     /* one rank per GPU; RCCL over xGMI / PCIe (librccl is loaded on first use)            */
     RMHIP_COMM_HOST_SHM = 1  /* ranks of ONE node staged through POSIX shared memory: several ranks may share a GPU */
 };
+/* @serves - */
 RMHIP_API int rmhip_comm_unique_id(int transport, void* id_out /* RMHIP_COMM_ID_BYTES */);
+/* @serves - */
 RMHIP_API int rmhip_comm_init(rmhip_ctx* ctx, const void* unique_id, int rank, int world);
+/* @serves - */
 RMHIP_API int rmhip_comm_destroy(rmhip_ctx* ctx);
 /* rank 0 / world 1 when the context has no communicator */
+/* @serves - */
 RMHIP_API int rmhip_comm_rank(rmhip_ctx* ctx, int* rank, int* world);
+/* @serves - */
 RMHIP_API int rmhip_comm_barrier(rmhip_ctx* ctx);
 /* In-place broadcast of a sub-block (or, with the full extent, of a whole buffer) from `root`.  async != 0: the
  * broadcast runs on the context's communication stream behind everything enqueued so far, and later calls do NOT wait
  * for it - the look-ahead of the block-cyclic solver posts the next panel's broadcast and keeps updating; call
  * rmhip_comm_wait before anything reads (or frees) the block.  Only dense blocks (whole columns) stay asynchronous;
  * a strided sub-block is packed through a staging buffer and the call stream waits for it. */
+/* @serves - */
 RMHIP_API int rmhip_comm_bcast(rmhip_ctx* ctx, const rmhip_view_t* block, int root, int async);
+/* @serves - */
 RMHIP_API int rmhip_comm_wait(rmhip_ctx* ctx);
 /* Every rank contributes its k-element f64 vector `local`; *out is a new [k, world] buffer, column r = rank r's values,
  * identical on all ranks: the caller adds the columns in rank order, so sums do not depend on a reduction tree. */
+/* @serves - */
 RMHIP_API int rmhip_comm_allgather_f64(rmhip_ctx* ctx, rmhip_buf local, rmhip_buf* out);
 /* Row-block all-gather of a column-major matrix: rank r holds rows [start_r, stop_r) x n of a rows_total x n matrix,
  * the balanced contiguous split of rows_total in units of `granule` (first ranks take the extra units, the last one the
  * ragged tail); *out is the replicated rows_total x n matrix. */
+/* @serves - */
 RMHIP_API int rmhip_comm_allgather_rows(rmhip_ctx* ctx, rmhip_buf local, size_t rows_total, size_t granule, rmhip_buf* out);
 
 /* ---- RNG  (lib.rs:1713-1728, 1772) ---------------------------------------------------------- */
 
 /* `set_rng_state`: raw 64-bit LCG state (random.rs:7-13). rmhip_rng_seed applies mix_seed
  * (random.rs:128-141) like `rng(seed)`. */
+/* @serves set_rng_state */
 RMHIP_API int rmhip_set_rng_state(rmhip_ctx* ctx, uint64_t state);
+/* @serves - */
 RMHIP_API int rmhip_get_rng_state(rmhip_ctx* ctx, uint64_t* state);
+/* @serves - */
 RMHIP_API int rmhip_rng_seed(rmhip_ctx* ctx, uint64_t seed);
 /* `random_uniform` / `random_normal`: CPU-parity stream (64-bit LCG + Box-Muller pairs,
  * random.rs:271-288,530-543); the state advances exactly as the CPU generator's does. */
+/* @serves random_uniform */
 RMHIP_API int rmhip_random_uniform(rmhip_ctx* ctx, const size_t* shape, size_t rank,
                                    rmhip_buf* out);
+/* @serves random_normal */
 RMHIP_API int rmhip_random_normal(rmhip_ctx* ctx, const size_t* shape, size_t rank,
                                   rmhip_buf* out);
 /* `stochastic_evolution` (lib.rs:1759-1769; CPU loop builtins/stats/random/stochastic_evolution.rs:10-30):
  * `steps` times { z = randn(size(state)) from the shared stream; state .*= exp(drift + scale .* z) }, as one
  * kernel that keeps the state in registers.  Advances the RNG state exactly as the CPU loop does
  * (steps * 2 * ceil(numel / 2) draws).  steps == 0 returns a copy. */
+/* @serves stochastic_evolution */
 RMHIP_API int rmhip_stochastic_evolution(rmhip_ctx* ctx, rmhip_buf state, double drift, double scale, uint32_t steps,
                                          rmhip_buf* out);
 /* Multi-GPU form (no counterpart in the reference, which has no multi-device code): `state` is the
@@ -407,6 +524,7 @@ RMHIP_API int rmhip_stochastic_evolution(rmhip_ctx* ctx, rmhip_buf state, double
  * (2 * ceil(global_numel / 2)); the caller positions the RNG at global_state + offset beforehand
  * (rmhip_set_rng_state) and the shard then consumes exactly the normals the single-device run would give
  * those elements.  The RNG state advances by steps * draws_per_step.  draws_per_step == 0 is the plain call. */
+/* @serves - */
 RMHIP_API int rmhip_stochastic_evolution_sharded(rmhip_ctx* ctx, rmhip_buf state, double drift, double scale,
                                                  uint32_t steps, uint64_t draws_per_step, rmhip_buf* out);
 
@@ -424,11 +542,14 @@ typedef struct rmhip_telemetry {
     uint64_t linsolve_count, linsolve_ns;   /* ProviderTelemetry::linsolve / mrdivide (lib.rs:1342-1344) */
     uint64_t mrdivide_count, mrdivide_ns;
 } rmhip_telemetry_t;
+/* @serves telemetry_snapshot fused_cache_counters */
 RMHIP_API int rmhip_telemetry(rmhip_ctx* ctx, rmhip_telemetry_t* out);
+/* @serves reset_telemetry */
 RMHIP_API int rmhip_reset_telemetry(rmhip_ctx* ctx);
 /* `ProviderTelemetry::solve_fallbacks` (lib.rs:1347, `ProviderFallbackStat` :1331-1335): one (reason, count) pair per
  * distinct reason a solve was handed back to the caller's CPU path ("mldivide:unsupported", "mldivide:singular",
  * "linsolve:unsupported", ...).  index >= the number of reasons returns RMHIP_ERR_NOT_FOUND. */
+/* @serves telemetry_snapshot */
 RMHIP_API int rmhip_telemetry_solve_fallback(rmhip_ctx* ctx, size_t index, char* reason, size_t cap, uint64_t* count);
 /* `ProviderTelemetry::kernel_launches` (lib.rs:1355-1356, `KernelLaunchTelemetry` :1372-1378): bounded log of recent
  * dispatches, oldest first (index 0); same kernel names and attribute keys as the reference's wgpu provider records
@@ -445,6 +566,7 @@ typedef struct rmhip_kernel_launch {
     rmhip_kernel_attr_t shape[6];
     rmhip_kernel_attr_t tuning[6];
 } rmhip_kernel_launch_t;
+/* @serves telemetry_snapshot */
 RMHIP_API int rmhip_telemetry_kernel_launch(rmhip_ctx* ctx, size_t index, rmhip_kernel_launch_t* out);
 
 /* Counters of the LU / solve machinery (no counterpart in the reference, whose GPU solve is a host round trip,
@@ -462,11 +584,14 @@ typedef struct rmhip_lu_stats {
     uint64_t svd_solves;                /* systems the LU / Gram paths refused (singular, rank deficient, ill conditioned) that were answered by the
                                            Jacobi-SVD path with the reference's tolerance rule (min(rows, cols) <= 4096) */
 } rmhip_lu_stats_t;
+/* @serves - */
 RMHIP_API int rmhip_lu_stats(rmhip_ctx* ctx, rmhip_lu_stats_t* out);
 
 /* HIP-event timing on the context stream (for bench.py's roofline leg): begin records an event,
  * end records another, synchronizes and returns the elapsed milliseconds between them. */
+/* @serves - */
 RMHIP_API int rmhip_timer_begin(rmhip_ctx* ctx);
+/* @serves - */
 RMHIP_API int rmhip_timer_end(rmhip_ctx* ctx, double* elapsed_ms);
 
 #ifdef __cplusplus

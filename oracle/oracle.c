@@ -86,7 +86,7 @@ enum {
     ORC_ASINH, ORC_ACOSH, ORC_ATANH, ORC_EXP, ORC_EXPM1, ORC_LOG, ORC_LOG2, ORC_LOG10, ORC_LOG1P,
     ORC_SQRT, ORC_ABS, ORC_SIGN, ORC_FLOOR, ORC_CEIL, ORC_ROUND, ORC_FIX, ORC_NEG, ORC_EXP2,
     ORC_HEAVISIDE, ORC_ISNAN, ORC_ISINF, ORC_ISFINITE, ORC_UPLUS, ORC_SINGLE, ORC_DOUBLE, ORC_ERF, ORC_SINC, ORC_NOT,
-    ORC_GAMMA, ORC_FACTORIAL, ORC_NEXTPOW2, ORC_GAMMALN, ORC_ERFCINV, ORC_UNARY_COUNT
+    ORC_GAMMA, ORC_FACTORIAL, ORC_NEXTPOW2, ORC_GAMMALN, ORC_ERFCINV, ORC_NAN_TO_ZERO, ORC_NOT_NAN, ORC_UNARY_COUNT
 };
 
 /* ---- special functions: crates/runmat-runtime/src/builtins/math/elementwise/{gamma,gammaln,factorial,nextpow2,
@@ -228,6 +228,10 @@ static double unary_apply(int op, double v) {
         case ORC_NEXTPOW2: { double ax = fabs(v); return ax == 0.0 ? 0.0 : ceil(log2(ax)); } /* nextpow2.rs:157-164 */
         case ORC_GAMMALN: return gammaln_nonnegative_scalar(v);
         case ORC_ERFCINV: return erfcinv_scalar(v);
+        /* map_nan_to_zero / not_nan_mask: crates/runmat-accelerate/src/backend/wgpu/shaders/nan.rs (`select(v, 0, v != v)`,
+         * `select(0, 1, !(v != v))`); the CPU omitnan paths they replace skip NaNs the same way (reduction/sum.rs:1058-1066) */
+        case ORC_NAN_TO_ZERO: return (v != v) ? 0.0 : v;
+        case ORC_NOT_NAN: return (v != v) ? 0.0 : 1.0;
         case ORC_SINC: {                          /* sinc.rs:302-311 */
             if (v == 0.0) return 1.0;
             if (isfinite(v) && v == trunc(v)) return 0.0;
@@ -1079,4 +1083,111 @@ ORC_API int orc_cumulative(const double* x, size_t pre, size_t len, size_t post,
             }
         }
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Shape / indexing hooks -- crates/runmat-accelerate/src/simple_provider.rs
+ * ---------------------------------------------------------------------------------------- */
+
+/* repmat_numeric, simple_provider.rs:2174-2240.  reps: nreps >= 1 factors; one factor = every dimension of
+ * max(rank, 2) dimensions.  Writes the tiled shape to out_shape (capacity >= max(rank, nreps, 2)) and its rank to *out_rank;
+ * `out` may be NULL to query the shape only.  Returns 1 for an empty factor list. */
+ORC_API int orc_repmat(const double* data, const size_t* shape, size_t rank_in, const size_t* reps, size_t nreps, double* out,
+                       size_t* out_shape, size_t* out_rank) {
+    if (nreps == 0) return 1;
+    const size_t orig_rank = rank_in == 0 ? 1 : rank_in;
+    size_t rank = nreps == 1 ? (orig_rank > 2 ? orig_rank : 2) : (orig_rank > nreps ? orig_rank : nreps);
+    size_t base[32], factors[32], strides[32];
+    if (rank > 32) return 2;
+    for (size_t i = 0; i < rank; ++i) base[i] = i < rank_in ? shape[i] : 1;
+    for (size_t i = 0; i < rank; ++i) factors[i] = nreps == 1 ? reps[0] : (i < nreps ? reps[i] : 1);
+    size_t new_total = 1;
+    for (size_t i = 0; i < rank; ++i) {
+        out_shape[i] = base[i] * factors[i];
+        new_total *= out_shape[i];
+    }
+    *out_rank = rank;
+    if (!out || new_total == 0) return 0;
+    size_t s = 1;
+    for (size_t i = 0; i < rank; ++i) { /* compute_strides */
+        strides[i] = s;
+        s *= base[i];
+    }
+    for (size_t idx = 0; idx < new_total; ++idx) {
+        size_t rem = idx, src = 0;
+        for (size_t d = 0; d < rank; ++d) {
+            const size_t dim_size = out_shape[d];
+            const size_t coord = rem % dim_size;
+            rem /= dim_size;
+            const size_t orig = base[d] == 0 ? 0 : coord % base[d];
+            src += orig * strides[d];
+        }
+        out[idx] = data[src];
+    }
+    return 0;
+}
+
+/* permute_data, simple_provider.rs:1645-1740 (lane factor 1).  order: zero-based permutation of 0..norder-1, norder >= rank_in.
+ * Returns 1 empty order, 2 order shorter than the rank, 3 index out of range, 4 duplicate. */
+ORC_API int orc_permute(const double* data, const size_t* shape, size_t rank_in, const size_t* order, size_t norder, double* out,
+                        size_t* out_shape) {
+    if (norder == 0) return 1;
+    if (rank_in > norder) return 2;
+    if (norder > 32) return 5;
+    int seen[32] = {0};
+    for (size_t d = 0; d < norder; ++d) {
+        if (order[d] >= norder) return 3;
+        if (seen[order[d]]) return 4;
+        seen[order[d]] = 1;
+    }
+    size_t src_shape[32], src_strides[32], dst_coords[32], src_coords[32];
+    size_t total = 1, s = 1;
+    for (size_t d = 0; d < norder; ++d) src_shape[d] = d < rank_in ? shape[d] : 1;
+    for (size_t d = 0; d < norder; ++d) {
+        src_strides[d] = s;
+        s *= src_shape[d];
+        out_shape[d] = src_shape[order[d]];
+    }
+    for (size_t d = 0; d < norder; ++d) total *= out_shape[d];
+    for (size_t idx = 0; idx < total; ++idx) {
+        size_t rem = idx;
+        for (size_t d = 0; d < norder; ++d) {
+            dst_coords[d] = rem % out_shape[d];
+            rem /= out_shape[d];
+        }
+        for (size_t d = 0; d < norder; ++d) src_coords[order[d]] = dst_coords[d];
+        size_t src = 0;
+        for (size_t d = 0; d < norder; ++d) src += src_coords[d] * src_strides[d];
+        out[idx] = data[src];
+    }
+    return 0;
+}
+
+/* gather_linear, simple_provider.rs:2609-2654: returns position + 1 of the first out-of-range index, 0 on success */
+ORC_API size_t orc_gather_linear(const double* data, size_t len, const uint32_t* indices, size_t n, double* out) {
+    for (size_t pos = 0; pos < n; ++pos) {
+        if ((size_t)indices[pos] >= len) return pos + 1;
+        out[pos] = data[indices[pos]];
+    }
+    return 0;
+}
+
+/* scatter_linear, simple_provider.rs:2656-2720: sequential, so a repeated index keeps its LAST value */
+ORC_API size_t orc_scatter_linear(double* target, size_t len, const uint32_t* indices, size_t n, const double* values) {
+    for (size_t pos = 0; pos < n; ++pos)
+        if ((size_t)indices[pos] >= len) return pos + 1;
+    for (size_t pos = 0; pos < n; ++pos) target[indices[pos]] = values[pos];
+    return 0;
+}
+
+/* linspace, simple_provider.rs:3488-3503 */
+ORC_API void orc_linspace(double start, double stop, size_t count, double* out) {
+    if (count == 0) return;
+    if (count == 1) {
+        out[0] = stop;
+        return;
+    }
+    const double step = (stop - start) / (double)(count - 1);
+    for (size_t idx = 0; idx < count; ++idx) out[idx] = start + (double)idx * step;
+    out[count - 1] = stop;
 }

@@ -19,7 +19,7 @@ UNARY = {n: i for i, n in enumerate((
     "sin", "cos", "tan", "asin", "acos", "atan", "sinh", "cosh", "tanh", "asinh", "acosh", "atanh", "exp", "expm1",
     "log", "log2", "log10", "log1p", "sqrt", "abs", "sign", "floor", "ceil", "round", "fix", "neg", "exp2",
     "heaviside", "isnan", "isinf", "isfinite", "uplus", "single", "double", "erf", "sinc", "not",
-    "gamma", "factorial", "nextpow2", "gammaln", "erfcinv"))}
+    "gamma", "factorial", "nextpow2", "gammaln", "erfcinv", "nan_to_zero", "not_nan"))}
 BINARY = {"add": 0, "sub": 1, "mul": 2, "div": 3, "pow": 4, "max": 5, "min": 6, "hypot": 7, "atan2": 8, "mod": 9,
           "rem": 10, "eq": 11, "ne": 12, "lt": 13, "le": 14, "gt": 15, "ge": 16, "and": 17, "or": 18, "xor": 19}
 
@@ -428,3 +428,84 @@ def cumulative(x, dim: int, prod: bool = False, reverse: bool = False, omitnan: 
     out = np.empty(xf.size)
     f(_p(xf), pre, red, post, int(prod), int(reverse), int(omitnan), _p(out))
     return out.reshape(x.shape, order="F")
+
+
+# ---- shape / indexing hooks (simple_provider.rs) -------------------------------------------------------------------------
+_U32P = C.POINTER(C.c_uint32)
+
+
+def repmat(x: np.ndarray, reps, shape=None) -> np.ndarray:
+    """repmat_numeric (simple_provider.rs:2174-2240); `shape` overrides x.shape (rank-1 / padded shapes numpy cannot carry)."""
+    x = np.asarray(x, dtype=np.float64)
+    shape = tuple(x.shape if shape is None else shape)
+    fx = _f(x) if shape == x.shape else np.ascontiguousarray(x.reshape(-1, order="F"))
+    reps = [int(r) for r in reps]
+    sh = (C.c_size_t * max(len(shape), 1))(*shape)
+    rp = (C.c_size_t * max(len(reps), 1))(*reps)
+    oshape = (C.c_size_t * 32)()
+    orank = C.c_size_t()
+    l = lib()
+    l.orc_repmat.restype = C.c_int
+    l.orc_repmat.argtypes = [_DP, _SZP, C.c_size_t, _SZP, C.c_size_t, _DP, _SZP, _SZP]
+    if l.orc_repmat(_p(fx), sh, len(shape), rp, len(reps), None, oshape, C.byref(orank)):
+        raise ValueError("repmat: replication factors must be specified")
+    out_shape = tuple(int(oshape[i]) for i in range(orank.value))
+    out = np.empty(int(np.prod(out_shape, dtype=np.int64)), dtype=np.float64)
+    l.orc_repmat(_p(fx), sh, len(shape), rp, len(reps), _p(out), oshape, C.byref(orank))
+    return out.reshape(out_shape, order="F")
+
+
+def permute(x: np.ndarray, order) -> np.ndarray:
+    """permute_data (simple_provider.rs:1645-1740); zero-based order."""
+    x = np.asarray(x, dtype=np.float64)
+    fx = _f(x)
+    order = [int(o) for o in order]
+    sh = (C.c_size_t * max(x.ndim, 1))(*x.shape)
+    od = (C.c_size_t * max(len(order), 1))(*order)
+    oshape = (C.c_size_t * 32)()
+    n = max(len(order), x.ndim)
+    out = np.empty(fx.size, dtype=np.float64)
+    l = lib()
+    l.orc_permute.restype = C.c_int
+    l.orc_permute.argtypes = [_DP, _SZP, C.c_size_t, _SZP, C.c_size_t, _DP, _SZP]
+    rc = l.orc_permute(_p(fx), sh, x.ndim, od, len(order), _p(out), oshape)
+    if rc:
+        raise ValueError({1: "permute: order must not be empty", 2: "permute: order length must be at least the number of dimensions",
+                          3: "permute: invalid dimension index", 4: "permute: duplicate dimension index"}.get(rc, "permute"))
+    return out.reshape(tuple(int(oshape[i]) for i in range(len(order))), order="F")
+
+
+def gather_linear(x: np.ndarray, indices, out_shape) -> np.ndarray:
+    fx = _f(np.asarray(x, dtype=np.float64))
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    out = np.empty(idx.size, dtype=np.float64)
+    l = lib()
+    l.orc_gather_linear.restype = C.c_size_t
+    l.orc_gather_linear.argtypes = [_DP, C.c_size_t, _U32P, C.c_size_t, _DP]
+    bad = l.orc_gather_linear(_p(fx), fx.size, idx.ctypes.data_as(_U32P), idx.size, _p(out))
+    if bad:
+        raise IndexError(f"gather_linear: index at position {bad - 1} out of bounds")
+    return out.reshape(tuple(out_shape), order="F")
+
+
+def scatter_linear(target: np.ndarray, indices, values) -> np.ndarray:
+    t = np.asarray(target, dtype=np.float64)
+    ft = _f(t).copy()
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    fv = _f(np.asarray(values, dtype=np.float64))
+    l = lib()
+    l.orc_scatter_linear.restype = C.c_size_t
+    l.orc_scatter_linear.argtypes = [_DP, C.c_size_t, _U32P, C.c_size_t, _DP]
+    bad = l.orc_scatter_linear(_p(ft), ft.size, idx.ctypes.data_as(_U32P), idx.size, _p(fv))
+    if bad:
+        raise IndexError(f"scatter_linear: index at position {bad - 1} out of bounds")
+    return ft.reshape(t.shape, order="F")
+
+
+def linspace(start: float, stop: float, count: int) -> np.ndarray:
+    out = np.empty(int(count), dtype=np.float64)
+    l = lib()
+    l.orc_linspace.restype = None
+    l.orc_linspace.argtypes = [C.c_double, C.c_double, C.c_size_t, _DP]
+    l.orc_linspace(float(start), float(stop), int(count), _p(out))
+    return out.reshape((1, int(count)))

@@ -420,7 +420,7 @@ int rmhip_comm_bcast(rmhip_ctx* ctx, const rmhip_view_t* v, int root, int async)
     if (root < 0 || root >= cm->world) return fail(RMHIP_ERR_INVALID, "bcast: root %d of %d", root, cm->world);
     Buffer b;
     RMHIP_TRY(c->get_raw(v->buf, &b));
-    if (b.dtype != DT_F64 || b.tview) return fail(RMHIP_ERR_UNSUPPORTED, "bcast: plain f64 buffers only");
+    if (b.dtype != DT_F64 || b.lazy()) return fail(RMHIP_ERR_UNSUPPORTED, "bcast: plain f64 buffers only");
     std::vector<size_t> s = b.shape;
     if (s.empty()) s = {1, 1};
     if (s.size() == 1) s.push_back(1);

@@ -76,6 +76,20 @@ struct Buffer {
     // tensors as f32 in HBM; arithmetic stays f64 in registers (the CPU path computes `single` arrays in f64 and
     // rounds the result, runmat-builtins lib.rs:426-436), so only loads and stores differ.
     uint8_t dtype = DT_F64;
+    // Lazy repmat view (`repmat`, lib.rs:2689-2695; tiling rule simple_provider.rs:2174-2240): `shape` is the LOGICAL tiled
+    // shape, the storage still holds the base tensor whose extents (padded with 1s to shape.size()) are `rep_base`;
+    // element (c0, c1, ...) of the view is base element (c0 % rep_base[0], c1 % rep_base[1], ...).  rmhip_binary and
+    // rmhip_fused_elementwise read views in place with stride-0 indexing - the reference's plus/minus/times/rdivide/power
+    // callers expand an operand with `repmat` only to hand it to `elem_*` and free it (times.rs:501-543) - every other
+    // consumer sees a materialised copy on first use (Context::get / get_view).  Never combined with `tview`.
+    std::vector<size_t> rep_base;
+    bool lazy() const { return tview || !rep_base.empty(); }
+    size_t stored_numel() const {  // elements the storage holds (the base of a repmat view)
+        if (rep_base.empty()) return numel;
+        size_t n = 1;
+        for (size_t e : rep_base) n *= e;
+        return n;
+    }
     double* data() const { return alloc ? alloc->ptr : nullptr; }
     float* data_f32() const { return alloc ? reinterpret_cast<float*>(alloc->ptr) : nullptr; }
 };
@@ -186,9 +200,9 @@ struct Context {
     int register_buffer(Buffer&& b, uint64_t* id);
     int new_buffer_f32(const size_t* shape, size_t rank, uint64_t* id, Buffer* out);  // f32 storage, never narrowed
     int get(uint64_t id, Buffer* out);       // f64 data, plain layout: widens f32 storage into a temporary, materialises a transpose view
-    int get_view(uint64_t id, Buffer* out);  // f64 data, `tview` may be set (matmul / syrk read views in place)
-    int get_raw(uint64_t id, Buffer* out);   // the record as stored: dtype may be DT_F32, `tview` may be set
-    int settle_view(uint64_t id);            // materialise a transpose view in its own storage type and keep it under this id
+    int get_view(uint64_t id, Buffer* out);  // f64 data, `tview` may be set (matmul / syrk read views in place); repmat views are materialised
+    int get_raw(uint64_t id, Buffer* out);   // the record as stored: dtype may be DT_F32, `tview` / `rep_base` may be set
+    int settle_view(uint64_t id);            // materialise a transpose / repmat view in its own storage type and keep it under this id
     int narrow(uint64_t id);                 // replace an f64 buffer's storage by its f32 rounding
     void finish_outputs(size_t mark);        // narrow everything new_buffer created since `mark` (precision 32 only)
     int ensure_scratch(size_t bytes);
@@ -250,6 +264,18 @@ int launch_binary_bcast(Context* c, int op, const double* a, const double* b, do
                         size_t n, const BroadcastDesc& d);
 int launch_binary_bcast_f32(Context* c, int op, const float* a, const float* b, float* out, size_t n,
                             const BroadcastDesc& d);
+
+// tensor_ops.hip: out[idx] = src[sum_d map_d(c_d) * stride[d]] with (c_0, c_1, ...) the column-major coordinates of idx in
+// `shape`; map_d(c) = (off[d] + c) % mod[d], or off[d] - c when rev[d] (flip).  One kernel family behind repmat
+// (mod = base extent), permute (permuted strides), circshift (off) and flip.  rank <= 8.
+struct IndexMap {
+    int rank = 0;
+    uint64_t shape[8], stride[8], off[8], mod[8];
+    uint8_t rev[8];
+};
+int launch_index_copy(Context* c, const double* src, double* dst, size_t n, const IndexMap& m);
+int launch_index_copy_f32(Context* c, const float* src, float* dst, size_t n, const IndexMap& m);
+int materialize_repmat(Context* c, const Buffer& view, void* dst);  // tile a repmat view's base into dst (the view's storage type)
 
 // reductions (reduce_kernels.hip)
 int launch_reduce_all(Context* c, int op, int nan_mode, const double* x, size_t n, double* out);

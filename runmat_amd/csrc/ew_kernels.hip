@@ -187,6 +187,8 @@ __device__ __forceinline__ double unary_op(double v) {
         case RMHIP_NEXTPOW2: return rm_nextpow2(v);
         case RMHIP_GAMMALN: return rm_gammaln(v);
         case RMHIP_ERFCINV: return rm_erfcinv(v);
+        case RMHIP_NAN_TO_ZERO: return rm_isnan(v) ? 0.0 : v;  // backend/wgpu/shaders/nan.rs: select(v, 0, v != v)
+        case RMHIP_NOT_NAN: return rm_isnan(v) ? 0.0 : 1.0;
         default: return v;
     }
 }

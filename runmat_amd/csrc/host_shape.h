@@ -30,6 +30,96 @@ inline bool padded_strides(const std::vector<size_t>& shape_in, const size_t* ou
     return true;
 }
 
+// Operand of a broadcasting elementwise launch: its logical shape and, for a lazy repmat view (common.h `Buffer::rep_base`),
+// the extents of the base tensor the storage really holds (same rank as `shape`; empty for a plain tensor).
+struct OperandDims {
+    std::vector<size_t> shape;
+    std::vector<size_t> base;
+};
+
+// Strides of every operand over a REFINED output shape, so that repmat views are read in place: an output dimension of
+// extent E that a view tiles from a base extent b (1 < b < E) is split into [b, E / b] - column-major, coordinate
+// c = c_lo + b * c_hi - and the view gets strides (s, 0) there while a plain operand gets (s, s * b); a pure broadcast
+// (b == 1) is stride 0, as for an extent-1 operand.  Shapes are front-padded to `rank` exactly like padded_strides.
+// Returns 0 on success; 1 when operand *bad does not broadcast to `out`; 2 when operand *bad tiles a dimension that
+// another view already splits differently (the caller materialises it and retries).
+inline int refined_strides(const std::vector<OperandDims>& ops, const size_t* out, size_t rank, std::vector<uint64_t>* rshape,
+                           std::vector<std::vector<uint64_t>>* strides, size_t* bad) {
+    std::vector<OperandDims> nd(ops.size());
+    for (size_t k = 0; k < ops.size(); ++k) {
+        std::vector<size_t> shape = ops[k].shape, base = ops[k].base;
+        const bool view = !base.empty();
+        while (shape.size() > rank && shape.back() == 1) {
+            shape.pop_back();
+            if (view) base.pop_back();
+        }
+        while (shape.size() > rank && shape.front() == 1) {
+            shape.erase(shape.begin());
+            if (view) base.erase(base.begin());
+        }
+        if (shape.size() > rank) {
+            *bad = k;
+            return 1;
+        }
+        const size_t pad = rank - shape.size();
+        nd[k].shape.assign(rank, 1);
+        for (size_t d = 0; d < shape.size(); ++d) nd[k].shape[pad + d] = shape[d];
+        if (view) {
+            nd[k].base.assign(rank, 1);
+            for (size_t d = 0; d < base.size(); ++d) nd[k].base[pad + d] = base[d];
+        }
+    }
+    std::vector<size_t> split(rank, 1);
+    for (size_t k = 0; k < ops.size(); ++k)
+        for (size_t d = 0; d < rank; ++d) {
+            const size_t e = nd[k].shape[d];
+            if (e != 1 && e != out[d]) {
+                *bad = k;
+                return 1;
+            }
+            if (nd[k].base.empty() || e == 1) continue;
+            const size_t b = nd[k].base[d];
+            if (b == e || b == 1) continue;
+            if (split[d] == 1) split[d] = b;
+            else if (split[d] != b) {
+                *bad = k;
+                return 2;
+            }
+        }
+    rshape->clear();
+    for (size_t d = 0; d < rank; ++d) {
+        if (split[d] > 1) {
+            rshape->push_back(split[d]);
+            rshape->push_back(out[d] / split[d]);
+        } else {
+            rshape->push_back(out[d]);
+        }
+    }
+    strides->assign(ops.size(), std::vector<uint64_t>());
+    for (size_t k = 0; k < ops.size(); ++k) {
+        std::vector<uint64_t>& st = (*strides)[k];
+        const bool view = !nd[k].base.empty();
+        uint64_t s = 1;
+        for (size_t d = 0; d < rank; ++d) {
+            const size_t e = nd[k].shape[d];
+            const size_t b = view ? nd[k].base[d] : e;  // extent the storage holds along d
+            uint64_t lo, hi;                            // strides of the two halves of a split dimension
+            if (e == 1 || b == 1) lo = hi = 0;          // broadcast operand, or a view replicating one element
+            else if (b == e) {
+                lo = s;
+                hi = s * split[d];
+            } else {  // tiled: b == split[d]
+                lo = s;
+                hi = 0;
+            }
+            st.push_back(lo);
+            if (split[d] > 1) st.push_back(hi);
+            s *= b;
+        }
+    }
+    return 0;
+}
+
 // Collapse dims: drop extent-1 dims, merge dim d+1 into d when every operand is contiguous across
 // the boundary (stride[d+1] == stride[d]*shape[d]) or broadcast on both (0 and 0).
 inline void collapse(std::vector<uint64_t>* shape, std::vector<std::vector<uint64_t>>* strides) {

@@ -155,6 +155,10 @@ int Context::get_raw(uint64_t id, Buffer* out) {
 
 int Context::get_view(uint64_t id, Buffer* out) {
     RMHIP_TRY(get_raw(id, out));
+    if (!out->rep_base.empty()) {  // a consumer that cannot index a repmat view: tile it once, keep the copy under this id
+        RMHIP_TRY(settle_view(id));
+        RMHIP_TRY(get_raw(id, out));
+    }
     if (out->dtype == DT_F64) return RMHIP_OK;
     RMHIP_TRACEF("widen id %llu numel %zu tview %d", (unsigned long long)id, out->numel, (int)out->tview);
     // f32 storage read by an f64 kernel: widen into a temporary that lives as long as the caller's Buffer copy
@@ -169,6 +173,20 @@ int Context::get_view(uint64_t id, Buffer* out) {
 int Context::settle_view(uint64_t id) {
     Buffer raw;
     RMHIP_TRY(get_raw(id, &raw));
+    if (!raw.rep_base.empty()) {
+        RMHIP_TRACEF("materialise repmat view id %llu numel %zu (base %zu)", (unsigned long long)id, raw.numel, raw.stored_numel());
+        std::shared_ptr<Allocation> tiled;
+        const size_t words = raw.dtype == DT_F32 ? (raw.numel + 1) / 2 : raw.numel;
+        RMHIP_TRY(alloc_device(words ? words : 1, &tiled));
+        RMHIP_TRY(materialize_repmat(this, raw, tiled->ptr));
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = table.find(id);
+        if (it != table.end() && !it->second.rep_base.empty() && it->second.alloc == raw.alloc) {
+            it->second.alloc = tiled;  // `raw` still references the base storage: nothing is released under the lock
+            it->second.rep_base.clear();
+        }
+        return RMHIP_OK;
+    }
     if (!raw.tview) return RMHIP_OK;
     const size_t R = raw.shape[0], C = raw.shape[1];  // logical R x C, storage = base C x R
     RMHIP_TRACEF("materialise view id %llu %zux%zu (%s storage)", (unsigned long long)id, R, C, raw.dtype == DT_F32 ? "f32" : "f64");
@@ -198,6 +216,7 @@ int Context::narrow(uint64_t id) {
         b = it->second;
     }
     if (b.dtype != DT_F64 || !b.alloc || b.alloc->external) return RMHIP_OK;
+    if (!b.rep_base.empty()) return RMHIP_OK;  // a view of somebody else's storage: not this entry point's to convert
     RMHIP_TRACEF("narrow id %llu numel %zu", (unsigned long long)id, b.numel);
     std::shared_ptr<Allocation> slim;
     RMHIP_TRY(alloc_device((b.numel + 1) / 2 ? (b.numel + 1) / 2 : 1, &slim));
@@ -220,7 +239,7 @@ void Context::finish_outputs(size_t mark) {
 int Context::get(uint64_t id, Buffer* out) {
     // a consumer that cannot address a transposed operand: materialise once and keep the plain copy under this id
     RMHIP_TRY(get_raw(id, out));
-    if (out->tview) RMHIP_TRY(settle_view(id));
+    if (out->lazy()) RMHIP_TRY(settle_view(id));
     return get_view(id, out);
 }
 
@@ -556,7 +575,7 @@ int rmhip_reshape(rmhip_ctx* ctx, rmhip_buf id, const size_t* shape, size_t rank
     // return the SAME buffer_id, and callers such as the reshape builtin consume the source handle without freeing
     // it - a second table entry would orphan the first and pin the allocation.  A transpose view is materialised first
     // (the bytes of a view are those of its base matrix).
-    if (b.tview) RMHIP_TRY(c->settle_view(id));
+    if (b.lazy()) RMHIP_TRY(c->settle_view(id));
     {
         std::lock_guard<std::mutex> lk(c->mu);
         auto it = c->table.find(id);
@@ -587,6 +606,9 @@ void* rmhip_device_ptr(rmhip_ctx* ctx, rmhip_buf id) {
     DeviceGuard _dg(&ctx->c);
     Buffer b;
     if (ctx->c.get_raw(id, &b) != RMHIP_OK) return nullptr;
+    if (b.dtype == DT_F32 && !b.rep_base.empty()) {  // tile first: the pointer must address numel elements
+        if (ctx->c.settle_view(id) != RMHIP_OK || ctx->c.get_raw(id, &b) != RMHIP_OK) return nullptr;
+    }
     if (b.dtype == DT_F32) return b.tview ? nullptr : (void*)b.data();  // the f32 storage itself (rmhip_buffer_bits says which)
     if (ctx->c.get(id, &b) != RMHIP_OK) return nullptr;
     return b.data();

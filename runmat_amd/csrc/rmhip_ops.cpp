@@ -99,14 +99,50 @@ static int lu_solve_padded(Context* c, const double* LU, size_t n, size_t np, si
 int get_operand(Context* c, rmhip_buf id, Buffer* out, bool* native) {
     if (*native) {
         RMHIP_TRY(c->get_raw(id, out));
-        if (out->dtype == DT_F32 && out->tview) {  // materialise the view once, as f32
+        if (out->dtype == DT_F32 && out->lazy()) {  // materialise the view once, as f32
             RMHIP_TRY(c->settle_view(id));
             RMHIP_TRY(c->get_raw(id, out));
         }
-        if (out->dtype == DT_F32 && !out->tview) return RMHIP_OK;
+        if (out->dtype == DT_F32 && !out->lazy()) return RMHIP_OK;
         *native = false;
     }
     return c->get(id, out);
+}
+
+// Operand of a broadcasting elementwise launch (rmhip_binary, rmhip_fused_elementwise): as get_operand, but a repmat view
+// stays a view - the launch indexes its base with stride 0 (host_shape.h refined_strides).
+int get_bcast_operand(Context* c, rmhip_buf id, Buffer* out, bool* native) {
+    RMHIP_TRY(c->get_raw(id, out));
+    if (out->tview) {
+        RMHIP_TRY(c->settle_view(id));
+        RMHIP_TRY(c->get_raw(id, out));
+    }
+    if (*native) {
+        if (out->dtype == DT_F32) return RMHIP_OK;
+        *native = false;
+    }
+    if (out->dtype == DT_F64) return RMHIP_OK;
+    return c->get(id, out);  // f32 storage read by the f64 variant: tiled (if a view) and widened
+}
+
+// refined_strides over Buffers; an operand whose tiling conflicts with another view's is materialised and the preparation repeated
+int bcast_prepare(Context* c, const rmhip_buf* ids, std::vector<Buffer>* in, bool f32, const size_t* out_shape, size_t rank,
+                  std::vector<uint64_t>* rshape, std::vector<std::vector<uint64_t>>* strides, const char* what) {
+    for (size_t attempt = 0; attempt <= in->size(); ++attempt) {
+        std::vector<OperandDims> ops(in->size());
+        for (size_t k = 0; k < in->size(); ++k) {
+            ops[k].shape = (*in)[k].shape;
+            ops[k].base = (*in)[k].rep_base;
+        }
+        size_t bad = 0;
+        const int rc = refined_strides(ops, out_shape, rank, rshape, strides, &bad);
+        if (rc == 0) return RMHIP_OK;
+        if (rc == 1) return fail(RMHIP_ERR_SHAPE, "%s: input %zu does not broadcast to the output shape", what, bad);
+        RMHIP_TRY(c->settle_view(ids[bad]));
+        if (f32) RMHIP_TRY(c->get_raw(ids[bad], &(*in)[bad]));
+        else RMHIP_TRY(c->get(ids[bad], &(*in)[bad]));
+    }
+    return fail(RMHIP_ERR_UNSUPPORTED, "%s: could not reconcile the operands' tilings", what);
 }
 
 // Precision 32: may this product run on the f32 matrix cores (sgemm.hip)?  RMHIP_F32_MATMUL=f64 keeps the widen ->
@@ -223,12 +259,14 @@ int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf*
     // (externally wrapped f64 memory, transpose views) runs the f64 variant on widened copies
     bool f32 = c->precision == 32;
     size_t tried = 0;  // when the native attempt gives up at operand tried - 1, that one already holds its f64 copy
-    for (; tried < n_in && f32; ++tried) RMHIP_TRY(get_operand(c, inputs[tried], &in[tried], &f32));
-    for (size_t k = 0; k < n_in; ++k) {
-        if (!f32 && k + 1 != tried) RMHIP_TRY(c->get(inputs[k], &in[k]));
-        if (!padded_strides(in[k].shape, out_shape, rank, &strides[k]))
-            return fail(RMHIP_ERR_SHAPE, "fused_elementwise: input %zu does not broadcast to the output shape", k);
-    }
+    // repmat views are read in place (stride 0 over their base)
+    for (; tried < n_in && f32; ++tried) RMHIP_TRY(get_bcast_operand(c, inputs[tried], &in[tried], &f32));
+    for (size_t k = 0; k < n_in; ++k)
+        if (!f32 && (k + 1 != tried || in[k].dtype == DT_F32)) {
+            bool no = false;
+            RMHIP_TRY(get_bcast_operand(c, inputs[k], &in[k], &no));
+        }
+    RMHIP_TRY(bcast_prepare(c, inputs, &in, f32, out_shape, rank, &oshape, &strides, "fused_elementwise"));
     RMHIP_TRACEF("fused_elementwise: operands ready (f32 storage path %d)", (int)f32);
     collapse(&oshape, &strides);
     const size_t crank = oshape.size();
@@ -497,8 +535,9 @@ int rmhip_binary(rmhip_ctx* ctx, int op, rmhip_buf a, rmhip_buf b, rmhip_buf* ou
     if (op < 0 || op >= RMHIP_BINARY_OP_COUNT) return fail(RMHIP_ERR_UNSUPPORTED, "binary op %d not supported by provider", op);
     Buffer ab, bb, ob;
     bool f32 = c->precision == 32;
-    RMHIP_TRY(get_operand(c, a, &ab, &f32));
-    RMHIP_TRY(get_operand(c, b, &bb, &f32));
+    // repmat views stay views: the reference's callers expand with `repmat`, call `elem_*`, free (times.rs:501-543)
+    RMHIP_TRY(get_bcast_operand(c, a, &ab, &f32));
+    RMHIP_TRY(get_bcast_operand(c, b, &bb, &f32));
     if (!f32 && ab.dtype == DT_F32) RMHIP_TRY(c->get(a, &ab));  // b turned out not to be plain f32 storage
     // broadcast_shapes (broadcast.rs:8-47): front-pad, extents equal or 1
     const size_t rank = std::max(ab.shape.size(), bb.shape.size());
@@ -516,14 +555,21 @@ int rmhip_binary(rmhip_ctx* ctx, int op, rmhip_buf a, rmhip_buf b, rmhip_buf* ou
     if (f32) RMHIP_TRY(c->new_buffer_f32(oshape.data(), rank, out, &ob));
     else RMHIP_TRY(c->new_buffer(oshape.data(), rank, out, &ob));
     int rc;
-    if (ab.numel == ob.numel && bb.numel == ob.numel) {
+    if (ab.numel == ob.numel && bb.numel == ob.numel && ab.rep_base.empty() && bb.rep_base.empty()) {
         rc = f32 ? launch_binary_same_f32(c, op, ab.data_f32(), bb.data_f32(), ob.data_f32(), ob.numel)
                  : launch_binary_same(c, op, ab.data(), bb.data(), ob.data(), ob.numel);
     } else {
-        std::vector<std::vector<uint64_t>> strides(2);
-        std::vector<uint64_t> os(oshape.begin(), oshape.end());
-        padded_strides(ab.shape, oshape.data(), rank, &strides[0]);
-        padded_strides(bb.shape, oshape.data(), rank, &strides[1]);
+        std::vector<std::vector<uint64_t>> strides;
+        std::vector<uint64_t> os;
+        const rmhip_buf ids[2] = {a, b};
+        std::vector<Buffer> in = {ab, bb};
+        rc = bcast_prepare(c, ids, &in, f32, oshape.data(), rank, &os, &strides, "binary");
+        if (rc) {
+            rmhip_free(ctx, *out);
+            return rc;
+        }
+        ab = in[0];
+        bb = in[1];
         collapse(&os, &strides);
         if (os.size() > 8) {
             rmhip_free(ctx, *out);
@@ -794,6 +840,14 @@ int rmhip_matmul(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
         Buffer ra, rb;
         RMHIP_TRY(c->get_raw(a, &ra));
         RMHIP_TRY(c->get_raw(b, &rb));
+        if (!ra.rep_base.empty()) {
+            RMHIP_TRY(c->settle_view(a));
+            RMHIP_TRY(c->get_raw(a, &ra));
+        }
+        if (!rb.rep_base.empty()) {
+            RMHIP_TRY(c->settle_view(b));
+            RMHIP_TRY(c->get_raw(b, &rb));
+        }
         if (ra.dtype == DT_F32 && rb.dtype == DT_F32 && ra.shape.size() == 2 && rb.shape.size() == 2) {
             if (ra.tview && rb.tview) {
                 RMHIP_TRY(c->settle_view(b));
@@ -1009,7 +1063,7 @@ int rmhip_matmul_epilogue(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, const rmhip_
     Buffer dg_raw;  // diag_output is written IN PLACE: f32 storage gets the widened copy narrowed back after the launch
     if (ep->diag_output) {
         RMHIP_TRY(c->get_raw(ep->diag_output, &dg_raw));
-        if (dg_raw.tview) return fail(RMHIP_ERR_UNSUPPORTED, "matmul_epilogue: diag_output must not be a transpose view");
+        if (dg_raw.lazy()) return fail(RMHIP_ERR_UNSUPPORTED, "matmul_epilogue: diag_output must not be a transpose / repmat view");
         RMHIP_TRY(c->get(ep->diag_output, &dg));
         const size_t expected = m < n ? m : n;
         if (dg.numel < expected)  // simple_provider.rs:7790-7799
@@ -1340,6 +1394,10 @@ int rmhip_transpose(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out) {
     Buffer ab;
     RMHIP_TRY(c->get_raw(a, &ab));  // the alias keeps the operand's storage type
     if (ab.shape.size() > 2) return fail(RMHIP_ERR_UNSUPPORTED, "transpose: only 2D supported");
+    if (!ab.rep_base.empty()) {  // a view of a repmat view: tile first
+        RMHIP_TRY(c->settle_view(a));
+        RMHIP_TRY(c->get_raw(a, &ab));
+    }
     const std::vector<size_t> as = normalize_matrix_shape(ab.shape);
     // No data moves: the result aliases the operand's storage as a transpose view (a view of a view is the plain
     // base again; a vector's transpose has the same memory layout).  RMHIP_EAGER_TRANSPOSE=1 materialises at once.

@@ -21,16 +21,19 @@ import numpy as np
 
 from . import _lib
 
-# op codes of include/rmhip.h
-BINARY_OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3, "pow": 4, "max": 5, "min": 6, "hypot": 7, "atan2": 8,
-              "mod": 9, "rem": 10, "eq": 11, "ne": 12, "lt": 13, "le": 14, "gt": 15, "ge": 16, "and": 17, "or": 18, "xor": 19}
-UNARY_OPS = {n: i for i, n in enumerate((
-    "sin", "cos", "tan", "asin", "acos", "atan", "sinh", "cosh", "tanh", "asinh", "acosh", "atanh", "exp", "expm1",
-    "log", "log2", "log10", "log1p", "sqrt", "abs", "sign", "floor", "ceil", "round", "fix", "neg", "exp2",
-    "heaviside", "isnan", "isinf", "isfinite", "uplus", "single", "double", "erf", "sinc", "not",
-    "gamma", "factorial", "nextpow2", "gammaln", "erfcinv"))}
-SCALAR_OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3, "rsub": 4, "rdiv": 5, "max": 6, "min": 7}
-REDUCE_OPS = {"sum": 0, "mean": 1, "min": 2, "max": 3, "prod": 4}
+# op codes: the enums of include/rmhip.h, via the generated table (runmat_amd/_abi.py)
+def _ops(enum: str, prefix: str) -> dict:
+    return {k[len(prefix):].lower(): v for k, v in _lib.ENUMS[enum].items() if not k.endswith("_COUNT")}
+
+
+BINARY_OPS = _ops("rmhip_binary_op", "RMHIP_")
+UNARY_OPS = _ops("rmhip_unary_op", "RMHIP_")
+SCALAR_OPS = _ops("rmhip_scalar_op", "RMHIP_S")
+REDUCE_OPS = _ops("rmhip_reduce_op", "RMHIP_R")
+# trait method -> unary op code name (lib.rs:2077-2331, 2053-2068, 2980-2988)
+UNARY_HOOKS = {f"unary_{n}": n for n in UNARY_OPS}  # unary_sin ... (plus unary_<op> for every op code without a trait method of that name)
+UNARY_HOOKS.update({"unary_pow2": "exp2", "logical_not": "not", "logical_isnan": "isnan", "logical_isinf": "isinf",
+                    "logical_isfinite": "isfinite", "map_nan_to_zero": "nan_to_zero", "not_nan_mask": "not_nan"})
 
 
 class ProviderError(RuntimeError):
@@ -343,7 +346,6 @@ class HipProvider:
     def logical_and(self, a, b): return self._binary("and", a, b)
     def logical_or(self, a, b): return self._binary("or", a, b)
     def logical_xor(self, a, b): return self._binary("xor", a, b)
-    def logical_not(self, a): return self._unary("not", a)
 
     def scalar_add(self, a, s): return self._scalar("add", a, s)
     def scalar_sub(self, a, s): return self._scalar("sub", a, s)
@@ -354,12 +356,62 @@ class HipProvider:
     def scalar_max(self, a, s): return self._scalar("max", a, s)
     def scalar_min(self, a, s): return self._scalar("min", a, s)
 
-    def __getattr__(self, name: str):
-        # unary_sin, unary_cos, ... (lib.rs:2077-2331)
-        if name.startswith("unary_") and name[6:] in UNARY_OPS:
-            op = name[6:]
-            return lambda a: self._unary(op, a)
-        raise AttributeError(name)
+    # unary_sin, unary_cos, ... logical_not / isnan / isinf / isfinite, map_nan_to_zero, not_nan_mask (lib.rs:2077-2331, 2053-2068,
+    # 2980-2988) are attached below the class from UNARY_HOOKS: one method per trait hook, all through rmhip_unary.
+
+    # -- shape / indexing hooks -------------------------------------------------------------------
+    def repmat(self, a: GpuTensorHandle, reps: Sequence[int]) -> GpuTensorHandle:
+        """`repmat` (lib.rs:2689-2695).  The result is a view of `a`'s storage; elem_* / fused_elementwise read it in
+        place, anything else materialises it on first use (include/rmhip.h)."""
+        arr, n = _shape_array(reps)
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_repmat(self._ctx, self._id(a), arr, n, C.byref(out)))
+        return self._handle(out.value)
+
+    def permute(self, a: GpuTensorHandle, order: Sequence[int]) -> GpuTensorHandle:
+        """`permute` (lib.rs:2579-2585): `order` is zero-based."""
+        arr, n = _shape_array(order)
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_permute(self._ctx, self._id(a), arr, n, C.byref(out)))
+        return self._handle(out.value)
+
+    def fill_like(self, prototype: GpuTensorHandle, value: float) -> GpuTensorHandle:
+        """`fill_like` (lib.rs:1524-1545)."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_fill_like(self._ctx, self._id(prototype), float(value), C.byref(out)))
+        return self._handle(out.value, prototype.shape)
+
+    def zeros_like(self, prototype): return self.fill_like(prototype, 0.0)  # lib.rs:1497
+    def ones_like(self, prototype): return self.fill_like(prototype, 1.0)   # lib.rs:1547
+
+    def read_scalar(self, h: GpuTensorHandle, linear_index: int) -> float:
+        """`read_scalar` (lib.rs:1463): zero-based column-major index; out of range raises."""
+        if linear_index < 0:
+            raise ProviderError(_lib.ERR_INVALID, "read_scalar: negative index")
+        out = C.c_double()
+        self._check(self._lib.rmhip_read_scalar(self._ctx, self._id(h), int(linear_index), C.byref(out)))
+        return out.value
+
+    def gather_linear(self, source: GpuTensorHandle, indices: Sequence[int], output_shape: Sequence[int]) -> GpuTensorHandle:
+        """`gather_linear` (lib.rs:1423-1430): zero-based u32 linear indices."""
+        idx = np.ascontiguousarray(indices, dtype=np.uint32)
+        sh, rank = _shape_array(output_shape)
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_gather_linear(self._ctx, self._id(source), idx.ctypes.data_as(C.POINTER(C.c_uint32)), idx.size, sh,
+                                                  rank, C.byref(out)))
+        return self._handle(out.value, output_shape)
+
+    def scatter_linear(self, target: GpuTensorHandle, indices: Sequence[int], values: GpuTensorHandle) -> None:
+        """`scatter_linear` (lib.rs:1438-1445): updates `target` in place."""
+        idx = np.ascontiguousarray(indices, dtype=np.uint32)
+        self._check(self._lib.rmhip_scatter_linear(self._ctx, self._id(target), idx.ctypes.data_as(C.POINTER(C.c_uint32)), idx.size,
+                                                   self._id(values)))
+
+    def linspace(self, start: float, stop: float, count: int) -> GpuTensorHandle:
+        """`linspace` (lib.rs:1887) -> [1, count]."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_linspace(self._ctx, float(start), float(stop), int(count), C.byref(out)))
+        return self._handle(out.value, (1, int(count)))
 
     # -- reductions -----------------------------------------------------------------------------
     def _reduce(self, op: str, a: GpuTensorHandle, dim: int, omitnan: bool = False) -> GpuTensorHandle:
@@ -733,3 +785,15 @@ def wgsl_compile_check(shader: str, kind: str = "elementwise") -> None:
     rc = lib.rmhip_wgsl_compile_check(shader.encode(), 0 if kind == "elementwise" else 1)
     if rc != _lib.OK:
         raise ProviderError(rc, _lib.last_error())
+
+
+def _attach_unary_hooks() -> None:
+    for name, op in UNARY_HOOKS.items():
+        def hook(self, a, _op=op):
+            return self._unary(_op, a)
+        hook.__name__ = name
+        hook.__doc__ = f"`{name}` through rmhip_unary(RMHIP_{op.upper()})"
+        setattr(HipProvider, name, hook)
+
+
+_attach_unary_hooks()
