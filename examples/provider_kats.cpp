@@ -60,6 +60,26 @@ int main() {
         auto mom = p.reduce_moments_nd(a, {0});
         ok = ok && near(p.download(mom.first).data, {1.5, 3.5}, 1e-15) && near(p.download(mom.second).data, {2.5, 12.5}, 1e-15);
         {
+            // the unfused implicit-expansion sequence of times.rs:501-543: repmat each operand, elem_mul, free the expansions
+            auto col = p.upload({1, 2, 3, 4}, {4, 1});
+            auto row = p.upload({10, 20, 30}, {1, 3});
+            auto ce = p.repmat(col, {1, 3}), re = p.repmat(row, {4, 1});
+            auto prod = p.elem_mul(ce, re);
+            p.free(ce);
+            p.free(re);
+            ok = ok && prod.shape == std::vector<size_t>{4, 3} &&
+                 eq(p.download(prod).data, {10, 20, 30, 40, 20, 40, 60, 80, 30, 60, 90, 120});
+            // repmat.rs:1044-1060 repmat_gpu_roundtrip; permute.rs:784-792; linspace.rs:495-512; read_scalar / gather_linear
+            ok = ok && eq(p.download(p.repmat(p.upload({1, 2}, {2, 1}), {2})).data, {1, 2, 1, 2, 1, 2, 1, 2});
+            ok = ok && eq(p.download(p.permute(p.upload({1, 99, 3, 4}, {2, 2}), {1, 0})).data, {1, 3, 99, 4});
+            ok = ok && near(p.download(p.linspace(0.0, 1.0, 5)).data, {0.0, 0.25, 0.5, 0.75, 1.0}, 1e-12);
+            ok = ok && p.read_scalar(prod, 5) == 40.0 && eq(p.download(p.gather_linear(prod, {11, 0, 6}, {3, 1})).data, {120, 10, 60});
+            ok = ok && eq(p.download(p.zeros_like(prod)).data, {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0});
+            const double nan = std::nan("");
+            ok = ok && eq(p.download(p.map_nan_to_zero(p.upload({1, nan, 3}, {3, 1}))).data, {1, 0, 3}) &&
+                 eq(p.download(p.not_nan_mask(p.upload({1, nan, 3}, {3, 1}))).data, {1, 0, 1});
+        }
+        {
             // ProviderPrecision::F32 (lib.rs:815-818): host views stay f64, storage is f32, results round once
             rmhip::HipProvider q(0, 32);
             ok = ok && std::string(q.precision()) == "F32";

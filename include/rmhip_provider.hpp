@@ -86,6 +86,17 @@ public:
         check(rmhip_telemetry(ctx_, &t));
         return t;
     }
+    std::string device_info() const {  // lib.rs:1390: the one-line description
+        const rmhip_device_info_t i = device_info_struct();
+        return std::string(i.name) + " (" + i.arch + ", " + i.backend + ")";
+    }
+    uint32_t default_reduction_workgroup_size() const { return device_info_struct().reduction_workgroup_size; }  // lib.rs:3048
+    uint32_t two_pass_threshold() const { return device_info_struct().two_pass_threshold; }                      // lib.rs:3053
+    std::pair<uint64_t, uint64_t> fused_cache_counters() const {  // (hits, misses), lib.rs:3014
+        const rmhip_telemetry_t t = telemetry_snapshot();
+        return {t.fusion_cache_hits, t.fusion_cache_misses};
+    }
+    void reset_telemetry() const { check(rmhip_reset_telemetry(ctx_)); }  // lib.rs:3046
     rmhip_lu_stats_t lu_stats() const {  // solve-path factorisations, pivot-growth refactorisations, time-outs
         rmhip_lu_stats_t st;
         check(rmhip_lu_stats(ctx_, &st));
@@ -114,6 +125,50 @@ public:
     }
     GpuTensorHandle zeros(const std::vector<size_t>& shape) const { return fill(shape, 0.0); }
     GpuTensorHandle ones(const std::vector<size_t>& shape) const { return fill(shape, 1.0); }
+    GpuTensorHandle fill_like(const GpuTensorHandle& prototype, double value) const {  // lib.rs:1524
+        uint64_t id = 0;
+        check(rmhip_fill_like(ctx_, own(prototype), value, &id));
+        return make(id, prototype.shape);
+    }
+    GpuTensorHandle zeros_like(const GpuTensorHandle& prototype) const { return fill_like(prototype, 0.0); }  // lib.rs:1497
+    GpuTensorHandle ones_like(const GpuTensorHandle& prototype) const { return fill_like(prototype, 1.0); }   // lib.rs:1547
+    // lib.rs:2676-2684: the SAME buffer id with a new shape
+    GpuTensorHandle reshape(const GpuTensorHandle& h, const std::vector<size_t>& shape) const {
+        uint64_t id = 0;
+        check(rmhip_reshape(ctx_, own(h), shape.data(), shape.size(), &id));
+        return make(id, shape);
+    }
+
+    // ---- shape / indexing hooks (lib.rs:2689, 2579, 1463, 1423-1445, 1887) ----
+    GpuTensorHandle repmat(const GpuTensorHandle& a, const std::vector<size_t>& reps) const {  // a view; elem_* read it in place
+        uint64_t id = 0;
+        check(rmhip_repmat(ctx_, own(a), reps.data(), reps.size(), &id));
+        return with_shape(id);
+    }
+    GpuTensorHandle permute(const GpuTensorHandle& a, const std::vector<size_t>& order_zero_based) const {
+        uint64_t id = 0;
+        check(rmhip_permute(ctx_, own(a), order_zero_based.data(), order_zero_based.size(), &id));
+        return with_shape(id);
+    }
+    double read_scalar(const GpuTensorHandle& h, size_t linear_index) const {
+        double v = 0.0;
+        check(rmhip_read_scalar(ctx_, own(h), linear_index, &v));
+        return v;
+    }
+    GpuTensorHandle gather_linear(const GpuTensorHandle& source, const std::vector<uint32_t>& indices,
+                                  const std::vector<size_t>& output_shape) const {
+        uint64_t id = 0;
+        check(rmhip_gather_linear(ctx_, own(source), indices.data(), indices.size(), output_shape.data(), output_shape.size(), &id));
+        return make(id, output_shape);
+    }
+    void scatter_linear(const GpuTensorHandle& target, const std::vector<uint32_t>& indices, const GpuTensorHandle& values) const {
+        check(rmhip_scatter_linear(ctx_, own(target), indices.data(), indices.size(), own(values)));
+    }
+    GpuTensorHandle linspace(double start, double stop, size_t count) const {
+        uint64_t id = 0;
+        check(rmhip_linspace(ctx_, start, stop, count, &id));
+        return make(id, {1, count});
+    }
 
     // ---- fused kernels (lib.rs:2946-3008) ----
     GpuTensorHandle fused_elementwise(const std::string& shader, const std::vector<GpuTensorHandle>& inputs,
@@ -184,6 +239,19 @@ public:
     GpuTensorHandle unary_erfcinv(const GpuTensorHandle& a) const { return unary(RMHIP_ERFCINV, a); }    // lib.rs:2107
     GpuTensorHandle unary_factorial(const GpuTensorHandle& a) const { return unary(RMHIP_FACTORIAL, a); }  // lib.rs:2113
     GpuTensorHandle unary_nextpow2(const GpuTensorHandle& a) const { return unary(RMHIP_NEXTPOW2, a); }  // lib.rs:2319
+#define RMHIP_UNARY_HOOK(name, code) \
+    GpuTensorHandle name(const GpuTensorHandle& a) const { return unary(code, a); }
+    RMHIP_UNARY_HOOK(unary_tan, RMHIP_TAN) RMHIP_UNARY_HOOK(unary_asin, RMHIP_ASIN) RMHIP_UNARY_HOOK(unary_acos, RMHIP_ACOS)
+    RMHIP_UNARY_HOOK(unary_atan, RMHIP_ATAN) RMHIP_UNARY_HOOK(unary_sinh, RMHIP_SINH) RMHIP_UNARY_HOOK(unary_cosh, RMHIP_COSH)
+    RMHIP_UNARY_HOOK(unary_asinh, RMHIP_ASINH) RMHIP_UNARY_HOOK(unary_acosh, RMHIP_ACOSH) RMHIP_UNARY_HOOK(unary_atanh, RMHIP_ATANH)
+    RMHIP_UNARY_HOOK(unary_expm1, RMHIP_EXPM1) RMHIP_UNARY_HOOK(unary_log2, RMHIP_LOG2) RMHIP_UNARY_HOOK(unary_log10, RMHIP_LOG10)
+    RMHIP_UNARY_HOOK(unary_log1p, RMHIP_LOG1P) RMHIP_UNARY_HOOK(unary_sign, RMHIP_SIGN) RMHIP_UNARY_HOOK(unary_floor, RMHIP_FLOOR)
+    RMHIP_UNARY_HOOK(unary_ceil, RMHIP_CEIL) RMHIP_UNARY_HOOK(unary_round, RMHIP_ROUND) RMHIP_UNARY_HOOK(unary_fix, RMHIP_FIX)
+    RMHIP_UNARY_HOOK(unary_pow2, RMHIP_EXP2) RMHIP_UNARY_HOOK(unary_heaviside, RMHIP_HEAVISIDE) RMHIP_UNARY_HOOK(unary_single, RMHIP_SINGLE)
+    RMHIP_UNARY_HOOK(unary_double, RMHIP_DOUBLE) RMHIP_UNARY_HOOK(unary_erf, RMHIP_ERF) RMHIP_UNARY_HOOK(unary_sinc, RMHIP_SINC)
+    RMHIP_UNARY_HOOK(logical_isnan, RMHIP_ISNAN) RMHIP_UNARY_HOOK(logical_isinf, RMHIP_ISINF) RMHIP_UNARY_HOOK(logical_isfinite, RMHIP_ISFINITE)
+    RMHIP_UNARY_HOOK(map_nan_to_zero, RMHIP_NAN_TO_ZERO) RMHIP_UNARY_HOOK(not_nan_mask, RMHIP_NOT_NAN)  // lib.rs:2980-2988
+#undef RMHIP_UNARY_HOOK
     GpuTensorHandle scalar(rmhip_scalar_op op, const GpuTensorHandle& a, double s) const {
         uint64_t out = 0;
         check(rmhip_scalar(ctx_, op, own(a), s, &out));
@@ -218,6 +286,13 @@ public:
         uint64_t mean = 0, ex2 = 0;
         check(rmhip_reduce_moments_nd(ctx_, own(a), dims_zero_based.data(), dims_zero_based.size(), &mean, &ex2));
         return {with_shape(mean), with_shape(ex2)};
+    }
+    GpuTensorHandle reduce_prod(const GpuTensorHandle& a) const { return reduce(RMHIP_RPROD, a, -1); }                        // lib.rs:2743
+    GpuTensorHandle reduce_prod_dim(const GpuTensorHandle& a, size_t dim) const { return reduce(RMHIP_RPROD, a, (int)dim); }  // lib.rs:2749
+    GpuTensorHandle dot(const GpuTensorHandle& a, const GpuTensorHandle& b, int dim = -1) const {  // lib.rs:2722; dim < 0: first non-singleton
+        uint64_t id = 0;
+        check(rmhip_dot(ctx_, own(a), own(b), dim, &id));
+        return with_shape(id);
     }
     GpuTensorHandle reduce_min(const GpuTensorHandle& a) const { return reduce(RMHIP_RMIN, a, -1); }
     GpuTensorHandle reduce_max(const GpuTensorHandle& a) const { return reduce(RMHIP_RMAX, a, -1); }
@@ -268,6 +343,11 @@ public:
         uint64_t out = 0;
         check(rmhip_matmul(ctx_, own(a), own(b), &out));
         return with_shape(out);
+    }
+    GpuTensorHandle matmul_epilogue(const GpuTensorHandle& a, const GpuTensorHandle& b, const rmhip_matmul_epilogue_t& ep) const {  // lib.rs:2394
+        uint64_t id = 0;
+        check(rmhip_matmul_epilogue(ctx_, own(a), own(b), &ep, &id));
+        return make(id, {a.shape[0], b.shape[1]});
     }
     GpuTensorHandle mldivide(const GpuTensorHandle& lhs, const GpuTensorHandle& rhs) const {
         uint64_t out = 0;

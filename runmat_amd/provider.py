@@ -202,11 +202,22 @@ class HipProvider:
         return {f: (getattr(info, f).decode() if isinstance(getattr(info, f), bytes) else getattr(info, f))
                 for f, _ in info._fields_}
 
+    def device_info(self) -> str:
+        """`device_info` (lib.rs:1390): the one-line description."""
+        i = self.device_info_struct()
+        return f"{i['name']} ({i['arch']}, {i['backend']})"
+
     def default_reduction_workgroup_size(self) -> int:
-        return 256
+        return int(self.device_info_struct()["reduction_workgroup_size"])  # lib.rs:3048
 
     def two_pass_threshold(self) -> int:
-        return 262144
+        return int(self.device_info_struct()["two_pass_threshold"])  # lib.rs:3053
+
+    def fused_cache_counters(self) -> Tuple[int, int]:
+        """(hits, misses) of the fused-kernel cache (lib.rs:3014)."""
+        t = _lib.Telemetry()
+        self._check(self._lib.rmhip_telemetry(self._ctx, C.byref(t)))
+        return int(t.fusion_cache_hits), int(t.fusion_cache_misses)
 
     # -- memory ---------------------------------------------------------------------------------
     def upload(self, data, shape: Optional[Sequence[int]] = None) -> GpuTensorHandle:

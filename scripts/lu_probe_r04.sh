@@ -1,0 +1,15 @@
+cd /tmp
+R=$GRAFT_REPO_ROOT
+run() { echo -n "$* : "; env "$@" python $R/scripts/lu_trace.py 16384 4 2>&1 | grep "rep=" | tail -2 | awk '{printf "%s ", $3}'; echo; }
+run X=1
+run RMHIP_LU_LA_PAD=0
+run RMHIP_LU_NB_EARLY=1024
+run RMHIP_LU_NB_EARLY=1024 RMHIP_LU_EARLY_ROWS=8192
+run RMHIP_LU_NB_EARLY=256
+run RMHIP_LU_LATE_XCD=2
+run RMHIP_LU_BAND=1
+run RMHIP_LU_NB_LATE=256 RMHIP_LU_LATE_ROWS=4096
+run RMHIP_LU_SKIP=2
+run RMHIP_LU_SKIP=1
+run RMHIP_LU_SKIP=13
+run X=1

@@ -1,9 +1,9 @@
 //! hip_provider.rs -- the binding a RunMat maintainer adds to plug librmhip.so in as a third
 //! `AccelProvider` backend (next to `WgpuProvider` and `InProcessProvider`).
 //!
-//! NOT compiled in this repository (the build image has no Rust toolchain); it documents, in the
-//! reference's own language, the exact FFI surface of `include/rmhip.h`.  Drop it into
-//! `crates/runmat-accelerate/src/backend/hip/mod.rs`, add `links = "rmhip"` / a build.rs that
+//! NOT compiled in this repository (the build image has no Rust toolchain).  Drop it, together with the generated
+//! `rmhip_sys.rs` (the FFI declarations, derived from `include/rmhip.h`), into
+//! `crates/runmat-accelerate/src/backend/hip/`, add `links = "rmhip"` / a build.rs that
 //! emits `cargo:rustc-link-lib=dylib=rmhip`, and call `register_hip_provider()` before
 //! `initialize_acceleration_provider_with` (which returns early when a provider is already
 //! registered, crates/runmat-accelerate/src/lib.rs:179-181).
@@ -14,174 +14,20 @@
 
 use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
-    AccelProvider, AccelProviderFuture, CovNormalization, CovRows, CovarianceOptions, GpuTensorHandle,
-    HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, PowerStepEpilogue, ProviderLinsolveOptions,
-    ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderNanMode, ProviderPrecision, ProviderScanDirection,
-    ProviderStdNormalization, ReduceDimResult, ReductionFlavor,
+    AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, GpuTensorHandle,
+    HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, KernelAttrTelemetry, KernelLaunchTelemetry, MatmulEpilogue,
+    PowerStepEpilogue, ProviderDispatchStats, ProviderFallbackStat, ProviderLinsolveOptions, ProviderLinsolveResult, ProviderLuResult,
+    ProviderMoments2, ProviderNanMode, ProviderPrecision, ProviderScanDirection, ProviderStdNormalization, ProviderTelemetry,
+    ReduceDimResult, ReductionFlavor, ScaleOp,
 };
-use std::ffi::{c_char, c_double, c_int, c_void, CStr, CString};
+use std::ffi::{c_char, c_int, c_void, CStr, CString};
 
-#[repr(C)]
-pub struct RmhipCtx {
-    _private: [u8; 0],
-}
-
-extern "C" {
-    fn rmhip_last_error() -> *const c_char;
-    fn rmhip_init(device_ordinal: c_int, out: *mut *mut RmhipCtx) -> c_int;
-    fn rmhip_shutdown(ctx: *mut RmhipCtx) -> c_int;
-    fn rmhip_set_precision(ctx: *mut RmhipCtx, bits: c_int) -> c_int;
-    fn rmhip_upload(ctx: *mut RmhipCtx, host: *const c_double, shape: *const usize, rank: usize, out: *mut u64) -> c_int;
-    fn rmhip_download(ctx: *mut RmhipCtx, id: u64, out: *mut c_double, n: usize) -> c_int;
-    fn rmhip_free(ctx: *mut RmhipCtx, id: u64) -> c_int;
-    fn rmhip_shape(ctx: *mut RmhipCtx, id: u64, rank_inout: *mut usize, shape_out: *mut usize) -> c_int;
-    fn rmhip_fill(ctx: *mut RmhipCtx, value: c_double, shape: *const usize, rank: usize, out: *mut u64) -> c_int;
-    fn rmhip_fused_elementwise(ctx: *mut RmhipCtx, shader: *const c_char, inputs: *const u64, n_in: usize,
-        out_shape: *const usize, rank: usize, len: usize, n_out: usize, out_ids: *mut u64) -> c_int;
-    fn rmhip_fused_reduction(ctx: *mut RmhipCtx, shader: *const c_char, inputs: *const u64, n_in: usize,
-        out_shape: *const usize, rank: usize, reduce_len: usize, num_slices: usize, workgroup_size: u32,
-        flavor: c_int, custom_scale: c_double, out: *mut u64) -> c_int;
-    fn rmhip_binary(ctx: *mut RmhipCtx, op: c_int, a: u64, b: u64, out: *mut u64) -> c_int;
-    fn rmhip_unary(ctx: *mut RmhipCtx, op: c_int, a: u64, out: *mut u64) -> c_int;
-    fn rmhip_scalar(ctx: *mut RmhipCtx, op: c_int, a: u64, s: c_double, out: *mut u64) -> c_int;
-    fn rmhip_reduce(ctx: *mut RmhipCtx, op: c_int, a: u64, dim: c_int, nan_mode: c_int, out: *mut u64) -> c_int;
-    fn rmhip_reduce_minmax_dim(ctx: *mut RmhipCtx, op: c_int, a: u64, dim: c_int, nan_mode: c_int, values: *mut u64, indices: *mut u64) -> c_int;
-    fn rmhip_reduce_std(ctx: *mut RmhipCtx, a: u64, dim: c_int, normalization: c_int, nan_mode: c_int, out: *mut u64) -> c_int;
-    fn rmhip_reduce_truth(ctx: *mut RmhipCtx, op: c_int, a: u64, dim: c_int, omit_nan: c_int, out: *mut u64) -> c_int;
-    fn rmhip_cumulative(ctx: *mut RmhipCtx, op: c_int, a: u64, dim: c_int, reverse: c_int, nan_mode: c_int, out: *mut u64) -> c_int;
-    fn rmhip_reduce_nd(ctx: *mut RmhipCtx, op: c_int, a: u64, dims: *const usize, ndims: usize, nan_mode: c_int, out: *mut u64) -> c_int;
-    fn rmhip_reduce_moments_nd(ctx: *mut RmhipCtx, a: u64, dims: *const usize, ndims: usize, mean: *mut u64, ex2: *mut u64) -> c_int;
-    fn rmhip_dot(ctx: *mut RmhipCtx, a: u64, b: u64, dim: c_int, out: *mut u64) -> c_int;
-    fn rmhip_reshape(ctx: *mut RmhipCtx, id: u64, shape: *const usize, rank: usize, out: *mut u64) -> c_int;
-    fn rmhip_matmul(ctx: *mut RmhipCtx, a: u64, b: u64, out: *mut u64) -> c_int;
-    fn rmhip_lu(ctx: *mut RmhipCtx, a: u64, out5: *mut u64) -> c_int;
-    fn rmhip_mldivide(ctx: *mut RmhipCtx, a: u64, b: u64, out: *mut u64) -> c_int;
-    fn rmhip_mrdivide(ctx: *mut RmhipCtx, b: u64, a: u64, out: *mut u64) -> c_int;
-    fn rmhip_linsolve(ctx: *mut RmhipCtx, a: u64, b: u64, opts: *const RmhipLinsolveOptions, out: *mut u64, rcond: *mut c_double) -> c_int;
-    fn rmhip_transpose(ctx: *mut RmhipCtx, a: u64, out: *mut u64) -> c_int;
-    fn rmhip_syrk(ctx: *mut RmhipCtx, a: u64, out: *mut u64) -> c_int;
-    fn rmhip_covariance(ctx: *mut RmhipCtx, matrix: u64, biased: c_int, out: *mut u64) -> c_int;
-    fn rmhip_diag_extract(ctx: *mut RmhipCtx, matrix: u64, offset: i64, out: *mut u64) -> c_int;
-    fn rmhip_matmul_power_step(ctx: *mut RmhipCtx, lhs: u64, rhs: u64, epsilon: c_double, out: *mut u64) -> c_int;
-    fn rmhip_image_normalize(ctx: *mut RmhipCtx, input: u64, desc: *const RmhipImageNormalize, out: *mut u64) -> c_int;
-    fn rmhip_set_rng_state(ctx: *mut RmhipCtx, state: u64) -> c_int;
-    fn rmhip_stochastic_evolution(ctx: *mut RmhipCtx, state: u64, drift: c_double, scale: c_double, steps: u32, out: *mut u64) -> c_int;
-    fn rmhip_random_normal(ctx: *mut RmhipCtx, shape: *const usize, rank: usize, out: *mut u64) -> c_int;
-    fn rmhip_random_uniform(ctx: *mut RmhipCtx, shape: *const usize, rank: usize, out: *mut u64) -> c_int;
-    // multi-GPU collectives (one process per GPU; no counterpart in the trait - see `impl HipProvider` at the end)
-    fn rmhip_comm_unique_id(transport: c_int, id_out: *mut c_void) -> c_int;
-    fn rmhip_comm_init(ctx: *mut RmhipCtx, unique_id: *const c_void, rank: c_int, world: c_int) -> c_int;
-    fn rmhip_comm_destroy(ctx: *mut RmhipCtx) -> c_int;
-    fn rmhip_comm_rank(ctx: *mut RmhipCtx, rank: *mut c_int, world: *mut c_int) -> c_int;
-    fn rmhip_comm_barrier(ctx: *mut RmhipCtx) -> c_int;
-    fn rmhip_comm_bcast(ctx: *mut RmhipCtx, block: *const RmhipView, root: c_int, async_: c_int) -> c_int;
-    fn rmhip_comm_wait(ctx: *mut RmhipCtx) -> c_int;
-    fn rmhip_comm_allgather_f64(ctx: *mut RmhipCtx, local: u64, out: *mut u64) -> c_int;
-    fn rmhip_comm_allgather_rows(ctx: *mut RmhipCtx, local: u64, rows_total: usize, granule: usize, out: *mut u64) -> c_int;
-}
-
-/// `rmhip_view_t`: rows [row_off, row_off + rows) x columns [col_off, col_off + cols) of a 2-D buffer.
-#[repr(C)]
-pub struct RmhipView {
-    pub buf: u64,
-    pub row_off: usize,
-    pub col_off: usize,
-    pub rows: usize,
-    pub cols: usize,
-}
-pub const RMHIP_COMM_ID_BYTES: usize = 128;
-pub const RMHIP_COMM_RCCL: c_int = 0;
-pub const RMHIP_COMM_HOST_SHM: c_int = 1;
-
-// Op codes: the enums of include/rmhip.h (tests/test_front_end.py checks every value against the header).
-const RMHIP_ADD: c_int = 0;
-const RMHIP_SUB: c_int = 1;
-const RMHIP_MUL: c_int = 2;
-const RMHIP_DIV: c_int = 3;
-const RMHIP_POW: c_int = 4;
-const RMHIP_MAX: c_int = 5;
-const RMHIP_MIN: c_int = 6;
-const RMHIP_HYPOT: c_int = 7;
-const RMHIP_ATAN2: c_int = 8;
-const RMHIP_MOD: c_int = 9;
-const RMHIP_REM: c_int = 10;
-const RMHIP_EQ: c_int = 11;
-const RMHIP_NE: c_int = 12;
-const RMHIP_LT: c_int = 13;
-const RMHIP_LE: c_int = 14;
-const RMHIP_GT: c_int = 15;
-const RMHIP_GE: c_int = 16;
-const RMHIP_AND: c_int = 17;
-const RMHIP_OR: c_int = 18;
-const RMHIP_XOR: c_int = 19;
-const RMHIP_SIN: c_int = 0;
-const RMHIP_COS: c_int = 1;
-const RMHIP_TAN: c_int = 2;
-const RMHIP_ASIN: c_int = 3;
-const RMHIP_ACOS: c_int = 4;
-const RMHIP_ATAN: c_int = 5;
-const RMHIP_SINH: c_int = 6;
-const RMHIP_COSH: c_int = 7;
-const RMHIP_TANH: c_int = 8;
-const RMHIP_ASINH: c_int = 9;
-const RMHIP_ACOSH: c_int = 10;
-const RMHIP_ATANH: c_int = 11;
-const RMHIP_EXP: c_int = 12;
-const RMHIP_EXPM1: c_int = 13;
-const RMHIP_LOG: c_int = 14;
-const RMHIP_LOG2: c_int = 15;
-const RMHIP_LOG10: c_int = 16;
-const RMHIP_LOG1P: c_int = 17;
-const RMHIP_SQRT: c_int = 18;
-const RMHIP_ABS: c_int = 19;
-const RMHIP_SIGN: c_int = 20;
-const RMHIP_FLOOR: c_int = 21;
-const RMHIP_CEIL: c_int = 22;
-const RMHIP_ROUND: c_int = 23;
-const RMHIP_FIX: c_int = 24;
-const RMHIP_NEG: c_int = 25;
-const RMHIP_EXP2: c_int = 26;
-const RMHIP_HEAVISIDE: c_int = 27;
-const RMHIP_ISNAN: c_int = 28;
-const RMHIP_ISINF: c_int = 29;
-const RMHIP_ISFINITE: c_int = 30;
-const RMHIP_UPLUS: c_int = 31;
-const RMHIP_SINGLE: c_int = 32;
-const RMHIP_DOUBLE: c_int = 33;
-const RMHIP_ERF: c_int = 34;
-const RMHIP_SINC: c_int = 35;
-const RMHIP_NOT: c_int = 36;
-const RMHIP_GAMMA: c_int = 37;
-const RMHIP_FACTORIAL: c_int = 38;
-const RMHIP_NEXTPOW2: c_int = 39;
-const RMHIP_GAMMALN: c_int = 40;
-const RMHIP_ERFCINV: c_int = 41;
-const RMHIP_SADD: c_int = 0;
-const RMHIP_SSUB: c_int = 1;
-const RMHIP_SMUL: c_int = 2;
-const RMHIP_SDIV: c_int = 3;
-const RMHIP_SRSUB: c_int = 4;
-const RMHIP_SRDIV: c_int = 5;
-const RMHIP_SMAX: c_int = 6;
-const RMHIP_SMIN: c_int = 7;
-const RMHIP_RSUM: c_int = 0;
-const RMHIP_RMEAN: c_int = 1;
-const RMHIP_RMIN: c_int = 2;
-const RMHIP_RMAX: c_int = 3;
-const RMHIP_RPROD: c_int = 4;
-
-#[repr(C)]
-struct RmhipImageNormalize {
-    batch: usize, height: usize, width: usize, epsilon: c_double,
-    has_gain: c_int, has_bias: c_int, has_gamma: c_int, clamp_zero: c_int,
-    gain: c_double, bias: c_double, gamma: c_double,
-}
-
-#[repr(C)]
-struct RmhipLinsolveOptions {
-    lower: c_int, upper: c_int, rectangular: c_int, transposed: c_int, conjugate: c_int, symmetric: c_int, posdef: c_int,
-    need_rcond: c_int, has_rcond: c_int, rcond: c_double,
-}
+// The raw FFI surface - `#[repr(C)]` structs, op-code constants and the `extern "C"` block - is GENERATED from include/rmhip.h
+// by scripts/gen_bindings.py (shim/rmhip_sys.rs); tests/test_bindings.py fails when it is stale or when a trait method an
+// `@serves` tag of the header names has no implementation below.
+#[path = "rmhip_sys.rs"]
+mod sys;
+use sys::*;
 
 pub struct HipProvider {
     ctx: *mut RmhipCtx,
@@ -581,8 +427,170 @@ impl AccelProvider for HipProvider {
         Ok(GpuTensorHandle { shape: shape.to_vec(), device_id: self.device_id, buffer_id: out })
     }
     fn set_rng_state(&self, state: u64) -> Result<()> { check(unsafe { rmhip_set_rng_state(self.ctx, state) }) }
-    // zeros/ones/fill, reduce_mean(_dim), reduce_min/max, scalar_*, telemetry_snapshot, device_info_struct:
-    // same pattern over rmhip_fill / rmhip_reduce / rmhip_scalar / rmhip_telemetry / rmhip_device_info.
+    fn random_uniform(&self, shape: &[usize]) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_random_uniform(self.ctx, shape.as_ptr(), shape.len(), &mut out) })?;
+        Ok(GpuTensorHandle { shape: shape.to_vec(), device_id: self.device_id, buffer_id: out })
+    }
+
+    // all-element truth reductions (lib.rs:2730-2735, 2803-2809, 2818-2824): dim = -1
+    fn reduce_nnz<'a>(&'a self, a: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move { self.truth(RMHIP_TNNZ, a, -1, false) })
+    }
+    fn reduce_any<'a>(&'a self, a: &'a GpuTensorHandle, omit_nan: bool) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move { self.truth(RMHIP_TANY, a, -1, omit_nan) })
+    }
+    fn reduce_all<'a>(&'a self, a: &'a GpuTensorHandle, omit_nan: bool) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move { self.truth(RMHIP_TALL, a, -1, omit_nan) })
+    }
+
+    // `matmul_epilogue` (lib.rs:2394-2405): the descriptor's Options become flags, absent handles buffer id 0
+    fn matmul_epilogue<'a>(&'a self, a: &'a GpuTensorHandle, b: &'a GpuTensorHandle, epilogue: &'a MatmulEpilogue)
+        -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let id_of = |h: &Option<GpuTensorHandle>| -> Result<u64> { h.as_ref().map(|h| self.own(h)).transpose().map(|v| v.unwrap_or(0)) };
+            let ep = RmhipMatmulEpilogue {
+                alpha: epilogue.alpha,
+                beta: epilogue.beta,
+                row_scale: id_of(&epilogue.row_scale)?,
+                col_scale: id_of(&epilogue.col_scale)?,
+                row_op: matches!(epilogue.row_op, ScaleOp::Divide) as c_int,
+                col_op: matches!(epilogue.col_op, ScaleOp::Divide) as c_int,
+                has_clamp_min: epilogue.clamp_min.is_some() as c_int,
+                has_clamp_max: epilogue.clamp_max.is_some() as c_int,
+                has_pow: epilogue.pow_exponent.is_some() as c_int,
+                clamp_min: epilogue.clamp_min.unwrap_or(0.0),
+                clamp_max: epilogue.clamp_max.unwrap_or(0.0),
+                pow_exponent: epilogue.pow_exponent.unwrap_or(1.0),
+                diag_output: id_of(&epilogue.diag_output)?,
+            };
+            let mut out = 0u64;
+            check(unsafe { rmhip_matmul_epilogue(self.ctx, self.own(a)?, self.own(b)?, &ep, &mut out) })?;
+            self.handle(out)
+        })
+    }
+
+    // shape / indexing hooks the hot-path builtins call around the kernels (include/rmhip.h "shape / indexing hooks")
+    fn repmat(&self, handle: &GpuTensorHandle, reps: &[usize]) -> Result<GpuTensorHandle> {
+        let mut out = 0u64; // a view: elem_* / fused_elementwise read it in place (times.rs:501-543)
+        check(unsafe { rmhip_repmat(self.ctx, self.own(handle)?, reps.as_ptr(), reps.len(), &mut out) })?;
+        self.handle(out)
+    }
+    fn permute(&self, handle: &GpuTensorHandle, order: &[usize]) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_permute(self.ctx, self.own(handle)?, order.as_ptr(), order.len(), &mut out) })?;
+        self.handle(out)
+    }
+    fn fill_like(&self, prototype: &GpuTensorHandle, value: f64) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_fill_like(self.ctx, self.own(prototype)?, value, &mut out) })?;
+        Ok(GpuTensorHandle { shape: prototype.shape.clone(), device_id: self.device_id, buffer_id: out })
+    }
+    fn zeros_like(&self, prototype: &GpuTensorHandle) -> Result<GpuTensorHandle> { self.fill_like(prototype, 0.0) }
+    fn ones_like(&self, prototype: &GpuTensorHandle) -> Result<GpuTensorHandle> { self.fill_like(prototype, 1.0) }
+    fn read_scalar(&self, h: &GpuTensorHandle, linear_index: usize) -> Result<f64> {
+        let mut v = 0.0f64;
+        check(unsafe { rmhip_read_scalar(self.ctx, self.own(h)?, linear_index, &mut v) })?;
+        Ok(v)
+    }
+    fn gather_linear(&self, source: &GpuTensorHandle, indices: &[u32], output_shape: &[usize]) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_gather_linear(self.ctx, self.own(source)?, indices.as_ptr(), indices.len(), output_shape.as_ptr(),
+            output_shape.len(), &mut out) })?;
+        Ok(GpuTensorHandle { shape: output_shape.to_vec(), device_id: self.device_id, buffer_id: out })
+    }
+    fn scatter_linear(&self, target: &GpuTensorHandle, indices: &[u32], values: &GpuTensorHandle) -> Result<()> {
+        check(unsafe { rmhip_scatter_linear(self.ctx, self.own(target)?, indices.as_ptr(), indices.len(), self.own(values)?) })
+    }
+    fn linspace(&self, start: f64, stop: f64, count: usize) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_linspace(self.ctx, start, stop, count, &mut out) })?;
+        Ok(GpuTensorHandle { shape: vec![1, count], device_id: self.device_id, buffer_id: out })
+    }
+    fn map_nan_to_zero(&self, a: &GpuTensorHandle) -> Result<GpuTensorHandle> { self.unary(RMHIP_NAN_TO_ZERO, a) }
+    fn not_nan_mask(&self, a: &GpuTensorHandle) -> Result<GpuTensorHandle> { self.unary(RMHIP_NOT_NAN, a) }
+
+    // identity / telemetry (lib.rs:1390, 1448-1456, 3014-3056)
+    fn device_info(&self) -> String {
+        let i = self.raw_device_info();
+        format!("{} ({}, {})", cstr(&i.name), cstr(&i.arch), cstr(&i.backend))
+    }
+    fn device_info_struct(&self) -> ApiDeviceInfo {
+        let i = self.raw_device_info();
+        ApiDeviceInfo { device_id: self.device_id, name: cstr(&i.name), vendor: cstr(&i.vendor), memory_bytes: Some(i.total_memory_bytes),
+            backend: Some(cstr(&i.backend)) }
+    }
+    fn default_reduction_workgroup_size(&self) -> u32 { self.raw_device_info().reduction_workgroup_size }
+    fn two_pass_threshold(&self) -> usize { self.raw_device_info().two_pass_threshold as usize }
+    fn fused_cache_counters(&self) -> (u64, u64) {
+        let t = self.raw_telemetry();
+        (t.fusion_cache_hits, t.fusion_cache_misses)
+    }
+    fn telemetry_snapshot(&self) -> ProviderTelemetry {
+        let t = self.raw_telemetry();
+        let stats = |count: u64, ns: u64| ProviderDispatchStats { count, total_wall_time_ns: ns };
+        // solve_fallbacks: (reason, count) pairs until the index runs out (RMHIP_ERR_NOT_FOUND)
+        let mut solve_fallbacks = Vec::new();
+        let mut reason = [0 as c_char; 64];
+        let mut count = 0u64;
+        let mut index = 0usize;
+        while unsafe { rmhip_telemetry_solve_fallback(self.ctx, index, reason.as_mut_ptr(), reason.len(), &mut count) } == 0 {
+            solve_fallbacks.push(ProviderFallbackStat { reason: cstr(&reason), count });
+            index += 1;
+        }
+        // kernel_launches: bounded log, oldest first
+        let mut kernel_launches = Vec::new();
+        let mut rec: RmhipKernelLaunch = unsafe { std::mem::zeroed() };
+        let mut index = 0usize;
+        while unsafe { rmhip_telemetry_kernel_launch(self.ctx, index, &mut rec) } == 0 {
+            let attrs = |a: &[RmhipKernelAttr; 6], n: u32| a[..n as usize].iter()
+                .map(|kv| KernelAttrTelemetry { key: cstr(&kv.key), value: kv.value }).collect::<Vec<_>>();
+            kernel_launches.push(KernelLaunchTelemetry { kernel: cstr(&rec.kernel), precision: Some(cstr(&rec.precision)),
+                shape: attrs(&rec.shape, rec.n_shape), tuning: attrs(&rec.tuning, rec.n_tuning) });
+            index += 1;
+        }
+        ProviderTelemetry {
+            fused_elementwise: stats(t.fused_elementwise_count, t.fused_elementwise_ns),
+            fused_reduction: stats(t.fused_reduction_count, t.fused_reduction_ns),
+            matmul: stats(t.matmul_count, t.matmul_ns),
+            linsolve: stats(t.linsolve_count, t.linsolve_ns),
+            mldivide: stats(t.mldivide_count, t.mldivide_ns),
+            mrdivide: stats(t.mrdivide_count, t.mrdivide_ns),
+            upload_bytes: t.upload_bytes,
+            download_bytes: t.download_bytes,
+            solve_fallbacks,
+            fusion_cache_hits: t.fusion_cache_hits,
+            fusion_cache_misses: t.fusion_cache_misses,
+            bind_group_cache_hits: 0, // no bind groups on this backend
+            bind_group_cache_misses: 0,
+            bind_group_cache_by_layout: None,
+            kernel_launches,
+        }
+    }
+    fn reset_telemetry(&self) { unsafe { rmhip_reset_telemetry(self.ctx) }; }
+}
+
+fn cstr(bytes: &[c_char]) -> String {
+    let end = bytes.iter().position(|&b| b == 0).unwrap_or(bytes.len());
+    String::from_utf8_lossy(&bytes[..end].iter().map(|&b| b as u8).collect::<Vec<u8>>()).into_owned()
+}
+
+impl HipProvider {
+    fn raw_device_info(&self) -> RmhipDeviceInfo {
+        let mut info: RmhipDeviceInfo = unsafe { std::mem::zeroed() };
+        unsafe { rmhip_device_info(self.ctx, &mut info) };
+        info
+    }
+    fn raw_telemetry(&self) -> RmhipTelemetry {
+        let mut t: RmhipTelemetry = unsafe { std::mem::zeroed() };
+        unsafe { rmhip_telemetry(self.ctx, &mut t) };
+        t
+    }
+    fn truth(&self, op: c_int, a: &GpuTensorHandle, dim: c_int, omit_nan: bool) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_reduce_truth(self.ctx, op, self.own(a)?, dim, omit_nan as c_int, &mut out) })?;
+        self.handle(out)
+    }
 }
 
 /// Sharded forms of the hot path: one process per GPU, one provider per process.  The trait has no
