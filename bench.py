@@ -33,8 +33,43 @@ sys.path.insert(1, str(ROOT / "tests"))  # the request emitter (tests/planner_re
 import numpy as np  # noqa: E402
 
 N_DIM = 8192
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# Stated spec (MI355X_MICROARCH.md): what the `peak_spec` fields carry.  The `peak` every roofline fraction is taken against is derived
+# from the box the run is on (device_peaks below: rmhip_device_info's CU count, clocks and memory bus) - BASELINE.md section 4.
+HBM_PEAK_GBS = 8000.0      # HBM3E 8.0 TB/s
 FP64_MFMA_PEAK_TF = 78.6   # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (v_mfma_f64_16x16x4_f64, 64 cyc)
+F32_MFMA_PEAK_TF = 157.3   # 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz (v_mfma_f32_32x32x2_f32)
+VALU_F64_PEAK_GIPS = 614.4  # wave64 fp64 VALU instructions per second: 1024 SIMDs x 2.4 GHz / 4 cycles (16 lanes per clock)
+
+
+def device_peaks(info: dict) -> dict:
+    """Peaks of THIS box from rmhip_device_info (hipDeviceProp_t): compute_units x clock for the matrix / vector pipes, memory bus x
+    pin rate for HBM (HBM3E moves 4 bits per pin per reported memory clock: 2000 MHz -> 8 Gb/s per pin).  amd-smi's view of the memory
+    clock is recorded beside it when the tool is there."""
+    cus, mhz = int(info["compute_units"]), int(info["clock_mhz"])
+    simds = cus * 4
+    mem_khz, bus = int(info.get("memory_clock_khz", 0)), int(info.get("memory_bus_width_bits", 0))
+    peaks = {
+        "source": "rmhip_device_info (hipDeviceProp_t) of the device this run used",
+        "compute_units": cus, "clock_mhz": mhz, "xcd_count": int(info.get("xcd_count", 0)),
+        "memory_clock_khz": mem_khz, "memory_bus_width_bits": bus,
+        "mfma_f64_tflops": round(simds * 32 * mhz * 1e6 / 1e12, 2),
+        "mfma_f32_tflops": round(simds * 64 * mhz * 1e6 / 1e12, 2),
+        "valu_f64_ginstr_per_s": round(simds * mhz * 1e6 / 4 / 1e9, 1),
+        "hbm_gbs": round(bus / 8 * 4 * mem_khz * 1e3 / 1e9, 1) if mem_khz and bus else HBM_PEAK_GBS,
+        "spec": {"hbm_gbs": HBM_PEAK_GBS, "mfma_f64_tflops": FP64_MFMA_PEAK_TF, "mfma_f32_tflops": F32_MFMA_PEAK_TF,
+                 "valu_f64_ginstr_per_s": VALU_F64_PEAK_GIPS},
+    }
+    try:
+        import subprocess
+
+        r = subprocess.run(["amd-smi", "metric", "--clock", "--json"], capture_output=True, text=True, timeout=20)
+        if r.returncode == 0:
+            j = json.loads(r.stdout)
+            clk = (j[0] if isinstance(j, list) else j).get("clock", {})
+            peaks["amd_smi_mem_clock"] = {k: v for k, v in clk.items() if k.lower().startswith("mem")}
+    except Exception:  # noqa: BLE001 - optional context only
+        pass
+    return peaks
 
 
 def host_info() -> dict:
@@ -160,6 +195,22 @@ def pmc_traffic(workload: str, kernel: str = None):
     return None
 
 
+PMC_VALU_SOURCE = "profiles/pmc_valu.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU ... pass of this command, committed; not re-measured in this run)"
+
+
+def pmc_valu(workload: str, kernel: str):
+    """VALU counters of `kernel` (prefix match) in the profiled run of `workload` (profiles/pmc_valu.json, scripts/profile_r04.sh): wave-level
+    VALU instructions per launch, the share of SIMD cycles they kept busy under the profiler, their mean issue cost.  None if absent."""
+    try:
+        t = json.loads((ROOT / "profiles" / "pmc_valu.json").read_text()).get(workload) or {}
+    except Exception:
+        return None
+    for k, v in t.items():
+        if k.startswith(kernel):
+            return v
+    return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,6 +263,49 @@ def main() -> None:
 
     prov = HipProvider(local_rank)
     n = N_DIM
+    peaks = device_peaks(prov.device_info_struct())
+    # every roofline below divides by the peaks of the box it ran on; the spec values ride along as `peak_spec`
+    hbm_peak, mfma_peak, mfma32_peak, valu_peak = peaks["hbm_gbs"], peaks["mfma_f64_tflops"], peaks["mfma_f32_tflops"], peaks["valu_f64_ginstr_per_s"]
+
+    def roofline(bound: str, achieved: float, digits: int = 2, **extra) -> dict:
+        peak, spec, unit = {"hbm": (hbm_peak, HBM_PEAK_GBS, "GB/s"), "mfma": (mfma_peak, FP64_MFMA_PEAK_TF, "TFLOP/s"),
+                            "mfma_f32": (mfma32_peak, F32_MFMA_PEAK_TF, "TFLOP/s"), "valu": (valu_peak, VALU_F64_PEAK_GIPS, "Ginstr/s")}[bound]
+        return {"bound": "mfma" if bound == "mfma_f32" else bound, "achieved": round(achieved, digits), "peak": peak, "peak_spec": spec, "unit": unit,
+                "frac": round(achieved / peak, 4), **extra}
+
+    def valu_roofline(workload: str, kernel: str, kernel_s: float, **extra) -> dict:
+        """fp64-VALU roofline of one kernel: achieved = wave-level VALU instructions per launch (committed counter pass) / the launch time
+        measured in THIS run; peak = SIMDs x clock / 4 (an fp64 instruction occupies its SIMD for four cycles).  The counter pass's busy
+        share and mean issue cost ride along.  Falls back to an HBM block when the counter file has no entry (fresh checkout)."""
+        v = pmc_valu(workload, kernel)
+        if not v or not v.get("insts_valu_per_launch"):
+            return {**roofline("hbm", 0.0), "note": f"no VALU counters for {workload}/{kernel} in profiles/pmc_valu.json", **extra}
+        return roofline("valu", v["insts_valu_per_launch"] / kernel_s / 1e9, 1, valu_insts_per_launch=v["insts_valu_per_launch"],
+                        valu_busy_profiled=v.get("valu_busy"), cycles_per_valu_inst=v.get("cycles_per_valu_inst"), counters_source=PMC_VALU_SOURCE, **extra)
+
+    def mc_kernel_rooflines(samples: int):
+        """Per-kernel view of one Monte-Carlo step from the committed profile (durations, bytes and VALU counters of the same command):
+        which of the three kernels is bound by what."""
+        out = {}
+        try:
+            tr = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get("mc", {})
+            dur = json.loads((ROOT / "profiles" / "pmc_valu.json").read_text()).get("_durations_us", {}).get("mc", {})
+        except Exception:  # noqa: BLE001
+            return None
+        for name, moved in (("k_rng_normal", 8 * samples), ("rm_ew_fast", 16 * samples), ("rm_red_contig", 8 * samples)):
+            us = next((v for k, v in dur.items() if k.startswith(name)), None)
+            val = pmc_valu("mc", name)
+            if us is None:
+                continue
+            rec = {"avg_us_profiled": us, "hbm_gbs": round(moved / (us * 1e-6) / 1e9, 1), "hbm_frac": round(moved / (us * 1e-6) / 1e9 / hbm_peak, 4),
+                   "measured_bytes": next((v for k, v in tr.items() if k.startswith(name)), None)}
+            if val and val.get("insts_valu_per_launch"):
+                rec["valu_ginstr_per_s"] = round(val["insts_valu_per_launch"] / (us * 1e-6) / 1e9, 1)
+                rec["valu_frac"] = round(rec["valu_ginstr_per_s"] / valu_peak, 4)
+                rec["valu_busy_profiled"] = val.get("valu_busy")
+                rec["bound"] = "valu" if (val.get("valu_busy") or 0) > rec["hbm_frac"] else "hbm"
+            out[name] = rec
+        return out or None
     # Data-path collectives go through the C ABI (rmhip_comm_*: RCCL over xGMI, one rank per GPU); torch.distributed
     # is the control plane only (rendezvous of the 128-byte communicator id, the timing reduction).
     from runmat_amd import sharding as sh
@@ -319,9 +413,8 @@ def main() -> None:
             "ms_per_step": round(ms, 5), "scaling": "weak", "dtype": "f64",
             "config": {"workload": "fused D=sin(A).*B+C 8192x8192 f64 via rmhip_fused_elementwise (WGSL request)",
                        "bytes_per_step_per_gpu": fused_bytes, "parallelism": f"independent x{world}"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("fused", "rm_ew_fast"), "traffic_source": PMC_TRAFFIC_SOURCE,
-                         "kernel": "rm_ew_fast (hipRTC, generated)", "kernel_ms": round(kern_ms, 5)},
+            "roofline": roofline("hbm", achieved, traffic=pmc_traffic("fused", "rm_ew_fast"), traffic_source=PMC_TRAFFIC_SOURCE,
+                                 kernel="rm_ew_fast (hipRTC, generated)", kernel_ms=round(kern_ms, 5)),
         }
 
     def dgemm_record(steps, warmup):
@@ -335,10 +428,8 @@ def main() -> None:
             "ms_per_step": round(ms, 5), "scaling": "strong", "dtype": "f64",
             "config": {"workload": "C=A*B dgemm 8192x8192x8192 f64 via rmhip_matmul", "flops_per_step": dgemm_flops,
                        "parallelism": f"row-block x{world}, B replicated, no collective"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TF,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TF, 4),
-                         "traffic": pmc_traffic("dgemm", "k_dgemm_w8"), "traffic_source": PMC_TRAFFIC_SOURCE, "kernel": "k_dgemm_w8<false> (eight waves, pipelined k loop; v_mfma_f64_16x16x4_f64)",
-                         "kernel_ms": round(kern_ms, 5)},
+            "roofline": roofline("mfma", achieved, 3, traffic=pmc_traffic("dgemm", "k_dgemm_w8"), traffic_source=PMC_TRAFFIC_SOURCE,
+                                 kernel="k_dgemm_w8<false> (eight waves, pipelined k loop; v_mfma_f64_16x16x4_f64)", kernel_ms=round(kern_ms, 5)),
         }
 
     def mc_record(steps, warmup):
@@ -358,17 +449,23 @@ def main() -> None:
         barrier()
         wall = max_over_ranks(time.perf_counter() - t0)
         ms = wall / steps * 1e3
-        bytes_total = (32 * T + 8) * M
+        # Bytes the three kernels MOVE per sample: randn writes Z (8), the fused update reads Z and writes S (16; S0 is a scalar
+        # operand at T = 1), the payoff reduction reads S (8) = 32.  SURVEY.md 8(d) prices the reference's MATERIALISED plan at
+        # (32 T + 8) = 40 B/sample (it also reads a resident S vector); that figure is reported beside, it is not what the roofline
+        # fraction is taken on (round-3 review: a fraction on bytes the kernels do not move is not a roofline fraction).
+        bytes_moved = 32 * T * M
+        bytes_materialised = (32 * T + 8) * M
         return {
             "metric": "Monte-Carlo samples/s (1e8-sample randn + fused elementwise + sum reduction)",
             "value": round(M * T / (ms * 1e-3), 1), "unit": "samples/s", "ms_per_step": round(ms, 4), "scaling": "strong",
             "dtype": "f64",
             "config": {"workload": "monte-carlo-analysis f64, M=1e8, T=1, CPU-parity LCG randn stream", "price": price,
-                       "algorithmic_bytes": bytes_total, "parallelism": f"sample ranges x{world}, ordered 1-value exchange"},
-            "roofline": {"bound": "hbm", "achieved": round(bytes_total / world / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(bytes_total / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("mc"), "traffic_source": PMC_TRAFFIC_SOURCE + " - per step, all kernels",
-                         "kernel": "k_rng_normal + rm_ew_fast + rm_red_contig (whole step, wall clock)"},
+                       "algorithmic_bytes": bytes_moved, "materialised_plan_bytes_survey_8d": bytes_materialised,
+                       "parallelism": f"sample ranges x{world}, ordered 1-value exchange"},
+            "roofline": roofline("hbm", bytes_moved / world / (ms * 1e-3) / 1e9, 1, traffic=pmc_traffic("mc"),
+                                 traffic_source=PMC_TRAFFIC_SOURCE + " - per step, all kernels",
+                                 kernel="k_rng_normal + rm_ew_fast + rm_red_contig (whole step, wall clock; 32 B per sample moved)",
+                                 per_kernel=mc_kernel_rooflines(M // world)),
         }
 
     def mc_evolved_record(steps, warmup):
@@ -397,11 +494,10 @@ def main() -> None:
             "config": {"workload": "monte-carlo-analysis f64, M=1e6, T=256, CPU-parity LCG randn stream, fused time loop",
                        "price": price, "algorithmic_bytes": 32 * M,
                        "parallelism": f"sample ranges x{world}, ordered 1-value exchange"},
-            "roofline": {"bound": "hbm", "achieved": round(32 * M / world / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(32 * M / world / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("mc_evolved"), "traffic_source": PMC_TRAFFIC_SOURCE + " - per step, all kernels",
-                         "kernel": "k_stochastic_evolution (32 B per path for the whole loop: fp64 VALU bound, "
-                                   "the HBM fraction is reported for completeness)"},
+            "roofline": valu_roofline("mc_evolved", "k_stochastic_evolution", ms * 1e-3,
+                                      kernel="k_stochastic_evolution (state in registers: 24 B per path for the whole time loop, fp64 VALU bound)",
+                                      hbm_frac_for_completeness=round(24 * M / world / (ms * 1e-3) / 1e9 / hbm_peak, 4),
+                                      traffic=pmc_traffic("mc_evolved"), traffic_source=PMC_TRAFFIC_SOURCE + " - per step, all kernels"),
         }
 
     def image_record(steps, warmup):
@@ -430,9 +526,9 @@ def main() -> None:
             "dtype": "f64",
             "config": {"workload": "benchmarks/4k-image-processing f64, image_normalize(gain, bias, clamp, gamma = 1.8)",
                        "bytes_per_step_per_gpu": nbytes, "parallelism": f"frames x{world}, no collective"},
-            "roofline": {"bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": {**roofline("hbm", nbytes / (ms * 1e-3) / 1e9, 1),
                          "traffic": pmc_traffic("image"), "traffic_source": PMC_TRAFFIC_SOURCE + " - per step, all kernels",
+                         "valu": pmc_valu("image", "k_imgnorm_apply"),
                          "kernel": "k_plane_moments (one-pass mean / M2, fixed-order Chan merge), k_plane_moments_final, k_imgnorm_apply "
                                    "(24 B per element; round 1 moved 32 with a two-pass variance)"},
         }
@@ -515,9 +611,11 @@ def main() -> None:
             "dtype": "f64",
             "config": {"workload": "x=A\\b 16384x16384 f64 via rmhip_mldivide, A=U(-1,1), b=A*1", "flops_per_step": flops,
                        "max_abs_err_vs_ones": err,
+                       # forward-error bounds by generator (tests/test_gpu_lookahead.py): U(-1,1) as here - cond ~ 1e5 at this order - 1e-7;
+                       # SURVEY.md 8(d)'s 1e-9 belongs to the diagonally dominant U(-1,1) + n*I generator
+                       "max_abs_err_bound": {"generator": "U(-1,1) (this run)", "bound": 1e-7, "diagonally_dominant_U_plus_nI_bound": 1e-9},
                        "parallelism": form["name"]},
-            "roofline": {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 3), "peak": FP64_MFMA_PEAK_TF,
-                         "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF, 4),
+            "roofline": {**roofline("mfma", flops / (ms * 1e-3) / 1e12, 3),
                          "traffic": pmc_traffic("mldivide"), "traffic_source": PMC_TRAFFIC_SOURCE + " - per solve, all kernels (fabric side: Infinity-Cache hits included)",
                          "kernel": "k_rp_top / k_rp_below panels + k_dgemm_w8 trailing updates (whole solve, wall clock)"},
         }
@@ -546,6 +644,13 @@ def main() -> None:
         barrier()
         wall = max_over_ranks(time.perf_counter() - t0)
         ms = wall / steps * 1e3
+        # kernel time: HIP events on the library's stream around a back-to-back run (the host issues a call in less time than the kernel
+        # runs, so the stream stays full and elapsed / steps is the launch duration plus the dispatch gap - an upper bound of the former)
+        prov.synchronize()
+        prov.timer_begin()
+        for _ in range(steps):
+            step()
+        kern_ms = max_over_ranks(prov.timer_end() / steps)
         for h in [hx] + consts:
             prov.free(h)
         nbytes = 16 * m * m  # fused form: one read + one write per element
@@ -555,10 +660,12 @@ def main() -> None:
             "scaling": "weak", "dtype": "f64",
             "config": {"workload": "benchmarks/elementwise-math chain, 1024x1024 f64, one fused kernel",
                        "bytes_per_step_per_gpu": nbytes, "parallelism": f"independent x{world}"},
-            "roofline": {"bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("chain", "rm_ew_fast"), "traffic_source": PMC_TRAFFIC_SOURCE,
-                         "kernel": "rm_ew_fast (16.8 MB per launch: launch-latency bound, not a roofline case)"},
+            # 14 fp64 ops per element with five transcendentals (sin, exp, cos, tanh, pow 2 -> x*x): ~2 us of HBM time against a kernel of
+            # ~16 us - the bound is the fp64 VALU (16 lanes per clock and SIMD), not HBM and not the launch
+            "roofline": valu_roofline("chain", "rm_ew_fast", kern_ms * 1e-3,
+                                      kernel="rm_ew_fast (14-op chain, 1024 x 1024: fp64 VALU bound)", kernel_ms=round(kern_ms, 5),
+                                      hbm_frac_for_completeness=round(nbytes / (kern_ms * 1e-3) / 1e9 / hbm_peak, 4),
+                                      host_ms_per_call=round(ms, 5), traffic=pmc_traffic("chain", "rm_ew_fast"), traffic_source=PMC_TRAFFIC_SOURCE),
         }
 
     def fused_f32_record(steps, warmup):
@@ -597,9 +704,8 @@ def main() -> None:
             "config": {"workload": "fused D=sin(A).*B+C 8192x8192 via rmhip_fused_elementwise (f32 WGSL request)",
                        "bytes_per_step_per_gpu": nbytes, "elements_per_s": round(world * n * n / (ms * 1e-3), 1),
                        "parallelism": f"independent x{world}"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("fused_f32", "rm_ew_fast"), "traffic_source": PMC_TRAFFIC_SOURCE,
-                         "kernel": "rm_ew_fast (f32 variant: 16-byte vectors of four, body in f64)", "kernel_ms": round(kern_ms, 5)},
+            "roofline": roofline("hbm", achieved, traffic=pmc_traffic("fused_f32", "rm_ew_fast"), traffic_source=PMC_TRAFFIC_SOURCE,
+                                 kernel="rm_ew_fast (f32 variant: 16-byte vectors of four, body in f64)", kernel_ms=round(kern_ms, 5)),
         }
 
     def sgemm_record(steps, warmup):
@@ -635,10 +741,8 @@ def main() -> None:
             "scaling": "strong", "dtype": "f32 (f32 MFMA accumulation)",
             "config": {"workload": "C=A*B 8192x8192x8192 f32 storage via rmhip_matmul", "flops_per_step": dgemm_flops,
                        "parallelism": f"row-block x{world}, B replicated, no collective"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": round(achieved / 157.3, 4),
-                         "traffic": pmc_traffic("sgemm", "k_sgemm_w8"), "traffic_source": PMC_TRAFFIC_SOURCE,
-                         "kernel": "k_sgemm_w8 (eight waves, pipelined k loop; v_mfma_f32_16x16x4_f32)", "kernel_ms": round(kern_ms, 5)},
+            "roofline": roofline("mfma_f32", achieved, 3, traffic=pmc_traffic("sgemm", "k_sgemm_w8"), traffic_source=PMC_TRAFFIC_SOURCE,
+                                 kernel="k_sgemm_w8 (eight waves, pipelined k loop; v_mfma_f32_16x16x4_f32)", kernel_ms=round(kern_ms, 5)),
         }
 
     def agreed(ok: bool) -> bool:

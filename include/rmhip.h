@@ -82,6 +82,11 @@ typedef struct rmhip_device_info {
     char backend[32];       /* ApiDeviceInfo::backend: "hip"                                                */
     int xcd_count;          /* accelerator dies the workgroup dispatcher interleaves over (8 on an MI355X in SPX mode, 1 in CPX),
                                probed at init; the LU's one-XCD placement and XCD-avoiding update kernels need exactly 8    */
+    int memory_clock_khz;   /* hipDeviceProp_t::memoryClockRate as the driver reports it (MI355X: 2 000 000; HBM3E moves 4 bits per pin
+                               and reported clock = 8 Gb/s per pin)                                                          */
+    int memory_bus_width_bits; /* hipDeviceProp_t::memoryBusWidth (MI355X: 8192): bench.py derives the box's HBM and MFMA peaks from
+                               these two, compute_units and clock_mhz instead of trusting constants                         */
+    int l2_cache_bytes;     /* per-XCD L2 (4 MiB) */
 } rmhip_device_info_t;
 /* @serves device_info device_info_struct default_reduction_workgroup_size two_pass_threshold */
 RMHIP_API int rmhip_device_info(rmhip_ctx* ctx, rmhip_device_info_t* out);

@@ -434,6 +434,9 @@ int rmhip_device_info(rmhip_ctx* ctx, rmhip_device_info_t* out) {
     out->compute_units = c->num_cus;
     out->wavefront_size = c->props.warpSize;
     out->clock_mhz = c->props.clockRate / 1000;
+    out->memory_clock_khz = c->props.memoryClockRate;
+    out->memory_bus_width_bits = c->props.memoryBusWidth;
+    out->l2_cache_bytes = c->props.l2CacheSize;
     out->total_memory_bytes = c->props.totalGlobalMem;
     out->precision_bits = c->precision;
     out->reduction_workgroup_size = 256;

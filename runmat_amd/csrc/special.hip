@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "skel_common.h"
+#include "pow_tab.h"
 
 namespace rmhip {
 
@@ -177,27 +178,30 @@ __global__ void __launch_bounds__(FIN_BLOCK) k_plane_moments_final(const Mom* __
 }
 
 // one pixel: y = (x - mean) * inv [* gain] [+ bias] [max 0] [^ gamma]
+template <bool TAB>
 __device__ __forceinline__ double imgnorm_value(double x, double mu, double inv, int has_gain, double gain, int has_bias, double bias,
-                                                int clamp_zero, int has_gamma, double gamma) {
+                                                int clamp_zero, int has_gamma, double gamma, const PowTables& tb) {
     double w = (x - mu) * inv;
     if (has_gain) w *= gain;
     if (has_bias) w += bias;
     if (clamp_zero) w = fmax(w, 0.0);  // f64::max: a NaN operand loses
-    // gamma step: for a positive base one fused log -> multiply -> exp (rm_pow_pos, skel_common.h: ~55 instructions, the
-    // library pow is ~200 and made this pass VALU-bound); relative error <= (0.45 |g ln w| + 1.5) 2^-53, |g ln w| <= 32,
-    // beyond that (pixels below e^(-32 / g)) and for 0, +Inf, NaN and negative bases (no clamp requested) the library pow.
-    // (+0 - half of a clamped image - is answered in place: pow(+0, g > 0) = +0)
+    // gamma step: for a positive base table log -> multiply -> table exp (rm_pow_tab above; the library pow is ~200 instructions and
+    // made this pass VALU-bound); for 0, +Inf, NaN, subnormal and negative bases (no clamp requested) and beyond |g ln w| > 700 the
+    // library pow.  (+0 - half of a clamped image - is answered in place: pow(+0, g > 0) = +0)
     if (has_gamma) {
-        if (gamma > 0.0 && w > 0.0) w = rm_pow_pos(w, gamma);
+        if (gamma > 0.0 && w > 0.0) w = TAB ? rm_pow_tab(w, gamma, tb) : rm_pow_pos(w, gamma);
         else if (!(gamma > 0.0 && __double_as_longlong(w) == 0ll)) w = rm_pow_cold(w, gamma);
     }
     return w;
 }
 
-template <class T, int VEC>
+template <class T, int VEC, bool TAB = true>
 __global__ void __launch_bounds__(IN_BLOCK) k_imgnorm_apply(const T* __restrict__ x, T* __restrict__ y, size_t total,
                                                        int batch, const double* __restrict__ stats, int has_gain, double gain,
                                                        int has_bias, double bias, int clamp_zero, int has_gamma, double gamma) {
+    __shared__ __attribute__((aligned(16))) double s_pow[kPowLdsDoubles];
+    PowTables tb{};
+    if (TAB && has_gamma && gamma > 0.0) tb = pow_stage_tables(s_pow, threadIdx.x, blockDim.x);  // uniform branch: the barrier inside is safe
     const int b = (VEC * (int)threadIdx.x) % batch;
     double mu[VEC], inv[VEC];
 #pragma unroll
@@ -213,7 +217,7 @@ __global__ void __launch_bounds__(IN_BLOCK) k_imgnorm_apply(const T* __restrict_
     constexpr int APPLY_U = 1;
     auto one = [&](double (&v)[VEC], size_t i) {
 #pragma unroll
-        for (int l = 0; l < VEC; ++l) v[l] = imgnorm_value(v[l], mu[l], inv[l], has_gain, gain, has_bias, bias, clamp_zero, has_gamma, gamma);
+        for (int l = 0; l < VEC; ++l) v[l] = imgnorm_value<TAB>(v[l], mu[l], inv[l], has_gain, gain, has_bias, bias, clamp_zero, has_gamma, gamma, tb);
         if constexpr (VEC == 1) {
             __builtin_nontemporal_store((T)v[0], y + i);
         } else {
@@ -249,7 +253,8 @@ __global__ void __launch_bounds__(256) k_imgnorm_apply_flat(const double* __rest
         load_vec<double, VEC>(x, i, v);
         const unsigned b = (unsigned)((i * VEC) % batch);  // VEC divides batch: b + l stays below it
 #pragma unroll
-        for (int l = 0; l < VEC; ++l) v[l] = imgnorm_value(v[l], stats[b + l], stats[batch + b + l], has_gain, gain, has_bias, bias, clamp_zero, has_gamma, gamma);
+        for (int l = 0; l < VEC; ++l)
+            v[l] = imgnorm_value<false>(v[l], stats[b + l], stats[batch + b + l], has_gain, gain, has_bias, bias, clamp_zero, has_gamma, gamma, PowTables{});
         if constexpr (VEC == 1) {
             __builtin_nontemporal_store(v[0], y + i);
         } else {
@@ -298,18 +303,23 @@ static int image_normalize_vec(Context* c, const T* x, T* y, size_t batch, size_
     hipLaunchKernelGGL((k_plane_moments<T, VEC>), dim3(grid), dim3(threads), 0, c->stream, x, total, (int)batch, partial);
     hipLaunchKernelGGL(k_plane_moments_final, dim3((unsigned)batch), dim3(FIN_BLOCK), 0, c->stream, partial, (int)grid, (int)batch, (double)plane,
                        epsilon, stats);
-    // the apply pass with the gamma step runs 512-thread blocks: with the cold pow out of line (skel_common.h: rm_pow_cold) it needs 51
-    // registers instead of 84 and three such blocks share a CU - 0.645 -> 0.633 ms at 16 x 2160 x 3840; without gamma the 1024-thread
-    // blocks stay (0.551 against 0.567 / 0.587 ms with 512 / 256).  RMHIP_IMG_APPLY_BLOCK overrides (A/B).
+    // the apply pass with the gamma step runs 256-thread blocks (round 4, table pow: 0.617 / 0.632 / 0.651 ms at 256 / 512 / 1024 threads,
+    // 16 x 2160 x 3840; round 3's rm_pow_pos on the same box 0.721 / 0.744 / 0.757); without gamma the 1024-thread blocks stay (0.551
+    // against 0.567 / 0.587 ms with 512 / 256).  RMHIP_IMG_APPLY_BLOCK overrides (A/B).
     static const int apply_env = std::getenv("RMHIP_IMG_APPLY_BLOCK") ? std::atoi(std::getenv("RMHIP_IMG_APPLY_BLOCK")) : 0;
-    const int apply_block = apply_env > 0 ? apply_env : (has_gamma ? 512 : IN_BLOCK);
+    const int apply_block = apply_env > 0 ? apply_env : (has_gamma ? 256 : IN_BLOCK);
     const unsigned athreads = (unsigned)(((size_t)(apply_block < 64 ? 64 : (apply_block > IN_BLOCK ? IN_BLOCK : apply_block)) / batch) * batch);
     const unsigned at = athreads ? athreads : threads;
     size_t awant = (total / VEC + (size_t)at * 2 - 1) / ((size_t)at * 2);
     const size_t acap = (size_t)c->num_cus * 8 * (threads / at ? threads / at : 1);
     const unsigned agrid = (unsigned)(awant < acap ? (awant < 1 ? 1 : awant) : acap);
-    hipLaunchKernelGGL((k_imgnorm_apply<T, VEC>), dim3(agrid), dim3(at), 0, c->stream, x, y, total, (int)batch, stats, has_gain, gain,
-                       has_bias, bias, clamp_zero, has_gamma, gamma);
+    static const bool pow_tab = !(std::getenv("RMHIP_IMG_POW") && std::getenv("RMHIP_IMG_POW")[0] == 'p');  // RMHIP_IMG_POW=pos: round 3's rm_pow_pos (A/B)
+    if (pow_tab)
+        hipLaunchKernelGGL((k_imgnorm_apply<T, VEC, true>), dim3(agrid), dim3(at), 0, c->stream, x, y, total, (int)batch, stats, has_gain, gain,
+                           has_bias, bias, clamp_zero, has_gamma, gamma);
+    else
+        hipLaunchKernelGGL((k_imgnorm_apply<T, VEC, false>), dim3(agrid), dim3(at), 0, c->stream, x, y, total, (int)batch, stats, has_gain, gain,
+                           has_bias, bias, clamp_zero, has_gamma, gamma);
     c->tel.kernel_launches += 3;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;

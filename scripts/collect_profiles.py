@@ -1,4 +1,4 @@
-"""Developer tool (this container): copy what scripts/profile_r03.sh left under gpurun_out/prof_<tag>/ into profiles/ under the round's
+"""Developer tool (this container): copy what scripts/profile_r03.sh / profile_r04.sh left under gpurun_out/prof_<tag>/ into profiles/ under the round's
 names - per workload the `--kernel-trace --stats` kernel summary and the bench line printed under the profiler, the counter summary
 and the traffic table bench.py reads.  Usage: collect_profiles.py <tag>   (e.g. r03)"""
 import glob, shutil, sys
@@ -23,4 +23,6 @@ for name in ("mldivide_timeline.txt", "tier2_rates.txt", "red2_rates.txt", "red_
         shutil.copy(src / name, dst / f"{tag}_{name}"); n += 1
 shutil.copy(src / "pmc_summary.json", dst / f"{tag}_pmc_summary.json")
 shutil.copy(src / "pmc_traffic.json", dst / "pmc_traffic.json")
+if (src / "pmc_valu.json").exists():
+    shutil.copy(src / "pmc_valu.json", dst / "pmc_valu.json")
 print(f"copied {n + 2} files into {dst}")

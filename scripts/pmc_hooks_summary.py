@@ -23,5 +23,5 @@ for mode in ("lazy", "eager"):
         fv, wv = fetch.get(k, [0.0]), write.get(k, [0.0])
         f_mib, w_mib = 2 * sum(fv) / len(fv) / 1024, sum(wv) / len(wv) / 1024
         calls, avg = dur.get(k, (len(fv), float("nan")))
-        short = k.split("(")[0].replace("void rmhip::", "").replace("rmhip::", "").replace("(anonymous namespace)::", "")[:70]
+        short = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void rmhip::", "").replace("rmhip::", "")[:70]
         print(f"{short:70s} {calls:5d} {avg:9.1f} {f_mib:10.1f} {w_mib:10.1f} {f_mib + w_mib:9.1f}")

@@ -68,6 +68,36 @@ for w in workloads:
             for cn, v in d.items():
                 rec[cn + "_mean"] = sum(v) / len(v)
             summary.append(rec)
+# VALU pass (scripts/profile_r04.sh): wave-level VALU instructions per launch and the share of the SIMDs' cycles they keep busy.
+# SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves (MI355X_MICROARCH.md, counter units); a SIMD issues one VALU instruction at a
+# time, so busy = 4 * SQ_ACTIVE_INST_VALU / (SIMDs * GRBM_GUI_ACTIVE) with 1024 SIMDs.
+valu = {"_durations_us": {}}
+for w in workloads:
+    valu["_durations_us"][w] = {k.replace("(anonymous namespace)::", "").split("(")[0].replace("void rmhip::", "").replace("rmhip::", "")[:80]: round(v[1], 2)
+                                for k, v in durations(f"trace_{w}").items()}
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(f"{out}/pmc_valu_{w}/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            agg[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k, d in agg.items():
+        if not d.get("SQ_INSTS_VALU"):
+            continue
+        mean = {cn: sum(v) / len(v) for cn, v in d.items()}
+        short = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void rmhip::", "").replace("rmhip::", "")[:80]
+        gui = mean.get("GRBM_GUI_ACTIVE", 0.0)
+        rec = {"launches": len(d["SQ_INSTS_VALU"]), "insts_valu_per_launch": round(mean["SQ_INSTS_VALU"]),
+               "active_inst_valu_quadcycles": round(mean.get("SQ_ACTIVE_INST_VALU", 0.0)), "wave_quadcycles": round(mean.get("SQ_WAVE_CYCLES", 0.0)),
+               "gui_active_cycles": round(gui),
+               "valu_busy": round(4.0 * mean.get("SQ_ACTIVE_INST_VALU", 0.0) / (1024.0 * gui), 4) if gui else None,
+               "cycles_per_valu_inst": round(4.0 * mean.get("SQ_ACTIVE_INST_VALU", 0.0) / mean["SQ_INSTS_VALU"], 2) if mean["SQ_INSTS_VALU"] else None}
+        valu.setdefault(w, {})[short] = rec
+        summary.append({"workload": w, "kernel": k[:120], **{cn + "_mean": v for cn, v in mean.items()}})
+json.dump({"_method": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace over the bench command of each "
+                      "workload (scripts/profile_r04.sh), means per launch.  valu_busy = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE): the share of "
+                      "SIMD cycles spent issuing VALU instructions; cycles_per_valu_inst = their average issue cost (fp64 arithmetic 4, conversions 8, "
+                      "rcp / rsq / sqrt 16, 32-bit integer 2: profiles/r04_valu_instruction_rates.txt).  _durations_us: average launch durations of the "
+                      "--kernel-trace --stats pass of the same command.", **valu},
+          open(f"{out}/pmc_valu.json", "w"), indent=1)
 json.dump(summary, open(f"{out}/pmc_summary.json", "w"), indent=1)
 traffic = {"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (plus a --kernel-trace --stats pass for the durations) over "
                       "`bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-also --workload <w>` (mldivide: --steps 2 --warmup 1; reductions: scripts/red_driver.py) - "
