@@ -273,13 +273,13 @@ def main() -> None:
         return {"bound": "mfma" if bound == "mfma_f32" else bound, "achieved": round(achieved, digits), "peak": peak, "peak_spec": spec, "unit": unit,
                 "frac": round(achieved / peak, 4), **extra}
 
-    def valu_roofline(workload: str, kernel: str, kernel_s: float, **extra) -> dict:
+    def valu_roofline(workload: str, kname: str, kernel_s: float, **extra) -> dict:
         """fp64-VALU roofline of one kernel: achieved = wave-level VALU instructions per launch (committed counter pass) / the launch time
         measured in THIS run; peak = SIMDs x clock / 4 (an fp64 instruction occupies its SIMD for four cycles).  The counter pass's busy
         share and mean issue cost ride along.  Falls back to an HBM block when the counter file has no entry (fresh checkout)."""
-        v = pmc_valu(workload, kernel)
+        v = pmc_valu(workload, kname)
         if not v or not v.get("insts_valu_per_launch"):
-            return {**roofline("hbm", 0.0), "note": f"no VALU counters for {workload}/{kernel} in profiles/pmc_valu.json", **extra}
+            return {**roofline("hbm", 0.0), "note": f"no VALU counters for {workload}/{kname} in profiles/pmc_valu.json", **extra}
         return roofline("valu", v["insts_valu_per_launch"] / kernel_s / 1e9, 1, valu_insts_per_launch=v["insts_valu_per_launch"],
                         valu_busy_profiled=v.get("valu_busy"), cycles_per_valu_inst=v.get("cycles_per_valu_inst"), counters_source=PMC_VALU_SOURCE, **extra)
 
@@ -303,7 +303,7 @@ def main() -> None:
                 rec["valu_ginstr_per_s"] = round(val["insts_valu_per_launch"] / (us * 1e-6) / 1e9, 1)
                 rec["valu_frac"] = round(rec["valu_ginstr_per_s"] / valu_peak, 4)
                 rec["valu_busy_profiled"] = val.get("valu_busy")
-                rec["bound"] = "valu" if (val.get("valu_busy") or 0) > rec["hbm_frac"] else "hbm"
+                rec["bound"] = "valu" if rec["valu_frac"] > rec["hbm_frac"] else "hbm"
             out[name] = rec
         return out or None
     # Data-path collectives go through the C ABI (rmhip_comm_*: RCCL over xGMI, one rank per GPU); torch.distributed

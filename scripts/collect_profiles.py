@@ -22,7 +22,12 @@ for name in ("mldivide_timeline.txt", "tier2_rates.txt", "red2_rates.txt", "red_
     if (src / name).exists() and (src / name).stat().st_size:
         shutil.copy(src / name, dst / f"{tag}_{name}"); n += 1
 shutil.copy(src / "pmc_summary.json", dst / f"{tag}_pmc_summary.json")
-shutil.copy(src / "pmc_traffic.json", dst / "pmc_traffic.json")
+# merge: a round may re-profile only some workloads; the entries of the others stay
+import json
+new = json.loads((src / "pmc_traffic.json").read_text())
+cur = json.loads((dst / "pmc_traffic.json").read_text()) if (dst / "pmc_traffic.json").exists() else {}
+cur.update({k: v for k, v in new.items() if not k.startswith("_") or k not in cur})
+(dst / "pmc_traffic.json").write_text(json.dumps(cur, indent=1))
 if (src / "pmc_valu.json").exists():
     shutil.copy(src / "pmc_valu.json", dst / "pmc_valu.json")
 print(f"copied {n + 2} files into {dst}")

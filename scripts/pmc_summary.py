@@ -6,7 +6,7 @@ import collections, csv, glob, json, sys
 
 out = sys.argv[1]
 workloads = sys.argv[2:]
-LEGS = {"fused": 2, "dgemm": 2, "sgemm": 2, "fused_f32": 2}  # workloads whose record runs its steps twice (wall-clock leg + HIP-event leg)
+LEGS = {"fused": 2, "dgemm": 2, "sgemm": 2, "fused_f32": 2, "chain": 2}  # workloads whose record runs its steps twice (wall-clock leg + HIP-event leg)
 SETUP = ("k_fill", "k_probe_xcc", "__amd_rocclr", "k_narrow", "k_widen")  # not part of a step
 SETUP_BY_WORKLOAD = {"mldivide": ("k_fill", "k_probe_xcc", "__amd_rocclr_fillBuffer", "__amd_rocclr_copyBuffer(", "__amd_rocclr_copyBufferAligned")}  # the rect copy of A into the padded workspace IS part of a solve
 
@@ -69,8 +69,10 @@ for w in workloads:
                 rec[cn + "_mean"] = sum(v) / len(v)
             summary.append(rec)
 # VALU pass (scripts/profile_r04.sh): wave-level VALU instructions per launch and the share of the SIMDs' cycles they keep busy.
-# SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves (MI355X_MICROARCH.md, counter units); a SIMD issues one VALU instruction at a
-# time, so busy = 4 * SQ_ACTIVE_INST_VALU / (SIMDs * GRBM_GUI_ACTIVE) with 1024 SIMDs.
+# SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves (MI355X_MICROARCH.md, counter units) - one per issued VALU instruction, whatever
+# its execution rate - and GRBM_GUI_ACTIVE comes back summed over the eight XCDs; a SIMD issues one VALU instruction at a time, so the
+# issue-slot share is 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8).  (Under the profiler the clock sits near 1.9 GHz and
+# GUI_ACTIVE includes the dispatch ramp, so bench.py's VALU roofline uses instructions / the launch time IT measures instead.)
 valu = {"_durations_us": {}}
 for w in workloads:
     valu["_durations_us"][w] = {k.replace("(anonymous namespace)::", "").split("(")[0].replace("void rmhip::", "").replace("rmhip::", "")[:80]: round(v[1], 2)
@@ -88,13 +90,13 @@ for w in workloads:
         rec = {"launches": len(d["SQ_INSTS_VALU"]), "insts_valu_per_launch": round(mean["SQ_INSTS_VALU"]),
                "active_inst_valu_quadcycles": round(mean.get("SQ_ACTIVE_INST_VALU", 0.0)), "wave_quadcycles": round(mean.get("SQ_WAVE_CYCLES", 0.0)),
                "gui_active_cycles": round(gui),
-               "valu_busy": round(4.0 * mean.get("SQ_ACTIVE_INST_VALU", 0.0) / (1024.0 * gui), 4) if gui else None,
+               "valu_busy": round(4.0 * mean.get("SQ_ACTIVE_INST_VALU", 0.0) / (1024.0 * gui / 8.0), 4) if gui else None,
                "cycles_per_valu_inst": round(4.0 * mean.get("SQ_ACTIVE_INST_VALU", 0.0) / mean["SQ_INSTS_VALU"], 2) if mean["SQ_INSTS_VALU"] else None}
         valu.setdefault(w, {})[short] = rec
         summary.append({"workload": w, "kernel": k[:120], **{cn + "_mean": v for cn, v in mean.items()}})
 json.dump({"_method": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace over the bench command of each "
-                      "workload (scripts/profile_r04.sh), means per launch.  valu_busy = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE): the share of "
-                      "SIMD cycles spent issuing VALU instructions; cycles_per_valu_inst = their average issue cost (fp64 arithmetic 4, conversions 8, "
+                      "workload (scripts/profile_r04.sh), means per launch.  valu_busy = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs): the share of "
+                      "SIMD issue slots taken by VALU instructions while the GPU was active (profiler clock, dispatch ramp included); cycles_per_valu_inst = their average issue cost (fp64 arithmetic 4, conversions 8, "
                       "rcp / rsq / sqrt 16, 32-bit integer 2: profiles/r04_valu_instruction_rates.txt).  _durations_us: average launch durations of the "
                       "--kernel-trace --stats pass of the same command.", **valu},
           open(f"{out}/pmc_valu.json", "w"), indent=1)
