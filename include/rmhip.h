@@ -48,7 +48,9 @@ enum rmhip_status {
     RMHIP_ERR_COMPILE = 6,     /* WGSL front-end or hipRTC failure                              */
     RMHIP_ERR_SINGULAR = 7,    /* LU pivot <= 1e-12: caller must use the CPU SVD path           */
     RMHIP_ERR_OOM = 8,
-    RMHIP_ERR_NO_DEVICE = 9
+    RMHIP_ERR_NO_DEVICE = 9,
+    RMHIP_ERR_GROWTH = 10      /* sharded solve: a multiplier outside the diagonal domains exceeded the bound (or a rank failed): use
+                                  the block-column form, whose pivot rule is grid-wide                                            */
 };
 
 /* ---- library / context ---------------------------------------------------------------------- */
@@ -456,6 +458,10 @@ RMHIP_API int rmhip_blk_lu(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf* ipi
 /* @serves - */
 RMHIP_API int rmhip_blk_swap_rows(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf ipiv);
 
+/* max |a_ij| over a view (NaN if the view holds one): the multiplier guard of the row-partitioned solve. */
+/* @serves - */
+RMHIP_API int rmhip_blk_absmax(rmhip_ctx* ctx, const rmhip_view_t* a, double* out);
+
 /* ---- multi-GPU collectives ------------------------------------------------------------------------- *
  * One process per GPU, one context per process.  The reference has no multi-device code; these entry
  * points are what the sharded forms of the hot path need from a host that is not Python: a row-block
@@ -498,6 +504,32 @@ RMHIP_API int rmhip_comm_allgather_f64(rmhip_ctx* ctx, rmhip_buf local, rmhip_bu
  * ragged tail); *out is the replicated rows_total x n matrix. */
 /* @serves - */
 RMHIP_API int rmhip_comm_allgather_rows(rmhip_ctx* ctx, rmhip_buf local, size_t rows_total, size_t granule, rmhip_buf* out);
+
+/* ---- sharded forms of the hot path behind the C ABI ---------------------------------------------- *
+ * For hosts that are not Python (runmat_amd/sharding.py issues the same sequences from Python; tests/test_gpu_multirank.py
+ * runs both side by side).  Every rank calls the same entry point with its local block, after rmhip_comm_init.
+ *
+ * rmhip_matmul_row_sharded: C[rows_g, :] = A[rows_g, :] * B with B replicated - the embarrassingly parallel form, no exchange.
+ * gather != 0 appends the row-block all-gather (rmhip_comm_allgather_rows: balanced split of rows_total in units of `granule`,
+ * 0 = 128) and returns the replicated rows_total x n product; gather == 0 returns this rank's rows. */
+/* @serves - */
+RMHIP_API int rmhip_matmul_row_sharded(rmhip_ctx* ctx, rmhip_buf a_rows, rmhip_buf b, size_t rows_total, size_t granule, int gather,
+                                       rmhip_buf* out);
+/* rmhip_mldivide_row_partitioned: x = A \ b with [A | b] (n x (n + nrhs)) distributed BY ROWS - row block q of height rb lives on rank
+ * q % world, blocks in ownership order in `ab_local`, which is OVERWRITTEN with this rank's rows of the factors.  *out is the
+ * replicated n x nrhs solution, identical on every rank.  Pivots never leave a solve, so - as on one GPU (lu.hip, solve path) -
+ * pivoting is restricted to a diagonal domain and verified: panel p is factored by its owner with partial pivoting among the owner's
+ * OWN rows from the diagonal tile down, one broadcast per panel carries the owner's tile row [L11\U11 | U12 | y], every rank forms
+ * its rows' multipliers and trailing update without further exchange, the last `world` row blocks are gathered and finished by every
+ * rank with the single-GPU solve, the back substitution is redundant.  Depth-1 look-ahead: the owner of panel p + 1 updates that
+ * panel first, factors it and posts its broadcast on the communication stream under the rest of update p.  Guard: the largest
+ * multiplier outside the owners' domains, one exchange at the end; beyond `tau` (8 is the single-GPU default) - or when ANY rank
+ * failed (a singular pivot inside its domain, an allocation): the failing rank keeps taking part in every collective with NaN-poisoned
+ * data, so no rank is left blocked - every rank returns RMHIP_ERR_GROWTH and the host falls back to the block-column form.  Needs a
+ * precision-64 provider. */
+/* @serves - */
+RMHIP_API int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n, size_t nrhs, size_t rb, double tau,
+                                             rmhip_buf* out);
 
 /* ---- RNG  (lib.rs:1713-1728, 1772) ---------------------------------------------------------- */
 

@@ -17,7 +17,7 @@ OK = 0
 COMM_ID_BYTES = 128
 COMM_RCCL, COMM_HOST_SHM = 0, 1
 ERR_INVALID, ERR_UNSUPPORTED, ERR_SHAPE, ERR_HIP, ERR_NOT_FOUND = 1, 2, 3, 4, 5
-ERR_COMPILE, ERR_SINGULAR, ERR_OOM, ERR_NO_DEVICE = 6, 7, 8, 9
+ERR_COMPILE, ERR_SINGULAR, ERR_OOM, ERR_NO_DEVICE, ERR_GROWTH = 6, 7, 8, 9, 10
 
 
 # Structures, signatures and constants are GENERATED from include/rmhip.h (scripts/gen_bindings.py -> _abi.py); the table is

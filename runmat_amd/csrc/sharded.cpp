@@ -1,0 +1,346 @@
+// sharded.cpp -- the sharded forms of the hot path behind the C ABI, for hosts that are not Python:
+//   rmhip_matmul_row_sharded        C[rows_g, :] = A[rows_g, :] * B, optionally followed by the row-block all-gather
+//   rmhip_mldivide_row_partitioned  x = A \ b with [A | b] distributed by row blocks (BASELINE.json configs[4])
+//   rmhip_blk_absmax                max |a_ij| over a view (the multiplier guard)
+// The reference has no multi-device code: nothing here replaces a trait method.  One process per GPU, one
+// context per process, a communicator attached with rmhip_comm_init (RCCL over xGMI, or host shared memory for tests); every
+// rank calls the same entry point with its local block.  The drivers are written over the library's own block-level entry
+// points (rmhip_blk_* on sub-blocks, rmhip_comm_bcast / allgather) - the same sequence runmat_amd/sharding.py issues from
+// Python, with which tests/test_gpu_multirank.py compares them bit for bit - plus a depth-1 look-ahead in the solver.
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+using namespace rmhip;
+
+#define CTX_OR_FAIL(ctx)                                            \
+    if (!(ctx)) return fail(RMHIP_ERR_INVALID, "null context");     \
+    Context* c = context_of(ctx);                                   \
+    std::lock_guard<std::recursive_mutex> _call(c->call_mu);        \
+    DeviceGuard _dg(c);                                             \
+    NarrowScope _ns(c)
+
+namespace {
+
+rmhip_view_t view(rmhip_buf buf, size_t r0, size_t c0, size_t rows, size_t cols) { return rmhip_view_t{buf, r0, c0, rows, cols}; }
+
+// frees every buffer it was handed when it goes out of scope (error paths included)
+struct Temps {
+    rmhip_ctx* ctx;
+    std::vector<rmhip_buf> ids;
+    explicit Temps(rmhip_ctx* x) : ctx(x) {}
+    rmhip_buf keep(rmhip_buf id) {
+        ids.push_back(id);
+        return id;
+    }
+    void drop(rmhip_buf id) {
+        for (auto& v : ids)
+            if (v == id) {
+                (void)rmhip_free(ctx, id);
+                v = 0;
+                return;
+            }
+    }
+    ~Temps() {
+        for (rmhip_buf id : ids)
+            if (id) (void)rmhip_free(ctx, id);
+    }
+};
+
+int zeros(rmhip_ctx* ctx, size_t rows, size_t cols, rmhip_buf* out) {
+    const size_t shape[2] = {rows, cols};
+    return rmhip_fill(ctx, 0.0, shape, 2, out);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rmhip_blk_absmax(rmhip_ctx* ctx, const rmhip_view_t* v, double* out) {
+    CTX_OR_FAIL(ctx);
+    if (!v || !out) return fail(RMHIP_ERR_INVALID, "blk_absmax: null argument");
+    *out = 0.0;
+    if (v->rows * v->cols == 0) return RMHIP_OK;
+    rmhip_buf blk = 0, ab = 0, mx = 0;
+    Temps t(ctx);
+    RMHIP_TRY(rmhip_blk_copy(ctx, v, &blk));
+    t.keep(blk);
+    RMHIP_TRY(rmhip_unary(ctx, RMHIP_ABS, blk, &ab));
+    t.keep(ab);
+    RMHIP_TRY(rmhip_reduce(ctx, RMHIP_RMAX, ab, -1, /*include NaN: a NaN multiplier must fail the guard*/ 0, &mx));
+    t.keep(mx);
+    return rmhip_read_scalar(ctx, mx, 0, out);
+}
+
+int rmhip_matmul_row_sharded(rmhip_ctx* ctx, rmhip_buf a_rows, rmhip_buf b, size_t rows_total, size_t granule, int gather, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    rmhip_buf local = 0;
+    RMHIP_TRY(rmhip_matmul(ctx, a_rows, b, &local));  // the embarrassingly parallel part: no exchange
+    int rank = 0, world = 1;
+    RMHIP_TRY(rmhip_comm_rank(ctx, &rank, &world));
+    if (!gather || world == 1) {
+        *out = local;
+        return RMHIP_OK;
+    }
+    const int rc = rmhip_comm_allgather_rows(ctx, local, rows_total, granule ? granule : 128, out);
+    (void)rmhip_free(ctx, local);
+    return rc;
+}
+
+// Row block q (height rb) of the n x (n + nrhs) augmented matrix lives on rank q % world, blocks in ownership order in `ab_local`
+// (overwritten with this rank's rows of the factors).  Algorithm, guard and failure modes: include/rmhip.h.
+int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n, size_t nrhs, size_t rb, double tau, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    if (c->precision != 64) return fail(RMHIP_ERR_UNSUPPORTED, "mldivide_row_partitioned: needs a precision-64 provider (block views update f64 storage in place)");
+    if (n == 0 || nrhs == 0 || rb == 0) return fail(RMHIP_ERR_INVALID, "mldivide_row_partitioned: empty system");
+    int rank = 0, world = 1;
+    RMHIP_TRY(rmhip_comm_rank(ctx, &rank, &world));
+    const size_t ncols = n + nrhs, nblocks = (n + rb - 1) / rb;
+    std::vector<size_t> mine;  // owned row blocks, ascending = local storage order
+    for (size_t q = 0; q < nblocks; ++q)
+        if ((int)(q % (size_t)world) == rank) mine.push_back(q);
+    size_t nloc = 0;
+    for (size_t q : mine) nloc += std::min(rb, n - q * rb);
+    {
+        size_t shape[8], r = 8;
+        RMHIP_TRY(rmhip_shape(ctx, ab_local, &r, shape));
+        if (r != 2 || shape[0] != nloc || shape[1] != ncols)
+            return fail(RMHIP_ERR_SHAPE, "mldivide_row_partitioned: rank %d of %d owns %zu rows of the %zu x %zu augmented matrix, the local block is not %zu x %zu",
+                        rank, world, nloc, n, ncols, nloc, ncols);
+    }
+    auto local_row_offset = [&](size_t q) { return (q / (size_t)world) * rb; };
+    auto first_local_row_at_or_after = [&](size_t q) {
+        for (size_t b : mine)
+            if (b >= q) return local_row_offset(b);
+        return nloc;
+    };
+    const size_t n_direct = nblocks > (size_t)world ? nblocks - (size_t)world : 0;  // panels whose owner still has a block below the tile
+    const bool overlap = world > 1;  // asynchronous broadcasts on the communication stream (look-ahead)
+    Temps temps(ctx);
+    // A failure on one rank (singular pivot inside its domain, an allocation) must not leave the others blocked in the panel
+    // broadcast: the failing rank poisons what it sends with NaN and keeps taking part in every collective; the NaN reaches every
+    // rank's multiplier guard, so all of them leave together after the one exchange at the end.
+    bool failed = false;
+    std::string why;
+    auto poison = [&](rmhip_buf tile, size_t rows, size_t cols) {
+        rmhip_buf nanb = 0;
+        const size_t shape[2] = {rows, cols};
+        if (rmhip_fill(ctx, std::numeric_limits<double>::quiet_NaN(), shape, 2, &nanb) != RMHIP_OK) return;
+        const rmhip_view_t dst = view(tile, 0, 0, rows, cols);
+        (void)rmhip_blk_assign(ctx, &dst, nanb);
+        (void)rmhip_free(ctx, nanb);
+    };
+    double growth = 0.0;
+    auto note_growth = [&](double v) {
+        if (v != v || v > growth) growth = v;  // NaN sticks (max(0, NaN) must not be 0)
+    };
+    struct Tile {
+        size_t j, w;
+        rmhip_buf id;
+    };
+    std::vector<Tile> tiles;  // every direct panel's tile row [w x (ncols - j)], kept for the back substitution
+
+    // the owner's share of panel p: factor among its own rows from the tile down, interchanges, [pending work on the interchanged tile
+    // rows], U12 and the y part; returns the tile row.  `before_trsm` runs between the interchanges and the triangular solve: the
+    // look-ahead applies the previous panel's update to the (now final) tile rows there - rows exchanged above carry their
+    // multipliers with them (the left part is swapped too), so update-after-swap equals swap-after-update.
+    auto factor_panel = [&](size_t p, rmhip_buf* tile_out, const std::function<int()>& before_trsm) -> int {
+        const size_t j = p * rb, w = rb, width = ncols - j;
+        const size_t lr = local_row_offset(p);
+        rmhip_buf ipiv = 0;
+        int info = 0;
+        const rmhip_view_t pan = view(ab_local, lr, j, nloc - lr, w);
+        int rc = rmhip_blk_lu(ctx, &pan, &ipiv, &info);
+        if (rc == RMHIP_OK && info > 0) {
+            (void)rmhip_free(ctx, ipiv);
+            return fail(RMHIP_ERR_GROWTH, "panel %zu: %d pivot(s) at the singular cut-off inside the diagonal domain", p, info);
+        }
+        if (rc != RMHIP_OK) return rc;
+        if (j > 0) {
+            const rmhip_view_t left = view(ab_local, lr, 0, nloc - lr, j);
+            rc = rmhip_blk_swap_rows(ctx, &left, ipiv);
+        }
+        if (rc == RMHIP_OK) {
+            const rmhip_view_t right = view(ab_local, lr, j + w, nloc - lr, width - w);
+            rc = rmhip_blk_swap_rows(ctx, &right, ipiv);
+        }
+        (void)rmhip_free(ctx, ipiv);
+        if (rc != RMHIP_OK) return rc;
+        if (before_trsm) RMHIP_TRY(before_trsm());
+        const rmhip_view_t t11 = view(ab_local, lr, j, w, w), a12 = view(ab_local, lr, j + w, w, width - w);
+        RMHIP_TRY(rmhip_blk_trsm(ctx, 0, &t11, &a12));  // U12 and the y part: L11^-1 [A12 | b]
+        const rmhip_view_t row = view(ab_local, lr, j, w, width);
+        return rmhip_blk_copy(ctx, &row, tile_out);
+    };
+    // post panel p: the owner factors and sends, everybody else posts the receive (asynchronous when there is someone to talk to)
+    auto post_panel = [&](size_t p, rmhip_buf* tile_out, const std::function<int()>& before_trsm) -> int {
+        const size_t j = p * rb, w = rb, width = ncols - j;
+        const int owner = (int)(p % (size_t)world);
+        rmhip_buf tile = 0;
+        if (rank == owner && !failed) {
+            const int rc = factor_panel(p, &tile, before_trsm);
+            if (rc != RMHIP_OK) {
+                failed = true;
+                why = rmhip_last_error();
+                tile = 0;
+            }
+        }
+        if (!tile) {
+            RMHIP_TRY(zeros(ctx, w, width, &tile));
+            if (rank == owner) poison(tile, w, width);  // failed owner: everybody learns through the guard
+        }
+        temps.keep(tile);
+        const rmhip_view_t tv = view(tile, 0, 0, w, width);
+        if (world > 1) RMHIP_TRY(rmhip_comm_bcast(ctx, &tv, owner, overlap ? 1 : 0));
+        *tile_out = tile;
+        return RMHIP_OK;
+    };
+    // this rank's rows below `below`: multipliers against the tile (not on the owner, whose rows were factored with it) and the
+    // trailing update restricted to tile columns [c0, c1) (tile-relative, c0 >= w)
+    auto multipliers = [&](rmhip_buf tile, size_t j, size_t w, size_t below, bool is_owner) -> int {
+        const size_t mb = nloc - below;
+        if (mb == 0 || is_owner) return RMHIP_OK;
+        const rmhip_view_t t11 = view(tile, 0, 0, w, w), a21 = view(ab_local, below, j, mb, w);
+        RMHIP_TRY(rmhip_blk_trsm(ctx, 2, &t11, &a21));  // L21 = A21 U11^-1
+        double g = 0.0;
+        RMHIP_TRY(rmhip_blk_absmax(ctx, &a21, &g));
+        note_growth(g);
+        return RMHIP_OK;
+    };
+    auto update = [&](rmhip_buf tile, size_t j, size_t w, size_t r0, size_t r1, size_t c0, size_t c1) -> int {
+        if (r1 <= r0 || c1 <= c0) return RMHIP_OK;
+        const rmhip_view_t l21 = view(ab_local, r0, j, r1 - r0, w), u12 = view(tile, 0, c0, w, c1 - c0), a22 = view(ab_local, r0, j + c0, r1 - r0, c1 - c0);
+        return rmhip_blk_gemm(ctx, -1.0, &l21, &u12, 1.0, &a22);
+    };
+
+    rmhip_buf cur = 0;
+    if (n_direct > 0) RMHIP_TRY(post_panel(0, &cur, nullptr));
+    for (size_t p = 0; p < n_direct; ++p) {
+        const size_t j = p * rb, w = rb, width = ncols - j;
+        const int owner = (int)(p % (size_t)world);
+        if (overlap) RMHIP_TRY(rmhip_comm_wait(ctx));
+        const rmhip_buf tile = cur;
+        const bool is_owner = rank == owner;
+        const size_t below = is_owner ? local_row_offset(p) + w : first_local_row_at_or_after(p + 1);
+        rmhip_buf nxt = 0;
+        if (!failed) {
+            int rc = multipliers(tile, j, w, below, is_owner);
+            // depth-1 look-ahead: the owner of panel p + 1 brings that panel's columns (all its rows) and its tile's rows (all
+            // columns) up to date first, factors and posts the broadcast; the rest of update p then runs under the transfer
+            const bool next_mine = p + 1 < n_direct && (int)((p + 1) % (size_t)world) == rank;
+            if (rc == RMHIP_OK && next_mine) {
+                const size_t lr1 = local_row_offset(p + 1);  // == below: the next owner's first block at or after p + 1 is p + 1 itself
+                rc = update(tile, j, w, lr1, nloc, w, 2 * w);  // panel p + 1's columns, every row from its tile down
+                if (rc == RMHIP_OK)
+                    rc = post_panel(p + 1, &nxt, [&]() { return update(tile, j, w, lr1, lr1 + rb, 2 * w, width); });  // its tile's rows, the other columns
+                if (rc == RMHIP_OK) rc = update(tile, j, w, lr1 + rb, nloc, 2 * w, width);  // everything else, under the transfer
+            } else if (rc == RMHIP_OK) {
+                if (p + 1 < n_direct) rc = post_panel(p + 1, &nxt, nullptr);
+                if (rc == RMHIP_OK) rc = update(tile, j, w, below, nloc, w, width);
+            }
+            if (rc != RMHIP_OK) {
+                failed = true;
+                why = rmhip_last_error();
+            }
+        }
+        if (failed && !nxt && p + 1 < n_direct) RMHIP_TRY(post_panel(p + 1, &nxt, nullptr));  // keep the collectives in step
+        tiles.push_back(Tile{j, w, tile});
+        cur = nxt;
+    }
+    // ---- the guard: one exchange, every rank decides the same way (a failed rank reports NaN)
+    {
+        rmhip_buf mineb = 0, all = 0;
+        const size_t one[2] = {1, 1};
+        RMHIP_TRY(rmhip_fill(ctx, failed ? std::numeric_limits<double>::quiet_NaN() : growth, one, 2, &mineb));
+        temps.keep(mineb);
+        double worst = failed ? std::numeric_limits<double>::quiet_NaN() : growth;
+        if (world > 1) {
+            RMHIP_TRY(rmhip_comm_allgather_f64(ctx, mineb, &all));
+            temps.keep(all);
+            std::vector<double> h((size_t)world);
+            RMHIP_TRY(rmhip_download(ctx, all, h.data(), h.size()));
+            worst = 0.0;
+            for (double v : h)
+                if (v != v || v > worst) worst = v;
+        }
+        if (failed) return fail(RMHIP_ERR_GROWTH, "mldivide_row_partitioned: rank %d failed (%s)", rank, why.c_str());
+        if (!(worst <= tau))
+            return fail(RMHIP_ERR_GROWTH, "largest multiplier outside the diagonal domains %.3g > %g (or a rank failed): use the block-column form (grid-wide pivot rule)",
+                        worst, tau);
+    }
+    // ---- the remaining rows: gathered, then the single-GPU solve on every rank
+    const size_t j0 = n_direct * rb, m_rem = n - j0;
+    rmhip_buf x = 0;
+    RMHIP_TRY(zeros(ctx, n, nrhs, &x));
+    temps.keep(x);
+    if (m_rem > 0) {
+        rmhip_buf trailing = 0;
+        RMHIP_TRY(zeros(ctx, m_rem, m_rem + nrhs, &trailing));
+        temps.keep(trailing);
+        for (size_t q = n_direct; q < nblocks; ++q) {
+            const size_t h = std::min(rb, n - q * rb);
+            const int owner = (int)(q % (size_t)world);
+            rmhip_buf blk = 0;
+            if (rank == owner) {
+                const rmhip_view_t src = view(ab_local, local_row_offset(q), j0, h, m_rem + nrhs);
+                RMHIP_TRY(rmhip_blk_copy(ctx, &src, &blk));
+            } else {
+                RMHIP_TRY(zeros(ctx, h, m_rem + nrhs, &blk));
+            }
+            temps.keep(blk);
+            const rmhip_view_t bv = view(blk, 0, 0, h, m_rem + nrhs);
+            if (world > 1) RMHIP_TRY(rmhip_comm_bcast(ctx, &bv, owner, 0));
+            const rmhip_view_t dst = view(trailing, q * rb - j0, 0, h, m_rem + nrhs);
+            RMHIP_TRY(rmhip_blk_assign(ctx, &dst, blk));
+            temps.drop(blk);
+        }
+        rmhip_buf a_rem = 0, b_rem = 0, x_rem = 0;
+        const rmhip_view_t av = view(trailing, 0, 0, m_rem, m_rem), bv = view(trailing, 0, m_rem, m_rem, nrhs);
+        RMHIP_TRY(rmhip_blk_copy(ctx, &av, &a_rem));
+        temps.keep(a_rem);
+        RMHIP_TRY(rmhip_blk_copy(ctx, &bv, &b_rem));
+        temps.keep(b_rem);
+        RMHIP_TRY(rmhip_mldivide(ctx, a_rem, b_rem, &x_rem));  // identical inputs on every rank: identical result, same status everywhere
+        temps.keep(x_rem);
+        const rmhip_view_t xd = view(x, j0, 0, m_rem, nrhs);
+        RMHIP_TRY(rmhip_blk_assign(ctx, &xd, x_rem));
+        temps.drop(trailing);
+        temps.drop(a_rem);
+        temps.drop(b_rem);
+        temps.drop(x_rem);
+    }
+    // ---- back substitution over the direct panels: every rank holds every tile row, so it is redundant and needs no exchange
+    for (size_t k = tiles.size(); k-- > 0;) {
+        const size_t j = tiles[k].j, w = tiles[k].w, width = ncols - j;
+        const rmhip_buf tile = tiles[k].id;
+        rmhip_buf rhs = 0;
+        const rmhip_view_t yv = view(tile, 0, width - nrhs, w, nrhs);
+        RMHIP_TRY(rmhip_blk_copy(ctx, &yv, &rhs));  // y_p
+        temps.keep(rhs);
+        const size_t later = n - j - w;
+        const rmhip_view_t rv = view(rhs, 0, 0, w, nrhs);
+        if (later > 0) {
+            const rmhip_view_t u12 = view(tile, 0, w, w, later), xl = view(x, j + w, 0, later, nrhs);
+            RMHIP_TRY(rmhip_blk_gemm(ctx, -1.0, &u12, &xl, 1.0, &rv));  // y_p - U12 x_later
+        }
+        const rmhip_view_t u11 = view(tile, 0, 0, w, w);
+        RMHIP_TRY(rmhip_blk_trsm(ctx, 1, &u11, &rv));  // U11^-1
+        const rmhip_view_t xd = view(x, j, 0, w, nrhs);
+        RMHIP_TRY(rmhip_blk_assign(ctx, &xd, rhs));
+        temps.drop(rhs);
+        temps.drop(tile);
+    }
+    for (auto& id : temps.ids)
+        if (id == x) id = 0;  // the result outlives the scope
+    *out = x;
+    return RMHIP_OK;
+}
+
+}  // extern "C"

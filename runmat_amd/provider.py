@@ -642,14 +642,27 @@ class HipProvider:
         self._check(self._lib.rmhip_blk_trsm(self._ctx, mode, C.byref(vt), C.byref(vb)))
 
     def blk_absmax(self, view) -> float:
-        """max |a_ij| over a view (copy, abs, max: three calls and a download - a host-side check, not a hot path)."""
-        blk = self.blk_copy(view)
-        ab = self._unary("abs", blk)
-        mx = self._reduce("max", ab, -1)
-        v = float(self.download(mx)[0])
-        for h in (blk, ab, mx):
-            self.free(h)
-        return v
+        """max |a_ij| over a view; NaN if the view holds one (rmhip_blk_absmax: the multiplier guard of the row-partitioned solve)."""
+        out = C.c_double()
+        va = self._view(view)
+        self._check(self._lib.rmhip_blk_absmax(self._ctx, C.byref(va), C.byref(out)))
+        return out.value
+
+    def matmul_row_sharded(self, a_rows: GpuTensorHandle, b: GpuTensorHandle, rows_total: int, gather: bool = False,
+                           granule: int = 128) -> GpuTensorHandle:
+        """rmhip_matmul_row_sharded: this rank's rows of C = A * B (B replicated); gather=True appends the row-block all-gather."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_matmul_row_sharded(self._ctx, self._id(a_rows), self._id(b), int(rows_total), int(granule),
+                                                       1 if gather else 0, C.byref(out)))
+        return self._handle(out.value)
+
+    def mldivide_row_partitioned(self, ab_local: GpuTensorHandle, n: int, nrhs: int, rb: int = 512, tau: float = 8.0) -> GpuTensorHandle:
+        """rmhip_mldivide_row_partitioned: the row-partitioned A\\b driver inside the library (depth-1 look-ahead); raises ProviderError
+        with code ERR_GROWTH (10) on every rank when the multiplier guard or any rank fails."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_mldivide_row_partitioned(self._ctx, self._id(ab_local), int(n), int(nrhs), int(rb), float(tau),
+                                                             C.byref(out)))
+        return self._handle(out.value, (int(n), int(nrhs)))
 
     def blk_lu(self, a) -> Tuple[GpuTensorHandle, int]:
         out, info = C.c_uint64(), C.c_int()

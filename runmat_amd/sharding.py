@@ -577,39 +577,62 @@ def mldivide_row_partitioned(prov, group: Group, ab_local, n: int, nrhs: int, rb
         return nloc
 
     tiles = []  # (j, w, tile-row handle [w x (ncols - j)]) of every direct panel, kept for the back substitution
+    # A failure on ONE rank (a pivot at the singular cut-off inside its domain, a ProviderError from a block kernel) must not leave the
+    # others blocked in the panel broadcast: the failing rank sends a NaN-poisoned tile, keeps taking part in every collective and
+    # reports NaN to the guard, so every rank raises PivotGrowth together after the one exchange at the end (the same protocol as
+    # rmhip_mldivide_row_partitioned, csrc/sharded.cpp).
+    failed = None
+
+    def note(v):
+        nonlocal growth
+        if v != v or v > growth:  # NaN sticks: max(0.0, nan) is 0.0 in Python
+            growth = v
+
     for p in range(n_direct):
         j, w, owner = p * rb, rb, p % world
         width = ncols - j
-        if rank == owner:
+        tile = None
+        if rank == owner and failed is None:
             lr = local_row_offset(p, rb, group)
-            ipiv, info = prov.blk_lu((ab_local, lr, j, nloc - lr, w))  # partial pivoting among this rank's rows from the tile down
-            if info > 0:
+            try:
+                ipiv, info = prov.blk_lu((ab_local, lr, j, nloc - lr, w))  # partial pivoting among this rank's rows from the tile down
+                if info > 0:
+                    prov.free(ipiv)
+                    raise PivotGrowth(f"panel {p}: {info} pivot(s) at the singular cut-off inside the diagonal domain")
+                if j > 0:
+                    prov.blk_swap_rows((ab_local, lr, 0, nloc - lr, j), ipiv)               # the interchanges on the L part ...
+                prov.blk_swap_rows((ab_local, lr, j + w, nloc - lr, width - w), ipiv)       # ... and on everything to the right (b included)
                 prov.free(ipiv)
-                raise PivotGrowth(f"panel {p}: {info} pivot(s) at the singular cut-off inside the diagonal domain")
-            if j > 0:
-                prov.blk_swap_rows((ab_local, lr, 0, nloc - lr, j), ipiv)               # the interchanges on the L part ...
-            prov.blk_swap_rows((ab_local, lr, j + w, nloc - lr, width - w), ipiv)       # ... and on everything to the right (b included)
-            prov.free(ipiv)
-            prov.blk_trsm(False, (ab_local, lr, j, w, w), (ab_local, lr, j + w, w, width - w))  # U12 and the y part: L11^-1 [A12 | b]
-            tile = prov.blk_copy((ab_local, lr, j, w, width))
+                prov.blk_trsm(False, (ab_local, lr, j, w, w), (ab_local, lr, j + w, w, width - w))  # U12 and the y part: L11^-1 [A12 | b]
+                tile = prov.blk_copy((ab_local, lr, j, w, width))
+            except (PivotGrowth, ProviderError) as e:
+                failed = str(e)
             below = lr + w
         else:
-            tile = prov.zeros((w, width))
             below = first_local_row_at_or_after(p + 1)
+        if tile is None:
+            tile = prov.fill((w, width), float("nan")) if rank == owner else prov.zeros((w, width))
         bcast(tile, (w, width), owner)
         mb = nloc - below
-        if mb > 0:
-            if rank != owner:  # the owner's rows below the tile were factored with it
-                prov.blk_trsm(2, (tile, 0, 0, w, w), (ab_local, below, j, mb, w))       # L21 = A21 U11^-1
-                growth = max(growth, prov.blk_absmax((ab_local, below, j, mb, w)))
-            prov.blk_gemm(-1.0, (ab_local, below, j, mb, w), (tile, 0, w, w, width - w), 1.0, (ab_local, below, j + w, mb, width - w))
+        if mb > 0 and failed is None:
+            try:
+                if rank != owner:  # the owner's rows below the tile were factored with it
+                    prov.blk_trsm(2, (tile, 0, 0, w, w), (ab_local, below, j, mb, w))       # L21 = A21 U11^-1
+                    note(prov.blk_absmax((ab_local, below, j, mb, w)))
+                prov.blk_gemm(-1.0, (ab_local, below, j, mb, w), (tile, 0, w, w, width - w), 1.0, (ab_local, below, j + w, mb, width - w))
+            except ProviderError as e:
+                failed = str(e)
         tiles.append((j, w, tile))
-    # ---- the guard: one exchange, every rank decides the same way
-    worst = float(np.max(group.all_gather_f64([growth])))
-    if not worst <= tau:
+    # ---- the guard: one exchange, every rank decides the same way (a failed rank reports NaN)
+    gathered = group.all_gather_f64([float("nan") if failed is not None else growth])
+    worst = 0.0
+    for v in np.asarray(gathered, dtype=np.float64).reshape(-1):
+        if v != v or v > worst:
+            worst = float(v)
+    if failed is not None or not worst <= tau:
         for _, _, t in tiles:
             prov.free(t)
-        raise PivotGrowth(f"largest multiplier outside the diagonal domains {worst:.3g} > {tau:g}")
+        raise PivotGrowth(failed if failed is not None else f"largest multiplier outside the diagonal domains {worst:.3g} > {tau:g} (or another rank failed)")
     # ---- the remaining rows: gathered, then the single-GPU solve on every rank
     j0 = n_direct * rb
     m_rem = n - j0

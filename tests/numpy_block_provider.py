@@ -24,6 +24,9 @@ class NumpyBlockProvider:
     def zeros(self, shape):
         return H(np.zeros((shape[1], shape[0])))
 
+    def fill(self, shape, value):
+        return H(np.full((shape[1], shape[0]), float(value)))
+
     def download(self, h):
         return h.arr.reshape(-1).copy()  # transposed row-major == column-major flat
 
@@ -49,9 +52,9 @@ class NumpyBlockProvider:
 
         T, Bv = self._v(t).T, self._v(b)
         if upper in (2, "right"):  # B <- B U^-1
-            Bv[...] = sl.solve_triangular(T, Bv, trans="T", lower=False)  # Bv is B' : U' X' = B'
+            Bv[...] = sl.solve_triangular(T, Bv, trans="T", lower=False, check_finite=False)  # Bv is B' : U' X' = B'
             return
-        Bv[...] = sl.solve_triangular(T, Bv.T, lower=not upper, unit_diagonal=not upper).T
+        Bv[...] = sl.solve_triangular(T, Bv.T, lower=not upper, unit_diagonal=not upper, check_finite=False).T
 
     def blk_absmax(self, v):
         a = self._v(v)

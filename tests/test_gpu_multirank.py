@@ -77,8 +77,30 @@ def _worker(rank, world, port, out_dir, native):
             sh.mldivide_row_partitioned(prov, group, prov.upload(np.hstack([bad, BB])[rows, :]), nn, nrhs, rb=rbk)
         except sh.PivotGrowth:
             refused = True
+        # the same two sharded forms through the C-ABI drivers (rmhip_matmul_row_sharded, rmhip_mldivide_row_partitioned: csrc/sharded.cpp),
+        # what a host that is not Python calls - they need the native communicator
+        xc = cc = None
+        refused_c = collective_c = False
+        if native:
+            from runmat_amd import ProviderError
+
+            cc = prov.download_matrix(prov.matmul_row_sharded(prov.upload(A[r0:r1, :]), prov.upload(B), m, gather=True))
+            xc = prov.download_matrix(prov.mldivide_row_partitioned(prov.upload(np.hstack([AA, BB])[rows, :]), nn, nrhs, rb=rbk))
+            try:
+                prov.mldivide_row_partitioned(prov.upload(np.hstack([bad, BB])[rows, :]), nn, nrhs, rb=rbk)
+            except ProviderError as e:
+                refused_c = e.code == 10  # RMHIP_ERR_GROWTH, on every rank
+            # a singular diagonal domain on rank 0 only: nobody hangs, everybody gets RMHIP_ERR_GROWTH
+            sing = AA.copy()
+            own0 = [r for q in range(0, (nn + rbk - 1) // rbk, world) for r in range(q * rbk, min(nn, (q + 1) * rbk))]
+            sing[own0, 5] = 0.0
+            try:
+                prov.mldivide_row_partitioned(prov.upload(np.hstack([sing, BB])[rows, :]), nn, nrhs, rb=rbk)
+            except ProviderError as e:
+                collective_c = e.code == 10
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), p_fused=p_fused, s_fused=np.uint64(s_fused), p_evol=p_evol,
-                 s_evol=np.uint64(s_evol), C=C, x=x, xr=xr, refused=refused)
+                 s_evol=np.uint64(s_evol), C=C, x=x, xr=xr, refused=refused, xc=xc if xc is not None else np.zeros(0),
+                 cc=cc if cc is not None else np.zeros(0), refused_c=refused_c, collective_c=collective_c)
         prov.close()
     finally:
         dist.destroy_process_group()
@@ -113,6 +135,15 @@ def test_two_ranks_on_one_gpu(oracle, tmp_path, native):
         assert bool(r["refused"])
     assert np.array_equal(res[0]["x"], res[1]["x"])
     assert np.array_equal(res[0]["xr"], res[1]["xr"])  # replicated, bit-identical
+    if native:  # the C-ABI drivers beside the Python ones
+        for r in res:
+            assert np.array_equal(r["cc"], r["C"])  # same kernel on the same rows, same gather: identical bits
+            assert np.max(np.abs(r["xc"] - xr)) <= 1e-9 * max(1.0, np.abs(xr).max())
+            # the look-ahead splits each trailing update into column / row pieces (same products, possibly another tile kernel):
+            # agreement with the Python driver to rounding, identity where the kernels coincide
+            assert np.max(np.abs(r["xc"] - r["xr"])) <= 1e-11 * max(1.0, np.abs(xr).max())
+            assert bool(r["refused_c"]) and bool(r["collective_c"])
+        assert np.array_equal(res[0]["xc"], res[1]["xc"])  # replicated, bit-identical across ranks
 
 
 def test_rccl_one_rank_communicator(prov, oracle):

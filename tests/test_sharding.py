@@ -188,7 +188,19 @@ def _rows_worker(rank, world, port, out_dir):
             sh.mldivide_row_partitioned(prov, group, prov.upload(np.hstack([bad, A @ X])[rows, :]), n, nrhs, rb=rb)
         except sh.PivotGrowth:
             refused = True
-        np.savez(os.path.join(out_dir, f"rows_rank{rank}.npz"), x=prov.download(x).reshape(n, nrhs, order="F"), X=X, refused=refused)
+        # a singular diagonal domain on ONE rank (column 3 is zero on every row rank 0 owns: panel 0 finds no pivot there): the owner
+        # must not leave the others blocked in the broadcast - it sends a poisoned tile, stays in step, and every rank raises after
+        # the guard's exchange
+        sing = A.copy()
+        own0 = np.concatenate([np.arange(q * rb, min((q + 1) * rb, n)) for q in range(0, (n + rb - 1) // rb, world)])
+        sing[own0, 3] = 0.0
+        collective = False
+        try:
+            sh.mldivide_row_partitioned(prov, group, prov.upload(np.hstack([sing, A @ X])[rows, :]), n, nrhs, rb=rb, tau=64.0)
+        except sh.PivotGrowth:
+            collective = True
+        np.savez(os.path.join(out_dir, f"rows_rank{rank}.npz"), x=prov.download(x).reshape(n, nrhs, order="F"), X=X, refused=refused,
+                 collective=collective)
     finally:
         dist.destroy_process_group()
 
@@ -203,7 +215,48 @@ def test_world2_gloo_row_partitioned_solve(tmp_path):
     res = [np.load(tmp_path / f"rows_rank{r}.npz") for r in range(world)]
     for r in res:
         assert np.max(np.abs(r["x"] - r["X"])) < 1e-9 and bool(r["refused"])
+        assert bool(r["collective"])  # the failure of one rank's domain reached every rank (no hang: the test has a timeout)
     assert np.array_equal(res[0]["x"], res[1]["x"])
+
+
+def _rows8_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    from numpy_block_provider import NumpyBlockProvider
+    from runmat_amd import sharding as sh
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        group = sh.Group.from_env()
+        prov = NumpyBlockProvider()
+        n, rb, nrhs = 300, 16, 1  # 19 row blocks (the last one ragged) over 8 ranks: 11 direct panels, 8 gathered blocks
+        rng = np.random.default_rng(8)
+        A = rng.uniform(-1, 1, (n, n)) + 4.0 * np.eye(n)
+        X = np.ones((n, 1))
+        AB = np.hstack([A, A @ X])
+        rows = np.concatenate([np.arange(q * rb, min((q + 1) * rb, n)) for q in sh.owned_row_blocks(n, rb, group)])
+        x = sh.mldivide_row_partitioned(prov, group, prov.upload(AB[rows, :]), n, nrhs, rb=rb, tau=64.0)
+        nb = 16
+        mine = sh.owned_blocks(n, nb, group)
+        cols = np.concatenate([np.arange(p * nb, min((p + 1) * nb, n)) for p in mine])
+        y = sh.mldivide_block_cyclic(prov, group, prov.upload(A[:, cols]), n, prov.upload(A @ X), nb=nb)
+        np.savez(os.path.join(out_dir, f"rows8_rank{rank}.npz"), x=prov.download(x), y=prov.download(y))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world8_gloo_solvers_block_ownership(tmp_path):
+    """The target machine has 8 GPUs: block ownership, the gathered tail (world row blocks) and the panel broadcasts of both sharded
+    solvers with world = 8 (gloo, numpy block double)."""
+    import torch.multiprocessing as mp
+
+    world, port = 8, _free_port()
+    mp.spawn(_rows8_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(tmp_path / f"rows8_rank{r}.npz") for r in range(world)]
+    for r in res:
+        assert np.max(np.abs(r["x"] - 1.0)) < 1e-9 and np.max(np.abs(r["y"] - 1.0)) < 1e-9
+        assert np.array_equal(r["x"], res[0]["x"]) and np.array_equal(r["y"], res[0]["y"])
 
 
 def test_row_partitioned_solve_single_rank_double():
