@@ -269,9 +269,11 @@ enum rmhip_truth_op { RMHIP_TNNZ = 0, RMHIP_TANY, RMHIP_TALL, RMHIP_TRUTH_OP_COU
 RMHIP_API int rmhip_reduce_truth(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int omit_nan, rmhip_buf* out);
 /* `cumsum_scan` / `cumprod_scan` (lib.rs:2884-2891, 2908-2915): running sum (op 0) / product (op 1) along `dim` (zero-based),
  * forward or reverse (`ProviderScanDirection`, :1053-1056), NaN modes of cumsum.rs:586-650 (include: NaN from the first NaN
- * on; omit: NaNs leave the running value unchanged).  Same shape as the input.  Along a strided dimension every line is the
- * CPU's own left-to-right sequence (bit-identical); long contiguous lines are scanned in blocks (equal up to rounding, exact for
- * integer-valued data). */
+ * on; omit: NaNs leave the running value unchanged).  Same shape as the input.  Short lines and many strided lines are the CPU's own
+ * left-to-right sequence (bit-identical).  LONG lines - contiguous ones, and strided ones of >= 4096 elements when there are too few
+ * lines to fill the chip - are scanned in chunks whose totals are carried forward: equal to the CPU up to rounding (exact for
+ * integer-valued data), and a chunk TOTAL can overflow where the running prefix would not (cumprod over magnitudes like 1e-300 then
+ * 1e+310 inside later chunks: Inf from that chunk on) - the reference's sequential loop is the authority for such data. */
 /* @serves cumsum_scan cumprod_scan */
 RMHIP_API int rmhip_cumulative(rmhip_ctx* ctx, int op, rmhip_buf a, int dim, int reverse, int nan_mode, rmhip_buf* out);
 

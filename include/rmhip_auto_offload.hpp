@@ -21,6 +21,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cerrno>
 #include <cstdlib>
 #include <functional>
 #include <limits>
@@ -51,10 +52,14 @@ inline bool apply_env_overrides(Thresholds& t, const std::function<const char*(c
     auto get = [&](const char* key, size_t* out) {
         const char* v = lookup(key);
         if (!v || !*v) return false;
+        // Rust's usize parser: ASCII digits with an optional leading '+', nothing else - no sign, no white space of any kind
+        // (strtoull alone would skip leading tabs / newlines), and a value that does not fit is an error, not a saturated maximum
+        const char* d = *v == '+' ? v + 1 : v;
+        if (*d < '0' || *d > '9') return false;
         char* end = nullptr;
-        if (*v == '-' || *v == ' ') return false;  // Rust's usize parser: digits with an optional '+', no sign, no blanks
-        const unsigned long long x = std::strtoull(v, &end, 10);
-        if (end == v || *end != '\0') return false;
+        errno = 0;
+        const unsigned long long x = std::strtoull(d, &end, 10);
+        if (end == d || *end != '\0' || errno == ERANGE) return false;
         *out = (size_t)x;
         return true;
     };
@@ -273,6 +278,12 @@ struct JsonParser {
         return out;
     }
 };
+// a JSON number as a count: negative, NaN and out-of-range values clamp instead of hitting the undefined double -> integer conversion
+inline size_t to_size(double v) {
+    if (!(v > 0.0)) return 0;
+    if (v >= 18446744073709549568.0) return (size_t)-1;
+    return (size_t)v;
+}
 inline double num_or(const Json* j, const char* key, double dflt) {
     const Json* v = j ? j->get(key) : nullptr;
     return v && v->kind == Json::Num ? v->num : dflt;
@@ -290,7 +301,7 @@ inline CalibrationSample load_calibration_sample(const std::string& json_text) {
     if (!sec || sec->kind != detail::Json::Obj) sec = root.get("auto_offload_calibration");
     if (!sec || sec->kind != detail::Json::Obj) throw std::runtime_error("calibration file does not contain an auto_offload_calibration section");
     CalibrationSample s;
-    s.runs = (size_t)detail::num_or(sec, "runs", 0.0);
+    s.runs = detail::to_size(detail::num_or(sec, "runs", 0.0));
     const detail::Json* t = sec->get("cpu_time_ms");
     s.cpu_ms_elementwise = detail::num_or(t, "elementwise", 0.0);
     s.cpu_ms_reduction = detail::num_or(t, "reduction", 0.0);
@@ -304,7 +315,7 @@ inline CalibrationSample load_calibration_sample(const std::string& json_text) {
         if (const detail::Json* v = pr->get("name"); v && v->kind == detail::Json::Str) cp.name = v->str;
         if (const detail::Json* v = pr->get("vendor"); v && v->kind == detail::Json::Str) cp.vendor = v->str;
         if (const detail::Json* v = pr->get("backend"); v && v->kind == detail::Json::Str) cp.backend = v->str;
-        cp.device_id = (uint32_t)detail::num_or(pr, "device_id", 0.0);
+        cp.device_id = (uint32_t)std::min<size_t>(detail::to_size(detail::num_or(pr, "device_id", 0.0)), 0xffffffffu);
         s.provider = cp;
     }
     if (const detail::Json* v = sec->get("provider_conflict"); v && v->kind == detail::Json::Bool) s.provider_conflict = v->b;

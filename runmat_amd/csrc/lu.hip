@@ -2336,6 +2336,7 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
         // solve path: RMHIP_LU_FAST=0 keeps the grid-wide pivot rule everywhere; RMHIP_LU_TAU sets the multiplier bound (read per call: tests)
         const char* fe = std::getenv("RMHIP_LU_FAST");
         s.fast = mode == 1 && !(fe && fe[0] == '0') && s.persistent;
+        c->lu_last_fast = s.fast;  // the caller counts solve-path factorisations on what actually ran (rmhip_lu_stats)
         if (const char* tv = std::getenv("RMHIP_LU_TAU")) s.tau = std::atof(tv);
         c->lu_tau = s.tau;
         s.ucomp = (double*)(blk + off_ucomp);

@@ -977,7 +977,8 @@ __global__ void __launch_bounds__(R2_BLOCK) k_scan_chunks(const double* __restri
 int launch_cumulative(Context* c, int prod, int reverse, int omit, const double* x, size_t pre, size_t len, size_t post, double* y) {
     if (pre == 0 || len == 0 || post == 0) return RMHIP_OK;
     const size_t lines = pre * post;
-    if (pre > 1) {  // lines along a strided dimension: every line is the CPU's own chain
+    if (pre > 1) {  // lines along a strided dimension: every line is the CPU's own chain - except the chunked form below (few lines of >= 4096 steps:
+                    // chunk totals carried forward, equal to rounding; include/rmhip.h states the contract and the overflow caveat)
         if (pre >= 8 && len >= 256 && lines < (size_t)c->num_cus * 256 && post <= 65535) {  // few long lines: staged tiles
             const bool half = pre < 64 || ceil_div_u64(pre, 64) * post < (u64)c->num_cus;   // 64 lines per block would leave CUs (or lanes) idle
             const u64 line_blocks = ceil_div_u64(pre, half ? 32 : 64) * post;

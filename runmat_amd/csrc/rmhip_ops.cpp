@@ -61,7 +61,7 @@ static int lu_copy_and_factor(Context* c, const double* src, size_t rows, size_t
             if (!(c->lu_last_growth <= c->lu_tau) || std::getenv("RMHIP_LU_TEST_GROWTH")) c->record_solve_fallback("lu:pivot_growth");
             continue;
         }
-        if (rc == RMHIP_OK && mode == 1) c->lu_fast_count++;
+        if (rc == RMHIP_OK && mode == 1 && c->lu_last_fast) c->lu_fast_count++;  // RMHIP_LU_FAST=0 / conservative panels: the grid-wide rule ran
         if (rc != RMHIP_LU_RETRY) return rc;
     }
     return fail(RMHIP_ERR_HIP, "lu: factorisation failed on every panel path");
@@ -83,6 +83,7 @@ static size_t lu_pad_rows(size_t n) {
 }
 // X (n x nrhs, ld n) = A^-1 B from factors of order np >= n (np > n: the padded system)
 static int lu_solve_padded(Context* c, const double* LU, size_t n, size_t np, size_t ldw, const int* perm, const double* B, size_t nrhs, double* X) {
+    if (nrhs == 0) return RMHIP_OK;  // (a zero-height hipMemcpy2DAsync is hipErrorInvalidValue)
     if (np == n) return lu_solve_device(c, LU, n, ldw, perm, B, nrhs, n, X, n);
     std::shared_ptr<Allocation> bp, xp;
     RMHIP_TRY(c->alloc_device(np * nrhs, &bp));
