@@ -1645,6 +1645,8 @@ static int lu_dgemm(Context* c, size_t m, size_t n, size_t k, double alpha, cons
         mmax = v ? std::atol(v) : 0;
     }
     if ((long)k < kmin || (long)m < mmax) return RMHIP_OK;
+    static const bool log_shapes = std::getenv("RMHIP_LU_GEMM_LOG") != nullptr;  // developer aid: every update's shape and stream, in launch order (stderr)
+    if (log_shapes) std::fprintf(stderr, "[lu_dgemm] stream %p m %zu n %zu k %zu pad %zu\n", (void*)c->stream, m, n, k, c->gemm_lds_pad);
     return launch_dgemm(c, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
 }
 

@@ -1,0 +1,9 @@
+cd /tmp
+R=$GRAFT_REPO_ROOT
+run() { echo -n "$* : "; env "$@" python $R/scripts/lu_trace.py 16384 4 2>&1 | grep "rep=" | tail -2 | awk '{printf "%s ", $3}'; echo; }
+run X=1
+run RMHIP_GEMM_PRELOAD=0
+run RMHIP_GEMM_PRELOAD=0 RMHIP_LU_NB_EARLY=1024
+run RMHIP_GEMM_PRELOAD=0 RMHIP_LU_SKIP=13
+run RMHIP_LU_SKIP=13
+run X=1

@@ -33,9 +33,11 @@ def _run_bench(extra_args, extra_env, nproc=2, timeout=900):
 
 
 def _check_roofline(rf):
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s")
+    assert rf["bound"] in ("hbm", "mfma", "valu") and rf["unit"] in ("GB/s", "TFLOP/s", "Ginstr/s")
     assert rf["achieved"] > 0 and rf["peak"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 2e-3
-    assert "kernel" in rf
+    assert "kernel" in rf and rf["peak_spec"] > 0 and abs(rf["peak"] / rf["peak_spec"] - 1.0) < 0.1  # peaks derived from the box, the spec beside
+    if rf["bound"] == "valu":  # instruction counts from the committed counter pass, time measured in this run
+        assert rf["valu_insts_per_launch"] > 0 and "pmc_valu.json" in rf["counters_source"]
     # every roofline that names a kernel carries the counter-measured bytes (profiles/pmc_traffic.json): never null
     assert isinstance(rf["traffic"], int) and rf["traffic"] > 0 and "pmc_traffic.json" in rf["traffic_source"]
 
