@@ -1026,7 +1026,9 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
         // update stream of the look-ahead LU while the panels sit on one XCD: persistent eight-wave kernel that stays off it
         g.tile_counter = c->gemm_tile_counters + c->gemm_counter_next++;
         g.avoid_xcc = c->gemm_avoid_xcc;
-        const unsigned grid = (unsigned)c->num_cus < blocks ? (unsigned)c->num_cus : blocks;
+        static const long grid_cap = std::getenv("RMHIP_GEMM_W8P_GRID") ? std::atol(std::getenv("RMHIP_GEMM_W8P_GRID")) : 0;  // A/B: fewer persistent workgroups than CUs
+        unsigned grid = (unsigned)c->num_cus < blocks ? (unsigned)c->num_cus : blocks;
+        if (grid_cap > 0 && grid > (unsigned)grid_cap) grid = (unsigned)grid_cap;
         c->ensure_max_lds((const void*)k_dgemm_w8p, kMaxLds);
         hipLaunchKernelGGL(k_dgemm_w8p, dim3(grid), dim3(512), lds_bytes, c->stream, g);
         c->tel.kernel_launches++;

@@ -186,10 +186,15 @@ __global__ void __launch_bounds__(kBlock) k_scatter(T* __restrict__ target, cons
 // simple_provider.rs:3494-3503: start + idx * step with step = (stop - start) / (count - 1), the last element set to stop
 template <class T>
 __global__ void __launch_bounds__(kBlock) k_linspace(T* __restrict__ out, size_t n, double start, double step, double stop) {
-    const size_t stride = (size_t)gridDim.x * kBlock;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const double prod = (double)i * step;  // separate multiply and add (-ffp-contract=off), as the CPU loop rounds
-        out[i] = (T)(i + 1 == n ? stop : start + prod);
+    // write-only: one contiguous chunk of 1024 elements per block (ew_kernels.hip k_fill, scripts/micro/write_patterns.hip)
+    const size_t b = (size_t)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const size_t i = b + e * 256;
+        if (i < n) {
+            const double prod = (double)i * step;  // separate multiply and add (-ffp-contract=off), as the CPU loop rounds
+            out[i] = (T)(i + 1 == n ? stop : start + prod);
+        }
     }
 }
 
@@ -540,7 +545,11 @@ int rmhip_linspace(rmhip_ctx* ctx, double start, double stop, size_t count, rmhi
     RMHIP_TRY(c->new_buffer(shape, 2, out, &ob));  // f64, narrowed on return by a precision-32 context
     if (count == 0) return RMHIP_OK;
     const double step = count > 1 ? (stop - start) / (double)(count - 1) : 0.0;
-    hipLaunchKernelGGL((k_linspace<double>), dim3(flat_grid(c, count)), dim3(kBlock), 0, c->stream, ob.data(), count, start, step, stop);
+    if ((count + 1023) / 1024 > 0x7fffffffULL) {
+        rmhip_free(ctx, *out);
+        return fail(RMHIP_ERR_UNSUPPORTED, "linspace: %zu elements exceed the launch limits", count);
+    }
+    hipLaunchKernelGGL((k_linspace<double>), dim3((unsigned)((count + 1023) / 1024)), dim3(kBlock), 0, c->stream, ob.data(), count, start, step, stop);
     c->tel.kernel_launches++;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
