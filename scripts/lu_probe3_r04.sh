@@ -1,3 +1,4 @@
+# Developer tool (GPU box): wall-clock A/B of look-ahead LU knobs and phase-dropping masks (RMHIP_LU_SKIP) at n = 16384, round 4.
 cd /tmp
 R=$GRAFT_REPO_ROOT
 run() { echo -n "$* : "; env "$@" python $R/scripts/lu_trace.py 16384 4 2>&1 | grep "rep=" | tail -2 | awk '{printf "%s ", $3}'; echo; }
