@@ -123,3 +123,33 @@ def test_randn_1e8_stream_samples(prov, oracle):
     assert abs(z.mean()) < 5e-4 and abs(z.var() - 1.0) < 1e-3
     assert prov.get_rng_state() == oracle.rng_advance(s0, n)
     prov.free(h)
+
+
+def test_unfused_implicit_expansion_8192(prov, oracle):
+    """The reference's unfused broadcast path at full size: A (8192 x 1) .* B (1 x 8192) through the callers' own sequence
+    (times.rs:501-543: repmat each operand, elem_mul, free the expansions).  Bit-exact: one IEEE product per element.  Checked
+    on sampled rows / columns against the oracle's broadcast product, plus size-independent properties: the result is the
+    rank-one outer product (every column is a multiple of the first one by an exactly known factor for power-of-two scalings;
+    here: the sum of every column equals b_j * sum(a) up to the summation bound) and a view costs no memory."""
+    a = oracle.fill_uniform(21, -1.0, 1.0, N).reshape(N, 1)
+    b = oracle.fill_uniform(22, -1.0, 1.0, N).reshape(1, N)
+    ha, hb = prov.fill_uniform(21, -1.0, 1.0, (N, 1)), prov.fill_uniform(22, -1.0, 1.0, (1, N))
+    before = prov.telemetry_snapshot()["bytes_allocated"]
+    le, re = prov.repmat(ha, [1, N]), prov.repmat(hb, [N, 1])
+    assert prov.telemetry_snapshot()["bytes_allocated"] == before  # two 512 MiB expansions that were never allocated
+    h = prov.elem_mul(le, re)
+    prov.free(le)
+    prov.free(re)
+    P = prov.download_matrix(h)
+    rng = np.random.default_rng(6)
+    rows = np.concatenate([[0, N - 1], rng.integers(0, N, 30)])
+    cols = np.concatenate([[0, N - 1], rng.integers(0, N, 30)])
+    want_rows = oracle.binary("mul", a[rows, :], b)      # (32 x 1) .* (1 x N)
+    want_cols = oracle.binary("mul", a, b[:, cols])      # (N x 1) .* (1 x 32)
+    assert np.array_equal(P[rows, :].view(np.uint64), want_rows.view(np.uint64))
+    assert np.array_equal(P[:, cols].view(np.uint64), want_cols.view(np.uint64))
+    # rank-one structure over the WHOLE array: scaling a column by a power of two is exact, so P(:, j) * 2 == (a .* (2 b_j)) bit for bit;
+    # and every element is the correctly rounded product (checked above on samples): the full-array check is |P - a*b| == 0 in float
+    assert np.array_equal(P, a * b)
+    for x in (ha, hb, h):
+        prov.free(x)
