@@ -460,6 +460,27 @@ RMHIP_API int rmhip_blk_lu(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf* ipi
 /* @serves - */
 RMHIP_API int rmhip_blk_swap_rows(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf ipiv);
 
+/* `eye` / `eye_like` (lib.rs:1552-1559; simple_provider.rs:2293-2336, 3471-3486): ones on the leading diagonal of the first two
+ * dimensions of every page, zeros elsewhere; shape [] is [1,1], [n] is [n,n] (normalize_shape, simple_provider.rs:779-788). */
+/* @serves eye eye_like */
+RMHIP_API int rmhip_eye(rmhip_ctx* ctx, const size_t* shape, size_t rank, rmhip_buf* out);
+/* `flip` (lib.rs:2586; simple_provider.rs:1739-1776): reverse the zero-based `axes` (an axis named twice flips back; axes beyond
+ * the rank are extent-1 dimensions).  Same shape. */
+/* @serves flip */
+RMHIP_API int rmhip_flip(rmhip_ctx* ctx, rmhip_buf a, const size_t* axes, size_t n_axes, rmhip_buf* out);
+/* `circshift` (lib.rs:2589-2595; simple_provider.rs:2083-2143, 6431-6455): out(c) = in((c - shift) mod extent) per dimension;
+ * `shifts` may be shorter than the rank (missing = 0) or longer (the shape is padded with 1s). */
+/* @serves circshift */
+RMHIP_API int rmhip_circshift(rmhip_ctx* ctx, rmhip_buf a, const long long* shifts, size_t n_shifts, rmhip_buf* out);
+/* `tril` / `triu` (lib.rs:1635-1651; simple_provider.rs:1974-2081): zero the entries above (upper == 0: row - col < -offset) or below
+ * (upper != 0: col - row < offset) the offset-th diagonal of the first two dimensions of every page. */
+/* @serves tril triu */
+RMHIP_API int rmhip_tri(rmhip_ctx* ctx, rmhip_buf a, int upper, long long offset, rmhip_buf* out);
+/* `cat` (lib.rs:2686; shape rules backend/wgpu/provider/ops/tensor.rs:457-540): concatenate >= 2 tensors along the ONE-based `dim`;
+ * every other extent must agree; the result drops trailing 1s down to max(dim, 2) dimensions (normalize_concat_shape). */
+/* @serves cat */
+RMHIP_API int rmhip_cat(rmhip_ctx* ctx, size_t dim_one_based, const rmhip_buf* inputs, size_t n_inputs, rmhip_buf* out);
+
 /* max |a_ij| over a view (NaN if the view holds one): the multiplier guard of the row-partitioned solve. */
 /* @serves - */
 RMHIP_API int rmhip_blk_absmax(rmhip_ctx* ctx, const rmhip_view_t* a, double* out);

@@ -164,6 +164,38 @@ public:
     void scatter_linear(const GpuTensorHandle& target, const std::vector<uint32_t>& indices, const GpuTensorHandle& values) const {
         check(rmhip_scatter_linear(ctx_, own(target), indices.data(), indices.size(), own(values)));
     }
+    GpuTensorHandle eye(const std::vector<size_t>& shape) const {  // lib.rs:1552
+        uint64_t id = 0;
+        check(rmhip_eye(ctx_, shape.data(), shape.size(), &id));
+        return with_shape(id);
+    }
+    GpuTensorHandle eye_like(const GpuTensorHandle& prototype) const { return eye(prototype.shape); }  // lib.rs:1557
+    GpuTensorHandle flip(const GpuTensorHandle& a, const std::vector<size_t>& axes_zero_based) const {  // lib.rs:2586
+        uint64_t id = 0;
+        check(rmhip_flip(ctx_, own(a), axes_zero_based.data(), axes_zero_based.size(), &id));
+        return make(id, a.shape);
+    }
+    GpuTensorHandle circshift(const GpuTensorHandle& a, const std::vector<long long>& shifts) const {  // lib.rs:2589
+        uint64_t id = 0;
+        check(rmhip_circshift(ctx_, own(a), shifts.data(), shifts.size(), &id));
+        return make(id, a.shape);
+    }
+    GpuTensorHandle tril(const GpuTensorHandle& a, long long offset = 0) const {  // lib.rs:1635
+        uint64_t id = 0;
+        check(rmhip_tri(ctx_, own(a), 0, offset, &id));
+        return make(id, a.shape);
+    }
+    GpuTensorHandle triu(const GpuTensorHandle& a, long long offset = 0) const {  // lib.rs:1644
+        uint64_t id = 0;
+        check(rmhip_tri(ctx_, own(a), 1, offset, &id));
+        return make(id, a.shape);
+    }
+    GpuTensorHandle cat(size_t dim_one_based, const std::vector<GpuTensorHandle>& inputs) const {  // lib.rs:2686
+        std::vector<uint64_t> ids = ids_of(inputs);
+        uint64_t id = 0;
+        check(rmhip_cat(ctx_, dim_one_based, ids.data(), ids.size(), &id));
+        return with_shape(id);
+    }
     GpuTensorHandle linspace(double start, double stop, size_t count) const {
         uint64_t id = 0;
         check(rmhip_linspace(ctx_, start, stop, count, &id));

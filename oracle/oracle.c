@@ -1191,3 +1191,71 @@ ORC_API void orc_linspace(double start, double stop, size_t count, double* out) 
     for (size_t idx = 0; idx < count; ++idx) out[idx] = start + (double)idx * step;
     out[count - 1] = stop;
 }
+
+/* identity_data, simple_provider.rs:2293-2336 (shape already normalised by the caller: [] -> [1,1], [n] -> [n,n]) */
+ORC_API void orc_eye(const size_t* shape, size_t rank, double* out) {
+    size_t total = 1;
+    for (size_t d = 0; d < rank; ++d) total *= shape[d];
+    for (size_t i = 0; i < total; ++i) out[i] = 0.0;
+    if (rank < 2 || total == 0) return;
+    const size_t rows = shape[0], cols = shape[1], plane = rows * cols;
+    const size_t diag = rows < cols ? rows : cols;
+    for (size_t page = 0; page < total / plane; ++page)
+        for (size_t d = 0; d < diag; ++d) out[page * plane + d + d * rows] = 1.0;
+}
+
+/* flip_data, simple_provider.rs:1739-1776: flags[axis] toggled per occurrence; shape already extended to cover the axes */
+ORC_API void orc_flip(const double* data, const size_t* shape, size_t rank, const int* flags, double* out) {
+    size_t total = 1;
+    for (size_t d = 0; d < rank; ++d) total *= shape[d];
+    for (size_t idx = 0; idx < total; ++idx) {
+        size_t rem = idx, src = 0, stride = 1;
+        for (size_t d = 0; d < rank; ++d) {
+            size_t coord = rem % shape[d];
+            rem /= shape[d];
+            if (flags[d] && shape[d] > 1) coord = shape[d] - 1 - coord;
+            src += coord * stride;
+            stride *= shape[d];
+        }
+        out[idx] = data[src];
+    }
+}
+
+/* circshift_data, simple_provider.rs:2083-2143: shifts has one entry per dimension of `shape` */
+ORC_API void orc_circshift(const double* data, const size_t* shape, size_t rank, const long long* shifts, double* out) {
+    size_t total = 1;
+    for (size_t d = 0; d < rank; ++d) total *= shape[d];
+    for (size_t idx = 0; idx < total; ++idx) {
+        size_t rem = idx, src = 0, stride = 1;
+        for (size_t d = 0; d < rank; ++d) {
+            const size_t len = shape[d];
+            size_t coord = rem % len;
+            rem /= len;
+            if (len > 1) {
+                long long v = shifts[d] % (long long)len;
+                if (v < 0) v += (long long)len;
+                if (v != 0) coord = (coord + len - (size_t)v) % len;
+            }
+            src += coord * stride;
+            stride *= len;
+        }
+        out[idx] = data[src];
+    }
+}
+
+/* tril_data / triu_data, simple_provider.rs:1974-2081 */
+ORC_API void orc_tri(const double* data, const size_t* shape, size_t rank, int upper, long long offset, double* out) {
+    const size_t rows = rank > 0 ? shape[0] : 1, cols = rank > 1 ? shape[1] : 1;
+    size_t pages = 1;
+    for (size_t d = 2; d < rank; ++d) pages *= shape[d];
+    const size_t plane = rows * cols;
+    for (size_t page = 0; page < pages; ++page)
+        for (size_t col = 0; col < cols; ++col)
+            for (size_t row = 0; row < rows; ++row) {
+                const size_t i = page * plane + col * rows + row;
+                const long long r = (long long)row, c = (long long)col;
+                const int zero = upper ? (c - r < offset) : (r - c < -offset);
+                out[i] = zero ? 0.0 : data[i];
+            }
+}
+

@@ -509,3 +509,58 @@ def linspace(start: float, stop: float, count: int) -> np.ndarray:
     l.orc_linspace.argtypes = [C.c_double, C.c_double, C.c_size_t, _DP]
     l.orc_linspace(float(start), float(stop), int(count), _p(out))
     return out.reshape((1, int(count)))
+
+
+def eye(shape) -> np.ndarray:
+    shape = tuple(int(x) for x in shape)
+    shape = (1, 1) if len(shape) == 0 else (shape[0], shape[0]) if len(shape) == 1 else shape  # normalize_shape, simple_provider.rs:779-788
+    out = np.empty(int(np.prod(shape, dtype=np.int64)), dtype=np.float64)
+    l = lib()
+    l.orc_eye.restype = None
+    l.orc_eye.argtypes = [_SZP, C.c_size_t, _DP]
+    l.orc_eye(_shape(shape), len(shape), _p(out))
+    return out.reshape(shape, order="F")
+
+
+def flip(x: np.ndarray, axes) -> np.ndarray:
+    x = np.asarray(x, dtype=np.float64)
+    shape = list(x.shape)
+    for a in axes:
+        while len(shape) <= a:
+            shape.append(1)
+    flags = np.zeros(len(shape), dtype=np.int32)
+    for a in axes:
+        flags[a] ^= 1
+    fx = _f(x)
+    out = np.empty_like(fx)
+    l = lib()
+    l.orc_flip.restype = None
+    l.orc_flip.argtypes = [_DP, _SZP, C.c_size_t, C.POINTER(C.c_int), _DP]
+    l.orc_flip(_p(fx), _shape(shape), len(shape), flags.ctypes.data_as(C.POINTER(C.c_int)), _p(out))
+    return out.reshape(x.shape, order="F")
+
+
+def circshift(x: np.ndarray, shifts) -> np.ndarray:
+    x = np.asarray(x, dtype=np.float64)
+    shape = list(x.shape) + [1] * max(0, len(shifts) - x.ndim)
+    full = np.zeros(len(shape), dtype=np.int64)
+    full[:len(shifts)] = shifts
+    fx = _f(x)
+    out = np.empty_like(fx)
+    l = lib()
+    l.orc_circshift.restype = None
+    l.orc_circshift.argtypes = [_DP, _SZP, C.c_size_t, C.POINTER(C.c_longlong), _DP]
+    l.orc_circshift(_p(fx), _shape(shape), len(shape), full.ctypes.data_as(C.POINTER(C.c_longlong)), _p(out))
+    return out.reshape(x.shape, order="F")
+
+
+def tri(x: np.ndarray, upper: bool, offset: int) -> np.ndarray:
+    x = np.asarray(x, dtype=np.float64)
+    fx = _f(x)
+    out = np.empty_like(fx)
+    l = lib()
+    l.orc_tri.restype = None
+    l.orc_tri.argtypes = [_DP, _SZP, C.c_size_t, C.c_int, C.c_longlong, _DP]
+    l.orc_tri(_p(fx), _shape(x.shape), x.ndim, 1 if upper else 0, int(offset), _p(out))
+    return out.reshape(x.shape, order="F")
+

@@ -198,6 +198,33 @@ __global__ void __launch_bounds__(kBlock) k_linspace(T* __restrict__ out, size_t
     }
 }
 
+// identity_data (simple_provider.rs:2293-2336): 1 where row == col inside a page, written as one chunk of 1024 elements per block
+__global__ void __launch_bounds__(kBlock) k_eye(double* __restrict__ out, size_t n, size_t rows, size_t cols) {
+    const size_t b = (size_t)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const size_t i = b + e * 256;
+        if (i < n) {
+            const size_t r = i % rows, c = (i / rows) % cols;
+            out[i] = r == c ? 1.0 : 0.0;
+        }
+    }
+}
+// tril_data / triu_data (simple_provider.rs:1974-2081)
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_tri(const T* __restrict__ in, T* __restrict__ out, size_t n, size_t rows, size_t cols, int upper, long long offset) {
+    const size_t b = (size_t)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const size_t i = b + e * 256;
+        if (i < n) {
+            const long long r = (long long)(i % rows), c = (long long)((i / rows) % cols);
+            const bool zero = upper ? (c - r < offset) : (r - c < -offset);
+            out[i] = zero ? (T)0 : in[i];
+        }
+    }
+}
+
 unsigned flat_grid(const Context* c, size_t n) {
     const size_t want = (n + kBlock - 1) / kBlock, cap = (size_t)c->num_cus * 16;
     return (unsigned)std::max<size_t>(1, std::min(want, cap));
@@ -555,6 +582,196 @@ int rmhip_linspace(rmhip_ctx* ctx, double start, double stop, size_t count, rmhi
     if (e != hipSuccess) {
         rmhip_free(ctx, *out);
         return fail(RMHIP_ERR_HIP, "linspace launch: %s", hipGetErrorString(e));
+    }
+    return RMHIP_OK;
+}
+
+int rmhip_eye(rmhip_ctx* ctx, const size_t* shape, size_t rank, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out || (rank && !shape)) return fail(RMHIP_ERR_INVALID, "eye: null argument");
+    std::vector<size_t> s(shape, shape + rank);
+    if (s.empty()) s = {1, 1};
+    else if (s.size() == 1) s = {s[0], s[0]};  // normalize_shape, simple_provider.rs:779-788
+    Buffer ob;
+    RMHIP_TRY(c->new_buffer(s.data(), s.size(), out, &ob));
+    if (ob.numel == 0) return RMHIP_OK;
+    if ((ob.numel + 1023) / 1024 > 0x7fffffffULL) {
+        rmhip_free(ctx, *out);
+        return fail(RMHIP_ERR_UNSUPPORTED, "eye: %zu elements exceed the launch limits", ob.numel);
+    }
+    hipLaunchKernelGGL(k_eye, dim3((unsigned)((ob.numel + 1023) / 1024)), dim3(kBlock), 0, c->stream, ob.data(), ob.numel, s[0], s[1]);
+    c->tel.kernel_launches++;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        rmhip_free(ctx, *out);
+        return fail(RMHIP_ERR_HIP, "eye launch: %s", hipGetErrorString(e));
+    }
+    return RMHIP_OK;
+}
+
+namespace {
+// out = in with per-dimension maps (flip: rev, circshift: off): one IndexMap copy over the dimensions that are not trivial
+int mapped_copy(rmhip_ctx* ctx, Context* c, const Buffer& ab, const std::vector<size_t>& shape, const std::vector<uint64_t>& off,
+                const std::vector<uint8_t>& rev, rmhip_buf* out) {
+    Buffer ob;
+    RMHIP_TRY(new_like(c, ab, ab.shape.data(), ab.shape.size(), out, &ob));  // the operand's own shape (flip / circshift keep it)
+    if (ab.numel == 0) return RMHIP_OK;
+    // merge runs of identity dimensions (contiguous in source and output alike), drop extent-1 dimensions
+    IndexMap m;
+    m.rank = 0;
+    uint64_t stride = 1;
+    bool prev_identity = false;
+    for (size_t d = 0; d < shape.size(); ++d) {
+        const uint64_t e = shape[d];
+        const bool identity = !rev[d] && off[d] == 0;
+        if (e != 1) {
+            if (identity && prev_identity && m.rank > 0) {
+                m.shape[m.rank - 1] *= e;
+                m.mod[m.rank - 1] = m.shape[m.rank - 1];
+            } else {
+                if (m.rank == 8) {
+                    rmhip_free(ctx, *out);
+                    return fail(RMHIP_ERR_UNSUPPORTED, "more than 8 mapped dimensions");
+                }
+                m.shape[m.rank] = e;
+                m.stride[m.rank] = stride;
+                m.off[m.rank] = off[d];
+                m.mod[m.rank] = e;
+                m.rev[m.rank] = rev[d];
+                ++m.rank;
+            }
+            prev_identity = identity;
+        }
+        stride *= e;
+    }
+    if (m.rank == 0) {
+        m.rank = 1;
+        m.shape[0] = 1;
+        m.stride[0] = 1;
+        m.off[0] = 0;
+        m.mod[0] = 1;
+        m.rev[0] = 0;
+    }
+    const int rc = ab.dtype == DT_F32 ? launch_index_copy_f32(c, ab.data_f32(), ob.data_f32(), ab.numel, m)
+                                      : launch_index_copy(c, ab.data(), ob.data(), ab.numel, m);
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+}  // namespace
+
+int rmhip_flip(rmhip_ctx* ctx, rmhip_buf a, const size_t* axes, size_t n_axes, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out || (n_axes && !axes)) return fail(RMHIP_ERR_INVALID, "flip: null argument");
+    Buffer ab;
+    RMHIP_TRY(get_settled(c, a, &ab));
+    std::vector<size_t> shape = ab.shape;
+    for (size_t k = 0; k < n_axes; ++k)
+        if (axes[k] >= shape.size()) shape.resize(axes[k] + 1, 1);  // flip_data: axes beyond the rank are extent-1 dimensions
+    std::vector<uint8_t> rev(shape.size(), 0);
+    std::vector<uint64_t> off(shape.size(), 0);
+    for (size_t k = 0; k < n_axes; ++k) rev[axes[k]] ^= 1;  // named twice: flipped back (simple_provider.rs:1757-1762)
+    for (size_t d = 0; d < shape.size(); ++d) {
+        if (shape[d] <= 1) rev[d] = 0;
+        if (rev[d]) off[d] = shape[d] - 1;
+    }
+    return mapped_copy(ctx, c, ab, shape, off, rev, out);
+}
+
+int rmhip_circshift(rmhip_ctx* ctx, rmhip_buf a, const long long* shifts, size_t n_shifts, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out || (n_shifts && !shifts)) return fail(RMHIP_ERR_INVALID, "circshift: null argument");
+    Buffer ab;
+    RMHIP_TRY(get_settled(c, a, &ab));
+    std::vector<size_t> shape = ab.shape;
+    if (n_shifts > shape.size()) shape.resize(n_shifts, 1);  // simple_provider.rs:6439-6442
+    std::vector<uint8_t> rev(shape.size(), 0);
+    std::vector<uint64_t> off(shape.size(), 0);
+    for (size_t d = 0; d < shape.size() && d < n_shifts; ++d) {
+        const long long len = (long long)shape[d];
+        if (len <= 1) continue;
+        long long v = shifts[d] % len;  // circshift_data: normalised into [0, len)
+        if (v < 0) v += len;
+        off[d] = (uint64_t)((len - v) % len);  // src = (coord + len - shift) % len
+    }
+    return mapped_copy(ctx, c, ab, shape, off, rev, out);
+}
+
+int rmhip_tri(rmhip_ctx* ctx, rmhip_buf a, int upper, long long offset, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer ab, ob;
+    RMHIP_TRY(get_settled(c, a, &ab));
+    RMHIP_TRY(new_like(c, ab, ab.shape.data(), ab.shape.size(), out, &ob));
+    if (ab.numel == 0) return RMHIP_OK;
+    const size_t rows = ab.shape.empty() ? 1 : ab.shape[0], cols = ab.shape.size() > 1 ? ab.shape[1] : 1;
+    if ((ab.numel + 1023) / 1024 > 0x7fffffffULL) {
+        rmhip_free(ctx, *out);
+        return fail(RMHIP_ERR_UNSUPPORTED, "tril / triu: %zu elements exceed the launch limits", ab.numel);
+    }
+    const dim3 grid((unsigned)((ab.numel + 1023) / 1024));
+    if (ab.dtype == DT_F32) hipLaunchKernelGGL((k_tri<float>), grid, dim3(kBlock), 0, c->stream, ab.data_f32(), ob.data_f32(), ab.numel, rows, cols, upper, offset);
+    else hipLaunchKernelGGL((k_tri<double>), grid, dim3(kBlock), 0, c->stream, ab.data(), ob.data(), ab.numel, rows, cols, upper, offset);
+    c->tel.kernel_launches++;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        rmhip_free(ctx, *out);
+        return fail(RMHIP_ERR_HIP, "tril / triu launch: %s", hipGetErrorString(e));
+    }
+    return RMHIP_OK;
+}
+
+int rmhip_cat(rmhip_ctx* ctx, size_t dim, const rmhip_buf* inputs, size_t n_inputs, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out || !inputs) return fail(RMHIP_ERR_INVALID, "cat: null argument");
+    if (n_inputs < 2) return fail(RMHIP_ERR_INVALID, "cat: at least two input arrays are required");  // tensor.rs:462-465
+    if (dim < 1) return fail(RMHIP_ERR_INVALID, "cat: dimension must be >= 1");
+    const size_t dz = dim - 1;
+    std::vector<Buffer> in(n_inputs);
+    size_t rank = dz + 1;
+    for (size_t k = 0; k < n_inputs; ++k) {
+        RMHIP_TRY(get_settled(c, inputs[k], &in[k]));
+        if (in[k].dtype != in[0].dtype) return fail(RMHIP_ERR_UNSUPPORTED, "cat: input precision mismatch");
+        rank = std::max(rank, in[k].shape.size());
+    }
+    std::vector<std::vector<size_t>> shapes(n_inputs);
+    for (size_t k = 0; k < n_inputs; ++k) {
+        shapes[k] = in[k].shape;
+        shapes[k].resize(rank, 1);
+    }
+    for (size_t ax = 0; ax < rank; ++ax) {
+        if (ax == dz) continue;
+        for (size_t k = 1; k < n_inputs; ++k)
+            if (shapes[k][ax] != shapes[0][ax])
+                return fail(RMHIP_ERR_SHAPE, "cat: dimension %zu mismatch between input 1 (size %zu) and input %zu (size %zu)", ax + 1, shapes[0][ax], k + 1,
+                            shapes[k][ax]);
+    }
+    std::vector<size_t> oshape = shapes[0];
+    size_t cat_extent = 0;
+    for (size_t k = 0; k < n_inputs; ++k) cat_extent += shapes[k][dz];
+    oshape[dz] = cat_extent;
+    size_t inner = 1, outer = 1;
+    for (size_t ax = 0; ax < dz; ++ax) inner *= oshape[ax];
+    for (size_t ax = dz + 1; ax < rank; ++ax) outer *= oshape[ax];
+    std::vector<size_t> nshape = oshape;  // normalize_concat_shape (backend_shared.rs:330-339)
+    const size_t min_len = std::min(std::max<size_t>(dz + 1, 2), nshape.size());
+    while (nshape.size() > min_len && nshape.back() == 1) nshape.pop_back();
+    if (nshape.size() == 1) nshape.push_back(1);
+    Buffer ob;
+    RMHIP_TRY(new_like(c, in[0], nshape.data(), nshape.size(), out, &ob));
+    if (ob.numel == 0) return RMHIP_OK;
+    const size_t esz = in[0].dtype == DT_F32 ? sizeof(float) : sizeof(double);
+    size_t at = 0;  // offset along the concatenated dimension
+    for (size_t k = 0; k < n_inputs; ++k) {
+        const size_t w = inner * shapes[k][dz];  // contiguous elements per outer index
+        if (w && outer) {
+            char* dst = (char*)ob.alloc->ptr + at * inner * esz;
+            const hipError_t e = hipMemcpy2DAsync(dst, inner * cat_extent * esz, in[k].alloc->ptr, w * esz, w * esz, outer, hipMemcpyDeviceToDevice, c->stream);
+            if (e != hipSuccess) {
+                rmhip_free(ctx, *out);
+                return fail(RMHIP_ERR_HIP, "cat copy: %s", hipGetErrorString(e));
+            }
+        }
+        at += shapes[k][dz];
     }
     return RMHIP_OK;
 }

@@ -418,6 +418,45 @@ class HipProvider:
         self._check(self._lib.rmhip_scatter_linear(self._ctx, self._id(target), idx.ctypes.data_as(C.POINTER(C.c_uint32)), idx.size,
                                                    self._id(values)))
 
+    def eye(self, shape: Sequence[int]) -> GpuTensorHandle:
+        """`eye` (lib.rs:1552): identity on the first two dimensions of every page; [n] means [n, n]."""
+        sh, rank = _shape_array(shape)
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_eye(self._ctx, sh, rank, C.byref(out)))
+        return self._handle(out.value)
+
+    def eye_like(self, prototype: GpuTensorHandle) -> GpuTensorHandle:
+        return self.eye(prototype.shape)  # lib.rs:1557
+
+    def flip(self, a: GpuTensorHandle, axes: Sequence[int]) -> GpuTensorHandle:
+        """`flip` (lib.rs:2586): zero-based axes."""
+        arr, n = _shape_array(axes)
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_flip(self._ctx, self._id(a), arr, n, C.byref(out)))
+        return self._handle(out.value, a.shape)
+
+    def circshift(self, a: GpuTensorHandle, shifts: Sequence[int]) -> GpuTensorHandle:
+        """`circshift` (lib.rs:2589-2595): signed shifts per dimension."""
+        arr = (C.c_longlong * max(len(shifts), 1))(*[int(v) for v in shifts])
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_circshift(self._ctx, self._id(a), arr, len(shifts), C.byref(out)))
+        return self._handle(out.value, a.shape)
+
+    def _tri(self, a: GpuTensorHandle, upper: bool, offset: int) -> GpuTensorHandle:
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_tri(self._ctx, self._id(a), 1 if upper else 0, int(offset), C.byref(out)))
+        return self._handle(out.value, a.shape)
+
+    def tril(self, a, offset: int = 0): return self._tri(a, False, offset)  # lib.rs:1635
+    def triu(self, a, offset: int = 0): return self._tri(a, True, offset)   # lib.rs:1644
+
+    def cat(self, dim: int, inputs: Sequence[GpuTensorHandle]) -> GpuTensorHandle:
+        """`cat` (lib.rs:2686): ONE-based dimension."""
+        ids = (C.c_uint64 * max(len(inputs), 1))(*[self._id(h) for h in inputs])
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_cat(self._ctx, int(dim), ids, len(inputs), C.byref(out)))
+        return self._handle(out.value)
+
     def linspace(self, start: float, stop: float, count: int) -> GpuTensorHandle:
         """`linspace` (lib.rs:1887) -> [1, count]."""
         out = C.c_uint64()

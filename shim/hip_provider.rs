@@ -507,6 +507,43 @@ impl AccelProvider for HipProvider {
         check(unsafe { rmhip_linspace(self.ctx, start, stop, count, &mut out) })?;
         Ok(GpuTensorHandle { shape: vec![1, count], device_id: self.device_id, buffer_id: out })
     }
+    fn eye(&self, shape: &[usize]) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_eye(self.ctx, shape.as_ptr(), shape.len(), &mut out) })?;
+        self.handle(out)
+    }
+    fn eye_like(&self, prototype: &GpuTensorHandle) -> Result<GpuTensorHandle> { self.eye(&prototype.shape) }
+    fn flip(&self, handle: &GpuTensorHandle, axes: &[usize]) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_flip(self.ctx, self.own(handle)?, axes.as_ptr(), axes.len(), &mut out) })?;
+        Ok(GpuTensorHandle { shape: handle.shape.clone(), device_id: self.device_id, buffer_id: out })
+    }
+    fn circshift(&self, handle: &GpuTensorHandle, shifts: &[isize]) -> Result<GpuTensorHandle> {
+        let s: Vec<std::ffi::c_longlong> = shifts.iter().map(|&v| v as std::ffi::c_longlong).collect();
+        let mut out = 0u64;
+        check(unsafe { rmhip_circshift(self.ctx, self.own(handle)?, s.as_ptr(), s.len(), &mut out) })?;
+        Ok(GpuTensorHandle { shape: handle.shape.clone(), device_id: self.device_id, buffer_id: out })
+    }
+    fn tril<'a>(&'a self, matrix: &'a GpuTensorHandle, offset: isize) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_tri(self.ctx, self.own(matrix)?, 0, offset as std::ffi::c_longlong, &mut out) })?;
+            Ok(GpuTensorHandle { shape: matrix.shape.clone(), device_id: self.device_id, buffer_id: out })
+        })
+    }
+    fn triu<'a>(&'a self, matrix: &'a GpuTensorHandle, offset: isize) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_tri(self.ctx, self.own(matrix)?, 1, offset as std::ffi::c_longlong, &mut out) })?;
+            Ok(GpuTensorHandle { shape: matrix.shape.clone(), device_id: self.device_id, buffer_id: out })
+        })
+    }
+    fn cat(&self, dim: usize, inputs: &[GpuTensorHandle]) -> Result<GpuTensorHandle> {
+        let ids = inputs.iter().map(|h| self.own(h)).collect::<Result<Vec<_>>>()?;
+        let mut out = 0u64;
+        check(unsafe { rmhip_cat(self.ctx, dim, ids.as_ptr(), ids.len(), &mut out) })?;
+        self.handle(out)
+    }
     fn map_nan_to_zero(&self, a: &GpuTensorHandle) -> Result<GpuTensorHandle> { self.unary(RMHIP_NAN_TO_ZERO, a) }
     fn not_nan_mask(&self, a: &GpuTensorHandle) -> Result<GpuTensorHandle> { self.unary(RMHIP_NOT_NAN, a) }
 

@@ -290,3 +290,52 @@ def test_hooks_on_f32_provider(oracle):
         assert p.buffer_bits(z) == 32 and bits_equal(p.download_matrix(z), X)
     finally:
         p.close()
+
+
+@pytest.mark.parametrize("shape", [(4, 5), (3, 4, 5), (7, 1), (2, 1, 3), (300, 257), (1025, 3, 2), (5, 6, 7, 3)])
+def test_flip_circshift_tri_vs_oracle(prov, oracle, shape):
+    X = np.random.default_rng(41).standard_normal(shape)
+    h = prov.upload(X)
+    for axes in ([0], [len(shape) - 1], list(range(len(shape))), [0, 0], [len(shape) + 1]):
+        f = prov.flip(h, axes)
+        assert f.shape == tuple(shape) and bits_equal(prov.download_matrix(f), oracle.flip(X, axes)), axes
+        prov.free(f)
+    for shifts in ([2], [0, -1], [2, -1, 5][:len(shape)], [-7], [1] * (len(shape) + 1)):
+        s = prov.circshift(h, shifts)
+        assert bits_equal(prov.download_matrix(s), oracle.circshift(X, shifts)), shifts
+        prov.free(s)
+    for off in (-2, 0, 1, 1000):
+        lo, up = prov.tril(h, off), prov.triu(h, off)
+        assert bits_equal(prov.download_matrix(lo), oracle.tri(X, False, off)) and bits_equal(prov.download_matrix(up), oracle.tri(X, True, off))
+        prov.free(lo)
+        prov.free(up)
+    prov.free(h)
+
+
+def test_eye_and_cat(prov, oracle):
+    from runmat_amd import ProviderError
+
+    for shape in ([3], [2, 3], [5, 2], [2, 3, 2], [1025, 1030], []):
+        e = prov.eye(shape)
+        want = oracle.eye(shape)
+        assert e.shape == want.shape and bits_equal(prov.download_matrix(e), want)
+        prov.free(e)
+    rng = np.random.default_rng(42)
+    A, B, C3 = rng.standard_normal((4, 3)), rng.standard_normal((2, 3)), rng.standard_normal((4, 5))
+    ha, hb, hc = prov.upload(A), prov.upload(B), prov.upload(C3)
+    v = prov.cat(1, [ha, hb])            # vertical
+    assert v.shape == (6, 3) and bits_equal(prov.download_matrix(v), np.vstack([A, B]))
+    hcat = prov.cat(2, [ha, hc, ha])     # horizontal, three inputs
+    assert hcat.shape == (4, 11) and bits_equal(prov.download_matrix(hcat), np.hstack([A, C3, A]))
+    d3 = prov.cat(3, [ha, ha])           # a new trailing dimension
+    assert d3.shape == (4, 3, 2) and bits_equal(prov.download_matrix(d3), np.stack([A, A], axis=2))
+    X3, Y3 = rng.standard_normal((3, 2, 4)), rng.standard_normal((3, 5, 4))
+    h3 = prov.cat(2, [prov.upload(X3), prov.upload(Y3)])
+    assert h3.shape == (3, 7, 4) and bits_equal(prov.download_matrix(h3), np.concatenate([X3, Y3], axis=1))
+    with pytest.raises(ProviderError, match="mismatch"):
+        prov.cat(1, [ha, hc])
+    with pytest.raises(ProviderError, match="at least two"):
+        prov.cat(1, [ha])
+    big = rng.standard_normal((2048, 700))
+    hbig = prov.upload(big)
+    assert bits_equal(prov.download_matrix(prov.cat(2, [hbig, hbig])), np.hstack([big, big]))

@@ -103,3 +103,44 @@ def test_gather_scatter_and_nan_maps(oracle):
     z = oracle.unary("nan_to_zero", v)
     assert list(z[[0, 1, 3, 4]]) == [1.0, 0.0, np.inf, 0.0] and np.signbit(z[2])
     assert list(oracle.unary("not_nan", v)) == [1.0, 0.0, 1.0, 1.0, 0.0]
+
+
+def test_flip_circshift_tri_eye_reference_kats(oracle):
+    m32 = cm([1, 4, 2, 5, 3, 6], (3, 2))
+    # array/shape/flip.rs:740-761: vertical (dim 1) and horizontal (dim 2)
+    assert list(oracle.flip(m32, [0]).reshape(-1, order="F")) == [2, 4, 1, 6, 3, 5]
+    assert list(oracle.flip(m32, [1]).reshape(-1, order="F")) == [5, 3, 6, 1, 4, 2]
+    assert np.array_equal(oracle.flip(m32, [0, 0]), m32)  # named twice: flipped back (simple_provider.rs:1757-1762)
+    # array/shape/circshift.rs:971-1005
+    assert list(oracle.circshift(cm([1, 2, 3, 4, 5], (5, 1)), [2]).reshape(-1)) == [4, 5, 1, 2, 3]
+    m23 = cm([1, 4, 2, 5, 3, 6], (2, 3))
+    assert list(oracle.circshift(m23, [0, -1]).reshape(-1, order="F")) == [2, 5, 3, 6, 1, 4]
+    # array/shape/tril.rs:432-470, triu.rs:431-470
+    assert list(oracle.tri(m23, False, 0).reshape(-1, order="F")) == [1, 4, 0, 5, 0, 0]
+    assert list(oracle.tri(m23, False, 1).reshape(-1, order="F")) == [1, 4, 2, 5, 0, 6]
+    assert list(oracle.tri(m23, False, -1).reshape(-1, order="F")) == [0, 4, 0, 0, 0, 0]
+    assert list(oracle.tri(m23, True, 0).reshape(-1, order="F")) == [1, 0, 2, 5, 3, 6]
+    assert list(oracle.tri(m23, True, 1).reshape(-1, order="F")) == [0, 0, 2, 0, 3, 6]
+    assert list(oracle.tri(m23, True, -1).reshape(-1, order="F")) == [1, 4, 2, 5, 3, 6]
+    # identity_data (simple_provider.rs:2293-2336): [n] is n x n, pages repeat the identity
+    assert np.array_equal(oracle.eye([3]), np.eye(3)) and np.array_equal(oracle.eye([2, 3]), np.eye(2, 3))
+    e = oracle.eye([2, 3, 2])
+    assert e.shape == (2, 3, 2) and np.array_equal(e[:, :, 0], np.eye(2, 3)) and np.array_equal(e[:, :, 1], np.eye(2, 3))
+
+
+@pytest.mark.parametrize("shape", [(4, 5), (3, 4, 5), (7,), (2, 1, 3)])
+def test_flip_circshift_tri_match_numpy(oracle, shape):
+    X = np.random.default_rng(9).standard_normal(shape)
+    for axes in ([0], [len(shape) - 1], list(range(len(shape)))):
+        assert np.array_equal(oracle.flip(X, axes), np.flip(X, axes))
+    shifts = [2, -1, 5][:len(shape)]
+    assert np.array_equal(oracle.circshift(X, shifts), np.roll(X, shifts, axis=tuple(range(len(shifts)))))
+    if len(shape) >= 2:
+        for off in (-2, 0, 1):
+            want_l, want_u = X.copy(), X.copy()
+            r, c = np.indices(shape[:2])
+            ml = (r - c < -off)
+            mu = (c - r < off)
+            want_l[ml] = 0.0
+            want_u[mu] = 0.0
+            assert np.array_equal(oracle.tri(X, False, off), want_l) and np.array_equal(oracle.tri(X, True, off), want_u)
