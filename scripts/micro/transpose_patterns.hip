@@ -23,6 +23,34 @@ __global__ void __launch_bounds__(256) k_t(const double* __restrict__ src, doubl
     for (int p = 0; p < TS / G; ++p) dst[(c0 + lane) + (r0 + grp + G * p) * n] = tile[lane][grp + G * p];
 }
 
+// t64 with non-temporal loads and stores
+__global__ void __launch_bounds__(256) k_t64nt(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
+    __shared__ double tile[64][65];
+    const size_t r0 = (size_t)blockIdx.x * 64, c0 = (size_t)blockIdx.y * 64;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    double v[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) v[p] = __builtin_nontemporal_load(src + (r0 + lane) + (c0 + grp + 4 * p) * n);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) tile[grp + 4 * p][lane] = v[p];
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 16; ++p) __builtin_nontemporal_store(tile[lane][grp + 4 * p], dst + (c0 + lane) + (r0 + grp + 4 * p) * n);
+}
+// plain copy kernels for the ceiling: grid-stride 1024 threads NT v2 (k_stream1's shape) and chunk-per-block
+__global__ void __launch_bounds__(1024) k_copy_gs(const double* __restrict__ src, double* __restrict__ dst, size_t n2) {
+    const size_t nv = n2 >> 1, st = (size_t)gridDim.x * 1024;
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < nv; i += st) __builtin_nontemporal_store(__builtin_nontemporal_load((const v2*)src + i), (v2*)dst + i);
+}
+__global__ void __launch_bounds__(256) k_copy_chunk(const double* __restrict__ src, double* __restrict__ dst, size_t n2) {
+    const size_t b = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    double v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = src[b + e * 256];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dst[b + e * 256] = v[e];
+}
+
 // 64 x 64 tile, 16-byte accesses: 32 lanes cover a 64-element row
 __global__ void __launch_bounds__(256) k_t64v(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
     __shared__ double tile[64][65];
@@ -94,6 +122,9 @@ int main() {
         printf("%-44s %7.1f us  %6.3f TB/s\n", name, ms * 50.f, 2.0 * n * n * 8 / (ms / 20 * 1e-3) / 1e12);
     };
     run("t64   64x64, 8 B", [&] { hipLaunchKernelGGL(k_t<64>, dim3(n / 64, n / 64), dim3(256), 0, 0, a, b, n); });
+    run("t64nt 64x64, 8 B, non-temporal", [&] { hipLaunchKernelGGL(k_t64nt, dim3(n / 64, n / 64), dim3(256), 0, 0, a, b, n); });
+    run("copy  grid-stride 1024 thr NT v2, grid 4096", [&] { hipLaunchKernelGGL(k_copy_gs, dim3(4096), dim3(1024), 0, 0, a, b, n * n); });
+    run("copy  chunk 1024 per block, plain", [&] { hipLaunchKernelGGL(k_copy_chunk, dim3(n * n / 1024), dim3(256), 0, 0, a, b, n * n); });
     run("t32   32x32, 8 B", [&] { hipLaunchKernelGGL(k_t<32>, dim3(n / 32, n / 32), dim3(256), 0, 0, a, b, n); });
     run("t64v  64x64, 16 B", [&] { hipLaunchKernelGGL(k_t64v, dim3(n / 64, n / 64), dim3(256), 0, 0, a, b, n); });
     run("t128x64  128x64, 8 B, 512 threads", [&] { hipLaunchKernelGGL(k_t128x64, dim3(n / 128, n / 64), dim3(512), 0, 0, a, b, n); });
