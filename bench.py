@@ -216,7 +216,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["fused", "dgemm", "mc", "mldivide", "chain", "mc_evolved", "image", "fused_f32", "sgemm"], default="fused")
+    ap.add_argument("--workload", choices=["fused", "dgemm", "mc", "mldivide", "chain", "mc_evolved", "image", "fused_f32", "sgemm", "bcast"], default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     args = ap.parse_args()
@@ -668,6 +668,45 @@ def main() -> None:
                                       host_ms_per_call=round(ms, 5), traffic=pmc_traffic("chain", "rm_ew_fast"), traffic_source=PMC_TRAFFIC_SOURCE),
         }
 
+    def bcast_record(steps, warmup):
+        """The reference's UNFUSED implicit-expansion path (north_star: "broadcast"): A (8192 x 1) .* B (1 x 8192) through the call sequence
+        of its times builtin (math/elementwise/times.rs:501-543): broadcast_reps -> repmat each operand -> elem_mul -> free the
+        expansions.  `repmat` is a zero-copy view here and elem_mul reads it in place, so a step must move one 512 MiB write."""
+        ha, hb = prov.fill_uniform(31 + rank, -1.0, 1.0, (n, 1)), prov.fill_uniform(32 + rank, -1.0, 1.0, (1, n))
+
+        def step():
+            le, re = prov.repmat(ha, [1, n]), prov.repmat(hb, [n, 1])
+            h = prov.elem_mul(le, re)
+            prov.free(le)
+            prov.free(re)
+            prov.free(h)
+
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        wall = max_over_ranks(time.perf_counter() - t0)
+        ms = wall / steps * 1e3
+        prov.synchronize()
+        prov.timer_begin()
+        for _ in range(steps):
+            step()
+        kern_ms = max_over_ranks(prov.timer_end() / steps)
+        prov.free(ha)
+        prov.free(hb)
+        nbytes = 8 * n * n + 16 * n  # the product written once, the two vectors read once
+        return {
+            "metric": "unfused implicit expansion GB/s (A(8192x1) .* B(1x8192) via repmat -> elem_mul -> free, f64)",
+            "value": round(world * nbytes / (ms * 1e-3) / 1e9, 2), "unit": "GB/s", "ms_per_step": round(ms, 5), "scaling": "weak", "dtype": "f64",
+            "config": {"workload": "times builtin's unfused broadcast sequence on resident operands (repmat views + rmhip_binary)",
+                       "bytes_per_step_per_gpu": nbytes, "parallelism": f"independent x{world}"},
+            "roofline": roofline("hbm", nbytes / (kern_ms * 1e-3) / 1e9, traffic=pmc_traffic("bcast", "k_bcast2"), traffic_source=PMC_TRAFFIC_SOURCE,
+                                 kernel="k_bcast2<double, mul> (both operands stride-0 views: write-only traffic)", kernel_ms=round(kern_ms, 5)),
+        }
+
     def fused_f32_record(steps, warmup):
         # SURVEY.md 8(f) row 2: the same request on a precision-32 provider (f32 in HBM, f64 arithmetic in registers)
         p32 = HipProvider(local_rank, precision="F32")
@@ -772,7 +811,7 @@ def main() -> None:
         return rec
 
     records = {"sgemm": sgemm_record, "fused_f32": fused_f32_record, "fused": fused_record, "dgemm": dgemm_record, "mc": mc_record, "mldivide": mldivide_record,
-               "chain": chain_record, "mc_evolved": mc_evolved_record, "image": image_record}
+               "chain": chain_record, "mc_evolved": mc_evolved_record, "image": image_record, "bcast": bcast_record}
     primary = records[args.workload]
     rec = safe_record(args.workload, primary, args.steps, args.warmup)
     if "error" in rec:  # the line still comes out, with the reason where the number would be
@@ -801,14 +840,14 @@ def main() -> None:
     out["comm"] = comm
     if not args.no_also:
         # the other configs of BASELINE.json, short runs; every rank takes part (collectives inside)
-        others = [w for w in ("fused", "dgemm", "mc", "mc_evolved", "image", "chain", "fused_f32", "sgemm") if w != args.workload]
+        others = [w for w in ("fused", "dgemm", "mc", "mc_evolved", "image", "chain", "bcast", "fused_f32", "sgemm") if w != args.workload]
         if args.workload != "mldivide":
             others.append("mldivide")  # one GPU: rmhip_mldivide; N > 1: the block-column cyclic driver (BASELINE configs[4])
         also = []
         for w in others:
             # enough steps that the two synchronisations around the timed region (~1 ms together) stay below 1 % of it: a 20-step run
             # of the 0.65 ms image workload read 0.73 ms per step
-            steps = {"fused": 200, "dgemm": 10, "mc": 200, "mc_evolved": 100, "image": 200, "mldivide": 3, "chain": 2000, "fused_f32": 200, "sgemm": 10}[w]
+            steps = {"fused": 200, "dgemm": 10, "mc": 200, "mc_evolved": 100, "image": 200, "mldivide": 3, "chain": 2000, "fused_f32": 200, "sgemm": 10, "bcast": 500}[w]
             sec = safe_record(w, records[w], steps, 5 if w != "mldivide" else 1)
             if "error" in sec:
                 also.append(sec)
@@ -820,7 +859,7 @@ def main() -> None:
         out["cpu_baseline"] = {"fused": cpu_baseline_fused, "dgemm": cpu_baseline_dgemm, "mc": cpu_baseline_mc,
                                "mldivide": cpu_baseline_mldivide, "chain": cpu_baseline_chain,
                                "mc_evolved": cpu_baseline_mc, "image": cpu_baseline_fused,
-                               "fused_f32": cpu_baseline_fused, "sgemm": cpu_baseline_dgemm}[args.workload]()
+                               "fused_f32": cpu_baseline_fused, "sgemm": cpu_baseline_dgemm, "bcast": cpu_baseline_fused}[args.workload]()
         for a in out.get("also", []):
             if "error" in a:
                 continue

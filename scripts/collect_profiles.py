@@ -21,13 +21,28 @@ for name in ("mldivide_timeline.txt", "tier2_rates.txt", "red2_rates.txt", "red_
              "bench_default.json", "offload_calibration.json"):
     if (src / name).exists() and (src / name).stat().st_size:
         shutil.copy(src / name, dst / f"{tag}_{name}"); n += 1
-shutil.copy(src / "pmc_summary.json", dst / f"{tag}_pmc_summary.json")
 # merge: a round may re-profile only some workloads; the entries of the others stay
 import json
-new = json.loads((src / "pmc_traffic.json").read_text())
-cur = json.loads((dst / "pmc_traffic.json").read_text()) if (dst / "pmc_traffic.json").exists() else {}
-cur.update({k: v for k, v in new.items() if not k.startswith("_") or k not in cur})
-(dst / "pmc_traffic.json").write_text(json.dumps(cur, indent=1))
+
+
+def merge(src_file, dst_file):
+    new = json.loads(src_file.read_text())
+    if isinstance(new, list):           # rows tagged with their workload: replace the rows of the workloads profiled again
+        cur = json.loads(dst_file.read_text()) if dst_file.exists() else []
+        again = {r["workload"] for r in new}
+        dst_file.write_text(json.dumps([r for r in cur if r["workload"] not in again] + new, indent=1))
+        return
+    cur = json.loads(dst_file.read_text()) if dst_file.exists() else {}
+    for k, v in new.items():
+        if isinstance(v, dict) and isinstance(cur.get(k), dict) and k.startswith("_"):
+            cur[k].update(v)            # per-workload tables kept under an underscore key (e.g. _durations_us)
+        elif not k.startswith("_") or k not in cur:
+            cur[k] = v
+    dst_file.write_text(json.dumps(cur, indent=1))
+
+
+merge(src / "pmc_summary.json", dst / f"{tag}_pmc_summary.json")
+merge(src / "pmc_traffic.json", dst / "pmc_traffic.json")
 if (src / "pmc_valu.json").exists():
-    shutil.copy(src / "pmc_valu.json", dst / "pmc_valu.json")
-print(f"copied {n + 2} files into {dst}")
+    merge(src / "pmc_valu.json", dst / "pmc_valu.json")
+print(f"copied {n + 3} files into {dst}")
