@@ -295,6 +295,39 @@ RMHIP_API int rmhip_dot(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, int dim, rmhip
 
 /* ---- linear algebra  (lib.rs:2375-2405, 2477-2500) ------------------------------------------ */
 
+/* ---- order statistics along a dimension (runmat_amd/csrc/order_ops.hip) ----
+ * `cummin_scan` / `cummax_scan` (lib.rs:2918-2935; CPU semantics cummin.rs:719-876, cummax.rs): the running minimum (is_max 0) or maximum
+ * along zero-based `dim` (< rank, as the caller guarantees: cummin.rs:676-688), forward or from the end (reverse != 0), and the 1-based
+ * position along the dimension of the FIRST occurrence of that extreme in scan order.  nan_mode 0 (include): from the first NaN of a line on
+ * the value is NaN and the index is that NaN's position; 1 (omit): NaNs are skipped, and until a number has been seen value AND index are
+ * NaN.  Both outputs have the operand's shape.  Bit-exact (copies of input elements and positions). */
+/* @serves cummin_scan cummax_scan */
+RMHIP_API int rmhip_cumextreme(rmhip_ctx* ctx, int is_max, rmhip_buf a, int dim, int reverse, int nan_mode, rmhip_buf* values,
+                               rmhip_buf* indices);
+/* `diff_dim(handle, order, dim)` (lib.rs:2596-2603; diff.rs:439-507 through simple_provider.rs:6474-6496): `order` first differences
+ * x[k+1] - x[k] along zero-based `dim` (dimensions beyond the rank are extents of one), each pass rounding once; order 0 = a copy; a pass
+ * that leaves nothing ends the loop.  column_major 0 reproduces the reference's OUTPUT ORDER: diff_tensor_once pushes the results with
+ * k fastest inside every (before, after) line whatever the dimension (diff.rs:493-503; the wgpu shader shaders/diff.rs:26-45 writes the
+ * same order), which is the column-major array of the differences only when the dimensions before `dim` have extent one - and the next
+ * pass reads that buffer as if it were.  column_major != 0 writes the column-major array (the two agree for dim 0 and for vectors). */
+/* @serves diff_dim */
+RMHIP_API int rmhip_diff_dim(rmhip_ctx* ctx, rmhip_buf a, size_t order, int dim, int column_major, rmhip_buf* out);
+/* `sort_dim(a, dim, order, comparison)` (lib.rs:2358-2366; sort.rs:413-468, 538-574): every line along zero-based `dim` sorted STABLY,
+ * ascending or descending (descend != 0); by_abs != 0 orders by |x| first and by x among equal magnitudes (ComparisonMethod::Abs; Auto
+ * and Real are by_abs 0 for real data).  NaNs go last ascending and first descending, -0 and +0 compare equal, equal elements keep
+ * their input order.  `indices` holds the 1-based original positions.  A dimension beyond the rank or of extent <= 1 returns the values
+ * and ones.  The trait's SortResult carries HOST tensors: the shim downloads both buffers (shim/hip_provider.rs). */
+/* @serves sort_dim */
+RMHIP_API int rmhip_sort_dim(rmhip_ctx* ctx, rmhip_buf a, int dim, int descend, int by_abs, rmhip_buf* sorted, rmhip_buf* indices);
+/* `reduce_median_dim(a, dim)` (lib.rs:2839-2845; median.rs:644-741, called in include-NaN mode only: median.rs:425-431): per line along
+ * zero-based `dim` NaN if the line holds a NaN, else the middle element of the stably sorted line or 0.5 * (lower + upper); an extent of
+ * zero gives NaN, of one the operand.  Output shape = the operand's with extent 1 at `dim` (any rank; the in-process provider takes 2-D
+ * only).  dim < 0 is `reduce_median(a)`: ALL elements as one line -> [1, 1] - what both of the reference's providers compute
+ * (simple_provider.rs:7167-7193); the host path of median(x, 'all') instead takes medians dimension after dimension
+ * (median.rs:531-541), which is a different number on general inputs: callers wanting that chain the per-dimension form. */
+/* @serves reduce_median reduce_median_dim */
+RMHIP_API int rmhip_reduce_median(rmhip_ctx* ctx, rmhip_buf a, int dim, rmhip_buf* out);
+
 /* `matmul`: C = A*B, 2-D, column-major; inner dims must agree else RMHIP_ERR_SHAPE
  * (simple_provider.rs:7698-7741). fp64 MFMA kernel. */
 /* @serves matmul */

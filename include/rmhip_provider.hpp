@@ -332,6 +332,9 @@ public:
     struct ReduceDimResult {
         GpuTensorHandle values, indices;
     };
+    struct SortResult {  // lib.rs:1085-1088
+        HostTensorOwned values, indices;
+    };
     ReduceDimResult reduce_min_dim(const GpuTensorHandle& a, size_t dim) const { return minmax_dim(RMHIP_RMIN, a, dim); }
     ReduceDimResult reduce_max_dim(const GpuTensorHandle& a, size_t dim) const { return minmax_dim(RMHIP_RMAX, a, dim); }
     // lib.rs:2786-2802 (normalization: 0 sample / 1 population; nan_mode: 0 include / 1 omit)
@@ -349,6 +352,38 @@ public:
     // lib.rs:2884-2891, 2908-2915 (reverse: ProviderScanDirection::Reverse; nan_mode: ProviderNanMode)
     GpuTensorHandle cumsum_scan(const GpuTensorHandle& a, size_t dim, bool reverse, int nan_mode) const { return cumulative(0, a, dim, reverse, nan_mode); }
     GpuTensorHandle cumprod_scan(const GpuTensorHandle& a, size_t dim, bool reverse, int nan_mode) const { return cumulative(1, a, dim, reverse, nan_mode); }
+    // lib.rs:2918-2935 (ProviderCumminResult / ProviderCummaxResult = {values, indices}; nan_mode: 0 include / 1 omit)
+    ReduceDimResult cummin_scan(const GpuTensorHandle& a, size_t dim, bool reverse, int nan_mode) const { return cumextreme(0, a, dim, reverse, nan_mode); }
+    ReduceDimResult cummax_scan(const GpuTensorHandle& a, size_t dim, bool reverse, int nan_mode) const { return cumextreme(1, a, dim, reverse, nan_mode); }
+    ReduceDimResult cumextreme(int is_max, const GpuTensorHandle& a, size_t dim, bool reverse, int nan_mode) const {
+        uint64_t v = 0, i = 0;
+        check(rmhip_cumextreme(ctx_, is_max, own(a), (int)dim, reverse ? 1 : 0, nan_mode, &v, &i));
+        return {with_shape(v), with_shape(i)};
+    }
+    // lib.rs:2596-2603 (the reference's output order; column_major = true for the column-major array of the differences)
+    GpuTensorHandle diff_dim(const GpuTensorHandle& a, size_t order, size_t dim, bool column_major = false) const {
+        uint64_t out = 0;
+        check(rmhip_diff_dim(ctx_, own(a), order, (int)dim, column_major ? 1 : 0, &out));
+        return with_shape(out);
+    }
+    // lib.rs:2358-2366: SortResult carries host tensors (lib.rs:1085-1088); descend = SortOrder::Descend, by_abs = SortComparison::Abs
+    SortResult sort_dim(const GpuTensorHandle& a, size_t dim, bool descend, bool by_abs) const {
+        uint64_t v = 0, i = 0;
+        check(rmhip_sort_dim(ctx_, own(a), (int)dim, descend ? 1 : 0, by_abs ? 1 : 0, &v, &i));
+        const GpuTensorHandle hv = with_shape(v), hi = with_shape(i);
+        SortResult r{download(hv), download(hi)};
+        free(hv);
+        free(hi);
+        return r;
+    }
+    // lib.rs:2833-2845
+    GpuTensorHandle reduce_median(const GpuTensorHandle& a) const { return median_(a, -1); }
+    GpuTensorHandle reduce_median_dim(const GpuTensorHandle& a, size_t dim) const { return median_(a, (int)dim); }
+    GpuTensorHandle median_(const GpuTensorHandle& a, int dim) const {
+        uint64_t out = 0;
+        check(rmhip_reduce_median(ctx_, own(a), dim, &out));
+        return with_shape(out);
+    }
     ReduceDimResult minmax_dim(int op, const GpuTensorHandle& a, size_t dim) const {
         uint64_t v = 0, i = 0;
         check(rmhip_reduce_minmax_dim(ctx_, op, own(a), (int)dim, 0, &v, &i));

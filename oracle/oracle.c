@@ -1259,3 +1259,144 @@ ORC_API void orc_tri(const double* data, const size_t* shape, size_t rank, int u
             }
 }
 
+
+/* ---- order hooks: cummin / cummax, diff, median, sort (the CPU paths the GPU builtins fall back to) ---- */
+
+/* cummin_tensor / cummax_tensor, runmat-runtime builtins/math/reduction/cummin.rs:719-876 (cummax.rs mirrors it with `>`):
+ * running extreme along dim with the 1-based position of its FIRST occurrence in scan order; include-NaN: from the first NaN on the value
+ * is NaN and the index is that NaN's position; omit: NaNs are skipped, and before any number has been seen value and index are NaN. */
+ORC_API void orc_cumextreme(const double* data, size_t pre, size_t len, size_t post, int is_max, int reverse, int omit, double* values,
+                            double* indices) {
+    for (size_t after = 0; after < post; ++after)
+        for (size_t before = 0; before < pre; ++before) {
+            double current = 0.0;
+            size_t current_index = 0, nan_index = 0;
+            int has_value = 0, nan_fixed = 0;
+            for (size_t s = 0; s < len; ++s) {
+                const size_t k = reverse ? len - 1 - s : s;
+                const size_t idx = after * pre * len + before + k * pre;
+                const double value = data[idx];
+                const size_t position = k + 1;
+                if (!omit) {
+                    if (nan_fixed) {
+                        values[idx] = NAN;
+                        indices[idx] = (double)nan_index;
+                        continue;
+                    }
+                    if (value != value) {
+                        nan_fixed = 1;
+                        nan_index = position;
+                        values[idx] = NAN;
+                        indices[idx] = (double)position;
+                        continue;
+                    }
+                } else if (value != value) {
+                    values[idx] = has_value ? current : NAN;
+                    indices[idx] = has_value ? (double)current_index : NAN;
+                    continue;
+                }
+                if (!has_value || (is_max ? value > current : value < current)) {
+                    has_value = 1;
+                    current = value;
+                    current_index = position;
+                }
+                values[idx] = current;
+                indices[idx] = (double)current_index;
+            }
+        }
+}
+
+/* diff_tensor_once, builtins/math/reduction/diff.rs:474-507: out.push order is (after, before, k) - k FASTEST - whatever the dimension:
+ * for dim >= 2 with leading dimensions > 1 the output buffer is therefore NOT the column-major array of the differences (the wgpu shader
+ * shaders/diff.rs:26-45 writes the same order).  column_major != 0 gives the column-major layout instead (k at stride pre). */
+ORC_API void orc_diff_once(const double* data, size_t pre, size_t len, size_t post, int column_major, double* out) {
+    if (len <= 1) return;
+    for (size_t after = 0; after < post; ++after)
+        for (size_t before = 0; before < pre; ++before)
+            for (size_t k = 0; k + 1 < len; ++k) {
+                const size_t idx0 = before + after * pre * len + k * pre;
+                const double d = data[idx0 + pre] - data[idx0];
+                if (column_major) out[before + after * pre * (len - 1) + k * pre] = d;
+                else out[(after * pre + before) * (len - 1) + k] = d;
+            }
+}
+
+/* stable insertion-free merge sort of (key order given by cmp) used by both restatements: Rust's slice::sort_by is stable */
+typedef struct { size_t k; double v; } orc_pair;
+static int orc_cmp_mode_desc, orc_cmp_mode_abs;
+static int orc_sort_cmp(double a, double b) { /* compare_real_values, sorting_sets/sort.rs:538-574; <0: a first */
+    const int an = a != a, bn = b != b;
+    if (an && bn) return 0;
+    if (an) return orc_cmp_mode_desc ? -1 : 1;
+    if (bn) return orc_cmp_mode_desc ? 1 : -1;
+    if (orc_cmp_mode_abs) {
+        const double fa = fabs(a), fb = fabs(b);
+        if (fa != fb) {
+            const int c = fa < fb ? -1 : 1;
+            return orc_cmp_mode_desc ? -c : c;
+        }
+    }
+    if (a == b) return 0;
+    if (orc_cmp_mode_desc) return b < a ? -1 : 1;
+    return a < b ? -1 : 1;
+}
+static void orc_merge_sort(orc_pair* a, orc_pair* tmp, size_t n) {
+    if (n < 2) return;
+    const size_t h = n / 2;
+    orc_merge_sort(a, tmp, h);
+    orc_merge_sort(a + h, tmp, n - h);
+    size_t i = 0, j = h, o = 0;
+    while (i < h && j < n) tmp[o++] = orc_sort_cmp(a[j].v, a[i].v) < 0 ? a[j++] : a[i++];  /* ties: the left (earlier) one first */
+    while (i < h) tmp[o++] = a[i++];
+    while (j < n) tmp[o++] = a[j++];
+    memcpy(a, tmp, n * sizeof(orc_pair));
+}
+
+/* sort_real_tensor, sorting_sets/sort.rs:413-468: every line along dim sorted stably; indices = 1-based original positions */
+ORC_API void orc_sort_dim(const double* data, size_t pre, size_t len, size_t post, int descend, int by_abs, double* sorted, double* indices) {
+    orc_pair* buf = (orc_pair*)malloc((len ? len : 1) * sizeof(orc_pair));
+    orc_pair* tmp = (orc_pair*)malloc((len ? len : 1) * sizeof(orc_pair));
+    orc_cmp_mode_desc = descend;
+    orc_cmp_mode_abs = by_abs;
+    for (size_t after = 0; after < post; ++after)
+        for (size_t before = 0; before < pre; ++before) {
+            for (size_t k = 0; k < len; ++k) {
+                buf[k].k = k;
+                buf[k].v = data[before + k * pre + after * pre * len];
+            }
+            orc_merge_sort(buf, tmp, len);
+            for (size_t pos = 0; pos < len; ++pos) {
+                const size_t target = before + pos * pre + after * pre * len;
+                sorted[target] = buf[pos].v;
+                indices[target] = (double)(buf[pos].k + 1);
+            }
+        }
+    free(buf);
+    free(tmp);
+}
+
+/* reduce_tensor_median_dim (include-NaN: the only mode the provider hook is called with), builtins/math/reduction/median.rs:644-741:
+ * a NaN in the slice -> NaN; else the slice sorted by partial_cmp (stable), middle element or 0.5 * (lower + upper).  len == 0 -> NaN. */
+ORC_API void orc_median_dim(const double* data, size_t pre, size_t len, size_t post, double* out) {
+    orc_pair* buf = (orc_pair*)malloc((len ? len : 1) * sizeof(orc_pair));
+    orc_pair* tmp = (orc_pair*)malloc((len ? len : 1) * sizeof(orc_pair));
+    orc_cmp_mode_desc = 0;
+    orc_cmp_mode_abs = 0;
+    for (size_t after = 0; after < post; ++after)
+        for (size_t before = 0; before < pre; ++before) {
+            int saw_nan = 0;
+            for (size_t k = 0; k < len; ++k) {
+                buf[k].k = k;
+                buf[k].v = data[before + k * pre + after * pre * len];
+                if (buf[k].v != buf[k].v) saw_nan = 1;
+            }
+            double m = NAN;
+            if (!saw_nan && len > 0) {
+                orc_merge_sort(buf, tmp, len);
+                m = (len % 2 == 1) ? buf[len / 2].v : 0.5 * (buf[len / 2 - 1].v + buf[len / 2].v);
+            }
+            out[after * pre + before] = m;
+        }
+    free(buf);
+    free(tmp);
+}

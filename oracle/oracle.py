@@ -564,3 +564,88 @@ def tri(x: np.ndarray, upper: bool, offset: int) -> np.ndarray:
     l.orc_tri(_p(fx), _shape(x.shape), x.ndim, 1 if upper else 0, int(offset), _p(out))
     return out.reshape(x.shape, order="F")
 
+
+
+def _pre_len_post(shape, dim):
+    shape = list(shape)
+    pre = int(np.prod(shape[:dim], dtype=np.int64)) if dim > 0 else 1
+    post = int(np.prod(shape[dim + 1:], dtype=np.int64)) if dim + 1 < len(shape) else 1
+    return pre, shape[dim], post
+
+
+def cumextreme(x: np.ndarray, dim: int, is_max: bool, reverse: bool = False, omit_nan: bool = False):
+    """cummin / cummax along zero-based `dim` (< ndim): (values, 1-based indices)  (cummin.rs:719-876)."""
+    x = np.asarray(x, dtype=np.float64)
+    pre, ln, post = _pre_len_post(x.shape, dim)
+    fx = _f(x)
+    vals, idx = np.empty_like(fx), np.empty_like(fx)
+    l = lib()
+    l.orc_cumextreme.restype = None
+    l.orc_cumextreme.argtypes = [_DP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, _DP, _DP]
+    l.orc_cumextreme(_p(fx), pre, ln, post, int(is_max), int(reverse), int(omit_nan), _p(vals), _p(idx))
+    return vals.reshape(x.shape, order="F"), idx.reshape(x.shape, order="F")
+
+
+def diff(x: np.ndarray, order: int, dim: int, column_major: bool = False) -> np.ndarray:
+    """diff_tensor_host with an explicit zero-based dim (diff.rs:439-507): `order` first differences, each in the reference's output
+    order (k fastest; see orc_diff_once) unless column_major.  The result is returned as a flat buffer plus its shape when the layout is
+    the reference's (it is not a column-major array for dim >= 1 with leading extents > 1), as an array otherwise."""
+    x = np.asarray(x, dtype=np.float64)
+    shape = list(x.shape)
+    while len(shape) <= dim:
+        shape.append(1)
+    cur = _f(x)
+    l = lib()
+    l.orc_diff_once.restype = None
+    l.orc_diff_once.argtypes = [_DP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _DP]
+    for _ in range(order):
+        pre, ln, post = _pre_len_post(shape, dim)
+        oshape = list(shape)
+        oshape[dim] = max(ln, 1) - 1
+        if ln <= 1 or cur.size == 0:
+            cur, shape = np.zeros(0), oshape
+            break
+        out = np.empty(pre * (ln - 1) * post)
+        l.orc_diff_once(_p(cur), pre, ln, post, int(column_major), _p(out))
+        cur, shape = out, oshape
+    return cur, shape
+
+
+def sort_dim(x: np.ndarray, dim: int, descend: bool = False, by_abs: bool = False):
+    """Stable sort of every line along zero-based dim: (sorted, 1-based original positions)  (sort.rs:413-468, 538-574)."""
+    x = np.asarray(x, dtype=np.float64)
+    pre, ln, post = _pre_len_post(x.shape, dim)
+    fx = _f(x)
+    vals, idx = np.empty_like(fx), np.empty_like(fx)
+    l = lib()
+    l.orc_sort_dim.restype = None
+    l.orc_sort_dim.argtypes = [_DP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, _DP, _DP]
+    l.orc_sort_dim(_p(fx), pre, ln, post, int(descend), int(by_abs), _p(vals), _p(idx))
+    return vals.reshape(x.shape, order="F"), idx.reshape(x.shape, order="F")
+
+
+def median_dim(x: np.ndarray, dim: int) -> np.ndarray:
+    """Include-NaN median along zero-based dim (median.rs:644-741)."""
+    x = np.asarray(x, dtype=np.float64)
+    pre, ln, post = _pre_len_post(x.shape, dim)
+    fx = _f(x)
+    oshape = list(x.shape)
+    oshape[dim] = 1
+    out = np.empty(pre * post)
+    l = lib()
+    l.orc_median_dim.restype = None
+    l.orc_median_dim.argtypes = [_DP, C.c_size_t, C.c_size_t, C.c_size_t, _DP]
+    l.orc_median_dim(_p(fx), pre, ln, post, _p(out))
+    return out.reshape(oshape, order="F")
+
+
+def median_all(x: np.ndarray, successive: bool = False) -> float:
+    """median(x, 'all'): the provider hook (reduce_median: simple_provider.rs:7167-7193) sorts ALL elements; the host path
+    (median.rs:531-541) takes medians dimension after dimension - the two differ on general inputs."""
+    x = np.asarray(x, dtype=np.float64)
+    if not successive:
+        return float(median_dim(x.reshape(-1, 1, order="F"), 0)[0, 0]) if x.size else float("nan")
+    cur = x
+    for d in range(x.ndim):
+        cur = median_dim(cur, d)
+    return float(cur.reshape(-1)[0])

@@ -1,0 +1,657 @@
+// order_ops.hip -- the order-statistics hooks of the reduction / sorting builtins
+//   cummin_scan / cummax_scan     crates/runmat-accelerate-api/src/lib.rs:2918-2935   (CPU semantics cummin.rs:719-876, cummax.rs)
+//   diff_dim                      lib.rs:2596-2603    (diff.rs:439-507; the provider form simple_provider.rs:6474-6496)
+//   reduce_median(_dim)           lib.rs:2833-2845    (median.rs:644-741; simple_provider.rs:7167-7270)
+//   sort_dim                      lib.rs:2358-2366    (sorting_sets/sort.rs:413-468, 538-574)
+// Integer / comparison work on f64 data: every result is a copy of an input element, a position, or one rounded operation
+// (a difference, the mean of two middle elements) - bit-exact against the oracle.
+//   * running extremes: the (value, first position, NaN state) triple is associative, so lines are scanned in any grouping - a wave per
+//     contiguous line piece (shuffle scan over rows of 64), a thread per strided line piece (coalesced across the lines), long lines cut
+//     into chunks with a carry pass in between.
+//   * sort / median: every line becomes (u64 key, u32 position) pairs in a workspace padded to a power of two - the key orders the
+//     values exactly as compare_real_values does (NaNs last / first, |x| then x, -0 == +0) and the position breaks ties, which IS the
+//     stable order - and is sorted by a bitonic network: all steps below 2048 elements in LDS, the wider ones in global passes.
+#include <algorithm>
+#include <cstring>
+#include <limits>
+
+#include "common.h"
+
+using namespace rmhip;
+
+#define CTX_OR_FAIL(ctx)                                            \
+    if (!(ctx)) return fail(RMHIP_ERR_INVALID, "null context");     \
+    Context* c = context_of(ctx);                                   \
+    std::lock_guard<std::recursive_mutex> _call(c->call_mu);        \
+    DeviceGuard _dg(c);                                             \
+    NarrowScope _ns(c)
+
+namespace rmhip {
+namespace {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+struct Lines {  // element (line, k) of the operand sits at (line / pre) * pre * len + line % pre + k * pre
+    u64 pre, len, post;
+};
+
+std::vector<size_t> matrix_shape(const std::vector<size_t>& s) {
+    if (s.empty()) return {1, 1};
+    if (s.size() == 1) return {s[0], 1};
+    return s;
+}
+
+__device__ __forceinline__ double quiet_nan() { return __longlong_as_double(0x7ff8000000000000ll); }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// cummin / cummax
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct Ext {
+    double v;
+    u32 pos;   // 1-based position along the dimension
+    int kind;  // 0 nothing yet, 1 a number, 2 fixed at a NaN (include mode)
+};
+
+template <bool MAX>
+__device__ __forceinline__ Ext ext_combine(const Ext& l, const Ext& r) {  // l covers the earlier part of the scan
+    if (l.kind == 2 || r.kind == 0) return l;
+    if (l.kind == 0 || r.kind == 2) return r;
+    return (MAX ? r.v > l.v : r.v < l.v) ? r : l;  // strict: the first occurrence keeps a tie
+}
+__device__ __forceinline__ Ext ext_of(double x, u32 pos, int omit) {
+    Ext e;
+    e.v = x;
+    e.pos = pos;
+    e.kind = (x != x) ? (omit ? 0 : 2) : 1;
+    return e;
+}
+__device__ __forceinline__ void ext_store(const Ext& e, double* v, double* idx) {
+    __builtin_nontemporal_store(e.kind == 1 ? e.v : quiet_nan(), v);
+    __builtin_nontemporal_store(e.kind == 0 ? quiet_nan() : (double)e.pos, idx);
+}
+__device__ __forceinline__ Ext ext_shfl(const Ext& e, int src_lane) {
+    Ext o;
+    o.v = __shfl(e.v, src_lane);
+    o.pos = __shfl(e.pos, src_lane);
+    o.kind = __shfl(e.kind, src_lane);
+    return o;
+}
+__device__ __forceinline__ Ext ext_shfl_up(const Ext& e, int d) {
+    Ext o;
+    o.v = __shfl_up(e.v, d);
+    o.pos = __shfl_up(e.pos, d);
+    o.kind = __shfl_up(e.kind, d);
+    return o;
+}
+
+struct ExtSum {  // chunk summaries / carries
+    double* v;
+    u32* pos;
+    int* kind;
+};
+
+// pre == 1: one wave per (line, chunk); MODE 0 = summary of the chunk only, 1 = scan from the carry and write.  WE rows of 64
+// consecutive elements per trip: loaded together (every access a contiguous 512 bytes of the line), scanned by WE independent shuffle
+// chains, their totals combined in order.  Inside the wave the state is ONE ordered 64-bit key and the position: the value's bits
+// mapped monotonically (inverted for max, both zeros on one key), 0 = "fixed at a NaN" (beats everything, the earlier one on a tie)
+// and ~0 = "nothing yet" (loses to everything) - combine is `right key < left key ? right : left`, three shuffles per step.
+constexpr int WE = 4;
+constexpr u64 KEY_ZERO = 0x8000000000000000ull;
+template <bool MAX>
+__device__ __forceinline__ u64 ext_key(double x, int omit) {
+    if (x != x) return omit ? ~0ull : 0ull;
+    if (x == 0.0) x = 0.0;
+    const u64 u = (u64)__double_as_longlong(x);
+    const u64 b = (u >> 63) ? ~u : (u | KEY_ZERO);
+    return MAX ? ~b : b;
+}
+template <bool MAX>
+__device__ __forceinline__ u64 ext_key_of(const Ext& e) { return e.kind == 0 ? ~0ull : (e.kind == 2 ? 0ull : ext_key<MAX>(e.v, 0)); }
+template <bool MAX>
+__device__ __forceinline__ Ext ext_from_key(u64 key, u32 pos, const double* line_data) {
+    Ext e;
+    e.pos = pos;
+    e.kind = key == 0ull ? 2 : (key == ~0ull ? 0 : 1);
+    const u64 b = MAX ? ~key : key;
+    e.v = 0.0;
+    if (e.kind == 1) e.v = b == KEY_ZERO ? line_data[pos - 1] : __longlong_as_double((long long)((b >> 63) ? (b & ~KEY_ZERO) : ~b));  // a zero: its own sign
+    return e;
+}
+template <bool MAX, int MODE>
+__global__ void __launch_bounds__(256) k_cumext_wave(const double* __restrict__ x, double* __restrict__ vals, double* __restrict__ idxs, u64 len,
+                                                     u64 nlines, u64 chunk_len, u64 nchunks, int reverse, int omit, ExtSum sum) {
+    const u64 w = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= nlines * nchunks) return;
+    const u64 line = w / nchunks, ch = w % nchunks;
+    const u64 s0 = ch * chunk_len, s1 = (s0 + chunk_len < len) ? s0 + chunk_len : len;
+    const double* xs = x + line * len;
+    u64 ckey = ~0ull;
+    u32 cpos = 0;
+    if (MODE == 1 && nchunks > 1) {
+        Ext c0;
+        c0.v = sum.v[w];
+        c0.pos = sum.pos[w];
+        c0.kind = sum.kind[w];
+        ckey = ext_key_of<MAX>(c0);
+        cpos = c0.pos;
+    }
+    for (u64 s = s0; s < s1; s += 64 * WE) {
+        u64 key[WE];
+        u32 pos[WE];
+#pragma unroll
+        for (int u = 0; u < WE; ++u) {
+            const u64 me = s + (u64)u * 64 + lane;
+            const u64 k = reverse ? len - 1 - me : me;
+            key[u] = ~0ull;
+            pos[u] = 0;
+            if (me < s1) {
+                key[u] = ext_key<MAX>(__builtin_nontemporal_load(xs + k), omit);
+                pos[u] = (u32)(k + 1);
+            }
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+            for (int u = 0; u < WE; ++u) {
+                const u64 uk = __shfl_up(key[u], d);
+                const u32 up = __shfl_up(pos[u], d);
+                if (lane >= d && !(key[u] < uk)) {  // the earlier one unless the later is strictly better
+                    key[u] = uk;
+                    pos[u] = up;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < WE; ++u) {
+            const u64 me = s + (u64)u * 64 + lane;
+            const u64 k = reverse ? len - 1 - me : me;
+            if (!(key[u] < ckey)) {
+                key[u] = ckey;
+                pos[u] = cpos;
+            }
+            if (MODE == 1 && me < s1) ext_store(ext_from_key<MAX>(key[u], pos[u], xs), vals + line * len + k, idxs + line * len + k);
+            ckey = __shfl(key[u], 63);
+            cpos = __shfl(pos[u], 63);
+        }
+    }
+    if (MODE == 0 && lane == 0) {
+        const Ext e = ext_from_key<MAX>(ckey, cpos, xs);
+        sum.v[w] = e.v;
+        sum.pos[w] = e.pos;
+        sum.kind[w] = e.kind;
+    }
+}
+
+// pre > 1: one thread per (line, chunk), consecutive threads on consecutive lines of the same `after` block: coalesced across the lines
+template <bool MAX, int MODE>
+__global__ void __launch_bounds__(256) k_cumext_thread(const double* __restrict__ x, double* __restrict__ vals, double* __restrict__ idxs, Lines g,
+                                                       u64 chunk_len, u64 nchunks, int reverse, int omit, ExtSum sum) {
+    const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 nlines = g.pre * g.post;
+    if (t >= nlines * nchunks) return;
+    const u64 line = t % nlines, ch = t / nlines;  // (chunk-major: the threads of a wave share their chunk)
+    const u64 base = (line / g.pre) * g.pre * g.len + line % g.pre;
+    const u64 s0 = ch * chunk_len, s1 = (s0 + chunk_len < g.len) ? s0 + chunk_len : g.len;
+    const u64 slot = line * nchunks + ch;
+    Ext run;
+    run.v = 0.0;
+    run.pos = 0;
+    run.kind = 0;
+    if (MODE == 1 && nchunks > 1) {
+        run.v = sum.v[slot];
+        run.pos = sum.pos[slot];
+        run.kind = sum.kind[slot];
+    }
+    constexpr int TU = 8;  // loads of TU steps in flight before the dependent chain consumes them
+    for (u64 s = s0; s < s1; s += TU) {
+        double v[TU];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const u64 sc = s + u < s1 ? s + u : s1 - 1;
+            const u64 k = reverse ? g.len - 1 - sc : sc;
+            v[u] = __builtin_nontemporal_load(x + base + k * g.pre);
+        }
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            if (s + u < s1) {
+                const u64 k = reverse ? g.len - 1 - (s + u) : s + u;
+                const u64 at = base + k * g.pre;
+                run = ext_combine<MAX>(run, ext_of(v[u], (u32)(k + 1), omit));
+                if (MODE == 1) ext_store(run, vals + at, idxs + at);
+            }
+        }
+    }
+    if (MODE == 0) {
+        sum.v[slot] = run.v;
+        sum.pos[slot] = run.pos;
+        sum.kind[slot] = run.kind;
+    }
+}
+
+// summaries[line][chunk] -> what is carried INTO the chunk.  One block per line: thread t owns a run of consecutive chunks, the runs'
+// totals are scanned across the block in LDS, then every thread walks its run again from what precedes it.
+template <bool MAX>
+__global__ void __launch_bounds__(256) k_cumext_carries(ExtSum sum, u64 nlines, u64 nchunks) {
+    __shared__ double sv[256];
+    __shared__ u32 sp[256];
+    __shared__ int sk[256];
+    const u64 line = blockIdx.x;
+    const int t = threadIdx.x;
+    const u64 per = (nchunks + 255) / 256;
+    const u64 c0 = (u64)t * per, c1 = (c0 + per < nchunks) ? c0 + per : nchunks;
+    Ext run;
+    run.v = 0.0;
+    run.pos = 0;
+    run.kind = 0;
+    for (u64 ch = c0; ch < c1; ++ch) {
+        const u64 slot = line * nchunks + ch;
+        Ext e;
+        e.v = sum.v[slot];
+        e.pos = sum.pos[slot];
+        e.kind = sum.kind[slot];
+        run = ext_combine<MAX>(run, e);
+    }
+    sv[t] = run.v;
+    sp[t] = run.pos;
+    sk[t] = run.kind;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {  // inclusive scan of the run totals
+        Ext up, me;
+        me.v = sv[t];
+        me.pos = sp[t];
+        me.kind = sk[t];
+        if (t >= d) {
+            up.v = sv[t - d];
+            up.pos = sp[t - d];
+            up.kind = sk[t - d];
+            me = ext_combine<MAX>(up, me);
+        }
+        __syncthreads();
+        sv[t] = me.v;
+        sp[t] = me.pos;
+        sk[t] = me.kind;
+        __syncthreads();
+    }
+    run.v = 0.0;
+    run.pos = 0;
+    run.kind = 0;
+    if (t > 0) {
+        run.v = sv[t - 1];
+        run.pos = sp[t - 1];
+        run.kind = sk[t - 1];
+    }
+    for (u64 ch = c0; ch < c1; ++ch) {
+        const u64 slot = line * nchunks + ch;
+        Ext e;
+        e.v = sum.v[slot];
+        e.pos = sum.pos[slot];
+        e.kind = sum.kind[slot];
+        sum.v[slot] = run.v;
+        sum.pos[slot] = run.pos;
+        sum.kind[slot] = run.kind;
+        run = ext_combine<MAX>(run, e);
+    }
+}
+
+template <bool MAX>
+int launch_cumextreme(Context* c, const double* x, Lines g, int reverse, int omit, double* vals, double* idxs) {
+    const u64 nlines = g.pre * g.post;
+    if (nlines == 0 || g.len == 0) return RMHIP_OK;
+    if (g.len >= 0xffffffffull) return fail(RMHIP_ERR_UNSUPPORTED, "cummin / cummax: a dimension of %llu elements", g.len);
+    const bool wave = g.pre == 1;
+    // enough independent pieces for the device (two waves per SIMD of threads, or eight waves per CU of wave-pieces), pieces of >= 256
+    const u64 want = wave ? (u64)c->num_cus * 8 : (u64)c->num_cus * 512;
+    u64 nchunks = 1;
+    if (nlines < want && g.len >= 512) {
+        nchunks = std::min<u64>((want + nlines - 1) / nlines, g.len / 256);
+        nchunks = std::min<u64>(nchunks, 8192);
+    }
+    u64 chunk_len = (g.len + nchunks - 1) / nchunks;
+    if (wave) chunk_len = (chunk_len + 64 * WE - 1) / (64 * WE) * (64 * WE);
+    nchunks = (g.len + chunk_len - 1) / chunk_len;
+    ExtSum sum{nullptr, nullptr, nullptr};
+    std::shared_ptr<Allocation> ws;
+    if (nchunks > 1) {
+        const u64 slots = nlines * nchunks;
+        RMHIP_TRY(c->alloc_device(slots * 2, &ws));  // v: slots doubles; pos + kind: slots * (4 + 4) bytes
+        sum.v = ws->ptr;
+        sum.pos = (u32*)(ws->ptr + slots);
+        sum.kind = (int*)(sum.pos + slots);
+    }
+    const u64 pieces = nlines * nchunks;
+    const unsigned grid = (unsigned)(wave ? (pieces + 3) / 4 : (pieces + 255) / 256);
+    if (nchunks > 1) {
+        if (wave) hipLaunchKernelGGL((k_cumext_wave<MAX, 0>), dim3(grid), dim3(256), 0, c->stream, x, vals, idxs, g.len, nlines, chunk_len, nchunks, reverse, omit, sum);
+        else hipLaunchKernelGGL((k_cumext_thread<MAX, 0>), dim3(grid), dim3(256), 0, c->stream, x, vals, idxs, g, chunk_len, nchunks, reverse, omit, sum);
+        hipLaunchKernelGGL(k_cumext_carries<MAX>, dim3((unsigned)nlines), dim3(256), 0, c->stream, sum, nlines, nchunks);
+        c->tel.kernel_launches += 2;
+    }
+    if (wave) hipLaunchKernelGGL((k_cumext_wave<MAX, 1>), dim3(grid), dim3(256), 0, c->stream, x, vals, idxs, g.len, nlines, chunk_len, nchunks, reverse, omit, sum);
+    else hipLaunchKernelGGL((k_cumext_thread<MAX, 1>), dim3(grid), dim3(256), 0, c->stream, x, vals, idxs, g, chunk_len, nchunks, reverse, omit, sum);
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// diff
+// ---------------------------------------------------------------------------------------------------------------------------------
+// one thread per output element, output order = memory order of the result: COLMAJ: (before, k, after); else the reference's (k, before, after)
+template <bool COLMAJ>
+__global__ void __launch_bounds__(256) k_diff(const double* __restrict__ x, double* __restrict__ y, Lines g, u64 total) {
+    const u64 o = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (o >= total) return;
+    const u64 m = g.len - 1;
+    u64 before, k, after;
+    if (COLMAJ) {
+        before = o % g.pre;
+        k = (o / g.pre) % m;
+        after = o / (g.pre * m);
+    } else {
+        k = o % m;
+        before = (o / m) % g.pre;
+        after = o / (m * g.pre);
+    }
+    const u64 i0 = before + after * g.pre * g.len + k * g.pre;
+    __builtin_nontemporal_store(x[i0 + g.pre] - x[i0], y + o);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// sort / median
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int SORT_C = 2048;       // elements sorted inside one workgroup's LDS
+constexpr int SORT_THREADS = 512;  // two compare-exchanges per thread and step
+
+__device__ __forceinline__ u64 sort_key(double x, int descend, int by_abs) {
+    if (x != x) return descend ? 0ull : ~0ull;  // NaNs last ascending, first descending (sort.rs:538-551)
+    u64 b;
+    if (by_abs) {  // |x| first, then x itself (sort.rs:553-574): the sign bit of a nonzero x as the lowest key bit, both zeros alike
+        b = ((u64)__double_as_longlong(fabs(x)) << 1) | (x > 0.0 ? 1ull : 0ull);
+    } else {
+        if (x == 0.0) x = 0.0;  // -0 == +0 under partial_cmp
+        const u64 u = (u64)__double_as_longlong(x);
+        b = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+    }
+    return descend ? ~b : b;
+}
+
+// workspace[line][i], i < lp: keys + positions of the line's elements, max-key padding beyond len (and beyond the last line)
+__global__ void __launch_bounds__(256) k_sort_keys(const double* __restrict__ x, u64* __restrict__ keys, u32* __restrict__ pos, Lines g, u64 lp, u64 ws_total,
+                                                   int descend, int by_abs, int before_fastest) {
+    const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ws_total) return;
+    const u64 nlines = g.pre * g.post;
+    u64 line, i;
+    if (before_fastest && t < nlines * lp) {  // strided lines: consecutive threads read consecutive lines (coalesced reads, scattered writes)
+        const u64 blk = t / (g.pre * lp), r = t % (g.pre * lp);
+        line = blk * g.pre + r % g.pre;
+        i = r / g.pre;
+    } else {
+        line = t / lp;
+        i = t % lp;
+    }
+    u64 key = ~0ull;
+    u32 p = 0xffffffffu;
+    if (line < nlines && i < g.len) {
+        key = sort_key(x[(line / g.pre) * g.pre * g.len + line % g.pre + i * g.pre], descend, by_abs);
+        p = (u32)i;
+    }
+    keys[line * lp + i] = key;
+    pos[line * lp + i] = p;
+}
+
+__device__ __forceinline__ bool pair_after(u64 ka, u32 pa, u64 kb, u32 pb) { return ka > kb || (ka == kb && pa > pb); }
+
+// FULL: every step of the network with k <= min(SORT_C, lp); else the steps j = SORT_C / 2 ... 1 of the given k (> SORT_C)
+template <bool FULL>
+__global__ void __launch_bounds__(SORT_THREADS) k_bitonic_local(u64* __restrict__ keys, u32* __restrict__ pos, u64 lp, u64 kk) {
+    __shared__ u64 sk[SORT_C];
+    __shared__ u32 sp[SORT_C];
+    const u64 g0 = (u64)blockIdx.x * SORT_C;
+    for (int i = threadIdx.x; i < SORT_C; i += SORT_THREADS) {
+        sk[i] = keys[g0 + i];
+        sp[i] = pos[g0 + i];
+    }
+    __syncthreads();
+    const u64 kmax = FULL ? (lp < (u64)SORT_C ? lp : (u64)SORT_C) : kk;
+    for (u64 k = FULL ? 2 : kk; k <= kmax; k <<= 1) {
+        for (u32 j = (u32)((FULL ? k : (u64)SORT_C) >> 1); j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < SORT_C / 2; t += SORT_THREADS) {
+                const u32 i = ((t / j) * 2 * j) + (t % j), l = i + j;
+                const bool asc = (((g0 + i) & (lp - 1)) & k) == 0;  // the position INSIDE the line decides the direction
+                const u64 ki = sk[i], kl = sk[l];
+                const u32 pi = sp[i], pl = sp[l];
+                if (pair_after(ki, pi, kl, pl) == asc) {
+                    sk[i] = kl;
+                    sk[l] = ki;
+                    sp[i] = pl;
+                    sp[l] = pi;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < SORT_C; i += SORT_THREADS) {
+        keys[g0 + i] = sk[i];
+        pos[g0 + i] = sp[i];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bitonic_global(u64* __restrict__ keys, u32* __restrict__ pos, u64 lp, u64 k, u64 j, u64 half_total) {
+    const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= half_total) return;
+    const u64 i = (t / j) * 2 * j + (t % j), l = i + j;
+    const bool asc = ((i & (lp - 1)) & k) == 0;
+    const u64 ki = keys[i], kl = keys[l];
+    const u32 pi = pos[i], pl = pos[l];
+    if (pair_after(ki, pi, kl, pl) == asc) {
+        keys[i] = kl;
+        keys[l] = ki;
+        pos[i] = pl;
+        pos[l] = pi;
+    }
+}
+
+// sorted[line][r] = x[line][pos[r]], indices = pos + 1 (output in the operand's layout)
+__global__ void __launch_bounds__(256) k_sort_emit(const double* __restrict__ x, const u32* __restrict__ pos, Lines g, u64 lp, double* __restrict__ sorted,
+                                                   double* __restrict__ indices, u64 total) {
+    const u64 o = (u64)blockIdx.x * 256 + threadIdx.x;  // output element in memory order
+    if (o >= total) return;
+    const u64 before = o % g.pre, r = (o / g.pre) % g.len, after = o / (g.pre * g.len);
+    const u64 line = after * g.pre + before;
+    const u32 p = pos[line * lp + r];
+    const u64 base = after * g.pre * g.len + before;
+    __builtin_nontemporal_store(x[base + (u64)p * g.pre], sorted + o);
+    __builtin_nontemporal_store((double)(p + 1), indices + o);
+}
+
+// median of every sorted line: NaN keys sort last, so one look at the last element tells whether the line held a NaN
+__global__ void __launch_bounds__(256) k_median_emit(const double* __restrict__ x, const u64* __restrict__ keys, const u32* __restrict__ pos, Lines g, u64 lp,
+                                                     double* __restrict__ out) {
+    const u64 line = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (line >= g.pre * g.post) return;
+    const u64 base = (line / g.pre) * g.pre * g.len + line % g.pre;
+    double m = quiet_nan();
+    if (g.len > 0 && keys[line * lp + g.len - 1] != ~0ull) {
+        const double hi = x[base + (u64)pos[line * lp + g.len / 2] * g.pre];
+        if (g.len & 1) m = hi;
+        else m = 0.5 * (x[base + (u64)pos[line * lp + g.len / 2 - 1] * g.pre] + hi);  // median.rs:733-737
+    }
+    out[line] = m;
+}
+
+struct SortSpace {
+    std::shared_ptr<Allocation> mem;
+    u64* keys = nullptr;
+    u32* pos = nullptr;
+    u64 lp = 0, total = 0;
+};
+
+// keys + positions of every line, sorted
+int sort_lines(Context* c, const double* x, Lines g, int descend, int by_abs, SortSpace* ws) {
+    const u64 nlines = g.pre * g.post;
+    if (g.len >= 0x7fffffffull) return fail(RMHIP_ERR_UNSUPPORTED, "sort: a dimension of %llu elements", g.len);
+    u64 lp = 2;
+    while (lp < g.len) lp <<= 1;
+    u64 total = nlines * lp;
+    total = (total + SORT_C - 1) / SORT_C * SORT_C;
+    if (total / lp > 0x7fffffffull || total > (1ull << 40)) return fail(RMHIP_ERR_UNSUPPORTED, "sort: workspace of %llu pairs", total);
+    RMHIP_TRY(c->alloc_device(total + (total + 1) / 2, &ws->mem));  // 8 + 4 bytes per pair
+    ws->keys = (u64*)ws->mem->ptr;
+    ws->pos = (u32*)(ws->mem->ptr + total);
+    ws->lp = lp;
+    ws->total = total;
+    hipLaunchKernelGGL(k_sort_keys, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, x, ws->keys, ws->pos, g, lp, total, descend, by_abs,
+                       g.pre > 1 ? 1 : 0);
+    hipLaunchKernelGGL(k_bitonic_local<true>, dim3((unsigned)(total / SORT_C)), dim3(SORT_THREADS), 0, c->stream, ws->keys, ws->pos, lp, (u64)0);
+    c->tel.kernel_launches += 2;
+    for (u64 k = 2 * (u64)SORT_C; k <= lp; k <<= 1) {
+        for (u64 j = k >> 1; j >= (u64)SORT_C; j >>= 1) {
+            hipLaunchKernelGGL(k_bitonic_global, dim3((unsigned)((total / 2 + 255) / 256)), dim3(256), 0, c->stream, ws->keys, ws->pos, lp, k, j, total / 2);
+            c->tel.kernel_launches++;
+        }
+        hipLaunchKernelGGL(k_bitonic_local<false>, dim3((unsigned)(total / SORT_C)), dim3(SORT_THREADS), 0, c->stream, ws->keys, ws->pos, lp, k);
+        c->tel.kernel_launches++;
+    }
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+
+int lines_of(const std::vector<size_t>& shape, int dim, const char* what, Lines* g) {
+    if (dim < 0 || (size_t)dim >= shape.size()) return fail(RMHIP_ERR_UNSUPPORTED, "%s: dim %d out of range for rank %zu", what, dim, shape.size());
+    g->pre = g->post = 1;
+    for (int d = 0; d < dim; ++d) g->pre *= shape[d];
+    for (size_t d = dim + 1; d < shape.size(); ++d) g->post *= shape[d];
+    g->len = shape[dim];
+    return RMHIP_OK;
+}
+
+}  // namespace
+}  // namespace rmhip
+
+int rmhip_cumextreme(rmhip_ctx* ctx, int is_max, rmhip_buf a, int dim, int reverse, int nan_mode, rmhip_buf* values, rmhip_buf* indices) {
+    CTX_OR_FAIL(ctx);
+    if (!values || !indices) return fail(RMHIP_ERR_INVALID, "cumextreme: null output");
+    *values = *indices = 0;
+    Buffer ab, vb, ib;
+    RMHIP_TRY(c->get(a, &ab));
+    const std::vector<size_t> shape = matrix_shape(ab.shape);
+    Lines g;
+    RMHIP_TRY(lines_of(shape, dim, "cummin / cummax", &g));
+    RMHIP_TRY(c->new_buffer(shape.data(), shape.size(), values, &vb));
+    int rc = c->new_buffer(shape.data(), shape.size(), indices, &ib);
+    if (rc == RMHIP_OK && ab.numel > 0)
+        rc = is_max ? launch_cumextreme<true>(c, ab.data(), g, reverse ? 1 : 0, nan_mode ? 1 : 0, vb.data(), ib.data())
+                    : launch_cumextreme<false>(c, ab.data(), g, reverse ? 1 : 0, nan_mode ? 1 : 0, vb.data(), ib.data());
+    if (rc) {
+        rmhip_free(ctx, *values);
+        if (*indices) rmhip_free(ctx, *indices);
+    }
+    return rc;
+}
+
+int rmhip_diff_dim(rmhip_ctx* ctx, rmhip_buf a, size_t order, int dim, int column_major, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    if (dim < 0) return fail(RMHIP_ERR_INVALID, "diff_dim: dim must be >= 0");
+    Buffer cur;
+    RMHIP_TRY(c->get(a, &cur));
+    std::vector<size_t> shape = cur.shape;  // diff_tensor_once: the shape is extended with ones up to the dimension (diff.rs:479-481)
+    while (shape.size() <= (size_t)dim) shape.push_back(1);
+    if (order == 0) {  // simple_provider.rs:6480-6482: the operand itself
+        Buffer ob;
+        RMHIP_TRY(c->new_buffer(cur.shape.data(), cur.shape.size(), out, &ob));
+        if (cur.numel) RMHIP_HIP_CHECK(hipMemcpyAsync(ob.data(), cur.data(), cur.numel * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        return RMHIP_OK;
+    }
+    rmhip_buf cur_id = 0;
+    for (size_t pass = 0; pass < order; ++pass) {
+        Lines g;
+        RMHIP_TRY(lines_of(shape, dim, "diff_dim", &g));
+        std::vector<size_t> oshape = shape;
+        oshape[dim] = g.len > 0 ? g.len - 1 : 0;
+        rmhip_buf next = 0;
+        Buffer nb;
+        const int rc = c->new_buffer(oshape.data(), oshape.size(), &next, &nb);
+        if (rc == RMHIP_OK && nb.numel > 0) {
+            if (column_major || g.pre == 1) hipLaunchKernelGGL(k_diff<true>, dim3((unsigned)((nb.numel + 255) / 256)), dim3(256), 0, c->stream, cur.data(), nb.data(), g, (u64)nb.numel);
+            else hipLaunchKernelGGL(k_diff<false>, dim3((unsigned)((nb.numel + 255) / 256)), dim3(256), 0, c->stream, cur.data(), nb.data(), g, (u64)nb.numel);
+            c->tel.kernel_launches++;
+        }
+        if (cur_id) rmhip_free(ctx, cur_id);
+        if (rc) return rc;
+        cur_id = next;
+        cur = nb;
+        shape = oshape;
+        if (nb.numel == 0) break;  // diff_tensor_host stops at the first empty result (diff.rs:444-446)
+    }
+    RMHIP_HIP_CHECK(hipGetLastError());
+    *out = cur_id;
+    return RMHIP_OK;
+}
+
+int rmhip_sort_dim(rmhip_ctx* ctx, rmhip_buf a, int dim, int descend, int by_abs, rmhip_buf* sorted, rmhip_buf* indices) {
+    CTX_OR_FAIL(ctx);
+    if (!sorted || !indices) return fail(RMHIP_ERR_INVALID, "sort_dim: null output");
+    if (dim < 0) return fail(RMHIP_ERR_INVALID, "sort_dim: dim must be >= 0");
+    *sorted = *indices = 0;
+    Buffer ab, sb, ib;
+    RMHIP_TRY(c->get(a, &ab));
+    const std::vector<size_t> shape = matrix_shape(ab.shape);
+    Lines g{ab.numel, 1, 1};  // a dimension beyond the rank: lines of one element (sort.rs:428-437: values unchanged, indices all one)
+    if ((size_t)dim < shape.size()) RMHIP_TRY(lines_of(shape, dim, "sort_dim", &g));
+    RMHIP_TRY(c->new_buffer(shape.data(), shape.size(), sorted, &sb));
+    int rc = c->new_buffer(shape.data(), shape.size(), indices, &ib);
+    if (rc == RMHIP_OK && ab.numel > 0 && g.len <= 1) {  // sort.rs:428-437: nothing to order - the values themselves, every index one
+        RMHIP_HIP_CHECK(hipMemcpyAsync(sb.data(), ab.data(), ab.numel * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        rc = launch_fill(c, ib.data(), ib.numel, 1.0);
+    } else if (rc == RMHIP_OK && ab.numel > 0) {
+        SortSpace ws;
+        rc = sort_lines(c, ab.data(), g, descend ? 1 : 0, by_abs ? 1 : 0, &ws);
+        if (rc == RMHIP_OK) {
+            hipLaunchKernelGGL(k_sort_emit, dim3((unsigned)((ab.numel + 255) / 256)), dim3(256), 0, c->stream, ab.data(), ws.pos, g, ws.lp, sb.data(), ib.data(), (u64)ab.numel);
+            c->tel.kernel_launches++;
+            if (hipGetLastError() != hipSuccess) rc = fail(RMHIP_ERR_HIP, "sort_dim: launch failed");
+        }
+    }
+    if (rc) {
+        rmhip_free(ctx, *sorted);
+        if (*indices) rmhip_free(ctx, *indices);
+    }
+    return rc;
+}
+
+int rmhip_reduce_median(rmhip_ctx* ctx, rmhip_buf a, int dim, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer ab, ob;
+    RMHIP_TRY(c->get(a, &ab));
+    const std::vector<size_t> shape = matrix_shape(ab.shape);
+    Lines g{1, ab.numel, 1};  // dim < 0: every element (reduce_median, simple_provider.rs:7167-7193) -> [1, 1]
+    std::vector<size_t> oshape{1, 1};
+    if (dim >= 0) {
+        RMHIP_TRY(lines_of(shape, dim, "reduce_median_dim", &g));
+        oshape = shape;
+        oshape[dim] = 1;
+    }
+    RMHIP_TRY(c->new_buffer(oshape.data(), oshape.size(), out, &ob));
+    if (ob.numel == 0) return RMHIP_OK;
+    int rc = RMHIP_OK;
+    if (g.len == 0) {  // empty slices: NaN (median.rs:668-672)
+        rc = launch_fill(c, ob.data(), ob.numel, std::numeric_limits<double>::quiet_NaN());
+    } else if (g.len == 1) {
+        RMHIP_HIP_CHECK(hipMemcpyAsync(ob.data(), ab.data(), ab.numel * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        SortSpace ws;
+        rc = sort_lines(c, ab.data(), g, 0, 0, &ws);
+        if (rc == RMHIP_OK) {
+            hipLaunchKernelGGL(k_median_emit, dim3((unsigned)((ob.numel + 255) / 256)), dim3(256), 0, c->stream, ab.data(), ws.keys, ws.pos, g, ws.lp, ob.data());
+            c->tel.kernel_launches++;
+            if (hipGetLastError() != hipSuccess) rc = fail(RMHIP_ERR_HIP, "reduce_median: launch failed");
+        }
+    }
+    if (rc) rmhip_free(ctx, *out);
+    return rc;
+}

@@ -72,6 +72,13 @@ class ReductionFlavor:
 
 
 @dataclass
+class SortResult:
+    """`SortResult` (lib.rs:1085-1088): host tensors."""
+    values: np.ndarray
+    indices: np.ndarray
+
+
+@dataclass
 class ReduceDimResult:
     """`ReduceDimResult` (lib.rs:513-517)."""
     values: "GpuTensorHandle"
@@ -527,6 +534,53 @@ class HipProvider:
     def cumprod_scan(self, a, dim: int, reverse: bool = False, omitnan: bool = False) -> GpuTensorHandle:
         """lib.rs:2908-2915; cumprod.rs:581-670."""
         return self._cumulative(1, a, dim, reverse, omitnan)
+
+    def _cumextreme(self, is_max: bool, a, dim: int, reverse: bool, omitnan: bool) -> "ReduceDimResult":
+        values, indices = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.rmhip_cumextreme(self._ctx, 1 if is_max else 0, self._id(a), int(dim), 1 if reverse else 0, 1 if omitnan else 0,
+                                               C.byref(values), C.byref(indices)))
+        return ReduceDimResult(self._handle(values.value), self._handle(indices.value))
+
+    def cummin_scan(self, a, dim: int, reverse: bool = False, omitnan: bool = False) -> "ReduceDimResult":
+        """lib.rs:2918-2926 -> `ProviderCumminResult{values, indices}` (:520-523); zero-based dim < rank; cummin.rs:719-876."""
+        return self._cumextreme(False, a, dim, reverse, omitnan)
+
+    def cummax_scan(self, a, dim: int, reverse: bool = False, omitnan: bool = False) -> "ReduceDimResult":
+        """lib.rs:2927-2935; cummax.rs (the mirror image of cummin.rs)."""
+        return self._cumextreme(True, a, dim, reverse, omitnan)
+
+    def diff_dim(self, a, order: int, dim: int, column_major: bool = False) -> GpuTensorHandle:
+        """lib.rs:2596-2603: `order` first differences along zero-based dim, in the reference's output order (k fastest inside every
+        line, diff.rs:493-503) unless column_major; the handle carries the shape diff_tensor_host reports."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_diff_dim(self._ctx, self._id(a), int(order), int(dim), 1 if column_major else 0, C.byref(out)))
+        return self._handle(out.value)
+
+    def sort_dim(self, a, dim: int, order: str = "ascend", comparison: str = "auto") -> "SortResult":
+        """lib.rs:2358-2366 -> `SortResult{values, indices}` with HOST tensors (:1085-1088): stable sort of every line along zero-based dim
+        (`SortOrder::{Ascend, Descend}`, `SortComparison::{Auto, Real, Abs}`); indices are 1-based original positions."""
+        if order not in ("ascend", "descend") or comparison not in ("auto", "real", "abs"):
+            raise RmhipError(1, f"sort_dim: order {order!r} / comparison {comparison!r}")
+        sv, si = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.rmhip_sort_dim(self._ctx, self._id(a), int(dim), 1 if order == "descend" else 0, 1 if comparison == "abs" else 0,
+                                             C.byref(sv), C.byref(si)))
+        hv, hi = self._handle(sv.value), self._handle(si.value)
+        try:
+            return SortResult(self.download_matrix(hv), self.download_matrix(hi))
+        finally:
+            self.free(hv)
+            self.free(hi)
+
+    def reduce_median(self, a) -> GpuTensorHandle:
+        """lib.rs:2833-2838: the median of ALL elements -> [1, 1] (NaN if any element is NaN; simple_provider.rs:7167-7193)."""
+        return self.reduce_median_dim(a, -1)
+
+    def reduce_median_dim(self, a, dim: int) -> GpuTensorHandle:
+        """lib.rs:2839-2845: include-NaN median along zero-based dim (median.rs:644-741)."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_reduce_median(self._ctx, self._id(a), int(dim), C.byref(out)))
+        return self._handle(out.value)
+
     def reduce_prod(self, a): return self._reduce("prod", a, -1)
     def reduce_prod_dim(self, a, dim): return self._reduce("prod", a, dim)
 

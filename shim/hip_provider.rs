@@ -16,9 +16,9 @@ use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, GpuTensorHandle,
     HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, KernelAttrTelemetry, KernelLaunchTelemetry, MatmulEpilogue,
-    PowerStepEpilogue, ProviderDispatchStats, ProviderFallbackStat, ProviderLinsolveOptions, ProviderLinsolveResult, ProviderLuResult,
-    ProviderMoments2, ProviderNanMode, ProviderPrecision, ProviderScanDirection, ProviderStdNormalization, ProviderTelemetry,
-    ReduceDimResult, ReductionFlavor, ScaleOp,
+    PowerStepEpilogue, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderFallbackStat, ProviderLinsolveOptions,
+    ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderNanMode, ProviderPrecision, ProviderScanDirection,
+    ProviderStdNormalization, ProviderTelemetry, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult,
 };
 use std::ffi::{c_char, c_int, c_void, CStr, CString};
 
@@ -313,6 +313,57 @@ impl AccelProvider for HipProvider {
         let nan = matches!(nan_mode, ProviderNanMode::Omit) as c_int;
         check(unsafe { rmhip_cumulative(self.ctx, 1, self.own(input)?, dim as c_int, rev, nan, &mut out) })?;
         self.handle(out)
+    }
+    // cummin_scan / cummax_scan -> ProviderCumminResult { values, indices } (lib.rs:2918-2935; ProviderCummaxResult is its alias)
+    fn cummin_scan(&self, input: &GpuTensorHandle, dim: usize, direction: ProviderScanDirection, nan_mode: ProviderNanMode) -> Result<ProviderCumminResult> {
+        let (mut v, mut i) = (0u64, 0u64);
+        let rev = matches!(direction, ProviderScanDirection::Reverse) as c_int;
+        let nan = matches!(nan_mode, ProviderNanMode::Omit) as c_int;
+        check(unsafe { rmhip_cumextreme(self.ctx, 0, self.own(input)?, dim as c_int, rev, nan, &mut v, &mut i) })?;
+        Ok(ProviderCumminResult { values: self.handle(v)?, indices: self.handle(i)? })
+    }
+    fn cummax_scan(&self, input: &GpuTensorHandle, dim: usize, direction: ProviderScanDirection, nan_mode: ProviderNanMode) -> Result<ProviderCummaxResult> {
+        let (mut v, mut i) = (0u64, 0u64);
+        let rev = matches!(direction, ProviderScanDirection::Reverse) as c_int;
+        let nan = matches!(nan_mode, ProviderNanMode::Omit) as c_int;
+        check(unsafe { rmhip_cumextreme(self.ctx, 1, self.own(input)?, dim as c_int, rev, nan, &mut v, &mut i) })?;
+        Ok(ProviderCummaxResult { values: self.handle(v)?, indices: self.handle(i)? })
+    }
+    // diff_dim (lib.rs:2596-2603): the reference's own output order (column_major = 0), the shape diff_tensor_host reports
+    fn diff_dim(&self, handle: &GpuTensorHandle, order: usize, dim: usize) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_diff_dim(self.ctx, self.own(handle)?, order, dim as c_int, 0, &mut out) })?;
+        self.handle(out)
+    }
+    // sort_dim -> SortResult with HOST tensors (lib.rs:2358-2366, 1085-1088): both device results are downloaded and freed
+    fn sort_dim<'a>(&'a self, a: &'a GpuTensorHandle, dim: usize, order: SortOrder, comparison: SortComparison) -> AccelProviderFuture<'a, SortResult> {
+        Box::pin(async move {
+            let (mut v, mut i) = (0u64, 0u64);
+            let desc = matches!(order, SortOrder::Descend) as c_int;
+            let abs = matches!(comparison, SortComparison::Abs) as c_int;
+            check(unsafe { rmhip_sort_dim(self.ctx, self.own(a)?, dim as c_int, desc, abs, &mut v, &mut i) })?;
+            let (hv, hi) = (self.handle(v)?, self.handle(i)?);
+            let values = self.download(&hv).await;
+            let indices = self.download(&hi).await;
+            self.free(&hv)?;
+            self.free(&hi)?;
+            Ok(SortResult { values: values?, indices: indices? })
+        })
+    }
+    // reduce_median: every element as one line; reduce_median_dim: include-NaN median along the zero-based dim (lib.rs:2833-2845)
+    fn reduce_median<'a>(&'a self, a: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_reduce_median(self.ctx, self.own(a)?, -1, &mut out) })?;
+            self.handle(out)
+        })
+    }
+    fn reduce_median_dim<'a>(&'a self, a: &'a GpuTensorHandle, dim: usize) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_reduce_median(self.ctx, self.own(a)?, dim as c_int, &mut out) })?;
+            self.handle(out)
+        })
     }
     fn reduce_mean_nd<'a>(&'a self, a: &'a GpuTensorHandle, dims_zero_based: &'a [usize]) -> AccelProviderFuture<'a, GpuTensorHandle> {
         Box::pin(async move {
