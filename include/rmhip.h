@@ -599,12 +599,29 @@ RMHIP_API int rmhip_get_rng_state(rmhip_ctx* ctx, uint64_t* state);
 RMHIP_API int rmhip_rng_seed(rmhip_ctx* ctx, uint64_t seed);
 /* `random_uniform` / `random_normal`: CPU-parity stream (64-bit LCG + Box-Muller pairs,
  * random.rs:271-288,530-543); the state advances exactly as the CPU generator's does. */
-/* @serves random_uniform */
+/* @serves random_uniform random_uniform_like */
 RMHIP_API int rmhip_random_uniform(rmhip_ctx* ctx, const size_t* shape, size_t rank,
                                    rmhip_buf* out);
-/* @serves random_normal */
+/* @serves random_normal random_normal_like */
 RMHIP_API int rmhip_random_normal(rmhip_ctx* ctx, const size_t* shape, size_t rank,
                                   rmhip_buf* out);
+/* Scaled / transformed draws of the same stream (lib.rs:1732-1757, 1820-1839; CPU forms random.rs:290-320, 514-528; the in-process
+ * provider simple_provider.rs:3560-3626, 3683-3725), one draw per element in column-major order:
+ *   unifrnd:        a + (b - a) * u, the difference rounded once, then one multiply and one add (bit-exact)
+ *   exponential:    -mu * ln(max(u, f64::MIN_POSITIVE))   (the logarithm within 2 ulp of the exact value; against the CPU's libm chain 8e-16 relative)
+ *   normrnd:        mu + sigma * z over whole Box-Muller pairs, the stream of rmhip_random_normal (an odd count drops the last z1)
+ *   integer_range:  lower + min(floor(u * span), span - 1), span = upper - lower + 1 (bit-exact); lower > upper or span > 2^53 is
+ *                   RMHIP_ERR_INVALID; span == 1 fills `lower` and consumes no draws.
+ * The state advances by the draws consumed, exactly as the CPU generator's. */
+/* @serves random_unifrnd */
+RMHIP_API int rmhip_random_unifrnd(rmhip_ctx* ctx, double a, double b, const size_t* shape, size_t rank, rmhip_buf* out);
+/* @serves random_exponential */
+RMHIP_API int rmhip_random_exponential(rmhip_ctx* ctx, double mu, const size_t* shape, size_t rank, rmhip_buf* out);
+/* @serves random_normrnd */
+RMHIP_API int rmhip_random_normrnd(rmhip_ctx* ctx, double mu, double sigma, const size_t* shape, size_t rank, rmhip_buf* out);
+/* @serves random_integer_range random_integer_like */
+RMHIP_API int rmhip_random_integer_range(rmhip_ctx* ctx, long long lower, long long upper, const size_t* shape, size_t rank,
+                                         rmhip_buf* out);
 /* `stochastic_evolution` (lib.rs:1759-1769; CPU loop builtins/stats/random/stochastic_evolution.rs:10-30):
  * `steps` times { z = randn(size(state)) from the shared stream; state .*= exp(drift + scale .* z) }, as one
  * kernel that keeps the state in registers.  Advances the RNG state exactly as the CPU loop does

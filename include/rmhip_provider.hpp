@@ -490,6 +490,32 @@ public:
         check(rmhip_random_normal(ctx_, shape.data(), shape.size(), &out));
         return make(out, shape);
     }
+    // lib.rs:1718-1757, 1820-1839: the prototype forms and the scaled / transformed draws of the same stream
+    GpuTensorHandle random_uniform_like(const GpuTensorHandle& prototype) const { return random_uniform(prototype.shape); }
+    GpuTensorHandle random_normal_like(const GpuTensorHandle& prototype) const { return random_normal(prototype.shape); }
+    GpuTensorHandle random_unifrnd(double a, double b, const std::vector<size_t>& shape) const {
+        uint64_t out = 0;
+        check(rmhip_random_unifrnd(ctx_, a, b, shape.data(), shape.size(), &out));
+        return make(out, shape);
+    }
+    GpuTensorHandle random_exponential(double mu, const std::vector<size_t>& shape) const {
+        uint64_t out = 0;
+        check(rmhip_random_exponential(ctx_, mu, shape.data(), shape.size(), &out));
+        return make(out, shape);
+    }
+    GpuTensorHandle random_normrnd(double mu, double sigma, const std::vector<size_t>& shape) const {
+        uint64_t out = 0;
+        check(rmhip_random_normrnd(ctx_, mu, sigma, shape.data(), shape.size(), &out));
+        return make(out, shape);
+    }
+    GpuTensorHandle random_integer_range(long long lower, long long upper, const std::vector<size_t>& shape) const {
+        uint64_t out = 0;
+        check(rmhip_random_integer_range(ctx_, lower, upper, shape.data(), shape.size(), &out));
+        return make(out, shape);
+    }
+    GpuTensorHandle random_integer_like(const GpuTensorHandle& prototype, long long lower, long long upper) const {
+        return random_integer_range(lower, upper, prototype.shape);
+    }
 
     // ---- multi-GPU collectives (include/rmhip.h "multi-GPU collectives"; one process per GPU, no trait counterpart) ----
     static std::array<unsigned char, RMHIP_COMM_ID_BYTES> comm_unique_id(bool rccl = true) {

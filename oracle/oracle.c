@@ -495,6 +495,54 @@ ORC_API void orc_rng_normal(uint64_t* state, size_t len, double* out) {
     }
 }
 
+/* generate_uniform_scaled (random.rs:514-528; simple_provider.rs:3607-3626): a + (b - a) * u, one draw per element */
+ORC_API void orc_rng_unifrnd(uint64_t* state, double a, double b, size_t len, double* out) {
+    for (size_t i = 0; i < len; ++i) out[i] = a + (b - a) * next_uniform_state(state);
+}
+
+/* generate_exponential (random.rs:290-300; simple_provider.rs:3560-3580): -mu * ln(max(u, MIN_POSITIVE)) */
+ORC_API void orc_rng_exponential(uint64_t* state, double mu, size_t len, double* out) {
+    for (size_t i = 0; i < len; ++i) {
+        double u = next_uniform_state(state);
+        if (!(u >= 2.2250738585072014e-308)) u = 2.2250738585072014e-308;
+        out[i] = -mu * log(u);
+    }
+}
+
+/* generate_normal_scaled (random.rs:302-320; simple_provider.rs:3582-3605): mu + sigma * z over whole Box-Muller pairs */
+ORC_API void orc_rng_normrnd(uint64_t* state, double mu, double sigma, size_t len, double* out) {
+    size_t n = 0;
+    while (n < len) {
+        double u1 = next_uniform_state(state);
+        if (u1 <= 0.0) u1 = 2.2250738585072014e-308;
+        double u2 = next_uniform_state(state);
+        double radius = sqrt(-2.0 * log(u1));
+        double angle = 2.0 * M_PI * u2;
+        out[n++] = mu + sigma * (radius * cos(angle));
+        if (n < len) out[n++] = mu + sigma * (radius * sin(angle));
+    }
+}
+
+/* random_integer_range (simple_provider.rs:3683-3725): lower + min(floor(u * span), span - 1), span = upper - lower + 1 <= 2^53;
+ * a span of one consumes no draws.  Returns 0, or 1 for a refused range (lower > upper, span > 2^53). */
+ORC_API int orc_rng_integer_range(uint64_t* state, long long lower, long long upper, size_t len, double* out) {
+    if (lower > upper) return 1;
+    const __int128 span128 = (__int128)upper - (__int128)lower + 1;
+    if (span128 > ((__int128)1 << 53)) return 1;
+    const uint64_t span = (uint64_t)span128;
+    if (span == 1) {
+        for (size_t i = 0; i < len; ++i) out[i] = (double)lower;
+        return 0;
+    }
+    const double span_f = (double)span;
+    for (size_t i = 0; i < len; ++i) {
+        uint64_t offset = (uint64_t)floor(next_uniform_state(state) * span_f);
+        if (offset >= span) offset = span - 1;
+        out[i] = (double)((__int128)lower + (__int128)offset);
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * LU -- crates/runmat-accelerate/src/host_lu.rs:19-119 (lu_factor_host)
  * Doolittle with partial pivoting on a row-major working copy; pivot = FIRST row with strictly

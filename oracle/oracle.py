@@ -212,6 +212,48 @@ def rng_normal(state: int, n: int):
     return out, int(s.value)
 
 
+def rng_unifrnd(state: int, a: float, b: float, n: int):
+    s = C.c_uint64(state)
+    out = np.empty(n, dtype=np.float64)
+    l = lib()
+    l.orc_rng_unifrnd.restype = None
+    l.orc_rng_unifrnd.argtypes = [C.POINTER(C.c_uint64), C.c_double, C.c_double, C.c_size_t, _DP]
+    l.orc_rng_unifrnd(C.byref(s), a, b, n, _p(out))
+    return out, int(s.value)
+
+
+def rng_exponential(state: int, mu: float, n: int):
+    s = C.c_uint64(state)
+    out = np.empty(n, dtype=np.float64)
+    l = lib()
+    l.orc_rng_exponential.restype = None
+    l.orc_rng_exponential.argtypes = [C.POINTER(C.c_uint64), C.c_double, C.c_size_t, _DP]
+    l.orc_rng_exponential(C.byref(s), mu, n, _p(out))
+    return out, int(s.value)
+
+
+def rng_normrnd(state: int, mu: float, sigma: float, n: int):
+    s = C.c_uint64(state)
+    out = np.empty(n, dtype=np.float64)
+    l = lib()
+    l.orc_rng_normrnd.restype = None
+    l.orc_rng_normrnd.argtypes = [C.POINTER(C.c_uint64), C.c_double, C.c_double, C.c_size_t, _DP]
+    l.orc_rng_normrnd(C.byref(s), mu, sigma, n, _p(out))
+    return out, int(s.value)
+
+
+def rng_integer_range(state: int, lower: int, upper: int, n: int):
+    """(values, state) or None when the reference refuses the range (simple_provider.rs:3689-3698)."""
+    s = C.c_uint64(state)
+    out = np.empty(n, dtype=np.float64)
+    l = lib()
+    l.orc_rng_integer_range.restype = C.c_int
+    l.orc_rng_integer_range.argtypes = [C.POINTER(C.c_uint64), C.c_longlong, C.c_longlong, C.c_size_t, _DP]
+    if l.orc_rng_integer_range(C.byref(s), lower, upper, n, _p(out)):
+        return None
+    return out, int(s.value)
+
+
 def lu(a: np.ndarray):
     a = np.asarray(a, dtype=np.float64)
     rows, cols = a.shape

@@ -328,6 +328,11 @@ int launch_dgemm_epilogue(Context* c, size_t m, size_t n, size_t k, const double
 // rng (rng.hip)
 int launch_rng_uniform(Context* c, uint64_t state, double* out, size_t n);
 int launch_rng_normal(Context* c, uint64_t state, double* out, size_t n);
+// scaled / transformed draws of the same stream (rng.hip): exactly one of out64 / out32 is set
+int launch_rng_unifrnd(Context* c, uint64_t state, double a, double b, double* out64, float* out32, size_t n);
+int launch_rng_exponential(Context* c, uint64_t state, double mu, double* out64, float* out32, size_t n);
+int launch_rng_normrnd(Context* c, uint64_t state, double mu, double sigma, double* out64, float* out32, size_t n);
+int launch_rng_integer_range(Context* c, uint64_t state, long long lower, unsigned long long span, double* out64, float* out32, size_t n);
 int launch_rng_uniform_f32(Context* c, uint64_t state, float* out, size_t n);
 int launch_rng_normal_f32(Context* c, uint64_t state, float* out, size_t n);
 int launch_stochastic_evolution_f32(Context* c, uint64_t state, const float* in, float* out, size_t n, double drift,

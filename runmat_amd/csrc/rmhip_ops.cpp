@@ -9,6 +9,7 @@
 #include <memory>
 #include <string>
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstring>
 
@@ -1740,6 +1741,66 @@ int rmhip_random_normal(rmhip_ctx* ctx, const size_t* shape, size_t rank, rmhip_
     }
     c->rng_state = lcg_advance(c->rng_state, 2 * ((ob.numel + 1) / 2));  // whole pairs are consumed
     return RMHIP_OK;
+}
+
+namespace {
+// one transformed draw per element (or whole Box-Muller pairs): allocate in the provider's storage type, launch, advance the stream
+int random_dist(rmhip_ctx* ctx, Context* c, const size_t* shape, size_t rank, rmhip_buf* out, bool pairs, bool consumes,
+                const std::function<int(double*, float*, size_t)>& launch) {
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer ob;
+    int rc;
+    if (c->precision == 32) {
+        RMHIP_TRY(c->new_buffer_f32(shape, rank, out, &ob));
+        rc = launch((double*)nullptr, ob.data_f32(), ob.numel);
+    } else {
+        RMHIP_TRY(c->new_buffer(shape, rank, out, &ob));
+        rc = launch(ob.data(), (float*)nullptr, ob.numel);
+    }
+    if (rc) {
+        rmhip_free(ctx, *out);
+        return rc;
+    }
+    if (consumes) c->rng_state = lcg_advance(c->rng_state, pairs ? 2 * ((ob.numel + 1) / 2) : ob.numel);
+    return RMHIP_OK;
+}
+}  // namespace
+
+int rmhip_random_unifrnd(rmhip_ctx* ctx, double a, double b, const size_t* shape, size_t rank, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    return random_dist(ctx, c, shape, rank, out, false, true,
+                       [&](double* o64, float* o32, size_t n) { return launch_rng_unifrnd(c, c->rng_state, a, b, o64, o32, n); });
+}
+
+int rmhip_random_exponential(rmhip_ctx* ctx, double mu, const size_t* shape, size_t rank, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    return random_dist(ctx, c, shape, rank, out, false, true,
+                       [&](double* o64, float* o32, size_t n) { return launch_rng_exponential(c, c->rng_state, mu, o64, o32, n); });
+}
+
+int rmhip_random_normrnd(rmhip_ctx* ctx, double mu, double sigma, const size_t* shape, size_t rank, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    return random_dist(ctx, c, shape, rank, out, true, true,
+                       [&](double* o64, float* o32, size_t n) { return launch_rng_normrnd(c, c->rng_state, mu, sigma, o64, o32, n); });
+}
+
+int rmhip_random_integer_range(rmhip_ctx* ctx, long long lower, long long upper, const size_t* shape, size_t rank, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    // simple_provider.rs:3689-3698: an empty range, or one of more than 2^53 values (not exactly representable), is an error
+    if (lower > upper) return fail(RMHIP_ERR_INVALID, "random_integer_range: lower bound must be <= upper bound");
+    const __int128 span128 = (__int128)upper - (__int128)lower + 1;
+    if (span128 > ((__int128)1 << 53)) return fail(RMHIP_ERR_INVALID, "random_integer_range: integer range exceeds 2^53 and cannot be represented exactly");
+    const unsigned long long span = (unsigned long long)span128;
+    if (span == 1) {  // one value: no draws are consumed (simple_provider.rs:3703-3704)
+        if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+        Buffer ob;
+        RMHIP_TRY(c->new_buffer(shape, rank, out, &ob));  // (narrowed on return at precision 32, as rmhip_fill)
+        const int rc = launch_fill(c, ob.data(), ob.numel, (double)lower);
+        if (rc) rmhip_free(ctx, *out);
+        return rc;
+    }
+    return random_dist(ctx, c, shape, rank, out, false, true,
+                       [&](double* o64, float* o32, size_t n) { return launch_rng_integer_range(c, c->rng_state, lower, span, o64, o32, n); });
 }
 
 int rmhip_stochastic_evolution(rmhip_ctx* ctx, rmhip_buf state, double drift, double scale, uint32_t steps, rmhip_buf* out) {

@@ -67,15 +67,30 @@ __device__ __forceinline__ double lcg_uniform(unsigned long long s) { return lcg
 // rand/randn(..., 'single') produce).
 // A thread follows the states it EMITS, not the ones before them: x_i -> x_(i + stride) is the same affine jump whatever the
 // starting point, so an element costs one 64-bit multiply (three quarter-rate 32-bit ones) instead of two.
-template <class T>
+// KIND 0: u; 1: a + (b - a) u with d = b - a rounded on the host as the CPU rounds it (random.rs:514-528); 3: lower + min(floor(u span),
+// span - 1) in integer arithmetic, converted once (simple_provider.rs:3707-3714)
+struct UniformXform {
+    double a, d;           // KIND 1
+    long long lower;       // KIND 3
+    unsigned long long span;
+};
+template <class T, int KIND>
 __global__ void __launch_bounds__(256) k_rng_uniform(unsigned long long state, T* __restrict__ out, size_t n,
-                                                     unsigned long long jm, unsigned long long jp) {
+                                                     unsigned long long jm, unsigned long long jp, UniformXform xf) {
     const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
     if (g >= n) return;
     unsigned long long x = lcg_skip2(state, 256ULL * blockIdx.x, threadIdx.x + 1ULL);  // the state element g is drawn from
     for (size_t i = g; i < n; i += stride) {
-        out[i] = (T)lcg_uniform(x);
+        const double u = lcg_uniform(x);
+        double v = u;
+        if (KIND == 1) v = xf.a + xf.d * u;
+        if (KIND == 3) {
+            unsigned long long off = (unsigned long long)__builtin_floor(u * (double)xf.span);
+            if (off >= xf.span) off = xf.span - 1;
+            v = (double)(xf.lower + (long long)off);
+        }
+        out[i] = (T)v;
         x = jm * x + jp;  // jump `stride` steps
     }
 }
@@ -128,7 +143,7 @@ __device__ __forceinline__ BmTables bm_stage_tables(double* lds, int tid, int nt
     return t;
 }
 
-__device__ __forceinline__ double bm_radius(unsigned long long x1, const BmTables& tb) {
+__device__ __forceinline__ double bm_radius(unsigned long long x1, const BmTables& tb, double* ln_out = nullptr) {
     const double vd = lcg_bits53(x1);  // u1 2^53
     const unsigned long long bits = (unsigned long long)__double_as_longlong(vd);
     const unsigned hi = (unsigned)(bits >> 32);
@@ -148,6 +163,7 @@ __device__ __forceinline__ double bm_radius(unsigned long long x1, const BmTable
     const double dk = (double)e;
     const double head = __builtin_fma(dk, 0x1.62e42fee00000p-1, te.y);         // e ln2_hi is exact (32-bit constant)
     const double tail = __builtin_fma(dk, 0x1.a39ef35793c76p-33, lp);
+    if (ln_out) *ln_out = (x1 >> 11) == 0 ? -0x1.6232bdd7abcd2p+9 : head + tail;  // ln u1 (u1 = 0 stands for f64::MIN_POSITIVE: ln 2^-1022)
     const double x = -2.0 * (head + tail);                                     // -2 ln u1 in [2.2e-16, 1417]
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = 0.5 * y;
@@ -176,9 +192,28 @@ __device__ __forceinline__ void bm_sincos(unsigned long long x2, const BmTables&
     *cs = te.y + __builtin_fma(te.y, w, -(te.x * sd));
 }
 
+// `random_exponential` (random.rs:290-300): -mu ln(max(u, MIN_POSITIVE)), the table logarithm of the Box-Muller radius (<= 1 ulp)
 template <class T>
+__global__ void __launch_bounds__(256) k_rng_exponential(unsigned long long state, T* __restrict__ out, size_t n, unsigned long long jm,
+                                                         unsigned long long jp, double mu) {
+    __shared__ __attribute__((aligned(16))) double s_tab[kBmLdsDoubles];
+    const BmTables tb = bm_stage_tables(s_tab, threadIdx.x, 256);
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    if (g >= n) return;
+    unsigned long long x = lcg_skip2(state, 256ULL * blockIdx.x, threadIdx.x + 1ULL);
+    for (size_t i = g; i < n; i += stride) {
+        double ln_u;
+        (void)bm_radius(x, tb, &ln_u);
+        out[i] = (T)(-mu * ln_u);
+        x = jm * x + jp;
+    }
+}
+
+// SCALED: mu + sigma z (generate_normal_scaled, random.rs:302-320)
+template <class T, bool SCALED = false>
 __global__ void __launch_bounds__(256) k_rng_normal(unsigned long long state, T* __restrict__ out, size_t n,
-                                                    unsigned long long jm, unsigned long long jp) {
+                                                    unsigned long long jm, unsigned long long jp, double mu = 0.0, double sigma = 1.0) {
     typedef typename PairOf<T>::type P;
     __shared__ __attribute__((aligned(16))) double s_tab[kBmLdsDoubles];
     const BmTables tb = bm_stage_tables(s_tab, threadIdx.x, 256);
@@ -194,7 +229,11 @@ __global__ void __launch_bounds__(256) k_rng_normal(unsigned long long state, T*
         const double radius = bm_radius(x1, tb);
         double sn, cs;
         bm_sincos(x2, tb, &sn, &cs);
-        const double z0 = radius * cs, z1 = radius * sn;
+        double z0 = radius * cs, z1 = radius * sn;
+        if (SCALED) {
+            z0 = mu + sigma * z0;
+            z1 = mu + sigma * z1;
+        }
         if (2 * i + 1 < n) {
             if (aligned) *(P*)(out + 2 * i) = P{(T)z0, (T)z1};
             else {
@@ -265,33 +304,63 @@ static unsigned rng_grid(const Context* c, size_t work) {
     return (unsigned)(want < cap ? want : cap);
 }
 
-template <class T>
-static int rng_uniform_any(Context* c, uint64_t state, T* out, size_t n) {
+template <class T, int KIND>
+static int rng_uniform_any(Context* c, uint64_t state, T* out, size_t n, const UniformXform& xf) {
     if (n == 0) return RMHIP_OK;
     const unsigned grid = rng_grid(c, n);
     unsigned long long jm, jp;
     lcg_jump((unsigned long long)grid * 256ULL, &jm, &jp);
-    hipLaunchKernelGGL(k_rng_uniform<T>, dim3(grid), dim3(256), 0, c->stream, (unsigned long long)state, out, n, jm, jp);
+    hipLaunchKernelGGL((k_rng_uniform<T, KIND>), dim3(grid), dim3(256), 0, c->stream, (unsigned long long)state, out, n, jm, jp, xf);
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
 }
-int launch_rng_uniform(Context* c, uint64_t state, double* out, size_t n) { return rng_uniform_any(c, state, out, n); }
-int launch_rng_uniform_f32(Context* c, uint64_t state, float* out, size_t n) { return rng_uniform_any(c, state, out, n); }
-
+int launch_rng_uniform(Context* c, uint64_t state, double* out, size_t n) { return rng_uniform_any<double, 0>(c, state, out, n, UniformXform{}); }
+int launch_rng_uniform_f32(Context* c, uint64_t state, float* out, size_t n) { return rng_uniform_any<float, 0>(c, state, out, n, UniformXform{}); }
+// a + (b - a) u: the difference is rounded here, once, as the CPU does
+int launch_rng_unifrnd(Context* c, uint64_t state, double a, double b, double* out64, float* out32, size_t n) {
+    UniformXform xf{};
+    xf.a = a;
+    xf.d = b - a;
+    return out32 ? rng_uniform_any<float, 1>(c, state, out32, n, xf) : rng_uniform_any<double, 1>(c, state, out64, n, xf);
+}
+int launch_rng_integer_range(Context* c, uint64_t state, long long lower, unsigned long long span, double* out64, float* out32, size_t n) {
+    UniformXform xf{};
+    xf.lower = lower;
+    xf.span = span;
+    return out32 ? rng_uniform_any<float, 3>(c, state, out32, n, xf) : rng_uniform_any<double, 3>(c, state, out64, n, xf);
+}
 template <class T>
-static int rng_normal_any(Context* c, uint64_t state, T* out, size_t n) {
+static int rng_exponential_any(Context* c, uint64_t state, double mu, T* out, size_t n) {
+    if (n == 0) return RMHIP_OK;
+    const unsigned grid = rng_grid(c, n);
+    unsigned long long jm, jp;
+    lcg_jump((unsigned long long)grid * 256ULL, &jm, &jp);
+    hipLaunchKernelGGL(k_rng_exponential<T>, dim3(grid), dim3(256), 0, c->stream, (unsigned long long)state, out, n, jm, jp, mu);
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+int launch_rng_exponential(Context* c, uint64_t state, double mu, double* out64, float* out32, size_t n) {
+    return out32 ? rng_exponential_any(c, state, mu, out32, n) : rng_exponential_any(c, state, mu, out64, n);
+}
+
+template <class T, bool SCALED>
+static int rng_normal_any(Context* c, uint64_t state, T* out, size_t n, double mu = 0.0, double sigma = 1.0) {
     if (n == 0) return RMHIP_OK;
     const unsigned grid = rng_grid(c, (n + 1) / 2);
     unsigned long long jm, jp;
     lcg_jump(2ULL * grid * 256ULL, &jm, &jp);
-    hipLaunchKernelGGL(k_rng_normal<T>, dim3(grid), dim3(256), 0, c->stream, (unsigned long long)state, out, n, jm, jp);
+    hipLaunchKernelGGL((k_rng_normal<T, SCALED>), dim3(grid), dim3(256), 0, c->stream, (unsigned long long)state, out, n, jm, jp, mu, sigma);
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
 }
-int launch_rng_normal(Context* c, uint64_t state, double* out, size_t n) { return rng_normal_any(c, state, out, n); }
-int launch_rng_normal_f32(Context* c, uint64_t state, float* out, size_t n) { return rng_normal_any(c, state, out, n); }
+int launch_rng_normal(Context* c, uint64_t state, double* out, size_t n) { return rng_normal_any<double, false>(c, state, out, n); }
+int launch_rng_normal_f32(Context* c, uint64_t state, float* out, size_t n) { return rng_normal_any<float, false>(c, state, out, n); }
+int launch_rng_normrnd(Context* c, uint64_t state, double mu, double sigma, double* out64, float* out32, size_t n) {
+    return out32 ? rng_normal_any<float, true>(c, state, out32, n, mu, sigma) : rng_normal_any<double, true>(c, state, out64, n, mu, sigma);
+}
 
 template <class T>
 static int stochastic_evolution_any(Context* c, uint64_t state, const T* in, T* out, size_t n, double drift, double scale,

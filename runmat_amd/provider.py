@@ -839,6 +839,42 @@ class HipProvider:
         self._check(self._lib.rmhip_random_normal(self._ctx, sh, rank, C.byref(out)))
         return self._handle(out.value, shape)
 
+    def random_uniform_like(self, prototype: GpuTensorHandle) -> GpuTensorHandle:
+        """lib.rs:1718-1720: `random_uniform(&prototype.shape)`."""
+        return self.random_uniform(prototype.shape)
+
+    def random_normal_like(self, prototype: GpuTensorHandle) -> GpuTensorHandle:
+        """lib.rs:1728-1730."""
+        return self.random_normal(prototype.shape)
+
+    def _random_dist(self, fn, args, shape) -> GpuTensorHandle:
+        sh, rank = _shape_array(shape)
+        out = C.c_uint64()
+        self._check(fn(self._ctx, *args, sh, rank, C.byref(out)))
+        return self._handle(out.value, shape)
+
+    def random_unifrnd(self, a: float, b: float, shape: Sequence[int]) -> GpuTensorHandle:
+        """lib.rs:1750-1757: a + (b - a) * u per element (random.rs:514-528)."""
+        return self._random_dist(self._lib.rmhip_random_unifrnd, (float(a), float(b)), shape)
+
+    def random_exponential(self, mu: float, shape: Sequence[int]) -> GpuTensorHandle:
+        """lib.rs:1733-1737: -mu * ln(max(u, MIN_POSITIVE)) (random.rs:290-300)."""
+        return self._random_dist(self._lib.rmhip_random_exponential, (float(mu),), shape)
+
+    def random_normrnd(self, mu: float, sigma: float, shape: Sequence[int]) -> GpuTensorHandle:
+        """lib.rs:1740-1747: mu + sigma * z over Box-Muller pairs (random.rs:302-320)."""
+        return self._random_dist(self._lib.rmhip_random_normrnd, (float(mu), float(sigma)), shape)
+
+    def random_integer_range(self, lower: int, upper: int, shape: Sequence[int]) -> GpuTensorHandle:
+        """lib.rs:1820-1829: uniform integers in [lower, upper] (simple_provider.rs:3683-3725); an empty or > 2^53 range is an error."""
+        if not (-2**63 <= int(lower) < 2**63 and -2**63 <= int(upper) < 2**63):
+            raise RmhipError(1, "random_integer_range: bounds outside i64")
+        return self._random_dist(self._lib.rmhip_random_integer_range, (int(lower), int(upper)), shape)
+
+    def random_integer_like(self, prototype: GpuTensorHandle, lower: int, upper: int) -> GpuTensorHandle:
+        """lib.rs:1832-1839."""
+        return self.random_integer_range(lower, upper, prototype.shape)
+
     # -- telemetry / timing ---------------------------------------------------------------------
     def telemetry_snapshot(self) -> dict:
         """`telemetry_snapshot` (lib.rs:3023-3045): the counters of `ProviderTelemetry` (:1337-1357) plus its two lists,

@@ -483,6 +483,32 @@ impl AccelProvider for HipProvider {
         check(unsafe { rmhip_random_uniform(self.ctx, shape.as_ptr(), shape.len(), &mut out) })?;
         Ok(GpuTensorHandle { shape: shape.to_vec(), device_id: self.device_id, buffer_id: out })
     }
+    // the prototype forms (lib.rs:1718-1730, 1832-1839: the trait's defaults, spelled out) and the scaled / transformed draws
+    fn random_uniform_like(&self, prototype: &GpuTensorHandle) -> Result<GpuTensorHandle> { self.random_uniform(&prototype.shape) }
+    fn random_normal_like(&self, prototype: &GpuTensorHandle) -> Result<GpuTensorHandle> { self.random_normal(&prototype.shape) }
+    fn random_unifrnd(&self, a: f64, b: f64, shape: &[usize]) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_random_unifrnd(self.ctx, a, b, shape.as_ptr(), shape.len(), &mut out) })?;
+        Ok(GpuTensorHandle { shape: shape.to_vec(), device_id: self.device_id, buffer_id: out })
+    }
+    fn random_exponential(&self, mu: f64, shape: &[usize]) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_random_exponential(self.ctx, mu, shape.as_ptr(), shape.len(), &mut out) })?;
+        Ok(GpuTensorHandle { shape: shape.to_vec(), device_id: self.device_id, buffer_id: out })
+    }
+    fn random_normrnd(&self, mu: f64, sigma: f64, shape: &[usize]) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_random_normrnd(self.ctx, mu, sigma, shape.as_ptr(), shape.len(), &mut out) })?;
+        Ok(GpuTensorHandle { shape: shape.to_vec(), device_id: self.device_id, buffer_id: out })
+    }
+    fn random_integer_range(&self, lower: i64, upper: i64, shape: &[usize]) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_random_integer_range(self.ctx, lower, upper, shape.as_ptr(), shape.len(), &mut out) })?;
+        Ok(GpuTensorHandle { shape: shape.to_vec(), device_id: self.device_id, buffer_id: out })
+    }
+    fn random_integer_like(&self, prototype: &GpuTensorHandle, lower: i64, upper: i64) -> Result<GpuTensorHandle> {
+        self.random_integer_range(lower, upper, &prototype.shape)
+    }
 
     // all-element truth reductions (lib.rs:2730-2735, 2803-2809, 2818-2824): dim = -1
     fn reduce_nnz<'a>(&'a self, a: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> {

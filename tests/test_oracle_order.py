@@ -87,3 +87,22 @@ def test_sort_is_stable_and_places_nans_and_zeros_like_the_reference():
 def test_median_all_hook_and_host_path_differ():
     x = np.array([[1.0, 2.0, 30.0], [4.0, 50.0, 6.0], [7.0, 8.0, 9.0]])
     assert oracle.median_all(x) == 7.0 and oracle.median_all(x, successive=True) == 8.0
+
+
+def test_random_distribution_restatements_follow_their_definitions():
+    """generate_uniform_scaled / generate_exponential / generate_normal_scaled / random_integer_range written out over the oracle's own
+    (pinned) uniform and normal streams - the reference's tests define the expected sequences the same way (random.rs:574-606)."""
+    s0 = oracle.rng_default_seed()
+    u, s1 = oracle.rng_uniform(s0, 9)
+    got, state = oracle.rng_unifrnd(s0, 2.0, 5.0, 9)
+    assert np.array_equal(got, 2.0 + (5.0 - 2.0) * u) and state == s1
+    got, state = oracle.rng_exponential(s0, 2.5, 9)
+    assert np.array_equal(got, -2.5 * np.log(np.maximum(u, 2.2250738585072014e-308))) and state == s1
+    z, s2 = oracle.rng_normal(s0, 9)
+    got, state = oracle.rng_normrnd(s0, 1.0, 3.0, 9)
+    assert np.array_equal(got, 1.0 + 3.0 * z) and state == s2
+    got, state = oracle.rng_integer_range(s0, -3, 3, 9)
+    assert np.array_equal(got, -3 + np.minimum(np.floor(u * 7.0), 6.0)) and state == s1
+    got, state = oracle.rng_integer_range(s0, 4, 4, 9)
+    assert np.array_equal(got, np.full(9, 4.0)) and state == s0
+    assert oracle.rng_integer_range(s0, 2, 1, 3) is None and oracle.rng_integer_range(s0, 0, 2**53, 3) is None
