@@ -328,6 +328,33 @@ RMHIP_API int rmhip_sort_dim(rmhip_ctx* ctx, rmhip_buf a, int dim, int descend, 
 /* @serves reduce_median reduce_median_dim */
 RMHIP_API int rmhip_reduce_median(rmhip_ctx* ctx, rmhip_buf a, int dim, rmhip_buf* out);
 
+/* ---- small construction / linear-algebra hooks (runmat_amd/csrc/misc_ops.hip): one or two rounded operations per element, bit-exact ----
+ * `diag_from_vector(vector, offset)` / `diag_from_vector_sized(vector, offset, rows, cols)` (lib.rs:1600-1623; simple_provider.rs:3222-3281):
+ * element idx of a vector-like operand on (idx, idx + offset) or (idx - offset, idx), zeros elsewhere; rows / cols < 0 = the square of
+ * size len + |offset|; elements that fall outside an explicit size are dropped.  A matrix operand is RMHIP_ERR_UNSUPPORTED. */
+/* @serves diag_from_vector diag_from_vector_sized */
+RMHIP_API int rmhip_diag_from_vector(rmhip_ctx* ctx, rmhip_buf vector, long long offset, long long rows_or_neg, long long cols_or_neg,
+                                     rmhip_buf* out);
+/* `kron(a, b)` (lib.rs:2697-2699; kron.rs:358-485): shapes padded with ones to a common rank (<= 8), out[a_c * extent_b + b_c] = a * b. */
+/* @serves kron */
+RMHIP_API int rmhip_kron(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out);
+/* `cross(lhs, rhs, dim)` (lib.rs:2701-2708; cross.rs:332-364, 443-467): operands of one shape; `dim` ONE-based as the trait passes it,
+ * 0 = None = the first dimension of extent 3; a dimension beyond the rank or not of extent 3 is RMHIP_ERR_INVALID.  Each component
+ * is two products and a difference, unfused. */
+/* @serves cross */
+RMHIP_API int rmhip_cross(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, int dim_one_based_or_0, rmhip_buf* out);
+/* `gradient_dim(handle, dim, spacing)` / `gradient_dim_with_coordinates(handle, dim, coordinates)` (lib.rs:2604-2620;
+ * gradient.rs:650-720, 814-833): along zero-based `dim`, (x[1] - x[0]) / h and (x[n-1] - x[n-2]) / h at the ends, (x[k+1] - x[k-1]) /
+ * (2 h) inside - or the matching coordinate differences when `coordinates` (a resident vector of the dimension's extent) is given;
+ * an extent of one gives zeros.  A zero coordinate difference is the caller's to refuse (gradient.rs:1044-1051): here it divides. */
+/* @serves gradient_dim gradient_dim_with_coordinates */
+RMHIP_API int rmhip_gradient_dim(rmhip_ctx* ctx, rmhip_buf a, int dim, double spacing, rmhip_buf coordinates_or_0, rmhip_buf* out);
+/* `issymmetric(matrix, kind, tolerance)` (lib.rs:3115-3124; issymmetric.rs:461-487, 517-526): 1 when a(i,j) equals a(j,i) (skew != 0:
+ * -a(j,i), and a zero diagonal), pairs compared as `v == r || (both finite && |v - r| <= tolerance)`; a non-square operand is 0, an
+ * operand with trailing extents > 1 RMHIP_ERR_INVALID.  Synchronises the stream (a host bool comes back). */
+/* @serves issymmetric */
+RMHIP_API int rmhip_issymmetric(rmhip_ctx* ctx, rmhip_buf a, int skew, double tolerance, int* result);
+
 /* `matmul`: C = A*B, 2-D, column-major; inner dims must agree else RMHIP_ERR_SHAPE
  * (simple_provider.rs:7698-7741). fp64 MFMA kernel. */
 /* @serves matmul */

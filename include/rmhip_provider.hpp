@@ -490,6 +490,43 @@ public:
         check(rmhip_random_normal(ctx_, shape.data(), shape.size(), &out));
         return make(out, shape);
     }
+    // lib.rs:1600-1623, 2697-2708, 2604-2620, 3115-3124 (misc_ops.hip)
+    GpuTensorHandle diag_from_vector(const GpuTensorHandle& v, long long offset) const {
+        uint64_t out = 0;
+        check(rmhip_diag_from_vector(ctx_, own(v), offset, -1, -1, &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle diag_from_vector_sized(const GpuTensorHandle& v, long long offset, size_t rows, size_t cols) const {
+        uint64_t out = 0;
+        check(rmhip_diag_from_vector(ctx_, own(v), offset, (long long)rows, (long long)cols, &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle kron(const GpuTensorHandle& a, const GpuTensorHandle& b) const {
+        uint64_t out = 0;
+        check(rmhip_kron(ctx_, own(a), own(b), &out));
+        return with_shape(out);
+    }
+    // dim: ONE-based as the trait's Option<usize>; 0 = None (the first dimension of extent 3)
+    GpuTensorHandle cross(const GpuTensorHandle& lhs, const GpuTensorHandle& rhs, size_t dim_one_based_or_0 = 0) const {
+        uint64_t out = 0;
+        check(rmhip_cross(ctx_, own(lhs), own(rhs), (int)dim_one_based_or_0, &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle gradient_dim(const GpuTensorHandle& a, size_t dim, double spacing) const {
+        uint64_t out = 0;
+        check(rmhip_gradient_dim(ctx_, own(a), (int)dim, spacing, 0, &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle gradient_dim_with_coordinates(const GpuTensorHandle& a, size_t dim, const GpuTensorHandle& coordinates) const {
+        uint64_t out = 0;
+        check(rmhip_gradient_dim(ctx_, own(a), (int)dim, 1.0, own(coordinates), &out));
+        return with_shape(out);
+    }
+    bool issymmetric(const GpuTensorHandle& m, bool skew, double tolerance) const {
+        int r = 0;
+        check(rmhip_issymmetric(ctx_, own(m), skew ? 1 : 0, tolerance, &r));
+        return r != 0;
+    }
     // lib.rs:1718-1757, 1820-1839: the prototype forms and the scaled / transformed draws of the same stream
     GpuTensorHandle random_uniform_like(const GpuTensorHandle& prototype) const { return random_uniform(prototype.shape); }
     GpuTensorHandle random_normal_like(const GpuTensorHandle& prototype) const { return random_normal(prototype.shape); }

@@ -1448,3 +1448,85 @@ ORC_API void orc_median_dim(const double* data, size_t pre, size_t len, size_t p
     free(buf);
     free(tmp);
 }
+
+/* ---- small linear-algebra / construction hooks ---- */
+
+/* diag_from_vector_sized, simple_provider.rs:3241-3281: element idx of the vector goes to (idx, idx + offset) or (idx - offset, idx) when
+ * that lies inside rows x cols; everything else is zero */
+ORC_API void orc_diag_from_vector(const double* v, size_t len, long long offset, size_t rows, size_t cols, double* out) {
+    for (size_t i = 0; i < rows * cols; ++i) out[i] = 0.0;
+    for (size_t idx = 0; idx < len; ++idx) {
+        const size_t row = offset >= 0 ? idx : idx + (size_t)(-offset);
+        const size_t col = offset >= 0 ? idx + (size_t)offset : idx;
+        if (row < rows && col < cols) out[row + col * rows] = v[idx];
+    }
+}
+
+/* kron_tensor, builtins/array/shape/kron.rs:358-382, 415-485: shapes padded with ones to a common rank; out coordinate = a * extent_b + b */
+ORC_API void orc_kron(const double* a, const size_t* shape_a, const double* b, const size_t* shape_b, size_t rank, double* out) {
+    size_t na = 1, nb = 1, stride[16], cur = 1;
+    for (size_t d = 0; d < rank; ++d) {
+        na *= shape_a[d];
+        nb *= shape_b[d];
+        stride[d] = cur;
+        cur *= shape_a[d] * shape_b[d];
+    }
+    for (size_t ia = 0; ia < na; ++ia)
+        for (size_t ib = 0; ib < nb; ++ib) {
+            size_t ra = ia, rb = ib, o = 0;
+            for (size_t d = 0; d < rank; ++d) {
+                const size_t ca = ra % shape_a[d], cb = rb % shape_b[d];
+                ra /= shape_a[d];
+                rb /= shape_b[d];
+                o += (ca * shape_b[d] + cb) * stride[d];
+            }
+            out[o] = a[ia] * b[ib];
+        }
+}
+
+/* cross_real_tensor, builtins/math/linalg/ops/cross.rs:332-364: the three components sit `pre` apart */
+ORC_API void orc_cross(const double* a, const double* b, size_t pre, size_t post, double* out) {
+    for (size_t after = 0; after < post; ++after)
+        for (size_t before = 0; before < pre; ++before) {
+            const size_t i1 = after * pre * 3 + before, i2 = i1 + pre, i3 = i2 + pre;
+            out[i1] = a[i2] * b[i3] - a[i3] * b[i2];
+            out[i2] = a[i3] * b[i1] - a[i1] * b[i3];
+            out[i3] = a[i1] * b[i2] - a[i2] * b[i1];
+        }
+}
+
+/* gradient_real_tensor_host_with_spacing, builtins/math/reduction/gradient.rs:650-720, 814-833: one-sided differences at the ends,
+ * central ones inside; the denominator is the scalar spacing (doubled inside) or coordinate differences.  coords == NULL: scalar. */
+ORC_API void orc_gradient(const double* x, size_t pre, size_t len, size_t post, double spacing, const double* coords, double* out) {
+    for (size_t i = 0; i < pre * len * post; ++i) out[i] = 0.0;
+    if (len <= 1) return;
+    for (size_t after = 0; after < post; ++after)
+        for (size_t before = 0; before < pre; ++before)
+            for (size_t k = 0; k < len; ++k) {
+                const size_t idx = after * pre * len + before + k * pre;
+                double den;
+                if (coords) den = k == 0 ? coords[1] - coords[0] : (k + 1 == len ? coords[len - 1] - coords[len - 2] : coords[k + 1] - coords[k - 1]);
+                else den = (k == 0 || k + 1 == len) ? spacing : 2.0 * spacing;
+                if (k == 0) out[idx] = (x[idx + pre] - x[idx]) / den;
+                else if (k + 1 == len) out[idx] = (x[idx] - x[idx - pre]) / den;
+                else out[idx] = (x[idx + pre] - x[idx - pre]) / den;
+            }
+}
+
+/* is_symmetric_real + real_within, builtins/math/linalg/structure/issymmetric.rs:461-487, 517-526 (rows != cols -> false: :546-548) */
+ORC_API int orc_issymmetric(const double* data, size_t rows, size_t cols, int skew, double tol) {
+    if (rows != cols) return 0;
+    for (size_t col = 0; col < cols; ++col) {
+        if (skew) {
+            const double d = data[col + col * rows];
+            if (!(d == 0.0) && (!isfinite(d) || !(fabs(d - 0.0) <= tol))) return 0;
+        }
+        for (size_t row = 0; row < col; ++row) {
+            const double v = data[row + col * rows], r = skew ? -data[col + row * rows] : data[col + row * rows];
+            if (v == r) continue;
+            if (!isfinite(v) || !isfinite(r)) return 0;
+            if (!(fabs(v - r) <= tol)) return 0;
+        }
+    }
+    return 1;
+}

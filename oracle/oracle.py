@@ -691,3 +691,73 @@ def median_all(x: np.ndarray, successive: bool = False) -> float:
     for d in range(x.ndim):
         cur = median_dim(cur, d)
     return float(cur.reshape(-1)[0])
+
+
+def diag_from_vector(v: np.ndarray, offset: int, rows: int = None, cols: int = None) -> np.ndarray:
+    """diag_from_vector(_sized) (simple_provider.rs:3222-3281): square of size len + |offset| unless rows / cols are given."""
+    v = np.asarray(v, dtype=np.float64).ravel(order="F")
+    if rows is None:
+        rows = cols = v.size + abs(int(offset))
+    out = np.empty(rows * cols)
+    l = lib()
+    l.orc_diag_from_vector.restype = None
+    l.orc_diag_from_vector.argtypes = [_DP, C.c_size_t, C.c_longlong, C.c_size_t, C.c_size_t, _DP]
+    l.orc_diag_from_vector(_p(np.ascontiguousarray(v)), v.size, int(offset), rows, cols, _p(out))
+    return out.reshape((rows, cols), order="F")
+
+
+def kron(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    rank = max(a.ndim, b.ndim, 1)
+    sa, sb = list(a.shape) + [1] * (rank - a.ndim), list(b.shape) + [1] * (rank - b.ndim)
+    so = [x * y for x, y in zip(sa, sb)]
+    out = np.empty(int(np.prod(so, dtype=np.int64)))
+    l = lib()
+    l.orc_kron.restype = None
+    l.orc_kron.argtypes = [_DP, _SZP, _DP, _SZP, C.c_size_t, _DP]
+    fa, fb = _f(a), _f(b)
+    if out.size:
+        l.orc_kron(_p(fa), _shape(sa), _p(fb), _shape(sb), rank, _p(out))
+    return out.reshape(so, order="F")
+
+
+def cross(a: np.ndarray, b: np.ndarray, dim_one_based: int = None) -> np.ndarray:
+    """cross.rs:332-364, 443-467: along the given 1-based dimension (length 3) or the first of length 3."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    if dim_one_based is None:
+        dim_one_based = list(a.shape).index(3) + 1
+    assert a.shape[dim_one_based - 1] == 3
+    pre, _, post = _pre_len_post(a.shape, dim_one_based - 1)
+    out = np.empty(a.size)
+    l = lib()
+    l.orc_cross.restype = None
+    l.orc_cross.argtypes = [_DP, _DP, C.c_size_t, C.c_size_t, _DP]
+    l.orc_cross(_p(_f(a)), _p(_f(b)), pre, post, _p(out))
+    return out.reshape(a.shape, order="F")
+
+
+def gradient(x: np.ndarray, dim: int, spacing: float = 1.0, coords=None) -> np.ndarray:
+    """gradient.rs:650-720 along zero-based dim (beyond the rank: extent one -> zeros)."""
+    x = np.asarray(x, dtype=np.float64)
+    shape = list(x.shape) + [1] * max(0, dim + 1 - x.ndim)
+    pre, ln, post = _pre_len_post(shape, dim)
+    out = np.empty(x.size)
+    l = lib()
+    l.orc_gradient.restype = None
+    l.orc_gradient.argtypes = [_DP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, _DP, _DP]
+    cp = None
+    if coords is not None:
+        cc = np.ascontiguousarray(np.asarray(coords, dtype=np.float64).ravel())
+        cp = _p(cc)
+    l.orc_gradient(_p(_f(x)), pre, ln, post, float(spacing), cp, _p(out))
+    return out.reshape(x.shape, order="F")
+
+
+def issymmetric(a: np.ndarray, skew: bool = False, tol: float = 0.0) -> bool:
+    a = np.asarray(a, dtype=np.float64)
+    rows, cols = (a.shape[0], a.shape[1]) if a.ndim >= 2 else (a.size, 1)
+    l = lib()
+    l.orc_issymmetric.restype = C.c_int
+    l.orc_issymmetric.argtypes = [_DP, C.c_size_t, C.c_size_t, C.c_int, C.c_double]
+    return bool(l.orc_issymmetric(_p(_f(a)), rows, cols, int(skew), float(tol)))

@@ -1,0 +1,257 @@
+// misc_ops.hip -- small construction / linear-algebra hooks of array and linalg builtins: one thread per output element, one or two
+// rounded operations each (bit-exact against the oracle), HBM-bound.
+//   diag_from_vector(_sized)          crates/runmat-accelerate-api/src/lib.rs:1600-1623   (simple_provider.rs:3222-3281)
+//   kron                              lib.rs:2697-2699    (builtins/array/shape/kron.rs:358-485)
+//   cross                             lib.rs:2701-2708    (builtins/math/linalg/ops/cross.rs:332-364, 443-467)
+//   gradient_dim(_with_coordinates)   lib.rs:2604-2620    (builtins/math/reduction/gradient.rs:650-720, 814-833)
+//   issymmetric                       lib.rs:3115-3124    (builtins/math/linalg/structure/issymmetric.rs:461-487, 517-526)
+#include <algorithm>
+#include <cstring>
+
+#include "common.h"
+
+using namespace rmhip;
+
+#define CTX_OR_FAIL(ctx)                                            \
+    if (!(ctx)) return fail(RMHIP_ERR_INVALID, "null context");     \
+    Context* c = context_of(ctx);                                   \
+    std::lock_guard<std::recursive_mutex> _call(c->call_mu);        \
+    DeviceGuard _dg(c);                                             \
+    NarrowScope _ns(c)
+
+namespace rmhip {
+namespace {
+
+typedef unsigned long long u64;
+constexpr int kB = 256;
+
+inline unsigned grid_for(u64 n) { return (unsigned)((n + kB - 1) / kB); }
+
+__global__ void __launch_bounds__(kB) k_diag_from_vector(const double* __restrict__ v, u64 len, long long offset, u64 rows, u64 cols, double* __restrict__ out) {
+    const u64 o = (u64)blockIdx.x * kB + threadIdx.x;
+    if (o >= rows * cols) return;
+    const u64 row = o % rows, col = o / rows;
+    // (row, col) holds element idx when row == idx + max(-offset, 0) and col == idx + max(offset, 0)
+    double val = 0.0;
+    const long long idx = offset >= 0 ? (long long)row : (long long)col;
+    if ((long long)col - (long long)row == offset && idx >= 0 && (u64)idx < len) val = v[idx];
+    __builtin_nontemporal_store(val, out + o);
+}
+
+struct KronDims {
+    int rank;
+    u64 sa[8], sb[8];  // padded extents; strides of the operands follow from them
+};
+__global__ void __launch_bounds__(kB) k_kron(const double* __restrict__ a, const double* __restrict__ b, KronDims d, u64 total, double* __restrict__ out) {
+    const u64 o = (u64)blockIdx.x * kB + threadIdx.x;
+    if (o >= total) return;
+    u64 rem = o, ia = 0, ib = 0, stra = 1, strb = 1;
+    for (int k = 0; k < d.rank; ++k) {
+        const u64 ext = d.sa[k] * d.sb[k];
+        const u64 cd = rem % ext;
+        rem /= ext;
+        ia += (cd / d.sb[k]) * stra;
+        ib += (cd % d.sb[k]) * strb;
+        stra *= d.sa[k];
+        strb *= d.sb[k];
+    }
+    __builtin_nontemporal_store(a[ia] * b[ib], out + o);
+}
+
+__global__ void __launch_bounds__(kB) k_cross(const double* __restrict__ a, const double* __restrict__ b, u64 pre, u64 post, double* __restrict__ out) {
+    const u64 t = (u64)blockIdx.x * kB + threadIdx.x;
+    if (t >= pre * post) return;
+    const u64 before = t % pre, after = t / pre;
+    const u64 i1 = after * pre * 3 + before, i2 = i1 + pre, i3 = i2 + pre;
+    const double a1 = a[i1], a2 = a[i2], a3 = a[i3], b1 = b[i1], b2 = b[i2], b3 = b[i3];
+    out[i1] = a2 * b3 - a3 * b2;
+    out[i2] = a3 * b1 - a1 * b3;
+    out[i3] = a1 * b2 - a2 * b1;
+}
+
+__global__ void __launch_bounds__(kB) k_gradient(const double* __restrict__ x, u64 pre, u64 len, u64 total, double spacing, const double* __restrict__ coords,
+                                                 double* __restrict__ out) {
+    const u64 o = (u64)blockIdx.x * kB + threadIdx.x;
+    if (o >= total) return;
+    const u64 k = (o / pre) % len;
+    double num, den;
+    if (k == 0) {
+        num = x[o + pre] - x[o];
+        den = coords ? coords[1] - coords[0] : spacing;
+    } else if (k + 1 == len) {
+        num = x[o] - x[o - pre];
+        den = coords ? coords[len - 1] - coords[len - 2] : spacing;
+    } else {
+        num = x[o + pre] - x[o - pre];
+        den = coords ? coords[k + 1] - coords[k - 1] : 2.0 * spacing;
+    }
+    __builtin_nontemporal_store(num / den, out + o);
+}
+
+// one thread per element above the diagonal (and the diagonal for skew): any failing pair raises the flag
+__global__ void __launch_bounds__(kB) k_issymmetric(const double* __restrict__ a, u64 n, int skew, double tol, int* __restrict__ bad) {
+    const u64 t = (u64)blockIdx.x * kB + threadIdx.x;
+    if (t >= n * n) return;
+    const u64 row = t % n, col = t / n;
+    if (row > col || (row == col && !skew)) return;
+    const double v = a[row + col * n];
+    const double r = row == col ? 0.0 : (skew ? -a[col + row * n] : a[col + row * n]);
+    bool ok = v == r;
+    if (!ok && isfinite(v) && isfinite(r)) ok = fabs(v - r) <= tol;
+    if (!ok) *bad = 1;
+}
+
+std::vector<size_t> matrix_shape(const std::vector<size_t>& s) {
+    if (s.empty()) return {1, 1};
+    if (s.size() == 1) return {s[0], 1};
+    return s;
+}
+
+// ensure_diag_shape + is_vector_like (simple_provider.rs:2394-2412)
+int vector_operand(const Buffer& b, const char* what) {
+    const std::vector<size_t>& s = b.shape;
+    for (size_t d = 2; d < s.size(); ++d)
+        if (s[d] != 1) return fail(RMHIP_ERR_UNSUPPORTED, "%s: input must be 2-D", what);
+    const size_t rows = s.empty() ? 1 : s[0], cols = s.size() < 2 ? 1 : s[1];
+    if (!(rows == 1 || cols == 1 || s.size() <= 1)) return fail(RMHIP_ERR_UNSUPPORTED, "%s: input must be a vector", what);
+    return RMHIP_OK;
+}
+
+}  // namespace
+}  // namespace rmhip
+
+int rmhip_diag_from_vector(rmhip_ctx* ctx, rmhip_buf vector, long long offset, long long rows_or_neg, long long cols_or_neg, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer vb, ob;
+    RMHIP_TRY(c->get(vector, &vb));
+    RMHIP_TRY(vector_operand(vb, "diag"));
+    size_t rows, cols;
+    if (rows_or_neg < 0 || cols_or_neg < 0) {  // diag_from_vector: square, len + |offset| (simple_provider.rs:2346-2355)
+        const unsigned long long shift = offset < 0 ? (unsigned long long)(-offset) : (unsigned long long)offset;
+        rows = cols = vb.numel + (size_t)shift;
+    } else {
+        rows = (size_t)rows_or_neg;
+        cols = (size_t)cols_or_neg;
+    }
+    if (rows && cols > (size_t)-1 / 8 / rows) return fail(RMHIP_ERR_INVALID, "diag: result size exceeds limits");
+    const size_t shape[2] = {rows, cols};
+    RMHIP_TRY(c->new_buffer(shape, 2, out, &ob));
+    if (ob.numel) {
+        hipLaunchKernelGGL(k_diag_from_vector, dim3(grid_for(ob.numel)), dim3(kB), 0, c->stream, vb.data(), (u64)vb.numel, offset, (u64)rows, (u64)cols, ob.data());
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+    }
+    return RMHIP_OK;
+}
+
+int rmhip_kron(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer ab, bb, ob;
+    RMHIP_TRY(c->get(a, &ab));
+    RMHIP_TRY(c->get(b, &bb));
+    const size_t rank = std::max<size_t>(std::max(ab.shape.size(), bb.shape.size()), 1);
+    if (rank > 8) return fail(RMHIP_ERR_UNSUPPORTED, "kron: more than 8 dimensions");
+    KronDims d;
+    d.rank = (int)rank;
+    std::vector<size_t> oshape(rank);
+    for (size_t k = 0; k < rank; ++k) {
+        d.sa[k] = k < ab.shape.size() ? ab.shape[k] : 1;
+        d.sb[k] = k < bb.shape.size() ? bb.shape[k] : 1;
+        oshape[k] = (size_t)(d.sa[k] * d.sb[k]);
+    }
+    RMHIP_TRY(c->new_buffer(oshape.data(), rank, out, &ob));
+    if (ob.numel) {
+        hipLaunchKernelGGL(k_kron, dim3(grid_for(ob.numel)), dim3(kB), 0, c->stream, ab.data(), bb.data(), d, (u64)ob.numel, ob.data());
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+    }
+    return RMHIP_OK;
+}
+
+int rmhip_cross(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, int dim_one_based_or_0, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer ab, bb, ob;
+    RMHIP_TRY(c->get(a, &ab));
+    RMHIP_TRY(c->get(b, &bb));
+    const std::vector<size_t> shape = matrix_shape(ab.shape);
+    if (ab.numel != bb.numel || shape != matrix_shape(bb.shape)) return fail(RMHIP_ERR_SHAPE, "cross: inputs must be the same size");
+    size_t dim = 0;  // zero-based
+    if (dim_one_based_or_0 > 0) {
+        if ((size_t)dim_one_based_or_0 > shape.size())
+            return fail(RMHIP_ERR_INVALID, "cross: dimension %d exceeds the number of array dimensions (%zu)", dim_one_based_or_0, shape.size());
+        dim = (size_t)dim_one_based_or_0 - 1;
+        if (shape[dim] != 3) return fail(RMHIP_ERR_INVALID, "cross: dimension %d must have length 3", dim_one_based_or_0);
+    } else if (dim_one_based_or_0 == 0) {
+        while (dim < shape.size() && shape[dim] != 3) ++dim;
+        if (dim == shape.size()) return fail(RMHIP_ERR_INVALID, "cross: inputs must have a dimension of length 3");
+    } else {
+        return fail(RMHIP_ERR_INVALID, "cross: dimension must be >= 1");
+    }
+    u64 pre = 1, post = 1;
+    for (size_t k = 0; k < dim; ++k) pre *= shape[k];
+    for (size_t k = dim + 1; k < shape.size(); ++k) post *= shape[k];
+    RMHIP_TRY(c->new_buffer(shape.data(), shape.size(), out, &ob));
+    if (ob.numel) {
+        hipLaunchKernelGGL(k_cross, dim3(grid_for(pre * post)), dim3(kB), 0, c->stream, ab.data(), bb.data(), pre, post, ob.data());
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+    }
+    return RMHIP_OK;
+}
+
+int rmhip_gradient_dim(rmhip_ctx* ctx, rmhip_buf a, int dim, double spacing, rmhip_buf coordinates_or_0, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    if (dim < 0) return fail(RMHIP_ERR_INVALID, "gradient_dim: dim must be >= 0");
+    Buffer ab, cb, ob;
+    RMHIP_TRY(c->get(a, &ab));
+    const std::vector<size_t> shape = matrix_shape(ab.shape);
+    u64 pre = 1, len = 1;
+    for (size_t k = 0; k < shape.size() && k < (size_t)dim; ++k) pre *= shape[k];
+    if ((size_t)dim < shape.size()) len = shape[dim];
+    const double* coords = nullptr;
+    if (coordinates_or_0) {
+        RMHIP_TRY(c->get(coordinates_or_0, &cb));
+        if (cb.numel != len) return fail(RMHIP_ERR_SHAPE, "gradient: coordinate vector length must match the dimension (%zu vs %llu)", cb.numel, len);
+        coords = cb.data();
+    }
+    RMHIP_TRY(c->new_buffer(shape.data(), shape.size(), out, &ob));
+    if (ob.numel == 0) return RMHIP_OK;
+    if (len <= 1) return launch_fill(c, ob.data(), ob.numel, 0.0);  // gradient.rs:691-692: nothing to difference
+    hipLaunchKernelGGL(k_gradient, dim3(grid_for(ob.numel)), dim3(kB), 0, c->stream, ab.data(), pre, len, (u64)ob.numel, spacing, coords, ob.data());
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+
+int rmhip_issymmetric(rmhip_ctx* ctx, rmhip_buf a, int skew, double tolerance, int* result) {
+    CTX_OR_FAIL(ctx);
+    if (!result) return fail(RMHIP_ERR_INVALID, "null result");
+    Buffer ab;
+    RMHIP_TRY(c->get(a, &ab));
+    const std::vector<size_t>& s = ab.shape;
+    for (size_t d = 2; d < s.size(); ++d)
+        if (s[d] != 1) return fail(RMHIP_ERR_INVALID, "issymmetric: inputs must be 2-D matrices or vectors");
+    const size_t rows = s.empty() ? 1 : s[0], cols = s.size() < 2 ? 1 : s[1];
+    if (rows != cols) {
+        *result = 0;
+        return RMHIP_OK;
+    }
+    if (rows == 0) {
+        *result = 1;
+        return RMHIP_OK;
+    }
+    std::shared_ptr<Allocation> flag;
+    RMHIP_TRY(c->alloc_device(1, &flag));
+    RMHIP_HIP_CHECK(hipMemsetAsync(flag->ptr, 0, sizeof(double), c->stream));
+    hipLaunchKernelGGL(k_issymmetric, dim3(grid_for((u64)rows * rows)), dim3(kB), 0, c->stream, ab.data(), (u64)rows, skew ? 1 : 0, tolerance, (int*)flag->ptr);
+    c->tel.kernel_launches++;
+    int bad = 0;
+    RMHIP_HIP_CHECK(hipMemcpyAsync(&bad, flag->ptr, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *result = bad ? 0 : 1;
+    return RMHIP_OK;
+}

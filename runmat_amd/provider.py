@@ -839,6 +839,53 @@ class HipProvider:
         self._check(self._lib.rmhip_random_normal(self._ctx, sh, rank, C.byref(out)))
         return self._handle(out.value, shape)
 
+    # -- small construction / linear-algebra hooks (misc_ops.hip) -----------------------------------
+    def diag_from_vector(self, vector, offset: int = 0) -> GpuTensorHandle:
+        """lib.rs:1600-1608: the square matrix of size len + |offset| with the vector on diagonal `offset`."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_diag_from_vector(self._ctx, self._id(vector), int(offset), -1, -1, C.byref(out)))
+        return self._handle(out.value)
+
+    def diag_from_vector_sized(self, vector, offset: int, rows: int, cols: int) -> GpuTensorHandle:
+        """lib.rs:1613-1623: the same into an explicit rows x cols (elements outside are dropped)."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_diag_from_vector(self._ctx, self._id(vector), int(offset), int(rows), int(cols), C.byref(out)))
+        return self._handle(out.value)
+
+    def kron(self, a, b) -> GpuTensorHandle:
+        """lib.rs:2697-2699; kron.rs:358-485."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_kron(self._ctx, self._id(a), self._id(b), C.byref(out)))
+        return self._handle(out.value)
+
+    def cross(self, lhs, rhs, dim: Optional[int] = None) -> GpuTensorHandle:
+        """lib.rs:2701-2708: `dim` is ONE-based (`Option<usize>` as the builtin parsed it), None = the first dimension of extent 3."""
+        if dim is not None and int(dim) < 1:
+            raise RmhipError(1, "cross: dimension must be >= 1")
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_cross(self._ctx, self._id(lhs), self._id(rhs), 0 if dim is None else int(dim), C.byref(out)))
+        return self._handle(out.value)
+
+    def gradient_dim(self, a, dim: int, spacing: float = 1.0) -> GpuTensorHandle:
+        """lib.rs:2604-2611: zero-based dim, scalar spacing (gradient.rs:650-720)."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_gradient_dim(self._ctx, self._id(a), int(dim), float(spacing), 0, C.byref(out)))
+        return self._handle(out.value)
+
+    def gradient_dim_with_coordinates(self, a, dim: int, coordinates) -> GpuTensorHandle:
+        """lib.rs:2612-2620: denominators from a resident coordinate vector of the dimension's extent."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_gradient_dim(self._ctx, self._id(a), int(dim), 1.0, self._id(coordinates), C.byref(out)))
+        return self._handle(out.value)
+
+    def issymmetric(self, matrix, kind: str = "symmetric", tolerance: float = 0.0) -> bool:
+        """lib.rs:3115-3124 (`ProviderSymmetryKind::{Symmetric, Skew}`): decided on the device, only the bool comes back."""
+        if kind not in ("symmetric", "skew"):
+            raise RmhipError(1, f"issymmetric: kind {kind!r}")
+        res = C.c_int()
+        self._check(self._lib.rmhip_issymmetric(self._ctx, self._id(matrix), 1 if kind == "skew" else 0, float(tolerance), C.byref(res)))
+        return bool(res.value)
+
     def random_uniform_like(self, prototype: GpuTensorHandle) -> GpuTensorHandle:
         """lib.rs:1718-1720: `random_uniform(&prototype.shape)`."""
         return self.random_uniform(prototype.shape)

@@ -18,7 +18,7 @@ use runmat_accelerate_api::{
     HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, KernelAttrTelemetry, KernelLaunchTelemetry, MatmulEpilogue,
     PowerStepEpilogue, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderFallbackStat, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderNanMode, ProviderPrecision, ProviderScanDirection,
-    ProviderStdNormalization, ProviderTelemetry, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult,
+    ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult,
 };
 use std::ffi::{c_char, c_int, c_void, CStr, CString};
 
@@ -482,6 +482,47 @@ impl AccelProvider for HipProvider {
         let mut out = 0u64;
         check(unsafe { rmhip_random_uniform(self.ctx, shape.as_ptr(), shape.len(), &mut out) })?;
         Ok(GpuTensorHandle { shape: shape.to_vec(), device_id: self.device_id, buffer_id: out })
+    }
+    // small construction / linear-algebra hooks (misc_ops.hip)
+    fn diag_from_vector(&self, vector: &GpuTensorHandle, offset: isize) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_diag_from_vector(self.ctx, self.own(vector)?, offset as i64, -1, -1, &mut out) })?;
+        self.handle(out)
+    }
+    fn diag_from_vector_sized(&self, vector: &GpuTensorHandle, offset: isize, rows: usize, cols: usize) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_diag_from_vector(self.ctx, self.own(vector)?, offset as i64, rows as i64, cols as i64, &mut out) })?;
+        self.handle(out)
+    }
+    fn kron(&self, a: &GpuTensorHandle, b: &GpuTensorHandle) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_kron(self.ctx, self.own(a)?, self.own(b)?, &mut out) })?;
+        self.handle(out)
+    }
+    // `dim` arrives ONE-based (cross.rs:231-238); None -> 0 = the first dimension of extent 3
+    fn cross(&self, lhs: &GpuTensorHandle, rhs: &GpuTensorHandle, dim: Option<usize>) -> Result<GpuTensorHandle> {
+        if dim == Some(0) {
+            return Err(anyhow!("cross: dimension must be >= 1"));
+        }
+        let mut out = 0u64;
+        check(unsafe { rmhip_cross(self.ctx, self.own(lhs)?, self.own(rhs)?, dim.unwrap_or(0) as c_int, &mut out) })?;
+        self.handle(out)
+    }
+    fn gradient_dim(&self, handle: &GpuTensorHandle, dim: usize, spacing: f64) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_gradient_dim(self.ctx, self.own(handle)?, dim as c_int, spacing, 0, &mut out) })?;
+        self.handle(out)
+    }
+    fn gradient_dim_with_coordinates(&self, handle: &GpuTensorHandle, dim: usize, coordinates: &GpuTensorHandle) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_gradient_dim(self.ctx, self.own(handle)?, dim as c_int, 1.0, self.own(coordinates)?, &mut out) })?;
+        self.handle(out)
+    }
+    fn issymmetric(&self, matrix: &GpuTensorHandle, kind: ProviderSymmetryKind, tolerance: f64) -> Result<bool> {
+        let mut res: c_int = 0;
+        let skew = matches!(kind, ProviderSymmetryKind::Skew) as c_int;
+        check(unsafe { rmhip_issymmetric(self.ctx, self.own(matrix)?, skew, tolerance, &mut res) })?;
+        Ok(res != 0)
     }
     // the prototype forms (lib.rs:1718-1730, 1832-1839: the trait's defaults, spelled out) and the scaled / transformed draws
     fn random_uniform_like(&self, prototype: &GpuTensorHandle) -> Result<GpuTensorHandle> { self.random_uniform(&prototype.shape) }

@@ -1,0 +1,138 @@
+"""GPU parity of the small construction / linear-algebra hooks (include/rmhip.h, misc_ops.hip): diag_from_vector(_sized), kron, cross,
+gradient_dim(_with_coordinates), issymmetric - one or two rounded operations per element: bit-exact against the oracle."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+K = json.loads((Path(__file__).parent / "golden" / "linear_hooks_kats.json").read_text())
+
+
+def arr(v, shape):
+    return np.array(v, dtype=np.float64).reshape(shape, order="F")
+
+
+def bits_equal(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    return got.shape == want.shape and np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+def test_reference_kats(prov):
+    for k in K["kron"]:
+        h = prov.kron(prov.upload(arr(k["a"], k["sa"])), prov.upload(arr(k["b"], k["sb"])))
+        assert list(h.shape) == k["so"] and np.array_equal(prov.download_matrix(h).ravel(order="F"), k["out"])
+    for k in K["cross"]:
+        h = prov.cross(prov.upload(arr(k["a"], k["shape"])), prov.upload(arr(k["b"], k["shape"])), k["dim"])
+        assert np.array_equal(prov.download_matrix(h).ravel(order="F"), k["out"])
+    for k in K["gradient"]:
+        hx = prov.upload(arr(k["x"], k["shape"]))
+        h = prov.gradient_dim(hx, k["dim"], k["spacing"]) if k["coords"] is None else \
+            prov.gradient_dim_with_coordinates(hx, k["dim"], prov.upload(np.array(k["coords"]).reshape(1, -1)))
+        assert np.array_equal(prov.download_matrix(h).ravel(order="F"), np.array(k["out"])), k
+    for k in K["issymmetric"]:
+        assert prov.issymmetric(prov.upload(arr(k["a"], k["shape"])), "skew" if k["skew"] else "symmetric", k["tol"]) == k["out"]
+
+
+@pytest.mark.parametrize("sa,sb", [((1, 1), (1, 1)), ((3, 4), (2, 5)), ((64, 3), (5, 70)), ((2, 3, 2), (3, 1, 2)), ((7,), (1, 9)), ((300, 200), (4, 3)),
+                                   ((0, 2), (1, 2)), ((2, 2, 2, 2), (1, 3))], ids=str)
+def test_kron(prov, oracle, sa, sb):
+    rng = np.random.default_rng(5)
+    a, b = rng.standard_normal(sa), rng.standard_normal(sb)
+    h = prov.kron(prov.upload(a), prov.upload(b))
+    want = oracle.kron(a.reshape(-1, 1) if a.ndim == 1 else a, b)
+    assert tuple(h.shape) == want.shape and bits_equal(prov.download_matrix(h), want)
+
+
+@pytest.mark.parametrize("shape", [(3, 1), (1, 3), (5, 3), (3, 5), (3, 3), (2, 3, 4), (1000, 3), (3, 100000), (7, 5, 3), (3, 3, 3)], ids=str)
+def test_cross(prov, oracle, shape):
+    rng = np.random.default_rng(6)
+    a, b = rng.standard_normal(shape), rng.standard_normal(shape)
+    ha, hb = prov.upload(a), prov.upload(b)
+    assert bits_equal(prov.download_matrix(prov.cross(ha, hb)), oracle.cross(a, b))
+    for d, ext in enumerate(shape):
+        if ext == 3:
+            assert bits_equal(prov.download_matrix(prov.cross(ha, hb, d + 1)), oracle.cross(a, b, d + 1))
+        else:
+            with pytest.raises(Exception):
+                prov.cross(ha, hb, d + 1)                                        # cross.rs:453-458
+    with pytest.raises(Exception):
+        prov.cross(ha, hb, len(shape) + 1)
+    with pytest.raises(Exception):
+        prov.cross(ha, prov.upload(rng.standard_normal(shape[::-1] if shape[::-1] != shape else (3, 2))))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (2, 1), (1, 2), (3, 1), (1, 9), (100, 7), (7, 100), (5, 6, 7), (100003, 2), (2, 100003)], ids=str)
+def test_gradient(prov, oracle, shape):
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(shape)
+    hx = prov.upload(x)
+    for dim in range(len(shape) + 1):
+        for h in (1.0, 0.37):
+            assert bits_equal(prov.download_matrix(prov.gradient_dim(hx, dim, h)), oracle.gradient(x, dim, h)), (shape, dim, h)
+        ext = shape[dim] if dim < len(shape) else 1
+        if ext >= 2:
+            c = np.cumsum(rng.uniform(0.5, 1.5, ext))
+            got = prov.gradient_dim_with_coordinates(hx, dim, prov.upload(c.reshape(-1, 1)))
+            assert bits_equal(prov.download_matrix(got), oracle.gradient(x, dim, coords=c)), (shape, dim)
+            with pytest.raises(Exception):
+                prov.gradient_dim_with_coordinates(hx, dim, prov.upload(np.zeros((ext + 1, 1))))   # gradient.rs:1022-1029
+
+
+def test_diag_from_vector(prov, oracle):
+    rng = np.random.default_rng(8)
+    for n in (1, 2, 5, 300, 4097):
+        v = rng.standard_normal(n)
+        for vec in (v.reshape(-1, 1), v.reshape(1, -1)):
+            hv = prov.upload(vec)
+            for off in (0, 1, -1, 7, -3):
+                h = prov.diag_from_vector(hv, off)
+                assert tuple(h.shape) == (n + abs(off),) * 2 and bits_equal(prov.download_matrix(h), oracle.diag_from_vector(v, off))
+                for rows, cols in ((n, n), (3, n + 9), (n + 2, 2), (1, 1)):
+                    hs = prov.diag_from_vector_sized(hv, off, rows, cols)
+                    assert bits_equal(prov.download_matrix(hs), oracle.diag_from_vector(v, off, rows, cols)), (n, off, rows, cols)
+    with pytest.raises(Exception):
+        prov.diag_from_vector(prov.upload(np.zeros((2, 3))), 0)                   # a matrix: simple_provider.rs:3225-3228
+
+
+def test_issymmetric(prov, oracle):
+    rng = np.random.default_rng(9)
+    for n in (1, 2, 17, 300, 2049):
+        a = rng.standard_normal((n, n))
+        s, k = a + a.T, a - a.T
+        cases = [(s, False, 0.0), (s, True, 0.0), (k, True, 0.0), (k, False, 0.0), (a, False, 0.0), (a, False, 100.0)]
+        if n > 1:
+            s2 = s.copy()
+            s2[0, n - 1] += 1e-9
+            cases += [(s2, False, 0.0), (s2, False, 1e-8)]
+            s3 = s.copy()
+            s3[1, 0] = s3[0, 1] = np.inf
+            cases += [(s3, False, 0.0)]
+            s4 = s.copy()
+            s4[1, 0] = np.nan
+            cases += [(s4, False, 1e300)]
+            k2 = k.copy()
+            k2[n - 1, n - 1] = 1e-12
+            cases += [(k2, True, 0.0), (k2, True, 1e-10)]
+        for m, skew, tol in cases:
+            assert prov.issymmetric(prov.upload(m), "skew" if skew else "symmetric", tol) == oracle.issymmetric(m, skew, tol), (n, skew, tol)
+    assert prov.issymmetric(prov.upload(np.zeros((3, 4)))) is False
+    with pytest.raises(Exception):
+        prov.issymmetric(prov.upload(np.zeros((2, 2, 2))))
+
+
+def test_full_size_properties(prov):
+    """BASELINE's 8192 x 8192 operand through gradient (against numpy's formula element for element) and issymmetric."""
+    n = 8192
+    h = prov.fill_uniform(3, -1.0, 1.0, (n, n))
+    x = prov.download_matrix(h)
+    for dim in (0, 1):
+        g = prov.download_matrix(prov.gradient_dim(h, dim, 0.25))
+        inner = (np.take(x, range(2, n), axis=dim) - np.take(x, range(0, n - 2), axis=dim)) / 0.5
+        assert np.array_equal(np.take(g, range(1, n - 1), axis=dim), inner)
+    assert prov.issymmetric(h) is False
+    ht = prov.transpose(h)
+    sym = prov.elem_add(h, ht)
+    assert prov.issymmetric(sym) is True

@@ -1,0 +1,58 @@
+"""The oracle's restatements of diag_from_vector, kron, cross, gradient and issymmetric against the reference's own unit-test vectors
+(tests/golden/linear_hooks_kats.json) and against numpy where numpy computes the same thing."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+K = json.loads((Path(__file__).parent / "golden" / "linear_hooks_kats.json").read_text())
+
+
+def arr(v, shape):
+    return np.array(v, dtype=np.float64).reshape(shape, order="F")
+
+
+def test_reference_kats():
+    for k in K["kron"]:
+        out = oracle.kron(arr(k["a"], k["sa"]), arr(k["b"], k["sb"]))
+        assert list(out.shape) == k["so"] and np.array_equal(out.ravel(order="F"), k["out"])
+    for k in K["cross"]:
+        out = oracle.cross(arr(k["a"], k["shape"]), arr(k["b"], k["shape"]), k["dim"])
+        assert np.array_equal(out.ravel(order="F"), k["out"])
+    for k in K["gradient"]:
+        out = oracle.gradient(arr(k["x"], k["shape"]), k["dim"], k["spacing"], k["coords"])
+        assert np.array_equal(out.ravel(order="F"), np.array(k["out"])), k
+    for k in K["issymmetric"]:
+        assert oracle.issymmetric(arr(k["a"], k["shape"]), k["skew"], k["tol"]) == k["out"]
+
+
+def test_against_numpy():
+    rng = np.random.default_rng(2)
+    a, b = rng.standard_normal((3, 4)), rng.standard_normal((2, 5))
+    assert np.array_equal(oracle.kron(a, b), np.kron(a, b))
+    a3, b3 = rng.standard_normal((2, 3, 2)), rng.standard_normal((3, 1, 2))
+    assert np.array_equal(oracle.kron(a3, b3), np.kron(a3, b3))
+    assert oracle.kron(np.zeros((0, 2)), b).shape == (0, 10)                      # kron.rs:704-712
+    u, v = rng.standard_normal((5, 3, 4)), rng.standard_normal((5, 3, 4))
+    assert np.allclose(oracle.cross(u, v), np.cross(u, v, axis=1), rtol=0, atol=1e-15)
+    x = rng.standard_normal((7, 6, 3))
+    for d in range(3):
+        assert np.allclose(oracle.gradient(x, d, 0.5), np.gradient(x, 0.5, axis=d), rtol=0, atol=1e-14)
+    assert np.array_equal(oracle.gradient(x, 3), np.zeros_like(x))                 # a dimension beyond the rank: extent one
+    v = rng.standard_normal(5)
+    for off in (-2, 0, 3):
+        assert np.array_equal(oracle.diag_from_vector(v, off), np.diag(v, off))
+    assert np.array_equal(oracle.diag_from_vector(v, 1, 3, 4), np.diag(v, 1)[:3, :4])
+    s = a @ a.T
+    assert oracle.issymmetric(s) and not oracle.issymmetric(a) and oracle.issymmetric(s - s.T, True)
+    s2 = s.copy()
+    s2[0, 1] += 1e-9
+    assert not oracle.issymmetric(s2) and oracle.issymmetric(s2, tol=1e-8)
+    s2[1, 2] = s2[2, 1] = np.nan
+    assert not oracle.issymmetric(s2, tol=1.0)                                      # NaN never equals, never within (issymmetric.rs:517-526)
+    s3 = s.copy()
+    s3[0, 1] = s3[1, 0] = np.inf
+    assert oracle.issymmetric(s3)                                                   # equal infinities pass the == test
