@@ -418,6 +418,13 @@ RMHIP_API int rmhip_mldivide(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf
  * back); here the same transposition around the LU solve, with the same soft failures as rmhip_mldivide. */
 /* @serves mrdivide */
 RMHIP_API int rmhip_mrdivide(rmhip_ctx* ctx, rmhip_buf b, rmhip_buf a, rmhip_buf* out);
+/* `inv(matrix, options)` (lib.rs:2430-2436, ProviderInvOptions {} :716; CPU inv.rs:209-230, 258-280: nalgebra 0.32.6 `try_inverse`, an LU
+ * with partial pivoting and substitutions on the identity - absent from /root/reference, parity by residual as for mldivide): X = A \ I on
+ * the LU path.  Scalars, [n, n] and [n, n, 1, ...] operands (the shape is kept); a non-square or higher-rank operand is
+ * RMHIP_ERR_INVALID with the reference's wording; a pivot below the solver's cut-off is RMHIP_ERR_SINGULAR (the CPU path then raises
+ * "matrix is singular to working precision" or returns nalgebra's answer for a pivot in (0, 1e-12]).  [0, 0] gives [0, 0]. */
+/* @serves inv */
+RMHIP_API int rmhip_inv(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out);
 /* `linsolve` + ProviderLinsolveOptions / ProviderLinsolveResult (lib.rs:2422-2429, 679-697); CPU
  * semantics crates/runmat-runtime/src/builtins/math/linalg/solve/linsolve.rs:691-726 (option order:
  * TRANSA transposes A and swaps LT<->UT), 769-833 (substitution; a zero diagonal entry is the

@@ -421,6 +421,12 @@ public:
         check(rmhip_mldivide(ctx_, own(lhs), own(rhs), &out));
         return with_shape(out);
     }
+    // lib.rs:2430-2436 (ProviderInvOptions is empty)
+    GpuTensorHandle inv(const GpuTensorHandle& matrix) const {
+        uint64_t out = 0;
+        check(rmhip_inv(ctx_, own(matrix), &out));
+        return with_shape(out);
+    }
     GpuTensorHandle mrdivide(const GpuTensorHandle& lhs, const GpuTensorHandle& rhs) const {
         uint64_t out = 0;
         check(rmhip_mrdivide(ctx_, own(lhs), own(rhs), &out));

@@ -1530,3 +1530,59 @@ ORC_API int orc_issymmetric(const double* data, size_t rows, size_t cols, int sk
     }
     return 1;
 }
+
+/* inv: the reference calls nalgebra 0.32.6 `DMatrix::try_inverse` (inv.rs:224-228) - a third-party dependency that is not under
+ * /root/reference (Cargo.lock pins it).  Its published algorithm for dynamic sizes: LU with partial (row) pivoting, pivot = the entry
+ * of largest magnitude in the column, `None` when a pivot is exactly zero, then the inverse by substitutions on the permuted identity.
+ * Restated here; parity of the solution is by residual / forward error, as for mldivide (bit-level parity unpinned).
+ * Returns 0, or 1 when a pivot is exactly zero ("matrix is singular to working precision"). */
+ORC_API int orc_inv(const double* a, size_t n, double* out) {
+    double* lu = (double*)malloc(n * n * sizeof(double));
+    size_t* perm = (size_t*)malloc(n * sizeof(size_t));
+    memcpy(lu, a, n * n * sizeof(double));
+    for (size_t i = 0; i < n; ++i) perm[i] = i;
+    int singular = 0;
+    for (size_t k = 0; k < n && !singular; ++k) {
+        size_t p = k;
+        double best = fabs(lu[k + k * n]);
+        for (size_t i = k + 1; i < n; ++i)
+            if (fabs(lu[i + k * n]) > best) {
+                best = fabs(lu[i + k * n]);
+                p = i;
+            }
+        if (best == 0.0) {
+            singular = 1;
+            break;
+        }
+        if (p != k) {
+            for (size_t j = 0; j < n; ++j) {
+                const double t = lu[k + j * n];
+                lu[k + j * n] = lu[p + j * n];
+                lu[p + j * n] = t;
+            }
+            const size_t t = perm[k];
+            perm[k] = perm[p];
+            perm[p] = t;
+        }
+        const double piv = lu[k + k * n];
+        for (size_t i = k + 1; i < n; ++i) lu[i + k * n] /= piv;
+        for (size_t j = k + 1; j < n; ++j) {
+            const double u = lu[k + j * n];
+            for (size_t i = k + 1; i < n; ++i) lu[i + j * n] -= lu[i + k * n] * u;
+        }
+    }
+    if (!singular)
+        for (size_t c = 0; c < n; ++c) {
+            double* x = out + c * n;
+            for (size_t i = 0; i < n; ++i) x[i] = perm[i] == c ? 1.0 : 0.0;  /* P e_c */
+            for (size_t i = 0; i < n; ++i)
+                for (size_t j = 0; j < i; ++j) x[i] -= lu[i + j * n] * x[j];
+            for (size_t ii = n; ii-- > 0;) {
+                for (size_t j = ii + 1; j < n; ++j) x[ii] -= lu[ii + j * n] * x[j];
+                x[ii] /= lu[ii + ii * n];
+            }
+        }
+    free(lu);
+    free(perm);
+    return singular;
+}

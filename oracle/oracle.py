@@ -761,3 +761,17 @@ def issymmetric(a: np.ndarray, skew: bool = False, tol: float = 0.0) -> bool:
     l.orc_issymmetric.restype = C.c_int
     l.orc_issymmetric.argtypes = [_DP, C.c_size_t, C.c_size_t, C.c_int, C.c_double]
     return bool(l.orc_issymmetric(_p(_f(a)), rows, cols, int(skew), float(tol)))
+
+
+def inv(a: np.ndarray):
+    """The inverse of a square matrix by LU with partial pivoting (the published algorithm of nalgebra's try_inverse, inv.rs:224-228), or
+    None when a pivot is exactly zero."""
+    a = np.asarray(a, dtype=np.float64)
+    n = a.shape[0]
+    out = np.empty(n * n)
+    l = lib()
+    l.orc_inv.restype = C.c_int
+    l.orc_inv.argtypes = [_DP, C.c_size_t, _DP]
+    if l.orc_inv(_p(_f(a)), n, _p(out)):
+        return None
+    return out.reshape((n, n), order="F")

@@ -180,6 +180,7 @@ struct Context {
     bool one_xcd_ok = true;  // LU panels may place their blocks on one XCD (cleared when such a panel timed out once)
     bool lu_used_one_xcd = false;
     bool lu_last_fast = false;  // the last lu_factor_device call restricted pivoting to the panels' top blocks (mode 1 taken, not merely asked for)
+    bool solve_strict = false;  // a refused square solve stays refused (inv): no SVD answer for a singular matrix
     double lu_last_growth = 0.0;       // largest multiplier the last solve-path factorisation saw below its top blocks
     uint64_t lu_fast_count = 0, lu_growth_fallbacks = 0;  // solve-path factorisations accepted / refactored with the grid-wide rule
     uint64_t lu_exchange_timeouts = 0, lu_subst_timeouts = 0;

@@ -1139,6 +1139,54 @@ int rmhip_mldivide(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf* out) {
     return count_fallback(c, mldivide_impl(ctx, c, a, b, out), "mldivide:unsupported", "mldivide:singular");
 }
 
+int rmhip_inv(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer ab;
+    RMHIP_TRY(c->get_raw(a, &ab));
+    // matrix_dimensions + inv_real_tensor_impl (inv.rs:209-230, 258-280)
+    const std::vector<size_t>& s = ab.shape;
+    size_t rows = 1, cols = 1;
+    if (s.size() == 1) {
+        if (s[0] != 1) return fail(RMHIP_ERR_INVALID, "inv: input must be a square matrix.");
+    } else if (s.size() >= 2) {
+        for (size_t d = 2; d < s.size(); ++d)
+            if (s[d] != 1) return fail(RMHIP_ERR_INVALID, "inv: inputs must be 2-D matrices.");
+        rows = s[0];
+        cols = s[1];
+    }
+    if (rows != cols) return fail(RMHIP_ERR_INVALID, "inv: input must be a square matrix.");
+    if (rows == 0) {
+        Buffer ob;
+        return c->new_buffer(s.data(), s.size(), out, &ob);
+    }
+    // X = A \ I on the LU path (the CPU's nalgebra `try_inverse` is the same factorisation followed by the same substitutions); a pivot
+    // below the solver's cut-off is RMHIP_ERR_SINGULAR and the caller's CPU path words the "singular to working precision" error
+    rmhip_buf eye = 0, x = 0, same = 0;
+    const size_t sq[2] = {rows, rows};
+    const std::vector<size_t> given = s;  // (rmhip_reshape renames the shape of the SAME buffer: the operand gets its own back below)
+    int rc = rmhip_eye(ctx, sq, 2, &eye);
+    const bool reshaped = !rc && given.size() != 2;
+    if (reshaped) rc = rmhip_reshape(ctx, a, sq, 2, &same);
+    if (!rc) {
+        c->solve_strict = true;  // mldivide answers a singular square system with the minimum-norm solution; inv must not
+        rc = count_fallback(c, mldivide_impl(ctx, c, a, eye, &x), "inv:unsupported", "inv:singular");
+        c->solve_strict = false;
+    }
+    if (reshaped) rmhip_reshape(ctx, a, given.data(), given.size(), &same);
+    if (eye) rmhip_free(ctx, eye);
+    if (rc) return rc;
+    if (given.size() > 2) {  // inv.rs:402-412: a trailing singleton dimension is kept
+        rc = rmhip_reshape(ctx, x, given.data(), given.size(), &same);
+        if (rc) {
+            rmhip_free(ctx, x);
+            return rc;
+        }
+    }
+    *out = x;
+    return RMHIP_OK;
+}
+
 int rmhip_mrdivide(rmhip_ctx* ctx, rmhip_buf b, rmhip_buf a, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);
     ScopedTimer timer(&c->tel.mrdivide_count, &c->tel.mrdivide_ns);
@@ -1276,7 +1324,7 @@ static int lstsq_full_rank(rmhip_ctx* ctx, Context* c, const double* A, size_t m
 // system: minimum-norm least squares from an SVD with its tolerance rule (svdsolve.hip), as long as min(rows, cols) <= svd_max_cols().
 // `refused` is the status of the path that gave up (returned unchanged when the system is too large for the SVD path).
 static int svd_fallback(rmhip_ctx* ctx, Context* c, int refused, const double* A, size_t m, size_t n, const double* B, size_t nrhs, rmhip_buf* out) {
-    if ((m < n ? m : n) > (size_t)svd_max_cols() || std::getenv("RMHIP_NO_SVD_PATH")) return refused;
+    if (c->solve_strict || (m < n ? m : n) > (size_t)svd_max_cols() || std::getenv("RMHIP_NO_SVD_PATH")) return refused;
     Buffer ob;
     rmhip_buf oid = 0;
     const size_t oshape[2] = {n, nrhs};

@@ -646,6 +646,12 @@ class HipProvider:
         self._check(self._lib.rmhip_mrdivide(self._ctx, self._id(lhs), self._id(rhs), C.byref(out)))
         return self._handle(out.value)
 
+    def inv(self, matrix: GpuTensorHandle, options=None) -> GpuTensorHandle:
+        """`inv` (lib.rs:2430-2436; `ProviderInvOptions {}`): X = A \\ I on the LU path; SINGULAR -> the caller's CPU path (inv.rs:225-227)."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_inv(self._ctx, self._id(matrix), C.byref(out)))
+        return self._handle(out.value)
+
     def stochastic_evolution(self, state: GpuTensorHandle, drift: float, scale: float, steps: int,
                              draws_per_step: int = 0) -> GpuTensorHandle:
         """lib.rs:1759-1769; `draws_per_step` > 0 selects the sharded form (see include/rmhip.h)."""

@@ -16,7 +16,7 @@ use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, GpuTensorHandle,
     HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, KernelAttrTelemetry, KernelLaunchTelemetry, MatmulEpilogue,
-    PowerStepEpilogue, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderFallbackStat, ProviderLinsolveOptions,
+    PowerStepEpilogue, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderNanMode, ProviderPrecision, ProviderScanDirection,
     ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult,
 };
@@ -390,6 +390,14 @@ impl AccelProvider for HipProvider {
         Box::pin(async move {
             let mut out = 0u64;
             check(unsafe { rmhip_mldivide(self.ctx, self.own(lhs)?, self.own(rhs)?, &mut out) })?;
+            self.handle(out)
+        })
+    }
+    // inv(A) = A \ I on the LU path; Err (singular, non-square) sends inv.rs back to its host code, which words the error
+    fn inv<'a>(&'a self, matrix: &'a GpuTensorHandle, _options: ProviderInvOptions) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_inv(self.ctx, self.own(matrix)?, &mut out) })?;
             self.handle(out)
         })
     }

@@ -136,3 +136,37 @@ def test_full_size_properties(prov):
     ht = prov.transpose(h)
     sym = prov.elem_add(h, ht)
     assert prov.issymmetric(sym) is True
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 65, 300, 1153])
+def test_inv_matches_the_oracle(prov, oracle, n):
+    """inv = A \\ I on the LU path against the restated partial-pivoting inverse: forward error within cond * eps * n, residual
+    ||A X - I|| at rounding level (the reference's own tests ask 1e-12 on a 2 x 2, inv.rs:365-383)."""
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal((n, n)) + np.sqrt(n) * np.eye(n)
+    h = prov.inv(prov.upload(a))
+    x = prov.download_matrix(h)
+    assert x.shape == (n, n)
+    want = oracle.inv(a)
+    cond = np.linalg.cond(a)
+    assert np.max(np.abs(x - want)) <= 50 * cond * np.finfo(float).eps * np.max(np.abs(want)), (n, cond)
+    assert np.max(np.abs(a @ x - np.eye(n))) <= 1e-12 * n
+
+
+def test_inv_shapes_and_errors(prov):
+    assert np.array_equal(prov.download_matrix(prov.inv(prov.upload(np.array([[4.0]])))), [[0.25]])
+    h = prov.inv(prov.upload(np.array([4.0, 0.0, 0.0, 2.0]).reshape(2, 2, 1)))
+    assert tuple(h.shape) == (2, 2, 1) and np.array_equal(prov.download(h).ravel(), [0.25, 0.0, 0.0, 0.5])   # inv.rs:402-412
+    assert tuple(prov.inv(prov.upload(np.zeros((0, 0)))).shape) == (0, 0)                                  # inv.rs:388-396
+    for bad in (np.zeros((2, 3)), np.ones((2, 2, 2)), np.array([[1.0, 2.0], [2.0, 4.0]]), np.zeros((3, 1))):
+        with pytest.raises(Exception):
+            prov.inv(prov.upload(bad))
+    tel = prov.telemetry_snapshot()
+    assert any("inv:singular" in str(r) for r in tel.get("solve_fallbacks", [])), tel.get("solve_fallbacks")
+
+
+def test_inv_residual_at_4096(prov):
+    n = 4096
+    a = np.random.default_rng(1).standard_normal((n, n)) + np.sqrt(n) * np.eye(n)
+    x = prov.download_matrix(prov.inv(prov.upload(a)))
+    assert np.max(np.abs(a @ x - np.eye(n))) <= 1e-12 * n

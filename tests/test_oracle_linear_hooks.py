@@ -56,3 +56,16 @@ def test_against_numpy():
     s3 = s.copy()
     s3[0, 1] = s3[1, 0] = np.inf
     assert oracle.issymmetric(s3)                                                   # equal infinities pass the == test
+
+
+def test_inv_restatement_on_the_reference_vectors_and_against_numpy():
+    """inv.rs:365-383 (A = [4 -2; 1 3]: A * inv(A) = I to 1e-12), :402-412 (diag(4, 2) -> diag(0.25, 0.5) exactly), :484-488 (singular)."""
+    a = np.array([4.0, 1.0, -2.0, 3.0]).reshape(2, 2, order="F")
+    x = oracle.inv(a)
+    assert np.max(np.abs(a @ x - np.eye(2))) < 1e-12
+    assert np.array_equal(oracle.inv(np.diag([4.0, 2.0])), np.diag([0.25, 0.5]))
+    assert oracle.inv(np.array([[1.0, 2.0], [2.0, 4.0]])) is None
+    rng = np.random.default_rng(4)
+    for n in (1, 3, 50, 200):
+        m = rng.standard_normal((n, n)) + n * np.eye(n)
+        assert np.max(np.abs(oracle.inv(m) - np.linalg.inv(m))) <= 1e-13
