@@ -328,6 +328,15 @@ RMHIP_API int rmhip_sort_dim(rmhip_ctx* ctx, rmhip_buf a, int dim, int descend, 
 /* @serves reduce_median reduce_median_dim */
 RMHIP_API int rmhip_reduce_median(rmhip_ctx* ctx, rmhip_buf a, int dim, rmhip_buf* out);
 
+/* `find(a, limit, direction)` (lib.rs:2937-2944 -> ProviderFindResult { linear, rows, cols, values } :623-628; find.rs:593-633,
+ * simple_provider.rs:7500-7575): the elements != 0 (a NaN counts) in ascending linear order (last == 0) or in DESCENDING order from the
+ * end (last != 0), at most `limit` of them - limit < 0 is `None`: everything for first, ONE for last.  Four [count, 1] outputs: 1-based
+ * linear indices, rows = idx % extent0 + 1, cols = idx / extent0 + 1, and the values.  Index work: bit-exact.  Synchronises the stream
+ * once (the count sizes the outputs).  In a precision-32 context the index outputs are stored as f32 like every other buffer: exact up to
+ * 2^24 elements. */
+/* @serves find */
+RMHIP_API int rmhip_find(rmhip_ctx* ctx, rmhip_buf a, long long limit_or_neg, int last, rmhip_buf* linear, rmhip_buf* rows, rmhip_buf* cols,
+                         rmhip_buf* values);
 /* ---- small construction / linear-algebra hooks (runmat_amd/csrc/misc_ops.hip): one or two rounded operations per element, bit-exact ----
  * `diag_from_vector(vector, offset)` / `diag_from_vector_sized(vector, offset, rows, cols)` (lib.rs:1600-1623; simple_provider.rs:3222-3281):
  * element idx of a vector-like operand on (idx, idx + offset) or (idx - offset, idx), zeros elsewhere; rows / cols < 0 = the square of

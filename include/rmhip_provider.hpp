@@ -376,6 +376,15 @@ public:
         free(hi);
         return r;
     }
+    // lib.rs:2937-2944 -> ProviderFindResult (lib.rs:623-628); limit < 0 = None; last = FindDirection::Last
+    struct FindResult {
+        GpuTensorHandle linear, rows, cols, values;
+    };
+    FindResult find(const GpuTensorHandle& a, long long limit_or_neg, bool last) const {
+        uint64_t l = 0, r = 0, c = 0, v = 0;
+        check(rmhip_find(ctx_, own(a), limit_or_neg, last ? 1 : 0, &l, &r, &c, &v));
+        return {with_shape(l), with_shape(r), with_shape(c), with_shape(v)};
+    }
     // lib.rs:2833-2845
     GpuTensorHandle reduce_median(const GpuTensorHandle& a) const { return median_(a, -1); }
     GpuTensorHandle reduce_median_dim(const GpuTensorHandle& a, size_t dim) const { return median_(a, (int)dim); }

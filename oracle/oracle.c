@@ -1586,3 +1586,23 @@ ORC_API int orc_inv(const double* a, size_t n, double* out) {
     free(perm);
     return singular;
 }
+
+/* find (builtins/array/indexing/find.rs:593-633; simple_provider.rs:7500-7575): linear indices (1-based) of the elements != 0 (a NaN is
+ * nonzero) in ascending order (direction first) or DESCENDING order from the end (last), at most `cap` of them; rows / cols from the
+ * first extent.  Returns the number found (<= cap). */
+ORC_API size_t orc_find(const double* data, size_t len, size_t row_extent, size_t cap, int last, double* linear, double* rows, double* cols,
+                        double* values) {
+    size_t n = 0;
+    if (row_extent == 0) row_extent = 1;
+    for (size_t s = 0; s < len && n < cap; ++s) {
+        const size_t idx = last ? len - 1 - s : s;
+        if (data[idx] != 0.0) {
+            linear[n] = (double)(idx + 1);
+            rows[n] = (double)(idx % row_extent + 1);
+            cols[n] = (double)(idx / row_extent + 1);
+            values[n] = data[idx];
+            ++n;
+        }
+    }
+    return n;
+}

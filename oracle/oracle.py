@@ -775,3 +775,17 @@ def inv(a: np.ndarray):
     if l.orc_inv(_p(_f(a)), n, _p(out)):
         return None
     return out.reshape((n, n), order="F")
+
+
+def find(x: np.ndarray, limit=None, last: bool = False):
+    """find.rs:593-633 / simple_provider.rs:7500-7575: (linear, rows, cols, values), each [count, 1]; limit None = all (first) or 1 (last)."""
+    x = np.asarray(x, dtype=np.float64)
+    fx = _f(x)
+    cap = fx.size if (limit is None and not last) else (1 if limit is None else int(limit))
+    cap = min(cap, fx.size)
+    outs = [np.empty(max(cap, 1)) for _ in range(4)]
+    l = lib()
+    l.orc_find.restype = C.c_size_t
+    l.orc_find.argtypes = [_DP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _DP, _DP, _DP, _DP]
+    n = l.orc_find(_p(fx), fx.size, max(x.shape[0] if x.ndim else 1, 1), cap, int(last), *[_p(o) for o in outs])
+    return tuple(o[:n].reshape(-1, 1) for o in outs)

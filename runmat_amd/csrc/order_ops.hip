@@ -519,6 +519,74 @@ int sort_lines(Context* c, const double* x, Lines g, int descend, int by_abs, So
     return RMHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// find: ordered stream compaction.  A wave owns FIND_ROWS rows of 64 consecutive scan positions; pass 1 counts its nonzeros, one
+// workgroup turns the counts into offsets, pass 2 places every nonzero at offset + (number of nonzeros before it in the wave).
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int FIND_ROWS = 16;
+
+__global__ void __launch_bounds__(256) k_find_count(const double* __restrict__ x, u64 n, int last, u32* __restrict__ counts, u64 nchunks) {
+    const u64 w = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= nchunks) return;
+    u32 cnt = 0;
+#pragma unroll 4
+    for (int r = 0; r < FIND_ROWS; ++r) {
+        const u64 p = (w * FIND_ROWS + r) * 64 + lane;
+        const bool nz = p < n && x[last ? n - 1 - p : p] != 0.0;
+        cnt += (u32)__popcll(__ballot(nz));
+    }
+    if (lane == 0) counts[w] = cnt;
+}
+
+// exclusive scan of the chunk counts by ONE workgroup: thread t owns a run of consecutive chunks
+__global__ void __launch_bounds__(1024) k_find_scan(const u32* __restrict__ counts, u64 nchunks, u64* __restrict__ offsets, u64* __restrict__ total) {
+    __shared__ u64 run[1024];
+    const int t = threadIdx.x;
+    const u64 per = (nchunks + 1023) / 1024;
+    const u64 c0 = (u64)t * per, c1 = (c0 + per < nchunks) ? c0 + per : nchunks;
+    u64 sum = 0;
+    for (u64 ch = c0; ch < c1; ++ch) sum += counts[ch];
+    run[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const u64 add = t >= d ? run[t - d] : 0;
+        __syncthreads();
+        run[t] += add;
+        __syncthreads();
+    }
+    u64 off = t > 0 ? run[t - 1] : 0;
+    for (u64 ch = c0; ch < c1; ++ch) {
+        offsets[ch] = off;
+        off += counts[ch];
+    }
+    if (t == 1023) *total = run[1023];
+}
+
+__global__ void __launch_bounds__(256) k_find_emit(const double* __restrict__ x, u64 n, int last, const u64* __restrict__ offsets, u64 nchunks, u64 count,
+                                                   u64 row_extent, double* __restrict__ linear, double* __restrict__ rows, double* __restrict__ cols,
+                                                   double* __restrict__ values) {
+    const u64 w = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= nchunks) return;
+    u64 off = offsets[w];
+    for (int r = 0; r < FIND_ROWS && off < count; ++r) {
+        const u64 p = (w * FIND_ROWS + r) * 64 + lane;
+        const u64 idx = last ? n - 1 - p : p;
+        const double v = p < n ? x[idx] : 0.0;
+        const bool nz = p < n && v != 0.0;
+        const u64 mask = __ballot(nz);
+        const u64 at = off + (u64)__popcll(mask & ((1ull << lane) - 1ull));
+        if (nz && at < count) {
+            linear[at] = (double)(idx + 1);
+            rows[at] = (double)(idx % row_extent + 1);
+            cols[at] = (double)(idx / row_extent + 1);
+            values[at] = v;
+        }
+        off += (u64)__popcll(mask);
+    }
+}
+
 int lines_of(const std::vector<size_t>& shape, int dim, const char* what, Lines* g) {
     if (dim < 0 || (size_t)dim >= shape.size()) return fail(RMHIP_ERR_UNSUPPORTED, "%s: dim %d out of range for rank %zu", what, dim, shape.size());
     g->pre = g->post = 1;
@@ -653,5 +721,52 @@ int rmhip_reduce_median(rmhip_ctx* ctx, rmhip_buf a, int dim, rmhip_buf* out) {
         }
     }
     if (rc) rmhip_free(ctx, *out);
+    return rc;
+}
+
+int rmhip_find(rmhip_ctx* ctx, rmhip_buf a, long long limit_or_neg, int last, rmhip_buf* linear, rmhip_buf* rows, rmhip_buf* cols, rmhip_buf* values) {
+    CTX_OR_FAIL(ctx);
+    if (!linear || !rows || !cols || !values) return fail(RMHIP_ERR_INVALID, "find: null output");
+    *linear = *rows = *cols = *values = 0;
+    Buffer ab;
+    RMHIP_TRY(c->get(a, &ab));
+    const u64 n = ab.numel;
+    // simple_provider.rs:7513-7517: first -> limit or everything, last -> limit or ONE
+    u64 cap = limit_or_neg >= 0 ? (u64)limit_or_neg : (last ? 1ull : n);
+    if (cap > n) cap = n;
+    u64 count = 0;
+    std::shared_ptr<Allocation> ws;
+    u64* offsets = nullptr;
+    const u64 nchunks = (n + 64 * FIND_ROWS - 1) / (64 * FIND_ROWS);
+    if (cap > 0) {
+        RMHIP_TRY(c->alloc_device(nchunks + (nchunks + 1) / 2 + 2, &ws));  // offsets (u64), total (u64), counts (u32)
+        offsets = (u64*)ws->ptr;
+        u64* total = offsets + nchunks;
+        u32* counts = (u32*)(total + 1);
+        hipLaunchKernelGGL(k_find_count, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, c->stream, ab.data(), n, last ? 1 : 0, counts, nchunks);
+        hipLaunchKernelGGL(k_find_scan, dim3(1), dim3(1024), 0, c->stream, counts, nchunks, offsets, total);
+        c->tel.kernel_launches += 2;
+        RMHIP_HIP_CHECK(hipGetLastError());
+        unsigned long long found = 0;
+        RMHIP_HIP_CHECK(hipMemcpyAsync(&found, total, sizeof(found), hipMemcpyDeviceToHost, c->stream));
+        RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));  // the outputs' size is the answer
+        count = found < cap ? found : cap;
+    }
+    const size_t oshape[2] = {(size_t)count, 1};
+    Buffer lb, rb, cb, vb;
+    rmhip_buf* outs[4] = {linear, rows, cols, values};
+    Buffer* bufs[4] = {&lb, &rb, &cb, &vb};
+    int rc = RMHIP_OK;
+    for (int i = 0; i < 4 && rc == RMHIP_OK; ++i) rc = c->new_buffer(oshape, 2, outs[i], bufs[i]);
+    if (rc == RMHIP_OK && count > 0) {
+        const u64 row_extent = ab.shape.empty() || ab.shape[0] == 0 ? 1 : ab.shape[0];
+        hipLaunchKernelGGL(k_find_emit, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, c->stream, ab.data(), n, last ? 1 : 0, offsets, nchunks, count, row_extent,
+                           lb.data(), rb.data(), cb.data(), vb.data());
+        c->tel.kernel_launches++;
+        if (hipGetLastError() != hipSuccess) rc = fail(RMHIP_ERR_HIP, "find: launch failed");
+    }
+    if (rc)
+        for (int i = 0; i < 4; ++i)
+            if (*outs[i]) rmhip_free(ctx, *outs[i]);
     return rc;
 }

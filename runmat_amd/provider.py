@@ -72,6 +72,15 @@ class ReductionFlavor:
 
 
 @dataclass
+class ProviderFindResult:
+    """`ProviderFindResult` (lib.rs:623-628); `values` is always present here."""
+    linear: "GpuTensorHandle"
+    rows: "GpuTensorHandle"
+    cols: "GpuTensorHandle"
+    values: "GpuTensorHandle"
+
+
+@dataclass
 class SortResult:
     """`SortResult` (lib.rs:1085-1088): host tensors."""
     values: np.ndarray
@@ -570,6 +579,15 @@ class HipProvider:
         finally:
             self.free(hv)
             self.free(hi)
+
+    def find(self, a, limit: Optional[int] = None, direction: str = "first") -> "ProviderFindResult":
+        """lib.rs:2937-2944 (`FindDirection::{First, Last}`) -> `ProviderFindResult{linear, rows, cols, values}` (:623-628)."""
+        if direction not in ("first", "last"):
+            raise RmhipError(1, f"find: direction {direction!r}")
+        outs = [C.c_uint64() for _ in range(4)]
+        self._check(self._lib.rmhip_find(self._ctx, self._id(a), -1 if limit is None else int(limit), 1 if direction == "last" else 0,
+                                         *[C.byref(o) for o in outs]))
+        return ProviderFindResult(*[self._handle(o.value) for o in outs])
 
     def reduce_median(self, a) -> GpuTensorHandle:
         """lib.rs:2833-2838: the median of ALL elements -> [1, 1] (NaN if any element is NaN; simple_provider.rs:7167-7193)."""

@@ -41,6 +41,16 @@ for dim in (0, 1):
         prov._check(lib.rmhip_free(prov._ctx, sv)); prov._check(lib.rmhip_free(prov._ctx, si))
         return []
     timed(f"sort_dim 8192^2 dim {dim} (device part)", sort_device, 24 * e, reps=2)
+def find_device(hx, limit=-1, last=0):
+    outs = [C.c_uint64() for _ in range(4)]
+    prov._check(lib.rmhip_find(prov._ctx, hx.buffer_id, limit, last, *[C.byref(o) for o in outs]))
+    for o in outs: prov._check(lib.rmhip_free(prov._ctx, o))
+    return []
+dense = prov.elem_gt(h, prov.fill((n, n), 0.0))
+sparse = prov.elem_gt(h, prov.fill((n, n), 0.999))
+timed("find 8192^2, half of the elements nonzero", lambda: find_device(dense), 8 * e + 32 * e // 2)
+timed("find 8192^2, 0.05 % nonzero", lambda: find_device(sparse), 8 * e)
+timed("find 8192^2, first 10 (limit)", lambda: find_device(dense, 10), 8 * e)
 prov.free(h)
 for m in (10**6, 10**7, 10**8):
     v = prov.fill_uniform(6, -1.0, 1.0, (m, 1))

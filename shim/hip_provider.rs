@@ -14,9 +14,9 @@
 
 use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
-    AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, GpuTensorHandle,
+    AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle,
     HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, KernelAttrTelemetry, KernelLaunchTelemetry, MatmulEpilogue,
-    PowerStepEpilogue, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderLinsolveOptions,
+    PowerStepEpilogue, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderNanMode, ProviderPrecision, ProviderScanDirection,
     ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult,
 };
@@ -349,6 +349,14 @@ impl AccelProvider for HipProvider {
             self.free(&hi)?;
             Ok(SortResult { values: values?, indices: indices? })
         })
+    }
+    // find -> ProviderFindResult { linear, rows, cols, values: Some(..) } (lib.rs:2937-2944, 623-628)
+    fn find(&self, a: &GpuTensorHandle, limit: Option<usize>, direction: FindDirection) -> Result<ProviderFindResult> {
+        let (mut l, mut r, mut c, mut v) = (0u64, 0u64, 0u64, 0u64);
+        let last = matches!(direction, FindDirection::Last) as c_int;
+        let lim = limit.map(|k| k as i64).unwrap_or(-1);
+        check(unsafe { rmhip_find(self.ctx, self.own(a)?, lim, last, &mut l, &mut r, &mut c, &mut v) })?;
+        Ok(ProviderFindResult { linear: self.handle(l)?, rows: self.handle(r)?, cols: self.handle(c)?, values: Some(self.handle(v)?) })
     }
     // reduce_median: every element as one line; reduce_median_dim: include-NaN median along the zero-based dim (lib.rs:2833-2845)
     fn reduce_median<'a>(&'a self, a: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> {

@@ -184,3 +184,34 @@ def test_full_size_properties(prov):
         prov.free(c.indices)
         d = prov.download_matrix(prov.diff_dim(h, 1, dim, True))
         assert np.array_equal(d, np.diff(x, axis=dim))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 5), (64, 1), (65, 3), (1024, 1), (1025, 1), (300, 700), (7, 5, 11), (2000003, 1), (3, 700001)], ids=str)
+def test_find_matches_the_oracle(prov, oracle, shape):
+    rng = np.random.default_rng(shape[0])
+    for density in (0.0, 0.01, 0.5, 1.0):
+        x = rng.standard_normal(shape) * (rng.random(shape) < density)
+        if x.size > 4:
+            x.reshape(-1)[rng.integers(0, x.size, 2)] = [np.nan, -0.0]
+        h = prov.upload(x)
+        for limit in (None, 0, 1, 7, x.size, x.size + 5):
+            for direction in ("first", "last"):
+                got = prov.find(h, limit, direction)
+                want = oracle.find(x, limit, direction == "last")
+                for g, w, name in zip((got.linear, got.rows, got.cols, got.values), want, ("linear", "rows", "cols", "values")):
+                    assert tuple(g.shape) == w.shape, (shape, density, limit, direction, name, g.shape, w.shape)
+                    assert bits_equal(prov.download_matrix(g), w), (shape, density, limit, direction, name)
+                    prov.free(g)
+        prov.free(h)
+
+
+def test_find_at_full_size(prov):
+    n = 8192
+    h = prov.fill_uniform(5, -1.0, 1.0, (n, n))
+    m = prov.elem_gt(h, prov.fill((n, n), 0.999))
+    x = prov.download_matrix(m)
+    got = prov.find(m)
+    want = np.flatnonzero(x.ravel(order="F")) + 1
+    assert np.array_equal(prov.download_matrix(got.linear).ravel(), want)
+    assert np.array_equal(prov.download_matrix(got.rows).ravel(), (want - 1) % n + 1) and np.array_equal(prov.download_matrix(got.cols).ravel(), (want - 1) // n + 1)
+    assert np.array_equal(prov.download_matrix(prov.find(m, 3, "last").linear).ravel(), want[::-1][:3])

@@ -106,3 +106,14 @@ def test_random_distribution_restatements_follow_their_definitions():
     got, state = oracle.rng_integer_range(s0, 4, 4, 9)
     assert np.array_equal(got, np.full(9, 4.0)) and state == s0
     assert oracle.rng_integer_range(s0, 2, 1, 3) is None and oracle.rng_integer_range(s0, 0, 2**53, 3) is None
+
+
+def test_find_restatement():
+    """find.rs tests: find([0 2 0 4]) = [2 4]; 'last' walks from the end (descending); NaN is nonzero; limits clamp."""
+    l, r, c, v = oracle.find(np.array([[0.0, 2.0, 0.0, 4.0]]))
+    assert list(l.ravel()) == [2, 4] and list(r.ravel()) == [1, 1] and list(c.ravel()) == [2, 4] and list(v.ravel()) == [2, 4]
+    x = np.array([[0.0, 3.0, np.nan], [5.0, 0.0, -0.0]])
+    l, r, c, v = oracle.find(x)
+    assert list(l.ravel()) == [2, 3, 5] and list(r.ravel()) == [2, 1, 1] and list(c.ravel()) == [1, 2, 3] and np.isnan(v.ravel()[2])
+    assert list(oracle.find(x, 2)[0].ravel()) == [2, 3] and list(oracle.find(x, None, True)[0].ravel()) == [5]
+    assert list(oracle.find(x, 2, True)[0].ravel()) == [5, 3] and oracle.find(x, 0)[0].shape == (0, 1) and list(oracle.find(x, 99)[0].ravel()) == [2, 3, 5]
