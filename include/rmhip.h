@@ -358,6 +358,14 @@ RMHIP_API int rmhip_cross(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, int dim_one_
  * an extent of one gives zeros.  A zero coordinate difference is the caller's to refuse (gradient.rs:1044-1051): here it divides. */
 /* @serves gradient_dim gradient_dim_with_coordinates */
 RMHIP_API int rmhip_gradient_dim(rmhip_ctx* ctx, rmhip_buf a, int dim, double spacing, rmhip_buf coordinates_or_0, rmhip_buf* out);
+/* `trapz_dim` / `cumtrapz_dim(input, dim, spacing)` (lib.rs:2893-2908, ProviderTrapezoidSpacing :1060-1066; simple_provider.rs:2421-2598):
+ * along zero-based `dim`, terms 0.5 * w_k * (x[k] + x[k+1]) formed exactly as on the CPU and summed by the library's reduction (trapz:
+ * extent 1 at `dim`) or cumulative scan (cumtrapz: the operand's shape, 0 at k = 0).  spacing_kind 0 Unit, 1 Scalar(`scalar`),
+ * 2 ScalarHandle (first element of `spacing`), 3 Vector (coordinates of the dimension), 4 Tensor (coordinates of the operand's shape).
+ * The CPU sums the terms strictly in order: results agree to the summation-order tolerance of `cumsum` / `sum` (n eps sum|t|). */
+/* @serves trapz_dim cumtrapz_dim */
+RMHIP_API int rmhip_trapz_dim(rmhip_ctx* ctx, rmhip_buf a, int dim, int cumulative, int spacing_kind, double scalar, rmhip_buf spacing_or_0,
+                              rmhip_buf* out);
 /* `issymmetric(matrix, kind, tolerance)` (lib.rs:3115-3124; issymmetric.rs:461-487, 517-526): 1 when a(i,j) equals a(j,i) (skew != 0:
  * -a(j,i), and a zero diagonal), pairs compared as `v == r || (both finite && |v - r| <= tolerance)`; a non-square operand is 0, an
  * operand with trailing extents > 1 RMHIP_ERR_INVALID.  Synchronises the stream (a host bool comes back). */

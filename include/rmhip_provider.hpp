@@ -537,6 +537,17 @@ public:
         check(rmhip_gradient_dim(ctx_, own(a), (int)dim, 1.0, own(coordinates), &out));
         return with_shape(out);
     }
+    // lib.rs:2893-2908; spacing_kind as ProviderTrapezoidSpacing: 0 Unit, 1 Scalar, 2 ScalarHandle, 3 Vector, 4 Tensor
+    GpuTensorHandle trapz_dim(const GpuTensorHandle& a, size_t dim, int spacing_kind = 0, double scalar = 1.0, const GpuTensorHandle* spacing = nullptr) const {
+        uint64_t out = 0;
+        check(rmhip_trapz_dim(ctx_, own(a), (int)dim, 0, spacing_kind, scalar, spacing ? own(*spacing) : 0, &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle cumtrapz_dim(const GpuTensorHandle& a, size_t dim, int spacing_kind = 0, double scalar = 1.0, const GpuTensorHandle* spacing = nullptr) const {
+        uint64_t out = 0;
+        check(rmhip_trapz_dim(ctx_, own(a), (int)dim, 1, spacing_kind, scalar, spacing ? own(*spacing) : 0, &out));
+        return with_shape(out);
+    }
     bool issymmetric(const GpuTensorHandle& m, bool skew, double tolerance) const {
         int r = 0;
         check(rmhip_issymmetric(ctx_, own(m), skew ? 1 : 0, tolerance, &r));

@@ -1606,3 +1606,22 @@ ORC_API size_t orc_find(const double* data, size_t len, size_t row_extent, size_
     }
     return n;
 }
+
+/* simple_trapezoid, simple_provider.rs:2421-2598 (the runtime's trapz.rs / cumtrapz.rs host loops are the same): per line
+ * acc += 0.5 * width * (x[k] + x[k+1]) in order, width = 1, a scalar, coords[k+1] - coords[k] (vector) or the difference of the spacing
+ * tensor's neighbours; cumulative writes acc at k + 1 (0 at k = 0), otherwise one value per line.  kind: 0 unit, 1 scalar, 3 vector, 4 tensor. */
+ORC_API void orc_trapz(const double* x, size_t pre, size_t len, size_t post, int kind, double scalar, const double* sp, int cumulative, double* out) {
+    if (cumulative) for (size_t i = 0; i < pre * len * post; ++i) out[i] = 0.0;
+    else for (size_t i = 0; i < pre * post; ++i) out[i] = 0.0;
+    for (size_t after = 0; after < post; ++after)
+        for (size_t before = 0; before < pre; ++before) {
+            double acc = 0.0;
+            for (size_t k = 0; k + 1 < len; ++k) {
+                const size_t i0 = after * pre * len + before + k * pre, i1 = i0 + pre;
+                const double w = kind == 0 ? 1.0 : (kind == 1 ? scalar : (kind == 3 ? sp[k + 1] - sp[k] : sp[i1] - sp[i0]));
+                acc += 0.5 * w * (x[i0] + x[i1]);
+                if (cumulative) out[i1] = acc;
+            }
+            if (!cumulative) out[after * pre + before] = acc;
+        }
+}

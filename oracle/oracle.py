@@ -789,3 +789,28 @@ def find(x: np.ndarray, limit=None, last: bool = False):
     l.orc_find.argtypes = [_DP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _DP, _DP, _DP, _DP]
     n = l.orc_find(_p(fx), fx.size, max(x.shape[0] if x.ndim else 1, 1), cap, int(last), *[_p(o) for o in outs])
     return tuple(o[:n].reshape(-1, 1) for o in outs)
+
+
+def trapz(x: np.ndarray, dim: int, spacing=None, cumulative: bool = False) -> np.ndarray:
+    """trapz / cumtrapz along zero-based dim (simple_provider.rs:2421-2598): spacing None (unit), a float, a vector of the dimension's
+    extent, or a tensor of x's shape."""
+    x = np.asarray(x, dtype=np.float64)
+    shape = list(x.shape) + [1] * max(0, dim + 1 - x.ndim)
+    pre, ln, post = _pre_len_post(shape, dim)
+    kind, scalar, sp = 0, 0.0, None
+    if spacing is not None:
+        if np.isscalar(spacing):
+            kind, scalar = 1, float(spacing)
+        else:
+            sa = np.asarray(spacing, dtype=np.float64)
+            kind = 4 if sa.size == x.size and sa.size != ln else 3
+            sp = np.ascontiguousarray(_f(sa))
+    oshape = list(shape)
+    if not cumulative:
+        oshape[dim] = 1
+    out = np.empty(int(np.prod(oshape, dtype=np.int64)))
+    l = lib()
+    l.orc_trapz.restype = None
+    l.orc_trapz.argtypes = [_DP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_double, _DP, C.c_int, _DP]
+    l.orc_trapz(_p(_f(x)), pre, ln, post, kind, scalar, _p(sp) if sp is not None else None, int(cumulative), _p(out))
+    return out.reshape(oshape, order="F")

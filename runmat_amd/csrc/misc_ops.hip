@@ -101,6 +101,26 @@ __global__ void __launch_bounds__(kB) k_issymmetric(const double* __restrict__ a
     if (!ok) *bad = 1;
 }
 
+// trapezoid terms: t[k + 1] = 0.5 * w_k * (x[k] + x[k + 1]), t[0] = 0 along the dimension (simple_provider.rs:2534-2563); their running /
+// total sums are the library's cumulative-scan and reduction kernels.  KIND: 0 unit, 1 scalar, 3 coordinate vector, 4 spacing tensor.
+template <int KIND>
+__global__ void __launch_bounds__(kB) k_trapz_terms(const double* __restrict__ x, u64 pre, u64 len, u64 total, double scalar, const double* __restrict__ sp,
+                                                    double* __restrict__ t) {
+    const u64 o = (u64)blockIdx.x * kB + threadIdx.x;
+    if (o >= total) return;
+    const u64 k1 = (o / pre) % len;
+    double v = 0.0;
+    if (k1 > 0) {
+        const u64 i0 = o - pre;
+        double w = 1.0;
+        if (KIND == 1) w = scalar;
+        if (KIND == 3) w = sp[k1] - sp[k1 - 1];
+        if (KIND == 4) w = sp[o] - sp[i0];
+        v = 0.5 * w * (x[i0] + x[o]);
+    }
+    __builtin_nontemporal_store(v, t + o);
+}
+
 std::vector<size_t> matrix_shape(const std::vector<size_t>& s) {
     if (s.empty()) return {1, 1};
     if (s.size() == 1) return {s[0], 1};
@@ -254,4 +274,55 @@ int rmhip_issymmetric(rmhip_ctx* ctx, rmhip_buf a, int skew, double tolerance, i
     RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
     *result = bad ? 0 : 1;
     return RMHIP_OK;
+}
+
+int rmhip_trapz_dim(rmhip_ctx* ctx, rmhip_buf a, int dim, int cumulative, int spacing_kind, double scalar, rmhip_buf spacing_or_0, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    if (dim < 0) return fail(RMHIP_ERR_INVALID, "trapezoid: dim must be >= 0");
+    Buffer ab, sb;
+    RMHIP_TRY(c->get(a, &ab));
+    std::vector<size_t> shape = matrix_shape(ab.shape);
+    while (shape.size() <= (size_t)dim) shape.push_back(1);  // simple_provider.rs:2497-2499
+    u64 pre = 1;
+    for (int k = 0; k < dim; ++k) pre *= shape[k];
+    const u64 len = shape[dim];
+    const double* sp = nullptr;
+    int kind = spacing_kind;
+    if (kind == 2) {  // ScalarHandle: the first element of a resident tensor
+        RMHIP_TRY(c->get(spacing_or_0, &sb));
+        if (sb.numel == 0) return fail(RMHIP_ERR_INVALID, "trapezoid: scalar spacing is empty");
+        RMHIP_HIP_CHECK(hipMemcpyAsync(&scalar, sb.data(), sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        kind = 1;
+    } else if (kind == 3 || kind == 4) {
+        RMHIP_TRY(c->get(spacing_or_0, &sb));
+        if (kind == 3 && sb.numel < len) return fail(RMHIP_ERR_SHAPE, "trapezoid: spacing vector is shorter than integration dimension");
+        if (kind == 4 && sb.numel < ab.numel) return fail(RMHIP_ERR_SHAPE, "trapezoid: spacing tensor is smaller than input");
+        sp = sb.data();
+    } else if (kind != 0 && kind != 1) {
+        return fail(RMHIP_ERR_INVALID, "trapezoid: spacing kind %d", spacing_kind);
+    }
+    std::vector<size_t> oshape = shape;
+    if (!cumulative) oshape[dim] = 1;
+    if (ab.numel == 0 || len <= 1) {  // nothing to integrate: zeros of the output's shape (simple_provider.rs:2544-2546, 2576-2577)
+        Buffer ob;
+        RMHIP_TRY(c->new_buffer(oshape.data(), oshape.size(), out, &ob));
+        return ob.numel ? launch_fill(c, ob.data(), ob.numel, 0.0) : RMHIP_OK;
+    }
+    rmhip_buf tid = 0;
+    Buffer tb;
+    RMHIP_TRY(c->new_buffer(shape.data(), shape.size(), &tid, &tb));
+    const unsigned grid = grid_for(tb.numel);
+    switch (kind) {
+        case 0: hipLaunchKernelGGL(k_trapz_terms<0>, dim3(grid), dim3(kB), 0, c->stream, ab.data(), pre, len, (u64)tb.numel, scalar, sp, tb.data()); break;
+        case 1: hipLaunchKernelGGL(k_trapz_terms<1>, dim3(grid), dim3(kB), 0, c->stream, ab.data(), pre, len, (u64)tb.numel, scalar, sp, tb.data()); break;
+        case 3: hipLaunchKernelGGL(k_trapz_terms<3>, dim3(grid), dim3(kB), 0, c->stream, ab.data(), pre, len, (u64)tb.numel, scalar, sp, tb.data()); break;
+        default: hipLaunchKernelGGL(k_trapz_terms<4>, dim3(grid), dim3(kB), 0, c->stream, ab.data(), pre, len, (u64)tb.numel, scalar, sp, tb.data()); break;
+    }
+    c->tel.kernel_launches++;
+    int rc = hipGetLastError() == hipSuccess ? RMHIP_OK : fail(RMHIP_ERR_HIP, "trapezoid: launch failed");
+    if (!rc) rc = cumulative ? rmhip_cumulative(ctx, 0, tid, dim, 0, 0, out) : rmhip_reduce(ctx, RMHIP_RSUM, tid, dim, 0, out);
+    rmhip_free(ctx, tid);
+    return rc;
 }

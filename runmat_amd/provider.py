@@ -902,6 +902,29 @@ class HipProvider:
         self._check(self._lib.rmhip_gradient_dim(self._ctx, self._id(a), int(dim), 1.0, self._id(coordinates), C.byref(out)))
         return self._handle(out.value)
 
+    def _trapz(self, a, dim: int, spacing, cumulative: bool) -> GpuTensorHandle:
+        kind, scalar, sid = 0, 0.0, 0
+        if spacing is None:
+            pass
+        elif isinstance(spacing, (int, float)):
+            kind, scalar = 1, float(spacing)
+        else:
+            name, h = spacing
+            kind = {"scalar_handle": 2, "vector": 3, "tensor": 4}[name]
+            sid = self._id(h)
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_trapz_dim(self._ctx, self._id(a), int(dim), 1 if cumulative else 0, kind, scalar, sid, C.byref(out)))
+        return self._handle(out.value)
+
+    def trapz_dim(self, a, dim: int, spacing=None) -> GpuTensorHandle:
+        """lib.rs:2893-2900; `ProviderTrapezoidSpacing` (:1060-1066) as None (Unit), a float (Scalar) or ("scalar_handle" | "vector" |
+        "tensor", handle)."""
+        return self._trapz(a, dim, spacing, False)
+
+    def cumtrapz_dim(self, a, dim: int, spacing=None) -> GpuTensorHandle:
+        """lib.rs:2901-2908."""
+        return self._trapz(a, dim, spacing, True)
+
     def issymmetric(self, matrix, kind: str = "symmetric", tolerance: float = 0.0) -> bool:
         """lib.rs:3115-3124 (`ProviderSymmetryKind::{Symmetric, Skew}`): decided on the device, only the bool comes back."""
         if kind not in ("symmetric", "skew"):

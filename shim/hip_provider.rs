@@ -18,7 +18,7 @@ use runmat_accelerate_api::{
     HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, KernelAttrTelemetry, KernelLaunchTelemetry, MatmulEpilogue,
     PowerStepEpilogue, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderNanMode, ProviderPrecision, ProviderScanDirection,
-    ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult,
+    ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult,
 };
 use std::ffi::{c_char, c_int, c_void, CStr, CString};
 
@@ -51,6 +51,20 @@ fn check(rc: c_int) -> Result<()> {
 }
 
 impl HipProvider {
+    // trapz_dim / cumtrapz_dim: ProviderTrapezoidSpacing (lib.rs:1060-1066) -> (kind, scalar, handle) of rmhip_trapz_dim
+    fn trapezoid(&self, input: &GpuTensorHandle, dim: usize, spacing: ProviderTrapezoidSpacing<'_>, cumulative: c_int) -> Result<GpuTensorHandle> {
+        let (kind, scalar, handle) = match spacing {
+            ProviderTrapezoidSpacing::Unit => (0, 0.0, 0u64),
+            ProviderTrapezoidSpacing::Scalar(v) => (1, v, 0u64),
+            ProviderTrapezoidSpacing::ScalarHandle(h) => (2, 0.0, self.own(h)?),
+            ProviderTrapezoidSpacing::Vector(h) => (3, 0.0, self.own(h)?),
+            ProviderTrapezoidSpacing::Tensor(h) => (4, 0.0, self.own(h)?),
+        };
+        let mut out = 0u64;
+        check(unsafe { rmhip_trapz_dim(self.ctx, self.own(input)?, dim as c_int, cumulative, kind, scalar, handle, &mut out) })?;
+        self.handle(out)
+    }
+
     pub fn new(device_ordinal: i32) -> Result<Self> {
         Self::with_precision(device_ordinal, ProviderPrecision::F64)
     }
@@ -533,6 +547,12 @@ impl AccelProvider for HipProvider {
         let mut out = 0u64;
         check(unsafe { rmhip_gradient_dim(self.ctx, self.own(handle)?, dim as c_int, 1.0, self.own(coordinates)?, &mut out) })?;
         self.handle(out)
+    }
+    fn trapz_dim(&self, input: &GpuTensorHandle, dim: usize, spacing: ProviderTrapezoidSpacing<'_>) -> Result<GpuTensorHandle> {
+        self.trapezoid(input, dim, spacing, 0)
+    }
+    fn cumtrapz_dim(&self, input: &GpuTensorHandle, dim: usize, spacing: ProviderTrapezoidSpacing<'_>) -> Result<GpuTensorHandle> {
+        self.trapezoid(input, dim, spacing, 1)
     }
     fn issymmetric(&self, matrix: &GpuTensorHandle, kind: ProviderSymmetryKind, tolerance: f64) -> Result<bool> {
         let mut res: c_int = 0;

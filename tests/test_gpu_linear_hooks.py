@@ -170,3 +170,35 @@ def test_inv_residual_at_4096(prov):
     a = np.random.default_rng(1).standard_normal((n, n)) + np.sqrt(n) * np.eye(n)
     x = prov.download_matrix(prov.inv(prov.upload(a)))
     assert np.max(np.abs(a @ x - np.eye(n))) <= 1e-12 * n
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (2, 1), (1, 2), (9, 1), (100, 7), (7, 100), (5, 6, 7), (100003, 2), (2, 100003), (4096, 300)], ids=str)
+def test_trapz_and_cumtrapz(prov, oracle, shape):
+    """Terms formed exactly as on the CPU, summed by the library's reduction / scan: within the summation-order tolerance of sum and
+    cumsum (n eps sum|t|) of the oracle's in-order accumulation (simple_provider.rs:2421-2598)."""
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(shape)
+    hx = prov.upload(x)
+    for dim in range(len(shape) + 1):
+        ext = shape[dim] if dim < len(shape) else 1
+        spacings = [(None, None), (0.37, 0.37)]
+        if ext >= 2:
+            c = np.cumsum(rng.uniform(0.5, 1.5, ext))
+            spacings.append((("vector", prov.upload(c.reshape(-1, 1))), c))
+            t = np.cumsum(rng.uniform(0.5, 1.5, shape), axis=dim) if dim < len(shape) else None
+            if t is not None:
+                spacings.append((("tensor", prov.upload(t)), t))
+        sh = prov.upload(np.array([[0.37]]))
+        spacings.append((("scalar_handle", sh), 0.37))
+        for sp_dev, sp_host in spacings:
+            for cumulative in (False, True):
+                got = (prov.cumtrapz_dim if cumulative else prov.trapz_dim)(hx, dim, sp_dev)
+                want = oracle.trapz(x, dim, sp_host, cumulative)
+                g = prov.download(got)
+                assert g.size == want.size, (shape, dim, cumulative, got.shape, want.shape)
+                scale = max(ext, 2) * 2.3e-16 * (np.max(np.abs(x)) * 2.0 * (np.max(np.abs(np.diff(sp_host, axis=dim if np.ndim(sp_host) > 1 else 0))) if np.ndim(sp_host) else (abs(sp_host) if sp_host else 1.0))) * max(ext, 1)
+                assert np.max(np.abs(np.asarray(g).ravel(order="F") - want.ravel(order="F")), initial=0.0) <= scale + 1e-300, (shape, dim, cumulative)
+                prov.free(got)
+    if shape[0] > 1:
+        with pytest.raises(Exception):                                               # simple_provider.rs:2523-2526
+            prov.trapz_dim(hx, 0, ("vector", prov.upload(np.zeros((shape[0] - 1, 1)))))
