@@ -587,6 +587,199 @@ __global__ void __launch_bounds__(256) k_find_emit(const double* __restrict__ x,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// median of LONG lines by radix selection: the two middle ranks are located digit by digit (eight passes over the line's keys, one
+// byte each, most significant first) instead of sorting the line - ~8 reads of the data against the 100+ passes of the network.
+// Per line and target rank the state is (the key's decided high bytes, the rank inside that group); a pass histograms the next byte
+// of the elements that match the prefix, a one-wave kernel picks the bucket.  The key decodes to the value except for a zero, whose
+// sign is that of the rank-th zero in index order (stable order): found by an ordered count when - and only when - it matters.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct SelState {
+    u64 prefix[2];  // lower middle, upper middle
+    u64 rank[2];
+    u32 nan;        // the line holds a NaN
+    u32 pad;
+};
+
+__global__ void __launch_bounds__(256) k_sel_init(SelState* __restrict__ st, u32* __restrict__ hist, u64 len, u64 nlines) {
+    const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t < nlines) {
+        st[t].prefix[0] = st[t].prefix[1] = 0;
+        st[t].rank[0] = (len - 1) / 2;
+        st[t].rank[1] = len / 2;
+        st[t].nan = 0;
+    }
+    if (t < nlines * 512) hist[t] = 0;
+}
+
+// one (line, piece) per workgroup: byte `shift / 8` of every key whose higher bytes equal the target's prefix
+__global__ void __launch_bounds__(256) k_sel_hist(const double* __restrict__ x, Lines g, SelState* __restrict__ st, u32* __restrict__ hist, int shift, u64 piece) {
+    __shared__ u32 h[2][256];
+    const u64 line = blockIdx.y;
+    const int t = threadIdx.x;
+    h[0][t] = 0;
+    h[1][t] = 0;
+    __syncthreads();
+    const SelState s = st[line];
+    const bool same = s.prefix[0] == s.prefix[1];
+    const u64 base = (line / g.pre) * g.pre * g.len + line % g.pre;
+    const u64 k0 = (u64)blockIdx.x * piece, k1 = (k0 + piece < g.len) ? k0 + piece : g.len;
+    const int hs = shift + 8;  // bits above the byte under the histogram
+    u32 saw_nan = 0;
+    for (u64 k = k0 + t; k < k1; k += 256) {
+        const u64 key = sort_key(__builtin_nontemporal_load(x + base + k * g.pre), 0, 0);
+        if (shift == 56 && key == ~0ull) saw_nan = 1;
+        const u32 bin = (u32)(key >> shift) & 255u;
+        const bool m0 = hs >= 64 || (key >> hs) == (s.prefix[0] >> hs);
+        const bool m1 = !same && (hs >= 64 || (key >> hs) == (s.prefix[1] >> hs));
+        // wave-aggregated increments: data of one magnitude shares its leading bytes, and same-address LDS atomics serialise
+        u64 todo = __ballot(m0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const u32 lb = __shfl(bin, leader);
+            const u64 grp = __ballot(m0 && bin == lb) & todo;
+            if ((t & 63) == leader) atomicAdd(&h[0][lb], (u32)__popcll(grp));
+            todo &= ~grp;
+        }
+        if (!same) {
+            todo = __ballot(m1);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const u32 lb = __shfl(bin, leader);
+                const u64 grp = __ballot(m1 && bin == lb) & todo;
+                if ((t & 63) == leader) atomicAdd(&h[1][lb], (u32)__popcll(grp));
+                todo &= ~grp;
+            }
+        }
+    }
+    if (saw_nan) st[line].nan = 1;
+    __syncthreads();
+    if (h[0][t]) atomicAdd(hist + line * 512 + t, h[0][t]);
+    if (!same && h[1][t]) atomicAdd(hist + line * 512 + 256 + t, h[1][t]);
+}
+
+// one wave per line: the bucket that holds each target rank; the histograms are cleared for the next pass
+__global__ void __launch_bounds__(64) k_sel_pick(SelState* __restrict__ st, u32* __restrict__ hist, int shift) {
+    const u64 line = blockIdx.x;
+    const int lane = threadIdx.x;
+    SelState s = st[line];
+    const bool same = s.prefix[0] == s.prefix[1];
+    for (int tg = 0; tg < 2; ++tg) {
+        const u32* h = hist + line * 512 + ((tg == 1 && !same) ? 256 : 0);
+        // lane l owns buckets 4 l .. 4 l + 3
+        u64 c[4], mine = 0;
+        for (int q = 0; q < 4; ++q) {
+            c[q] = h[4 * lane + q];
+            mine += c[q];
+        }
+        u64 incl = mine;
+        for (int d = 1; d < 64; d <<= 1) {
+            const u64 up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        u64 before = incl - mine;
+        const u64 r = s.rank[tg];
+        int found = -1;
+        u64 nr = 0;
+        for (int q = 0; q < 4; ++q) {
+            if (found < 0 && r >= before && r < before + c[q]) {
+                found = 4 * lane + q;
+                nr = r - before;
+            }
+            before += c[q];
+        }
+        const u64 who = __ballot(found >= 0);
+        const int src = who ? __ffsll((long long)who) - 1 : 0;
+        const int bucket = __shfl(found, src);
+        const u64 newrank = __shfl(nr, src);
+        if (lane == 0) {
+            st[line].prefix[tg] = s.prefix[tg] | ((u64)(u32)bucket << shift);
+            st[line].rank[tg] = newrank;
+        }
+    }
+    __syncthreads();
+    for (int q = lane; q < 512; q += 64) hist[line * 512 + q] = 0;
+}
+
+// the rank-th (0-based) zero of a line in index order: its sign decides a median that lands on a zero
+__global__ void __launch_bounds__(256) k_kth_zero(const double* __restrict__ x, Lines g, u64 line, u64 kth, double* __restrict__ out) {
+    __shared__ u64 cnt[256];
+    const int t = threadIdx.x;
+    const u64 base = (line / g.pre) * g.pre * g.len + line % g.pre;
+    const u64 per = (g.len + 255) / 256, k0 = (u64)t * per, k1 = (k0 + per < g.len) ? k0 + per : g.len;
+    u64 mine = 0;
+    for (u64 k = k0; k < k1; ++k) mine += x[base + k * g.pre] == 0.0 ? 1 : 0;
+    cnt[t] = mine;
+    __syncthreads();
+    u64 before = 0;
+    for (int i = 0; i < t; ++i) before += cnt[i];
+    if (kth >= before && kth < before + mine) {
+        u64 seen = before;
+        for (u64 k = k0; k < k1; ++k) {
+            const double v = x[base + k * g.pre];
+            if (v == 0.0) {
+                if (seen == kth) {
+                    *out = v;
+                    break;
+                }
+                ++seen;
+            }
+        }
+    }
+}
+
+__device__ __host__ inline double key_to_value(u64 key) {  // inverse of sort_key (ascending, by value); a zero decodes to +0
+    const u64 u = (key >> 63) ? (key & 0x7fffffffffffffffull) : ~key;
+    double v;
+    memcpy(&v, &u, sizeof v);
+    return v;
+}
+
+// medians of g's lines into out[line]; lines are long and few (the caller's choice)
+int median_select(Context* c, const double* x, Lines g, double* out) {
+    const u64 nlines = g.pre * g.post;
+    std::shared_ptr<Allocation> ws;
+    const u64 st_doubles = nlines * (sizeof(SelState) / 8), hist_doubles = nlines * 256;  // 512 u32 per line
+    RMHIP_TRY(c->alloc_device(st_doubles + hist_doubles + 2, &ws));
+    SelState* st = (SelState*)ws->ptr;
+    u32* hist = (u32*)(ws->ptr + st_doubles);
+    double* zero_out = ws->ptr + st_doubles + hist_doubles;
+    hipLaunchKernelGGL(k_sel_init, dim3((unsigned)((nlines * 512 + 255) / 256)), dim3(256), 0, c->stream, st, hist, g.len, nlines);
+    // pieces of >= 16 Ki elements, enough workgroups for the device
+    u64 pieces = std::max<u64>(1, std::min<u64>((u64)c->num_cus * 8 / std::max<u64>(nlines, 1), g.len / 16384));
+    const u64 piece = (g.len + pieces - 1) / pieces;
+    pieces = (g.len + piece - 1) / piece;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(k_sel_hist, dim3((unsigned)pieces, (unsigned)nlines), dim3(256), 0, c->stream, x, g, st, hist, shift, piece);
+        hipLaunchKernelGGL(k_sel_pick, dim3((unsigned)nlines), dim3(64), 0, c->stream, st, hist, shift);
+        c->tel.kernel_launches += 2;
+    }
+    RMHIP_HIP_CHECK(hipGetLastError());
+    std::vector<SelState> host(nlines);
+    RMHIP_HIP_CHECK(hipMemcpyAsync(host.data(), st, nlines * sizeof(SelState), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    std::vector<double> med(nlines);
+    for (u64 l = 0; l < nlines; ++l) {
+        if (host[l].nan) {
+            med[l] = std::numeric_limits<double>::quiet_NaN();
+            continue;
+        }
+        double v[2];
+        for (int tg = 0; tg < 2; ++tg) {
+            v[tg] = key_to_value(host[l].prefix[tg]);
+            if (host[l].prefix[tg] == 0x8000000000000000ull && (tg == 1 || (g.len & 1) == 0)) {  // a zero: which one?
+                hipLaunchKernelGGL(k_kth_zero, dim3(1), dim3(256), 0, c->stream, x, g, l, host[l].rank[tg], zero_out);
+                RMHIP_HIP_CHECK(hipMemcpyAsync(&v[tg], zero_out, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+            }
+        }
+        med[l] = (g.len & 1) ? v[1] : 0.5 * (v[0] + v[1]);  // median.rs:733-737
+    }
+    RMHIP_HIP_CHECK(hipMemcpyAsync(out, med.data(), nlines * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));  // `med` leaves scope
+    return RMHIP_OK;
+}
+
 int lines_of(const std::vector<size_t>& shape, int dim, const char* what, Lines* g) {
     if (dim < 0 || (size_t)dim >= shape.size()) return fail(RMHIP_ERR_UNSUPPORTED, "%s: dim %d out of range for rank %zu", what, dim, shape.size());
     g->pre = g->post = 1;
@@ -711,6 +904,8 @@ int rmhip_reduce_median(rmhip_ctx* ctx, rmhip_buf a, int dim, rmhip_buf* out) {
         rc = launch_fill(c, ob.data(), ob.numel, std::numeric_limits<double>::quiet_NaN());
     } else if (g.len == 1) {
         RMHIP_HIP_CHECK(hipMemcpyAsync(ob.data(), ab.data(), ab.numel * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    } else if (g.len >= (1u << 17) && g.pre * g.post <= 64 && !std::getenv("RMHIP_MEDIAN_SORT")) {
+        rc = median_select(c, ab.data(), g, ob.data());  // long lines, few of them: selection instead of a full sort
     } else {
         SortSpace ws;
         rc = sort_lines(c, ab.data(), g, 0, 0, &ws);

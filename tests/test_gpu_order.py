@@ -130,7 +130,7 @@ def test_sort_dim_matches_the_oracle(prov, oracle, shape):
         prov.free(h)
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (2, 1), (5, 1), (4, 1), (100, 3), (3, 100), (101, 7), (2049, 2), (4, 4100), (6, 5, 4), (70001, 1), (3, 70000)], ids=str)
+@pytest.mark.parametrize("shape", [(1, 1), (2, 1), (5, 1), (4, 1), (100, 3), (3, 100), (101, 7), (2049, 2), (4, 4100), (6, 5, 4), (70001, 1), (3, 70000), (300001, 1), (2, 200000), (200000, 3), (3, 1, 140000)], ids=str)
 def test_median_matches_the_oracle(prov, oracle, shape):
     rng = np.random.default_rng(shape[0])
     for nan_frac, ties in ((0.0, False), (0.0, True), (0.001, False)):
@@ -215,3 +215,23 @@ def test_find_at_full_size(prov):
     assert np.array_equal(prov.download_matrix(got.linear).ravel(), want)
     assert np.array_equal(prov.download_matrix(got.rows).ravel(), (want - 1) % n + 1) and np.array_equal(prov.download_matrix(got.cols).ravel(), (want - 1) // n + 1)
     assert np.array_equal(prov.download_matrix(prov.find(m, 3, "last").linear).ravel(), want[::-1][:3])
+
+
+def test_median_selection_lands_on_signed_zeros(prov, oracle):
+    """Long lines take the radix-selection path: a median that falls on a zero must carry the sign of the zero the stable sort puts
+    there (odd length), or of the sum of the two middle zeros (even length)."""
+    rng = np.random.default_rng(17)
+    for n in (262145, 262144):
+        for trial in range(4):
+            x = rng.standard_normal(n)
+            zeros = rng.random(n) < 0.5                                   # half of the elements are zeros: the median is one
+            x[zeros] = np.where(rng.random(np.count_nonzero(zeros)) < 0.5, -0.0, 0.0)
+            nz = np.count_nonzero(~zeros)
+            x[~zeros] = np.abs(x[~zeros]) * np.where(np.arange(nz) % 2 == 0, 1.0, -1.0)
+            h = prov.upload(x.reshape(-1, 1))
+            got = prov.download_matrix(prov.reduce_median(h))
+            want = oracle.median_dim(x.reshape(-1, 1), 0)
+            assert bits_equal(got, want), (n, trial, got, want)
+            prov.free(h)
+    x = np.full(200000, -0.0)
+    assert bits_equal(prov.download_matrix(prov.reduce_median(prov.upload(x.reshape(-1, 1)))), np.array([[-0.0]]))
