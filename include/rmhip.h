@@ -337,6 +337,49 @@ RMHIP_API int rmhip_reduce_median(rmhip_ctx* ctx, rmhip_buf a, int dim, rmhip_bu
 /* @serves find */
 RMHIP_API int rmhip_find(rmhip_ctx* ctx, rmhip_buf a, long long limit_or_neg, int last, rmhip_buf* linear, rmhip_buf* rows, rmhip_buf* cols,
                          rmhip_buf* values);
+/* ---- subscript / grid / slice-write hooks and the per-element forms of a real tensor (runmat_amd/csrc/index_ops.hip): bit-exact ----
+ * `ndgrid(request)` (lib.rs:1567-1569, ProviderNdgridRequest :3395-3399; simple_provider.rs:2784-2855): for the first `output_count` axes
+ * (resident vectors whose lengths equal the leading output extents) the grid out_d[i] = axis_d[(i / stride_d) % extent_d] of shape
+ * `output_shape`; output_count == 0 or > n_axes, an empty shape or a length mismatch are errors as there. */
+/* @serves ndgrid */
+RMHIP_API int rmhip_ndgrid(rmhip_ctx* ctx, const rmhip_buf* axes, size_t n_axes, const size_t* output_shape, size_t rank, size_t output_count,
+                           rmhip_buf* outputs);
+/* `sub2ind(dims, strides, inputs, scalar_mask, len, output_shape)` (lib.rs:3084-3094; simple_provider.rs:8340-8420, 2268-2291): 1-based
+ * linear indices 1 + sum (s_d - 1) * stride_d from `rank` resident subscript tensors (a masked one is a scalar); every subscript must be
+ * finite, integral (|round(v) - v| <= eps) and within 1..dims[d]: the FIRST offender in the CPU's (element, dimension) order gives
+ * RMHIP_ERR_INVALID with the CPU's message ("sub2ind: subscript in dimension 2 must be an integer", ...).  One stream synchronisation. */
+/* @serves sub2ind */
+RMHIP_API int rmhip_sub2ind(rmhip_ctx* ctx, const size_t* dims, const size_t* strides, const rmhip_buf* inputs, const unsigned char* scalar_mask,
+                            size_t rank, size_t len, const size_t* output_shape, size_t out_rank, rmhip_buf* out);
+/* `ind2sub(dims, strides, indices, total, len, output_shape)` (lib.rs:3102-3112, `supports_ind2sub` :3097; CPU ind2sub.rs:289-353): `rank`
+ * subscript tensors ((idx - 1) / stride_d) % dims[d] + 1 of shape `output_shape`; a non-finite, non-integral or < 1 index is
+ * "Linear indices must be positive integers.", one above `total` "Index exceeds number of array elements. Index must not exceed N." -
+ * the builtin hands a provider error on to the user (ind2sub.rs:284), so the wording is the CPU's. */
+/* @serves ind2sub supports_ind2sub */
+RMHIP_API int rmhip_ind2sub(rmhip_ctx* ctx, const size_t* dims, const size_t* strides, size_t rank, rmhip_buf indices, size_t total, size_t len,
+                            const size_t* output_shape, size_t out_rank, rmhip_buf* outputs);
+/* `scatter_column(matrix, col_index, values)` / `scatter_row(matrix, row_index, values)` (lib.rs:3064-3082; the slice-assignment fast path of
+ * runmat-vm/src/indexing/write_slice.rs:680-709): a NEW handle holding the matrix with one whole column (is_column != 0) or row replaced by
+ * the `rows` (`cols`) resident values; zero-based index; the operand is untouched. */
+/* @serves scatter_column scatter_row */
+RMHIP_API int rmhip_scatter_line(rmhip_ctx* ctx, rmhip_buf matrix, int is_column, size_t index, rmhip_buf values, rmhip_buf* out);
+/* `pow2_scale(mantissa, exponent)` (lib.rs:2325-2331; simple_provider.rs:5822-5850): m .* 2.^e for operands of one shape (else
+ * "shape mismatch"); an integral exponent is the exact power of two (bit-exact product), a fractional one goes through exp2 (2 ulp). */
+/* @serves pow2_scale */
+RMHIP_API int rmhip_pow2_scale(rmhip_ctx* ctx, rmhip_buf mantissa, rmhip_buf exponent, rmhip_buf* out);
+/* `round_digits(a, digits, significant)` (lib.rs:2197-2204; simple_provider.rs:5359-5420): round(x * 10^digits) / 10^digits with the factor
+ * formed as Rust's powi does (square-and-multiply, reciprocal last), half away from zero, non-finite values and overflowing factors passed
+ * through: bit-exact.  significant != 0 (digits counted from floor(log10|x|) of the host's libm) is RMHIP_ERR_UNSUPPORTED. */
+/* @serves round_digits */
+RMHIP_API int rmhip_round_digits(rmhip_ctx* ctx, rmhip_buf a, int digits, int significant, rmhip_buf* out);
+/* `unary_real / unary_imag / unary_conj / unary_angle` on REAL storage (lib.rs:2217-2240; simple_provider.rs:5482-5640): part 0 real = the
+ * operand, 1 imag = zeros, 2 conj = the operand, 3 angle = atan2(+0, x): +0 for x > 0 and +0, pi for x < 0 and -0, NaN for NaN.
+ * `logical_isreal` (lib.rs:2055; simple_provider.rs:4786): always 1 here - this library has no complex-interleaved storage. */
+/* @serves unary_real unary_imag unary_conj unary_angle */
+RMHIP_API int rmhip_real_part(rmhip_ctx* ctx, int part, rmhip_buf a, rmhip_buf* out);
+/* @serves logical_isreal */
+RMHIP_API int rmhip_isreal(rmhip_ctx* ctx, rmhip_buf a, int* result);
+
 /* ---- small construction / linear-algebra hooks (runmat_amd/csrc/misc_ops.hip): one or two rounded operations per element, bit-exact ----
  * `diag_from_vector(vector, offset)` / `diag_from_vector_sized(vector, offset, rows, cols)` (lib.rs:1600-1623; simple_provider.rs:3222-3281):
  * element idx of a vector-like operand on (idx, idx + offset) or (idx - offset, idx), zeros elsewhere; rows / cols < 0 = the square of

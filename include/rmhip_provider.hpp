@@ -505,6 +505,69 @@ public:
         check(rmhip_random_normal(ctx_, shape.data(), shape.size(), &out));
         return make(out, shape);
     }
+    // lib.rs:1567-1569, 3064-3112, 2325-2331, 2197-2240, 2055 (index_ops.hip)
+    std::vector<GpuTensorHandle> ndgrid(const std::vector<GpuTensorHandle>& axes, const std::vector<size_t>& output_shape, size_t output_count) const {
+        std::vector<uint64_t> ids, outs(output_count ? output_count : 1);
+        for (const auto& a : axes) ids.push_back(own(a));
+        check(rmhip_ndgrid(ctx_, ids.data(), ids.size(), output_shape.data(), output_shape.size(), output_count, outs.data()));
+        std::vector<GpuTensorHandle> r;
+        for (size_t i = 0; i < output_count; ++i) r.push_back(with_shape(outs[i]));
+        return r;
+    }
+    GpuTensorHandle sub2ind(const std::vector<size_t>& dims, const std::vector<size_t>& strides, const std::vector<GpuTensorHandle>& inputs,
+                            const std::vector<bool>& scalar_mask, size_t len, const std::vector<size_t>& output_shape) const {
+        std::vector<uint64_t> ids;
+        std::vector<unsigned char> mask;
+        for (const auto& h : inputs) ids.push_back(own(h));
+        for (bool m : scalar_mask) mask.push_back(m ? 1 : 0);
+        if (dims.size() != strides.size() || dims.size() != ids.size() || dims.size() != mask.size()) throw std::runtime_error("sub2ind: expected one subscript per dimension");
+        uint64_t out = 0;
+        check(rmhip_sub2ind(ctx_, dims.data(), strides.data(), ids.data(), mask.data(), dims.size(), len, output_shape.data(), output_shape.size(), &out));
+        return with_shape(out);
+    }
+    bool supports_ind2sub() const { return true; }
+    std::vector<GpuTensorHandle> ind2sub(const std::vector<size_t>& dims, const std::vector<size_t>& strides, const GpuTensorHandle& indices, size_t total,
+                                         size_t len, const std::vector<size_t>& output_shape) const {
+        std::vector<uint64_t> outs(dims.size() ? dims.size() : 1);
+        check(rmhip_ind2sub(ctx_, dims.data(), strides.data(), dims.size(), own(indices), total, len, output_shape.data(), output_shape.size(), outs.data()));
+        std::vector<GpuTensorHandle> r;
+        for (size_t i = 0; i < dims.size(); ++i) r.push_back(with_shape(outs[i]));
+        return r;
+    }
+    GpuTensorHandle scatter_column(const GpuTensorHandle& m, size_t col, const GpuTensorHandle& v) const {
+        uint64_t out = 0;
+        check(rmhip_scatter_line(ctx_, own(m), 1, col, own(v), &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle scatter_row(const GpuTensorHandle& m, size_t row, const GpuTensorHandle& v) const {
+        uint64_t out = 0;
+        check(rmhip_scatter_line(ctx_, own(m), 0, row, own(v), &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle pow2_scale(const GpuTensorHandle& m, const GpuTensorHandle& e) const {
+        uint64_t out = 0;
+        check(rmhip_pow2_scale(ctx_, own(m), own(e), &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle round_digits(const GpuTensorHandle& a, int digits, bool significant) const {
+        uint64_t out = 0;
+        check(rmhip_round_digits(ctx_, own(a), digits, significant ? 1 : 0, &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle real_part_(int part, const GpuTensorHandle& a) const {
+        uint64_t out = 0;
+        check(rmhip_real_part(ctx_, part, own(a), &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle unary_real(const GpuTensorHandle& a) const { return real_part_(0, a); }
+    GpuTensorHandle unary_imag(const GpuTensorHandle& a) const { return real_part_(1, a); }
+    GpuTensorHandle unary_conj(const GpuTensorHandle& a) const { return real_part_(2, a); }
+    GpuTensorHandle unary_angle(const GpuTensorHandle& a) const { return real_part_(3, a); }
+    bool logical_isreal(const GpuTensorHandle& a) const {
+        int r = 0;
+        check(rmhip_isreal(ctx_, own(a), &r));
+        return r != 0;
+    }
     // lib.rs:1600-1623, 2697-2708, 2604-2620, 3115-3124 (misc_ops.hip)
     GpuTensorHandle diag_from_vector(const GpuTensorHandle& v, long long offset) const {
         uint64_t out = 0;

@@ -814,3 +814,116 @@ def trapz(x: np.ndarray, dim: int, spacing=None, cumulative: bool = False) -> np
     l.orc_trapz.argtypes = [_DP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_double, _DP, C.c_int, _DP]
     l.orc_trapz(_p(_f(x)), pre, ln, post, kind, scalar, _p(sp) if sp is not None else None, int(cumulative), _p(out))
     return out.reshape(oshape, order="F")
+
+
+# ---- subscript / grid / slice-write hooks (numpy restatements of integer / copy work; file:line of what each follows) ----
+
+def ndgrid(axes, output_shape, output_count):
+    """simple_provider.rs:2784-2855: out_d[i] = axis_d[(i / stride_d) % extent_d]."""
+    total = int(np.prod(output_shape, dtype=np.int64))
+    i = np.arange(total, dtype=np.int64)
+    outs, stride = [], 1
+    for d in range(output_count):
+        ext = output_shape[d] if d < len(output_shape) else 1
+        ax = np.asarray(axes[d], dtype=np.float64).ravel(order="F")
+        assert ax.size == ext
+        outs.append(ax[(i // stride) % max(ext, 1)].reshape(output_shape, order="F") if total else np.zeros(output_shape))
+        stride *= ext
+    return outs
+
+
+def _round_half_away(v):
+    """f64::round: to the nearest integer, halves away from zero - exactly (trunc + comparison of the exact fraction, no v + 0.5)."""
+    v = np.asarray(v, dtype=np.float64)
+    t = np.trunc(v)
+    with np.errstate(invalid="ignore"):
+        return np.where(np.abs(v - t) >= 0.5, t + np.copysign(1.0, v), t)
+
+
+def _coerce_index(v, upper):
+    """coerce_sub2ind_value / coerce_linear_index (simple_provider.rs:2268-2291, ind2sub.rs:326-353): None when refused."""
+    if not np.isfinite(v):
+        return None
+    r = _round_half_away(np.float64(v))
+    if abs(r - v) > np.finfo(float).eps or r < 1.0 or r > upper:
+        return None
+    return int(r)
+
+
+def sub2ind(dims, strides, inputs, scalar_mask, length, output_shape):
+    """simple_provider.rs:8340-8420: the linear indices, or (i, d) of the first refused subscript in (element, dimension) order."""
+    cols = [np.asarray(x, dtype=np.float64).ravel(order="F") for x in inputs]
+    out = np.empty(length)
+    for i in range(length):
+        off = 0
+        for d, (dim, st) in enumerate(zip(dims, strides)):
+            c = _coerce_index(cols[d][0 if scalar_mask[d] else i], dim)
+            if c is None:
+                return (i, d)
+            off += (c - 1) * st
+        out[i] = off + 1
+    return out.reshape(output_shape, order="F")
+
+
+def ind2sub(dims, strides, indices, total):
+    """ind2sub.rs:289-324: one subscript array per dimension, or the position of the first refused index."""
+    idx = np.asarray(indices, dtype=np.float64)
+    flat = idx.ravel(order="F")
+    outs = [np.empty(flat.size) for _ in dims]
+    for i, v in enumerate(flat):
+        c = _coerce_index(v, total)
+        if c is None:
+            return i
+        for d, (dim, st) in enumerate(zip(dims, strides)):
+            outs[d][i] = ((c - 1) // st) % dim + 1
+    return [o.reshape(idx.shape, order="F") for o in outs]
+
+
+def scatter_line(matrix, is_column, index, values):
+    """write_slice.rs:680-709: the matrix with one whole column / row replaced."""
+    m = np.array(matrix, dtype=np.float64, order="F", copy=True)
+    v = np.asarray(values, dtype=np.float64).ravel(order="F")
+    if is_column:
+        m[:, index] = v
+    else:
+        m[index, :] = v
+    return m
+
+
+def pow2_scale(m, e):
+    """simple_provider.rs:5838-5840: m * exp2(e)."""
+    return np.asarray(m, dtype=np.float64) * np.exp2(np.asarray(e, dtype=np.float64))
+
+
+def powi10(b: int) -> float:
+    """Rust f64::powi (compiler-rt __powidf2): square-and-multiply, reciprocal last."""
+    recip, e, a, r = b < 0, abs(int(b)), np.float64(10.0), np.float64(1.0)
+    with np.errstate(over="ignore"):
+        while True:
+            if e & 1:
+                r = r * a
+            e //= 2
+            if e == 0:
+                break
+            a = a * a
+        return float(np.float64(1.0) / r) if recip else float(r)
+
+
+def round_decimals(x, digits: int):
+    """round_decimals, simple_provider.rs:5366-5378."""
+    x = np.asarray(x, dtype=np.float64)
+    f = powi10(digits)
+    rnd = _round_half_away
+    out = x.copy()
+    fin = np.isfinite(x)
+    if digits == 0:
+        out[fin] = rnd(x[fin])
+    elif np.isfinite(f) and f != 0.0:
+        with np.errstate(over="ignore", invalid="ignore"):
+            out[fin] = rnd(x[fin] * f) / f
+    return out
+
+
+def angle_real(x):
+    """0.0f64.atan2(x), simple_provider.rs:5502."""
+    return np.arctan2(np.zeros_like(np.asarray(x, dtype=np.float64)), np.asarray(x, dtype=np.float64))

@@ -863,6 +863,83 @@ class HipProvider:
         self._check(self._lib.rmhip_random_normal(self._ctx, sh, rank, C.byref(out)))
         return self._handle(out.value, shape)
 
+    # -- subscript / grid / slice-write hooks, per-element forms of a real tensor (index_ops.hip) -----
+    def ndgrid(self, axes: Sequence[GpuTensorHandle], output_shape: Sequence[int], output_count: int) -> List[GpuTensorHandle]:
+        """lib.rs:1567-1569 (`ProviderNdgridRequest{axes, output_shape, output_count}` -> `ProviderNdgridResult{outputs}`)."""
+        ids = (C.c_uint64 * max(len(axes), 1))(*[self._id(a) for a in axes])
+        sh, rank = _shape_array(output_shape)
+        outs = (C.c_uint64 * max(int(output_count), 1))()
+        self._check(self._lib.rmhip_ndgrid(self._ctx, ids, len(axes), sh, rank, int(output_count), outs))
+        return [self._handle(outs[i]) for i in range(int(output_count))]
+
+    def sub2ind(self, dims: Sequence[int], strides: Sequence[int], inputs: Sequence[GpuTensorHandle], scalar_mask: Sequence[bool], length: int,
+                output_shape: Sequence[int]) -> GpuTensorHandle:
+        """lib.rs:3084-3094."""
+        if not (len(dims) == len(strides) == len(inputs) == len(scalar_mask)):
+            raise RmhipError(1, f"sub2ind: expected {len(dims)} subscripts for {len(dims)} dimensions")
+        n = len(dims)
+        d, st = (C.c_size_t * max(n, 1))(*dims), (C.c_size_t * max(n, 1))(*strides)
+        ids = (C.c_uint64 * max(n, 1))(*[self._id(h) for h in inputs])
+        mask = (C.c_ubyte * max(n, 1))(*[1 if m else 0 for m in scalar_mask])
+        sh, rank = _shape_array(output_shape)
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_sub2ind(self._ctx, d, st, ids, mask, n, int(length), sh, rank, C.byref(out)))
+        return self._handle(out.value)
+
+    def supports_ind2sub(self) -> bool:
+        """lib.rs:3097-3099."""
+        return True
+
+    def ind2sub(self, dims: Sequence[int], strides: Sequence[int], indices: GpuTensorHandle, total: int, length: int,
+                output_shape: Sequence[int]) -> List[GpuTensorHandle]:
+        """lib.rs:3102-3112: one subscript tensor per dimension."""
+        n = len(dims)
+        d, st = (C.c_size_t * max(n, 1))(*dims), (C.c_size_t * max(n, 1))(*strides)
+        sh, rank = _shape_array(output_shape)
+        outs = (C.c_uint64 * max(n, 1))()
+        self._check(self._lib.rmhip_ind2sub(self._ctx, d, st, n, self._id(indices), int(total), int(length), sh, rank, outs))
+        return [self._handle(outs[i]) for i in range(n)]
+
+    def scatter_column(self, matrix, col_index: int, values) -> GpuTensorHandle:
+        """lib.rs:3064-3071: a new handle = the matrix with column `col_index` (zero-based) replaced."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_scatter_line(self._ctx, self._id(matrix), 1, int(col_index), self._id(values), C.byref(out)))
+        return self._handle(out.value)
+
+    def scatter_row(self, matrix, row_index: int, values) -> GpuTensorHandle:
+        """lib.rs:3075-3082."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_scatter_line(self._ctx, self._id(matrix), 0, int(row_index), self._id(values), C.byref(out)))
+        return self._handle(out.value)
+
+    def pow2_scale(self, mantissa, exponent) -> GpuTensorHandle:
+        """lib.rs:2325-2331: mantissa .* 2.^exponent, operands of one shape."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_pow2_scale(self._ctx, self._id(mantissa), self._id(exponent), C.byref(out)))
+        return self._handle(out.value)
+
+    def round_digits(self, a, digits: int, significant: bool = False) -> GpuTensorHandle:
+        """lib.rs:2197-2204 (decimals; `significant` is refused -> the host path)."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_round_digits(self._ctx, self._id(a), int(digits), 1 if significant else 0, C.byref(out)))
+        return self._handle(out.value)
+
+    def _real_part(self, part: int, a) -> GpuTensorHandle:
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_real_part(self._ctx, part, self._id(a), C.byref(out)))
+        return self._handle(out.value)
+
+    def unary_real(self, a): return self._real_part(0, a)   # lib.rs:2229
+    def unary_imag(self, a): return self._real_part(1, a)   # lib.rs:2223
+    def unary_conj(self, a): return self._real_part(2, a)   # lib.rs:2235
+    def unary_angle(self, a): return self._real_part(3, a)  # lib.rs:2217
+
+    def logical_isreal(self, a) -> bool:
+        """lib.rs:2055-2057."""
+        res = C.c_int()
+        self._check(self._lib.rmhip_isreal(self._ctx, self._id(a), C.byref(res)))
+        return bool(res.value)
+
     # -- small construction / linear-algebra hooks (misc_ops.hip) -----------------------------------
     def diag_from_vector(self, vector, offset: int = 0) -> GpuTensorHandle:
         """lib.rs:1600-1608: the square matrix of size len + |offset| with the vector on diagonal `offset`."""

@@ -17,7 +17,7 @@ use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle,
     HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, KernelAttrTelemetry, KernelLaunchTelemetry, MatmulEpilogue,
     PowerStepEpilogue, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderLinsolveOptions,
-    ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderNanMode, ProviderPrecision, ProviderScanDirection,
+    ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderNanMode, ProviderNdgridRequest, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
     ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult,
 };
 use std::ffi::{c_char, c_int, c_void, CStr, CString};
@@ -51,6 +51,11 @@ fn check(rc: c_int) -> Result<()> {
 }
 
 impl HipProvider {
+    fn real_part(&self, part: c_int, a: &GpuTensorHandle) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_real_part(self.ctx, part, self.own(a)?, &mut out) })?;
+        self.handle(out)
+    }
     // trapz_dim / cumtrapz_dim: ProviderTrapezoidSpacing (lib.rs:1060-1066) -> (kind, scalar, handle) of rmhip_trapz_dim
     fn trapezoid(&self, input: &GpuTensorHandle, dim: usize, spacing: ProviderTrapezoidSpacing<'_>, cumulative: c_int) -> Result<GpuTensorHandle> {
         let (kind, scalar, handle) = match spacing {
@@ -512,6 +517,70 @@ impl AccelProvider for HipProvider {
         let mut out = 0u64;
         check(unsafe { rmhip_random_uniform(self.ctx, shape.as_ptr(), shape.len(), &mut out) })?;
         Ok(GpuTensorHandle { shape: shape.to_vec(), device_id: self.device_id, buffer_id: out })
+    }
+    // subscript / grid / slice-write hooks and the per-element forms of a real tensor (index_ops.hip)
+    fn ndgrid(&self, request: &ProviderNdgridRequest<'_>) -> Result<ProviderNdgridResult> {
+        let ids: Vec<u64> = request.axes.iter().map(|a| self.own(a.handle)).collect::<Result<_>>()?;
+        let mut outs = vec![0u64; request.output_count.max(1)];
+        check(unsafe {
+            rmhip_ndgrid(self.ctx, ids.as_ptr(), ids.len(), request.output_shape.as_ptr(), request.output_shape.len(), request.output_count, outs.as_mut_ptr())
+        })?;
+        let outputs = outs[..request.output_count].iter().map(|&id| self.handle(id)).collect::<Result<Vec<_>>>()?;
+        Ok(ProviderNdgridResult { outputs })
+    }
+    fn sub2ind(&self, dims: &[usize], strides: &[usize], inputs: &[&GpuTensorHandle], scalar_mask: &[bool], len: usize, output_shape: &[usize]) -> Result<GpuTensorHandle> {
+        if inputs.len() != dims.len() || inputs.len() != scalar_mask.len() || strides.len() != dims.len() {
+            return Err(anyhow!("sub2ind: expected {} subscripts for {} dimensions", dims.len(), dims.len()));
+        }
+        let ids: Vec<u64> = inputs.iter().map(|h| self.own(h)).collect::<Result<_>>()?;
+        let mask: Vec<u8> = scalar_mask.iter().map(|&m| m as u8).collect();
+        let mut out = 0u64;
+        check(unsafe {
+            rmhip_sub2ind(self.ctx, dims.as_ptr(), strides.as_ptr(), ids.as_ptr(), mask.as_ptr(), dims.len(), len, output_shape.as_ptr(), output_shape.len(), &mut out)
+        })?;
+        self.handle(out)
+    }
+    fn supports_ind2sub(&self) -> bool { true }
+    fn ind2sub(&self, dims: &[usize], strides: &[usize], indices: &GpuTensorHandle, total: usize, len: usize, output_shape: &[usize]) -> Result<Vec<GpuTensorHandle>> {
+        if dims.len() != strides.len() {
+            return Err(anyhow!("ind2sub: size vector mismatch"));
+        }
+        let mut outs = vec![0u64; dims.len().max(1)];
+        check(unsafe {
+            rmhip_ind2sub(self.ctx, dims.as_ptr(), strides.as_ptr(), dims.len(), self.own(indices)?, total, len, output_shape.as_ptr(), output_shape.len(), outs.as_mut_ptr())
+        })?;
+        outs[..dims.len()].iter().map(|&id| self.handle(id)).collect()
+    }
+    fn scatter_column(&self, matrix: &GpuTensorHandle, col_index: usize, values: &GpuTensorHandle) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_scatter_line(self.ctx, self.own(matrix)?, 1, col_index, self.own(values)?, &mut out) })?;
+        self.handle(out)
+    }
+    fn scatter_row(&self, matrix: &GpuTensorHandle, row_index: usize, values: &GpuTensorHandle) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_scatter_line(self.ctx, self.own(matrix)?, 0, row_index, self.own(values)?, &mut out) })?;
+        self.handle(out)
+    }
+    fn pow2_scale(&self, mantissa: &GpuTensorHandle, exponent: &GpuTensorHandle) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_pow2_scale(self.ctx, self.own(mantissa)?, self.own(exponent)?, &mut out) })?;
+        self.handle(out)
+    }
+    fn round_digits<'a>(&'a self, a: &'a GpuTensorHandle, digits: i32, significant: bool) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_round_digits(self.ctx, self.own(a)?, digits, significant as c_int, &mut out) })?;
+            self.handle(out)
+        })
+    }
+    fn unary_real<'a>(&'a self, a: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> { Box::pin(async move { self.real_part(0, a) }) }
+    fn unary_imag<'a>(&'a self, a: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> { Box::pin(async move { self.real_part(1, a) }) }
+    fn unary_conj<'a>(&'a self, a: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> { Box::pin(async move { self.real_part(2, a) }) }
+    fn unary_angle<'a>(&'a self, a: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> { Box::pin(async move { self.real_part(3, a) }) }
+    fn logical_isreal(&self, a: &GpuTensorHandle) -> Result<bool> {
+        let mut res: c_int = 0;
+        check(unsafe { rmhip_isreal(self.ctx, self.own(a)?, &mut res) })?;
+        Ok(res != 0)
     }
     // small construction / linear-algebra hooks (misc_ops.hip)
     fn diag_from_vector(&self, vector: &GpuTensorHandle, offset: isize) -> Result<GpuTensorHandle> {

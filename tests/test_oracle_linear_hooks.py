@@ -69,3 +69,22 @@ def test_inv_restatement_on_the_reference_vectors_and_against_numpy():
     for n in (1, 3, 50, 200):
         m = rng.standard_normal((n, n)) + n * np.eye(n)
         assert np.max(np.abs(oracle.inv(m) - np.linalg.inv(m))) <= 1e-13
+
+
+def test_index_hook_restatements_on_the_reference_vectors():
+    """sub2ind.rs / ind2sub.rs unit tests (sub2ind([3 4], 2, 3) = 8 and back; out-of-range and non-integer subscripts refused),
+    ndgrid.rs ([X, Y] = ndgrid(1:2, 1:3)), round.rs (round(2.345, 2) = 2.35 on doubles; halves away from zero), pow2 (ldexp on integers)."""
+    assert oracle.sub2ind([3, 4], [1, 3], [np.array([2.0]), np.array([3.0])], [False, False], 1, [1, 1]).ravel()[0] == 8.0
+    r, c = oracle.ind2sub([3, 4], [1, 3], np.array([[8.0]]), 12)
+    assert r.ravel()[0] == 2.0 and c.ravel()[0] == 3.0
+    assert oracle.sub2ind([3, 4], [1, 3], [np.array([4.0]), np.array([1.0])], [False, False], 1, [1, 1]) == (0, 0)
+    assert oracle.sub2ind([3, 4], [1, 3], [np.array([1.0, 2.0]), np.array([1.0, 1.5])], [False, False], 2, [2, 1]) == (1, 1)
+    assert oracle.ind2sub([3, 4], [1, 3], np.array([[1.0, 13.0]]), 12) == 1
+    X, Y = oracle.ndgrid([np.array([1.0, 2.0]), np.array([1.0, 2.0, 3.0])], [2, 3], 2)
+    assert np.array_equal(X, [[1, 1, 1], [2, 2, 2]]) and np.array_equal(Y, [[1, 2, 3], [1, 2, 3]])
+    assert list(oracle.round_decimals(np.array([2.5, -2.5, 0.5, 0.49999999999999994, -0.2]), 0)) == [3.0, -3.0, 1.0, 0.0, -0.0]
+    assert oracle.round_decimals(np.array([2.345]), 2)[0] == 2.35 and oracle.round_decimals(np.array([1234.0]), -2)[0] == 1200.0
+    assert oracle.powi10(3) == 1000.0 and oracle.powi10(-2) == 0.01 and oracle.powi10(22) == 1e22 and oracle.powi10(400) == np.inf
+    assert np.array_equal(oracle.pow2_scale(np.array([3.0, -1.5]), np.array([4.0, -1.0])), [48.0, -0.75])
+    a = oracle.angle_real(np.array([1.0, -1.0, 0.0, -0.0]))
+    assert list(a) == [0.0, np.pi, 0.0, np.pi]
