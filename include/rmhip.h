@@ -478,6 +478,13 @@ RMHIP_API int rmhip_mldivide(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, rmhip_buf
  * back); here the same transposition around the LU solve, with the same soft failures as rmhip_mldivide. */
 /* @serves mrdivide */
 RMHIP_API int rmhip_mrdivide(rmhip_ctx* ctx, rmhip_buf b, rmhip_buf a, rmhip_buf* out);
+/* `chol(a, lower)` (lib.rs:2502-2508 -> ProviderCholResult { factor, info } :658-662; host algorithm chol.rs:374-433: the reference's own
+ * Cholesky-Crout with a symmetry check of every pair to 1e-12 relative): the upper factor R (A = R'R) or, lower != 0, L = R'.  The SUCCESS
+ * path only - a recursive blocked factorisation (deep MFMA products, 64 x 64 leaves in LDS), *info = 0, forward error ~ cond * eps against
+ * the host's in-order sums.  A matrix that fails the symmetry check or has a pivot that is not positive and finite is
+ * RMHIP_ERR_UNSUPPORTED: the builtin falls back (chol.rs:331-342) and its host code produces `info` and the partial factor. */
+/* @serves chol */
+RMHIP_API int rmhip_chol(rmhip_ctx* ctx, rmhip_buf a, int lower, rmhip_buf* factor, unsigned* info);
 /* `inv(matrix, options)` (lib.rs:2430-2436, ProviderInvOptions {} :716; CPU inv.rs:209-230, 258-280: nalgebra 0.32.6 `try_inverse`, an LU
  * with partial pivoting and substitutions on the identity - absent from /root/reference, parity by residual as for mldivide): X = A \ I on
  * the LU path.  Scalars, [n, n] and [n, n, 1, ...] operands (the shape is kept); a non-square or higher-rank operand is

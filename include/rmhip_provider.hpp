@@ -430,6 +430,17 @@ public:
         check(rmhip_mldivide(ctx_, own(lhs), own(rhs), &out));
         return with_shape(out);
     }
+    // lib.rs:2502-2508 -> ProviderCholResult { factor, info } (lib.rs:658-662); throws for a matrix the host path must judge
+    struct CholResult {
+        GpuTensorHandle factor;
+        unsigned info;
+    };
+    CholResult chol(const GpuTensorHandle& a, bool lower) const {
+        uint64_t out = 0;
+        unsigned info = 0;
+        check(rmhip_chol(ctx_, own(a), lower ? 1 : 0, &out, &info));
+        return {with_shape(out), info};
+    }
     // lib.rs:2430-2436 (ProviderInvOptions is empty)
     GpuTensorHandle inv(const GpuTensorHandle& matrix) const {
         uint64_t out = 0;

@@ -1625,3 +1625,46 @@ ORC_API void orc_trapz(const double* x, size_t pre, size_t len, size_t post, int
             if (!cumulative) out[after * pre + before] = acc;
         }
 }
+
+/* chol_factor for real data, builtins/math/linalg/factor/chol.rs:374-433 (Cholesky-Crout on a row-major copy; here column-major in and
+ * out): per column j first the symmetry of every pair (i, j), i < j, to 1e-12 max(|a|, |b|, 1); then r_ij = (a_ij - sum_k r_ki r_kj) /
+ * r_ii in order k = 0 .. i-1, r_jj = sqrt of a positive finite sum.  info = 1-based column of the first failure (a tiny denominator
+ * reports ITS row); the rows from info - 1 on are zeroed.  Returns info (0 = success); `upper` is n x n column-major. */
+ORC_API unsigned orc_chol(const double* a, size_t n, double* upper) {
+    const double EPS = 1.0e-12;
+    size_t info = 0;
+    for (size_t i = 0; i < n * n; ++i) upper[i] = 0.0;
+    for (size_t j = 0; j < n && !info; ++j) {
+        for (size_t i = 0; i < j; ++i) {
+            const double x = a[i + j * n], y = a[j + i * n];
+            const double scale = fmax(fmax(fabs(x), fabs(y)), 1.0);
+            if (!(fabs(x - y) <= EPS * scale)) {
+                info = j + 1;
+                break;
+            }
+        }
+        if (info) break;
+        for (size_t i = 0; i <= j; ++i) {
+            double sum = a[i + j * n];
+            for (size_t k = 0; k < i; ++k) sum -= upper[k + i * n] * upper[k + j * n];
+            if (i == j) {
+                if (!isfinite(sum) || sum <= 0.0) {
+                    info = j + 1;
+                    break;
+                }
+                upper[i + i * n] = sqrt(sum);
+            } else {
+                const double den = upper[i + i * n];
+                if (fabs(den) <= EPS) {
+                    info = i + 1;
+                    break;
+                }
+                upper[i + j * n] = sum / den;
+            }
+        }
+    }
+    if (info)
+        for (size_t row = info - 1; row < n; ++row)
+            for (size_t col = row; col < n; ++col) upper[row + col * n] = 0.0;
+    return (unsigned)info;
+}

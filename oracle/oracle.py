@@ -927,3 +927,15 @@ def round_decimals(x, digits: int):
 def angle_real(x):
     """0.0f64.atan2(x), simple_provider.rs:5502."""
     return np.arctan2(np.zeros_like(np.asarray(x, dtype=np.float64)), np.asarray(x, dtype=np.float64))
+
+
+def chol(a: np.ndarray):
+    """(upper factor R with A = R'R, info) as chol.rs:374-433 computes them (info > 0: rows from info - 1 on are zero)."""
+    a = np.asarray(a, dtype=np.float64)
+    n = a.shape[0]
+    out = np.empty(max(n * n, 1))
+    l = lib()
+    l.orc_chol.restype = C.c_uint
+    l.orc_chol.argtypes = [_DP, C.c_size_t, _DP]
+    info = l.orc_chol(_p(_f(a)), n, _p(out))
+    return out[:n * n].reshape((n, n), order="F"), int(info)

@@ -72,6 +72,13 @@ class ReductionFlavor:
 
 
 @dataclass
+class ProviderCholResult:
+    """`ProviderCholResult` (lib.rs:658-662)."""
+    factor: "GpuTensorHandle"
+    info: int
+
+
+@dataclass
 class ProviderFindResult:
     """`ProviderFindResult` (lib.rs:623-628); `values` is always present here."""
     linear: "GpuTensorHandle"
@@ -663,6 +670,13 @@ class HipProvider:
         out = C.c_uint64()
         self._check(self._lib.rmhip_mrdivide(self._ctx, self._id(lhs), self._id(rhs), C.byref(out)))
         return self._handle(out.value)
+
+    def chol(self, a: GpuTensorHandle, lower: bool = False) -> "ProviderCholResult":
+        """`chol` (lib.rs:2502-2508) -> `ProviderCholResult{factor, info}` (:658-662): the success path only (info == 0); a matrix that is
+        not symmetric / positive definite raises (UNSUPPORTED) and chol.rs:331-342 takes its host path."""
+        out, info = C.c_uint64(), C.c_uint()
+        self._check(self._lib.rmhip_chol(self._ctx, self._id(a), 1 if lower else 0, C.byref(out), C.byref(info)))
+        return ProviderCholResult(self._handle(out.value), int(info.value))
 
     def inv(self, matrix: GpuTensorHandle, options=None) -> GpuTensorHandle:
         """`inv` (lib.rs:2430-2436; `ProviderInvOptions {}`): X = A \\ I on the LU path; SINGULAR -> the caller's CPU path (inv.rs:225-227)."""

@@ -54,3 +54,10 @@ for m in (2048, 4096, 8192):
     prov.free(prov.inv(am)); prov.synchronize(); prov.timer_begin(); prov.free(prov.inv(am)); t = prov.timer_end()
     print(f"inv {m}^2: {t:9.3f} ms  {(8.0/3.0)*m**3/(t*1e-3)/1e12:6.1f} TFLOP/s on (8/3) n^3", flush=True)
     prov.free(am)
+for m in (2048, 4096, 8192, 16384):
+    hm = prov.fill_uniform(20, -1.0, 1.0, (m, m))
+    spd = prov.elem_add(prov.syrk(hm), prov.scalar_mul(prov.eye((m, m)), float(m)))
+    prov.free(hm)
+    prov.free(prov.chol(spd).factor); prov.synchronize(); prov.timer_begin(); prov.free(prov.chol(spd).factor); t = prov.timer_end()
+    print(f"chol {m}^2: {t:9.3f} ms  {(1.0/3.0)*m**3/(t*1e-3)/1e12:6.1f} TFLOP/s on n^3 / 3", flush=True)
+    prov.free(spd)

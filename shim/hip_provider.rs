@@ -16,7 +16,7 @@ use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle,
     HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, KernelAttrTelemetry, KernelLaunchTelemetry, MatmulEpilogue,
-    PowerStepEpilogue, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderLinsolveOptions,
+    PowerStepEpilogue, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderNanMode, ProviderNdgridRequest, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
     ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult,
 };
@@ -418,6 +418,14 @@ impl AccelProvider for HipProvider {
             let mut out = 0u64;
             check(unsafe { rmhip_mldivide(self.ctx, self.own(lhs)?, self.own(rhs)?, &mut out) })?;
             self.handle(out)
+        })
+    }
+    // chol: the device's success path (info = 0); Err for a matrix that is not symmetric positive definite -> chol.rs:331-342 host path
+    fn chol<'a>(&'a self, a: &'a GpuTensorHandle, lower: bool) -> AccelProviderFuture<'a, ProviderCholResult> {
+        Box::pin(async move {
+            let (mut out, mut info) = (0u64, 0u32);
+            check(unsafe { rmhip_chol(self.ctx, self.own(a)?, lower as c_int, &mut out, &mut info) })?;
+            Ok(ProviderCholResult { factor: self.handle(out)?, info })
         })
     }
     // inv(A) = A \ I on the LU path; Err (singular, non-square) sends inv.rs back to its host code, which words the error

@@ -202,3 +202,58 @@ def test_trapz_and_cumtrapz(prov, oracle, shape):
     if shape[0] > 1:
         with pytest.raises(Exception):                                               # simple_provider.rs:2523-2526
             prov.trapz_dim(hx, 0, ("vector", prov.upload(np.zeros((shape[0] - 1, 1)))))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 65, 100, 128, 129, 300, 1000, 2049])
+def test_chol_matches_the_oracle(prov, oracle, n):
+    """The blocked factorisation against the reference's Cholesky-Crout restatement: forward error within cond * eps (the two sum in
+    different orders), R'R = A to rounding, the strict other triangle exactly zero; `lower` is the transpose."""
+    rng = np.random.default_rng(n)
+    b = rng.standard_normal((n, n))
+    a = b @ b.T + n * np.eye(n)
+    a = 0.5 * (a + a.T)
+    h = prov.upload(a)
+    res = prov.chol(h)
+    r = prov.download_matrix(res.factor)
+    want, info = oracle.chol(a)
+    assert info == 0 and res.info == 0
+    cond = np.linalg.cond(a)
+    assert np.max(np.abs(r - want)) <= 20 * cond * np.finfo(float).eps * np.max(np.abs(want)), n
+    assert np.max(np.abs(r.T @ r - a)) <= 50 * n * np.finfo(float).eps * np.max(np.abs(a))
+    assert np.array_equal(np.tril(r, -1), np.zeros((n, n)))
+    low = prov.download_matrix(prov.chol(h, True).factor)
+    assert np.array_equal(low, r.T)
+
+
+def test_chol_reference_vector_and_refusals(prov, oracle):
+    a = np.array([[4.0, 12, -16], [12, 37, -43], [-16, -43, 98]])
+    assert np.array_equal(prov.download_matrix(prov.chol(prov.upload(a)).factor), [[2, 6, -8], [0, 1, 5], [0, 0, 3]])   # chol.rs unit test
+    assert tuple(prov.chol(prov.upload(np.zeros((0, 0)))).factor.shape) == (0, 0)
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal((200, 200))
+    spd = b @ b.T + 200 * np.eye(200)
+    bad_pd = spd.copy()
+    bad_pd[150, 150] = -5.0                                  # not positive definite from column 151 on
+    bad_sym = spd.copy()
+    bad_sym[3, 170] += 1e-6                                  # pair (3, 170) differs by more than 1e-12 relative
+    nan = spd.copy()
+    nan[10, 10] = np.nan
+    for m in (bad_pd, bad_sym, nan, np.zeros((3, 4)), np.array([[-1.0]])):
+        if m.shape[0] == m.shape[1]:
+            assert oracle.chol(m)[1] != 0                    # the host path reports a failure index for each of these
+        with pytest.raises(Exception):
+            prov.chol(prov.upload(m))
+
+
+def test_chol_at_8192(prov):
+    n = 8192
+    h = prov.fill_uniform(4, -1.0, 1.0, (n, n))
+    g = prov.syrk(h)                                         # A'A: symmetric by construction, SPD for a random square A... plus a shift
+    shifted = prov.elem_add(g, prov.scalar_mul(prov.eye((n, n)), float(n)))
+    a = prov.download_matrix(shifted)
+    assert np.array_equal(a, a.T)
+    res = prov.chol(shifted)
+    r = prov.download_matrix(res.factor)
+    assert res.info == 0 and np.array_equal(np.tril(r, -1), np.zeros((n, n)))
+    x = np.random.default_rng(0).standard_normal((n, 4))
+    assert np.max(np.abs(r.T @ (r @ x) - a @ x)) <= 1e-9 * np.max(np.abs(a @ x))

@@ -88,3 +88,19 @@ def test_index_hook_restatements_on_the_reference_vectors():
     assert np.array_equal(oracle.pow2_scale(np.array([3.0, -1.5]), np.array([4.0, -1.0])), [48.0, -0.75])
     a = oracle.angle_real(np.array([1.0, -1.0, 0.0, -0.0]))
     assert list(a) == [0.0, np.pi, 0.0, np.pi]
+
+
+def test_chol_restatement():
+    """chol.rs unit tests: the SPD 3 x 3 [[4 12 -16]; [12 37 -43]; [-16 -43 98]] -> R = [[2 6 -8]; [0 1 5]; [0 0 3]]; a non-positive pivot
+    reports its column and zeroes the rest; an asymmetric pair reports the column it is found in."""
+    a = np.array([[4.0, 12, -16], [12, 37, -43], [-16, -43, 98]])
+    r, info = oracle.chol(a)
+    assert info == 0 and np.array_equal(r, [[2, 6, -8], [0, 1, 5], [0, 0, 3]])
+    r, info = oracle.chol(np.array([[1.0, 2.0], [2.0, 1.0]]))
+    assert info == 2 and np.array_equal(r, [[1.0, 2.0], [0.0, 0.0]])
+    assert oracle.chol(np.array([[4.0, 2.0], [2.000001, 3.0]]))[1] == 2 and oracle.chol(np.array([[-1.0]]))[1] == 1
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal((80, 80))
+    a = b @ b.T + 80 * np.eye(80)
+    r, info = oracle.chol(a)
+    assert info == 0 and np.max(np.abs(r - np.linalg.cholesky(a).T)) < 1e-12 and np.array_equal(np.tril(r, -1), np.zeros((80, 80)))
