@@ -409,6 +409,14 @@ RMHIP_API int rmhip_gradient_dim(rmhip_ctx* ctx, rmhip_buf a, int dim, double sp
 /* @serves trapz_dim cumtrapz_dim */
 RMHIP_API int rmhip_trapz_dim(rmhip_ctx* ctx, rmhip_buf a, int dim, int cumulative, int spacing_kind, double scalar, rmhip_buf spacing_or_0,
                               rmhip_buf* out);
+/* `norm(tensor, order)` (lib.rs:2451-2457, ProviderNormOrder :745-754; CPU norm.rs:269-529) -> a [1, 1] tensor.  order 1 One, 2 Two,
+ * 3 Inf, 4 NegInf, 5 Zero, 6 Fro, 7 Nuc, 8 P(p).  Vectors (a dimension <= 1): sum |x|, root of the sum of squares (scaled by a power
+ * of two when the squares would overflow or underflow), max / min |x| (an empty or all-infinite minimum is 0), the count of nonzeros,
+ * (sum |x|^p)^(1/p) for finite p >= 1.  Matrices: One = largest column sum of |a|, Inf = largest row sum, Fro as for vectors.  Any NaN
+ * gives NaN.  The matrix 2-norm and the nuclear norm (singular values) are RMHIP_ERR_UNSUPPORTED; orders the builtin refuses (matrix
+ * -Inf / 0 / p, a vector's nuclear norm, p < 1) are RMHIP_ERR_INVALID.  Sums in a different order than the CPU's loops: n eps relative. */
+/* @serves norm */
+RMHIP_API int rmhip_norm(rmhip_ctx* ctx, rmhip_buf a, int order, double p, rmhip_buf* out);
 /* `issymmetric(matrix, kind, tolerance)` (lib.rs:3115-3124; issymmetric.rs:461-487, 517-526): 1 when a(i,j) equals a(j,i) (skew != 0:
  * -a(j,i), and a zero diagonal), pairs compared as `v == r || (both finite && |v - r| <= tolerance)`; a non-square operand is 0, an
  * operand with trailing extents > 1 RMHIP_ERR_INVALID.  Synchronises the stream (a host bool comes back). */

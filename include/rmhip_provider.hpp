@@ -622,6 +622,12 @@ public:
         check(rmhip_trapz_dim(ctx_, own(a), (int)dim, 1, spacing_kind, scalar, spacing ? own(*spacing) : 0, &out));
         return with_shape(out);
     }
+    // lib.rs:2451-2457; order as ProviderNormOrder: 1 One, 2 Two, 3 Inf, 4 NegInf, 5 Zero, 6 Fro, 7 Nuc, 8 P(p)
+    GpuTensorHandle norm(const GpuTensorHandle& t, int order, double p = 2.0) const {
+        uint64_t out = 0;
+        check(rmhip_norm(ctx_, own(t), order, p, &out));
+        return with_shape(out);
+    }
     bool issymmetric(const GpuTensorHandle& m, bool skew, double tolerance) const {
         int r = 0;
         check(rmhip_issymmetric(ctx_, own(m), skew ? 1 : 0, tolerance, &r));

@@ -1668,3 +1668,76 @@ ORC_API unsigned orc_chol(const double* a, size_t n, double* upper) {
             for (size_t col = row; col < n; ++col) upper[row + col * n] = 0.0;
     return (unsigned)info;
 }
+
+/* norm of real data, builtins/math/linalg/norm.rs:269-282, 320-380, 381-411, 413-452, 497-529.  kind: 0 vector, 1 matrix (rows x cols).
+ * order: 1 one, 2 two, 3 inf, 4 -inf, 5 zero, 6 fro, 7 nuc, 8 P(p).  Returns NaN for what the CPU refuses or computes with an SVD
+ * (matrix 2-norm, nuclear norm, vector p < 1): *refused is set for those. */
+static double orc_rss(const double* v, size_t n) { /* root_sum_of_squares, norm.rs:381-411 */
+    double scale = 0.0, sumsq = 1.0;
+    size_t count = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const double a = fabs(v[i]);
+        if (a != a) return NAN;
+        if (isinf(a)) return INFINITY;
+        if (a == 0.0) continue;
+        if (scale < a) {
+            const double ratio = scale == 0.0 ? 0.0 : scale / a;
+            sumsq = 1.0 + sumsq * ratio * ratio;
+            scale = a;
+        } else {
+            const double ratio = a / scale;
+            sumsq += ratio * ratio;
+        }
+        ++count;
+    }
+    return count == 0 ? 0.0 : scale * sqrt(sumsq);
+}
+ORC_API double orc_norm(const double* data, size_t rows, size_t cols, int is_matrix, int order, double p, int* refused) {
+    const size_t n = rows * cols;
+    *refused = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (data[i] != data[i]) return NAN;  /* any NaN: NaN (norm.rs:321-323, 419-421) */
+    if (!is_matrix) {
+        if (order == 1) { double s = 0.0; for (size_t i = 0; i < n; ++i) s += fabs(data[i]); return s; }
+        if (order == 2 || order == 6) return orc_rss(data, n);
+        if (order == 3) { double m = 0.0; for (size_t i = 0; i < n; ++i) if (fabs(data[i]) > m) m = fabs(data[i]); return m; }
+        if (order == 4) {
+            if (n == 0) return 0.0;
+            double m = INFINITY;
+            for (size_t i = 0; i < n; ++i) if (fabs(data[i]) < m) m = fabs(data[i]);
+            return m == INFINITY ? 0.0 : m;
+        }
+        if (order == 5) { double c = 0.0; for (size_t i = 0; i < n; ++i) if (fabs(data[i]) != 0.0) c += 1.0; return c; }
+        if (order == 8) {
+            if (!isfinite(p) || p < 1.0) { *refused = 1; return NAN; }
+            if (n == 0) return 0.0;
+            double s = 0.0;
+            for (size_t i = 0; i < n; ++i) s += pow(fabs(data[i]), p);
+            return pow(s, 1.0 / p);
+        }
+        *refused = 1;
+        return NAN;
+    }
+    if (rows == 0 || cols == 0) return 0.0;
+    if (order == 1) { /* max_column_sum */
+        double best = 0.0;
+        for (size_t c = 0; c < cols; ++c) {
+            double s = 0.0;
+            for (size_t r = 0; r < rows; ++r) s += fabs(data[r + c * rows]);
+            if (s > best) best = s;
+        }
+        return best;
+    }
+    if (order == 3) { /* max_row_sum */
+        double best = 0.0;
+        for (size_t r = 0; r < rows; ++r) {
+            double s = 0.0;
+            for (size_t c = 0; c < cols; ++c) s += fabs(data[r + c * rows]);
+            if (s > best) best = s;
+        }
+        return best;
+    }
+    if (order == 6) return orc_rss(data, n);
+    *refused = 1;
+    return NAN;
+}

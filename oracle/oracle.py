@@ -939,3 +939,20 @@ def chol(a: np.ndarray):
     l.orc_chol.argtypes = [_DP, C.c_size_t, _DP]
     info = l.orc_chol(_p(_f(a)), n, _p(out))
     return out[:n * n].reshape((n, n), order="F"), int(info)
+
+
+NORM_ORDERS = {"one": 1, "two": 2, "inf": 3, "-inf": 4, "zero": 5, "fro": 6, "nuc": 7, "p": 8}
+
+
+def norm(x: np.ndarray, order="two", p: float = 2.0):
+    """norm.rs:269-529 for real data: the value, or None where the CPU refuses / needs an SVD (matrix 2-norm, nuclear, vector p < 1)."""
+    x = np.asarray(x, dtype=np.float64)
+    rows = x.shape[0] if x.ndim >= 1 else 1
+    cols = x.shape[1] if x.ndim >= 2 else 1
+    is_matrix = not (x.ndim <= 1 or rows <= 1 or cols <= 1)
+    l = lib()
+    l.orc_norm.restype = C.c_double
+    l.orc_norm.argtypes = [_DP, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int)]
+    refused = C.c_int(0)
+    v = l.orc_norm(_p(_f(x)), rows if is_matrix else x.size, cols if is_matrix else 1, int(is_matrix), NORM_ORDERS[order], float(p), C.byref(refused))
+    return None if refused.value else float(v)

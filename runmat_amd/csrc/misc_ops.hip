@@ -6,7 +6,9 @@
 //   gradient_dim(_with_coordinates)   lib.rs:2604-2620    (builtins/math/reduction/gradient.rs:650-720, 814-833)
 //   issymmetric                       lib.rs:3115-3124    (builtins/math/linalg/structure/issymmetric.rs:461-487, 517-526)
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <limits>
 
 #include "common.h"
 
@@ -147,6 +149,99 @@ __global__ void __launch_bounds__(kB) k_trapz_terms(const double* __restrict__ x
         v = 0.5 * w * (x[i0] + x[o]);
     }
     __builtin_nontemporal_store(v, t + o);
+}
+
+// norm: per-workgroup partials of one sweep - sum |x|, max |x|, min |x|, count of nonzeros, NaN seen, sum (|x| scale)^2, sum |x|^p -
+// combined by the last workgroup to finish (ticket), so every vector norm and the Frobenius norm is ONE launch after the sweep that
+// found the scale.  The squares are scaled by an exact power of two taken from max |x| (the CPU's root_sum_of_squares rescales as it
+// goes, norm.rs:381-411: same protection against overflow / underflow, different summation order).
+struct NormPartial {
+    double sum_abs, max_abs, min_abs, nnz, sumsq, sump;
+    int nan;
+    int pad;
+};
+__global__ void __launch_bounds__(256) k_norm_sweep(const double* __restrict__ x, u64 n, double scale, double p, int want_p, NormPartial* __restrict__ parts,
+                                                    unsigned* __restrict__ ticket, NormPartial* __restrict__ out) {
+    __shared__ NormPartial sh[256];
+    __shared__ int last;
+    NormPartial a;
+    a.sum_abs = 0.0;
+    a.max_abs = 0.0;
+    a.min_abs = __longlong_as_double(0x7ff0000000000000ll);
+    a.nnz = 0.0;
+    a.sumsq = 0.0;
+    a.sump = 0.0;
+    a.nan = 0;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+        const double v = fabs(__builtin_nontemporal_load(x + i));
+        if (v != v) a.nan = 1;
+        a.sum_abs += v;
+        a.max_abs = v > a.max_abs ? v : a.max_abs;
+        a.min_abs = v < a.min_abs ? v : a.min_abs;
+        a.nnz += v != 0.0 ? 1.0 : 0.0;
+        const double sv = v * scale;
+        a.sumsq += sv * sv;
+        if (want_p) a.sump += pow(v, p);
+    }
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            NormPartial& m = sh[threadIdx.x];
+            const NormPartial& o = sh[threadIdx.x + d];
+            m.sum_abs += o.sum_abs;
+            m.max_abs = o.max_abs > m.max_abs ? o.max_abs : m.max_abs;
+            m.min_abs = o.min_abs < m.min_abs ? o.min_abs : m.min_abs;
+            m.nnz += o.nnz;
+            m.sumsq += o.sumsq;
+            m.sump += o.sump;
+            m.nan |= o.nan;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        parts[blockIdx.x] = sh[0];
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    NormPartial t = sh[0];
+    t.sum_abs = t.nnz = t.sumsq = t.sump = 0.0;
+    t.max_abs = 0.0;
+    t.min_abs = __longlong_as_double(0x7ff0000000000000ll);
+    t.nan = 0;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) {
+        const NormPartial o = parts[b];
+        t.sum_abs += o.sum_abs;
+        t.max_abs = o.max_abs > t.max_abs ? o.max_abs : t.max_abs;
+        t.min_abs = o.min_abs < t.min_abs ? o.min_abs : t.min_abs;
+        t.nnz += o.nnz;
+        t.sumsq += o.sumsq;
+        t.sump += o.sump;
+        t.nan |= o.nan;
+    }
+    sh[threadIdx.x] = t;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            NormPartial& m = sh[threadIdx.x];
+            const NormPartial& o = sh[threadIdx.x + d];
+            m.sum_abs += o.sum_abs;
+            m.max_abs = o.max_abs > m.max_abs ? o.max_abs : m.max_abs;
+            m.min_abs = o.min_abs < m.min_abs ? o.min_abs : m.min_abs;
+            m.nnz += o.nnz;
+            m.sumsq += o.sumsq;
+            m.sump += o.sump;
+            m.nan |= o.nan;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *out = sh[0];
+        *ticket = 0;
+    }
 }
 
 std::vector<size_t> matrix_shape(const std::vector<size_t>& s) {
@@ -355,5 +450,96 @@ int rmhip_trapz_dim(rmhip_ctx* ctx, rmhip_buf a, int dim, int cumulative, int sp
     int rc = hipGetLastError() == hipSuccess ? RMHIP_OK : fail(RMHIP_ERR_HIP, "trapezoid: launch failed");
     if (!rc) rc = cumulative ? rmhip_cumulative(ctx, 0, tid, dim, 0, 0, out) : rmhip_reduce(ctx, RMHIP_RSUM, tid, dim, 0, out);
     rmhip_free(ctx, tid);
+    return rc;
+}
+
+// order: 1 One, 2 Two, 3 Inf, 4 NegInf, 5 Zero, 6 Fro, 7 Nuc, 8 P(p)  (ProviderNormOrder, lib.rs:745-754)
+int rmhip_norm(rmhip_ctx* ctx, rmhip_buf a, int order, double p, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    if (order < 1 || order > 8) return fail(RMHIP_ERR_INVALID, "norm: order %d", order);
+    Buffer ab;
+    RMHIP_TRY(c->get(a, &ab));
+    // classify_tensor (norm.rs:299-318)
+    const std::vector<size_t>& s = ab.shape;
+    for (size_t d = 2; d < s.size(); ++d)
+        if (s[d] > 1) return fail(RMHIP_ERR_INVALID, "norm: input must be a vector or 2-D matrix.");
+    const size_t rows = s.empty() ? 0 : s[0], cols = s.size() < 2 ? 1 : s[1];
+    const bool matrix = !(s.size() <= 1 || rows <= 1 || cols <= 1);
+    if (matrix && (order == 2 || order == 7)) return fail(RMHIP_ERR_UNSUPPORTED, "norm: the spectral / nuclear norm of a matrix needs its singular values");
+    if (matrix && (order == 4 || order == 5 || order == 8)) return fail(RMHIP_ERR_INVALID, "norm: order not defined for matrices");  // norm.rs:441-451
+    if (!matrix && order == 7) return fail(RMHIP_ERR_INVALID, "norm: nuclear norm is only defined for matrices.");
+    if (!matrix && order == 8 && !(std::isfinite(p) && p >= 1.0)) return fail(RMHIP_ERR_INVALID, "norm: vector norm order %g must satisfy p >= 1 (or use 0, Inf, or -Inf).", p);
+    const size_t one[2] = {1, 1};
+    double value = 0.0;
+    const u64 n = ab.numel;
+    if (n > 0 && matrix && (order == 1 || order == 3)) {
+        // max column / row sum of |a| (norm.rs:497-529): |a|, sum along one dimension, max of the sums - the library's kernels
+        rmhip_buf absb = 0, sums = 0, mx = 0;
+        int rc = rmhip_unary(ctx, RMHIP_ABS, a, &absb);
+        if (!rc) rc = rmhip_reduce(ctx, RMHIP_RSUM, absb, order == 1 ? 0 : 1, 0, &sums);
+        if (!rc) rc = rmhip_reduce(ctx, RMHIP_RMAX, sums, -1, 0, &mx);
+        if (!rc) rc = rmhip_read_scalar(ctx, mx, 0, &value);
+        if (!rc) {  // any NaN in the matrix is a NaN sum: the norm is NaN (norm.rs:419-421) whatever the maximum made of it
+            rmhip_buf tot = 0;
+            double t = 0.0;
+            rc = rmhip_reduce(ctx, RMHIP_RSUM, sums, -1, 0, &tot);
+            if (!rc) rc = rmhip_read_scalar(ctx, tot, 0, &t);
+            if (tot) rmhip_free(ctx, tot);
+            if (!rc && t != t) value = t;
+        }
+        if (absb) rmhip_free(ctx, absb);
+        if (sums) rmhip_free(ctx, sums);
+        if (mx) rmhip_free(ctx, mx);
+        if (rc) return rc;
+    } else if (n > 0) {
+        const unsigned grid = (unsigned)std::min<u64>((n + 1023) / 1024, (u64)c->num_cus * 8);
+        std::shared_ptr<Allocation> ws;
+        RMHIP_TRY(c->alloc_device((size_t)(grid + 1) * (sizeof(NormPartial) / 8) + 1, &ws));
+        NormPartial* parts = (NormPartial*)ws->ptr;
+        NormPartial* total = parts + grid;
+        unsigned* ticket = (unsigned*)(total + 1);
+        RMHIP_HIP_CHECK(hipMemsetAsync(ticket, 0, sizeof(unsigned), c->stream));
+        NormPartial h;
+        auto sweep = [&](double scale, int want_p) -> int {
+            hipLaunchKernelGGL(k_norm_sweep, dim3(grid), dim3(256), 0, c->stream, ab.data(), n, scale, p, want_p, parts, ticket, total);
+            c->tel.kernel_launches++;
+            RMHIP_HIP_CHECK(hipMemcpyAsync(&h, total, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+            return RMHIP_OK;
+        };
+        RMHIP_TRY(sweep(1.0, order == 8));
+        if (h.nan) {
+            value = std::numeric_limits<double>::quiet_NaN();
+        } else if (order == 1) {
+            value = h.sum_abs;
+        } else if (order == 3) {
+            value = h.max_abs;
+        } else if (order == 4) {
+            value = std::isinf(h.min_abs) ? 0.0 : h.min_abs;  // norm.rs:341-345
+        } else if (order == 5) {
+            value = h.nnz;
+        } else if (order == 8) {
+            value = std::pow(h.sump, 1.0 / p);
+        } else {  // Two (vector) / Fro
+            if (std::isinf(h.max_abs)) value = h.max_abs;
+            else if (h.max_abs == 0.0) value = 0.0;
+            else {
+                int e = 0;
+                (void)std::frexp(h.max_abs, &e);
+                const double scale = std::ldexp(1.0, -e);  // max |x| * scale in [0.5, 1): the squares neither overflow nor all underflow
+                if (e > 500 || e < -500) {
+                    RMHIP_TRY(sweep(scale, 0));
+                    value = std::sqrt(h.sumsq) * std::ldexp(1.0, e);
+                } else {
+                    value = std::sqrt(h.sumsq);  // the first sweep's plain squares
+                }
+            }
+        }
+    }
+    Buffer ob;
+    RMHIP_TRY(c->new_buffer(one, 2, out, &ob));
+    const int rc = launch_fill(c, ob.data(), 1, value);
+    if (rc) rmhip_free(ctx, *out);
     return rc;
 }

@@ -1016,6 +1016,15 @@ class HipProvider:
         """lib.rs:2901-2908."""
         return self._trapz(a, dim, spacing, True)
 
+    def norm(self, tensor, order="two", p: float = 2.0) -> GpuTensorHandle:
+        """lib.rs:2451-2457; `ProviderNormOrder` (:745-754) as "one" | "two" | "inf" | "-inf" | "zero" | "fro" | "nuc" | "p" (with `p`) -> [1, 1]."""
+        codes = {"one": 1, "two": 2, "inf": 3, "-inf": 4, "zero": 5, "fro": 6, "nuc": 7, "p": 8}
+        if order not in codes:
+            raise RmhipError(1, f"norm: order {order!r}")
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_norm(self._ctx, self._id(tensor), codes[order], float(p), C.byref(out)))
+        return self._handle(out.value)
+
     def issymmetric(self, matrix, kind: str = "symmetric", tolerance: float = 0.0) -> bool:
         """lib.rs:3115-3124 (`ProviderSymmetryKind::{Symmetric, Skew}`): decided on the device, only the bool comes back."""
         if kind not in ("symmetric", "skew"):

@@ -17,7 +17,7 @@ use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle,
     HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, KernelAttrTelemetry, KernelLaunchTelemetry, MatmulEpilogue,
     PowerStepEpilogue, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderLinsolveOptions,
-    ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderNanMode, ProviderNdgridRequest, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
+    ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderNanMode, ProviderNdgridRequest, ProviderNormOrder, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
     ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult,
 };
 use std::ffi::{c_char, c_int, c_void, CStr, CString};
@@ -630,6 +630,23 @@ impl AccelProvider for HipProvider {
     }
     fn cumtrapz_dim(&self, input: &GpuTensorHandle, dim: usize, spacing: ProviderTrapezoidSpacing<'_>) -> Result<GpuTensorHandle> {
         self.trapezoid(input, dim, spacing, 1)
+    }
+    fn norm<'a>(&'a self, tensor: &'a GpuTensorHandle, order: ProviderNormOrder) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let (code, p) = match order {
+                ProviderNormOrder::One => (1, 0.0),
+                ProviderNormOrder::Two => (2, 0.0),
+                ProviderNormOrder::Inf => (3, 0.0),
+                ProviderNormOrder::NegInf => (4, 0.0),
+                ProviderNormOrder::Zero => (5, 0.0),
+                ProviderNormOrder::Fro => (6, 0.0),
+                ProviderNormOrder::Nuc => (7, 0.0),
+                ProviderNormOrder::P(p) => (8, p),
+            };
+            let mut out = 0u64;
+            check(unsafe { rmhip_norm(self.ctx, self.own(tensor)?, code, p, &mut out) })?;
+            self.handle(out)
+        })
     }
     fn issymmetric(&self, matrix: &GpuTensorHandle, kind: ProviderSymmetryKind, tolerance: f64) -> Result<bool> {
         let mut res: c_int = 0;

@@ -257,3 +257,51 @@ def test_chol_at_8192(prov):
     assert res.info == 0 and np.array_equal(np.tril(r, -1), np.zeros((n, n)))
     x = np.random.default_rng(0).standard_normal((n, 4))
     assert np.max(np.abs(r.T @ (r @ x) - a @ x)) <= 1e-9 * np.max(np.abs(a @ x))
+
+
+def test_norm(prov, oracle):
+    """Every order the CPU computes without singular values, on vectors and matrices, against the restated loops (norm.rs:269-529):
+    sums in another order (n eps), maxima / counts exact; the reference's unit-test values; NaN, infinities, huge and tiny magnitudes."""
+    rng = np.random.default_rng(12)
+
+    def val(h, order, p=2.0):
+        return float(prov.download(prov.norm(h, order, p)).ravel()[0])
+
+    kats = [(np.array([[3.0], [4.0]]), "two", 2.0, 5.0), (np.array([[2.0], [-7.0], [4.0]]), "inf", 2.0, 7.0), (np.array([[2.0], [-7.0], [4.0]]), "-inf", 2.0, 2.0),
+            (np.array([[0.0], [0.0], [5.0], [0.0]]), "zero", 2.0, 1.0), (np.array([[2.0, 0.0], [0.0, 1.0]]), "fro", 2.0, np.sqrt(5.0)), (np.array([[2.0], [-3.0]]), "one", 2.0, 5.0)]
+    for x, order, p, want in kats:                                                   # norm.rs:795-960
+        assert abs(val(prov.upload(x), order, p) - want) < 1e-12
+    assert abs(val(prov.upload(np.array([[1.0], [2.0], [3.0]])), "p", 1.5) - (1 + 2 ** 1.5 + 3 ** 1.5) ** (1 / 1.5)) < 1e-12
+    for shape in ((1, 1), (7, 1), (1, 1000), (100003, 1), (300, 200), (2, 5000), (4096, 3)):
+        x = rng.standard_normal(shape)
+        h = prov.upload(x)
+        is_matrix = min(shape) > 1
+        for order in (("one", "inf", "fro") if is_matrix else ("one", "two", "inf", "-inf", "zero", "fro", "p")):
+            want = oracle.norm(x, order, 3.0)
+            got = val(h, order, 3.0)
+            assert abs(got - want) <= 1e-13 * max(x.size, 16) * abs(want) + 1e-300, (shape, order, got, want)
+        if is_matrix:
+            for order in ("two", "nuc", "zero", "-inf", "p"):
+                assert oracle.norm(x, order, 3.0) is None or order in ("zero", "-inf", "p")
+                with pytest.raises(Exception):
+                    prov.norm(h, order, 3.0)
+        else:
+            with pytest.raises(Exception):
+                prov.norm(h, "nuc")
+            with pytest.raises(Exception):
+                prov.norm(h, "p", 0.5)
+    big = np.array([1e200, -3e200, 2e-200, 0.0]).reshape(-1, 1)
+    assert abs(val(prov.upload(big), "two") / oracle.norm(big, "two") - 1) < 1e-15       # squares overflow without the scale
+    tiny = np.array([3e-200, 4e-200]).reshape(-1, 1)
+    assert abs(val(prov.upload(tiny), "two") / 5e-200 - 1) < 1e-15
+    for bad, order in ((np.array([[1.0], [np.nan]]), "inf"), (np.array([[1.0, np.nan], [2.0, 3.0]]), "one"), (np.array([[1.0, 2.0], [np.nan, 3.0]]), "fro")):
+        assert np.isnan(val(prov.upload(bad), order))
+    assert val(prov.upload(np.array([[1.0], [-np.inf]])), "two") == np.inf and val(prov.upload(np.array([[np.inf], [np.inf]])), "-inf") == 0.0
+    assert val(prov.upload(np.zeros((0, 1))), "two") == 0.0 and val(prov.upload(np.zeros((5, 1))), "two") == 0.0
+    with pytest.raises(Exception):
+        prov.norm(prov.upload(np.zeros((2, 2, 2))), "fro")
+    n = 8192
+    h = prov.fill_uniform(6, -1.0, 1.0, (n, n))
+    x = prov.download_matrix(h)
+    assert abs(val(h, "fro") / np.linalg.norm(x) - 1) < 1e-13 and abs(val(h, "one") / np.abs(x).sum(axis=0).max() - 1) < 1e-13
+    assert abs(val(h, "inf") / np.abs(x).sum(axis=1).max() - 1) < 1e-13

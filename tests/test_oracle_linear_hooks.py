@@ -104,3 +104,18 @@ def test_chol_restatement():
     a = b @ b.T + 80 * np.eye(80)
     r, info = oracle.chol(a)
     assert info == 0 and np.max(np.abs(r - np.linalg.cholesky(a).T)) < 1e-12 and np.array_equal(np.tril(r, -1), np.zeros((80, 80)))
+
+
+def test_norm_restatement_on_the_reference_vectors():
+    """norm.rs:795-960: norm([3 4]) = 5, norm([2 -7 4], Inf) = 7 / -Inf = 2, norm([0 0 5 0], 0) = 1, fro of diag(2, 1) = sqrt 5, the
+    fractional p-norm; what needs singular values is refused here (the GPU hook returns UNSUPPORTED for it)."""
+    assert oracle.norm(np.array([[3.0], [4.0]])) == 5.0 and oracle.norm(np.array([[2.0], [-7.0], [4.0]]), "inf") == 7.0
+    assert oracle.norm(np.array([[2.0], [-7.0], [4.0]]), "-inf") == 2.0 and oracle.norm(np.array([[0.0], [0.0], [5.0], [0.0]]), "zero") == 1.0
+    assert abs(oracle.norm(np.array([[2.0, 0.0], [0.0, 1.0]]), "fro") - np.sqrt(5.0)) < 1e-15
+    assert abs(oracle.norm(np.array([[1.0], [2.0], [3.0]]), "p", 1.5) - (1 + 2 ** 1.5 + 3 ** 1.5) ** (1 / 1.5)) < 1e-14
+    assert oracle.norm(np.array([[3.0, 0.0], [0.0, 1.0]]), "two") is None and oracle.norm(np.array([[1.0], [2.0]]), "p", 0.5) is None
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((50, 30))
+    assert abs(oracle.norm(x, "fro") - np.linalg.norm(x)) < 1e-12 and abs(oracle.norm(x, "one") - np.linalg.norm(x, 1)) < 1e-12
+    assert abs(oracle.norm(x, "inf") - np.linalg.norm(x, np.inf)) < 1e-12 and np.isnan(oracle.norm(np.array([[1.0], [np.nan]]), "inf"))
+    assert oracle.norm(np.array([[1e200], [1e200]])) == np.sqrt(2.0) * 1e200                      # the running rescale: no overflow
