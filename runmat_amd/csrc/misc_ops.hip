@@ -151,96 +151,171 @@ __global__ void __launch_bounds__(kB) k_trapz_terms(const double* __restrict__ x
     __builtin_nontemporal_store(v, t + o);
 }
 
-// norm: per-workgroup partials of one sweep - sum |x|, max |x|, min |x|, count of nonzeros, NaN seen, sum (|x| scale)^2, sum |x|^p -
-// combined by the last workgroup to finish (ticket), so every vector norm and the Frobenius norm is ONE launch after the sweep that
-// found the scale.  The squares are scaled by an exact power of two taken from max |x| (the CPU's root_sum_of_squares rescales as it
-// goes, norm.rs:381-411: same protection against overflow / underflow, different summation order).
+// norm: one sweep leaves per-workgroup partials - sum |x| (NaN iff the operand holds one), and what the order needs of max |x|, min |x|,
+// the count of nonzeros, the sum of squares, sum |x|^p - and a one-workgroup kernel folds them and writes the [1, 1] result: no read-back.
+// Two / Fro square the values as they are; when the largest magnitude turns out to lie beyond 2^+-500 the fold asks a second sweep for
+// squares of x * 2^-e (the CPU's root_sum_of_squares rescales as it goes, norm.rs:381-411: same protection, another summation order) -
+// that sweep is always enqueued and leaves at once when it is not wanted.
 struct NormPartial {
-    double sum_abs, max_abs, min_abs, nnz, sumsq, sump;
+    double sum_abs, max_abs, min_abs, nnz, sq_big, sq_mid, sq_small, sump;  // the squares in three magnitude classes (Blue's accumulators)
     int nan;
     int pad;
 };
-__global__ void __launch_bounds__(256) k_norm_sweep(const double* __restrict__ x, u64 n, double scale, double p, int want_p, NormPartial* __restrict__ parts,
-                                                    unsigned* __restrict__ ticket, NormPartial* __restrict__ out) {
-    __shared__ NormPartial sh[256];
-    __shared__ int last;
-    NormPartial a;
-    a.sum_abs = 0.0;
+// |x| above 2^500 is squared after scaling by 2^-600, below 2^-500 after scaling by 2^600: no overflow, no total underflow, ONE sweep
+#define NORM_BIG 0x1p+500
+#define NORM_SMALL 0x1p-500
+#define NORM_SBIG 0x1p-600
+#define NORM_SSMALL 0x1p+600
+__device__ __forceinline__ void norm_fold(NormPartial& m, const NormPartial& o) {
+    m.sum_abs += o.sum_abs;
+    m.max_abs = o.max_abs > m.max_abs ? o.max_abs : m.max_abs;
+    m.min_abs = o.min_abs < m.min_abs ? o.min_abs : m.min_abs;
+    m.nnz += o.nnz;
+    m.sq_big += o.sq_big;
+    m.sq_mid += o.sq_mid;
+    m.sq_small += o.sq_small;
+    m.sump += o.sump;
+    m.nan |= o.nan;
+}
+__device__ __forceinline__ void norm_clear(NormPartial& a) {
+    a.sum_abs = a.nnz = a.sq_big = a.sq_mid = a.sq_small = a.sump = 0.0;
     a.max_abs = 0.0;
     a.min_abs = __longlong_as_double(0x7ff0000000000000ll);
-    a.nnz = 0.0;
-    a.sumsq = 0.0;
-    a.sump = 0.0;
     a.nan = 0;
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
-        const double v = fabs(__builtin_nontemporal_load(x + i));
-        if (v != v) a.nan = 1;
-        a.sum_abs += v;
-        a.max_abs = v > a.max_abs ? v : a.max_abs;
-        a.min_abs = v < a.min_abs ? v : a.min_abs;
-        a.nnz += v != 0.0 ? 1.0 : 0.0;
-        const double sv = v * scale;
-        a.sumsq += sv * sv;
-        if (want_p) a.sump += pow(v, p);
+}
+// ORDER (compile time): only the accumulators that order needs run per element - fp64 compares and selects are the cost of this sweep, not
+// HBM (all seven accumulators in one loop: 33 instructions per element, 2.8 TB/s).  sum |x| is always kept: a NaN anywhere makes it NaN.
+__device__ __forceinline__ NormPartial norm_shfl_down(const NormPartial& a, int d) {
+    NormPartial o;
+    o.sum_abs = __shfl_down(a.sum_abs, d);
+    o.max_abs = __shfl_down(a.max_abs, d);
+    o.min_abs = __shfl_down(a.min_abs, d);
+    o.nnz = __shfl_down(a.nnz, d);
+    o.sq_big = __shfl_down(a.sq_big, d);
+    o.sq_mid = __shfl_down(a.sq_mid, d);
+    o.sq_small = __shfl_down(a.sq_small, d);
+    o.sump = __shfl_down(a.sump, d);
+    o.nan = __shfl_down(a.nan, d);
+    o.pad = 0;
+    return o;
+}
+// a workgroup's partial in thread 0: shuffles inside the waves, sixteen records through LDS
+__device__ __forceinline__ NormPartial norm_block_fold(NormPartial a, NormPartial* sh) {
+    for (int d = 32; d > 0; d >>= 1) {
+        const NormPartial o = norm_shfl_down(a, d);
+        norm_fold(a, o);
     }
-    sh[threadIdx.x] = a;
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[wv] = a;
     __syncthreads();
-    for (int d = 128; d > 0; d >>= 1) {
-        if ((int)threadIdx.x < d) {
-            NormPartial& m = sh[threadIdx.x];
-            const NormPartial& o = sh[threadIdx.x + d];
-            m.sum_abs += o.sum_abs;
-            m.max_abs = o.max_abs > m.max_abs ? o.max_abs : m.max_abs;
-            m.min_abs = o.min_abs < m.min_abs ? o.min_abs : m.min_abs;
-            m.nnz += o.nnz;
-            m.sumsq += o.sumsq;
-            m.sump += o.sump;
-            m.nan |= o.nan;
-        }
-        __syncthreads();
+    if (threadIdx.x == 0)
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) norm_fold(a, sh[w]);
+    __syncthreads();
+    return a;
+}
+constexpr int NORM_THREADS = 1024;  // (the reductions' measurement: 1024-thread workgroups stream 8-20 % faster than 256)
+template <int ORDER>
+__global__ void __launch_bounds__(NORM_THREADS) k_norm_sweep(const double* __restrict__ x, u64 n, double p, NormPartial* __restrict__ parts,
+                                                    const double* __restrict__ rescale_io) {
+    __shared__ NormPartial sh[NORM_THREADS / 64];
+    // ORDER 9 = the second sweep of a Two / Fro norm whose largest magnitude lies outside 2^+-500: squares of x * 2^-e.  It is always
+    // launched and leaves at once when the first sweep (ORDER 2: plain squares) did not ask for it.
+    const double rescale = ORDER == 9 ? *rescale_io : 1.0;
+    if (ORDER == 9 && rescale == 0.0) return;
+    // four independent accumulator sets, one per load of a trip (a single set chains eight dependent adds per trip: 3.2 TB/s)
+    double sum_abs4[4] = {0.0, 0.0, 0.0, 0.0}, max_abs4[4] = {0.0, 0.0, 0.0, 0.0}, sq4[4] = {0.0, 0.0, 0.0, 0.0}, nnz4[4] = {0.0, 0.0, 0.0, 0.0},
+           sump4[4] = {0.0, 0.0, 0.0, 0.0};
+    const double inf_ = __longlong_as_double(0x7ff0000000000000ll);
+    double min_abs4[4] = {inf_, inf_, inf_, inf_};
+#define NORM_TAKE(raw, S)                                                      \
+    {                                                                          \
+        const double v_ = fabs(raw);                                           \
+        sum_abs4[S] += v_;                                                     \
+        if (ORDER == 2 || ORDER == 3) max_abs4[S] = fmax(v_, max_abs4[S]);     \
+        if (ORDER == 4) min_abs4[S] = fmin(v_, min_abs4[S]);                   \
+        if (ORDER == 5) nnz4[S] += v_ != 0.0 ? 1.0 : 0.0;                      \
+        if (ORDER == 2) sq4[S] += v_ * v_;                                     \
+        if (ORDER == 9) {                                                      \
+            const double sv_ = v_ * rescale;                                   \
+            sq4[S] += sv_ * sv_;                                               \
+        }                                                                      \
+        if (ORDER == 8) sump4[S] += pow(v_, p);                                \
     }
+    // four 16-byte loads in flight per thread and trip (an aligned body), the ragged ends element by element
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const u64 head = (((uintptr_t)x & 15) && n) ? 1 : 0;  // x is 8-byte aligned: at most one element before the 16-byte boundary
+    const u64 pairs = (n - head) / 2;
+    const v2d* xp = reinterpret_cast<const v2d*>(x + head);
+    // every workgroup owns ONE contiguous run of the operand
+    const u64 per = (pairs + gridDim.x - 1) / gridDim.x;
+    const u64 p0 = (u64)blockIdx.x * per, p1 = (p0 + per < pairs) ? p0 + per : pairs;
+    u64 i = p0 + threadIdx.x;
+    for (; i + 3 * NORM_THREADS < p1; i += 4 * NORM_THREADS) {
+        const v2d q0 = __builtin_nontemporal_load(xp + i), q1 = __builtin_nontemporal_load(xp + i + NORM_THREADS);
+        const v2d q2 = __builtin_nontemporal_load(xp + i + 2 * NORM_THREADS), q3 = __builtin_nontemporal_load(xp + i + 3 * NORM_THREADS);
+        NORM_TAKE(q0.x, 0) NORM_TAKE(q1.x, 1) NORM_TAKE(q2.x, 2) NORM_TAKE(q3.x, 3) NORM_TAKE(q0.y, 0) NORM_TAKE(q1.y, 1) NORM_TAKE(q2.y, 2) NORM_TAKE(q3.y, 3)
+    }
+    for (; i < p1; i += NORM_THREADS) {
+        const v2d q = __builtin_nontemporal_load(xp + i);
+        NORM_TAKE(q.x, 0) NORM_TAKE(q.y, 1)
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (head) NORM_TAKE(x[0], 0)
+        if (head + 2 * pairs < n) NORM_TAKE(x[n - 1], 1)
+    }
+    const double sum_abs = (sum_abs4[0] + sum_abs4[1]) + (sum_abs4[2] + sum_abs4[3]);
+    const double max_abs = fmax(fmax(max_abs4[0], max_abs4[1]), fmax(max_abs4[2], max_abs4[3]));
+    const double min_abs = fmin(fmin(min_abs4[0], min_abs4[1]), fmin(min_abs4[2], min_abs4[3]));
+    const double nnz = (nnz4[0] + nnz4[1]) + (nnz4[2] + nnz4[3]);
+    const double sq_mid = (sq4[0] + sq4[1]) + (sq4[2] + sq4[3]), sq_big = 0.0, sq_small = 0.0;
+    const double sump = (sump4[0] + sump4[1]) + (sump4[2] + sump4[3]);
+#undef NORM_TAKE
+    NormPartial a;
+    a.sum_abs = sum_abs;
+    a.max_abs = max_abs;
+    a.min_abs = min_abs;
+    a.nnz = nnz;
+    a.sq_big = sq_big;
+    a.sq_mid = sq_mid;
+    a.sq_small = sq_small;
+    a.sump = sump;
+    a.nan = sum_abs != sum_abs ? 1 : 0;
+    a.pad = 0;
+    a = norm_block_fold(a, sh);
+    if (threadIdx.x == 0) parts[blockIdx.x] = a;
+}
+
+// the partials of a sweep -> the norm.  A kernel of its own: folding them in the sweep's last workgroup needs a device-scope fence per
+// workgroup, and on this part (eight XCDs, L2s that are not coherent with each other) each of those writes the XCD's dirty lines back -
+// 77 us for an 80 MB vector against 18 us for the two-kernel reductions.
+template <int ORDER>
+__global__ void __launch_bounds__(NORM_THREADS) k_norm_final(const NormPartial* __restrict__ parts, unsigned nparts, double p, double* __restrict__ rescale_io,
+                                                             double* __restrict__ out) {
+    __shared__ NormPartial sh[NORM_THREADS / 64];
+    const double rescale = ORDER == 9 ? *rescale_io : 1.0;
+    if (ORDER == 9 && rescale == 0.0) return;
+    NormPartial t;
+    norm_clear(t);
+    for (unsigned b = threadIdx.x; b < nparts; b += NORM_THREADS) norm_fold(t, parts[b]);
+    t = norm_block_fold(t, sh);
     if (threadIdx.x == 0) {
-        parts[blockIdx.x] = sh[0];
-        __threadfence();
-        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    NormPartial t = sh[0];
-    t.sum_abs = t.nnz = t.sumsq = t.sump = 0.0;
-    t.max_abs = 0.0;
-    t.min_abs = __longlong_as_double(0x7ff0000000000000ll);
-    t.nan = 0;
-    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) {
-        const NormPartial o = parts[b];
-        t.sum_abs += o.sum_abs;
-        t.max_abs = o.max_abs > t.max_abs ? o.max_abs : t.max_abs;
-        t.min_abs = o.min_abs < t.min_abs ? o.min_abs : t.min_abs;
-        t.nnz += o.nnz;
-        t.sumsq += o.sumsq;
-        t.sump += o.sump;
-        t.nan |= o.nan;
-    }
-    sh[threadIdx.x] = t;
-    __syncthreads();
-    for (int d = 128; d > 0; d >>= 1) {
-        if ((int)threadIdx.x < d) {
-            NormPartial& m = sh[threadIdx.x];
-            const NormPartial& o = sh[threadIdx.x + d];
-            m.sum_abs += o.sum_abs;
-            m.max_abs = o.max_abs > m.max_abs ? o.max_abs : m.max_abs;
-            m.min_abs = o.min_abs < m.min_abs ? o.min_abs : m.min_abs;
-            m.nnz += o.nnz;
-            m.sumsq += o.sumsq;
-            m.sump += o.sump;
-            m.nan |= o.nan;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        *out = sh[0];
-        *ticket = 0;
+        const NormPartial r = t;
+        double v;
+        if (r.nan) v = __longlong_as_double(0x7ff8000000000000ll);
+        else if (ORDER == 1) v = r.sum_abs;
+        else if (ORDER == 3) v = r.max_abs;
+        else if (ORDER == 4) v = isinf(r.min_abs) ? 0.0 : r.min_abs;  // norm.rs:341-345
+        else if (ORDER == 5) v = r.nnz;
+        else if (ORDER == 8) v = pow(r.sump, 1.0 / p);
+        else if (ORDER == 9) v = sqrt(r.sq_mid) / rescale;
+        else if (isinf(r.max_abs) || r.max_abs == 0.0) v = r.max_abs;
+        else if (r.max_abs > NORM_BIG || r.max_abs < NORM_SMALL) {
+            // the plain squares overflowed or vanished: ask the second sweep for x * 2^-e, e the exponent of the largest magnitude
+            const int e = (int)((unsigned)__double2hiint(r.max_abs) >> 20) - 1022;
+            *rescale_io = ldexp(1.0, -e);
+            v = 0.0;
+        } else v = sqrt(r.sq_mid);
+        *out = v;
     }
 }
 
@@ -475,67 +550,42 @@ int rmhip_norm(rmhip_ctx* ctx, rmhip_buf a, int order, double p, rmhip_buf* out)
     const u64 n = ab.numel;
     if (n > 0 && matrix && (order == 1 || order == 3)) {
         // max column / row sum of |a| (norm.rs:497-529): |a|, sum along one dimension, max of the sums - the library's kernels
-        rmhip_buf absb = 0, sums = 0, mx = 0;
+        // (rmhip_reduce in include mode: a NaN sum makes the maximum NaN, as norm.rs:419-421 wants) - the [1, 1] maximum IS the result
+        rmhip_buf absb = 0, sums = 0;
         int rc = rmhip_unary(ctx, RMHIP_ABS, a, &absb);
         if (!rc) rc = rmhip_reduce(ctx, RMHIP_RSUM, absb, order == 1 ? 0 : 1, 0, &sums);
-        if (!rc) rc = rmhip_reduce(ctx, RMHIP_RMAX, sums, -1, 0, &mx);
-        if (!rc) rc = rmhip_read_scalar(ctx, mx, 0, &value);
-        if (!rc) {  // any NaN in the matrix is a NaN sum: the norm is NaN (norm.rs:419-421) whatever the maximum made of it
-            rmhip_buf tot = 0;
-            double t = 0.0;
-            rc = rmhip_reduce(ctx, RMHIP_RSUM, sums, -1, 0, &tot);
-            if (!rc) rc = rmhip_read_scalar(ctx, tot, 0, &t);
-            if (tot) rmhip_free(ctx, tot);
-            if (!rc && t != t) value = t;
-        }
+        if (!rc) rc = rmhip_reduce(ctx, RMHIP_RMAX, sums, -1, 0, out);
         if (absb) rmhip_free(ctx, absb);
         if (sums) rmhip_free(ctx, sums);
-        if (mx) rmhip_free(ctx, mx);
-        if (rc) return rc;
+        return rc;
     } else if (n > 0) {
-        const unsigned grid = (unsigned)std::min<u64>((n + 1023) / 1024, (u64)c->num_cus * 8);
+        // one sweep, the value formed on the device by the last workgroup: no read-back, no synchronisation
+        const unsigned grid = (unsigned)std::max<u64>(1, std::min<u64>((n + 8191) / 8192, (u64)c->num_cus * 8));
         std::shared_ptr<Allocation> ws;
-        RMHIP_TRY(c->alloc_device((size_t)(grid + 1) * (sizeof(NormPartial) / 8) + 1, &ws));
+        RMHIP_TRY(c->alloc_device((size_t)grid * (sizeof(NormPartial) / 8) + 2, &ws));
         NormPartial* parts = (NormPartial*)ws->ptr;
-        NormPartial* total = parts + grid;
-        unsigned* ticket = (unsigned*)(total + 1);
-        RMHIP_HIP_CHECK(hipMemsetAsync(ticket, 0, sizeof(unsigned), c->stream));
-        NormPartial h;
-        auto sweep = [&](double scale, int want_p) -> int {
-            hipLaunchKernelGGL(k_norm_sweep, dim3(grid), dim3(256), 0, c->stream, ab.data(), n, scale, p, want_p, parts, ticket, total);
-            c->tel.kernel_launches++;
-            RMHIP_HIP_CHECK(hipMemcpyAsync(&h, total, sizeof h, hipMemcpyDeviceToHost, c->stream));
-            RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
-            return RMHIP_OK;
-        };
-        RMHIP_TRY(sweep(1.0, order == 8));
-        if (h.nan) {
-            value = std::numeric_limits<double>::quiet_NaN();
-        } else if (order == 1) {
-            value = h.sum_abs;
-        } else if (order == 3) {
-            value = h.max_abs;
-        } else if (order == 4) {
-            value = std::isinf(h.min_abs) ? 0.0 : h.min_abs;  // norm.rs:341-345
-        } else if (order == 5) {
-            value = h.nnz;
-        } else if (order == 8) {
-            value = std::pow(h.sump, 1.0 / p);
-        } else {  // Two (vector) / Fro
-            if (std::isinf(h.max_abs)) value = h.max_abs;
-            else if (h.max_abs == 0.0) value = 0.0;
-            else {
-                int e = 0;
-                (void)std::frexp(h.max_abs, &e);
-                const double scale = std::ldexp(1.0, -e);  // max |x| * scale in [0.5, 1): the squares neither overflow nor all underflow
-                if (e > 500 || e < -500) {
-                    RMHIP_TRY(sweep(scale, 0));
-                    value = std::sqrt(h.sumsq) * std::ldexp(1.0, e);
-                } else {
-                    value = std::sqrt(h.sumsq);  // the first sweep's plain squares
-                }
-            }
+        double* rescale = (double*)(parts + grid);
+        RMHIP_HIP_CHECK(hipMemsetAsync(rescale, 0, sizeof(double), c->stream));
+        Buffer ob;
+        RMHIP_TRY(c->new_buffer(one, 2, out, &ob));
+#define RMHIP_NORM_LAUNCH(O)                                                                                                             \
+    hipLaunchKernelGGL(k_norm_sweep<O>, dim3(grid), dim3(NORM_THREADS), 0, c->stream, ab.data(), n, p, parts, (const double*)rescale); \
+    hipLaunchKernelGGL(k_norm_final<O>, dim3(1), dim3(NORM_THREADS), 0, c->stream, (const NormPartial*)parts, grid, p, rescale, ob.data()); \
+    c->tel.kernel_launches += 2
+        switch (order) {
+            case 1: RMHIP_NORM_LAUNCH(1); break;
+            case 3: RMHIP_NORM_LAUNCH(3); break;
+            case 4: RMHIP_NORM_LAUNCH(4); break;
+            case 5: RMHIP_NORM_LAUNCH(5); break;
+            case 8: RMHIP_NORM_LAUNCH(8); break;
+            default:  // Two (vector) and Fro: plain squares, and the rescaled sweep that only runs when they were not enough
+                RMHIP_NORM_LAUNCH(2);
+                RMHIP_NORM_LAUNCH(9);
+                break;
         }
+#undef RMHIP_NORM_LAUNCH
+        RMHIP_HIP_CHECK(hipGetLastError());
+        return RMHIP_OK;
     }
     Buffer ob;
     RMHIP_TRY(c->new_buffer(one, 2, out, &ob));

@@ -33,6 +33,13 @@ for dim in (0, 1):
 timed("round_digits 8192^2 (2 decimals)", lambda: prov.round_digits(h, 2), 16 * e)
 timed("pow2_scale 8192^2 (fractional exponents)", lambda: prov.pow2_scale(h, g), 24 * e)
 timed("unary_angle 8192^2", lambda: prov.unary_angle(h), 16 * e)
+timed("norm 8192^2 fro (sweep + fold on the device)", lambda: prov.norm(h, "fro"), 8 * e)
+timed("norm 8192^2 one (|a|, column sums, max)", lambda: prov.norm(h, "one"), 8 * e)
+timed("norm 8192^2 inf (|a|, row sums, max)", lambda: prov.norm(h, "inf"), 8 * e)
+vv = prov.fill_uniform(15, -1.0, 1.0, (10**8, 1))
+timed("norm 1e8 vector, two", lambda: prov.norm(vv, "two"), 8 * 10**8)
+timed("norm 1e8 vector, p = 3", lambda: prov.norm(vv, "p", 3.0), 8 * 10**8)
+prov.free(vv)
 timed("issymmetric 8192^2 (not symmetric)", lambda: [prov.issymmetric(h)] and [], 8 * e)
 v = prov.fill_uniform(7, -1.0, 1.0, (n, 1))
 timed("scatter_column 8192^2", lambda: prov.scatter_column(h, 100, v), 16 * e)
