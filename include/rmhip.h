@@ -422,6 +422,14 @@ RMHIP_API int rmhip_norm(rmhip_ctx* ctx, rmhip_buf a, int order, double p, rmhip
  * operand with trailing extents > 1 RMHIP_ERR_INVALID.  Synchronises the stream (a host bool comes back). */
 /* @serves issymmetric */
 RMHIP_API int rmhip_issymmetric(rmhip_ctx* ctx, rmhip_buf a, int skew, double tolerance, int* result);
+/* `ishermitian(matrix, kind, tolerance)` for this backend's real data (lib.rs:3126-3138; ishermitian.rs:455-482, 522-530): the test of
+ * `rmhip_issymmetric` with one more rule - the Hermitian kind fails on a NaN diagonal entry.  Same shape rules and errors. */
+/* @serves ishermitian */
+RMHIP_API int rmhip_ishermitian(rmhip_ctx* ctx, rmhip_buf a, int skew, double tolerance, int* result);
+/* `bandwidth(matrix)` (lib.rs:3140-3143; bandwidth.rs:303-318, 341-365): lower = max(row - col), upper = max(col - row) over the entries
+ * that are non-zero or NaN; (0, 0) for an empty matrix; a rank-1 shape is a row; trailing dimensions > 1 -> RMHIP_ERR_INVALID. */
+/* @serves bandwidth */
+RMHIP_API int rmhip_bandwidth(rmhip_ctx* ctx, rmhip_buf a, unsigned* lower, unsigned* upper);
 
 /* `matmul`: C = A*B, 2-D, column-major; inner dims must agree else RMHIP_ERR_SHAPE
  * (simple_provider.rs:7698-7741). fp64 MFMA kernel. */

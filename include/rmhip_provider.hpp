@@ -633,6 +633,16 @@ public:
         check(rmhip_issymmetric(ctx_, own(m), skew ? 1 : 0, tolerance, &r));
         return r != 0;
     }
+    bool ishermitian(const GpuTensorHandle& m, bool skew, double tolerance) const {  // lib.rs:3126-3138
+        int r = 0;
+        check(rmhip_ishermitian(ctx_, own(m), skew ? 1 : 0, tolerance, &r));
+        return r != 0;
+    }
+    std::pair<uint32_t, uint32_t> bandwidth(const GpuTensorHandle& m) const {  // lib.rs:3140-3143: (lower, upper)
+        unsigned lo = 0, up = 0;
+        check(rmhip_bandwidth(ctx_, own(m), &lo, &up));
+        return {lo, up};
+    }
     // lib.rs:1718-1757, 1820-1839: the prototype forms and the scaled / transformed draws of the same stream
     GpuTensorHandle random_uniform_like(const GpuTensorHandle& prototype) const { return random_uniform(prototype.shape); }
     GpuTensorHandle random_normal_like(const GpuTensorHandle& prototype) const { return random_normal(prototype.shape); }

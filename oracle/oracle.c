@@ -1531,6 +1531,37 @@ ORC_API int orc_issymmetric(const double* data, size_t rows, size_t cols, int sk
     return 1;
 }
 
+/* is_hermitian_real, ishermitian.rs:455-482 (real_within :522-530; rows != cols -> false :550-552) */
+ORC_API int orc_ishermitian(const double* data, size_t rows, size_t cols, int skew, double tol) {
+    if (rows != cols) return 0;
+    for (size_t col = 0; col < cols; ++col) {
+        const double d = data[col + col * rows];
+        if (isnan(d)) return 0;
+        if (skew && !(d == 0.0) && (!isfinite(d) || !(fabs(d - 0.0) <= tol))) return 0;
+        for (size_t row = 0; row < col; ++row) {
+            const double v = data[row + col * rows], r = skew ? -data[col + row * rows] : data[col + row * rows];
+            if (v == r) continue;
+            if (!isfinite(v) || !isfinite(r)) return 0;
+            if (!(fabs(v - r) <= tol)) return 0;
+        }
+    }
+    return 1;
+}
+
+/* compute_real_bandwidth, bandwidth.rs:341-365 */
+ORC_API void orc_bandwidth(const double* data, size_t rows, size_t cols, size_t* lower, size_t* upper) {
+    *lower = *upper = 0;
+    if (rows == 0 || cols == 0) return;
+    for (size_t col = 0; col < cols; ++col)
+        for (size_t row = 0; row < rows; ++row) {
+            const double v = data[row + col * rows];
+            if (v != 0.0 || isnan(v)) {
+                if (row >= col) { if (row - col > *lower) *lower = row - col; }
+                else if (col - row > *upper) *upper = col - row;
+            }
+        }
+}
+
 /* inv: the reference calls nalgebra 0.32.6 `DMatrix::try_inverse` (inv.rs:224-228) - a third-party dependency that is not under
  * /root/reference (Cargo.lock pins it).  Its published algorithm for dynamic sizes: LU with partial (row) pivoting, pivot = the entry
  * of largest magnitude in the column, `None` when a pivot is exactly zero, then the inverse by substitutions on the permuted identity.

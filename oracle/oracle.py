@@ -763,6 +763,28 @@ def issymmetric(a: np.ndarray, skew: bool = False, tol: float = 0.0) -> bool:
     return bool(l.orc_issymmetric(_p(_f(a)), rows, cols, int(skew), float(tol)))
 
 
+def ishermitian(a: np.ndarray, skew: bool = False, tol: float = 0.0) -> bool:
+    """ishermitian.rs:455-482 for real data."""
+    a = np.asarray(a, dtype=np.float64)
+    rows, cols = (a.shape[0], a.shape[1]) if a.ndim >= 2 else (a.size, 1)
+    l = lib()
+    l.orc_ishermitian.restype = C.c_int
+    l.orc_ishermitian.argtypes = [_DP, C.c_size_t, C.c_size_t, C.c_int, C.c_double]
+    return bool(l.orc_ishermitian(_p(_f(a)), rows, cols, int(skew), float(tol)))
+
+
+def bandwidth(a: np.ndarray):
+    """(lower, upper), bandwidth.rs:303-318 (a rank-1 shape is a row) and :341-365."""
+    a = np.asarray(a, dtype=np.float64)
+    rows, cols = (a.shape[0], a.shape[1]) if a.ndim >= 2 else (1, a.size)
+    l = lib()
+    l.orc_bandwidth.restype = None
+    l.orc_bandwidth.argtypes = [_DP, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lo, up = C.c_size_t(), C.c_size_t()
+    l.orc_bandwidth(_p(_f(a)), rows, cols, C.byref(lo), C.byref(up))
+    return int(lo.value), int(up.value)
+
+
 def inv(a: np.ndarray):
     """The inverse of a square matrix by LU with partial pivoting (the published algorithm of nalgebra's try_inverse, inv.rs:224-228), or
     None when a pivot is exactly zero."""

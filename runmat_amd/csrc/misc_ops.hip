@@ -97,6 +97,7 @@ __global__ void __launch_bounds__(kB) k_gradient(const double* __restrict__ x, u
 // One workgroup per pair of 32 x 32 tiles (ti <= tj): tile (ti, tj) and its mirror (tj, ti) are both read along their columns
 // (coalesced) and meet in LDS - the element-per-thread form read the mirror with a stride of n doubles (0.44 ms at 8192^2).  Any pair
 // that fails `v == r || (finite && |v - r| <= tol)` raises the flag; the diagonal is checked against zero for the skew kind.
+// `skew` bit 0: the skew kind; bit 1: ishermitian's rule for real data (same test, plus "a NaN on the diagonal fails").
 constexpr int SYM_T = 32;
 __global__ void __launch_bounds__(256) k_issymmetric(const double* __restrict__ a, u64 n, u64 tiles, int skew, double tol, int* __restrict__ bad) {
     __shared__ double up[SYM_T][SYM_T + 1], lo[SYM_T][SYM_T + 1];
@@ -120,15 +121,67 @@ __global__ void __launch_bounds__(256) k_issymmetric(const double* __restrict__ 
     for (int q = 0; q < 4; ++q) {
         const int c = ty + 8 * q;
         const u64 row = ti * SYM_T + tx, col = tj * SYM_T + c;
-        if (row >= n || col >= n || row > col || (row == col && !skew)) continue;
+        if (row >= n || col >= n || row > col) continue;
         const double v = up[c][tx];
+        if (row == col && !(skew & 1)) {  // the Hermitian kind also refuses a NaN on the diagonal (ishermitian.rs:462-465)
+            fail |= (skew & 2) && isnan(v);
+            continue;
+        }
         const double m = lo[tx][c];  // a(col, row)
-        const double r = row == col ? 0.0 : (skew ? -m : m);
+        const double r = row == col ? 0.0 : ((skew & 1) ? -m : m);
         bool ok = v == r;
         if (!ok && isfinite(v) && isfinite(r)) ok = fabs(v - r) <= tol;
         fail |= !ok;
     }
     if (fail) *bad = 1;
+}
+
+// bandwidth (bandwidth.rs:341-365): the largest row - col (lower) and col - row (upper) over the entries that are non-zero or NaN.  A
+// grid-stride sweep in storage order; (row, col) advance with the stride by one add and one wrap instead of a 64-bit division per
+// element.  At most one atomicMax pair per workgroup - atomics resolve at the memory side, no fence is needed for a max.
+__global__ void __launch_bounds__(kB) k_bandwidth(const double* __restrict__ a, u64 rows, u64 total, unsigned* __restrict__ res) {
+    const u64 stride = (u64)gridDim.x * kB;
+    u64 i = (u64)blockIdx.x * kB + threadIdx.x;
+    u64 r = i % rows, col = i / rows;
+    const u64 sr = stride % rows, sc = stride / rows;
+    unsigned lo = 0, up = 0;
+    constexpr int U = 8;  // eight loads in flight per thread: one at a time left the sweep latency-bound (0.45 ms at 8192^2)
+    while (i < total) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = i + u * stride < total ? __builtin_nontemporal_load(a + i + u * stride) : 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (v[u] != 0.0) {  // NaN != 0 is true: NaN counts (bandwidth.rs:354)
+                if (r >= col) lo = max(lo, (unsigned)(r - col));
+                else up = max(up, (unsigned)(col - r));
+            }
+            r += sr;
+            col += sc;
+            if (r >= rows) {
+                r -= rows;
+                ++col;
+            }
+        }
+        i += U * stride;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = max(lo, (unsigned)__shfl_xor((int)lo, o));
+        up = max(up, (unsigned)__shfl_xor((int)up, o));
+    }
+    __shared__ unsigned part[2][kB / 64];
+    if ((threadIdx.x & 63) == 0) {
+        part[0][threadIdx.x >> 6] = lo;
+        part[1][threadIdx.x >> 6] = up;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {  // thread 0: lower, thread 1: upper
+        unsigned m = 0;
+        for (int w = 0; w < kB / 64; ++w) m = max(m, part[threadIdx.x][w]);
+        // same-address atomics serialise (one per wave cost 0.33 ms at 8192^2): one per workgroup, and only when it can still raise
+        // the running maximum (a stale read only lets a redundant atomic through - the maximum is monotonic)
+        if (m > __hip_atomic_load(res + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(res + threadIdx.x, m);
+    }
 }
 
 // trapezoid terms: t[k + 1] = 0.5 * w_k * (x[k] + x[k + 1]), t[0] = 0 along the dimension (simple_provider.rs:2534-2563); their running /
@@ -446,14 +499,13 @@ int rmhip_gradient_dim(rmhip_ctx* ctx, rmhip_buf a, int dim, double spacing, rmh
     return RMHIP_OK;
 }
 
-int rmhip_issymmetric(rmhip_ctx* ctx, rmhip_buf a, int skew, double tolerance, int* result) {
-    CTX_OR_FAIL(ctx);
+static int symmetry_test(Context* c, const char* who, rmhip_buf a, int mode, double tolerance, int* result) {
     if (!result) return fail(RMHIP_ERR_INVALID, "null result");
     Buffer ab;
     RMHIP_TRY(c->get(a, &ab));
     const std::vector<size_t>& s = ab.shape;
     for (size_t d = 2; d < s.size(); ++d)
-        if (s[d] != 1) return fail(RMHIP_ERR_INVALID, "issymmetric: inputs must be 2-D matrices or vectors");
+        if (s[d] != 1) return fail(RMHIP_ERR_INVALID, "%s: inputs must be 2-D matrices or vectors", who);
     const size_t rows = s.empty() ? 1 : s[0], cols = s.size() < 2 ? 1 : s[1];
     if (rows != cols) {
         *result = 0;
@@ -467,13 +519,51 @@ int rmhip_issymmetric(rmhip_ctx* ctx, rmhip_buf a, int skew, double tolerance, i
     RMHIP_TRY(c->alloc_device(1, &flag));
     RMHIP_HIP_CHECK(hipMemsetAsync(flag->ptr, 0, sizeof(double), c->stream));
     const u64 tiles = (rows + SYM_T - 1) / SYM_T, pairs = tiles * (tiles + 1) / 2;
-    if (pairs > 0x7fffffffull) return fail(RMHIP_ERR_UNSUPPORTED, "issymmetric: %zu rows", rows);
-    hipLaunchKernelGGL(k_issymmetric, dim3((unsigned)pairs), dim3(256), 0, c->stream, ab.data(), (u64)rows, tiles, skew ? 1 : 0, tolerance, (int*)flag->ptr);
+    if (pairs > 0x7fffffffull) return fail(RMHIP_ERR_UNSUPPORTED, "%s: %zu rows", who, rows);
+    hipLaunchKernelGGL(k_issymmetric, dim3((unsigned)pairs), dim3(256), 0, c->stream, ab.data(), (u64)rows, tiles, mode, tolerance, (int*)flag->ptr);
     c->tel.kernel_launches++;
     int bad = 0;
     RMHIP_HIP_CHECK(hipMemcpyAsync(&bad, flag->ptr, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
     *result = bad ? 0 : 1;
+    return RMHIP_OK;
+}
+
+int rmhip_issymmetric(rmhip_ctx* ctx, rmhip_buf a, int skew, double tolerance, int* result) {
+    CTX_OR_FAIL(ctx);
+    return symmetry_test(c, "issymmetric", a, skew ? 1 : 0, tolerance, result);
+}
+
+int rmhip_ishermitian(rmhip_ctx* ctx, rmhip_buf a, int skew, double tolerance, int* result) {
+    CTX_OR_FAIL(ctx);
+    return symmetry_test(c, "ishermitian", a, (skew ? 1 : 0) | 2, tolerance, result);
+}
+
+int rmhip_bandwidth(rmhip_ctx* ctx, rmhip_buf a, unsigned* lower, unsigned* upper) {
+    CTX_OR_FAIL(ctx);
+    if (!lower || !upper) return fail(RMHIP_ERR_INVALID, "null result");
+    Buffer ab;
+    RMHIP_TRY(c->get(a, &ab));
+    const std::vector<size_t>& s = ab.shape;
+    for (size_t d = 2; d < s.size(); ++d)
+        if (s[d] > 1) return fail(RMHIP_ERR_INVALID, "bandwidth: invalid input: input must be a 2-D matrix");
+    // bandwidth.rs:303-318: a rank-1 shape is a ROW here
+    const u64 rows = s.empty() ? 1 : (s.size() == 1 ? 1 : s[0]), cols = s.empty() ? 1 : (s.size() == 1 ? s[0] : s[1]);
+    *lower = *upper = 0;
+    if (rows == 0 || cols == 0) return RMHIP_OK;
+    if (rows > 0xffffffffull || cols > 0xffffffffull) return fail(RMHIP_ERR_UNSUPPORTED, "bandwidth: %zu x %zu", (size_t)rows, (size_t)cols);
+    std::shared_ptr<Allocation> res;
+    RMHIP_TRY(c->alloc_device(1, &res));
+    RMHIP_HIP_CHECK(hipMemsetAsync(res->ptr, 0, sizeof(double), c->stream));
+    const u64 total = rows * cols;
+    const unsigned grid = (unsigned)std::min<u64>((total + kB - 1) / kB, 2048);
+    hipLaunchKernelGGL(k_bandwidth, dim3(grid), dim3(kB), 0, c->stream, ab.data(), rows, total, (unsigned*)res->ptr);
+    c->tel.kernel_launches++;
+    unsigned host[2] = {0, 0};
+    RMHIP_HIP_CHECK(hipMemcpyAsync(host, res->ptr, sizeof(host), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *lower = host[0];
+    *upper = host[1];
     return RMHIP_OK;
 }
 

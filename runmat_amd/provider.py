@@ -1033,6 +1033,20 @@ class HipProvider:
         self._check(self._lib.rmhip_issymmetric(self._ctx, self._id(matrix), 1 if kind == "skew" else 0, float(tolerance), C.byref(res)))
         return bool(res.value)
 
+    def ishermitian(self, matrix, kind: str = "hermitian", tolerance: float = 0.0) -> bool:
+        """lib.rs:3126-3138 (`ProviderHermitianKind::{Hermitian, Skew}`), real data: issymmetric's test plus "a NaN diagonal fails"."""
+        if kind not in ("hermitian", "skew"):
+            raise RmhipError(1, f"ishermitian: kind {kind!r}")
+        res = C.c_int()
+        self._check(self._lib.rmhip_ishermitian(self._ctx, self._id(matrix), 1 if kind == "skew" else 0, float(tolerance), C.byref(res)))
+        return bool(res.value)
+
+    def bandwidth(self, matrix) -> Tuple[int, int]:
+        """lib.rs:3140-3143 -> `ProviderBandwidth { lower, upper }` as a pair; only the two counts leave the device."""
+        lo, up = C.c_uint(), C.c_uint()
+        self._check(self._lib.rmhip_bandwidth(self._ctx, self._id(matrix), C.byref(lo), C.byref(up)))
+        return int(lo.value), int(up.value)
+
     def random_uniform_like(self, prototype: GpuTensorHandle) -> GpuTensorHandle:
         """lib.rs:1718-1720: `random_uniform(&prototype.shape)`."""
         return self.random_uniform(prototype.shape)

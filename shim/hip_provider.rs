@@ -16,7 +16,7 @@ use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle,
     HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, KernelAttrTelemetry, KernelLaunchTelemetry, MatmulEpilogue,
-    PowerStepEpilogue, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderLinsolveOptions,
+    PowerStepEpilogue, ProviderBandwidth, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderNanMode, ProviderNdgridRequest, ProviderNormOrder, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
     ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult,
 };
@@ -653,6 +653,19 @@ impl AccelProvider for HipProvider {
         let skew = matches!(kind, ProviderSymmetryKind::Skew) as c_int;
         check(unsafe { rmhip_issymmetric(self.ctx, self.own(matrix)?, skew, tolerance, &mut res) })?;
         Ok(res != 0)
+    }
+    fn ishermitian<'a>(&'a self, matrix: &'a GpuTensorHandle, kind: ProviderHermitianKind, tolerance: f64) -> AccelProviderFuture<'a, bool> {
+        Box::pin(async move {
+            let mut res: c_int = 0;
+            let skew = matches!(kind, ProviderHermitianKind::Skew) as c_int;
+            check(unsafe { rmhip_ishermitian(self.ctx, self.own(matrix)?, skew, tolerance, &mut res) })?;
+            Ok(res != 0)
+        })
+    }
+    fn bandwidth(&self, matrix: &GpuTensorHandle) -> Result<ProviderBandwidth> {
+        let (mut lower, mut upper) = (0u32, 0u32);
+        check(unsafe { rmhip_bandwidth(self.ctx, self.own(matrix)?, &mut lower, &mut upper) })?;
+        Ok(ProviderBandwidth { lower, upper })
     }
     // the prototype forms (lib.rs:1718-1730, 1832-1839: the trait's defaults, spelled out) and the scaled / transformed draws
     fn random_uniform_like(&self, prototype: &GpuTensorHandle) -> Result<GpuTensorHandle> { self.random_uniform(&prototype.shape) }

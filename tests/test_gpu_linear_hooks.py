@@ -34,6 +34,10 @@ def test_reference_kats(prov):
         assert np.array_equal(prov.download_matrix(h).ravel(order="F"), np.array(k["out"])), k
     for k in K["issymmetric"]:
         assert prov.issymmetric(prov.upload(arr(k["a"], k["shape"])), "skew" if k["skew"] else "symmetric", k["tol"]) == k["out"]
+    for k in K["ishermitian"]:
+        assert prov.ishermitian(prov.upload(arr(k["a"], k["shape"])), "skew" if k["skew"] else "hermitian", k["tol"]) == k["out"], k
+    for k in K["bandwidth"]:
+        assert list(prov.bandwidth(prov.upload(arr(k["a"], k["shape"])))) == k["out"], k
 
 
 @pytest.mark.parametrize("sa,sb", [((1, 1), (1, 1)), ((3, 4), (2, 5)), ((64, 3), (5, 70)), ((2, 3, 2), (3, 1, 2)), ((7,), (1, 9)), ((300, 200), (4, 3)),
@@ -118,9 +122,33 @@ def test_issymmetric(prov, oracle):
             cases += [(k2, True, 0.0), (k2, True, 1e-10)]
         for m, skew, tol in cases:
             assert prov.issymmetric(prov.upload(m), "skew" if skew else "symmetric", tol) == oracle.issymmetric(m, skew, tol), (n, skew, tol)
+            assert prov.ishermitian(prov.upload(m), "skew" if skew else "hermitian", tol) == oracle.ishermitian(m, skew, tol), (n, skew, tol)
+        d = s.copy()
+        d[n // 2, n // 2] = np.nan                                                 # the NaN diagonal: the one case the two predicates split on
+        hd = prov.upload(d)
+        assert prov.issymmetric(hd) is True and prov.ishermitian(hd) is False and prov.ishermitian(hd, "skew", 1e300) is False
     assert prov.issymmetric(prov.upload(np.zeros((3, 4)))) is False
     with pytest.raises(Exception):
         prov.issymmetric(prov.upload(np.zeros((2, 2, 2))))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (5, 5), (64, 64), (300, 200), (200, 300), (1, 4097), (4097, 1), (2049, 2049), (0, 3), (7,)], ids=str)
+def test_bandwidth(prov, oracle, shape):
+    rng = np.random.default_rng(sum(shape))
+    rows, cols = shape if len(shape) == 2 else (1, shape[0])
+    up_ = lambda m: prov.upload(m.ravel(order="F"), shape)                      # keeps a rank-1 shape rank-1 (a row: bandwidth.rs:306)
+    assert prov.bandwidth(up_(np.zeros(shape))) == (0, 0)
+    for lo, up in ((0, 0), (1, 2), (rows // 2, cols // 3), (rows, cols)):
+        m = np.tril(np.triu(rng.standard_normal((rows, cols)), -lo), up).reshape(shape)
+        assert prov.bandwidth(up_(m)) == oracle.bandwidth(m)
+    if rows * cols:
+        m = np.zeros((rows, cols))
+        m[rows - 1, 0] = np.nan                                                    # a NaN counts (bandwidth.rs:354)
+        m[0, cols - 1] = -0.0                                                      # a negative zero does not
+        assert prov.bandwidth(up_(m)) == oracle.bandwidth(m.reshape(shape)) == (rows - 1, 0)
+    with pytest.raises(Exception):
+        prov.bandwidth(prov.upload(np.zeros((2, 2, 2))))
+    assert prov.bandwidth(prov.upload(np.ones((3, 3, 1)))) == (2, 2)
 
 
 def test_full_size_properties(prov):
@@ -135,7 +163,9 @@ def test_full_size_properties(prov):
     assert prov.issymmetric(h) is False
     ht = prov.transpose(h)
     sym = prov.elem_add(h, ht)
-    assert prov.issymmetric(sym) is True
+    assert prov.issymmetric(sym) is True and prov.ishermitian(sym) is True
+    assert prov.bandwidth(h) == (n - 1, n - 1)
+    assert prov.bandwidth(prov.tril(prov.triu(h, -5), 77)) == (5, 77)
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 65, 300, 1153])

@@ -27,6 +27,10 @@ def test_reference_kats():
         assert np.array_equal(out.ravel(order="F"), np.array(k["out"])), k
     for k in K["issymmetric"]:
         assert oracle.issymmetric(arr(k["a"], k["shape"]), k["skew"], k["tol"]) == k["out"]
+    for k in K["ishermitian"]:
+        assert oracle.ishermitian(arr(k["a"], k["shape"]), k["skew"], k["tol"]) == k["out"], k
+    for k in K["bandwidth"]:
+        assert list(oracle.bandwidth(arr(k["a"], k["shape"]))) == k["out"], k
 
 
 def test_against_numpy():
@@ -56,6 +60,15 @@ def test_against_numpy():
     s3 = s.copy()
     s3[0, 1] = s3[1, 0] = np.inf
     assert oracle.issymmetric(s3)                                                   # equal infinities pass the == test
+    s5 = s.copy()
+    s5[2, 2] = np.nan                                                               # the one place the two predicates differ: a NaN
+    assert oracle.issymmetric(s5) and not oracle.ishermitian(s5)                    # diagonal (ishermitian.rs:462-465)
+    assert oracle.ishermitian(s) and oracle.ishermitian(s - s.T, True) and not oracle.ishermitian(a)
+    t = np.triu(rng.standard_normal((6, 9)), -2)
+    t = np.tril(t, 3)
+    t[2, 0], t[0, 3] = 1.0, 1.0
+    assert oracle.bandwidth(t) == (2, 3) and oracle.bandwidth(np.zeros((4, 4))) == (0, 0)
+    assert oracle.bandwidth(np.array([0.0, 0.0, 5.0])) == (0, 2)                    # a rank-1 shape is a row (bandwidth.rs:306)
 
 
 def test_inv_restatement_on_the_reference_vectors_and_against_numpy():
