@@ -422,6 +422,31 @@ RMHIP_API int rmhip_norm(rmhip_ctx* ctx, rmhip_buf a, int order, double p, rmhip
  * operand with trailing extents > 1 RMHIP_ERR_INVALID.  Synchronises the stream (a host bool comes back). */
 /* @serves issymmetric */
 RMHIP_API int rmhip_issymmetric(rmhip_ctx* ctx, rmhip_buf a, int skew, double tolerance, int* result);
+/* ---- discrete Fourier transforms and complex-interleaved storage (fft.hip) --------------------------------------------------------
+ * A transform's result is a COMPLEX-INTERLEAVED tensor (`GpuTensorStorage::ComplexInterleaved`, lib.rs:247-251): its shape is the
+ * logical one, its storage 2 * numel doubles (re, im, re, im, ...).  `rmhip_download` hands such a tensor back as 2 * numel doubles
+ * (what `HostTensorOwned { data, shape, storage }` carries, lib.rs:3362-3366); `rmhip_storage` tells which kind an id is.  Only the
+ * entry points of this section accept complex tensors; every other one returns RMHIP_ERR_UNSUPPORTED for them (the caller gathers,
+ * as for any `Err`).  A precision-32 context rounds the values of a complex result through f32 (storage stays 2 x f64). */
+/* @serves - */
+RMHIP_API int rmhip_storage(rmhip_ctx* ctx, rmhip_buf id, int* complex_interleaved);
+/* `fft_dim(handle, len, dim)` / `ifft_dim` (lib.rs:2622-2638; semantics of the wgpu provider's host form, ops/fft/fallback.rs:4-150):
+ * the DFT of every line along zero-based `dim` (a dimension beyond the rank has extent 1 and extends the shape), zero-padded or
+ * truncated to `len_or_neg` points (< 0: the extent); forward unnormalised (exp(-2 pi i jk / n)), inverse scaled by 1 / n; real or
+ * complex input; any length up to 2^24 (powers of two by LDS-resident radix-8 passes, others by Bluestein's chirp convolution).
+ * Accuracy: error <= a small multiple of eps * log2(n) * ||line||_2 per point (tests/test_gpu_fft.py); the reference transforms
+ * with rustfft 6.4.1, so parity is by that tolerance, not by bits. */
+/* @serves fft_dim ifft_dim */
+RMHIP_API int rmhip_fft_dim(rmhip_ctx* ctx, rmhip_buf a, long long len_or_neg, int dim, int inverse, rmhip_buf* out);
+/* `complex_from_real(real)` (imag_or_0 == 0) / `complex_from_real_imag(real, imag)` (lib.rs:1940-1959): equal shapes, or either
+ * operand a one-element tensor that expands. */
+/* @serves complex_from_real complex_from_real_imag */
+RMHIP_API int rmhip_complex(rmhip_ctx* ctx, rmhip_buf real, rmhip_buf imag_or_0, rmhip_buf* out);
+/* `fft_extract_real(handle)` (lib.rs:2639-2644; ifft(..., 'symmetric'), ifft.rs:362-372): the real parts as a new real tensor of the
+ * same shape (a real input is copied: the caller frees the handle it passed). */
+/* @serves fft_extract_real */
+RMHIP_API int rmhip_complex_real(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out);
+
 /* `ishermitian(matrix, kind, tolerance)` for this backend's real data (lib.rs:3126-3138; ishermitian.rs:455-482, 522-530): the test of
  * `rmhip_issymmetric` with one more rule - the Hermitian kind fails on a NaN diagonal entry.  Same shape rules and errors. */
 /* @serves ishermitian */

@@ -40,9 +40,10 @@ struct HostTensorView {
     const size_t* shape;
     size_t rank;
 };
-struct HostTensorOwned {
+struct HostTensorOwned {  // lib.rs:3362-3366
     std::vector<double> data;
     std::vector<size_t> shape;
+    bool complex_interleaved = false;  // `storage == GpuTensorStorage::ComplexInterleaved`: data holds (re, im) pairs
 };
 
 // lib.rs:865-890
@@ -113,9 +114,15 @@ public:
         return upload(HostTensorView{data.data(), shape.data(), shape.size()});
     }
     HostTensorOwned download(const GpuTensorHandle& h) const {
-        HostTensorOwned out{std::vector<double>(h.numel()), h.shape};
+        const bool cplx = is_complex(h);
+        HostTensorOwned out{std::vector<double>(h.numel() * (cplx ? 2 : 1)), h.shape, cplx};
         check(rmhip_download(ctx_, own(h), out.data.data(), out.data.size()));
         return out;
+    }
+    bool is_complex(const GpuTensorHandle& h) const {  // `handle_storage`, lib.rs:588-594
+        int r = 0;
+        check(rmhip_storage(ctx_, own(h), &r));
+        return r != 0;
     }
     void free(const GpuTensorHandle& h) const { check(rmhip_free(ctx_, own(h))); }
     GpuTensorHandle fill(const std::vector<size_t>& shape, double value) const {
@@ -632,6 +639,32 @@ public:
         int r = 0;
         check(rmhip_issymmetric(ctx_, own(m), skew ? 1 : 0, tolerance, &r));
         return r != 0;
+    }
+    // lib.rs:2622-2644: transforms along zero-based `dim`, padded / truncated to `len` (-1: the extent) -> complex-interleaved tensors
+    GpuTensorHandle fft_dim(const GpuTensorHandle& a, long long len, size_t dim) const {
+        uint64_t out = 0;
+        check(rmhip_fft_dim(ctx_, own(a), len, (int)dim, 0, &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle ifft_dim(const GpuTensorHandle& a, long long len, size_t dim) const {
+        uint64_t out = 0;
+        check(rmhip_fft_dim(ctx_, own(a), len, (int)dim, 1, &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle fft_extract_real(const GpuTensorHandle& a) const {
+        uint64_t out = 0;
+        check(rmhip_complex_real(ctx_, own(a), &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle complex_from_real(const GpuTensorHandle& re) const {  // lib.rs:1940-1947
+        uint64_t out = 0;
+        check(rmhip_complex(ctx_, own(re), 0, &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle complex_from_real_imag(const GpuTensorHandle& re, const GpuTensorHandle& im) const {  // lib.rs:1949-1959
+        uint64_t out = 0;
+        check(rmhip_complex(ctx_, own(re), own(im), &out));
+        return with_shape(out);
     }
     bool ishermitian(const GpuTensorHandle& m, bool skew, double tolerance) const {  // lib.rs:3126-3138
         int r = 0;

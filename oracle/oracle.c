@@ -1531,6 +1531,43 @@ ORC_API int orc_issymmetric(const double* data, size_t rows, size_t cols, int sk
     return 1;
 }
 
+/* fft_dim / ifft_dim: the reference transforms each line with rustfft 6.4.1 (`FftPlanner::plan_fft_forward/inverse(len).process`,
+ * builtins/math/fft/common.rs and the wgpu provider's host form ops/fft/fallback.rs:84-125) - a third-party crate that is not under
+ * /root/reference (Cargo.lock:6116-6118).  What it computes is the discrete Fourier transform X[j] = sum_k x[k] exp(-+2 pi i jk / n);
+ * restated here by DIRECT evaluation in long double (the angle index jk is reduced mod n in integers), with the reference's framing:
+ * lines along a dimension of a column-major tensor (inner = product of the leading extents), zero-padded or truncated to n points
+ * (fallback.rs:36-47, 100-108), the inverse scaled by 1 / n (:113-118), complex-interleaved output (:127-131).  Bit-level parity is
+ * unpinned (rustfft's operation order is its own); the reference's tests pin 1e-12 / 1e-10 absolute on small vectors. */
+ORC_API void orc_dft_dim(const double* in, int in_complex, size_t inner, size_t len_in, size_t outer, size_t n, int inverse, double* out) {
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    long double* wr = (long double*)malloc((n ? n : 1) * sizeof(long double));
+    long double* wi = (long double*)malloc((n ? n : 1) * sizeof(long double));
+    for (size_t k = 0; k < n; ++k) {
+        const long double a = two_pi * (long double)k / (long double)n;
+        wr[k] = cosl(a);
+        wi[k] = inverse ? sinl(a) : -sinl(a);
+    }
+    const size_t copy = len_in < n ? len_in : n;
+    for (size_t o = 0; o < outer; ++o)
+        for (size_t i = 0; i < inner; ++i)
+            for (size_t j = 0; j < n; ++j) {
+                long double sr = 0.0L, si = 0.0L;
+                for (size_t k = 0; k < copy; ++k) {
+                    const size_t src = i + inner * (k + len_in * o);
+                    const long double xr = in_complex ? in[2 * src] : in[src], xi = in_complex ? in[2 * src + 1] : 0.0;
+                    const size_t t = (size_t)(((unsigned __int128)j * k) % n);
+                    sr += xr * wr[t] - xi * wi[t];
+                    si += xr * wi[t] + xi * wr[t];
+                }
+                if (inverse) sr /= (long double)n, si /= (long double)n;
+                const size_t dst = i + inner * (j + n * o);
+                out[2 * dst] = (double)sr;
+                out[2 * dst + 1] = (double)si;
+            }
+    free(wr);
+    free(wi);
+}
+
 /* is_hermitian_real, ishermitian.rs:455-482 (real_within :522-530; rows != cols -> false :550-552) */
 ORC_API int orc_ishermitian(const double* data, size_t rows, size_t cols, int skew, double tol) {
     if (rows != cols) return 0;

@@ -763,6 +763,32 @@ def issymmetric(a: np.ndarray, skew: bool = False, tol: float = 0.0) -> bool:
     return bool(l.orc_issymmetric(_p(_f(a)), rows, cols, int(skew), float(tol)))
 
 
+def fft_dim(x: np.ndarray, length=None, dim: int = 0, inverse: bool = False) -> np.ndarray:
+    """The transform of every line along zero-based `dim`, padded / truncated to `length` points, by direct evaluation of the DFT in
+    long double (orc_dft_dim); real or complex input, complex128 output of the reference's shape rule (the shape extended to
+    dim + 1 axes, that axis set to the length; ops/fft/fallback.rs:30-52)."""
+    x = np.asarray(x)
+    cplx = np.iscomplexobj(x)
+    x = x.astype(np.complex128 if cplx else np.float64)
+    shape = list(x.shape) if x.ndim else [x.size]
+    while len(shape) <= dim:
+        shape.append(1)
+    cur = shape[dim]
+    n = cur if length is None else int(length)
+    inner = int(np.prod(shape[:dim], dtype=np.int64))
+    outer = int(np.prod(shape[dim + 1:], dtype=np.int64))
+    oshape = list(shape)
+    oshape[dim] = n
+    flat = np.ascontiguousarray(x.reshape(-1, order="F"))
+    out = np.zeros(inner * n * outer, dtype=np.complex128)
+    if out.size and cur:
+        l = lib()
+        l.orc_dft_dim.restype = None
+        l.orc_dft_dim.argtypes = [_DP, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _DP]
+        l.orc_dft_dim(flat.view(np.float64).ctypes.data_as(_DP), int(cplx), inner, cur, outer, n, int(inverse), out.view(np.float64).ctypes.data_as(_DP))
+    return out.reshape(oshape, order="F")
+
+
 def ishermitian(a: np.ndarray, skew: bool = False, tol: float = 0.0) -> bool:
     """ishermitian.rs:455-482 for real data."""
     a = np.asarray(a, dtype=np.float64)

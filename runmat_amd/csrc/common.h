@@ -83,6 +83,11 @@ struct Buffer {
     // callers expand an operand with `repmat` only to hand it to `elem_*` and free it (times.rs:501-543) - every other
     // consumer sees a materialised copy on first use (Context::get / get_view).  Never combined with `tview`.
     std::vector<size_t> rep_base;
+    // Complex storage (`GpuTensorStorage::ComplexInterleaved`, lib.rs:247-251): `shape` / `numel` are the LOGICAL complex extents, the
+    // storage holds 2 * numel doubles (re, im, re, im, ...) and is always f64 (a precision-32 context rounds the VALUES through f32).
+    // Only the transforms and the complex constructors (fft.hip) and upload-free plumbing (download, shape, free) accept such a
+    // buffer; every real-valued entry point refuses it (Context::get_raw), so the caller gathers - as it does for any `Err`.
+    bool cplx = false;
     bool lazy() const { return tview || !rep_base.empty(); }
     size_t stored_numel() const {  // elements the storage holds (the base of a repmat view)
         if (rep_base.empty()) return numel;
@@ -145,6 +150,7 @@ struct Context {
     size_t pool_limit_bytes = 0;  // set at init (fraction of HBM)
 
     std::unordered_map<uint64_t, std::shared_ptr<FusedKernel>> kernel_cache;
+    std::unordered_map<uint64_t, std::shared_ptr<Allocation>> fft_tables;  // twiddle / chirp tables by (kind, length) (fft.hip)
 
     uint64_t rng_state = 0x9e3779b97f4a7c15ULL;  // DEFAULT_RNG_SEED, random.rs:7
 
@@ -200,6 +206,9 @@ struct Context {
     void release_device(double* ptr, size_t bytes);
     int new_buffer(const size_t* shape, size_t rank, uint64_t* id, Buffer* out);
     int register_buffer(Buffer&& b, uint64_t* id);
+    int new_buffer_complex(const size_t* shape, size_t rank, uint64_t* id, Buffer* out = nullptr);
+    int lookup(uint64_t id, Buffer* out);   // the table entry as it is (plumbing: shape, storage, download)
+    int get_any(uint64_t id, Buffer* out);  // like get(), but a complex buffer is handed over as it is
     int new_buffer_f32(const size_t* shape, size_t rank, uint64_t* id, Buffer* out);  // f32 storage, never narrowed
     int get(uint64_t id, Buffer* out);       // f64 data, plain layout: widens f32 storage into a temporary, materialises a transpose view
     int get_view(uint64_t id, Buffer* out);  // f64 data, `tview` may be set (matmul / syrk read views in place); repmat views are materialised

@@ -1,0 +1,590 @@
+// fft.hip -- discrete Fourier transforms along one dimension of a resident tensor, and the complex-interleaved storage they produce.
+//   fft_dim / ifft_dim        crates/runmat-accelerate-api/src/lib.rs:2622-2638   (semantics: the wgpu provider's host form,
+//                             runmat-accelerate/src/backend/wgpu/provider/ops/fft/fallback.rs:4-150 - zero-pad / truncate to `len`,
+//                             unnormalised forward transform, inverse scaled by 1 / len, complex-interleaved result)
+//   fft_extract_real          lib.rs:2639-2644    (ifft(..., 'symmetric'): builtins/math/fft/ifft.rs:362-372)
+//   complex_from_real(_imag)  lib.rs:1940-1959
+// The reference transforms with rustfft 6.4.1 (Cargo.lock:6116-6118; not under /root/reference): parity is by tolerance against the
+// DFT definition (tests/test_gpu_fft.py states it), not by bits.
+//
+// Kernel: `k_fft_tile` - a workgroup holds a tile of up to 4096 complex points (B lines x m points, m a power of two) in LDS as
+// split re / im arrays with one pad slot per 32, runs in-place decimation-in-frequency passes of radix 8 (then 4 or 2) with ONE
+// barrier per pass, and leaves through a digit-reversed LDS read, so both the loads and the stores are coalesced: along the points
+// when the line is contiguous, across neighbouring lines otherwise (lines along a trailing dimension).  Lengths above the tile take
+// two such passes (n = m1 * m2: strided length-m1 transforms, the step twiddle, length-m2 transforms); lengths that are not powers of
+// two go through Bluestein's chirp convolution on the same kernel.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+using namespace rmhip;
+
+#define CTX_OR_FAIL(ctx)                                            \
+    if (!(ctx)) return fail(RMHIP_ERR_INVALID, "null context");     \
+    Context* c = context_of(ctx);                                   \
+    std::lock_guard<std::recursive_mutex> _call(c->call_mu);        \
+    DeviceGuard _dg(c);                                             \
+    NarrowScope _ns(c)
+
+namespace rmhip {
+namespace {
+
+typedef unsigned long long u64;
+constexpr int FT = 256;         // threads per workgroup
+constexpr int TILE = 4096;      // complex points per workgroup
+constexpr int MAXB = 256;       // lines per workgroup
+constexpr u64 NOLINE = ~0ull;
+constexpr int STEP_LO = 12;     // step twiddle w_n^t = lo[t & 4095] * hi[t >> 12]
+
+__device__ __forceinline__ int padi(int i) { return i + (i >> 5); }
+
+struct Side {  // where point p of line (i, q, o) lives: element offset i*si + q*sq + o*so + p*sp
+    u64 si, sq, so, sp;
+};
+
+struct FftPass {
+    u64 nlines, inner, qcnt;  // line l = i + inner * (q + qcnt * o)
+    const double* in;
+    double* out;
+    Side a, b;                // input / output addressing (in complex elements, or real elements for a real input)
+    u64 in_pk, in_qk, in_len; // point p of a line with sub-index q exists iff p*in_pk + q*in_qk < in_len (else it reads as zero)
+    const double2* tw;        // w_m^k = exp(-2 pi i k / m), k < m
+    const double2* step_lo;   // step twiddle tables of the enclosing length (two-pass transforms), or null
+    const double2* step_hi;
+    const double2* mul_in;    // per-point factor on load, indexed by the point's position p*in_pk + q*in_qk (Bluestein's chirp), or null
+    double scale;
+    int log2m, log2b;
+    int in_complex, fast_lines_in, fast_lines_out, conj_in, conj_out, round32;
+    int nrad, rad[5];
+};
+
+__device__ __forceinline__ void cmul(double& xr, double& xi, double wr, double wi) {
+    const double r = xr * wr - xi * wi, i = xr * wi + xi * wr;
+    xr = r;
+    xi = i;
+}
+
+// natural-order in, natural-order out, forward sign
+template <int R>
+__device__ __forceinline__ void dft_small(double (&xr)[R], double (&xi)[R]);
+
+template <>
+__device__ __forceinline__ void dft_small<2>(double (&xr)[2], double (&xi)[2]) {
+    const double ar = xr[0] + xr[1], ai = xi[0] + xi[1], br = xr[0] - xr[1], bi = xi[0] - xi[1];
+    xr[0] = ar, xi[0] = ai, xr[1] = br, xi[1] = bi;
+}
+
+__device__ __forceinline__ void dft4(double& r0, double& i0, double& r1, double& i1, double& r2, double& i2, double& r3, double& i3) {
+    const double t0r = r0 + r2, t0i = i0 + i2, t1r = r0 - r2, t1i = i0 - i2;
+    const double t2r = r1 + r3, t2i = i1 + i3;
+    const double t3r = i1 - i3, t3i = -(r1 - r3);  // (a1 - a3) * (-i)
+    r0 = t0r + t2r, i0 = t0i + t2i;
+    r2 = t0r - t2r, i2 = t0i - t2i;
+    r1 = t1r + t3r, i1 = t1i + t3i;
+    r3 = t1r - t3r, i3 = t1i - t3i;
+}
+
+template <>
+__device__ __forceinline__ void dft_small<4>(double (&xr)[4], double (&xi)[4]) {
+    dft4(xr[0], xi[0], xr[1], xi[1], xr[2], xi[2], xr[3], xi[3]);
+}
+
+template <>
+__device__ __forceinline__ void dft_small<8>(double (&xr)[8], double (&xi)[8]) {
+    // even and odd halves, then X[k] = E[k] + w8^k O[k], X[k + 4] = E[k] - w8^k O[k]
+    dft4(xr[0], xi[0], xr[2], xi[2], xr[4], xi[4], xr[6], xi[6]);
+    dft4(xr[1], xi[1], xr[3], xi[3], xr[5], xi[5], xr[7], xi[7]);
+    constexpr double h = 0.70710678118654752440;
+    double er[4] = {xr[0], xr[2], xr[4], xr[6]}, ei[4] = {xi[0], xi[2], xi[4], xi[6]};
+    double orr[4], oi[4];
+    orr[0] = xr[1], oi[0] = xi[1];
+    orr[1] = h * (xr[3] + xi[3]), oi[1] = h * (xi[3] - xr[3]);   // * (1 - i) / sqrt 2
+    orr[2] = xi[5], oi[2] = -xr[5];                              // * (-i)
+    orr[3] = h * (xi[7] - xr[7]), oi[3] = -h * (xr[7] + xi[7]);  // * (-1 - i) / sqrt 2
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        xr[k] = er[k] + orr[k], xi[k] = ei[k] + oi[k];
+        xr[k + 4] = er[k] - orr[k], xi[k + 4] = ei[k] - oi[k];
+    }
+}
+
+// one in-place decimation-in-frequency pass of radix R over sub-blocks of length L = 1 << log2l of every line of the tile
+template <int R>
+__device__ __forceinline__ void dif_pass(double* __restrict__ re, double* __restrict__ im, const double2* __restrict__ tw, int tile, int log2m, int log2l) {
+    constexpr int LR = R == 8 ? 3 : (R == 4 ? 2 : 1);
+    const int log2s = log2l - LR;  // butterfly stride L / R
+    const int nb = tile >> LR;
+    for (int id = threadIdx.x; id < nb; id += FT) {
+        const int j = id & ((1 << log2s) - 1);
+        const int base = ((id >> log2s) << log2l) + j;  // (line, block) are the high bits of id: lines are m long, m a multiple of L
+        double xr[R], xi[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int a = padi(base + (q << log2s));
+            xr[q] = re[a], xi[q] = im[a];
+        }
+        dft_small<R>(xr, xi);
+        if (log2s > 0) {  // w_L^{j r} = w_m^{j r m / L}
+            const int sh = log2m - log2l;
+#pragma unroll
+            for (int r = 1; r < R; ++r) {
+                const double2 w = tw[(j * r) << sh];
+                cmul(xr[r], xi[r], w.x, w.y);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int a = padi(base + (r << log2s));
+            re[a] = xr[r], im[a] = xi[r];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(FT) k_fft_tile(const FftPass P) {
+    extern __shared__ __attribute__((aligned(16))) double fft_lds[];
+    const int t = threadIdx.x;
+    const int log2m = P.log2m, log2b = P.log2b, m = 1 << log2m, B = 1 << log2b, tile = 1 << (log2m + log2b);
+    const int plane = tile + (tile >> 5) + 1;
+    double* const re = fft_lds;
+    double* const im = re + plane;
+    u64* const ibase = reinterpret_cast<u64*>(im + plane);
+    u64* const obase = ibase + B;
+    unsigned* const lq = reinterpret_cast<unsigned*>(obase + B);
+    if (t < B) {
+        const u64 l = (u64)blockIdx.x * B + t;
+        if (l < P.nlines) {
+            const u64 i = l % P.inner, r = l / P.inner, q = r % P.qcnt, o = r / P.qcnt;
+            ibase[t] = i * P.a.si + q * P.a.sq + o * P.a.so;
+            obase[t] = i * P.b.si + q * P.b.sq + o * P.b.so;
+            lq[t] = (unsigned)q;
+        } else {
+            ibase[t] = NOLINE;
+            obase[t] = NOLINE;
+            lq[t] = 0;
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int e = t; e < tile; e += FT) {
+        int b, p;
+        if (P.fast_lines_in) b = e & (B - 1), p = e >> log2b;
+        else p = e & (m - 1), b = e >> log2m;
+        double xr = 0.0, xi = 0.0;
+        const u64 base = ibase[b];
+        const u64 pos = (u64)p * P.in_pk + (u64)lq[b] * P.in_qk;
+        if (base != NOLINE && pos < P.in_len) {
+            const u64 off = base + (u64)p * P.a.sp;
+            if (P.in_complex) {
+                const double2 v = reinterpret_cast<const double2*>(P.in)[off];
+                xr = v.x, xi = v.y;
+            } else {
+                xr = P.in[off];
+            }
+            if (P.conj_in) xi = -xi;
+            if (P.mul_in) {
+                const double2 w = P.mul_in[pos];
+                cmul(xr, xi, w.x, w.y);
+            }
+        }
+        const int a = padi((b << log2m) + p);
+        re[a] = xr, im[a] = xi;
+    }
+    __syncthreads();
+    int log2l = log2m;
+    for (int s = 0; s < P.nrad; ++s) {
+        const int R = P.rad[s];
+        if (R == 8) dif_pass<8>(re, im, P.tw, tile, log2m, log2l), log2l -= 3;
+        else if (R == 4) dif_pass<4>(re, im, P.tw, tile, log2m, log2l), log2l -= 2;
+        else dif_pass<2>(re, im, P.tw, tile, log2m, log2l), log2l -= 1;
+        __syncthreads();
+    }
+#pragma unroll 4
+    for (int e = t; e < tile; e += FT) {
+        int b, p;
+        if (P.fast_lines_out) b = e & (B - 1), p = e >> log2b;
+        else p = e & (m - 1), b = e >> log2m;
+        const u64 base = obase[b];
+        if (base == NOLINE) continue;
+        // X[k] of a line sits at the digit-reversed position: the first pass files k mod R1 as the coarsest digit, and so on
+        int k = p, pos = 0, lg = log2m;
+        for (int s = 0; s < P.nrad; ++s) {
+            const int lr = P.rad[s] == 8 ? 3 : (P.rad[s] == 4 ? 2 : 1);
+            lg -= lr;
+            pos += (k & (P.rad[s] - 1)) << lg;
+            k >>= lr;
+        }
+        const int a = padi((b << log2m) + pos);
+        double xr = re[a], xi = im[a];
+        if (P.step_lo) {
+            const u64 tt = (u64)p * lq[b];
+            const double2 wl = P.step_lo[tt & ((1u << STEP_LO) - 1)], wh = P.step_hi[tt >> STEP_LO];
+            double wr = wl.x, wi = wl.y;
+            cmul(wr, wi, wh.x, wh.y);
+            cmul(xr, xi, wr, wi);
+        }
+        if (P.conj_out) xi = -xi;
+        xr *= P.scale, xi *= P.scale;
+        if (P.round32) xr = (double)(float)xr, xi = (double)(float)xi;
+        double2 v;
+        v.x = xr, v.y = xi;
+        reinterpret_cast<double2*>(P.out)[base + (u64)p * P.b.sp] = v;
+    }
+}
+
+// tables ---------------------------------------------------------------------------------------------------------------------------------
+// kind 0: w_n^k, k < count                 (count = n)
+// kind 1: w_n^(k * 4096), k < count        (the coarse half of the step twiddle)
+// kind 2: exp(-i pi k^2 / n), k < count    (Bluestein's chirp; k^2 mod 2n is taken in integers)
+__global__ void __launch_bounds__(FT) k_fft_table(double2* __restrict__ out, u64 count, u64 n, int kind) {
+    const u64 k = (u64)blockIdx.x * FT + threadIdx.x;
+    if (k >= count) return;
+    double s, co;
+    if (kind == 2) {
+        const u64 k2 = (unsigned long long)(((unsigned __int128)k * k) % (2 * n));
+        sincospi((double)k2 / (double)n, &s, &co);
+    } else {
+        const u64 kk = kind == 1 ? ((k << STEP_LO) % n) : k;
+        sincospi(2.0 * (double)kk / (double)n, &s, &co);
+    }
+    double2 v;
+    v.x = co, v.y = -s;
+    out[k] = v;
+}
+
+typedef std::shared_ptr<Allocation> Table;  // callers hold the reference while their launches are being queued
+inline const double2* tptr(const Table& t) { return reinterpret_cast<const double2*>(t->ptr); }
+
+int fft_table(Context* c, int kind, u64 n, u64 count, Table* out) {
+    const uint64_t key = ((uint64_t)kind << 60) ^ (n << 28) ^ count;
+    auto it = c->fft_tables.find(key);
+    if (it == c->fft_tables.end()) {
+        std::shared_ptr<Allocation> a;
+        RMHIP_TRY(c->alloc_device(2 * count, &a));
+        hipLaunchKernelGGL(k_fft_table, dim3((unsigned)((count + FT - 1) / FT)), dim3(FT), 0, c->stream, reinterpret_cast<double2*>(a->ptr), count, n, kind);
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+        if (c->fft_tables.size() > 64) c->fft_tables.clear();  // bounded: a table is a few microseconds to rebuild
+        it = c->fft_tables.emplace(key, a).first;
+    }
+    *out = it->second;
+    return RMHIP_OK;
+}
+
+inline int ilog2(u64 v) {
+    int l = 0;
+    while ((1ull << l) < v) ++l;
+    return l;
+}
+inline bool is_pow2(u64 v) { return v && !(v & (v - 1)); }
+
+void set_radices(FftPass& P) {
+    int rem = P.log2m;
+    P.nrad = 0;
+    while (rem >= 3) P.rad[P.nrad++] = 8, rem -= 3;
+    if (rem == 2) P.rad[P.nrad++] = 4;
+    if (rem == 1) P.rad[P.nrad++] = 2;
+}
+
+int launch_pass(Context* c, FftPass& P) {
+    set_radices(P);
+    const int m = 1 << P.log2m;
+    int lb = 0;
+    while ((m << (lb + 1)) <= TILE && (1 << (lb + 1)) <= MAXB && (1ull << lb) < P.nlines) ++lb;
+    P.log2b = lb;
+    Table tw;
+    RMHIP_TRY(fft_table(c, 0, (u64)m, (u64)m, &tw));
+    P.tw = tptr(tw);
+    const u64 blocks = (P.nlines + (1ull << lb) - 1) >> lb;
+    if (blocks > 0x7fffffffull) return fail(RMHIP_ERR_UNSUPPORTED, "fft: %llu lines", P.nlines);
+    const size_t tile = (size_t)m << lb, lds = (2 * (tile + (tile >> 5) + 1) + 2 * ((size_t)1 << lb)) * sizeof(double) + ((size_t)1 << lb) * sizeof(unsigned);
+    hipLaunchKernelGGL(k_fft_tile, dim3((unsigned)blocks), dim3(FT), lds, c->stream, P);
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+
+// A set of lines in tensor layout: point k of line (i, o) at element i + inner * (k + len * o).
+struct Lines {
+    const double* in;
+    int in_complex;
+    u64 inner, outer, len_in;  // len_in: points the input holds per line
+    double* out;               // complex, n points per line, same layout
+};
+
+// forward transform of conj^a(x), conjugated b times (a = b = 1: the unscaled inverse) - power-of-two length n along the lines; `scale` multiplies the result.
+// `mul_in` (or null): a factor per input point k (Bluestein's chirp); points from `valid` on read as zero whatever the input holds.
+int fft_pow2(Context* c, const Lines& L, u64 n, bool conj_in, bool conj_out, double scale, bool round32, const double2* mul_in = nullptr, u64 valid = ~0ull) {
+    const int lg = ilog2(n);
+    const u64 in_len = std::min<u64>(std::min<u64>(L.len_in, n), valid);
+    const u64 lines = L.inner * L.outer;
+    // a line along a trailing dimension is read across neighbouring lines: short transforms, many lines per tile
+    const bool single = L.inner == 1 ? lg <= 12 : lg <= 8;
+    if (single) {
+        FftPass P{};
+        P.nlines = lines, P.inner = L.inner, P.qcnt = 1;
+        P.in = L.in, P.out = L.out, P.in_complex = L.in_complex;
+        P.a = Side{1, 0, L.len_in * L.inner, L.inner};
+        P.b = Side{1, 0, n * L.inner, L.inner};
+        P.in_pk = 1, P.in_qk = 0, P.in_len = in_len;
+        P.mul_in = mul_in;
+        P.scale = scale, P.log2m = lg;
+        P.fast_lines_in = P.fast_lines_out = L.inner > 1;
+        P.conj_in = conj_in, P.conj_out = conj_out;
+        P.round32 = round32;
+        return launch_pass(c, P);
+    }
+    if (lg > 24) return fail(RMHIP_ERR_UNSUPPORTED, "fft: length %llu", n);
+    // n = m1 * m2: (1) length-m1 transforms over k1 of x[k1 * m2 + k2], times w_n^(j1 k2), into T[j1 * m2 + k2];
+    //              (2) length-m2 transforms over k2 of T[j1 * m2 + k2] into y[j1 + m1 * j2]
+    const int l1 = lg / 2, l2 = lg - l1;
+    const u64 m1 = 1ull << l1, m2 = 1ull << l2;
+    std::shared_ptr<Allocation> tmp;
+    RMHIP_TRY(c->alloc_device(2 * n * lines, &tmp));
+    Table slo, shi;
+    RMHIP_TRY(fft_table(c, 0, n, std::min<u64>(n, 1ull << STEP_LO), &slo));
+    RMHIP_TRY(fft_table(c, 1, n, std::max<u64>(1, n >> STEP_LO), &shi));
+    {
+        FftPass P{};
+        P.nlines = lines * m2, P.inner = L.inner, P.qcnt = m2;
+        P.in = L.in, P.out = tmp->ptr, P.in_complex = L.in_complex;
+        P.a = Side{1, L.inner, L.len_in * L.inner, m2 * L.inner};
+        P.b = Side{1, L.inner, n * L.inner, m2 * L.inner};
+        P.in_pk = m2, P.in_qk = 1, P.in_len = in_len;
+        P.mul_in = mul_in;
+        P.step_lo = tptr(slo), P.step_hi = tptr(shi);
+        P.scale = 1.0, P.log2m = l1;
+        P.fast_lines_in = P.fast_lines_out = 1;  // neighbouring lines (i, then k2) are neighbours in memory
+        P.conj_in = conj_in;
+        RMHIP_TRY(launch_pass(c, P));
+    }
+    {
+        FftPass P{};
+        P.nlines = lines * m1, P.inner = L.inner, P.qcnt = m1;
+        P.in = tmp->ptr, P.out = L.out, P.in_complex = 1;
+        P.a = Side{1, L.inner * m2, n * L.inner, L.inner};
+        P.b = Side{1, L.inner, n * L.inner, m1 * L.inner};
+        P.in_pk = 1, P.in_qk = 0, P.in_len = m2;
+        P.scale = scale, P.log2m = l2;
+        P.fast_lines_in = L.inner > 1;
+        P.fast_lines_out = 1;
+        P.conj_out = conj_out;
+        P.round32 = round32;
+        RMHIP_TRY(launch_pass(c, P));
+    }
+    return RMHIP_OK;
+}
+
+// Bluestein: X[j] = conj-chirp[j] * sum_k (x[k] chirp[k]) * conj(chirp)[j - k], chirp[k] = exp(-i pi k^2 / n); the convolution by
+// power-of-two transforms of length M >= 2n - 1.  G = FFT_M(g), g[k] = conj(chirp[|k|]) wrapped, is computed once per (n, M).
+__global__ void __launch_bounds__(FT) k_bluestein_kernel(const double2* __restrict__ chirp, u64 n, u64 M, double2* __restrict__ g) {
+    const u64 k = (u64)blockIdx.x * FT + threadIdx.x;
+    if (k >= M) return;
+    double2 v;
+    v.x = 0.0, v.y = 0.0;
+    if (k < n) v.x = chirp[k].x, v.y = -chirp[k].y;
+    else if (M - k < n) v.x = chirp[M - k].x, v.y = -chirp[M - k].y;
+    g[k] = v;
+}
+
+// y(i, k, o) *= G[k] (in place; tensor layout with M points per line)
+__global__ void __launch_bounds__(FT) k_line_mul(double2* __restrict__ a, const double2* __restrict__ g, u64 inner, u64 M, u64 total) {
+    const u64 e = (u64)blockIdx.x * FT + threadIdx.x;
+    if (e >= total) return;
+    double2 v = a[e];
+    const double2 w = g[(e / inner) % M];
+    cmul(v.x, v.y, w.x, w.y);
+    a[e] = v;
+}
+
+// out(i, j, o) = scale * op(chirp[j] * y(i, j, o)) for j < n: the first n points of the M-long lines
+__global__ void __launch_bounds__(FT) k_bluestein_finish(const double2* __restrict__ y, const double2* __restrict__ chirp, u64 inner, u64 n, u64 M, u64 total,
+                                                         double scale, int conj_out, int round32, double2* __restrict__ out) {
+    const u64 e = (u64)blockIdx.x * FT + threadIdx.x;  // output element i + inner * (j + n * o)
+    if (e >= total) return;
+    const u64 i = e % inner, r = e / inner, j = r % n, o = r / n;
+    double2 v = y[i + inner * (j + M * o)];
+    const double2 w = chirp[j];
+    cmul(v.x, v.y, w.x, w.y);
+    if (conj_out) v.y = -v.y;
+    v.x *= scale, v.y *= scale;
+    if (round32) v.x = (double)(float)v.x, v.y = (double)(float)v.y;
+    out[e] = v;
+}
+
+int fft_bluestein(Context* c, const Lines& L, u64 n, bool inverse, double scale, bool round32) {
+    u64 M = 1;
+    while (M < 2 * n - 1) M <<= 1;
+    if (M > (1ull << 24)) return fail(RMHIP_ERR_UNSUPPORTED, "fft: length %llu", n);
+    Table chirp;
+    RMHIP_TRY(fft_table(c, 2, n, n, &chirp));
+    // G = FFT_M of the wrapped conjugate chirp, kept beside the tables (kind 3)
+    const uint64_t gkey = (3ull << 60) ^ (n << 28) ^ M;
+    Table G;
+    auto it = c->fft_tables.find(gkey);
+    if (it != c->fft_tables.end()) {
+        G = it->second;
+    } else {
+        Table g;
+        RMHIP_TRY(c->alloc_device(2 * M, &g));
+        RMHIP_TRY(c->alloc_device(2 * M, &G));
+        hipLaunchKernelGGL(k_bluestein_kernel, dim3((unsigned)((M + FT - 1) / FT)), dim3(FT), 0, c->stream, tptr(chirp), n, M, reinterpret_cast<double2*>(g->ptr));
+        c->tel.kernel_launches++;
+        Lines gl{g->ptr, 1, 1, 1, M, G->ptr};
+        RMHIP_TRY(fft_pow2(c, gl, M, false, false, 1.0, false));
+        c->fft_tables[gkey] = G;
+    }
+    // the two work tensors [inner, M, outer'] stay below ~1 GiB each: whole outer slabs at a time
+    const u64 slab = L.inner * M;
+    if (slab > (1ull << 27)) return fail(RMHIP_ERR_UNSUPPORTED, "fft: %llu lines of chirp length %llu along a trailing dimension", L.inner, M);
+    const u64 outer_per = std::min<u64>(L.outer, std::max<u64>(1, (1ull << 26) / slab));
+    Table A, Y;
+    RMHIP_TRY(c->alloc_device(2 * slab * outer_per, &A));
+    RMHIP_TRY(c->alloc_device(2 * slab * outer_per, &Y));
+    const u64 valid = std::min<u64>(L.len_in, n);
+    for (u64 o0 = 0; o0 < L.outer; o0 += outer_per) {
+        const u64 oc = std::min<u64>(outer_per, L.outer - o0), total = oc * slab;
+        const double* in = L.in + (L.in_complex ? 2 : 1) * (o0 * L.len_in * L.inner);
+        double* out = L.out + 2 * (o0 * n * L.inner);
+        Lines f{in, L.in_complex, L.inner, oc, L.len_in, A->ptr};  // a = op(x) .* chirp, zero-extended to M, transformed
+        RMHIP_TRY(fft_pow2(c, f, M, inverse, false, 1.0, false, tptr(chirp), valid));
+        hipLaunchKernelGGL(k_line_mul, dim3((unsigned)((total + FT - 1) / FT)), dim3(FT), 0, c->stream, reinterpret_cast<double2*>(A->ptr), tptr(G), L.inner, M, total);
+        Lines b{A->ptr, 1, L.inner, oc, M, Y->ptr};
+        RMHIP_TRY(fft_pow2(c, b, M, true, true, 1.0 / (double)M, false));
+        const u64 ototal = oc * L.inner * n;
+        hipLaunchKernelGGL(k_bluestein_finish, dim3((unsigned)((ototal + FT - 1) / FT)), dim3(FT), 0, c->stream, reinterpret_cast<const double2*>(Y->ptr), tptr(chirp),
+                           L.inner, n, M, ototal, scale, inverse ? 1 : 0, round32 ? 1 : 0, reinterpret_cast<double2*>(out));
+        c->tel.kernel_launches += 2;
+        RMHIP_HIP_CHECK(hipGetLastError());
+    }
+    return RMHIP_OK;
+}
+
+int fft_entry(Context* c, rmhip_buf a, long long len_or_neg, int dim, bool inverse, rmhip_buf* out) {
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    if (dim < 0) return fail(RMHIP_ERR_INVALID, "fft: dim must be >= 0");
+    Buffer ab;
+    RMHIP_TRY(c->get_any(a, &ab));
+    std::vector<size_t> shape = ab.shape;
+    if (shape.empty()) shape.push_back(ab.numel);  // fallback.rs:20-29
+    const size_t origin_rank = shape.size();
+    while (shape.size() <= (size_t)dim) shape.push_back(1);
+    const u64 cur = shape[dim], n = len_or_neg < 0 ? cur : (u64)len_or_neg;
+    u64 inner = 1, outer = 1;
+    for (int k = 0; k < dim; ++k) inner *= shape[k];
+    for (size_t k = dim + 1; k < shape.size(); ++k) outer *= shape[k];
+    std::vector<size_t> oshape = shape;
+    oshape[dim] = n;
+    // fft_trim_trailing_ones(out_shape, max(origin_rank, dim + 1)) (mod.rs:14-19): nothing beyond that rank was added, so only the
+    // scalar normalisation is left
+    (void)origin_rank;
+    bool scalar = true;
+    for (size_t e : oshape) scalar = scalar && e == 1;
+    if (scalar) oshape = {1, 1};
+    Buffer ob;
+    RMHIP_TRY(c->new_buffer_complex(oshape.data(), oshape.size(), out, &ob));
+    if (ob.numel == 0) return RMHIP_OK;
+    const bool r32 = c->precision == 32;
+    Lines L{ab.data(), ab.cplx ? 1 : 0, inner, outer, cur, ob.data()};
+    const double scale = inverse ? 1.0 / (double)n : 1.0;
+    int rc;
+    if (n == 1 || cur == 0) {
+        // a one-point transform is the point itself (or zero where the input has none): the tile kernel with m = 1 has no pass to run
+        FftPass P{};
+        P.nlines = inner * outer, P.inner = inner, P.qcnt = 1;
+        P.in = L.in, P.out = L.out, P.in_complex = L.in_complex;
+        P.a = Side{1, 0, cur * inner, inner};
+        P.b = Side{1, 0, n * inner, inner};
+        P.in_pk = 1, P.in_qk = 0, P.in_len = std::min<u64>(cur, n);
+        P.scale = scale, P.log2m = 0, P.round32 = r32;
+        P.fast_lines_in = P.fast_lines_out = 1;
+        if (n == 1) rc = launch_pass(c, P);
+        else {
+            RMHIP_HIP_CHECK(hipMemsetAsync(ob.data(), 0, 2 * ob.numel * sizeof(double), c->stream));
+            rc = RMHIP_OK;
+        }
+    } else if (is_pow2(n)) {
+        rc = fft_pow2(c, L, n, inverse, inverse, scale, r32);
+    } else {
+        rc = fft_bluestein(c, L, n, inverse, scale, r32);
+    }
+    if (rc != RMHIP_OK) {
+        Buffer victim;
+        std::lock_guard<std::mutex> lk(c->mu);
+        auto it = c->table.find(*out);
+        if (it != c->table.end()) victim = std::move(it->second), c->table.erase(it);
+        *out = 0;
+    }
+    return rc;
+}
+
+__global__ void __launch_bounds__(FT) k_complex_make(const double* __restrict__ re, u64 re_n, const double* __restrict__ im, u64 im_n, u64 total, int round32,
+                                                     double2* __restrict__ out) {
+    const u64 e = (u64)blockIdx.x * FT + threadIdx.x;
+    if (e >= total) return;
+    double2 v;
+    v.x = re[re_n == 1 ? 0 : e];
+    v.y = im ? im[im_n == 1 ? 0 : e] : 0.0;
+    if (round32) v.x = (double)(float)v.x, v.y = (double)(float)v.y;
+    out[e] = v;
+}
+
+__global__ void __launch_bounds__(FT) k_complex_real(const double2* __restrict__ a, u64 total, double* __restrict__ out) {
+    const u64 e = (u64)blockIdx.x * FT + threadIdx.x;
+    if (e < total) out[e] = a[e].x;
+}
+
+}  // namespace
+}  // namespace rmhip
+
+extern "C" {
+
+int rmhip_fft_dim(rmhip_ctx* ctx, rmhip_buf a, long long len_or_neg, int dim, int inverse, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    return fft_entry(c, a, len_or_neg, dim, inverse != 0, out);
+}
+
+int rmhip_complex(rmhip_ctx* ctx, rmhip_buf real, rmhip_buf imag_or_0, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer rb, ib;
+    RMHIP_TRY(c->get(real, &rb));
+    if (imag_or_0) RMHIP_TRY(c->get(imag_or_0, &ib));
+    // complex(real, imag): equal shapes, or either operand a scalar that expands (lib.rs:1949-1959)
+    const Buffer* shape_of = &rb;
+    if (imag_or_0) {
+        if (rb.numel == 1 && ib.numel != 1) shape_of = &ib;
+        else if (ib.numel != 1 && ib.shape != rb.shape) return fail(RMHIP_ERR_SHAPE, "complex: real and imaginary parts must have the same size");
+    }
+    Buffer ob;
+    RMHIP_TRY(c->new_buffer_complex(shape_of->shape.data(), shape_of->shape.size(), out, &ob));
+    if (ob.numel == 0) return RMHIP_OK;
+    hipLaunchKernelGGL(k_complex_make, dim3((unsigned)((ob.numel + FT - 1) / FT)), dim3(FT), 0, c->stream, rb.data(), (u64)rb.numel, imag_or_0 ? ib.data() : nullptr,
+                       (u64)(imag_or_0 ? ib.numel : 0), (u64)ob.numel, c->precision == 32 ? 1 : 0, reinterpret_cast<double2*>(ob.data()));
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+
+int rmhip_complex_real(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer ab;
+    RMHIP_TRY(c->get_any(a, &ab));
+    Buffer ob;
+    RMHIP_TRY(c->new_buffer(ab.shape.data(), ab.shape.size(), out, &ob));
+    if (ob.numel == 0) return RMHIP_OK;
+    if (!ab.cplx) {  // already real: the caller frees the transform's handle and keeps this one (ifft.rs:368-371), so it is a copy
+        RMHIP_HIP_CHECK(hipMemcpyAsync(ob.data(), ab.data(), ob.numel * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        return RMHIP_OK;
+    }
+    hipLaunchKernelGGL(k_complex_real, dim3((unsigned)((ob.numel + FT - 1) / FT)), dim3(FT), 0, c->stream, reinterpret_cast<const double2*>(ab.data()), (u64)ob.numel,
+                       ob.data());
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+
+}  // extern "C"

@@ -348,7 +348,7 @@ int rmhip_isreal(rmhip_ctx* ctx, rmhip_buf a, int* result) {
     CTX_OR_FAIL(ctx);
     if (!result) return fail(RMHIP_ERR_INVALID, "null result");
     Buffer ab;
-    RMHIP_TRY(c->get_raw(a, &ab));  // (an unknown handle is an error: simple_provider.rs:4786-4795)
-    *result = 1;                    // every buffer of this library is real storage (no complex-interleaved tensors)
+    RMHIP_TRY(c->lookup(a, &ab));  // (an unknown handle is an error: simple_provider.rs:4786-4795)
+    *result = ab.cplx ? 0 : 1;     // complex-interleaved storage only comes out of the transforms / complex constructors (fft.hip)
     return RMHIP_OK;
 }

@@ -129,6 +129,21 @@ int Context::new_buffer(const size_t* shape, size_t rank, uint64_t* id, Buffer* 
     return RMHIP_OK;
 }
 
+int Context::new_buffer_complex(const size_t* shape, size_t rank, uint64_t* id, Buffer* out) {
+    Buffer b;
+    b.shape.assign(shape, shape + rank);
+    b.numel = shape_numel(shape, rank);
+    b.cplx = true;
+    RMHIP_TRY(alloc_device(2 * b.numel, &b.alloc));
+    if (out) *out = b;
+    return register_buffer(std::move(b), id);  // f64 storage in either precision mode: never queued for narrowing
+}
+
+int Context::get_any(uint64_t id, Buffer* out) {
+    RMHIP_TRY(lookup(id, out));
+    return out->cplx ? RMHIP_OK : get(id, out);
+}
+
 int Context::new_buffer_f32(const size_t* shape, size_t rank, uint64_t* id, Buffer* out) {
     Buffer b;
     b.shape.assign(shape, shape + rank);
@@ -140,6 +155,12 @@ int Context::new_buffer_f32(const size_t* shape, size_t rank, uint64_t* id, Buff
 }
 
 int Context::get_raw(uint64_t id, Buffer* out) {
+    RMHIP_TRY(lookup(id, out));
+    if (out->cplx) return fail(RMHIP_ERR_UNSUPPORTED, "complex-interleaved tensor %llu: this entry point takes real tensors", (unsigned long long)id);
+    return RMHIP_OK;
+}
+
+int Context::lookup(uint64_t id, Buffer* out) {
     Buffer rec;
     {
         std::lock_guard<std::mutex> lk(mu);
@@ -502,8 +523,10 @@ int rmhip_upload(rmhip_ctx* ctx, const double* host, const size_t* shape, size_t
 int rmhip_download(rmhip_ctx* ctx, rmhip_buf id, double* out_host, size_t n) {
     CTX_OR_FAIL(ctx);
     Buffer b;
-    RMHIP_TRY(c->get(id, &b));
-    if (n != b.numel) return fail(RMHIP_ERR_SHAPE, "download: expected %zu elements, got %zu", b.numel, n);
+    RMHIP_TRY(c->get_any(id, &b));
+    // a complex-interleaved tensor comes back as 2 * numel doubles (re, im, ...), as `HostTensorOwned` carries it (lib.rs:3362-3366)
+    if (n != (b.cplx ? 2 * b.numel : b.numel))
+        return fail(RMHIP_ERR_SHAPE, "download: expected %zu elements, got %zu", b.cplx ? 2 * b.numel : b.numel, n);
     if (n && !out_host) return fail(RMHIP_ERR_INVALID, "download: null destination");
     if (n) {
         RMHIP_HIP_CHECK(hipMemcpyAsync(out_host, b.data(), n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -526,11 +549,20 @@ int rmhip_free(rmhip_ctx* ctx, rmhip_buf id) {
     return RMHIP_OK;  // `victim` drops the allocation reference outside the lock
 }
 
+int rmhip_storage(rmhip_ctx* ctx, rmhip_buf id, int* complex_interleaved) {
+    CTX_OR_FAIL(ctx);
+    if (!complex_interleaved) return fail(RMHIP_ERR_INVALID, "null result");
+    Buffer b;
+    RMHIP_TRY(c->lookup(id, &b));
+    *complex_interleaved = b.cplx ? 1 : 0;
+    return RMHIP_OK;
+}
+
 int rmhip_shape(rmhip_ctx* ctx, rmhip_buf id, size_t* rank_inout, size_t* shape_out) {
     CTX_OR_FAIL(ctx);
     if (!rank_inout) return fail(RMHIP_ERR_INVALID, "null rank");
     Buffer b;
-    RMHIP_TRY(c->get_raw(id, &b));
+    RMHIP_TRY(c->lookup(id, &b));
     if (*rank_inout < b.shape.size() || !shape_out) {
         *rank_inout = b.shape.size();
         return shape_out ? fail(RMHIP_ERR_INVALID, "shape buffer too small") : RMHIP_OK;
@@ -543,7 +575,7 @@ int rmhip_shape(rmhip_ctx* ctx, rmhip_buf id, size_t* rank_inout, size_t* shape_
 int rmhip_numel(rmhip_ctx* ctx, rmhip_buf id, size_t* out) {
     CTX_OR_FAIL(ctx);
     Buffer b;
-    RMHIP_TRY(c->get_raw(id, &b));
+    RMHIP_TRY(c->lookup(id, &b));
     *out = b.numel;
     return RMHIP_OK;
 }

@@ -267,11 +267,22 @@ class HipProvider:
         return self._handle(out.value, shape)
 
     def download(self, h: GpuTensorHandle) -> np.ndarray:
-        """Returns the column-major flat data (`HostTensorOwned.data`)."""
+        """Returns the column-major flat data (`HostTensorOwned.data`); a complex-interleaved tensor (`storage`, lib.rs:3362-3366)
+        comes back as a complex128 array of the logical length (its re, im pairs viewed as complex numbers)."""
         n = int(np.prod(h.shape, dtype=np.int64)) if len(h.shape) else 1
+        if self.is_complex(h):
+            out = np.empty(2 * n, dtype=np.float64)
+            self._check(self._lib.rmhip_download(self._ctx, self._id(h), out.ctypes.data_as(C.POINTER(C.c_double)), 2 * n))
+            return out.view(np.complex128)
         out = np.empty(n, dtype=np.float64)
         self._check(self._lib.rmhip_download(self._ctx, self._id(h), out.ctypes.data_as(C.POINTER(C.c_double)), n))
         return out
+
+    def is_complex(self, h: GpuTensorHandle) -> bool:
+        """`handle_storage(h) == GpuTensorStorage::ComplexInterleaved` (lib.rs:588-594), asked of the library."""
+        res = C.c_int()
+        self._check(self._lib.rmhip_storage(self._ctx, self._id(h), C.byref(res)))
+        return bool(res.value)
 
     def download_matrix(self, h: GpuTensorHandle) -> np.ndarray:
         """Convenience: data reshaped (Fortran order) to the handle's shape."""
@@ -1032,6 +1043,37 @@ class HipProvider:
         res = C.c_int()
         self._check(self._lib.rmhip_issymmetric(self._ctx, self._id(matrix), 1 if kind == "skew" else 0, float(tolerance), C.byref(res)))
         return bool(res.value)
+
+    def fft_dim(self, handle, length: Optional[int], dim: int) -> GpuTensorHandle:
+        """lib.rs:2622-2630: the transform along zero-based `dim`, padded / truncated to `length` (None: the extent) -> complex tensor."""
+        return self._fft(handle, length, dim, 0)
+
+    def ifft_dim(self, handle, length: Optional[int], dim: int) -> GpuTensorHandle:
+        """lib.rs:2631-2638: the inverse transform (scaled by 1 / length)."""
+        return self._fft(handle, length, dim, 1)
+
+    def _fft(self, handle, length, dim, inverse):
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_fft_dim(self._ctx, self._id(handle), -1 if length is None else int(length), int(dim), inverse, C.byref(out)))
+        return self._handle(out.value)
+
+    def fft_extract_real(self, handle) -> GpuTensorHandle:
+        """lib.rs:2639-2644: the real parts of a complex tensor as a real tensor."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_complex_real(self._ctx, self._id(handle), C.byref(out)))
+        return self._handle(out.value)
+
+    def complex_from_real(self, real) -> GpuTensorHandle:
+        """lib.rs:1940-1947: complex-interleaved storage with a zero imaginary lane."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_complex(self._ctx, self._id(real), 0, C.byref(out)))
+        return self._handle(out.value)
+
+    def complex_from_real_imag(self, real, imag) -> GpuTensorHandle:
+        """lib.rs:1949-1959: `complex(real, imag)`, a one-element operand expands."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_complex(self._ctx, self._id(real), self._id(imag), C.byref(out)))
+        return self._handle(out.value)
 
     def ishermitian(self, matrix, kind: str = "hermitian", tolerance: float = 0.0) -> bool:
         """lib.rs:3126-3138 (`ProviderHermitianKind::{Hermitian, Skew}`), real data: issymmetric's test plus "a NaN diagonal fails"."""

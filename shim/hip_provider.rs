@@ -14,7 +14,7 @@
 
 use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
-    AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle,
+    AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle, GpuTensorStorage,
     HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, KernelAttrTelemetry, KernelLaunchTelemetry, MatmulEpilogue,
     PowerStepEpilogue, ProviderBandwidth, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderNanMode, ProviderNdgridRequest, ProviderNormOrder, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
@@ -88,6 +88,23 @@ impl HipProvider {
         check(unsafe { rmhip_shape(self.ctx, id, &mut rank, shape.as_mut_ptr()) })?;
         Ok(GpuTensorHandle { shape: shape[..rank].to_vec(), device_id: self.device_id, buffer_id: id })
     }
+    fn complex_handle(&self, id: u64) -> Result<GpuTensorHandle> {
+        let h = self.handle(id)?;
+        runmat_accelerate_api::set_handle_storage(&h, GpuTensorStorage::ComplexInterleaved);
+        Ok(h)
+    }
+    fn transform(&self, handle: &GpuTensorHandle, len: Option<usize>, dim: usize, inverse: c_int) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        let len = len.map(|l| l as i64).unwrap_or(-1);
+        check(unsafe { rmhip_fft_dim(self.ctx, self.own(handle)?, len, dim as c_int, inverse, &mut out) })?;
+        self.complex_handle(out)
+    }
+    fn complex(&self, real: &GpuTensorHandle, imag: Option<&GpuTensorHandle>) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        let im = match imag { Some(h) => self.own(h)?, None => 0 };
+        check(unsafe { rmhip_complex(self.ctx, self.own(real)?, im, &mut out) })?;
+        self.complex_handle(out)
+    }
     fn own(&self, h: &GpuTensorHandle) -> Result<u64> {
         if h.device_id != self.device_id {
             return Err(anyhow!("handle belongs to device {}", h.device_id)); // io.rs:269-275
@@ -156,10 +173,13 @@ impl AccelProvider for HipProvider {
     }
     fn download<'a>(&'a self, h: &'a GpuTensorHandle) -> AccelProviderFuture<'a, HostTensorOwned> {
         Box::pin(async move {
-            let n: usize = h.shape.iter().product();
+            let mut cplx: c_int = 0;
+            check(unsafe { rmhip_storage(self.ctx, self.own(h)?, &mut cplx) })?;
+            let storage = if cplx != 0 { GpuTensorStorage::ComplexInterleaved } else { GpuTensorStorage::Real };
+            let n: usize = h.shape.iter().product::<usize>() * if cplx != 0 { 2 } else { 1 };
             let mut data = vec![0.0f64; n];
             check(unsafe { rmhip_download(self.ctx, self.own(h)?, data.as_mut_ptr(), n) })?;
-            Ok(HostTensorOwned { data, shape: h.shape.clone() })
+            Ok(HostTensorOwned { data, shape: h.shape.clone(), storage })
         })
     }
     fn free(&self, h: &GpuTensorHandle) -> Result<()> {
@@ -653,6 +673,26 @@ impl AccelProvider for HipProvider {
         let skew = matches!(kind, ProviderSymmetryKind::Skew) as c_int;
         check(unsafe { rmhip_issymmetric(self.ctx, self.own(matrix)?, skew, tolerance, &mut res) })?;
         Ok(res != 0)
+    }
+    // transforms -> complex-interleaved tensors; the storage kind is recorded for the callers that ask `handle_storage` (lib.rs:582-594)
+    fn fft_dim<'a>(&'a self, handle: &'a GpuTensorHandle, len: Option<usize>, dim: usize) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move { self.transform(handle, len, dim, 0) })
+    }
+    fn ifft_dim<'a>(&'a self, handle: &'a GpuTensorHandle, len: Option<usize>, dim: usize) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move { self.transform(handle, len, dim, 1) })
+    }
+    fn fft_extract_real<'a>(&'a self, handle: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_complex_real(self.ctx, self.own(handle)?, &mut out) })?;
+            self.handle(out)
+        })
+    }
+    fn complex_from_real<'a>(&'a self, real: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move { self.complex(real, None) })
+    }
+    fn complex_from_real_imag<'a>(&'a self, real: &'a GpuTensorHandle, imag: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move { self.complex(real, Some(imag)) })
     }
     fn ishermitian<'a>(&'a self, matrix: &'a GpuTensorHandle, kind: ProviderHermitianKind, tolerance: f64) -> AccelProviderFuture<'a, bool> {
         Box::pin(async move {
