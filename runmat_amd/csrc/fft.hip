@@ -20,6 +20,10 @@
 
 #include "common.h"
 
+// parity here is by tolerance against the exact transform (the reference's rustfft has its own operation order): fused
+// multiply-adds are allowed in this file - fewer instructions and one rounding less per complex product
+#pragma clang fp contract(fast)
+
 using namespace rmhip;
 
 #define CTX_OR_FAIL(ctx)                                            \
@@ -33,13 +37,12 @@ namespace rmhip {
 namespace {
 
 typedef unsigned long long u64;
-constexpr int FT = 256;         // threads per workgroup
-constexpr int TILE = 4096;      // complex points per workgroup
+constexpr int FT = 256;         // threads per workgroup of the small elementwise kernels
+constexpr int TILE = 4096;      // complex points per workgroup (512 threads, two workgroups per CU) ...
+constexpr int TILE_BIG = 8192;  // ... or a whole 8192-point line (1024 threads, one workgroup per CU: 132 KiB of LDS)
 constexpr int MAXB = 256;       // lines per workgroup
 constexpr u64 NOLINE = ~0ull;
 constexpr int STEP_LO = 12;     // step twiddle w_n^t = lo[t & 4095] * hi[t >> 12]
-
-__device__ __forceinline__ int padi(int i) { return i + (i >> 5); }
 
 struct Side {  // where point p of line (i, q, o) lives: element offset i*si + q*sq + o*so + p*sp
     u64 si, sq, so, sp;
@@ -57,7 +60,7 @@ struct FftPass {
     const double2* mul_in;    // per-point factor on load, indexed by the point's position p*in_pk + q*in_qk (Bluestein's chirp), or null
     double scale;
     int log2m, log2b;
-    int in_complex, fast_lines_in, fast_lines_out, conj_in, conj_out, round32;
+    int in_complex, mode, step_by_i, conj_in, conj_out, round32;  // mode: see k_fft_tile
     int nrad, rad[5];
 };
 
@@ -111,127 +114,266 @@ __device__ __forceinline__ void dft_small<8>(double (&xr)[8], double (&xi)[8]) {
     }
 }
 
-// one in-place decimation-in-frequency pass of radix R over sub-blocks of length L = 1 << log2l of every line of the tile
+// ---- the tile kernel ---------------------------------------------------------------------------------------------------------------
+// Stockham autosort passes over a tile of B lines x m points, eight points per thread (one radix-8 butterfly, two radix-4 or four
+// radix-2).  Pass s (Ns = product of the radices before it) takes butterfly j's inputs from points j + q m/R - whatever Ns is, so
+// neighbouring threads always read neighbouring points -, multiplies them by w_{Ns R}^(kq), k = j mod Ns, and files result r at point
+// (j - k) R + k + r Ns.  The FIRST pass therefore loads straight from global memory and the LAST one (k = j) stores straight to it,
+// both coalesced; LDS only carries the exchanges in between (read all - barrier - write all - barrier: one copy of the tile).
+// Thread-to-butterfly order and LDS layout follow what is contiguous in memory:
+//   mode 0  points of a line are contiguous (a transform along dimension 0): threads along j, LDS index b m + point;
+//   mode 1  neighbouring lines are contiguous (a trailing dimension, or the strided first step of a long transform): threads along b,
+//           LDS index point B + b;
+//   mode 2  contiguous points in, neighbouring lines out (the second step of a long transform - the transposition of the four-step
+//           algorithm): the tile is first staged through LDS (4 points x 16 lines per wave), then as mode 1.
+// One pad slot per eight keeps the exchange patterns (stride R, stride 8 R, runs of Ns) at two lanes per bank.
+__device__ __forceinline__ int padi(int i) { return i + (i >> 3); }
+
+template <int NT>
+struct TileCtx {
+    double* re;
+    double* im;
+    const u64* ibase;
+    const u64* obase;
+    const unsigned* lpos;
+    const unsigned* lmul;
+    int log2m, log2b, lines_fast;
+    __device__ __forceinline__ int lidx(int b, int pt) const { return padi(lines_fast ? (pt << log2b) + b : (b << log2m) + pt); }
+};
+
 template <int R>
-__device__ __forceinline__ void dif_pass(double* __restrict__ re, double* __restrict__ im, const double2* __restrict__ tw, int tile, int log2m, int log2l) {
-    constexpr int LR = R == 8 ? 3 : (R == 4 ? 2 : 1);
-    const int log2s = log2l - LR;  // butterfly stride L / R
-    const int nb = tile >> LR;
-    for (int id = threadIdx.x; id < nb; id += FT) {
-        const int j = id & ((1 << log2s) - 1);
-        const int base = ((id >> log2s) << log2l) + j;  // (line, block) are the high bits of id: lines are m long, m a multiple of L
-        double xr[R], xi[R];
+struct RadixLog {
+    static constexpr int v = R == 8 ? 3 : (R == 4 ? 2 : 1);
+};
+
+// one pass: K = 8 / R butterflies per thread.  FIRST: inputs come from global memory (unless STAGED: from LDS, like a later pass);
+// LAST: results go to global memory.
+template <int NT, int R, bool first_from_global, bool last>
+__device__ __forceinline__ void stockham_pass(const FftPass& P, const TileCtx<NT>& T, int log2ns) {
+    constexpr int LR = RadixLog<R>::v, K = 8 / R;
+    const int log2m = T.log2m, log2b = T.log2b;
+    const int nb = 1 << (log2m + log2b - LR);  // butterflies in the tile
+    const int log2s = log2m - LR;              // input stride m / R
+    double xr[K][R], xi[K][R];
+    int bb[K], jj[K];
+    bool live[K];
 #pragma unroll
-        for (int q = 0; q < R; ++q) {
-            const int a = padi(base + (q << log2s));
-            xr[q] = re[a], xi[q] = im[a];
-        }
-        dft_small<R>(xr, xi);
-        if (log2s > 0) {  // w_L^{j r} = w_m^{j r m / L}
-            const int sh = log2m - log2l;
+    for (int kk = 0; kk < K; ++kk) {
+        const int id = threadIdx.x + NT * kk;
+        live[kk] = id < nb;
+        if (T.lines_fast) bb[kk] = id & ((1 << log2b) - 1), jj[kk] = id >> log2b;
+        else jj[kk] = id & ((1 << log2s) - 1), bb[kk] = id >> log2s;
+    }
+    if (first_from_global) {
 #pragma unroll
-            for (int r = 1; r < R; ++r) {
-                const double2 w = tw[(j * r) << sh];
-                cmul(xr[r], xi[r], w.x, w.y);
+        for (int kk = 0; kk < K; ++kk) {
+            const u64 base = live[kk] ? T.ibase[bb[kk]] : NOLINE;
+            const u64 lp = live[kk] ? (u64)T.lpos[bb[kk]] : 0;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int pt = jj[kk] + (q << log2s);
+                const u64 pos = (u64)pt * P.in_pk + lp;
+                double vr = 0.0, vi = 0.0;
+                if (base != NOLINE && pos < P.in_len) {
+                    const u64 off = base + (u64)pt * P.a.sp;
+                    if (P.in_complex) {
+                        const double2 v = reinterpret_cast<const double2*>(P.in)[off];
+                        vr = v.x, vi = v.y;
+                    } else {
+                        vr = P.in[off];
+                    }
+                    if (P.conj_in) vi = -vi;
+                    if (P.mul_in) {
+                        const double2 f = P.mul_in[pos];
+                        cmul(vr, vi, f.x, f.y);
+                    }
+                }
+                xr[kk][q] = vr, xi[kk][q] = vi;
             }
         }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk)
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int a = T.lidx(bb[kk], jj[kk] + (q << log2s));
+                xr[kk][q] = live[kk] ? T.re[a] : 0.0, xi[kk][q] = live[kk] ? T.im[a] : 0.0;
+            }
+    }
+    if (!first_from_global && log2ns > 0) {  // (the first pass has Ns = 1: no twiddles)
+        const int sh = log2m - log2ns - LR;
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+            const int k = jj[kk] & ((1 << log2ns) - 1);
+            if (R == 8) {
+                // w, w^2, w^4 from the table; w^3 = w w^2, w^5 = w w^4, w^6 = w^2 w^4, w^7 = w^3 w^4 (at most two roundings more than a
+                // table entry; seven loads per butterfly were as much L1 traffic as the tile's LDS exchange)
+                const double2 w1 = P.tw[k << sh], w2 = P.tw[(2 * k) << sh], w4 = P.tw[(4 * k) << sh];
+                double w3r = w1.x, w3i = w1.y, w5r = w1.x, w5i = w1.y, w6r = w2.x, w6i = w2.y;
+                cmul(w3r, w3i, w2.x, w2.y);
+                cmul(w5r, w5i, w4.x, w4.y);
+                cmul(w6r, w6i, w4.x, w4.y);
+                double w7r = w3r, w7i = w3i;
+                cmul(w7r, w7i, w4.x, w4.y);
+                cmul(xr[kk][1], xi[kk][1], w1.x, w1.y);
+                cmul(xr[kk][2], xi[kk][2], w2.x, w2.y);
+                cmul(xr[kk][3], xi[kk][3], w3r, w3i);
+                cmul(xr[kk][4], xi[kk][4], w4.x, w4.y);
+                cmul(xr[kk][5], xi[kk][5], w5r, w5i);
+                cmul(xr[kk][6], xi[kk][6], w6r, w6i);
+                cmul(xr[kk][7], xi[kk][7], w7r, w7i);
+            } else {
+#pragma unroll
+                for (int q = 1; q < R; ++q) {
+                    const double2 w = P.tw[(k * q) << sh];
+                    cmul(xr[kk][q], xi[kk][q], w.x, w.y);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) dft_small<R>(xr[kk], xi[kk]);
+    if (!last) {
+        __syncthreads();  // every thread has read its inputs: the tile may be overwritten
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) {
+            if (!live[kk]) continue;
+            const int k = jj[kk] & ((1 << log2ns) - 1);
+            const int o0 = ((jj[kk] - k) << LR) + k;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int a = T.lidx(bb[kk], o0 + (r << log2ns));
+                T.re[a] = xr[kk][r], T.im[a] = xi[kk][r];
+            }
+        }
+        __syncthreads();
+        return;
+    }
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) {
+        if (!live[kk]) continue;
+        const u64 base = T.obase[bb[kk]];
+        if (base == NOLINE) continue;
+        const unsigned lm = T.lmul[bb[kk]];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int a = padi(base + (r << log2s));
-            re[a] = xr[r], im[a] = xi[r];
+            const int pt = jj[kk] + (r << log2ns);  // (in the last pass k = j and Ns = m / R)
+            double vr = xr[kk][r], vi = xi[kk][r];
+            if (P.step_lo) {
+                const u64 tt = (u64)pt * lm;
+                const double2 wl = P.step_lo[tt & ((1u << STEP_LO) - 1)], wh = P.step_hi[tt >> STEP_LO];
+                double wr = wl.x, wi = wl.y;
+                cmul(wr, wi, wh.x, wh.y);
+                cmul(vr, vi, wr, wi);
+            }
+            if (P.conj_out) vi = -vi;
+            vr *= P.scale, vi *= P.scale;
+            if (P.round32) vr = (double)(float)vr, vi = (double)(float)vi;
+            double2 v;
+            v.x = vr, v.y = vi;
+            reinterpret_cast<double2*>(P.out)[base + (u64)pt * P.b.sp] = v;
         }
     }
 }
 
-__global__ void __launch_bounds__(FT) k_fft_tile(const FftPass P) {
+template <int NT, int R>
+__device__ __forceinline__ void run_pass(int variant, const FftPass& P, const TileCtx<NT>& T, int log2ns) {
+    switch (variant) {
+        case 0: stockham_pass<NT, R, false, false>(P, T, log2ns); break;
+        case 1: stockham_pass<NT, R, false, true>(P, T, log2ns); break;
+        case 2: stockham_pass<NT, R, true, false>(P, T, log2ns); break;
+        default: stockham_pass<NT, R, true, true>(P, T, log2ns); break;
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT, 4) k_fft_tile(const FftPass P) {
     extern __shared__ __attribute__((aligned(16))) double fft_lds[];
     const int t = threadIdx.x;
-    const int log2m = P.log2m, log2b = P.log2b, m = 1 << log2m, B = 1 << log2b, tile = 1 << (log2m + log2b);
-    const int plane = tile + (tile >> 5) + 1;
-    double* const re = fft_lds;
-    double* const im = re + plane;
-    u64* const ibase = reinterpret_cast<u64*>(im + plane);
+    const int log2m = P.log2m, log2b = P.log2b, B = 1 << log2b, tile = 1 << (log2m + log2b);
+    const int plane = tile + (tile >> 3) + 1;
+    TileCtx<NT> T;
+    T.re = fft_lds;
+    T.im = T.re + plane;
+    u64* const ibase = reinterpret_cast<u64*>(T.im + plane);
     u64* const obase = ibase + B;
-    unsigned* const lq = reinterpret_cast<unsigned*>(obase + B);
-    if (t < B) {
-        const u64 l = (u64)blockIdx.x * B + t;
+    unsigned* const lpos = reinterpret_cast<unsigned*>(obase + B);
+    unsigned* const lmul = lpos + B;
+    T.ibase = ibase, T.obase = obase, T.lpos = lpos, T.lmul = lmul;
+    T.log2m = log2m, T.log2b = log2b, T.lines_fast = P.mode != 0;
+    for (int b = t; b < B; b += NT) {
+        const u64 l = (u64)blockIdx.x * B + b;
         if (l < P.nlines) {
             const u64 i = l % P.inner, r = l / P.inner, q = r % P.qcnt, o = r / P.qcnt;
-            ibase[t] = i * P.a.si + q * P.a.sq + o * P.a.so;
-            obase[t] = i * P.b.si + q * P.b.sq + o * P.b.so;
-            lq[t] = (unsigned)q;
+            ibase[b] = i * P.a.si + q * P.a.sq + o * P.a.so;
+            obase[b] = i * P.b.si + q * P.b.sq + o * P.b.so;
+            lpos[b] = (unsigned)(q * P.in_qk);
+            lmul[b] = (unsigned)(P.step_by_i ? i : q);
         } else {
-            ibase[t] = NOLINE;
-            obase[t] = NOLINE;
-            lq[t] = 0;
+            ibase[b] = NOLINE, obase[b] = NOLINE, lpos[b] = 0, lmul[b] = 0;
         }
     }
     __syncthreads();
-#pragma unroll 4
-    for (int e = t; e < tile; e += FT) {
-        int b, p;
-        if (P.fast_lines_in) b = e & (B - 1), p = e >> log2b;
-        else p = e & (m - 1), b = e >> log2m;
-        double xr = 0.0, xi = 0.0;
-        const u64 base = ibase[b];
-        const u64 pos = (u64)p * P.in_pk + (u64)lq[b] * P.in_qk;
-        if (base != NOLINE && pos < P.in_len) {
-            const u64 off = base + (u64)p * P.a.sp;
-            if (P.in_complex) {
-                const double2 v = reinterpret_cast<const double2*>(P.in)[off];
-                xr = v.x, xi = v.y;
-            } else {
-                xr = P.in[off];
+    bool from_global = true;
+    if (P.mode == 2 || P.nrad == 0) {
+        // staged load: a wave takes PW points x LW lines, so that a line's PW points are one contiguous piece of memory and the LW
+        // lines are neighbours in the LDS layout (point B + b)
+        int lpw = log2m < 2 ? log2m : 2;                       // up to four points of a line ...
+        const int llw = log2b < 6 - lpw ? log2b : 6 - lpw;     // ... across up to sixteen lines (more when the lines are shorter)
+        if (llw + lpw < 6) lpw = log2m < 6 - llw ? log2m : 6 - llw;
+        const int cl = llw + lpw, nbb = B >> llw;              // chunk of 2^cl elements; chunks across the lines
+        for (int e = t; e < tile; e += NT) {
+            const int chunk = e >> cl, lane = e & ((1 << cl) - 1);
+            const int b = ((chunk % nbb) << llw) + (lane >> lpw), pt = ((chunk / nbb) << lpw) + (lane & ((1 << lpw) - 1));
+            double vr = 0.0, vi = 0.0;
+            const u64 base = ibase[b];
+            const u64 pos = (u64)pt * P.in_pk + lpos[b];
+            if (base != NOLINE && pos < P.in_len) {
+                const u64 off = base + (u64)pt * P.a.sp;
+                if (P.in_complex) {
+                    const double2 v = reinterpret_cast<const double2*>(P.in)[off];
+                    vr = v.x, vi = v.y;
+                } else {
+                    vr = P.in[off];
+                }
+                if (P.conj_in) vi = -vi;
+                if (P.mul_in) {
+                    const double2 f = P.mul_in[pos];
+                    cmul(vr, vi, f.x, f.y);
+                }
             }
-            if (P.conj_in) xi = -xi;
-            if (P.mul_in) {
-                const double2 w = P.mul_in[pos];
-                cmul(xr, xi, w.x, w.y);
-            }
+            const int a = T.lidx(b, pt);
+            T.re[a] = vr, T.im[a] = vi;
         }
-        const int a = padi((b << log2m) + p);
-        re[a] = xr, im[a] = xi;
-    }
-    __syncthreads();
-    int log2l = log2m;
-    for (int s = 0; s < P.nrad; ++s) {
-        const int R = P.rad[s];
-        if (R == 8) dif_pass<8>(re, im, P.tw, tile, log2m, log2l), log2l -= 3;
-        else if (R == 4) dif_pass<4>(re, im, P.tw, tile, log2m, log2l), log2l -= 2;
-        else dif_pass<2>(re, im, P.tw, tile, log2m, log2l), log2l -= 1;
         __syncthreads();
+        from_global = false;
     }
-#pragma unroll 4
-    for (int e = t; e < tile; e += FT) {
-        int b, p;
-        if (P.fast_lines_out) b = e & (B - 1), p = e >> log2b;
-        else p = e & (m - 1), b = e >> log2m;
-        const u64 base = obase[b];
-        if (base == NOLINE) continue;
-        // X[k] of a line sits at the digit-reversed position: the first pass files k mod R1 as the coarsest digit, and so on
-        int k = p, pos = 0, lg = log2m;
-        for (int s = 0; s < P.nrad; ++s) {
-            const int lr = P.rad[s] == 8 ? 3 : (P.rad[s] == 4 ? 2 : 1);
-            lg -= lr;
-            pos += (k & (P.rad[s] - 1)) << lg;
-            k >>= lr;
+    if (P.nrad == 0) {  // one-point lines: the point itself
+        for (int e = t; e < tile; e += NT) {
+            const int b = e;
+            if (obase[b] == NOLINE) continue;
+            const int a = T.lidx(b, 0);
+            double vr = T.re[a], vi = T.im[a];
+            if (P.conj_out) vi = -vi;
+            vr *= P.scale, vi *= P.scale;
+            if (P.round32) vr = (double)(float)vr, vi = (double)(float)vi;
+            double2 v;
+            v.x = vr, v.y = vi;
+            reinterpret_cast<double2*>(P.out)[obase[b]] = v;
         }
-        const int a = padi((b << log2m) + pos);
-        double xr = re[a], xi = im[a];
-        if (P.step_lo) {
-            const u64 tt = (u64)p * lq[b];
-            const double2 wl = P.step_lo[tt & ((1u << STEP_LO) - 1)], wh = P.step_hi[tt >> STEP_LO];
-            double wr = wl.x, wi = wl.y;
-            cmul(wr, wi, wh.x, wh.y);
-            cmul(xr, xi, wr, wi);
-        }
-        if (P.conj_out) xi = -xi;
-        xr *= P.scale, xi *= P.scale;
-        if (P.round32) xr = (double)(float)xr, xi = (double)(float)xi;
-        double2 v;
-        v.x = xr, v.y = xi;
-        reinterpret_cast<double2*>(P.out)[base + (u64)p * P.b.sp] = v;
+        return;
     }
+    // the radices are (4 or 2,) 8, 8, ...: the first pass is dispatched on its radix, every later one is a radix-8 pass - the middle
+    // ones in a loop of their own (one variant inside the loop: what the compiler hoists out of it stays small)
+    const bool only = P.nrad == 1;
+    const int variant = (from_global ? 2 : 0) | (only ? 1 : 0);
+    int log2ns;
+    if (P.rad[0] == 8) run_pass<NT, 8>(variant, P, T, 0), log2ns = 3;
+    else if (P.rad[0] == 4) run_pass<NT, 4>(variant, P, T, 0), log2ns = 2;
+    else run_pass<NT, 2>(variant, P, T, 0), log2ns = 1;
+    if (only) return;
+    for (int s = 1; s + 1 < P.nrad; ++s, log2ns += 3) stockham_pass<NT, 8, false, false>(P, T, log2ns);
+    stockham_pass<NT, 8, false, true>(P, T, log2ns);
 }
 
 // tables ---------------------------------------------------------------------------------------------------------------------------------
@@ -283,24 +425,25 @@ inline bool is_pow2(u64 v) { return v && !(v & (v - 1)); }
 void set_radices(FftPass& P) {
     int rem = P.log2m;
     P.nrad = 0;
+    if (rem % 3 == 2) P.rad[P.nrad++] = 4, rem -= 2;  // the odd radix first: that pass has no twiddles
+    if (rem % 3 == 1) P.rad[P.nrad++] = 2, rem -= 1;
     while (rem >= 3) P.rad[P.nrad++] = 8, rem -= 3;
-    if (rem == 2) P.rad[P.nrad++] = 4;
-    if (rem == 1) P.rad[P.nrad++] = 2;
 }
 
 int launch_pass(Context* c, FftPass& P) {
     set_radices(P);
     const int m = 1 << P.log2m;
     int lb = 0;
-    while ((m << (lb + 1)) <= TILE && (1 << (lb + 1)) <= MAXB && (1ull << lb) < P.nlines) ++lb;
+    while (((size_t)m << (lb + 1)) <= (size_t)TILE && (1 << (lb + 1)) <= MAXB && (1ull << lb) < P.nlines) ++lb;
     P.log2b = lb;
     Table tw;
     RMHIP_TRY(fft_table(c, 0, (u64)m, (u64)m, &tw));
     P.tw = tptr(tw);
     const u64 blocks = (P.nlines + (1ull << lb) - 1) >> lb;
     if (blocks > 0x7fffffffull) return fail(RMHIP_ERR_UNSUPPORTED, "fft: %llu lines", P.nlines);
-    const size_t tile = (size_t)m << lb, lds = (2 * (tile + (tile >> 5) + 1) + 2 * ((size_t)1 << lb)) * sizeof(double) + ((size_t)1 << lb) * sizeof(unsigned);
-    hipLaunchKernelGGL(k_fft_tile, dim3((unsigned)blocks), dim3(FT), lds, c->stream, P);
+    const size_t tile = (size_t)m << lb, lds = (2 * (tile + (tile >> 3) + 1) + 2 * ((size_t)1 << lb)) * sizeof(double) + 2 * ((size_t)1 << lb) * sizeof(unsigned);
+    if (tile > (size_t)TILE) hipLaunchKernelGGL(k_fft_tile<1024>, dim3((unsigned)blocks), dim3(1024), lds, c->stream, P);
+    else hipLaunchKernelGGL(k_fft_tile<512>, dim3((unsigned)blocks), dim3(512), lds, c->stream, P);
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
@@ -321,7 +464,7 @@ int fft_pow2(Context* c, const Lines& L, u64 n, bool conj_in, bool conj_out, dou
     const u64 in_len = std::min<u64>(std::min<u64>(L.len_in, n), valid);
     const u64 lines = L.inner * L.outer;
     // a line along a trailing dimension is read across neighbouring lines: short transforms, many lines per tile
-    const bool single = L.inner == 1 ? lg <= 12 : lg <= 8;
+    const bool single = L.inner == 1 ? n <= (u64)TILE_BIG : lg <= 8;
     if (single) {
         FftPass P{};
         P.nlines = lines, P.inner = L.inner, P.qcnt = 1;
@@ -331,7 +474,7 @@ int fft_pow2(Context* c, const Lines& L, u64 n, bool conj_in, bool conj_out, dou
         P.in_pk = 1, P.in_qk = 0, P.in_len = in_len;
         P.mul_in = mul_in;
         P.scale = scale, P.log2m = lg;
-        P.fast_lines_in = P.fast_lines_out = L.inner > 1;
+        P.mode = L.inner > 1 ? 1 : 0;
         P.conj_in = conj_in, P.conj_out = conj_out;
         P.round32 = round32;
         return launch_pass(c, P);
@@ -356,7 +499,7 @@ int fft_pow2(Context* c, const Lines& L, u64 n, bool conj_in, bool conj_out, dou
         P.mul_in = mul_in;
         P.step_lo = tptr(slo), P.step_hi = tptr(shi);
         P.scale = 1.0, P.log2m = l1;
-        P.fast_lines_in = P.fast_lines_out = 1;  // neighbouring lines (i, then k2) are neighbours in memory
+        P.mode = 1;  // neighbouring lines (i, then k2) are neighbours in memory
         P.conj_in = conj_in;
         RMHIP_TRY(launch_pass(c, P));
     }
@@ -368,8 +511,7 @@ int fft_pow2(Context* c, const Lines& L, u64 n, bool conj_in, bool conj_out, dou
         P.b = Side{1, L.inner, n * L.inner, m1 * L.inner};
         P.in_pk = 1, P.in_qk = 0, P.in_len = m2;
         P.scale = scale, P.log2m = l2;
-        P.fast_lines_in = L.inner > 1;
-        P.fast_lines_out = 1;
+        P.mode = L.inner > 1 ? 1 : 2;
         P.conj_out = conj_out;
         P.round32 = round32;
         RMHIP_TRY(launch_pass(c, P));
@@ -499,7 +641,7 @@ int fft_entry(Context* c, rmhip_buf a, long long len_or_neg, int dim, bool inver
         P.b = Side{1, 0, n * inner, inner};
         P.in_pk = 1, P.in_qk = 0, P.in_len = std::min<u64>(cur, n);
         P.scale = scale, P.log2m = 0, P.round32 = r32;
-        P.fast_lines_in = P.fast_lines_out = 1;
+        P.mode = 1;
         if (n == 1) rc = launch_pass(c, P);
         else {
             RMHIP_HIP_CHECK(hipMemsetAsync(ob.data(), 0, 2 * ob.numel * sizeof(double), c->stream));
