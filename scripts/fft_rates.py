@@ -2,7 +2,9 @@
 queued; a read_scalar-free sync is the download of one small tensor) - and print the algorithmic HBM rate: bytes of the input read
 once + the complex result written once."""
 import sys, time
+from pathlib import Path
 import numpy as np
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from runmat_amd.provider import HipProvider
 
 p = HipProvider()

@@ -75,3 +75,25 @@ def test_order_and_index_hooks_round_once(prov, prov32):
     prov.set_rng_state(12345)
     assert same(prov32.download(prov32.random_unifrnd(2.0, 5.0, (1001, 1))), f32r(prov.download(prov.random_unifrnd(2.0, 5.0, (1001, 1)))))
     assert same(prov32.download(prov32.random_integer_range(-9, 9, (1001, 1))), prov.download(prov.random_integer_range(-9, 9, (1001, 1))))
+
+
+def test_transforms_round_once(prov, prov32):
+    """fft_dim / ifft_dim / complex constructors on a precision-32 provider: f32 operands widened, the f64 transform, every real and
+    imaginary part rounded to f32 once (complex storage itself stays 2 x f64)."""
+    rng = np.random.default_rng(21)
+    for shape, dim, length in (((64, 5), 0, None), ((6, 100), 1, None), ((1000,), 0, 1024), ((9, 8192), 1, None)):
+        x = f32r(rng.standard_normal(shape))
+        up = lambda p: p.upload(x.ravel(order="F"), shape)
+        f64, f32 = prov.fft_dim(up(prov), length, dim), prov32.fft_dim(up(prov32), length, dim)
+        assert prov32.is_complex(f32) and list(f32.shape) == list(f64.shape)
+        want = prov.download(f64)
+        got = prov32.download(f32)
+        assert np.array_equal(got.real, f32r(want.real)) and np.array_equal(got.imag, f32r(want.imag))
+        back = prov32.ifft_dim(f32, None, dim)
+        b = prov32.download(back)
+        assert np.array_equal(b.real, f32r(b.real)) and np.array_equal(b.imag, f32r(b.imag))
+        re = prov32.fft_extract_real(back)
+        assert prov32.is_complex(re) is False and np.array_equal(prov32.download(re), b.real)
+    a = rng.standard_normal((4, 3))
+    z = prov32.complex_from_real_imag(prov32.upload(a), prov32.upload(2 * a))
+    assert np.array_equal(prov32.download(z), f32r(a).ravel(order="F") + 2j * f32r(a).ravel(order="F"))
