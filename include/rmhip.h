@@ -422,6 +422,22 @@ RMHIP_API int rmhip_norm(rmhip_ctx* ctx, rmhip_buf a, int order, double p, rmhip
  * operand with trailing extents > 1 RMHIP_ERR_INVALID.  Synchronises the stream (a host bool comes back). */
 /* @serves issymmetric */
 RMHIP_API int rmhip_issymmetric(rmhip_ctx* ctx, rmhip_buf a, int skew, double tolerance, int* result);
+/* ---- convolutions and windows (signal_ops.hip) ---------------------------------------------------------------------------------------
+ * `conv1d(signal, kernel, options)` (lib.rs:2535-2542; conv.rs:481-517): the 1-D convolution of the two tensors' elements (any shapes,
+ * taken in storage order), direct sums in the CPU's order - bit-exact.  mode: 0 full, 1 same, 2 valid (`ProviderConvMode`, lib.rs:1277-1281);
+ * column != 0: the result is [len, 1], otherwise [1, len] (`ProviderConvOrientation`); an empty operand or a valid-mode kernel longer than
+ * the signal gives the empty result of that orientation (simple_provider.rs:1780-1787). */
+/* @serves conv1d */
+RMHIP_API int rmhip_conv1d(rmhip_ctx* ctx, rmhip_buf signal, rmhip_buf kernel, int mode, int column, rmhip_buf* out);
+/* `conv2d(signal, kernel, mode)` (lib.rs:2543-2550; conv2.rs:595-640, the reference's kernel indexing included): 2-D operands (trailing
+ * singleton dimensions allowed, else RMHIP_ERR_INVALID "input must be 2-D"); bit-exact; empty operands give [0, 0] (same: the signal's shape). */
+/* @serves conv2d */
+RMHIP_API int rmhip_conv2d(rmhip_ctx* ctx, rmhip_buf signal, rmhip_buf kernel, int mode, rmhip_buf* out);
+/* `hann_window / hamming_window / blackman_window(len, periodic)` (lib.rs:1797-1807; simple_provider.rs:95-120) -> [len, 1]; kind 0 / 1 / 2.
+ * One cosine (two for Blackman) per point: within 2 ulp of the cosine of the CPU's libm (tests state the bound). */
+/* @serves hann_window hamming_window blackman_window */
+RMHIP_API int rmhip_window(rmhip_ctx* ctx, int kind, size_t len, int periodic, rmhip_buf* out);
+
 /* ---- discrete Fourier transforms and complex-interleaved storage (fft.hip) --------------------------------------------------------
  * A transform's result is a COMPLEX-INTERLEAVED tensor (`GpuTensorStorage::ComplexInterleaved`, lib.rs:247-251): its shape is the
  * logical one, its storage 2 * numel doubles (re, im, re, im, ...).  `rmhip_download` hands such a tensor back as 2 * numel doubles

@@ -640,6 +640,26 @@ public:
         check(rmhip_issymmetric(ctx_, own(m), skew ? 1 : 0, tolerance, &r));
         return r != 0;
     }
+    // lib.rs:2535-2550; mode: 0 full, 1 same, 2 valid (`ProviderConvMode`); column: `ProviderConvOrientation::Column`
+    GpuTensorHandle conv1d(const GpuTensorHandle& signal, const GpuTensorHandle& kernel, int mode, bool column) const {
+        uint64_t out = 0;
+        check(rmhip_conv1d(ctx_, own(signal), own(kernel), mode, column ? 1 : 0, &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle conv2d(const GpuTensorHandle& signal, const GpuTensorHandle& kernel, int mode) const {
+        uint64_t out = 0;
+        check(rmhip_conv2d(ctx_, own(signal), own(kernel), mode, &out));
+        return with_shape(out);
+    }
+    // lib.rs:1797-1807
+    GpuTensorHandle hann_window(size_t len, bool periodic) const { return window(0, len, periodic); }
+    GpuTensorHandle hamming_window(size_t len, bool periodic) const { return window(1, len, periodic); }
+    GpuTensorHandle blackman_window(size_t len, bool periodic) const { return window(2, len, periodic); }
+    GpuTensorHandle window(int kind, size_t len, bool periodic) const {
+        uint64_t out = 0;
+        check(rmhip_window(ctx_, kind, len, periodic ? 1 : 0, &out));
+        return with_shape(out);
+    }
     // lib.rs:2622-2644: transforms along zero-based `dim`, padded / truncated to `len` (-1: the extent) -> complex-interleaved tensors
     GpuTensorHandle fft_dim(const GpuTensorHandle& a, long long len, size_t dim) const {
         uint64_t out = 0;

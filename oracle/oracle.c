@@ -1531,6 +1531,89 @@ ORC_API int orc_issymmetric(const double* data, size_t rows, size_t cols, int sk
     return 1;
 }
 
+/* conv (1-D): `convolve` + `apply_mode`, builtins/math/signal/conv.rs:481-517 (the same loops on real data in the in-process provider,
+ * simple_provider.rs:1789-1842): out[i + j] += a[i] * b[j] over i ascending then j ascending, from zeros - so output n receives its terms in
+ * order of increasing i, each product rounded before it is added.  mode 0 full, 1 same (start (len_b - 1) / 2, len_a points), 2 valid
+ * (start len_b - 1, len_a - len_b + 1 points; none when len_a < len_b).  Returns the number of points written to `out`. */
+ORC_API size_t orc_conv1d(const double* a, size_t la, const double* b, size_t lb, int mode, double* out) {
+    if (la == 0 || lb == 0) return 0;
+    const size_t full = la + lb - 1;
+    double* f = (double*)calloc(full, sizeof(double));
+    for (size_t i = 0; i < la; ++i)
+        for (size_t j = 0; j < lb; ++j) {
+            const double p = a[i] * b[j];
+            f[i + j] = f[i + j] + p;
+        }
+    size_t start = 0, len = full;
+    if (mode == 1) start = (lb - 1) / 2, len = la;
+    if (mode == 2) {
+        if (la < lb) {
+            free(f);
+            return 0;
+        }
+        start = lb - 1, len = la - lb + 1;
+    }
+    if (start + len > full) len = full > start ? full - start : 0;
+    memcpy(out, f + start, len * sizeof(double));
+    free(f);
+    return len;
+}
+
+/* conv2: `conv2_matrices`, builtins/math/signal/conv2.rs:595-640 - full[ar + br, ac + bc] += a[ar, ac] * b[B_r - 1 - br, B_c - 1 - bc] over
+ * ac, ar, bc, br ascending (the reference's loops, kernel indexing included: its `conv2_same_flips_kernel` test pins it), then the 'same'
+ * ((B - 1) / 2 offsets, a's shape) or 'valid' (B - 1 offsets) window.  Column-major; writes out_rows x out_cols, returns their product. */
+ORC_API size_t orc_conv2d(const double* a, size_t ar_n, size_t ac_n, const double* b, size_t br_n, size_t bc_n, int mode, double* out, size_t* out_rows,
+                          size_t* out_cols) {
+    *out_rows = *out_cols = 0;
+    if (ar_n == 0 || ac_n == 0 || br_n == 0 || bc_n == 0) {
+        if (mode == 1) *out_rows = ar_n, *out_cols = ac_n;
+        return 0;
+    }
+    const size_t fr = ar_n + br_n - 1, fc = ac_n + bc_n - 1;
+    double* f = (double*)calloc(fr * fc, sizeof(double));
+    for (size_t ac = 0; ac < ac_n; ++ac)
+        for (size_t ar = 0; ar < ar_n; ++ar) {
+            const double av = a[ac * ar_n + ar];
+            for (size_t bc = 0; bc < bc_n; ++bc)
+                for (size_t br = 0; br < br_n; ++br) {
+                    const double p = av * b[(bc_n - 1 - bc) * br_n + (br_n - 1 - br)];
+                    double* d = f + (ac + bc) * fr + (ar + br);
+                    *d = *d + p;
+                }
+        }
+    size_t r0 = 0, c0 = 0, rows = fr, cols = fc;
+    if (mode == 1) r0 = (br_n - 1) / 2, c0 = (bc_n - 1) / 2, rows = ar_n, cols = ac_n;
+    if (mode == 2) {
+        if (ar_n < br_n || ac_n < bc_n) {
+            free(f);
+            return 0;
+        }
+        r0 = br_n - 1, c0 = bc_n - 1, rows = ar_n - br_n + 1, cols = ac_n - bc_n + 1;
+    }
+    for (size_t c = 0; c < cols; ++c)
+        for (size_t r = 0; r < rows; ++r) out[c * rows + r] = f[(c0 + c) * fr + (r0 + r)];
+    free(f);
+    *out_rows = rows, *out_cols = cols;
+    return rows * cols;
+}
+
+/* hann / hamming / blackman windows: generate_window_data, runmat-accelerate/src/simple_provider.rs:95-120 (kind 0, 1, 2): len 0 -> empty,
+ * 1 -> [1]; otherwise phase = 2 pi idx / (L - 1) with L = len + 1 when periodic (the extra point is dropped). */
+ORC_API void orc_window(int kind, size_t len, int periodic, double* out) {
+    if (len == 0) return;
+    if (len == 1) {
+        out[0] = 1.0;
+        return;
+    }
+    const double denom = (double)((periodic ? len + 1 : len) - 1);
+    for (size_t i = 0; i < len; ++i) {
+        const double phase = 2.0 * 3.14159265358979323846 * (double)i / denom;
+        if (kind == 0) out[i] = 0.5 - 0.5 * cos(phase);
+        else if (kind == 1) out[i] = 0.54 - 0.46 * cos(phase);
+        else out[i] = 0.42 - 0.5 * cos(phase) + 0.08 * cos(2.0 * phase);
+    }
+}
+
 /* fft_dim / ifft_dim: the reference transforms each line with rustfft 6.4.1 (`FftPlanner::plan_fft_forward/inverse(len).process`,
  * builtins/math/fft/common.rs and the wgpu provider's host form ops/fft/fallback.rs:84-125) - a third-party crate that is not under
  * /root/reference (Cargo.lock:6116-6118).  What it computes is the discrete Fourier transform X[j] = sum_k x[k] exp(-+2 pi i jk / n);

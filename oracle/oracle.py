@@ -763,6 +763,44 @@ def issymmetric(a: np.ndarray, skew: bool = False, tol: float = 0.0) -> bool:
     return bool(l.orc_issymmetric(_p(_f(a)), rows, cols, int(skew), float(tol)))
 
 
+_CONV_MODES = {"full": 0, "same": 1, "valid": 2}
+
+
+def conv1d(a, b, mode: str = "full") -> np.ndarray:
+    """conv.rs:481-517 on the flattened operands -> the 1-D result (the caller's orientation only shapes it)."""
+    a, b = _f(np.asarray(a, dtype=np.float64).ravel(order="F")), _f(np.asarray(b, dtype=np.float64).ravel(order="F"))
+    out = np.zeros(max(1, a.size + b.size))
+    l = lib()
+    l.orc_conv1d.restype = C.c_size_t
+    l.orc_conv1d.argtypes = [_DP, C.c_size_t, _DP, C.c_size_t, C.c_int, _DP]
+    n = l.orc_conv1d(_p(a), a.size, _p(b), b.size, _CONV_MODES[mode], _p(out))
+    return out[:n].copy()
+
+
+def conv2d(a, b, mode: str = "full") -> np.ndarray:
+    """conv2.rs:595-640 on 2-D operands."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    two = lambda x: x.reshape(1, 1) if x.ndim == 0 else x.reshape(x.shape[0], 1) if x.ndim == 1 else x.reshape(x.shape[0], x.shape[1], order="F")
+    a2, b2 = two(a), two(b)
+    out = np.zeros(max(1, (a2.shape[0] + b2.shape[0]) * (a2.shape[1] + b2.shape[1])))
+    rows, cols = C.c_size_t(), C.c_size_t()
+    l = lib()
+    l.orc_conv2d.restype = C.c_size_t
+    l.orc_conv2d.argtypes = [_DP, C.c_size_t, C.c_size_t, _DP, C.c_size_t, C.c_size_t, C.c_int, _DP, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    n = l.orc_conv2d(_p(_f(a2)), a2.shape[0], a2.shape[1], _p(_f(b2)), b2.shape[0], b2.shape[1], _CONV_MODES[mode], _p(out), C.byref(rows), C.byref(cols))
+    return out[:n].reshape((rows.value, cols.value), order="F").copy()
+
+
+def window(kind: str, length: int, periodic: bool = False) -> np.ndarray:
+    """simple_provider.rs:95-120 -> [length, 1]."""
+    out = np.zeros(max(1, length))
+    l = lib()
+    l.orc_window.restype = None
+    l.orc_window.argtypes = [C.c_int, C.c_size_t, C.c_int, _DP]
+    l.orc_window({"hann": 0, "hamming": 1, "blackman": 2}[kind], length, int(periodic), _p(out))
+    return out[:length].reshape(length, 1).copy()
+
+
 def fft_dim(x: np.ndarray, length=None, dim: int = 0, inverse: bool = False) -> np.ndarray:
     """The transform of every line along zero-based `dim`, padded / truncated to `length` points, by direct evaluation of the DFT in
     long double (orc_dft_dim); real or complex input, complex128 output of the reference's shape rule (the shape extended to

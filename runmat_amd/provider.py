@@ -1044,6 +1044,33 @@ class HipProvider:
         self._check(self._lib.rmhip_issymmetric(self._ctx, self._id(matrix), 1 if kind == "skew" else 0, float(tolerance), C.byref(res)))
         return bool(res.value)
 
+    def conv1d(self, signal, kernel, mode: str = "full", orientation: str = "row") -> GpuTensorHandle:
+        """lib.rs:2535-2542 (`ProviderConv1dOptions { mode, orientation }`, :1277-1293)."""
+        modes = {"full": 0, "same": 1, "valid": 2}
+        if mode not in modes or orientation not in ("row", "column"):
+            raise RmhipError(1, f"conv1d: mode {mode!r} / orientation {orientation!r}")
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_conv1d(self._ctx, self._id(signal), self._id(kernel), modes[mode], 1 if orientation == "column" else 0, C.byref(out)))
+        return self._handle(out.value)
+
+    def conv2d(self, signal, kernel, mode: str = "full") -> GpuTensorHandle:
+        """lib.rs:2543-2550."""
+        modes = {"full": 0, "same": 1, "valid": 2}
+        if mode not in modes:
+            raise RmhipError(1, f"conv2d: mode {mode!r}")
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_conv2d(self._ctx, self._id(signal), self._id(kernel), modes[mode], C.byref(out)))
+        return self._handle(out.value)
+
+    def _window(self, kind: int, length: int, periodic: bool) -> GpuTensorHandle:
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_window(self._ctx, kind, int(length), 1 if periodic else 0, C.byref(out)))
+        return self._handle(out.value)
+
+    def hann_window(self, length: int, periodic: bool = False): return self._window(0, length, periodic)      # lib.rs:1797
+    def hamming_window(self, length: int, periodic: bool = False): return self._window(1, length, periodic)   # lib.rs:1801
+    def blackman_window(self, length: int, periodic: bool = False): return self._window(2, length, periodic)  # lib.rs:1805
+
     def fft_dim(self, handle, length: Optional[int], dim: int) -> GpuTensorHandle:
         """lib.rs:2622-2630: the transform along zero-based `dim`, padded / truncated to `length` (None: the extent) -> complex tensor."""
         return self._fft(handle, length, dim, 0)

@@ -16,7 +16,7 @@ use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle, GpuTensorStorage,
     HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, KernelAttrTelemetry, KernelLaunchTelemetry, MatmulEpilogue,
-    PowerStepEpilogue, ProviderBandwidth, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
+    PowerStepEpilogue, ProviderBandwidth, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderNanMode, ProviderNdgridRequest, ProviderNormOrder, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
     ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult,
 };
@@ -88,6 +88,11 @@ impl HipProvider {
         check(unsafe { rmhip_shape(self.ctx, id, &mut rank, shape.as_mut_ptr()) })?;
         Ok(GpuTensorHandle { shape: shape[..rank].to_vec(), device_id: self.device_id, buffer_id: id })
     }
+    fn window(&self, kind: c_int, len: usize, periodic: bool) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_window(self.ctx, kind, len, periodic as c_int, &mut out) })?;
+        self.handle(out)
+    }
     fn complex_handle(&self, id: u64) -> Result<GpuTensorHandle> {
         let h = self.handle(id)?;
         runmat_accelerate_api::set_handle_storage(&h, GpuTensorStorage::ComplexInterleaved);
@@ -130,6 +135,10 @@ impl Drop for HipProvider {
 }
 
 // One trait method per line: the hooks differ only in the op code handed to the library.
+fn conv_mode(mode: ProviderConvMode) -> c_int {
+    match mode { ProviderConvMode::Full => 0, ProviderConvMode::Same => 1, ProviderConvMode::Valid => 2 }
+}
+
 macro_rules! unary_hooks { ($($name:ident => $op:expr),* $(,)?) => { $(
     fn $name<'a>(&'a self, a: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> { Box::pin(async move { self.unary($op, a) }) }
 )* } }
@@ -674,6 +683,20 @@ impl AccelProvider for HipProvider {
         check(unsafe { rmhip_issymmetric(self.ctx, self.own(matrix)?, skew, tolerance, &mut res) })?;
         Ok(res != 0)
     }
+    fn conv1d(&self, signal: &GpuTensorHandle, kernel: &GpuTensorHandle, options: ProviderConv1dOptions) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        let column = matches!(options.orientation, ProviderConvOrientation::Column) as c_int;
+        check(unsafe { rmhip_conv1d(self.ctx, self.own(signal)?, self.own(kernel)?, conv_mode(options.mode), column, &mut out) })?;
+        self.handle(out)
+    }
+    fn conv2d(&self, signal: &GpuTensorHandle, kernel: &GpuTensorHandle, mode: ProviderConvMode) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_conv2d(self.ctx, self.own(signal)?, self.own(kernel)?, conv_mode(mode), &mut out) })?;
+        self.handle(out)
+    }
+    fn hann_window(&self, len: usize, periodic: bool) -> Result<GpuTensorHandle> { self.window(0, len, periodic) }
+    fn hamming_window(&self, len: usize, periodic: bool) -> Result<GpuTensorHandle> { self.window(1, len, periodic) }
+    fn blackman_window(&self, len: usize, periodic: bool) -> Result<GpuTensorHandle> { self.window(2, len, periodic) }
     // transforms -> complex-interleaved tensors; the storage kind is recorded for the callers that ask `handle_storage` (lib.rs:582-594)
     fn fft_dim<'a>(&'a self, handle: &'a GpuTensorHandle, len: Option<usize>, dim: usize) -> AccelProviderFuture<'a, GpuTensorHandle> {
         Box::pin(async move { self.transform(handle, len, dim, 0) })

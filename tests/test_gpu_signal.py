@@ -1,0 +1,99 @@
+"""GPU parity of conv1d / conv2d / hann_window / hamming_window / blackman_window (include/rmhip.h, signal_ops.hip).  The convolutions
+are direct sums in the CPU's order with every product rounded before it is added: bit-exact against the oracle.  The windows take one
+cosine per point (two for Blackman): within 2 ulp of the cosine's magnitude of the oracle's libm value, i.e. 4.5e-16 absolute."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+K = json.loads((Path(__file__).parent / "golden" / "signal_kats.json").read_text())
+
+
+def bits_equal(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    return got.shape == want.shape and np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+def test_reference_kats(prov):
+    for k in K["conv1d"]:
+        h = prov.conv1d(prov.upload(np.array(k["a"], dtype=np.float64).reshape(1, -1)), prov.upload(np.array(k["b"], dtype=np.float64).reshape(1, -1)), k["mode"])
+        assert list(h.shape) == [1, len(k["out"])] and np.array_equal(prov.download(h), np.array(k["out"], dtype=np.float64)), k
+    for k in K["conv2d"]:
+        h = prov.conv2d(prov.upload(np.array(k["a"], dtype=np.float64)), prov.upload(np.array(k["b"], dtype=np.float64)), k["mode"])
+        assert np.array_equal(prov.download_matrix(h), np.array(k["out"], dtype=np.float64)), k
+
+
+@pytest.mark.parametrize("la,lb", [(1, 1), (5, 3), (3, 5), (64, 7), (1000, 100), (100, 1000), (4097, 255), (300, 5000), (70000, 33)], ids=str)
+def test_conv1d(prov, oracle, la, lb):
+    rng = np.random.default_rng(la * 7 + lb)
+    a, b = rng.standard_normal(la), rng.standard_normal(lb)
+    a[rng.integers(0, la)] = 0.0
+    ha, hb = prov.upload(a.reshape(-1, 1)), prov.upload(b.reshape(1, -1))
+    for mode in ("full", "same", "valid"):
+        for orient in ("row", "column"):
+            want = oracle.conv1d(a, b, mode)
+            h = prov.conv1d(ha, hb, mode, orient)
+            assert list(h.shape) == ([1, want.size] if orient == "row" else [want.size, 1])
+            assert bits_equal(prov.download(h), want), (mode, orient)
+    e = prov.conv1d(prov.upload(np.zeros((1, 0))), hb, "full", "column")
+    assert list(e.shape) == [0, 1]
+
+
+@pytest.mark.parametrize("sa,sb", [((1, 1), (1, 1)), ((3, 3), (3, 3)), ((9, 7), (3, 4)), ((3, 4), (9, 7)), ((64, 65), (5, 5)), ((200, 300), (17, 1)), ((200, 300), (1, 17)),
+                                   ((40, 40), (70, 66)), ((5,), (3,))], ids=str)
+def test_conv2d(prov, oracle, sa, sb):
+    rng = np.random.default_rng(sum(sa) * 13 + sum(sb))
+    a, b = rng.standard_normal(sa), rng.standard_normal(sb)
+    up = lambda x: prov.upload(x.ravel(order="F"), x.shape)
+    for mode in ("full", "same", "valid"):
+        want = oracle.conv2d(a, b, mode)
+        h = prov.conv2d(up(a), up(b), mode)
+        assert list(h.shape) == list(want.shape), (mode, h.shape, want.shape)
+        assert bits_equal(prov.download_matrix(h), want), mode
+    with pytest.raises(Exception):
+        prov.conv2d(prov.upload(np.zeros((2, 2, 2))), up(b))
+    z = prov.upload(np.zeros((0, 3)))
+    assert list(prov.conv2d(z, up(b)).shape) == [0, 0] and list(prov.conv2d(z, up(b), "same").shape) == [0, 3]
+
+
+def test_conv2d_infinite_tap_against_a_zero(prov, oracle):
+    """The CPU adds 0 * inf = NaN like any other term (conv2.rs:603-616 has no zero test; the in-process provider's skip of zero signal
+    entries, simple_provider.rs:1860-1862, is not what the oracle restates)."""
+    a = np.array([[0.0, 1.0], [2.0, 3.0]])
+    b = np.array([[np.inf, 1.0], [1.0, 1.0]])
+    want = oracle.conv2d(a, b)
+    got = prov.download_matrix(prov.conv2d(prov.upload(a), prov.upload(b)))
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(want).any()
+
+
+def test_windows(prov, oracle):
+    for n in (0, 1, 2, 5, 64, 255, 4096, 100001):
+        for periodic in (False, True):
+            for kind in ("hann", "hamming", "blackman"):
+                h = getattr(prov, kind + "_window")(n, periodic)
+                want = oracle.window(kind, n, periodic)
+                assert list(h.shape) == [n, 1]
+                if n:
+                    assert np.max(np.abs(prov.download(h) - want.ravel())) <= 4.5e-16, (kind, n, periodic)
+
+
+def test_full_size_image_filter(prov, oracle):
+    """An 8192 x 8192 operand through a 5 x 5 'same' convolution: sampled outputs against the oracle on the sample's neighbourhood,
+    and linearity (conv(a, 2 b) == 2 conv(a, b) exactly: scaling by two commutes with every rounding)."""
+    n = 8192
+    h = prov.fill_uniform(9, -1.0, 1.0, (n, n))
+    rng = np.random.default_rng(1)
+    b = rng.standard_normal((5, 5))
+    hb = prov.upload(b)
+    out = prov.conv2d(h, hb, "same")
+    assert list(out.shape) == [n, n]
+    x, y = prov.download_matrix(h), prov.download_matrix(out)
+    for r, c in ((0, 0), (n - 1, n - 1), (4000, 17), (2, n - 3), (8191, 0), (1234, 5678)):
+        r0, r1, c0, c1 = max(0, r - 4), min(n, r + 5), max(0, c - 4), min(n, c + 5)
+        want = oracle.conv2d(x[r0:r1, c0:c1], b, "same")
+        assert y[r, c] == want[r - r0, c - c0] or (r - r0 < 2 or c - c0 < 2 or r1 - r <= 2 or c1 - c <= 2) and abs(y[r, c] - want[r - r0, c - c0]) < 1e-12
+    y2 = prov.download_matrix(prov.conv2d(h, prov.upload(2.0 * b), "same"))
+    assert np.array_equal(y2, 2.0 * y)
