@@ -433,6 +433,15 @@ RMHIP_API int rmhip_conv1d(rmhip_ctx* ctx, rmhip_buf signal, rmhip_buf kernel, i
  * singleton dimensions allowed, else RMHIP_ERR_INVALID "input must be 2-D"); bit-exact; empty operands give [0, 0] (same: the signal's shape). */
 /* @serves conv2d */
 RMHIP_API int rmhip_conv2d(rmhip_ctx* ctx, rmhip_buf signal, rmhip_buf kernel, int mode, rmhip_buf* out);
+/* `moving_window(request)` (lib.rs:2852-2857, `ProviderMovingWindowRequest` :990-1003; moving.rs:737-825): movsum / movmean / movprod /
+ * movmin / movmax / movmedian / movstd / movvar over the count window [center - before, center + after] along zero-based `dim`.
+ * op: 0 sum 1 mean 2 prod 3 min 4 max 5 median 6 std 7 var (`ProviderMovingWindowOp`); endpoints: 0 shrink, 1 discard, 2 fill(`fill`);
+ * nan_omit / population: `ProviderNanMode::Omit` / `ProviderStdNormalization::Population`.  out_shape: the request's output shape (checked).
+ * Bit-exact (the CPU's accumulation order).  RMHIP_ERR_UNSUPPORTED: a median window of more than 64 points; a product padded with a
+ * value other than 0, 1 or NaN (the CPU multiplies by `powf(fill, count)`). */
+/* @serves moving_window */
+RMHIP_API int rmhip_moving_window(rmhip_ctx* ctx, rmhip_buf a, int dim, size_t before, size_t after, int op, int endpoints, double fill, int nan_omit,
+                                  int population, const size_t* out_shape, size_t out_rank, rmhip_buf* out);
 /* `hann_window / hamming_window / blackman_window(len, periodic)` (lib.rs:1797-1807; simple_provider.rs:95-120) -> [len, 1]; kind 0 / 1 / 2.
  * One cosine (two for Blackman) per point: within 2 ulp of the cosine of the CPU's libm (tests state the bound). */
 /* @serves hann_window hamming_window blackman_window */

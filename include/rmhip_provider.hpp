@@ -651,6 +651,14 @@ public:
         check(rmhip_conv2d(ctx_, own(signal), own(kernel), mode, &out));
         return with_shape(out);
     }
+    // lib.rs:2852-2857; op 0 sum 1 mean 2 prod 3 min 4 max 5 median 6 std 7 var; endpoints 0 shrink 1 discard 2 fill(fill)
+    GpuTensorHandle moving_window(const GpuTensorHandle& input, const std::vector<size_t>& output_shape, size_t dim, size_t before, size_t after, int op,
+                                  int endpoints, double fill, bool nan_omit, bool population) const {
+        uint64_t out = 0;
+        check(rmhip_moving_window(ctx_, own(input), (int)dim, before, after, op, endpoints, fill, nan_omit ? 1 : 0, population ? 1 : 0, output_shape.data(),
+                                  output_shape.size(), &out));
+        return with_shape(out);
+    }
     // lib.rs:1797-1807
     GpuTensorHandle hann_window(size_t len, bool periodic) const { return window(0, len, periodic); }
     GpuTensorHandle hamming_window(size_t len, bool periodic) const { return window(1, len, periodic); }

@@ -1531,6 +1531,112 @@ ORC_API int orc_issymmetric(const double* data, size_t rows, size_t cols, int sk
     return 1;
 }
 
+/* moving-window statistics over count windows: `moving_real` + `count_window` + `reduce_real_window(_with_fill)` + `RealVarianceAccumulator`
+ * + `median(_with_fill)`, builtins/math/reduction/moving.rs:737-825, 1441-1480, 929-1003, 1198-1237, 1282-1323.  op: 0 sum 1 mean 2 prod 3 min
+ * 4 max 5 median 6 std 7 var; endpoints: 0 shrink 1 discard 2 fill(fill); nan_mode: 0 include 1 omit; normalization: 0 sample 1 population.
+ * `Iterator::sum` of f64 folds from -0.0 on the reference's toolchain (1.90; since 1.83), `product` from 1.0; min / max fold from +-inf with
+ * `f64::min / max`.  pre / len / post: the input's extents around the dimension; out_len: the output's extent there. */
+static int orc_cmp_double(const void* a, const void* b) {
+    const double x = *(const double*)a, y = *(const double*)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+static double orc_kth_fill(const double* sorted, size_t n, double fill, size_t fill_count, size_t k) {
+    size_t less = 0;
+    while (less < n && sorted[less] < fill) ++less;
+    size_t equal = 0;
+    while (less + equal < n && sorted[less + equal] == fill) ++equal;
+    if (k < less) return sorted[k];
+    if (k < less + equal + fill_count) return fill;
+    return sorted[k - fill_count];
+}
+ORC_API void orc_moving_window(const double* x, size_t pre, size_t len, size_t post, size_t out_len, size_t before, size_t after, int op, int endpoints,
+                               double fill, int nan_mode, int normalization, double* out) {
+    double* vals = (double*)malloc((before + after + 2) * sizeof(double));
+    for (size_t o = 0; o < post; ++o)
+        for (size_t p = 0; p < out_len; ++p) {
+            const long long center = (long long)(endpoints == 1 ? p + before : p);
+            const long long start = center - (long long)before, end = center + (long long)after;
+            long long s0 = start < 0 ? 0 : start, e0 = end + 1;
+            if (s0 > (long long)len) s0 = (long long)len;
+            if (e0 < 0) e0 = 0;
+            if (e0 > (long long)len) e0 = (long long)len;
+            size_t fill_count = 0;
+            if (endpoints == 2) fill_count = (size_t)(start < 0 ? -start : 0) + (size_t)(end >= (long long)len ? end - (long long)len + 1 : 0);
+            for (size_t i = 0; i < pre; ++i) {
+                size_t n = 0;
+                int saw_nan = 0;
+                for (long long pos = s0; pos < e0; ++pos) {
+                    const double v = x[i + (size_t)pos * pre + o * pre * len];
+                    if (isnan(v)) {
+                        if (nan_mode == 0) {
+                            saw_nan = 1;
+                            break;
+                        }
+                        continue;
+                    }
+                    vals[n++] = v;
+                }
+                size_t fc = fill_count;
+                double r;
+                if (fc && (saw_nan || (isnan(fill) && nan_mode == 0))) {
+                    r = NAN;
+                } else {
+                    if (fc && isnan(fill)) fc = 0, saw_nan = 0;  /* omitted NaN padding: reduce the values alone */
+                    if (saw_nan) {
+                        r = NAN;
+                    } else if (n == 0 && fc == 0) {
+                        r = op == 0 ? 0.0 : (op == 2 ? 1.0 : NAN);
+                    } else {
+                        double sum = -0.0, prod = 1.0, mn = INFINITY, mx = -INFINITY;
+                        for (size_t k = 0; k < n; ++k) {
+                            sum = sum + vals[k];
+                            prod = prod * vals[k];
+                            mn = fmin(mn, vals[k]);
+                            mx = fmax(mx, vals[k]);
+                        }
+                        if (op == 0) r = fc ? sum + fill * (double)fc : sum;
+                        else if (op == 1) r = fc ? (sum + fill * (double)fc) / (double)(n + fc) : sum / (double)n;
+                        else if (op == 2) r = fc ? prod * pow(fill, (double)fc) : prod;
+                        else if (op == 3) r = fc ? fmin(mn, fill) : mn;
+                        else if (op == 4) r = fc ? fmax(mx, fill) : mx;
+                        else if (op == 5) {
+                            qsort(vals, n, sizeof(double), orc_cmp_double);
+                            const size_t total = n + fc, mid = total / 2;
+                            if (fc == 0) r = total % 2 ? vals[mid] : (vals[mid - 1] + vals[mid]) / 2.0;
+                            else r = total % 2 ? orc_kth_fill(vals, n, fill, fc, mid) : (orc_kth_fill(vals, n, fill, fc, mid - 1) + orc_kth_fill(vals, n, fill, fc, mid)) / 2.0;
+                        } else {
+                            size_t cnt = 0;
+                            double mean = 0.0, m2 = 0.0;
+                            for (size_t k = 0; k < n; ++k) {
+                                cnt += 1;
+                                const double d = vals[k] - mean;
+                                mean = mean + d / (double)cnt;
+                                const double d2 = vals[k] - mean;
+                                m2 = m2 + d * d2;
+                            }
+                            if (fc) {
+                                if (cnt == 0) {
+                                    cnt = fc, mean = fill, m2 = 0.0;
+                                } else {
+                                    const size_t total = cnt + fc;
+                                    const double d = fill - mean;
+                                    mean = mean + d * ((double)fc / (double)total);
+                                    m2 = m2 + d * d * ((double)cnt * (double)fc / (double)total);
+                                    cnt = total;
+                                }
+                            }
+                            const double den = normalization == 1 ? (double)cnt : (cnt > 1 ? (double)(cnt - 1) : (double)cnt);
+                            r = m2 / den;
+                            if (op == 6) r = sqrt(r);
+                        }
+                    }
+                }
+                out[i + p * pre + o * pre * out_len] = r;
+            }
+        }
+    free(vals);
+}
+
 /* conv (1-D): `convolve` + `apply_mode`, builtins/math/signal/conv.rs:481-517 (the same loops on real data in the in-process provider,
  * simple_provider.rs:1789-1842): out[i + j] += a[i] * b[j] over i ascending then j ascending, from zeros - so output n receives its terms in
  * order of increasing i, each product rounded before it is added.  mode 0 full, 1 same (start (len_b - 1) / 2, len_a points), 2 valid

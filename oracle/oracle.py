@@ -763,6 +763,27 @@ def issymmetric(a: np.ndarray, skew: bool = False, tol: float = 0.0) -> bool:
     return bool(l.orc_issymmetric(_p(_f(a)), rows, cols, int(skew), float(tol)))
 
 
+_MOVING_OPS = {"sum": 0, "mean": 1, "prod": 2, "min": 3, "max": 4, "median": 5, "std": 6, "var": 7}
+
+
+def moving_window(x, dim: int, before: int, after: int, op: str, endpoints="shrink", nan_mode: str = "include", normalization: str = "sample") -> np.ndarray:
+    """moving.rs:737-825 for count windows; endpoints: "shrink" | "discard" | a fill value."""
+    x = np.asarray(x, dtype=np.float64)
+    shape = list(x.shape) + [1] * max(0, dim + 1 - x.ndim)
+    pre, ln, post = int(np.prod(shape[:dim], dtype=np.int64)), shape[dim], int(np.prod(shape[dim + 1:], dtype=np.int64))
+    ep, fill = (0, 0.0) if endpoints == "shrink" else (1, 0.0) if endpoints == "discard" else (2, float(endpoints))
+    oshape = list(shape)
+    if ep == 1:
+        oshape[dim] = max(0, ln - before - after)
+    out = np.zeros(max(1, int(np.prod(oshape, dtype=np.int64))))
+    l = lib()
+    l.orc_moving_window.restype = None
+    l.orc_moving_window.argtypes = [_DP] + [C.c_size_t] * 6 + [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _DP]
+    l.orc_moving_window(_p(_f(x.reshape(shape))), pre, ln, post, oshape[dim], before, after, _MOVING_OPS[op], ep, fill, 0 if nan_mode == "include" else 1,
+                        0 if normalization == "sample" else 1, _p(out))
+    return out[:int(np.prod(oshape, dtype=np.int64))].reshape(oshape, order="F").copy()
+
+
 _CONV_MODES = {"full": 0, "same": 1, "valid": 2}
 
 

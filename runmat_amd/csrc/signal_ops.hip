@@ -2,6 +2,7 @@
 //   conv1d            crates/runmat-accelerate-api/src/lib.rs:2535-2542   (builtins/math/signal/conv.rs:481-517; simple_provider.rs:1780-1842, 6015-6064)
 //   conv2d            lib.rs:2543-2550    (builtins/math/signal/conv2.rs:595-640; simple_provider.rs:6065-6154)
 //   hann_window / hamming_window / blackman_window   lib.rs:1797-1807   (simple_provider.rs:95-120, 6453-6472)
+//   moving_window     lib.rs:2852-2857    (builtins/math/reduction/moving.rs:737-825, 929-1003, 1198-1237, 1282-1323)
 // The convolutions are DIRECT sums in the CPU's order (output n receives a[i] * b[n - i] for i ascending, every product rounded before it
 // is added - this file keeps contraction off): bit-exact against the oracle.  One thread per output point, neighbouring threads read
 // neighbouring signal points, the kernel operand is staged in LDS when it fits.
@@ -86,6 +87,115 @@ __global__ void __launch_bounds__(kB) k_window(int kind, u64 len, double denom, 
     out[i] = v;
 }
 
+// moving-window statistics (moving.rs:737-825, 929-1003, 1198-1237, 1282-1323): one thread per output element walks its window in
+// ascending position - the CPU's order, every operation rounded as written (sums fold from -0.0, products from 1.0, Welford's running
+// mean / M2 for std and var) - so results are bit-exact.  Neighbouring threads are neighbouring lines: coalesced for a window along any
+// dimension but the first; along the first, neighbouring outputs share all but two window points (cache hits).
+constexpr int MED_MAX = 64;  // median: the window's values are insertion-sorted in a per-thread array
+struct MovingArgs {
+    u64 pre, len, post, out_len, before, after, total;
+    int op, endpoints, nan_omit, population;
+    double fill;
+};
+
+__device__ __forceinline__ double kth_fill(const double* sorted, int n, double fill, u64 fill_count, u64 k) {
+    int less = 0;
+    while (less < n && sorted[less] < fill) ++less;
+    int equal = 0;
+    while (less + equal < n && sorted[less + equal] == fill) ++equal;
+    if (k < (u64)less) return sorted[k];
+    if (k < (u64)(less + equal) + fill_count) return fill;
+    return sorted[k - fill_count];
+}
+
+template <int OP>
+__global__ void __launch_bounds__(kB) k_moving(const double* __restrict__ x, MovingArgs A, double* __restrict__ out) {
+    const u64 e = (u64)blockIdx.x * kB + threadIdx.x;
+    if (e >= A.total) return;
+    const u64 i = e % A.pre, r = e / A.pre, p = r % A.out_len, o = r / A.out_len;
+    const long long center = (long long)(A.endpoints == 1 ? p + A.before : p);
+    const long long start = center - (long long)A.before, end = center + (long long)A.after;
+    long long s0 = start < 0 ? 0 : start, e0 = end + 1;
+    if (s0 > (long long)A.len) s0 = (long long)A.len;
+    if (e0 < 0) e0 = 0;
+    if (e0 > (long long)A.len) e0 = (long long)A.len;
+    u64 fc = 0;
+    if (A.endpoints == 2) fc = (u64)(start < 0 ? -start : 0) + (u64)(end >= (long long)A.len ? end - (long long)A.len + 1 : 0);
+    const double* src = x + i + o * A.pre * A.len;
+    double sum = -0.0, prod = 1.0, mn = INFINITY, mx = -INFINITY, mean = 0.0, m2 = 0.0;
+    double med[OP == 5 ? MED_MAX : 1];
+    u64 n = 0;
+    bool saw_nan = false;
+    for (long long pos = s0; pos < e0; ++pos) {
+        const double v = src[(u64)pos * A.pre];
+        if (isnan(v)) {
+            if (!A.nan_omit) {
+                saw_nan = true;
+                break;
+            }
+            continue;
+        }
+        ++n;
+        if (OP == 0 || OP == 1) sum = sum + v;
+        if (OP == 2) prod = prod * v;
+        if (OP == 3) mn = fmin(mn, v);
+        if (OP == 4) mx = fmax(mx, v);
+        if (OP == 5) {  // insertion into the sorted prefix (a stable sort of non-NaN values: equal values keep their order, as the CPU's)
+            int k = (int)n - 1;
+            while (k > 0 && med[k - 1] > v) med[k] = med[k - 1], --k;
+            med[k] = v;
+        }
+        if (OP == 6 || OP == 7) {
+            const double d = v - mean;
+            mean = mean + d / (double)n;
+            const double d2 = v - mean;
+            m2 = m2 + d * d2;
+        }
+    }
+    double res;
+    if (fc && (saw_nan || (isnan(A.fill) && !A.nan_omit))) {
+        res = NAN;
+    } else {
+        if (fc && isnan(A.fill)) fc = 0, saw_nan = false;  // omitted NaN padding: the values alone
+        if (saw_nan) {
+            res = NAN;
+        } else if (n == 0 && fc == 0) {
+            res = OP == 0 ? 0.0 : (OP == 2 ? 1.0 : NAN);
+        } else if (OP == 0) {
+            res = fc ? sum + A.fill * (double)fc : sum;
+        } else if (OP == 1) {
+            res = fc ? (sum + A.fill * (double)fc) / (double)(n + fc) : sum / (double)n;
+        } else if (OP == 2) {
+            res = fc ? prod * A.fill : prod;  // (the entry point only lets fills through whose power is the fill itself: 0, 1)
+        } else if (OP == 3) {
+            res = fc ? fmin(mn, A.fill) : mn;
+        } else if (OP == 4) {
+            res = fc ? fmax(mx, A.fill) : mx;
+        } else if (OP == 5) {
+            const u64 total = n + fc, mid = total / 2;
+            if (fc == 0) res = total % 2 ? med[mid] : (med[mid - 1] + med[mid]) / 2.0;
+            else res = total % 2 ? kth_fill(med, (int)n, A.fill, fc, mid) : (kth_fill(med, (int)n, A.fill, fc, mid - 1) + kth_fill(med, (int)n, A.fill, fc, mid)) / 2.0;
+        } else {
+            u64 cnt = n;
+            if (fc) {
+                if (cnt == 0) {
+                    cnt = fc, mean = A.fill, m2 = 0.0;
+                } else {
+                    const u64 total = cnt + fc;
+                    const double d = A.fill - mean;
+                    mean = mean + d * ((double)fc / (double)total);
+                    m2 = m2 + d * d * ((double)cnt * (double)fc / (double)total);
+                    cnt = total;
+                }
+            }
+            const double den = A.population ? (double)cnt : (cnt > 1 ? (double)(cnt - 1) : (double)cnt);
+            res = m2 / den;
+            if (OP == 6) res = sqrt(res);
+        }
+    }
+    out[e] = res;
+}
+
 inline unsigned grid_for(u64 n) { return (unsigned)((n + kB - 1) / kB); }
 
 }  // namespace
@@ -161,6 +271,55 @@ int rmhip_conv2d(rmhip_ctx* ctx, rmhip_buf signal, rmhip_buf kernel, int mode, r
     const int in_lds = bb.numel <= LDS_TAPS;
     hipLaunchKernelGGL(k_conv2d, dim3(grid_for(ob.numel)), dim3(kB), in_lds ? bb.numel * sizeof(double) : 0, c->stream, ab.data(), ar_n, ac_n, bb.data(), br_n, bc_n, r0, c0,
                        rows, cols, in_lds, ob.data());
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+
+int rmhip_moving_window(rmhip_ctx* ctx, rmhip_buf a, int dim, size_t before, size_t after, int op, int endpoints, double fill, int nan_omit, int population,
+                        const size_t* out_shape, size_t out_rank, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out || (out_rank && !out_shape)) return fail(RMHIP_ERR_INVALID, "moving_window: null argument");
+    if (dim < 0 || op < 0 || op > 7 || endpoints < 0 || endpoints > 2) return fail(RMHIP_ERR_INVALID, "moving_window: dim %d, op %d, endpoints %d", dim, op, endpoints);
+    Buffer ab;
+    RMHIP_TRY(c->get(a, &ab));
+    std::vector<size_t> shape = ab.shape;
+    if ((size_t)dim >= shape.size()) shape.resize(dim + 1, 1);  // simple_provider.rs:1266-1269
+    if ((size_t)dim >= out_rank) return fail(RMHIP_ERR_INVALID, "moving_window: dimension exceeds tensor rank");
+    // the caller's output shape (moving.rs:1545-1570): the input's, the dimension trimmed by before + after for 'discard'
+    std::vector<size_t> want = shape;
+    if (endpoints == 1) want[dim] = shape[dim] > before + after ? shape[dim] - before - after : 0;
+    std::vector<size_t> given(out_shape, out_shape + out_rank);
+    while (given.size() > want.size() && given.back() == 1) given.pop_back();
+    if (given != want) return fail(RMHIP_ERR_SHAPE, "moving_window: output shape does not match the request");
+    MovingArgs A{};
+    A.pre = 1, A.post = 1;
+    for (int k = 0; k < dim; ++k) A.pre *= shape[k];
+    for (size_t k = dim + 1; k < shape.size(); ++k) A.post *= shape[k];
+    A.len = shape[dim], A.out_len = want[dim], A.before = before, A.after = after;
+    A.op = op, A.endpoints = endpoints, A.nan_omit = nan_omit ? 1 : 0, A.population = population ? 1 : 0, A.fill = fill;
+    if (before > (1ull << 40) || after > (1ull << 40)) return fail(RMHIP_ERR_UNSUPPORTED, "moving_window: window %zu + %zu", before, after);
+    if (op == 5 && std::min<u64>(A.len, before + after + 1) > (u64)MED_MAX)
+        return fail(RMHIP_ERR_UNSUPPORTED, "moving_window: median over windows of more than %d points", MED_MAX);
+    // prod with padding multiplies by fill^count (`powf`, moving.rs:991): only fills whose every power is the fill itself stay exact
+    if (op == 2 && endpoints == 2 && !(fill == 0.0 || fill == 1.0 || std::isnan(fill)))
+        return fail(RMHIP_ERR_UNSUPPORTED, "moving_window: product with a padding value other than 0, 1 or NaN");
+    Buffer ob;
+    RMHIP_TRY(c->new_buffer(out_shape, out_rank, out, &ob));
+    A.total = ob.numel;
+    if (ob.numel == 0) return RMHIP_OK;
+    if (ob.numel > 0x7fffffffull * kB) return fail(RMHIP_ERR_UNSUPPORTED, "moving_window: %zu outputs", ob.numel);
+    const dim3 grid(grid_for(ob.numel)), block(kB);
+    switch (op) {
+        case 0: hipLaunchKernelGGL(k_moving<0>, grid, block, 0, c->stream, ab.data(), A, ob.data()); break;
+        case 1: hipLaunchKernelGGL(k_moving<1>, grid, block, 0, c->stream, ab.data(), A, ob.data()); break;
+        case 2: hipLaunchKernelGGL(k_moving<2>, grid, block, 0, c->stream, ab.data(), A, ob.data()); break;
+        case 3: hipLaunchKernelGGL(k_moving<3>, grid, block, 0, c->stream, ab.data(), A, ob.data()); break;
+        case 4: hipLaunchKernelGGL(k_moving<4>, grid, block, 0, c->stream, ab.data(), A, ob.data()); break;
+        case 5: hipLaunchKernelGGL(k_moving<5>, grid, block, 0, c->stream, ab.data(), A, ob.data()); break;
+        case 6: hipLaunchKernelGGL(k_moving<6>, grid, block, 0, c->stream, ab.data(), A, ob.data()); break;
+        default: hipLaunchKernelGGL(k_moving<7>, grid, block, 0, c->stream, ab.data(), A, ob.data()); break;
+    }
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;

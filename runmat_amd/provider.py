@@ -1062,6 +1062,19 @@ class HipProvider:
         self._check(self._lib.rmhip_conv2d(self._ctx, self._id(signal), self._id(kernel), modes[mode], C.byref(out)))
         return self._handle(out.value)
 
+    def moving_window(self, input, output_shape, dim: int, before: int, after: int, op: str, endpoints="shrink", nan_mode: str = "include",
+                      normalization: str = "sample") -> GpuTensorHandle:
+        """lib.rs:2852-2857 (`ProviderMovingWindowRequest`, :990-1003); endpoints: "shrink" | "discard" | a fill value."""
+        ops = {"sum": 0, "mean": 1, "prod": 2, "min": 3, "max": 4, "median": 5, "std": 6, "var": 7}
+        if op not in ops or nan_mode not in ("include", "omit") or normalization not in ("sample", "population"):
+            raise RmhipError(1, f"moving_window: op {op!r} / nan_mode {nan_mode!r} / normalization {normalization!r}")
+        ep, fill = (0, 0.0) if endpoints == "shrink" else (1, 0.0) if endpoints == "discard" else (2, float(endpoints))
+        sh, rank = _shape_array(output_shape)
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_moving_window(self._ctx, self._id(input), int(dim), int(before), int(after), ops[op], ep, fill, 1 if nan_mode == "omit" else 0,
+                                                  1 if normalization == "population" else 0, sh, rank, C.byref(out)))
+        return self._handle(out.value)
+
     def _window(self, kind: int, length: int, periodic: bool) -> GpuTensorHandle:
         out = C.c_uint64()
         self._check(self._lib.rmhip_window(self._ctx, kind, int(length), 1 if periodic else 0, C.byref(out)))

@@ -17,7 +17,7 @@ use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle, GpuTensorStorage,
     HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, KernelAttrTelemetry, KernelLaunchTelemetry, MatmulEpilogue,
     PowerStepEpilogue, ProviderBandwidth, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
-    ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderNanMode, ProviderNdgridRequest, ProviderNormOrder, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
+    ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderMovingWindowEndpoints, ProviderMovingWindowOp, ProviderMovingWindowRequest, ProviderNanMode, ProviderNdgridRequest, ProviderNormOrder, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
     ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult,
 };
 use std::ffi::{c_char, c_int, c_void, CStr, CString};
@@ -682,6 +682,27 @@ impl AccelProvider for HipProvider {
         let skew = matches!(kind, ProviderSymmetryKind::Skew) as c_int;
         check(unsafe { rmhip_issymmetric(self.ctx, self.own(matrix)?, skew, tolerance, &mut res) })?;
         Ok(res != 0)
+    }
+    fn moving_window<'a>(&'a self, request: &'a ProviderMovingWindowRequest<'a>) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let op = match request.op {
+                ProviderMovingWindowOp::Sum => 0, ProviderMovingWindowOp::Mean => 1, ProviderMovingWindowOp::Prod => 2, ProviderMovingWindowOp::Min => 3,
+                ProviderMovingWindowOp::Max => 4, ProviderMovingWindowOp::Median => 5, ProviderMovingWindowOp::Std => 6, ProviderMovingWindowOp::Var => 7,
+            };
+            let (endpoints, fill) = match request.endpoints {
+                ProviderMovingWindowEndpoints::Shrink => (0, 0.0),
+                ProviderMovingWindowEndpoints::Discard => (1, 0.0),
+                ProviderMovingWindowEndpoints::Fill(v) => (2, v),
+            };
+            let omit = matches!(request.nan_mode, ProviderNanMode::Omit) as c_int;
+            let population = matches!(request.normalization, ProviderStdNormalization::Population) as c_int;
+            let mut out = 0u64;
+            check(unsafe {
+                rmhip_moving_window(self.ctx, self.own(request.input)?, request.dim as c_int, request.before, request.after, op, endpoints, fill, omit, population,
+                                    request.output_shape.as_ptr(), request.output_shape.len(), &mut out)
+            })?;
+            self.handle(out)
+        })
     }
     fn conv1d(&self, signal: &GpuTensorHandle, kernel: &GpuTensorHandle, options: ProviderConv1dOptions) -> Result<GpuTensorHandle> {
         let mut out = 0u64;

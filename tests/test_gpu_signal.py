@@ -97,3 +97,56 @@ def test_full_size_image_filter(prov, oracle):
         assert y[r, c] == want[r - r0, c - c0] or (r - r0 < 2 or c - c0 < 2 or r1 - r <= 2 or c1 - c <= 2) and abs(y[r, c] - want[r - r0, c - c0]) < 1e-12
     y2 = prov.download_matrix(prov.conv2d(h, prov.upload(2.0 * b), "same"))
     assert np.array_equal(y2, 2.0 * y)
+
+
+def _nan(v):
+    return np.nan if v == "nan" else v
+
+
+def test_moving_window_kats(prov):
+    for k in K["moving"]:
+        x = np.array([_nan(v) for v in k["x"]], dtype=np.float64)
+        h = prov.moving_window(prov.upload(x, k["shape"]), k["shape"], k["dim"], k["before"], k["after"], k["op"], k["endpoints"], k["nan"], k["norm"])
+        assert np.array_equal(prov.download(h), np.array(k["out"], dtype=np.float64)), k
+
+
+@pytest.mark.parametrize("shape,dim", [((9, 11), 0), ((9, 11), 1), ((300,), 0), ((5, 40, 3), 1), ((64, 3), 2), ((1, 1), 0), ((2049, 5), 0)], ids=str)
+def test_moving_window(prov, oracle, shape, dim):
+    rng = np.random.default_rng(sum(shape) + dim)
+    x = rng.standard_normal(shape)
+    x.ravel()[rng.integers(0, x.size, size=max(1, x.size // 17))] = np.nan
+    x.ravel()[rng.integers(0, x.size, size=max(1, x.size // 23))] = 0.5          # repeated values (median ties)
+    h = prov.upload(x.ravel(order="F"), shape)
+    for before, after in ((1, 1), (0, 3), (4, 0), (7, 9)):
+        for op in ("sum", "mean", "prod", "min", "max", "median", "std", "var"):
+            for endpoints in ("shrink", "discard", 0.0, 1.0, float("nan")) + (() if op == "prod" else (2.5, -3.0)):
+                for nan_mode in ("include", "omit"):
+                    for norm in (("sample", "population") if op in ("std", "var") else ("sample",)):
+                        want = oracle.moving_window(x, dim, before, after, op, endpoints, nan_mode, norm)
+                        got = prov.moving_window(h, want.shape, dim, before, after, op, endpoints, nan_mode, norm)
+                        assert list(got.shape) == list(want.shape)
+                        assert bits_equal(prov.download(got).reshape(want.shape, order="F"), want), (before, after, op, endpoints, nan_mode, norm)
+                        prov.free(got)
+
+
+def test_moving_window_limits(prov):
+    h = prov.upload(np.arange(200.0).reshape(200, 1))
+    with pytest.raises(Exception):
+        prov.moving_window(h, (200, 1), 0, 40, 40, "median")                       # more than 64 points per window
+    with pytest.raises(Exception):
+        prov.moving_window(h, (200, 1), 0, 1, 1, "prod", 2.0)                      # the CPU multiplies by powf(2.0, count)
+    with pytest.raises(Exception):
+        prov.moving_window(h, (199, 1), 0, 1, 1, "sum")                            # output shape of another request
+    got = prov.moving_window(h, (200, 1), 0, 100, 100, "mean")                     # wide windows are fine for the other statistics
+    assert abs(prov.download(got)[100] - 99.5) < 1e-12                             # [0, 200] clipped to the 200 points: their mean
+
+
+def test_moving_mean_at_baseline_size(prov, oracle):
+    n = 8192
+    h = prov.fill_uniform(12, -1.0, 1.0, (n, n))
+    x = prov.download_matrix(h)
+    for dim in (0, 1):
+        got = prov.download_matrix(prov.moving_window(h, (n, n), dim, 2, 2, "mean"))
+        sl = (slice(0, 64), slice(None)) if dim == 1 else (slice(None), slice(0, 64))
+        want = oracle.moving_window(x[sl], dim, 2, 2, "mean")
+        assert bits_equal(got[sl], want)

@@ -40,3 +40,34 @@ def test_against_numpy():
         if n > 1:
             assert np.allclose(oracle.window("hann", n, True).ravel(), np.hanning(n + 1)[:-1], rtol=0, atol=1e-15)
     assert oracle.window("hann", 0).shape == (0, 1)
+
+
+def test_moving_window_kats_and_definitions():
+    for k in K["moving"]:
+        x = np.array([np.nan if v == "nan" else v for v in k["x"]], dtype=np.float64).reshape(k["shape"], order="F")
+        got = oracle.moving_window(x, k["dim"], k["before"], k["after"], k["op"], k["endpoints"], k["nan"], k["norm"])
+        assert np.array_equal(got.ravel(order="F"), np.array(k["out"], dtype=np.float64)), k
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((9, 11))
+    for dim in (0, 1):
+        for before, after in ((1, 1), (0, 3), (4, 0), (20, 20)):
+            lo = lambda p: max(0, p - before)
+            hi = lambda p: min(x.shape[dim], p + after + 1)
+            win = lambda p: np.take(x, range(lo(p), hi(p)), axis=dim)
+            n = x.shape[dim]
+            for op, f in (("sum", np.sum), ("mean", np.mean), ("prod", np.prod), ("min", np.min), ("max", np.max), ("median", np.median),
+                          ("var", lambda w, axis: np.var(w, axis=axis, ddof=1 if w.shape[axis] > 1 else 0)),
+                          ("std", lambda w, axis: np.std(w, axis=axis, ddof=1 if w.shape[axis] > 1 else 0))):
+                want = np.stack([f(win(p), axis=dim) for p in range(n)], axis=dim)
+                got = oracle.moving_window(x, dim, before, after, op)
+                assert got.shape == x.shape and np.allclose(got, want, rtol=1e-12, atol=1e-13), (dim, before, after, op)
+            d = oracle.moving_window(x, dim, before, after, "sum", "discard")
+            assert d.shape[dim] == max(0, n - before - after)
+            if d.size:
+                assert np.allclose(d, np.take(oracle.moving_window(x, dim, before, after, "sum"), range(before, n - after), axis=dim))
+    z = oracle.moving_window(x, 0, 2, 2, "sum", 10.0)                                # padding counts as values
+    assert np.isclose(z[0, 0], x[:3, 0].sum() + 20.0)
+    assert np.isnan(oracle.moving_window(x, 0, 2, 2, "mean", float("nan"))[0, 0])      # NaN padding, include-mode
+    assert np.isclose(oracle.moving_window(x, 0, 2, 2, "mean", float("nan"), "omit")[0, 0], x[:3, 0].mean())
+    assert oracle.moving_window(np.zeros((0, 3)), 0, 1, 1, "sum").shape == (0, 3)
+    assert oracle.moving_window(x, 2, 1, 1, "max").shape == (9, 11, 1)                 # a dimension beyond the rank
