@@ -344,6 +344,10 @@ RMHIP_API int rmhip_find(rmhip_ctx* ctx, rmhip_buf a, long long limit_or_neg, in
 /* @serves ndgrid */
 RMHIP_API int rmhip_ndgrid(rmhip_ctx* ctx, const rmhip_buf* axes, size_t n_axes, const size_t* output_shape, size_t rank, size_t output_count,
                            rmhip_buf* outputs);
+/* `meshgrid(axes)` (lib.rs:1561-1564; host axes `MeshgridAxisView`, :3376-3378; ops/constructors.rs:230-308): X(iy, ix, iz) = x[ix],
+ * Y = y[iy] (and Z = z[iz] when z_or_null != 0) on [ny, nx] - [ny, nx, nz] when nz > 1.  outputs: 2 ids, or 3 with a Z axis. */
+/* @serves meshgrid */
+RMHIP_API int rmhip_meshgrid(rmhip_ctx* ctx, const double* x, size_t nx, const double* y, size_t ny, const double* z_or_null, size_t nz, rmhip_buf* outputs);
 /* `sub2ind(dims, strides, inputs, scalar_mask, len, output_shape)` (lib.rs:3084-3094; simple_provider.rs:8340-8420, 2268-2291): 1-based
  * linear indices 1 + sum (s_d - 1) * stride_d from `rank` resident subscript tensors (a masked one is a scalar); every subscript must be
  * finite, integral (|round(v) - v| <= eps) and within 1..dims[d]: the FIRST offender in the CPU's (element, dimension) order gives
@@ -442,6 +446,12 @@ RMHIP_API int rmhip_conv2d(rmhip_ctx* ctx, rmhip_buf signal, rmhip_buf kernel, i
 /* @serves moving_window */
 RMHIP_API int rmhip_moving_window(rmhip_ctx* ctx, rmhip_buf a, int dim, size_t before, size_t after, int op, int endpoints, double fill, int nan_omit,
                                   int population, const size_t* out_shape, size_t out_rank, rmhip_buf* out);
+/* `polyval(coefficients, points, options)` (lib.rs:1652-1660; polyval.rs:886-905): Horner's rule over the coefficients (highest power
+ * first) at every point, the result in the points' shape; has_mu: the point is centred and scaled first, ((x - mean) * scale) / (scale *
+ * scale) as the CPU's complex division rounds it.  Bit-exact while every intermediate is finite; otherwise RMHIP_ERR_UNSUPPORTED (the
+ * CPU's complex recurrence yields NaN + NaN i there: a complex result the caller forms on the host).  Synchronises the stream once. */
+/* @serves polyval */
+RMHIP_API int rmhip_polyval(rmhip_ctx* ctx, rmhip_buf coefficients, rmhip_buf points, int has_mu, double mean, double scale, rmhip_buf* out);
 /* `hann_window / hamming_window / blackman_window(len, periodic)` (lib.rs:1797-1807; simple_provider.rs:95-120) -> [len, 1]; kind 0 / 1 / 2.
  * One cosine (two for Blackman) per point: within 2 ulp of the cosine of the CPU's libm (tests state the bound). */
 /* @serves hann_window hamming_window blackman_window */
@@ -467,6 +477,9 @@ RMHIP_API int rmhip_fft_dim(rmhip_ctx* ctx, rmhip_buf a, long long len_or_neg, i
  * operand a one-element tensor that expands. */
 /* @serves complex_from_real complex_from_real_imag */
 RMHIP_API int rmhip_complex(rmhip_ctx* ctx, rmhip_buf real, rmhip_buf imag_or_0, rmhip_buf* out);
+/* `zeros_with_storage(shape, ComplexInterleaved)` (lib.rs:1472-1489): a zero complex tensor (the Real kind is `rmhip_fill`). */
+/* @serves zeros_with_storage */
+RMHIP_API int rmhip_zeros_complex(rmhip_ctx* ctx, const size_t* shape, size_t rank, rmhip_buf* out);
 /* `fft_extract_real(handle)` (lib.rs:2639-2644; ifft(..., 'symmetric'), ifft.rs:362-372): the real parts as a new real tensor of the
  * same shape (a real input is copied: the caller frees the handle it passed). */
 /* @serves fft_extract_real */

@@ -640,6 +640,29 @@ public:
         check(rmhip_issymmetric(ctx_, own(m), skew ? 1 : 0, tolerance, &r));
         return r != 0;
     }
+    // lib.rs:1652-1660; mu == nullptr: no centring / scaling, else {mean, scale}
+    GpuTensorHandle polyval(const GpuTensorHandle& coefficients, const GpuTensorHandle& points, const double* mu = nullptr) const {
+        uint64_t out = 0;
+        check(rmhip_polyval(ctx_, own(coefficients), own(points), mu ? 1 : 0, mu ? mu[0] : 0.0, mu ? mu[1] : 1.0, &out));
+        return with_shape(out);
+    }
+    // lib.rs:1561-1564: two or three host axes -> X, Y[, Z]
+    std::vector<GpuTensorHandle> meshgrid(const std::vector<std::vector<double>>& axes) const {
+        if (axes.size() != 2 && axes.size() != 3) throw ProviderError(RMHIP_ERR_INVALID, "meshgrid: provider expects two or three axes");
+        uint64_t outs[3] = {0, 0, 0};
+        check(rmhip_meshgrid(ctx_, axes[0].data(), axes[0].size(), axes[1].data(), axes[1].size(), axes.size() == 3 ? axes[2].data() : nullptr,
+                             axes.size() == 3 ? axes[2].size() : 0, outs));
+        std::vector<GpuTensorHandle> r;
+        for (size_t i = 0; i < axes.size(); ++i) r.push_back(with_shape(outs[i]));
+        return r;
+    }
+    // lib.rs:1472-1489 (complex == false: `zeros`)
+    GpuTensorHandle zeros_with_storage(const std::vector<size_t>& shape, bool complex) const {
+        if (!complex) return zeros(shape);
+        uint64_t out = 0;
+        check(rmhip_zeros_complex(ctx_, shape.data(), shape.size(), &out));
+        return with_shape(out);
+    }
     // lib.rs:2535-2550; mode: 0 full, 1 same, 2 valid (`ProviderConvMode`); column: `ProviderConvOrientation::Column`
     GpuTensorHandle conv1d(const GpuTensorHandle& signal, const GpuTensorHandle& kernel, int mode, bool column) const {
         uint64_t out = 0;

@@ -763,6 +763,35 @@ def issymmetric(a: np.ndarray, skew: bool = False, tol: float = 0.0) -> bool:
     return bool(l.orc_issymmetric(_p(_f(a)), rows, cols, int(skew), float(tol)))
 
 
+def polyval(coefficients, points, mu=None) -> np.ndarray:
+    """polyval.rs:886-905 restated on real data: the CPU evaluates acc = acc * x + c in `Complex64` (num-complex: re = a.re * b.re - a.im *
+    b.im, rounded product by product), whose real part for real operands is the real recurrence with the product rounded before the sum;
+    `mu` first maps x to ((x - mean) * scale) / (scale * scale) - the real part of its complex division by (scale + 0i)."""
+    c = np.asarray(coefficients, dtype=np.float64).ravel(order="F")
+    x = np.asarray(points, dtype=np.float64)
+    v = x.copy()
+    if mu is not None:
+        mean, scale = float(mu[0]), float(mu[1])
+        v = ((v - mean) * scale + 0.0) / (scale * scale + 0.0)
+    acc = np.zeros_like(v)
+    for cj in c:
+        acc = acc * v + cj
+    return acc
+
+
+def meshgrid(axes):
+    """ops/constructors.rs:230-308: X(iy, ix[, iz]) = x[ix], Y = y[iy], Z = z[iz]; a one-point Z axis keeps the grids two-dimensional."""
+    x, y = (np.asarray(a, dtype=np.float64).ravel() for a in axes[:2])
+    z = np.asarray(axes[2], dtype=np.float64).ravel() if len(axes) == 3 else None
+    nz = z.size if z is not None else 1
+    shape = (y.size, x.size) if nz == 1 else (y.size, x.size, nz)
+    iy, ix, iz = np.meshgrid(np.arange(y.size), np.arange(x.size), np.arange(nz), indexing="ij")
+    outs = [x[ix].reshape(shape), y[iy].reshape(shape)]
+    if z is not None:
+        outs.append(z[iz].reshape(shape))
+    return outs
+
+
 _MOVING_OPS = {"sum": 0, "mean": 1, "prod": 2, "min": 3, "max": 4, "median": 5, "std": 6, "var": 7}
 
 

@@ -710,6 +710,15 @@ int rmhip_complex(rmhip_ctx* ctx, rmhip_buf real, rmhip_buf imag_or_0, rmhip_buf
     return RMHIP_OK;
 }
 
+int rmhip_zeros_complex(rmhip_ctx* ctx, const size_t* shape, size_t rank, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out || (rank && !shape)) return fail(RMHIP_ERR_INVALID, "zeros: null argument");
+    Buffer ob;
+    RMHIP_TRY(c->new_buffer_complex(shape, rank, out, &ob));
+    if (ob.numel) RMHIP_HIP_CHECK(hipMemsetAsync(ob.data(), 0, 2 * ob.numel * sizeof(double), c->stream));
+    return RMHIP_OK;
+}
+
 int rmhip_complex_real(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");

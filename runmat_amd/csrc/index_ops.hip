@@ -183,6 +183,31 @@ int rmhip_ndgrid(rmhip_ctx* ctx, const rmhip_buf* axes, size_t n_axes, const siz
     return rc;
 }
 
+int rmhip_meshgrid(rmhip_ctx* ctx, const double* x, size_t nx, const double* y, size_t ny, const double* z_or_null, size_t nz, rmhip_buf* outputs) {
+    CTX_OR_FAIL(ctx);
+    if (!outputs || (nx && !x) || (ny && !y)) return fail(RMHIP_ERR_INVALID, "meshgrid: null argument");
+    // ops/constructors.rs:230-308: X(iy, ix, iz) = x[ix], Y = y[iy], Z = z[iz] on [ny, nx] or [ny, nx, nz] - the N-D grid of the axes
+    // (y, x, z) with the first two outputs exchanged; a one-point Z axis keeps the shape two-dimensional and still yields Z
+    const size_t n_out = z_or_null ? 3 : 2;
+    if (!z_or_null) nz = 1;
+    const size_t shape[3] = {ny, nx, nz};
+    const size_t rank = nz == 1 ? 2 : 3;
+    rmhip_buf axes[3] = {0, 0, 0}, grids[3] = {0, 0, 0};
+    const double* src[3] = {y, x, z_or_null};
+    int rc = RMHIP_OK;
+    for (size_t d = 0; d < n_out && rc == RMHIP_OK; ++d) {
+        const size_t ashape[2] = {shape[d], 1};
+        rc = rmhip_upload(ctx, src[d], ashape, 2, &axes[d]);
+    }
+    if (rc == RMHIP_OK) rc = rmhip_ndgrid(ctx, axes, n_out, shape, rank, n_out, grids);
+    for (size_t d = 0; d < n_out; ++d)
+        if (axes[d]) rmhip_free(ctx, axes[d]);
+    if (rc != RMHIP_OK) return rc;
+    outputs[0] = grids[1], outputs[1] = grids[0];
+    if (n_out == 3) outputs[2] = grids[2];
+    return RMHIP_OK;
+}
+
 int rmhip_sub2ind(rmhip_ctx* ctx, const size_t* dims, const size_t* strides, const rmhip_buf* inputs, const unsigned char* scalar_mask, size_t rank, size_t len,
                   const size_t* output_shape, size_t out_rank, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);

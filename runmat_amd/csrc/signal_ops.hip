@@ -2,6 +2,7 @@
 //   conv1d            crates/runmat-accelerate-api/src/lib.rs:2535-2542   (builtins/math/signal/conv.rs:481-517; simple_provider.rs:1780-1842, 6015-6064)
 //   conv2d            lib.rs:2543-2550    (builtins/math/signal/conv2.rs:595-640; simple_provider.rs:6065-6154)
 //   hann_window / hamming_window / blackman_window   lib.rs:1797-1807   (simple_provider.rs:95-120, 6453-6472)
+//   polyval           lib.rs:1652-1660    (builtins/math/poly/polyval.rs:886-905, 352-435)
 //   moving_window     lib.rs:2852-2857    (builtins/math/reduction/moving.rs:737-825, 929-1003, 1198-1237, 1282-1323)
 // The convolutions are DIRECT sums in the CPU's order (output n receives a[i] * b[n - i] for i ascending, every product rounded before it
 // is added - this file keeps contraction off): bit-exact against the oracle.  One thread per output point, neighbouring threads read
@@ -196,6 +197,37 @@ __global__ void __launch_bounds__(kB) k_moving(const double* __restrict__ x, Mov
     out[e] = res;
 }
 
+// polyval (builtins/math/poly/polyval.rs:886-905): Horner's rule acc = acc * x + c over the coefficients, product rounded before the sum;
+// with `mu` the point is first centred and scaled the way the CPU's complex division by (scale + 0i) does it:
+// ((x - mean) * scale) / (scale * scale).  The CPU runs this in complex arithmetic; for real data the real part is this recurrence as long
+// as every intermediate stays finite (an infinite one makes the imaginary lane inf * 0 = NaN there): `nonfinite` records that.
+__global__ void __launch_bounds__(kB) k_polyval(const double* __restrict__ coef, u64 m, const double* __restrict__ x, u64 n, int has_mu, double mean, double scale,
+                                                int c_in_lds, double* __restrict__ out, int* __restrict__ nonfinite) {
+    extern __shared__ double taps[];
+    if (c_in_lds) {
+        for (u64 j = threadIdx.x; j < m; j += kB) taps[j] = coef[j];
+        __syncthreads();
+    }
+    const double* cc = c_in_lds ? taps : coef;
+    const u64 e = (u64)blockIdx.x * kB + threadIdx.x;
+    if (e >= n) return;
+    double v = x[e];
+    if (has_mu) {
+        const double t = v - mean;
+        const double num = t * scale + 0.0, den = scale * scale + 0.0;
+        v = num / den;
+    }
+    double acc = 0.0;
+    bool bad = !isfinite(v);
+    for (u64 j = 0; j < m; ++j) {
+        const double p = acc * v;
+        acc = p + cc[j];
+        bad |= !isfinite(acc);
+    }
+    out[e] = acc;
+    if (bad) *nonfinite = 1;
+}
+
 inline unsigned grid_for(u64 n) { return (unsigned)((n + kB - 1) / kB); }
 
 }  // namespace
@@ -322,6 +354,34 @@ int rmhip_moving_window(rmhip_ctx* ctx, rmhip_buf a, int dim, size_t before, siz
     }
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
+}
+
+int rmhip_polyval(rmhip_ctx* ctx, rmhip_buf coefficients, rmhip_buf points, int has_mu, double mean, double scale, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer cb, xb;
+    RMHIP_TRY(c->get(coefficients, &cb));
+    RMHIP_TRY(c->get(points, &xb));
+    Buffer ob;
+    RMHIP_TRY(c->new_buffer(xb.shape.data(), xb.shape.size(), out, &ob));
+    if (ob.numel == 0) return RMHIP_OK;
+    if (ob.numel > 0x7fffffffull * kB) return fail(RMHIP_ERR_UNSUPPORTED, "polyval: %zu points", ob.numel);
+    std::shared_ptr<Allocation> flag;
+    RMHIP_TRY(c->alloc_device(1, &flag));
+    RMHIP_HIP_CHECK(hipMemsetAsync(flag->ptr, 0, sizeof(double), c->stream));
+    const int in_lds = cb.numel <= LDS_TAPS;
+    hipLaunchKernelGGL(k_polyval, dim3(grid_for(ob.numel)), dim3(kB), in_lds ? cb.numel * sizeof(double) : 0, c->stream, cb.data(), (u64)cb.numel, xb.data(), (u64)ob.numel,
+                       has_mu ? 1 : 0, mean, scale, in_lds, ob.data(), (int*)flag->ptr);
+    c->tel.kernel_launches++;
+    int bad = 0;
+    RMHIP_HIP_CHECK(hipMemcpyAsync(&bad, flag->ptr, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (bad) {  // the CPU's complex recurrence turns these into NaN + NaN i (a complex result): the caller evaluates on the host
+        rmhip_free(ctx, *out);
+        *out = 0;
+        return fail(RMHIP_ERR_UNSUPPORTED, "polyval: a non-finite intermediate value");
+    }
     return RMHIP_OK;
 }
 

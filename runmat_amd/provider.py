@@ -1044,6 +1044,36 @@ class HipProvider:
         self._check(self._lib.rmhip_issymmetric(self._ctx, self._id(matrix), 1 if kind == "skew" else 0, float(tolerance), C.byref(res)))
         return bool(res.value)
 
+    def polyval(self, coefficients, points, mu: Optional[Tuple[float, float]] = None) -> GpuTensorHandle:
+        """lib.rs:1652-1660 (`ProviderPolyvalOptions { mu: Option<{mean, scale}> }`, :705-713)."""
+        out = C.c_uint64()
+        mean, scale = (float(mu[0]), float(mu[1])) if mu is not None else (0.0, 1.0)
+        self._check(self._lib.rmhip_polyval(self._ctx, self._id(coefficients), self._id(points), 1 if mu is not None else 0, mean, scale, C.byref(out)))
+        return self._handle(out.value)
+
+    def meshgrid(self, axes: Sequence[Sequence[float]]) -> List[GpuTensorHandle]:
+        """lib.rs:1561-1564: two or three HOST axes (`MeshgridAxisView`) -> `ProviderMeshgridResult.outputs` (X, Y[, Z])."""
+        if len(axes) not in (2, 3):
+            raise RmhipError(1, "meshgrid: provider expects two or three axes")
+        arrs = [np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel()) for a in axes]
+        ptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        outs = (C.c_uint64 * 3)()
+        z = arrs[2] if len(arrs) == 3 else None
+        self._check(self._lib.rmhip_meshgrid(self._ctx, ptr(arrs[0]), arrs[0].size, ptr(arrs[1]), arrs[1].size, ptr(z) if z is not None else None,
+                                             z.size if z is not None else 0, outs))
+        return [self._handle(outs[i]) for i in range(len(arrs))]
+
+    def zeros_with_storage(self, shape: Sequence[int], storage: str = "real") -> GpuTensorHandle:
+        """lib.rs:1472-1489: `GpuTensorStorage::{Real, ComplexInterleaved}` as "real" | "complex"."""
+        if storage == "real":
+            return self.zeros(shape)
+        if storage != "complex":
+            raise RmhipError(1, f"zeros_with_storage: storage {storage!r}")
+        sh, rank = _shape_array(shape)
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_zeros_complex(self._ctx, sh, rank, C.byref(out)))
+        return self._handle(out.value)
+
     def conv1d(self, signal, kernel, mode: str = "full", orientation: str = "row") -> GpuTensorHandle:
         """lib.rs:2535-2542 (`ProviderConv1dOptions { mode, orientation }`, :1277-1293)."""
         modes = {"full": 0, "same": 1, "valid": 2}

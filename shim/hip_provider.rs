@@ -15,7 +15,7 @@
 use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle, GpuTensorStorage,
-    HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, KernelAttrTelemetry, KernelLaunchTelemetry, MatmulEpilogue,
+    HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, KernelAttrTelemetry, MeshgridAxisView, ProviderMeshgridResult, ProviderPolyvalOptions, KernelLaunchTelemetry, MatmulEpilogue,
     PowerStepEpilogue, ProviderBandwidth, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderMovingWindowEndpoints, ProviderMovingWindowOp, ProviderMovingWindowRequest, ProviderNanMode, ProviderNdgridRequest, ProviderNormOrder, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
     ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult,
@@ -682,6 +682,30 @@ impl AccelProvider for HipProvider {
         let skew = matches!(kind, ProviderSymmetryKind::Skew) as c_int;
         check(unsafe { rmhip_issymmetric(self.ctx, self.own(matrix)?, skew, tolerance, &mut res) })?;
         Ok(res != 0)
+    }
+    fn polyval(&self, coefficients: &GpuTensorHandle, points: &GpuTensorHandle, options: &ProviderPolyvalOptions) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        let (has_mu, mean, scale) = match options.mu { Some(mu) => (1, mu.mean, mu.scale), None => (0, 0.0, 1.0) };
+        check(unsafe { rmhip_polyval(self.ctx, self.own(coefficients)?, self.own(points)?, has_mu, mean, scale, &mut out) })?;
+        self.handle(out)
+    }
+    fn meshgrid(&self, axes: &[MeshgridAxisView<'_>]) -> Result<ProviderMeshgridResult> {
+        if axes.len() != 2 && axes.len() != 3 {
+            return Err(anyhow!("meshgrid: provider expects two or three axes"));
+        }
+        let mut outs = [0u64; 3];
+        let (zp, zn) = match axes.get(2) { Some(z) => (z.data.as_ptr(), z.data.len()), None => (std::ptr::null(), 0) };
+        check(unsafe { rmhip_meshgrid(self.ctx, axes[0].data.as_ptr(), axes[0].data.len(), axes[1].data.as_ptr(), axes[1].data.len(), zp, zn, outs.as_mut_ptr()) })?;
+        let outputs = outs[..axes.len()].iter().map(|&id| self.handle(id)).collect::<Result<Vec<_>>>()?;
+        Ok(ProviderMeshgridResult { outputs })
+    }
+    fn zeros_with_storage(&self, shape: &[usize], storage: GpuTensorStorage) -> Result<GpuTensorHandle> {
+        if storage == GpuTensorStorage::Real {
+            return self.zeros(shape);
+        }
+        let mut out = 0u64;
+        check(unsafe { rmhip_zeros_complex(self.ctx, shape.as_ptr(), shape.len(), &mut out) })?;
+        self.complex_handle(out)
     }
     fn moving_window<'a>(&'a self, request: &'a ProviderMovingWindowRequest<'a>) -> AccelProviderFuture<'a, GpuTensorHandle> {
         Box::pin(async move {

@@ -150,3 +150,34 @@ def test_moving_mean_at_baseline_size(prov, oracle):
         sl = (slice(0, 64), slice(None)) if dim == 1 else (slice(None), slice(0, 64))
         want = oracle.moving_window(x[sl], dim, 2, 2, "mean")
         assert bits_equal(got[sl], want)
+
+
+def test_polyval(prov, oracle):
+    rng = np.random.default_rng(15)
+    for m, shape in ((1, (3, 3)), (4, (5, 7)), (12, (1000,)), (5000, (33, 2)), (3, (0, 4))):
+        c, x = rng.standard_normal(m), rng.uniform(-0.9, 0.9, shape)                    # (|x| < 1: a degree-4999 polynomial stays finite)
+        hc, hx = prov.upload(c.reshape(1, -1)), prov.upload(x.ravel(order="F"), shape)
+        for mu in (None, (0.25, 3.0), (-0.5, 2.0)):
+            got = prov.polyval(hc, hx, mu)
+            assert list(got.shape) == list(shape) and bits_equal(prov.download(got).reshape(shape, order="F"), oracle.polyval(c, x, mu)), (m, shape, mu)
+    with pytest.raises(Exception):                                                  # inf intermediate: NaN + NaN i on the CPU, a complex result
+        prov.polyval(prov.upload(np.array([[1e308, 1e308, 1.0]])), prov.upload(np.array([[1e10]])))
+    big = prov.fill_uniform(2, -1.0, 1.0, (8192, 8192))
+    coef = rng.standard_normal(9)
+    y = prov.download_matrix(prov.polyval(prov.upload(coef.reshape(1, -1)), big))
+    assert bits_equal(y[:, :8], oracle.polyval(coef, prov.download_matrix(big)[:, :8]))
+
+
+def test_meshgrid_and_complex_zeros(prov, oracle):
+    for axes in ([[1.0, 2.0, 3.0], [10.0, 20.0]], [[1.0, 2.0], [5.0], [7.0, 8.0, 9.0]], [[1.0, 2.0], [5.0, 6.0], [4.0]], [np.arange(300.0), np.arange(70.0)],
+                 [[], [1.0, 2.0]]):
+        got, want = prov.meshgrid(axes), oracle.meshgrid(axes)
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert list(g.shape) == list(w.shape) and np.array_equal(prov.download(g).reshape(w.shape, order="F"), w)
+    with pytest.raises(Exception):
+        prov.meshgrid([[1.0]])
+    z = prov.zeros_with_storage((3, 5), "complex")
+    assert prov.is_complex(z) and list(z.shape) == [3, 5] and not prov.download(z).any() and prov.download(z).size == 15
+    r = prov.zeros_with_storage((3, 5))
+    assert not prov.is_complex(r) and not prov.download(r).any()

@@ -71,3 +71,17 @@ def test_moving_window_kats_and_definitions():
     assert np.isclose(oracle.moving_window(x, 0, 2, 2, "mean", float("nan"), "omit")[0, 0], x[:3, 0].mean())
     assert oracle.moving_window(np.zeros((0, 3)), 0, 1, 1, "sum").shape == (0, 3)
     assert oracle.moving_window(x, 2, 1, 1, "max").shape == (9, 11, 1)                 # a dimension beyond the rank
+
+
+def test_polyval_and_meshgrid():
+    rng = np.random.default_rng(6)
+    c, x = rng.standard_normal(7), rng.standard_normal((5, 4))
+    assert np.allclose(oracle.polyval(c, x), np.polyval(c, x), rtol=1e-13, atol=1e-13)
+    assert np.allclose(oracle.polyval(c, x, (0.3, 2.0)), np.polyval(c, (x - 0.3) / 2.0), rtol=1e-13, atol=1e-13)
+    assert np.array_equal(oracle.polyval([2.0], x), np.full(x.shape, 2.0)) and np.array_equal(oracle.polyval([1.0, 2.0, 3.0], np.array([2.0])), [11.0])
+    X, Y = oracle.meshgrid([[1.0, 2.0, 3.0], [10.0, 20.0]])
+    assert np.array_equal(X, [[1, 2, 3], [1, 2, 3]]) and np.array_equal(Y, [[10, 10, 10], [20, 20, 20]])
+    X, Y, Z = oracle.meshgrid([[1.0, 2.0], [5.0], [7.0, 8.0, 9.0]])
+    want = np.meshgrid([1.0, 2.0], [5.0], [7.0, 8.0, 9.0])
+    assert all(np.array_equal(a, b) for a, b in zip((X, Y, Z), want))
+    assert oracle.meshgrid([[1.0, 2.0], [5.0, 6.0], [4.0]])[2].shape == (2, 2)
