@@ -337,6 +337,19 @@ RMHIP_API int rmhip_reduce_median(rmhip_ctx* ctx, rmhip_buf a, int dim, rmhip_bu
 /* @serves find */
 RMHIP_API int rmhip_find(rmhip_ctx* ctx, rmhip_buf a, long long limit_or_neg, int last, rmhip_buf* linear, rmhip_buf* rows, rmhip_buf* cols,
                          rmhip_buf* values);
+/* `unique(handle, options)` for elements (lib.rs:2645-2651; `UniqueOptions` :1110-1116 with rows == false; unique.rs:473-556): the distinct
+ * values - every NaN one value, both zeros one value, each keeping the bits of its FIRST occurrence -, sorted ascending with NaN last or
+ * (stable != 0) in order of first occurrence; ia: the 1-based position of each value's first (or last_occurrence != 0: last) occurrence;
+ * ic: for every element the 1-based rank of its value.  The results are HOST tensors as in `UniqueResult` (:1118-1124): values_host and
+ * ia_host need room for numel doubles (*count are written: shape [count, 1]), ic_host for numel (shape [numel, 1]).  Integer work on
+ * sorted (key, position) pairs: bit-exact. */
+/* @serves unique */
+RMHIP_API int rmhip_unique(rmhip_ctx* ctx, rmhip_buf a, int stable, int last_occurrence, size_t* count, double* values_host, double* ia_host, double* ic_host);
+/* `ismember(a, b, options)` for elements (lib.rs:2668-2675; `IsMemberOptions { rows: false }`, :1256-1274; ismember.rs:413-438):
+ * mask_host[i] = 1 when a's element i occurs in b (NaN matches NaN, -0 matches +0), loc_host[i] = the 1-based lowest position in b or 0;
+ * both in a's shape, numel(a) entries (`HostLogicalOwned` / `HostTensorOwned`). */
+/* @serves ismember */
+RMHIP_API int rmhip_ismember(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, unsigned char* mask_host, double* loc_host);
 /* ---- subscript / grid / slice-write hooks and the per-element forms of a real tensor (runmat_amd/csrc/index_ops.hip): bit-exact ----
  * `ndgrid(request)` (lib.rs:1567-1569, ProviderNdgridRequest :3395-3399; simple_provider.rs:2784-2855): for the first `output_count` axes
  * (resident vectors whose lengths equal the leading output extents) the grid out_d[i] = axis_d[(i / stride_d) % extent_d] of shape

@@ -640,6 +640,32 @@ public:
         check(rmhip_issymmetric(ctx_, own(m), skew ? 1 : 0, tolerance, &r));
         return r != 0;
     }
+    // lib.rs:2645-2651 (elements; rows: not served) -> host tensors [count, 1], [count, 1], [numel, 1]
+    struct UniqueResult {
+        HostTensorOwned values, ia, ic;
+    };
+    UniqueResult unique(const GpuTensorHandle& a, bool stable, bool last_occurrence) const {
+        const size_t n = a.numel();
+        UniqueResult r;
+        r.values.data.resize(n), r.ia.data.resize(n), r.ic.data.resize(n);
+        size_t count = 0;
+        check(rmhip_unique(ctx_, own(a), stable ? 1 : 0, last_occurrence ? 1 : 0, &count, r.values.data.data(), r.ia.data.data(), r.ic.data.data()));
+        r.values.data.resize(count), r.ia.data.resize(count);
+        r.values.shape = {count, 1}, r.ia.shape = {count, 1}, r.ic.shape = {n, 1};
+        return r;
+    }
+    struct IsMemberResult {  // lib.rs:1262-1274
+        std::vector<unsigned char> mask;
+        HostTensorOwned loc;
+        std::vector<size_t> shape;
+    };
+    IsMemberResult ismember(const GpuTensorHandle& a, const GpuTensorHandle& b) const {
+        IsMemberResult r;
+        r.mask.resize(a.numel()), r.loc.data.resize(a.numel());
+        r.shape = a.shape, r.loc.shape = a.shape;
+        check(rmhip_ismember(ctx_, own(a), own(b), r.mask.data(), r.loc.data.data()));
+        return r;
+    }
     // lib.rs:1652-1660; mu == nullptr: no centring / scaling, else {mean, scale}
     GpuTensorHandle polyval(const GpuTensorHandle& coefficients, const GpuTensorHandle& points, const double* mu = nullptr) const {
         uint64_t out = 0;

@@ -763,6 +763,48 @@ def issymmetric(a: np.ndarray, skew: bool = False, tol: float = 0.0) -> bool:
     return bool(l.orc_issymmetric(_p(_f(a)), rows, cols, int(skew), float(tol)))
 
 
+def _canon_key(v: float):
+    """canonicalize_f64, unique.rs:1347-1355 / ismember.rs:814-822: every NaN one key, both zeros one key, otherwise the bits."""
+    if v != v:
+        return "nan"
+    if v == 0.0:
+        return 0.0
+    return np.float64(v).tobytes()
+
+
+def unique(x, order: str = "sorted", occurrence: str = "first"):
+    """unique_numeric_elements, unique.rs:473-556 -> (values [g, 1], ia [g, 1], ic [n, 1]) with 1-based indices."""
+    data = np.asarray(x, dtype=np.float64).ravel(order="F")
+    entries, index, entry_of = [], {}, []
+    for i, v in enumerate(data):
+        k = _canon_key(v)
+        if k in index:
+            entries[index[k]][2] = i
+        else:
+            index[k] = len(entries)
+            entries.append([v, i, i])
+        entry_of.append(index[k])
+    ordering = list(range(len(entries)))
+    if order == "sorted":  # compare_f64 (unique.rs:1357-1369): NaN last; a stable sort over distinct keys
+        ordering.sort(key=lambda e: (entries[e][0] != entries[e][0], 0.0 if entries[e][0] != entries[e][0] else entries[e][0]))
+    position = {e: p for p, e in enumerate(ordering)}
+    values = np.array([entries[e][0] for e in ordering], dtype=np.float64).reshape(-1, 1)
+    ia = np.array([entries[e][1 if occurrence == "first" else 2] + 1 for e in ordering], dtype=np.float64).reshape(-1, 1)
+    ic = np.array([position[e] + 1 for e in entry_of], dtype=np.float64).reshape(-1, 1)
+    return values, ia, ic
+
+
+def ismember(a, b):
+    """ismember_numeric_elements, ismember.rs:413-438 -> (mask uint8, loc) in a's shape."""
+    a = np.asarray(a, dtype=np.float64)
+    first = {}
+    for i, v in enumerate(np.asarray(b, dtype=np.float64).ravel(order="F")):
+        first.setdefault(_canon_key(v), i + 1)
+    flat = a.ravel(order="F")
+    loc = np.array([first.get(_canon_key(v), 0) for v in flat], dtype=np.float64)
+    return (loc > 0).astype(np.uint8).reshape(a.shape, order="F"), loc.reshape(a.shape, order="F")
+
+
 def polyval(coefficients, points, mu=None) -> np.ndarray:
     """polyval.rs:886-905 restated on real data: the CPU evaluates acc = acc * x + c in `Complex64` (num-complex: re = a.re * b.re - a.im *
     b.im, rounded product by product), whose real part for real operands is the real recurrence with the product rounded before the sum;

@@ -789,6 +789,125 @@ int lines_of(const std::vector<size_t>& shape, int dim, const char* what, Lines*
     return RMHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// unique / ismember (elements): the CPU's hash maps keyed by `canonicalize_f64` (unique.rs:1347-1355: every NaN one key, both zeros one
+// key) become the sorted (key, position) pairs of the whole tensor - equal keys are neighbours, ordered by position, so a group's head
+// is its FIRST occurrence and its tail the LAST.  Group ids are a scan of the head flags.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int SCAN_CHUNK = 1024;  // flags per workgroup (256 threads x 4)
+
+__global__ void __launch_bounds__(256) k_group_heads(const u64* __restrict__ keys, u64 n, u32* __restrict__ flags, u32* __restrict__ counts) {
+    __shared__ u32 part[4];
+    const u64 base = (u64)blockIdx.x * SCAN_CHUNK + threadIdx.x * 4;
+    u32 cnt = 0;
+    for (int e = 0; e < 4; ++e) {
+        const u64 i = base + e;
+        u32 f = 0;
+        if (i < n) f = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+        if (i < n) flags[i] = f;
+        cnt += f;
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// exclusive scan of the chunk counts by one workgroup; total[0] = number of groups
+__global__ void __launch_bounds__(1024) k_chunk_offsets(const u32* __restrict__ counts, u64 nchunks, u32* __restrict__ offsets, u32* __restrict__ total) {
+    __shared__ u32 warp_sums[16];
+    __shared__ u32 carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (u64 base = 0; base < nchunks; base += 1024) {
+        const u64 i = base + threadIdx.x;
+        const u32 v = i < nchunks ? counts[i] : 0;
+        u32 incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 up = __shfl_up(incl, o);
+            if ((int)(threadIdx.x & 63) >= o) incl += up;
+        }
+        if ((threadIdx.x & 63) == 63) warp_sums[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        u32 before = carry;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += warp_sums[w];
+        if (i < nchunks) offsets[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[0] = carry;
+}
+
+// gid[i] = (heads at or before i) - 1; the head of group g records its sorted index, the tail its element position
+__global__ void __launch_bounds__(256) k_group_ids(const u32* __restrict__ flags, const u32* __restrict__ offsets, const u32* __restrict__ pos, u64 n,
+                                                   u32* __restrict__ gid, u32* __restrict__ first_pos, u32* __restrict__ last_pos) {
+    __shared__ u32 wave_tot[4];
+    const u64 base = (u64)blockIdx.x * SCAN_CHUNK + threadIdx.x * 4;
+    u32 f[4], mine = 0;
+    for (int e = 0; e < 4; ++e) {
+        f[e] = base + e < n ? flags[base + e] : 0;
+        mine += f[e];
+    }
+    u32 incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 up = __shfl_up(incl, o);
+        if ((int)(threadIdx.x & 63) >= o) incl += up;
+    }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    u32 run = offsets[blockIdx.x] + incl - mine;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wave_tot[w];
+    for (int e = 0; e < 4; ++e) {
+        const u64 i = base + e;
+        if (i >= n) break;
+        run += f[e];
+        const u32 g = run - 1;
+        gid[i] = g;
+        if (f[e]) first_pos[g] = pos[i];
+        if (i + 1 == n || flags[i + 1]) last_pos[g] = pos[i];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_u32_to_double(const u32* __restrict__ src, u64 n, double* __restrict__ dst) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (double)src[i];
+}
+
+// rank_of[group] = r for the r-th group in output order (`order[r]` = group, or null: sorted order, rank = group)
+__global__ void __launch_bounds__(256) k_unique_outputs(const double* __restrict__ x, const u32* __restrict__ order, const u32* __restrict__ first_pos,
+                                                        const u32* __restrict__ last_pos, u64 groups, int take_last, double* __restrict__ values, double* __restrict__ ia,
+                                                        u32* __restrict__ rank_of) {
+    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (r >= groups) return;
+    const u32 g = order ? order[r] : (u32)r;
+    values[r] = x[first_pos[g]];  // the entry keeps the value of its first occurrence (unique.rs:505-511)
+    ia[r] = (double)(take_last ? last_pos[g] : first_pos[g]) + 1.0;
+    rank_of[g] = (u32)r;
+}
+
+__global__ void __launch_bounds__(256) k_unique_inverse(const u32* __restrict__ pos, const u32* __restrict__ gid, const u32* __restrict__ rank_of, u64 n, double* __restrict__ ic) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) ic[pos[i]] = (double)rank_of[gid[i]] + 1.0;
+}
+
+// mask / loc of every element of a against the sorted pairs of b: the first pair with the element's key holds b's lowest position
+__global__ void __launch_bounds__(256) k_ismember(const double* __restrict__ a, u64 na, const u64* __restrict__ keys, const u32* __restrict__ pos, u64 nb,
+                                                  unsigned char* __restrict__ mask, double* __restrict__ loc) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= na) return;
+    const u64 key = sort_key(a[i], 0, 0);
+    u64 lo = 0, hi = nb;
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    const bool hit = lo < nb && keys[lo] == key;
+    mask[i] = hit ? 1 : 0;
+    loc[i] = hit ? (double)pos[lo] + 1.0 : 0.0;
+}
+
 }  // namespace
 }  // namespace rmhip
 
@@ -964,4 +1083,85 @@ int rmhip_find(rmhip_ctx* ctx, rmhip_buf a, long long limit_or_neg, int last, rm
         for (int i = 0; i < 4; ++i)
             if (*outs[i]) rmhip_free(ctx, *outs[i]);
     return rc;
+}
+
+int rmhip_unique(rmhip_ctx* ctx, rmhip_buf a, int stable, int last_occurrence, size_t* count, double* values_host, double* ia_host, double* ic_host) {
+    CTX_OR_FAIL(ctx);
+    if (!count) return fail(RMHIP_ERR_INVALID, "unique: null count");
+    Buffer ab;
+    RMHIP_TRY(c->get(a, &ab));
+    const u64 n = ab.numel;
+    *count = 0;
+    if (n == 0) return RMHIP_OK;
+    if (!values_host || !ia_host || !ic_host) return fail(RMHIP_ERR_INVALID, "unique: null output");
+    SortSpace ws;
+    RMHIP_TRY(sort_lines(c, ab.data(), Lines{1, n, 1}, 0, 0, &ws));
+    const u64 nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    // u32 work arrays: flags n | gid n | first n | last n | rank n | counts nchunks | offsets nchunks | total 2
+    std::shared_ptr<Allocation> wk, outs;
+    RMHIP_TRY(c->alloc_device((5 * n + 2 * nchunks + 2 + 1) / 2 + 1, &wk));
+    u32* flags = (u32*)wk->ptr;
+    u32 *gid = flags + n, *first_pos = gid + n, *last_pos = first_pos + n, *rank_of = last_pos + n, *counts = rank_of + n, *offsets = counts + nchunks, *total = offsets + nchunks;
+    hipLaunchKernelGGL(k_group_heads, dim3((unsigned)nchunks), dim3(256), 0, c->stream, ws.keys, n, flags, counts);
+    hipLaunchKernelGGL(k_chunk_offsets, dim3(1), dim3(1024), 0, c->stream, counts, nchunks, offsets, total);
+    hipLaunchKernelGGL(k_group_ids, dim3((unsigned)nchunks), dim3(256), 0, c->stream, flags, offsets, ws.pos, n, gid, first_pos, last_pos);
+    c->tel.kernel_launches += 3;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    u32 groups32 = 0;
+    RMHIP_HIP_CHECK(hipMemcpyAsync(&groups32, total, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));  // the outputs' size is part of the answer
+    const u64 groups = groups32;
+    RMHIP_TRY(c->alloc_device(2 * groups + n, &outs));  // values | ia | ic
+    double *dv = outs->ptr, *dia = dv + groups, *dic = dia + groups;
+    const u32* order = nullptr;
+    SortSpace ws2;
+    std::shared_ptr<Allocation> fp;
+    if (stable && groups > 1) {  // groups in order of their first occurrence (unique.rs:516-519: `order` stays the insertion order)
+        RMHIP_TRY(c->alloc_device(groups, &fp));
+        hipLaunchKernelGGL(k_u32_to_double, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, c->stream, first_pos, groups, fp->ptr);
+        c->tel.kernel_launches++;
+        RMHIP_TRY(sort_lines(c, fp->ptr, Lines{1, groups, 1}, 0, 0, &ws2));
+        order = ws2.pos;
+    }
+    hipLaunchKernelGGL(k_unique_outputs, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, c->stream, ab.data(), order, first_pos, last_pos, groups, last_occurrence ? 1 : 0,
+                       dv, dia, rank_of);
+    hipLaunchKernelGGL(k_unique_inverse, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, ws.pos, gid, rank_of, n, dic);
+    c->tel.kernel_launches += 2;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    RMHIP_HIP_CHECK(hipMemcpyAsync(values_host, dv, groups * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipMemcpyAsync(ia_host, dia, groups * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipMemcpyAsync(ic_host, dic, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->tel.download_bytes += (2 * groups + n) * sizeof(double);
+    *count = groups;
+    return RMHIP_OK;
+}
+
+int rmhip_ismember(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, unsigned char* mask_host, double* loc_host) {
+    CTX_OR_FAIL(ctx);
+    Buffer ab, bb;
+    RMHIP_TRY(c->get(a, &ab));
+    RMHIP_TRY(c->get(b, &bb));
+    const u64 na = ab.numel, nb = bb.numel;
+    if (na == 0) return RMHIP_OK;
+    if (!mask_host || !loc_host) return fail(RMHIP_ERR_INVALID, "ismember: null output");
+    if (nb == 0) {
+        std::memset(mask_host, 0, na);
+        for (u64 i = 0; i < na; ++i) loc_host[i] = 0.0;
+        return RMHIP_OK;
+    }
+    SortSpace ws;
+    RMHIP_TRY(sort_lines(c, bb.data(), Lines{1, nb, 1}, 0, 0, &ws));
+    std::shared_ptr<Allocation> outs;
+    RMHIP_TRY(c->alloc_device(na + (na + 7) / 8, &outs));  // loc (f64) | mask (bytes)
+    double* dloc = outs->ptr;
+    unsigned char* dmask = (unsigned char*)(dloc + na);
+    hipLaunchKernelGGL(k_ismember, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, c->stream, ab.data(), na, ws.keys, ws.pos, nb, dmask, dloc);
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    RMHIP_HIP_CHECK(hipMemcpyAsync(loc_host, dloc, na * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipMemcpyAsync(mask_host, dmask, na, hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->tel.download_bytes += na * 9;
+    return RMHIP_OK;
 }

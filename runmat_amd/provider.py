@@ -1044,6 +1044,30 @@ class HipProvider:
         self._check(self._lib.rmhip_issymmetric(self._ctx, self._id(matrix), 1 if kind == "skew" else 0, float(tolerance), C.byref(res)))
         return bool(res.value)
 
+    def unique(self, handle, rows: bool = False, order: str = "sorted", occurrence: str = "first"):
+        """lib.rs:2645-2651 -> `UniqueResult { values, ia, ic }` as host arrays ([count, 1], [count, 1], [numel, 1])."""
+        if rows:
+            raise ProviderError(_lib.ERR_UNSUPPORTED, "unique: the 'rows' form is not served")
+        if order not in ("sorted", "stable") or occurrence not in ("first", "last"):
+            raise RmhipError(1, f"unique: order {order!r} / occurrence {occurrence!r}")
+        n = int(np.prod(handle.shape, dtype=np.int64)) if len(handle.shape) else 1
+        values, ia, ic = np.empty(max(n, 1)), np.empty(max(n, 1)), np.empty(max(n, 1))
+        count = C.c_size_t()
+        ptr = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+        self._check(self._lib.rmhip_unique(self._ctx, self._id(handle), 1 if order == "stable" else 0, 1 if occurrence == "last" else 0, C.byref(count),
+                                           ptr(values), ptr(ia), ptr(ic)))
+        g = count.value
+        return values[:g].reshape(g, 1).copy(), ia[:g].reshape(g, 1).copy(), ic[:n].reshape(n, 1).copy()
+
+    def ismember(self, a, b, rows: bool = False):
+        """lib.rs `ismember` -> `IsMemberResult { mask, loc }` as host arrays in a's shape (mask: uint8)."""
+        if rows:
+            raise ProviderError(_lib.ERR_UNSUPPORTED, "ismember: the 'rows' form is not served")
+        n = int(np.prod(a.shape, dtype=np.int64)) if len(a.shape) else 1
+        mask, loc = np.zeros(max(n, 1), dtype=np.uint8), np.zeros(max(n, 1))
+        self._check(self._lib.rmhip_ismember(self._ctx, self._id(a), self._id(b), mask.ctypes.data_as(C.POINTER(C.c_ubyte)), loc.ctypes.data_as(C.POINTER(C.c_double))))
+        return mask[:n].reshape(a.shape, order="F").copy(), loc[:n].reshape(a.shape, order="F").copy()
+
     def polyval(self, coefficients, points, mu: Optional[Tuple[float, float]] = None) -> GpuTensorHandle:
         """lib.rs:1652-1660 (`ProviderPolyvalOptions { mu: Option<{mean, scale}> }`, :705-713)."""
         out = C.c_uint64()

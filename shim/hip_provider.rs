@@ -15,7 +15,7 @@
 use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle, GpuTensorStorage,
-    HostTensorOwned, HostTensorView, ImageNormalizeDescriptor, KernelAttrTelemetry, MeshgridAxisView, ProviderMeshgridResult, ProviderPolyvalOptions, KernelLaunchTelemetry, MatmulEpilogue,
+    HostLogicalOwned, HostTensorOwned, HostTensorView, IsMemberOptions, IsMemberResult, UniqueOccurrence, UniqueOptions, UniqueOrder, UniqueResult, ImageNormalizeDescriptor, KernelAttrTelemetry, MeshgridAxisView, ProviderMeshgridResult, ProviderPolyvalOptions, KernelLaunchTelemetry, MatmulEpilogue,
     PowerStepEpilogue, ProviderBandwidth, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderMovingWindowEndpoints, ProviderMovingWindowOp, ProviderMovingWindowRequest, ProviderNanMode, ProviderNdgridRequest, ProviderNormOrder, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
     ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult,
@@ -682,6 +682,41 @@ impl AccelProvider for HipProvider {
         let skew = matches!(kind, ProviderSymmetryKind::Skew) as c_int;
         check(unsafe { rmhip_issymmetric(self.ctx, self.own(matrix)?, skew, tolerance, &mut res) })?;
         Ok(res != 0)
+    }
+    fn unique<'a>(&'a self, handle: &'a GpuTensorHandle, options: &'a UniqueOptions) -> AccelProviderFuture<'a, UniqueResult> {
+        Box::pin(async move {
+            if options.rows {
+                return Err(anyhow!("unique: the 'rows' form is not served by this provider"));
+            }
+            let n: usize = handle.shape.iter().product();
+            let (mut values, mut ia, mut ic) = (vec![0.0f64; n], vec![0.0f64; n], vec![0.0f64; n]);
+            let mut count = 0usize;
+            let stable = matches!(options.order, UniqueOrder::Stable) as c_int;
+            let last = matches!(options.occurrence, UniqueOccurrence::Last) as c_int;
+            check(unsafe { rmhip_unique(self.ctx, self.own(handle)?, stable, last, &mut count, values.as_mut_ptr(), ia.as_mut_ptr(), ic.as_mut_ptr()) })?;
+            values.truncate(count);
+            ia.truncate(count);
+            let real = GpuTensorStorage::Real;
+            Ok(UniqueResult {
+                values: HostTensorOwned { data: values, shape: vec![count, 1], storage: real },
+                ia: HostTensorOwned { data: ia, shape: vec![count, 1], storage: real },
+                ic: HostTensorOwned { data: ic, shape: vec![n, 1], storage: real },
+            })
+        })
+    }
+    fn ismember<'a>(&'a self, a: &'a GpuTensorHandle, b: &'a GpuTensorHandle, options: &'a IsMemberOptions) -> AccelProviderFuture<'a, IsMemberResult> {
+        Box::pin(async move {
+            if options.rows {
+                return Err(anyhow!("ismember: the 'rows' form is not served by this provider"));
+            }
+            let n: usize = a.shape.iter().product();
+            let (mut mask, mut loc) = (vec![0u8; n], vec![0.0f64; n]);
+            check(unsafe { rmhip_ismember(self.ctx, self.own(a)?, self.own(b)?, mask.as_mut_ptr(), loc.as_mut_ptr()) })?;
+            Ok(IsMemberResult {
+                mask: HostLogicalOwned { data: mask, shape: a.shape.clone() },
+                loc: HostTensorOwned { data: loc, shape: a.shape.clone(), storage: GpuTensorStorage::Real },
+            })
+        })
     }
     fn polyval(&self, coefficients: &GpuTensorHandle, points: &GpuTensorHandle, options: &ProviderPolyvalOptions) -> Result<GpuTensorHandle> {
         let mut out = 0u64;

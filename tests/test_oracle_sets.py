@@ -1,0 +1,46 @@
+"""The oracle's restatements of unique / ismember (elements) against the reference's own unit-test vectors (tests/golden/set_kats.json)
+and against numpy's set routines where they agree on the definition."""
+import json
+from pathlib import Path
+
+import numpy as np
+
+from oracle import oracle
+
+K = json.loads((Path(__file__).parent / "golden" / "set_kats.json").read_text())
+
+
+def arr(v):
+    return np.array([np.nan if e == "nan" else e for e in v], dtype=np.float64)
+
+
+def test_reference_kats():
+    for k in K["unique"]:
+        values, ia, ic = oracle.unique(arr(k["x"]), k["order"], k["occ"])
+        assert np.array_equal(values.ravel(), arr(k["values"]), equal_nan=True), k
+        if "ia" in k:
+            assert np.array_equal(ia.ravel(), k["ia"]) and np.array_equal(ic.ravel(), k["ic"]), k
+    for k in K["ismember"]:
+        mask, loc = oracle.ismember(arr(k["a"]), arr(k["b"]))
+        assert list(mask) == k["mask"] and list(loc) == k["loc"], k
+
+
+def test_against_numpy():
+    rng = np.random.default_rng(3)
+    x = rng.integers(-5, 6, size=(7, 9)).astype(np.float64)
+    values, ia, ic = oracle.unique(x)
+    u, first, inv = np.unique(x.ravel(order="F"), return_index=True, return_inverse=True)
+    assert np.array_equal(values.ravel(), u) and np.array_equal(ia.ravel(), first + 1) and np.array_equal(ic.ravel(), inv + 1)
+    z = np.array([-0.0, 0.0, np.nan, 1.0, np.nan, -0.0])
+    values, ia, ic = oracle.unique(z)
+    assert values.shape == (3, 1) and np.signbit(values[0, 0]) and np.isnan(values[2, 0]) and list(ia.ravel()) == [1, 4, 3] and list(ic.ravel()) == [1, 1, 3, 2, 3, 1]
+    assert list(oracle.unique(z, "stable", "last")[1].ravel()) == [6, 5, 4]
+    a, b = rng.integers(0, 8, size=(4, 5)).astype(np.float64), rng.integers(3, 12, size=11).astype(np.float64)
+    mask, loc = oracle.ismember(a, b)
+    assert np.array_equal(mask.astype(bool), np.isin(a, b)) and mask.shape == a.shape
+    for v, l in zip(a.ravel(), loc.ravel()):
+        assert (l == 0 and v not in b) or b[int(l) - 1] == v and v not in b[:int(l) - 1]
+    m2, l2 = oracle.ismember(np.array([np.nan, -0.0, 5.0]), np.array([1.0, 0.0, np.nan, np.nan]))
+    assert list(m2) == [1, 1, 0] and list(l2) == [3, 2, 0]
+    e = oracle.unique(np.zeros((0, 3)))
+    assert e[0].shape == (0, 1) and e[2].shape == (0, 1)
