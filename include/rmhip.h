@@ -481,7 +481,7 @@ RMHIP_API int rmhip_storage(rmhip_ctx* ctx, rmhip_buf id, int* complex_interleav
 /* `fft_dim(handle, len, dim)` / `ifft_dim` (lib.rs:2622-2638; semantics of the wgpu provider's host form, ops/fft/fallback.rs:4-150):
  * the DFT of every line along zero-based `dim` (a dimension beyond the rank has extent 1 and extends the shape), zero-padded or
  * truncated to `len_or_neg` points (< 0: the extent); forward unnormalised (exp(-2 pi i jk / n)), inverse scaled by 1 / n; real or
- * complex input; any length up to 2^24 (powers of two by LDS-resident radix-8 passes, others by Bluestein's chirp convolution).
+ * complex input; any length up to 2^24 (2^27 for a power of two along dimension 0; powers of two by LDS-resident radix-8 passes, others by Bluestein's chirp convolution).
  * Accuracy: error <= a small multiple of eps * log2(n) * ||line||_2 per point (tests/test_gpu_fft.py); the reference transforms
  * with rustfft 6.4.1, so parity is by that tolerance, not by bits. */
 /* @serves fft_dim ifft_dim */

@@ -479,7 +479,61 @@ int fft_pow2(Context* c, const Lines& L, u64 n, bool conj_in, bool conj_out, dou
         P.round32 = round32;
         return launch_pass(c, P);
     }
-    if (lg > 24) return fail(RMHIP_ERR_UNSUPPORTED, "fft: length %llu", n);
+    if (lg > (L.inner == 1 ? 27 : 24)) return fail(RMHIP_ERR_UNSUPPORTED, "fft: length %llu", n);
+    if (L.inner == 1 && lg >= 23) {  // measured crossover (scripts/fft_long_ab.py): 2^22 equal, 2^23 0.33 -> 0.22 ms, 2^24 0.78 -> 0.49 ms
+        // Two factors of a very long line pass 2048 and a tile holds one or two lines: the strided side of each pass moves 16- or 32-byte
+        // pieces (a 2^24-point vector: 0.80 ms).  Three passes instead, n = m1 m2 m3, k = k1 m2 m3 + k2 m3 + k3,
+        // j = j1 + m1 j2 + m1 m2 j3, every one reading and writing neighbouring lines:
+        //   (A) over k1 (stride m2 m3), lines (k', o), k' = k2 m3 + k3, times w_n^(j1 k')          -> T[o][j1][k']
+        //   (B) over k2 (stride m3),   lines (k3, j1, o),            times w_{m2 m3}^(j2 k3)       -> T[o][j1][j2][k3]   (in place)
+        //   (C) over k3 (contiguous),  lines (j1, j2, o)                                           -> y[o][j1 + m1 j2 + m1 m2 j3]
+        const int l1 = lg / 3, l2 = (lg - l1) / 2, l3 = lg - l1 - l2;
+        const u64 m1 = 1ull << l1, m2 = 1ull << l2, m3 = 1ull << l3, N1 = m2 * m3;
+        std::shared_ptr<Allocation> t;
+        RMHIP_TRY(c->alloc_device(2 * n * lines, &t));
+        Table slo, shi, rlo, rhi;
+        RMHIP_TRY(fft_table(c, 0, n, std::min<u64>(n, 1ull << STEP_LO), &slo));
+        RMHIP_TRY(fft_table(c, 1, n, std::max<u64>(1, n >> STEP_LO), &shi));
+        RMHIP_TRY(fft_table(c, 0, N1, std::min<u64>(N1, 1ull << STEP_LO), &rlo));
+        RMHIP_TRY(fft_table(c, 1, N1, std::max<u64>(1, N1 >> STEP_LO), &rhi));
+        {
+            FftPass P{};
+            P.nlines = lines * N1, P.inner = 1, P.qcnt = N1;
+            P.in = L.in, P.out = t->ptr, P.in_complex = L.in_complex;
+            P.a = Side{0, 1, L.len_in, N1};
+            P.b = Side{0, 1, n, N1};
+            P.in_pk = N1, P.in_qk = 1, P.in_len = in_len;
+            P.mul_in = mul_in;
+            P.step_lo = tptr(slo), P.step_hi = tptr(shi);
+            P.scale = 1.0, P.log2m = l1, P.mode = 1;
+            P.conj_in = conj_in;
+            RMHIP_TRY(launch_pass(c, P));
+        }
+        {
+            FftPass P{};
+            P.nlines = lines * m1 * m3, P.inner = m3, P.qcnt = m1;
+            P.in = t->ptr, P.out = t->ptr, P.in_complex = 1;
+            P.a = Side{1, N1, n, m3};
+            P.b = Side{1, N1, n, m3};
+            P.in_pk = 1, P.in_qk = 0, P.in_len = m2;
+            P.step_lo = tptr(rlo), P.step_hi = tptr(rhi), P.step_by_i = 1;
+            P.scale = 1.0, P.log2m = l2, P.mode = 1;
+            RMHIP_TRY(launch_pass(c, P));
+        }
+        {
+            FftPass P{};
+            P.nlines = lines * m1 * m2, P.inner = m1, P.qcnt = m2;
+            P.in = t->ptr, P.out = L.out, P.in_complex = 1;
+            P.a = Side{N1, m3, n, 1};
+            P.b = Side{1, m1, n, m1 * m2};
+            P.in_pk = 1, P.in_qk = 0, P.in_len = m3;
+            P.scale = scale, P.log2m = l3, P.mode = 2;
+            P.conj_out = conj_out;
+            P.round32 = round32;
+            RMHIP_TRY(launch_pass(c, P));
+        }
+        return RMHIP_OK;
+    }
     // n = m1 * m2: (1) length-m1 transforms over k1 of x[k1 * m2 + k2], times w_n^(j1 k2), into T[j1 * m2 + k2];
     //              (2) length-m2 transforms over k2 of T[j1 * m2 + k2] into y[j1 + m1 * j2]
     const int l1 = lg / 2, l2 = lg - l1;

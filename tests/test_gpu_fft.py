@@ -101,7 +101,7 @@ def test_other_lengths(prov, oracle, shape, dim, length):
 
 def test_round_trip_linearity_and_a_long_vector(prov):
     rng = np.random.default_rng(77)
-    for n in (1 << 20, 1 << 22, 1000003 // 7):
+    for n in (1 << 19, 1 << 20, 1 << 22, 1 << 25, 1000003 // 7, 300007):
         x, y = rng.standard_normal(n), rng.standard_normal(n)
         hx, hy = prov.upload(x), prov.upload(y)
         fx, fy = prov.fft_dim(hx, None, 0), prov.fft_dim(hy, None, 0)
