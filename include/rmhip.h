@@ -345,6 +345,17 @@ RMHIP_API int rmhip_find(rmhip_ctx* ctx, rmhip_buf a, long long limit_or_neg, in
  * sorted (key, position) pairs: bit-exact. */
 /* @serves unique */
 RMHIP_API int rmhip_unique(rmhip_ctx* ctx, rmhip_buf a, int stable, int last_occurrence, size_t* count, double* values_host, double* ia_host, double* ic_host);
+/* `union(a, b, options)` / `setdiff(a, b, options)` for elements (lib.rs:2652-2667; `UnionOptions` / `SetdiffOptions` with rows == false,
+ * :1126-1146, :1237-1254; union.rs:491-544, 1238-1279; setdiff.rs:463-496): union - the distinct values of a's elements followed by b's
+ * (first occurrences; sorted, or stable != 0: in order of appearance), ia the 1-based positions in a of the values first seen in a, ib
+ * those in b of the rest, both in output order; values_host needs numel(a) + numel(b) doubles, ia_host numel(a), ib_host numel(b).
+ * setdiff - a's distinct values that do not occur in b, with their first positions in a; numel(a) doubles each.  Host results, as
+ * `UnionResult` / `SetdiffResult`.  Bit-exact. */
+/* @serves union */
+RMHIP_API int rmhip_union(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, int stable, size_t* count, double* values_host, size_t* ia_count, double* ia_host,
+                          size_t* ib_count, double* ib_host);
+/* @serves setdiff */
+RMHIP_API int rmhip_setdiff(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, int stable, size_t* count, double* values_host, double* ia_host);
 /* `ismember(a, b, options)` for elements (lib.rs:2668-2675; `IsMemberOptions { rows: false }`, :1256-1274; ismember.rs:413-438):
  * mask_host[i] = 1 when a's element i occurs in b (NaN matches NaN, -0 matches +0), loc_host[i] = the 1-based lowest position in b or 0;
  * both in a's shape, numel(a) entries (`HostLogicalOwned` / `HostTensorOwned`). */

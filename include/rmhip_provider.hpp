@@ -654,6 +654,30 @@ public:
         r.values.shape = {count, 1}, r.ia.shape = {count, 1}, r.ic.shape = {n, 1};
         return r;
     }
+    struct UnionResult {  // lib.rs:1140-1146
+        HostTensorOwned values, ia, ib;
+    };
+    UnionResult set_union(const GpuTensorHandle& a, const GpuTensorHandle& b, bool stable) const {  // `union` is a keyword here
+        UnionResult r;
+        r.values.data.resize(a.numel() + b.numel()), r.ia.data.resize(a.numel()), r.ib.data.resize(b.numel());
+        size_t n = 0, na = 0, nb = 0;
+        check(rmhip_union(ctx_, own(a), own(b), stable ? 1 : 0, &n, r.values.data.data(), &na, r.ia.data.data(), &nb, r.ib.data.data()));
+        r.values.data.resize(n), r.ia.data.resize(na), r.ib.data.resize(nb);
+        r.values.shape = {n, 1}, r.ia.shape = {na, 1}, r.ib.shape = {nb, 1};
+        return r;
+    }
+    struct SetdiffResult {  // lib.rs:1249-1254
+        HostTensorOwned values, ia;
+    };
+    SetdiffResult setdiff(const GpuTensorHandle& a, const GpuTensorHandle& b, bool stable) const {
+        SetdiffResult r;
+        r.values.data.resize(a.numel()), r.ia.data.resize(a.numel());
+        size_t n = 0;
+        check(rmhip_setdiff(ctx_, own(a), own(b), stable ? 1 : 0, &n, r.values.data.data(), r.ia.data.data()));
+        r.values.data.resize(n), r.ia.data.resize(n);
+        r.values.shape = {n, 1}, r.ia.shape = {n, 1};
+        return r;
+    }
     struct IsMemberResult {  // lib.rs:1262-1274
         std::vector<unsigned char> mask;
         HostTensorOwned loc;

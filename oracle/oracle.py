@@ -794,6 +794,24 @@ def unique(x, order: str = "sorted", occurrence: str = "first"):
     return values, ia, ic
 
 
+def union(a, b, order: str = "sorted"):
+    """union_numeric_elements + assemble_numeric_union, union.rs:491-544, 1238-1279 -> (values, ia, ib), each [g, 1]."""
+    da, db = (np.asarray(v, dtype=np.float64).ravel(order="F") for v in (a, b))
+    values, first, _ = unique(np.concatenate([da, db]), order, "first")
+    first = first.ravel()
+    ia = first[first <= da.size]
+    ib = first[first > da.size] - da.size
+    return values, ia.reshape(-1, 1), ib.reshape(-1, 1)
+
+
+def setdiff(a, b, order: str = "sorted"):
+    """setdiff_numeric_elements, setdiff.rs:463-496 -> (values, ia)."""
+    values, ia, _ = unique(a, order, "first")
+    mask, _ = ismember(values.ravel(), np.asarray(b, dtype=np.float64).ravel(order="F")) if values.size else (np.zeros(0, dtype=np.uint8), None)
+    keep = mask == 0
+    return values.ravel()[keep].reshape(-1, 1), ia.ravel()[keep].reshape(-1, 1)
+
+
 def ismember(a, b):
     """ismember_numeric_elements, ismember.rs:413-438 -> (mask uint8, loc) in a's shape."""
     a = np.asarray(a, dtype=np.float64)

@@ -1085,20 +1085,21 @@ int rmhip_find(rmhip_ctx* ctx, rmhip_buf a, long long limit_or_neg, int last, rm
     return rc;
 }
 
-int rmhip_unique(rmhip_ctx* ctx, rmhip_buf a, int stable, int last_occurrence, size_t* count, double* values_host, double* ia_host, double* ic_host) {
-    CTX_OR_FAIL(ctx);
-    if (!count) return fail(RMHIP_ERR_INVALID, "unique: null count");
-    Buffer ab;
-    RMHIP_TRY(c->get(a, &ab));
-    const u64 n = ab.numel;
-    *count = 0;
-    if (n == 0) return RMHIP_OK;
-    if (!values_host || !ia_host || !ic_host) return fail(RMHIP_ERR_INVALID, "unique: null output");
+namespace rmhip {
+namespace {
+struct UniqueDev {
+    std::shared_ptr<Allocation> outs;  // values | ia | ic
+    double *dv = nullptr, *dia = nullptr, *dic = nullptr;
+    u64 groups = 0;
+};
+
+// the distinct values of x[0 .. n) (n > 0) with their first / last positions and the inverse map, left on the device
+int unique_device(Context* c, const double* x, u64 n, int stable, int last_occurrence, UniqueDev* r) {
     SortSpace ws;
-    RMHIP_TRY(sort_lines(c, ab.data(), Lines{1, n, 1}, 0, 0, &ws));
+    RMHIP_TRY(sort_lines(c, x, Lines{1, n, 1}, 0, 0, &ws));
     const u64 nchunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
     // u32 work arrays: flags n | gid n | first n | last n | rank n | counts nchunks | offsets nchunks | total 2
-    std::shared_ptr<Allocation> wk, outs;
+    std::shared_ptr<Allocation> wk;
     RMHIP_TRY(c->alloc_device((5 * n + 2 * nchunks + 2 + 1) / 2 + 1, &wk));
     u32* flags = (u32*)wk->ptr;
     u32 *gid = flags + n, *first_pos = gid + n, *last_pos = first_pos + n, *rank_of = last_pos + n, *counts = rank_of + n, *offsets = counts + nchunks, *total = offsets + nchunks;
@@ -1111,8 +1112,8 @@ int rmhip_unique(rmhip_ctx* ctx, rmhip_buf a, int stable, int last_occurrence, s
     RMHIP_HIP_CHECK(hipMemcpyAsync(&groups32, total, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));  // the outputs' size is part of the answer
     const u64 groups = groups32;
-    RMHIP_TRY(c->alloc_device(2 * groups + n, &outs));  // values | ia | ic
-    double *dv = outs->ptr, *dia = dv + groups, *dic = dia + groups;
+    RMHIP_TRY(c->alloc_device(2 * groups + n, &r->outs));
+    r->dv = r->outs->ptr, r->dia = r->dv + groups, r->dic = r->dia + groups, r->groups = groups;
     const u32* order = nullptr;
     SortSpace ws2;
     std::shared_ptr<Allocation> fp;
@@ -1123,17 +1124,105 @@ int rmhip_unique(rmhip_ctx* ctx, rmhip_buf a, int stable, int last_occurrence, s
         RMHIP_TRY(sort_lines(c, fp->ptr, Lines{1, groups, 1}, 0, 0, &ws2));
         order = ws2.pos;
     }
-    hipLaunchKernelGGL(k_unique_outputs, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, c->stream, ab.data(), order, first_pos, last_pos, groups, last_occurrence ? 1 : 0,
-                       dv, dia, rank_of);
-    hipLaunchKernelGGL(k_unique_inverse, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, ws.pos, gid, rank_of, n, dic);
+    hipLaunchKernelGGL(k_unique_outputs, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, c->stream, x, order, first_pos, last_pos, groups, last_occurrence ? 1 : 0, r->dv,
+                       r->dia, rank_of);
+    hipLaunchKernelGGL(k_unique_inverse, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, ws.pos, gid, rank_of, n, r->dic);
     c->tel.kernel_launches += 2;
     RMHIP_HIP_CHECK(hipGetLastError());
-    RMHIP_HIP_CHECK(hipMemcpyAsync(values_host, dv, groups * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    RMHIP_HIP_CHECK(hipMemcpyAsync(ia_host, dia, groups * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    RMHIP_HIP_CHECK(hipMemcpyAsync(ic_host, dic, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));  // (the work arrays above are released on return)
+    return RMHIP_OK;
+}
+}  // namespace
+}  // namespace rmhip
+
+int rmhip_unique(rmhip_ctx* ctx, rmhip_buf a, int stable, int last_occurrence, size_t* count, double* values_host, double* ia_host, double* ic_host) {
+    CTX_OR_FAIL(ctx);
+    if (!count) return fail(RMHIP_ERR_INVALID, "unique: null count");
+    Buffer ab;
+    RMHIP_TRY(c->get(a, &ab));
+    const u64 n = ab.numel;
+    *count = 0;
+    if (n == 0) return RMHIP_OK;
+    if (!values_host || !ia_host || !ic_host) return fail(RMHIP_ERR_INVALID, "unique: null output");
+    UniqueDev r;
+    RMHIP_TRY(unique_device(c, ab.data(), n, stable, last_occurrence, &r));
+    RMHIP_HIP_CHECK(hipMemcpyAsync(values_host, r.dv, r.groups * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipMemcpyAsync(ia_host, r.dia, r.groups * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipMemcpyAsync(ic_host, r.dic, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
-    c->tel.download_bytes += (2 * groups + n) * sizeof(double);
-    *count = groups;
+    c->tel.download_bytes += (2 * r.groups + n) * sizeof(double);
+    *count = r.groups;
+    return RMHIP_OK;
+}
+
+int rmhip_union(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, int stable, size_t* count, double* values_host, size_t* ia_count, double* ia_host, size_t* ib_count,
+                double* ib_host) {
+    CTX_OR_FAIL(ctx);
+    if (!count || !ia_count || !ib_count) return fail(RMHIP_ERR_INVALID, "union: null count");
+    Buffer ab, bb;
+    RMHIP_TRY(c->get(a, &ab));
+    RMHIP_TRY(c->get(b, &bb));
+    const u64 na = ab.numel, nb = bb.numel, n = na + nb;
+    *count = *ia_count = *ib_count = 0;
+    if (n == 0) return RMHIP_OK;
+    if (!values_host || (na && !ia_host) || (nb && !ib_host)) return fail(RMHIP_ERR_INVALID, "union: null output");
+    // union.rs:491-544 + 1238-1279: the CPU's map over a's elements, then b's, is `unique` of the two in sequence, first occurrences;
+    // a value whose first occurrence lies in a reports that position in ia, the others their position in b in ib - both in output order
+    std::shared_ptr<Allocation> cat;
+    RMHIP_TRY(c->alloc_device(n, &cat));
+    if (na) RMHIP_HIP_CHECK(hipMemcpyAsync(cat->ptr, ab.data(), na * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (nb) RMHIP_HIP_CHECK(hipMemcpyAsync(cat->ptr + na, bb.data(), nb * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    UniqueDev r;
+    RMHIP_TRY(unique_device(c, cat->ptr, n, stable, 0, &r));
+    std::vector<double> first(r.groups);
+    RMHIP_HIP_CHECK(hipMemcpyAsync(values_host, r.dv, r.groups * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipMemcpyAsync(first.data(), r.dia, r.groups * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    size_t ia = 0, ib = 0;
+    for (u64 g = 0; g < r.groups; ++g) {
+        if (first[g] <= (double)na) ia_host[ia++] = first[g];
+        else ib_host[ib++] = first[g] - (double)na;
+    }
+    c->tel.download_bytes += 2 * r.groups * sizeof(double);
+    *count = r.groups, *ia_count = ia, *ib_count = ib;
+    return RMHIP_OK;
+}
+
+int rmhip_setdiff(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, int stable, size_t* count, double* values_host, double* ia_host) {
+    CTX_OR_FAIL(ctx);
+    if (!count) return fail(RMHIP_ERR_INVALID, "setdiff: null count");
+    Buffer ab, bb;
+    RMHIP_TRY(c->get(a, &ab));
+    RMHIP_TRY(c->get(b, &bb));
+    const u64 na = ab.numel, nb = bb.numel;
+    *count = 0;
+    if (na == 0) return RMHIP_OK;
+    if (!values_host || !ia_host) return fail(RMHIP_ERR_INVALID, "setdiff: null output");
+    // setdiff.rs:463-496: a's distinct values (first occurrences, in the requested order) whose key does not occur in b
+    UniqueDev r;
+    RMHIP_TRY(unique_device(c, ab.data(), na, stable, 0, &r));
+    std::vector<double> v(r.groups), first(r.groups);
+    std::vector<unsigned char> hit(r.groups, 0);
+    if (nb) {
+        SortSpace ws;
+        RMHIP_TRY(sort_lines(c, bb.data(), Lines{1, nb, 1}, 0, 0, &ws));
+        std::shared_ptr<Allocation> m;
+        RMHIP_TRY(c->alloc_device(r.groups + (r.groups + 7) / 8, &m));
+        unsigned char* dmask = (unsigned char*)(m->ptr + r.groups);
+        hipLaunchKernelGGL(k_ismember, dim3((unsigned)((r.groups + 255) / 256)), dim3(256), 0, c->stream, r.dv, r.groups, ws.keys, ws.pos, nb, dmask, m->ptr);
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+        RMHIP_HIP_CHECK(hipMemcpyAsync(hit.data(), dmask, r.groups, hipMemcpyDeviceToHost, c->stream));
+        RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    RMHIP_HIP_CHECK(hipMemcpyAsync(v.data(), r.dv, r.groups * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipMemcpyAsync(first.data(), r.dia, r.groups * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    size_t kept = 0;
+    for (u64 g = 0; g < r.groups; ++g)
+        if (!hit[g]) values_host[kept] = v[g], ia_host[kept] = first[g], ++kept;
+    c->tel.download_bytes += 2 * r.groups * sizeof(double);
+    *count = kept;
     return RMHIP_OK;
 }
 

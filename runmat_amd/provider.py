@@ -1059,6 +1059,33 @@ class HipProvider:
         g = count.value
         return values[:g].reshape(g, 1).copy(), ia[:g].reshape(g, 1).copy(), ic[:n].reshape(n, 1).copy()
 
+    def union(self, a, b, rows: bool = False, order: str = "sorted"):
+        """lib.rs:2652-2659 -> `UnionResult { values, ia, ib }` as host arrays ([g, 1] each)."""
+        if rows:
+            raise ProviderError(_lib.ERR_UNSUPPORTED, "union: the 'rows' form is not served")
+        if order not in ("sorted", "stable"):
+            raise RmhipError(1, f"union: order {order!r}")
+        na, nb = (int(np.prod(h.shape, dtype=np.int64)) if len(h.shape) else 1 for h in (a, b))
+        values, ia, ib = np.empty(max(na + nb, 1)), np.empty(max(na, 1)), np.empty(max(nb, 1))
+        cnt, ca, cb = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        ptr = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+        self._check(self._lib.rmhip_union(self._ctx, self._id(a), self._id(b), 1 if order == "stable" else 0, C.byref(cnt), ptr(values), C.byref(ca), ptr(ia),
+                                          C.byref(cb), ptr(ib)))
+        return values[:cnt.value].reshape(-1, 1).copy(), ia[:ca.value].reshape(-1, 1).copy(), ib[:cb.value].reshape(-1, 1).copy()
+
+    def setdiff(self, a, b, rows: bool = False, order: str = "sorted"):
+        """lib.rs:2660-2667 -> `SetdiffResult { values, ia }` as host arrays."""
+        if rows:
+            raise ProviderError(_lib.ERR_UNSUPPORTED, "setdiff: the 'rows' form is not served")
+        if order not in ("sorted", "stable"):
+            raise RmhipError(1, f"setdiff: order {order!r}")
+        na = int(np.prod(a.shape, dtype=np.int64)) if len(a.shape) else 1
+        values, ia = np.empty(max(na, 1)), np.empty(max(na, 1))
+        cnt = C.c_size_t()
+        ptr = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+        self._check(self._lib.rmhip_setdiff(self._ctx, self._id(a), self._id(b), 1 if order == "stable" else 0, C.byref(cnt), ptr(values), ptr(ia)))
+        return values[:cnt.value].reshape(-1, 1).copy(), ia[:cnt.value].reshape(-1, 1).copy()
+
     def ismember(self, a, b, rows: bool = False):
         """lib.rs `ismember` -> `IsMemberResult { mask, loc }` as host arrays in a's shape (mask: uint8)."""
         if rows:

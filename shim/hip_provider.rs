@@ -15,7 +15,7 @@
 use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle, GpuTensorStorage,
-    HostLogicalOwned, HostTensorOwned, HostTensorView, IsMemberOptions, IsMemberResult, UniqueOccurrence, UniqueOptions, UniqueOrder, UniqueResult, ImageNormalizeDescriptor, KernelAttrTelemetry, MeshgridAxisView, ProviderMeshgridResult, ProviderPolyvalOptions, KernelLaunchTelemetry, MatmulEpilogue,
+    HostLogicalOwned, HostTensorOwned, HostTensorView, IsMemberOptions, IsMemberResult, SetdiffOptions, SetdiffOrder, SetdiffResult, UnionOptions, UnionOrder, UnionResult, UniqueOccurrence, UniqueOptions, UniqueOrder, UniqueResult, ImageNormalizeDescriptor, KernelAttrTelemetry, MeshgridAxisView, ProviderMeshgridResult, ProviderPolyvalOptions, KernelLaunchTelemetry, MatmulEpilogue,
     PowerStepEpilogue, ProviderBandwidth, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderMovingWindowEndpoints, ProviderMovingWindowOp, ProviderMovingWindowRequest, ProviderNanMode, ProviderNdgridRequest, ProviderNormOrder, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
     ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult,
@@ -701,6 +701,48 @@ impl AccelProvider for HipProvider {
                 values: HostTensorOwned { data: values, shape: vec![count, 1], storage: real },
                 ia: HostTensorOwned { data: ia, shape: vec![count, 1], storage: real },
                 ic: HostTensorOwned { data: ic, shape: vec![n, 1], storage: real },
+            })
+        })
+    }
+    fn union<'a>(&'a self, a: &'a GpuTensorHandle, b: &'a GpuTensorHandle, options: &'a UnionOptions) -> AccelProviderFuture<'a, UnionResult> {
+        Box::pin(async move {
+            if options.rows {
+                return Err(anyhow!("union: the 'rows' form is not served by this provider"));
+            }
+            let (na, nb): (usize, usize) = (a.shape.iter().product(), b.shape.iter().product());
+            let (mut values, mut ia, mut ib) = (vec![0.0f64; na + nb], vec![0.0f64; na], vec![0.0f64; nb]);
+            let (mut n, mut ca, mut cb) = (0usize, 0usize, 0usize);
+            let stable = matches!(options.order, UnionOrder::Stable) as c_int;
+            check(unsafe {
+                rmhip_union(self.ctx, self.own(a)?, self.own(b)?, stable, &mut n, values.as_mut_ptr(), &mut ca, ia.as_mut_ptr(), &mut cb, ib.as_mut_ptr())
+            })?;
+            values.truncate(n);
+            ia.truncate(ca);
+            ib.truncate(cb);
+            let real = GpuTensorStorage::Real;
+            Ok(UnionResult {
+                values: HostTensorOwned { data: values, shape: vec![n, 1], storage: real },
+                ia: HostTensorOwned { data: ia, shape: vec![ca, 1], storage: real },
+                ib: HostTensorOwned { data: ib, shape: vec![cb, 1], storage: real },
+            })
+        })
+    }
+    fn setdiff<'a>(&'a self, a: &'a GpuTensorHandle, b: &'a GpuTensorHandle, options: &'a SetdiffOptions) -> AccelProviderFuture<'a, SetdiffResult> {
+        Box::pin(async move {
+            if options.rows {
+                return Err(anyhow!("setdiff: the 'rows' form is not served by this provider"));
+            }
+            let na: usize = a.shape.iter().product();
+            let (mut values, mut ia) = (vec![0.0f64; na], vec![0.0f64; na]);
+            let mut n = 0usize;
+            let stable = matches!(options.order, SetdiffOrder::Stable) as c_int;
+            check(unsafe { rmhip_setdiff(self.ctx, self.own(a)?, self.own(b)?, stable, &mut n, values.as_mut_ptr(), ia.as_mut_ptr()) })?;
+            values.truncate(n);
+            ia.truncate(n);
+            let real = GpuTensorStorage::Real;
+            Ok(SetdiffResult {
+                values: HostTensorOwned { data: values, shape: vec![n, 1], storage: real },
+                ia: HostTensorOwned { data: ia, shape: vec![n, 1], storage: real },
             })
         })
     }

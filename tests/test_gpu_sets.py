@@ -26,6 +26,12 @@ def test_reference_kats(prov):
         assert np.array_equal(values.ravel(), arr(k["values"]), equal_nan=True), k
         if "ia" in k:
             assert list(ia.ravel()) == k["ia"] and list(ic.ravel()) == k["ic"], k
+    for k in K["union"]:
+        values, ia, ib = prov.union(prov.upload(arr(k["a"]).reshape(-1, 1)), prov.upload(arr(k["b"]).reshape(-1, 1)), order=k["order"])
+        assert np.array_equal(values.ravel(), arr(k["values"]), equal_nan=True) and list(ia.ravel()) == k["ia"] and list(ib.ravel()) == k["ib"], k
+    for k in K["setdiff"]:
+        values, ia = prov.setdiff(prov.upload(arr(k["a"]).reshape(-1, 1)), prov.upload(arr(k["b"]).reshape(-1, 1)), order=k["order"])
+        assert np.array_equal(values.ravel(), arr(k["values"]), equal_nan=True) and list(ia.ravel()) == k["ia"], k
     for k in K["ismember"]:
         mask, loc = prov.ismember(prov.upload(arr(k["a"]).reshape(1, -1)), prov.upload(arr(k["b"]).reshape(1, -1)))
         assert list(mask.ravel()) == k["mask"] and list(loc.ravel()) == k["loc"], k
@@ -87,3 +93,21 @@ def test_unique_at_baseline_size(prov):
     first = np.full(1000, x.size, dtype=np.int64)
     np.minimum.at(first, x.astype(np.int64), np.arange(x.size))
     assert np.array_equal(ia.ravel(), first + 1.0)
+
+
+@pytest.mark.parametrize("na,nb,span", [(1, 1, 2), (40, 25, 30), (3000, 5000, 800), (70000, 1000, 100000), (5, 0, 3), (0, 5, 3), (0, 0, 1)], ids=str)
+def test_union_and_setdiff(prov, oracle, na, nb, span):
+    rng = np.random.default_rng(na + 3 * nb)
+    a, b = rng.integers(-span, span, size=na).astype(np.float64), rng.integers(-span // 2, 2 * span, size=nb).astype(np.float64)
+    for v in (a, b):
+        if v.size > 6:
+            v[rng.integers(0, v.size, size=2)] = np.nan
+            v[rng.integers(0, v.size)] = -0.0
+    ha, hb = prov.upload(a.reshape(-1, 1)), prov.upload(b.reshape(1, -1))
+    for order in ("sorted", "stable"):
+        for got, want in ((prov.union(ha, hb, order=order), oracle.union(a, b, order)), (prov.setdiff(ha, hb, order=order), oracle.setdiff(a, b, order))):
+            assert len(got) == len(want)
+            for g, w in zip(got, want):
+                assert same_bits(g, w), (order, g.shape, w.shape)
+    with pytest.raises(Exception):
+        prov.union(ha, hb, rows=True)

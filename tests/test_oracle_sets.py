@@ -20,6 +20,12 @@ def test_reference_kats():
         assert np.array_equal(values.ravel(), arr(k["values"]), equal_nan=True), k
         if "ia" in k:
             assert np.array_equal(ia.ravel(), k["ia"]) and np.array_equal(ic.ravel(), k["ic"]), k
+    for k in K["union"]:
+        values, ia, ib = oracle.union(arr(k["a"]), arr(k["b"]), k["order"])
+        assert np.array_equal(values.ravel(), arr(k["values"]), equal_nan=True) and list(ia.ravel()) == k["ia"] and list(ib.ravel()) == k["ib"], k
+    for k in K["setdiff"]:
+        values, ia = oracle.setdiff(arr(k["a"]), arr(k["b"]), k["order"])
+        assert np.array_equal(values.ravel(), arr(k["values"]), equal_nan=True) and list(ia.ravel()) == k["ia"], k
     for k in K["ismember"]:
         mask, loc = oracle.ismember(arr(k["a"]), arr(k["b"]))
         assert list(mask) == k["mask"] and list(loc) == k["loc"], k
@@ -42,5 +48,7 @@ def test_against_numpy():
         assert (l == 0 and v not in b) or b[int(l) - 1] == v and v not in b[:int(l) - 1]
     m2, l2 = oracle.ismember(np.array([np.nan, -0.0, 5.0]), np.array([1.0, 0.0, np.nan, np.nan]))
     assert list(m2) == [1, 1, 0] and list(l2) == [3, 2, 0]
+    p, q = rng.integers(0, 30, size=40).astype(np.float64), rng.integers(10, 50, size=25).astype(np.float64)
+    assert np.array_equal(oracle.union(p, q)[0].ravel(), np.union1d(p, q)) and np.array_equal(oracle.setdiff(p, q)[0].ravel(), np.setdiff1d(p, q))
     e = oracle.unique(np.zeros((0, 3)))
     assert e[0].shape == (0, 1) and e[2].shape == (0, 1)
