@@ -107,6 +107,20 @@ def cpu_baseline_fused(budget_s: float = 12.0):
                       f"orc_sin_mul_add, {t_total:.1f} s"}
 
 
+def cpu_baseline_fft():
+    """The oracle transforms by DIRECT evaluation of the DFT in long double (a definition, not an algorithm: O(n^2) per line) - timed on a
+    few 2048-point lines and reported in the workload's unit on its 24 B per input element; not a statement about CPU FFT libraries."""
+    from oracle import oracle
+
+    lines, m = 4, 2048
+    x = oracle.fill_uniform(41, -1.0, 1.0, lines * m).reshape(m, lines, order="F")
+    t0 = time.perf_counter()
+    oracle.fft_dim(x, None, 0)
+    dt = time.perf_counter() - t0
+    return {"value": round(24.0 * lines * m / dt / 1e9, 6), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"{lines} lines of {m} points, oracle/oracle.c orc_dft_dim (direct O(n^2) sums in long double), {dt:.1f} s"}
+
+
 def cpu_baseline_dgemm():
     """Naive column-major triple loop (linalg.rs:6-32) at two sizes; the 8192^3 figure is the n^3 extrapolation the
     survey planned, labelled as such."""
@@ -216,7 +230,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["fused", "dgemm", "mc", "mldivide", "chain", "mc_evolved", "image", "fused_f32", "sgemm", "bcast"], default="fused")
+    ap.add_argument("--workload", choices=["fused", "dgemm", "mc", "mldivide", "chain", "mc_evolved", "image", "fused_f32", "sgemm", "bcast", "fft"], default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     args = ap.parse_args()
@@ -707,6 +721,41 @@ def main() -> None:
                                  kernel="k_bcast2<double, mul> (both operands stride-0 views: write-only traffic)", kernel_ms=round(kern_ms, 5)),
         }
 
+    def fft_record(steps, warmup):
+        """fft(X) of the 8192 x 8192 real operand along its columns (widened surface: lib.rs:2622, fft.hip): every line one pass over HBM -
+        the 8 B/element input read once, the 16 B/element complex result written once."""
+        h = prov.fill_uniform(41 + rank, -1.0, 1.0, (n, n))
+
+        def step():
+            prov.free(prov.fft_dim(h, None, 0))
+
+        for _ in range(warmup):
+            step()
+        prov.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        prov.synchronize()
+        barrier()
+        wall = max_over_ranks(time.perf_counter() - t0)
+        ms = wall / steps * 1e3
+        prov.timer_begin()
+        for _ in range(steps):
+            step()
+        kern_ms = max_over_ranks(prov.timer_end() / steps)
+        prov.free(h)
+        nbytes = 24 * n * n
+        return {
+            "metric": "fft GB/s (fft(X, [], 1) of an 8192x8192 real f64 matrix, complex-interleaved result)",
+            "value": round(world * nbytes / (ms * 1e-3) / 1e9, 2), "unit": "GB/s", "ms_per_step": round(ms, 5), "scaling": "weak", "dtype": "f64",
+            "config": {"workload": "fft_dim along dimension 0 of 8192x8192 f64 (8192-point lines, one workgroup per line)", "bytes_per_step_per_gpu": nbytes,
+                       "flops_per_step": 5.0 * n * n * 13, "parallelism": f"independent x{world}"},
+            "roofline": roofline("hbm", nbytes / (kern_ms * 1e-3) / 1e9, traffic=pmc_traffic("fft", "k_fft_tile"), traffic_source=PMC_TRAFFIC_SOURCE,
+                                 kernel="k_fft_tile<1024> (Stockham radix-8 passes in LDS; first pass loads, last pass stores)",
+                                 kernel_ms=round(kern_ms, 5)),
+        }
+
     def fused_f32_record(steps, warmup):
         # SURVEY.md 8(f) row 2: the same request on a precision-32 provider (f32 in HBM, f64 arithmetic in registers)
         p32 = HipProvider(local_rank, precision="F32")
@@ -811,7 +860,7 @@ def main() -> None:
         return rec
 
     records = {"sgemm": sgemm_record, "fused_f32": fused_f32_record, "fused": fused_record, "dgemm": dgemm_record, "mc": mc_record, "mldivide": mldivide_record,
-               "chain": chain_record, "mc_evolved": mc_evolved_record, "image": image_record, "bcast": bcast_record}
+               "chain": chain_record, "mc_evolved": mc_evolved_record, "image": image_record, "bcast": bcast_record, "fft": fft_record}
     primary = records[args.workload]
     rec = safe_record(args.workload, primary, args.steps, args.warmup)
     if "error" in rec:  # the line still comes out, with the reason where the number would be
@@ -840,14 +889,14 @@ def main() -> None:
     out["comm"] = comm
     if not args.no_also:
         # the other configs of BASELINE.json, short runs; every rank takes part (collectives inside)
-        others = [w for w in ("fused", "dgemm", "mc", "mc_evolved", "image", "chain", "bcast", "fused_f32", "sgemm") if w != args.workload]
+        others = [w for w in ("fused", "dgemm", "mc", "mc_evolved", "image", "chain", "bcast", "fft", "fused_f32", "sgemm") if w != args.workload]
         if args.workload != "mldivide":
             others.append("mldivide")  # one GPU: rmhip_mldivide; N > 1: the block-column cyclic driver (BASELINE configs[4])
         also = []
         for w in others:
             # enough steps that the two synchronisations around the timed region (~1 ms together) stay below 1 % of it: a 20-step run
             # of the 0.65 ms image workload read 0.73 ms per step
-            steps = {"fused": 200, "dgemm": 10, "mc": 200, "mc_evolved": 100, "image": 200, "mldivide": 3, "chain": 2000, "fused_f32": 200, "sgemm": 10, "bcast": 500}[w]
+            steps = {"fused": 200, "dgemm": 10, "mc": 200, "mc_evolved": 100, "image": 200, "mldivide": 3, "chain": 2000, "fused_f32": 200, "sgemm": 10, "bcast": 500, "fft": 100}[w]
             sec = safe_record(w, records[w], steps, 5 if w != "mldivide" else 1)
             if "error" in sec:
                 also.append(sec)
@@ -859,7 +908,7 @@ def main() -> None:
         out["cpu_baseline"] = {"fused": cpu_baseline_fused, "dgemm": cpu_baseline_dgemm, "mc": cpu_baseline_mc,
                                "mldivide": cpu_baseline_mldivide, "chain": cpu_baseline_chain,
                                "mc_evolved": cpu_baseline_mc, "image": cpu_baseline_fused,
-                               "fused_f32": cpu_baseline_fused, "sgemm": cpu_baseline_dgemm, "bcast": cpu_baseline_fused}[args.workload]()
+                               "fused_f32": cpu_baseline_fused, "sgemm": cpu_baseline_dgemm, "bcast": cpu_baseline_fused, "fft": cpu_baseline_fft}[args.workload]()
         for a in out.get("also", []):
             if "error" in a:
                 continue

@@ -6,7 +6,7 @@ import collections, csv, glob, json, sys
 
 out = sys.argv[1]
 workloads = sys.argv[2:]
-LEGS = {"fused": 2, "dgemm": 2, "sgemm": 2, "fused_f32": 2, "chain": 2, "bcast": 2}  # workloads whose record runs its steps twice (wall-clock leg + HIP-event leg)
+LEGS = {"fused": 2, "dgemm": 2, "sgemm": 2, "fused_f32": 2, "chain": 2, "bcast": 2, "fft": 2}  # workloads whose record runs its steps twice (wall-clock leg + HIP-event leg)
 SETUP = ("k_fill", "k_probe_xcc", "__amd_rocclr", "k_narrow", "k_widen")  # not part of a step
 SETUP_BY_WORKLOAD = {"mldivide": ("k_fill", "k_probe_xcc", "__amd_rocclr_fillBuffer", "__amd_rocclr_copyBuffer(", "__amd_rocclr_copyBufferAligned")}  # the rect copy of A into the padded workspace IS part of a solve
 
@@ -52,7 +52,7 @@ for w in workloads:
         summary.append(rec)
         if not any(k.startswith(s) or s in k[:40] for s in SETUP_BY_WORKLOAD.get(w, SETUP)):
             total += bytes_per * n
-        short = k.split("(")[0].replace("void rmhip::", "").replace("rmhip::", "")
+        short = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void rmhip::", "").replace("rmhip::", "")
         traffic.setdefault(w, {})[short[:80]] = round(bytes_per)
     if steps:
         traffic.setdefault(w, {})["_bytes_per_step"] = round(total / steps)

@@ -11,7 +11,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-WORKLOADS=${*:-fused dgemm mc mc_evolved image chain bcast fused_f32 sgemm mldivide reductions}
+WORKLOADS=${*:-fused dgemm mc mc_evolved image chain bcast fft fused_f32 sgemm mldivide reductions}
 for W in $WORKLOADS; do
   case $W in
     reductions) CMD="python $ROOT/scripts/red_driver.py 6" ;;

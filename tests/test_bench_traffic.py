@@ -18,7 +18,7 @@ def _bench():
 def test_every_bench_workload_has_measured_traffic():
     b = _bench()
     for w, k in (("fused", "rm_ew_fast"), ("dgemm", "k_dgemm_w8"), ("mc", None), ("mc_evolved", None), ("image", None), ("mldivide", None),
-                 ("chain", "rm_ew_fast"), ("fused_f32", "rm_ew_fast"), ("sgemm", "k_sgemm_w8"), ("bcast", "k_bcast2")):
+                 ("chain", "rm_ew_fast"), ("fused_f32", "rm_ew_fast"), ("sgemm", "k_sgemm_w8"), ("bcast", "k_bcast2"), ("fft", "k_fft_tile")):
         v = b.pmc_traffic(w, k)
         assert isinstance(v, int) and v > 0, (w, k)
     assert '"traffic": None' not in (ROOT / "bench.py").read_text()
@@ -30,6 +30,7 @@ def test_streaming_kernels_move_their_algorithmic_bytes():
     assert abs(t["fused"]["rm_ew_fast"] / (32 * n) - 1) < 0.02          # three reads + one write of 8192^2 f64
     assert abs(t["fused_f32"]["rm_ew_fast"] / (16 * n) - 1) < 0.02      # the same in f32 storage
     assert abs([v for k, v in t["bcast"].items() if k.startswith("k_bcast2")][0] / (8 * n) - 1) < 0.02  # repmat views: only the product is written
+    assert abs([v for k, v in t["fft"].items() if k.startswith("k_fft_tile")][0] / (24 * n) - 1) < 0.02  # one pass: 8 B read + 16 B written per element
     assert abs(t["mc"]["k_rng_normal<double>"] / 8e8 - 1) < 0.02        # 1e8 normals written once
     assert abs(t["mc"]["_bytes_per_step"] / (40 * 1e8) - 1) < 0.25      # (32 T + 8) M, T = 1: generator + update + payoff sum
     frames = 16 * 2160 * 3840 * 8
