@@ -39,6 +39,7 @@ namespace {
 typedef unsigned long long u64;
 constexpr int FT = 256;         // threads per workgroup of the small elementwise kernels
 constexpr int TILE = 4096;      // complex points per workgroup (512 threads, two workgroups per CU) ...
+constexpr int TILE_SMALL = 2048;  // ... half of that for lines of up to 2048 points (256 threads, four per CU) ...
 constexpr int TILE_BIG = 8192;  // ... or a whole 8192-point line (1024 threads, one workgroup per CU: 132 KiB of LDS)
 constexpr int MAXB = 256;       // lines per workgroup
 constexpr u64 NOLINE = ~0ull;
@@ -434,7 +435,10 @@ int launch_pass(Context* c, FftPass& P) {
     set_radices(P);
     const int m = 1 << P.log2m;
     int lb = 0;
-    while (((size_t)m << (lb + 1)) <= (size_t)TILE && (1 << (lb + 1)) <= MAXB && (1ull << lb) < P.nlines) ++lb;
+    // lines of up to 2048 points take half-size tiles (256 threads, 37 KiB: four workgroups per CU instead of two - the same threads per CU
+    // in more independent phases: 3-7 % on every shape measured), unless that would leave fewer than eight neighbouring lines to a tile
+    const size_t cap = (size_t)m <= (size_t)TILE_SMALL && (P.mode == 0 || (size_t)m * 8 <= (size_t)TILE_SMALL) ? (size_t)TILE_SMALL : (size_t)TILE;
+    while (((size_t)m << (lb + 1)) <= cap && (1 << (lb + 1)) <= MAXB && (1ull << lb) < P.nlines) ++lb;
     P.log2b = lb;
     Table tw;
     RMHIP_TRY(fft_table(c, 0, (u64)m, (u64)m, &tw));
@@ -443,6 +447,7 @@ int launch_pass(Context* c, FftPass& P) {
     if (blocks > 0x7fffffffull) return fail(RMHIP_ERR_UNSUPPORTED, "fft: %llu lines", P.nlines);
     const size_t tile = (size_t)m << lb, lds = (2 * (tile + (tile >> 3) + 1) + 2 * ((size_t)1 << lb)) * sizeof(double) + 2 * ((size_t)1 << lb) * sizeof(unsigned);
     if (tile > (size_t)TILE) hipLaunchKernelGGL(k_fft_tile<1024>, dim3((unsigned)blocks), dim3(1024), lds, c->stream, P);
+    else if (tile <= (size_t)TILE_SMALL) hipLaunchKernelGGL(k_fft_tile<256>, dim3((unsigned)blocks), dim3(256), lds, c->stream, P);
     else hipLaunchKernelGGL(k_fft_tile<512>, dim3((unsigned)blocks), dim3(512), lds, c->stream, P);
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
