@@ -470,6 +470,14 @@ RMHIP_API int rmhip_conv2d(rmhip_ctx* ctx, rmhip_buf signal, rmhip_buf kernel, i
 /* @serves moving_window */
 RMHIP_API int rmhip_moving_window(rmhip_ctx* ctx, rmhip_buf a, int dim, size_t before, size_t after, int op, int endpoints, double fill, int nan_omit,
                                   int population, const size_t* out_shape, size_t out_rank, rmhip_buf* out);
+/* `iir_filter(b, a, x, options)` (lib.rs:2551-2559; `ProviderIirFilterOptions { dim, zi, unit_denominator }`, :1295-1306; filter.rs:1119-1222):
+ * `filter(b, a, x, zi, dim)` in direct form II transposed along zero-based `dim`, every channel an independent recurrence (one thread per
+ * channel); coefficients normalised by a(1) as the CPU's complex division rounds them; `zi_or_0`: initial states in the signal's shape with
+ * `dim` of extent max(nb, na) - 1.  output: x's shape; final_state: that state shape (`ProviderIirFilterResult`).  Bit-exact.
+ * RMHIP_ERR_UNSUPPORTED: order > 64; fewer than 256 channels on more than 4096 samples (a recurrence: the host's one core is faster). */
+/* @serves iir_filter */
+RMHIP_API int rmhip_iir_filter(rmhip_ctx* ctx, rmhip_buf b, rmhip_buf a, rmhip_buf x, int dim, rmhip_buf zi_or_0, int unit_denominator, rmhip_buf* output,
+                               rmhip_buf* final_state);
 /* `polyval(coefficients, points, options)` (lib.rs:1652-1660; polyval.rs:886-905): Horner's rule over the coefficients (highest power
  * first) at every point, the result in the points' shape; has_mu: the point is centred and scaled first, ((x - mean) * scale) / (scale *
  * scale) as the CPU's complex division rounds it.  Bit-exact while every intermediate is finite; otherwise RMHIP_ERR_UNSUPPORTED (the

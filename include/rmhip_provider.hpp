@@ -690,6 +690,15 @@ public:
         check(rmhip_ismember(ctx_, own(a), own(b), r.mask.data(), r.loc.data.data()));
         return r;
     }
+    struct IirFilterResult {  // lib.rs:1308-1314
+        GpuTensorHandle output, final_state;
+    };
+    IirFilterResult iir_filter(const GpuTensorHandle& b, const GpuTensorHandle& a, const GpuTensorHandle& x, size_t dim, const GpuTensorHandle* zi,
+                               bool unit_denominator) const {  // lib.rs:2551-2559
+        uint64_t out = 0, fin = 0;
+        check(rmhip_iir_filter(ctx_, own(b), own(a), own(x), (int)dim, zi ? own(*zi) : 0, unit_denominator ? 1 : 0, &out, &fin));
+        return {with_shape(out), with_shape(fin)};
+    }
     // lib.rs:1652-1660; mu == nullptr: no centring / scaling, else {mean, scale}
     GpuTensorHandle polyval(const GpuTensorHandle& coefficients, const GpuTensorHandle& points, const double* mu = nullptr) const {
         uint64_t out = 0;

@@ -823,6 +823,40 @@ def ismember(a, b):
     return (loc > 0).astype(np.uint8).reshape(a.shape, order="F"), loc.reshape(a.shape, order="F")
 
 
+def iir_filter(b, a, x, dim: int = 0, zi=None):
+    """filter_host, filter.rs:1119-1222, on real data: direct form II transposed per channel, all channels advanced together (numpy applies
+    the same rounded operation to each).  Coefficients normalised as `Complex /= a0` rounds them: (c * a0 + 0) / (a0 * a0 + 0).
+    Returns (y in x's shape, final states with `dim` of extent max(nb, na) - 1)."""
+    b, a = (np.asarray(v, dtype=np.float64).ravel(order="F") for v in (b, a))
+    x = np.asarray(x, dtype=np.float64)
+    shape = list(x.shape) + [1] * max(0, dim + 1 - x.ndim)
+    order = max(b.size, a.size)
+    a0 = a[0]
+    den = a0 * a0 + 0.0
+    bn, an = np.zeros(order), np.zeros(order)
+    bn[:b.size] = (b * a0 + 0.0) / den
+    an[0] = 1.0
+    an[1:a.size] = (a[1:] * a0 + 0.0) / den
+    xs = np.moveaxis(x.reshape(shape), dim, 0)
+    st = np.zeros((max(order - 1, 0),) + xs.shape[1:])
+    if zi is not None and order > 1:
+        zshape = list(shape)
+        zshape[dim] = order - 1
+        st = np.moveaxis(np.asarray(zi, dtype=np.float64).reshape(zshape), dim, 0).copy()
+    y = np.empty_like(xs)
+    if order == 1:
+        y = bn[0] * xs
+    else:
+        for n in range(xs.shape[0]):
+            xn = xs[n]
+            yv = bn[0] * xn + st[0]
+            y[n] = yv
+            for i in range(1, order):
+                nxt = st[i] if i < order - 1 else 0.0
+                st[i - 1] = (bn[i] * xn + nxt) - an[i] * yv
+    return np.moveaxis(y, 0, dim).reshape(x.shape), np.moveaxis(st, 0, dim)
+
+
 def polyval(coefficients, points, mu=None) -> np.ndarray:
     """polyval.rs:886-905 restated on real data: the CPU evaluates acc = acc * x + c in `Complex64` (num-complex: re = a.re * b.re - a.im *
     b.im, rounded product by product), whose real part for real operands is the real recurrence with the product rounded before the sum;

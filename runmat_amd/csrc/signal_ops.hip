@@ -2,6 +2,7 @@
 //   conv1d            crates/runmat-accelerate-api/src/lib.rs:2535-2542   (builtins/math/signal/conv.rs:481-517; simple_provider.rs:1780-1842, 6015-6064)
 //   conv2d            lib.rs:2543-2550    (builtins/math/signal/conv2.rs:595-640; simple_provider.rs:6065-6154)
 //   hann_window / hamming_window / blackman_window   lib.rs:1797-1807   (simple_provider.rs:95-120, 6453-6472)
+//   iir_filter        lib.rs:2551-2559    (builtins/math/signal/filter.rs:1119-1222, 1311-1319, 1370-1460)
 //   polyval           lib.rs:1652-1660    (builtins/math/poly/polyval.rs:886-905, 352-435)
 //   moving_window     lib.rs:2852-2857    (builtins/math/reduction/moving.rs:737-825, 929-1003, 1198-1237, 1282-1323)
 // The convolutions are DIRECT sums in the CPU's order (output n receives a[i] * b[n - i] for i ascending, every product rounded before it
@@ -228,6 +229,43 @@ __global__ void __launch_bounds__(kB) k_polyval(const double* __restrict__ coef,
     if (bad) *nonfinite = 1;
 }
 
+// filter(b, a, x) along a dimension (builtins/math/signal/filter.rs:1119-1222): direct form II transposed, y = b0 x + s0,
+// s[i-1] = (b[i] x + s[i]) - a[i] y - a recurrence along the dimension, so ONE THREAD PER CHANNEL walks it in order with the states in
+// registers (order <= 8) or a per-thread array; neighbouring threads are neighbouring channels.  Every operation as the CPU rounds it.
+template <int MAXO>
+__global__ void __launch_bounds__(kB) k_iir(const double* __restrict__ x, const double* __restrict__ zi, const double* __restrict__ coef, int order, u64 leading,
+                                            u64 dim_len, u64 channels, double* __restrict__ y, double* __restrict__ zf) {
+    const u64 ch = (u64)blockIdx.x * kB + threadIdx.x;
+    if (ch >= channels) return;
+    const u64 l = ch % leading, t = ch / leading;
+    const u64 state_len = (u64)order - 1;
+    double bn[MAXO], an[MAXO], st[MAXO];
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i) {
+        bn[i] = i < order ? coef[i] : 0.0;
+        an[i] = i < order ? coef[order + i] : 0.0;
+        st[i] = (zi && (u64)i < state_len) ? zi[l + (u64)i * leading + t * leading * state_len] : 0.0;
+    }
+    const double* src = x + t * dim_len * leading + l;
+    double* dst = y + t * dim_len * leading + l;
+    for (u64 step = 0; step < dim_len; ++step) {
+        const double xn = src[step * leading];
+        const double yv = bn[0] * xn + st[0];
+        dst[step * leading] = yv;
+#pragma unroll
+        for (int i = 1; i < MAXO; ++i) {
+            if (i < order) {
+                const double next = (u64)i < state_len ? st[i] : 0.0;
+                const double p = bn[i] * xn, q = an[i] * yv;
+                st[i - 1] = (p + next) - q;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i)
+        if ((u64)i < state_len) zf[l + (u64)i * leading + t * leading * state_len] = st[i];
+}
+
 inline unsigned grid_for(u64 n) { return (unsigned)((n + kB - 1) / kB); }
 
 }  // namespace
@@ -355,6 +393,81 @@ int rmhip_moving_window(rmhip_ctx* ctx, rmhip_buf a, int dim, size_t before, siz
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
+}
+
+int rmhip_iir_filter(rmhip_ctx* ctx, rmhip_buf b, rmhip_buf a, rmhip_buf x, int dim, rmhip_buf zi_or_0, int unit_denominator, rmhip_buf* output,
+                     rmhip_buf* final_state) {
+    CTX_OR_FAIL(ctx);
+    if (!output || !final_state) return fail(RMHIP_ERR_INVALID, "iir_filter: null output");
+    if (dim < 0) return fail(RMHIP_ERR_INVALID, "iir_filter: dim must be >= 0");
+    *output = *final_state = 0;
+    Buffer bb, ab, xb, zb;
+    RMHIP_TRY(c->get(b, &bb));
+    RMHIP_TRY(c->get(a, &ab));
+    RMHIP_TRY(c->get(x, &xb));
+    const size_t nb = bb.numel, na = unit_denominator ? 1 : ab.numel;
+    if (nb == 0) return fail(RMHIP_ERR_INVALID, "iir_filter: numerator coefficients must not be empty");
+    if (ab.numel == 0) return fail(RMHIP_ERR_INVALID, "iir_filter: denominator coefficients must not be empty");
+    if (unit_denominator && ab.numel != 1) return fail(RMHIP_ERR_INVALID, "iir_filter: unit-denominator FIR path requires scalar denominator");
+    const size_t order = std::max(nb, na), state_len = order - 1;
+    if (order > 64) return fail(RMHIP_ERR_UNSUPPORTED, "iir_filter: order %zu", order);
+    std::vector<size_t> shape = xb.shape;
+    if ((size_t)dim >= shape.size()) shape.resize(dim + 1, 1);
+    u64 leading = 1, trailing = 1;
+    for (int k = 0; k < dim; ++k) leading *= shape[k];
+    for (size_t k = dim + 1; k < shape.size(); ++k) trailing *= shape[k];
+    const u64 dim_len = shape[dim], channels = leading * trailing;
+    // a recurrence per channel: with few channels the chip idles and the host's one core is faster - the caller keeps those
+    if (state_len > 0 && channels < 256 && xb.numel > 4096) return fail(RMHIP_ERR_UNSUPPORTED, "iir_filter: %llu channels", channels);
+    std::vector<size_t> zshape = shape;  // filter_state_shape, filter.rs:1311-1319
+    zshape[dim] = state_len;
+    if (zi_or_0) {
+        RMHIP_TRY(c->get(zi_or_0, &zb));
+        const size_t rk = std::max(zshape.size(), zb.shape.size());
+        for (size_t k = 0; k < rk; ++k)
+            if ((k < zshape.size() ? zshape[k] : 1) != (k < zb.shape.size() ? zb.shape[k] : 1))
+                return fail(RMHIP_ERR_SHAPE, "iir_filter: initial conditions are not compatible with the signal shape");
+    }
+    // coefficients: read back (<= 128 doubles), normalised as the CPU's complex division by (a0 + 0i) rounds them (filter.rs:1119-1138)
+    std::vector<double> hb(nb), ha(ab.numel), coef(2 * order, 0.0);
+    RMHIP_HIP_CHECK(hipMemcpyAsync(hb.data(), bb.data(), nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipMemcpyAsync(ha.data(), ab.data(), ab.numel * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const double a0 = unit_denominator ? 1.0 : ha[0];
+    if (a0 == 0.0) return fail(RMHIP_ERR_INVALID, "iir_filter: denominator coefficient a(1) must be non-zero");
+    const double den = a0 * a0 + 0.0;
+    for (size_t i = 0; i < nb; ++i) coef[i] = (hb[i] * a0 + 0.0) / den;
+    coef[order] = 1.0;
+    for (size_t i = 1; i < na; ++i) coef[order + i] = (ha[i] * a0 + 0.0) / den;
+    Buffer yb, fb;
+    RMHIP_TRY(c->new_buffer(xb.shape.data(), xb.shape.size(), output, &yb));
+    int rc = c->new_buffer(zshape.data(), zshape.size(), final_state, &fb);
+    if (rc == RMHIP_OK && state_len == 0) {
+        if (yb.numel) rc = launch_scalar(c, RMHIP_SMUL, xb.data(), coef[0], yb.data(), yb.numel);  // gain * x (filter.rs:1172-1176)
+    } else if (rc == RMHIP_OK && zi_or_0 && (dim_len == 0 || channels == 0)) {
+        if (fb.numel) RMHIP_HIP_CHECK(hipMemcpyAsync(fb.data(), zb.data(), fb.numel * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    } else if (rc == RMHIP_OK && channels > 0) {
+        std::shared_ptr<Allocation> dc;
+        rc = c->alloc_device(2 * order, &dc);
+        if (rc == RMHIP_OK) {
+            // (pageable source: the copy is staged before the call returns, so `coef` may go out of scope)
+            RMHIP_HIP_CHECK(hipMemcpyAsync(dc->ptr, coef.data(), 2 * order * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            const double* zi = zi_or_0 ? zb.data() : nullptr;
+            if (order <= 8)
+                hipLaunchKernelGGL(k_iir<8>, dim3(grid_for(channels)), dim3(kB), 0, c->stream, xb.data(), zi, dc->ptr, (int)order, leading, dim_len, channels, yb.data(), fb.data());
+            else
+                hipLaunchKernelGGL(k_iir<64>, dim3(grid_for(channels)), dim3(kB), 0, c->stream, xb.data(), zi, dc->ptr, (int)order, leading, dim_len, channels, yb.data(), fb.data());
+            c->tel.kernel_launches++;
+            if (hipGetLastError() != hipSuccess) rc = fail(RMHIP_ERR_HIP, "iir_filter: launch failed");
+            RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));  // the coefficient block is released on return
+        }
+    }
+    if (rc != RMHIP_OK) {
+        rmhip_free(ctx, *output);
+        if (*final_state) rmhip_free(ctx, *final_state);
+        *output = *final_state = 0;
+    }
+    return rc;
 }
 
 int rmhip_polyval(rmhip_ctx* ctx, rmhip_buf coefficients, rmhip_buf points, int has_mu, double mean, double scale, rmhip_buf* out) {

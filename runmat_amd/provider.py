@@ -1095,6 +1095,13 @@ class HipProvider:
         self._check(self._lib.rmhip_ismember(self._ctx, self._id(a), self._id(b), mask.ctypes.data_as(C.POINTER(C.c_ubyte)), loc.ctypes.data_as(C.POINTER(C.c_double))))
         return mask[:n].reshape(a.shape, order="F").copy(), loc[:n].reshape(a.shape, order="F").copy()
 
+    def iir_filter(self, b, a, x, dim: int, zi=None, unit_denominator: bool = False):
+        """lib.rs:2551-2559 -> `ProviderIirFilterResult { output, final_state }` as a pair of handles."""
+        out, fin = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.rmhip_iir_filter(self._ctx, self._id(b), self._id(a), self._id(x), int(dim), self._id(zi) if zi is not None else 0,
+                                               1 if unit_denominator else 0, C.byref(out), C.byref(fin)))
+        return self._handle(out.value), self._handle(fin.value)
+
     def polyval(self, coefficients, points, mu: Optional[Tuple[float, float]] = None) -> GpuTensorHandle:
         """lib.rs:1652-1660 (`ProviderPolyvalOptions { mu: Option<{mean, scale}> }`, :705-713)."""
         out = C.c_uint64()

@@ -16,7 +16,7 @@ use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle, GpuTensorStorage,
     HostLogicalOwned, HostTensorOwned, HostTensorView, IsMemberOptions, IsMemberResult, SetdiffOptions, SetdiffOrder, SetdiffResult, UnionOptions, UnionOrder, UnionResult, UniqueOccurrence, UniqueOptions, UniqueOrder, UniqueResult, ImageNormalizeDescriptor, KernelAttrTelemetry, MeshgridAxisView, ProviderMeshgridResult, ProviderPolyvalOptions, KernelLaunchTelemetry, MatmulEpilogue,
-    PowerStepEpilogue, ProviderBandwidth, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
+    PowerStepEpilogue, ProviderBandwidth, ProviderIirFilterOptions, ProviderIirFilterResult, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderMovingWindowEndpoints, ProviderMovingWindowOp, ProviderMovingWindowRequest, ProviderNanMode, ProviderNdgridRequest, ProviderNormOrder, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
     ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult,
 };
@@ -758,6 +758,17 @@ impl AccelProvider for HipProvider {
                 mask: HostLogicalOwned { data: mask, shape: a.shape.clone() },
                 loc: HostTensorOwned { data: loc, shape: a.shape.clone(), storage: GpuTensorStorage::Real },
             })
+        })
+    }
+    fn iir_filter<'a>(&'a self, b: &'a GpuTensorHandle, a: &'a GpuTensorHandle, x: &'a GpuTensorHandle, options: ProviderIirFilterOptions)
+        -> AccelProviderFuture<'a, ProviderIirFilterResult> {
+        Box::pin(async move {
+            let (mut out, mut fin) = (0u64, 0u64);
+            let zi = match &options.zi { Some(h) => self.own(h)?, None => 0 };
+            check(unsafe {
+                rmhip_iir_filter(self.ctx, self.own(b)?, self.own(a)?, self.own(x)?, options.dim as c_int, zi, options.unit_denominator as c_int, &mut out, &mut fin)
+            })?;
+            Ok(ProviderIirFilterResult { output: self.handle(out)?, final_state: Some(self.handle(fin)?) })
         })
     }
     fn polyval(&self, coefficients: &GpuTensorHandle, points: &GpuTensorHandle, options: &ProviderPolyvalOptions) -> Result<GpuTensorHandle> {

@@ -181,3 +181,52 @@ def test_meshgrid_and_complex_zeros(prov, oracle):
     assert prov.is_complex(z) and list(z.shape) == [3, 5] and not prov.download(z).any() and prov.download(z).size == 15
     r = prov.zeros_with_storage((3, 5))
     assert not prov.is_complex(r) and not prov.download(r).any()
+
+
+def test_filter_kats(prov):
+    for k in K["filter"]:
+        x = np.array(k["x"], dtype=np.float64)
+        y, zf = prov.iir_filter(prov.upload(np.array(k["b"]).reshape(1, -1)), prov.upload(np.array(k["a"]).reshape(1, -1)), prov.upload(x, k["shape"]), k["dim"])
+        assert list(y.shape) == k["shape"] and np.allclose(prov.download(y), k["y"], rtol=0, atol=1e-9), k
+        if "zf" in k:
+            assert list(zf.shape) == k["zshape"] and np.allclose(prov.download(zf), k["zf"], rtol=0, atol=1e-9), k
+
+
+@pytest.mark.parametrize("shape,dim", [((40, 7, 3), 0), ((40, 7, 3), 1), ((40, 7, 3), 2), ((300, 260), 0), ((260, 300), 1), ((5,), 0), ((64, 300), 2)], ids=str)
+def test_iir_filter(prov, oracle, shape, dim):
+    rng = np.random.default_rng(sum(shape) + dim)
+    x = rng.standard_normal(shape)
+    hx = prov.upload(x.ravel(order="F"), shape)
+    for b, a in (([0.2, 0.3, 0.1], [1.0, -0.5, 0.25]), ([1.0, -1.0], [1.0]), ([0.5], [2.0, 0.4, 0.1, 0.05]), ([3.0], [1.5]),
+                 (list(rng.standard_normal(12)), [1.0] + list(0.05 * rng.standard_normal(9)))):
+        hb, ha = prov.upload(np.array(b).reshape(1, -1)), prov.upload(np.array(a).reshape(1, -1))
+        wy, wz = oracle.iir_filter(b, a, x, dim)
+        y, zf = prov.iir_filter(hb, ha, hx, dim)
+        assert list(y.shape) == list(shape) and bits_equal(prov.download(y).reshape(shape, order="F"), wy), (b, a)
+        assert list(zf.shape) == list(wz.shape) and bits_equal(prov.download(zf).reshape(wz.shape, order="F"), wz), (b, a)
+        if wz.size:
+            zi = rng.standard_normal(wz.shape)
+            wy2, wz2 = oracle.iir_filter(b, a, x, dim, zi)
+            y2, zf2 = prov.iir_filter(hb, ha, hx, dim, prov.upload(zi.ravel(order="F"), zi.shape))
+            assert bits_equal(prov.download(y2).reshape(shape, order="F"), wy2) and bits_equal(prov.download(zf2).reshape(wz.shape, order="F"), wz2)
+        if len(a) == 1 and a[0] == 1.0:
+            y3, _ = prov.iir_filter(hb, ha, hx, dim, unit_denominator=True)
+            assert bits_equal(prov.download(y3).reshape(shape, order="F"), wy)
+
+
+def test_iir_filter_limits_and_baseline_size(prov, oracle):
+    b, a = prov.upload(np.array([[0.1, 0.2]])), prov.upload(np.array([[1.0, -0.3]]))
+    with pytest.raises(Exception):
+        prov.iir_filter(b, a, prov.upload(np.zeros((100000, 1))), 0)                 # one long channel: the host's one core is faster
+    with pytest.raises(Exception):
+        prov.iir_filter(b, prov.upload(np.array([[0.0, 1.0]])), prov.upload(np.zeros((8, 300))), 0)   # a(1) == 0
+    with pytest.raises(Exception):
+        prov.iir_filter(b, a, prov.upload(np.zeros((8, 300))), 0, prov.upload(np.zeros((2, 300))))    # one state per channel expected
+    n = 8192
+    h = prov.fill_uniform(14, -1.0, 1.0, (n, n))
+    x = prov.download_matrix(h)
+    for dim in (0, 1):
+        y, zf = prov.iir_filter(b, a, h, dim)
+        sl = (slice(None), slice(0, 48)) if dim == 0 else (slice(0, 48), slice(None))
+        wy, wz = oracle.iir_filter([0.1, 0.2], [1.0, -0.3], x[sl], dim)
+        assert bits_equal(prov.download_matrix(y)[sl], wy) and bits_equal(prov.download(zf).reshape(zf.shape, order="F")[sl], wz)

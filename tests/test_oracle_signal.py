@@ -85,3 +85,27 @@ def test_polyval_and_meshgrid():
     want = np.meshgrid([1.0, 2.0], [5.0], [7.0, 8.0, 9.0])
     assert all(np.array_equal(a, b) for a, b in zip((X, Y, Z), want))
     assert oracle.meshgrid([[1.0, 2.0], [5.0, 6.0], [4.0]])[2].shape == (2, 2)
+
+
+def test_filter_kats_and_scipy():
+    for k in K["filter"]:
+        y, zf = oracle.iir_filter(k["b"], k["a"], np.array(k["x"], dtype=np.float64).reshape(k["shape"], order="F"), k["dim"])
+        assert np.allclose(y.ravel(order="F"), k["y"], rtol=0, atol=1e-9), k
+        if "zf" in k:
+            assert list(zf.shape) == k["zshape"] and np.allclose(zf.ravel(order="F"), k["zf"], rtol=0, atol=1e-9), k
+    from scipy.signal import lfilter, lfilter_zi
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((40, 7, 3))
+    for b, a in (([0.2, 0.3, 0.1], [1.0, -0.5, 0.25]), ([1.0, -1.0], [1.0]), ([0.5], [2.0, 0.4, 0.1, 0.05]), ([3.0], [1.5])):
+        for dim in (0, 1, 2):
+            y, zf = oracle.iir_filter(b, a, x, dim)
+            order = max(len(b), len(a))
+            if order > 1:
+                want, wz = lfilter(b, a, x, axis=dim, zi=np.zeros([order - 1 if d == dim else x.shape[d] for d in range(3)]))
+                assert np.allclose(y, want, rtol=1e-12, atol=1e-12) and np.allclose(zf, wz, rtol=1e-12, atol=1e-12)
+                zi = rng.standard_normal(wz.shape)
+                y2, zf2 = oracle.iir_filter(b, a, x, dim, zi)
+                w2, wz2 = lfilter(b, a, x, axis=dim, zi=zi)
+                assert np.allclose(y2, w2, rtol=1e-12, atol=1e-12) and np.allclose(zf2, wz2, rtol=1e-12, atol=1e-12)
+            else:
+                assert np.allclose(y, lfilter(b, a, x, axis=dim), rtol=1e-14, atol=0) and zf.shape[dim] == 0
