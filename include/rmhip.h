@@ -337,6 +337,13 @@ RMHIP_API int rmhip_reduce_median(rmhip_ctx* ctx, rmhip_buf a, int dim, rmhip_bu
 /* @serves find */
 RMHIP_API int rmhip_find(rmhip_ctx* ctx, rmhip_buf a, long long limit_or_neg, int last, rmhip_buf* linear, rmhip_buf* rows, rmhip_buf* cols,
                          rmhip_buf* values);
+/* `sort_rows(a, columns, comparison)` (lib.rs:2367-2374; `SortRowsColumnSpec { index, order }`, :1091-1094; sortrows_host.rs:11-140): the rows
+ * of a 2-D tensor in lexicographic order of the listed columns (zero-based; column_descend[k] != 0: that key descending; indices beyond the
+ * column count are skipped), NaN last ascending / first descending, by_abs as `SortComparison::Abs`; a stable order (equal rows keep
+ * theirs).  sorted: a's shape; indices: [rows, 1], 1-based source rows.  One stable sort pass per key, last key first: bit-exact. */
+/* @serves sort_rows */
+RMHIP_API int rmhip_sort_rows(rmhip_ctx* ctx, rmhip_buf a, const size_t* column_index, const int* column_descend, size_t n_columns, int by_abs, rmhip_buf* sorted,
+                              rmhip_buf* indices);
 /* `unique(handle, options)` for elements (lib.rs:2645-2651; `UniqueOptions` :1110-1116 with rows == false; unique.rs:473-556): the distinct
  * values - every NaN one value, both zeros one value, each keeping the bits of its FIRST occurrence -, sorted ascending with NaN last or
  * (stable != 0) in order of first occurrence; ia: the 1-based position of each value's first (or last_occurrence != 0: last) occurrence;

@@ -383,6 +383,19 @@ public:
         free(hi);
         return r;
     }
+    // lib.rs:2367-2374: columns as (zero-based index, descend) pairs
+    SortResult sort_rows(const GpuTensorHandle& a, const std::vector<std::pair<size_t, bool>>& columns, bool by_abs) const {
+        std::vector<size_t> idx;
+        std::vector<int> desc;
+        for (const auto& cspec : columns) idx.push_back(cspec.first), desc.push_back(cspec.second ? 1 : 0);
+        uint64_t v = 0, i = 0;
+        check(rmhip_sort_rows(ctx_, own(a), idx.data(), desc.data(), columns.size(), by_abs ? 1 : 0, &v, &i));
+        const GpuTensorHandle hv = with_shape(v), hi = with_shape(i);
+        SortResult r{download(hv), download(hi)};
+        free(hv);
+        free(hi);
+        return r;
+    }
     // lib.rs:2937-2944 -> ProviderFindResult (lib.rs:623-628); limit < 0 = None; last = FindDirection::Last
     struct FindResult {
         GpuTensorHandle linear, rows, cols, values;

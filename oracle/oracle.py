@@ -763,6 +763,44 @@ def issymmetric(a: np.ndarray, skew: bool = False, tol: float = 0.0) -> bool:
     return bool(l.orc_issymmetric(_p(_f(a)), rows, cols, int(skew), float(tol)))
 
 
+def sort_rows(a, columns, comparison: str = "auto"):
+    """sort_rows_host, runmat-accelerate/src/sortrows_host.rs:11-140: a stable sort of the row indices under `compare_rows`; columns as
+    (zero-based index, "ascend" | "descend") pairs -> (sorted matrix, 1-based source rows [rows, 1])."""
+    import functools
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim >= 2:
+        m = a.reshape(a.shape[0], a.shape[1], order="F")
+    else:
+        m = a.reshape(max(a.size, 1), 1)
+    rows, cols = m.shape
+
+    def scalar(x, y, descend):
+        if x != x or y != y:
+            if x != x and y != y:
+                return 0
+            gt = 1 if x != x else -1  # NaN is the greater one ascending ...
+            return -gt if descend else gt  # ... and comes first descending
+        if comparison == "abs" and abs(x) != abs(y):
+            c = -1 if abs(x) < abs(y) else 1
+            return -c if descend else c
+        c = int(x > y) - int(x < y)
+        return -c if descend else c
+
+    def cmp(r, s):
+        for idx, order in columns:
+            if idx >= cols:
+                continue
+            c = scalar(m[r, idx], m[s, idx], order == "descend")
+            if c:
+                return c
+        return 0
+
+    order = list(range(rows))
+    if rows > 1 and cols > 0 and columns:
+        order.sort(key=functools.cmp_to_key(cmp))
+    return m[order, :].reshape(a.shape, order="F") if a.size else a.copy(), (np.array(order, dtype=np.float64) + 1.0).reshape(-1, 1)
+
+
 def _canon_key(v: float):
     """canonicalize_f64, unique.rs:1347-1355 / ismember.rs:814-822: every NaN one key, both zeros one key, otherwise the bits."""
     if v != v:

@@ -489,12 +489,11 @@ struct SortSpace {
     u64 lp = 0, total = 0;
 };
 
-// keys + positions of every line, sorted
-int sort_lines(Context* c, const double* x, Lines g, int descend, int by_abs, SortSpace* ws) {
-    const u64 nlines = g.pre * g.post;
-    if (g.len >= 0x7fffffffull) return fail(RMHIP_ERR_UNSUPPORTED, "sort: a dimension of %llu elements", g.len);
+// workspace for `nlines` lines of `len` pairs (padded to a power of two each, the total to whole workgroup tiles)
+int sort_alloc(Context* c, u64 nlines, u64 len, SortSpace* ws) {
+    if (len >= 0x7fffffffull) return fail(RMHIP_ERR_UNSUPPORTED, "sort: a dimension of %llu elements", len);
     u64 lp = 2;
-    while (lp < g.len) lp <<= 1;
+    while (lp < len) lp <<= 1;
     u64 total = nlines * lp;
     total = (total + SORT_C - 1) / SORT_C * SORT_C;
     if (total / lp > 0x7fffffffull || total > (1ull << 40)) return fail(RMHIP_ERR_UNSUPPORTED, "sort: workspace of %llu pairs", total);
@@ -503,10 +502,14 @@ int sort_lines(Context* c, const double* x, Lines g, int descend, int by_abs, So
     ws->pos = (u32*)(ws->mem->ptr + total);
     ws->lp = lp;
     ws->total = total;
-    hipLaunchKernelGGL(k_sort_keys, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, x, ws->keys, ws->pos, g, lp, total, descend, by_abs,
-                       g.pre > 1 ? 1 : 0);
+    return RMHIP_OK;
+}
+
+// the bitonic network over the (key, position) pairs already in the workspace
+int sort_pairs(Context* c, SortSpace* ws) {
+    const u64 lp = ws->lp, total = ws->total;
     hipLaunchKernelGGL(k_bitonic_local<true>, dim3((unsigned)(total / SORT_C)), dim3(SORT_THREADS), 0, c->stream, ws->keys, ws->pos, lp, (u64)0);
-    c->tel.kernel_launches += 2;
+    c->tel.kernel_launches++;
     for (u64 k = 2 * (u64)SORT_C; k <= lp; k <<= 1) {
         for (u64 j = k >> 1; j >= (u64)SORT_C; j >>= 1) {
             hipLaunchKernelGGL(k_bitonic_global, dim3((unsigned)((total / 2 + 255) / 256)), dim3(256), 0, c->stream, ws->keys, ws->pos, lp, k, j, total / 2);
@@ -517,6 +520,46 @@ int sort_lines(Context* c, const double* x, Lines g, int descend, int by_abs, So
     }
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
+}
+
+// keys + positions of every line, sorted
+int sort_lines(Context* c, const double* x, Lines g, int descend, int by_abs, SortSpace* ws) {
+    RMHIP_TRY(sort_alloc(c, g.pre * g.post, g.len, ws));
+    hipLaunchKernelGGL(k_sort_keys, dim3((unsigned)((ws->total + 255) / 256)), dim3(256), 0, c->stream, x, ws->keys, ws->pos, g, ws->lp, ws->total, descend, by_abs,
+                       g.pre > 1 ? 1 : 0);
+    c->tel.kernel_launches++;
+    return sort_pairs(c, ws);
+}
+
+// sortrows (runmat-accelerate/src/sortrows_host.rs:11-140): one stable pass per key column, last key first.  `perm[r]`: the row now at rank r.
+__global__ void __launch_bounds__(256) k_rows_keys(const double* __restrict__ x, u64 rows, u64 col, const u32* __restrict__ perm, int descend, int by_abs, u64* __restrict__ keys,
+                                                   u32* __restrict__ pos, u64 total) {
+    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (r >= total) return;
+    u64 key = ~0ull;
+    u32 p = 0xffffffffu;
+    if (r < rows) key = sort_key(x[(perm ? perm[r] : (u32)r) + col * rows], descend, by_abs), p = (u32)r;
+    keys[r] = key, pos[r] = p;
+}
+
+__global__ void __launch_bounds__(256) k_iota1(double* __restrict__ out, u64 n) {
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (double)i + 1.0;
+}
+
+__global__ void __launch_bounds__(256) k_rows_compose(const u32* __restrict__ perm, const u32* __restrict__ pos, u64 rows, u32* __restrict__ out) {
+    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (r < rows) out[r] = perm ? perm[pos[r]] : pos[r];
+}
+
+__global__ void __launch_bounds__(256) k_rows_emit(const double* __restrict__ x, const u32* __restrict__ perm, u64 rows, u64 total, double* __restrict__ sorted,
+                                                   double* __restrict__ indices) {
+    const u64 o = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (o >= total) return;
+    const u64 r = o % rows, col = o / rows;
+    const u32 src = perm ? perm[r] : (u32)r;
+    sorted[o] = x[src + col * rows];
+    if (col == 0) indices[r] = (double)src + 1.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -1253,4 +1296,63 @@ int rmhip_ismember(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, unsigned char* mask
     RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->tel.download_bytes += na * 9;
     return RMHIP_OK;
+}
+
+int rmhip_sort_rows(rmhip_ctx* ctx, rmhip_buf a, const size_t* column_index, const int* column_descend, size_t n_columns, int by_abs, rmhip_buf* sorted,
+                    rmhip_buf* indices) {
+    CTX_OR_FAIL(ctx);
+    if (!sorted || !indices || (n_columns && (!column_index || !column_descend))) return fail(RMHIP_ERR_INVALID, "sort_rows: null argument");
+    *sorted = *indices = 0;
+    Buffer ab, sb, ib;
+    RMHIP_TRY(c->get(a, &ab));
+    for (size_t d = 2; d < ab.shape.size(); ++d)
+        if (ab.shape[d] != 1) return fail(RMHIP_ERR_INVALID, "sortrows: input must be a 2-D matrix on the provider path");
+    // rows_cols_for_shape, sortrows_host.rs:67-73
+    const u64 rows = ab.shape.empty() ? 1 : (ab.shape.size() == 1 ? std::max<size_t>(ab.shape[0], 1) : ab.shape[0]);
+    const u64 cols = ab.shape.size() < 2 ? 1 : ab.shape[1];
+    if (rows * cols != ab.numel) return fail(RMHIP_ERR_SHAPE, "sortrows: tensor data length %zu does not match its shape", ab.numel);
+    RMHIP_TRY(c->new_buffer(ab.shape.data(), ab.shape.size(), sorted, &sb));
+    const size_t ishape[2] = {(size_t)rows, 1};
+    int rc = c->new_buffer(ishape, 2, indices, &ib);
+    std::shared_ptr<Allocation> pm;
+    u32* perm = nullptr;
+    if (rc == RMHIP_OK && rows > 1 && cols > 0 && ab.numel > 0) {
+        SortSpace ws;
+        rc = sort_alloc(c, 1, rows, &ws);
+        if (rc == RMHIP_OK) rc = c->alloc_device(rows, &pm);  // two u32 arrays of `rows`
+        u32 *cur = nullptr, *nxt = pm ? (u32*)pm->ptr : nullptr;
+        for (size_t s = n_columns; s-- > 0 && rc == RMHIP_OK;) {  // the last key first: every pass is stable (ties keep the ranks of the pass before)
+            if (column_index[s] >= cols) continue;               // sortrows_host.rs:86-88
+            hipLaunchKernelGGL(k_rows_keys, dim3((unsigned)((ws.total + 255) / 256)), dim3(256), 0, c->stream, ab.data(), rows, (u64)column_index[s], cur, column_descend[s] ? 1 : 0,
+                               by_abs ? 1 : 0, ws.keys, ws.pos, ws.total);
+            c->tel.kernel_launches++;
+            rc = sort_pairs(c, &ws);
+            if (rc != RMHIP_OK) break;
+            hipLaunchKernelGGL(k_rows_compose, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, cur, ws.pos, rows, nxt);
+            c->tel.kernel_launches++;
+            u32* was = cur;
+            cur = nxt;
+            nxt = was ? was : (u32*)pm->ptr + rows;
+        }
+        perm = cur;
+        if (rc == RMHIP_OK && perm) {
+            hipLaunchKernelGGL(k_rows_emit, dim3((unsigned)((ab.numel + 255) / 256)), dim3(256), 0, c->stream, ab.data(), perm, rows, (u64)ab.numel, sb.data(), ib.data());
+            c->tel.kernel_launches++;
+            if (hipGetLastError() != hipSuccess) rc = fail(RMHIP_ERR_HIP, "sort_rows: launch failed");
+            RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));  // the permutation arrays are released on return
+        }
+    }
+    if (rc == RMHIP_OK && !perm && ab.numel > 0) {  // nothing to order: the rows as they are, identity indices (sortrows_host.rs:33-39)
+        hipLaunchKernelGGL(k_rows_emit, dim3((unsigned)((ab.numel + 255) / 256)), dim3(256), 0, c->stream, ab.data(), (const u32*)nullptr, rows, (u64)ab.numel, sb.data(), ib.data());
+        c->tel.kernel_launches++;
+    } else if (rc == RMHIP_OK && ab.numel == 0 && ib.numel > 0) {  // rows without columns: identity indices
+        hipLaunchKernelGGL(k_iota1, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, ib.data(), rows);
+        c->tel.kernel_launches++;
+    }
+    if (rc != RMHIP_OK) {
+        rmhip_free(ctx, *sorted);
+        if (*indices) rmhip_free(ctx, *indices);
+        *sorted = *indices = 0;
+    }
+    return rc;
 }

@@ -598,6 +598,22 @@ class HipProvider:
             self.free(hv)
             self.free(hi)
 
+    def sort_rows(self, a, columns: Sequence[Tuple[int, str]], comparison: str = "auto") -> "SortResult":
+        """lib.rs:2367-2374: `columns` as (zero-based index, "ascend" | "descend") pairs (`SortRowsColumnSpec`) -> `SortResult` (host tensors)."""
+        if comparison not in ("auto", "real", "abs") or any(o not in ("ascend", "descend") for _, o in columns):
+            raise RmhipError(1, f"sort_rows: columns {columns!r} / comparison {comparison!r}")
+        n = len(columns)
+        idx = (C.c_size_t * max(n, 1))(*[int(i) for i, _ in columns])
+        desc = (C.c_int * max(n, 1))(*[1 if o == "descend" else 0 for _, o in columns])
+        sv, si = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.rmhip_sort_rows(self._ctx, self._id(a), idx, desc, n, 1 if comparison == "abs" else 0, C.byref(sv), C.byref(si)))
+        hv, hi = self._handle(sv.value), self._handle(si.value)
+        try:
+            return SortResult(self.download_matrix(hv), self.download_matrix(hi))
+        finally:
+            self.free(hv)
+            self.free(hi)
+
     def find(self, a, limit: Optional[int] = None, direction: str = "first") -> "ProviderFindResult":
         """lib.rs:2937-2944 (`FindDirection::{First, Last}`) -> `ProviderFindResult{linear, rows, cols, values}` (:623-628)."""
         if direction not in ("first", "last"):

@@ -18,7 +18,7 @@ use runmat_accelerate_api::{
     HostLogicalOwned, HostTensorOwned, HostTensorView, IsMemberOptions, IsMemberResult, SetdiffOptions, SetdiffOrder, SetdiffResult, UnionOptions, UnionOrder, UnionResult, UniqueOccurrence, UniqueOptions, UniqueOrder, UniqueResult, ImageNormalizeDescriptor, KernelAttrTelemetry, MeshgridAxisView, ProviderMeshgridResult, ProviderPolyvalOptions, KernelLaunchTelemetry, MatmulEpilogue,
     PowerStepEpilogue, ProviderBandwidth, ProviderIirFilterOptions, ProviderIirFilterResult, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderMovingWindowEndpoints, ProviderMovingWindowOp, ProviderMovingWindowRequest, ProviderNanMode, ProviderNdgridRequest, ProviderNormOrder, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
-    ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult,
+    ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult, SortRowsColumnSpec,
 };
 use std::ffi::{c_char, c_int, c_void, CStr, CString};
 
@@ -390,6 +390,21 @@ impl AccelProvider for HipProvider {
             let desc = matches!(order, SortOrder::Descend) as c_int;
             let abs = matches!(comparison, SortComparison::Abs) as c_int;
             check(unsafe { rmhip_sort_dim(self.ctx, self.own(a)?, dim as c_int, desc, abs, &mut v, &mut i) })?;
+            let (hv, hi) = (self.handle(v)?, self.handle(i)?);
+            let values = self.download(&hv).await;
+            let indices = self.download(&hi).await;
+            self.free(&hv)?;
+            self.free(&hi)?;
+            Ok(SortResult { values: values?, indices: indices? })
+        })
+    }
+    fn sort_rows<'a>(&'a self, a: &'a GpuTensorHandle, columns: &'a [SortRowsColumnSpec], comparison: SortComparison) -> AccelProviderFuture<'a, SortResult> {
+        Box::pin(async move {
+            let idx: Vec<usize> = columns.iter().map(|s| s.index).collect();
+            let desc: Vec<c_int> = columns.iter().map(|s| matches!(s.order, SortOrder::Descend) as c_int).collect();
+            let abs = matches!(comparison, SortComparison::Abs) as c_int;
+            let (mut v, mut i) = (0u64, 0u64);
+            check(unsafe { rmhip_sort_rows(self.ctx, self.own(a)?, idx.as_ptr(), desc.as_ptr(), columns.len(), abs, &mut v, &mut i) })?;
             let (hv, hi) = (self.handle(v)?, self.handle(i)?);
             let values = self.download(&hv).await;
             let indices = self.download(&hi).await;

@@ -26,6 +26,11 @@ def test_reference_kats(prov):
         assert np.array_equal(values.ravel(), arr(k["values"]), equal_nan=True), k
         if "ia" in k:
             assert list(ia.ravel()) == k["ia"] and list(ic.ravel()) == k["ic"], k
+    for k in K["sort_rows"]:
+        r = prov.sort_rows(prov.upload(arr(k["a"]), k["shape"]), [tuple(c) for c in k["columns"]])
+        assert np.array_equal(r.values.ravel(order="F"), k["values"]), k
+        if "indices" in k:
+            assert list(r.indices.ravel()) == k["indices"], k
     for k in K["union"]:
         values, ia, ib = prov.union(prov.upload(arr(k["a"]).reshape(-1, 1)), prov.upload(arr(k["b"]).reshape(-1, 1)), order=k["order"])
         assert np.array_equal(values.ravel(), arr(k["values"]), equal_nan=True) and list(ia.ravel()) == k["ia"] and list(ib.ravel()) == k["ib"], k
@@ -111,3 +116,24 @@ def test_union_and_setdiff(prov, oracle, na, nb, span):
                 assert same_bits(g, w), (order, g.shape, w.shape)
     with pytest.raises(Exception):
         prov.union(ha, hb, rows=True)
+
+
+@pytest.mark.parametrize("shape", [(1, 3), (2, 2), (50, 3), (3000, 5), (70000, 2), (5, 0), (0, 4), (300, 1)], ids=str)
+def test_sort_rows(prov, oracle, shape):
+    rng = np.random.default_rng(sum(shape))
+    m = rng.integers(-3, 4, size=shape).astype(np.float64)
+    if m.size > 20:
+        flat = m.reshape(-1)
+        flat[rng.integers(0, flat.size, size=max(2, flat.size // 9))] = np.nan
+        flat[rng.integers(0, flat.size, size=max(2, flat.size // 11))] = -0.0
+    h = prov.upload(m.ravel(order="F"), shape)
+    cols = shape[1]
+    specs = [[(c, "ascend") for c in range(cols)], [(c, "descend") for c in range(cols)], [(cols - 1, "descend"), (0, "ascend")], [(0, "ascend"), (7, "descend")], []]
+    for columns in specs:
+        for comparison in ("auto", "abs"):
+            want_v, want_i = oracle.sort_rows(m, columns, comparison)
+            r = prov.sort_rows(h, columns, comparison)
+            assert list(r.indices.shape) == [shape[0], 1] and np.array_equal(r.indices, want_i), (columns, comparison)
+            assert same_bits(r.values, want_v), (columns, comparison)
+    with pytest.raises(Exception):
+        prov.sort_rows(prov.upload(np.zeros((2, 2, 2))), [(0, "ascend")])

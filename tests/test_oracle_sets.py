@@ -20,6 +20,11 @@ def test_reference_kats():
         assert np.array_equal(values.ravel(), arr(k["values"]), equal_nan=True), k
         if "ia" in k:
             assert np.array_equal(ia.ravel(), k["ia"]) and np.array_equal(ic.ravel(), k["ic"]), k
+    for k in K["sort_rows"]:
+        values, idx = oracle.sort_rows(arr(k["a"]).reshape(k["shape"], order="F"), [tuple(c) for c in k["columns"]])
+        assert np.array_equal(values.ravel(order="F"), k["values"]), k
+        if "indices" in k:
+            assert list(idx.ravel()) == k["indices"], k
     for k in K["union"]:
         values, ia, ib = oracle.union(arr(k["a"]), arr(k["b"]), k["order"])
         assert np.array_equal(values.ravel(), arr(k["values"]), equal_nan=True) and list(ia.ravel()) == k["ia"] and list(ib.ravel()) == k["ib"], k
@@ -50,5 +55,8 @@ def test_against_numpy():
     assert list(m2) == [1, 1, 0] and list(l2) == [3, 2, 0]
     p, q = rng.integers(0, 30, size=40).astype(np.float64), rng.integers(10, 50, size=25).astype(np.float64)
     assert np.array_equal(oracle.union(p, q)[0].ravel(), np.union1d(p, q)) and np.array_equal(oracle.setdiff(p, q)[0].ravel(), np.setdiff1d(p, q))
+    m = rng.integers(0, 4, size=(50, 3)).astype(np.float64)
+    got, idx = oracle.sort_rows(m, [(0, "ascend"), (1, "ascend"), (2, "ascend")])
+    assert np.array_equal(got, m[np.lexsort((m[:, 2], m[:, 1], m[:, 0]))]) and np.array_equal(m[idx.ravel().astype(int) - 1], got)
     e = oracle.unique(np.zeros((0, 3)))
     assert e[0].shape == (0, 1) and e[2].shape == (0, 1)
