@@ -45,8 +45,13 @@ __global__ void __launch_bounds__(kB) k_conv1d(const double* __restrict__ a, u64
     const u64 n = start + o;
     const u64 lo = n >= lb - 1 ? n - (lb - 1) : 0, hi = n < la - 1 ? n : la - 1;
     double acc = 0.0;
-    for (u64 i = lo; i <= hi; ++i) {
-        const double p = a[i] * bb[n - i];
+    // (32-bit trip count, two running pointers: the loop was 20 instructions per tap with 64-bit index arithmetic)
+    const double* ap = a + lo;
+    const double* bp = bb + (n - lo);
+    const unsigned cnt = (unsigned)(hi - lo + 1);
+#pragma unroll 4
+    for (unsigned k = 0; k < cnt; ++k) {
+        const double p = ap[k] * *(bp - k);
         acc = acc + p;
     }
     out[o] = acc;
@@ -67,13 +72,17 @@ __global__ void __launch_bounds__(kB) k_conv2d(const double* __restrict__ a, u64
     const u64 ac_lo = Cc >= bc_n - 1 ? Cc - (bc_n - 1) : 0, ac_hi = Cc < ac_n - 1 ? Cc : ac_n - 1;
     const u64 ar_lo = R >= br_n - 1 ? R - (br_n - 1) : 0, ar_hi = R < ar_n - 1 ? R : ar_n - 1;
     double acc = 0.0;
-    for (u64 ac = ac_lo; ac <= ac_hi; ++ac) {
-        const double* acol = a + ac * ar_n;
-        const double* bcol = bb + (bc_n - 1 - (Cc - ac)) * br_n;
-        for (u64 ar = ar_lo; ar <= ar_hi; ++ar) {
-            const double p = acol[ar] * bcol[br_n - 1 - (R - ar)];
+    const unsigned ncol = (unsigned)(ac_hi - ac_lo + 1), nrow = (unsigned)(ar_hi - ar_lo + 1);
+    const double* acol = a + ac_lo * ar_n + ar_lo;
+    const double* bcol = bb + (bc_n - 1 - (Cc - ac_lo)) * br_n + (br_n - 1 - (R - ar_lo));  // the tap of (ar_lo, ac_lo); rows and columns both ascend
+    for (unsigned c = 0; c < ncol; ++c) {
+#pragma unroll 4
+        for (unsigned k = 0; k < nrow; ++k) {
+            const double p = acol[k] * bcol[k];
             acc = acc + p;
         }
+        acol += ar_n;
+        bcol += br_n;
     }
     out[o] = acc;
 }
