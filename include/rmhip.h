@@ -485,6 +485,14 @@ RMHIP_API int rmhip_moving_window(rmhip_ctx* ctx, rmhip_buf a, int dim, size_t b
 /* @serves iir_filter */
 RMHIP_API int rmhip_iir_filter(rmhip_ctx* ctx, rmhip_buf b, rmhip_buf a, rmhip_buf x, int dim, rmhip_buf zi_or_0, int unit_denominator, rmhip_buf* output,
                                rmhip_buf* final_state);
+/* `interp1(request)` (lib.rs:2458-2463; `ProviderInterp1Request`, :769-783; simple_provider.rs:1396-1472, 8135-8204): every series of y
+ * (sample_len values each, back to back) interpolated at the query_len points of xq over the strictly increasing coordinates x - the
+ * result holds series after series, in `output_shape`.  nearest: `ProviderInterp1Method::Nearest` (ties to the left sample), else Linear
+ * (y0 + ((xq - x0) / (x1 - x0)) * (y1 - y0), as the CPU rounds it); extrapolation: 0 NaN, 1 extrapolate, 2 `extrapolation_value`; a
+ * non-finite query yields NaN.  Bit-exact. */
+/* @serves interp1 */
+RMHIP_API int rmhip_interp1(rmhip_ctx* ctx, rmhip_buf x, rmhip_buf y, rmhip_buf xq, size_t sample_len, size_t series_count, size_t query_len,
+                            const size_t* output_shape, size_t out_rank, int nearest, int extrapolation, double extrapolation_value, rmhip_buf* out);
 /* `polyval(coefficients, points, options)` (lib.rs:1652-1660; polyval.rs:886-905): Horner's rule over the coefficients (highest power
  * first) at every point, the result in the points' shape; has_mu: the point is centred and scaled first, ((x - mean) * scale) / (scale *
  * scale) as the CPU's complex division rounds it.  Bit-exact while every intermediate is finite; otherwise RMHIP_ERR_UNSUPPORTED (the

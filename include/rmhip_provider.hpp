@@ -703,6 +703,14 @@ public:
         check(rmhip_ismember(ctx_, own(a), own(b), r.mask.data(), r.loc.data.data()));
         return r;
     }
+    // lib.rs:2458-2463; extrapolation: 0 NaN, 1 extrapolate, 2 the value
+    GpuTensorHandle interp1(const GpuTensorHandle& x, const GpuTensorHandle& y, const GpuTensorHandle& xq, size_t sample_len, size_t series_count, size_t query_len,
+                            const std::vector<size_t>& output_shape, bool nearest, int extrapolation, double value) const {
+        uint64_t out = 0;
+        check(rmhip_interp1(ctx_, own(x), own(y), own(xq), sample_len, series_count, query_len, output_shape.data(), output_shape.size(), nearest ? 1 : 0, extrapolation, value,
+                            &out));
+        return with_shape(out);
+    }
     struct IirFilterResult {  // lib.rs:1308-1314
         GpuTensorHandle output, final_state;
     };

@@ -861,6 +861,54 @@ def ismember(a, b):
     return (loc > 0).astype(np.uint8).reshape(a.shape, order="F"), loc.reshape(a.shape, order="F")
 
 
+def interp1(x, y, xq, method: str = "linear", extrapolation="nan") -> np.ndarray:
+    """interp1_value / interp1_interval_index, simple_provider.rs:1396-1472: y as [sample_len, series]; returns [query_len, series].
+    extrapolation: "nan" | "extrapolate" | a fill value."""
+    import bisect
+    x = np.asarray(x, dtype=np.float64).ravel()
+    y = np.asarray(y, dtype=np.float64).reshape(x.size, -1, order="F")
+    q = np.asarray(xq, dtype=np.float64).ravel(order="F")
+    extrap = extrapolation == "extrapolate"
+    oor = np.nan if extrapolation in ("nan", "extrapolate") else float(extrapolation)
+    xs = x.tolist()
+    last = x.size - 1
+    out = np.empty((q.size, y.shape[1]))
+    for s in range(y.shape[1]):
+        ys = y[:, s]
+        for i, v in enumerate(q):
+            if not np.isfinite(v):
+                out[i, s] = np.nan
+                continue
+            if method == "linear":
+                if v < x[0]:
+                    piece = 0 if extrap else None
+                elif v > x[last]:
+                    piece = last - 1 if extrap else None
+                elif v == x[last]:
+                    piece = last - 1
+                else:
+                    idx = bisect.bisect_left(xs, v)
+                    piece = min(idx, last - 1) if idx < x.size and x[idx] == v else (idx - 1 if 0 < idx < x.size else None)
+                if piece is None:
+                    out[i, s] = oor
+                else:
+                    h = x[piece + 1] - x[piece]
+                    t = (v - x[piece]) / h
+                    out[i, s] = ys[piece] + t * (ys[piece + 1] - ys[piece])
+            elif v < x[0]:
+                out[i, s] = ys[0] if extrap else oor
+            elif v > x[last]:
+                out[i, s] = ys[last] if extrap else oor
+            else:
+                idx = bisect.bisect_left(xs, v)
+                if idx < x.size and x[idx] == v:
+                    out[i, s] = ys[idx]
+                else:
+                    left, right = max(idx - 1, 0), min(idx, last)
+                    out[i, s] = ys[left] if abs(v - x[left]) <= abs(x[right] - v) else ys[right]
+    return out
+
+
 def iir_filter(b, a, x, dim: int = 0, zi=None):
     """filter_host, filter.rs:1119-1222, on real data: direct form II transposed per channel, all channels advanced together (numpy applies
     the same rounded operation to each).  Coefficients normalised as `Complex /= a0` rounds them: (c * a0 + 0) / (a0 * a0 + 0).

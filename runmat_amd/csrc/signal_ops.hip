@@ -3,6 +3,7 @@
 //   conv2d            lib.rs:2543-2550    (builtins/math/signal/conv2.rs:595-640; simple_provider.rs:6065-6154)
 //   hann_window / hamming_window / blackman_window   lib.rs:1797-1807   (simple_provider.rs:95-120, 6453-6472)
 //   iir_filter        lib.rs:2551-2559    (builtins/math/signal/filter.rs:1119-1222, 1311-1319, 1370-1460)
+//   interp1           lib.rs:2458-2463    (runmat-accelerate/src/simple_provider.rs:1396-1472, 8135-8204)
 //   polyval           lib.rs:1652-1660    (builtins/math/poly/polyval.rs:886-905, 352-435)
 //   moving_window     lib.rs:2852-2857    (builtins/math/reduction/moving.rs:737-825, 929-1003, 1198-1237, 1282-1323)
 // The convolutions are DIRECT sums in the CPU's order (output n receives a[i] * b[n - i] for i ascending, every product rounded before it
@@ -275,6 +276,67 @@ __global__ void __launch_bounds__(kB) k_iir(const double* __restrict__ x, const 
         if ((u64)i < state_len) zf[l + (u64)i * leading + t * leading * state_len] = st[i];
 }
 
+// interp1 (runmat-accelerate/src/simple_provider.rs:1396-1472, 8135-8204): one thread per (series, query) - a binary search of the strictly
+// increasing sample coordinates, then the CPU's four operations (linear) or its nearer-neighbour rule (ties to the left).
+__device__ __forceinline__ long long interp_search(const double* __restrict__ x, u64 n, double q, bool* exact) {  // Rust's binary_search_by on distinct keys
+    u64 lo = 0, hi = n;
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (x[mid] < q) lo = mid + 1;
+        else hi = mid;
+    }
+    *exact = lo < n && x[lo] == q;
+    return (long long)lo;  // Ok(lo) when exact, else Err(lo): the insertion point
+}
+
+__global__ void __launch_bounds__(kB) k_interp1(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ xq, u64 n, u64 qlen, u64 total, int nearest,
+                                                int extrapolation, double fill, double* __restrict__ out) {
+    const u64 o = (u64)blockIdx.x * kB + threadIdx.x;
+    if (o >= total) return;
+    const double q = xq[o % qlen];
+    const double* ys = y + (o / qlen) * n;
+    const double oor = extrapolation == 2 ? fill : NAN;  // interp1_out_of_range
+    double r;
+    if (!isfinite(q)) {
+        r = NAN;
+    } else if (!nearest) {
+        long long piece = -1;
+        const u64 last = n - 1;
+        if (q < x[0]) piece = extrapolation == 1 ? 0 : -1;
+        else if (q > x[last]) piece = extrapolation == 1 ? (long long)last - 1 : -1;
+        else if (q == x[last]) piece = (long long)last - 1;
+        else {
+            bool exact;
+            const long long idx = interp_search(x, n, q, &exact);
+            if (exact) piece = idx < (long long)last - 1 ? idx : (long long)last - 1;
+            else if (idx > 0 && idx < (long long)n) piece = idx - 1;
+        }
+        if (piece < 0) {
+            r = oor;
+        } else {
+            const double h = x[piece + 1] - x[piece];
+            const double t = (q - x[piece]) / h;
+            const double d = ys[piece + 1] - ys[piece];
+            const double p = t * d;
+            r = ys[piece] + p;
+        }
+    } else if (q < x[0]) {
+        r = extrapolation == 1 ? ys[0] : oor;
+    } else if (q > x[n - 1]) {
+        r = extrapolation == 1 ? ys[n - 1] : oor;
+    } else {
+        bool exact;
+        const long long idx = interp_search(x, n, q, &exact);
+        if (exact) {
+            r = ys[idx];
+        } else {
+            const u64 left = idx > 0 ? (u64)idx - 1 : 0, right = (u64)idx < n - 1 ? (u64)idx : n - 1;
+            r = fabs(q - x[left]) <= fabs(x[right] - q) ? ys[left] : ys[right];
+        }
+    }
+    out[o] = r;
+}
+
 inline unsigned grid_for(u64 n) { return (unsigned)((n + kB - 1) / kB); }
 
 }  // namespace
@@ -477,6 +539,34 @@ int rmhip_iir_filter(rmhip_ctx* ctx, rmhip_buf b, rmhip_buf a, rmhip_buf x, int 
         *output = *final_state = 0;
     }
     return rc;
+}
+
+int rmhip_interp1(rmhip_ctx* ctx, rmhip_buf x, rmhip_buf y, rmhip_buf xq, size_t sample_len, size_t series_count, size_t query_len, const size_t* output_shape,
+                  size_t out_rank, int nearest, int extrapolation, double extrapolation_value, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out || (out_rank && !output_shape)) return fail(RMHIP_ERR_INVALID, "interp1: null argument");
+    if (extrapolation < 0 || extrapolation > 2) return fail(RMHIP_ERR_INVALID, "interp1: extrapolation %d", extrapolation);
+    if (sample_len < 2) return fail(RMHIP_ERR_INVALID, "interp1: sample_len must be at least 2");
+    if (series_count < 1) return fail(RMHIP_ERR_INVALID, "interp1: series_count must be positive");
+    Buffer xb, yb, qb;
+    RMHIP_TRY(c->get(x, &xb));
+    RMHIP_TRY(c->get(y, &yb));
+    RMHIP_TRY(c->get(xq, &qb));
+    u64 olen = 1;
+    for (size_t d = 0; d < out_rank; ++d) olen *= output_shape[d];
+    if (olen != (u64)query_len * series_count) return fail(RMHIP_ERR_SHAPE, "interp1: output shape does not match query/series count");
+    if (xb.numel != sample_len) return fail(RMHIP_ERR_SHAPE, "interp1: X length does not match sample_len");
+    if (yb.numel != sample_len * series_count) return fail(RMHIP_ERR_SHAPE, "interp1: Y length does not match sample/series count");
+    if (qb.numel != query_len) return fail(RMHIP_ERR_SHAPE, "interp1: Xq length does not match query_len");
+    Buffer ob;
+    RMHIP_TRY(c->new_buffer(output_shape, out_rank, out, &ob));
+    if (ob.numel == 0) return RMHIP_OK;
+    if (ob.numel > 0x7fffffffull * kB) return fail(RMHIP_ERR_UNSUPPORTED, "interp1: %zu outputs", ob.numel);
+    hipLaunchKernelGGL(k_interp1, dim3(grid_for(ob.numel)), dim3(kB), 0, c->stream, xb.data(), yb.data(), qb.data(), (u64)sample_len, (u64)query_len, (u64)ob.numel, nearest ? 1 : 0,
+                       extrapolation, extrapolation_value, ob.data());
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
 }
 
 int rmhip_polyval(rmhip_ctx* ctx, rmhip_buf coefficients, rmhip_buf points, int has_mu, double mean, double scale, rmhip_buf* out) {

@@ -1118,6 +1118,17 @@ class HipProvider:
                                                1 if unit_denominator else 0, C.byref(out), C.byref(fin)))
         return self._handle(out.value), self._handle(fin.value)
 
+    def interp1(self, x, y, xq, sample_len: int, series_count: int, query_len: int, output_shape, method: str = "linear", extrapolation="nan") -> GpuTensorHandle:
+        """lib.rs:2458-2463 (`ProviderInterp1Request`, :769-783); extrapolation: "nan" | "extrapolate" | a fill value."""
+        if method not in ("linear", "nearest"):
+            raise RmhipError(1, f"interp1: method {method!r}")
+        mode, fill = (0, 0.0) if extrapolation == "nan" else (1, 0.0) if extrapolation == "extrapolate" else (2, float(extrapolation))
+        sh, rank = _shape_array(output_shape)
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_interp1(self._ctx, self._id(x), self._id(y), self._id(xq), int(sample_len), int(series_count), int(query_len), sh, rank,
+                                            1 if method == "nearest" else 0, mode, fill, C.byref(out)))
+        return self._handle(out.value)
+
     def polyval(self, coefficients, points, mu: Optional[Tuple[float, float]] = None) -> GpuTensorHandle:
         """lib.rs:1652-1660 (`ProviderPolyvalOptions { mu: Option<{mean, scale}> }`, :705-713)."""
         out = C.c_uint64()

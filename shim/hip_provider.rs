@@ -16,7 +16,7 @@ use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle, GpuTensorStorage,
     HostLogicalOwned, HostTensorOwned, HostTensorView, IsMemberOptions, IsMemberResult, SetdiffOptions, SetdiffOrder, SetdiffResult, UnionOptions, UnionOrder, UnionResult, UniqueOccurrence, UniqueOptions, UniqueOrder, UniqueResult, ImageNormalizeDescriptor, KernelAttrTelemetry, MeshgridAxisView, ProviderMeshgridResult, ProviderPolyvalOptions, KernelLaunchTelemetry, MatmulEpilogue,
-    PowerStepEpilogue, ProviderBandwidth, ProviderIirFilterOptions, ProviderIirFilterResult, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
+    PowerStepEpilogue, ProviderBandwidth, ProviderIirFilterOptions, ProviderIirFilterResult, ProviderInterp1Extrapolation, ProviderInterp1Method, ProviderInterp1Request, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderMovingWindowEndpoints, ProviderMovingWindowOp, ProviderMovingWindowRequest, ProviderNanMode, ProviderNdgridRequest, ProviderNormOrder, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
     ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult, SortRowsColumnSpec,
 };
@@ -773,6 +773,22 @@ impl AccelProvider for HipProvider {
                 mask: HostLogicalOwned { data: mask, shape: a.shape.clone() },
                 loc: HostTensorOwned { data: loc, shape: a.shape.clone(), storage: GpuTensorStorage::Real },
             })
+        })
+    }
+    fn interp1<'a>(&'a self, request: &'a ProviderInterp1Request<'a>) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let nearest = matches!(request.method, ProviderInterp1Method::Nearest) as c_int;
+            let mode = match request.extrapolation {
+                ProviderInterp1Extrapolation::Nan => 0,
+                ProviderInterp1Extrapolation::Extrapolate => 1,
+                ProviderInterp1Extrapolation::Value => 2,
+            };
+            let mut out = 0u64;
+            check(unsafe {
+                rmhip_interp1(self.ctx, self.own(request.x)?, self.own(request.y)?, self.own(request.xq)?, request.sample_len, request.series_count, request.query_len,
+                              request.output_shape.as_ptr(), request.output_shape.len(), nearest, mode, request.extrapolation_value, &mut out)
+            })?;
+            self.handle(out)
         })
     }
     fn iir_filter<'a>(&'a self, b: &'a GpuTensorHandle, a: &'a GpuTensorHandle, x: &'a GpuTensorHandle, options: ProviderIirFilterOptions)

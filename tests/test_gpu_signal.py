@@ -230,3 +230,26 @@ def test_iir_filter_limits_and_baseline_size(prov, oracle):
         sl = (slice(None), slice(0, 48)) if dim == 0 else (slice(0, 48), slice(None))
         wy, wz = oracle.iir_filter([0.1, 0.2], [1.0, -0.3], x[sl], dim)
         assert bits_equal(prov.download_matrix(y)[sl], wy) and bits_equal(prov.download(zf).reshape(zf.shape, order="F")[sl], wz)
+
+
+@pytest.mark.parametrize("n,series,nq", [(2, 1, 5), (40, 3, 205), (1000, 1, 70000), (5000, 16, 4096)], ids=str)
+def test_interp1(prov, oracle, n, series, nq):
+    rng = np.random.default_rng(n + nq)
+    x = np.cumsum(rng.uniform(0.1, 1.0, n))
+    y = rng.standard_normal((n, series))
+    q = rng.uniform(x[0] - 2, x[-1] + 2, nq)
+    q[:min(nq, n):3] = x[:min(nq, n):3]                                              # exact hits, the last sample among them
+    q[-1] = x[-1]
+    if nq > 4:
+        q[1], q[2] = np.nan, np.inf
+    hx, hy, hq = prov.upload(x.reshape(-1, 1)), prov.upload(y), prov.upload(q.reshape(1, -1))
+    for method in ("linear", "nearest"):
+        for extrapolation in ("nan", "extrapolate", -3.5):
+            want = oracle.interp1(x, y, q, method, extrapolation) if nq * series <= 20000 else None
+            got = prov.download(prov.interp1(hx, hy, hq, n, series, nq, (nq, series), method, extrapolation)).reshape((nq, series), order="F")
+            if want is None:                                                      # the python restatement is slow: a sample of the queries
+                pick = rng.integers(0, nq, size=400)
+                want, got = oracle.interp1(x, y, q[pick], method, extrapolation), got[pick]
+            assert bits_equal(got, want), (method, extrapolation)
+    with pytest.raises(Exception):
+        prov.interp1(hx, hy, hq, n, series, nq, (nq + 1, series))

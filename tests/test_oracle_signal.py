@@ -109,3 +109,26 @@ def test_filter_kats_and_scipy():
                 assert np.allclose(y2, w2, rtol=1e-12, atol=1e-12) and np.allclose(zf2, wz2, rtol=1e-12, atol=1e-12)
             else:
                 assert np.allclose(y, lfilter(b, a, x, axis=dim), rtol=1e-14, atol=0) and zf.shape[dim] == 0
+
+
+def test_interp1_against_numpy():
+    for k in K["interp1"]:
+        got = oracle.interp1(k["x"], np.array(k["y"], dtype=np.float64).reshape(k["yshape"], order="F"), k["xq"])
+        assert np.allclose(got.ravel(order="F"), k["out"], rtol=0, atol=1e-12), k
+    rng = np.random.default_rng(31)
+    x = np.cumsum(rng.uniform(0.1, 1.0, 40))
+    y = rng.standard_normal((40, 3))
+    q = np.concatenate([rng.uniform(x[0] - 2, x[-1] + 2, 200), x[[0, 5, 39]], [np.nan, np.inf]])
+    got = oracle.interp1(x, y, q, "linear", "nan")
+    inside = np.isfinite(q) & (q >= x[0]) & (q <= x[-1])
+    for s in range(3):
+        assert np.allclose(got[inside, s], np.interp(q[inside], x, y[:, s]), rtol=1e-13, atol=1e-13)
+    assert np.isnan(got[~inside]).all()
+    ex = oracle.interp1(x, y, q, "linear", "extrapolate")
+    lo = np.isfinite(q) & (q < x[0])
+    assert np.allclose(ex[lo, 0], y[0, 0] + (q[lo] - x[0]) / (x[1] - x[0]) * (y[1, 0] - y[0, 0]), rtol=1e-12)
+    assert np.all(oracle.interp1(x, y, q, "linear", 7.5)[np.isfinite(q) & ~inside] == 7.5)
+    nn = oracle.interp1(x, y, q, "nearest", "nan")
+    near = np.abs(q[inside, None] - x[None, :]).argmin(axis=1)
+    assert np.array_equal(nn[inside, 1], y[near, 1])
+    assert np.array_equal(oracle.interp1([0.0, 1.0, 2.0], [10.0, 20.0, 30.0], [0.5, 1.5], "nearest")[:, 0], [10.0, 20.0])   # ties to the left
