@@ -69,7 +69,13 @@ __global__ void __launch_bounds__(kB) k_conv2d(const double* __restrict__ a, u64
     const double* bb = b_in_lds ? taps : b;
     const u64 o = (u64)blockIdx.x * kB + threadIdx.x;
     if (o >= rows * cols) return;
-    const u64 R = r0 + o % rows, Cc = c0 + o / rows;
+    u64 R, Cc;
+    if (rows * cols <= 0xffffffffull) {
+        const unsigned q = (unsigned)o / (unsigned)rows;
+        R = r0 + ((unsigned)o - q * (unsigned)rows), Cc = c0 + q;
+    } else {
+        R = r0 + o % rows, Cc = c0 + o / rows;
+    }
     const u64 ac_lo = Cc >= bc_n - 1 ? Cc - (bc_n - 1) : 0, ac_hi = Cc < ac_n - 1 ? Cc : ac_n - 1;
     const u64 ar_lo = R >= br_n - 1 ? R - (br_n - 1) : 0, ar_hi = R < ar_n - 1 ? R : ar_n - 1;
     double acc = 0.0;
@@ -124,7 +130,14 @@ template <int OP>
 __global__ void __launch_bounds__(kB) k_moving(const double* __restrict__ x, MovingArgs A, double* __restrict__ out) {
     const u64 e = (u64)blockIdx.x * kB + threadIdx.x;
     if (e >= A.total) return;
-    const u64 i = e % A.pre, r = e / A.pre, p = r % A.out_len, o = r / A.out_len;
+    u64 i, p, o;
+    if (A.total <= 0xffffffffull) {  // 32-bit divisions when the output has fewer than 2^32 elements (a 64-bit one is ~40 instructions)
+        const unsigned e32 = (unsigned)e, pre32 = (unsigned)A.pre, ol32 = (unsigned)A.out_len, r32 = e32 / pre32;
+        i = e32 - r32 * pre32, o = r32 / ol32, p = r32 - (unsigned)o * ol32;
+    } else {
+        const u64 r = e / A.pre;
+        i = e % A.pre, p = r % A.out_len, o = r / A.out_len;
+    }
     const long long center = (long long)(A.endpoints == 1 ? p + A.before : p);
     const long long start = center - (long long)A.before, end = center + (long long)A.after;
     long long s0 = start < 0 ? 0 : start, e0 = end + 1;
@@ -136,15 +149,22 @@ __global__ void __launch_bounds__(kB) k_moving(const double* __restrict__ x, Mov
     const double* src = x + i + o * A.pre * A.len;
     double sum = -0.0, prod = 1.0, mn = INFINITY, mx = -INFINITY, mean = 0.0, m2 = 0.0;
     double med[OP == 5 ? MED_MAX : 1];
-    u64 n = 0;
+    unsigned n = 0;  // (window lengths fit 32 bits: checked by the entry point)
     bool saw_nan = false;
-    for (long long pos = s0; pos < e0; ++pos) {
-        const double v = src[(u64)pos * A.pre];
+    const double* wp = src + (u64)s0 * A.pre;  // a running pointer and a 32-bit trip count instead of 64-bit index arithmetic per point
+    const unsigned wlen = (unsigned)(e0 - s0);
+    // the window in batches of eight loads issued together: with one load per trip every point waited out a memory latency (the NaN test
+    // between two loads keeps the compiler from batching them itself)
+    for (unsigned w0 = 0; w0 < wlen && !saw_nan; w0 += 8, wp += 8 * A.pre) {
+        double batch[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) batch[u] = w0 + u < wlen ? wp[(u64)u * A.pre] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+        if (saw_nan || w0 + u >= wlen) continue;
+        const double v = batch[u];
         if (isnan(v)) {
-            if (!A.nan_omit) {
-                saw_nan = true;
-                break;
-            }
+            if (!A.nan_omit) saw_nan = true;
             continue;
         }
         ++n;
@@ -163,6 +183,7 @@ __global__ void __launch_bounds__(kB) k_moving(const double* __restrict__ x, Mov
             const double d2 = v - mean;
             m2 = m2 + d * d2;
         }
+    }
     }
     double res;
     if (fc && (saw_nan || (isnan(A.fill) && !A.nan_omit))) {
@@ -439,7 +460,7 @@ int rmhip_moving_window(rmhip_ctx* ctx, rmhip_buf a, int dim, size_t before, siz
     for (size_t k = dim + 1; k < shape.size(); ++k) A.post *= shape[k];
     A.len = shape[dim], A.out_len = want[dim], A.before = before, A.after = after;
     A.op = op, A.endpoints = endpoints, A.nan_omit = nan_omit ? 1 : 0, A.population = population ? 1 : 0, A.fill = fill;
-    if (before > (1ull << 40) || after > (1ull << 40)) return fail(RMHIP_ERR_UNSUPPORTED, "moving_window: window %zu + %zu", before, after);
+    if (before > (1ull << 30) || after > (1ull << 30)) return fail(RMHIP_ERR_UNSUPPORTED, "moving_window: window %zu + %zu", before, after);
     if (op == 5 && std::min<u64>(A.len, before + after + 1) > (u64)MED_MAX)
         return fail(RMHIP_ERR_UNSUPPORTED, "moving_window: median over windows of more than %d points", MED_MAX);
     // prod with padding multiplies by fill^count (`powf`, moving.rs:991): only fills whose every power is the fill itself stay exact
