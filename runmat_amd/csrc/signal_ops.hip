@@ -279,16 +279,25 @@ __global__ void __launch_bounds__(kB) k_iir(const double* __restrict__ x, const 
     }
     const double* src = x + t * dim_len * leading + l;
     double* dst = y + t * dim_len * leading + l;
-    for (u64 step = 0; step < dim_len; ++step) {
-        const double xn = src[step * leading];
-        const double yv = bn[0] * xn + st[0];
-        dst[step * leading] = yv;
+    // eight samples are fetched together ahead of the recurrence that consumes them: with one load per step every step waited out a memory
+    // latency (4.0 ms for 8192 channels x 8192 samples)
+    for (u64 s0 = 0; s0 < dim_len; s0 += 8) {
+        double xb[8];
 #pragma unroll
-        for (int i = 1; i < MAXO; ++i) {
-            if (i < order) {
-                const double next = (u64)i < state_len ? st[i] : 0.0;
-                const double p = bn[i] * xn, q = an[i] * yv;
-                st[i - 1] = (p + next) - q;
+        for (int u = 0; u < 8; ++u) xb[u] = s0 + u < dim_len ? src[(s0 + u) * leading] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (s0 + u >= dim_len) break;
+            const double xn = xb[u];
+            const double yv = bn[0] * xn + st[0];
+            dst[(s0 + u) * leading] = yv;
+#pragma unroll
+            for (int i = 1; i < MAXO; ++i) {
+                if (i < order) {
+                    const double next = (u64)i < state_len ? st[i] : 0.0;
+                    const double p = bn[i] * xn, q = an[i] * yv;
+                    st[i - 1] = (p + next) - q;
+                }
             }
         }
     }
