@@ -584,6 +584,12 @@ RMHIP_API int rmhip_image_normalize(rmhip_ctx* ctx, rmhip_buf input, const rmhip
  * rows - 1 <= 0 gives the all-NaN matrix the CPU returns.  The centred product runs as A'*A on the MFMA path. */
 /* @serves covariance */
 RMHIP_API int rmhip_covariance(rmhip_ctx* ctx, rmhip_buf matrix, int biased, rmhip_buf* out);
+/* `corrcoef(matrix, options)` (lib.rs:1867-1874; `CorrcoefOptions { normalization, rows }`, :906-911; corrcoef.rs:720-787, 895-926) for
+ * rows == All (rows_mode 0; Complete / Pairwise: RMHIP_ERR_UNSUPPORTED): the covariance path above, then r = cov / (sd_i sd_j) with the CPU's
+ * NaN rules (a variance that is not finite and positive), its 1e-12 clamp onto [-1, 1] and an exact unit diagonal.  Sums of products:
+ * parity by tolerance, as for `covariance` (the reference's own test allows 1e-10). */
+/* @serves corrcoef */
+RMHIP_API int rmhip_corrcoef(rmhip_ctx* ctx, rmhip_buf matrix, int biased, int rows_mode, rmhip_buf* out);
 /* `diag_extract` (lib.rs:1625-1632; simple_provider.rs:3281-3312): the offset-th diagonal of a matrix as a column
  * vector [len, 1]; vectors are rejected ("matrix input required"). */
 /* @serves diag_extract */

@@ -498,6 +498,11 @@ public:
         check(rmhip_covariance(ctx_, own(matrix), biased ? 1 : 0, &out));
         return with_shape(out);
     }
+    GpuTensorHandle corrcoef(const GpuTensorHandle& matrix, bool biased, int rows_mode = 0) const {  // lib.rs:1867 (rows_mode: 0 All, 1 Complete, 2 Pairwise)
+        uint64_t out = 0;
+        check(rmhip_corrcoef(ctx_, own(matrix), biased ? 1 : 0, rows_mode, &out));
+        return with_shape(out);
+    }
     GpuTensorHandle diag_extract(const GpuTensorHandle& matrix, long long offset) const {  // lib.rs:1625
         uint64_t out = 0;
         check(rmhip_diag_extract(ctx_, own(matrix), offset, &out));

@@ -861,6 +861,56 @@ def ismember(a, b):
     return (loc > 0).astype(np.uint8).reshape(a.shape, order="F"), loc.reshape(a.shape, order="F")
 
 
+def corrcoef(matrix, normalization: str = "unbiased") -> np.ndarray:
+    """corrcoef_dense + column_pair_corr + divide_covariance + clamp_correlation, corrcoef.rs:720-926 (rows == All): sequential sums in the
+    CPU's order; the result is written on and above the diagonal and mirrored (set_entry, :928-935)."""
+    m = np.asarray(matrix, dtype=np.float64)
+    m = m.reshape(m.shape[0], -1, order="F") if m.ndim >= 2 else m.reshape(-1, 1)
+    rows, cols = m.shape
+    out = np.full((cols, cols), np.nan)
+    if cols == 0 or rows == 0:
+        return out
+    denom = float(rows) - 1.0 if normalization == "unbiased" else float(rows)
+    if denom <= 0.0:
+        return out
+    means = np.full(cols, np.nan)
+    for c in range(cols):
+        fin = m[np.isfinite(m[:, c]), c]
+        if fin.size:
+            s = 0.0
+            for v in fin:
+                s += v
+            means[c] = s / fin.size
+    for c in range(cols):
+        if not np.isfinite(means[c]) or not np.isfinite(m[:, c]).all():
+            continue
+        var = 0.0
+        for v in m[:, c]:
+            d = v - means[c]
+            var += d * d
+        var /= denom
+        out[c, c] = 1.0 if np.sqrt(max(var, 0.0) if -1e-12 < var < 0 else var) > 0.0 else np.nan
+        for o in range(c + 1, cols):
+            if not np.isfinite(means[o]) or not np.isfinite(m[:, o]).all():
+                continue
+            vx = vy = cv = 0.0
+            for a, b in zip(m[:, c], m[:, o]):
+                dx, dy = a - means[c], b - means[o]
+                vx += dx * dx
+                vy += dy * dy
+                cv += dx * dy
+            vx, vy, cv = vx / denom, vy / denom, cv / denom
+            r = np.nan
+            if np.isfinite(vx) and np.isfinite(vy) and vx > 0 and vy > 0:
+                r = cv / (np.sqrt(vx) * np.sqrt(vy))
+                if r > 1.0 and r - 1.0 < 1e-12:
+                    r = 1.0
+                elif r < -1.0 and -1.0 - r < 1e-12:
+                    r = -1.0
+            out[c, o] = out[o, c] = r
+    return out
+
+
 def interp1(x, y, xq, method: str = "linear", extrapolation="nan") -> np.ndarray:
     """interp1_value / interp1_interval_index, simple_provider.rs:1396-1472: y as [sample_len, series]; returns [query_len, series].
     extrapolation: "nan" | "extrapolate" | a fill value."""

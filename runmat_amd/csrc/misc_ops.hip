@@ -184,6 +184,29 @@ __global__ void __launch_bounds__(kB) k_bandwidth(const double* __restrict__ a, 
     }
 }
 
+// corrcoef from the covariance matrix (corrcoef.rs:720-787, 895-926): r(i, j) = cov(i, j) / (sqrt(var_i) sqrt(var_j)), NaN unless both variances
+// are finite and positive, values within 1e-12 outside [-1, 1] pulled onto the bound; the diagonal is exactly 1 where the deviation is positive.
+__global__ void __launch_bounds__(kB) k_corr_from_cov(const double* __restrict__ cov, u64 n, double* __restrict__ out) {
+    const u64 o = (u64)blockIdx.x * kB + threadIdx.x;
+    if (o >= n * n) return;
+    const u64 i = o % n, j = o / n;
+    const double vi = cov[i + i * n], vj = cov[j + j * n];
+    double r = NAN;
+    if (i == j) {
+        double v = vi;
+        if (v < 0.0 && v > -1.0e-12) v = 0.0;
+        if (!isnan(v) && sqrt(v) > 0.0) r = 1.0;
+    } else if (isfinite(vi) && isfinite(vj) && vi > 0.0 && vj > 0.0) {
+        const double sx = sqrt(vi), sy = sqrt(vj);
+        if (sx != 0.0 && sy != 0.0) {
+            r = cov[o] / (sx * sy);
+            if (r > 1.0 && r - 1.0 < 1.0e-12) r = 1.0;
+            else if (r < -1.0 && -1.0 - r < 1.0e-12) r = -1.0;
+        }
+    }
+    out[o] = r;
+}
+
 // trapezoid terms: t[k + 1] = 0.5 * w_k * (x[k] + x[k + 1]), t[0] = 0 along the dimension (simple_provider.rs:2534-2563); their running /
 // total sums are the library's cumulative-scan and reduction kernels.  KIND: 0 unit, 1 scalar, 3 coordinate vector, 4 spacing tensor.
 template <int KIND>
@@ -565,6 +588,28 @@ int rmhip_bandwidth(rmhip_ctx* ctx, rmhip_buf a, unsigned* lower, unsigned* uppe
     *lower = host[0];
     *upper = host[1];
     return RMHIP_OK;
+}
+
+int rmhip_corrcoef(rmhip_ctx* ctx, rmhip_buf matrix, int biased, int rows_mode, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    if (rows_mode != 0) return fail(RMHIP_ERR_UNSUPPORTED, "corrcoef: 'complete' / 'pairwise' row selection uses the CPU path");
+    Buffer mb;
+    RMHIP_TRY(c->get_raw(matrix, &mb));  // shape only
+    if (mb.shape.size() > 2) return fail(RMHIP_ERR_INVALID, "corrcoef: inputs must be 2-D matrices or vectors");
+    rmhip_buf cov = 0;
+    RMHIP_TRY(rmhip_covariance(ctx, matrix, biased, &cov));  // [cols, cols]; all NaN when the denominator is not positive (corrcoef.rs:726-735)
+    Buffer cb, ob;
+    int rc = c->get(cov, &cb);
+    if (rc == RMHIP_OK) rc = c->new_buffer(cb.shape.data(), cb.shape.size(), out, &ob);
+    if (rc == RMHIP_OK && ob.numel) {
+        const u64 n = cb.shape.empty() ? 1 : cb.shape[0];
+        hipLaunchKernelGGL(k_corr_from_cov, dim3(grid_for(ob.numel)), dim3(kB), 0, c->stream, cb.data(), n, ob.data());
+        c->tel.kernel_launches++;
+        if (hipGetLastError() != hipSuccess) rc = fail(RMHIP_ERR_HIP, "corrcoef: launch failed");
+    }
+    rmhip_free(ctx, cov);
+    return rc;
 }
 
 int rmhip_trapz_dim(rmhip_ctx* ctx, rmhip_buf a, int dim, int cumulative, int spacing_kind, double scalar, rmhip_buf spacing_or_0, rmhip_buf* out) {

@@ -762,6 +762,14 @@ class HipProvider:
         self._check(self._lib.rmhip_covariance(self._ctx, self._id(matrix), int(bool(biased)), C.byref(out)))
         return self._handle(out.value)
 
+    def corrcoef(self, matrix: GpuTensorHandle, normalization: str = "unbiased", rows: str = "all") -> GpuTensorHandle:
+        """lib.rs:1867-1874 (`CorrcoefOptions`, :906-911): only rows == "all" is offloaded (what corrcoef_try_gpu issues, corrcoef.rs:480-483)."""
+        if normalization not in ("unbiased", "biased") or rows not in ("all", "complete", "pairwise"):
+            raise RmhipError(1, f"corrcoef: normalization {normalization!r} / rows {rows!r}")
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_corrcoef(self._ctx, self._id(matrix), 1 if normalization == "biased" else 0, {"all": 0, "complete": 1, "pairwise": 2}[rows], C.byref(out)))
+        return self._handle(out.value)
+
     def diag_extract(self, matrix: GpuTensorHandle, offset: int = 0) -> GpuTensorHandle:
         """lib.rs:1625-1632"""
         out = C.c_uint64()

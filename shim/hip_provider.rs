@@ -14,7 +14,7 @@
 
 use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
-    AccelProvider, AccelProviderFuture, ApiDeviceInfo, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle, GpuTensorStorage,
+    AccelProvider, AccelProviderFuture, ApiDeviceInfo, CorrcoefNormalization, CorrcoefOptions, CorrcoefRows, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle, GpuTensorStorage,
     HostLogicalOwned, HostTensorOwned, HostTensorView, IsMemberOptions, IsMemberResult, SetdiffOptions, SetdiffOrder, SetdiffResult, UnionOptions, UnionOrder, UnionResult, UniqueOccurrence, UniqueOptions, UniqueOrder, UniqueResult, ImageNormalizeDescriptor, KernelAttrTelemetry, MeshgridAxisView, ProviderMeshgridResult, ProviderPolyvalOptions, KernelLaunchTelemetry, MatmulEpilogue,
     PowerStepEpilogue, ProviderBandwidth, ProviderIirFilterOptions, ProviderIirFilterResult, ProviderInterp1Extrapolation, ProviderInterp1Method, ProviderInterp1Request, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderMovingWindowEndpoints, ProviderMovingWindowOp, ProviderMovingWindowRequest, ProviderNanMode, ProviderNdgridRequest, ProviderNormOrder, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
@@ -526,6 +526,15 @@ impl AccelProvider for HipProvider {
             let mut out = 0u64;
             let biased = matches!(options.normalization, CovNormalization::Biased) as c_int;
             check(unsafe { rmhip_covariance(self.ctx, self.own(matrix)?, biased, &mut out) })?;
+            self.handle(out)
+        })
+    }
+    fn corrcoef<'a>(&'a self, matrix: &'a GpuTensorHandle, options: &'a CorrcoefOptions) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let biased = matches!(options.normalization, CorrcoefNormalization::Biased) as c_int;
+            let rows = match options.rows { CorrcoefRows::All => 0, CorrcoefRows::Complete => 1, CorrcoefRows::Pairwise => 2 };
+            let mut out = 0u64;
+            check(unsafe { rmhip_corrcoef(self.ctx, self.own(matrix)?, biased, rows, &mut out) })?;
             self.handle(out)
         })
     }

@@ -335,3 +335,26 @@ def test_norm(prov, oracle):
     x = prov.download_matrix(h)
     assert abs(val(h, "fro") / np.linalg.norm(x) - 1) < 1e-13 and abs(val(h, "one") / np.abs(x).sum(axis=0).max() - 1) < 1e-13
     assert abs(val(h, "inf") / np.abs(x).sum(axis=1).max() - 1) < 1e-13
+
+
+@pytest.mark.parametrize("shape", [(4, 3), (50, 6), (3000, 40), (100000, 8), (1, 3), (2, 2)], ids=str)
+def test_corrcoef(prov, oracle, shape):
+    """Sums of products: parity by tolerance, as for covariance - 1e-12 absolute on values in [-1, 1] (the reference's test allows 1e-10)."""
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape) * rng.uniform(0.1, 10.0, (1, shape[1])) + rng.uniform(-5, 5, (1, shape[1]))
+    for norm in ("unbiased", "biased"):
+        got = prov.download_matrix(prov.corrcoef(prov.upload(x), norm))
+        want = oracle.corrcoef(x, norm) if shape[0] <= 5000 else np.corrcoef(x, rowvar=False)
+        assert got.shape == want.shape and np.array_equal(np.isnan(got), np.isnan(want))
+        ok = ~np.isnan(want)
+        assert np.all(np.abs(got[ok] - want[ok]) <= 1e-12) and (shape[0] < 2 or np.all(np.diag(got) == 1.0))
+    if shape[0] >= 4:
+        y = x.copy()
+        y[:, 0] = 2.5                                                               # constant column
+        y[1, -1] = np.inf                                                           # non-finite sample
+        got, want = prov.download_matrix(prov.corrcoef(prov.upload(y))), oracle.corrcoef(y) if shape[0] <= 5000 else None
+        assert np.isnan(got[0]).all() and np.isnan(got[:, 0]).all() and np.isnan(got[-1]).all()
+        if want is not None:
+            assert np.array_equal(np.isnan(got), np.isnan(want))
+    with pytest.raises(Exception):
+        prov.corrcoef(prov.upload(x), rows="pairwise")

@@ -132,3 +132,19 @@ def test_norm_restatement_on_the_reference_vectors():
     assert abs(oracle.norm(x, "fro") - np.linalg.norm(x)) < 1e-12 and abs(oracle.norm(x, "one") - np.linalg.norm(x, 1)) < 1e-12
     assert abs(oracle.norm(x, "inf") - np.linalg.norm(x, np.inf)) < 1e-12 and np.isnan(oracle.norm(np.array([[1.0], [np.nan]]), "inf"))
     assert oracle.norm(np.array([[1e200], [1e200]])) == np.sqrt(2.0) * 1e200                      # the running rescale: no overflow
+
+
+def test_corrcoef_kat_and_numpy():
+    # corrcoef.rs:1005-1034 (`corrcoef_matrix_basic`, tolerance 1e-10)
+    m = np.array([1.0, 2.0, 3.0, 4.0, 2.0, 4.0, 6.0, 8.0, 4.0, 1.0, -1.0, 0.0]).reshape((4, 3), order="F")
+    want = np.array([1.0, 1.0, -0.836660026534, 1.0, 1.0, -0.836660026534, -0.836660026534, -0.836660026534, 1.0]).reshape(3, 3)
+    assert np.allclose(oracle.corrcoef(m), want, rtol=0, atol=1e-10)
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((50, 6))
+    assert np.allclose(oracle.corrcoef(x), np.corrcoef(x, rowvar=False), rtol=0, atol=1e-14)
+    assert np.allclose(oracle.corrcoef(x, "biased"), np.corrcoef(x, rowvar=False), rtol=0, atol=1e-14)   # the denominators cancel
+    x[:, 2] = 3.0                                                                   # a constant column: NaN row / column, NaN diagonal
+    x[7, 4] = np.nan
+    r = oracle.corrcoef(x)
+    assert np.isnan(r[2]).all() and np.isnan(r[:, 4]).all() and r[0, 0] == 1.0 and np.isfinite(r[0, 1])
+    assert np.isnan(oracle.corrcoef(np.ones((1, 3)))).all() and oracle.corrcoef(np.zeros((4, 0))).shape == (0, 0)
