@@ -584,6 +584,11 @@ RMHIP_API int rmhip_image_normalize(rmhip_ctx* ctx, rmhip_buf input, const rmhip
  * rows - 1 <= 0 gives the all-NaN matrix the CPU returns.  The centred product runs as A'*A on the MFMA path. */
 /* @serves covariance */
 RMHIP_API int rmhip_covariance(rmhip_ctx* ctx, rmhip_buf matrix, int biased, rmhip_buf* out);
+/* `peaks(n)` (x_or_0 == y_or_0 == 0; lib.rs:1781-1785) / `peaks_xy(x, y)` (lib.rs:1787-1795; peaks.rs:511-550): the `peaks` test surface on the
+ * n x n grid over [-3, 3]^2 (n == 1: the point (3, 3)), or at same-shape coordinate tensors.  Products and sums in the CPU's order; three
+ * exponentials per point: within 2e-14 absolute of the oracle (terms of magnitude up to ~8). */
+/* @serves peaks peaks_xy */
+RMHIP_API int rmhip_peaks(rmhip_ctx* ctx, size_t n, rmhip_buf x_or_0, rmhip_buf y_or_0, rmhip_buf* out);
 /* `corrcoef(matrix, options)` (lib.rs:1867-1874; `CorrcoefOptions { normalization, rows }`, :906-911; corrcoef.rs:720-787, 895-926) for
  * rows == All (rows_mode 0; Complete / Pairwise: RMHIP_ERR_UNSUPPORTED): the covariance path above, then r = cov / (sd_i sd_j) with the CPU's
  * NaN rules (a variance that is not finite and positive), its 1e-12 clamp onto [-1, 1] and an exact unit diagonal.  Sums of products:

@@ -498,6 +498,16 @@ public:
         check(rmhip_covariance(ctx_, own(matrix), biased ? 1 : 0, &out));
         return with_shape(out);
     }
+    GpuTensorHandle peaks(size_t n) const {  // lib.rs:1781
+        uint64_t out = 0;
+        check(rmhip_peaks(ctx_, n, 0, 0, &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle peaks_xy(const GpuTensorHandle& x, const GpuTensorHandle& y) const {  // lib.rs:1787
+        uint64_t out = 0;
+        check(rmhip_peaks(ctx_, 0, own(x), own(y), &out));
+        return with_shape(out);
+    }
     GpuTensorHandle corrcoef(const GpuTensorHandle& matrix, bool biased, int rows_mode = 0) const {  // lib.rs:1867 (rows_mode: 0 All, 1 Complete, 2 Pairwise)
         uint64_t out = 0;
         check(rmhip_corrcoef(ctx_, own(matrix), biased ? 1 : 0, rows_mode, &out));

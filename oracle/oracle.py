@@ -861,6 +861,23 @@ def ismember(a, b):
     return (loc > 0).astype(np.uint8).reshape(a.shape, order="F"), loc.reshape(a.shape, order="F")
 
 
+def peaks_xy(x, y) -> np.ndarray:
+    """peaks_at, peaks.rs:546-550 (powi(2/3/5) as the repeated products they compile to), elementwise."""
+    x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+    x2, y2 = x * x, y * y
+    a, yp, xp = 1.0 - x, y + 1.0, x + 1.0
+    t1 = 3.0 * (a * a) * np.exp(-x2 - yp * yp)
+    t2 = 10.0 * (x / 5.0 - x2 * x - (y2 * y2) * y) * np.exp(-x2 - y2)
+    t3 = 1.0 / 3.0 * np.exp(-(xp * xp) - y2)
+    return t1 - t2 - t3
+
+
+def peaks(n: int) -> np.ndarray:
+    """make_axis + make_grids, peaks.rs:511-541: X(row, col) = axis[col], Y(row, col) = axis[row]."""
+    axis = np.array([3.0]) if n == 1 else np.array([-3.0 + 6.0 * i / (n - 1) for i in range(n)], dtype=np.float64).reshape(-1) if n else np.zeros(0)
+    return peaks_xy(np.tile(axis.reshape(1, -1), (n, 1)), np.tile(axis.reshape(-1, 1), (1, n)))
+
+
 def corrcoef(matrix, normalization: str = "unbiased") -> np.ndarray:
     """corrcoef_dense + column_pair_corr + divide_covariance + clamp_correlation, corrcoef.rs:720-926 (rows == All): sequential sums in the
     CPU's order; the result is written on and above the diagonal and mirrored (set_entry, :928-935)."""

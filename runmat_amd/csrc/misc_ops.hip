@@ -184,6 +184,32 @@ __global__ void __launch_bounds__(kB) k_bandwidth(const double* __restrict__ a, 
     }
 }
 
+// peaks (builtins/array/creation/peaks.rs:511-550): the test surface, every product and sum in the CPU's order; three exponentials per point
+// (the device's, within an ulp of the host libm's: tests state the bound).  GRID: x = -3 + 6 col / (n - 1), y likewise from the row.
+__device__ __forceinline__ double peaks_at(double x, double y) {
+    const double x2 = x * x, y2 = y * y, x3 = x2 * x, y5 = (y2 * y2) * y;
+    const double a = 1.0 - x, yp = y + 1.0, xp = x + 1.0;
+    const double t1 = 3.0 * (a * a) * exp(-x2 - yp * yp);
+    const double t2 = 10.0 * (x / 5.0 - x3 - y5) * exp(-x2 - y2);
+    const double t3 = 1.0 / 3.0 * exp(-(xp * xp) - y2);
+    return t1 - t2 - t3;
+}
+
+template <bool GRID>
+__global__ void __launch_bounds__(kB) k_peaks(const double* __restrict__ xs, const double* __restrict__ ys, u64 n, u64 total, double* __restrict__ out) {
+    const u64 o = (u64)blockIdx.x * kB + threadIdx.x;
+    if (o >= total) return;
+    double x, y;
+    if (GRID) {
+        const u64 row = o % n, col = o / n;
+        x = n == 1 ? 3.0 : -3.0 + 6.0 * (double)col / (double)(n - 1);
+        y = n == 1 ? 3.0 : -3.0 + 6.0 * (double)row / (double)(n - 1);
+    } else {
+        x = xs[o], y = ys[o];
+    }
+    out[o] = peaks_at(x, y);
+}
+
 // corrcoef from the covariance matrix (corrcoef.rs:720-787, 895-926): r(i, j) = cov(i, j) / (sqrt(var_i) sqrt(var_j)), NaN unless both variances
 // are finite and positive, values within 1e-12 outside [-1, 1] pulled onto the bound; the diagonal is exactly 1 where the deviation is positive.
 __global__ void __launch_bounds__(kB) k_corr_from_cov(const double* __restrict__ cov, u64 n, double* __restrict__ out) {
@@ -587,6 +613,29 @@ int rmhip_bandwidth(rmhip_ctx* ctx, rmhip_buf a, unsigned* lower, unsigned* uppe
     RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
     *lower = host[0];
     *upper = host[1];
+    return RMHIP_OK;
+}
+
+int rmhip_peaks(rmhip_ctx* ctx, size_t n, rmhip_buf x_or_0, rmhip_buf y_or_0, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer xb, yb, ob;
+    if (x_or_0 || y_or_0) {  // peaks_xy: same-shape coordinate tensors
+        if (!x_or_0 || !y_or_0) return fail(RMHIP_ERR_INVALID, "peaks_xy: both coordinate tensors are required");
+        RMHIP_TRY(c->get(x_or_0, &xb));
+        RMHIP_TRY(c->get(y_or_0, &yb));
+        if (xb.shape != yb.shape) return fail(RMHIP_ERR_SHAPE, "peaks: X and Y must be the same size");
+        RMHIP_TRY(c->new_buffer(xb.shape.data(), xb.shape.size(), out, &ob));
+        if (ob.numel == 0) return RMHIP_OK;
+        hipLaunchKernelGGL(k_peaks<false>, dim3(grid_for(ob.numel)), dim3(kB), 0, c->stream, xb.data(), yb.data(), (u64)0, (u64)ob.numel, ob.data());
+    } else {
+        const size_t shape[2] = {n, n};
+        RMHIP_TRY(c->new_buffer(shape, 2, out, &ob));
+        if (ob.numel == 0) return RMHIP_OK;
+        hipLaunchKernelGGL(k_peaks<true>, dim3(grid_for(ob.numel)), dim3(kB), 0, c->stream, (const double*)nullptr, (const double*)nullptr, (u64)n, (u64)ob.numel, ob.data());
+    }
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
 }
 

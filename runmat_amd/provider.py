@@ -762,6 +762,18 @@ class HipProvider:
         self._check(self._lib.rmhip_covariance(self._ctx, self._id(matrix), int(bool(biased)), C.byref(out)))
         return self._handle(out.value)
 
+    def peaks(self, n: int) -> GpuTensorHandle:
+        """lib.rs:1781-1785: Z of the peaks surface on the n x n grid over [-3, 3] x [-3, 3]."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_peaks(self._ctx, int(n), 0, 0, C.byref(out)))
+        return self._handle(out.value)
+
+    def peaks_xy(self, x, y) -> GpuTensorHandle:
+        """lib.rs:1787-1795: the peaks formula at same-shape coordinate tensors."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_peaks(self._ctx, 0, self._id(x), self._id(y), C.byref(out)))
+        return self._handle(out.value)
+
     def corrcoef(self, matrix: GpuTensorHandle, normalization: str = "unbiased", rows: str = "all") -> GpuTensorHandle:
         """lib.rs:1867-1874 (`CorrcoefOptions`, :906-911): only rows == "all" is offloaded (what corrcoef_try_gpu issues, corrcoef.rs:480-483)."""
         if normalization not in ("unbiased", "biased") or rows not in ("all", "complete", "pairwise"):

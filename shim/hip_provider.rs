@@ -529,6 +529,16 @@ impl AccelProvider for HipProvider {
             self.handle(out)
         })
     }
+    fn peaks(&self, n: usize) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_peaks(self.ctx, n, 0, 0, &mut out) })?;
+        self.handle(out)
+    }
+    fn peaks_xy(&self, x: &GpuTensorHandle, y: &GpuTensorHandle) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_peaks(self.ctx, 0, self.own(x)?, self.own(y)?, &mut out) })?;
+        self.handle(out)
+    }
     fn corrcoef<'a>(&'a self, matrix: &'a GpuTensorHandle, options: &'a CorrcoefOptions) -> AccelProviderFuture<'a, GpuTensorHandle> {
         Box::pin(async move {
             let biased = matches!(options.normalization, CorrcoefNormalization::Biased) as c_int;

@@ -358,3 +358,14 @@ def test_corrcoef(prov, oracle, shape):
             assert np.array_equal(np.isnan(got), np.isnan(want))
     with pytest.raises(Exception):
         prov.corrcoef(prov.upload(x), rows="pairwise")
+
+
+def test_peaks(prov, oracle):
+    for n in (0, 1, 2, 49, 1000):
+        got, want = prov.download_matrix(prov.peaks(n)), oracle.peaks(n)
+        assert got.shape == want.shape and (n == 0 or np.max(np.abs(got - want)) <= 2e-14)
+    rng = np.random.default_rng(8)
+    x, y = rng.uniform(-3, 3, (300, 7)), rng.uniform(-3, 3, (300, 7))
+    assert np.max(np.abs(prov.download_matrix(prov.peaks_xy(prov.upload(x), prov.upload(y))) - oracle.peaks_xy(x, y))) <= 2e-14
+    with pytest.raises(Exception):
+        prov.peaks_xy(prov.upload(x), prov.upload(y.T))

@@ -148,3 +148,11 @@ def test_corrcoef_kat_and_numpy():
     r = oracle.corrcoef(x)
     assert np.isnan(r[2]).all() and np.isnan(r[:, 4]).all() and r[0, 0] == 1.0 and np.isfinite(r[0, 1])
     assert np.isnan(oracle.corrcoef(np.ones((1, 3)))).all() and oracle.corrcoef(np.zeros((4, 0))).shape == (0, 0)
+
+
+def test_peaks_known_values():
+    # peaks.rs:735-746 (`peaks_formula_known_value`): Z(0, 0) = exp(-1) * 8 / 3 within 1e-12
+    assert abs(oracle.peaks_xy(0.0, 0.0) - np.exp(-1.0) * 8.0 / 3.0) < 1e-12
+    z = oracle.peaks(49)
+    assert z.shape == (49, 49) and abs(z.max() - 8.1) < 0.1 and abs(z.min() + 6.55) < 0.1      # MATLAB's surface: peak ~8.1, trough ~-6.55
+    assert oracle.peaks(1).shape == (1, 1) and oracle.peaks(0).shape == (0, 0)
