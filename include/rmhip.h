@@ -584,6 +584,17 @@ RMHIP_API int rmhip_image_normalize(rmhip_ctx* ctx, rmhip_buf input, const rmhip
  * rows - 1 <= 0 gives the all-NaN matrix the CPU returns.  The centred product runs as A'*A on the MFMA path. */
 /* @serves covariance */
 RMHIP_API int rmhip_covariance(rmhip_ctx* ctx, rmhip_buf matrix, int biased, rmhip_buf* out);
+/* `rank(matrix, tolerance)` (lib.rs:2464-2470; rank.rs:280-295), `cond(matrix, norm)` for the 2-norm (norm == 0; lib.rs:2444-2450; cond.rs:276-330,
+ * 448-467; the other norms: RMHIP_ERR_UNSUPPORTED) and `pinv(matrix, options)` (lib.rs:2437-2443; pinv.rs:242-285) from the one-sided Jacobi SVD of
+ * svdsolve.hip (min(rows, cols) <= 4096, finite data; else RMHIP_ERR_UNSUPPORTED): rank = singular values above the tolerance (default max(m, n) *
+ * eps(s_max), common/linalg.rs:209-228), cond = s_max / s_min (inf when s_min == 0; 0 for an empty matrix), pinv = V diag(1 / s_i, s_i > tol) U' as
+ * [cols, rows].  rank and cond return [1, 1] tensors.  The CPU decomposes with nalgebra: parity by tolerance (singular values to relative accuracy). */
+/* @serves rank */
+RMHIP_API int rmhip_rank(rmhip_ctx* ctx, rmhip_buf matrix, int has_tolerance, double tolerance, rmhip_buf* out);
+/* @serves cond */
+RMHIP_API int rmhip_cond(rmhip_ctx* ctx, rmhip_buf matrix, int norm, rmhip_buf* out);
+/* @serves pinv */
+RMHIP_API int rmhip_pinv(rmhip_ctx* ctx, rmhip_buf matrix, int has_tolerance, double tolerance, rmhip_buf* out);
 /* `peaks(n)` (x_or_0 == y_or_0 == 0; lib.rs:1781-1785) / `peaks_xy(x, y)` (lib.rs:1787-1795; peaks.rs:511-550): the `peaks` test surface on the
  * n x n grid over [-3, 3]^2 (n == 1: the point (3, 3)), or at same-shape coordinate tensors.  Products and sums in the CPU's order; three
  * exponentials per point: within 2e-14 absolute of the oracle (terms of magnitude up to ~8). */

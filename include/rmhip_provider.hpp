@@ -498,6 +498,22 @@ public:
         check(rmhip_covariance(ctx_, own(matrix), biased ? 1 : 0, &out));
         return with_shape(out);
     }
+    // lib.rs:2437-2470; tolerance == nullptr: the default rule; cond norm: 0 Two (served), 1 One, 2 Inf, 3 Fro
+    GpuTensorHandle rank(const GpuTensorHandle& m, const double* tolerance = nullptr) const {
+        uint64_t out = 0;
+        check(rmhip_rank(ctx_, own(m), tolerance ? 1 : 0, tolerance ? *tolerance : 0.0, &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle cond(const GpuTensorHandle& m, int norm = 0) const {
+        uint64_t out = 0;
+        check(rmhip_cond(ctx_, own(m), norm, &out));
+        return with_shape(out);
+    }
+    GpuTensorHandle pinv(const GpuTensorHandle& m, const double* tolerance = nullptr) const {
+        uint64_t out = 0;
+        check(rmhip_pinv(ctx_, own(m), tolerance ? 1 : 0, tolerance ? *tolerance : 0.0, &out));
+        return with_shape(out);
+    }
     GpuTensorHandle peaks(size_t n) const {  // lib.rs:1781
         uint64_t out = 0;
         check(rmhip_peaks(ctx_, n, 0, 0, &out));

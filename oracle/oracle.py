@@ -861,6 +861,55 @@ def ismember(a, b):
     return (loc > 0).astype(np.uint8).reshape(a.shape, order="F"), loc.reshape(a.shape, order="F")
 
 
+def _eps_like(v: float) -> float:
+    """common/linalg.rs:218-228: the gap from |v| to the next double."""
+    a = abs(float(v))
+    return float(np.nextafter(a, np.inf) - a)
+
+
+def svd_default_tolerance(sv, rows: int, cols: int) -> float:
+    """common/linalg.rs:209-215."""
+    return max(rows, cols) * _eps_like(max([abs(v) for v in sv], default=0.0))
+
+
+def rank(a, tolerance=None) -> int:
+    """rank_real_tensor_impl, rank.rs:280-295: singular values (nalgebra's SVD on the CPU - LAPACK's here, same values to rounding) above
+    the tolerance."""
+    a = np.asarray(a, dtype=np.float64)
+    a = a.reshape(a.shape[0], a.shape[1]) if a.ndim >= 2 else a.reshape(-1, 1)
+    if a.shape[0] == 0 or a.shape[1] == 0:
+        return 0
+    sv = np.linalg.svd(a, compute_uv=False)
+    cut = svd_default_tolerance(sv, *a.shape) if tolerance is None else tolerance
+    return int(sum(1 for v in sv if np.isinf(v) or v > cut))
+
+
+def cond2(a) -> float:
+    """cond_real_tensor / singular_value_cond, cond.rs:276-330, 448-467 (2-norm)."""
+    a = np.asarray(a, dtype=np.float64)
+    a = a.reshape(a.shape[0], a.shape[1]) if a.ndim >= 2 else a.reshape(-1, 1)
+    if a.shape[0] == 0 or a.shape[1] == 0:
+        return 0.0
+    if a.size == 1:
+        return float("inf") if a.ravel()[0] == 0.0 else 1.0
+    sv = np.abs(np.linalg.svd(a, compute_uv=False))
+    if not np.isfinite(sv).all():
+        return float("inf")
+    return float("inf") if sv.min() == 0.0 else float(sv.max() / sv.min())
+
+
+def pinv(a, tolerance=None) -> np.ndarray:
+    """pseudoinverse_real, pinv.rs:276-285: V diag(1 / s_i, s_i > cutoff) U'."""
+    a = np.asarray(a, dtype=np.float64)
+    a = a.reshape(a.shape[0], a.shape[1]) if a.ndim >= 2 else a.reshape(-1, 1)
+    if a.shape[0] == 0 or a.shape[1] == 0:
+        return np.zeros((a.shape[1], a.shape[0]))
+    u, sv, vt = np.linalg.svd(a, full_matrices=False)
+    cut = svd_default_tolerance(sv, *a.shape) if tolerance is None else tolerance
+    inv = np.array([1.0 / v if (np.isinf(v) or v > cut) else 0.0 for v in sv])
+    return (vt.T * inv) @ u.T
+
+
 def peaks_xy(x, y) -> np.ndarray:
     """peaks_at, peaks.rs:546-550 (powi(2/3/5) as the repeated products they compile to), elementwise."""
     x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)

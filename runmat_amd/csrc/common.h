@@ -390,6 +390,10 @@ static constexpr int kSvdMaxColsDefault = 4096;  // 0.15 s at 512, 0.45 s at 102
 int svd_max_cols();
 static constexpr int kSvdProxyMaxCols = 1024;  // up to here an LU with a tiny pivot RATIO (no pivot below the cut-off) is re-answered by the SVD
 int svd_solve_device(Context* c, const double* A, size_t m, size_t n, const double* B, size_t nrhs, double* X, int* rank_out);
+// the same decomposition behind rank / cond / pinv (rank.rs, cond.rs, pinv.rs: nalgebra's SVD on the CPU)
+int svd_values_host(Context* c, const char* who, const double* A, size_t m, size_t n, std::vector<double>* values);
+double svd_default_tolerance(const std::vector<double>& values, size_t m, size_t n);
+int svd_pinv_device(Context* c, const double* A, size_t m, size_t n, double tol, double* X);
 
 // small_solve.hip: x = A \ B for small n (policy: <= 64), nrhs <= 16 in one launch (the augmented matrix in the LDS of one CU) + the pivot statistics
 bool small_solve_applies(size_t n, size_t nrhs);

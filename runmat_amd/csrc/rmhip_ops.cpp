@@ -930,6 +930,78 @@ int rmhip_image_normalize(rmhip_ctx* ctx, rmhip_buf input, const rmhip_image_nor
     return rc;
 }
 
+// rank / cond / pinv: the CPU decomposes with nalgebra's SVD (rank.rs:280-295, cond.rs:326-330, 448-467, pinv.rs:276-285); here the one-sided
+// Jacobi decomposition of svdsolve.hip supplies the singular values (relative accuracy) and the pseudo-inverse.
+static int matrix_dims_2d(const char* who, const Buffer& b, size_t* rows, size_t* cols) {
+    for (size_t d = 2; d < b.shape.size(); ++d)
+        if (b.shape[d] != 1) return fail(RMHIP_ERR_INVALID, "%s: inputs must be 2-D matrices or vectors", who);
+    *rows = b.shape.empty() ? 1 : b.shape[0];
+    *cols = b.shape.size() < 2 ? 1 : b.shape[1];
+    return RMHIP_OK;
+}
+
+static int scalar_result(Context* c, double v, rmhip_buf* out) {
+    const size_t one[2] = {1, 1};
+    Buffer ob;
+    RMHIP_TRY(c->new_buffer(one, 2, out, &ob));
+    return launch_fill(c, ob.data(), 1, v);
+}
+
+int rmhip_rank(rmhip_ctx* ctx, rmhip_buf matrix, int has_tolerance, double tolerance, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer mb;
+    RMHIP_TRY(c->get(matrix, &mb));
+    size_t rows, cols;
+    RMHIP_TRY(matrix_dims_2d("rank", mb, &rows, &cols));
+    if (rows == 0 || cols == 0) return scalar_result(c, 0.0, out);  // rank.rs:283-285
+    std::vector<double> sv;
+    RMHIP_TRY(svd_values_host(c, "rank", mb.data(), rows, cols, &sv));
+    const double cutoff = has_tolerance ? tolerance : svd_default_tolerance(sv, rows, cols);
+    size_t r = 0;
+    for (double v : sv) r += (std::isinf(v) || v > cutoff) ? 1 : 0;
+    return scalar_result(c, (double)r, out);
+}
+
+int rmhip_cond(rmhip_ctx* ctx, rmhip_buf matrix, int norm, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    if (norm != 0) return fail(RMHIP_ERR_UNSUPPORTED, "cond: only the 2-norm is served (the 1 / inf / fro forms invert on the CPU path)");
+    Buffer mb;
+    RMHIP_TRY(c->get(matrix, &mb));
+    size_t rows, cols;
+    RMHIP_TRY(matrix_dims_2d("cond", mb, &rows, &cols));
+    if (rows == 0 || cols == 0) return scalar_result(c, 0.0, out);  // cond.rs:278-280
+    std::vector<double> sv;
+    RMHIP_TRY(svd_values_host(c, "cond", mb.data(), rows, cols, &sv));
+    double mn = INFINITY, mx = 0.0;  // singular_value_cond, cond.rs:448-467
+    for (double v : sv) {
+        const double a = std::fabs(v);
+        if (!std::isfinite(a)) return scalar_result(c, INFINITY, out);
+        mn = a < mn ? a : mn, mx = a > mx ? a : mx;
+    }
+    return scalar_result(c, mn == 0.0 ? INFINITY : mx / mn, out);
+}
+
+int rmhip_pinv(rmhip_ctx* ctx, rmhip_buf matrix, int has_tolerance, double tolerance, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    if (has_tolerance && !(tolerance >= 0.0)) return fail(RMHIP_ERR_INVALID, "pinv: tolerance must be >= 0");
+    Buffer mb, ob;
+    RMHIP_TRY(c->get(matrix, &mb));
+    size_t rows, cols;
+    RMHIP_TRY(matrix_dims_2d("pinv", mb, &rows, &cols));
+    const size_t oshape[2] = {cols, rows};
+    RMHIP_TRY(c->new_buffer(oshape, 2, out, &ob));
+    if (ob.numel == 0) return RMHIP_OK;  // pinv.rs:245-248
+    const int rc = svd_pinv_device(c, mb.data(), rows, cols, has_tolerance ? tolerance : -1.0, ob.data());
+    if (rc != RMHIP_OK) {
+        rmhip_free(ctx, *out);
+        *out = 0;
+    }
+    return rc;
+}
+
 int rmhip_covariance(rmhip_ctx* ctx, rmhip_buf matrix, int biased, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");

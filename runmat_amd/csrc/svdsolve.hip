@@ -14,8 +14,10 @@
 // (sweeps x (q - 1) launches of a few us) up to q ~ 1024 - 0.15 s at 512, 0.45 s at 1024 -, bound by the traffic of the column pairs
 // beyond (1.7 s at 2048, 9.6 s at 4096: every step streams W and V once and a half); that is the price of exact rank semantics,
 // against a host round trip of the whole matrix plus a CPU SVD of the same order (minutes at 4096).
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "common.h"
 
@@ -140,21 +142,29 @@ __global__ void __launch_bounds__(JAC_THREADS) k_jacobi_scale(double* __restrict
 }
 
 // X (n x nrhs) = pinv(A) B for A m x n (lda = m), B m x nrhs (ldb = m); *rank_out = numerical rank by the reference's tolerance.
-int svd_solve_device(Context* c, const double* A, size_t m, size_t n, const double* B, size_t nrhs, double* X, int* rank_out) {
-    const bool transposed = m < n;
-    const size_t p = transposed ? n : m, q = transposed ? m : n;  // W is p x q, tall
-    if (q == 0 || p == 0 || nrhs == 0) return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: empty system");
-    if (q > (size_t)svd_max_cols()) return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: the SVD path handles min(rows, cols) <= %d, got %zu", svd_max_cols(), q);
-    std::shared_ptr<Allocation> w_mem, v_mem, aux_mem, coef_mem;
-    RMHIP_TRY(c->alloc_device(p * q, &w_mem));
-    RMHIP_TRY(c->alloc_device(q * q, &v_mem));
-    RMHIP_TRY(c->alloc_device(q + 8, &aux_mem));
-    RMHIP_TRY(c->alloc_device(q * nrhs, &coef_mem));
-    double* W = w_mem->ptr;
-    double* V = v_mem->ptr;
-    double* sig = aux_mem->ptr;
-    unsigned long long* ctl = reinterpret_cast<unsigned long long*>(aux_mem->ptr + q);  // [0] off, [1] smax, [2] rank (int)
-    if (transposed) RMHIP_TRY(transpose_device(c, A, m, m, n, W, n));
+// the decomposition step: W (p x q, tall) with orthogonal columns, V, the singular values and their maximum (on the host)
+struct JacobiSvd {
+    std::shared_ptr<Allocation> w_mem, v_mem, aux_mem;
+    double *W = nullptr, *V = nullptr, *sig = nullptr;
+    unsigned long long* ctl = nullptr;  // [0] off, [1] smax, [2] rank (int)
+    size_t p = 0, q = 0;
+    bool transposed = false;
+    double smax = 0.0;
+};
+
+static int jacobi_svd(Context* c, const char* who, const double* A, size_t m, size_t n, JacobiSvd* s) {
+    s->transposed = m < n;
+    const size_t p = s->transposed ? n : m, q = s->transposed ? m : n;  // W is p x q, tall
+    s->p = p, s->q = q;
+    if (q > (size_t)svd_max_cols()) return fail(RMHIP_ERR_UNSUPPORTED, "%s: the SVD path handles min(rows, cols) <= %d, got %zu", who, svd_max_cols(), q);
+    RMHIP_TRY(c->alloc_device(p * q, &s->w_mem));
+    RMHIP_TRY(c->alloc_device(q * q, &s->v_mem));
+    RMHIP_TRY(c->alloc_device(q + 8, &s->aux_mem));
+    double* W = s->W = s->w_mem->ptr;
+    double* V = s->V = s->v_mem->ptr;
+    s->sig = s->aux_mem->ptr;
+    unsigned long long* ctl = s->ctl = reinterpret_cast<unsigned long long*>(s->aux_mem->ptr + q);
+    if (s->transposed) RMHIP_TRY(transpose_device(c, A, m, m, n, W, n));
     else RMHIP_HIP_CHECK(hipMemcpyAsync(W, A, p * q * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     hipLaunchKernelGGL(k_jacobi_identity, dim3((unsigned)((q * q + JAC_THREADS - 1) / JAC_THREADS)), dim3(JAC_THREADS), 0, c->stream, V, (int)q);
     const int Q = (int)((q + 1) & ~(size_t)1);
@@ -169,41 +179,98 @@ int svd_solve_device(Context* c, const double* A, size_t m, size_t n, const doub
         RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
         double off;
         std::memcpy(&off, &bits, sizeof off);
-        if (!(off == off) || off > 1.0e300) return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: non-finite data in the SVD path");
+        if (!(off == off) || off > 1.0e300) return fail(RMHIP_ERR_UNSUPPORTED, "%s: non-finite data in the SVD path", who);
         converged = off < 1e-15;
     }
     // (like the oracle, 60 sweeps that did not converge still give the best decomposition found; in practice 6-10 suffice)
     RMHIP_HIP_CHECK(hipMemsetAsync(ctl + 1, 0, 2 * sizeof(unsigned long long), c->stream));
-    hipLaunchKernelGGL(k_jacobi_sigma, dim3((unsigned)q), dim3(JAC_THREADS), 0, c->stream, (const double*)W, p, sig, ctl + 1);
+    hipLaunchKernelGGL(k_jacobi_sigma, dim3((unsigned)q), dim3(JAC_THREADS), 0, c->stream, (const double*)W, p, s->sig, ctl + 1);
     unsigned long long sbits = 0;
     RMHIP_HIP_CHECK(hipMemcpyAsync(&sbits, ctl + 1, sizeof sbits, hipMemcpyDeviceToHost, c->stream));
     RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
-    double smax;
-    std::memcpy(&smax, &sbits, sizeof smax);
-    const double maxdim = (double)(m > n ? m : n);
-    const double tol = 2.220446049250313e-16 * maxdim * (smax > 1.0 ? smax : 1.0);  // mldivide.rs:396-404
+    std::memcpy(&s->smax, &sbits, sizeof s->smax);
+    c->tel.kernel_launches += 2;
+    return RMHIP_OK;
+}
+
+// X (n x nrhs) = V diag(1 / s_i, s_i > tol) U' B from the decomposition of the m x n matrix; *rank_out = values kept
+static int svd_apply(Context* c, const JacobiSvd& s, size_t m, size_t n, const double* B, size_t nrhs, double tol, double* X, int* rank_out) {
+    const size_t p = s.p, q = s.q;
+    std::shared_ptr<Allocation> coef_mem;
+    RMHIP_TRY(c->alloc_device(q * nrhs, &coef_mem));
     double* coef = coef_mem->ptr;
-    int* rank_dev = reinterpret_cast<int*>(ctl + 2);
-    if (!transposed) {
+    int* rank_dev = reinterpret_cast<int*>(s.ctl + 2);
+    if (!s.transposed) {
         // A = U S V' with U S = W:  X = V S^-1 U' B = V diag(1/s^2) W' B
-        RMHIP_TRY(launch_dgemm_trans(c, true, false, q, nrhs, p, 1.0, W, p, B, m, 0.0, coef, q));
+        RMHIP_TRY(launch_dgemm_trans(c, true, false, q, nrhs, p, 1.0, s.W, p, B, m, 0.0, coef, q));
         hipLaunchKernelGGL(k_jacobi_scale, dim3((unsigned)((q * nrhs + JAC_THREADS - 1) / JAC_THREADS)), dim3(JAC_THREADS), 0, c->stream, coef, (int)q, nrhs,
-                           (const double*)sig, tol, rank_dev);
-        RMHIP_TRY(launch_dgemm(c, n, nrhs, q, 1.0, V, q, coef, q, 0.0, X, n));
+                           (const double*)s.sig, tol, rank_dev);
+        RMHIP_TRY(launch_dgemm(c, n, nrhs, q, 1.0, s.V, q, coef, q, 0.0, X, n));
     } else {
         // A' = U S V' with U S = W (n x m):  A = V S U',  X = U S^-1 V' B = W diag(1/s^2) V' B
-        RMHIP_TRY(launch_dgemm_trans(c, true, false, q, nrhs, q, 1.0, V, q, B, m, 0.0, coef, q));
+        RMHIP_TRY(launch_dgemm_trans(c, true, false, q, nrhs, q, 1.0, s.V, q, B, m, 0.0, coef, q));
         hipLaunchKernelGGL(k_jacobi_scale, dim3((unsigned)((q * nrhs + JAC_THREADS - 1) / JAC_THREADS)), dim3(JAC_THREADS), 0, c->stream, coef, (int)q, nrhs,
-                           (const double*)sig, tol, rank_dev);
-        RMHIP_TRY(launch_dgemm(c, n, nrhs, q, 1.0, W, p, coef, q, 0.0, X, n));
+                           (const double*)s.sig, tol, rank_dev);
+        RMHIP_TRY(launch_dgemm(c, n, nrhs, q, 1.0, s.W, p, coef, q, 0.0, X, n));
     }
     int h_rank = 0;
     RMHIP_HIP_CHECK(hipMemcpyAsync(&h_rank, rank_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));  // also: the temporaries go back to the pool on return
     if (rank_out) *rank_out = h_rank;
-    c->tel.kernel_launches += 5;
+    c->tel.kernel_launches += 3;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
+}
+
+int svd_solve_device(Context* c, const double* A, size_t m, size_t n, const double* B, size_t nrhs, double* X, int* rank_out) {
+    if (m == 0 || n == 0 || nrhs == 0) return fail(RMHIP_ERR_UNSUPPORTED, "mldivide: empty system");
+    JacobiSvd s;
+    RMHIP_TRY(jacobi_svd(c, "mldivide", A, m, n, &s));
+    const double maxdim = (double)(m > n ? m : n);
+    const double tol = 2.220446049250313e-16 * maxdim * (s.smax > 1.0 ? s.smax : 1.0);  // mldivide.rs:396-404
+    return svd_apply(c, s, m, n, B, nrhs, tol, X, rank_out);
+}
+
+// `eps(x)` as common/linalg.rs:218-228 defines it: the gap to the next double above |x|
+static double eps_like(double v) {
+    if (v != v) return v;
+    if (std::isinf(v)) return INFINITY;
+    const double a = std::fabs(v);
+    unsigned long long bits;
+    std::memcpy(&bits, &a, sizeof bits);
+    ++bits;
+    double next;
+    std::memcpy(&next, &bits, sizeof next);
+    return next - a;
+}
+
+// the singular values of an m x n matrix on the host (min(m, n) of them, unordered), by the same decomposition
+int svd_values_host(Context* c, const char* who, const double* A, size_t m, size_t n, std::vector<double>* values) {
+    JacobiSvd s;
+    RMHIP_TRY(jacobi_svd(c, who, A, m, n, &s));
+    values->resize(s.q);
+    RMHIP_HIP_CHECK(hipMemcpyAsync(values->data(), s.sig, s.q * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return RMHIP_OK;
+}
+
+// `svd_default_tolerance` (common/linalg.rs:209-215): max(m, n) * eps(largest singular value)
+double svd_default_tolerance(const std::vector<double>& values, size_t m, size_t n) {
+    double mx = 0.0;
+    for (double v : values) mx = std::fabs(v) > mx ? std::fabs(v) : mx;
+    return (double)(m > n ? m : n) * eps_like(mx);
+}
+
+// X (n x m) = pinv(A) with the cutoff `tol` (< 0: the default rule)
+int svd_pinv_device(Context* c, const double* A, size_t m, size_t n, double tol, double* X) {
+    JacobiSvd s;
+    RMHIP_TRY(jacobi_svd(c, "pinv", A, m, n, &s));
+    if (tol < 0.0) tol = (double)(m > n ? m : n) * eps_like(s.smax);
+    std::shared_ptr<Allocation> eye;
+    RMHIP_TRY(c->alloc_device(m * m, &eye));
+    hipLaunchKernelGGL(k_jacobi_identity, dim3((unsigned)((m * m + JAC_THREADS - 1) / JAC_THREADS)), dim3(JAC_THREADS), 0, c->stream, eye->ptr, (int)m);
+    c->tel.kernel_launches++;
+    return svd_apply(c, s, m, n, eye->ptr, m, tol, X, nullptr);
 }
 
 }  // namespace rmhip

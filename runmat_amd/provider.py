@@ -762,6 +762,27 @@ class HipProvider:
         self._check(self._lib.rmhip_covariance(self._ctx, self._id(matrix), int(bool(biased)), C.byref(out)))
         return self._handle(out.value)
 
+    def rank(self, matrix, tolerance: Optional[float] = None) -> GpuTensorHandle:
+        """lib.rs:2464-2470 -> a [1, 1] tensor holding the numerical rank."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_rank(self._ctx, self._id(matrix), 0 if tolerance is None else 1, 0.0 if tolerance is None else float(tolerance), C.byref(out)))
+        return self._handle(out.value)
+
+    def cond(self, matrix, norm: str = "two") -> GpuTensorHandle:
+        """lib.rs:2444-2450 (`ProviderCondNorm::{Two, One, Inf, Fro}`, :736-741): the 2-norm is served."""
+        codes = {"two": 0, "one": 1, "inf": 2, "fro": 3}
+        if norm not in codes:
+            raise RmhipError(1, f"cond: norm {norm!r}")
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_cond(self._ctx, self._id(matrix), codes[norm], C.byref(out)))
+        return self._handle(out.value)
+
+    def pinv(self, matrix, tolerance: Optional[float] = None) -> GpuTensorHandle:
+        """lib.rs:2437-2443 (`ProviderPinvOptions { tolerance }`) -> [cols, rows]."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_pinv(self._ctx, self._id(matrix), 0 if tolerance is None else 1, 0.0 if tolerance is None else float(tolerance), C.byref(out)))
+        return self._handle(out.value)
+
     def peaks(self, n: int) -> GpuTensorHandle:
         """lib.rs:1781-1785: Z of the peaks surface on the n x n grid over [-3, 3] x [-3, 3]."""
         out = C.c_uint64()

@@ -16,7 +16,7 @@ use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, ApiDeviceInfo, CorrcoefNormalization, CorrcoefOptions, CorrcoefRows, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle, GpuTensorStorage,
     HostLogicalOwned, HostTensorOwned, HostTensorView, IsMemberOptions, IsMemberResult, SetdiffOptions, SetdiffOrder, SetdiffResult, UnionOptions, UnionOrder, UnionResult, UniqueOccurrence, UniqueOptions, UniqueOrder, UniqueResult, ImageNormalizeDescriptor, KernelAttrTelemetry, MeshgridAxisView, ProviderMeshgridResult, ProviderPolyvalOptions, KernelLaunchTelemetry, MatmulEpilogue,
-    PowerStepEpilogue, ProviderBandwidth, ProviderIirFilterOptions, ProviderIirFilterResult, ProviderInterp1Extrapolation, ProviderInterp1Method, ProviderInterp1Request, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
+    PowerStepEpilogue, ProviderBandwidth, ProviderCondNorm, ProviderPinvOptions, ProviderIirFilterOptions, ProviderIirFilterResult, ProviderInterp1Extrapolation, ProviderInterp1Method, ProviderInterp1Request, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderMovingWindowEndpoints, ProviderMovingWindowOp, ProviderMovingWindowRequest, ProviderNanMode, ProviderNdgridRequest, ProviderNormOrder, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
     ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult, SortRowsColumnSpec,
 };
@@ -526,6 +526,28 @@ impl AccelProvider for HipProvider {
             let mut out = 0u64;
             let biased = matches!(options.normalization, CovNormalization::Biased) as c_int;
             check(unsafe { rmhip_covariance(self.ctx, self.own(matrix)?, biased, &mut out) })?;
+            self.handle(out)
+        })
+    }
+    fn rank<'a>(&'a self, matrix: &'a GpuTensorHandle, tolerance: Option<f64>) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_rank(self.ctx, self.own(matrix)?, tolerance.is_some() as c_int, tolerance.unwrap_or(0.0), &mut out) })?;
+            self.handle(out)
+        })
+    }
+    fn cond<'a>(&'a self, matrix: &'a GpuTensorHandle, norm: ProviderCondNorm) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let code = match norm { ProviderCondNorm::Two => 0, ProviderCondNorm::One => 1, ProviderCondNorm::Inf => 2, ProviderCondNorm::Fro => 3 };
+            let mut out = 0u64;
+            check(unsafe { rmhip_cond(self.ctx, self.own(matrix)?, code, &mut out) })?;
+            self.handle(out)
+        })
+    }
+    fn pinv<'a>(&'a self, matrix: &'a GpuTensorHandle, options: ProviderPinvOptions) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_pinv(self.ctx, self.own(matrix)?, options.tolerance.is_some() as c_int, options.tolerance.unwrap_or(0.0), &mut out) })?;
             self.handle(out)
         })
     }

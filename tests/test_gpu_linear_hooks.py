@@ -369,3 +369,29 @@ def test_peaks(prov, oracle):
     assert np.max(np.abs(prov.download_matrix(prov.peaks_xy(prov.upload(x), prov.upload(y))) - oracle.peaks_xy(x, y))) <= 2e-14
     with pytest.raises(Exception):
         prov.peaks_xy(prov.upload(x), prov.upload(y.T))
+
+
+def test_rank_cond_pinv(prov, oracle):
+    """The CPU decomposes with nalgebra's SVD, the device by one-sided Jacobi: parity by tolerance - ranks equal (decisions away from the
+    cutoff), cond to 1e-10 relative, pinv to 1e-11 * ||pinv|| (and the four Moore-Penrose identities to 1e-10)."""
+    assert prov.download(prov.rank(prov.upload(np.array([1.0, 3.0, 2.0, 4.0]).reshape(2, 2, order="F"))))[0] == 2
+    assert prov.download(prov.rank(prov.upload(np.diag([1.0, 1e-16]))))[0] == 1
+    assert prov.download(prov.rank(prov.upload(np.diag([1.0, 1e-4])), 1e-3))[0] == 1 and prov.download(prov.rank(prov.upload(np.zeros((0, 0)))))[0] == 0
+    assert np.allclose(prov.download_matrix(prov.pinv(prov.upload(np.diag([1.0, 1e-12])), 1e-6)), np.diag([1.0, 0.0]), atol=1e-15)
+    rng = np.random.default_rng(23)
+    for m, n, r in ((6, 4, 4), (4, 6, 3), (50, 50, 50), (200, 120, 60), (120, 200, 120), (7, 1, 1), (1, 7, 1)):
+        a = rng.standard_normal((m, r)) @ rng.standard_normal((r, n))
+        h = prov.upload(a)
+        assert prov.download(prov.rank(h))[0] == oracle.rank(a) == r
+        c_got, c_want = prov.download(prov.cond(h))[0], oracle.cond2(a)
+        if r == min(m, n):
+            assert abs(c_got - c_want) <= 1e-10 * c_want
+        p_got, p_want = prov.download_matrix(prov.pinv(h)), oracle.pinv(a)
+        assert p_got.shape == (n, m) and np.max(np.abs(p_got - p_want)) <= 1e-11 * np.max(np.abs(p_want))
+        assert np.max(np.abs(a @ p_got @ a - a)) <= 1e-10 * np.max(np.abs(a)) and np.max(np.abs(p_got @ a @ p_got - p_got)) <= 1e-10 * np.max(np.abs(p_got))
+    assert prov.download(prov.cond(prov.upload(np.diag([1.0, 0.0]))))[0] == np.inf and prov.download(prov.cond(prov.upload(np.zeros((0, 3)))))[0] == 0.0
+    assert list(prov.pinv(prov.upload(np.zeros((3, 0)))).shape) == [0, 3]
+    with pytest.raises(Exception):
+        prov.cond(prov.upload(np.eye(3)), "fro")
+    with pytest.raises(Exception):
+        prov.pinv(prov.upload(np.eye(3)), -1.0)

@@ -156,3 +156,17 @@ def test_peaks_known_values():
     z = oracle.peaks(49)
     assert z.shape == (49, 49) and abs(z.max() - 8.1) < 0.1 and abs(z.min() + 6.55) < 0.1      # MATLAB's surface: peak ~8.1, trough ~-6.55
     assert oracle.peaks(1).shape == (1, 1) and oracle.peaks(0).shape == (0, 0)
+
+
+def test_rank_cond_pinv_reference_vectors():
+    # rank.rs:337-341, 389-391, 397-401, 407-410
+    assert oracle.rank(np.array([1.0, 3.0, 2.0, 4.0]).reshape(2, 2, order="F")) == 2
+    assert oracle.rank(np.diag([1.0, 1e-16])) == 1
+    assert oracle.rank(np.diag([1.0, 1e-4])) == 2 and oracle.rank(np.diag([1.0, 1e-4]), 1e-3) == 1 and oracle.rank(np.zeros((0, 0))) == 0
+    # pinv.rs:404-440: a rank-one matrix, a tall selection matrix, a custom tolerance that drops 1e-12
+    a = np.array([1.0, 2.0, 2.0, 4.0]).reshape(2, 2, order="F")
+    assert np.allclose(oracle.pinv(a), np.linalg.pinv(a), atol=1e-14) and oracle.pinv(np.zeros((3, 0))).shape == (0, 3)
+    t = np.array([1.0, 0.0, 0.0, 0.0, 0.0, 1.0]).reshape(3, 2, order="F")
+    assert np.allclose(oracle.pinv(t), t.T, atol=1e-15)
+    assert np.allclose(oracle.pinv(np.diag([1.0, 1e-12]), 1e-6), np.diag([1.0, 0.0]), atol=1e-15)
+    assert oracle.cond2(np.diag([4.0, 2.0])) == 2.0 and oracle.cond2(np.diag([1.0, 0.0])) == float("inf") and oracle.cond2(np.zeros((0, 3))) == 0.0
