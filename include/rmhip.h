@@ -448,7 +448,8 @@ RMHIP_API int rmhip_trapz_dim(rmhip_ctx* ctx, rmhip_buf a, int dim, int cumulati
  * 3 Inf, 4 NegInf, 5 Zero, 6 Fro, 7 Nuc, 8 P(p).  Vectors (a dimension <= 1): sum |x|, root of the sum of squares (scaled by a power
  * of two when the squares would overflow or underflow), max / min |x| (an empty or all-infinite minimum is 0), the count of nonzeros,
  * (sum |x|^p)^(1/p) for finite p >= 1.  Matrices: One = largest column sum of |a|, Inf = largest row sum, Fro as for vectors.  Any NaN
- * gives NaN.  The matrix 2-norm and the nuclear norm (singular values) are RMHIP_ERR_UNSUPPORTED; orders the builtin refuses (matrix
+ * gives NaN.  The matrix 2-norm and the nuclear norm are the largest / the sum of the singular values of the one-sided Jacobi
+ * decomposition (min(rows, cols) <= 4096 and finite data, else RMHIP_ERR_UNSUPPORTED); orders the builtin refuses (matrix
  * -Inf / 0 / p, a vector's nuclear norm, p < 1) are RMHIP_ERR_INVALID.  Sums in a different order than the CPU's loops: n eps relative. */
 /* @serves norm */
 RMHIP_API int rmhip_norm(rmhip_ctx* ctx, rmhip_buf a, int order, double p, rmhip_buf* out);

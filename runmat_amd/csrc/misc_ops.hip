@@ -725,7 +725,23 @@ int rmhip_norm(rmhip_ctx* ctx, rmhip_buf a, int order, double p, rmhip_buf* out)
         if (s[d] > 1) return fail(RMHIP_ERR_INVALID, "norm: input must be a vector or 2-D matrix.");
     const size_t rows = s.empty() ? 0 : s[0], cols = s.size() < 2 ? 1 : s[1];
     const bool matrix = !(s.size() <= 1 || rows <= 1 || cols <= 1);
-    if (matrix && (order == 2 || order == 7)) return fail(RMHIP_ERR_UNSUPPORTED, "norm: the spectral / nuclear norm of a matrix needs its singular values");
+    if (matrix && (order == 2 || order == 7)) {
+        // spectral / nuclear norm (norm.rs:531-541, 560-567): the largest / the sum of the singular values, from the one-sided Jacobi
+        // decomposition of svdsolve.hip (min(rows, cols) <= 4096, finite data; the CPU uses nalgebra's SVD: parity by tolerance)
+        std::vector<double> sv;
+        RMHIP_TRY(svd_values_host(c, "norm", ab.data(), rows, cols, &sv));
+        double r = 0.0;
+        if (order == 2) {
+            for (double v : sv) r = v > r ? v : r;
+        } else {
+            std::sort(sv.begin(), sv.end(), [](double x, double y) { return x > y; });  // (nalgebra hands them over in decreasing order)
+            for (double v : sv) r += v;
+        }
+        const size_t one1[2] = {1, 1};
+        Buffer rb;
+        RMHIP_TRY(c->new_buffer(one1, 2, out, &rb));
+        return launch_fill(c, rb.data(), 1, r);
+    }
     if (matrix && (order == 4 || order == 5 || order == 8)) return fail(RMHIP_ERR_INVALID, "norm: order not defined for matrices");  // norm.rs:441-451
     if (!matrix && order == 7) return fail(RMHIP_ERR_INVALID, "norm: nuclear norm is only defined for matrices.");
     if (!matrix && order == 8 && !(std::isfinite(p) && p >= 1.0)) return fail(RMHIP_ERR_INVALID, "norm: vector norm order %g must satisfy p >= 1 (or use 0, Inf, or -Inf).", p);

@@ -311,8 +311,9 @@ def test_norm(prov, oracle):
             got = val(h, order, 3.0)
             assert abs(got - want) <= 1e-13 * max(x.size, 16) * abs(want) + 1e-300, (shape, order, got, want)
         if is_matrix:
-            for order in ("two", "nuc", "zero", "-inf", "p"):
-                assert oracle.norm(x, order, 3.0) is None or order in ("zero", "-inf", "p")
+            sv = np.linalg.svd(x, compute_uv=False)                                  # spectral / nuclear norm: the Jacobi decomposition's singular values
+            assert abs(val(h, "two") - sv.max()) <= 1e-12 * sv.max() and abs(val(h, "nuc") - sv.sum()) <= 1e-12 * sv.sum()
+            for order in ("zero", "-inf", "p"):
                 with pytest.raises(Exception):
                     prov.norm(h, order, 3.0)
         else:
