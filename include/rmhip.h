@@ -594,6 +594,10 @@ RMHIP_API int rmhip_covariance(rmhip_ctx* ctx, rmhip_buf matrix, int biased, rmh
 RMHIP_API int rmhip_rank(rmhip_ctx* ctx, rmhip_buf matrix, int has_tolerance, double tolerance, rmhip_buf* out);
 /* @serves cond */
 RMHIP_API int rmhip_cond(rmhip_ctx* ctx, rmhip_buf matrix, int norm, rmhip_buf* out);
+/* `rcond(matrix)` (lib.rs:2471-2476; rcond.rs:304-320): s_min / s_max of a square matrix from the same decomposition (0 when s_max == 0, inf for the
+ * empty matrix; a non-square input is RMHIP_ERR_INVALID). */
+/* @serves rcond */
+RMHIP_API int rmhip_rcond(rmhip_ctx* ctx, rmhip_buf matrix, rmhip_buf* out);
 /* @serves pinv */
 RMHIP_API int rmhip_pinv(rmhip_ctx* ctx, rmhip_buf matrix, int has_tolerance, double tolerance, rmhip_buf* out);
 /* `peaks(n)` (x_or_0 == y_or_0 == 0; lib.rs:1781-1785) / `peaks_xy(x, y)` (lib.rs:1787-1795; peaks.rs:511-550): the `peaks` test surface on the

@@ -509,6 +509,11 @@ public:
         check(rmhip_cond(ctx_, own(m), norm, &out));
         return with_shape(out);
     }
+    GpuTensorHandle rcond(const GpuTensorHandle& m) const {  // lib.rs:2471
+        uint64_t out = 0;
+        check(rmhip_rcond(ctx_, own(m), &out));
+        return with_shape(out);
+    }
     GpuTensorHandle pinv(const GpuTensorHandle& m, const double* tolerance = nullptr) const {
         uint64_t out = 0;
         check(rmhip_pinv(ctx_, own(m), tolerance ? 1 : 0, tolerance ? *tolerance : 0.0, &out));

@@ -983,6 +983,26 @@ int rmhip_cond(rmhip_ctx* ctx, rmhip_buf matrix, int norm, rmhip_buf* out) {
     return scalar_result(c, mn == 0.0 ? INFINITY : mx / mn, out);
 }
 
+int rmhip_rcond(rmhip_ctx* ctx, rmhip_buf matrix, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer mb;
+    RMHIP_TRY(c->get(matrix, &mb));
+    size_t rows, cols;
+    RMHIP_TRY(matrix_dims_2d("rcond", mb, &rows, &cols));
+    if (rows != cols) return fail(RMHIP_ERR_INVALID, "rcond: input must be a square matrix.");
+    if (rows == 0) return scalar_result(c, INFINITY, out);  // rcond.rs:311-313
+    std::vector<double> sv;
+    RMHIP_TRY(svd_values_host(c, "rcond", mb.data(), rows, cols, &sv));
+    double mn = INFINITY, mx = 0.0;  // singular_value_rcond, common/linalg.rs:241-259
+    for (double v : sv) {
+        const double a = std::fabs(v);
+        if (!std::isfinite(a)) return scalar_result(c, 0.0, out);
+        mn = a < mn ? a : mn, mx = a > mx ? a : mx;
+    }
+    return scalar_result(c, mx == 0.0 ? 0.0 : mn / mx, out);
+}
+
 int rmhip_pinv(rmhip_ctx* ctx, rmhip_buf matrix, int has_tolerance, double tolerance, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);
     if (!out) return fail(RMHIP_ERR_INVALID, "null out");

@@ -777,6 +777,12 @@ class HipProvider:
         self._check(self._lib.rmhip_cond(self._ctx, self._id(matrix), codes[norm], C.byref(out)))
         return self._handle(out.value)
 
+    def rcond(self, matrix) -> GpuTensorHandle:
+        """lib.rs:2471-2476 -> [1, 1]: s_min / s_max of a square matrix."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_rcond(self._ctx, self._id(matrix), C.byref(out)))
+        return self._handle(out.value)
+
     def pinv(self, matrix, tolerance: Optional[float] = None) -> GpuTensorHandle:
         """lib.rs:2437-2443 (`ProviderPinvOptions { tolerance }`) -> [cols, rows]."""
         out = C.c_uint64()

@@ -544,6 +544,13 @@ impl AccelProvider for HipProvider {
             self.handle(out)
         })
     }
+    fn rcond<'a>(&'a self, matrix: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_rcond(self.ctx, self.own(matrix)?, &mut out) })?;
+            self.handle(out)
+        })
+    }
     fn pinv<'a>(&'a self, matrix: &'a GpuTensorHandle, options: ProviderPinvOptions) -> AccelProviderFuture<'a, GpuTensorHandle> {
         Box::pin(async move {
             let mut out = 0u64;

@@ -392,6 +392,12 @@ def test_rank_cond_pinv(prov, oracle):
         assert np.max(np.abs(a @ p_got @ a - a)) <= 1e-10 * np.max(np.abs(a)) and np.max(np.abs(p_got @ a @ p_got - p_got)) <= 1e-10 * np.max(np.abs(p_got))
     assert prov.download(prov.cond(prov.upload(np.diag([1.0, 0.0]))))[0] == np.inf and prov.download(prov.cond(prov.upload(np.zeros((0, 3)))))[0] == 0.0
     assert list(prov.pinv(prov.upload(np.zeros((3, 0)))).shape) == [0, 3]
+    sq = rng.standard_normal((40, 40))
+    sv = np.linalg.svd(sq, compute_uv=False)
+    assert abs(prov.download(prov.rcond(prov.upload(sq)))[0] - sv.min() / sv.max()) <= 1e-10 * sv.min() / sv.max()      # rcond.rs:304-320
+    assert prov.download(prov.rcond(prov.upload(np.zeros((3, 3)))))[0] == 0.0 and prov.download(prov.rcond(prov.upload(np.zeros((0, 0)))))[0] == np.inf
+    with pytest.raises(Exception):
+        prov.rcond(prov.upload(np.zeros((3, 4))))
     with pytest.raises(Exception):
         prov.cond(prov.upload(np.eye(3)), "fro")
     with pytest.raises(Exception):
