@@ -521,6 +521,12 @@ RMHIP_API int rmhip_storage(rmhip_ctx* ctx, rmhip_buf id, int* complex_interleav
  * with rustfft 6.4.1, so parity is by that tolerance, not by bits. */
 /* @serves fft_dim ifft_dim */
 RMHIP_API int rmhip_fft_dim(rmhip_ctx* ctx, rmhip_buf a, long long len_or_neg, int dim, int inverse, rmhip_buf* out);
+/* `signal_hilbert(request)` (lib.rs:2572-2577; `ProviderHilbertRequest { input, length, dim }`, :331-338; hilbert.rs:349-412): the analytic signal of a
+ * real tensor along zero-based `dim` (< rank), padded / truncated to `len_or_neg` points (< 0: the extent; 0 is invalid): forward transform, the
+ * one-sided mask (1, 2 ... 2, [1], 0 ... 0), inverse transform - a complex-interleaved result whose real part is the input.  Tolerance as the
+ * transforms'. */
+/* @serves signal_hilbert */
+RMHIP_API int rmhip_hilbert(rmhip_ctx* ctx, rmhip_buf a, long long len_or_neg, int dim, rmhip_buf* out);
 /* `complex_from_real(real)` (imag_or_0 == 0) / `complex_from_real_imag(real, imag)` (lib.rs:1940-1959): equal shapes, or either
  * operand a one-element tensor that expands. */
 /* @serves complex_from_real complex_from_real_imag */

@@ -818,6 +818,11 @@ public:
         check(rmhip_fft_dim(ctx_, own(a), len, (int)dim, 1, &out));
         return with_shape(out);
     }
+    GpuTensorHandle signal_hilbert(const GpuTensorHandle& a, long long len, size_t dim) const {  // lib.rs:2572
+        uint64_t out = 0;
+        check(rmhip_hilbert(ctx_, own(a), len, (int)dim, &out));
+        return with_shape(out);
+    }
     GpuTensorHandle fft_extract_real(const GpuTensorHandle& a) const {
         uint64_t out = 0;
         check(rmhip_complex_real(ctx_, own(a), &out));

@@ -1173,6 +1173,18 @@ def fft_dim(x: np.ndarray, length=None, dim: int = 0, inverse: bool = False) -> 
     return out.reshape(oshape, order="F")
 
 
+def hilbert(x, length=None, dim: int = 0) -> np.ndarray:
+    """hilbert.rs:349-412 on the oracle's DFT: ifft(fft(x, n, dim) .* mask, n, dim), mask = analytic_signal_multiplier."""
+    spec = fft_dim(x, length, dim)
+    n = spec.shape[dim]
+    mask = np.zeros(n)
+    for f in range(n):
+        mask[f] = 1.0 if f == 0 else (2.0 if f < n // 2 else (1.0 if f == n // 2 else 0.0)) if n % 2 == 0 else (2.0 if f <= n // 2 else 0.0)
+    shape = [1] * spec.ndim
+    shape[dim] = n
+    return fft_dim(spec * mask.reshape(shape), None, dim, True)
+
+
 def ishermitian(a: np.ndarray, skew: bool = False, tol: float = 0.0) -> bool:
     """ishermitian.rs:455-482 for real data."""
     a = np.asarray(a, dtype=np.float64)

@@ -721,6 +721,21 @@ int fft_entry(Context* c, rmhip_buf a, long long len_or_neg, int dim, bool inver
     return rc;
 }
 
+// the analytic-signal mask of hilbert (builtins/math/signal/hilbert.rs:349-412): the spectrum times 1 at frequency 0 (and at n / 2 for even n),
+// 2 on the positive half, 0 on the negative half - in place, tensor layout [inner, n, outer]
+__global__ void __launch_bounds__(FT) k_hilbert_mask(double2* __restrict__ a, u64 inner, u64 n, u64 total) {
+    const u64 e = (u64)blockIdx.x * FT + threadIdx.x;
+    if (e >= total) return;
+    const u64 f = (e / inner) % n;
+    double sc;
+    if (f == 0) sc = 1.0;
+    else if (n % 2 == 0) sc = f < n / 2 ? 2.0 : (f == n / 2 ? 1.0 : 0.0);
+    else sc = f <= n / 2 ? 2.0 : 0.0;
+    double2 v = a[e];
+    v.x *= sc, v.y *= sc;
+    a[e] = v;
+}
+
 __global__ void __launch_bounds__(FT) k_complex_make(const double* __restrict__ re, u64 re_n, const double* __restrict__ im, u64 im_n, u64 total, int round32,
                                                      double2* __restrict__ out) {
     const u64 e = (u64)blockIdx.x * FT + threadIdx.x;
@@ -745,6 +760,31 @@ extern "C" {
 int rmhip_fft_dim(rmhip_ctx* ctx, rmhip_buf a, long long len_or_neg, int dim, int inverse, rmhip_buf* out) {
     CTX_OR_FAIL(ctx);
     return fft_entry(c, a, len_or_neg, dim, inverse != 0, out);
+}
+
+int rmhip_hilbert(rmhip_ctx* ctx, rmhip_buf a, long long len_or_neg, int dim, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    if (len_or_neg == 0) return fail(RMHIP_ERR_INVALID, "signal_hilbert: invalid request");  // lib.rs:492-494
+    Buffer ab;
+    RMHIP_TRY(c->get(a, &ab));  // (real input: a complex one is refused here)
+    if (dim < 0 || (size_t)dim >= ab.shape.size()) return fail(RMHIP_ERR_INVALID, "signal_hilbert: invalid request");  // lib.rs:495-497
+    // hilbert.rs: the analytic signal ifft(fft(x, n, dim) .* mask, n, dim)
+    rmhip_buf spec = 0;
+    RMHIP_TRY(fft_entry(c, a, len_or_neg, dim, false, &spec));
+    Buffer sb;
+    int rc = c->get_any(spec, &sb);
+    if (rc == RMHIP_OK && sb.numel) {
+        u64 inner = 1;
+        for (int k = 0; k < dim; ++k) inner *= sb.shape[k];
+        const u64 n = (size_t)dim < sb.shape.size() ? sb.shape[dim] : 1;
+        hipLaunchKernelGGL(k_hilbert_mask, dim3((unsigned)((sb.numel + FT - 1) / FT)), dim3(FT), 0, c->stream, reinterpret_cast<double2*>(sb.data()), inner, n, (u64)sb.numel);
+        c->tel.kernel_launches++;
+        if (hipGetLastError() != hipSuccess) rc = fail(RMHIP_ERR_HIP, "signal_hilbert: launch failed");
+    }
+    if (rc == RMHIP_OK) rc = fft_entry(c, spec, -1, dim, true, out);
+    rmhip_free(ctx, spec);
+    return rc;
 }
 
 int rmhip_complex(rmhip_ctx* ctx, rmhip_buf real, rmhip_buf imag_or_0, rmhip_buf* out) {

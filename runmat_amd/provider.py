@@ -1259,6 +1259,12 @@ class HipProvider:
         self._check(self._lib.rmhip_fft_dim(self._ctx, self._id(handle), -1 if length is None else int(length), int(dim), inverse, C.byref(out)))
         return self._handle(out.value)
 
+    def signal_hilbert(self, input, length: Optional[int], dim: int) -> GpuTensorHandle:
+        """lib.rs:2572-2577 (`ProviderHilbertRequest`): the analytic signal along zero-based `dim` -> complex tensor."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_hilbert(self._ctx, self._id(input), -1 if length is None else int(length), int(dim), C.byref(out)))
+        return self._handle(out.value)
+
     def fft_extract_real(self, handle) -> GpuTensorHandle:
         """lib.rs:2639-2644: the real parts of a complex tensor as a real tensor."""
         out = C.c_uint64()

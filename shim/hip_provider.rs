@@ -16,7 +16,7 @@ use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, ApiDeviceInfo, CorrcoefNormalization, CorrcoefOptions, CorrcoefRows, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle, GpuTensorStorage,
     HostLogicalOwned, HostTensorOwned, HostTensorView, IsMemberOptions, IsMemberResult, SetdiffOptions, SetdiffOrder, SetdiffResult, UnionOptions, UnionOrder, UnionResult, UniqueOccurrence, UniqueOptions, UniqueOrder, UniqueResult, ImageNormalizeDescriptor, KernelAttrTelemetry, MeshgridAxisView, ProviderMeshgridResult, ProviderPolyvalOptions, KernelLaunchTelemetry, MatmulEpilogue,
-    PowerStepEpilogue, ProviderBandwidth, ProviderCondNorm, ProviderPinvOptions, ProviderIirFilterOptions, ProviderIirFilterResult, ProviderInterp1Extrapolation, ProviderInterp1Method, ProviderInterp1Request, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
+    PowerStepEpilogue, ProviderBandwidth, ProviderHilbertRequest, ProviderCondNorm, ProviderPinvOptions, ProviderIirFilterOptions, ProviderIirFilterResult, ProviderInterp1Extrapolation, ProviderInterp1Method, ProviderInterp1Request, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderMovingWindowEndpoints, ProviderMovingWindowOp, ProviderMovingWindowRequest, ProviderNanMode, ProviderNdgridRequest, ProviderNormOrder, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
     ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult, SortRowsColumnSpec,
 };
@@ -915,6 +915,14 @@ impl AccelProvider for HipProvider {
     }
     fn ifft_dim<'a>(&'a self, handle: &'a GpuTensorHandle, len: Option<usize>, dim: usize) -> AccelProviderFuture<'a, GpuTensorHandle> {
         Box::pin(async move { self.transform(handle, len, dim, 1) })
+    }
+    fn signal_hilbert<'a>(&'a self, request: &'a ProviderHilbertRequest<'a>) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            let len = request.length.map(|l| l as i64).unwrap_or(-1);
+            check(unsafe { rmhip_hilbert(self.ctx, self.own(request.input)?, len, request.dim as c_int, &mut out) })?;
+            self.complex_handle(out)
+        })
     }
     fn fft_extract_real<'a>(&'a self, handle: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> {
         Box::pin(async move {

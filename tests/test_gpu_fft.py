@@ -167,3 +167,24 @@ def test_baseline_size_matrix(prov):
         back = prov.fft_extract_real(prov.ifft_dim(f, None, dim))
         assert np.max(np.abs(prov.download_matrix(back) - x)) <= 64 * EPS
         del got, want
+
+
+@pytest.mark.parametrize("shape,dim,length", [((16,), 0, None), ((15,), 0, None), ((4096, 3), 0, None), ((7, 1000), 1, None), ((100,), 0, 128), ((300,), 0, 100),
+                                              ((8192, 4), 0, None)], ids=str)
+def test_signal_hilbert(prov, oracle, shape, dim, length):
+    """hilbert = fft -> one-sided mask -> ifft: two transforms' worth of the transform tolerance, checked against the oracle (direct DFTs)
+    or scipy for long lines; the real part returns the (padded / truncated) input."""
+    from scipy.signal import hilbert
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape)
+    n = length if length is not None else shape[dim]
+    want = oracle.hilbert(x, length, dim) if n <= 1024 else hilbert(x, N=length, axis=dim)
+    h = prov.signal_hilbert(prov.upload(x.ravel(order="F"), shape), length, dim)
+    assert prov.is_complex(h) and list(h.shape) == list(want.shape)
+    got = prov.download(h).reshape(want.shape, order="F")
+    lim = 2 * bound(np.asarray(x), n, dim, False) * 2.0 / np.sqrt(n)                 # forward error through the 1 / n of the inverse, mask factor 2
+    assert np.all(np.abs(got - want) <= lim + 1e-300), float(np.max(np.abs(got - want) / lim))
+    with pytest.raises(Exception):
+        prov.signal_hilbert(prov.upload(x.ravel(order="F"), shape), 0, dim)
+    with pytest.raises(Exception):
+        prov.signal_hilbert(prov.upload(x.ravel(order="F"), shape), None, len(shape))

@@ -45,3 +45,13 @@ def test_round_trip_and_empty():
     assert np.max(np.abs(oracle.fft_dim(oracle.fft_dim(x, None, 0), None, 0, True) - x)) <= 1e-15 * 12
     assert oracle.fft_dim(np.zeros((0, 3)), 4, 0).shape == (4, 3) and not oracle.fft_dim(np.zeros((0, 3)), 4, 0).any()
     assert oracle.fft_dim(x, 0, 1).shape == (12, 0)
+
+
+def test_hilbert_against_scipy():
+    from scipy.signal import hilbert
+    rng = np.random.default_rng(9)
+    for shape, dim, n in (((16,), 0, None), ((15,), 0, None), ((12, 3), 0, None), ((4, 10), 1, None), ((9,), 0, 16), ((20,), 0, 7)):
+        x = rng.standard_normal(shape)
+        want = hilbert(x, N=n, axis=dim)
+        got = oracle.hilbert(x, n, dim)
+        assert got.shape == want.shape and np.max(np.abs(got - want)) <= 1e-13
