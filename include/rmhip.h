@@ -606,6 +606,12 @@ RMHIP_API int rmhip_cond(rmhip_ctx* ctx, rmhip_buf matrix, int norm, rmhip_buf* 
 RMHIP_API int rmhip_rcond(rmhip_ctx* ctx, rmhip_buf matrix, rmhip_buf* out);
 /* @serves pinv */
 RMHIP_API int rmhip_pinv(rmhip_ctx* ctx, rmhip_buf matrix, int has_tolerance, double tolerance, rmhip_buf* out);
+/* `covariance_to_correlation(matrix)` (lib.rs:1876-1884; simple_provider.rs:885-975): a covariance matrix validated as the CPU validates it
+ * (finite-or-NaN entries, non-negative diagonal, symmetric to 1e-10 relative, |cov| within the variance bound - the CPU's messages, its order of
+ * checks) and scaled: correlation = cov / (sd_i sd_j) (NaN where that product is zero), sigma = sqrt(diag) as [n, 1].  Bit-exact; one
+ * stream synchronisation for the verdict. */
+/* @serves covariance_to_correlation */
+RMHIP_API int rmhip_covariance_to_correlation(rmhip_ctx* ctx, rmhip_buf matrix, rmhip_buf* correlation, rmhip_buf* sigma);
 /* `peaks(n)` (x_or_0 == y_or_0 == 0; lib.rs:1781-1785) / `peaks_xy(x, y)` (lib.rs:1787-1795; peaks.rs:511-550): the `peaks` test surface on the
  * n x n grid over [-3, 3]^2 (n == 1: the point (3, 3)), or at same-shape coordinate tensors.  Products and sums in the CPU's order; three
  * exponentials per point: within 2e-14 absolute of the oracle (terms of magnitude up to ~8). */

@@ -498,6 +498,11 @@ public:
         check(rmhip_covariance(ctx_, own(matrix), biased ? 1 : 0, &out));
         return with_shape(out);
     }
+    std::pair<GpuTensorHandle, GpuTensorHandle> covariance_to_correlation(const GpuTensorHandle& m) const {  // lib.rs:1876: (correlation, sigma)
+        uint64_t corr = 0, sig = 0;
+        check(rmhip_covariance_to_correlation(ctx_, own(m), &corr, &sig));
+        return {with_shape(corr), with_shape(sig)};
+    }
     // lib.rs:2437-2470; tolerance == nullptr: the default rule; cond norm: 0 Two (served), 1 One, 2 Inf, 3 Fro
     GpuTensorHandle rank(const GpuTensorHandle& m, const double* tolerance = nullptr) const {
         uint64_t out = 0;

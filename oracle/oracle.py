@@ -861,6 +861,37 @@ def ismember(a, b):
     return (loc > 0).astype(np.uint8).reshape(a.shape, order="F"), loc.reshape(a.shape, order="F")
 
 
+def covariance_to_correlation(m):
+    """provider_validate_covariance_matrix + provider_covariance_to_correlation, simple_provider.rs:896-975 -> (correlation, sigma [n, 1]); raises
+    ValueError with the CPU's message when the matrix is refused."""
+    m = np.asarray(m, dtype=np.float64)
+    n = m.shape[0]
+    if m.ndim != 2 or m.shape[0] != m.shape[1]:
+        raise ValueError("covariance matrix must be square")
+    if np.any(~np.isnan(m) & ~np.isfinite(m)):
+        raise ValueError("covariance matrix must contain finite values or NaN")
+    if any(not (m[i, i] >= 0.0) for i in range(n)):
+        raise ValueError("covariance matrix diagonal entries must be nonnegative")
+    for col in range(n):
+        for row in range(col):
+            a, b = m[row, col], m[col, row]
+            if np.isnan(a) and np.isnan(b):
+                continue
+            if np.isnan(a) or np.isnan(b) or not abs(a - b) <= 1e-10 * max(abs(a), abs(b), 1.0):
+                raise ValueError("covariance matrix must be symmetric")
+            vr, vc = m[row, row], m[col, col]
+            if np.isnan(vr) or np.isnan(vc):
+                continue
+            mc = np.sqrt(vr * vc)
+            if not abs(a) <= mc + 1e-10 * max(mc, abs(a), 1.0):
+                raise ValueError("covariance magnitude exceeds variance bounds")
+    sigma = np.sqrt(np.diag(m)) if n else np.zeros(0)
+    den = np.outer(sigma, sigma)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        corr = np.where(den == 0.0, np.nan, m / np.where(den == 0.0, 1.0, den))
+    return corr, sigma.reshape(-1, 1)
+
+
 def _eps_like(v: float) -> float:
     """common/linalg.rs:218-228: the gap from |v| to the next double."""
     a = abs(float(v))

@@ -210,6 +210,47 @@ __global__ void __launch_bounds__(kB) k_peaks(const double* __restrict__ xs, con
     out[o] = peaks_at(x, y);
 }
 
+// covariance_to_correlation (runmat-accelerate/src/simple_provider.rs:885-975): validate a covariance matrix the way the CPU does - finite or NaN
+// entries, non-negative diagonal, symmetric to 1e-10 relative, |cov| within sqrt(var_i var_j) - and scale it by the standard deviations.
+// flags[0]: a non-finite entry; flags[1]: a diagonal entry that is not >= 0; flags[2] / flags[3]: the smallest (col, row) order index of a pair
+// that is not symmetric / exceeds the variance bound (the CPU stops at the first pair in that order, symmetry tested first).
+__global__ void __launch_bounds__(kB) k_cov_validate(const double* __restrict__ m, u64 n, unsigned long long* __restrict__ flags) {
+    const u64 o = (u64)blockIdx.x * kB + threadIdx.x;
+    if (o >= n * n) return;
+    const u64 row = o % n, col = o / n;
+    const double a = m[o];
+    if (!isnan(a) && !isfinite(a)) flags[0] = 1;
+    if (row == col && !(a >= 0.0)) flags[1] = 1;
+    if (row < col) {
+        const double b = m[col + row * n];
+        if (isnan(a) && isnan(b)) return;
+        bool sym_bad = isnan(a) || isnan(b);
+        if (!sym_bad) {
+            const double tol = 1.0e-10 * fmax(fmax(fabs(a), fabs(b)), 1.0);
+            sym_bad = !(fabs(a - b) <= tol);
+        }
+        if (sym_bad) {
+            atomicMin(flags + 2, (unsigned long long)o);
+            return;
+        }
+        const double vr = m[row + row * n], vc = m[col + col * n];
+        if (isnan(vr) || isnan(vc)) return;
+        const double mc = sqrt(vr * vc);
+        const double bt = 1.0e-10 * fmax(fmax(mc, fabs(a)), 1.0);
+        if (!(fabs(a) <= mc + bt)) atomicMin(flags + 3, (unsigned long long)o);
+    }
+}
+
+__global__ void __launch_bounds__(kB) k_cov_to_corr(const double* __restrict__ m, u64 n, double* __restrict__ corr, double* __restrict__ sigma) {
+    const u64 o = (u64)blockIdx.x * kB + threadIdx.x;
+    if (o >= n * n) return;
+    const u64 row = o % n, col = o / n;
+    const double sr = sqrt(m[row + row * n]), sc = sqrt(m[col + col * n]);
+    const double den = sr * sc;
+    corr[o] = den == 0.0 ? NAN : m[o] / den;
+    if (col == 0) sigma[row] = sr;
+}
+
 // corrcoef from the covariance matrix (corrcoef.rs:720-787, 895-926): r(i, j) = cov(i, j) / (sqrt(var_i) sqrt(var_j)), NaN unless both variances
 // are finite and positive, values within 1e-12 outside [-1, 1] pulled onto the bound; the diagonal is exactly 1 where the deviation is positive.
 __global__ void __launch_bounds__(kB) k_corr_from_cov(const double* __restrict__ cov, u64 n, double* __restrict__ out) {
@@ -637,6 +678,48 @@ int rmhip_peaks(rmhip_ctx* ctx, size_t n, rmhip_buf x_or_0, rmhip_buf y_or_0, rm
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
+}
+
+int rmhip_covariance_to_correlation(rmhip_ctx* ctx, rmhip_buf matrix, rmhip_buf* correlation, rmhip_buf* sigma) {
+    CTX_OR_FAIL(ctx);
+    if (!correlation || !sigma) return fail(RMHIP_ERR_INVALID, "null output");
+    *correlation = *sigma = 0;
+    Buffer mb;
+    RMHIP_TRY(c->get(matrix, &mb));
+    if (mb.shape.size() > 2) return fail(RMHIP_ERR_INVALID, "covariance_to_correlation: covariance matrix must be two-dimensional");
+    const u64 rows = mb.shape.empty() ? 1 : mb.shape[0], cols = mb.shape.size() < 2 ? 1 : mb.shape[1];  // simple_provider.rs:885-894
+    if (rows != cols) return fail(RMHIP_ERR_INVALID, "covariance_to_correlation: covariance matrix must be square");
+    const u64 n = rows;
+    if (n > 0) {
+        std::shared_ptr<Allocation> fl;
+        RMHIP_TRY(c->alloc_device(4, &fl));
+        unsigned long long init[4] = {0, 0, ~0ull, ~0ull}, host[4];
+        RMHIP_HIP_CHECK(hipMemcpyAsync(fl->ptr, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_cov_validate, dim3(grid_for(n * n)), dim3(kB), 0, c->stream, mb.data(), n, (unsigned long long*)fl->ptr);
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipMemcpyAsync(host, fl->ptr, sizeof host, hipMemcpyDeviceToHost, c->stream));
+        RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        // the CPU's order of checks (simple_provider.rs:908-952)
+        if (host[0]) return fail(RMHIP_ERR_INVALID, "covariance_to_correlation: covariance matrix must contain finite values or NaN");
+        if (host[1]) return fail(RMHIP_ERR_INVALID, "covariance_to_correlation: covariance matrix diagonal entries must be nonnegative");
+        if (host[2] != ~0ull && host[2] <= host[3]) return fail(RMHIP_ERR_INVALID, "covariance_to_correlation: covariance matrix must be symmetric");
+        if (host[3] != ~0ull) return fail(RMHIP_ERR_INVALID, "covariance_to_correlation: covariance magnitude exceeds variance bounds");
+    }
+    const size_t cshape[2] = {(size_t)n, (size_t)n}, sshape[2] = {(size_t)n, 1};
+    Buffer cb, sb;
+    RMHIP_TRY(c->new_buffer(cshape, 2, correlation, &cb));
+    int rc = c->new_buffer(sshape, 2, sigma, &sb);
+    if (rc == RMHIP_OK && n > 0) {
+        hipLaunchKernelGGL(k_cov_to_corr, dim3(grid_for(n * n)), dim3(kB), 0, c->stream, mb.data(), n, cb.data(), sb.data());
+        c->tel.kernel_launches++;
+        if (hipGetLastError() != hipSuccess) rc = fail(RMHIP_ERR_HIP, "covariance_to_correlation: launch failed");
+    }
+    if (rc != RMHIP_OK) {
+        rmhip_free(ctx, *correlation);
+        if (*sigma) rmhip_free(ctx, *sigma);
+        *correlation = *sigma = 0;
+    }
+    return rc;
 }
 
 int rmhip_corrcoef(rmhip_ctx* ctx, rmhip_buf matrix, int biased, int rows_mode, rmhip_buf* out) {

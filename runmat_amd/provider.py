@@ -762,6 +762,12 @@ class HipProvider:
         self._check(self._lib.rmhip_covariance(self._ctx, self._id(matrix), int(bool(biased)), C.byref(out)))
         return self._handle(out.value)
 
+    def covariance_to_correlation(self, matrix):
+        """lib.rs:1876-1884 -> `ProviderCovarianceToCorrelationResult { correlation, sigma }` as a pair of handles."""
+        corr, sig = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.rmhip_covariance_to_correlation(self._ctx, self._id(matrix), C.byref(corr), C.byref(sig)))
+        return self._handle(corr.value), self._handle(sig.value)
+
     def rank(self, matrix, tolerance: Optional[float] = None) -> GpuTensorHandle:
         """lib.rs:2464-2470 -> a [1, 1] tensor holding the numerical rank."""
         out = C.c_uint64()

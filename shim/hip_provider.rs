@@ -16,7 +16,7 @@ use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, ApiDeviceInfo, CorrcoefNormalization, CorrcoefOptions, CorrcoefRows, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle, GpuTensorStorage,
     HostLogicalOwned, HostTensorOwned, HostTensorView, IsMemberOptions, IsMemberResult, SetdiffOptions, SetdiffOrder, SetdiffResult, UnionOptions, UnionOrder, UnionResult, UniqueOccurrence, UniqueOptions, UniqueOrder, UniqueResult, ImageNormalizeDescriptor, KernelAttrTelemetry, MeshgridAxisView, ProviderMeshgridResult, ProviderPolyvalOptions, KernelLaunchTelemetry, MatmulEpilogue,
-    PowerStepEpilogue, ProviderBandwidth, ProviderHilbertRequest, ProviderCondNorm, ProviderPinvOptions, ProviderIirFilterOptions, ProviderIirFilterResult, ProviderInterp1Extrapolation, ProviderInterp1Method, ProviderInterp1Request, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
+    PowerStepEpilogue, ProviderBandwidth, ProviderCovarianceToCorrelationResult, ProviderHilbertRequest, ProviderCondNorm, ProviderPinvOptions, ProviderIirFilterOptions, ProviderIirFilterResult, ProviderInterp1Extrapolation, ProviderInterp1Method, ProviderInterp1Request, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderMovingWindowEndpoints, ProviderMovingWindowOp, ProviderMovingWindowRequest, ProviderNanMode, ProviderNdgridRequest, ProviderNormOrder, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
     ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult, SortRowsColumnSpec,
 };
@@ -528,6 +528,11 @@ impl AccelProvider for HipProvider {
             check(unsafe { rmhip_covariance(self.ctx, self.own(matrix)?, biased, &mut out) })?;
             self.handle(out)
         })
+    }
+    fn covariance_to_correlation(&self, matrix: &GpuTensorHandle) -> Result<ProviderCovarianceToCorrelationResult> {
+        let (mut corr, mut sig) = (0u64, 0u64);
+        check(unsafe { rmhip_covariance_to_correlation(self.ctx, self.own(matrix)?, &mut corr, &mut sig) })?;
+        Ok(ProviderCovarianceToCorrelationResult { correlation: self.handle(corr)?, sigma: self.handle(sig)? })
     }
     fn rank<'a>(&'a self, matrix: &'a GpuTensorHandle, tolerance: Option<f64>) -> AccelProviderFuture<'a, GpuTensorHandle> {
         Box::pin(async move {

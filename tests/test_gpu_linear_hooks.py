@@ -402,3 +402,30 @@ def test_rank_cond_pinv(prov, oracle):
         prov.cond(prov.upload(np.eye(3)), "fro")
     with pytest.raises(Exception):
         prov.pinv(prov.upload(np.eye(3)), -1.0)
+
+
+def test_covariance_to_correlation(prov, oracle):
+    # simple_provider.rs:8869-8900
+    corr, sig = prov.covariance_to_correlation(prov.upload(np.array([[4.0, 2.0], [2.0, 9.0]])))
+    assert np.allclose(prov.download_matrix(corr), [[1.0, 1.0 / 3.0], [1.0 / 3.0, 1.0]], atol=1e-15) and np.array_equal(prov.download(sig), [2.0, 3.0]) and list(sig.shape) == [2, 1]
+    rng = np.random.default_rng(41)
+    for n in (1, 3, 50, 700):
+        x = rng.standard_normal((n + 5, n))
+        cov = np.cov(x, rowvar=False).reshape(n, n)
+        cov[0, 0] = 0.0 if n > 2 else cov[0, 0]
+        if n > 2:
+            cov[0, 1:] = cov[1:, 0] = 0.0                                             # a zero-variance variable: NaN row / column
+            cov[1, 2] = cov[2, 1] = np.nan
+        want_c, want_s = oracle.covariance_to_correlation(cov)
+        c, s = prov.covariance_to_correlation(prov.upload(cov))
+        assert bits_equal(prov.download_matrix(c), want_c) and bits_equal(prov.download_matrix(s), want_s)
+    bad = {"symmetric": np.array([[1.0, 0.1], [0.2, 1.0]]), "nonnegative": np.array([[-1.0, 0.0], [0.0, 1.0]]), "finite": np.array([[1.0, np.inf], [np.inf, 1.0]]),
+           "bounds": np.array([[1.0, 5.0], [5.0, 1.0]]), "square": np.zeros((2, 3))}
+    for word, m in bad.items():
+        with pytest.raises(Exception, match=word):
+            prov.covariance_to_correlation(prov.upload(m))
+        if word != "square":
+            with pytest.raises(ValueError, match=word):
+                oracle.covariance_to_correlation(m)
+    e = prov.covariance_to_correlation(prov.upload(np.zeros((0, 0))))
+    assert list(e[0].shape) == [0, 0] and list(e[1].shape) == [0, 1]
