@@ -486,6 +486,13 @@ RMHIP_API int rmhip_moving_window(rmhip_ctx* ctx, rmhip_buf a, int dim, size_t b
 /* @serves iir_filter */
 RMHIP_API int rmhip_iir_filter(rmhip_ctx* ctx, rmhip_buf b, rmhip_buf a, rmhip_buf x, int dim, rmhip_buf zi_or_0, int unit_denominator, rmhip_buf* output,
                                rmhip_buf* final_state);
+/* `imfilter(image, kernel, options)` (lib.rs:1809-1817; `ImfilterOptions`, :1193-1222; imfilter.rs:476-545, 620-783): N-D correlation (or,
+ * convolution != 0, convolution: the kernel read back to front) of up to four dimensions.  padding: 0 constant (`constant_value`), 1 replicate,
+ * 2 symmetric, 3 circular; shape_mode: 0 same, 1 full, 2 valid; the kernel's origin is floor(extent / 2) per dimension.  Sums over the kernel's
+ * points in storage order, products rounded before the sum: bit-exact. */
+/* @serves imfilter */
+RMHIP_API int rmhip_imfilter(rmhip_ctx* ctx, rmhip_buf image, rmhip_buf kernel, int padding, double constant_value, int shape_mode, int convolution,
+                             rmhip_buf* out);
 /* `interp1(request)` (lib.rs:2458-2463; `ProviderInterp1Request`, :769-783; simple_provider.rs:1396-1472, 8135-8204): every series of y
  * (sample_len values each, back to back) interpolated at the query_len points of xq over the strictly increasing coordinates x - the
  * result holds series after series, in `output_shape`.  nearest: `ProviderInterp1Method::Nearest` (ties to the left sample), else Linear

@@ -744,6 +744,12 @@ public:
         check(rmhip_ismember(ctx_, own(a), own(b), r.mask.data(), r.loc.data.data()));
         return r;
     }
+    // lib.rs:1809-1817; padding 0 constant / 1 replicate / 2 symmetric / 3 circular; shape 0 same / 1 full / 2 valid
+    GpuTensorHandle imfilter(const GpuTensorHandle& image, const GpuTensorHandle& kernel, int padding, double constant_value, int shape, bool convolution) const {
+        uint64_t out = 0;
+        check(rmhip_imfilter(ctx_, own(image), own(kernel), padding, constant_value, shape, convolution ? 1 : 0, &out));
+        return with_shape(out);
+    }
     // lib.rs:2458-2463; extrapolation: 0 NaN, 1 extrapolate, 2 the value
     GpuTensorHandle interp1(const GpuTensorHandle& x, const GpuTensorHandle& y, const GpuTensorHandle& xq, size_t sample_len, size_t series_count, size_t query_len,
                             const std::vector<size_t>& output_shape, bool nearest, int extrapolation, double value) const {

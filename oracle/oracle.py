@@ -1008,6 +1008,62 @@ def corrcoef(matrix, normalization: str = "unbiased") -> np.ndarray:
     return out
 
 
+def imfilter(image, kernel, padding="constant", shape: str = "same", mode: str = "correlation") -> np.ndarray:
+    """build_imfilter_plan + evaluate_filter + sample_with_padding, builtins/image/filters/imfilter.rs:476-545, 620-783.  padding: a number
+    (constant fill) | "replicate" | "symmetric" | "circular".  The sum runs over the kernel's points in storage order (first dimension
+    fastest), vectorised over the outputs (numpy applies the same rounded operation to each)."""
+    img, ker = np.asarray(image, dtype=np.float64), np.asarray(kernel, dtype=np.float64)
+    ishape = list(img.shape) if img.ndim else [1, 1]
+    kshape = list(ker.shape) if ker.ndim else [1, 1]
+    rank = max(len(ishape), len(kshape))
+    iext, kext = ishape + [1] * (rank - len(ishape)), kshape + [1] * (rank - len(kshape))
+    origin = [k // 2 for k in kext]
+    if shape == "full":
+        oext, base = [i + k - 1 for i, k in zip(iext, kext)], [o - (k - 1) for o, k in zip(origin, kext)]
+    elif shape == "valid":
+        oext, base = [i - k + 1 if i >= k else 0 for i, k in zip(iext, kext)], list(origin)
+    else:
+        oext, base = list(iext), [0] * rank
+    final = list(oext)
+    while len(final) > len(ishape) and final[-1] == 1:
+        final.pop()
+    im = img.reshape(iext, order="F")
+    kr = ker.reshape(kext, order="F")
+    out = np.zeros(oext)
+    if out.size == 0:
+        return out.reshape(final, order="F")
+    grids = np.meshgrid(*[np.arange(n) for n in oext], indexing="ij")
+    const = padding if not isinstance(padding, str) else 0.0
+
+    def resolve(coord, n):
+        inside = (coord >= 0) & (coord < n)
+        if not isinstance(padding, str) or padding == "constant":
+            return np.where(inside, coord, 0), inside
+        if padding == "replicate":
+            return np.clip(coord, 0, n - 1), np.ones_like(inside)
+        if padding == "circular":
+            return np.mod(coord, n), np.ones_like(inside)
+        if n == 1:
+            return np.zeros_like(coord), np.ones_like(inside)
+        period = 2 * n - 2
+        v = np.mod(coord, period)
+        return np.where(v >= n, period - v, v), np.ones_like(inside)
+
+    for kidx in np.ndindex(*kext[::-1]):            # storage order: the first dimension fastest
+        kidx = kidx[::-1]
+        src = tuple(kext[d] - 1 - kidx[d] for d in range(rank)) if mode == "convolution" else kidx
+        kv = kr[src]
+        ok = np.ones(oext, dtype=bool)
+        coords = []
+        for d in range(rank):
+            c, inside = resolve(grids[d] + base[d] + kidx[d] - origin[d], iext[d])
+            coords.append(c)
+            ok &= inside
+        sample = np.where(ok, im[tuple(coords)], const)
+        out = out + kv * sample
+    return out.reshape(final, order="F")
+
+
 def interp1(x, y, xq, method: str = "linear", extrapolation="nan") -> np.ndarray:
     """interp1_value / interp1_interval_index, simple_provider.rs:1396-1472: y as [sample_len, series]; returns [query_len, series].
     extrapolation: "nan" | "extrapolate" | a fill value."""

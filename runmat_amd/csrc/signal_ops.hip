@@ -3,6 +3,7 @@
 //   conv2d            lib.rs:2543-2550    (builtins/math/signal/conv2.rs:595-640; simple_provider.rs:6065-6154)
 //   hann_window / hamming_window / blackman_window   lib.rs:1797-1807   (simple_provider.rs:95-120, 6453-6472)
 //   iir_filter        lib.rs:2551-2559    (builtins/math/signal/filter.rs:1119-1222, 1311-1319, 1370-1460)
+//   imfilter          lib.rs:1809-1817    (builtins/image/filters/imfilter.rs:476-545, 620-783)
 //   interp1           lib.rs:2458-2463    (runmat-accelerate/src/simple_provider.rs:1396-1472, 8135-8204)
 //   polyval           lib.rs:1652-1660    (builtins/math/poly/polyval.rs:886-905, 352-435)
 //   moving_window     lib.rs:2852-2857    (builtins/math/reduction/moving.rs:737-825, 929-1003, 1198-1237, 1282-1323)
@@ -367,6 +368,71 @@ __global__ void __launch_bounds__(kB) k_interp1(const double* __restrict__ x, co
     out[o] = r;
 }
 
+// imfilter (builtins/image/filters/imfilter.rs:476-545, 620-783): N-D correlation / convolution with the four padding rules.  One thread per
+// output element walks the kernel's points in their storage order (first dimension fastest) and adds value * sample, the product rounded
+// before the sum - the CPU's loop; up to four dimensions.
+struct ImfArgs {
+    int rank, padding, convolution;  // padding: 0 constant, 1 replicate, 2 symmetric, 3 circular
+    long long img[4], ker[4], out[4], base[4], origin[4];
+    u64 istride[4], kstride[4], total;
+    double constant;
+};
+
+__device__ __forceinline__ long long imf_resolve(long long coord, long long len, int padding) {  // -1: outside under constant padding
+    if (coord >= 0 && coord < len) return coord;
+    if (padding == 0) return -1;
+    if (padding == 1) return coord <= 0 ? 0 : len - 1;             // clamp_index
+    if (padding == 3) {                                            // wrap_index
+        long long c = coord % len;
+        return c < 0 ? c + len : c;
+    }
+    if (len == 1) return 0;                                        // reflect_index
+    const long long period = 2 * len - 2;
+    long long v = coord % period;
+    if (v < 0) v += period;
+    return v >= len ? period - v : v;
+}
+
+__global__ void __launch_bounds__(kB) k_imfilter(const double* __restrict__ image, const double* __restrict__ kernel, ImfArgs A, int k_in_lds, double* __restrict__ out) {
+    extern __shared__ double taps[];
+    const u64 ktotal = (u64)(A.ker[0] * A.ker[1] * A.ker[2] * A.ker[3]);
+    if (k_in_lds) {
+        for (u64 j = threadIdx.x; j < ktotal; j += kB) taps[j] = kernel[j];
+        __syncthreads();
+    }
+    const double* kk = k_in_lds ? taps : kernel;
+    const u64 o = (u64)blockIdx.x * kB + threadIdx.x;
+    if (o >= A.total) return;
+    long long oc[4];
+    u64 r = o;
+    for (int d = 0; d < 4; ++d) {
+        oc[d] = (long long)(r % (u64)A.out[d]) + A.base[d] - A.origin[d];  // image coordinate of kernel index 0 along d
+        r /= (u64)A.out[d];
+    }
+    double sum = 0.0;
+    for (long long k3 = 0; k3 < A.ker[3]; ++k3) {
+        const long long c3 = imf_resolve(oc[3] + k3, A.img[3], A.padding);
+        for (long long k2 = 0; k2 < A.ker[2]; ++k2) {
+            const long long c2 = imf_resolve(oc[2] + k2, A.img[2], A.padding);
+            for (long long k1 = 0; k1 < A.ker[1]; ++k1) {
+                const long long c1 = imf_resolve(oc[1] + k1, A.img[1], A.padding);
+                const bool outside_hi = c1 < 0 || c2 < 0 || c3 < 0;
+                const u64 ibase = outside_hi ? 0 : (u64)c1 * A.istride[1] + (u64)c2 * A.istride[2] + (u64)c3 * A.istride[3];
+                const u64 kbase = A.convolution ? (u64)(A.ker[1] - 1 - k1) * A.kstride[1] + (u64)(A.ker[2] - 1 - k2) * A.kstride[2] + (u64)(A.ker[3] - 1 - k3) * A.kstride[3]
+                                                : (u64)k1 * A.kstride[1] + (u64)k2 * A.kstride[2] + (u64)k3 * A.kstride[3];
+                for (long long k0 = 0; k0 < A.ker[0]; ++k0) {
+                    const long long c0 = imf_resolve(oc[0] + k0, A.img[0], A.padding);
+                    const double sample = (outside_hi || c0 < 0) ? A.constant : image[ibase + (u64)c0];
+                    const double kv = kk[kbase + (u64)(A.convolution ? A.ker[0] - 1 - k0 : k0)];
+                    const double p = kv * sample;
+                    sum = sum + p;
+                }
+            }
+        }
+    }
+    out[o] = sum;
+}
+
 inline unsigned grid_for(u64 n) { return (unsigned)((n + kB - 1) / kB); }
 
 }  // namespace
@@ -569,6 +635,52 @@ int rmhip_iir_filter(rmhip_ctx* ctx, rmhip_buf b, rmhip_buf a, rmhip_buf x, int 
         *output = *final_state = 0;
     }
     return rc;
+}
+
+int rmhip_imfilter(rmhip_ctx* ctx, rmhip_buf image, rmhip_buf kernel, int padding, double constant_value, int shape_mode, int convolution, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    if (padding < 0 || padding > 3 || shape_mode < 0 || shape_mode > 2) return fail(RMHIP_ERR_INVALID, "imfilter: padding %d / shape %d", padding, shape_mode);
+    Buffer ib, kb, ob;
+    RMHIP_TRY(c->get(image, &ib));
+    RMHIP_TRY(c->get(kernel, &kb));
+    if (kb.numel == 0) return fail(RMHIP_ERR_INVALID, "imfilter: filter must be non-empty along every dimension");  // imfilter.rs:482-487
+    std::vector<size_t> ishape = ib.shape.empty() ? std::vector<size_t>{1, 1} : ib.shape, kshape = kb.shape.empty() ? std::vector<size_t>{1, 1} : kb.shape;
+    const size_t rank = std::max(ishape.size(), kshape.size());
+    if (rank > 4) return fail(RMHIP_ERR_UNSUPPORTED, "imfilter: %zu dimensions", rank);
+    for (size_t d = 0; d < kshape.size(); ++d) {  // validate_kernel_shape, imfilter.rs:567-593
+        if (d >= ishape.size() && kshape[d] > 1)
+            return fail(RMHIP_ERR_INVALID, "imfilter: filter dimension %zu is %zu, but the image has no corresponding axis", d + 1, kshape[d]);
+        if ((d < ishape.size() ? ishape[d] : 1) == 0) return fail(RMHIP_ERR_INVALID, "imfilter: image must not have zero-length dimensions");
+    }
+    ImfArgs A{};
+    A.rank = (int)rank, A.padding = padding, A.convolution = convolution ? 1 : 0, A.constant = constant_value;
+    std::vector<size_t> oshape(rank);
+    u64 is = 1, ks = 1;
+    for (size_t d = 0; d < 4; ++d) {
+        const long long img = d < ishape.size() ? (long long)ishape[d] : 1, ker = d < kshape.size() ? (long long)kshape[d] : 1;
+        A.img[d] = img, A.ker[d] = ker, A.origin[d] = ker / 2;
+        A.istride[d] = is, A.kstride[d] = ks;
+        is *= (u64)img, ks *= (u64)ker;
+        long long o = img, base = 0;                                              // same
+        if (shape_mode == 1) o = img + ker - 1, base = A.origin[d] - (ker - 1);   // full
+        if (shape_mode == 2) o = img >= ker ? img - ker + 1 : 0, base = A.origin[d];  // valid
+        A.out[d] = o, A.base[d] = base;
+        if (d < rank) oshape[d] = (size_t)o;
+    }
+    while (oshape.size() > ishape.size() && oshape.back() == 1) oshape.pop_back();  // imfilter.rs:526-532
+    if (oshape.empty()) oshape.push_back(1);
+    RMHIP_TRY(c->new_buffer(oshape.data(), oshape.size(), out, &ob));
+    A.total = ob.numel;
+    if (ob.numel == 0) return RMHIP_OK;
+    if (ob.numel > 0x7fffffffull * kB) return fail(RMHIP_ERR_UNSUPPORTED, "imfilter: %zu outputs", ob.numel);
+    for (int d = 0; d < 4; ++d)
+        if (A.out[d] == 0) A.out[d] = 1;  // (never reached with numel > 0)
+    const int in_lds = kb.numel <= LDS_TAPS;
+    hipLaunchKernelGGL(k_imfilter, dim3(grid_for(ob.numel)), dim3(kB), in_lds ? kb.numel * sizeof(double) : 0, c->stream, ib.data(), kb.data(), A, in_lds, ob.data());
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    return RMHIP_OK;
 }
 
 int rmhip_interp1(rmhip_ctx* ctx, rmhip_buf x, rmhip_buf y, rmhip_buf xq, size_t sample_len, size_t series_count, size_t query_len, const size_t* output_shape,

@@ -1171,6 +1171,17 @@ class HipProvider:
                                                1 if unit_denominator else 0, C.byref(out), C.byref(fin)))
         return self._handle(out.value), self._handle(fin.value)
 
+    def imfilter(self, image, kernel, padding="constant", shape: str = "same", mode: str = "correlation") -> GpuTensorHandle:
+        """lib.rs:1809-1817 (`ImfilterOptions`, :1193-1222); padding: a number (constant fill) | "replicate" | "symmetric" | "circular" ("constant": 0)."""
+        pads = {"constant": (0, 0.0), "replicate": (1, 0.0), "symmetric": (2, 0.0), "circular": (3, 0.0)}
+        pad, fill = pads[padding] if isinstance(padding, str) else (0, float(padding))
+        shapes, modes = {"same": 0, "full": 1, "valid": 2}, {"correlation": 0, "convolution": 1}
+        if shape not in shapes or mode not in modes:
+            raise RmhipError(1, f"imfilter: shape {shape!r} / mode {mode!r}")
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_imfilter(self._ctx, self._id(image), self._id(kernel), pad, fill, shapes[shape], modes[mode], C.byref(out)))
+        return self._handle(out.value)
+
     def interp1(self, x, y, xq, sample_len: int, series_count: int, query_len: int, output_shape, method: str = "linear", extrapolation="nan") -> GpuTensorHandle:
         """lib.rs:2458-2463 (`ProviderInterp1Request`, :769-783); extrapolation: "nan" | "extrapolate" | a fill value."""
         if method not in ("linear", "nearest"):

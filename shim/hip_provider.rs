@@ -15,7 +15,7 @@
 use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, ApiDeviceInfo, CorrcoefNormalization, CorrcoefOptions, CorrcoefRows, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle, GpuTensorStorage,
-    HostLogicalOwned, HostTensorOwned, HostTensorView, IsMemberOptions, IsMemberResult, SetdiffOptions, SetdiffOrder, SetdiffResult, UnionOptions, UnionOrder, UnionResult, UniqueOccurrence, UniqueOptions, UniqueOrder, UniqueResult, ImageNormalizeDescriptor, KernelAttrTelemetry, MeshgridAxisView, ProviderMeshgridResult, ProviderPolyvalOptions, KernelLaunchTelemetry, MatmulEpilogue,
+    HostLogicalOwned, HostTensorOwned, HostTensorView, IsMemberOptions, IsMemberResult, SetdiffOptions, SetdiffOrder, SetdiffResult, UnionOptions, UnionOrder, UnionResult, UniqueOccurrence, UniqueOptions, UniqueOrder, UniqueResult, ImageNormalizeDescriptor, ImfilterMode, ImfilterOptions, ImfilterPadding, ImfilterShape, KernelAttrTelemetry, MeshgridAxisView, ProviderMeshgridResult, ProviderPolyvalOptions, KernelLaunchTelemetry, MatmulEpilogue,
     PowerStepEpilogue, ProviderBandwidth, ProviderCovarianceToCorrelationResult, ProviderHilbertRequest, ProviderCondNorm, ProviderPinvOptions, ProviderIirFilterOptions, ProviderIirFilterResult, ProviderInterp1Extrapolation, ProviderInterp1Method, ProviderInterp1Request, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderMovingWindowEndpoints, ProviderMovingWindowOp, ProviderMovingWindowRequest, ProviderNanMode, ProviderNdgridRequest, ProviderNormOrder, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
     ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult, SortRowsColumnSpec,
@@ -826,6 +826,16 @@ impl AccelProvider for HipProvider {
                 mask: HostLogicalOwned { data: mask, shape: a.shape.clone() },
                 loc: HostTensorOwned { data: loc, shape: a.shape.clone(), storage: GpuTensorStorage::Real },
             })
+        })
+    }
+    fn imfilter<'a>(&'a self, image: &'a GpuTensorHandle, kernel: &'a GpuTensorHandle, options: &'a ImfilterOptions) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let padding = match options.padding { ImfilterPadding::Constant => 0, ImfilterPadding::Replicate => 1, ImfilterPadding::Symmetric => 2, ImfilterPadding::Circular => 3 };
+            let shape = match options.shape { ImfilterShape::Same => 0, ImfilterShape::Full => 1, ImfilterShape::Valid => 2 };
+            let conv = matches!(options.mode, ImfilterMode::Convolution) as c_int;
+            let mut out = 0u64;
+            check(unsafe { rmhip_imfilter(self.ctx, self.own(image)?, self.own(kernel)?, padding, options.constant_value, shape, conv, &mut out) })?;
+            self.handle(out)
         })
     }
     fn interp1<'a>(&'a self, request: &'a ProviderInterp1Request<'a>) -> AccelProviderFuture<'a, GpuTensorHandle> {

@@ -253,3 +253,35 @@ def test_interp1(prov, oracle, n, series, nq):
             assert bits_equal(got, want), (method, extrapolation)
     with pytest.raises(Exception):
         prov.interp1(hx, hy, hq, n, series, nq, (nq + 1, series))
+
+
+@pytest.mark.parametrize("ishape,kshape", [((9, 11), (3, 3)), ((9, 11), (2, 5)), ((9, 11), (4, 1)), ((9, 11), (1, 1)), ((4, 5, 3), (3, 3, 3)), ((7,), (3,)), ((6, 6), (9, 9)),
+                                           ((300, 257), (5, 5)), ((3, 4, 5, 2), (2, 2, 2, 2))], ids=str)
+def test_imfilter(prov, oracle, ishape, kshape):
+    rng = np.random.default_rng(sum(ishape) * 3 + sum(kshape))
+    img, ker = rng.standard_normal(ishape), rng.standard_normal(kshape)
+    hi, hk = prov.upload(img.ravel(order="F"), ishape), prov.upload(ker.ravel(order="F"), kshape)
+    for padding in (0.0, 2.5, "replicate", "symmetric", "circular"):
+        for shape in ("same", "full", "valid"):
+            for mode in ("correlation", "convolution"):
+                want = oracle.imfilter(img, ker, padding, shape, mode)
+                got = prov.imfilter(hi, hk, padding, shape, mode)
+                assert list(got.shape) == list(want.shape), (padding, shape, mode, got.shape, want.shape)
+                assert bits_equal(prov.download(got).reshape(want.shape, order="F"), want), (padding, shape, mode)
+                prov.free(got)
+
+
+def test_imfilter_limits_and_baseline_size(prov, oracle):
+    with pytest.raises(Exception):
+        prov.imfilter(prov.upload(np.zeros((4, 4))), prov.upload(np.zeros((0, 3))))
+    with pytest.raises(Exception):
+        prov.imfilter(prov.upload(np.zeros((4, 4))), prov.upload(np.ones((2, 2, 2))))     # the image has no third axis
+    n = 8192
+    h = prov.fill_uniform(19, -1.0, 1.0, (n, n))
+    ker = np.random.default_rng(2).standard_normal((5, 5))
+    y = prov.download_matrix(prov.imfilter(h, prov.upload(ker), "replicate"))
+    x = prov.download_matrix(h)
+    want = oracle.imfilter(x[:40, :40], ker, "replicate")
+    assert bits_equal(y[:38, :38], want[:38, :38])                                    # (the block's own lower / right padding differs from the image's interior)
+    want = oracle.imfilter(x[-40:, -40:], ker, "replicate")
+    assert bits_equal(y[-38:, -38:], want[-38:, -38:])

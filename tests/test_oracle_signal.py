@@ -132,3 +132,27 @@ def test_interp1_against_numpy():
     near = np.abs(q[inside, None] - x[None, :]).argmin(axis=1)
     assert np.array_equal(nn[inside, 1], y[near, 1])
     assert np.array_equal(oracle.interp1([0.0, 1.0, 2.0], [10.0, 20.0, 30.0], [0.5, 1.5], "nearest")[:, 0], [10.0, 20.0])   # ties to the left
+
+
+def test_imfilter_against_scipy():
+    from scipy import ndimage
+    rng = np.random.default_rng(44)
+    img = rng.standard_normal((9, 11))
+    for kshape in ((3, 3), (2, 5), (4, 1), (1, 1)):
+        ker = rng.standard_normal(kshape)
+        origin = [0] * len(kshape)                                                 # both centre a kernel at floor(extent / 2)
+        for pad, smode in (("replicate", "nearest"), ("symmetric", "mirror"), ("circular", "wrap"), (0.0, "constant"), (2.5, "constant")):
+            want = ndimage.correlate(img, ker, mode=smode, cval=pad if smode == "constant" else 0.0, origin=origin)
+            assert np.allclose(oracle.imfilter(img, ker, pad), want, rtol=0, atol=1e-13), (kshape, pad)
+            wconv = ndimage.convolve(img, ker, mode=smode, cval=pad if smode == "constant" else 0.0, origin=origin)
+            got = oracle.imfilter(img, ker, pad, mode="convolution")
+            assert got.shape == img.shape
+            if all(k % 2 for k in kshape):
+                assert np.allclose(got, wconv, rtol=0, atol=1e-13), (kshape, pad)
+    ker = rng.standard_normal((3, 4))
+    from scipy.signal import correlate2d
+    assert np.allclose(oracle.imfilter(img, ker, 0.0, "full"), correlate2d(img, ker, "full"), atol=1e-13)
+    assert oracle.imfilter(img, ker, 0.0, "valid").shape == (7, 8) and oracle.imfilter(img, np.ones((12, 3)), 0.0, "valid").shape == (0, 9)
+    vol = rng.standard_normal((4, 5, 3))
+    k3 = rng.standard_normal((3, 3, 3))
+    assert np.allclose(oracle.imfilter(vol, k3, "replicate"), ndimage.correlate(vol, k3, mode="nearest"), rtol=0, atol=1e-13)
