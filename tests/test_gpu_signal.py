@@ -272,6 +272,9 @@ def test_imfilter(prov, oracle, ishape, kshape):
 
 
 def test_imfilter_limits_and_baseline_size(prov, oracle):
+    for k in K["imfilter"]:
+        got = prov.imfilter(prov.upload(np.array(k["image"], dtype=np.float64), k["ishape"]), prov.upload(np.array(k["kernel"], dtype=np.float64), k["kshape"]), k["padding"], k["shape"])
+        assert list(got.shape) == k["oshape"] and np.array_equal(prov.download(got), k["out"]), k
     with pytest.raises(Exception):
         prov.imfilter(prov.upload(np.zeros((4, 4))), prov.upload(np.zeros((0, 3))))
     with pytest.raises(Exception):

@@ -135,6 +135,10 @@ def test_interp1_against_numpy():
 
 
 def test_imfilter_against_scipy():
+    for k in K["imfilter"]:
+        got = oracle.imfilter(np.array(k["image"], dtype=np.float64).reshape(k["ishape"], order="F"), np.array(k["kernel"], dtype=np.float64).reshape(k["kshape"], order="F"),
+                              k["padding"], k["shape"])
+        assert list(got.shape) == k["oshape"] and np.array_equal(got.ravel(order="F"), k["out"]), k
     from scipy import ndimage
     rng = np.random.default_rng(44)
     img = rng.standard_normal((9, 11))
