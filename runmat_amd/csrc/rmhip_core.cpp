@@ -425,6 +425,7 @@ int rmhip_shutdown(rmhip_ctx* ctx) {
     }
     c->pool_limit_bytes = 0;  // frees bypass the pool from here on
     c->table.clear();
+    c->fft_tables.clear();  // (cached twiddle / chirp tables hold allocations of this context: released while it is still whole)
     for (auto& kv : c->pool) (void)hipFree(kv.second);
     c->pool.clear();
     if (c->scratch) (void)hipFree(c->scratch);
