@@ -526,9 +526,10 @@ int rmhip_moving_window(rmhip_ctx* ctx, rmhip_buf a, int dim, size_t before, siz
     // the caller's output shape (moving.rs:1545-1570): the input's, the dimension trimmed by before + after for 'discard'
     std::vector<size_t> want = shape;
     if (endpoints == 1) want[dim] = shape[dim] > before + after ? shape[dim] - before - after : 0;
-    std::vector<size_t> given(out_shape, out_shape + out_rank);
-    while (given.size() > want.size() && given.back() == 1) given.pop_back();
-    if (given != want) return fail(RMHIP_ERR_SHAPE, "moving_window: output shape does not match the request");
+    std::vector<size_t> given(out_shape, out_shape + out_rank), wanted = want;  // compared without trailing singleton dimensions beyond `dim`
+    while (given.size() > (size_t)dim + 1 && given.back() == 1) given.pop_back();
+    while (wanted.size() > (size_t)dim + 1 && wanted.back() == 1) wanted.pop_back();
+    if (given != wanted) return fail(RMHIP_ERR_SHAPE, "moving_window: output shape does not match the request");
     MovingArgs A{};
     A.pre = 1, A.post = 1;
     for (int k = 0; k < dim; ++k) A.pre *= shape[k];
