@@ -256,7 +256,8 @@ def test_interp1(prov, oracle, n, series, nq):
 
 
 @pytest.mark.parametrize("ishape,kshape", [((9, 11), (3, 3)), ((9, 11), (2, 5)), ((9, 11), (4, 1)), ((9, 11), (1, 1)), ((4, 5, 3), (3, 3, 3)), ((7,), (3,)), ((6, 6), (9, 9)),
-                                           ((300, 257), (5, 5)), ((3, 4, 5, 2), (2, 2, 2, 2))], ids=str)
+                                           ((300, 257), (5, 5)), ((3, 4, 5, 2), (2, 2, 2, 2)),
+                                           ((70, 37, 3), (3, 4)), ((66, 18, 2, 2), (1, 7)), ((130, 20), (65, 2)), ((40, 90), (6, 70))], ids=str)
 def test_imfilter(prov, oracle, ishape, kshape):
     rng = np.random.default_rng(sum(ishape) * 3 + sum(kshape))
     img, ker = rng.standard_normal(ishape), rng.standard_normal(kshape)
