@@ -95,6 +95,63 @@ __global__ void __launch_bounds__(kB) k_conv2d(const double* __restrict__ a, u64
     out[o] = acc;
 }
 
+// The same sums on an LDS-staged patch (see k_imfilter_tile below for why): 64 rows x 16 columns of outputs per workgroup, four per thread.  A
+// term whose sample lies outside `a` is skipped, not added as a zero - the CPU never forms that product (0 * Inf would be NaN).
+constexpr int CONV_TX = 64, CONV_TY = 16;
+__global__ void __launch_bounds__(kB) k_conv2d_tile(const double* __restrict__ a, u64 ar_n, u64 ac_n, const double* __restrict__ b, int br_n, int bc_n, u64 r0, u64 c0,
+                                                    u64 rows, u64 cols, double* __restrict__ out) {
+    extern __shared__ double patch[];
+    const int W = CONV_TX + br_n - 1, H = CONV_TY + bc_n - 1;
+    // full-result coordinates of this tile's first output, and the sample its first tap reads (negative: outside)
+    const long long R0 = (long long)(r0 + (u64)blockIdx.x * CONV_TX), C0 = (long long)(c0 + (u64)blockIdx.y * CONV_TY);
+    const long long ar0 = R0 - (br_n - 1), ac0 = C0 - (bc_n - 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int ly = wave; ly < H; ly += kB / 64) {
+        const long long ac = ac0 + ly;
+        const bool col_in = ac >= 0 && ac < (long long)ac_n;
+        for (int lx = lane; lx < W; lx += 64) {
+            const long long ar = ar0 + lx;
+            patch[ly * W + lx] = (col_in && ar >= 0 && ar < (long long)ar_n) ? a[(u64)ac * ar_n + (u64)ar] : 0.0;
+        }
+    }
+    __syncthreads();
+    constexpr int OUTS = CONV_TY / (kB / 64);
+    double acc[OUTS];
+#pragma unroll
+    for (int j = 0; j < OUTS; ++j) acc[j] = 0.0;
+    // the taps whose sample exists: kr in [kr_lo, kr_hi] for this thread's row, kc in [kc_lo, kc_hi] for each of its columns
+    const long long ar_first = ar0 + lane;
+    const int kr_lo = ar_first < 0 ? (int)(-ar_first) : 0;
+    const long long kr_room = (long long)ar_n - 1 - ar_first;
+    const int kr_hi = kr_room < br_n - 1 ? (int)kr_room : br_n - 1;
+    for (int kc = 0; kc < bc_n; ++kc) {
+        bool col_ok[OUTS];
+#pragma unroll
+        for (int j = 0; j < OUTS; ++j) {
+            const long long ac = ac0 + wave + j * (kB / 64) + kc;
+            col_ok[j] = ac >= 0 && ac < (long long)ac_n;
+        }
+        const double* row = patch + (wave + kc) * W + lane;
+        for (int kr = 0; kr < br_n; ++kr) {
+            const double bv = b[kc * br_n + kr];  // uniform: a scalar load
+            const bool row_ok = kr >= kr_lo && kr <= kr_hi;
+#pragma unroll
+            for (int j = 0; j < OUTS; ++j) {
+                const double p = row[j * (kB / 64) * W + kr] * bv;
+                const double next = acc[j] + p;
+                acc[j] = (row_ok && col_ok[j]) ? next : acc[j];
+            }
+        }
+    }
+    const u64 orow = (u64)blockIdx.x * CONV_TX + lane;
+    if (orow >= rows) return;
+#pragma unroll
+    for (int j = 0; j < OUTS; ++j) {
+        const u64 ocol = (u64)blockIdx.y * CONV_TY + wave + j * (kB / 64);
+        if (ocol < cols) out[ocol * rows + orow] = acc[j];
+    }
+}
+
 __global__ void __launch_bounds__(kB) k_window(int kind, u64 len, double denom, double* __restrict__ out) {
     const u64 i = (u64)blockIdx.x * kB + threadIdx.x;
     if (i >= len) return;
@@ -594,6 +651,15 @@ int rmhip_conv2d(rmhip_ctx* ctx, rmhip_buf signal, rmhip_buf kernel, int mode, r
     RMHIP_TRY(c->new_buffer(shape, 2, out, &ob));
     if (ob.numel == 0) return RMHIP_OK;
     if (ob.numel > 0x7fffffffull * kB) return fail(RMHIP_ERR_UNSUPPORTED, "conv2d: %zu outputs", ob.numel);
+    const size_t patch_bytes = (size_t)(CONV_TX + br_n - 1) * (size_t)(CONV_TY + bc_n - 1) * sizeof(double);
+    const u64 tiles_y = (cols + CONV_TY - 1) / CONV_TY;
+    if (br_n <= 64 && bc_n <= 512 && patch_bytes <= 48u * 1024 && tiles_y <= 65535) {
+        const dim3 grid((unsigned)((rows + CONV_TX - 1) / CONV_TX), (unsigned)tiles_y);
+        hipLaunchKernelGGL(k_conv2d_tile, grid, dim3(kB), patch_bytes, c->stream, ab.data(), ar_n, ac_n, bb.data(), (int)br_n, (int)bc_n, r0, c0, rows, cols, ob.data());
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+        return RMHIP_OK;
+    }
     const int in_lds = bb.numel <= LDS_TAPS;
     hipLaunchKernelGGL(k_conv2d, dim3(grid_for(ob.numel)), dim3(kB), in_lds ? bb.numel * sizeof(double) : 0, c->stream, ab.data(), ar_n, ac_n, bb.data(), br_n, bc_n, r0, c0,
                        rows, cols, in_lds, ob.data());

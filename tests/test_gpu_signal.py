@@ -43,7 +43,7 @@ def test_conv1d(prov, oracle, la, lb):
 
 
 @pytest.mark.parametrize("sa,sb", [((1, 1), (1, 1)), ((3, 3), (3, 3)), ((9, 7), (3, 4)), ((3, 4), (9, 7)), ((64, 65), (5, 5)), ((200, 300), (17, 1)), ((200, 300), (1, 17)),
-                                   ((40, 40), (70, 66)), ((5,), (3,))], ids=str)
+                                   ((40, 40), (70, 66)), ((5,), (3,)), ((130, 50), (64, 3)), ((70, 45), (2, 40)), ((3, 100), (5, 2))], ids=str)
 def test_conv2d(prov, oracle, sa, sb):
     rng = np.random.default_rng(sum(sa) * 13 + sum(sb))
     a, b = rng.standard_normal(sa), rng.standard_normal(sb)
