@@ -507,6 +507,17 @@ RMHIP_API int rmhip_interp1(rmhip_ctx* ctx, rmhip_buf x, rmhip_buf y, rmhip_buf 
  * CPU's complex recurrence yields NaN + NaN i there: a complex result the caller forms on the host).  Synchronises the stream once. */
 /* @serves polyval */
 RMHIP_API int rmhip_polyval(rmhip_ctx* ctx, rmhip_buf coefficients, rmhip_buf points, int has_mu, double mean, double scale, rmhip_buf* out);
+/* `polyder_single(p)`, `polyder_product(p, q)`, `polyder_quotient(u, v)` (lib.rs:1674-1701; simple_provider.rs:3137-3188): the derivative
+ * of a polynomial (coefficient vector, highest power first), of a product (p'q + pq') or of a quotient (numerator u'v - uv' in `out`,
+ * denominator v*v in `denominator_or_null`); q_or_0 = 0 selects the single form.  Results are trimmed of leading coefficients with
+ * |c| <= 1e-12 ([0] when nothing is left) and take the first operand's orientation (the denominator: v's); an input with more than one
+ * extent above 1 is RMHIP_ERR_INVALID.  Bit-exact: the CPU's sums in the CPU's order.  Synchronises the stream (the length is data). */
+/* @serves polyder_single polyder_product polyder_quotient */
+RMHIP_API int rmhip_polyder(rmhip_ctx* ctx, rmhip_buf p, rmhip_buf q_or_0, int quotient, rmhip_buf* out, rmhip_buf* denominator_or_null);
+/* `polyint(polynomial, constant)` (lib.rs:1704-1710; simple_provider.rs:374-390, 3190-3215): coefficient i divided by its new power, the
+ * constant appended; real polynomials (a complex-interleaved one is RMHIP_ERR_UNSUPPORTED).  Bit-exact. */
+/* @serves polyint */
+RMHIP_API int rmhip_polyint(rmhip_ctx* ctx, rmhip_buf p, double constant, rmhip_buf* out);
 /* `hann_window / hamming_window / blackman_window(len, periodic)` (lib.rs:1797-1807; simple_provider.rs:95-120) -> [len, 1]; kind 0 / 1 / 2.
  * One cosine (two for Blackman) per point: within 2 ulp of the cosine of the CPU's libm (tests state the bound). */
 /* @serves hann_window hamming_window blackman_window */

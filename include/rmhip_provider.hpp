@@ -773,6 +773,27 @@ public:
         check(rmhip_polyval(ctx_, own(coefficients), own(points), mu ? 1 : 0, mu ? mu[0] : 0.0, mu ? mu[1] : 1.0, &out));
         return with_shape(out);
     }
+    // lib.rs:1674-1710: polynomial derivative (single / product rule / quotient rule: {numerator, denominator}) and integral
+    GpuTensorHandle polyder_single(const GpuTensorHandle& polynomial) const {
+        uint64_t out = 0;
+        check(rmhip_polyder(ctx_, own(polynomial), 0, 0, &out, nullptr));
+        return with_shape(out);
+    }
+    GpuTensorHandle polyder_product(const GpuTensorHandle& p, const GpuTensorHandle& q) const {
+        uint64_t out = 0;
+        check(rmhip_polyder(ctx_, own(p), own(q), 0, &out, nullptr));
+        return with_shape(out);
+    }
+    std::pair<GpuTensorHandle, GpuTensorHandle> polyder_quotient(const GpuTensorHandle& u, const GpuTensorHandle& v) const {
+        uint64_t num = 0, den = 0;
+        check(rmhip_polyder(ctx_, own(u), own(v), 1, &num, &den));
+        return {with_shape(num), with_shape(den)};
+    }
+    GpuTensorHandle polyint(const GpuTensorHandle& polynomial, double constant) const {
+        uint64_t out = 0;
+        check(rmhip_polyint(ctx_, own(polynomial), constant, &out));
+        return with_shape(out);
+    }
     // lib.rs:1561-1564: two or three host axes -> X, Y[, Z]
     std::vector<GpuTensorHandle> meshgrid(const std::vector<std::vector<double>>& axes) const {
         if (axes.size() != 2 && axes.size() != 3) throw ProviderError(RMHIP_ERR_INVALID, "meshgrid: provider expects two or three axes");

@@ -1146,6 +1146,95 @@ def iir_filter(b, a, x, dim: int = 0, zi=None):
     return np.moveaxis(y, 0, dim).reshape(x.shape), np.moveaxis(st, 0, dim)
 
 
+def _poly_orientation(shape) -> str:
+    """poly_orientation_from_shape, runmat-accelerate/src/simple_provider.rs:320-338."""
+    kinds = ["column" if d == 0 else "row" for d, n in enumerate(shape) if n > 1]
+    if len(kinds) > 1:
+        raise ValueError("polyder: coefficient inputs must be vectors")
+    return kinds[0] if kinds else "scalar"
+
+
+def _poly_shaped(values, orientation):
+    """allocate_polynomial / poly_shape_for_len, simple_provider.rs:341-348, 763-770 -> (values, shape)."""
+    v = np.array(values, dtype=np.float64)
+    return v, ([1, 1] if v.size <= 1 else [v.size, 1] if orientation == "column" else [1, v.size])
+
+
+def _poly_load(coefficients):
+    c = np.asarray(coefficients, dtype=np.float64)
+    flat = [float(x) for x in c.ravel(order="F")]
+    return (flat if flat else [0.0]), _poly_orientation(c.shape)  # load_polynomial, simple_provider.rs:750-761
+
+
+def _poly_raw_derivative(c):
+    """simple_provider.rs:361-372."""
+    if len(c) <= 1:
+        return [0.0]
+    return [float(np.float64(c[i]) * np.float64(len(c) - 1 - i)) for i in range(len(c) - 1)]
+
+
+def _poly_trim(c):
+    """poly_trim_slice, simple_provider.rs:350-359 (POLYDER_EPS = 1e-12, :72; a NaN is not above it)."""
+    for i, v in enumerate(c):
+        if abs(v) > 1.0e-12:
+            return list(c[i:])
+    return [0.0]
+
+
+def _poly_convolve(a, b):
+    """poly_convolve_real, simple_provider.rs:544-555: result[i + j] += a[i] * b[j], i outer."""
+    r = [np.float64(0.0)] * (len(a) + len(b) - 1)
+    with np.errstate(all="ignore"):
+        for i, ai in enumerate(a):
+            for j, bj in enumerate(b):
+                r[i + j] = r[i + j] + np.float64(ai) * np.float64(bj)
+    return [float(x) for x in r]
+
+
+def _poly_combine(a, b, sign):
+    """poly_add_real / poly_sub_real, simple_provider.rs:557-579: both right-aligned and added to (subtracted from) zeros."""
+    n = max(len(a), len(b))
+    r = [np.float64(0.0)] * n
+    with np.errstate(all="ignore"):
+        for i, v in enumerate(a):
+            r[n - len(a) + i] = r[n - len(a) + i] + np.float64(v)
+        for i, v in enumerate(b):
+            r[n - len(b) + i] = r[n - len(b) + i] + np.float64(v) if sign > 0 else r[n - len(b) + i] - np.float64(v)
+    return [float(x) for x in r]
+
+
+def polyder_single(polynomial):
+    """simple_provider.rs:3137-3147 -> (values, shape)."""
+    c, o = _poly_load(polynomial)
+    return _poly_shaped(_poly_trim(_poly_raw_derivative(c)), o)
+
+
+def polyder_product(p, q):
+    """simple_provider.rs:3149-3165: p' q + p q', in p's orientation."""
+    pc, o = _poly_load(p)
+    qc, _ = _poly_load(q)
+    s = _poly_combine(_poly_convolve(_poly_raw_derivative(pc), qc), _poly_convolve(pc, _poly_raw_derivative(qc)), +1)
+    return _poly_shaped(_poly_trim(s), o)
+
+
+def polyder_quotient(u, v):
+    """simple_provider.rs:3167-3188 -> ((numerator, shape), (denominator, shape)): u' v - u v' in u's orientation, v v in v's."""
+    uc, ou = _poly_load(u)
+    vc, ov = _poly_load(v)
+    num = _poly_combine(_poly_convolve(_poly_raw_derivative(uc), vc), _poly_convolve(uc, _poly_raw_derivative(vc)), -1)
+    return _poly_shaped(_poly_trim(num), ou), _poly_shaped(_poly_trim(_poly_convolve(vc, vc)), ov)
+
+
+def polyint(polynomial, constant=0.0):
+    """poly_integral_real, simple_provider.rs:374-390, 3190-3204 -> (values, shape)."""
+    c = np.asarray(polynomial, dtype=np.float64)
+    o = _poly_orientation(c.shape)
+    flat = c.ravel(order="F")
+    with np.errstate(all="ignore"):
+        out = [float(flat[i] / np.float64(flat.size - i)) for i in range(flat.size)] + [float(constant)]
+    return _poly_shaped(out, o)
+
+
 def polyval(coefficients, points, mu=None) -> np.ndarray:
     """polyval.rs:886-905 restated on real data: the CPU evaluates acc = acc * x + c in `Complex64` (num-complex: re = a.re * b.re - a.im *
     b.im, rounded product by product), whose real part for real operands is the real recurrence with the product rounded before the sum;

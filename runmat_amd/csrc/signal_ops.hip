@@ -579,6 +579,66 @@ __global__ void __launch_bounds__(kB) k_imfilter_tile(const double* __restrict__
     }
 }
 
+// polyder / polyint (simple_provider.rs:320-390, 544-585, 3137-3215): coefficient vectors, highest power first.  One thread per coefficient
+// of the untrimmed result, the CPU's sums in the CPU's order (a convolution entry accumulates from 0.0 over the first operand's index
+// ascending; the two rule terms are right-aligned and added - or subtracted - to 0.0 in turn).  An empty polynomial is [0].
+struct PolyVec {
+    const double* x;
+    u64 n;  // as stored; the effective length is max(n, 1)
+    __device__ u64 len() const { return n ? n : 1; }
+    __device__ double at(u64 i) const { return n ? x[i] : 0.0; }
+    __device__ u64 dlen() const { return n <= 1 ? 1 : n - 1; }                                      // poly_raw_derivative
+    __device__ double dat(u64 i) const { return n <= 1 ? 0.0 : x[i] * (double)(n - 1 - i); }
+};
+
+template <bool DA, bool DB>  // entry k of conv(a or a', b or b')
+__device__ double poly_conv_entry(const PolyVec& a, const PolyVec& b, u64 k) {
+    const u64 la = DA ? a.dlen() : a.len(), lb = DB ? b.dlen() : b.len();
+    const u64 lo = k >= lb - 1 ? k - (lb - 1) : 0, hi = k < la - 1 ? k : la - 1;
+    double t = 0.0;
+    for (u64 i = lo; i <= hi; ++i) {
+        const double p = (DA ? a.dat(i) : a.at(i)) * (DB ? b.dat(k - i) : b.at(k - i));
+        t = t + p;
+    }
+    return t;
+}
+
+// mode 0: p'; 1: p'q + pq'; 2: u'v - uv' (p = u, q = v); 3: v * v (q = v); 4: the integral of p with `constant` appended
+__global__ void __launch_bounds__(kB) k_poly(PolyVec p, PolyVec q, int mode, double constant, u64 len, double* __restrict__ out) {
+    const u64 k = (u64)blockIdx.x * kB + threadIdx.x;
+    if (k >= len) return;
+    double r = 0.0;
+    if (mode == 0) {
+        r = p.dat(k);
+    } else if (mode == 3) {
+        r = poly_conv_entry<false, false>(q, q, k);
+    } else if (mode == 4) {
+        r = k < p.n ? p.x[k] / (double)(p.n - k) : constant;
+    } else {
+        const u64 l1 = p.dlen() + q.len() - 1, l2 = p.len() + q.dlen() - 1;  // poly_add_real / poly_sub_real right-align the two terms
+        if (k >= len - l1) r = r + poly_conv_entry<true, false>(p, q, k - (len - l1));
+        if (k >= len - l2) {
+            const double t2 = poly_conv_entry<false, true>(p, q, k - (len - l2));
+            r = mode == 1 ? r + t2 : r - t2;
+        }
+    }
+    out[k] = r;
+}
+
+// poly_trim_slice: the first coefficient with |c| > 1e-12 (a NaN does not count), or len if there is none
+__global__ void __launch_bounds__(kB) k_poly_first(const double* __restrict__ x, u64 len, unsigned long long* __restrict__ first) {
+    __shared__ unsigned long long best;
+    if (threadIdx.x == 0) best = len;
+    __syncthreads();
+    for (u64 i = threadIdx.x; i < len && i < best; i += kB)
+        if (fabs(x[i]) > 1.0e-12) {
+            atomicMin(&best, (unsigned long long)i);
+            break;
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) *first = best;
+}
+
 inline unsigned grid_for(u64 n) { return (unsigned)((n + kB - 1) / kB); }
 
 }  // namespace
@@ -902,6 +962,88 @@ int rmhip_polyval(rmhip_ctx* ctx, rmhip_buf coefficients, rmhip_buf points, int 
         *out = 0;
         return fail(RMHIP_ERR_UNSUPPORTED, "polyval: a non-finite intermediate value");
     }
+    return RMHIP_OK;
+}
+
+namespace {
+// poly_orientation_from_shape (simple_provider.rs:320-338): 0 scalar, 1 row, 2 column; more than one extent above 1 is not a vector
+int poly_orientation(const std::vector<size_t>& shape, int* orientation) {
+    int non_unit = 0;
+    *orientation = 0;
+    for (size_t d = 0; d < shape.size(); ++d)
+        if (shape[d] > 1) ++non_unit, *orientation = d == 0 ? 2 : 1;
+    return non_unit > 1 ? rmhip::fail(RMHIP_ERR_INVALID, "polyder: coefficient inputs must be vectors") : RMHIP_OK;
+}
+
+// allocate_polynomial / poly_shape_for_len (simple_provider.rs:341-348, 763-770) of work[first .. len), or of [0] when nothing is left
+int poly_emit(rmhip::Context* c, const double* work, rmhip::u64 first, rmhip::u64 len, int orientation, rmhip_buf* out) {
+    const rmhip::u64 kept = first < len ? len - first : 1;
+    const size_t shape[2] = {orientation == 2 && kept > 1 ? (size_t)kept : 1, orientation == 2 || kept <= 1 ? 1 : (size_t)kept};
+    rmhip::Buffer ob;
+    RMHIP_TRY(c->new_buffer(shape, 2, out, &ob));
+    if (first < len) RMHIP_HIP_CHECK(hipMemcpyAsync(ob.data(), work + first, kept * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    else RMHIP_HIP_CHECK(hipMemsetAsync(ob.data(), 0, sizeof(double), c->stream));
+    return RMHIP_OK;
+}
+
+// one untrimmed result of k_poly, trimmed and emitted
+int poly_run(rmhip::Context* c, const rmhip::PolyVec& p, const rmhip::PolyVec& q, int mode, rmhip::u64 len, int orientation, rmhip_buf* out) {
+    using namespace rmhip;
+    if (len > 0x7fffffffull * kB) return fail(RMHIP_ERR_UNSUPPORTED, "polyder: %llu coefficients", (unsigned long long)len);
+    std::shared_ptr<Allocation> work;
+    RMHIP_TRY(c->alloc_device(len + 1, &work));
+    unsigned long long* first_dev = (unsigned long long*)(work->ptr + len);
+    hipLaunchKernelGGL(k_poly, dim3(grid_for(len)), dim3(kB), 0, c->stream, p, q, mode, 0.0, len, work->ptr);
+    hipLaunchKernelGGL(k_poly_first, dim3(1), dim3(kB), 0, c->stream, work->ptr, len, first_dev);
+    c->tel.kernel_launches += 2;
+    RMHIP_HIP_CHECK(hipGetLastError());
+    unsigned long long first = 0;
+    RMHIP_HIP_CHECK(hipMemcpyAsync(&first, first_dev, sizeof(first), hipMemcpyDeviceToHost, c->stream));
+    RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));  // the result's length is part of the answer
+    return poly_emit(c, work->ptr, first, len, orientation, out);
+}
+}  // namespace
+
+int rmhip_polyder(rmhip_ctx* ctx, rmhip_buf p, rmhip_buf q_or_0, int quotient, rmhip_buf* out, rmhip_buf* denominator_or_null) {
+    CTX_OR_FAIL(ctx);
+    if (!out || (quotient && (!q_or_0 || !denominator_or_null))) return fail(RMHIP_ERR_INVALID, "polyder: null argument");
+    Buffer pb, qb;
+    RMHIP_TRY(c->get(p, &pb));
+    int op = 0, oq = 0;
+    RMHIP_TRY(poly_orientation(pb.shape, &op));
+    const PolyVec pv{pb.numel ? pb.data() : nullptr, (u64)pb.numel};
+    if (!q_or_0) return poly_run(c, pv, pv, 0, pv.n <= 1 ? 1 : pv.n - 1, op, out);
+    RMHIP_TRY(c->get(q_or_0, &qb));
+    RMHIP_TRY(poly_orientation(qb.shape, &oq));
+    const PolyVec qv{qb.numel ? qb.data() : nullptr, (u64)qb.numel};
+    const u64 lp = pv.n ? pv.n : 1, lq = qv.n ? qv.n : 1, dp = pv.n <= 1 ? 1 : pv.n - 1, dq = qv.n <= 1 ? 1 : qv.n - 1;
+    const u64 len = std::max(dp + lq - 1, lp + dq - 1);
+    RMHIP_TRY(poly_run(c, pv, qv, quotient ? 2 : 1, len, op, out));
+    if (!quotient) return RMHIP_OK;
+    const int rc = poly_run(c, pv, qv, 3, 2 * lq - 1, oq, denominator_or_null);
+    if (rc != RMHIP_OK) {
+        rmhip_free(ctx, *out);
+        *out = 0;
+    }
+    return rc;
+}
+
+int rmhip_polyint(rmhip_ctx* ctx, rmhip_buf p, double constant, rmhip_buf* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return fail(RMHIP_ERR_INVALID, "null out");
+    Buffer pb;
+    RMHIP_TRY(c->get(p, &pb));
+    int orientation = 0;
+    RMHIP_TRY(poly_orientation(pb.shape, &orientation));
+    const u64 len = (u64)pb.numel + 1;
+    if (len > 0x7fffffffull * kB) return fail(RMHIP_ERR_UNSUPPORTED, "polyint: %zu coefficients", pb.numel);
+    const size_t shape[2] = {orientation == 2 && len > 1 ? (size_t)len : 1, orientation == 2 || len <= 1 ? 1 : (size_t)len};
+    Buffer ob;
+    RMHIP_TRY(c->new_buffer(shape, 2, out, &ob));
+    const PolyVec pv{pb.numel ? pb.data() : nullptr, (u64)pb.numel};
+    hipLaunchKernelGGL(k_poly, dim3(grid_for(len)), dim3(kB), 0, c->stream, pv, pv, 4, constant, len, ob.data());
+    c->tel.kernel_launches++;
+    RMHIP_HIP_CHECK(hipGetLastError());
     return RMHIP_OK;
 }
 

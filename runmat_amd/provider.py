@@ -1200,6 +1200,30 @@ class HipProvider:
         self._check(self._lib.rmhip_polyval(self._ctx, self._id(coefficients), self._id(points), 1 if mu is not None else 0, mean, scale, C.byref(out)))
         return self._handle(out.value)
 
+    def _polyder(self, p, q, quotient: bool):
+        out, den = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.rmhip_polyder(self._ctx, self._id(p), self._id(q) if q is not None else 0, 1 if quotient else 0, C.byref(out),
+                                            C.byref(den) if quotient else None))
+        return (self._handle(out.value), self._handle(den.value)) if quotient else self._handle(out.value)
+
+    def polyder_single(self, polynomial) -> GpuTensorHandle:
+        """lib.rs:1674-1679: the derivative's coefficients, trimmed of leading zeros, in the input's orientation."""
+        return self._polyder(polynomial, None, False)
+
+    def polyder_product(self, p, q) -> GpuTensorHandle:
+        """lib.rs:1682-1688: (p q)' = p' q + p q'."""
+        return self._polyder(p, q, False)
+
+    def polyder_quotient(self, u, v) -> Tuple[GpuTensorHandle, GpuTensorHandle]:
+        """lib.rs:1691-1701 (`ProviderPolyderQuotient { numerator, denominator }`): u' v - u v' and v v."""
+        return self._polyder(u, v, True)
+
+    def polyint(self, polynomial, constant: float = 0.0) -> GpuTensorHandle:
+        """lib.rs:1704-1710."""
+        out = C.c_uint64()
+        self._check(self._lib.rmhip_polyint(self._ctx, self._id(polynomial), float(constant), C.byref(out)))
+        return self._handle(out.value)
+
     def meshgrid(self, axes: Sequence[Sequence[float]]) -> List[GpuTensorHandle]:
         """lib.rs:1561-1564: two or three HOST axes (`MeshgridAxisView`) -> `ProviderMeshgridResult.outputs` (X, Y[, Z])."""
         if len(axes) not in (2, 3):

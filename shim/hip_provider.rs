@@ -15,7 +15,7 @@
 use anyhow::{anyhow, Result};
 use runmat_accelerate_api::{
     AccelProvider, AccelProviderFuture, ApiDeviceInfo, CorrcoefNormalization, CorrcoefOptions, CorrcoefRows, CovNormalization, CovRows, CovarianceOptions, FindDirection, GpuTensorHandle, GpuTensorStorage,
-    HostLogicalOwned, HostTensorOwned, HostTensorView, IsMemberOptions, IsMemberResult, SetdiffOptions, SetdiffOrder, SetdiffResult, UnionOptions, UnionOrder, UnionResult, UniqueOccurrence, UniqueOptions, UniqueOrder, UniqueResult, ImageNormalizeDescriptor, ImfilterMode, ImfilterOptions, ImfilterPadding, ImfilterShape, KernelAttrTelemetry, MeshgridAxisView, ProviderMeshgridResult, ProviderPolyvalOptions, KernelLaunchTelemetry, MatmulEpilogue,
+    HostLogicalOwned, HostTensorOwned, HostTensorView, IsMemberOptions, IsMemberResult, SetdiffOptions, SetdiffOrder, SetdiffResult, UnionOptions, UnionOrder, UnionResult, UniqueOccurrence, UniqueOptions, UniqueOrder, UniqueResult, ImageNormalizeDescriptor, ImfilterMode, ImfilterOptions, ImfilterPadding, ImfilterShape, KernelAttrTelemetry, MeshgridAxisView, ProviderMeshgridResult, ProviderPolyderQuotient, ProviderPolyvalOptions, KernelLaunchTelemetry, MatmulEpilogue,
     PowerStepEpilogue, ProviderBandwidth, ProviderCovarianceToCorrelationResult, ProviderHilbertRequest, ProviderCondNorm, ProviderPinvOptions, ProviderIirFilterOptions, ProviderIirFilterResult, ProviderInterp1Extrapolation, ProviderInterp1Method, ProviderInterp1Request, ProviderConv1dOptions, ProviderConvMode, ProviderConvOrientation, ProviderCholResult, ProviderCummaxResult, ProviderCumminResult, ProviderDispatchStats, ProviderInvOptions, ProviderFallbackStat, ProviderFindResult, ProviderHermitianKind, ProviderLinsolveOptions,
     ProviderLinsolveResult, ProviderLuResult, ProviderMoments2, ProviderMovingWindowEndpoints, ProviderMovingWindowOp, ProviderMovingWindowRequest, ProviderNanMode, ProviderNdgridRequest, ProviderNormOrder, ProviderNdgridResult, ProviderPrecision, ProviderScanDirection,
     ProviderStdNormalization, ProviderSymmetryKind, ProviderTelemetry, ProviderTrapezoidSpacing, ReduceDimResult, ReductionFlavor, ScaleOp, SortComparison, SortOrder, SortResult, SortRowsColumnSpec,
@@ -869,6 +869,32 @@ impl AccelProvider for HipProvider {
         let mut out = 0u64;
         let (has_mu, mean, scale) = match options.mu { Some(mu) => (1, mu.mean, mu.scale), None => (0, 0.0, 1.0) };
         check(unsafe { rmhip_polyval(self.ctx, self.own(coefficients)?, self.own(points)?, has_mu, mean, scale, &mut out) })?;
+        self.handle(out)
+    }
+    fn polyder_single<'a>(&'a self, polynomial: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_polyder(self.ctx, self.own(polynomial)?, 0, 0, &mut out, std::ptr::null_mut()) })?;
+            self.handle(out)
+        })
+    }
+    fn polyder_product<'a>(&'a self, p: &'a GpuTensorHandle, q: &'a GpuTensorHandle) -> AccelProviderFuture<'a, GpuTensorHandle> {
+        Box::pin(async move {
+            let mut out = 0u64;
+            check(unsafe { rmhip_polyder(self.ctx, self.own(p)?, self.own(q)?, 0, &mut out, std::ptr::null_mut()) })?;
+            self.handle(out)
+        })
+    }
+    fn polyder_quotient<'a>(&'a self, u: &'a GpuTensorHandle, v: &'a GpuTensorHandle) -> AccelProviderFuture<'a, ProviderPolyderQuotient> {
+        Box::pin(async move {
+            let (mut num, mut den) = (0u64, 0u64);
+            check(unsafe { rmhip_polyder(self.ctx, self.own(u)?, self.own(v)?, 1, &mut num, &mut den) })?;
+            Ok(ProviderPolyderQuotient { numerator: self.handle(num)?, denominator: self.handle(den)? })
+        })
+    }
+    fn polyint(&self, polynomial: &GpuTensorHandle, constant: f64) -> Result<GpuTensorHandle> {
+        let mut out = 0u64;
+        check(unsafe { rmhip_polyint(self.ctx, self.own(polynomial)?, constant, &mut out) })?;
         self.handle(out)
     }
     fn meshgrid(&self, axes: &[MeshgridAxisView<'_>]) -> Result<ProviderMeshgridResult> {

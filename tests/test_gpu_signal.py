@@ -289,3 +289,53 @@ def test_imfilter_limits_and_baseline_size(prov, oracle):
     assert bits_equal(y[:38, :38], want[:38, :38])                                    # (the block's own lower / right padding differs from the image's interior)
     want = oracle.imfilter(x[-40:, -40:], ker, "replicate")
     assert bits_equal(y[-38:, -38:], want[-38:, -38:])
+
+
+def test_polyder_polyint(prov, oracle):
+    """lib.rs:1674-1710 against the restatement of simple_provider.rs:3137-3215 (bit-exact) and the reference's own vectors."""
+    shaped = lambda values, shape: np.array(values, dtype=np.float64).reshape(shape, order="F")
+    up = lambda x: prov.upload(np.asarray(x, dtype=np.float64).ravel(order="F"), x.shape)
+
+    def same(handle, want):
+        values, shape = want
+        assert list(handle.shape) == shape, (handle.shape, shape)
+        assert bits_equal(prov.download(handle).ravel(), values), (prov.download(handle), values)
+
+    for k in K["polyder"]:
+        p = shaped(k["p"], k["pshape"])
+        if "q" not in k:
+            got = prov.polyder_single(up(p))
+        elif k.get("quotient"):
+            got, den = prov.polyder_quotient(up(p), up(shaped(k["q"], k["qshape"])))
+            assert list(den.shape) == k["dshape"] and np.allclose(prov.download(den), k["den"], rtol=0, atol=1e-12)
+        else:
+            got = prov.polyder_product(up(p), up(shaped(k["q"], k["qshape"])))
+        assert list(got.shape) == k["oshape"] and np.allclose(prov.download(got), k["out"], rtol=0, atol=1e-12), k
+    for k in K["polyint"]:
+        got = prov.polyint(up(shaped(k["p"], k["pshape"])), k["constant"])
+        assert list(got.shape) == k["oshape"] and np.allclose(prov.download(got), k["out"], rtol=0, atol=1e-12), k
+
+    rng = np.random.default_rng(77)
+    for np_, nq in ((0, 0), (1, 1), (0, 3), (3, 0), (2, 1), (1, 4), (5, 3), (3, 9), (64, 65), (700, 300), (1, 1000)):
+        for orient in ((1, -1), (-1, 1)):
+            p, q = rng.standard_normal(np_).reshape(orient), rng.standard_normal(nq).reshape(orient[::-1])
+            if np_ > 3:
+                p.ravel()[:2] = (0.0, 1e-13)                                           # trimmed from the derivative
+            hp, hq = up(p), up(q)
+            same(prov.polyder_single(hp), oracle.polyder_single(p))
+            same(prov.polyder_product(hp, hq), oracle.polyder_product(p, q))
+            num, den = prov.polyder_quotient(hp, hq)
+            wnum, wden = oracle.polyder_quotient(p, q)
+            same(num, wnum)
+            same(den, wden)
+            same(prov.polyint(hp, -1.25), oracle.polyint(p, -1.25))
+    special = np.array([[np.nan, 0.0, np.inf, -2.0, 0.0, 1.0]])
+    same(prov.polyder_single(up(special)), oracle.polyder_single(special))
+    same(prov.polyder_product(up(special), up(special.T.copy())), oracle.polyder_product(special, special.T))
+    same(prov.polyint(up(special), np.nan), oracle.polyint(special, np.nan))
+    zeros = np.zeros((1, 5))
+    same(prov.polyder_product(up(zeros), up(zeros)), oracle.polyder_product(zeros, zeros))      # nothing left: [0], 1 x 1
+    for bad in (lambda: prov.polyder_single(up(np.ones((2, 2)))), lambda: prov.polyint(up(np.ones((2, 3))), 0.0),
+                lambda: prov.polyder_product(up(np.ones((1, 3))), up(np.ones((2, 2))))):
+        with pytest.raises(Exception):
+            bad()

@@ -160,3 +160,41 @@ def test_imfilter_against_scipy():
     vol = rng.standard_normal((4, 5, 3))
     k3 = rng.standard_normal((3, 3, 3))
     assert np.allclose(oracle.imfilter(vol, k3, "replicate"), ndimage.correlate(vol, k3, mode="nearest"), rtol=0, atol=1e-13)
+
+
+def test_polyder_polyint_reference_kats():
+    shaped = lambda values, shape: np.array(values, dtype=np.float64).reshape(shape, order="F")
+    for k in K["polyder"]:
+        p = shaped(k["p"], k["pshape"])
+        if "q" not in k:
+            got = [oracle.polyder_single(p)]
+        elif k.get("quotient"):
+            got = list(oracle.polyder_quotient(p, shaped(k["q"], k["qshape"])))
+        else:
+            got = [oracle.polyder_product(p, shaped(k["q"], k["qshape"]))]
+        assert got[0][1] == k["oshape"] and np.allclose(got[0][0], k["out"], rtol=0, atol=1e-12), k
+        if k.get("quotient"):
+            assert got[1][1] == k["dshape"] and np.allclose(got[1][0], k["den"], rtol=0, atol=1e-12), k
+    for k in K["polyint"]:
+        values, shape = oracle.polyint(shaped(k["p"], k["pshape"]), k["constant"])
+        assert shape == k["oshape"] and np.allclose(values, k["out"], rtol=0, atol=1e-12), k
+
+
+def test_polyder_polyint_against_numpy_and_edge_rules():
+    rng = np.random.default_rng(12)
+    for np_, nq in ((1, 1), (2, 1), (1, 4), (5, 3), (3, 9), (12, 12)):
+        p, q = rng.standard_normal(np_), rng.standard_normal(nq)
+        assert np.allclose(np.polyder(p) if np_ > 1 else [0.0], oracle.polyder_single(p.reshape(1, -1))[0], rtol=0, atol=1e-12)
+        want = np.polyder(np.polymul(p, q))
+        assert np.allclose(want if want.size else [0.0], oracle.polyder_product(p.reshape(1, -1), q.reshape(1, -1))[0], rtol=0, atol=1e-10)
+        (num, _), (den, _) = oracle.polyder_quotient(p.reshape(1, -1), q.reshape(-1, 1))
+        want = np.polysub(np.polymul(np.polyder(p), q), np.polymul(p, np.polyder(q)))
+        assert np.allclose(np.trim_zeros(np.where(np.abs(want) > 1e-12, want, 0.0), "f") if np.any(np.abs(want) > 1e-12) else [0.0], num, rtol=0, atol=1e-10) or np_ == 1 or nq == 1
+        assert np.allclose(np.polymul(q, q), den, rtol=0, atol=1e-10)
+        assert np.allclose(np.polyint(p, k=2.5), oracle.polyint(p.reshape(-1, 1), 2.5)[0], rtol=0, atol=1e-14)
+    assert oracle.polyder_single(np.zeros((1, 0)))[1] == [1, 1] and oracle.polyder_single(np.array([[0.0, 0.0, 1e-13, 0.0]]))[0].tolist() == [0.0]
+    assert oracle.polyder_single(np.array([[0.0, 0.0, 3.0, 1.0]]))[0].tolist() == [3.0]           # leading zeros trimmed
+    assert oracle.polyder_single(np.array([[np.nan, 2.0, 1.0]]))[0].tolist() == [2.0]             # a NaN is not above the threshold
+    assert oracle.polyint(np.zeros((0, 0)), 4.0) [0].tolist() == [4.0] and oracle.polyint(np.zeros((0, 0)), 4.0)[1] == [1, 1]
+    with pytest.raises(ValueError):
+        oracle.polyder_single(np.ones((2, 2)))
