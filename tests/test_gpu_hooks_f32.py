@@ -97,3 +97,23 @@ def test_transforms_round_once(prov, prov32):
     a = rng.standard_normal((4, 3))
     z = prov32.complex_from_real_imag(prov32.upload(a), prov32.upload(2 * a))
     assert np.array_equal(prov32.download(z), f32r(a).ravel(order="F") + 2j * f32r(a).ravel(order="F"))
+
+
+def test_filters_and_polynomials_round_once(prov, prov32):
+    rng = np.random.default_rng(5)
+    img, ker = f32r(rng.standard_normal((150, 70, 2))), f32r(rng.standard_normal((5, 4)))
+    up = lambda p, x: p.upload(x.ravel(order="F"), x.shape)
+    for padding in ("replicate", 1.5):
+        a, b = prov.imfilter(up(prov, img), up(prov, ker), padding, "full"), prov32.imfilter(up(prov32, img), up(prov32, ker), padding, "full")
+        assert list(a.shape) == list(b.shape) and same(prov32.download(b), f32r(prov.download(a)))
+    a, b = prov.conv2d(up(prov, img[:, :, 0]), up(prov, ker), "same"), prov32.conv2d(up(prov32, img[:, :, 0]), up(prov32, ker), "same")
+    assert same(prov32.download(b), f32r(prov.download(a)))
+    p, q = f32r(rng.standard_normal((1, 9))), f32r(rng.standard_normal((4, 1)))
+    p[0, 0] = 0.0
+    a, b = prov.polyder_product(up(prov, p), up(prov, q)), prov32.polyder_product(up(prov32, p), up(prov32, q))
+    assert list(a.shape) == list(b.shape) and same(prov32.download(b), f32r(prov.download(a)))
+    (an, ad), (bn, bd) = prov.polyder_quotient(up(prov, p), up(prov, q)), prov32.polyder_quotient(up(prov32, p), up(prov32, q))
+    assert list(ad.shape) == list(bd.shape) == [7, 1] and same(prov32.download(bn), f32r(prov.download(an))) and same(prov32.download(bd), f32r(prov.download(ad)))
+    a, b = prov.polyint(up(prov, p), 0.1), prov32.polyint(up(prov32, p), 0.1)
+    assert list(b.shape) == [1, 10] and same(prov32.download(b), f32r(prov.download(a)))
+    assert same(prov32.download(prov32.polyder_single(up(prov32, p))), f32r(prov.download(prov.polyder_single(up(prov, p)))))
