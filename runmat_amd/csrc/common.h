@@ -174,12 +174,16 @@ struct Context {
     unsigned* gemm_tile_counters = nullptr;  // device, zeroed by the driver; one per launch
     size_t gemm_counter_next = 0, gemm_counter_cap = 0;
     const int* gemm_avoid_xcc = nullptr;     // device word written by the panel kernel (-1: none)
+    bool gemm_chain_prio = false;  // the look-ahead LU's main-stream dgemm launches raise their wave priority (RMHIP_LU_GEMM_PRIO=0 disables)
+    const unsigned* gemm_yield_word = nullptr;  // two-level LU: the CU (key) whose update blocks pause while k_rp_top runs there (device word; 0: none)
     bool in_lookahead = false;  // inside the LU's look-ahead driver: main-stream dgemm blocks must fit beside the update stream's
     // set after a persistent-panel factorisation found its workgroups not co-resident (device shared with
     // another context): from then on LU uses the one-launch-per-column panels on a single stream
     hipStream_t lu_side_stream = nullptr;  // update stream of the look-ahead LU (low priority), created on first use
     hipStream_t lu_aux_stream = nullptr;   // solve path: the full-height kernels' rows below the band of the panel in flight (lu.hip, LuState::aux)
     hipStream_t lu_prep_stream = nullptr;  // interchanges + triangular solves of one half of the trailing columns under the other half's dgemm
+    hipStream_t lu_far_stream = nullptr;   // two-level driver (solve path): the deep rank-W updates of the columns beyond the next super-panel
+    hipStream_t lu_mid_stream = nullptr;   // two-level driver: the updates inside the super-panel in flight (normal priority)
     std::vector<hipEvent_t> lu_events;     // its event pool
     bool lu_conservative = false;
     bool subst_chain_failed = false;  // the one-launch substitution timed out once: keep the launch-per-block form

@@ -78,6 +78,10 @@ struct GemmArgs {
     // k_dgemm_w8p (persistent form): tile counter (zero before the launch) and the XCD to stay away from (may be null / -1)
     unsigned* tile_counter;
     const int* avoid_xcc;
+    // eight-wave tile on the LU's update streams: a device word naming the CU (key: bit 31 | XCC id << 8 | HW_ID cu/sh/se byte) on which
+    // k_rp_top is running right now; a block on that CU pauses until the word changes (nullptr: no check)
+    const unsigned* yield_word;
+    int prio;  // nonzero: raise the wave priority (s_setprio 3) - the LU's main-stream updates, which share SIMDs with the update streams' blocks
 };
 
 // MatmulEpilogue on one output element, order of crates/runmat-accelerate/src/simple_provider.rs:7800-7836
@@ -138,6 +142,7 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs& g, unsigned& tm, u
 template <bool EDGE, bool EPI, bool TA, bool TB, bool PRE = false>
 __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (g.prio) __builtin_amdgcn_s_setprio(3);
     double* As = lds;                    // [2][A_TILE]
     double* Bs = lds + 2 * A_TILE;       // [2][B_TILE]   (A_TILE == B_TILE)
 
@@ -435,6 +440,7 @@ static constexpr int S_B_TILE = SN * SB;     // 1152 doubles
 // 1000^3 on the guarded 128 x 128 kernel: 173 us (64 blocks, every element checked); 1024^3 here: 65 us.
 template <bool PRE, bool GUARD = false>  // PRE: C <- C - A*B with the C tile preloaded into the accumulators (see k_dgemm)
 __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
+    if (g.prio) __builtin_amdgcn_s_setprio(3);
     __shared__ __attribute__((aligned(16))) double As[2][S_A_TILE];
     __shared__ __attribute__((aligned(16))) double Bs[2][S_B_TILE];
     const unsigned tm = blockIdx.x % g.tiles_m, tn = blockIdx.x / g.tiles_m;  // column-major tile order: neighbours share B
@@ -691,7 +697,23 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
         fetch(clampt(1));
         double af0[4], bf0[2], af1[4], bf1[2];
         frags(As + a_off, Bs + b_off, 0, af0, bf0);
+        // cooperative yield (GemmArgs::yield_word): the word read during the previous k tile names the CU on which the LU's k_rp_top is
+        // running; if that is this CU, sleep until it changes (bounded: ~2 ms)
+        unsigned my_cu = 0, yv = 0;
+        if (g.yield_word) {
+            unsigned xcc, hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            my_cu = 0x80000000u | ((xcc & 0xfu) << 8) | ((hw >> 8) & 0xffu);
+        }
         for (unsigned kt = 0; kt < ktiles; ++kt) {
+            if (g.yield_word) {
+                if (__builtin_amdgcn_readfirstlane(yv) == my_cu) {
+                    for (int spin = 0; spin < 4096 && __hip_atomic_load(g.yield_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_cu; ++spin)
+                        __builtin_amdgcn_s_sleep(16);
+                }
+                yv = __hip_atomic_load(g.yield_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             const int cur = kt & 1;
             const double* a = As + cur * A_TILE + a_off;
             const double* b = Bs + cur * B_TILE + b_off;
@@ -939,6 +961,8 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
     g.c_split_stride = 0;
     g.tile_counter = nullptr;
     g.avoid_xcc = nullptr;
+    g.yield_word = (c->gemm_lds_pad != 0) ? c->gemm_yield_word : nullptr;  // update streams of the two-level LU only
+    g.prio = (c->in_lookahead && c->gemm_lds_pad == 0 && c->gemm_chain_prio) ? 1 : 0;  // the look-ahead LU's main stream
     std::shared_ptr<Allocation> partials;
     // (round 3: from k = 1024 - slices of multiples of 128 - outside the LU.  A block walks its k range at about 1 us per 16 columns
     // - one memory latency per tile with nothing else resident - so few blocks with a long k are latency bound whatever the tile:

@@ -26,6 +26,13 @@ namespace rmhip {
 // instruction they wait to issue is on the critical path.  Set once per process (lu_factor_device); RMHIP_LU_CHAIN_PRIO=0 turns it
 // off.  Measured at n = 16384: 74.0-74.1 ms with, 74.6-75.2 without; with the panel block sharing its CU (no LDS padding) 75.1
 // against 77.4 - the priority recovers most of what sharing costs, a CU of its own is still better.
+// (XCC id, HW_ID cu / sh / se byte) of the CU this wave runs on, bit 31 set: never 0
+__device__ __forceinline__ unsigned cu_key() {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    return 0x80000000u | ((xcc & 0xfu) << 8) | ((hw >> 8) & 0xffu);
+}
 __device__ int d_chain_prio = 0;
 __device__ __forceinline__ void chain_prio() {
     if (d_chain_prio) __builtin_amdgcn_s_setprio(3);
@@ -73,8 +80,12 @@ struct LuState {
     size_t ev_used = 0;                   // events drawn from the context's pool by this factorisation
     unsigned ucomp_slot = 0;              // ring of compact U copies: k_rp_below on `aux` may still read panel p's while k_rp_top writes p + 1's
     hipEvent_t aux_tail = nullptr;        // last event recorded on aux (what the main stream's next look-ahead update has to wait for)
+    unsigned* yield_word = nullptr;       // two-level driver: device word through which k_rp_top asks the update blocks on its CU to pause
 };
 static constexpr unsigned kUcompSlots = 16;  // >= base panels per look-ahead panel (512 / 64) with room to spare
+// one slot: the 64 x 64 compact U of k_rp_top, then the inverses of its four 16 x 16 diagonal blocks (row-major [k][i], zero below the
+// diagonal) for k_rp_below_mfma
+static constexpr size_t UCOMP_STRIDE = (size_t)BASE_W * BASE_W + 4 * 256;
 
 static hipEvent_t lu_new_event(LuState& s) {
     Context* c = s.c;
@@ -893,6 +904,8 @@ struct RtArgs {
     int2* plist;    // this panel's row-move list (PLIST entries, the layout k_lu_panel2 writes)
     double* ucomp;  // [BASE_W][BASE_W] compact copy of the pivot rows for k_rp_below: ucomp[k * BASE_W + c] = U[k][c], 1 / u_kk on the diagonal
     int* xcc_out;   // receives the XCD this workgroup runs on (read by the update stream's persistent kernels), or nullptr
+    int uinv_on;    // also leave the inverses of U11's 16 x 16 diagonal blocks behind the compact copy (k_rp_below_mfma)
+    unsigned* yield_word;  // two-level driver: receives this workgroup's CU key while it runs, 0 when it is done (update blocks on that CU pause), or nullptr
 };
 struct RtLds {
     unsigned* wmax; // [2][4] every wave's best key (high word of |a|, low byte = 255 - thread), by step parity
@@ -1018,6 +1031,11 @@ __global__ void __launch_bounds__(RT_ROWS) k_rp_top(const RtArgs g, pk_u64* dbg)
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         *g.xcc_out = (int)(xcc & 0xf);
     }
+    // Cooperative yield (two-level driver).  This workgroup's fp64 FMAs queue behind the matrix-core instructions of any dgemm wave on
+    // the same SIMD - 57-63 us for a 64-column top block on a CU of its own, 120-250 us beside a block of the deep update (rocprofv3
+    // timeline, round 5) - and it is a quarter of the critical chain.  It names its CU in a device word; the update streams' eight-wave
+    // blocks read that word once per k tile and the one that finds its own CU there sleeps until the word changes (dgemm.hip, w8_tile).
+    if (t == 0 && g.yield_word) __hip_atomic_store(g.yield_word, cu_key(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const size_t r = (size_t)g.j0 + t;
     const bool in_rows = r < g.rows;
     int pos = in_rows ? (int)r : -1, retk = -1, rpiv = 0;
@@ -1103,6 +1121,115 @@ __global__ void __launch_bounds__(RT_ROWS) k_rp_top(const RtArgs g, pk_u64* dbg)
         g.plist[BASE_W + t] = e;
         if (t >= g.w) g.plist[t] = make_int2(-1, -1);
     }
+    if (g.w == BASE_W && g.uinv_on) {
+        // Inverses of U11's four 16 x 16 diagonal blocks for k_rp_below_mfma (the rows below then need matrix-core products only).
+        // Thread (b, i) solves U_bb x = e_i by back substitution - every index static, x[m] = 0 beyond i - and writes column i.
+        __syncthreads();  // the pivot rows' stores to ucomp (other threads of this workgroup) are visible
+        if (t < 64) {
+            const int b = t >> 4, i = t & 15;
+            const double* ub = g.ucomp + (size_t)(16 * b) * BASE_W + 16 * b;  // ub[k * BASE_W + m] = U_bb[k][m], 1 / u_kk on the diagonal
+            double x[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) x[m] = (m == i) ? ub[m * BASE_W + m] : 0.0;
+#pragma unroll
+            for (int k = 14; k >= 0; --k) {
+                double sum = 0.0;
+#pragma unroll
+                for (int m = k + 1; m < 16; ++m) sum = __builtin_fma(ub[k * BASE_W + m], x[m], sum);
+                if (k < i) x[k] = -sum * ub[k * BASE_W + k];
+            }
+            double* dst = g.ucomp + (size_t)BASE_W * BASE_W + 256 * b + i;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dst[16 * k] = x[k];
+        }
+    }
+    if (g.yield_word) {
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(g.yield_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Rows below the top block on the matrix cores (round 5).  Beside an update block every fp64 VALU instruction of a chain kernel waits
+// for the matrix-core instruction in flight on its SIMD - the two share the fp64 datapath (scripts/micro/chain_contention.hip: 2048
+// dependent FMAs 12.8 us alone, 113 us beside MFMA waves even at wave priority 3, integer work unaffected) - so what a chain kernel
+// pays for is its NUMBER of fp64 instructions: 2080 v_fma_f64 per row-wave in k_rp_below, 60-130 us in the solve against 20 alone.
+// Here l = a U11^-1 is a blocked substitution over U11's 16 x 16 blocks with the diagonal blocks inverted (by k_rp_top, above):
+//   for b = 0..3:  X_b = A_b inv(U_bb);   for c > b:  A_c -= X_b U_bc
+// 80 v_mfma_f64_16x16x4 per 32-row wave and nothing else in fp64.  Roles are transposed (D[i][j]: i = panel column, j = matrix row) so
+// that the accumulator layout of one product (register r of lane (lq, l15) = column 4 r + lq, row l15) IS the B operand of the next
+// (k = 4 s + lq at step s = r): no shuffles, no LDS round trip, the A operands (inverses and negated U blocks, row-major [k][i]) come
+// from LDS with conflict-free 64-lane reads.  Rounding differs from the substitution's (products with an inverted block: error
+// ~ cond(U_bb) eps per block instead of eps per step); the multiplier bound is checked exactly as before.
+static constexpr int RBM_JT = 2;  // 16-row tiles per wave (32 rows: 64 accumulator registers - the wave must fit beside an update block's two waves per SIMD)
+__global__ void __launch_bounds__(64) k_rp_below_mfma(double* __restrict__ A, const size_t lda, const size_t rows, const size_t r0, const int j0,
+                                                      const double* __restrict__ ut, pk_u64* __restrict__ growth) {
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) double Ub[10 * 256];  // block id(b, c), b <= c: diagonal = inv(U_bb), off-diagonal = -U_bc; [k][i] row-major
+    const int t = threadIdx.x, l15 = t & 15, lq = t >> 4;
+    chain_prio();
+    {
+        constexpr int BB[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, CC[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+#pragma unroll
+        for (int e0 = 0; e0 < 40; e0 += 8) {  // eight loads in flight, then their LDS writes
+            double stage[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = e0 + q, blk = e >> 2, within = (e & 3) * 64 + t, kk = within >> 4, ii = within & 15;
+                stage[q] = BB[blk] == CC[blk] ? ut[BASE_W * BASE_W + 256 * BB[blk] + within] : -ut[(16 * BB[blk] + kk) * BASE_W + 16 * CC[blk] + ii];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) Ub[(e0 + q) * 64 + t] = stage[q];
+        }
+    }
+    const size_t rbase = r0 + (size_t)blockIdx.x * (16 * RBM_JT);
+    v4d acc[4][RBM_JT];  // acc[b][jt][r] = A[rbase + 16 jt + l15][j0 + 16 b + 4 r + lq]
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int jt = 0; jt < RBM_JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t row = rbase + 16 * jt + l15;
+                acc[b][jt][r] = row < rows ? A[row + (size_t)(j0 + 16 * b + 4 * r + lq) * lda] : 0.0;
+            }
+    lds_barrier();
+    pk_u64 mx = 0;
+    constexpr int DIAG[4] = {0, 4, 7, 9};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        double aop[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) aop[s4] = Ub[DIAG[b] * 256 + (4 * s4 + lq) * 16 + l15];
+        v4d x[RBM_JT];
+#pragma unroll
+        for (int jt = 0; jt < RBM_JT; ++jt) {
+            x[jt] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) x[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[s4], acc[b][jt][s4], x[jt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = b + 1; c < 4; ++c) {
+            double uop[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) uop[s4] = Ub[(DIAG[b] + (c - b)) * 256 + (4 * s4 + lq) * 16 + l15];
+#pragma unroll
+            for (int jt = 0; jt < RBM_JT; ++jt)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) acc[c][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(uop[s4], x[jt][s4], acc[c][jt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int jt = 0; jt < RBM_JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t row = rbase + 16 * jt + l15;
+                const double v = x[jt][r];
+                if (row < rows) A[row + (size_t)(j0 + 16 * b + 4 * r + lq) * lda] = v;
+                const pk_u64 bits = (pk_u64)__double_as_longlong(v) & 0x7fffffffffffffffull;  // |v| as an integer: a NaN sorts above every number
+                mx = bits > mx ? bits : mx;
+            }
+    }
+    mx = wave_max_u64(mx);
+    if (t == 0 && mx != 0) atomicMax(growth, mx > 0x7ff0000000000000ull ? 0x7ff8000000000000ull : mx);
 }
 
 // Rows below the top block: l = a U11^-1, one thread per row, U (transposed, as k_rp_top left it) staged in LDS.  One wave per
@@ -1772,9 +1899,13 @@ static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller =
             g.ipiv = s.ipiv;
             g.info = s.info;
             g.plist = s.plist + pid * PLIST;
-            double* const ucomp = s.ucomp + (size_t)(s.ucomp_slot++ % kUcompSlots) * BASE_W * BASE_W;
+            double* const ucomp = s.ucomp + (size_t)(s.ucomp_slot++ % kUcompSlots) * UCOMP_STRIDE;
             g.ucomp = ucomp;
             g.xcc_out = s.panel_xcc;
+            g.yield_word = s.yield_word;
+            static const int rb_mfma = std::getenv("RMHIP_LU_RB_MFMA") ? std::atoi(std::getenv("RMHIP_LU_RB_MFMA")) : 1;
+            const bool below_mfma = rb_mfma && w == (size_t)BASE_W && !s.xdbg;
+            g.uinv_on = below_mfma ? 1 : 0;
             // like k_lu_panel2 the block ASKS for more LDS than it uses (48.6 KiB static) so that it does not share its CU with an
             // update-stream dgemm block: every column step would run slower beside one (RMHIP_LU_PANEL_PAD_KB; the phase-dependent
             // values of getrf_blocked apply)
@@ -1800,6 +1931,12 @@ static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller =
                            : (rbt == 256 ? k_rp_below<256, false> : (rbt == 128 ? k_rp_below<128, false> : k_rp_below<64, false>));
                 auto below = [&](hipStream_t st, size_t r0, size_t r1) {  // rows [r0, r1)
                     if (r1 <= r0) return;
+                    if (below_mfma) {
+                        hipLaunchKernelGGL(k_rp_below_mfma, dim3((unsigned)((r1 - r0 + 16 * RBM_JT - 1) / (16 * RBM_JT))), dim3(64), 0, st, s.A, s.lda, r1, r0, (int)j0,
+                                           (const double*)ucomp, (pk_u64*)s.growth);
+                        s.c->tel.kernel_launches++;
+                        return;
+                    }
                     hipLaunchKernelGGL(kern, dim3((unsigned)((r1 - r0 + rbt - 1) / rbt)), dim3((unsigned)rbt), 0, st, s.A, s.lda, r1, r0, (int)j0, (int)w,
                                        (const double*)ucomp, (pk_u64*)s.growth, s.tau, (pk_u64*)s.xdbg);
                     s.c->tel.kernel_launches++;
@@ -2280,6 +2417,234 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     return rc;
 }
 
+// ---- two-level blocked driver (solve path, round 5) --------------------------------------------------------------------------
+// The one-level driver above applies every panel of nb <= 512 columns to the WHOLE trailing matrix at once: 120 in-place rank-k
+// updates that read and write all of C for 128..512 steps of k each - the C tile's load and store, the first operand tiles and a
+// k loop whose operands are touched once cost a third of the matrix pipe's time (50 TFLOP/s at k = 512, 34 at k = 128 against 72
+// for a deep product; profiles/r04_lu_attribution.txt).  Here the columns are grouped into SUPER-PANELS of W columns (2048 while the
+// trailing matrix is large).  Inside a super-panel the panels of nb columns are factored with look-ahead exactly as above, but their
+// updates stop at the super-panel's right edge; the columns beyond it receive the whole super-panel at once - one interchange pass,
+// one W-wide triangular solve, ONE rank-W update (k = W: the C traffic of 2048 / nb updates paid once) - on a third stream:
+//   main:  P_j -> LA_j (next panel's columns; at a super-panel boundary: the rank-W update of the next super-panel's first panel)
+//   mid:   the other columns of the super-panel in flight (rank-nb; at a boundary: rank-W of the next super-panel's other columns)
+//          and the interchanges of the super-panel's own left columns (L21 of the super-panel is final when it completes)
+//   far:   at a boundary, everything right of the next super-panel: interchange + W-wide solve + rank-W update, the columns of the
+//          super-panel after next first (event), then the rest; last the interchanges of the columns left of the super-panel
+// A super-panel of ONE panel is the one-level scheme (far = the update stream above), which is what the plan ends with once the
+// panel chain is the critical path.  Same kernels, same per-element operation order inside a panel; the trailing updates sum in
+// super-panel-sized groups (results agree with the one-level driver to rounding, pivots are identical).
+struct SuperPanel {
+    size_t s0, s1, nb;
+};
+
+static std::vector<std::pair<size_t, size_t>> parse_super_seq(const char* v) {
+    std::vector<std::pair<size_t, size_t>> out;  // (W, nb)
+    while (v && *v) {
+        char* end = nullptr;
+        const size_t W = (size_t)std::strtoull(v, &end, 10);
+        size_t nb = W;
+        if (end && *end == ':') nb = (size_t)std::strtoull(end + 1, &end, 10);
+        if (W >= 64) out.emplace_back((W / 64) * 64, nb < 64 ? 64 : (nb / 64) * 64);
+        v = end;
+        while (v && (*v == ',' || *v == '/' || *v == ' ')) ++v;
+        if (!end) break;
+    }
+    return out;
+}
+
+static int getrf_super(LuState& s, size_t kmin) {
+    Context* c = s.c;
+    hipStream_t main_stream = c->stream;
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    if (!c->lu_mid_stream) RMHIP_HIP_CHECK(hipStreamCreateWithPriority(&c->lu_mid_stream, hipStreamNonBlocking, (prio_low + prio_high) / 2));
+    if (!c->lu_far_stream) RMHIP_HIP_CHECK(hipStreamCreateWithPriority(&c->lu_far_stream, hipStreamNonBlocking, prio_low));
+    hipStream_t mid = c->lu_mid_stream, far = c->lu_far_stream;
+    std::shared_ptr<Allocation> yield_ctl;  // the yield word (outlives the guard below)
+    struct Restore {
+        Context* c;
+        LuState* s;
+        int trsm_base;
+        bool clear_yield = false;
+        ~Restore() {
+            if (c->lu_aux_stream) (void)hipStreamSynchronize(c->lu_aux_stream);
+            s->aux = nullptr;
+            s->band_end = 0;
+            s->yield_word = nullptr;
+            c->gemm_chain_prio = false;
+            if (c->lu_mid_stream) (void)hipStreamSynchronize(c->lu_mid_stream);
+            if (c->lu_far_stream) (void)hipStreamSynchronize(c->lu_far_stream);
+            c->gemm_yield_word = nullptr;
+            s->panel_pad_kb = -1;
+            c->in_lookahead = false;
+            c->trsm_base = trsm_base;
+        }
+    } restore{c, &s, c->trsm_base};
+    if (const char* v = std::getenv("RMHIP_LU_LA_TRSM")) c->trsm_base = std::atoi(v) == 64 ? 64 : 128;
+    c->in_lookahead = true;
+    static const int gemm_prio_on = std::getenv("RMHIP_LU_GEMM_PRIO") ? std::atoi(std::getenv("RMHIP_LU_GEMM_PRIO")) : 1;
+    c->gemm_chain_prio = gemm_prio_on != 0;
+    // ---- the plan: super-panels (W, nb) while more than super_rows rows remain, single panels afterwards
+    static const std::vector<std::pair<size_t, size_t>> seq = [] {
+        auto q = parse_super_seq(std::getenv("RMHIP_LU_SUPER_SEQ"));
+        if (q.empty()) q = {{512, 512}, {1024, 512}, {2048, 512}};
+        return q;
+    }();
+    static const std::pair<size_t, size_t> late = [] {
+        auto q = parse_super_seq(std::getenv("RMHIP_LU_SUPER_LATE"));
+        return q.empty() ? std::pair<size_t, size_t>{128, 128} : q[0];
+    }();
+    static const size_t super_rows = std::getenv("RMHIP_LU_SUPER_ROWS") ? (size_t)std::atoll(std::getenv("RMHIP_LU_SUPER_ROWS")) : 6144;
+    std::vector<SuperPanel> plan;
+    for (size_t s0 = 0, i = 0; s0 < kmin;) {
+        const size_t rem = kmin - s0;
+        std::pair<size_t, size_t> e = late;
+        if (rem > super_rows) {
+            e = seq[i < seq.size() ? i : seq.size() - 1];
+            ++i;
+            if (e.first > rem - super_rows && rem - super_rows >= e.second) e.first = ((rem - super_rows + e.second - 1) / e.second) * e.second;  // do not overshoot the switch point by much
+        }
+        const size_t s1 = s0 + e.first < kmin ? s0 + e.first : kmin;
+        plan.push_back({s0, s1, e.second < e.first ? e.second : e.first});
+        s0 = s1;
+    }
+    // LDS asked for by the update streams' dgemm blocks (see getrf_blocked: 84 KiB = one eight-wave block per CU with room beside it)
+    const size_t pad_default = 84 * 1024 - 73728;
+    static const long mid_pad_env = std::getenv("RMHIP_LU_MID_PAD") ? std::atol(std::getenv("RMHIP_LU_MID_PAD")) : -1;
+    static const long far_pad_env = std::getenv("RMHIP_LU_FAR_PAD") ? std::atol(std::getenv("RMHIP_LU_FAR_PAD")) : -1;
+    static const long super_panel_pad = std::getenv("RMHIP_LU_SUPER_PANEL_PAD_KB") ? std::atol(std::getenv("RMHIP_LU_SUPER_PANEL_PAD_KB")) : 0;
+    const size_t mid_pad = mid_pad_env >= 0 ? (size_t)mid_pad_env : pad_default;
+    const size_t far_pad = far_pad_env >= 0 ? (size_t)far_pad_env : pad_default;
+    // band split (getrf_rec): the panel chain on the main stream touches only the rows the following top blocks of the panel live in; the
+    // rows below get their multipliers and in-panel updates on a stream of their own and rejoin at the end of the panel
+    static const int band_on = std::getenv("RMHIP_LU_SUPER_BAND") ? std::atoi(std::getenv("RMHIP_LU_SUPER_BAND")) : 0;
+    static const long band_extra = std::getenv("RMHIP_LU_BAND_ROWS") ? std::atol(std::getenv("RMHIP_LU_BAND_ROWS")) : 320;
+    static const size_t band_min_rows = std::getenv("RMHIP_LU_BAND_MIN_ROWS") ? (size_t)std::atoll(std::getenv("RMHIP_LU_BAND_MIN_ROWS")) : 2048;
+    if (band_on) {
+        if (!c->lu_aux_stream) RMHIP_HIP_CHECK(hipStreamCreateWithFlags(&c->lu_aux_stream, hipStreamNonBlocking));
+        s.aux = c->lu_aux_stream;
+    }
+    // cooperative yield of the update blocks on k_rp_top's CU (RMHIP_LU_YIELD=0 disables)
+    static const int yield_on = std::getenv("RMHIP_LU_YIELD") ? std::atoi(std::getenv("RMHIP_LU_YIELD")) : 1;
+    static const long top_pad_env = std::getenv("RMHIP_LU_TOP_PAD_KB") ? std::atol(std::getenv("RMHIP_LU_TOP_PAD_KB")) : (yield_on ? 0 : -1);
+    if (yield_on) {
+        RMHIP_TRY(c->alloc_device(2, &yield_ctl));
+        RMHIP_HIP_CHECK(hipMemsetAsync(yield_ctl->ptr, 0, 16, main_stream));
+        s.yield_word = (unsigned*)yield_ctl->ptr;
+        c->gemm_yield_word = s.yield_word;
+        restore.clear_yield = true;
+    }
+    auto new_event = [&]() { return lu_new_event(s); };
+    auto record = [&](hipStream_t st) {
+        hipEvent_t e = new_event();
+        (void)hipEventRecord(e, st);
+        return e;
+    };
+    {
+        hipEvent_t e0 = record(main_stream);  // the update streams start after whatever main already has queued (the copy of A)
+        (void)hipStreamWaitEvent(mid, e0, 0);
+        (void)hipStreamWaitEvent(far, e0, 0);
+        if (s.aux) (void)hipStreamWaitEvent(s.aux, e0, 0);
+    }
+    hipEvent_t ev_mid = nullptr;       // everything the mid stream was given so far
+    hipEvent_t ev_far_next = nullptr;  // far finished the columns of the super-panel after the one in flight
+    hipEvent_t ev_far_all = nullptr;
+    int rc = RMHIP_OK;
+    for (size_t J = 0; J < plan.size() && rc == RMHIP_OK; ++J) {
+        const size_t S0 = plan[J].s0, S1 = plan[J].s1, nbJ = plan[J].nb, W = S1 - S0;
+        const size_t S1n = J + 1 < plan.size() ? plan[J + 1].s1 : S1;
+        const size_t S1nn = J + 2 < plan.size() ? plan[J + 2].s1 : S1n;
+        const bool multi = W > nbJ;
+        s.panel_pad_kb = top_pad_env >= 0 ? top_pad_env : ((kmin - S0 > super_rows) ? super_panel_pad : -1);
+        for (size_t j = S0; j < S1 && rc == RMHIP_OK;) {
+            const size_t w = (S1 - j) < nbJ ? (S1 - j) : nbJ;
+            if (s.aux) {
+                const size_t be = j + w + (size_t)band_extra;
+                s.band_end = (be < s.rows && kmin - j > band_min_rows) ? be : 0;  // nothing below the band: no split
+                s.aux_tail = nullptr;
+            }
+            rc = getrf_rec(s, j, w);  // P_j on main (rows below the band: on aux)
+            if (rc != RMHIP_OK) break;
+            if (s.aux && s.aux_tail) (void)hipStreamWaitEvent(main_stream, s.aux_tail, 0);  // L21 of the panel is complete when both are
+            hipEvent_t panel_done = record(main_stream);
+            const size_t next = j + w;
+            const bool boundary = next == S1;
+            size_t la_w = 0;
+            if (next < kmin) {
+                if (!boundary) la_w = (S1 - next) < nbJ ? (S1 - next) : nbJ;
+                else la_w = (plan[J + 1].s1 - next) < plan[J + 1].nb ? (plan[J + 1].s1 - next) : plan[J + 1].nb;
+            }
+            const size_t t0 = next + la_w;
+            if (!boundary) {
+                if (ev_mid) (void)hipStreamWaitEvent(main_stream, ev_mid, 0);
+                rc = update_columns(s, j, w, next, t0);  // LA_j on main
+                if (rc != RMHIP_OK) break;
+                (void)hipStreamWaitEvent(mid, panel_done, 0);
+                {
+                    StreamScope scope(c, mid, mid_pad);
+                    rc = update_columns(s, j, w, t0, S1);
+                    if (rc == RMHIP_OK && j > S0) rc = laswp(s, S0, j, j, j + w);  // the super-panel's own left columns
+                }
+                ev_mid = record(mid);
+            } else {
+                // the super-panel is complete: its last panel's interchanges reach its left columns first - everything below reads L21
+                // of the whole super-panel
+                hipEvent_t ev_left = panel_done;
+                if (multi && j > S0) {
+                    (void)hipStreamWaitEvent(mid, panel_done, 0);
+                    {
+                        StreamScope scope(c, mid, mid_pad);
+                        rc = laswp(s, S0, j, j, j + w);
+                    }
+                    if (rc != RMHIP_OK) break;
+                    ev_left = record(mid);
+                    ev_mid = ev_left;
+                }
+                if (la_w) {
+                    if (ev_mid) (void)hipStreamWaitEvent(main_stream, ev_mid, 0);
+                    if (ev_far_next) (void)hipStreamWaitEvent(main_stream, ev_far_next, 0);
+                    rc = update_columns(s, S0, W, next, t0);  // rank-W look-ahead update on main
+                    if (rc != RMHIP_OK) break;
+                }
+                if (t0 < S1n) {
+                    (void)hipStreamWaitEvent(mid, panel_done, 0);
+                    if (ev_far_next) (void)hipStreamWaitEvent(mid, ev_far_next, 0);
+                    {
+                        StreamScope scope(c, mid, mid_pad);
+                        rc = update_columns(s, S0, W, t0, S1n);
+                    }
+                    if (rc != RMHIP_OK) break;
+                    ev_mid = record(mid);
+                }
+                (void)hipStreamWaitEvent(far, ev_left, 0);
+                {
+                    StreamScope scope(c, far, far_pad);
+                    ev_far_next = nullptr;
+                    if (S1n < s.cols) {
+                        rc = prep_columns(s, S0, W, S1n, s.cols);
+                        const size_t cn = S1nn < s.cols ? S1nn : s.cols;
+                        if (rc == RMHIP_OK && cn > S1n) {
+                            rc = gemm_columns(s, S0, W, S1n, cn);
+                            ev_far_next = record(far);
+                        }
+                        if (rc == RMHIP_OK) rc = gemm_columns(s, S0, W, cn, s.cols);
+                    }
+                    if (rc == RMHIP_OK && S0 > 0) rc = laswp(s, 0, S0, S0, S1);  // columns left of the super-panel: all of its interchanges at once
+                }
+                ev_far_all = record(far);
+            }
+            j = next;
+        }
+    }
+    s.panel_pad_kb = -1;
+    if (ev_far_all) (void)hipStreamWaitEvent(main_stream, ev_far_all, 0);
+    if (ev_mid) (void)hipStreamWaitEvent(main_stream, ev_mid, 0);
+    (void)hipStreamSynchronize(mid);
+    (void)hipStreamSynchronize(far);
+    (void)hipStreamSynchronize(main_stream);
+    return rc;
+}
+
 // In-place LU of A (rows x cols, lda). perm_dev[rows] receives the row permutation as the
 // reference reports it (perm[k] = original row now at position k, host_lu.rs:50,107).
 // *info_host = number of pivots that hit the singular cut-off.
@@ -2314,7 +2679,7 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     const size_t off_xb = off_xa + sizeof(unsigned long long) * 2 * PK_MAXB;
     const size_t off_xctl = off_xb + sizeof(unsigned long long) * 2 * PK_MAXB;
     const size_t off_ucomp = off_xctl + 64 + 16 * sizeof(unsigned long long);
-    const size_t total = off_ucomp + sizeof(double) * BASE_W * BASE_W * kUcompSlots;
+    const size_t total = off_ucomp + sizeof(double) * UCOMP_STRIDE * kUcompSlots;
     std::shared_ptr<Allocation> blk_mem;  // pooled: a hipMalloc / hipFree pair costs two device synchronisations per factorisation
     RMHIP_TRY(c->alloc_device(total / sizeof(double) + 2, &blk_mem));
     char* blk = (char*)blk_mem->ptr;
@@ -2367,7 +2732,11 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     // (~55 us) and the bounded spins absorb that.  128-row blocks (66 KiB) fit BESIDE a dgemm block and start at
     // once, but twice as many blocks make every exchange slower: measured 145.8 ms against 129.0 ms at n = 16384
     // (RMHIP_LU_PANEL_ROWS=128 selects them).
-    int rc = blocked ? getrf_blocked(s, kmin, nb) : getrf_rec(s, 0, kmin);
+    // two-level driver (super-panels) on the solve path from kmin = 8192 (RMHIP_LU_SUPER=0: the one-level driver; RMHIP_LU_SUPER_MIN)
+    static const int super_on = std::getenv("RMHIP_LU_SUPER") ? std::atoi(std::getenv("RMHIP_LU_SUPER")) : 1;
+    static const size_t super_min = std::getenv("RMHIP_LU_SUPER_MIN") ? (size_t)std::atoll(std::getenv("RMHIP_LU_SUPER_MIN")) : 8192;
+    const bool super = blocked && s.fast && super_on && kmin >= super_min;
+    int rc = super ? getrf_super(s, kmin) : (blocked ? getrf_blocked(s, kmin, nb) : getrf_rec(s, 0, kmin));
     if (rc == RMHIP_OK && cols > rows && !blocked) {  // wide: finish U's right block (the blocked driver covers it)
         rc = laswp(s, rows, cols, 0, rows);
         if (rc == RMHIP_OK) rc = trsm_lower_rec(c, A, lda, rows, A + rows * lda, lda, cols - rows);

@@ -434,6 +434,8 @@ int rmhip_shutdown(rmhip_ctx* ctx) {
     if (c->lu_side_stream) (void)hipStreamDestroy(c->lu_side_stream);
     if (c->lu_prep_stream) (void)hipStreamDestroy(c->lu_prep_stream);
     if (c->lu_aux_stream) (void)hipStreamDestroy(c->lu_aux_stream);
+    if (c->lu_far_stream) (void)hipStreamDestroy(c->lu_far_stream);
+    if (c->lu_mid_stream) (void)hipStreamDestroy(c->lu_mid_stream);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
