@@ -22,6 +22,9 @@
 #include <thread>
 
 #include "common.h"
+#include <memory>
+#include <mutex>
+#include <condition_variable>
 
 namespace rmhip {
 
@@ -368,7 +371,55 @@ int rmhip_comm_init(rmhip_ctx* ctx, const void* unique_id, int rank, int world) 
         const hipError_t stale = hipGetLastError();
         if (stale != hipSuccess) RMHIP_TRACEF("comm_init: cleared a stale HIP error (%s)", hipGetErrorString(stale));
     }
-    const ncclResult_t r = rccl().CommInitRank(&cm->nccl, world, id, rank);
+    // ncclCommInitRank returns when EVERY rank has joined: a peer that failed before it got here (librccl missing there, a device
+    // error, a crashed process) would leave this rank inside the call for good.  The call runs on a helper thread and is waited for
+    // with a bound (RMHIP_COMM_INIT_TIMEOUT_S, default 60): past it this rank gives up - the caller's ranks then agree on a fall-back
+    // through their control plane (runmat_amd/sharding.py try_native_comm) - and the helper, if the call ever returns, destroys the
+    // communicator it got.  RMHIP_COMM_TEST_FAIL_RANK=r makes rank r fail here at once (test hook for exactly that situation).
+    if (const char* tf = std::getenv("RMHIP_COMM_TEST_FAIL_RANK"))
+        if (std::atoi(tf) == rank) {
+            comm_destroy(c);
+            return fail(RMHIP_ERR_HIP, "comm_init: forced failure on rank %d (RMHIP_COMM_TEST_FAIL_RANK)", rank);
+        }
+    struct InitState {
+        std::mutex mu;
+        std::condition_variable cv;
+        bool done = false, abandoned = false;
+        ncclComm_t comm = nullptr;
+        ncclResult_t result = ncclSuccess;
+    };
+    auto st = std::make_shared<InitState>();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::thread([st, id, world, rank, dev]() {
+        (void)hipSetDevice(dev);
+        ncclComm_t comm = nullptr;
+        const ncclResult_t r = rccl().CommInitRank(&comm, world, id, rank);
+        std::unique_lock<std::mutex> lk(st->mu);
+        st->result = r;
+        st->comm = comm;
+        st->done = true;
+        if (st->abandoned && r == ncclSuccess && comm) {  // nobody is waiting any more
+            lk.unlock();
+            (void)rccl().CommDestroy(comm);
+            return;
+        }
+        st->cv.notify_all();
+    }).detach();
+    double timeout_s = 60.0;
+    if (const char* v = std::getenv("RMHIP_COMM_INIT_TIMEOUT_S")) timeout_s = std::atof(v) > 0 ? std::atof(v) : timeout_s;
+    ncclResult_t r = ncclSuccess;
+    {
+        std::unique_lock<std::mutex> lk(st->mu);
+        if (!st->cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return st->done; })) {
+            st->abandoned = true;
+            lk.unlock();
+            comm_destroy(c);
+            return fail(RMHIP_ERR_HIP, "comm_init: ncclCommInitRank did not return within %.0f s (a peer never joined?)", timeout_s);
+        }
+        r = st->result;
+        cm->nccl = st->comm;
+    }
     if (r != ncclSuccess) {
         cm->nccl = nullptr;
         comm_destroy(c);

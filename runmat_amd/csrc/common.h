@@ -174,6 +174,12 @@ struct Context {
     unsigned* gemm_tile_counters = nullptr;  // device, zeroed by the driver; one per launch
     size_t gemm_counter_next = 0, gemm_counter_cap = 0;
     const int* gemm_avoid_xcc = nullptr;     // device word written by the panel kernel (-1: none)
+    // solve-path LU: inverses of the 16 x 16 unit-lower diagonal blocks of L (k_rp_top leaves them: block q = columns 16 q .. 16 q + 15,
+    // 256 doubles, [k][i] = inv(L_qq)[i][k]) for the matrix-core triangular solve; lu_work / lu_work_ld locate a T operand's diagonal
+    const double* lu_linv = nullptr;
+    std::vector<unsigned char>* lu_linv_ok = nullptr;  // host: block q has its inverse queued (a base panel of another width leaves none)
+    const double* lu_work = nullptr;
+    size_t lu_work_ld = 0;
     bool gemm_chain_prio = false;  // the look-ahead LU's main-stream dgemm launches raise their wave priority (RMHIP_LU_GEMM_PRIO=0 disables)
     const unsigned* gemm_yield_word = nullptr;  // two-level LU: the CU (key) whose update blocks pause while k_rp_top runs there (device word; 0: none)
     bool in_lookahead = false;  // inside the LU's look-ahead driver: main-stream dgemm blocks must fit beside the update stream's
@@ -218,6 +224,10 @@ struct Context {
     int get_view(uint64_t id, Buffer* out);  // f64 data, `tview` may be set (matmul / syrk read views in place); repmat views are materialised
     int get_raw(uint64_t id, Buffer* out);   // the record as stored: dtype may be DT_F32, `tview` / `rep_base` may be set
     int settle_view(uint64_t id);            // materialise a transpose / repmat view in its own storage type and keep it under this id
+    // Before an IN-PLACE write to buffer `id` (scatter_linear, the block views' assign / gemm / trsm / lu / swap_rows, the epilogue's
+    // diagonal output, a raw device pointer handed out): every OTHER handle that is a lazy view of the same storage is materialised
+    // first, so that it keeps the values it was created from (the reference's repmat / transpose results are buffers of their own).
+    int detach_views_of(uint64_t id);
     int narrow(uint64_t id);                 // replace an f64 buffer's storage by its f32 rounding
     void finish_outputs(size_t mark);        // narrow everything new_buffer created since `mark` (precision 32 only)
     int ensure_scratch(size_t bytes);

@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
 // a plain A, no transposed B).  Tile rows / columns beyond the matrix re-read its last ones - their accumulators are never stored -
 // and the k tail of the LAST tile is zeroed in both operands; every other iteration runs the unguarded loads.  The guarded k_dgemm
 // checks every element of every tile: 8200^3 58.8 TFLOP/s against 72.5 at 8192^3.
-template <bool PRE, bool TA = false, bool TB = false, int EPI = 0, bool GUARD = false>
+template <bool PRE, bool TA = false, bool TB = false, int EPI = 0, bool GUARD = false, bool YIELD = false>
 __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, const unsigned tn, double* As, double* Bs,
                                         const unsigned kbeg = 0, const unsigned klen_or_0 = 0, const size_t c_off = 0) {
     // (kbeg, klen, c_off): the k slice and the partial-product offset of a split-K block; defaults = the whole product
@@ -697,17 +697,18 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
         fetch(clampt(1));
         double af0[4], bf0[2], af1[4], bf1[2];
         frags(As + a_off, Bs + b_off, 0, af0, bf0);
-        // cooperative yield (GemmArgs::yield_word): the word read during the previous k tile names the CU on which the LU's k_rp_top is
-        // running; if that is this CU, sleep until it changes (bounded: ~2 ms)
+        // cooperative yield (YIELD instantiation, GemmArgs::yield_word): the word read during the previous k tile names the CU on which the
+        // LU's k_rp_top is running; if that is this CU, sleep until it changes (bounded: ~2 ms).  A separate instantiation: the check in the
+        // plain kernel's pipelined loop cost the 8192^3 product 5 % (15.2 -> 16.0 ms)
         unsigned my_cu = 0, yv = 0;
-        if (g.yield_word) {
+        if (YIELD && g.yield_word) {
             unsigned xcc, hw;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
             my_cu = 0x80000000u | ((xcc & 0xfu) << 8) | ((hw >> 8) & 0xffu);
         }
         for (unsigned kt = 0; kt < ktiles; ++kt) {
-            if (g.yield_word) {
+            if (YIELD && g.yield_word) {
                 if (__builtin_amdgcn_readfirstlane(yv) == my_cu) {
                     for (int spin = 0; spin < 4096 && __hip_atomic_load(g.yield_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_cu; ++spin)
                         __builtin_amdgcn_s_sleep(16);
@@ -814,14 +815,14 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
 }
 
 // gridDim.y > 1: split-K (GemmArgs::k_chunk) - blockIdx.y owns a slice of k and writes its partial product
-template <bool PRE, bool TA = false, bool TB = false, int EPI = 0>
+template <bool PRE, bool TA = false, bool TB = false, int EPI = 0, bool YIELD = false>
 __global__ void __launch_bounds__(512) k_dgemm_w8(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     unsigned tm, tn;
     tile_of_block(g, tm, tn);
     const unsigned kbeg = blockIdx.y * g.k_chunk;  // one slice (gridDim.y == 1): k_chunk == k
     const unsigned klen = (g.k - kbeg) < g.k_chunk ? (g.k - kbeg) : g.k_chunk;
-    w8_tile<PRE, TA, TB, EPI, false>(g, tm, tn, lds, lds + 2 * A_TILE, kbeg, klen, (size_t)blockIdx.y * g.c_split_stride);
+    w8_tile<PRE, TA, TB, EPI, false, YIELD>(g, tm, tn, lds, lds + 2 * A_TILE, kbeg, klen, (size_t)blockIdx.y * g.c_split_stride);
 }
 // the guarded tile (any shape).  Four waves per SIMD (two blocks per CU) are asked for explicitly: the edge bookkeeping would otherwise push the kernel a
 // couple of registers over the 128 that four waves per SIMD allow (one block per CU: 59.5 instead of 63.8 TFLOP/s at 8200^3).
@@ -1102,7 +1103,10 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
     }
     if (fast_k && splits == 1 && !ep && !ta && !tb &&
         ((w8_mode == 1 && (c->gemm_lds_pad != 0 || !c->in_lookahead)) || w8_mode == 2)) {
-        if (preload) {
+        if (preload && g.yield_word) {  // the two-level LU's update streams: the variant that checks the yield word
+            c->ensure_max_lds((const void*)k_dgemm_w8<true, false, false, 0, true>, kMaxLds);
+            hipLaunchKernelGGL((k_dgemm_w8<true, false, false, 0, true>), dim3(blocks), dim3(512), lds_bytes, c->stream, g);
+        } else if (preload) {
             c->ensure_max_lds((const void*)k_dgemm_w8<true>, kMaxLds);
             hipLaunchKernelGGL(k_dgemm_w8<true>, dim3(blocks), dim3(512), lds_bytes, c->stream, g);
         } else {

@@ -19,6 +19,8 @@
 #include <vector>
 
 #include "common.h"
+#include <chrono>
+#include <string>
 
 namespace rmhip {
 
@@ -80,6 +82,7 @@ struct LuState {
     size_t ev_used = 0;                   // events drawn from the context's pool by this factorisation
     unsigned ucomp_slot = 0;              // ring of compact U copies: k_rp_below on `aux` may still read panel p's while k_rp_top writes p + 1's
     hipEvent_t aux_tail = nullptr;        // last event recorded on aux (what the main stream's next look-ahead update has to wait for)
+    double* linv = nullptr;               // solve path: inverted 16 x 16 diagonal blocks of L, block q at 256 q (k_trsm_lower_mfma)
     unsigned* yield_word = nullptr;       // two-level driver: device word through which k_rp_top asks the update blocks on its CU to pause
 };
 static constexpr unsigned kUcompSlots = 16;  // >= base panels per look-ahead panel (512 / 64) with room to spare
@@ -904,6 +907,7 @@ struct RtArgs {
     int2* plist;    // this panel's row-move list (PLIST entries, the layout k_lu_panel2 writes)
     double* ucomp;  // [BASE_W][BASE_W] compact copy of the pivot rows for k_rp_below: ucomp[k * BASE_W + c] = U[k][c], 1 / u_kk on the diagonal
     int* xcc_out;   // receives the XCD this workgroup runs on (read by the update stream's persistent kernels), or nullptr
+    double* linv;   // receives the inverses of L11's four unit-lower 16 x 16 diagonal blocks (4 x 256 doubles, [k][i]), or nullptr
     int uinv_on;    // also leave the inverses of U11's 16 x 16 diagonal blocks behind the compact copy (k_rp_below_mfma)
     unsigned* yield_word;  // two-level driver: receives this workgroup's CU key while it runs, 0 when it is done (update blocks on that CU pause), or nullptr
 };
@@ -1012,6 +1016,7 @@ __global__ void __launch_bounds__(RT_ROWS) k_rp_top(const RtArgs g, pk_u64* dbg)
     __shared__ int s_pos[2 * 4];
     __shared__ __attribute__((aligned(16))) double s_pw[8 * RT_VS];
     __shared__ __attribute__((aligned(16))) double s_pt[8 * RT_TRAIL];
+    __shared__ int s_prow[BASE_W];  // physical row of pivot k (for the inverses of L11's diagonal blocks at the end)
     extern __shared__ double rt_pad[];  // only asked for: keeps update-stream dgemm blocks off this CU (getrf_rec)
     RtLds L;
     L.wmax = s_wmax;
@@ -1121,6 +1126,7 @@ __global__ void __launch_bounds__(RT_ROWS) k_rp_top(const RtArgs g, pk_u64* dbg)
         g.plist[BASE_W + t] = e;
         if (t >= g.w) g.plist[t] = make_int2(-1, -1);
     }
+    if (g.w == BASE_W && g.uinv_on && in_rows && retk >= 0) s_prow[retk] = (int)r;
     if (g.w == BASE_W && g.uinv_on) {
         // Inverses of U11's four 16 x 16 diagonal blocks for k_rp_below_mfma (the rows below then need matrix-core products only).
         // Thread (b, i) solves U_bb x = e_i by back substitution - every index static, x[m] = 0 beyond i - and writes column i.
@@ -1141,6 +1147,29 @@ __global__ void __launch_bounds__(RT_ROWS) k_rp_top(const RtArgs g, pk_u64* dbg)
             double* dst = g.ucomp + (size_t)BASE_W * BASE_W + 256 * b + i;
 #pragma unroll
             for (int k = 0; k < 16; ++k) dst[16 * k] = x[k];
+        } else if (t < 128 && g.linv) {
+            // the same for L11's unit-lower diagonal blocks (k_trsm_lower_mfma): thread (b, k) solves L_bb x = e_k forwards and writes
+            // column k as 16 contiguous values ([k][i] storage).  The multipliers sit below the diagonal of the compact copy.
+            // (the compact copy only holds a pivot row's multipliers inside its own micro-panel; the full rows are in A, where each
+            // pivot row was loaded from - s_prow - and were stored by other threads of this workgroup: read past the L1)
+            const int b = (t - 64) >> 4, k = (t - 64) & 15;
+            double x[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) x[m] = (m == k) ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 1; i < 16; ++i) {
+                const unsigned long long* lrow = reinterpret_cast<const unsigned long long*>(g.A + (size_t)s_prow[16 * b + i] + (size_t)(g.j0 + 16 * b) * g.lda);
+                double sum = 0.0;
+#pragma unroll
+                for (int m = 0; m < i; ++m) {
+                    const double lim = __longlong_as_double((long long)__hip_atomic_load(lrow + (size_t)m * g.lda, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    sum = __builtin_fma(lim, x[m], sum);
+                }
+                if (i > k) x[i] = -sum;
+            }
+            double* dst = g.linv + (size_t)256 * b + 16 * k;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[i] = x[i];
         }
     }
     if (g.yield_word) {
@@ -1712,6 +1741,65 @@ __global__ void __launch_bounds__(TRSM_THREADS) k_trsm_lower_2p(const double* __
     }
 }
 
+// Unit-lower triangular solve on the matrix cores (solve path, round 5): B <- L^-1 B for a 64- or 128-wide L whose 16 x 16 diagonal
+// blocks k_rp_top has inverted (Context::lu_linv).  k_trsm_fused / k_trsm_lower_2p are chains of fp64 VALU FMAs fed by v_readlane:
+// 10-15 us alone, 50-80 us beside the update streams' blocks (every fp64 instruction waits for the MFMA in flight on its SIMD), and
+// 31 of them in a row are the W-wide solve of a super-panel boundary.  Here one wave owns 16 right-hand sides: right-looking over
+// L's blocks, X_c = inv(L_cc) B_c, then B_b -= L_bc X_c for b > c - all v_mfma_f64_16x16x4 (D[i][j]: i = row, j = right-hand side), the
+// accumulator layout of X_c (register r of lane (lq, l15) = row 4 r + lq) being the B operand of the updates (k = 4 s + lq at step
+// s = r).  L's blocks come straight from memory as A operands (lane l15 = row: 128-byte segments; every wave reads the same 72 KiB:
+// L2 hits), no LDS.  Rounding: products with an inverted 16 x 16 block instead of 16 substitution steps.
+template <int NB>  // 16 x 16 blocks of L: 4 (w = 64) or 8 (w = 128)
+__global__ void __launch_bounds__(64) k_trsm_lower_mfma(const double* __restrict__ T, const size_t ldt, const double* __restrict__ linv,
+                                                        double* __restrict__ B, const size_t ldb, const size_t nc) {
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    constexpr int W = 16 * NB;
+    constexpr int CS = W + 2;  // LDS column stride: 2 (mod 32) doubles puts the 32 lanes of a half-wave read on 64 distinct banks
+    __shared__ __attribute__((aligned(16))) double tile[16 * CS];  // this wave's 16 right-hand sides, [column][row]
+    const int t = threadIdx.x, l15 = t & 15, lq = t >> 4;
+    chain_prio();
+    const size_t col0 = (size_t)blockIdx.x * 16;
+    // coalesced load: one right-hand side per step, W rows as W / 2 lanes x 16 bytes (the rows of a column are contiguous in memory)
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        if (2 * t < W) {
+            v2d v = v2d{0.0, 0.0};
+            if (col0 + cc < nc) v = *(const v2d*)(B + (col0 + cc) * ldb + 2 * t);
+            *(v2d*)(tile + cc * CS + 2 * t) = v;
+        }
+    }
+    lds_barrier();
+    v4d acc[NB];  // acc[b][r] = B[16 b + 4 r + lq][col0 + l15]
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[b][r] = tile[l15 * CS + 16 * b + 4 * r + lq];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        double iop[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) iop[s4] = linv[256 * c + (4 * s4 + lq) * 16 + l15];  // inv(L_cc)[i = l15][k = 4 s + lq]
+        v4d x = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) x = __builtin_amdgcn_mfma_f64_16x16x4f64(iop[s4], acc[c][s4], x, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[l15 * CS + 16 * c + 4 * r + lq] = x[r];
+#pragma unroll
+        for (int b = c + 1; b < NB; ++b) {
+            double lop[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) lop[s4] = -T[(size_t)(16 * b + l15) + (size_t)(16 * c + 4 * s4 + lq) * ldt];  // -L_bc[i = l15][k = 4 s + lq]
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(lop[s4], x[s4], acc[b], 0, 0, 0);
+        }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc)
+        if (2 * t < W && col0 + cc < nc) *(v2d*)(B + (col0 + cc) * ldb + 2 * t) = *(const v2d*)(tile + cc * CS + 2 * t);
+}
+
 static int launch_check(Context* c);
 template <int MODE, int NC, int TRSM_THREADS>
 static int launch_trsm_fused_nc(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
@@ -1745,6 +1833,20 @@ static int launch_trsm_fused_nc(Context* c, const double* T, size_t ldt, size_t 
 }
 template <int MODE>
 static int launch_trsm_fused(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc) {
+    if (MODE == 0 && c->lu_linv && (w == 64 || w == 128) && ldt == c->lu_work_ld && T >= c->lu_work && ((uintptr_t)B & 15) == 0 && ldb % 2 == 0) {
+        // a diagonal block of the solve-path factorisation in flight: the matrix-core solve with k_rp_top's inverted 16 x 16 blocks
+        const size_t off = (size_t)(T - c->lu_work);
+        const size_t j = off / (ldt + 1);
+        bool have = j * (ldt + 1) == off && j % 16 == 0 && c->lu_linv_ok && (j + w) / 16 <= c->lu_linv_ok->size();
+        for (size_t q = j / 16; have && q < (j + w) / 16; ++q) have = (*c->lu_linv_ok)[q] != 0;
+        if (have) {
+            const double* linv = c->lu_linv + (j / 16) * 256;
+            const unsigned grid = (unsigned)((nc + 15) / 16);
+            if (w == 64) hipLaunchKernelGGL(k_trsm_lower_mfma<4>, dim3(grid), dim3(64), 0, c->stream, T, ldt, linv, B, ldb, nc);
+            else hipLaunchKernelGGL(k_trsm_lower_mfma<8>, dim3(grid), dim3(64), 0, c->stream, T, ldt, linv, B, ldb, nc);
+            return launch_check(c);
+        }
+    }
     const size_t waves_on_chip = (size_t)c->num_cus * 4;  // one wave per SIMD
     return nc > 2 * waves_on_chip ? launch_trsm_fused_nc<MODE, 4, 512>(c, T, ldt, w, B, ldb, nc)
                                   : launch_trsm_fused_nc<MODE, 1, 256>(c, T, ldt, w, B, ldb, nc);
@@ -1862,16 +1964,19 @@ struct StreamScope {
     hipStream_t saved;
     size_t saved_pad;
     int saved_base;
+    bool saved_prio;
     StreamScope(Context* ctx, hipStream_t s, size_t gemm_lds_pad, int base = 128)
-        : c(ctx), saved(ctx->stream), saved_pad(ctx->gemm_lds_pad), saved_base(ctx->trsm_base) {
+        : c(ctx), saved(ctx->stream), saved_pad(ctx->gemm_lds_pad), saved_base(ctx->trsm_base), saved_prio(ctx->gemm_chain_prio) {
         c->stream = s;
         c->gemm_lds_pad = gemm_lds_pad;
         c->trsm_base = base;  // (128: the update stream owns whole CUs between its dgemm blocks anyway)
+        c->gemm_chain_prio = false;  // only the main stream's dgemm launches raise their wave priority
     }
     ~StreamScope() {
         c->stream = saved;
         c->gemm_lds_pad = saved_pad;
         c->trsm_base = saved_base;
+        c->gemm_chain_prio = saved_prio;
     }
 };
 
@@ -1906,6 +2011,9 @@ static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller =
             static const int rb_mfma = std::getenv("RMHIP_LU_RB_MFMA") ? std::atoi(std::getenv("RMHIP_LU_RB_MFMA")) : 1;
             const bool below_mfma = rb_mfma && w == (size_t)BASE_W && !s.xdbg;
             g.uinv_on = below_mfma ? 1 : 0;
+            g.linv = (below_mfma && s.linv) ? s.linv + (j0 / 16) * 256 : nullptr;
+            if (g.linv && s.c->lu_linv_ok)
+                for (size_t q = j0 / 16; q < (j0 + BASE_W) / 16 && q < s.c->lu_linv_ok->size(); ++q) (*s.c->lu_linv_ok)[q] = 1;
             // like k_lu_panel2 the block ASKS for more LDS than it uses (48.6 KiB static) so that it does not share its CU with an
             // update-stream dgemm block: every column step would run slower beside one (RMHIP_LU_PANEL_PAD_KB; the phase-dependent
             // values of getrf_blocked apply)
@@ -2226,7 +2334,6 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
         (void)hipEventRecord(e0, main_stream);
         (void)hipStreamWaitEvent(side, e0, 0);
         if (prep) (void)hipStreamWaitEvent(prep, e0, 0);
-        if (s.aux) (void)hipStreamWaitEvent(s.aux, e0, 0);
     }
     // Panel width by phase.  While the trailing matrix is large the update stream is the bottleneck and the main stream
     // idles a third of the time: wider panels there (fewer, deeper rank-k updates: the dgemm runs 53 instead of 47
@@ -2467,9 +2574,6 @@ static int getrf_super(LuState& s, size_t kmin) {
         int trsm_base;
         bool clear_yield = false;
         ~Restore() {
-            if (c->lu_aux_stream) (void)hipStreamSynchronize(c->lu_aux_stream);
-            s->aux = nullptr;
-            s->band_end = 0;
             s->yield_word = nullptr;
             c->gemm_chain_prio = false;
             if (c->lu_mid_stream) (void)hipStreamSynchronize(c->lu_mid_stream);
@@ -2515,15 +2619,6 @@ static int getrf_super(LuState& s, size_t kmin) {
     static const long super_panel_pad = std::getenv("RMHIP_LU_SUPER_PANEL_PAD_KB") ? std::atol(std::getenv("RMHIP_LU_SUPER_PANEL_PAD_KB")) : 0;
     const size_t mid_pad = mid_pad_env >= 0 ? (size_t)mid_pad_env : pad_default;
     const size_t far_pad = far_pad_env >= 0 ? (size_t)far_pad_env : pad_default;
-    // band split (getrf_rec): the panel chain on the main stream touches only the rows the following top blocks of the panel live in; the
-    // rows below get their multipliers and in-panel updates on a stream of their own and rejoin at the end of the panel
-    static const int band_on = std::getenv("RMHIP_LU_SUPER_BAND") ? std::atoi(std::getenv("RMHIP_LU_SUPER_BAND")) : 0;
-    static const long band_extra = std::getenv("RMHIP_LU_BAND_ROWS") ? std::atol(std::getenv("RMHIP_LU_BAND_ROWS")) : 320;
-    static const size_t band_min_rows = std::getenv("RMHIP_LU_BAND_MIN_ROWS") ? (size_t)std::atoll(std::getenv("RMHIP_LU_BAND_MIN_ROWS")) : 2048;
-    if (band_on) {
-        if (!c->lu_aux_stream) RMHIP_HIP_CHECK(hipStreamCreateWithFlags(&c->lu_aux_stream, hipStreamNonBlocking));
-        s.aux = c->lu_aux_stream;
-    }
     // cooperative yield of the update blocks on k_rp_top's CU (RMHIP_LU_YIELD=0 disables)
     static const int yield_on = std::getenv("RMHIP_LU_YIELD") ? std::atoi(std::getenv("RMHIP_LU_YIELD")) : 1;
     static const long top_pad_env = std::getenv("RMHIP_LU_TOP_PAD_KB") ? std::atol(std::getenv("RMHIP_LU_TOP_PAD_KB")) : (yield_on ? 0 : -1);
@@ -2550,22 +2645,32 @@ static int getrf_super(LuState& s, size_t kmin) {
     hipEvent_t ev_far_next = nullptr;  // far finished the columns of the super-panel after the one in flight
     hipEvent_t ev_far_all = nullptr;
     int rc = RMHIP_OK;
+    const bool verbose = std::getenv("RMHIP_LU_VERBOSE") != nullptr;
+    // developer aid (RMHIP_LU_TIMELINE=1): timed events on the main stream around every super-panel boundary, printed after the factorisation
+    const bool tl_on = std::getenv("RMHIP_LU_TIMELINE") != nullptr;
+    std::vector<std::pair<std::string, hipEvent_t>> tl;
+    auto tl_mark = [&](const std::string& what) {
+        if (!tl_on) return;
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        (void)hipEventRecord(e, main_stream);
+        tl.emplace_back(what, e);
+    };
+    tl_mark("start");
+    const auto host_t0 = std::chrono::steady_clock::now();
+    auto host_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count(); };
     for (size_t J = 0; J < plan.size() && rc == RMHIP_OK; ++J) {
         const size_t S0 = plan[J].s0, S1 = plan[J].s1, nbJ = plan[J].nb, W = S1 - S0;
+        if (verbose && (W > nbJ || J + 1 == plan.size())) std::fprintf(stderr, "[lu] host %.2f ms: super-panel %zu [%zu, %zu) nb %zu queued so far %llu launches\n", host_ms(), J, S0, S1, nbJ, (unsigned long long)c->tel.kernel_launches);
         const size_t S1n = J + 1 < plan.size() ? plan[J + 1].s1 : S1;
         const size_t S1nn = J + 2 < plan.size() ? plan[J + 2].s1 : S1n;
         const bool multi = W > nbJ;
         s.panel_pad_kb = top_pad_env >= 0 ? top_pad_env : ((kmin - S0 > super_rows) ? super_panel_pad : -1);
         for (size_t j = S0; j < S1 && rc == RMHIP_OK;) {
             const size_t w = (S1 - j) < nbJ ? (S1 - j) : nbJ;
-            if (s.aux) {
-                const size_t be = j + w + (size_t)band_extra;
-                s.band_end = (be < s.rows && kmin - j > band_min_rows) ? be : 0;  // nothing below the band: no split
-                s.aux_tail = nullptr;
-            }
-            rc = getrf_rec(s, j, w);  // P_j on main (rows below the band: on aux)
+            rc = getrf_rec(s, j, w);  // P_j on main
             if (rc != RMHIP_OK) break;
-            if (s.aux && s.aux_tail) (void)hipStreamWaitEvent(main_stream, s.aux_tail, 0);  // L21 of the panel is complete when both are
+            if (tl_on && W > nbJ) tl_mark("J" + std::to_string(J) + " panel " + std::to_string(j) + " done");
             hipEvent_t panel_done = record(main_stream);
             const size_t next = j + w;
             const bool boundary = next == S1;
@@ -2601,10 +2706,14 @@ static int getrf_super(LuState& s, size_t kmin) {
                     ev_mid = ev_left;
                 }
                 if (la_w) {
+                    tl_mark("J" + std::to_string(J) + " chain done");
                     if (ev_mid) (void)hipStreamWaitEvent(main_stream, ev_mid, 0);
+                    tl_mark("J" + std::to_string(J) + " mid ready");
                     if (ev_far_next) (void)hipStreamWaitEvent(main_stream, ev_far_next, 0);
+                    tl_mark("J" + std::to_string(J) + " far ready");
                     rc = update_columns(s, S0, W, next, t0);  // rank-W look-ahead update on main
                     if (rc != RMHIP_OK) break;
+                    tl_mark("J" + std::to_string(J) + " LA done");
                 }
                 if (t0 < S1n) {
                     (void)hipStreamWaitEvent(mid, panel_done, 0);
@@ -2616,6 +2725,12 @@ static int getrf_super(LuState& s, size_t kmin) {
                     if (rc != RMHIP_OK) break;
                     ev_mid = record(mid);
                 }
+                // far: everything right of the next super-panel - interchange, W-wide solve, rank-W update (the next super-panel's columns
+                // first: event) - then the interchanges of the columns left of this super-panel.
+                // (Tried: the interchange + solve on a stream of their own, pipelined against the updates over two column parts as in
+                // getrf_blocked - 100 ms against 73 with four HIP streams active, 71.2 against 73.0 when GPU_MAX_HW_QUEUES=2 makes them
+                // share hardware queues; on the mid stream 75.5.  Deferring far updates under a per-boundary flop budget - identical
+                // factors - 84.5 / 75.4 / 73.3 ms at budgets of 1 / 2 / 3 chain times against 73.4 eager.  docs/EXPERIMENTS.md.)
                 (void)hipStreamWaitEvent(far, ev_left, 0);
                 {
                     StreamScope scope(c, far, far_pad);
@@ -2639,6 +2754,17 @@ static int getrf_super(LuState& s, size_t kmin) {
     s.panel_pad_kb = -1;
     if (ev_far_all) (void)hipStreamWaitEvent(main_stream, ev_far_all, 0);
     if (ev_mid) (void)hipStreamWaitEvent(main_stream, ev_mid, 0);
+    if (tl_on) {
+        (void)hipStreamSynchronize(main_stream);
+        for (size_t i = 1; i < tl.size(); ++i) {
+            float ms0 = 0.f, ms1 = 0.f;
+            (void)hipEventElapsedTime(&ms0, tl[0].second, tl[i].second);
+            (void)hipEventElapsedTime(&ms1, tl[i - 1].second, tl[i].second);
+            std::fprintf(stderr, "[lu timeline] %8.2f ms (+%6.2f) %s\n", ms0, ms1, tl[i].first.c_str());
+        }
+        for (auto& kv : tl) (void)hipEventDestroy(kv.second);
+    }
+    if (verbose) std::fprintf(stderr, "[lu] host %.2f ms: everything queued (%llu launches)\n", host_ms(), (unsigned long long)c->tel.kernel_launches);
     (void)hipStreamSynchronize(mid);
     (void)hipStreamSynchronize(far);
     (void)hipStreamSynchronize(main_stream);
@@ -2679,7 +2805,8 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     const size_t off_xb = off_xa + sizeof(unsigned long long) * 2 * PK_MAXB;
     const size_t off_xctl = off_xb + sizeof(unsigned long long) * 2 * PK_MAXB;
     const size_t off_ucomp = off_xctl + 64 + 16 * sizeof(unsigned long long);
-    const size_t total = off_ucomp + sizeof(double) * UCOMP_STRIDE * kUcompSlots;
+    const size_t off_linv = off_ucomp + sizeof(double) * UCOMP_STRIDE * kUcompSlots;
+    const size_t total = off_linv + sizeof(double) * 256 * (rows / 16 + 8);
     std::shared_ptr<Allocation> blk_mem;  // pooled: a hipMalloc / hipFree pair costs two device synchronisations per factorisation
     RMHIP_TRY(c->alloc_device(total / sizeof(double) + 2, &blk_mem));
     char* blk = (char*)blk_mem->ptr;
@@ -2708,6 +2835,25 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
         c->lu_tau = s.tau;
         s.ucomp = (double*)(blk + off_ucomp);
         s.growth = (unsigned long long*)(blk + off_xctl + 32);
+        // matrix-core triangular solves with k_rp_top's inverted diagonal blocks: every base panel must be 64 columns wide
+        static const int trsm_mfma = std::getenv("RMHIP_LU_TRSM_MFMA") ? std::atoi(std::getenv("RMHIP_LU_TRSM_MFMA")) : 1;
+        if (s.fast && trsm_mfma && !s.xdbg) s.linv = (double*)(blk + off_linv);
+    }
+    std::vector<unsigned char> linv_ok(rows / 16 + 8, 0);
+    struct LinvScope {  // the solves find the inverses through the context while this factorisation runs
+        Context* c;
+        ~LinvScope() {
+            c->lu_linv = nullptr;
+            c->lu_linv_ok = nullptr;
+            c->lu_work = nullptr;
+            c->lu_work_ld = 0;
+        }
+    } linv_scope{c};
+    if (s.linv) {
+        c->lu_linv = s.linv;
+        c->lu_linv_ok = &linv_ok;
+        c->lu_work = A;
+        c->lu_work_ld = lda;
     }
     // Panel width of the look-ahead driver and its threshold, from an interleaved sweep (scripts/lu_knobs.py, ms for
     // x = A\b): n = 6144: 38.7 without look-ahead, 33.6 with nb 128, 34.9 with 256, 36.8 with 512; 8192: 51.2 (nb 512)

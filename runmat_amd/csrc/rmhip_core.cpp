@@ -228,6 +228,20 @@ int Context::settle_view(uint64_t id) {
     return RMHIP_OK;
 }
 
+int Context::detach_views_of(uint64_t id) {
+    std::vector<uint64_t> sharers;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = table.find(id);
+        if (it == table.end() || !it->second.alloc) return RMHIP_OK;
+        if (it->second.alloc.use_count() <= 1) return RMHIP_OK;  // nobody else holds this storage
+        for (auto& kv : table)
+            if (kv.first != id && kv.second.alloc == it->second.alloc && kv.second.lazy()) sharers.push_back(kv.first);
+    }
+    for (uint64_t v : sharers) RMHIP_TRY(settle_view(v));
+    return RMHIP_OK;
+}
+
 int Context::narrow(uint64_t id) {
     Buffer b;
     {
@@ -644,6 +658,7 @@ void* rmhip_device_ptr(rmhip_ctx* ctx, rmhip_buf id) {
     DeviceGuard _dg(&ctx->c);
     Buffer b;
     if (ctx->c.get_raw(id, &b) != RMHIP_OK) return nullptr;
+    if (ctx->c.detach_views_of(id) != RMHIP_OK) return nullptr;  // the caller may write through the pointer: views of this storage keep their values
     if (b.dtype == DT_F32 && !b.rep_base.empty()) {  // tile first: the pointer must address numel elements
         if (ctx->c.settle_view(id) != RMHIP_OK || ctx->c.get_raw(id, &b) != RMHIP_OK) return nullptr;
     }

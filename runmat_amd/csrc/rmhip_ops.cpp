@@ -1158,6 +1158,7 @@ int rmhip_matmul_epilogue(rmhip_ctx* ctx, rmhip_buf a, rmhip_buf b, const rmhip_
     if (ep->diag_output) {
         RMHIP_TRY(c->get_raw(ep->diag_output, &dg_raw));
         if (dg_raw.lazy()) return fail(RMHIP_ERR_UNSUPPORTED, "matmul_epilogue: diag_output must not be a transpose / repmat view");
+        RMHIP_TRY(c->detach_views_of(ep->diag_output));  // written in place
         RMHIP_TRY(c->get(ep->diag_output, &dg));
         const size_t expected = m < n ? m : n;
         if (dg.numel < expected)  // simple_provider.rs:7790-7799
@@ -1682,9 +1683,11 @@ struct ViewPtr {
     double* ptr = nullptr;
     size_t ld = 0, rows = 0, cols = 0;
 };
-int resolve_view(Context* c, const rmhip_view_t* v, ViewPtr* out) {
+// write: the block is updated in place - lazy views of the same storage held under other handles are materialised first
+int resolve_view(Context* c, const rmhip_view_t* v, ViewPtr* out, bool write = false) {
     if (!v) return fail(RMHIP_ERR_INVALID, "null view");
     RMHIP_TRY(c->get_raw(v->buf, &out->buf));
+    if (write) RMHIP_TRY(c->detach_views_of(v->buf));
     if (out->buf.dtype != DT_F64)  // in-place block updates cannot go through a widened temporary
         return fail(RMHIP_ERR_UNSUPPORTED, "block views address f64 storage; this buffer is f32 (precision-32 provider)");
     RMHIP_TRY(c->get(v->buf, &out->buf));
@@ -1717,7 +1720,7 @@ int rmhip_blk_copy(rmhip_ctx* ctx, const rmhip_view_t* src, rmhip_buf* out) {
 int rmhip_blk_assign(rmhip_ctx* ctx, const rmhip_view_t* dst, rmhip_buf src) {
     CTX_OR_FAIL(ctx);
     ViewPtr v;
-    RMHIP_TRY(resolve_view(c, dst, &v));
+    RMHIP_TRY(resolve_view(c, dst, &v, true));
     Buffer sb;
     RMHIP_TRY(c->get(src, &sb));
     if (sb.numel != v.rows * v.cols) return fail(RMHIP_ERR_SHAPE, "blk_assign: source has %zu elements, view %zux%zu", sb.numel, v.rows, v.cols);
@@ -1733,7 +1736,7 @@ int rmhip_blk_gemm(rmhip_ctx* ctx, double alpha, const rmhip_view_t* a, const rm
     ViewPtr va, vb, vc;
     RMHIP_TRY(resolve_view(c, a, &va));
     RMHIP_TRY(resolve_view(c, b, &vb));
-    RMHIP_TRY(resolve_view(c, cv, &vc));
+    RMHIP_TRY(resolve_view(c, cv, &vc, true));
     if (va.cols != vb.rows || vc.rows != va.rows || vc.cols != vb.cols)
         return fail(RMHIP_ERR_SHAPE, "blk_gemm: %zux%zu * %zux%zu -> %zux%zu", va.rows, va.cols, vb.rows, vb.cols, vc.rows, vc.cols);
     if (va.cols == 0) return RMHIP_OK;
@@ -1744,7 +1747,7 @@ int rmhip_blk_trsm(rmhip_ctx* ctx, int upper, const rmhip_view_t* t, const rmhip
     CTX_OR_FAIL(ctx);
     ViewPtr vt, vb;
     RMHIP_TRY(resolve_view(c, t, &vt));
-    RMHIP_TRY(resolve_view(c, b, &vb));
+    RMHIP_TRY(resolve_view(c, b, &vb, true));
     if (upper == 2) {
         // B <- B U^-1 (the multipliers of a row block against a factored diagonal tile: L21 = A21 U11^-1).  X U = B is U' X' = B': both
         // operands are transposed into temporaries (k_transpose, 64 x 64 LDS tiles), U' is lower with a stored diagonal - the
@@ -1772,7 +1775,7 @@ int rmhip_blk_lu(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf* ipiv_out, int
     CTX_OR_FAIL(ctx);
     if (!ipiv_out) return fail(RMHIP_ERR_INVALID, "null ipiv_out");
     ViewPtr va;
-    RMHIP_TRY(resolve_view(c, a, &va));
+    RMHIP_TRY(resolve_view(c, a, &va, true));
     std::vector<int> ipiv;
     int inf = 0;
     {
@@ -1801,7 +1804,7 @@ int rmhip_blk_lu(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf* ipiv_out, int
 int rmhip_blk_swap_rows(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf ipiv) {
     CTX_OR_FAIL(ctx);
     ViewPtr va;
-    RMHIP_TRY(resolve_view(c, a, &va));
+    RMHIP_TRY(resolve_view(c, a, &va, true));
     Buffer pb;
     RMHIP_TRY(c->get(ipiv, &pb));
     std::vector<double> host(pb.numel);

@@ -538,6 +538,7 @@ int rmhip_scatter_linear(rmhip_ctx* ctx, rmhip_buf target, const uint32_t* indic
     if (n_indices && !indices) return fail(RMHIP_ERR_INVALID, "scatter_linear: null indices");
     Buffer tb, vb;
     RMHIP_TRY(get_settled(c, target, &tb));
+    RMHIP_TRY(c->detach_views_of(target));  // written in place: a repmat / transpose view of the target keeps the values it was made from
     RMHIP_TRY(get_settled(c, values, &vb));
     if (tb.dtype != vb.dtype)  // simple_provider.rs:2663-2669 (storage mismatch)
         return fail(RMHIP_ERR_UNSUPPORTED, "scatter_linear: storage mismatch target=%s values=%s", tb.dtype == DT_F32 ? "f32" : "f64", vb.dtype == DT_F32 ? "f32" : "f64");

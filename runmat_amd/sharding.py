@@ -105,6 +105,34 @@ class Group:
         self.native = prov
         return self
 
+    def try_native_comm(self, prov, transport: str = "rccl"):
+        """`with_native_comm`, then the ranks AGREE on the outcome through the control plane (a MIN over one flag): either every rank
+        holds the native communicator afterwards, or none does (a rank whose init succeeded while a peer's failed - or timed out waiting
+        for it, rmhip_comm_init's bounded wait - destroys its half) and the group keeps exchanging through torch.distributed.
+        Returns (ok, note): the same on every rank."""
+        ok, why = 1, ""
+        try:
+            self.with_native_comm(prov, transport=transport)
+        except Exception as e:  # noqa: BLE001 - any failure means "fall back"
+            ok, why = 0, str(e)[:200]
+        if self.world > 1:
+            import torch
+
+            flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+            agreed = int(flag.item()) == 1
+        else:
+            agreed = ok == 1
+        if agreed:
+            return True, f"rmhip_comm_* ({'RCCL' if transport == 'rccl' else 'host shared memory'})"
+        if self.native is not None:
+            try:
+                prov.comm_destroy()
+            except Exception:  # noqa: BLE001
+                pass
+            self.native = None
+        return False, "torch.distributed (native communicator unavailable" + (f": {why}" if why else " on another rank") + ")"
+
     @staticmethod
     def from_env() -> "Group":
         import torch.distributed as dist

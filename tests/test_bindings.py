@@ -68,3 +68,83 @@ def test_rust_binding_implements_every_served_method():
     missing = [n for n in served() if not re.search(rf"\bfn {n}\b|\b{n}\s*=>", body)]
     assert not missing, missing
     assert "same pattern" not in text  # no elided methods
+
+
+# ---- signature level: the shim's impl block against the trait, method by method (no Rust toolchain in the image) --------------------
+def _shim_signatures():
+    """Every method of `impl AccelProvider for HipProvider`, hook macros expanded (their templates are `fn $name ...` bodies)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from rust_sig import parse_fn_signatures, parse_signature
+
+    text = (ROOT / "shim" / "hip_provider.rs").read_text()
+    macros = {}
+    for m in re.finditer(r"macro_rules!\s+([a-z_]+)\s*\{\s*\(\$\(\$name:ident => \$op:expr\),\*\s*\$\(,\)\?\)\s*=>\s*\{\s*\$\(\s*(.*?)\)\*\s*\}\s*\}", text, flags=re.S):
+        macros[m.group(1)] = m.group(2)
+    start = text.index("impl AccelProvider for HipProvider")
+    depth, i = 0, text.index("{", start)
+    j = i
+    while True:
+        depth += text[j] == "{"
+        depth -= text[j] == "}"
+        j += 1
+        if depth == 0:
+            break
+    body = text[i:j]
+    first_line = text[:i].count("\n") + 1
+    sigs = parse_fn_signatures(body, first_line=first_line, indent="    ")
+    for mname, tmpl in macros.items():
+        for inv in re.finditer(rf"\b{mname}!\s*\{{(.*?)\}}", body, flags=re.S):
+            for name in re.findall(r"([a-z_0-9]+)\s*=>", inv.group(1)):
+                head = re.split(r"\{", tmpl.replace("$name", name), maxsplit=1)[0]
+                sig = parse_signature(head)
+                assert sig, (mname, name)
+                sig["line"] = first_line + body[:inv.start()].count("\n")
+                sig["macro"] = mname
+                sigs[name] = sig
+    return sigs
+
+
+def _canon(t: str) -> str:
+    return t.replace("crate::", "").replace("runmat_accelerate_api::", "")
+
+
+def test_shim_signatures_match_the_trait():
+    golden = json.loads((ROOT / "tests" / "golden" / "accel_provider_methods.json").read_text())
+    trait = golden["signatures"]
+    assert len(trait) == 243 and set(trait) == set(golden["methods"])
+    shim = _shim_signatures()
+    unknown = sorted(set(shim) - set(trait))
+    assert not unknown, f"methods of the impl block that the trait does not have: {unknown}"
+    assert len(shim) >= 200, len(shim)
+    bad = []
+    for name, s in shim.items():
+        t = trait[name]
+        if s["async"] != t["async"]:
+            bad.append((name, "async", s["async"], t["async"]))
+        if len(s["params"]) != len(t["params"]):
+            bad.append((name, "arity", len(s["params"]), len(t["params"])))
+            continue
+        for k, (ps, pt) in enumerate(zip(s["params"], t["params"])):
+            if ps["ref"] != pt["ref"] or _canon(ps["type"]) != _canon(pt["type"]):
+                bad.append((name, f"param {k}", ps["ref"] + " " + ps["type"], pt["ref"] + " " + pt["type"]))
+        if _canon(s["ret"]) != _canon(t["ret"]):
+            bad.append((name, "return", s["ret"], t["ret"]))
+        if ("'a" in s["generics"]) != ("'a" in t["generics"]):
+            bad.append((name, "lifetime parameter", s["generics"], t["generics"]))
+    assert not bad, bad[:20]
+    # every served method is in the impl block with the trait's signature
+    missing = [n for n in served() if n not in shim]
+    assert not missing, missing
+
+
+def test_shim_enum_variants_exist_in_the_api_crate():
+    golden = json.loads((ROOT / "tests" / "golden" / "accel_provider_methods.json").read_text())
+    enums = golden["enums"]
+    assert "ReductionFlavor" in enums and "ProviderPrecision" in enums and len(enums) >= 40
+    text = (ROOT / "shim" / "hip_provider.rs").read_text() + (ROOT / "shim" / "wiring.rs").read_text()
+    bad = []
+    for m in re.finditer(r"\b([A-Z][A-Za-z0-9]+)::([A-Z][A-Za-z0-9]+)\b", text):
+        e, v = m.group(1), m.group(2)
+        if e in enums and v not in enums[e]:
+            bad.append(f"{e}::{v}")
+    assert not bad, sorted(set(bad))

@@ -70,3 +70,39 @@ def test_a_failing_workload_becomes_an_error_record():
     out = _run_bench(["--steps", "2", "--warmup", "1", "--workload", "chain", "--no-also", "--no-cpu-baseline"], {"RMHIP_BENCH_TEST_FAIL": "chain"})
     assert out["value"] is None and "forced by RMHIP_BENCH_TEST_FAIL" in out["error"] and out["n_gpus"] == 2
     assert out["comm"]["world_seen"] == 2
+
+
+def test_eight_rank_line_on_one_gpu():
+    """The line the driver launches on an 8-GPU node (`--gpus 8`), with all eight ranks sharing cuda:0 over the host shared-memory
+    transport and every linear size divided by four (RMHIP_BENCH_SHRINK): the row-sharded dgemm, the sample-sharded Monte-Carlo and the
+    row-partitioned solve all run with world = 8 - shard arithmetic, skip-ahead, eight-way exchanges - and the line keeps its schema."""
+    out = _run_bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline"], {"RMHIP_BENCH_SHRINK": "4", "RMHIP_BENCH_BUSY_S": "0"}, nproc=8,
+                     timeout=1500)
+    assert out["n_gpus"] == 8 and out["config"]["shrink"] == 4 and out["value"] > 0
+    assert out["comm"] == {"transport": "host-shm", "world_seen": 8, "rank_seen": 0}
+    seen = {}
+    for a in out["also"]:
+        assert "error" not in a, a
+        assert a["value"] > 0 and a["ms_per_step"] > 0
+        seen[a["metric"]] = a
+    solve = next(a for m, a in seen.items() if "A\\b" in m)
+    assert "row-partitioned x8" in solve["config"]["parallelism"] and solve["config"]["max_abs_err_vs_ones"] < 1e-6
+    mc = next(a for m, a in seen.items() if m.startswith("Monte-Carlo samples/s"))
+    assert "x8" in mc["config"]["parallelism"]
+    gemm = next(a for m, a in seen.items() if "8192^3 matmul" in m and m.startswith("fp64"))
+    assert "x8" in gemm["config"]["parallelism"] or "8" in gemm["config"]["parallelism"]
+    # the BASELINE configs close the line (the driver records its tail)
+    order = [a["metric"] for a in out["also"]]
+    assert "A\\b" in order[-1] and "8192^3 matmul" in order[-2] and order[-3].startswith("Monte-Carlo samples/s")
+
+
+def test_a_rank_that_fails_its_comm_init_makes_every_rank_fall_back():
+    """RCCL's ncclCommInitRank only returns when every rank joined.  Rank 1 is made to fail before it gets there
+    (RMHIP_COMM_TEST_FAIL_RANK); rank 0 is inside the real call on the real device and must come back - rmhip_comm_init's bounded
+    wait, 4 s here - after which the ranks agree (sharding.Group.try_native_comm) and the line is produced over the control plane."""
+    out = _run_bench(["--steps", "2", "--warmup", "1", "--workload", "mc", "--no-also", "--no-cpu-baseline"],
+                     {"RMHIP_BENCH_TRANSPORT": "rccl", "RMHIP_COMM_TEST_FAIL_RANK": "1", "RMHIP_COMM_INIT_TIMEOUT_S": "4",
+                      "RMHIP_BENCH_SHRINK": "4", "RMHIP_BENCH_BUSY_S": "0"})
+    assert out["n_gpus"] == 2 and out["value"] > 0 and "error" not in out
+    assert out["comm"]["transport"].startswith("torch.distributed") and out["comm"]["world_seen"] == 2
+    assert "native communicator unavailable" in out["config"]["collectives"]

@@ -339,3 +339,36 @@ def test_eye_and_cat(prov, oracle):
     big = rng.standard_normal((2048, 700))
     hbig = prov.upload(big)
     assert bits_equal(prov.download_matrix(prov.cat(2, [hbig, hbig])), np.hstack([big, big]))
+
+
+def test_views_keep_their_values_when_the_base_is_written_in_place(prov, oracle):
+    """`B = repmat(A, 2, 2); A(idx) = v` (write_slice.rs:723 -> scatter_linear): the reference's repmat result is a buffer of its own,
+    so B must keep the tiling of the OLD A whether or not it was materialised before the write; the same for a transpose view, and
+    for the in-place block updates (rmhip_blk_assign) and a raw device pointer handed out for the base."""
+    rng = np.random.default_rng(11)
+    A = rng.uniform(-1, 1, (5, 3))
+    old_tiled = np.tile(A, (2, 2))
+    ha = prov.upload(A)
+    view = prov.repmat(ha, [2, 2])          # lazy: shares A's storage
+    tview = prov.transpose(ha)              # lazy as well
+    vals = prov.upload(np.array([[9.0], [8.0]]))
+    prov.scatter_linear(ha, np.array([0, 7], dtype=np.uint32), vals)
+    A2 = A.copy(order="F")
+    A2.reshape(-1, order="F")[[0, 7]] = [9.0, 8.0]
+    assert np.array_equal(prov.download_matrix(ha), A2)
+    assert np.array_equal(prov.download_matrix(view), old_tiled)
+    assert np.array_equal(prov.download_matrix(tview), A.T)
+    # a view made AFTER the write sees the new values, and reading it through the stride-0 elementwise path does too
+    view2 = prov.repmat(ha, [1, 2])
+    z = prov.upload(np.zeros((5, 6)))
+    assert np.array_equal(prov.download_matrix(prov.elem_add(view2, z)), np.tile(A2, (1, 2)))
+    # block-level in-place update of the base: the earlier view is untouched again
+    view3 = prov.repmat(ha, [2, 1])
+    blk = prov.upload(np.full((2, 2), -4.0))
+    prov.blk_assign((ha, 1, 0, 2, 2), blk)
+    assert np.array_equal(prov.download_matrix(view3), np.tile(A2, (2, 1)))
+    A3 = A2.copy()
+    A3[1:3, 0:2] = -4.0
+    assert np.array_equal(prov.download_matrix(ha), A3)
+    for h in (ha, view, tview, vals, view2, z, view3, blk):
+        prov.free(h)
