@@ -553,7 +553,8 @@ def main() -> None:
             blocks = sh.owned_blocks(nn, nbk, group)
             row_blocks = sh.owned_row_blocks(nn, nbk, group)
             form["name"] = (f"row-partitioned x{world}, rb=512: diagonal-domain pivoting, one tile-row broadcast per panel (rmhip_comm_bcast), "
-                            f"last {world} row blocks all-gathered")
+                            f"last {world} row blocks all-gathered"
+                            + ("; driver inside the library (look-ahead 1)" if world == 1 or group.native is not None else "; Python driver over the control plane"))
 
             def solve_rows():
                 nloc = sum(min(nbk, nn - q * nbk) for q in row_blocks)
@@ -566,6 +567,15 @@ def main() -> None:
                         prov.blk_assign((ab, lo, c0, h, wd), blk)
                         prov.free(blk)
                 try:
+                    if world == 1 or group.native is not None:
+                        # the driver inside the library (csrc/sharded.cpp: depth-1 look-ahead, asynchronous panel broadcasts, panels on
+                        # the solve path's kernels); its multiplier guard reports through the error code
+                        try:
+                            return prov.mldivide_row_partitioned(ab, nn, 1, rb=nbk)
+                        except Exception as e:  # noqa: BLE001 - ProviderError carrying RMHIP_ERR_GROWTH on every rank alike
+                            if "multiplier" in str(e) or "growth" in str(e).lower() or "failed" in str(e):
+                                raise sh.PivotGrowth(str(e)) from e
+                            raise
                     return sh.mldivide_row_partitioned(prov, group, ab, nn, 1, rb=nbk)
                 finally:
                     prov.free(ab)

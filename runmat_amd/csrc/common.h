@@ -174,6 +174,10 @@ struct Context {
     unsigned* gemm_tile_counters = nullptr;  // device, zeroed by the driver; one per launch
     size_t gemm_counter_next = 0, gemm_counter_cap = 0;
     const int* gemm_avoid_xcc = nullptr;     // device word written by the panel kernel (-1: none)
+    // rmhip_blk_lu factors with the solve path's panel kernels (pivoting inside each base panel's top block, multiplier bound checked;
+    // a violation restores the block and factors it with the grid-wide rule): set by the row-partitioned multi-GPU solve around its
+    // panel factorisations, whose pivots never leave the provider
+    bool blk_lu_solve_path = false;
     // solve-path LU: inverses of the 16 x 16 unit-lower diagonal blocks of L (k_rp_top leaves them: block q = columns 16 q .. 16 q + 15,
     // 256 doubles, [k][i] = inv(L_qq)[i][k]) for the matrix-core triangular solve; lu_work / lu_work_ld locate a T operand's diagonal
     const double* lu_linv = nullptr;

@@ -1779,7 +1779,23 @@ int rmhip_blk_lu(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf* ipiv_out, int
     std::vector<int> ipiv;
     int inf = 0;
     {
-        const int frc = lu_factor_device(c, va.ptr, va.rows, va.cols, va.ld, nullptr, &inf, &ipiv);
+        int frc = RMHIP_LU_GROWTH;
+        if (c->blk_lu_solve_path && va.rows > 0 && va.cols > 0) {
+            // the solve path's kernels (k_rp_top / k_rp_below_mfma / matrix-core solves): the block is saved first - a multiplier beyond
+            // the bound clobbers it - and restored for the grid-wide rule
+            std::shared_ptr<Allocation> keep;
+            RMHIP_TRY(c->alloc_device(va.rows * va.cols, &keep));
+            RMHIP_HIP_CHECK(hipMemcpy2DAsync(keep->ptr, va.rows * sizeof(double), va.ptr, va.ld * sizeof(double), va.rows * sizeof(double), va.cols,
+                                             hipMemcpyDeviceToDevice, c->stream));
+            frc = lu_factor_device(c, va.ptr, va.rows, va.cols, va.ld, nullptr, &inf, &ipiv, 1);
+            if (frc == RMHIP_LU_GROWTH || frc == RMHIP_LU_RETRY) {
+                RMHIP_HIP_CHECK(hipMemcpy2DAsync(va.ptr, va.ld * sizeof(double), keep->ptr, va.rows * sizeof(double), va.rows * sizeof(double), va.cols,
+                                                 hipMemcpyDeviceToDevice, c->stream));
+                RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+                frc = RMHIP_LU_GROWTH;
+            }
+        }
+        if (frc == RMHIP_LU_GROWTH) frc = lu_factor_device(c, va.ptr, va.rows, va.cols, va.ld, nullptr, &inf, &ipiv);
         if (frc == RMHIP_LU_RETRY)  // in place: the block is clobbered and there is no copy to restart from
             return fail(RMHIP_ERR_HIP, "blk_lu: panel workgroups were not co-resident (device shared?); the block is invalid");
         RMHIP_TRY(frc);

@@ -121,6 +121,17 @@ int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n,
             if (b >= q) return local_row_offset(b);
         return nloc;
     };
+    // the panels are factored with the solve path's kernels (RMHIP_RP_SOLVE_PATH=0: the grid-wide panel kernels of `lu`); the flag goes
+    // back on every way out
+    struct SolvePathScope {
+        Context* c;
+        bool saved;
+        ~SolvePathScope() { c->blk_lu_solve_path = saved; }
+    } sp_scope{c, c->blk_lu_solve_path};
+    {
+        const char* v = std::getenv("RMHIP_RP_SOLVE_PATH");
+        c->blk_lu_solve_path = !(v && v[0] == '0');
+    }
     const size_t n_direct = nblocks > (size_t)world ? nblocks - (size_t)world : 0;  // panels whose owner still has a block below the tile
     const bool overlap = world > 1;  // asynchronous broadcasts on the communication stream (look-ahead)
     Temps temps(ctx);

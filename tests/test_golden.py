@@ -4,8 +4,8 @@ import pytest
 
 import numpy as np
 
-from workloads import (OracleOps, golden_elementwise_math, golden_image_cases, golden_monte_carlo_cases, lcg_image_field,
-                       lcg_monte_carlo_price)
+from workloads import (OracleOps, golden_elementwise_math, golden_image_cases, golden_monte_carlo_cases, golden_reference_f64,
+                       lcg_image_field, lcg_monte_carlo_price)
 
 
 @pytest.mark.parametrize("case", golden_monte_carlo_cases(), ids=lambda c: f"M{c['M']}_T{c['T']}")
@@ -37,3 +37,20 @@ def test_oracle_elementwise_chain_matches_reference_script(oracle, case):
     y2 = oracle.elementwise_math_chain(x)[:, 0]
     got = y2[case["indices"]]
     assert np.max(np.abs(got - np.array(case["y2"]))) <= 2e-6, np.max(np.abs(got - np.array(case["y2"])))
+
+
+# ---- the same comparators forced to f64 (tests/golden/reference_f64.json): the f64 oracle pinned at rounding level ---------------------
+@pytest.mark.parametrize("case", golden_reference_f64()["elementwise_math"], ids=lambda c: f"f64_points{c['points']}")
+def test_oracle_elementwise_chain_matches_the_f64_run_of_the_reference_script(oracle, case):
+    n = case["points"]
+    x = np.linspace(0.0, 4.0 * np.pi, n).reshape(n, 1)
+    y2 = oracle.elementwise_math_chain(x)[:, 0]
+    # numpy's and the C library's sin / exp / cos / tanh differ by an ulp or two per call; |y2| <= 1.1
+    assert np.max(np.abs(y2[case["indices"]] - np.array(case["y2"]))) <= 1e-14
+    assert abs(float(y2.sum()) - case["y2_sum"]) <= 1e-12 * n ** 0.5 + 1e-13 * abs(case["y2_sum"])
+
+
+@pytest.mark.parametrize("case", golden_reference_f64()["monte_carlo_lcg"]["cases"], ids=lambda c: f"f64_M{c['M']}_T{c['T']}")
+def test_oracle_lcg_monte_carlo_matches_the_f64_run_of_the_reference_script(oracle, case):
+    price = lcg_monte_carlo_price(OracleOps(oracle), case["M"], case["T"], f32_constants=False)
+    assert abs(price - case["price"]) <= 1e-12 * max(1.0, abs(case["price"])), (price, case["price"])

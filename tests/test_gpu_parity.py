@@ -853,6 +853,32 @@ def test_lcg_monte_carlo_vs_oracle_and_reference_golden(prov, oracle, case):
     assert abs(g - case["price"]) <= 2e-4 * max(1.0, abs(case["price"]))  # the reference script's own output (f32 pipeline)
 
 
+def test_device_pipelines_vs_the_f64_runs_of_the_reference_scripts(prov):
+    """tests/golden/reference_f64.json: the reference's numpy comparators run in f64 (make_golden.py main_f64).  The device's per-op
+    kernels - the unfused path the planner takes without a fusion plan - reproduce the LCG Monte-Carlo price to 1e-10 (SURVEY.md 8(d)
+    config 4) and the fused 14-op chain the script's y2 samples to a few ulp."""
+    from planner_requests import elementwise_math_plan
+    from workloads import golden_reference_f64
+
+    ref = golden_reference_f64()
+    for case in ref["monte_carlo_lcg"]["cases"][:2]:
+        g = lcg_monte_carlo_price(ProviderOps(prov), case["M"], case["T"], f32_constants=False)
+        assert abs(g - case["price"]) <= 1e-10 * max(1.0, abs(case["price"])), (g, case)
+    plan, out_id = elementwise_math_plan()
+    shader = plan.generate_wgsl_for_output(out_id, "f64")
+    consts = [prov.upload(np.array([v]), (1, 1)) for v in (10.0, 4.0, 0.25, 2.0, 0.1)]
+    for case in ref["elementwise_math"]:
+        n = case["points"]
+        hx = prov.upload(np.linspace(0.0, 4.0 * np.pi, n), (n, 1))
+        hy = prov.fused_elementwise(shader, [hx] + consts, (n, 1), n)
+        y2 = prov.download(hy)
+        assert np.max(np.abs(y2[case["indices"]] - np.array(case["y2"]))) <= 2e-14
+        prov.free(hx)
+        prov.free(hy)
+    for h in consts:
+        prov.free(h)
+
+
 def test_rng_monte_carlo_price_vs_oracle(prov, oracle):
     # benchmarks/monte-carlo-analysis/runmat_rng.m in f64 on the CPU-parity randn stream
     M, T = 200000, 4

@@ -69,11 +69,15 @@ class ProviderOps:
         self.p.free(a)
 
 
-def lcg_monte_carlo_price(ops, M, T, S0=100.0, mu=0.05, sigma=0.2, dt=1.0 / 252.0, K=100.0, seed=0):
+def lcg_monte_carlo_price(ops, M, T, S0=100.0, mu=0.05, sigma=0.2, dt=1.0 / 252.0, K=100.0, seed=0, f32_constants=True):
     """benchmarks/monte-carlo-analysis/runmat_lcg.m:27-52 in f64 (drift/scale pre-rounded through
-    f32 exactly as the reference scripts do)."""
-    drift = float(np.float32((mu - 0.5 * sigma * sigma) * dt))
-    scale = float(np.float32(sigma) * np.sqrt(np.float32(dt)))
+    f32 exactly as the reference scripts do; f32_constants=False: the all-f64 pipeline of tests/golden/reference_f64.json)."""
+    if f32_constants:
+        drift = float(np.float32((mu - 0.5 * sigma * sigma) * dt))
+        scale = float(np.float32(sigma) * np.sqrt(np.float32(dt)))
+    else:
+        drift = float((mu - 0.5 * sigma * sigma) * dt)
+        scale = float(sigma * np.sqrt(dt))
     rid = ops.tensor(np.arange(M, dtype=np.float64).reshape(M, 1))
     S = ops.tensor(np.full((M, 1), S0))
     two32 = ops.tensor(np.array([[4294967296.0]]))
@@ -95,6 +99,11 @@ def lcg_monte_carlo_price(ops, M, T, S0=100.0, mu=0.05, sigma=0.2, dt=1.0 / 252.
 
 def golden_monte_carlo_cases():
     return json.loads((GOLDEN / "monte_carlo_lcg.json").read_text())["cases"]
+
+
+def golden_reference_f64():
+    """The comparators forced to f64 (tests/golden/make_golden.py main_f64): chain samples and LCG Monte-Carlo prices at full precision."""
+    return json.loads((GOLDEN / "reference_f64.json").read_text())
 
 
 def golden_image_cases():
