@@ -387,7 +387,7 @@ def test_rust_shim_op_codes_are_the_header_enums():
 
 
 def test_every_environment_knob_is_documented():
-    """Every RMHIP_* variable the library reads with getenv is named in INTEGRATION.md or DESIGN.md (developer knobs included:
+    """Every RMHIP_* variable the library reads with getenv is named in INTEGRATION.md, DESIGN.md or docs/*.md (developer knobs included:
     a maintainer who meets one in a bug report must be able to look it up)."""
     import re
 
@@ -396,6 +396,6 @@ def test_every_environment_knob_is_documented():
     for f in list(src.glob("*.cpp")) + list(src.glob("*.hip")) + list(src.glob("*.h")):
         knobs.update(re.findall(r'getenv\("(RMHIP_[A-Z0-9_]+)"\)', f.read_text()))
     assert len(knobs) > 20
-    docs = (ROOT / "INTEGRATION.md").read_text() + (ROOT / "DESIGN.md").read_text()
+    docs = (ROOT / "INTEGRATION.md").read_text() + (ROOT / "DESIGN.md").read_text() + "".join(f.read_text() for f in sorted((ROOT / "docs").glob("*.md")))
     missing = sorted(k for k in knobs if k not in docs)
     assert not missing, f"undocumented environment variables: {missing}"
