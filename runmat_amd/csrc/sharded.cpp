@@ -47,6 +47,10 @@ struct Temps {
             }
     }
     ~Temps() {
+        // an early way out may leave an asynchronous broadcast in flight on the communication stream whose target is one of these
+        // tiles: the context's stream waits for it before any of them goes back to the pool
+        int r = 0, w = 1;
+        if (rmhip_comm_rank(ctx, &r, &w) == RMHIP_OK && w > 1) (void)rmhip_comm_wait(ctx);
         for (rmhip_buf id : ids)
             if (id) (void)rmhip_free(ctx, id);
     }

@@ -667,10 +667,10 @@ int rmhip_conv1d(rmhip_ctx* ctx, rmhip_buf signal, rmhip_buf kernel, int mode, i
     }
     // conv1d_output_shape (simple_provider.rs:1780-1787): [1, len] or [len, 1], an empty result keeps the orientation
     const size_t shape[2] = {column ? (size_t)len : 1, column ? 1 : (size_t)len};
+    if (len > 0x7fffffffull * kB) return fail(RMHIP_ERR_UNSUPPORTED, "conv1d: %llu outputs", len);  // before the output exists
     Buffer ob;
     RMHIP_TRY(c->new_buffer(shape, 2, out, &ob));
     if (len == 0) return RMHIP_OK;
-    if (len > 0x7fffffffull * kB) return fail(RMHIP_ERR_UNSUPPORTED, "conv1d: %llu outputs", len);
     const int in_lds = lb <= LDS_TAPS;
     hipLaunchKernelGGL(k_conv1d, dim3(grid_for(len)), dim3(kB), in_lds ? lb * sizeof(double) : 0, c->stream, ab.data(), la, bb.data(), lb, start, len, in_lds, ob.data());
     c->tel.kernel_launches++;
@@ -710,7 +710,12 @@ int rmhip_conv2d(rmhip_ctx* ctx, rmhip_buf signal, rmhip_buf kernel, int mode, r
     Buffer ob;
     RMHIP_TRY(c->new_buffer(shape, 2, out, &ob));
     if (ob.numel == 0) return RMHIP_OK;
-    if (ob.numel > 0x7fffffffull * kB) return fail(RMHIP_ERR_UNSUPPORTED, "conv2d: %zu outputs", ob.numel);
+    if (ob.numel > 0x7fffffffull * kB) {  // (the output is registered by now: released here, the caller never learns its id)
+        const size_t too_many = ob.numel;
+        (void)rmhip_free(ctx, *out);
+        *out = 0;
+        return fail(RMHIP_ERR_UNSUPPORTED, "conv2d: %zu outputs", too_many);
+    }
     const size_t patch_bytes = (size_t)(CONV_TX + br_n - 1) * (size_t)(CONV_TY + bc_n - 1) * sizeof(double);
     const u64 tiles_y = (cols + CONV_TY - 1) / CONV_TY;
     if (br_n <= 64 && bc_n <= 512 && patch_bytes <= 48u * 1024 && tiles_y <= 65535) {
@@ -761,7 +766,12 @@ int rmhip_moving_window(rmhip_ctx* ctx, rmhip_buf a, int dim, size_t before, siz
     RMHIP_TRY(c->new_buffer(out_shape, out_rank, out, &ob));
     A.total = ob.numel;
     if (ob.numel == 0) return RMHIP_OK;
-    if (ob.numel > 0x7fffffffull * kB) return fail(RMHIP_ERR_UNSUPPORTED, "moving_window: %zu outputs", ob.numel);
+    if (ob.numel > 0x7fffffffull * kB) {  // (the output is registered by now: released here, the caller never learns its id)
+        const size_t too_many = ob.numel;
+        (void)rmhip_free(ctx, *out);
+        *out = 0;
+        return fail(RMHIP_ERR_UNSUPPORTED, "moving_window: %zu outputs", too_many);
+    }
     const dim3 grid(grid_for(ob.numel)), block(kB);
     switch (op) {
         case 0: hipLaunchKernelGGL(k_moving<0>, grid, block, 0, c->stream, ab.data(), A, ob.data()); break;
@@ -889,7 +899,12 @@ int rmhip_imfilter(rmhip_ctx* ctx, rmhip_buf image, rmhip_buf kernel, int paddin
     RMHIP_TRY(c->new_buffer(oshape.data(), oshape.size(), out, &ob));
     A.total = ob.numel;
     if (ob.numel == 0) return RMHIP_OK;
-    if (ob.numel > 0x7fffffffull * kB) return fail(RMHIP_ERR_UNSUPPORTED, "imfilter: %zu outputs", ob.numel);
+    if (ob.numel > 0x7fffffffull * kB) {  // (the output is registered by now: released here, the caller never learns its id)
+        const size_t too_many = ob.numel;
+        (void)rmhip_free(ctx, *out);
+        *out = 0;
+        return fail(RMHIP_ERR_UNSUPPORTED, "imfilter: %zu outputs", too_many);
+    }
     for (int d = 0; d < 4; ++d)
         if (A.out[d] == 0) A.out[d] = 1;  // (never reached with numel > 0)
     const u64 planes = (u64)A.out[2] * (u64)A.out[3];  // with a two-dimensional filter every further image dimension is a batch of planes
@@ -929,7 +944,12 @@ int rmhip_interp1(rmhip_ctx* ctx, rmhip_buf x, rmhip_buf y, rmhip_buf xq, size_t
     Buffer ob;
     RMHIP_TRY(c->new_buffer(output_shape, out_rank, out, &ob));
     if (ob.numel == 0) return RMHIP_OK;
-    if (ob.numel > 0x7fffffffull * kB) return fail(RMHIP_ERR_UNSUPPORTED, "interp1: %zu outputs", ob.numel);
+    if (ob.numel > 0x7fffffffull * kB) {  // (the output is registered by now: released here, the caller never learns its id)
+        const size_t too_many = ob.numel;
+        (void)rmhip_free(ctx, *out);
+        *out = 0;
+        return fail(RMHIP_ERR_UNSUPPORTED, "interp1: %zu outputs", too_many);
+    }
     hipLaunchKernelGGL(k_interp1, dim3(grid_for(ob.numel)), dim3(kB), 0, c->stream, xb.data(), yb.data(), qb.data(), (u64)sample_len, (u64)query_len, (u64)ob.numel, nearest ? 1 : 0,
                        extrapolation, extrapolation_value, ob.data());
     c->tel.kernel_launches++;
