@@ -2565,7 +2565,11 @@ static int getrf_super(LuState& s, size_t kmin) {
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
     if (!c->lu_mid_stream) RMHIP_HIP_CHECK(hipStreamCreateWithPriority(&c->lu_mid_stream, hipStreamNonBlocking, (prio_low + prio_high) / 2));
-    if (!c->lu_far_stream) RMHIP_HIP_CHECK(hipStreamCreateWithPriority(&c->lu_far_stream, hipStreamNonBlocking, prio_low));
+    // Both update streams at the DEFAULT priority: HIP keeps default-priority streams inside a pool of four hardware queues, a stream of
+    // another priority gets a queue of its own - and with five queues in use by the process (null stream, main, mid, a low-priority far
+    // and any fourth stream of the driver's) every solve took 100-120 ms instead of 72: the same cliff hit the prep-stream, band-split
+    // and seat-holder experiments of round 5.  With far at the default priority a fourth stream costs 2 ms, not 47 (docs/EXPERIMENTS.md R5).
+    if (!c->lu_far_stream) RMHIP_HIP_CHECK(hipStreamCreateWithPriority(&c->lu_far_stream, hipStreamNonBlocking, (prio_low + prio_high) / 2));
     hipStream_t mid = c->lu_mid_stream, far = c->lu_far_stream;
     std::shared_ptr<Allocation> yield_ctl;  // the yield word (outlives the guard below)
     struct Restore {
