@@ -2593,16 +2593,21 @@ static int getrf_super(LuState& s, size_t kmin) {
     static const int gemm_prio_on = std::getenv("RMHIP_LU_GEMM_PRIO") ? std::atoi(std::getenv("RMHIP_LU_GEMM_PRIO")) : 1;
     c->gemm_chain_prio = gemm_prio_on != 0;
     // ---- the plan: super-panels (W, nb) while more than super_rows rows remain, single panels afterwards
-    static const std::vector<std::pair<size_t, size_t>> seq = [] {
-        auto q = parse_super_seq(std::getenv("RMHIP_LU_SUPER_SEQ"));
-        if (q.empty()) q = {{512, 512}, {1024, 512}, {2048, 512}};
-        return q;
-    }();
+    // (defaults by order, interleaved runs of scripts/lu_super_ab.sh: n = 16384 69.7-69.9 ms with 256 / 1024 / 2048-column super-panels of
+    // 256-column panels down to 4096 remaining rows against 71.6-72.7 with the plan below; 12288 41.0-41.5 against 40.9, 8192 22.1 against 20.8:
+    // the shorter plan stays below 14336)
+    static const std::vector<std::pair<size_t, size_t>> seq_env = parse_super_seq(std::getenv("RMHIP_LU_SUPER_SEQ"));
+    const bool large = kmin >= 14336;
+    const std::vector<std::pair<size_t, size_t>> seq =
+        !seq_env.empty() ? seq_env
+                         : (large ? std::vector<std::pair<size_t, size_t>>{{256, 256}, {1024, 256}, {2048, 256}}
+                                  : std::vector<std::pair<size_t, size_t>>{{512, 512}, {1024, 512}, {2048, 512}});
     static const std::pair<size_t, size_t> late = [] {
         auto q = parse_super_seq(std::getenv("RMHIP_LU_SUPER_LATE"));
         return q.empty() ? std::pair<size_t, size_t>{128, 128} : q[0];
     }();
-    static const size_t super_rows = std::getenv("RMHIP_LU_SUPER_ROWS") ? (size_t)std::atoll(std::getenv("RMHIP_LU_SUPER_ROWS")) : 6144;
+    static const long super_rows_env = std::getenv("RMHIP_LU_SUPER_ROWS") ? std::atol(std::getenv("RMHIP_LU_SUPER_ROWS")) : -1;
+    const size_t super_rows = super_rows_env >= 0 ? (size_t)super_rows_env : (large ? 4096 : 6144);
     std::vector<SuperPanel> plan;
     for (size_t s0 = 0, i = 0; s0 < kmin;) {
         const size_t rem = kmin - s0;

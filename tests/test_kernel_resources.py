@@ -81,6 +81,20 @@ def test_lu_kernels_do_not_spill():
         assert r["vgpr"] + r["agpr"] <= 96, (name, r)
 
 
+def test_solve_path_chain_kernels_fit_beside_an_update_block():
+    """Round 5's occupancy facts: the update streams' eight-wave block - the YIELD instantiation included - holds two
+    waves of <= 144 registers per SIMD (288 of 512), and every chain kernel of the solve path must fit into the 224 that are left on
+    the same SIMD, or it waits for a 260-us deep tile to retire: k_rp_top (one wave per SIMD), the matrix-core rows-below kernel and
+    triangular solve (one-wave workgroups).  None may spill."""
+    gemm = _resources("dgemm.hip")
+    for name, r in {**_pick(gemm, "k_dgemm_w8ILb1ELb0ELb0ELi0ELb1E"), **_pick(gemm, "k_dgemm_w8ILb1ELb0ELb0ELi0ELb0E")}.items():
+        assert r["vgpr"] + r["agpr"] <= 144 and r["scratch"] == 0, (name, r)
+    lu = _resources("lu.hip")
+    for key in ("8k_rp_topILb0E", "k_rp_below_mfma", "k_trsm_lower_mfma"):
+        for name, r in _pick(lu, key).items():
+            assert r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 224, (name, r)
+
+
 def test_special_kernels_keep_their_register_budgets():
     res = _resources("special.hip")
     # the tall-skinny Gram kernel holds an 8 x 8 block of products and two rows of operands per thread: no spills, two workgroups per CU
