@@ -1017,8 +1017,14 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
     // (skinny products - at most 64 rows or columns of output - waste half of every 128 x 128 tile or more: 100000 x 50 x 50 52 -> 30 us,
     // 200000 x 16 x 16 34 -> 20 us on the 64 x 64 tiles, whatever the block count)
     const bool skinny = (m <= (size_t)SM || n <= (size_t)SN) && k < 1024 && !c->in_lookahead;  // (longer k: split-K above)
-    const bool small_shape = !ep && !ta && !tb && splits == 1 && (c->gemm_lds_pad == 0 || small_force) && k > 0 &&
-                             ((k <= 1024 && (size_t)blocks * 2 <= (size_t)c->num_cus) || skinny || small_force);
+    // The look-ahead LU's update streams run their few-tile products - the dgemm steps of the W-wide triangular solves, 14-112 tiles of
+    // 128 x 128 for 0.1-0.2 ms each - on the 64 x 64 tiles as well: four times the blocks, 16384 69.1 -> 67.6 ms, 8192 20.6 -> 20.2
+    // (RMHIP_LU_SMALL_UPD = largest k, 0 = off; _BLOCKS = most 128 x 128 tiles)
+    static const long small_upd = std::getenv("RMHIP_LU_SMALL_UPD") ? std::atol(std::getenv("RMHIP_LU_SMALL_UPD")) : 1024;
+    static const long small_upd_blocks = std::getenv("RMHIP_LU_SMALL_UPD_BLOCKS") ? std::atol(std::getenv("RMHIP_LU_SMALL_UPD_BLOCKS")) : 128;
+    const bool upd_small = small_upd > 0 && c->gemm_lds_pad != 0 && c->in_lookahead && (long)k <= small_upd && (long)blocks <= small_upd_blocks;
+    const bool small_shape = !ep && !ta && !tb && splits == 1 && (c->gemm_lds_pad == 0 || small_force || upd_small) && k > 0 &&
+                             ((k <= 1024 && (size_t)blocks * 2 <= (size_t)c->num_cus) || skinny || small_force || upd_small);
     const bool small_whole = (m % SM == 0) && (n % SN == 0) && (k % BK == 0) && vec_ok;
     if (small_on && small_shape && (small_whole || guard_ok)) {
         g.tiles_m = (unsigned)((m + SM - 1) / SM);

@@ -2227,6 +2227,19 @@ static int update_columns(LuState& s, size_t j, size_t w, size_t c0, size_t c1) 
     RMHIP_TRY(prep_columns(s, j, w, c0, c1));
     return gemm_columns(s, j, w, c0, c1);
 }
+// Incremental form of prep_columns(S0, W, c0, c1) for a super-panel [S0, S0 + W) whose inner panels finish one after the other: once
+// panel [j, j + w) is factored (and its interchanges have reached the super-panel's left columns), columns [c0, c1) right of the
+// super-panel receive its interchanges and ITS block row of U - the rows still lack the inner panels before it:
+//   A[j : j+w, c] -= L[j : j+w, S0 : j] U[S0 : j, c];   A[j : j+w, c] <- L_jj^-1 A[j : j+w, c]
+// After the last inner panel the columns hold what the W-wide solve would have produced (same operations, grouped by panel instead
+// of by the solve's recursive halving) and only the deep rank-W update is left for the boundary.
+static int iprep_columns(LuState& s, size_t S0, size_t j, size_t w, size_t c0, size_t c1) {
+    if (c1 <= c0) return RMHIP_OK;
+    RMHIP_TRY(laswp(s, c0, c1, j, j + w));
+    double* A12 = s.A + j + c0 * s.lda;
+    if (j > S0) RMHIP_TRY(lu_dgemm(s.c, w, c1 - c0, j - S0, -1.0, s.A + j + S0 * s.lda, s.lda, s.A + S0 + c0 * s.lda, s.lda, 1.0, A12, s.lda));
+    return trsm_lower_rec(s.c, s.A + j + j * s.lda, s.lda, w, A12, s.lda, c1 - c0);
+}
 
 static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
     Context* c = s.c;
@@ -2653,6 +2666,13 @@ static int getrf_super(LuState& s, size_t kmin) {
     hipEvent_t ev_mid = nullptr;       // everything the mid stream was given so far
     hipEvent_t ev_far_next = nullptr;  // far finished the columns of the super-panel after the one in flight
     hipEvent_t ev_far_all = nullptr;
+    hipEvent_t ev_iprep = nullptr;     // the mid stream's last incremental block row of U for the next super-panel's columns
+    // incremental block rows of U for the next super-panel's columns (iprep_columns): 12288 40.4-40.8 -> 39.3-39.9 ms with the 512-column
+    // plan; with the large-order plan the far stream delivers those columns too late - the mid stream stalls behind the wait and
+    // 16384 goes 69.4 -> 73 ms (docs/EXPERIMENTS.md R5 22)
+    static const int iprep_env = std::getenv("RMHIP_LU_IPREP") ? std::atoi(std::getenv("RMHIP_LU_IPREP")) : -1;
+    const bool iprep = iprep_env >= 0 ? iprep_env != 0 : !large;
+    static const int iprep_split = std::getenv("RMHIP_LU_IPREP_SPLIT") ? std::atoi(std::getenv("RMHIP_LU_IPREP_SPLIT")) : 1;
     int rc = RMHIP_OK;
     const bool verbose = std::getenv("RMHIP_LU_VERBOSE") != nullptr;
     // developer aid (RMHIP_LU_TIMELINE=1): timed events on the main stream around every super-panel boundary, printed after the factorisation
@@ -2700,6 +2720,18 @@ static int getrf_super(LuState& s, size_t kmin) {
                     if (rc == RMHIP_OK && j > S0) rc = laswp(s, S0, j, j, j + w);  // the super-panel's own left columns
                 }
                 ev_mid = record(mid);
+                if (iprep && S1 < S1n) {
+                    // the next super-panel's columns receive this panel's block row of U now (not at the boundary): they are complete up
+                    // to the previous super-panel once far's first update of boundary J - 1 is in
+                    // (on a stream of their own instead: 76-79 ms at n = 16384)
+                    if (ev_far_next) (void)hipStreamWaitEvent(mid, ev_far_next, 0);
+                    {
+                        StreamScope scope(c, mid, mid_pad);
+                        rc = iprep_columns(s, S0, j, w, S1, S1n);
+                    }
+                    if (rc != RMHIP_OK) break;
+                    ev_iprep = record(mid);
+                }
             } else {
                 // the super-panel is complete: its last panel's interchanges reach its left columns first - everything below reads L21
                 // of the whole super-panel
@@ -2720,7 +2752,14 @@ static int getrf_super(LuState& s, size_t kmin) {
                     tl_mark("J" + std::to_string(J) + " mid ready");
                     if (ev_far_next) (void)hipStreamWaitEvent(main_stream, ev_far_next, 0);
                     tl_mark("J" + std::to_string(J) + " far ready");
-                    rc = update_columns(s, S0, W, next, t0);  // rank-W look-ahead update on main
+                    if (iprep && multi) {
+                        // the columns hold every block row of U but the last panel's: that one, then the deep update alone
+                        if (ev_iprep) (void)hipStreamWaitEvent(main_stream, ev_iprep, 0);
+                        rc = iprep_columns(s, S0, j, w, next, t0);
+                        if (rc == RMHIP_OK) rc = gemm_columns(s, S0, W, next, t0);
+                    } else {
+                        rc = update_columns(s, S0, W, next, t0);  // rank-W look-ahead update on main
+                    }
                     if (rc != RMHIP_OK) break;
                     tl_mark("J" + std::to_string(J) + " LA done");
                 }
@@ -2729,10 +2768,24 @@ static int getrf_super(LuState& s, size_t kmin) {
                     if (ev_far_next) (void)hipStreamWaitEvent(mid, ev_far_next, 0);
                     {
                         StreamScope scope(c, mid, mid_pad);
-                        rc = update_columns(s, S0, W, t0, S1n);
+                        if (iprep && multi) {
+                            rc = iprep_columns(s, S0, j, w, t0, S1n);
+                            // the second panel's columns first: the main stream's next look-ahead update waits for these only
+                            const size_t nbn = plan[J + 1].nb, t1 = (iprep_split && t0 + nbn < S1n) ? t0 + nbn : S1n;
+                            if (rc == RMHIP_OK) rc = gemm_columns(s, S0, W, t0, t1);
+                            if (rc == RMHIP_OK && t1 < S1n) {
+                                ev_mid = record(mid);
+                                rc = gemm_columns(s, S0, W, t1, S1n);
+                            } else if (rc == RMHIP_OK) {
+                                ev_mid = record(mid);
+                            }
+                        } else {
+                            rc = update_columns(s, S0, W, t0, S1n);
+                            if (rc == RMHIP_OK) ev_mid = record(mid);
+                        }
                     }
                     if (rc != RMHIP_OK) break;
-                    ev_mid = record(mid);
+                    ev_iprep = nullptr;
                 }
                 // far: everything right of the next super-panel - interchange, W-wide solve, rank-W update (the next super-panel's columns
                 // first: event) - then the interchanges of the columns left of this super-panel.
@@ -2745,8 +2798,10 @@ static int getrf_super(LuState& s, size_t kmin) {
                     StreamScope scope(c, far, far_pad);
                     ev_far_next = nullptr;
                     if (S1n < s.cols) {
-                        rc = prep_columns(s, S0, W, S1n, s.cols);
                         const size_t cn = S1nn < s.cols ? S1nn : s.cols;
+                        // (tried: interchange + solve + update of the next super-panel's columns first, then the rest's - a second
+                        // 31-launch solve per boundary on this stream: 69.4 -> 73.8 ms; the far stream is the bottleneck of the first phase)
+                        rc = prep_columns(s, S0, W, S1n, s.cols);
                         if (rc == RMHIP_OK && cn > S1n) {
                             rc = gemm_columns(s, S0, W, S1n, cn);
                             ev_far_next = record(far);

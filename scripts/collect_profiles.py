@@ -17,7 +17,7 @@ for d in sorted(src.glob("trace_*")):
     b = src / f"trace_{w}_bench.json"
     if b.exists() and b.stat().st_size:
         shutil.copy(b, dst / f"{tag}_{w}_bench_under_rocprof.json"); n += 1
-for name in ("mldivide_timeline.txt", "tier2_rates.txt", "red2_rates.txt", "red_shapes.txt", "gemm_variants.txt", "rng_accuracy.txt", "solve_sizes.txt",
+for name in ("mldivide_timeline.txt", "lu_attribution.txt", "mldivide_main_events.txt", "tier2_rates.txt", "red2_rates.txt", "red_shapes.txt", "gemm_variants.txt", "rng_accuracy.txt", "solve_sizes.txt",
              "bench_default.json", "offload_calibration.json"):
     if (src / name).exists() and (src / name).stat().st_size:
         shutil.copy(src / name, dst / f"{tag}_{name}"); n += 1

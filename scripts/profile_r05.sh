@@ -16,6 +16,6 @@ T=$ROOT/gpurun_out/lu_r05trace
   echo; echo "== main stream, per 10 ms window: launches x mean duration"; python $ROOT/scripts/lu_main_stats.py $T;
   echo; echo "== schedule skeleton: kernels >= 400 us and main-stream idle gaps >= 200 us"; python $ROOT/scripts/lu_skeleton.py $T 400 200; } > "$OUT/mldivide_timeline.txt" 2>&1
 { echo "== wall clock of x = A\\b at n = 16384 (scripts/lu_trace.py, 4 solves each: first is cold), interleaved on one box";
-  bash $ROOT/scripts/lu_super_ab.sh - RMHIP_LU_SUPER=0 RMHIP_LU_YIELD=0 RMHIP_LU_GEMM_PRIO=0 RMHIP_LU_RB_MFMA=0 RMHIP_LU_TRSM_MFMA=0 RMHIP_LU_RB_MFMA=0,RMHIP_LU_TRSM_MFMA=0,RMHIP_LU_YIELD=0,RMHIP_LU_GEMM_PRIO=0 RMHIP_LU_SUPER=0,RMHIP_LU_RB_MFMA=0,RMHIP_LU_TRSM_MFMA=0 - RMHIP_LU_SKIP=2 RMHIP_LU_SKIP=13 RMHIP_LU_SUPER_SEQ=512:512/1024:512 RMHIP_LU_SUPER_SEQ=512:512 RMHIP_LU_SUPER_LATE=512:128 RMHIP_LU_FAR_PAD=0 RMHIP_LU_MID_PAD=0 -;
+  bash $ROOT/scripts/lu_super_ab.sh - RMHIP_LU_SUPER=0 RMHIP_LU_YIELD=0 RMHIP_LU_GEMM_PRIO=0 RMHIP_LU_RB_MFMA=0 RMHIP_LU_TRSM_MFMA=0 RMHIP_LU_RB_MFMA=0,RMHIP_LU_TRSM_MFMA=0,RMHIP_LU_YIELD=0,RMHIP_LU_GEMM_PRIO=0 RMHIP_LU_SUPER=0,RMHIP_LU_RB_MFMA=0,RMHIP_LU_TRSM_MFMA=0 - RMHIP_LU_SKIP=2 RMHIP_LU_SKIP=13 RMHIP_LU_SUPER_SEQ=512:512/1024:512/2048:512,RMHIP_LU_SUPER_ROWS=6144 RMHIP_LU_SUPER_SEQ=512:512 RMHIP_LU_SUPER_LATE=512:128 RMHIP_LU_FAR_PAD=0 RMHIP_LU_MID_PAD=0 -;
   for n in 12288 8192 4096; do echo "== n = $n"; N=$n bash $ROOT/scripts/lu_super_ab.sh - RMHIP_LU_SUPER=0,RMHIP_LU_RB_MFMA=0,RMHIP_LU_TRSM_MFMA=0; done; } > "$OUT/lu_attribution.txt" 2>&1
 cd /tmp; RMHIP_LU_TIMELINE=1 python $ROOT/scripts/lu_trace.py 16384 2 2>&1 | grep -E "timeline|rep=" | awk '/rep=0/{f=1} f' | grep -v "rep=0" > "$OUT/mldivide_main_events.txt"

@@ -51,6 +51,8 @@ SWITCHES = [
     {"RMHIP_LU_TRSM_MFMA": "0"},
     {"RMHIP_LU_YIELD": "0", "RMHIP_LU_GEMM_PRIO": "0"},
     {"RMHIP_LU_SUPER_SEQ": "512:256/1024:256", "RMHIP_LU_SUPER_ROWS": "2048", "RMHIP_LU_SUPER_LATE": "512:128"},  # another plan
+    {"RMHIP_LU_IPREP": "0", "RMHIP_LU_SMALL_UPD": "0"},           # W-wide solve at the boundary, 128 x 128 tiles only on the update streams
+    {"RMHIP_LU_IPREP": "1", "RMHIP_LU_IPREP_SPLIT": "0", "RMHIP_LU_SUPER_SEQ": "256:256/1024:256/2048:256", "RMHIP_LU_SUPER_ROWS": "4096"},  # the large-order plan with incremental block rows
 ]
 
 
@@ -68,8 +70,14 @@ def test_every_switch_combination_solves_to_the_same_accuracy(n):
 
 
 def test_two_level_driver_is_bit_identical_from_run_to_run():
-    r = _solve(12288, {}, reps=3)
+    r = _solve(12288, {}, reps=3)  # 512-column plan, incremental block rows of U for the next super-panel
     assert r["same"] and r["res"] <= 1e-12 * 12288, r
+
+
+def test_large_order_plan_is_bit_identical_from_run_to_run():
+    r = _solve(14336, {}, reps=2)  # first order of the 256-column plan (W-wide solves at the boundaries)
+    assert r["same"] and r["res"] <= 1e-12 * 14336, r
+    assert r["fallbacks"] in (0, None), r
 
 
 def test_small_orders_take_the_matrix_core_kernels_too():
