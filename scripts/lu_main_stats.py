@@ -13,8 +13,8 @@ cnt = collections.Counter(r[3] for r in last)
 main = cnt.most_common(1)[0][0]
 end = max(r[1] for r in last)
 print(f"span {(end - s0) / 1e6:.2f} ms; main stream {main} ({cnt[main]} kernels)")
-names = ["k_rp_top<false>", "k_rp_below<64, false>", "k_laswp_lists", "k_trsm_fused", "k_trsm_lower_2p", "k_dgemm_small", "k_dgemm<"]
-print("window      " + "".join(f"{n[:14]:>22s}" for n in names) + "   gaps")
+names = ["k_rp_top<false>", "k_rp_below_mfma", "k_laswp_lists", "k_trsm_lower_mfma<4>", "k_trsm_lower_mfma<8>", "k_dgemm_small", "k_dgemm<"]
+print("window      " + "".join(f"{n[:20]:>22s}" for n in names) + "   gaps")
 nw = int((end - s0) / 1e6 / win) + 1
 prev_end = {}
 for w in range(nw):
