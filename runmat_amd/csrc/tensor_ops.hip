@@ -195,6 +195,27 @@ __global__ void __launch_bounds__(kBlock) k_scatter(T* __restrict__ target, cons
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
         if (!winner || winner[i]) target[idx[i]] = values[i];
 }
+// Large index sets: bounds and duplicates resolved on the device.  Pass 1 leaves in owner[idx] the largest position + 1 that carries
+// idx (the reference's sequential loop lets the LAST occurrence win, simple_provider.rs:2698-2711) and in *bad the smallest position
+// whose index is out of bounds; pass 2 stores only from the owning position, so no two stores race.
+__global__ void __launch_bounds__(kBlock) k_scatter_mark(const unsigned* __restrict__ idx, size_t n, size_t numel, unsigned* __restrict__ owner,
+                                                         unsigned long long* __restrict__ bad) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const unsigned t = idx[i];
+        if (t >= numel) atomicMin(bad, (unsigned long long)i);
+        else atomicMax(owner + t, (unsigned)(i + 1));
+    }
+}
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_scatter_owned(T* __restrict__ target, const unsigned* __restrict__ idx, const unsigned* __restrict__ owner,
+                                                          const T* __restrict__ values, size_t n) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const unsigned t = idx[i];
+        if (owner[t] == (unsigned)(i + 1)) target[t] = values[i];
+    }
+}
 // simple_provider.rs:3494-3503: start + idx * step with step = (stop - start) / (count - 1), the last element set to stop
 template <class T>
 __global__ void __launch_bounds__(kBlock) k_linspace(T* __restrict__ out, size_t n, double start, double step, double stop) {
@@ -544,10 +565,38 @@ int rmhip_scatter_linear(rmhip_ctx* ctx, rmhip_buf target, const uint32_t* indic
         return fail(RMHIP_ERR_UNSUPPORTED, "scatter_linear: storage mismatch target=%s values=%s", tb.dtype == DT_F32 ? "f32" : "f64", vb.dtype == DT_F32 ? "f32" : "f64");
     if (vb.numel != n_indices)
         return fail(RMHIP_ERR_SHAPE, "scatter_linear: values raw length %zu does not match index count %zu for lane factor 1", vb.numel, n_indices);
+    if (n_indices == 0) return RMHIP_OK;
+    // From kScatterDeviceMin indices on (and fewer than 2^32 - 1 of them) the host does nothing per index: an O(n) bounds loop, a sort
+    // and a hash map per call were the cost of a large `A(idx) = v` (1e7 indices: seconds on the host against two short kernels).
+    // The owner table costs 4 bytes per target element, cleared per call (RMHIP_SCATTER_DEVICE_MIN, 0 = never).
+    static const size_t device_min = std::getenv("RMHIP_SCATTER_DEVICE_MIN") ? (size_t)std::atol(std::getenv("RMHIP_SCATTER_DEVICE_MIN")) : 4096;
+    if (device_min && n_indices >= device_min && n_indices < 0xffffffffULL && tb.numel <= 64 * n_indices) {
+        std::shared_ptr<Allocation> didx, owner;
+        RMHIP_TRY(upload_indices(c, indices, n_indices, &didx, sizeof(unsigned long long) + 8));
+        RMHIP_TRY(c->alloc_device((tb.numel + 1) / 2 + 1, &owner));
+        const unsigned* di = reinterpret_cast<const unsigned*>(didx->ptr);
+        unsigned long long* bad = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(didx->ptr) + ((n_indices * sizeof(uint32_t) + 7) & ~(size_t)7));
+        unsigned* own = reinterpret_cast<unsigned*>(owner->ptr);
+        RMHIP_HIP_CHECK(hipMemsetAsync(own, 0, tb.numel * sizeof(unsigned), c->stream));
+        RMHIP_HIP_CHECK(hipMemsetAsync(bad, 0xff, sizeof(unsigned long long), c->stream));
+        hipLaunchKernelGGL(k_scatter_mark, dim3(flat_grid(c, n_indices)), dim3(kBlock), 0, c->stream, di, n_indices, tb.numel, own, bad);
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+        unsigned long long first_bad = 0;
+        RMHIP_HIP_CHECK(hipMemcpyAsync(&first_bad, bad, sizeof(first_bad), hipMemcpyDeviceToHost, c->stream));
+        RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));  // (also: the caller's index array has been read)
+        if (first_bad != ~0ULL)  // nothing was stored (the reference's loop stores the positions before the offending one, then fails: simple_provider.rs:2698-2706; both paths here validate first)
+            return fail(RMHIP_ERR_INVALID, "scatter_linear: index %u (position %zu) out of bounds for target (logical_len=%zu)", indices[first_bad],
+                        (size_t)first_bad, tb.numel);
+        if (tb.dtype == DT_F32) hipLaunchKernelGGL((k_scatter_owned<float>), dim3(flat_grid(c, n_indices)), dim3(kBlock), 0, c->stream, tb.data_f32(), di, own, vb.data_f32(), n_indices);
+        else hipLaunchKernelGGL((k_scatter_owned<double>), dim3(flat_grid(c, n_indices)), dim3(kBlock), 0, c->stream, tb.data(), di, own, vb.data(), n_indices);
+        c->tel.kernel_launches++;
+        RMHIP_HIP_CHECK(hipGetLastError());
+        return RMHIP_OK;  // (didx / owner return to the pool in stream order)
+    }
     for (size_t k = 0; k < n_indices; ++k)
         if (indices[k] >= tb.numel)
             return fail(RMHIP_ERR_INVALID, "scatter_linear: index %u (position %zu) out of bounds for target (logical_len=%zu)", indices[k], k, tb.numel);
-    if (n_indices == 0) return RMHIP_OK;
     // last occurrence of an index wins, as in the reference's sequential loop: mark winners on the host (only when duplicates exist)
     std::vector<unsigned char> winner;
     {

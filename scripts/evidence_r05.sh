@@ -1,3 +1,6 @@
+#!/bin/bash
+# Developer tool (GPU box): the round-5 evidence run - the un-profiled default bench line, then scripts/profile_r05.sh for the solve
+# (WORKLOADS=mldivide); copy into profiles/ with scripts/collect_profiles.py r05.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof_r05
 python bench.py > gpurun_out/prof_r05/bench_default.json 2> gpurun_out/prof_r05/bench_default.err

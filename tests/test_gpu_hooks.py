@@ -250,6 +250,42 @@ def test_gather_scatter_linear(prov, oracle):
         prov.free(x)
 
 
+def test_scatter_linear_large_index_sets_resolve_on_the_device(prov, oracle):
+    """From 4096 indices on, bounds and duplicates are resolved by two kernels (owner table: the last occurrence wins, as in the
+    reference's sequential loop, simple_provider.rs:2698-2711); an out-of-bounds index fails before anything is stored."""
+    from runmat_amd import ProviderError
+
+    rng = np.random.default_rng(381)
+    X = rng.standard_normal((300, 200))
+    h = prov.upload(X)
+    n = 50000  # heavy duplication: 60000 cells, 50000 draws + forced repeats at both ends of the position range
+    sidx = rng.integers(0, X.size, n).astype(np.uint32)
+    sidx[-3:] = sidx[:3]
+    sidx[100:200] = 4242
+    vals = rng.standard_normal(n)
+    hv = prov.upload(vals)
+    prov.scatter_linear(h, sidx, hv)
+    want = oracle.scatter_linear(X, sidx, vals)
+    assert bits_equal(prov.download_matrix(h), want)
+    # out of bounds somewhere in the middle: error names the first offending position, the target keeps its values
+    bad = sidx.copy()
+    bad[31000] = X.size
+    bad[45000] = X.size + 7
+    with pytest.raises(ProviderError, match=r"position 31000\) out of bounds"):
+        prov.scatter_linear(h, bad, hv)
+    assert bits_equal(prov.download_matrix(h), want)
+    # exactly at the threshold, and one below it (host path): same result
+    for m in (4096, 4095):
+        h2 = prov.upload(X)
+        hv2 = prov.upload(vals[:m])
+        prov.scatter_linear(h2, sidx[:m], hv2)
+        assert bits_equal(prov.download_matrix(h2), oracle.scatter_linear(X, sidx[:m], vals[:m])), m
+        prov.free(h2)
+        prov.free(hv2)
+    prov.free(h)
+    prov.free(hv)
+
+
 def test_nan_maps_and_omitnan_sum_sequence(prov, oracle):
     """sum(x, 'omitnan') on a resident tensor (reduction/sum.rs:795): map_nan_to_zero, then the plain reduction."""
     X = np.random.default_rng(39).standard_normal((33, 17))
