@@ -186,6 +186,17 @@ __global__ void __launch_bounds__(kBlock) k_gather(const T* __restrict__ src, co
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) dst[i] = src[idx[i]];
 }
+// large index sets: the bounds check rides along (smallest offending position in *bad; such an element reads nothing)
+template <class T>
+__global__ void __launch_bounds__(kBlock) k_gather_checked(const T* __restrict__ src, const unsigned* __restrict__ idx, T* __restrict__ dst, size_t n,
+                                                           size_t numel, unsigned long long* __restrict__ bad) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const unsigned t = idx[i];
+        if (t < numel) dst[i] = src[t];
+        else atomicMin(bad, (unsigned long long)i);
+    }
+}
 // Duplicates: the reference writes sequentially, so the LAST occurrence of an index wins (simple_provider.rs:2706-2717).
 // `winner[k]` (host-computed) is 1 when position k is the last one carrying its index: the stores never race.
 template <class T>
@@ -533,15 +544,35 @@ int rmhip_gather_linear(rmhip_ctx* ctx, rmhip_buf source, const uint32_t* indice
         return fail(RMHIP_ERR_SHAPE, "gather_linear: output shape holds %zu elements, %zu indices given", shape_numel(out_shape, rank), n_indices);
     Buffer sb, ob;
     RMHIP_TRY(get_settled(c, source, &sb));
-    for (size_t k = 0; k < n_indices; ++k)
-        if (indices[k] >= sb.numel)  // simple_provider.rs:2636-2643
-            return fail(RMHIP_ERR_INVALID, "gather_linear: index %u (position %zu) out of bounds for buffer %llu (logical_len=%zu)", indices[k], k,
-                        (unsigned long long)source, sb.numel);
+    static const size_t device_min = std::getenv("RMHIP_SCATTER_DEVICE_MIN") ? (size_t)std::atol(std::getenv("RMHIP_SCATTER_DEVICE_MIN")) : 4096;
+    const bool on_device = device_min && n_indices >= device_min;  // the bounds check inside the gather kernel instead of a host loop
+    if (!on_device)
+        for (size_t k = 0; k < n_indices; ++k)
+            if (indices[k] >= sb.numel)  // simple_provider.rs:2636-2643
+                return fail(RMHIP_ERR_INVALID, "gather_linear: index %u (position %zu) out of bounds for buffer %llu (logical_len=%zu)", indices[k], k,
+                            (unsigned long long)source, sb.numel);
     RMHIP_TRY(new_like(c, sb, out_shape, rank, out, &ob));
     if (n_indices == 0) return RMHIP_OK;
     std::shared_ptr<Allocation> didx;
-    int rc = upload_indices(c, indices, n_indices, &didx);
-    if (rc == RMHIP_OK) {
+    int rc = upload_indices(c, indices, n_indices, &didx, sizeof(unsigned long long) + 8);
+    if (rc == RMHIP_OK && on_device) {
+        const unsigned* di = reinterpret_cast<const unsigned*>(didx->ptr);
+        unsigned long long* bad = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(didx->ptr) + ((n_indices * sizeof(uint32_t) + 7) & ~(size_t)7));
+        unsigned long long first_bad = ~0ULL;
+        hipError_t e = hipMemsetAsync(bad, 0xff, sizeof(unsigned long long), c->stream);
+        if (e == hipSuccess) {
+            if (sb.dtype == DT_F32) hipLaunchKernelGGL((k_gather_checked<float>), dim3(flat_grid(c, n_indices)), dim3(kBlock), 0, c->stream, sb.data_f32(), di, ob.data_f32(), n_indices, sb.numel, bad);
+            else hipLaunchKernelGGL((k_gather_checked<double>), dim3(flat_grid(c, n_indices)), dim3(kBlock), 0, c->stream, sb.data(), di, ob.data(), n_indices, sb.numel, bad);
+            c->tel.kernel_launches++;
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&first_bad, bad, sizeof(first_bad), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(RMHIP_ERR_HIP, "gather_linear: %s", hipGetErrorString(e));
+        else if (first_bad != ~0ULL)
+            rc = fail(RMHIP_ERR_INVALID, "gather_linear: index %u (position %zu) out of bounds for buffer %llu (logical_len=%zu)", indices[first_bad],
+                      (size_t)first_bad, (unsigned long long)source, sb.numel);
+    } else if (rc == RMHIP_OK) {
         const unsigned* di = reinterpret_cast<const unsigned*>(didx->ptr);
         if (sb.dtype == DT_F32) hipLaunchKernelGGL((k_gather<float>), dim3(flat_grid(c, n_indices)), dim3(kBlock), 0, c->stream, sb.data_f32(), di, ob.data_f32(), n_indices);
         else hipLaunchKernelGGL((k_gather<double>), dim3(flat_grid(c, n_indices)), dim3(kBlock), 0, c->stream, sb.data(), di, ob.data(), n_indices);

@@ -274,6 +274,12 @@ def test_scatter_linear_large_index_sets_resolve_on_the_device(prov, oracle):
     with pytest.raises(ProviderError, match=r"position 31000\) out of bounds"):
         prov.scatter_linear(h, bad, hv)
     assert bits_equal(prov.download_matrix(h), want)
+    # gather of a large index set: the bounds check rides in the kernel
+    g = prov.gather_linear(h, sidx, (n, 1))
+    assert bits_equal(prov.download_matrix(g), oracle.gather_linear(want, sidx, (n, 1)))
+    prov.free(g)
+    with pytest.raises(ProviderError, match=r"position 31000\) out of bounds"):
+        prov.gather_linear(h, bad, (n, 1))
     # exactly at the threshold, and one below it (host path): same result
     for m in (4096, 4095):
         h2 = prov.upload(X)
