@@ -821,6 +821,12 @@ RMHIP_API int rmhip_comm_unique_id(int transport, void* id_out /* RMHIP_COMM_ID_
 RMHIP_API int rmhip_comm_init(rmhip_ctx* ctx, const void* unique_id, int rank, int world);
 /* @serves - */
 RMHIP_API int rmhip_comm_destroy(rmhip_ctx* ctx);
+/* A rank that cannot go on inside a sequence of collectives (a local allocation or device failure) calls this instead of leaving
+ * its peers blocked: on the host shared-memory transport every rank's next (or current) barrier fails at once with RMHIP_ERR_HIP; on
+ * RCCL the local communicator is aborted (ncclCommAbort) and the peers are released by RCCL's own error propagation / watchdog.
+ * Afterwards every collective on this context fails until rmhip_comm_destroy + rmhip_comm_init.  No communicator: no-op. */
+/* @serves - */
+RMHIP_API int rmhip_comm_abort(rmhip_ctx* ctx);
 /* rank 0 / world 1 when the context has no communicator */
 /* @serves - */
 RMHIP_API int rmhip_comm_rank(rmhip_ctx* ctx, int* rank, int* world);

@@ -49,6 +49,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -90,6 +91,7 @@ RcclApi& rccl() {
         api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
         api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
         api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.CommAbort = (decltype(api.CommAbort))sym("ncclCommAbort");
         api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
         api.Broadcast = (decltype(api.Broadcast))sym("ncclBroadcast");
         api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
@@ -112,7 +114,8 @@ struct ShmHeader {
     std::atomic<uint32_t> arrived;   // barrier: arrivals of the current generation
     std::atomic<uint32_t> generation;
     uint32_t world;
-    uint32_t pad[11];
+    std::atomic<uint32_t> aborted;   // a rank gave up inside a collective sequence (rmhip_comm_abort): every barrier fails from now on
+    uint32_t pad[10];
 };
 static_assert(sizeof(ShmHeader) == 64, "header is one cache line");
 
@@ -126,6 +129,7 @@ struct Comm {
     hipStream_t stream = nullptr;       // communication stream of the asynchronous form
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
     bool pending = false;
+    bool aborted = false;  // rmhip_comm_abort was called here: every later collective fails at once
     // host shared memory
     std::string shm_name;
     ShmHeader* hdr = nullptr;
@@ -137,6 +141,7 @@ namespace {
 
 int shm_barrier(Comm* cm) {
     ShmHeader* h = cm->hdr;
+    if (h->aborted.load(std::memory_order_acquire)) return fail(RMHIP_ERR_HIP, "comm: a rank aborted the communicator");
     const uint32_t gen = h->generation.load(std::memory_order_acquire);
     if (h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)cm->world) {
         h->arrived.store(0, std::memory_order_relaxed);
@@ -147,6 +152,7 @@ int shm_barrier(Comm* cm) {
     int spins = 0;
     while (h->generation.load(std::memory_order_acquire) == gen) {
         if (++spins > 2000) {
+            if (h->aborted.load(std::memory_order_acquire)) return fail(RMHIP_ERR_HIP, "comm: a rank aborted the communicator");
             std::this_thread::sleep_for(std::chrono::microseconds(50));
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
                 return fail(RMHIP_ERR_HIP, "comm: a rank did not reach the host barrier within 60 s");
@@ -234,6 +240,7 @@ int join_pending(Context* c, Comm* cm) {
 
 int require_comm(Context* c, Comm** out) {
     if (!c->comm) return fail(RMHIP_ERR_INVALID, "no communicator on this context: call rmhip_comm_init first");
+    if (c->comm->aborted) return fail(RMHIP_ERR_HIP, "comm: this communicator was aborted (rmhip_comm_destroy, then a new rmhip_comm_init)");
     *out = c->comm;
     return RMHIP_OK;
 }
@@ -445,6 +452,20 @@ int rmhip_comm_destroy(rmhip_ctx* ctx) {
     return RMHIP_OK;
 }
 
+int rmhip_comm_abort(rmhip_ctx* ctx) {
+    CTX_OR_FAIL(ctx);
+    Comm* cm = c->comm;
+    if (!cm || cm->aborted) return RMHIP_OK;
+    cm->aborted = true;
+    if (cm->host && cm->hdr) cm->hdr->aborted.store(1, std::memory_order_release);
+    if (cm->nccl && rccl().CommAbort) {  // frees the communicator: nothing left for rmhip_comm_destroy to destroy
+        (void)rccl().CommAbort(cm->nccl);
+        cm->nccl = nullptr;
+    }
+    cm->pending = false;
+    return RMHIP_OK;
+}
+
 int rmhip_comm_rank(rmhip_ctx* ctx, int* rank, int* world) {
     CTX_OR_FAIL(ctx);
     if (rank) *rank = c->comm ? c->comm->rank : 0;
@@ -455,6 +476,7 @@ int rmhip_comm_rank(rmhip_ctx* ctx, int* rank, int* world) {
 int rmhip_comm_wait(rmhip_ctx* ctx) {
     CTX_OR_FAIL(ctx);
     Comm* cm;
+    if (c->comm && c->comm->aborted) return RMHIP_OK;  // nothing of it is in flight any more
     RMHIP_TRY(require_comm(c, &cm));
     if (cm->pending) {
         RMHIP_HIP_CHECK(hipStreamWaitEvent(c->stream, cm->ev_done, 0));

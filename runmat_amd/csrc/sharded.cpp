@@ -138,6 +138,19 @@ int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n,
     }
     const size_t n_direct = nblocks > (size_t)world ? nblocks - (size_t)world : 0;  // panels whose owner still has a block below the tile
     const bool overlap = world > 1;  // asynchronous broadcasts on the communication stream (look-ahead)
+    // Any way out that the ranks did not agree on (a local allocation or device failure between two collectives) aborts the
+    // communicator, so that the peers fail in their next barrier instead of waiting for a broadcast that never comes; declared before
+    // `temps`, whose destructor (tiles that may still be the target of a broadcast in flight) runs first.
+    struct AbortUnlessAgreed {
+        rmhip_ctx* ctx;
+        int world;
+        bool agreed = false;
+        ~AbortUnlessAgreed() {
+            if (!agreed && world > 1) (void)rmhip_comm_abort(ctx);
+        }
+    } exit_guard{ctx, world};
+    if (const char* v = std::getenv("RMHIP_RP_TEST_FAIL_RANK"))  // test hook: this rank leaves before its first collective
+        if (world > 1 && std::atoi(v) == rank) return fail(RMHIP_ERR_HIP, "mldivide_row_partitioned: injected local failure on rank %d", rank);
     Temps temps(ctx);
     // A failure on one rank (singular pivot inside its domain, an allocation) must not leave the others blocked in the panel
     // broadcast: the failing rank poisons what it sends with NaN and keeps taking part in every collective; the NaN reaches every
@@ -285,6 +298,7 @@ int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n,
             for (double v : h)
                 if (v != v || v > worst) worst = v;
         }
+        if (failed || !(worst <= tau)) exit_guard.agreed = true;  // every rank holds the same `worst` (NaN from a failed rank): all leave here
         if (failed) return fail(RMHIP_ERR_GROWTH, "mldivide_row_partitioned: rank %d failed (%s)", rank, why.c_str());
         if (!(worst <= tau))
             return fail(RMHIP_ERR_GROWTH, "largest multiplier outside the diagonal domains %.3g > %g (or a rank failed): use the block-column form (grid-wide pivot rule)",
@@ -316,6 +330,7 @@ int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n,
             RMHIP_TRY(rmhip_blk_assign(ctx, &dst, blk));
             temps.drop(blk);
         }
+        exit_guard.agreed = true;  // the last collective is behind us: what follows is local, on replicated data
         rmhip_buf a_rem = 0, b_rem = 0, x_rem = 0;
         const rmhip_view_t av = view(trailing, 0, 0, m_rem, m_rem), bv = view(trailing, 0, m_rem, m_rem, nrhs);
         RMHIP_TRY(rmhip_blk_copy(ctx, &av, &a_rem));
@@ -331,6 +346,7 @@ int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n,
         temps.drop(b_rem);
         temps.drop(x_rem);
     }
+    exit_guard.agreed = true;  // (no remaining rows: the guard was the last collective)
     // ---- back substitution over the direct panels: every rank holds every tile row, so it is redundant and needs no exchange
     for (size_t k = tiles.size(); k-- > 0;) {
         const size_t j = tiles[k].j, w = tiles[k].w, width = ncols - j;

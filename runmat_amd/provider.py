@@ -903,6 +903,10 @@ class HipProvider:
     def comm_destroy(self) -> None:
         self._check(self._lib.rmhip_comm_destroy(self._ctx))
 
+    def comm_abort(self) -> None:
+        """rmhip_comm_abort: give up inside a sequence of collectives without leaving the peers blocked (they fail in their next barrier)."""
+        self._check(self._lib.rmhip_comm_abort(self._ctx))
+
     def comm_rank(self) -> Tuple[int, int]:
         r, w = C.c_int(), C.c_int()
         self._check(self._lib.rmhip_comm_rank(self._ctx, C.byref(r), C.byref(w)))

@@ -146,6 +146,57 @@ def test_two_ranks_on_one_gpu(oracle, tmp_path, native):
         assert np.array_equal(res[0]["xc"], res[1]["xc"])  # replicated, bit-identical across ranks
 
 
+def _abort_worker(rank, world, port, out_dir):
+    import time
+
+    import torch.distributed as dist
+
+    from runmat_amd import HipProvider, ProviderError
+    from runmat_amd import sharding as sh
+
+    os.environ["RMHIP_RP_TEST_FAIL_RANK"] = "1"  # rank 1 leaves the driver before its first collective (a local failure)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        group = sh.Group.from_env()
+        prov = HipProvider(0)
+        group.with_native_comm(prov, transport="shm")
+        nn, nrhs, rbk = 1000, 2, 128
+        rng = np.random.default_rng(12)
+        AB = np.hstack([rng.standard_normal((nn, nn)), rng.standard_normal((nn, nrhs))])
+        rows = [r for q in sh.owned_row_blocks(nn, rbk, group) for r in range(q * rbk, min(nn, (q + 1) * rbk))]
+        t0 = time.perf_counter()
+        code, msg = 0, ""
+        try:
+            prov.mldivide_row_partitioned(prov.upload(AB[rows, :]), nn, nrhs, rb=rbk)
+        except ProviderError as e:
+            code, msg = e.code, str(e)
+        dt = time.perf_counter() - t0
+        again = ""
+        try:  # the communicator stays unusable until it is destroyed and made again
+            prov.comm_barrier()
+        except ProviderError as e:
+            again = str(e)
+        prov.comm_destroy()
+        np.savez(os.path.join(out_dir, f"abort{rank}.npz"), code=code, msg=msg, dt=dt, again=again)
+        prov.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_a_local_failure_aborts_the_communicator_instead_of_hanging_the_peer(tmp_path):
+    """a rank that leaves rmhip_mldivide_row_partitioned between two collectives (allocation / device failure; here the
+    test hook) must not leave the others blocked in the next broadcast: it aborts the communicator, the peer's barrier fails at once."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_abort_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (np.load(tmp_path / f"abort{r}.npz") for r in range(2))
+    assert int(r1["code"]) != 0 and "injected local failure" in str(r1["msg"])
+    assert int(r0["code"]) != 0 and "aborted the communicator" in str(r0["msg"]), str(r0["msg"])
+    assert float(r0["dt"]) < 20.0, float(r0["dt"])  # not the 60 s barrier timeout
+    assert "abort" in str(r0["again"]) and "abort" in str(r1["again"])
+
+
 def test_rccl_one_rank_communicator(prov, oracle):
     """The RCCL transport itself (librccl through dlopen, ncclCommInitRank / ncclAllGather / ncclBroadcast on the
     context's streams) with the one-rank communicator a single-GPU box allows, plus the sharded drivers on it."""
