@@ -913,8 +913,7 @@ struct RtArgs {
 };
 struct RtLds {
     unsigned* wmax; // [2][4] every wave's best key (high word of |a|, low byte = 255 - thread), by step parity
-    double* vals;   // [2][4][RT_VS] the wave candidate's window values (+ its reciprocal in slot 8)
-    int* posv;      // [2][4] its current position
+    double* vals;   // [2][4][RT_VS] the wave candidate's window values (+ its reciprocal in slot 8, its current position in the low word of slot 9)
     double* pw;     // [8][RT_VS] pivot j of the micro-panel: its window values (multipliers w.r.t. pivots < j, then u_jj ...)
     double* pt;     // [8][RT_TRAIL] pt[j][c] = pivot j's value in trailing slot c, as it was when the micro-panel began
 };
@@ -958,7 +957,7 @@ __device__ __forceinline__ void rt_step(const RtArgs& g, const RtLds& L, const i
 #pragma unroll
         for (int i = J; i < 8; ++i) mine[i] = a[i];
         mine[8] = rinv;
-        L.posv[par * 4 + wv] = pos;
+        mine[9] = __hiloint2double(0, pos);  // its position rides in the record's spare slot: one LDS round trip for the readers
     }
     if ((t & 63) == 0) L.wmax[par * 4 + wv] = wm;
     RT_TICK(1)  // candidate: wave maximum, reciprocal, the wave winner's record
@@ -969,7 +968,14 @@ __device__ __forceinline__ void rt_step(const RtArgs& g, const RtLds& L, const i
     const unsigned best = b01 > b23 ? b01 : b23;
     const bool none = best == 0;  // all-zero / NaN-only column: the row at position k retires (host_lu.rs:38)
     const int btid = 255 - (int)(best & 0xffu), bwv = btid >> 6;
-    const double* pv = L.vals + (par * 4 + bwv) * RT_VS;
+    const double* pvp = L.vals + (par * 4 + bwv) * RT_VS;
+    // the whole record of the winning wave in ONE LDS round trip, before any of the decisions below (read on demand - the pivot for
+    // the singular test, then the position, then the window values inside the branch that uses them - they were three dependent
+    // round trips of ~120 cycles on the per-column chain).  With no candidate at all the record is stale: nothing below uses it then.
+    double pv[10];
+#pragma unroll
+    for (int i = J; i < 10; ++i) pv[i] = pvp[i];
+    const int bpos = __double2loint(pv[9]);
     const bool skip = none || !(fabs(pv[J]) > LU_EPS);  // counted as a singular pivot; the solve path then refactors with the grid-wide rule
     if (none) {
         if (pos == kabs) {
@@ -978,7 +984,6 @@ __device__ __forceinline__ void rt_step(const RtArgs& g, const RtLds& L, const i
             rpiv = kabs | 0x40000000;
         }
     } else {
-        const int bpos = L.posv[par * 4 + bwv];
         if (t == btid) {
             pos = -1;  // retires as row k of U
             retk = k;
@@ -1013,7 +1018,6 @@ template <bool DBG>
 __global__ void __launch_bounds__(RT_ROWS) k_rp_top(const RtArgs g, pk_u64* dbg) {
     __shared__ __attribute__((aligned(16))) unsigned s_wmax[2 * 4];
     __shared__ __attribute__((aligned(16))) double s_vals[2 * 4 * RT_VS];
-    __shared__ int s_pos[2 * 4];
     __shared__ __attribute__((aligned(16))) double s_pw[8 * RT_VS];
     __shared__ __attribute__((aligned(16))) double s_pt[8 * RT_TRAIL];
     __shared__ int s_prow[BASE_W];  // physical row of pivot k (for the inverses of L11's diagonal blocks at the end)
@@ -1021,7 +1025,6 @@ __global__ void __launch_bounds__(RT_ROWS) k_rp_top(const RtArgs g, pk_u64* dbg)
     RtLds L;
     L.wmax = s_wmax;
     L.vals = s_vals;
-    L.posv = s_pos;
     L.pw = s_pw;
     L.pt = s_pt;
     const int t = threadIdx.x;
