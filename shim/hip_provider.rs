@@ -1235,6 +1235,8 @@ impl HipProvider {
         Ok((r, w))
     }
     pub fn comm_barrier(&self) -> Result<()> { check(unsafe { rmhip_comm_barrier(self.ctx) }) }
+    /// Leave a sequence of collectives without blocking the peers (their next barrier fails); the communicator is unusable afterwards.
+    pub fn comm_abort(&self) -> Result<()> { check(unsafe { rmhip_comm_abort(self.ctx) }) }
     /// In-place broadcast of a sub-block from `root`; `asynchronous` posts it on the communication stream (the
     /// block-cyclic solver's look-ahead) and `comm_wait` joins it before the block is read.
     pub fn comm_bcast(&self, block: &RmhipView, root: i32, asynchronous: bool) -> Result<()> {
