@@ -259,18 +259,40 @@ def main() -> None:
     # device count) so the multi-rank control flow can be exercised on a single-GPU box; numbers from such a
     # run are meaningless.  The driver's runs use nccl (= RCCL), one rank per GPU.
     backend = os.environ.get("RMHIP_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
+    if backend != "nccl" or os.environ.get("RMHIP_BENCH_TEST_PG_FAIL"):
         local_rank = local_rank % max(1, torch.cuda.device_count())
     coll_device = "cuda" if backend == "nccl" else "cpu"
+    control_plane = "none (single rank)"
     if world > 1:
+        import datetime
+
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # The control plane must not cost the line either: if torch's own RCCL process group cannot be made (the eager init is a
+            # collective, so every rank sees the failure), the ranks of this node meet again on gloo through a file store (under
+            # torchrun the workers never host a TCP store themselves); the data path stays rmhip_comm_*.
+            try:
+                if os.environ.get("RMHIP_BENCH_TEST_PG_FAIL"):  # test hook (every rank)
+                    raise RuntimeError("forced by RMHIP_BENCH_TEST_PG_FAIL")
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                control_plane = "torch.distributed nccl"
+            except Exception as e:  # noqa: BLE001
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                store = f"/tmp/rmhip_bench_pg_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}"  # one launcher, one file
+                dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=world,
+                                        timeout=datetime.timedelta(seconds=300))
+                coll_device = "cpu"
+                control_plane = f"torch.distributed gloo (nccl process group failed: {type(e).__name__}: {str(e)[:120]})"
         else:
             dist.init_process_group(backend)
+            control_plane = f"torch.distributed {backend}"
     else:
         torch.cuda.set_device(local_rank)
 
@@ -895,7 +917,7 @@ def main() -> None:
     }
     if "error" in rec:
         out["error"] = rec["error"]
-    out["config"] = dict(out["config"], collectives=comm_note)
+    out["config"] = dict(out["config"], collectives=comm_note, control_plane=control_plane)
     if shrink > 1:
         out["config"]["shrink"] = shrink  # NOT the benchmark: every linear size divided by this (test runs only)
     # what the data path actually ran on: the library's own view of the communicator (rmhip_comm_rank), not what was asked for

@@ -21,8 +21,11 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _run_bench(extra_args, extra_env, nproc=2, timeout=900):
-    env = dict(os.environ, RMHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", **extra_env)
+def _run_bench(extra_args, extra_env, nproc=2, timeout=900, backend="gloo"):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", **extra_env)
+    env.pop("RMHIP_BENCH_BACKEND", None)
+    if backend:
+        env["RMHIP_BENCH_BACKEND"] = backend
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", str(nproc)] + extra_args
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
@@ -106,3 +109,16 @@ def test_a_rank_that_fails_its_comm_init_makes_every_rank_fall_back():
     assert out["n_gpus"] == 2 and out["value"] > 0 and "error" not in out
     assert out["comm"]["transport"].startswith("torch.distributed") and out["comm"]["world_seen"] == 2
     assert "native communicator unavailable" in out["config"]["collectives"]
+
+
+@pytest.mark.timeout(240)
+def test_a_failing_torch_process_group_does_not_cost_the_line():
+    """The driver's launch (default backend: torch's RCCL process group as control plane) with that process group made to fail on every
+    rank: the ranks meet again on gloo through a file store and the line comes out (data path here: the host transport, as two ranks
+    share the device)."""
+    out = _run_bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-also"],
+                     {"RMHIP_BENCH_TEST_PG_FAIL": "1", "RMHIP_BENCH_SHRINK": "4", "RMHIP_BENCH_TRANSPORT": "shm", "RMHIP_BENCH_BUSY_S": "0"},
+                     backend=None, timeout=200)
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert "gloo" in out["config"]["control_plane"] and "forced by RMHIP_BENCH_TEST_PG_FAIL" in out["config"]["control_plane"]
+    assert out["comm"]["transport"] == "host-shm"
