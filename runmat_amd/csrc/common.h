@@ -142,6 +142,7 @@ struct Context {
     // kernels whose dynamic-LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) was set on THIS context's device
     std::vector<const void*> lds_opt_in;
     std::unordered_map<uint64_t, Buffer> table;
+    size_t n_lazy = 0;  // records in `table` with lazy() set (guarded by `mu`): lets detach_views_of return at once when there are none
     uint64_t next_id = 1;
 
     // pool: bucket bytes -> free device pointers

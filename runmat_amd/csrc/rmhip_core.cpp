@@ -114,6 +114,7 @@ void Context::release_device(double* ptr, size_t bytes) {
 int Context::register_buffer(Buffer&& b, uint64_t* id) {
     std::lock_guard<std::mutex> lk(mu);
     *id = next_id++;
+    if (b.lazy()) ++n_lazy;
     table.emplace(*id, std::move(b));
     return RMHIP_OK;
 }
@@ -205,6 +206,7 @@ int Context::settle_view(uint64_t id) {
         if (it != table.end() && !it->second.rep_base.empty() && it->second.alloc == raw.alloc) {
             it->second.alloc = tiled;  // `raw` still references the base storage: nothing is released under the lock
             it->second.rep_base.clear();
+            --n_lazy;
         }
         return RMHIP_OK;
     }
@@ -224,6 +226,7 @@ int Context::settle_view(uint64_t id) {
     if (it != table.end() && it->second.tview && it->second.alloc == raw.alloc) {
         it->second.alloc = fresh;  // `raw` still references the base storage: nothing is released under the lock
         it->second.tview = false;
+        --n_lazy;
     }
     return RMHIP_OK;
 }
@@ -233,8 +236,9 @@ int Context::detach_views_of(uint64_t id) {
     {
         std::lock_guard<std::mutex> lk(mu);
         auto it = table.find(id);
-        if (it == table.end() || !it->second.alloc) return RMHIP_OK;
-        if (it->second.alloc.use_count() <= 1) return RMHIP_OK;  // nobody else holds this storage
+        // O(1) in the common case: no lazy view is alive in this context (the count is kept where records enter / leave the table and
+        // where views are settled).  The earlier `use_count() <= 1` test never fired - every caller holds a copy of the record.
+        if (n_lazy == 0 || it == table.end() || !it->second.alloc) return RMHIP_OK;
         for (auto& kv : table)
             if (kv.first != id && kv.second.alloc == it->second.alloc && kv.second.lazy()) sharers.push_back(kv.first);
     }
@@ -439,6 +443,7 @@ int rmhip_shutdown(rmhip_ctx* ctx) {
     }
     c->pool_limit_bytes = 0;  // frees bypass the pool from here on
     c->table.clear();
+    c->n_lazy = 0;
     c->fft_tables.clear();  // (cached twiddle / chirp tables hold allocations of this context: released while it is still whole)
     for (auto& kv : c->pool) (void)hipFree(kv.second);
     c->pool.clear();
@@ -560,6 +565,7 @@ int rmhip_free(rmhip_ctx* ctx, rmhip_buf id) {
         std::lock_guard<std::mutex> lk(c->mu);
         auto it = c->table.find(id);
         if (it == c->table.end()) return fail(RMHIP_ERR_NOT_FOUND, "free: buffer not found: %llu", (unsigned long long)id);
+        if (it->second.lazy()) --c->n_lazy;
         victim = std::move(it->second);
         c->table.erase(it);
     }

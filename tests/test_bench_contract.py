@@ -42,3 +42,59 @@ def test_committed_default_line_keeps_the_baseline_configs_in_its_tail():
         assert '"ms_per_step"' in line[start:end]
     # the headline itself (fused D = sin(A).*B + C) is the first thing on the line; its number is repeated by the driver's parser
     assert out["metric"].startswith("fused elementwise") and out["roofline"]["frac"] > 0
+
+
+def _fake_line():
+    """A bench line shaped like bench.py's, with long strings where the real one has them (no GPU needed)."""
+    import bench
+
+    long = "x" * 400
+
+    def rec(metric, unit, bound, extra=None, cpu=True):
+        r = {"metric": metric, "value": 123456.789, "unit": unit, "ms_per_step": 12.34567, "scaling": "weak",
+             "config": {"workload": long}, "roofline": {"bound": bound, "achieved": 1234.56, "peak": 8192.0, "unit": "GB/s", "frac": 0.7236,
+                                                        "kernel": long, "kernel_ms": 0.36229, **(extra or {})}}
+        if cpu:
+            r["cpu_baseline"] = {"value": 2.2784, "unit": "GB/s", "cores": 1, "kind": "port", "sample": long}
+        return r
+
+    out = rec("fused elementwise GB/s (D = sin(A).*B + C, 8192x8192 f64, per-GPU matrices)", "GB/s", "hbm")
+    out["roofline_slow_path"] = {"bound": "hbm", "frac": 0.5, "kernel_ms": 0.5}
+    out["n_gpus"] = 1
+    out["also"] = [
+        rec("image_normalize GB/s (4k-image-processing: ...)", "GB/s", "hbm", cpu=False),
+        rec("fused elementwise GB/s (elementwise-math 14-op chain, 1024x1024 f64)", "GB/s", "valu"),
+        rec("Monte-Carlo samples/s (1e8-sample randn + fused elementwise + sum reduction)", "samples/s", "hbm",
+            {"frac_on_32B_moved": 0.68, "frac_on_40B_survey_8d_plan": 0.85}),
+        rec("fp64 GFLOP/s (8192^3 matmul, row-block sharded across GPUs)", "GFLOP/s", "mfma"),
+        rec("fp64 GFLOP/s (x = A\\b, 16384x16384, blocked LU)", "GFLOP/s", "mfma"),
+    ]
+    out["device"] = {"arch": "gfx950"}
+    out["baseline_configs"] = bench.baseline_configs(out)
+    return out
+
+
+def test_baseline_configs_is_the_last_key_and_fits_the_drivers_2000_character_tail():
+    """Round-5 review: the driver's short `tail` is 2 000 characters and began mid-dgemm.  bench.py now ends the line with a compact
+    `baseline_configs` object; whatever keeps only the last 2 000 characters still holds all five BASELINE configs."""
+    out = _fake_line()
+    assert list(out)[-1] == "baseline_configs"
+    bc = out["baseline_configs"]
+    assert [k for k in bc if k.startswith("c")] == ["c0_chain_1024", "c1_fused_8192", "c2_dgemm_8192", "c3_mc_1e8", "c4_mldivide_16384"]
+    for k in ("c0_chain_1024", "c1_fused_8192", "c2_dgemm_8192", "c3_mc_1e8", "c4_mldivide_16384"):
+        assert bc[k] is not None and bc[k]["ms"] == 12.34567 and bc[k]["frac"] == 0.7236 and bc[k]["cpu"] == 2.2784, (k, bc[k])
+    assert bc["c1_fused_8192"]["frac_slow_sin"] == 0.5 and bc["c3_mc_1e8"]["frac_40B"] == 0.85
+    line = json.dumps(out)
+    i = line.rfind('"baseline_configs"')
+    assert len(line) - i <= 1800, len(line) - i
+    tail = line[-2000:]
+    assert '"baseline_configs"' in tail and '"c2_dgemm_8192"' in tail and '"c4_mldivide_16384"' in tail
+    # and bench.py really emits it last
+    src = (ROOT / "bench.py").read_text()
+    assert src.index('out["baseline_configs"] = baseline_configs(out)') > src.index('out["device"] =')
+
+
+def test_cpu_baselines_are_bounded_and_the_busy_loop_is_opt_in():
+    src = (ROOT / "bench.py").read_text()
+    assert 'os.environ.get("RMHIP_BENCH_BUSY_S", "0")' in src          # advisor r5 (medium): no default busy loop
+    assert "n, cols = 2048, 256" in src and "np.log(t1_ / t0_)" not in src  # dgemm: measured rate on a bounded sample, no fitted exponent
