@@ -264,7 +264,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["fused", "dgemm", "mc", "mldivide", "chain", "mc_evolved", "image", "fused_f32", "sgemm", "bcast", "fft"], default="fused")
+    ap.add_argument("--workload", choices=["fused", "dgemm", "mc", "mc_lazy", "mldivide", "chain", "mc_evolved", "image", "fused_f32", "sgemm", "bcast", "fft"], default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     args = ap.parse_args()
@@ -508,23 +508,44 @@ def main() -> None:
                                  kernel="k_dgemm_w8<false> (eight waves, pipelined k loop; v_mfma_f64_16x16x4_f64)", kernel_ms=round(kern_ms, 5)),
         }
 
-    def mc_record(steps, warmup):
+    def mc_record(steps, warmup, lazy=False):
         """BASELINE configs[3]: Monte-Carlo GBM, M = 1e8 paths (sharded over ranks with LCG skip-ahead),
-        T = 1 step, planner-shaped fused kernels; one step = one full pricing."""
+        T = 1 step, planner-shaped fused kernels; one step = one full pricing.  `lazy` False: Z = randn(M, 1) is MATERIALISED (the
+        plan SURVEY.md 8(d) prices: rmhip_set_lazy_random off for this record); True: the library's default, Z is a lazy handle the
+        update kernel generates in registers - reported as its own entry (mc_lazy_record)."""
         from planner_requests import monte_carlo_shaders
 
         M, T = 100_000_000 // (shrink * shrink), 1
         shaders = monte_carlo_shaders(100.0)  # compiled once per script by the planner, not per call (fusion.rs:679-682)
         price = 0.0
-        for _ in range(warmup):
-            price, _ = sh.monte_carlo_price_fused(prov, group, M, T, shaders, rng_state=0x9E3779B97F4A7C15)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            price, _ = sh.monte_carlo_price_fused(prov, group, M, T, shaders, rng_state=0x9E3779B97F4A7C15)
-        barrier()
-        wall = max_over_ranks(time.perf_counter() - t0)
+        prov.set_lazy_random(lazy)
+        try:
+            for _ in range(warmup):
+                price, _ = sh.monte_carlo_price_fused(prov, group, M, T, shaders, rng_state=0x9E3779B97F4A7C15)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                price, _ = sh.monte_carlo_price_fused(prov, group, M, T, shaders, rng_state=0x9E3779B97F4A7C15)
+            barrier()
+            wall = max_over_ranks(time.perf_counter() - t0)
+        finally:
+            prov.set_lazy_random(True)
         ms = wall / steps * 1e3
+        if lazy:
+            # bytes the two kernels move per sample: the update writes S (8), the payoff reduction reads it (8).  The update kernel now
+            # carries the Box-Muller step and exp: it is bound by the fp64 VALU, the fraction of HBM is what the step as a whole reaches
+            moved = 16 * T * M
+            return {
+                "metric": "Monte-Carlo samples/s (1e8 samples, lazy randn generated inside the fused update + sum reduction)",
+                "value": round(M * T / (ms * 1e-3), 1), "unit": "samples/s", "ms_per_step": round(ms, 4), "scaling": "strong", "dtype": "f64",
+                "config": {"workload": "monte-carlo-analysis f64, M=1e8, T=1, CPU-parity LCG randn stream, Z never materialised "
+                                       "(rmhip_set_lazy_random on: the library's default)", "price": price, "algorithmic_bytes": moved,
+                           "parallelism": f"sample ranges x{world}, ordered 1-value exchange"},
+                "roofline": roofline("hbm", moved / world / (ms * 1e-3) / 1e9, 1,
+                                     kernel="rm_ew_fast with an in-register Box-Muller operand (fp64 VALU bound) + rm_red_contig (whole step, wall clock; "
+                                            "16 B per sample moved)",
+                                     speedup_vs_32B_plan_bytes=2.0),
+            }
         # Bytes the three kernels MOVE per sample: randn writes Z (8), the fused update reads Z and writes S (16; S0 is a scalar
         # operand at T = 1), the payoff reduction reads S (8) = 32.  SURVEY.md 8(d) prices the reference's MATERIALISED plan at
         # (32 T + 8) = 40 B/sample (it also reads a resident S vector); that figure is reported beside, it is not what the roofline
@@ -545,6 +566,9 @@ def main() -> None:
                                  kernel="k_rng_normal + rm_ew_fast + rm_red_contig (whole step, wall clock; 32 B per sample moved)",
                                  **({"per_kernel": mc_kernel_rooflines(M // world)} if args.workload == "mc" else {})),
         }
+
+    def mc_lazy_record(steps, warmup):
+        return mc_record(steps, warmup, lazy=True)
 
     def mc_evolved_record(steps, warmup):
         """Benchmark-shaped secondary of SURVEY.md 8(d) config 4: M = 1e6 paths, T = 256 steps, the whole time
@@ -933,7 +957,7 @@ def main() -> None:
             return {"workload": name, "error": why or "failed on another rank"}
         return rec
 
-    records = {"sgemm": sgemm_record, "fused_f32": fused_f32_record, "fused": fused_record, "dgemm": dgemm_record, "mc": mc_record, "mldivide": mldivide_record,
+    records = {"mc_lazy": mc_lazy_record, "sgemm": sgemm_record, "fused_f32": fused_f32_record, "fused": fused_record, "dgemm": dgemm_record, "mc": mc_record, "mldivide": mldivide_record,
                "chain": chain_record, "mc_evolved": mc_evolved_record, "image": image_record, "bcast": bcast_record, "fft": fft_record}
     primary = records[args.workload]
     rec = safe_record(args.workload, primary, args.steps, args.warmup)
@@ -992,14 +1016,14 @@ def main() -> None:
         # Order matters: the driver keeps the TAIL of this line, so the extras come first and BASELINE.json's own configs - the 1024^2
         # chain, the 1e8-sample Monte-Carlo, the 8192^3 dgemm, the 16384^2 solve - last (tests/test_bench_contract.py pins that they
         # sit inside the last 6000 characters).  bcast and fft are workloads of their own (--workload), not part of the default line.
-        others = [w for w in ("image", "fused_f32", "sgemm", "mc_evolved", "fused", "chain", "mc", "dgemm") if w != args.workload]
+        others = [w for w in ("image", "fused_f32", "sgemm", "mc_evolved", "mc_lazy", "fused", "chain", "mc", "dgemm") if w != args.workload]
         if args.workload != "mldivide":
             others.append("mldivide")  # one GPU: rmhip_mldivide; N > 1: the block-column cyclic driver (BASELINE configs[4])
         also = []
         for w in others:
             # enough steps that the two synchronisations around the timed region (~1 ms together) stay below 1 % of it: a 20-step run
             # of the 0.65 ms image workload read 0.73 ms per step
-            steps = {"fused": 200, "dgemm": 10, "mc": 200, "mc_evolved": 100, "image": 200, "mldivide": 3, "chain": 2000, "fused_f32": 200, "sgemm": 10, "bcast": 500, "fft": 100}[w]
+            steps = {"fused": 200, "dgemm": 10, "mc": 200, "mc_lazy": 200, "mc_evolved": 100, "image": 200, "mldivide": 3, "chain": 2000, "fused_f32": 200, "sgemm": 10, "bcast": 500, "fft": 100}[w]
             sec = safe_record(w, records[w], steps, 5 if w != "mldivide" else 1)
             if "error" in sec:
                 also.append(sec)
@@ -1010,7 +1034,7 @@ def main() -> None:
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = {"fused": cpu_baseline_fused, "dgemm": cpu_baseline_dgemm, "mc": cpu_baseline_mc,
                                "mldivide": cpu_baseline_mldivide, "chain": cpu_baseline_chain,
-                               "mc_evolved": cpu_baseline_mc, "image": cpu_baseline_fused,
+                               "mc_evolved": cpu_baseline_mc, "mc_lazy": cpu_baseline_mc, "image": cpu_baseline_fused,
                                "fused_f32": cpu_baseline_fused, "sgemm": cpu_baseline_dgemm, "bcast": cpu_baseline_fused, "fft": cpu_baseline_fft}[args.workload]()
         for a in out.get("also", []):
             if "error" in a:

@@ -185,7 +185,8 @@ RMHIP_API int rmhip_fused_reduction(rmhip_ctx* ctx, const char* shader, const rm
                                     int flavor, double custom_scale, rmhip_buf* out);
 
 /* Front-end only (no GPU needed): translate a reference WGSL shader to the HIP source the library
- * would compile. `kind` 0 = elementwise, 1 = reduction. Writes a NUL-terminated string of at most
+ * would compile. `kind` 0 = elementwise, 1 = reduction, 0x100 | mask = elementwise whose inputs `mask` (bit k = input k)
+ * are lazy random_normal operands (see rmhip_set_lazy_random). Writes a NUL-terminated string of at most
  * `cap` bytes to `out` and the required size to *needed. */
 /* @serves - */
 RMHIP_API int rmhip_wgsl_translate(const char* shader, int kind, char* out, size_t cap,
@@ -895,6 +896,18 @@ RMHIP_API int rmhip_random_uniform(rmhip_ctx* ctx, const size_t* shape, size_t r
 /* @serves random_normal random_normal_like */
 RMHIP_API int rmhip_random_normal(rmhip_ctx* ctx, const size_t* shape, size_t rank,
                                   rmhip_buf* out);
+/* Lazy `random_normal` (f64 contexts, on by default from 1024 elements; RMHIP_LAZY_RANDN=0 / RMHIP_LAZY_RANDN_MIN=<n> in the
+ * environment): rmhip_random_normal returns a handle with NO storage - the stream advances as usual - and a streaming
+ * rmhip_fused_elementwise kernel that reads it generates the normals in registers, bit for bit the values an eager call writes
+ * (8 B per sample neither written nor read back: the Monte-Carlo step `S .* exp(drift + scale .* randn(M, 1))` moves 16 B per sample
+ * instead of 32).  Every other consumer (download, per-op calls, reductions, views, device pointers) first materialises the tensor
+ * under the same id from the recorded stream position; the two forms are indistinguishable through the API except by
+ * rmhip_lazy_random_stats.  `min_numel` == 0 keeps the current threshold. */
+/* @serves - */
+RMHIP_API int rmhip_set_lazy_random(rmhip_ctx* ctx, int enabled, size_t min_numel);
+/* counts since rmhip_init: lazy handles created, consumed in registers by a fused kernel (per use), materialised */
+/* @serves - */
+RMHIP_API int rmhip_lazy_random_stats(rmhip_ctx* ctx, uint64_t* created, uint64_t* fused, uint64_t* materialised);
 /* Scaled / transformed draws of the same stream (lib.rs:1732-1757, 1820-1839; CPU forms random.rs:290-320, 514-528; the in-process
  * provider simple_provider.rs:3560-3626, 3683-3725), one draw per element in column-major order:
  *   unifrnd:        a + (b - a) * u, the difference rounded once, then one multiply and one add (bit-exact)

@@ -567,6 +567,8 @@ public:
         return make(out, state.shape);
     }
     void set_rng_state(uint64_t state) const { check(rmhip_set_rng_state(ctx_, state)); }
+    // storage-less `random_normal` handles generated in registers by the consuming fused kernel (rmhip.h: rmhip_set_lazy_random)
+    void set_lazy_random(bool enabled, size_t min_numel = 0) const { check(rmhip_set_lazy_random(ctx_, enabled ? 1 : 0, min_numel)); }
     GpuTensorHandle random_uniform(const std::vector<size_t>& shape) const {
         uint64_t out = 0;
         check(rmhip_random_uniform(ctx_, shape.data(), shape.size(), &out));

@@ -20,6 +20,13 @@ static const char* kSkelCommon =
 static const char* kSkelReduce =
 #include "skel_reduce_str.inc"
     ;
+// lazy random_normal operands: the Box-Muller tables and the stream's device functions (skel_rng.h), text for hipRTC like the above
+static const char* kRngTables =
+#include "rng_tables_str.inc"
+    ;
+static const char* kSkelRng =
+#include "skel_rng_str.inc"
+    ;
 
 uint64_t fnv1a(const std::string& s) {
     uint64_t h = 1469598103934665603ULL;
@@ -104,8 +111,13 @@ static std::string body_function(const ElementwiseProgram& p) {
 // One streaming kernel. `vec` = 2 (16-byte accesses) or 1. Bit k of `mask` marks input k as a
 // 1-element tensor (the executor uploads scalars that way, fusion_exec.rs:305-326): it is read
 // once into an SGPR-resident value instead of being streamed.
-static void emit_fast_kernel(std::ostringstream& s, const ElementwiseProgram& p, const EwTuning& t, int vec,
-                             unsigned mask, const char* name, bool f32) {
+// Bit k of `rng_mask` (vec == 2, f64 only) marks input k as a LAZY random_normal operand: the kernel receives the stream state the
+// tensor was drawn at instead of a pointer and generates pair i - elements 2i, 2i + 1, one 16-byte vector - in registers with the
+// functions of skel_rng.h, following the state by the constant jump of its grid stride exactly as k_rng_normal does.
+static void emit_fast_kernel(std::ostringstream& s, const ElementwiseProgram& p, const EwTuning& t_in, int vec,
+                             unsigned mask, const char* name, bool f32, unsigned rng_mask = 0) {
+    EwTuning t = t_in;
+    if (rng_mask) t.chunked = 0;  // the state jump is one constant per launch: grid-stride only
     const int nin = p.n_inputs, nout = (int)p.outputs.size();
     // storage type S: f32 tensors are read and written as f32 (16-byte vectors of four), the body computes in f64
     const char* S = f32 ? "float" : "double";
@@ -113,13 +125,21 @@ static void emit_fast_kernel(std::ostringstream& s, const ElementwiseProgram& p,
     const std::string cast_in = f32 ? "(double)" : "";
     const std::string cast_out = f32 ? "(float)" : "";
     auto is_scalar = [&](int k) { return (mask >> k) & 1u; };
+    auto is_rng = [&](int k) { return (rng_mask >> k) & 1u; };
     int n_stream = 0;
     for (int k = 0; k < nin; ++k) n_stream += is_scalar(k) ? 0 : 1;
     const int U = t.unroll_for(n_stream, program_is_heavy(p));
     s << "extern \"C\" __global__ void __launch_bounds__(" << t.block << ") " << name << "(";
-    for (int k = 0; k < nin; ++k) s << "const " << S << "* __restrict__ in" << k << ", ";
+    for (int k = 0; k < nin; ++k) {
+        if (is_rng(k)) s << "const rm_u64 in" << k << ", ";
+        else s << "const " << S << "* __restrict__ in" << k << ", ";
+    }
     for (int k = 0; k < nout; ++k) s << S << "* __restrict__ out" << k << ", ";
-    s << "const rm_u64 n) {\n";
+    s << "const rm_u64 n" << (rng_mask ? ", const rm_u64 rng_jm, const rm_u64 rng_jp" : "") << ") {\n";
+    if (rng_mask) {
+        s << "    __shared__ __attribute__((aligned(16))) double rm_tab[kBmLdsDoubles];\n";
+        s << "    const BmTables tb = bm_stage_tables(rm_tab, threadIdx.x, " << t.block << ");\n";
+    }
     s << "    const rm_u64 nvec_all = n / " << vec << ";\n";
     if (t.chunked) {
         // contiguous chunk per block (multiple of the per-iteration footprint), block-stride inside
@@ -137,8 +157,19 @@ static void emit_fast_kernel(std::ostringstream& s, const ElementwiseProgram& p,
     }
     for (int k = 0; k < nin; ++k)
         if (is_scalar(k)) s << "    const double s" << k << " = " << cast_in << "in" << k << "[0];\n";
+    for (int k = 0; k < nin; ++k)  // the state u1 of this thread's first pair is drawn from (2 i + 1 steps into the tensor's stream)
+        if (is_rng(k))
+            s << "    rm_u64 x" << k << " = lcg_skip2(in" << k << ", " << (2 * t.block) << "ull * blockIdx.x, 2ull * threadIdx.x + 1ull);\n";
     auto load = [&](int k, const std::string& idx, const std::string& dst) {
         if (is_scalar(k)) return;
+        if (is_rng(k)) {  // loads are emitted in index order, so the state simply follows them
+            s << "        rm_v2 " << dst << ";\n        {\n";
+            s << "            const double rad = bm_radius(x" << k << ", tb);\n            double sn, cs;\n";
+            s << "            bm_sincos(lcg_step(x" << k << "), tb, &sn, &cs);\n";
+            s << "            " << dst << " = rm_v2{rad * cs, rad * sn};\n";
+            s << "            x" << k << " = rng_jm * x" << k << " + rng_jp;\n        }\n";
+            return;
+        }
         s << "        const " << vt << " " << dst << " = " << (t.nt_load ? "__builtin_nontemporal_load" : "*")
           << "((const " << vt << "*)in" << k << " + (" << idx << "));\n";
     };
@@ -201,7 +232,10 @@ static void emit_fast_kernel(std::ostringstream& s, const ElementwiseProgram& p,
         for (int k = 0; k < nout; ++k) s << "double q" << k << "; ";
         s << "rm_body(";
         for (int k = 0; k < nin; ++k)
-            s << (k ? ", " : "") << (is_scalar(k) ? "s" + std::to_string(k) : cast_in + "in" + std::to_string(k) + "[n - 1]");
+            s << (k ? ", " : "")
+              << (is_scalar(k) ? "s" + std::to_string(k)
+                  : is_rng(k)  ? "rm_rng_tail(in" + std::to_string(k) + ", n, tb)"
+                               : cast_in + "in" + std::to_string(k) + "[n - 1]");
         for (int k = 0; k < nout; ++k) s << ", q" << k;
         s << ");\n";
         for (int k = 0; k < nout; ++k) s << "        out" << k << "[n - 1] = " << cast_out << "q" << k << ";\n";
@@ -283,8 +317,21 @@ static void emit_bcast_kernel(std::ostringstream& s, const ElementwiseProgram& p
     s << "    }\n}\n\n";
 }
 
-std::string generate_elementwise_source(const ElementwiseProgram& p, const EwTuning& t, unsigned mask, bool f32) {
+std::string generate_elementwise_source(const ElementwiseProgram& p, const EwTuning& t, unsigned mask, bool f32, unsigned rng_mask) {
     std::ostringstream s;
+    if (rng_mask) {  // the streaming kernel alone (16-byte vectors, f64): every other shape of request sees materialised operands
+        s << "// generated by librmhip from a fused elementwise plan (" << p.lets.size() << " ops, " << p.n_inputs << " inputs, lazy random_normal mask "
+          << rng_mask << ")\n";
+        s << kSkelCommon << "\n" << kRngTables << "\n" << kSkelRng << "\n";
+        s << "typedef double rm_v2 __attribute__((ext_vector_type(2)));\n";
+        // element n - 1 of an odd-length tensor: z0 of pair (n - 1) / 2, whose u1 comes from the state n steps in
+        s << "__device__ __noinline__ double rm_rng_tail(rm_u64 state, rm_u64 n, const BmTables& tb) {\n"
+             "    rm_u64 m, q;\n    lcg_jump(n, &m, &q);\n    const rm_u64 x1 = m * state + q;\n"
+             "    const double rad = bm_radius(x1, tb);\n    double sn, cs;\n    bm_sincos(lcg_step(x1), tb, &sn, &cs);\n    return rad * cs;\n}\n";
+        s << "\n" << body_function(p);
+        emit_fast_kernel(s, p, t, 2, mask, "rm_ew_fast", false, rng_mask);
+        return s.str();
+    }
     s << "// generated by librmhip from a fused elementwise plan (" << p.lets.size() << " ops, " << p.n_inputs
       << " inputs, " << p.outputs.size() << " outputs)\n";
     if (f32) s << "#define RM_RESULT_F32 1\n";  // results are stored as f32: skel_common.h's short sin / cos
@@ -437,14 +484,14 @@ static int load_function(hipModule_t m, const char* name, hipFunction_t* fn) {
 }
 
 int get_elementwise_kernel(Context* c, const ElementwiseProgram& p, unsigned mask, bool f32,
-                           std::shared_ptr<FusedKernel>* out) {
+                           std::shared_ptr<FusedKernel>* out, unsigned rng_mask) {
     EwTuning t = EwTuning::from_env();
     // f32 storage: 4-byte accesses in the broadcast kernel, so twice the elements per thread keep the same bytes in flight
     // (interleaved A/B at 8192^2, `A - row`: 4051 -> 4244 GB/s)
     if (f32 && !std::getenv("RMHIP_EW_BCAST_ELEMS")) t.bcast_elems = 8;
     char tun[96];
     std::snprintf(tun, sizeof tun, "|u%d|b%d|bb%dx%d|nt%d%d|c%d|m%x", t.unroll, t.block, t.bcast_block, t.bcast_elems, t.nt_load, t.nt_store, t.chunked, mask);
-    const std::string key_text = p.canonical + tun + (f32 ? "|f32" : "");
+    const std::string key_text = p.canonical + tun + (f32 ? "|f32" : "") + (rng_mask ? "|rng" + std::to_string(rng_mask) : "");
     const uint64_t key = fnv1a(key_text);
     {
         std::lock_guard<std::mutex> lk(c->mu);
@@ -457,7 +504,7 @@ int get_elementwise_kernel(Context* c, const ElementwiseProgram& p, unsigned mas
     }
     c->tel.cache_misses++;
     std::vector<char> code;
-    RMHIP_TRY(compile_to_code_object(generate_elementwise_source(p, t, mask, f32), &code));
+    RMHIP_TRY(compile_to_code_object(generate_elementwise_source(p, t, mask, f32, rng_mask), &code));
     auto k = std::make_shared<FusedKernel>();
     k->key_text = key_text;
     k->tuning = t;
@@ -465,9 +512,11 @@ int get_elementwise_kernel(Context* c, const ElementwiseProgram& p, unsigned mas
     k->n_outputs = (int)p.outputs.size();
     RMHIP_HIP_CHECK(hipModuleLoadData(&k->module, code.data()));
     RMHIP_TRY(load_function(k->module, "rm_ew_fast", &k->fn_fast));
-    RMHIP_TRY(load_function(k->module, "rm_ew_fast1", &k->fn_fast1));
-    RMHIP_TRY(load_function(k->module, "rm_ew_bcast", &k->fn_bcast));
-    RMHIP_TRY(load_function(k->module, "rm_ew_bcast_flat", &k->fn_bcast_flat));
+    if (!rng_mask) {  // (a kernel with lazy random_normal operands is the streaming form alone)
+        RMHIP_TRY(load_function(k->module, "rm_ew_fast1", &k->fn_fast1));
+        RMHIP_TRY(load_function(k->module, "rm_ew_bcast", &k->fn_bcast));
+        RMHIP_TRY(load_function(k->module, "rm_ew_bcast_flat", &k->fn_bcast_flat));
+    }
     std::lock_guard<std::mutex> lk(c->mu);
     c->kernel_cache[key] = k;
     *out = k;

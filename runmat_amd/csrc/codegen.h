@@ -56,7 +56,8 @@ bool program_is_heavy(const ElementwiseProgram& p);
 
 // Source generation (no GPU needed).
 // `f32`: tensors are stored as f32 (precision-32 contexts); the body still computes in f64.
-std::string generate_elementwise_source(const ElementwiseProgram& p, const EwTuning& t, unsigned scalar_mask, bool f32 = false);
+// `rng_mask` bit k set => input k is a lazy random_normal operand (f64, streaming kernel only; Buffer::rng_lazy).
+std::string generate_elementwise_source(const ElementwiseProgram& p, const EwTuning& t, unsigned scalar_mask, bool f32 = false, unsigned rng_mask = 0);
 std::string generate_reduction_source(const ReductionProgram& p, bool f32 = false);
 
 // hipRTC compile for gfx950; on failure returns nonzero and sets the error string (with the log).
@@ -64,7 +65,7 @@ int compile_to_code_object(const std::string& source, std::vector<char>* code);
 
 // Cached lookups (compile on miss). `scalar_mask` bit k set => input k is a 1-element tensor.
 int get_elementwise_kernel(Context* c, const ElementwiseProgram& p, unsigned scalar_mask, bool f32,
-                           std::shared_ptr<FusedKernel>* out);
+                           std::shared_ptr<FusedKernel>* out, unsigned rng_mask = 0);
 int get_reduction_kernel(Context* c, const ReductionProgram& p, bool f32, std::shared_ptr<FusedKernel>* out);
 
 uint64_t fnv1a(const std::string& s);

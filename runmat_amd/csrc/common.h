@@ -88,6 +88,12 @@ struct Buffer {
     // Only the transforms and the complex constructors (fft.hip) and upload-free plumbing (download, shape, free) accept such a
     // buffer; every real-valued entry point refuses it (Context::get_raw), so the caller gathers - as it does for any `Err`.
     bool cplx = false;
+    // Lazy `random_normal` (f64 contexts): no storage yet - element 2g / 2g + 1 is the Box-Muller pair drawn from the stream `rng_state`
+    // advanced by 2g + 1 / 2g + 2 steps (rng.hip k_rng_normal).  rmhip_fused_elementwise's streaming kernel generates the values in
+    // registers (codegen.cpp, skel_rng.h: bit for bit what k_rng_normal writes); every other consumer - anything that goes through
+    // Context::get_raw - sees the tensor materialised under the same id first.  Not part of lazy(): it shares no storage with anyone.
+    bool rng_lazy = false;
+    uint64_t rng_state = 0;
     bool lazy() const { return tview || !rep_base.empty(); }
     size_t stored_numel() const {  // elements the storage holds (the base of a repmat view)
         if (rep_base.empty()) return numel;
@@ -154,6 +160,11 @@ struct Context {
     std::unordered_map<uint64_t, std::shared_ptr<Allocation>> fft_tables;  // twiddle / chirp tables by (kind, length) (fft.hip)
 
     uint64_t rng_state = 0x9e3779b97f4a7c15ULL;  // DEFAULT_RNG_SEED, random.rs:7
+    // random_normal returns lazy records (Buffer::rng_lazy) from `lazy_randn_min` elements on (f64 contexts); RMHIP_LAZY_RANDN=0 or
+    // rmhip_set_lazy_random(ctx, 0, 0) turn it off
+    bool lazy_randn = true;
+    size_t lazy_randn_min = 1024;
+    uint64_t lazy_randn_created = 0, lazy_randn_fused = 0, lazy_randn_materialised = 0;  // rmhip_lazy_random_stats
 
     // scratch for reductions / LU (grown on demand, reused)
     double* scratch = nullptr;
@@ -227,7 +238,10 @@ struct Context {
     int new_buffer_f32(const size_t* shape, size_t rank, uint64_t* id, Buffer* out);  // f32 storage, never narrowed
     int get(uint64_t id, Buffer* out);       // f64 data, plain layout: widens f32 storage into a temporary, materialises a transpose view
     int get_view(uint64_t id, Buffer* out);  // f64 data, `tview` may be set (matmul / syrk read views in place); repmat views are materialised
-    int get_raw(uint64_t id, Buffer* out);   // the record as stored: dtype may be DT_F32, `tview` / `rep_base` may be set
+    // the record as stored: dtype may be DT_F32, `tview` / `rep_base` may be set.  A lazy random_normal record is materialised first
+    // unless `keep_rng` (only the fused elementwise entry point consumes one as it is)
+    int get_raw(uint64_t id, Buffer* out, bool keep_rng = false);
+    int settle_rng(uint64_t id);             // materialise a lazy random_normal record under its id (k_rng_normal on its recorded state)
     int settle_view(uint64_t id);            // materialise a transpose / repmat view in its own storage type and keep it under this id
     // Before an IN-PLACE write to buffer `id` (scatter_linear, the block views' assign / gemm / trsm / lu / swap_rows, the epilogue's
     // diagonal output, a raw device pointer handed out): every OTHER handle that is a lazy view of the same storage is materialised
@@ -356,6 +370,7 @@ int launch_dgemm_epilogue(Context* c, size_t m, size_t n, size_t k, const double
 
 // rng (rng.hip)
 int launch_rng_uniform(Context* c, uint64_t state, double* out, size_t n);
+void lcg_jump_host(unsigned long long delta, unsigned long long* mult, unsigned long long* plus);  // s -> mult * s + plus advances `delta` steps
 int launch_rng_normal(Context* c, uint64_t state, double* out, size_t n);
 // scaled / transformed draws of the same stream (rng.hip): exactly one of out64 / out32 is set
 int launch_rng_unifrnd(Context* c, uint64_t state, double a, double b, double* out64, float* out32, size_t n);

@@ -155,9 +155,31 @@ int Context::new_buffer_f32(const size_t* shape, size_t rank, uint64_t* id, Buff
     return register_buffer(std::move(b), id);
 }
 
-int Context::get_raw(uint64_t id, Buffer* out) {
+int Context::get_raw(uint64_t id, Buffer* out, bool keep_rng) {
     RMHIP_TRY(lookup(id, out));
     if (out->cplx) return fail(RMHIP_ERR_UNSUPPORTED, "complex-interleaved tensor %llu: this entry point takes real tensors", (unsigned long long)id);
+    if (out->rng_lazy && !keep_rng) {
+        RMHIP_TRY(settle_rng(id));
+        RMHIP_TRY(lookup(id, out));
+    }
+    return RMHIP_OK;
+}
+
+int Context::settle_rng(uint64_t id) {
+    Buffer raw;
+    RMHIP_TRY(lookup(id, &raw));
+    if (!raw.rng_lazy) return RMHIP_OK;
+    RMHIP_TRACEF("materialise lazy random_normal id %llu numel %zu", (unsigned long long)id, raw.numel);
+    std::shared_ptr<Allocation> fresh;
+    RMHIP_TRY(alloc_device(raw.numel ? raw.numel : 1, &fresh));
+    RMHIP_TRY(launch_rng_normal(this, raw.rng_state, fresh->ptr, raw.numel));
+    lazy_randn_materialised++;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = table.find(id);
+    if (it != table.end() && it->second.rng_lazy) {
+        it->second.alloc = fresh;
+        it->second.rng_lazy = false;
+    }
     return RMHIP_OK;
 }
 
@@ -426,6 +448,8 @@ int rmhip_init(int device_ordinal, rmhip_ctx** out_ctx) {
     // Keep at most a quarter of HBM parked in the pool (288 GB parts: plenty for 512 MiB operands).
     c->pool_limit_bytes = (size_t)(c->props.totalGlobalMem / 4);
     if (const char* v = std::getenv("RMHIP_POOL_LIMIT_MB")) c->pool_limit_bytes = (size_t)std::atoll(v) << 20;
+    if (const char* v = std::getenv("RMHIP_LAZY_RANDN")) c->lazy_randn = *v != '0';
+    if (const char* v = std::getenv("RMHIP_LAZY_RANDN_MIN")) c->lazy_randn_min = (size_t)std::atoll(v);
     probe_xcds(c);
     *out_ctx = h;
     return RMHIP_OK;

@@ -113,8 +113,9 @@ int get_operand(Context* c, rmhip_buf id, Buffer* out, bool* native) {
 
 // Operand of a broadcasting elementwise launch (rmhip_binary, rmhip_fused_elementwise): as get_operand, but a repmat view
 // stays a view - the launch indexes its base with stride 0 (host_shape.h refined_strides).
-int get_bcast_operand(Context* c, rmhip_buf id, Buffer* out, bool* native) {
-    RMHIP_TRY(c->get_raw(id, out));
+int get_bcast_operand(Context* c, rmhip_buf id, Buffer* out, bool* native, bool keep_rng = false) {
+    RMHIP_TRY(c->get_raw(id, out, keep_rng));
+    if (out->rng_lazy) return RMHIP_OK;  // (f64 contexts only; consumed in registers by the streaming kernel)
     if (out->tview) {
         RMHIP_TRY(c->settle_view(id));
         RMHIP_TRY(c->get_raw(id, out));
@@ -200,10 +201,11 @@ extern "C" {
 int rmhip_wgsl_translate(const char* shader, int kind, char* out, size_t cap, size_t* needed) {
     if (!shader) return fail(RMHIP_ERR_INVALID, "null shader");
     std::string err, src;
-    if (kind == 0) {
+    if (kind == 0 || (kind & 0x100)) {
         ElementwiseProgram p;
         if (!parse_elementwise_wgsl(shader, &p, &err)) return fail(RMHIP_ERR_COMPILE, "WGSL front-end: %s", err.c_str());
-        src = generate_elementwise_source(p, EwTuning::from_env(), 0u, p.f32);
+        if ((kind & 0x100) && p.f32) return fail(RMHIP_ERR_UNSUPPORTED, "lazy random_normal operands are f64 only");
+        src = generate_elementwise_source(p, EwTuning::from_env(), 0u, p.f32, (kind & 0x100) ? (unsigned)(kind & 0xff) : 0u);
     } else {
         ReductionProgram p;
         if (!parse_reduction_wgsl(shader, &p, &err)) return fail(RMHIP_ERR_COMPILE, "WGSL front-end: %s", err.c_str());
@@ -221,10 +223,11 @@ int rmhip_wgsl_translate(const char* shader, int kind, char* out, size_t cap, si
 int rmhip_wgsl_compile_check(const char* shader, int kind) {
     if (!shader) return fail(RMHIP_ERR_INVALID, "null shader");
     std::string err, src;
-    if (kind == 0) {
+    if (kind == 0 || (kind & 0x100)) {
         ElementwiseProgram p;
         if (!parse_elementwise_wgsl(shader, &p, &err)) return fail(RMHIP_ERR_COMPILE, "WGSL front-end: %s", err.c_str());
-        src = generate_elementwise_source(p, EwTuning::from_env(), 0u, p.f32);
+        if ((kind & 0x100) && p.f32) return fail(RMHIP_ERR_UNSUPPORTED, "lazy random_normal operands are f64 only");
+        src = generate_elementwise_source(p, EwTuning::from_env(), 0u, p.f32, (kind & 0x100) ? (unsigned)(kind & 0xff) : 0u);
     } else {
         ReductionProgram p;
         if (!parse_reduction_wgsl(shader, &p, &err)) return fail(RMHIP_ERR_COMPILE, "WGSL front-end: %s", err.c_str());
@@ -257,6 +260,37 @@ int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf*
     std::vector<Buffer> in(n_in);
     std::vector<uint64_t> oshape(out_shape, out_shape + rank);
     std::vector<std::vector<uint64_t>> strides(n_in);
+    // Lazy random_normal operands (Buffer::rng_lazy) stay lazy only for the streaming kernel over 16-byte vectors: every operand is
+    // either a plain full-size tensor of the output's shape or a 1-element tensor.  Any other request materialises them first.
+    unsigned rng_mask = 0;
+    if (c->precision != 32) {
+        bool any = false, eligible = len >= 2;
+        auto extents = [](const std::vector<size_t>& sh) {
+            std::vector<size_t> e;
+            for (size_t d : sh)
+                if (d != 1) e.push_back(d);
+            return e;
+        };
+        const std::vector<size_t> want = extents(std::vector<size_t>(out_shape, out_shape + rank));
+        for (size_t k = 0; k < n_in; ++k) {
+            RMHIP_TRY(c->get_raw(inputs[k], &in[k], /*keep_rng=*/true));
+            any |= in[k].rng_lazy;
+        }
+        if (any) {
+            for (size_t k = 0; k < n_in && eligible; ++k) {
+                const Buffer& b = in[k];
+                const bool full = b.numel == len && extents(b.shape) == want;
+                if (b.rng_lazy) eligible = full;
+                else eligible = !b.lazy() && b.dtype == DT_F64 && (b.numel == 1 || (full && aligned16(b.data())));
+            }
+            for (size_t k = 0; k < n_in; ++k) {
+                if (!in[k].rng_lazy) continue;
+                if (eligible) rng_mask |= 1u << k;
+                else RMHIP_TRY(c->settle_rng(inputs[k]));
+            }
+        }
+        for (auto& b : in) b = Buffer();
+    }
     // f32 storage is read and written in place by the f32 variant of the generated kernel; a mixed operand list
     // (externally wrapped f64 memory, transpose views) runs the f64 variant on widened copies
     bool f32 = c->precision == 32;
@@ -266,7 +300,7 @@ int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf*
     for (size_t k = 0; k < n_in; ++k)
         if (!f32 && (k + 1 != tried || in[k].dtype == DT_F32)) {
             bool no = false;
-            RMHIP_TRY(get_bcast_operand(c, inputs[k], &in[k], &no));
+            RMHIP_TRY(get_bcast_operand(c, inputs[k], &in[k], &no, (rng_mask >> k) & 1u));
         }
     RMHIP_TRY(bcast_prepare(c, inputs, &in, f32, out_shape, rank, &oshape, &strides, "fused_elementwise"));
     RMHIP_TRACEF("fused_elementwise: operands ready (f32 storage path %d)", (int)f32);
@@ -280,9 +314,14 @@ int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf*
         for (size_t k = 0; k < n_in; ++k)
             if (strides[k][0] == 0) mask |= 1u << k;
     if (!fast) mask = 0;
+    if (rng_mask && !fast) {  // (not expected after the eligibility test above: materialise and run the request again)
+        for (size_t k = 0; k < n_in; ++k)
+            if ((rng_mask >> k) & 1u) RMHIP_TRY(c->settle_rng(inputs[k]));
+        return rmhip_fused_elementwise(ctx, shader, inputs, n_in, out_shape, rank, len, n_out, out_ids);
+    }
 
     std::shared_ptr<FusedKernel> kern;
-    RMHIP_TRY(get_elementwise_kernel(c, prog, mask, f32, &kern));
+    RMHIP_TRY(get_elementwise_kernel(c, prog, mask, f32, &kern, rng_mask));
     RMHIP_TRACEF("fused_elementwise: kernel ready (fast %d mask %x)", (int)fast, mask);
 
     std::vector<Buffer> outs(n_out);
@@ -300,15 +339,21 @@ int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf*
     for (size_t k = 0; k < n_in; ++k) in_ptr[k] = in[k].data();
     for (size_t k = 0; k < n_out; ++k) out_ptr[k] = outs[k].data();
     std::vector<void*> args;
-    for (size_t k = 0; k < n_in; ++k) args.push_back(&in_ptr[k]);
+    std::vector<unsigned long long> rng_states(n_in, 0);
+    for (size_t k = 0; k < n_in; ++k) {
+        rng_states[k] = in[k].rng_state;
+        if ((rng_mask >> k) & 1u) args.push_back(&rng_states[k]);  // the stream state the tensor was drawn at, by value
+        else args.push_back(&in_ptr[k]);
+    }
     for (size_t k = 0; k < n_out; ++k) args.push_back(&out_ptr[k]);
+    unsigned long long rng_jm = 1, rng_jp = 0;
 
     const EwTuning& t = kern->tuning;
     hipError_t e;
     if (fast) {
         bool vec_ok = true;
         for (size_t k = 0; k < n_in; ++k)
-            if (!((mask >> k) & 1u) && !aligned16(in_ptr[k])) vec_ok = false;
+            if (!((mask >> k) & 1u) && !((rng_mask >> k) & 1u) && !aligned16(in_ptr[k])) vec_ok = false;
         for (size_t k = 0; k < n_out; ++k)
             if (!aligned16(out_ptr[k])) vec_ok = false;
         unsigned long long n = len;
@@ -318,9 +363,22 @@ int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf*
         for (size_t k = 0; k < n_in; ++k) n_stream += ((mask >> k) & 1u) ? 0 : 1;
         const size_t per_block = (size_t)t.block * t.unroll_for(n_stream, program_is_heavy(prog));
         size_t want = (work + per_block - 1) / per_block;
-        const size_t cap = (size_t)c->num_cus * t.blocks_per_cu;
+        // a kernel that generates normals is VALU-bound and pays a skip-ahead + 10 KiB of table staging per block: one resident set of
+        // blocks (2048 threads per CU) walks the tensor instead of blocks_per_cu waves of them
+        const size_t cap = rng_mask ? (size_t)c->num_cus * std::max(1, 2048 / t.block) : (size_t)c->num_cus * t.blocks_per_cu;
         if (want < 1) want = 1;
         const unsigned grid = (unsigned)std::min(want, cap);
+        if (rng_mask) {
+            if (!vec_ok) {  // (outputs are fresh allocations and the inputs were tested above)
+                for (size_t k = 0; k < n_out; ++k) rmhip_free(ctx, ids[k]);
+                return fail(RMHIP_ERR_HIP, "fused_elementwise: unaligned buffer beside a lazy random_normal operand");
+            }
+            // one 16-byte vector is one Box-Muller pair (two draws): the thread's state jumps 2 * grid * block steps per iteration
+            lcg_jump_host(2ull * grid * (unsigned long long)t.block, &rng_jm, &rng_jp);
+            args.push_back(&rng_jm);
+            args.push_back(&rng_jp);
+            for (size_t k = 0; k < n_in; ++k) c->lazy_randn_fused += (rng_mask >> k) & 1u;
+        }
         e = hipModuleLaunchKernel(vec_ok ? kern->fn_fast : kern->fn_fast1, grid, 1, 1, t.block, 1, 1, 0, c->stream,
                                   args.data(), nullptr);
     } else {
@@ -1842,6 +1900,21 @@ int rmhip_set_rng_state(rmhip_ctx* ctx, uint64_t state) {
     return RMHIP_OK;
 }
 
+int rmhip_set_lazy_random(rmhip_ctx* ctx, int enabled, size_t min_numel) {
+    CTX_OR_FAIL(ctx);
+    c->lazy_randn = enabled != 0;
+    if (min_numel) c->lazy_randn_min = min_numel;
+    return RMHIP_OK;
+}
+
+int rmhip_lazy_random_stats(rmhip_ctx* ctx, uint64_t* created, uint64_t* fused, uint64_t* materialised) {
+    CTX_OR_FAIL(ctx);
+    if (created) *created = c->lazy_randn_created;
+    if (fused) *fused = c->lazy_randn_fused;
+    if (materialised) *materialised = c->lazy_randn_materialised;
+    return RMHIP_OK;
+}
+
 int rmhip_get_rng_state(rmhip_ctx* ctx, uint64_t* state) {
     CTX_OR_FAIL(ctx);
     if (!state) return fail(RMHIP_ERR_INVALID, "null state");
@@ -1887,6 +1960,22 @@ int rmhip_random_normal(rmhip_ctx* ctx, const size_t* shape, size_t rank, rmhip_
     CTX_OR_FAIL(ctx);
     Buffer ob;
     int rc;
+    if (c->precision != 32 && c->lazy_randn && out && (rank == 0 || shape) && shape_numel(shape, rank) >= c->lazy_randn_min &&
+        shape_numel(shape, rank) >= 2) {
+        // Lazy record: no storage, no launch.  A streaming fused elementwise kernel that reads it generates the normals in registers
+        // (8 B per sample never written and never read back); anything else materialises it under this id with k_rng_normal on the
+        // recorded state.  The stream advances now, exactly as for an eager call.
+        Buffer b;
+        b.shape.assign(shape, shape + rank);
+        b.numel = shape_numel(shape, rank);
+        b.rng_lazy = true;
+        b.rng_state = c->rng_state;
+        const size_t numel = b.numel;
+        RMHIP_TRY(c->register_buffer(std::move(b), out));
+        c->lazy_randn_created++;
+        c->rng_state = lcg_advance(c->rng_state, 2 * ((numel + 1) / 2));
+        return RMHIP_OK;
+    }
     if (c->precision == 32) {
         RMHIP_TRY(c->new_buffer_f32(shape, rank, out, &ob));
         rc = launch_rng_normal_f32(c, c->rng_state, ob.data_f32(), ob.numel);

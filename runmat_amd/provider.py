@@ -941,6 +941,16 @@ class HipProvider:
     def set_rng_state(self, state: int) -> None:
         self._check(self._lib.rmhip_set_rng_state(self._ctx, int(state) & 0xFFFFFFFFFFFFFFFF))
 
+    def set_lazy_random(self, enabled: bool, min_numel: int = 0) -> None:
+        """rmhip_set_lazy_random: whether `random_normal` returns storage-less handles that a streaming fused elementwise kernel
+        generates in registers (default on from 1024 elements on f64 providers); `min_numel` 0 keeps the threshold."""
+        self._check(self._lib.rmhip_set_lazy_random(self._ctx, 1 if enabled else 0, int(min_numel)))
+
+    def lazy_random_stats(self) -> dict:
+        a, b, c_ = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self._lib.rmhip_lazy_random_stats(self._ctx, C.byref(a), C.byref(b), C.byref(c_)))
+        return {"created": int(a.value), "fused": int(b.value), "materialised": int(c_.value)}
+
     def get_rng_state(self) -> int:
         s = C.c_uint64()
         self._check(self._lib.rmhip_get_rng_state(self._ctx, C.byref(s)))
