@@ -103,7 +103,9 @@ __global__ void __launch_bounds__(256) k_rng_normal(unsigned long long state, T*
     // the state u1 of pair g is drawn from; the thread follows it (see k_rng_uniform)
     unsigned long long x1 = lcg_skip2(state, 512ULL * blockIdx.x, 2ULL * threadIdx.x + 1ULL);
     const bool aligned = (((uintptr_t)out) & (2 * sizeof(T) - 1)) == 0;
-    for (size_t i = g; i < npairs; i += stride) {
+    const size_t full = n / 2;  // whole pairs; an odd length adds z0 of one more pair (random.rs:536-540), stored by the thread whose turn it is
+    size_t i = g;
+    for (; i < full; i += stride) {
         const unsigned long long x2 = lcg_step(x1);
         const double radius = bm_radius(x1, tb);
         double sn, cs;
@@ -113,16 +115,21 @@ __global__ void __launch_bounds__(256) k_rng_normal(unsigned long long state, T*
             z0 = mu + sigma * z0;
             z1 = mu + sigma * z1;
         }
-        if (2 * i + 1 < n) {
-            if (aligned) *(P*)(out + 2 * i) = P{(T)z0, (T)z1};
-            else {
-                out[2 * i] = (T)z0;
-                out[2 * i + 1] = (T)z1;
-            }
-        } else {
-            out[2 * i] = (T)z0;  // odd length: z1 of the last pair is dropped (random.rs:536-540)
+        if (aligned) *(P*)(out + 2 * i) = P{(T)z0, (T)z1};
+        else {
+            out[2 * i] = (T)z0;
+            out[2 * i + 1] = (T)z1;
         }
         x1 = jm * x1 + jp;  // jump 2*stride steps
+    }
+    if (i < npairs) {  // i == full, n odd
+        const unsigned long long x2 = lcg_step(x1);
+        const double radius = bm_radius(x1, tb);
+        double sn, cs;
+        bm_sincos(x2, tb, &sn, &cs);
+        double z0 = radius * cs;
+        if (SCALED) z0 = mu + sigma * z0;
+        out[2 * i] = (T)z0;
     }
 }
 

@@ -88,7 +88,8 @@ __device__ __forceinline__ double bm_radius(unsigned long long x1, const BmTable
     const unsigned mh = hi & 0xfffffu;
     const unsigned jr = mh + 0x1000u;                       // round to the nearest 1/128 (may carry into bit 20: j = 128)
     const unsigned j = jr >> 13;
-    const int e = (int)(hi >> 20) - 1076 + (jr >= ((unsigned)RM_LOG_SPLIT << 13) ? 1 : 0);  // exponent of u1 (+ 1 above sqrt(2))
+    // exponent of u1 (+ 1 above sqrt(2)); the comparison as bit 31 of a sum (jr < 2^21): three 32-bit integer ops, no vcc round trip
+    const int e = (int)(hi >> 20) - 1076 + (int)((jr + (0x80000000u - ((unsigned)RM_LOG_SPLIT << 13))) >> 31);
     const double m = __longlong_as_double((long long)(((unsigned long long)(mh | 0x3ff00000u) << 32) | (bits & 0xffffffffull)));
     const v2d te = tb.lg[j];
     const double r = __builtin_fma(m, te.x, -1.0);
@@ -110,8 +111,11 @@ __device__ __forceinline__ double bm_radius(unsigned long long x1, const BmTable
     h = __builtin_fma(h, c, h);
     const double d = __builtin_fma(-g, g, x);
     g = __builtin_fma(d, h, g);
-    // u1 = 0 is replaced by f64::MIN_POSITIVE (random.rs:13,281-283): sqrt(-2 ln 2^-1022)
-    return (x1 >> 11) == 0 ? 0x1.2d1f5a276d140p+5 : g;
+    // u1 = 0 is replaced by f64::MIN_POSITIVE (random.rs:13,281-283): sqrt(-2 ln 2^-1022).  One draw in 2^53: tested for the whole wave
+    // (a compare and a scalar branch) instead of two v_cndmask on vcc per pair - that form costs 23 cycles per instruction on gfx950
+    // (profiles/r04_valu_instruction_rates.txt)
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64((x1 >> 11) == 0) != 0, 0)) return (x1 >> 11) == 0 ? 0x1.2d1f5a276d140p+5 : g;
+    return g;
 }
 
 __device__ __forceinline__ void bm_sincos(unsigned long long x2, const BmTables& tb, double* sn, double* cs) {
