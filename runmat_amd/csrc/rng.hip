@@ -90,6 +90,37 @@ __global__ void __launch_bounds__(256) k_rng_exponential(unsigned long long stat
 }
 
 // SCALED: mu + sigma z (generate_normal_scaled, random.rs:302-320)
+// Affine maps of the first 256 odd step counts: thread t of a block draws u1 of its first pair 2 t + 1 steps past the block's start
+// state - one 64-bit multiply-add from this table instead of a skip-ahead loop per thread (computed by the compiler).
+struct LcgSkipTable {
+    unsigned long long mp[512];
+};
+static constexpr LcgSkipTable make_skip_table() {
+    LcgSkipTable t{};
+    for (int i = 0; i < 256; ++i) {
+        unsigned long long delta = 2ULL * i + 1ULL, cur_mult = 6364136223846793005ULL, cur_plus = 1ULL, acc_mult = 1ULL, acc_plus = 0ULL;
+        while (delta > 0) {
+            if (delta & 1ULL) {
+                acc_mult = acc_mult * cur_mult;
+                acc_plus = acc_plus * cur_mult + cur_plus;
+            }
+            cur_plus = cur_plus * (cur_mult + 1ULL);
+            cur_mult = cur_mult * cur_mult;
+            delta >>= 1;
+        }
+        t.mp[2 * i] = acc_mult;
+        t.mp[2 * i + 1] = acc_plus;
+    }
+    return t;
+}
+static __device__ const LcgSkipTable kPairSkip = make_skip_table();
+
+// Round 6: WHICH pairs a block generates.  A grid-stride loop over the whole tensor wrote 4.7 TB/s whatever the arithmetic cost (the
+// step without its stores takes 130 us per 1e8 samples, with them 169); one contiguous chunk of kPairsPerThread * 256 pairs per block,
+// walked front to back in 4 KiB rows, writes 5.2 TB/s (153 us; scripts/micro/rng_patterns.hip: 8 / 16 / 32 / 64 pairs per thread
+// 162 / 153 / 156 / 154 us, per-wave chunks and a doubling skip-ahead per thread slower) - the write-only pattern that also serves
+// k_fill / k_linspace best (profiles/r04_write_patterns.txt).
+static constexpr int kPairsPerThread = 16;
 template <class T, bool SCALED = false>
 __global__ void __launch_bounds__(256) k_rng_normal(unsigned long long state, T* __restrict__ out, size_t n,
                                                     unsigned long long jm, unsigned long long jp, double mu = 0.0, double sigma = 1.0) {
@@ -97,15 +128,17 @@ __global__ void __launch_bounds__(256) k_rng_normal(unsigned long long state, T*
     __shared__ __attribute__((aligned(16))) double s_tab[kBmLdsDoubles];
     const BmTables tb = bm_stage_tables(s_tab, threadIdx.x, 256);
     const size_t npairs = (n + 1) / 2;
-    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * 256;
-    if (g >= npairs) return;
-    // the state u1 of pair g is drawn from; the thread follows it (see k_rng_uniform)
-    unsigned long long x1 = lcg_skip2(state, 512ULL * blockIdx.x, 2ULL * threadIdx.x + 1ULL);
+    const size_t full = n / 2;  // whole pairs; an odd length adds z0 of one more pair (random.rs:536-540)
+    const size_t base = (size_t)blockIdx.x * (256 * kPairsPerThread);
+    const size_t lim = base + 256 * kPairsPerThread < full ? base + 256 * kPairsPerThread : full;
+    // the state u1 of this thread's first pair is drawn from: 2 base steps to the block's chunk (uniform: scalar unit), 2 t + 1 more by table
+    unsigned long long mb, pb;
+    lcg_jump(2ULL * base, &mb, &pb);
+    unsigned long long x1 = kPairSkip.mp[2 * threadIdx.x] * (mb * state + pb) + kPairSkip.mp[2 * threadIdx.x + 1];
     const bool aligned = (((uintptr_t)out) & (2 * sizeof(T) - 1)) == 0;
-    const size_t full = n / 2;  // whole pairs; an odd length adds z0 of one more pair (random.rs:536-540), stored by the thread whose turn it is
-    size_t i = g;
-    for (; i < full; i += stride) {
+    size_t i = base + threadIdx.x;
+#pragma unroll 1
+    for (; i < lim; i += 256) {
         const unsigned long long x2 = lcg_step(x1);
         const double radius = bm_radius(x1, tb);
         double sn, cs;
@@ -120,9 +153,9 @@ __global__ void __launch_bounds__(256) k_rng_normal(unsigned long long state, T*
             out[2 * i] = (T)z0;
             out[2 * i + 1] = (T)z1;
         }
-        x1 = jm * x1 + jp;  // jump 2*stride steps
+        x1 = jm * x1 + jp;  // the next row of the chunk: 256 pairs = 512 steps on
     }
-    if (i < npairs) {  // i == full, n odd
+    if (i == full && i < npairs && i < base + 256 * kPairsPerThread) {  // n odd: z0 of the last pair
         const unsigned long long x2 = lcg_step(x1);
         const double radius = bm_radius(x1, tb);
         double sn, cs;
@@ -234,9 +267,11 @@ int launch_rng_exponential(Context* c, uint64_t state, double mu, double* out64,
 template <class T, bool SCALED>
 static int rng_normal_any(Context* c, uint64_t state, T* out, size_t n, double mu = 0.0, double sigma = 1.0) {
     if (n == 0) return RMHIP_OK;
-    const unsigned grid = rng_grid(c, (n + 1) / 2);
+    const size_t npairs = (n + 1) / 2, per_block = (size_t)256 * kPairsPerThread;
+    if ((npairs + per_block - 1) / per_block > 0x7fffffffULL) return fail(RMHIP_ERR_UNSUPPORTED, "random_normal: tensor too large");
+    const unsigned grid = (unsigned)((npairs + per_block - 1) / per_block);  // one contiguous chunk per block
     unsigned long long jm, jp;
-    lcg_jump(2ULL * grid * 256ULL, &jm, &jp);
+    lcg_jump(512ULL, &jm, &jp);  // one 256-pair row
     hipLaunchKernelGGL((k_rng_normal<T, SCALED>), dim3(grid), dim3(256), 0, c->stream, (unsigned long long)state, out, n, jm, jp, mu, sigma);
     c->tel.kernel_launches++;
     RMHIP_HIP_CHECK(hipGetLastError());

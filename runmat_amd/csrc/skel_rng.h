@@ -37,11 +37,14 @@ __device__ __forceinline__ unsigned long long lcg_skip2(unsigned long long state
 __device__ __forceinline__ unsigned long long lcg_step(unsigned long long s) { return s * kMult + kInc; }
 // (s >> 11) as a double, exactly (53 bits): two conversions and one fma
 __device__ __forceinline__ double lcg_bits53(unsigned long long s) {
-    // 32-bit pieces throughout: a 64-bit integer -> double conversion is expanded into four instructions even when the value is
-    // known to be small
+    // 32-bit pieces throughout (a 64-bit integer -> double conversion is expanded into four instructions even when the value is known
+    // to be small), and no v_cvt_f64_u32 either (8 cycles each, profiles/r04_valu_instruction_rates.txt): the pieces are dropped into
+    // the mantissas of 2^84 and 2^52 and the offsets subtracted - two exact additions
     const unsigned s_hi = (unsigned)(s >> 32), s_lo = (unsigned)s;
     const unsigned hi = s_hi >> 11, lo = (s_hi << 21) | (s_lo >> 11);
-    return __builtin_fma((double)hi, 4294967296.0, (double)lo);
+    const double a = __longlong_as_double((long long)(((unsigned long long)0x45300000u << 32) | hi));   // 2^84 + hi 2^32 (unit 2^32)
+    const double b = __longlong_as_double((long long)(((unsigned long long)0x43300000u << 32) | lo));   // 2^52 + lo
+    return (a - 0x1.00000001p+84) + b;  // (hi 2^32 - 2^52) + (2^52 + lo), both steps exact
 }
 __device__ __forceinline__ double lcg_uniform(unsigned long long s) { return lcg_bits53(s) * (1.0 / 9007199254740992.0); }
 
@@ -119,11 +122,17 @@ __device__ __forceinline__ double bm_radius(unsigned long long x1, const BmTable
 }
 
 __device__ __forceinline__ void bm_sincos(unsigned long long x2, const BmTables& tb, double* sn, double* cs) {
-    const double vd = lcg_bits53(x2);                              // t 2^52, t = 2 u2
-    const double jf = __builtin_rint(vd * 0x1p-44);                // round(256 t), 0 .. 512
-    const double dv = __builtin_fma(jf, -0x1p44, vd);              // (t - j / 256) 2^52, exact
+    // t = 2 u2 = v 2^-52 with v = x2 >> 11 (53 bits); j = round(256 t) = round(v 2^-44), d = v - j 2^44 in [-2^43, 2^43] - all in
+    // 32-bit integer arithmetic on the upper word (the lower one only decides exact ties), and d enters the floating-point unit by one
+    // addition: its two words are laid over the mantissa of 1.5 2^52
+    const unsigned s_hi = (unsigned)(x2 >> 32), s_lo = (unsigned)x2;
+    const unsigned hi = s_hi >> 11, lo = (s_hi << 21) | (s_lo >> 11);
+    const unsigned tmp = hi + 0x800u;
+    const unsigned j = tmp >> 12;                                   // 0 .. 512
+    const unsigned dh = (tmp & 0xfffu) + (0x43380000u - 0x800u);    // upper word of 1.5 2^52 + d
+    const double dv = __longlong_as_double((long long)(((unsigned long long)dh << 32) | lo)) - 0x1.8p+52;  // (t - j / 256) 2^52, exact
     const double x = dv * 0x1.921fb54442d18p-51;                   // pi 2^-52
-    const v2d te = tb.sc[(int)jf];
+    const v2d te = tb.sc[j];
     const double z = x * x;
     const double ps = __builtin_fma(z, 0x1.1111111111111p-7, -0x1.5555555555555p-3);  // 1/120, -1/6
     const double sd = __builtin_fma(x * z, ps, x);                 // sin x
