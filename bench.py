@@ -544,7 +544,7 @@ def main() -> None:
                 "roofline": roofline("hbm", moved / world / (ms * 1e-3) / 1e9, 1,
                                      kernel="rm_ew_fast with an in-register Box-Muller operand (fp64 VALU bound) + rm_red_contig (whole step, wall clock; "
                                             "16 B per sample moved)",
-                                     speedup_vs_32B_plan_bytes=2.0),
+                                     traffic=pmc_traffic("mc_lazy"), traffic_source=PMC_TRAFFIC_SOURCE + " (per step)"),
             }
         # Bytes the three kernels MOVE per sample: randn writes Z (8), the fused update reads Z and writes S (16; S0 is a scalar
         # operand at T = 1), the payoff reduction reads S (8) = 32.  SURVEY.md 8(d) prices the reference's MATERIALISED plan at
@@ -717,7 +717,14 @@ def main() -> None:
         flops = (2.0 / 3.0) * nn ** 3 + 2.0 * nn * nn
         for h in (ha, ones, hb):
             prov.free(h)
+        phases = None
+        if cyclic and not form.get("cols"):
+            try:  # device time by phase of the LAST solve on this rank (rmhip_rp_phase_ms): what a measured SCALE run is laid against
+                phases = {k: round(v, 3) for k, v in prov.rp_phase_ms().items()}
+            except Exception:  # noqa: BLE001
+                phases = None
         return {
+            "phases_ms_rank0": phases,
             "metric": "fp64 GFLOP/s (x = A\\b, 16384x16384, blocked LU)",
             "value": round(flops / (ms * 1e-3) / 1e9, 1), "unit": "GFLOP/s", "ms_per_step": round(ms, 3), "scaling": "strong",
             "dtype": "f64",
@@ -726,6 +733,7 @@ def main() -> None:
                        # forward-error bounds by generator (tests/test_gpu_lookahead.py): U(-1,1) as here - cond ~ 1e5 at this order - 1e-7;
                        # SURVEY.md 8(d)'s 1e-9 belongs to the diagonally dominant U(-1,1) + n*I generator
                        "max_abs_err_bound": {"generator": "U(-1,1) (this run)", "bound": 1e-7, "diagonally_dominant_U_plus_nI_bound": 1e-9},
+                       **({"row_partitioned_phases_ms_rank0": phases} if phases else {}),
                        "parallelism": form["name"]},
             "roofline": {**roofline("mfma", flops / (ms * 1e-3) / 1e12, 3),
                          "traffic": pmc_traffic("mldivide"), "traffic_source": PMC_TRAFFIC_SOURCE + " (per solve, fabric side)",

@@ -877,6 +877,13 @@ RMHIP_API int rmhip_matmul_row_sharded(rmhip_ctx* ctx, rmhip_buf a_rows, rmhip_b
 /* @serves - */
 RMHIP_API int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n, size_t nrhs, size_t rb, double tau,
                                              rmhip_buf* out);
+/* Device time of the last rmhip_mldivide_row_partitioned call on this context by phase, in milliseconds (timed events on the streams the
+ * phases ran on): out4 = { panel (the owner's factorisation, interchanges, U12, tile copy), wait (this rank's stream idling for a tile
+ * broadcast), update (multipliers + trailing updates; with the overlap on they run beside the panels, so the sum may exceed the wall
+ * clock), exchange (the multiplier guard's gather, the gathered tail and its replicated solve, the back substitution) }.
+ * RMHIP_RP_TIMERS=0 turns the events off (zeros). */
+/* @serves - */
+RMHIP_API int rmhip_rp_phase_ms(rmhip_ctx* ctx, double* out4);
 
 /* ---- RNG  (lib.rs:1713-1728, 1772) ---------------------------------------------------------- */
 

@@ -197,10 +197,18 @@ struct Context {
     const double* lu_work = nullptr;
     size_t lu_work_ld = 0;
     bool gemm_chain_prio = false;  // the look-ahead LU's main-stream dgemm launches raise their wave priority (RMHIP_LU_GEMM_PRIO=0 disables)
+    unsigned* gemm_announce_tab = nullptr;  // the table itself while a two-level factorisation runs (k_trsm_lower_mfma on the main stream)
+    bool lu_yield_trsm = false;
+    unsigned* gemm_announce = nullptr;  // two-level LU: the yield table for the main stream's dgemm blocks to count themselves into (RMHIP_LU_YIELD_ALL)
     const unsigned* gemm_yield_word = nullptr;  // two-level LU: the CU (key) whose update blocks pause while k_rp_top runs there (device word; 0: none)
+    double* gemm_split_ws = nullptr;  // caller-owned workspace for split-K partial products (per stream; see launch_dgemm)
+    size_t gemm_split_ws_elems = 0;
+    size_t gemm_split_min_k = 0;  // != 0: launch_dgemm splits the inner dimension of few-tile products from this k on (the LU's products with inverted L11 blocks)
+    double lu_last_minv = 0.0;    // largest |entry| of the inverted L11 blocks of the last solve-path factorisation (0: none were formed)
     bool in_lookahead = false;  // inside the LU's look-ahead driver: main-stream dgemm blocks must fit beside the update stream's
     // set after a persistent-panel factorisation found its workgroups not co-resident (device shared with
     // another context): from then on LU uses the one-launch-per-column panels on a single stream
+    double rp_phase_ms[4] = {0, 0, 0, 0};  // rmhip_rp_phase_ms: panel / broadcast wait / update / exchange device time of the last row-partitioned solve
     hipStream_t lu_side_stream = nullptr;  // update stream of the look-ahead LU (low priority), created on first use
     hipStream_t lu_aux_stream = nullptr;   // solve path: the full-height kernels' rows below the band of the panel in flight (lu.hip, LuState::aux)
     hipStream_t lu_prep_stream = nullptr;  // interchanges + triangular solves of one half of the trailing columns under the other half's dgemm
@@ -404,7 +412,10 @@ static constexpr int RMHIP_LU_RETRY = -77;
 static constexpr int RMHIP_LU_GROWTH = -79;  // internal status of lu_factor_device (mode 1): a multiplier exceeded the bound, refactor a fresh copy in mode 0
 static constexpr int RMHIP_SUBST_RETRY = -78;  // internal status of substitute_few_rhs: the chain kernel timed out, gather the right-hand side again
 int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda, int* perm_dev,
-                     int* info_host, std::vector<int>* ipiv_host = nullptr, int mode = 0);
+                     int* info_host, std::vector<int>* ipiv_host = nullptr, int mode = 0, double* ipiv_dev_f64 = nullptr);
+// interchanges from a device vector of doubles (rmhip_blk_lu's result), composed and applied on the device; RMHIP_ERR_UNSUPPORTED (no error
+// string) when the view is too tall for the LDS map - the caller then composes on the host
+int lu_swap_rows_from_device(Context* c, double* A, size_t lda, size_t nrows, size_t ncols, const double* ipiv_dev, size_t npiv);
 int lu_swap_rows_device(Context* c, double* A, size_t lda, size_t ncols, const std::vector<int>& ipiv);
 int trsm_lower_unit_device(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc);
 int trsm_upper_device(Context* c, const double* T, size_t ldt, size_t w, double* B, size_t ldb, size_t nc);
@@ -436,5 +447,33 @@ int small_solve_device(Context* c, const double* A, const double* B, size_t n, s
 // opaque handle -> Context (rmhip_core.cpp)
 Context* context_of(rmhip_ctx* h);
 void comm_destroy(Context* c);  // comm.cpp
+
+
+// ---- cooperative yield table (two-level LU) -----------------------------------------------------------------------------------------
+// One counter per CU (index: XCC id << 8 | the cu / sh / se byte of HW_ID; kYieldSlots entries).  A workgroup of the LU's critical chain
+// (k_rp_top, the main stream's dgemm / trsm / rows-below kernels) counts itself in while it runs; the update streams' eight-wave dgemm
+// blocks read their CU's counter once per k tile and sleep while it is non-zero (dgemm.hip w8_tile<YIELD>): the fp64 VALU and the matrix
+// pipe are one datapath per SIMD, and every instruction of a chain kernel otherwise queues behind the update block's MFMAs.
+static constexpr unsigned kYieldSlots = 4096;
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned cu_slot() {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    return ((xcc & 0xfu) << 8) | ((hw >> 8) & 0xffu);
+}
+struct CuAnnounce {
+    unsigned* p;
+    __device__ __forceinline__ explicit CuAnnounce(unsigned* tab) : p(tab ? tab + cu_slot() : nullptr) {
+        if (p && threadIdx.x == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // every thread of the workgroup calls this (it synchronises the workgroup first: no wave is still computing when the CU is released)
+    __device__ __forceinline__ void done() const {
+        if (!p) return;
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_sub(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+#endif
 
 }  // namespace rmhip

@@ -81,6 +81,7 @@ struct GemmArgs {
     // eight-wave tile on the LU's update streams: a device word naming the CU (key: bit 31 | XCC id << 8 | HW_ID cu/sh/se byte) on which
     // k_rp_top is running right now; a block on that CU pauses until the word changes (nullptr: no check)
     const unsigned* yield_word;
+    unsigned* announce;  // the same table, for a block of the LU's main stream: it counts itself in on its CU while it runs (CuAnnounce), or nullptr
     int prio;  // nonzero: raise the wave priority (s_setprio 3) - the LU's main-stream updates, which share SIMDs with the update streams' blocks
 };
 
@@ -143,6 +144,7 @@ template <bool EDGE, bool EPI, bool TA, bool TB, bool PRE = false>
 __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (g.prio) __builtin_amdgcn_s_setprio(3);
+    const CuAnnounce on_cu(g.announce);
     double* As = lds;                    // [2][A_TILE]
     double* Bs = lds + 2 * A_TILE;       // [2][B_TILE]   (A_TILE == B_TILE)
 
@@ -419,6 +421,7 @@ __global__ void __launch_bounds__(256, 2) k_dgemm(const GemmArgs g) {
             }
         }
     }
+    on_cu.done();
 }
 
 
@@ -441,6 +444,7 @@ static constexpr int S_B_TILE = SN * SB;     // 1152 doubles
 template <bool PRE, bool GUARD = false>  // PRE: C <- C - A*B with the C tile preloaded into the accumulators (see k_dgemm)
 __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
     if (g.prio) __builtin_amdgcn_s_setprio(3);
+    const CuAnnounce on_cu(g.announce);
     __shared__ __attribute__((aligned(16))) double As[2][S_A_TILE];
     __shared__ __attribute__((aligned(16))) double Bs[2][S_B_TILE];
     const unsigned tm = blockIdx.x % g.tiles_m, tn = blockIdx.x / g.tiles_m;  // column-major tile order: neighbours share B
@@ -561,6 +565,7 @@ __global__ void __launch_bounds__(256) k_dgemm_small(const GemmArgs g) {
                 }
                 if (ok[e]) *dst[e] = v;
             }
+    on_cu.done();
 }
 
 
@@ -700,20 +705,16 @@ __device__ __forceinline__ void w8_tile(const GemmArgs& g, const unsigned tm, co
         // cooperative yield (YIELD instantiation, GemmArgs::yield_word): the word read during the previous k tile names the CU on which the
         // LU's k_rp_top is running; if that is this CU, sleep until it changes (bounded: ~2 ms).  A separate instantiation: the check in the
         // plain kernel's pipelined loop cost the 8192^3 product 5 % (15.2 -> 16.0 ms)
-        unsigned my_cu = 0, yv = 0;
-        if (YIELD && g.yield_word) {
-            unsigned xcc, hw;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-            my_cu = 0x80000000u | ((xcc & 0xfu) << 8) | ((hw >> 8) & 0xffu);
-        }
+        const unsigned* my_slot = nullptr;
+        unsigned yv = 0;
+        if (YIELD && g.yield_word) my_slot = g.yield_word + cu_slot();  // this CU's counter of the table (common.h: CuAnnounce)
         for (unsigned kt = 0; kt < ktiles; ++kt) {
             if (YIELD && g.yield_word) {
-                if (__builtin_amdgcn_readfirstlane(yv) == my_cu) {
-                    for (int spin = 0; spin < 4096 && __hip_atomic_load(g.yield_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_cu; ++spin)
+                if (__builtin_amdgcn_readfirstlane(yv) != 0) {
+                    for (int spin = 0; spin < 4096 && __hip_atomic_load(my_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; ++spin)
                         __builtin_amdgcn_s_sleep(16);
                 }
-                yv = __hip_atomic_load(g.yield_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                yv = __hip_atomic_load(my_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             const int cur = kt & 1;
             const double* a = As + cur * A_TILE + a_off;
@@ -964,11 +965,12 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
     g.avoid_xcc = nullptr;
     g.yield_word = (c->gemm_lds_pad != 0) ? c->gemm_yield_word : nullptr;  // update streams of the two-level LU only
     g.prio = (c->in_lookahead && c->gemm_lds_pad == 0 && c->gemm_chain_prio) ? 1 : 0;  // the look-ahead LU's main stream
+    g.announce = (c->in_lookahead && c->gemm_lds_pad == 0) ? c->gemm_announce : nullptr;     // ... whose blocks ask the update blocks on their CU to pause
     std::shared_ptr<Allocation> partials;
     // (round 3: from k = 1024 - slices of multiples of 128 - outside the LU.  A block walks its k range at about 1 us per 16 columns
     // - one memory latency per tile with nothing else resident - so few blocks with a long k are latency bound whatever the tile:
     // 4096 x 100 with k = 4096 (32 tiles) 547 -> 97 us, 32 x 512 with k = 8192 on one slice 1100 us.)
-    const size_t split_min_k = c->in_lookahead ? 8192 : 1024;
+    const size_t split_min_k = c->gemm_split_min_k ? c->gemm_split_min_k : (c->in_lookahead ? 8192 : 1024);
     if (!ep && blocks * 4 <= (unsigned)c->num_cus && k >= split_min_k) {
         const size_t want = (2 * (size_t)c->num_cus + blocks - 1) / blocks;
         size_t chunk = (k + want - 1) / want;
@@ -976,9 +978,13 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
         chunk = ((chunk + gran - 1) / gran) * gran;
         splits = (unsigned)((k + chunk - 1) / chunk);
         if (splits > 1) {
-            RMHIP_TRY(c->alloc_device((size_t)splits * m * n, &partials));
+            // a caller that runs several streams (the two-level LU) lends a workspace per stream: a pooled block released at the end of
+            // this call could be handed to another stream's call while this one's kernels are still queued
+            double* ws = nullptr;
+            if (c->gemm_split_ws && c->gemm_split_ws_elems >= (size_t)splits * m * n) ws = c->gemm_split_ws;
+            else RMHIP_TRY(c->alloc_device((size_t)splits * m * n, &partials));
             g.k_chunk = (unsigned)chunk;
-            g.C = partials->ptr;
+            g.C = ws ? ws : partials->ptr;
             g.ldc = m;
             g.c_split_stride = (unsigned long long)m * n;
             g.alpha = 1.0;
@@ -1071,7 +1077,7 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
         if (splits > 1) {
             const size_t mn = m * n;
             const unsigned rgrid = (unsigned)((mn + 255) / 256 < (size_t)c->num_cus * 4 ? (mn + 255) / 256 : (size_t)c->num_cus * 4);
-            hipLaunchKernelGGL(k_reduce_splits, dim3(rgrid), dim3(256), 0, c->stream, partials->ptr, mn, m, splits, alpha, beta, C, ldc);
+            hipLaunchKernelGGL(k_reduce_splits, dim3(rgrid), dim3(256), 0, c->stream, (const double*)g.C, mn, m, splits, alpha, beta, C, ldc);
             c->tel.kernel_launches++;
             RMHIP_HIP_CHECK(hipGetLastError());
         }
@@ -1166,7 +1172,7 @@ static int launch_dgemm_impl(Context* c, size_t m, size_t n, size_t k, double al
     if (splits > 1) {
         const size_t mn = m * n;
         const unsigned rgrid = (unsigned)((mn + 255) / 256 < (size_t)c->num_cus * 4 ? (mn + 255) / 256 : (size_t)c->num_cus * 4);
-        hipLaunchKernelGGL(k_reduce_splits, dim3(rgrid), dim3(256), 0, c->stream, partials->ptr, mn, m, splits, alpha, beta, C,
+        hipLaunchKernelGGL(k_reduce_splits, dim3(rgrid), dim3(256), 0, c->stream, (const double*)g.C, mn, m, splits, alpha, beta, C,
                            ldc);
         c->tel.kernel_launches++;
         RMHIP_HIP_CHECK(hipGetLastError());

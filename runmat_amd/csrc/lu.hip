@@ -83,7 +83,9 @@ struct LuState {
     unsigned ucomp_slot = 0;              // ring of compact U copies: k_rp_below on `aux` may still read panel p's while k_rp_top writes p + 1's
     hipEvent_t aux_tail = nullptr;        // last event recorded on aux (what the main stream's next look-ahead update has to wait for)
     double* linv = nullptr;               // solve path: inverted 16 x 16 diagonal blocks of L, block q at 256 q (k_trsm_lower_mfma)
-    unsigned* yield_word = nullptr;       // two-level driver: device word through which k_rp_top asks the update blocks on its CU to pause
+    unsigned* yield_word = nullptr;       // two-level driver: the yield table (common.h CuAnnounce) through which chain kernels ask the update blocks on their CU to pause
+    int yield_all = 0;                    // which chain kernels besides k_rp_top count themselves in: 1 main-stream dgemm, 2 k_rp_below_mfma, 4 k_trsm_lower_mfma
+    unsigned long long* minv_max = nullptr;  // two-level driver: bits of the largest |entry| of the super-panels' inverted L11 blocks (guard, see getrf_super)
 };
 static constexpr unsigned kUcompSlots = 16;  // >= base panels per look-ahead panel (512 / 64) with room to spare
 // one slot: the 64 x 64 compact U of k_rp_top, then the inverses of its four 16 x 16 diagonal blocks (row-major [k][i], zero below the
@@ -1043,7 +1045,7 @@ __global__ void __launch_bounds__(RT_ROWS) k_rp_top(const RtArgs g, pk_u64* dbg)
     // the same SIMD - 57-63 us for a 64-column top block on a CU of its own, 120-250 us beside a block of the deep update (rocprofv3
     // timeline, round 5) - and it is a quarter of the critical chain.  It names its CU in a device word; the update streams' eight-wave
     // blocks read that word once per k tile and the one that finds its own CU there sleeps until the word changes (dgemm.hip, w8_tile).
-    if (t == 0 && g.yield_word) __hip_atomic_store(g.yield_word, cu_key(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const CuAnnounce on_cu(g.yield_word);
     const size_t r = (size_t)g.j0 + t;
     const bool in_rows = r < g.rows;
     int pos = in_rows ? (int)r : -1, retk = -1, rpiv = 0;
@@ -1175,10 +1177,7 @@ __global__ void __launch_bounds__(RT_ROWS) k_rp_top(const RtArgs g, pk_u64* dbg)
             for (int i = 0; i < 16; ++i) dst[i] = x[i];
         }
     }
-    if (g.yield_word) {
-        __syncthreads();
-        if (t == 0) __hip_atomic_store(g.yield_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    on_cu.done();
 }
 
 // Rows below the top block on the matrix cores (round 5).  Beside an update block every fp64 VALU instruction of a chain kernel waits
@@ -1194,11 +1193,12 @@ __global__ void __launch_bounds__(RT_ROWS) k_rp_top(const RtArgs g, pk_u64* dbg)
 // ~ cond(U_bb) eps per block instead of eps per step); the multiplier bound is checked exactly as before.
 static constexpr int RBM_JT = 2;  // 16-row tiles per wave (32 rows: 64 accumulator registers - the wave must fit beside an update block's two waves per SIMD)
 __global__ void __launch_bounds__(64) k_rp_below_mfma(double* __restrict__ A, const size_t lda, const size_t rows, const size_t r0, const int j0,
-                                                      const double* __restrict__ ut, pk_u64* __restrict__ growth) {
+                                                      const double* __restrict__ ut, pk_u64* __restrict__ growth, unsigned* yield_tab) {
     typedef double v4d __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) double Ub[10 * 256];  // block id(b, c), b <= c: diagonal = inv(U_bb), off-diagonal = -U_bc; [k][i] row-major
     const int t = threadIdx.x, l15 = t & 15, lq = t >> 4;
     chain_prio();
+    const CuAnnounce on_cu(yield_tab);
     {
         constexpr int BB[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, CC[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
 #pragma unroll
@@ -1262,6 +1262,7 @@ __global__ void __launch_bounds__(64) k_rp_below_mfma(double* __restrict__ A, co
     }
     mx = wave_max_u64(mx);
     if (t == 0 && mx != 0) atomicMax(growth, mx > 0x7ff0000000000000ull ? 0x7ff8000000000000ull : mx);
+    on_cu.done();
 }
 
 // Rows below the top block: l = a U11^-1, one thread per row, U (transposed, as k_rp_top left it) staged in LDS.  One wave per
@@ -1754,7 +1755,7 @@ __global__ void __launch_bounds__(TRSM_THREADS) k_trsm_lower_2p(const double* __
 // L2 hits), no LDS.  Rounding: products with an inverted 16 x 16 block instead of 16 substitution steps.
 template <int NB>  // 16 x 16 blocks of L: 4 (w = 64) or 8 (w = 128)
 __global__ void __launch_bounds__(64) k_trsm_lower_mfma(const double* __restrict__ T, const size_t ldt, const double* __restrict__ linv,
-                                                        double* __restrict__ B, const size_t ldb, const size_t nc) {
+                                                        double* __restrict__ B, const size_t ldb, const size_t nc, unsigned* yield_tab) {
     typedef double v4d __attribute__((ext_vector_type(4)));
     typedef double v2d __attribute__((ext_vector_type(2)));
     constexpr int W = 16 * NB;
@@ -1762,6 +1763,7 @@ __global__ void __launch_bounds__(64) k_trsm_lower_mfma(const double* __restrict
     __shared__ __attribute__((aligned(16))) double tile[16 * CS];  // this wave's 16 right-hand sides, [column][row]
     const int t = threadIdx.x, l15 = t & 15, lq = t >> 4;
     chain_prio();
+    const CuAnnounce on_cu(yield_tab);
     const size_t col0 = (size_t)blockIdx.x * 16;
     // coalesced load: one right-hand side per step, W rows as W / 2 lanes x 16 bytes (the rows of a column are contiguous in memory)
 #pragma unroll
@@ -1801,6 +1803,7 @@ __global__ void __launch_bounds__(64) k_trsm_lower_mfma(const double* __restrict
 #pragma unroll
     for (int cc = 0; cc < 16; ++cc)
         if (2 * t < W && col0 + cc < nc) *(v2d*)(B + (col0 + cc) * ldb + 2 * t) = *(const v2d*)(tile + cc * CS + 2 * t);
+    on_cu.done();
 }
 
 static int launch_check(Context* c);
@@ -1845,8 +1848,9 @@ static int launch_trsm_fused(Context* c, const double* T, size_t ldt, size_t w, 
         if (have) {
             const double* linv = c->lu_linv + (j / 16) * 256;
             const unsigned grid = (unsigned)((nc + 15) / 16);
-            if (w == 64) hipLaunchKernelGGL(k_trsm_lower_mfma<4>, dim3(grid), dim3(64), 0, c->stream, T, ldt, linv, B, ldb, nc);
-            else hipLaunchKernelGGL(k_trsm_lower_mfma<8>, dim3(grid), dim3(64), 0, c->stream, T, ldt, linv, B, ldb, nc);
+            unsigned* const ytab = (c->in_lookahead && c->gemm_lds_pad == 0 && c->lu_yield_trsm) ? c->gemm_announce_tab : nullptr;  // main stream of the two-level driver
+            if (w == 64) hipLaunchKernelGGL(k_trsm_lower_mfma<4>, dim3(grid), dim3(64), 0, c->stream, T, ldt, linv, B, ldb, nc, ytab);
+            else hipLaunchKernelGGL(k_trsm_lower_mfma<8>, dim3(grid), dim3(64), 0, c->stream, T, ldt, linv, B, ldb, nc, ytab);
             return launch_check(c);
         }
     }
@@ -2044,7 +2048,7 @@ static int getrf_rec(LuState& s, size_t j0, size_t w, bool own_swaps_by_caller =
                     if (r1 <= r0) return;
                     if (below_mfma) {
                         hipLaunchKernelGGL(k_rp_below_mfma, dim3((unsigned)((r1 - r0 + 16 * RBM_JT - 1) / (16 * RBM_JT))), dim3(64), 0, st, s.A, s.lda, r1, r0, (int)j0,
-                                           (const double*)ucomp, (pk_u64*)s.growth);
+                                           (const double*)ucomp, (pk_u64*)s.growth, (s.yield_all & 2) ? s.yield_word : (unsigned*)nullptr);
                         s.c->tel.kernel_launches++;
                         return;
                     }
@@ -2556,6 +2560,39 @@ static int getrf_blocked(LuState& s, size_t kmin, size_t nb) {
 // A super-panel of ONE panel is the one-level scheme (far = the update stream above), which is what the plan ends with once the
 // panel chain is the critical path.  Same kernels, same per-element operation order inside a panel; the trailing updates sum in
 // super-panel-sized groups (results agree with the one-level driver to rounding, pivots are identical).
+// ---- round 6: the W-wide unit-lower solves of the two-level driver as products with the explicit inverse ----------------------------
+// At a super-panel boundary every column right of it needs U12 = L11^-1 A12 with L11 the W x W unit-lower block of the super-panel
+// (W = 1024 / 2048) before the deep rank-W update.  As a recursive solve that is 31 launches of 128-wide solves and few-tile products
+// at low fill: 17 of the far stream's 58 ms, 1.2 of the 2 ms the main stream spends at every boundary, and the mid stream's 3 ms
+// before every second inner panel (round 5's timeline).  Instead the mid stream builds M = L11^-1 row block by row block while the
+// super-panel's inner panels are being factored (row block p as soon as panel p's interchanges have reached the columns left of it:
+// M_pp = L_pp^-1 by the 256-wide solve on an identity, M_p,0:p = -M_pp (L_p,0:p M_0:p,0:p), two small products), and the boundary
+// computes T = M A12 as ONE deep product per column chunk (twice the flops of the substitution, all of them at the deep-product rate),
+// updates with T as the B operand and copies T into A12 afterwards.
+// Error: |T - U12| <= c W eps |M| |L11| |U12|-like, i.e. the condition of L11 enters where substitution is backward stable.  The
+// solve path already bounds every multiplier by tau = 8; here the largest |M_ij| of every super-panel is recorded as well (k_absmax_word)
+// and a value above RMHIP_LU_MINV_MAX (default 1e6) sends the factorisation to the caller's fall-back like a multiplier above tau.
+// RMHIP_LU_MINV=0 restores the recursive solves.
+__global__ void __launch_bounds__(256) k_set_identity(double* __restrict__ M, size_t ld, unsigned w) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)w * w) return;
+    const unsigned r = (unsigned)(idx % w), cidx = (unsigned)(idx / w);
+    M[r + (size_t)cidx * ld] = r == cidx ? 1.0 : 0.0;
+}
+__global__ void __launch_bounds__(256) k_absmax_word(const double* __restrict__ M, size_t ld, unsigned rows, unsigned cols, pk_u64* __restrict__ word) {
+    pk_u64 mx = 0;
+    const size_t total = (size_t)rows * cols;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const pk_u64 b = (pk_u64)__double_as_longlong(M[idx % rows + (idx / rows) * ld]) & 0x7fffffffffffffffull;  // |x| (NaN sorts above Inf)
+        mx = b > mx ? b : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const pk_u64 o = __shfl_down(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    if ((threadIdx.x & 63) == 0 && mx != 0) atomicMax(word, mx > 0x7ff0000000000000ull ? 0x7ff8000000000000ull : mx);
+}
+
 struct SuperPanel {
     size_t s0, s1, nb;
 };
@@ -2600,6 +2637,9 @@ static int getrf_super(LuState& s, size_t kmin) {
             if (c->lu_mid_stream) (void)hipStreamSynchronize(c->lu_mid_stream);
             if (c->lu_far_stream) (void)hipStreamSynchronize(c->lu_far_stream);
             c->gemm_yield_word = nullptr;
+            c->gemm_announce = nullptr;
+            c->gemm_announce_tab = nullptr;
+            c->lu_yield_trsm = false;
             s->panel_pad_kb = -1;
             c->in_lookahead = false;
             c->trsm_base = trsm_base;
@@ -2649,12 +2689,45 @@ static int getrf_super(LuState& s, size_t kmin) {
     static const int yield_on = std::getenv("RMHIP_LU_YIELD") ? std::atoi(std::getenv("RMHIP_LU_YIELD")) : 1;
     static const long top_pad_env = std::getenv("RMHIP_LU_TOP_PAD_KB") ? std::atol(std::getenv("RMHIP_LU_TOP_PAD_KB")) : (yield_on ? 0 : -1);
     if (yield_on) {
-        RMHIP_TRY(c->alloc_device(2, &yield_ctl));
-        RMHIP_HIP_CHECK(hipMemsetAsync(yield_ctl->ptr, 0, 16, main_stream));
+        RMHIP_TRY(c->alloc_device(kYieldSlots / 2, &yield_ctl));
+        RMHIP_HIP_CHECK(hipMemsetAsync(yield_ctl->ptr, 0, sizeof(unsigned) * kYieldSlots, main_stream));
         s.yield_word = (unsigned*)yield_ctl->ptr;
         c->gemm_yield_word = s.yield_word;
         restore.clear_yield = true;
+        // round 6: other chain kernels count themselves in as well (RMHIP_LU_YIELD_ALL bit mask: 1 the main stream's dgemm blocks,
+        // 2 k_rp_below_mfma, 4 k_trsm_lower_mfma; 0 = k_rp_top alone as in round 5)
+        static const int yield_all = std::getenv("RMHIP_LU_YIELD_ALL") ? std::atoi(std::getenv("RMHIP_LU_YIELD_ALL")) : 0;
+        s.yield_all = yield_all;
+        c->gemm_announce = (yield_all & 1) ? s.yield_word : nullptr;
+        c->gemm_announce_tab = s.yield_word;
+        c->lu_yield_trsm = (yield_all & 4) != 0;
     }
+    // ---- explicit inverses of the super-panels' L11 blocks (see the note above k_set_identity)
+    const int minv_env = std::getenv("RMHIP_LU_MINV") ? std::atoi(std::getenv("RMHIP_LU_MINV")) : 0;  // (read per call: the tests run both forms; default off, see docs/EXPERIMENTS.md R6 1)
+    static const int minv_who = std::getenv("RMHIP_LU_MINV_WHO") ? std::atoi(std::getenv("RMHIP_LU_MINV_WHO")) : 7;   // dev: 1 main, 2 mid, 4 far use the inverse
+    static const int minv_ext_far = std::getenv("RMHIP_LU_MINV_EXT") ? std::atoi(std::getenv("RMHIP_LU_MINV_EXT")) : 0;  // dev: the inverse is built on the far stream
+    static const size_t far_chunk = std::getenv("RMHIP_LU_MINV_CHUNK") ? (size_t)std::atol(std::getenv("RMHIP_LU_MINV_CHUNK")) / 128 * 128 : 4096;
+    size_t Wmax = 0, nbmax = 0;
+    for (const SuperPanel& sp : plan)
+        if (sp.s1 - sp.s0 > sp.nb) {
+            Wmax = sp.s1 - sp.s0 > Wmax ? sp.s1 - sp.s0 : Wmax;
+            nbmax = sp.nb > nbmax ? sp.nb : nbmax;
+        }
+    std::shared_ptr<Allocation> minv_mem[2], mtmp_mem, t_main_mem, t_mid_mem, t_far_mem, split_ws[3];  // (split-K partials: one per stream)
+    const size_t kSplitWsElems = (size_t)8 << 20;  // at most 64 output tiles x 8 slices
+    const bool minv_on = minv_env != 0 && Wmax > 0 && s.minv_max != nullptr && far_chunk >= 128;
+    if (minv_on) {
+        const size_t far_cols = far_chunk > Wmax ? far_chunk : Wmax;
+        RMHIP_TRY(c->alloc_device(Wmax * Wmax, &minv_mem[0]));
+        RMHIP_TRY(c->alloc_device(Wmax * Wmax, &minv_mem[1]));
+        RMHIP_TRY(c->alloc_device(nbmax * Wmax, &mtmp_mem));
+        RMHIP_TRY(c->alloc_device(Wmax * 512, &t_main_mem));
+        RMHIP_TRY(c->alloc_device(Wmax * Wmax, &t_mid_mem));
+        RMHIP_TRY(c->alloc_device(Wmax * far_cols, &t_far_mem));
+        for (auto& w : split_ws) RMHIP_TRY(c->alloc_device(kSplitWsElems, &w));
+    }
+    hipEvent_t ev_minv = nullptr;                      // the inverse of the super-panel in flight is complete (mid stream)
+    hipEvent_t ev_minv_read[2] = {nullptr, nullptr};   // the far stream's last product with inverse buffer 0 / 1
     auto new_event = [&]() { return lu_new_event(s); };
     auto record = [&](hipStream_t st) {
         hipEvent_t e = new_event();
@@ -2692,12 +2765,71 @@ static int getrf_super(LuState& s, size_t kmin) {
     tl_mark("start");
     const auto host_t0 = std::chrono::steady_clock::now();
     auto host_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count(); };
+    // columns [c0, c1) right of the complete super-panel [S0, S1) (M = its inverted L11, leading dimension W): its interchanges (unless the
+    // caller applied them), T = M A12, the rank-W update with T as the B operand, then T into A12 (U's block row) - on the stream in scope
+    auto minv_update_sp = [&](size_t S0, size_t S1, size_t W, const double* M, double* T, size_t c0, size_t c1, bool swaps) -> int {
+        if (c1 <= c0) return RMHIP_OK;
+        struct WsScope {
+            Context* c;
+            ~WsScope() {
+                c->gemm_split_ws = nullptr;
+                c->gemm_split_ws_elems = 0;
+            }
+        } ws_scope{c};
+        c->gemm_split_ws = split_ws[c->stream == main_stream ? 0 : (c->stream == mid ? 1 : 2)]->ptr;
+        c->gemm_split_ws_elems = kSplitWsElems;
+        if (swaps) RMHIP_TRY(laswp(s, c0, c1, S0, S1));
+        const size_t nc = c1 - c0;
+        double* A12 = s.A + S0 + c0 * s.lda;
+        const size_t keep = c->gemm_split_min_k;
+        c->gemm_split_min_k = 1024;  // few output tiles and k = W: split the inner dimension (one block alone walks 16 k per us)
+        int r;
+        const size_t h = (W / 2 / 128) * 128;
+        if (nc >= 1024 && h >= 256) {  // M is lower triangular: the upper half of T only needs the leading h x h block
+            r = lu_dgemm(c, h, nc, h, 1.0, M, W, A12, s.lda, 0.0, T, W);
+            if (r == RMHIP_OK) r = lu_dgemm(c, W - h, nc, W, 1.0, M + h, W, A12, s.lda, 0.0, T + h, W);
+        } else {
+            r = lu_dgemm(c, W, nc, W, 1.0, M, W, A12, s.lda, 0.0, T, W);
+        }
+        c->gemm_split_min_k = keep;
+        RMHIP_TRY(r);
+        if (S1 < s.rows) RMHIP_TRY(lu_dgemm(c, s.rows - S1, nc, W, -1.0, s.A + S1 + S0 * s.lda, s.lda, T, W, 1.0, s.A + S1 + c0 * s.lda, s.lda));
+        RMHIP_HIP_CHECK(hipMemcpy2DAsync(A12, s.lda * sizeof(double), T, W * sizeof(double), W * sizeof(double), nc, hipMemcpyDeviceToDevice, c->stream));
+        return RMHIP_OK;
+    };
+    // The mid stream's share of a boundary beyond the next super-panel's first two inner panels is issued LATER - behind that
+    // super-panel's first inner update of its second panel's columns (see the boundary code): the main stream's look-ahead after the
+    // second inner panel then waits for two small launches instead of the deep update of 1280 columns (round 5: 1-4 ms per super-panel)
+    std::function<int()> mid_deferred;
     for (size_t J = 0; J < plan.size() && rc == RMHIP_OK; ++J) {
         const size_t S0 = plan[J].s0, S1 = plan[J].s1, nbJ = plan[J].nb, W = S1 - S0;
         if (verbose && (W > nbJ || J + 1 == plan.size())) std::fprintf(stderr, "[lu] host %.2f ms: super-panel %zu [%zu, %zu) nb %zu queued so far %llu launches\n", host_ms(), J, S0, S1, nbJ, (unsigned long long)c->tel.kernel_launches);
         const size_t S1n = J + 1 < plan.size() ? plan[J + 1].s1 : S1;
         const size_t S1nn = J + 2 < plan.size() ? plan[J + 2].s1 : S1n;
         const bool multi = W > nbJ;
+        const bool use_minv = minv_on && multi && !iprep && W <= Wmax;
+        double* const minv = use_minv ? minv_mem[J & 1]->ptr : nullptr;
+        const size_t ldm = W;
+        // row block [j - S0, j - S0 + w) of M = L11^-1, on the stream in scope (mid), once panel [j, j + w)'s interchanges are in columns [S0, j)
+        auto minv_extend = [&](size_t j, size_t w) -> int {
+            const size_t off = j - S0;
+            double* Mpp = minv + off + off * ldm;
+            if (off == 0) {
+                if (ev_minv_read[J & 1]) (void)hipStreamWaitEvent(c->stream, ev_minv_read[J & 1], 0);  // far may still read this buffer (boundary J - 2)
+                RMHIP_HIP_CHECK(hipMemsetAsync(minv, 0, sizeof(double) * W * W, c->stream));
+            }
+            hipLaunchKernelGGL(k_set_identity, dim3((unsigned)((w * w + 255) / 256)), dim3(256), 0, c->stream, Mpp, ldm, (unsigned)w);
+            RMHIP_TRY(launch_check(c));
+            RMHIP_TRY(trsm_lower_rec(c, s.A + j + j * s.lda, s.lda, w, Mpp, ldm, w));
+            if (off) {
+                RMHIP_TRY(lu_dgemm(c, w, off, off, 1.0, s.A + j + S0 * s.lda, s.lda, minv, ldm, 0.0, mtmp_mem->ptr, w));
+                RMHIP_TRY(lu_dgemm(c, w, off, w, -1.0, Mpp, ldm, mtmp_mem->ptr, w, 0.0, minv + off, ldm));
+            }
+            return RMHIP_OK;
+        };
+        auto minv_update = [&, S0, S1, W, minv](double* T, size_t c0, size_t c1, bool swaps) -> int {
+            return minv_update_sp(S0, S1, W, minv, T, c0, c1, swaps);
+        };
         s.panel_pad_kb = top_pad_env >= 0 ? top_pad_env : ((kmin - S0 > super_rows) ? super_panel_pad : -1);
         for (size_t j = S0; j < S1 && rc == RMHIP_OK;) {
             const size_t w = (S1 - j) < nbJ ? (S1 - j) : nbJ;
@@ -2720,10 +2852,28 @@ static int getrf_super(LuState& s, size_t kmin) {
                 (void)hipStreamWaitEvent(mid, panel_done, 0);
                 {
                     StreamScope scope(c, mid, mid_pad);
-                    rc = update_columns(s, j, w, t0, S1);
-                    if (rc == RMHIP_OK && j > S0) rc = laswp(s, S0, j, j, j + w);  // the super-panel's own left columns
+                    if (mid_deferred) {
+                        // first inner panel after a boundary: the next panel's columns first (what the main stream's next look-ahead
+                        // needs), then the boundary's remaining columns, then this panel's update of those
+                        const size_t ts = t0 + nbJ < S1 ? t0 + nbJ : S1;
+                        rc = update_columns(s, j, w, t0, ts);
+                        ev_mid = record(mid);
+                        if (rc == RMHIP_OK) rc = mid_deferred();
+                        mid_deferred = nullptr;
+                        if (rc == RMHIP_OK) rc = update_columns(s, j, w, ts, S1);
+                    } else {
+                        rc = update_columns(s, j, w, t0, S1);
+                        if (rc == RMHIP_OK && j > S0) rc = laswp(s, S0, j, j, j + w);  // the super-panel's own left columns
+                        ev_mid = record(mid);
+                    }
+                    if (rc == RMHIP_OK && use_minv && !minv_ext_far) rc = minv_extend(j, w);  // (behind the event: the main stream does not wait for it)
                 }
-                ev_mid = record(mid);
+                if (rc == RMHIP_OK && use_minv && minv_ext_far) {
+                    (void)hipStreamWaitEvent(far, ev_mid, 0);  // (this panel's interchanges are in the columns left of it)
+                    StreamScope scope(c, far, far_pad);
+                    rc = minv_extend(j, w);
+                }
+                if (rc != RMHIP_OK) break;
                 if (iprep && S1 < S1n) {
                     // the next super-panel's columns receive this panel's block row of U now (not at the boundary): they are complete up
                     // to the previous super-panel once far's first update of boundary J - 1 is in
@@ -2740,15 +2890,42 @@ static int getrf_super(LuState& s, size_t kmin) {
                 // the super-panel is complete: its last panel's interchanges reach its left columns first - everything below reads L21
                 // of the whole super-panel
                 hipEvent_t ev_left = panel_done;
+                if (mid_deferred) {  // (a super-panel of a single panel: nobody consumed the previous boundary's second piece)
+                    StreamScope scope(c, mid, mid_pad);
+                    rc = mid_deferred();
+                    mid_deferred = nullptr;
+                    if (rc != RMHIP_OK) break;
+                    ev_mid = record(mid);
+                }
                 if (multi && j > S0) {
                     (void)hipStreamWaitEvent(mid, panel_done, 0);
                     {
                         StreamScope scope(c, mid, mid_pad);
                         rc = laswp(s, S0, j, j, j + w);
+                        if (rc == RMHIP_OK) {
+                            ev_left = record(mid);
+                            ev_mid = ev_left;
+                        }
+                        if (rc == RMHIP_OK && use_minv && !minv_ext_far) {  // the last row block of the inverse, then its largest entry for the guard
+                            rc = minv_extend(j, w);
+                            if (rc == RMHIP_OK) {
+                                hipLaunchKernelGGL(k_absmax_word, dim3(256), dim3(256), 0, mid, (const double*)minv, ldm, (unsigned)W, (unsigned)W, (pk_u64*)s.minv_max);
+                                rc = launch_check(c);
+                            }
+                            ev_minv = record(mid);
+                        }
+                    }
+                    if (rc == RMHIP_OK && use_minv && minv_ext_far) {
+                        (void)hipStreamWaitEvent(far, ev_left, 0);
+                        StreamScope scope(c, far, far_pad);
+                        rc = minv_extend(j, w);
+                        if (rc == RMHIP_OK) {
+                            hipLaunchKernelGGL(k_absmax_word, dim3(256), dim3(256), 0, far, (const double*)minv, ldm, (unsigned)W, (unsigned)W, (pk_u64*)s.minv_max);
+                            rc = launch_check(c);
+                        }
+                        ev_minv = record(far);
                     }
                     if (rc != RMHIP_OK) break;
-                    ev_left = record(mid);
-                    ev_mid = ev_left;
                 }
                 if (la_w) {
                     tl_mark("J" + std::to_string(J) + " chain done");
@@ -2756,7 +2933,10 @@ static int getrf_super(LuState& s, size_t kmin) {
                     tl_mark("J" + std::to_string(J) + " mid ready");
                     if (ev_far_next) (void)hipStreamWaitEvent(main_stream, ev_far_next, 0);
                     tl_mark("J" + std::to_string(J) + " far ready");
-                    if (iprep && multi) {
+                    if (use_minv && (minv_who & 1)) {
+                        (void)hipStreamWaitEvent(main_stream, ev_minv, 0);
+                        rc = minv_update(t_main_mem->ptr, next, t0, true);
+                    } else if (iprep && multi) {
                         // the columns hold every block row of U but the last panel's: that one, then the deep update alone
                         if (ev_iprep) (void)hipStreamWaitEvent(main_stream, ev_iprep, 0);
                         rc = iprep_columns(s, S0, j, w, next, t0);
@@ -2772,7 +2952,23 @@ static int getrf_super(LuState& s, size_t kmin) {
                     if (ev_far_next) (void)hipStreamWaitEvent(mid, ev_far_next, 0);
                     {
                         StreamScope scope(c, mid, mid_pad);
-                        if (iprep && multi) {
+                        if (use_minv && (minv_who & 2)) {
+                            (void)hipStreamWaitEvent(mid, ev_minv, 0);
+                            // The second inner panel's columns first: the main stream's next look-ahead
+                            // update waits for these only
+                            static const int defer_on = std::getenv("RMHIP_LU_MINV_DEFER") ? std::atoi(std::getenv("RMHIP_LU_MINV_DEFER")) : 1;
+                            const size_t nbn = plan[J + 1].nb, t1 = t0 + 2 * nbn < S1n ? t0 + 2 * nbn : S1n;
+                            rc = minv_update(t_mid_mem->ptr, t0, t1, true);  // the second and third inner panels' columns now
+                            if (rc == RMHIP_OK) ev_mid = record(mid);
+                            if (rc == RMHIP_OK && t1 < S1n) {
+                                double* const Tm = t_mid_mem->ptr;
+                                const double* const Mc = minv;
+                                const size_t S0c = S0, S1c = S1, Wc = W, c1c = S1n;
+                                auto rest = [&minv_update_sp, S0c, S1c, Wc, Mc, Tm, t1, c1c]() { return minv_update_sp(S0c, S1c, Wc, Mc, Tm, t1, c1c, true); };
+                                if (defer_on && plan[J + 1].s1 - plan[J + 1].s0 > plan[J + 1].nb) mid_deferred = rest;  // the rest behind the next panel's first update
+                                else rc = rest();
+                            }
+                        } else if (iprep && multi) {
                             rc = iprep_columns(s, S0, j, w, t0, S1n);
                             // the second panel's columns first: the main stream's next look-ahead update waits for these only
                             const size_t nbn = plan[J + 1].nb, t1 = (iprep_split && t0 + nbn < S1n) ? t0 + nbn : S1n;
@@ -2805,12 +3001,26 @@ static int getrf_super(LuState& s, size_t kmin) {
                         const size_t cn = S1nn < s.cols ? S1nn : s.cols;
                         // (tried: interchange + solve + update of the next super-panel's columns first, then the rest's - a second
                         // 31-launch solve per boundary on this stream: 69.4 -> 73.8 ms; the far stream is the bottleneck of the first phase)
+                        if (use_minv && (minv_who & 4)) {
+                            // one interchange pass, then per column chunk T = M A12, the deep update, T -> A12; the next super-panel's
+                            // columns are the first chunk (the event no longer waits for the solve of ALL columns)
+                            (void)hipStreamWaitEvent(far, ev_minv, 0);
+                            rc = laswp(s, S1n, s.cols, S0, S1);
+                            if (rc == RMHIP_OK && cn > S1n) {
+                                rc = minv_update(t_far_mem->ptr, S1n, cn, false);
+                                ev_far_next = record(far);
+                            }
+                            for (size_t q0 = cn; q0 < s.cols && rc == RMHIP_OK; q0 += far_chunk)
+                                rc = minv_update(t_far_mem->ptr, q0, q0 + far_chunk < s.cols ? q0 + far_chunk : s.cols, false);
+                            ev_minv_read[J & 1] = record(far);
+                        } else {
                         rc = prep_columns(s, S0, W, S1n, s.cols);
                         if (rc == RMHIP_OK && cn > S1n) {
                             rc = gemm_columns(s, S0, W, S1n, cn);
                             ev_far_next = record(far);
                         }
                         if (rc == RMHIP_OK) rc = gemm_columns(s, S0, W, cn, s.cols);
+                        }
                     }
                     if (rc == RMHIP_OK && S0 > 0) rc = laswp(s, 0, S0, S0, S1);  // columns left of the super-panel: all of its interchanges at once
                 }
@@ -2845,8 +3055,13 @@ static int getrf_super(LuState& s, size_t kmin) {
 // mode 0: the reference's pivot sequence (host_lu.rs:37-59: grid-wide first maximum) - `lu`, and the fallback of the solve path.
 // mode 1: solve path (pivots unobservable): pivoting restricted to each panel's top block, multipliers checked against tau
 //         (k_rp_below); RMHIP_LU_GROWTH when the check fails - the matrix is clobbered, the caller refactors a fresh copy in mode 0.
+__global__ void __launch_bounds__(256) k_ipiv_to_f64(const int* __restrict__ ipiv, double* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (double)ipiv[i];
+}
+
 int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda, int* perm_dev, int* info_host,
-                     std::vector<int>* ipiv_host, int mode) {
+                     std::vector<int>* ipiv_host, int mode, double* ipiv_dev_f64) {
     const size_t kmin = rows < cols ? rows : cols;
     if (rows > 0x7fffffffULL || cols > 0x7fffffffULL) return fail(RMHIP_ERR_UNSUPPORTED, "lu: dimension exceeds 2^31");
     c->lu_used_one_xcd = false;
@@ -2903,6 +3118,7 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
         c->lu_tau = s.tau;
         s.ucomp = (double*)(blk + off_ucomp);
         s.growth = (unsigned long long*)(blk + off_xctl + 32);
+        s.minv_max = (unsigned long long*)(blk + off_xctl + 40);
         // matrix-core triangular solves with k_rp_top's inverted diagonal blocks: every base panel must be 64 columns wide
         static const int trsm_mfma = std::getenv("RMHIP_LU_TRSM_MFMA") ? std::atoi(std::getenv("RMHIP_LU_TRSM_MFMA")) : 1;
         if (s.fast && trsm_mfma && !s.xdbg) s.linv = (double*)(blk + off_linv);
@@ -2958,10 +3174,11 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     std::vector<int> h_ipiv(rows + 1, 0);
     if (rc == RMHIP_OK) {
         int h_xerr = 0;
-        unsigned long long h_growth = 0;
+        unsigned long long h_growth = 0, h_minv = 0;
         e = hipMemcpyAsync(h_ipiv.data(), ipiv, sizeof(int) * (rows + 1), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(&h_xerr, s.xerr, sizeof(int), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess && s.fast) e = hipMemcpyAsync(&h_growth, s.growth, sizeof(h_growth), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && s.fast) e = hipMemcpyAsync(&h_minv, s.minv_max, sizeof(h_minv), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) rc = fail(RMHIP_ERR_HIP, "lu: reading pivots: %s", hipGetErrorString(e));
         if (e == hipSuccess && s.fast) {
@@ -2969,6 +3186,15 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
             std::memcpy(&gmax, &h_growth, sizeof(gmax));
             c->lu_last_growth = gmax;
             // a multiplier beyond tau, a NaN, or a pivot at the singular cut-off inside a top block (a larger entry may lie below it)
+            double minv_abs;
+            std::memcpy(&minv_abs, &h_minv, sizeof(minv_abs));
+            c->lu_last_minv = minv_abs;
+            static const double minv_limit = std::getenv("RMHIP_LU_MINV_MAX") ? std::atof(std::getenv("RMHIP_LU_MINV_MAX")) : 1.0e6;
+            if (!(minv_abs <= minv_limit)) {  // an ill-conditioned L11: the products with its inverse are not to be trusted (also NaN)
+                if (std::getenv("RMHIP_LU_VERBOSE"))
+                    std::fprintf(stderr, "[lu] solve path: largest entry of an inverted L11 block %.3g (limit %.3g): refactoring with the grid-wide rule\n", minv_abs, minv_limit);
+                return RMHIP_LU_GROWTH;
+            }
             if (!(gmax <= s.tau) || h_ipiv[rows] > 0 || std::getenv("RMHIP_LU_TEST_GROWTH")) {
                 if (std::getenv("RMHIP_LU_VERBOSE"))
                     std::fprintf(stderr, "[lu] solve path: max multiplier %.3g (tau %.3g), %d small pivot(s): refactoring with the grid-wide rule\n", gmax,
@@ -3013,6 +3239,10 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     if (rc != RMHIP_OK) return rc;
     if (info_host) *info_host = h_ipiv[rows];
     if (ipiv_host) ipiv_host->assign(h_ipiv.begin(), h_ipiv.begin() + (long)kmin);
+    if (ipiv_dev_f64 && kmin) {  // the interchange targets as a device tensor (rmhip_blk_lu): no trip through the host
+        hipLaunchKernelGGL(k_ipiv_to_f64, dim3((unsigned)((kmin + 255) / 256)), dim3(256), 0, c->stream, (const int*)ipiv, ipiv_dev_f64, (int)kmin);
+        RMHIP_TRY(launch_check(c));
+    }
     std::vector<int> perm(rows);
     for (size_t r = 0; r < rows; ++r) perm[r] = (int)r;
     for (size_t k = 0; k < kmin; ++k) {
@@ -3050,6 +3280,91 @@ __global__ void __launch_bounds__(256) k_permute_rows(double* __restrict__ A, si
 #pragma unroll
     for (int q = 0; q < PERM_PER_THREAD; ++q)
         if (dst[q] >= 0) col[dst[q]] = vals[q];
+}
+
+// The same from a DEVICE interchange vector (doubles, as rmhip_blk_lu returns them), nothing crossing to the host: one workgroup
+// composes the swaps k <-> ipiv[k] in an LDS map of the view's rows (thread 0 walks them in order - at most a few hundred), every thread
+// then reports the positions whose content changed as (dst, src) moves; k_permute_rows_dev applies the list.  Entries outside
+// [0, nrows) are ignored and counted in *bad (the caller's guard reads it with the factorisation's other status words).
+__global__ void __launch_bounds__(256) k_compose_swaps(const double* __restrict__ ipiv, int npiv, int nrows, int2* __restrict__ list,
+                                                      int* __restrict__ len_bad, int cap) {
+    extern __shared__ int s_map[];  // [nrows] map, then [npiv] interchange targets (-1: out of range)
+    __shared__ int s_len, s_bad;
+    int* s_piv = s_map + nrows;
+    for (int i = threadIdx.x; i < nrows; i += 256) s_map[i] = i;
+    if (threadIdx.x == 0) s_len = s_bad = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < npiv; k += 256) {
+        const double pv = ipiv[k];
+        const bool ok = pv >= 0.0 && pv < (double)nrows && k < nrows;
+        s_piv[k] = ok ? (int)pv : -1;
+        if (!ok) atomicAdd(&s_bad, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < npiv; ++k) {
+            const int p = s_piv[k];
+            if (p < 0 || p == k) continue;
+            const int a = s_map[k], b = s_map[p];
+            s_map[k] = b;
+            s_map[p] = a;
+        }
+        len_bad[1] = s_bad;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nrows; i += 256) {
+        const int src = s_map[i];
+        if (src != i) {
+            const int slot = atomicAdd(&s_len, 1);
+            if (slot < cap) list[slot] = make_int2(i, src);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) len_bad[0] = s_len < cap ? s_len : cap;
+}
+__global__ void __launch_bounds__(256) k_permute_rows_dev(double* __restrict__ A, size_t lda, size_t ncols, const int2* __restrict__ list,
+                                                         const int* __restrict__ len_ptr) {
+    const size_t cc = blockIdx.x;
+    if (cc >= ncols) return;
+    const int len = *len_ptr;
+    double* col = A + cc * lda;
+    double vals[PERM_PER_THREAD];
+    int dst[PERM_PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < PERM_PER_THREAD; ++q) {
+        const int i = threadIdx.x + 256 * q;
+        dst[q] = -1;
+        if (i < len) {
+            const int2 e = list[i];
+            dst[q] = e.x;
+            vals[q] = col[e.y];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PERM_PER_THREAD; ++q)
+        if (dst[q] >= 0) col[dst[q]] = vals[q];
+}
+// (rows up to 36864: the map must fit the CU's LDS; the caller falls back to the host composition beyond)
+static constexpr size_t kSwapDevMaxRows = 36864;
+int lu_swap_rows_from_device(Context* c, double* A, size_t lda, size_t nrows, size_t ncols, const double* ipiv_dev, size_t npiv) {
+    if (ncols == 0 || npiv == 0 || nrows == 0) return RMHIP_OK;
+    if (nrows > kSwapDevMaxRows || npiv > (size_t)128 * PERM_PER_THREAD) return RMHIP_ERR_UNSUPPORTED;  // (not an error: the caller takes the host path)
+    const int cap = 256 * PERM_PER_THREAD;
+    std::shared_ptr<Allocation> ws;  // [cap] moves + (len, bad); stream-ordered reuse: everything below runs on c->stream
+    RMHIP_TRY(c->alloc_device((size_t)cap + 2, &ws));
+    int2* list = (int2*)ws->ptr;
+    int* len_bad = (int*)(list + cap);
+    const size_t lds = (nrows + npiv) * sizeof(int);
+    if (lds > 65536) c->ensure_max_lds((const void*)k_compose_swaps, (kSwapDevMaxRows + 1024) * sizeof(int));
+    hipLaunchKernelGGL(k_compose_swaps, dim3(1), dim3(256), lds, c->stream, ipiv_dev, (int)npiv, (int)nrows, list, len_bad, cap);
+    RMHIP_TRY(launch_check(c));
+    for (size_t c0 = 0; c0 < ncols; c0 += 65535) {
+        const size_t nc = (ncols - c0) < 65535 ? (ncols - c0) : 65535;
+        hipLaunchKernelGGL(k_permute_rows_dev, dim3((unsigned)nc), dim3(256), 0, c->stream, A + c0 * lda, lda, nc, (const int2*)list, (const int*)len_bad);
+        RMHIP_TRY(launch_check(c));
+    }
+    return RMHIP_OK;
 }
 
 // Apply the sequential interchanges k <-> ipiv[k] (k = 0..npiv-1, rows relative to A) to ncols columns.

@@ -1834,44 +1834,41 @@ int rmhip_blk_lu(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf* ipiv_out, int
     if (!ipiv_out) return fail(RMHIP_ERR_INVALID, "null ipiv_out");
     ViewPtr va;
     RMHIP_TRY(resolve_view(c, a, &va, true));
-    std::vector<int> ipiv;
-    int inf = 0;
-    {
-        int frc = RMHIP_LU_GROWTH;
-        if (c->blk_lu_solve_path && va.rows > 0 && va.cols > 0) {
-            // the solve path's kernels (k_rp_top / k_rp_below_mfma / matrix-core solves): the block is saved first - a multiplier beyond
-            // the bound clobbers it - and restored for the grid-wide rule
-            std::shared_ptr<Allocation> keep;
-            RMHIP_TRY(c->alloc_device(va.rows * va.cols, &keep));
-            RMHIP_HIP_CHECK(hipMemcpy2DAsync(keep->ptr, va.rows * sizeof(double), va.ptr, va.ld * sizeof(double), va.rows * sizeof(double), va.cols,
-                                             hipMemcpyDeviceToDevice, c->stream));
-            frc = lu_factor_device(c, va.ptr, va.rows, va.cols, va.ld, nullptr, &inf, &ipiv, 1);
-            if (frc == RMHIP_LU_GROWTH || frc == RMHIP_LU_RETRY) {
-                RMHIP_HIP_CHECK(hipMemcpy2DAsync(va.ptr, va.ld * sizeof(double), keep->ptr, va.rows * sizeof(double), va.rows * sizeof(double), va.cols,
-                                                 hipMemcpyDeviceToDevice, c->stream));
-                RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
-                frc = RMHIP_LU_GROWTH;
-            }
-        }
-        if (frc == RMHIP_LU_GROWTH) frc = lu_factor_device(c, va.ptr, va.rows, va.cols, va.ld, nullptr, &inf, &ipiv);
-        if (frc == RMHIP_LU_RETRY)  // in place: the block is clobbered and there is no copy to restart from
-            return fail(RMHIP_ERR_HIP, "blk_lu: panel workgroups were not co-resident (device shared?); the block is invalid");
-        RMHIP_TRY(frc);
-    }
-    if (info) *info = inf;
-    std::vector<double> host(ipiv.begin(), ipiv.end());
-    const size_t oshape[2] = {host.size(), 1};
+    // the interchange vector is written on the device by the factorisation itself (round 6: it used to travel device -> host -> device
+    // with a stream drain at each end, and rmhip_blk_swap_rows fetched it back again)
+    const size_t kmin = va.rows < va.cols ? va.rows : va.cols;
+    const size_t oshape[2] = {kmin, 1};
     Buffer ob;
     RMHIP_TRY(c->new_buffer(oshape, 2, ipiv_out, &ob));
-    if (!host.empty()) {
-        hipError_t e = hipMemcpyAsync(ob.data(), host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) {
-            rmhip_free(ctx, *ipiv_out);  // do not leak the interchange vector on the HIP error paths
-            *ipiv_out = 0;
-            return fail(RMHIP_ERR_HIP, "blk_lu: copying the interchanges: %s", hipGetErrorString(e));
+    int inf = 0;
+    int frc = RMHIP_LU_GROWTH;
+    if (c->blk_lu_solve_path && va.rows > 0 && va.cols > 0) {
+        // the solve path's kernels (k_rp_top / k_rp_below_mfma / matrix-core solves): the block is saved first - a multiplier beyond
+        // the bound clobbers it - and restored for the grid-wide rule
+        std::shared_ptr<Allocation> keep;
+        frc = c->alloc_device(va.rows * va.cols, &keep);
+        if (frc == RMHIP_OK) {
+            hipError_t e = hipMemcpy2DAsync(keep->ptr, va.rows * sizeof(double), va.ptr, va.ld * sizeof(double), va.rows * sizeof(double), va.cols,
+                                            hipMemcpyDeviceToDevice, c->stream);
+            frc = e == hipSuccess ? lu_factor_device(c, va.ptr, va.rows, va.cols, va.ld, nullptr, &inf, nullptr, 1, ob.data())
+                                  : fail(RMHIP_ERR_HIP, "blk_lu: saving the block: %s", hipGetErrorString(e));
+            if (frc == RMHIP_LU_GROWTH || frc == RMHIP_LU_RETRY) {
+                e = hipMemcpy2DAsync(va.ptr, va.ld * sizeof(double), keep->ptr, va.rows * sizeof(double), va.rows * sizeof(double), va.cols,
+                                     hipMemcpyDeviceToDevice, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                frc = e == hipSuccess ? RMHIP_LU_GROWTH : fail(RMHIP_ERR_HIP, "blk_lu: restoring the block: %s", hipGetErrorString(e));
+            }
         }
     }
+    if (frc == RMHIP_LU_GROWTH) frc = lu_factor_device(c, va.ptr, va.rows, va.cols, va.ld, nullptr, &inf, nullptr, 0, ob.data());
+    if (frc == RMHIP_LU_RETRY)  // in place: the block is clobbered and there is no copy to restart from
+        frc = fail(RMHIP_ERR_HIP, "blk_lu: panel workgroups were not co-resident (device shared?); the block is invalid");
+    if (frc != RMHIP_OK) {
+        rmhip_free(ctx, *ipiv_out);  // do not leak the interchange vector on the error paths
+        *ipiv_out = 0;
+        return frc;
+    }
+    if (info) *info = inf;
     return RMHIP_OK;
 }
 
@@ -1881,6 +1878,13 @@ int rmhip_blk_swap_rows(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf ipiv) {
     RMHIP_TRY(resolve_view(c, a, &va, true));
     Buffer pb;
     RMHIP_TRY(c->get(ipiv, &pb));
+    // composed and applied on the device (no stream drain, no hipMalloc / hipFree); RMHIP_BLK_SWAP_DEVICE=0 or a view too tall for
+    // the LDS map: the host composition, which also REPORTS an out-of-range target (the device form skips it)
+    static const bool dev_path = !(std::getenv("RMHIP_BLK_SWAP_DEVICE") && std::getenv("RMHIP_BLK_SWAP_DEVICE")[0] == '0');
+    if (dev_path) {
+        const int rc = lu_swap_rows_from_device(c, va.ptr, va.ld, va.rows, va.cols, pb.data(), pb.numel);
+        if (rc != RMHIP_ERR_UNSUPPORTED) return rc;
+    }
     std::vector<double> host(pb.numel);
     if (pb.numel) {
         RMHIP_HIP_CHECK(hipMemcpyAsync(host.data(), pb.data(), pb.numel * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -56,6 +56,64 @@ struct Temps {
     }
 };
 
+// max |a_ij| over a view as a DEVICE scalar (1 x 1 tensor): the per-panel multiplier guard no longer reads it back
+int absmax_dev(rmhip_ctx* ctx, const rmhip_view_t* v, rmhip_buf* out) {
+    rmhip_buf blk = 0, ab = 0;
+    RMHIP_TRY(rmhip_blk_copy(ctx, v, &blk));
+    int rc = rmhip_unary(ctx, RMHIP_ABS, blk, &ab);
+    (void)rmhip_free(ctx, blk);
+    if (rc != RMHIP_OK) return rc;
+    rc = rmhip_reduce(ctx, RMHIP_RMAX, ab, -1, /*include NaN: a NaN multiplier must fail the guard*/ 0, out);
+    (void)rmhip_free(ctx, ab);
+    return rc;
+}
+
+// Per-phase device time of one row-partitioned solve (rmhip_rp_phase_ms): pairs of timed events around the phases' launches on the stream
+// they run on, summed after the solve.  panel = the owner's factorisation, interchanges, U12 and tile copy; wait = the stream idling for
+// a tile broadcast (rmhip_comm_wait); update = multipliers and trailing updates; exchange = the guard's gather and the replicated tail.
+struct PhaseTimers {
+    enum { PANEL = 0, WAIT, UPDATE, EXCHANGE, NPHASE };
+    struct Span {
+        int phase;
+        hipEvent_t a, b;
+    };
+    std::vector<Span> spans;
+    bool on = true;
+    hipEvent_t begin(hipStream_t st) {
+        if (!on) return nullptr;
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        (void)hipEventRecord(e, st);
+        return e;
+    }
+    void end(int phase, hipEvent_t a, hipStream_t st) {
+        if (!a) return;
+        hipEvent_t b = nullptr;
+        if (hipEventCreate(&b) != hipSuccess) {
+            (void)hipEventDestroy(a);
+            return;
+        }
+        (void)hipEventRecord(b, st);
+        spans.push_back(Span{phase, a, b});
+    }
+    void collect(double out[NPHASE]) {
+        for (int i = 0; i < NPHASE; ++i) out[i] = 0.0;
+        for (Span& sp : spans) {
+            float ms = 0.f;
+            if (hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) out[sp.phase] += ms;
+            (void)hipEventDestroy(sp.a);
+            (void)hipEventDestroy(sp.b);
+        }
+        spans.clear();
+    }
+    ~PhaseTimers() {
+        for (Span& sp : spans) {
+            (void)hipEventDestroy(sp.a);
+            (void)hipEventDestroy(sp.b);
+        }
+    }
+};
+
 int zeros(rmhip_ctx* ctx, size_t rows, size_t cols, rmhip_buf* out) {
     const size_t shape[2] = {rows, cols};
     return rmhip_fill(ctx, 0.0, shape, 2, out);
@@ -95,6 +153,13 @@ int rmhip_matmul_row_sharded(rmhip_ctx* ctx, rmhip_buf a_rows, rmhip_buf b, size
     const int rc = rmhip_comm_allgather_rows(ctx, local, rows_total, granule ? granule : 128, out);
     (void)rmhip_free(ctx, local);
     return rc;
+}
+
+int rmhip_rp_phase_ms(rmhip_ctx* ctx, double* out4) {
+    CTX_OR_FAIL(ctx);
+    if (!out4) return fail(RMHIP_ERR_INVALID, "null out");
+    for (int i = 0; i < 4; ++i) out4[i] = c->rp_phase_ms[i];
+    return RMHIP_OK;
 }
 
 // Row block q (height rb) of the n x (n + nrhs) augmented matrix lives on rank q % world, blocks in ownership order in `ab_local`
@@ -165,9 +230,57 @@ int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n,
         (void)rmhip_blk_assign(ctx, &dst, nanb);
         (void)rmhip_free(ctx, nanb);
     };
-    double growth = 0.0;
-    auto note_growth = [&](double v) {
-        if (v != v || v > growth) growth = v;  // NaN sticks (max(0, NaN) must not be 0)
+    // the largest multiplier outside the diagonal domains, accumulated ON THE DEVICE (elementwise max keeps a NaN): one read at the guard
+    rmhip_buf growth_dev = 0;
+    {
+        const size_t one[2] = {1, 1};
+        RMHIP_TRY(rmhip_fill(ctx, 0.0, one, 2, &growth_dev));
+    }
+    struct GrowthScope {  // (replaced as it accumulates: not in `temps`)
+        rmhip_ctx* ctx;
+        rmhip_buf* id;
+        ~GrowthScope() {
+            if (*id) (void)rmhip_free(ctx, *id);
+        }
+    } growth_scope{ctx, &growth_dev};
+    PhaseTimers timers;
+    timers.on = !(std::getenv("RMHIP_RP_TIMERS") && std::getenv("RMHIP_RP_TIMERS")[0] == '0');
+    for (double& v : c->rp_phase_ms) v = 0.0;
+    // second stream: the trailing update of panel p beyond panel p + 1's columns runs there while this stream factors panel p + 1
+    // (RMHIP_RP_OVERLAP=0: everything on the context's stream, as in round 5)
+    const bool side_on = !(std::getenv("RMHIP_RP_OVERLAP") && std::getenv("RMHIP_RP_OVERLAP")[0] == '0');
+    hipStream_t const main_stream = c->stream;
+    if (side_on && !c->lu_side_stream) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        RMHIP_HIP_CHECK(hipStreamCreateWithPriority(&c->lu_side_stream, hipStreamNonBlocking, lo));
+    }
+    hipStream_t const side = side_on ? c->lu_side_stream : main_stream;
+    const size_t side_pad = std::getenv("RMHIP_RP_SIDE_PAD") ? (size_t)std::atol(std::getenv("RMHIP_RP_SIDE_PAD")) : (size_t)(84 * 1024 - 73728);
+    struct StreamRestore {  // whatever happens, the context's stream comes back and the side stream is drained
+        Context* c;
+        hipStream_t main_stream, side;
+        ~StreamRestore() {
+            c->stream = main_stream;
+            if (side != main_stream) (void)hipStreamSynchronize(side);
+        }
+    } stream_restore{c, main_stream, side};
+    hipEvent_t ev_side_done = nullptr, ev_main_ready = nullptr;  // (reused: a wait enqueued earlier has captured the earlier record)
+    if (side != main_stream) {
+        RMHIP_HIP_CHECK(hipEventCreateWithFlags(&ev_side_done, hipEventDisableTiming));
+        RMHIP_HIP_CHECK(hipEventCreateWithFlags(&ev_main_ready, hipEventDisableTiming));
+    }
+    struct EventScope {
+        hipEvent_t *a, *b;
+        ~EventScope() {
+            if (*a) (void)hipEventDestroy(*a);
+            if (*b) (void)hipEventDestroy(*b);
+        }
+    } event_scope{&ev_side_done, &ev_main_ready};
+    bool side_pending = false;  // the side stream holds an update the main stream has not waited for yet
+    auto join_side = [&]() {
+        if (side_pending) (void)hipStreamWaitEvent(main_stream, ev_side_done, 0);
+        side_pending = false;
     };
     struct Tile {
         size_t j, w;
@@ -185,7 +298,17 @@ int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n,
         rmhip_buf ipiv = 0;
         int info = 0;
         const rmhip_view_t pan = view(ab_local, lr, j, nloc - lr, w);
+        hipEvent_t t_panel = timers.begin(main_stream);
+        struct PanelSpan {
+            PhaseTimers& t;
+            hipEvent_t a;
+            hipStream_t st;
+            ~PanelSpan() { t.end(PhaseTimers::PANEL, a, st); }
+        } panel_span{timers, t_panel, main_stream};
         int rc = rmhip_blk_lu(ctx, &pan, &ipiv, &info);
+        // the interchanges move rows the side stream's update of the previous panel reads (its multipliers, left of the panel) and
+        // writes (right of it): that update has to be through first - it ran under the factorisation above
+        join_side();
         if (rc == RMHIP_OK && info > 0) {
             (void)rmhip_free(ctx, ipiv);
             return fail(RMHIP_ERR_GROWTH, "panel %zu: %d pivot(s) at the singular cut-off inside the diagonal domain", p, info);
@@ -237,15 +360,40 @@ int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n,
         if (mb == 0 || is_owner) return RMHIP_OK;
         const rmhip_view_t t11 = view(tile, 0, 0, w, w), a21 = view(ab_local, below, j, mb, w);
         RMHIP_TRY(rmhip_blk_trsm(ctx, 2, &t11, &a21));  // L21 = A21 U11^-1
-        double g = 0.0;
-        RMHIP_TRY(rmhip_blk_absmax(ctx, &a21, &g));
-        note_growth(g);
+        rmhip_buf g = 0, acc = 0;
+        RMHIP_TRY(absmax_dev(ctx, &a21, &g));
+        const int rc = rmhip_binary(ctx, RMHIP_MAX, growth_dev, g, &acc);
+        (void)rmhip_free(ctx, g);
+        RMHIP_TRY(rc);
+        (void)rmhip_free(ctx, growth_dev);
+        growth_dev = acc;
         return RMHIP_OK;
     };
-    auto update = [&](rmhip_buf tile, size_t j, size_t w, size_t r0, size_t r1, size_t c0, size_t c1) -> int {
+    auto update = [&](rmhip_buf tile, size_t j, size_t w, size_t r0, size_t r1, size_t c0, size_t c1, bool on_side = false) -> int {
         if (r1 <= r0 || c1 <= c0) return RMHIP_OK;
         const rmhip_view_t l21 = view(ab_local, r0, j, r1 - r0, w), u12 = view(tile, 0, c0, w, c1 - c0), a22 = view(ab_local, r0, j + c0, r1 - r0, c1 - c0);
-        return rmhip_blk_gemm(ctx, -1.0, &l21, &u12, 1.0, &a22);
+        if (on_side && side != main_stream) {
+            // everything this product reads is final on the main stream by now (multipliers, the tile): the side stream starts behind it
+            (void)hipEventRecord(ev_main_ready, main_stream);
+            (void)hipStreamWaitEvent(side, ev_main_ready, 0);
+            c->stream = side;
+            // one eight-wave block per CU (84 KiB of LDS asked for) as on the look-ahead LU's update stream: the panel's one-workgroup
+            // kernels take a CU whenever a block retires instead of queueing behind two resident blocks per CU
+            const size_t keep_pad = c->gemm_lds_pad;
+            c->gemm_lds_pad = side_pad;
+            hipEvent_t t0 = timers.begin(side);
+            const int rc = rmhip_blk_gemm(ctx, -1.0, &l21, &u12, 1.0, &a22);
+            timers.end(PhaseTimers::UPDATE, t0, side);
+            c->gemm_lds_pad = keep_pad;
+            c->stream = main_stream;
+            (void)hipEventRecord(ev_side_done, side);
+            side_pending = true;
+            return rc;
+        }
+        hipEvent_t t0 = timers.begin(main_stream);
+        const int rc = rmhip_blk_gemm(ctx, -1.0, &l21, &u12, 1.0, &a22);
+        timers.end(PhaseTimers::UPDATE, t0, main_stream);
+        return rc;
     };
 
     rmhip_buf cur = 0;
@@ -253,7 +401,12 @@ int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n,
     for (size_t p = 0; p < n_direct; ++p) {
         const size_t j = p * rb, w = rb, width = ncols - j;
         const int owner = (int)(p % (size_t)world);
-        if (overlap) RMHIP_TRY(rmhip_comm_wait(ctx));
+        if (overlap) {
+            hipEvent_t t0 = timers.begin(main_stream);
+            const int wrc = rmhip_comm_wait(ctx);
+            timers.end(PhaseTimers::WAIT, t0, main_stream);
+            RMHIP_TRY(wrc);
+        }
         const rmhip_buf tile = cur;
         const bool is_owner = rank == owner;
         const size_t below = is_owner ? local_row_offset(p) + w : first_local_row_at_or_after(p + 1);
@@ -263,7 +416,16 @@ int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n,
             // depth-1 look-ahead: the owner of panel p + 1 brings that panel's columns (all its rows) and its tile's rows (all
             // columns) up to date first, factors and posts the broadcast; the rest of update p then runs under the transfer
             const bool next_mine = p + 1 < n_direct && (int)((p + 1) % (size_t)world) == rank;
-            if (rc == RMHIP_OK && next_mine) {
+            if (rc == RMHIP_OK && next_mine && side != main_stream) {
+                // round 6: panel p + 1's columns on this stream, EVERYTHING else of update p (the next tile's rows included) on the side
+                // stream - it runs while this stream factors panel p + 1; factor_panel joins the side stream before the interchanges.
+                // Same products on the same operands as the one-stream order below (update-after-swap equals swap-after-update, row
+                // by row): the results are bit-identical.
+                const size_t lr1 = local_row_offset(p + 1);
+                rc = update(tile, j, w, lr1, nloc, w, 2 * w);
+                if (rc == RMHIP_OK) rc = update(tile, j, w, lr1, nloc, 2 * w, width, /*on_side=*/true);
+                if (rc == RMHIP_OK) rc = post_panel(p + 1, &nxt, nullptr);
+            } else if (rc == RMHIP_OK && next_mine) {
                 const size_t lr1 = local_row_offset(p + 1);  // == below: the next owner's first block at or after p + 1 is p + 1 itself
                 rc = update(tile, j, w, lr1, nloc, w, 2 * w);  // panel p + 1's columns, every row from its tile down
                 if (rc == RMHIP_OK)
@@ -284,10 +446,18 @@ int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n,
     }
     // ---- the guard: one exchange, every rank decides the same way (a failed rank reports NaN)
     {
+        join_side();
+        hipEvent_t t_exch = timers.begin(main_stream);
         rmhip_buf mineb = 0, all = 0;
         const size_t one[2] = {1, 1};
-        RMHIP_TRY(rmhip_fill(ctx, failed ? std::numeric_limits<double>::quiet_NaN() : growth, one, 2, &mineb));
-        temps.keep(mineb);
+        double growth = 0.0;
+        if (failed) {
+            RMHIP_TRY(rmhip_fill(ctx, std::numeric_limits<double>::quiet_NaN(), one, 2, &mineb));
+            temps.keep(mineb);
+        } else {
+            mineb = growth_dev;  // the accumulated device scalar itself goes into the exchange
+            if (world == 1) RMHIP_TRY(rmhip_read_scalar(ctx, growth_dev, 0, &growth));
+        }
         double worst = failed ? std::numeric_limits<double>::quiet_NaN() : growth;
         if (world > 1) {
             RMHIP_TRY(rmhip_comm_allgather_f64(ctx, mineb, &all));
@@ -298,6 +468,7 @@ int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n,
             for (double v : h)
                 if (v != v || v > worst) worst = v;
         }
+        timers.end(PhaseTimers::EXCHANGE, t_exch, main_stream);
         if (failed || !(worst <= tau)) exit_guard.agreed = true;  // every rank holds the same `worst` (NaN from a failed rank): all leave here
         if (failed) return fail(RMHIP_ERR_GROWTH, "mldivide_row_partitioned: rank %d failed (%s)", rank, why.c_str());
         if (!(worst <= tau))
@@ -306,6 +477,7 @@ int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n,
     }
     // ---- the remaining rows: gathered, then the single-GPU solve on every rank
     const size_t j0 = n_direct * rb, m_rem = n - j0;
+    hipEvent_t t_tail = timers.begin(main_stream);
     rmhip_buf x = 0;
     RMHIP_TRY(zeros(ctx, n, nrhs, &x));
     temps.keep(x);
@@ -371,6 +543,8 @@ int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n,
     for (auto& id : temps.ids)
         if (id == x) id = 0;  // the result outlives the scope
     *out = x;
+    timers.end(PhaseTimers::EXCHANGE, t_tail, main_stream);
+    if (timers.on) timers.collect(c->rp_phase_ms);  // (synchronises on the last event: the caller reads x next anyway)
     return RMHIP_OK;
 }
 

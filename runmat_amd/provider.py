@@ -867,6 +867,12 @@ class HipProvider:
                                                        1 if gather else 0, C.byref(out)))
         return self._handle(out.value)
 
+    def rp_phase_ms(self) -> dict:
+        """rmhip_rp_phase_ms: device milliseconds of the last `mldivide_row_partitioned` call by phase."""
+        out = (C.c_double * 4)()
+        self._check(self._lib.rmhip_rp_phase_ms(self._ctx, out))
+        return {"panel": out[0], "broadcast_wait": out[1], "update": out[2], "exchange": out[3]}
+
     def mldivide_row_partitioned(self, ab_local: GpuTensorHandle, n: int, nrhs: int, rb: int = 512, tau: float = 8.0) -> GpuTensorHandle:
         """rmhip_mldivide_row_partitioned: the row-partitioned A\\b driver inside the library (depth-1 look-ahead); raises ProviderError
         with code ERR_GROWTH (10) on every rank when the multiplier guard or any rank fails."""
