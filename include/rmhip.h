@@ -824,10 +824,18 @@ RMHIP_API int rmhip_comm_init(rmhip_ctx* ctx, const void* unique_id, int rank, i
 RMHIP_API int rmhip_comm_destroy(rmhip_ctx* ctx);
 /* A rank that cannot go on inside a sequence of collectives (a local allocation or device failure) calls this instead of leaving
  * its peers blocked: on the host shared-memory transport every rank's next (or current) barrier fails at once with RMHIP_ERR_HIP; on
- * RCCL the local communicator is aborted (ncclCommAbort) and the peers are released by RCCL's own error propagation / watchdog.
+ * RCCL only the LOCAL communicator is aborted (ncclCommAbort): RCCL does not release the peers by itself - a peer already inside a
+ * collective keeps polling on the device.  What bounds their wait is rmhip_comm_wait_bounded below, which the library's own sequences
+ * (rmhip_mldivide_row_partitioned's guard) call before the host blocks on a result of a collective.
  * Afterwards every collective on this context fails until rmhip_comm_destroy + rmhip_comm_init.  No communicator: no-op. */
 /* @serves - */
 RMHIP_API int rmhip_comm_abort(rmhip_ctx* ctx);
+/* Host-side bounded wait for everything queued on the context's stream so far (collectives included): polls an event for at most
+ * `timeout_s` seconds (<= 0: RMHIP_COMM_TIMEOUT_S, default 300) and the communicator's asynchronous error state; on expiry or error the
+ * local communicator is aborted - which makes its device-side kernels exit - the stream is drained and RMHIP_ERR_HIP returned
+ * ("comm: timed out ...").  With no communicator it is a plain stream synchronisation. */
+/* @serves - */
+RMHIP_API int rmhip_comm_wait_bounded(rmhip_ctx* ctx, double timeout_s);
 /* rank 0 / world 1 when the context has no communicator */
 /* @serves - */
 RMHIP_API int rmhip_comm_rank(rmhip_ctx* ctx, int* rank, int* world);

@@ -42,6 +42,7 @@ typedef struct {
 typedef int ncclResult_t;
 typedef int ncclDataType_t;
 static constexpr ncclResult_t ncclSuccess = 0;
+static constexpr ncclResult_t ncclInProgress = 7;  // (nccl.h: ncclInProgress)
 static constexpr ncclDataType_t ncclFloat64 = 8;
 
 struct RcclApi {
@@ -50,6 +51,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;  // optional
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -92,6 +94,7 @@ RcclApi& rccl() {
         api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
         api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
         api.CommAbort = (decltype(api.CommAbort))sym("ncclCommAbort");
+        api.CommGetAsyncError = (decltype(api.CommGetAsyncError))sym("ncclCommGetAsyncError");
         api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
         api.Broadcast = (decltype(api.Broadcast))sym("ncclBroadcast");
         api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
@@ -463,6 +466,58 @@ int rmhip_comm_abort(rmhip_ctx* ctx) {
         cm->nccl = nullptr;
     }
     cm->pending = false;
+    return RMHIP_OK;
+}
+
+int rmhip_comm_wait_bounded(rmhip_ctx* ctx, double timeout_s) {
+    CTX_OR_FAIL(ctx);
+    Comm* cm = c->comm;
+    if (!cm || cm->aborted || cm->world <= 1) {
+        RMHIP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        return RMHIP_OK;
+    }
+    RMHIP_TRY(join_pending(c, cm));
+    if (!(timeout_s > 0.0)) timeout_s = std::getenv("RMHIP_COMM_TIMEOUT_S") ? std::atof(std::getenv("RMHIP_COMM_TIMEOUT_S")) : 300.0;
+    const bool test_expire = std::getenv("RMHIP_COMM_TEST_EXPIRE") != nullptr;  // test hook: behave as if the wait had expired
+    hipEvent_t ev = nullptr;
+    RMHIP_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, c->stream);
+    const auto t0 = std::chrono::steady_clock::now();
+    bool expired = false, comm_error = false;
+    while (e == hipSuccess) {
+        const hipError_t q = test_expire ? hipErrorNotReady : hipEventQuery(ev);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) {
+            e = q;
+            break;
+        }
+        if (cm->nccl && rccl().CommGetAsyncError) {
+            ncclResult_t ar = ncclSuccess;
+            if (rccl().CommGetAsyncError(cm->nccl, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) comm_error = true;
+        }
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (comm_error || waited > timeout_s || test_expire) {
+            expired = true;
+            break;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(waited < 0.01 ? 20 : 500));
+    }
+    if (expired) {
+        // a peer left (or the fabric failed): abort locally - the collective kernels of this rank exit - and drain the stream
+        cm->aborted = true;
+        if (cm->host && cm->hdr) cm->hdr->aborted.store(1, std::memory_order_release);
+        if (cm->nccl && rccl().CommAbort) {
+            (void)rccl().CommAbort(cm->nccl);
+            cm->nccl = nullptr;
+        }
+        cm->pending = false;
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipEventDestroy(ev);
+        return fail(RMHIP_ERR_HIP, comm_error ? "comm: the communicator reported an asynchronous error; aborted"
+                                               : "comm: timed out after %.0f s waiting for a collective (a peer left?); aborted", timeout_s);
+    }
+    (void)hipEventDestroy(ev);
+    if (e != hipSuccess) return fail(RMHIP_ERR_HIP, "comm: %s", hipGetErrorString(e));
     return RMHIP_OK;
 }
 

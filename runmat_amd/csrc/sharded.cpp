@@ -462,6 +462,9 @@ int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n,
         if (world > 1) {
             RMHIP_TRY(rmhip_comm_allgather_f64(ctx, mineb, &all));
             temps.keep(all);
+            // the first point where this rank's HOST blocks on the result of a collective: bounded, so that a peer that left without
+            // being able to say so (killed, a device fault) costs a timeout and an error here instead of a hang
+            RMHIP_TRY(rmhip_comm_wait_bounded(ctx, 0.0));
             std::vector<double> h((size_t)world);
             RMHIP_TRY(rmhip_download(ctx, all, h.data(), h.size()));
             worst = 0.0;

@@ -867,6 +867,10 @@ class HipProvider:
                                                        1 if gather else 0, C.byref(out)))
         return self._handle(out.value)
 
+    def comm_wait_bounded(self, timeout_s: float = 0.0) -> None:
+        """rmhip_comm_wait_bounded: host-side wait for everything queued so far, bounded (the communicator is aborted on expiry)."""
+        self._check(self._lib.rmhip_comm_wait_bounded(self._ctx, float(timeout_s)))
+
     def rp_phase_ms(self) -> dict:
         """rmhip_rp_phase_ms: device milliseconds of the last `mldivide_row_partitioned` call by phase."""
         out = (C.c_double * 4)()

@@ -197,6 +197,56 @@ def test_a_local_failure_aborts_the_communicator_instead_of_hanging_the_peer(tmp
     assert "abort" in str(r0["again"]) and "abort" in str(r1["again"])
 
 
+def _expire_worker(rank, world, port, out_dir):
+    import time
+
+    import torch.distributed as dist
+
+    from runmat_amd import HipProvider, ProviderError
+    from runmat_amd import sharding as sh
+
+    if rank == 1:
+        os.environ["RMHIP_COMM_TEST_EXPIRE"] = "1"  # rank 1's bounded wait behaves as if its time had run out
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        group = sh.Group.from_env()
+        prov = HipProvider(0)
+        group.with_native_comm(prov, transport="shm")
+        h = prov.upload(np.arange(6.0).reshape(3, 2) + rank)
+        prov.comm_bcast(h, 0)
+        t0 = time.perf_counter()
+        first, second = "", ""
+        try:
+            prov.comm_wait_bounded(5.0)
+        except ProviderError as e:
+            first = str(e)
+        dist.barrier()  # rank 1 has aborted by now
+        try:
+            prov.comm_barrier()
+        except ProviderError as e:
+            second = str(e)
+        dt = time.perf_counter() - t0
+        prov.comm_destroy()
+        np.savez(os.path.join(out_dir, f"expire{rank}.npz"), first=first, second=second, dt=dt)
+        prov.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bounded_wait_aborts_the_communicator_on_expiry(tmp_path):
+    """ADVICE r5: on expiry (here a test hook on rank 1) rmhip_comm_wait_bounded aborts the local communicator and reports an error;
+    the peer's next collective fails at once instead of blocking (host transport: the shared abort flag; on RCCL the local
+    ncclCommAbort lets this rank's own collective kernels exit, and the peers' bounded waits expire in turn)."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_expire_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (np.load(tmp_path / f"expire{r}.npz") for r in range(2))
+    assert "timed out" in str(r1["first"]) and str(r0["first"]) == ""
+    assert "abort" in str(r0["second"]) and "abort" in str(r1["second"])
+    assert float(r0["dt"]) < 20.0 and float(r1["dt"]) < 20.0
+
+
 def test_rccl_one_rank_communicator(prov, oracle):
     """The RCCL transport itself (librccl through dlopen, ncclCommInitRank / ncclAllGather / ncclBroadcast on the
     context's streams) with the one-rank communicator a single-GPU box allows, plus the sharded drivers on it."""
