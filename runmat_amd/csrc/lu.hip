@@ -3655,6 +3655,10 @@ __global__ void __launch_bounds__(SC_THREADS) k_subst_chain(const double* __rest
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
+            // acquire side of the producer's release store (agent scope): pairs the flag with the x values stored before it.  The x
+            // reads below are agent-scope atomic loads (served by L2, the coherence point) and would see them anyway; the fence makes
+            // the protocol correct by the memory model, not only by the cache hierarchy ("ordering protocols")
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();  // also: every thread is done with the previous tile's xs
         if (t < TRSM_W) {
