@@ -1,8 +1,8 @@
 """The default bench line must keep BASELINE.json's own configs where the driver can see them: it records the TAIL of the line
 (8 081 characters in rounds 1-4), and in round 4 a longer `also` list pushed the dgemm and Monte-Carlo entries out of it.
 Checked here without a GPU: the order bench.py emits the secondary workloads in, and - on the committed default line of the
-round (profiles/r05_bench_default.json, written on the GPU box by `python bench.py > ...`) - that the last 6 000 characters still
-hold the dgemm, Monte-Carlo (1e8 samples) and mldivide entries with their ms_per_step."""
+round (profiles/r06_bench_default.json, written on the GPU box by `python bench.py > ...`) - that the last 8 000 characters still
+hold the dgemm, Monte-Carlo (1e8 samples) and mldivide entries with their ms_per_step and the last 2 000 the compact `baseline_configs`."""
 import json
 import re
 from pathlib import Path
@@ -30,18 +30,32 @@ def _entry_span(line: str, needle: str):
 
 
 def test_committed_default_line_keeps_the_baseline_configs_in_its_tail():
-    f = ROOT / "profiles" / "r05_bench_default.json"
+    """profiles/r06_bench_default.json is the line `python bench.py` printed on the GPU box this round: its `also` list still ends with
+    BASELINE's configs inside the last 8 000 characters (the driver's long tail), and - round 6 - its LAST 2 000 characters (the driver's
+    short `tail`) hold the compact `baseline_configs` object with all five configs."""
+    f = ROOT / "profiles" / "r06_bench_default.json"
     line = f.read_text().strip().splitlines()[-1]
     out = json.loads(line)
     metrics = [a.get("metric", "") for a in out["also"]]
     assert any("8192^3 matmul" in m and m.startswith("fp64") for m in metrics)
-    tail_start = len(line) - 6000
+    tail_start = len(line) - 8000
     for needle in ("fp64 GFLOP/s (8192^3 matmul", "Monte-Carlo samples/s (1e8-sample", "fp64 GFLOP/s (x = A\\\\b"):
         start, end = _entry_span(line, needle)
         assert start >= tail_start, (needle, start, tail_start, len(line))
         assert '"ms_per_step"' in line[start:end]
     # the headline itself (fused D = sin(A).*B + C) is the first thing on the line; its number is repeated by the driver's parser
     assert out["metric"].startswith("fused elementwise") and out["roofline"]["frac"] > 0
+    assert list(out)[-1] == "baseline_configs"
+    short = line[-2000:]
+    i = short.find('"baseline_configs"')
+    assert i >= 0, "the compact object does not fit the driver's 2 000-character tail"
+    bc = json.loads(short[i + len('"baseline_configs": '):-1])
+    for k in ("c0_chain_1024", "c1_fused_8192", "c2_dgemm_8192", "c3_mc_1e8", "c4_mldivide_16384"):
+        assert bc[k]["ms"] > 0 and 0 < bc[k]["frac"] < 1 and bc[k]["cpu"] > 0, (k, bc[k])
+    assert bc["c2_dgemm_8192"]["unit"] == "GFLOP/s" and bc["c1_fused_8192"]["frac_slow_sin"] > 0.5 and bc["c3_mc_1e8"]["frac_40B"] > bc["c3_mc_1e8"]["frac"]
+    assert "roofline_slow_path" in out and "untimed_busy_loop" not in out["config"]
+    lazy = [a for a in out["also"] if "lazy randn" in a.get("metric", "")]
+    assert lazy and lazy[0]["ms_per_step"] < 0.45  # the lazy-Z Monte-Carlo step as its own entry
 
 
 def _fake_line():
