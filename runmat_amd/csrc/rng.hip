@@ -137,8 +137,9 @@ __global__ void __launch_bounds__(256) k_rng_normal(unsigned long long state, T*
     unsigned long long x1 = kPairSkip.mp[2 * threadIdx.x] * (mb * state + pb) + kPairSkip.mp[2 * threadIdx.x + 1];
     const bool aligned = (((uintptr_t)out) & (2 * sizeof(T) - 1)) == 0;
     size_t i = base + threadIdx.x;
+    const int iters = i < lim ? (int)((lim - i + 255) / 256) : 0;  // (a 32-bit trip count: no 64-bit compare per pair)
 #pragma unroll 1
-    for (; i < lim; i += 256) {
+    for (int it = 0; it < iters; ++it, i += 256) {
         const unsigned long long x2 = lcg_step(x1);
         const double radius = bm_radius(x1, tb);
         double sn, cs;

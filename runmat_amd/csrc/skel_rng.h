@@ -102,7 +102,8 @@ __device__ __forceinline__ double bm_radius(unsigned long long x1, const BmTable
     p = __builtin_fma(r, p, 0x1.5555555555555p-2);                             // 1/3
     p = __builtin_fma(r, p, -0.5);
     const double lp = __builtin_fma(r * r, p, r);                              // log1p(r)
-    const double dk = (double)e;
+    // e in [-1076, 1] as a double without v_cvt_f64_i32 (8 cycles): e + 2048 sits in the low word of 2^52's mantissa
+    const double dk = __longlong_as_double((long long)(((unsigned long long)0x43300000u << 32) | (unsigned)(e + 2048))) - 0x1.00000000008p+52;
     const double head = __builtin_fma(dk, 0x1.62e42fee00000p-1, te.y);         // e ln2_hi is exact (32-bit constant)
     const double tail = __builtin_fma(dk, 0x1.a39ef35793c76p-33, lp);
     if (ln_out) *ln_out = (x1 >> 11) == 0 ? -0x1.6232bdd7abcd2p+9 : head + tail;  // ln u1 (u1 = 0 stands for f64::MIN_POSITIVE: ln 2^-1022)
@@ -111,8 +112,7 @@ __device__ __forceinline__ double bm_radius(unsigned long long x1, const BmTable
     double g = x * y, h = 0.5 * y;
     const double c = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, c, g);
-    h = __builtin_fma(h, c, h);
-    const double d = __builtin_fma(-g, g, x);
+    const double d = __builtin_fma(-g, g, x);  // (h = y / 2 is good to 2^-26: enough for the correction term d h, itself <= 2^-50 g)
     g = __builtin_fma(d, h, g);
     // u1 = 0 is replaced by f64::MIN_POSITIVE (random.rs:13,281-283): sqrt(-2 ln 2^-1022).  One draw in 2^53: tested for the whole wave
     // (a compare and a scalar branch) instead of two v_cndmask on vcc per pair - that form costs 23 cycles per instruction on gfx950
@@ -139,8 +139,10 @@ __device__ __forceinline__ void bm_sincos(unsigned long long x2, const BmTables&
     double w = __builtin_fma(z, -0x1.6c16c16c16c17p-10, 0x1.5555555555555p-5);        // -1/720, 1/24
     w = __builtin_fma(z, w, -0.5);
     w = z * w;                                                     // cos x - 1
-    *sn = te.x + __builtin_fma(te.x, w, te.y * sd);
-    *cs = te.y + __builtin_fma(te.y, w, -(te.x * sd));
+    // S_j (1 + w) + C_j sin x and C_j (1 + w) - S_j sin x, two fmas each (round 6: was mul + fma + add with the table value entering
+    // unrounded - 1.6e-16 absolute; this form 2.3e-16, inside the 6e-16-of-the-radius bound the tests state)
+    *sn = __builtin_fma(te.y, sd, __builtin_fma(te.x, w, te.x));
+    *cs = __builtin_fma(-te.x, sd, __builtin_fma(te.y, w, te.y));
 }
 
 #endif  // RMHIP_SKEL_RNG

@@ -56,6 +56,30 @@ __global__ void __launch_bounds__(256) k_chunk(unsigned long long state, double*
     }
 }
 
+// D: as B with the tables read from GLOBAL memory (L1 / L2 hits: 10 KiB) - no staging, no barrier per block, so small chunks become
+// affordable (the pattern that serves k_fill best is 8 KiB per block)
+template <int PPT>
+__global__ void __launch_bounds__(256) k_chunk_gtab(unsigned long long state, double* __restrict__ out, size_t n, unsigned long long jm, unsigned long long jp,
+                                                   const unsigned long long* __restrict__ skip) {
+    BmTables tb;
+    tb.sc = reinterpret_cast<const v2d*>(&kSinCosPi[0][0]);
+    tb.lg = reinterpret_cast<const v2d*>(&kLogTab[0][0]);
+    const size_t full = n / 2, base = (size_t)blockIdx.x * (256 * PPT);
+    unsigned long long mb, pb;
+    lcg_jump(2ULL * base, &mb, &pb);
+    unsigned long long x1 = skip[2 * threadIdx.x] * (mb * state + pb) + skip[2 * threadIdx.x + 1];
+#pragma unroll 1
+    for (int it = 0; it < PPT; ++it) {
+        const size_t i = base + (size_t)it * 256 + threadIdx.x;
+        if (i >= full) break;
+        const double radius = bm_radius(x1, tb);
+        double sn, cs;
+        bm_sincos(lcg_step(x1), tb, &sn, &cs);
+        *(v2d*)(out + 2 * i) = v2d{radius * cs, radius * sn};
+        x1 = jm * x1 + jp;
+    }
+}
+
 // C: as B but a thread generates PPT consecutive pairs?  (no: stores would not coalesce) - instead each WAVE owns a contiguous piece:
 // wave w of the block walks pairs [base + w * 64 * PPT, ...) in 1 KiB steps
 template <int PPT>
@@ -112,6 +136,9 @@ int main() {
         #define CHUNK(PPT, TAB) { const unsigned g = (unsigned)((n / 2 + 256 * PPT - 1) / (256 * PPT)); \
             timeit(TAB ? "B block chunk PPT " #PPT ", skip table" : "B block chunk PPT " #PPT ", doubling skip", [&] { hipLaunchKernelGGL((k_chunk<PPT, TAB>), dim3(g), dim3(256), 0, 0, st, out, n, jm, jp, skip); }); }
         CHUNK(4, true) CHUNK(8, true) CHUNK(8, false) CHUNK(16, true) CHUNK(32, true) CHUNK(64, true)
+        #define GCHUNK(PPT) { const unsigned g = (unsigned)((n / 2 + 256 * PPT - 1) / (256 * PPT)); \
+            timeit("D block chunk PPT " #PPT ", tables from global memory", [&] { hipLaunchKernelGGL((k_chunk_gtab<PPT>), dim3(g), dim3(256), 0, 0, st, out, n, jm, jp, skip); }); }
+        GCHUNK(1) GCHUNK(2) GCHUNK(4) GCHUNK(8) GCHUNK(16)
         unsigned long long wm, wp; lcg_jump(128ULL, &wm, &wp);
         #define WCHUNK(PPT) { const unsigned g = (unsigned)((n / 2 + 256 * PPT - 1) / (256 * PPT)); \
             timeit("C wave chunk PPT " #PPT, [&] { hipLaunchKernelGGL((k_wavechunk<PPT>), dim3(g), dim3(256), 0, 0, st, out, n, wm, wp, skip); }); }
