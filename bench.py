@@ -648,10 +648,10 @@ def main() -> None:
             # the row blocks of [A | b] it owns, pivoting inside the owner's rows, one tile-row broadcast per panel, the last `world`
             # blocks all-gathered); if its multiplier guard refuses the matrix, the block-column cyclic form with the grid-wide rule.
             # Every rank builds the same A and keeps only what it owns.
-            nbk = 512
+            nbk = int(os.environ.get("RMHIP_BENCH_RB", "512"))  # row-block height = panel width of the row-partitioned form (developer knob)
             blocks = sh.owned_blocks(nn, nbk, group)
             row_blocks = sh.owned_row_blocks(nn, nbk, group)
-            form["name"] = (f"row-partitioned x{world}, rb=512: diagonal-domain pivoting, one tile-row broadcast per panel (rmhip_comm_bcast), "
+            form["name"] = (f"row-partitioned x{world}, rb={nbk}: diagonal-domain pivoting, one tile-row broadcast per panel (rmhip_comm_bcast), "
                             f"last {world} row blocks all-gathered"
                             + ("; driver inside the library (look-ahead 1)" if world == 1 or group.native is not None else "; Python driver over the control plane"))
 

@@ -774,6 +774,13 @@ RMHIP_API int rmhip_blk_trsm(rmhip_ctx* ctx, int upper, const rmhip_view_t* t, c
  * view).  *info = number of pivots <= 1e-12. */
 /* @serves - */
 RMHIP_API int rmhip_blk_lu(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf* ipiv_out, int* info);
+/* The same factorisation for a driver that has a guard of its own (rmhip_mldivide_row_partitioned): solve-path panel kernels
+ * (pivoting inside the top blocks, multipliers recorded), NO host round trip - the interchange vector is written on the device and the
+ * status is folded into `guard`, a 1 x 1 f64 tensor: NaN once a pivot hit the singular cut-off, else max(guard, largest multiplier).
+ * The block is not saved: a value above the caller's bound means the caller's whole factorisation is refused.  Falls back to the
+ * ordinary checks (and may then return RMHIP_ERR_GROWTH) when the solve-path kernels do not apply (RMHIP_LU_FAST=0). */
+/* @serves - */
+RMHIP_API int rmhip_blk_lu_deferred(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf guard, rmhip_buf* ipiv_out);
 /* Apply those interchanges (in order) to every column of a view whose row 0 is the panel's row 0. */
 /* @serves - */
 RMHIP_API int rmhip_blk_swap_rows(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf ipiv);

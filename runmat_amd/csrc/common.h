@@ -412,7 +412,8 @@ static constexpr int RMHIP_LU_RETRY = -77;
 static constexpr int RMHIP_LU_GROWTH = -79;  // internal status of lu_factor_device (mode 1): a multiplier exceeded the bound, refactor a fresh copy in mode 0
 static constexpr int RMHIP_SUBST_RETRY = -78;  // internal status of substitute_few_rhs: the chain kernel timed out, gather the right-hand side again
 int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda, int* perm_dev,
-                     int* info_host, std::vector<int>* ipiv_host = nullptr, int mode = 0, double* ipiv_dev_f64 = nullptr);
+                     int* info_host, std::vector<int>* ipiv_host = nullptr, int mode = 0, double* ipiv_dev_f64 = nullptr,
+                     double* deferred_guard = nullptr);  // deferred_guard (mode 1): no host read at all, status folded into *deferred_guard (device)
 // interchanges from a device vector of doubles (rmhip_blk_lu's result), composed and applied on the device; RMHIP_ERR_UNSUPPORTED (no error
 // string) when the view is too tall for the LDS map - the caller then composes on the host
 int lu_swap_rows_from_device(Context* c, double* A, size_t lda, size_t nrows, size_t ncols, const double* ipiv_dev, size_t npiv);

@@ -3060,8 +3060,19 @@ __global__ void __launch_bounds__(256) k_ipiv_to_f64(const int* __restrict__ ipi
     if (i < n) out[i] = (double)ipiv[i];
 }
 
+// deferred form (deferred_guard != nullptr): the factorisation's status words folded into the caller's running guard value on the
+// device - NaN once a pivot hit the singular cut-off, else the larger of the old value and this panel's largest multiplier
+__global__ void k_lu_fold_status(const int* __restrict__ info, const unsigned long long* __restrict__ growth_bits, double* __restrict__ guard) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double g = __longlong_as_double((long long)*growth_bits);
+    const double cur = *guard;
+    double out = (cur != cur || g != g) ? __longlong_as_double(0x7ff8000000000000LL) : (g > cur ? g : cur);
+    if (*info > 0) out = __longlong_as_double(0x7ff8000000000000LL);
+    *guard = out;
+}
+
 int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda, int* perm_dev, int* info_host,
-                     std::vector<int>* ipiv_host, int mode, double* ipiv_dev_f64) {
+                     std::vector<int>* ipiv_host, int mode, double* ipiv_dev_f64, double* deferred_guard) {
     const size_t kmin = rows < cols ? rows : cols;
     if (rows > 0x7fffffffULL || cols > 0x7fffffffULL) return fail(RMHIP_ERR_UNSUPPORTED, "lu: dimension exceeds 2^31");
     c->lu_used_one_xcd = false;
@@ -3119,6 +3130,7 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
         s.ucomp = (double*)(blk + off_ucomp);
         s.growth = (unsigned long long*)(blk + off_xctl + 32);
         s.minv_max = (unsigned long long*)(blk + off_xctl + 40);
+        if (deferred_guard) s.screened = true;  // no early read of the first panel's multipliers: the caller's guard sees them at the end
         // matrix-core triangular solves with k_rp_top's inverted diagonal blocks: every base panel must be 64 columns wide
         static const int trsm_mfma = std::getenv("RMHIP_LU_TRSM_MFMA") ? std::atoi(std::getenv("RMHIP_LU_TRSM_MFMA")) : 1;
         if (s.fast && trsm_mfma && !s.xdbg) s.linv = (double*)(blk + off_linv);
@@ -3170,6 +3182,19 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
     if (rc == RMHIP_OK && cols > rows && !blocked) {  // wide: finish U's right block (the blocked driver covers it)
         rc = laswp(s, rows, cols, 0, rows);
         if (rc == RMHIP_OK) rc = trsm_lower_rec(c, A, lda, rows, A + rows * lda, lda, cols - rows);
+    }
+    if (rc == RMHIP_OK && deferred_guard && s.fast && !s.xdbg) {
+        // Deferred checks (a panel of a larger factorisation whose driver has a guard of its own - csrc/sharded.cpp): nothing is read
+        // back; the interchange vector goes out as a device tensor, the status words into the caller's guard value.  Everything above
+        // and these two launches are queued on the context's stream: the workspace block goes back to the pool stream-ordered.
+        if (ipiv_dev_f64 && kmin) {
+            hipLaunchKernelGGL(k_ipiv_to_f64, dim3((unsigned)((kmin + 255) / 256)), dim3(256), 0, c->stream, (const int*)ipiv, ipiv_dev_f64, (int)kmin);
+            RMHIP_TRY(launch_check(c));
+        }
+        hipLaunchKernelGGL(k_lu_fold_status, dim3(1), dim3(64), 0, c->stream, (const int*)info, (const unsigned long long*)s.growth, deferred_guard);
+        RMHIP_TRY(launch_check(c));
+        if (info_host) *info_host = 0;
+        return RMHIP_OK;
     }
     std::vector<int> h_ipiv(rows + 1, 0);
     if (rc == RMHIP_OK) {

@@ -1872,6 +1872,31 @@ int rmhip_blk_lu(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf* ipiv_out, int
     return RMHIP_OK;
 }
 
+int rmhip_blk_lu_deferred(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf guard, rmhip_buf* ipiv_out) {
+    CTX_OR_FAIL(ctx);
+    if (!ipiv_out) return fail(RMHIP_ERR_INVALID, "null ipiv_out");
+    ViewPtr va;
+    RMHIP_TRY(resolve_view(c, a, &va, true));
+    Buffer gb;
+    RMHIP_TRY(c->get(guard, &gb));
+    if (gb.numel != 1 || gb.dtype != DT_F64) return fail(RMHIP_ERR_INVALID, "blk_lu_deferred: the guard is a 1 x 1 f64 tensor");
+    const size_t kmin = va.rows < va.cols ? va.rows : va.cols;
+    if (kmin == 0) return fail(RMHIP_ERR_INVALID, "blk_lu_deferred: empty view");
+    const size_t oshape[2] = {kmin, 1};
+    Buffer ob;
+    RMHIP_TRY(c->new_buffer(oshape, 2, ipiv_out, &ob));
+    int inf = 0;
+    // solve-path panel kernels, no saved copy, no host read: the status lands in *guard (lu.hip, deferred form)
+    int frc = lu_factor_device(c, va.ptr, va.rows, va.cols, va.ld, nullptr, &inf, nullptr, 1, ob.data(), gb.data());
+    if (frc == RMHIP_LU_GROWTH || frc == RMHIP_LU_RETRY)  // (only when the deferred form was not taken: the ordinary checks ran and refused)
+        frc = fail(RMHIP_ERR_GROWTH, "blk_lu_deferred: the panel was refused (multiplier bound or panel placement); the block is invalid");
+    if (frc != RMHIP_OK) {
+        rmhip_free(ctx, *ipiv_out);
+        *ipiv_out = 0;
+    }
+    return frc;
+}
+
 int rmhip_blk_swap_rows(rmhip_ctx* ctx, const rmhip_view_t* a, rmhip_buf ipiv) {
     CTX_OR_FAIL(ctx);
     ViewPtr va;

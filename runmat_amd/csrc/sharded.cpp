@@ -243,6 +243,7 @@ int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n,
             if (*id) (void)rmhip_free(ctx, *id);
         }
     } growth_scope{ctx, &growth_dev};
+    const bool deferred_on = !(std::getenv("RMHIP_RP_DEFERRED") && std::getenv("RMHIP_RP_DEFERRED")[0] == '0');
     PhaseTimers timers;
     timers.on = !(std::getenv("RMHIP_RP_TIMERS") && std::getenv("RMHIP_RP_TIMERS")[0] == '0');
     for (double& v : c->rp_phase_ms) v = 0.0;
@@ -305,7 +306,9 @@ int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n,
             hipStream_t st;
             ~PanelSpan() { t.end(PhaseTimers::PANEL, a, st); }
         } panel_span{timers, t_panel, main_stream};
-        int rc = rmhip_blk_lu(ctx, &pan, &ipiv, &info);
+        // (round 6) the panel without any host round trip when the solve path's kernels are in use: its status - a singular pivot, its
+        // largest multiplier - is folded into this rank's guard value on the device and seen by every rank at the one exchange
+        int rc = c->blk_lu_solve_path && deferred_on ? rmhip_blk_lu_deferred(ctx, &pan, growth_dev, &ipiv) : rmhip_blk_lu(ctx, &pan, &ipiv, &info);
         // the interchanges move rows the side stream's update of the previous panel reads (its multipliers, left of the panel) and
         // writes (right of it): that update has to be through first - it ran under the factorisation above
         join_side();
