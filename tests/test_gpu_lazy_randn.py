@@ -120,8 +120,11 @@ def test_a_lazy_handle_read_twice_and_two_lazy_handles_in_one_kernel(lazy):
     r = prov.fused_elementwise(shader, [z1, z1e], (n, 1), n)  # one lazy, one resident
     assert np.array_equal(prov.download(r).ravel(), a * a + a)
     prov.free(r)
+    r = prov.fused_elementwise(shader, [z1, z1], (n, 1), n)  # the SAME lazy handle bound to two inputs of one kernel
+    assert np.array_equal(prov.download(r).ravel(), a * a + a)
+    prov.free(r)
     after = prov.lazy_random_stats()
-    assert after["fused"] - before["fused"] == 5 and after["materialised"] == before["materialised"]
+    assert after["fused"] - before["fused"] == 7 and after["materialised"] == before["materialised"]
     for h in (z1, z2, z1e, z2e):
         prov.free(h)
 
