@@ -165,6 +165,7 @@ struct Context {
     bool lazy_randn = true;
     size_t lazy_randn_min = 1024;
     uint64_t lazy_randn_created = 0, lazy_randn_fused = 0, lazy_randn_materialised = 0;  // rmhip_lazy_random_stats
+    size_t n_rng_lazy = 0;  // lazy random_normal records alive (guarded by `mu`): rmhip_fused_elementwise skips its look for them when there are none
 
     // scratch for reductions / LU (grown on demand, reused)
     double* scratch = nullptr;

@@ -115,6 +115,7 @@ int Context::register_buffer(Buffer&& b, uint64_t* id) {
     std::lock_guard<std::mutex> lk(mu);
     *id = next_id++;
     if (b.lazy()) ++n_lazy;
+    if (b.rng_lazy) ++n_rng_lazy;
     table.emplace(*id, std::move(b));
     return RMHIP_OK;
 }
@@ -179,6 +180,7 @@ int Context::settle_rng(uint64_t id) {
     if (it != table.end() && it->second.rng_lazy) {
         it->second.alloc = fresh;
         it->second.rng_lazy = false;
+        --n_rng_lazy;
     }
     return RMHIP_OK;
 }
@@ -468,6 +470,7 @@ int rmhip_shutdown(rmhip_ctx* ctx) {
     c->pool_limit_bytes = 0;  // frees bypass the pool from here on
     c->table.clear();
     c->n_lazy = 0;
+    c->n_rng_lazy = 0;
     c->fft_tables.clear();  // (cached twiddle / chirp tables hold allocations of this context: released while it is still whole)
     for (auto& kv : c->pool) (void)hipFree(kv.second);
     c->pool.clear();
@@ -590,6 +593,7 @@ int rmhip_free(rmhip_ctx* ctx, rmhip_buf id) {
         auto it = c->table.find(id);
         if (it == c->table.end()) return fail(RMHIP_ERR_NOT_FOUND, "free: buffer not found: %llu", (unsigned long long)id);
         if (it->second.lazy()) --c->n_lazy;
+        if (it->second.rng_lazy) --c->n_rng_lazy;
         victim = std::move(it->second);
         c->table.erase(it);
     }

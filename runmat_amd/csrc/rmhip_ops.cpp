@@ -263,7 +263,7 @@ int rmhip_fused_elementwise(rmhip_ctx* ctx, const char* shader, const rmhip_buf*
     // Lazy random_normal operands (Buffer::rng_lazy) stay lazy only for the streaming kernel over 16-byte vectors: every operand is
     // either a plain full-size tensor of the output's shape or a 1-element tensor.  Any other request materialises them first.
     unsigned rng_mask = 0;
-    if (c->precision != 32) {
+    if (c->precision != 32 && c->n_rng_lazy != 0) {  // (no lazy record alive in this context: nothing to look for)
         bool any = false, eligible = len >= 2;
         auto extents = [](const std::vector<size_t>& sh) {
             std::vector<size_t> e;
