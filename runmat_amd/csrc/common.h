@@ -201,6 +201,7 @@ struct Context {
     unsigned* gemm_announce_tab = nullptr;  // the table itself while a two-level factorisation runs (k_trsm_lower_mfma on the main stream)
     bool lu_yield_trsm = false;
     unsigned* gemm_announce = nullptr;  // two-level LU: the yield table for the main stream's dgemm blocks to count themselves into (RMHIP_LU_YIELD_ALL)
+    unsigned* ext_yield_tab = nullptr;  // a yield table (kYieldSlots counters) owned by a driver outside lu.hip for the panels it factors (sharded.cpp), or nullptr
     const unsigned* gemm_yield_word = nullptr;  // two-level LU: the CU (key) whose update blocks pause while k_rp_top runs there (device word; 0: none)
     double* gemm_split_ws = nullptr;  // caller-owned workspace for split-K partial products (per stream; see launch_dgemm)
     size_t gemm_split_ws_elems = 0;

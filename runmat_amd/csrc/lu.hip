@@ -3131,6 +3131,9 @@ int lu_factor_device(Context* c, double* A, size_t rows, size_t cols, size_t lda
         s.growth = (unsigned long long*)(blk + off_xctl + 32);
         s.minv_max = (unsigned long long*)(blk + off_xctl + 40);
         if (deferred_guard) s.screened = true;  // no early read of the first panel's multipliers: the caller's guard sees them at the end
+        // a driver that runs updates on a stream of its own beside this factorisation (csrc/sharded.cpp) lends its yield table: k_rp_top
+        // counts itself in and that stream's eight-wave blocks on its CU pause (the two-level driver below installs its own)
+        if (c->ext_yield_tab) s.yield_word = c->ext_yield_tab;
         // matrix-core triangular solves with k_rp_top's inverted diagonal blocks: every base panel must be 64 columns wide
         static const int trsm_mfma = std::getenv("RMHIP_LU_TRSM_MFMA") ? std::atoi(std::getenv("RMHIP_LU_TRSM_MFMA")) : 1;
         if (s.fast && trsm_mfma && !s.xdbg) s.linv = (double*)(blk + off_linv);

@@ -278,6 +278,22 @@ int rmhip_mldivide_row_partitioned(rmhip_ctx* ctx, rmhip_buf ab_local, size_t n,
             if (*b) (void)hipEventDestroy(*b);
         }
     } event_scope{&ev_side_done, &ev_main_ready};
+    // cooperative yield, as in the single-GPU two-level driver: the panels' k_rp_top counts itself into a table and the side stream's
+    // eight-wave block on its CU sleeps meanwhile (RMHIP_RP_YIELD=1 enables)
+    std::shared_ptr<Allocation> yield_tab;
+    struct YieldScope {
+        Context* c;
+        ~YieldScope() {
+            c->ext_yield_tab = nullptr;
+            c->gemm_yield_word = nullptr;
+        }
+    } yield_scope{c};
+    if (side != main_stream && std::getenv("RMHIP_RP_YIELD") && std::getenv("RMHIP_RP_YIELD")[0] == '1') {  // (measured neutral: 95.7-96.1 with, 96.1-97.3 without - off by default)
+        RMHIP_TRY(c->alloc_device(kYieldSlots / 2, &yield_tab));
+        RMHIP_HIP_CHECK(hipMemsetAsync(yield_tab->ptr, 0, sizeof(unsigned) * kYieldSlots, main_stream));
+        c->ext_yield_tab = (unsigned*)yield_tab->ptr;
+        c->gemm_yield_word = c->ext_yield_tab;
+    }
     bool side_pending = false;  // the side stream holds an update the main stream has not waited for yet
     auto join_side = [&]() {
         if (side_pending) (void)hipStreamWaitEvent(main_stream, ev_side_done, 0);
